@@ -1,0 +1,123 @@
+/*
+ * jt_oracle.h — CPU ORACLE for the jivetalking four-pass speech-mastering path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing in the product path (jivetalking_amd/,
+ * include/) may link, import or call this.  Only tests/, __graft_entry__.smoke()
+ * and bench.py's cpu_baseline leg use it, and only as the checker.
+ *
+ * What it restates.  The reference (linuxmatters/jivetalking) contains no DSP of
+ * its own: internal/processor builds FFmpeg filter-graph strings
+ * (filters.go:607-962, normalise.go:257-264,446-480,1231-1334,
+ * analyser_bands.go:33, analyser_output.go:18) and pumps frames through
+ * libavfilter via the cgo binding github.com/linuxmatters/ffmpeg-statigo
+ * (go.mod:13,17 — a `replace` to an EMPTY un-vendored submodule, no version
+ * pin; bundled FFmpeg = 8.1 per docs/Spectral-Metrics-Reference.md:5).  The
+ * arithmetic therefore lives in a third-party dependency that is ABSENT from
+ * /root/reference.  This oracle restates the published algorithms of the
+ * FFmpeg 8.1 filters the reference instantiates (libavfilter/af_biquads.c,
+ * af_anlmdn.c, af_afftdn.c, af_agate.c, af_sidechaincompress.c, af_deesser.c,
+ * af_alimiter.c, af_loudnorm.c + ebur128.c, f_ebur128.c, af_astats.c,
+ * af_aspectralstats.c, af_volume.c, libswresample/resample.c) from knowledge
+ * of that source, plain sequential C, double/float exactly where FFmpeg uses
+ * double/float.
+ *
+ * PARITY STATUS: **parity unpinned** at the FFmpeg boundary.  Neither Go nor
+ * FFmpeg exists in the build container, so the restatement cannot be checked
+ * against the reference executable.  It IS pinned against: (a) the in-repo
+ * formula statement docs/Spectral-Metrics-Reference.md:9-56 (aspectralstats,
+ * astats), (b) standards known-answer tests (ITU-R BS.1770-4 / EBU Tech
+ * 3341/3342) in tests/test_oracle_kat.py, (c) the reference's own range
+ * assertions (analyser_test.go:185-207).  The scalar control logic around
+ * FFmpeg (VAD, AdaptConfig, limiter planning) is NOT here: it is product host
+ * code checked directly against the reference's golden tables (tests/golden/).
+ */
+#ifndef JT_ORACLE_H
+#define JT_ORACLE_H
+#include <stdint.h>
+#include <stddef.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- biquads: highpass/lowpass, RBJ, a=tdii, flt (af_biquads.c) ---- */
+/* type: 0 = highpass, 1 = lowpass.  poles=2, width_type=q, normalize=1. */
+void orc_biquad_coeffs(int type, double freq, double q, int sample_rate, double b[3], double a[3]);
+void orc_biquad_tdii_f32(const float *in, float *out, int64_t n, const double b[3], const double a[3]);
+/* double-precision variant (band-RMS graphs run biquads on the decoder format; dbl used for s16/flt-agnostic checks) */
+void orc_biquad_tdii_f64(const double *in, double *out, int64_t n, const double b[3], const double a[3]);
+
+/* ---- anlmdn (af_anlmdn.c) ---- */
+void orc_anlmdn_f32(const float *in, float *out, int64_t n, int sample_rate,
+                    double strength, double patch_s, double research_s, double smooth);
+
+/* ---- afftdn (af_afftdn.c), tn=0 static floor ---- */
+/* band_noise: 15 custom band values (dB) or NULL for white. */
+void orc_afftdn_f32(const float *in, float *out, int64_t n, int sample_rate,
+                    double nr_db, double nf_db, const double *band_noise);
+
+/* ---- agate / acompressor / deesser (dbl) ---- */
+typedef struct {
+    double threshold, ratio, attack_ms, release_ms, range, knee, makeup;
+    int detection_rms;
+} orc_gate_params;
+typedef struct {
+    double threshold, ratio, attack_ms, release_ms, makeup, knee, mix;
+    int detection_rms;
+} orc_comp_params;
+void orc_agate_f64(const double *in, double *out, int64_t n, int sample_rate, const orc_gate_params *p);
+void orc_acompressor_f64(const double *in, double *out, int64_t n, int sample_rate, const orc_comp_params *p);
+void orc_deesser_f64(const double *in, double *out, int64_t n, int sample_rate,
+                     double intensity, double max_deess, double frequency);
+
+/* ---- alimiter (af_alimiter.c): level=0 (no auto level), latency=1, asc on ---- */
+void orc_alimiter_f64(const double *in, double *out, int64_t n, int sample_rate,
+                      double limit, double attack_ms, double release_ms, double asc_level);
+
+/* ---- libswresample polyphase resampler (resample.c), kaiser beta 9, filter_size 32, cutoff 0.97 ---- */
+/* out_cap >= ceil(n*out_rate/in_rate)+2.  flush!=0: aresample-style (right edge mirrored, M=ceil(n*out/in));
+ * flush==0: streaming, only outputs whose taps are inside the input (ebur128 true-peak use).  Returns #outputs. */
+int64_t orc_swr_resample_f64(const double *in, int64_t n, int in_rate, int out_rate, double *out, int64_t out_cap, int flush);
+int64_t orc_swr_resample_f32(const float *in, int64_t n, int in_rate, int out_rate, float *out, int64_t out_cap, int flush);
+/* dbl -> s16 as swresample's audioconvert: clip_int16(lrint(x*32768)) */
+void orc_f64_to_s16(const double *in, int16_t *out, int64_t n);
+
+/* ---- ebur128 filter (f_ebur128.c) on mono ---- */
+typedef struct {
+    double integrated, lra, lra_low, lra_high;
+    double momentary_last, shortterm_last;   /* last 100 ms block values */
+    double sample_peak, true_peak;           /* linear */
+    double target_threshold;                 /* rel gate threshold of I (LUFS) */
+    int64_t nblocks;
+} orc_ebur128_out;
+/* m_series/s_series: per-100ms-block M and S (caller buffers, cap entries), may be NULL.
+ * tp_series/sp_series: cumulative linear peaks at each block, may be NULL. */
+void orc_ebur128_mono(const double *in, int64_t n, int sample_rate, int dualmono, int true_peak,
+                      orc_ebur128_out *out, double *m_series, double *s_series,
+                      double *tp_series, double *sp_series, int64_t cap);
+
+/* ---- loudnorm input measurement: libebur128 port (ebur128.c) at the given rate, mono, dual_mono ---- */
+typedef struct { double input_i, input_tp, input_lra, input_thresh; } orc_loudnorm_in;
+void orc_loudnorm_measure_mono(const double *in, int64_t n, int sample_rate, int dual_mono, orc_loudnorm_in *out);
+
+/* ---- astats (af_astats.c) on mono, length=0.05 ---- */
+typedef struct {
+    double dc_offset, min_level, max_level, min_difference, max_difference, mean_difference,
+           rms_difference, peak_level_db, rms_level_db, rms_peak_db, rms_trough_db, crest_factor,
+           flat_factor, peak_count, noise_floor_db, noise_floor_count, entropy, dynamic_range,
+           zero_crossings, zero_crossings_rate, number_of_samples, abs_peak_count;
+} orc_astats_out;
+void orc_astats_mono(const double *in, int64_t n, int sample_rate, orc_astats_out *out);
+
+/* ---- aspectralstats (af_aspectralstats.c), hann, overlap 0.5, mono ---- */
+/* stats: nhops x 13 doubles in key order mean,variance,centroid,spread,skewness,kurtosis,
+ * entropy,flatness,crest,flux,slope,decrease,rolloff. Returns number of hops written. */
+int64_t orc_aspectralstats_mono(const float *in, int64_t n, int sample_rate, int win_size,
+                                double *stats, int64_t cap_hops);
+
+/* ---- helpers ---- */
+void orc_rfft_mag_f32(const float *in, int n_fft, float *mag_half);  /* |FFT|, n_fft/2 bins, unscaled */
+
+#ifdef __cplusplus
+}
+#endif
+#endif

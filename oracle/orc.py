@@ -1,0 +1,219 @@
+"""ctypes binding for the CPU ORACLE (oracle/liboracle.so).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and bench.py's
+cpu_baseline leg — never by the product package (jivetalking_amd/).  See jt_oracle.h.
+"""
+import ctypes as C
+import os
+import subprocess
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+
+def build():
+    subprocess.check_call(["make", "-s", "-C", _HERE])
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        path = os.path.join(_HERE, "liboracle.so")
+        if not os.path.exists(path):
+            build()
+        _LIB = C.CDLL(path)
+    return _LIB
+
+
+def _p(a, t):
+    return a.ctypes.data_as(C.POINTER(t))
+
+
+f32p, f64p, i16p = C.POINTER(C.c_float), C.POINTER(C.c_double), C.POINTER(C.c_int16)
+
+
+def biquad_coeffs(kind, freq, q, sr):
+    b = (C.c_double * 3)()
+    a = (C.c_double * 3)()
+    lib().orc_biquad_coeffs(C.c_int(kind), C.c_double(freq), C.c_double(q), C.c_int(sr), b, a)
+    return np.array(b[:]), np.array(a[:])
+
+
+def biquad_f32(x, kind, freq, sr, q=0.707):
+    x = np.ascontiguousarray(x, np.float32)
+    y = np.empty_like(x)
+    b = (C.c_double * 3)()
+    a = (C.c_double * 3)()
+    lib().orc_biquad_coeffs(C.c_int(kind), C.c_double(freq), C.c_double(q), C.c_int(sr), b, a)
+    lib().orc_biquad_tdii_f32(_p(x, C.c_float), _p(y, C.c_float), C.c_int64(x.size), b, a)
+    return y
+
+
+def biquad_f64(x, kind, freq, sr, q=0.707):
+    x = np.ascontiguousarray(x, np.float64)
+    y = np.empty_like(x)
+    b = (C.c_double * 3)()
+    a = (C.c_double * 3)()
+    lib().orc_biquad_coeffs(C.c_int(kind), C.c_double(freq), C.c_double(q), C.c_int(sr), b, a)
+    lib().orc_biquad_tdii_f64(_p(x, C.c_double), _p(y, C.c_double), C.c_int64(x.size), b, a)
+    return y
+
+
+def anlmdn(x, sr, s=0.00001, p=0.006, r=0.002, m=3.0):
+    x = np.ascontiguousarray(x, np.float32)
+    y = np.zeros_like(x)
+    lib().orc_anlmdn_f32(_p(x, C.c_float), _p(y, C.c_float), C.c_int64(x.size), C.c_int(sr),
+                         C.c_double(s), C.c_double(p), C.c_double(r), C.c_double(m))
+    return y
+
+
+def afftdn(x, sr, nr=12.0, nf=-50.0, band_noise=None):
+    x = np.ascontiguousarray(x, np.float32)
+    y = np.zeros_like(x)
+    bn = None
+    if band_noise is not None:
+        bn_arr = np.ascontiguousarray(band_noise, np.float64)
+        assert bn_arr.size == 15
+        bn = _p(bn_arr, C.c_double)
+    lib().orc_afftdn_f32(_p(x, C.c_float), _p(y, C.c_float), C.c_int64(x.size), C.c_int(sr),
+                         C.c_double(nr), C.c_double(nf), bn)
+    return y
+
+
+class GateParams(C.Structure):
+    _fields_ = [("threshold", C.c_double), ("ratio", C.c_double), ("attack_ms", C.c_double),
+                ("release_ms", C.c_double), ("range", C.c_double), ("knee", C.c_double),
+                ("makeup", C.c_double), ("detection_rms", C.c_int)]
+
+
+class CompParams(C.Structure):
+    _fields_ = [("threshold", C.c_double), ("ratio", C.c_double), ("attack_ms", C.c_double),
+                ("release_ms", C.c_double), ("makeup", C.c_double), ("knee", C.c_double),
+                ("mix", C.c_double), ("detection_rms", C.c_int)]
+
+
+def agate(x, sr, threshold=0.01, ratio=2.0, attack=5.0, release=200.0, range_=0.1995, knee=3.0, makeup=1.0):
+    x = np.ascontiguousarray(x, np.float64)
+    y = np.empty_like(x)
+    p = GateParams(threshold, ratio, attack, release, range_, knee, makeup, 1)
+    lib().orc_agate_f64(_p(x, C.c_double), _p(y, C.c_double), C.c_int64(x.size), C.c_int(sr), C.byref(p))
+    return y
+
+
+def acompressor(x, sr, threshold=0.125893, ratio=3.0, attack=10.0, release=200.0, makeup=1.0, knee=4.0, mix=1.0):
+    x = np.ascontiguousarray(x, np.float64)
+    y = np.empty_like(x)
+    p = CompParams(threshold, ratio, attack, release, makeup, knee, mix, 1)
+    lib().orc_acompressor_f64(_p(x, C.c_double), _p(y, C.c_double), C.c_int64(x.size), C.c_int(sr), C.byref(p))
+    return y
+
+
+def deesser(x, sr, i=0.5, m=0.5, f=0.8):
+    x = np.ascontiguousarray(x, np.float64)
+    y = np.empty_like(x)
+    lib().orc_deesser_f64(_p(x, C.c_double), _p(y, C.c_double), C.c_int64(x.size), C.c_int(sr),
+                          C.c_double(i), C.c_double(m), C.c_double(f))
+    return y
+
+
+def alimiter(x, sr, limit, attack=5.0, release=100.0, asc_level=0.8):
+    x = np.ascontiguousarray(x, np.float64)
+    y = np.empty_like(x)
+    lib().orc_alimiter_f64(_p(x, C.c_double), _p(y, C.c_double), C.c_int64(x.size), C.c_int(sr),
+                           C.c_double(limit), C.c_double(attack), C.c_double(release), C.c_double(asc_level))
+    return y
+
+
+def swr_f64(x, in_rate, out_rate, flush=True):
+    x = np.ascontiguousarray(x, np.float64)
+    cap = int(np.ceil(x.size * out_rate / in_rate)) + 4
+    y = np.empty(cap, np.float64)
+    fn = lib().orc_swr_resample_f64
+    fn.restype = C.c_int64
+    m = fn(_p(x, C.c_double), C.c_int64(x.size), C.c_int(in_rate), C.c_int(out_rate),
+           _p(y, C.c_double), C.c_int64(cap), C.c_int(1 if flush else 0))
+    return y[:m].copy()
+
+
+def swr_f32(x, in_rate, out_rate, flush=True):
+    x = np.ascontiguousarray(x, np.float32)
+    cap = int(np.ceil(x.size * out_rate / in_rate)) + 4
+    y = np.empty(cap, np.float32)
+    fn = lib().orc_swr_resample_f32
+    fn.restype = C.c_int64
+    m = fn(_p(x, C.c_float), C.c_int64(x.size), C.c_int(in_rate), C.c_int(out_rate),
+           _p(y, C.c_float), C.c_int64(cap), C.c_int(1 if flush else 0))
+    return y[:m].copy()
+
+
+def f64_to_s16(x):
+    x = np.ascontiguousarray(x, np.float64)
+    y = np.empty(x.size, np.int16)
+    lib().orc_f64_to_s16(_p(x, C.c_double), _p(y, C.c_int16), C.c_int64(x.size))
+    return y
+
+
+class Ebur128Out(C.Structure):
+    _fields_ = [("integrated", C.c_double), ("lra", C.c_double), ("lra_low", C.c_double),
+                ("lra_high", C.c_double), ("momentary_last", C.c_double), ("shortterm_last", C.c_double),
+                ("sample_peak", C.c_double), ("true_peak", C.c_double), ("target_threshold", C.c_double),
+                ("nblocks", C.c_int64)]
+
+
+def ebur128(x, sr, dualmono=True, true_peak=True):
+    x = np.ascontiguousarray(x, np.float64)
+    cap = x.size // (sr // 10) + 2
+    m = np.empty(cap); s = np.empty(cap); tp = np.empty(cap); sp = np.empty(cap)
+    o = Ebur128Out()
+    lib().orc_ebur128_mono(_p(x, C.c_double), C.c_int64(x.size), C.c_int(sr), C.c_int(int(dualmono)),
+                           C.c_int(int(true_peak)), C.byref(o), _p(m, C.c_double), _p(s, C.c_double),
+                           _p(tp, C.c_double), _p(sp, C.c_double), C.c_int64(cap))
+    nb = o.nblocks
+    d = {k: getattr(o, k) for k, _ in Ebur128Out._fields_}
+    d.update(M=m[:nb].copy(), S=s[:nb].copy(), TP=tp[:nb].copy(), SP=sp[:nb].copy())
+    return d
+
+
+class LoudnormIn(C.Structure):
+    _fields_ = [("input_i", C.c_double), ("input_tp", C.c_double), ("input_lra", C.c_double),
+                ("input_thresh", C.c_double)]
+
+
+def loudnorm_measure(x, sr, dual_mono=True):
+    x = np.ascontiguousarray(x, np.float64)
+    o = LoudnormIn()
+    lib().orc_loudnorm_measure_mono(_p(x, C.c_double), C.c_int64(x.size), C.c_int(sr), C.c_int(int(dual_mono)), C.byref(o))
+    return {k: getattr(o, k) for k, _ in LoudnormIn._fields_}
+
+
+ASTATS_FIELDS = ["dc_offset", "min_level", "max_level", "min_difference", "max_difference", "mean_difference",
+                 "rms_difference", "peak_level_db", "rms_level_db", "rms_peak_db", "rms_trough_db", "crest_factor",
+                 "flat_factor", "peak_count", "noise_floor_db", "noise_floor_count", "entropy", "dynamic_range",
+                 "zero_crossings", "zero_crossings_rate", "number_of_samples", "abs_peak_count"]
+
+
+class AstatsOut(C.Structure):
+    _fields_ = [(k, C.c_double) for k in ASTATS_FIELDS]
+
+
+def astats(x, sr):
+    x = np.ascontiguousarray(x, np.float64)
+    o = AstatsOut()
+    lib().orc_astats_mono(_p(x, C.c_double), C.c_int64(x.size), C.c_int(sr), C.byref(o))
+    return {k: getattr(o, k) for k in ASTATS_FIELDS}
+
+
+SPECTRAL_KEYS = ["mean", "variance", "centroid", "spread", "skewness", "kurtosis", "entropy",
+                 "flatness", "crest", "flux", "slope", "decrease", "rolloff"]
+
+
+def aspectralstats(x, sr, win_size=2048):
+    x = np.ascontiguousarray(x, np.float32)
+    hop = win_size // 2
+    cap = (x.size + hop - 1) // hop + 1
+    st = np.zeros((cap, 13), np.float64)
+    fn = lib().orc_aspectralstats_mono
+    fn.restype = C.c_int64
+    nh = fn(_p(x, C.c_float), C.c_int64(x.size), C.c_int(sr), C.c_int(win_size), _p(st, C.c_double), C.c_int64(cap))
+    return st[:nh].copy()

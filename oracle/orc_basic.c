@@ -1,0 +1,398 @@
+/*
+ * orc_basic.c — ORACLE (test infrastructure only; see jt_oracle.h).
+ * Biquads (af_biquads.c), agate (af_agate.c), acompressor (af_sidechaincompress.c),
+ * deesser (af_deesser.c), alimiter (af_alimiter.c) restated from FFmpeg 8.1.
+ * Reference call sites: filters.go:740-769 (biquads), :869-894 (agate), :900-916
+ * (acompressor), :921-932 (deesser); normalise.go:446-480 (alimiter).
+ * parity unpinned (FFmpeg source/binary absent) — see jt_oracle.h.
+ */
+#include "jt_oracle.h"
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define FFMIN(a,b) ((a) < (b) ? (a) : (b))
+#define FFMAX(a,b) ((a) > (b) ? (a) : (b))
+
+/* ------------------------------------------------------------------ biquads */
+/* af_biquads.c config_filter(): RBJ cookbook, width_type=q => alpha = sin(w0)/(2Q);
+ * all coefficients divided by a0; normalize=1 rescales b by (sum a)/(sum b) when |sum b|>1e-6. */
+void orc_biquad_coeffs(int type, double freq, double q, int sample_rate, double b[3], double a[3])
+{
+    double w0 = 2 * M_PI * freq / sample_rate;
+    double alpha = sin(w0) / (2 * q);
+    a[0] = 1 + alpha;
+    a[1] = -2 * cos(w0);
+    a[2] = 1 - alpha;
+    if (type == 0) { /* highpass, poles=2 */
+        b[0] = (1 + cos(w0)) / 2;
+        b[1] = -(1 + cos(w0));
+        b[2] = (1 + cos(w0)) / 2;
+    } else {         /* lowpass, poles=2 */
+        b[0] = (1 - cos(w0)) / 2;
+        b[1] = 1 - cos(w0);
+        b[2] = (1 - cos(w0)) / 2;
+    }
+    a[1] /= a[0]; a[2] /= a[0];
+    b[0] /= a[0]; b[1] /= a[0]; b[2] /= a[0];
+    a[0] /= a[0];
+    if (fabs(b[0] + b[1] + b[2]) > 1e-6) {
+        double factor = (a[0] + a[1] + a[2]) / (b[0] + b[1] + b[2]);
+        b[0] *= factor; b[1] *= factor; b[2] *= factor;
+    }
+}
+
+/* BIQUAD_TDII_FILTER(flt, float, float, ...): float coefficients, float state. */
+void orc_biquad_tdii_f32(const float *in, float *out, int64_t n, const double b[3], const double a[3])
+{
+    float a1 = -(float)a[1], a2 = -(float)a[2];
+    float b0 = (float)b[0], b1 = (float)b[1], b2 = (float)b[2];
+    float w1 = 0.f, w2 = 0.f;
+    for (int64_t i = 0; i < n; i++) {
+        float x = in[i];
+        float y = b0 * x + w1;
+        w1 = b1 * x + w2 + a1 * y;
+        w2 = b2 * x + a2 * y;
+        out[i] = y;             /* mix = 1: out*wet + in*dry with wet=1, dry=0 */
+    }
+}
+
+void orc_biquad_tdii_f64(const double *in, double *out, int64_t n, const double b[3], const double a[3])
+{
+    double a1 = -a[1], a2 = -a[2], b0 = b[0], b1 = b[1], b2 = b[2];
+    double w1 = 0., w2 = 0.;
+    for (int64_t i = 0; i < n; i++) {
+        double x = in[i];
+        double y = b0 * x + w1;
+        w1 = b1 * x + w2 + a1 * y;
+        w2 = b2 * x + a2 * y;
+        out[i] = y;
+    }
+}
+
+/* ------------------------------------------------- hermite_interpolation.h */
+static double hermite_interpolation(double x, double x0, double x1,
+                                    double p0, double p1, double m0, double m1)
+{
+    double width = x1 - x0;
+    double t = (x - x0) / width;
+    double t2, t3, ct0, ct1, ct2, ct3;
+    m0 *= width;
+    m1 *= width;
+    t2 = t * t;
+    t3 = t2 * t;
+    ct0 = p0;
+    ct1 = m0;
+    ct2 = -3 * p0 - 2 * m0 + 3 * p1 - m1;
+    ct3 = 2 * p0 + m0 - 2 * p1 + m1;
+    return ct3 * t3 + ct2 * t2 + ct1 * t + ct0;
+}
+
+#define FAKE_INFINITY (65536.0 * 65536.0)
+#define IS_FAKE_INFINITY(v) (fabs((v) - FAKE_INFINITY) < 1.0)
+
+/* -------------------------------------------------------------------- agate */
+/* af_agate.c: mode=downward, link=average (mono), level_in=level_sc=1. */
+static double gate_output_gain(double lin_slope, double ratio, double thres, double knee,
+                               double knee_start, double knee_stop, double range)
+{
+    double slope = log(lin_slope);
+    double tratio = ratio;
+    double gain, delta;
+    if (IS_FAKE_INFINITY(ratio))
+        tratio = 1000.;
+    gain = (slope - thres) * tratio + thres;
+    delta = tratio;
+    if (knee > 1. && slope > knee_start)
+        gain = hermite_interpolation(slope, knee_start, knee_stop,
+                                     ((knee_start - thres) * tratio + thres), knee_stop, delta, 1.);
+    return FFMAX(range, exp(gain - slope));
+}
+
+void orc_agate_f64(const double *in, double *out, int64_t n, int sample_rate, const orc_gate_params *p)
+{
+    double lin_threshold = p->threshold;
+    double lin_knee_sqrt = sqrt(p->knee);
+    if (p->detection_rms)
+        lin_threshold *= lin_threshold;
+    double attack_coeff  = FFMIN(1., 1. / (p->attack_ms * sample_rate / 4000.));
+    double release_coeff = FFMIN(1., 1. / (p->release_ms * sample_rate / 4000.));
+    double lin_knee_stop  = lin_threshold * lin_knee_sqrt;
+    double lin_knee_start = lin_threshold / lin_knee_sqrt;
+    double thres = log(lin_threshold);
+    double knee_start = log(lin_knee_start);
+    double knee_stop = log(lin_knee_stop);
+    double lin_slope = 0.;
+    for (int64_t i = 0; i < n; i++) {
+        double abs_sample = fabs(in[i]), gain = 1.0;
+        if (p->detection_rms)
+            abs_sample *= abs_sample;
+        lin_slope += (abs_sample - lin_slope) * (abs_sample > lin_slope ? attack_coeff : release_coeff);
+        int detected = lin_slope < lin_knee_stop;
+        if (lin_slope > 0.0 && detected)
+            gain = gate_output_gain(lin_slope, p->ratio, thres, p->knee, knee_start, knee_stop, p->range);
+        out[i] = in[i] * (1.0 * gain * p->makeup);
+    }
+}
+
+/* -------------------------------------------------------------- acompressor */
+static double comp_output_gain(double lin_slope, double ratio, double thres, double knee,
+                               double knee_start, double knee_stop,
+                               double compressed_knee_start, double compressed_knee_stop, int detection)
+{
+    double slope = log(lin_slope);
+    double gain, delta;
+    (void)compressed_knee_start;
+    if (detection)
+        slope *= 0.5;
+    if (IS_FAKE_INFINITY(ratio)) {
+        gain = thres;
+        delta = 0.0;
+    } else {
+        gain = (slope - thres) / ratio + thres;
+        delta = 1.0 / ratio;
+    }
+    if (knee > 1.0 && slope < knee_stop)
+        gain = hermite_interpolation(slope, knee_start, knee_stop,
+                                     knee_start, compressed_knee_stop, 1.0, delta);
+    return exp(gain - slope);
+}
+
+void orc_acompressor_f64(const double *in, double *out, int64_t n, int sample_rate, const orc_comp_params *p)
+{
+    double thres = log(p->threshold);
+    double lin_knee_start = p->threshold / sqrt(p->knee);
+    double lin_knee_stop  = p->threshold * sqrt(p->knee);
+    double adj_knee_start = lin_knee_start * lin_knee_start;
+    double knee_start = log(lin_knee_start);
+    double knee_stop  = log(lin_knee_stop);
+    double compressed_knee_start = (knee_start - thres) / p->ratio + thres;
+    double compressed_knee_stop  = (knee_stop - thres) / p->ratio + thres;
+    double attack_coeff  = FFMIN(1., 1. / (p->attack_ms * sample_rate / 4000.));
+    double release_coeff = FFMIN(1., 1. / (p->release_ms * sample_rate / 4000.));
+    double lin_slope = 0.;
+    for (int64_t i = 0; i < n; i++) {
+        double abs_sample = fabs(in[i]), gain = 1.0;
+        if (p->detection_rms)
+            abs_sample *= abs_sample;
+        lin_slope += (abs_sample - lin_slope) * (abs_sample > lin_slope ? attack_coeff : release_coeff);
+        double detector = p->detection_rms ? adj_knee_start : lin_knee_start;
+        int detected = lin_slope > detector;
+        if (lin_slope > 0.0 && detected)
+            gain = comp_output_gain(lin_slope, p->ratio, thres, p->knee, knee_start, knee_stop,
+                                    compressed_knee_start, compressed_knee_stop, p->detection_rms);
+        out[i] = in[i] * 1.0 * (gain * p->makeup * p->mix + (1. - p->mix));
+    }
+}
+
+/* ------------------------------------------------------------------ deesser */
+void orc_deesser_f64(const double *in, double *out, int64_t n, int sample_rate,
+                     double intensity_opt, double max_opt, double frequency_opt)
+{
+    double s1 = 0, s2 = 0, s3 = 0, m1, m2;
+    double ratioA = 1.0, ratioB = 1.0, iirSampleA = 0, iirSampleB = 0;
+    int flip = 0;
+    double overallscale = sample_rate < 44100 ? 44100.0 / sample_rate : sample_rate / 44100.0;
+    double intensity = pow(intensity_opt, 5) * (8192 / overallscale);
+    double maxdess = 1.0 / pow(10.0, ((max_opt - 1.0) * 48.0) / 20);
+    double iirAmount = pow(frequency_opt, 2) / overallscale;
+    for (int64_t i = 0; i < n; i++) {
+        double sample = in[i];
+        double offset, sense, recovery, attackspeed;
+        s3 = s2; s2 = s1; s1 = sample;
+        m1 = (s1 - s2) * ((s1 - s2) / 1.3);
+        m2 = (s2 - s3) * ((s1 - s2) / 1.3);
+        sense = (m1 - m2) * ((m1 - m2) / 1.3);
+        attackspeed = 7.0 + sense * 1024;
+        sense = 1.0 + intensity * intensity * sense;
+        sense = FFMIN(sense, intensity);
+        recovery = 1.0 + (0.01 / sense);
+        offset = 1.0 - fabs(sample);
+        if (flip) {
+            iirSampleA = (iirSampleA * (1.0 - (offset * iirAmount))) + (sample * (offset * iirAmount));
+            if (ratioA < sense)
+                ratioA = ((ratioA * attackspeed) + sense) / (attackspeed + 1.0);
+            else
+                ratioA = 1.0 + ((ratioA - 1.0) / recovery);
+            ratioA = FFMIN(ratioA, maxdess);
+            sample = iirSampleA + ((sample - iirSampleA) / ratioA);
+        } else {
+            iirSampleB = (iirSampleB * (1.0 - (offset * iirAmount))) + (sample * (offset * iirAmount));
+            if (ratioB < sense)
+                ratioB = ((ratioB * attackspeed) + sense) / (attackspeed + 1.0);
+            else
+                ratioB = 1.0 + ((ratioB - 1.0) / recovery);
+            ratioB = FFMIN(ratioB, maxdess);
+            sample = iirSampleB + ((sample - iirSampleB) / ratioB);
+        }
+        flip = !flip;
+        out[i] = sample;
+    }
+}
+
+/* ----------------------------------------------------------------- alimiter */
+/* af_alimiter.c, mono, level_in=level_out=1, level=0 (auto_level off), asc=1,
+ * latency=1 (output aligned with input: first buffer_size-1 outputs trimmed, tail flushed with zeros). */
+typedef struct {
+    double limit, release, att, asc, asc_coeff, delta;
+    int asc_c, asc_pos, asc_changed, auto_release;
+    double *buffer, *nextdelta;
+    int *nextpos;
+    int buffer_size, pos, nextiter, nextlen;
+    int sample_rate;
+} Limiter;
+
+static double get_rdelta(Limiter *s, double release, int sample_rate,
+                         double peak, double limit, double patt, int asc)
+{
+    double rdelta = (1.0 - patt) / (sample_rate * release);
+    (void)peak;
+    if (asc && s->auto_release && s->asc_c > 0) {
+        double a_att = limit / (s->asc_coeff * s->asc) * (double)s->asc_c;
+        if (a_att > patt) {
+            double delta = FFMAX((a_att - patt) / (sample_rate * release), rdelta / 10);
+            if (delta < rdelta)
+                rdelta = delta;
+        }
+    }
+    return rdelta;
+}
+
+static double limiter_step(Limiter *s, double x)
+{
+    const int channels = 1;
+    const int buffer_size = s->buffer_size;
+    double *buffer = s->buffer, *nextdelta = s->nextdelta;
+    int *nextpos = s->nextpos;
+    const double limit = s->limit, release = s->release;
+    double peak = 0, out;
+    int i;
+
+    buffer[s->pos] = x;
+    peak = FFMAX(peak, fabs(x));
+
+    if (s->auto_release && peak > limit) {
+        s->asc += peak;
+        s->asc_c++;
+    }
+
+    if (peak > limit) {
+        double patt = FFMIN(limit / peak, 1.);
+        double rdelta = get_rdelta(s, release, s->sample_rate, peak, limit, patt, 0);
+        double delta = (limit / peak - s->att) / buffer_size * channels;
+        int found = 0;
+
+        if (delta < s->delta) {
+            s->delta = delta;
+            nextpos[0] = s->pos;
+            nextpos[1] = -1;
+            nextdelta[0] = rdelta;
+            s->nextlen = 1;
+            s->nextiter = 0;
+        } else {
+            for (i = s->nextiter; i < s->nextiter + s->nextlen; i++) {
+                int j = i % buffer_size;
+                double ppeak = 0, pdelta;
+                ppeak = FFMAX(ppeak, fabs(buffer[nextpos[j]]));
+                pdelta = (limit / peak - limit / ppeak) /
+                         (((buffer_size - nextpos[j] + s->pos) % buffer_size) / channels);
+                if (pdelta < nextdelta[j]) {
+                    nextdelta[j] = pdelta;
+                    found = 1;
+                    break;
+                }
+            }
+            if (found) {
+                s->nextlen = i - s->nextiter + 1;
+                nextpos[(s->nextiter + s->nextlen) % buffer_size] = s->pos;
+                nextdelta[(s->nextiter + s->nextlen) % buffer_size] = rdelta;
+                nextpos[(s->nextiter + s->nextlen + 1) % buffer_size] = -1;
+                s->nextlen++;
+            }
+        }
+    }
+
+    {
+        double *buf = &s->buffer[(s->pos + channels) % buffer_size];
+        peak = FFMAX(0, fabs(buf[0]));
+
+        if (s->pos == s->asc_pos && !s->asc_changed)
+            s->asc_pos = -1;
+
+        if (s->auto_release && s->asc_pos == -1 && peak > limit) {
+            s->asc -= peak;
+            s->asc_c--;
+        }
+
+        s->att += s->delta;
+        out = buf[0] * s->att;
+    }
+
+    if ((s->pos + channels) % buffer_size == nextpos[s->nextiter]) {
+        if (s->auto_release) {
+            s->delta = get_rdelta(s, release, s->sample_rate, peak, limit, s->att, 1);
+            if (s->nextlen > 1) {
+                double ppeak = 0, pdelta;
+                int pnextpos = nextpos[(s->nextiter + 1) % buffer_size];
+                ppeak = FFMAX(ppeak, fabs(buffer[pnextpos]));
+                pdelta = (limit / ppeak - s->att) /
+                         (((buffer_size + pnextpos - ((s->pos + channels) % buffer_size)) % buffer_size) / channels);
+                if (pdelta < s->delta)
+                    s->delta = pdelta;
+            }
+        } else {
+            s->delta = nextdelta[s->nextiter];
+            s->att = limit / peak;
+        }
+        s->nextlen -= 1;
+        nextpos[s->nextiter] = -1;
+        s->nextiter = (s->nextiter + 1) % buffer_size;
+    }
+
+    if (s->att > 1.) {
+        s->att = 1.;
+        s->delta = 0.;
+        s->nextiter = 0;
+        s->nextlen = 0;
+        nextpos[0] = -1;
+    }
+    if (s->att <= 0.) {
+        s->att = 0.0000000000001;
+        s->delta = (1.0 - s->att) / (s->sample_rate * release);
+    }
+    if (s->att != 1. && (1. - s->att) < 0.0000000000001)
+        s->att = 1.;
+    if (s->delta != 0. && fabs(s->delta) < 0.00000000000001)
+        s->delta = 0.;
+
+    out = (out < -limit ? -limit : (out > limit ? limit : out)) * 1.0 /* level */ * 1.0 /* level_out */;
+    s->pos = (s->pos + channels) % buffer_size;
+    return out;
+}
+
+void orc_alimiter_f64(const double *in, double *out, int64_t n, int sample_rate,
+                      double limit, double attack_ms, double release_ms, double asc_level)
+{
+    Limiter s;
+    memset(&s, 0, sizeof(s));
+    double attack = attack_ms / 1000., release = release_ms / 1000.;
+    s.limit = limit; s.release = release; s.att = 1.; s.asc_pos = -1;
+    s.asc_coeff = pow(0.5, asc_level - 0.5) * 2 * -1;   /* af_alimiter.c init() */
+    s.auto_release = 1;
+    s.sample_rate = sample_rate;
+    int obuffer_size = (int)(sample_rate * 1 * 100 / 1000. + 1);
+    s.buffer = calloc(obuffer_size, sizeof(double));
+    s.nextdelta = calloc(obuffer_size, sizeof(double));
+    s.nextpos = malloc(obuffer_size * sizeof(int));
+    for (int i = 0; i < obuffer_size; i++) s.nextpos[i] = -1;
+    s.buffer_size = (int)(sample_rate * attack * 1);
+    if (s.buffer_size < 1) s.buffer_size = 1;
+    int trim = s.buffer_size - 1;   /* in_trim = out_pad = buffer_size/channels - 1 */
+    for (int64_t i = 0; i < n + trim; i++) {
+        double x = i < n ? in[i] : 0.0;
+        double y = limiter_step(&s, x);
+        if (i >= trim)
+            out[i - trim] = y;
+    }
+    free(s.buffer); free(s.nextdelta); free(s.nextpos);
+}
