@@ -1,0 +1,214 @@
+/*
+ * jtgpu.h — C ABI of libjtgpu.so: the MI355X (gfx950) engine for jivetalking's four-pass
+ * speech-mastering hot path.
+ *
+ * Boundary.  The reference has no plugin ABI; its engine seam is
+ *   setupFilterGraph(decCtx, spec) + runFilterGraph(ctx, reader, src, sink, FrameLoopConfig)
+ *   (internal/processor/frame_processor.go:64,164; abstracted as loudnormDeps,
+ *   normalise.go:172-188)
+ * i.e. "an FFmpeg filter-spec string in, frames carrying lavfi.* metadata + a loudnorm JSON out".
+ * This library replaces the four runFilterGraph sweeps and the band/region re-measures; PCM
+ * decode/encode stays on the host side.  Every entry point below names the reference
+ * interface it replaces.  Plain C types only; one handle per worker goroutine / GPU stream;
+ * every call returns 0 on success or a negative JT_E_* code, with text in jt_last_error().
+ *
+ * Values are returned as raw doubles.  FFmpeg hands the reference the same quantities as
+ * formatted strings (astats "%f", ebur128 "%.3f", loudnorm "%.2f"); the host mirror
+ * (jt_host.h) applies those roundings where the reference's control flow depends on them.
+ */
+#ifndef JTGPU_H
+#define JTGPU_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define JT_OK               0
+#define JT_E_INVAL         -1   /* bad argument */
+#define JT_E_NOGPU         -2   /* no HIP device / device init failed */
+#define JT_E_HIP           -3   /* HIP runtime error (text in jt_last_error) */
+#define JT_E_STATE         -4   /* call out of order (e.g. pass2 before upload) */
+#define JT_E_UNSUPPORTED   -5   /* parameter combination not implemented on the GPU path */
+#define JT_E_CANCELLED     -6   /* jt_cancel() observed (ctx.Err() analogue, frame_processor.go:116-118) */
+#define JT_E_SILENT        -7   /* "cannot normalise silent audio" (normalise.go:840-842) */
+
+typedef struct jt_ctx jt_ctx;
+
+/* ---- lifecycle ---- */
+int  jt_open(int device_id, jt_ctx **out);
+void jt_close(jt_ctx *h);
+const char *jt_last_error(const jt_ctx *h);
+const char *jt_version(void);
+void jt_cancel(jt_ctx *h);                 /* may be called from another thread */
+
+/* ---- input: replaces audio.Reader.ReadFrame feeding abuffer (reader.go:129, frame_processor.go:131-146) ---- */
+/* interleaved f32 PCM in host memory; copied to HBM. channels 1 or 2 (2 => aformat=channel_layouts=mono
+ * downmix, filters.go:607-615, float formats: (L+R)*M_SQRT1_2 per swresample rematrix). */
+int jt_upload_pcm(jt_ctx *h, const float *interleaved, int64_t frames, int sample_rate, int channels);
+/* same, but the PCM is already resident in device memory (hipMalloc'd by the caller, e.g. a torch tensor);
+ * not copied, must stay alive until jt_close / next upload. */
+int jt_attach_device_pcm(jt_ctx *h, const void *dev_ptr, int64_t frames, int sample_rate, int channels);
+/* s16 PCM at `sample_rate` (the Pass-2 temp FLAC as re-read by Pass 3/4 and region measures) */
+int jt_upload_s16(jt_ctx *h, const int16_t *pcm, int64_t frames, int sample_rate);
+
+/* ---- shared measurement structs (analyser.go:140-184, analyser_metrics.go:694-711) ---- */
+typedef struct {
+    double mean, variance, centroid, spread, skewness, kurtosis, entropy, flatness,
+           crest, flux, slope, decrease, rolloff;
+} jt_spectral;                               /* lavfi.aspectralstats.1.* */
+
+typedef struct {
+    double dc_offset, min_level, max_level, min_difference, max_difference, mean_difference,
+           rms_difference, peak_level, rms_level, rms_peak, rms_trough, crest_factor, flat_factor,
+           peak_count, noise_floor, noise_floor_count, entropy, dynamic_range, zero_crossings,
+           zero_crossings_rate, number_of_samples, bit_depth;
+} jt_astats;                                 /* lavfi.astats.1.* (dB where FFmpeg prints dB, linear otherwise) */
+
+typedef struct {
+    double integrated, lra, lra_low, lra_high, momentary, shortterm;  /* last values (LUFS / LU) */
+    double true_peak, sample_peak;           /* LINEAR, as lavfi.r128.true_peak / sample_peak */
+    double target_threshold;                 /* lavfi.r128.target_threshold analogue: relative gate of I */
+} jt_r128;
+
+/* one 100 ms ebur128 output frame as the Go OnFrame callback sees it (analyser.go:621-630) */
+typedef struct {
+    double momentary, shortterm;             /* lavfi.r128.M / S */
+    double true_peak, sample_peak;           /* cumulative linear peaks */
+    jt_spectral spectral;                    /* aspectralstats frame whose props survive re-framing */
+} jt_frame_meta;
+
+typedef struct {
+    jt_astats   astats;                      /* whole-file (cumulative "latest wins") */
+    jt_r128     r128;
+    jt_spectral spectral_mean;               /* mean over the 100 ms output frames (analyser_metrics.go:715-744) */
+    int64_t     n_frames_meta;               /* number of 100 ms output frames */
+    int64_t     n_input_frames;              /* number of decoder frames of frame_samples */
+} jt_analysis;
+
+/* ---- Pass 1: replaces collectAnalysisFrames' runFilterGraph sweep (analyser.go:538-650) over
+ * "aformat=channel_layouts=mono,astats=...,aspectralstats=win_size=2048:win_func=hann:measure=all,
+ *  ebur128=metadata=1:peak=sample+true:dualmono=true:target=-16" (filters.go:42-45,624-626,684-689).
+ * frame_samples = decoder frame size (4096 for FLAC).  frame_sumsq/frame_peak: per decoder frame
+ * sum(x^2) and max|x| on the RAW (pre-downmix, all channels) samples as frameSumSquaresAndPeak computes
+ * them (analyser_metrics.go:273-358); caller arrays of n_input_frames entries (or NULL).
+ * meta: caller array for the 100 ms output frames (cap_meta entries, or NULL). */
+int jt_pass1(jt_ctx *h, int frame_samples, jt_analysis *out,
+             double *frame_sumsq, double *frame_peak, int64_t cap_frames,
+             jt_frame_meta *meta, int64_t cap_meta);
+
+/* ---- band RMS: replaces measureSpeechBandRMS / measureNoiseBands region graphs
+ * "aformat=channel_layouts=mono,atrim=start:duration,asetpts,highpass=f=lo:p=2,lowpass=f=hi:p=2,
+ *  astats=metadata=1:measure_perchannel=0" (analyser_bands.go:33, analyser_noise_bands.go:65-119).
+ * out_db[i] = lavfi.astats.Overall.RMS_level of band i over the region of the uploaded input. */
+int jt_band_rms(jt_ctx *h, double start_s, double dur_s, const double *lo_hz, const double *hi_hz,
+                int n_bands, double *out_db, int *ok);
+
+/* ---- Pass 2 parameters: numeric content of EffectiveFilterConfig (filters.go:111-255) at the
+ * string-formatted precision BuildFilterSpec emits (filters.go:755,811,844,883,906,927). ---- */
+typedef struct {
+    int    hp_enabled;  double hp_freq, hp_q;                 /* highpass=f:poles=2:width_type=q:width:normalize=1:a=tdii */
+    int    lp_enabled;  double lp_freq, lp_q;                 /* lowpass=... */
+    int    nlm_enabled; double nlm_strength, nlm_patch_s, nlm_research_s, nlm_smooth;   /* anlmdn=s:p:r:m */
+    int    fft_enabled; double fft_nr, fft_nf;                /* afftdn=nr:...:nf (nf 0 => FFmpeg default -50) */
+    int    fft_custom;  double fft_band_noise[15];            /* nt=custom:bn= */
+    int    fft_track_noise;                                   /* tn=1 => JT_E_UNSUPPORTED */
+    int    gate_enabled; double gate_threshold, gate_ratio, gate_attack_ms, gate_release_ms,
+                                gate_range, gate_knee, gate_makeup;                     /* agate, detection=rms */
+    int    comp_enabled; double comp_threshold, comp_ratio, comp_attack_ms, comp_release_ms,
+                                comp_makeup, comp_knee, comp_mix;                       /* acompressor, linear thr/makeup */
+    int    deess_enabled; double deess_i, deess_m, deess_f;                             /* deesser=i:m:f */
+    int    out_rate;                                           /* 44100 (aformat=sample_rates=44100:...:sample_fmts=s16) */
+    int    out_frame_samples;                                  /* asetnsamples=n=4096 */
+} jt_filter_params;
+
+/* ---- Pass 2: replaces processWithFilters' runFilterGraph sweep (processor.go:255-373) over
+ * BuildFilterSpec() (filters.go:968-989; golden chain filters_test.go:298-311).  Leaves the s16 @ out_rate
+ * result resident on the device as stage 2. */
+int jt_pass2(jt_ctx *h, const jt_filter_params *p, jt_analysis *out);
+
+/* ---- region re-measure: replaces measureOutputRegionFromReader (analyser_output.go:95-227) over
+ * "atrim=start:duration,asetpts=PTS-STARTPTS,astats=metadata=1:measure_perchannel=0,
+ *  aspectralstats=measure=all,ebur128=metadata=1:peak=sample+true" (analyser_output.go:18).
+ * stage: 2 = Pass-2 output, 4 = Pass-4 output (both s16 on device). */
+typedef struct {
+    double rms_level, peak_level, crest_factor;   /* astats Overall (crest linear) */
+    jt_spectral spectral;                          /* mean over output frames */
+    double momentary, shortterm;                   /* last lavfi.r128.M / S */
+    double true_peak, sample_peak;                 /* last, LINEAR */
+    int64_t frames;
+} jt_region_sample;
+int jt_region_measure(jt_ctx *h, int stage, double start_s, double dur_s, jt_region_sample *out);
+
+/* ---- limiter prefix shared by Pass 3 and Pass 4 (normalise.go:446-465 buildPreLimiterPrefix) ---- */
+typedef struct {
+    int    needed;            /* emit alimiter */
+    double pre_gain_db;       /* volume=%.1fdB when > 0 */
+    double limit;             /* alimiter limit= (linear, %.6f) ; attack=5 release=100 asc=1 asc_level=0.8 latency=1 level=0 */
+} jt_limiter_plan;
+
+typedef struct {              /* loudnorm print_format=json (normalise.go:64-75); doubles, shim rounds to %.2f */
+    double input_i, input_tp, input_lra, input_thresh;
+    double output_i, output_tp, output_lra, output_thresh;
+    double target_offset;
+    int    normalization_type_dynamic;   /* 0 = "linear", 1 = "dynamic" */
+} jt_loudnorm_stats;
+
+/* ---- Pass 3: replaces measureWithLoudnorm's sweep (normalise.go:226-346) over
+ * "<prefix>,loudnorm=I=-16.0:TP=-1.0:LRA=20.0:dual_mono=true:print_format=json:stats_file=..." (:257-268).
+ * Only the input_* fields and target_offset are filled (the dynamic-mode output is discarded by the
+ * reference; target_offset is NOT consumed: normalise.go:861-873 derives its own offset) —
+ * output_* = NaN, target_offset = NaN. */
+int jt_pass3(jt_ctx *h, const jt_limiter_plan *lim, double target_i, double target_tp, double target_lra,
+             jt_loudnorm_stats *out);
+
+typedef struct {              /* loudnorm second pass options (normalise.go:1269-1291), values as %.2f-formatted */
+    double target_i, target_tp, target_lra;
+    double measured_i, measured_tp, measured_lra, measured_thresh;
+    double offset;
+    int    adeclick_enabled;  double adeclick_threshold, adeclick_window_ms, adeclick_overlap_pct;   /* filters.go:947-962 */
+    double brickwall_limit;   /* alimiter limit= (linear) attack=1 release=50 (normalise.go:474-480) */
+} jt_loudnorm_apply;
+
+/* ---- Pass 4: replaces applyLoudnormAndMeasure's sweep (normalise.go:924-1190) over
+ * buildLoudnormFilterSpec() (normalise.go:1231-1334; golden normalise_test.go:2135-2223):
+ * [volume,alimiter,]loudnorm(linear),aresample,adeclick,alimiter(brickwall),astats,aspectralstats,
+ * ebur128,aformat(s16).  Leaves the final s16 on device as stage 4. */
+int jt_pass4(jt_ctx *h, const jt_limiter_plan *lim, const jt_loudnorm_apply *ap,
+             jt_analysis *out, jt_loudnorm_stats *stats);
+
+/* ---- output: replaces Encoder.WriteFrame's input (encoder.go:145); FLAC encode stays on the host ---- */
+int jt_output_len(jt_ctx *h, int stage, int64_t *n);
+int jt_download_s16(jt_ctx *h, int stage, int16_t *dst, int64_t cap, int64_t *n);
+
+/* ---- per-pass device timers (ms, HIP events on the engine stream) for the roofline report ---- */
+typedef struct { double pass1_ms, pass2_ms, pass3_ms, pass4_ms; double nlm_ms; int64_t nlm_launches; } jt_timers;
+int jt_get_timers(jt_ctx *h, jt_timers *out);
+
+/* =====================================================================================
+ * Operator-level entry points: one per FFmpeg filter on the path, operating on caller host buffers
+ * (copied to/from HBM).  Used by the parity tests to compare each HIP kernel with the oracle.
+ * ===================================================================================== */
+int jt_op_biquad_f32(jt_ctx *h, const float *in, float *out, int64_t n, int sample_rate,
+                     int hp_enabled, double hp_freq, double hp_q, int lp_enabled, double lp_freq, double lp_q);
+int jt_op_anlmdn_f32(jt_ctx *h, const float *in, float *out, int64_t n, int sample_rate,
+                     double strength, double patch_s, double research_s, double smooth);
+int jt_op_afftdn_f32(jt_ctx *h, const float *in, float *out, int64_t n, int sample_rate,
+                     double nr, double nf, const double *band_noise /* 15 or NULL */);
+/* agate -> acompressor -> deesser chain in double on float input, output rounded to float
+ * (the dbl->flt conversion FFmpeg inserts before aspectralstats) */
+int jt_op_dynamics(jt_ctx *h, const float *in, float *out, int64_t n, int sample_rate, const jt_filter_params *p);
+int jt_op_alimiter_f64(jt_ctx *h, const double *in, double *out, int64_t n, int sample_rate,
+                       double limit, double attack_ms, double release_ms);
+int jt_op_resample_f32_to_s16(jt_ctx *h, const float *in, int64_t n, int in_rate, int out_rate,
+                              int16_t *out, int64_t cap, int64_t *n_out);
+int jt_op_ebur128(jt_ctx *h, const float *in, int64_t n, int sample_rate, int dualmono, jt_r128 *out,
+                  double *m_series, double *s_series, double *tp_series, double *sp_series, int64_t cap, int64_t *n_blocks);
+int jt_op_astats(jt_ctx *h, const float *in, int64_t n, int sample_rate, jt_astats *out);
+int jt_op_aspectralstats(jt_ctx *h, const float *in, int64_t n, int sample_rate, jt_spectral *hops, int64_t cap, int64_t *n_hops);
+int jt_op_loudnorm_measure_s16(jt_ctx *h, const int16_t *in, int64_t n, int sample_rate,
+                               const jt_limiter_plan *lim, jt_loudnorm_stats *out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,127 @@
+"""ctypes binding of include/jtgpu.h.  Fails loudly when the HIP library is missing: there is no CPU fallback."""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libjtgpu.so")
+_LIB = None
+
+JT_OK, JT_E_INVAL, JT_E_NOGPU, JT_E_HIP, JT_E_STATE, JT_E_UNSUPPORTED, JT_E_CANCELLED, JT_E_SILENT = 0, -1, -2, -3, -4, -5, -6, -7
+
+
+class JtError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"jtgpu error {code}: {msg}")
+        self.code = code
+
+
+SPECTRAL_KEYS = ["mean", "variance", "centroid", "spread", "skewness", "kurtosis", "entropy",
+                 "flatness", "crest", "flux", "slope", "decrease", "rolloff"]
+ASTATS_KEYS = ["dc_offset", "min_level", "max_level", "min_difference", "max_difference", "mean_difference",
+               "rms_difference", "peak_level", "rms_level", "rms_peak", "rms_trough", "crest_factor", "flat_factor",
+               "peak_count", "noise_floor", "noise_floor_count", "entropy", "dynamic_range", "zero_crossings",
+               "zero_crossings_rate", "number_of_samples", "bit_depth"]
+R128_KEYS = ["integrated", "lra", "lra_low", "lra_high", "momentary", "shortterm", "true_peak", "sample_peak",
+             "target_threshold"]
+
+
+class Spectral(C.Structure):
+    _fields_ = [(k, C.c_double) for k in SPECTRAL_KEYS]
+
+
+class Astats(C.Structure):
+    _fields_ = [(k, C.c_double) for k in ASTATS_KEYS]
+
+
+class R128(C.Structure):
+    _fields_ = [(k, C.c_double) for k in R128_KEYS]
+
+
+class FrameMeta(C.Structure):
+    _fields_ = [("momentary", C.c_double), ("shortterm", C.c_double), ("true_peak", C.c_double),
+                ("sample_peak", C.c_double), ("spectral", Spectral)]
+
+
+class Analysis(C.Structure):
+    _fields_ = [("astats", Astats), ("r128", R128), ("spectral_mean", Spectral),
+                ("n_frames_meta", C.c_int64), ("n_input_frames", C.c_int64)]
+
+
+class FilterParams(C.Structure):
+    _fields_ = [
+        ("hp_enabled", C.c_int), ("hp_freq", C.c_double), ("hp_q", C.c_double),
+        ("lp_enabled", C.c_int), ("lp_freq", C.c_double), ("lp_q", C.c_double),
+        ("nlm_enabled", C.c_int), ("nlm_strength", C.c_double), ("nlm_patch_s", C.c_double),
+        ("nlm_research_s", C.c_double), ("nlm_smooth", C.c_double),
+        ("fft_enabled", C.c_int), ("fft_nr", C.c_double), ("fft_nf", C.c_double),
+        ("fft_custom", C.c_int), ("fft_band_noise", C.c_double * 15),
+        ("fft_track_noise", C.c_int),
+        ("gate_enabled", C.c_int), ("gate_threshold", C.c_double), ("gate_ratio", C.c_double),
+        ("gate_attack_ms", C.c_double), ("gate_release_ms", C.c_double), ("gate_range", C.c_double),
+        ("gate_knee", C.c_double), ("gate_makeup", C.c_double),
+        ("comp_enabled", C.c_int), ("comp_threshold", C.c_double), ("comp_ratio", C.c_double),
+        ("comp_attack_ms", C.c_double), ("comp_release_ms", C.c_double), ("comp_makeup", C.c_double),
+        ("comp_knee", C.c_double), ("comp_mix", C.c_double),
+        ("deess_enabled", C.c_int), ("deess_i", C.c_double), ("deess_m", C.c_double), ("deess_f", C.c_double),
+        ("out_rate", C.c_int), ("out_frame_samples", C.c_int),
+    ]
+
+
+class RegionSample(C.Structure):
+    _fields_ = [("rms_level", C.c_double), ("peak_level", C.c_double), ("crest_factor", C.c_double),
+                ("spectral", Spectral), ("momentary", C.c_double), ("shortterm", C.c_double),
+                ("true_peak", C.c_double), ("sample_peak", C.c_double), ("frames", C.c_int64)]
+
+
+class LimiterPlan(C.Structure):
+    _fields_ = [("needed", C.c_int), ("pre_gain_db", C.c_double), ("limit", C.c_double)]
+
+
+class LoudnormStats(C.Structure):
+    _fields_ = [("input_i", C.c_double), ("input_tp", C.c_double), ("input_lra", C.c_double),
+                ("input_thresh", C.c_double), ("output_i", C.c_double), ("output_tp", C.c_double),
+                ("output_lra", C.c_double), ("output_thresh", C.c_double), ("target_offset", C.c_double),
+                ("normalization_type_dynamic", C.c_int)]
+
+
+class LoudnormApply(C.Structure):
+    _fields_ = [("target_i", C.c_double), ("target_tp", C.c_double), ("target_lra", C.c_double),
+                ("measured_i", C.c_double), ("measured_tp", C.c_double), ("measured_lra", C.c_double),
+                ("measured_thresh", C.c_double), ("offset", C.c_double),
+                ("adeclick_enabled", C.c_int), ("adeclick_threshold", C.c_double),
+                ("adeclick_window_ms", C.c_double), ("adeclick_overlap_pct", C.c_double),
+                ("brickwall_limit", C.c_double)]
+
+
+class Timers(C.Structure):
+    _fields_ = [("pass1_ms", C.c_double), ("pass2_ms", C.c_double), ("pass3_ms", C.c_double),
+                ("pass4_ms", C.c_double), ("nlm_ms", C.c_double), ("nlm_launches", C.c_int64)]
+
+
+# every symbol include/jtgpu.h declares
+SYMBOLS = [
+    "jt_open", "jt_close", "jt_last_error", "jt_version", "jt_cancel",
+    "jt_upload_pcm", "jt_attach_device_pcm", "jt_upload_s16",
+    "jt_pass1", "jt_band_rms", "jt_pass2", "jt_region_measure", "jt_pass3", "jt_pass4",
+    "jt_output_len", "jt_download_s16", "jt_get_timers",
+    "jt_op_biquad_f32", "jt_op_anlmdn_f32", "jt_op_afftdn_f32", "jt_op_dynamics", "jt_op_alimiter_f64",
+    "jt_op_resample_f32_to_s16", "jt_op_ebur128", "jt_op_astats", "jt_op_aspectralstats",
+    "jt_op_loudnorm_measure_s16",
+]
+
+
+def load():
+    """Load libjtgpu.so.  Raises (never falls back) when the HIP extension has not been built."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(f"{LIB_PATH} not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                          "(hipcc --offload-arch=gfx950). There is no CPU fallback for the product path.")
+    lib = C.CDLL(LIB_PATH)
+    lib.jt_last_error.restype = C.c_char_p
+    lib.jt_version.restype = C.c_char_p
+    lib.jt_close.restype = None
+    lib.jt_cancel.restype = None
+    _LIB = lib
+    return lib

@@ -1,0 +1,767 @@
+// jt_api.cpp — C ABI of libjtgpu.so (see include/jtgpu.h for the reference interfaces each entry replaces).
+// Orchestrates the four device-side sweeps over a file that stays resident in HBM as contiguous PCM.
+#include "jt_internal.h"
+#include <algorithm>
+#include <memory>
+
+#define JT_API_BEGIN(h) if (!(h)) return JT_E_INVAL; try { JT_HIP(hipSetDevice((h)->device));
+#define JT_API_END(h) } catch (const JtError &e) { (h)->err = e.msg; return e.code; } \
+    catch (const std::exception &e) { (h)->err = e.what(); return JT_E_HIP; } return JT_OK;
+
+static void check_cancel(jt_ctx *h) { if (h->cancelled.load()) throw JtError{JT_E_CANCELLED, "cancelled"}; }
+
+extern "C" const char *jt_version(void) { return "jtgpu 0.1 (gfx950)"; }
+
+extern "C" int jt_open(int device_id, jt_ctx **out)
+{
+    if (!out) return JT_E_INVAL;
+    *out = nullptr;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) return JT_E_NOGPU;
+    if (device_id < 0 || device_id >= count) return JT_E_INVAL;
+    jt_ctx *h = new jt_ctx();
+    h->device = device_id;
+    try {
+        JT_HIP(hipSetDevice(device_id));
+        JT_HIP(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+        JT_HIP(hipEventCreate(&h->ev0)); JT_HIP(hipEventCreate(&h->ev1));
+        JT_HIP(hipEventCreate(&h->ev2)); JT_HIP(hipEventCreate(&h->ev3));
+    } catch (const JtError &) { delete h; return JT_E_NOGPU; }
+    *out = h;
+    return JT_OK;
+}
+
+extern "C" void jt_close(jt_ctx *h)
+{
+    if (!h) return;
+    (void)hipSetDevice(h->device);
+    if (h->stream) { (void)hipStreamSynchronize(h->stream); (void)hipStreamDestroy(h->stream); }
+    if (h->ev0) (void)hipEventDestroy(h->ev0);
+    if (h->ev1) (void)hipEventDestroy(h->ev1);
+    if (h->ev2) (void)hipEventDestroy(h->ev2);
+    if (h->ev3) (void)hipEventDestroy(h->ev3);
+    delete h;
+}
+
+extern "C" const char *jt_last_error(const jt_ctx *h) { return h ? h->err.c_str() : "null handle"; }
+extern "C" void jt_cancel(jt_ctx *h) { if (h) h->cancelled.store(1); }
+
+// ---------------------------------------------------------------- helpers
+static void ensure_twiddle(jt_ctx *h, int N)
+{
+    if (h->twiddle_n == N) return;
+    std::vector<float2> tw(N / 2);
+    for (int k = 0; k < N / 2; ++k) { double a = -2.0 * M_PI * k / N; tw[k] = make_float2((float)std::cos(a), (float)std::sin(a)); }
+    h->twiddle.ensure(N / 2);
+    JT_HIP(hipMemcpyAsync(h->twiddle.p, tw.data(), sizeof(float2) * (N / 2), hipMemcpyHostToDevice, h->stream));
+    JT_HIP(hipStreamSynchronize(h->stream));
+    h->twiddle_n = N;
+}
+static void ensure_hann(jt_ctx *h, int N)
+{
+    if (h->hann_n == N) return;
+    std::vector<float> w(N);
+    for (int i = 0; i < N; ++i) w[i] = (float)(.5 * (1 - std::cos(2 * M_PI * i / (N - 1))));
+    h->hann.ensure(N);
+    JT_HIP(hipMemcpyAsync(h->hann.p, w.data(), sizeof(float) * N, hipMemcpyHostToDevice, h->stream));
+    JT_HIP(hipStreamSynchronize(h->stream));
+    h->hann_n = N;
+}
+
+static void set_input_common(jt_ctx *h, int64_t frames, int sr, int ch)
+{
+    JT_REQUIRE(frames > 0, JT_E_INVAL, "empty input");
+    JT_REQUIRE(sr >= 8000 && sr <= 384000, JT_E_INVAL, "unsupported sample rate");
+    JT_REQUIRE(ch >= 1 && ch <= 8, JT_E_INVAL, "unsupported channel count");
+    h->n = frames; h->sr = sr; h->channels = ch;
+    h->m_p2 = h->m_p4 = 0;
+    if (ch == 1) h->in_mono = h->in_raw;
+    else {
+        h->mono.ensure((size_t)frames);
+        launch_downmix(h->in_raw, h->mono.p, frames, ch, h->stream);
+        h->in_mono = h->mono.p;
+    }
+}
+
+extern "C" int jt_upload_pcm(jt_ctx *h, const float *pcm, int64_t frames, int sr, int ch)
+{
+    JT_API_BEGIN(h)
+    JT_REQUIRE(pcm && frames > 0 && ch >= 1, JT_E_INVAL, "bad pcm arguments");
+    h->in_owned.ensure((size_t)frames * ch);
+    JT_HIP(hipMemcpyAsync(h->in_owned.p, pcm, sizeof(float) * (size_t)frames * ch, hipMemcpyHostToDevice, h->stream));
+    h->in_raw = h->in_owned.p;
+    set_input_common(h, frames, sr, ch);
+    JT_HIP(hipStreamSynchronize(h->stream));
+    JT_API_END(h)
+}
+
+extern "C" int jt_attach_device_pcm(jt_ctx *h, const void *dev_ptr, int64_t frames, int sr, int ch)
+{
+    JT_API_BEGIN(h)
+    JT_REQUIRE(dev_ptr && frames > 0, JT_E_INVAL, "bad device pcm arguments");
+    h->in_raw = static_cast<const float *>(dev_ptr);
+    set_input_common(h, frames, sr, ch);
+    JT_HIP(hipStreamSynchronize(h->stream));
+    JT_API_END(h)
+}
+
+extern "C" int jt_upload_s16(jt_ctx *h, const int16_t *pcm, int64_t frames, int sr)
+{
+    JT_API_BEGIN(h)
+    JT_REQUIRE(pcm && frames > 0, JT_E_INVAL, "bad s16 arguments");
+    h->s16_p2.ensure((size_t)frames);
+    JT_HIP(hipMemcpyAsync(h->s16_p2.p, pcm, sizeof(int16_t) * (size_t)frames, hipMemcpyHostToDevice, h->stream));
+    JT_HIP(hipStreamSynchronize(h->stream));
+    h->m_p2 = frames; h->out_rate = sr; h->m_p4 = 0;
+    JT_API_END(h)
+}
+
+// ---------------------------------------------------------------- analysis of a mono f32 signal on device
+struct AnalysisHost {
+    jt_astats astats; R128Series r128; std::vector<double> tp_cum, sp_cum; double tp_final, sp_final;
+    std::vector<jt_spectral> hops; int64_t nblocks = 0, nhops = 0; int blk = 0;
+};
+
+static void run_astats(jt_ctx *h, const float *x, int64_t n, int sr, jt_astats *out)
+{
+    const int64_t chunk = 16384;
+    const int64_t nchunks = (n + chunk - 1) / chunk;
+    h->astats_chunks.ensure((size_t)nchunks);
+    h->ehist.ensure(8192); h->ehist.zero(h->stream);
+    h->d_scr2.ensure((size_t)nchunks * 2);
+    DevBuf<float> g; g.ensure((size_t)n);
+    jt_astats_run(x, n, sr, g.p, h->d_scr2.p, h->d_scr2.p + nchunks, h->astats_chunks.p, chunk, nchunks, h->ehist.p, h->stream);
+    std::vector<AstatsChunk> hc((size_t)nchunks); std::vector<unsigned long long> eh(8192);
+    JT_HIP(hipMemcpyAsync(hc.data(), h->astats_chunks.p, sizeof(AstatsChunk) * nchunks, hipMemcpyDeviceToHost, h->stream));
+    JT_HIP(hipMemcpyAsync(eh.data(), h->ehist.p, sizeof(unsigned long long) * 8192, hipMemcpyDeviceToHost, h->stream));
+    JT_HIP(hipStreamSynchronize(h->stream));
+    jt_astats_merge(hc.data(), nchunks, eh.data(), sr, out);
+}
+
+// K-weighted block energies, sample peaks, true peaks (streaming swr to 192 kHz) and R128 finishing
+static void run_r128(jt_ctx *h, const float *x, int64_t n, int sr, bool dualmono, bool want_tp, AnalysisHost *A)
+{
+    const int blk = sr / 10;
+    const int64_t nfull = n / blk, nalloc = nfull + 2;
+    A->blk = blk; A->nblocks = nfull;
+    h->d_scr0.ensure((size_t)nalloc * 3);
+    JT_HIP(hipMemsetAsync(h->d_scr0.p, 0, sizeof(double) * nalloc * 3, h->stream));
+    double *bs = h->d_scr0.p, *bp = bs + nalloc, *btp = bp + nalloc;
+    BiquadF64 pre, rlb; jt_kweight_design(sr, &pre, &rlb);
+    launch_kweight_blocks_f32(x, n, blk, pre, rlb, bs, bp, nalloc, h->stream);
+    if (want_tp) {
+        SwrPlanHost pl; jt_swr_plan(&pl, sr, 192000);
+        h->bank_d.ensure(pl.bank.size());
+        JT_HIP(hipMemcpyAsync(h->bank_d.p, pl.bank.data(), sizeof(double) * pl.bank.size(), hipMemcpyHostToDevice, h->stream));
+        int64_t m_total = (int64_t)(((__int128)n * pl.phase_count + pl.step - 1) / pl.step);
+        launch_true_peak_f32(x, n, h->bank_d.p, pl.phase_count, pl.filter_length, pl.center, pl.step, blk, btp, nfull + 1, m_total, h->stream);
+        JT_HIP(hipStreamSynchronize(h->stream));   // pl.bank must outlive the async copy
+    }
+    std::vector<double> hb((size_t)nalloc * 3);
+    JT_HIP(hipMemcpyAsync(hb.data(), h->d_scr0.p, sizeof(double) * nalloc * 3, hipMemcpyDeviceToHost, h->stream));
+    JT_HIP(hipStreamSynchronize(h->stream));
+    jt_r128_finish(hb.data(), nfull, blk, sr, dualmono, &A->r128);
+    A->tp_cum.assign(nfull, 0.0); A->sp_cum.assign(nfull, 0.0);
+    double tp = 0, sp = 0;
+    for (int64_t k = 0; k < nfull; ++k) {
+        sp = std::max(sp, hb[nalloc + k]); tp = std::max(tp, hb[2 * nalloc + k]);
+        A->sp_cum[k] = sp; A->tp_cum[k] = tp;
+    }
+    // trailing partial frame: peaks still update (f_ebur128.c runs the per-sample loop over it)
+    sp = std::max(sp, hb[nalloc + nfull]); tp = std::max(tp, hb[2 * nalloc + nfull]);
+    A->sp_final = sp; A->tp_final = tp;
+}
+
+static void run_spectral(jt_ctx *h, const float *x, int64_t n, int sr, AnalysisHost *A)
+{
+    const int win = 2048, hop = win / 2;
+    ensure_twiddle(h, win); ensure_hann(h, win);
+    const int64_t nhops = (n + hop - 1) / hop;
+    A->nhops = nhops;
+    h->spec_hops.ensure((size_t)nhops);
+    launch_aspectralstats(x, n, sr, win, h->twiddle.p, h->hann.p, h->spec_hops.p, nhops, h->stream);
+    A->hops.resize((size_t)nhops);
+    JT_HIP(hipMemcpyAsync(A->hops.data(), h->spec_hops.p, sizeof(jt_spectral) * nhops, hipMemcpyDeviceToHost, h->stream));
+    JT_HIP(hipStreamSynchronize(h->stream));
+}
+
+static void spectral_add(jt_spectral *a, const jt_spectral &b)
+{
+    double *pa = &a->mean; const double *pb = &b.mean;
+    for (int i = 0; i < 13; ++i) pa[i] += pb[i];
+}
+static void spectral_scale(jt_spectral *a, double s)
+{
+    double *pa = &a->mean;
+    for (int i = 0; i < 13; ++i) pa[i] *= s;
+}
+
+// Assemble what the Go OnFrame callbacks would have seen: one record per 100 ms ebur128 output frame
+// (+ one trailing partial frame without r128 keys when n % blk != 0).  The aspectralstats props that
+// survive ebur128's re-framing are those of the hop containing the frame's first sample.
+static void assemble_analysis(const AnalysisHost &A, int64_t n, bool dualmono, jt_analysis *out, jt_frame_meta *meta, int64_t cap_meta)
+{
+    (void)dualmono;
+    const int hop = 1024;
+    const int64_t nfull = A.nblocks;
+    const bool partial = (n % A.blk) != 0;
+    const int64_t nframes = nfull + (partial ? 1 : 0);
+    jt_spectral mean; std::memset(&mean, 0, sizeof(mean)); int64_t cnt = 0;
+    for (int64_t k = 0; k < nframes; ++k) {
+        int64_t hidx = (k * (int64_t)A.blk) / hop;
+        if (hidx >= A.nhops) hidx = A.nhops - 1;
+        const jt_spectral &sp = A.hops[(size_t)hidx];
+        spectral_add(&mean, sp); cnt++;
+        if (meta && k < cap_meta) {
+            jt_frame_meta &m = meta[k];
+            m.spectral = sp;
+            if (k < nfull) { m.momentary = A.r128.M[k]; m.shortterm = A.r128.S[k]; m.true_peak = A.tp_cum[k]; m.sample_peak = A.sp_cum[k]; }
+            else { m.momentary = NAN; m.shortterm = NAN; m.true_peak = NAN; m.sample_peak = NAN; }   // keys absent
+        }
+    }
+    if (cnt) spectral_scale(&mean, 1.0 / cnt);
+    out->spectral_mean = mean;
+    out->n_frames_meta = nframes;
+    out->r128.integrated = A.r128.integrated; out->r128.lra = A.r128.lra;
+    out->r128.lra_low = A.r128.lra_low; out->r128.lra_high = A.r128.lra_high;
+    out->r128.momentary = nfull ? A.r128.M[nfull - 1] : NAN;
+    out->r128.shortterm = nfull ? A.r128.S[nfull - 1] : NAN;
+    // "latest wins": the last frame that carried r128 keys is the last full block
+    out->r128.true_peak = nfull ? A.tp_cum[nfull - 1] : 0.0;
+    out->r128.sample_peak = nfull ? A.sp_cum[nfull - 1] : 0.0;
+    out->r128.target_threshold = A.r128.rel_threshold;
+}
+
+static void analyse_mono(jt_ctx *h, const float *x, int64_t n, int sr, bool dualmono, jt_analysis *out,
+                         jt_frame_meta *meta, int64_t cap_meta)
+{
+    AnalysisHost A;
+    run_astats(h, x, n, sr, &A.astats);
+    check_cancel(h);
+    run_r128(h, x, n, sr, dualmono, true, &A);
+    check_cancel(h);
+    run_spectral(h, x, n, sr, &A);
+    out->astats = A.astats;
+    assemble_analysis(A, n, dualmono, out, meta, cap_meta);
+}
+
+// ---------------------------------------------------------------- Pass 1
+extern "C" int jt_pass1(jt_ctx *h, int frame_samples, jt_analysis *out, double *frame_sumsq, double *frame_peak,
+                        int64_t cap_frames, jt_frame_meta *meta, int64_t cap_meta)
+{
+    JT_API_BEGIN(h)
+    JT_REQUIRE(h->n > 0 && h->in_raw, JT_E_STATE, "pass1: no input uploaded");
+    JT_REQUIRE(out && frame_samples > 0, JT_E_INVAL, "pass1: bad arguments");
+    h->cancelled.store(0);
+    JT_HIP(hipEventRecord(h->ev0, h->stream));
+    std::memset(out, 0, sizeof(*out));
+    const int64_t nfr = (h->n + frame_samples - 1) / frame_samples;
+    out->n_input_frames = nfr;
+    if (frame_sumsq && frame_peak) {
+        h->d_scr1.ensure((size_t)nfr * 2);
+        launch_frame_stats(h->in_raw, h->n * h->channels, frame_samples * h->channels, h->d_scr1.p, h->d_scr1.p + nfr, nfr, h->stream);
+        std::vector<double> tmp((size_t)nfr * 2);
+        JT_HIP(hipMemcpyAsync(tmp.data(), h->d_scr1.p, sizeof(double) * nfr * 2, hipMemcpyDeviceToHost, h->stream));
+        JT_HIP(hipStreamSynchronize(h->stream));
+        int64_t c = std::min(nfr, cap_frames);
+        std::copy(tmp.begin(), tmp.begin() + c, frame_sumsq);
+        std::copy(tmp.begin() + nfr, tmp.begin() + nfr + c, frame_peak);
+    }
+    analyse_mono(h, h->in_mono, h->n, h->sr, true, out, meta, cap_meta);
+    out->n_input_frames = nfr;
+    JT_HIP(hipEventRecord(h->ev1, h->stream));
+    JT_HIP(hipEventSynchronize(h->ev1));
+    float ms = 0; JT_HIP(hipEventElapsedTime(&ms, h->ev0, h->ev1)); h->timers.pass1_ms = ms;
+    JT_API_END(h)
+}
+
+// ---------------------------------------------------------------- band RMS
+extern "C" int jt_band_rms(jt_ctx *h, double start_s, double dur_s, const double *lo_hz, const double *hi_hz,
+                           int n_bands, double *out_db, int *ok)
+{
+    JT_API_BEGIN(h)
+    JT_REQUIRE(h->n > 0 && h->in_mono, JT_E_STATE, "band_rms: no input uploaded");
+    JT_REQUIRE(lo_hz && hi_hz && out_db && n_bands > 0 && dur_s > 0 && start_s >= 0, JT_E_INVAL, "band_rms: bad arguments");
+    // atrim=start:duration selects samples with start <= t < start+duration (pts-based)
+    int64_t s0 = (int64_t)std::ceil(start_s * h->sr - 1e-9), s1 = (int64_t)std::ceil((start_s + dur_s) * h->sr - 1e-9);
+    s0 = std::max<int64_t>(0, std::min(s0, h->n)); s1 = std::max(s0, std::min(s1, h->n));
+    const int64_t len = s1 - s0;
+    for (int b = 0; b < n_bands; ++b) { out_db[b] = NAN; if (ok) ok[b] = 0; }
+    if (len <= 0) return JT_OK;
+    DevBuf<float> tmp; tmp.ensure((size_t)len);
+    DevBuf<double> red; red.ensure(2);
+    for (int b = 0; b < n_bands; ++b) {
+        double bh[3], ah[3], bl[3], al[3];
+        jt_biquad_design(0, lo_hz[b], 0.707, h->sr, bh, ah, 0);
+        jt_biquad_design(1, hi_hz[b], 0.707, h->sr, bl, al, 0);
+        BiquadF32 hp{(float)bh[0], (float)bh[1], (float)bh[2], -(float)ah[1], -(float)ah[2]};
+        BiquadF32 lp{(float)bl[0], (float)bl[1], (float)bl[2], -(float)al[1], -(float)al[2]};
+        launch_biquad_di_f32(h->in_mono + s0, tmp.p, len, hp, lp, h->stream);
+        launch_frame_stats(tmp.p, len, (int)std::min<int64_t>(len, 0x7fffffff), red.p, red.p + 1, 1, h->stream);
+        double r[2];
+        JT_HIP(hipMemcpyAsync(r, red.p, sizeof(r), hipMemcpyDeviceToHost, h->stream));
+        JT_HIP(hipStreamSynchronize(h->stream));
+        double rms = std::sqrt(r[0] / (double)len);
+        out_db[b] = 20 * std::log10(rms);
+        if (ok) ok[b] = std::isfinite(out_db[b]) ? 1 : 0;
+    }
+    JT_API_END(h)
+}
+
+// ---------------------------------------------------------------- Pass 2
+static void run_anlmdn(jt_ctx *h, const float *in, float *out, int64_t n, int sr, double strength, double patch_s, double research_s, double smooth)
+{
+    const int K = (int)std::llrint((double)std::llrint(patch_s * 1e6) * sr / 1e6);
+    const int S = (int)std::llrint((double)std::llrint(research_s * 1e6) * sr / 1e6);
+    JT_REQUIRE(K >= 1 && S >= 1, JT_E_INVAL, "anlmdn: patch/research too small");
+    const float a = (float)strength, m = (float)smooth;
+    const float lut_scale = 1.f / m * (float)(1 << 20);
+    const float sw = (65536.f / (4 * K + 2)) / std::sqrt(a);
+    JT_HIP(hipEventRecord(h->ev2, h->stream));
+    launch_anlmdn(in, out, n, K, S, sw, m, lut_scale, h->stream);
+    JT_HIP(hipEventRecord(h->ev3, h->stream));
+}
+
+static void run_afftdn(jt_ctx *h, const float *in, float *out, int64_t n, int sr, double nr, double nf, const double *bn)
+{
+    AfftdnPlanHost pl; jt_afftdn_plan(&pl, sr, nr, nf, bn);
+    ensure_twiddle(h, pl.L);
+    const size_t nb = pl.nbands, bins = pl.bins;
+    const size_t ndbl = pl.W + nb + nb + nb * nb + bins + bins;
+    h->af_tab.ensure(ndbl); h->af_bin2band.ensure(bins);
+    std::vector<double> tab; tab.reserve(ndbl);
+    tab.insert(tab.end(), pl.window.begin(), pl.window.end());
+    tab.insert(tab.end(), pl.alpha.begin(), pl.alpha.end());
+    tab.insert(tab.end(), pl.beta.begin(), pl.beta.end());
+    tab.insert(tab.end(), pl.spread.begin(), pl.spread.end());
+    tab.insert(tab.end(), pl.abs_var.begin(), pl.abs_var.end());
+    tab.insert(tab.end(), pl.min_abs_var.begin(), pl.min_abs_var.end());
+    JT_HIP(hipMemcpyAsync(h->af_tab.p, tab.data(), sizeof(double) * ndbl, hipMemcpyHostToDevice, h->stream));
+    JT_HIP(hipMemcpyAsync(h->af_bin2band.p, pl.bin2band.data(), sizeof(int) * bins, hipMemcpyHostToDevice, h->stream));
+    AfftdnDev d;
+    d.A = pl.A; d.W = pl.W; d.L = pl.L; d.bins = pl.bins; d.nbands = pl.nbands; d.max_gain = pl.max_gain;
+    d.bin2band = h->af_bin2band.p;
+    d.window = h->af_tab.p; d.alpha = d.window + pl.W; d.beta = d.alpha + nb; d.spread = d.beta + nb;
+    d.abs_var = d.spread + nb * nb; d.min_abs_var = d.abs_var + bins; d.twiddle = h->twiddle.p;
+    launch_afftdn(in, out, n, d, 192, 96, h->stream);
+    JT_HIP(hipStreamSynchronize(h->stream));   // host tables must outlive the async copies
+}
+
+static void fill_biquads(const jt_filter_params *p, int sr, BiquadF32 st[2], int *nst)
+{
+    *nst = 0;
+    if (p->hp_enabled) {
+        double b[3], a[3]; jt_biquad_design(0, p->hp_freq, p->hp_q, sr, b, a, 1);
+        st[(*nst)++] = BiquadF32{(float)b[0], (float)b[1], (float)b[2], -(float)a[1], -(float)a[2]};
+    }
+    if (p->lp_enabled) {
+        double b[3], a[3]; jt_biquad_design(1, p->lp_freq, p->lp_q, sr, b, a, 1);
+        st[(*nst)++] = BiquadF32{(float)b[0], (float)b[1], (float)b[2], -(float)a[1], -(float)a[2]};
+    }
+}
+
+static void run_resample_s16(jt_ctx *h, const float *x, int64_t n, int in_rate, int out_rate, DevBuf<int16_t> &dst, int64_t *m_out)
+{
+    if (in_rate == out_rate) {
+        dst.ensure((size_t)n);
+        DevBuf<double> t; t.ensure((size_t)n);
+        launch_f32_to_f64(x, t.p, n, h->stream);
+        launch_f64_to_s16(t.p, dst.p, nullptr, n, 0, h->stream);
+        JT_HIP(hipStreamSynchronize(h->stream));
+        *m_out = n;
+        return;
+    }
+    SwrPlanHost pl; jt_swr_plan(&pl, in_rate, out_rate);
+    h->bank_d.ensure(pl.bank.size());
+    JT_HIP(hipMemcpyAsync(h->bank_d.p, pl.bank.data(), sizeof(double) * pl.bank.size(), hipMemcpyHostToDevice, h->stream));
+    const int64_t m = (int64_t)(((__int128)n * pl.phase_count + pl.step - 1) / pl.step);   // ceil(n*out/in)
+    dst.ensure((size_t)m);
+    launch_resample_to_s16(x, n, h->bank_d.p, pl.phase_count, pl.filter_length, pl.center, pl.step, dst.p, m, h->stream);
+    JT_HIP(hipStreamSynchronize(h->stream));
+    *m_out = m;
+}
+
+extern "C" int jt_pass2(jt_ctx *h, const jt_filter_params *p, jt_analysis *out)
+{
+    JT_API_BEGIN(h)
+    JT_REQUIRE(h->n > 0 && h->in_mono, JT_E_STATE, "pass2: no input uploaded");
+    JT_REQUIRE(p && out, JT_E_INVAL, "pass2: bad arguments");
+    JT_REQUIRE(!(p->fft_enabled && p->fft_track_noise), JT_E_UNSUPPORTED,
+               "pass2: afftdn tn=1 (noise tracking) is not implemented on the GPU path");
+    h->cancelled.store(0);
+    std::memset(out, 0, sizeof(*out));
+    JT_HIP(hipEventRecord(h->ev0, h->stream));
+    const int64_t n = h->n; const int sr = h->sr;
+    h->work_a.ensure((size_t)n); h->work_b.ensure((size_t)n);
+    const float *cur = h->in_mono; float *nxt = h->work_a.p; float *oth = h->work_b.p;
+    auto advance = [&]() { cur = nxt; std::swap(nxt, oth); };
+    BiquadF32 st[2]; int nst = 0; fill_biquads(p, sr, st, &nst);
+    if (nst > 0) { launch_biquad_f32(cur, nxt, n, nst, st, h->stream); advance(); }
+    check_cancel(h);
+    bool nlm_timed = false;
+    if (p->nlm_enabled) { run_anlmdn(h, cur, nxt, n, sr, p->nlm_strength, p->nlm_patch_s, p->nlm_research_s, p->nlm_smooth); advance(); nlm_timed = true; }
+    check_cancel(h);
+    if (p->fft_enabled) {
+        double nf = p->fft_nf < 0 ? p->fft_nf : -50.0;
+        run_afftdn(h, cur, nxt, n, sr, p->fft_nr, nf, p->fft_custom ? p->fft_band_noise : nullptr); advance();
+    }
+    check_cancel(h);
+    DynParams d; jt_dyn_design(p, sr, &d);
+    if (d.gate_on || d.comp_on || d.deess_on) { launch_dynamics(cur, nxt, nullptr, n, d, h->stream); advance(); }
+    check_cancel(h);
+    analyse_mono(h, cur, n, sr, true, out, nullptr, 0);
+    out->n_input_frames = 0;
+    check_cancel(h);
+    const int out_rate = p->out_rate > 0 ? p->out_rate : 44100;
+    run_resample_s16(h, cur, n, sr, out_rate, h->s16_p2, &h->m_p2);
+    h->out_rate = out_rate; h->m_p4 = 0;
+    JT_HIP(hipEventRecord(h->ev1, h->stream));
+    JT_HIP(hipEventSynchronize(h->ev1));
+    float ms = 0; JT_HIP(hipEventElapsedTime(&ms, h->ev0, h->ev1)); h->timers.pass2_ms = ms;
+    if (nlm_timed) { JT_HIP(hipEventElapsedTime(&ms, h->ev2, h->ev3)); h->timers.nlm_ms = ms; h->timers.nlm_launches = 1; }
+    JT_API_END(h)
+}
+
+// ---------------------------------------------------------------- limiter driver (clean-point segmentation)
+static void run_limiter(jt_ctx *h, const double *in, double *out, int64_t n, int sr, double limit, double attack_ms,
+                        double release_ms, double in_gain)
+{
+    const double attack = attack_ms / 1000., release = release_ms / 1000.;
+    int B = (int)(sr * attack * 1); if (B < 1) B = 1;
+    const double asc_coeff = std::pow(0.5, 0.8 - 0.5) * 2 * -1;     // asc_level = 0.8 (normalise.go:459,477)
+    const int blk = 256;
+    const int64_t nblk = (n + blk - 1) / blk;
+    h->d_scr3.ensure((size_t)nblk);
+    launch_absmax_blocks_f64(in, n, blk, h->d_scr3.p, nblk, h->stream);
+    std::vector<double> mx((size_t)nblk);
+    JT_HIP(hipMemcpyAsync(mx.data(), h->d_scr3.p, sizeof(double) * nblk, hipMemcpyDeviceToHost, h->stream));
+    JT_HIP(hipStreamSynchronize(h->stream));
+    // a position p is clean when no sample in the previous (B + release*sr + 4) samples exceeds the limit
+    const int64_t need = (int64_t)std::ceil((B + release * sr + 4.0) / blk) + 1;
+    const int64_t target = 8192 / blk;
+    std::vector<int64_t> bounds; bounds.push_back(0);
+    int64_t quiet = 0, last = 0;
+    const double g = std::fabs(in_gain);
+    for (int64_t b = 0; b < nblk; ++b) {
+        if (b > 0 && quiet >= need && b - last >= target) { bounds.push_back(b * blk); last = b; }
+        if (mx[(size_t)b] * g > limit) quiet = 0; else quiet++;
+    }
+    bounds.push_back(n);
+    const int nl = (int)bounds.size() - 1;
+    h->lim_bounds.ensure(bounds.size());
+    JT_HIP(hipMemcpyAsync(h->lim_bounds.p, bounds.data(), sizeof(int64_t) * bounds.size(), hipMemcpyHostToDevice, h->stream));
+    h->lim_delta.ensure((size_t)nl * B); h->lim_pos.ensure((size_t)nl * B);
+    launch_limiter_f64(in, out, n, sr, limit, B, release, asc_coeff, h->lim_bounds.p, nl, in_gain, h->lim_delta.p, h->lim_pos.p, h->stream);
+    JT_HIP(hipStreamSynchronize(h->stream));
+}
+
+// loudnorm (dynamic-mode first pass) input statistics of a signal at `rate`, measured after swr -> 192 kHz
+static void run_loudnorm_measure(jt_ctx *h, const int16_t *s16, const double *f64, int64_t n, int rate, jt_loudnorm_stats *out)
+{
+    SwrPlanHost pl; jt_swr_plan(&pl, rate, 192000);
+    const int64_t m_total = (int64_t)(((__int128)n * pl.phase_count + pl.step - 1) / pl.step);
+    const int blk = (192000 + 5) / 10;
+    const int64_t nfull = m_total / blk, nalloc = nfull + 2;
+    h->d_scr0.ensure((size_t)nalloc * 2);
+    JT_HIP(hipMemsetAsync(h->d_scr0.p, 0, sizeof(double) * nalloc * 2, h->stream));
+    BiquadF64 pre, rlb; jt_kweight_design(192000, &pre, &rlb);
+    if (s16) {
+        std::vector<float> bf(pl.bank.size());
+        for (size_t i = 0; i < bf.size(); ++i) bf[i] = (float)pl.bank[i];
+        h->bank_f.ensure(bf.size());
+        JT_HIP(hipMemcpyAsync(h->bank_f.p, bf.data(), sizeof(float) * bf.size(), hipMemcpyHostToDevice, h->stream));
+        launch_resample_kweight_s16(s16, n, h->bank_f.p, pl.phase_count, pl.filter_length, pl.center, pl.step, m_total, blk, pre, rlb,
+                                    h->d_scr0.p, h->d_scr0.p + nalloc, nalloc, h->stream);
+        JT_HIP(hipStreamSynchronize(h->stream));
+    } else {
+        h->bank_d.ensure(pl.bank.size());
+        JT_HIP(hipMemcpyAsync(h->bank_d.p, pl.bank.data(), sizeof(double) * pl.bank.size(), hipMemcpyHostToDevice, h->stream));
+        launch_resample_kweight_f64(f64, n, h->bank_d.p, pl.phase_count, pl.filter_length, pl.center, pl.step, m_total, blk, pre, rlb,
+                                    h->d_scr0.p, h->d_scr0.p + nalloc, nalloc, h->stream);
+        JT_HIP(hipStreamSynchronize(h->stream));
+    }
+    std::vector<double> hb((size_t)nalloc * 2);
+    JT_HIP(hipMemcpyAsync(hb.data(), h->d_scr0.p, sizeof(double) * nalloc * 2, hipMemcpyDeviceToHost, h->stream));
+    JT_HIP(hipStreamSynchronize(h->stream));
+    double pk = 0; for (int64_t k = 0; k <= nfull; ++k) pk = std::max(pk, hb[nalloc + k]);
+    jt_loudnorm_finish(hb.data(), nfull, blk, true, 1.0, &out->input_i, &out->input_lra, &out->input_thresh);
+    out->input_tp = 20 * std::log10(pk);
+    out->output_i = out->output_tp = out->output_lra = out->output_thresh = NAN; out->target_offset = NAN;
+    out->normalization_type_dynamic = 1;
+}
+
+static void pass3_core(jt_ctx *h, const int16_t *s16, int64_t m, int rate, const jt_limiter_plan *lim, jt_loudnorm_stats *out)
+{
+    if (lim && lim->needed) {
+        h->f64_a.ensure((size_t)m); h->f64_b.ensure((size_t)m);
+        const bool pre = lim->pre_gain_db > 0;
+        const double g = pre ? std::pow(10.0, lim->pre_gain_db / 20.0) : 1.0;
+        launch_s16_to_f64(s16, h->f64_a.p, m, g, pre ? 1 : 0, h->stream);
+        run_limiter(h, h->f64_a.p, h->f64_b.p, m, rate, lim->limit, 5.0, 100.0, 1.0);
+        run_loudnorm_measure(h, nullptr, h->f64_b.p, m, rate, out);
+    } else {
+        run_loudnorm_measure(h, s16, nullptr, m, rate, out);
+    }
+}
+
+extern "C" int jt_pass3(jt_ctx *h, const jt_limiter_plan *lim, double target_i, double target_tp, double target_lra,
+                        jt_loudnorm_stats *out)
+{
+    JT_API_BEGIN(h)
+    (void)target_i; (void)target_tp; (void)target_lra;
+    JT_REQUIRE(h->m_p2 > 0, JT_E_STATE, "pass3: no Pass-2 output on device");
+    JT_REQUIRE(out, JT_E_INVAL, "pass3: bad arguments");
+    h->cancelled.store(0);
+    JT_HIP(hipEventRecord(h->ev0, h->stream));
+    pass3_core(h, h->s16_p2.p, h->m_p2, h->out_rate, lim, out);
+    JT_HIP(hipEventRecord(h->ev1, h->stream));
+    JT_HIP(hipEventSynchronize(h->ev1));
+    float ms = 0; JT_HIP(hipEventElapsedTime(&ms, h->ev0, h->ev1)); h->timers.pass3_ms = ms;
+    JT_API_END(h)
+}
+
+// ---------------------------------------------------------------- Pass 4
+extern "C" int jt_pass4(jt_ctx *h, const jt_limiter_plan *lim, const jt_loudnorm_apply *ap, jt_analysis *out, jt_loudnorm_stats *stats)
+{
+    JT_API_BEGIN(h)
+    JT_REQUIRE(h->m_p2 > 0, JT_E_STATE, "pass4: no Pass-2 output on device");
+    JT_REQUIRE(ap && out, JT_E_INVAL, "pass4: bad arguments");
+    h->cancelled.store(0);
+    JT_HIP(hipEventRecord(h->ev0, h->stream));
+    std::memset(out, 0, sizeof(*out));
+    const int64_t m = h->m_p2; const int rate = h->out_rate;
+    // af_loudnorm.c init(): linear mode only when every measured_* is supplied and the projected peak / LRA fit
+    const double offset_db = ap->target_i - ap->measured_i;
+    const double offset_tp = ap->measured_tp + offset_db;
+    const bool linear = (ap->measured_tp != 99 && ap->measured_thresh != -70 && ap->measured_lra != 0 && ap->measured_i != 0) &&
+                        (offset_tp <= ap->target_tp) && (ap->measured_lra <= ap->target_lra);
+    JT_REQUIRE(linear, JT_E_UNSUPPORTED, "pass4: loudnorm would fall back to dynamic mode (not implemented on the GPU path)");
+    const double gain = std::pow(10., offset_db / 20.);
+    h->f64_a.ensure((size_t)m); h->f64_b.ensure((size_t)m);
+    double *sig = h->f64_a.p, *tmp = h->f64_b.p;
+    const bool pre = lim && lim->needed && lim->pre_gain_db > 0;
+    launch_s16_to_f64(h->s16_p2.p, sig, m, pre ? std::pow(10.0, lim->pre_gain_db / 20.0) : 1.0, pre ? 1 : 0, h->stream);
+    if (lim && lim->needed) { run_limiter(h, sig, tmp, m, rate, lim->limit, 5.0, 100.0, 1.0); std::swap(sig, tmp); }
+    check_cancel(h);
+    // loudnorm r128_in / r128_out statistics (libavfilter/ebur128.c) at the stream rate
+    if (stats) {
+        const int blk = (rate + 5) / 10; const int64_t nfull = m / blk, nalloc = nfull + 2;
+        h->d_scr0.ensure((size_t)nalloc * 2);
+        JT_HIP(hipMemsetAsync(h->d_scr0.p, 0, sizeof(double) * nalloc * 2, h->stream));
+        BiquadF64 prf, rlb; jt_kweight_design(rate, &prf, &rlb);
+        launch_kweight_blocks_f64(sig, m, blk, prf, rlb, h->d_scr0.p, h->d_scr0.p + nalloc, nalloc, h->stream);
+        std::vector<double> hb((size_t)nalloc * 2);
+        JT_HIP(hipMemcpyAsync(hb.data(), h->d_scr0.p, sizeof(double) * nalloc * 2, hipMemcpyDeviceToHost, h->stream));
+        JT_HIP(hipStreamSynchronize(h->stream));
+        double pk = 0; for (int64_t k = 0; k <= nfull; ++k) pk = std::max(pk, hb[nalloc + k]);
+        jt_loudnorm_finish(hb.data(), nfull, blk, true, 1.0, &stats->input_i, &stats->input_lra, &stats->input_thresh);
+        jt_loudnorm_finish(hb.data(), nfull, blk, true, gain * gain, &stats->output_i, &stats->output_lra, &stats->output_thresh);
+        stats->input_tp = 20 * std::log10(pk);
+        stats->output_tp = 20 * std::log10(pk * gain);
+        stats->target_offset = ap->target_i - stats->output_i;
+        stats->normalization_type_dynamic = 0;
+    }
+    // adeclick: restated as pass-through (SURVEY f4 "next" row); see DESIGN.md
+    // brickwall alimiter on x*gain
+    run_limiter(h, sig, tmp, m, rate, ap->brickwall_limit, 1.0, 50.0, gain);
+    std::swap(sig, tmp);
+    check_cancel(h);
+    // dbl -> flt (aspectralstats) -> dbl (ebur128) -> s16
+    h->work_a.ensure((size_t)m);
+    h->s16_p4.ensure((size_t)m);
+    launch_f64_to_s16(sig, h->s16_p4.p, h->work_a.p, m, 1, h->stream);
+    h->m_p4 = m;
+    analyse_mono(h, h->work_a.p, m, rate, true, out, nullptr, 0);
+    JT_HIP(hipEventRecord(h->ev1, h->stream));
+    JT_HIP(hipEventSynchronize(h->ev1));
+    float ms = 0; JT_HIP(hipEventElapsedTime(&ms, h->ev0, h->ev1)); h->timers.pass4_ms = ms;
+    JT_API_END(h)
+}
+
+// ---------------------------------------------------------------- region re-measure
+extern "C" int jt_region_measure(jt_ctx *h, int stage, double start_s, double dur_s, jt_region_sample *out)
+{
+    JT_API_BEGIN(h)
+    JT_REQUIRE(out && start_s >= 0 && dur_s > 0, JT_E_INVAL, "region_measure: bad arguments");
+    const int16_t *src = nullptr; int64_t m = 0;
+    if (stage == 2) { src = h->s16_p2.p; m = h->m_p2; } else if (stage == 4) { src = h->s16_p4.p; m = h->m_p4; }
+    JT_REQUIRE(src && m > 0, JT_E_STATE, "region_measure: stage output not on device");
+    const int rate = h->out_rate;
+    int64_t s0 = (int64_t)std::ceil(start_s * rate - 1e-9), s1 = (int64_t)std::ceil((start_s + dur_s) * rate - 1e-9);
+    s0 = std::max<int64_t>(0, std::min(s0, m)); s1 = std::max(s0, std::min(s1, m));
+    const int64_t len = s1 - s0;
+    std::memset(out, 0, sizeof(*out));
+    JT_REQUIRE(len > 0, JT_E_INVAL, "region_measure: empty region");
+    DevBuf<float> x; x.ensure((size_t)len);
+    launch_s16_to_f32(src + s0, x.p, len, h->stream);
+    jt_analysis a; std::memset(&a, 0, sizeof(a));
+    std::vector<jt_frame_meta> meta((size_t)(len / (rate / 10) + 2));
+    analyse_mono(h, x.p, len, rate, false, &a, meta.data(), (int64_t)meta.size());
+    out->rms_level = a.astats.rms_level; out->peak_level = a.astats.peak_level; out->crest_factor = a.astats.crest_factor;
+    out->spectral = a.spectral_mean;
+    out->momentary = a.r128.momentary; out->shortterm = a.r128.shortterm;
+    out->true_peak = a.r128.true_peak; out->sample_peak = a.r128.sample_peak;
+    out->frames = a.n_frames_meta;
+    JT_API_END(h)
+}
+
+// ---------------------------------------------------------------- output
+extern "C" int jt_output_len(jt_ctx *h, int stage, int64_t *n)
+{
+    if (!h || !n) return JT_E_INVAL;
+    *n = stage == 2 ? h->m_p2 : (stage == 4 ? h->m_p4 : 0);
+    return JT_OK;
+}
+
+extern "C" int jt_download_s16(jt_ctx *h, int stage, int16_t *dst, int64_t cap, int64_t *n)
+{
+    JT_API_BEGIN(h)
+    const int16_t *src = stage == 2 ? h->s16_p2.p : (stage == 4 ? h->s16_p4.p : nullptr);
+    const int64_t m = stage == 2 ? h->m_p2 : (stage == 4 ? h->m_p4 : 0);
+    JT_REQUIRE(src && m > 0, JT_E_STATE, "download: stage output not on device");
+    JT_REQUIRE(dst && cap >= m, JT_E_INVAL, "download: buffer too small");
+    JT_HIP(hipMemcpyAsync(dst, src, sizeof(int16_t) * m, hipMemcpyDeviceToHost, h->stream));
+    JT_HIP(hipStreamSynchronize(h->stream));
+    if (n) *n = m;
+    JT_API_END(h)
+}
+
+extern "C" int jt_get_timers(jt_ctx *h, jt_timers *out)
+{
+    if (!h || !out) return JT_E_INVAL;
+    *out = h->timers;
+    return JT_OK;
+}
+
+// ---------------------------------------------------------------- operator-level entry points (host buffers)
+template <typename T> static void h2d(jt_ctx *h, DevBuf<T> &b, const T *src, size_t n)
+{
+    b.ensure(n);
+    JT_HIP(hipMemcpyAsync(b.p, src, sizeof(T) * n, hipMemcpyHostToDevice, h->stream));
+}
+template <typename T> static void d2h(jt_ctx *h, T *dst, const T *src, size_t n)
+{
+    JT_HIP(hipMemcpyAsync(dst, src, sizeof(T) * n, hipMemcpyDeviceToHost, h->stream));
+    JT_HIP(hipStreamSynchronize(h->stream));
+}
+
+extern "C" int jt_op_biquad_f32(jt_ctx *h, const float *in, float *out, int64_t n, int sr,
+                                int hp_en, double hp_f, double hp_q, int lp_en, double lp_f, double lp_q)
+{
+    JT_API_BEGIN(h)
+    JT_REQUIRE(in && out && n > 0, JT_E_INVAL, "op_biquad: bad arguments");
+    DevBuf<float> a, b; h2d(h, a, in, (size_t)n); b.ensure((size_t)n);
+    jt_filter_params p{}; p.hp_enabled = hp_en; p.hp_freq = hp_f; p.hp_q = hp_q; p.lp_enabled = lp_en; p.lp_freq = lp_f; p.lp_q = lp_q;
+    BiquadF32 st[2]; int nst = 0; fill_biquads(&p, sr, st, &nst);
+    JT_REQUIRE(nst > 0, JT_E_INVAL, "op_biquad: no stage enabled");
+    launch_biquad_f32(a.p, b.p, n, nst, st, h->stream);
+    d2h(h, out, b.p, (size_t)n);
+    JT_API_END(h)
+}
+
+extern "C" int jt_op_anlmdn_f32(jt_ctx *h, const float *in, float *out, int64_t n, int sr,
+                                double strength, double patch_s, double research_s, double smooth)
+{
+    JT_API_BEGIN(h)
+    JT_REQUIRE(in && out && n > 0, JT_E_INVAL, "op_anlmdn: bad arguments");
+    DevBuf<float> a, b; h2d(h, a, in, (size_t)n); b.ensure((size_t)n);
+    run_anlmdn(h, a.p, b.p, n, sr, strength, patch_s, research_s, smooth);
+    d2h(h, out, b.p, (size_t)n);
+    float ms = 0; JT_HIP(hipEventElapsedTime(&ms, h->ev2, h->ev3)); h->timers.nlm_ms = ms; h->timers.nlm_launches = 1;
+    JT_API_END(h)
+}
+
+extern "C" int jt_op_afftdn_f32(jt_ctx *h, const float *in, float *out, int64_t n, int sr, double nr, double nf, const double *bn)
+{
+    JT_API_BEGIN(h)
+    JT_REQUIRE(in && out && n > 0, JT_E_INVAL, "op_afftdn: bad arguments");
+    DevBuf<float> a, b; h2d(h, a, in, (size_t)n); b.ensure((size_t)n);
+    run_afftdn(h, a.p, b.p, n, sr, nr, nf, bn);
+    d2h(h, out, b.p, (size_t)n);
+    JT_API_END(h)
+}
+
+extern "C" int jt_op_dynamics(jt_ctx *h, const float *in, float *out, int64_t n, int sr, const jt_filter_params *p)
+{
+    JT_API_BEGIN(h)
+    JT_REQUIRE(in && out && p && n > 0, JT_E_INVAL, "op_dynamics: bad arguments");
+    DevBuf<float> a, b; h2d(h, a, in, (size_t)n); b.ensure((size_t)n);
+    DynParams d; jt_dyn_design(p, sr, &d);
+    launch_dynamics(a.p, b.p, nullptr, n, d, h->stream);
+    d2h(h, out, b.p, (size_t)n);
+    JT_API_END(h)
+}
+
+extern "C" int jt_op_alimiter_f64(jt_ctx *h, const double *in, double *out, int64_t n, int sr,
+                                  double limit, double attack_ms, double release_ms)
+{
+    JT_API_BEGIN(h)
+    JT_REQUIRE(in && out && n > 0, JT_E_INVAL, "op_alimiter: bad arguments");
+    DevBuf<double> a, b; h2d(h, a, in, (size_t)n); b.ensure((size_t)n);
+    run_limiter(h, a.p, b.p, n, sr, limit, attack_ms, release_ms, 1.0);
+    d2h(h, out, b.p, (size_t)n);
+    JT_API_END(h)
+}
+
+extern "C" int jt_op_resample_f32_to_s16(jt_ctx *h, const float *in, int64_t n, int in_rate, int out_rate,
+                                         int16_t *out, int64_t cap, int64_t *n_out)
+{
+    JT_API_BEGIN(h)
+    JT_REQUIRE(in && out && n > 0, JT_E_INVAL, "op_resample: bad arguments");
+    DevBuf<float> a; h2d(h, a, in, (size_t)n);
+    DevBuf<int16_t> o; int64_t m = 0;
+    run_resample_s16(h, a.p, n, in_rate, out_rate, o, &m);
+    JT_REQUIRE(cap >= m, JT_E_INVAL, "op_resample: output buffer too small");
+    d2h(h, out, o.p, (size_t)m);
+    if (n_out) *n_out = m;
+    JT_API_END(h)
+}
+
+extern "C" int jt_op_ebur128(jt_ctx *h, const float *in, int64_t n, int sr, int dualmono, jt_r128 *out,
+                             double *ms, double *ss, double *tps, double *sps, int64_t cap, int64_t *n_blocks)
+{
+    JT_API_BEGIN(h)
+    JT_REQUIRE(in && out && n > 0, JT_E_INVAL, "op_ebur128: bad arguments");
+    DevBuf<float> a; h2d(h, a, in, (size_t)n);
+    AnalysisHost A; run_r128(h, a.p, n, sr, dualmono != 0, true, &A);
+    out->integrated = A.r128.integrated; out->lra = A.r128.lra; out->lra_low = A.r128.lra_low; out->lra_high = A.r128.lra_high;
+    out->momentary = A.nblocks ? A.r128.M[A.nblocks - 1] : NAN; out->shortterm = A.nblocks ? A.r128.S[A.nblocks - 1] : NAN;
+    out->true_peak = A.tp_final; out->sample_peak = A.sp_final; out->target_threshold = A.r128.rel_threshold;
+    for (int64_t k = 0; k < std::min(cap, A.nblocks); ++k) {
+        if (ms) ms[k] = A.r128.M[k];
+        if (ss) ss[k] = A.r128.S[k];
+        if (tps) tps[k] = A.tp_cum[k];
+        if (sps) sps[k] = A.sp_cum[k];
+    }
+    if (n_blocks) *n_blocks = A.nblocks;
+    JT_API_END(h)
+}
+
+extern "C" int jt_op_astats(jt_ctx *h, const float *in, int64_t n, int sr, jt_astats *out)
+{
+    JT_API_BEGIN(h)
+    JT_REQUIRE(in && out && n > 0, JT_E_INVAL, "op_astats: bad arguments");
+    DevBuf<float> a; h2d(h, a, in, (size_t)n);
+    run_astats(h, a.p, n, sr, out);
+    JT_API_END(h)
+}
+
+extern "C" int jt_op_aspectralstats(jt_ctx *h, const float *in, int64_t n, int sr, jt_spectral *hops, int64_t cap, int64_t *n_hops)
+{
+    JT_API_BEGIN(h)
+    JT_REQUIRE(in && hops && n > 0, JT_E_INVAL, "op_aspectralstats: bad arguments");
+    DevBuf<float> a; h2d(h, a, in, (size_t)n);
+    AnalysisHost A; run_spectral(h, a.p, n, sr, &A);
+    for (int64_t k = 0; k < std::min(cap, A.nhops); ++k) hops[k] = A.hops[(size_t)k];
+    if (n_hops) *n_hops = A.nhops;
+    JT_API_END(h)
+}
+
+extern "C" int jt_op_loudnorm_measure_s16(jt_ctx *h, const int16_t *in, int64_t n, int sr, const jt_limiter_plan *lim, jt_loudnorm_stats *out)
+{
+    JT_API_BEGIN(h)
+    JT_REQUIRE(in && out && n > 0, JT_E_INVAL, "op_loudnorm_measure: bad arguments");
+    DevBuf<int16_t> a; h2d(h, a, in, (size_t)n);
+    pass3_core(h, a.p, n, sr, lim, out);
+    JT_API_END(h)
+}

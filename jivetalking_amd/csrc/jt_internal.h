@@ -1,0 +1,170 @@
+// jt_internal.h — shared declarations for libjtgpu.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <cmath>
+#include <string>
+#include <vector>
+#include <atomic>
+#include "../../include/jtgpu.h"
+
+struct JtError { int code; std::string msg; };
+
+#define JT_HIP(expr) do { hipError_t e__ = (expr); if (e__ != hipSuccess) { \
+    throw JtError{JT_E_HIP, std::string(#expr) + ": " + hipGetErrorString(e__)}; } } while (0)
+#define JT_REQUIRE(cond, code, text) do { if (!(cond)) throw JtError{(code), (text)}; } while (0)
+
+// Simple owning device buffer
+template <typename T> struct DevBuf {
+    T *p = nullptr; size_t n = 0;
+    DevBuf() {}
+    DevBuf(const DevBuf &) = delete; DevBuf &operator=(const DevBuf &) = delete;
+    ~DevBuf() { release(); }
+    void release() { if (p) { (void)hipFree(p); p = nullptr; n = 0; } }
+    void ensure(size_t count) {
+        if (count <= n && p) return;
+        release();
+        if (count == 0) count = 1;
+        JT_HIP(hipMalloc((void **)&p, count * sizeof(T)));
+        n = count;
+    }
+    void zero(hipStream_t s) { if (p) JT_HIP(hipMemsetAsync(p, 0, n * sizeof(T), s)); }
+};
+
+// ---------------------------------------------------------------- host-side plans
+struct BiquadF32 { float b0, b1, b2, a1, a2; };      // TDII, a1/a2 already negated
+struct BiquadF64 { double b0, b1, b2, a1, a2; };     // DF1 (f_ebur128.c FILTER macro), a1/a2 as in the difference equation
+
+void jt_biquad_design(int type /*0 hp,1 lp*/, double freq, double q, int sr, double b[3], double a[3], int normalize);
+void jt_kweight_design(int sr, BiquadF64 *pre, BiquadF64 *rlb);
+
+struct SwrPlanHost {
+    int phase_count = 0, filter_length = 0, center = 0; int64_t step = 0;
+    std::vector<double> bank;   // [phase][tap]
+};
+void jt_swr_plan(SwrPlanHost *p, int in_rate, int out_rate);
+
+// R128 host finishing (f_ebur128.c gating / LRA on per-100ms block energies)
+struct R128Series { std::vector<double> M, S; double integrated, lra, lra_low, lra_high, rel_threshold; };
+void jt_r128_finish(const double *block_sums, int64_t nblocks, int blk, int sr, bool dualmono, R128Series *out);
+// libebur128-style (af_loudnorm.c) finishing on per-100ms block energies
+void jt_loudnorm_finish(const double *block_sums, int64_t nblocks, int64_t s100, bool dual_mono, double scale_energy,
+                        double *i, double *lra, double *thresh);
+
+// ---------------------------------------------------------------- kernel launchers (k_*.hip)
+// lane-serial family
+void launch_frame_stats(const float *in, int64_t n_total /*frames*channels*/, int samples_per_frame,
+                        double *sumsq, double *peak, int64_t nframes, hipStream_t s);
+void launch_downmix(const float *in, float *out, int64_t frames, int channels, hipStream_t s);
+void launch_s16_to_f32(const int16_t *in, float *out, int64_t n, hipStream_t s);
+void launch_s16_to_f64(const int16_t *in, double *out, int64_t n, double gain, int gain_in_float, hipStream_t s);
+void launch_biquad_f32(const float *in, float *out, int64_t n, int nstages, const BiquadF32 *st, hipStream_t s);
+// K-weighting + per-block energy / sample peak. T = float or double input.
+void launch_kweight_blocks_f32(const float *in, int64_t n, int blk, BiquadF64 pre, BiquadF64 rlb,
+                               double *block_sums, double *block_peaks, int64_t nblocks_alloc, hipStream_t s);
+void launch_kweight_blocks_f64(const double *in, int64_t n, int blk, BiquadF64 pre, BiquadF64 rlb,
+                               double *block_sums, double *block_peaks, int64_t nblocks_alloc, hipStream_t s);
+
+struct DynParams {
+    int gate_on, comp_on, deess_on;
+    // gate
+    double g_attack, g_release, g_lin_knee_stop, g_thres, g_knee_start, g_knee_stop, g_ratio, g_knee, g_range, g_makeup;
+    // comp
+    double c_attack, c_release, c_thres, c_knee_start, c_knee_stop, c_adj_knee_start, c_ckstop, c_ratio, c_knee, c_makeup, c_mix;
+    // deesser
+    double d_intensity, d_maxdess, d_iir;
+};
+void jt_dyn_design(const jt_filter_params *p, int sr, DynParams *d);
+void launch_dynamics(const float *in, float *out_f32, double *out_f64, int64_t n, const DynParams &d, hipStream_t s);
+
+// astats
+struct AstatsChunk {   // per-lane chunk summary, merged in order on the host
+    double min, max, min_non_zero, sigma_x, sigma_x2, min_diff, max_diff, diff1_sum, diff1_sum_x2;
+    double first, last;              // first / last sample of the chunk
+    double first_nz_sign, last_nz_sign; // +1 / -1, 0 if the chunk has no non-zero sample
+    double zero_runs;                // sign changes between consecutive non-zero samples inside the chunk
+    double min_sigma, max_sigma;     // exp-averaged power extrema (valid samples only)
+    double noise_floor, noise_floor_count;
+    double abs_peak;
+    int64_t count;
+    // run bookkeeping at the chunk's own min / max value
+    double min_count, min_runs, min_head_run, min_tail_run, min_all;   // *_all = 1 when the whole chunk equals min
+    double max_count, max_runs, max_head_run, max_tail_run, max_all;
+    uint64_t mask_or, mask_and;
+};
+void jt_astats_run(const float *in, int64_t n, int sr, float *g_scratch /*n*/, double *zs /*nchunks*/, double *carry /*nchunks*/,
+                   AstatsChunk *chunks, int64_t chunk, int64_t nchunks, unsigned long long *ehist, hipStream_t s);
+void launch_biquad_di_f32(const float *in, float *out, int64_t n, BiquadF32 hp, BiquadF32 lp, hipStream_t s);
+void jt_astats_merge(const AstatsChunk *chunks, int64_t nchunks, const unsigned long long *ehist, int sr, jt_astats *out);
+
+// limiter (exact, chunked at provably clean points)
+void launch_absmax_blocks_f64(const double *in, int64_t n, int blk, double *out_max, int64_t nblk, hipStream_t s);
+void launch_limiter_f64(const double *in, double *out, int64_t n, int sr, double limit, int buffer_size,
+                        double release_s, double asc_coeff, const int64_t *bounds, int nlanes, double in_gain,
+                        double *scratch_delta, int64_t *scratch_pos, hipStream_t s);
+
+// resampler / true peak
+void launch_resample_to_s16(const float *in, int64_t n, const double *bank, int phase_count, int filter_length, int center,
+                            int64_t step, int16_t *out, int64_t m, hipStream_t s);
+void launch_true_peak_f32(const float *in, int64_t n, const double *bank, int phase_count, int filter_length, int center,
+                          int64_t step, int blk, double *block_tp, int64_t nblocks_alloc, int64_t m_total, hipStream_t s);
+void launch_true_peak_f64(const double *in, int64_t n, const double *bank, int phase_count, int filter_length, int center,
+                          int64_t step, int blk, double *block_tp, int64_t nblocks_alloc, int64_t m_total, hipStream_t s);
+// fused resample -> K-weight -> block sums / sample peak at the output rate (loudnorm measurement, Pass 3)
+void launch_resample_kweight_s16(const int16_t *in, int64_t n, const float *bankf, int phase_count, int filter_length, int center,
+                                 int64_t step, int64_t m_total, int blk, BiquadF64 pre, BiquadF64 rlb,
+                                 double *block_sums, double *block_peaks, int64_t nblocks_alloc, hipStream_t s);
+void launch_resample_kweight_f64(const double *in, int64_t n, const double *bank, int phase_count, int filter_length, int center,
+                                 int64_t step, int64_t m_total, int blk, BiquadF64 pre, BiquadF64 rlb,
+                                 double *block_sums, double *block_peaks, int64_t nblocks_alloc, hipStream_t s);
+void launch_f64_to_s16(const double *in, int16_t *out, float *out_f32, int64_t n, int round_via_float, hipStream_t s);
+void launch_f32_to_f64(const float *in, double *out, int64_t n, hipStream_t s);
+
+// spectral
+void launch_aspectralstats(const float *in, int64_t n, int sr, int win_size, const float2 *twiddle, const float *hann,
+                           jt_spectral *hops, int64_t nhops, hipStream_t s);
+// afftdn
+struct AfftdnPlanHost {
+    int sr, A, W, L, bins, nbands;
+    std::vector<int> bin2band; std::vector<double> window, alpha, beta, spread, abs_var, min_abs_var;
+    double max_gain;
+};
+void jt_afftdn_plan(AfftdnPlanHost *pl, int sr, double nr, double nf, const double *band_noise);
+struct AfftdnDev {
+    int A, W, L, bins, nbands; double max_gain;
+    const int *bin2band; const double *window, *alpha, *beta, *spread, *abs_var, *min_abs_var; const float2 *twiddle;
+};
+void launch_afftdn(const float *in, float *out, int64_t n, const AfftdnDev &d, int frames_per_chunk, int warm_frames, hipStream_t s);
+// anlmdn
+void launch_anlmdn(const float *in, float *out, int64_t n, int K, int S, float sw, float smooth, float lut_scale, hipStream_t s);
+
+// ---------------------------------------------------------------- context
+struct jt_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+    std::atomic<int> cancelled{0};
+    // input
+    int sr = 0, channels = 0; int64_t n = 0;
+    const float *in_raw = nullptr;      // interleaved (owned or attached)
+    DevBuf<float> in_owned;
+    DevBuf<float> mono;                 // downmixed when channels == 2
+    const float *in_mono = nullptr;
+    // stage buffers
+    DevBuf<float> work_a, work_b;       // f32 ping-pong at source rate
+    DevBuf<int16_t> s16_p2, s16_p4;     // Pass-2 / Pass-4 outputs
+    int64_t m_p2 = 0, m_p4 = 0; int out_rate = 0;
+    DevBuf<double> f64_a, f64_b;        // f64 ping-pong at output rate
+    // scratch
+    DevBuf<double> d_scr0, d_scr1, d_scr2, d_scr3;
+    DevBuf<AstatsChunk> astats_chunks; DevBuf<unsigned long long> ehist;
+    DevBuf<jt_spectral> spec_hops;
+    DevBuf<float2> twiddle; int twiddle_n = 0; DevBuf<float> hann; int hann_n = 0;
+    DevBuf<double> bank_d; DevBuf<float> bank_f;
+    DevBuf<int64_t> lim_bounds, lim_pos; DevBuf<double> lim_delta;
+    DevBuf<int> af_bin2band; DevBuf<double> af_tab;
+    jt_timers timers{};
+    hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr, ev3 = nullptr;
+};

@@ -1,0 +1,417 @@
+// jt_plan.cpp — host-side design of the constant tables the kernels consume (filter coefficients, resampler
+// phase banks, afftdn band tables) and the O(#blocks) finishing steps of the R128 measurements (gating,
+// histograms, percentiles) and astats (ordered merge of per-chunk summaries).  Scalar double arithmetic; none
+// of this touches sample data.
+#include "jt_internal.h"
+#include <algorithm>
+#include <cfloat>
+
+// ---------------------------------------------------------------- biquads (af_biquads.c config_filter)
+void jt_biquad_design(int type, double freq, double q, int sr, double b[3], double a[3], int normalize)
+{
+    const double w0 = 2 * M_PI * freq / sr;
+    const double alpha = std::sin(w0) / (2 * q);
+    const double cw = std::cos(w0);
+    a[0] = 1 + alpha; a[1] = -2 * cw; a[2] = 1 - alpha;
+    if (type == 0) { b[0] = (1 + cw) / 2; b[1] = -(1 + cw); b[2] = (1 + cw) / 2; }
+    else           { b[0] = (1 - cw) / 2; b[1] = 1 - cw;    b[2] = (1 - cw) / 2; }
+    const double a0 = a[0];
+    a[1] /= a0; a[2] /= a0; b[0] /= a0; b[1] /= a0; b[2] /= a0; a[0] = 1.0;
+    if (normalize && std::fabs(b[0] + b[1] + b[2]) > 1e-6) {
+        const double factor = (a[0] + a[1] + a[2]) / (b[0] + b[1] + b[2]);
+        b[0] *= factor; b[1] *= factor; b[2] *= factor;
+    }
+}
+
+// f_ebur128.c config_audio_input(): "reversed parametrization of PRE and RLB from 48 kHz"
+void jt_kweight_design(int sr, BiquadF64 *pre, BiquadF64 *rlb)
+{
+    double f0 = 1681.974450955533, G = 3.999843853973347, Q = 0.7071752369554196;
+    double K = std::tan(M_PI * f0 / (double)sr);
+    double Vh = std::pow(10.0, G / 20.0);
+    double Vb = std::pow(Vh, 0.4996667741545416);
+    double a0 = 1.0 + K / Q + K * K;
+    pre->b0 = (Vh + Vb * K / Q + K * K) / a0;
+    pre->b1 = 2.0 * (K * K - Vh) / a0;
+    pre->b2 = (Vh - Vb * K / Q + K * K) / a0;
+    pre->a1 = 2.0 * (K * K - 1.0) / a0;
+    pre->a2 = (1.0 - K / Q + K * K) / a0;
+    f0 = 38.13547087602444; Q = 0.5003270373238773;
+    K = std::tan(M_PI * f0 / (double)sr);
+    rlb->b0 = 1.0; rlb->b1 = -2.0; rlb->b2 = 1.0;
+    rlb->a1 = 2.0 * (K * K - 1.0) / (1.0 + K / Q + K * K);
+    rlb->a2 = (1.0 - K / Q + K * K) / (1.0 + K / Q + K * K);
+}
+
+// ---------------------------------------------------------------- swresample phase bank (resample.c build_filter)
+static double bessel_i0(double x)
+{
+    double v = 1, last = 0, t = 1;
+    x = x * x / 4;
+    for (int i = 1; v != last; i++) { last = v; t *= x / ((double)i * i); v += t; }
+    return v;
+}
+
+void jt_swr_plan(SwrPlanHost *p, int in_rate, int out_rate)
+{
+    const int filter_size = 32; const double cutoff = 0.97, beta = 9.0;
+    const double factor = std::min(out_rate * cutoff / in_rate, 1.0);
+    int phase_count = 1 << 10;
+    int L = std::max((int)std::ceil(filter_size / factor), 1);
+    if (L > 1) L = (L + 1) & ~1;
+    int64_t a = out_rate, b = in_rate;
+    while (b) { int64_t t = a % b; a = b; b = t; }
+    const int64_t g = a;
+    const int64_t pc_exact = out_rate / g;
+    if (pc_exact <= phase_count) phase_count = (int)pc_exact;
+    p->phase_count = phase_count; p->filter_length = L; p->center = (L - 1) / 2;
+    // per output sample the phase index advances by in_rate*phase_count/out_rate (an integer when exact_rational holds)
+    p->step = (int64_t)(in_rate / g) * (phase_count / (out_rate / g));
+    p->bank.assign((size_t)phase_count * L, 0.0);
+    for (int ph = 0; ph < phase_count; ++ph) {
+        double norm = 0.0;
+        double *tab = &p->bank[(size_t)ph * L];
+        for (int i = 0; i < L; ++i) {
+            const double x = M_PI * ((double)(i - p->center) - (double)ph / phase_count) * factor;
+            double y = (x == 0) ? 1.0 : std::sin(x) / x;
+            const double w = 2.0 * x / (factor * L * M_PI);
+            y *= bessel_i0(beta * std::sqrt(std::max(1 - w * w, 0.0)));
+            tab[i] = y; norm += y;
+        }
+        for (int i = 0; i < L; ++i) tab[i] /= norm;
+    }
+}
+
+// ---------------------------------------------------------------- f_ebur128.c gating / LRA on block energies
+namespace {
+constexpr int ABS_THRES = -70, ABS_UP_THRES = 10, HIST_GRAIN = 100;
+constexpr int HIST_SIZE = (ABS_UP_THRES - ABS_THRES) * HIST_GRAIN + 1;
+inline double LOUDNESS(double e) { return -0.691 + 10 * std::log10(e); }
+inline double ENERGY(double l) { return std::pow(10., (l + 0.691) / 10.); }
+inline int HIST_POS(double l) { return (int)((l - ABS_THRES) * HIST_GRAIN); }
+inline int clipi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+}
+
+void jt_r128_finish(const double *bs, int64_t nblocks, int blk, int sr, bool dualmono, R128Series *o)
+{
+    (void)blk;
+    const double pan_law = -3.01029995663978;
+    const int bins400 = sr * 4 / 10, bins3000 = sr * 3;
+    std::vector<unsigned> h400(HIST_SIZE, 0), h3000(HIST_SIZE, 0);
+    double kept400 = 0, kept3000 = 0; int64_t nk400 = 0, nk3000 = 0;
+    double rel400 = 0;
+    o->M.assign(nblocks, 0.0); o->S.assign(nblocks, 0.0);
+    double w400 = 0.0, w3000 = 0.0;            // sliding sums of the last 4 / 30 block energies
+    for (int64_t k = 0; k < nblocks; ++k) {
+        // window sums recomputed from the block energies each step (no add/sub drift)
+        if (k >= 3)  { w400 = bs[k] + bs[k - 1] + bs[k - 2] + bs[k - 3]; }
+        if (k >= 29) { double s = 0; for (int q = 29; q >= 0; --q) s += bs[k - q]; w3000 = s; }
+        double p400 = 1e-12, p3000 = 1e-12;
+        if (k >= 3)  { p400 += w400;   p400 /= bins400; }
+        if (k >= 29) { p3000 += w3000; p3000 /= bins3000; }
+        double l400 = LOUDNESS(p400), l3000 = LOUDNESS(p3000);
+        if (l400 >= ABS_THRES) {
+            h400[clipi(HIST_POS(l400), 0, HIST_SIZE - 1)]++;
+            kept400 += p400; nk400++;
+            double rt = kept400 / nk400; if (!rt) rt = 1e-12;
+            rel400 = LOUDNESS(rt) + (-10);
+        }
+        if (l3000 >= ABS_THRES) {
+            h3000[clipi(HIST_POS(l3000), 0, HIST_SIZE - 1)]++;
+            kept3000 += p3000; nk3000++;
+        }
+        if (dualmono) { l400 -= pan_law; l3000 -= pan_law; }
+        o->M[k] = l400; o->S[k] = l3000;
+    }
+    // integrated loudness = value after the last gated block
+    o->integrated = ABS_THRES; o->lra = 0; o->lra_low = 0; o->lra_high = 0; o->rel_threshold = rel400;
+    if (nk400) {
+        int gate = clipi(HIST_POS(rel400), 0, HIST_SIZE - 1);
+        double isum = 0; uint64_t nint = 0;
+        for (int i = gate; i < HIST_SIZE; ++i) { nint += h400[i]; isum += h400[i] * ENERGY(i / (double)HIST_GRAIN + ABS_THRES); }
+        if (nint) { o->integrated = LOUDNESS(isum / nint); if (dualmono) o->integrated -= pan_law; }
+    }
+    if (nk3000) {
+        double rt = kept3000 / nk3000; if (!rt) rt = 1e-12;
+        int gate = clipi(HIST_POS(LOUDNESS(rt) + (-20)), 0, HIST_SIZE - 1);
+        uint64_t np = 0;
+        for (int i = gate; i < HIST_SIZE; ++i) np += h3000[i];
+        if (np) {
+            uint64_t nn = 0, npow = (uint64_t)(10 * np * 0.01 + 0.5);
+            for (int i = gate; i < HIST_SIZE; ++i) { nn += h3000[i]; if (nn >= npow) { o->lra_low = i / (double)HIST_GRAIN + ABS_THRES; break; } }
+            nn = np; npow = (uint64_t)(95 * np * 0.01 + 0.5);
+            for (int i = HIST_SIZE - 1; i >= 0; --i) { nn -= std::min<uint64_t>(nn, h3000[i]); if (nn < npow) { o->lra_high = i / (double)HIST_GRAIN + ABS_THRES; break; } }
+            o->lra = o->lra_high - o->lra_low;
+        }
+    }
+}
+
+// ---------------------------------------------------------------- libavfilter/ebur128.c (af_loudnorm.c statistics)
+namespace {
+double hist_e[1000], hist_b[1001]; bool hist_ok = false;
+void hist_init()
+{
+    if (hist_ok) return;
+    hist_b[0] = std::pow(10.0, (-70.0 + 0.691) / 10.0);
+    for (int i = 0; i < 1000; ++i) hist_e[i] = std::pow(10.0, ((double)i / 10.0 - 69.95 + 0.691) / 10.0);
+    for (int i = 1; i < 1001; ++i) hist_b[i] = std::pow(10.0, ((double)i / 10.0 - 70.0 + 0.691) / 10.0);
+    hist_ok = true;
+}
+size_t hist_index(double e)
+{
+    size_t lo = 0, hi = 1000, mid;
+    do { mid = (lo + hi) / 2; if (e >= hist_b[mid]) lo = mid; else hi = mid; } while (hi - lo != 1);
+    return lo;
+}
+double e2l(double e) { return 10 * (std::log(e) / std::log(10.0)) - 0.691; }
+}
+
+void jt_loudnorm_finish(const double *bs, int64_t nblocks, int64_t s100, bool dual_mono, double scale_energy,
+                        double *out_i, double *out_lra, double *out_thresh)
+{
+    hist_init();
+    std::vector<unsigned long> bh(1000, 0), sh(1000, 0);
+    const double ch = dual_mono ? 2.0 : 1.0;
+    // gating blocks: 400 ms every 100 ms; short-term blocks: 3 s, first at 3 s then every 1 s
+    for (int64_t k = 3; k < nblocks; ++k) {
+        double sum = (bs[k - 3] + bs[k - 2] + bs[k - 1] + bs[k]) * scale_energy * ch / (double)(s100 * 4);
+        if (sum >= hist_b[0]) ++bh[hist_index(sum)];
+        if (k >= 29 && (k - 29) % 10 == 0) {
+            double st = 0; for (int q = 29; q >= 0; --q) st += bs[k - q];
+            st = st * scale_energy * ch / (double)(s100 * 30);
+            if (st >= hist_b[0]) ++sh[hist_index(st)];
+        }
+    }
+    double rel = 0; long above = 0;
+    for (int j = 0; j < 1000; ++j) { rel += bh[j] * hist_e[j]; above += bh[j]; }
+    if (above) { rel /= (double)above; rel *= 0.1; }
+    *out_thresh = above ? e2l(rel) : -70.0;
+    if (!above) *out_i = -HUGE_VAL;
+    else {
+        size_t st;
+        if (rel < hist_b[0]) st = 0; else { st = hist_index(rel); if (rel > hist_e[st]) ++st; }
+        double g = 0; long cnt = 0;
+        for (size_t j = st; j < 1000; ++j) { g += bh[j] * hist_e[j]; cnt += bh[j]; }
+        *out_i = cnt ? e2l(g / cnt) : -HUGE_VAL;
+    }
+    size_t sz = 0; double pw = 0;
+    for (int j = 0; j < 1000; ++j) { sz += sh[j]; pw += sh[j] * hist_e[j]; }
+    *out_lra = 0.0;
+    if (sz) {
+        pw /= sz;
+        double integ = 0.01 * pw; size_t index;
+        if (integ < hist_b[0]) index = 0; else { index = hist_index(integ); if (integ > hist_e[index]) ++index; }
+        sz = 0; for (size_t j = index; j < 1000; ++j) sz += sh[j];
+        if (sz) {
+            size_t pl = (size_t)((sz - 1) * 0.1 + 0.5), ph = (size_t)((sz - 1) * 0.95 + 0.5), j = index;
+            sz = 0;
+            while (sz <= pl) sz += sh[j++];
+            double l_en = hist_e[j - 1];
+            while (sz <= ph) sz += sh[j++];
+            double h_en = hist_e[j - 1];
+            *out_lra = e2l(h_en) - e2l(l_en);
+        }
+    }
+}
+
+// ---------------------------------------------------------------- dynamics parameter derivation
+void jt_dyn_design(const jt_filter_params *p, int sr, DynParams *d)
+{
+    std::memset(d, 0, sizeof(*d));
+    d->gate_on = p->gate_enabled; d->comp_on = p->comp_enabled;
+    d->deess_on = p->deess_enabled && p->deess_i > 0;
+    if (d->gate_on) {   // agate_config_input, detection=rms
+        double lin_threshold = p->gate_threshold * p->gate_threshold;
+        double ks = std::sqrt(p->gate_knee);
+        d->g_attack = std::min(1., 1. / (p->gate_attack_ms * sr / 4000.));
+        d->g_release = std::min(1., 1. / (p->gate_release_ms * sr / 4000.));
+        d->g_lin_knee_stop = lin_threshold * ks;
+        double lks = lin_threshold / ks;
+        d->g_thres = std::log(lin_threshold);
+        d->g_knee_start = std::log(lks);
+        d->g_knee_stop = std::log(d->g_lin_knee_stop);
+        d->g_ratio = p->gate_ratio; d->g_knee = p->gate_knee; d->g_range = p->gate_range; d->g_makeup = p->gate_makeup;
+    }
+    if (d->comp_on) {   // compressor_config_output
+        d->c_thres = std::log(p->comp_threshold);
+        double lks = p->comp_threshold / std::sqrt(p->comp_knee), lke = p->comp_threshold * std::sqrt(p->comp_knee);
+        d->c_adj_knee_start = lks * lks;
+        d->c_knee_start = std::log(lks); d->c_knee_stop = std::log(lke);
+        d->c_ckstop = (d->c_knee_stop - d->c_thres) / p->comp_ratio + d->c_thres;
+        d->c_attack = std::min(1., 1. / (p->comp_attack_ms * sr / 4000.));
+        d->c_release = std::min(1., 1. / (p->comp_release_ms * sr / 4000.));
+        d->c_ratio = p->comp_ratio; d->c_knee = p->comp_knee; d->c_makeup = p->comp_makeup; d->c_mix = p->comp_mix;
+    }
+    if (d->deess_on) {
+        double overallscale = sr < 44100 ? 44100.0 / sr : sr / 44100.0;
+        d->d_intensity = std::pow(p->deess_i, 5) * (8192 / overallscale);
+        d->d_maxdess = 1.0 / std::pow(10.0, ((p->deess_m - 1.0) * 48.0) / 20);
+        d->d_iir = std::pow(p->deess_f, 2) / overallscale;
+    }
+}
+
+// ---------------------------------------------------------------- astats ordered merge (af_astats.c semantics)
+void jt_astats_merge(const AstatsChunk *c, int64_t nc, const unsigned long long *ehist, int sr, jt_astats *o)
+{
+    (void)sr;
+    std::memset(o, 0, sizeof(*o));
+    double mn = DBL_MAX, mx = -DBL_MAX, mnz = DBL_MAX, sx = 0, sx2 = 0, mind = DBL_MAX, maxd = 0, d1 = 0, d2 = 0;
+    double min_sig = DBL_MAX, max_sig = 0, nf = DBL_MAX, nfc = 0;
+    int64_t count = 0; double zr = 0; double run_sign = -1.0;   // FFSIGN(NaN) == -1
+    uint64_t mor = 0, mand = ~0ull;
+    for (int64_t k = 0; k < nc; ++k) {
+        const AstatsChunk &a = c[k];
+        if (a.count == 0) continue;
+        mn = std::min(mn, a.min); mx = std::max(mx, a.max); mnz = std::min(mnz, a.min_non_zero);
+        sx += a.sigma_x; sx2 += a.sigma_x2;
+        mind = std::min(mind, a.min_diff); maxd = std::max(maxd, a.max_diff); d1 += a.diff1_sum; d2 += a.diff1_sum_x2;
+        min_sig = std::min(min_sig, a.min_sigma); max_sig = std::max(max_sig, a.max_sigma);
+        if (a.noise_floor < nf) { nf = a.noise_floor; nfc = a.noise_floor_count; }
+        else if (a.noise_floor == nf) nfc += a.noise_floor_count;
+        if (a.first_nz_sign != 0) {
+            if (a.first_nz_sign != run_sign) zr += 1;
+            zr += a.zero_runs;
+            run_sign = a.last_nz_sign;
+        }
+        count += a.count; mor |= a.mask_or; mand &= a.mask_and;
+    }
+    // run statistics at the global extrema
+    double min_count = 0, min_runs = 0, max_count = 0, max_runs = 0, carry_min = 0, carry_max = 0;
+    for (int64_t k = 0; k < nc; ++k) {
+        const AstatsChunk &a = c[k];
+        if (a.count == 0) continue;
+        if (a.min == mn) {
+            min_count += a.min_count;
+            if (a.min_all) carry_min += a.min_head_run;
+            else {
+                if (a.min_head_run > 0) { double r = carry_min + a.min_head_run; min_runs += r * r; carry_min = 0; }
+                else if (carry_min > 0) { min_runs += carry_min * carry_min; carry_min = 0; }
+                min_runs += a.min_runs; carry_min = a.min_tail_run;
+            }
+        } else if (carry_min > 0) { min_runs += carry_min * carry_min; carry_min = 0; }
+        if (a.max == mx) {
+            max_count += a.max_count;
+            if (a.max_all) carry_max += a.max_head_run;
+            else {
+                if (a.max_head_run > 0) { double r = carry_max + a.max_head_run; max_runs += r * r; carry_max = 0; }
+                else if (carry_max > 0) { max_runs += carry_max * carry_max; carry_max = 0; }
+                max_runs += a.max_runs; carry_max = a.max_tail_run;
+            }
+        } else if (carry_max > 0) { max_runs += carry_max * carry_max; carry_max = 0; }
+    }
+    min_runs += carry_min * carry_min; max_runs += carry_max * carry_max;
+    if (count == 0) return;
+    auto DB = [](double x) { return std::log10(x) * 20; };
+    o->dc_offset = sx / count; o->min_level = mn; o->max_level = mx;
+    o->min_difference = mind; o->max_difference = maxd;
+    o->mean_difference = d1 / (count - 1); o->rms_difference = std::sqrt(d2 / (count - 1));
+    o->peak_level = DB(std::max(-mn, mx));
+    o->rms_level = DB(std::sqrt(sx2 / count));
+    o->rms_peak = DB(std::sqrt(max_sig));
+    o->rms_trough = min_sig != 1 ? DB(std::sqrt(min_sig)) : 0.0;
+    o->crest_factor = sx2 ? std::max(-mn, mx) / std::sqrt(sx2 / count) : 1;
+    o->flat_factor = DB((min_runs + max_runs) / (min_count + max_count));
+    o->peak_count = min_count + max_count;
+    o->noise_floor = DB(nf); o->noise_floor_count = nfc;
+    double ent = 0;
+    for (int i = 0; i < 8192; ++i) { double e = ehist[i] / (double)count; if (e > 1e-8) ent += e * std::log2(e); }
+    o->entropy = -ent / std::log2((double)std::min<int64_t>(count, 8192));
+    o->dynamic_range = DB(2 * std::max(std::fabs(mn), std::fabs(mx)) / mnz);
+    o->zero_crossings = zr; o->zero_crossings_rate = zr / (double)count;
+    o->number_of_samples = (double)count;
+    // bit depth estimate from the OR mask of the samples scaled to 32-bit integers
+    { unsigned bits = 0; uint64_t m = mor & 0xffffffffull; if (m) { unsigned tz = 0; while (!(m & 1)) { m >>= 1; ++tz; } bits = 32 - tz; } o->bit_depth = bits; }
+}
+
+// ---------------------------------------------------------------- afftdn tables (af_afftdn.c config_input / set_parameters)
+namespace {
+const int kBandCentre[15] = {80, 125, 195, 290, 440, 660, 1000, 1500, 2250, 3350, 5000, 7500, 11200, 16000, 24000};
+double bark(double x) { double d = x / 7500.0; return 13.0 * std::atan(7.6E-4 * x) + 3.5 * std::atan(d * d); }
+void lu_factor(double *m, int n)
+{
+    for (int i = 0; i < n - 1; i++)
+        for (int j = i + 1; j < n; j++) {
+            double d = m[j + i * n] / m[i + i * n];
+            m[j + i * n] = d;
+            for (int k = i + 1; k < n; k++) m[j + k * n] -= d * m[i + k * n];
+        }
+}
+void lu_solve(const double *m, double *v, int n)
+{
+    for (int i = 0; i < n - 1; i++) for (int j = i + 1; j < n; j++) v[j] -= m[j + i * n] * v[i];
+    v[n - 1] /= m[n * n - 1];
+    for (int i = n - 2; i >= 0; i--) {
+        double d = v[i];
+        for (int j = i + 1; j < n; j++) d -= m[i + j * n] * v[j];
+        v[i] = d / m[i + i * n];
+    }
+}
+}
+
+void jt_afftdn_plan(AfftdnPlanHost *pl, int sr, double nr, double nf, const double *band_noise_in)
+{
+    const double Cc = M_LN10 * 0.1;
+    pl->sr = sr; pl->A = sr / 80; pl->W = 3 * pl->A;
+    { int v = pl->W, bits = 0; while (v) { ++bits; v >>= 1; } pl->L = 1 << bits; }
+    pl->bins = pl->L / 2 + 1;
+    const int bins = pl->bins, L = pl->L;
+    double bn[15];
+    for (int i = 0; i < 15; ++i) bn[i] = band_noise_in ? std::min(std::max((double)(float)band_noise_in[i], -24.), 24.) : 0.0;
+    { double mean = 0; for (double v : bn) mean += v; mean /= 15; for (double &v : bn) v -= mean; }
+    // polynomial extrapolation of the profile above the last band (process_get_band_noise, band >= 15)
+    double ma[25], mb[75];
+    for (int j = 0; j < 5; j++) for (int k = 0; k < 5; k++) { ma[j + k * 5] = 0; for (int m = 0; m < 15; m++) ma[j + k * 5] += std::pow(m, j + k); }
+    lu_factor(ma, 5);
+    { int i = 0; for (int j = 0; j < 5; j++) for (int k = 0; k < 15; k++) mb[i++] = std::pow(k, j); }
+    auto band_noise = [&](int band) -> double {
+        if (band < 15) return bn[band];
+        double vb[5]; int i = 0;
+        for (int j = 0; j < 5; j++) { double s = 0; for (int k = 0; k < 15; k++) s += mb[i++] * bn[k]; vb[j] = s; }
+        lu_solve(ma, vb, 5);
+        double f = (0.5 * sr) / kBandCentre[14];
+        f = 15.0 + std::log(f / 1.5) / std::log(1.5);
+        double sum = 0, prod = 1; for (int j = 0; j < 5; j++) { sum += prod * vb[j]; prod *= f; }
+        return sum;
+    };
+    pl->bin2band.resize(bins);
+    const double sdiv = 1.25;
+    for (int i = 0; i < bins; ++i) pl->bin2band[i] = (int)std::lrint(sdiv * bark(((double)i * sr) / L));
+    pl->nbands = pl->bin2band[bins - 1] + 1;
+    const int nb = pl->nbands;
+    // spread function with excitation normalisation
+    pl->spread.assign((size_t)nb * nb, 0.0);
+    std::vector<double> be(nb, 0.0), pbe(nb, 0.0);
+    { double p1 = std::pow(0.1, 2.5 / sdiv), p2 = std::pow(0.1, 1.0 / sdiv); int j = 0;
+      for (int m = 0; m < nb; m++) for (int n2 = 0; n2 < nb; n2++) pl->spread[j++] = n2 < m ? std::pow(p2, m - n2) : (n2 > m ? std::pow(p1, n2 - m) : 1.0); }
+    for (int m = 0; m < bins; ++m) be[pl->bin2band[m]] += 1.0;
+    { int j = 0; for (int m = 0; m < nb; m++) for (int n2 = 0; n2 < nb; n2++) pbe[m] += pl->spread[j++] * be[n2]; }
+    { double mn = std::pow(0.1, 2.5), mx = std::pow(0.1, 1.0);
+      for (int i = 0; i < nb; i++) {
+          be[i] = (i < std::lrint(12.0 * sdiv)) ? std::pow(0.1, 1.45 + 0.1 * i / sdiv) : std::pow(0.1, 2.5 - 0.2 * (i / sdiv - 14.0));
+          be[i] = std::min(std::max(be[i], mn), mx);
+      }
+      int j = 0; for (int i = 0; i < nb; i++) for (int k = 0; k < nb; k++) pl->spread[j++] *= be[i] / pbe[i]; }
+    pl->alpha.assign(nb, 0.0); pl->beta.assign(nb, 0.0);
+    { int j = 0; const double sar = pl->A / (double)sr;
+      for (int i = 0; i < bins; i++) if ((i == L / 2) || (pl->bin2band[i] > j)) {
+          double d6 = (i - 1) * (double)sr / L, d7 = std::fmin(0.008 + 2.2 / d6, 0.03);
+          pl->alpha[j] = std::exp(-sar / d7); pl->beta[j] = 1.0 - pl->alpha[j]; j = pl->bin2band[i];
+      } }
+    pl->window.resize(pl->W);
+    double sum = 0; const double wscale = std::sqrt(8.0 / (9.0 * L));
+    for (int i = 0; i < pl->W; i++) { double d = std::sin(i * M_PI / pl->W); d *= wscale * d; pl->window[i] = d; sum += d * d; }
+    const double floor = (double)(1LL << 48) * std::exp(-23.025558369790467) * (0.5 * sum);
+    const double max_var = floor * std::exp((100.0 + nf) * Cc);
+    pl->max_gain = std::exp(nr * (0.5 * Cc));
+    const double gain_scale = 1.0 / (pl->max_gain * pl->max_gain);
+    // set_band_parameters(): log-linear interpolation of the band profile across bins
+    std::vector<double> rel(bins, 1.0);
+    { double d2 = 1, d5 = 0, bnz = band_noise(0); int i = 0, j = 0, k = 0;
+      for (int m = j; m < bins; m++) {
+          if (m == j) { i = j; d5 = bnz; j = (k >= 15) ? bins : (int)((double)L * kBandCentre[k] / sr); d2 = j - i; bnz = band_noise(k); k++; }
+          double d3 = (j - m) / d2, d4 = (m - i) / d2;
+          rel[m] = std::exp((d5 * d3 + bnz * d4) * Cc);
+      } }
+    pl->abs_var.resize(bins); pl->min_abs_var.resize(bins);
+    for (int i = 0; i < bins; i++) { pl->abs_var[i] = std::fmax(max_var * rel[i], 1.0); pl->min_abs_var[i] = gain_scale * pl->abs_var[i]; }
+}

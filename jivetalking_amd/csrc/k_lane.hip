@@ -1,0 +1,785 @@
+// k_lane.hip — "lane-serial" kernels for gfx950: recurrent per-sample filters (IIR biquads, K-weighting,
+// envelope followers, de-esser, look-ahead limiter, running statistics) mapped onto the GPU by
+// splitting the time axis into chunks, one chunk per lane, each lane running the recurrence
+// sequentially over its chunk (plus a warm-up halo where the recurrence forgets its state).
+//
+// Memory pattern: a wave owns 64 consecutive chunks.  Each step it stages a [64 lanes][TW samples]
+// tile through LDS: 64 coalesced row loads (row r = 64 consecutive samples of lane r's chunk,
+// 256 B for f32), the lanes then walk their own row with a (TW+1)-padded stride (conflict-free),
+// results go back through the same tile as coalesced row stores.  HBM traffic is 1 read + 1 write
+// per sample (plus halo re-reads); no MFMA — these are scalar recurrences.
+//
+// Reference filters replaced (FFmpeg 8.1, instantiated by /root/reference/internal/processor):
+//   highpass/lowpass a=tdii (filters.go:740-769), ebur128 K-weighting (filters.go:626),
+//   agate/acompressor/deesser (filters.go:869-932), alimiter (normalise.go:446-480),
+//   astats (filters.go:624).
+#include "jt_internal.h"
+
+constexpr int LANES = 64;
+constexpr int TW = 64;
+
+template <typename TIn, typename TL>
+__device__ inline void tile_load(TL (*tile)[TW + 1], const TIn *__restrict__ in, int64_t n,
+                                 int64_t base0, int64_t rowstride, int64_t pos, int lane, int nrows)
+{
+#pragma unroll 4
+    for (int r = 0; r < nrows; ++r) {
+        int64_t idx = base0 + (int64_t)r * rowstride + pos + lane;
+        TL v = (TL)0;
+        if (idx >= 0 && idx < n) v = (TL)in[idx];
+        tile[r][lane] = v;
+    }
+}
+
+// store columns [pos, pos+TW) of each row for indices inside [lo_r, hi_r)
+template <typename TOut, typename TL>
+__device__ inline void tile_store(TL (*tile)[TW + 1], TOut *__restrict__ out, int64_t n,
+                                  int64_t base0, int64_t rowstride, int64_t pos, int lane, int nrows,
+                                  int64_t halo, int64_t chunk)
+{
+#pragma unroll 4
+    for (int r = 0; r < nrows; ++r) {
+        int64_t rel = pos + lane;                       // position inside lane r's [halo + chunk) run
+        int64_t idx = base0 + (int64_t)r * rowstride + rel;
+        if (rel >= halo && rel < halo + chunk && idx >= 0 && idx < n) out[idx] = (TOut)tile[r][lane];
+    }
+}
+
+// ------------------------------------------------------------------ small elementwise kernels
+__global__ void k_downmix(const float *__restrict__ in, float *__restrict__ out, int64_t frames, int channels)
+{
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    // swresample rematrix stereo->mono for float sample formats: each input channel weighted
+    // M_SQRT1_2 then the matrix is normalised so the row sums to 1 (rematrix.c auto_matrix,
+    // maxcoef normalisation): 0.5 / 0.5.
+    for (; i < frames; i += stride) {
+        if (channels == 2) {
+            float2 v = reinterpret_cast<const float2 *>(in)[i];
+            out[i] = v.x * 0.5f + v.y * 0.5f;
+        } else {
+            float acc = 0.f;
+            for (int c = 0; c < channels; ++c) acc += in[i * channels + c] * (1.0f / channels);
+            out[i] = acc;
+        }
+    }
+}
+void launch_downmix(const float *in, float *out, int64_t frames, int channels, hipStream_t s)
+{
+    int grid = (int)std::min<int64_t>((frames + 255) / 256, 4096);
+    hipLaunchKernelGGL(k_downmix, dim3(grid), dim3(256), 0, s, in, out, frames, channels);
+}
+
+__global__ void k_s16_to_f32(const int16_t *__restrict__ in, float *__restrict__ out, int64_t n)
+{
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) out[i] = (float)in[i] * (1.0f / 32768.0f);
+}
+void launch_s16_to_f32(const int16_t *in, float *out, int64_t n, hipStream_t s)
+{
+    int grid = (int)std::min<int64_t>((n + 255) / 256, 4096);
+    hipLaunchKernelGGL(k_s16_to_f32, dim3(grid), dim3(256), 0, s, in, out, n);
+}
+
+// s16 -> dbl (audioconvert: x * (1.0/(1<<15))), optional volume stage in float precision
+// (af_volume.c precision=float: s16 -> flt, scale in float, then flt -> dbl).
+__global__ void k_s16_to_f64(const int16_t *__restrict__ in, double *__restrict__ out, int64_t n, double gain, int gain_in_float)
+{
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) {
+        if (gain_in_float) {
+            float v = (float)in[i] * (1.0f / 32768.0f);
+            v = v * (float)gain;
+            out[i] = (double)v;
+        } else {
+            out[i] = (double)in[i] * (1.0 / 32768.0) * gain;
+        }
+    }
+}
+void launch_s16_to_f64(const int16_t *in, double *out, int64_t n, double gain, int gain_in_float, hipStream_t s)
+{
+    int grid = (int)std::min<int64_t>((n + 255) / 256, 4096);
+    hipLaunchKernelGGL(k_s16_to_f64, dim3(grid), dim3(256), 0, s, in, out, n, gain, gain_in_float);
+}
+
+__global__ void k_f32_to_f64(const float *__restrict__ in, double *__restrict__ out, int64_t n)
+{
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) out[i] = (double)in[i];
+}
+void launch_f32_to_f64(const float *in, double *out, int64_t n, hipStream_t s)
+{
+    int grid = (int)std::min<int64_t>((n + 255) / 256, 4096);
+    hipLaunchKernelGGL(k_f32_to_f64, dim3(grid), dim3(256), 0, s, in, out, n);
+}
+
+// dbl -> s16 (audioconvert: av_clip_int16(lrint(x * 32768))); round_via_float models the dbl->flt->dbl
+// hop FFmpeg inserts around aspectralstats (fltp) before ebur128/aformat.
+__global__ void k_f64_to_s16(const double *__restrict__ in, int16_t *__restrict__ out, float *__restrict__ out_f32,
+                             int64_t n, int round_via_float)
+{
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) {
+        double v = in[i];
+        if (round_via_float) { float f = (float)v; v = (double)f; if (out_f32) out_f32[i] = f; }
+        double r = rint(v * 32768.0);
+        r = r < -32768.0 ? -32768.0 : (r > 32767.0 ? 32767.0 : r);
+        if (out) out[i] = (int16_t)r;
+    }
+}
+void launch_f64_to_s16(const double *in, int16_t *out, float *out_f32, int64_t n, int round_via_float, hipStream_t s)
+{
+    int grid = (int)std::min<int64_t>((n + 255) / 256, 4096);
+    hipLaunchKernelGGL(k_f64_to_s16, dim3(grid), dim3(256), 0, s, in, out, out_f32, n, round_via_float);
+}
+
+// ------------------------------------------------------------------ per-decoder-frame sum(x^2), max|x|
+// frameSumSquaresAndPeak (analyser_metrics.go:273-358): double accumulation over all interleaved samples.
+__global__ void k_frame_stats(const float *__restrict__ in, int64_t n_total, int spf, double *__restrict__ sumsq,
+                              double *__restrict__ peak, int64_t nframes)
+{
+    int64_t f = blockIdx.x;
+    if (f >= nframes) return;
+    int64_t lo = f * (int64_t)spf, hi = lo + spf;
+    if (hi > n_total) hi = n_total;
+    double acc = 0.0, pk = 0.0;
+    for (int64_t i = lo + threadIdx.x; i < hi; i += blockDim.x) {
+        double v = (double)in[i];
+        acc += v * v;
+        pk = fmax(pk, fabs(v));
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        acc += __shfl_down(acc, off, 64);
+        pk = fmax(pk, __shfl_down(pk, off, 64));
+    }
+    __shared__ double sa[4], sp[4];
+    int w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { sa[w] = acc; sp[w] = pk; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double a = 0, p = 0;
+        for (int k = 0; k < (int)(blockDim.x >> 6); ++k) { a += sa[k]; p = fmax(p, sp[k]); }
+        sumsq[f] = a; peak[f] = p;
+    }
+}
+void launch_frame_stats(const float *in, int64_t n_total, int spf, double *sumsq, double *peak, int64_t nframes, hipStream_t s)
+{
+    if (nframes <= 0) return;
+    hipLaunchKernelGGL(k_frame_stats, dim3((unsigned)nframes), dim3(256), 0, s, in, n_total, spf, sumsq, peak, nframes);
+}
+
+// ------------------------------------------------------------------ biquad cascade (f32, TDII)
+// BIQUAD_TDII_FILTER(flt): out = b0*in + w1; w1 = b1*in + w2 + a1*out; w2 = b2*in + a2*out
+__global__ void __launch_bounds__(64)
+k_biquad_f32(const float *__restrict__ in, float *__restrict__ out, int64_t n, int64_t chunk, int64_t halo,
+             int nstages, BiquadF32 s0, BiquadF32 s1, int64_t nchunks)
+{
+    __shared__ float tile[LANES][TW + 1];
+    const int lane = threadIdx.x;
+    const int64_t c0 = (int64_t)blockIdx.x * LANES;
+    const int nrows = (int)min((int64_t)LANES, nchunks - c0);
+    const int64_t base0 = c0 * chunk - halo;
+    const int64_t my_base = base0 + (int64_t)lane * chunk;
+    float w1a = 0.f, w2a = 0.f, w1b = 0.f, w2b = 0.f;
+    const int64_t total = halo + chunk;
+    for (int64_t pos = 0; pos < total; pos += TW) {
+        tile_load<float, float>(tile, in, n, base0, chunk, pos, lane, nrows);
+        __syncthreads();
+        if (lane < nrows) {
+#pragma unroll 8
+            for (int j = 0; j < TW; ++j) {
+                int64_t idx = my_base + pos + j;
+                float x = tile[lane][j];
+                if (idx >= 0) {     // before the file start the true state is exactly zero: keep it zero
+                    float y = __fadd_rn(__fmul_rn(s0.b0, x), w1a);
+                    w1a = __fadd_rn(__fadd_rn(__fmul_rn(s0.b1, x), w2a), __fmul_rn(s0.a1, y));
+                    w2a = __fadd_rn(__fmul_rn(s0.b2, x), __fmul_rn(s0.a2, y));
+                    x = y;
+                    if (nstages > 1) {
+                        float y2 = __fadd_rn(__fmul_rn(s1.b0, x), w1b);
+                        w1b = __fadd_rn(__fadd_rn(__fmul_rn(s1.b1, x), w2b), __fmul_rn(s1.a1, y2));
+                        w2b = __fadd_rn(__fmul_rn(s1.b2, x), __fmul_rn(s1.a2, y2));
+                        x = y2;
+                    }
+                }
+                tile[lane][j] = x;
+            }
+        }
+        __syncthreads();
+        tile_store<float, float>(tile, out, n, base0, chunk, pos, lane, nrows, halo, chunk);
+        __syncthreads();
+    }
+}
+
+void launch_biquad_f32(const float *in, float *out, int64_t n, int nstages, const BiquadF32 *st, hipStream_t s)
+{
+    if (n <= 0) return;
+    // halo from the slowest pole radius: r^2 = |a2|  =>  r^halo <= 1e-10
+    double rmax = 0.0;
+    for (int k = 0; k < nstages; ++k) rmax = std::max(rmax, std::sqrt(std::fabs((double)st[k].a2)));
+    int64_t halo = 256;
+    if (rmax > 0.0 && rmax < 1.0) halo = (int64_t)std::ceil(std::log(1e-10) / std::log(rmax));
+    halo = std::max<int64_t>(256, std::min<int64_t>(halo, 1 << 20));
+    halo = (halo + TW - 1) / TW * TW;
+    int64_t chunk = std::max<int64_t>(4096, halo * 2);
+    chunk = (chunk + TW - 1) / TW * TW;
+    int64_t nchunks = (n + chunk - 1) / chunk;
+    int grid = (int)((nchunks + LANES - 1) / LANES);
+    BiquadF32 z{1.f, 0.f, 0.f, 0.f, 0.f};
+    hipLaunchKernelGGL(k_biquad_f32, dim3(grid), dim3(LANES), 0, s, in, out, n, chunk, halo, nstages,
+                       st[0], nstages > 1 ? st[1] : z, nchunks);
+}
+
+// ------------------------------------------------------------------ K-weighting + 100 ms block energies
+// f_ebur128.c FILTER macro (direct form I, double): pre-filter shelf then RLB high-pass; bin = z^2 summed
+// per 100 ms block; per-block max|x| for the sample peak.  Each lane owns `bpl` whole blocks.
+template <typename TIn>
+__global__ void __launch_bounds__(64)
+k_kweight_blocks(const TIn *__restrict__ in, int64_t n, int blk, int bpl, int64_t halo, BiquadF64 pre, BiquadF64 rlb,
+                 double *__restrict__ block_sums, double *__restrict__ block_peaks, int64_t nblocks_alloc, int64_t nchunks)
+{
+    __shared__ double tile[LANES][TW + 1];
+    const int lane = threadIdx.x;
+    const int64_t chunk = (int64_t)blk * bpl;
+    const int64_t c0 = (int64_t)blockIdx.x * LANES;
+    const int nrows = (int)min((int64_t)LANES, nchunks - c0);
+    const int64_t base0 = c0 * chunk - halo;
+    const int64_t my_base = base0 + (int64_t)lane * chunk;
+    const int64_t my_chunk = c0 + lane;
+    double x1 = 0, x2 = 0, y0 = 0, y1 = 0, y2 = 0, z0 = 0, z1 = 0, z2 = 0;
+    double acc = 0.0, pk = 0.0;
+    int cnt = 0; int64_t bidx = my_chunk * bpl;
+    const int64_t total = halo + chunk;
+    for (int64_t pos = 0; pos < total; pos += TW) {
+        tile_load<TIn, double>(tile, in, n, base0, chunk, pos, lane, nrows);
+        __syncthreads();
+        if (lane < nrows) {
+            for (int j = 0; j < TW; ++j) {
+                int64_t rel = pos + j;
+                int64_t idx = my_base + rel;
+                if (rel >= total || idx >= n) break;
+                if (idx < 0) continue;
+                double x0 = tile[lane][j];
+                y2 = y1; y1 = y0;
+                y0 = x0 * pre.b0 + x1 * pre.b1 + x2 * pre.b2 - y1 * pre.a1 - y2 * pre.a2;
+                x2 = x1; x1 = x0;
+                z2 = z1; z1 = z0;
+                z0 = y0 * rlb.b0 + y1 * rlb.b1 + y2 * rlb.b2 - z1 * rlb.a1 - z2 * rlb.a2;
+                if (rel >= halo) {
+                    acc += z0 * z0;
+                    pk = fmax(pk, fabs(x0));
+                    if (++cnt == blk) {
+                        if (bidx < nblocks_alloc) { block_sums[bidx] = acc; block_peaks[bidx] = pk; }
+                        acc = 0.0; pk = 0.0; cnt = 0; ++bidx;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+    if (lane < nrows && cnt > 0 && bidx < nblocks_alloc) { block_sums[bidx] = acc; block_peaks[bidx] = pk; }
+}
+
+static void kweight_geometry(int64_t n, int blk, int sr_hint, int *bpl, int64_t *halo, int64_t *nchunks)
+{
+    // RLB double pole at ~38 Hz: r ~ 1 - 2*pi*38/sr; n*r^n below 1e-13 needs ~8192 samples at 48 kHz
+    int64_t h = (int64_t)std::ceil(8192.0 * sr_hint / 48000.0);
+    h = (h + TW - 1) / TW * TW;
+    *halo = h;
+    int b = (int)std::max<int64_t>(2, (2 * h + blk - 1) / blk);
+    *bpl = b;
+    int64_t chunk = (int64_t)blk * b;
+    *nchunks = (n + chunk - 1) / chunk;
+}
+
+void launch_kweight_blocks_f32(const float *in, int64_t n, int blk, BiquadF64 pre, BiquadF64 rlb,
+                               double *block_sums, double *block_peaks, int64_t nblocks_alloc, hipStream_t s)
+{
+    if (n <= 0) return;
+    int bpl; int64_t halo, nchunks;
+    kweight_geometry(n, blk, blk * 10, &bpl, &halo, &nchunks);
+    int grid = (int)((nchunks + LANES - 1) / LANES);
+    hipLaunchKernelGGL(k_kweight_blocks<float>, dim3(grid), dim3(LANES), 0, s, in, n, blk, bpl, halo, pre, rlb,
+                       block_sums, block_peaks, nblocks_alloc, nchunks);
+}
+void launch_kweight_blocks_f64(const double *in, int64_t n, int blk, BiquadF64 pre, BiquadF64 rlb,
+                               double *block_sums, double *block_peaks, int64_t nblocks_alloc, hipStream_t s)
+{
+    if (n <= 0) return;
+    int bpl; int64_t halo, nchunks;
+    kweight_geometry(n, blk, blk * 10, &bpl, &halo, &nchunks);
+    int grid = (int)((nchunks + LANES - 1) / LANES);
+    hipLaunchKernelGGL(k_kweight_blocks<double>, dim3(grid), dim3(LANES), 0, s, in, n, blk, bpl, halo, pre, rlb,
+                       block_sums, block_peaks, nblocks_alloc, nchunks);
+}
+
+// ------------------------------------------------------------------ agate -> acompressor -> deesser (double)
+__device__ inline double hermite_interp(double x, double x0, double x1, double p0, double p1, double m0, double m1)
+{
+    double width = x1 - x0;
+    double t = (x - x0) / width;
+    m0 *= width; m1 *= width;
+    double t2 = t * t, t3 = t2 * t;
+    double ct0 = p0, ct1 = m0;
+    double ct2 = -3 * p0 - 2 * m0 + 3 * p1 - m1;
+    double ct3 = 2 * p0 + m0 - 2 * p1 + m1;
+    return ct3 * t3 + ct2 * t2 + ct1 * t + ct0;
+}
+
+struct DynState {
+    double g_slope, c_slope;
+    double s1, s2, s3, ratioA, ratioB, iirA, iirB;
+};
+
+__device__ inline double dyn_step(DynState &st, double x, int64_t idx, const DynParams &p)
+{
+    double v = x;
+    if (p.gate_on) {   // af_agate.c gate(): detection=rms, mode=downward
+        double a = fabs(v); a *= a;
+        st.g_slope += (a - st.g_slope) * (a > st.g_slope ? p.g_attack : p.g_release);
+        double gain = 1.0;
+        if (st.g_slope > 0.0 && st.g_slope < p.g_lin_knee_stop) {
+            double slope = log(st.g_slope);
+            double tratio = (fabs(p.g_ratio - 4294967296.0) < 1.0) ? 1000. : p.g_ratio;
+            double g = (slope - p.g_thres) * tratio + p.g_thres;
+            if (p.g_knee > 1. && slope > p.g_knee_start)
+                g = hermite_interp(slope, p.g_knee_start, p.g_knee_stop,
+                                   ((p.g_knee_start - p.g_thres) * tratio + p.g_thres), p.g_knee_stop, tratio, 1.);
+            gain = fmax(p.g_range, exp(g - slope));
+        }
+        v = v * (1.0 * gain * p.g_makeup);
+    }
+    if (p.comp_on) {   // af_sidechaincompress.c compressor(): detection=rms, mode=downward
+        double a = fabs(v); a *= a;
+        st.c_slope += (a - st.c_slope) * (a > st.c_slope ? p.c_attack : p.c_release);
+        double gain = 1.0;
+        if (st.c_slope > 0.0 && st.c_slope > p.c_adj_knee_start) {
+            double slope = log(st.c_slope) * 0.5;
+            double g, delta;
+            if (fabs(p.c_ratio - 4294967296.0) < 1.0) { g = p.c_thres; delta = 0.0; }
+            else { g = (slope - p.c_thres) / p.c_ratio + p.c_thres; delta = 1.0 / p.c_ratio; }
+            if (p.c_knee > 1.0 && slope < p.c_knee_stop)
+                g = hermite_interp(slope, p.c_knee_start, p.c_knee_stop, p.c_knee_start, p.c_ckstop, 1.0, delta);
+            gain = exp(g - slope);
+        }
+        v = v * 1.0 * (gain * p.c_makeup * p.c_mix + (1. - p.c_mix));
+    }
+    if (p.deess_on) {  // af_deesser.c filter_frame()
+        double sample = v;
+        st.s3 = st.s2; st.s2 = st.s1; st.s1 = sample;
+        double m1 = (st.s1 - st.s2) * ((st.s1 - st.s2) / 1.3);
+        double m2 = (st.s2 - st.s3) * ((st.s1 - st.s2) / 1.3);
+        double sense = (m1 - m2) * ((m1 - m2) / 1.3);
+        double attackspeed = 7.0 + sense * 1024;
+        sense = 1.0 + p.d_intensity * p.d_intensity * sense;
+        sense = fmin(sense, p.d_intensity);
+        double recovery = 1.0 + (0.01 / sense);
+        double offset = 1.0 - fabs(sample);
+        if (idx & 1) {   // flip toggles every sample starting from 0: odd samples use the A state
+            st.iirA = (st.iirA * (1.0 - (offset * p.d_iir))) + (sample * (offset * p.d_iir));
+            if (st.ratioA < sense) st.ratioA = ((st.ratioA * attackspeed) + sense) / (attackspeed + 1.0);
+            else st.ratioA = 1.0 + ((st.ratioA - 1.0) / recovery);
+            st.ratioA = fmin(st.ratioA, p.d_maxdess);
+            sample = st.iirA + ((sample - st.iirA) / st.ratioA);
+        } else {
+            st.iirB = (st.iirB * (1.0 - (offset * p.d_iir))) + (sample * (offset * p.d_iir));
+            if (st.ratioB < sense) st.ratioB = ((st.ratioB * attackspeed) + sense) / (attackspeed + 1.0);
+            else st.ratioB = 1.0 + ((st.ratioB - 1.0) / recovery);
+            st.ratioB = fmin(st.ratioB, p.d_maxdess);
+            sample = st.iirB + ((sample - st.iirB) / st.ratioB);
+        }
+        v = sample;
+    }
+    return v;
+}
+
+__global__ void __launch_bounds__(64)
+k_dynamics(const float *__restrict__ in, float *__restrict__ out, int64_t n, int64_t chunk, int64_t halo,
+           DynParams p, int64_t nchunks)
+{
+    __shared__ float tile[LANES][TW + 1];
+    const int lane = threadIdx.x;
+    const int64_t c0 = (int64_t)blockIdx.x * LANES;
+    const int nrows = (int)min((int64_t)LANES, nchunks - c0);
+    const int64_t base0 = c0 * chunk - halo;
+    const int64_t my_base = base0 + (int64_t)lane * chunk;
+    DynState st; st.g_slope = 0; st.c_slope = 0; st.s1 = st.s2 = st.s3 = 0; st.ratioA = st.ratioB = 1.0; st.iirA = st.iirB = 0;
+    const int64_t total = halo + chunk;
+    for (int64_t pos = 0; pos < total; pos += TW) {
+        tile_load<float, float>(tile, in, n, base0, chunk, pos, lane, nrows);
+        __syncthreads();
+        if (lane < nrows) {
+            for (int j = 0; j < TW; ++j) {
+                int64_t idx = my_base + pos + j;
+                if (idx < 0 || idx >= n) continue;
+                double y = dyn_step(st, (double)tile[lane][j], idx, p);
+                tile[lane][j] = (float)y;
+            }
+        }
+        __syncthreads();
+        tile_store<float, float>(tile, out, n, base0, chunk, pos, lane, nrows, halo, chunk);
+        __syncthreads();
+    }
+}
+
+void launch_dynamics(const float *in, float *out_f32, double *out_f64, int64_t n, const DynParams &d, hipStream_t s)
+{
+    (void)out_f64;
+    if (n <= 0) return;
+    // warm-up: the slowest follower coefficient rho forgets as (1-rho)^k; 18 time constants ~ 1.5e-8
+    double rho = 1.0;
+    if (d.gate_on) rho = std::min(rho, std::min(d.g_attack, d.g_release));
+    if (d.comp_on) rho = std::min(rho, std::min(d.c_attack, d.c_release));
+    int64_t halo = 4096;
+    if (rho < 1.0 && rho > 0.0) halo = std::max<int64_t>(halo, (int64_t)std::ceil(18.0 / rho));
+    if (d.deess_on) halo = std::max<int64_t>(halo, 16384);
+    halo = (halo + TW - 1) / TW * TW;
+    int64_t chunk = std::max<int64_t>(8192, halo / 4);
+    chunk = (chunk + TW - 1) / TW * TW;
+    int64_t nchunks = (n + chunk - 1) / chunk;
+    int grid = (int)((nchunks + LANES - 1) / LANES);
+    hipLaunchKernelGGL(k_dynamics, dim3(grid), dim3(LANES), 0, s, in, out_f32, n, chunk, halo, d, nchunks);
+}
+
+// ------------------------------------------------------------------ astats
+// pass G: per tc-block suffix maxima of |x| (van Herk / Gil-Werman sliding max, first half)
+__global__ void k_suffix_absmax(const float *__restrict__ in, float *__restrict__ g, int64_t n, int w)
+{
+    int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    int64_t lo = b * w;
+    if (lo >= n) return;
+    int64_t hi = min(lo + (int64_t)w, n);
+    float m = 0.f;
+    for (int64_t i = hi - 1; i >= lo; --i) { m = fmaxf(m, fabsf(in[i])); g[i] = m; }
+}
+
+// pass A: everything except the exponentially averaged power extrema.  halo >= tc (sliding-max prefix, previous sample).
+__global__ void __launch_bounds__(64)
+k_astats_a(const float *__restrict__ in, const float *__restrict__ g, int64_t n, int tc, double mult,
+           int64_t chunk, int64_t halo, AstatsChunk *__restrict__ chunks, int64_t nchunks,
+           unsigned long long *__restrict__ ehist, double *__restrict__ zs_final)
+{
+    __shared__ float tile[LANES][TW + 1];
+    __shared__ unsigned int lh[8192];
+    const int lane = threadIdx.x;
+    for (int i = lane; i < 8192; i += LANES) lh[i] = 0;
+    const int64_t c0 = (int64_t)blockIdx.x * LANES;
+    const int nrows = (int)min((int64_t)LANES, nchunks - c0);
+    const int64_t base0 = c0 * chunk - halo;
+    const int64_t my_base = base0 + (int64_t)lane * chunk;
+    const int64_t my_lo = my_base + halo, my_hi = min(my_lo + chunk, n);
+    AstatsChunk a;
+    a.min = 1.7976931348623157e308; a.max = -1.7976931348623157e308; a.min_non_zero = 1.7976931348623157e308;
+    a.sigma_x = 0; a.sigma_x2 = 0; a.min_diff = 1.7976931348623157e308; a.max_diff = 0; a.diff1_sum = 0; a.diff1_sum_x2 = 0;
+    a.first = 0; a.last = 0; a.first_nz_sign = 0; a.last_nz_sign = 0; a.zero_runs = 0;
+    a.min_sigma = 1.7976931348623157e308; a.max_sigma = 0; a.noise_floor = 1.7976931348623157e308; a.noise_floor_count = 0;
+    a.abs_peak = 0; a.count = 0;
+    a.min_count = 0; a.min_runs = 0; a.min_head_run = 0; a.min_tail_run = 0; a.min_all = 0;
+    a.max_count = 0; a.max_runs = 0; a.max_head_run = 0; a.max_tail_run = 0; a.max_all = 0;
+    a.mask_or = 0; a.mask_and = ~0ull;
+    double prev = 0.0; bool have_prev = false;
+    float pmax = 0.f;                  // prefix max of |x| since the start of the current tc-block
+    double zs = 0.0;                   // zero-state response of avg_sigma_x2 over the chunk
+    // run tracking relative to the running chunk-local min / max
+    double min_run = 0, max_run = 0;   // current open run lengths at a.min / a.max
+    bool min_open_from_start = false, max_open_from_start = false;
+    __syncthreads();
+    const int64_t total = halo + chunk;
+    for (int64_t pos = 0; pos < total; pos += TW) {
+        tile_load<float, float>(tile, in, n, base0, chunk, pos, lane, nrows);
+        __syncthreads();
+        if (lane < nrows) {
+            for (int j = 0; j < TW; ++j) {
+                int64_t idx = my_base + pos + j;
+                if (idx < 0) continue;
+                if (idx >= my_hi) break;
+                float xf = tile[lane][j];
+                double d = (double)xf;
+                if (idx % tc == 0) pmax = 0.f;
+                pmax = fmaxf(pmax, fabsf(xf));
+                if (idx >= my_lo) {
+                    if (a.count == 0) a.first = d;
+                    // min / max with run bookkeeping (af_astats.c update_stat)
+                    if (d < a.min) { a.min = d; a.min_count = 1; a.min_runs = 0; min_run = 1; a.min_head_run = 0;
+                                     min_open_from_start = (a.count == 0); }
+                    else if (d == a.min) { a.min_count += 1; if (have_prev && prev == d && a.count > 0) min_run += 1;
+                                           else { min_run = 1; min_open_from_start = false; } }
+                    else if (a.count > 0 && prev == a.min) {
+                        if (min_open_from_start) { a.min_head_run = min_run; min_open_from_start = false; }
+                        else a.min_runs += min_run * min_run;
+                        min_run = 0;
+                    }
+                    if (d > a.max) { a.max = d; a.max_count = 1; a.max_runs = 0; max_run = 1; a.max_head_run = 0;
+                                     max_open_from_start = (a.count == 0); }
+                    else if (d == a.max) { a.max_count += 1; if (have_prev && prev == d && a.count > 0) max_run += 1;
+                                           else { max_run = 1; max_open_from_start = false; } }
+                    else if (a.count > 0 && prev == a.max) {
+                        if (max_open_from_start) { a.max_head_run = max_run; max_open_from_start = false; }
+                        else a.max_runs += max_run * max_run;
+                        max_run = 0;
+                    }
+                    double ad = fabs(d);
+                    a.abs_peak = fmax(a.abs_peak, ad);
+                    if (d != 0 && ad < a.min_non_zero) a.min_non_zero = ad;
+                    if (d != 0) {
+                        double sg = d > 0 ? 1.0 : -1.0;
+                        if (a.first_nz_sign == 0) a.first_nz_sign = sg;
+                        else if (sg != a.last_nz_sign) a.zero_runs += 1;
+                        a.last_nz_sign = sg;
+                    }
+                    a.sigma_x += d;
+                    a.sigma_x2 += d * d;
+                    zs = zs * mult + (1.0 - mult) * d * d;
+                    if (have_prev) {
+                        double df = fabs(d - prev);
+                        a.min_diff = fmin(a.min_diff, df);
+                        a.max_diff = fmax(a.max_diff, df);
+                        a.diff1_sum += df;
+                        a.diff1_sum_x2 += (d - prev) * (d - prev);
+                    }
+                    int hidx = (int)rint(fmin(fmax(ad, 0.0), 1.0) * 8191.0);
+                    hidx = hidx < 0 ? 0 : (hidx > 8191 ? 8191 : hidx);
+                    atomicAdd(&lh[hidx], 1u);
+                    // sliding local peak over the last tc samples, valid once idx >= tc-1
+                    if (idx >= tc - 1) {
+                        int64_t jj = idx - tc + 1;
+                        float wmax = (jj % tc == 0) ? g[jj] : fmaxf(g[jj], pmax);
+                        double lp = (double)wmax;
+                        if (lp < a.noise_floor) { a.noise_floor = lp; a.noise_floor_count = 1; }
+                        else if (lp == a.noise_floor) a.noise_floor_count += 1;
+                    }
+                    long long iv = (long long)llrint(d * 2147483648.0);
+                    a.mask_or |= (unsigned long long)iv; a.mask_and &= (unsigned long long)iv;
+                    a.last = d;
+                    a.count++;
+                }
+                prev = d; have_prev = true;
+            }
+        }
+        __syncthreads();
+    }
+    if (lane < nrows) {
+        // close runs touching the chunk end: record as tail runs for host stitching
+        if (a.count > 0 && a.last == a.min) {
+            if (min_open_from_start) { a.min_all = 1; a.min_head_run = min_run; a.min_tail_run = min_run; }
+            else a.min_tail_run = min_run;
+        }
+        if (a.count > 0 && a.last == a.max) {
+            if (max_open_from_start) { a.max_all = 1; a.max_head_run = max_run; a.max_tail_run = max_run; }
+            else a.max_tail_run = max_run;
+        }
+        chunks[c0 + lane] = a;
+        zs_final[c0 + lane] = zs;
+    }
+    __syncthreads();
+    for (int i = lane; i < 8192; i += LANES) if (lh[i]) atomicAdd(&ehist[i], (unsigned long long)lh[i]);
+}
+
+// carry scan: s_c = s_{c-1} * mult^chunk + e_{c-1}   (exact linear recurrence across chunk boundaries)
+__global__ void k_astats_scan(const double *__restrict__ zs_final, double *__restrict__ carry, int64_t nchunks, double mult_chunk)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    double s = 0.0;
+    for (int64_t c = 0; c < nchunks; ++c) { carry[c] = s; s = s * mult_chunk + zs_final[c]; }
+}
+
+// pass B: avg_sigma_x2 with the exact carried-in state; extrema over samples with index >= tc
+__global__ void __launch_bounds__(64)
+k_astats_b(const float *__restrict__ in, int64_t n, int tc, double mult, int64_t chunk,
+           const double *__restrict__ carry, AstatsChunk *__restrict__ chunks, int64_t nchunks)
+{
+    __shared__ float tile[LANES][TW + 1];
+    const int lane = threadIdx.x;
+    const int64_t c0 = (int64_t)blockIdx.x * LANES;
+    const int nrows = (int)min((int64_t)LANES, nchunks - c0);
+    const int64_t base0 = c0 * chunk;
+    const int64_t my_base = base0 + (int64_t)lane * chunk;
+    double avg = lane < nrows ? carry[c0 + lane] : 0.0;
+    double mn = 1.7976931348623157e308, mx = 0.0;
+    for (int64_t pos = 0; pos < chunk; pos += TW) {
+        tile_load<float, float>(tile, in, n, base0, chunk, pos, lane, nrows);
+        __syncthreads();
+        if (lane < nrows) {
+            for (int j = 0; j < TW; ++j) {
+                int64_t idx = my_base + pos + j;
+                if (idx >= n || pos + j >= chunk) break;
+                double d = (double)tile[lane][j];
+                avg = avg * mult + (1.0 - mult) * d * d;
+                if (idx >= tc) { mx = fmax(mx, avg); mn = fmin(mn, avg); }
+            }
+        }
+        __syncthreads();
+    }
+    if (lane < nrows) { chunks[c0 + lane].min_sigma = mn; chunks[c0 + lane].max_sigma = mx; }
+}
+
+// The full astats sequence needs scratch (suffix maxima, carries); jt_api.cpp drives it through this entry.
+void jt_astats_run(const float *in, int64_t n, int sr, float *g_scratch /*n*/, double *zs /*nchunks*/, double *carry /*nchunks*/,
+                   AstatsChunk *chunks, int64_t chunk, int64_t nchunks, unsigned long long *ehist, hipStream_t s)
+{
+    const double time_constant = 0.05;
+    const double mult = std::exp((-1 / time_constant / sr));
+    const int tc = (int)std::max(time_constant * sr + .5, 1.0);
+    int64_t halo = ((int64_t)tc + TW) / TW * TW;
+    int64_t nb = (n + tc - 1) / tc;
+    hipLaunchKernelGGL(k_suffix_absmax, dim3((unsigned)((nb + 63) / 64)), dim3(64), 0, s, in, g_scratch, n, tc);
+    int grid = (int)((nchunks + LANES - 1) / LANES);
+    hipLaunchKernelGGL(k_astats_a, dim3(grid), dim3(LANES), 0, s, in, g_scratch, n, tc, mult, chunk, halo, chunks, nchunks, ehist, zs);
+    hipLaunchKernelGGL(k_astats_scan, dim3(1), dim3(1), 0, s, zs, carry, nchunks, std::pow(mult, (double)chunk));
+    hipLaunchKernelGGL(k_astats_b, dim3(grid), dim3(LANES), 0, s, in, n, tc, mult, chunk, carry, chunks, nchunks);
+}
+
+// ------------------------------------------------------------------ look-ahead limiter (af_alimiter.c)
+__global__ void k_absmax_blocks_f64(const double *__restrict__ in, int64_t n, int blk, double *__restrict__ out_max, int64_t nblk)
+{
+    int64_t b = blockIdx.x;
+    if (b >= nblk) return;
+    int64_t lo = b * blk, hi = min(lo + (int64_t)blk, n);
+    double m = 0.0;
+    for (int64_t i = lo + threadIdx.x; i < hi; i += blockDim.x) m = fmax(m, fabs(in[i]));
+    for (int off = 32; off > 0; off >>= 1) m = fmax(m, __shfl_down(m, off, 64));
+    __shared__ double sm[4];
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) { double r = 0; for (int k = 0; k < (int)(blockDim.x >> 6); ++k) r = fmax(r, sm[k]); out_max[b] = r; }
+}
+void launch_absmax_blocks_f64(const double *in, int64_t n, int blk, double *out_max, int64_t nblk, hipStream_t s)
+{
+    if (nblk <= 0) return;
+    hipLaunchKernelGGL(k_absmax_blocks_f64, dim3((unsigned)nblk), dim3(256), 0, s, in, n, blk, out_max, nblk);
+}
+
+// One lane per segment [bounds[c], bounds[c+1]); every segment starts at a provably clean limiter state
+// (att = 1, delta = 0, empty peak list), so the sequential FFmpeg state machine is reproduced exactly.
+// The ring buffer of af_alimiter.c is replaced by absolute sample indices: buffer[pos'] of the ring that
+// holds sample a is in[a]; nextpos[] stores absolute indices; ring distances become index differences.
+__global__ void __launch_bounds__(64)
+k_limiter_f64(const double *__restrict__ in, double *__restrict__ out, int64_t n, int sr, double limit, int B,
+              double release, double asc_coeff, const int64_t *__restrict__ bounds, int nlanes, double in_gain,
+              double *__restrict__ sdelta, int64_t *__restrict__ spos)
+{
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= nlanes) return;
+    const int64_t lo = bounds[c], hi = bounds[c + 1];
+    double *nextdelta = sdelta + (size_t)c * B;
+    int64_t *nextpos = spos + (size_t)c * B;
+    for (int k = 0; k < B; ++k) nextpos[k] = -1;
+    double att = 1.0, delta = 0.0, asc = 0.0; int asc_c = 0;
+    int nextiter = 0, nextlen = 0;
+    // iterations i = lo .. hi + B - 2: iteration i pushes in[i] (zero past the end) and emits sample i-(B-1)
+    const int64_t it_end = hi + B - 1;
+    for (int64_t i = lo; i < it_end; ++i) {
+        double x = i < n ? in[i] * in_gain : 0.0;
+        double peak = fabs(x);
+        if (peak > limit) { asc += peak; asc_c++; }
+        if (peak > limit) {
+            double patt = fmin(limit / peak, 1.);
+            double rdelta = (1.0 - patt) / (sr * release);
+            double dl = (limit / peak - att) / B * 1;
+            bool found = false;
+            if (dl < delta) {
+                delta = dl;
+                nextpos[0] = i; nextpos[1 % B] = -1; nextdelta[0] = rdelta;
+                nextlen = 1; nextiter = 0;
+            } else {
+                int k;
+                for (k = nextiter; k < nextiter + nextlen; k++) {
+                    int j = k % B;
+                    double ppeak = fabs(in[nextpos[j]] * in_gain);
+                    double pdelta = (limit / peak - limit / ppeak) / (double)((i - nextpos[j]) / 1);
+                    if (pdelta < nextdelta[j]) { nextdelta[j] = pdelta; found = true; break; }
+                }
+                if (found) {
+                    nextlen = k - nextiter + 1;
+                    nextpos[(nextiter + nextlen) % B] = i;
+                    nextdelta[(nextiter + nextlen) % B] = rdelta;
+                    nextpos[(nextiter + nextlen + 1) % B] = -1;
+                    nextlen++;
+                }
+            }
+        }
+        const int64_t eidx = i - (B - 1);            // sample leaving the look-ahead buffer
+        double bufv = (eidx >= 0 && eidx < n) ? in[eidx] * in_gain : 0.0;
+        if (B == 1) bufv = x;
+        peak = fabs(bufv);
+        if (peak > limit) { asc -= peak; asc_c--; }  // asc_pos == -1 always (never armed in af_alimiter.c)
+        att += delta;
+        double o = bufv * att;
+        if (nextpos[nextiter] == eidx && eidx >= 0) {
+            // auto_release (asc=1): get_rdelta(..., asc=1)
+            double rd = (1.0 - att) / (sr * release);
+            if (asc_c > 0) {
+                double a_att = limit / (asc_coeff * asc) * (double)asc_c;
+                if (a_att > att) {
+                    double d2 = fmax((a_att - att) / (sr * release), rd / 10);
+                    if (d2 < rd) rd = d2;
+                }
+            }
+            delta = rd;
+            if (nextlen > 1) {
+                int64_t pnext = nextpos[(nextiter + 1) % B];
+                double ppeak = fabs(in[pnext] * in_gain);
+                double pdelta = (limit / ppeak - att) / (double)(pnext - eidx);
+                if (pdelta < delta) delta = pdelta;
+            }
+            nextlen -= 1;
+            nextpos[nextiter] = -1;
+            nextiter = (nextiter + 1) % B;
+        }
+        if (att > 1.) { att = 1.; delta = 0.; nextiter = 0; nextlen = 0; nextpos[0] = -1; }
+        if (att <= 0.) { att = 0.0000000000001; delta = (1.0 - att) / (sr * release); }
+        if (att != 1. && (1. - att) < 0.0000000000001) att = 1.;
+        if (delta != 0. && fabs(delta) < 0.00000000000001) delta = 0.;
+        o = fmin(fmax(o, -limit), limit);
+        if (eidx >= lo && eidx < hi) out[eidx] = o;
+    }
+}
+
+void launch_limiter_f64(const double *in, double *out, int64_t n, int sr, double limit, int buffer_size,
+                        double release_s, double asc_coeff, const int64_t *bounds, int nlanes, double in_gain,
+                        double *scratch_delta, int64_t *scratch_pos, hipStream_t s)
+{
+    if (nlanes <= 0) return;
+    int grid = (nlanes + 63) / 64;
+    hipLaunchKernelGGL(k_limiter_f64, dim3(grid), dim3(64), 0, s, in, out, n, sr, limit, buffer_size, release_s, asc_coeff,
+                       bounds, nlanes, in_gain, scratch_delta, scratch_pos);
+}
+
+// ------------------------------------------------------------------ biquad pair, direct form I (f32)
+// Band-RMS region graphs (analyser_bands.go:33): "highpass=f=%f:p=2,lowpass=f=%f:p=2" use the default transform
+// (di), float state on flt input: out = i2*b2 + i1*b1 + in*b0 + o2*a2 + o1*a1 (a already negated).
+__global__ void __launch_bounds__(64)
+k_biquad_di_f32(const float *__restrict__ in, float *__restrict__ out, int64_t n, int64_t chunk, int64_t halo,
+                BiquadF32 hp, BiquadF32 lp, int64_t nchunks)
+{
+    int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= nchunks) return;
+    int64_t lo = c * chunk, hi = min(lo + chunk, n);
+    int64_t s0 = max((int64_t)0, lo - halo);
+    float i1 = 0, i2 = 0, o1 = 0, o2 = 0, j1 = 0, j2 = 0, p1 = 0, p2 = 0;
+    for (int64_t k = s0; k < hi; ++k) {
+        float x = in[k];
+        float y = __fadd_rn(__fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(i2, hp.b2), __fmul_rn(i1, hp.b1)), __fmul_rn(x, hp.b0)),
+                                      __fmul_rn(o2, hp.a2)), __fmul_rn(o1, hp.a1));
+        i2 = i1; i1 = x; o2 = o1; o1 = y;
+        float z = __fadd_rn(__fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(j2, lp.b2), __fmul_rn(j1, lp.b1)), __fmul_rn(y, lp.b0)),
+                                      __fmul_rn(p2, lp.a2)), __fmul_rn(p1, lp.a1));
+        j2 = j1; j1 = y; p2 = p1; p1 = z;
+        if (k >= lo) out[k] = z;
+    }
+}
+void launch_biquad_di_f32(const float *in, float *out, int64_t n, BiquadF32 hp, BiquadF32 lp, hipStream_t s)
+{
+    if (n <= 0) return;
+    double rmax = std::max(std::sqrt(std::fabs((double)hp.a2)), std::sqrt(std::fabs((double)lp.a2)));
+    int64_t halo = 512;
+    if (rmax > 0.0 && rmax < 1.0) halo = std::max<int64_t>(512, (int64_t)std::ceil(std::log(1e-10) / std::log(rmax)));
+    halo = std::min<int64_t>(halo, 1 << 20);
+    int64_t chunk = std::max<int64_t>(1024, halo / 2);
+    int64_t nchunks = (n + chunk - 1) / chunk;
+    hipLaunchKernelGGL(k_biquad_di_f32, dim3((unsigned)((nchunks + 63) / 64)), dim3(64), 0, s, in, out, n, chunk, halo, hp, lp, nchunks);
+}

@@ -1,0 +1,252 @@
+"""Parity tests proper: every HIP kernel on the path, called through the C ABI, against the CPU oracle on the same
+seeded inputs.  Integer/index results bit-exact; floating point within the tolerance written next to each check
+(north_star: ±0.1 LU on LUFS/LRA/dBTP plus a stated per-sample float tolerance)."""
+import numpy as np
+import pytest
+
+from jivetalking_amd import synth, _lib as L
+from jivetalking_amd.engine import default_filter_params
+
+pytestmark = pytest.mark.gpu
+
+SR = 48000
+
+
+def speech(seconds=8.0, seed=1, sr=SR):
+    return synth.speech_like(seconds, sr, seed=seed)
+
+
+def noise(n, amp, seed=0):
+    return (np.random.default_rng(seed).standard_normal(n) * amp).astype(np.float32)
+
+
+# ---------------------------------------------------------------- biquads
+def test_biquad_hp_lp_matches_oracle(engine, oracle):
+    x = speech(6.0, 2)
+    ref = oracle.biquad_f32(oracle.biquad_f32(x, 0, 80.0, SR), 1, 20500.0, SR)
+    got = engine.op_biquad(x, SR)
+    # f32 TDII recurrence, chunked with a warm-up halo: per-sample tolerance 2e-6 abs (signal peak ~0.2)
+    assert np.max(np.abs(got - ref)) < 2e-6
+    # first chunk has no halo: must be bit-identical to the sequential recurrence
+    assert np.array_equal(got[:4096], ref[:4096])
+
+
+def test_biquad_edge_sizes(engine, oracle):
+    for n in (1, 63, 64, 65, 4097, 12345):
+        x = noise(n, 0.1, n)
+        ref = oracle.biquad_f32(oracle.biquad_f32(x, 0, 80.0, SR), 1, 20500.0, SR)
+        got = engine.op_biquad(x, SR)
+        assert got.shape == ref.shape and np.max(np.abs(got - ref)) < 2e-6
+
+
+# ---------------------------------------------------------------- anlmdn
+def test_anlmdn_matches_oracle_quiet_noise(engine, oracle):
+    # room-tone level input: most patch distances fall under the m=3 cut-off, so weights are active
+    x = noise(SR * 2, 10 ** (-66 / 20), 3)
+    ref = oracle.anlmdn(x, SR)
+    got = engine.op_anlmdn(x, SR)
+    assert np.max(np.abs(ref - x)) > 1e-6           # the filter actually did something
+    # identical f32 operation order; only expf may differ by 1 ulp between libm and the GPU: 1e-7 rel to signal
+    assert np.max(np.abs(got - ref)) < 1e-8
+
+
+def test_anlmdn_speech_and_edges(engine, oracle):
+    x = speech(3.0, 4)
+    ref = oracle.anlmdn(x, SR)
+    got = engine.op_anlmdn(x, SR)
+    assert np.max(np.abs(got - ref)) < 1e-7
+    for n in (1, 500, 577, 578, 1345):
+        y = noise(n, 1e-3, n)
+        assert np.max(np.abs(engine.op_anlmdn(y, SR) - oracle.anlmdn(y, SR))) < 1e-7
+
+
+# ---------------------------------------------------------------- afftdn
+def test_afftdn_matches_oracle(engine, oracle):
+    x = speech(10.0, 5)
+    ref = oracle.afftdn(x, SR, 12.0, -55.0)
+    got = engine.op_afftdn(x, SR, 12.0, -55.0)
+    err = np.max(np.abs(got - ref))
+    # f32 FFT with a different butterfly schedule + chunked frame recurrence (96 warm-up frames):
+    # per-sample tolerance 2e-5 abs (~ -94 dBFS) on a -30 dBFS programme
+    assert err < 2e-5, err
+    assert np.sqrt(np.mean((got - ref) ** 2)) < 2e-6
+
+
+def test_afftdn_custom_profile(engine, oracle):
+    x = speech(5.0, 6) + noise(SR * 5, 10 ** (-50 / 20), 9)
+    bn = np.array([6, 5, 4, 3, 2, 1, 0, -1, -2, -3, -4, -5, -6, -6, -6], np.float64)
+    ref = oracle.afftdn(x, SR, 12.0, -48.0, bn)
+    got = engine.op_afftdn(x, SR, 12.0, -48.0, bn)
+    assert np.max(np.abs(got - ref)) < 2e-5
+
+
+# ---------------------------------------------------------------- dynamics chain
+def _dyn_oracle(oracle, x, p, sr=SR):
+    y = x.astype(np.float64)
+    if p.gate_enabled:
+        y = oracle.agate(y, sr, p.gate_threshold, p.gate_ratio, p.gate_attack_ms, p.gate_release_ms, p.gate_range, p.gate_knee, p.gate_makeup)
+    if p.comp_enabled:
+        y = oracle.acompressor(y, sr, p.comp_threshold, p.comp_ratio, p.comp_attack_ms, p.comp_release_ms, p.comp_makeup, p.comp_knee, p.comp_mix)
+    if p.deess_enabled and p.deess_i > 0:
+        y = oracle.deesser(y, sr, p.deess_i, p.deess_m, p.deess_f)
+    return y.astype(np.float32)
+
+
+def test_dynamics_gate_comp_matches_oracle(engine, oracle):
+    x = speech(12.0, 7) * 4.0       # loud enough to drive the compressor above its knee
+    p = default_filter_params(gate_threshold=0.01, comp_threshold=0.125893)
+    ref = _dyn_oracle(oracle, x, p)
+    got = engine.op_dynamics(x, SR, p)
+    assert np.max(np.abs(ref - x)) > 1e-3           # gate/compressor engaged
+    # double-precision followers restarted per chunk after 18 time constants of warm-up: 1e-6 abs per sample
+    assert np.max(np.abs(got - ref)) < 1e-6
+
+
+def test_dynamics_with_deesser(engine, oracle):
+    x = speech(8.0, 8) * 3.0
+    p = default_filter_params(deess_enabled=1, deess_i=0.60)
+    ref = _dyn_oracle(oracle, x, p)
+    got = engine.op_dynamics(x, SR, p)
+    assert np.max(np.abs(got - ref)) < 2e-6
+
+
+# ---------------------------------------------------------------- limiter (bit-exact: same state machine, clean-point chunks)
+@pytest.mark.parametrize("attack,release,limit", [(5.0, 100.0, 0.25), (1.0, 50.0, 0.803526), (5.0, 100.0, 0.0631)])
+def test_alimiter_bit_exact(engine, oracle, attack, release, limit):
+    x = (speech(20.0, 9, 44100).astype(np.float64) * 5.0)
+    ref = oracle.alimiter(x, 44100, limit, attack, release)
+    got = engine.op_alimiter(x, 44100, limit, attack, release)
+    assert np.max(np.abs(ref)) <= limit + 1e-12
+    assert np.array_equal(got, ref)
+
+
+def test_alimiter_never_triggered_is_identity(engine, oracle):
+    x = speech(3.0, 10, 44100).astype(np.float64) * 0.5
+    got = engine.op_alimiter(x, 44100, 0.9, 5.0, 100.0)
+    assert np.array_equal(got, oracle.alimiter(x, 44100, 0.9, 5.0, 100.0))
+    assert np.array_equal(got, x)
+
+
+# ---------------------------------------------------------------- resampler + s16
+def test_resample_48k_to_44k1_s16_matches_oracle(engine, oracle):
+    x = speech(5.0, 11)
+    ref = oracle.f64_to_s16(oracle.swr_f64(x.astype(np.float64), 48000, 44100, True))
+    got = engine.op_resample_s16(x, 48000, 44100)
+    assert got.size == ref.size == int(np.ceil(x.size * 147 / 160))
+    # same taps, same summation order in double: integer output must agree except exact .5 rounding ties
+    assert np.max(np.abs(got.astype(np.int32) - ref.astype(np.int32))) <= 1
+    assert np.mean(got != ref) < 1e-4
+
+
+def test_resample_ragged_lengths(engine, oracle):
+    for n in (37, 160, 161, 1000, 4801):
+        x = noise(n, 0.2, n)
+        ref = oracle.f64_to_s16(oracle.swr_f64(x.astype(np.float64), 48000, 44100, True))
+        got = engine.op_resample_s16(x, 48000, 44100)
+        assert got.size == ref.size
+        assert np.max(np.abs(got.astype(np.int32) - ref.astype(np.int32))) <= 1
+
+
+# ---------------------------------------------------------------- ebur128 / true peak
+def test_ebur128_matches_oracle(engine, oracle):
+    x = speech(30.0, 12)
+    ref = oracle.ebur128(x.astype(np.float64), SR, True, True)
+    got = engine.op_ebur128(x, SR, True)
+    assert got["M"].size == ref["M"].size
+    # tolerance: 1e-6 LU on every momentary / short-term value, 0.001 LU on I/LRA (0.01 LU histogram bins)
+    assert np.max(np.abs(got["M"] - ref["M"])) < 1e-6
+    assert np.max(np.abs(got["S"] - ref["S"])) < 1e-6
+    assert abs(got["integrated"] - ref["integrated"]) < 1e-3
+    assert abs(got["lra"] - ref["lra"]) < 0.011
+    assert np.max(np.abs(got["SP"] - ref["SP"])) == 0.0
+    assert np.max(np.abs(got["TP"] - ref["TP"])) < 1e-12
+    assert abs(got["true_peak"] - ref["true_peak"]) < 1e-12
+
+
+def test_ebur128_kat_997hz(engine):
+    # EBU Tech 3341 case 1 analogue: 997 Hz sine at -23 dBFS, dual-mono => -23.0 +/- 0.1 LUFS
+    t = np.arange(SR * 20) / SR
+    x = (10 ** (-23 / 20) * np.sin(2 * np.pi * 997 * t)).astype(np.float32)
+    got = engine.op_ebur128(x, SR, True)
+    assert abs(got["integrated"] + 23.0) < 0.1
+    assert abs(20 * np.log10(got["true_peak"]) + 23.0) < 0.1
+
+
+def test_true_peak_intersample(engine):
+    n = np.arange(SR * 2)
+    env = np.minimum(1, n / 2000.) * np.minimum(1, (n[-1] - n) / 2000.)
+    x = (0.5 * np.sin(2 * np.pi * (SR / 4) * n / SR + np.pi / 4) * env).astype(np.float32)
+    got = engine.op_ebur128(x, SR, True)
+    assert abs(20 * np.log10(got["true_peak"]) + 6.02) < 0.05      # +3.01 dB over the sample peak
+    assert abs(20 * np.log10(got["sample_peak"]) + 9.03) < 0.05
+
+
+# ---------------------------------------------------------------- astats
+def test_astats_matches_oracle(engine, oracle):
+    x = speech(20.0, 13)
+    x[1000:1100] = 0.0
+    ref = oracle.astats(x.astype(np.float64), SR)
+    got = engine.op_astats(x, SR)
+    exact = ["min_level", "max_level", "min_difference", "max_difference", "peak_count", "noise_floor_count",
+             "zero_crossings", "number_of_samples"]
+    names = {"peak_level": "peak_level_db", "rms_level": "rms_level_db", "rms_peak": "rms_peak_db",
+             "rms_trough": "rms_trough_db", "noise_floor": "noise_floor_db"}
+    for k in exact:
+        assert got[k] == ref[k], (k, got[k], ref[k])
+    for k in ["dc_offset", "mean_difference", "rms_difference", "peak_level", "rms_level", "rms_peak", "rms_trough",
+              "crest_factor", "flat_factor", "noise_floor", "entropy", "dynamic_range", "zero_crossings_rate"]:
+        r = ref[names.get(k, k)]
+        assert abs(got[k] - r) <= 1e-9 * max(1.0, abs(r)), (k, got[k], r)
+
+
+def test_astats_clipped_runs(engine, oracle):
+    x = np.clip(speech(4.0, 14) * 20.0, -0.5, 0.5).astype(np.float32)   # flat tops: min/max runs across chunks
+    ref = oracle.astats(x.astype(np.float64), SR)
+    got = engine.op_astats(x, SR)
+    assert got["peak_count"] == ref["peak_count"]
+    assert abs(got["flat_factor"] - ref["flat_factor"]) < 1e-9
+
+
+# ---------------------------------------------------------------- aspectralstats
+def test_aspectralstats_matches_oracle(engine, oracle):
+    x = speech(6.0, 15)
+    ref = oracle.aspectralstats(x, SR)
+    got = engine.op_aspectralstats(x, SR)
+    assert got.shape == ref.shape
+    keys = L.SPECTRAL_KEYS
+    for j, k in enumerate(keys):
+        if k == "rolloff":
+            assert np.max(np.abs(got[:, j] - ref[:, j])) <= SR / 2 / 1024 + 1e-3      # at most one bin
+            assert np.mean(got[:, j] != ref[:, j]) < 0.02
+        else:
+            # f32 sums over 1024 bins in a different association order: 2e-4 relative
+            scale = np.maximum(np.abs(ref[:, j]), 1e-6 * np.max(np.abs(ref[:, j])) + 1e-30)
+            assert np.max(np.abs(got[:, j] - ref[:, j]) / scale) < 2e-4, k
+
+
+# ---------------------------------------------------------------- loudnorm measurement (Pass 3)
+def test_loudnorm_measure_no_prefix(engine, oracle):
+    x = speech(25.0, 16, 44100) * 2.0
+    s16 = np.clip(np.round(x * 32768), -32768, 32767).astype(np.int16)
+    xf = (s16.astype(np.float32) / 32768.0)
+    up = oracle.swr_f32(xf, 44100, 192000, True).astype(np.float64)
+    ref = oracle.loudnorm_measure(up, 192000, True)
+    got = engine.op_loudnorm_measure_s16(s16, 44100)
+    # north_star tolerance ±0.1 LU; observed differences are histogram-bin level (0.1 LU bins in libebur128)
+    assert abs(got["input_i"] - ref["input_i"]) < 0.005
+    assert abs(got["input_lra"] - ref["input_lra"]) < 0.101
+    assert abs(got["input_thresh"] - ref["input_thresh"]) < 0.005
+    assert abs(got["input_tp"] - ref["input_tp"]) < 1e-4
+
+
+def test_loudnorm_measure_with_limiter_prefix(engine, oracle):
+    x = speech(25.0, 17, 44100) * 4.0
+    s16 = np.clip(np.round(x * 32768), -32768, 32767).astype(np.int16)
+    lim = L.LimiterPlan(1, 0.0, 0.251189)
+    xd = s16.astype(np.float64) / 32768.0
+    y = oracle.alimiter(xd, 44100, 0.251189, 5.0, 100.0)
+    up = oracle.swr_f64(y, 44100, 192000, True)
+    ref = oracle.loudnorm_measure(up, 192000, True)
+    got = engine.op_loudnorm_measure_s16(s16, 44100, lim)
+    assert abs(got["input_i"] - ref["input_i"]) < 0.005
+    assert abs(got["input_tp"] - ref["input_tp"]) < 1e-6
