@@ -1,0 +1,177 @@
+/*
+ * jt_host.h — host-side mirror of the reference's per-file control logic for the four-pass path, as a C ABI
+ * (same shared library, libjtgpu.so).  The reference keeps this logic in Go (internal/processor); Go is not
+ * available in the build image, so it is restated in C++ (jivetalking_amd/csrc/jt_host.cpp) with the same
+ * names, argument meaning and results, and exported here so the cgo shim / tests can call each step.
+ *
+ *   interval construction ........ collectAnalysisFrames + intervalAccumulator   (analyser.go:538-650, analyser_metrics.go:165-428)
+ *   noise-floor seed ............. estimateNoiseFloorAndThreshold                 (analyser_noise_seed.go:78-241)
+ *   voice-activity detection ..... detectVoiceActivity and helpers                (analyser_vad.go:108-813)
+ *   speech election .............. findBestSpeechRegion, scoring, refinement      (analyser_candidates_{shared,speech}.go)
+ *   adaptive tuning .............. AdaptConfig                                    (adaptive*.go)
+ *   filter-spec strings .......... BuildFilterSpec and builders                   (filters.go:607-998)
+ *   limiter / loudnorm planning .. planLimiterForLoudnorm, calculateLinearModeTarget, buildLoudnormFilterSpec (normalise.go)
+ *   orchestration ................ ProcessAudio / AnalyseOnlyDetailed            (processor.go:29-216)
+ */
+#ifndef JT_HOST_H
+#define JT_HOST_H
+#include "jtgpu.h"
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- IntervalSample (analyser_metrics.go:17-32); times are Go time.Duration nanoseconds ---- */
+typedef struct {
+    int64_t     timestamp_ns;
+    double      rms_level, peak_level;
+    jt_spectral spectral;
+    int         spectral_found;
+    double      momentary_lufs, shortterm_lufs, true_peak, sample_peak;
+} jt_interval;
+
+/* Build the 250 ms interval stream exactly as collectAnalysisFrames does from decoder frames and the 100 ms
+ * output frames.  meta entries whose momentary is NaN carry no r128 keys (trailing partial frame).
+ * quantize != 0 applies FFmpeg's metadata print formats (ebur128 "%.3f", aspectralstats "%g") before use.
+ * Returns the number of intervals written (<= cap). */
+int64_t jt_host_build_intervals(int sample_rate, int64_t n_samples, int frame_samples, int channels,
+                                const double *frame_sumsq, const double *frame_peak, int64_t n_frames,
+                                const jt_frame_meta *meta, int64_t n_meta, int quantize,
+                                jt_interval *out, int64_t cap);
+
+/* ---- regions / profiles (analyser.go:25-135) ---- */
+typedef struct { int64_t start_ns, end_ns, duration_ns; } jt_region;
+
+typedef struct {
+    double rms_level, peak_level, crest_factor;
+    jt_spectral spectral;
+    double momentary_lufs, shortterm_lufs, true_peak, sample_peak;
+} jt_region_metrics;                           /* RegionSample */
+
+typedef struct {
+    int64_t start_ns, duration_ns;
+    double  measured_noise_floor, peak_level, crest_factor, entropy;
+    jt_spectral spectral;
+    double  band_noise[15]; int band_noise_n; int bands_measured;
+    int     warning;                           /* 0 none, 1 short region, 2 long region */
+} jt_noise_profile;
+
+typedef struct {
+    jt_region region;
+    jt_region_metrics sample;
+    double voicing_density;
+    double body_band_rms, sib_band_rms; int bands_measured;
+    double score;
+    int64_t original_start_ns, original_duration_ns; int was_refined;
+} jt_speech_candidate;
+
+#define JT_MAX_REGIONS 512
+typedef struct {
+    /* Loudness (InputLoudnessMetrics) */
+    double input_i, input_tp, input_lra, input_thresh, target_offset, momentary, shortterm, sample_peak;
+    /* Dynamics (astats with the Go-side conversions: crest in dB, min/max level in dBFS) + Noise.FloorAstats */
+    jt_astats dynamics; double floor_astats;
+    jt_spectral spectral;
+    /* Noise */
+    double floor; int floor_source;            /* 0 astats, 1 rms_estimate, 2 ebur128_estimate, 3 vad_percentile */
+    double floor_prescan, room_tone_detect_level; int voice_activated; double floored_fraction, reduction_headroom;
+    /* Regions */
+    int n_speech_regions; jt_region speech_regions[JT_MAX_REGIONS];
+    int n_candidates;     jt_speech_candidate candidates[JT_MAX_REGIONS];
+    int has_speech_profile; jt_speech_candidate speech_profile;
+    int has_noise_profile;  jt_noise_profile noise_profile;
+    int has_room_tone_sample; jt_region_metrics room_tone_sample;
+    double voiced_low_percentile, noise_high_percentile, gate_separation_db;
+    double duration_s;
+    /* diagnostics of the detector itself */
+    double vad_split, vad_margin; int vad_gap_tol;
+} jt_measurements;
+
+/* buildInputMeasurements + detectVoiceActivity (analyser.go:364-406, analyser_vad.go:728-783) from the Pass-1
+ * whole-file analysis (already Go-converted by this call: crest -> dB, levels -> dBFS, peaks -> dB) and intervals. */
+int jt_host_detect(const jt_analysis *pass1, const jt_interval *intervals, int64_t n_intervals,
+                   double duration_s, double target_i, int quantize, jt_measurements *out);
+/* assignInputMeasurementSuggestions (analyser.go:513-528), after the band measurements */
+void jt_host_finish_measurements(jt_measurements *m);
+/* afftdnBandEdgesHz (analyser_noise_bands.go:29-51) */
+void jt_host_afftdn_band_edges(int index, double *lo_hz, double *hi_hz);
+
+/* ---- filter configuration (filters.go:111-255) ---- */
+typedef struct { int enabled; double frequency; int poles; double width, mix; int transform_tdii; } jt_biquad_cfg;
+typedef struct {
+    int downmix_enabled, analysis_enabled;
+    int resample_enabled, resample_rate, resample_frame;
+    jt_biquad_cfg rumble_hp, bandlimit_lp;
+    int nr_enabled; double nr_strength, nr_patch_s, nr_research_s, nr_smooth;
+    int afftdn_enabled; double afftdn_nr; int afftdn_custom; int afftdn_track_noise; double afftdn_noise_floor; char afftdn_band_noise[256];
+    int gate_enabled; double gate_threshold, gate_ratio, gate_attack, gate_release, gate_range, gate_knee, gate_makeup; int gate_detection_set;
+    int comp_enabled; double comp_threshold_db, comp_ratio, comp_attack, comp_release, comp_makeup_db, comp_knee, comp_mix;
+    int deess_enabled; double deess_intensity, deess_amount, deess_frequency;
+    int adeclick_enabled; double adeclick_threshold, adeclick_window, adeclick_overlap; int adeclick_method_s;
+    int loudnorm_enabled; double target_i, target_tp, target_lra; int dual_mono, linear;
+} jt_host_config;
+
+typedef struct {
+    double gate_quiet_speech_estimate, gate_separation, gate_speech_headroom, gate_threshold_unclamped, gate_depth_db;
+    int gate_narrow_gap; int afftdn_enabled; double afftdn_noise_floor_db; int afftdn_disabled_voice_activated; int afftdn_custom;
+} jt_adaptive_diag;
+
+void jt_host_default_config(jt_host_config *c);                                  /* DefaultFilterConfig (filters.go:353) */
+void jt_host_adapt(const jt_host_config *base, const jt_measurements *m, jt_host_config *effective, jt_adaptive_diag *diag); /* AdaptConfig (adaptive.go:13) */
+/* BuildFilterSpec with Pass1FilterOrder (pass=1) or Pass2FilterOrder (pass=2) (filters.go:42-68,968-989); returns length */
+int  jt_host_filter_spec(const jt_host_config *effective, int pass, char *buf, int cap);
+/* numeric jt_filter_params at the precision the spec string carries */
+void jt_host_filter_params(const jt_host_config *effective, jt_filter_params *out);
+
+/* ---- normalisation planning (normalise.go) ---- */
+typedef struct {
+    double pre_gain_db, ceiling_db, gain_db, filtered_tp; int needed, clamped;
+    char pass3_prefix[256];
+} jt_limiter_decision;
+void jt_host_calculate_limiter_ceiling(double measured_i, double measured_tp, double target_i, double target_tp,
+                                       double *ceiling, int *needed, int *clamped);                 /* :373-396 */
+void jt_host_calculate_pre_gain(double measured_i, double target_i, double target_tp, double *pre_gain, double *rederived); /* :411-431 */
+void jt_host_plan_limiter(double output_i, double output_tp_db, const jt_host_config *cfg, jt_limiter_decision *out, jt_limiter_plan *plan); /* :539-561 */
+void jt_host_calculate_linear_mode_target(double measured_i, double measured_tp, double desired_i, double target_tp,
+                                          double *effective_i, double *offset, int *linear_possible);  /* :614-632 */
+double jt_host_loudnorm_internal_target_tp(double target_i, double measured_tp, double measured_i);  /* :583-585 */
+/* buildLoudnormFilterSpec (normalise.go:1231-1334) + the numeric jt_loudnorm_apply it implies */
+int  jt_host_pass4_spec(const jt_host_config *cfg, const jt_loudnorm_stats *measurement, double offset, const jt_limiter_decision *lim,
+                        int source_rate, const char *stats_path, char *buf, int cap, jt_loudnorm_apply *apply);
+
+/* ---- orchestration: ProcessAudio on PCM already uploaded to the engine (processor.go:78-216) ---- */
+typedef struct {
+    jt_measurements input;                     /* Pass 1 (+bands) */
+    jt_host_config  effective; jt_adaptive_diag diag;
+    jt_analysis     filtered;                  /* Pass 2 whole-file */
+    jt_limiter_decision limiter;
+    jt_loudnorm_stats measure;                 /* Pass 3 (values rounded to the JSON's %.2f) */
+    double effective_target_i, offset; int linear_possible;
+    jt_analysis     final_;                    /* Pass 4 whole-file */
+    jt_loudnorm_stats loudnorm;                /* Pass 4 loudnorm JSON */
+    jt_region_sample filtered_room_tone, filtered_speech, final_room_tone, final_speech; int has_region_samples;
+    double output_lufs, output_tp_db, input_lufs, input_tp_db; int within_target;
+    char pass2_spec[2048]; char pass4_spec[2048];
+    double pass_ms[4];
+} jt_process_result;
+
+int jt_process_audio(jt_ctx *h, const jt_host_config *base, int frame_samples, jt_process_result *out);
+int jt_analyse_only(jt_ctx *h, const jt_host_config *base, int frame_samples, jt_process_result *out);   /* AnalyseOnlyDetailed (processor.go:29-69) */
+
+/* ---- granular detector steps (the reference table-tests each of these: analyser_vad_test.go) ---- */
+int    jt_host_vad_detect(const jt_interval *iv, int64_t n, double noise_floor_seed, jt_measurements *out);      /* detectVoiceActivity :728 */
+void   jt_host_vad_split(const jt_interval *iv, int64_t n, double seed, double *otsu_raw, double *split, double *floor_, double *margin, int *tol);
+int    jt_host_vad_speech_runs(const jt_interval *iv, int64_t n, double split, double margin, int tol, jt_region *out, int cap);  /* buildSpeechRuns :473 */
+int    jt_host_vad_gap_tolerance(const int *flags, int64_t n);                                                     /* gapToleranceIntervals :405 */
+void   jt_host_vad_gate_stats(const jt_interval *iv, int64_t n, double split, const jt_region *region,
+                              double *voiced_low, double *noise_high, double *separation);                        /* deriveGateStatistics :220 */
+int    jt_host_vad_noise_seed(const jt_interval *iv, int64_t n, double *noise_floor, double *threshold);           /* estimateNoiseFloorAndThreshold */
+int    jt_host_vad_pick_low_cluster(const jt_interval *iv, int64_t n, double split, jt_region *out);               /* pickLowClusterRegion :630 */
+double jt_host_vad_floored_fraction(const jt_interval *iv, int64_t n);                                             /* flooredFraction :708 */
+
+/* sizeof() of the ABI structs, for binding self-checks (0 interval, 1 measurements, 2 host_config, 3 process_result, ...) */
+int64_t jt_host_sizeof(int which);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

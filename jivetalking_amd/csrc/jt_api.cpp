@@ -275,6 +275,19 @@ extern "C" int jt_pass1(jt_ctx *h, int frame_samples, jt_analysis *out, double *
     JT_API_END(h)
 }
 
+
+// atrim=start:duration (libavfilter/trim.c): option strings are "%f" seconds -> AV_OPT_TYPE_DURATION microseconds ->
+// av_rescale_q to the 1/rate time base (nearest); sample i is kept iff start_pts <= i < start_pts + duration_tb.
+static void trim_range(double start_s, double dur_s, int rate, int64_t total, int64_t *s0, int64_t *len)
+{
+    const long long s_us = std::llround(start_s * 1e6), d_us = std::llround(dur_s * 1e6);
+    auto rescale = [&](long long us) { return (int64_t)(((__int128)us * rate + 500000) / 1000000); };
+    int64_t a = rescale(s_us), d = rescale(d_us);
+    a = std::max<int64_t>(0, std::min(a, total));
+    int64_t b = std::max(a, std::min(a + d, total));
+    *s0 = a; *len = b - a;
+}
+
 // ---------------------------------------------------------------- band RMS
 extern "C" int jt_band_rms(jt_ctx *h, double start_s, double dur_s, const double *lo_hz, const double *hi_hz,
                            int n_bands, double *out_db, int *ok)
@@ -283,15 +296,14 @@ extern "C" int jt_band_rms(jt_ctx *h, double start_s, double dur_s, const double
     JT_REQUIRE(h->n > 0 && h->in_mono, JT_E_STATE, "band_rms: no input uploaded");
     JT_REQUIRE(lo_hz && hi_hz && out_db && n_bands > 0 && dur_s > 0 && start_s >= 0, JT_E_INVAL, "band_rms: bad arguments");
     // atrim=start:duration selects samples with start <= t < start+duration (pts-based)
-    int64_t s0 = (int64_t)std::ceil(start_s * h->sr - 1e-9), s1 = (int64_t)std::ceil((start_s + dur_s) * h->sr - 1e-9);
-    s0 = std::max<int64_t>(0, std::min(s0, h->n)); s1 = std::max(s0, std::min(s1, h->n));
-    const int64_t len = s1 - s0;
+    int64_t s0, len; trim_range(start_s, dur_s, h->sr, h->n, &s0, &len);
     for (int b = 0; b < n_bands; ++b) { out_db[b] = NAN; if (ok) ok[b] = 0; }
     if (len <= 0) return JT_OK;
     DevBuf<float> tmp; tmp.ensure((size_t)len);
     DevBuf<double> red; red.ensure(2);
     for (int b = 0; b < n_bands; ++b) {
         double bh[3], ah[3], bl[3], al[3];
+        if (hi_hz[b] >= h->sr * 0.5 || lo_hz[b] >= h->sr * 0.5) { out_db[b] = NAN; if (ok) ok[b] = 1; continue; }
         jt_biquad_design(0, lo_hz[b], 0.707, h->sr, bh, ah, 0);
         jt_biquad_design(1, hi_hz[b], 0.707, h->sr, bl, al, 0);
         BiquadF32 hp{(float)bh[0], (float)bh[1], (float)bh[2], -(float)ah[1], -(float)ah[2]};
@@ -303,7 +315,7 @@ extern "C" int jt_band_rms(jt_ctx *h, double start_s, double dur_s, const double
         JT_HIP(hipStreamSynchronize(h->stream));
         double rms = std::sqrt(r[0] / (double)len);
         out_db[b] = 20 * std::log10(rms);
-        if (ok) ok[b] = std::isfinite(out_db[b]) ? 1 : 0;
+        if (ok) ok[b] = 1;   // astats Overall.RMS_level key present (may be -inf on digital silence)
     }
     JT_API_END(h)
 }
@@ -587,9 +599,7 @@ extern "C" int jt_region_measure(jt_ctx *h, int stage, double start_s, double du
     if (stage == 2) { src = h->s16_p2.p; m = h->m_p2; } else if (stage == 4) { src = h->s16_p4.p; m = h->m_p4; }
     JT_REQUIRE(src && m > 0, JT_E_STATE, "region_measure: stage output not on device");
     const int rate = h->out_rate;
-    int64_t s0 = (int64_t)std::ceil(start_s * rate - 1e-9), s1 = (int64_t)std::ceil((start_s + dur_s) * rate - 1e-9);
-    s0 = std::max<int64_t>(0, std::min(s0, m)); s1 = std::max(s0, std::min(s1, m));
-    const int64_t len = s1 - s0;
+    int64_t s0, len; trim_range(start_s, dur_s, rate, m, &s0, &len);
     std::memset(out, 0, sizeof(*out));
     JT_REQUIRE(len > 0, JT_E_INVAL, "region_measure: empty region");
     DevBuf<float> x; x.ensure((size_t)len);

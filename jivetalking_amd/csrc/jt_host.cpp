@@ -1,0 +1,1064 @@
+// jt_host.cpp — C++ restatement of the reference's per-file control logic (Go, internal/processor) for the
+// four-pass path: interval construction, noise-floor seed, voice-activity detection, speech election, adaptive
+// tuning, filter-spec strings, limiter/loudnorm planning and the ProcessAudio orchestration over the GPU engine.
+// Scalar double arithmetic in the same order as the Go code so results are bit-identical; durations are Go
+// time.Duration nanoseconds (int64).  See include/jt_host.h for the file:line map.
+#include "jt_internal.h"
+#include "../../include/jt_host.h"
+#include <algorithm>
+#include <cstdarg>
+#include <cstdlib>
+#include <functional>
+
+namespace {
+
+constexpr int64_t kSecond = 1000000000LL, kMs = 1000000LL;
+constexpr int64_t kHop = 250 * kMs;                 // analysisIntervalHop (analyser_vad.go:16)
+
+std::string sfmt(const char *fmt, ...)
+{
+    char buf[512];
+    va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof(buf), fmt, ap); va_end(ap);
+    return std::string(buf);
+}
+double qfmt(const char *fmt, double v)
+{
+    if (!std::isfinite(v)) return v;
+    char buf[64]; snprintf(buf, sizeof(buf), fmt, v); return std::strtod(buf, nullptr);
+}
+// Go's %g / strconv 'g' with shortest round-trip precision
+std::string go_g(double v)
+{
+    if (std::isnan(v)) return "NaN";
+    if (std::isinf(v)) return v > 0 ? "+Inf" : "-Inf";
+    char buf[64];
+    for (int p = 1; p <= 17; ++p) {
+        snprintf(buf, sizeof(buf), "%.*e", p - 1, v);
+        if (std::strtod(buf, nullptr) == v) {
+            int exp10 = 0; const char *e = std::strchr(buf, 'e'); if (e) exp10 = std::atoi(e + 1);
+            if (exp10 < -4 || exp10 >= 21) {
+                // Go prints e-notation with at least two exponent digits
+                std::string m(buf, e - buf);
+                return m + sfmt("e%c%02d", exp10 < 0 ? '-' : '+', std::abs(exp10));
+            }
+            int decimals = std::max(0, p - 1 - exp10);
+            snprintf(buf, sizeof(buf), "%.*f", decimals, v);
+            return std::string(buf);
+        }
+    }
+    snprintf(buf, sizeof(buf), "%.17g", v); return std::string(buf);
+}
+
+double DbToLinear(double db) { return std::pow(10.0, db / 20.0); }
+double LinearToDb(double lin) { return lin <= 0 ? -120.0 : 20.0 * std::log10(lin); }
+double linearRatioToDB(double r) { return r <= 0 ? -120.0 : 20 * std::log10(r); }
+double linearSampleToDBFS(double s)
+{
+    double a = std::fabs(s);
+    if (a <= 0) return -120.0;
+    if (a > 1.0) a /= 32768.0;
+    if (a > 1.0) a = 1.0;
+    return 20 * std::log10(a);
+}
+bool isFiniteD(double v) { return !std::isnan(v) && !std::isinf(v); }
+double sanitizeFloat(double v, double d) { return isFiniteD(v) ? v : d; }
+
+// ------------------------------------------------------------------ spectral helpers
+void spec_add(jt_spectral &a, const jt_spectral &b) { double *pa = &a.mean; const double *pb = &b.mean; for (int i = 0; i < 13; ++i) pa[i] += pb[i]; }
+jt_spectral spec_avg(const jt_spectral &a, double n) { jt_spectral o; double *po = &o.mean; const double *pa = &a.mean; for (int i = 0; i < 13; ++i) po[i] = pa[i] / n; return o; }
+jt_spectral spec_zero() { jt_spectral z; std::memset(&z, 0, sizeof(z)); return z; }
+jt_spectral spec_quant(const jt_spectral &a) { jt_spectral o; double *po = &o.mean; const double *pa = &a.mean; for (int i = 0; i < 13; ++i) po[i] = qfmt("%g", pa[i]); return o; }
+
+// ------------------------------------------------------------------ VAD (analyser_vad.go)
+constexpr double vadLevelFloorDB = -115.0;
+constexpr double speechCentroidMin = 200.0, speechCentroidMax = 6000.0, speechMinimumNoiseMarginDB = 2.0, speechEntropyMax = 0.70;
+bool isFlooredLevel(double l) { return std::isinf(l) || std::isnan(l) || l <= vadLevelFloorDB; }
+int intervalsForDuration(int64_t d, int64_t hop) { return hop <= 0 ? 0 : (int)((d + hop / 2) / hop); }
+double level_of(const jt_interval &s) { return s.momentary_lufs; }     // axisMomentaryLUFS
+
+struct Hist { std::vector<int> bins; double binWidth = 0, minLevel = 0, maxLevel = 0; int count = 0;
+              double centre(int i) const { return minLevel + ((double)i + 0.5) * binWidth; } };
+
+Hist buildLevelHistogram(const std::vector<jt_interval> &iv, double bw)
+{
+    Hist h; if (bw <= 0) return h;
+    std::vector<double> levels; double mn = INFINITY, mx = -INFINITY;
+    for (auto &s : iv) { double l = level_of(s); if (isFlooredLevel(l)) continue; levels.push_back(l); mn = std::min(mn, l); mx = std::max(mx, l); }
+    if (levels.empty()) return h;
+    int bc = (int)((mx - mn) / bw) + 1;
+    h.bins.assign(bc, 0); h.binWidth = bw; h.minLevel = mn; h.maxLevel = mx;
+    for (double l : levels) { int idx = (int)((l - mn) / bw); if (idx >= bc) idx = bc - 1; h.bins[idx]++; h.count++; }
+    return h;
+}
+std::vector<double> vadLevels(const std::vector<jt_interval> &iv)
+{
+    std::vector<double> l; for (auto &s : iv) { double v = level_of(s); if (!isFlooredLevel(v)) l.push_back(v); }
+    std::sort(l.begin(), l.end()); return l;
+}
+double percentileOfSorted(const std::vector<double> &s, double pct)
+{
+    if (s.empty()) return 0;
+    pct = std::max(0.0, std::min(100.0, pct));
+    int idx = (int)(pct / 100 * (double)(s.size() - 1));
+    return s[idx];
+}
+double otsuSplit(const Hist &h)
+{
+    if (h.count == 0 || h.bins.size() < 2) return (h.minLevel + h.maxLevel) / 2;
+    double total = (double)h.count, sumAll = 0;
+    for (size_t i = 0; i < h.bins.size(); ++i) sumAll += h.centre((int)i) * (double)h.bins[i];
+    double wB = 0, sB = 0, best = 0; int bestIdx = -1;
+    for (size_t i = 0; i + 1 < h.bins.size(); ++i) {
+        wB += (double)h.bins[i]; sB += h.centre((int)i) * (double)h.bins[i];
+        double wF = total - wB;
+        if (wB == 0 || wF == 0) continue;
+        double mB = sB / wB, mF = (sumAll - sB) / wF, diff = mB - mF, var = wB * wF * diff * diff;
+        if (var > best) { best = var; bestIdx = (int)i; }
+    }
+    if (bestIdx < 0) return (h.minLevel + h.maxLevel) / 2;
+    return h.minLevel + (double)(bestIdx + 1) * h.binWidth;
+}
+double percentileFloor(const std::vector<double> &levels, double seed)
+{ return std::max(percentileOfSorted(levels, 10.0), seed + speechMinimumNoiseMarginDB); }
+double clampSplit(double split, double nf, double p75)
+{ double lower = nf + speechMinimumNoiseMarginDB; if (p75 < lower) return lower; return std::max(lower, std::min(p75, split)); }
+bool passesSpectralVeto(const jt_interval &s)
+{ return s.spectral.centroid >= speechCentroidMin && s.spectral.centroid <= speechCentroidMax && s.spectral.entropy < speechEntropyMax; }
+bool isSpeechInterval(const jt_interval &s, double split) { return level_of(s) >= split && passesSpectralVeto(s); }
+double hysteresisMargin(const Hist &h, double split)
+{
+    double w = 0, c = 0;
+    for (size_t i = 0; i < h.bins.size(); ++i) { double ce = h.centre((int)i); if (ce >= split) { w += ce * (double)h.bins[i]; c += (double)h.bins[i]; } }
+    double upper = c == 0 ? split : w / c;
+    double dist = upper - split;
+    return dist <= 0 ? 1.0 : dist * 0.25;
+}
+int gapToleranceIntervals(const std::vector<bool> &flags, int64_t hop)
+{
+    int floor_ = intervalsForDuration(2 * kSecond, hop), ceil_ = intervalsForDuration(10 * kSecond, hop);
+    int first = -1, last = -1;
+    for (size_t i = 0; i < flags.size(); ++i) if (flags[i]) { if (first < 0) first = (int)i; last = (int)i; }
+    if (first < 0) return floor_;
+    std::vector<double> gaps; int gl = 0;
+    for (int i = first; i <= last; ++i) { if (flags[i]) { if (gl > 0) gaps.push_back((double)gl); gl = 0; continue; } gl++; }
+    if (gaps.empty()) return floor_;
+    std::sort(gaps.begin(), gaps.end());
+    int p75 = (int)std::round(percentileOfSorted(gaps, 75));
+    return std::max(floor_, std::min(ceil_, p75));
+}
+std::vector<jt_region> buildSpeechRuns(const std::vector<jt_interval> &iv, double split, double margin, int tol, int64_t hop)
+{
+    std::vector<jt_region> runs;
+    int minIntervals = intervalsForDuration(10 * kSecond, hop);
+    if ((int)iv.size() < minIntervals || minIntervals <= 0) return runs;
+    double high = split + margin, low = split - margin;
+    int64_t runStart = 0; int runSpeech = 0, lastSpeechIdx = 0, pendingGap = 0; bool inRun = false;
+    auto flush = [&](int endIdx) {
+        if (inRun && runSpeech >= minIntervals) { int64_t e = iv[endIdx].timestamp_ns + hop; runs.push_back(jt_region{runStart, e, e - runStart}); }
+        inRun = false; runSpeech = 0; pendingGap = 0;
+    };
+    for (size_t i = 0; i < iv.size(); ++i) {
+        const jt_interval &s = iv[i];
+        double level = level_of(s); bool veto = passesSpectralVeto(s); bool isSpeech = level >= split && veto;
+        if (!inRun) { if (level >= high && veto) { runStart = s.timestamp_ns; runSpeech = 1; lastSpeechIdx = (int)i; pendingGap = 0; inRun = true; } continue; }
+        if (isSpeech) { runSpeech++; lastSpeechIdx = (int)i; pendingGap = 0; continue; }
+        if (level >= split && !veto) { flush(lastSpeechIdx); continue; }
+        if (level < low) { pendingGap++; if (pendingGap > tol) flush(lastSpeechIdx); }
+    }
+    flush(lastSpeechIdx);
+    return runs;
+}
+
+// ------------------------------------------------------------------ candidates (analyser_candidates_shared.go)
+constexpr int64_t goldenIntervalSize = 250 * kMs;
+std::vector<jt_interval> getIntervalsInRange(const std::vector<jt_interval> &iv, int64_t start, int64_t end)
+{
+    std::vector<jt_interval> r;
+    if (iv.empty()) return r;
+    size_t lo = 0, hi = iv.size();
+    while (lo < hi) { size_t mid = (lo + hi) / 2; if (iv[mid].timestamp_ns < start) lo = mid + 1; else hi = mid; }
+    for (size_t i = lo; i < iv.size(); ++i) { if (iv[i].timestamp_ns >= end) break; r.push_back(iv[i]); }
+    return r;
+}
+struct Acc { double rmsSum = 0, peakMax = -120, tpMax = -120, spMax = -120, mSum = 0, sSum = 0; jt_spectral spec = spec_zero(); };
+Acc accumulateIntervalMetrics(const std::vector<jt_interval> &r)
+{
+    Acc a;
+    for (auto &s : r) {
+        a.rmsSum += s.rms_level; if (s.peak_level > a.peakMax) a.peakMax = s.peak_level;
+        spec_add(a.spec, s.spectral); a.mSum += s.momentary_lufs; a.sSum += s.shortterm_lufs;
+        if (s.true_peak > a.tpMax) a.tpMax = s.true_peak;
+        if (s.sample_peak > a.spMax) a.spMax = s.sample_peak;
+    }
+    return a;
+}
+double scoreIntervalWindow(const jt_interval *p, size_t n) { if (!n) return 0; double s = 0; for (size_t i = 0; i < n; ++i) s += p[i].rms_level; return s / (double)n; }
+
+double calculateRolloffScore(double r)
+{
+    if (r >= 4000.0 && r <= 8000.0) return 1.0;
+    if (r >= 2500.0 && r < 4000.0) return 0.5 + 0.5 * (r - 2500.0) / (4000.0 - 2500.0);
+    if (r > 8000.0 && r <= 10000.0) return 0.5 + 0.5 * (10000.0 - r) / (10000.0 - 8000.0);
+    return 0.0;
+}
+double calculateFluxScore(double f)
+{
+    if (f <= 0.004) return 1.0;
+    if (f <= 0.010) return 1.0 - (f - 0.004) / (0.010 - 0.004) * 0.3;
+    if (f <= 0.020) return 0.7 - (f - 0.010) / (0.020 - 0.010) * 0.3;
+    if (f <= 0.030) return 0.4 - (f - 0.020) / (0.030 - 0.020) * 0.2;
+    return 0.2;
+}
+double scoreSpeechIntervalWindow(const jt_interval *p, size_t cnt)
+{
+    if (!cnt) return 0;
+    double n = (double)cnt, kS = 0, fS = 0, cS = 0, rS = 0, roS = 0, flS = 0;
+    for (size_t i = 0; i < cnt; ++i) { kS += p[i].spectral.kurtosis; fS += p[i].spectral.flatness; cS += p[i].spectral.centroid;
+        rS += p[i].rms_level; roS += p[i].spectral.rolloff; flS += p[i].spectral.flux; }
+    double aK = kS / n, aF = fS / n, aC = cS / n, aR = rS / n, aRo = roS / n, aFl = flS / n;
+    double kv = 0; for (size_t i = 0; i < cnt; ++i) { double d = p[i].spectral.kurtosis - aK; kv += d * d; }
+    double kVar = kv / n;
+    int voiced = 0; for (size_t i = 0; i < cnt; ++i) if (p[i].spectral.kurtosis > 4.5) voiced++;
+    double voicingScore = std::max(0.0, std::min(((double)voiced / n) / 0.6, 1.0));
+    double kurtosisScore = std::max(0.0, std::min(aK / 7.5, 1.0));
+    double flatnessScore = std::max(0.0, std::min(1.0 - aF, 1.0));
+    double centroidScore = 0.0;
+    if (aC >= speechCentroidMin && aC <= speechCentroidMax) {
+        double mid = (speechCentroidMin + speechCentroidMax) / 2, hw = (speechCentroidMax - speechCentroidMin) / 2;
+        centroidScore = 1.0 - (std::fabs(aC - mid) / hw) * 0.5;
+    }
+    double consistencyScore = std::max(0.0, std::min(1.0 - (kVar / 100.0), 1.0));
+    double rmsScore = 0.0; if (aR > -30.0) rmsScore = std::max(0.0, std::min((aR - (-30.0)) / 18.0, 1.0));
+    return kurtosisScore * 0.15 + flatnessScore * 0.10 + centroidScore * 0.10 + consistencyScore * 0.10 + rmsScore * 0.10 +
+           voicingScore * 0.15 + calculateRolloffScore(aRo) * 0.15 + calculateFluxScore(aFl) * 0.15;
+}
+
+struct Refined { int64_t start, end, duration; bool ok; };
+Refined refineToSubregion(int64_t rs, int64_t re, int64_t rd, const std::vector<jt_interval> &iv, int64_t winDur, int64_t winMin,
+                          const std::function<double(const jt_interval *, size_t)> &score, bool higher_is_better)
+{
+    Refined out{rs, re, rd, false};
+    if (rd <= winDur) return out;
+    std::vector<jt_interval> c = getIntervalsInRange(iv, rs, re);
+    if (c.empty()) return out;
+    int w = (int)(winDur / goldenIntervalSize), mn = (int)(winMin / goldenIntervalSize);
+    if ((int)c.size() < mn) return out;
+    if ((int)c.size() < w) w = (int)c.size();
+    int bestIdx = 0; double best = score(c.data(), (size_t)w);
+    for (int s = 1; s <= (int)c.size() - w; ++s) {
+        double sc = score(c.data() + s, (size_t)w);
+        bool better = higher_is_better ? (sc > best) : (sc < best);
+        if (better) { best = sc; bestIdx = s; }
+    }
+    int64_t st = c[bestIdx].timestamp_ns, du = (int64_t)w * goldenIntervalSize;
+    return Refined{st, st + du, du, true};
+}
+
+double levelVariance(const std::vector<jt_interval> &r)
+{
+    double n = (double)r.size(); if (n == 0) return 0;
+    double s = 0; for (auto &x : r) s += level_of(x); double mean = s / n;
+    double v = 0; for (auto &x : r) { double d = level_of(x) - mean; v += d * d; }
+    return v / n;
+}
+bool measureSpeechCandidate(const jt_region &reg, const std::vector<jt_interval> &iv, jt_speech_candidate *out)
+{
+    std::vector<jt_interval> r = getIntervalsInRange(iv, reg.start_ns, reg.end_ns);
+    if (r.empty()) return false;
+    Acc a = accumulateIntervalMetrics(r);
+    double n = (double)r.size(), avgRMS = a.rmsSum / n;
+    int voiced = 0; for (auto &x : r) if (x.spectral.kurtosis > 4.5) voiced++;
+    std::memset(out, 0, sizeof(*out));
+    out->region = reg;
+    out->sample.rms_level = avgRMS; out->sample.peak_level = a.peakMax; out->sample.crest_factor = a.peakMax - avgRMS;
+    out->sample.spectral = spec_avg(a.spec, n);
+    out->sample.momentary_lufs = a.mSum / n; out->sample.shortterm_lufs = a.sSum / n;
+    out->sample.true_peak = a.tpMax; out->sample.sample_peak = a.spMax;
+    out->voicing_density = (double)voiced / n;
+    return true;
+}
+double groundedSNRScore(double snr)
+{
+    if (snr <= 0) return 0.0;
+    if (snr < 20.0) return 0.5 * (snr / 20.0);
+    if (snr >= 40.0) return 1.0;
+    return 0.5 + 0.5 * (snr - 20.0) / (40.0 - 20.0);
+}
+double scoreSpeechCandidateGrounded(const jt_speech_candidate &m, double noiseFloorDB, double levelVar)
+{
+    double snr = groundedSNRScore(m.sample.rms_level - noiseFloorDB);
+    const int64_t adequacy = 30 * kSecond;
+    double dur = m.region.duration_ns >= adequacy ? 1.0
+               : std::max(0.0, std::min(((double)m.region.duration_ns / 1e9) / ((double)adequacy / 1e9), 1.0));
+    double tie = std::max(0.0, std::min(1.0 - (levelVar / 25.0), 1.0)) * 0.02;
+    return snr * 0.6 + dur * 0.4 + tie;
+}
+
+struct BestResult { bool has = false; jt_region best{}; std::vector<jt_speech_candidate> cands; };
+BestResult findBestSpeechRegion(const std::vector<jt_region> &regions, const std::vector<jt_interval> &iv, bool hasNoise, double noiseFloor)
+{
+    BestResult res;
+    if (regions.empty()) return res;
+    double nf = hasNoise ? noiseFloor : -INFINITY;
+    int bestI = -1; double bestScore = 0; bool hasFb = false; jt_region fb{}; double fbScore = 0;
+    for (size_t i = 0; i < regions.size(); ++i) {
+        jt_speech_candidate m;
+        if (!measureSpeechCandidate(regions[i], iv, &m)) continue;
+        std::vector<jt_interval> r = getIntervalsInRange(iv, regions[i].start_ns, regions[i].end_ns);
+        double score = scoreSpeechCandidateGrounded(m, nf, levelVariance(r));
+        m.score = score;
+        res.cands.push_back(m);
+        if (!hasFb || score > fbScore) { fb = m.region; fbScore = score; hasFb = true; }
+        if (score >= 0.3 && (bestI < 0 || score > bestScore)) { bestI = (int)i; bestScore = score; }
+    }
+    bool have = false; jt_region best{};
+    if (bestI >= 0) { best = regions[bestI]; have = true; } else if (hasFb) { best = fb; have = true; }
+    const int64_t gw = 60 * kSecond, gmin = 30 * kSecond;
+    if (have && best.duration_ns > gw) {
+        jt_region orig = best;
+        Refined rf = refineToSubregion(best.start_ns, best.end_ns, best.duration_ns, iv, gw, gmin, scoreSpeechIntervalWindow, true);
+        jt_region refined = rf.ok ? jt_region{rf.start, rf.end, rf.duration} : best;
+        bool wasRefined = refined.start_ns != orig.start_ns || refined.duration_ns != orig.duration_ns;
+        if (wasRefined) {
+            jt_speech_candidate rm;
+            if (measureSpeechCandidate(refined, iv, &rm)) {
+                std::vector<jt_interval> ri = getIntervalsInRange(iv, refined.start_ns, refined.end_ns);
+                rm.score = scoreSpeechCandidateGrounded(rm, nf, levelVariance(ri));
+                rm.was_refined = 1; rm.original_start_ns = orig.start_ns; rm.original_duration_ns = orig.duration_ns;
+                for (auto &c : res.cands) if (c.region.start_ns == orig.start_ns) { c = rm; break; }
+                best = refined;
+            }
+        }
+    }
+    res.has = have; res.best = best;
+    return res;
+}
+
+bool pickLowClusterRegion(const std::vector<jt_interval> &iv, double split, int64_t hop, jt_region *out)
+{
+    bool haveBest = false; jt_region best{}; int64_t runStart = 0; bool inRun = false;
+    auto closeRun = [&](int endIdx) {
+        if (!inRun) return;
+        int64_t e = iv[endIdx].timestamp_ns + hop; jt_region r{runStart, e, e - runStart};
+        if (!haveBest || r.duration_ns > best.duration_ns) { best = r; haveBest = true; }
+        inRun = false;
+    };
+    for (size_t i = 0; i < iv.size(); ++i) {
+        bool below = level_of(iv[i]) < split;
+        if (below) { if (!inRun) { runStart = iv[i].timestamp_ns; inRun = true; } continue; }
+        if (inRun) closeRun((int)i - 1);
+    }
+    if (inRun) closeRun((int)iv.size() - 1);
+    if (!haveBest) return false;
+    Refined rf = refineToSubregion(best.start_ns, best.end_ns, best.duration_ns, iv, 10 * kSecond, 8 * kSecond, scoreIntervalWindow, false);
+    *out = rf.ok ? jt_region{rf.start, rf.end, rf.duration} : best;
+    return true;
+}
+
+// ------------------------------------------------------------------ noise seed (analyser_noise_seed.go)
+double roomToneScore(const jt_interval &s, double levelP50, double fluxP50)
+{
+    double amp = 1.0;
+    if (s.momentary_lufs > levelP50) { amp = 1.0 - (s.momentary_lufs - levelP50) / 6.0; if (amp < 0) amp = 0; }
+    double fl = 1.0;
+    if (fluxP50 > 0 && s.spectral.flux > fluxP50) { double ratio = s.spectral.flux / fluxP50; if (ratio > 1) fl = 1.0 / ratio; }
+    return 0.6 * amp + 0.4 * fl;
+}
+bool nan_less(double a, double b) { if (std::isnan(a)) return !std::isnan(b); if (std::isnan(b)) return false; return a < b; }   // Go slices.Sort: NaN first
+int cmpd(double a, double b) { if (nan_less(a, b)) return -1; if (nan_less(b, a)) return 1; return 0; }
+bool estimateNoiseFloorAndThreshold(const std::vector<jt_interval> &iv, double *nf, double *thr)
+{
+    if (iv.size() < 10) return false;
+    std::vector<double> levels(iv.size()), flux(iv.size());
+    for (size_t i = 0; i < iv.size(); ++i) { levels[i] = iv[i].momentary_lufs; flux[i] = iv[i].spectral.flux; }
+    std::sort(levels.begin(), levels.end(), nan_less); std::sort(flux.begin(), flux.end(), nan_less);
+    double levelP50 = levels[levels.size() / 2], fluxP50 = flux[flux.size() / 2];
+    struct SI { int idx; double level, score; };
+    std::vector<SI> sc(iv.size());
+    for (size_t i = 0; i < iv.size(); ++i) sc[i] = SI{(int)i, iv[i].momentary_lufs, roomToneScore(iv[i], levelP50, fluxP50)};
+    std::sort(sc.begin(), sc.end(), [](const SI &a, const SI &b) {
+        int c = cmpd(b.score, a.score); if (c) return c < 0;
+        c = cmpd(a.level, b.level); if (c) return c < 0;
+        return a.idx < b.idx; });
+    size_t cc = sc.size() / 5; cc = std::max<size_t>(cc, 8); cc = std::min(cc, sc.size());
+    double mx = -120.0; bool seen = false;
+    for (size_t i = 0; i < cc; ++i) { double l = sc[i].level; if (isFlooredLevel(l)) continue; if (!seen || l > mx) { mx = l; seen = true; } }
+    if (!seen) return false;
+    *nf = mx; *thr = mx + 1.0;
+    return true;
+}
+double calculateAdaptiveSilenceThreshold(double nf) { double t = nf + 6.0; if (t < -70.0) t = -70.0; if (t > -35.0) t = -35.0; return t; }
+
+}  // namespace
+
+// =====================================================================================================
+// intervals
+// =====================================================================================================
+extern "C" int64_t jt_host_build_intervals(int sr, int64_t n_samples, int frame_samples, int channels,
+                                           const double *fss, const double *fpk, int64_t n_frames,
+                                           const jt_frame_meta *meta, int64_t n_meta, int quantize, jt_interval *out, int64_t cap)
+{
+    struct IA { int frameCount = 0; double rawSS = 0; int64_t rawN = 0; double rawPk = 0; jt_spectral spec = spec_zero(); bool specFound = false;
+                double mSum = 0, sSum = 0, tpMax = 0, spMax = 0; };
+    IA acc; int64_t nout = 0; int64_t intervalStart = 0; int64_t processed = 0;
+    const int blk = sr / 10;
+    int64_t meta_next = 0;
+    auto finalize = [&](int64_t ts) {
+        if (nout >= cap) { nout++; return; }
+        jt_interval s; std::memset(&s, 0, sizeof(s));
+        s.timestamp_ns = ts;
+        s.peak_level = acc.rawPk > 0 ? 20.0 * std::log10(acc.rawPk) : -120.0;
+        s.true_peak = acc.tpMax; s.sample_peak = acc.spMax;
+        if (acc.rawN > 0) { double rms = std::sqrt(acc.rawSS / (double)acc.rawN); s.rms_level = rms < 0.00001 ? -120.0 : 20.0 * std::log10(rms); }
+        else s.rms_level = -120.0;
+        if (acc.frameCount > 0) {
+            double n = (double)acc.frameCount;
+            s.spectral = spec_avg(acc.spec, n); s.spectral_found = acc.specFound ? 1 : 0;
+            s.momentary_lufs = acc.mSum / n; s.shortterm_lufs = acc.sSum / n;
+        }
+        out[nout++] = s;
+    };
+    auto reset = [&]() { acc = IA(); acc.tpMax = -120.0; acc.spMax = -120.0; };
+    auto add_meta = [&](const jt_frame_meta &m) {
+        bool has = !std::isnan(m.momentary);
+        double tp = 0, sp = 0, M = 0, S = 0;
+        if (has) {
+            M = quantize ? qfmt("%.3f", m.momentary) : m.momentary; S = quantize ? qfmt("%.3f", m.shortterm) : m.shortterm;
+            tp = linearRatioToDB(quantize ? qfmt("%.3f", m.true_peak) : m.true_peak);
+            sp = linearRatioToDB(quantize ? qfmt("%.3f", m.sample_peak) : m.sample_peak);
+        }
+        if (acc.frameCount == 0 || tp > acc.tpMax) acc.tpMax = tp;
+        if (acc.frameCount == 0 || sp > acc.spMax) acc.spMax = sp;
+        spec_add(acc.spec, quantize ? spec_quant(m.spectral) : m.spectral); acc.specFound = true;
+        acc.mSum += M; acc.sSum += S; acc.frameCount++;
+    };
+    for (int64_t f = 0; f < n_frames; ++f) {
+        int64_t nb = std::min<int64_t>(frame_samples, n_samples - f * (int64_t)frame_samples);
+        int64_t t = (int64_t)((double)processed / (double)sr * 1e9);
+        processed += nb;
+        acc.rawSS += fss[f]; acc.rawN += nb * channels; if (fpk[f] > acc.rawPk) acc.rawPk = fpk[f];
+        if (t - intervalStart >= kHop) { finalize(intervalStart); intervalStart = t; reset(); }
+        // output frames released by this push: ebur128 has seen floor(processed/1024)*1024 samples (aspectralstats hop buffering)
+        int64_t seen = (processed / 1024) * 1024;
+        while (meta_next < n_meta && (meta_next + 1) * (int64_t)blk <= seen) add_meta(meta[meta_next++]);
+    }
+    while (meta_next < n_meta) add_meta(meta[meta_next++]);     // EOF flush
+    if (acc.rawN > 0) finalize(intervalStart);
+    return nout;
+}
+
+// =====================================================================================================
+// measurements + VAD
+// =====================================================================================================
+extern "C" void jt_host_afftdn_band_edges(int index, double *lo, double *hi)
+{
+    static const double c[15] = {80, 125, 195, 290, 440, 660, 1000, 1500, 2250, 3350, 5000, 7500, 11200, 16000, 24000};
+    const int last = 14;
+    if (index <= 0) *lo = c[0] / std::sqrt(c[1] / c[0]); else *lo = std::sqrt(c[index - 1] * c[index]);
+    if (index >= last) *hi = c[last] * std::sqrt(c[last] / c[last - 1]); else *hi = std::sqrt(c[index] * c[index + 1]);
+}
+
+static void detect_vad(const std::vector<jt_interval> &iv, double seed, jt_measurements *m)
+{
+    // detectVoiceActivity (analyser_vad.go:728-783)
+    const int64_t hop = kHop;
+    Hist h = buildLevelHistogram(iv, 1.0);
+    std::vector<double> levels = vadLevels(iv);
+    double p75 = percentileOfSorted(levels, 75);
+    double split = clampSplit(otsuSplit(h), seed, p75);
+    double floor_ = percentileFloor(levels, seed);
+    std::vector<bool> flags(iv.size());
+    for (size_t i = 0; i < iv.size(); ++i) flags[i] = isSpeechInterval(iv[i], split);
+    double margin = hysteresisMargin(h, split);
+    int tol = gapToleranceIntervals(flags, hop);
+    std::vector<jt_region> runs = buildSpeechRuns(iv, split, margin, tol, hop);
+    m->vad_split = split; m->vad_margin = margin; m->vad_gap_tol = tol;
+    m->n_speech_regions = (int)std::min<size_t>(runs.size(), JT_MAX_REGIONS);
+    for (int i = 0; i < m->n_speech_regions; ++i) m->speech_regions[i] = runs[i];
+
+    jt_region noiseRegion{};
+    bool haveNoiseRegion = pickLowClusterRegion(iv, split, hop, &noiseRegion);
+    bool haveProfile = false;
+    if (haveNoiseRegion) {
+        std::vector<jt_interval> r = getIntervalsInRange(iv, noiseRegion.start_ns, noiseRegion.start_ns + noiseRegion.duration_ns);
+        if (!r.empty()) {
+            Acc ac = accumulateIntervalMetrics(r);
+            double n = (double)r.size(), avgRMS = ac.rmsSum / n;
+            jt_spectral avg = spec_avg(ac.spec, n);
+            jt_noise_profile &np = m->noise_profile;
+            np.start_ns = noiseRegion.start_ns; np.duration_ns = noiseRegion.duration_ns;
+            np.measured_noise_floor = floor_;           // overwritten with the percentile floor (analyser_vad.go:751)
+            np.peak_level = ac.peakMax; np.crest_factor = ac.peakMax - avgRMS; np.entropy = avg.entropy; np.spectral = avg;
+            np.warning = noiseRegion.duration_ns < 8 * kSecond ? 1 : (noiseRegion.duration_ns > 18 * kSecond ? 2 : 0);
+            haveProfile = true; m->has_noise_profile = 1;
+            // setVADRoomToneSample
+            m->has_room_tone_sample = 1;
+            m->room_tone_sample.rms_level = avgRMS; m->room_tone_sample.peak_level = ac.peakMax; m->room_tone_sample.crest_factor = ac.peakMax - avgRMS;
+            m->room_tone_sample.spectral = avg; m->room_tone_sample.momentary_lufs = ac.mSum / n; m->room_tone_sample.shortterm_lufs = ac.sSum / n;
+            m->room_tone_sample.true_peak = ac.tpMax; m->room_tone_sample.sample_peak = ac.spMax;
+        }
+    }
+    BestResult br = findBestSpeechRegion(runs, iv, haveProfile, floor_);
+    m->n_candidates = (int)std::min<size_t>(br.cands.size(), JT_MAX_REGIONS);
+    for (int i = 0; i < m->n_candidates; ++i) m->candidates[i] = br.cands[i];
+    bool elected = false; jt_region electedRegion{};
+    if (br.has) for (auto &c : br.cands) if (c.region.start_ns == br.best.start_ns) { m->speech_profile = c; m->has_speech_profile = 1; elected = true; electedRegion = c.region; break; }
+    // deriveGateStatistics
+    {
+        std::vector<double> voiced, noise;
+        for (auto &s : iv) { double l = level_of(s); if (isFlooredLevel(l)) continue; if (l < split) noise.push_back(l); }
+        if (elected) { std::vector<jt_interval> r = getIntervalsInRange(iv, electedRegion.start_ns, electedRegion.end_ns);
+                       for (auto &s : r) if (isSpeechInterval(s, split)) voiced.push_back(level_of(s)); }
+        std::sort(voiced.begin(), voiced.end()); std::sort(noise.begin(), noise.end());
+        m->voiced_low_percentile = percentileOfSorted(voiced, 10.0);
+        m->noise_high_percentile = percentileOfSorted(noise, 95.0);
+        m->gate_separation_db = m->voiced_low_percentile - m->noise_high_percentile;
+    }
+    m->floor = floor_; m->floor_source = 3;
+    { double counted = 0, fl = 0; for (auto &s : iv) { double l = level_of(s); counted++; if (std::isnan(l) || l <= vadLevelFloorDB) fl++; }
+      m->floored_fraction = counted == 0 ? 0 : fl / counted; }
+    m->voice_activated = m->floored_fraction >= 0.20 ? 1 : 0;
+}
+
+extern "C" int jt_host_detect(const jt_analysis *p1, const jt_interval *ivp, int64_t n_iv, double duration_s, double target_i,
+                              int quantize, jt_measurements *m)
+{
+    if (!p1 || !m || (n_iv > 0 && !ivp)) return JT_E_INVAL;
+    std::memset(m, 0, sizeof(*m));
+    std::vector<jt_interval> iv(ivp, ivp + n_iv);
+    auto q3 = [&](double v) { return quantize ? qfmt("%.3f", v) : v; };
+    auto q6 = [&](double v) { return quantize ? qfmt("%f", v) : v; };
+    m->duration_s = duration_s;
+    // buildInputMeasurements (analyser.go:364-406)
+    double nf = 0, thr = 0;
+    if (!estimateNoiseFloorAndThreshold(iv, &nf, &thr)) { nf = vadLevelFloorDB; thr = calculateAdaptiveSilenceThreshold(vadLevelFloorDB); }
+    m->floor_prescan = nf; m->room_tone_detect_level = thr;
+    m->input_i = q3(p1->r128.integrated);
+    m->input_tp = linearRatioToDB(q3(p1->r128.true_peak));
+    m->input_lra = q3(p1->r128.lra);
+    m->input_thresh = m->input_i - 10.0;
+    m->target_offset = target_i - m->input_i;
+    m->momentary = q3(p1->r128.momentary); m->shortterm = q3(p1->r128.shortterm);
+    m->sample_peak = linearRatioToDB(q3(p1->r128.sample_peak));
+    m->spectral = p1->spectral_mean;
+    // assignAstatsMeasurements with the metadata conversions (analyser_metrics.go:535-605)
+    const jt_astats &a = p1->astats;
+    jt_astats d = a;
+    d.dc_offset = q6(a.dc_offset); d.min_difference = q6(a.min_difference); d.max_difference = q6(a.max_difference);
+    d.mean_difference = q6(a.mean_difference); d.rms_difference = q6(a.rms_difference);
+    d.peak_level = q6(a.peak_level); d.rms_level = q6(a.rms_level); d.rms_peak = q6(a.rms_peak); d.rms_trough = q6(a.rms_trough);
+    d.crest_factor = linearRatioToDB(q6(a.crest_factor)); d.flat_factor = q6(a.flat_factor);
+    d.min_level = linearSampleToDBFS(q6(a.min_level)); d.max_level = linearSampleToDBFS(q6(a.max_level));
+    d.noise_floor = q6(a.noise_floor); d.entropy = q6(a.entropy); d.dynamic_range = q6(a.dynamic_range);
+    d.zero_crossings_rate = q6(a.zero_crossings_rate);
+    m->dynamics = d; m->floor_astats = d.noise_floor;
+    // assignInputNoiseFloor (analyser.go:488-511)
+    if (d.rms_trough != 0 && !(std::isinf(d.rms_trough) && d.rms_trough < 0)) { m->floor = d.rms_trough; m->floor_source = 0; }
+    else if (d.rms_level != 0 && !(std::isinf(d.rms_level) && d.rms_level < 0)) { m->floor = d.rms_level - 15.0; m->floor_source = 1; }
+    else { double off = m->input_i > -20.0 ? 18.0 : (m->input_i > -30.0 ? 12.0 : 8.0); m->floor = m->input_thresh - off; m->floor_source = 2; }
+    m->floor = std::max(-90.0, std::min(-30.0, m->floor));
+
+    detect_vad(iv, m->floor_prescan, m);
+    return JT_OK;
+}
+
+extern "C" void jt_host_finish_measurements(jt_measurements *m)
+{
+    if (m->dynamics.rms_level != 0 && m->floor != 0) {
+        m->reduction_headroom = std::max(0.0, std::min(60.0, m->dynamics.rms_level - m->floor));
+        return;
+    }
+    m->reduction_headroom = m->input_i > -20.0 ? 40.0 : (m->input_i > -30.0 ? 25.0 : 15.0);
+}
+
+// =====================================================================================================
+// configuration, adaptation, filter-spec strings
+// =====================================================================================================
+extern "C" void jt_host_default_config(jt_host_config *c)
+{
+    std::memset(c, 0, sizeof(*c));
+    c->downmix_enabled = 1; c->analysis_enabled = 1;
+    c->resample_enabled = 1; c->resample_rate = 44100; c->resample_frame = 4096;
+    c->rumble_hp = jt_biquad_cfg{1, 80.0, 2, 0.707, 1.0, 1};
+    c->bandlimit_lp = jt_biquad_cfg{1, 20500.0, 2, 0.707, 1.0, 1};
+    c->nr_enabled = 1; c->nr_strength = 0.00001; c->nr_patch_s = 0.0060; c->nr_research_s = 0.0020; c->nr_smooth = 3.0;
+    c->afftdn_enabled = 1; c->afftdn_nr = 12; c->afftdn_custom = 0; c->afftdn_track_noise = 1; c->afftdn_noise_floor = 0;
+    c->gate_enabled = 1; c->gate_threshold = 0.01; c->gate_ratio = 2.0; c->gate_attack = 5.0; c->gate_release = 200.0;
+    c->gate_range = DbToLinear(-14.0); c->gate_knee = 3.0; c->gate_makeup = 1.0; c->gate_detection_set = 1;
+    c->comp_enabled = 1; c->comp_threshold_db = -18; c->comp_ratio = 3.0; c->comp_attack = 10; c->comp_release = 200;
+    c->comp_makeup_db = 0; c->comp_knee = 4.0; c->comp_mix = 1.0;
+    c->deess_enabled = 1; c->deess_intensity = 0.0; c->deess_amount = 0.50; c->deess_frequency = 0.80;
+    c->adeclick_enabled = 1; c->adeclick_threshold = 1.7; c->adeclick_window = 55.0; c->adeclick_overlap = 50.0; c->adeclick_method_s = 1;
+    c->loudnorm_enabled = 1; c->target_i = -16.0; c->target_tp = -1.0; c->target_lra = 20.0; c->dual_mono = 1; c->linear = 1;
+}
+
+static std::string buildAfftdnBandNoise(const double *bands, int n)
+{
+    if (n == 0) return "";
+    double sum = 0; int fin = 0;
+    for (int i = 0; i < n; ++i) if (isFiniteD(bands[i])) { sum += bands[i]; fin++; }
+    if (!fin) return "";
+    double mean = sum / (double)fin;
+    std::string out;
+    for (int i = 0; i < n; ++i) {
+        if (i) out += "|";
+        if (!isFiniteD(bands[i])) { out += sfmt("%.1f", 0.0); continue; }
+        double shape = std::max(-24.0, std::min(24.0, bands[i] - mean));
+        out += sfmt("%.1f", shape);
+    }
+    return out;
+}
+
+extern "C" void jt_host_adapt(const jt_host_config *base, const jt_measurements *m, jt_host_config *c, jt_adaptive_diag *dg)
+{
+    *c = *base;
+    jt_adaptive_diag d; std::memset(&d, 0, sizeof(d));
+    // tuneBandlimitLowPass
+    c->bandlimit_lp.enabled = 1; c->bandlimit_lp.frequency = 20500.0; c->bandlimit_lp.poles = 2; c->bandlimit_lp.mix = 1.0;
+    // tuneNoiseReduction
+    if (m->voice_activated) { c->afftdn_enabled = 0; d.afftdn_enabled = 0; d.afftdn_disabled_voice_activated = 1; }
+    else {
+        d.afftdn_enabled = c->afftdn_enabled;
+        if (m->floor != 0) {
+            double fl = std::max(-80.0, std::min(-20.0, m->floor));
+            c->afftdn_noise_floor = fl; c->afftdn_track_noise = 0; d.afftdn_noise_floor_db = fl;
+            c->afftdn_custom = 0;
+            bool custom = m->has_noise_profile && m->noise_profile.bands_measured && !(m->gate_separation_db < 12.0) &&
+                          m->noise_profile.spectral.flatness >= 0.45;
+            if (custom) {
+                std::string bn = buildAfftdnBandNoise(m->noise_profile.band_noise, m->noise_profile.band_noise_n);
+                if (!bn.empty()) { c->afftdn_custom = 1; snprintf(c->afftdn_band_noise, sizeof(c->afftdn_band_noise), "%s", bn.c_str()); }
+            }
+            d.afftdn_custom = c->afftdn_custom;
+        }
+    }
+    // tuneSpeechGate
+    {
+        double crest = 15.0, peak = 0;
+        if (m->has_noise_profile) { crest = m->noise_profile.crest_factor; peak = m->noise_profile.peak_level; }
+        double lufsGap = c->target_i - m->input_i; if (lufsGap < 0) lufsGap = 0;
+        c->gate_ratio = m->input_lra > 15.0 ? 1.5 : 2.0;
+        bool narrow = false;
+        if (m->has_speech_profile) {
+            double thrDB = m->voiced_low_percentile - 6.0;
+            narrow = m->gate_separation_db < (6.0 + 6.0);
+            thrDB = std::max(-80.0, std::min(thrDB, -25.0));
+            c->gate_threshold = DbToLinear(thrDB);
+            d.gate_narrow_gap = narrow; d.gate_quiet_speech_estimate = m->voiced_low_percentile; d.gate_separation = m->gate_separation_db;
+            d.gate_threshold_unclamped = m->voiced_low_percentile - 6.0;
+            d.gate_speech_headroom = m->voiced_low_percentile - LinearToDb(c->gate_threshold);
+        } else {
+            double thrDB;
+            bool usePeak = crest > 20.0 && peak != 0 && lufsGap < 25.0;
+            if (usePeak) thrDB = peak + 3.0;
+            else { double minGap = 12.0 / (1.0 - 1.0 / c->gate_ratio); thrDB = std::max(m->floor + minGap, -40.0); }
+            thrDB = std::max(-80.0, std::min(thrDB, -25.0));
+            c->gate_threshold = DbToLinear(thrDB);
+        }
+        c->gate_attack = 5.0; c->gate_release = 200.0;
+        double depth = narrow ? 8.0 : 14.0;
+        c->gate_range = DbToLinear(-depth); d.gate_depth_db = depth;
+        c->gate_knee = 3.0; c->gate_detection_set = 1;
+    }
+    // tuneDeesser
+    if (!m->has_speech_profile || !m->speech_profile.bands_measured) c->deess_intensity = 0.0;
+    else {
+        double ex = m->speech_profile.sib_band_rms - m->speech_profile.body_band_rms;
+        if (ex < -6.0) c->deess_intensity = 0.0;
+        else if (ex < -3.0) c->deess_intensity = ((ex - (-6.0)) / (-3.0 - (-6.0))) * 0.6;
+        else if (ex < 0.0) c->deess_intensity = 0.6 + ((ex - (-3.0)) / (0.0 - (-3.0))) * (0.85 - 0.6);
+        else c->deess_intensity = 0.85;
+    }
+    // tuneLevellingCompressor
+    c->comp_ratio = 3.0; c->comp_attack = 10.0; c->comp_release = 200.0; c->comp_knee = 4.0; c->comp_mix = 1.0; c->comp_makeup_db = 0.0;
+    {
+        bool set = false; double thr = 0;
+        if (m->has_speech_profile) {
+            double eff = m->speech_profile.sample.rms_level, full = m->dynamics.rms_level;
+            if (full < 0 && !(std::isinf(full) && full < 0)) eff = std::max(eff, full);
+            thr = eff + 9.0; set = true;
+        } else if (std::isnan(m->dynamics.peak_level) || std::isinf(m->dynamics.peak_level)) c->comp_threshold_db = -18.0;
+        else { thr = m->dynamics.peak_level - 20.0; set = true; }
+        if (set) c->comp_threshold_db = std::max(-45.0, std::min(thr, -6.0));
+    }
+    // sanitizeConfig
+    c->rumble_hp.frequency = sanitizeFloat(c->rumble_hp.frequency, 80.0); c->rumble_hp.width = sanitizeFloat(c->rumble_hp.width, 0.707); c->rumble_hp.mix = sanitizeFloat(c->rumble_hp.mix, 1.0);
+    c->bandlimit_lp.frequency = sanitizeFloat(c->bandlimit_lp.frequency, 20500.0); c->bandlimit_lp.width = sanitizeFloat(c->bandlimit_lp.width, 0.707); c->bandlimit_lp.mix = sanitizeFloat(c->bandlimit_lp.mix, 1.0);
+    c->nr_strength = sanitizeFloat(c->nr_strength, 0.00001); c->nr_patch_s = sanitizeFloat(c->nr_patch_s, 0.0060);
+    c->nr_research_s = sanitizeFloat(c->nr_research_s, 0.0020); c->nr_smooth = sanitizeFloat(c->nr_smooth, 3.0);
+    c->afftdn_nr = sanitizeFloat(c->afftdn_nr, 12); c->afftdn_noise_floor = sanitizeFloat(c->afftdn_noise_floor, 0);
+    if (c->afftdn_custom && c->afftdn_band_noise[0] == 0) c->afftdn_custom = 0;
+    if (!isFiniteD(c->gate_threshold) || c->gate_threshold <= 0) c->gate_threshold = 0.01;
+    c->gate_ratio = sanitizeFloat(c->gate_ratio, 2.0); c->gate_attack = sanitizeFloat(c->gate_attack, 5.0); c->gate_release = sanitizeFloat(c->gate_release, 200.0);
+    c->gate_range = sanitizeFloat(c->gate_range, DbToLinear(-14.0)); c->gate_knee = sanitizeFloat(c->gate_knee, 3.0); c->gate_makeup = sanitizeFloat(c->gate_makeup, 1.0);
+    c->comp_ratio = sanitizeFloat(c->comp_ratio, 3.0); c->comp_threshold_db = sanitizeFloat(c->comp_threshold_db, -18.0);
+    c->comp_attack = sanitizeFloat(c->comp_attack, 10); c->comp_release = sanitizeFloat(c->comp_release, 200); c->comp_makeup_db = sanitizeFloat(c->comp_makeup_db, 0);
+    c->comp_knee = sanitizeFloat(c->comp_knee, 4.0); c->comp_mix = sanitizeFloat(c->comp_mix, 1.0);
+    c->deess_intensity = sanitizeFloat(c->deess_intensity, 0.0); c->deess_amount = sanitizeFloat(c->deess_amount, 0.50); c->deess_frequency = sanitizeFloat(c->deess_frequency, 0.80);
+    if (dg) *dg = d;
+}
+
+namespace {
+std::string buildBiquadFilter(const jt_biquad_cfg &b, const char *kw)
+{
+    if (!b.enabled) return "";
+    int poles = b.poles < 1 ? 2 : b.poles; double width = b.width <= 0 ? 0.707 : b.width;
+    std::string s = sfmt("%s=f=%.0f:poles=%d:width_type=q:width=%.3f:normalize=1", kw, b.frequency, poles, width);
+    if (b.transform_tdii) s += ":a=tdii";
+    if (b.mix > 0 && b.mix < 1.0) s += sfmt(":m=%.2f", b.mix);
+    return s;
+}
+std::string buildAfftdn(const jt_host_config &c)
+{
+    if (!c.afftdn_enabled) return "";
+    int tn = c.afftdn_track_noise ? 1 : 0; std::string s;
+    if (c.afftdn_custom && c.afftdn_band_noise[0]) s = "afftdn=nr=" + go_g(c.afftdn_nr) + ":nt=custom:bn=" + c.afftdn_band_noise + sfmt(":tn=%d", tn);
+    else s = "afftdn=nr=" + go_g(c.afftdn_nr) + ":nt=" + (c.afftdn_custom ? "custom" : "w") + sfmt(":tn=%d", tn);
+    if (c.afftdn_noise_floor < 0) s += ":nf=" + go_g(c.afftdn_noise_floor);
+    return s;
+}
+std::string analysisSpec(const jt_host_config &c)
+{
+    if (!c.analysis_enabled) return "";
+    return sfmt("astats=metadata=1:measure_perchannel=all,aspectralstats=win_size=2048:win_func=hann:measure=all,"
+                "ebur128=metadata=1:peak=sample+true:dualmono=true:target=%.0f", c.target_i);
+}
+std::string outputFormatSpec(const jt_host_config &c)
+{ return sfmt("aformat=sample_rates=%d:channel_layouts=mono:sample_fmts=s16,asetnsamples=n=%d", c.resample_rate, c.resample_frame); }
+void join(std::string &acc, const std::string &part) { if (part.empty()) return; if (!acc.empty()) acc += ","; acc += part; }
+std::string preLimiterPrefix(double preGain, double ceiling, bool needed)
+{
+    if (!needed) return "";
+    std::string s;
+    if (preGain > 0) join(s, sfmt("volume=%.1fdB", preGain));
+    join(s, sfmt("alimiter=limit=%.6f:attack=5:release=100:level_in=1:level_out=1:level=0:latency=1:asc=1:asc_level=0.8", DbToLinear(ceiling)));
+    return s;
+}
+}  // namespace
+
+extern "C" int jt_host_filter_spec(const jt_host_config *c, int pass, char *buf, int cap)
+{
+    std::string s;
+    if (c->downmix_enabled) join(s, "aformat=channel_layouts=mono");
+    if (pass == 2) {
+        join(s, buildBiquadFilter(c->rumble_hp, "highpass"));
+        join(s, buildBiquadFilter(c->bandlimit_lp, "lowpass"));
+        if (c->nr_enabled) {
+            std::string nr = sfmt("anlmdn=s=%.5f:p=%.4f:r=%.4f:m=%.0f", c->nr_strength, c->nr_patch_s, c->nr_research_s, c->nr_smooth);
+            join(nr, buildAfftdn(*c));
+            join(s, nr);
+        }
+        if (c->gate_enabled)
+            join(s, sfmt("agate=threshold=%.6f:ratio=%.1f:attack=%.2f:release=%.0f:range=%.4f:knee=%.1f:detection=%s:makeup=%.1f",
+                         c->gate_threshold, c->gate_ratio, c->gate_attack, c->gate_release, c->gate_range, c->gate_knee, "rms", c->gate_makeup));
+        if (c->comp_enabled)
+            join(s, sfmt("acompressor=threshold=%.6f:ratio=%.1f:attack=%.0f:release=%.0f:makeup=%.2f:knee=%.1f:detection=rms:mix=%.2f",
+                         DbToLinear(c->comp_threshold_db), c->comp_ratio, c->comp_attack, c->comp_release, DbToLinear(c->comp_makeup_db), c->comp_knee, c->comp_mix));
+        if (c->deess_enabled && c->deess_intensity > 0)
+            join(s, sfmt("deesser=i=%.2f:m=%.2f:f=%.2f", c->deess_intensity, c->deess_amount, c->deess_frequency));
+    }
+    join(s, analysisSpec(*c));
+    if (pass == 2 && c->resample_enabled) join(s, outputFormatSpec(*c));
+    if (buf && cap > 0) snprintf(buf, (size_t)cap, "%s", s.c_str());
+    return (int)s.size();
+}
+
+extern "C" void jt_host_filter_params(const jt_host_config *c, jt_filter_params *p)
+{
+    std::memset(p, 0, sizeof(*p));
+    p->hp_enabled = c->rumble_hp.enabled; p->hp_freq = qfmt("%.0f", c->rumble_hp.frequency); p->hp_q = qfmt("%.3f", c->rumble_hp.width <= 0 ? 0.707 : c->rumble_hp.width);
+    p->lp_enabled = c->bandlimit_lp.enabled; p->lp_freq = qfmt("%.0f", c->bandlimit_lp.frequency); p->lp_q = qfmt("%.3f", c->bandlimit_lp.width <= 0 ? 0.707 : c->bandlimit_lp.width);
+    p->nlm_enabled = c->nr_enabled; p->nlm_strength = qfmt("%.5f", c->nr_strength); p->nlm_patch_s = qfmt("%.4f", c->nr_patch_s);
+    p->nlm_research_s = qfmt("%.4f", c->nr_research_s); p->nlm_smooth = qfmt("%.0f", c->nr_smooth);
+    p->fft_enabled = c->nr_enabled && c->afftdn_enabled; p->fft_nr = std::strtod(go_g(c->afftdn_nr).c_str(), nullptr);
+    p->fft_nf = c->afftdn_noise_floor < 0 ? std::strtod(go_g(c->afftdn_noise_floor).c_str(), nullptr) : 0.0;
+    p->fft_track_noise = c->afftdn_track_noise;
+    p->fft_custom = (c->afftdn_custom && c->afftdn_band_noise[0]) ? 1 : 0;
+    if (p->fft_custom) {
+        const char *s = c->afftdn_band_noise; int i = 0;
+        while (*s && i < 15) { char *e; p->fft_band_noise[i++] = std::strtod(s, &e); s = e; while (*s == '|' || *s == ' ') ++s; }
+    }
+    p->gate_enabled = c->gate_enabled; p->gate_threshold = qfmt("%.6f", c->gate_threshold); p->gate_ratio = qfmt("%.1f", c->gate_ratio);
+    p->gate_attack_ms = qfmt("%.2f", c->gate_attack); p->gate_release_ms = qfmt("%.0f", c->gate_release); p->gate_range = qfmt("%.4f", c->gate_range);
+    p->gate_knee = qfmt("%.1f", c->gate_knee); p->gate_makeup = qfmt("%.1f", c->gate_makeup);
+    p->comp_enabled = c->comp_enabled; p->comp_threshold = qfmt("%.6f", DbToLinear(c->comp_threshold_db)); p->comp_ratio = qfmt("%.1f", c->comp_ratio);
+    p->comp_attack_ms = qfmt("%.0f", c->comp_attack); p->comp_release_ms = qfmt("%.0f", c->comp_release);
+    p->comp_makeup = qfmt("%.2f", DbToLinear(c->comp_makeup_db)); p->comp_knee = qfmt("%.1f", c->comp_knee); p->comp_mix = qfmt("%.2f", c->comp_mix);
+    p->deess_enabled = (c->deess_enabled && c->deess_intensity > 0) ? 1 : 0;
+    p->deess_i = qfmt("%.2f", c->deess_intensity); p->deess_m = qfmt("%.2f", c->deess_amount); p->deess_f = qfmt("%.2f", c->deess_frequency);
+    p->out_rate = c->resample_rate; p->out_frame_samples = c->resample_frame;
+}
+
+// =====================================================================================================
+// normalisation planning (normalise.go)
+// =====================================================================================================
+extern "C" void jt_host_calculate_limiter_ceiling(double mi, double mtp, double ti, double ttp, double *ceiling, int *needed, int *clamped)
+{
+    double gain = ti - mi, proj = mtp + gain;
+    *ceiling = 0; *needed = 0; *clamped = 0;
+    if (proj <= ttp) return;
+    double c = ttp - gain;
+    if (c < -24.0) { c = -24.0; *clamped = 1; }
+    *ceiling = c; *needed = 1;
+}
+extern "C" void jt_host_calculate_pre_gain(double mi, double ti, double ttp, double *pre, double *red)
+{
+    double gain = ti - mi, ideal = ttp - gain;
+    *pre = 0; *red = 0;
+    if (ideal >= -24.0) return;
+    *pre = -24.0 - ideal;
+    double postI = mi + *pre, ng = ti - postI;
+    *red = ttp - ng;
+}
+extern "C" void jt_host_plan_limiter(double oi, double otp, const jt_host_config *cfg, jt_limiter_decision *o, jt_limiter_plan *plan)
+{
+    std::memset(o, 0, sizeof(*o));
+    double ceiling; int needed, clamped; jt_host_calculate_limiter_ceiling(oi, otp, cfg->target_i, cfg->target_tp, &ceiling, &needed, &clamped);
+    double pre, red; jt_host_calculate_pre_gain(oi, cfg->target_i, cfg->target_tp, &pre, &red);
+    if (clamped) ceiling = red;
+    o->pre_gain_db = pre; o->ceiling_db = ceiling; o->needed = needed; o->clamped = clamped; o->gain_db = cfg->target_i - oi; o->filtered_tp = otp;
+    std::string pf = preLimiterPrefix(pre, ceiling, needed != 0);
+    snprintf(o->pass3_prefix, sizeof(o->pass3_prefix), "%s", pf.c_str());
+    if (plan) {
+        plan->needed = needed; plan->pre_gain_db = (needed && pre > 0) ? qfmt("%.1f", pre) : 0.0;
+        plan->limit = needed ? qfmt("%.6f", DbToLinear(ceiling)) : 1.0;
+    }
+}
+extern "C" double jt_host_loudnorm_internal_target_tp(double ti, double mtp, double mi) { return mtp + (ti - mi) + 0.1 + 0.2; }
+extern "C" void jt_host_calculate_linear_mode_target(double mi, double mtp, double di, double ttp, double *eff, double *off, int *lin)
+{
+    double maxLinear = ttp - mtp + mi - 0.1;
+    if (di <= maxLinear) { *eff = di; *off = di - mi; *lin = 1; return; }
+    *eff = maxLinear; *off = maxLinear - mi; *lin = 0;
+}
+extern "C" int jt_host_pass4_spec(const jt_host_config *cfg, const jt_loudnorm_stats *ms, double offset, const jt_limiter_decision *lim,
+                                  int source_rate, const char *stats_path, char *buf, int cap, jt_loudnorm_apply *ap)
+{
+    double internalTP = jt_host_loudnorm_internal_target_tp(cfg->target_i, ms->input_tp, ms->input_i);
+    double emittedTP = std::max(-9.0, std::min(internalTP, 0.0));
+    double brickDB = cfg->target_tp - 0.9;
+    std::string s;
+    if (lim) join(s, preLimiterPrefix(lim->pre_gain_db, lim->ceiling_db, lim->needed != 0));
+    std::string ln = sfmt("loudnorm=I=%.2f:TP=%.2f:LRA=%.1f:measured_I=%.2f:measured_TP=%.2f:measured_LRA=%.2f:measured_thresh=%.2f:offset=%.2f:dual_mono=%s:linear=%s:print_format=json",
+                          cfg->target_i, emittedTP, cfg->target_lra, ms->input_i, ms->input_tp, ms->input_lra, ms->input_thresh, offset,
+                          cfg->dual_mono ? "true" : "false", cfg->linear ? "true" : "false");
+    if (stats_path && stats_path[0]) ln += std::string(":stats_file=") + stats_path;
+    join(s, ln);
+    if (source_rate > 0) join(s, sfmt("aresample=%d", source_rate));
+    if (cfg->adeclick_enabled) {
+        std::string a = sfmt("adeclick=t=%.1f:w=%.0f:o=%.0f", cfg->adeclick_threshold, cfg->adeclick_window, cfg->adeclick_overlap);
+        if (cfg->adeclick_method_s) a += ":m=s";
+        join(s, a);
+    }
+    join(s, sfmt("alimiter=limit=%.6f:attack=1:release=50:level_in=1:level_out=1:level=0:latency=1:asc=1:asc_level=0.8", DbToLinear(brickDB)));
+    join(s, "astats=metadata=1:measure_perchannel=all");
+    join(s, "aspectralstats=win_size=2048:win_func=hann:measure=all");
+    join(s, "ebur128=metadata=1:peak=sample+true:dualmono=true");
+    join(s, outputFormatSpec(*cfg));
+    if (buf && cap > 0) snprintf(buf, (size_t)cap, "%s", s.c_str());
+    if (ap) {
+        std::memset(ap, 0, sizeof(*ap));
+        ap->target_i = qfmt("%.2f", cfg->target_i); ap->target_tp = qfmt("%.2f", emittedTP); ap->target_lra = qfmt("%.1f", cfg->target_lra);
+        ap->measured_i = qfmt("%.2f", ms->input_i); ap->measured_tp = qfmt("%.2f", ms->input_tp);
+        ap->measured_lra = qfmt("%.2f", ms->input_lra); ap->measured_thresh = qfmt("%.2f", ms->input_thresh);
+        ap->offset = qfmt("%.2f", offset);
+        ap->adeclick_enabled = cfg->adeclick_enabled; ap->adeclick_threshold = qfmt("%.1f", cfg->adeclick_threshold);
+        ap->adeclick_window_ms = qfmt("%.0f", cfg->adeclick_window); ap->adeclick_overlap_pct = qfmt("%.0f", cfg->adeclick_overlap);
+        ap->brickwall_limit = qfmt("%.6f", DbToLinear(brickDB));
+    }
+    return (int)s.size();
+}
+
+// =====================================================================================================
+// orchestration (processor.go:29-216)
+// =====================================================================================================
+static double secs_of(int64_t ns) { return qfmt("%f", (double)ns / 1e9); }    // regions travel through "%f"-formatted filter options
+
+static int analyse_core(jt_ctx *h, const jt_host_config *base, int frame_samples, jt_process_result *out,
+                        jt_host_config *eff_out)
+{
+    int rc;
+    jt_analysis a1; std::memset(&a1, 0, sizeof(a1));
+    const int64_t n = h->n; const int sr = h->sr;
+    const int64_t nfr = (n + frame_samples - 1) / frame_samples;
+    const int64_t cap_meta = n / (sr / 10) + 2;
+    std::vector<double> fss((size_t)nfr), fpk((size_t)nfr);
+    std::vector<jt_frame_meta> meta((size_t)cap_meta);
+    if ((rc = jt_pass1(h, frame_samples, &a1, fss.data(), fpk.data(), nfr, meta.data(), cap_meta)) != JT_OK) return rc;
+    out->pass_ms[0] = h->timers.pass1_ms;
+    std::vector<jt_interval> iv((size_t)(n / (sr / 5) + 16));
+    int64_t niv = jt_host_build_intervals(sr, n, frame_samples, h->channels, fss.data(), fpk.data(), nfr, meta.data(), a1.n_frames_meta, 1,
+                                          iv.data(), (int64_t)iv.size());
+    if (niv > (int64_t)iv.size()) niv = (int64_t)iv.size();
+    jt_measurements &m = out->input;
+    if ((rc = jt_host_detect(&a1, iv.data(), niv, (double)n / sr, base->target_i, 1, &m)) != JT_OK) return rc;
+    // measureSpeechBands (analyser_bands.go:115-166)
+    if (m.has_speech_profile && m.speech_profile.region.duration_ns > 0) {
+        const double lo[2] = {1000.0, 6000.0}, hi[2] = {3000.0, 9000.0}; double db[2]; int ok[2];
+        rc = jt_band_rms(h, secs_of(m.speech_profile.region.start_ns), secs_of(m.speech_profile.region.duration_ns), lo, hi, 2, db, ok);
+        if (rc == JT_OK) {
+            if (ok[0]) m.speech_profile.body_band_rms = qfmt("%f", db[0]);
+            if (ok[1]) m.speech_profile.sib_band_rms = qfmt("%f", db[1]);
+            m.speech_profile.bands_measured = (ok[0] && ok[1]) ? 1 : 0;
+        }
+    }
+    // measureNoiseBands (analyser_noise_bands.go:65-119)
+    if (m.has_noise_profile && m.noise_profile.duration_ns > 0) {
+        double lo[15], hi[15], db[15]; int ok[15];
+        for (int i = 0; i < 15; ++i) jt_host_afftdn_band_edges(i, &lo[i], &hi[i]);
+        rc = jt_band_rms(h, secs_of(m.noise_profile.start_ns), secs_of(m.noise_profile.duration_ns), lo, hi, 15, db, ok);
+        if (rc == JT_OK) {
+            int finite = 0;
+            for (int i = 0; i < 15; ++i) { m.noise_profile.band_noise[i] = ok[i] ? qfmt("%f", db[i]) : 0.0; if (ok[i] && isFiniteD(db[i])) finite++; }
+            m.noise_profile.band_noise_n = 15; m.noise_profile.bands_measured = finite >= 10 ? 1 : 0;
+        }
+    }
+    jt_host_finish_measurements(&m);
+    jt_host_adapt(base, &m, eff_out, &out->diag);
+    out->effective = *eff_out;
+    out->input_lufs = m.input_i; out->input_tp_db = m.input_tp;
+    return JT_OK;
+}
+
+extern "C" int jt_analyse_only(jt_ctx *h, const jt_host_config *base, int frame_samples, jt_process_result *out)
+{
+    if (!h || !base || !out) return JT_E_INVAL;
+    std::memset(out, 0, sizeof(*out));
+    jt_host_config eff;
+    return analyse_core(h, base, frame_samples, out, &eff);
+}
+
+extern "C" int jt_process_audio(jt_ctx *h, const jt_host_config *base, int frame_samples, jt_process_result *out)
+{
+    if (!h || !base || !out) return JT_E_INVAL;
+    std::memset(out, 0, sizeof(*out));
+    int rc; jt_host_config eff;
+    if ((rc = analyse_core(h, base, frame_samples, out, &eff)) != JT_OK) return rc;
+    jt_measurements &m = out->input;
+    // Pass 2
+    jt_host_filter_spec(&eff, 2, out->pass2_spec, (int)sizeof(out->pass2_spec));
+    jt_filter_params fp; jt_host_filter_params(&eff, &fp);
+    if ((rc = jt_pass2(h, &fp, &out->filtered)) != JT_OK) return rc;
+    out->pass_ms[1] = h->timers.pass2_ms;
+    auto measure_regions = [&](int stage, jt_region_sample *rt, jt_region_sample *sp) {
+        if (m.has_noise_profile && m.noise_profile.duration_ns > 0)
+            (void)jt_region_measure(h, stage, secs_of(m.noise_profile.start_ns), secs_of(m.noise_profile.duration_ns), rt);
+        if (m.has_speech_profile && m.speech_profile.region.duration_ns > 0)
+            (void)jt_region_measure(h, stage, secs_of(m.speech_profile.region.start_ns), secs_of(m.speech_profile.region.duration_ns), sp);
+    };
+    measure_regions(2, &out->filtered_room_tone, &out->filtered_speech);
+    // Pass 3/4 (ApplyNormalisation, normalise.go:806-922)
+    if (!eff.loudnorm_enabled) return JT_OK;
+    const double outI = qfmt("%.3f", out->filtered.r128.integrated);
+    const double outTP = linearRatioToDB(qfmt("%.3f", out->filtered.r128.true_peak));
+    jt_limiter_plan plan; jt_host_plan_limiter(outI, outTP, &eff, &out->limiter, &plan);
+    jt_loudnorm_stats m3;
+    if ((rc = jt_pass3(h, &plan, eff.target_i, eff.target_tp, eff.target_lra, &m3)) != JT_OK) return rc;
+    out->pass_ms[2] = h->timers.pass3_ms;
+    m3.input_i = qfmt("%.2f", m3.input_i); m3.input_tp = qfmt("%.2f", m3.input_tp);
+    m3.input_lra = qfmt("%.2f", m3.input_lra); m3.input_thresh = qfmt("%.2f", m3.input_thresh);
+    out->measure = m3;
+    if ((std::isinf(m3.input_i) && m3.input_i < 0) || m3.input_i < -70.0) {
+        h->err = sfmt("cannot normalise silent audio (measured %.1f LUFS)", m3.input_i);
+        return JT_E_SILENT;
+    }
+    double effI, offs; int lin;
+    jt_host_calculate_linear_mode_target(m3.input_i, m3.input_tp, eff.target_i,
+                                         jt_host_loudnorm_internal_target_tp(eff.target_i, m3.input_tp, m3.input_i), &effI, &offs, &lin);
+    const double offset = effI - m3.input_i;
+    out->effective_target_i = effI; out->offset = offset; out->linear_possible = lin;
+    jt_host_config effcfg = eff; effcfg.target_i = effI;
+    jt_loudnorm_apply ap;
+    jt_host_pass4_spec(&effcfg, &m3, offset, &out->limiter, h->out_rate, nullptr, out->pass4_spec, (int)sizeof(out->pass4_spec), &ap);
+    if ((rc = jt_pass4(h, &plan, &ap, &out->final_, &out->loudnorm)) != JT_OK) return rc;
+    out->pass_ms[3] = h->timers.pass4_ms;
+    measure_regions(4, &out->final_room_tone, &out->final_speech);
+    out->has_region_samples = 1;
+    out->output_lufs = qfmt("%.3f", out->final_.r128.integrated);
+    out->output_tp_db = linearRatioToDB(qfmt("%.3f", out->final_.r128.true_peak));
+    out->within_target = std::fabs(out->output_lufs - effI) <= 0.5 ? 1 : 0;
+    return JT_OK;
+}
+
+extern "C" int64_t jt_host_sizeof(int which)
+{
+    switch (which) {
+    case 0: return sizeof(jt_interval);
+    case 1: return sizeof(jt_measurements);
+    case 2: return sizeof(jt_host_config);
+    case 3: return sizeof(jt_process_result);
+    case 4: return sizeof(jt_speech_candidate);
+    case 5: return sizeof(jt_noise_profile);
+    case 6: return sizeof(jt_limiter_decision);
+    case 7: return sizeof(jt_adaptive_diag);
+    case 8: return sizeof(jt_filter_params);
+    case 9: return sizeof(jt_loudnorm_apply);
+    case 10: return sizeof(jt_analysis);
+    case 11: return sizeof(jt_region_sample);
+    }
+    return -1;
+}
+
+// ---- granular VAD helpers, exported so the parity tests can mirror the reference's own table tests
+// (analyser_vad_test.go) one function at a time
+extern "C" int jt_host_vad_detect(const jt_interval *ivp, int64_t n, double seed, jt_measurements *m)
+{
+    if (!m || (n > 0 && !ivp)) return JT_E_INVAL;
+    std::memset(m, 0, sizeof(*m));
+    std::vector<jt_interval> iv(ivp, ivp + n);
+    detect_vad(iv, seed, m);
+    return JT_OK;
+}
+extern "C" void jt_host_vad_split(const jt_interval *ivp, int64_t n, double seed, double *otsu_raw, double *split, double *floor_, double *margin, int *tol)
+{
+    std::vector<jt_interval> iv(ivp, ivp + n);
+    Hist h = buildLevelHistogram(iv, 1.0);
+    std::vector<double> levels = vadLevels(iv);
+    double o = otsuSplit(h), sp = clampSplit(o, seed, percentileOfSorted(levels, 75));
+    if (otsu_raw) *otsu_raw = o;
+    if (split) *split = sp;
+    if (floor_) *floor_ = percentileFloor(levels, seed);
+    if (margin) *margin = hysteresisMargin(h, sp);
+    if (tol) { std::vector<bool> f(iv.size()); for (size_t i = 0; i < iv.size(); ++i) f[i] = isSpeechInterval(iv[i], sp); *tol = gapToleranceIntervals(f, kHop); }
+}
+extern "C" int jt_host_vad_speech_runs(const jt_interval *ivp, int64_t n, double split, double margin, int tol, jt_region *out, int cap)
+{
+    std::vector<jt_interval> iv(ivp, ivp + n);
+    std::vector<jt_region> r = buildSpeechRuns(iv, split, margin, tol, kHop);
+    for (int i = 0; i < (int)r.size() && i < cap; ++i) out[i] = r[i];
+    return (int)r.size();
+}
+extern "C" int jt_host_vad_gap_tolerance(const int *flags, int64_t n)
+{
+    std::vector<bool> f((size_t)n); for (int64_t i = 0; i < n; ++i) f[(size_t)i] = flags[i] != 0;
+    return gapToleranceIntervals(f, kHop);
+}
+extern "C" void jt_host_vad_gate_stats(const jt_interval *ivp, int64_t n, double split, const jt_region *region,
+                                       double *voiced_low, double *noise_high, double *separation)
+{
+    std::vector<jt_interval> iv(ivp, ivp + n);
+    std::vector<double> voiced, noise;
+    for (auto &s : iv) { double l = level_of(s); if (isFlooredLevel(l)) continue; if (l < split) noise.push_back(l); }
+    if (region) { std::vector<jt_interval> r = getIntervalsInRange(iv, region->start_ns, region->end_ns);
+                  for (auto &s : r) if (isSpeechInterval(s, split)) voiced.push_back(level_of(s)); }
+    std::sort(voiced.begin(), voiced.end()); std::sort(noise.begin(), noise.end());
+    double v = percentileOfSorted(voiced, 10.0), nh = percentileOfSorted(noise, 95.0);
+    *voiced_low = v; *noise_high = nh; *separation = v - nh;
+}
+extern "C" int jt_host_vad_noise_seed(const jt_interval *ivp, int64_t n, double *nf, double *thr)
+{
+    std::vector<jt_interval> iv(ivp, ivp + n);
+    double a = 0, b = 0; bool ok = estimateNoiseFloorAndThreshold(iv, &a, &b);
+    *nf = a; *thr = b; return ok ? 1 : 0;
+}
+extern "C" int jt_host_vad_pick_low_cluster(const jt_interval *ivp, int64_t n, double split, jt_region *out)
+{
+    std::vector<jt_interval> iv(ivp, ivp + n);
+    return pickLowClusterRegion(iv, split, kHop, out) ? 1 : 0;
+}
+extern "C" double jt_host_vad_floored_fraction(const jt_interval *ivp, int64_t n)
+{
+    double counted = 0, fl = 0;
+    for (int64_t i = 0; i < n; ++i) { double l = ivp[i].momentary_lufs; counted++; if (std::isnan(l) || l <= vadLevelFloorDB) fl++; }
+    return counted == 0 ? 0 : fl / counted;
+}

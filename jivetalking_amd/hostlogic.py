@@ -1,0 +1,179 @@
+"""ctypes binding of include/jt_host.h — the C++ host mirror of the reference's per-file control logic
+(internal/processor: VAD, AdaptConfig, filter-spec strings, normalisation planning, ProcessAudio)."""
+import ctypes as C
+import numpy as np
+from . import _lib as L
+
+JT_MAX_REGIONS = 512
+
+
+class Interval(C.Structure):
+    _fields_ = [("timestamp_ns", C.c_int64), ("rms_level", C.c_double), ("peak_level", C.c_double),
+                ("spectral", L.Spectral), ("spectral_found", C.c_int),
+                ("momentary_lufs", C.c_double), ("shortterm_lufs", C.c_double),
+                ("true_peak", C.c_double), ("sample_peak", C.c_double)]
+
+
+class Region(C.Structure):
+    _fields_ = [("start_ns", C.c_int64), ("end_ns", C.c_int64), ("duration_ns", C.c_int64)]
+
+
+class RegionMetrics(C.Structure):
+    _fields_ = [("rms_level", C.c_double), ("peak_level", C.c_double), ("crest_factor", C.c_double),
+                ("spectral", L.Spectral), ("momentary_lufs", C.c_double), ("shortterm_lufs", C.c_double),
+                ("true_peak", C.c_double), ("sample_peak", C.c_double)]
+
+
+class NoiseProfile(C.Structure):
+    _fields_ = [("start_ns", C.c_int64), ("duration_ns", C.c_int64), ("measured_noise_floor", C.c_double),
+                ("peak_level", C.c_double), ("crest_factor", C.c_double), ("entropy", C.c_double),
+                ("spectral", L.Spectral), ("band_noise", C.c_double * 15), ("band_noise_n", C.c_int),
+                ("bands_measured", C.c_int), ("warning", C.c_int)]
+
+
+class SpeechCandidate(C.Structure):
+    _fields_ = [("region", Region), ("sample", RegionMetrics), ("voicing_density", C.c_double),
+                ("body_band_rms", C.c_double), ("sib_band_rms", C.c_double), ("bands_measured", C.c_int),
+                ("score", C.c_double), ("original_start_ns", C.c_int64), ("original_duration_ns", C.c_int64),
+                ("was_refined", C.c_int)]
+
+
+class Measurements(C.Structure):
+    _fields_ = [
+        ("input_i", C.c_double), ("input_tp", C.c_double), ("input_lra", C.c_double), ("input_thresh", C.c_double),
+        ("target_offset", C.c_double), ("momentary", C.c_double), ("shortterm", C.c_double), ("sample_peak", C.c_double),
+        ("dynamics", L.Astats), ("floor_astats", C.c_double), ("spectral", L.Spectral),
+        ("floor", C.c_double), ("floor_source", C.c_int), ("floor_prescan", C.c_double),
+        ("room_tone_detect_level", C.c_double), ("voice_activated", C.c_int), ("floored_fraction", C.c_double),
+        ("reduction_headroom", C.c_double),
+        ("n_speech_regions", C.c_int), ("speech_regions", Region * JT_MAX_REGIONS),
+        ("n_candidates", C.c_int), ("candidates", SpeechCandidate * JT_MAX_REGIONS),
+        ("has_speech_profile", C.c_int), ("speech_profile", SpeechCandidate),
+        ("has_noise_profile", C.c_int), ("noise_profile", NoiseProfile),
+        ("has_room_tone_sample", C.c_int), ("room_tone_sample", RegionMetrics),
+        ("voiced_low_percentile", C.c_double), ("noise_high_percentile", C.c_double), ("gate_separation_db", C.c_double),
+        ("duration_s", C.c_double), ("vad_split", C.c_double), ("vad_margin", C.c_double), ("vad_gap_tol", C.c_int)]
+
+
+class BiquadCfg(C.Structure):
+    _fields_ = [("enabled", C.c_int), ("frequency", C.c_double), ("poles", C.c_int), ("width", C.c_double),
+                ("mix", C.c_double), ("transform_tdii", C.c_int)]
+
+
+class HostConfig(C.Structure):
+    _fields_ = [
+        ("downmix_enabled", C.c_int), ("analysis_enabled", C.c_int),
+        ("resample_enabled", C.c_int), ("resample_rate", C.c_int), ("resample_frame", C.c_int),
+        ("rumble_hp", BiquadCfg), ("bandlimit_lp", BiquadCfg),
+        ("nr_enabled", C.c_int), ("nr_strength", C.c_double), ("nr_patch_s", C.c_double), ("nr_research_s", C.c_double), ("nr_smooth", C.c_double),
+        ("afftdn_enabled", C.c_int), ("afftdn_nr", C.c_double), ("afftdn_custom", C.c_int), ("afftdn_track_noise", C.c_int),
+        ("afftdn_noise_floor", C.c_double), ("afftdn_band_noise", C.c_char * 256),
+        ("gate_enabled", C.c_int), ("gate_threshold", C.c_double), ("gate_ratio", C.c_double), ("gate_attack", C.c_double),
+        ("gate_release", C.c_double), ("gate_range", C.c_double), ("gate_knee", C.c_double), ("gate_makeup", C.c_double), ("gate_detection_set", C.c_int),
+        ("comp_enabled", C.c_int), ("comp_threshold_db", C.c_double), ("comp_ratio", C.c_double), ("comp_attack", C.c_double),
+        ("comp_release", C.c_double), ("comp_makeup_db", C.c_double), ("comp_knee", C.c_double), ("comp_mix", C.c_double),
+        ("deess_enabled", C.c_int), ("deess_intensity", C.c_double), ("deess_amount", C.c_double), ("deess_frequency", C.c_double),
+        ("adeclick_enabled", C.c_int), ("adeclick_threshold", C.c_double), ("adeclick_window", C.c_double), ("adeclick_overlap", C.c_double), ("adeclick_method_s", C.c_int),
+        ("loudnorm_enabled", C.c_int), ("target_i", C.c_double), ("target_tp", C.c_double), ("target_lra", C.c_double),
+        ("dual_mono", C.c_int), ("linear", C.c_int)]
+
+
+class AdaptiveDiag(C.Structure):
+    _fields_ = [("gate_quiet_speech_estimate", C.c_double), ("gate_separation", C.c_double), ("gate_speech_headroom", C.c_double),
+                ("gate_threshold_unclamped", C.c_double), ("gate_depth_db", C.c_double), ("gate_narrow_gap", C.c_int),
+                ("afftdn_enabled", C.c_int), ("afftdn_noise_floor_db", C.c_double), ("afftdn_disabled_voice_activated", C.c_int),
+                ("afftdn_custom", C.c_int)]
+
+
+class LimiterDecision(C.Structure):
+    _fields_ = [("pre_gain_db", C.c_double), ("ceiling_db", C.c_double), ("gain_db", C.c_double), ("filtered_tp", C.c_double),
+                ("needed", C.c_int), ("clamped", C.c_int), ("pass3_prefix", C.c_char * 256)]
+
+
+class ProcessResult(C.Structure):
+    _fields_ = [("input", Measurements), ("effective", HostConfig), ("diag", AdaptiveDiag),
+                ("filtered", L.Analysis), ("limiter", LimiterDecision), ("measure", L.LoudnormStats),
+                ("effective_target_i", C.c_double), ("offset", C.c_double), ("linear_possible", C.c_int),
+                ("final_", L.Analysis), ("loudnorm", L.LoudnormStats),
+                ("filtered_room_tone", L.RegionSample), ("filtered_speech", L.RegionSample),
+                ("final_room_tone", L.RegionSample), ("final_speech", L.RegionSample), ("has_region_samples", C.c_int),
+                ("output_lufs", C.c_double), ("output_tp_db", C.c_double), ("input_lufs", C.c_double), ("input_tp_db", C.c_double),
+                ("within_target", C.c_int), ("pass2_spec", C.c_char * 2048), ("pass4_spec", C.c_char * 2048),
+                ("pass_ms", C.c_double * 4)]
+
+
+SIZEOF_IDS = {0: Interval, 1: Measurements, 2: HostConfig, 3: ProcessResult, 4: SpeechCandidate, 5: NoiseProfile,
+              6: LimiterDecision, 7: AdaptiveDiag, 8: L.FilterParams, 9: L.LoudnormApply, 10: L.Analysis, 11: L.RegionSample}
+
+HOST_SYMBOLS = ["jt_host_build_intervals", "jt_host_detect", "jt_host_finish_measurements", "jt_host_afftdn_band_edges",
+                "jt_host_default_config", "jt_host_adapt", "jt_host_filter_spec", "jt_host_filter_params",
+                "jt_host_calculate_limiter_ceiling", "jt_host_calculate_pre_gain", "jt_host_plan_limiter",
+                "jt_host_calculate_linear_mode_target", "jt_host_loudnorm_internal_target_tp", "jt_host_pass4_spec",
+                "jt_process_audio", "jt_analyse_only", "jt_host_vad_detect", "jt_host_vad_split", "jt_host_vad_speech_runs",
+                "jt_host_vad_gap_tolerance", "jt_host_vad_gate_stats", "jt_host_vad_noise_seed",
+                "jt_host_vad_pick_low_cluster", "jt_host_vad_floored_fraction", "jt_host_sizeof"]
+
+
+def lib():
+    l = L.load()
+    l.jt_host_sizeof.restype = C.c_int64
+    l.jt_host_build_intervals.restype = C.c_int64
+    l.jt_host_loudnorm_internal_target_tp.restype = C.c_double
+    l.jt_host_vad_floored_fraction.restype = C.c_double
+    l.jt_host_finish_measurements.restype = None
+    l.jt_host_afftdn_band_edges.restype = None
+    l.jt_host_default_config.restype = None
+    l.jt_host_adapt.restype = None
+    l.jt_host_filter_params.restype = None
+    l.jt_host_calculate_limiter_ceiling.restype = None
+    l.jt_host_calculate_pre_gain.restype = None
+    l.jt_host_plan_limiter.restype = None
+    l.jt_host_calculate_linear_mode_target.restype = None
+    l.jt_host_vad_split.restype = None
+    l.jt_host_vad_gate_stats.restype = None
+    return l
+
+
+def default_config():
+    c = HostConfig()
+    lib().jt_host_default_config(C.byref(c))
+    return c
+
+
+def filter_spec(cfg, pass_no=2):
+    buf = C.create_string_buffer(4096)
+    lib().jt_host_filter_spec(C.byref(cfg), C.c_int(pass_no), buf, C.c_int(4096))
+    return buf.value.decode()
+
+
+def adapt(base, meas):
+    eff = HostConfig(); diag = AdaptiveDiag()
+    lib().jt_host_adapt(C.byref(base), C.byref(meas), C.byref(eff), C.byref(diag))
+    return eff, diag
+
+
+def make_intervals(rows):
+    """rows: list of dicts (timestamp_ns, rms_level, momentary_lufs, centroid, entropy, ...)"""
+    arr = (Interval * len(rows))()
+    for i, r in enumerate(rows):
+        iv = arr[i]
+        iv.timestamp_ns = int(r.get("timestamp_ns", i * 250_000_000))
+        iv.rms_level = r.get("rms_level", 0.0); iv.peak_level = r.get("peak_level", 0.0)
+        iv.momentary_lufs = r.get("momentary_lufs", 0.0); iv.shortterm_lufs = r.get("shortterm_lufs", 0.0)
+        iv.true_peak = r.get("true_peak", 0.0); iv.sample_peak = r.get("sample_peak", 0.0)
+        iv.spectral_found = int(r.get("spectral_found", 1))
+        for k in L.SPECTRAL_KEYS:
+            setattr(iv.spectral, k, float(r.get(k, 0.0)))
+    return arr
+
+
+def process_audio(engine, base=None, frame_samples=4096, analyse_only=False):
+    """jt_process_audio / jt_analyse_only on the PCM already uploaded to `engine`."""
+    l = lib()
+    base = base or default_config()
+    res = ProcessResult()
+    fn = l.jt_analyse_only if analyse_only else l.jt_process_audio
+    rc = fn(engine.h, C.byref(base), C.c_int(frame_samples), C.byref(res))
+    if rc != 0:
+        raise L.JtError(rc, l.jt_last_error(engine.h).decode())
+    return res
