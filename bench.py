@@ -72,7 +72,7 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
-    from jivetalking_amd import Engine, synth, pipeline
+    from jivetalking_amd import Engine, synth, hostlogic, shard
     sr = 48000
     seconds = args.minutes * 60.0
     x = synth.speech_like_torch(seconds, sr, seed=1000 + rank, device=f"cuda:{local_rank}")
@@ -81,8 +81,11 @@ def main():
     eng = Engine(local_rank)
     eng.attach_device_pcm(x.data_ptr(), n, sr, 1, keepalive=x)
 
+    base = hostlogic.default_config()
+
     def step():
-        return pipeline.process_resident(eng, n, sr, 4096, want_meta=True)
+        # ProcessAudio mirror in C++ (jt_process_audio): four GPU passes + VAD / AdaptConfig / limiter planning between them
+        return hostlogic.process_audio(eng, base, 4096)
 
     res = None
     for _ in range(args.warmup):
@@ -102,10 +105,7 @@ def main():
         nlm_ms.append(t["nlm_ms"]); p_ms.append([t["pass1_ms"], t["pass2_ms"], t["pass3_ms"], t["pass4_ms"]])
     barrier()
     dt = time.perf_counter() - t0
-    if world > 1:
-        tt = torch.tensor([dt], device=f"cuda:{local_rank}", dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
+    dt = shard.max_over_ranks(dt, device=f"cuda:{local_rank}")
 
     if rank == 0:
         import numpy as np
@@ -124,9 +124,10 @@ def main():
             "vs_baseline": None, "dtype": "f32/f64", "data": "synthetic",
             "config": {"workload": f"1 x {args.minutes:g} min 48 kHz mono f32 PCM per GPU, full 4-pass pipeline, input resident in HBM",
                        "files_per_gpu_per_step": 1, "adeclick": "pass-through (SURVEY f4 next row)",
-                       "adaptive": "minimal (static afftdn floor from momentary p10)"},
-            "result": {"output_lufs": round(res["output_lufs"], 3), "output_dbtp": round(res["output_tp_db"], 3),
-                       "input_lufs": round(res["input"]["r128"]["integrated"], 3)},
+                       "adaptive": "full host mirror (VAD, speech election, AdaptConfig, band RMS) in C++",
+                       "pass2_spec": res.pass2_spec.decode()},
+            "result": {"output_lufs": round(res.output_lufs, 3), "output_dbtp": round(res.output_tp_db, 3),
+                       "input_lufs": round(res.input_lufs, 3), "within_target": bool(res.within_target)},
             "pass_ms": {"pass1": round(float(pm[0]), 3), "pass2": round(float(pm[1]), 3),
                         "pass3": round(float(pm[2]), 3), "pass4": round(float(pm[3]), 3)},
             "pipeline_hbm": {"algorithmic_bytes_per_file": alg_bytes_file,

@@ -1,0 +1,122 @@
+"""End-to-end parity: jt_process_audio (four passes on the GPU, C++ host logic between them) against the same
+pipeline composed from the CPU oracle with the SAME effective parameters, plus the north_star landing targets."""
+import ctypes as C
+import numpy as np
+import pytest
+
+from jivetalking_amd import synth, hostlogic as H, _lib as L
+
+pytestmark = pytest.mark.gpu
+SR = 48000
+
+
+def oracle_pass2(orc, x, fp, sr):
+    y = x
+    if fp.hp_enabled:
+        y = orc.biquad_f32(y, 0, fp.hp_freq, sr, fp.hp_q)
+    if fp.lp_enabled:
+        y = orc.biquad_f32(y, 1, fp.lp_freq, sr, fp.lp_q)
+    if fp.nlm_enabled:
+        y = orc.anlmdn(y, sr, fp.nlm_strength, fp.nlm_patch_s, fp.nlm_research_s, fp.nlm_smooth)
+    if fp.fft_enabled:
+        bn = list(fp.fft_band_noise) if fp.fft_custom else None
+        y = orc.afftdn(y, sr, fp.fft_nr, fp.fft_nf if fp.fft_nf < 0 else -50.0, bn)
+    yd = y.astype(np.float64)
+    if fp.gate_enabled:
+        yd = orc.agate(yd, sr, fp.gate_threshold, fp.gate_ratio, fp.gate_attack_ms, fp.gate_release_ms, fp.gate_range, fp.gate_knee, fp.gate_makeup)
+    if fp.comp_enabled:
+        yd = orc.acompressor(yd, sr, fp.comp_threshold, fp.comp_ratio, fp.comp_attack_ms, fp.comp_release_ms, fp.comp_makeup, fp.comp_knee, fp.comp_mix)
+    if fp.deess_enabled:
+        yd = orc.deesser(yd, sr, fp.deess_i, fp.deess_m, fp.deess_f)
+    yf = yd.astype(np.float32)          # dbl -> flt before aspectralstats
+    s16 = orc.f64_to_s16(orc.swr_f64(yf.astype(np.float64), sr, 44100, True))
+    return yf, s16
+
+
+@pytest.fixture(scope="module")
+def processed(engine):
+    x = synth.speech_like(45.0, SR, seed=21)
+    engine.upload_pcm(x, SR, 1)
+    res = H.process_audio(engine)
+    return x, res, engine.download_s16(2), engine.download_s16(4)
+
+
+def test_pipeline_lands_on_target(processed, oracle):
+    x, res, p2, p4 = processed
+    # measured independently by the oracle on the delivered s16 PCM
+    e = oracle.ebur128(p4.astype(np.float64) / 32768.0, 44100, True, True)
+    assert abs(e["integrated"] - (-16.0)) <= 0.1, e["integrated"]          # north_star: -16.0 +/- 0.1 LUFS
+    assert 20 * np.log10(e["true_peak"]) <= -1.0                            # <= -1.0 dBTP
+    assert abs(res.output_lufs - e["integrated"]) < 0.01
+    assert res.within_target == 1 and res.loudnorm.normalization_type_dynamic == 0
+    assert p4.size == p2.size == int(np.ceil(x.size * 147 / 160))
+
+
+def test_pass1_measurements_match_oracle(processed, oracle):
+    x, res, _, _ = processed
+    e = oracle.ebur128(x.astype(np.float64), SR, True, True)
+    assert abs(res.input.input_i - e["integrated"]) < 0.002                 # %.3f-quantised on the host side
+    assert abs(res.input.input_lra - e["lra"]) < 0.011
+    assert abs(res.input.input_tp - 20 * np.log10(e["true_peak"])) < 0.05   # '%.3f' linear quantisation of the metadata
+    a = oracle.astats(x.astype(np.float64), SR)
+    assert abs(res.input.dynamics.rms_level - a["rms_level_db"]) < 1e-5
+    assert abs(res.input.dynamics.peak_level - a["peak_level_db"]) < 1e-5
+
+
+def test_pass2_output_matches_oracle_chain(processed, oracle):
+    x, res, p2, _ = processed
+    fp = L.FilterParams()
+    H.lib().jt_host_filter_params(C.byref(res.effective), C.byref(fp))
+    _, ref = oracle_pass2(oracle, x, fp, SR)
+    assert ref.size == p2.size
+    d = np.abs(ref.astype(np.int32) - p2.astype(np.int32))
+    # afftdn (f32 FFT schedule) dominates the difference: <= 3 LSB of s16 anywhere, < 0.3 LSB on average
+    assert d.max() <= 3, d.max()
+    assert d.mean() < 0.3
+
+
+def test_pass3_pass4_match_oracle(processed, oracle):
+    x, res, p2, p4 = processed
+    # Pass 3 (no limiter prefix expected on this material)
+    assert res.limiter.needed == 0
+    up = oracle.swr_f32(p2.astype(np.float32) / 32768.0, 44100, 192000, True).astype(np.float64)
+    m = oracle.loudnorm_measure(up, 192000, True)
+    assert abs(res.measure.input_i - m["input_i"]) <= 0.011                 # both rounded to the JSON's %.2f
+    assert abs(res.measure.input_tp - m["input_tp"]) <= 0.011
+    # Pass 4: linear gain -> brickwall -> (flt) -> s16
+    gain = 10 ** ((res.effective_target_i - res.measure.input_i) / 20.0)
+    z = oracle.alimiter(p2.astype(np.float64) / 32768.0 * gain, 44100, 0.803526, 1.0, 50.0)
+    ref = oracle.f64_to_s16(z.astype(np.float32).astype(np.float64))
+    assert np.array_equal(ref, p4)                                         # bit-exact: same doubles, same limiter state machine
+
+
+def test_region_samples_and_specs_present(processed):
+    _, res, _, _ = processed
+    assert res.pass2_spec.decode().startswith("aformat=channel_layouts=mono,highpass=f=80")
+    assert "loudnorm=I=-16.00" in res.pass4_spec.decode()
+    if res.input.has_noise_profile:
+        assert res.filtered_room_tone.frames > 0 and res.final_room_tone.frames > 0
+        # noise reduction + gate must not raise the room tone
+        assert res.filtered_room_tone.rms_level <= res.input.room_tone_sample.rms_level + 1.0
+
+
+def test_analyse_only_matches_process_pass1(engine):
+    x = synth.speech_like(20.0, SR, seed=22)
+    engine.upload_pcm(x, SR, 1)
+    a = H.process_audio(engine, analyse_only=True)
+    b = H.process_audio(engine)
+    assert a.input.input_i == b.input.input_i and a.input.floor == b.input.floor
+    assert H.filter_spec(a.effective, 2) == H.filter_spec(b.effective, 2)
+
+
+def test_stereo_downmix_and_silence_guard(engine):
+    x = synth.speech_like(15.0, SR, seed=23)
+    st = np.stack([x, 0.5 * x], axis=1).reshape(-1)
+    engine.upload_pcm(st, SR, 2)
+    r = H.process_audio(engine)
+    assert abs(r.output_lufs + 16.0) <= 0.15
+    z = np.zeros(SR * 12, np.float32)
+    engine.upload_pcm(z, SR, 1)
+    with pytest.raises(L.JtError) as ei:
+        H.process_audio(engine)
+    assert ei.value.code in (L.JT_E_SILENT, L.JT_E_UNSUPPORTED)

@@ -1,0 +1,60 @@
+"""N>1 path on CPU: world_size-2 gloo processes exercise the file->rank partition and the timing reduction that
+bench.py uses (one process per GPU, no data-path collective)."""
+import os
+import subprocess
+import sys
+import textwrap
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+WORKER = textwrap.dedent('''
+    import os, sys, json
+    sys.path.insert(0, %r)
+    import torch.distributed as dist
+    from jivetalking_amd import shard
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%%s" %% os.environ["JT_PORT"],
+                            rank=int(os.environ["RANK"]), world_size=int(os.environ["WORLD_SIZE"]))
+    rank, world = shard.rank_world()
+    durs = [3600, 600, 600, 1200, 300, 2400, 60]
+    mine = shard.assign_files(len(durs), world, rank, durs)
+    shard.barrier()
+    t = shard.max_over_ranks(1.0 + rank)                 # max wall-clock over ranks
+    total = shard.sum_over_ranks(sum(durs[i] for i in mine))
+    print(json.dumps({"rank": rank, "mine": mine, "tmax": t, "total": total}))
+    dist.destroy_process_group()
+''') % ROOT
+
+
+def test_partition_is_disjoint_complete_and_balanced():
+    from jivetalking_amd import shard
+    durs = [3600, 600, 600, 1200, 300, 2400, 60, 60, 1800]
+    for world in (1, 2, 4, 8):
+        parts = [shard.assign_files(len(durs), world, r, durs) for r in range(world)]
+        flat = sorted(i for p in parts for i in p)
+        assert flat == list(range(len(durs)))
+        loads = [sum(durs[i] for i in p) for p in parts]
+        assert max(loads) <= max(max(durs), sum(durs) / world * 1.5)
+    # one file per GPU for the 8 x 60 min configuration (BASELINE.json configs[2])
+    parts = [shard.assign_files(8, 8, r, [3600] * 8) for r in range(8)]
+    assert sorted(p[0] for p in parts) == list(range(8)) and all(len(p) == 1 for p in parts)
+
+
+def test_two_rank_gloo_run(tmp_path):
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER)
+    port = str(29500 + (os.getpid() % 2000))
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", JT_PORT=port, MASTER_ADDR="127.0.0.1")
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = []
+    for p in procs:
+        o, e = p.communicate(timeout=180)
+        assert p.returncode == 0, e[-2000:]
+        outs.append(o.strip().splitlines()[-1])
+    import json
+    res = sorted((json.loads(o) for o in outs), key=lambda d: d["rank"])
+    assert sorted(res[0]["mine"] + res[1]["mine"]) == list(range(7))
+    assert not set(res[0]["mine"]) & set(res[1]["mine"])
+    assert res[0]["tmax"] == res[1]["tmax"] == 2.0            # MAX over ranks
+    assert res[0]["total"] == res[1]["total"] == 8760.0       # every second of audio assigned exactly once
