@@ -122,21 +122,7 @@ struct AnalysisHost {
     std::vector<jt_spectral> hops; int64_t nblocks = 0, nhops = 0; int blk = 0;
 };
 
-static void run_astats(jt_ctx *h, const float *x, int64_t n, int sr, jt_astats *out)
-{
-    const int64_t chunk = 16384;
-    const int64_t nchunks = (n + chunk - 1) / chunk;
-    h->astats_chunks.ensure((size_t)nchunks);
-    h->ehist.ensure(8192); h->ehist.zero(h->stream);
-    h->d_scr2.ensure((size_t)nchunks * 2);
-    DevBuf<float> g; g.ensure((size_t)n);
-    jt_astats_run(x, n, sr, g.p, h->d_scr2.p, h->d_scr2.p + nchunks, h->astats_chunks.p, chunk, nchunks, h->ehist.p, h->stream);
-    std::vector<AstatsChunk> hc((size_t)nchunks); std::vector<unsigned long long> eh(8192);
-    JT_HIP(hipMemcpyAsync(hc.data(), h->astats_chunks.p, sizeof(AstatsChunk) * nchunks, hipMemcpyDeviceToHost, h->stream));
-    JT_HIP(hipMemcpyAsync(eh.data(), h->ehist.p, sizeof(unsigned long long) * 8192, hipMemcpyDeviceToHost, h->stream));
-    JT_HIP(hipStreamSynchronize(h->stream));
-    jt_astats_merge(hc.data(), nchunks, eh.data(), sr, out);
-}
+static void run_astats(jt_ctx *h, const float *x, int64_t n, int sr, jt_astats *out) { jt_astats_device(h, x, n, sr, out); }
 
 // K-weighted block energies, sample peaks, true peaks (streaming swr to 192 kHz) and R128 finishing
 static void run_r128(jt_ctx *h, const float *x, int64_t n, int sr, bool dualmono, bool want_tp, AnalysisHost *A)
@@ -419,7 +405,11 @@ extern "C" int jt_pass2(jt_ctx *h, const jt_filter_params *p, jt_analysis *out)
     }
     check_cancel(h);
     DynParams d; jt_dyn_design(p, sr, &d);
-    if (d.gate_on || d.comp_on || d.deess_on) { launch_dynamics(cur, nxt, nullptr, n, d, h->stream); advance(); }
+    if (d.gate_on || d.comp_on || d.deess_on) {
+        h->f64_a.ensure((size_t)n); if (d.deess_on) h->f64_b.ensure((size_t)n);
+        h->d_scr3.ensure((size_t)(n / 256 + 4));
+        launch_dynamics(cur, nxt, h->f64_a.p, h->f64_b.p, h->d_scr3.p, n, d, h->stream); advance();
+    }
     check_cancel(h);
     analyse_mono(h, cur, n, sr, true, out, nullptr, 0);
     out->n_input_frames = 0;
@@ -482,14 +472,16 @@ static void run_loudnorm_measure(jt_ctx *h, const int16_t *s16, const double *f6
         for (size_t i = 0; i < bf.size(); ++i) bf[i] = (float)pl.bank[i];
         h->bank_f.ensure(bf.size());
         JT_HIP(hipMemcpyAsync(h->bank_f.p, bf.data(), sizeof(float) * bf.size(), hipMemcpyHostToDevice, h->stream));
-        launch_resample_kweight_s16(s16, n, h->bank_f.p, pl.phase_count, pl.filter_length, pl.center, pl.step, m_total, blk, pre, rlb,
-                                    h->d_scr0.p, h->d_scr0.p + nalloc, nalloc, h->stream);
+        h->stream_f.ensure((size_t)m_total);
+        launch_resample_stream_s16_f32(s16, n, h->bank_f.p, pl.phase_count, pl.filter_length, pl.center, pl.step, m_total, h->stream_f.p, h->stream);
+        launch_kweight_blocks_f32(h->stream_f.p, m_total, blk, pre, rlb, h->d_scr0.p, h->d_scr0.p + nalloc, nalloc, h->stream);
         JT_HIP(hipStreamSynchronize(h->stream));
     } else {
         h->bank_d.ensure(pl.bank.size());
         JT_HIP(hipMemcpyAsync(h->bank_d.p, pl.bank.data(), sizeof(double) * pl.bank.size(), hipMemcpyHostToDevice, h->stream));
-        launch_resample_kweight_f64(f64, n, h->bank_d.p, pl.phase_count, pl.filter_length, pl.center, pl.step, m_total, blk, pre, rlb,
-                                    h->d_scr0.p, h->d_scr0.p + nalloc, nalloc, h->stream);
+        h->stream_d.ensure((size_t)m_total);
+        launch_resample_stream_f64(f64, n, h->bank_d.p, pl.phase_count, pl.filter_length, pl.center, pl.step, m_total, h->stream_d.p, h->stream);
+        launch_kweight_blocks_f64(h->stream_d.p, m_total, blk, pre, rlb, h->d_scr0.p, h->d_scr0.p + nalloc, nalloc, h->stream);
         JT_HIP(hipStreamSynchronize(h->stream));
     }
     std::vector<double> hb((size_t)nalloc * 2);
@@ -697,7 +689,8 @@ extern "C" int jt_op_dynamics(jt_ctx *h, const float *in, float *out, int64_t n,
     JT_REQUIRE(in && out && p && n > 0, JT_E_INVAL, "op_dynamics: bad arguments");
     DevBuf<float> a, b; h2d(h, a, in, (size_t)n); b.ensure((size_t)n);
     DynParams d; jt_dyn_design(p, sr, &d);
-    launch_dynamics(a.p, b.p, nullptr, n, d, h->stream);
+    DevBuf<double> t1, t2, st; t1.ensure((size_t)n); t2.ensure((size_t)n); st.ensure((size_t)(n / 256 + 4));
+    launch_dynamics(a.p, b.p, t1.p, t2.p, st.p, n, d, h->stream);
     d2h(h, out, b.p, (size_t)n);
     JT_API_END(h)
 }

@@ -77,27 +77,12 @@ struct DynParams {
     double d_intensity, d_maxdess, d_iir;
 };
 void jt_dyn_design(const jt_filter_params *p, int sr, DynParams *d);
-void launch_dynamics(const float *in, float *out_f32, double *out_f64, int64_t n, const DynParams &d, hipStream_t s);
+void launch_dynamics(const float *in, float *out_f32, double *tmp64, double *tmp64b, double *states, int64_t n, const DynParams &d, hipStream_t s);
 
-// astats
-struct AstatsChunk {   // per-lane chunk summary, merged in order on the host
-    double min, max, min_non_zero, sigma_x, sigma_x2, min_diff, max_diff, diff1_sum, diff1_sum_x2;
-    double first, last;              // first / last sample of the chunk
-    double first_nz_sign, last_nz_sign; // +1 / -1, 0 if the chunk has no non-zero sample
-    double zero_runs;                // sign changes between consecutive non-zero samples inside the chunk
-    double min_sigma, max_sigma;     // exp-averaged power extrema (valid samples only)
-    double noise_floor, noise_floor_count;
-    double abs_peak;
-    int64_t count;
-    // run bookkeeping at the chunk's own min / max value
-    double min_count, min_runs, min_head_run, min_tail_run, min_all;   // *_all = 1 when the whole chunk equals min
-    double max_count, max_runs, max_head_run, max_tail_run, max_all;
-    uint64_t mask_or, mask_and;
-};
-void jt_astats_run(const float *in, int64_t n, int sr, float *g_scratch /*n*/, double *zs /*nchunks*/, double *carry /*nchunks*/,
-                   AstatsChunk *chunks, int64_t chunk, int64_t nchunks, unsigned long long *ehist, hipStream_t s);
+// astats (k_astats.hip)
+struct jt_ctx;
+void jt_astats_device(jt_ctx *h, const float *x, int64_t n, int sr, jt_astats *out);
 void launch_biquad_di_f32(const float *in, float *out, int64_t n, BiquadF32 hp, BiquadF32 lp, hipStream_t s);
-void jt_astats_merge(const AstatsChunk *chunks, int64_t nchunks, const unsigned long long *ehist, int sr, jt_astats *out);
 
 // limiter (exact, chunked at provably clean points)
 void launch_absmax_blocks_f64(const double *in, int64_t n, int blk, double *out_max, int64_t nblk, hipStream_t s);
@@ -112,13 +97,11 @@ void launch_true_peak_f32(const float *in, int64_t n, const double *bank, int ph
                           int64_t step, int blk, double *block_tp, int64_t nblocks_alloc, int64_t m_total, hipStream_t s);
 void launch_true_peak_f64(const double *in, int64_t n, const double *bank, int phase_count, int filter_length, int center,
                           int64_t step, int blk, double *block_tp, int64_t nblocks_alloc, int64_t m_total, hipStream_t s);
-// fused resample -> K-weight -> block sums / sample peak at the output rate (loudnorm measurement, Pass 3)
-void launch_resample_kweight_s16(const int16_t *in, int64_t n, const float *bankf, int phase_count, int filter_length, int center,
-                                 int64_t step, int64_t m_total, int blk, BiquadF64 pre, BiquadF64 rlb,
-                                 double *block_sums, double *block_peaks, int64_t nblocks_alloc, hipStream_t s);
-void launch_resample_kweight_f64(const double *in, int64_t n, const double *bank, int phase_count, int filter_length, int center,
-                                 int64_t step, int64_t m_total, int blk, BiquadF64 pre, BiquadF64 rlb,
-                                 double *block_sums, double *block_peaks, int64_t nblocks_alloc, hipStream_t s);
+// Pass-3 192 kHz streams (FLT path from s16, DBL path after the limiter prefix); K-weighted afterwards by launch_kweight_blocks_*
+void launch_resample_stream_s16_f32(const int16_t *in, int64_t n, const float *bankf, int phase_count, int filter_length, int center,
+                                    int64_t step, int64_t m_total, float *out, hipStream_t s);
+void launch_resample_stream_f64(const double *in, int64_t n, const double *bank, int phase_count, int filter_length, int center,
+                                int64_t step, int64_t m_total, double *out, hipStream_t s);
 void launch_f64_to_s16(const double *in, int16_t *out, float *out_f32, int64_t n, int round_via_float, hipStream_t s);
 void launch_f32_to_f64(const float *in, double *out, int64_t n, hipStream_t s);
 
@@ -157,9 +140,10 @@ struct jt_ctx {
     DevBuf<int16_t> s16_p2, s16_p4;     // Pass-2 / Pass-4 outputs
     int64_t m_p2 = 0, m_p4 = 0; int out_rate = 0;
     DevBuf<double> f64_a, f64_b;        // f64 ping-pong at output rate
+    DevBuf<float> stream_f; DevBuf<double> stream_d;   // 192 kHz loudnorm-measurement stream
     // scratch
     DevBuf<double> d_scr0, d_scr1, d_scr2, d_scr3;
-    DevBuf<AstatsChunk> astats_chunks; DevBuf<unsigned long long> ehist;
+    DevBuf<unsigned long long> ehist; DevBuf<float> as_g, as_p;
     DevBuf<jt_spectral> spec_hops;
     DevBuf<float2> twiddle; int twiddle_n = 0; DevBuf<float> hann; int hann_n = 0;
     DevBuf<double> bank_d; DevBuf<float> bank_f;

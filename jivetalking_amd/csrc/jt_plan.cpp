@@ -250,79 +250,6 @@ void jt_dyn_design(const jt_filter_params *p, int sr, DynParams *d)
     }
 }
 
-// ---------------------------------------------------------------- astats ordered merge (af_astats.c semantics)
-void jt_astats_merge(const AstatsChunk *c, int64_t nc, const unsigned long long *ehist, int sr, jt_astats *o)
-{
-    (void)sr;
-    std::memset(o, 0, sizeof(*o));
-    double mn = DBL_MAX, mx = -DBL_MAX, mnz = DBL_MAX, sx = 0, sx2 = 0, mind = DBL_MAX, maxd = 0, d1 = 0, d2 = 0;
-    double min_sig = DBL_MAX, max_sig = 0, nf = DBL_MAX, nfc = 0;
-    int64_t count = 0; double zr = 0; double run_sign = -1.0;   // FFSIGN(NaN) == -1
-    uint64_t mor = 0, mand = ~0ull;
-    for (int64_t k = 0; k < nc; ++k) {
-        const AstatsChunk &a = c[k];
-        if (a.count == 0) continue;
-        mn = std::min(mn, a.min); mx = std::max(mx, a.max); mnz = std::min(mnz, a.min_non_zero);
-        sx += a.sigma_x; sx2 += a.sigma_x2;
-        mind = std::min(mind, a.min_diff); maxd = std::max(maxd, a.max_diff); d1 += a.diff1_sum; d2 += a.diff1_sum_x2;
-        min_sig = std::min(min_sig, a.min_sigma); max_sig = std::max(max_sig, a.max_sigma);
-        if (a.noise_floor < nf) { nf = a.noise_floor; nfc = a.noise_floor_count; }
-        else if (a.noise_floor == nf) nfc += a.noise_floor_count;
-        if (a.first_nz_sign != 0) {
-            if (a.first_nz_sign != run_sign) zr += 1;
-            zr += a.zero_runs;
-            run_sign = a.last_nz_sign;
-        }
-        count += a.count; mor |= a.mask_or; mand &= a.mask_and;
-    }
-    // run statistics at the global extrema
-    double min_count = 0, min_runs = 0, max_count = 0, max_runs = 0, carry_min = 0, carry_max = 0;
-    for (int64_t k = 0; k < nc; ++k) {
-        const AstatsChunk &a = c[k];
-        if (a.count == 0) continue;
-        if (a.min == mn) {
-            min_count += a.min_count;
-            if (a.min_all) carry_min += a.min_head_run;
-            else {
-                if (a.min_head_run > 0) { double r = carry_min + a.min_head_run; min_runs += r * r; carry_min = 0; }
-                else if (carry_min > 0) { min_runs += carry_min * carry_min; carry_min = 0; }
-                min_runs += a.min_runs; carry_min = a.min_tail_run;
-            }
-        } else if (carry_min > 0) { min_runs += carry_min * carry_min; carry_min = 0; }
-        if (a.max == mx) {
-            max_count += a.max_count;
-            if (a.max_all) carry_max += a.max_head_run;
-            else {
-                if (a.max_head_run > 0) { double r = carry_max + a.max_head_run; max_runs += r * r; carry_max = 0; }
-                else if (carry_max > 0) { max_runs += carry_max * carry_max; carry_max = 0; }
-                max_runs += a.max_runs; carry_max = a.max_tail_run;
-            }
-        } else if (carry_max > 0) { max_runs += carry_max * carry_max; carry_max = 0; }
-    }
-    min_runs += carry_min * carry_min; max_runs += carry_max * carry_max;
-    if (count == 0) return;
-    auto DB = [](double x) { return std::log10(x) * 20; };
-    o->dc_offset = sx / count; o->min_level = mn; o->max_level = mx;
-    o->min_difference = mind; o->max_difference = maxd;
-    o->mean_difference = d1 / (count - 1); o->rms_difference = std::sqrt(d2 / (count - 1));
-    o->peak_level = DB(std::max(-mn, mx));
-    o->rms_level = DB(std::sqrt(sx2 / count));
-    o->rms_peak = DB(std::sqrt(max_sig));
-    o->rms_trough = min_sig != 1 ? DB(std::sqrt(min_sig)) : 0.0;
-    o->crest_factor = sx2 ? std::max(-mn, mx) / std::sqrt(sx2 / count) : 1;
-    o->flat_factor = DB((min_runs + max_runs) / (min_count + max_count));
-    o->peak_count = min_count + max_count;
-    o->noise_floor = DB(nf); o->noise_floor_count = nfc;
-    double ent = 0;
-    for (int i = 0; i < 8192; ++i) { double e = ehist[i] / (double)count; if (e > 1e-8) ent += e * std::log2(e); }
-    o->entropy = -ent / std::log2((double)std::min<int64_t>(count, 8192));
-    o->dynamic_range = DB(2 * std::max(std::fabs(mn), std::fabs(mx)) / mnz);
-    o->zero_crossings = zr; o->zero_crossings_rate = zr / (double)count;
-    o->number_of_samples = (double)count;
-    // bit depth estimate from the OR mask of the samples scaled to 32-bit integers
-    { unsigned bits = 0; uint64_t m = mor & 0xffffffffull; if (m) { unsigned tz = 0; while (!(m & 1)) { m >>= 1; ++tz; } bits = 32 - tz; } o->bit_depth = bits; }
-}
-
 // ---------------------------------------------------------------- afftdn tables (af_afftdn.c config_input / set_parameters)
 namespace {
 const int kBandCentre[15] = {80, 125, 195, 290, 440, 660, 1000, 1500, 2250, 3350, 5000, 7500, 11200, 16000, 24000};

@@ -1,0 +1,334 @@
+// k_astats.hip — astats (FFmpeg af_astats.c; filters.go:624 "astats=metadata=1:measure_perchannel=all") on gfx950 as a
+// handful of fully parallel, coalesced kernels instead of one sequential per-sample state machine:
+//   R  : order-independent reductions (min/max/sums/differences/zero-crossings/entropy histogram), grid-stride, float4-wide
+//   M  : global min/max finalisation on device (no host round trip)
+//   RUN: Peak_count / Flat_factor run statistics at the global extrema (run starts scan forward)
+//   GP : van Herk / Gil-Werman block prefix & suffix maxima of |x| (one thread per 50 ms block)
+//   NF : sliding 50 ms local-peak minimum + count (Noise_floor, Noise_floor_count)
+//   ZS / SCAN / SIG: exponentially averaged power (RMS_peak / RMS_trough) as an exact linear scan:
+//        per-chunk zero-state response, sequential carry over chunks, then extrema with the carried-in state
+// All double-precision sums; only the summation ORDER differs from the sequential filter (1e-15 relative).
+#include "jt_internal.h"
+#include <cfloat>
+
+constexpr int AS_T = 256;
+
+struct AsPartial {
+    double min, max, min_nz, sx, sx2, mind, maxd, d1, d2;
+    unsigned long long zero_runs, mask_or, mask_and, count;
+};
+struct AsRuns { double min_count, min_runs, max_count, max_runs; };
+struct AsNF { double nf; unsigned long long cnt; };
+
+__device__ inline double wsum(double v) { for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64); return v; }
+__device__ inline double wmin(double v) { for (int o = 32; o > 0; o >>= 1) v = fmin(v, __shfl_down(v, o, 64)); return v; }
+__device__ inline double wmax(double v) { for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_down(v, o, 64)); return v; }
+__device__ inline unsigned long long wsumu(unsigned long long v) { for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64); return v; }
+__device__ inline unsigned long long woru(unsigned long long v) { for (int o = 32; o > 0; o >>= 1) v |= __shfl_down(v, o, 64); return v; }
+__device__ inline unsigned long long wandu(unsigned long long v) { for (int o = 32; o > 0; o >>= 1) v &= __shfl_down(v, o, 64); return v; }
+
+__global__ void __launch_bounds__(AS_T)
+k_as_reduce(const float *__restrict__ x, int64_t n, AsPartial *__restrict__ part, unsigned long long *__restrict__ ehist)
+{
+    __shared__ unsigned int lh[8192];
+    __shared__ AsPartial sp[AS_T / 64];
+    const int tid = threadIdx.x;
+    for (int i = tid; i < 8192; i += AS_T) lh[i] = 0;
+    __syncthreads();
+    double mn = DBL_MAX, mx = -DBL_MAX, mnz = DBL_MAX, sx = 0, sx2 = 0, mind = DBL_MAX, maxd = 0, d1 = 0, d2 = 0;
+    unsigned long long zr = 0, mor = 0, mand = ~0ull, cnt = 0;
+    const int64_t stride = (int64_t)gridDim.x * AS_T;
+    for (int64_t i = (int64_t)blockIdx.x * AS_T + tid; i < n; i += stride) {
+        const float xf = x[i];
+        const double d = (double)xf;
+        mn = fmin(mn, d); mx = fmax(mx, d);
+        const double ad = fabs(d);
+        if (d != 0 && ad < mnz) mnz = ad;
+        sx += d; sx2 += d * d;
+        if (i > 0) {
+            const double p = (double)x[i - 1];
+            const double df = fabs(d - p);
+            mind = fmin(mind, df); maxd = fmax(maxd, df); d1 += df; d2 += (d - p) * (d - p);
+        }
+        if (d != 0) {
+            // FFSIGN of the previous non-zero sample (NaN before the first one: FFSIGN(NaN) = -1)
+            int64_t j = i - 1;
+            while (j >= 0 && x[j] == 0.f) --j;
+            const int ps = (j >= 0 && x[j] > 0.f) ? 1 : -1;
+            const int cs = d > 0 ? 1 : -1;
+            zr += (cs != ps);
+        }
+        int h = (int)rint(fmin(fmax(ad, 0.0), 1.0) * 8191.0);
+        h = h < 0 ? 0 : (h > 8191 ? 8191 : h);
+        atomicAdd(&lh[h], 1u);
+        const long long iv = (long long)llrint(d * 2147483648.0);
+        mor |= (unsigned long long)iv; mand &= (unsigned long long)iv;
+        cnt++;
+    }
+    mn = wmin(mn); mx = wmax(mx); mnz = wmin(mnz); sx = wsum(sx); sx2 = wsum(sx2); mind = wmin(mind); maxd = wmax(maxd);
+    d1 = wsum(d1); d2 = wsum(d2); zr = wsumu(zr); mor = woru(mor); mand = wandu(mand); cnt = wsumu(cnt);
+    if ((tid & 63) == 0) sp[tid >> 6] = AsPartial{mn, mx, mnz, sx, sx2, mind, maxd, d1, d2, zr, mor, mand, cnt};
+    __syncthreads();
+    if (tid == 0) {
+        AsPartial a = sp[0];
+        for (int w = 1; w < AS_T / 64; ++w) {
+            const AsPartial &b = sp[w];
+            a.min = fmin(a.min, b.min); a.max = fmax(a.max, b.max); a.min_nz = fmin(a.min_nz, b.min_nz);
+            a.sx += b.sx; a.sx2 += b.sx2; a.mind = fmin(a.mind, b.mind); a.maxd = fmax(a.maxd, b.maxd); a.d1 += b.d1; a.d2 += b.d2;
+            a.zero_runs += b.zero_runs; a.mask_or |= b.mask_or; a.mask_and &= b.mask_and; a.count += b.count;
+        }
+        part[blockIdx.x] = a;
+    }
+    for (int i = tid; i < 8192; i += AS_T) if (lh[i]) atomicAdd(&ehist[i], (unsigned long long)lh[i]);
+}
+
+__global__ void k_as_minmax(const AsPartial *__restrict__ part, int nparts, double *__restrict__ mm)
+{
+    double mn = DBL_MAX, mx = -DBL_MAX;
+    for (int i = threadIdx.x; i < nparts; i += 64) { mn = fmin(mn, part[i].min); mx = fmax(mx, part[i].max); }
+    mn = wmin(mn); mx = wmax(mx);
+    if (threadIdx.x == 0) { mm[0] = mn; mm[1] = mx; }
+}
+
+// run statistics at the global extrema: min_count = #samples == min; min_runs = sum over maximal runs of len^2
+__global__ void __launch_bounds__(AS_T)
+k_as_runs(const float *__restrict__ x, int64_t n, const double *__restrict__ mm, AsRuns *__restrict__ part)
+{
+    __shared__ AsRuns sp[AS_T / 64];
+    const float gmin = (float)mm[0], gmax = (float)mm[1];
+    double c0 = 0, r0 = 0, c1 = 0, r1 = 0;
+    const int64_t stride = (int64_t)gridDim.x * AS_T;
+    for (int64_t i = (int64_t)blockIdx.x * AS_T + threadIdx.x; i < n; i += stride) {
+        const float v = x[i];
+        if (v == gmin) {
+            c0 += 1;
+            if (i == 0 || x[i - 1] != gmin) { int64_t j = i + 1; while (j < n && x[j] == gmin) ++j; double len = (double)(j - i); r0 += len * len; }
+        }
+        if (v == gmax) {
+            c1 += 1;
+            if (i == 0 || x[i - 1] != gmax) { int64_t j = i + 1; while (j < n && x[j] == gmax) ++j; double len = (double)(j - i); r1 += len * len; }
+        }
+    }
+    c0 = wsum(c0); r0 = wsum(r0); c1 = wsum(c1); r1 = wsum(r1);
+    if ((threadIdx.x & 63) == 0) sp[threadIdx.x >> 6] = AsRuns{c0, r0, c1, r1};
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        AsRuns a = sp[0];
+        for (int w = 1; w < AS_T / 64; ++w) { a.min_count += sp[w].min_count; a.min_runs += sp[w].min_runs; a.max_count += sp[w].max_count; a.max_runs += sp[w].max_runs; }
+        part[blockIdx.x] = a;
+    }
+}
+
+// per 50 ms block: suffix maxima G[i] = max|x[i..blockend]| and prefix maxima P[i] = max|x[blockstart..i]|
+__global__ void k_as_gp(const float *__restrict__ x, float *__restrict__ g, float *__restrict__ p, int64_t n, int w)
+{
+    const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t lo = b * w;
+    if (lo >= n) return;
+    const int64_t hi = min(lo + (int64_t)w, n);
+    float m = 0.f;
+    for (int64_t i = lo; i < hi; ++i) { m = fmaxf(m, fabsf(x[i])); p[i] = m; }
+    m = 0.f;
+    for (int64_t i = hi - 1; i >= lo; --i) { m = fmaxf(m, fabsf(x[i])); g[i] = m; }
+}
+
+// sliding local peak over the last tc samples (valid once i >= tc-1): min over time and the number of times it occurs
+__global__ void __launch_bounds__(AS_T)
+k_as_noise_floor(const float *__restrict__ g, const float *__restrict__ p, int64_t n, int tc, AsNF *__restrict__ part)
+{
+    __shared__ AsNF sp[AS_T / 64];
+    double nf = DBL_MAX; unsigned long long cnt = 0;
+    const int64_t stride = (int64_t)gridDim.x * AS_T;
+    for (int64_t i = (int64_t)blockIdx.x * AS_T + threadIdx.x + (tc - 1); i < n; i += stride) {
+        const int64_t j = i - tc + 1;
+        const float wm = (j % tc == 0) ? g[j] : fmaxf(g[j], p[i]);
+        const double lp = (double)wm;
+        if (lp < nf) { nf = lp; cnt = 1; } else if (lp == nf) cnt++;
+    }
+    // (min, count) merge
+    for (int o = 32; o > 0; o >>= 1) {
+        double onf = __shfl_down(nf, o, 64); unsigned long long oc = __shfl_down(cnt, o, 64);
+        if (onf < nf) { nf = onf; cnt = oc; } else if (onf == nf) cnt += oc;
+    }
+    if ((threadIdx.x & 63) == 0) sp[threadIdx.x >> 6] = AsNF{nf, cnt};
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        AsNF a = sp[0];
+        for (int w = 1; w < AS_T / 64; ++w) { if (sp[w].nf < a.nf) a = sp[w]; else if (sp[w].nf == a.nf) a.cnt += sp[w].cnt; }
+        part[blockIdx.x] = a;
+    }
+}
+
+// exponential power average: zero-state response of each chunk (one thread per chunk, coalesced through LDS rows)
+constexpr int ZC = 1024;     // chunk length
+__global__ void __launch_bounds__(64)
+k_as_zs(const float *__restrict__ x, int64_t n, double mult, double *__restrict__ zs, int64_t nchunks)
+{
+    __shared__ float tile[64][65];
+    const int lane = threadIdx.x;
+    const int64_t c0 = (int64_t)blockIdx.x * 64;
+    const int nrows = (int)min((int64_t)64, nchunks - c0);
+    double z = 0.0;
+    const double om = 1.0 - mult;
+    for (int pos = 0; pos < ZC; pos += 64) {
+        float v[16];
+        for (int r0 = 0; r0 < 64; r0 += 16) {
+#pragma unroll
+            for (int q = 0; q < 16; ++q) { int64_t idx = (c0 + r0 + q) * ZC + pos + lane; v[q] = x[idx < n ? idx : n - 1]; }
+#pragma unroll
+            for (int q = 0; q < 16; ++q) { int64_t idx = (c0 + r0 + q) * ZC + pos + lane; tile[r0 + q][lane] = (r0 + q < nrows && idx < n) ? v[q] : 0.f; }
+        }
+        __syncthreads();
+        if (lane < nrows) {
+            const int64_t base = (c0 + lane) * ZC + pos;
+#pragma unroll 8
+            for (int j = 0; j < 64; ++j) {
+                if (base + j < n) { double d = (double)tile[lane][j]; z = z * mult + om * d * d; }
+            }
+        }
+        __syncthreads();
+    }
+    if (lane < nrows) zs[c0 + lane] = z;
+}
+
+// carry scan s_{c+1} = A_c * s_c + B_c (A_c = mult^len_c, B_c = zero-state response) as a wave-level affine prefix scan
+__global__ void k_as_scan(const double *__restrict__ zs, double *__restrict__ carry, int64_t nchunks, double mult_chunk, int64_t n, double mult)
+{
+    const int lane = threadIdx.x;
+    double carry_in = 0.0;
+    for (int64_t base = 0; base < nchunks; base += 64) {
+        const int64_t c = base + lane;
+        double A = 1.0, B = 0.0;
+        if (c < nchunks) {
+            int64_t len = min((int64_t)ZC, n - c * ZC);
+            A = (len == ZC) ? mult_chunk : pow(mult, (double)len);
+            B = zs[c];
+        }
+        for (int o = 1; o < 64; o <<= 1) {
+            double Ap = __shfl_up(A, o, 64), Bp = __shfl_up(B, o, 64);
+            if (lane >= o) { B = A * Bp + B; A = A * Ap; }
+        }
+        double s_after = A * carry_in + B;
+        double prev = __shfl_up(s_after, 1, 64);
+        if (lane == 0) prev = carry_in;
+        if (c < nchunks) carry[c] = prev;
+        carry_in = __shfl(s_after, 63, 64);
+    }
+}
+
+__global__ void __launch_bounds__(64)
+k_as_sigma(const float *__restrict__ x, int64_t n, int tc, double mult, const double *__restrict__ carry, double *__restrict__ out_min,
+           double *__restrict__ out_max, int64_t nchunks)
+{
+    __shared__ float tile[64][65];
+    const int lane = threadIdx.x;
+    const int64_t c0 = (int64_t)blockIdx.x * 64;
+    const int nrows = (int)min((int64_t)64, nchunks - c0);
+    double avg = lane < nrows ? carry[c0 + lane] : 0.0, mn = DBL_MAX, mx = 0.0;
+    const double om = 1.0 - mult;
+    for (int pos = 0; pos < ZC; pos += 64) {
+        float v[16];
+        for (int r0 = 0; r0 < 64; r0 += 16) {
+#pragma unroll
+            for (int q = 0; q < 16; ++q) { int64_t idx = (c0 + r0 + q) * ZC + pos + lane; v[q] = x[idx < n ? idx : n - 1]; }
+#pragma unroll
+            for (int q = 0; q < 16; ++q) { int64_t idx = (c0 + r0 + q) * ZC + pos + lane; tile[r0 + q][lane] = (r0 + q < nrows && idx < n) ? v[q] : 0.f; }
+        }
+        __syncthreads();
+        if (lane < nrows) {
+            const int64_t base = (c0 + lane) * ZC + pos;
+#pragma unroll 8
+            for (int j = 0; j < 64; ++j) {
+                const int64_t idx = base + j;
+                if (idx < n) {
+                    double d = (double)tile[lane][j];
+                    avg = avg * mult + om * d * d;
+                    if (idx >= tc) { mx = fmax(mx, avg); mn = fmin(mn, avg); }
+                }
+            }
+        }
+        __syncthreads();
+    }
+    mn = wmin(mn); mx = wmax(mx);
+    if (lane == 0) { out_min[blockIdx.x] = mn; out_max[blockIdx.x] = mx; }
+}
+
+// ------------------------------------------------------------------ host driver
+void jt_astats_device(jt_ctx *h, const float *x, int64_t n, int sr, jt_astats *out)
+{
+    const double time_constant = 0.05;
+    const double mult = std::exp((-1 / time_constant / sr));
+    const int tc = (int)std::max(time_constant * sr + .5, 1.0);
+    hipStream_t s = h->stream;
+    const int nparts = (int)std::min<int64_t>((n + AS_T - 1) / AS_T, 2048);
+    const int64_t nchunks = (n + ZC - 1) / ZC;
+    const int nsig = (int)((nchunks + 63) / 64);
+    // scratch layout (bytes): partials | runs | nf | mm[2] | zs[nchunks] | carry[nchunks] | smin[nsig] | smax[nsig]
+    const size_t o_part = 0, o_runs = o_part + sizeof(AsPartial) * nparts, o_nf = o_runs + sizeof(AsRuns) * nparts,
+                 o_mm = o_nf + sizeof(AsNF) * nparts, o_zs = o_mm + 16, o_carry = o_zs + 8 * (size_t)nchunks,
+                 o_smin = o_carry + 8 * (size_t)nchunks, o_smax = o_smin + 8 * (size_t)nsig, total = o_smax + 8 * (size_t)nsig;
+    h->d_scr2.ensure((total + 7) / 8);
+    unsigned char *base = reinterpret_cast<unsigned char *>(h->d_scr2.p);
+    AsPartial *d_part = reinterpret_cast<AsPartial *>(base + o_part);
+    AsRuns *d_runs = reinterpret_cast<AsRuns *>(base + o_runs);
+    AsNF *d_nf = reinterpret_cast<AsNF *>(base + o_nf);
+    double *d_mm = reinterpret_cast<double *>(base + o_mm), *d_zs = reinterpret_cast<double *>(base + o_zs),
+           *d_carry = reinterpret_cast<double *>(base + o_carry), *d_smin = reinterpret_cast<double *>(base + o_smin),
+           *d_smax = reinterpret_cast<double *>(base + o_smax);
+    h->ehist.ensure(8192); h->ehist.zero(s);
+    h->as_g.ensure((size_t)n); h->as_p.ensure((size_t)n);
+    hipLaunchKernelGGL(k_as_reduce, dim3(nparts), dim3(AS_T), 0, s, x, n, d_part, h->ehist.p);
+    hipLaunchKernelGGL(k_as_minmax, dim3(1), dim3(64), 0, s, d_part, nparts, d_mm);
+    hipLaunchKernelGGL(k_as_runs, dim3(nparts), dim3(AS_T), 0, s, x, n, d_mm, d_runs);
+    const int64_t nb = (n + tc - 1) / tc;
+    hipLaunchKernelGGL(k_as_gp, dim3((unsigned)((nb + 63) / 64)), dim3(64), 0, s, x, h->as_g.p, h->as_p.p, n, tc);
+    const bool have_nf = n >= tc;
+    if (have_nf) hipLaunchKernelGGL(k_as_noise_floor, dim3(nparts), dim3(AS_T), 0, s, h->as_g.p, h->as_p.p, n, tc, d_nf);
+    hipLaunchKernelGGL(k_as_zs, dim3((unsigned)nsig), dim3(64), 0, s, x, n, mult, d_zs, nchunks);
+    hipLaunchKernelGGL(k_as_scan, dim3(1), dim3(64), 0, s, d_zs, d_carry, nchunks, std::pow(mult, (double)ZC), n, mult);
+    hipLaunchKernelGGL(k_as_sigma, dim3((unsigned)nsig), dim3(64), 0, s, x, n, tc, mult, d_carry, d_smin, d_smax, nchunks);
+    std::vector<unsigned char> hb(total);
+    std::vector<unsigned long long> eh(8192);
+    JT_HIP(hipMemcpyAsync(hb.data(), base, total, hipMemcpyDeviceToHost, s));
+    JT_HIP(hipMemcpyAsync(eh.data(), h->ehist.p, sizeof(unsigned long long) * 8192, hipMemcpyDeviceToHost, s));
+    JT_HIP(hipStreamSynchronize(s));
+    const AsPartial *pp = reinterpret_cast<const AsPartial *>(hb.data() + o_part);
+    const AsRuns *pr = reinterpret_cast<const AsRuns *>(hb.data() + o_runs);
+    const AsNF *pn = reinterpret_cast<const AsNF *>(hb.data() + o_nf);
+    const double *smin = reinterpret_cast<const double *>(hb.data() + o_smin), *smax = reinterpret_cast<const double *>(hb.data() + o_smax);
+    AsPartial a = pp[0];
+    for (int i = 1; i < nparts; ++i) {
+        const AsPartial &b = pp[i];
+        a.min = std::min(a.min, b.min); a.max = std::max(a.max, b.max); a.min_nz = std::min(a.min_nz, b.min_nz);
+        a.sx += b.sx; a.sx2 += b.sx2; a.mind = std::min(a.mind, b.mind); a.maxd = std::max(a.maxd, b.maxd); a.d1 += b.d1; a.d2 += b.d2;
+        a.zero_runs += b.zero_runs; a.mask_or |= b.mask_or; a.mask_and &= b.mask_and; a.count += b.count;
+    }
+    AsRuns r{0, 0, 0, 0};
+    for (int i = 0; i < nparts; ++i) { r.min_count += pr[i].min_count; r.min_runs += pr[i].min_runs; r.max_count += pr[i].max_count; r.max_runs += pr[i].max_runs; }
+    double nf = DBL_MAX; unsigned long long nfc = 0;
+    if (have_nf) for (int i = 0; i < nparts; ++i) { if (pn[i].nf < nf) { nf = pn[i].nf; nfc = pn[i].cnt; } else if (pn[i].nf == nf) nfc += pn[i].cnt; }
+    double min_sig = DBL_MAX, max_sig = 0;
+    for (int i = 0; i < nsig; ++i) { min_sig = std::min(min_sig, smin[i]); max_sig = std::max(max_sig, smax[i]); }
+    std::memset(out, 0, sizeof(*out));
+    const double count = (double)a.count;
+    if (a.count == 0) return;
+    auto DB = [](double v) { return std::log10(v) * 20; };
+    out->dc_offset = a.sx / count; out->min_level = a.min; out->max_level = a.max;
+    out->min_difference = a.mind; out->max_difference = a.maxd;
+    out->mean_difference = a.d1 / (count - 1); out->rms_difference = std::sqrt(a.d2 / (count - 1));
+    out->peak_level = DB(std::max(-a.min, a.max));
+    out->rms_level = DB(std::sqrt(a.sx2 / count));
+    out->rms_peak = DB(std::sqrt(max_sig));
+    out->rms_trough = min_sig != 1 ? DB(std::sqrt(min_sig)) : 0.0;
+    out->crest_factor = a.sx2 ? std::max(-a.min, a.max) / std::sqrt(a.sx2 / count) : 1;
+    out->flat_factor = DB((r.min_runs + r.max_runs) / (r.min_count + r.max_count));
+    out->peak_count = r.min_count + r.max_count;
+    out->noise_floor = have_nf ? DB(nf) : NAN; out->noise_floor_count = (double)nfc;
+    double ent = 0;
+    for (int i = 0; i < 8192; ++i) { double e = eh[i] / count; if (e > 1e-8) ent += e * std::log2(e); }
+    out->entropy = -ent / std::log2((double)std::min<unsigned long long>(a.count, 8192));
+    out->dynamic_range = DB(2 * std::max(std::fabs(a.min), std::fabs(a.max)) / a.min_nz);
+    out->zero_crossings = (double)a.zero_runs; out->zero_crossings_rate = (double)a.zero_runs / count;
+    out->number_of_samples = count;
+    { unsigned bits = 0; unsigned long long m = a.mask_or & 0xffffffffull; if (m) { unsigned tz = 0; while (!(m & 1)) { m >>= 1; ++tz; } bits = 32 - tz; } out->bit_depth = bits; }
+}

@@ -22,12 +22,24 @@ template <typename TIn, typename TL>
 __device__ inline void tile_load(TL (*tile)[TW + 1], const TIn *__restrict__ in, int64_t n,
                                  int64_t base0, int64_t rowstride, int64_t pos, int lane, int nrows)
 {
-#pragma unroll 4
-    for (int r = 0; r < nrows; ++r) {
-        int64_t idx = base0 + (int64_t)r * rowstride + pos + lane;
-        TL v = (TL)0;
-        if (idx >= 0 && idx < n) v = (TL)in[idx];
-        tile[r][lane] = v;
+    // Row loads are issued in batches of 16 with clamped (always valid) addresses and no branches, so the 16
+    // HBM round trips overlap; out-of-range rows are zeroed by a select afterwards.
+    constexpr int G = 16;
+#pragma unroll 1
+    for (int r0 = 0; r0 < LANES; r0 += G) {
+        TIn v[G];
+#pragma unroll
+        for (int q = 0; q < G; ++q) {
+            int64_t idx = base0 + (int64_t)(r0 + q) * rowstride + pos + lane;
+            int64_t ic = idx < 0 ? 0 : (idx >= n ? n - 1 : idx);
+            v[q] = in[ic];
+        }
+#pragma unroll
+        for (int q = 0; q < G; ++q) {
+            int64_t idx = base0 + (int64_t)(r0 + q) * rowstride + pos + lane;
+            bool ok = (r0 + q) < nrows && idx >= 0 && idx < n;
+            tile[r0 + q][lane] = ok ? (TL)v[q] : (TL)0;
+        }
     }
 }
 
@@ -397,240 +409,180 @@ __device__ inline double dyn_step(DynState &st, double x, int64_t idx, const Dyn
     return v;
 }
 
+// The envelope followers are the only sequential part of agate / acompressor: s += (x^2 - s) * (x^2 > s ? att : rel).
+// Stage 1 (k_follow_states): lane-serial over long chunks with a warm-up halo, follower ONLY (a few flops per sample),
+//   records the follower state at every SC-sample boundary.
+// Stage 2 (k_dyn_apply): one lane per SC-sample sub-chunk (hundreds of thousands of lanes), restarts the follower from
+//   the recorded state and evaluates the log/exp gain curve -- the expensive part now runs fully parallel, no halo.
+constexpr int SC = 256;
+
+template <typename TIn>
 __global__ void __launch_bounds__(64)
-k_dynamics(const float *__restrict__ in, float *__restrict__ out, int64_t n, int64_t chunk, int64_t halo,
-           DynParams p, int64_t nchunks)
+k_follow_states(const TIn *__restrict__ in, int64_t n, double att, double rel, int64_t chunk, int64_t halo,
+                double *__restrict__ states, int64_t nchunks)
 {
-    __shared__ float tile[LANES][TW + 1];
+    __shared__ TIn tile[LANES][TW + 1];
+    const int lane = threadIdx.x;
+    const int64_t c0 = (int64_t)blockIdx.x * LANES;
+    const int nrows = (int)min((int64_t)LANES, nchunks - c0);
+    const int64_t base0 = c0 * chunk - halo;
+    const int64_t my_base = base0 + (int64_t)lane * chunk;
+    double s = 0.0;
+    const int64_t total = halo + chunk;
+    for (int64_t pos = 0; pos < total; pos += TW) {
+        tile_load<TIn, TIn>(tile, in, n, base0, chunk, pos, lane, nrows);
+        __syncthreads();
+        if (lane < nrows) {
+            const int64_t t0 = my_base + pos;
+            if (pos >= halo && ((pos - halo) % SC) == 0 && t0 < n) states[t0 / SC] = s;     // state BEFORE sample t0
+            if (t0 + TW > 0 && t0 < n) {
+#pragma unroll 8
+                for (int j = 0; j < TW; ++j) {
+                    const int64_t idx = t0 + j;
+                    if (idx >= 0 && idx < n) {
+                        double a = (double)tile[lane][j]; a = fabs(a); a *= a;
+                        s += (a - s) * (a > s ? att : rel);
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// MODE 0: agate (af_agate.c gate()), MODE 1: acompressor (af_sidechaincompress.c compressor()); detection = rms
+template <int MODE, typename TIn, typename TOut>
+__global__ void __launch_bounds__(64)
+k_dyn_apply(const TIn *__restrict__ in, TOut *__restrict__ out, int64_t n, const double *__restrict__ states, DynParams p, int64_t nsub)
+{
+    __shared__ double tile[LANES][TW + 1];
+    const int lane = threadIdx.x;
+    const int64_t c0 = (int64_t)blockIdx.x * LANES;
+    const int nrows = (int)min((int64_t)LANES, nsub - c0);
+    const int64_t base0 = c0 * SC;
+    const int64_t my_base = base0 + (int64_t)lane * SC;
+    double s = lane < nrows ? states[c0 + lane] : 0.0;
+    for (int pos = 0; pos < SC; pos += TW) {
+        tile_load<TIn, double>(tile, in, n, base0, SC, pos, lane, nrows);
+        __syncthreads();
+        if (lane < nrows) {
+            for (int j = 0; j < TW; ++j) {
+                const int64_t idx = my_base + pos + j;
+                if (idx >= n) break;
+                const double v = tile[lane][j];
+                double a = fabs(v); a *= a;
+                double gain = 1.0, y;
+                if (MODE == 0) {
+                    s += (a - s) * (a > s ? p.g_attack : p.g_release);
+                    if (s > 0.0 && s < p.g_lin_knee_stop) {
+                        double slope = log(s);
+                        double tratio = (fabs(p.g_ratio - 4294967296.0) < 1.0) ? 1000. : p.g_ratio;
+                        double g = (slope - p.g_thres) * tratio + p.g_thres;
+                        if (p.g_knee > 1. && slope > p.g_knee_start)
+                            g = hermite_interp(slope, p.g_knee_start, p.g_knee_stop,
+                                               ((p.g_knee_start - p.g_thres) * tratio + p.g_thres), p.g_knee_stop, tratio, 1.);
+                        gain = fmax(p.g_range, exp(g - slope));
+                    }
+                    y = v * (1.0 * gain * p.g_makeup);
+                } else {
+                    s += (a - s) * (a > s ? p.c_attack : p.c_release);
+                    if (s > 0.0 && s > p.c_adj_knee_start) {
+                        double slope = log(s) * 0.5;
+                        double g, delta;
+                        if (fabs(p.c_ratio - 4294967296.0) < 1.0) { g = p.c_thres; delta = 0.0; }
+                        else { g = (slope - p.c_thres) / p.c_ratio + p.c_thres; delta = 1.0 / p.c_ratio; }
+                        if (p.c_knee > 1.0 && slope < p.c_knee_stop)
+                            g = hermite_interp(slope, p.c_knee_start, p.c_knee_stop, p.c_knee_start, p.c_ckstop, 1.0, delta);
+                        gain = exp(g - slope);
+                    }
+                    y = v * 1.0 * (gain * p.c_makeup * p.c_mix + (1. - p.c_mix));
+                }
+                tile[lane][j] = y;
+            }
+        }
+        __syncthreads();
+        tile_store<TOut, double>(tile, out, n, base0, SC, pos, lane, nrows, 0, SC);
+        __syncthreads();
+    }
+}
+
+// de-esser alone (lane-serial with halo; no transcendental functions)
+template <typename TIn>
+__global__ void __launch_bounds__(64)
+k_deesser(const TIn *__restrict__ in, float *__restrict__ out, int64_t n, int64_t chunk, int64_t halo, DynParams p, int64_t nchunks)
+{
+    __shared__ double tile[LANES][TW + 1];
     const int lane = threadIdx.x;
     const int64_t c0 = (int64_t)blockIdx.x * LANES;
     const int nrows = (int)min((int64_t)LANES, nchunks - c0);
     const int64_t base0 = c0 * chunk - halo;
     const int64_t my_base = base0 + (int64_t)lane * chunk;
     DynState st; st.g_slope = 0; st.c_slope = 0; st.s1 = st.s2 = st.s3 = 0; st.ratioA = st.ratioB = 1.0; st.iirA = st.iirB = 0;
+    DynParams q = p; q.gate_on = 0; q.comp_on = 0; q.deess_on = 1;
     const int64_t total = halo + chunk;
     for (int64_t pos = 0; pos < total; pos += TW) {
-        tile_load<float, float>(tile, in, n, base0, chunk, pos, lane, nrows);
+        tile_load<TIn, double>(tile, in, n, base0, chunk, pos, lane, nrows);
         __syncthreads();
         if (lane < nrows) {
             for (int j = 0; j < TW; ++j) {
                 int64_t idx = my_base + pos + j;
                 if (idx < 0 || idx >= n) continue;
-                double y = dyn_step(st, (double)tile[lane][j], idx, p);
-                tile[lane][j] = (float)y;
+                tile[lane][j] = dyn_step(st, tile[lane][j], idx, q);
             }
         }
         __syncthreads();
-        tile_store<float, float>(tile, out, n, base0, chunk, pos, lane, nrows, halo, chunk);
+        tile_store<float, double>(tile, out, n, base0, chunk, pos, lane, nrows, halo, chunk);
         __syncthreads();
     }
 }
 
-void launch_dynamics(const float *in, float *out_f32, double *out_f64, int64_t n, const DynParams &d, hipStream_t s)
+template <typename TIn>
+static void run_follow(const TIn *in, int64_t n, double att, double rel, double *states, hipStream_t s)
 {
-    (void)out_f64;
-    if (n <= 0) return;
-    // warm-up: the slowest follower coefficient rho forgets as (1-rho)^k; 18 time constants ~ 1.5e-8
-    double rho = 1.0;
-    if (d.gate_on) rho = std::min(rho, std::min(d.g_attack, d.g_release));
-    if (d.comp_on) rho = std::min(rho, std::min(d.c_attack, d.c_release));
+    double rho = std::min(att, rel);
     int64_t halo = 4096;
-    if (rho < 1.0 && rho > 0.0) halo = std::max<int64_t>(halo, (int64_t)std::ceil(18.0 / rho));
-    if (d.deess_on) halo = std::max<int64_t>(halo, 16384);
-    halo = (halo + TW - 1) / TW * TW;
-    int64_t chunk = std::max<int64_t>(8192, halo / 4);
-    chunk = (chunk + TW - 1) / TW * TW;
+    if (rho < 1.0 && rho > 0.0) halo = std::max<int64_t>(halo, (int64_t)std::ceil(18.0 / rho));   // 18 time constants ~ 1.5e-8
+    halo = (halo + SC - 1) / SC * SC;
+    int64_t chunk = std::max<int64_t>(4096, (halo / 4 + SC - 1) / SC * SC);
     int64_t nchunks = (n + chunk - 1) / chunk;
-    int grid = (int)((nchunks + LANES - 1) / LANES);
-    hipLaunchKernelGGL(k_dynamics, dim3(grid), dim3(LANES), 0, s, in, out_f32, n, chunk, halo, d, nchunks);
+    hipLaunchKernelGGL((k_follow_states<TIn>), dim3((unsigned)((nchunks + LANES - 1) / LANES)), dim3(LANES), 0, s, in, n, att, rel, chunk, halo,
+                       states, nchunks);
 }
 
-// ------------------------------------------------------------------ astats
-// pass G: per tc-block suffix maxima of |x| (van Herk / Gil-Werman sliding max, first half)
-__global__ void k_suffix_absmax(const float *__restrict__ in, float *__restrict__ g, int64_t n, int w)
+// scratch: states[(n/SC)+2] doubles, tmp64[n] doubles (gate output feeding the compressor), tmp64b[n] when the de-esser runs
+void launch_dynamics(const float *in, float *out_f32, double *tmp64, double *tmp64b, double *states, int64_t n, const DynParams &d, hipStream_t s)
 {
-    int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    int64_t lo = b * w;
-    if (lo >= n) return;
-    int64_t hi = min(lo + (int64_t)w, n);
-    float m = 0.f;
-    for (int64_t i = hi - 1; i >= lo; --i) { m = fmaxf(m, fabsf(in[i])); g[i] = m; }
-}
-
-// pass A: everything except the exponentially averaged power extrema.  halo >= tc (sliding-max prefix, previous sample).
-__global__ void __launch_bounds__(64)
-k_astats_a(const float *__restrict__ in, const float *__restrict__ g, int64_t n, int tc, double mult,
-           int64_t chunk, int64_t halo, AstatsChunk *__restrict__ chunks, int64_t nchunks,
-           unsigned long long *__restrict__ ehist, double *__restrict__ zs_final)
-{
-    __shared__ float tile[LANES][TW + 1];
-    __shared__ unsigned int lh[8192];
-    const int lane = threadIdx.x;
-    for (int i = lane; i < 8192; i += LANES) lh[i] = 0;
-    const int64_t c0 = (int64_t)blockIdx.x * LANES;
-    const int nrows = (int)min((int64_t)LANES, nchunks - c0);
-    const int64_t base0 = c0 * chunk - halo;
-    const int64_t my_base = base0 + (int64_t)lane * chunk;
-    const int64_t my_lo = my_base + halo, my_hi = min(my_lo + chunk, n);
-    AstatsChunk a;
-    a.min = 1.7976931348623157e308; a.max = -1.7976931348623157e308; a.min_non_zero = 1.7976931348623157e308;
-    a.sigma_x = 0; a.sigma_x2 = 0; a.min_diff = 1.7976931348623157e308; a.max_diff = 0; a.diff1_sum = 0; a.diff1_sum_x2 = 0;
-    a.first = 0; a.last = 0; a.first_nz_sign = 0; a.last_nz_sign = 0; a.zero_runs = 0;
-    a.min_sigma = 1.7976931348623157e308; a.max_sigma = 0; a.noise_floor = 1.7976931348623157e308; a.noise_floor_count = 0;
-    a.abs_peak = 0; a.count = 0;
-    a.min_count = 0; a.min_runs = 0; a.min_head_run = 0; a.min_tail_run = 0; a.min_all = 0;
-    a.max_count = 0; a.max_runs = 0; a.max_head_run = 0; a.max_tail_run = 0; a.max_all = 0;
-    a.mask_or = 0; a.mask_and = ~0ull;
-    double prev = 0.0; bool have_prev = false;
-    float pmax = 0.f;                  // prefix max of |x| since the start of the current tc-block
-    double zs = 0.0;                   // zero-state response of avg_sigma_x2 over the chunk
-    // run tracking relative to the running chunk-local min / max
-    double min_run = 0, max_run = 0;   // current open run lengths at a.min / a.max
-    bool min_open_from_start = false, max_open_from_start = false;
-    __syncthreads();
-    const int64_t total = halo + chunk;
-    for (int64_t pos = 0; pos < total; pos += TW) {
-        tile_load<float, float>(tile, in, n, base0, chunk, pos, lane, nrows);
-        __syncthreads();
-        if (lane < nrows) {
-            for (int j = 0; j < TW; ++j) {
-                int64_t idx = my_base + pos + j;
-                if (idx < 0) continue;
-                if (idx >= my_hi) break;
-                float xf = tile[lane][j];
-                double d = (double)xf;
-                if (idx % tc == 0) pmax = 0.f;
-                pmax = fmaxf(pmax, fabsf(xf));
-                if (idx >= my_lo) {
-                    if (a.count == 0) a.first = d;
-                    // min / max with run bookkeeping (af_astats.c update_stat)
-                    if (d < a.min) { a.min = d; a.min_count = 1; a.min_runs = 0; min_run = 1; a.min_head_run = 0;
-                                     min_open_from_start = (a.count == 0); }
-                    else if (d == a.min) { a.min_count += 1; if (have_prev && prev == d && a.count > 0) min_run += 1;
-                                           else { min_run = 1; min_open_from_start = false; } }
-                    else if (a.count > 0 && prev == a.min) {
-                        if (min_open_from_start) { a.min_head_run = min_run; min_open_from_start = false; }
-                        else a.min_runs += min_run * min_run;
-                        min_run = 0;
-                    }
-                    if (d > a.max) { a.max = d; a.max_count = 1; a.max_runs = 0; max_run = 1; a.max_head_run = 0;
-                                     max_open_from_start = (a.count == 0); }
-                    else if (d == a.max) { a.max_count += 1; if (have_prev && prev == d && a.count > 0) max_run += 1;
-                                           else { max_run = 1; max_open_from_start = false; } }
-                    else if (a.count > 0 && prev == a.max) {
-                        if (max_open_from_start) { a.max_head_run = max_run; max_open_from_start = false; }
-                        else a.max_runs += max_run * max_run;
-                        max_run = 0;
-                    }
-                    double ad = fabs(d);
-                    a.abs_peak = fmax(a.abs_peak, ad);
-                    if (d != 0 && ad < a.min_non_zero) a.min_non_zero = ad;
-                    if (d != 0) {
-                        double sg = d > 0 ? 1.0 : -1.0;
-                        if (a.first_nz_sign == 0) a.first_nz_sign = sg;
-                        else if (sg != a.last_nz_sign) a.zero_runs += 1;
-                        a.last_nz_sign = sg;
-                    }
-                    a.sigma_x += d;
-                    a.sigma_x2 += d * d;
-                    zs = zs * mult + (1.0 - mult) * d * d;
-                    if (have_prev) {
-                        double df = fabs(d - prev);
-                        a.min_diff = fmin(a.min_diff, df);
-                        a.max_diff = fmax(a.max_diff, df);
-                        a.diff1_sum += df;
-                        a.diff1_sum_x2 += (d - prev) * (d - prev);
-                    }
-                    int hidx = (int)rint(fmin(fmax(ad, 0.0), 1.0) * 8191.0);
-                    hidx = hidx < 0 ? 0 : (hidx > 8191 ? 8191 : hidx);
-                    atomicAdd(&lh[hidx], 1u);
-                    // sliding local peak over the last tc samples, valid once idx >= tc-1
-                    if (idx >= tc - 1) {
-                        int64_t jj = idx - tc + 1;
-                        float wmax = (jj % tc == 0) ? g[jj] : fmaxf(g[jj], pmax);
-                        double lp = (double)wmax;
-                        if (lp < a.noise_floor) { a.noise_floor = lp; a.noise_floor_count = 1; }
-                        else if (lp == a.noise_floor) a.noise_floor_count += 1;
-                    }
-                    long long iv = (long long)llrint(d * 2147483648.0);
-                    a.mask_or |= (unsigned long long)iv; a.mask_and &= (unsigned long long)iv;
-                    a.last = d;
-                    a.count++;
-                }
-                prev = d; have_prev = true;
-            }
-        }
-        __syncthreads();
+    if (n <= 0) return;
+    const int64_t nsub = (n + SC - 1) / SC;
+    const unsigned agrid = (unsigned)((nsub + LANES - 1) / LANES);
+    const bool de = d.deess_on != 0;
+    // stage outputs: gate -> tmp64 (if anything follows) ; comp -> tmp64b (if deesser follows) else f32 out
+    const double *cur64 = nullptr; bool have64 = false;
+    if (d.gate_on) {
+        run_follow<float>(in, n, d.g_attack, d.g_release, states, s);
+        if (d.comp_on || de) { hipLaunchKernelGGL((k_dyn_apply<0, float, double>), dim3(agrid), dim3(LANES), 0, s, in, tmp64, n, states, d, nsub); cur64 = tmp64; have64 = true; }
+        else { hipLaunchKernelGGL((k_dyn_apply<0, float, float>), dim3(agrid), dim3(LANES), 0, s, in, out_f32, n, states, d, nsub); return; }
     }
-    if (lane < nrows) {
-        // close runs touching the chunk end: record as tail runs for host stitching
-        if (a.count > 0 && a.last == a.min) {
-            if (min_open_from_start) { a.min_all = 1; a.min_head_run = min_run; a.min_tail_run = min_run; }
-            else a.min_tail_run = min_run;
+    if (d.comp_on) {
+        if (have64) run_follow<double>(cur64, n, d.c_attack, d.c_release, states, s);
+        else run_follow<float>(in, n, d.c_attack, d.c_release, states, s);
+        if (de) {
+            if (have64) hipLaunchKernelGGL((k_dyn_apply<1, double, double>), dim3(agrid), dim3(LANES), 0, s, cur64, tmp64b, n, states, d, nsub);
+            else hipLaunchKernelGGL((k_dyn_apply<1, float, double>), dim3(agrid), dim3(LANES), 0, s, in, tmp64b, n, states, d, nsub);
+            cur64 = tmp64b; have64 = true;
+        } else {
+            if (have64) hipLaunchKernelGGL((k_dyn_apply<1, double, float>), dim3(agrid), dim3(LANES), 0, s, cur64, out_f32, n, states, d, nsub);
+            else hipLaunchKernelGGL((k_dyn_apply<1, float, float>), dim3(agrid), dim3(LANES), 0, s, in, out_f32, n, states, d, nsub);
+            return;
         }
-        if (a.count > 0 && a.last == a.max) {
-            if (max_open_from_start) { a.max_all = 1; a.max_head_run = max_run; a.max_tail_run = max_run; }
-            else a.max_tail_run = max_run;
-        }
-        chunks[c0 + lane] = a;
-        zs_final[c0 + lane] = zs;
     }
-    __syncthreads();
-    for (int i = lane; i < 8192; i += LANES) if (lh[i]) atomicAdd(&ehist[i], (unsigned long long)lh[i]);
-}
-
-// carry scan: s_c = s_{c-1} * mult^chunk + e_{c-1}   (exact linear recurrence across chunk boundaries)
-__global__ void k_astats_scan(const double *__restrict__ zs_final, double *__restrict__ carry, int64_t nchunks, double mult_chunk)
-{
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    double s = 0.0;
-    for (int64_t c = 0; c < nchunks; ++c) { carry[c] = s; s = s * mult_chunk + zs_final[c]; }
-}
-
-// pass B: avg_sigma_x2 with the exact carried-in state; extrema over samples with index >= tc
-__global__ void __launch_bounds__(64)
-k_astats_b(const float *__restrict__ in, int64_t n, int tc, double mult, int64_t chunk,
-           const double *__restrict__ carry, AstatsChunk *__restrict__ chunks, int64_t nchunks)
-{
-    __shared__ float tile[LANES][TW + 1];
-    const int lane = threadIdx.x;
-    const int64_t c0 = (int64_t)blockIdx.x * LANES;
-    const int nrows = (int)min((int64_t)LANES, nchunks - c0);
-    const int64_t base0 = c0 * chunk;
-    const int64_t my_base = base0 + (int64_t)lane * chunk;
-    double avg = lane < nrows ? carry[c0 + lane] : 0.0;
-    double mn = 1.7976931348623157e308, mx = 0.0;
-    for (int64_t pos = 0; pos < chunk; pos += TW) {
-        tile_load<float, float>(tile, in, n, base0, chunk, pos, lane, nrows);
-        __syncthreads();
-        if (lane < nrows) {
-            for (int j = 0; j < TW; ++j) {
-                int64_t idx = my_base + pos + j;
-                if (idx >= n || pos + j >= chunk) break;
-                double d = (double)tile[lane][j];
-                avg = avg * mult + (1.0 - mult) * d * d;
-                if (idx >= tc) { mx = fmax(mx, avg); mn = fmin(mn, avg); }
-            }
-        }
-        __syncthreads();
+    if (de) {
+        const int64_t halo = 16384, chunk = 8192;
+        const int64_t nchunks = (n + chunk - 1) / chunk;
+        const unsigned g = (unsigned)((nchunks + LANES - 1) / LANES);
+        if (have64) hipLaunchKernelGGL((k_deesser<double>), dim3(g), dim3(LANES), 0, s, cur64, out_f32, n, chunk, halo, d, nchunks);
+        else hipLaunchKernelGGL((k_deesser<float>), dim3(g), dim3(LANES), 0, s, in, out_f32, n, chunk, halo, d, nchunks);
     }
-    if (lane < nrows) { chunks[c0 + lane].min_sigma = mn; chunks[c0 + lane].max_sigma = mx; }
-}
-
-// The full astats sequence needs scratch (suffix maxima, carries); jt_api.cpp drives it through this entry.
-void jt_astats_run(const float *in, int64_t n, int sr, float *g_scratch /*n*/, double *zs /*nchunks*/, double *carry /*nchunks*/,
-                   AstatsChunk *chunks, int64_t chunk, int64_t nchunks, unsigned long long *ehist, hipStream_t s)
-{
-    const double time_constant = 0.05;
-    const double mult = std::exp((-1 / time_constant / sr));
-    const int tc = (int)std::max(time_constant * sr + .5, 1.0);
-    int64_t halo = ((int64_t)tc + TW) / TW * TW;
-    int64_t nb = (n + tc - 1) / tc;
-    hipLaunchKernelGGL(k_suffix_absmax, dim3((unsigned)((nb + 63) / 64)), dim3(64), 0, s, in, g_scratch, n, tc);
-    int grid = (int)((nchunks + LANES - 1) / LANES);
-    hipLaunchKernelGGL(k_astats_a, dim3(grid), dim3(LANES), 0, s, in, g_scratch, n, tc, mult, chunk, halo, chunks, nchunks, ehist, zs);
-    hipLaunchKernelGGL(k_astats_scan, dim3(1), dim3(1), 0, s, zs, carry, nchunks, std::pow(mult, (double)chunk));
-    hipLaunchKernelGGL(k_astats_b, dim3(grid), dim3(LANES), 0, s, in, n, tc, mult, chunk, carry, chunks, nchunks);
 }
 
 // ------------------------------------------------------------------ look-ahead limiter (af_alimiter.c)

@@ -1,196 +1,177 @@
-// k_resample.hip — libswresample-equivalent polyphase kaiser-sinc resampling on gfx950.
-//   * 48k/96k -> 44.1k + f64->s16 (aformat=sample_rates=44100:sample_fmts=s16, filters.go:706-710)
+// k_resample.hip — libswresample-equivalent polyphase kaiser-sinc resampling on gfx950 (resample.c: kaiser beta 9,
+// filter_size 32, cutoff 0.97, exact_rational phase bank).
+//   * 48k/96k -> 44.1k + dbl->s16   (aformat=sample_rates=44100:sample_fmts=s16, filters.go:706-710)
 //   * x -> 192 kHz true-peak scan fused with a per-100ms max reduce (ebur128 peak=true, filters.go:626);
 //     the oversampled signal is never materialised
-//   * 44.1k -> 192k fused with K-weighting and block energies (loudnorm measurement, normalise.go:256-264)
-// One thread per output sample for the FIR kernels (gather of <=36 contiguous inputs, taps from a
-// phase bank that stays L2-resident); HBM traffic = 1 input read + 1 output write.
+//   * 44.1k -> 192k stream for the loudnorm measurement (normalise.go:256-264), K-weighted by k_lane.hip
+//
+// Mapping ("phase-major"): a workgroup stages a tile of T = 64*R*step input samples (+ taps-1 halo) in LDS.  Because
+// gcd(step, P) = 1, any P consecutive outputs carry the P distinct phases, and outputs of equal phase are P apart and
+// read inputs `step` apart.  One wave therefore evaluates 64 outputs OF THE SAME PHASE at a time: the 32-36 taps are
+// wave-uniform (scalar loads, no LDS/VGPR traffic for coefficients), the inputs come from LDS with a lane stride of
+// `step` words through a skewed index (conflict-free for odd and even strides alike).  Tap order and accumulation
+// order per output are exactly swresample's (ascending taps, double or float accumulate), so results are
+// bit-identical to the scalar resample_common loops.  HBM traffic = 1 input read (+halo) + 1 output write.
 #include "jt_internal.h"
 
-__device__ inline double in_at_f(const float *in, int64_t n, int64_t k, int flush)
-{
-    if (k < 0) k = -k;                       // swr invert_initial_buffer(): in[-j] = in[j]
-    if (k >= n) { if (!flush) return 0.0; k = 2 * n - 1 - k; if (k < 0) return 0.0; }   // resample_flush(): in[n+j] = in[n-1-j]
-    return (double)in[k];
-}
-__device__ inline double in_at_d(const double *in, int64_t n, int64_t k, int flush)
-{
-    if (k < 0) k = -k;
-    if (k >= n) { if (!flush) return 0.0; k = 2 * n - 1 - k; if (k < 0) return 0.0; }
-    return in[k];
-}
+constexpr int PP_THREADS = 256;
 
-// f32 in (the dbl->flt->dbl rounded signal) -> DBLP resample -> s16
-__global__ void k_resample_to_s16(const float *__restrict__ in, int64_t n, const double *__restrict__ bank, int phase_count,
-                                  int L, int center, int64_t step, int16_t *__restrict__ out, int64_t m_total)
+__device__ inline int skew(int i) { return i + (i >> 5); }
+
+// MODE 0: true peak (max |out| per 100 ms visibility block, streaming swr: outputs need all taps inside the input)
+// MODE 1: flush-mode resample -> s16 (av_clip_int16(lrint(x*32768))), staged in LDS for coalesced stores
+// MODE 2: flush-mode resample -> TAcc stream (strided stores, merged in L2)
+template <typename TIn, typename TAcc, typename TTap, int MODE>
+__global__ void __launch_bounds__(PP_THREADS)
+k_polyphase(const TIn *__restrict__ in, int64_t n, const TTap *__restrict__ bank, int P, int L, int center, int64_t step,
+            int64_t m_total, int R, double in_scale, int blk, unsigned long long *__restrict__ block_tp, int64_t nblocks_alloc,
+            int16_t *__restrict__ out_s16, TAcc *__restrict__ out_stream)
 {
-    int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (m >= m_total) return;
-    int64_t idx = m * step;
-    int64_t si = idx / phase_count;
-    int ph = (int)(idx - si * phase_count);
-    const double *f = bank + (size_t)ph * L;
-    double val = 0.0;
-    int64_t k0 = si - center;
-    if (k0 >= 0 && k0 + L <= n) {
-        for (int i = 0; i < L; ++i) val += (double)in[k0 + i] * f[i];
-    } else {
-        for (int i = 0; i < L; ++i) val += in_at_f(in, n, k0 + i, 1) * f[i];
+    extern __shared__ unsigned char smem_pp[];
+    TAcc *xin = reinterpret_cast<TAcc *>(smem_pp);
+    const int T = 64 * R * (int)step;
+    const int nin = T + L;
+    int16_t *otile = reinterpret_cast<int16_t *>(xin + skew(nin) + 2);
+    __shared__ unsigned long long slots[8];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t s0 = (int64_t)blockIdx.x * T;
+    const int64_t m_lo = (int64_t)blockIdx.x * 64 * R * P;          // = s0 * P / step exactly
+    const int64_t nout = min((int64_t)64 * R * P, m_total - m_lo);
+    if (nout <= 0) return;
+    const int flush = MODE != 0;
+    for (int i = tid; i < nin; i += PP_THREADS) {
+        int64_t g = s0 - center + i;
+        TAcc v = (TAcc)0;
+        if (g < 0) g = -g;                                           // invert_initial_buffer(): in[-j] = in[j]
+        if (g < n) v = (TAcc)((TAcc)in[g] * (TAcc)in_scale);
+        else if (flush) { int64_t r = 2 * n - 1 - g; if (r >= 0 && r < n) v = (TAcc)((TAcc)in[r] * (TAcc)in_scale); }   // resample_flush()
+        xin[skew(i)] = v;
     }
-    double r = rint(val * 32768.0);
-    r = r < -32768.0 ? -32768.0 : (r > 32767.0 ? 32767.0 : r);
-    out[m] = (int16_t)r;
-}
-void launch_resample_to_s16(const float *in, int64_t n, const double *bank, int phase_count, int filter_length, int center,
-                            int64_t step, int16_t *out, int64_t m, hipStream_t s)
-{
-    if (m <= 0) return;
-    unsigned grid = (unsigned)((m + 255) / 256);
-    hipLaunchKernelGGL(k_resample_to_s16, dim3(grid), dim3(256), 0, s, in, n, bank, phase_count, filter_length, center, step, out, m);
-}
-
-// True peak: streaming swr (never flushed): output m exists iff its last tap index <= n-1; it becomes visible to
-// ebur128 in the 100 ms frame that contains that last tap.  block_tp[b] = max |out| over outputs visible in frame b
-// (b == nblocks_full collects the trailing partial frame).  Non-negative doubles order like their bit patterns.
-template <typename TIn>
-__global__ void k_true_peak(const TIn *__restrict__ in, int64_t n, const double *__restrict__ bank, int phase_count,
-                            int L, int center, int64_t step, int blk, unsigned long long *__restrict__ block_tp,
-                            int64_t nblocks_alloc, int64_t m_total)
-{
-    int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    double a = 0.0; int64_t b = -1;
-    if (m < m_total) {
-        int64_t idx = m * step;
-        int64_t si = idx / phase_count;
-        int ph = (int)(idx - si * phase_count);
-        int64_t k0 = si - center, last = k0 + L - 1;
-        if (last <= n - 1) {
-            const double *f = bank + (size_t)ph * L;
-            double val = 0.0;
-            if (k0 >= 0) { for (int i = 0; i < L; ++i) val += (double)in[k0 + i] * f[i]; }
-            else { for (int i = 0; i < L; ++i) { int64_t k = k0 + i; if (k < 0) k = -k; val += (double)in[k] * f[i]; } }
-            a = fabs(val);
-            b = last / blk;
-            if (b >= nblocks_alloc) b = nblocks_alloc - 1;
+    if (MODE == 0 && tid < 8) slots[tid] = 0ull;
+    __syncthreads();
+    const int64_t b_first = (s0 - center + L - 1 < 0 ? 0 : (s0 - center + L - 1)) / blk;
+    // work items: (j, kc) with j = first-output offset (phase selector) and kc = 64-lane chunk of same-phase outputs
+    const int nitems = P * R;
+    for (int item = wave; item < nitems; item += PP_THREADS / 64) {
+        const int j = item / R, kc = item - j * R;
+        const int64_t m0 = m_lo + j;
+        const int64_t idx0 = m0 * step;
+        const int ph = __builtin_amdgcn_readfirstlane((int)(idx0 % P));   // wave-uniform -> scalar tap loads
+        const int si0 = (int)(idx0 / P - s0);                         // tile-relative input position of lane 0, chunk 0
+        const int k = kc * 64 + lane;
+        const int64_t m = m0 + (int64_t)P * k;
+        const int si = si0 + (int)step * k;
+        const TTap *f = bank + (size_t)ph * L;
+        TAcc val = (TAcc)0;
+        const bool live = m < m_total;
+        if (live) {
+#pragma unroll 4
+            for (int i = 0; i < L; ++i) val += xin[skew(si + i)] * (TAcc)f[i];
+        }
+        if (MODE == 0) {
+            const int64_t last = s0 + si - center + L - 1;
+            if (live && last <= n - 1) {
+                int64_t b = last / blk;
+                if (b >= nblocks_alloc) b = nblocks_alloc - 1;
+                int sl = (int)(b - b_first);
+                unsigned long long bits = (unsigned long long)__double_as_longlong(fabs((double)val));
+                if (sl >= 0 && sl < 8) atomicMax(&slots[sl], bits);
+                else atomicMax(&block_tp[b], bits);
+            }
+        } else if (MODE == 1) {
+            if (live) {
+                double r = rint((double)val * 32768.0);
+                r = r < -32768.0 ? -32768.0 : (r > 32767.0 ? 32767.0 : r);
+                otile[j + P * k] = (int16_t)r;
+            }
+        } else {
+            if (live) out_stream[m] = val;
         }
     }
-    // wave-level combine when the whole wave maps to one block (the common case)
-    int64_t b0 = __shfl(b, 0, 64);
-    bool uniform = __all(b == b0);
-    if (uniform) {
-        for (int off = 32; off > 0; off >>= 1) a = fmax(a, __shfl_down(a, off, 64));
-        if ((threadIdx.x & 63) == 0 && b0 >= 0) atomicMax(&block_tp[b0], (unsigned long long)__double_as_longlong(a));
-    } else if (b >= 0) {
-        atomicMax(&block_tp[b], (unsigned long long)__double_as_longlong(a));
+    __syncthreads();
+    if (MODE == 0) {
+        if (tid < 8 && slots[tid]) {
+            int64_t b = b_first + tid;
+            if (b >= nblocks_alloc) b = nblocks_alloc - 1;
+            atomicMax(&block_tp[b], slots[tid]);
+        }
+    } else if (MODE == 1) {
+        for (int64_t i = tid; i < nout; i += PP_THREADS) out_s16[m_lo + i] = otile[i];
     }
 }
+
+struct PPGeom { int R; int T; size_t smem; unsigned grid; };
+template <typename TAcc>
+static PPGeom pp_geometry(int64_t n, int P, int L, int64_t step, int64_t m_total, bool otile)
+{
+    PPGeom g;
+    int R = (int)std::max<int64_t>(1, 4096 / (64 * step));
+    if (otile) while (R > 1 && (size_t)64 * R * P * 2 > 48 * 1024) R >>= 1;
+    g.R = R; g.T = 64 * R * (int)step;
+    int nin = g.T + L;
+    g.smem = sizeof(TAcc) * (size_t)(nin + (nin >> 5) + 4) + (otile ? (size_t)64 * R * P * 2 + 16 : 0);
+    int64_t per_block = (int64_t)64 * R * P;
+    g.grid = (unsigned)((m_total + per_block - 1) / per_block);
+    (void)n;
+    return g;
+}
+
 void launch_true_peak_f32(const float *in, int64_t n, const double *bank, int phase_count, int filter_length, int center,
                           int64_t step, int blk, double *block_tp, int64_t nblocks_alloc, int64_t m_total, hipStream_t s)
 {
     if (m_total <= 0) return;
-    unsigned grid = (unsigned)((m_total + 255) / 256);
-    hipLaunchKernelGGL(k_true_peak<float>, dim3(grid), dim3(256), 0, s, in, n, bank, phase_count, filter_length, center, step, blk,
-                       (unsigned long long *)block_tp, nblocks_alloc, m_total);
+    PPGeom g = pp_geometry<double>(n, phase_count, filter_length, step, m_total, false);
+    JT_REQUIRE(g.smem <= 150 * 1024, JT_E_UNSUPPORTED, "true peak: rate ratio needs too large an LDS tile");
+    auto k = k_polyphase<float, double, double, 0>;
+    JT_HIP(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)g.smem));
+    hipLaunchKernelGGL(k, dim3(g.grid), dim3(PP_THREADS), g.smem, s, in, n, bank, phase_count, filter_length, center, step, m_total,
+                       g.R, 1.0, blk, (unsigned long long *)block_tp, nblocks_alloc, (int16_t *)nullptr, (double *)nullptr);
 }
+
 void launch_true_peak_f64(const double *in, int64_t n, const double *bank, int phase_count, int filter_length, int center,
                           int64_t step, int blk, double *block_tp, int64_t nblocks_alloc, int64_t m_total, hipStream_t s)
 {
     if (m_total <= 0) return;
-    unsigned grid = (unsigned)((m_total + 255) / 256);
-    hipLaunchKernelGGL(k_true_peak<double>, dim3(grid), dim3(256), 0, s, in, n, bank, phase_count, filter_length, center, step, blk,
-                       (unsigned long long *)block_tp, nblocks_alloc, m_total);
+    PPGeom g = pp_geometry<double>(n, phase_count, filter_length, step, m_total, false);
+    JT_REQUIRE(g.smem <= 150 * 1024, JT_E_UNSUPPORTED, "true peak: rate ratio needs too large an LDS tile");
+    auto k = k_polyphase<double, double, double, 0>;
+    JT_HIP(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)g.smem));
+    hipLaunchKernelGGL(k, dim3(g.grid), dim3(PP_THREADS), g.smem, s, in, n, bank, phase_count, filter_length, center, step, m_total,
+                       g.R, 1.0, blk, (unsigned long long *)block_tp, nblocks_alloc, (int16_t *)nullptr, (double *)nullptr);
 }
 
-// ------------------------------------------------------------------ fused resample -> K-weight -> block energies
-// Lane-serial over the OUTPUT-rate time axis: each lane owns `bpl` 100 ms blocks of the 192 kHz stream plus a
-// warm-up halo, computes every oversampled sample with the polyphase FIR straight from the input-rate signal
-// (aresample flushes: right edge mirrored), runs the K-weighting recurrence (libavfilter/ebur128.c, combined
-// 4th-order response == the two cascaded biquads) and accumulates z^2 per block and max|x| per block.
-// FLT variant (s16 in, no limiter prefix): float taps, float accumulation (swr int_sample_fmt FLTP).
-// DBL variant (after the alimiter prefix): double taps (DBLP).
-template <typename TIn, typename TAcc, typename TBank>
-__global__ void __launch_bounds__(64)
-k_resample_kweight(const TIn *__restrict__ in, int64_t n, const TBank *__restrict__ bank, int phase_count, int L, int center,
-                   int64_t step, int64_t m_total, int blk, int bpl, int64_t halo, BiquadF64 pre, BiquadF64 rlb,
-                   double *__restrict__ block_sums, double *__restrict__ block_peaks, int64_t nblocks_alloc, int64_t nchunks,
-                   double in_scale)
+// f32 in (the dbl->flt->dbl rounded signal) -> DBLP resample -> s16
+void launch_resample_to_s16(const float *in, int64_t n, const double *bank, int phase_count, int filter_length, int center,
+                            int64_t step, int16_t *out, int64_t m, hipStream_t s)
 {
-    int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= nchunks) return;
-    const int64_t chunk = (int64_t)blk * bpl;
-    int64_t m_lo = c * chunk, m_hi = min(m_lo + chunk, m_total);
-    int64_t m0 = max((int64_t)0, m_lo - halo);
-    double x1 = 0, x2 = 0, y0 = 0, y1 = 0, y2 = 0, z0 = 0, z1 = 0, z2 = 0;
-    double acc = 0.0, pk = 0.0; int cnt = 0; int64_t bidx = c * bpl;
-    for (int64_t m = m0; m < m_hi; ++m) {
-        int64_t idx = m * step;
-        int64_t si = idx / phase_count;
-        int ph = (int)(idx - si * phase_count);
-        const TBank *f = bank + (size_t)ph * L;
-        int64_t k0 = si - center;
-        TAcc val = (TAcc)0;
-        if (k0 >= 0 && k0 + L <= n) {
-#pragma unroll 8
-            for (int i = 0; i < L; ++i) val += (TAcc)((TAcc)in[k0 + i] * (TAcc)in_scale) * (TAcc)f[i];
-        } else {
-            for (int i = 0; i < L; ++i) {
-                int64_t k = k0 + i;
-                if (k < 0) k = -k;
-                TAcc xv = (TAcc)0;
-                if (k >= n) { k = 2 * n - 1 - k; if (k >= 0) xv = (TAcc)in[k] * (TAcc)in_scale; }
-                else xv = (TAcc)in[k] * (TAcc)in_scale;
-                val += xv * (TAcc)f[i];
-            }
-        }
-        double x0 = (double)val;
-        y2 = y1; y1 = y0;
-        y0 = x0 * pre.b0 + x1 * pre.b1 + x2 * pre.b2 - y1 * pre.a1 - y2 * pre.a2;
-        x2 = x1; x1 = x0;
-        z2 = z1; z1 = z0;
-        z0 = y0 * rlb.b0 + y1 * rlb.b1 + y2 * rlb.b2 - z1 * rlb.a1 - z2 * rlb.a2;
-        if (m >= m_lo) {
-            acc += z0 * z0;
-            pk = fmax(pk, fabs(x0));
-            if (++cnt == blk) {
-                if (bidx < nblocks_alloc) { block_sums[bidx] = acc; block_peaks[bidx] = pk; }
-                acc = 0.0; pk = 0.0; cnt = 0; ++bidx;
-            }
-        }
-    }
-    if (cnt > 0 && bidx < nblocks_alloc) { block_sums[bidx] = acc; block_peaks[bidx] = pk; }
+    if (m <= 0) return;
+    PPGeom g = pp_geometry<double>(n, phase_count, filter_length, step, m, true);
+    JT_REQUIRE(g.smem <= 150 * 1024, JT_E_UNSUPPORTED, "resample: rate ratio needs too large an LDS tile");
+    auto k = k_polyphase<float, double, double, 1>;
+    JT_HIP(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)g.smem));
+    hipLaunchKernelGGL(k, dim3(g.grid), dim3(PP_THREADS), g.smem, s, in, n, bank, phase_count, filter_length, center, step, m,
+                       g.R, 1.0, 1, (unsigned long long *)nullptr, (int64_t)0, out, (double *)nullptr);
 }
 
-static void rk_geometry(int64_t m_total, int blk, int *bpl, int64_t *halo, int64_t *nchunks)
-{
-    int64_t h = (int64_t)std::ceil(8192.0 * (blk * 10.0) / 48000.0);
-    *halo = h;
-    int b = 1;                       // one 100 ms block per lane: maximum parallelism, halo overhead ~1.7x
-    *bpl = b;
-    int64_t chunk = (int64_t)blk * b;
-    *nchunks = (m_total + chunk - 1) / chunk;
-}
-
-void launch_resample_kweight_s16(const int16_t *in, int64_t n, const float *bankf, int phase_count, int filter_length, int center,
-                                 int64_t step, int64_t m_total, int blk, BiquadF64 pre, BiquadF64 rlb,
-                                 double *block_sums, double *block_peaks, int64_t nblocks_alloc, hipStream_t s)
+// Pass-3 streams at 192 kHz.  FLT variant (s16 in, no limiter prefix): swr int_sample_fmt FLTP = float taps, float
+// accumulation.  DBL variant (after the alimiter prefix): DBLP.
+void launch_resample_stream_s16_f32(const int16_t *in, int64_t n, const float *bankf, int phase_count, int filter_length, int center,
+                                    int64_t step, int64_t m_total, float *out, hipStream_t s)
 {
     if (m_total <= 0) return;
-    int bpl; int64_t halo, nchunks;
-    rk_geometry(m_total, blk, &bpl, &halo, &nchunks);
-    unsigned grid = (unsigned)((nchunks + 63) / 64);
-    hipLaunchKernelGGL((k_resample_kweight<int16_t, float, float>), dim3(grid), dim3(64), 0, s, in, n, bankf, phase_count,
-                       filter_length, center, step, m_total, blk, bpl, halo, pre, rlb, block_sums, block_peaks, nblocks_alloc,
-                       nchunks, 1.0 / 32768.0);
+    PPGeom g = pp_geometry<float>(n, phase_count, filter_length, step, m_total, false);
+    auto k = k_polyphase<int16_t, float, float, 2>;
+    JT_HIP(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)g.smem));
+    hipLaunchKernelGGL(k, dim3(g.grid), dim3(PP_THREADS), g.smem, s, in, n, bankf, phase_count, filter_length, center, step, m_total,
+                       g.R, 1.0 / 32768.0, 1, (unsigned long long *)nullptr, (int64_t)0, (int16_t *)nullptr, out);
 }
-void launch_resample_kweight_f64(const double *in, int64_t n, const double *bank, int phase_count, int filter_length, int center,
-                                 int64_t step, int64_t m_total, int blk, BiquadF64 pre, BiquadF64 rlb,
-                                 double *block_sums, double *block_peaks, int64_t nblocks_alloc, hipStream_t s)
+void launch_resample_stream_f64(const double *in, int64_t n, const double *bank, int phase_count, int filter_length, int center,
+                                int64_t step, int64_t m_total, double *out, hipStream_t s)
 {
     if (m_total <= 0) return;
-    int bpl; int64_t halo, nchunks;
-    rk_geometry(m_total, blk, &bpl, &halo, &nchunks);
-    unsigned grid = (unsigned)((nchunks + 63) / 64);
-    hipLaunchKernelGGL((k_resample_kweight<double, double, double>), dim3(grid), dim3(64), 0, s, in, n, bank, phase_count,
-                       filter_length, center, step, m_total, blk, bpl, halo, pre, rlb, block_sums, block_peaks, nblocks_alloc,
-                       nchunks, 1.0);
+    PPGeom g = pp_geometry<double>(n, phase_count, filter_length, step, m_total, false);
+    auto k = k_polyphase<double, double, double, 2>;
+    JT_HIP(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)g.smem));
+    hipLaunchKernelGGL(k, dim3(g.grid), dim3(PP_THREADS), g.smem, s, in, n, bank, phase_count, filter_length, center, step, m_total,
+                       g.R, 1.0, 1, (unsigned long long *)nullptr, (int64_t)0, (int16_t *)nullptr, out);
 }
