@@ -57,6 +57,31 @@ __device__ inline void tile_store(TL (*tile)[TW + 1], TOut *__restrict__ out, in
     }
 }
 
+// Software-pipelined variant: the next tile's 64 row loads are issued into registers BEFORE the current tile is
+// processed, so their HBM latency hides behind the recurrence instead of stalling every tile.
+template <typename TIn>
+__device__ inline void rows_prefetch(TIn (&v)[LANES], const TIn *__restrict__ in, int64_t n, int64_t base0, int64_t rowstride,
+                                     int64_t pos, int lane)
+{
+#pragma unroll
+    for (int r = 0; r < LANES; ++r) {
+        int64_t idx = base0 + (int64_t)r * rowstride + pos + lane;
+        int64_t ic = idx < 0 ? 0 : (idx >= n ? n - 1 : idx);
+        v[r] = in[ic];
+    }
+}
+template <typename TIn, typename TL>
+__device__ inline void rows_commit(TL (*tile)[TW + 1], const TIn (&v)[LANES], int64_t n, int64_t base0, int64_t rowstride,
+                                   int64_t pos, int lane, int nrows)
+{
+#pragma unroll
+    for (int r = 0; r < LANES; ++r) {
+        int64_t idx = base0 + (int64_t)r * rowstride + pos + lane;
+        bool ok = r < nrows && idx >= 0 && idx < n;
+        tile[r][lane] = ok ? (TL)v[r] : (TL)0;
+    }
+}
+
 // ------------------------------------------------------------------ small elementwise kernels
 __global__ void k_downmix(const float *__restrict__ in, float *__restrict__ out, int64_t frames, int channels)
 {
@@ -254,45 +279,71 @@ __global__ void __launch_bounds__(64)
 k_kweight_blocks(const TIn *__restrict__ in, int64_t n, int blk, int bpl, int64_t halo, BiquadF64 pre, BiquadF64 rlb,
                  double *__restrict__ block_sums, double *__restrict__ block_peaks, int64_t nblocks_alloc, int64_t nchunks)
 {
-    __shared__ double tile[LANES][TW + 1];
+    __shared__ TIn tile[LANES][TW + 1];
     const int lane = threadIdx.x;
     const int64_t chunk = (int64_t)blk * bpl;
     const int64_t c0 = (int64_t)blockIdx.x * LANES;
     const int nrows = (int)min((int64_t)LANES, nchunks - c0);
     const int64_t base0 = c0 * chunk - halo;
     const int64_t my_base = base0 + (int64_t)lane * chunk;
-    const int64_t my_chunk = c0 + lane;
-    double x1 = 0, x2 = 0, y0 = 0, y1 = 0, y2 = 0, z0 = 0, z1 = 0, z2 = 0;
+    double x1 = 0, x2 = 0, y1 = 0, y2 = 0, z1 = 0, z2 = 0;
     double acc = 0.0, pk = 0.0;
-    int cnt = 0; int64_t bidx = my_chunk * bpl;
-    const int64_t total = halo + chunk;
+    int cnt = 0; int64_t bidx = (c0 + lane) * bpl;
+    const int64_t total = halo + chunk;          // halo and chunk are multiples of TW
+    const double na1 = -pre.a1, na2 = -pre.a2, nr1 = -rlb.a1, nr2 = -rlb.a2;
+    // one K-weighting step.  Same difference equations as f_ebur128.c's FILTER macro, evaluated with fused multiply-adds
+    // and the feed-forward part hoisted off the recurrence's critical path (rounding differs from the scalar code at 1e-16).
+#define KW_STEP(X0)                                                                   \
+    {                                                                                  \
+        const double ff = fma(pre.b2, x2, fma(pre.b1, x1, pre.b0 * (X0)));             \
+        const double y0 = fma(na1, y1, fma(na2, y2, ff));                              \
+        const double fz = fma(rlb.b2, y2, fma(rlb.b1, y1, rlb.b0 * y0));               \
+        z0 = fma(nr1, z1, fma(nr2, z2, fz));                                           \
+        x2 = x1; x1 = (X0); y2 = y1; y1 = y0; z2 = z1; z1 = z0;                        \
+    }
+    TIn v[LANES];
+    rows_prefetch<TIn>(v, in, n, base0, chunk, 0, lane);
     for (int64_t pos = 0; pos < total; pos += TW) {
-        tile_load<TIn, double>(tile, in, n, base0, chunk, pos, lane, nrows);
+        rows_commit<TIn, TIn>(tile, v, n, base0, chunk, pos, lane, nrows);
         __syncthreads();
+        if (pos + TW < total) rows_prefetch<TIn>(v, in, n, base0, chunk, pos + TW, lane);
         if (lane < nrows) {
-            for (int j = 0; j < TW; ++j) {
-                int64_t rel = pos + j;
-                int64_t idx = my_base + rel;
-                if (rel >= total || idx >= n) break;
-                if (idx < 0) continue;
-                double x0 = tile[lane][j];
-                y2 = y1; y1 = y0;
-                y0 = x0 * pre.b0 + x1 * pre.b1 + x2 * pre.b2 - y1 * pre.a1 - y2 * pre.a2;
-                x2 = x1; x1 = x0;
-                z2 = z1; z1 = z0;
-                z0 = y0 * rlb.b0 + y1 * rlb.b1 + y2 * rlb.b2 - z1 * rlb.a1 - z2 * rlb.a2;
-                if (rel >= halo) {
-                    acc += z0 * z0;
-                    pk = fmax(pk, fabs(x0));
-                    if (++cnt == blk) {
-                        if (bidx < nblocks_alloc) { block_sums[bidx] = acc; block_peaks[bidx] = pk; }
-                        acc = 0.0; pk = 0.0; cnt = 0; ++bidx;
+            const int64_t t0 = my_base + pos;
+            const bool inside = t0 >= 0 && t0 + TW <= n;
+            double z0;
+            const bool full = inside && pos + TW <= total;
+            if (full && pos + TW <= halo) {                         // warm-up: filter only
+#pragma unroll 16
+                for (int j = 0; j < TW; ++j) { const double x0 = (double)tile[lane][j]; KW_STEP(x0) }
+            } else if (full && pos >= halo && cnt + TW < blk) {     // steady state: no block boundary inside this tile
+                double a0 = 0.0, p0 = 0.0;
+#pragma unroll 16
+                for (int j = 0; j < TW; ++j) {
+                    const double x0 = (double)tile[lane][j];
+                    KW_STEP(x0)
+                    a0 = fma(z0, z0, a0); p0 = fmax(p0, fabs(x0));
+                }
+                acc += a0; pk = fmax(pk, p0); cnt += TW;
+            } else {                                                // edges: file start/end, block boundaries
+                for (int j = 0; j < TW; ++j) {
+                    const int64_t idx = t0 + j;
+                    if (pos + j >= total) break;
+                    if (idx < 0 || idx >= n) continue;
+                    const double x0 = (double)tile[lane][j];
+                    KW_STEP(x0)
+                    if (pos + j >= halo) {
+                        acc = fma(z0, z0, acc); pk = fmax(pk, fabs(x0));
+                        if (++cnt == blk) {
+                            if (bidx < nblocks_alloc) { block_sums[bidx] = acc; block_peaks[bidx] = pk; }
+                            acc = 0.0; pk = 0.0; cnt = 0; ++bidx;
+                        }
                     }
                 }
             }
         }
         __syncthreads();
     }
+#undef KW_STEP
     if (lane < nrows && cnt > 0 && bidx < nblocks_alloc) { block_sums[bidx] = acc; block_peaks[bidx] = pk; }
 }
 
@@ -302,7 +353,7 @@ static void kweight_geometry(int64_t n, int blk, int sr_hint, int *bpl, int64_t 
     int64_t h = (int64_t)std::ceil(8192.0 * sr_hint / 48000.0);
     h = (h + TW - 1) / TW * TW;
     *halo = h;
-    int b = (int)std::max<int64_t>(2, (2 * h + blk - 1) / blk);
+    int b = (int)std::max<int64_t>(1, (h / 2 + blk - 1) / blk);
     *bpl = b;
     int64_t chunk = (int64_t)blk * b;
     *nchunks = (n + chunk - 1) / chunk;
@@ -428,15 +479,23 @@ k_follow_states(const TIn *__restrict__ in, int64_t n, double att, double rel, i
     const int64_t base0 = c0 * chunk - halo;
     const int64_t my_base = base0 + (int64_t)lane * chunk;
     double s = 0.0;
-    const int64_t total = halo + chunk;
+    const int64_t total = halo + chunk;            // multiples of SC (hence of TW)
+    TIn v[LANES];
+    rows_prefetch<TIn>(v, in, n, base0, chunk, 0, lane);
     for (int64_t pos = 0; pos < total; pos += TW) {
-        tile_load<TIn, TIn>(tile, in, n, base0, chunk, pos, lane, nrows);
+        rows_commit<TIn, TIn>(tile, v, n, base0, chunk, pos, lane, nrows);
         __syncthreads();
+        if (pos + TW < total) rows_prefetch<TIn>(v, in, n, base0, chunk, pos + TW, lane);
         if (lane < nrows) {
             const int64_t t0 = my_base + pos;
             if (pos >= halo && ((pos - halo) % SC) == 0 && t0 < n) states[t0 / SC] = s;     // state BEFORE sample t0
-            if (t0 + TW > 0 && t0 < n) {
-#pragma unroll 8
+            if (t0 >= 0 && t0 + TW <= n) {
+#pragma unroll 16
+                for (int j = 0; j < TW; ++j) {
+                    double a = (double)tile[lane][j]; a = fabs(a); a *= a;
+                    s += (a - s) * (a > s ? att : rel);
+                }
+            } else if (t0 + TW > 0 && t0 < n) {
                 for (int j = 0; j < TW; ++j) {
                     const int64_t idx = t0 + j;
                     if (idx >= 0 && idx < n) {

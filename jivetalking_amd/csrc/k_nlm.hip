@@ -1,17 +1,120 @@
-// k_nlm.hip — anlmdn (FFmpeg af_anlmdn.c; filters.go:95-100,811-816: anlmdn=s=0.00001:p=0.0060:r=0.0020:m=3)
-// for gfx950.  This is the one ALU-bound stage of the path (~2S patch comparisons per sample).
+// k_nlm.hip — anlmdn (FFmpeg af_anlmdn.c; filters.go:95-100,811-816: anlmdn=s=0.00001:p=0.0060:r=0.0020:m=3) for gfx950.
+// The one ALU-bound stage of the path: 2S patch comparisons per sample (S = r*fs = 96 @48 kHz), each a running SSD over a
+// 2K+1 = 577-sample patch.
 //
-// Mapping.  FFmpeg processes hops of H = 2K+1 output samples; inside a hop it keeps, for each of the 2S search
-// offsets, a running patch SSD (`cache[j]`) that is seeded exactly at the hop start and then updated with two
-// squared differences per step — a recurrence ALONG TIME for fixed offset — and then, for each output sample,
-// accumulates the weighted neighbours sequentially ACROSS offsets.  One workgroup = one hop, one thread = one
-// offset: each thread carries its SSD in a register through the hop (identical f32 operation order to the C
-// code, no FMA contraction), writes its weight for TI consecutive outputs into a padded LDS tile, and the tile
-// is then reduced one-thread-per-output in ascending-offset order — i.e. the same summation order as FFmpeg,
-// so the result is bit-identical to a scalar build.  The hop's input window (H + 2(K+S) floats) is staged in
-// LDS once; HBM traffic is 1 read (+halo) and 1 write per sample.
+// FFmpeg's structure: hops of H = 2K+1 outputs; per hop and per search offset a running patch distance `cache[j]` that is
+// seeded exactly at the hop start and then updated with two squared differences per step (a recurrence ALONG TIME for a
+// fixed offset); per output, weights exp(-d*sw) (via a 2^20-entry LUT) are accumulated across the offsets.
+//
+// k_anlmdn_wave (fast path, 2S = 64*NOFF and S % NOFF == 0: 48 kHz -> NOFF 3, 96 kHz -> NOFF 6):
+//   ONE WAVE PER HOP, no barriers.  Lane l owns NOFF ADJACENT offsets, so the three sample streams each offset consumes
+//   (f[j+K], f[j-K-1], f[j]) overlap between its offsets and between consecutive steps: per step a lane reads one new value
+//   per stream (register rotation) + 2 broadcast values, instead of 4 LDS reads per offset.  The patch-distance recurrence
+//   keeps FFmpeg's exact f32 operation order (no FMA contraction).  The per-output sums over the 2S offsets are a lane-local
+//   sum of NOFF terms followed by a DPP row/bank reduction over the 64 lanes (deterministic, but not FFmpeg's sequential
+//   order: results agree to f32 round-off of the weighted mean).  LDS per wave: the hop's input window (5.4 KB @48 kHz) + H
+//   outputs, so occupancy is bounded by registers only.  HBM traffic: 1 read (+ (2K+2S)/H halo) and 1 write per sample.
+// k_anlmdn (generic path, any K/S): one workgroup per hop, one thread per offset, weights transposed through an LDS tile and
+//   summed in FFmpeg's sequential offset order.
 #include "jt_internal.h"
 
+// ------------------------------------------------------------------ wave-per-hop fast path
+#define JT_DPP(v, ctrl, rmask) __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), (ctrl), (rmask), 0xf, false))
+// wave64 sum, total valid in lane 63 (gfx9 DPP: quad_perm x2, row_shr 4/8, row_bcast 15/31)
+__device__ inline float wave_sum63(float v)
+{
+    v += JT_DPP(v, 0xb1, 0xf);     // quad_perm:[1,0,3,2]
+    v += JT_DPP(v, 0x4e, 0xf);     // quad_perm:[2,3,0,1]
+    v += JT_DPP(v, 0x114, 0xf);    // row_shr:4
+    v += JT_DPP(v, 0x118, 0xf);    // row_shr:8
+    v += JT_DPP(v, 0x142, 0xa);    // row_bcast:15 -> rows 1,3
+    v += JT_DPP(v, 0x143, 0xc);    // row_bcast:31 -> rows 2,3
+    return v;
+}
+
+template <int NOFF>
+__global__ void __launch_bounds__(64)
+k_anlmdn_wave(const float *__restrict__ in, float *__restrict__ out, int64_t n, int K, int S, float sw, float smooth,
+              float lut_scale, int64_t nhops)
+{
+    extern __shared__ float smem_nlm[];
+    const int H = 2 * K + 1;
+    const int NW = H + 2 * (K + S);
+    float *win = smem_nlm;                         // [NW]
+    float *obuf = smem_nlm + ((NW + 3) & ~3);      // [H]
+    const int lane = threadIdx.x;
+    const int64_t hop = (int64_t)blockIdx.x;
+    const int64_t hs = hop * H - (K + S);
+    for (int w = lane; w < NW; w += 64) {
+        int64_t k = hs - (K + S) + w;
+        win[w] = (k >= 0 && k < n) ? in[k] : 0.f;
+    }
+    __syncthreads();
+    const float *f = win + K;                      // f[i], i in [-K, NW-K)
+    // lane-owned adjacent offsets j0 .. j0+NOFF-1, all on the same side of the centre (S % NOFF == 0)
+    const int j0 = lane * NOFF;
+    const int d0 = j0 - S + (j0 >= S ? 1 : 0);     // neighbour offset of the first owned offset
+    float cache[NOFF];
+    // seed: compute_distance_ssd(f + S, f + S + dj, K), k ascending, f32 mul then add (as the C code)
+    {
+        const int i = S;
+#pragma unroll
+        for (int q = 0; q < NOFF; ++q) cache[q] = 0.f;
+        for (int k = -K; k <= K; ++k) {
+            const float c = f[i + k];
+#pragma unroll
+            for (int q = 0; q < NOFF; ++q) {
+                float dd = __fsub_rn(c, f[i + d0 + q + k]);
+                cache[q] = __fadd_rn(cache[q], __fmul_rn(dd, dd));
+            }
+        }
+    }
+    // stream registers: hi[q] = f[i + d0 + q + K], lo[q] = f[i + d0 + q - K - 1], ce[q] = f[i + d0 + q] for the CURRENT i
+    float hi[NOFF], lo[NOFF], ce[NOFF];
+#pragma unroll
+    for (int q = 0; q < NOFF; ++q) {
+        hi[q] = f[S + d0 + q + K]; ce[q] = f[S + d0 + q];
+        const int li = S + d0 + q - K - 1;              // first used at i = S+1 (never below f[-K])
+        lo[q] = li >= -K ? f[li] : 0.f;
+    }
+    for (int i = S; i < H + S; ++i) {
+        const float cm = f[i - K - 1], cp = f[i + K], cc = f[i];   // wave-uniform (broadcast) reads
+        float P = 0.f, Q = 0.f;
+#pragma unroll
+        for (int q = 0; q < NOFF; ++q) {
+            if (i != S) {
+                // compute_cache(): cache += -(f[i-K-1]-f[j-K-1])^2 + (f[i+K]-f[j+K])^2
+                const float a = __fsub_rn(cm, lo[q]);
+                const float b = __fsub_rn(cp, hi[q]);
+                cache[q] = __fadd_rn(cache[q], __fadd_rn(-__fmul_rn(a, a), __fmul_rn(b, b)));
+            }
+            float distance = cache[q];
+            if (distance < 0.f) cache[q] = distance = 0.f;
+            const float w = __fmul_rn(distance, sw);
+            if (!(w >= smooth)) {
+                const unsigned idx = (unsigned)__fmul_rn(w, lut_scale);
+                const float wt = __expf(-(float)idx / lut_scale);         // weight_lut[idx] = expf(-idx/scale)
+                P = __fadd_rn(P, __fmul_rn(wt, ce[q]));
+                Q = __fadd_rn(Q, wt);
+            }
+        }
+        P = wave_sum63(P);
+        Q = wave_sum63(Q);
+        if (lane == 63) obuf[i - S] = __fadd_rn(P, cc) / __fadd_rn(Q, 1.f);
+        // advance the three streams by one sample: NOFF-1 values shift, one new value per stream is read
+#pragma unroll
+        for (int q = 0; q + 1 < NOFF; ++q) { hi[q] = hi[q + 1]; lo[q] = lo[q + 1]; ce[q] = ce[q + 1]; }
+        const int nx = i + 1 + d0 + (NOFF - 1);
+        hi[NOFF - 1] = f[nx + K]; lo[NOFF - 1] = f[nx - K - 1]; ce[NOFF - 1] = f[nx];
+    }
+    __syncthreads();
+    for (int t = lane; t < H; t += 64) {
+        int64_t o = hs + t;
+        if (o >= 0 && o < n) out[o] = obuf[t];
+    }
+}
+
+// ------------------------------------------------------------------ generic path (any K, S)
 constexpr int NLM_TI = 64;     // outputs per weight tile
 
 __global__ void k_anlmdn(const float *__restrict__ in, float *__restrict__ out, int64_t n, int K, int S,
@@ -41,7 +144,6 @@ __global__ void k_anlmdn(const float *__restrict__ in, float *__restrict__ out, 
             for (int ii = 0; ii < ti_n; ++ii) {
                 const int i = i0 + ii;
                 if (i == S) {
-                    // compute_distance_ssd(f + i, f + j, K), j = i + dj
                     float dist = 0.f;
                     const float *f1 = f + i, *f2 = f + i + dj;
                     for (int k = -K; k <= K; ++k) {
@@ -50,7 +152,6 @@ __global__ void k_anlmdn(const float *__restrict__ in, float *__restrict__ out, 
                     }
                     cache = dist;
                 } else {
-                    // compute_cache(): cache += -(f[i-K-1]-f[j-K-1])^2 + (f[i+K]-f[j+K])^2
                     const int j = i + dj;
                     float a = __fsub_rn(f[i - K - 1], f[j - K - 1]);
                     float b = __fsub_rn(f[i + K], f[j + K]);
@@ -63,7 +164,7 @@ __global__ void k_anlmdn(const float *__restrict__ in, float *__restrict__ out, 
                 float weight = 0.f;
                 if (!(w >= smooth)) {
                     unsigned idx = (unsigned)__fmul_rn(w, lut_scale);
-                    weight = expf(-(float)idx / lut_scale);      // weight_lut[idx]
+                    weight = __expf(-(float)idx / lut_scale);
                 }
                 wt[ii * wstride + tid] = weight;
             }
@@ -73,12 +174,11 @@ __global__ void k_anlmdn(const float *__restrict__ in, float *__restrict__ out, 
             const int i = i0 + tid;
             const float *wr = wt + tid * wstride;
             float P = 0.f, Q = 0.f;
+#pragma unroll 8
             for (int j = 0; j < S2; ++j) {
-                float w = wr[j];
-                if (w != 0.f) {       // skipped offsets contribute nothing (w >= smooth -> continue)
-                    P = __fadd_rn(P, __fmul_rn(w, f[i - S + j + (j >= S ? 1 : 0)]));
-                    Q = __fadd_rn(Q, w);
-                }
+                const float w = wr[j];        // skipped offsets carry weight 0: adding 0*f and 0 leaves P, Q unchanged
+                P = __fadd_rn(P, __fmul_rn(w, f[i - S + j + (j >= S ? 1 : 0)]));
+                Q = __fadd_rn(Q, w);
             }
             P = __fadd_rn(P, f[i]);
             Q = __fadd_rn(Q, 1.f);
@@ -95,6 +195,19 @@ void launch_anlmdn(const float *in, float *out, int64_t n, int K, int S, float s
     const int H = 2 * K + 1;
     const int NW = H + 2 * (K + S);
     int64_t nhops = (n + (K + S) + H - 1) / H;
+    const int noff = (2 * S) / 64;
+    const bool fast = (2 * S) % 64 == 0 && noff >= 1 && S % noff == 0 && (noff == 3 || noff == 6 || noff == 2 || noff == 4);
+    if (fast) {
+        size_t smem = sizeof(float) * (size_t)(((NW + 3) & ~3) + H + 4);
+        JT_REQUIRE(smem <= 64 * 1024, JT_E_UNSUPPORTED, "anlmdn: window exceeds the wave-per-hop LDS budget");
+        switch (noff) {
+        case 2: hipLaunchKernelGGL((k_anlmdn_wave<2>), dim3((unsigned)nhops), dim3(64), smem, s, in, out, n, K, S, sw, smooth, lut_scale, nhops); break;
+        case 3: hipLaunchKernelGGL((k_anlmdn_wave<3>), dim3((unsigned)nhops), dim3(64), smem, s, in, out, n, K, S, sw, smooth, lut_scale, nhops); break;
+        case 4: hipLaunchKernelGGL((k_anlmdn_wave<4>), dim3((unsigned)nhops), dim3(64), smem, s, in, out, n, K, S, sw, smooth, lut_scale, nhops); break;
+        default: hipLaunchKernelGGL((k_anlmdn_wave<6>), dim3((unsigned)nhops), dim3(64), smem, s, in, out, n, K, S, sw, smooth, lut_scale, nhops); break;
+        }
+        return;
+    }
     int threads = ((2 * S + 63) / 64) * 64;
     if (threads < NLM_TI) threads = NLM_TI;
     JT_REQUIRE(threads <= 1024, JT_E_UNSUPPORTED, "anlmdn: research radius too large for one workgroup");

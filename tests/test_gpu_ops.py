@@ -48,18 +48,22 @@ def test_anlmdn_matches_oracle_quiet_noise(engine, oracle):
     ref = oracle.anlmdn(x, SR)
     got = engine.op_anlmdn(x, SR)
     assert np.max(np.abs(ref - x)) > 1e-6           # the filter actually did something
-    # identical f32 operation order; only expf may differ by 1 ulp between libm and the GPU: 1e-7 rel to signal
-    assert np.max(np.abs(got - ref)) < 1e-8
+    # patch-distance recurrence in FFmpeg's exact f32 order; weights use the hardware exp (2 ulp) and the per-output sum
+    # over the 192 offsets is a fixed lane/DPP tree instead of the sequential loop: tolerance 1e-5 of the signal scale
+    assert np.max(np.abs(got - ref)) < 1e-5 * np.max(np.abs(x))
 
 
 def test_anlmdn_speech_and_edges(engine, oracle):
     x = speech(3.0, 4)
     ref = oracle.anlmdn(x, SR)
     got = engine.op_anlmdn(x, SR)
-    assert np.max(np.abs(got - ref)) < 1e-7
+    assert np.max(np.abs(got - ref)) < 1e-5 * np.max(np.abs(x))
     for n in (1, 500, 577, 578, 1345):
         y = noise(n, 1e-3, n)
-        assert np.max(np.abs(engine.op_anlmdn(y, SR) - oracle.anlmdn(y, SR))) < 1e-7
+        assert np.max(np.abs(engine.op_anlmdn(y, SR) - oracle.anlmdn(y, SR))) < 1e-8
+    # generic (workgroup-per-hop, sequential-order) path: 44.1 kHz gives 2S = 176, not a multiple of 64
+    z = speech(2.0, 5, 44100)
+    assert np.max(np.abs(engine.op_anlmdn(z, 44100) - oracle.anlmdn(z, 44100))) < 1e-5 * np.max(np.abs(z))
 
 
 # ---------------------------------------------------------------- afftdn
