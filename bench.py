@@ -130,9 +130,11 @@ def main():
                        "input_lufs": round(res.input_lufs, 3), "within_target": bool(res.within_target)},
             "pass_ms": {"pass1": round(float(pm[0]), 3), "pass2": round(float(pm[1]), 3),
                         "pass3": round(float(pm[2]), 3), "pass4": round(float(pm[3]), 3)},
+            "stage_wall_ms": dict(zip(["pass1", "intervals_vad", "bands", "adapt", "pass2", "regions2", "plan", "pass3", "pass4", "regions4"],
+                                      [round(float(v), 3) for v in res.stage_ms])),
             "pipeline_hbm": {"algorithmic_bytes_per_file": alg_bytes_file,
                              "achieved_GBps": round(alg_bytes_file * world * args.steps / dt / 1e9, 2), "peak_GBps": 8000},
-            "roofline": {"kernel": "k_anlmdn", "bound": "hbm", "achieved": round(nlm_bytes / nlm_avg_s / 1e9, 2),
+            "roofline": {"kernel": "k_anlmdn_wave<3>", "bound": "hbm", "achieved": round(nlm_bytes / nlm_avg_s / 1e9, 2),
                          "peak": 8000, "unit": "GB/s", "frac": round(nlm_bytes / nlm_avg_s / 1e9 / 8000, 5), "traffic": None,
                          "note": "anlmdn is vector-FP32 bound, not HBM bound (SURVEY §8d): see valu",
                          "valu": {"achieved_TFLOPs": round(nlm_flops / nlm_avg_s / 1e12, 2), "peak_TFLOPs": 157.3,

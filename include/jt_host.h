@@ -152,6 +152,7 @@ typedef struct {
     double output_lufs, output_tp_db, input_lufs, input_tp_db; int within_target;
     char pass2_spec[2048]; char pass4_spec[2048];
     double pass_ms[4];
+    double stage_ms[10];     /* host wall-clock: pass1, intervals+VAD, bands, adapt, pass2, regions(2), plan, pass3, pass4, regions(4) */
 } jt_process_result;
 
 int jt_process_audio(jt_ctx *h, const jt_host_config *base, int frame_samples, jt_process_result *out);

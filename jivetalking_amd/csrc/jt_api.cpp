@@ -285,23 +285,29 @@ extern "C" int jt_band_rms(jt_ctx *h, double start_s, double dur_s, const double
     int64_t s0, len; trim_range(start_s, dur_s, h->sr, h->n, &s0, &len);
     for (int b = 0; b < n_bands; ++b) { out_db[b] = NAN; if (ok) ok[b] = 0; }
     if (len <= 0) return JT_OK;
-    DevBuf<float> tmp; tmp.ensure((size_t)len);
-    DevBuf<double> red; red.ensure(2);
+    JT_REQUIRE(n_bands <= 16, JT_E_INVAL, "band_rms: at most 16 bands per call");
+    BiquadF32 hp[16], lp[16]; int slot[16]; int nb = 0;
     for (int b = 0; b < n_bands; ++b) {
-        double bh[3], ah[3], bl[3], al[3];
+        // a corner at/above Nyquist has no valid biquad: the reference treats those bands as unmeasurable (non-finite)
         if (hi_hz[b] >= h->sr * 0.5 || lo_hz[b] >= h->sr * 0.5) { out_db[b] = NAN; if (ok) ok[b] = 1; continue; }
+        double bh[3], ah[3], bl[3], al[3];
         jt_biquad_design(0, lo_hz[b], 0.707, h->sr, bh, ah, 0);
         jt_biquad_design(1, hi_hz[b], 0.707, h->sr, bl, al, 0);
-        BiquadF32 hp{(float)bh[0], (float)bh[1], (float)bh[2], -(float)ah[1], -(float)ah[2]};
-        BiquadF32 lp{(float)bl[0], (float)bl[1], (float)bl[2], -(float)al[1], -(float)al[2]};
-        launch_biquad_di_f32(h->in_mono + s0, tmp.p, len, hp, lp, h->stream);
-        launch_frame_stats(tmp.p, len, (int)std::min<int64_t>(len, 0x7fffffff), red.p, red.p + 1, 1, h->stream);
-        double r[2];
-        JT_HIP(hipMemcpyAsync(r, red.p, sizeof(r), hipMemcpyDeviceToHost, h->stream));
+        hp[nb] = BiquadF32{(float)bh[0], (float)bh[1], (float)bh[2], -(float)ah[1], -(float)ah[2]};
+        lp[nb] = BiquadF32{(float)bl[0], (float)bl[1], (float)bl[2], -(float)al[1], -(float)al[2]};
+        slot[nb++] = b;
+    }
+    if (nb > 0) {
+        h->d_scr1.ensure(16);
+        JT_HIP(hipMemsetAsync(h->d_scr1.p, 0, sizeof(double) * 16, h->stream));
+        launch_band_rms(h->in_mono + s0, len, nb, hp, lp, h->d_scr1.p, h->stream);
+        double sums[16];
+        JT_HIP(hipMemcpyAsync(sums, h->d_scr1.p, sizeof(double) * 16, hipMemcpyDeviceToHost, h->stream));
         JT_HIP(hipStreamSynchronize(h->stream));
-        double rms = std::sqrt(r[0] / (double)len);
-        out_db[b] = 20 * std::log10(rms);
-        if (ok) ok[b] = 1;   // astats Overall.RMS_level key present (may be -inf on digital silence)
+        for (int k = 0; k < nb; ++k) {
+            out_db[slot[k]] = 20 * std::log10(std::sqrt(sums[k] / (double)len));
+            if (ok) ok[slot[k]] = 1;   // astats Overall.RMS_level key present (may be -inf on digital silence)
+        }
     }
     JT_API_END(h)
 }

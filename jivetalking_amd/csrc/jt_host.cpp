@@ -9,6 +9,7 @@
 #include <cstdarg>
 #include <cstdlib>
 #include <functional>
+#include <chrono>
 
 namespace {
 
@@ -21,10 +22,45 @@ std::string sfmt(const char *fmt, ...)
     va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof(buf), fmt, ap); va_end(ap);
     return std::string(buf);
 }
-double qfmt(const char *fmt, double v)
+double qfmt_slow(const char *fmt, double v)
 {
     if (!std::isfinite(v)) return v;
     char buf[64]; snprintf(buf, sizeof(buf), fmt, v); return std::strtod(buf, nullptr);
+}
+// Value a C "%.Nf" / "%g" print-and-reparse would yield, without going through printf on the hot path (hundreds of
+// thousands of metadata values per file).  Decimal scaling + round-to-nearest-even; falls back to printf when the scaled
+// value sits within a few ulp of a rounding tie, so the result always equals the printf round trip.
+double qdec(double v, int decimals)
+{
+    if (!std::isfinite(v)) return v;
+    static const double p10[] = {1, 1e1, 1e2, 1e3, 1e4, 1e5, 1e6, 1e7, 1e8, 1e9};
+    const double sc = p10[decimals];
+    const double t = v * sc;
+    if (std::fabs(t) > 4e15) return v;
+    const double r = std::nearbyint(t);
+    const double frac = std::fabs(t - r);
+    if (std::fabs(frac - 0.5) < 1e-6) { char f[8]; snprintf(f, sizeof(f), "%%.%df", decimals); return qfmt_slow(f, v); }
+    return r / sc;
+}
+double qsig6(double v)      // "%g": 6 significant digits
+{
+    if (!std::isfinite(v) || v == 0.0) return v;
+    const int e = (int)std::floor(std::log10(std::fabs(v)));
+    const int dec = 5 - e;
+    if (dec < 0 || dec > 18) return qfmt_slow("%g", v);
+    const double sc = std::pow(10.0, dec);
+    const double t = v * sc;
+    const double r = std::nearbyint(t);
+    if (std::fabs(std::fabs(t - r) - 0.5) < 1e-6 || std::fabs(r) >= 1e6 || std::fabs(r) < 1e5) return qfmt_slow("%g", v);
+    return r / sc;
+}
+double qfmt(const char *fmt, double v)
+{
+    if (!std::strcmp(fmt, "%.3f")) return qdec(v, 3);
+    if (!std::strcmp(fmt, "%f")) return qdec(v, 6);
+    if (!std::strcmp(fmt, "%.2f")) return qdec(v, 2);
+    if (!std::strcmp(fmt, "%g")) return qsig6(v);
+    return qfmt_slow(fmt, v);
 }
 // Go's %g / strconv 'g' with shortest round-trip precision
 std::string go_g(double v)
@@ -192,8 +228,6 @@ Acc accumulateIntervalMetrics(const std::vector<jt_interval> &r)
     }
     return a;
 }
-double scoreIntervalWindow(const jt_interval *p, size_t n) { if (!n) return 0; double s = 0; for (size_t i = 0; i < n; ++i) s += p[i].rms_level; return s / (double)n; }
-
 double calculateRolloffScore(double r)
 {
     if (r >= 4000.0 && r <= 8000.0) return 1.0;
@@ -209,16 +243,20 @@ double calculateFluxScore(double f)
     if (f <= 0.030) return 0.4 - (f - 0.020) / (0.030 - 0.020) * 0.2;
     return 0.2;
 }
-double scoreSpeechIntervalWindow(const jt_interval *p, size_t cnt)
+// Window scorer over structure-of-arrays views (identical arithmetic and summation order to the per-interval form;
+// the sliding-window refinement evaluates O(N*W) windows, so the fields are laid out contiguously once).
+struct ScoreSoA { std::vector<double> kurt, flat, cent, rms, roll, flux; };
+double scoreSpeechWindowSoA(const ScoreSoA &a, size_t off, size_t cnt)
 {
     if (!cnt) return 0;
+    const double *K = a.kurt.data() + off, *F = a.flat.data() + off, *Cc = a.cent.data() + off, *R = a.rms.data() + off,
+                 *Ro = a.roll.data() + off, *Fl = a.flux.data() + off;
     double n = (double)cnt, kS = 0, fS = 0, cS = 0, rS = 0, roS = 0, flS = 0;
-    for (size_t i = 0; i < cnt; ++i) { kS += p[i].spectral.kurtosis; fS += p[i].spectral.flatness; cS += p[i].spectral.centroid;
-        rS += p[i].rms_level; roS += p[i].spectral.rolloff; flS += p[i].spectral.flux; }
+    for (size_t i = 0; i < cnt; ++i) { kS += K[i]; fS += F[i]; cS += Cc[i]; rS += R[i]; roS += Ro[i]; flS += Fl[i]; }
     double aK = kS / n, aF = fS / n, aC = cS / n, aR = rS / n, aRo = roS / n, aFl = flS / n;
-    double kv = 0; for (size_t i = 0; i < cnt; ++i) { double d = p[i].spectral.kurtosis - aK; kv += d * d; }
+    double kv = 0; for (size_t i = 0; i < cnt; ++i) { double d = K[i] - aK; kv += d * d; }
     double kVar = kv / n;
-    int voiced = 0; for (size_t i = 0; i < cnt; ++i) if (p[i].spectral.kurtosis > 4.5) voiced++;
+    int voiced = 0; for (size_t i = 0; i < cnt; ++i) if (K[i] > 4.5) voiced++;
     double voicingScore = std::max(0.0, std::min(((double)voiced / n) / 0.6, 1.0));
     double kurtosisScore = std::max(0.0, std::min(aK / 7.5, 1.0));
     double flatnessScore = std::max(0.0, std::min(1.0 - aF, 1.0));
@@ -235,7 +273,7 @@ double scoreSpeechIntervalWindow(const jt_interval *p, size_t cnt)
 
 struct Refined { int64_t start, end, duration; bool ok; };
 Refined refineToSubregion(int64_t rs, int64_t re, int64_t rd, const std::vector<jt_interval> &iv, int64_t winDur, int64_t winMin,
-                          const std::function<double(const jt_interval *, size_t)> &score, bool higher_is_better)
+                          bool speech_scorer /* false: lowest mean RMS (room tone) */)
 {
     Refined out{rs, re, rd, false};
     if (rd <= winDur) return out;
@@ -244,11 +282,24 @@ Refined refineToSubregion(int64_t rs, int64_t re, int64_t rd, const std::vector<
     int w = (int)(winDur / goldenIntervalSize), mn = (int)(winMin / goldenIntervalSize);
     if ((int)c.size() < mn) return out;
     if ((int)c.size() < w) w = (int)c.size();
-    int bestIdx = 0; double best = score(c.data(), (size_t)w);
-    for (int s = 1; s <= (int)c.size() - w; ++s) {
-        double sc = score(c.data() + s, (size_t)w);
-        bool better = higher_is_better ? (sc > best) : (sc < best);
-        if (better) { best = sc; bestIdx = s; }
+    ScoreSoA a;
+    const size_t nc = c.size();
+    a.rms.resize(nc);
+    for (size_t i = 0; i < nc; ++i) a.rms[i] = c[i].rms_level;
+    if (speech_scorer) {
+        a.kurt.resize(nc); a.flat.resize(nc); a.cent.resize(nc); a.roll.resize(nc); a.flux.resize(nc);
+        for (size_t i = 0; i < nc; ++i) { a.kurt[i] = c[i].spectral.kurtosis; a.flat[i] = c[i].spectral.flatness; a.cent[i] = c[i].spectral.centroid;
+                                          a.roll[i] = c[i].spectral.rolloff; a.flux[i] = c[i].spectral.flux; }
+    }
+    auto score = [&](size_t off) -> double {
+        if (speech_scorer) return scoreSpeechWindowSoA(a, off, (size_t)w);
+        double sum = 0; const double *R = a.rms.data() + off; for (int i = 0; i < w; ++i) sum += R[i]; return sum / (double)w;   // scoreIntervalWindow
+    };
+    int bestIdx = 0; double best = score(0);
+    for (int st = 1; st <= (int)nc - w; ++st) {
+        double sc = score((size_t)st);
+        bool better = speech_scorer ? (sc > best) : (sc < best);
+        if (better) { best = sc; bestIdx = st; }
     }
     int64_t st = c[bestIdx].timestamp_ns, du = (int64_t)w * goldenIntervalSize;
     return Refined{st, st + du, du, true};
@@ -316,7 +367,7 @@ BestResult findBestSpeechRegion(const std::vector<jt_region> &regions, const std
     const int64_t gw = 60 * kSecond, gmin = 30 * kSecond;
     if (have && best.duration_ns > gw) {
         jt_region orig = best;
-        Refined rf = refineToSubregion(best.start_ns, best.end_ns, best.duration_ns, iv, gw, gmin, scoreSpeechIntervalWindow, true);
+        Refined rf = refineToSubregion(best.start_ns, best.end_ns, best.duration_ns, iv, gw, gmin, true);
         jt_region refined = rf.ok ? jt_region{rf.start, rf.end, rf.duration} : best;
         bool wasRefined = refined.start_ns != orig.start_ns || refined.duration_ns != orig.duration_ns;
         if (wasRefined) {
@@ -350,7 +401,7 @@ bool pickLowClusterRegion(const std::vector<jt_interval> &iv, double split, int6
     }
     if (inRun) closeRun((int)iv.size() - 1);
     if (!haveBest) return false;
-    Refined rf = refineToSubregion(best.start_ns, best.end_ns, best.duration_ns, iv, 10 * kSecond, 8 * kSecond, scoreIntervalWindow, false);
+    Refined rf = refineToSubregion(best.start_ns, best.end_ns, best.duration_ns, iv, 10 * kSecond, 8 * kSecond, false);
     *out = rf.ok ? jt_region{rf.start, rf.end, rf.duration} : best;
     return true;
 }
@@ -872,6 +923,7 @@ extern "C" int jt_host_pass4_spec(const jt_host_config *cfg, const jt_loudnorm_s
 // =====================================================================================================
 // orchestration (processor.go:29-216)
 // =====================================================================================================
+static double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 static double secs_of(int64_t ns) { return qfmt("%f", (double)ns / 1e9); }    // regions travel through "%f"-formatted filter options
 
 static int analyse_core(jt_ctx *h, const jt_host_config *base, int frame_samples, jt_process_result *out,
@@ -884,14 +936,17 @@ static int analyse_core(jt_ctx *h, const jt_host_config *base, int frame_samples
     const int64_t cap_meta = n / (sr / 10) + 2;
     std::vector<double> fss((size_t)nfr), fpk((size_t)nfr);
     std::vector<jt_frame_meta> meta((size_t)cap_meta);
+    double t0 = now_ms();
     if ((rc = jt_pass1(h, frame_samples, &a1, fss.data(), fpk.data(), nfr, meta.data(), cap_meta)) != JT_OK) return rc;
     out->pass_ms[0] = h->timers.pass1_ms;
+    out->stage_ms[0] = now_ms() - t0; t0 = now_ms();
     std::vector<jt_interval> iv((size_t)(n / (sr / 5) + 16));
     int64_t niv = jt_host_build_intervals(sr, n, frame_samples, h->channels, fss.data(), fpk.data(), nfr, meta.data(), a1.n_frames_meta, 1,
                                           iv.data(), (int64_t)iv.size());
     if (niv > (int64_t)iv.size()) niv = (int64_t)iv.size();
     jt_measurements &m = out->input;
     if ((rc = jt_host_detect(&a1, iv.data(), niv, (double)n / sr, base->target_i, 1, &m)) != JT_OK) return rc;
+    out->stage_ms[1] = now_ms() - t0; t0 = now_ms();
     // measureSpeechBands (analyser_bands.go:115-166)
     if (m.has_speech_profile && m.speech_profile.region.duration_ns > 0) {
         const double lo[2] = {1000.0, 6000.0}, hi[2] = {3000.0, 9000.0}; double db[2]; int ok[2];
@@ -913,8 +968,10 @@ static int analyse_core(jt_ctx *h, const jt_host_config *base, int frame_samples
             m.noise_profile.band_noise_n = 15; m.noise_profile.bands_measured = finite >= 10 ? 1 : 0;
         }
     }
+    out->stage_ms[2] = now_ms() - t0; t0 = now_ms();
     jt_host_finish_measurements(&m);
     jt_host_adapt(base, &m, eff_out, &out->diag);
+    out->stage_ms[3] = now_ms() - t0;
     out->effective = *eff_out;
     out->input_lufs = m.input_i; out->input_tp_db = m.input_tp;
     return JT_OK;
@@ -938,8 +995,10 @@ extern "C" int jt_process_audio(jt_ctx *h, const jt_host_config *base, int frame
     // Pass 2
     jt_host_filter_spec(&eff, 2, out->pass2_spec, (int)sizeof(out->pass2_spec));
     jt_filter_params fp; jt_host_filter_params(&eff, &fp);
+    double t0 = now_ms();
     if ((rc = jt_pass2(h, &fp, &out->filtered)) != JT_OK) return rc;
     out->pass_ms[1] = h->timers.pass2_ms;
+    out->stage_ms[4] = now_ms() - t0; t0 = now_ms();
     auto measure_regions = [&](int stage, jt_region_sample *rt, jt_region_sample *sp) {
         if (m.has_noise_profile && m.noise_profile.duration_ns > 0)
             (void)jt_region_measure(h, stage, secs_of(m.noise_profile.start_ns), secs_of(m.noise_profile.duration_ns), rt);
@@ -947,14 +1006,17 @@ extern "C" int jt_process_audio(jt_ctx *h, const jt_host_config *base, int frame
             (void)jt_region_measure(h, stage, secs_of(m.speech_profile.region.start_ns), secs_of(m.speech_profile.region.duration_ns), sp);
     };
     measure_regions(2, &out->filtered_room_tone, &out->filtered_speech);
+    out->stage_ms[5] = now_ms() - t0; t0 = now_ms();
     // Pass 3/4 (ApplyNormalisation, normalise.go:806-922)
     if (!eff.loudnorm_enabled) return JT_OK;
     const double outI = qfmt("%.3f", out->filtered.r128.integrated);
     const double outTP = linearRatioToDB(qfmt("%.3f", out->filtered.r128.true_peak));
     jt_limiter_plan plan; jt_host_plan_limiter(outI, outTP, &eff, &out->limiter, &plan);
     jt_loudnorm_stats m3;
+    out->stage_ms[6] = now_ms() - t0; t0 = now_ms();
     if ((rc = jt_pass3(h, &plan, eff.target_i, eff.target_tp, eff.target_lra, &m3)) != JT_OK) return rc;
     out->pass_ms[2] = h->timers.pass3_ms;
+    out->stage_ms[7] = now_ms() - t0; t0 = now_ms();
     m3.input_i = qfmt("%.2f", m3.input_i); m3.input_tp = qfmt("%.2f", m3.input_tp);
     m3.input_lra = qfmt("%.2f", m3.input_lra); m3.input_thresh = qfmt("%.2f", m3.input_thresh);
     out->measure = m3;
@@ -972,7 +1034,9 @@ extern "C" int jt_process_audio(jt_ctx *h, const jt_host_config *base, int frame
     jt_host_pass4_spec(&effcfg, &m3, offset, &out->limiter, h->out_rate, nullptr, out->pass4_spec, (int)sizeof(out->pass4_spec), &ap);
     if ((rc = jt_pass4(h, &plan, &ap, &out->final_, &out->loudnorm)) != JT_OK) return rc;
     out->pass_ms[3] = h->timers.pass4_ms;
+    out->stage_ms[8] = now_ms() - t0; t0 = now_ms();
     measure_regions(4, &out->final_room_tone, &out->final_speech);
+    out->stage_ms[9] = now_ms() - t0;
     out->has_region_samples = 1;
     out->output_lufs = qfmt("%.3f", out->final_.r128.integrated);
     out->output_tp_db = linearRatioToDB(qfmt("%.3f", out->final_.r128.true_peak));

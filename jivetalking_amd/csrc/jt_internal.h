@@ -83,6 +83,7 @@ void launch_dynamics(const float *in, float *out_f32, double *tmp64, double *tmp
 struct jt_ctx;
 void jt_astats_device(jt_ctx *h, const float *x, int64_t n, int sr, jt_astats *out);
 void launch_biquad_di_f32(const float *in, float *out, int64_t n, BiquadF32 hp, BiquadF32 lp, hipStream_t s);
+void launch_band_rms(const float *in, int64_t n, int nbands, const BiquadF32 *hp, const BiquadF32 *lp, double *sums, hipStream_t s);
 
 // limiter (exact, chunked at provably clean points)
 void launch_absmax_blocks_f64(const double *in, int64_t n, int blk, double *out_max, int64_t nblk, hipStream_t s);

@@ -794,3 +794,50 @@ void launch_biquad_di_f32(const float *in, float *out, int64_t n, BiquadF32 hp, 
     int64_t nchunks = (n + chunk - 1) / chunk;
     hipLaunchKernelGGL(k_biquad_di_f32, dim3((unsigned)((nchunks + 63) / 64)), dim3(64), 0, s, in, out, n, chunk, halo, hp, lp, nchunks);
 }
+
+// ------------------------------------------------------------------ fused band RMS (all bands of one region, one launch)
+// grid.y = band.  Each lane filters one chunk (+ warm-up halo) of the region with that band's highpass/lowpass pair
+// (direct form I, float state, as k_biquad_di_f32) and accumulates sum(z^2) in double; wave-reduced, one atomic per wave.
+struct BandBiquads { BiquadF32 hp[16]; BiquadF32 lp[16]; };
+__global__ void __launch_bounds__(64)
+k_band_rms(const float *__restrict__ in, int64_t n, int64_t chunk, int64_t halo, BandBiquads bq, double *__restrict__ sums, int64_t nchunks)
+{
+    const int band = blockIdx.y;
+    const BiquadF32 hp = bq.hp[band], lp = bq.lp[band];
+    const int64_t c = (int64_t)blockIdx.x * 64 + threadIdx.x;
+    double acc = 0.0;
+    if (c < nchunks) {
+        const int64_t lo = c * chunk, hi = min(lo + chunk, n);
+        const int64_t s0 = max((int64_t)0, lo - halo);
+        float i1 = 0, i2 = 0, o1 = 0, o2 = 0, j1 = 0, j2 = 0, p1 = 0, p2 = 0;
+        for (int64_t k = s0; k < hi; ++k) {
+            const float x = in[k];
+            const float y = __fadd_rn(__fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(i2, hp.b2), __fmul_rn(i1, hp.b1)), __fmul_rn(x, hp.b0)),
+                                                __fmul_rn(o2, hp.a2)), __fmul_rn(o1, hp.a1));
+            i2 = i1; i1 = x; o2 = o1; o1 = y;
+            const float z = __fadd_rn(__fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(j2, lp.b2), __fmul_rn(j1, lp.b1)), __fmul_rn(y, lp.b0)),
+                                                __fmul_rn(p2, lp.a2)), __fmul_rn(p1, lp.a1));
+            j2 = j1; j1 = y; p2 = p1; p1 = z;
+            if (k >= lo) acc += (double)z * (double)z;
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o, 64);
+    if (threadIdx.x == 0 && acc != 0.0) atomicAdd(&sums[band], acc);
+}
+
+void launch_band_rms(const float *in, int64_t n, int nbands, const BiquadF32 *hp, const BiquadF32 *lp, double *sums, hipStream_t s)
+{
+    if (n <= 0 || nbands <= 0) return;
+    BandBiquads bq;
+    double rmax = 0.0;
+    for (int b = 0; b < nbands && b < 16; ++b) {
+        bq.hp[b] = hp[b]; bq.lp[b] = lp[b];
+        rmax = std::max(rmax, std::max(std::sqrt(std::fabs((double)hp[b].a2)), std::sqrt(std::fabs((double)lp[b].a2))));
+    }
+    int64_t halo = 512;
+    if (rmax > 0.0 && rmax < 1.0) halo = std::max<int64_t>(512, (int64_t)std::ceil(std::log(1e-10) / std::log(rmax)));
+    halo = std::min<int64_t>(halo, 1 << 20);
+    int64_t chunk = std::max<int64_t>(1024, halo / 2);
+    int64_t nchunks = (n + chunk - 1) / chunk;
+    hipLaunchKernelGGL(k_band_rms, dim3((unsigned)((nchunks + 63) / 64), (unsigned)nbands), dim3(64), 0, s, in, n, chunk, halo, bq, sums, nchunks);
+}

@@ -99,7 +99,7 @@ class ProcessResult(C.Structure):
                 ("final_room_tone", L.RegionSample), ("final_speech", L.RegionSample), ("has_region_samples", C.c_int),
                 ("output_lufs", C.c_double), ("output_tp_db", C.c_double), ("input_lufs", C.c_double), ("input_tp_db", C.c_double),
                 ("within_target", C.c_int), ("pass2_spec", C.c_char * 2048), ("pass4_spec", C.c_char * 2048),
-                ("pass_ms", C.c_double * 4)]
+                ("pass_ms", C.c_double * 4), ("stage_ms", C.c_double * 10)]
 
 
 SIZEOF_IDS = {0: Interval, 1: Measurements, 2: HostConfig, 3: ProcessResult, 4: SpeechCandidate, 5: NoiseProfile,
