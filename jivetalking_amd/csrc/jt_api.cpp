@@ -128,46 +128,48 @@ static void run_astats(jt_ctx *h, const float *x, int64_t n, int sr, jt_astats *
 static void run_r128(jt_ctx *h, const float *x, int64_t n, int sr, bool dualmono, bool want_tp, AnalysisHost *A)
 {
     const int blk = sr / 10;
-    const int64_t nfull = n / blk, nalloc = nfull + 2;
+    const int64_t nfull = n / blk;
     A->blk = blk; A->nblocks = nfull;
-    h->d_scr0.ensure((size_t)nalloc * 3);
-    JT_HIP(hipMemsetAsync(h->d_scr0.p, 0, sizeof(double) * nalloc * 3, h->stream));
-    double *bs = h->d_scr0.p, *bp = bs + nalloc, *btp = bp + nalloc;
-    BiquadF64 pre, rlb; jt_kweight_design(sr, &pre, &rlb);
-    launch_kweight_blocks_f32(x, n, blk, pre, rlb, bs, bp, nalloc, h->stream);
+    std::vector<double> bsum, bpk, btp((size_t)nfull + 2, 0.0);
     if (want_tp) {
         SwrPlanHost pl; jt_swr_plan(&pl, sr, 192000);
         h->bank_d.ensure(pl.bank.size());
         JT_HIP(hipMemcpyAsync(h->bank_d.p, pl.bank.data(), sizeof(double) * pl.bank.size(), hipMemcpyHostToDevice, h->stream));
+        h->d_scr1.ensure((size_t)nfull + 2);
+        JT_HIP(hipMemsetAsync(h->d_scr1.p, 0, sizeof(double) * (nfull + 2), h->stream));
         int64_t m_total = (int64_t)(((__int128)n * pl.phase_count + pl.step - 1) / pl.step);
-        launch_true_peak_f32(x, n, h->bank_d.p, pl.phase_count, pl.filter_length, pl.center, pl.step, blk, btp, nfull + 1, m_total, h->stream);
+        launch_true_peak_f32(x, n, h->bank_d.p, pl.phase_count, pl.filter_length, pl.center, pl.step, blk, h->d_scr1.p, nfull + 1, m_total, h->stream);
+        JT_HIP(hipMemcpyAsync(btp.data(), h->d_scr1.p, sizeof(double) * (nfull + 2), hipMemcpyDeviceToHost, h->stream));
         JT_HIP(hipStreamSynchronize(h->stream));   // pl.bank must outlive the async copy
     }
-    std::vector<double> hb((size_t)nalloc * 3);
-    JT_HIP(hipMemcpyAsync(hb.data(), h->d_scr0.p, sizeof(double) * nalloc * 3, hipMemcpyDeviceToHost, h->stream));
-    JT_HIP(hipStreamSynchronize(h->stream));
-    jt_r128_finish(hb.data(), nfull, blk, sr, dualmono, &A->r128);
+    jt_kweight_blocks_f32(h, x, n, sr, blk, bsum, bpk);
+    jt_r128_finish(bsum.data(), nfull, blk, sr, dualmono, &A->r128);
     A->tp_cum.assign(nfull, 0.0); A->sp_cum.assign(nfull, 0.0);
     double tp = 0, sp = 0;
     for (int64_t k = 0; k < nfull; ++k) {
-        sp = std::max(sp, hb[nalloc + k]); tp = std::max(tp, hb[2 * nalloc + k]);
+        sp = std::max(sp, bpk[(size_t)k]); tp = std::max(tp, btp[(size_t)k]);
         A->sp_cum[k] = sp; A->tp_cum[k] = tp;
     }
     // trailing partial frame: peaks still update (f_ebur128.c runs the per-sample loop over it)
-    sp = std::max(sp, hb[nalloc + nfull]); tp = std::max(tp, hb[2 * nalloc + nfull]);
+    sp = std::max(sp, bpk[(size_t)nfull]); tp = std::max(tp, btp[(size_t)nfull]);
     A->sp_final = sp; A->tp_final = tp;
 }
 
-static void run_spectral(jt_ctx *h, const float *x, int64_t n, int sr, AnalysisHost *A)
+// sel_blk > 0: only the hops the Go side would ever see (one per 100 ms ebur128 output frame); A->hops[k] is then the
+// record of output frame k.  sel_blk == 0: every hop (operator-level parity entry).
+static void run_spectral(jt_ctx *h, const float *x, int64_t n, int sr, AnalysisHost *A, int sel_blk)
 {
     const int win = 2048, hop = win / 2;
     ensure_twiddle(h, win); ensure_hann(h, win);
     const int64_t nhops = (n + hop - 1) / hop;
     A->nhops = nhops;
-    h->spec_hops.ensure((size_t)nhops);
-    launch_aspectralstats(x, n, sr, win, h->twiddle.p, h->hann.p, h->spec_hops.p, nhops, h->stream);
-    A->hops.resize((size_t)nhops);
-    JT_HIP(hipMemcpyAsync(A->hops.data(), h->spec_hops.p, sizeof(jt_spectral) * nhops, hipMemcpyDeviceToHost, h->stream));
+    int64_t nframes = 0;
+    if (sel_blk > 0) nframes = n / sel_blk + ((n % sel_blk) ? 1 : 0);
+    const int64_t nout = sel_blk > 0 ? nframes : nhops;
+    h->spec_hops.ensure((size_t)std::max<int64_t>(nout, 1));
+    launch_aspectralstats(x, n, sr, win, h->twiddle.p, h->hann.p, h->spec_hops.p, nhops, sel_blk, nframes, h->stream);
+    A->hops.resize((size_t)nout);
+    if (nout > 0) JT_HIP(hipMemcpyAsync(A->hops.data(), h->spec_hops.p, sizeof(jt_spectral) * nout, hipMemcpyDeviceToHost, h->stream));
     JT_HIP(hipStreamSynchronize(h->stream));
 }
 
@@ -188,15 +190,12 @@ static void spectral_scale(jt_spectral *a, double s)
 static void assemble_analysis(const AnalysisHost &A, int64_t n, bool dualmono, jt_analysis *out, jt_frame_meta *meta, int64_t cap_meta)
 {
     (void)dualmono;
-    const int hop = 1024;
     const int64_t nfull = A.nblocks;
     const bool partial = (n % A.blk) != 0;
     const int64_t nframes = nfull + (partial ? 1 : 0);
     jt_spectral mean; std::memset(&mean, 0, sizeof(mean)); int64_t cnt = 0;
     for (int64_t k = 0; k < nframes; ++k) {
-        int64_t hidx = (k * (int64_t)A.blk) / hop;
-        if (hidx >= A.nhops) hidx = A.nhops - 1;
-        const jt_spectral &sp = A.hops[(size_t)hidx];
+        const jt_spectral &sp = A.hops[(size_t)k];      // selected-frames mode: one record per output frame
         spectral_add(&mean, sp); cnt++;
         if (meta && k < cap_meta) {
             jt_frame_meta &m = meta[k];
@@ -226,7 +225,7 @@ static void analyse_mono(jt_ctx *h, const float *x, int64_t n, int sr, bool dual
     check_cancel(h);
     run_r128(h, x, n, sr, dualmono, true, &A);
     check_cancel(h);
-    run_spectral(h, x, n, sr, &A);
+    run_spectral(h, x, n, sr, &A, sr / 10);
     out->astats = A.astats;
     assemble_analysis(A, n, dualmono, out, meta, cap_meta);
 }
@@ -469,10 +468,8 @@ static void run_loudnorm_measure(jt_ctx *h, const int16_t *s16, const double *f6
     SwrPlanHost pl; jt_swr_plan(&pl, rate, 192000);
     const int64_t m_total = (int64_t)(((__int128)n * pl.phase_count + pl.step - 1) / pl.step);
     const int blk = (192000 + 5) / 10;
-    const int64_t nfull = m_total / blk, nalloc = nfull + 2;
-    h->d_scr0.ensure((size_t)nalloc * 2);
-    JT_HIP(hipMemsetAsync(h->d_scr0.p, 0, sizeof(double) * nalloc * 2, h->stream));
-    BiquadF64 pre, rlb; jt_kweight_design(192000, &pre, &rlb);
+    const int64_t nfull = m_total / blk;
+    std::vector<double> bsum, bpk;
     if (s16) {
         std::vector<float> bf(pl.bank.size());
         for (size_t i = 0; i < bf.size(); ++i) bf[i] = (float)pl.bank[i];
@@ -480,21 +477,18 @@ static void run_loudnorm_measure(jt_ctx *h, const int16_t *s16, const double *f6
         JT_HIP(hipMemcpyAsync(h->bank_f.p, bf.data(), sizeof(float) * bf.size(), hipMemcpyHostToDevice, h->stream));
         h->stream_f.ensure((size_t)m_total);
         launch_resample_stream_s16_f32(s16, n, h->bank_f.p, pl.phase_count, pl.filter_length, pl.center, pl.step, m_total, h->stream_f.p, h->stream);
-        launch_kweight_blocks_f32(h->stream_f.p, m_total, blk, pre, rlb, h->d_scr0.p, h->d_scr0.p + nalloc, nalloc, h->stream);
         JT_HIP(hipStreamSynchronize(h->stream));
+        jt_kweight_blocks_f32(h, h->stream_f.p, m_total, 192000, blk, bsum, bpk);
     } else {
         h->bank_d.ensure(pl.bank.size());
         JT_HIP(hipMemcpyAsync(h->bank_d.p, pl.bank.data(), sizeof(double) * pl.bank.size(), hipMemcpyHostToDevice, h->stream));
         h->stream_d.ensure((size_t)m_total);
         launch_resample_stream_f64(f64, n, h->bank_d.p, pl.phase_count, pl.filter_length, pl.center, pl.step, m_total, h->stream_d.p, h->stream);
-        launch_kweight_blocks_f64(h->stream_d.p, m_total, blk, pre, rlb, h->d_scr0.p, h->d_scr0.p + nalloc, nalloc, h->stream);
         JT_HIP(hipStreamSynchronize(h->stream));
+        jt_kweight_blocks_f64(h, h->stream_d.p, m_total, 192000, blk, bsum, bpk);
     }
-    std::vector<double> hb((size_t)nalloc * 2);
-    JT_HIP(hipMemcpyAsync(hb.data(), h->d_scr0.p, sizeof(double) * nalloc * 2, hipMemcpyDeviceToHost, h->stream));
-    JT_HIP(hipStreamSynchronize(h->stream));
-    double pk = 0; for (int64_t k = 0; k <= nfull; ++k) pk = std::max(pk, hb[nalloc + k]);
-    jt_loudnorm_finish(hb.data(), nfull, blk, true, 1.0, &out->input_i, &out->input_lra, &out->input_thresh);
+    double pk = 0; for (int64_t k = 0; k <= nfull; ++k) pk = std::max(pk, bpk[(size_t)k]);
+    jt_loudnorm_finish(bsum.data(), nfull, blk, true, 1.0, &out->input_i, &out->input_lra, &out->input_thresh);
     out->input_tp = 20 * std::log10(pk);
     out->output_i = out->output_tp = out->output_lra = out->output_thresh = NAN; out->target_offset = NAN;
     out->normalization_type_dynamic = 1;
@@ -555,17 +549,12 @@ extern "C" int jt_pass4(jt_ctx *h, const jt_limiter_plan *lim, const jt_loudnorm
     check_cancel(h);
     // loudnorm r128_in / r128_out statistics (libavfilter/ebur128.c) at the stream rate
     if (stats) {
-        const int blk = (rate + 5) / 10; const int64_t nfull = m / blk, nalloc = nfull + 2;
-        h->d_scr0.ensure((size_t)nalloc * 2);
-        JT_HIP(hipMemsetAsync(h->d_scr0.p, 0, sizeof(double) * nalloc * 2, h->stream));
-        BiquadF64 prf, rlb; jt_kweight_design(rate, &prf, &rlb);
-        launch_kweight_blocks_f64(sig, m, blk, prf, rlb, h->d_scr0.p, h->d_scr0.p + nalloc, nalloc, h->stream);
-        std::vector<double> hb((size_t)nalloc * 2);
-        JT_HIP(hipMemcpyAsync(hb.data(), h->d_scr0.p, sizeof(double) * nalloc * 2, hipMemcpyDeviceToHost, h->stream));
-        JT_HIP(hipStreamSynchronize(h->stream));
-        double pk = 0; for (int64_t k = 0; k <= nfull; ++k) pk = std::max(pk, hb[nalloc + k]);
-        jt_loudnorm_finish(hb.data(), nfull, blk, true, 1.0, &stats->input_i, &stats->input_lra, &stats->input_thresh);
-        jt_loudnorm_finish(hb.data(), nfull, blk, true, gain * gain, &stats->output_i, &stats->output_lra, &stats->output_thresh);
+        const int blk = (rate + 5) / 10; const int64_t nfull = m / blk;
+        std::vector<double> bsum, bpk;
+        jt_kweight_blocks_f64(h, sig, m, rate, blk, bsum, bpk);
+        double pk = 0; for (int64_t k = 0; k <= nfull; ++k) pk = std::max(pk, bpk[(size_t)k]);
+        jt_loudnorm_finish(bsum.data(), nfull, blk, true, 1.0, &stats->input_i, &stats->input_lra, &stats->input_thresh);
+        jt_loudnorm_finish(bsum.data(), nfull, blk, true, gain * gain, &stats->output_i, &stats->output_lra, &stats->output_thresh);
         stats->input_tp = 20 * std::log10(pk);
         stats->output_tp = 20 * std::log10(pk * gain);
         stats->target_offset = ap->target_i - stats->output_i;
@@ -760,7 +749,7 @@ extern "C" int jt_op_aspectralstats(jt_ctx *h, const float *in, int64_t n, int s
     JT_API_BEGIN(h)
     JT_REQUIRE(in && hops && n > 0, JT_E_INVAL, "op_aspectralstats: bad arguments");
     DevBuf<float> a; h2d(h, a, in, (size_t)n);
-    AnalysisHost A; run_spectral(h, a.p, n, sr, &A);
+    AnalysisHost A; run_spectral(h, a.p, n, sr, &A, 0);
     for (int64_t k = 0; k < std::min(cap, A.nhops); ++k) hops[k] = A.hops[(size_t)k];
     if (n_hops) *n_hops = A.nhops;
     JT_API_END(h)

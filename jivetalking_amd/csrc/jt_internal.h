@@ -61,11 +61,10 @@ void launch_downmix(const float *in, float *out, int64_t frames, int channels, h
 void launch_s16_to_f32(const int16_t *in, float *out, int64_t n, hipStream_t s);
 void launch_s16_to_f64(const int16_t *in, double *out, int64_t n, double gain, int gain_in_float, hipStream_t s);
 void launch_biquad_f32(const float *in, float *out, int64_t n, int nstages, const BiquadF32 *st, hipStream_t s);
-// K-weighting + per-block energy / sample peak. T = float or double input.
-void launch_kweight_blocks_f32(const float *in, int64_t n, int blk, BiquadF64 pre, BiquadF64 rlb,
-                               double *block_sums, double *block_peaks, int64_t nblocks_alloc, hipStream_t s);
-void launch_kweight_blocks_f64(const double *in, int64_t n, int blk, BiquadF64 pre, BiquadF64 rlb,
-                               double *block_sums, double *block_peaks, int64_t nblocks_alloc, hipStream_t s);
+// K-weighting + per-100ms-block energy / sample peak (zero-state + truncated-carry linear scan); host results, nfull+1 entries
+struct jt_ctx;
+void jt_kweight_blocks_f32(jt_ctx *h, const float *in, int64_t n, int rate, int blk, std::vector<double> &sums, std::vector<double> &peaks);
+void jt_kweight_blocks_f64(jt_ctx *h, const double *in, int64_t n, int rate, int blk, std::vector<double> &sums, std::vector<double> &peaks);
 
 struct DynParams {
     int gate_on, comp_on, deess_on;
@@ -108,7 +107,7 @@ void launch_f32_to_f64(const float *in, double *out, int64_t n, hipStream_t s);
 
 // spectral
 void launch_aspectralstats(const float *in, int64_t n, int sr, int win_size, const float2 *twiddle, const float *hann,
-                           jt_spectral *hops, int64_t nhops, hipStream_t s);
+                           jt_spectral *hops, int64_t nhops, int sel_blk, int64_t nframes, hipStream_t s);
 // afftdn
 struct AfftdnPlanHost {
     int sr, A, W, L, bins, nbands;

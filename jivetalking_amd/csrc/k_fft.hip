@@ -56,9 +56,12 @@ __device__ inline void block_reduce_sum(float (&v)[K], float *scratch /* [K][4] 
 // ------------------------------------------------------------------ aspectralstats
 constexpr int SP_LOG2 = 11, SP_N = 1 << SP_LOG2, SP_HALF = SP_N / 2, SP_RUN = 32;
 
+// sel_blk == 0: every hop (out[h]).  sel_blk > 0: only the hops whose props survive ebur128's 100 ms re-framing, i.e. for
+// output frame k the hop containing sample k*sel_blk (+ its predecessor for flux); out[k].  A run of SP_RUN consecutive
+// frames per workgroup; a hop already in LDS as "previous magnitudes" is not recomputed.
 __global__ void __launch_bounds__(FT)
 k_aspectralstats(const float *__restrict__ in, int64_t n, int sr, const float2 *__restrict__ tw, const float *__restrict__ hann,
-                 jt_spectral *__restrict__ hops, int64_t nhops)
+                 jt_spectral *__restrict__ hops, int64_t nhops, int sel_blk, int64_t nframes)
 {
     __shared__ float re[SP_N], im[SP_N];
     __shared__ float mag[SP_HALF], prev[SP_HALF];
@@ -66,13 +69,19 @@ k_aspectralstats(const float *__restrict__ in, int64_t n, int sr, const float2 *
     __shared__ float psum[FT];
     __shared__ int roll_idx;
     const int tid = threadIdx.x;
-    const int64_t h0 = (int64_t)blockIdx.x * SP_RUN;
+    const int64_t u0 = (int64_t)blockIdx.x * SP_RUN;     // first hop (all-hops mode) or first frame (selected mode)
     const float max_freq = (float)(sr / 2);
     const float scale = max_freq / (float)SP_HALF;
     const float fscale = 1.f / SP_N;
     for (int i = tid; i < SP_HALF; i += FT) prev[i] = 0.f;
     __syncthreads();
-    for (int64_t h = (h0 > 0 ? h0 - 1 : h0); h < h0 + SP_RUN && h < nhops; ++h) {
+    const int64_t nunits = sel_blk > 0 ? nframes : nhops;
+    int64_t have_prev = -2;                           // hop whose magnitudes sit in prev[] (-2: none, prev[] = zeros for hop -1)
+    for (int64_t unit = u0; unit < u0 + SP_RUN && unit < nunits; ++unit) {
+      int64_t htarget = sel_blk > 0 ? min((unit * (int64_t)sel_blk) / SP_HALF, nhops - 1) : unit;
+      for (int64_t h = (have_prev == htarget - 1 || htarget == 0) ? htarget : htarget - 1; h <= htarget; ++h) {
+        const bool emit = (h == htarget);
+        if (h == 0 && have_prev != -2) { for (int i = tid; i < SP_HALF; i += FT) prev[i] = 0.f; __syncthreads(); }
         // window after pushing hop h = samples [(h+1)*1024 - 2048, (h+1)*1024)
         const int64_t w0 = (h + 1) * (int64_t)SP_HALF - SP_N;
         for (int i = tid; i < SP_N; i += FT) {
@@ -86,7 +95,7 @@ k_aspectralstats(const float *__restrict__ in, int64_t n, int sr, const float2 *
         fft_lds<SP_LOG2>(re, im, tw);
         for (int i = tid; i < SP_HALF; i += FT) mag[i] = hypotf(re[i] * fscale, im[i] * fscale);
         __syncthreads();
-        if (h >= h0) {
+        if (emit) {
             // pass 1
             float v[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
             float mx = 0.f;
@@ -168,22 +177,26 @@ k_aspectralstats(const float *__restrict__ in, int64_t n, int sr, const float2 *
                 o.slope = fabsf(u[5]) <= FLT_EPSILON ? 0.f : u[4] / u[5];
                 o.decrease = v[7] <= FLT_EPSILON ? 0.f : v[6] / v[7];
                 o.rolloff = roll_idx * scale;
-                hops[h] = o;
+                hops[sel_blk > 0 ? unit : h] = o;
             }
             __syncthreads();
         }
         for (int i = tid; i < SP_HALF; i += FT) prev[i] = mag[i];
         __syncthreads();
+        have_prev = h;
+      }
     }
 }
 
 void launch_aspectralstats(const float *in, int64_t n, int sr, int win_size, const float2 *twiddle, const float *hann,
-                           jt_spectral *hops, int64_t nhops, hipStream_t s)
+                           jt_spectral *hops, int64_t nhops, int sel_blk, int64_t nframes, hipStream_t s)
 {
     if (nhops <= 0) return;
     JT_REQUIRE(win_size == SP_N, JT_E_UNSUPPORTED, "aspectralstats: only win_size=2048 is built");
-    unsigned grid = (unsigned)((nhops + SP_RUN - 1) / SP_RUN);
-    hipLaunchKernelGGL(k_aspectralstats, dim3(grid), dim3(FT), 0, s, in, n, sr, twiddle, hann, hops, nhops);
+    const int64_t units = sel_blk > 0 ? nframes : nhops;
+    if (units <= 0) return;
+    unsigned grid = (unsigned)((units + SP_RUN - 1) / SP_RUN);
+    hipLaunchKernelGGL(k_aspectralstats, dim3(grid), dim3(FT), 0, s, in, n, sr, twiddle, hann, hops, nhops, sel_blk, nframes);
 }
 
 // ------------------------------------------------------------------ afftdn

@@ -272,113 +272,149 @@ void launch_biquad_f32(const float *in, float *out, int64_t n, int nstages, cons
 }
 
 // ------------------------------------------------------------------ K-weighting + 100 ms block energies
-// f_ebur128.c FILTER macro (direct form I, double): pre-filter shelf then RLB high-pass; bin = z^2 summed
-// per 100 ms block; per-block max|x| for the sample peak.  Each lane owns `bpl` whole blocks.
-template <typename TIn>
+// BS.1770 K-weighting (f_ebur128.c / ebur128.c coefficients: pre-filter shelf + RLB high-pass) is a LINEAR 4-state filter,
+// so chunk boundary states need no warm-up halo:   state_c = e_{c-1} + F^L e_{c-2} + F^2L e_{c-3} + ...
+// where e_c is the zero-state response of chunk c at its end and F the homogeneous transition matrix (|eig| ~ 0.995, so the
+// series is truncated once ||F^kL|| < 1e-18: exact to double precision).
+//   k_kw_zs  : one lane per L-sample chunk, zero initial state -> e_c                       (N sample-steps)
+//   k_kw_run : one lane per chunk, carried-in state from the series, accumulates sum(z^2) and max|x| per chunk (N sample-steps)
+// Chunks are sub-divisions of the 100 ms blocks; the host adds the per-chunk partials of each block in order.
+// Both biquads run in transposed direct form II with fused multiply-adds (same transfer function as the FILTER macro of
+// f_ebur128.c; rounding differs at 1e-16).
+struct KwCoef { double b0, b1, b2, a1, a2, c0, c1, c2, d1, d2; };
+
+#define KW2_STEP(X)                                                     \
+    {                                                                    \
+        const double xx = (X);                                           \
+        const double y = fma(k.b0, xx, s1);                              \
+        s1 = fma(-k.a1, y, fma(k.b1, xx, s2));                           \
+        s2 = fma(-k.a2, y, k.b2 * xx);                                   \
+        zz = fma(k.c0, y, t1);                                           \
+        t1 = fma(-k.d1, zz, fma(k.c1, y, t2));                           \
+        t2 = fma(-k.d2, zz, k.c2 * y);                                   \
+    }
+
+template <typename TIn, bool RUN>
 __global__ void __launch_bounds__(64)
-k_kweight_blocks(const TIn *__restrict__ in, int64_t n, int blk, int bpl, int64_t halo, BiquadF64 pre, BiquadF64 rlb,
-                 double *__restrict__ block_sums, double *__restrict__ block_peaks, int64_t nblocks_alloc, int64_t nchunks)
+k_kw(const TIn *__restrict__ in, int64_t n, int64_t L, KwCoef k, const double *__restrict__ zs_in, const double *__restrict__ fpow, int nterms,
+     double *__restrict__ zs_out, double *__restrict__ csum, double *__restrict__ cpeak, int64_t nchunks)
 {
     __shared__ TIn tile[LANES][TW + 1];
     const int lane = threadIdx.x;
-    const int64_t chunk = (int64_t)blk * bpl;
     const int64_t c0 = (int64_t)blockIdx.x * LANES;
     const int nrows = (int)min((int64_t)LANES, nchunks - c0);
-    const int64_t base0 = c0 * chunk - halo;
-    const int64_t my_base = base0 + (int64_t)lane * chunk;
-    double x1 = 0, x2 = 0, y1 = 0, y2 = 0, z1 = 0, z2 = 0;
-    double acc = 0.0, pk = 0.0;
-    int cnt = 0; int64_t bidx = (c0 + lane) * bpl;
-    const int64_t total = halo + chunk;          // halo and chunk are multiples of TW
-    const double na1 = -pre.a1, na2 = -pre.a2, nr1 = -rlb.a1, nr2 = -rlb.a2;
-    // one K-weighting step.  Same difference equations as f_ebur128.c's FILTER macro, evaluated with fused multiply-adds
-    // and the feed-forward part hoisted off the recurrence's critical path (rounding differs from the scalar code at 1e-16).
-#define KW_STEP(X0)                                                                   \
-    {                                                                                  \
-        const double ff = fma(pre.b2, x2, fma(pre.b1, x1, pre.b0 * (X0)));             \
-        const double y0 = fma(na1, y1, fma(na2, y2, ff));                              \
-        const double fz = fma(rlb.b2, y2, fma(rlb.b1, y1, rlb.b0 * y0));               \
-        z0 = fma(nr1, z1, fma(nr2, z2, fz));                                           \
-        x2 = x1; x1 = (X0); y2 = y1; y1 = y0; z2 = z1; z1 = z0;                        \
+    const int64_t base0 = c0 * L;
+    const int64_t my_c = c0 + lane;
+    const int64_t my_base = base0 + (int64_t)lane * L;
+    double s1 = 0, s2 = 0, t1 = 0, t2 = 0;
+    if (RUN && lane < nrows) {
+        // carried-in state: sum_k F^(kL) e_{c-1-k}   (k = 0 term is e_{c-1} itself)
+        for (int q = 0; q < nterms; ++q) {
+            const int64_t cc = my_c - 1 - q;
+            if (cc < 0) break;
+            const double e0 = zs_in[cc * 4 + 0], e1 = zs_in[cc * 4 + 1], e2 = zs_in[cc * 4 + 2], e3 = zs_in[cc * 4 + 3];
+            if (q == 0) { s1 += e0; s2 += e1; t1 += e2; t2 += e3; }
+            else {
+                const double *M = fpow + (size_t)(q - 1) * 16;
+                s1 += M[0] * e0 + M[1] * e1 + M[2] * e2 + M[3] * e3;
+                s2 += M[4] * e0 + M[5] * e1 + M[6] * e2 + M[7] * e3;
+                t1 += M[8] * e0 + M[9] * e1 + M[10] * e2 + M[11] * e3;
+                t2 += M[12] * e0 + M[13] * e1 + M[14] * e2 + M[15] * e3;
+            }
+        }
     }
+    double acc = 0.0, pk = 0.0, zz = 0.0;
     TIn v[LANES];
-    rows_prefetch<TIn>(v, in, n, base0, chunk, 0, lane);
-    for (int64_t pos = 0; pos < total; pos += TW) {
-        rows_commit<TIn, TIn>(tile, v, n, base0, chunk, pos, lane, nrows);
+    rows_prefetch<TIn>(v, in, n, base0, L, 0, lane);
+    for (int64_t pos = 0; pos < L; pos += TW) {
+        rows_commit<TIn, TIn>(tile, v, n, base0, L, pos, lane, nrows);
         __syncthreads();
-        if (pos + TW < total) rows_prefetch<TIn>(v, in, n, base0, chunk, pos + TW, lane);
+        if (pos + TW < L) rows_prefetch<TIn>(v, in, n, base0, L, pos + TW, lane);
         if (lane < nrows) {
             const int64_t t0 = my_base + pos;
-            const bool inside = t0 >= 0 && t0 + TW <= n;
-            double z0;
-            const bool full = inside && pos + TW <= total;
-            if (full && pos + TW <= halo) {                         // warm-up: filter only
-#pragma unroll 16
-                for (int j = 0; j < TW; ++j) { const double x0 = (double)tile[lane][j]; KW_STEP(x0) }
-            } else if (full && pos >= halo && cnt + TW < blk) {     // steady state: no block boundary inside this tile
-                double a0 = 0.0, p0 = 0.0;
+            if (pos + TW <= L && t0 + TW <= n) {
 #pragma unroll 16
                 for (int j = 0; j < TW; ++j) {
                     const double x0 = (double)tile[lane][j];
-                    KW_STEP(x0)
-                    a0 = fma(z0, z0, a0); p0 = fmax(p0, fabs(x0));
+                    KW2_STEP(x0)
+                    if (RUN) { acc = fma(zz, zz, acc); pk = fmax(pk, fabs(x0)); }
                 }
-                acc += a0; pk = fmax(pk, p0); cnt += TW;
-            } else {                                                // edges: file start/end, block boundaries
+            } else {
                 for (int j = 0; j < TW; ++j) {
-                    const int64_t idx = t0 + j;
-                    if (pos + j >= total) break;
-                    if (idx < 0 || idx >= n) continue;
+                    if (pos + j >= L || t0 + j >= n) break;
                     const double x0 = (double)tile[lane][j];
-                    KW_STEP(x0)
-                    if (pos + j >= halo) {
-                        acc = fma(z0, z0, acc); pk = fmax(pk, fabs(x0));
-                        if (++cnt == blk) {
-                            if (bidx < nblocks_alloc) { block_sums[bidx] = acc; block_peaks[bidx] = pk; }
-                            acc = 0.0; pk = 0.0; cnt = 0; ++bidx;
-                        }
-                    }
+                    KW2_STEP(x0)
+                    if (RUN) { acc = fma(zz, zz, acc); pk = fmax(pk, fabs(x0)); }
                 }
             }
         }
         __syncthreads();
     }
-#undef KW_STEP
-    if (lane < nrows && cnt > 0 && bidx < nblocks_alloc) { block_sums[bidx] = acc; block_peaks[bidx] = pk; }
+    if (lane < nrows) {
+        if (RUN) { csum[my_c] = acc; cpeak[my_c] = pk; }
+        else { zs_out[my_c * 4 + 0] = s1; zs_out[my_c * 4 + 1] = s2; zs_out[my_c * 4 + 2] = t1; zs_out[my_c * 4 + 3] = t2; }
+    }
+}
+#undef KW2_STEP
+
+static void mat4_mul(const double *A, const double *B, double *C)
+{
+    double t[16];
+    for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) { double s = 0; for (int q = 0; q < 4; ++q) s += A[i * 4 + q] * B[q * 4 + j]; t[i * 4 + j] = s; }
+    std::memcpy(C, t, sizeof(t));
 }
 
-static void kweight_geometry(int64_t n, int blk, int sr_hint, int *bpl, int64_t *halo, int64_t *nchunks)
+// Per-100ms-block K-weighted energies and sample peaks of a device signal; results on the host:
+// sums/peaks have nfull+1 entries (the last one is the trailing partial block, zero if none).
+template <typename TIn>
+static void kweight_blocks_run(jt_ctx *h, const TIn *in, int64_t n, int rate, int blk, std::vector<double> &sums, std::vector<double> &peaks)
 {
-    // RLB double pole at ~38 Hz: r ~ 1 - 2*pi*38/sr; n*r^n below 1e-13 needs ~8192 samples at 48 kHz
-    int64_t h = (int64_t)std::ceil(8192.0 * sr_hint / 48000.0);
-    h = (h + TW - 1) / TW * TW;
-    *halo = h;
-    int b = (int)std::max<int64_t>(1, (h / 2 + blk - 1) / blk);
-    *bpl = b;
-    int64_t chunk = (int64_t)blk * b;
-    *nchunks = (n + chunk - 1) / chunk;
+    BiquadF64 pre, rlb; jt_kweight_design(rate, &pre, &rlb);
+    KwCoef k{pre.b0, pre.b1, pre.b2, pre.a1, pre.a2, rlb.b0, rlb.b1, rlb.b2, rlb.a1, rlb.a2};
+    // chunk length: a divisor of the block, at most ~2400 samples, preferably a multiple of the 64-sample tile
+    int m = 1, best = -1;
+    for (int q = 1; q <= 32; ++q) if (blk % q == 0 && blk / q <= 2400) { if (best < 0) best = q; if ((blk / q) % TW == 0) { best = q; break; } }
+    m = best > 0 ? best : 1;
+    const int64_t L = blk / m;
+    const int64_t nchunks = (n + L - 1) / L;
+    // homogeneous transition matrix (state s1,s2,t1,t2; input 0) and its powers F^L, F^2L, ...
+    double F[16] = {-k.a1, 1, 0, 0,   -k.a2, 0, 0, 0,   k.c1 - k.d1 * k.c0, 0, -k.d1, 1,   k.c2 - k.d2 * k.c0, 0, -k.d2, 0};
+    double FL[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1}, Bq[16];
+    std::memcpy(Bq, F, sizeof(F));
+    for (int64_t e = L; e > 0; e >>= 1) { if (e & 1) mat4_mul(FL, Bq, FL); mat4_mul(Bq, Bq, Bq); }
+    std::vector<double> pw; double cur[16]; std::memcpy(cur, FL, sizeof(cur));
+    int nterms = 1;
+    for (int q = 0; q < 24; ++q) {
+        double mx = 0; for (double v : cur) mx = std::max(mx, std::fabs(v));
+        if (mx < 1e-19) break;
+        pw.insert(pw.end(), cur, cur + 16); nterms++;
+        mat4_mul(cur, FL, cur);
+    }
+    const size_t o_zs = 0, o_pw = o_zs + 4 * (size_t)nchunks, o_cs = o_pw + std::max<size_t>(pw.size(), 16), o_cp = o_cs + (size_t)nchunks,
+                 total = o_cp + (size_t)nchunks;
+    h->d_scr0.ensure(total);
+    double *base = h->d_scr0.p;
+    if (!pw.empty()) JT_HIP(hipMemcpyAsync(base + o_pw, pw.data(), sizeof(double) * pw.size(), hipMemcpyHostToDevice, h->stream));
+    const unsigned grid = (unsigned)((nchunks + LANES - 1) / LANES);
+    hipLaunchKernelGGL((k_kw<TIn, false>), dim3(grid), dim3(LANES), 0, h->stream, in, n, L, k, (const double *)nullptr, (const double *)nullptr, 0,
+                       base + o_zs, (double *)nullptr, (double *)nullptr, nchunks);
+    hipLaunchKernelGGL((k_kw<TIn, true>), dim3(grid), dim3(LANES), 0, h->stream, in, n, L, k, base + o_zs, base + o_pw, nterms,
+                       (double *)nullptr, base + o_cs, base + o_cp, nchunks);
+    std::vector<double> hc((size_t)nchunks * 2);
+    JT_HIP(hipMemcpyAsync(hc.data(), base + o_cs, sizeof(double) * nchunks * 2, hipMemcpyDeviceToHost, h->stream));
+    JT_HIP(hipStreamSynchronize(h->stream));     // also keeps `pw` alive until its async copy has completed
+    const int64_t nfull = n / blk;
+    sums.assign((size_t)nfull + 1, 0.0); peaks.assign((size_t)nfull + 1, 0.0);
+    for (int64_t c = 0; c < nchunks; ++c) {
+        const int64_t b = std::min<int64_t>(c / m, nfull);
+        sums[(size_t)b] += hc[(size_t)c];
+        peaks[(size_t)b] = std::max(peaks[(size_t)b], hc[(size_t)(nchunks + c)]);
+    }
 }
-
-void launch_kweight_blocks_f32(const float *in, int64_t n, int blk, BiquadF64 pre, BiquadF64 rlb,
-                               double *block_sums, double *block_peaks, int64_t nblocks_alloc, hipStream_t s)
-{
-    if (n <= 0) return;
-    int bpl; int64_t halo, nchunks;
-    kweight_geometry(n, blk, blk * 10, &bpl, &halo, &nchunks);
-    int grid = (int)((nchunks + LANES - 1) / LANES);
-    hipLaunchKernelGGL(k_kweight_blocks<float>, dim3(grid), dim3(LANES), 0, s, in, n, blk, bpl, halo, pre, rlb,
-                       block_sums, block_peaks, nblocks_alloc, nchunks);
-}
-void launch_kweight_blocks_f64(const double *in, int64_t n, int blk, BiquadF64 pre, BiquadF64 rlb,
-                               double *block_sums, double *block_peaks, int64_t nblocks_alloc, hipStream_t s)
-{
-    if (n <= 0) return;
-    int bpl; int64_t halo, nchunks;
-    kweight_geometry(n, blk, blk * 10, &bpl, &halo, &nchunks);
-    int grid = (int)((nchunks + LANES - 1) / LANES);
-    hipLaunchKernelGGL(k_kweight_blocks<double>, dim3(grid), dim3(LANES), 0, s, in, n, blk, bpl, halo, pre, rlb,
-                       block_sums, block_peaks, nblocks_alloc, nchunks);
-}
+void jt_kweight_blocks_f32(jt_ctx *h, const float *in, int64_t n, int rate, int blk, std::vector<double> &sums, std::vector<double> &peaks)
+{ kweight_blocks_run<float>(h, in, n, rate, blk, sums, peaks); }
+void jt_kweight_blocks_f64(jt_ctx *h, const double *in, int64_t n, int rate, int blk, std::vector<double> &sums, std::vector<double> &peaks)
+{ kweight_blocks_run<double>(h, in, n, rate, blk, sums, peaks); }
 
 // ------------------------------------------------------------------ agate -> acompressor -> deesser (double)
 __device__ inline double hermite_interp(double x, double x0, double x1, double p0, double p1, double m0, double m1)
