@@ -159,6 +159,71 @@ k_as_noise_floor(const float *__restrict__ g, const float *__restrict__ p, int64
     }
 }
 
+// Fused sliding-window peak + (min, count) reduction: the noise-floor measure without the G/P arrays in HBM.
+// A workgroup owns NF_TILE window starts; |x| of the tile (+ tc-1 halo) is scanned per 64-sample block in registers
+// (inclusive prefix / suffix maxima by wave shuffles) and parked in LDS; a window [s, s+tc) is then
+//   max( suffix-max of its head block from s,  max of the full blocks in between,  prefix-max of its tail block up to s+tc-1 ).
+// The in-between run has c0 or c0+1 blocks (c0 = (tc-1)/64 - 1), so one width-c0 running maximum over the block maxima serves all.
+// Maxima of floats are order-independent, so the result is identical to the sequential filter's.
+constexpr int NF_TILE = 6144;
+__global__ void __launch_bounds__(AS_T)
+k_as_nf_fused(const float *__restrict__ x, int64_t n, int tc, int64_t ntiles, AsNF *__restrict__ part)
+{
+    extern __shared__ float nf_smem[];
+    const int E = NF_TILE + tc - 1;
+    const int nb64 = (E + 63) >> 6;
+    float *sP = nf_smem, *sG = sP + nb64 * 64, *sBM = sG + nb64 * 64, *sR = sBM + nb64;
+    __shared__ AsNF sp[AS_T / 64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int c0 = (tc - 1) / 64 - 1;
+    double nf = DBL_MAX; unsigned long long cnt = 0;
+    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int64_t S0 = tile * NF_TILE;
+        for (int b = wave; b < nb64; b += AS_T / 64) {
+            const int64_t idx = S0 + (int64_t)b * 64 + lane;
+            const float a = idx < n ? fabsf(x[idx]) : 0.f;
+            float pm = a, gm = a;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const float tu = __shfl_up(pm, o, 64), td = __shfl_down(gm, o, 64);
+                if (lane >= o) pm = fmaxf(pm, tu);
+                if (lane + o < 64) gm = fmaxf(gm, td);
+            }
+            sP[b * 64 + lane] = pm; sG[b * 64 + lane] = gm;
+            if (lane == 63) sBM[b] = pm;
+        }
+        __syncthreads();
+        for (int b = tid; b < nb64; b += AS_T) {
+            float m = 0.f;
+            for (int q = 0; q < c0 && b + q < nb64; ++q) m = fmaxf(m, sBM[b + q]);
+            sR[b] = m;
+        }
+        __syncthreads();
+        for (int k = tid; k < NF_TILE; k += AS_T) {
+            const int64_t i = S0 + k + tc - 1;
+            if (i >= n) break;
+            const int e = k + tc - 1, bs = k >> 6, be = e >> 6;
+            float m = fmaxf(sG[k], sP[e]);
+            m = fmaxf(m, sR[bs + 1]);
+            if (be - bs - 1 > c0) m = fmaxf(m, sBM[be - 1]);
+            const double lp = (double)m;
+            if (lp < nf) { nf = lp; cnt = 1; } else if (lp == nf) cnt++;
+        }
+        __syncthreads();
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        double onf = __shfl_down(nf, o, 64); unsigned long long oc = __shfl_down(cnt, o, 64);
+        if (onf < nf) { nf = onf; cnt = oc; } else if (onf == nf) cnt += oc;
+    }
+    if (lane == 0) sp[wave] = AsNF{nf, cnt};
+    __syncthreads();
+    if (tid == 0) {
+        AsNF a = sp[0];
+        for (int w = 1; w < AS_T / 64; ++w) { if (sp[w].nf < a.nf) a = sp[w]; else if (sp[w].nf == a.nf) a.cnt += sp[w].cnt; }
+        part[blockIdx.x] = a;
+    }
+}
+
 // exponential power average: zero-state response of each chunk (one thread per chunk, coalesced through LDS rows)
 constexpr int ZC = 1024;     // chunk length
 __global__ void __launch_bounds__(64)
@@ -276,14 +341,26 @@ void jt_astats_device(jt_ctx *h, const float *x, int64_t n, int sr, jt_astats *o
            *d_carry = reinterpret_cast<double *>(base + o_carry), *d_smin = reinterpret_cast<double *>(base + o_smin),
            *d_smax = reinterpret_cast<double *>(base + o_smax);
     h->ehist.ensure(8192); h->ehist.zero(s);
-    h->as_g.ensure((size_t)n); h->as_p.ensure((size_t)n);
     hipLaunchKernelGGL(k_as_reduce, dim3(nparts), dim3(AS_T), 0, s, x, n, d_part, h->ehist.p);
     hipLaunchKernelGGL(k_as_minmax, dim3(1), dim3(64), 0, s, d_part, nparts, d_mm);
     hipLaunchKernelGGL(k_as_runs, dim3(nparts), dim3(AS_T), 0, s, x, n, d_mm, d_runs);
-    const int64_t nb = (n + tc - 1) / tc;
-    hipLaunchKernelGGL(k_as_gp, dim3((unsigned)((nb + 63) / 64)), dim3(64), 0, s, x, h->as_g.p, h->as_p.p, n, tc);
     const bool have_nf = n >= tc;
-    if (have_nf) hipLaunchKernelGGL(k_as_noise_floor, dim3(nparts), dim3(AS_T), 0, s, h->as_g.p, h->as_p.p, n, tc, d_nf);
+    int nf_parts = nparts;
+    if (have_nf) {
+        const int nb64 = (NF_TILE + tc - 1 + 63) / 64;
+        const size_t smem = sizeof(float) * ((size_t)nb64 * 130);
+        if (tc >= 129 && smem <= 150 * 1024) {
+            const int64_t ntiles = (n - tc + 1 + NF_TILE - 1) / NF_TILE;
+            nf_parts = (int)std::min<int64_t>(ntiles, nparts);
+            JT_HIP(hipFuncSetAttribute((const void *)k_as_nf_fused, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+            hipLaunchKernelGGL(k_as_nf_fused, dim3(nf_parts), dim3(AS_T), smem, s, x, n, tc, ntiles, d_nf);
+        } else {                                   // very low / very high sample rates: van Herk arrays in HBM
+            h->as_g.ensure((size_t)n); h->as_p.ensure((size_t)n);
+            const int64_t nb = (n + tc - 1) / tc;
+            hipLaunchKernelGGL(k_as_gp, dim3((unsigned)((nb + 63) / 64)), dim3(64), 0, s, x, h->as_g.p, h->as_p.p, n, tc);
+            hipLaunchKernelGGL(k_as_noise_floor, dim3(nparts), dim3(AS_T), 0, s, h->as_g.p, h->as_p.p, n, tc, d_nf);
+        }
+    }
     hipLaunchKernelGGL(k_as_zs, dim3((unsigned)nsig), dim3(64), 0, s, x, n, mult, d_zs, nchunks);
     hipLaunchKernelGGL(k_as_scan, dim3(1), dim3(64), 0, s, d_zs, d_carry, nchunks, std::pow(mult, (double)ZC), n, mult);
     hipLaunchKernelGGL(k_as_sigma, dim3((unsigned)nsig), dim3(64), 0, s, x, n, tc, mult, d_carry, d_smin, d_smax, nchunks);
@@ -306,7 +383,7 @@ void jt_astats_device(jt_ctx *h, const float *x, int64_t n, int sr, jt_astats *o
     AsRuns r{0, 0, 0, 0};
     for (int i = 0; i < nparts; ++i) { r.min_count += pr[i].min_count; r.min_runs += pr[i].min_runs; r.max_count += pr[i].max_count; r.max_runs += pr[i].max_runs; }
     double nf = DBL_MAX; unsigned long long nfc = 0;
-    if (have_nf) for (int i = 0; i < nparts; ++i) { if (pn[i].nf < nf) { nf = pn[i].nf; nfc = pn[i].cnt; } else if (pn[i].nf == nf) nfc += pn[i].cnt; }
+    if (have_nf) for (int i = 0; i < nf_parts; ++i) { if (pn[i].nf < nf) { nf = pn[i].nf; nfc = pn[i].cnt; } else if (pn[i].nf == nf) nfc += pn[i].cnt; }
     double min_sig = DBL_MAX, max_sig = 0;
     for (int i = 0; i < nsig; ++i) { min_sig = std::min(min_sig, smin[i]); max_sig = std::max(max_sig, smax[i]); }
     std::memset(out, 0, sizeof(*out));

@@ -110,6 +110,123 @@ k_polyphase(const TIn *__restrict__ in, int64_t n, const TTap *__restrict__ bank
     }
 }
 
+// ---- upsampling variant (step < P, 32 taps): "window-major".  All outputs whose first tap reads the same input sample share
+// one 32-sample window, so a lane loads the window from LDS ONCE into registers and evaluates the ~P/step phases that use it
+// (4 at 48k->192k, 4.35 at 44.1k->192k); the taps of each phase stay wave-uniform scalars.  LDS reads per output drop from 32
+// to ~7 (QL = 1) or ~2 (step == 1, QL = 4 adjacent windows per lane), leaving the FMA pipe as the limiter.  Tap order per
+// output is unchanged (ascending), so results are bit-identical to k_polyphase.
+template <typename TIn, typename TAcc, typename TTap, int MODE, int QL>
+__global__ void __launch_bounds__(PP_THREADS)
+k_upsample32(const TIn *__restrict__ in, int64_t n, const TTap *__restrict__ bank, int P, int center, int step,
+             int64_t m_total, int R, double in_scale, int blk, unsigned long long *__restrict__ block_tp, int64_t nblocks_alloc,
+             TAcc *__restrict__ out_stream)
+{
+    constexpr int L = 32;
+    constexpr int WL = L + QL - 1;                                    // QL > 1 only with step == 1
+    extern __shared__ unsigned char smem_pp[];
+    TAcc *xin = reinterpret_cast<TAcc *>(smem_pp);
+    const int T = 64 * R * QL * step;
+    const int nin = T + L;
+    __shared__ unsigned long long slots[8];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t s0 = (int64_t)blockIdx.x * T;
+    const int64_t m_lo = (int64_t)blockIdx.x * 64 * R * QL * P;
+    if (m_lo >= m_total) return;
+    const int flush = MODE != 0;
+    for (int i = tid; i < nin; i += PP_THREADS) {
+        int64_t g = s0 - center + i;
+        TAcc v = (TAcc)0;
+        if (g < 0) g = -g;                                           // invert_initial_buffer(): in[-j] = in[j]
+        if (g < n) v = (TAcc)((TAcc)in[g] * (TAcc)in_scale);
+        else if (flush) { int64_t r = 2 * n - 1 - g; if (r >= 0 && r < n) v = (TAcc)((TAcc)in[r] * (TAcc)in_scale); }   // resample_flush()
+        xin[skew(i)] = v;
+    }
+    if (MODE == 0 && tid < 8) slots[tid] = 0ull;
+    __syncthreads();
+    const int64_t b_first = (s0 - center + L - 1 < 0 ? 0 : (s0 - center + L - 1)) / blk;
+    const int nitems = step * R;
+    for (int item0 = wave; item0 < nitems; item0 += PP_THREADS / 64) {
+        const int item = __builtin_amdgcn_readfirstlane(item0);
+        const int off = item / R, kc = item - off * R;
+        const int j_lo = (int)(((int64_t)off * P + step - 1) / step);
+        const int j_hi = min(P, (int)(((int64_t)(off + 1) * P + step - 1) / step));
+        const int qq = (kc * 64 + lane) * QL;                       // first window of this lane (tile-relative q)
+        const int si = off + step * qq;
+        TAcc xw[WL];
+#pragma unroll
+        for (int i = 0; i < WL; ++i) xw[i] = xin[skew(si + i)];
+        TAcc vmax[QL];
+#pragma unroll
+        for (int u = 0; u < QL; ++u) vmax[u] = (TAcc)0;
+        for (int j = j_lo; j < j_hi; ++j) {
+            const int ph = (int)(((int64_t)j * step) % P);
+            const TTap *f = bank + (size_t)ph * L;
+            TTap tp[L];
+#pragma unroll
+            for (int i = 0; i < L; ++i) tp[i] = f[i];
+#pragma unroll
+            for (int u = 0; u < QL; ++u) {
+                TAcc val = (TAcc)0;
+#pragma unroll
+                for (int i = 0; i < L; ++i) val = fma(xw[u + i], (TAcc)tp[i], val);
+                const int64_t m = m_lo + j + (int64_t)P * (qq + u);
+                if (m < m_total) {
+                    if (MODE == 0) vmax[u] = fmax(vmax[u], fabs(val));
+                    else out_stream[m] = val;
+                }
+            }
+        }
+        if (MODE == 0) {
+#pragma unroll
+            for (int u = 0; u < QL; ++u) {
+                const int64_t last = s0 + si + u * step - center + L - 1;
+                if (last <= n - 1 && vmax[u] > (TAcc)0) {
+                    int64_t b = last / blk;
+                    if (b >= nblocks_alloc) b = nblocks_alloc - 1;
+                    const int sl = (int)(b - b_first);
+                    const unsigned long long bits = (unsigned long long)__double_as_longlong((double)vmax[u]);
+                    if (sl >= 0 && sl < 8) atomicMax(&slots[sl], bits);
+                    else atomicMax(&block_tp[b], bits);
+                }
+            }
+        }
+    }
+    if (MODE == 0) {
+        __syncthreads();
+        if (tid < 8 && slots[tid]) {
+            int64_t b = b_first + tid;
+            if (b >= nblocks_alloc) b = nblocks_alloc - 1;
+            atomicMax(&block_tp[b], slots[tid]);
+        }
+    }
+}
+
+template <typename TIn, typename TAcc, typename TTap, int MODE>
+static bool launch_upsample32(const TIn *in, int64_t n, const TTap *bank, int P, int L, int center, int64_t step, int64_t m_total,
+                              double in_scale, int blk, double *block_tp, int64_t nblocks_alloc, TAcc *out, hipStream_t s)
+{
+    if (L != 32 || step >= P || step > 512) return false;
+    const int ql = step == 1 ? 4 : 1;
+    const int R = (int)std::max<int64_t>(1, 4096 / (64 * ql * step));
+    const int T = 64 * R * ql * (int)step, nin = T + 32;
+    const size_t smem = sizeof(TAcc) * (size_t)(nin + (nin >> 5) + 4);
+    if (smem > 150 * 1024) return false;
+    const int64_t per_block = (int64_t)64 * R * ql * P;
+    const unsigned grid = (unsigned)((m_total + per_block - 1) / per_block);
+    if (ql == 4) {
+        auto k = k_upsample32<TIn, TAcc, TTap, MODE, 4>;
+        JT_HIP(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        hipLaunchKernelGGL(k, dim3(grid), dim3(PP_THREADS), smem, s, in, n, bank, P, center, (int)step, m_total, R, in_scale, blk,
+                           (unsigned long long *)block_tp, nblocks_alloc, out);
+    } else {
+        auto k = k_upsample32<TIn, TAcc, TTap, MODE, 1>;
+        JT_HIP(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        hipLaunchKernelGGL(k, dim3(grid), dim3(PP_THREADS), smem, s, in, n, bank, P, center, (int)step, m_total, R, in_scale, blk,
+                           (unsigned long long *)block_tp, nblocks_alloc, out);
+    }
+    return true;
+}
+
 struct PPGeom { int R; int T; size_t smem; unsigned grid; };
 template <typename TAcc>
 static PPGeom pp_geometry(int64_t n, int P, int L, int64_t step, int64_t m_total, bool otile)
@@ -130,6 +247,8 @@ void launch_true_peak_f32(const float *in, int64_t n, const double *bank, int ph
                           int64_t step, int blk, double *block_tp, int64_t nblocks_alloc, int64_t m_total, hipStream_t s)
 {
     if (m_total <= 0) return;
+    if (launch_upsample32<float, double, double, 0>(in, n, bank, phase_count, filter_length, center, step, m_total, 1.0, blk, block_tp,
+                                                   nblocks_alloc, (double *)nullptr, s)) return;
     PPGeom g = pp_geometry<double>(n, phase_count, filter_length, step, m_total, false);
     JT_REQUIRE(g.smem <= 150 * 1024, JT_E_UNSUPPORTED, "true peak: rate ratio needs too large an LDS tile");
     auto k = k_polyphase<float, double, double, 0>;
@@ -142,6 +261,8 @@ void launch_true_peak_f64(const double *in, int64_t n, const double *bank, int p
                           int64_t step, int blk, double *block_tp, int64_t nblocks_alloc, int64_t m_total, hipStream_t s)
 {
     if (m_total <= 0) return;
+    if (launch_upsample32<double, double, double, 0>(in, n, bank, phase_count, filter_length, center, step, m_total, 1.0, blk, block_tp,
+                                                    nblocks_alloc, (double *)nullptr, s)) return;
     PPGeom g = pp_geometry<double>(n, phase_count, filter_length, step, m_total, false);
     JT_REQUIRE(g.smem <= 150 * 1024, JT_E_UNSUPPORTED, "true peak: rate ratio needs too large an LDS tile");
     auto k = k_polyphase<double, double, double, 0>;
@@ -169,6 +290,8 @@ void launch_resample_stream_s16_f32(const int16_t *in, int64_t n, const float *b
                                     int64_t step, int64_t m_total, float *out, hipStream_t s)
 {
     if (m_total <= 0) return;
+    if (launch_upsample32<int16_t, float, float, 2>(in, n, bankf, phase_count, filter_length, center, step, m_total, 1.0 / 32768.0, 1,
+                                                   (double *)nullptr, (int64_t)0, out, s)) return;
     PPGeom g = pp_geometry<float>(n, phase_count, filter_length, step, m_total, false);
     auto k = k_polyphase<int16_t, float, float, 2>;
     JT_HIP(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)g.smem));
@@ -179,6 +302,8 @@ void launch_resample_stream_f64(const double *in, int64_t n, const double *bank,
                                 int64_t step, int64_t m_total, double *out, hipStream_t s)
 {
     if (m_total <= 0) return;
+    if (launch_upsample32<double, double, double, 2>(in, n, bank, phase_count, filter_length, center, step, m_total, 1.0, 1,
+                                                    (double *)nullptr, (int64_t)0, out, s)) return;
     PPGeom g = pp_geometry<double>(n, phase_count, filter_length, step, m_total, false);
     auto k = k_polyphase<double, double, double, 2>;
     JT_HIP(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)g.smem));
