@@ -346,7 +346,7 @@ static void run_afftdn(jt_ctx *h, const float *in, float *out, int64_t n, int sr
     d.bin2band = h->af_bin2band.p;
     d.window = h->af_tab.p; d.alpha = d.window + pl.W; d.beta = d.alpha + nb; d.spread = d.beta + nb;
     d.abs_var = d.spread + nb * nb; d.min_abs_var = d.abs_var + bins; d.twiddle = h->twiddle.p;
-    launch_afftdn(in, out, n, d, 192, 96, h->stream);
+    launch_afftdn(in, out, n, d, 0, 96, h->stream);     // chunk length chosen from the frame count; 96 warm-up frames
     JT_HIP(hipStreamSynchronize(h->stream));   // host tables must outlive the async copies
 }
 

@@ -208,88 +208,240 @@ __device__ inline double limit_gain(double a, double b)
 }
 
 constexpr int AF_MAXBANDS = 48;
-constexpr int AF_BPT = 5;      // bins per thread for L = 2048 (1025 bins over 256 threads)
 
+// Stockham autosort FFT of H = 2^LOG2H complex points in LDS (radix-4 stages, one radix-2 stage when LOG2H is odd):
+// natural order in and out, ping-pong between `a` and `b`; returns the buffer holding the result.
+// tw[q] = exp(-2*pi*i*q/H), q < H.  INV uses conjugated twiddles (unnormalised inverse).
+template <int LOG2H, bool INV>
+__device__ inline float2 *fft_stockham(float2 *a, float2 *b, const float2 *__restrict__ tw)
+{
+    constexpr int H = 1 << LOG2H;
+    int Ns = 1;
+#pragma unroll 1
+    for (int st = 0; st < LOG2H / 2; ++st) {
+        for (int j = threadIdx.x; j < H / 4; j += FT) {
+            const int k = j & (Ns - 1);
+            const int tq = k * (H / 4 / Ns);                       // twiddle step: angle = -2 pi k t / (4 Ns)
+            float2 v0 = a[j], v1 = a[j + H / 4], v2 = a[j + H / 2], v3 = a[j + 3 * H / 4];
+            if (Ns > 1) {
+                float2 w1 = tw[tq], w2 = tw[2 * tq], w3 = tw[3 * tq];
+                if (INV) { w1.y = -w1.y; w2.y = -w2.y; w3.y = -w3.y; }
+                float2 t;
+                t.x = v1.x * w1.x - v1.y * w1.y; t.y = v1.x * w1.y + v1.y * w1.x; v1 = t;
+                t.x = v2.x * w2.x - v2.y * w2.y; t.y = v2.x * w2.y + v2.y * w2.x; v2 = t;
+                t.x = v3.x * w3.x - v3.y * w3.y; t.y = v3.x * w3.y + v3.y * w3.x; v3 = t;
+            }
+            const float2 s02 = make_float2(v0.x + v2.x, v0.y + v2.y), d02 = make_float2(v0.x - v2.x, v0.y - v2.y);
+            const float2 s13 = make_float2(v1.x + v3.x, v1.y + v3.y), d13 = make_float2(v1.x - v3.x, v1.y - v3.y);
+            // forward: -i*d13 = (d13.y, -d13.x); inverse: +i*d13 = (-d13.y, d13.x)
+            const float2 r13 = INV ? make_float2(-d13.y, d13.x) : make_float2(d13.y, -d13.x);
+            const int o = ((j - k) << 2) + k;
+            b[o] = make_float2(s02.x + s13.x, s02.y + s13.y);
+            b[o + Ns] = make_float2(d02.x + r13.x, d02.y + r13.y);
+            b[o + 2 * Ns] = make_float2(s02.x - s13.x, s02.y - s13.y);
+            b[o + 3 * Ns] = make_float2(d02.x - r13.x, d02.y - r13.y);
+        }
+        __syncthreads();
+        float2 *t = a; a = b; b = t;
+        Ns <<= 2;
+    }
+    if (LOG2H & 1) {
+        for (int j = threadIdx.x; j < H / 2; j += FT) {
+            const int k = j & (Ns - 1);
+            float2 v0 = a[j], v1 = a[j + H / 2];
+            float2 w = tw[k * (H / 2 / Ns)];
+            if (INV) w.y = -w.y;
+            float2 t; t.x = v1.x * w.x - v1.y * w.y; t.y = v1.x * w.y + v1.y * w.x;
+            const int o = ((j - k) << 1) + k;
+            b[o] = make_float2(v0.x + t.x, v0.y + t.y);
+            b[o + Ns] = make_float2(v0.x - t.x, v0.y - t.y);
+        }
+        __syncthreads();
+        float2 *t = a; a = b; b = t;
+    }
+    return a;
+}
+
+__device__ inline double fast_rcp(double a)
+{
+    double r = __builtin_amdgcn_rcp(a);
+    r = fma(fma(-a, r, 1.0), r, r);
+    r = fma(fma(-a, r, 1.0), r, r);
+    return r;
+}
+
+// af_afftdn.c process_frame(), tn = 0.  Real FFT of length N = 2^LOG2N through an N/2-point complex transform
+// (z[m] = x[2m] + i x[2m+1]; X[k] = E + W^k O, X[N/2-k] = conj(E - W^k O)), so a thread that owns the pair (k, N/2-k) owns
+// both bins for the whole chunk: their decision-directed priors and noise constants live in registers.
+// Band excitation sums: lanes hold consecutive bins, so each wave does a segmented shuffle reduction per bark band and the
+// <= 8 per-segment partials of a band are added in ascending-bin order by the band's thread (deterministic).
+// Overlap-add accumulator is a circular double buffer in LDS (no per-hop shifting).
 template <int LOG2N>
 __global__ void __launch_bounds__(FT)
 k_afftdn(const float *__restrict__ in, float *__restrict__ out, int64_t n, AfftdnDev d, int frames_per_chunk, int warm_frames,
          int64_t nframes)
 {
-    constexpr int L = 1 << LOG2N;
-    constexpr int BINS = L / 2 + 1;
-    constexpr int BPT = (BINS + FT - 1) / FT;
+    constexpr int N = 1 << LOG2N, H = N / 2, HH = H / 2;
+    constexpr int QP = (H + FT - 1) / FT;           // complex points per thread (load / overlap-add)
+    constexpr int KP = (HH + FT - 1) / FT;          // bin pairs per thread
+    constexpr int FSEG = (HH + 63) / 64;            // 64-bin segments per direction
+    constexpr int NSEG = 2 * FSEG + 1;
     extern __shared__ unsigned char smem_raw[];
-    // layout: re[L] im[L] re2[L] im2[L] (float) | clean[BINS] acc[W] (double) | band arrays
-    float *re = reinterpret_cast<float *>(smem_raw);
-    float *im = re + L;
-    float *re2 = im + L;
-    float *im2 = re2 + L;
-    double *clean = reinterpret_cast<double *>(im2 + L);
-    double *acc = clean + ((BINS + 1) & ~1);
-    double *band_excit = acc + ((d.W + 1) & ~1);
+    float2 *bufA = reinterpret_cast<float2 *>(smem_raw);
+    float2 *bufB = bufA + H;
+    float2 *tw = bufB + H;
+    double *acc = reinterpret_cast<double *>(tw + H);
+    const int Wp = (d.W + 1) & ~1;
+    double *part = acc + Wp;                                  // [NSEG][AF_MAXBANDS]
+    double *spread = part + NSEG * AF_MAXBANDS;               // [nb][nb]
+    double *band_excit = spread + d.nbands * d.nbands;
     double *prior_band = band_excit + AF_MAXBANDS;
-    double *band_amt = prior_band + AF_MAXBANDS;
-    int *band_lo = reinterpret_cast<int *>(band_amt + AF_MAXBANDS);
-    int *band_hi = band_lo + AF_MAXBANDS;
+    double *band_rs = prior_band + AF_MAXBANDS;               // 1/sqrt(band_amt)
+    double *band_amt = band_rs + AF_MAXBANDS;
+    int *seg_bmin = reinterpret_cast<int *>(band_amt + AF_MAXBANDS);   // [NSEG] lowest band id in the segment
+    int *band_s0 = seg_bmin + NSEG + 1;                       // first / last segment touching the band
+    int *band_s1 = band_s0 + AF_MAXBANDS;
 
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int A = d.A, W = d.W, nb = d.nbands;
     const int64_t t_lo = (int64_t)blockIdx.x * frames_per_chunk;
     const int64_t t_hi = min(t_lo + frames_per_chunk, nframes);
+    if (t_lo >= nframes) return;
     const int64_t t0 = max((int64_t)0, t_lo - warm_frames);
 
-    // band bin ranges (bin2band is non-decreasing)
-    if (tid < nb) { band_lo[tid] = BINS; band_hi[tid] = 0; }
-    __syncthreads();
-    for (int i = tid; i < BINS; i += FT) {
-        int b = d.bin2band[i];
-        if (i == 0 || d.bin2band[i - 1] != b) band_lo[b] = i;
-        if (i == BINS - 1 || d.bin2band[i + 1] != b) band_hi[b] = i + 1;
+    // ---- per-chunk constants
+    for (int q = tid; q < H; q += FT) { double sn, cs; sincospi(2.0 * q / H, &sn, &cs); tw[q] = make_float2((float)cs, (float)-sn); }
+    for (int m = tid; m < Wp; m += FT) acc[m] = 0.0;
+    for (int i = tid; i < nb * nb; i += FT) spread[i] = d.spread[i];
+    if (tid < AF_MAXBANDS) { prior_band[tid] = 0.0; band_s0[tid] = NSEG; band_s1[tid] = -1; }
+    // segment ids ascend with bin index: forward rows 0..FSEG-1, the self-paired bin H/2, mirrored rows in reverse
+    if (tid < NSEG) {
+        int lo;
+        if (tid < FSEG) lo = 64 * tid;
+        else if (tid == FSEG) lo = HH;
+        else { const int j = FSEG - 1 - (tid - FSEG - 1); lo = max(H - 64 * j - 63, HH + 1); }
+        seg_bmin[tid] = d.bin2band[lo];
     }
-    if (tid < nb) prior_band[tid] = 0.0;
-    for (int m = tid; m < W; m += FT) acc[m] = 0.0;
-    double prior[BPT];
+    double win[2 * QP];
 #pragma unroll
-    for (int q = 0; q < BPT; ++q) prior[q] = 0.0;
+    for (int q = 0; q < QP; ++q) {
+        const int m = tid + q * FT;
+        win[2 * q] = (2 * m < W) ? d.window[2 * m] : 0.0;
+        win[2 * q + 1] = (2 * m + 1 < W) ? d.window[2 * m + 1] : 0.0;
+    }
+    // bins owned: pair p -> k = tid + p*FT (bins k and H-k); slot 2*KP = bin H/2 (thread 0 only)
+    constexpr int NBIN = 2 * KP + 1;
+    double prior[NBIN], av[NBIN], inv_av[NBIN], sqrt_av[NBIN];
+    int bband[NBIN], bseg[NBIN]; unsigned same[NBIN]; bool head[NBIN], valid[NBIN];
+    float2 wk[KP];
+#pragma unroll
+    for (int p = 0; p < KP; ++p) {
+        const int k = tid + p * FT;
+        double sn, cs; sincospi(2.0 * k / N, &sn, &cs); wk[p] = make_float2((float)cs, (float)-sn);
+#pragma unroll
+        for (int side = 0; side < 2; ++side) {
+            const int e = 2 * p + side;
+            const int bin = side == 0 ? k : H - k;
+            valid[e] = (k < HH) && !(side == 1 && false);
+            const int bi = valid[e] ? bin : 0;
+            prior[e] = 0.0; av[e] = d.abs_var[bi]; inv_av[e] = 1.0 / av[e]; sqrt_av[e] = sqrt(av[e]);
+            bband[e] = valid[e] ? d.bin2band[bi] : -1 - e;
+            const int row = (k >> 6);                                      // forward wave-row
+            bseg[e] = side == 0 ? row : FSEG + 1 + (FSEG - 1 - row);
+        }
+    }
+    {
+        const int e = 2 * KP;
+        valid[e] = (tid == 0);
+        prior[e] = 0.0; av[e] = d.abs_var[HH]; inv_av[e] = 1.0 / av[e]; sqrt_av[e] = sqrt(av[e]);
+        bband[e] = valid[e] ? d.bin2band[HH] : -100;
+        bseg[e] = FSEG;
+    }
+#pragma unroll
+    for (int e = 0; e < NBIN; ++e) {
+        unsigned msk = 0;
+#pragma unroll
+        for (int o = 1, bit = 0; o < 64; o <<= 1, ++bit) {
+            const int other = __shfl_down(bband[e], o, 64);
+            if (lane + o < 64 && other == bband[e] && valid[e]) msk |= 1u << bit;
+        }
+        same[e] = msk;
+        const int prev = __shfl_up(bband[e], 1, 64);
+        head[e] = valid[e] && (lane == 0 || prev != bband[e]);
+    }
     __syncthreads();
+    // which segments touch each band (band_s0/band_s1), from the head lanes
+#pragma unroll
+    for (int e = 0; e < NBIN; ++e)
+        if (head[e]) { atomicMin(&band_s0[bband[e]], bseg[e]); atomicMax(&band_s1[bband[e]], bseg[e]); }
+    __syncthreads();
+    const double gain_scale = 1.0 / (d.max_gain * d.max_gain);
+    const double max_gain = d.max_gain;
 
+    int off = (int)(((t0 % 3) * (int64_t)A) % W);            // circular overlap-add origin: slot of frame sample 0
     for (int64_t t = t0; t < t_hi; ++t) {
         const int64_t start = t * A - (W - A);
-        for (int m = tid; m < L; m += FT) {
-            float v = 0.f;
-            if (m < W) {
-                int64_t k = start + m;
-                float x = (k >= 0 && k < n) ? in[k] : 0.f;
-                v = (float)(d.window[m] * x * 8388608.0);
+        // ---- windowed frame -> packed complex
+#pragma unroll
+        for (int q = 0; q < QP; ++q) {
+            const int m = tid + q * FT;
+            if (m < H) {
+                const int64_t k0 = start + 2 * m, k1 = k0 + 1;
+                const float x0 = (2 * m < W && k0 >= 0 && k0 < n) ? in[k0] : 0.f;
+                const float x1 = (2 * m + 1 < W && k1 >= 0 && k1 < n) ? in[k1] : 0.f;
+                bufA[m] = make_float2((float)(win[2 * q] * x0 * 8388608.0), (float)(win[2 * q + 1] * x1 * 8388608.0));
             }
-            unsigned r = brev((unsigned)m, LOG2N);
-            re[r] = v; im[r] = 0.f;
         }
         __syncthreads();
-        fft_lds<LOG2N>(re, im, d.twiddle);
-        // per-bin gains (process_frame); the very first frame of the stream uses ratio = 1
+        float2 *Z = fft_stockham<LOG2N - 1, false>(bufA, bufB, tw);
+        float2 *Zo = (Z == bufA) ? bufB : bufA;
+        // ---- split to real-signal bins, first-stage gains (decision-directed prior), clean power
         const double ratio = (t == 0) ? 1.0 : 0.5, rratio = 1.0 - ratio;
-        double gain_r[BPT];
+        float2 X[NBIN]; double g1[NBIN], clean[NBIN];
 #pragma unroll
-        for (int q = 0; q < BPT; ++q) {
-            int i = tid + q * FT;
-            gain_r[q] = 0.0;
-            if (i < BINS) {
-                double mag = hypot((double)re[i], (double)im[i]);
-                double power = mag * mag;
-                double mav = power / d.abs_var[i];
-                double nmav = ratio * prior[q] + rratio * fmax(mav - 1.0, 0.0);
-                double ng = nmav / (1.0 + nmav);
-                double sq = ng * ng;
-                prior[q] = mav * sq;
-                clean[i] = power * sq;
-                gain_r[q] = ng;
+        for (int p = 0; p < KP; ++p) {
+            const int k = tid + p * FT;
+            if (k < HH) {
+                const float2 zk = Z[k], zm = Z[(H - k) & (H - 1)];
+                const float er = 0.5f * (zk.x + zm.x), ei = 0.5f * (zk.y - zm.y);          // E = (Zk + conj Zm)/2
+                const float orr = 0.5f * (zk.y + zm.y), oi = -0.5f * (zk.x - zm.x);        // O = -i (Zk - conj Zm)/2
+                if (k == 0) { X[2 * p] = make_float2(er + orr, 0.f); X[2 * p + 1] = make_float2(er - orr, 0.f); }
+                else {
+                    const float cr = wk[p].x * orr - wk[p].y * oi, ci = wk[p].x * oi + wk[p].y * orr;   // W^k O
+                    X[2 * p] = make_float2(er + cr, ei + ci);
+                    X[2 * p + 1] = make_float2(er - cr, -(ei - ci));
+                }
+            } else { X[2 * p] = make_float2(0.f, 0.f); X[2 * p + 1] = make_float2(0.f, 0.f); }
+        }
+        { const float2 zk = Z[HH]; X[2 * KP] = make_float2(zk.x, -zk.y); }
+#pragma unroll
+        for (int e = 0; e < NBIN; ++e) {
+            const double xr = (double)X[e].x, xi = (double)X[e].y;
+            const double power = fma(xr, xr, xi * xi);
+            const double mav = power * inv_av[e];
+            const double nmav = ratio * prior[e] + rratio * fmax(mav - 1.0, 0.0);
+            const double ng = nmav * fast_rcp(1.0 + nmav);
+            const double sq = ng * ng;
+            if (valid[e]) prior[e] = mav * sq;
+            clean[e] = valid[e] ? power * sq : 0.0;
+            g1[e] = ng;
+        }
+        // ---- band sums of the clean power: segmented wave reduction, partials per (segment, band)
+#pragma unroll
+        for (int e = 0; e < NBIN; ++e) {
+            if (e == 2 * KP) { if (valid[e]) part[bseg[e] * AF_MAXBANDS + 0] = clean[e]; continue; }
+            double v = clean[e];
+#pragma unroll
+            for (int o = 1, bit = 0; o < 64; o <<= 1, ++bit) {
+                const double other = __shfl_down(v, o, 64);
+                if (same[e] & (1u << bit)) v += other;
             }
+            if (head[e]) part[bseg[e] * AF_MAXBANDS + (bband[e] - seg_bmin[bseg[e]])] = v;
         }
         __syncthreads();
         if (tid < nb) {
             double e = 0.0;
-            for (int i = band_lo[tid]; i < band_hi[tid]; ++i) e += clean[i];
+            for (int sg = band_s0[tid]; sg <= band_s1[tid]; ++sg) e += part[sg * AF_MAXBANDS + (tid - seg_bmin[sg])];
             e = fmax(e, d.alpha[tid] * e + d.beta[tid] * prior_band[tid]);
             prior_band[tid] = e;
             band_excit[tid] = e;
@@ -297,58 +449,69 @@ k_afftdn(const float *__restrict__ in, float *__restrict__ out, int64_t n, Afftd
         __syncthreads();
         if (tid < nb) {
             double a = 0.0;
-            const double *sp = d.spread + (size_t)tid * nb;
+            const double *sp = spread + tid * nb;
             for (int k = 0; k < nb; ++k) a += sp[k] * band_excit[k];
             band_amt[tid] = a;
+            band_rs[tid] = 1.0 / sqrt(a);
         }
         __syncthreads();
         const bool need_out = (t + 2 >= t_lo);     // frames whose overlap-add reaches the emitted range
-#pragma unroll
-        for (int q = 0; q < BPT; ++q) {
-            int i = tid + q * FT;
-            if (i < BINS) {
-                double amt = band_amt[d.bin2band[i]];
-                double g = gain_r[q];
-                double av = d.abs_var[i];
-                if (amt > av) g = 1.0;
-                else if (amt > d.min_abs_var[i]) g = limit_gain(g, sqrt(av / amt));
-                else g = limit_gain(g, d.max_gain);
-                float gf = (float)g;
-                re[i] *= gf; im[i] *= gf;
-            }
-        }
-        __syncthreads();
         if (need_out) {
-            // inverse real transform: rebuild the conjugate half, conjugate, forward FFT (unnormalised inverse)
-            for (int k = tid; k < L; k += FT) {
-                float r, ii;
-                if (k == 0) { r = re[0]; ii = 0.f; }
-                else if (k == L / 2) { r = re[L / 2]; ii = 0.f; }
-                else if (k < L / 2) { r = re[k]; ii = im[k]; }
-                else { r = re[L - k]; ii = -im[L - k]; }
-                unsigned rr = brev((unsigned)k, LOG2N);
-                re2[rr] = r; im2[rr] = -ii;
+            // ---- masking-limited gains, then fold the pair back into the packed inverse transform input
+#pragma unroll
+            for (int e = 0; e < NBIN; ++e) {
+                if (!valid[e]) continue;
+                const double amt = band_amt[bband[e]];
+                double g = g1[e];
+                double b;
+                if (amt > av[e]) g = 1.0;
+                else {
+                    b = (amt > gain_scale * av[e]) ? sqrt_av[e] * band_rs[bband[e]] : max_gain;
+                    if (g < 1.0) g = (b * g - 2.0 * g + 1.0) * fast_rcp(b - g);
+                    else if (g > 1.0) g = (b * g - 1.0) * fast_rcp(b + g - 2.0);
+                }
+                const float gf = (float)g;
+                X[e].x *= gf; X[e].y *= gf;
             }
+#pragma unroll
+            for (int p = 0; p < KP; ++p) {
+                const int k = tid + p * FT;
+                if (k < HH) {
+                    const float2 yk = X[2 * p], ym = X[2 * p + 1];
+                    if (k == 0) Zo[0] = make_float2(yk.x + ym.x, yk.x - ym.x);
+                    else {
+                        const float ar = yk.x + ym.x, ai = yk.y - ym.y;           // A = Yk + conj Ym
+                        const float br = yk.x - ym.x, bi = yk.y + ym.y;           // B = Yk - conj Ym
+                        const float cr = wk[p].x * br + wk[p].y * bi, ci = wk[p].x * bi - wk[p].y * br;   // C = conj(W) B
+                        Zo[k] = make_float2(ar - ci, ai + cr);                    // A + iC
+                        Zo[H - k] = make_float2(ar + ci, -(ai - cr));             // conj(A - iC)
+                    }
+                }
+            }
+            if (tid == 0) { const float2 y = X[2 * KP]; Zo[HH] = make_float2(2.f * y.x, -2.f * y.y); }
             __syncthreads();
-            fft_lds<LOG2N>(re2, im2, d.twiddle);
-            for (int m = tid; m < W; m += FT) acc[m] += d.window[m] * (double)re2[m] / 8388608.0;
-            __syncthreads();
-            if (t >= t_lo) {
-                for (int m = tid; m < A; m += FT) {
-                    int64_t k = start + m;
-                    if (k >= 0 && k < n) out[k] = (float)acc[m];
+            float2 *zt = fft_stockham<LOG2N - 1, true>(Zo, Z, tw);
+            // ---- overlap-add into the circular accumulator, emit the first hop, clear it
+#pragma unroll
+            for (int q = 0; q < QP; ++q) {
+                const int m = tid + q * FT;
+                if (m < H) {
+                    const float2 v = zt[m];
+                    const int m0 = 2 * m, m1 = m0 + 1;
+                    if (m0 < W) { int sl = m0 + off; if (sl >= W) sl -= W; acc[sl] += win[2 * q] * (double)v.x / 8388608.0; }
+                    if (m1 < W) { int sl = m1 + off; if (sl >= W) sl -= W; acc[sl] += win[2 * q + 1] * (double)v.y / 8388608.0; }
                 }
             }
             __syncthreads();
-            // shift the accumulator by one hop
-            double tmp[16];
-            int cnt = 0;
-            for (int m = tid; m < W; m += FT) { tmp[cnt++] = (m + A < W) ? acc[m + A] : 0.0; }
-            __syncthreads();
-            cnt = 0;
-            for (int m = tid; m < W; m += FT) acc[m] = tmp[cnt++];
-            __syncthreads();
+            for (int m = tid; m < A; m += FT) {
+                int sl = m + off; if (sl >= W) sl -= W;
+                const int64_t k = start + m;
+                if (t >= t_lo && k >= 0 && k < n) out[k] = (float)acc[sl];
+                acc[sl] = 0.0;
+            }
         }
+        off += A; if (off >= W) off -= W;
+        __syncthreads();
     }
 }
 
@@ -356,12 +519,16 @@ void launch_afftdn(const float *in, float *out, int64_t n, const AfftdnDev &d, i
 {
     if (n <= 0) return;
     JT_REQUIRE(d.nbands <= AF_MAXBANDS, JT_E_UNSUPPORTED, "afftdn: too many bark bands");
-    JT_REQUIRE(d.W <= 16 * FT, JT_E_UNSUPPORTED, "afftdn: window too long for this build");
     int64_t nframes = (n + d.A - 1) / d.A + (d.W - d.A) / d.A;
+    if (frames_per_chunk <= 0) {
+        // one resident round of workgroups where possible (256 CUs x 3 workgroups), chunks of 128..512 frames
+        frames_per_chunk = (int)std::min<int64_t>(512, std::max<int64_t>(128, (nframes + 767) / 768));
+    }
     unsigned grid = (unsigned)((nframes + frames_per_chunk - 1) / frames_per_chunk);
-    size_t bins = d.L / 2 + 1;
-    size_t smem = sizeof(float) * 4 * d.L + sizeof(double) * (((bins + 1) & ~(size_t)1) + ((d.W + 1) & ~1) + 3 * AF_MAXBANDS)
-                + sizeof(int) * 2 * AF_MAXBANDS;
+    const size_t H = d.L / 2, nseg = 2 * ((H / 2 + 63) / 64) + 1;
+    size_t smem = sizeof(float2) * 3 * H + sizeof(double) * (((d.W + 1) & ~1) + nseg * AF_MAXBANDS + (size_t)d.nbands * d.nbands + 4 * AF_MAXBANDS)
+                + sizeof(int) * (nseg + 1 + 2 * AF_MAXBANDS);
+    JT_REQUIRE(smem <= 160 * 1024, JT_E_UNSUPPORTED, "afftdn: window too long for this build");
     if (d.L == 2048) {
         JT_HIP(hipFuncSetAttribute((const void *)k_afftdn<11>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
         hipLaunchKernelGGL(k_afftdn<11>, dim3(grid), dim3(FT), smem, s, in, out, n, d, frames_per_chunk, warm_frames, nframes);
