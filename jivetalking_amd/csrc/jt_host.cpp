@@ -10,7 +10,9 @@
 #include <cstdlib>
 #include <functional>
 #include <chrono>
+#include <thread>
 
+static double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 namespace {
 
 constexpr int64_t kSecond = 1000000000LL, kMs = 1000000LL;
@@ -45,10 +47,20 @@ double qdec(double v, int decimals)
 double qsig6(double v)      // "%g": 6 significant digits
 {
     if (!std::isfinite(v) || v == 0.0) return v;
-    const int e = (int)std::floor(std::log10(std::fabs(v)));
+    // decimal exponent from the binary one (no log10/pow on the hot path); a mis-estimate at a power-of-ten boundary leaves
+    // r outside [1e5, 1e6) and takes the printf path, so the result never depends on the estimate being exact
+    static const double p10[] = {1, 1e1, 1e2, 1e3, 1e4, 1e5, 1e6, 1e7, 1e8, 1e9, 1e10, 1e11, 1e12, 1e13, 1e14, 1e15, 1e16, 1e17, 1e18};
+    static const double n10[] = {1, 1e-1, 1e-2, 1e-3, 1e-4, 1e-5, 1e-6, 1e-7, 1e-8, 1e-9, 1e-10, 1e-11, 1e-12, 1e-13};
+    const double av = std::fabs(v);
+    int be; std::frexp(av, &be);                       // av in [2^(be-1), 2^be)
+    int e = (int)std::floor((be - 1) * 0.30102999566398120);
+    if (e >= -13 && e < 6) {
+        const double up = e + 1 >= 0 ? p10[e + 1] : n10[-(e + 1)];
+        if (av >= up) ++e;
+    } else return qfmt_slow("%g", v);
     const int dec = 5 - e;
     if (dec < 0 || dec > 18) return qfmt_slow("%g", v);
-    const double sc = std::pow(10.0, dec);
+    const double sc = p10[dec];
     const double t = v * sc;
     const double r = std::nearbyint(t);
     if (std::fabs(std::fabs(t - r) - 0.5) < 1e-6 || std::fabs(r) >= 1e6 || std::fabs(r) < 1e5) return qfmt_slow("%g", v);
@@ -422,15 +434,38 @@ bool estimateNoiseFloorAndThreshold(const std::vector<jt_interval> &iv, double *
     if (iv.size() < 10) return false;
     std::vector<double> levels(iv.size()), flux(iv.size());
     for (size_t i = 0; i < iv.size(); ++i) { levels[i] = iv[i].momentary_lufs; flux[i] = iv[i].spectral.flux; }
-    std::sort(levels.begin(), levels.end(), nan_less); std::sort(flux.begin(), flux.end(), nan_less);
-    double levelP50 = levels[levels.size() / 2], fluxP50 = flux[flux.size() / 2];
+    // element at index n/2 of the NaN-first sorted slice (computeSilenceMedians sorts; only the median is read): selection, not a sort
+    auto median_nan_first = [](std::vector<double> &v) {
+        const size_t k = v.size() / 2;
+        auto mid = std::partition(v.begin(), v.end(), [](double x) { return std::isnan(x); });
+        const size_t nn = (size_t)(mid - v.begin());
+        if (k < nn) return v[k];
+        std::nth_element(mid, v.begin() + k, v.end());
+        return v[k];
+    };
+    double levelP50 = median_nan_first(levels), fluxP50 = median_nan_first(flux);
     struct SI { int idx; double level, score; };
     std::vector<SI> sc(iv.size());
-    for (size_t i = 0; i < iv.size(); ++i) sc[i] = SI{(int)i, iv[i].momentary_lufs, roomToneScore(iv[i], levelP50, fluxP50)};
-    std::sort(sc.begin(), sc.end(), [](const SI &a, const SI &b) {
-        int c = cmpd(b.score, a.score); if (c) return c < 0;
-        c = cmpd(a.level, b.level); if (c) return c < 0;
-        return a.idx < b.idx; });
+    bool any_nan = false;
+    for (size_t i = 0; i < iv.size(); ++i) {
+        sc[i] = SI{(int)i, iv[i].momentary_lufs, roomToneScore(iv[i], levelP50, fluxP50)};
+        any_nan |= std::isnan(sc[i].level) || std::isnan(sc[i].score);
+    }
+    // top fifth by (score desc, level asc, index asc): a strict total order, so selecting the first cc elements gives the same
+    // set as the reference's full sort (analyser_noise_seed.go:150-175)
+    size_t cc0 = sc.size() / 5; cc0 = std::max<size_t>(cc0, 8); cc0 = std::min(cc0, sc.size());
+    if (cc0 < sc.size()) {
+        if (any_nan)
+            std::nth_element(sc.begin(), sc.begin() + cc0, sc.end(), [](const SI &a, const SI &b) {
+                int c = cmpd(b.score, a.score); if (c) return c < 0;
+                c = cmpd(a.level, b.level); if (c) return c < 0;
+                return a.idx < b.idx; });
+        else
+            std::nth_element(sc.begin(), sc.begin() + cc0, sc.end(), [](const SI &a, const SI &b) {
+                if (a.score != b.score) return a.score > b.score;
+                if (a.level != b.level) return a.level < b.level;
+                return a.idx < b.idx; });
+    }
     size_t cc = sc.size() / 5; cc = std::max<size_t>(cc, 8); cc = std::min(cc, sc.size());
     double mx = -120.0; bool seen = false;
     for (size_t i = 0; i < cc; ++i) { double l = sc[i].level; if (isFlooredLevel(l)) continue; if (!seen || l > mx) { mx = l; seen = true; } }
@@ -470,17 +505,46 @@ extern "C" int64_t jt_host_build_intervals(int sr, int64_t n_samples, int frame_
         out[nout++] = s;
     };
     auto reset = [&]() { acc = IA(); acc.tpMax = -120.0; acc.spMax = -120.0; };
+    // The print-format quantisation of the metadata (17 values per 100 ms frame: "%.3f" ebur128, "%g" aspectralstats) is the only
+    // O(file) host work on this path; it is elementwise, so long files split it across a few threads before the serial walk.
+    std::vector<jt_frame_meta> qmeta;
+    if (quantize && n_meta > 0) {
+        const double tq0 = now_ms();
+        qmeta.resize((size_t)n_meta);
+        auto quant_range = [&](int64_t lo, int64_t hi) {
+            for (int64_t i = lo; i < hi; ++i) {
+                jt_frame_meta q = meta[i];
+                if (!std::isnan(q.momentary)) {
+                    q.momentary = qdec(q.momentary, 3); q.shortterm = qdec(q.shortterm, 3);
+                    q.true_peak = qdec(q.true_peak, 3); q.sample_peak = qdec(q.sample_peak, 3);
+                }
+                q.spectral = spec_quant(q.spectral);
+                qmeta[(size_t)i] = q;
+            }
+        };
+        unsigned nt = n_meta >= 8192 ? std::min(8u, std::max(1u, std::thread::hardware_concurrency())) : 1u;
+        if (nt <= 1) quant_range(0, n_meta);
+        else {
+            std::vector<std::thread> th;
+            const int64_t per = (n_meta + nt - 1) / nt;
+            for (unsigned k = 1; k < nt; ++k) th.emplace_back(quant_range, std::min<int64_t>(n_meta, k * per), std::min<int64_t>(n_meta, (k + 1) * per));
+            quant_range(0, std::min<int64_t>(n_meta, per));
+            for (auto &t : th) t.join();
+        }
+        meta = qmeta.data();
+        if (getenv("JT_HOST_TIMING")) fprintf(stderr, "quant prepass %.3f ms (%u threads)\n", now_ms() - tq0, nt);
+    }
     auto add_meta = [&](const jt_frame_meta &m) {
         bool has = !std::isnan(m.momentary);
         double tp = 0, sp = 0, M = 0, S = 0;
         if (has) {
-            M = quantize ? qfmt("%.3f", m.momentary) : m.momentary; S = quantize ? qfmt("%.3f", m.shortterm) : m.shortterm;
-            tp = linearRatioToDB(quantize ? qfmt("%.3f", m.true_peak) : m.true_peak);
-            sp = linearRatioToDB(quantize ? qfmt("%.3f", m.sample_peak) : m.sample_peak);
+            M = m.momentary; S = m.shortterm;
+            tp = linearRatioToDB(m.true_peak);
+            sp = linearRatioToDB(m.sample_peak);
         }
         if (acc.frameCount == 0 || tp > acc.tpMax) acc.tpMax = tp;
         if (acc.frameCount == 0 || sp > acc.spMax) acc.spMax = sp;
-        spec_add(acc.spec, quantize ? spec_quant(m.spectral) : m.spectral); acc.specFound = true;
+        spec_add(acc.spec, m.spectral); acc.specFound = true;
         acc.mSum += M; acc.sSum += S; acc.frameCount++;
     };
     for (int64_t f = 0; f < n_frames; ++f) {
@@ -518,6 +582,7 @@ static void detect_vad(const std::vector<jt_interval> &iv, double seed, jt_measu
     double p75 = percentileOfSorted(levels, 75);
     double split = clampSplit(otsuSplit(h), seed, p75);
     double floor_ = percentileFloor(levels, seed);
+    const double tv0 = now_ms();
     std::vector<bool> flags(iv.size());
     for (size_t i = 0; i < iv.size(); ++i) flags[i] = isSpeechInterval(iv[i], split);
     double margin = hysteresisMargin(h, split);
@@ -549,7 +614,9 @@ static void detect_vad(const std::vector<jt_interval> &iv, double seed, jt_measu
             m->room_tone_sample.true_peak = ac.tpMax; m->room_tone_sample.sample_peak = ac.spMax;
         }
     }
+    const double tv1 = now_ms();
     BestResult br = findBestSpeechRegion(runs, iv, haveProfile, floor_);
+    if (getenv("JT_HOST_TIMING")) fprintf(stderr, "vad: runs+noise %.3f ms, best speech %.3f ms\n", tv1 - tv0, now_ms() - tv1);
     m->n_candidates = (int)std::min<size_t>(br.cands.size(), JT_MAX_REGIONS);
     for (int i = 0; i < m->n_candidates; ++i) m->candidates[i] = br.cands[i];
     bool elected = false; jt_region electedRegion{};
@@ -582,6 +649,7 @@ extern "C" int jt_host_detect(const jt_analysis *p1, const jt_interval *ivp, int
     m->duration_s = duration_s;
     // buildInputMeasurements (analyser.go:364-406)
     double nf = 0, thr = 0;
+    const double td0 = now_ms();
     if (!estimateNoiseFloorAndThreshold(iv, &nf, &thr)) { nf = vadLevelFloorDB; thr = calculateAdaptiveSilenceThreshold(vadLevelFloorDB); }
     m->floor_prescan = nf; m->room_tone_detect_level = thr;
     m->input_i = q3(p1->r128.integrated);
@@ -609,7 +677,9 @@ extern "C" int jt_host_detect(const jt_analysis *p1, const jt_interval *ivp, int
     else { double off = m->input_i > -20.0 ? 18.0 : (m->input_i > -30.0 ? 12.0 : 8.0); m->floor = m->input_thresh - off; m->floor_source = 2; }
     m->floor = std::max(-90.0, std::min(-30.0, m->floor));
 
+    const double td1 = now_ms();
     detect_vad(iv, m->floor_prescan, m);
+    if (getenv("JT_HOST_TIMING")) fprintf(stderr, "detect: seed %.3f ms, vad %.3f ms\n", td1 - td0, now_ms() - td1);
     return JT_OK;
 }
 
@@ -923,7 +993,6 @@ extern "C" int jt_host_pass4_spec(const jt_host_config *cfg, const jt_loudnorm_s
 // =====================================================================================================
 // orchestration (processor.go:29-216)
 // =====================================================================================================
-static double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 static double secs_of(int64_t ns) { return qfmt("%f", (double)ns / 1e9); }    // regions travel through "%f"-formatted filter options
 
 static int analyse_core(jt_ctx *h, const jt_host_config *base, int frame_samples, jt_process_result *out,
