@@ -114,6 +114,148 @@ k_anlmdn_wave(const float *__restrict__ in, float *__restrict__ out, int64_t n, 
     }
 }
 
+// ------------------------------------------------------------------ wave-per-hop-PAIR fast path (packed f32)
+// Same mapping as k_anlmdn_wave, but a wave carries TWO consecutive hops in the two halves of packed-f32 registers
+// (v_pk_add_f32 / v_pk_mul_f32: CDNA's full FP32 rate needs packed issue), and the weight stage is skipped for an output
+// when no lane of the wave has a patch distance under the smoothing cut (FFmpeg's `if (w >= smooth) continue;` taken for
+// all 2S offsets: the output is the input sample).  On speech at the reference's strength (s = 1e-5) that is the common
+// case, so the steady-state cost is the patch-distance recurrence alone: 2 sub, 2 mul, 2 add per offset, exact f32 order.
+typedef float f2 __attribute__((ext_vector_type(2)));
+
+template <int NOFF, bool INTERIOR>
+__device__ inline void nlm_pair_body(const float *__restrict__ in, int64_t gwin, const float *fA, const float *fB, float *obuf,
+                                     int K, int S, int H, int flimit, float sw, float smooth, float lut_scale, float neg_inv_scale_log2e,
+                                     int lane)
+{
+    const int j0 = lane * NOFF;
+    const int d0 = j0 - S + (j0 >= S ? 1 : 0);
+    f2 cache[NOFF];
+#pragma unroll
+    for (int q = 0; q < NOFF; ++q) cache[q] = f2{0.f, 0.f};
+    // ---- seed: compute_distance_ssd over k = -K..K (ascending, mul then add), stream-rotated reads
+    {
+        f2 st[NOFF];
+#pragma unroll
+        for (int q = 0; q < NOFF; ++q) { const int x = S + d0 + q - K; st[q] = f2{fA[x], fB[x]}; }
+        for (int k0 = -K; k0 <= K; k0 += NOFF) {
+#pragma unroll
+            for (int u = 0; u < NOFF; ++u) {
+                const int k = k0 + u;
+                if (k <= K) {
+                    f2 c;
+                    if (INTERIOR) { c.x = in[gwin + K + S + k]; c.y = in[gwin + K + S + k + H]; }
+                    else { c.x = fA[S + k]; c.y = fB[S + k]; }
+#pragma unroll
+                    for (int q = 0; q < NOFF; ++q) {
+                        const f2 dd = c - st[(q + u) % NOFF];
+                        cache[q] = cache[q] + dd * dd;
+                    }
+                    const int nx = min(S + d0 + (NOFF - 1) + k + 1, flimit);
+                    st[u % NOFF] = f2{fA[nx], fB[nx]};
+                }
+            }
+        }
+    }
+    // ---- main recurrence.  hi[(q+u)%NOFF] = f[i + d0 + q + K], lo[...] = f[i + d0 + q - K - 1] at step i = i0 + u
+    f2 hi[NOFF], lo[NOFF];
+#pragma unroll
+    for (int q = 0; q < NOFF; ++q) {
+        const int xh = S + d0 + q + K; hi[q] = f2{fA[xh], fB[xh]};
+        const int xl = max(S + d0 + q - K - 1, -K); lo[q] = f2{fA[xl], fB[xl]};     // first used at i = S+1
+    }
+    for (int i0 = S; i0 < H + S; i0 += NOFF) {
+#pragma unroll
+        for (int u = 0; u < NOFF; ++u) {
+            const int i = i0 + u;
+            if (i < H + S) {
+                f2 wv[NOFF];
+                if (i != S) {
+                    f2 cm, cp;
+                    if (INTERIOR) { cm.x = in[gwin + K + i - K - 1]; cm.y = in[gwin + K + i - K - 1 + H]; cp.x = in[gwin + K + i + K]; cp.y = in[gwin + K + i + K + H]; }
+                    else { cm.x = fA[i - K - 1]; cm.y = fB[i - K - 1]; cp.x = fA[i + K]; cp.y = fB[i + K]; }
+#pragma unroll
+                    for (int q = 0; q < NOFF; ++q) {
+                        const f2 a = cm - lo[(q + u) % NOFF];
+                        const f2 b = cp - hi[(q + u) % NOFF];
+                        cache[q] = cache[q] + (-(a * a) + b * b);
+                    }
+                }
+                float wmin = 3.0e38f;
+#pragma unroll
+                for (int q = 0; q < NOFF; ++q) {
+                    cache[q].x = fmaxf(cache[q].x, 0.f); cache[q].y = fmaxf(cache[q].y, 0.f);     // if (distance < 0) cache = distance = 0
+                    wv[q] = cache[q] * sw;
+                    wmin = fminf(wmin, fminf(wv[q].x, wv[q].y));
+                }
+                if (__any(wmin < smooth)) {
+                    // some offset contributes: weights, lane-local sums, wave reductions (per hop of the pair)
+                    float Px = 0.f, Qx = 0.f, Py = 0.f, Qy = 0.f;
+#pragma unroll
+                    for (int q = 0; q < NOFF; ++q) {
+                        const int xc = i + d0 + q;
+                        if (!(wv[q].x >= smooth)) {
+                            const float idx = truncf(__fmul_rn(wv[q].x, lut_scale));
+                            const float wt = __builtin_amdgcn_exp2f(idx * neg_inv_scale_log2e);      // weight_lut[idx] = expf(-idx / scale)
+                            Px = __fadd_rn(Px, __fmul_rn(wt, fA[xc])); Qx = __fadd_rn(Qx, wt);
+                        }
+                        if (!(wv[q].y >= smooth)) {
+                            const float idx = truncf(__fmul_rn(wv[q].y, lut_scale));
+                            const float wt = __builtin_amdgcn_exp2f(idx * neg_inv_scale_log2e);
+                            Py = __fadd_rn(Py, __fmul_rn(wt, fB[xc])); Qy = __fadd_rn(Qy, wt);
+                        }
+                    }
+                    Px = wave_sum63(Px); Qx = wave_sum63(Qx); Py = wave_sum63(Py); Qy = wave_sum63(Qy);
+                    if (lane == 63) {
+                        obuf[i - S] = __fadd_rn(Px, fA[i]) / __fadd_rn(Qx, 1.f);
+                        obuf[i - S + H] = __fadd_rn(Py, fB[i]) / __fadd_rn(Qy, 1.f);
+                    }
+                }
+                // advance the streams: slot u held offset-0's values of this step; it becomes offset NOFF-1 of the next step
+                const int nx = i + 1 + d0 + (NOFF - 1);
+                const int xh = min(nx + K, flimit), xl = nx - K - 1;
+                hi[u % NOFF] = f2{fA[xh], fB[xh]};
+                lo[u % NOFF] = f2{fA[xl], fB[xl]};
+            }
+        }
+    }
+}
+
+template <int NOFF>
+__global__ void __launch_bounds__(64)
+k_anlmdn_pair(const float *__restrict__ in, float *__restrict__ out, int64_t n, int K, int S, float sw, float smooth,
+              float lut_scale, int64_t nhops)
+{
+    extern __shared__ float smem_nlm[];
+    const int H = 2 * K + 1;
+    const int NW = H + 2 * (K + S);
+    const int NW2 = NW + H;                        // two consecutive hops share one window
+    float *win = smem_nlm;                         // [NW2]
+    float *obuf = smem_nlm + ((NW2 + 3) & ~3);     // [2H]
+    const int lane = threadIdx.x;
+    const int64_t hopA = (int64_t)blockIdx.x * 2;
+    const int64_t hs = hopA * H - (K + S);         // first output sample of hop A
+    const int64_t gwin = hs - (K + S);             // global index of win[0]
+    for (int w = lane; w < NW2; w += 64) {
+        int64_t k = gwin + w;
+        win[w] = (k >= 0 && k < n) ? in[k] : 0.f;
+    }
+    __syncthreads();
+    const float *fA = win + K;                     // f[i], i in [-K, NW-K)
+    const float *fB = fA + H;
+    for (int t = lane; t < 2 * H; t += 64) obuf[t] = fA[t + S];      // default output = input (all offsets skipped)
+    __syncthreads();
+    const int flimit = NW - K - 1;                 // highest valid f index (per hop)
+    const float nisl = -1.4426950408889634f / lut_scale;
+    const bool interior = gwin >= 0 && gwin + NW2 <= n;
+    if (interior) nlm_pair_body<NOFF, true>(in, gwin, fA, fB, obuf, K, S, H, flimit, sw, smooth, lut_scale, nisl, lane);
+    else nlm_pair_body<NOFF, false>(in, gwin, fA, fB, obuf, K, S, H, flimit, sw, smooth, lut_scale, nisl, lane);
+    __syncthreads();
+    for (int t = lane; t < 2 * H; t += 64) {
+        int64_t o = hs + t;
+        if (o >= 0 && o < n) out[o] = obuf[t];
+    }
+}
+
 // ------------------------------------------------------------------ generic path (any K, S)
 constexpr int NLM_TI = 64;     // outputs per weight tile
 
@@ -198,13 +340,15 @@ void launch_anlmdn(const float *in, float *out, int64_t n, int K, int S, float s
     const int noff = (2 * S) / 64;
     const bool fast = (2 * S) % 64 == 0 && noff >= 1 && S % noff == 0 && (noff == 3 || noff == 6 || noff == 2 || noff == 4);
     if (fast) {
-        size_t smem = sizeof(float) * (size_t)(((NW + 3) & ~3) + H + 4);
+        const int NW2 = NW + H;
+        size_t smem = sizeof(float) * (size_t)(((NW2 + 3) & ~3) + 2 * H + 4);
         JT_REQUIRE(smem <= 64 * 1024, JT_E_UNSUPPORTED, "anlmdn: window exceeds the wave-per-hop LDS budget");
+        const unsigned grid = (unsigned)((nhops + 1) / 2);
         switch (noff) {
-        case 2: hipLaunchKernelGGL((k_anlmdn_wave<2>), dim3((unsigned)nhops), dim3(64), smem, s, in, out, n, K, S, sw, smooth, lut_scale, nhops); break;
-        case 3: hipLaunchKernelGGL((k_anlmdn_wave<3>), dim3((unsigned)nhops), dim3(64), smem, s, in, out, n, K, S, sw, smooth, lut_scale, nhops); break;
-        case 4: hipLaunchKernelGGL((k_anlmdn_wave<4>), dim3((unsigned)nhops), dim3(64), smem, s, in, out, n, K, S, sw, smooth, lut_scale, nhops); break;
-        default: hipLaunchKernelGGL((k_anlmdn_wave<6>), dim3((unsigned)nhops), dim3(64), smem, s, in, out, n, K, S, sw, smooth, lut_scale, nhops); break;
+        case 2: hipLaunchKernelGGL((k_anlmdn_pair<2>), dim3(grid), dim3(64), smem, s, in, out, n, K, S, sw, smooth, lut_scale, nhops); break;
+        case 3: hipLaunchKernelGGL((k_anlmdn_pair<3>), dim3(grid), dim3(64), smem, s, in, out, n, K, S, sw, smooth, lut_scale, nhops); break;
+        case 4: hipLaunchKernelGGL((k_anlmdn_pair<4>), dim3(grid), dim3(64), smem, s, in, out, n, K, S, sw, smooth, lut_scale, nhops); break;
+        default: hipLaunchKernelGGL((k_anlmdn_pair<6>), dim3(grid), dim3(64), smem, s, in, out, n, K, S, sw, smooth, lut_scale, nhops); break;
         }
         return;
     }
