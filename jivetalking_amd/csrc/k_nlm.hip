@@ -122,101 +122,154 @@ k_anlmdn_wave(const float *__restrict__ in, float *__restrict__ out, int64_t n, 
 // case, so the steady-state cost is the patch-distance recurrence alone: 2 sub, 2 mul, 2 add per offset, exact f32 order.
 typedef float f2 __attribute__((ext_vector_type(2)));
 
-template <int NOFF, bool INTERIOR>
-__device__ inline void nlm_pair_body(const float *__restrict__ in, int64_t gwin, const float *fA, const float *fB, float *obuf,
-                                     int K, int S, int H, int flimit, float sw, float smooth, float lut_scale, float neg_inv_scale_log2e,
-                                     int lane)
+typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
+constexpr int NLM_PADF = 4, NLM_PADB = 24;      // zero/real-sample padding of the LDS window: no index clamps in the loops
+
+// Four consecutive uniform ("centre") samples of both hops starting at tile-relative position x: one scalar x4 load per hop
+// from global memory in the interior (wave-uniform address), LDS broadcast reads at the file edges (zero-padded window).
+template <bool INTERIOR>
+__device__ inline void nlm_centre4(const float *__restrict__ in, int64_t gbase, const float *fA, const float *fB, int x, int H, f2 (&c)[4])
 {
+    if (INTERIOR) {
+        const f4u a = *reinterpret_cast<const f4u *>(in + gbase + x);
+        const f4u b = *reinterpret_cast<const f4u *>(in + gbase + x + H);
+        c[0] = f2{a.x, b.x}; c[1] = f2{a.y, b.y}; c[2] = f2{a.z, b.z}; c[3] = f2{a.w, b.w};
+    } else {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) c[u] = f2{fA[x + u], fB[x + u]};
+    }
+}
+
+// One step of the patch-distance recurrence + the engagement test for both hops of the pair (v = unrolled position, ring
+// slot of offset q is (q + v) % R).  `first` = hop start (no recurrence update).
+template <int NOFF, int V, bool FIRST>
+__device__ inline void nlm_step(f2 (&cache)[NOFF], f2 (&hi)[NOFF + 1], f2 (&lo)[NOFF + 1], const f2 cm, const f2 cp, const float *pA,
+                                const float *pB, int i, int d0, int K, int S, int H, const float *fA, const float *fB,
+                                float *__restrict__ out, int64_t hs, int64_t n, float sw, float smooth, float lut_scale,
+                                float neg_inv_scale_log2e, float dthr, int lane)
+{
+    constexpr int R = NOFF + 1;
+    if (!FIRST) {
+#pragma unroll
+        for (int q = 0; q < NOFF; ++q) {
+            const f2 a = cm - lo[(q + V) % R];
+            const f2 b = cp - hi[(q + V) % R];
+            cache[q] = cache[q] + (-(a * a) + b * b);
+        }
+    }
+    // refill the slot offset 0 just released with what offset NOFF-1 reads two steps ahead: f[i+2+d0+NOFF-1 (+K | -K-1)];
+    // pA/pB point at f[i0 + d0 + NOFF + 1] of the block so the offsets below are compile-time constants
+    hi[V % R] = f2{pA[V + K], pB[V + K]};
+    lo[V % R] = f2{pA[V - K - 1], pB[V - K - 1]};
+    float dmin = 3.0e38f;
+#pragma unroll
+    for (int q = 0; q < NOFF; ++q) {
+        // if (distance < 0) cache = distance = 0
+        cache[q].x = __builtin_amdgcn_fmed3f(cache[q].x, 0.f, 3.0e38f);
+        cache[q].y = __builtin_amdgcn_fmed3f(cache[q].y, 0.f, 3.0e38f);
+        dmin = fminf(dmin, fminf(cache[q].x, cache[q].y));
+    }
+    if (__any(dmin < dthr)) {
+        // some offset may contribute: exact per-offset test, weights, lane-local sums, wave reductions (per hop)
+        float Px = 0.f, Qx = 0.f, Py = 0.f, Qy = 0.f;
+#pragma unroll
+        for (int q = 0; q < NOFF; ++q) {
+            const int xc = i + d0 + q;
+            const float wx = __fmul_rn(cache[q].x, sw), wy = __fmul_rn(cache[q].y, sw);
+            if (!(wx >= smooth)) {
+                const float idx = truncf(__fmul_rn(wx, lut_scale));
+                const float wt = __builtin_amdgcn_exp2f(idx * neg_inv_scale_log2e);      // weight_lut[idx] = expf(-idx / scale)
+                Px = __fadd_rn(Px, __fmul_rn(wt, fA[xc])); Qx = __fadd_rn(Qx, wt);
+            }
+            if (!(wy >= smooth)) {
+                const float idx = truncf(__fmul_rn(wy, lut_scale));
+                const float wt = __builtin_amdgcn_exp2f(idx * neg_inv_scale_log2e);
+                Py = __fadd_rn(Py, __fmul_rn(wt, fB[xc])); Qy = __fadd_rn(Qy, wt);
+            }
+        }
+        Px = wave_sum63(Px); Qx = wave_sum63(Qx); Py = wave_sum63(Py); Qy = wave_sum63(Qy);
+        if (lane == 63 && i - S < H) {
+            const int64_t oA = hs + (i - S), oB = oA + H;
+            if (oA >= 0 && oA < n) out[oA] = __fadd_rn(Px, fA[i]) / __fadd_rn(Qx, 1.f);
+            if (oB >= 0 && oB < n) out[oB] = __fadd_rn(Py, fB[i]) / __fadd_rn(Qy, 1.f);
+        }
+    }
+}
+
+template <int NOFF, bool INTERIOR>
+__device__ inline void nlm_pair_body(const float *__restrict__ in, float *__restrict__ out, int64_t n, int64_t hs, int64_t gwin,
+                                     const float *fA, const float *fB, int K, int S, int H, float sw, float smooth, float lut_scale,
+                                     float neg_inv_scale_log2e, int lane)
+{
+    // Streams live in a ring of R = NOFF+1 packed registers: slot (v+q)%R is offset q at unrolled step v, and the spare slot
+    // already holds the value offset NOFF-1 needs at the NEXT step, so every LDS refill is issued more than a full step before
+    // its first use; the wave-uniform centre samples arrive by scalar x4 loads issued 4 steps ahead (ping-pong A/B sets).
+    constexpr int R = NOFF + 1;
+    static_assert(R == 4, "the unrolled ring below is written for NOFF = 3");
     const int j0 = lane * NOFF;
     const int d0 = j0 - S + (j0 >= S ? 1 : 0);
+    const int64_t gbase = gwin + K;                       // global index of f[0] of hop A
     f2 cache[NOFF];
 #pragma unroll
     for (int q = 0; q < NOFF; ++q) cache[q] = f2{0.f, 0.f};
-    // ---- seed: compute_distance_ssd over k = -K..K (ascending, mul then add), stream-rotated reads
+    // ---- seed: compute_distance_ssd over k = -K..K (ascending, mul then add); 2K+1 = 4*(K/2) + 1 steps (K even)
     {
-        f2 st[NOFF];
+        f2 st[R], ca[4], cb[4];
 #pragma unroll
-        for (int q = 0; q < NOFF; ++q) { const int x = S + d0 + q - K; st[q] = f2{fA[x], fB[x]}; }
-        for (int k0 = -K; k0 <= K; k0 += NOFF) {
+        for (int q = 0; q < R; ++q) { const int x = S + d0 + q - K; st[q] = f2{fA[x], fB[x]}; }   // slot NOFF = (offset NOFF-1, k = -K+1)
+        nlm_centre4<INTERIOR>(in, gbase, fA, fB, S - K, H, ca);
+        const float *pA = fA + S + d0 + (NOFF - 1) + 2 - K, *pB = pA + H;       // refill source of step k: p[k + K]
+        for (int k0 = -K; k0 < K; k0 += 8) {
+            nlm_centre4<INTERIOR>(in, gbase, fA, fB, S + k0 + 4, H, cb);
 #pragma unroll
-            for (int u = 0; u < NOFF; ++u) {
-                const int k = k0 + u;
-                if (k <= K) {
-                    f2 c;
-                    if (INTERIOR) { c.x = in[gwin + K + S + k]; c.y = in[gwin + K + S + k + H]; }
-                    else { c.x = fA[S + k]; c.y = fB[S + k]; }
+            for (int u = 0; u < 4; ++u) {
 #pragma unroll
-                    for (int q = 0; q < NOFF; ++q) {
-                        const f2 dd = c - st[(q + u) % NOFF];
-                        cache[q] = cache[q] + dd * dd;
-                    }
-                    const int nx = min(S + d0 + (NOFF - 1) + k + 1, flimit);
-                    st[u % NOFF] = f2{fA[nx], fB[nx]};
-                }
+                for (int q = 0; q < NOFF; ++q) { const f2 dd = ca[u] - st[(q + u) % R]; cache[q] = cache[q] + dd * dd; }
+                st[u % R] = f2{pA[u], pB[u]};
             }
-        }
-    }
-    // ---- main recurrence.  hi[(q+u)%NOFF] = f[i + d0 + q + K], lo[...] = f[i + d0 + q - K - 1] at step i = i0 + u
-    f2 hi[NOFF], lo[NOFF];
+            nlm_centre4<INTERIOR>(in, gbase, fA, fB, S + k0 + 8, H, ca);
 #pragma unroll
-    for (int q = 0; q < NOFF; ++q) {
+            for (int u = 0; u < 4; ++u) {
+#pragma unroll
+                for (int q = 0; q < NOFF; ++q) { const f2 dd = cb[u] - st[(q + u) % R]; cache[q] = cache[q] + dd * dd; }
+                st[u % R] = f2{pA[4 + u], pB[4 + u]};
+            }
+            pA += 8; pB += 8;
+        }
+        // k = K, the (2K+1)-th term: 2K % 8 == 0 puts it at ring position 0 with its centre already in ca[0]
+#pragma unroll
+        for (int q = 0; q < NOFF; ++q) { const f2 dd = ca[0] - st[q % R]; cache[q] = cache[q] + dd * dd; }
+    }
+    // ---- main recurrence.  hi[(q+v)%R] = f[i + d0 + q + K], lo[...] = f[i + d0 + q - K - 1] at step i, v = (i - S) % R
+    f2 hi[R], lo[R];
+#pragma unroll
+    for (int q = 0; q < R; ++q) {
         const int xh = S + d0 + q + K; hi[q] = f2{fA[xh], fB[xh]};
-        const int xl = max(S + d0 + q - K - 1, -K); lo[q] = f2{fA[xl], fB[xl]};     // first used at i = S+1
+        const int xl = S + d0 + q - K - 1; lo[q] = f2{fA[xl], fB[xl]};         // first used at i = S+1 (front padding covers lane 0)
     }
-    for (int i0 = S; i0 < H + S; i0 += NOFF) {
-#pragma unroll
-        for (int u = 0; u < NOFF; ++u) {
-            const int i = i0 + u;
-            if (i < H + S) {
-                f2 wv[NOFF];
-                if (i != S) {
-                    f2 cm, cp;
-                    if (INTERIOR) { cm.x = in[gwin + K + i - K - 1]; cm.y = in[gwin + K + i - K - 1 + H]; cp.x = in[gwin + K + i + K]; cp.y = in[gwin + K + i + K + H]; }
-                    else { cm.x = fA[i - K - 1]; cm.y = fB[i - K - 1]; cp.x = fA[i + K]; cp.y = fB[i + K]; }
-#pragma unroll
-                    for (int q = 0; q < NOFF; ++q) {
-                        const f2 a = cm - lo[(q + u) % NOFF];
-                        const f2 b = cp - hi[(q + u) % NOFF];
-                        cache[q] = cache[q] + (-(a * a) + b * b);
-                    }
-                }
-                float wmin = 3.0e38f;
-#pragma unroll
-                for (int q = 0; q < NOFF; ++q) {
-                    cache[q].x = fmaxf(cache[q].x, 0.f); cache[q].y = fmaxf(cache[q].y, 0.f);     // if (distance < 0) cache = distance = 0
-                    wv[q] = cache[q] * sw;
-                    wmin = fminf(wmin, fminf(wv[q].x, wv[q].y));
-                }
-                if (__any(wmin < smooth)) {
-                    // some offset contributes: weights, lane-local sums, wave reductions (per hop of the pair)
-                    float Px = 0.f, Qx = 0.f, Py = 0.f, Qy = 0.f;
-#pragma unroll
-                    for (int q = 0; q < NOFF; ++q) {
-                        const int xc = i + d0 + q;
-                        if (!(wv[q].x >= smooth)) {
-                            const float idx = truncf(__fmul_rn(wv[q].x, lut_scale));
-                            const float wt = __builtin_amdgcn_exp2f(idx * neg_inv_scale_log2e);      // weight_lut[idx] = expf(-idx / scale)
-                            Px = __fadd_rn(Px, __fmul_rn(wt, fA[xc])); Qx = __fadd_rn(Qx, wt);
-                        }
-                        if (!(wv[q].y >= smooth)) {
-                            const float idx = truncf(__fmul_rn(wv[q].y, lut_scale));
-                            const float wt = __builtin_amdgcn_exp2f(idx * neg_inv_scale_log2e);
-                            Py = __fadd_rn(Py, __fmul_rn(wt, fB[xc])); Qy = __fadd_rn(Qy, wt);
-                        }
-                    }
-                    Px = wave_sum63(Px); Qx = wave_sum63(Qx); Py = wave_sum63(Py); Qy = wave_sum63(Qy);
-                    if (lane == 63) {
-                        obuf[i - S] = __fadd_rn(Px, fA[i]) / __fadd_rn(Qx, 1.f);
-                        obuf[i - S + H] = __fadd_rn(Py, fB[i]) / __fadd_rn(Qy, 1.f);
-                    }
-                }
-                // advance the streams: slot u held offset-0's values of this step; it becomes offset NOFF-1 of the next step
-                const int nx = i + 1 + d0 + (NOFF - 1);
-                const int xh = min(nx + K, flimit), xl = nx - K - 1;
-                hi[u % NOFF] = f2{fA[xh], fB[xh]};
-                lo[u % NOFF] = f2{fA[xl], fB[xl]};
-            }
-        }
+    const float dthr = (smooth / sw) * 1.000002f;          // cache >= dthr  =>  fl(cache*sw) >= smooth (the exact test follows)
+    const f2 zero2 = f2{0.f, 0.f};
+    const float *pA = fA + S + d0 + NOFF + 1, *pB = pA + H;                       // p[v] = f[i0 + v + 2 + d0 + NOFF - 1], i0 = S
+    nlm_step<NOFF, 0, true>(cache, hi, lo, zero2, zero2, pA, pB, S, d0, K, S, H, fA, fB, out, hs, n, sw, smooth, lut_scale,
+                            neg_inv_scale_log2e, dthr, lane);
+    // steps S+1 .. S+2K in blocks of 8 (2K % 8 == 0): v = 1..8, ring slot (v % R)
+    f2 ma[4], pa[4], mb[4], pb[4];
+    nlm_centre4<INTERIOR>(in, gbase, fA, fB, S + 1 - K - 1, H, ma);
+    nlm_centre4<INTERIOR>(in, gbase, fA, fB, S + 1 + K, H, pa);
+    for (int i0 = S + 1; i0 < H + S; i0 += 8) {
+        pA = fA + i0 + d0 + NOFF + 1 - 1; pB = pA + H;                            // so that p[v], v = 1.., is step (i0 + v - 1)'s refill
+        nlm_centre4<INTERIOR>(in, gbase, fA, fB, i0 + 4 - K - 1, H, mb);
+        nlm_centre4<INTERIOR>(in, gbase, fA, fB, i0 + 4 + K, H, pb);
+        nlm_step<NOFF, 1, false>(cache, hi, lo, ma[0], pa[0], pA, pB, i0 + 0, d0, K, S, H, fA, fB, out, hs, n, sw, smooth, lut_scale, neg_inv_scale_log2e, dthr, lane);
+        nlm_step<NOFF, 2, false>(cache, hi, lo, ma[1], pa[1], pA, pB, i0 + 1, d0, K, S, H, fA, fB, out, hs, n, sw, smooth, lut_scale, neg_inv_scale_log2e, dthr, lane);
+        nlm_step<NOFF, 3, false>(cache, hi, lo, ma[2], pa[2], pA, pB, i0 + 2, d0, K, S, H, fA, fB, out, hs, n, sw, smooth, lut_scale, neg_inv_scale_log2e, dthr, lane);
+        nlm_step<NOFF, 4, false>(cache, hi, lo, ma[3], pa[3], pA, pB, i0 + 3, d0, K, S, H, fA, fB, out, hs, n, sw, smooth, lut_scale, neg_inv_scale_log2e, dthr, lane);
+        nlm_centre4<INTERIOR>(in, gbase, fA, fB, i0 + 8 - K - 1, H, ma);
+        nlm_centre4<INTERIOR>(in, gbase, fA, fB, i0 + 8 + K, H, pa);
+        nlm_step<NOFF, 5, false>(cache, hi, lo, mb[0], pb[0], pA, pB, i0 + 4, d0, K, S, H, fA, fB, out, hs, n, sw, smooth, lut_scale, neg_inv_scale_log2e, dthr, lane);
+        nlm_step<NOFF, 6, false>(cache, hi, lo, mb[1], pb[1], pA, pB, i0 + 5, d0, K, S, H, fA, fB, out, hs, n, sw, smooth, lut_scale, neg_inv_scale_log2e, dthr, lane);
+        nlm_step<NOFF, 7, false>(cache, hi, lo, mb[2], pb[2], pA, pB, i0 + 6, d0, K, S, H, fA, fB, out, hs, n, sw, smooth, lut_scale, neg_inv_scale_log2e, dthr, lane);
+        nlm_step<NOFF, 8, false>(cache, hi, lo, mb[3], pb[3], pA, pB, i0 + 7, d0, K, S, H, fA, fB, out, hs, n, sw, smooth, lut_scale, neg_inv_scale_log2e, dthr, lane);
     }
 }
 
@@ -229,31 +282,30 @@ k_anlmdn_pair(const float *__restrict__ in, float *__restrict__ out, int64_t n, 
     const int H = 2 * K + 1;
     const int NW = H + 2 * (K + S);
     const int NW2 = NW + H;                        // two consecutive hops share one window
-    float *win = smem_nlm;                         // [NW2]
-    float *obuf = smem_nlm + ((NW2 + 3) & ~3);     // [2H]
+    const int NWP = NLM_PADF + NW2 + NLM_PADB;
+    float *win = smem_nlm;                         // [NWP]
     const int lane = threadIdx.x;
     const int64_t hopA = (int64_t)blockIdx.x * 2;
     const int64_t hs = hopA * H - (K + S);         // first output sample of hop A
-    const int64_t gwin = hs - (K + S);             // global index of win[0]
-    for (int w = lane; w < NW2; w += 64) {
-        int64_t k = gwin + w;
+    const int64_t gwin = hs - (K + S);             // global index of f[-K] of hop A
+    for (int w = lane; w < NWP; w += 64) {
+        int64_t k = gwin - NLM_PADF + w;
         win[w] = (k >= 0 && k < n) ? in[k] : 0.f;
     }
     __syncthreads();
-    const float *fA = win + K;                     // f[i], i in [-K, NW-K)
+    const float *fA = win + NLM_PADF + K;          // f[i], i in [-K, NW-K)
     const float *fB = fA + H;
-    for (int t = lane; t < 2 * H; t += 64) obuf[t] = fA[t + S];      // default output = input (all offsets skipped)
-    __syncthreads();
-    const int flimit = NW - K - 1;                 // highest valid f index (per hop)
-    const float nisl = -1.4426950408889634f / lut_scale;
-    const bool interior = gwin >= 0 && gwin + NW2 <= n;
-    if (interior) nlm_pair_body<NOFF, true>(in, gwin, fA, fB, obuf, K, S, H, flimit, sw, smooth, lut_scale, nisl, lane);
-    else nlm_pair_body<NOFF, false>(in, gwin, fA, fB, obuf, K, S, H, flimit, sw, smooth, lut_scale, nisl, lane);
-    __syncthreads();
+    // default output = input (every offset skipped); outputs with contributing offsets are overwritten from inside the loop.
+    // The fence orders the two stores to the same address (they come from different lanes of this wave).
     for (int t = lane; t < 2 * H; t += 64) {
-        int64_t o = hs + t;
-        if (o >= 0 && o < n) out[o] = obuf[t];
+        const int64_t o = hs + t;
+        if (o >= 0 && o < n) out[o] = fA[t + S];
     }
+    __threadfence();
+    const float nisl = -1.4426950408889634f / lut_scale;
+    const bool interior = gwin - NLM_PADF >= 0 && gwin + NW2 + NLM_PADB <= n;
+    if (interior) nlm_pair_body<NOFF, true>(in, out, n, hs, gwin, fA, fB, K, S, H, sw, smooth, lut_scale, nisl, lane);
+    else nlm_pair_body<NOFF, false>(in, out, n, hs, gwin, fA, fB, K, S, H, sw, smooth, lut_scale, nisl, lane);
 }
 
 // ------------------------------------------------------------------ generic path (any K, S)
@@ -338,18 +390,13 @@ void launch_anlmdn(const float *in, float *out, int64_t n, int K, int S, float s
     const int NW = H + 2 * (K + S);
     int64_t nhops = (n + (K + S) + H - 1) / H;
     const int noff = (2 * S) / 64;
-    const bool fast = (2 * S) % 64 == 0 && noff >= 1 && S % noff == 0 && (noff == 3 || noff == 6 || noff == 2 || noff == 4);
+    const bool fast = (2 * S) == 192 && K % 4 == 0;          // 48 kHz defaults: 64 lanes x 3 adjacent offsets, 2K a multiple of 8
     if (fast) {
         const int NW2 = NW + H;
-        size_t smem = sizeof(float) * (size_t)(((NW2 + 3) & ~3) + 2 * H + 4);
+        size_t smem = sizeof(float) * (size_t)(NLM_PADF + NW2 + NLM_PADB);
         JT_REQUIRE(smem <= 64 * 1024, JT_E_UNSUPPORTED, "anlmdn: window exceeds the wave-per-hop LDS budget");
         const unsigned grid = (unsigned)((nhops + 1) / 2);
-        switch (noff) {
-        case 2: hipLaunchKernelGGL((k_anlmdn_pair<2>), dim3(grid), dim3(64), smem, s, in, out, n, K, S, sw, smooth, lut_scale, nhops); break;
-        case 3: hipLaunchKernelGGL((k_anlmdn_pair<3>), dim3(grid), dim3(64), smem, s, in, out, n, K, S, sw, smooth, lut_scale, nhops); break;
-        case 4: hipLaunchKernelGGL((k_anlmdn_pair<4>), dim3(grid), dim3(64), smem, s, in, out, n, K, S, sw, smooth, lut_scale, nhops); break;
-        default: hipLaunchKernelGGL((k_anlmdn_pair<6>), dim3(grid), dim3(64), smem, s, in, out, n, K, S, sw, smooth, lut_scale, nhops); break;
-        }
+        hipLaunchKernelGGL((k_anlmdn_pair<3>), dim3(grid), dim3(64), smem, s, in, out, n, K, S, sw, smooth, lut_scale, nhops);
         return;
     }
     int threads = ((2 * S + 63) / 64) * 64;
