@@ -116,61 +116,95 @@ extern "C" int jt_upload_s16(jt_ctx *h, const int16_t *pcm, int64_t frames, int 
     JT_API_END(h)
 }
 
-// ---------------------------------------------------------------- analysis of a mono f32 signal on device
-struct AnalysisHost {
-    jt_astats astats; R128Series r128; std::vector<double> tp_cum, sp_cum; double tp_final, sp_final;
-    std::vector<jt_spectral> hops; int64_t nblocks = 0, nhops = 0; int blk = 0;
-};
-
-static void run_astats(jt_ctx *h, const float *x, int64_t n, int sr, jt_astats *out) { jt_astats_device(h, x, n, sr, out); }
-
-// K-weighted block energies, sample peaks, true peaks (streaming swr to 192 kHz) and R128 finishing
-static void run_r128(jt_ctx *h, const float *x, int64_t n, int sr, bool dualmono, bool want_tp, AnalysisHost *A)
+// ---------------------------------------------------------------- cached resampler plans
+static SwrDev &get_swr(jt_ctx *h, int in_rate, int out_rate)
 {
-    const int blk = sr / 10;
-    const int64_t nfull = n / blk;
-    A->blk = blk; A->nblocks = nfull;
-    std::vector<double> bsum, bpk, btp((size_t)nfull + 2, 0.0);
-    if (want_tp) {
-        SwrPlanHost pl; jt_swr_plan(&pl, sr, 192000);
-        h->bank_d.ensure(pl.bank.size());
-        JT_HIP(hipMemcpyAsync(h->bank_d.p, pl.bank.data(), sizeof(double) * pl.bank.size(), hipMemcpyHostToDevice, h->stream));
-        h->d_scr1.ensure((size_t)nfull + 2);
-        JT_HIP(hipMemsetAsync(h->d_scr1.p, 0, sizeof(double) * (nfull + 2), h->stream));
-        int64_t m_total = (int64_t)(((__int128)n * pl.phase_count + pl.step - 1) / pl.step);
-        launch_true_peak_f32(x, n, h->bank_d.p, pl.phase_count, pl.filter_length, pl.center, pl.step, blk, h->d_scr1.p, nfull + 1, m_total, h->stream);
-        JT_HIP(hipMemcpyAsync(btp.data(), h->d_scr1.p, sizeof(double) * (nfull + 2), hipMemcpyDeviceToHost, h->stream));
-        JT_HIP(hipStreamSynchronize(h->stream));   // pl.bank must outlive the async copy
-    }
-    jt_kweight_blocks_f32(h, x, n, sr, blk, bsum, bpk);
-    jt_r128_finish(bsum.data(), nfull, blk, sr, dualmono, &A->r128);
-    A->tp_cum.assign(nfull, 0.0); A->sp_cum.assign(nfull, 0.0);
-    double tp = 0, sp = 0;
-    for (int64_t k = 0; k < nfull; ++k) {
-        sp = std::max(sp, bpk[(size_t)k]); tp = std::max(tp, btp[(size_t)k]);
-        A->sp_cum[k] = sp; A->tp_cum[k] = tp;
-    }
-    // trailing partial frame: peaks still update (f_ebur128.c runs the per-sample loop over it)
-    sp = std::max(sp, bpk[(size_t)nfull]); tp = std::max(tp, btp[(size_t)nfull]);
-    A->sp_final = sp; A->tp_final = tp;
+    for (auto &e : h->swr) if (e.in_rate == in_rate && e.out_rate == out_rate) return e;
+    SwrDev &e = h->swr[h->swr_next]; h->swr_next = (h->swr_next + 1) % 4;
+    JT_HIP(hipStreamSynchronize(h->stream));             // the slot's old banks may still be read by queued kernels
+    jt_swr_plan(&e.pl, in_rate, out_rate);
+    std::vector<float> bf(e.pl.bank.size());
+    for (size_t i = 0; i < bf.size(); ++i) bf[i] = (float)e.pl.bank[i];
+    e.bank_d.ensure(e.pl.bank.size()); e.bank_f.ensure(bf.size());
+    JT_HIP(hipMemcpyAsync(e.bank_d.p, e.pl.bank.data(), sizeof(double) * e.pl.bank.size(), hipMemcpyHostToDevice, h->stream));
+    JT_HIP(hipMemcpyAsync(e.bank_f.p, bf.data(), sizeof(float) * bf.size(), hipMemcpyHostToDevice, h->stream));
+    JT_HIP(hipStreamSynchronize(h->stream));
+    e.in_rate = in_rate; e.out_rate = out_rate;
+    return e;
 }
 
-// sel_blk > 0: only the hops the Go side would ever see (one per 100 ms ebur128 output frame); A->hops[k] is then the
-// record of output frame k.  sel_blk == 0: every hop (operator-level parity entry).
-static void run_spectral(jt_ctx *h, const float *x, int64_t n, int sr, AnalysisHost *A, int sel_blk)
+// start of a pass: size the pinned arena and the K-weighting scratch for everything the pass will stage (nothing in flight)
+static void pass_begin(jt_ctx *h, int64_t max_samples, int analyses)
 {
-    const int win = 2048, hop = win / 2;
-    ensure_twiddle(h, win); ensure_hann(h, win);
-    const int64_t nhops = (n + hop - 1) / hop;
-    A->nhops = nhops;
-    int64_t nframes = 0;
-    if (sel_blk > 0) nframes = n / sel_blk + ((n % sel_blk) ? 1 : 0);
-    const int64_t nout = sel_blk > 0 ? nframes : nhops;
-    h->spec_hops.ensure((size_t)std::max<int64_t>(nout, 1));
-    launch_aspectralstats(x, n, sr, win, h->twiddle.p, h->hann.p, h->spec_hops.p, nhops, sel_blk, nframes, h->stream);
-    A->hops.resize((size_t)nout);
-    if (nout > 0) JT_HIP(hipMemcpyAsync(A->hops.data(), h->spec_hops.p, sizeof(jt_spectral) * nout, hipMemcpyDeviceToHost, h->stream));
-    JT_HIP(hipStreamSynchronize(h->stream));
+    h->pin.begin(jt_arena_bytes_for(max_samples) * (size_t)std::max(1, analyses) + (4u << 20));
+    h->kw_begin((size_t)(max_samples / 512 + 1024) * 8 * (size_t)std::max(1, analyses));
+}
+
+// ---------------------------------------------------------------- analysis of a mono f32 signal on device
+// (astats + aspectralstats + ebur128 of the Pass-1 / Pass-2 / Pass-4 / region graphs).  enqueue: every kernel and every
+// device->host copy of the analysis, no synchronisation; finish: the host arithmetic (gating, LRA, merges) after the sync.
+struct AnalysisHost {
+    jt_astats astats; R128Series r128; std::vector<double> tp_cum, sp_cum; double tp_final, sp_final;
+    const jt_spectral *hops = nullptr; int64_t nblocks = 0, nhops = 0, nout = 0; int blk = 0;
+};
+struct AnalysisJob {
+    AstatsJob as; KwJob kw; const double *btp = nullptr; const jt_spectral *hops = nullptr;
+    int64_t n = 0, nfull = 0, nhops = 0, nout = 0; int blk = 0, sr = 0; bool dualmono = false, want_astats = true, want_r128 = true, want_spec = true;
+};
+
+static void analysis_enqueue(jt_ctx *h, const float *x, int64_t n, int sr, bool dualmono, int sel_blk, AnalysisJob *J)
+{
+    J->n = n; J->sr = sr; J->dualmono = dualmono;
+    if (J->want_astats) jt_astats_enqueue(h, x, n, sr, &J->as);
+    if (J->want_r128) {
+        const int blk = sr / 10; const int64_t nfull = n / blk;
+        J->blk = blk; J->nfull = nfull;
+        SwrDev &sw = get_swr(h, sr, 192000);
+        h->d_scr1.ensure((size_t)nfull + 2);
+        JT_HIP(hipMemsetAsync(h->d_scr1.p, 0, sizeof(double) * (nfull + 2), h->stream));
+        launch_true_peak_f32(x, n, sw.bank_d.p, sw.pl.phase_count, sw.pl.filter_length, sw.pl.center, sw.pl.step, blk, h->d_scr1.p, nfull + 1,
+                             sw.out_len(n), h->stream);
+        double *btp = h->pin.take<double>((size_t)nfull + 2);
+        JT_HIP(hipMemcpyAsync(btp, h->d_scr1.p, sizeof(double) * (nfull + 2), hipMemcpyDeviceToHost, h->stream));
+        J->btp = btp;
+        jt_kweight_enqueue_f32(h, x, n, sr, blk, &J->kw);
+    }
+    if (J->want_spec) {
+        const int win = 2048, hop = win / 2;
+        ensure_twiddle(h, win); ensure_hann(h, win);
+        const int64_t nhops = (n + hop - 1) / hop;
+        int64_t nframes = 0;
+        if (sel_blk > 0) nframes = n / sel_blk + ((n % sel_blk) ? 1 : 0);
+        const int64_t nout = sel_blk > 0 ? nframes : nhops;
+        J->nhops = nhops; J->nout = nout;
+        h->spec_hops.ensure((size_t)std::max<int64_t>(nout, 1));
+        launch_aspectralstats(x, n, sr, win, h->twiddle.p, h->hann.p, h->spec_hops.p, nhops, sel_blk, nframes, h->stream);
+        jt_spectral *hops = h->pin.take<jt_spectral>((size_t)std::max<int64_t>(nout, 1));
+        if (nout > 0) JT_HIP(hipMemcpyAsync(hops, h->spec_hops.p, sizeof(jt_spectral) * nout, hipMemcpyDeviceToHost, h->stream));
+        J->hops = hops;
+    }
+}
+
+static void analysis_finish(const AnalysisJob &J, AnalysisHost *A)
+{
+    if (J.want_astats) jt_astats_finish(&J.as, &A->astats);
+    if (J.want_r128) {
+        const int64_t nfull = J.nfull;
+        A->blk = J.blk; A->nblocks = nfull;
+        std::vector<double> bsum, bpk;
+        jt_kweight_finish(&J.kw, bsum, bpk);
+        jt_r128_finish(bsum.data(), nfull, J.blk, J.sr, J.dualmono, &A->r128);
+        A->tp_cum.assign(nfull, 0.0); A->sp_cum.assign(nfull, 0.0);
+        double tp = 0, sp = 0;
+        for (int64_t k = 0; k < nfull; ++k) {
+            sp = std::max(sp, bpk[(size_t)k]); tp = std::max(tp, J.btp[(size_t)k]);
+            A->sp_cum[k] = sp; A->tp_cum[k] = tp;
+        }
+        // trailing partial frame: peaks still update (f_ebur128.c runs the per-sample loop over it)
+        sp = std::max(sp, bpk[(size_t)nfull]); tp = std::max(tp, J.btp[(size_t)nfull]);
+        A->sp_final = sp; A->tp_final = tp;
+    }
+    if (J.want_spec) { A->hops = J.hops; A->nhops = J.nhops; A->nout = J.nout; }
 }
 
 static void spectral_add(jt_spectral *a, const jt_spectral &b)
@@ -217,17 +251,13 @@ static void assemble_analysis(const AnalysisHost &A, int64_t n, bool dualmono, j
     out->r128.target_threshold = A.r128.rel_threshold;
 }
 
-static void analyse_mono(jt_ctx *h, const float *x, int64_t n, int sr, bool dualmono, jt_analysis *out,
-                         jt_frame_meta *meta, int64_t cap_meta)
+static void analysis_complete(jt_ctx *h, const AnalysisJob &J, jt_analysis *out, jt_frame_meta *meta, int64_t cap_meta)
 {
+    (void)h;
     AnalysisHost A;
-    run_astats(h, x, n, sr, &A.astats);
-    check_cancel(h);
-    run_r128(h, x, n, sr, dualmono, true, &A);
-    check_cancel(h);
-    run_spectral(h, x, n, sr, &A, sr / 10);
+    analysis_finish(J, &A);
     out->astats = A.astats;
-    assemble_analysis(A, n, dualmono, out, meta, cap_meta);
+    assemble_analysis(A, J.n, J.dualmono, out, meta, cap_meta);
 }
 
 // ---------------------------------------------------------------- Pass 1
@@ -242,17 +272,25 @@ extern "C" int jt_pass1(jt_ctx *h, int frame_samples, jt_analysis *out, double *
     std::memset(out, 0, sizeof(*out));
     const int64_t nfr = (h->n + frame_samples - 1) / frame_samples;
     out->n_input_frames = nfr;
+    pass_begin(h, h->n, 1);
+    const double *fst = nullptr;
     if (frame_sumsq && frame_peak) {
-        h->d_scr1.ensure((size_t)nfr * 2);
-        launch_frame_stats(h->in_raw, h->n * h->channels, frame_samples * h->channels, h->d_scr1.p, h->d_scr1.p + nfr, nfr, h->stream);
-        std::vector<double> tmp((size_t)nfr * 2);
-        JT_HIP(hipMemcpyAsync(tmp.data(), h->d_scr1.p, sizeof(double) * nfr * 2, hipMemcpyDeviceToHost, h->stream));
-        JT_HIP(hipStreamSynchronize(h->stream));
-        int64_t c = std::min(nfr, cap_frames);
-        std::copy(tmp.begin(), tmp.begin() + c, frame_sumsq);
-        std::copy(tmp.begin() + nfr, tmp.begin() + nfr + c, frame_peak);
+        h->d_scr3.ensure((size_t)nfr * 2);
+        launch_frame_stats(h->in_raw, h->n * h->channels, frame_samples * h->channels, h->d_scr3.p, h->d_scr3.p + nfr, nfr, h->stream);
+        double *tmp = h->pin.take<double>((size_t)nfr * 2);
+        JT_HIP(hipMemcpyAsync(tmp, h->d_scr3.p, sizeof(double) * nfr * 2, hipMemcpyDeviceToHost, h->stream));
+        fst = tmp;
     }
-    analyse_mono(h, h->in_mono, h->n, h->sr, true, out, meta, cap_meta);
+    AnalysisJob J;
+    analysis_enqueue(h, h->in_mono, h->n, h->sr, true, h->sr / 10, &J);
+    JT_HIP(hipStreamSynchronize(h->stream));
+    check_cancel(h);
+    if (fst) {
+        const int64_t c = std::min(nfr, cap_frames);
+        std::copy(fst, fst + c, frame_sumsq);
+        std::copy(fst + nfr, fst + nfr + c, frame_peak);
+    }
+    analysis_complete(h, J, out, meta, cap_meta);
     out->n_input_frames = nfr;
     JT_HIP(hipEventRecord(h->ev1, h->stream));
     JT_HIP(hipEventSynchronize(h->ev1));
@@ -332,22 +370,24 @@ static void run_afftdn(jt_ctx *h, const float *in, float *out, int64_t n, int sr
     const size_t nb = pl.nbands, bins = pl.bins;
     const size_t ndbl = pl.W + nb + nb + nb * nb + bins + bins;
     h->af_tab.ensure(ndbl); h->af_bin2band.ensure(bins);
-    std::vector<double> tab; tab.reserve(ndbl);
-    tab.insert(tab.end(), pl.window.begin(), pl.window.end());
-    tab.insert(tab.end(), pl.alpha.begin(), pl.alpha.end());
-    tab.insert(tab.end(), pl.beta.begin(), pl.beta.end());
-    tab.insert(tab.end(), pl.spread.begin(), pl.spread.end());
-    tab.insert(tab.end(), pl.abs_var.begin(), pl.abs_var.end());
-    tab.insert(tab.end(), pl.min_abs_var.begin(), pl.min_abs_var.end());
-    JT_HIP(hipMemcpyAsync(h->af_tab.p, tab.data(), sizeof(double) * ndbl, hipMemcpyHostToDevice, h->stream));
-    JT_HIP(hipMemcpyAsync(h->af_bin2band.p, pl.bin2band.data(), sizeof(int) * bins, hipMemcpyHostToDevice, h->stream));
+    // staged in the pinned arena: the copies stay valid until the pass's single synchronisation
+    double *tab = h->pin.take<double>(ndbl); double *w = tab;
+    w = std::copy(pl.window.begin(), pl.window.end(), w);
+    w = std::copy(pl.alpha.begin(), pl.alpha.end(), w);
+    w = std::copy(pl.beta.begin(), pl.beta.end(), w);
+    w = std::copy(pl.spread.begin(), pl.spread.end(), w);
+    w = std::copy(pl.abs_var.begin(), pl.abs_var.end(), w);
+    w = std::copy(pl.min_abs_var.begin(), pl.min_abs_var.end(), w);
+    int *b2b = h->pin.take<int>(bins);
+    std::copy(pl.bin2band.begin(), pl.bin2band.end(), b2b);
+    JT_HIP(hipMemcpyAsync(h->af_tab.p, tab, sizeof(double) * ndbl, hipMemcpyHostToDevice, h->stream));
+    JT_HIP(hipMemcpyAsync(h->af_bin2band.p, b2b, sizeof(int) * bins, hipMemcpyHostToDevice, h->stream));
     AfftdnDev d;
     d.A = pl.A; d.W = pl.W; d.L = pl.L; d.bins = pl.bins; d.nbands = pl.nbands; d.max_gain = pl.max_gain;
     d.bin2band = h->af_bin2band.p;
     d.window = h->af_tab.p; d.alpha = d.window + pl.W; d.beta = d.alpha + nb; d.spread = d.beta + nb;
     d.abs_var = d.spread + nb * nb; d.min_abs_var = d.abs_var + bins; d.twiddle = h->twiddle.p;
     launch_afftdn(in, out, n, d, 0, 96, h->stream);     // chunk length chosen from the frame count; 96 warm-up frames
-    JT_HIP(hipStreamSynchronize(h->stream));   // host tables must outlive the async copies
 }
 
 static void fill_biquads(const jt_filter_params *p, int sr, BiquadF32 st[2], int *nst)
@@ -374,13 +414,10 @@ static void run_resample_s16(jt_ctx *h, const float *x, int64_t n, int in_rate, 
         *m_out = n;
         return;
     }
-    SwrPlanHost pl; jt_swr_plan(&pl, in_rate, out_rate);
-    h->bank_d.ensure(pl.bank.size());
-    JT_HIP(hipMemcpyAsync(h->bank_d.p, pl.bank.data(), sizeof(double) * pl.bank.size(), hipMemcpyHostToDevice, h->stream));
-    const int64_t m = (int64_t)(((__int128)n * pl.phase_count + pl.step - 1) / pl.step);   // ceil(n*out/in)
+    SwrDev &sw = get_swr(h, in_rate, out_rate);
+    const int64_t m = sw.out_len(n);                      // ceil(n*out/in)
     dst.ensure((size_t)m);
-    launch_resample_to_s16(x, n, h->bank_d.p, pl.phase_count, pl.filter_length, pl.center, pl.step, dst.p, m, h->stream);
-    JT_HIP(hipStreamSynchronize(h->stream));
+    launch_resample_to_s16(x, n, sw.bank_d.p, sw.pl.phase_count, sw.pl.filter_length, sw.pl.center, sw.pl.step, dst.p, m, h->stream);
     *m_out = m;
 }
 
@@ -395,6 +432,7 @@ extern "C" int jt_pass2(jt_ctx *h, const jt_filter_params *p, jt_analysis *out)
     std::memset(out, 0, sizeof(*out));
     JT_HIP(hipEventRecord(h->ev0, h->stream));
     const int64_t n = h->n; const int sr = h->sr;
+    pass_begin(h, n, 1);
     h->work_a.ensure((size_t)n); h->work_b.ensure((size_t)n);
     const float *cur = h->in_mono; float *nxt = h->work_a.p; float *oth = h->work_b.p;
     auto advance = [&]() { cur = nxt; std::swap(nxt, oth); };
@@ -416,14 +454,16 @@ extern "C" int jt_pass2(jt_ctx *h, const jt_filter_params *p, jt_analysis *out)
         launch_dynamics(cur, nxt, h->f64_a.p, h->f64_b.p, h->d_scr3.p, n, d, h->stream); advance();
     }
     check_cancel(h);
-    analyse_mono(h, cur, n, sr, true, out, nullptr, 0);
-    out->n_input_frames = 0;
-    check_cancel(h);
+    AnalysisJob J;
+    analysis_enqueue(h, cur, n, sr, true, sr / 10, &J);
     const int out_rate = p->out_rate > 0 ? p->out_rate : 44100;
     run_resample_s16(h, cur, n, sr, out_rate, h->s16_p2, &h->m_p2);
     h->out_rate = out_rate; h->m_p4 = 0;
     JT_HIP(hipEventRecord(h->ev1, h->stream));
     JT_HIP(hipEventSynchronize(h->ev1));
+    check_cancel(h);
+    analysis_complete(h, J, out, nullptr, 0);
+    out->n_input_frames = 0;
     float ms = 0; JT_HIP(hipEventElapsedTime(&ms, h->ev0, h->ev1)); h->timers.pass2_ms = ms;
     if (nlm_timed) { JT_HIP(hipEventElapsedTime(&ms, h->ev2, h->ev3)); h->timers.nlm_ms = ms; h->timers.nlm_launches = 1; }
     JT_API_END(h)
@@ -463,32 +503,29 @@ static void run_limiter(jt_ctx *h, const double *in, double *out, int64_t n, int
 }
 
 // loudnorm (dynamic-mode first pass) input statistics of a signal at `rate`, measured after swr -> 192 kHz
-static void run_loudnorm_measure(jt_ctx *h, const int16_t *s16, const double *f64, int64_t n, int rate, jt_loudnorm_stats *out)
+struct LoudnormJob { KwJob kw; int64_t nfull = 0; int blk = 0; };
+static void loudnorm_measure_enqueue(jt_ctx *h, const int16_t *s16, const double *f64, int64_t n, int rate, LoudnormJob *J)
 {
-    SwrPlanHost pl; jt_swr_plan(&pl, rate, 192000);
-    const int64_t m_total = (int64_t)(((__int128)n * pl.phase_count + pl.step - 1) / pl.step);
+    SwrDev &sw = get_swr(h, rate, 192000);
+    const int64_t m_total = sw.out_len(n);
     const int blk = (192000 + 5) / 10;
-    const int64_t nfull = m_total / blk;
-    std::vector<double> bsum, bpk;
+    J->blk = blk; J->nfull = m_total / blk;
     if (s16) {
-        std::vector<float> bf(pl.bank.size());
-        for (size_t i = 0; i < bf.size(); ++i) bf[i] = (float)pl.bank[i];
-        h->bank_f.ensure(bf.size());
-        JT_HIP(hipMemcpyAsync(h->bank_f.p, bf.data(), sizeof(float) * bf.size(), hipMemcpyHostToDevice, h->stream));
         h->stream_f.ensure((size_t)m_total);
-        launch_resample_stream_s16_f32(s16, n, h->bank_f.p, pl.phase_count, pl.filter_length, pl.center, pl.step, m_total, h->stream_f.p, h->stream);
-        JT_HIP(hipStreamSynchronize(h->stream));
-        jt_kweight_blocks_f32(h, h->stream_f.p, m_total, 192000, blk, bsum, bpk);
+        launch_resample_stream_s16_f32(s16, n, sw.bank_f.p, sw.pl.phase_count, sw.pl.filter_length, sw.pl.center, sw.pl.step, m_total, h->stream_f.p, h->stream);
+        jt_kweight_enqueue_f32(h, h->stream_f.p, m_total, 192000, blk, &J->kw);
     } else {
-        h->bank_d.ensure(pl.bank.size());
-        JT_HIP(hipMemcpyAsync(h->bank_d.p, pl.bank.data(), sizeof(double) * pl.bank.size(), hipMemcpyHostToDevice, h->stream));
         h->stream_d.ensure((size_t)m_total);
-        launch_resample_stream_f64(f64, n, h->bank_d.p, pl.phase_count, pl.filter_length, pl.center, pl.step, m_total, h->stream_d.p, h->stream);
-        JT_HIP(hipStreamSynchronize(h->stream));
-        jt_kweight_blocks_f64(h, h->stream_d.p, m_total, 192000, blk, bsum, bpk);
+        launch_resample_stream_f64(f64, n, sw.bank_d.p, sw.pl.phase_count, sw.pl.filter_length, sw.pl.center, sw.pl.step, m_total, h->stream_d.p, h->stream);
+        jt_kweight_enqueue_f64(h, h->stream_d.p, m_total, 192000, blk, &J->kw);
     }
-    double pk = 0; for (int64_t k = 0; k <= nfull; ++k) pk = std::max(pk, bpk[(size_t)k]);
-    jt_loudnorm_finish(bsum.data(), nfull, blk, true, 1.0, &out->input_i, &out->input_lra, &out->input_thresh);
+}
+static void loudnorm_measure_finish(const LoudnormJob &J, jt_loudnorm_stats *out)
+{
+    std::vector<double> bsum, bpk;
+    jt_kweight_finish(&J.kw, bsum, bpk);
+    double pk = 0; for (int64_t k = 0; k <= J.nfull; ++k) pk = std::max(pk, bpk[(size_t)k]);
+    jt_loudnorm_finish(bsum.data(), J.nfull, J.blk, true, 1.0, &out->input_i, &out->input_lra, &out->input_thresh);
     out->input_tp = 20 * std::log10(pk);
     out->output_i = out->output_tp = out->output_lra = out->output_thresh = NAN; out->target_offset = NAN;
     out->normalization_type_dynamic = 1;
@@ -496,16 +533,20 @@ static void run_loudnorm_measure(jt_ctx *h, const int16_t *s16, const double *f6
 
 static void pass3_core(jt_ctx *h, const int16_t *s16, int64_t m, int rate, const jt_limiter_plan *lim, jt_loudnorm_stats *out)
 {
+    pass_begin(h, m * 192000 / rate + 1024, 1);
+    LoudnormJob J;
     if (lim && lim->needed) {
         h->f64_a.ensure((size_t)m); h->f64_b.ensure((size_t)m);
         const bool pre = lim->pre_gain_db > 0;
         const double g = pre ? std::pow(10.0, lim->pre_gain_db / 20.0) : 1.0;
         launch_s16_to_f64(s16, h->f64_a.p, m, g, pre ? 1 : 0, h->stream);
         run_limiter(h, h->f64_a.p, h->f64_b.p, m, rate, lim->limit, 5.0, 100.0, 1.0);
-        run_loudnorm_measure(h, nullptr, h->f64_b.p, m, rate, out);
+        loudnorm_measure_enqueue(h, nullptr, h->f64_b.p, m, rate, &J);
     } else {
-        run_loudnorm_measure(h, s16, nullptr, m, rate, out);
+        loudnorm_measure_enqueue(h, s16, nullptr, m, rate, &J);
     }
+    JT_HIP(hipStreamSynchronize(h->stream));
+    loudnorm_measure_finish(J, out);
 }
 
 extern "C" int jt_pass3(jt_ctx *h, const jt_limiter_plan *lim, double target_i, double target_tp, double target_lra,
@@ -541,6 +582,7 @@ extern "C" int jt_pass4(jt_ctx *h, const jt_limiter_plan *lim, const jt_loudnorm
                         (offset_tp <= ap->target_tp) && (ap->measured_lra <= ap->target_lra);
     JT_REQUIRE(linear, JT_E_UNSUPPORTED, "pass4: loudnorm would fall back to dynamic mode (not implemented on the GPU path)");
     const double gain = std::pow(10., offset_db / 20.);
+    pass_begin(h, m, 2);
     h->f64_a.ensure((size_t)m); h->f64_b.ensure((size_t)m);
     double *sig = h->f64_a.p, *tmp = h->f64_b.p;
     const bool pre = lim && lim->needed && lim->pre_gain_db > 0;
@@ -548,18 +590,8 @@ extern "C" int jt_pass4(jt_ctx *h, const jt_limiter_plan *lim, const jt_loudnorm
     if (lim && lim->needed) { run_limiter(h, sig, tmp, m, rate, lim->limit, 5.0, 100.0, 1.0); std::swap(sig, tmp); }
     check_cancel(h);
     // loudnorm r128_in / r128_out statistics (libavfilter/ebur128.c) at the stream rate
-    if (stats) {
-        const int blk = (rate + 5) / 10; const int64_t nfull = m / blk;
-        std::vector<double> bsum, bpk;
-        jt_kweight_blocks_f64(h, sig, m, rate, blk, bsum, bpk);
-        double pk = 0; for (int64_t k = 0; k <= nfull; ++k) pk = std::max(pk, bpk[(size_t)k]);
-        jt_loudnorm_finish(bsum.data(), nfull, blk, true, 1.0, &stats->input_i, &stats->input_lra, &stats->input_thresh);
-        jt_loudnorm_finish(bsum.data(), nfull, blk, true, gain * gain, &stats->output_i, &stats->output_lra, &stats->output_thresh);
-        stats->input_tp = 20 * std::log10(pk);
-        stats->output_tp = 20 * std::log10(pk * gain);
-        stats->target_offset = ap->target_i - stats->output_i;
-        stats->normalization_type_dynamic = 0;
-    }
+    KwJob sj; const int sblk = (rate + 5) / 10;
+    if (stats) jt_kweight_enqueue_f64(h, sig, m, rate, sblk, &sj);
     // adeclick: restated as pass-through (SURVEY f4 "next" row); see DESIGN.md
     // brickwall alimiter on x*gain
     run_limiter(h, sig, tmp, m, rate, ap->brickwall_limit, 1.0, 50.0, gain);
@@ -570,9 +602,24 @@ extern "C" int jt_pass4(jt_ctx *h, const jt_limiter_plan *lim, const jt_loudnorm
     h->s16_p4.ensure((size_t)m);
     launch_f64_to_s16(sig, h->s16_p4.p, h->work_a.p, m, 1, h->stream);
     h->m_p4 = m;
-    analyse_mono(h, h->work_a.p, m, rate, true, out, nullptr, 0);
+    AnalysisJob J;
+    analysis_enqueue(h, h->work_a.p, m, rate, true, rate / 10, &J);
     JT_HIP(hipEventRecord(h->ev1, h->stream));
     JT_HIP(hipEventSynchronize(h->ev1));
+    check_cancel(h);
+    if (stats) {
+        const int64_t nfull = m / sblk;
+        std::vector<double> bsum, bpk;
+        jt_kweight_finish(&sj, bsum, bpk);
+        double pk = 0; for (int64_t k = 0; k <= nfull; ++k) pk = std::max(pk, bpk[(size_t)k]);
+        jt_loudnorm_finish(bsum.data(), nfull, sblk, true, 1.0, &stats->input_i, &stats->input_lra, &stats->input_thresh);
+        jt_loudnorm_finish(bsum.data(), nfull, sblk, true, gain * gain, &stats->output_i, &stats->output_lra, &stats->output_thresh);
+        stats->input_tp = 20 * std::log10(pk);
+        stats->output_tp = 20 * std::log10(pk * gain);
+        stats->target_offset = ap->target_i - stats->output_i;
+        stats->normalization_type_dynamic = 0;
+    }
+    analysis_complete(h, J, out, nullptr, 0);
     float ms = 0; JT_HIP(hipEventElapsedTime(&ms, h->ev0, h->ev1)); h->timers.pass4_ms = ms;
     JT_API_END(h)
 }
@@ -589,11 +636,15 @@ extern "C" int jt_region_measure(jt_ctx *h, int stage, double start_s, double du
     int64_t s0, len; trim_range(start_s, dur_s, rate, m, &s0, &len);
     std::memset(out, 0, sizeof(*out));
     JT_REQUIRE(len > 0, JT_E_INVAL, "region_measure: empty region");
-    DevBuf<float> x; x.ensure((size_t)len);
-    launch_s16_to_f32(src + s0, x.p, len, h->stream);
+    pass_begin(h, len, 1);
+    h->region_f.ensure((size_t)len);
+    launch_s16_to_f32(src + s0, h->region_f.p, len, h->stream);
     jt_analysis a; std::memset(&a, 0, sizeof(a));
     std::vector<jt_frame_meta> meta((size_t)(len / (rate / 10) + 2));
-    analyse_mono(h, x.p, len, rate, false, &a, meta.data(), (int64_t)meta.size());
+    AnalysisJob J;
+    analysis_enqueue(h, h->region_f.p, len, rate, false, rate / 10, &J);
+    JT_HIP(hipStreamSynchronize(h->stream));
+    analysis_complete(h, J, &a, meta.data(), (int64_t)meta.size());
     out->rms_level = a.astats.rms_level; out->peak_level = a.astats.peak_level; out->crest_factor = a.astats.crest_factor;
     out->spectral = a.spectral_mean;
     out->momentary = a.r128.momentary; out->shortterm = a.r128.shortterm;
@@ -673,6 +724,7 @@ extern "C" int jt_op_afftdn_f32(jt_ctx *h, const float *in, float *out, int64_t 
     JT_API_BEGIN(h)
     JT_REQUIRE(in && out && n > 0, JT_E_INVAL, "op_afftdn: bad arguments");
     DevBuf<float> a, b; h2d(h, a, in, (size_t)n); b.ensure((size_t)n);
+    pass_begin(h, 1 << 16, 1);
     run_afftdn(h, a.p, b.p, n, sr, nr, nf, bn);
     d2h(h, out, b.p, (size_t)n);
     JT_API_END(h)
@@ -721,7 +773,11 @@ extern "C" int jt_op_ebur128(jt_ctx *h, const float *in, int64_t n, int sr, int 
     JT_API_BEGIN(h)
     JT_REQUIRE(in && out && n > 0, JT_E_INVAL, "op_ebur128: bad arguments");
     DevBuf<float> a; h2d(h, a, in, (size_t)n);
-    AnalysisHost A; run_r128(h, a.p, n, sr, dualmono != 0, true, &A);
+    pass_begin(h, n, 1);
+    AnalysisJob J; J.want_astats = false; J.want_spec = false;
+    analysis_enqueue(h, a.p, n, sr, dualmono != 0, 0, &J);
+    JT_HIP(hipStreamSynchronize(h->stream));
+    AnalysisHost A; analysis_finish(J, &A);
     out->integrated = A.r128.integrated; out->lra = A.r128.lra; out->lra_low = A.r128.lra_low; out->lra_high = A.r128.lra_high;
     out->momentary = A.nblocks ? A.r128.M[A.nblocks - 1] : NAN; out->shortterm = A.nblocks ? A.r128.S[A.nblocks - 1] : NAN;
     out->true_peak = A.tp_final; out->sample_peak = A.sp_final; out->target_threshold = A.r128.rel_threshold;
@@ -740,7 +796,10 @@ extern "C" int jt_op_astats(jt_ctx *h, const float *in, int64_t n, int sr, jt_as
     JT_API_BEGIN(h)
     JT_REQUIRE(in && out && n > 0, JT_E_INVAL, "op_astats: bad arguments");
     DevBuf<float> a; h2d(h, a, in, (size_t)n);
-    run_astats(h, a.p, n, sr, out);
+    pass_begin(h, n, 1);
+    AstatsJob J; jt_astats_enqueue(h, a.p, n, sr, &J);
+    JT_HIP(hipStreamSynchronize(h->stream));
+    jt_astats_finish(&J, out);
     JT_API_END(h)
 }
 
@@ -749,7 +808,11 @@ extern "C" int jt_op_aspectralstats(jt_ctx *h, const float *in, int64_t n, int s
     JT_API_BEGIN(h)
     JT_REQUIRE(in && hops && n > 0, JT_E_INVAL, "op_aspectralstats: bad arguments");
     DevBuf<float> a; h2d(h, a, in, (size_t)n);
-    AnalysisHost A; run_spectral(h, a.p, n, sr, &A, 0);
+    pass_begin(h, n, 1);
+    AnalysisJob J; J.want_astats = false; J.want_r128 = false;
+    analysis_enqueue(h, a.p, n, sr, false, 0, &J);
+    JT_HIP(hipStreamSynchronize(h->stream));
+    AnalysisHost A; analysis_finish(J, &A);
     for (int64_t k = 0; k < std::min(cap, A.nhops); ++k) hops[k] = A.hops[(size_t)k];
     if (n_hops) *n_hops = A.nhops;
     JT_API_END(h)

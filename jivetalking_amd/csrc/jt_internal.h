@@ -61,11 +61,6 @@ void launch_downmix(const float *in, float *out, int64_t frames, int channels, h
 void launch_s16_to_f32(const int16_t *in, float *out, int64_t n, hipStream_t s);
 void launch_s16_to_f64(const int16_t *in, double *out, int64_t n, double gain, int gain_in_float, hipStream_t s);
 void launch_biquad_f32(const float *in, float *out, int64_t n, int nstages, const BiquadF32 *st, hipStream_t s);
-// K-weighting + per-100ms-block energy / sample peak (zero-state + truncated-carry linear scan); host results, nfull+1 entries
-struct jt_ctx;
-void jt_kweight_blocks_f32(jt_ctx *h, const float *in, int64_t n, int rate, int blk, std::vector<double> &sums, std::vector<double> &peaks);
-void jt_kweight_blocks_f64(jt_ctx *h, const double *in, int64_t n, int rate, int blk, std::vector<double> &sums, std::vector<double> &peaks);
-
 struct DynParams {
     int gate_on, comp_on, deess_on;
     // gate
@@ -80,7 +75,6 @@ void launch_dynamics(const float *in, float *out_f32, double *tmp64, double *tmp
 
 // astats (k_astats.hip)
 struct jt_ctx;
-void jt_astats_device(jt_ctx *h, const float *x, int64_t n, int sr, jt_astats *out);
 void launch_biquad_di_f32(const float *in, float *out, int64_t n, BiquadF32 hp, BiquadF32 lp, hipStream_t s);
 void launch_band_rms(const float *in, int64_t n, int nbands, const BiquadF32 *hp, const BiquadF32 *lp, double *sums, hipStream_t s);
 
@@ -123,6 +117,52 @@ void launch_afftdn(const float *in, float *out, int64_t n, const AfftdnDev &d, i
 // anlmdn
 void launch_anlmdn(const float *in, float *out, int64_t n, int K, int S, float sw, float smooth, float lut_scale, hipStream_t s);
 
+// ---------------------------------------------------------------- pinned host staging
+// Every device->host result of a pass lands in one pinned arena, so a pass enqueues all its kernels and copies back to back
+// and synchronises ONCE (pageable destinations would serialise each copy through a bounce buffer).
+struct HostArena {
+    unsigned char *p = nullptr; size_t cap = 0, off = 0;
+    HostArena() {}
+    HostArena(const HostArena &) = delete; HostArena &operator=(const HostArena &) = delete;
+    ~HostArena() { if (p) (void)hipHostFree(p); }
+    // caller guarantees nothing is in flight (start of a pass)
+    void begin(size_t bytes) {
+        off = 0;
+        if (bytes <= cap) return;
+        if (p) { (void)hipHostFree(p); p = nullptr; cap = 0; }
+        size_t want = bytes + bytes / 2 + (1u << 20);
+        JT_HIP(hipHostMalloc((void **)&p, want, hipHostMallocDefault));
+        cap = want;
+    }
+    template <typename T> T *take(size_t count) {
+        off = (off + 63) & ~(size_t)63;
+        if (off + sizeof(T) * count > cap) throw JtError{JT_E_HIP, "pinned host arena exhausted"};
+        T *r = reinterpret_cast<T *>(p + off); off += sizeof(T) * count; return r;
+    }
+};
+
+// cached resampler plans (the kaiser bank depends on the rate pair only) with their device copies
+struct SwrDev {
+    int in_rate = 0, out_rate = 0; SwrPlanHost pl; DevBuf<double> bank_d; DevBuf<float> bank_f;
+    int64_t out_len(int64_t n) const { return (int64_t)(((__int128)n * pl.phase_count + pl.step - 1) / pl.step); }
+};
+
+// deferred results ("jobs"): enqueue = kernels + async copies into the arena; finish = host arithmetic after the pass's sync
+struct jt_ctx;
+struct AstatsJob {
+    const unsigned char *hb = nullptr; const unsigned long long *eh = nullptr;
+    size_t o_part = 0, o_runs = 0, o_nf = 0, o_smin = 0, o_smax = 0;
+    int nparts = 0, nf_parts = 0, nsig = 0; bool have_nf = false; int64_t n = 0;
+};
+void jt_astats_enqueue(jt_ctx *h, const float *x, int64_t n, int sr, AstatsJob *job);
+void jt_astats_finish(const AstatsJob *job, jt_astats *out);
+struct KwJob { const double *hc = nullptr; int64_t nchunks = 0, nfull = 0; int m = 1; };
+void jt_kweight_enqueue_f32(jt_ctx *h, const float *in, int64_t n, int rate, int blk, KwJob *job);
+void jt_kweight_enqueue_f64(jt_ctx *h, const double *in, int64_t n, int rate, int blk, KwJob *job);
+// sums/peaks: nfull+1 entries (last = trailing partial block)
+void jt_kweight_finish(const KwJob *job, std::vector<double> &sums, std::vector<double> &peaks);
+size_t jt_arena_bytes_for(int64_t n);          // generous bound on the arena bytes one analysis of n samples stages
+
 // ---------------------------------------------------------------- context
 struct jt_ctx {
     int device = 0;
@@ -149,6 +189,16 @@ struct jt_ctx {
     DevBuf<double> bank_d; DevBuf<float> bank_f;
     DevBuf<int64_t> lim_bounds, lim_pos; DevBuf<double> lim_delta;
     DevBuf<int> af_bin2band; DevBuf<double> af_tab;
+    HostArena pin;
+    // per-pass bump allocator over d_scr0 for the K-weighting jobs (several can be in flight before the pass's sync)
+    size_t kw_off = 0;
+    void kw_begin(size_t doubles) { d_scr0.ensure(doubles); kw_off = 0; }
+    double *kw_take(size_t doubles) {
+        if (kw_off + doubles > d_scr0.n) throw JtError{JT_E_HIP, "K-weighting scratch exhausted"};
+        double *r = d_scr0.p + kw_off; kw_off += (doubles + 7) & ~(size_t)7; return r;
+    }
+    SwrDev swr[4]; int swr_next = 0;
+    DevBuf<float> region_f;
     jt_timers timers{};
     hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr, ev3 = nullptr;
 };

@@ -256,27 +256,56 @@ k_as_zs(const float *__restrict__ x, int64_t n, double mult, double *__restrict_
     if (lane < nrows) zs[c0 + lane] = z;
 }
 
-// carry scan s_{c+1} = A_c * s_c + B_c (A_c = mult^len_c, B_c = zero-state response) as a wave-level affine prefix scan
-__global__ void k_as_scan(const double *__restrict__ zs, double *__restrict__ carry, int64_t nchunks, double mult_chunk, int64_t n, double mult)
+// carry scan s_{c+1} = A_c * s_c + B_c (A_c = mult^len_c, B_c = zero-state response of chunk c): 16 waves each own a
+// contiguous range of chunks; pass 1 composes the range's affine map (wave-level scan per 64 chunks, coalesced loads),
+// the 16 maps are chained through LDS, pass 2 replays the range writing the state ENTERING every chunk.
+constexpr int SCAN_T = 1024;
+__global__ void __launch_bounds__(SCAN_T)
+k_as_scan(const double *__restrict__ zs, double *__restrict__ carry, int64_t nchunks, double mult_chunk, int64_t n, double mult)
 {
-    const int lane = threadIdx.x;
-    double carry_in = 0.0;
-    for (int64_t base = 0; base < nchunks; base += 64) {
-        const int64_t c = base + lane;
-        double A = 1.0, B = 0.0;
-        if (c < nchunks) {
-            int64_t len = min((int64_t)ZC, n - c * ZC);
+    __shared__ double sA[SCAN_T / 64], sB[SCAN_T / 64], sIn[SCAN_T / 64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t per = (((nchunks + SCAN_T / 64 - 1) / (SCAN_T / 64)) + 63) / 64 * 64;     // chunks per wave, multiple of 64
+    const int64_t lo = (int64_t)wave * per, hi = min(lo + per, nchunks);
+    auto load = [&](int64_t c, double &A, double &B) {
+        A = 1.0; B = 0.0;
+        if (c < hi) {
+            const int64_t len = min((int64_t)ZC, n - c * ZC);
             A = (len == ZC) ? mult_chunk : pow(mult, (double)len);
             B = zs[c];
         }
+    };
+    // pass 1: composite map of the wave's range
+    double RA = 1.0, RB = 0.0;
+    for (int64_t base = lo; base < hi; base += 64) {
+        double A, B; load(base + lane, A, B);
         for (int o = 1; o < 64; o <<= 1) {
-            double Ap = __shfl_up(A, o, 64), Bp = __shfl_up(B, o, 64);
+            const double Ap = __shfl_up(A, o, 64), Bp = __shfl_up(B, o, 64);
             if (lane >= o) { B = A * Bp + B; A = A * Ap; }
         }
-        double s_after = A * carry_in + B;
+        const double TA = __shfl(A, 63, 64), TB = __shfl(B, 63, 64);     // map of these 64 chunks
+        RB = TA * RB + TB; RA = TA * RA;
+    }
+    if (lane == 0) { sA[wave] = RA; sB[wave] = RB; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double st = 0.0;
+        for (int w = 0; w < SCAN_T / 64; ++w) { sIn[w] = st; st = sA[w] * st + sB[w]; }
+    }
+    __syncthreads();
+    // pass 2: replay with the entering state
+    double carry_in = sIn[wave];
+    for (int64_t base = lo; base < hi; base += 64) {
+        const int64_t c = base + lane;
+        double A, B; load(c, A, B);
+        for (int o = 1; o < 64; o <<= 1) {
+            const double Ap = __shfl_up(A, o, 64), Bp = __shfl_up(B, o, 64);
+            if (lane >= o) { B = A * Bp + B; A = A * Ap; }
+        }
+        const double s_after = A * carry_in + B;
         double prev = __shfl_up(s_after, 1, 64);
         if (lane == 0) prev = carry_in;
-        if (c < nchunks) carry[c] = prev;
+        if (c < hi) carry[c] = prev;
         carry_in = __shfl(s_after, 63, 64);
     }
 }
@@ -318,8 +347,15 @@ k_as_sigma(const float *__restrict__ x, int64_t n, int tc, double mult, const do
     if (lane == 0) { out_min[blockIdx.x] = mn; out_max[blockIdx.x] = mx; }
 }
 
-// ------------------------------------------------------------------ host driver
-void jt_astats_device(jt_ctx *h, const float *x, int64_t n, int sr, jt_astats *out)
+// ------------------------------------------------------------------ host driver (enqueue / finish)
+size_t jt_arena_bytes_for(int64_t n)
+{
+    // astats partials + entropy histogram + K-weighting chunk sums (chunks are > 1000 samples, 16 B each) + per-100ms records
+    return (size_t)(2048 * (sizeof(AsPartial) + sizeof(AsRuns) + sizeof(AsNF)) + 8192 * 8 + (size_t)(n / ZC + 64) * 16 / 32
+                    + (size_t)(n / 512 + 64) * 16 + (size_t)(n / 800 + 64) * (sizeof(jt_spectral) + 64) + (1u << 20));
+}
+
+void jt_astats_enqueue(jt_ctx *h, const float *x, int64_t n, int sr, AstatsJob *job)
 {
     const double time_constant = 0.05;
     const double mult = std::exp((-1 / time_constant / sr));
@@ -328,10 +364,11 @@ void jt_astats_device(jt_ctx *h, const float *x, int64_t n, int sr, jt_astats *o
     const int nparts = (int)std::min<int64_t>((n + AS_T - 1) / AS_T, 2048);
     const int64_t nchunks = (n + ZC - 1) / ZC;
     const int nsig = (int)((nchunks + 63) / 64);
-    // scratch layout (bytes): partials | runs | nf | mm[2] | zs[nchunks] | carry[nchunks] | smin[nsig] | smax[nsig]
+    // scratch layout (bytes): [head: partials | runs | nf | mm[2] | smin[nsig] | smax[nsig]] | zs[nchunks] | carry[nchunks]
     const size_t o_part = 0, o_runs = o_part + sizeof(AsPartial) * nparts, o_nf = o_runs + sizeof(AsRuns) * nparts,
-                 o_mm = o_nf + sizeof(AsNF) * nparts, o_zs = o_mm + 16, o_carry = o_zs + 8 * (size_t)nchunks,
-                 o_smin = o_carry + 8 * (size_t)nchunks, o_smax = o_smin + 8 * (size_t)nsig, total = o_smax + 8 * (size_t)nsig;
+                 o_mm = o_nf + sizeof(AsNF) * nparts, o_smin = o_mm + 16, o_smax = o_smin + 8 * (size_t)nsig,
+                 head = o_smax + 8 * (size_t)nsig, o_zs = head, o_carry = o_zs + 8 * (size_t)nchunks,
+                 total = o_carry + 8 * (size_t)nchunks;
     h->d_scr2.ensure((total + 7) / 8);
     unsigned char *base = reinterpret_cast<unsigned char *>(h->d_scr2.p);
     AsPartial *d_part = reinterpret_cast<AsPartial *>(base + o_part);
@@ -362,17 +399,24 @@ void jt_astats_device(jt_ctx *h, const float *x, int64_t n, int sr, jt_astats *o
         }
     }
     hipLaunchKernelGGL(k_as_zs, dim3((unsigned)nsig), dim3(64), 0, s, x, n, mult, d_zs, nchunks);
-    hipLaunchKernelGGL(k_as_scan, dim3(1), dim3(64), 0, s, d_zs, d_carry, nchunks, std::pow(mult, (double)ZC), n, mult);
+    hipLaunchKernelGGL(k_as_scan, dim3(1), dim3(SCAN_T), 0, s, d_zs, d_carry, nchunks, std::pow(mult, (double)ZC), n, mult);
     hipLaunchKernelGGL(k_as_sigma, dim3((unsigned)nsig), dim3(64), 0, s, x, n, tc, mult, d_carry, d_smin, d_smax, nchunks);
-    std::vector<unsigned char> hb(total);
-    std::vector<unsigned long long> eh(8192);
-    JT_HIP(hipMemcpyAsync(hb.data(), base, total, hipMemcpyDeviceToHost, s));
-    JT_HIP(hipMemcpyAsync(eh.data(), h->ehist.p, sizeof(unsigned long long) * 8192, hipMemcpyDeviceToHost, s));
-    JT_HIP(hipStreamSynchronize(s));
-    const AsPartial *pp = reinterpret_cast<const AsPartial *>(hb.data() + o_part);
-    const AsRuns *pr = reinterpret_cast<const AsRuns *>(hb.data() + o_runs);
-    const AsNF *pn = reinterpret_cast<const AsNF *>(hb.data() + o_nf);
-    const double *smin = reinterpret_cast<const double *>(hb.data() + o_smin), *smax = reinterpret_cast<const double *>(hb.data() + o_smax);
+    unsigned char *hb = h->pin.take<unsigned char>(head);
+    unsigned long long *eh = h->pin.take<unsigned long long>(8192);
+    JT_HIP(hipMemcpyAsync(hb, base, head, hipMemcpyDeviceToHost, s));
+    JT_HIP(hipMemcpyAsync(eh, h->ehist.p, sizeof(unsigned long long) * 8192, hipMemcpyDeviceToHost, s));
+    job->hb = hb; job->eh = eh; job->o_part = o_part; job->o_runs = o_runs; job->o_nf = o_nf; job->o_smin = o_smin; job->o_smax = o_smax;
+    job->nparts = nparts; job->nf_parts = nf_parts; job->nsig = nsig; job->have_nf = have_nf; job->n = n;
+}
+
+void jt_astats_finish(const AstatsJob *job, jt_astats *out)
+{
+    const int nparts = job->nparts, nf_parts = job->nf_parts, nsig = job->nsig; const bool have_nf = job->have_nf;
+    const unsigned long long *eh = job->eh;
+    const AsPartial *pp = reinterpret_cast<const AsPartial *>(job->hb + job->o_part);
+    const AsRuns *pr = reinterpret_cast<const AsRuns *>(job->hb + job->o_runs);
+    const AsNF *pn = reinterpret_cast<const AsNF *>(job->hb + job->o_nf);
+    const double *smin = reinterpret_cast<const double *>(job->hb + job->o_smin), *smax = reinterpret_cast<const double *>(job->hb + job->o_smax);
     AsPartial a = pp[0];
     for (int i = 1; i < nparts; ++i) {
         const AsPartial &b = pp[i];

@@ -364,10 +364,10 @@ static void mat4_mul(const double *A, const double *B, double *C)
     std::memcpy(C, t, sizeof(t));
 }
 
-// Per-100ms-block K-weighted energies and sample peaks of a device signal; results on the host:
-// sums/peaks have nfull+1 entries (the last one is the trailing partial block, zero if none).
+// Per-100ms-block K-weighted energies and sample peaks of a device signal.  enqueue: both kernels + the async copy of the
+// per-chunk partials into the pinned arena; finish (after the pass's sync): per-block sums in chunk order.
 template <typename TIn>
-static void kweight_blocks_run(jt_ctx *h, const TIn *in, int64_t n, int rate, int blk, std::vector<double> &sums, std::vector<double> &peaks)
+static void kweight_enqueue(jt_ctx *h, const TIn *in, int64_t n, int rate, int blk, KwJob *job)
 {
     BiquadF64 pre, rlb; jt_kweight_design(rate, &pre, &rlb);
     KwCoef k{pre.b0, pre.b1, pre.b2, pre.a1, pre.a2, rlb.b0, rlb.b1, rlb.b2, rlb.a1, rlb.a2};
@@ -382,39 +382,41 @@ static void kweight_blocks_run(jt_ctx *h, const TIn *in, int64_t n, int rate, in
     double FL[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1}, Bq[16];
     std::memcpy(Bq, F, sizeof(F));
     for (int64_t e = L; e > 0; e >>= 1) { if (e & 1) mat4_mul(FL, Bq, FL); mat4_mul(Bq, Bq, Bq); }
-    std::vector<double> pw; double cur[16]; std::memcpy(cur, FL, sizeof(cur));
-    int nterms = 1;
+    double *pw = h->pin.take<double>(24 * 16);            // pinned: the H2D source must stay valid until the pass's sync
+    double cur[16]; std::memcpy(cur, FL, sizeof(cur));
+    int nterms = 1, npw = 0;
     for (int q = 0; q < 24; ++q) {
         double mx = 0; for (double v : cur) mx = std::max(mx, std::fabs(v));
         if (mx < 1e-19) break;
-        pw.insert(pw.end(), cur, cur + 16); nterms++;
+        std::memcpy(pw + 16 * npw, cur, sizeof(cur)); npw++; nterms++;
         mat4_mul(cur, FL, cur);
     }
-    const size_t o_zs = 0, o_pw = o_zs + 4 * (size_t)nchunks, o_cs = o_pw + std::max<size_t>(pw.size(), 16), o_cp = o_cs + (size_t)nchunks,
-                 total = o_cp + (size_t)nchunks;
-    h->d_scr0.ensure(total);
-    double *base = h->d_scr0.p;
-    if (!pw.empty()) JT_HIP(hipMemcpyAsync(base + o_pw, pw.data(), sizeof(double) * pw.size(), hipMemcpyHostToDevice, h->stream));
+    // device scratch: zs | pw | csum | cpeak.  Each job gets its own region of d_scr0 (several may be in flight in one pass).
+    const size_t need = 4 * (size_t)nchunks + 24 * 16 + 2 * (size_t)nchunks;
+    double *base = h->kw_take(need);
+    double *d_zs = base, *d_pw = base + 4 * (size_t)nchunks, *d_cs = d_pw + 24 * 16;
+    if (npw) JT_HIP(hipMemcpyAsync(d_pw, pw, sizeof(double) * 16 * npw, hipMemcpyHostToDevice, h->stream));
     const unsigned grid = (unsigned)((nchunks + LANES - 1) / LANES);
     hipLaunchKernelGGL((k_kw<TIn, false>), dim3(grid), dim3(LANES), 0, h->stream, in, n, L, k, (const double *)nullptr, (const double *)nullptr, 0,
-                       base + o_zs, (double *)nullptr, (double *)nullptr, nchunks);
-    hipLaunchKernelGGL((k_kw<TIn, true>), dim3(grid), dim3(LANES), 0, h->stream, in, n, L, k, base + o_zs, base + o_pw, nterms,
-                       (double *)nullptr, base + o_cs, base + o_cp, nchunks);
-    std::vector<double> hc((size_t)nchunks * 2);
-    JT_HIP(hipMemcpyAsync(hc.data(), base + o_cs, sizeof(double) * nchunks * 2, hipMemcpyDeviceToHost, h->stream));
-    JT_HIP(hipStreamSynchronize(h->stream));     // also keeps `pw` alive until its async copy has completed
-    const int64_t nfull = n / blk;
+                       d_zs, (double *)nullptr, (double *)nullptr, nchunks);
+    hipLaunchKernelGGL((k_kw<TIn, true>), dim3(grid), dim3(LANES), 0, h->stream, in, n, L, k, d_zs, d_pw, nterms,
+                       (double *)nullptr, d_cs, d_cs + nchunks, nchunks);
+    double *hc = h->pin.take<double>((size_t)nchunks * 2);
+    JT_HIP(hipMemcpyAsync(hc, d_cs, sizeof(double) * nchunks * 2, hipMemcpyDeviceToHost, h->stream));
+    job->hc = hc; job->nchunks = nchunks; job->nfull = n / blk; job->m = m;
+}
+void jt_kweight_enqueue_f32(jt_ctx *h, const float *in, int64_t n, int rate, int blk, KwJob *job) { kweight_enqueue<float>(h, in, n, rate, blk, job); }
+void jt_kweight_enqueue_f64(jt_ctx *h, const double *in, int64_t n, int rate, int blk, KwJob *job) { kweight_enqueue<double>(h, in, n, rate, blk, job); }
+void jt_kweight_finish(const KwJob *job, std::vector<double> &sums, std::vector<double> &peaks)
+{
+    const int64_t nfull = job->nfull, nchunks = job->nchunks;
     sums.assign((size_t)nfull + 1, 0.0); peaks.assign((size_t)nfull + 1, 0.0);
     for (int64_t c = 0; c < nchunks; ++c) {
-        const int64_t b = std::min<int64_t>(c / m, nfull);
-        sums[(size_t)b] += hc[(size_t)c];
-        peaks[(size_t)b] = std::max(peaks[(size_t)b], hc[(size_t)(nchunks + c)]);
+        const int64_t b = std::min<int64_t>(c / job->m, nfull);
+        sums[(size_t)b] += job->hc[(size_t)c];
+        peaks[(size_t)b] = std::max(peaks[(size_t)b], job->hc[(size_t)(nchunks + c)]);
     }
 }
-void jt_kweight_blocks_f32(jt_ctx *h, const float *in, int64_t n, int rate, int blk, std::vector<double> &sums, std::vector<double> &peaks)
-{ kweight_blocks_run<float>(h, in, n, rate, blk, sums, peaks); }
-void jt_kweight_blocks_f64(jt_ctx *h, const double *in, int64_t n, int rate, int blk, std::vector<double> &sums, std::vector<double> &peaks)
-{ kweight_blocks_run<double>(h, in, n, rate, blk, sums, peaks); }
 
 // ------------------------------------------------------------------ agate -> acompressor -> deesser (double)
 __device__ inline double hermite_interp(double x, double x0, double x1, double p0, double p1, double m0, double m1)

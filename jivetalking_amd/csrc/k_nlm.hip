@@ -6,14 +6,17 @@
 // seeded exactly at the hop start and then updated with two squared differences per step (a recurrence ALONG TIME for a
 // fixed offset); per output, weights exp(-d*sw) (via a 2^20-entry LUT) are accumulated across the offsets.
 //
-// k_anlmdn_wave (fast path, 2S = 64*NOFF and S % NOFF == 0: 48 kHz -> NOFF 3, 96 kHz -> NOFF 6):
-//   ONE WAVE PER HOP, no barriers.  Lane l owns NOFF ADJACENT offsets, so the three sample streams each offset consumes
-//   (f[j+K], f[j-K-1], f[j]) overlap between its offsets and between consecutive steps: per step a lane reads one new value
-//   per stream (register rotation) + 2 broadcast values, instead of 4 LDS reads per offset.  The patch-distance recurrence
-//   keeps FFmpeg's exact f32 operation order (no FMA contraction).  The per-output sums over the 2S offsets are a lane-local
-//   sum of NOFF terms followed by a DPP row/bank reduction over the 64 lanes (deterministic, but not FFmpeg's sequential
-//   order: results agree to f32 round-off of the weighted mean).  LDS per wave: the hop's input window (5.4 KB @48 kHz) + H
-//   outputs, so occupancy is bounded by registers only.  HBM traffic: 1 read (+ (2K+2S)/H halo) and 1 write per sample.
+// k_anlmdn_pair (fast path, 2S = 192 and K % 4 == 0: the 48 kHz defaults):
+//   ONE WAVE PER PAIR OF HOPS, no barriers.  Lane l owns 3 ADJACENT offsets, so the sample streams each offset consumes
+//   (f[j+K], f[j-K-1]) overlap between its offsets and between consecutive steps: per step a lane reads one new value per
+//   stream into a 4-slot register ring.  The two hops of the pair ride in the two halves of packed-f32 registers
+//   (v_pk_add_f32 / v_pk_mul_f32).  The patch-distance recurrence keeps FFmpeg's exact f32 operation order (no FMA
+//   contraction), so the engagement decisions (`w >= smooth`) are the reference's; when no lane of the wave has a distance
+//   under the cut the weight stage is skipped and the output is the input sample (what FFmpeg computes: (0 + x) / (0 + 1)).
+//   When engaged, the per-output sums over the 2S offsets are a lane-local sum of 3 terms followed by a DPP row/bank
+//   reduction over the 64 lanes (deterministic, but not FFmpeg's sequential order: results agree to f32 round-off of the
+//   weighted mean).  LDS per wave: the pair's input window (7.8 KB @48 kHz).  HBM traffic: 1 read (+ halo) and 1 write per
+//   sample.
 // k_anlmdn (generic path, any K/S): one workgroup per hop, one thread per offset, weights transposed through an LDS tile and
 //   summed in FFmpeg's sequential offset order.
 #include "jt_internal.h"
@@ -32,88 +35,6 @@ __device__ inline float wave_sum63(float v)
     return v;
 }
 
-template <int NOFF>
-__global__ void __launch_bounds__(64)
-k_anlmdn_wave(const float *__restrict__ in, float *__restrict__ out, int64_t n, int K, int S, float sw, float smooth,
-              float lut_scale, int64_t nhops)
-{
-    extern __shared__ float smem_nlm[];
-    const int H = 2 * K + 1;
-    const int NW = H + 2 * (K + S);
-    float *win = smem_nlm;                         // [NW]
-    float *obuf = smem_nlm + ((NW + 3) & ~3);      // [H]
-    const int lane = threadIdx.x;
-    const int64_t hop = (int64_t)blockIdx.x;
-    const int64_t hs = hop * H - (K + S);
-    for (int w = lane; w < NW; w += 64) {
-        int64_t k = hs - (K + S) + w;
-        win[w] = (k >= 0 && k < n) ? in[k] : 0.f;
-    }
-    __syncthreads();
-    const float *f = win + K;                      // f[i], i in [-K, NW-K)
-    // lane-owned adjacent offsets j0 .. j0+NOFF-1, all on the same side of the centre (S % NOFF == 0)
-    const int j0 = lane * NOFF;
-    const int d0 = j0 - S + (j0 >= S ? 1 : 0);     // neighbour offset of the first owned offset
-    float cache[NOFF];
-    // seed: compute_distance_ssd(f + S, f + S + dj, K), k ascending, f32 mul then add (as the C code)
-    {
-        const int i = S;
-#pragma unroll
-        for (int q = 0; q < NOFF; ++q) cache[q] = 0.f;
-        for (int k = -K; k <= K; ++k) {
-            const float c = f[i + k];
-#pragma unroll
-            for (int q = 0; q < NOFF; ++q) {
-                float dd = __fsub_rn(c, f[i + d0 + q + k]);
-                cache[q] = __fadd_rn(cache[q], __fmul_rn(dd, dd));
-            }
-        }
-    }
-    // stream registers: hi[q] = f[i + d0 + q + K], lo[q] = f[i + d0 + q - K - 1], ce[q] = f[i + d0 + q] for the CURRENT i
-    float hi[NOFF], lo[NOFF], ce[NOFF];
-#pragma unroll
-    for (int q = 0; q < NOFF; ++q) {
-        hi[q] = f[S + d0 + q + K]; ce[q] = f[S + d0 + q];
-        const int li = S + d0 + q - K - 1;              // first used at i = S+1 (never below f[-K])
-        lo[q] = li >= -K ? f[li] : 0.f;
-    }
-    for (int i = S; i < H + S; ++i) {
-        const float cm = f[i - K - 1], cp = f[i + K], cc = f[i];   // wave-uniform (broadcast) reads
-        float P = 0.f, Q = 0.f;
-#pragma unroll
-        for (int q = 0; q < NOFF; ++q) {
-            if (i != S) {
-                // compute_cache(): cache += -(f[i-K-1]-f[j-K-1])^2 + (f[i+K]-f[j+K])^2
-                const float a = __fsub_rn(cm, lo[q]);
-                const float b = __fsub_rn(cp, hi[q]);
-                cache[q] = __fadd_rn(cache[q], __fadd_rn(-__fmul_rn(a, a), __fmul_rn(b, b)));
-            }
-            float distance = cache[q];
-            if (distance < 0.f) cache[q] = distance = 0.f;
-            const float w = __fmul_rn(distance, sw);
-            if (!(w >= smooth)) {
-                const unsigned idx = (unsigned)__fmul_rn(w, lut_scale);
-                const float wt = __expf(-(float)idx / lut_scale);         // weight_lut[idx] = expf(-idx/scale)
-                P = __fadd_rn(P, __fmul_rn(wt, ce[q]));
-                Q = __fadd_rn(Q, wt);
-            }
-        }
-        P = wave_sum63(P);
-        Q = wave_sum63(Q);
-        if (lane == 63) obuf[i - S] = __fadd_rn(P, cc) / __fadd_rn(Q, 1.f);
-        // advance the three streams by one sample: NOFF-1 values shift, one new value per stream is read
-#pragma unroll
-        for (int q = 0; q + 1 < NOFF; ++q) { hi[q] = hi[q + 1]; lo[q] = lo[q + 1]; ce[q] = ce[q + 1]; }
-        const int nx = i + 1 + d0 + (NOFF - 1);
-        hi[NOFF - 1] = f[nx + K]; lo[NOFF - 1] = f[nx - K - 1]; ce[NOFF - 1] = f[nx];
-    }
-    __syncthreads();
-    for (int t = lane; t < H; t += 64) {
-        int64_t o = hs + t;
-        if (o >= 0 && o < n) out[o] = obuf[t];
-    }
-}
-
 // ------------------------------------------------------------------ wave-per-hop-PAIR fast path (packed f32)
 // Same mapping as k_anlmdn_wave, but a wave carries TWO consecutive hops in the two halves of packed-f32 registers
 // (v_pk_add_f32 / v_pk_mul_f32: CDNA's full FP32 rate needs packed issue), and the weight stage is skipped for an output
@@ -123,7 +44,8 @@ k_anlmdn_wave(const float *__restrict__ in, float *__restrict__ out, int64_t n, 
 typedef float f2 __attribute__((ext_vector_type(2)));
 
 typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
-constexpr int NLM_PADF = 4, NLM_PADB = 24;      // zero/real-sample padding of the LDS window: no index clamps in the loops
+constexpr int NLM_PADF = 4, NLM_PADB = 24;
+constexpr bool NLM_SMEM_CENTRE = false;          // centre samples by scalar loads (true) or LDS broadcast reads (false)      // zero/real-sample padding of the LDS window: no index clamps in the loops
 
 // Four consecutive uniform ("centre") samples of both hops starting at tile-relative position x: one scalar x4 load per hop
 // from global memory in the interior (wave-uniform address), LDS broadcast reads at the file edges (zero-padded window).
@@ -163,17 +85,15 @@ __device__ inline void nlm_step(f2 (&cache)[NOFF], f2 (&hi)[NOFF + 1], f2 (&lo)[
     lo[V % R] = f2{pA[V - K - 1], pB[V - K - 1]};
     float dmin = 3.0e38f;
 #pragma unroll
-    for (int q = 0; q < NOFF; ++q) {
-        // if (distance < 0) cache = distance = 0
-        cache[q].x = __builtin_amdgcn_fmed3f(cache[q].x, 0.f, 3.0e38f);
-        cache[q].y = __builtin_amdgcn_fmed3f(cache[q].y, 0.f, 3.0e38f);
-        dmin = fminf(dmin, fminf(cache[q].x, cache[q].y));
-    }
+    for (int q = 0; q < NOFF; ++q) dmin = fminf(dmin, fminf(cache[q].x, cache[q].y));
     if (__any(dmin < dthr)) {
-        // some offset may contribute: exact per-offset test, weights, lane-local sums, wave reductions (per hop)
+        // some offset may contribute (or a distance went negative by round-off, which is also < dthr): FFmpeg's clamp
+        // `if (distance < 0) cache = distance = 0`, the exact per-offset test, weights, lane-local sums, wave reductions
         float Px = 0.f, Qx = 0.f, Py = 0.f, Qy = 0.f;
 #pragma unroll
         for (int q = 0; q < NOFF; ++q) {
+            cache[q].x = __builtin_amdgcn_fmed3f(cache[q].x, 0.f, 3.0e38f);
+            cache[q].y = __builtin_amdgcn_fmed3f(cache[q].y, 0.f, 3.0e38f);
             const int xc = i + d0 + q;
             const float wx = __fmul_rn(cache[q].x, sw), wy = __fmul_rn(cache[q].y, sw);
             if (!(wx >= smooth)) {
@@ -304,7 +224,7 @@ k_anlmdn_pair(const float *__restrict__ in, float *__restrict__ out, int64_t n, 
     __threadfence();
     const float nisl = -1.4426950408889634f / lut_scale;
     const bool interior = gwin - NLM_PADF >= 0 && gwin + NW2 + NLM_PADB <= n;
-    if (interior) nlm_pair_body<NOFF, true>(in, out, n, hs, gwin, fA, fB, K, S, H, sw, smooth, lut_scale, nisl, lane);
+    if (interior && NLM_SMEM_CENTRE) nlm_pair_body<NOFF, true>(in, out, n, hs, gwin, fA, fB, K, S, H, sw, smooth, lut_scale, nisl, lane);
     else nlm_pair_body<NOFF, false>(in, out, n, hs, gwin, fA, fB, K, S, H, sw, smooth, lut_scale, nisl, lane);
 }
 
