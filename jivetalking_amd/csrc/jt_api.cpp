@@ -480,26 +480,15 @@ static void run_limiter(jt_ctx *h, const double *in, double *out, int64_t n, int
     const int64_t nblk = (n + blk - 1) / blk;
     h->d_scr3.ensure((size_t)nblk);
     launch_absmax_blocks_f64(in, n, blk, h->d_scr3.p, nblk, h->stream);
-    std::vector<double> mx((size_t)nblk);
-    JT_HIP(hipMemcpyAsync(mx.data(), h->d_scr3.p, sizeof(double) * nblk, hipMemcpyDeviceToHost, h->stream));
-    JT_HIP(hipStreamSynchronize(h->stream));
-    // a position p is clean when no sample in the previous (B + release*sr + 4) samples exceeds the limit
-    const int64_t need = (int64_t)std::ceil((B + release * sr + 4.0) / blk) + 1;
-    const int64_t target = 8192 / blk;
-    std::vector<int64_t> bounds; bounds.push_back(0);
-    int64_t quiet = 0, last = 0;
-    const double g = std::fabs(in_gain);
-    for (int64_t b = 0; b < nblk; ++b) {
-        if (b > 0 && quiet >= need && b - last >= target) { bounds.push_back(b * blk); last = b; }
-        if (mx[(size_t)b] * g > limit) quiet = 0; else quiet++;
-    }
-    bounds.push_back(n);
-    const int nl = (int)bounds.size() - 1;
-    h->lim_bounds.ensure(bounds.size());
-    JT_HIP(hipMemcpyAsync(h->lim_bounds.p, bounds.data(), sizeof(int64_t) * bounds.size(), hipMemcpyHostToDevice, h->stream));
-    h->lim_delta.ensure((size_t)nl * B); h->lim_pos.ensure((size_t)nl * B);
-    launch_limiter_f64(in, out, n, sr, limit, B, release, asc_coeff, h->lim_bounds.p, nl, in_gain, h->lim_delta.p, h->lim_pos.p, h->stream);
-    JT_HIP(hipStreamSynchronize(h->stream));
+    // a position p is clean when no sample in the previous (B + release*sr + 4) samples exceeds the limit; segment starts are
+    // picked on the device (one candidate per 2048 samples), so the limiter needs no host round trip
+    const int need = (int)std::ceil((B + release * sr + 4.0) / blk) + 1;
+    const int target = 2048 / blk;
+    const int64_t ntargets = (nblk + target - 1) / target;
+    h->lim_bounds.ensure((size_t)ntargets);
+    h->lim_delta.ensure((size_t)ntargets * B); h->lim_pos.ensure((size_t)ntargets * B);
+    launch_limiter_f64(in, out, n, sr, limit, B, release, asc_coeff, h->d_scr3.p, nblk, blk, need, target, h->lim_bounds.p, ntargets,
+                       in_gain, h->lim_delta.p, h->lim_pos.p, h->stream);
 }
 
 // loudnorm (dynamic-mode first pass) input statistics of a signal at `rate`, measured after swr -> 192 kHz

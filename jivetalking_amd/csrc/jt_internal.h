@@ -81,8 +81,8 @@ void launch_band_rms(const float *in, int64_t n, int nbands, const BiquadF32 *hp
 // limiter (exact, chunked at provably clean points)
 void launch_absmax_blocks_f64(const double *in, int64_t n, int blk, double *out_max, int64_t nblk, hipStream_t s);
 void launch_limiter_f64(const double *in, double *out, int64_t n, int sr, double limit, int buffer_size,
-                        double release_s, double asc_coeff, const int64_t *bounds, int nlanes, double in_gain,
-                        double *scratch_delta, int64_t *scratch_pos, hipStream_t s);
+                        double release_s, double asc_coeff, const double *block_max, int64_t nblk, int blk, int need, int target,
+                        int64_t *cand, int64_t ntargets, double in_gain, double *scratch_delta, int64_t *scratch_pos, hipStream_t s);
 
 // resampler / true peak
 void launch_resample_to_s16(const float *in, int64_t n, const double *bank, int phase_count, int filter_length, int center,

@@ -702,100 +702,174 @@ void launch_absmax_blocks_f64(const double *in, int64_t n, int blk, double *out_
     hipLaunchKernelGGL(k_absmax_blocks_f64, dim3((unsigned)nblk), dim3(256), 0, s, in, n, blk, out_max, nblk);
 }
 
-// One lane per segment [bounds[c], bounds[c+1]); every segment starts at a provably clean limiter state
+// Segment starts ("clean points") chosen on the device.  A block b is clean when the `need` blocks before it are all at or
+// under the limit (after in_gain): no peak is pending, att has recovered to 1 and delta is 0 there, so a lane can start the
+// state machine from its initial state.  One candidate per `target`-block stride: cand[k] = first clean block in
+// [k*target, (k+1)*target), or -1.  cand[0] = 0 (the stream start is clean by definition).
+__global__ void k_lim_bounds(const double *__restrict__ mx, int64_t nblk, int need, int target, double g, double limit,
+                             int64_t *__restrict__ cand, int64_t ntargets)
+{
+    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= ntargets) return;
+    if (k == 0) { cand[0] = 0; return; }
+    const int64_t t0 = k * target;
+    // consecutive quiet blocks immediately before t0 (capped at need; never counts past block 0, as the sequential counter)
+    int64_t quiet = 0;
+    for (int64_t b = t0 - 1; b >= 0 && quiet < need; --b) { if (mx[b] * g > limit) break; quiet++; }
+    int64_t found = -1;
+    for (int64_t b = t0; b < min(t0 + (int64_t)target, nblk); ++b) {
+        if (quiet >= need) { found = b; break; }
+        if (mx[b] * g > limit) quiet = 0; else quiet++;
+    }
+    cand[k] = found;
+}
+
+// One lane per segment [lo, hi) between consecutive clean points; every segment starts at a provably clean limiter state
 // (att = 1, delta = 0, empty peak list), so the sequential FFmpeg state machine is reproduced exactly.
 // The ring buffer of af_alimiter.c is replaced by absolute sample indices: buffer[pos'] of the ring that
 // holds sample a is in[a]; nextpos[] stores absolute indices; ring distances become index differences.
+// The two sample streams a lane walks (the sample entering the look-ahead buffer and the one leaving it) are staged
+// through [64][65] LDS tiles with row-coalesced loads; outputs leave through the same tile.
 __global__ void __launch_bounds__(64)
 k_limiter_f64(const double *__restrict__ in, double *__restrict__ out, int64_t n, int sr, double limit, int B,
-              double release, double asc_coeff, const int64_t *__restrict__ bounds, int nlanes, double in_gain,
+              double release, double asc_coeff, const int64_t *__restrict__ cand, int64_t ntargets, int blk, double in_gain,
               double *__restrict__ sdelta, int64_t *__restrict__ spos)
 {
-    int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= nlanes) return;
-    const int64_t lo = bounds[c], hi = bounds[c + 1];
+    __shared__ double tx[LANES][TW + 1];
+    __shared__ double te[LANES][TW + 1];
+    __shared__ int64_t s_lo[LANES], s_hi[LANES];
+    const int lane = threadIdx.x;
+    const int64_t c = (int64_t)blockIdx.x * LANES + lane;
+    int64_t lo = -1, hi = -1;
+    if (c < ntargets && cand[c] >= 0) {
+        lo = cand[c] * blk;
+        hi = n;
+        for (int64_t q = c + 1; q < ntargets; ++q) { const int64_t v = cand[q]; if (v >= 0) { hi = v * blk; break; } }
+        if (lo >= n) { lo = -1; hi = -1; }
+    }
+    s_lo[lane] = lo; s_hi[lane] = hi;
+    const bool active = lo >= 0;
+    // iterations i = lo .. hi + B - 2: iteration i pushes in[i] (zero past the end) and emits sample i-(B-1)
+    const int64_t my_len = active ? (hi - lo) + B - 1 : 0;
+    int64_t max_len = my_len;
+    for (int o = 32; o > 0; o >>= 1) max_len = max(max_len, __shfl_xor(max_len, o, 64));
+    __syncthreads();
     double *nextdelta = sdelta + (size_t)c * B;
     int64_t *nextpos = spos + (size_t)c * B;
-    for (int k = 0; k < B; ++k) nextpos[k] = -1;
+    if (active) nextpos[0] = -1;      // list entries are always written (with their -1 terminator) before they are read
     double att = 1.0, delta = 0.0, asc = 0.0; int asc_c = 0;
     int nextiter = 0, nextlen = 0;
-    // iterations i = lo .. hi + B - 2: iteration i pushes in[i] (zero past the end) and emits sample i-(B-1)
-    const int64_t it_end = hi + B - 1;
-    for (int64_t i = lo; i < it_end; ++i) {
-        double x = i < n ? in[i] * in_gain : 0.0;
-        double peak = fabs(x);
-        if (peak > limit) { asc += peak; asc_c++; }
-        if (peak > limit) {
-            double patt = fmin(limit / peak, 1.);
-            double rdelta = (1.0 - patt) / (sr * release);
-            double dl = (limit / peak - att) / B * 1;
-            bool found = false;
-            if (dl < delta) {
-                delta = dl;
-                nextpos[0] = i; nextpos[1 % B] = -1; nextdelta[0] = rdelta;
-                nextlen = 1; nextiter = 0;
-            } else {
-                int k;
-                for (k = nextiter; k < nextiter + nextlen; k++) {
-                    int j = k % B;
-                    double ppeak = fabs(in[nextpos[j]] * in_gain);
-                    double pdelta = (limit / peak - limit / ppeak) / (double)((i - nextpos[j]) / 1);
-                    if (pdelta < nextdelta[j]) { nextdelta[j] = pdelta; found = true; break; }
-                }
-                if (found) {
-                    nextlen = k - nextiter + 1;
-                    nextpos[(nextiter + nextlen) % B] = i;
-                    nextdelta[(nextiter + nextlen) % B] = rdelta;
-                    nextpos[(nextiter + nextlen + 1) % B] = -1;
-                    nextlen++;
-                }
+    for (int64_t pos = 0; pos < max_len; pos += TW) {
+        // stage: row r, column = lane
+        for (int r0 = 0; r0 < LANES; r0 += 16) {
+            double vx[16], ve[16];
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const int64_t rl = s_lo[r0 + q];
+                const int64_t ix = rl + pos + lane, ie = ix - (B - 1);
+                const int64_t cx = ix < 0 ? 0 : (ix >= n ? n - 1 : ix), ce = ie < 0 ? 0 : (ie >= n ? n - 1 : ie);
+                vx[q] = in[cx]; ve[q] = in[ce];
+            }
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const int64_t rl = s_lo[r0 + q];
+                const int64_t ix = rl + pos + lane, ie = ix - (B - 1);
+                tx[r0 + q][lane] = (rl >= 0 && ix < n) ? vx[q] * in_gain : 0.0;
+                te[r0 + q][lane] = (rl >= 0 && ie >= 0 && ie < n) ? ve[q] * in_gain : 0.0;
             }
         }
-        const int64_t eidx = i - (B - 1);            // sample leaving the look-ahead buffer
-        double bufv = (eidx >= 0 && eidx < n) ? in[eidx] * in_gain : 0.0;
-        if (B == 1) bufv = x;
-        peak = fabs(bufv);
-        if (peak > limit) { asc -= peak; asc_c--; }  // asc_pos == -1 always (never armed in af_alimiter.c)
-        att += delta;
-        double o = bufv * att;
-        if (nextpos[nextiter] == eidx && eidx >= 0) {
-            // auto_release (asc=1): get_rdelta(..., asc=1)
-            double rd = (1.0 - att) / (sr * release);
-            if (asc_c > 0) {
-                double a_att = limit / (asc_coeff * asc) * (double)asc_c;
-                if (a_att > att) {
-                    double d2 = fmax((a_att - att) / (sr * release), rd / 10);
-                    if (d2 < rd) rd = d2;
+        __syncthreads();
+        if (active && pos < my_len) {
+            const int jn = (int)min((int64_t)TW, my_len - pos);
+            for (int j = 0; j < jn; ++j) {
+                const int64_t i = lo + pos + j;
+                const double x = tx[lane][j];
+                double peak = fabs(x);
+                if (peak > limit) { asc += peak; asc_c++; }
+                if (peak > limit) {
+                    double patt = fmin(limit / peak, 1.);
+                    double rdelta = (1.0 - patt) / (sr * release);
+                    double dl = (limit / peak - att) / B * 1;
+                    bool found = false;
+                    if (dl < delta) {
+                        delta = dl;
+                        nextpos[0] = i; nextpos[1 % B] = -1; nextdelta[0] = rdelta;
+                        nextlen = 1; nextiter = 0;
+                    } else {
+                        int k;
+                        for (k = nextiter; k < nextiter + nextlen; k++) {
+                            int jj = k % B;
+                            double ppeak = fabs(in[nextpos[jj]] * in_gain);
+                            double pdelta = (limit / peak - limit / ppeak) / (double)((i - nextpos[jj]) / 1);
+                            if (pdelta < nextdelta[jj]) { nextdelta[jj] = pdelta; found = true; break; }
+                        }
+                        if (found) {
+                            nextlen = k - nextiter + 1;
+                            nextpos[(nextiter + nextlen) % B] = i;
+                            nextdelta[(nextiter + nextlen) % B] = rdelta;
+                            nextpos[(nextiter + nextlen + 1) % B] = -1;
+                            nextlen++;
+                        }
+                    }
                 }
+                const int64_t eidx = i - (B - 1);            // sample leaving the look-ahead buffer
+                double bufv = te[lane][j];
+                if (B == 1) bufv = x;
+                peak = fabs(bufv);
+                if (peak > limit) { asc -= peak; asc_c--; }  // asc_pos == -1 always (never armed in af_alimiter.c)
+                att += delta;
+                double o = bufv * att;
+                if (nextlen > 0 && nextpos[nextiter] == eidx && eidx >= 0) {
+                    // auto_release (asc=1): get_rdelta(..., asc=1)
+                    double rd = (1.0 - att) / (sr * release);
+                    if (asc_c > 0) {
+                        double a_att = limit / (asc_coeff * asc) * (double)asc_c;
+                        if (a_att > att) {
+                            double d2 = fmax((a_att - att) / (sr * release), rd / 10);
+                            if (d2 < rd) rd = d2;
+                        }
+                    }
+                    delta = rd;
+                    if (nextlen > 1) {
+                        int64_t pnext = nextpos[(nextiter + 1) % B];
+                        double ppeak = fabs(in[pnext] * in_gain);
+                        double pdelta = (limit / ppeak - att) / (double)(pnext - eidx);
+                        if (pdelta < delta) delta = pdelta;
+                    }
+                    nextlen -= 1;
+                    nextpos[nextiter] = -1;
+                    nextiter = (nextiter + 1) % B;
+                }
+                if (att > 1.) { att = 1.; delta = 0.; nextiter = 0; nextlen = 0; nextpos[0] = -1; }
+                if (att <= 0.) { att = 0.0000000000001; delta = (1.0 - att) / (sr * release); }
+                if (att != 1. && (1. - att) < 0.0000000000001) att = 1.;
+                if (delta != 0. && fabs(delta) < 0.00000000000001) delta = 0.;
+                o = fmin(fmax(o, -limit), limit);
+                te[lane][j] = o;
             }
-            delta = rd;
-            if (nextlen > 1) {
-                int64_t pnext = nextpos[(nextiter + 1) % B];
-                double ppeak = fabs(in[pnext] * in_gain);
-                double pdelta = (limit / ppeak - att) / (double)(pnext - eidx);
-                if (pdelta < delta) delta = pdelta;
-            }
-            nextlen -= 1;
-            nextpos[nextiter] = -1;
-            nextiter = (nextiter + 1) % B;
         }
-        if (att > 1.) { att = 1.; delta = 0.; nextiter = 0; nextlen = 0; nextpos[0] = -1; }
-        if (att <= 0.) { att = 0.0000000000001; delta = (1.0 - att) / (sr * release); }
-        if (att != 1. && (1. - att) < 0.0000000000001) att = 1.;
-        if (delta != 0. && fabs(delta) < 0.00000000000001) delta = 0.;
-        o = fmin(fmax(o, -limit), limit);
-        if (eidx >= lo && eidx < hi) out[eidx] = o;
+        __syncthreads();
+        // coalesced store of the emitted samples: row r column lane is sample lo_r + pos + lane - (B-1)
+#pragma unroll 4
+        for (int r = 0; r < LANES; ++r) {
+            const int64_t rl = s_lo[r];
+            if (rl < 0) continue;
+            const int64_t e = rl + pos + lane - (B - 1);
+            if (e >= rl && e < s_hi[r]) out[e] = te[r][lane];
+        }
+        __syncthreads();
     }
 }
 
 void launch_limiter_f64(const double *in, double *out, int64_t n, int sr, double limit, int buffer_size,
-                        double release_s, double asc_coeff, const int64_t *bounds, int nlanes, double in_gain,
-                        double *scratch_delta, int64_t *scratch_pos, hipStream_t s)
+                        double release_s, double asc_coeff, const double *block_max, int64_t nblk, int blk, int need, int target,
+                        int64_t *cand, int64_t ntargets, double in_gain, double *scratch_delta, int64_t *scratch_pos, hipStream_t s)
 {
-    if (nlanes <= 0) return;
-    int grid = (nlanes + 63) / 64;
-    hipLaunchKernelGGL(k_limiter_f64, dim3(grid), dim3(64), 0, s, in, out, n, sr, limit, buffer_size, release_s, asc_coeff,
-                       bounds, nlanes, in_gain, scratch_delta, scratch_pos);
+    if (n <= 0) return;
+    hipLaunchKernelGGL(k_lim_bounds, dim3((unsigned)((ntargets + 255) / 256)), dim3(256), 0, s, block_max, nblk, need, target,
+                       std::fabs(in_gain), limit, cand, ntargets);
+    hipLaunchKernelGGL(k_limiter_f64, dim3((unsigned)((ntargets + LANES - 1) / LANES)), dim3(LANES), 0, s, in, out, n, sr, limit,
+                       buffer_size, release_s, asc_coeff, cand, ntargets, blk, in_gain, scratch_delta, scratch_pos);
 }
 
 // ------------------------------------------------------------------ biquad pair, direct form I (f32)

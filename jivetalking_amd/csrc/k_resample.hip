@@ -15,6 +15,7 @@
 #include "jt_internal.h"
 
 constexpr int PP_THREADS = 256;
+namespace d147 { constexpr int P = 147, STEP = 160, L = 36, RING = 40, SW = 32, NOUT = 64 * P, NIN = 64 * STEP; }
 
 __device__ inline int skew(int i) { return i + (i >> 5); }
 
@@ -25,8 +26,12 @@ template <typename TIn, typename TAcc, typename TTap, int MODE>
 __global__ void __launch_bounds__(PP_THREADS)
 k_polyphase(const TIn *__restrict__ in, int64_t n, const TTap *__restrict__ bank, int P, int L, int center, int64_t step,
             int64_t m_total, int R, double in_scale, int blk, unsigned long long *__restrict__ block_tp, int64_t nblocks_alloc,
-            int16_t *__restrict__ out_s16, TAcc *__restrict__ out_stream)
+            int16_t *__restrict__ out_s16, TAcc *__restrict__ out_stream, int skip_interior)
 {
+    if (skip_interior) {     // 48k -> 44.1k: interior blocks belong to k_down147 (same block geometry, same interior test)
+        const int64_t s0i = (int64_t)blockIdx.x * d147::NIN, mlo = (int64_t)blockIdx.x * d147::NOUT;
+        if ((s0i - center >= 0) && (s0i - center + 63 * d147::STEP + 7 * d147::SW <= n) && (mlo + d147::NOUT <= m_total)) return;
+    }
     extern __shared__ unsigned char smem_pp[];
     TAcc *xin = reinterpret_cast<TAcc *>(smem_pp);
     const int T = 64 * R * (int)step;
@@ -227,6 +232,77 @@ static bool launch_upsample32(const TIn *in, int64_t n, const TTap *bank, int P,
     return true;
 }
 
+// ---- 48 kHz -> 44.1 kHz (+ s16): the default output stage (filters.go:706-710), P = 147 phases, 160 input samples per
+// 147 outputs, 36 taps.  "Period-per-lane": lane l of a wave produces the 147 consecutive outputs of one polyphase period
+// (lanes = 64 consecutive periods), so at every step all lanes are at the SAME phase (taps = wave-uniform scalar loads) and
+// a lane's 36-sample window slides by 1 or 2 inputs per output.  The whole period is unrolled at compile time: the window
+// is a 40-slot register ring with static indices (160 % 40 == 0, so the ring realigns every period), each input sample is
+// read from LDS exactly once, and the inner work is 36 register-operand f64 FMAs per output -- the FMA pipe is the only
+// limiter.  Inputs are staged 32 samples x 64 lanes at a time ([64][33] f32, row-coalesced loads), outputs leave through a
+// [64][34] s16 tile.  Tap order per output is unchanged (ascending), so results are bit-identical to k_polyphase<.,.,.,1>.
+// Interior blocks only; blocks touching the stream edges (reflection / flush) are left to k_polyphase.
+namespace d147 {
+__host__ __device__ constexpr int win_start(int r) { return (r * STEP) / P; }      // relative input index of the first tap of output r
+__host__ __device__ constexpr int phase(int r) { return (r * STEP) % P; }
+}
+
+__global__ void __launch_bounds__(64)
+k_down147(const float *__restrict__ in, int64_t n, const double *__restrict__ bank, int center, int64_t m_total,
+          int16_t *__restrict__ out)
+{
+    using namespace d147;
+    __shared__ float stage[64][SW + 1];
+    __shared__ int16_t ostage[64][34];
+    const int lane = threadIdx.x;
+    const int64_t s0 = (int64_t)blockIdx.x * NIN;           // first input sample of the block's first period
+    const int64_t m_lo = (int64_t)blockIdx.x * NOUT;
+    // interior test (must match k_polyphase's complementary early-out): every staged read is inside [0, n) and every output exists
+    const bool interior = (s0 - center >= 0) && (s0 - center + 63 * STEP + 7 * SW <= n) && (m_lo + NOUT <= m_total);
+    if (!interior) return;
+    const float *src = in + (s0 - center);                  // row r, relative index x  ->  src[r*STEP + x]
+    double ring[RING];
+    int staged = -1;                                        // stage number currently in LDS (compile-time after unrolling)
+    int have = 0;                                           // inputs [0, have) are in the ring (or were)
+#pragma clang loop unroll(full)
+    for (int r = 0; r < P; ++r) {
+        const int a = win_start(r);
+        // bring the window [a, a+L) into the ring
+#pragma clang loop unroll(full)
+        for (int x = have; x < a + L; ++x) {
+            if (x / SW != staged) {
+                staged = x / SW;
+                __syncthreads();
+#pragma unroll
+                for (int it = 0; it < 32; ++it) {
+                    const int row = it * 2 + (lane >> 5), col = lane & 31;
+                    stage[row][col] = src[(int64_t)row * STEP + staged * SW + col];
+                }
+                __syncthreads();
+            }
+            ring[x % RING] = (double)stage[lane][x % SW];
+        }
+        have = a + L > have ? a + L : have;
+        __asm__ volatile("" ::: "memory");          // keep each output's 36 scalar tap loads next to their FMAs (SGPR budget)
+        const double *f = bank + phase(r) * L;
+        double val = 0.0;
+#pragma clang loop unroll(full)
+        for (int t = 0; t < L; ++t) val = fma(ring[(a + t) % RING], f[t], val);
+        double q = rint(val * 32768.0);
+        q = q < -32768.0 ? -32768.0 : (q > 32767.0 ? 32767.0 : q);
+        ostage[lane][r % 32] = (int16_t)q;
+        if (r % 32 == 31 || r == P - 1) {
+            const int g0 = (r / 32) * 32, cnt = r - g0 + 1;
+            __syncthreads();
+#pragma unroll
+            for (int it = 0; it < 32; ++it) {
+                const int row = it * 2 + (lane >> 5), col = lane & 31;
+                if (col < cnt) out[m_lo + (int64_t)row * P + g0 + col] = ostage[row][col];
+            }
+            __syncthreads();
+        }
+    }
+}
+
 struct PPGeom { int R; int T; size_t smem; unsigned grid; };
 template <typename TAcc>
 static PPGeom pp_geometry(int64_t n, int P, int L, int64_t step, int64_t m_total, bool otile)
@@ -254,7 +330,7 @@ void launch_true_peak_f32(const float *in, int64_t n, const double *bank, int ph
     auto k = k_polyphase<float, double, double, 0>;
     JT_HIP(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)g.smem));
     hipLaunchKernelGGL(k, dim3(g.grid), dim3(PP_THREADS), g.smem, s, in, n, bank, phase_count, filter_length, center, step, m_total,
-                       g.R, 1.0, blk, (unsigned long long *)block_tp, nblocks_alloc, (int16_t *)nullptr, (double *)nullptr);
+                       g.R, 1.0, blk, (unsigned long long *)block_tp, nblocks_alloc, (int16_t *)nullptr, (double *)nullptr, 0);
 }
 
 void launch_true_peak_f64(const double *in, int64_t n, const double *bank, int phase_count, int filter_length, int center,
@@ -268,7 +344,7 @@ void launch_true_peak_f64(const double *in, int64_t n, const double *bank, int p
     auto k = k_polyphase<double, double, double, 0>;
     JT_HIP(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)g.smem));
     hipLaunchKernelGGL(k, dim3(g.grid), dim3(PP_THREADS), g.smem, s, in, n, bank, phase_count, filter_length, center, step, m_total,
-                       g.R, 1.0, blk, (unsigned long long *)block_tp, nblocks_alloc, (int16_t *)nullptr, (double *)nullptr);
+                       g.R, 1.0, blk, (unsigned long long *)block_tp, nblocks_alloc, (int16_t *)nullptr, (double *)nullptr, 0);
 }
 
 // f32 in (the dbl->flt->dbl rounded signal) -> DBLP resample -> s16
@@ -278,10 +354,12 @@ void launch_resample_to_s16(const float *in, int64_t n, const double *bank, int 
     if (m <= 0) return;
     PPGeom g = pp_geometry<double>(n, phase_count, filter_length, step, m, true);
     JT_REQUIRE(g.smem <= 150 * 1024, JT_E_UNSUPPORTED, "resample: rate ratio needs too large an LDS tile");
+    const bool fast = phase_count == d147::P && step == d147::STEP && filter_length == d147::L && g.R == 1;
+    if (fast) hipLaunchKernelGGL(k_down147, dim3(g.grid), dim3(64), 0, s, in, n, bank, center, m, out);
     auto k = k_polyphase<float, double, double, 1>;
     JT_HIP(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)g.smem));
     hipLaunchKernelGGL(k, dim3(g.grid), dim3(PP_THREADS), g.smem, s, in, n, bank, phase_count, filter_length, center, step, m,
-                       g.R, 1.0, 1, (unsigned long long *)nullptr, (int64_t)0, out, (double *)nullptr);
+                       g.R, 1.0, 1, (unsigned long long *)nullptr, (int64_t)0, out, (double *)nullptr, fast ? 1 : 0);
 }
 
 // Pass-3 streams at 192 kHz.  FLT variant (s16 in, no limiter prefix): swr int_sample_fmt FLTP = float taps, float
@@ -296,7 +374,7 @@ void launch_resample_stream_s16_f32(const int16_t *in, int64_t n, const float *b
     auto k = k_polyphase<int16_t, float, float, 2>;
     JT_HIP(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)g.smem));
     hipLaunchKernelGGL(k, dim3(g.grid), dim3(PP_THREADS), g.smem, s, in, n, bankf, phase_count, filter_length, center, step, m_total,
-                       g.R, 1.0 / 32768.0, 1, (unsigned long long *)nullptr, (int64_t)0, (int16_t *)nullptr, out);
+                       g.R, 1.0 / 32768.0, 1, (unsigned long long *)nullptr, (int64_t)0, (int16_t *)nullptr, out, 0);
 }
 void launch_resample_stream_f64(const double *in, int64_t n, const double *bank, int phase_count, int filter_length, int center,
                                 int64_t step, int64_t m_total, double *out, hipStream_t s)
@@ -308,5 +386,5 @@ void launch_resample_stream_f64(const double *in, int64_t n, const double *bank,
     auto k = k_polyphase<double, double, double, 2>;
     JT_HIP(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)g.smem));
     hipLaunchKernelGGL(k, dim3(g.grid), dim3(PP_THREADS), g.smem, s, in, n, bank, phase_count, filter_length, center, step, m_total,
-                       g.R, 1.0, 1, (unsigned long long *)nullptr, (int64_t)0, (int16_t *)nullptr, out);
+                       g.R, 1.0, 1, (unsigned long long *)nullptr, (int64_t)0, (int16_t *)nullptr, out, 0);
 }
