@@ -54,149 +54,210 @@ __device__ inline void block_reduce_sum(float (&v)[K], float *scratch /* [K][4] 
 }
 
 // ------------------------------------------------------------------ aspectralstats
-constexpr int SP_LOG2 = 11, SP_N = 1 << SP_LOG2, SP_HALF = SP_N / 2, SP_RUN = 32;
+// One WAVE per analysis unit, four independent waves per workgroup, no workgroup barriers after the table setup.
+// A unit = one hop whose statistics are wanted (+ its predecessor, whose magnitudes feed the flux term): two real FFTs of
+// 2048 points, each through a 1024-point complex Stockham radix-4 transform held in the wave's own LDS slab (in place:
+// a stage's 16 points per lane are read into registers before any is written back; LDS operations of one wave are ordered).
+// The 13 statistics are two strided passes over the 1024 magnitudes with wave-shuffle reductions, and the roll-off is a
+// wave prefix scan over 16-bin lane runs.
+constexpr int SP_LOG2 = 11, SP_N = 1 << SP_LOG2, SP_HALF = SP_N / 2, SP_Q = SP_HALF / 2, SP_RUN = 8, SP_WAVES = 4;
+
+__device__ inline float wsumf(float v) { for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64); return v; }
+__device__ inline int sp_skew(int i) { return i + (i >> 4); }
+
+// in-place Stockham radix-4, H = 1024 complex points, one wave (64 lanes x 4 butterflies per stage)
+__device__ inline void fft1024_wave(float2 *a, const float2 *__restrict__ tw, int lane)
+{
+    constexpr int H = SP_HALF;
+    int Ns = 1;
+#pragma unroll 1
+    for (int st = 0; st < 5; ++st) {
+        float2 v[4][4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int j = lane + 64 * q;
+            v[q][0] = a[j]; v[q][1] = a[j + H / 4]; v[q][2] = a[j + H / 2]; v[q][3] = a[j + 3 * H / 4];
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int j = lane + 64 * q;
+            const int k = j & (Ns - 1);
+            float2 v0 = v[q][0], v1 = v[q][1], v2 = v[q][2], v3 = v[q][3];
+            if (Ns > 1) {
+                const int tq = k * (H / 4 / Ns);
+                const float2 w1 = tw[tq], w2 = tw[2 * tq], w3 = tw[3 * tq];
+                float2 t;
+                t.x = v1.x * w1.x - v1.y * w1.y; t.y = v1.x * w1.y + v1.y * w1.x; v1 = t;
+                t.x = v2.x * w2.x - v2.y * w2.y; t.y = v2.x * w2.y + v2.y * w2.x; v2 = t;
+                t.x = v3.x * w3.x - v3.y * w3.y; t.y = v3.x * w3.y + v3.y * w3.x; v3 = t;
+            }
+            const float2 s02 = make_float2(v0.x + v2.x, v0.y + v2.y), d02 = make_float2(v0.x - v2.x, v0.y - v2.y);
+            const float2 s13 = make_float2(v1.x + v3.x, v1.y + v3.y), d13 = make_float2(v1.x - v3.x, v1.y - v3.y);
+            const float2 r13 = make_float2(d13.y, -d13.x);            // -i * d13
+            const int o = ((j - k) << 2) + k;
+            a[o] = make_float2(s02.x + s13.x, s02.y + s13.y);
+            a[o + Ns] = make_float2(d02.x + r13.x, d02.y + r13.y);
+            a[o + 2 * Ns] = make_float2(s02.x - s13.x, s02.y - s13.y);
+            a[o + 3 * Ns] = make_float2(d02.x - r13.x, d02.y - r13.y);
+        }
+        Ns <<= 2;
+    }
+}
+
+// magnitudes |X[i]| / 2048, i < 1024, of the hann-windowed frame ending at sample (h+1)*1024, into mag[sp_skew(i)]
+__device__ inline void sp_frame_mags(const float *__restrict__ in, int64_t n, int64_t h, float2 *zbuf, const float2 *tw, const float *hann,
+                                     const float2 (&wk)[8], float *mag, int lane)
+{
+    const int64_t w0 = (h + 1) * (int64_t)SP_HALF - SP_N;
+#pragma unroll 4
+    for (int q = 0; q < 16; ++q) {
+        const int m = lane + 64 * q;
+        const int64_t k0 = w0 + 2 * m, k1 = k0 + 1;
+        const float x0 = (k0 >= 0 && k0 < n) ? in[k0] : 0.f, x1 = (k1 >= 0 && k1 < n) ? in[k1] : 0.f;
+        const int i0 = 2 * m, i1 = 2 * m + 1;
+        zbuf[m] = make_float2(x0 * hann[i0 < SP_HALF ? i0 : SP_N - 1 - i0], x1 * hann[i1 < SP_HALF ? i1 : SP_N - 1 - i1]);
+    }
+    fft1024_wave(zbuf, tw, lane);
+    const float fscale = 1.f / SP_N;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const int k = lane + 64 * q;                       // pair (k, 1024 - k), k < 512
+        const float2 zk = zbuf[k], zm = zbuf[(SP_HALF - k) & (SP_HALF - 1)];
+        const float er = 0.5f * (zk.x + zm.x), ei = 0.5f * (zk.y - zm.y);          // E = (Zk + conj Zm)/2
+        const float orr = 0.5f * (zk.y + zm.y), oi = -0.5f * (zk.x - zm.x);        // O = -i (Zk - conj Zm)/2
+        if (k == 0) mag[sp_skew(0)] = fabsf((er + orr) * fscale);                 // X[0] = Re Z0 + Im Z0 (real)
+        else {
+            const float cr = wk[q].x * orr - wk[q].y * oi, ci = wk[q].x * oi + wk[q].y * orr;   // W^k O
+            mag[sp_skew(k)] = hypotf((er + cr) * fscale, (ei + ci) * fscale);                   // X[k] = E + W^k O
+            mag[sp_skew(SP_HALF - k)] = hypotf((er - cr) * fscale, (ei - ci) * fscale);         // X[1024-k] = conj(E - W^k O)
+        }
+    }
+    if (lane == 0) { const float2 z = zbuf[SP_Q]; mag[sp_skew(SP_Q)] = hypotf(z.x * fscale, z.y * fscale); }   // X[512] = conj(Z[512])
+}
 
 // sel_blk == 0: every hop (out[h]).  sel_blk > 0: only the hops whose props survive ebur128's 100 ms re-framing, i.e. for
-// output frame k the hop containing sample k*sel_blk (+ its predecessor for flux); out[k].  A run of SP_RUN consecutive
-// frames per workgroup; a hop already in LDS as "previous magnitudes" is not recomputed.
-__global__ void __launch_bounds__(FT)
-k_aspectralstats(const float *__restrict__ in, int64_t n, int sr, const float2 *__restrict__ tw, const float *__restrict__ hann,
+// output frame k the hop containing sample k*sel_blk; out[k].
+__global__ void __launch_bounds__(64 * SP_WAVES)
+k_aspectralstats(const float *__restrict__ in, int64_t n, int sr, const float *__restrict__ hann_g,
                  jt_spectral *__restrict__ hops, int64_t nhops, int sel_blk, int64_t nframes)
 {
-    __shared__ float re[SP_N], im[SP_N];
-    __shared__ float mag[SP_HALF], prev[SP_HALF];
-    __shared__ float scratch[16 * 4];
-    __shared__ float psum[FT];
-    __shared__ int roll_idx;
-    const int tid = threadIdx.x;
-    const int64_t u0 = (int64_t)blockIdx.x * SP_RUN;     // first hop (all-hops mode) or first frame (selected mode)
+    __shared__ float2 tw[SP_HALF];
+    __shared__ float hann[SP_HALF];                  // the f32 hann table is exactly symmetric: w[i] == w[N-1-i]
+    __shared__ float2 zb[SP_WAVES][SP_HALF];
+    __shared__ float magb[SP_WAVES][SP_HALF + 64], prevb[SP_WAVES][SP_HALF + 64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int q = tid; q < SP_HALF; q += 64 * SP_WAVES) { float sn, cs; sincospif(2.0f * q / SP_HALF, &sn, &cs); tw[q] = make_float2(cs, -sn); }
+    for (int q = tid; q < SP_HALF; q += 64 * SP_WAVES) hann[q] = hann_g[q];
+    __syncthreads();
+    float2 wk[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) { double sn, cs; sincospi(2.0 * (lane + 64 * q) / SP_N, &sn, &cs); wk[q] = make_float2((float)cs, (float)-sn); }
+    float2 *zbuf = zb[wave]; float *mag = magb[wave], *prev = prevb[wave];
     const float max_freq = (float)(sr / 2);
     const float scale = max_freq / (float)SP_HALF;
-    const float fscale = 1.f / SP_N;
-    for (int i = tid; i < SP_HALF; i += FT) prev[i] = 0.f;
-    __syncthreads();
     const int64_t nunits = sel_blk > 0 ? nframes : nhops;
-    int64_t have_prev = -2;                           // hop whose magnitudes sit in prev[] (-2: none, prev[] = zeros for hop -1)
+    const int64_t u0 = ((int64_t)blockIdx.x * SP_WAVES + wave) * SP_RUN;
     for (int64_t unit = u0; unit < u0 + SP_RUN && unit < nunits; ++unit) {
-      int64_t htarget = sel_blk > 0 ? min((unit * (int64_t)sel_blk) / SP_HALF, nhops - 1) : unit;
-      for (int64_t h = (have_prev == htarget - 1 || htarget == 0) ? htarget : htarget - 1; h <= htarget; ++h) {
-        const bool emit = (h == htarget);
-        if (h == 0 && have_prev != -2) { for (int i = tid; i < SP_HALF; i += FT) prev[i] = 0.f; __syncthreads(); }
-        // window after pushing hop h = samples [(h+1)*1024 - 2048, (h+1)*1024)
-        const int64_t w0 = (h + 1) * (int64_t)SP_HALF - SP_N;
-        for (int i = tid; i < SP_N; i += FT) {
-            int64_t k = w0 + i;
-            float x = (k >= 0 && k < n) ? in[k] : 0.f;
-            unsigned r = brev((unsigned)i, SP_LOG2);
-            re[r] = x * hann[i];
-            im[r] = 0.f;
+        const int64_t h = sel_blk > 0 ? min((unit * (int64_t)sel_blk) / SP_HALF, nhops - 1) : unit;
+        // previous hop's magnitudes (zeros before the first hop)
+        if (h == 0) { for (int i = lane; i < SP_HALF + 64; i += 64) prev[i] = 0.f; }
+        else sp_frame_mags(in, n, h - 1, zbuf, tw, hann, wk, prev, lane);
+        sp_frame_mags(in, n, h, zbuf, tw, hann, wk, mag, lane);
+        // pass 1
+        float v[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+        float mx = 0.f;
+        const float m0 = mag[sp_skew(0)];
+#pragma unroll 4
+        for (int q = 0; q < 16; ++q) {
+            const int i = lane + 64 * q;
+            const float m = mag[sp_skew(i)];
+            v[0] += m;                                   // sum mag
+            v[1] += m * i * scale;                       // centroid numerator
+            const float me = FLT_EPSILON + m;
+            v[2] += logf(me);                            // flatness log-sum
+            v[3] += me;                                  // flatness den
+            v[4] += m * logf(m + FLT_EPSILON);           // entropy
+            const float df = m - prev[sp_skew(i)];
+            v[5] += df * df;                             // flux
+            if (i >= 1) { v[6] += (m - m0) / i; v[7] += m; }   // decrease
+            mx = fmaxf(mx, m);
         }
-        __syncthreads();
-        fft_lds<SP_LOG2>(re, im, tw);
-        for (int i = tid; i < SP_HALF; i += FT) mag[i] = hypotf(re[i] * fscale, im[i] * fscale);
-        __syncthreads();
-        if (emit) {
-            // pass 1
-            float v[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-            float mx = 0.f;
-            const float m0 = mag[0];
-            for (int i = tid; i < SP_HALF; i += FT) {
-                float m = mag[i];
-                v[0] += m;                                   // sum mag
-                v[1] += m * i * scale;                       // centroid numerator
-                float me = FLT_EPSILON + m;
-                v[2] += logf(me);                            // flatness log-sum
-                v[3] += me;                                  // flatness den
-                v[4] += m * logf(m + FLT_EPSILON);           // entropy
-                float df = m - prev[i];
-                v[5] += df * df;                             // flux
-                if (i >= 1) { v[6] += (m - m0) / i; v[7] += m; }   // decrease
-                mx = fmaxf(mx, m);
-            }
-            block_reduce_sum<9>(v, scratch);
-            for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_down(mx, off, 64));
-            if ((tid & 63) == 0) scratch[tid >> 6] = mx;
-            __syncthreads();
-            mx = fmaxf(fmaxf(scratch[0], scratch[1]), fmaxf(scratch[2], scratch[3]));
-            __syncthreads();
-            const float sum = v[0];
-            const float mean = sum / SP_HALF;
-            const float centroid = sum <= FLT_EPSILON ? 1.f : v[1] / sum;
-            // pass 2
-            float u[6] = {0, 0, 0, 0, 0, 0};
-            const float mm = SP_HALF * 0.5f;
-            for (int i = tid; i < SP_HALF; i += FT) {
-                float m = mag[i];
-                float dm = m - mean;
-                u[0] += dm * dm;
-                float d = i * scale - centroid;
-                u[1] += m * d * d;
-                u[2] += m * d * d * d;
-                u[3] += m * d * d * d * d;
-                float a = (i - mm) / mm;
-                u[4] += a * dm;
-                u[5] += a * a;
-            }
-            block_reduce_sum<6>(u, scratch);
-            // rolloff: contiguous 4-bin partial sums -> block scan
-            float p4 = 0.f;
-            for (int q = 0; q < 4; ++q) p4 += mag[tid * 4 + q];
-            psum[tid] = p4;
-            if (tid == 0) roll_idx = 0;
-            __syncthreads();
-            if (tid == 0) {   // sequential inclusive scan over 256 partials (exact left-to-right order)
-                float run = 0.f;
-                for (int t = 0; t < FT; ++t) { float s0 = run; run += psum[t]; psum[t] = s0; }
-            }
-            __syncthreads();
-            {
-                const float norm = sum * 0.85f;
-                float run = psum[tid];
-                int found = -1;
-                for (int q = 0; q < 4; ++q) { run += mag[tid * 4 + q]; if (found < 0 && run >= norm) found = tid * 4 + q; }
-                // first thread (lowest index) whose range crosses the threshold wins
-                if (found >= 0 && psum[tid] < norm) roll_idx = found;
-            }
-            __syncthreads();
-            if (tid == 0) {
-                jt_spectral o;
-                float spread = sum <= FLT_EPSILON ? 1.f : sqrtf(u[1] / sum);
-                float d3 = sum * spread * spread * spread;
-                float d4 = d3 * spread;
-                o.mean = mean;
-                o.variance = u[0] / SP_HALF;
-                o.centroid = centroid;
-                o.spread = spread;
-                o.skewness = d3 <= FLT_EPSILON ? 1.f : u[2] / d3;
-                o.kurtosis = d4 <= FLT_EPSILON ? 1.f : u[3] / d4;
-                o.entropy = -v[4] / logf((float)SP_HALF);
-                float fnum = expf(v[2] / SP_HALF), fden = v[3] / SP_HALF;
-                o.flatness = fden <= FLT_EPSILON ? 0.f : fnum / fden;
-                o.crest = mean <= FLT_EPSILON ? 0.f : mx / mean;
-                o.flux = sqrtf(v[5]);
-                o.slope = fabsf(u[5]) <= FLT_EPSILON ? 0.f : u[4] / u[5];
-                o.decrease = v[7] <= FLT_EPSILON ? 0.f : v[6] / v[7];
-                o.rolloff = roll_idx * scale;
-                hops[sel_blk > 0 ? unit : h] = o;
-            }
-            __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v[q] = wsumf(v[q]);
+        for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+        const float sum = v[0];
+        const float mean = sum / SP_HALF;
+        const float centroid = sum <= FLT_EPSILON ? 1.f : v[1] / sum;
+        // pass 2
+        float u[6] = {0, 0, 0, 0, 0, 0};
+        const float mm = SP_HALF * 0.5f;
+#pragma unroll 4
+        for (int q = 0; q < 16; ++q) {
+            const int i = lane + 64 * q;
+            const float m = mag[sp_skew(i)];
+            const float dm = m - mean;
+            u[0] += dm * dm;
+            const float d = i * scale - centroid;
+            u[1] += m * d * d;
+            u[2] += m * d * d * d;
+            u[3] += m * d * d * d * d;
+            const float a = (i - mm) / mm;
+            u[4] += a * dm;
+            u[5] += a * a;
         }
-        for (int i = tid; i < SP_HALF; i += FT) prev[i] = mag[i];
-        __syncthreads();
-        have_prev = h;
-      }
+#pragma unroll
+        for (int q = 0; q < 6; ++q) u[q] = wsumf(u[q]);
+        // roll-off: first bin where the running sum reaches 85 % of the total; lane l owns bins [16 l, 16 l + 16)
+        int roll_idx = 0;
+        {
+            float loc = 0.f;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) loc += mag[sp_skew(16 * lane + q)];
+            float inc = loc;
+            for (int o = 1; o < 64; o <<= 1) { const float t = __shfl_up(inc, o, 64); if (lane >= o) inc += t; }
+            float run = inc - loc;                       // exclusive prefix
+            const float norm = sum * 0.85f;
+            int found = -1;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) { run += mag[sp_skew(16 * lane + q)]; if (found < 0 && run >= norm) found = 16 * lane + q; }
+            const unsigned long long bal = __ballot(found >= 0);
+            if (bal) { const int first = __ffsll((long long)bal) - 1; roll_idx = __shfl(found, first, 64); }
+        }
+        if (lane == 0) {
+            jt_spectral o;
+            const float spread = sum <= FLT_EPSILON ? 1.f : sqrtf(u[1] / sum);
+            const float d3 = sum * spread * spread * spread;
+            const float d4 = d3 * spread;
+            o.mean = mean;
+            o.variance = u[0] / SP_HALF;
+            o.centroid = centroid;
+            o.spread = spread;
+            o.skewness = d3 <= FLT_EPSILON ? 1.f : u[2] / d3;
+            o.kurtosis = d4 <= FLT_EPSILON ? 1.f : u[3] / d4;
+            o.entropy = -v[4] / logf((float)SP_HALF);
+            const float fnum = expf(v[2] / SP_HALF), fden = v[3] / SP_HALF;
+            o.flatness = fden <= FLT_EPSILON ? 0.f : fnum / fden;
+            o.crest = mean <= FLT_EPSILON ? 0.f : mx / mean;
+            o.flux = sqrtf(v[5]);
+            o.slope = fabsf(u[5]) <= FLT_EPSILON ? 0.f : u[4] / u[5];
+            o.decrease = v[7] <= FLT_EPSILON ? 0.f : v[6] / v[7];
+            o.rolloff = roll_idx * scale;
+            hops[sel_blk > 0 ? unit : h] = o;
+        }
     }
 }
 
 void launch_aspectralstats(const float *in, int64_t n, int sr, int win_size, const float2 *twiddle, const float *hann,
                            jt_spectral *hops, int64_t nhops, int sel_blk, int64_t nframes, hipStream_t s)
 {
+    (void)twiddle;
     if (nhops <= 0) return;
     JT_REQUIRE(win_size == SP_N, JT_E_UNSUPPORTED, "aspectralstats: only win_size=2048 is built");
     const int64_t units = sel_blk > 0 ? nframes : nhops;
     if (units <= 0) return;
-    unsigned grid = (unsigned)((units + SP_RUN - 1) / SP_RUN);
-    hipLaunchKernelGGL(k_aspectralstats, dim3(grid), dim3(FT), 0, s, in, n, sr, twiddle, hann, hops, nhops, sel_blk, nframes);
+    const int per_wg = SP_WAVES * SP_RUN;
+    unsigned grid = (unsigned)((units + per_wg - 1) / per_wg);
+    hipLaunchKernelGGL(k_aspectralstats, dim3(grid), dim3(64 * SP_WAVES), 0, s, in, n, sr, hann, hops, nhops, sel_blk, nframes);
 }
 
 // ------------------------------------------------------------------ afftdn
