@@ -138,6 +138,9 @@ typedef struct {
     int64_t frames;
 } jt_region_sample;
 int jt_region_measure(jt_ctx *h, int stage, double start_s, double dur_s, jt_region_sample *out);
+/* MeasureOutputRegions (analyser_output.go:276-317) measures the room-tone and the speech region of one output back to
+ * back: both analyses in one call, one synchronisation.  A region with dur_s[i] <= 0 is skipped (out[i] zeroed). */
+int jt_region_measure_pair(jt_ctx *h, int stage, const double start_s[2], const double dur_s[2], jt_region_sample out[2]);
 
 /* ---- limiter prefix shared by Pass 3 and Pass 4 (normalise.go:446-465 buildPreLimiterPrefix) ---- */
 typedef struct {

@@ -614,32 +614,54 @@ extern "C" int jt_pass4(jt_ctx *h, const jt_limiter_plan *lim, const jt_loudnorm
 }
 
 // ---------------------------------------------------------------- region re-measure
-extern "C" int jt_region_measure(jt_ctx *h, int stage, double start_s, double dur_s, jt_region_sample *out)
+// MeasureOutputRegions (analyser_output.go:276-317) measures the room-tone and the speech region of one output back to
+// back; jt_region_measure_pair enqueues both analyses and synchronises once.  A region with dur_s <= 0 is skipped (out zeroed).
+extern "C" int jt_region_measure_pair(jt_ctx *h, int stage, const double start_s[2], const double dur_s[2], jt_region_sample out[2])
 {
     JT_API_BEGIN(h)
-    JT_REQUIRE(out && start_s >= 0 && dur_s > 0, JT_E_INVAL, "region_measure: bad arguments");
+    JT_REQUIRE(out && start_s && dur_s, JT_E_INVAL, "region_measure: bad arguments");
     const int16_t *src = nullptr; int64_t m = 0;
     if (stage == 2) { src = h->s16_p2.p; m = h->m_p2; } else if (stage == 4) { src = h->s16_p4.p; m = h->m_p4; }
     JT_REQUIRE(src && m > 0, JT_E_STATE, "region_measure: stage output not on device");
     const int rate = h->out_rate;
-    int64_t s0, len; trim_range(start_s, dur_s, rate, m, &s0, &len);
-    std::memset(out, 0, sizeof(*out));
-    JT_REQUIRE(len > 0, JT_E_INVAL, "region_measure: empty region");
-    pass_begin(h, len, 1);
-    h->region_f.ensure((size_t)len);
-    launch_s16_to_f32(src + s0, h->region_f.p, len, h->stream);
-    jt_analysis a; std::memset(&a, 0, sizeof(a));
-    std::vector<jt_frame_meta> meta((size_t)(len / (rate / 10) + 2));
-    AnalysisJob J;
-    analysis_enqueue(h, h->region_f.p, len, rate, false, rate / 10, &J);
+    int64_t s0[2] = {0, 0}, len[2] = {0, 0}; bool want[2];
+    for (int r = 0; r < 2; ++r) {
+        std::memset(&out[r], 0, sizeof(out[r]));
+        want[r] = dur_s[r] > 0 && start_s[r] >= 0;
+        if (want[r]) { trim_range(start_s[r], dur_s[r], rate, m, &s0[r], &len[r]); JT_REQUIRE(len[r] > 0, JT_E_INVAL, "region_measure: empty region"); }
+    }
+    pass_begin(h, std::max<int64_t>(len[0] + len[1], 1), 2);
+    h->region_f.ensure((size_t)(len[0] + len[1] + 1));
+    AnalysisJob J[2];
+    for (int r = 0; r < 2; ++r) {
+        if (!want[r]) continue;
+        float *x = h->region_f.p + (r ? len[0] : 0);
+        launch_s16_to_f32(src + s0[r], x, len[r], h->stream);
+        analysis_enqueue(h, x, len[r], rate, false, rate / 10, &J[r]);
+    }
     JT_HIP(hipStreamSynchronize(h->stream));
-    analysis_complete(h, J, &a, meta.data(), (int64_t)meta.size());
-    out->rms_level = a.astats.rms_level; out->peak_level = a.astats.peak_level; out->crest_factor = a.astats.crest_factor;
-    out->spectral = a.spectral_mean;
-    out->momentary = a.r128.momentary; out->shortterm = a.r128.shortterm;
-    out->true_peak = a.r128.true_peak; out->sample_peak = a.r128.sample_peak;
-    out->frames = a.n_frames_meta;
+    for (int r = 0; r < 2; ++r) {
+        if (!want[r]) continue;
+        jt_analysis a; std::memset(&a, 0, sizeof(a));
+        std::vector<jt_frame_meta> meta((size_t)(len[r] / (rate / 10) + 2));
+        analysis_complete(h, J[r], &a, meta.data(), (int64_t)meta.size());
+        out[r].rms_level = a.astats.rms_level; out[r].peak_level = a.astats.peak_level; out[r].crest_factor = a.astats.crest_factor;
+        out[r].spectral = a.spectral_mean;
+        out[r].momentary = a.r128.momentary; out[r].shortterm = a.r128.shortterm;
+        out[r].true_peak = a.r128.true_peak; out[r].sample_peak = a.r128.sample_peak;
+        out[r].frames = a.n_frames_meta;
+    }
     JT_API_END(h)
+}
+
+extern "C" int jt_region_measure(jt_ctx *h, int stage, double start_s, double dur_s, jt_region_sample *out)
+{
+    if (!h || !out || !(start_s >= 0) || !(dur_s > 0)) { if (h) h->err = "region_measure: bad arguments"; return JT_E_INVAL; }
+    const double st[2] = {start_s, 0.0}, du[2] = {dur_s, 0.0};
+    jt_region_sample o[2];
+    const int rc = jt_region_measure_pair(h, stage, st, du, o);
+    if (rc == JT_OK) *out = o[0];
+    return rc;
 }
 
 // ---------------------------------------------------------------- output

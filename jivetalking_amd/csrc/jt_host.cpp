@@ -1069,10 +1069,12 @@ extern "C" int jt_process_audio(jt_ctx *h, const jt_host_config *base, int frame
     out->pass_ms[1] = h->timers.pass2_ms;
     out->stage_ms[4] = now_ms() - t0; t0 = now_ms();
     auto measure_regions = [&](int stage, jt_region_sample *rt, jt_region_sample *sp) {
-        if (m.has_noise_profile && m.noise_profile.duration_ns > 0)
-            (void)jt_region_measure(h, stage, secs_of(m.noise_profile.start_ns), secs_of(m.noise_profile.duration_ns), rt);
-        if (m.has_speech_profile && m.speech_profile.region.duration_ns > 0)
-            (void)jt_region_measure(h, stage, secs_of(m.speech_profile.region.start_ns), secs_of(m.speech_profile.region.duration_ns), sp);
+        double st[2] = {0, 0}, du[2] = {0, 0};
+        if (m.has_noise_profile && m.noise_profile.duration_ns > 0) { st[0] = secs_of(m.noise_profile.start_ns); du[0] = secs_of(m.noise_profile.duration_ns); }
+        if (m.has_speech_profile && m.speech_profile.region.duration_ns > 0) { st[1] = secs_of(m.speech_profile.region.start_ns); du[1] = secs_of(m.speech_profile.region.duration_ns); }
+        if (du[0] <= 0 && du[1] <= 0) return;
+        jt_region_sample o[2];
+        if (jt_region_measure_pair(h, stage, st, du, o) == JT_OK) { if (du[0] > 0) *rt = o[0]; if (du[1] > 0) *sp = o[1]; }
     };
     measure_regions(2, &out->filtered_room_tone, &out->filtered_speech);
     out->stage_ms[5] = now_ms() - t0; t0 = now_ms();

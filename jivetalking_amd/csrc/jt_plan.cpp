@@ -5,6 +5,8 @@
 #include "jt_internal.h"
 #include <algorithm>
 #include <cfloat>
+#include <thread>
+#include <functional>
 
 // ---------------------------------------------------------------- biquads (af_biquads.c config_filter)
 void jt_biquad_design(int type, double freq, double q, int sr, double b[3], double a[3], int normalize)
@@ -82,6 +84,22 @@ void jt_swr_plan(SwrPlanHost *p, int in_rate, int out_rate)
     }
 }
 
+// ---------------------------------------------------------------- small fork-join helper for the O(blocks) host finishing
+// fn(lo, hi, part) over [0, n) in contiguous parts; one part when n is small.  The per-block work (2-3 log10 each) is the
+// only host arithmetic that scales with the file, so long files spread it over a few cores.
+static void jt_parallel_for(int64_t n, const std::function<void(int64_t, int64_t, int)> &fn, int *nparts_out = nullptr)
+{
+    int nt = n >= 8192 ? (int)std::min(8u, std::max(1u, std::thread::hardware_concurrency())) : 1;
+    if (nparts_out) *nparts_out = nt;
+    if (nt <= 1) { fn(0, n, 0); return; }
+    const int64_t per = (n + nt - 1) / nt;
+    std::vector<std::thread> th;
+    for (int k = 1; k < nt; ++k) th.emplace_back(fn, std::min(n, k * per), std::min(n, (k + 1) * per), k);
+    fn(0, std::min(n, per), 0);
+    for (auto &t : th) t.join();
+}
+constexpr int JT_MAX_PARTS = 8;
+
 // ---------------------------------------------------------------- f_ebur128.c gating / LRA on block energies
 namespace {
 constexpr int ABS_THRES = -70, ABS_UP_THRES = 10, HIST_GRAIN = 100;
@@ -101,28 +119,33 @@ void jt_r128_finish(const double *bs, int64_t nblocks, int blk, int sr, bool dua
     double kept400 = 0, kept3000 = 0; int64_t nk400 = 0, nk3000 = 0;
     double rel400 = 0;
     o->M.assign(nblocks, 0.0); o->S.assign(nblocks, 0.0);
-    double w400 = 0.0, w3000 = 0.0;            // sliding sums of the last 4 / 30 block energies
+    // per block: momentary / short-term loudness (the log10s) in parallel, un-panned values kept in M/S for the serial gating walk
+    jt_parallel_for(nblocks, [&](int64_t lo, int64_t hi, int) {
+        for (int64_t k = lo; k < hi; ++k) {
+            // window sums recomputed from the block energies each step (no add/sub drift)
+            double p400 = 1e-12, p3000 = 1e-12;
+            if (k >= 3)  { const double w400 = bs[k] + bs[k - 1] + bs[k - 2] + bs[k - 3]; p400 += w400; p400 /= bins400; }
+            if (k >= 29) { double w = 0; for (int q = 29; q >= 0; --q) w += bs[k - q]; p3000 += w; p3000 /= bins3000; }
+            o->M[k] = LOUDNESS(p400); o->S[k] = LOUDNESS(p3000);
+        }
+    });
     for (int64_t k = 0; k < nblocks; ++k) {
-        // window sums recomputed from the block energies each step (no add/sub drift)
-        if (k >= 3)  { w400 = bs[k] + bs[k - 1] + bs[k - 2] + bs[k - 3]; }
-        if (k >= 29) { double s = 0; for (int q = 29; q >= 0; --q) s += bs[k - q]; w3000 = s; }
         double p400 = 1e-12, p3000 = 1e-12;
-        if (k >= 3)  { p400 += w400;   p400 /= bins400; }
-        if (k >= 29) { p3000 += w3000; p3000 /= bins3000; }
-        double l400 = LOUDNESS(p400), l3000 = LOUDNESS(p3000);
+        if (k >= 3)  { const double w400 = bs[k] + bs[k - 1] + bs[k - 2] + bs[k - 3]; p400 += w400; p400 /= bins400; }
+        const double l400 = o->M[k], l3000 = o->S[k];
         if (l400 >= ABS_THRES) {
             h400[clipi(HIST_POS(l400), 0, HIST_SIZE - 1)]++;
             kept400 += p400; nk400++;
-            double rt = kept400 / nk400; if (!rt) rt = 1e-12;
-            rel400 = LOUDNESS(rt) + (-10);
         }
         if (l3000 >= ABS_THRES) {
+            if (k >= 29) { double w = 0; for (int q = 29; q >= 0; --q) w += bs[k - q]; p3000 += w; p3000 /= bins3000; }
             h3000[clipi(HIST_POS(l3000), 0, HIST_SIZE - 1)]++;
             kept3000 += p3000; nk3000++;
         }
-        if (dualmono) { l400 -= pan_law; l3000 -= pan_law; }
-        o->M[k] = l400; o->S[k] = l3000;
+        if (dualmono) { o->M[k] = l400 - pan_law; o->S[k] = l3000 - pan_law; }
     }
+    // relative threshold as of the last gated block (f_ebur128.c recomputes it per gated block; only the final value is read)
+    if (nk400) { double rt = kept400 / nk400; if (!rt) rt = 1e-12; rel400 = LOUDNESS(rt) + (-10); }
     // integrated loudness = value after the last gated block
     o->integrated = ABS_THRES; o->lra = 0; o->lra_low = 0; o->lra_high = 0; o->rel_threshold = rel400;
     if (nk400) {
@@ -172,16 +195,23 @@ void jt_loudnorm_finish(const double *bs, int64_t nblocks, int64_t s100, bool du
     hist_init();
     std::vector<unsigned long> bh(1000, 0), sh(1000, 0);
     const double ch = dual_mono ? 2.0 : 1.0;
-    // gating blocks: 400 ms every 100 ms; short-term blocks: 3 s, first at 3 s then every 1 s
-    for (int64_t k = 3; k < nblocks; ++k) {
-        double sum = (bs[k - 3] + bs[k - 2] + bs[k - 1] + bs[k]) * scale_energy * ch / (double)(s100 * 4);
-        if (sum >= hist_b[0]) ++bh[hist_index(sum)];
-        if (k >= 29 && (k - 29) % 10 == 0) {
-            double st = 0; for (int q = 29; q >= 0; --q) st += bs[k - q];
-            st = st * scale_energy * ch / (double)(s100 * 30);
-            if (st >= hist_b[0]) ++sh[hist_index(st)];
+    // gating blocks: 400 ms every 100 ms; short-term blocks: 3 s, first at 3 s then every 1 s.  Histogram counts are
+    // order-independent, so the blocks are binned in parallel parts and the counts added.
+    std::vector<unsigned long> pbh((size_t)JT_MAX_PARTS * 1000, 0), psh((size_t)JT_MAX_PARTS * 1000, 0);
+    int nparts = 1;
+    jt_parallel_for(nblocks, [&](int64_t lo, int64_t hi, int part) {
+        unsigned long *b = &pbh[(size_t)part * 1000], *sm = &psh[(size_t)part * 1000];
+        for (int64_t k = std::max<int64_t>(lo, 3); k < hi; ++k) {
+            double sum = (bs[k - 3] + bs[k - 2] + bs[k - 1] + bs[k]) * scale_energy * ch / (double)(s100 * 4);
+            if (sum >= hist_b[0]) ++b[hist_index(sum)];
+            if (k >= 29 && (k - 29) % 10 == 0) {
+                double st = 0; for (int q = 29; q >= 0; --q) st += bs[k - q];
+                st = st * scale_energy * ch / (double)(s100 * 30);
+                if (st >= hist_b[0]) ++sm[hist_index(st)];
+            }
         }
-    }
+    }, &nparts);
+    for (int pt = 0; pt < nparts; ++pt) for (int j = 0; j < 1000; ++j) { bh[j] += pbh[(size_t)pt * 1000 + j]; sh[j] += psh[(size_t)pt * 1000 + j]; }
     double rel = 0; long above = 0;
     for (int j = 0; j < 1000; ++j) { rel += bh[j] * hist_e[j]; above += bh[j]; }
     if (above) { rel /= (double)above; rel *= 0.1; }
