@@ -38,23 +38,26 @@ k_as_reduce(const float *__restrict__ x, int64_t n, AsPartial *__restrict__ part
     double mn = DBL_MAX, mx = -DBL_MAX, mnz = DBL_MAX, sx = 0, sx2 = 0, mind = DBL_MAX, maxd = 0, d1 = 0, d2 = 0;
     unsigned long long zr = 0, mor = 0, mand = ~0ull, cnt = 0;
     const int64_t stride = (int64_t)gridDim.x * AS_T;
-    for (int64_t i = (int64_t)blockIdx.x * AS_T + tid; i < n; i += stride) {
-        const float xf = x[i];
+    auto step = [&](int64_t i, float xf, float xp) {
         const double d = (double)xf;
         mn = fmin(mn, d); mx = fmax(mx, d);
         const double ad = fabs(d);
         if (d != 0 && ad < mnz) mnz = ad;
         sx += d; sx2 += d * d;
         if (i > 0) {
-            const double p = (double)x[i - 1];
+            const double p = (double)xp;
             const double df = fabs(d - p);
             mind = fmin(mind, df); maxd = fmax(maxd, df); d1 += df; d2 += (d - p) * (d - p);
         }
         if (d != 0) {
             // FFSIGN of the previous non-zero sample (NaN before the first one: FFSIGN(NaN) = -1)
-            int64_t j = i - 1;
-            while (j >= 0 && x[j] == 0.f) --j;
-            const int ps = (j >= 0 && x[j] > 0.f) ? 1 : -1;
+            int ps;
+            if (xp != 0.f && i > 0) ps = xp > 0.f ? 1 : -1;
+            else {
+                int64_t j = i - 1;
+                while (j >= 0 && x[j] == 0.f) --j;
+                ps = (j >= 0 && x[j] > 0.f) ? 1 : -1;
+            }
             const int cs = d > 0 ? 1 : -1;
             zr += (cs != ps);
         }
@@ -64,7 +67,17 @@ k_as_reduce(const float *__restrict__ x, int64_t n, AsPartial *__restrict__ part
         const long long iv = (long long)llrint(d * 2147483648.0);
         mor |= (unsigned long long)iv; mand &= (unsigned long long)iv;
         cnt++;
+    };
+    // four grid-strided samples per round: the eight loads are issued together (one HBM round trip instead of four)
+    int64_t i = (int64_t)blockIdx.x * AS_T + tid;
+    for (; i + 3 * stride < n; i += 4 * stride) {
+        float xv[4], xq[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { const int64_t k = i + q * stride; xv[q] = x[k]; xq[q] = k > 0 ? x[k - 1] : 0.f; }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) step(i + q * stride, xv[q], xq[q]);
     }
+    for (; i < n; i += stride) step(i, x[i], i > 0 ? x[i - 1] : 0.f);
     mn = wmin(mn); mx = wmax(mx); mnz = wmin(mnz); sx = wsum(sx); sx2 = wsum(sx2); mind = wmin(mind); maxd = wmax(maxd);
     d1 = wsum(d1); d2 = wsum(d2); zr = wsumu(zr); mor = woru(mor); mand = wandu(mand); cnt = wsumu(cnt);
     if ((tid & 63) == 0) sp[tid >> 6] = AsPartial{mn, mx, mnz, sx, sx2, mind, maxd, d1, d2, zr, mor, mand, cnt};
@@ -159,6 +172,20 @@ k_as_noise_floor(const float *__restrict__ g, const float *__restrict__ p, int64
     }
 }
 
+// wave64 inclusive prefix maximum of non-negative values (gfx9 DPP: row_shr 1/2/4/8, row_bcast 15/31; lanes shifted in from
+// outside a row read 0)
+#define JT_DPPF(v, ctrl, rmask) __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), (ctrl), (rmask), 0xf, false))
+__device__ inline float wave_prefix_max(float v)
+{
+    v = fmaxf(v, JT_DPPF(v, 0x111, 0xf));
+    v = fmaxf(v, JT_DPPF(v, 0x112, 0xf));
+    v = fmaxf(v, JT_DPPF(v, 0x114, 0xf));
+    v = fmaxf(v, JT_DPPF(v, 0x118, 0xf));
+    v = fmaxf(v, JT_DPPF(v, 0x142, 0xa));
+    v = fmaxf(v, JT_DPPF(v, 0x143, 0xc));
+    return v;
+}
+
 // Fused sliding-window peak + (min, count) reduction: the noise-floor measure without the G/P arrays in HBM.
 // A workgroup owns NF_TILE window starts; |x| of the tile (+ tc-1 halo) is scanned per 64-sample block in registers
 // (inclusive prefix / suffix maxima by wave shuffles) and parked in LDS; a window [s, s+tc) is then
@@ -179,18 +206,28 @@ k_as_nf_fused(const float *__restrict__ x, int64_t n, int tc, int64_t ntiles, As
     double nf = DBL_MAX; unsigned long long cnt = 0;
     for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const int64_t S0 = tile * NF_TILE;
-        for (int b = wave; b < nb64; b += AS_T / 64) {
-            const int64_t idx = S0 + (int64_t)b * 64 + lane;
-            const float a = idx < n ? fabsf(x[idx]) : 0.f;
-            float pm = a, gm = a;
+        // 8 blocks per wave per round: all 16 loads are issued before the first scan so their HBM latency overlaps
+        for (int b0 = wave; b0 < nb64; b0 += 8 * (AS_T / 64)) {
+            float av[8], rv[8];
 #pragma unroll
-            for (int o = 1; o < 64; o <<= 1) {
-                const float tu = __shfl_up(pm, o, 64), td = __shfl_down(gm, o, 64);
-                if (lane >= o) pm = fmaxf(pm, tu);
-                if (lane + o < 64) gm = fmaxf(gm, td);
+            for (int q = 0; q < 8; ++q) {
+                const int b = b0 + q * (AS_T / 64);
+                const int64_t idx = S0 + (int64_t)b * 64 + lane, ridx = S0 + (int64_t)b * 64 + (63 - lane);
+                av[q] = (b < nb64 && idx < n) ? x[idx] : 0.f;
+                rv[q] = (b < nb64 && ridx < n) ? x[ridx] : 0.f;
             }
-            sP[b * 64 + lane] = pm; sG[b * 64 + lane] = gm;
-            if (lane == 63) sBM[b] = pm;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int b = b0 + q * (AS_T / 64);
+                if (b < nb64) {
+                    // inclusive prefix maxima by DPP (no LDS traffic); the suffix maxima are the prefix maxima of the block
+                    // read in reversed lane order.  |x| >= 0, so 0 is the identity the out-of-row DPP lanes return.
+                    const float pm = wave_prefix_max(fabsf(av[q]));
+                    const float gm = wave_prefix_max(fabsf(rv[q]));
+                    sP[b * 64 + lane] = pm; sG[b * 64 + (63 - lane)] = gm;
+                    if (lane == 63) sBM[b] = pm;
+                }
+            }
         }
         __syncthreads();
         for (int b = tid; b < nb64; b += AS_T) {

@@ -129,7 +129,7 @@ k_upsample32(const TIn *__restrict__ in, int64_t n, const TTap *__restrict__ ban
     constexpr int L = 32;
     constexpr int WL = L + QL - 1;                                    // QL > 1 only with step == 1
     extern __shared__ unsigned char smem_pp[];
-    TAcc *xin = reinterpret_cast<TAcc *>(smem_pp);
+    TIn *xin = reinterpret_cast<TIn *>(smem_pp);          // staged in the input type (halves the LDS footprint for f32 / s16 sources)
     const int T = 64 * R * QL * step;
     const int nin = T + L;
     __shared__ unsigned long long slots[8];
@@ -140,10 +140,10 @@ k_upsample32(const TIn *__restrict__ in, int64_t n, const TTap *__restrict__ ban
     const int flush = MODE != 0;
     for (int i = tid; i < nin; i += PP_THREADS) {
         int64_t g = s0 - center + i;
-        TAcc v = (TAcc)0;
+        TIn v = (TIn)0;
         if (g < 0) g = -g;                                           // invert_initial_buffer(): in[-j] = in[j]
-        if (g < n) v = (TAcc)((TAcc)in[g] * (TAcc)in_scale);
-        else if (flush) { int64_t r = 2 * n - 1 - g; if (r >= 0 && r < n) v = (TAcc)((TAcc)in[r] * (TAcc)in_scale); }   // resample_flush()
+        if (g < n) v = in[g];
+        else if (flush) { int64_t r = 2 * n - 1 - g; if (r >= 0 && r < n) v = in[r]; }   // resample_flush()
         xin[skew(i)] = v;
     }
     if (MODE == 0 && tid < 8) slots[tid] = 0ull;
@@ -159,7 +159,7 @@ k_upsample32(const TIn *__restrict__ in, int64_t n, const TTap *__restrict__ ban
         const int si = off + step * qq;
         TAcc xw[WL];
 #pragma unroll
-        for (int i = 0; i < WL; ++i) xw[i] = xin[skew(si + i)];
+        for (int i = 0; i < WL; ++i) xw[i] = (TAcc)((TAcc)xin[skew(si + i)] * (TAcc)in_scale);
         TAcc vmax[QL];
 #pragma unroll
         for (int u = 0; u < QL; ++u) vmax[u] = (TAcc)0;
@@ -214,7 +214,7 @@ static bool launch_upsample32(const TIn *in, int64_t n, const TTap *bank, int P,
     const int ql = step == 1 ? 4 : 1;
     const int R = (int)std::max<int64_t>(1, 4096 / (64 * ql * step));
     const int T = 64 * R * ql * (int)step, nin = T + 32;
-    const size_t smem = sizeof(TAcc) * (size_t)(nin + (nin >> 5) + 4);
+    const size_t smem = sizeof(TIn) * (size_t)(nin + (nin >> 5) + 4);
     if (smem > 150 * 1024) return false;
     const int64_t per_block = (int64_t)64 * R * ql * P;
     const unsigned grid = (unsigned)((m_total + per_block - 1) / per_block);
