@@ -26,6 +26,11 @@ extern "C" int jt_open(int device_id, jt_ctx **out)
         JT_HIP(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
         JT_HIP(hipEventCreate(&h->ev0)); JT_HIP(hipEventCreate(&h->ev1));
         JT_HIP(hipEventCreate(&h->ev2)); JT_HIP(hipEventCreate(&h->ev3));
+        JT_HIP(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
+        for (int i = 0; i < 4; ++i) {
+            JT_HIP(hipStreamCreateWithFlags(&h->aux[i], hipStreamNonBlocking));
+            JT_HIP(hipEventCreateWithFlags(&h->ev_join[i], hipEventDisableTiming));
+        }
     } catch (const JtError &) { delete h; return JT_E_NOGPU; }
     *out = h;
     return JT_OK;
@@ -40,6 +45,11 @@ extern "C" void jt_close(jt_ctx *h)
     if (h->ev1) (void)hipEventDestroy(h->ev1);
     if (h->ev2) (void)hipEventDestroy(h->ev2);
     if (h->ev3) (void)hipEventDestroy(h->ev3);
+    if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
+    for (int i = 0; i < 4; ++i) {
+        if (h->aux[i]) { (void)hipStreamSynchronize(h->aux[i]); (void)hipStreamDestroy(h->aux[i]); }
+        if (h->ev_join[i]) (void)hipEventDestroy(h->ev_join[i]);
+    }
     delete h;
 }
 
@@ -136,6 +146,7 @@ static SwrDev &get_swr(jt_ctx *h, int in_rate, int out_rate)
 // start of a pass: size the pinned arena and the K-weighting scratch for everything the pass will stage (nothing in flight)
 static void pass_begin(jt_ctx *h, int64_t max_samples, int analyses)
 {
+    ensure_twiddle(h, 2048); ensure_hann(h, 2048);
     h->pin.begin(jt_arena_bytes_for(max_samples) * (size_t)std::max(1, analyses) + (4u << 20));
     h->kw_begin((size_t)(max_samples / 512 + 1024) * 8 * (size_t)std::max(1, analyses));
 }
@@ -152,37 +163,52 @@ struct AnalysisJob {
     int64_t n = 0, nfull = 0, nhops = 0, nout = 0; int blk = 0, sr = 0; bool dualmono = false, want_astats = true, want_r128 = true, want_spec = true;
 };
 
-static void analysis_enqueue(jt_ctx *h, const float *x, int64_t n, int sr, bool dualmono, int sel_blk, AnalysisJob *J)
+static void analysis_join(jt_ctx *h)
+{
+    // later main-stream work (and the pass's final synchronisation of the main stream) orders after every chain
+    for (int i = 0; i < 4; ++i) { JT_HIP(hipEventRecord(h->ev_join[i], h->aux[i])); JT_HIP(hipStreamWaitEvent(h->stream, h->ev_join[i], 0)); }
+}
+static void fork_aux(jt_ctx *h, int first, int last)
+{
+    JT_HIP(hipEventRecord(h->ev_fork, h->stream));
+    for (int i = first; i <= last; ++i) JT_HIP(hipStreamWaitEvent(h->aux[i], h->ev_fork, 0));
+}
+
+// join = false: the caller queues more independent main-stream work first and calls analysis_join() itself
+static void analysis_enqueue(jt_ctx *h, const float *x, int64_t n, int sr, bool dualmono, int sel_blk, AnalysisJob *J, bool join = true)
 {
     J->n = n; J->sr = sr; J->dualmono = dualmono;
-    if (J->want_astats) jt_astats_enqueue(h, x, n, sr, &J->as);
+    // fork: x is ready once everything queued on the main stream so far has run
+    hipStream_t a0 = h->aux[0], a1 = h->aux[1], a2 = h->aux[2], a3 = h->aux[3];
+    fork_aux(h, 0, 3);
+    if (J->want_astats) jt_astats_enqueue(h, x, n, sr, &J->as, a0, a1, a2);
     if (J->want_r128) {
         const int blk = sr / 10; const int64_t nfull = n / blk;
         J->blk = blk; J->nfull = nfull;
         SwrDev &sw = get_swr(h, sr, 192000);
         h->d_scr1.ensure((size_t)nfull + 2);
-        JT_HIP(hipMemsetAsync(h->d_scr1.p, 0, sizeof(double) * (nfull + 2), h->stream));
+        JT_HIP(hipMemsetAsync(h->d_scr1.p, 0, sizeof(double) * (nfull + 2), a3));
         launch_true_peak_f32(x, n, sw.bank_d.p, sw.pl.phase_count, sw.pl.filter_length, sw.pl.center, sw.pl.step, blk, h->d_scr1.p, nfull + 1,
-                             sw.out_len(n), h->stream);
+                             sw.out_len(n), a3);
         double *btp = h->pin.take<double>((size_t)nfull + 2);
-        JT_HIP(hipMemcpyAsync(btp, h->d_scr1.p, sizeof(double) * (nfull + 2), hipMemcpyDeviceToHost, h->stream));
+        JT_HIP(hipMemcpyAsync(btp, h->d_scr1.p, sizeof(double) * (nfull + 2), hipMemcpyDeviceToHost, a3));
         J->btp = btp;
-        jt_kweight_enqueue_f32(h, x, n, sr, blk, &J->kw);
+        jt_kweight_enqueue_f32(h, x, n, sr, blk, &J->kw, a3);
     }
     if (J->want_spec) {
         const int win = 2048, hop = win / 2;
-        ensure_twiddle(h, win); ensure_hann(h, win);
         const int64_t nhops = (n + hop - 1) / hop;
         int64_t nframes = 0;
         if (sel_blk > 0) nframes = n / sel_blk + ((n % sel_blk) ? 1 : 0);
         const int64_t nout = sel_blk > 0 ? nframes : nhops;
         J->nhops = nhops; J->nout = nout;
         h->spec_hops.ensure((size_t)std::max<int64_t>(nout, 1));
-        launch_aspectralstats(x, n, sr, win, h->twiddle.p, h->hann.p, h->spec_hops.p, nhops, sel_blk, nframes, h->stream);
+        launch_aspectralstats(x, n, sr, win, h->twiddle.p, h->hann.p, h->spec_hops.p, nhops, sel_blk, nframes, a2);
         jt_spectral *hops = h->pin.take<jt_spectral>((size_t)std::max<int64_t>(nout, 1));
-        if (nout > 0) JT_HIP(hipMemcpyAsync(hops, h->spec_hops.p, sizeof(jt_spectral) * nout, hipMemcpyDeviceToHost, h->stream));
+        if (nout > 0) JT_HIP(hipMemcpyAsync(hops, h->spec_hops.p, sizeof(jt_spectral) * nout, hipMemcpyDeviceToHost, a2));
         J->hops = hops;
     }
+    if (join) analysis_join(h);
 }
 
 static void analysis_finish(const AnalysisJob &J, AnalysisHost *A)
@@ -455,9 +481,10 @@ extern "C" int jt_pass2(jt_ctx *h, const jt_filter_params *p, jt_analysis *out)
     }
     check_cancel(h);
     AnalysisJob J;
-    analysis_enqueue(h, cur, n, sr, true, sr / 10, &J);
+    analysis_enqueue(h, cur, n, sr, true, sr / 10, &J, false);
     const int out_rate = p->out_rate > 0 ? p->out_rate : 44100;
-    run_resample_s16(h, cur, n, sr, out_rate, h->s16_p2, &h->m_p2);
+    run_resample_s16(h, cur, n, sr, out_rate, h->s16_p2, &h->m_p2);     // main stream, concurrent with the analysis chains
+    analysis_join(h);
     h->out_rate = out_rate; h->m_p4 = 0;
     JT_HIP(hipEventRecord(h->ev1, h->stream));
     JT_HIP(hipEventSynchronize(h->ev1));
@@ -502,11 +529,11 @@ static void loudnorm_measure_enqueue(jt_ctx *h, const int16_t *s16, const double
     if (s16) {
         h->stream_f.ensure((size_t)m_total);
         launch_resample_stream_s16_f32(s16, n, sw.bank_f.p, sw.pl.phase_count, sw.pl.filter_length, sw.pl.center, sw.pl.step, m_total, h->stream_f.p, h->stream);
-        jt_kweight_enqueue_f32(h, h->stream_f.p, m_total, 192000, blk, &J->kw);
+        jt_kweight_enqueue_f32(h, h->stream_f.p, m_total, 192000, blk, &J->kw, h->stream);
     } else {
         h->stream_d.ensure((size_t)m_total);
         launch_resample_stream_f64(f64, n, sw.bank_d.p, sw.pl.phase_count, sw.pl.filter_length, sw.pl.center, sw.pl.step, m_total, h->stream_d.p, h->stream);
-        jt_kweight_enqueue_f64(h, h->stream_d.p, m_total, 192000, blk, &J->kw);
+        jt_kweight_enqueue_f64(h, h->stream_d.p, m_total, 192000, blk, &J->kw, h->stream);
     }
 }
 static void loudnorm_measure_finish(const LoudnormJob &J, jt_loudnorm_stats *out)
@@ -580,7 +607,7 @@ extern "C" int jt_pass4(jt_ctx *h, const jt_limiter_plan *lim, const jt_loudnorm
     check_cancel(h);
     // loudnorm r128_in / r128_out statistics (libavfilter/ebur128.c) at the stream rate
     KwJob sj; const int sblk = (rate + 5) / 10;
-    if (stats) jt_kweight_enqueue_f64(h, sig, m, rate, sblk, &sj);
+    if (stats) { fork_aux(h, 3, 3); jt_kweight_enqueue_f64(h, sig, m, rate, sblk, &sj, h->aux[3]); }   // joined with the analysis below
     // adeclick: restated as pass-through (SURVEY f4 "next" row); see DESIGN.md
     // brickwall alimiter on x*gain
     run_limiter(h, sig, tmp, m, rate, ap->brickwall_limit, 1.0, 50.0, gain);
@@ -633,12 +660,9 @@ extern "C" int jt_region_measure_pair(jt_ctx *h, int stage, const double start_s
     pass_begin(h, std::max<int64_t>(len[0] + len[1], 1), 2);
     h->region_f.ensure((size_t)(len[0] + len[1] + 1));
     AnalysisJob J[2];
-    for (int r = 0; r < 2; ++r) {
-        if (!want[r]) continue;
-        float *x = h->region_f.p + (r ? len[0] : 0);
-        launch_s16_to_f32(src + s0[r], x, len[r], h->stream);
-        analysis_enqueue(h, x, len[r], rate, false, rate / 10, &J[r]);
-    }
+    for (int r = 0; r < 2; ++r) if (want[r]) launch_s16_to_f32(src + s0[r], h->region_f.p + (r ? len[0] : 0), len[r], h->stream);
+    for (int r = 0; r < 2; ++r) if (want[r]) analysis_enqueue(h, h->region_f.p + (r ? len[0] : 0), len[r], rate, false, rate / 10, &J[r], false);
+    analysis_join(h);
     JT_HIP(hipStreamSynchronize(h->stream));
     for (int r = 0; r < 2; ++r) {
         if (!want[r]) continue;
@@ -808,7 +832,7 @@ extern "C" int jt_op_astats(jt_ctx *h, const float *in, int64_t n, int sr, jt_as
     JT_REQUIRE(in && out && n > 0, JT_E_INVAL, "op_astats: bad arguments");
     DevBuf<float> a; h2d(h, a, in, (size_t)n);
     pass_begin(h, n, 1);
-    AstatsJob J; jt_astats_enqueue(h, a.p, n, sr, &J);
+    AstatsJob J; jt_astats_enqueue(h, a.p, n, sr, &J, h->stream, h->stream, h->stream);
     JT_HIP(hipStreamSynchronize(h->stream));
     jt_astats_finish(&J, out);
     JT_API_END(h)

@@ -154,11 +154,12 @@ struct AstatsJob {
     size_t o_part = 0, o_runs = 0, o_nf = 0, o_smin = 0, o_smax = 0;
     int nparts = 0, nf_parts = 0, nsig = 0; bool have_nf = false; int64_t n = 0;
 };
-void jt_astats_enqueue(jt_ctx *h, const float *x, int64_t n, int sr, AstatsJob *job);
+// sA: reduce -> min/max -> runs; sB: noise floor; sC: exp-average sigma chain (three independent chains; pass the same stream to serialise)
+void jt_astats_enqueue(jt_ctx *h, const float *x, int64_t n, int sr, AstatsJob *job, hipStream_t sA, hipStream_t sB, hipStream_t sC);
 void jt_astats_finish(const AstatsJob *job, jt_astats *out);
 struct KwJob { const double *hc = nullptr; int64_t nchunks = 0, nfull = 0; int m = 1; };
-void jt_kweight_enqueue_f32(jt_ctx *h, const float *in, int64_t n, int rate, int blk, KwJob *job);
-void jt_kweight_enqueue_f64(jt_ctx *h, const double *in, int64_t n, int rate, int blk, KwJob *job);
+void jt_kweight_enqueue_f32(jt_ctx *h, const float *in, int64_t n, int rate, int blk, KwJob *job, hipStream_t s);
+void jt_kweight_enqueue_f64(jt_ctx *h, const double *in, int64_t n, int rate, int blk, KwJob *job, hipStream_t s);
 // sums/peaks: nfull+1 entries (last = trailing partial block)
 void jt_kweight_finish(const KwJob *job, std::vector<double> &sums, std::vector<double> &peaks);
 size_t jt_arena_bytes_for(int64_t n);          // generous bound on the arena bytes one analysis of n samples stages
@@ -167,6 +168,10 @@ size_t jt_arena_bytes_for(int64_t n);          // generous bound on the arena by
 struct jt_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
+    // auxiliary streams: the independent parts of an analysis (astats chains, true peak + K-weighting, spectral) are forked
+    // onto them and joined back into `stream` with events, so latency-bound kernels overlap instead of queueing
+    hipStream_t aux[4] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t ev_fork = nullptr, ev_join[4] = {nullptr, nullptr, nullptr, nullptr};
     std::string err;
     std::atomic<int> cancelled{0};
     // input

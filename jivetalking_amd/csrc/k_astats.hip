@@ -392,12 +392,11 @@ size_t jt_arena_bytes_for(int64_t n)
                     + (size_t)(n / 512 + 64) * 16 + (size_t)(n / 800 + 64) * (sizeof(jt_spectral) + 64) + (1u << 20));
 }
 
-void jt_astats_enqueue(jt_ctx *h, const float *x, int64_t n, int sr, AstatsJob *job)
+void jt_astats_enqueue(jt_ctx *h, const float *x, int64_t n, int sr, AstatsJob *job, hipStream_t sA, hipStream_t sB, hipStream_t sC)
 {
     const double time_constant = 0.05;
     const double mult = std::exp((-1 / time_constant / sr));
     const int tc = (int)std::max(time_constant * sr + .5, 1.0);
-    hipStream_t s = h->stream;
     const int nparts = (int)std::min<int64_t>((n + AS_T - 1) / AS_T, 2048);
     const int64_t nchunks = (n + ZC - 1) / ZC;
     const int nsig = (int)((nchunks + 63) / 64);
@@ -414,10 +413,10 @@ void jt_astats_enqueue(jt_ctx *h, const float *x, int64_t n, int sr, AstatsJob *
     double *d_mm = reinterpret_cast<double *>(base + o_mm), *d_zs = reinterpret_cast<double *>(base + o_zs),
            *d_carry = reinterpret_cast<double *>(base + o_carry), *d_smin = reinterpret_cast<double *>(base + o_smin),
            *d_smax = reinterpret_cast<double *>(base + o_smax);
-    h->ehist.ensure(8192); h->ehist.zero(s);
-    hipLaunchKernelGGL(k_as_reduce, dim3(nparts), dim3(AS_T), 0, s, x, n, d_part, h->ehist.p);
-    hipLaunchKernelGGL(k_as_minmax, dim3(1), dim3(64), 0, s, d_part, nparts, d_mm);
-    hipLaunchKernelGGL(k_as_runs, dim3(nparts), dim3(AS_T), 0, s, x, n, d_mm, d_runs);
+    h->ehist.ensure(8192); h->ehist.zero(sA);
+    hipLaunchKernelGGL(k_as_reduce, dim3(nparts), dim3(AS_T), 0, sA, x, n, d_part, h->ehist.p);
+    hipLaunchKernelGGL(k_as_minmax, dim3(1), dim3(64), 0, sA, d_part, nparts, d_mm);
+    hipLaunchKernelGGL(k_as_runs, dim3(nparts), dim3(AS_T), 0, sA, x, n, d_mm, d_runs);
     const bool have_nf = n >= tc;
     int nf_parts = nparts;
     if (have_nf) {
@@ -427,21 +426,25 @@ void jt_astats_enqueue(jt_ctx *h, const float *x, int64_t n, int sr, AstatsJob *
             const int64_t ntiles = (n - tc + 1 + NF_TILE - 1) / NF_TILE;
             nf_parts = (int)std::min<int64_t>(ntiles, nparts);
             JT_HIP(hipFuncSetAttribute((const void *)k_as_nf_fused, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-            hipLaunchKernelGGL(k_as_nf_fused, dim3(nf_parts), dim3(AS_T), smem, s, x, n, tc, ntiles, d_nf);
+            hipLaunchKernelGGL(k_as_nf_fused, dim3(nf_parts), dim3(AS_T), smem, sB, x, n, tc, ntiles, d_nf);
         } else {                                   // very low / very high sample rates: van Herk arrays in HBM
             h->as_g.ensure((size_t)n); h->as_p.ensure((size_t)n);
             const int64_t nb = (n + tc - 1) / tc;
-            hipLaunchKernelGGL(k_as_gp, dim3((unsigned)((nb + 63) / 64)), dim3(64), 0, s, x, h->as_g.p, h->as_p.p, n, tc);
-            hipLaunchKernelGGL(k_as_noise_floor, dim3(nparts), dim3(AS_T), 0, s, h->as_g.p, h->as_p.p, n, tc, d_nf);
+            hipLaunchKernelGGL(k_as_gp, dim3((unsigned)((nb + 63) / 64)), dim3(64), 0, sB, x, h->as_g.p, h->as_p.p, n, tc);
+            hipLaunchKernelGGL(k_as_noise_floor, dim3(nparts), dim3(AS_T), 0, sB, h->as_g.p, h->as_p.p, n, tc, d_nf);
         }
     }
-    hipLaunchKernelGGL(k_as_zs, dim3((unsigned)nsig), dim3(64), 0, s, x, n, mult, d_zs, nchunks);
-    hipLaunchKernelGGL(k_as_scan, dim3(1), dim3(SCAN_T), 0, s, d_zs, d_carry, nchunks, std::pow(mult, (double)ZC), n, mult);
-    hipLaunchKernelGGL(k_as_sigma, dim3((unsigned)nsig), dim3(64), 0, s, x, n, tc, mult, d_carry, d_smin, d_smax, nchunks);
+    hipLaunchKernelGGL(k_as_zs, dim3((unsigned)nsig), dim3(64), 0, sC, x, n, mult, d_zs, nchunks);
+    hipLaunchKernelGGL(k_as_scan, dim3(1), dim3(SCAN_T), 0, sC, d_zs, d_carry, nchunks, std::pow(mult, (double)ZC), n, mult);
+    hipLaunchKernelGGL(k_as_sigma, dim3((unsigned)nsig), dim3(64), 0, sC, x, n, tc, mult, d_carry, d_smin, d_smax, nchunks);
     unsigned char *hb = h->pin.take<unsigned char>(head);
     unsigned long long *eh = h->pin.take<unsigned long long>(8192);
-    JT_HIP(hipMemcpyAsync(hb, base, head, hipMemcpyDeviceToHost, s));
-    JT_HIP(hipMemcpyAsync(eh, h->ehist.p, sizeof(unsigned long long) * 8192, hipMemcpyDeviceToHost, s));
+    // one copy per chain, each covering the bytes that chain wrote (the chains may run on different streams)
+    JT_HIP(hipMemcpyAsync(hb + o_part, base + o_part, o_nf - o_part, hipMemcpyDeviceToHost, sA));          // partials | runs
+    JT_HIP(hipMemcpyAsync(hb + o_mm, base + o_mm, 16, hipMemcpyDeviceToHost, sA));
+    JT_HIP(hipMemcpyAsync(eh, h->ehist.p, sizeof(unsigned long long) * 8192, hipMemcpyDeviceToHost, sA));
+    if (have_nf) JT_HIP(hipMemcpyAsync(hb + o_nf, base + o_nf, o_mm - o_nf, hipMemcpyDeviceToHost, sB));
+    JT_HIP(hipMemcpyAsync(hb + o_smin, base + o_smin, head - o_smin, hipMemcpyDeviceToHost, sC));
     job->hb = hb; job->eh = eh; job->o_part = o_part; job->o_runs = o_runs; job->o_nf = o_nf; job->o_smin = o_smin; job->o_smax = o_smax;
     job->nparts = nparts; job->nf_parts = nf_parts; job->nsig = nsig; job->have_nf = have_nf; job->n = n;
 }

@@ -367,7 +367,7 @@ static void mat4_mul(const double *A, const double *B, double *C)
 // Per-100ms-block K-weighted energies and sample peaks of a device signal.  enqueue: both kernels + the async copy of the
 // per-chunk partials into the pinned arena; finish (after the pass's sync): per-block sums in chunk order.
 template <typename TIn>
-static void kweight_enqueue(jt_ctx *h, const TIn *in, int64_t n, int rate, int blk, KwJob *job)
+static void kweight_enqueue(jt_ctx *h, const TIn *in, int64_t n, int rate, int blk, KwJob *job, hipStream_t st)
 {
     BiquadF64 pre, rlb; jt_kweight_design(rate, &pre, &rlb);
     KwCoef k{pre.b0, pre.b1, pre.b2, pre.a1, pre.a2, rlb.b0, rlb.b1, rlb.b2, rlb.a1, rlb.a2};
@@ -395,18 +395,18 @@ static void kweight_enqueue(jt_ctx *h, const TIn *in, int64_t n, int rate, int b
     const size_t need = 4 * (size_t)nchunks + 24 * 16 + 2 * (size_t)nchunks;
     double *base = h->kw_take(need);
     double *d_zs = base, *d_pw = base + 4 * (size_t)nchunks, *d_cs = d_pw + 24 * 16;
-    if (npw) JT_HIP(hipMemcpyAsync(d_pw, pw, sizeof(double) * 16 * npw, hipMemcpyHostToDevice, h->stream));
+    if (npw) JT_HIP(hipMemcpyAsync(d_pw, pw, sizeof(double) * 16 * npw, hipMemcpyHostToDevice, st));
     const unsigned grid = (unsigned)((nchunks + LANES - 1) / LANES);
-    hipLaunchKernelGGL((k_kw<TIn, false>), dim3(grid), dim3(LANES), 0, h->stream, in, n, L, k, (const double *)nullptr, (const double *)nullptr, 0,
+    hipLaunchKernelGGL((k_kw<TIn, false>), dim3(grid), dim3(LANES), 0, st, in, n, L, k, (const double *)nullptr, (const double *)nullptr, 0,
                        d_zs, (double *)nullptr, (double *)nullptr, nchunks);
-    hipLaunchKernelGGL((k_kw<TIn, true>), dim3(grid), dim3(LANES), 0, h->stream, in, n, L, k, d_zs, d_pw, nterms,
+    hipLaunchKernelGGL((k_kw<TIn, true>), dim3(grid), dim3(LANES), 0, st, in, n, L, k, d_zs, d_pw, nterms,
                        (double *)nullptr, d_cs, d_cs + nchunks, nchunks);
     double *hc = h->pin.take<double>((size_t)nchunks * 2);
-    JT_HIP(hipMemcpyAsync(hc, d_cs, sizeof(double) * nchunks * 2, hipMemcpyDeviceToHost, h->stream));
+    JT_HIP(hipMemcpyAsync(hc, d_cs, sizeof(double) * nchunks * 2, hipMemcpyDeviceToHost, st));
     job->hc = hc; job->nchunks = nchunks; job->nfull = n / blk; job->m = m;
 }
-void jt_kweight_enqueue_f32(jt_ctx *h, const float *in, int64_t n, int rate, int blk, KwJob *job) { kweight_enqueue<float>(h, in, n, rate, blk, job); }
-void jt_kweight_enqueue_f64(jt_ctx *h, const double *in, int64_t n, int rate, int blk, KwJob *job) { kweight_enqueue<double>(h, in, n, rate, blk, job); }
+void jt_kweight_enqueue_f32(jt_ctx *h, const float *in, int64_t n, int rate, int blk, KwJob *job, hipStream_t s) { kweight_enqueue<float>(h, in, n, rate, blk, job, s); }
+void jt_kweight_enqueue_f64(jt_ctx *h, const double *in, int64_t n, int rate, int blk, KwJob *job, hipStream_t s) { kweight_enqueue<double>(h, in, n, rate, blk, job, s); }
 void jt_kweight_finish(const KwJob *job, std::vector<double> &sums, std::vector<double> &peaks)
 {
     const int64_t nfull = job->nfull, nchunks = job->nchunks;
