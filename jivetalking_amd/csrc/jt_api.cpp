@@ -2,6 +2,7 @@
 // Orchestrates the four device-side sweeps over a file that stays resident in HBM as contiguous PCM.
 #include "jt_internal.h"
 #include <algorithm>
+#include <cstdlib>
 #include <memory>
 
 #define JT_API_BEGIN(h) if (!(h)) return JT_E_INVAL; try { JT_HIP(hipSetDevice((h)->device));
@@ -16,6 +17,9 @@ extern "C" int jt_open(int device_id, jt_ctx **out)
 {
     if (!out) return JT_E_INVAL;
     *out = nullptr;
+    // one context drives five streams (main + four analysis chains); ROCclr multiplexes streams onto GPU_MAX_HW_QUEUES (default 4)
+    // hardware queues, fixed when the runtime initialises.  Ask for more unless the host application already decided.
+    setenv("GPU_MAX_HW_QUEUES", "8", 0);
     int count = 0;
     if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) return JT_E_NOGPU;
     if (device_id < 0 || device_id >= count) return JT_E_INVAL;

@@ -264,7 +264,8 @@ k_as_nf_fused(const float *__restrict__ x, int64_t n, int tc, int64_t ntiles, As
 // exponential power average: zero-state response of each chunk (one thread per chunk, coalesced through LDS rows)
 constexpr int ZC = 1024;     // chunk length
 __global__ void __launch_bounds__(64)
-k_as_zs(const float *__restrict__ x, int64_t n, double mult, double *__restrict__ zs, int64_t nchunks)
+k_as_zs(const float *__restrict__ x, int64_t n, double mult, double mult_chunk, double *__restrict__ zs, double *__restrict__ blkA,
+        double *__restrict__ blkB, int64_t nchunks)
 {
     __shared__ float tile[64][65];
     const int lane = threadIdx.x;
@@ -291,50 +292,32 @@ k_as_zs(const float *__restrict__ x, int64_t n, double mult, double *__restrict_
         __syncthreads();
     }
     if (lane < nrows) zs[c0 + lane] = z;
+    // affine map of this block's 64 chunks (s_out = A s_in + B), composed in chunk order by a wave scan
+    double A = 1.0, B = 0.0;
+    if (lane < nrows) {
+        const int64_t len = min((int64_t)ZC, n - (c0 + lane) * ZC);
+        A = (len == ZC) ? mult_chunk : pow(mult, (double)len);
+        B = z;
+    }
+    for (int o = 1; o < 64; o <<= 1) {
+        const double Ap = __shfl_up(A, o, 64), Bp = __shfl_up(B, o, 64);
+        if (lane >= o) { B = A * Bp + B; A = A * Ap; }
+    }
+    if (lane == 63) { blkA[blockIdx.x] = A; blkB[blockIdx.x] = B; }
 }
 
-// carry scan s_{c+1} = A_c * s_c + B_c (A_c = mult^len_c, B_c = zero-state response of chunk c): 16 waves each own a
-// contiguous range of chunks; pass 1 composes the range's affine map (wave-level scan per 64 chunks, coalesced loads),
-// the 16 maps are chained through LDS, pass 2 replays the range writing the state ENTERING every chunk.
-constexpr int SCAN_T = 1024;
-__global__ void __launch_bounds__(SCAN_T)
-k_as_scan(const double *__restrict__ zs, double *__restrict__ carry, int64_t nchunks, double mult_chunk, int64_t n, double mult)
+// carry scan over the per-block affine maps (one map per 64 chunks, composed in k_as_zs): state entering every block.
+// One wave; 64 maps per round by a wave-level inclusive scan, the loads of the next round issued ahead.
+__global__ void __launch_bounds__(64)
+k_as_scan(const double *__restrict__ blkA, const double *__restrict__ blkB, double *__restrict__ blk_in, int64_t nblocks)
 {
-    __shared__ double sA[SCAN_T / 64], sB[SCAN_T / 64], sIn[SCAN_T / 64];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int64_t per = (((nchunks + SCAN_T / 64 - 1) / (SCAN_T / 64)) + 63) / 64 * 64;     // chunks per wave, multiple of 64
-    const int64_t lo = (int64_t)wave * per, hi = min(lo + per, nchunks);
-    auto load = [&](int64_t c, double &A, double &B) {
-        A = 1.0; B = 0.0;
-        if (c < hi) {
-            const int64_t len = min((int64_t)ZC, n - c * ZC);
-            A = (len == ZC) ? mult_chunk : pow(mult, (double)len);
-            B = zs[c];
-        }
-    };
-    // pass 1: composite map of the wave's range
-    double RA = 1.0, RB = 0.0;
-    for (int64_t base = lo; base < hi; base += 64) {
-        double A, B; load(base + lane, A, B);
-        for (int o = 1; o < 64; o <<= 1) {
-            const double Ap = __shfl_up(A, o, 64), Bp = __shfl_up(B, o, 64);
-            if (lane >= o) { B = A * Bp + B; A = A * Ap; }
-        }
-        const double TA = __shfl(A, 63, 64), TB = __shfl(B, 63, 64);     // map of these 64 chunks
-        RB = TA * RB + TB; RA = TA * RA;
-    }
-    if (lane == 0) { sA[wave] = RA; sB[wave] = RB; }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        double st = 0.0;
-        for (int w = 0; w < SCAN_T / 64; ++w) { sIn[w] = st; st = sA[w] * st + sB[w]; }
-    }
-    __syncthreads();
-    // pass 2: replay with the entering state
-    double carry_in = sIn[wave];
-    for (int64_t base = lo; base < hi; base += 64) {
-        const int64_t c = base + lane;
-        double A, B; load(c, A, B);
+    const int lane = threadIdx.x;
+    double carry_in = 0.0;
+    double nA = lane < nblocks ? blkA[lane] : 1.0, nB = lane < nblocks ? blkB[lane] : 0.0;
+    for (int64_t base = 0; base < nblocks; base += 64) {
+        double A = nA, B = nB;
+        const int64_t nx = base + 64 + lane;
+        nA = nx < nblocks ? blkA[nx] : 1.0; nB = nx < nblocks ? blkB[nx] : 0.0;
         for (int o = 1; o < 64; o <<= 1) {
             const double Ap = __shfl_up(A, o, 64), Bp = __shfl_up(B, o, 64);
             if (lane >= o) { B = A * Bp + B; A = A * Ap; }
@@ -342,20 +325,34 @@ k_as_scan(const double *__restrict__ zs, double *__restrict__ carry, int64_t nch
         const double s_after = A * carry_in + B;
         double prev = __shfl_up(s_after, 1, 64);
         if (lane == 0) prev = carry_in;
-        if (c < hi) carry[c] = prev;
+        if (base + lane < nblocks) blk_in[base + lane] = prev;
         carry_in = __shfl(s_after, 63, 64);
     }
 }
 
 __global__ void __launch_bounds__(64)
-k_as_sigma(const float *__restrict__ x, int64_t n, int tc, double mult, const double *__restrict__ carry, double *__restrict__ out_min,
-           double *__restrict__ out_max, int64_t nchunks)
+k_as_sigma(const float *__restrict__ x, int64_t n, int tc, double mult, double mult_chunk, const double *__restrict__ zs,
+           const double *__restrict__ blk_in, double *__restrict__ out_min, double *__restrict__ out_max, int64_t nchunks)
 {
     __shared__ float tile[64][65];
     const int lane = threadIdx.x;
     const int64_t c0 = (int64_t)blockIdx.x * 64;
     const int nrows = (int)min((int64_t)64, nchunks - c0);
-    double avg = lane < nrows ? carry[c0 + lane] : 0.0, mn = DBL_MAX, mx = 0.0;
+    // state entering this lane's chunk: the block's entering state pushed through the preceding chunks of the block
+    double avg;
+    {
+        double A = 1.0, B = 0.0;
+        if (lane < nrows) { A = mult_chunk; B = zs[c0 + lane]; }     // only a file's last chunk is short, and nothing follows it
+        for (int o = 1; o < 64; o <<= 1) {
+            const double Ap = __shfl_up(A, o, 64), Bp = __shfl_up(B, o, 64);
+            if (lane >= o) { B = A * Bp + B; A = A * Ap; }
+        }
+        const double cin = blk_in[blockIdx.x];
+        const double s_after = A * cin + B;
+        avg = __shfl_up(s_after, 1, 64);
+        if (lane == 0) avg = cin;
+    }
+    double mn = DBL_MAX, mx = 0.0;
     const double om = 1.0 - mult;
     for (int pos = 0; pos < ZC; pos += 64) {
         float v[16];
@@ -404,7 +401,7 @@ void jt_astats_enqueue(jt_ctx *h, const float *x, int64_t n, int sr, AstatsJob *
     const size_t o_part = 0, o_runs = o_part + sizeof(AsPartial) * nparts, o_nf = o_runs + sizeof(AsRuns) * nparts,
                  o_mm = o_nf + sizeof(AsNF) * nparts, o_smin = o_mm + 16, o_smax = o_smin + 8 * (size_t)nsig,
                  head = o_smax + 8 * (size_t)nsig, o_zs = head, o_carry = o_zs + 8 * (size_t)nchunks,
-                 total = o_carry + 8 * (size_t)nchunks;
+                 total = o_carry + 8 * 3 * (size_t)nsig;      // blkA | blkB | blk_in
     h->d_scr2.ensure((total + 7) / 8);
     unsigned char *base = reinterpret_cast<unsigned char *>(h->d_scr2.p);
     AsPartial *d_part = reinterpret_cast<AsPartial *>(base + o_part);
@@ -434,9 +431,11 @@ void jt_astats_enqueue(jt_ctx *h, const float *x, int64_t n, int sr, AstatsJob *
             hipLaunchKernelGGL(k_as_noise_floor, dim3(nparts), dim3(AS_T), 0, sB, h->as_g.p, h->as_p.p, n, tc, d_nf);
         }
     }
-    hipLaunchKernelGGL(k_as_zs, dim3((unsigned)nsig), dim3(64), 0, sC, x, n, mult, d_zs, nchunks);
-    hipLaunchKernelGGL(k_as_scan, dim3(1), dim3(SCAN_T), 0, sC, d_zs, d_carry, nchunks, std::pow(mult, (double)ZC), n, mult);
-    hipLaunchKernelGGL(k_as_sigma, dim3((unsigned)nsig), dim3(64), 0, sC, x, n, tc, mult, d_carry, d_smin, d_smax, nchunks);
+    const double mult_chunk = std::pow(mult, (double)ZC);
+    double *d_blkA = d_carry, *d_blkB = d_carry + nsig, *d_blkin = d_carry + 2 * (size_t)nsig;
+    hipLaunchKernelGGL(k_as_zs, dim3((unsigned)nsig), dim3(64), 0, sC, x, n, mult, mult_chunk, d_zs, d_blkA, d_blkB, nchunks);
+    hipLaunchKernelGGL(k_as_scan, dim3(1), dim3(64), 0, sC, d_blkA, d_blkB, d_blkin, (int64_t)nsig);
+    hipLaunchKernelGGL(k_as_sigma, dim3((unsigned)nsig), dim3(64), 0, sC, x, n, tc, mult, mult_chunk, d_zs, d_blkin, d_smin, d_smax, nchunks);
     unsigned char *hb = h->pin.take<unsigned char>(head);
     unsigned long long *eh = h->pin.take<unsigned long long>(8192);
     // one copy per chain, each covering the bytes that chain wrote (the chains may run on different streams)
