@@ -440,19 +440,28 @@ k_afftdn(const float *__restrict__ in, float *__restrict__ out, int64_t n, Afftd
     const double max_gain = d.max_gain;
 
     int off = (int)(((t0 % 3) * (int64_t)A) % W);            // circular overlap-add origin: slot of frame sample 0
+    // the frame's samples are fetched one frame ahead so the HBM round trip hides behind the previous frame's transforms
+    float xr[2 * QP];
+    auto fetch = [&](int64_t t) {
+        const int64_t start = t * A - (W - A);
+#pragma unroll
+        for (int q = 0; q < QP; ++q) {
+            const int m = tid + q * FT;
+            const int64_t k0 = start + 2 * m, k1 = k0 + 1;
+            xr[2 * q] = (m < H && 2 * m < W && k0 >= 0 && k0 < n) ? in[k0] : 0.f;
+            xr[2 * q + 1] = (m < H && 2 * m + 1 < W && k1 >= 0 && k1 < n) ? in[k1] : 0.f;
+        }
+    };
+    fetch(t0);
     for (int64_t t = t0; t < t_hi; ++t) {
         const int64_t start = t * A - (W - A);
         // ---- windowed frame -> packed complex
 #pragma unroll
         for (int q = 0; q < QP; ++q) {
             const int m = tid + q * FT;
-            if (m < H) {
-                const int64_t k0 = start + 2 * m, k1 = k0 + 1;
-                const float x0 = (2 * m < W && k0 >= 0 && k0 < n) ? in[k0] : 0.f;
-                const float x1 = (2 * m + 1 < W && k1 >= 0 && k1 < n) ? in[k1] : 0.f;
-                bufA[m] = make_float2((float)(win[2 * q] * x0 * 8388608.0), (float)(win[2 * q + 1] * x1 * 8388608.0));
-            }
+            if (m < H) bufA[m] = make_float2((float)(win[2 * q] * xr[2 * q] * 8388608.0), (float)(win[2 * q + 1] * xr[2 * q + 1] * 8388608.0));
         }
+        if (t + 1 < t_hi) fetch(t + 1);
         __syncthreads();
         float2 *Z = fft_stockham<LOG2N - 1, false>(bufA, bufB, tw);
         float2 *Zo = (Z == bufA) ? bufB : bufA;
@@ -508,12 +517,13 @@ k_afftdn(const float *__restrict__ in, float *__restrict__ out, int64_t n, Afftd
             band_excit[tid] = e;
         }
         __syncthreads();
-        if (tid < nb) {
+        // masking amounts: spread (nb x nb) times the band excitations, 8 lanes per band + a 3-step shuffle reduction
+        for (int b = tid >> 3; b < nb; b += FT / 8) {
             double a = 0.0;
-            const double *sp = spread + tid * nb;
-            for (int k = 0; k < nb; ++k) a += sp[k] * band_excit[k];
-            band_amt[tid] = a;
-            band_rs[tid] = 1.0 / sqrt(a);
+            const double *sp = spread + b * nb;
+            for (int k = tid & 7; k < nb; k += 8) a += sp[k] * band_excit[k];
+            a += __shfl_xor(a, 1, 64); a += __shfl_xor(a, 2, 64); a += __shfl_xor(a, 4, 64);
+            if ((tid & 7) == 0) { band_amt[b] = a; band_rs[b] = 1.0 / sqrt(a); }
         }
         __syncthreads();
         const bool need_out = (t + 2 >= t_lo);     // frames whose overlap-add reaches the emitted range
@@ -582,8 +592,9 @@ void launch_afftdn(const float *in, float *out, int64_t n, const AfftdnDev &d, i
     JT_REQUIRE(d.nbands <= AF_MAXBANDS, JT_E_UNSUPPORTED, "afftdn: too many bark bands");
     int64_t nframes = (n + d.A - 1) / d.A + (d.W - d.A) / d.A;
     if (frames_per_chunk <= 0) {
-        // one resident round of workgroups where possible (256 CUs x 3 workgroups), chunks of 128..512 frames
-        frames_per_chunk = (int)std::min<int64_t>(512, std::max<int64_t>(128, (nframes + 767) / 768));
+        // one resident round of workgroups: the kernel's register footprint admits 2 workgroups per CU (256 CUs), so 512 chunks;
+        // never shorter than 128 frames (warm-up overhead) nor longer than 1024
+        frames_per_chunk = (int)std::min<int64_t>(1024, std::max<int64_t>(128, (nframes + 511) / 512));
     }
     unsigned grid = (unsigned)((nframes + frames_per_chunk - 1) / frames_per_chunk);
     const size_t H = d.L / 2, nseg = 2 * ((H / 2 + 63) / 64) + 1;
