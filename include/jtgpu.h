@@ -169,6 +169,7 @@ typedef struct {              /* loudnorm second pass options (normalise.go:1269
     double measured_i, measured_tp, measured_lra, measured_thresh;
     double offset;
     int    adeclick_enabled;  double adeclick_threshold, adeclick_window_ms, adeclick_overlap_pct;   /* filters.go:947-962 */
+    int    adeclick_method;   /* 1 = m=s (overlap-save, the reference default filters.go:513-521), 0 = option omitted (overlap-add) */
     double brickwall_limit;   /* alimiter limit= (linear) attack=1 release=50 (normalise.go:474-480) */
 } jt_loudnorm_apply;
 
@@ -184,7 +185,8 @@ int jt_output_len(jt_ctx *h, int stage, int64_t *n);
 int jt_download_s16(jt_ctx *h, int stage, int16_t *dst, int64_t cap, int64_t *n);
 
 /* ---- per-pass device timers (ms, HIP events on the engine stream) for the roofline report ---- */
-typedef struct { double pass1_ms, pass2_ms, pass3_ms, pass4_ms; double nlm_ms; int64_t nlm_launches; } jt_timers;
+typedef struct { double pass1_ms, pass2_ms, pass3_ms, pass4_ms; double nlm_ms; int64_t nlm_launches;
+                 int64_t declick_repaired;   /* samples adeclick re-interpolated in the last Pass 4 (diagnostic) */ } jt_timers;
 int jt_get_timers(jt_ctx *h, jt_timers *out);
 
 /* =====================================================================================
@@ -202,6 +204,9 @@ int jt_op_afftdn_f32(jt_ctx *h, const float *in, float *out, int64_t n, int samp
 int jt_op_dynamics(jt_ctx *h, const float *in, float *out, int64_t n, int sample_rate, const jt_filter_params *p);
 int jt_op_alimiter_f64(jt_ctx *h, const double *in, double *out, int64_t n, int sample_rate,
                        double limit, double attack_ms, double release_ms);
+/* adeclick=t:w:o[:m=s] on a double stream (af_adeclick.c; arorder=2, burst=2 defaults).  method: 1 = overlap-save. */
+int jt_op_adeclick_f64(jt_ctx *h, const double *in, double *out, int64_t n, int sr, double threshold, double window_ms,
+                       double overlap_pct, int method, int64_t *n_repaired);
 int jt_op_resample_f32_to_s16(jt_ctx *h, const float *in, int64_t n, int in_rate, int out_rate,
                               int16_t *out, int64_t cap, int64_t *n_out);
 int jt_op_ebur128(jt_ctx *h, const float *in, int64_t n, int sample_rate, int dualmono, jt_r128 *out,

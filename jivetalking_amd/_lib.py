@@ -89,13 +89,14 @@ class LoudnormApply(C.Structure):
                 ("measured_i", C.c_double), ("measured_tp", C.c_double), ("measured_lra", C.c_double),
                 ("measured_thresh", C.c_double), ("offset", C.c_double),
                 ("adeclick_enabled", C.c_int), ("adeclick_threshold", C.c_double),
-                ("adeclick_window_ms", C.c_double), ("adeclick_overlap_pct", C.c_double),
+                ("adeclick_window_ms", C.c_double), ("adeclick_overlap_pct", C.c_double), ("adeclick_method", C.c_int),
                 ("brickwall_limit", C.c_double)]
 
 
 class Timers(C.Structure):
     _fields_ = [("pass1_ms", C.c_double), ("pass2_ms", C.c_double), ("pass3_ms", C.c_double),
-                ("pass4_ms", C.c_double), ("nlm_ms", C.c_double), ("nlm_launches", C.c_int64)]
+                ("pass4_ms", C.c_double), ("nlm_ms", C.c_double), ("nlm_launches", C.c_int64),
+                ("declick_repaired", C.c_int64)]
 
 
 # every symbol include/jtgpu.h declares
@@ -104,7 +105,7 @@ SYMBOLS = [
     "jt_upload_pcm", "jt_attach_device_pcm", "jt_upload_s16",
     "jt_pass1", "jt_band_rms", "jt_pass2", "jt_region_measure", "jt_region_measure_pair", "jt_pass3", "jt_pass4",
     "jt_output_len", "jt_download_s16", "jt_get_timers",
-    "jt_op_biquad_f32", "jt_op_anlmdn_f32", "jt_op_afftdn_f32", "jt_op_dynamics", "jt_op_alimiter_f64",
+    "jt_op_biquad_f32", "jt_op_anlmdn_f32", "jt_op_afftdn_f32", "jt_op_dynamics", "jt_op_alimiter_f64", "jt_op_adeclick_f64",
     "jt_op_resample_f32_to_s16", "jt_op_ebur128", "jt_op_astats", "jt_op_aspectralstats",
     "jt_op_loudnorm_measure_s16",
 ]

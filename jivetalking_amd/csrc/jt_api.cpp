@@ -612,9 +612,25 @@ extern "C" int jt_pass4(jt_ctx *h, const jt_limiter_plan *lim, const jt_loudnorm
     // loudnorm r128_in / r128_out statistics (libavfilter/ebur128.c) at the stream rate
     KwJob sj; const int sblk = (rate + 5) / 10;
     if (stats) { fork_aux(h, 3, 3); jt_kweight_enqueue_f64(h, sig, m, rate, sblk, &sj, h->aux[3]); }   // joined with the analysis below
-    // adeclick: restated as pass-through (SURVEY f4 "next" row); see DESIGN.md
-    // brickwall alimiter on x*gain
-    run_limiter(h, sig, tmp, m, rate, ap->brickwall_limit, 1.0, 50.0, gain);
+    // adeclick on the gained stream (af_adeclick.c), then the brickwall alimiter
+    double brick_gain = gain;
+    const unsigned long long *dk_stats = nullptr;
+    if (ap->adeclick_enabled) {
+        std::string why;
+        JT_REQUIRE(jt_adeclick_supported(rate, ap->adeclick_window_ms, ap->adeclick_overlap_pct, 2.0, ap->adeclick_method, &why), JT_E_UNSUPPORTED, why);
+        h->declick_stats.ensure(2);
+        JT_HIP(hipMemsetAsync(h->declick_stats.p, 0, 2 * sizeof(unsigned long long), h->stream));
+        launch_adeclick(h, sig, tmp, m, rate, ap->adeclick_threshold, ap->adeclick_window_ms, ap->adeclick_overlap_pct, 2.0, 2.0, gain,
+                        h->declick_stats.p, h->stream);
+        unsigned long long *hs = h->pin.take<unsigned long long>(2);
+        JT_HIP(hipMemcpyAsync(hs, h->declick_stats.p, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));
+        dk_stats = hs;
+        std::swap(sig, tmp);
+        brick_gain = 1.0;
+        // the brickwall writes the buffer the statistics job (aux stream 3) is still reading: join that chain first
+        if (stats) { JT_HIP(hipEventRecord(h->ev_join[3], h->aux[3])); JT_HIP(hipStreamWaitEvent(h->stream, h->ev_join[3], 0)); }
+    }
+    run_limiter(h, sig, tmp, m, rate, ap->brickwall_limit, 1.0, 50.0, brick_gain);
     std::swap(sig, tmp);
     check_cancel(h);
     // dbl -> flt (aspectralstats) -> dbl (ebur128) -> s16
@@ -627,6 +643,10 @@ extern "C" int jt_pass4(jt_ctx *h, const jt_limiter_plan *lim, const jt_loudnorm
     JT_HIP(hipEventRecord(h->ev1, h->stream));
     JT_HIP(hipEventSynchronize(h->ev1));
     check_cancel(h);
+    if (dk_stats) {
+        h->timers.declick_repaired = (int64_t)dk_stats[0];
+        JT_REQUIRE(dk_stats[1] == 0, JT_E_HIP, "adeclick: singular interpolation matrix (af_adeclick.c would fail the graph)");
+    }
     if (stats) {
         const int64_t nfull = m / sblk;
         std::vector<double> bsum, bpk;
@@ -789,6 +809,25 @@ extern "C" int jt_op_alimiter_f64(jt_ctx *h, const double *in, double *out, int6
     DevBuf<double> a, b; h2d(h, a, in, (size_t)n); b.ensure((size_t)n);
     run_limiter(h, a.p, b.p, n, sr, limit, attack_ms, release_ms, 1.0);
     d2h(h, out, b.p, (size_t)n);
+    JT_API_END(h)
+}
+
+extern "C" int jt_op_adeclick_f64(jt_ctx *h, const double *in, double *out, int64_t n, int sr, double threshold, double window_ms,
+                                  double overlap_pct, int method, int64_t *n_repaired)
+{
+    JT_API_BEGIN(h)
+    JT_REQUIRE(in && out && n > 0, JT_E_INVAL, "op_adeclick: bad arguments");
+    std::string why;
+    JT_REQUIRE(jt_adeclick_supported(sr, window_ms, overlap_pct, 2.0, method, &why), JT_E_UNSUPPORTED, why);
+    DevBuf<double> a, b; h2d(h, a, in, (size_t)n); b.ensure((size_t)n);
+    h->declick_stats.ensure(2);
+    JT_HIP(hipMemsetAsync(h->declick_stats.p, 0, 2 * sizeof(unsigned long long), h->stream));
+    launch_adeclick(h, a.p, b.p, n, sr, threshold, window_ms, overlap_pct, 2.0, 2.0, 1.0, h->declick_stats.p, h->stream);
+    unsigned long long st[2] = {0, 0};
+    JT_HIP(hipMemcpyAsync(st, h->declick_stats.p, sizeof(st), hipMemcpyDeviceToHost, h->stream));
+    d2h(h, out, b.p, (size_t)n);
+    if (n_repaired) *n_repaired = (int64_t)st[0];
+    JT_REQUIRE(st[1] == 0, JT_E_HIP, "adeclick: singular interpolation matrix");
     JT_API_END(h)
 }
 

@@ -985,6 +985,7 @@ extern "C" int jt_host_pass4_spec(const jt_host_config *cfg, const jt_loudnorm_s
         ap->offset = qfmt("%.2f", offset);
         ap->adeclick_enabled = cfg->adeclick_enabled; ap->adeclick_threshold = qfmt("%.1f", cfg->adeclick_threshold);
         ap->adeclick_window_ms = qfmt("%.0f", cfg->adeclick_window); ap->adeclick_overlap_pct = qfmt("%.0f", cfg->adeclick_overlap);
+        ap->adeclick_method = cfg->adeclick_method_s ? 1 : 0;
         ap->brickwall_limit = qfmt("%.6f", DbToLinear(brickDB));
     }
     return (int)s.size();

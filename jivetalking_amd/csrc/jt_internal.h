@@ -117,6 +117,12 @@ void launch_afftdn(const float *in, float *out, int64_t n, const AfftdnDev &d, i
 // anlmdn
 void launch_anlmdn(const float *in, float *out, int64_t n, int K, int S, float sw, float smooth, float lut_scale, hipStream_t s);
 
+// adeclick (k_declick.hip)
+struct jt_ctx;
+bool jt_adeclick_supported(int sample_rate, double window_ms, double overlap_pct, double ar_pct, int method, std::string *why);
+void launch_adeclick(jt_ctx *h, const double *in, double *out, int64_t n, int sample_rate, double threshold, double window_ms,
+                     double overlap_pct, double ar_pct, double burst, double gain, unsigned long long *d_stats, hipStream_t s);
+
 // ---------------------------------------------------------------- pinned host staging
 // Every device->host result of a pass lands in one pinned arena, so a pass enqueues all its kernels and copies back to back
 // and synchronises ONCE (pageable destinations would serialise each copy through a bounce buffer).
@@ -204,6 +210,7 @@ struct jt_ctx {
     }
     SwrDev swr[4]; int swr_next = 0;
     DevBuf<float> region_f;
+    DevBuf<double> declick_scr; DevBuf<unsigned long long> declick_stats;
     jt_timers timers{};
     hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr, ev3 = nullptr;
 };

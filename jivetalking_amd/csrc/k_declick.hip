@@ -1,0 +1,309 @@
+// k_declick.hip — adeclick (FFmpeg af_adeclick.c) for gfx950: the click/pop repair of Pass 4
+// (normalise.go:1306-1311; filters.go:947-962, defaults t=1.7 w=55 o=50 m=s, filters.go:513-521).
+//
+// Per window of W = rate*w/1000 samples (hop = W*(1-o/100), overlap-save): biased autocorrelation -> Levinson-Durbin AR
+// model of order W*2% -> prediction error -> samples above threshold*sigma_e flagged (+ burst fusion) -> the flagged samples
+// are replaced by the least-squares AR interpolation, i.e. the solution of a symmetric positive system whose (j,i) entry is
+// the AR-coefficient autocorrelation at lag index[j]-index[i] (zero beyond the AR order).
+//
+// Mapping: ONE WAVE PER WINDOW, windows are independent (131 k of them for an hour at 44.1 kHz), no workgroup barriers.
+// Every floating-point sum keeps FFmpeg's order (sequential, multiply then add), so flags and repaired samples are
+// bit-identical to the scalar code; parallelism comes from the independent sums:
+//   * autocorrelation: lane = lag (49 chains of W terms);   * detection: lane = sample (49-term chains);
+//   * LDL^T of the normal matrix, right-looking, restricted to the true band: entries are zero whenever two flagged samples
+//     are more than the AR order apart, and no fill-in leaves that profile, so with ~10 % of the samples flagged the band is
+//     a handful of rows instead of 48 — the work per pivot is bw*(bw+1)/2 updates, one per lane.  Skipped terms are exact
+//     zeros, and the updates reach every entry in FFmpeg's k-ascending order;
+//   * forward substitution fused into the factorisation sweep; back substitution walks the (short) band per row.
+// LDS per wave: the window's samples (f64), later reused as the 49x49 sliding block of the factorisation.
+#include "jt_internal.h"
+
+namespace dk {
+constexpr int MAXW = 4864;        // window samples (110 ms at 44.1 kHz); LDS: 8*MAXW bytes per wave
+constexpr int MAXAR = 48;         // AR order the sliding block is laid out for (2 % of a 55 ms window at 44.1 kHz)
+constexpr int BS = MAXAR + 1;     // sliding block side
+}
+
+struct DeclickParams {
+    int W, hop, skip, ar, nburst;
+    int sa;                       // doubles reserved for the window samples / factorisation block: max(W, BS*BS), even
+    double threshold, gain;
+    int64_t nwindows;
+};
+
+// value of `v` in lane `l` (l wave-uniform): two v_readlane, no LDS round trip
+__device__ inline double dk_readlane(double v, int l)
+{
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), l), hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
+    return __hiloint2double(hi, lo);
+}
+
+__global__ void __launch_bounds__(64)
+k_adeclick(const double *__restrict__ in, double *__restrict__ out, int64_t n, DeclickParams P, double *scratch,
+           size_t scratch_per_wave, unsigned long long *__restrict__ stats /* [0] repaired samples, [1] singular windows */)
+{
+    extern __shared__ unsigned char dk_smem[];
+    const int lane = threadIdx.x;
+    const int W = P.W, AR = P.ar;
+    constexpr int BS = dk::BS, MAXAR = dk::MAXAR;
+    double *src = reinterpret_cast<double *>(dk_smem);                 // [W] ; later the BS x BS sliding block
+    double *rr = src + P.sa;                                            // r[AR+1]
+    double *ac = rr + BS + 1;                                           // acoefficients k[AR+1]
+    double *aa = ac + BS + 1;                                           // a[AR]
+    double *aux = aa + BS + 1;                                          // aux[AR+1]
+    double *lvec = aux + BS + 1;                                        // pivot column multipliers
+    double *ywin = lvec + BS + 1;                                       // sliding right-hand side / y
+    double *solring = ywin + BS + 1;                                    // most recent solutions (back substitution)
+    unsigned short *index = reinterpret_cast<unsigned short *>(solring + BS + 1);   // [W]
+    unsigned char *click = reinterpret_cast<unsigned char *>(index + ((W + 3) & ~3));   // [W]
+    // global scratch of this wave (cross-lane traffic: volatile = L1-bypassing): L[W][MAXAR] | D[W] | y[W] | rhs[W]
+    volatile double *gL = scratch + (size_t)blockIdx.x * scratch_per_wave;
+    volatile double *gD = gL + (size_t)W * MAXAR, *gY = gD + W, *gV = gY + W;
+    unsigned long long repaired = 0, singular = 0;
+
+    for (int64_t w = blockIdx.x; w < P.nwindows; w += gridDim.x) {
+        const int64_t s0 = w * P.hop - P.skip;                          // input position of src[0]
+        const int64_t o0 = w * P.hop;
+        // ---- 1. window samples (zeros before the stream and past its end), loudnorm's linear gain applied on the way in
+        for (int j = lane; j < W; j += 64) {
+            const int64_t p = s0 + j;
+            src[j] = (p >= 0 && p < n) ? __dmul_rn(in[p], P.gain) : 0.0;
+            click[j] = 0;
+        }
+        // ---- 2. autocorrelation(src, AR, W, r, 1/W): lane = lag, terms in j-ascending order
+        if (lane <= AR) {
+            double value = 0.0;
+            int j = lane;
+            for (; j + 3 < W; j += 4) {
+                const double a0 = src[j], a1 = src[j + 1], a2 = src[j + 2], a3 = src[j + 3];
+                const double b0 = src[j - lane], b1 = src[j + 1 - lane], b2 = src[j + 2 - lane], b3 = src[j + 3 - lane];
+                value = __dadd_rn(value, __dmul_rn(a0, b0)); value = __dadd_rn(value, __dmul_rn(a1, b1));
+                value = __dadd_rn(value, __dmul_rn(a2, b2)); value = __dadd_rn(value, __dmul_rn(a3, b3));
+            }
+            for (; j < W; ++j) value = __dadd_rn(value, __dmul_rn(src[j], src[j - lane]));
+            rr[lane] = __dmul_rn(value, 1.0 / W);
+        }
+        // ---- 3. Levinson-Durbin (autoregression()): k -> ac[], sigma_e = sqrt(alpha)
+        double sigmae;
+        {
+            if (lane < AR) aa[lane] = 0.0;
+            const double r0 = rr[0], r1 = rr[1];
+            const double k0 = -r1 / r0;
+            if (lane == 0) aa[0] = k0;
+            double alpha = __dmul_rn(r0, __dsub_rn(1.0, __dmul_rn(k0, k0)));
+            for (int i = 1; i < AR; ++i) {
+                // epsilon = sum_{j<i} a[j] * r[i-j] (j ascending) + r[i+1]: the products in parallel, the sum as a readlane chain
+                const double prod = lane < i ? __dmul_rn(aa[lane], rr[i - lane]) : 0.0;
+                double eps = 0.0;
+                for (int j = 0; j < i; ++j) eps = __dadd_rn(eps, dk_readlane(prod, j));
+                eps = __dadd_rn(eps, rr[i + 1]);
+                const double ki = -eps / alpha;
+                alpha = __dmul_rn(alpha, __dsub_rn(1.0, __dmul_rn(ki, ki)));
+                // k[j] = a[j] + k[i] * a[i-j-1], j = i-1..0 (independent); k[i] = ki; then a[0..i] = k[0..i]
+                double nk = 0.0;
+                if (lane < i) nk = __dadd_rn(aa[lane], __dmul_rn(ki, aa[i - lane - 1]));
+                else if (lane == i) nk = ki;
+                if (lane <= i) aa[lane] = nk;
+            }
+            if (lane == 0) ac[0] = 1.0;
+            if (lane >= 1 && lane <= AR) ac[lane] = aa[lane - 1];
+            sigmae = sqrt(alpha);
+        }
+        bool finite;
+        {
+            const double v = lane <= AR ? ac[lane] : 0.0;
+            finite = !__any(!isfinite(v));
+        }
+        int F = 0;
+        if (finite) {
+            // ---- 4. detection[i] = sum_{j=0..AR} ac[j] * src[i-j] (j ascending), click = |detection| > sigmae * threshold
+            const double thr = __dmul_rn(sigmae, P.threshold);
+            for (int i0 = AR; i0 < W; i0 += 256) {
+                int ii[4]; double dd[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { ii[q] = i0 + 64 * q + lane; dd[q] = 0.0; if (ii[q] >= W) ii[q] = -1; }
+                for (int j = 0; j <= AR; ++j) {
+                    const double c = ac[j];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) if (ii[q] >= 0) dd[q] = __dadd_rn(dd[q], __dmul_rn(c, src[ii[q] - j]));
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) if (ii[q] >= 0) click[ii[q]] = fabs(dd[q]) > thr;
+            }
+            // ---- 5. burst fusion: the gap between two consecutive flagged samples p < q is filled when 1 < q-p <= nburst
+            //         (the sequential loop only ever compares original flags, bit 0; fills go to bit 1)
+            if (P.nburst > 1) {
+                for (int i0 = 0; i0 < W; i0 += 64) {
+                    const int j = i0 + lane;
+                    if (j < W && !(click[j] & 1)) {
+                        int p = -1, q = -1;
+                        for (int t = 1; t < P.nburst && j - t >= 0; ++t) if (click[j - t] & 1) { p = j - t; break; }
+                        for (int t = 1; t < P.nburst && j + t < W; ++t) if (click[j + t] & 1) { q = j + t; break; }
+                        if (p >= 0 && q >= 0 && q - p <= P.nburst) click[j] |= 2;
+                    }
+                }
+            }
+            // ---- 6. index list of the flagged samples inside [AR, W-AR); click[] becomes that set's indicator
+            for (int i0 = 0; i0 < W; i0 += 64) {
+                const int j = i0 + lane;
+                const bool fl = j >= AR && j < W - AR && click[j] != 0;
+                const unsigned long long bal = __ballot(fl);
+                if (fl) index[F + __popcll(bal & ((1ull << lane) - 1ull))] = (unsigned short)j;
+                if (j < W) click[j] = fl ? 1 : 0;
+                F += __popcll(bal);
+            }
+        }
+        bool ok = true;
+        if (F > 0) {
+            // ---- 7. aux = autocorrelation(ac, AR, AR+1, ., 1.)
+            if (lane <= AR) {
+                double value = 0.0;
+                for (int j = lane; j <= AR; ++j) value = __dadd_rn(value, __dmul_rn(ac[j], ac[j - lane]));
+                aux[lane] = __dmul_rn(value, 1.0);
+            }
+            // ---- 8. right-hand side: vector[e] = -sum_{j=-AR..AR, index[e]-j not flagged} src[index[e]-j] * aux[|j|]
+            for (int e0 = 0; e0 < F; e0 += 64) {
+                const int e = e0 + lane;
+                if (e < F) {
+                    const int ie = index[e];
+                    double value = 0.0;
+                    for (int j = -AR; j <= AR; ++j) {
+                        const int pos = ie - j;
+                        if (!click[pos]) value = __dsub_rn(value, __dmul_rn(src[pos], aux[j < 0 ? -j : j]));
+                    }
+                    gV[e] = value;
+                }
+            }
+            __threadfence_block();
+            // ---- 9. LDL^T (cholesky_decomposition) right-looking inside the band, forward substitution fused.
+            // blk[(j % BS) * BS + (i % BS)] holds entry (j, i), i <= j, of the rows currently within reach of the pivot.
+            double *blk = src;
+            auto entry0 = [&](int j, int i) -> double {           // original matrix entry (j >= i)
+                const int dlt = (int)index[j] - (int)index[i];
+                return dlt <= AR ? aux[dlt] : 0.0;
+            };
+            {
+                const int nr = F < BS ? F : BS;                    // rows 0 .. nr-1 enter before the first pivot
+                for (int t = lane; t < nr * BS; t += 64) {
+                    const int j = t / BS, i = t - j * BS;
+                    if (i <= j) blk[j * BS + i] = entry0(j, i);
+                }
+                if (lane < nr) ywin[lane] = gV[lane];
+            }
+            int vbase = BS; double vreg = (vbase + lane < F) ? gV[vbase + lane] : 0.0;      // right-hand sides of the rows about to enter
+            for (int k = 0; k < F; ++k) {
+                const int ks = k % BS;
+                int bw;                                            // rows k+1 .. k+bw are within AR samples of the pivot
+                {
+                    const int row = k + 1 + lane;
+                    const bool inb = lane < MAXAR && row < F && ((int)index[row] - (int)index[k]) <= AR;
+                    bw = __popcll(__ballot(inb));                  // index[] increases: the in-band rows are a prefix
+                }
+                const double d = blk[ks * BS + ks];
+                if (d == 0.0) { ok = false; break; }
+                double l = 0.0;
+                if (lane < bw) l = blk[((k + 1 + lane) % BS) * BS + ks] / d;
+                if (lane < MAXAR) { gL[(size_t)k * MAXAR + lane] = l; lvec[lane] = l; }
+                const double yk = ywin[ks];
+                if (lane == 0) { gD[k] = d; gY[k] = yk; }
+                // forward substitution (k ascending = FFmpeg's j-ascending order for every row)
+                if (lane < bw) { const int sl = (k + 1 + lane) % BS; ywin[sl] = __dsub_rn(ywin[sl], __dmul_rn(l, yk)); }
+                // trailing update: entry (j, i), k < i <= j <= k+bw:  -= (d * L_ik) * L_jk
+                const int npairs = bw * (bw + 1) / 2;
+                for (int t = lane; t < npairs; t += 64) {
+                    int a = (int)((sqrtf(8.0f * (float)t + 1.0f) - 1.0f) * 0.5f);       // unrank t -> (a, b), 0 <= b <= a < bw
+                    while ((a + 1) * (a + 2) / 2 <= t) ++a;
+                    while (a * (a + 1) / 2 > t) --a;
+                    const int b = t - a * (a + 1) / 2;
+                    double *e = &blk[((k + 1 + a) % BS) * BS + ((k + 1 + b) % BS)];
+                    *e = __dsub_rn(*e, __dmul_rn(__dmul_rn(d, lvec[b]), lvec[a]));
+                }
+                // row k leaves the block; row k + BS enters with its original entries against the rows still in reach
+                const int nj = k + BS;
+                if (nj < F) {
+                    for (int i = k + 1 + lane; i <= nj; i += 64) blk[ks * BS + (i % BS)] = entry0(nj, i);
+                    if (nj >= vbase + 64) { vbase += 64; vreg = (vbase + lane < F) ? gV[vbase + lane] : 0.0; }
+                    const double vn = dk_readlane(vreg, nj - vbase);
+                    if (lane == 0) ywin[ks] = vn;
+                }
+            }
+            if (ok) {
+                __threadfence_block();
+                // ---- 10. back substitution: out[i] = y[i]/d[i] - sum_{j>i} L[j][i] * out[j] (j ascending; exact zeros beyond the
+                // band are skipped).  L[j][i] = gL[i][j-i-1].  Rows in batches of 16: the batch's factors are fetched together.
+                for (int ib = F - 1; ib >= 0; ib -= 16) {
+                    double Lr[16];
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) { const int i = ib - q; Lr[q] = (i >= 0 && lane < MAXAR) ? gL[(size_t)i * MAXAR + lane] : 0.0; }
+                    double yr = 0.0, dr = 1.0;
+                    if (lane < 16 && ib - lane >= 0) { yr = gY[ib - lane]; dr = gD[ib - lane]; }
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) {
+                        const int i = ib - q;
+                        if (i < 0) break;
+                        int nt;
+                        {
+                            const int row = i + 1 + lane;
+                            const bool inb = lane < MAXAR && row < F && ((int)index[row] - (int)index[i]) <= AR;
+                            nt = __popcll(__ballot(inb));
+                        }
+                        double v = dk_readlane(yr, q) / dk_readlane(dr, q);
+                        const double term = lane < nt ? __dmul_rn(Lr[q], solring[(i + 1 + lane) % BS]) : 0.0;
+                        for (int t = 0; t < nt; ++t) v = __dsub_rn(v, dk_readlane(term, t));
+                        solring[i % BS] = v;
+                        const int pos = index[i];
+                        if (lane == 0 && pos >= P.skip && pos < P.skip + P.hop && o0 + (pos - P.skip) < n) out[o0 + (pos - P.skip)] = v;
+                    }
+                }
+                repaired += (lane == 0) ? (unsigned long long)F : 0ull;
+            } else {
+                singular += (lane == 0) ? 1ull : 0ull;
+            }
+        }
+        // ---- 11. overlap-save output of the samples that were not repaired: out[w*hop + j] = src[skip + j]
+        const bool rep = F > 0 && ok;
+        for (int j = lane; j < P.hop; j += 64) {
+            const int64_t o = o0 + j;
+            const int pos = P.skip + j;
+            if (o < n && !(rep && click[pos])) {
+                const int64_t p = s0 + pos;
+                out[o] = (p >= 0 && p < n) ? __dmul_rn(in[p], P.gain) : 0.0;
+            }
+        }
+    }
+    if (lane == 0 && (repaired || singular)) { atomicAdd(&stats[0], repaired); atomicAdd(&stats[1], singular); }
+}
+
+// host side --------------------------------------------------------------------------------------------------------
+bool jt_adeclick_supported(int sample_rate, double window_ms, double overlap_pct, double ar_pct, int method, std::string *why)
+{
+    int W = (int)(sample_rate * window_ms / 1000.); if (W < 100) W = 100;
+    int ar = (int)(W * ar_pct / 100.); if (ar < 1) ar = 1;
+    (void)overlap_pct;
+    if (method != 1) { if (why) *why = "adeclick: only the overlap-save method (m=s) is built"; return false; }
+    if (W > dk::MAXW) { if (why) *why = "adeclick: window too long for this build"; return false; }
+    if (ar > dk::MAXAR) { if (why) *why = "adeclick: AR order above 48 is not built"; return false; }
+    return true;
+}
+
+void launch_adeclick(jt_ctx *h, const double *in, double *out, int64_t n, int sample_rate, double threshold, double window_ms,
+                     double overlap_pct, double ar_pct, double burst, double gain, unsigned long long *d_stats, hipStream_t s)
+{
+    DeclickParams P;
+    P.W = (int)(sample_rate * window_ms / 1000.); if (P.W < 100) P.W = 100;
+    P.ar = (int)(P.W * ar_pct / 100.); if (P.ar < 1) P.ar = 1;
+    P.nburst = (int)(P.W * burst / 1000.);
+    P.hop = (int)(P.W * (1. - (overlap_pct / 100.))); if (P.hop < 1) P.hop = 1;
+    P.skip = (P.W - P.hop) / 2;
+    P.threshold = threshold; P.gain = gain;
+    P.nwindows = (n + P.hop - 1) / P.hop;
+    const size_t per_wave = (size_t)P.W * dk::MAXAR + 3 * (size_t)P.W;
+    P.sa = (std::max(P.W, dk::BS * dk::BS) + 1) & ~1;
+    const size_t smem = sizeof(double) * (size_t)(P.sa + 7 * (dk::BS + 1)) + sizeof(unsigned short) * (size_t)((P.W + 3) & ~3) + (size_t)P.W + 16;
+    JT_REQUIRE(smem <= 64 * 1024, JT_E_UNSUPPORTED, "adeclick: window does not fit the per-wave LDS budget");
+    int waves_per_cu = (int)std::min<size_t>(8, (160 * 1024) / smem);
+    const int64_t grid = std::min<int64_t>(P.nwindows, (int64_t)256 * waves_per_cu);
+    h->declick_scr.ensure(per_wave * (size_t)grid);
+    JT_HIP(hipFuncSetAttribute((const void *)k_adeclick, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    hipLaunchKernelGGL(k_adeclick, dim3((unsigned)grid), dim3(64), smem, s, in, out, n, P, h->declick_scr.p, per_wave, d_stats);
+}

@@ -173,6 +173,13 @@ class Engine:
                                              C.c_int64(x.size), C.c_int(sr), C.c_double(limit), C.c_double(attack), C.c_double(release)))
         return y
 
+    def op_adeclick(self, x, sr, t=1.7, w=55.0, o=50.0, method="s", return_count=False):
+        x = np.ascontiguousarray(x, np.float64); y = np.empty_like(x); cnt = C.c_int64()
+        self._ck(self.lib.jt_op_adeclick_f64(self.h, x.ctypes.data_as(C.POINTER(C.c_double)), y.ctypes.data_as(C.POINTER(C.c_double)),
+                                             C.c_int64(x.size), C.c_int(sr), C.c_double(t), C.c_double(w), C.c_double(o),
+                                             C.c_int(1 if method == "s" else 0), C.byref(cnt)))
+        return (y, cnt.value) if return_count else y
+
     def op_resample_s16(self, x, in_rate, out_rate):
         x = np.ascontiguousarray(x, np.float32)
         cap = int(np.ceil(x.size * out_rate / in_rate)) + 8

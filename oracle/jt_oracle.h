@@ -69,6 +69,10 @@ void orc_acompressor_f64(const double *in, double *out, int64_t n, int sample_ra
 void orc_deesser_f64(const double *in, double *out, int64_t n, int sample_rate,
                      double intensity, double max_deess, double frequency);
 
+/* ---- adeclick (af_adeclick.c): method 0 = overlap-add, 1 = overlap-save; returns -1 if a window's normal matrix is singular ---- */
+int orc_adeclick_f64(const double *in, double *out, int64_t n, int sample_rate, double threshold, double window_ms,
+                     double overlap_pct, double ar_pct, double burst, int method, int64_t *n_clicks_out);
+
 /* ---- alimiter (af_alimiter.c): level=0 (no auto level), latency=1, asc on ---- */
 void orc_alimiter_f64(const double *in, double *out, int64_t n, int sample_rate,
                       double limit, double attack_ms, double release_ms, double asc_level);

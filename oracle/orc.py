@@ -125,6 +125,19 @@ def alimiter(x, sr, limit, attack=5.0, release=100.0, asc_level=0.8):
     return y
 
 
+def adeclick(x, sr, t=1.7, w=55.0, o=50.0, a=2.0, b=2.0, method="s", return_count=False):
+    """af_adeclick.c; method 'a' = overlap-add, 's' = overlap-save."""
+    x = np.ascontiguousarray(x, np.float64)
+    y = np.empty_like(x)
+    cnt = C.c_int64(0)
+    l = lib(); l.orc_adeclick_f64.restype = C.c_int
+    rc = l.orc_adeclick_f64(_p(x, C.c_double), _p(y, C.c_double), C.c_int64(x.size), C.c_int(sr), C.c_double(t), C.c_double(w),
+                            C.c_double(o), C.c_double(a), C.c_double(b), C.c_int(1 if method == "s" else 0), C.byref(cnt))
+    if rc != 0:
+        raise RuntimeError("adeclick: singular interpolation matrix")
+    return (y, cnt.value) if return_count else y
+
+
 def swr_f64(x, in_rate, out_rate, flush=True):
     x = np.ascontiguousarray(x, np.float64)
     cap = int(np.ceil(x.size * out_rate / in_rate)) + 4

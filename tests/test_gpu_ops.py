@@ -133,6 +133,42 @@ def test_alimiter_never_triggered_is_identity(engine, oracle):
     assert np.array_equal(got, x)
 
 
+# ---------------------------------------------------------------- adeclick
+def test_adeclick_matches_oracle_speech(engine, oracle):
+    x = (speech(6.0, 11, 44100) * 3.0).astype(np.float64)
+    ref, nref = oracle.adeclick(x, 44100, 1.7, 55.0, 50.0, method="s", return_count=True)
+    got, ngot = engine.op_adeclick(x, 44100, 1.7, 55.0, 50.0, method="s", return_count=True)
+    assert nref > 1000 and np.max(np.abs(ref - x)) > 1e-3          # the filter re-interpolated a sizeable part of the signal
+    assert ngot == nref                                             # identical detection decisions
+    assert np.array_equal(got, ref)                                 # identical sums, identical order: bit-exact
+
+
+def test_adeclick_click_on_tone_and_edges(engine, oracle):
+    sr = 44100
+    t = np.arange(sr) / sr
+    x = 0.3 * np.sin(2 * np.pi * 220 * t)
+    x[20000] += 0.5; x[20001] -= 0.4; x[33333] += 0.25             # clicks, one of them a 2-sample burst
+    ref = oracle.adeclick(x, sr)
+    got = engine.op_adeclick(x, sr)
+    assert np.array_equal(got, ref)
+    assert abs(got[20000] - 0.3 * np.sin(2 * np.pi * 220 * 20000 / sr)) < 1e-3     # the click is gone
+    for n in (1, 100, 1212, 1213, 2425, 2426, 5000):               # shorter than a hop / a window, and ragged tails
+        y = noise(n, 0.05, n).astype(np.float64)
+        assert np.array_equal(engine.op_adeclick(y, sr), oracle.adeclick(y, sr))
+    z = np.zeros(6000)                                              # digital silence: the AR fit is not finite, windows pass through
+    assert np.array_equal(engine.op_adeclick(z, sr), z)
+
+
+def test_adeclick_other_thresholds_and_rates(engine, oracle):
+    x = (speech(3.0, 12, 48000) * 2.0).astype(np.float64)
+    for thr in (2.0, 4.0):                                           # w=50 ms at 48 kHz: AR order 48, the largest this build lays out
+        assert np.array_equal(engine.op_adeclick(x, 48000, thr, 50.0, 50.0), oracle.adeclick(x, 48000, thr, 50.0, 50.0))
+    assert np.array_equal(engine.op_adeclick(x, 48000, 1.7, 40.0, 75.0), oracle.adeclick(x, 48000, 1.7, 40.0, 75.0))
+    with pytest.raises(L.JtError) as ei:                             # 55 ms at 48 kHz needs order 52: refused, never approximated
+        engine.op_adeclick(x, 48000, 1.7, 55.0, 50.0)
+    assert ei.value.code == L.JT_E_UNSUPPORTED
+
+
 # ---------------------------------------------------------------- resampler + s16
 def test_resample_48k_to_44k1_s16_matches_oracle(engine, oracle):
     x = speech(5.0, 11)

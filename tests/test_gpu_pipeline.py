@@ -83,11 +83,14 @@ def test_pass3_pass4_match_oracle(processed, oracle):
     m = oracle.loudnorm_measure(up, 192000, True)
     assert abs(res.measure.input_i - m["input_i"]) <= 0.011                 # both rounded to the JSON's %.2f
     assert abs(res.measure.input_tp - m["input_tp"]) <= 0.011
-    # Pass 4: linear gain -> brickwall -> (flt) -> s16
+    # Pass 4: linear gain -> adeclick (t=1.7 w=55 o=50 m=s) -> brickwall -> (flt) -> s16
     gain = 10 ** ((res.effective_target_i - res.measure.input_i) / 20.0)
-    z = oracle.alimiter(p2.astype(np.float64) / 32768.0 * gain, 44100, 0.803526, 1.0, 50.0)
+    y, repaired = oracle.adeclick(p2.astype(np.float64) / 32768.0 * gain, 44100, 1.7, 55.0, 50.0, method="s", return_count=True)
+    assert repaired > 0                                                     # the repair stage is active on this material
+    z = oracle.alimiter(y, 44100, 0.803526, 1.0, 50.0)
     ref = oracle.f64_to_s16(z.astype(np.float32).astype(np.float64))
-    assert np.array_equal(ref, p4)                                         # bit-exact: same doubles, same limiter state machine
+    # bit-exact: every sum of the AR fit / detection / LDL^T solve keeps af_adeclick.c's order, same limiter state machine
+    assert np.array_equal(ref, p4)
 
 
 def test_region_samples_and_specs_present(processed):
