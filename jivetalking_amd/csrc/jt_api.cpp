@@ -618,8 +618,8 @@ extern "C" int jt_pass4(jt_ctx *h, const jt_limiter_plan *lim, const jt_loudnorm
     if (ap->adeclick_enabled) {
         std::string why;
         JT_REQUIRE(jt_adeclick_supported(rate, ap->adeclick_window_ms, ap->adeclick_overlap_pct, 2.0, ap->adeclick_method, &why), JT_E_UNSUPPORTED, why);
-        h->declick_stats.ensure(2);
-        JT_HIP(hipMemsetAsync(h->declick_stats.p, 0, 2 * sizeof(unsigned long long), h->stream));
+        h->declick_stats.ensure(16);
+        JT_HIP(hipMemsetAsync(h->declick_stats.p, 0, 16 * sizeof(unsigned long long), h->stream));
         launch_adeclick(h, sig, tmp, m, rate, ap->adeclick_threshold, ap->adeclick_window_ms, ap->adeclick_overlap_pct, 2.0, 2.0, gain,
                         h->declick_stats.p, h->stream);
         unsigned long long *hs = h->pin.take<unsigned long long>(2);
@@ -820,12 +820,13 @@ extern "C" int jt_op_adeclick_f64(jt_ctx *h, const double *in, double *out, int6
     std::string why;
     JT_REQUIRE(jt_adeclick_supported(sr, window_ms, overlap_pct, 2.0, method, &why), JT_E_UNSUPPORTED, why);
     DevBuf<double> a, b; h2d(h, a, in, (size_t)n); b.ensure((size_t)n);
-    h->declick_stats.ensure(2);
-    JT_HIP(hipMemsetAsync(h->declick_stats.p, 0, 2 * sizeof(unsigned long long), h->stream));
+    h->declick_stats.ensure(16);
+    JT_HIP(hipMemsetAsync(h->declick_stats.p, 0, 16 * sizeof(unsigned long long), h->stream));
     launch_adeclick(h, a.p, b.p, n, sr, threshold, window_ms, overlap_pct, 2.0, 2.0, 1.0, h->declick_stats.p, h->stream);
-    unsigned long long st[2] = {0, 0};
+    unsigned long long st[16] = {0};
     JT_HIP(hipMemcpyAsync(st, h->declick_stats.p, sizeof(st), hipMemcpyDeviceToHost, h->stream));
     d2h(h, out, b.p, (size_t)n);
+    if (getenv("JT_DK_PROFILE")) { fprintf(stderr, "adeclick phase clocks:"); for (int i = 2; i < 10; ++i) fprintf(stderr, " %llu", st[i]); fprintf(stderr, "\n"); }
     if (n_repaired) *n_repaired = (int64_t)st[0];
     JT_REQUIRE(st[1] == 0, JT_E_HIP, "adeclick: singular interpolation matrix");
     JT_API_END(h)

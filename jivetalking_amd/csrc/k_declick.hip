@@ -31,6 +31,8 @@ struct DeclickParams {
     int64_t nwindows;
 };
 
+__device__ inline double dk_ld(const double *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
 // value of `v` in lane `l` (l wave-uniform): two v_readlane, no LDS round trip
 __device__ inline double dk_readlane(double v, int l)
 {
@@ -53,13 +55,20 @@ k_adeclick(const double *__restrict__ in, double *__restrict__ out, int64_t n, D
     double *aux = aa + BS + 1;                                          // aux[AR+1]
     double *lvec = aux + BS + 1;                                        // pivot column multipliers
     double *ywin = lvec + BS + 1;                                       // sliding right-hand side / y
-    double *solring = ywin + BS + 1;                                    // most recent solutions (back substitution)
-    unsigned short *index = reinterpret_cast<unsigned short *>(solring + BS + 1);   // [W]
+    unsigned short *index = reinterpret_cast<unsigned short *>(ywin + BS + 1);   // [W]
     unsigned char *click = reinterpret_cast<unsigned char *>(index + ((W + 3) & ~3));   // [W]
-    // global scratch of this wave (cross-lane traffic: volatile = L1-bypassing): L[W][MAXAR] | D[W] | y[W] | rhs[W]
-    volatile double *gL = scratch + (size_t)blockIdx.x * scratch_per_wave;
-    volatile double *gD = gL + (size_t)W * MAXAR, *gY = gD + W, *gV = gY + W;
+    unsigned char *bwv = click + ((W + 3) & ~3);                                        // [W] band width per pivot
+    // global scratch of this wave: L[W][MAXAR] | D[W] | y[W] | rhs[W].  Written with plain stores, read back (by other lanes, after
+    // a fence) with agent-scope relaxed loads, which bypass the CU's L1 and may be pipelined freely.
+    double *gL = scratch + (size_t)blockIdx.x * scratch_per_wave;
+    double *gD = gL + (size_t)W * MAXAR, *gY = gD + W, *gV = gY + W;
     unsigned long long repaired = 0, singular = 0;
+#ifdef JT_DK_PROFILE
+    unsigned long long tph[8] = {0,0,0,0,0,0,0,0}; unsigned long long tc = wall_clock64();
+#define DK_MARK(i) { unsigned long long t_ = wall_clock64(); tph[i] += t_ - tc; tc = t_; }
+#else
+#define DK_MARK(i)
+#endif
 
     for (int64_t w = blockIdx.x; w < P.nwindows; w += gridDim.x) {
         const int64_t s0 = w * P.hop - P.skip;                          // input position of src[0]
@@ -70,19 +79,41 @@ k_adeclick(const double *__restrict__ in, double *__restrict__ out, int64_t n, D
             src[j] = (p >= 0 && p < n) ? __dmul_rn(in[p], P.gain) : 0.0;
             click[j] = 0;
         }
+        DK_MARK(0)
         // ---- 2. autocorrelation(src, AR, W, r, 1/W): lane = lag, terms in j-ascending order
         if (lane <= AR) {
+            // 8 terms per block; the next block's 16 LDS reads are in flight while this block's adds (the sequential chain) retire
             double value = 0.0;
             int j = lane;
-            for (; j + 3 < W; j += 4) {
-                const double a0 = src[j], a1 = src[j + 1], a2 = src[j + 2], a3 = src[j + 3];
-                const double b0 = src[j - lane], b1 = src[j + 1 - lane], b2 = src[j + 2 - lane], b3 = src[j + 3 - lane];
-                value = __dadd_rn(value, __dmul_rn(a0, b0)); value = __dadd_rn(value, __dmul_rn(a1, b1));
-                value = __dadd_rn(value, __dmul_rn(a2, b2)); value = __dadd_rn(value, __dmul_rn(a3, b3));
+            double a0[8], b0[8], a1[8], b1[8];
+            const int nb = (W - lane) / 8;
+            if (nb > 0) {
+#pragma unroll
+                for (int u = 0; u < 8; ++u) { a0[u] = src[j + u]; b0[u] = src[j + u - lane]; }
+            }
+            int blk8 = 0;
+            for (; blk8 + 1 < nb; blk8 += 2) {
+#pragma unroll
+                for (int u = 0; u < 8; ++u) { a1[u] = src[j + 8 + u]; b1[u] = src[j + 8 + u - lane]; }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) value = __dadd_rn(value, __dmul_rn(a0[u], b0[u]));
+                if (blk8 + 2 < nb) {
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) { a0[u] = src[j + 16 + u]; b0[u] = src[j + 16 + u - lane]; }
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) value = __dadd_rn(value, __dmul_rn(a1[u], b1[u]));
+                j += 16;
+            }
+            if (blk8 < nb) {
+#pragma unroll
+                for (int u = 0; u < 8; ++u) value = __dadd_rn(value, __dmul_rn(a0[u], b0[u]));
+                j += 8;
             }
             for (; j < W; ++j) value = __dadd_rn(value, __dmul_rn(src[j], src[j - lane]));
             rr[lane] = __dmul_rn(value, 1.0 / W);
         }
+        DK_MARK(1)
         // ---- 3. Levinson-Durbin (autoregression()): k -> ac[], sigma_e = sqrt(alpha)
         double sigmae;
         {
@@ -109,6 +140,7 @@ k_adeclick(const double *__restrict__ in, double *__restrict__ out, int64_t n, D
             if (lane >= 1 && lane <= AR) ac[lane] = aa[lane - 1];
             sigmae = sqrt(alpha);
         }
+        DK_MARK(2)
         bool finite;
         {
             const double v = lane <= AR ? ac[lane] : 0.0;
@@ -118,17 +150,18 @@ k_adeclick(const double *__restrict__ in, double *__restrict__ out, int64_t n, D
         if (finite) {
             // ---- 4. detection[i] = sum_{j=0..AR} ac[j] * src[i-j] (j ascending), click = |detection| > sigmae * threshold
             const double thr = __dmul_rn(sigmae, P.threshold);
-            for (int i0 = AR; i0 < W; i0 += 256) {
-                int ii[4]; double dd[4];
+            for (int i0 = AR; i0 < W; i0 += 512) {
+                int ii[8], ic[8]; double dd[8];
 #pragma unroll
-                for (int q = 0; q < 4; ++q) { ii[q] = i0 + 64 * q + lane; dd[q] = 0.0; if (ii[q] >= W) ii[q] = -1; }
+                for (int q = 0; q < 8; ++q) { ii[q] = i0 + 64 * q + lane; ic[q] = ii[q] < W ? ii[q] : W - 1; dd[q] = 0.0; }
+#pragma unroll 7
                 for (int j = 0; j <= AR; ++j) {
                     const double c = ac[j];
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) if (ii[q] >= 0) dd[q] = __dadd_rn(dd[q], __dmul_rn(c, src[ii[q] - j]));
+                    for (int q = 0; q < 8; ++q) dd[q] = __dadd_rn(dd[q], __dmul_rn(c, src[ic[q] - j]));
                 }
 #pragma unroll
-                for (int q = 0; q < 4; ++q) if (ii[q] >= 0) click[ii[q]] = fabs(dd[q]) > thr;
+                for (int q = 0; q < 8; ++q) if (ii[q] < W) click[ii[q]] = fabs(dd[q]) > thr;
             }
             // ---- 5. burst fusion: the gap between two consecutive flagged samples p < q is filled when 1 < q-p <= nburst
             //         (the sequential loop only ever compares original flags, bit 0; fills go to bit 1)
@@ -152,7 +185,15 @@ k_adeclick(const double *__restrict__ in, double *__restrict__ out, int64_t n, D
                 if (j < W) click[j] = fl ? 1 : 0;
                 F += __popcll(bal);
             }
+            // band width of every pivot: rows k+1 .. k+bw are within AR samples of row k (index[] increases): upper bound by bisection
+            for (int k = lane; k < F; k += 64) {
+                const int lim = (int)index[k] + AR;
+                int lo = k, hi = min(F - 1, k + MAXAR);              // last row r in [k, hi] with index[r] <= lim
+                while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if ((int)index[mid] <= lim) lo = mid; else hi = mid - 1; }
+                bwv[k] = (unsigned char)(lo - k);
+            }
         }
+        DK_MARK(3)
         bool ok = true;
         if (F > 0) {
             // ---- 7. aux = autocorrelation(ac, AR, AR+1, ., 1.)
@@ -162,19 +203,25 @@ k_adeclick(const double *__restrict__ in, double *__restrict__ out, int64_t n, D
                 aux[lane] = __dmul_rn(value, 1.0);
             }
             // ---- 8. right-hand side: vector[e] = -sum_{j=-AR..AR, index[e]-j not flagged} src[index[e]-j] * aux[|j|]
-            for (int e0 = 0; e0 < F; e0 += 64) {
-                const int e = e0 + lane;
-                if (e < F) {
-                    const int ie = index[e];
-                    double value = 0.0;
-                    for (int j = -AR; j <= AR; ++j) {
-                        const int pos = ie - j;
-                        if (!click[pos]) value = __dsub_rn(value, __dmul_rn(src[pos], aux[j < 0 ? -j : j]));
+            for (int e0 = 0; e0 < F; e0 += 256) {
+                int ie[4]; double val[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { const int e = e0 + 64 * q + lane; ie[q] = index[e < F ? e : F - 1]; val[q] = 0.0; }
+#pragma unroll 4
+                for (int j = -AR; j <= AR; ++j) {
+                    const double ax = aux[j < 0 ? -j : j];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int pos = ie[q] - j;
+                        const double t = click[pos] ? 0.0 : __dmul_rn(src[pos], ax);     // flagged samples are the unknowns: x - 0 is exact
+                        val[q] = __dsub_rn(val[q], t);
                     }
-                    gV[e] = value;
                 }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { const int e = e0 + 64 * q + lane; if (e < F) gV[e] = val[q]; }
             }
-            __threadfence_block();
+            __threadfence();
+            DK_MARK(4)
             // ---- 9. LDL^T (cholesky_decomposition) right-looking inside the band, forward substitution fused.
             // blk[(j % BS) * BS + (i % BS)] holds entry (j, i), i <= j, of the rows currently within reach of the pivot.
             double *blk = src;
@@ -188,32 +235,28 @@ k_adeclick(const double *__restrict__ in, double *__restrict__ out, int64_t n, D
                     const int j = t / BS, i = t - j * BS;
                     if (i <= j) blk[j * BS + i] = entry0(j, i);
                 }
-                if (lane < nr) ywin[lane] = gV[lane];
+                if (lane < nr) ywin[lane] = dk_ld(&gV[lane]);
             }
-            int vbase = BS; double vreg = (vbase + lane < F) ? gV[vbase + lane] : 0.0;      // right-hand sides of the rows about to enter
+            int vbase = BS; double vreg = (vbase + lane < F) ? dk_ld(&gV[vbase + lane]) : 0.0;      // right-hand sides of the rows about to enter
             for (int k = 0; k < F; ++k) {
                 const int ks = k % BS;
-                int bw;                                            // rows k+1 .. k+bw are within AR samples of the pivot
-                {
-                    const int row = k + 1 + lane;
-                    const bool inb = lane < MAXAR && row < F && ((int)index[row] - (int)index[k]) <= AR;
-                    bw = __popcll(__ballot(inb));                  // index[] increases: the in-band rows are a prefix
-                }
+                const int bw = bwv[k];
                 const double d = blk[ks * BS + ks];
                 if (d == 0.0) { ok = false; break; }
+                const int rs = (k + 1 + lane) % BS;                // LDS row of this lane's band row
                 double l = 0.0;
-                if (lane < bw) l = blk[((k + 1 + lane) % BS) * BS + ks] / d;
-                if (lane < MAXAR) { gL[(size_t)k * MAXAR + lane] = l; lvec[lane] = l; }
+                if (lane < bw) l = blk[rs * BS + ks] / d;
+                if (lane < MAXAR) gL[(size_t)k * MAXAR + lane] = l;
                 const double yk = ywin[ks];
-                if (lane == 0) { gD[k] = d; gY[k] = yk; }
+                if (lane == 0) { gD[k] = d; gY[k] = yk / d; }      // y/d is what the back substitution starts every row from
                 // forward substitution (k ascending = FFmpeg's j-ascending order for every row)
-                if (lane < bw) { const int sl = (k + 1 + lane) % BS; ywin[sl] = __dsub_rn(ywin[sl], __dmul_rn(l, yk)); }
-                // trailing update: entry (j, i), k < i <= j <= k+bw:  -= (d * L_ik) * L_jk
+                if (lane < bw) ywin[rs] = __dsub_rn(ywin[rs], __dmul_rn(l, yk));
+                // trailing update: entry (k+1+a, k+1+b), 0 <= b <= a < bw:  -= (d * L_b) * L_a   (one pair per lane)
+                if (lane < MAXAR) lvec[lane] = l;
                 const int npairs = bw * (bw + 1) / 2;
                 for (int t = lane; t < npairs; t += 64) {
-                    int a = (int)((sqrtf(8.0f * (float)t + 1.0f) - 1.0f) * 0.5f);       // unrank t -> (a, b), 0 <= b <= a < bw
-                    while ((a + 1) * (a + 2) / 2 <= t) ++a;
-                    while (a * (a + 1) / 2 > t) --a;
+                    int a = (int)((sqrtf(8.0f * (float)t + 1.0f) - 1.0f) * 0.5f);       // unrank t -> (a, b)
+                    a += ((a + 1) * (a + 2) / 2 <= t); a -= (a * (a + 1) / 2 > t);
                     const int b = t - a * (a + 1) / 2;
                     double *e = &blk[((k + 1 + a) % BS) * BS + ((k + 1 + b) % BS)];
                     *e = __dsub_rn(*e, __dmul_rn(__dmul_rn(d, lvec[b]), lvec[a]));
@@ -222,35 +265,37 @@ k_adeclick(const double *__restrict__ in, double *__restrict__ out, int64_t n, D
                 const int nj = k + BS;
                 if (nj < F) {
                     for (int i = k + 1 + lane; i <= nj; i += 64) blk[ks * BS + (i % BS)] = entry0(nj, i);
-                    if (nj >= vbase + 64) { vbase += 64; vreg = (vbase + lane < F) ? gV[vbase + lane] : 0.0; }
+                    if (nj >= vbase + 64) { vbase += 64; vreg = (vbase + lane < F) ? dk_ld(&gV[vbase + lane]) : 0.0; }
                     const double vn = dk_readlane(vreg, nj - vbase);
                     if (lane == 0) ywin[ks] = vn;
                 }
             }
+            DK_MARK(5)
             if (ok) {
-                __threadfence_block();
+                __threadfence();
                 // ---- 10. back substitution: out[i] = y[i]/d[i] - sum_{j>i} L[j][i] * out[j] (j ascending; exact zeros beyond the
                 // band are skipped).  L[j][i] = gL[i][j-i-1].  Rows in batches of 16: the batch's factors are fetched together.
+                double sw = 0.0;                                    // lane t: solution of row (current row + 1 + t)
                 for (int ib = F - 1; ib >= 0; ib -= 16) {
                     double Lr[16];
 #pragma unroll
-                    for (int q = 0; q < 16; ++q) { const int i = ib - q; Lr[q] = (i >= 0 && lane < MAXAR) ? gL[(size_t)i * MAXAR + lane] : 0.0; }
-                    double yr = 0.0, dr = 1.0;
-                    if (lane < 16 && ib - lane >= 0) { yr = gY[ib - lane]; dr = gD[ib - lane]; }
+                    for (int q = 0; q < 16; ++q) { const int i = ib - q; Lr[q] = (i >= 0 && lane < MAXAR) ? dk_ld(&gL[(size_t)i * MAXAR + lane]) : 0.0; }
+                    double qr = 0.0;
+                    if (lane < 16 && ib - lane >= 0) qr = dk_ld(&gY[ib - lane]);
 #pragma unroll
                     for (int q = 0; q < 16; ++q) {
                         const int i = ib - q;
                         if (i < 0) break;
-                        int nt;
-                        {
-                            const int row = i + 1 + lane;
-                            const bool inb = lane < MAXAR && row < F && ((int)index[row] - (int)index[i]) <= AR;
-                            nt = __popcll(__ballot(inb));
-                        }
-                        double v = dk_readlane(yr, q) / dk_readlane(dr, q);
-                        const double term = lane < nt ? __dmul_rn(Lr[q], solring[(i + 1 + lane) % BS]) : 0.0;
+                        const int nt = bwv[i];
+                        double v = dk_readlane(qr, q);
+                        const double term = __dmul_rn(Lr[q], sw);
                         for (int t = 0; t < nt; ++t) v = __dsub_rn(v, dk_readlane(term, t));
-                        solring[i % BS] = v;
+                        // slide the window: lane t takes lane t-1's solution, lane 0 the new one
+                        {
+                            const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(sw), 0x138, 0xf, 0xf, false);   // wave_shr:1
+                            const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(sw), 0x138, 0xf, 0xf, false);
+                            sw = lane == 0 ? v : __hiloint2double(hi, lo);
+                        }
                         const int pos = index[i];
                         if (lane == 0 && pos >= P.skip && pos < P.skip + P.hop && o0 + (pos - P.skip) < n) out[o0 + (pos - P.skip)] = v;
                     }
@@ -260,6 +305,7 @@ k_adeclick(const double *__restrict__ in, double *__restrict__ out, int64_t n, D
                 singular += (lane == 0) ? 1ull : 0ull;
             }
         }
+        DK_MARK(6)
         // ---- 11. overlap-save output of the samples that were not repaired: out[w*hop + j] = src[skip + j]
         const bool rep = F > 0 && ok;
         for (int j = lane; j < P.hop; j += 64) {
@@ -272,6 +318,10 @@ k_adeclick(const double *__restrict__ in, double *__restrict__ out, int64_t n, D
         }
     }
     if (lane == 0 && (repaired || singular)) { atomicAdd(&stats[0], repaired); atomicAdd(&stats[1], singular); }
+#ifdef JT_DK_PROFILE
+    DK_MARK(7)
+    if (lane == 0) for (int i = 0; i < 8; ++i) atomicAdd(&stats[2 + i], tph[i]);
+#endif
 }
 
 // host side --------------------------------------------------------------------------------------------------------
@@ -299,7 +349,7 @@ void launch_adeclick(jt_ctx *h, const double *in, double *out, int64_t n, int sa
     P.nwindows = (n + P.hop - 1) / P.hop;
     const size_t per_wave = (size_t)P.W * dk::MAXAR + 3 * (size_t)P.W;
     P.sa = (std::max(P.W, dk::BS * dk::BS) + 1) & ~1;
-    const size_t smem = sizeof(double) * (size_t)(P.sa + 7 * (dk::BS + 1)) + sizeof(unsigned short) * (size_t)((P.W + 3) & ~3) + (size_t)P.W + 16;
+    const size_t smem = sizeof(double) * (size_t)(P.sa + 6 * (dk::BS + 1)) + sizeof(unsigned short) * (size_t)((P.W + 3) & ~3) + 2 * (size_t)((P.W + 3) & ~3) + 16;
     JT_REQUIRE(smem <= 64 * 1024, JT_E_UNSUPPORTED, "adeclick: window does not fit the per-wave LDS budget");
     int waves_per_cu = (int)std::min<size_t>(8, (160 * 1024) / smem);
     const int64_t grid = std::min<int64_t>(P.nwindows, (int64_t)256 * waves_per_cu);
