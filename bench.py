@@ -4,7 +4,7 @@
 Contract: `python bench.py --gpus N --steps K --warmup W` (N>1 launched by torch.distributed.run, one rank per
 GPU).  A step = all four passes over one 60-min 48 kHz mono f32 file that is already resident in HBM
 (BASELINE.json configs[1]); files shard one per GPU, no data-path collective (scaling: weak).  Rank 0 prints ONE
-JSON line with `roofline` (dominant kernel: anlmdn) and `cpu_baseline` (oracle port, bounded sample, rank 0, N=1).
+JSON line with `roofline` (dominant kernel by measured time) and `cpu_baseline` (oracle port, bounded sample, rank 0, N=1).
 """
 import argparse
 import json
@@ -44,7 +44,7 @@ def cpu_baseline(sample_seconds, sr):
     m = orc.loudnorm_measure(up.astype(np.float64), 192000, True)
     # Pass 4
     g = 10 ** ((-16.0 - m["input_i"]) / 20.0)
-    z = orc.alimiter(s16.astype(np.float64) / 32768.0 * g, 44100, 10 ** (-1.9 / 20), 1.0, 50.0)
+    z = orc.alimiter(orc.adeclick(s16.astype(np.float64) / 32768.0 * g, 44100), 44100, 10 ** (-1.9 / 20), 1.0, 50.0)
     zf = z.astype(np.float32)
     orc.astats(z, 44100); orc.aspectralstats(zf, 44100); orc.ebur128(zf.astype(np.float64), 44100, True, True)
     orc.f64_to_s16(zf.astype(np.float64))
@@ -99,13 +99,13 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    nlm_ms, p_ms = [], []
+    nlm_ms, dk_ms, p_ms = [], [], []
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         res = step()
         t = eng.timers()
-        nlm_ms.append(t["nlm_ms"]); p_ms.append([t["pass1_ms"], t["pass2_ms"], t["pass3_ms"], t["pass4_ms"]])
+        nlm_ms.append(t["nlm_ms"]); dk_ms.append(t["declick_ms"]); p_ms.append([t["pass1_ms"], t["pass2_ms"], t["pass3_ms"], t["pass4_ms"]])
     barrier()
     dt = time.perf_counter() - t0
     dt = shard.max_over_ranks(dt, device=f"cuda:{local_rank}")
@@ -120,13 +120,42 @@ def main():
         nlm_bytes = 8 * n                                    # anlmdn: read f32 + write f32 per sample
         nlm_flops = n * (2 * S) * 6                          # patch-distance recurrence: 2 sub, 2 mul, 2 add per (sample, offset)
         pm = np.mean(np.array(p_ms), axis=0)
+        nlm_roof = {"kernel": "k_anlmdn_pair<3>", "bound": "hbm", "achieved": round(nlm_bytes / nlm_avg_s / 1e9, 2),
+                    "peak": 8000, "unit": "GB/s", "frac": round(nlm_bytes / nlm_avg_s / 1e9 / 8000, 5), "traffic": None,
+                    "note": "vector-FP32 bound, not HBM bound (SURVEY §8d): add/mul-only recurrence (FFmpeg's unfused f32 order), "
+                            "so the applicable peak is the non-FMA packed rate",
+                    "valu": {"achieved_TFLOPs": round(nlm_flops / nlm_avg_s / 1e12, 2), "peak_TFLOPs_no_fma": 78.6,
+                             "frac": round(nlm_flops / nlm_avg_s / 1e12 / 78.6, 4)},
+                    "avg_launch_ms": round(nlm_avg_s * 1e3, 3)}
+        dk_avg_s = float(np.mean(dk_ms)) / 1e3
+        if dk_avg_s > nlm_avg_s:
+            dk_bytes = 16 * m                                  # adeclick: read f64 + write f64 per 44.1 kHz sample
+            roof = {"kernel": "k_adeclick", "bound": "hbm", "achieved": round(dk_bytes / dk_avg_s / 1e9, 2), "peak": 8000,
+                    "unit": "GB/s", "frac": round(dk_bytes / dk_avg_s / 1e9 / 8000, 5), "traffic": None,
+                    "note": "dominant kernel this round; not bandwidth bound: every window is a set of strictly ordered f64 chains "
+                            "(af_adeclick.c's summation order is kept bit for bit), so it is dependent-issue latency x occupancy "
+                            "(LDS-limited to 5 waves per CU) that sets the time, see DESIGN.md",
+                    "avg_launch_ms": round(dk_avg_s * 1e3, 3), "repaired_samples": int(eng.timers()["declick_repaired"])}
+        else:
+            roof, nlm_roof = nlm_roof, None
+        # HBM traffic per launch from the committed PMC passes (profiles/r01_pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE and
+        # --pmc WRITE_SIZE in separate runs of this same command); FETCH_SIZE doubled per MI355X_MICROARCH.md's gfx950 note
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))["kernels"]
+            for r_ in (roof, nlm_roof):
+                if r_ and r_["kernel"] in pmc:
+                    k_ = pmc[r_["kernel"]]
+                    r_["traffic"] = int((2 * k_["FETCH_SIZE_KB_max_call"] + k_["WRITE_SIZE_KB_max_call"]) * 1024)
+                    r_["traffic_source"] = "profiles/r01_pmc_traffic.json (PMC pass of this command, not collected live)"
+        except (OSError, KeyError, ValueError):
+            pass
         out = {
             "metric": "realtime factor (xRT) on 48 kHz mono speech, 1/2/4/8 GPUs; LUFS error vs ref",
             "value": round(value, 1), "unit": "xRT", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32/f64", "data": "synthetic",
             "config": {"workload": f"1 x {args.minutes:g} min 48 kHz mono f32 PCM per GPU, full 4-pass pipeline, input resident in HBM",
-                       "files_per_gpu_per_step": 1, "adeclick": "pass-through (SURVEY f4 next row)",
+                       "files_per_gpu_per_step": 1, "adeclick": "on (t=1.7 w=55 o=50 m=s, the reference default)",
                        "adaptive": "full host mirror (VAD, speech election, AdaptConfig, band RMS) in C++",
                        "pass2_spec": res.pass2_spec.decode()},
             "result": {"output_lufs": round(res.output_lufs, 3), "output_dbtp": round(res.output_tp_db, 3),
@@ -137,13 +166,8 @@ def main():
                                       [round(float(v), 3) for v in res.stage_ms])),
             "pipeline_hbm": {"algorithmic_bytes_per_file": alg_bytes_file,
                              "achieved_GBps": round(alg_bytes_file * world * args.steps / dt / 1e9, 2), "peak_GBps": 8000},
-            "roofline": {"kernel": "k_anlmdn_pair<3>", "bound": "hbm", "achieved": round(nlm_bytes / nlm_avg_s / 1e9, 2),
-                         "peak": 8000, "unit": "GB/s", "frac": round(nlm_bytes / nlm_avg_s / 1e9 / 8000, 5), "traffic": None,
-                         "note": "anlmdn is vector-FP32 bound, not HBM bound (SURVEY §8d): see valu; its recurrence is "
-                                 "add/mul only (FFmpeg's unfused f32 order), so the applicable peak is the non-FMA packed rate",
-                         "valu": {"achieved_TFLOPs": round(nlm_flops / nlm_avg_s / 1e12, 2), "peak_TFLOPs_no_fma": 78.6,
-                                  "frac": round(nlm_flops / nlm_avg_s / 1e12 / 78.6, 4)},
-                         "avg_launch_ms": round(nlm_avg_s * 1e3, 3)},
+            "roofline": roof,
+            "second_kernel": nlm_roof,
         }
         if world == 1 and args.cpu_sample > 0:
             out["cpu_baseline"] = cpu_baseline(args.cpu_sample, sr)

@@ -602,6 +602,7 @@ extern "C" int jt_pass4(jt_ctx *h, const jt_limiter_plan *lim, const jt_loudnorm
                         (offset_tp <= ap->target_tp) && (ap->measured_lra <= ap->target_lra);
     JT_REQUIRE(linear, JT_E_UNSUPPORTED, "pass4: loudnorm would fall back to dynamic mode (not implemented on the GPU path)");
     const double gain = std::pow(10., offset_db / 20.);
+    h->timers.declick_ms = 0; h->timers.declick_repaired = 0;
     pass_begin(h, m, 2);
     h->f64_a.ensure((size_t)m); h->f64_b.ensure((size_t)m);
     double *sig = h->f64_a.p, *tmp = h->f64_b.p;
@@ -620,8 +621,10 @@ extern "C" int jt_pass4(jt_ctx *h, const jt_limiter_plan *lim, const jt_loudnorm
         JT_REQUIRE(jt_adeclick_supported(rate, ap->adeclick_window_ms, ap->adeclick_overlap_pct, 2.0, ap->adeclick_method, &why), JT_E_UNSUPPORTED, why);
         h->declick_stats.ensure(16);
         JT_HIP(hipMemsetAsync(h->declick_stats.p, 0, 16 * sizeof(unsigned long long), h->stream));
+        JT_HIP(hipEventRecord(h->ev2, h->stream));
         launch_adeclick(h, sig, tmp, m, rate, ap->adeclick_threshold, ap->adeclick_window_ms, ap->adeclick_overlap_pct, 2.0, 2.0, gain,
                         h->declick_stats.p, h->stream);
+        JT_HIP(hipEventRecord(h->ev3, h->stream));
         unsigned long long *hs = h->pin.take<unsigned long long>(2);
         JT_HIP(hipMemcpyAsync(hs, h->declick_stats.p, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));
         dk_stats = hs;
@@ -645,6 +648,7 @@ extern "C" int jt_pass4(jt_ctx *h, const jt_limiter_plan *lim, const jt_loudnorm
     check_cancel(h);
     if (dk_stats) {
         h->timers.declick_repaired = (int64_t)dk_stats[0];
+        { float dms = 0; JT_HIP(hipEventElapsedTime(&dms, h->ev2, h->ev3)); h->timers.declick_ms = dms; }
         JT_REQUIRE(dk_stats[1] == 0, JT_E_HIP, "adeclick: singular interpolation matrix (af_adeclick.c would fail the graph)");
     }
     if (stats) {
