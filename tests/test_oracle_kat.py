@@ -217,3 +217,37 @@ def test_afftdn_properties(oracle):
     z = oracle.afftdn(n, SR, 12.0, -50.0)
     red = 20 * np.log10(np.std(z[SR:]) / np.std(n[SR:]))
     assert -13.0 < red < -6.0                                       # broadband noise at/below the floor: ~nr dB down
+
+
+# ---------------------------------------------------------------- adeclick (af_adeclick.c restatement)
+def test_adeclick_removes_an_isolated_click_and_leaves_unflagged_samples_untouched(oracle):
+    sr = 44100
+    t = np.arange(sr) / sr
+    clean = 0.3 * np.sin(2 * np.pi * 220 * t) + 0.02 * np.sin(2 * np.pi * 3100 * t)
+    x = clean.copy(); x[20000] += 0.5
+    y, n = oracle.adeclick(x, sr, 2.0, 55.0, 50.0, method="s", return_count=True)
+    assert y.size == x.size and n > 0
+    assert abs(y[20000] - clean[20000]) < 2e-3                   # the AR interpolation restores the sample
+    changed = np.nonzero(y != x)[0]
+    assert changed.size <= n                                      # only re-interpolated samples differ (overlap-save copies the rest)
+    assert 20000 in changed
+
+
+def test_adeclick_silence_and_scale_invariance(oracle):
+    sr = 44100
+    z = np.zeros(8000)
+    assert np.array_equal(oracle.adeclick(z, sr), z)              # r[0] = 0: the AR fit is not finite, windows pass through
+    rng = np.random.default_rng(5)
+    x = rng.standard_normal(3 * sr) * 0.05
+    y1, n1 = oracle.adeclick(x, sr, return_count=True)
+    y2, n2 = oracle.adeclick(x * 4.0, sr, return_count=True)     # power-of-two gain: detection is relative to sigma_e
+    assert n1 == n2 and n1 > 0
+    assert np.array_equal(y2, y1 * 4.0)
+
+
+def test_adeclick_threshold_monotone(oracle):
+    sr = 44100
+    rng = np.random.default_rng(6)
+    x = rng.standard_normal(2 * sr) * 0.05
+    counts = [oracle.adeclick(x, sr, thr, return_count=True)[1] for thr in (1.5, 2.0, 3.0, 5.0)]
+    assert counts == sorted(counts, reverse=True) and counts[-1] < counts[0] // 10
