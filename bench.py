@@ -135,7 +135,8 @@ def main():
                     "note": "dominant kernel this round; not bandwidth bound: every window is a set of strictly ordered f64 chains "
                             "(af_adeclick.c's summation order is kept bit for bit), so it is dependent-issue latency x occupancy "
                             "(LDS-limited to 5 waves per CU) that sets the time, see DESIGN.md",
-                    "avg_launch_ms": round(dk_avg_s * 1e3, 3), "repaired_samples": int(eng.timers()["declick_repaired"])}
+                    "avg_launch_ms": round(dk_avg_s * 1e3, 3), "repaired_samples": int(eng.timers()["declick_repaired"]),
+                    "heavy_windows": int(eng.timers()["declick_heavy_windows"])}
         else:
             roof, nlm_roof = nlm_roof, None
         # HBM traffic per launch from the committed PMC passes (profiles/r01_pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE and

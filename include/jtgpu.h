@@ -187,7 +187,8 @@ int jt_download_s16(jt_ctx *h, int stage, int16_t *dst, int64_t cap, int64_t *n)
 /* ---- per-pass device timers (ms, HIP events on the engine stream) for the roofline report ---- */
 typedef struct { double pass1_ms, pass2_ms, pass3_ms, pass4_ms; double nlm_ms; int64_t nlm_launches;
                  int64_t declick_repaired;   /* samples adeclick re-interpolated in the last Pass 4 (diagnostic) */
-                 double declick_ms;          /* adeclick kernel time in the last Pass 4 */ } jt_timers;
+                 double declick_ms;          /* adeclick kernel time in the last Pass 4 */
+                 int64_t declick_heavy_windows; /* windows that needed the full-capacity second pass */ } jt_timers;
 int jt_get_timers(jt_ctx *h, jt_timers *out);
 
 /* =====================================================================================

@@ -625,8 +625,8 @@ extern "C" int jt_pass4(jt_ctx *h, const jt_limiter_plan *lim, const jt_loudnorm
         launch_adeclick(h, sig, tmp, m, rate, ap->adeclick_threshold, ap->adeclick_window_ms, ap->adeclick_overlap_pct, 2.0, 2.0, gain,
                         h->declick_stats.p, h->stream);
         JT_HIP(hipEventRecord(h->ev3, h->stream));
-        unsigned long long *hs = h->pin.take<unsigned long long>(2);
-        JT_HIP(hipMemcpyAsync(hs, h->declick_stats.p, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));
+        unsigned long long *hs = h->pin.take<unsigned long long>(4);
+        JT_HIP(hipMemcpyAsync(hs, h->declick_stats.p, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));
         dk_stats = hs;
         std::swap(sig, tmp);
         brick_gain = 1.0;
@@ -647,7 +647,7 @@ extern "C" int jt_pass4(jt_ctx *h, const jt_limiter_plan *lim, const jt_loudnorm
     JT_HIP(hipEventSynchronize(h->ev1));
     check_cancel(h);
     if (dk_stats) {
-        h->timers.declick_repaired = (int64_t)dk_stats[0];
+        h->timers.declick_repaired = (int64_t)dk_stats[0]; h->timers.declick_heavy_windows = (int64_t)dk_stats[2];
         { float dms = 0; JT_HIP(hipEventElapsedTime(&dms, h->ev2, h->ev3)); h->timers.declick_ms = dms; }
         JT_REQUIRE(dk_stats[1] == 0, JT_E_HIP, "adeclick: singular interpolation matrix (af_adeclick.c would fail the graph)");
     }
@@ -830,7 +830,7 @@ extern "C" int jt_op_adeclick_f64(jt_ctx *h, const double *in, double *out, int6
     unsigned long long st[16] = {0};
     JT_HIP(hipMemcpyAsync(st, h->declick_stats.p, sizeof(st), hipMemcpyDeviceToHost, h->stream));
     d2h(h, out, b.p, (size_t)n);
-    if (getenv("JT_DK_PROFILE")) { fprintf(stderr, "adeclick phase clocks:"); for (int i = 2; i < 10; ++i) fprintf(stderr, " %llu", st[i]); fprintf(stderr, "\n"); }
+    if (getenv("JT_DK_PROFILE")) { fprintf(stderr, "adeclick phase clocks:"); for (int i = 4; i < 12; ++i) fprintf(stderr, " %llu", st[i]); fprintf(stderr, " heavy %llu", st[2]); fprintf(stderr, "\n"); }
     if (n_repaired) *n_repaired = (int64_t)st[0];
     JT_REQUIRE(st[1] == 0, JT_E_HIP, "adeclick: singular interpolation matrix");
     JT_API_END(h)

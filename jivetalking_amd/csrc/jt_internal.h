@@ -210,7 +210,7 @@ struct jt_ctx {
     }
     SwrDev swr[4]; int swr_next = 0;
     DevBuf<float> region_f;
-    DevBuf<double> declick_scr; DevBuf<unsigned long long> declick_stats;
+    DevBuf<double> declick_scr; DevBuf<unsigned long long> declick_stats; DevBuf<int> declick_heavy;
     jt_timers timers{};
     hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr, ev3 = nullptr;
 };

@@ -22,6 +22,7 @@ namespace dk {
 constexpr int MAXW = 4864;        // window samples (110 ms at 44.1 kHz); LDS: 8*MAXW bytes per wave
 constexpr int MAXAR = 48;         // AR order the sliding block is laid out for (2 % of a 55 ms window at 44.1 kHz)
 constexpr int BS = MAXAR + 1;     // sliding block side
+constexpr int NWORD = MAXW / 64;  // 64-sample flag words per window
 }
 
 struct DeclickParams {
@@ -40,9 +41,13 @@ __device__ inline double dk_readlane(double v, int l)
     return __hiloint2double(hi, lo);
 }
 
+// FCAP = flagged samples per window the LDS layout holds.  The light instance (512) runs first at 7 waves per CU; windows with
+// more flags than that append themselves to `heavy` and are redone by the full-capacity instance (HEAVY = true), which takes its
+// window ids from that list.  stats: [0] repaired samples, [1] singular windows, [2] length of the heavy list.
+template <int FCAP, bool HEAVY>
 __global__ void __launch_bounds__(64)
 k_adeclick(const double *__restrict__ in, double *__restrict__ out, int64_t n, DeclickParams P, double *scratch,
-           size_t scratch_per_wave, unsigned long long *__restrict__ stats /* [0] repaired samples, [1] singular windows */)
+           size_t scratch_per_wave, unsigned long long *__restrict__ stats, int *__restrict__ heavy)
 {
     extern __shared__ unsigned char dk_smem[];
     const int lane = threadIdx.x;
@@ -55,14 +60,23 @@ k_adeclick(const double *__restrict__ in, double *__restrict__ out, int64_t n, D
     double *aux = aa + BS + 1;                                          // aux[AR+1]
     double *lvec = aux + BS + 1;                                        // pivot column multipliers
     double *ywin = lvec + BS + 1;                                       // sliding right-hand side / y
-    unsigned short *index = reinterpret_cast<unsigned short *>(ywin + BS + 1);   // [W]
-    unsigned char *click = reinterpret_cast<unsigned char *>(index + ((W + 3) & ~3));   // [W]
-    unsigned char *bwv = click + ((W + 3) & ~3);                                        // [W] band width per pivot
+    unsigned long long *obits = reinterpret_cast<unsigned long long *>(ywin + BS + 1);   // [NWORD] detector flags (bit = sample)
+    unsigned long long *fbits = obits + dk::NWORD;                                         // [NWORD] flags after fusion / border clearing
+    unsigned short *index = reinterpret_cast<unsigned short *>(fbits + dk::NWORD);       // [FCAP]
+    unsigned char *bwv = reinterpret_cast<unsigned char *>(index + FCAP);                 // [FCAP] band width per pivot
+    auto fbit = [&](int pos) -> bool { return (fbits[pos >> 6] >> (pos & 63)) & 1ull; };
+    auto obit = [&](int pos) -> bool { return (obits[pos >> 6] >> (pos & 63)) & 1ull; };
     // global scratch of this wave: L[W][MAXAR] | D[W] | y[W] | rhs[W].  Written with plain stores, read back (by other lanes, after
     // a fence) with agent-scope relaxed loads, which bypass the CU's L1 and may be pipelined freely.
     double *gL = scratch + (size_t)blockIdx.x * scratch_per_wave;
     double *gD = gL + (size_t)W * MAXAR, *gY = gD + W, *gV = gY + W;
     unsigned long long repaired = 0, singular = 0;
+    int a0, b0;                                                     // pair (row, column) of the trailing update this lane owns first
+    {
+        a0 = (int)((sqrtf(8.0f * (float)lane + 1.0f) - 1.0f) * 0.5f);
+        a0 += ((a0 + 1) * (a0 + 2) / 2 <= lane); a0 -= (a0 * (a0 + 1) / 2 > lane);
+        b0 = lane - a0 * (a0 + 1) / 2;
+    }
 #ifdef JT_DK_PROFILE
     unsigned long long tph[8] = {0,0,0,0,0,0,0,0}; unsigned long long tc = wall_clock64();
 #define DK_MARK(i) { unsigned long long t_ = wall_clock64(); tph[i] += t_ - tc; tc = t_; }
@@ -70,14 +84,15 @@ k_adeclick(const double *__restrict__ in, double *__restrict__ out, int64_t n, D
 #define DK_MARK(i)
 #endif
 
-    for (int64_t w = blockIdx.x; w < P.nwindows; w += gridDim.x) {
+    const int64_t nwork = HEAVY ? (int64_t)stats[2] : P.nwindows;
+    for (int64_t wi = blockIdx.x; wi < nwork; wi += gridDim.x) {
+        const int64_t w = HEAVY ? (int64_t)heavy[wi] : wi;
         const int64_t s0 = w * P.hop - P.skip;                          // input position of src[0]
         const int64_t o0 = w * P.hop;
         // ---- 1. window samples (zeros before the stream and past its end), loudnorm's linear gain applied on the way in
         for (int j = lane; j < W; j += 64) {
             const int64_t p = s0 + j;
             src[j] = (p >= 0 && p < n) ? __dmul_rn(in[p], P.gain) : 0.0;
-            click[j] = 0;
         }
         DK_MARK(0)
         // ---- 2. autocorrelation(src, AR, W, r, 1/W): lane = lag, terms in j-ascending order
@@ -117,27 +132,28 @@ k_adeclick(const double *__restrict__ in, double *__restrict__ out, int64_t n, D
         // ---- 3. Levinson-Durbin (autoregression()): k -> ac[], sigma_e = sqrt(alpha)
         double sigmae;
         {
-            if (lane < AR) aa[lane] = 0.0;
+            // lane j keeps a[j] in a register; a[i-j-1] arrives by a lane permute that only depends on the previous iteration, so the
+            // per-iteration chain is: readlane sum -> divide -> one multiply-add
             const double r0 = rr[0], r1 = rr[1];
             const double k0 = -r1 / r0;
-            if (lane == 0) aa[0] = k0;
+            double areg = lane == 0 ? k0 : 0.0;
             double alpha = __dmul_rn(r0, __dsub_rn(1.0, __dmul_rn(k0, k0)));
             for (int i = 1; i < AR; ++i) {
                 // epsilon = sum_{j<i} a[j] * r[i-j] (j ascending) + r[i+1]: the products in parallel, the sum as a readlane chain
-                const double prod = lane < i ? __dmul_rn(aa[lane], rr[i - lane]) : 0.0;
+                const double rrev = rr[lane < i ? i - lane : 0];
+                const double arev = __shfl(areg, lane < i ? i - lane - 1 : 0, 64);
+                const double prod = lane < i ? __dmul_rn(areg, rrev) : 0.0;
                 double eps = 0.0;
                 for (int j = 0; j < i; ++j) eps = __dadd_rn(eps, dk_readlane(prod, j));
                 eps = __dadd_rn(eps, rr[i + 1]);
                 const double ki = -eps / alpha;
                 alpha = __dmul_rn(alpha, __dsub_rn(1.0, __dmul_rn(ki, ki)));
                 // k[j] = a[j] + k[i] * a[i-j-1], j = i-1..0 (independent); k[i] = ki; then a[0..i] = k[0..i]
-                double nk = 0.0;
-                if (lane < i) nk = __dadd_rn(aa[lane], __dmul_rn(ki, aa[i - lane - 1]));
-                else if (lane == i) nk = ki;
-                if (lane <= i) aa[lane] = nk;
+                if (lane < i) areg = __dadd_rn(areg, __dmul_rn(ki, arev));
+                else if (lane == i) areg = ki;
             }
             if (lane == 0) ac[0] = 1.0;
-            if (lane >= 1 && lane <= AR) ac[lane] = aa[lane - 1];
+            if (lane < AR) ac[lane + 1] = areg;
             sigmae = sqrt(alpha);
         }
         DK_MARK(2)
@@ -150,10 +166,11 @@ k_adeclick(const double *__restrict__ in, double *__restrict__ out, int64_t n, D
         if (finite) {
             // ---- 4. detection[i] = sum_{j=0..AR} ac[j] * src[i-j] (j ascending), click = |detection| > sigmae * threshold
             const double thr = __dmul_rn(sigmae, P.threshold);
-            for (int i0 = AR; i0 < W; i0 += 512) {
+            const int nword = (W + 63) >> 6;
+            for (int i0 = 0; i0 < W; i0 += 512) {
                 int ii[8], ic[8]; double dd[8];
 #pragma unroll
-                for (int q = 0; q < 8; ++q) { ii[q] = i0 + 64 * q + lane; ic[q] = ii[q] < W ? ii[q] : W - 1; dd[q] = 0.0; }
+                for (int q = 0; q < 8; ++q) { ii[q] = i0 + 64 * q + lane; ic[q] = ii[q] < AR ? AR : (ii[q] < W ? ii[q] : W - 1); dd[q] = 0.0; }
 #pragma unroll 7
                 for (int j = 0; j <= AR; ++j) {
                     const double c = ac[j];
@@ -161,29 +178,36 @@ k_adeclick(const double *__restrict__ in, double *__restrict__ out, int64_t n, D
                     for (int q = 0; q < 8; ++q) dd[q] = __dadd_rn(dd[q], __dmul_rn(c, src[ic[q] - j]));
                 }
 #pragma unroll
-                for (int q = 0; q < 8; ++q) if (ii[q] < W) click[ii[q]] = fabs(dd[q]) > thr;
-            }
-            // ---- 5. burst fusion: the gap between two consecutive flagged samples p < q is filled when 1 < q-p <= nburst
-            //         (the sequential loop only ever compares original flags, bit 0; fills go to bit 1)
-            if (P.nburst > 1) {
-                for (int i0 = 0; i0 < W; i0 += 64) {
-                    const int j = i0 + lane;
-                    if (j < W && !(click[j] & 1)) {
-                        int p = -1, q = -1;
-                        for (int t = 1; t < P.nburst && j - t >= 0; ++t) if (click[j - t] & 1) { p = j - t; break; }
-                        for (int t = 1; t < P.nburst && j + t < W; ++t) if (click[j + t] & 1) { q = j + t; break; }
-                        if (p >= 0 && q >= 0 && q - p <= P.nburst) click[j] |= 2;
-                    }
+                for (int q = 0; q < 8; ++q) {
+                    const unsigned long long bal = __ballot(ii[q] >= AR && ii[q] < W && fabs(dd[q]) > thr);   // detection[i < AR] = 0
+                    if (lane == 0 && (i0 >> 6) + q < nword) obits[(i0 >> 6) + q] = bal;
                 }
             }
-            // ---- 6. index list of the flagged samples inside [AR, W-AR); click[] becomes that set's indicator
-            for (int i0 = 0; i0 < W; i0 += 64) {
-                const int j = i0 + lane;
-                const bool fl = j >= AR && j < W - AR && click[j] != 0;
+            // ---- 5. burst fusion: the gap between two consecutive flagged samples p < q is filled when 1 < q-p <= nburst (the
+            //         sequential loop only ever compares the detector's own flags); 6. borders cleared, index list in order
+            for (int wd = 0; wd < nword; ++wd) {
+                const int j = wd * 64 + lane;
+                bool fl = false;
+                if (j < W) {
+                    fl = obit(j);
+                    if (!fl && P.nburst > 1) {
+                        int p = -1, q = -1;
+                        for (int t = 1; t < P.nburst && j - t >= 0; ++t) if (obit(j - t)) { p = j - t; break; }
+                        for (int t = 1; t < P.nburst && j + t < W; ++t) if (obit(j + t)) { q = j + t; break; }
+                        fl = p >= 0 && q >= 0 && q - p <= P.nburst;
+                    }
+                    fl = fl && j >= AR && j < W - AR;
+                }
                 const unsigned long long bal = __ballot(fl);
-                if (fl) index[F + __popcll(bal & ((1ull << lane) - 1ull))] = (unsigned short)j;
-                if (j < W) click[j] = fl ? 1 : 0;
+                if (lane == 0) fbits[wd] = bal;
+                const int slot = F + __popcll(bal & ((1ull << lane) - 1ull));
+                if (fl && slot < FCAP) index[slot] = (unsigned short)j;
                 F += __popcll(bal);
+            }
+            if (F > FCAP) {
+                // does not fit this instance's LDS layout: hand the window to the full-capacity pass
+                if (!HEAVY && lane == 0) heavy[atomicAdd(&stats[2], 1ull)] = (int)w;
+                continue;
             }
             // band width of every pivot: rows k+1 .. k+bw are within AR samples of row k (index[] increases): upper bound by bisection
             for (int k = lane; k < F; k += 64) {
@@ -203,22 +227,29 @@ k_adeclick(const double *__restrict__ in, double *__restrict__ out, int64_t n, D
                 aux[lane] = __dmul_rn(value, 1.0);
             }
             // ---- 8. right-hand side: vector[e] = -sum_{j=-AR..AR, index[e]-j not flagged} src[index[e]-j] * aux[|j|]
-            for (int e0 = 0; e0 < F; e0 += 256) {
-                int ie[4]; double val[4];
+            for (int e0 = 0; e0 < F; e0 += 128) {
+                int ie[2]; double val[2];
 #pragma unroll
-                for (int q = 0; q < 4; ++q) { const int e = e0 + 64 * q + lane; ie[q] = index[e < F ? e : F - 1]; val[q] = 0.0; }
-#pragma unroll 4
-                for (int j = -AR; j <= AR; ++j) {
-                    const double ax = aux[j < 0 ? -j : j];
+                for (int q = 0; q < 2; ++q) { const int e = e0 + 64 * q + lane; ie[q] = index[e < F ? e : F - 1]; val[q] = 0.0; }
+                // terms j = -AR .. AR in order; 8 at a time: the 8 x 2 x (flag, sample) reads are issued before the chain consumes them
+                for (int j0 = -AR; j0 <= AR; j0 += 8) {
+                    double tv[2][8];
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const int pos = ie[q] - j;
-                        const double t = click[pos] ? 0.0 : __dmul_rn(src[pos], ax);     // flagged samples are the unknowns: x - 0 is exact
-                        val[q] = __dsub_rn(val[q], t);
+                    for (int u = 0; u < 8; ++u) {
+                        const int j = j0 + u;
+                        const int jj = j <= AR ? j : AR;                         // clamp the tail batch (its extra terms are dropped below)
+                        const double ax = aux[jj < 0 ? -jj : jj];
+#pragma unroll
+                        for (int q = 0; q < 2; ++q) {
+                            const int pos = ie[q] - jj;
+                            tv[q][u] = (fbit(pos) || j > AR) ? 0.0 : __dmul_rn(src[pos], ax);   // flagged samples are the unknowns: x - 0 is exact
+                        }
                     }
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) { val[0] = __dsub_rn(val[0], tv[0][u]); val[1] = __dsub_rn(val[1], tv[1][u]); }
                 }
 #pragma unroll
-                for (int q = 0; q < 4; ++q) { const int e = e0 + 64 * q + lane; if (e < F) gV[e] = val[q]; }
+                for (int q = 0; q < 2; ++q) { const int e = e0 + 64 * q + lane; if (e < F) gV[e] = val[q]; }
             }
             __threadfence();
             DK_MARK(4)
@@ -251,15 +282,24 @@ k_adeclick(const double *__restrict__ in, double *__restrict__ out, int64_t n, D
                 if (lane == 0) { gD[k] = d; gY[k] = yk / d; }      // y/d is what the back substitution starts every row from
                 // forward substitution (k ascending = FFmpeg's j-ascending order for every row)
                 if (lane < bw) ywin[rs] = __dsub_rn(ywin[rs], __dmul_rn(l, yk));
-                // trailing update: entry (k+1+a, k+1+b), 0 <= b <= a < bw:  -= (d * L_b) * L_a   (one pair per lane)
-                if (lane < MAXAR) lvec[lane] = l;
+                // trailing update: entry (k+1+a, k+1+b), 0 <= b <= a < bw:  -= (d * L_b) * L_a.  Pair t = lane (a0, b0 fixed per lane) takes
+                // its two multipliers by lane permutes; bands wider than 10 rows (more than 64 pairs) finish through LDS.
                 const int npairs = bw * (bw + 1) / 2;
-                for (int t = lane; t < npairs; t += 64) {
-                    int a = (int)((sqrtf(8.0f * (float)t + 1.0f) - 1.0f) * 0.5f);       // unrank t -> (a, b)
-                    a += ((a + 1) * (a + 2) / 2 <= t); a -= (a * (a + 1) / 2 > t);
-                    const int b = t - a * (a + 1) / 2;
-                    double *e = &blk[((k + 1 + a) % BS) * BS + ((k + 1 + b) % BS)];
-                    *e = __dsub_rn(*e, __dmul_rn(__dmul_rn(d, lvec[b]), lvec[a]));
+                {
+                    double *e = &blk[((k + 1 + a0) % BS) * BS + ((k + 1 + b0) % BS)];
+                    const double eold = lane < npairs ? *e : 0.0;
+                    const double la = __shfl(l, a0, 64), lb = __shfl(l, b0, 64);
+                    if (lane < npairs) *e = __dsub_rn(eold, __dmul_rn(__dmul_rn(d, lb), la));
+                }
+                if (npairs > 64) {
+                    if (lane < MAXAR) lvec[lane] = l;
+                    for (int t = lane + 64; t < npairs; t += 64) {
+                        int a = (int)((sqrtf(8.0f * (float)t + 1.0f) - 1.0f) * 0.5f);       // unrank t -> (a, b)
+                        a += ((a + 1) * (a + 2) / 2 <= t); a -= (a * (a + 1) / 2 > t);
+                        const int b = t - a * (a + 1) / 2;
+                        double *e = &blk[((k + 1 + a) % BS) * BS + ((k + 1 + b) % BS)];
+                        *e = __dsub_rn(*e, __dmul_rn(__dmul_rn(d, lvec[b]), lvec[a]));
+                    }
                 }
                 // row k leaves the block; row k + BS enters with its original entries against the rows still in reach
                 const int nj = k + BS;
@@ -280,13 +320,13 @@ k_adeclick(const double *__restrict__ in, double *__restrict__ out, int64_t n, D
                     double Lr[16];
 #pragma unroll
                     for (int q = 0; q < 16; ++q) { const int i = ib - q; Lr[q] = (i >= 0 && lane < MAXAR) ? dk_ld(&gL[(size_t)i * MAXAR + lane]) : 0.0; }
-                    double qr = 0.0;
-                    if (lane < 16 && ib - lane >= 0) qr = dk_ld(&gY[ib - lane]);
+                    double qr = 0.0; int ntr = 0, posr = 0;
+                    if (lane < 16 && ib - lane >= 0) { qr = dk_ld(&gY[ib - lane]); ntr = bwv[ib - lane]; posr = index[ib - lane]; }
 #pragma unroll
                     for (int q = 0; q < 16; ++q) {
                         const int i = ib - q;
                         if (i < 0) break;
-                        const int nt = bwv[i];
+                        const int nt = __builtin_amdgcn_readlane(ntr, q);
                         double v = dk_readlane(qr, q);
                         const double term = __dmul_rn(Lr[q], sw);
                         for (int t = 0; t < nt; ++t) v = __dsub_rn(v, dk_readlane(term, t));
@@ -296,7 +336,7 @@ k_adeclick(const double *__restrict__ in, double *__restrict__ out, int64_t n, D
                             const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(sw), 0x138, 0xf, 0xf, false);
                             sw = lane == 0 ? v : __hiloint2double(hi, lo);
                         }
-                        const int pos = index[i];
+                        const int pos = __builtin_amdgcn_readlane(posr, q);
                         if (lane == 0 && pos >= P.skip && pos < P.skip + P.hop && o0 + (pos - P.skip) < n) out[o0 + (pos - P.skip)] = v;
                     }
                 }
@@ -311,7 +351,7 @@ k_adeclick(const double *__restrict__ in, double *__restrict__ out, int64_t n, D
         for (int j = lane; j < P.hop; j += 64) {
             const int64_t o = o0 + j;
             const int pos = P.skip + j;
-            if (o < n && !(rep && click[pos])) {
+            if (o < n && !(rep && fbit(pos))) {
                 const int64_t p = s0 + pos;
                 out[o] = (p >= 0 && p < n) ? __dmul_rn(in[p], P.gain) : 0.0;
             }
@@ -320,7 +360,7 @@ k_adeclick(const double *__restrict__ in, double *__restrict__ out, int64_t n, D
     if (lane == 0 && (repaired || singular)) { atomicAdd(&stats[0], repaired); atomicAdd(&stats[1], singular); }
 #ifdef JT_DK_PROFILE
     DK_MARK(7)
-    if (lane == 0) for (int i = 0; i < 8; ++i) atomicAdd(&stats[2 + i], tph[i]);
+    if (lane == 0) for (int i = 0; i < 8; ++i) atomicAdd(&stats[4 + i], tph[i]);
 #endif
 }
 
@@ -347,13 +387,24 @@ void launch_adeclick(jt_ctx *h, const double *in, double *out, int64_t n, int sa
     P.skip = (P.W - P.hop) / 2;
     P.threshold = threshold; P.gain = gain;
     P.nwindows = (n + P.hop - 1) / P.hop;
-    const size_t per_wave = (size_t)P.W * dk::MAXAR + 3 * (size_t)P.W;
     P.sa = (std::max(P.W, dk::BS * dk::BS) + 1) & ~1;
-    const size_t smem = sizeof(double) * (size_t)(P.sa + 6 * (dk::BS + 1)) + sizeof(unsigned short) * (size_t)((P.W + 3) & ~3) + 2 * (size_t)((P.W + 3) & ~3) + 16;
-    JT_REQUIRE(smem <= 64 * 1024, JT_E_UNSUPPORTED, "adeclick: window does not fit the per-wave LDS budget");
-    int waves_per_cu = (int)std::min<size_t>(8, (160 * 1024) / smem);
-    const int64_t grid = std::min<int64_t>(P.nwindows, (int64_t)256 * waves_per_cu);
-    h->declick_scr.ensure(per_wave * (size_t)grid);
-    JT_HIP(hipFuncSetAttribute((const void *)k_adeclick, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-    hipLaunchKernelGGL(k_adeclick, dim3((unsigned)grid), dim3(64), smem, s, in, out, n, P, h->declick_scr.p, per_wave, d_stats);
+    constexpr int LIGHT = 512;
+    const int fullcap = (P.W + 63) & ~63;
+    auto smem_for = [&](int fcap) {
+        return sizeof(double) * (size_t)(P.sa + 6 * (dk::BS + 1)) + sizeof(unsigned long long) * 2 * dk::NWORD + (size_t)fcap * 3 + 16;
+    };
+    (void)fullcap;
+    const size_t smem_l = smem_for(LIGHT), smem_h = smem_for(dk::MAXW);
+    JT_REQUIRE(smem_h <= 64 * 1024, JT_E_UNSUPPORTED, "adeclick: window does not fit the per-wave LDS budget");
+    const size_t per_wave = (size_t)P.W * dk::MAXAR + 3 * (size_t)P.W;
+    const int wl = (int)std::min<size_t>(8, (160 * 1024) / smem_l), wh = (int)std::min<size_t>(8, (160 * 1024) / smem_h);
+    const int64_t grid_l = std::min<int64_t>(P.nwindows, (int64_t)256 * wl), grid_h = std::min<int64_t>(P.nwindows, (int64_t)256 * wh);
+    h->declick_scr.ensure(per_wave * (size_t)std::max(grid_l, grid_h));
+    h->declick_heavy.ensure((size_t)P.nwindows);
+    auto kl = k_adeclick<LIGHT, false>; auto kh = k_adeclick<dk::MAXW, true>;
+    JT_HIP(hipFuncSetAttribute((const void *)kl, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_l));
+    JT_HIP(hipFuncSetAttribute((const void *)kh, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_h));
+    hipLaunchKernelGGL(kl, dim3((unsigned)grid_l), dim3(64), smem_l, s, in, out, n, P, h->declick_scr.p, per_wave, d_stats, h->declick_heavy.p);
+    // windows with more than LIGHT flagged samples (none on ordinary speech): same kernel, full-capacity LDS layout, list length read on the device
+    hipLaunchKernelGGL(kh, dim3((unsigned)grid_h), dim3(64), smem_h, s, in, out, n, P, h->declick_scr.p, per_wave, d_stats, h->declick_heavy.p);
 }

@@ -164,6 +164,12 @@ def test_adeclick_other_thresholds_and_rates(engine, oracle):
     for thr in (2.0, 4.0):                                           # w=50 ms at 48 kHz: AR order 48, the largest this build lays out
         assert np.array_equal(engine.op_adeclick(x, 48000, thr, 50.0, 50.0), oracle.adeclick(x, 48000, thr, 50.0, 50.0))
     assert np.array_equal(engine.op_adeclick(x, 48000, 1.7, 40.0, 75.0), oracle.adeclick(x, 48000, 1.7, 40.0, 75.0))
+    # dense flags (a third of the samples at t = 1.0): more than the light instance's 512-entry layout, so the windows go
+    # through the full-capacity second pass, and the band reaches the AR order
+    z = noise(12000, 0.05, 77).astype(np.float64)
+    ref, nz = oracle.adeclick(z, 44100, 1.0, 55.0, 50.0, return_count=True)
+    assert nz / (z.size / 1212) > 512
+    assert np.array_equal(engine.op_adeclick(z, 44100, 1.0, 55.0, 50.0), ref)
     with pytest.raises(L.JtError) as ei:                             # 55 ms at 48 kHz needs order 52: refused, never approximated
         engine.op_adeclick(x, 48000, 1.7, 55.0, 50.0)
     assert ei.value.code == L.JT_E_UNSUPPORTED
