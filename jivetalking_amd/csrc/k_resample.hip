@@ -33,10 +33,10 @@ k_polyphase(const TIn *__restrict__ in, int64_t n, const TTap *__restrict__ bank
         if ((s0i - center >= 0) && (s0i - center + 63 * d147::STEP + 7 * d147::SW <= n) && (mlo + d147::NOUT <= m_total)) return;
     }
     extern __shared__ unsigned char smem_pp[];
-    TAcc *xin = reinterpret_cast<TAcc *>(smem_pp);
+    TIn *xin = reinterpret_cast<TIn *>(smem_pp);            // staged in the input type (a 96 k -> 44.1 k tile is 20 k samples)
     const int T = 64 * R * (int)step;
     const int nin = T + L;
-    int16_t *otile = reinterpret_cast<int16_t *>(xin + skew(nin) + 2);
+    int16_t *otile = reinterpret_cast<int16_t *>(smem_pp + (((size_t)(skew(nin) + 2) * sizeof(TIn) + 7) & ~(size_t)7));
     __shared__ unsigned long long slots[8];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int64_t s0 = (int64_t)blockIdx.x * T;
@@ -46,10 +46,10 @@ k_polyphase(const TIn *__restrict__ in, int64_t n, const TTap *__restrict__ bank
     const int flush = MODE != 0;
     for (int i = tid; i < nin; i += PP_THREADS) {
         int64_t g = s0 - center + i;
-        TAcc v = (TAcc)0;
+        TIn v = (TIn)0;
         if (g < 0) g = -g;                                           // invert_initial_buffer(): in[-j] = in[j]
-        if (g < n) v = (TAcc)((TAcc)in[g] * (TAcc)in_scale);
-        else if (flush) { int64_t r = 2 * n - 1 - g; if (r >= 0 && r < n) v = (TAcc)((TAcc)in[r] * (TAcc)in_scale); }   // resample_flush()
+        if (g < n) v = in[g];
+        else if (flush) { int64_t r = 2 * n - 1 - g; if (r >= 0 && r < n) v = in[r]; }   // resample_flush()
         xin[skew(i)] = v;
     }
     if (MODE == 0 && tid < 8) slots[tid] = 0ull;
@@ -74,13 +74,13 @@ k_polyphase(const TIn *__restrict__ in, int64_t n, const TTap *__restrict__ bank
             // of the accumulator per tap and halves the VALU work)
             if (L == 32) {
 #pragma unroll
-                for (int i = 0; i < 32; ++i) val = fma(xin[skew(si + i)], (TAcc)f[i], val);
+                for (int i = 0; i < 32; ++i) val = fma((TAcc)((TAcc)xin[skew(si + i)] * (TAcc)in_scale), (TAcc)f[i], val);
             } else if (L == 36) {
 #pragma unroll
-                for (int i = 0; i < 36; ++i) val = fma(xin[skew(si + i)], (TAcc)f[i], val);
+                for (int i = 0; i < 36; ++i) val = fma((TAcc)((TAcc)xin[skew(si + i)] * (TAcc)in_scale), (TAcc)f[i], val);
             } else {
 #pragma unroll 4
-                for (int i = 0; i < L; ++i) val = fma(xin[skew(si + i)], (TAcc)f[i], val);
+                for (int i = 0; i < L; ++i) val = fma((TAcc)((TAcc)xin[skew(si + i)] * (TAcc)in_scale), (TAcc)f[i], val);
             }
         }
         if (MODE == 0) {
@@ -304,7 +304,7 @@ k_down147(const float *__restrict__ in, int64_t n, const double *__restrict__ ba
 }
 
 struct PPGeom { int R; int T; size_t smem; unsigned grid; };
-template <typename TAcc>
+template <typename TIn>
 static PPGeom pp_geometry(int64_t n, int P, int L, int64_t step, int64_t m_total, bool otile)
 {
     PPGeom g;
@@ -312,7 +312,7 @@ static PPGeom pp_geometry(int64_t n, int P, int L, int64_t step, int64_t m_total
     if (otile) while (R > 1 && (size_t)64 * R * P * 2 > 48 * 1024) R >>= 1;
     g.R = R; g.T = 64 * R * (int)step;
     int nin = g.T + L;
-    g.smem = sizeof(TAcc) * (size_t)(nin + (nin >> 5) + 4) + (otile ? (size_t)64 * R * P * 2 + 16 : 0);
+    g.smem = ((sizeof(TIn) * (size_t)(nin + (nin >> 5) + 4) + 7) & ~(size_t)7) + (otile ? (size_t)64 * R * P * 2 + 16 : 0);
     int64_t per_block = (int64_t)64 * R * P;
     g.grid = (unsigned)((m_total + per_block - 1) / per_block);
     (void)n;
@@ -325,7 +325,7 @@ void launch_true_peak_f32(const float *in, int64_t n, const double *bank, int ph
     if (m_total <= 0) return;
     if (launch_upsample32<float, double, double, 0>(in, n, bank, phase_count, filter_length, center, step, m_total, 1.0, blk, block_tp,
                                                    nblocks_alloc, (double *)nullptr, s)) return;
-    PPGeom g = pp_geometry<double>(n, phase_count, filter_length, step, m_total, false);
+    PPGeom g = pp_geometry<float>(n, phase_count, filter_length, step, m_total, false);
     JT_REQUIRE(g.smem <= 150 * 1024, JT_E_UNSUPPORTED, "true peak: rate ratio needs too large an LDS tile");
     auto k = k_polyphase<float, double, double, 0>;
     JT_HIP(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)g.smem));
@@ -352,7 +352,7 @@ void launch_resample_to_s16(const float *in, int64_t n, const double *bank, int 
                             int64_t step, int16_t *out, int64_t m, hipStream_t s)
 {
     if (m <= 0) return;
-    PPGeom g = pp_geometry<double>(n, phase_count, filter_length, step, m, true);
+    PPGeom g = pp_geometry<float>(n, phase_count, filter_length, step, m, true);
     JT_REQUIRE(g.smem <= 150 * 1024, JT_E_UNSUPPORTED, "resample: rate ratio needs too large an LDS tile");
     const bool fast = phase_count == d147::P && step == d147::STEP && filter_length == d147::L && g.R == 1;
     if (fast) hipLaunchKernelGGL(k_down147, dim3(g.grid), dim3(64), 0, s, in, n, bank, center, m, out);
@@ -370,7 +370,7 @@ void launch_resample_stream_s16_f32(const int16_t *in, int64_t n, const float *b
     if (m_total <= 0) return;
     if (launch_upsample32<int16_t, float, float, 2>(in, n, bankf, phase_count, filter_length, center, step, m_total, 1.0 / 32768.0, 1,
                                                    (double *)nullptr, (int64_t)0, out, s)) return;
-    PPGeom g = pp_geometry<float>(n, phase_count, filter_length, step, m_total, false);
+    PPGeom g = pp_geometry<int16_t>(n, phase_count, filter_length, step, m_total, false);
     auto k = k_polyphase<int16_t, float, float, 2>;
     JT_HIP(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)g.smem));
     hipLaunchKernelGGL(k, dim3(g.grid), dim3(PP_THREADS), g.smem, s, in, n, bankf, phase_count, filter_length, center, step, m_total,

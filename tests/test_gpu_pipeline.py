@@ -123,3 +123,31 @@ def test_stereo_downmix_and_silence_guard(engine):
     with pytest.raises(L.JtError) as ei:
         H.process_audio(engine)
     assert ei.value.code in (L.JT_E_SILENT, L.JT_E_UNSUPPORTED)
+
+
+# ---------------------------------------------------------------- BASELINE.json configs[4]: 96 kHz stereo input
+def test_96k_stereo_downmix_and_resample_path(engine, oracle):
+    """96 kHz stereo with L != R: rematrix downmix (0.5/0.5), Pass-1/2 at 96 kHz (anlmdn generic path K=576 S=192, afftdn 4096-point
+    instance), 96 k -> 44.1 k polyphase (72 taps, 147 phases, step 320), true peak via 96 k -> 192 k; Pass 3/4 at 44.1 kHz."""
+    sr = 96000
+    a = synth.speech_like(40.0, sr, seed=31)
+    b = np.roll(a, 37) * 0.8 + synth.speech_like(40.0, sr, seed=32) * 0.1
+    st = np.empty(a.size * 2, np.float32); st[0::2] = a; st[1::2] = b
+    engine.upload_pcm(st, sr, 2)
+    res = H.process_audio(engine)
+    p2, p4 = engine.download_s16(2), engine.download_s16(4)
+    mono = (a * np.float32(0.5) + b * np.float32(0.5)).astype(np.float32)          # swresample rematrix, float path
+    # Pass 1 on the downmix
+    e = oracle.ebur128(mono.astype(np.float64), sr, True, True)
+    assert abs(res.input.input_i - e["integrated"]) < 0.002
+    assert abs(res.input.input_tp - 20 * np.log10(e["true_peak"])) < 0.05
+    # Pass 2 chain + 96k -> 44.1k
+    fp = L.FilterParams()
+    H.lib().jt_host_filter_params(C.byref(res.effective), C.byref(fp))
+    _, ref2 = oracle_pass2(oracle, mono, fp, sr)
+    assert ref2.size == p2.size == int(np.ceil(mono.size * 147 / 320))
+    d = np.abs(ref2.astype(np.int32) - p2.astype(np.int32))
+    assert d.max() <= 3 and d.mean() < 0.3
+    # landing
+    f = oracle.ebur128(p4.astype(np.float64) / 32768.0, 44100, True, True)
+    assert abs(f["integrated"] + 16.0) <= 0.15 and 20 * np.log10(f["true_peak"]) <= -1.0
