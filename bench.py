@@ -61,6 +61,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--minutes", type=float, default=60.0, help="audio minutes per file (BASELINE configs[1] = 60)")
     ap.add_argument("--cpu-sample", type=float, default=20.0, help="seconds of audio for the CPU oracle baseline (0 = skip)")
+    ap.add_argument("--in-flight", type=int, default=1,
+                    help="extra measurement (not `value`): K files per GPU processed concurrently, one context + host thread each "
+                         "(BASELINE configs[3], throughput saturation); reported as `saturation`")
     args = ap.parse_args()
 
     import torch
@@ -110,6 +113,27 @@ def main():
     dt = time.perf_counter() - t0
     dt = shard.max_over_ranks(dt, device=f"cuda:{local_rank}")
 
+    sat = None
+    if args.in_flight > 1:
+        # K independent contexts (own streams, own buffers) share the GPU; the C calls release the GIL
+        import threading
+        engs = [eng] + [Engine(local_rank) for _ in range(args.in_flight - 1)]
+        for e2 in engs[1:]:
+            e2.attach_device_pcm(x.data_ptr(), n, sr, 1, keepalive=x)
+            hostlogic.process_audio(e2, base, 4096)                       # warm-up (allocations)
+        def worker(e2, k):
+            for _ in range(k):
+                hostlogic.process_audio(e2, base, 4096)
+        barrier()
+        t1 = time.perf_counter()
+        th = [threading.Thread(target=worker, args=(e2, args.steps)) for e2 in engs]
+        for t_ in th: t_.start()
+        for t_ in th: t_.join()
+        barrier()
+        dt2 = shard.max_over_ranks(time.perf_counter() - t1, device=f"cuda:{local_rank}")
+        sat = {"files_in_flight_per_gpu": args.in_flight, "xRT": round(world * args.in_flight * args.steps * seconds / dt2, 1),
+               "ms_per_file": round(dt2 / (args.in_flight * args.steps) * 1e3, 3)}
+        for e2 in engs[1:]: e2.close()
     if rank == 0:
         import numpy as np
         m = int(-(-n * 147 // 160))
@@ -170,6 +194,8 @@ def main():
             "roofline": roof,
             "second_kernel": nlm_roof,
         }
+        if sat is not None:
+            out["saturation"] = sat
         if world == 1 and args.cpu_sample > 0:
             out["cpu_baseline"] = cpu_baseline(args.cpu_sample, sr)
         print(json.dumps(out))
