@@ -27,7 +27,8 @@ constexpr int NWORD = MAXW / 64;  // 64-sample flag words per window
 
 struct DeclickParams {
     int W, hop, skip, ar, nburst;
-    int sa;                       // doubles reserved for the window samples / factorisation block: max(W, BS*BS), even
+    int sa;                       // doubles reserved for the sample buffer / factorisation block of the instance being launched
+    int lb;                       // half-window buffer length (light instance)
     double threshold, gain;
     int64_t nwindows;
 };
@@ -41,10 +42,13 @@ __device__ inline double dk_readlane(double v, int l)
     return __hiloint2double(hi, lo);
 }
 
-// FCAP = flagged samples per window the LDS layout holds.  The light instance (512) runs first at 7 waves per CU; windows with
-// more flags than that append themselves to `heavy` and are redone by the full-capacity instance (HEAVY = true), which takes its
-// window ids from that list.  stats: [0] repaired samples, [1] singular windows, [2] length of the heavy list.
-template <int FCAP, bool HEAVY>
+// Two instances of one kernel:
+//   light  <FCAP 512, BSD 33, HALF>:  the window's samples stream through LDS in two overlapping halves (every phase that reads them
+//          only looks AR samples around its position), the factorisation block is 33 x 33 (bands up to 32 rows): 15 KB of LDS per
+//          wave, 10 waves per CU.  A window with more than 512 flagged samples or a band wider than 32 rows appends itself to `heavy`;
+//   heavy  <FCAP MAXW, BSD 49, full window resident, HEAVY>: redoes exactly those windows (list length read on the device).
+// stats: [0] repaired samples, [1] singular windows, [2] length of the heavy list.
+template <int FCAP, int BSD, bool HALF, bool HEAVY>
 __global__ void __launch_bounds__(64)
 k_adeclick(const double *__restrict__ in, double *__restrict__ out, int64_t n, DeclickParams P, double *scratch,
            size_t scratch_per_wave, unsigned long long *__restrict__ stats, int *__restrict__ heavy)
@@ -52,18 +56,17 @@ k_adeclick(const double *__restrict__ in, double *__restrict__ out, int64_t n, D
     extern __shared__ unsigned char dk_smem[];
     const int lane = threadIdx.x;
     const int W = P.W, AR = P.ar;
-    constexpr int BS = dk::BS, MAXAR = dk::MAXAR;
-    double *src = reinterpret_cast<double *>(dk_smem);                 // [W] ; later the BS x BS sliding block
-    double *rr = src + P.sa;                                            // r[AR+1]
-    double *ac = rr + BS + 1;                                           // acoefficients k[AR+1]
-    double *aa = ac + BS + 1;                                           // a[AR]
-    double *aux = aa + BS + 1;                                          // aux[AR+1]
-    double *lvec = aux + BS + 1;                                        // pivot column multipliers
-    double *ywin = lvec + BS + 1;                                       // sliding right-hand side / y
-    unsigned long long *obits = reinterpret_cast<unsigned long long *>(ywin + BS + 1);   // [NWORD] detector flags (bit = sample)
-    unsigned long long *fbits = obits + dk::NWORD;                                         // [NWORD] flags after fusion / border clearing
-    unsigned short *index = reinterpret_cast<unsigned short *>(fbits + dk::NWORD);       // [FCAP]
-    unsigned char *bwv = reinterpret_cast<unsigned char *>(index + FCAP);                 // [FCAP] band width per pivot
+    constexpr int BS = BSD, MAXAR = dk::MAXAR;
+    double *sbuf = reinterpret_cast<double *>(dk_smem);                // window samples [LB] ; later the BS x BS sliding block
+    double *rr = sbuf + P.sa;                                           // r[AR+1]
+    double *ac = rr + dk::BS + 1;                                       // acoefficients k[AR+1]
+    double *aux = ac + dk::BS + 1;                                      // aux[AR+1]
+    double *lvec = aux + dk::BS + 1;                                    // pivot column multipliers (bands wider than 10 rows)
+    double *ywin = lvec + dk::BS + 1;                                   // sliding right-hand side / y
+    unsigned long long *obits = reinterpret_cast<unsigned long long *>(ywin + dk::BS + 1);   // [NWORD] detector flags (bit = sample)
+    unsigned long long *fbits = obits + dk::NWORD;                                            // [NWORD] flags after fusion / border clearing
+    unsigned short *index = reinterpret_cast<unsigned short *>(fbits + dk::NWORD);          // [FCAP]
+    unsigned char *bwv = reinterpret_cast<unsigned char *>(index + FCAP);                    // [FCAP] band width per pivot
     auto fbit = [&](int pos) -> bool { return (fbits[pos >> 6] >> (pos & 63)) & 1ull; };
     auto obit = [&](int pos) -> bool { return (obits[pos >> 6] >> (pos & 63)) & 1ull; };
     // global scratch of this wave: L[W][MAXAR] | D[W] | y[W] | rhs[W].  Written with plain stores, read back (by other lanes, after
@@ -77,6 +80,10 @@ k_adeclick(const double *__restrict__ in, double *__restrict__ out, int64_t n, D
         a0 += ((a0 + 1) * (a0 + 2) / 2 <= lane); a0 -= (a0 * (a0 + 1) / 2 > lane);
         b0 = lane - a0 * (a0 + 1) / 2;
     }
+    // half-window geometry: buffer A = samples [0, LB), buffer B = samples [W-LB, W); positions >= SPLIT are served by B
+    const int LB = HALF ? P.lb : W;
+    const int SB_B = W - LB;                                         // first sample held by buffer B
+    const int SPLIT = HALF ? SB_B + AR : W;
 #ifdef JT_DK_PROFILE
     unsigned long long tph[8] = {0,0,0,0,0,0,0,0}; unsigned long long tc = wall_clock64();
 #define DK_MARK(i) { unsigned long long t_ = wall_clock64(); tph[i] += t_ - tc; tc = t_; }
@@ -87,46 +94,59 @@ k_adeclick(const double *__restrict__ in, double *__restrict__ out, int64_t n, D
     const int64_t nwork = HEAVY ? (int64_t)stats[2] : P.nwindows;
     for (int64_t wi = blockIdx.x; wi < nwork; wi += gridDim.x) {
         const int64_t w = HEAVY ? (int64_t)heavy[wi] : wi;
-        const int64_t s0 = w * P.hop - P.skip;                          // input position of src[0]
+        const int64_t s0 = w * P.hop - P.skip;                          // input position of window sample 0
         const int64_t o0 = w * P.hop;
-        // ---- 1. window samples (zeros before the stream and past its end), loudnorm's linear gain applied on the way in
-        for (int j = lane; j < W; j += 64) {
-            const int64_t p = s0 + j;
-            src[j] = (p >= 0 && p < n) ? __dmul_rn(in[p], P.gain) : 0.0;
-        }
+        int sb = 0;                                                     // window sample held in sbuf[0]
+        // window samples (zeros before the stream and past its end), loudnorm's linear gain applied on the way in
+        auto load_buf = [&](int base) {
+            sb = base;
+            for (int j = lane; j < LB; j += 64) {
+                const int64_t p = s0 + base + j;
+                sbuf[j] = (p >= 0 && p < n) ? __dmul_rn(in[p], P.gain) : 0.0;
+            }
+        };
+        const double *S = sbuf;                                         // S[x - sb] = window sample x
+        load_buf(0);
         DK_MARK(0)
-        // ---- 2. autocorrelation(src, AR, W, r, 1/W): lane = lag, terms in j-ascending order
-        if (lane <= AR) {
+        // ---- 2. autocorrelation(src, AR, W, r, 1/W): lane = lag, terms in j-ascending order, in one or two buffer phases
+        double acv = 0.0;
+        auto autocorr_range = [&](int ja, int jb) {                     // terms j in [ja, jb) of this lane's lag
+            if (lane > AR || ja >= jb) return;
             // 8 terms per block; the next block's 16 LDS reads are in flight while this block's adds (the sequential chain) retire
-            double value = 0.0;
-            int j = lane;
-            double a0[8], b0[8], a1[8], b1[8];
-            const int nb = (W - lane) / 8;
+            const double *sj = S - sb;
+            int j = ja;
+            double x0[8], y0[8], x1[8], y1[8];
+            const int nb = (jb - ja) / 8;
             if (nb > 0) {
 #pragma unroll
-                for (int u = 0; u < 8; ++u) { a0[u] = src[j + u]; b0[u] = src[j + u - lane]; }
+                for (int u = 0; u < 8; ++u) { x0[u] = sj[j + u]; y0[u] = sj[j + u - lane]; }
             }
             int blk8 = 0;
             for (; blk8 + 1 < nb; blk8 += 2) {
 #pragma unroll
-                for (int u = 0; u < 8; ++u) { a1[u] = src[j + 8 + u]; b1[u] = src[j + 8 + u - lane]; }
+                for (int u = 0; u < 8; ++u) { x1[u] = sj[j + 8 + u]; y1[u] = sj[j + 8 + u - lane]; }
 #pragma unroll
-                for (int u = 0; u < 8; ++u) value = __dadd_rn(value, __dmul_rn(a0[u], b0[u]));
+                for (int u = 0; u < 8; ++u) acv = __dadd_rn(acv, __dmul_rn(x0[u], y0[u]));
                 if (blk8 + 2 < nb) {
 #pragma unroll
-                    for (int u = 0; u < 8; ++u) { a0[u] = src[j + 16 + u]; b0[u] = src[j + 16 + u - lane]; }
+                    for (int u = 0; u < 8; ++u) { x0[u] = sj[j + 16 + u]; y0[u] = sj[j + 16 + u - lane]; }
                 }
 #pragma unroll
-                for (int u = 0; u < 8; ++u) value = __dadd_rn(value, __dmul_rn(a1[u], b1[u]));
+                for (int u = 0; u < 8; ++u) acv = __dadd_rn(acv, __dmul_rn(x1[u], y1[u]));
                 j += 16;
             }
             if (blk8 < nb) {
 #pragma unroll
-                for (int u = 0; u < 8; ++u) value = __dadd_rn(value, __dmul_rn(a0[u], b0[u]));
+                for (int u = 0; u < 8; ++u) acv = __dadd_rn(acv, __dmul_rn(x0[u], y0[u]));
                 j += 8;
             }
-            for (; j < W; ++j) value = __dadd_rn(value, __dmul_rn(src[j], src[j - lane]));
-            rr[lane] = __dmul_rn(value, 1.0 / W);
+            for (; j < jb; ++j) acv = __dadd_rn(acv, __dmul_rn(sj[j], sj[j - lane]));
+        };
+        {
+            const int jsplit = lane > SPLIT ? lane : SPLIT;
+            autocorr_range(lane, jsplit < W ? jsplit : W);
+            if (HALF) { load_buf(SB_B); autocorr_range(jsplit, W); }
+            if (lane <= AR) rr[lane] = __dmul_rn(acv, 1.0 / W);
         }
         DK_MARK(1)
         // ---- 3. Levinson-Durbin (autoregression()): k -> ac[], sigma_e = sqrt(alpha)
@@ -163,26 +183,33 @@ k_adeclick(const double *__restrict__ in, double *__restrict__ out, int64_t n, D
             finite = !__any(!isfinite(v));
         }
         int F = 0;
+        bool to_heavy = false;
         if (finite) {
             // ---- 4. detection[i] = sum_{j=0..AR} ac[j] * src[i-j] (j ascending), click = |detection| > sigmae * threshold
             const double thr = __dmul_rn(sigmae, P.threshold);
             const int nword = (W + 63) >> 6;
-            for (int i0 = 0; i0 < W; i0 += 512) {
-                int ii[8], ic[8]; double dd[8];
+            for (int wd = lane; wd < nword; wd += 64) obits[wd] = 0ull;
+            auto detect_range = [&](int ia, int ib) {                  // samples i in [ia, ib) against the buffer currently loaded
+                const double *sj = S - sb;
+                for (int i0 = (ia >> 6) << 6; i0 < ib; i0 += 512) {
+                    int ii[8], ic[8]; double dd[8];
 #pragma unroll
-                for (int q = 0; q < 8; ++q) { ii[q] = i0 + 64 * q + lane; ic[q] = ii[q] < AR ? AR : (ii[q] < W ? ii[q] : W - 1); dd[q] = 0.0; }
+                    for (int q = 0; q < 8; ++q) { ii[q] = i0 + 64 * q + lane; ic[q] = ii[q] < ia ? ia : (ii[q] < ib ? ii[q] : ib - 1); dd[q] = 0.0; }
 #pragma unroll 7
-                for (int j = 0; j <= AR; ++j) {
-                    const double c = ac[j];
+                    for (int j = 0; j <= AR; ++j) {
+                        const double c = ac[j];
 #pragma unroll
-                    for (int q = 0; q < 8; ++q) dd[q] = __dadd_rn(dd[q], __dmul_rn(c, src[ic[q] - j]));
-                }
+                        for (int q = 0; q < 8; ++q) dd[q] = __dadd_rn(dd[q], __dmul_rn(c, sj[ic[q] - j]));
+                    }
 #pragma unroll
-                for (int q = 0; q < 8; ++q) {
-                    const unsigned long long bal = __ballot(ii[q] >= AR && ii[q] < W && fabs(dd[q]) > thr);   // detection[i < AR] = 0
-                    if (lane == 0 && (i0 >> 6) + q < nword) obits[(i0 >> 6) + q] = bal;
+                    for (int q = 0; q < 8; ++q) {
+                        const unsigned long long bal = __ballot(ii[q] >= ia && ii[q] < ib && fabs(dd[q]) > thr);
+                        if (lane == 0 && (i0 >> 6) + q < nword && bal) obits[(i0 >> 6) + q] |= bal;
+                    }
                 }
-            }
+            };
+            if (HALF) { detect_range(SPLIT > AR ? SPLIT : AR, W); load_buf(0); detect_range(AR, SPLIT < W ? SPLIT : W); }   // detection[i < AR] = 0
+            else detect_range(AR, W);
             // ---- 5. burst fusion: the gap between two consecutive flagged samples p < q is filled when 1 < q-p <= nburst (the
             //         sequential loop only ever compares the detector's own flags); 6. borders cleared, index list in order
             for (int wd = 0; wd < nword; ++wd) {
@@ -204,18 +231,24 @@ k_adeclick(const double *__restrict__ in, double *__restrict__ out, int64_t n, D
                 if (fl && slot < FCAP) index[slot] = (unsigned short)j;
                 F += __popcll(bal);
             }
-            if (F > FCAP) {
-                // does not fit this instance's LDS layout: hand the window to the full-capacity pass
-                if (!HEAVY && lane == 0) heavy[atomicAdd(&stats[2], 1ull)] = (int)w;
-                continue;
+            to_heavy = F > FCAP;
+            if (!to_heavy) {
+                // band width of every pivot: rows k+1 .. k+bw are within AR samples of row k (index[] increases): upper bound by bisection
+                int bwmax = 0;
+                for (int k = lane; k < F; k += 64) {
+                    const int lim = (int)index[k] + AR;
+                    int lo = k, hi = min(F - 1, k + MAXAR);              // last row r in [k, hi] with index[r] <= lim
+                    while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if ((int)index[mid] <= lim) lo = mid; else hi = mid - 1; }
+                    bwv[k] = (unsigned char)(lo - k);
+                    bwmax = max(bwmax, lo - k);
+                }
+                to_heavy = __any(bwmax > BS - 1);
             }
-            // band width of every pivot: rows k+1 .. k+bw are within AR samples of row k (index[] increases): upper bound by bisection
-            for (int k = lane; k < F; k += 64) {
-                const int lim = (int)index[k] + AR;
-                int lo = k, hi = min(F - 1, k + MAXAR);              // last row r in [k, hi] with index[r] <= lim
-                while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if ((int)index[mid] <= lim) lo = mid; else hi = mid - 1; }
-                bwv[k] = (unsigned char)(lo - k);
-            }
+        }
+        if (to_heavy) {
+            // does not fit this instance's LDS layout: hand the window to the full-capacity pass
+            if (!HEAVY && lane == 0) heavy[atomicAdd(&stats[2], 1ull)] = (int)w;
+            continue;
         }
         DK_MARK(3)
         bool ok = true;
@@ -227,35 +260,45 @@ k_adeclick(const double *__restrict__ in, double *__restrict__ out, int64_t n, D
                 aux[lane] = __dmul_rn(value, 1.0);
             }
             // ---- 8. right-hand side: vector[e] = -sum_{j=-AR..AR, index[e]-j not flagged} src[index[e]-j] * aux[|j|]
-            for (int e0 = 0; e0 < F; e0 += 128) {
-                int ie[2]; double val[2];
+            auto rhs_range = [&](int ea, int eb) {                     // entries [ea, eb) against the buffer currently loaded
+                const double *sj = S - sb;
+                for (int e0 = ea; e0 < eb; e0 += 128) {
+                    int ie[2]; double val[2];
 #pragma unroll
-                for (int q = 0; q < 2; ++q) { const int e = e0 + 64 * q + lane; ie[q] = index[e < F ? e : F - 1]; val[q] = 0.0; }
-                // terms j = -AR .. AR in order; 8 at a time: the 8 x 2 x (flag, sample) reads are issued before the chain consumes them
-                for (int j0 = -AR; j0 <= AR; j0 += 8) {
-                    double tv[2][8];
+                    for (int q = 0; q < 2; ++q) { const int e = e0 + 64 * q + lane; ie[q] = index[e < eb ? e : eb - 1]; val[q] = 0.0; }
+                    // terms j = -AR .. AR in order; 8 at a time: the reads are issued before the chain consumes them
+                    for (int j0 = -AR; j0 <= AR; j0 += 8) {
+                        double tv[2][8];
 #pragma unroll
-                    for (int u = 0; u < 8; ++u) {
-                        const int j = j0 + u;
-                        const int jj = j <= AR ? j : AR;                         // clamp the tail batch (its extra terms are dropped below)
-                        const double ax = aux[jj < 0 ? -jj : jj];
+                        for (int u = 0; u < 8; ++u) {
+                            const int j = j0 + u;
+                            const int jj = j <= AR ? j : AR;                     // clamp the tail batch (its extra terms are dropped below)
+                            const double ax = aux[jj < 0 ? -jj : jj];
 #pragma unroll
-                        for (int q = 0; q < 2; ++q) {
-                            const int pos = ie[q] - jj;
-                            tv[q][u] = (fbit(pos) || j > AR) ? 0.0 : __dmul_rn(src[pos], ax);   // flagged samples are the unknowns: x - 0 is exact
+                            for (int q = 0; q < 2; ++q) {
+                                const int pos = ie[q] - jj;
+                                tv[q][u] = (fbit(pos) || j > AR) ? 0.0 : __dmul_rn(sj[pos], ax);   // flagged samples are the unknowns: x - 0 is exact
+                            }
                         }
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) { val[0] = __dsub_rn(val[0], tv[0][u]); val[1] = __dsub_rn(val[1], tv[1][u]); }
                     }
 #pragma unroll
-                    for (int u = 0; u < 8; ++u) { val[0] = __dsub_rn(val[0], tv[0][u]); val[1] = __dsub_rn(val[1], tv[1][u]); }
+                    for (int q = 0; q < 2; ++q) { const int e = e0 + 64 * q + lane; if (e < eb) gV[e] = val[q]; }
                 }
-#pragma unroll
-                for (int q = 0; q < 2; ++q) { const int e = e0 + 64 * q + lane; if (e < F) gV[e] = val[q]; }
-            }
+            };
+            if (HALF) {
+                // entries whose +-AR neighbourhood lies inside buffer A (currently loaded), then the rest against buffer B
+                int ea = 0;
+                for (int e0 = 0; e0 < F; e0 += 64) { const int e = e0 + lane; ea += __popcll(__ballot(e < F && (int)index[e] + AR < LB)); }
+                rhs_range(0, ea);
+                if (ea < F) { load_buf(SB_B); rhs_range(ea, F); }
+            } else rhs_range(0, F);
             __threadfence();
             DK_MARK(4)
             // ---- 9. LDL^T (cholesky_decomposition) right-looking inside the band, forward substitution fused.
             // blk[(j % BS) * BS + (i % BS)] holds entry (j, i), i <= j, of the rows currently within reach of the pivot.
-            double *blk = src;
+            double *blk = sbuf;
             auto entry0 = [&](int j, int i) -> double {           // original matrix entry (j >= i)
                 const int dlt = (int)index[j] - (int)index[i];
                 return dlt <= AR ? aux[dlt] : 0.0;
@@ -387,24 +430,36 @@ void launch_adeclick(jt_ctx *h, const double *in, double *out, int64_t n, int sa
     P.skip = (P.W - P.hop) / 2;
     P.threshold = threshold; P.gain = gain;
     P.nwindows = (n + P.hop - 1) / P.hop;
-    P.sa = (std::max(P.W, dk::BS * dk::BS) + 1) & ~1;
-    constexpr int LIGHT = 512;
-    const int fullcap = (P.W + 63) & ~63;
-    auto smem_for = [&](int fcap) {
-        return sizeof(double) * (size_t)(P.sa + 6 * (dk::BS + 1)) + sizeof(unsigned long long) * 2 * dk::NWORD + (size_t)fcap * 3 + 16;
+    constexpr int LIGHT = 512, LBS = 33;
+    // half-window buffer: every +-AR neighbourhood must fit one of the two halves (lb >= (W + 2 AR) / 2), multiple of 8
+    P.lb = ((P.W + 2 * P.ar + 1) / 2 + 16 + 7) & ~7;
+    const bool half_ok = P.lb < P.W && P.ar < P.lb / 4;
+    const int sa_l = ((half_ok ? std::max(P.lb, LBS * LBS) : std::max(P.W, LBS * LBS)) + 1) & ~1;
+    const int sa_h = (std::max(P.W, dk::BS * dk::BS) + 1) & ~1;
+    auto smem_for = [&](int sa, int fcap) {
+        return sizeof(double) * (size_t)(sa + 5 * (dk::BS + 1)) + sizeof(unsigned long long) * 2 * dk::NWORD + (size_t)fcap * 3 + 16;
     };
-    (void)fullcap;
-    const size_t smem_l = smem_for(LIGHT), smem_h = smem_for(dk::MAXW);
+    const size_t smem_l = smem_for(sa_l, LIGHT), smem_h = smem_for(sa_h, dk::MAXW);
     JT_REQUIRE(smem_h <= 64 * 1024, JT_E_UNSUPPORTED, "adeclick: window does not fit the per-wave LDS budget");
     const size_t per_wave = (size_t)P.W * dk::MAXAR + 3 * (size_t)P.W;
-    const int wl = (int)std::min<size_t>(8, (160 * 1024) / smem_l), wh = (int)std::min<size_t>(8, (160 * 1024) / smem_h);
+    int wl = (int)std::min<size_t>(12, (160 * 1024) / smem_l), wh = (int)std::min<size_t>(8, (160 * 1024) / smem_h);
+    if (const char *ev = getenv("JT_DK_WAVES")) wl = std::max(1, std::min(wl, atoi(ev)));      // occupancy experiments
     const int64_t grid_l = std::min<int64_t>(P.nwindows, (int64_t)256 * wl), grid_h = std::min<int64_t>(P.nwindows, (int64_t)256 * wh);
     h->declick_scr.ensure(per_wave * (size_t)std::max(grid_l, grid_h));
     h->declick_heavy.ensure((size_t)P.nwindows);
-    auto kl = k_adeclick<LIGHT, false>; auto kh = k_adeclick<dk::MAXW, true>;
-    JT_HIP(hipFuncSetAttribute((const void *)kl, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_l));
+    DeclickParams Pl = P, Ph = P; Pl.sa = sa_l; Ph.sa = sa_h;
+    auto kh = k_adeclick<dk::MAXW, dk::BS, false, true>;
     JT_HIP(hipFuncSetAttribute((const void *)kh, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_h));
-    hipLaunchKernelGGL(kl, dim3((unsigned)grid_l), dim3(64), smem_l, s, in, out, n, P, h->declick_scr.p, per_wave, d_stats, h->declick_heavy.p);
-    // windows with more than LIGHT flagged samples (none on ordinary speech): same kernel, full-capacity LDS layout, list length read on the device
-    hipLaunchKernelGGL(kh, dim3((unsigned)grid_h), dim3(64), smem_h, s, in, out, n, P, h->declick_scr.p, per_wave, d_stats, h->declick_heavy.p);
+    if (half_ok) {
+        auto kl = k_adeclick<LIGHT, LBS, true, false>;
+        JT_HIP(hipFuncSetAttribute((const void *)kl, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_l));
+        hipLaunchKernelGGL(kl, dim3((unsigned)grid_l), dim3(64), smem_l, s, in, out, n, Pl, h->declick_scr.p, per_wave, d_stats, h->declick_heavy.p);
+    } else {
+        auto kl = k_adeclick<LIGHT, LBS, false, false>;
+        JT_HIP(hipFuncSetAttribute((const void *)kl, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_l));
+        hipLaunchKernelGGL(kl, dim3((unsigned)grid_l), dim3(64), smem_l, s, in, out, n, Pl, h->declick_scr.p, per_wave, d_stats, h->declick_heavy.p);
+    }
+    // windows with more than LIGHT flagged samples or a band wider than 32 rows (few on ordinary speech): full-capacity instance over
+    // the list the first pass built; its length is read on the device
+    hipLaunchKernelGGL(kh, dim3((unsigned)grid_h), dim3(64), smem_h, s, in, out, n, Ph, h->declick_scr.p, per_wave, d_stats, h->declick_heavy.p);
 }
