@@ -6,8 +6,15 @@
 #include <memory>
 
 #define JT_API_BEGIN(h) if (!(h)) return JT_E_INVAL; try { JT_HIP(hipSetDevice((h)->device));
-#define JT_API_END(h) } catch (const JtError &e) { (h)->err = e.msg; return e.code; } \
-    catch (const std::exception &e) { (h)->err = e.what(); return JT_E_HIP; } return JT_OK;
+// On failure the streams are drained before returning: a pass may have queued kernels and copies into the pinned arena, and the
+// next call is allowed to resize or reuse both.
+static void jt_drain(jt_ctx *h)
+{
+    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    for (int i = 0; i < 4; ++i) if (h->aux[i]) (void)hipStreamSynchronize(h->aux[i]);
+}
+#define JT_API_END(h) } catch (const JtError &e) { jt_drain(h); (h)->err = e.msg; return e.code; } \
+    catch (const std::exception &e) { jt_drain(h); (h)->err = e.what(); return JT_E_HIP; } return JT_OK;
 
 static void check_cancel(jt_ctx *h) { if (h->cancelled.load()) throw JtError{JT_E_CANCELLED, "cancelled"}; }
 
@@ -153,6 +160,11 @@ static void pass_begin(jt_ctx *h, int64_t max_samples, int analyses)
     ensure_twiddle(h, 2048); ensure_hann(h, 2048);
     h->pin.begin(jt_arena_bytes_for(max_samples) * (size_t)std::max(1, analyses) + (4u << 20));
     h->kw_begin((size_t)(max_samples / 512 + 1024) * 8 * (size_t)std::max(1, analyses));
+    h->as_begin(((size_t)(1u << 20) + (size_t)max_samples / 64) * (size_t)std::max(1, analyses));
+    // the remaining analysis scratch is shared by jobs that are serialised on one stream; size it now, while nothing is queued
+    h->d_scr1.ensure((size_t)(max_samples / 400 + 16));
+    h->spec_hops.ensure((size_t)(max_samples / 512 + 16));
+    h->ehist.ensure(8192);
 }
 
 // ---------------------------------------------------------------- analysis of a mono f32 signal on device

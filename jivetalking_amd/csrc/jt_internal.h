@@ -201,6 +201,14 @@ struct jt_ctx {
     DevBuf<int64_t> lim_bounds, lim_pos; DevBuf<double> lim_delta;
     DevBuf<int> af_bin2band; DevBuf<double> af_tab;
     HostArena pin;
+    // per-pass bump allocator over d_scr2 for the astats jobs: the three chains of different jobs run on different streams, so
+    // every job needs its own scratch slice (sized at the start of the pass, never reallocated while work is queued)
+    size_t as_off = 0;
+    void as_begin(size_t bytes) { d_scr2.ensure((bytes + 7) / 8); as_off = 0; }
+    unsigned char *as_take(size_t bytes) {
+        if (as_off + bytes > d_scr2.n * sizeof(double)) throw JtError{JT_E_HIP, "astats scratch exhausted"};
+        unsigned char *r = reinterpret_cast<unsigned char *>(d_scr2.p) + as_off; as_off += (bytes + 255) & ~(size_t)255; return r;
+    }
     // per-pass bump allocator over d_scr0 for the K-weighting jobs (several can be in flight before the pass's sync)
     size_t kw_off = 0;
     void kw_begin(size_t doubles) { d_scr0.ensure(doubles); kw_off = 0; }

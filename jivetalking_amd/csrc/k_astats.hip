@@ -402,8 +402,7 @@ void jt_astats_enqueue(jt_ctx *h, const float *x, int64_t n, int sr, AstatsJob *
                  o_mm = o_nf + sizeof(AsNF) * nparts, o_smin = o_mm + 16, o_smax = o_smin + 8 * (size_t)nsig,
                  head = o_smax + 8 * (size_t)nsig, o_zs = head, o_carry = o_zs + 8 * (size_t)nchunks,
                  total = o_carry + 8 * 3 * (size_t)nsig;      // blkA | blkB | blk_in
-    h->d_scr2.ensure((total + 7) / 8);
-    unsigned char *base = reinterpret_cast<unsigned char *>(h->d_scr2.p);
+    unsigned char *base = h->as_take(total);
     AsPartial *d_part = reinterpret_cast<AsPartial *>(base + o_part);
     AsRuns *d_runs = reinterpret_cast<AsRuns *>(base + o_runs);
     AsNF *d_nf = reinterpret_cast<AsNF *>(base + o_nf);

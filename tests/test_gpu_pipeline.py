@@ -151,3 +151,56 @@ def test_96k_stereo_downmix_and_resample_path(engine, oracle):
     # landing
     f = oracle.ebur128(p4.astype(np.float64) / 32768.0, 44100, True, True)
     assert abs(f["integrated"] + 16.0) <= 0.15 and 20 * np.log10(f["true_peak"]) <= -1.0
+
+
+# ---------------------------------------------------------------- error behaviour and the smaller entry points
+def test_error_codes_and_refusals():
+    from jivetalking_amd import Engine
+    from jivetalking_amd.engine import default_filter_params
+    with Engine(0) as e:
+        with pytest.raises(L.JtError) as ei:                        # nothing uploaded yet
+            e.pass2(default_filter_params())
+        assert ei.value.code == L.JT_E_STATE
+        x = synth.speech_like(8.0, SR, seed=41)
+        e.upload_pcm(x, SR, 1)
+        p = default_filter_params()
+        p.fft_enabled = 1; p.fft_track_noise = 1                   # afftdn tn=1 is refused, never approximated
+        with pytest.raises(L.JtError) as ei:
+            e.pass2(p)
+        assert ei.value.code == L.JT_E_UNSUPPORTED
+        with pytest.raises(L.JtError) as ei:                        # Pass 3 before any Pass-2 output exists
+            e.pass3()
+        assert ei.value.code == L.JT_E_STATE
+        # the context stays usable after a refused call
+        p.fft_track_noise = 0
+        a = e.pass2(p)
+        assert np.isfinite(a["r128"]["integrated"])
+
+
+def test_region_pair_equals_two_single_calls(engine, oracle):
+    x = synth.speech_like(25.0, SR, seed=42)
+    engine.upload_pcm(x, SR, 1)
+    H.process_audio(engine)
+    p2 = engine.download_s16(2)
+    # the region pair call must agree with two single-region calls bit for bit, and with the oracle on the same samples
+    st = [3.0, 11.5]; du = [4.0, 6.25]
+    pair = (L.RegionSample * 2)()
+    rc = engine.lib.jt_region_measure_pair(engine.h, C.c_int(2), (C.c_double * 2)(*st), (C.c_double * 2)(*du), pair)
+    assert rc == 0
+    for k in range(2):
+        one = engine.region_measure(2, st[k], du[k])
+        assert one["rms_level"] == pair[k].rms_level and one["true_peak"] == pair[k].true_peak
+        assert one["spectral"]["centroid"] == pair[k].spectral.centroid and one["frames"] == pair[k].frames
+        # and with the oracle on the downloaded Pass-2 samples of that region
+        s0 = int(round(st[k] * 44100)); n = int(round(du[k] * 44100))
+        seg = p2[s0:s0 + n].astype(np.float64) / 32768.0
+        a = oracle.astats(seg, 44100)
+        assert abs(one["rms_level"] - a["rms_level_db"]) < 1e-6
+
+
+def test_two_runs_are_bit_identical(engine):
+    x = synth.speech_like(20.0, SR, seed=43)
+    engine.upload_pcm(x, SR, 1)
+    r1 = H.process_audio(engine); o1 = engine.download_s16(4).copy()
+    r2 = H.process_audio(engine); o2 = engine.download_s16(4)
+    assert np.array_equal(o1, o2) and r1.output_lufs == r2.output_lufs and r1.pass2_spec == r2.pass2_spec
