@@ -155,6 +155,11 @@ typedef struct {
     double stage_ms[10];     /* host wall-clock: pass1, intervals+VAD, bands, adapt, pass2, regions(2), plan, pass3, pass4, regions(4) */
 } jt_process_result;
 
+/* Output naming (processor.go:379-388): "<dir>/<name without its last extension>-LUFS-<n>-processed.flac",
+ * n = round-half-away(|output LUFS|).  Returns the length written (excluding the NUL), or -1 when cap is too small. */
+int jt_host_lufs_filename_value(double output_lufs);
+int jt_host_output_path(const char *input_path, int lufs_value, char *out, int cap);
+
 int jt_process_audio(jt_ctx *h, const jt_host_config *base, int frame_samples, jt_process_result *out);
 int jt_analyse_only(jt_ctx *h, const jt_host_config *base, int frame_samples, jt_process_result *out);   /* AnalyseOnlyDetailed (processor.go:29-69) */
 

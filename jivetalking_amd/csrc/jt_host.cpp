@@ -1055,6 +1055,25 @@ extern "C" int jt_analyse_only(jt_ctx *h, const jt_host_config *base, int frame_
     return analyse_core(h, base, frame_samples, out, &eff);
 }
 
+// generateLUFSOutputPath / lufsFilenameValue (processor.go:379-388): filepath.Dir / Base / Ext semantics for slash-separated paths
+extern "C" int jt_host_lufs_filename_value(double output_lufs) { return (int)std::round(std::fabs(output_lufs)); }
+extern "C" int jt_host_output_path(const char *input_path, int lufs_value, char *out, int cap)
+{
+    if (!input_path || !out || cap <= 0) return -1;
+    std::string p(input_path);
+    while (p.size() > 1 && p.back() == '/') p.pop_back();                      // filepath.Base strips trailing separators
+    const size_t sl = p.find_last_of('/');
+    std::string dir = sl == std::string::npos ? "." : (sl == 0 ? "/" : p.substr(0, sl));
+    std::string base = sl == std::string::npos ? p : p.substr(sl + 1);
+    const size_t dot = base.find_last_of('.');                                 // filepath.Ext: from the last '.' of the last element
+    if (dot != std::string::npos) base = base.substr(0, dot);
+    std::string joined = dir == "." ? "" : (dir == "/" ? "/" : dir + "/");     // filepath.Join cleans "./x" to "x"
+    std::string r = joined + sfmt("%s-LUFS-%d-processed.flac", base.c_str(), lufs_value);
+    if ((int)r.size() + 1 > cap) return -1;
+    std::memcpy(out, r.c_str(), r.size() + 1);
+    return (int)r.size();
+}
+
 extern "C" int jt_process_audio(jt_ctx *h, const jt_host_config *base, int frame_samples, jt_process_result *out)
 {
     if (!h || !base || !out) return JT_E_INVAL;

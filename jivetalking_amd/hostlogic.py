@@ -111,7 +111,8 @@ HOST_SYMBOLS = ["jt_host_build_intervals", "jt_host_detect", "jt_host_finish_mea
                 "jt_host_calculate_linear_mode_target", "jt_host_loudnorm_internal_target_tp", "jt_host_pass4_spec",
                 "jt_process_audio", "jt_analyse_only", "jt_host_vad_detect", "jt_host_vad_split", "jt_host_vad_speech_runs",
                 "jt_host_vad_gap_tolerance", "jt_host_vad_gate_stats", "jt_host_vad_noise_seed",
-                "jt_host_vad_pick_low_cluster", "jt_host_vad_floored_fraction", "jt_host_sizeof"]
+                "jt_host_vad_pick_low_cluster", "jt_host_vad_floored_fraction", "jt_host_sizeof",
+                "jt_host_lufs_filename_value", "jt_host_output_path"]
 
 
 def lib():
@@ -177,3 +178,15 @@ def process_audio(engine, base=None, frame_samples=4096, analyse_only=False):
     if rc != 0:
         raise L.JtError(rc, l.jt_last_error(engine.h).decode())
     return res
+
+
+def output_path(input_path, lufs_value):
+    buf = C.create_string_buffer(4096)
+    n = lib().jt_host_output_path(input_path.encode(), C.c_int(lufs_value), buf, C.c_int(4096))
+    if n < 0:
+        raise ValueError("output path too long")
+    return buf.value.decode()
+
+
+def lufs_filename_value(lufs):
+    return lib().jt_host_lufs_filename_value(C.c_double(lufs))

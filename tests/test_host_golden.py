@@ -395,3 +395,15 @@ def test_afftdn_band_edges(lib):
         wlo = c[0] / math.sqrt(c[1] / c[0]) if i == 0 else math.sqrt(c[i - 1] * c[i])
         whi = c[14] * math.sqrt(c[14] / c[13]) if i == 14 else math.sqrt(c[i] * c[i + 1])
         assert lo.value == wlo and hi.value == whi
+
+
+# ---------------------------------------------------------------- output naming (processor_test.go:18-62)
+def test_output_path_and_lufs_filename_value():
+    cases = [("/tmp/foo.wav", "/tmp/foo-LUFS-16-processed.flac"), ("/tmp/foo.WAV", "/tmp/foo-LUFS-16-processed.flac"),
+             ("/tmp/foo.flac", "/tmp/foo-LUFS-16-processed.flac"), ("/tmp/foo.mp3", "/tmp/foo-LUFS-16-processed.flac"),
+             ("/tmp/foo", "/tmp/foo-LUFS-16-processed.flac"), ("/tmp/foo.bar.wav", "/tmp/foo.bar-LUFS-16-processed.flac")]
+    for inp, want in cases:
+        assert H.output_path(inp, 16) == want
+    assert H.output_path("clip.wav", 16) == "clip-LUFS-16-processed.flac"
+    for lufs, want in [(-16.4, 16), (-16.5, 17), (-16.6, 17), (15.5, 16)]:
+        assert H.lufs_filename_value(lufs) == want
