@@ -247,7 +247,7 @@ k_adeclick(const double *__restrict__ in, double *__restrict__ out, int64_t n, D
         }
         if (to_heavy) {
             // does not fit this instance's LDS layout: hand the window to the full-capacity pass
-            if (!HEAVY && lane == 0) heavy[atomicAdd(&stats[2], 1ull)] = (int)w;
+            if (!HEAVY && lane == 0) { heavy[atomicAdd(&stats[2], 1ull)] = (int)w; if (F > FCAP) atomicAdd(&stats[3], 1ull); }
             continue;
         }
         DK_MARK(3)
