@@ -160,7 +160,7 @@ static void pass_begin(jt_ctx *h, int64_t max_samples, int analyses)
     ensure_twiddle(h, 2048); ensure_hann(h, 2048);
     h->pin.begin(jt_arena_bytes_for(max_samples) * (size_t)std::max(1, analyses) + (4u << 20));
     h->kw_begin((size_t)(max_samples / 512 + 1024) * 8 * (size_t)std::max(1, analyses));
-    h->as_begin(((size_t)(1u << 20) + (size_t)max_samples / 64) * (size_t)std::max(1, analyses));
+    h->as_begin(((size_t)(2u << 20) + (size_t)max_samples / 6) * (size_t)std::max(1, analyses));
     // the remaining analysis scratch is shared by jobs that are serialised on one stream; size it now, while nothing is queued
     h->d_scr1.ensure((size_t)(max_samples / 400 + 16));
     h->spec_hops.ensure((size_t)(max_samples / 512 + 16));

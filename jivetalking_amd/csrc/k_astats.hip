@@ -261,6 +261,74 @@ k_as_nf_fused(const float *__restrict__ x, int64_t n, int tc, int64_t ntiles, As
     }
 }
 
+// Noise floor without LDS: sliding-window peak from registers.  Window [s, s+tc) with s = 64 bs + l (lane l) ends at
+// e = 64 (bs + q) + l + r, q = (tc-1)/64, r = (tc-1)%64.  Its maximum is
+//     max( suffix-max of block bs from lane l,  max of the whole blocks in between,  prefix-max of the end block up to its lane ),
+// the whole blocks being bs+1 .. bs+q-1 (one more, bs+q, for the lanes whose end wraps into block bs+q+1).  Block maxima and
+// their (q-1)-wide running maxima are two tiny pre-passes; the main kernel is three DPP scans and three lane permutes per
+// 64 outputs.  Maxima are order independent, so the result equals the sequential filter's.
+__global__ void __launch_bounds__(256)
+k_nf_blockmax(const float *__restrict__ x, int64_t n, float *__restrict__ bm, int64_t nblocks)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t w = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 6, nw = ((int64_t)gridDim.x * 256) >> 6;
+    for (int64_t b = w; b < nblocks; b += nw) {
+        const int64_t i = b * 64 + lane;
+        float v = i < n ? fabsf(x[i]) : 0.f;
+        for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+        if (lane == 0) bm[b] = v;
+    }
+}
+__global__ void __launch_bounds__(256)
+k_nf_runmax(const float *__restrict__ bm, float *__restrict__ rq, int64_t nblocks, int width)
+{
+    const int64_t b = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (b >= nblocks) return;
+    float m = 0.f;
+    for (int k = 0; k < width && b + k < nblocks; ++k) m = fmaxf(m, bm[b + k]);
+    rq[b] = m;
+}
+__global__ void __launch_bounds__(256)
+k_nf_main(const float *__restrict__ x, int64_t n, int tc, const float *__restrict__ bm, const float *__restrict__ rq, int64_t nstartblocks,
+          AsNF *__restrict__ part)
+{
+    __shared__ AsNF sp[4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int q = (tc - 1) >> 6, r = (tc - 1) & 63;
+    const int64_t w0 = (int64_t)blockIdx.x * 4 + wave, nw = (int64_t)gridDim.x * 4;
+    double nf = DBL_MAX; unsigned long long cnt = 0;
+    for (int64_t bs = w0; bs < nstartblocks; bs += nw) {
+        const int64_t i0 = bs * 64, iq = (bs + q) * 64, iq1 = iq + 64;
+        const int64_t ir = i0 + (63 - lane);
+        const float xr = ir < n ? fabsf(x[ir]) : 0.f;                                  // block bs, reversed lane order
+        const float xq = iq + lane < n ? fabsf(x[iq + lane]) : 0.f, xq1 = iq1 + lane < n ? fabsf(x[iq1 + lane]) : 0.f;
+        const float grev = wave_prefix_max(xr);                                        // lane j: max of block positions 63-j .. 63
+        const float pq = wave_prefix_max(xq), pq1 = wave_prefix_max(xq1);
+        const float g = __shfl(grev, 63 - lane, 64);                                   // suffix max from position `lane`
+        const int el = lane + r;
+        const float pa = __shfl(pq, el & 63, 64), pb = __shfl(pq1, el & 63, 64);
+        float m = fmaxf(g, el < 64 ? pa : pb);
+        if (q >= 2) m = fmaxf(m, rq[bs + 1]);                                          // blocks bs+1 .. bs+q-1
+        if (el >= 64 && q >= 1) m = fmaxf(m, bm[bs + q]);                              // the end wrapped: block bs+q is whole too
+        const int64_t e = i0 + lane + tc - 1;
+        if (e < n) {
+            const double lp = (double)m;
+            if (lp < nf) { nf = lp; cnt = 1; } else if (lp == nf) cnt++;
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        double onf = __shfl_down(nf, o, 64); unsigned long long oc = __shfl_down(cnt, o, 64);
+        if (onf < nf) { nf = onf; cnt = oc; } else if (onf == nf) cnt += oc;
+    }
+    if (lane == 0) sp[wave] = AsNF{nf, cnt};
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        AsNF a = sp[0];
+        for (int w = 1; w < 4; ++w) { if (sp[w].nf < a.nf) a = sp[w]; else if (sp[w].nf == a.nf) a.cnt += sp[w].cnt; }
+        part[blockIdx.x] = a;
+    }
+}
+
 // exponential power average: zero-state response of each chunk (one thread per chunk, coalesced through LDS rows)
 constexpr int ZC = 1024;     // chunk length
 __global__ void __launch_bounds__(64)
@@ -416,14 +484,17 @@ void jt_astats_enqueue(jt_ctx *h, const float *x, int64_t n, int sr, AstatsJob *
     const bool have_nf = n >= tc;
     int nf_parts = nparts;
     if (have_nf) {
-        const int nb64 = (NF_TILE + tc - 1 + 63) / 64;
-        const size_t smem = sizeof(float) * ((size_t)nb64 * 130);
-        if (tc >= 129 && smem <= 150 * 1024) {
-            const int64_t ntiles = (n - tc + 1 + NF_TILE - 1) / NF_TILE;
-            nf_parts = (int)std::min<int64_t>(ntiles, nparts);
-            JT_HIP(hipFuncSetAttribute((const void *)k_as_nf_fused, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-            hipLaunchKernelGGL(k_as_nf_fused, dim3(nf_parts), dim3(AS_T), smem, sB, x, n, tc, ntiles, d_nf);
-        } else {                                   // very low / very high sample rates: van Herk arrays in HBM
+        if (tc >= 65) {
+            // register/DPP sliding maximum: block maxima, their running maxima, then the per-output combination
+            const int64_t nblocks = (n + 63) / 64 + 2;
+            const int q = (tc - 1) >> 6;
+            float *d_bm = reinterpret_cast<float *>(h->as_take(sizeof(float) * 2 * (size_t)nblocks)), *d_rq = d_bm + nblocks;
+            const int64_t nstart = (n - tc + 1 + 63) / 64;                       // start blocks that contain a complete window start
+            nf_parts = (int)std::min<int64_t>((nstart + 3) / 4, nparts);
+            hipLaunchKernelGGL(k_nf_blockmax, dim3((unsigned)std::min<int64_t>((nblocks + 3) / 4, 4096)), dim3(256), 0, sB, x, n, d_bm, nblocks);
+            hipLaunchKernelGGL(k_nf_runmax, dim3((unsigned)((nblocks + 255) / 256)), dim3(256), 0, sB, d_bm, d_rq, nblocks, std::max(q - 1, 0));
+            hipLaunchKernelGGL(k_nf_main, dim3(nf_parts), dim3(256), 0, sB, x, n, tc, d_bm, d_rq, nstart, d_nf);
+        } else {                                   // very low sample rates: van Herk arrays in HBM
             h->as_g.ensure((size_t)n); h->as_p.ensure((size_t)n);
             const int64_t nb = (n + tc - 1) / tc;
             hipLaunchKernelGGL(k_as_gp, dim3((unsigned)((nb + 63) / 64)), dim3(64), 0, sB, x, h->as_g.p, h->as_p.p, n, tc);
