@@ -660,7 +660,7 @@ extern "C" int jt_pass4(jt_ctx *h, const jt_limiter_plan *lim, const jt_loudnorm
     check_cancel(h);
     if (dk_stats) {
         h->timers.declick_repaired = (int64_t)dk_stats[0]; h->timers.declick_heavy_windows = (int64_t)dk_stats[2];
-        if (getenv("JT_DK_PROFILE")) fprintf(stderr, "adeclick: heavy windows %llu, of which over the flag capacity %llu\n", dk_stats[2], dk_stats[3]);
+        if (getenv("JT_DK_PROFILE")) fprintf(stderr, "adeclick: second-pass windows %llu, third-pass windows %llu\n", dk_stats[2], dk_stats[3]);
         { float dms = 0; JT_HIP(hipEventElapsedTime(&dms, h->ev2, h->ev3)); h->timers.declick_ms = dms; }
         JT_REQUIRE(dk_stats[1] == 0, JT_E_HIP, "adeclick: singular interpolation matrix (af_adeclick.c would fail the graph)");
     }

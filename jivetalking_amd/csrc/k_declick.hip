@@ -46,9 +46,10 @@ __device__ inline double dk_readlane(double v, int l)
 //   light  <FCAP 512, BSD 33, HALF>:  the window's samples stream through LDS in two overlapping halves (every phase that reads them
 //          only looks AR samples around its position), the factorisation block is 33 x 33 (bands up to 32 rows): 15 KB of LDS per
 //          wave, 10 waves per CU.  A window with more than 512 flagged samples or a band wider than 32 rows appends itself to `heavy`;
-//   heavy  <FCAP MAXW, BSD 49, full window resident, HEAVY>: redoes exactly those windows (list length read on the device).
+//   middle <FCAP 1024, BSD 49, HALF> redoes exactly those windows (list length read on the device), and <FCAP MAXW, BSD 49, full
+//          window resident> whatever is denser still.
 // stats: [0] repaired samples, [1] singular windows, [2] length of the heavy list.
-template <int FCAP, int BSD, bool HALF, bool HEAVY>
+template <int FCAP, int BSD, bool HALF, int LEVEL>
 __global__ void __launch_bounds__(64)
 k_adeclick(const double *__restrict__ in, double *__restrict__ out, int64_t n, DeclickParams P, double *scratch,
            size_t scratch_per_wave, unsigned long long *__restrict__ stats, int *__restrict__ heavy)
@@ -91,9 +92,12 @@ k_adeclick(const double *__restrict__ in, double *__restrict__ out, int64_t n, D
 #define DK_MARK(i)
 #endif
 
-    const int64_t nwork = HEAVY ? (int64_t)stats[2] : P.nwindows;
+    // LEVEL 0: every window, overflow -> list A (heavy[0..], stats[2]); LEVEL 1: list A, overflow -> list B (heavy[nwindows..], stats[3]);
+    // LEVEL 2: list B (full capacity, nothing overflows)
+    const int *worklist = LEVEL == 1 ? heavy : heavy + P.nwindows;
+    const int64_t nwork = LEVEL == 0 ? P.nwindows : (int64_t)stats[1 + LEVEL];
     for (int64_t wi = blockIdx.x; wi < nwork; wi += gridDim.x) {
-        const int64_t w = HEAVY ? (int64_t)heavy[wi] : wi;
+        const int64_t w = LEVEL == 0 ? wi : (int64_t)worklist[wi];
         const int64_t s0 = w * P.hop - P.skip;                          // input position of window sample 0
         const int64_t o0 = w * P.hop;
         int sb = 0;                                                     // window sample held in sbuf[0]
@@ -247,7 +251,8 @@ k_adeclick(const double *__restrict__ in, double *__restrict__ out, int64_t n, D
         }
         if (to_heavy) {
             // does not fit this instance's LDS layout: hand the window to the full-capacity pass
-            if (!HEAVY && lane == 0) { heavy[atomicAdd(&stats[2], 1ull)] = (int)w; if (F > FCAP) atomicAdd(&stats[3], 1ull); }
+            if (LEVEL == 0 && lane == 0) heavy[atomicAdd(&stats[2], 1ull)] = (int)w;
+            if (LEVEL == 1 && lane == 0) heavy[P.nwindows + (int64_t)atomicAdd(&stats[3], 1ull)] = (int)w;
             continue;
         }
         DK_MARK(3)
@@ -430,36 +435,38 @@ void launch_adeclick(jt_ctx *h, const double *in, double *out, int64_t n, int sa
     P.skip = (P.W - P.hop) / 2;
     P.threshold = threshold; P.gain = gain;
     P.nwindows = (n + P.hop - 1) / P.hop;
-    constexpr int LIGHT = 512, LBS = 33;
+    constexpr int LIGHT = 512, LBS = 33, MID = 1024;
     // half-window buffer: every +-AR neighbourhood must fit one of the two halves (lb >= (W + 2 AR) / 2), multiple of 8
     P.lb = ((P.W + 2 * P.ar + 1) / 2 + 16 + 7) & ~7;
     const bool half_ok = P.lb < P.W && P.ar < P.lb / 4;
-    const int sa_l = ((half_ok ? std::max(P.lb, LBS * LBS) : std::max(P.W, LBS * LBS)) + 1) & ~1;
-    const int sa_h = (std::max(P.W, dk::BS * dk::BS) + 1) & ~1;
+    auto sa_for = [&](bool half, int bs) { return ((half ? std::max(P.lb, bs * bs) : std::max(P.W, bs * bs)) + 1) & ~1; };
     auto smem_for = [&](int sa, int fcap) {
         return sizeof(double) * (size_t)(sa + 5 * (dk::BS + 1)) + sizeof(unsigned long long) * 2 * dk::NWORD + (size_t)fcap * 3 + 16;
     };
-    const size_t smem_l = smem_for(sa_l, LIGHT), smem_h = smem_for(sa_h, dk::MAXW);
-    JT_REQUIRE(smem_h <= 64 * 1024, JT_E_UNSUPPORTED, "adeclick: window does not fit the per-wave LDS budget");
+    const int sa0 = sa_for(half_ok, LBS), sa1 = sa_for(half_ok, dk::BS), sa2 = sa_for(false, dk::BS);
+    const size_t sm0 = smem_for(sa0, LIGHT), sm1 = smem_for(sa1, MID), sm2 = smem_for(sa2, dk::MAXW);
+    JT_REQUIRE(sm2 <= 64 * 1024, JT_E_UNSUPPORTED, "adeclick: window does not fit the per-wave LDS budget");
     const size_t per_wave = (size_t)P.W * dk::MAXAR + 3 * (size_t)P.W;
-    int wl = (int)std::min<size_t>(12, (160 * 1024) / smem_l), wh = (int)std::min<size_t>(8, (160 * 1024) / smem_h);
-    if (const char *ev = getenv("JT_DK_WAVES")) wl = std::max(1, std::min(wl, atoi(ev)));      // occupancy experiments
-    const int64_t grid_l = std::min<int64_t>(P.nwindows, (int64_t)256 * wl), grid_h = std::min<int64_t>(P.nwindows, (int64_t)256 * wh);
-    h->declick_scr.ensure(per_wave * (size_t)std::max(grid_l, grid_h));
-    h->declick_heavy.ensure((size_t)P.nwindows);
-    DeclickParams Pl = P, Ph = P; Pl.sa = sa_l; Ph.sa = sa_h;
-    auto kh = k_adeclick<dk::MAXW, dk::BS, false, true>;
-    JT_HIP(hipFuncSetAttribute((const void *)kh, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_h));
+    int w0 = (int)std::min<size_t>(12, (160 * 1024) / sm0);
+    const int w1 = (int)std::min<size_t>(8, (160 * 1024) / sm1), w2 = (int)std::min<size_t>(8, (160 * 1024) / sm2);
+    if (const char *ev = getenv("JT_DK_WAVES")) w0 = std::max(1, std::min(w0, atoi(ev)));      // occupancy experiments
+    const int64_t g0 = std::min<int64_t>(P.nwindows, (int64_t)256 * w0), g1 = std::min<int64_t>(P.nwindows, (int64_t)256 * w1),
+                  g2 = std::min<int64_t>(P.nwindows, (int64_t)256 * w2);
+    h->declick_scr.ensure(per_wave * (size_t)std::max(g0, std::max(g1, g2)));
+    h->declick_heavy.ensure(2 * (size_t)P.nwindows);
+    DeclickParams P0 = P, P1 = P, P2 = P; P0.sa = sa0; P1.sa = sa1; P2.sa = sa2;
+    // pass 0: 512 flags / 33 x 33 block per window; pass 1: the windows that overflowed that (bands wider than 32 rows: 7 % of the
+    // bench signal), 1024 flags / 49 x 49; pass 2: anything denser still, full capacity.  List lengths are read on the device.
+#define DK_LAUNCH(KERN, GRID, SMEM, PP) do { auto k_ = KERN; \
+        JT_HIP(hipFuncSetAttribute((const void *)k_, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(SMEM))); \
+        hipLaunchKernelGGL(k_, dim3((unsigned)(GRID)), dim3(64), (SMEM), s, in, out, n, PP, h->declick_scr.p, per_wave, d_stats, h->declick_heavy.p); } while (0)
     if (half_ok) {
-        auto kl = k_adeclick<LIGHT, LBS, true, false>;
-        JT_HIP(hipFuncSetAttribute((const void *)kl, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_l));
-        hipLaunchKernelGGL(kl, dim3((unsigned)grid_l), dim3(64), smem_l, s, in, out, n, Pl, h->declick_scr.p, per_wave, d_stats, h->declick_heavy.p);
+        DK_LAUNCH((k_adeclick<LIGHT, LBS, true, 0>), g0, sm0, P0);
+        DK_LAUNCH((k_adeclick<MID, dk::BS, true, 1>), g1, sm1, P1);
     } else {
-        auto kl = k_adeclick<LIGHT, LBS, false, false>;
-        JT_HIP(hipFuncSetAttribute((const void *)kl, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_l));
-        hipLaunchKernelGGL(kl, dim3((unsigned)grid_l), dim3(64), smem_l, s, in, out, n, Pl, h->declick_scr.p, per_wave, d_stats, h->declick_heavy.p);
+        DK_LAUNCH((k_adeclick<LIGHT, LBS, false, 0>), g0, sm0, P0);
+        DK_LAUNCH((k_adeclick<MID, dk::BS, false, 1>), g1, sm1, P1);
     }
-    // windows with more than LIGHT flagged samples or a band wider than 32 rows (few on ordinary speech): full-capacity instance over
-    // the list the first pass built; its length is read on the device
-    hipLaunchKernelGGL(kh, dim3((unsigned)grid_h), dim3(64), smem_h, s, in, out, n, Ph, h->declick_scr.p, per_wave, d_stats, h->declick_heavy.p);
+    DK_LAUNCH((k_adeclick<dk::MAXW, dk::BS, false, 2>), g2, sm2, P2);
+#undef DK_LAUNCH
 }
