@@ -161,6 +161,23 @@ int jt_host_lufs_filename_value(double output_lufs);
 int jt_host_output_path(const char *input_path, int lufs_value, char *out, int cap);
 
 int jt_process_audio(jt_ctx *h, const jt_host_config *base, int frame_samples, jt_process_result *out);
+
+/* ProgressUpdate / ProgressCallback (progress.go:5-39).  The callback runs synchronously on the calling thread at the same
+ * lifecycle points the reference emits (processor.go:80-158, normalise.go:737-772): pass start (progress 0) and pass end
+ * (progress 1) of Analysing / Processing / Measuring / Normalising.  Pointers are valid only during the call:
+ *   measurements : Pass-1 end, Pass-2 start and end;   config + diag : Pass-2 start only;   limiter_* : Pass-4 start only.
+ * Intra-pass ticks (every 100 decoder frames in the reference) do not exist here: a pass is a few milliseconds. */
+typedef struct {
+    int pass;                      /* 1 Analysing, 2 Processing, 3 Measuring, 4 Normalising (filters.go:340-345) */
+    const char *pass_name;
+    double progress, level, duration;
+    const jt_measurements *measurements;
+    const jt_host_config *config;
+    const jt_adaptive_diag *diag;
+    int has_limiter, limiter_enabled; double limiter_ceiling;
+} jt_progress_update;
+typedef void (*jt_progress_fn)(void *user, const jt_progress_update *u);
+int jt_process_audio_cb(jt_ctx *h, const jt_host_config *base, int frame_samples, jt_progress_fn cb, void *user, jt_process_result *out);
 int jt_analyse_only(jt_ctx *h, const jt_host_config *base, int frame_samples, jt_process_result *out);   /* AnalyseOnlyDetailed (processor.go:29-69) */
 
 /* ---- granular detector steps (the reference table-tests each of these: analyser_vad_test.go) ---- */

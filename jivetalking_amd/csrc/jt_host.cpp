@@ -1074,13 +1074,25 @@ extern "C" int jt_host_output_path(const char *input_path, int lufs_value, char 
     return (int)r.size();
 }
 
-extern "C" int jt_process_audio(jt_ctx *h, const jt_host_config *base, int frame_samples, jt_process_result *out)
+extern "C" int jt_process_audio_cb(jt_ctx *h, const jt_host_config *base, int frame_samples, jt_progress_fn cb, void *user, jt_process_result *out)
 {
     if (!h || !base || !out) return JT_E_INVAL;
     std::memset(out, 0, sizeof(*out));
+    auto emit = [&](int pass, const char *name, double progress, double duration, const jt_measurements *ms, const jt_host_config *cfg,
+                    const jt_adaptive_diag *dg, const jt_limiter_decision *lim) {
+        if (!cb) return;
+        jt_progress_update u; std::memset(&u, 0, sizeof(u));
+        u.pass = pass; u.pass_name = name; u.progress = progress; u.duration = duration; u.measurements = ms; u.config = cfg; u.diag = dg;
+        if (lim) { u.has_limiter = 1; u.limiter_enabled = lim->needed; u.limiter_ceiling = lim->ceiling_db; }
+        cb(user, &u);
+    };
     int rc; jt_host_config eff;
+    emit(1, "Analysing", 0.0, 0.0, nullptr, nullptr, nullptr, nullptr);
     if ((rc = analyse_core(h, base, frame_samples, out, &eff)) != JT_OK) return rc;
     jt_measurements &m = out->input;
+    const double dur = m.duration_s;
+    emit(1, "Analysing", 1.0, dur, &m, nullptr, nullptr, nullptr);
+    emit(2, "Processing", 0.0, dur, &m, &eff, &out->diag, nullptr);
     // Pass 2
     jt_host_filter_spec(&eff, 2, out->pass2_spec, (int)sizeof(out->pass2_spec));
     jt_filter_params fp; jt_host_filter_params(&eff, &fp);
@@ -1088,6 +1100,7 @@ extern "C" int jt_process_audio(jt_ctx *h, const jt_host_config *base, int frame
     if ((rc = jt_pass2(h, &fp, &out->filtered)) != JT_OK) return rc;
     out->pass_ms[1] = h->timers.pass2_ms;
     out->stage_ms[4] = now_ms() - t0; t0 = now_ms();
+    emit(2, "Processing", 1.0, dur, &m, nullptr, nullptr, nullptr);
     auto measure_regions = [&](int stage, jt_region_sample *rt, jt_region_sample *sp) {
         double st[2] = {0, 0}, du[2] = {0, 0};
         if (m.has_noise_profile && m.noise_profile.duration_ns > 0) { st[0] = secs_of(m.noise_profile.start_ns); du[0] = secs_of(m.noise_profile.duration_ns); }
@@ -1105,6 +1118,7 @@ extern "C" int jt_process_audio(jt_ctx *h, const jt_host_config *base, int frame
     jt_limiter_plan plan; jt_host_plan_limiter(outI, outTP, &eff, &out->limiter, &plan);
     jt_loudnorm_stats m3;
     out->stage_ms[6] = now_ms() - t0; t0 = now_ms();
+    emit(3, "Measuring", 0.0, dur, nullptr, nullptr, nullptr, nullptr);
     if ((rc = jt_pass3(h, &plan, eff.target_i, eff.target_tp, eff.target_lra, &m3)) != JT_OK) return rc;
     out->pass_ms[2] = h->timers.pass3_ms;
     out->stage_ms[7] = now_ms() - t0; t0 = now_ms();
@@ -1123,7 +1137,10 @@ extern "C" int jt_process_audio(jt_ctx *h, const jt_host_config *base, int frame
     jt_host_config effcfg = eff; effcfg.target_i = effI;
     jt_loudnorm_apply ap;
     jt_host_pass4_spec(&effcfg, &m3, offset, &out->limiter, h->out_rate, nullptr, out->pass4_spec, (int)sizeof(out->pass4_spec), &ap);
+    emit(3, "Measuring", 1.0, dur, nullptr, nullptr, nullptr, nullptr);
+    emit(4, "Normalising", 0.0, dur, nullptr, nullptr, nullptr, &out->limiter);
     if ((rc = jt_pass4(h, &plan, &ap, &out->final_, &out->loudnorm)) != JT_OK) return rc;
+    emit(4, "Normalising", 1.0, dur, nullptr, nullptr, nullptr, nullptr);
     out->pass_ms[3] = h->timers.pass4_ms;
     out->stage_ms[8] = now_ms() - t0; t0 = now_ms();
     measure_regions(4, &out->final_room_tone, &out->final_speech);
@@ -1133,6 +1150,11 @@ extern "C" int jt_process_audio(jt_ctx *h, const jt_host_config *base, int frame
     out->output_tp_db = linearRatioToDB(qfmt("%.3f", out->final_.r128.true_peak));
     out->within_target = std::fabs(out->output_lufs - effI) <= 0.5 ? 1 : 0;
     return JT_OK;
+}
+
+extern "C" int jt_process_audio(jt_ctx *h, const jt_host_config *base, int frame_samples, jt_process_result *out)
+{
+    return jt_process_audio_cb(h, base, frame_samples, nullptr, nullptr, out);
 }
 
 extern "C" int64_t jt_host_sizeof(int which)

@@ -112,7 +112,7 @@ HOST_SYMBOLS = ["jt_host_build_intervals", "jt_host_detect", "jt_host_finish_mea
                 "jt_process_audio", "jt_analyse_only", "jt_host_vad_detect", "jt_host_vad_split", "jt_host_vad_speech_runs",
                 "jt_host_vad_gap_tolerance", "jt_host_vad_gate_stats", "jt_host_vad_noise_seed",
                 "jt_host_vad_pick_low_cluster", "jt_host_vad_floored_fraction", "jt_host_sizeof",
-                "jt_host_lufs_filename_value", "jt_host_output_path"]
+                "jt_host_lufs_filename_value", "jt_host_output_path", "jt_process_audio_cb"]
 
 
 def lib():
@@ -175,6 +175,27 @@ def process_audio(engine, base=None, frame_samples=4096, analyse_only=False):
     res = ProcessResult()
     fn = l.jt_analyse_only if analyse_only else l.jt_process_audio
     rc = fn(engine.h, C.byref(base), C.c_int(frame_samples), C.byref(res))
+    if rc != 0:
+        raise L.JtError(rc, l.jt_last_error(engine.h).decode())
+    return res
+
+
+class ProgressUpdate(C.Structure):
+    _fields_ = [("pass_", C.c_int), ("pass_name", C.c_char_p), ("progress", C.c_double), ("level", C.c_double), ("duration", C.c_double),
+                ("measurements", C.POINTER(Measurements)), ("config", C.POINTER(HostConfig)), ("diag", C.POINTER(AdaptiveDiag)),
+                ("has_limiter", C.c_int), ("limiter_enabled", C.c_int), ("limiter_ceiling", C.c_double)]
+
+
+PROGRESS_FN = C.CFUNCTYPE(None, C.c_void_p, C.POINTER(ProgressUpdate))
+
+
+def process_audio_with_progress(engine, on_update, base=None, frame_samples=4096):
+    """jt_process_audio_cb: `on_update(ProgressUpdate)` is called synchronously at every pass start / end."""
+    l = lib()
+    base = base or default_config()
+    res = ProcessResult()
+    fn = PROGRESS_FN(lambda user, u: on_update(u.contents))
+    rc = l.jt_process_audio_cb(engine.h, C.byref(base), C.c_int(frame_samples), fn, None, C.byref(res))
     if rc != 0:
         raise L.JtError(rc, l.jt_last_error(engine.h).decode())
     return res

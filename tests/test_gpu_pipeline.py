@@ -204,3 +204,23 @@ def test_two_runs_are_bit_identical(engine):
     r1 = H.process_audio(engine); o1 = engine.download_s16(4).copy()
     r2 = H.process_audio(engine); o2 = engine.download_s16(4)
     assert np.array_equal(o1, o2) and r1.output_lufs == r2.output_lufs and r1.pass2_spec == r2.pass2_spec
+
+
+def test_progress_events_follow_the_reference_lifecycle(engine):
+    """processor.go:80-158 + normalise.go:737-772: start/end per pass, measurements on the Pass-1 end and Pass-2 events,
+    config + diagnostics on the Pass-2 start only, limiter snapshot on the Pass-4 start only."""
+    x = synth.speech_like(20.0, SR, seed=44)
+    engine.upload_pcm(x, SR, 1)
+    seen = []
+
+    def on_update(u):
+        seen.append((u.pass_, u.pass_name.decode(), u.progress, bool(u.measurements), bool(u.config), bool(u.diag), u.has_limiter,
+                     u.duration, u.measurements.contents.input_i if u.measurements else None))
+    res = H.process_audio_with_progress(engine, on_update)
+    assert [(p, n, pr) for p, n, pr, *_ in seen] == [
+        (1, "Analysing", 0.0), (1, "Analysing", 1.0), (2, "Processing", 0.0), (2, "Processing", 1.0),
+        (3, "Measuring", 0.0), (3, "Measuring", 1.0), (4, "Normalising", 0.0), (4, "Normalising", 1.0)]
+    assert [s[3] for s in seen] == [False, True, True, True, False, False, False, False]       # measurements
+    assert [s[4] and s[5] for s in seen] == [False, False, True, False, False, False, False, False]   # config + diagnostics
+    assert [s[6] for s in seen] == [0, 0, 0, 0, 0, 0, 1, 0]                                     # limiter snapshot
+    assert seen[1][8] == res.input.input_i and abs(seen[1][7] - 20.0) < 1e-9
