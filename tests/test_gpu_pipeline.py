@@ -224,3 +224,87 @@ def test_progress_events_follow_the_reference_lifecycle(engine):
     assert [s[4] and s[5] for s in seen] == [False, False, True, False, False, False, False, False]   # config + diagnostics
     assert [s[6] for s in seen] == [0, 0, 0, 0, 0, 0, 1, 0]                                     # limiter snapshot
     assert seen[1][8] == res.input.input_i and abs(seen[1][7] - 20.0) < 1e-9
+
+
+# ---------------------------------------------------------------- the less-travelled branches of the path, end to end
+def _oracle_pass34(oracle, p2, res, rate=44100):
+    """Oracle restatement of Pass 3 / Pass 4 given the Pass-2 s16 output and the host decisions in `res`."""
+    x = p2.astype(np.float64) / 32768.0
+    lim = res.limiter
+    pre = 10 ** (lim.pre_gain_db / 20.0) if (lim.needed and lim.pre_gain_db > 0) else 1.0
+    if lim.needed:
+        limit = float("%.6f" % (10 ** (lim.ceiling_db / 20.0)))
+        y = oracle.alimiter(x * pre, rate, limit, 5.0, 100.0)
+        m = oracle.loudnorm_measure(oracle.swr_f64(y, rate, 192000, True), 192000, True)
+    else:
+        y = x
+        m = oracle.loudnorm_measure(oracle.swr_f32(p2.astype(np.float32) / 32768.0, rate, 192000, True).astype(np.float64), 192000, True)
+    gain = 10 ** ((res.effective_target_i - res.measure.input_i) / 20.0)
+    z = oracle.adeclick(y * gain, rate, 1.7, 55.0, 50.0, method="s")
+    z = oracle.alimiter(z, rate, 0.803526, 1.0, 50.0)
+    return m, oracle.f64_to_s16(z.astype(np.float32).astype(np.float64))
+
+
+def test_limiter_prefix_path_loud_peaky_input(engine, oracle):
+    """Sparse strong peaks over quiet speech: the projected true peak exceeds the target, so planLimiterForLoudnorm arms the
+    alimiter prefix in Pass 3 and Pass 4 (normalise.go:373-561) and the DBLP 192 kHz measurement path is taken."""
+    x = synth.speech_like(30.0, SR, seed=51)
+    x[::24000] += 0.4 * np.sign(x[::24000] + 1e-9)                  # -8 dBFS ticks over -27 LUFS speech
+    x = np.clip(x, -0.98, 0.98).astype(np.float32)
+    engine.upload_pcm(x, SR, 1)
+    res = H.process_audio(engine)
+    p2, p4 = engine.download_s16(2), engine.download_s16(4)
+    assert res.limiter.needed == 1
+    m, ref = _oracle_pass34(oracle, p2, res)
+    assert abs(res.measure.input_i - m["input_i"]) <= 0.011 and abs(res.measure.input_tp - m["input_tp"]) <= 0.011
+    assert np.array_equal(ref, p4)
+    e = oracle.ebur128(p4.astype(np.float64) / 32768.0, 44100, True, True)
+    assert 20 * np.log10(e["true_peak"]) <= -1.0
+
+
+def test_44k1_input_no_rate_change(engine, oracle):
+    """44.1 kHz input: anlmdn's generic kernel (2S = 176 is not a multiple of 64), afftdn with A = 551, and no resampler in the
+    output format conversion (aformat only converts dbl -> s16)."""
+    sr = 44100
+    x = synth.speech_like(30.0, sr, seed=52)
+    engine.upload_pcm(x, sr, 1)
+    res = H.process_audio(engine)
+    p2, p4 = engine.download_s16(2), engine.download_s16(4)
+    fp = L.FilterParams()
+    H.lib().jt_host_filter_params(C.byref(res.effective), C.byref(fp))
+    y = x
+    if fp.hp_enabled: y = oracle.biquad_f32(y, 0, fp.hp_freq, sr, fp.hp_q)
+    if fp.lp_enabled: y = oracle.biquad_f32(y, 1, fp.lp_freq, sr, fp.lp_q)
+    if fp.nlm_enabled: y = oracle.anlmdn(y, sr, fp.nlm_strength, fp.nlm_patch_s, fp.nlm_research_s, fp.nlm_smooth)
+    if fp.fft_enabled: y = oracle.afftdn(y, sr, fp.fft_nr, fp.fft_nf if fp.fft_nf < 0 else -50.0, list(fp.fft_band_noise) if fp.fft_custom else None)
+    yd = y.astype(np.float64)
+    if fp.gate_enabled: yd = oracle.agate(yd, sr, fp.gate_threshold, fp.gate_ratio, fp.gate_attack_ms, fp.gate_release_ms, fp.gate_range, fp.gate_knee, fp.gate_makeup)
+    if fp.comp_enabled: yd = oracle.acompressor(yd, sr, fp.comp_threshold, fp.comp_ratio, fp.comp_attack_ms, fp.comp_release_ms, fp.comp_makeup, fp.comp_knee, fp.comp_mix)
+    ref2 = oracle.f64_to_s16(yd.astype(np.float32).astype(np.float64))
+    assert ref2.size == p2.size == x.size
+    d = np.abs(ref2.astype(np.int32) - p2.astype(np.int32))
+    assert d.max() <= 3 and d.mean() < 0.3
+    m, ref4 = _oracle_pass34(oracle, p2, res)
+    assert np.array_equal(ref4, p4)
+
+
+def test_deesser_enabled_and_short_clip(engine, oracle):
+    """De-esser switched on by the caller (off in the default adaptive outcome for this material), and a clip too short for any
+    room-tone / speech election (the no-profile fallbacks of AdaptConfig)."""
+    base = H.default_config()
+    base.deess_enabled = 1; base.deess_intensity = 0.6
+    x = synth.speech_like(20.0, SR, seed=53)
+    engine.upload_pcm(x, SR, 1)
+    res = H.process_audio(engine, base)
+    p2 = engine.download_s16(2)
+    fp = L.FilterParams()
+    H.lib().jt_host_filter_params(C.byref(res.effective), C.byref(fp))
+    if fp.deess_enabled and fp.deess_i > 0:
+        _, ref = oracle_pass2(oracle, x, fp, SR)
+        d = np.abs(ref.astype(np.int32) - p2.astype(np.int32))
+        assert d.max() <= 3 and d.mean() < 0.3
+    y = synth.speech_like(4.0, SR, seed=54)
+    engine.upload_pcm(y, SR, 1)
+    r2 = H.process_audio(engine)
+    assert r2.input.has_speech_profile == 0 or r2.input.speech_profile.region.duration_ns > 0
+    assert engine.download_s16(4).size == int(np.ceil(y.size * 147 / 160))
