@@ -180,9 +180,29 @@ typedef struct {              /* loudnorm second pass options (normalise.go:1269
 int jt_pass4(jt_ctx *h, const jt_limiter_plan *lim, const jt_loudnorm_apply *ap,
              jt_analysis *out, jt_loudnorm_stats *stats);
 
-/* ---- output: replaces Encoder.WriteFrame's input (encoder.go:145); FLAC encode stays on the host ---- */
+/* ---- output: replaces Encoder.WriteFrame's input (encoder.go:145): raw s16, or the finished FLAC file below ---- */
 int jt_output_len(jt_ctx *h, int stage, int64_t *n);
 int jt_download_s16(jt_ctx *h, int stage, int16_t *dst, int64_t cap, int64_t *n);
+
+/* ---- FLAC output leg: replaces createOutputEncoder + Encoder.WriteFrame/Flush/Close (encoder.go:54-110,145-215): the
+ * reference hands every 4096-sample s16 frame to FFmpeg's flac encoder (compression_level 5) and muxes a .flac file.  Here
+ * the stage output already in HBM is encoded on the GPU, one frame per wavefront, and the finished file image (fLaC marker,
+ * STREAMINFO, VORBIS_COMMENT, frames) is returned in a pinned host buffer owned by the handle (valid until the next
+ * jt_flac_encode / jt_op_flac_encode_s16 / jt_close on it).  Same container contract as the reference's files: mono, 16 bit,
+ * fixed block size 4096, STREAMINFO with total samples, min/max frame size and (JT_FLAC_MD5) the MD5 of the PCM.  FLAC is
+ * lossless, so parity = the decoded PCM equals jt_download_s16() bit for bit; the compressed bytes themselves are this
+ * encoder's (LPC order 1..8 by exhaustive search, 12-bit coefficients, Rice partition order 0..8). */
+#define JT_FLAC_MD5 1            /* compute the STREAMINFO MD5 (host, one core, ~0.6 GB/s); without it the field is 0 = "unknown" */
+typedef struct {
+    int64_t bytes, frames, total_samples;
+    int sample_rate, channels, bits_per_sample, block_size, min_frame_bytes, max_frame_bytes, header_bytes;
+    double gpu_ms, md5_ms, total_ms;
+    uint8_t md5[16];
+} jt_flac_info;
+int jt_flac_encode(jt_ctx *h, int stage, int flags, const uint8_t **data, int64_t *len, jt_flac_info *info);
+/* operator-level entry (host PCM in, used by the parity tests): any length >= 1, any rate FLAC can describe */
+int jt_op_flac_encode_s16(jt_ctx *h, const int16_t *pcm, int64_t n, int sample_rate, int flags,
+                          const uint8_t **data, int64_t *len, jt_flac_info *info);
 
 /* ---- per-pass device timers (ms, HIP events on the engine stream) for the roofline report ---- */
 typedef struct { double pass1_ms, pass2_ms, pass3_ms, pass4_ms; double nlm_ms; int64_t nlm_launches;

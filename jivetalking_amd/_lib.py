@@ -99,12 +99,21 @@ class Timers(C.Structure):
                 ("declick_repaired", C.c_int64), ("declick_ms", C.c_double), ("declick_heavy_windows", C.c_int64)]
 
 
+class FlacInfo(C.Structure):
+    _fields_ = [("bytes", C.c_int64), ("frames", C.c_int64), ("total_samples", C.c_int64),
+                ("sample_rate", C.c_int), ("channels", C.c_int), ("bits_per_sample", C.c_int), ("block_size", C.c_int),
+                ("min_frame_bytes", C.c_int), ("max_frame_bytes", C.c_int), ("header_bytes", C.c_int),
+                ("gpu_ms", C.c_double), ("md5_ms", C.c_double), ("total_ms", C.c_double), ("md5", C.c_uint8 * 16)]
+
+
+JT_FLAC_MD5 = 1
+
 # every symbol include/jtgpu.h declares
 SYMBOLS = [
     "jt_open", "jt_close", "jt_last_error", "jt_version", "jt_cancel",
     "jt_upload_pcm", "jt_attach_device_pcm", "jt_upload_s16",
     "jt_pass1", "jt_band_rms", "jt_pass2", "jt_region_measure", "jt_region_measure_pair", "jt_pass3", "jt_pass4",
-    "jt_output_len", "jt_download_s16", "jt_get_timers",
+    "jt_output_len", "jt_download_s16", "jt_flac_encode", "jt_op_flac_encode_s16", "jt_get_timers",
     "jt_op_biquad_f32", "jt_op_anlmdn_f32", "jt_op_afftdn_f32", "jt_op_dynamics", "jt_op_alimiter_f64", "jt_op_adeclick_f64",
     "jt_op_resample_f32_to_s16", "jt_op_ebur128", "jt_op_astats", "jt_op_aspectralstats",
     "jt_op_loudnorm_measure_s16",

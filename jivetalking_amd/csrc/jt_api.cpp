@@ -1,6 +1,7 @@
 // jt_api.cpp — C ABI of libjtgpu.so (see include/jtgpu.h for the reference interfaces each entry replaces).
 // Orchestrates the four device-side sweeps over a file that stays resident in HBM as contiguous PCM.
 #include "jt_internal.h"
+#include <chrono>
 #include <algorithm>
 #include <cstdlib>
 #include <memory>
@@ -747,6 +748,123 @@ extern "C" int jt_download_s16(jt_ctx *h, int stage, int16_t *dst, int64_t cap, 
     JT_HIP(hipMemcpyAsync(dst, src, sizeof(int16_t) * m, hipMemcpyDeviceToHost, h->stream));
     JT_HIP(hipStreamSynchronize(h->stream));
     if (n) *n = m;
+    JT_API_END(h)
+}
+
+// ---------------------------------------------------------------- FLAC output leg (k_flac.hip)
+namespace {
+double flac_now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+struct FlacSummary { long long total; int min_frame, max_frame, mismatches, pad; };
+
+void put_be(uint8_t *&p, uint64_t v, int bytes) { for (int i = bytes - 1; i >= 0; i--) *p++ = (uint8_t)(v >> (8 * i)); }
+void put_le32(uint8_t *&p, uint32_t v) { for (int i = 0; i < 4; i++) *p++ = (uint8_t)(v >> (8 * i)); }
+
+// d_pcm: n mono s16 samples on the device
+void flac_encode_core(jt_ctx *h, const int16_t *d_pcm, int64_t n, int rate, int flags, const uint8_t **data, int64_t *len,
+                      jt_flac_info *info)
+{
+    JT_REQUIRE(n > 0, JT_E_STATE, "flac: no samples to encode");
+    JT_REQUIRE(n < ((int64_t)1 << 36), JT_E_INVAL, "flac: more samples than STREAMINFO can describe");
+    JT_REQUIRE(rate > 0 && rate < (1 << 20), JT_E_INVAL, "flac: sample rate out of range");
+    const double t0 = flac_now_ms();
+    const int64_t nframes = (n + 4095) / 4096;
+    JT_REQUIRE(nframes < ((int64_t)1 << 31), JT_E_INVAL, "flac: too many frames");
+    // sample-rate code of the frame header (RFC 9639 §9.1.2)
+    static const int rates[12] = {0, 88200, 176400, 192000, 8000, 16000, 22050, 24000, 32000, 44100, 48000, 96000};
+    int sr_code = 0, sr_bytes = 0, sr_val = 0;
+    for (int c = 1; c < 12; c++) if (rates[c] == rate) sr_code = c;
+    if (!sr_code) {
+        if (rate % 1000 == 0 && rate / 1000 < 256) { sr_code = 12; sr_bytes = 1; sr_val = rate / 1000; }
+        else if (rate < 65536) { sr_code = 13; sr_bytes = 2; sr_val = rate; }
+        else if (rate % 10 == 0 && rate / 10 < 65536) { sr_code = 14; sr_bytes = 2; sr_val = rate / 10; }
+    }
+    const bool want_md5 = (flags & JT_FLAC_MD5) != 0;
+    h->fl_rec.ensure(jt_flac_rec_bytes(nframes));
+    h->fl_off.ensure((size_t)nframes + 8);
+    unsigned char *d_sum = h->fl_rec.p + (jt_flac_rec_bytes(nframes) - 256);
+    // the PCM travels to the host on an auxiliary stream while the analysis runs (only the MD5 needs it)
+    int16_t *h_pcm = nullptr;
+    if (want_md5) {
+        h->pin_pcm.begin(sizeof(int16_t) * (size_t)n + 64);
+        h_pcm = h->pin_pcm.take<int16_t>((size_t)n);
+        JT_HIP(hipEventRecord(h->ev_fork, h->stream));
+        JT_HIP(hipStreamWaitEvent(h->aux[0], h->ev_fork, 0));
+        JT_HIP(hipMemcpyAsync(h_pcm, d_pcm, sizeof(int16_t) * (size_t)n, hipMemcpyDeviceToHost, h->aux[0]));
+    }
+    JT_HIP(hipEventRecord(h->ev0, h->stream));
+    launch_flac_analyse(d_pcm, n, sr_code, sr_bytes, sr_val, h->fl_rec.p, h->fl_off.p, d_sum, h->stream);
+    FlacSummary sum{};
+    JT_HIP(hipMemcpyAsync(&sum, d_sum, sizeof sum, hipMemcpyDeviceToHost, h->stream));
+    JT_HIP(hipStreamSynchronize(h->stream));
+    JT_REQUIRE(sum.total > 0, JT_E_HIP, "flac: analysis produced no frames");
+
+    static const char vendor[] = "jivetalking-amd jtgpu 0.1";
+    const int vlen = (int)sizeof(vendor) - 1;
+    const int header_bytes = 4 + 4 + 34 + 4 + 4 + vlen + 4;
+    h->fl_out.ensure((size_t)sum.total + 64);
+    h->pin_flac.begin((size_t)header_bytes + (size_t)sum.total + 64);
+    uint8_t *file = h->pin_flac.take<uint8_t>((size_t)header_bytes + (size_t)sum.total);
+    launch_flac_emit(d_pcm, n, sr_code, sr_bytes, sr_val, h->fl_rec.p, h->fl_off.p, h->fl_out.p, d_sum, h->stream);
+    JT_HIP(hipEventRecord(h->ev1, h->stream));
+    JT_HIP(hipMemcpyAsync(file + header_bytes, h->fl_out.p, (size_t)sum.total, hipMemcpyDeviceToHost, h->stream));
+    FlacSummary sum2{};
+    JT_HIP(hipMemcpyAsync(&sum2, d_sum, sizeof sum2, hipMemcpyDeviceToHost, h->stream));
+
+    uint8_t md5[16] = {0};
+    double md5_ms = 0.0;
+    if (want_md5) {
+        JT_HIP(hipStreamSynchronize(h->aux[0]));
+        const double m0 = flac_now_ms();
+        jt_md5(h_pcm, sizeof(int16_t) * (size_t)n, md5);
+        md5_ms = flac_now_ms() - m0;
+    }
+    JT_HIP(hipStreamSynchronize(h->stream));
+    JT_REQUIRE(sum2.mismatches == 0, JT_E_HIP, "flac: emitted size differs from the analysed size");
+    float gpu_ms = 0.f;
+    JT_HIP(hipEventElapsedTime(&gpu_ms, h->ev0, h->ev1));
+
+    // fLaC marker, STREAMINFO (RFC 9639 §8.2), VORBIS_COMMENT (§8.6, vendor string only)
+    uint8_t *p = file;
+    memcpy(p, "fLaC", 4); p += 4;
+    put_be(p, 0x00, 1); put_be(p, 34, 3);
+    put_be(p, 4096, 2); put_be(p, 4096, 2);
+    put_be(p, (uint64_t)sum.min_frame, 3); put_be(p, (uint64_t)sum.max_frame, 3);
+    // 20 bits rate | 3 bits channels-1 | 5 bits depth-1 | 36 bits total samples
+    put_be(p, ((uint64_t)rate << 44) | ((uint64_t)0 << 41) | ((uint64_t)15 << 36) | (uint64_t)n, 8);
+    memcpy(p, md5, 16); p += 16;
+    put_be(p, 0x84, 1); put_be(p, (uint64_t)(4 + vlen + 4), 3);
+    put_le32(p, (uint32_t)vlen); memcpy(p, vendor, (size_t)vlen); p += vlen; put_le32(p, 0);
+
+    *data = file; *len = header_bytes + sum.total;
+    if (info) {
+        memset(info, 0, sizeof *info);
+        info->bytes = *len; info->frames = nframes; info->total_samples = n; info->sample_rate = rate; info->channels = 1;
+        info->bits_per_sample = 16; info->block_size = 4096; info->min_frame_bytes = sum.min_frame; info->max_frame_bytes = sum.max_frame;
+        info->header_bytes = header_bytes; info->gpu_ms = gpu_ms; info->md5_ms = md5_ms; info->total_ms = flac_now_ms() - t0;
+        memcpy(info->md5, md5, 16);
+    }
+}
+} // namespace
+
+extern "C" int jt_flac_encode(jt_ctx *h, int stage, int flags, const uint8_t **data, int64_t *len, jt_flac_info *info)
+{
+    JT_API_BEGIN(h)
+    JT_REQUIRE(data && len, JT_E_INVAL, "flac: null output arguments");
+    const int16_t *src = stage == 2 ? h->s16_p2.p : (stage == 4 ? h->s16_p4.p : nullptr);
+    const int64_t m = stage == 2 ? h->m_p2 : (stage == 4 ? h->m_p4 : 0);
+    JT_REQUIRE(src && m > 0, JT_E_STATE, "flac: stage output not on device");
+    flac_encode_core(h, src, m, h->out_rate, flags, data, len, info);
+    JT_API_END(h)
+}
+
+extern "C" int jt_op_flac_encode_s16(jt_ctx *h, const int16_t *pcm, int64_t n, int sample_rate, int flags,
+                                     const uint8_t **data, int64_t *len, jt_flac_info *info)
+{
+    JT_API_BEGIN(h)
+    JT_REQUIRE(pcm && n > 0 && data && len, JT_E_INVAL, "flac: bad arguments");
+    h->fl_pcm.ensure((size_t)n);
+    JT_HIP(hipMemcpyAsync(h->fl_pcm.p, pcm, sizeof(int16_t) * (size_t)n, hipMemcpyHostToDevice, h->stream));
+    flac_encode_core(h, h->fl_pcm.p, n, sample_rate, flags, data, len, info);
     JT_API_END(h)
 }
 

@@ -123,6 +123,14 @@ bool jt_adeclick_supported(int sample_rate, double window_ms, double overlap_pct
 void launch_adeclick(jt_ctx *h, const double *in, double *out, int64_t n, int sample_rate, double threshold, double window_ms,
                      double overlap_pct, double ar_pct, double burst, double gain, unsigned long long *d_stats, hipStream_t s);
 
+// FLAC encoder (k_flac.hip): analyse + scan fill recs/offs/summary, emit writes the frames at their byte offsets
+size_t jt_flac_rec_bytes(int64_t nframes);
+void launch_flac_analyse(const int16_t *pcm, int64_t n, int sr_code, int sr_extra_bytes, int sr_extra_val, void *recs,
+                         long long *offs, void *summary, hipStream_t s);
+void launch_flac_emit(const int16_t *pcm, int64_t n, int sr_code, int sr_extra_bytes, int sr_extra_val, const void *recs,
+                      const long long *offs, uint8_t *out, void *summary, hipStream_t s);
+void jt_md5(const void *data, size_t len, uint8_t out[16]);      // RFC 1321 (jt_plan.cpp), STREAMINFO signature
+
 // ---------------------------------------------------------------- pinned host staging
 // Every device->host result of a pass lands in one pinned arena, so a pass enqueues all its kernels and copies back to back
 // and synchronises ONCE (pageable destinations would serialise each copy through a bounce buffer).
@@ -219,6 +227,9 @@ struct jt_ctx {
     SwrDev swr[4]; int swr_next = 0;
     DevBuf<float> region_f;
     DevBuf<double> declick_scr; DevBuf<unsigned long long> declick_stats; DevBuf<int> declick_heavy;
+    // FLAC output leg: frame records, byte offsets, summary, encoded frames; pinned host copies of the PCM (MD5) and the file
+    DevBuf<unsigned char> fl_rec, fl_out; DevBuf<long long> fl_off; DevBuf<int16_t> fl_pcm;
+    HostArena pin_pcm, pin_flac;
     jt_timers timers{};
     hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr, ev3 = nullptr;
 };

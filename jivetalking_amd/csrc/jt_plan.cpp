@@ -372,3 +372,73 @@ void jt_afftdn_plan(AfftdnPlanHost *pl, int sr, double nr, double nf, const doub
     pl->abs_var.resize(bins); pl->min_abs_var.resize(bins);
     for (int i = 0; i < bins; i++) { pl->abs_var[i] = std::fmax(max_var * rel[i], 1.0); pl->min_abs_var[i] = gain_scale * pl->abs_var[i]; }
 }
+
+// ---------------------------------------------------------------- MD5 (RFC 1321) for the FLAC STREAMINFO signature
+// One dependent chain per stream by construction (Merkle-Damgard), so this stays on a host core next to the GPU encode.
+namespace {
+#define JT_MD5_STEP(f, a, b, c, d, x, t, s) do { (a) += f((b), (c), (d)) + (x) + (t); (a) = ((a) << (s)) | ((a) >> (32 - (s))); (a) += (b); } while (0)
+#define JT_F1(x, y, z) ((z) ^ ((x) & ((y) ^ (z))))
+#define JT_F2(x, y, z) JT_F1(z, x, y)
+#define JT_F3(x, y, z) ((x) ^ (y) ^ (z))
+#define JT_F4(x, y, z) ((y) ^ ((x) | ~(z)))
+inline void md5_blocks(uint32_t st[4], const unsigned char *p, size_t nblocks)
+{
+    uint32_t a = st[0], b = st[1], c = st[2], d = st[3];
+    for (; nblocks; nblocks--, p += 64) {
+        uint32_t w[16];
+        memcpy(w, p, 64);                                // little-endian host (x86-64)
+        const uint32_t sa = a, sb = b, sc = c, sd = d;
+        JT_MD5_STEP(JT_F1, a, b, c, d, w[0], 0xd76aa478, 7);  JT_MD5_STEP(JT_F1, d, a, b, c, w[1], 0xe8c7b756, 12);
+        JT_MD5_STEP(JT_F1, c, d, a, b, w[2], 0x242070db, 17); JT_MD5_STEP(JT_F1, b, c, d, a, w[3], 0xc1bdceee, 22);
+        JT_MD5_STEP(JT_F1, a, b, c, d, w[4], 0xf57c0faf, 7);  JT_MD5_STEP(JT_F1, d, a, b, c, w[5], 0x4787c62a, 12);
+        JT_MD5_STEP(JT_F1, c, d, a, b, w[6], 0xa8304613, 17); JT_MD5_STEP(JT_F1, b, c, d, a, w[7], 0xfd469501, 22);
+        JT_MD5_STEP(JT_F1, a, b, c, d, w[8], 0x698098d8, 7);  JT_MD5_STEP(JT_F1, d, a, b, c, w[9], 0x8b44f7af, 12);
+        JT_MD5_STEP(JT_F1, c, d, a, b, w[10], 0xffff5bb1, 17); JT_MD5_STEP(JT_F1, b, c, d, a, w[11], 0x895cd7be, 22);
+        JT_MD5_STEP(JT_F1, a, b, c, d, w[12], 0x6b901122, 7); JT_MD5_STEP(JT_F1, d, a, b, c, w[13], 0xfd987193, 12);
+        JT_MD5_STEP(JT_F1, c, d, a, b, w[14], 0xa679438e, 17); JT_MD5_STEP(JT_F1, b, c, d, a, w[15], 0x49b40821, 22);
+        JT_MD5_STEP(JT_F2, a, b, c, d, w[1], 0xf61e2562, 5);  JT_MD5_STEP(JT_F2, d, a, b, c, w[6], 0xc040b340, 9);
+        JT_MD5_STEP(JT_F2, c, d, a, b, w[11], 0x265e5a51, 14); JT_MD5_STEP(JT_F2, b, c, d, a, w[0], 0xe9b6c7aa, 20);
+        JT_MD5_STEP(JT_F2, a, b, c, d, w[5], 0xd62f105d, 5);  JT_MD5_STEP(JT_F2, d, a, b, c, w[10], 0x02441453, 9);
+        JT_MD5_STEP(JT_F2, c, d, a, b, w[15], 0xd8a1e681, 14); JT_MD5_STEP(JT_F2, b, c, d, a, w[4], 0xe7d3fbc8, 20);
+        JT_MD5_STEP(JT_F2, a, b, c, d, w[9], 0x21e1cde6, 5);  JT_MD5_STEP(JT_F2, d, a, b, c, w[14], 0xc33707d6, 9);
+        JT_MD5_STEP(JT_F2, c, d, a, b, w[3], 0xf4d50d87, 14); JT_MD5_STEP(JT_F2, b, c, d, a, w[8], 0x455a14ed, 20);
+        JT_MD5_STEP(JT_F2, a, b, c, d, w[13], 0xa9e3e905, 5); JT_MD5_STEP(JT_F2, d, a, b, c, w[2], 0xfcefa3f8, 9);
+        JT_MD5_STEP(JT_F2, c, d, a, b, w[7], 0x676f02d9, 14); JT_MD5_STEP(JT_F2, b, c, d, a, w[12], 0x8d2a4c8a, 20);
+        JT_MD5_STEP(JT_F3, a, b, c, d, w[5], 0xfffa3942, 4);  JT_MD5_STEP(JT_F3, d, a, b, c, w[8], 0x8771f681, 11);
+        JT_MD5_STEP(JT_F3, c, d, a, b, w[11], 0x6d9d6122, 16); JT_MD5_STEP(JT_F3, b, c, d, a, w[14], 0xfde5380c, 23);
+        JT_MD5_STEP(JT_F3, a, b, c, d, w[1], 0xa4beea44, 4);  JT_MD5_STEP(JT_F3, d, a, b, c, w[4], 0x4bdecfa9, 11);
+        JT_MD5_STEP(JT_F3, c, d, a, b, w[7], 0xf6bb4b60, 16); JT_MD5_STEP(JT_F3, b, c, d, a, w[10], 0xbebfbc70, 23);
+        JT_MD5_STEP(JT_F3, a, b, c, d, w[13], 0x289b7ec6, 4); JT_MD5_STEP(JT_F3, d, a, b, c, w[0], 0xeaa127fa, 11);
+        JT_MD5_STEP(JT_F3, c, d, a, b, w[3], 0xd4ef3085, 16); JT_MD5_STEP(JT_F3, b, c, d, a, w[6], 0x04881d05, 23);
+        JT_MD5_STEP(JT_F3, a, b, c, d, w[9], 0xd9d4d039, 4);  JT_MD5_STEP(JT_F3, d, a, b, c, w[12], 0xe6db99e5, 11);
+        JT_MD5_STEP(JT_F3, c, d, a, b, w[15], 0x1fa27cf8, 16); JT_MD5_STEP(JT_F3, b, c, d, a, w[2], 0xc4ac5665, 23);
+        JT_MD5_STEP(JT_F4, a, b, c, d, w[0], 0xf4292244, 6);  JT_MD5_STEP(JT_F4, d, a, b, c, w[7], 0x432aff97, 10);
+        JT_MD5_STEP(JT_F4, c, d, a, b, w[14], 0xab9423a7, 15); JT_MD5_STEP(JT_F4, b, c, d, a, w[5], 0xfc93a039, 21);
+        JT_MD5_STEP(JT_F4, a, b, c, d, w[12], 0x655b59c3, 6); JT_MD5_STEP(JT_F4, d, a, b, c, w[3], 0x8f0ccc92, 10);
+        JT_MD5_STEP(JT_F4, c, d, a, b, w[10], 0xffeff47d, 15); JT_MD5_STEP(JT_F4, b, c, d, a, w[1], 0x85845dd1, 21);
+        JT_MD5_STEP(JT_F4, a, b, c, d, w[8], 0x6fa87e4f, 6);  JT_MD5_STEP(JT_F4, d, a, b, c, w[15], 0xfe2ce6e0, 10);
+        JT_MD5_STEP(JT_F4, c, d, a, b, w[6], 0xa3014314, 15); JT_MD5_STEP(JT_F4, b, c, d, a, w[13], 0x4e0811a1, 21);
+        JT_MD5_STEP(JT_F4, a, b, c, d, w[4], 0xf7537e82, 6);  JT_MD5_STEP(JT_F4, d, a, b, c, w[11], 0xbd3af235, 10);
+        JT_MD5_STEP(JT_F4, c, d, a, b, w[2], 0x2ad7d2bb, 15); JT_MD5_STEP(JT_F4, b, c, d, a, w[9], 0xeb86d391, 21);
+        a += sa; b += sb; c += sc; d += sd;
+    }
+    st[0] = a; st[1] = b; st[2] = c; st[3] = d;
+}
+} // namespace
+
+void jt_md5(const void *data, size_t len, uint8_t out[16])
+{
+    uint32_t st[4] = {0x67452301u, 0xefcdab89u, 0x98badcfeu, 0x10325476u};
+    const unsigned char *p = static_cast<const unsigned char *>(data);
+    const size_t full = len / 64;
+    md5_blocks(st, p, full);
+    unsigned char tail[128] = {0};
+    const size_t rem = len - full * 64;
+    memcpy(tail, p + full * 64, rem);
+    tail[rem] = 0x80;
+    const size_t tl = rem < 56 ? 64 : 128;
+    const uint64_t bits = (uint64_t)len * 8;
+    memcpy(tail + tl - 8, &bits, 8);
+    md5_blocks(st, tail, tl / 64);
+    memcpy(out, st, 16);
+}

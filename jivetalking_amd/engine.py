@@ -39,6 +39,12 @@ def default_filter_params(**over):
     return p
 
 
+def _flac_info(info):
+    d = {k: getattr(info, k) for k, _ in info._fields_ if k != "md5"}
+    d["md5"] = bytes(info.md5).hex()
+    return d
+
+
 class Engine:
     def __init__(self, device=0):
         self.lib = L.load()
@@ -131,6 +137,22 @@ class Engine:
         out = np.empty(n.value, np.int16)
         self._ck(self.lib.jt_download_s16(self.h, C.c_int(stage), out.ctypes.data_as(C.POINTER(C.c_int16)), C.c_int64(out.size), C.byref(n)))
         return out
+
+    def flac_encode(self, stage, md5=True, return_info=False):
+        """The stage output as a finished .flac file image (bytes), encoded on the GPU (include/jtgpu.h: jt_flac_encode)."""
+        data = C.POINTER(C.c_uint8)(); n = C.c_int64(); info = L.FlacInfo()
+        self._ck(self.lib.jt_flac_encode(self.h, C.c_int(stage), C.c_int(L.JT_FLAC_MD5 if md5 else 0), C.byref(data), C.byref(n),
+                                         C.byref(info)))
+        out = C.string_at(data, n.value)
+        return (out, _flac_info(info)) if return_info else out
+
+    def op_flac_encode(self, pcm, sample_rate, md5=True, return_info=False):
+        x = np.ascontiguousarray(pcm, np.int16)
+        data = C.POINTER(C.c_uint8)(); n = C.c_int64(); info = L.FlacInfo()
+        self._ck(self.lib.jt_op_flac_encode_s16(self.h, x.ctypes.data_as(C.POINTER(C.c_int16)), C.c_int64(x.size), C.c_int(sample_rate),
+                                                C.c_int(L.JT_FLAC_MD5 if md5 else 0), C.byref(data), C.byref(n), C.byref(info)))
+        out = C.string_at(data, n.value)
+        return (out, _flac_info(info)) if return_info else out
 
     def timers(self):
         t = L.Timers()

@@ -121,6 +121,23 @@ int64_t orc_aspectralstats_mono(const float *in, int64_t n, int sample_rate, int
 /* ---- helpers ---- */
 void orc_rfft_mag_f32(const float *in, int n_fft, float *mag_half);  /* |FFT|, n_fft/2 bins, unscaled */
 
+/* ---- FLAC (RFC 9639): sequential decoder with CRC-8 / CRC-16 / MD5 verification, and a format-coverage encoder that makes
+ * decoder test streams (orc_flac.c) ---- */
+typedef struct {
+    int sample_rate, channels, bps, min_blocksize, max_blocksize, min_framesize, max_framesize;
+    int64_t total_samples, decoded_samples, frames, audio_offset;
+    int metadata_blocks, variable_blocksize, crc8_errors, crc16_errors;
+    int obs_min_framesize, obs_max_framesize, obs_max_blocksize, last_blocksize;
+    uint8_t md5_stored[16], md5_decoded[16];
+} orc_flac_info;
+/* out: interleaved int32 (may be NULL), cap_frames inter-channel samples.  0 = stream valid (all CRCs right); <0 = error. */
+int orc_flac_decode(const uint8_t *data, int64_t len, int32_t *out, int64_t cap_frames, orc_flac_info *info);
+int64_t orc_flac_encode(const int32_t *pcm, int64_t nframes, int channels, int bps, int sample_rate, int blocksize, int mode,
+                        int lpc_order, uint8_t *out, int64_t cap);
+uint8_t orc_flac_crc8(const uint8_t *p, int64_t n);
+uint16_t orc_flac_crc16(const uint8_t *p, int64_t n);
+void orc_md5(const uint8_t *data, int64_t len, uint8_t out[16]);
+
 #ifdef __cplusplus
 }
 #endif

@@ -230,3 +230,44 @@ def aspectralstats(x, sr, win_size=2048):
     fn.restype = C.c_int64
     nh = fn(_p(x, C.c_float), C.c_int64(x.size), C.c_int(sr), C.c_int(win_size), _p(st, C.c_double), C.c_int64(cap))
     return st[:nh].copy()
+
+
+# ---------------------------------------------------------------- FLAC (RFC 9639), orc_flac.c
+class FlacInfo(C.Structure):
+    _fields_ = [(k, C.c_int) for k in ("sample_rate", "channels", "bps", "min_blocksize", "max_blocksize", "min_framesize",
+                                       "max_framesize")] + \
+               [(k, C.c_int64) for k in ("total_samples", "decoded_samples", "frames", "audio_offset")] + \
+               [(k, C.c_int) for k in ("metadata_blocks", "variable_blocksize", "crc8_errors", "crc16_errors",
+                                       "obs_min_framesize", "obs_max_framesize", "obs_max_blocksize", "last_blocksize")] + \
+               [("md5_stored", C.c_uint8 * 16), ("md5_decoded", C.c_uint8 * 16)]
+
+
+def flac_decode(data, want_pcm=True):
+    """Sequential RFC 9639 decode with CRC-8/CRC-16 checks.  Returns (rc, pcm[int32, frames x channels] or None, info);
+    rc == 0 means every frame parsed and every CRC matched.  info.md5_decoded is the MD5 of the decoded PCM."""
+    buf = np.frombuffer(bytes(data), np.uint8)
+    info = FlacInfo()
+    fn = lib().orc_flac_decode
+    fn.restype = C.c_int
+    rc = fn(_p(buf, C.c_uint8), C.c_int64(buf.size), None, C.c_int64(0), C.byref(info))
+    pcm = None
+    if want_pcm and info.channels > 0 and info.decoded_samples > 0:
+        pcm = np.zeros((info.decoded_samples, info.channels), np.int32)
+        rc = fn(_p(buf, C.c_uint8), C.c_int64(buf.size), _p(pcm, C.c_int32), C.c_int64(info.decoded_samples), C.byref(info))
+    return rc, pcm, info
+
+
+def flac_encode(pcm, sample_rate, bps=16, blocksize=4096, mode=2, lpc_order=8):
+    """Format-coverage encoder for decoder tests (see orc_flac.c for the mode bits).  pcm: int array, frames x channels."""
+    a = np.ascontiguousarray(pcm, np.int32)
+    if a.ndim == 1:
+        a = a[:, None]
+    n, ch = a.shape
+    fn = lib().orc_flac_encode
+    fn.restype = C.c_int64
+    args = (_p(a, C.c_int32), C.c_int64(n), C.c_int(ch), C.c_int(bps), C.c_int(sample_rate), C.c_int(blocksize), C.c_int(mode),
+            C.c_int(lpc_order))
+    size = fn(*args, None, C.c_int64(0))
+    out = np.zeros(size, np.uint8)
+    fn(*args, _p(out, C.c_uint8), C.c_int64(size))
+    return out.tobytes()

@@ -251,3 +251,58 @@ def test_adeclick_threshold_monotone(oracle):
     x = rng.standard_normal(2 * sr) * 0.05
     counts = [oracle.adeclick(x, sr, thr, return_count=True)[1] for thr in (1.5, 2.0, 3.0, 5.0)]
     assert counts == sorted(counts, reverse=True) and counts[-1] < counts[0] // 10
+
+
+# ---------------------------------------------------------------- FLAC (RFC 9639): the oracle decoder's own pins
+# Appendix D.1 ("decoding example 1": one stereo frame of one sample, verbatim, two wasted bits on the first channel, four on
+# the second) and D.3 ("example 3": mono 8-bit, 24 samples, LPC order 3, precision 4, shift 2, one Rice partition), both with the
+# MD5 signatures the RFC's STREAMINFO blocks carry — the decoded PCM hashing to the stored MD5 is the known answer.
+RFC9639_EX1 = bytes.fromhex(
+    "664c614380000022" "10001000" "00000f" "00000f" "0ac442f000000001" "3e84b41807dc690307586a3dad1a2e0f"
+    "fff869180000bf" "0358fd" "03128b" "aa9a")
+RFC9639_EX3 = bytes.fromhex(
+    "664c614380000022" "10001000" "00001f" "00001f" "07d0007000000018" "f8f9e396f5cbcfc6dc807f9977906b32"
+    "fff868020017e9" "44004f6f313d1047d227cb6d09083145" "2bdc28222280" "57a3")
+
+
+def test_flac_rfc9639_example_1(oracle):
+    rc, pcm, info = oracle.flac_decode(RFC9639_EX1)
+    assert rc == 0 and info.frames == 1 and (info.sample_rate, info.channels, info.bps, info.total_samples) == (44100, 2, 16, 1)
+    assert pcm.tolist() == [[25588, 10416]]
+    assert bytes(info.md5_decoded).hex() == "3e84b41807dc690307586a3dad1a2e0f" == bytes(info.md5_stored).hex()
+
+
+def test_flac_rfc9639_example_3_lpc_rice(oracle):
+    rc, pcm, info = oracle.flac_decode(RFC9639_EX3)
+    assert rc == 0 and (info.sample_rate, info.channels, info.bps, info.total_samples) == (32000, 1, 8, 24)
+    assert pcm[:, 0].tolist() == [0, 79, 111, 78, 8, -61, -90, -68, -13, 42, 67, 53, 13, -27, -46, -38, -12, 14, 24, 19, 6, -4, -5, 0]
+    assert bytes(info.md5_decoded).hex() == "f8f9e396f5cbcfc6dc807f9977906b32" == bytes(info.md5_stored).hex()
+
+
+def test_flac_decoder_rejects_damage(oracle):
+    for pos in (42 + 3, 42 + 9, len(RFC9639_EX3) - 1):
+        bad = bytearray(RFC9639_EX3); bad[pos] ^= 0x10
+        rc, _, info = oracle.flac_decode(bytes(bad), want_pcm=False)
+        assert rc != 0
+    bad = bytearray(RFC9639_EX3); bad[30] ^= 1            # MD5 field: stream still parses, signature no longer matches
+    rc, _, info = oracle.flac_decode(bytes(bad))
+    assert rc == 0 and bytes(info.md5_decoded) != bytes(info.md5_stored)
+
+
+def test_flac_format_coverage_roundtrips(oracle):
+    """The oracle's coverage encoder (verbatim / every fixed order / LPC to order 32 / escapes / 5-bit Rice / wasted bits /
+    variable block sizes / all stereo modes) decodes back bit for bit, with hashlib agreeing on the MD5."""
+    import hashlib
+    rng = np.random.default_rng(1)
+    for mode in (0, 1, 2, 2 | 8, 2 | 16, 1 | 32, 2 | 64, 2 | 128, 2 | 192, 1 | 16 | 8):
+        for ch in (1, 2):
+            for bps, order in ((8, 3), (16, 8), (24, 32)):
+                x = (rng.standard_normal((9000, ch)).cumsum(0) * (1 << (bps - 6)) / 30).clip(-(1 << (bps - 1)), (1 << (bps - 1)) - 1).astype(np.int32)
+                if mode & 8:
+                    x[:512] &= ~7
+                f = oracle.flac_encode(x, 44100, bps, 1024 if mode & 32 else 4096, mode, order)
+                rc, y, info = oracle.flac_decode(f)
+                assert rc == 0 and np.array_equal(x, y), (mode, ch, bps)
+                le = x.astype("<i4").tobytes() if bps > 24 else b"".join(
+                    x.astype("<i4").reshape(-1, 1).view(np.uint8)[:, : (bps + 7) // 8].tobytes() for _ in (0,))
+                assert bytes(info.md5_stored) == bytes(info.md5_decoded) == hashlib.md5(le).digest()
