@@ -180,6 +180,26 @@ typedef struct {              /* loudnorm second pass options (normalise.go:1269
 int jt_pass4(jt_ctx *h, const jt_limiter_plan *lim, const jt_loudnorm_apply *ap,
              jt_analysis *out, jt_loudnorm_stats *stats);
 
+/* ---- input leg: replaces audio.OpenAudioFile + Reader.ReadFrame (reader.go:29-169), which every pass of the reference runs
+ * again over the file.  `file` is the whole file image in host memory: FLAC (RFC 9639: any block size, 4..24 bits, 1..8
+ * channels, all predictor / residual / stereo modes; an ID3v2 tag in front is skipped) is decoded on the GPU; RIFF/WAVE PCM
+ * (u8, s16, s24, s32, f32, f64, WAVE_FORMAT_EXTENSIBLE) is unpacked on the GPU.  Afterwards the handle is in the state
+ * jt_upload_pcm() leaves it in (interleaved f32 at the file's rate; integer PCM scaled by 2^(1-bits) exactly as
+ * libswresample's s16/s32 -> flt conversion does).  Errors: JT_E_INVAL for a damaged or truncated stream (frame CRC-16 /
+ * header CRC-8 / sample count), JT_E_UNSUPPORTED for other containers or 32-bit FLAC. */
+typedef struct {
+    int format;                  /* 1 = FLAC, 2 = WAV */
+    int sample_rate, channels, bits_per_sample, is_float;
+    int64_t frames;              /* inter-channel samples */
+    double duration_s;           /* Metadata.Duration (reader.go:22-27) */
+    int64_t flac_frames; int flac_candidates;
+    double gpu_ms, total_ms;
+} jt_audio_meta;
+int jt_load_audio(jt_ctx *h, const uint8_t *file, int64_t len, jt_audio_meta *meta);
+/* operator-level entry (parity tests): the decoded samples back on the host, interleaved; either pointer may be NULL */
+int jt_op_decode_audio(jt_ctx *h, const uint8_t *file, int64_t len, int32_t *pcm_i32, float *pcm_f32, int64_t cap_values,
+                       jt_audio_meta *meta);
+
 /* ---- output: replaces Encoder.WriteFrame's input (encoder.go:145): raw s16, or the finished FLAC file below ---- */
 int jt_output_len(jt_ctx *h, int stage, int64_t *n);
 int jt_download_s16(jt_ctx *h, int stage, int16_t *dst, int64_t cap, int64_t *n);

@@ -108,10 +108,16 @@ class FlacInfo(C.Structure):
 
 JT_FLAC_MD5 = 1
 
+
+class AudioMeta(C.Structure):
+    _fields_ = [("format", C.c_int), ("sample_rate", C.c_int), ("channels", C.c_int), ("bits_per_sample", C.c_int),
+                ("is_float", C.c_int), ("frames", C.c_int64), ("duration_s", C.c_double), ("flac_frames", C.c_int64),
+                ("flac_candidates", C.c_int), ("gpu_ms", C.c_double), ("total_ms", C.c_double)]
+
 # every symbol include/jtgpu.h declares
 SYMBOLS = [
     "jt_open", "jt_close", "jt_last_error", "jt_version", "jt_cancel",
-    "jt_upload_pcm", "jt_attach_device_pcm", "jt_upload_s16",
+    "jt_upload_pcm", "jt_attach_device_pcm", "jt_upload_s16", "jt_load_audio", "jt_op_decode_audio",
     "jt_pass1", "jt_band_rms", "jt_pass2", "jt_region_measure", "jt_region_measure_pair", "jt_pass3", "jt_pass4",
     "jt_output_len", "jt_download_s16", "jt_flac_encode", "jt_op_flac_encode_s16", "jt_get_timers",
     "jt_op_biquad_f32", "jt_op_anlmdn_f32", "jt_op_afftdn_f32", "jt_op_dynamics", "jt_op_alimiter_f64", "jt_op_adeclick_f64",

@@ -868,6 +868,215 @@ extern "C" int jt_op_flac_encode_s16(jt_ctx *h, const int16_t *pcm, int64_t n, i
     JT_API_END(h)
 }
 
+// ---------------------------------------------------------------- input leg: FLAC / WAV file image -> PCM on the device
+namespace {
+struct AudioDecoded { int64_t frames = 0; int channels = 0, rate = 0, bits = 0, is_float = 0, format = 0; int64_t flac_frames = 0; int cands = 0; };
+
+uint32_t rd_le32(const uint8_t *p) { return (uint32_t)p[0] | (uint32_t)p[1] << 8 | (uint32_t)p[2] << 16 | (uint32_t)p[3] << 24; }
+uint32_t rd_le16(const uint8_t *p) { return (uint32_t)p[0] | (uint32_t)p[1] << 8; }
+
+// FLAC: metadata walk on the host (a few hundred bytes), everything else on the device
+void decode_flac(jt_ctx *h, const uint8_t *file, int64_t len, int64_t start, bool want_i32, bool want_f32, AudioDecoded *out)
+{
+    JtFlacStream st; st.len = len;
+    int64_t pos = start + 4; bool last = false, have = false;
+    while (!last) {
+        JT_REQUIRE(pos + 4 <= len, JT_E_INVAL, "flac: truncated metadata");
+        last = (file[pos] & 0x80) != 0;
+        const int type = file[pos] & 0x7f;
+        const int64_t blen = (int64_t)file[pos + 1] << 16 | (int64_t)file[pos + 2] << 8 | file[pos + 3];
+        pos += 4;
+        JT_REQUIRE(pos + blen <= len, JT_E_INVAL, "flac: truncated metadata block");
+        JT_REQUIRE(type != 127, JT_E_INVAL, "flac: invalid metadata block type");
+        if (type == 0) {
+            JT_REQUIRE(blen == 34, JT_E_INVAL, "flac: bad STREAMINFO length");
+            const uint8_t *p = file + pos;
+            st.min_blocksize = p[0] << 8 | p[1]; st.max_blocksize = p[2] << 8 | p[3];
+            st.sample_rate = p[10] << 12 | p[11] << 4 | p[12] >> 4;
+            st.channels = ((p[12] >> 1) & 7) + 1;
+            st.bps = (((p[12] & 1) << 4) | (p[13] >> 4)) + 1;
+            st.total_samples = (int64_t)(p[13] & 15) << 32 | (int64_t)p[14] << 24 | (int64_t)p[15] << 16 | (int64_t)p[16] << 8 | p[17];
+            have = true;
+        }
+        pos += blen;
+    }
+    JT_REQUIRE(have, JT_E_INVAL, "flac: no STREAMINFO block");
+    JT_REQUIRE(st.bps >= 4 && st.bps <= 24, JT_E_UNSUPPORTED, "flac: only 4..24 bits per sample are supported");
+    JT_REQUIRE(st.max_blocksize >= 16 && st.min_blocksize <= st.max_blocksize, JT_E_INVAL, "flac: bad block sizes in STREAMINFO");
+    JT_REQUIRE(st.sample_rate > 0, JT_E_INVAL, "flac: sample rate 0");
+    st.audio_offset = pos;
+    JT_REQUIRE(pos < len, JT_E_INVAL, "flac: no audio frames");
+
+    // file image on the device, zero padded so header probes and bit-reader refills never leave the allocation
+    const size_t padded = ((size_t)len + 64 + 3) & ~(size_t)3;
+    h->in_file.ensure(padded);
+    JT_HIP(hipMemsetAsync(h->in_file.p + ((size_t)len & ~(size_t)3), 0, padded - ((size_t)len & ~(size_t)3), h->stream));
+    JT_HIP(hipMemcpyAsync(h->in_file.p, file, (size_t)len, hipMemcpyHostToDevice, h->stream));
+
+    // candidates: expected frame count plus room for look-alikes
+    const int64_t expect = st.total_samples > 0 ? st.total_samples / std::max(16, st.min_blocksize) + 2 : (len - pos) / 16 + 2;
+    int cap = (int)std::min<int64_t>((int64_t)1 << 28, expect * 2 + (len - pos) / 2048 + 4096);
+    std::vector<JtFlacCand> cands; std::vector<JtFlacParsed> parsed;
+    int ncand = 0;
+    for (int attempt = 0; attempt < 2; attempt++) {
+        const size_t tab_bytes = 256 + sizeof(JtFlacCand) * (size_t)cap + sizeof(JtFlacParsed) * (size_t)cap;
+        h->in_tab.ensure(tab_bytes);
+        int *d_count = reinterpret_cast<int *>(h->in_tab.p);
+        JtFlacCand *d_cand = reinterpret_cast<JtFlacCand *>(h->in_tab.p + 256);
+        JtFlacParsed *d_parsed = reinterpret_cast<JtFlacParsed *>(h->in_tab.p + 256 + sizeof(JtFlacCand) * (size_t)cap);
+        JT_HIP(hipMemsetAsync(d_count, 0, 256, h->stream));
+        launch_flacdec_find(h->in_file.p, st, d_cand, d_count, cap, h->stream);
+        JT_HIP(hipMemcpyAsync(&ncand, d_count, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+        JT_HIP(hipStreamSynchronize(h->stream));
+        if (ncand > cap) { cap = ncand + 1024; continue; }
+        JT_REQUIRE(ncand > 0, JT_E_INVAL, "flac: no frame headers found");
+        launch_flacdec_parse(h->in_file.p, st, d_cand, ncand, d_parsed, h->stream);
+        cands.resize((size_t)ncand); parsed.resize((size_t)ncand);
+        JT_HIP(hipMemcpyAsync(cands.data(), d_cand, sizeof(JtFlacCand) * (size_t)ncand, hipMemcpyDeviceToHost, h->stream));
+        JT_HIP(hipMemcpyAsync(parsed.data(), d_parsed, sizeof(JtFlacParsed) * (size_t)ncand, hipMemcpyDeviceToHost, h->stream));
+        JT_HIP(hipStreamSynchronize(h->stream));
+        break;
+    }
+    JT_REQUIRE(ncand <= cap, JT_E_HIP, "flac: candidate table overflow");
+
+    // follow end -> start links from the first frame; look-alike headers inside audio data are never reached
+    std::vector<int> order((size_t)ncand);
+    for (int i = 0; i < ncand; i++) order[(size_t)i] = i;
+    std::sort(order.begin(), order.end(), [&](int a, int b) { return cands[(size_t)a].pos < cands[(size_t)b].pos; });
+    std::vector<JtFlacFrame> frames; frames.reserve((size_t)ncand);
+    int64_t cur = st.audio_offset, total = 0; int variable = -1;
+    while (cur < len) {
+        auto it = std::lower_bound(order.begin(), order.end(), cur, [&](int a, int64_t v) { return cands[(size_t)a].pos < v; });
+        if (it == order.end() || cands[(size_t)*it].pos != cur) break;
+        const JtFlacCand &c = cands[(size_t)*it]; const JtFlacParsed &pr = parsed[(size_t)*it];
+        if (!pr.ok) break;
+        if (variable < 0) variable = c.variable;
+        JT_REQUIRE(c.variable == variable, JT_E_INVAL, "flac: blocking strategy changes inside the stream");
+        if (variable) JT_REQUIRE(c.number == total, JT_E_INVAL, "flac: frame sample number out of sequence");
+        else JT_REQUIRE(c.number == (int64_t)frames.size(), JT_E_INVAL, "flac: frame number out of sequence");
+        JtFlacFrame f; f.pos = c.pos; f.out_offset = total; f.blocksize = c.blocksize; f.ch_assign = c.ch_assign;
+        for (int k = 0; k < 8; k++) f.sub_bit[k] = pr.sub_bit[k];
+        frames.push_back(f);
+        total += c.blocksize; cur = pr.end;
+    }
+    JT_REQUIRE(!frames.empty(), JT_E_INVAL, "flac: the first audio frame is damaged");
+    if (st.total_samples > 0) JT_REQUIRE(total == st.total_samples, JT_E_INVAL, "flac: damaged or truncated stream (decoded sample count differs from STREAMINFO)");
+    else JT_REQUIRE(cur >= len - 128, JT_E_INVAL, "flac: damaged frame inside the stream");
+
+    const size_t nvals = (size_t)total * (size_t)st.channels;
+    h->in_planar.ensure(nvals + 64);
+    if (want_i32) h->in_i32.ensure(nvals);
+    if (want_f32) h->in_owned.ensure(nvals);
+    const size_t ftab = sizeof(JtFlacFrame) * frames.size();
+    h->in_tab.ensure(256 + ftab);                  // the candidate tables are dead now (copied to the host above)
+    int *d_err = reinterpret_cast<int *>(h->in_tab.p);
+    JtFlacFrame *d_frames = reinterpret_cast<JtFlacFrame *>(h->in_tab.p + 256);
+    JT_HIP(hipMemsetAsync(d_err, 0, 256, h->stream));
+    JT_HIP(hipMemcpyAsync(d_frames, frames.data(), ftab, hipMemcpyHostToDevice, h->stream));
+    launch_flacdec_decode(h->in_file.p, st, d_frames, (long long)frames.size(), total, h->in_planar.p, d_err,
+                          want_i32 ? h->in_i32.p : nullptr, want_f32 ? h->in_owned.p : nullptr, h->stream);
+    int nerr = 0;
+    JT_HIP(hipMemcpyAsync(&nerr, d_err, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    JT_HIP(hipStreamSynchronize(h->stream));
+    JT_REQUIRE(nerr == 0, JT_E_INVAL, "flac: subframe decode error");
+    out->frames = total; out->channels = st.channels; out->rate = st.sample_rate; out->bits = st.bps; out->is_float = 0; out->format = 1;
+    out->flac_frames = (int64_t)frames.size(); out->cands = ncand;
+}
+
+// RIFF/WAVE: chunk walk on the host, sample unpacking on the device
+void decode_wav(jt_ctx *h, const uint8_t *file, int64_t len, bool want_i32, bool want_f32, AudioDecoded *out)
+{
+    JT_REQUIRE(len >= 12 && !memcmp(file + 8, "WAVE", 4), JT_E_UNSUPPORTED, "wav: not a RIFF/WAVE file");
+    int64_t pos = 12; int tag = 0, ch = 0, rate = 0, bits = 0, align = 0; bool have_fmt = false;
+    int64_t data_off = -1, data_len = 0;
+    while (pos + 8 <= len) {
+        const uint32_t sz = rd_le32(file + pos + 4);
+        const uint8_t *body = file + pos + 8;
+        if (!memcmp(file + pos, "fmt ", 4)) {
+            JT_REQUIRE(sz >= 16 && pos + 8 + 16 <= len, JT_E_INVAL, "wav: short fmt chunk");
+            tag = (int)rd_le16(body); ch = (int)rd_le16(body + 2); rate = (int)rd_le32(body + 4); align = (int)rd_le16(body + 12); bits = (int)rd_le16(body + 14);
+            if (tag == 0xfffe) { JT_REQUIRE(sz >= 40 && pos + 8 + 40 <= len, JT_E_INVAL, "wav: short extensible fmt chunk"); tag = (int)rd_le16(body + 24); }
+            have_fmt = true;
+        } else if (!memcmp(file + pos, "data", 4)) {
+            data_off = pos + 8;
+            data_len = std::min<int64_t>((int64_t)sz, len - data_off);      // a streamed writer may leave 0xFFFFFFFF / short sizes
+            if (sz == 0xffffffffu || sz == 0) data_len = len - data_off;
+            break;
+        }
+        pos += 8 + (int64_t)sz + (sz & 1);
+    }
+    JT_REQUIRE(have_fmt && data_off >= 0, JT_E_INVAL, "wav: missing fmt or data chunk");
+    JT_REQUIRE(ch >= 1 && ch <= 8 && rate > 0, JT_E_INVAL, "wav: bad channel count or rate");
+    int fmt = -1;
+    if (tag == 1) fmt = bits == 8 ? 0 : bits == 16 ? 1 : bits == 24 ? 2 : bits == 32 ? 3 : -1;
+    else if (tag == 3) fmt = bits == 32 ? 4 : bits == 64 ? 5 : -1;
+    JT_REQUIRE(fmt >= 0, JT_E_UNSUPPORTED, "wav: only PCM 8/16/24/32-bit and IEEE float 32/64-bit are supported");
+    const int bytes = bits / 8;
+    JT_REQUIRE(align == 0 || align == bytes * ch, JT_E_INVAL, "wav: block alignment does not match the sample format");
+    const int64_t frames = data_len / ((int64_t)bytes * ch);
+    JT_REQUIRE(frames > 0, JT_E_INVAL, "wav: empty data chunk");
+    const size_t nvals = (size_t)frames * (size_t)ch, raw = nvals * (size_t)bytes;
+    h->in_file.ensure(raw + 16);
+    JT_HIP(hipMemcpyAsync(h->in_file.p, file + data_off, raw, hipMemcpyHostToDevice, h->stream));
+    if (want_i32) h->in_i32.ensure(nvals);
+    if (want_f32) h->in_owned.ensure(nvals);
+    launch_pcm_convert(h->in_file.p, (long long)nvals, fmt, want_f32 ? h->in_owned.p : nullptr, want_i32 ? h->in_i32.p : nullptr, h->stream);
+    JT_HIP(hipStreamSynchronize(h->stream));
+    out->frames = frames; out->channels = ch; out->rate = rate; out->bits = bits; out->is_float = tag == 3; out->format = 2;
+}
+
+void decode_audio(jt_ctx *h, const uint8_t *file, int64_t len, bool want_i32, bool want_f32, AudioDecoded *out, jt_audio_meta *meta)
+{
+    JT_REQUIRE(file && len > 12, JT_E_INVAL, "audio: empty file image");
+    const double t0 = flac_now_ms();
+    JT_HIP(hipEventRecord(h->ev0, h->stream));
+    int64_t start = 0;
+    if (!memcmp(file, "ID3", 3) && len > 10) {      // ID3v2 tag in front of the stream: 28-bit syncsafe size (+ footer)
+        start = 10 + ((int64_t)(file[6] & 0x7f) << 21 | (int64_t)(file[7] & 0x7f) << 14 | (int64_t)(file[8] & 0x7f) << 7 | (file[9] & 0x7f));
+        if (file[5] & 0x10) start += 10;
+        JT_REQUIRE(start + 4 < len, JT_E_INVAL, "audio: ID3 tag longer than the file");
+    }
+    if (!memcmp(file + start, "fLaC", 4)) decode_flac(h, file, len, start, want_i32, want_f32, out);
+    else if (!memcmp(file, "RIFF", 4)) decode_wav(h, file, len, want_i32, want_f32, out);
+    else throw JtError{JT_E_UNSUPPORTED, "audio: only FLAC and RIFF/WAVE inputs are decoded on the device"};
+    JT_HIP(hipEventRecord(h->ev1, h->stream));
+    JT_HIP(hipStreamSynchronize(h->stream));
+    float gpu_ms = 0.f;
+    JT_HIP(hipEventElapsedTime(&gpu_ms, h->ev0, h->ev1));
+    if (meta) {
+        memset(meta, 0, sizeof *meta);
+        meta->format = out->format; meta->sample_rate = out->rate; meta->channels = out->channels; meta->bits_per_sample = out->bits;
+        meta->is_float = out->is_float; meta->frames = out->frames; meta->duration_s = (double)out->frames / (double)out->rate;
+        meta->flac_frames = out->flac_frames; meta->flac_candidates = out->cands; meta->gpu_ms = gpu_ms; meta->total_ms = flac_now_ms() - t0;
+    }
+}
+} // namespace
+
+extern "C" int jt_load_audio(jt_ctx *h, const uint8_t *file, int64_t len, jt_audio_meta *meta)
+{
+    JT_API_BEGIN(h)
+    AudioDecoded d;
+    decode_audio(h, file, len, false, true, &d, meta);
+    h->in_raw = h->in_owned.p;
+    set_input_common(h, d.frames, d.rate, d.channels);
+    JT_HIP(hipStreamSynchronize(h->stream));
+    JT_API_END(h)
+}
+
+extern "C" int jt_op_decode_audio(jt_ctx *h, const uint8_t *file, int64_t len, int32_t *pcm_i32, float *pcm_f32, int64_t cap_values,
+                                  jt_audio_meta *meta)
+{
+    JT_API_BEGIN(h)
+    AudioDecoded d;
+    decode_audio(h, file, len, pcm_i32 != nullptr, true, &d, meta);
+    const int64_t nvals = d.frames * d.channels;
+    if (pcm_i32 || pcm_f32) JT_REQUIRE(cap_values >= nvals, JT_E_INVAL, "decode: output buffer too small");
+    if (pcm_i32) JT_HIP(hipMemcpyAsync(pcm_i32, h->in_i32.p, sizeof(int32_t) * (size_t)nvals, hipMemcpyDeviceToHost, h->stream));
+    if (pcm_f32) JT_HIP(hipMemcpyAsync(pcm_f32, h->in_owned.p, sizeof(float) * (size_t)nvals, hipMemcpyDeviceToHost, h->stream));
+    JT_HIP(hipStreamSynchronize(h->stream));
+    JT_API_END(h)
+}
+
 extern "C" int jt_get_timers(jt_ctx *h, jt_timers *out)
 {
     if (!h || !out) return JT_E_INVAL;

@@ -131,6 +131,17 @@ void launch_flac_emit(const int16_t *pcm, int64_t n, int sr_code, int sr_extra_b
                       const long long *offs, uint8_t *out, void *summary, hipStream_t s);
 void jt_md5(const void *data, size_t len, uint8_t out[16]);      // RFC 1321 (jt_plan.cpp), STREAMINFO signature
 
+// FLAC / WAV input leg (k_flacdec.hip); the structs mirror the kernels' layouts
+struct JtFlacStream { int channels = 0, bps = 0, sample_rate = 0, min_blocksize = 0, max_blocksize = 0; long long total_samples = 0, audio_offset = 0, len = 0; };
+struct JtFlacCand { long long pos, number; int blocksize, hdr_len, ch_assign, variable; };
+struct JtFlacParsed { long long end; int ok, wasted_any; long long sub_bit[8]; };
+struct JtFlacFrame { long long pos, out_offset; int blocksize, ch_assign; long long sub_bit[8]; };
+void launch_flacdec_find(const uint8_t *file, const JtFlacStream &s, JtFlacCand *cands, int *count, int cap, hipStream_t st);
+void launch_flacdec_parse(const uint8_t *file, const JtFlacStream &s, const JtFlacCand *cands, int ncand, JtFlacParsed *out, hipStream_t st);
+void launch_flacdec_decode(const uint8_t *file, const JtFlacStream &s, const JtFlacFrame *frames, long long nframes, long long total,
+                           int *planar, int *errs, int *out_i32, float *out_f32, hipStream_t st);
+void launch_pcm_convert(const uint8_t *raw, long long nvals, int fmt, float *out_f32, int *out_i32, hipStream_t st);
+
 // ---------------------------------------------------------------- pinned host staging
 // Every device->host result of a pass lands in one pinned arena, so a pass enqueues all its kernels and copies back to back
 // and synchronises ONCE (pageable destinations would serialise each copy through a bounce buffer).
@@ -230,6 +241,8 @@ struct jt_ctx {
     // FLAC output leg: frame records, byte offsets, summary, encoded frames; pinned host copies of the PCM (MD5) and the file
     DevBuf<unsigned char> fl_rec, fl_out; DevBuf<long long> fl_off; DevBuf<int16_t> fl_pcm;
     HostArena pin_pcm, pin_flac;
+    // input leg: file image, frame candidates / parse results / frame table, planar and interleaved integer PCM
+    DevBuf<unsigned char> in_file, in_tab; DevBuf<int> in_planar, in_i32;
     jt_timers timers{};
     hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr, ev3 = nullptr;
 };

@@ -84,6 +84,26 @@ class Engine:
         pcm = np.ascontiguousarray(pcm, np.int16)
         self._ck(self.lib.jt_upload_s16(self.h, pcm.ctypes.data_as(C.POINTER(C.c_int16)), C.c_int64(pcm.size), C.c_int(sample_rate)))
 
+    def load_audio(self, data):
+        """FLAC / WAV file image -> the handle's input (include/jtgpu.h: jt_load_audio).  Returns the metadata dict."""
+        buf = np.frombuffer(bytes(data), np.uint8); m = L.AudioMeta()
+        self._ck(self.lib.jt_load_audio(self.h, buf.ctypes.data_as(C.POINTER(C.c_uint8)), C.c_int64(buf.size), C.byref(m)))
+        return _st2dict(m)
+
+    def op_decode_audio(self, data, want_i32=True):
+        """Decoded samples back on the host: (int32 [frames, ch] or None, f32 [frames, ch], meta)."""
+        buf = np.frombuffer(bytes(data), np.uint8); m = L.AudioMeta()
+        self._ck(self.lib.jt_op_decode_audio(self.h, buf.ctypes.data_as(C.POINTER(C.c_uint8)), C.c_int64(buf.size), None, None,
+                                             C.c_int64(0), C.byref(m)))
+        n = m.frames * m.channels
+        i32 = np.empty(n, np.int32) if want_i32 and not m.is_float else None
+        f32 = np.empty(n, np.float32)
+        self._ck(self.lib.jt_op_decode_audio(self.h, buf.ctypes.data_as(C.POINTER(C.c_uint8)), C.c_int64(buf.size),
+                                             i32.ctypes.data_as(C.POINTER(C.c_int32)) if i32 is not None else None,
+                                             f32.ctypes.data_as(C.POINTER(C.c_float)), C.c_int64(n), C.byref(m)))
+        sh = (m.frames, m.channels)
+        return (i32.reshape(sh) if i32 is not None else None), f32.reshape(sh), _st2dict(m)
+
     # ---- passes
     def pass1(self, n_frames_input, frame_samples=4096, sample_rate=48000, want_meta=True):
         nfr = (n_frames_input + frame_samples - 1) // frame_samples

@@ -405,7 +405,9 @@ int64_t orc_flac_encode(const int32_t *pcm, int64_t nframes, int channels, int b
         uint8_t dg[16]; md5_final(&md, dg); for (int i = 0; i < 16; i++) bw_u(&w, dg[i], 8);
     }
     int64_t done = 0, fno = 0;
-    int64_t *chb[2] = {(int64_t *)malloc(sizeof(int64_t) * (size_t)blocksize), (int64_t *)malloc(sizeof(int64_t) * (size_t)blocksize)};
+    int64_t *chb[8];
+    if (channels < 1 || channels > 8) return -1;
+    for (int c = 0; c < 8; c++) chb[c] = (int64_t *)malloc(sizeof(int64_t) * (size_t)blocksize);
     while (done < nframes) {
         int bs = blocksize;
         if (variable && (fno & 1)) bs = minbs;
@@ -436,7 +438,7 @@ int64_t orc_flac_encode(const int32_t *pcm, int64_t nframes, int channels, int b
         bw_u(&w, orc_flac_crc16(w.p + fstart, (w.pos >> 3) - fstart), 16);
         done += bs; fno++;
     }
-    free(chb[0]); free(chb[1]);
+    for (int c = 0; c < 8; c++) free(chb[c]);
     const int64_t total = w.pos >> 3;
     if (out && total <= cap) memcpy(out, w.p, (size_t)total);
     free(w.p);

@@ -113,3 +113,170 @@ def test_stage_outputs_encode_to_the_downloaded_pcm(oracle):
             assert info["sample_rate"] == 44100 and info["block_size"] == 4096
     finally:
         e.close()
+
+
+# ================================================================ input leg: jt_load_audio / jt_op_decode_audio
+def coverage_signal(rng, n, ch, bps):
+    x = rng.standard_normal((n, ch)).cumsum(0) * (1 << (bps - 6)) / 30
+    return x.clip(-(1 << (bps - 1)), (1 << (bps - 1)) - 1).astype(np.int32)
+
+
+# oracle coverage-encoder modes (oracle/orc_flac.c): predictor | 8 escape | 16 five-bit rice | 32 variable blocks | 64.. stereo
+@pytest.mark.parametrize("mode", [0, 1, 2, 2 | 8, 2 | 16, 1 | 32, 2 | 32, 2 | 64, 2 | 128, 2 | 192, 1 | 16 | 8])
+def test_decoder_covers_the_format(engine, oracle, mode):
+    rng = np.random.default_rng(mode)
+    for ch in (1, 2, 3, 6):
+        if ch > 2 and mode >= 64:
+            continue
+        for bps, order in ((8, 3), (16, 8), (24, 32), (16, 12), (20, 5), (12, 2)):
+            x = coverage_signal(rng, 20000 + 77, ch, bps)
+            if mode & 8:
+                x[:512] &= ~7                                        # wasted bits
+            data = oracle.flac_encode(x, 44100, bps, 1152 if mode & 32 else 4096, mode, order)
+            rc, ref, _ = oracle.flac_decode(data)
+            assert rc == 0 and np.array_equal(ref, x)                 # the oracle agrees with itself first
+            i32, f32, meta = engine.op_decode_audio(data)
+            assert np.array_equal(i32, x), (mode, ch, bps)
+            # libswresample s16/s32 -> flt: exact scaling by 2^(1-bits)
+            assert np.array_equal(f32, (x.astype(np.float64) / (1 << (bps - 1))).astype(np.float32))
+            assert (meta["sample_rate"], meta["channels"], meta["bits_per_sample"], meta["frames"]) == (44100, ch, bps, x.shape[0])
+            assert abs(meta["duration_s"] - x.shape[0] / 44100) < 1e-12
+
+
+def test_decoder_block_sizes_and_rates(engine, oracle):
+    rng = np.random.default_rng(3)
+    for bs, rate in ((16, 8000), (192, 22050), (576, 48000), (1000, 96000), (4608, 192000), (65535, 44100), (256, 12345)):
+        x = coverage_signal(rng, bs * 3 + bs // 2 + 1, 2, 16)
+        data = oracle.flac_encode(x, rate, 16, bs, 2, 6)
+        i32, _, meta = engine.op_decode_audio(data)
+        assert np.array_equal(i32, x) and meta["sample_rate"] == rate
+
+
+def test_gpu_encoder_to_gpu_decoder_roundtrip(engine):
+    pcm = np.tile(speech_s16(10.0, seed=9), 30)                       # 5 minutes, 3 230 frames
+    data = engine.op_flac_encode(pcm, 44100)
+    i32, f32, meta = engine.op_decode_audio(data)
+    assert np.array_equal(i32[:, 0], pcm.astype(np.int32))
+    assert np.array_equal(f32[:, 0], pcm.astype(np.float32) / 32768.0)
+    assert meta["flac_frames"] == (pcm.size + 4095) // 4096
+
+
+def _crc8(b):
+    c = 0
+    for x in b:
+        c ^= x
+        for _ in range(8):
+            c = ((c << 1) ^ 0x07) & 0xff if c & 0x80 else (c << 1) & 0xff
+    return c
+
+
+def _crc16(b):
+    c = 0
+    for x in b:
+        c ^= x << 8
+        for _ in range(8):
+            c = ((c << 1) ^ 0x8005) & 0xffff if c & 0x8000 else (c << 1) & 0xffff
+    return c
+
+
+def test_header_lookalikes_inside_audio_data_are_not_frames(engine, oracle):
+    """Verbatim frames carry the PCM bytes as they are, so a valid-looking frame can sit inside one.  A header with a right
+    CRC-8 (fails its CRC-16), and a complete 11-byte frame with both CRCs right (parses, but nothing links to it)."""
+    rng = np.random.default_rng(8)
+    x = rng.integers(-32768, 32768, 4096 * 6).astype(np.int16)       # white noise: the GPU encoder emits VERBATIM subframes
+    hdr = bytes([0xff, 0xf8, 0xc9, 0x08, 0x02])                       # fixed 4096, 44.1 kHz, mono, 16 bit, frame number 2
+    fake1 = hdr + bytes([_crc8(hdr)])
+    body = hdr + bytes([_crc8(hdr)]) + bytes([0x00, 0x12, 0x34])      # CONSTANT subframe, value 0x1234
+    fake2 = body + _crc16(body).to_bytes(2, "big") + b"\x00"
+    for at, fake in ((5000, fake1), (4096 * 3 + 100, fake2)):
+        x[at:at + len(fake) // 2] = np.frombuffer(fake, ">i2")
+    data = engine.op_flac_encode(x, 44100)
+    rc, ref, _ = oracle.flac_decode(data)
+    assert rc == 0 and np.array_equal(ref[:, 0], x)
+    i32, _, meta = engine.op_decode_audio(data)
+    assert np.array_equal(i32[:, 0], x.astype(np.int32))
+    assert meta["flac_candidates"] >= meta["flac_frames"] + 2         # both look-alikes were seen and rejected
+
+
+def test_damaged_and_foreign_inputs_fail_loudly(engine):
+    pcm = speech_s16(3.0, seed=2)
+    data = bytearray(engine.op_flac_encode(pcm, 44100))
+    for pos in (len(data) // 2, len(data) - 1, 120):
+        bad = bytearray(data); bad[pos] ^= 0x04
+        with pytest.raises(L.JtError) as ei:
+            engine.op_decode_audio(bytes(bad))
+        assert ei.value.code == L.JT_E_INVAL
+    with pytest.raises(L.JtError) as ei:
+        engine.op_decode_audio(bytes(data[: len(data) * 2 // 3]))     # truncated
+    assert ei.value.code == L.JT_E_INVAL
+    with pytest.raises(L.JtError) as ei:
+        engine.op_decode_audio(b"OggS" + bytes(200))
+    assert ei.value.code == L.JT_E_UNSUPPORTED
+    # an ID3v2 tag in front of the stream is skipped
+    tag = b"ID3\x04\x00\x00" + bytes([0, 0, 0, 20]) + bytes(20)
+    i32, _, _ = engine.op_decode_audio(tag + bytes(data))
+    assert np.array_equal(i32[:, 0], pcm.astype(np.int32))
+
+
+def _wav(fmt_tag, bits, ch, rate, payload, extensible=False, extra_chunks=True):
+    import struct
+    align = ch * bits // 8
+    if extensible:
+        guid = struct.pack("<H", fmt_tag) + bytes.fromhex("000000001000800000aa00389b71")
+        fmt = struct.pack("<HHIIHHHHI", 0xfffe, ch, rate, rate * align, align, bits, 22, bits, 0) + guid
+    else:
+        fmt = struct.pack("<HHIIHH", fmt_tag, ch, rate, rate * align, align, bits)
+    chunks = b"fmt " + struct.pack("<I", len(fmt)) + fmt
+    if extra_chunks:
+        chunks += b"LIST" + struct.pack("<I", 5) + b"INFOx" + b"\x00"      # odd-sized chunk + pad byte
+    chunks += b"data" + struct.pack("<I", len(payload)) + payload
+    return b"RIFF" + struct.pack("<I", 4 + len(chunks)) + b"WAVE" + chunks
+
+
+def test_wav_formats(engine):
+    rng = np.random.default_rng(4)
+    n, ch = 30011, 2
+    f = rng.standard_normal((n, ch)).astype(np.float32) * 0.3
+    s32 = rng.integers(-2**31, 2**31, (n, ch)).astype(np.int64)
+    cases = []
+    u8 = rng.integers(0, 256, (n, ch)).astype(np.uint8)
+    cases.append((1, 8, u8.tobytes(), (u8.astype(np.int32) - 128), (u8.astype(np.float32) - 128) / 128, False))
+    s16 = (s32 >> 16).astype(np.int16)
+    cases.append((1, 16, s16.astype("<i2").tobytes(), s16.astype(np.int32), s16.astype(np.float32) / 32768, False))
+    s24 = (s32 >> 8).astype(np.int32)
+    cases.append((1, 24, s24.astype("<i4").reshape(-1, 1).view(np.uint8)[:, :3].tobytes(), s24, s24.astype(np.float32) / 8388608, True))
+    cases.append((1, 32, s32.astype("<i4").tobytes(), s32.astype(np.int32), (s32.astype(np.int32)).astype(np.float32) / np.float32(2147483648.0), False))
+    cases.append((3, 32, f.astype("<f4").tobytes(), None, f, False))
+    d = f.astype(np.float64) * 1.0000001
+    cases.append((3, 64, d.astype("<f8").tobytes(), None, d.astype(np.float32), True))
+    for tag, bits, payload, want_i, want_f, ext in cases:
+        i32, f32, meta = engine.op_decode_audio(_wav(tag, bits, ch, 48000, payload, extensible=ext))
+        assert (meta["format"], meta["sample_rate"], meta["channels"], meta["bits_per_sample"], meta["frames"]) == (2, 48000, ch, bits, n)
+        assert meta["is_float"] == (tag == 3)
+        if want_i is not None:
+            assert np.array_equal(i32, want_i), bits
+        assert np.array_equal(f32, want_f.astype(np.float32)), (tag, bits)
+    with pytest.raises(L.JtError) as ei:
+        engine.op_decode_audio(_wav(2, 4, 1, 8000, bytes(100)))          # ADPCM
+    assert ei.value.code == L.JT_E_UNSUPPORTED
+
+
+def test_load_audio_feeds_the_passes_like_upload_pcm(oracle):
+    """jt_load_audio of a 24-bit stereo FLAC == jt_upload_pcm of the same samples as f32: identical Pass-1 analysis."""
+    from jivetalking_amd import hostlogic
+    sr = 48000
+    x = np.asarray(synth.speech_like(12.0, sr, seed=21), np.float64)
+    st = np.stack([x, 0.8 * np.roll(x, 7)], 1)
+    pcm = np.clip(np.rint(st * (1 << 23)), -(1 << 23), (1 << 23) - 1).astype(np.int32)
+    data = oracle.flac_encode(pcm, sr, 24, 4096, 2 | 192, 8)
+    a = Engine(); b = Engine()
+    try:
+        meta = a.load_audio(data)
+        assert (meta["frames"], meta["channels"], meta["sample_rate"], meta["bits_per_sample"]) == (pcm.shape[0], 2, sr, 24)
+        b.upload_pcm((pcm.astype(np.float64) / (1 << 23)).astype(np.float32), sr, 2)
+        ra = hostlogic.process_audio(a, analyse_only=True)
+        rb = hostlogic.process_audio(b, analyse_only=True)
+        import ctypes as C
+        assert bytes(C.string_at(C.addressof(ra.input), C.sizeof(ra.input))) == bytes(C.string_at(C.addressof(rb.input), C.sizeof(rb.input)))
+    finally:
+        a.close(); b.close()
