@@ -196,6 +196,25 @@ def main():
         }
         if sat is not None:
             out["saturation"] = sat
+        if world == 1:
+            # the file formats either side of the path, outside the timed region: Pass-4 output -> .flac image on
+            # the GPU (with and without the host-side STREAMINFO MD5), and that image decoded again on the GPU by a second handle
+            enc = [eng.flac_encode(4, md5=False, return_info=True)[1] for _ in range(3)]
+            image, enc_md5 = eng.flac_encode(4, md5=True, return_info=True)
+            e3 = Engine(local_rank)
+            dec = [e3.load_audio(image) for _ in range(3)]
+            e3.close()
+            out["io_legs"] = {
+                "flac_encode": {"gpu_ms": round(min(i["gpu_ms"] for i in enc), 3), "total_ms": round(min(i["total_ms"] for i in enc), 3),
+                                "bytes": enc_md5["bytes"], "ratio_vs_s16": round(enc_md5["bytes"] / (2.0 * enc_md5["total_samples"]), 4),
+                                "frames": enc_md5["frames"], "md5_host_ms": round(enc_md5["md5_ms"], 1),
+                                "note": "jt_flac_encode(stage 4): analyse + scan + emit kernels, D2H of the image into pinned memory; "
+                                        "the MD5 is one dependent chain on one host core and is optional (JT_FLAC_MD5)"},
+                "flac_decode": {"gpu_ms": round(min(d["gpu_ms"] for d in dec), 3), "total_ms": round(min(d["total_ms"] for d in dec), 3),
+                                "frames": dec[0]["flac_frames"], "candidates": dec[0]["flac_candidates"],
+                                "note": "jt_load_audio of that image (44.1 kHz mono s16): H2D from pageable memory, find + parse + "
+                                        "decode + finish kernels, host chain walk"},
+            }
         if world == 1 and args.cpu_sample > 0:
             out["cpu_baseline"] = cpu_baseline(args.cpu_sample, sr)
         print(json.dumps(out))

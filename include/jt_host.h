@@ -180,6 +180,15 @@ typedef void (*jt_progress_fn)(void *user, const jt_progress_update *u);
 int jt_process_audio_cb(jt_ctx *h, const jt_host_config *base, int frame_samples, jt_progress_fn cb, void *user, jt_process_result *out);
 int jt_analyse_only(jt_ctx *h, const jt_host_config *base, int frame_samples, jt_process_result *out);   /* AnalyseOnlyDetailed (processor.go:29-69) */
 
+/* File in, file out — the reference's per-file entry point as the CLI calls it: ProcessAudio(ctx, inputPath, config, cb)
+ * (processor.go:78-330) reads inputPath through libavformat for every pass, writes a temp FLAC after Pass 2 and the final
+ * "<name>-LUFS-<n>-processed.flac" after Pass 4 (processor.go:379-388).  Here: read the file once, jt_load_audio (decode on
+ * the GPU), the four passes, jt_flac_encode(stage 4) and one write of the finished image.  flac_flags: JT_FLAC_MD5 or 0.
+ * output_path receives the written path (cap bytes).  io_ms: read, decode, encode, write (host wall clock).
+ * Errors: JT_E_INVAL when the input cannot be opened/read or the output cannot be written, otherwise as the calls above. */
+int jt_process_file(jt_ctx *h, const char *input_path, const jt_host_config *base, int frame_samples, int flac_flags,
+                    jt_progress_fn cb, void *user, jt_process_result *out, char *output_path, int cap, double io_ms[4]);
+
 /* ---- granular detector steps (the reference table-tests each of these: analyser_vad_test.go) ---- */
 int    jt_host_vad_detect(const jt_interval *iv, int64_t n, double noise_floor_seed, jt_measurements *out);      /* detectVoiceActivity :728 */
 void   jt_host_vad_split(const jt_interval *iv, int64_t n, double seed, double *otsu_raw, double *split, double *floor_, double *margin, int *tol);

@@ -8,6 +8,7 @@
 #include <algorithm>
 #include <cstdarg>
 #include <cstdlib>
+#include <cstdio>
 #include <functional>
 #include <chrono>
 #include <thread>
@@ -1238,4 +1239,53 @@ extern "C" double jt_host_vad_floored_fraction(const jt_interval *ivp, int64_t n
     double counted = 0, fl = 0;
     for (int64_t i = 0; i < n; ++i) { double l = ivp[i].momentary_lufs; counted++; if (std::isnan(l) || l <= vadLevelFloorDB) fl++; }
     return counted == 0 ? 0 : fl / counted;
+}
+
+// ---------------------------------------------------------------- file in, file out (processor.go:78-330)
+extern "C" int jt_process_file(jt_ctx *h, const char *input_path, const jt_host_config *base, int frame_samples, int flac_flags,
+                               jt_progress_fn cb, void *user, jt_process_result *out, char *output_path, int cap, double io_ms[4])
+{
+    if (!h || !input_path || !out) return JT_E_INVAL;
+    auto fail = [&](int code, const std::string &msg) { h->err = msg; return code; };
+    auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    double t = now();
+    std::vector<uint8_t> image;
+    {
+        FILE *f = fopen(input_path, "rb");
+        if (!f) return fail(JT_E_INVAL, std::string("failed to open input file: ") + input_path);
+        fseek(f, 0, SEEK_END); const long sz = ftell(f); fseek(f, 0, SEEK_SET);
+        if (sz <= 0) { fclose(f); return fail(JT_E_INVAL, std::string("empty input file: ") + input_path); }
+        image.resize((size_t)sz);
+        const size_t got = fread(image.data(), 1, (size_t)sz, f);
+        fclose(f);
+        if (got != (size_t)sz) return fail(JT_E_INVAL, std::string("short read on input file: ") + input_path);
+    }
+    if (io_ms) io_ms[0] = now() - t;
+    t = now();
+    jt_audio_meta meta;
+    int rc = jt_load_audio(h, image.data(), (int64_t)image.size(), &meta);
+    if (rc != JT_OK) return rc;
+    std::vector<uint8_t>().swap(image);
+    if (io_ms) io_ms[1] = now() - t;
+    rc = jt_process_audio_cb(h, base, frame_samples, cb, user, out);
+    if (rc != JT_OK) return rc;
+    t = now();
+    const uint8_t *data = nullptr; int64_t len = 0; jt_flac_info info;
+    rc = jt_flac_encode(h, 4, flac_flags, &data, &len, &info);
+    if (rc != JT_OK) return rc;
+    if (io_ms) io_ms[2] = now() - t;
+    t = now();
+    char path[4096];
+    if (jt_host_output_path(input_path, jt_host_lufs_filename_value(out->output_lufs), path, (int)sizeof path) < 0)
+        return fail(JT_E_INVAL, "output path too long");
+    {
+        FILE *f = fopen(path, "wb");
+        if (!f) return fail(JT_E_INVAL, std::string("failed to open output file: ") + path);
+        const size_t put = fwrite(data, 1, (size_t)len, f);
+        const int cl = fclose(f);
+        if (put != (size_t)len || cl != 0) { remove(path); return fail(JT_E_INVAL, std::string("failed to write output file: ") + path); }
+    }
+    if (io_ms) io_ms[3] = now() - t;
+    if (output_path && cap > 0) { strncpy(output_path, path, (size_t)cap - 1); output_path[cap - 1] = 0; }
+    return JT_OK;
 }

@@ -112,7 +112,7 @@ HOST_SYMBOLS = ["jt_host_build_intervals", "jt_host_detect", "jt_host_finish_mea
                 "jt_process_audio", "jt_analyse_only", "jt_host_vad_detect", "jt_host_vad_split", "jt_host_vad_speech_runs",
                 "jt_host_vad_gap_tolerance", "jt_host_vad_gate_stats", "jt_host_vad_noise_seed",
                 "jt_host_vad_pick_low_cluster", "jt_host_vad_floored_fraction", "jt_host_sizeof",
-                "jt_host_lufs_filename_value", "jt_host_output_path", "jt_process_audio_cb"]
+                "jt_host_lufs_filename_value", "jt_host_output_path", "jt_process_audio_cb", "jt_process_file"]
 
 
 def lib():
@@ -199,6 +199,18 @@ def process_audio_with_progress(engine, on_update, base=None, frame_samples=4096
     if rc != 0:
         raise L.JtError(rc, l.jt_last_error(engine.h).decode())
     return res
+
+
+def process_file(engine, input_path, base=None, frame_samples=4096, md5=True):
+    """jt_process_file: file in (FLAC / WAV), "<name>-LUFS-<n>-processed.flac" out.  Returns (result, output path, io_ms)."""
+    l = lib()
+    base = base or default_config()
+    res = ProcessResult(); out = C.create_string_buffer(4096); io = (C.c_double * 4)()
+    rc = l.jt_process_file(engine.h, str(input_path).encode(), C.byref(base), C.c_int(frame_samples), C.c_int(1 if md5 else 0),
+                           None, None, C.byref(res), out, C.c_int(4096), io)
+    if rc != 0:
+        raise L.JtError(rc, l.jt_last_error(engine.h).decode())
+    return res, out.value.decode(), list(io)
 
 
 def output_path(input_path, lufs_value):

@@ -280,3 +280,42 @@ def test_load_audio_feeds_the_passes_like_upload_pcm(oracle):
         assert bytes(C.string_at(C.addressof(ra.input), C.sizeof(ra.input))) == bytes(C.string_at(C.addressof(rb.input), C.sizeof(rb.input)))
     finally:
         a.close(); b.close()
+
+
+def test_process_file_flac_and_wav_in_flac_out(tmp_path, oracle):
+    """jt_process_file == ProcessAudio(inputPath): the same result for a FLAC and a WAV carrying the same samples, output named
+    <name>-LUFS-<n>-processed.flac (processor.go:379-388), 44.1 kHz / 16 bit / mono (filters.go:20), decodable, MD5 right, and
+    equal to the in-memory path (upload_pcm + process_audio + download_s16)."""
+    import struct
+    from jivetalking_amd import hostlogic
+    sr = 48000
+    x = np.asarray(synth.speech_like(15.0, sr, seed=31), np.float64)
+    pcm = np.clip(np.rint(x * 32768), -32768, 32767).astype(np.int16)
+    flac_in = tmp_path / "take one.flac"
+    flac_in.write_bytes(oracle.flac_encode(pcm.astype(np.int32), sr, 16, 4096, 2, 8))
+    wav_in = tmp_path / "take two.wav"
+    wav_in.write_bytes(_wav(1, 16, 1, sr, pcm.astype("<i2").tobytes(), extra_chunks=False))
+    e = Engine()
+    try:
+        e.upload_pcm(pcm.astype(np.float32) / 32768.0, sr, 1)
+        ref = hostlogic.process_audio(e)
+        want = e.download_s16(4)
+        outs = []
+        for src in (flac_in, wav_in):
+            res, out_path, io_ms = hostlogic.process_file(e, src)
+            n = int(round(abs(res.output_lufs)))
+            assert out_path == str(tmp_path / f"{src.stem}-LUFS-{n}-processed.flac")
+            data = open(out_path, "rb").read()
+            rc, dec, oi = oracle.flac_decode(data)
+            assert rc == 0 and (oi.sample_rate, oi.channels, oi.bps) == (44100, 1, 16)
+            assert bytes(oi.md5_stored) == bytes(oi.md5_decoded)
+            assert np.array_equal(dec[:, 0], want.astype(np.int32))
+            assert res.output_lufs == ref.output_lufs and res.output_tp_db == ref.output_tp_db
+            outs.append(data)
+            assert all(v >= 0 for v in io_ms)
+        assert outs[0] == outs[1]
+        with pytest.raises(L.JtError) as ei:
+            hostlogic.process_file(e, tmp_path / "missing.flac")
+        assert ei.value.code == L.JT_E_INVAL
+    finally:
+        e.close()
