@@ -908,7 +908,7 @@ void decode_flac(jt_ctx *h, const uint8_t *file, int64_t len, int64_t start, boo
     JT_REQUIRE(pos < len, JT_E_INVAL, "flac: no audio frames");
 
     // file image on the device, zero padded so header probes and bit-reader refills never leave the allocation
-    const size_t padded = ((size_t)len + 64 + 3) & ~(size_t)3;
+    const size_t padded = ((size_t)len + 1024 + 15) & ~(size_t)15;      // the bit readers fetch up to 64 dwords ahead
     h->in_file.ensure(padded);
     JT_HIP(hipMemsetAsync(h->in_file.p + ((size_t)len & ~(size_t)3), 0, padded - ((size_t)len & ~(size_t)3), h->stream));
     JT_HIP(hipMemcpyAsync(h->in_file.p, file, (size_t)len, hipMemcpyHostToDevice, h->stream));

@@ -90,17 +90,39 @@ struct BitReader {
     long long used;             // bits consumed since init
     long long limit;            // bits available from the start position to the end of the file
     bool err;
-    __device__ __forceinline__ void init(const uint8_t *base, long long bitpos, long long total_bits)
+    // lane-private window of the stream in LDS: ring[(dword index & 63) * 64 + lane] holds dwords [.., fill).  Lanes sit in different
+    // frames, so a refill straight from memory would make the whole wave wait for one lane's miss at nearly every sample;
+    // topup() brings 64 bytes per lane at wave-uniform checkpoints instead (all loads in flight together, one wait).
+    unsigned *ring; int lane; long long fill;
+    __device__ __forceinline__ void init(const uint8_t *base, long long bitpos, long long total_bits, unsigned *ring_, int lane_)
     {
         w = reinterpret_cast<const unsigned *>(base);
+        ring = ring_; lane = lane_;
         next = bitpos >> 5; acc = 0; cnt = 0; used = 0; limit = total_bits - bitpos; err = false;
+        fill = next & ~3ll;
+        topup(); topup(); topup();
         refill();
         const int skip = (int)(bitpos & 31);
         acc <<= skip; cnt -= skip;
     }
+    __device__ __forceinline__ void topup()
+    {
+        if (fill - next < 40) {
+            const uint4 *src = reinterpret_cast<const uint4 *>(w + fill);
+            const uint4 a = src[0], b = src[1], c = src[2], e = src[3];
+            const unsigned v[16] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, c.x, c.y, c.z, c.w, e.x, e.y, e.z, e.w};
+#pragma unroll
+            for (int j = 0; j < 16; j++) ring[(int)((fill + j) & 63) * 64 + lane] = v[j];
+            fill += 16;
+        }
+    }
     __device__ __forceinline__ void refill()
     {
-        if (cnt <= 32) { acc |= (unsigned long long)__builtin_bswap32(w[next++]) << (32 - cnt); cnt += 32; }
+        if (cnt <= 32) {
+            const unsigned wv = next < fill ? ring[(int)(next & 63) * 64 + lane] : w[next];
+            next++;
+            acc |= (unsigned long long)__builtin_bswap32(wv) << (32 - cnt); cnt += 32;
+        }
     }
     __device__ __forceinline__ unsigned u(int n)                  // n <= 32
     {
@@ -137,7 +159,7 @@ struct BitReader {
 // Per-lane decoding state of one subframe; step() yields the next sample (STORE) or just consumes its bits (!STORE).
 struct SubState {
     int type;            // 0 constant, 1 verbatim, 2 predicted (fixed or lpc)
-    int order, shift, bps, wasted, blocksize;
+    int order, shift, bps, wasted, blocksize, prec;
     int k, esc_width, part_left, psize, pbits;
     bool escaped;
     int constv;
@@ -147,7 +169,7 @@ struct SubState {
 template <bool STORE>
 __device__ __forceinline__ void sub_begin(BitReader &br, SubState &st, int blocksize, int bps, int *hist, int *coef, int lane)
 {
-    st.bad = false; st.blocksize = blocksize; st.order = 0; st.shift = 0; st.wasted = 0; st.constv = 0; st.type = 1;
+    st.bad = false; st.blocksize = blocksize; st.order = 0; st.shift = 0; st.prec = 0; st.wasted = 0; st.constv = 0; st.type = 1;
     st.k = 0; st.esc_width = 0; st.part_left = 0; st.psize = 0; st.pbits = 4; st.escaped = false;
     if (br.u(1)) st.bad = true;
     const int t = (int)br.u(6);
@@ -165,10 +187,12 @@ __device__ __forceinline__ void sub_begin(BitReader &br, SubState &st, int block
         if (lpc) {
             const int prec = (int)br.u(4) + 1;
             if (prec == 16) st.bad = true;
+            st.prec = prec;
             st.shift = br.s(5);
             if (st.shift < 0) { st.bad = true; st.shift = 0; }
             for (int j = 0; j < st.order; j++) { const int c = br.s(prec); if (STORE) coef[j * 64 + lane] = c; }
         } else if (STORE) {
+            st.prec = 4;
             // fixed predictors as LPC taps with shift 0: 1 | 2,-1 | 3,-3,1 | 4,-6,4,-1
             const int o = st.order;
             if (o >= 1) coef[0 * 64 + lane] = o;
@@ -187,13 +211,9 @@ __device__ __forceinline__ void sub_begin(BitReader &br, SubState &st, int block
     } else st.bad = true;
 }
 
-// sample index i (0-based in the block); returns the decoded sample (before the wasted-bits shift) when STORE
-template <bool STORE>
-__device__ __forceinline__ int sub_step(BitReader &br, SubState &st, int i, int *hist, const int *coef, int lane)
+// next residual of a predicted subframe (partition bookkeeping, Rice or escaped)
+__device__ __forceinline__ int sub_residual(BitReader &br, SubState &st)
 {
-    if (st.type == 0) return st.constv;
-    if (st.type == 1) return br.s(st.bps);
-    if (i < st.order) return STORE ? hist[(i & 31) * 64 + lane] : 0;
     for (int guard = 0; st.part_left <= 0; guard++) {
         // a new partition starts here (part_left is -order before the first one; a partition may be empty)
         const int k = (int)br.u(st.pbits);
@@ -204,13 +224,21 @@ __device__ __forceinline__ int sub_step(BitReader &br, SubState &st, int i, int 
         if (st.psize <= 0 || guard > 64) { st.bad = true; st.part_left = 1; }
     }
     st.part_left--;
-    int r;
-    if (st.escaped) r = br.s(st.esc_width);
-    else {
-        const unsigned q = br.unary();
-        const unsigned uu = (q << st.k) | br.u(st.k);
-        r = (int)(uu >> 1) ^ -(int)(uu & 1);
-    }
+    if (st.escaped) return br.s(st.esc_width);
+    const unsigned q = br.unary();
+    const unsigned uu = (q << st.k) | br.u(st.k);
+    return (int)(uu >> 1) ^ -(int)(uu & 1);
+}
+
+// sample index i (0-based in the block); returns the decoded sample (before the wasted-bits shift) when STORE.
+// General path: history and taps in LDS (any order up to 32), 64-bit accumulation.
+template <bool STORE>
+__device__ __forceinline__ int sub_step(BitReader &br, SubState &st, int i, int *hist, const int *coef, int lane)
+{
+    if (st.type == 0) return st.constv;
+    if (st.type == 1) return br.s(st.bps);
+    if (i < st.order) return STORE ? hist[(i & 31) * 64 + lane] : 0;
+    const int r = sub_residual(br, st);
     if (!STORE) return 0;
     long long acc = 0;
     for (int j = 0; j < st.order; j++) acc += (long long)coef[j * 64 + lane] * (long long)hist[((i - 1 - j) & 31) * 64 + lane];
@@ -224,6 +252,7 @@ __global__ __launch_bounds__(64) void k_flac_parse(const uint8_t *__restrict__ d
                                                    int ncand, Parsed *__restrict__ out)
 {
     __shared__ unsigned crc_tab[256];
+    __shared__ unsigned ring[64 * 64];
     for (int t = threadIdx.x; t < 256; t += 64) {
         unsigned c = (unsigned)t << 8;
         for (int k = 0; k < 8; k++) c = (c & 0x8000) ? (c << 1) ^ 0x8005 : (c << 1);
@@ -237,7 +266,7 @@ __global__ __launch_bounds__(64) void k_flac_parse(const uint8_t *__restrict__ d
     for (int ch = 0; ch < 8; ch++) pr.sub_bit[ch] = 0;
     BitReader br;
     const long long start_bit = (c.pos + c.hdr_len) * 8;
-    br.init(d, start_bit, si.len * 8);
+    br.init(d, start_bit, si.len * 8, ring, threadIdx.x);
     bool bad = false;
     for (int ch = 0; ch < si.channels && !bad; ch++) {
         const int side = (c.ch_assign == 8 && ch == 1) || (c.ch_assign == 9 && ch == 0) || (c.ch_assign == 10 && ch == 1);
@@ -248,9 +277,15 @@ __global__ __launch_bounds__(64) void k_flac_parse(const uint8_t *__restrict__ d
         if (st.type == 1) {
             // verbatim: skip blocksize * bps bits without touching them one by one
             long long skip = (long long)c.blocksize * st.bps;
-            while (skip > 0 && !br.err) { const int n = skip > 32 ? 32 : (int)skip; br.u(n); skip -= n; if (br.used > br.limit) br.err = true; }
+            for (int it = 0; skip > 0 && !br.err; it++) {
+                if ((it & 7) == 0) br.topup();
+                const int n = skip > 32 ? 32 : (int)skip; br.u(n); skip -= n; if (br.used > br.limit) br.err = true;
+            }
         } else if (st.type == 2) {
-            for (int i = st.order; i < c.blocksize && !st.bad && !br.err; i++) sub_step<false>(br, st, i, nullptr, nullptr, 0);
+            for (int i = st.order; i < c.blocksize && !st.bad && !br.err; i++) {
+                if ((i & 15) == 0) br.topup();
+                sub_residual(br, st);
+            }
         }
         bad = st.bad || br.err || br.used > br.limit;
     }
@@ -276,19 +311,21 @@ __global__ __launch_bounds__(64) void k_flac_decode(const uint8_t *__restrict__ 
 {
     __shared__ int tile[64 * ROW];
     __shared__ int hist[32 * 64], coef[32 * 64];
+    __shared__ unsigned ring[64 * 64];
     __shared__ long long rowdst[64];
     __shared__ int rowbs[64];
+    constexpr int NT = 12;                                              // taps held in registers (libFLAC's subset maximum)
     const int lane = threadIdx.x;
     const long long sidx = (long long)blockIdx.x * 64 + lane;
     const bool live = sidx < nsub;
     const long long f = live ? sidx / si.channels : 0;
     const int ch = live ? (int)(sidx % si.channels) : 0;
     Frame fr; fr.blocksize = 0; fr.ch_assign = 0; fr.out_offset = 0; fr.pos = 0;
-    BitReader br; SubState st; st.type = 0; st.constv = 0; st.wasted = 0; st.bad = false; st.order = 0;
+    BitReader br; SubState st; st.type = 0; st.constv = 0; st.wasted = 0; st.bad = false; st.order = 0; st.prec = 0; st.bps = 1; st.shift = 0;
+    br.init(d, live ? frames[f].sub_bit[ch] : si.audio_offset * 8, si.len * 8, ring, lane);
     if (live) {
         fr = frames[f];
         const int side = (fr.ch_assign == 8 && ch == 1) || (fr.ch_assign == 9 && ch == 0) || (fr.ch_assign == 10 && ch == 1);
-        br.init(d, fr.sub_bit[ch], si.len * 8);
         sub_begin<true>(br, st, fr.blocksize, si.bps + side, hist, coef, lane);
     }
     const int bs = live ? fr.blocksize : 0;
@@ -297,13 +334,50 @@ __global__ __launch_bounds__(64) void k_flac_decode(const uint8_t *__restrict__ 
     int maxbs = bs;
 #pragma unroll
     for (int m = 1; m < 64; m <<= 1) { const int o = __shfl_xor(maxbs, m); maxbs = o > maxbs ? o : maxbs; }
+    // wave-uniform choice of the predictor datapath (as libFLAC's decoder: 32-bit when bps + precision + log2(order) <= 32)
+    const bool pred = live && st.type == 2 && st.order > 0;
+    const bool in_regs = !__any(pred && st.order > NT);
+    const bool narrow = !__any(pred && st.bps + st.prec + (31 - __clz(st.order > 0 ? st.order : 1)) > 32) && si.bps <= 22;
+    int cr[NT], hr[NT];
+#pragma unroll
+    for (int j = 0; j < NT; j++) { cr[j] = (pred && j < st.order) ? coef[j * 64 + lane] : 0; hr[j] = 0; }
     __syncthreads();
     for (int i0 = 0; i0 < maxbs; i0 += 64) {
         if (i0 < bs) {
             const int n = bs - i0 < 64 ? bs - i0 : 64;
-            for (int c = 0; c < n; c++) {
-                const int v = sub_step<true>(br, st, i0 + c, hist, coef, lane);
-                tile[lane * ROW + c] = (int)((unsigned)v << st.wasted);
+            if (in_regs) {
+                for (int c = 0; c < n; c++) {
+                    if ((c & 15) == 0) br.topup();
+                    const int i = i0 + c;
+                    int v;
+                    if (st.type == 0) v = st.constv;
+                    else if (st.type == 1) v = br.s(st.bps);
+                    else if (i < st.order) v = hist[(i & 31) * 64 + lane];
+                    else {
+                        const int r = sub_residual(br, st);
+                        if (narrow) {
+                            int a = 0;
+#pragma unroll
+                            for (int j = 0; j < NT; j++) a += __mul24(cr[j], hr[j]);
+                            v = r + (a >> st.shift);
+                        } else {
+                            long long a = 0;
+#pragma unroll
+                            for (int j = 0; j < NT; j++) a += (long long)cr[j] * (long long)hr[j];
+                            v = r + (int)(a >> st.shift);
+                        }
+                    }
+#pragma unroll
+                    for (int j = NT - 1; j > 0; j--) hr[j] = hr[j - 1];
+                    hr[0] = v;
+                    tile[lane * ROW + c] = (int)((unsigned)v << st.wasted);
+                }
+            } else {
+                for (int c = 0; c < n; c++) {
+                    if ((c & 15) == 0) br.topup();
+                    const int v = sub_step<true>(br, st, i0 + c, hist, coef, lane);
+                    tile[lane * ROW + c] = (int)((unsigned)v << st.wasted);
+                }
             }
         }
         __syncthreads();
