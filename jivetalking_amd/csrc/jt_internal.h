@@ -246,3 +246,17 @@ struct jt_ctx {
     jt_timers timers{};
     hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr, ev3 = nullptr;
 };
+
+// ---------------------------------------------------------------- C-ABI entry wrappers (jt_api.cpp, jt_io.cpp)
+#define JT_API_BEGIN(h) if (!(h)) return JT_E_INVAL; try { JT_HIP(hipSetDevice((h)->device));
+// On failure the streams are drained before returning: a pass may have queued kernels and copies into the pinned arena, and the
+// next call is allowed to resize or reuse both.
+inline void jt_drain(jt_ctx *h)
+{
+    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    for (int i = 0; i < 4; ++i) if (h->aux[i]) (void)hipStreamSynchronize(h->aux[i]);
+}
+#define JT_API_END(h) } catch (const JtError &e) { jt_drain(h); (h)->err = e.msg; return e.code; } \
+    catch (const std::exception &e) { jt_drain(h); (h)->err = e.what(); return JT_E_HIP; } return JT_OK;
+// input state shared by jt_upload_pcm / jt_attach_device_pcm / jt_load_audio: h->in_raw is set, derive the mono signal
+void jt_set_input_common(jt_ctx *h, int64_t frames, int sr, int ch);

@@ -186,80 +186,6 @@ __device__ inline float wave_prefix_max(float v)
     return v;
 }
 
-// Fused sliding-window peak + (min, count) reduction: the noise-floor measure without the G/P arrays in HBM.
-// A workgroup owns NF_TILE window starts; |x| of the tile (+ tc-1 halo) is scanned per 64-sample block in registers
-// (inclusive prefix / suffix maxima by wave shuffles) and parked in LDS; a window [s, s+tc) is then
-//   max( suffix-max of its head block from s,  max of the full blocks in between,  prefix-max of its tail block up to s+tc-1 ).
-// The in-between run has c0 or c0+1 blocks (c0 = (tc-1)/64 - 1), so one width-c0 running maximum over the block maxima serves all.
-// Maxima of floats are order-independent, so the result is identical to the sequential filter's.
-constexpr int NF_TILE = 6144;
-__global__ void __launch_bounds__(AS_T)
-k_as_nf_fused(const float *__restrict__ x, int64_t n, int tc, int64_t ntiles, AsNF *__restrict__ part)
-{
-    extern __shared__ float nf_smem[];
-    const int E = NF_TILE + tc - 1;
-    const int nb64 = (E + 63) >> 6;
-    float *sP = nf_smem, *sG = sP + nb64 * 64, *sBM = sG + nb64 * 64, *sR = sBM + nb64;
-    __shared__ AsNF sp[AS_T / 64];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int c0 = (tc - 1) / 64 - 1;
-    double nf = DBL_MAX; unsigned long long cnt = 0;
-    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        const int64_t S0 = tile * NF_TILE;
-        // 8 blocks per wave per round: all 16 loads are issued before the first scan so their HBM latency overlaps
-        for (int b0 = wave; b0 < nb64; b0 += 8 * (AS_T / 64)) {
-            float av[8], rv[8];
-#pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                const int b = b0 + q * (AS_T / 64);
-                const int64_t idx = S0 + (int64_t)b * 64 + lane, ridx = S0 + (int64_t)b * 64 + (63 - lane);
-                av[q] = (b < nb64 && idx < n) ? x[idx] : 0.f;
-                rv[q] = (b < nb64 && ridx < n) ? x[ridx] : 0.f;
-            }
-#pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                const int b = b0 + q * (AS_T / 64);
-                if (b < nb64) {
-                    // inclusive prefix maxima by DPP (no LDS traffic); the suffix maxima are the prefix maxima of the block
-                    // read in reversed lane order.  |x| >= 0, so 0 is the identity the out-of-row DPP lanes return.
-                    const float pm = wave_prefix_max(fabsf(av[q]));
-                    const float gm = wave_prefix_max(fabsf(rv[q]));
-                    sP[b * 64 + lane] = pm; sG[b * 64 + (63 - lane)] = gm;
-                    if (lane == 63) sBM[b] = pm;
-                }
-            }
-        }
-        __syncthreads();
-        for (int b = tid; b < nb64; b += AS_T) {
-            float m = 0.f;
-            for (int q = 0; q < c0 && b + q < nb64; ++q) m = fmaxf(m, sBM[b + q]);
-            sR[b] = m;
-        }
-        __syncthreads();
-        for (int k = tid; k < NF_TILE; k += AS_T) {
-            const int64_t i = S0 + k + tc - 1;
-            if (i >= n) break;
-            const int e = k + tc - 1, bs = k >> 6, be = e >> 6;
-            float m = fmaxf(sG[k], sP[e]);
-            m = fmaxf(m, sR[bs + 1]);
-            if (be - bs - 1 > c0) m = fmaxf(m, sBM[be - 1]);
-            const double lp = (double)m;
-            if (lp < nf) { nf = lp; cnt = 1; } else if (lp == nf) cnt++;
-        }
-        __syncthreads();
-    }
-    for (int o = 32; o > 0; o >>= 1) {
-        double onf = __shfl_down(nf, o, 64); unsigned long long oc = __shfl_down(cnt, o, 64);
-        if (onf < nf) { nf = onf; cnt = oc; } else if (onf == nf) cnt += oc;
-    }
-    if (lane == 0) sp[wave] = AsNF{nf, cnt};
-    __syncthreads();
-    if (tid == 0) {
-        AsNF a = sp[0];
-        for (int w = 1; w < AS_T / 64; ++w) { if (sp[w].nf < a.nf) a = sp[w]; else if (sp[w].nf == a.nf) a.cnt += sp[w].cnt; }
-        part[blockIdx.x] = a;
-    }
-}
 
 // Noise floor without LDS: sliding-window peak from registers.  Window [s, s+tc) with s = 64 bs + l (lane l) ends at
 // e = 64 (bs + q) + l + r, q = (tc-1)/64, r = (tc-1)%64.  Its maximum is
