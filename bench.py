@@ -168,9 +168,10 @@ def main():
         try:
             pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))["kernels"]
             for r_ in (roof, nlm_roof):
-                if r_ and r_["kernel"] in pmc:
-                    k_ = pmc[r_["kernel"]]
-                    r_["traffic"] = int((2 * k_["FETCH_SIZE_KB_max_call"] + k_["WRITE_SIZE_KB_max_call"]) * 1024)
+                # a kernel launched as several template instances per step (adeclick's three capacity levels) is summed
+                ks = [v for k, v in pmc.items() if k == r_["kernel"] or k.startswith(r_["kernel"] + "<")] if r_ else []
+                if ks:
+                    r_["traffic"] = int(sum(2 * k_["FETCH_SIZE_KB_max_call"] + k_["WRITE_SIZE_KB_max_call"] for k_ in ks) * 1024)
                     r_["traffic_source"] = "profiles/r01_pmc_traffic.json (PMC pass of this command, not collected live)"
         except (OSError, KeyError, ValueError):
             pass

@@ -116,33 +116,16 @@ k_adeclick(const double *__restrict__ in, double *__restrict__ out, int64_t n, D
         double acv = 0.0;
         auto autocorr_range = [&](int ja, int jb) {                     // terms j in [ja, jb) of this lane's lag
             if (lane > AR || ja >= jb) return;
-            // 8 terms per block; the next block's 16 LDS reads are in flight while this block's adds (the sequential chain) retire
+            // 16 terms per block: all 32 LDS reads are issued, then the sequential chain consumes them (the other resident waves
+            // cover the latency; a hand-rolled double buffer only made the compiler shuffle 32 register pairs per block)
             const double *sj = S - sb;
             int j = ja;
-            double x0[8], y0[8], x1[8], y1[8];
-            const int nb = (jb - ja) / 8;
-            if (nb > 0) {
+            for (; j + 16 <= jb; j += 16) {
+                double xv[16], yv[16];
 #pragma unroll
-                for (int u = 0; u < 8; ++u) { x0[u] = sj[j + u]; y0[u] = sj[j + u - lane]; }
-            }
-            int blk8 = 0;
-            for (; blk8 + 1 < nb; blk8 += 2) {
+                for (int u = 0; u < 16; ++u) { xv[u] = sj[j + u]; yv[u] = sj[j + u - lane]; }
 #pragma unroll
-                for (int u = 0; u < 8; ++u) { x1[u] = sj[j + 8 + u]; y1[u] = sj[j + 8 + u - lane]; }
-#pragma unroll
-                for (int u = 0; u < 8; ++u) acv = __dadd_rn(acv, __dmul_rn(x0[u], y0[u]));
-                if (blk8 + 2 < nb) {
-#pragma unroll
-                    for (int u = 0; u < 8; ++u) { x0[u] = sj[j + 16 + u]; y0[u] = sj[j + 16 + u - lane]; }
-                }
-#pragma unroll
-                for (int u = 0; u < 8; ++u) acv = __dadd_rn(acv, __dmul_rn(x1[u], y1[u]));
-                j += 16;
-            }
-            if (blk8 < nb) {
-#pragma unroll
-                for (int u = 0; u < 8; ++u) acv = __dadd_rn(acv, __dmul_rn(x0[u], y0[u]));
-                j += 8;
+                for (int u = 0; u < 16; ++u) acv = __dadd_rn(acv, __dmul_rn(xv[u], yv[u]));
             }
             for (; j < jb; ++j) acv = __dadd_rn(acv, __dmul_rn(sj[j], sj[j - lane]));
         };
@@ -168,7 +151,14 @@ k_adeclick(const double *__restrict__ in, double *__restrict__ out, int64_t n, D
                 const double arev = __shfl(areg, lane < i ? i - lane - 1 : 0, 64);
                 const double prod = lane < i ? __dmul_rn(areg, rrev) : 0.0;
                 double eps = 0.0;
-                for (int j = 0; j < i; ++j) eps = __dadd_rn(eps, dk_readlane(prod, j));
+                {
+                    int j = 0;
+                    for (; j + 4 <= i; j += 4) {
+                        eps = __dadd_rn(eps, dk_readlane(prod, j)); eps = __dadd_rn(eps, dk_readlane(prod, j + 1));
+                        eps = __dadd_rn(eps, dk_readlane(prod, j + 2)); eps = __dadd_rn(eps, dk_readlane(prod, j + 3));
+                    }
+                    for (; j < i; ++j) eps = __dadd_rn(eps, dk_readlane(prod, j));
+                }
                 eps = __dadd_rn(eps, rr[i + 1]);
                 const double ki = -eps / alpha;
                 alpha = __dmul_rn(alpha, __dsub_rn(1.0, __dmul_rn(ki, ki)));
@@ -216,24 +206,39 @@ k_adeclick(const double *__restrict__ in, double *__restrict__ out, int64_t n, D
             else detect_range(AR, W);
             // ---- 5. burst fusion: the gap between two consecutive flagged samples p < q is filled when 1 < q-p <= nburst (the
             //         sequential loop only ever compares the detector's own flags); 6. borders cleared, index list in order
-            for (int wd = 0; wd < nword; ++wd) {
-                const int j = wd * 64 + lane;
-                bool fl = false;
-                if (j < W) {
-                    fl = obit(j);
-                    if (!fl && P.nburst > 1) {
-                        int p = -1, q = -1;
-                        for (int t = 1; t < P.nburst && j - t >= 0; ++t) if (obit(j - t)) { p = j - t; break; }
-                        for (int t = 1; t < P.nburst && j + t < W; ++t) if (obit(j + t)) { q = j + t; break; }
-                        fl = p >= 0 && q >= 0 && q - p <= P.nburst;
-                    }
-                    fl = fl && j >= AR && j < W - AR;
+            // bit-parallel, one 64-sample word per lane: sample j is filled when flags sit at j - d1 and j + d2 with d1, d2 >= 1 and
+            // d1 + d2 <= nburst (the nearest pair either side is the tightest one, so this is the same test)
+            for (int wd0 = 0; wd0 < nword; wd0 += 64) {
+                const int wd = wd0 + lane;
+                const bool in = wd < nword;
+                const unsigned long long cur = in ? obits[wd] : 0ull;
+                const unsigned long long prv = (in && wd > 0) ? obits[wd - 1] : 0ull;
+                const unsigned long long nxt = (wd + 1 < nword) ? obits[wd + 1] : 0ull;
+                unsigned long long fused = cur;
+                const int nb = P.nburst < 64 ? P.nburst : 64;
+                for (int d1 = 1; d1 < nb; ++d1) {
+                    const unsigned long long below = (cur << d1) | (prv >> (64 - d1));            // bit j = flag[j - d1]
+                    unsigned long long above = 0ull;
+                    for (int d2 = 1; d1 + d2 <= nb; ++d2) above |= (cur >> d2) | (nxt << (64 - d2));   // bit j = flag[j + d2]
+                    fused |= below & above;
                 }
-                const unsigned long long bal = __ballot(fl);
-                if (lane == 0) fbits[wd] = bal;
-                const int slot = F + __popcll(bal & ((1ull << lane) - 1ull));
-                if (fl && slot < FCAP) index[slot] = (unsigned short)j;
-                F += __popcll(bal);
+                // borders: only samples AR <= j < W - AR are repaired
+                const int lo = AR - wd * 64, hi = (W - AR) - wd * 64;                                  // keep bits [lo, hi)
+                const unsigned long long mlo = lo <= 0 ? ~0ull : (lo >= 64 ? 0ull : (~0ull << lo));
+                const unsigned long long mhi = hi >= 64 ? ~0ull : (hi <= 0 ? 0ull : ((1ull << hi) - 1ull));
+                unsigned long long fb = in ? (fused & mlo & mhi) : 0ull;
+                if (in) fbits[wd] = fb;
+                const int cnt = __popcll(fb);
+                int incl = cnt;
+#pragma unroll
+                for (int dd = 1; dd < 64; dd <<= 1) { const int o = __shfl_up(incl, dd, 64); incl += lane >= dd ? o : 0; }
+                int slot = F + incl - cnt;
+                while (fb) {
+                    const int bpos = __ffsll((long long)fb) - 1;
+                    if (slot < FCAP) index[slot] = (unsigned short)(wd * 64 + bpos);
+                    ++slot; fb &= fb - 1ull;
+                }
+                F += __shfl(incl, 63, 64);
             }
             to_heavy = F > FCAP;
             if (!to_heavy) {
@@ -263,8 +268,15 @@ k_adeclick(const double *__restrict__ in, double *__restrict__ out, int64_t n, D
                 double value = 0.0;
                 for (int j = lane; j <= AR; ++j) value = __dadd_rn(value, __dmul_rn(ac[j], ac[j - lane]));
                 aux[lane] = __dmul_rn(value, 1.0);
-            }
+            } else if (lane == AR + 1) aux[lane] = 0.0;      // entries beyond the band (LDL^T ring fill)
             // ---- 8. right-hand side: vector[e] = -sum_{j=-AR..AR, index[e]-j not flagged} src[index[e]-j] * aux[|j|]
+            // The flagged samples (the unknowns) are zeroed in the LDS copy first: their terms then contribute x - (+-0), which is
+            // exact because the running value is never -0 (it starts at +0 and x - x rounds to +0), so the inner loop carries no
+            // flag test at all.  Nothing reads the samples from LDS after this stage (the output copy reads the input stream).
+            auto zero_flagged = [&]() {
+                const int nb = HALF ? LB : W;
+                for (int e = lane; e < F; e += 64) { const int o = (int)index[e] - sb; if (o >= 0 && o < nb) sbuf[o] = 0.0; }
+            };
             auto rhs_range = [&](int ea, int eb) {                     // entries [ea, eb) against the buffer currently loaded
                 const double *sj = S - sb;
                 for (int e0 = ea; e0 < eb; e0 += 128) {
@@ -272,21 +284,23 @@ k_adeclick(const double *__restrict__ in, double *__restrict__ out, int64_t n, D
 #pragma unroll
                     for (int q = 0; q < 2; ++q) { const int e = e0 + 64 * q + lane; ie[q] = index[e < eb ? e : eb - 1]; val[q] = 0.0; }
                     // terms j = -AR .. AR in order; 8 at a time: the reads are issued before the chain consumes them
-                    for (int j0 = -AR; j0 <= AR; j0 += 8) {
+                    int j0 = -AR;
+                    for (; j0 + 7 <= AR; j0 += 8) {
                         double tv[2][8];
 #pragma unroll
                         for (int u = 0; u < 8; ++u) {
                             const int j = j0 + u;
-                            const int jj = j <= AR ? j : AR;                     // clamp the tail batch (its extra terms are dropped below)
-                            const double ax = aux[jj < 0 ? -jj : jj];
+                            const double ax = aux[j < 0 ? -j : j];
 #pragma unroll
-                            for (int q = 0; q < 2; ++q) {
-                                const int pos = ie[q] - jj;
-                                tv[q][u] = (fbit(pos) || j > AR) ? 0.0 : __dmul_rn(sj[pos], ax);   // flagged samples are the unknowns: x - 0 is exact
-                            }
+                            for (int q = 0; q < 2; ++q) tv[q][u] = __dmul_rn(sj[ie[q] - j], ax);
                         }
 #pragma unroll
                         for (int u = 0; u < 8; ++u) { val[0] = __dsub_rn(val[0], tv[0][u]); val[1] = __dsub_rn(val[1], tv[1][u]); }
+                    }
+                    for (; j0 <= AR; ++j0) {
+                        const double ax = aux[j0 < 0 ? -j0 : j0];
+                        val[0] = __dsub_rn(val[0], __dmul_rn(sj[ie[0] - j0], ax));
+                        val[1] = __dsub_rn(val[1], __dmul_rn(sj[ie[1] - j0], ax));
                     }
 #pragma unroll
                     for (int q = 0; q < 2; ++q) { const int e = e0 + 64 * q + lane; if (e < eb) gV[e] = val[q]; }
@@ -296,9 +310,10 @@ k_adeclick(const double *__restrict__ in, double *__restrict__ out, int64_t n, D
                 // entries whose +-AR neighbourhood lies inside buffer A (currently loaded), then the rest against buffer B
                 int ea = 0;
                 for (int e0 = 0; e0 < F; e0 += 64) { const int e = e0 + lane; ea += __popcll(__ballot(e < F && (int)index[e] + AR < LB)); }
+                zero_flagged();
                 rhs_range(0, ea);
-                if (ea < F) { load_buf(SB_B); rhs_range(ea, F); }
-            } else rhs_range(0, F);
+                if (ea < F) { load_buf(SB_B); zero_flagged(); rhs_range(ea, F); }
+            } else { zero_flagged(); rhs_range(0, F); }
             __threadfence();
             DK_MARK(4)
             // ---- 9. LDL^T (cholesky_decomposition) right-looking inside the band, forward substitution fused.
@@ -317,27 +332,38 @@ k_adeclick(const double *__restrict__ in, double *__restrict__ out, int64_t n, D
                 if (lane < nr) ywin[lane] = dk_ld(&gV[lane]);
             }
             int vbase = BS; double vreg = (vbase + lane < F) ? dk_ld(&gV[vbase + lane]) : 0.0;      // right-hand sides of the rows about to enter
+            // Packed factor stream in global scratch: per pivot k the bw multipliers of its column followed by y_k / d_k.
+            size_t goff = 0;
+            // The loop is issue-bound, so it is written for instruction count: every LDS operand is fetched unconditionally (rows
+            // outside the band read values that are never used), the ring positions are carried instead of recomputed with a
+            // division by BS, one f64 division serves the multipliers and y/d, and the row that enters the ring and its right-hand
+            // side go out in one store.
+            int ks = -1;                                       // k % BS
+            int rs = 1 + lane; rs -= rs >= BS ? BS : 0;        // (k + 1 + lane) % BS: ring row of this lane's band row
+            int ra = 1 + a0, rb = 1 + b0;                      // ring row / column of this lane's trailing pair (a0, b0 <= 10)
             for (int k = 0; k < F; ++k) {
-                const int ks = k % BS;
+                ks = ks + 1 == BS ? 0 : ks + 1;
                 const int bw = bwv[k];
                 const double d = blk[ks * BS + ks];
-                if (d == 0.0) { ok = false; break; }
-                const int rs = (k + 1 + lane) % BS;                // LDS row of this lane's band row
-                double l = 0.0;
-                if (lane < bw) l = blk[rs * BS + ks] / d;
-                if (lane < MAXAR) gL[(size_t)k * MAXAR + lane] = l;
                 const double yk = ywin[ks];
-                if (lane == 0) { gD[k] = d; gY[k] = yk / d; }      // y/d is what the back substitution starts every row from
+                const double colv = blk[rs * BS + ks];
+                const double yrow = ywin[rs];
+                double *ep = &blk[ra * BS + rb];
+                const double eold = *ep;
+                const int idx_i = index[k + 1 + lane];             // only lanes < BS use it (then k + 1 + lane <= k + BS < F)
+                if (d == 0.0) { ok = false; break; }
+                const double qv = (lane == bw ? yk : colv) / d;
+                const double l = lane < bw ? qv : 0.0;
+                if (lane <= bw) gL[goff + lane] = qv;
+                goff += (size_t)bw + 1;
                 // forward substitution (k ascending = FFmpeg's j-ascending order for every row)
-                if (lane < bw) ywin[rs] = __dsub_rn(ywin[rs], __dmul_rn(l, yk));
+                if (lane < bw) ywin[rs] = __dsub_rn(yrow, __dmul_rn(l, yk));
                 // trailing update: entry (k+1+a, k+1+b), 0 <= b <= a < bw:  -= (d * L_b) * L_a.  Pair t = lane (a0, b0 fixed per lane) takes
                 // its two multipliers by lane permutes; bands wider than 10 rows (more than 64 pairs) finish through LDS.
                 const int npairs = bw * (bw + 1) / 2;
                 {
-                    double *e = &blk[((k + 1 + a0) % BS) * BS + ((k + 1 + b0) % BS)];
-                    const double eold = lane < npairs ? *e : 0.0;
                     const double la = __shfl(l, a0, 64), lb = __shfl(l, b0, 64);
-                    if (lane < npairs) *e = __dsub_rn(eold, __dmul_rn(__dmul_rn(d, lb), la));
+                    if (lane < npairs) *ep = __dsub_rn(eold, __dmul_rn(__dmul_rn(d, lb), la));
                 }
                 if (npairs > 64) {
                     if (lane < MAXAR) lvec[lane] = l;
@@ -349,14 +375,20 @@ k_adeclick(const double *__restrict__ in, double *__restrict__ out, int64_t n, D
                         *e = __dsub_rn(*e, __dmul_rn(__dmul_rn(d, lvec[b]), lvec[a]));
                     }
                 }
-                // row k leaves the block; row k + BS enters with its original entries against the rows still in reach
+                // row k leaves the ring; row k + BS enters with its original entries against the rows still in reach (columns
+                // k+1 .. k+BS, lanes 0 .. BS-1; aux[AR+1] is 0), and lane BS stores its right-hand side
                 const int nj = k + BS;
                 if (nj < F) {
-                    for (int i = k + 1 + lane; i <= nj; i += 64) blk[ks * BS + (i % BS)] = entry0(nj, i);
                     if (nj >= vbase + 64) { vbase += 64; vreg = (vbase + lane < F) ? dk_ld(&gV[vbase + lane]) : 0.0; }
                     const double vn = dk_readlane(vreg, nj - vbase);
-                    if (lane == 0) ywin[ks] = vn;
+                    const int dlt = (int)index[nj] - idx_i;
+                    const double ent = aux[dlt < AR + 1 ? dlt : AR + 1];
+                    double *dst = lane == BS ? &ywin[ks] : &blk[ks * BS + rs];
+                    if (lane <= BS) *dst = lane == BS ? vn : ent;
                 }
+                rs = rs + 1 == BS ? 0 : rs + 1;
+                ra = ra + 1 == BS ? 0 : ra + 1;
+                rb = rb + 1 == BS ? 0 : rb + 1;
             }
             DK_MARK(5)
             if (ok) {
@@ -365,11 +397,21 @@ k_adeclick(const double *__restrict__ in, double *__restrict__ out, int64_t n, D
                 // band are skipped).  L[j][i] = gL[i][j-i-1].  Rows in batches of 16: the batch's factors are fetched together.
                 double sw = 0.0;                                    // lane t: solution of row (current row + 1 + t)
                 for (int ib = F - 1; ib >= 0; ib -= 16) {
+                    double qr = 0.0; int ntr = 0, posr = 0, cnt = 0;
+                    if (lane < 16 && ib - lane >= 0) { ntr = bwv[ib - lane]; posr = index[ib - lane]; cnt = ntr + 1; }
+                    // packed rows end at goff; row ib - q starts at goff - (cnt_0 + .. + cnt_q) and ends with its y/d
+                    int pref = cnt;
+#pragma unroll
+                    for (int dd = 1; dd < 16; dd <<= 1) { const int o = __shfl_up(pref, dd, 64); pref += lane >= dd ? o : 0; }
+                    if (cnt) qr = dk_ld(&gL[goff - (size_t)pref + (size_t)ntr]);
                     double Lr[16];
 #pragma unroll
-                    for (int q = 0; q < 16; ++q) { const int i = ib - q; Lr[q] = (i >= 0 && lane < MAXAR) ? dk_ld(&gL[(size_t)i * MAXAR + lane]) : 0.0; }
-                    double qr = 0.0; int ntr = 0, posr = 0;
-                    if (lane < 16 && ib - lane >= 0) { qr = dk_ld(&gY[ib - lane]); ntr = bwv[ib - lane]; posr = index[ib - lane]; }
+                    for (int q = 0; q < 16; ++q) {
+                        const int nq = __builtin_amdgcn_readlane(ntr, q);
+                        const size_t oq = goff - (size_t)__builtin_amdgcn_readlane(pref, q);
+                        Lr[q] = lane < nq ? dk_ld(&gL[oq + lane]) : 0.0;
+                    }
+                    goff -= (size_t)__builtin_amdgcn_readlane(pref, 15);
 #pragma unroll
                     for (int q = 0; q < 16; ++q) {
                         const int i = ib - q;
@@ -377,7 +419,14 @@ k_adeclick(const double *__restrict__ in, double *__restrict__ out, int64_t n, D
                         const int nt = __builtin_amdgcn_readlane(ntr, q);
                         double v = dk_readlane(qr, q);
                         const double term = __dmul_rn(Lr[q], sw);
-                        for (int t = 0; t < nt; ++t) v = __dsub_rn(v, dk_readlane(term, t));
+                        {
+                            int t = 0;
+                            for (; t + 4 <= nt; t += 4) {
+                                v = __dsub_rn(v, dk_readlane(term, t)); v = __dsub_rn(v, dk_readlane(term, t + 1));
+                                v = __dsub_rn(v, dk_readlane(term, t + 2)); v = __dsub_rn(v, dk_readlane(term, t + 3));
+                            }
+                            for (; t < nt; ++t) v = __dsub_rn(v, dk_readlane(term, t));
+                        }
                         // slide the window: lane t takes lane t-1's solution, lane 0 the new one
                         {
                             const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(sw), 0x138, 0xf, 0xf, false);   // wave_shr:1

@@ -1,8 +1,18 @@
-import sys, time, numpy as np, torch
-sys.path.insert(0, '.')
-from jivetalking_amd import Engine, synth
-sr=44100
-x=(synth.speech_like_torch(1200.0, sr, seed=3, device="cuda:0").cpu().numpy()*3.0).astype(np.float64)
-e=Engine(0)
-e.op_adeclick(x[:sr*10],sr)
-t=time.time(); y,c=e.op_adeclick(x,sr,return_count=True); print("wall",time.time()-t,"repaired/window",c/(x.size/1212))
+"""adeclick launch time inside Pass 4 on the bench workload (HIP events): min / median over N runs.  For A/B builds."""
+import os, sys
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+sys.path.insert(0, "/root/repo")
+import numpy as np, torch
+from jivetalking_amd import Engine, synth, hostlogic
+n_runs = int(sys.argv[1]) if len(sys.argv) > 1 else 10
+sr = 48000
+x = synth.speech_like_torch(3600.0, sr, seed=1000, device="cuda:0")
+e = Engine(0)
+e.attach_device_pcm(x.data_ptr(), x.numel(), sr, 1, keepalive=x)
+base = hostlogic.default_config()
+ms = []
+for i in range(n_runs + 1):
+    hostlogic.process_audio(e, base, 4096)
+    if i: ms.append(e.timers()["declick_ms"])
+ms = np.array(ms)
+print(f"declick_ms min {ms.min():.2f} median {np.median(ms):.2f} max {ms.max():.2f}")

@@ -1,0 +1,31 @@
+"""Fold the two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE counter_collection CSVs) into profiles/rNN_pmc_traffic.json:
+per kernel (short name) the largest call's counter value in KB and the call count."""
+import csv, json, re, sys
+
+fetch_csv, write_csv, out = sys.argv[1], sys.argv[2], sys.argv[3]
+
+
+def short(name):
+    name = re.sub(r"^void ", "", name)
+    name = name.replace("(anonymous namespace)::", "")
+    m = re.match(r"([A-Za-z_0-9:]+(<[^(]*>)?)", name)
+    s = m.group(1) if m else name
+    s = s.split("::")[-1] if "<" not in s else re.sub(r"^.*::(?=[A-Za-z_0-9]+<)", "", s)
+    return s.replace(" ", "")
+
+
+res = {}
+for path, key in ((fetch_csv, "FETCH_SIZE"), (write_csv, "WRITE_SIZE")):
+    for r in csv.DictReader(open(path)):
+        if r["Counter_Name"] != key or "at::native" in r["Kernel_Name"]:
+            continue
+        k = res.setdefault(short(r["Kernel_Name"]), {})
+        v = float(r["Counter_Value"])
+        k[key + "_KB_max_call"] = max(k.get(key + "_KB_max_call", 0.0), v)
+        k[key + "_calls"] = k.get(key + "_calls", 0) + 1
+json.dump({"note": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) of `python bench.py --steps 1 --warmup 1 "
+                   "--cpu-sample 0`, 60-min workload; values in KB as reported, largest call per kernel (the full-file launch). "
+                   "gfx950 FETCH_SIZE under-reports wide coalesced reads by 2x (MI355X_MICROARCH.md, HBM section); not corrected "
+                   "here, bench.py doubles it.",
+           "kernels": res}, open(out, "w"), indent=1)
+print(len(res), "kernels ->", out)
