@@ -496,7 +496,9 @@ void launch_adeclick(jt_ctx *h, const double *in, double *out, int64_t n, int sa
     const size_t sm0 = smem_for(sa0, LIGHT), sm1 = smem_for(sa1, MID), sm2 = smem_for(sa2, dk::MAXW);
     JT_REQUIRE(sm2 <= 64 * 1024, JT_E_UNSUPPORTED, "adeclick: window does not fit the per-wave LDS budget");
     const size_t per_wave = (size_t)P.W * dk::MAXAR + 3 * (size_t)P.W;
-    int w0 = (int)std::min<size_t>(12, (160 * 1024) / sm0);
+    // 8 resident waves per CU: measured on the 60-min workload, 6 -> 44.5 ms, 8 -> 38.1 ms, 10 (the LDS limit) -> 36.8..41.5 ms
+    // run to run (slower sustained, less stable), so the grid is capped below what LDS would allow
+    int w0 = (int)std::min<size_t>(8, (160 * 1024) / sm0);
     const int w1 = (int)std::min<size_t>(8, (160 * 1024) / sm1), w2 = (int)std::min<size_t>(8, (160 * 1024) / sm2);
     if (const char *ev = getenv("JT_DK_WAVES")) w0 = std::max(1, std::min(w0, atoi(ev)));      // occupancy experiments
     const int64_t g0 = std::min<int64_t>(P.nwindows, (int64_t)256 * w0), g1 = std::min<int64_t>(P.nwindows, (int64_t)256 * w1),
