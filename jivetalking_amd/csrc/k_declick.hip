@@ -397,8 +397,8 @@ k_adeclick(const double *__restrict__ in, double *__restrict__ out, int64_t n, D
                 // band are skipped).  L[j][i] = gL[i][j-i-1].  Rows in batches of 16: the batch's factors are fetched together.
                 double sw = 0.0;                                    // lane t: solution of row (current row + 1 + t)
                 for (int ib = F - 1; ib >= 0; ib -= 16) {
-                    double qr = 0.0; int ntr = 0, posr = 0, cnt = 0;
-                    if (lane < 16 && ib - lane >= 0) { ntr = bwv[ib - lane]; posr = index[ib - lane]; cnt = ntr + 1; }
+                    double qr = 0.0; int ntr = 0, cnt = 0;
+                    if (lane < 16 && ib - lane >= 0) { ntr = bwv[ib - lane]; cnt = ntr + 1; }
                     // packed rows end at goff; row ib - q starts at goff - (cnt_0 + .. + cnt_q) and ends with its y/d
                     int pref = cnt;
 #pragma unroll
@@ -414,8 +414,7 @@ k_adeclick(const double *__restrict__ in, double *__restrict__ out, int64_t n, D
                     goff -= (size_t)__builtin_amdgcn_readlane(pref, 15);
 #pragma unroll
                     for (int q = 0; q < 16; ++q) {
-                        const int i = ib - q;
-                        if (i < 0) break;
+                        // rows below 0 (last batch) run as empty rows: nt = 0, nothing is stored for them
                         const int nt = __builtin_amdgcn_readlane(ntr, q);
                         double v = dk_readlane(qr, q);
                         const double term = __dmul_rn(Lr[q], sw);
@@ -433,9 +432,14 @@ k_adeclick(const double *__restrict__ in, double *__restrict__ out, int64_t n, D
                             const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(sw), 0x138, 0xf, 0xf, false);
                             sw = lane == 0 ? v : __hiloint2double(hi, lo);
                         }
-                        const int pos = __builtin_amdgcn_readlane(posr, q);
-                        if (lane == 0 && pos >= P.skip && pos < P.skip + P.hop && o0 + (pos - P.skip) < n) out[o0 + (pos - P.skip)] = v;
                     }
+                    // lanes 0..15 now hold the solutions of rows ib-15 .. ib: park them in LDS (the factorisation block is dead)
+                    if (lane < 16 && ib - 15 + lane >= 0) blk[ib - 15 + lane] = sw;
+                }
+                // repaired samples of this window's output hop, all at once
+                for (int e = lane; e < F; e += 64) {
+                    const int pos = index[e];
+                    if (pos >= P.skip && pos < P.skip + P.hop && o0 + (pos - P.skip) < n) out[o0 + (pos - P.skip)] = blk[e];
                 }
                 repaired += (lane == 0) ? (unsigned long long)F : 0ull;
             } else {
