@@ -238,8 +238,9 @@ k_adeclick(const double *__restrict__ in, double *__restrict__ out, int64_t n, D
                     if (slot < FCAP) index[slot] = (unsigned short)(wd * 64 + bpos);
                     ++slot; fb &= fb - 1ull;
                 }
-                F += __shfl(incl, 63, 64);
+                F += __builtin_amdgcn_readlane(incl, 63);
             }
+            F = __builtin_amdgcn_readfirstlane(F);              // wave-uniform by construction: keep every loop over it scalar
             to_heavy = F > FCAP;
             if (!to_heavy) {
                 // band width of every pivot: rows k+1 .. k+bw are within AR samples of row k (index[] increases): upper bound by bisection
