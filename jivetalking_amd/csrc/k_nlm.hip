@@ -89,29 +89,46 @@ __device__ inline void nlm_step(f2 (&cache)[NOFF], f2 (&hi)[NOFF + 1], f2 (&lo)[
     if (__any(dmin < dthr)) {
         // some offset may contribute (or a distance went negative by round-off, which is also < dthr): FFmpeg's clamp
         // `if (distance < 0) cache = distance = 0`, the exact per-offset test, weights, lane-local sums, wave reductions
-        float Px = 0.f, Qx = 0.f, Py = 0.f, Qy = 0.f;
+        // The kernel is VALU-bound, so the stage is written for instruction count: both hops ride in packed registers, FFmpeg's
+        // `if (w >= smooth) continue;` is a select (a skipped offset contributes weight 0; P + 0*f and Q + 0 are exact because the
+        // sums start at +0 and never become -0), and the four wave sums share one transposed reduction.
+        f2 Pxy = f2{0.f, 0.f}, Qxy = f2{0.f, 0.f};
+        const f2 sw2 = f2{sw, sw}, ls2 = f2{lut_scale, lut_scale}, ns2 = f2{neg_inv_scale_log2e, neg_inv_scale_log2e};
 #pragma unroll
         for (int q = 0; q < NOFF; ++q) {
             cache[q].x = __builtin_amdgcn_fmed3f(cache[q].x, 0.f, 3.0e38f);
             cache[q].y = __builtin_amdgcn_fmed3f(cache[q].y, 0.f, 3.0e38f);
             const int xc = i + d0 + q;
-            const float wx = __fmul_rn(cache[q].x, sw), wy = __fmul_rn(cache[q].y, sw);
-            if (!(wx >= smooth)) {
-                const float idx = truncf(__fmul_rn(wx, lut_scale));
-                const float wt = __builtin_amdgcn_exp2f(idx * neg_inv_scale_log2e);      // weight_lut[idx] = expf(-idx / scale)
-                Px = __fadd_rn(Px, __fmul_rn(wt, fA[xc])); Qx = __fadd_rn(Qx, wt);
-            }
-            if (!(wy >= smooth)) {
-                const float idx = truncf(__fmul_rn(wy, lut_scale));
-                const float wt = __builtin_amdgcn_exp2f(idx * neg_inv_scale_log2e);
-                Py = __fadd_rn(Py, __fmul_rn(wt, fB[xc])); Qy = __fadd_rn(Qy, wt);
-            }
+            const f2 w = cache[q] * sw2;
+            f2 idx = w * ls2;
+            idx.x = truncf(idx.x); idx.y = truncf(idx.y);
+            const f2 ex = idx * ns2;                                                     // weight_lut[idx] = expf(-idx / scale)
+            f2 wt;
+            wt.x = w.x >= smooth ? 0.f : __builtin_amdgcn_exp2f(ex.x);
+            wt.y = w.y >= smooth ? 0.f : __builtin_amdgcn_exp2f(ex.y);
+            Pxy = Pxy + wt * f2{fA[xc], fB[xc]};
+            Qxy = Qxy + wt;
         }
-        Px = wave_sum63(Px); Qx = wave_sum63(Qx); Py = wave_sum63(Py); Qy = wave_sum63(Qy);
-        if (lane == 63 && i - S < H) {
-            const int64_t oA = hs + (i - S), oB = oA + H;
-            if (oA >= 0 && oA < n) out[oA] = __fadd_rn(Px, fA[i]) / __fadd_rn(Qx, 1.f);
-            if (oB >= 0 && oB < n) out[oB] = __fadd_rn(Py, fB[i]) / __fadd_rn(Qy, 1.f);
+        // after the two quad steps lane (4m + j) holds the quad sum of value j (j = 0..3: Px, Qx, Py, Qy), the row steps keep j
+        // in place, two cross-row permutes finish: lanes 60..63 = Px, Qx, Py, Qy
+        {
+            const bool odd = lane & 1, up = lane & 2;
+            const float s1 = odd ? Qxy.x : Pxy.x, o1 = odd ? Pxy.x : Qxy.x;
+            const float s2 = odd ? Qxy.y : Pxy.y, o2 = odd ? Pxy.y : Qxy.y;
+            const float x = s1 + JT_DPP(o1, 0xb1, 0xf);          // quad_perm:[1,0,3,2]
+            const float y = s2 + JT_DPP(o2, 0xb1, 0xf);
+            const float s3 = up ? y : x, o3 = up ? x : y;
+            float z = s3 + JT_DPP(o3, 0x4e, 0xf);                // quad_perm:[2,3,0,1]
+            z += JT_DPP(z, 0x114, 0xf);                          // row_shr:4
+            z += JT_DPP(z, 0x118, 0xf);                          // row_shr:8: lanes 12..15 of each row = row sums
+            z += __shfl_xor(z, 16, 64);
+            z += __shfl_xor(z, 32, 64);
+            const float pnum = JT_DPP(z, 0x111, 0xf);            // row_shr:1: lane 61 <- Px, lane 63 <- Py
+            const bool isA = lane == 61;
+            if ((isA || lane == 63) && i - S < H) {
+                const int64_t o = hs + (i - S) + (isA ? 0 : H);
+                if (o >= 0 && o < n) out[o] = __fadd_rn(pnum, isA ? fA[i] : fB[i]) / __fadd_rn(z, 1.f);
+            }
         }
     }
 }
