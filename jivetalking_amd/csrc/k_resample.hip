@@ -150,22 +150,40 @@ k_upsample32(const TIn *__restrict__ in, int64_t n, const TTap *__restrict__ ban
     __syncthreads();
     const int64_t b_first = (s0 - center + L - 1 < 0 ? 0 : (s0 - center + L - 1)) / blk;
     const int nitems = step * R;
+    // All index arithmetic below is 32-bit and strength-reduced: the phase advances by `step` modulo P from one output to the next,
+    // a lane's outputs of one item are m_base + j, and the end of the stream is a per-lane bound on j.  (Written with 64-bit
+    // products, divisions and modulos per output, this loop spent ~150 scalar instructions per 32 FMAs.)
     for (int item0 = wave; item0 < nitems; item0 += PP_THREADS / 64) {
         const int item = __builtin_amdgcn_readfirstlane(item0);
         const int off = item / R, kc = item - off * R;
-        const int j_lo = (int)(((int64_t)off * P + step - 1) / step);
-        const int j_hi = min(P, (int)(((int64_t)(off + 1) * P + step - 1) / step));
+        const unsigned uP = (unsigned)P, ustep = (unsigned)step;
+        const int j_lo = (int)(((unsigned)off * uP + ustep - 1u) / ustep);
+        int j_hi = (int)(((unsigned)(off + 1) * uP + ustep - 1u) / ustep);
+        j_hi = j_hi < P ? j_hi : P;
         const int qq = (kc * 64 + lane) * QL;                       // first window of this lane (tile-relative q)
         const int si = off + step * qq;
         TAcc xw[WL];
+        {
+            const int sb = si & 31, base = si + (si >> 5);          // skew(si + i) = base + i + ((sb + i) >> 5)
 #pragma unroll
-        for (int i = 0; i < WL; ++i) xw[i] = (TAcc)((TAcc)xin[skew(si + i)] * (TAcc)in_scale);
+            for (int i = 0; i < WL; ++i) {
+                const TAcc v = (TAcc)xin[base + i + ((sb + i) >> 5)];
+                xw[i] = MODE == 0 ? v : (TAcc)(v * (TAcc)in_scale);   // the true-peak instances run with in_scale == 1
+            }
+        }
         TAcc vmax[QL];
 #pragma unroll
         for (int u = 0; u < QL; ++u) vmax[u] = (TAcc)0;
+        const int64_t m_base = m_lo + (int64_t)P * qq;               // output index of (this lane's first window, phase 0)
+        int jlim[QL];                                                // outputs j < jlim[u] exist (m < m_total)
+#pragma unroll
+        for (int u = 0; u < QL; ++u) {
+            const int64_t left = m_total - (m_base + (int64_t)P * u);
+            jlim[u] = left <= 0 ? 0 : (left >= (int64_t)P ? P : (int)left);
+        }
+        int ph = (int)(((unsigned)j_lo * ustep) % uP);
         for (int j = j_lo; j < j_hi; ++j) {
-            const int ph = (int)(((int64_t)j * step) % P);
-            const TTap *f = bank + (size_t)ph * L;
+            const TTap *f = bank + (size_t)(unsigned)ph * L;
             TTap tp[L];
 #pragma unroll
             for (int i = 0; i < L; ++i) tp[i] = f[i];
@@ -174,24 +192,44 @@ k_upsample32(const TIn *__restrict__ in, int64_t n, const TTap *__restrict__ ban
                 TAcc val = (TAcc)0;
 #pragma unroll
                 for (int i = 0; i < L; ++i) val = fma(xw[u + i], (TAcc)tp[i], val);
-                const int64_t m = m_lo + j + (int64_t)P * (qq + u);
-                if (m < m_total) {
-                    if (MODE == 0) vmax[u] = fmax(vmax[u], fabs(val));
-                    else out_stream[m] = val;
-                }
+                if (MODE == 0) vmax[u] = j < jlim[u] ? fmax(vmax[u], fabs(val)) : vmax[u];
+                else if (j < jlim[u]) out_stream[m_base + (int64_t)P * u + j] = val;
             }
+            ph += step; ph -= ph >= P ? P : 0;
         }
         if (MODE == 0) {
+            // 100 ms block of every window's last input sample, relative to the tile's first block (32-bit: the tile spans a few
+            // blocks at most).  A wave's windows almost always sit in ONE block: then the wave reduces its maxima in registers and
+            // a single lane does the LDS atomic (64 lanes x QL atomics on one address serialise in the LDS unit otherwise).
+            const int64_t base0 = s0 - center + L - 1;                              // `last` of tile sample 0 (block-uniform)
+            const int64_t bq = (base0 < 0 ? base0 - (blk - 1) : base0) / blk;        // floor division, once per workgroup value
+            const unsigned brem = (unsigned)(base0 - bq * blk);
+            int sl[QL]; TAcc vm[QL];
 #pragma unroll
             for (int u = 0; u < QL; ++u) {
-                const int64_t last = s0 + si + u * step - center + L - 1;
-                if (last <= n - 1 && vmax[u] > (TAcc)0) {
-                    int64_t b = last / blk;
-                    if (b >= nblocks_alloc) b = nblocks_alloc - 1;
-                    const int sl = (int)(b - b_first);
-                    const unsigned long long bits = (unsigned long long)__double_as_longlong((double)vmax[u]);
-                    if (sl >= 0 && sl < 8) atomicMax(&slots[sl], bits);
-                    else atomicMax(&block_tp[b], bits);
+                const unsigned t = brem + (unsigned)(si + u * step);
+                const int64_t last = base0 + si + u * step;
+                int64_t b = bq + (int64_t)(t / (unsigned)blk);
+                if (b >= nblocks_alloc) b = nblocks_alloc - 1;
+                sl[u] = (int)(b - b_first);
+                vm[u] = (last >= 0 && last <= n - 1) ? vmax[u] : (TAcc)0;
+            }
+            const int sl_lo = __builtin_amdgcn_readfirstlane(sl[0]), sl_hi = __builtin_amdgcn_readlane(sl[QL - 1], 63);
+            if (sl_lo == sl_hi && sl_lo >= 0 && sl_lo < 8) {
+                TAcc v = vm[0];
+#pragma unroll
+                for (int u = 1; u < QL; ++u) v = fmax(v, vm[u]);
+#pragma unroll
+                for (int mm = 1; mm < 64; mm <<= 1) v = fmax(v, __shfl_xor(v, mm, 64));
+                if (lane == 0 && v > (TAcc)0) atomicMax(&slots[sl_lo], (unsigned long long)__double_as_longlong((double)v));
+            } else {
+#pragma unroll
+                for (int u = 0; u < QL; ++u) {
+                    if (vm[u] > (TAcc)0) {
+                        const unsigned long long bits = (unsigned long long)__double_as_longlong((double)vm[u]);
+                        if (sl[u] >= 0 && sl[u] < 8) atomicMax(&slots[sl[u]], bits);
+                        else atomicMax(&block_tp[b_first + sl[u]], bits);
+                    }
                 }
             }
         }
