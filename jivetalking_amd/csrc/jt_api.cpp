@@ -199,7 +199,8 @@ static void analysis_enqueue(jt_ctx *h, const float *x, int64_t n, int sr, bool 
         double *btp = h->pin.take<double>((size_t)nfull + 2);
         JT_HIP(hipMemcpyAsync(btp, h->d_scr1.p, sizeof(double) * (nfull + 2), hipMemcpyDeviceToHost, a3));
         J->btp = btp;
-        jt_kweight_enqueue_f32(h, x, n, sr, blk, &J->kw, a3);
+        // K-weighting rides behind the (short) noise-floor chain instead of behind the true-peak upsampler, the longest kernel
+        jt_kweight_enqueue_f32(h, x, n, sr, blk, &J->kw, a1);
     }
     if (J->want_spec) {
         const int win = 2048, hop = win / 2;
