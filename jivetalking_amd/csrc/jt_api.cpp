@@ -5,6 +5,8 @@
 #include <algorithm>
 #include <cstdlib>
 #include <memory>
+#include <thread>
+#include <exception>
 
 static void check_cancel(jt_ctx *h) { if (h->cancelled.load()) throw JtError{JT_E_CANCELLED, "cancelled"}; }
 
@@ -655,19 +657,30 @@ extern "C" int jt_pass4(jt_ctx *h, const jt_limiter_plan *lim, const jt_loudnorm
         { float dms = 0; JT_HIP(hipEventElapsedTime(&dms, h->ev2, h->ev3)); h->timers.declick_ms = dms; }
         JT_REQUIRE(dk_stats[1] == 0, JT_E_HIP, "adeclick: singular interpolation matrix (af_adeclick.c would fail the graph)");
     }
+    // host tail: the loudnorm statistics (two gated integrations over the 100 ms blocks) run on a second thread while this one
+    // finishes the output analysis
+    std::exception_ptr stats_err;
+    std::thread stats_thread;
     if (stats) {
-        const int64_t nfull = m / sblk;
-        std::vector<double> bsum, bpk;
-        jt_kweight_finish(&sj, bsum, bpk);
-        double pk = 0; for (int64_t k = 0; k <= nfull; ++k) pk = std::max(pk, bpk[(size_t)k]);
-        jt_loudnorm_finish(bsum.data(), nfull, sblk, true, 1.0, &stats->input_i, &stats->input_lra, &stats->input_thresh);
-        jt_loudnorm_finish(bsum.data(), nfull, sblk, true, gain * gain, &stats->output_i, &stats->output_lra, &stats->output_thresh);
-        stats->input_tp = 20 * std::log10(pk);
-        stats->output_tp = 20 * std::log10(pk * gain);
-        stats->target_offset = ap->target_i - stats->output_i;
-        stats->normalization_type_dynamic = 0;
+        stats_thread = std::thread([&]() {
+            try {
+                const int64_t nfull = m / sblk;
+                std::vector<double> bsum, bpk;
+                jt_kweight_finish(&sj, bsum, bpk);
+                double pk = 0; for (int64_t k = 0; k <= nfull; ++k) pk = std::max(pk, bpk[(size_t)k]);
+                jt_loudnorm_finish(bsum.data(), nfull, sblk, true, 1.0, &stats->input_i, &stats->input_lra, &stats->input_thresh);
+                jt_loudnorm_finish(bsum.data(), nfull, sblk, true, gain * gain, &stats->output_i, &stats->output_lra, &stats->output_thresh);
+                stats->input_tp = 20 * std::log10(pk);
+                stats->output_tp = 20 * std::log10(pk * gain);
+                stats->target_offset = ap->target_i - stats->output_i;
+                stats->normalization_type_dynamic = 0;
+            } catch (...) { stats_err = std::current_exception(); }
+        });
     }
-    analysis_complete(h, J, out, nullptr, 0);
+    try { analysis_complete(h, J, out, nullptr, 0); }
+    catch (...) { if (stats_thread.joinable()) stats_thread.join(); throw; }
+    if (stats_thread.joinable()) stats_thread.join();
+    if (stats_err) std::rethrow_exception(stats_err);
     float ms = 0; JT_HIP(hipEventElapsedTime(&ms, h->ev0, h->ev1)); h->timers.pass4_ms = ms;
     JT_API_END(h)
 }
