@@ -184,7 +184,8 @@ int jt_pass4(jt_ctx *h, const jt_limiter_plan *lim, const jt_loudnorm_apply *ap,
  * again over the file.  `file` is the whole file image in host memory: FLAC (RFC 9639: any block size, 4..24 bits, 1..8
  * channels, all predictor / residual / stereo modes; an ID3v2 tag in front is skipped) is decoded on the GPU; RIFF/WAVE PCM
  * (u8, s16, s24, s32, f32, f64, WAVE_FORMAT_EXTENSIBLE) is unpacked on the GPU.  Afterwards the handle is in the state
- * jt_upload_pcm() leaves it in (interleaved f32 at the file's rate; integer PCM scaled by 2^(1-bits) exactly as
+ * jt_upload_pcm() leaves it in — mono or stereo only, surround files are refused with JT_E_UNSUPPORTED like jt_upload_pcm does
+ * (jt_op_decode_audio decodes any layout) — (interleaved f32 at the file's rate; integer PCM scaled by 2^(1-bits) exactly as
  * libswresample's s16/s32 -> flt conversion does).  Errors: JT_E_INVAL for a damaged or truncated stream (frame CRC-16 /
  * header CRC-8 / sample count), JT_E_UNSUPPORTED for other containers or 32-bit FLAC. */
 typedef struct {

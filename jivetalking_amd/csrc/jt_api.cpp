@@ -86,6 +86,9 @@ void jt_set_input_common(jt_ctx *h, int64_t frames, int sr, int ch)
     JT_REQUIRE(frames > 0, JT_E_INVAL, "empty input");
     JT_REQUIRE(sr >= 8000 && sr <= 384000, JT_E_INVAL, "unsupported sample rate");
     JT_REQUIRE(ch >= 1 && ch <= 8, JT_E_INVAL, "unsupported channel count");
+    // aformat=channel_layouts=mono goes through libswresample's layout-specific rematrix; only the stereo matrix (0.5 / 0.5) is
+    // restated here, so surround layouts are refused instead of being averaged with the wrong weights
+    JT_REQUIRE(ch <= 2, JT_E_UNSUPPORTED, "only mono and stereo inputs are down-mixed on the device (surround layouts need swresample's matrix)");
     h->n = frames; h->sr = sr; h->channels = ch;
     h->m_p2 = h->m_p4 = 0;
     if (ch == 1) h->in_mono = h->in_raw;

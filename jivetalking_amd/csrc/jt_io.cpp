@@ -311,6 +311,8 @@ extern "C" int jt_load_audio(jt_ctx *h, const uint8_t *file, int64_t len, jt_aud
 {
     JT_API_BEGIN(h)
     AudioDecoded d;
+    // the decode overwrites the owned input buffer: until it has succeeded the handle holds no input at all
+    h->n = 0; h->in_raw = nullptr; h->in_mono = nullptr; h->m_p2 = h->m_p4 = 0;
     decode_audio(h, file, len, false, true, &d, meta);
     h->in_raw = h->in_owned.p;
     jt_set_input_common(h, d.frames, d.rate, d.channels);

@@ -94,11 +94,7 @@ __global__ void k_downmix(const float *__restrict__ in, float *__restrict__ out,
         if (channels == 2) {
             float2 v = reinterpret_cast<const float2 *>(in)[i];
             out[i] = v.x * 0.5f + v.y * 0.5f;
-        } else {
-            float acc = 0.f;
-            for (int c = 0; c < channels; ++c) acc += in[i * channels + c] * (1.0f / channels);
-            out[i] = acc;
-        }
+        } else out[i] = in[i * channels];            // not reached: jt_set_input_common refuses layouts above stereo
     }
 }
 void launch_downmix(const float *in, float *out, int64_t frames, int channels, hipStream_t s)

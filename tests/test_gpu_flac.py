@@ -261,6 +261,16 @@ def test_wav_formats(engine):
     assert ei.value.code == L.JT_E_UNSUPPORTED
 
 
+def test_surround_layouts_are_refused_not_averaged(engine, oracle):
+    x = coverage_signal(np.random.default_rng(2), 9000, 6, 16)
+    data = oracle.flac_encode(x, 48000, 16, 4096, 2, 8)
+    with pytest.raises(L.JtError) as ei:
+        engine.load_audio(data)
+    assert ei.value.code == L.JT_E_UNSUPPORTED
+    i32, _, _ = engine.op_decode_audio(data)                           # the decoder itself handles the layout
+    assert np.array_equal(i32, x)
+
+
 def test_load_audio_feeds_the_passes_like_upload_pcm(oracle):
     """jt_load_audio of a 24-bit stereo FLAC == jt_upload_pcm of the same samples as f32: identical Pass-1 analysis."""
     from jivetalking_amd import hostlogic
