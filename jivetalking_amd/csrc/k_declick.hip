@@ -68,6 +68,16 @@ k_adeclick(const double *__restrict__ in, double *__restrict__ out, int64_t n, D
     unsigned long long *fbits = obits + dk::NWORD;                                            // [NWORD] flags after fusion / border clearing
     unsigned short *index = reinterpret_cast<unsigned short *>(fbits + dk::NWORD);          // [FCAP]
     unsigned char *bwv = reinterpret_cast<unsigned char *>(index + FCAP);                    // [FCAP] band width per pivot
+    // (a, b) of trailing-update pair t >= 64, a | b << 8 (bands wider than 10 rows have more than 64 pairs): unranked once per wave
+    unsigned short *pairtab = reinterpret_cast<unsigned short *>(bwv + FCAP) - 64;
+    {
+        constexpr int NPAIR = BSD * (BSD - 1) / 2;
+        for (int t = lane + 64; t < NPAIR; t += 64) {
+            int a = (int)((sqrtf(8.0f * (float)t + 1.0f) - 1.0f) * 0.5f);
+            a += ((a + 1) * (a + 2) / 2 <= t); a -= (a * (a + 1) / 2 > t);
+            pairtab[t] = (unsigned short)(a | ((t - a * (a + 1) / 2) << 8));
+        }
+    }
     auto fbit = [&](int pos) -> bool { return (fbits[pos >> 6] >> (pos & 63)) & 1ull; };
     auto obit = [&](int pos) -> bool { return (obits[pos >> 6] >> (pos & 63)) & 1ull; };
     // global scratch of this wave: L[W][MAXAR] | D[W] | y[W] | rhs[W].  Written with plain stores, read back (by other lanes, after
@@ -369,10 +379,10 @@ k_adeclick(const double *__restrict__ in, double *__restrict__ out, int64_t n, D
                 if (npairs > 64) {
                     if (lane < MAXAR) lvec[lane] = l;
                     for (int t = lane + 64; t < npairs; t += 64) {
-                        int a = (int)((sqrtf(8.0f * (float)t + 1.0f) - 1.0f) * 0.5f);       // unrank t -> (a, b)
-                        a += ((a + 1) * (a + 2) / 2 <= t); a -= (a * (a + 1) / 2 > t);
-                        const int b = t - a * (a + 1) / 2;
-                        double *e = &blk[((k + 1 + a) % BS) * BS + ((k + 1 + b) % BS)];
+                        const int ab = pairtab[t], a = ab & 0xff, b = ab >> 8;
+                        int rra = ks + 1 + a, rrb = ks + 1 + b;
+                        rra -= rra >= BS ? BS : 0; rrb -= rrb >= BS ? BS : 0;
+                        double *e = &blk[rra * BS + rrb];
                         *e = __dsub_rn(*e, __dmul_rn(__dmul_rn(d, lvec[b]), lvec[a]));
                     }
                 }
@@ -495,7 +505,7 @@ void launch_adeclick(jt_ctx *h, const double *in, double *out, int64_t n, int sa
     const bool half_ok = P.lb < P.W && P.ar < P.lb / 4;
     auto sa_for = [&](bool half, int bs) { return ((half ? std::max(P.lb, bs * bs) : std::max(P.W, bs * bs)) + 1) & ~1; };
     auto smem_for = [&](int sa, int fcap) {
-        return sizeof(double) * (size_t)(sa + 5 * (dk::BS + 1)) + sizeof(unsigned long long) * 2 * dk::NWORD + (size_t)fcap * 3 + 16;
+        return sizeof(double) * (size_t)(sa + 5 * (dk::BS + 1)) + sizeof(unsigned long long) * 2 * dk::NWORD + (size_t)fcap * 3 + 16 + (size_t)dk::BS * (dk::BS - 1);
     };
     const int sa0 = sa_for(half_ok, LBS), sa1 = sa_for(half_ok, dk::BS), sa2 = sa_for(false, dk::BS);
     const size_t sm0 = smem_for(sa0, LIGHT), sm1 = smem_for(sa1, MID), sm2 = smem_for(sa2, dk::MAXW);
