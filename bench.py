@@ -57,8 +57,8 @@ def cpu_baseline(sample_seconds, sr):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--minutes", type=float, default=60.0, help="audio minutes per file (BASELINE configs[1] = 60)")
     ap.add_argument("--cpu-sample", type=float, default=20.0, help="seconds of audio for the CPU oracle baseline (0 = skip)")
     ap.add_argument("--in-flight", type=int, default=1,
