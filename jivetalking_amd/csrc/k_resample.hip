@@ -187,13 +187,20 @@ k_upsample32(const TIn *__restrict__ in, int64_t n, const TTap *__restrict__ ban
             TTap tp[L];
 #pragma unroll
             for (int i = 0; i < L; ++i) tp[i] = f[i];
+            // tap-major, window-minor: the QL accumulation chains advance together (each chain keeps its ascending tap order), so
+            // consecutive FMAs are independent
+            TAcc val[QL];
+#pragma unroll
+            for (int u = 0; u < QL; ++u) val[u] = (TAcc)0;
+#pragma unroll
+            for (int i = 0; i < L; ++i) {
+#pragma unroll
+                for (int u = 0; u < QL; ++u) val[u] = fma(xw[u + i], (TAcc)tp[i], val[u]);
+            }
 #pragma unroll
             for (int u = 0; u < QL; ++u) {
-                TAcc val = (TAcc)0;
-#pragma unroll
-                for (int i = 0; i < L; ++i) val = fma(xw[u + i], (TAcc)tp[i], val);
-                if (MODE == 0) vmax[u] = j < jlim[u] ? fmax(vmax[u], fabs(val)) : vmax[u];
-                else if (j < jlim[u]) out_stream[m_base + (int64_t)P * u + j] = val;
+                if (MODE == 0) vmax[u] = j < jlim[u] ? fmax(vmax[u], fabs(val[u])) : vmax[u];
+                else if (j < jlim[u]) out_stream[m_base + (int64_t)P * u + j] = val[u];
             }
             ph += step; ph -= ph >= P ? P : 0;
         }
