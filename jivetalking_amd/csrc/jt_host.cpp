@@ -523,17 +523,10 @@ extern "C" int64_t jt_host_build_intervals(int sr, int64_t n_samples, int frame_
                 qmeta[(size_t)i] = q;
             }
         };
-        unsigned nt = n_meta >= 8192 ? std::min(8u, std::max(1u, std::thread::hardware_concurrency())) : 1u;
-        if (nt <= 1) quant_range(0, n_meta);
-        else {
-            std::vector<std::thread> th;
-            const int64_t per = (n_meta + nt - 1) / nt;
-            for (unsigned k = 1; k < nt; ++k) th.emplace_back(quant_range, std::min<int64_t>(n_meta, k * per), std::min<int64_t>(n_meta, (k + 1) * per));
-            quant_range(0, std::min<int64_t>(n_meta, per));
-            for (auto &t : th) t.join();
-        }
+        int nt = 1;
+        jt_parallel_for(n_meta, [&](int64_t lo, int64_t hi, int) { quant_range(lo, hi); }, &nt);
         meta = qmeta.data();
-        if (getenv("JT_HOST_TIMING")) fprintf(stderr, "quant prepass %.3f ms (%u threads)\n", now_ms() - tq0, nt);
+        if (getenv("JT_HOST_TIMING")) fprintf(stderr, "quant prepass %.3f ms (%d parts)\n", now_ms() - tq0, nt);
     }
     auto add_meta = [&](const jt_frame_meta &m) {
         bool has = !std::isnan(m.momentary);

@@ -4,6 +4,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <functional>
 #include <cmath>
 #include <string>
 #include <vector>
@@ -129,6 +130,8 @@ void launch_flac_analyse(const int16_t *pcm, int64_t n, int sr_code, int sr_extr
                          long long *offs, void *summary, hipStream_t s);
 void launch_flac_emit(const int16_t *pcm, int64_t n, int sr_code, int sr_extra_bytes, int sr_extra_val, const void *recs,
                       const long long *offs, uint8_t *out, void *summary, hipStream_t s);
+// fork-join over [0, n) on the process-wide worker pool (jt_plan.cpp); fn(lo, hi, part)
+void jt_parallel_for(int64_t n, const std::function<void(int64_t, int64_t, int)> &fn, int *nparts_out = nullptr);
 void jt_md5(const void *data, size_t len, uint8_t out[16]);      // RFC 1321 (jt_plan.cpp), STREAMINFO signature
 
 // FLAC / WAV input leg (k_flacdec.hip); the structs mirror the kernels' layouts

@@ -6,6 +6,10 @@
 #include <algorithm>
 #include <cfloat>
 #include <thread>
+#include <exception>
+#include <deque>
+#include <condition_variable>
+#include <mutex>
 #include <functional>
 
 // ---------------------------------------------------------------- biquads (af_biquads.c config_filter)
@@ -86,17 +90,71 @@ void jt_swr_plan(SwrPlanHost *p, int in_rate, int out_rate)
 
 // ---------------------------------------------------------------- small fork-join helper for the O(blocks) host finishing
 // fn(lo, hi, part) over [0, n) in contiguous parts; one part when n is small.  The per-block work (2-3 log10 each) is the
-// only host arithmetic that scales with the file, so long files spread it over a few cores.
-static void jt_parallel_for(int64_t n, const std::function<void(int64_t, int64_t, int)> &fn, int *nparts_out = nullptr)
+// only host arithmetic that scales with the file, so long files spread it over a few cores.  The workers are a process-wide
+// pool created on first use (a pass calls this several times; spawning threads each time cost more than the work itself on
+// 10-minute files).  Callers may be concurrent (one host thread per file in flight): tasks of different calls share the queue
+// and every call waits on its own counter.
+namespace {
+struct JtPool {
+    std::mutex mu; std::condition_variable cv;
+    std::deque<std::function<void()>> q;
+    std::vector<std::thread> workers;
+    bool stop = false;
+    explicit JtPool(unsigned n)
+    {
+        for (unsigned i = 0; i < n; ++i)
+            workers.emplace_back([this] {
+                for (;;) {
+                    std::function<void()> job;
+                    {
+                        std::unique_lock<std::mutex> lk(mu);
+                        cv.wait(lk, [this] { return stop || !q.empty(); });
+                        if (stop && q.empty()) return;
+                        job = std::move(q.front()); q.pop_front();
+                    }
+                    job();
+                }
+            });
+    }
+    ~JtPool()
+    {
+        { std::lock_guard<std::mutex> lk(mu); stop = true; }
+        cv.notify_all();
+        for (auto &t : workers) t.join();
+    }
+};
+JtPool &jt_pool()
+{
+    static JtPool pool(std::min(7u, std::max(1u, std::thread::hardware_concurrency()) - 1u));
+    return pool;
+}
+} // namespace
+
+void jt_parallel_for(int64_t n, const std::function<void(int64_t, int64_t, int)> &fn, int *nparts_out)
 {
     int nt = n >= 8192 ? (int)std::min(8u, std::max(1u, std::thread::hardware_concurrency())) : 1;
     if (nparts_out) *nparts_out = nt;
     if (nt <= 1) { fn(0, n, 0); return; }
+    JtPool &pool = jt_pool();
     const int64_t per = (n + nt - 1) / nt;
-    std::vector<std::thread> th;
-    for (int k = 1; k < nt; ++k) th.emplace_back(fn, std::min(n, k * per), std::min(n, (k + 1) * per), k);
-    fn(0, std::min(n, per), 0);
-    for (auto &t : th) t.join();
+    struct Wait { std::mutex mu; std::condition_variable cv; int left; std::exception_ptr err; } w;
+    w.left = nt - 1;
+    {
+        std::lock_guard<std::mutex> lk(pool.mu);
+        for (int k = 1; k < nt; ++k)
+            pool.q.emplace_back([&, k] {
+                try { fn(std::min(n, k * per), std::min(n, (k + 1) * per), k); }
+                catch (...) { std::lock_guard<std::mutex> g(w.mu); if (!w.err) w.err = std::current_exception(); }
+                std::lock_guard<std::mutex> g(w.mu);
+                if (--w.left == 0) w.cv.notify_one();
+            });
+    }
+    pool.cv.notify_all();
+    std::exception_ptr mine;
+    try { fn(0, std::min(n, per), 0); } catch (...) { mine = std::current_exception(); }
+    { std::unique_lock<std::mutex> lk(w.mu); w.cv.wait(lk, [&] { return w.left == 0; }); }
+    if (mine) std::rethrow_exception(mine);
+    if (w.err) std::rethrow_exception(w.err);
 }
 constexpr int JT_MAX_PARTS = 8;
 
