@@ -106,7 +106,14 @@ k_adeclick(const double *__restrict__ in, double *__restrict__ out, int64_t n, D
     // LEVEL 2: list B (full capacity, nothing overflows)
     const int *worklist = LEVEL == 1 ? heavy : heavy + P.nwindows;
     const int64_t nwork = LEVEL == 0 ? P.nwindows : (int64_t)stats[1 + LEVEL];
-    for (int64_t wi = blockIdx.x; wi < nwork; wi += gridDim.x) {
+    // windows are handed out by a device-side counter: their cost varies with the number of flagged samples, and waves that start
+    // late (another stream's kernel holding LDS on their CU when the grid was placed) simply take fewer of them
+    for (;;) {
+        unsigned long long wi_;
+        if (lane == 0) wi_ = atomicAdd(&stats[12 + LEVEL], 1ull);
+        const int64_t wi = (int64_t)(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(wi_ >> 32)) << 32) |
+                                     (unsigned)__builtin_amdgcn_readfirstlane((int)wi_));
+        if (wi >= nwork) break;
         const int64_t w = LEVEL == 0 ? wi : (int64_t)worklist[wi];
         const int64_t s0 = w * P.hop - P.skip;                          // input position of window sample 0
         const int64_t o0 = w * P.hop;
