@@ -511,16 +511,16 @@ void launch_adeclick(jt_ctx *h, const double *in, double *out, int64_t n, int sa
     P.lb = ((P.W + 2 * P.ar + 1) / 2 + 16 + 7) & ~7;
     const bool half_ok = P.lb < P.W && P.ar < P.lb / 4;
     auto sa_for = [&](bool half, int bs) { return ((half ? std::max(P.lb, bs * bs) : std::max(P.W, bs * bs)) + 1) & ~1; };
-    auto smem_for = [&](int sa, int fcap) {
-        return sizeof(double) * (size_t)(sa + 5 * (dk::BS + 1)) + sizeof(unsigned long long) * 2 * dk::NWORD + (size_t)fcap * 3 + 16 + (size_t)dk::BS * (dk::BS - 1);
+    auto smem_for = [&](int sa, int fcap, int bs) {
+        return sizeof(double) * (size_t)(sa + 5 * (dk::BS + 1)) + sizeof(unsigned long long) * 2 * dk::NWORD + (size_t)fcap * 3 + 16 + (size_t)bs * (bs - 1);
     };
     const int sa0 = sa_for(half_ok, LBS), sa1 = sa_for(half_ok, dk::BS), sa2 = sa_for(false, dk::BS);
-    const size_t sm0 = smem_for(sa0, LIGHT), sm1 = smem_for(sa1, MID), sm2 = smem_for(sa2, dk::MAXW);
+    const size_t sm0 = smem_for(sa0, LIGHT, LBS), sm1 = smem_for(sa1, MID, dk::BS), sm2 = smem_for(sa2, dk::MAXW, dk::BS);
     JT_REQUIRE(sm2 <= 64 * 1024, JT_E_UNSUPPORTED, "adeclick: window does not fit the per-wave LDS budget");
     const size_t per_wave = (size_t)P.W * dk::MAXAR + 3 * (size_t)P.W;
-    // 8 resident waves per CU: measured on the 60-min workload, 6 -> 44.5 ms, 8 -> 38.1 ms, 10 (the LDS limit) -> 36.8..41.5 ms
-    // run to run (slower sustained, less stable), so the grid is capped below what LDS would allow
-    int w0 = (int)std::min<size_t>(8, (160 * 1024) / sm0);
+    // resident waves per CU = what LDS admits (10 at the 44.1 kHz defaults).  With the windows handed out dynamically the time
+    // falls monotonically with residency on the 60-min workload: 6 -> 33.8 ms, 7 -> 30.7, 8 -> 28.5, 9 -> 27.6
+    int w0 = (int)std::min<size_t>(12, (160 * 1024) / sm0);
     const int w1 = (int)std::min<size_t>(8, (160 * 1024) / sm1), w2 = (int)std::min<size_t>(8, (160 * 1024) / sm2);
     if (const char *ev = getenv("JT_DK_WAVES")) w0 = std::max(1, std::min(w0, atoi(ev)));      // occupancy experiments
     const int64_t g0 = std::min<int64_t>(P.nwindows, (int64_t)256 * w0), g1 = std::min<int64_t>(P.nwindows, (int64_t)256 * w1),
