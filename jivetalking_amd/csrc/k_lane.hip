@@ -18,6 +18,12 @@
 constexpr int LANES = 64;
 constexpr int TW = 64;
 
+// wave-uniform: all LANES rows of the TW-column tile at `pos` lie inside [0, n)
+__device__ inline bool tile_interior(int64_t n, int64_t base0, int64_t rowstride, int64_t pos)
+{
+    return base0 + pos >= 0 && base0 + (int64_t)(LANES - 1) * rowstride + pos + TW <= n;
+}
+
 template <typename TIn, typename TL>
 __device__ inline void tile_load(TL (*tile)[TW + 1], const TIn *__restrict__ in, int64_t n,
                                  int64_t base0, int64_t rowstride, int64_t pos, int lane, int nrows)
@@ -25,6 +31,20 @@ __device__ inline void tile_load(TL (*tile)[TW + 1], const TIn *__restrict__ in,
     // Row loads are issued in batches of 16 with clamped (always valid) addresses and no branches, so the 16
     // HBM round trips overlap; out-of-range rows are zeroed by a select afterwards.
     constexpr int G = 16;
+    if (tile_interior(n, base0, rowstride, pos) && nrows == LANES) {
+        // every element of the tile exists (all but the first and last workgroups): no clamps, no selects, 64-bit address
+        // arithmetic only on the wave-uniform row base
+        const TIn *p = in + (base0 + pos) + lane;
+#pragma unroll 1
+        for (int r0 = 0; r0 < LANES; r0 += G) {
+            TIn v[G];
+#pragma unroll
+            for (int q = 0; q < G; ++q) v[q] = p[(int64_t)(r0 + q) * rowstride];
+#pragma unroll
+            for (int q = 0; q < G; ++q) tile[r0 + q][lane] = (TL)v[q];
+        }
+        return;
+    }
 #pragma unroll 1
     for (int r0 = 0; r0 < LANES; r0 += G) {
         TIn v[G];
@@ -49,6 +69,12 @@ __device__ inline void tile_store(TL (*tile)[TW + 1], TOut *__restrict__ out, in
                                   int64_t base0, int64_t rowstride, int64_t pos, int lane, int nrows,
                                   int64_t halo, int64_t chunk)
 {
+    if (nrows == LANES && pos >= halo && pos + TW <= halo + chunk && tile_interior(n, base0, rowstride, pos)) {
+        TOut *p = out + (base0 + pos) + lane;
+#pragma unroll 8
+        for (int r = 0; r < LANES; ++r) p[(int64_t)r * rowstride] = (TOut)tile[r][lane];
+        return;
+    }
 #pragma unroll 4
     for (int r = 0; r < nrows; ++r) {
         int64_t rel = pos + lane;                       // position inside lane r's [halo + chunk) run
@@ -63,6 +89,12 @@ template <typename TIn>
 __device__ inline void rows_prefetch(TIn (&v)[LANES], const TIn *__restrict__ in, int64_t n, int64_t base0, int64_t rowstride,
                                      int64_t pos, int lane)
 {
+    if (tile_interior(n, base0, rowstride, pos)) {
+        const TIn *p = in + (base0 + pos) + lane;
+#pragma unroll
+        for (int r = 0; r < LANES; ++r) v[r] = p[(int64_t)r * rowstride];
+        return;
+    }
 #pragma unroll
     for (int r = 0; r < LANES; ++r) {
         int64_t idx = base0 + (int64_t)r * rowstride + pos + lane;
@@ -74,6 +106,11 @@ template <typename TIn, typename TL>
 __device__ inline void rows_commit(TL (*tile)[TW + 1], const TIn (&v)[LANES], int64_t n, int64_t base0, int64_t rowstride,
                                    int64_t pos, int lane, int nrows)
 {
+    if (nrows == LANES && tile_interior(n, base0, rowstride, pos)) {
+#pragma unroll
+        for (int r = 0; r < LANES; ++r) tile[r][lane] = (TL)v[r];
+        return;
+    }
 #pragma unroll
     for (int r = 0; r < LANES; ++r) {
         int64_t idx = base0 + (int64_t)r * rowstride + pos + lane;
