@@ -24,6 +24,65 @@ __device__ inline bool tile_interior(int64_t n, int64_t base0, int64_t rowstride
     return base0 + pos >= 0 && base0 + (int64_t)(LANES - 1) * rowstride + pos + TW <= n;
 }
 
+// Edge tiles: element (r, lane) sits at tile-relative index rel = r * rowstride + lane (32-bit) from the wave-uniform origin
+// base0 + pos; it exists when lo <= rel < hi.
+struct TileEdge { int lo, hi; };
+__device__ inline TileEdge tile_edge(int64_t n, int64_t base0, int64_t pos)
+{
+    const int64_t o = base0 + pos, big = (int64_t)1 << 30;
+    TileEdge e;
+    e.lo = (int)(-o < -big ? -big : (-o > big ? big : -o));
+    e.hi = (int)(n - o < -big ? -big : (n - o > big ? big : n - o));
+    return e;
+}
+
+// 16-byte row loads: a lane fetches E = 16 / sizeof(T) consecutive samples of one row, so a 64 x 64 tile takes 16 (f32) or 32 (f64)
+// load instructions per lane instead of 64.  A tile qualifies when it is 16-byte aligned and every row's TW-sample segment lies
+// either entirely inside [0, n) or entirely outside (rows outside load nothing and stage zeros) -- which, with chunk origins that
+// are multiples of TW, is every tile except the one that straddles the end of the signal.  The kernels' duration is set by their
+// slowest workgroup, and that used to be the first and the last one (clamped scalar loads); with this they stage like the rest.
+// v[k*E + e] = element (row k*RPL + lane/LPR, column (lane%LPR)*E + e).
+template <typename TIn> struct RowVec { static constexpr int E = 16 / (int)sizeof(TIn), LPR = TW / E, RPL = 64 / LPR, NLD = LANES / RPL; };
+// run-level (wave-uniform) test: every tile of rows starting at `in + base0` with this stride can use 16-byte loads
+template <typename TIn>
+__device__ inline bool rows_vec_aligned(const TIn *in, int64_t base0, int64_t rowstride)
+{
+    using RV = RowVec<TIn>;
+    return (rowstride % RV::E) == 0 && rowstride <= ((int64_t)1 << 24) && (reinterpret_cast<uintptr_t>(in + base0) & 15) == 0;
+}
+// elements outside [0, n) (or in rows >= nrows) come back as zeros; a vector that straddles the end of the signal is fetched
+// element by element, so nothing outside the caller's buffer is ever read
+template <typename TIn>
+__device__ inline void rows_prefetch_vec(TIn (&v)[LANES], const TIn *__restrict__ in, int64_t base0, int64_t rowstride, int64_t pos,
+                                         const TileEdge &eg, int nrows, int lane)
+{
+    using RV = RowVec<TIn>;
+    typedef TIn vecT __attribute__((ext_vector_type(RV::E)));
+    const int rs = (int)rowstride, col = (lane % RV::LPR) * RV::E;
+    const TIn *org = in + (base0 + pos);
+#pragma unroll
+    for (int k = 0; k < RV::NLD; ++k) {
+        const int row = k * RV::RPL + lane / RV::LPR, rel = row * rs + col;
+        vecT t = (vecT)(TIn)0;
+        if (row < nrows && rel >= eg.lo && rel + RV::E <= eg.hi) t = *reinterpret_cast<const vecT *>(org + rel);
+        else if (row < nrows && rel + RV::E > eg.lo && rel < eg.hi) {
+#pragma unroll
+            for (int e = 0; e < RV::E; ++e) if (rel + e >= eg.lo && rel + e < eg.hi) t[e] = org[rel + e];
+        }
+#pragma unroll
+        for (int e = 0; e < RV::E; ++e) v[k * RV::E + e] = t[e];
+    }
+}
+template <typename TIn, typename TL>
+__device__ inline void rows_commit_vec(TL (*tile)[TW + 1], const TIn (&v)[LANES], int lane)
+{
+    using RV = RowVec<TIn>;
+#pragma unroll
+    for (int k = 0; k < RV::NLD; ++k)
+#pragma unroll
+        for (int e = 0; e < RV::E; ++e) tile[k * RV::RPL + lane / RV::LPR][(lane % RV::LPR) * RV::E + e] = (TL)v[k * RV::E + e];
+}
+
 template <typename TIn, typename TL>
 __device__ inline void tile_load(TL (*tile)[TW + 1], const TIn *__restrict__ in, int64_t n,
                                  int64_t base0, int64_t rowstride, int64_t pos, int lane, int nrows)
@@ -31,6 +90,15 @@ __device__ inline void tile_load(TL (*tile)[TW + 1], const TIn *__restrict__ in,
     // Row loads are issued in batches of 16 with clamped (always valid) addresses and no branches, so the 16
     // HBM round trips overlap; out-of-range rows are zeroed by a select afterwards.
     constexpr int G = 16;
+    {
+        const TileEdge eg = tile_edge(n, base0, pos);
+        if (rows_vec_aligned(in, base0 + pos, rowstride)) {
+            TIn v[LANES];
+            rows_prefetch_vec<TIn>(v, in, base0, rowstride, pos, eg, nrows, lane);
+            rows_commit_vec<TIn, TL>(tile, v, lane);
+            return;
+        }
+    }
     if (tile_interior(n, base0, rowstride, pos) && nrows == LANES) {
         // every element of the tile exists (all but the first and last workgroups): no clamps, no selects, 64-bit address
         // arithmetic only on the wave-uniform row base
@@ -551,12 +619,7 @@ k_follow_states(const TIn *__restrict__ in, int64_t n, double att, double rel, i
     const int64_t my_base = base0 + (int64_t)lane * chunk;
     double s = 0.0;
     const int64_t total = halo + chunk;            // multiples of SC (hence of TW)
-    TIn v[LANES];
-    rows_prefetch<TIn>(v, in, n, base0, chunk, 0, lane);
-    for (int64_t pos = 0; pos < total; pos += TW) {
-        rows_commit<TIn, TIn>(tile, v, n, base0, chunk, pos, lane, nrows);
-        __syncthreads();
-        if (pos + TW < total) rows_prefetch<TIn>(v, in, n, base0, chunk, pos + TW, lane);
+    auto run_tile = [&](int64_t pos) {
         if (lane < nrows) {
             const int64_t t0 = my_base + pos;
             if (pos >= halo && ((pos - halo) % SC) == 0 && t0 < n) states[t0 / SC] = s;     // state BEFORE sample t0
@@ -576,6 +639,34 @@ k_follow_states(const TIn *__restrict__ in, int64_t n, double att, double rel, i
                 }
             }
         }
+    };
+    if (rows_vec_aligned(in, base0, chunk)) {
+        // 16-byte row loads, two tiles in flight (one wave per CU: nobody else hides the HBM round trip); the first and the last
+        // workgroup take this path too, their out-of-range rows simply load nothing
+        TIn va[LANES], vb[LANES];
+        rows_prefetch_vec<TIn>(va, in, base0, chunk, 0, tile_edge(n, base0, 0), nrows, lane);
+        rows_prefetch_vec<TIn>(vb, in, base0, chunk, TW, tile_edge(n, base0, TW), nrows, lane);
+        for (int64_t pos = 0; pos < total; pos += 2 * TW) {              // total is a multiple of SC = 4 TW
+            rows_commit_vec<TIn, TIn>(tile, va, lane);
+            __syncthreads();
+            if (pos + 2 * TW < total) rows_prefetch_vec<TIn>(va, in, base0, chunk, pos + 2 * TW, tile_edge(n, base0, pos + 2 * TW), nrows, lane);
+            run_tile(pos);
+            __syncthreads();
+            rows_commit_vec<TIn, TIn>(tile, vb, lane);
+            __syncthreads();
+            if (pos + 3 * TW < total) rows_prefetch_vec<TIn>(vb, in, base0, chunk, pos + 3 * TW, tile_edge(n, base0, pos + 3 * TW), nrows, lane);
+            run_tile(pos + TW);
+            __syncthreads();
+        }
+        return;
+    }
+    TIn v[LANES];
+    rows_prefetch<TIn>(v, in, n, base0, chunk, 0, lane);
+    for (int64_t pos = 0; pos < total; pos += TW) {
+        rows_commit<TIn, TIn>(tile, v, n, base0, chunk, pos, lane, nrows);
+        __syncthreads();
+        if (pos + TW < total) rows_prefetch<TIn>(v, in, n, base0, chunk, pos + TW, lane);
+        run_tile(pos);
         __syncthreads();
     }
 }
