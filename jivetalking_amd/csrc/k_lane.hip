@@ -764,7 +764,9 @@ static void run_follow(const TIn *in, int64_t n, double att, double rel, double 
     int64_t halo = 4096;
     if (rho < 1.0 && rho > 0.0) halo = std::max<int64_t>(halo, (int64_t)std::ceil(18.0 / rho));   // 18 time constants ~ 1.5e-8
     halo = (halo + SC - 1) / SC * SC;
-    int64_t chunk = std::max<int64_t>(4096, (halo / 4 + SC - 1) / SC * SC);
+    // chunk = halo / 8: a lane runs halo + chunk samples, so shorter chunks cut the serial length (halo/4 -> +2 ms, halo/8 best,
+    // halo/16 no better: the extra lanes re-read the halo and the launch becomes bandwidth-bound)
+    int64_t chunk = std::max<int64_t>(1024, (halo / 8 + SC - 1) / SC * SC);
     int64_t nchunks = (n + chunk - 1) / chunk;
     hipLaunchKernelGGL((k_follow_states<TIn>), dim3((unsigned)((nchunks + LANES - 1) / LANES)), dim3(LANES), 0, s, in, n, att, rel, chunk, halo,
                        states, nchunks);
