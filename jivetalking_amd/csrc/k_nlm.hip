@@ -15,7 +15,8 @@
 //   under the cut the weight stage is skipped and the output is the input sample (what FFmpeg computes: (0 + x) / (0 + 1)).
 //   When engaged, the per-output sums over the 2S offsets are a lane-local sum of 3 terms followed by a DPP row/bank
 //   reduction over the 64 lanes (deterministic, but not FFmpeg's sequential order: results agree to f32 round-off of the
-//   weighted mean).  LDS per wave: the pair's input window (7.8 KB @48 kHz).  HBM traffic: 1 read (+ halo) and 1 write per
+//   weighted mean).  LDS per wave: the pair's input window, stored interleaved {hop A, hop B} so a packed operand is one
+//   8-byte read (11 KB @48 kHz).  HBM traffic: 1 read (+ halo) and 1 write per
 //   sample.
 // k_anlmdn (generic path, any K/S): one workgroup per hop, one thread per offset, weights transposed through an LDS tile and
 //   summed in FFmpeg's sequential offset order.
@@ -50,7 +51,7 @@ constexpr bool NLM_SMEM_CENTRE = false;          // centre samples by scalar loa
 // Four consecutive uniform ("centre") samples of both hops starting at tile-relative position x: one scalar x4 load per hop
 // from global memory in the interior (wave-uniform address), LDS broadcast reads at the file edges (zero-padded window).
 template <bool INTERIOR>
-__device__ inline void nlm_centre4(const float *__restrict__ in, int64_t gbase, const float *fA, const float *fB, int x, int H, f2 (&c)[4])
+__device__ inline void nlm_centre4(const float *__restrict__ in, int64_t gbase, const f2 *fw, int x, int H, f2 (&c)[4])
 {
     if (INTERIOR) {
         const f4u a = *reinterpret_cast<const f4u *>(in + gbase + x);
@@ -58,15 +59,15 @@ __device__ inline void nlm_centre4(const float *__restrict__ in, int64_t gbase, 
         c[0] = f2{a.x, b.x}; c[1] = f2{a.y, b.y}; c[2] = f2{a.z, b.z}; c[3] = f2{a.w, b.w};
     } else {
 #pragma unroll
-        for (int u = 0; u < 4; ++u) c[u] = f2{fA[x + u], fB[x + u]};
+        for (int u = 0; u < 4; ++u) c[u] = fw[x + u];
     }
 }
 
 // One step of the patch-distance recurrence + the engagement test for both hops of the pair (v = unrolled position, ring
 // slot of offset q is (q + v) % R).  `first` = hop start (no recurrence update).
 template <int NOFF, int V, bool FIRST>
-__device__ inline void nlm_step(f2 (&cache)[NOFF], f2 (&hi)[NOFF + 1], f2 (&lo)[NOFF + 1], const f2 cm, const f2 cp, const float *pA,
-                                const float *pB, int i, int d0, int K, int S, int H, const float *fA, const float *fB,
+__device__ inline void nlm_step(f2 (&cache)[NOFF], f2 (&hi)[NOFF + 1], f2 (&lo)[NOFF + 1], const f2 cm, const f2 cp, const f2 *pw,
+                                int i, int d0, int K, int S, int H, const f2 *fw,
                                 float *__restrict__ out, int64_t hs, int64_t n, float sw, float smooth, float lut_scale,
                                 float neg_inv_scale_log2e, float dthr, int lane)
 {
@@ -80,9 +81,9 @@ __device__ inline void nlm_step(f2 (&cache)[NOFF], f2 (&hi)[NOFF + 1], f2 (&lo)[
         }
     }
     // refill the slot offset 0 just released with what offset NOFF-1 reads two steps ahead: f[i+2+d0+NOFF-1 (+K | -K-1)];
-    // pA/pB point at f[i0 + d0 + NOFF + 1] of the block so the offsets below are compile-time constants
-    hi[V % R] = f2{pA[V + K], pB[V + K]};
-    lo[V % R] = f2{pA[V - K - 1], pB[V - K - 1]};
+    // pw points at f[i0 + d0 + NOFF + 1] of the block so the offsets below are compile-time constants
+    hi[V % R] = pw[V + K];
+    lo[V % R] = pw[V - K - 1];
     float dmin = 3.0e38f;
 #pragma unroll
     for (int q = 0; q < NOFF; ++q) dmin = fminf(dmin, fminf(cache[q].x, cache[q].y));
@@ -106,7 +107,7 @@ __device__ inline void nlm_step(f2 (&cache)[NOFF], f2 (&hi)[NOFF + 1], f2 (&lo)[
             f2 wt;
             wt.x = w.x >= smooth ? 0.f : __builtin_amdgcn_exp2f(ex.x);
             wt.y = w.y >= smooth ? 0.f : __builtin_amdgcn_exp2f(ex.y);
-            Pxy = Pxy + wt * f2{fA[xc], fB[xc]};
+            Pxy = Pxy + wt * fw[xc];
             Qxy = Qxy + wt;
         }
         // after the two quad steps lane (4m + j) holds the quad sum of value j (j = 0..3: Px, Qx, Py, Qy), the row steps keep j
@@ -127,7 +128,7 @@ __device__ inline void nlm_step(f2 (&cache)[NOFF], f2 (&hi)[NOFF + 1], f2 (&lo)[
             const bool isA = lane == 61;
             if ((isA || lane == 63) && i - S < H) {
                 const int64_t o = hs + (i - S) + (isA ? 0 : H);
-                if (o >= 0 && o < n) out[o] = __fadd_rn(pnum, isA ? fA[i] : fB[i]) / __fadd_rn(z, 1.f);
+                if (o >= 0 && o < n) out[o] = __fadd_rn(pnum, isA ? fw[i].x : fw[i].y) / __fadd_rn(z, 1.f);
             }
         }
     }
@@ -135,7 +136,7 @@ __device__ inline void nlm_step(f2 (&cache)[NOFF], f2 (&hi)[NOFF + 1], f2 (&lo)[
 
 template <int NOFF, bool INTERIOR>
 __device__ inline void nlm_pair_body(const float *__restrict__ in, float *__restrict__ out, int64_t n, int64_t hs, int64_t gwin,
-                                     const float *fA, const float *fB, int K, int S, int H, float sw, float smooth, float lut_scale,
+                                     const f2 *fw, int K, int S, int H, float sw, float smooth, float lut_scale,
                                      float neg_inv_scale_log2e, int lane)
 {
     // Streams live in a ring of R = NOFF+1 packed registers: slot (v+q)%R is offset q at unrolled step v, and the spare slot
@@ -153,25 +154,25 @@ __device__ inline void nlm_pair_body(const float *__restrict__ in, float *__rest
     {
         f2 st[R], ca[4], cb[4];
 #pragma unroll
-        for (int q = 0; q < R; ++q) { const int x = S + d0 + q - K; st[q] = f2{fA[x], fB[x]}; }   // slot NOFF = (offset NOFF-1, k = -K+1)
-        nlm_centre4<INTERIOR>(in, gbase, fA, fB, S - K, H, ca);
-        const float *pA = fA + S + d0 + (NOFF - 1) + 2 - K, *pB = pA + H;       // refill source of step k: p[k + K]
+        for (int q = 0; q < R; ++q) { const int x = S + d0 + q - K; st[q] = fw[x]; }   // slot NOFF = (offset NOFF-1, k = -K+1)
+        nlm_centre4<INTERIOR>(in, gbase, fw, S - K, H, ca);
+        const f2 *pw = fw + S + d0 + (NOFF - 1) + 2 - K;       // refill source of step k: p[k + K]
         for (int k0 = -K; k0 < K; k0 += 8) {
-            nlm_centre4<INTERIOR>(in, gbase, fA, fB, S + k0 + 4, H, cb);
+            nlm_centre4<INTERIOR>(in, gbase, fw, S + k0 + 4, H, cb);
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
 #pragma unroll
                 for (int q = 0; q < NOFF; ++q) { const f2 dd = ca[u] - st[(q + u) % R]; cache[q] = cache[q] + dd * dd; }
-                st[u % R] = f2{pA[u], pB[u]};
+                st[u % R] = pw[u];
             }
-            nlm_centre4<INTERIOR>(in, gbase, fA, fB, S + k0 + 8, H, ca);
+            nlm_centre4<INTERIOR>(in, gbase, fw, S + k0 + 8, H, ca);
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
 #pragma unroll
                 for (int q = 0; q < NOFF; ++q) { const f2 dd = cb[u] - st[(q + u) % R]; cache[q] = cache[q] + dd * dd; }
-                st[u % R] = f2{pA[4 + u], pB[4 + u]};
+                st[u % R] = pw[4 + u];
             }
-            pA += 8; pB += 8;
+            pw += 8;
         }
         // k = K, the (2K+1)-th term: 2K % 8 == 0 puts it at ring position 0 with its centre already in ca[0]
 #pragma unroll
@@ -181,32 +182,32 @@ __device__ inline void nlm_pair_body(const float *__restrict__ in, float *__rest
     f2 hi[R], lo[R];
 #pragma unroll
     for (int q = 0; q < R; ++q) {
-        const int xh = S + d0 + q + K; hi[q] = f2{fA[xh], fB[xh]};
-        const int xl = S + d0 + q - K - 1; lo[q] = f2{fA[xl], fB[xl]};         // first used at i = S+1 (front padding covers lane 0)
+        const int xh = S + d0 + q + K; hi[q] = fw[xh];
+        const int xl = S + d0 + q - K - 1; lo[q] = fw[xl];         // first used at i = S+1 (front padding covers lane 0)
     }
     const float dthr = (smooth / sw) * 1.000002f;          // cache >= dthr  =>  fl(cache*sw) >= smooth (the exact test follows)
     const f2 zero2 = f2{0.f, 0.f};
-    const float *pA = fA + S + d0 + NOFF + 1, *pB = pA + H;                       // p[v] = f[i0 + v + 2 + d0 + NOFF - 1], i0 = S
-    nlm_step<NOFF, 0, true>(cache, hi, lo, zero2, zero2, pA, pB, S, d0, K, S, H, fA, fB, out, hs, n, sw, smooth, lut_scale,
+    const f2 *pw = fw + S + d0 + NOFF + 1;                       // p[v] = f[i0 + v + 2 + d0 + NOFF - 1], i0 = S
+    nlm_step<NOFF, 0, true>(cache, hi, lo, zero2, zero2, pw, S, d0, K, S, H, fw, out, hs, n, sw, smooth, lut_scale,
                             neg_inv_scale_log2e, dthr, lane);
     // steps S+1 .. S+2K in blocks of 8 (2K % 8 == 0): v = 1..8, ring slot (v % R)
     f2 ma[4], pa[4], mb[4], pb[4];
-    nlm_centre4<INTERIOR>(in, gbase, fA, fB, S + 1 - K - 1, H, ma);
-    nlm_centre4<INTERIOR>(in, gbase, fA, fB, S + 1 + K, H, pa);
+    nlm_centre4<INTERIOR>(in, gbase, fw, S + 1 - K - 1, H, ma);
+    nlm_centre4<INTERIOR>(in, gbase, fw, S + 1 + K, H, pa);
     for (int i0 = S + 1; i0 < H + S; i0 += 8) {
-        pA = fA + i0 + d0 + NOFF + 1 - 1; pB = pA + H;                            // so that p[v], v = 1.., is step (i0 + v - 1)'s refill
-        nlm_centre4<INTERIOR>(in, gbase, fA, fB, i0 + 4 - K - 1, H, mb);
-        nlm_centre4<INTERIOR>(in, gbase, fA, fB, i0 + 4 + K, H, pb);
-        nlm_step<NOFF, 1, false>(cache, hi, lo, ma[0], pa[0], pA, pB, i0 + 0, d0, K, S, H, fA, fB, out, hs, n, sw, smooth, lut_scale, neg_inv_scale_log2e, dthr, lane);
-        nlm_step<NOFF, 2, false>(cache, hi, lo, ma[1], pa[1], pA, pB, i0 + 1, d0, K, S, H, fA, fB, out, hs, n, sw, smooth, lut_scale, neg_inv_scale_log2e, dthr, lane);
-        nlm_step<NOFF, 3, false>(cache, hi, lo, ma[2], pa[2], pA, pB, i0 + 2, d0, K, S, H, fA, fB, out, hs, n, sw, smooth, lut_scale, neg_inv_scale_log2e, dthr, lane);
-        nlm_step<NOFF, 4, false>(cache, hi, lo, ma[3], pa[3], pA, pB, i0 + 3, d0, K, S, H, fA, fB, out, hs, n, sw, smooth, lut_scale, neg_inv_scale_log2e, dthr, lane);
-        nlm_centre4<INTERIOR>(in, gbase, fA, fB, i0 + 8 - K - 1, H, ma);
-        nlm_centre4<INTERIOR>(in, gbase, fA, fB, i0 + 8 + K, H, pa);
-        nlm_step<NOFF, 5, false>(cache, hi, lo, mb[0], pb[0], pA, pB, i0 + 4, d0, K, S, H, fA, fB, out, hs, n, sw, smooth, lut_scale, neg_inv_scale_log2e, dthr, lane);
-        nlm_step<NOFF, 6, false>(cache, hi, lo, mb[1], pb[1], pA, pB, i0 + 5, d0, K, S, H, fA, fB, out, hs, n, sw, smooth, lut_scale, neg_inv_scale_log2e, dthr, lane);
-        nlm_step<NOFF, 7, false>(cache, hi, lo, mb[2], pb[2], pA, pB, i0 + 6, d0, K, S, H, fA, fB, out, hs, n, sw, smooth, lut_scale, neg_inv_scale_log2e, dthr, lane);
-        nlm_step<NOFF, 8, false>(cache, hi, lo, mb[3], pb[3], pA, pB, i0 + 7, d0, K, S, H, fA, fB, out, hs, n, sw, smooth, lut_scale, neg_inv_scale_log2e, dthr, lane);
+        pw = fw + i0 + d0 + NOFF + 1 - 1;                            // so that p[v], v = 1.., is step (i0 + v - 1)'s refill
+        nlm_centre4<INTERIOR>(in, gbase, fw, i0 + 4 - K - 1, H, mb);
+        nlm_centre4<INTERIOR>(in, gbase, fw, i0 + 4 + K, H, pb);
+        nlm_step<NOFF, 1, false>(cache, hi, lo, ma[0], pa[0], pw, i0 + 0, d0, K, S, H, fw, out, hs, n, sw, smooth, lut_scale, neg_inv_scale_log2e, dthr, lane);
+        nlm_step<NOFF, 2, false>(cache, hi, lo, ma[1], pa[1], pw, i0 + 1, d0, K, S, H, fw, out, hs, n, sw, smooth, lut_scale, neg_inv_scale_log2e, dthr, lane);
+        nlm_step<NOFF, 3, false>(cache, hi, lo, ma[2], pa[2], pw, i0 + 2, d0, K, S, H, fw, out, hs, n, sw, smooth, lut_scale, neg_inv_scale_log2e, dthr, lane);
+        nlm_step<NOFF, 4, false>(cache, hi, lo, ma[3], pa[3], pw, i0 + 3, d0, K, S, H, fw, out, hs, n, sw, smooth, lut_scale, neg_inv_scale_log2e, dthr, lane);
+        nlm_centre4<INTERIOR>(in, gbase, fw, i0 + 8 - K - 1, H, ma);
+        nlm_centre4<INTERIOR>(in, gbase, fw, i0 + 8 + K, H, pa);
+        nlm_step<NOFF, 5, false>(cache, hi, lo, mb[0], pb[0], pw, i0 + 4, d0, K, S, H, fw, out, hs, n, sw, smooth, lut_scale, neg_inv_scale_log2e, dthr, lane);
+        nlm_step<NOFF, 6, false>(cache, hi, lo, mb[1], pb[1], pw, i0 + 5, d0, K, S, H, fw, out, hs, n, sw, smooth, lut_scale, neg_inv_scale_log2e, dthr, lane);
+        nlm_step<NOFF, 7, false>(cache, hi, lo, mb[2], pb[2], pw, i0 + 6, d0, K, S, H, fw, out, hs, n, sw, smooth, lut_scale, neg_inv_scale_log2e, dthr, lane);
+        nlm_step<NOFF, 8, false>(cache, hi, lo, mb[3], pb[3], pw, i0 + 7, d0, K, S, H, fw, out, hs, n, sw, smooth, lut_scale, neg_inv_scale_log2e, dthr, lane);
     }
 }
 
@@ -219,30 +220,31 @@ k_anlmdn_pair(const float *__restrict__ in, float *__restrict__ out, int64_t n, 
     const int H = 2 * K + 1;
     const int NW = H + 2 * (K + S);
     const int NW2 = NW + H;                        // two consecutive hops share one window
-    const int NWP = NLM_PADF + NW2 + NLM_PADB;
-    float *win = smem_nlm;                         // [NWP]
+    const int NWP = NLM_PADF + NW + NLM_PADB;
+    // the window is stored INTERLEAVED: entry x = {f[x], f[x + H]} = the same position of hop A and hop B, so every packed operand
+    // of the loops below is one 8-byte LDS read instead of two 4-byte reads and two moves
+    f2 *win = reinterpret_cast<f2 *>(smem_nlm);    // [NWP]
     const int lane = threadIdx.x;
     const int64_t hopA = (int64_t)blockIdx.x * 2;
     const int64_t hs = hopA * H - (K + S);         // first output sample of hop A
     const int64_t gwin = hs - (K + S);             // global index of f[-K] of hop A
     for (int w = lane; w < NWP; w += 64) {
-        int64_t k = gwin - NLM_PADF + w;
-        win[w] = (k >= 0 && k < n) ? in[k] : 0.f;
+        const int64_t k = gwin - NLM_PADF + w, k2 = k + H;
+        win[w] = f2{(k >= 0 && k < n) ? in[k] : 0.f, (k2 >= 0 && k2 < n) ? in[k2] : 0.f};
     }
     __syncthreads();
-    const float *fA = win + NLM_PADF + K;          // f[i], i in [-K, NW-K)
-    const float *fB = fA + H;
+    const f2 *fw = win + NLM_PADF + K;             // fw[i] = {f[i], f[i + H]}, i in [-K, NW-K)
     // default output = input (every offset skipped); outputs with contributing offsets are overwritten from inside the loop.
     // The fence orders the two stores to the same address (they come from different lanes of this wave).
     for (int t = lane; t < 2 * H; t += 64) {
         const int64_t o = hs + t;
-        if (o >= 0 && o < n) out[o] = fA[t + S];
+        if (o >= 0 && o < n) out[o] = t < H ? fw[t + S].x : fw[t - H + S].y;
     }
     __threadfence();
     const float nisl = -1.4426950408889634f / lut_scale;
     const bool interior = gwin - NLM_PADF >= 0 && gwin + NW2 + NLM_PADB <= n;
-    if (interior && NLM_SMEM_CENTRE) nlm_pair_body<NOFF, true>(in, out, n, hs, gwin, fA, fB, K, S, H, sw, smooth, lut_scale, nisl, lane);
-    else nlm_pair_body<NOFF, false>(in, out, n, hs, gwin, fA, fB, K, S, H, sw, smooth, lut_scale, nisl, lane);
+    if (interior && NLM_SMEM_CENTRE) nlm_pair_body<NOFF, true>(in, out, n, hs, gwin, fw, K, S, H, sw, smooth, lut_scale, nisl, lane);
+    else nlm_pair_body<NOFF, false>(in, out, n, hs, gwin, fw, K, S, H, sw, smooth, lut_scale, nisl, lane);
 }
 
 // ------------------------------------------------------------------ generic path (any K, S)
@@ -330,7 +332,7 @@ void launch_anlmdn(const float *in, float *out, int64_t n, int K, int S, float s
     const bool fast = (2 * S) == 192 && K % 4 == 0;          // 48 kHz defaults: 64 lanes x 3 adjacent offsets, 2K a multiple of 8
     if (fast) {
         const int NW2 = NW + H;
-        size_t smem = sizeof(float) * (size_t)(NLM_PADF + NW2 + NLM_PADB);
+        size_t smem = sizeof(float) * 2 * (size_t)(NLM_PADF + NW + NLM_PADB);      // interleaved {hop A, hop B} window
         JT_REQUIRE(smem <= 64 * 1024, JT_E_UNSUPPORTED, "anlmdn: window exceeds the wave-per-hop LDS budget");
         const unsigned grid = (unsigned)((nhops + 1) / 2);
         hipLaunchKernelGGL((k_anlmdn_pair<3>), dim3(grid), dim3(64), smem, s, in, out, n, K, S, sw, smooth, lut_scale, nhops);
