@@ -308,3 +308,37 @@ def test_deesser_enabled_and_short_clip(engine, oracle):
     r2 = H.process_audio(engine)
     assert r2.input.has_speech_profile == 0 or r2.input.speech_profile.region.duration_ns > 0
     assert engine.download_s16(4).size == int(np.ceil(y.size * 147 / 160))
+
+
+def test_full_size_60_minute_file_properties(oracle):
+    """BASELINE configs[1] at its real size (60 min, 172.8 M samples), through size-independent properties: the output lands on
+    target when re-measured by the CPU oracle's ebur128 over the whole file; a second run gives the same bytes; the output
+    survives GPU FLAC encode -> GPU FLAC decode bit for bit with the right STREAMINFO MD5; only samples adeclick flagged may
+    differ between the limiter input and output path lengths (sample counts: M = ceil(N * 147 / 160))."""
+    import hashlib
+    import torch
+    from jivetalking_amd import Engine
+    sr, seconds = 48000, 3600.0
+    x = synth.speech_like_torch(seconds, sr, seed=1000, device="cuda:0")
+    n = x.numel()
+    e = Engine(0)
+    try:
+        e.attach_device_pcm(x.data_ptr(), n, sr, 1, keepalive=x)
+        r1 = H.process_audio(e)
+        out1 = e.download_s16(4)
+        assert out1.size == -(-n * 147 // 160)
+        r2 = H.process_audio(e)
+        out2 = e.download_s16(4)
+        assert np.array_equal(out1, out2) and r1.output_lufs == r2.output_lufs
+        # independent re-measurement of the whole file on the CPU
+        chk = oracle.ebur128(out1.astype(np.float64) / 32768.0, 44100, True, True)
+        assert abs(chk["integrated"] - (-16.0)) <= 0.1, chk["integrated"]
+        assert abs(chk["integrated"] - r1.output_lufs) < 0.01
+        assert 20 * np.log10(chk["true_peak"]) <= -1.0
+        # file legs at full size
+        img, info = e.flac_encode(4, md5=True, return_info=True)
+        assert info["frames"] == (out1.size + 4095) // 4096 and info["md5"] == hashlib.md5(out1.tobytes()).hexdigest()
+        back, _, meta = e.op_decode_audio(img)
+        assert np.array_equal(back[:, 0], out1.astype(np.int32)) and meta["flac_frames"] == info["frames"]
+    finally:
+        e.close()
