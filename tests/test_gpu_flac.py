@@ -329,3 +329,26 @@ def test_process_file_flac_and_wav_in_flac_out(tmp_path, oracle):
         assert ei.value.code == L.JT_E_INVAL
     finally:
         e.close()
+
+
+def test_metadata_blocks_of_every_kind_are_skipped(engine, oracle):
+    """Real files carry SEEKTABLE / VORBIS_COMMENT / PADDING / APPLICATION / PICTURE blocks between STREAMINFO and the audio; a
+    big PICTURE block full of sync-code look-alikes must not confuse the frame search (it starts after the metadata)."""
+    rng = np.random.default_rng(12)
+    x = coverage_signal(rng, 30000, 2, 16)
+    base = oracle.flac_encode(x, 44100, 16, 4096, 2 | 192, 8)
+    assert base[4] == 0x80 and base[5:8] == bytes([0, 0, 34])        # STREAMINFO is the only (last) block
+    streaminfo = bytes([0x00]) + base[5:8] + base[8:42]               # same block, "last" flag cleared
+    def block(kind, payload, last=False):
+        return bytes([kind | (0x80 if last else 0)]) + len(payload).to_bytes(3, "big") + payload
+    lookalike = bytes([0xff, 0xf8, 0xc9, 0x18, 0x00]) * 5000          # 25 kB of frame-header prefixes
+    blocks = (block(3, bytes(18 * 10)) +                              # SEEKTABLE with placeholder points
+              block(4, (4).to_bytes(4, "little") + b"test" + (0).to_bytes(4, "little")) +
+              block(2, b"ABCD" + bytes(60)) +                         # APPLICATION
+              block(6, lookalike) +                                   # PICTURE (opaque here)
+              block(1, bytes(8192), last=True))                       # PADDING, last
+    data = base[:4] + streaminfo + blocks + base[42:]
+    rc, ref, _ = oracle.flac_decode(data)
+    assert rc == 0 and np.array_equal(ref, x)
+    i32, _, meta = engine.op_decode_audio(data)
+    assert np.array_equal(i32, x) and meta["flac_candidates"] == meta["flac_frames"]
