@@ -12,6 +12,7 @@
 #include <functional>
 #include <chrono>
 #include <thread>
+#include <atomic>
 
 static double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 namespace {
@@ -1287,4 +1288,41 @@ extern "C" int jt_process_file(jt_ctx *h, const char *input_path, const jt_host_
     if (io_ms) io_ms[3] = now() - t;
     if (output_path && cap > 0) { strncpy(output_path, path, (size_t)cap - 1); output_path[cap - 1] = 0; }
     return JT_OK;
+}
+
+// ---------------------------------------------------------------- several files in flight on one GPU (pool.go:122-228)
+extern "C" int jt_process_files(int device, const char *const *paths, int n_files, int in_flight, const jt_host_config *base,
+                                int frame_samples, int flac_flags, jt_file_result *results)
+{
+    if (!paths || !results || n_files < 0 || in_flight < 1) return JT_E_INVAL;
+    for (int i = 0; i < n_files; ++i) { std::memset(&results[i], 0, sizeof results[i]); results[i].rc = JT_E_STATE; }
+    if (n_files == 0) return 0;
+    const int workers = std::min(in_flight, n_files);
+    std::atomic<int> next{0}, failed{0};
+    auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    auto worker = [&]() {
+        jt_ctx *h = nullptr;
+        const int orc = jt_open(device, &h);
+        for (;;) {
+            const int i = next.fetch_add(1);
+            if (i >= n_files) break;
+            jt_file_result &r = results[i];
+            const double t0 = now();
+            if (orc != JT_OK || !h) { r.rc = orc != JT_OK ? orc : JT_E_NOGPU; snprintf(r.error, sizeof r.error, "jt_open failed (%d)", r.rc); }
+            else if (!paths[i]) { r.rc = JT_E_INVAL; snprintf(r.error, sizeof r.error, "null path"); }
+            else {
+                r.rc = jt_process_file(h, paths[i], base, frame_samples, flac_flags, nullptr, nullptr, &r.result, r.output_path,
+                                       (int)sizeof r.output_path, nullptr);
+                if (r.rc != JT_OK) snprintf(r.error, sizeof r.error, "%s", jt_last_error(h));
+            }
+            r.wall_ms = now() - t0;
+            if (r.rc != JT_OK) failed.fetch_add(1);
+        }
+        if (h) jt_close(h);
+    };
+    std::vector<std::thread> th;
+    for (int k = 1; k < workers; ++k) th.emplace_back(worker);
+    worker();
+    for (auto &t : th) t.join();
+    return failed.load();
 }

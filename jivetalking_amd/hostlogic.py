@@ -112,7 +112,7 @@ HOST_SYMBOLS = ["jt_host_build_intervals", "jt_host_detect", "jt_host_finish_mea
                 "jt_process_audio", "jt_analyse_only", "jt_host_vad_detect", "jt_host_vad_split", "jt_host_vad_speech_runs",
                 "jt_host_vad_gap_tolerance", "jt_host_vad_gate_stats", "jt_host_vad_noise_seed",
                 "jt_host_vad_pick_low_cluster", "jt_host_vad_floored_fraction", "jt_host_sizeof",
-                "jt_host_lufs_filename_value", "jt_host_output_path", "jt_process_audio_cb", "jt_process_file"]
+                "jt_host_lufs_filename_value", "jt_host_output_path", "jt_process_audio_cb", "jt_process_file", "jt_process_files"]
 
 
 def lib():
@@ -211,6 +211,25 @@ def process_file(engine, input_path, base=None, frame_samples=4096, md5=True):
     if rc != 0:
         raise L.JtError(rc, l.jt_last_error(engine.h).decode())
     return res, out.value.decode(), list(io)
+
+
+class FileResult(C.Structure):
+    _fields_ = [("rc", C.c_int), ("error", C.c_char * 256), ("output_path", C.c_char * 1024), ("wall_ms", C.c_double),
+                ("result", ProcessResult)]
+
+
+def process_files(paths, device=0, in_flight=2, base=None, frame_samples=4096, md5=True):
+    """jt_process_files: at most `in_flight` files at a time on one GPU, one result per path (failures do not stop the others)."""
+    l = lib()
+    base = base or default_config()
+    n = len(paths)
+    arr = (C.c_char_p * n)(*[str(p).encode() for p in paths])
+    res = (FileResult * n)()
+    failed = l.jt_process_files(C.c_int(device), arr, C.c_int(n), C.c_int(in_flight), C.byref(base), C.c_int(frame_samples),
+                                C.c_int(1 if md5 else 0), res)
+    if failed < 0:
+        raise L.JtError(failed, "jt_process_files: bad arguments")
+    return failed, res
 
 
 def output_path(input_path, lufs_value):

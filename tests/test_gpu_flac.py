@@ -352,3 +352,32 @@ def test_metadata_blocks_of_every_kind_are_skipped(engine, oracle):
     assert rc == 0 and np.array_equal(ref, x)
     i32, _, meta = engine.op_decode_audio(data)
     assert np.array_equal(i32, x) and meta["flac_candidates"] == meta["flac_frames"]
+
+
+def test_process_files_pool_semantics(tmp_path, oracle):
+    """jt_process_files == the reference's bounded pool (pool.go:122-228): results per path, the same bytes as one file at a
+    time, and a file that cannot be opened fails alone."""
+    from jivetalking_amd import hostlogic
+    sr = 48000
+    paths = []
+    for k, seconds in enumerate((12.0, 7.5, 15.0)):
+        x = np.asarray(synth.speech_like(seconds, sr, seed=41 + k), np.float64)
+        pcm = np.clip(np.rint(x * 32768), -32768, 32767).astype(np.int16)
+        p = tmp_path / f"ep{k}.wav"
+        p.write_bytes(_wav(1, 16, 1, sr, pcm.astype("<i2").tobytes(), extra_chunks=False))
+        paths.append(p)
+    e = Engine()
+    try:
+        want = []
+        for p in paths:
+            res, out_path, _ = hostlogic.process_file(e, p)
+            want.append((res.output_lufs, open(out_path, "rb").read()))
+    finally:
+        e.close()
+    mixed = [paths[0], tmp_path / "nope.flac", paths[1], paths[2]]
+    failed, res = hostlogic.process_files(mixed, in_flight=3)
+    assert failed == 1 and res[1].rc == L.JT_E_INVAL and b"failed to open" in res[1].error
+    for i, j in ((0, 0), (2, 1), (3, 2)):
+        assert res[i].rc == 0 and res[i].result.output_lufs == want[j][0]
+        assert open(res[i].output_path.decode(), "rb").read() == want[j][1]
+        assert res[i].wall_ms > 0
