@@ -61,6 +61,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--minutes", type=float, default=60.0, help="audio minutes per file (BASELINE configs[1] = 60)")
     ap.add_argument("--cpu-sample", type=float, default=20.0, help="seconds of audio for the CPU oracle baseline (0 = skip)")
+    ap.add_argument("--rate", type=int, default=48000, help="input sample rate (BASELINE configs[4]: 96000)")
+    ap.add_argument("--channels", type=int, default=1, help="input channels, 1 or 2 (configs[4]: 2, down-mixed on the device)")
     ap.add_argument("--in-flight", type=int, default=1,
                     help="extra measurement (not `value`): K files per GPU processed concurrently, one context + host thread each "
                          "(BASELINE configs[3], throughput saturation); reported as `saturation`")
@@ -79,13 +81,16 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     from jivetalking_amd import Engine, synth, hostlogic, shard
-    sr = 48000
+    sr = args.rate
     seconds = args.minutes * 60.0
     x = synth.speech_like_torch(seconds, sr, seed=1000 + rank, device=f"cuda:{local_rank}")
     n = x.numel()
+    if args.channels == 2:
+        # second channel: the same talker 0.15 ms later and 2 dB down (interleaved L R L R ...)
+        x = torch.stack([x, 0.8 * torch.roll(x, 14)], dim=1).contiguous().view(-1)
     torch.cuda.synchronize()
     eng = Engine(local_rank)
-    eng.attach_device_pcm(x.data_ptr(), n, sr, 1, keepalive=x)
+    eng.attach_device_pcm(x.data_ptr(), n, sr, args.channels, keepalive=x)
 
     base = hostlogic.default_config()
 
@@ -180,7 +185,7 @@ def main():
             "value": round(value, 1), "unit": "xRT", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32/f64", "data": "synthetic",
-            "config": {"workload": f"1 x {args.minutes:g} min 48 kHz mono f32 PCM per GPU, full 4-pass pipeline, input resident in HBM",
+            "config": {"workload": f"1 x {args.minutes:g} min {sr / 1000:g} kHz {'stereo' if args.channels == 2 else 'mono'} f32 PCM per GPU, full 4-pass pipeline, input resident in HBM",
                        "files_per_gpu_per_step": 1, "adeclick": "on (t=1.7 w=55 o=50 m=s, the reference default)",
                        "adaptive": "full host mirror (VAD, speech election, AdaptConfig, band RMS) in C++",
                        "pass2_spec": res.pass2_spec.decode()},
