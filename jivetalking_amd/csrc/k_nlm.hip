@@ -6,7 +6,7 @@
 // seeded exactly at the hop start and then updated with two squared differences per step (a recurrence ALONG TIME for a
 // fixed offset); per output, weights exp(-d*sw) (via a 2^20-entry LUT) are accumulated across the offsets.
 //
-// k_anlmdn_pair (fast path, 2S = 192 and K % 4 == 0: the 48 kHz defaults):
+// k_anlmdn_pair (fast path, 2S = 192 or 384 and K % 4 == 0: the 48 kHz and 96 kHz defaults; three or six offsets per lane):
 //   ONE WAVE PER PAIR OF HOPS, no barriers.  Lane l owns 3 ADJACENT offsets, so the sample streams each offset consumes
 //   (f[j+K], f[j-K-1]) overlap between its offsets and between consecutive steps: per step a lane reads one new value per
 //   stream into a 4-slot register ring.  The two hops of the pair ride in the two halves of packed-f32 registers
@@ -43,6 +43,8 @@ __device__ inline float wave_sum63(float v)
 // all 2S offsets: the output is the input sample).  On speech at the reference's strength (s = 1e-5) that is the common
 // case, so the steady-state cost is the patch-distance recurrence alone: 2 sub, 2 mul, 2 add per offset, exact f32 order.
 typedef float f2 __attribute__((ext_vector_type(2)));
+// stream ring size for NOFF offsets per lane: at least NOFF + 1 slots (one value is fetched ahead) and a divisor of the 8-step unroll
+__host__ __device__ constexpr int nlm_ring(int noff) { return noff + 1 <= 4 ? 4 : 8; }
 
 typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
 constexpr int NLM_PADF = 4, NLM_PADB = 24;
@@ -66,12 +68,12 @@ __device__ inline void nlm_centre4(const float *__restrict__ in, int64_t gbase, 
 // One step of the patch-distance recurrence + the engagement test for both hops of the pair (v = unrolled position, ring
 // slot of offset q is (q + v) % R).  `first` = hop start (no recurrence update).
 template <int NOFF, int V, bool FIRST>
-__device__ inline void nlm_step(f2 (&cache)[NOFF], f2 (&hi)[NOFF + 1], f2 (&lo)[NOFF + 1], const f2 cm, const f2 cp, const f2 *pw,
+__device__ inline void nlm_step(f2 (&cache)[NOFF], f2 (&hi)[nlm_ring(NOFF)], f2 (&lo)[nlm_ring(NOFF)], const f2 cm, const f2 cp, const f2 *pw,
                                 int i, int d0, int K, int S, int H, const f2 *fw,
                                 float *__restrict__ out, int64_t hs, int64_t n, float sw, float smooth, float lut_scale,
                                 float neg_inv_scale_log2e, float dthr, int lane)
 {
-    constexpr int R = NOFF + 1;
+    constexpr int R = nlm_ring(NOFF);
     if (!FIRST) {
 #pragma unroll
         for (int q = 0; q < NOFF; ++q) {
@@ -81,7 +83,8 @@ __device__ inline void nlm_step(f2 (&cache)[NOFF], f2 (&hi)[NOFF + 1], f2 (&lo)[
         }
     }
     // refill the slot offset 0 just released with what offset NOFF-1 reads two steps ahead: f[i+2+d0+NOFF-1 (+K | -K-1)];
-    // pw points at f[i0 + d0 + NOFF + 1] of the block so the offsets below are compile-time constants
+    // pw points at f[i0 + d0 + R] of the block (the slot offset 0 just released takes the value R positions ahead) so the
+    // offsets below are compile-time constants
     hi[V % R] = pw[V + K];
     lo[V % R] = pw[V - K - 1];
     float dmin = 3.0e38f;
@@ -139,11 +142,11 @@ __device__ inline void nlm_pair_body(const float *__restrict__ in, float *__rest
                                      const f2 *fw, int K, int S, int H, float sw, float smooth, float lut_scale,
                                      float neg_inv_scale_log2e, int lane)
 {
-    // Streams live in a ring of R = NOFF+1 packed registers: slot (v+q)%R is offset q at unrolled step v, and the spare slot
+    // Streams live in a ring of R >= NOFF+1 packed registers (4 for three offsets per lane, 8 for six): slot (v+q)%R is offset q at unrolled step v, and the spare slot
     // already holds the value offset NOFF-1 needs at the NEXT step, so every LDS refill is issued more than a full step before
     // its first use; the wave-uniform centre samples arrive by scalar x4 loads issued 4 steps ahead (ping-pong A/B sets).
-    constexpr int R = NOFF + 1;
-    static_assert(R == 4, "the unrolled ring below is written for NOFF = 3");
+    constexpr int R = nlm_ring(NOFF);
+    static_assert(8 % R == 0 && R > NOFF, "the loops below advance 8 steps at a time: the ring must realign");
     const int j0 = lane * NOFF;
     const int d0 = j0 - S + (j0 >= S ? 1 : 0);
     const int64_t gbase = gwin + K;                       // global index of f[0] of hop A
@@ -156,7 +159,7 @@ __device__ inline void nlm_pair_body(const float *__restrict__ in, float *__rest
 #pragma unroll
         for (int q = 0; q < R; ++q) { const int x = S + d0 + q - K; st[q] = fw[x]; }   // slot NOFF = (offset NOFF-1, k = -K+1)
         nlm_centre4<INTERIOR>(in, gbase, fw, S - K, H, ca);
-        const f2 *pw = fw + S + d0 + (NOFF - 1) + 2 - K;       // refill source of step k: p[k + K]
+        const f2 *pw = fw + S + d0 + R - K;                    // refill source of step k: p[k + K] = position (step + R) of the ring
         for (int k0 = -K; k0 < K; k0 += 8) {
             nlm_centre4<INTERIOR>(in, gbase, fw, S + k0 + 4, H, cb);
 #pragma unroll
@@ -169,8 +172,8 @@ __device__ inline void nlm_pair_body(const float *__restrict__ in, float *__rest
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
 #pragma unroll
-                for (int q = 0; q < NOFF; ++q) { const f2 dd = cb[u] - st[(q + u) % R]; cache[q] = cache[q] + dd * dd; }
-                st[u % R] = pw[4 + u];
+                for (int q = 0; q < NOFF; ++q) { const f2 dd = cb[u] - st[(q + 4 + u) % R]; cache[q] = cache[q] + dd * dd; }
+                st[(4 + u) % R] = pw[4 + u];
             }
             pw += 8;
         }
@@ -187,7 +190,7 @@ __device__ inline void nlm_pair_body(const float *__restrict__ in, float *__rest
     }
     const float dthr = (smooth / sw) * 1.000002f;          // cache >= dthr  =>  fl(cache*sw) >= smooth (the exact test follows)
     const f2 zero2 = f2{0.f, 0.f};
-    const f2 *pw = fw + S + d0 + NOFF + 1;                       // p[v] = f[i0 + v + 2 + d0 + NOFF - 1], i0 = S
+    const f2 *pw = fw + S + d0 + R;                              // p[v] = f[S + d0 + R + v]
     nlm_step<NOFF, 0, true>(cache, hi, lo, zero2, zero2, pw, S, d0, K, S, H, fw, out, hs, n, sw, smooth, lut_scale,
                             neg_inv_scale_log2e, dthr, lane);
     // steps S+1 .. S+2K in blocks of 8 (2K % 8 == 0): v = 1..8, ring slot (v % R)
@@ -195,7 +198,7 @@ __device__ inline void nlm_pair_body(const float *__restrict__ in, float *__rest
     nlm_centre4<INTERIOR>(in, gbase, fw, S + 1 - K - 1, H, ma);
     nlm_centre4<INTERIOR>(in, gbase, fw, S + 1 + K, H, pa);
     for (int i0 = S + 1; i0 < H + S; i0 += 8) {
-        pw = fw + i0 + d0 + NOFF + 1 - 1;                            // so that p[v], v = 1.., is step (i0 + v - 1)'s refill
+        pw = fw + i0 + d0 + R - 1;                                   // so that p[v], v = 1.., is step (i0 + v - 1)'s refill
         nlm_centre4<INTERIOR>(in, gbase, fw, i0 + 4 - K - 1, H, mb);
         nlm_centre4<INTERIOR>(in, gbase, fw, i0 + 4 + K, H, pb);
         nlm_step<NOFF, 1, false>(cache, hi, lo, ma[0], pa[0], pw, i0 + 0, d0, K, S, H, fw, out, hs, n, sw, smooth, lut_scale, neg_inv_scale_log2e, dthr, lane);
@@ -329,13 +332,14 @@ void launch_anlmdn(const float *in, float *out, int64_t n, int K, int S, float s
     const int NW = H + 2 * (K + S);
     int64_t nhops = (n + (K + S) + H - 1) / H;
     const int noff = (2 * S) / 64;
-    const bool fast = (2 * S) == 192 && K % 4 == 0;          // 48 kHz defaults: 64 lanes x 3 adjacent offsets, 2K a multiple of 8
+    // 64 lanes x 3 adjacent offsets (48 / 44.1 kHz defaults) or x 6 (96 kHz), 2K a multiple of 8
+    const bool fast = ((2 * S) == 192 || (2 * S) == 384) && K % 4 == 0;
     if (fast) {
-        const int NW2 = NW + H;
         size_t smem = sizeof(float) * 2 * (size_t)(NLM_PADF + NW + NLM_PADB);      // interleaved {hop A, hop B} window
         JT_REQUIRE(smem <= 64 * 1024, JT_E_UNSUPPORTED, "anlmdn: window exceeds the wave-per-hop LDS budget");
         const unsigned grid = (unsigned)((nhops + 1) / 2);
-        hipLaunchKernelGGL((k_anlmdn_pair<3>), dim3(grid), dim3(64), smem, s, in, out, n, K, S, sw, smooth, lut_scale, nhops);
+        if (2 * S == 192) hipLaunchKernelGGL((k_anlmdn_pair<3>), dim3(grid), dim3(64), smem, s, in, out, n, K, S, sw, smooth, lut_scale, nhops);
+        else hipLaunchKernelGGL((k_anlmdn_pair<6>), dim3(grid), dim3(64), smem, s, in, out, n, K, S, sw, smooth, lut_scale, nhops);
         return;
     }
     int threads = ((2 * S + 63) / 64) * 64;

@@ -66,6 +66,19 @@ def test_anlmdn_speech_and_edges(engine, oracle):
     assert np.max(np.abs(engine.op_anlmdn(z, 44100) - oracle.anlmdn(z, 44100))) < 1e-5 * np.max(np.abs(z))
 
 
+def test_anlmdn_96k_six_offsets_per_lane(engine, oracle):
+    # 96 kHz: K = 576, S = 192 -> the hop-pair kernel with six offsets per lane and an 8-slot ring
+    z = speech(2.0, 6, 96000)
+    assert np.max(np.abs(engine.op_anlmdn(z, 96000) - oracle.anlmdn(z, 96000))) < 1e-5 * np.max(np.abs(z))
+    q = noise(96000, 10 ** (-66 / 20), 7)                             # engaged (weights active) almost everywhere
+    ref = oracle.anlmdn(q, 96000)
+    assert np.max(np.abs(ref - q)) > 1e-6
+    assert np.max(np.abs(engine.op_anlmdn(q, 96000) - ref)) < 1e-5 * np.max(np.abs(q))
+    for n in (1, 1152, 1153, 1154, 2689, 5000):
+        y = noise(n, 1e-3, n)
+        assert np.max(np.abs(engine.op_anlmdn(y, 96000) - oracle.anlmdn(y, 96000))) < 1e-8
+
+
 # ---------------------------------------------------------------- afftdn
 def test_afftdn_matches_oracle(engine, oracle):
     x = speech(10.0, 5)
