@@ -1167,6 +1167,10 @@ extern "C" int64_t jt_host_sizeof(int which)
     case 9: return sizeof(jt_loudnorm_apply);
     case 10: return sizeof(jt_analysis);
     case 11: return sizeof(jt_region_sample);
+    case 12: return sizeof(jt_flac_info);
+    case 13: return sizeof(jt_audio_meta);
+    case 14: return sizeof(jt_file_result);
+    case 15: return sizeof(jt_timers);
     }
     return -1;
 }

@@ -103,7 +103,8 @@ class ProcessResult(C.Structure):
 
 
 SIZEOF_IDS = {0: Interval, 1: Measurements, 2: HostConfig, 3: ProcessResult, 4: SpeechCandidate, 5: NoiseProfile,
-              6: LimiterDecision, 7: AdaptiveDiag, 8: L.FilterParams, 9: L.LoudnormApply, 10: L.Analysis, 11: L.RegionSample}
+              6: LimiterDecision, 7: AdaptiveDiag, 8: L.FilterParams, 9: L.LoudnormApply, 10: L.Analysis, 11: L.RegionSample,
+              12: L.FlacInfo, 13: L.AudioMeta, 15: L.Timers}
 
 HOST_SYMBOLS = ["jt_host_build_intervals", "jt_host_detect", "jt_host_finish_measurements", "jt_host_afftdn_band_edges",
                 "jt_host_default_config", "jt_host_adapt", "jt_host_filter_spec", "jt_host_filter_params",
@@ -230,6 +231,9 @@ def process_files(paths, device=0, in_flight=2, base=None, frame_samples=4096, m
     if failed < 0:
         raise L.JtError(failed, "jt_process_files: bad arguments")
     return failed, res
+
+
+SIZEOF_IDS[14] = FileResult
 
 
 def output_path(input_path, lufs_value):
