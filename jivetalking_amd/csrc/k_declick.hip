@@ -42,13 +42,17 @@ __device__ inline double dk_readlane(double v, int l)
     return __hiloint2double(hi, lo);
 }
 
-// Two instances of one kernel:
-//   light  <FCAP 512, BSD 33, HALF>:  the window's samples stream through LDS in two overlapping halves (every phase that reads them
-//          only looks AR samples around its position), the factorisation block is 33 x 33 (bands up to 32 rows): 15 KB of LDS per
-//          wave, 10 waves per CU.  A window with more than 512 flagged samples or a band wider than 32 rows appends itself to `heavy`;
-//   middle <FCAP 1024, BSD 49, HALF> redoes exactly those windows (list length read on the device), and <FCAP MAXW, BSD 49, full
-//          window resident> whatever is denser still.
-// stats: [0] repaired samples, [1] singular windows, [2] length of the heavy list.
+// Three capacity levels of one kernel:
+//   light  <FCAP 512, BSD 33, HALF, 0>: the window's samples stream through LDS in two overlapping halves (every phase that reads
+//          them only looks AR samples around its position), the factorisation ring is 33 x 33 (bands up to 32 rows): 16 KB of LDS
+//          per wave, 10 waves per CU.  A window with more than 512 flagged samples or a band wider than 32 rows appends itself to
+//          the first overflow list;
+//   middle <FCAP 1024, BSD 49, HALF, 1> redoes exactly those windows (list length read on the device) and overflows into the
+//          second list, which <FCAP MAXW, BSD 49, full window resident, 2> takes.
+// Windows (or list entries) are handed out by a device-side counter, not by a static stride: their cost varies with the number
+// of flagged samples.  The kernel is instruction-issue bound (SQ counters in profiles/r01_pmc_issue.txt), so its phases are written
+// for instruction count: one division per LDL^T pivot, carried ring positions, bit-parallel flag handling, packed factor rows.
+// stats: [0] repaired samples, [1] singular windows, [2] / [3] lengths of the two overflow lists, [12 + LEVEL] work counters.
 template <int FCAP, int BSD, bool HALF, int LEVEL>
 __global__ void __launch_bounds__(64)
 k_adeclick(const double *__restrict__ in, double *__restrict__ out, int64_t n, DeclickParams P, double *scratch,
