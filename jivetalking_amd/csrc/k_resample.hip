@@ -138,13 +138,21 @@ k_upsample32(const TIn *__restrict__ in, int64_t n, const TTap *__restrict__ ban
     const int64_t m_lo = (int64_t)blockIdx.x * 64 * R * QL * P;
     if (m_lo >= m_total) return;
     const int flush = MODE != 0;
-    for (int i = tid; i < nin; i += PP_THREADS) {
-        int64_t g = s0 - center + i;
-        TIn v = (TIn)0;
-        if (g < 0) g = -g;                                           // invert_initial_buffer(): in[-j] = in[j]
-        if (g < n) v = in[g];
-        else if (flush) { int64_t r = 2 * n - 1 - g; if (r >= 0 && r < n) v = in[r]; }   // resample_flush()
-        xin[skew(i)] = v;
+    // QL > 1 (step == 1): lane windows start QL samples apart, so an UNSKEWED tile read with 16-byte loads is conflict-free (each
+    // lane a distinct 16-byte segment); the skew only pays for the odd lane strides of the fractional ratios
+    constexpr bool VEC = QL * sizeof(TIn) == 16;
+    if (s0 - center >= 0 && s0 - center + nin <= n) {
+        const TIn *src = in + (s0 - center);                         // interior workgroup: no reflection, no end of stream
+        for (int i = tid; i < nin; i += PP_THREADS) xin[VEC ? i : skew(i)] = src[i];
+    } else {
+        for (int i = tid; i < nin; i += PP_THREADS) {
+            int64_t g = s0 - center + i;
+            TIn v = (TIn)0;
+            if (g < 0) g = -g;                                       // invert_initial_buffer(): in[-j] = in[j]
+            if (g < n) v = in[g];
+            else if (flush) { int64_t r = 2 * n - 1 - g; if (r >= 0 && r < n) v = in[r]; }   // resample_flush()
+            xin[VEC ? i : skew(i)] = v;
+        }
     }
     if (MODE == 0 && tid < 8) slots[tid] = 0ull;
     __syncthreads();
@@ -163,7 +171,20 @@ k_upsample32(const TIn *__restrict__ in, int64_t n, const TTap *__restrict__ ban
         const int qq = (kc * 64 + lane) * QL;                       // first window of this lane (tile-relative q)
         const int si = off + step * qq;
         TAcc xw[WL];
-        {
+        if (VEC) {
+            // si = QL * window index: 16-byte aligned in the unskewed tile; the last vector reads up to QL - 1 staged words past
+            // the window (inside the tile's slack)
+            constexpr int E = 16 / (int)sizeof(TIn), NV = (WL + E - 1) / E;
+            typedef TIn vecT __attribute__((ext_vector_type(E)));
+            const vecT *vp = reinterpret_cast<const vecT *>(xin + si);
+#pragma unroll
+            for (int k = 0; k < NV; ++k) {
+                const vecT t = vp[k];
+#pragma unroll
+                for (int e = 0; e < E; ++e)
+                    if (k * E + e < WL) { const TAcc v = (TAcc)t[e]; xw[k * E + e] = MODE == 0 ? v : (TAcc)(v * (TAcc)in_scale); }
+            }
+        } else {
             const int sb = si & 31, base = si + (si >> 5);          // skew(si + i) = base + i + ((sb + i) >> 5)
 #pragma unroll
             for (int i = 0; i < WL; ++i) {
