@@ -171,14 +171,19 @@ k_adeclick(const double *__restrict__ in, double *__restrict__ out, int64_t n, D
                 const double rrev = rr[lane < i ? i - lane : 0];
                 const double arev = __shfl(areg, lane < i ? i - lane - 1 : 0, 64);
                 const double prod = lane < i ? __dmul_rn(areg, rrev) : 0.0;
+                // the sequential sum reads the products back as wave-uniform LDS broadcasts (one read per term instead of two
+                // v_readlane); the trip count is rounded up to 8 with the +0.0 of the lanes >= i, an exact identity because eps
+                // is never -0 (it starts at +0 and x + (-x) rounds to +0)
+                __builtin_amdgcn_wave_barrier();
+                if (lane < MAXAR) lvec[lane] = prod;
+                __builtin_amdgcn_wave_barrier();
                 double eps = 0.0;
-                {
-                    int j = 0;
-                    for (; j + 4 <= i; j += 4) {
-                        eps = __dadd_rn(eps, dk_readlane(prod, j)); eps = __dadd_rn(eps, dk_readlane(prod, j + 1));
-                        eps = __dadd_rn(eps, dk_readlane(prod, j + 2)); eps = __dadd_rn(eps, dk_readlane(prod, j + 3));
-                    }
-                    for (; j < i; ++j) eps = __dadd_rn(eps, dk_readlane(prod, j));
+                for (int j = 0; j < i; j += 8) {
+                    double t8[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) t8[u] = lvec[j + u];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) eps = __dadd_rn(eps, t8[u]);
                 }
                 eps = __dadd_rn(eps, rr[i + 1]);
                 const double ki = -eps / alpha;
@@ -439,14 +444,17 @@ k_adeclick(const double *__restrict__ in, double *__restrict__ out, int64_t n, D
                         // rows below 0 (last batch) run as empty rows: nt = 0, nothing is stored for them
                         const int nt = __builtin_amdgcn_readlane(ntr, q);
                         double v = dk_readlane(qr, q);
-                        const double term = __dmul_rn(Lr[q], sw);
-                        {
-                            int t = 0;
-                            for (; t + 4 <= nt; t += 4) {
-                                v = __dsub_rn(v, dk_readlane(term, t)); v = __dsub_rn(v, dk_readlane(term, t + 1));
-                                v = __dsub_rn(v, dk_readlane(term, t + 2)); v = __dsub_rn(v, dk_readlane(term, t + 3));
-                            }
-                            for (; t < nt; ++t) v = __dsub_rn(v, dk_readlane(term, t));
+                        // terms beyond the band are +0.0 (v - (+0) is exact for every v), read back as LDS broadcasts four at a time
+                        const double term = lane < nt ? __dmul_rn(Lr[q], sw) : 0.0;
+                        __builtin_amdgcn_wave_barrier();
+                        if (lane < MAXAR) lvec[lane] = term;
+                        __builtin_amdgcn_wave_barrier();
+                        for (int t = 0; t < nt; t += 4) {
+                            double t4[4];
+#pragma unroll
+                            for (int u = 0; u < 4; ++u) t4[u] = lvec[t + u];
+#pragma unroll
+                            for (int u = 0; u < 4; ++u) v = __dsub_rn(v, t4[u]);
                         }
                         // slide the window: lane t takes lane t-1's solution, lane 0 the new one
                         {
