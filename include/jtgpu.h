@@ -141,6 +141,11 @@ int jt_region_measure(jt_ctx *h, int stage, double start_s, double dur_s, jt_reg
 /* MeasureOutputRegions (analyser_output.go:276-317) measures the room-tone and the speech region of one output back to
  * back: both analyses in one call, one synchronisation.  A region with dur_s[i] <= 0 is skipped (out[i] zeroed). */
 int jt_region_measure_pair(jt_ctx *h, int stage, const double start_s[2], const double dur_s[2], jt_region_sample out[2]);
+/* Announces the regions MeasureOutputRegions will ask for BEFORE the stage's output exists: the next jt_pass2 (stage 2) /
+ * jt_pass4 (stage 4) then measures them in its own tail (same kernels, same arithmetic, no extra synchronisation), and a later
+ * jt_region_measure_pair with the identical stage / start_s / dur_s returns that stored result without device work.  The
+ * announcement is consumed by that one pass; any other request is measured on demand exactly as before. */
+int jt_region_prefetch(jt_ctx *h, int stage, const double start_s[2], const double dur_s[2]);
 
 /* ---- limiter prefix shared by Pass 3 and Pass 4 (normalise.go:446-465 buildPreLimiterPrefix) ---- */
 typedef struct {

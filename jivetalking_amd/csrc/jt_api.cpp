@@ -32,7 +32,7 @@ extern "C" int jt_open(int device_id, jt_ctx **out)
         JT_HIP(hipEventCreate(&h->ev0)); JT_HIP(hipEventCreate(&h->ev1));
         JT_HIP(hipEventCreate(&h->ev2)); JT_HIP(hipEventCreate(&h->ev3));
         JT_HIP(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < 8; ++i) {
             JT_HIP(hipStreamCreateWithFlags(&h->aux[i], hipStreamNonBlocking));
             JT_HIP(hipEventCreateWithFlags(&h->ev_join[i], hipEventDisableTiming));
         }
@@ -51,7 +51,7 @@ extern "C" void jt_close(jt_ctx *h)
     if (h->ev2) (void)hipEventDestroy(h->ev2);
     if (h->ev3) (void)hipEventDestroy(h->ev3);
     if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < 8; ++i) {
         if (h->aux[i]) { (void)hipStreamSynchronize(h->aux[i]); (void)hipStreamDestroy(h->aux[i]); }
         if (h->ev_join[i]) (void)hipEventDestroy(h->ev_join[i]);
     }
@@ -152,12 +152,14 @@ static SwrDev &get_swr(jt_ctx *h, int in_rate, int out_rate)
 }
 
 // start of a pass: size the pinned arena and the K-weighting scratch for everything the pass will stage (nothing in flight)
-static void pass_begin(jt_ctx *h, int64_t max_samples, int analyses)
+// (+ `extra_jobs` further analyses of at most `extra_samples` each: the announced output regions)
+static void pass_begin(jt_ctx *h, int64_t max_samples, int analyses, int64_t extra_samples = 0, int extra_jobs = 0)
 {
     ensure_twiddle(h, 2048); ensure_hann(h, 2048);
-    h->pin.begin(jt_arena_bytes_for(max_samples) * (size_t)std::max(1, analyses) + (4u << 20));
-    h->kw_begin((size_t)(max_samples / 512 + 1024) * 8 * (size_t)std::max(1, analyses));
-    h->as_begin(((size_t)(2u << 20) + (size_t)max_samples / 6) * (size_t)std::max(1, analyses));
+    const size_t na = (size_t)std::max(1, analyses), ne = (size_t)std::max(0, extra_jobs);
+    h->pin.begin(jt_arena_bytes_for(max_samples) * na + jt_arena_bytes_for(extra_samples) * ne + (4u << 20));
+    h->kw_begin((size_t)(max_samples / 512 + 1024) * 8 * na + ((size_t)(extra_samples / 512 + 1024) * 8 + (size_t)extra_samples / 128 + 16384) * ne);   // + the regions' own scratch
+    h->as_begin(((size_t)(2u << 20) + (size_t)max_samples / 6) * na + ((size_t)(2u << 20) + (size_t)extra_samples / 6) * ne);
     // the remaining analysis scratch is shared by jobs that are serialised on one stream; size it now, while nothing is queued
     h->d_scr1.ensure((size_t)(max_samples / 400 + 16));
     h->spec_hops.ensure((size_t)(max_samples / 512 + 16));
@@ -176,11 +178,15 @@ struct AnalysisJob {
     int64_t n = 0, nfull = 0, nhops = 0, nout = 0; int blk = 0, sr = 0; bool dualmono = false, want_astats = true, want_r128 = true, want_spec = true;
 };
 
-static void analysis_join(jt_ctx *h)
+// sets = 2: also the chains of the announced output regions (aux[4..7])
+static void analysis_join(jt_ctx *h, int sets = 1)
 {
     // later main-stream work (and the pass's final synchronisation of the main stream) orders after every chain
-    for (int i = 0; i < 4; ++i) { JT_HIP(hipEventRecord(h->ev_join[i], h->aux[i])); JT_HIP(hipStreamWaitEvent(h->stream, h->ev_join[i], 0)); }
+    for (int i = 0; i < 4 * sets; ++i) { JT_HIP(hipEventRecord(h->ev_join[i], h->aux[i])); JT_HIP(hipStreamWaitEvent(h->stream, h->ev_join[i], 0)); }
 }
+// where one analysis runs: the four streams aux[first .. first+3] and its block-true-peak / hop / histogram scratch (null = the
+// context's shared buffers, which serialise jobs on one stream set)
+struct AnalysisLanes { int first = 0; double *tp = nullptr; jt_spectral *hops = nullptr; unsigned long long *ehist = nullptr; };
 static void fork_aux(jt_ctx *h, int first, int last)
 {
     JT_HIP(hipEventRecord(h->ev_fork, h->stream));
@@ -188,23 +194,25 @@ static void fork_aux(jt_ctx *h, int first, int last)
 }
 
 // join = false: the caller queues more independent main-stream work first and calls analysis_join() itself
-static void analysis_enqueue(jt_ctx *h, const float *x, int64_t n, int sr, bool dualmono, int sel_blk, AnalysisJob *J, bool join = true)
+static void analysis_enqueue(jt_ctx *h, const float *x, int64_t n, int sr, bool dualmono, int sel_blk, AnalysisJob *J, bool join = true,
+                             const AnalysisLanes *ln = nullptr)
 {
     J->n = n; J->sr = sr; J->dualmono = dualmono;
     // fork: x is ready once everything queued on the main stream so far has run
-    hipStream_t a0 = h->aux[0], a1 = h->aux[1], a2 = h->aux[2], a3 = h->aux[3];
-    fork_aux(h, 0, 3);
-    if (J->want_astats) jt_astats_enqueue(h, x, n, sr, &J->as, a0, a1, a2);
+    const int f = ln ? ln->first : 0;
+    hipStream_t a0 = h->aux[f], a1 = h->aux[f + 1], a2 = h->aux[f + 2], a3 = h->aux[f + 3];
+    fork_aux(h, f, f + 3);
+    if (J->want_astats) jt_astats_enqueue(h, x, n, sr, &J->as, a0, a1, a2, ln ? ln->ehist : nullptr);
     if (J->want_r128) {
         const int blk = sr / 10; const int64_t nfull = n / blk;
         J->blk = blk; J->nfull = nfull;
         SwrDev &sw = get_swr(h, sr, 192000);
-        h->d_scr1.ensure((size_t)nfull + 2);
-        JT_HIP(hipMemsetAsync(h->d_scr1.p, 0, sizeof(double) * (nfull + 2), a3));
-        launch_true_peak_f32(x, n, sw.bank_d.p, sw.pl.phase_count, sw.pl.filter_length, sw.pl.center, sw.pl.step, blk, h->d_scr1.p, nfull + 1,
+        double *d_tp = ln && ln->tp ? ln->tp : (h->d_scr1.ensure((size_t)nfull + 2), h->d_scr1.p);
+        JT_HIP(hipMemsetAsync(d_tp, 0, sizeof(double) * (nfull + 2), a3));
+        launch_true_peak_f32(x, n, sw.bank_d.p, sw.pl.phase_count, sw.pl.filter_length, sw.pl.center, sw.pl.step, blk, d_tp, nfull + 1,
                              sw.out_len(n), a3);
         double *btp = h->pin.take<double>((size_t)nfull + 2);
-        JT_HIP(hipMemcpyAsync(btp, h->d_scr1.p, sizeof(double) * (nfull + 2), hipMemcpyDeviceToHost, a3));
+        JT_HIP(hipMemcpyAsync(btp, d_tp, sizeof(double) * (nfull + 2), hipMemcpyDeviceToHost, a3));
         J->btp = btp;
         // K-weighting rides behind the (short) noise-floor chain instead of behind the true-peak upsampler, the longest kernel
         jt_kweight_enqueue_f32(h, x, n, sr, blk, &J->kw, a1);
@@ -216,13 +224,13 @@ static void analysis_enqueue(jt_ctx *h, const float *x, int64_t n, int sr, bool 
         if (sel_blk > 0) nframes = n / sel_blk + ((n % sel_blk) ? 1 : 0);
         const int64_t nout = sel_blk > 0 ? nframes : nhops;
         J->nhops = nhops; J->nout = nout;
-        h->spec_hops.ensure((size_t)std::max<int64_t>(nout, 1));
-        launch_aspectralstats(x, n, sr, win, h->twiddle.p, h->hann.p, h->spec_hops.p, nhops, sel_blk, nframes, a2);
+        jt_spectral *d_hops = ln && ln->hops ? ln->hops : (h->spec_hops.ensure((size_t)std::max<int64_t>(nout, 1)), h->spec_hops.p);
+        launch_aspectralstats(x, n, sr, win, h->twiddle.p, h->hann.p, d_hops, nhops, sel_blk, nframes, a2);
         jt_spectral *hops = h->pin.take<jt_spectral>((size_t)std::max<int64_t>(nout, 1));
-        if (nout > 0) JT_HIP(hipMemcpyAsync(hops, h->spec_hops.p, sizeof(jt_spectral) * nout, hipMemcpyDeviceToHost, a2));
+        if (nout > 0) JT_HIP(hipMemcpyAsync(hops, d_hops, sizeof(jt_spectral) * nout, hipMemcpyDeviceToHost, a2));
         J->hops = hops;
     }
-    if (join) analysis_join(h);
+    if (join) analysis_join(h, f ? 2 : 1);
 }
 
 static void analysis_finish(const AnalysisJob &J, AnalysisHost *A)
@@ -351,6 +359,62 @@ static void trim_range(double start_s, double dur_s, int rate, int64_t total, in
     *s0 = a; *len = b - a;
 }
 
+// ---- output regions (MeasureOutputRegions, analyser_output.go:276-317): the analysis of up to two atrim'd ranges of a stage's s16
+// output.  Shared by jt_region_measure_pair (on demand) and the tails of Pass 2 / Pass 4 (regions announced by jt_region_prefetch).
+struct RegionJobs { AnalysisJob J[2]; int64_t s0[2] = {0, 0}, len[2] = {0, 0}; bool want[2] = {false, false}; };
+
+// false when a wanted region is empty after atrim's rounding (the on-demand call reports that as an error)
+static bool regions_resolve(const double start_s[2], const double dur_s[2], int rate, int64_t m, RegionJobs *R)
+{
+    for (int r = 0; r < 2; ++r) {
+        R->want[r] = dur_s[r] > 0 && start_s[r] >= 0;
+        R->s0[r] = R->len[r] = 0;
+        if (R->want[r]) { trim_range(start_s[r], dur_s[r], rate, m, &R->s0[r], &R->len[r]); if (R->len[r] <= 0) return false; }
+    }
+    return true;
+}
+// queues both analyses (after everything already queued on the main stream); the caller joins.  own_lanes: on the second stream
+// set with scratch of their own, so that they run beside a pass's full-length analysis instead of behind it
+static void regions_enqueue(jt_ctx *h, const int16_t *src, int rate, RegionJobs *R, bool own_lanes)
+{
+    h->region_f.ensure((size_t)(R->len[0] + R->len[1] + 1));
+    for (int r = 0; r < 2; ++r) if (R->want[r]) launch_s16_to_f32(src + R->s0[r], h->region_f.p + (r ? R->len[0] : 0), R->len[r], h->stream);
+    for (int r = 0; r < 2; ++r) {
+        if (!R->want[r]) continue;
+        AnalysisLanes ln;
+        if (own_lanes) {
+            const int64_t nfull = R->len[r] / (rate / 10), nout = nfull + 2;
+            const size_t hop_d = (sizeof(jt_spectral) * (size_t)nout + 7) / 8;
+            double *scr = h->kw_take((size_t)nfull + 2 + hop_d + 8192);
+            ln.first = 4; ln.tp = scr; ln.hops = reinterpret_cast<jt_spectral *>(scr + nfull + 2);
+            ln.ehist = reinterpret_cast<unsigned long long *>(scr + nfull + 2 + hop_d);
+        }
+        analysis_enqueue(h, h->region_f.p + (r ? R->len[0] : 0), R->len[r], rate, false, rate / 10, &R->J[r], false, own_lanes ? &ln : nullptr);
+    }
+}
+static void regions_finish(jt_ctx *h, int rate, const RegionJobs &R, jt_region_sample out[2])
+{
+    for (int r = 0; r < 2; ++r) {
+        std::memset(&out[r], 0, sizeof(out[r]));
+        if (!R.want[r]) continue;
+        jt_analysis a; std::memset(&a, 0, sizeof(a));
+        std::vector<jt_frame_meta> meta((size_t)(R.len[r] / (rate / 10) + 2));
+        analysis_complete(h, R.J[r], &a, meta.data(), (int64_t)meta.size());
+        out[r].rms_level = a.astats.rms_level; out[r].peak_level = a.astats.peak_level; out[r].crest_factor = a.astats.crest_factor;
+        out[r].spectral = a.spectral_mean;
+        out[r].momentary = a.r128.momentary; out[r].shortterm = a.r128.shortterm;
+        out[r].true_peak = a.r128.true_peak; out[r].sample_peak = a.r128.sample_peak;
+        out[r].frames = a.n_frames_meta;
+    }
+}
+// upper bound of an announced region's length at `rate` (pass_begin sizes the arenas before the output length is known)
+static int64_t region_slot_samples(const jt_ctx::RegionSlot &sl, int rate)
+{
+    double d = 0;
+    for (int r = 0; r < 2; ++r) if (sl.dur_s[r] > 0) d = std::max(d, sl.dur_s[r]);
+    return (int64_t)std::ceil(d * rate) + 4;
+}
+
 // ---------------------------------------------------------------- band RMS
 extern "C" int jt_band_rms(jt_ctx *h, double start_s, double dur_s, const double *lo_hz, const double *hi_hz,
                            int n_bands, double *out_db, int *ok)
@@ -472,7 +536,11 @@ extern "C" int jt_pass2(jt_ctx *h, const jt_filter_params *p, jt_analysis *out)
     std::memset(out, 0, sizeof(*out));
     JT_HIP(hipEventRecord(h->ev0, h->stream));
     const int64_t n = h->n; const int sr = h->sr;
-    pass_begin(h, n, 1);
+    const int out_rate = p->out_rate > 0 ? p->out_rate : 44100;
+    jt_ctx::RegionSlot &slot = h->region_slot[0];
+    slot.valid = false; h->region_slot[1].valid = false;            // both stage outputs are about to be replaced
+    const bool announced = slot.armed; slot.armed = false;
+    pass_begin(h, n, 1, announced ? region_slot_samples(slot, out_rate) : 0, announced ? 2 : 0);
     h->work_a.ensure((size_t)n); h->work_b.ensure((size_t)n);
     const float *cur = h->in_mono; float *nxt = h->work_a.p; float *oth = h->work_b.p;
     auto advance = [&]() { cur = nxt; std::swap(nxt, oth); };
@@ -496,14 +564,17 @@ extern "C" int jt_pass2(jt_ctx *h, const jt_filter_params *p, jt_analysis *out)
     check_cancel(h);
     AnalysisJob J;
     analysis_enqueue(h, cur, n, sr, true, sr / 10, &J, false);
-    const int out_rate = p->out_rate > 0 ? p->out_rate : 44100;
     run_resample_s16(h, cur, n, sr, out_rate, h->s16_p2, &h->m_p2);     // main stream, concurrent with the analysis chains
-    analysis_join(h);
+    RegionJobs RJ;
+    const bool regions = announced && regions_resolve(slot.start_s, slot.dur_s, out_rate, h->m_p2, &RJ);
+    if (regions) regions_enqueue(h, h->s16_p2.p, out_rate, &RJ, true);     // behind the resampler, on the second stream set
+    analysis_join(h, regions ? 2 : 1);
     h->out_rate = out_rate; h->m_p4 = 0;
     JT_HIP(hipEventRecord(h->ev1, h->stream));
     JT_HIP(hipEventSynchronize(h->ev1));
     check_cancel(h);
     analysis_complete(h, J, out, nullptr, 0);
+    if (regions) { regions_finish(h, out_rate, RJ, slot.out); slot.valid = true; }
     out->n_input_frames = 0;
     float ms = 0; JT_HIP(hipEventElapsedTime(&ms, h->ev0, h->ev1)); h->timers.pass2_ms = ms;
     if (nlm_timed) { JT_HIP(hipEventElapsedTime(&ms, h->ev2, h->ev3)); h->timers.nlm_ms = ms; h->timers.nlm_launches = 1; }
@@ -613,7 +684,10 @@ extern "C" int jt_pass4(jt_ctx *h, const jt_limiter_plan *lim, const jt_loudnorm
     JT_REQUIRE(linear, JT_E_UNSUPPORTED, "pass4: loudnorm would fall back to dynamic mode (not implemented on the GPU path)");
     const double gain = std::pow(10., offset_db / 20.);
     h->timers.declick_ms = 0; h->timers.declick_repaired = 0;
-    pass_begin(h, m, 2);
+    jt_ctx::RegionSlot &slot = h->region_slot[1];
+    slot.valid = false;
+    const bool announced = slot.armed; slot.armed = false;
+    pass_begin(h, m, 2, announced ? region_slot_samples(slot, rate) : 0, announced ? 2 : 0);
     h->f64_a.ensure((size_t)m); h->f64_b.ensure((size_t)m);
     double *sig = h->f64_a.p, *tmp = h->f64_b.p;
     const bool pre = lim && lim->needed && lim->pre_gain_db > 0;
@@ -652,7 +726,11 @@ extern "C" int jt_pass4(jt_ctx *h, const jt_limiter_plan *lim, const jt_loudnorm
     launch_f64_to_s16(sig, h->s16_p4.p, h->work_a.p, m, 1, h->stream);
     h->m_p4 = m;
     AnalysisJob J;
-    analysis_enqueue(h, h->work_a.p, m, rate, true, rate / 10, &J);
+    analysis_enqueue(h, h->work_a.p, m, rate, true, rate / 10, &J, false);
+    RegionJobs RJ;
+    const bool regions = announced && regions_resolve(slot.start_s, slot.dur_s, rate, m, &RJ);
+    if (regions) regions_enqueue(h, h->s16_p4.p, rate, &RJ, true);         // beside the full-length analysis
+    analysis_join(h, regions ? 2 : 1);
     JT_HIP(hipEventRecord(h->ev1, h->stream));
     JT_HIP(hipEventSynchronize(h->ev1));
     check_cancel(h);
@@ -686,6 +764,7 @@ extern "C" int jt_pass4(jt_ctx *h, const jt_limiter_plan *lim, const jt_loudnorm
     catch (...) { if (stats_thread.joinable()) stats_thread.join(); throw; }
     if (stats_thread.joinable()) stats_thread.join();
     if (stats_err) std::rethrow_exception(stats_err);
+    if (regions) { regions_finish(h, rate, RJ, slot.out); slot.valid = true; }
     float ms = 0; JT_HIP(hipEventElapsedTime(&ms, h->ev0, h->ev1)); h->timers.pass4_ms = ms;
     JT_API_END(h)
 }
@@ -693,6 +772,15 @@ extern "C" int jt_pass4(jt_ctx *h, const jt_limiter_plan *lim, const jt_loudnorm
 // ---------------------------------------------------------------- region re-measure
 // MeasureOutputRegions (analyser_output.go:276-317) measures the room-tone and the speech region of one output back to
 // back; jt_region_measure_pair enqueues both analyses and synchronises once.  A region with dur_s <= 0 is skipped (out zeroed).
+extern "C" int jt_region_prefetch(jt_ctx *h, int stage, const double start_s[2], const double dur_s[2])
+{
+    if (!h || !start_s || !dur_s || (stage != 2 && stage != 4)) { if (h) h->err = "region_prefetch: bad arguments"; return JT_E_INVAL; }
+    jt_ctx::RegionSlot &sl = h->region_slot[stage == 4];
+    sl.armed = true; sl.valid = false;
+    for (int r = 0; r < 2; ++r) { sl.start_s[r] = start_s[r]; sl.dur_s[r] = dur_s[r]; }
+    return JT_OK;
+}
+
 extern "C" int jt_region_measure_pair(jt_ctx *h, int stage, const double start_s[2], const double dur_s[2], jt_region_sample out[2])
 {
     JT_API_BEGIN(h)
@@ -700,31 +788,21 @@ extern "C" int jt_region_measure_pair(jt_ctx *h, int stage, const double start_s
     const int16_t *src = nullptr; int64_t m = 0;
     if (stage == 2) { src = h->s16_p2.p; m = h->m_p2; } else if (stage == 4) { src = h->s16_p4.p; m = h->m_p4; }
     JT_REQUIRE(src && m > 0, JT_E_STATE, "region_measure: stage output not on device");
-    const int rate = h->out_rate;
-    int64_t s0[2] = {0, 0}, len[2] = {0, 0}; bool want[2];
-    for (int r = 0; r < 2; ++r) {
-        std::memset(&out[r], 0, sizeof(out[r]));
-        want[r] = dur_s[r] > 0 && start_s[r] >= 0;
-        if (want[r]) { trim_range(start_s[r], dur_s[r], rate, m, &s0[r], &len[r]); JT_REQUIRE(len[r] > 0, JT_E_INVAL, "region_measure: empty region"); }
+    // measured by the stage's own pass (jt_region_prefetch)?
+    const jt_ctx::RegionSlot &sl = h->region_slot[stage == 4];
+    if (sl.valid && sl.start_s[0] == start_s[0] && sl.start_s[1] == start_s[1] && sl.dur_s[0] == dur_s[0] && sl.dur_s[1] == dur_s[1]) {
+        out[0] = sl.out[0]; out[1] = sl.out[1];
+        return JT_OK;
     }
-    pass_begin(h, std::max<int64_t>(len[0] + len[1], 1), 2);
-    h->region_f.ensure((size_t)(len[0] + len[1] + 1));
-    AnalysisJob J[2];
-    for (int r = 0; r < 2; ++r) if (want[r]) launch_s16_to_f32(src + s0[r], h->region_f.p + (r ? len[0] : 0), len[r], h->stream);
-    for (int r = 0; r < 2; ++r) if (want[r]) analysis_enqueue(h, h->region_f.p + (r ? len[0] : 0), len[r], rate, false, rate / 10, &J[r], false);
+    const int rate = h->out_rate;
+    RegionJobs RJ;
+    for (int r = 0; r < 2; ++r) std::memset(&out[r], 0, sizeof(out[r]));
+    JT_REQUIRE(regions_resolve(start_s, dur_s, rate, m, &RJ), JT_E_INVAL, "region_measure: empty region");
+    pass_begin(h, std::max<int64_t>(RJ.len[0] + RJ.len[1], 1), 2);
+    regions_enqueue(h, src, rate, &RJ, false);
     analysis_join(h);
     JT_HIP(hipStreamSynchronize(h->stream));
-    for (int r = 0; r < 2; ++r) {
-        if (!want[r]) continue;
-        jt_analysis a; std::memset(&a, 0, sizeof(a));
-        std::vector<jt_frame_meta> meta((size_t)(len[r] / (rate / 10) + 2));
-        analysis_complete(h, J[r], &a, meta.data(), (int64_t)meta.size());
-        out[r].rms_level = a.astats.rms_level; out[r].peak_level = a.astats.peak_level; out[r].crest_factor = a.astats.crest_factor;
-        out[r].spectral = a.spectral_mean;
-        out[r].momentary = a.r128.momentary; out[r].shortterm = a.r128.shortterm;
-        out[r].true_peak = a.r128.true_peak; out[r].sample_peak = a.r128.sample_peak;
-        out[r].frames = a.n_frames_meta;
-    }
+    regions_finish(h, rate, RJ, out);
     JT_API_END(h)
 }
 

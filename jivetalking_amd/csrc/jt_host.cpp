@@ -1091,18 +1091,21 @@ extern "C" int jt_process_audio_cb(jt_ctx *h, const jt_host_config *base, int fr
     // Pass 2
     jt_host_filter_spec(&eff, 2, out->pass2_spec, (int)sizeof(out->pass2_spec));
     jt_filter_params fp; jt_host_filter_params(&eff, &fp);
+    // MeasureOutputRegions' two ranges are known from Pass 1: announce them so that Pass 2 / Pass 4 measure them in their own tails
+    double reg_st[2] = {0, 0}, reg_du[2] = {0, 0};
+    if (m.has_noise_profile && m.noise_profile.duration_ns > 0) { reg_st[0] = secs_of(m.noise_profile.start_ns); reg_du[0] = secs_of(m.noise_profile.duration_ns); }
+    if (m.has_speech_profile && m.speech_profile.region.duration_ns > 0) { reg_st[1] = secs_of(m.speech_profile.region.start_ns); reg_du[1] = secs_of(m.speech_profile.region.duration_ns); }
+    const bool have_regions = reg_du[0] > 0 || reg_du[1] > 0;
+    if (have_regions) jt_region_prefetch(h, 2, reg_st, reg_du);
     double t0 = now_ms();
     if ((rc = jt_pass2(h, &fp, &out->filtered)) != JT_OK) return rc;
     out->pass_ms[1] = h->timers.pass2_ms;
     out->stage_ms[4] = now_ms() - t0; t0 = now_ms();
     emit(2, "Processing", 1.0, dur, &m, nullptr, nullptr, nullptr);
     auto measure_regions = [&](int stage, jt_region_sample *rt, jt_region_sample *sp) {
-        double st[2] = {0, 0}, du[2] = {0, 0};
-        if (m.has_noise_profile && m.noise_profile.duration_ns > 0) { st[0] = secs_of(m.noise_profile.start_ns); du[0] = secs_of(m.noise_profile.duration_ns); }
-        if (m.has_speech_profile && m.speech_profile.region.duration_ns > 0) { st[1] = secs_of(m.speech_profile.region.start_ns); du[1] = secs_of(m.speech_profile.region.duration_ns); }
-        if (du[0] <= 0 && du[1] <= 0) return;
+        if (!have_regions) return;
         jt_region_sample o[2];
-        if (jt_region_measure_pair(h, stage, st, du, o) == JT_OK) { if (du[0] > 0) *rt = o[0]; if (du[1] > 0) *sp = o[1]; }
+        if (jt_region_measure_pair(h, stage, reg_st, reg_du, o) == JT_OK) { if (reg_du[0] > 0) *rt = o[0]; if (reg_du[1] > 0) *sp = o[1]; }
     };
     measure_regions(2, &out->filtered_room_tone, &out->filtered_speech);
     out->stage_ms[5] = now_ms() - t0; t0 = now_ms();
@@ -1134,6 +1137,7 @@ extern "C" int jt_process_audio_cb(jt_ctx *h, const jt_host_config *base, int fr
     jt_host_pass4_spec(&effcfg, &m3, offset, &out->limiter, h->out_rate, nullptr, out->pass4_spec, (int)sizeof(out->pass4_spec), &ap);
     emit(3, "Measuring", 1.0, dur, nullptr, nullptr, nullptr, nullptr);
     emit(4, "Normalising", 0.0, dur, nullptr, nullptr, nullptr, &out->limiter);
+    if (have_regions) jt_region_prefetch(h, 4, reg_st, reg_du);
     if ((rc = jt_pass4(h, &plan, &ap, &out->final_, &out->loudnorm)) != JT_OK) return rc;
     emit(4, "Normalising", 1.0, dur, nullptr, nullptr, nullptr, nullptr);
     out->pass_ms[3] = h->timers.pass4_ms;

@@ -183,7 +183,8 @@ struct AstatsJob {
     int nparts = 0, nf_parts = 0, nsig = 0; bool have_nf = false; int64_t n = 0;
 };
 // sA: reduce -> min/max -> runs; sB: noise floor; sC: exp-average sigma chain (three independent chains; pass the same stream to serialise)
-void jt_astats_enqueue(jt_ctx *h, const float *x, int64_t n, int sr, AstatsJob *job, hipStream_t sA, hipStream_t sB, hipStream_t sC);
+void jt_astats_enqueue(jt_ctx *h, const float *x, int64_t n, int sr, AstatsJob *job, hipStream_t sA, hipStream_t sB, hipStream_t sC,
+                       unsigned long long *ehist = nullptr);     // ehist: the job's own 8192-bin histogram (default: the shared one)
 void jt_astats_finish(const AstatsJob *job, jt_astats *out);
 struct KwJob { const double *hc = nullptr; int64_t nchunks = 0, nfull = 0; int m = 1; };
 void jt_kweight_enqueue_f32(jt_ctx *h, const float *in, int64_t n, int rate, int blk, KwJob *job, hipStream_t s);
@@ -198,8 +199,8 @@ struct jt_ctx {
     hipStream_t stream = nullptr;
     // auxiliary streams: the independent parts of an analysis (astats chains, true peak + K-weighting, spectral) are forked
     // onto them and joined back into `stream` with events, so latency-bound kernels overlap instead of queueing
-    hipStream_t aux[4] = {nullptr, nullptr, nullptr, nullptr};
-    hipEvent_t ev_fork = nullptr, ev_join[4] = {nullptr, nullptr, nullptr, nullptr};
+    hipStream_t aux[8] = {};                   // [0..3] the analysis chains of a pass, [4..7] the chains of announced output regions
+    hipEvent_t ev_fork = nullptr, ev_join[8] = {};
     std::string err;
     std::atomic<int> cancelled{0};
     // input
@@ -240,6 +241,9 @@ struct jt_ctx {
     }
     SwrDev swr[4]; int swr_next = 0;
     DevBuf<float> region_f;
+    // regions announced by jt_region_prefetch ([0] = stage 2, [1] = stage 4) and the results their pass stored
+    struct RegionSlot { bool armed = false, valid = false; double start_s[2] = {0, 0}, dur_s[2] = {0, 0}; jt_region_sample out[2]; };
+    RegionSlot region_slot[2];
     DevBuf<double> declick_scr; DevBuf<unsigned long long> declick_stats; DevBuf<int> declick_heavy;
     // FLAC output leg: frame records, byte offsets, summary, encoded frames; pinned host copies of the PCM (MD5) and the file
     DevBuf<unsigned char> fl_rec, fl_out; DevBuf<long long> fl_off; DevBuf<int16_t> fl_pcm;
@@ -257,7 +261,7 @@ struct jt_ctx {
 inline void jt_drain(jt_ctx *h)
 {
     if (h->stream) (void)hipStreamSynchronize(h->stream);
-    for (int i = 0; i < 4; ++i) if (h->aux[i]) (void)hipStreamSynchronize(h->aux[i]);
+    for (int i = 0; i < 8; ++i) if (h->aux[i]) (void)hipStreamSynchronize(h->aux[i]);
 }
 #define JT_API_END(h) } catch (const JtError &e) { jt_drain(h); (h)->err = e.msg; return e.code; } \
     catch (const std::exception &e) { jt_drain(h); (h)->err = e.what(); return JT_E_HIP; } return JT_OK;

@@ -383,7 +383,8 @@ size_t jt_arena_bytes_for(int64_t n)
                     + (size_t)(n / 512 + 64) * 16 + (size_t)(n / 800 + 64) * (sizeof(jt_spectral) + 64) + (1u << 20));
 }
 
-void jt_astats_enqueue(jt_ctx *h, const float *x, int64_t n, int sr, AstatsJob *job, hipStream_t sA, hipStream_t sB, hipStream_t sC)
+void jt_astats_enqueue(jt_ctx *h, const float *x, int64_t n, int sr, AstatsJob *job, hipStream_t sA, hipStream_t sB, hipStream_t sC,
+                       unsigned long long *ehist)
 {
     const double time_constant = 0.05;
     const double mult = std::exp((-1 / time_constant / sr));
@@ -403,8 +404,9 @@ void jt_astats_enqueue(jt_ctx *h, const float *x, int64_t n, int sr, AstatsJob *
     double *d_mm = reinterpret_cast<double *>(base + o_mm), *d_zs = reinterpret_cast<double *>(base + o_zs),
            *d_carry = reinterpret_cast<double *>(base + o_carry), *d_smin = reinterpret_cast<double *>(base + o_smin),
            *d_smax = reinterpret_cast<double *>(base + o_smax);
-    h->ehist.ensure(8192); h->ehist.zero(sA);
-    hipLaunchKernelGGL(k_as_reduce, dim3(nparts), dim3(AS_T), 0, sA, x, n, d_part, h->ehist.p);
+    if (ehist) JT_HIP(hipMemsetAsync(ehist, 0, sizeof(unsigned long long) * 8192, sA));
+    else { h->ehist.ensure(8192); h->ehist.zero(sA); ehist = h->ehist.p; }
+    hipLaunchKernelGGL(k_as_reduce, dim3(nparts), dim3(AS_T), 0, sA, x, n, d_part, ehist);
     hipLaunchKernelGGL(k_as_minmax, dim3(1), dim3(64), 0, sA, d_part, nparts, d_mm);
     hipLaunchKernelGGL(k_as_runs, dim3(nparts), dim3(AS_T), 0, sA, x, n, d_mm, d_runs);
     const bool have_nf = n >= tc;
@@ -437,7 +439,7 @@ void jt_astats_enqueue(jt_ctx *h, const float *x, int64_t n, int sr, AstatsJob *
     // one copy per chain, each covering the bytes that chain wrote (the chains may run on different streams)
     JT_HIP(hipMemcpyAsync(hb + o_part, base + o_part, o_nf - o_part, hipMemcpyDeviceToHost, sA));          // partials | runs
     JT_HIP(hipMemcpyAsync(hb + o_mm, base + o_mm, 16, hipMemcpyDeviceToHost, sA));
-    JT_HIP(hipMemcpyAsync(eh, h->ehist.p, sizeof(unsigned long long) * 8192, hipMemcpyDeviceToHost, sA));
+    JT_HIP(hipMemcpyAsync(eh, ehist, sizeof(unsigned long long) * 8192, hipMemcpyDeviceToHost, sA));
     if (have_nf) JT_HIP(hipMemcpyAsync(hb + o_nf, base + o_nf, o_mm - o_nf, hipMemcpyDeviceToHost, sB));
     JT_HIP(hipMemcpyAsync(hb + o_smin, base + o_smin, head - o_smin, hipMemcpyDeviceToHost, sC));
     job->hb = hb; job->eh = eh; job->o_part = o_part; job->o_runs = o_runs; job->o_nf = o_nf; job->o_smin = o_smin; job->o_smax = o_smax;

@@ -15,7 +15,7 @@
 #include "jt_internal.h"
 
 constexpr int PP_THREADS = 256;
-namespace d147 { constexpr int P = 147, STEP = 160, L = 36, RING = 40, SW = 32, NOUT = 64 * P, NIN = 64 * STEP; }
+namespace d147 { constexpr int P = 147, STEP = 160, L = 36, RING = 40, SW = 32, REACH = 224, NOUT = 64 * P, NIN = 64 * STEP; }
 
 __device__ inline int skew(int i) { return i + (i >> 5); }
 
@@ -30,7 +30,7 @@ k_polyphase(const TIn *__restrict__ in, int64_t n, const TTap *__restrict__ bank
 {
     if (skip_interior) {     // 48k -> 44.1k: interior blocks belong to k_down147 (same block geometry, same interior test)
         const int64_t s0i = (int64_t)blockIdx.x * d147::NIN, mlo = (int64_t)blockIdx.x * d147::NOUT;
-        if ((s0i - center >= 0) && (s0i - center + 63 * d147::STEP + 7 * d147::SW <= n) && (mlo + d147::NOUT <= m_total)) return;
+        if ((s0i - center >= 0) && (s0i - center + 63 * d147::STEP + d147::REACH <= n) && (mlo + d147::NOUT <= m_total)) return;
     }
     extern __shared__ unsigned char smem_pp[];
     TIn *xin = reinterpret_cast<TIn *>(smem_pp);            // staged in the input type (a 96 k -> 44.1 k tile is 20 k samples)
@@ -323,9 +323,14 @@ k_down147(const float *__restrict__ in, int64_t n, const double *__restrict__ ba
     const int64_t s0 = (int64_t)blockIdx.x * NIN;           // first input sample of the block's first period
     const int64_t m_lo = (int64_t)blockIdx.x * NOUT;
     // interior test (must match k_polyphase's complementary early-out): every staged read is inside [0, n) and every output exists
-    const bool interior = (s0 - center >= 0) && (s0 - center + 63 * STEP + 7 * SW <= n) && (m_lo + NOUT <= m_total);
+    const bool interior = (s0 - center >= 0) && (s0 - center + 63 * STEP + REACH <= n) && (m_lo + NOUT <= m_total);
     if (!interior) return;
-    const float *src = in + (s0 - center);                  // row r, relative index x  ->  src[r*STEP + x]
+    // row r, relative index x -> src[r*STEP + x].  Block-uniform bases with 32-bit lane offsets: the 32 staging loads (and stores)
+    // then share one scalar base instead of pinning 29 address pairs in VGPRs for the whole kernel
+    const float *src = in + (s0 - center);
+    int16_t *dst = out + m_lo;
+    const unsigned ioff = (unsigned)(lane >> 5) * STEP + (unsigned)(lane & 31);
+    const unsigned ooff = (unsigned)(lane >> 5) * P + (unsigned)(lane & 31);
     double ring[RING];
     int staged = -1;                                        // stage number currently in LDS (compile-time after unrolling)
     int have = 0;                                           // inputs [0, have) are in the ring (or were)
@@ -341,7 +346,8 @@ k_down147(const float *__restrict__ in, int64_t n, const double *__restrict__ ba
 #pragma unroll
                 for (int it = 0; it < 32; ++it) {
                     const int row = it * 2 + (lane >> 5), col = lane & 31;
-                    stage[row][col] = src[(int64_t)row * STEP + staged * SW + col];
+                    stage[row][col] = src[ioff + (unsigned)(it * 2 * STEP + staged * SW)];
+                    if (it % 16 == 15) __asm__ volatile("" ::: "memory");     // 16 loads in flight
                 }
                 __syncthreads();
             }
@@ -362,7 +368,8 @@ k_down147(const float *__restrict__ in, int64_t n, const double *__restrict__ ba
 #pragma unroll
             for (int it = 0; it < 32; ++it) {
                 const int row = it * 2 + (lane >> 5), col = lane & 31;
-                if (col < cnt) out[m_lo + (int64_t)row * P + g0 + col] = ostage[row][col];
+                if (col < cnt) dst[ooff + (unsigned)(it * 2 * P + g0)] = ostage[row][col];
+                if (it % 8 == 7) __asm__ volatile("" ::: "memory");
             }
             __syncthreads();
         }

@@ -139,6 +139,15 @@ class Engine:
         self._ck(self.lib.jt_region_measure(self.h, C.c_int(stage), C.c_double(start_s), C.c_double(dur_s), C.byref(r)))
         return _st2dict(r)
 
+    def region_prefetch(self, stage, starts, durs):
+        """Announce the two MeasureOutputRegions ranges before the stage's pass runs (jt_region_prefetch)."""
+        self._ck(self.lib.jt_region_prefetch(self.h, C.c_int(stage), (C.c_double * 2)(*starts), (C.c_double * 2)(*durs)))
+
+    def region_measure_pair(self, stage, starts, durs):
+        pair = (L.RegionSample * 2)()
+        self._ck(self.lib.jt_region_measure_pair(self.h, C.c_int(stage), (C.c_double * 2)(*starts), (C.c_double * 2)(*durs), pair))
+        return [_st2dict(pair[0]), _st2dict(pair[1])]
+
     def pass3(self, limiter=None, target_i=-16.0, target_tp=-1.0, target_lra=20.0):
         s = L.LoudnormStats()
         lim = limiter if limiter is not None else L.LimiterPlan(0, 0.0, 1.0)

@@ -198,6 +198,48 @@ def test_region_pair_equals_two_single_calls(engine, oracle):
         assert abs(one["rms_level"] - a["rms_level_db"]) < 1e-6
 
 
+def _same(a, b):
+    return a == b or (a != a and b != b)
+
+
+def test_announced_regions_equal_on_demand_measurement(engine):
+    """jt_region_prefetch: Pass 2 / Pass 4 measure the announced regions in their own tails; the stored samples are the ones an
+    on-demand jt_region_measure_pair produces (same kernels, same arithmetic), and other requests are still measured on demand."""
+    x = synth.speech_like(30.0, SR, seed=45)
+    engine.upload_pcm(x, SR, 1)
+    res = H.process_audio(engine)                      # the orchestration announces its regions: these came from the pass tails
+    m = res.input
+    st = [0.0, 0.0]; du = [0.0, 0.0]
+    if m.has_noise_profile and m.noise_profile.duration_ns > 0:
+        st[0] = float("%f" % (m.noise_profile.start_ns / 1e9)); du[0] = float("%f" % (m.noise_profile.duration_ns / 1e9))
+    if m.has_speech_profile and m.speech_profile.region.duration_ns > 0:
+        st[1] = float("%f" % (m.speech_profile.region.start_ns / 1e9)); du[1] = float("%f" % (m.speech_profile.region.duration_ns / 1e9))
+    assert du[0] > 0 or du[1] > 0
+    stored = {2: (res.filtered_room_tone, res.filtered_speech), 4: (res.final_room_tone, res.final_speech)}
+    for stage in (2, 4):
+        # a request that differs in the last digit is measured on demand; the single-region call never uses the stored pair
+        for k in range(2):
+            if du[k] <= 0:
+                continue
+            one = engine.region_measure(stage, st[k], du[k])
+            got = stored[stage][k]
+            assert one["frames"] == got.frames and one["frames"] > 0
+            for f in ("rms_level", "peak_level", "crest_factor", "momentary", "shortterm", "true_peak", "sample_peak"):
+                assert _same(one[f], getattr(got, f)), (stage, k, f)
+            for f in L.SPECTRAL_KEYS:
+                assert _same(one["spectral"][f], getattr(got.spectral, f)), (stage, k, f)
+    # announced, then asked for something else: measured on demand, and the announcement does not leak into a later pass
+    p2_before = engine.region_measure_pair(2, [1.0, 5.0], [2.0, 3.0])
+    engine.region_prefetch(2, [1.0, 5.0], [2.0, 3.0])
+    engine.region_prefetch(2, [1.5, 5.0], [2.0, 3.0])              # the last announcement wins
+    res2 = H.process_audio(engine)                                 # (announces its own regions again, replacing ours)
+    assert res2.filtered_speech.rms_level == res.filtered_speech.rms_level
+    p2_after = engine.region_measure_pair(2, [1.0, 5.0], [2.0, 3.0])
+    for a, b in zip(p2_before, p2_after):
+        assert all(_same(a[f], b[f]) for f in ("rms_level", "peak_level", "momentary", "true_peak", "frames"))
+        assert all(_same(a["spectral"][f], b["spectral"][f]) for f in L.SPECTRAL_KEYS)
+
+
 def test_two_runs_are_bit_identical(engine):
     x = synth.speech_like(20.0, SR, seed=43)
     engine.upload_pcm(x, SR, 1)

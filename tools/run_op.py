@@ -9,4 +9,5 @@ e = Engine(0)
 for _ in range(2):
     if op == "anlmdn": e.op_anlmdn(x, SR)
     elif op == "afftdn": e.op_afftdn(x, SR, 12.0, -55.0)
+    elif op == "resample": e.op_resample_s16(x, SR, 44100)
 print("done", op, x.size)
