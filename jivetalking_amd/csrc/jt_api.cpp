@@ -186,10 +186,11 @@ static void analysis_join(jt_ctx *h, int sets = 1)
 }
 // where one analysis runs: the four streams aux[first .. first+3] and its block-true-peak / hop / histogram scratch (null = the
 // context's shared buffers, which serialise jobs on one stream set)
-struct AnalysisLanes { int first = 0; double *tp = nullptr; jt_spectral *hops = nullptr; unsigned long long *ehist = nullptr; };
-static void fork_aux(jt_ctx *h, int first, int last)
+// `from`: the stream whose queued work produces the signal (null = the main stream)
+struct AnalysisLanes { int first = 0; double *tp = nullptr; jt_spectral *hops = nullptr; unsigned long long *ehist = nullptr; hipStream_t from = nullptr; };
+static void fork_aux(jt_ctx *h, int first, int last, hipStream_t from = nullptr)
 {
-    JT_HIP(hipEventRecord(h->ev_fork, h->stream));
+    JT_HIP(hipEventRecord(h->ev_fork, from ? from : h->stream));
     for (int i = first; i <= last; ++i) JT_HIP(hipStreamWaitEvent(h->aux[i], h->ev_fork, 0));
 }
 
@@ -201,7 +202,7 @@ static void analysis_enqueue(jt_ctx *h, const float *x, int64_t n, int sr, bool 
     // fork: x is ready once everything queued on the main stream so far has run
     const int f = ln ? ln->first : 0;
     hipStream_t a0 = h->aux[f], a1 = h->aux[f + 1], a2 = h->aux[f + 2], a3 = h->aux[f + 3];
-    fork_aux(h, f, f + 3);
+    fork_aux(h, f, f + 3, ln ? ln->from : nullptr);
     if (J->want_astats) jt_astats_enqueue(h, x, n, sr, &J->as, a0, a1, a2, ln ? ln->ehist : nullptr);
     if (J->want_r128) {
         const int blk = sr / 10; const int64_t nfull = n / blk;
@@ -361,7 +362,7 @@ static void trim_range(double start_s, double dur_s, int rate, int64_t total, in
 
 // ---- output regions (MeasureOutputRegions, analyser_output.go:276-317): the analysis of up to two atrim'd ranges of a stage's s16
 // output.  Shared by jt_region_measure_pair (on demand) and the tails of Pass 2 / Pass 4 (regions announced by jt_region_prefetch).
-struct RegionJobs { AnalysisJob J[2]; int64_t s0[2] = {0, 0}, len[2] = {0, 0}; bool want[2] = {false, false}; };
+struct RegionJobs { AnalysisJob J[2]; int64_t s0[2] = {0, 0}, len[2] = {0, 0}; bool want[2] = {false, false}; const int16_t *src[2] = {nullptr, nullptr}; };
 
 // false when a wanted region is empty after atrim's rounding (the on-demand call reports that as an error)
 static bool regions_resolve(const double start_s[2], const double dur_s[2], int rate, int64_t m, RegionJobs *R)
@@ -375,13 +376,16 @@ static bool regions_resolve(const double start_s[2], const double dur_s[2], int 
 }
 // queues both analyses (after everything already queued on the main stream); the caller joins.  own_lanes: on the second stream
 // set with scratch of their own, so that they run beside a pass's full-length analysis instead of behind it
-static void regions_enqueue(jt_ctx *h, const int16_t *src, int rate, RegionJobs *R, bool own_lanes)
+// src: the stage's s16 output; or null with R->src[r] = the first sample of region r (Pass 2 resamples its regions on `from`, a
+// stream of the second set, while the main stream still produces the full output)
+static void regions_enqueue(jt_ctx *h, const int16_t *src, int rate, RegionJobs *R, bool own_lanes, hipStream_t from = nullptr)
 {
     h->region_f.ensure((size_t)(R->len[0] + R->len[1] + 1));
-    for (int r = 0; r < 2; ++r) if (R->want[r]) launch_s16_to_f32(src + R->s0[r], h->region_f.p + (r ? R->len[0] : 0), R->len[r], h->stream);
+    for (int r = 0; r < 2; ++r)
+        if (R->want[r]) launch_s16_to_f32(src ? src + R->s0[r] : R->src[r], h->region_f.p + (r ? R->len[0] : 0), R->len[r], from ? from : h->stream);
     for (int r = 0; r < 2; ++r) {
         if (!R->want[r]) continue;
-        AnalysisLanes ln;
+        AnalysisLanes ln; ln.from = from;
         if (own_lanes) {
             const int64_t nfull = R->len[r] / (rate / 10), nout = nfull + 2;
             const size_t hop_d = (sizeof(jt_spectral) * (size_t)nout + 7) / 8;
@@ -564,10 +568,33 @@ extern "C" int jt_pass2(jt_ctx *h, const jt_filter_params *p, jt_analysis *out)
     check_cancel(h);
     AnalysisJob J;
     analysis_enqueue(h, cur, n, sr, true, sr / 10, &J, false);
-    run_resample_s16(h, cur, n, sr, out_rate, h->s16_p2, &h->m_p2);     // main stream, concurrent with the analysis chains
+    // announced output regions: their samples are resampled separately (the same tap sums as the full output's) on the second
+    // stream set, so that their analysis runs beside the output stage instead of after it
     RegionJobs RJ;
-    const bool regions = announced && regions_resolve(slot.start_s, slot.dur_s, out_rate, h->m_p2, &RJ);
-    if (regions) regions_enqueue(h, h->s16_p2.p, out_rate, &RJ, true);     // behind the resampler, on the second stream set
+    bool regions = false;
+    if (announced && sr != out_rate) {
+        SwrDev &sw = get_swr(h, sr, out_rate);
+        const int64_t m = sw.out_len(n);
+        regions = regions_resolve(slot.start_s, slot.dur_s, out_rate, m, &RJ);
+        if (regions) {
+            int64_t cap[2] = {0, 0};
+            for (int r = 0; r < 2; ++r) if (RJ.want[r]) cap[r] = jt_resample_range_cap(n, sw.pl.phase_count, sw.pl.filter_length, sw.pl.step, m, RJ.len[r]);
+            h->region_s16.ensure((size_t)(cap[0] + cap[1] + 1));
+            fork_aux(h, 4, 4);
+            for (int r = 0; r < 2; ++r) {
+                if (!RJ.want[r]) continue;
+                int16_t *dst = h->region_s16.p + (r ? cap[0] : 0);
+                RJ.src[r] = dst + launch_resample_range_to_s16(cur, n, sw.bank_d.p, sw.pl.phase_count, sw.pl.filter_length, sw.pl.center, sw.pl.step,
+                                                               m, RJ.s0[r], RJ.len[r], dst, cap[r], h->aux[4]);
+            }
+            regions_enqueue(h, nullptr, out_rate, &RJ, true, h->aux[4]);
+        }
+    }
+    run_resample_s16(h, cur, n, sr, out_rate, h->s16_p2, &h->m_p2);     // main stream, concurrent with the analysis chains
+    if (announced && sr == out_rate) {
+        regions = regions_resolve(slot.start_s, slot.dur_s, out_rate, h->m_p2, &RJ);
+        if (regions) regions_enqueue(h, h->s16_p2.p, out_rate, &RJ, true);
+    }
     analysis_join(h, regions ? 2 : 1);
     h->out_rate = out_rate; h->m_p4 = 0;
     JT_HIP(hipEventRecord(h->ev1, h->stream));

@@ -88,6 +88,9 @@ void launch_limiter_f64(const double *in, double *out, int64_t n, int sr, double
 // resampler / true peak
 void launch_resample_to_s16(const float *in, int64_t n, const double *bank, int phase_count, int filter_length, int center,
                             int64_t step, int16_t *out, int64_t m, hipStream_t s);
+int64_t launch_resample_range_to_s16(const float *in, int64_t n, const double *bank, int phase_count, int filter_length, int center,
+                                     int64_t step, int64_t m, int64_t m_first, int64_t m_count, int16_t *dst, int64_t dst_cap, hipStream_t s);
+int64_t jt_resample_range_cap(int64_t n, int phase_count, int filter_length, int64_t step, int64_t m, int64_t m_count);
 void launch_true_peak_f32(const float *in, int64_t n, const double *bank, int phase_count, int filter_length, int center,
                           int64_t step, int blk, double *block_tp, int64_t nblocks_alloc, int64_t m_total, hipStream_t s);
 void launch_true_peak_f64(const double *in, int64_t n, const double *bank, int phase_count, int filter_length, int center,
@@ -240,7 +243,7 @@ struct jt_ctx {
         double *r = d_scr0.p + kw_off; kw_off += (doubles + 7) & ~(size_t)7; return r;
     }
     SwrDev swr[4]; int swr_next = 0;
-    DevBuf<float> region_f;
+    DevBuf<float> region_f; DevBuf<int16_t> region_s16;
     // regions announced by jt_region_prefetch ([0] = stage 2, [1] = stage 4) and the results their pass stored
     struct RegionSlot { bool armed = false, valid = false; double start_s[2] = {0, 0}, dur_s[2] = {0, 0}; jt_region_sample out[2]; };
     RegionSlot region_slot[2];

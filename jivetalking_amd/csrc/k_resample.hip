@@ -18,6 +18,7 @@ constexpr int PP_THREADS = 256;
 namespace d147 { constexpr int P = 147, STEP = 160, L = 36, RING = 40, SW = 32, REACH = 224, NOUT = 64 * P, NIN = 64 * STEP; }
 
 __device__ inline int skew(int i) { return i + (i >> 5); }
+struct PPRemap { int64_t skip_lo, skip_n, out_base; };     // k_polyphase block remap (see the kernel); out_base: first output of the s16 destination
 
 // MODE 0: true peak (max |out| per 100 ms visibility block, streaming swr: outputs need all taps inside the input)
 // MODE 1: flush-mode resample -> s16 (av_clip_int16(lrint(x*32768))), staged in LDS for coalesced stores
@@ -26,10 +27,13 @@ template <typename TIn, typename TAcc, typename TTap, int MODE>
 __global__ void __launch_bounds__(PP_THREADS)
 k_polyphase(const TIn *__restrict__ in, int64_t n, const TTap *__restrict__ bank, int P, int L, int center, int64_t step,
             int64_t m_total, int R, double in_scale, int blk, unsigned long long *__restrict__ block_tp, int64_t nblocks_alloc,
-            int16_t *__restrict__ out_s16, TAcc *__restrict__ out_stream, int skip_interior)
+            int16_t *__restrict__ out_s16, TAcc *__restrict__ out_stream, int skip_interior, PPRemap rm)
 {
+    // block of the tiling this workgroup computes: launches that cover only part of it (the stream edges around k_down147's
+    // interior, or the blocks of one output range) skip `skip_n` blocks from `skip_lo` on
+    const int64_t bid = (int64_t)blockIdx.x < rm.skip_lo ? (int64_t)blockIdx.x : (int64_t)blockIdx.x + rm.skip_n;
     if (skip_interior) {     // 48k -> 44.1k: interior blocks belong to k_down147 (same block geometry, same interior test)
-        const int64_t s0i = (int64_t)blockIdx.x * d147::NIN, mlo = (int64_t)blockIdx.x * d147::NOUT;
+        const int64_t s0i = bid * d147::NIN, mlo = bid * d147::NOUT;
         if ((s0i - center >= 0) && (s0i - center + 63 * d147::STEP + d147::REACH <= n) && (mlo + d147::NOUT <= m_total)) return;
     }
     extern __shared__ unsigned char smem_pp[];
@@ -39,8 +43,8 @@ k_polyphase(const TIn *__restrict__ in, int64_t n, const TTap *__restrict__ bank
     int16_t *otile = reinterpret_cast<int16_t *>(smem_pp + (((size_t)(skew(nin) + 2) * sizeof(TIn) + 7) & ~(size_t)7));
     __shared__ unsigned long long slots[8];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int64_t s0 = (int64_t)blockIdx.x * T;
-    const int64_t m_lo = (int64_t)blockIdx.x * 64 * R * P;          // = s0 * P / step exactly
+    const int64_t s0 = bid * T;
+    const int64_t m_lo = bid * 64 * R * P;                          // = s0 * P / step exactly
     const int64_t nout = min((int64_t)64 * R * P, m_total - m_lo);
     if (nout <= 0) return;
     const int flush = MODE != 0;
@@ -111,7 +115,7 @@ k_polyphase(const TIn *__restrict__ in, int64_t n, const TTap *__restrict__ bank
             atomicMax(&block_tp[b], slots[tid]);
         }
     } else if (MODE == 1) {
-        for (int64_t i = tid; i < nout; i += PP_THREADS) out_s16[m_lo + i] = otile[i];
+        for (int64_t i = tid; i < nout; i += PP_THREADS) out_s16[m_lo - rm.out_base + i] = otile[i];
     }
 }
 
@@ -403,7 +407,7 @@ void launch_true_peak_f32(const float *in, int64_t n, const double *bank, int ph
     auto k = k_polyphase<float, double, double, 0>;
     JT_HIP(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)g.smem));
     hipLaunchKernelGGL(k, dim3(g.grid), dim3(PP_THREADS), g.smem, s, in, n, bank, phase_count, filter_length, center, step, m_total,
-                       g.R, 1.0, blk, (unsigned long long *)block_tp, nblocks_alloc, (int16_t *)nullptr, (double *)nullptr, 0);
+                       g.R, 1.0, blk, (unsigned long long *)block_tp, nblocks_alloc, (int16_t *)nullptr, (double *)nullptr, 0, PPRemap{0, 0, 0});
 }
 
 void launch_true_peak_f64(const double *in, int64_t n, const double *bank, int phase_count, int filter_length, int center,
@@ -417,7 +421,7 @@ void launch_true_peak_f64(const double *in, int64_t n, const double *bank, int p
     auto k = k_polyphase<double, double, double, 0>;
     JT_HIP(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)g.smem));
     hipLaunchKernelGGL(k, dim3(g.grid), dim3(PP_THREADS), g.smem, s, in, n, bank, phase_count, filter_length, center, step, m_total,
-                       g.R, 1.0, blk, (unsigned long long *)block_tp, nblocks_alloc, (int16_t *)nullptr, (double *)nullptr, 0);
+                       g.R, 1.0, blk, (unsigned long long *)block_tp, nblocks_alloc, (int16_t *)nullptr, (double *)nullptr, 0, PPRemap{0, 0, 0});
 }
 
 // f32 in (the dbl->flt->dbl rounded signal) -> DBLP resample -> s16
@@ -428,11 +432,48 @@ void launch_resample_to_s16(const float *in, int64_t n, const double *bank, int 
     PPGeom g = pp_geometry<float>(n, phase_count, filter_length, step, m, true);
     JT_REQUIRE(g.smem <= 150 * 1024, JT_E_UNSUPPORTED, "resample: rate ratio needs too large an LDS tile");
     const bool fast = phase_count == d147::P && step == d147::STEP && filter_length == d147::L && g.R == 1;
-    if (fast) hipLaunchKernelGGL(k_down147, dim3(g.grid), dim3(64), 0, s, in, n, bank, center, m, out);
+    // interior blocks [b_lo, b_hi) (the kernels' own test, solved for the block index) go to k_down147; k_polyphase is launched
+    // for the stream-edge blocks only (a full-grid launch of early-outs costs ~1 ms of an hour-long file's critical path)
+    int64_t b_lo = 0, b_hi = 0;
+    if (fast) {
+        b_lo = center > 0 ? (center + d147::NIN - 1) / d147::NIN : 0;
+        const int64_t lim_in = n + center - 63 * d147::STEP - d147::REACH;
+        b_hi = std::min<int64_t>(lim_in >= 0 ? lim_in / d147::NIN + 1 : 0, m / d147::NOUT);
+        b_hi = std::min<int64_t>(b_hi, g.grid);
+        if (b_hi <= b_lo) b_lo = b_hi = 0;
+    }
+    if (b_hi > b_lo) hipLaunchKernelGGL(k_down147, dim3((unsigned)b_hi), dim3(64), 0, s, in, n, bank, center, m, out);
     auto k = k_polyphase<float, double, double, 1>;
     JT_HIP(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)g.smem));
-    hipLaunchKernelGGL(k, dim3(g.grid), dim3(PP_THREADS), g.smem, s, in, n, bank, phase_count, filter_length, center, step, m,
-                       g.R, 1.0, 1, (unsigned long long *)nullptr, (int64_t)0, out, (double *)nullptr, fast ? 1 : 0);
+    hipLaunchKernelGGL(k, dim3((unsigned)(g.grid - (b_hi - b_lo))), dim3(PP_THREADS), g.smem, s, in, n, bank, phase_count, filter_length,
+                       center, step, m, g.R, 1.0, 1, (unsigned long long *)nullptr, (int64_t)0, out, (double *)nullptr, fast ? 1 : 0,
+                       PPRemap{b_lo, b_hi - b_lo, 0});
+}
+
+// The same resample restricted to the outputs [m_first, m_first + m_count) of the m-sample result (the announced output regions
+// of Pass 2): the k_polyphase blocks that cover the range write dst[0 ..), and the range starts at dst[return value].  Every
+// output is the same tap sum whichever kernel or block computes it, so these samples equal the full resample's bit for bit.
+int64_t launch_resample_range_to_s16(const float *in, int64_t n, const double *bank, int phase_count, int filter_length, int center,
+                                     int64_t step, int64_t m, int64_t m_first, int64_t m_count, int16_t *dst, int64_t dst_cap, hipStream_t s)
+{
+    PPGeom g = pp_geometry<float>(n, phase_count, filter_length, step, m, true);
+    JT_REQUIRE(g.smem <= 150 * 1024, JT_E_UNSUPPORTED, "resample: rate ratio needs too large an LDS tile");
+    const int64_t per_block = (int64_t)64 * g.R * phase_count;
+    const int64_t b_a = m_first / per_block, b_b = (m_first + m_count - 1) / per_block;
+    JT_REQUIRE(m_count > 0 && m_first >= 0 && m_first + m_count <= m && (b_b - b_a + 1) * per_block <= dst_cap, JT_E_INVAL, "resample range: bad range");
+    auto k = k_polyphase<float, double, double, 1>;
+    JT_HIP(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)g.smem));
+    hipLaunchKernelGGL(k, dim3((unsigned)(b_b - b_a + 1)), dim3(PP_THREADS), g.smem, s, in, n, bank, phase_count, filter_length,
+                       center, step, m, g.R, 1.0, 1, (unsigned long long *)nullptr, (int64_t)0, dst, (double *)nullptr, 0,
+                       PPRemap{0, b_a, b_a * per_block});
+    return m_first - b_a * per_block;
+}
+// destination samples launch_resample_range_to_s16 needs for a range of m_count outputs
+int64_t jt_resample_range_cap(int64_t n, int phase_count, int filter_length, int64_t step, int64_t m, int64_t m_count)
+{
+    PPGeom g = pp_geometry<float>(n, phase_count, filter_length, step, m, true);
+    const int64_t per_block = (int64_t)64 * g.R * phase_count;
+    return (m_count / per_block + 2) * per_block;
 }
 
 // Pass-3 streams at 192 kHz.  FLT variant (s16 in, no limiter prefix): swr int_sample_fmt FLTP = float taps, float
@@ -447,7 +488,7 @@ void launch_resample_stream_s16_f32(const int16_t *in, int64_t n, const float *b
     auto k = k_polyphase<int16_t, float, float, 2>;
     JT_HIP(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)g.smem));
     hipLaunchKernelGGL(k, dim3(g.grid), dim3(PP_THREADS), g.smem, s, in, n, bankf, phase_count, filter_length, center, step, m_total,
-                       g.R, 1.0 / 32768.0, 1, (unsigned long long *)nullptr, (int64_t)0, (int16_t *)nullptr, out, 0);
+                       g.R, 1.0 / 32768.0, 1, (unsigned long long *)nullptr, (int64_t)0, (int16_t *)nullptr, out, 0, PPRemap{0, 0, 0});
 }
 void launch_resample_stream_f64(const double *in, int64_t n, const double *bank, int phase_count, int filter_length, int center,
                                 int64_t step, int64_t m_total, double *out, hipStream_t s)
@@ -459,5 +500,5 @@ void launch_resample_stream_f64(const double *in, int64_t n, const double *bank,
     auto k = k_polyphase<double, double, double, 2>;
     JT_HIP(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)g.smem));
     hipLaunchKernelGGL(k, dim3(g.grid), dim3(PP_THREADS), g.smem, s, in, n, bank, phase_count, filter_length, center, step, m_total,
-                       g.R, 1.0, 1, (unsigned long long *)nullptr, (int64_t)0, (int16_t *)nullptr, out, 0);
+                       g.R, 1.0, 1, (unsigned long long *)nullptr, (int64_t)0, (int16_t *)nullptr, out, 0, PPRemap{0, 0, 0});
 }
