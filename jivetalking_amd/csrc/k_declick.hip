@@ -83,7 +83,6 @@ k_adeclick(const double *__restrict__ in, double *__restrict__ out, int64_t n, D
         }
     }
     auto fbit = [&](int pos) -> bool { return (fbits[pos >> 6] >> (pos & 63)) & 1ull; };
-    auto obit = [&](int pos) -> bool { return (obits[pos >> 6] >> (pos & 63)) & 1ull; };
     // global scratch of this wave: L[W][MAXAR] | D[W] | y[W] | rhs[W].  Written with plain stores, read back (by other lanes, after
     // a fence) with agent-scope relaxed loads, which bypass the CU's L1 and may be pipelined freely.
     double *gL = scratch + (size_t)blockIdx.x * scratch_per_wave;
@@ -113,7 +112,7 @@ k_adeclick(const double *__restrict__ in, double *__restrict__ out, int64_t n, D
     // windows are handed out by a device-side counter: their cost varies with the number of flagged samples, and waves that start
     // late (another stream's kernel holding LDS on their CU when the grid was placed) simply take fewer of them
     for (;;) {
-        unsigned long long wi_;
+        unsigned long long wi_ = 0;
         if (lane == 0) wi_ = atomicAdd(&stats[12 + LEVEL], 1ull);
         const int64_t wi = (int64_t)(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(wi_ >> 32)) << 32) |
                                      (unsigned)__builtin_amdgcn_readfirstlane((int)wi_));

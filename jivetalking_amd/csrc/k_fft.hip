@@ -363,7 +363,7 @@ k_afftdn(const float *__restrict__ in, float *__restrict__ out, int64_t n, Afftd
     int *band_s0 = seg_bmin + NSEG + 1;                       // first / last segment touching the band
     int *band_s1 = band_s0 + AF_MAXBANDS;
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
     const int A = d.A, W = d.W, nb = d.nbands;
     const int64_t t_lo = (int64_t)blockIdx.x * frames_per_chunk;
     const int64_t t_hi = min(t_lo + frames_per_chunk, nframes);

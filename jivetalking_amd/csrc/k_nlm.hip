@@ -331,7 +331,6 @@ void launch_anlmdn(const float *in, float *out, int64_t n, int K, int S, float s
     const int H = 2 * K + 1;
     const int NW = H + 2 * (K + S);
     int64_t nhops = (n + (K + S) + H - 1) / H;
-    const int noff = (2 * S) / 64;
     // 64 lanes x 3 adjacent offsets (48 / 44.1 kHz defaults) or x 6 (96 kHz), 2K a multiple of 8
     const bool fast = ((2 * S) == 192 || (2 * S) == 384) && K % 4 == 0;
     if (fast) {

@@ -240,6 +240,34 @@ def test_announced_regions_equal_on_demand_measurement(engine):
         assert all(_same(a["spectral"][f], b["spectral"][f]) for f in L.SPECTRAL_KEYS)
 
 
+def test_announced_regions_without_a_rate_change_and_empty_regions(engine):
+    """out_rate == input rate (no resampler: the regions are measured behind the output stage), a region that atrim leaves empty
+    (the pass must not fail; the on-demand call still reports it), and an announcement for a stage that is not run."""
+    from jivetalking_amd.engine import default_filter_params
+    x = synth.speech_like(12.0, SR, seed=46)
+    engine.upload_pcm(x, SR, 1)
+    p = default_filter_params(); p.out_rate = SR
+    st = [2.0, 6.5]; du = [1.5, 3.0]
+    engine.region_prefetch(2, st, du)
+    engine.pass2(p)
+    pair = engine.region_measure_pair(2, st, du)
+    for k in range(2):
+        one = engine.region_measure(2, st[k], du[k])
+        assert one["frames"] == pair[k]["frames"] > 0
+        assert all(_same(one[f], pair[k][f]) for f in ("rms_level", "peak_level", "crest_factor", "momentary", "true_peak", "sample_peak"))
+        assert all(_same(one["spectral"][f], pair[k]["spectral"][f]) for f in L.SPECTRAL_KEYS)
+    # a region past the end of the output: Pass 2 runs, nothing is stored, the explicit request fails as it always did
+    engine.region_prefetch(2, [1.0, 500.0], [1.0, 2.0])
+    engine.pass2(p)
+    with pytest.raises(L.JtError) as ei:
+        engine.region_measure_pair(2, [1.0, 500.0], [1.0, 2.0])
+    assert ei.value.code == L.JT_E_INVAL
+    ok = engine.region_measure_pair(2, [1.0, 0.0], [1.0, 0.0])          # the second region skipped (dur <= 0)
+    assert ok[0]["frames"] > 0 and ok[1]["frames"] == 0
+    with pytest.raises(L.JtError):
+        engine.region_prefetch(3, st, du)                                # only stages 2 and 4 have outputs
+
+
 def test_two_runs_are_bit_identical(engine):
     x = synth.speech_like(20.0, SR, seed=43)
     engine.upload_pcm(x, SR, 1)
