@@ -146,6 +146,13 @@ static SwrDev &get_swr(jt_ctx *h, int in_rate, int out_rate)
     e.bank_d.ensure(e.pl.bank.size()); e.bank_f.ensure(bf.size());
     JT_HIP(hipMemcpyAsync(e.bank_d.p, e.pl.bank.data(), sizeof(double) * e.pl.bank.size(), hipMemcpyHostToDevice, h->stream));
     JT_HIP(hipMemcpyAsync(e.bank_f.p, bf.data(), sizeof(float) * bf.size(), hipMemcpyHostToDevice, h->stream));
+    // s16 sources are scaled by 2^-15 before the taps (swr's s16 -> flt conversion); a power of two commutes with the rounding of
+    // every fused multiply-add, so the scale may live in the taps instead -- as long as no scaled tap leaves the normal range
+    std::vector<float> bs(bf.size());
+    bool exact = true;
+    for (size_t i = 0; i < bf.size(); ++i) { bs[i] = std::ldexp(bf[i], -15); if (std::ldexp(bs[i], 15) != bf[i] || (bs[i] != 0 && !std::isnormal(bs[i]))) exact = false; }
+    e.bank_fs.release();
+    if (exact) { e.bank_fs.ensure(bs.size()); JT_HIP(hipMemcpyAsync(e.bank_fs.p, bs.data(), sizeof(float) * bs.size(), hipMemcpyHostToDevice, h->stream)); }
     JT_HIP(hipStreamSynchronize(h->stream));
     e.in_rate = in_rate; e.out_rate = out_rate;
     return e;
@@ -640,7 +647,7 @@ static void loudnorm_measure_enqueue(jt_ctx *h, const int16_t *s16, const double
     J->blk = blk; J->nfull = m_total / blk;
     if (s16) {
         h->stream_f.ensure((size_t)m_total);
-        launch_resample_stream_s16_f32(s16, n, sw.bank_f.p, sw.pl.phase_count, sw.pl.filter_length, sw.pl.center, sw.pl.step, m_total, h->stream_f.p, h->stream);
+        launch_resample_stream_s16_f32(s16, n, sw.bank_f.p, sw.bank_fs.p, sw.pl.phase_count, sw.pl.filter_length, sw.pl.center, sw.pl.step, m_total, h->stream_f.p, h->stream);
         jt_kweight_enqueue_f32(h, h->stream_f.p, m_total, 192000, blk, &J->kw, h->stream);
     } else {
         h->stream_d.ensure((size_t)m_total);

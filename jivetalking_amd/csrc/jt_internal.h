@@ -96,7 +96,7 @@ void launch_true_peak_f32(const float *in, int64_t n, const double *bank, int ph
 void launch_true_peak_f64(const double *in, int64_t n, const double *bank, int phase_count, int filter_length, int center,
                           int64_t step, int blk, double *block_tp, int64_t nblocks_alloc, int64_t m_total, hipStream_t s);
 // Pass-3 192 kHz streams (FLT path from s16, DBL path after the limiter prefix); K-weighted afterwards by launch_kweight_blocks_*
-void launch_resample_stream_s16_f32(const int16_t *in, int64_t n, const float *bankf, int phase_count, int filter_length, int center,
+void launch_resample_stream_s16_f32(const int16_t *in, int64_t n, const float *bankf, const float *bankf_scaled, int phase_count, int filter_length, int center,
                                     int64_t step, int64_t m_total, float *out, hipStream_t s);
 void launch_resample_stream_f64(const double *in, int64_t n, const double *bank, int phase_count, int filter_length, int center,
                                 int64_t step, int64_t m_total, double *out, hipStream_t s);
@@ -175,6 +175,7 @@ struct HostArena {
 // cached resampler plans (the kaiser bank depends on the rate pair only) with their device copies
 struct SwrDev {
     int in_rate = 0, out_rate = 0; SwrPlanHost pl; DevBuf<double> bank_d; DevBuf<float> bank_f;
+    DevBuf<float> bank_fs;       // bank_f * 2^-15 (s16 sources: the int -> float scale folded into the taps); empty unless that product is exact
     int64_t out_len(int64_t n) const { return (int64_t)(((__int128)n * pl.phase_count + pl.step - 1) / pl.step); }
 };
 

@@ -124,11 +124,102 @@ k_polyphase(const TIn *__restrict__ in, int64_t n, const TTap *__restrict__ bank
 // (4 at 48k->192k, 4.35 at 44.1k->192k); the taps of each phase stay wave-uniform scalars.  LDS reads per output drop from 32
 // to ~7 (QL = 1) or ~2 (step == 1, QL = 4 adjacent windows per lane), leaving the FMA pipe as the limiter.  Tap order per
 // output is unchanged (ascending), so results are bit-identical to k_polyphase.
+template <typename T> __device__ inline void store_quad(T *p, T a, T b, T c, T d)
+{
+    if constexpr (sizeof(T) == 4) { typedef T v4 __attribute__((ext_vector_type(4))); *reinterpret_cast<v4 *>(p) = v4{a, b, c, d}; }
+    else { typedef T v2 __attribute__((ext_vector_type(2))); reinterpret_cast<v2 *>(p)[0] = v2{a, b}; reinterpret_cast<v2 *>(p)[1] = v2{c, d}; }
+}
+
+// Stream output (MODE 2) with P % 16 == 0 and NW windows per lane (44.1 k -> 192 k: P = 640).  Two things set the time of the plain
+// item loop there, and neither is the FMAs:
+//   * a lane's outputs of one window period are P consecutive samples, P samples away from the next lane's, so storing them one
+//     by one makes every store instruction touch 64 cache lines for one element each;
+//   * every output phase needs its own 32-tap row (an 80 KB bank: the scalar cache holds a fifth of it), and a row fetched for 64
+//     windows x 32 FMAs keeps the scalar data path, not the vector ALU, busy.
+// Here each wave owns a quarter of the period's outputs (j in [jw0, jw1)) for ALL window offsets that produce them and walks the
+// offsets in order: a lane collects four consecutive outputs in registers before one 16-byte store (j & 3 is wave-uniform), and a
+// tap row, once in SGPRs, serves the NW windows (64 periods apart) a lane keeps in registers.  Offsets straddling a quarter boundary
+// are evaluated by both neighbours, each keeping its own outputs.  Tap order per output is unchanged.
+template <typename TIn, typename TAcc, typename TTap, int NW>
+__device__ inline void upsample32_stream_quads(const TIn *xin, const TTap *__restrict__ bank, int P, int step, int64_t m_lo, int64_t m_total,
+                                               double in_scale, int skewed, TAcc *__restrict__ out_stream)
+{
+    constexpr int L = 32;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const unsigned uP = (unsigned)P, ustep = (unsigned)step;
+    const int JW = P >> 2, jw0 = wave * JW, jw1 = jw0 + JW;
+    const int off_first = (int)(((unsigned)jw0 * ustep) / uP), off_last = (int)(((unsigned)(jw1 - 1) * ustep) / uP);
+    int jlim[NW]; TAcc *orow[NW];
+#pragma unroll
+    for (int w = 0; w < NW; ++w) {
+        const int64_t m_base = m_lo + (int64_t)P * (w * 64 + lane);
+        const int64_t left = m_total - m_base;
+        jlim[w] = left <= 0 ? 0 : (left >= (int64_t)P ? P : (int)left);
+        orow[w] = out_stream + m_base;
+    }
+    TAcc b0[NW], b1[NW], b2[NW];
+#pragma unroll
+    for (int w = 0; w < NW; ++w) b0[w] = b1[w] = b2[w] = (TAcc)0;
+    for (int off0 = off_first; off0 <= off_last; ++off0) {
+        const int off = __builtin_amdgcn_readfirstlane(off0);
+        int j_lo = (int)(((unsigned)off * uP + ustep - 1u) / ustep), j_hi = (int)(((unsigned)(off + 1) * uP + ustep - 1u) / ustep);
+        j_lo = j_lo > jw0 ? j_lo : jw0; j_hi = j_hi < jw1 ? j_hi : jw1;
+        TAcc xw[NW][L];
+#pragma unroll
+        for (int w = 0; w < NW; ++w) {
+            const int si = off + step * (w * 64 + lane);
+            if (!skewed) {
+                const TIn *wp = xin + si;
+                if (in_scale == 1.0) {
+#pragma unroll
+                    for (int i = 0; i < L; ++i) xw[w][i] = (TAcc)wp[i];
+                } else {
+#pragma unroll
+                    for (int i = 0; i < L; ++i) xw[w][i] = (TAcc)((TAcc)wp[i] * (TAcc)in_scale);
+                }
+            } else {
+                const int sb = si & 31, base = si + (si >> 5);
+#pragma unroll
+                for (int i = 0; i < L; ++i) xw[w][i] = (TAcc)((TAcc)xin[base + i + ((sb + i) >> 5)] * (TAcc)in_scale);
+            }
+        }
+        int ph = (int)(((unsigned)j_lo * ustep) % uP);
+        for (int j = j_lo; j < j_hi; ++j) {
+            const TTap *f = bank + (size_t)(unsigned)ph * L;
+            TTap tp[L];
+#pragma unroll
+            for (int i = 0; i < L; ++i) tp[i] = f[i];
+            TAcc val[NW];
+#pragma unroll
+            for (int w = 0; w < NW; ++w) val[w] = (TAcc)0;
+#pragma unroll
+            for (int i = 0; i < L; ++i) {
+#pragma unroll
+                for (int w = 0; w < NW; ++w) val[w] = fma(xw[w][i], (TAcc)tp[i], val[w]);
+            }
+            const int r = j & 3;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) {
+                if (r == 3) { if (j < jlim[w]) store_quad(orow[w] + (j - 3), b0[w], b1[w], b2[w], val[w]); }
+                else {
+                    if (r == 0) b0[w] = val[w]; else if (r == 1) b1[w] = val[w]; else b2[w] = val[w];
+                    if (j + 1 == jlim[w]) {                           // the stream ends inside this group of four (last windows only)
+                        orow[w][j - r] = b0[w];
+                        if (r >= 1) orow[w][j - r + 1] = b1[w];
+                        if (r == 2) orow[w][j] = b2[w];
+                    }
+                }
+            }
+            ph += step; ph -= ph >= P ? P : 0;
+        }
+    }
+}
+
 template <typename TIn, typename TAcc, typename TTap, int MODE, int QL>
 __global__ void __launch_bounds__(PP_THREADS)
 k_upsample32(const TIn *__restrict__ in, int64_t n, const TTap *__restrict__ bank, int P, int center, int step,
              int64_t m_total, int R, double in_scale, int blk, unsigned long long *__restrict__ block_tp, int64_t nblocks_alloc,
-             TAcc *__restrict__ out_stream)
+             TAcc *__restrict__ out_stream, int skewed)
 {
     constexpr int L = 32;
     constexpr int WL = L + QL - 1;                                    // QL > 1 only with step == 1
@@ -143,11 +234,14 @@ k_upsample32(const TIn *__restrict__ in, int64_t n, const TTap *__restrict__ ban
     if (m_lo >= m_total) return;
     const int flush = MODE != 0;
     // QL > 1 (step == 1): lane windows start QL samples apart, so an UNSKEWED tile read with 16-byte loads is conflict-free (each
-    // lane a distinct 16-byte segment); the skew only pays for the odd lane strides of the fractional ratios
+    // lane a distinct 16-byte segment).  QL == 1: lane windows start `step` samples apart; for an odd step the unskewed tile is
+    // (nearly) conflict-free as it is and a window is 32 reads off ONE address with immediate offsets, where the skewed index costs
+    // ~7 VALU instructions per read -- more than the 4.35 FMAs a staged sample feeds.  The skew remains for even steps.
     constexpr bool VEC = QL * sizeof(TIn) == 16;
+    const bool flat = VEC || !skewed;
     if (s0 - center >= 0 && s0 - center + nin <= n) {
         const TIn *src = in + (s0 - center);                         // interior workgroup: no reflection, no end of stream
-        for (int i = tid; i < nin; i += PP_THREADS) xin[VEC ? i : skew(i)] = src[i];
+        for (int i = tid; i < nin; i += PP_THREADS) xin[flat ? i : skew(i)] = src[i];
     } else {
         for (int i = tid; i < nin; i += PP_THREADS) {
             int64_t g = s0 - center + i;
@@ -155,11 +249,19 @@ k_upsample32(const TIn *__restrict__ in, int64_t n, const TTap *__restrict__ ban
             if (g < 0) g = -g;                                       // invert_initial_buffer(): in[-j] = in[j]
             if (g < n) v = in[g];
             else if (flush) { int64_t r = 2 * n - 1 - g; if (r >= 0 && r < n) v = in[r]; }   // resample_flush()
-            xin[VEC ? i : skew(i)] = v;
+            xin[flat ? i : skew(i)] = v;
         }
     }
     if (MODE == 0 && tid < 8) slots[tid] = 0ull;
     __syncthreads();
+    if constexpr (MODE == 2 && QL == 1) {
+        if ((P & 15) == 0 && (R == 1 || R == 2 || R == 4)) {
+            if (R == 4) upsample32_stream_quads<TIn, TAcc, TTap, 4>(xin, bank, P, step, m_lo, m_total, in_scale, skewed, out_stream);
+            else if (R == 2) upsample32_stream_quads<TIn, TAcc, TTap, 2>(xin, bank, P, step, m_lo, m_total, in_scale, skewed, out_stream);
+            else upsample32_stream_quads<TIn, TAcc, TTap, 1>(xin, bank, P, step, m_lo, m_total, in_scale, skewed, out_stream);
+            return;
+        }
+    }
     const int64_t b_first = (s0 - center + L - 1 < 0 ? 0 : (s0 - center + L - 1)) / blk;
     const int nitems = step * R;
     // All index arithmetic below is 32-bit and strength-reduced: the phase advances by `step` modulo P from one output to the next,
@@ -187,6 +289,15 @@ k_upsample32(const TIn *__restrict__ in, int64_t n, const TTap *__restrict__ ban
 #pragma unroll
                 for (int e = 0; e < E; ++e)
                     if (k * E + e < WL) { const TAcc v = (TAcc)t[e]; xw[k * E + e] = MODE == 0 ? v : (TAcc)(v * (TAcc)in_scale); }
+            }
+        } else if (!skewed) {
+            const TIn *wp = xin + si;
+            if (MODE == 0 || in_scale == 1.0) {                       // (s16 sources arrive with the scale folded into the taps)
+#pragma unroll
+                for (int i = 0; i < WL; ++i) xw[i] = (TAcc)wp[i];
+            } else {
+#pragma unroll
+                for (int i = 0; i < WL; ++i) xw[i] = (TAcc)((TAcc)wp[i] * (TAcc)in_scale);
             }
         } else {
             const int sb = si & 31, base = si + (si >> 5);          // skew(si + i) = base + i + ((sb + i) >> 5)
@@ -282,7 +393,10 @@ static bool launch_upsample32(const TIn *in, int64_t n, const TTap *bank, int P,
 {
     if (L != 32 || step >= P || step > 512) return false;
     const int ql = step == 1 ? 4 : 1;
-    const int R = (int)std::max<int64_t>(1, 4096 / (64 * ql * step));
+    int R = (int)std::max<int64_t>(1, 4096 / (64 * ql * step));
+    // stream output with per-lane window groups (upsample32_stream_quads): as many windows per lane as a <= 40 KB tile allows
+    if (MODE == 2 && ql == 1 && (P & 15) == 0 && R == 1)
+        for (int r = 4; r > 1; r >>= 1) if (sizeof(TIn) * (size_t)(64 * r * step + 64) <= 40 * 1024) { R = r; break; }
     const int T = 64 * R * ql * (int)step, nin = T + 32;
     const size_t smem = sizeof(TIn) * (size_t)(nin + (nin >> 5) + 4);
     if (smem > 150 * 1024) return false;
@@ -292,12 +406,12 @@ static bool launch_upsample32(const TIn *in, int64_t n, const TTap *bank, int P,
         auto k = k_upsample32<TIn, TAcc, TTap, MODE, 4>;
         JT_HIP(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
         hipLaunchKernelGGL(k, dim3(grid), dim3(PP_THREADS), smem, s, in, n, bank, P, center, (int)step, m_total, R, in_scale, blk,
-                           (unsigned long long *)block_tp, nblocks_alloc, out);
+                           (unsigned long long *)block_tp, nblocks_alloc, out, 0);
     } else {
         auto k = k_upsample32<TIn, TAcc, TTap, MODE, 1>;
         JT_HIP(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
         hipLaunchKernelGGL(k, dim3(grid), dim3(PP_THREADS), smem, s, in, n, bank, P, center, (int)step, m_total, R, in_scale, blk,
-                           (unsigned long long *)block_tp, nblocks_alloc, out);
+                           (unsigned long long *)block_tp, nblocks_alloc, out, (step & 1) ? 0 : 1);
     }
     return true;
 }
@@ -478,12 +592,13 @@ int64_t jt_resample_range_cap(int64_t n, int phase_count, int filter_length, int
 
 // Pass-3 streams at 192 kHz.  FLT variant (s16 in, no limiter prefix): swr int_sample_fmt FLTP = float taps, float
 // accumulation.  DBL variant (after the alimiter prefix): DBLP.
-void launch_resample_stream_s16_f32(const int16_t *in, int64_t n, const float *bankf, int phase_count, int filter_length, int center,
-                                    int64_t step, int64_t m_total, float *out, hipStream_t s)
+void launch_resample_stream_s16_f32(const int16_t *in, int64_t n, const float *bankf, const float *bankf_scaled, int phase_count,
+                                    int filter_length, int center, int64_t step, int64_t m_total, float *out, hipStream_t s)
 {
     if (m_total <= 0) return;
-    if (launch_upsample32<int16_t, float, float, 2>(in, n, bankf, phase_count, filter_length, center, step, m_total, 1.0 / 32768.0, 1,
-                                                   (double *)nullptr, (int64_t)0, out, s)) return;
+    // bankf_scaled (taps * 2^-15, null when that is not exact): the window then needs no multiply after the int -> float conversion
+    if (launch_upsample32<int16_t, float, float, 2>(in, n, bankf_scaled ? bankf_scaled : bankf, phase_count, filter_length, center, step,
+                                                   m_total, bankf_scaled ? 1.0 : 1.0 / 32768.0, 1, (double *)nullptr, (int64_t)0, out, s)) return;
     PPGeom g = pp_geometry<int16_t>(n, phase_count, filter_length, step, m_total, false);
     auto k = k_polyphase<int16_t, float, float, 2>;
     JT_HIP(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)g.smem));
