@@ -145,7 +145,7 @@ __device__ inline void upsample32_stream_quads(const TIn *xin, const TTap *__res
                                                double in_scale, int skewed, TAcc *__restrict__ out_stream)
 {
     constexpr int L = 32;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // uniform: scalar taps
     const unsigned uP = (unsigned)P, ustep = (unsigned)step;
     const int JW = P >> 2, jw0 = wave * JW, jw1 = jw0 + JW;
     const int off_first = (int)(((unsigned)jw0 * ustep) / uP), off_last = (int)(((unsigned)(jw1 - 1) * ustep) / uP);
@@ -255,9 +255,8 @@ k_upsample32(const TIn *__restrict__ in, int64_t n, const TTap *__restrict__ ban
     if (MODE == 0 && tid < 8) slots[tid] = 0ull;
     __syncthreads();
     if constexpr (MODE == 2 && QL == 1) {
-        if ((P & 15) == 0 && (R == 1 || R == 2 || R == 4)) {
-            if (R == 4) upsample32_stream_quads<TIn, TAcc, TTap, 4>(xin, bank, P, step, m_lo, m_total, in_scale, skewed, out_stream);
-            else if (R == 2) upsample32_stream_quads<TIn, TAcc, TTap, 2>(xin, bank, P, step, m_lo, m_total, in_scale, skewed, out_stream);
+        if ((P & 15) == 0 && (R == 1 || R == 2)) {
+            if (R == 2) upsample32_stream_quads<TIn, TAcc, TTap, 2>(xin, bank, P, step, m_lo, m_total, in_scale, skewed, out_stream);
             else upsample32_stream_quads<TIn, TAcc, TTap, 1>(xin, bank, P, step, m_lo, m_total, in_scale, skewed, out_stream);
             return;
         }
@@ -394,9 +393,9 @@ static bool launch_upsample32(const TIn *in, int64_t n, const TTap *bank, int P,
     if (L != 32 || step >= P || step > 512) return false;
     const int ql = step == 1 ? 4 : 1;
     int R = (int)std::max<int64_t>(1, 4096 / (64 * ql * step));
-    // stream output with per-lane window groups (upsample32_stream_quads): as many windows per lane as a <= 40 KB tile allows
+    // stream output with per-lane window groups (upsample32_stream_quads): as many windows per lane as a <= 80 KB tile allows
     if (MODE == 2 && ql == 1 && (P & 15) == 0 && R == 1)
-        for (int r = 4; r > 1; r >>= 1) if (sizeof(TIn) * (size_t)(64 * r * step + 64) <= 40 * 1024) { R = r; break; }
+        for (int r = 2; r > 1; r >>= 1) if (sizeof(TIn) * (size_t)(64 * r * step + 64) <= 80 * 1024) { R = r; break; }
     const int T = 64 * R * ql * (int)step, nin = T + 32;
     const size_t smem = sizeof(TIn) * (size_t)(nin + (nin >> 5) + 4);
     if (smem > 150 * 1024) return false;

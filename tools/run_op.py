@@ -10,4 +10,5 @@ for _ in range(2):
     if op == "anlmdn": e.op_anlmdn(x, SR)
     elif op == "afftdn": e.op_afftdn(x, SR, 12.0, -55.0)
     elif op == "resample": e.op_resample_s16(x, SR, 44100)
+    elif op == "loudnorm": e.op_loudnorm_measure_s16((x[: int(x.size * 0.91875)] * 32767).astype(np.int16), 44100)
 print("done", op, x.size)
