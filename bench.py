@@ -162,8 +162,8 @@ def main():
             roof = {"kernel": "k_adeclick", "bound": "hbm", "achieved": round(dk_bytes / dk_avg_s / 1e9, 2), "peak": 8000,
                     "unit": "GB/s", "frac": round(dk_bytes / dk_avg_s / 1e9 / 8000, 5), "traffic": None,
                     "note": "dominant kernel this round; not bandwidth bound: every window is a set of strictly ordered f64 chains "
-                            "(af_adeclick.c's summation order is kept bit for bit), so it is dependent-issue latency x occupancy "
-                            "(LDS-limited to 5 waves per CU) that sets the time, see DESIGN.md",
+                            "(af_adeclick.c's summation order is kept bit for bit) and the kernel is instruction-issue bound "
+                            "(10 waves per CU, ~60 k wave-instructions per window: profiles/r01_pmc_issue.txt, DESIGN.md s4/s9)",
                     "avg_launch_ms": round(dk_avg_s * 1e3, 3), "repaired_samples": int(eng.timers()["declick_repaired"]),
                     "heavy_windows": int(eng.timers()["declick_heavy_windows"])}
         else:
