@@ -42,6 +42,7 @@ extern "C" {
 /* ---- biquads: highpass/lowpass, RBJ, a=tdii, flt (af_biquads.c) ---- */
 /* type: 0 = highpass, 1 = lowpass.  poles=2, width_type=q, normalize=1. */
 void orc_biquad_coeffs(int type, double freq, double q, int sample_rate, double b[3], double a[3]);
+double orc_band_rms_db(const float *in, int64_t n, int sample_rate, double lo_hz, double hi_hz);   /* analyser_bands.go:33 */
 void orc_biquad_tdii_f32(const float *in, float *out, int64_t n, const double b[3], const double a[3]);
 /* double-precision variant (band-RMS graphs run biquads on the decoder format; dbl used for s16/flt-agnostic checks) */
 void orc_biquad_tdii_f64(const double *in, double *out, int64_t n, const double b[3], const double a[3]);

@@ -50,6 +50,14 @@ def biquad_f32(x, kind, freq, sr, q=0.707):
     return y
 
 
+def band_rms_db(x, sr, lo_hz, hi_hz):
+    """Band-limited Overall RMS of a region in dB (analyser_bands.go:33: highpass, lowpass, astats)."""
+    x = np.ascontiguousarray(x, np.float32)
+    f = lib().orc_band_rms_db
+    f.restype = C.c_double
+    return float(f(_p(x, C.c_float), C.c_int64(x.size), C.c_int(sr), C.c_double(lo_hz), C.c_double(hi_hz)))
+
+
 def biquad_f64(x, kind, freq, sr, q=0.707):
     x = np.ascontiguousarray(x, np.float64)
     y = np.empty_like(x)

@@ -17,7 +17,7 @@
 /* ------------------------------------------------------------------ biquads */
 /* af_biquads.c config_filter(): RBJ cookbook, width_type=q => alpha = sin(w0)/(2Q);
  * all coefficients divided by a0; normalize=1 rescales b by (sum a)/(sum b) when |sum b|>1e-6. */
-void orc_biquad_coeffs(int type, double freq, double q, int sample_rate, double b[3], double a[3])
+static void biquad_cookbook(int type, double freq, double q, int sample_rate, double b[3], double a[3])
 {
     double w0 = 2 * M_PI * freq / sample_rate;
     double alpha = sin(w0) / (2 * q);
@@ -36,10 +36,40 @@ void orc_biquad_coeffs(int type, double freq, double q, int sample_rate, double 
     a[1] /= a[0]; a[2] /= a[0];
     b[0] /= a[0]; b[1] /= a[0]; b[2] /= a[0];
     a[0] /= a[0];
+}
+
+void orc_biquad_coeffs(int type, double freq, double q, int sample_rate, double b[3], double a[3])
+{
+    biquad_cookbook(type, freq, q, sample_rate, b, a);
     if (fabs(b[0] + b[1] + b[2]) > 1e-6) {
         double factor = (a[0] + a[1] + a[2]) / (b[0] + b[1] + b[2]);
         b[0] *= factor; b[1] *= factor; b[2] *= factor;
     }
+}
+
+/* Band RMS of a region (analyser_bands.go:33, analyser_noise_bands.go:65-119): the graph
+ * "atrim=...,highpass=f=lo:p=2,lowpass=f=hi:p=2,astats=...measure_perchannel=0" with af_biquads.c's defaults: width_type q = 0.707,
+ * normalize = 0, transform di.  BIQUAD_FILTER(flt): float coefficients and state, one expression per sample
+ *   o = i2*b2 + i1*b1 + in*b0 + o2*a2 + o1*a1   (a1, a2 negated at configuration)
+ * evaluated left to right; astats' Overall RMS_level = 20 log10 sqrt(sum(x^2) / n) with the sum in double. */
+double orc_band_rms_db(const float *in, int64_t n, int sample_rate, double lo_hz, double hi_hz)
+{
+    double bh[3], ah[3], bl[3], al[3];
+    biquad_cookbook(0, lo_hz, 0.707, sample_rate, bh, ah);
+    biquad_cookbook(1, hi_hz, 0.707, sample_rate, bl, al);
+    const float hb0 = (float)bh[0], hb1 = (float)bh[1], hb2 = (float)bh[2], ha1 = -(float)ah[1], ha2 = -(float)ah[2];
+    const float lb0 = (float)bl[0], lb1 = (float)bl[1], lb2 = (float)bl[2], la1 = -(float)al[1], la2 = -(float)al[2];
+    float i1 = 0, i2 = 0, o1 = 0, o2 = 0, j1 = 0, j2 = 0, p1 = 0, p2 = 0;
+    double acc = 0.0;
+    for (int64_t k = 0; k < n; k++) {
+        const float x = in[k];
+        const float y = (((i2 * hb2 + i1 * hb1) + x * hb0) + o2 * ha2) + o1 * ha1;
+        i2 = i1; i1 = x; o2 = o1; o1 = y;
+        const float z = (((j2 * lb2 + j1 * lb1) + y * lb0) + p2 * la2) + p1 * la1;
+        j2 = j1; j1 = y; p2 = p1; p1 = z;
+        acc += (double)z * (double)z;
+    }
+    return n > 0 ? 20.0 * log10(sqrt(acc / (double)n)) : -INFINITY;
 }
 
 /* BIQUAD_TDII_FILTER(flt, float, float, ...): float coefficients, float state. */

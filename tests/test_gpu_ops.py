@@ -20,6 +20,29 @@ def noise(n, amp, seed=0):
     return (np.random.default_rng(seed).standard_normal(n) * amp).astype(np.float32)
 
 
+# ---------------------------------------------------------------- band RMS (analyser_bands.go / analyser_noise_bands.go)
+def test_band_rms_matches_oracle(engine, oracle):
+    """The 2 speech bands and the 15 afftdn noise bands of a region: highpass + lowpass (direct form I, f32) + Overall RMS.
+    The kernel restarts the recurrence per chunk behind a warm-up halo sized for 1e-10 of the slowest pole: 1e-4 dB."""
+    x = speech(14.0, 77)
+    engine.upload_pcm(x, SR, 1)
+    edges = [80, 125, 195, 290, 440, 660, 1000, 1500, 2250, 3350, 5000, 7500, 11200, 16000, 24000]
+    lo = []; hi = []
+    for i in range(15):
+        lo.append(edges[0] / np.sqrt(edges[1] / edges[0]) if i == 0 else np.sqrt(edges[i - 1] * edges[i]))
+        hi.append(edges[14] * np.sqrt(edges[14] / edges[13]) if i == 14 else np.sqrt(edges[i] * edges[i + 1]))
+    for (st, du, los, his) in ((2.0, 9.5, lo, hi), (0.0, 3.25, [1000.0, 6000.0], [3000.0, 9000.0]), (12.9, 5.0, [1000.0], [3000.0])):
+        got, ok = engine.band_rms(st, du, los, his)
+        s0 = int(round(st * SR)); seg = x[s0:s0 + int(round(du * SR))]
+        for b in range(len(los)):
+            assert ok[b] == 1
+            if his[b] >= SR / 2:                       # a corner at/above Nyquist: unmeasurable, reported non-finite
+                assert not np.isfinite(got[b])
+                continue
+            ref = oracle.band_rms_db(seg, SR, los[b], his[b])
+            assert abs(got[b] - ref) < 1e-4, (st, b, got[b], ref)
+
+
 # ---------------------------------------------------------------- biquads
 def test_biquad_hp_lp_matches_oracle(engine, oracle):
     x = speech(6.0, 2)
