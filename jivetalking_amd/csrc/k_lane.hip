@@ -324,9 +324,12 @@ k_biquad_f32(const float *__restrict__ in, float *__restrict__ out, int64_t n, i
     const int64_t my_base = base0 + (int64_t)lane * chunk;
     float w1a = 0.f, w2a = 0.f, w1b = 0.f, w2b = 0.f;
     const int64_t total = halo + chunk;
+    float v[LANES];
+    rows_prefetch<float>(v, in, n, base0, chunk, 0, lane);
     for (int64_t pos = 0; pos < total; pos += TW) {
-        tile_load<float, float>(tile, in, n, base0, chunk, pos, lane, nrows);
+        rows_commit<float, float>(tile, v, n, base0, chunk, pos, lane, nrows);
         __syncthreads();
+        if (pos + TW < total) rows_prefetch<float>(v, in, n, base0, chunk, pos + TW, lane);   // next tile's loads fly during this one
         if (lane < nrows) {
 #pragma unroll 8
             for (int j = 0; j < TW; ++j) {
@@ -348,7 +351,7 @@ k_biquad_f32(const float *__restrict__ in, float *__restrict__ out, int64_t n, i
             }
         }
         __syncthreads();
-        tile_store<float, float>(tile, out, n, base0, chunk, pos, lane, nrows, halo, chunk);
+        if (pos + TW > halo) tile_store<float, float>(tile, out, n, base0, chunk, pos, lane, nrows, halo, chunk);   // warm-up tiles store nothing
         __syncthreads();
     }
 }
@@ -363,7 +366,9 @@ void launch_biquad_f32(const float *in, float *out, int64_t n, int nstages, cons
     if (rmax > 0.0 && rmax < 1.0) halo = (int64_t)std::ceil(std::log(1e-10) / std::log(rmax));
     halo = std::max<int64_t>(256, std::min<int64_t>(halo, 1 << 20));
     halo = (halo + TW - 1) / TW * TW;
-    int64_t chunk = std::max<int64_t>(4096, halo * 2);
+    // one lane = one chunk and the launch lasts as long as a lane's serial run (halo + chunk dependent steps): chunks of half a
+    // halo keep that run short; an hour of audio is still ~1700 waves, and the re-read halo stays in L2
+    int64_t chunk = std::max<int64_t>(1024, halo / 2);
     chunk = (chunk + TW - 1) / TW * TW;
     int64_t nchunks = (n + chunk - 1) / chunk;
     int grid = (int)((nchunks + LANES - 1) / LANES);

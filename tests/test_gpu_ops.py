@@ -53,7 +53,7 @@ def test_biquad_hp_lp_matches_oracle(engine, oracle):
     # chunk restarts decorrelate that round-off: per-sample tolerance 5e-5 abs (-86 dBFS), 2e-6 on speech.
     assert np.max(np.abs(got - ref)) < 2e-6
     # first chunk has no halo: must be bit-identical to the sequential recurrence
-    assert np.array_equal(got[:4096], ref[:4096])
+    assert np.array_equal(got[:1024], ref[:1024])
 
 
 def test_biquad_edge_sizes(engine, oracle):
