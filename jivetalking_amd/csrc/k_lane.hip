@@ -864,7 +864,7 @@ __global__ void k_lim_bounds(const double *__restrict__ mx, int64_t nblk, int ne
 __global__ void __launch_bounds__(64)
 k_limiter_f64(const double *__restrict__ in, double *__restrict__ out, int64_t n, int sr, double limit, int B,
               double release, double asc_coeff, const int64_t *__restrict__ cand, int64_t ntargets, int blk, double in_gain,
-              double *__restrict__ sdelta, int64_t *__restrict__ spos)
+              double *__restrict__ sdelta, int64_t *__restrict__ spos, const double *__restrict__ block_max, int64_t nblk)
 {
     __shared__ double tx[LANES][TW + 1];
     __shared__ double te[LANES][TW + 1];
@@ -878,12 +878,23 @@ k_limiter_f64(const double *__restrict__ in, double *__restrict__ out, int64_t n
         for (int64_t q = c + 1; q < ntargets; ++q) { const int64_t v = cand[q]; if (v >= 0) { hi = v * blk; break; } }
         if (lo >= n) { lo = -1; hi = -1; }
     }
+    if (lo >= 0) {
+        // A segment starts at rest; if nothing it pushes (its own samples and the B-1 it looks ahead into the next segment) is above
+        // the limit it stays at rest throughout: att == 1, every output is in * in_gain, which k_lim_copy has already written.
+        // Only the segments with a block above the limit run the state machine (and overwrite their range).
+        const double g = fabs(in_gain);
+        const int64_t b0 = lo / blk, b1 = min(nblk - 1, (hi + B - 2) / blk);
+        bool hot = false;
+        for (int64_t b = b0; b <= b1; ++b) hot |= block_max[b] * g > limit;
+        if (!hot) { lo = -1; hi = -1; }
+    }
     s_lo[lane] = lo; s_hi[lane] = hi;
     const bool active = lo >= 0;
     // iterations i = lo .. hi + B - 2: iteration i pushes in[i] (zero past the end) and emits sample i-(B-1)
     const int64_t my_len = active ? (hi - lo) + B - 1 : 0;
     int64_t max_len = my_len;
     for (int o = 32; o > 0; o >>= 1) max_len = max(max_len, __shfl_xor(max_len, o, 64));
+    if (max_len == 0) return;                 // (one wave per workgroup: uniform) every segment of this workgroup stays at rest
     __syncthreads();
     double *nextdelta = sdelta + (size_t)c * B;
     int64_t *nextpos = spos + (size_t)c * B;
@@ -1002,6 +1013,19 @@ k_limiter_f64(const double *__restrict__ in, double *__restrict__ out, int64_t n
     }
 }
 
+// out = in * in_gain: what the limiter emits wherever it is at rest (att == 1 exactly, the clamp a no-op)
+__global__ void __launch_bounds__(256)
+k_lim_copy(const double *__restrict__ in, double *__restrict__ out, int64_t n, double in_gain)
+{
+    const int64_t i0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 2, stride = (int64_t)gridDim.x * 512;
+    for (int64_t i = i0; i < n; i += stride) {
+        if (i + 1 < n) {
+            const double2 v = *reinterpret_cast<const double2 *>(in + i);
+            *reinterpret_cast<double2 *>(out + i) = double2{v.x * in_gain, v.y * in_gain};
+        } else out[i] = in[i] * in_gain;
+    }
+}
+
 void launch_limiter_f64(const double *in, double *out, int64_t n, int sr, double limit, int buffer_size,
                         double release_s, double asc_coeff, const double *block_max, int64_t nblk, int blk, int need, int target,
                         int64_t *cand, int64_t ntargets, double in_gain, double *scratch_delta, int64_t *scratch_pos, hipStream_t s)
@@ -1009,8 +1033,9 @@ void launch_limiter_f64(const double *in, double *out, int64_t n, int sr, double
     if (n <= 0) return;
     hipLaunchKernelGGL(k_lim_bounds, dim3((unsigned)((ntargets + 255) / 256)), dim3(256), 0, s, block_max, nblk, need, target,
                        std::fabs(in_gain), limit, cand, ntargets);
+    hipLaunchKernelGGL(k_lim_copy, dim3((unsigned)std::min<int64_t>((n + 511) / 512, 8192)), dim3(256), 0, s, in, out, n, in_gain);
     hipLaunchKernelGGL(k_limiter_f64, dim3((unsigned)((ntargets + LANES - 1) / LANES)), dim3(LANES), 0, s, in, out, n, sr, limit,
-                       buffer_size, release_s, asc_coeff, cand, ntargets, blk, in_gain, scratch_delta, scratch_pos);
+                       buffer_size, release_s, asc_coeff, cand, ntargets, blk, in_gain, scratch_delta, scratch_pos, block_max, nblk);
 }
 
 // ------------------------------------------------------------------ biquad pair, direct form I (f32)
