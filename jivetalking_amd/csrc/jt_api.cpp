@@ -625,7 +625,7 @@ static void run_limiter(jt_ctx *h, const double *in, double *out, int64_t n, int
     const int blk = 256;
     const int64_t nblk = (n + blk - 1) / blk;
     h->d_scr3.ensure((size_t)nblk);
-    launch_absmax_blocks_f64(in, n, blk, h->d_scr3.p, nblk, h->stream);
+    launch_absmax_copy_f64(in, out, n, in_gain, h->d_scr3.p, nblk, h->stream);      // blk == 256
     // a position p is clean when no sample in the previous (B + release*sr + 4) samples exceeds the limit; segment starts are
     // picked on the device (one candidate per 2048 samples), so the limiter needs no host round trip
     const int need = (int)std::ceil((B + release * sr + 4.0) / blk) + 1;

@@ -814,23 +814,36 @@ void launch_dynamics(const float *in, float *out_f32, double *tmp64, double *tmp
 }
 
 // ------------------------------------------------------------------ look-ahead limiter (af_alimiter.c)
-__global__ void k_absmax_blocks_f64(const double *__restrict__ in, int64_t n, int blk, double *__restrict__ out_max, int64_t nblk)
+// The limiter's first sweep, fused: per-256-sample maxima of |in| (clean points, hot segments) and out = in * gain, the
+// limiter's output wherever it stays at rest.  One wave per block of 256 samples (four per lane as two 16-byte loads), eight
+// blocks per wave, no LDS.
+__global__ void __launch_bounds__(256)
+k_absmax_copy_f64(const double *__restrict__ in, double *__restrict__ out, int64_t n, double gain, double *__restrict__ out_max, int64_t nblk)
 {
-    int64_t b = blockIdx.x;
-    if (b >= nblk) return;
-    int64_t lo = b * blk, hi = min(lo + (int64_t)blk, n);
-    double m = 0.0;
-    for (int64_t i = lo + threadIdx.x; i < hi; i += blockDim.x) m = fmax(m, fabs(in[i]));
-    for (int off = 32; off > 0; off >>= 1) m = fmax(m, __shfl_down(m, off, 64));
-    __shared__ double sm[4];
-    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = m;
-    __syncthreads();
-    if (threadIdx.x == 0) { double r = 0; for (int k = 0; k < (int)(blockDim.x >> 6); ++k) r = fmax(r, sm[k]); out_max[b] = r; }
+    const int lane = threadIdx.x & 63;
+    const int64_t w = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    for (int q = 0; q < 8; ++q) {
+        const int64_t b = w * 8 + q;
+        if (b >= nblk) return;
+        const int64_t base = b * 256;
+        double m = 0.0;
+        if (base + 256 <= n) {
+            const double2 v0 = *reinterpret_cast<const double2 *>(in + base + 2 * lane);
+            const double2 v1 = *reinterpret_cast<const double2 *>(in + base + 128 + 2 * lane);
+            m = fmax(fmax(fabs(v0.x), fabs(v0.y)), fmax(fabs(v1.x), fabs(v1.y)));
+            *reinterpret_cast<double2 *>(out + base + 2 * lane) = double2{v0.x * gain, v0.y * gain};
+            *reinterpret_cast<double2 *>(out + base + 128 + 2 * lane) = double2{v1.x * gain, v1.y * gain};
+        } else {
+            for (int64_t i = base + lane; i < n; i += 64) { const double v = in[i]; m = fmax(m, fabs(v)); out[i] = v * gain; }
+        }
+        for (int off = 32; off > 0; off >>= 1) m = fmax(m, __shfl_down(m, off, 64));
+        if (lane == 0) out_max[b] = m;
+    }
 }
-void launch_absmax_blocks_f64(const double *in, int64_t n, int blk, double *out_max, int64_t nblk, hipStream_t s)
+void launch_absmax_copy_f64(const double *in, double *out, int64_t n, double gain, double *out_max, int64_t nblk, hipStream_t s)
 {
     if (nblk <= 0) return;
-    hipLaunchKernelGGL(k_absmax_blocks_f64, dim3((unsigned)nblk), dim3(256), 0, s, in, n, blk, out_max, nblk);
+    hipLaunchKernelGGL(k_absmax_copy_f64, dim3((unsigned)((nblk + 31) / 32)), dim3(256), 0, s, in, out, n, gain, out_max, nblk);
 }
 
 // Segment starts ("clean points") chosen on the device.  A block b is clean when the `need` blocks before it are all at or
@@ -880,7 +893,7 @@ k_limiter_f64(const double *__restrict__ in, double *__restrict__ out, int64_t n
     }
     if (lo >= 0) {
         // A segment starts at rest; if nothing it pushes (its own samples and the B-1 it looks ahead into the next segment) is above
-        // the limit it stays at rest throughout: att == 1, every output is in * in_gain, which k_lim_copy has already written.
+        // the limit it stays at rest throughout: att == 1, every output is in * in_gain, which k_absmax_copy_f64 has already written to `out`.
         // Only the segments with a block above the limit run the state machine (and overwrite their range).
         const double g = fabs(in_gain);
         const int64_t b0 = lo / blk, b1 = min(nblk - 1, (hi + B - 2) / blk);
@@ -1013,19 +1026,6 @@ k_limiter_f64(const double *__restrict__ in, double *__restrict__ out, int64_t n
     }
 }
 
-// out = in * in_gain: what the limiter emits wherever it is at rest (att == 1 exactly, the clamp a no-op)
-__global__ void __launch_bounds__(256)
-k_lim_copy(const double *__restrict__ in, double *__restrict__ out, int64_t n, double in_gain)
-{
-    const int64_t i0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 2, stride = (int64_t)gridDim.x * 512;
-    for (int64_t i = i0; i < n; i += stride) {
-        if (i + 1 < n) {
-            const double2 v = *reinterpret_cast<const double2 *>(in + i);
-            *reinterpret_cast<double2 *>(out + i) = double2{v.x * in_gain, v.y * in_gain};
-        } else out[i] = in[i] * in_gain;
-    }
-}
-
 void launch_limiter_f64(const double *in, double *out, int64_t n, int sr, double limit, int buffer_size,
                         double release_s, double asc_coeff, const double *block_max, int64_t nblk, int blk, int need, int target,
                         int64_t *cand, int64_t ntargets, double in_gain, double *scratch_delta, int64_t *scratch_pos, hipStream_t s)
@@ -1033,7 +1033,6 @@ void launch_limiter_f64(const double *in, double *out, int64_t n, int sr, double
     if (n <= 0) return;
     hipLaunchKernelGGL(k_lim_bounds, dim3((unsigned)((ntargets + 255) / 256)), dim3(256), 0, s, block_max, nblk, need, target,
                        std::fabs(in_gain), limit, cand, ntargets);
-    hipLaunchKernelGGL(k_lim_copy, dim3((unsigned)std::min<int64_t>((n + 511) / 512, 8192)), dim3(256), 0, s, in, out, n, in_gain);
     hipLaunchKernelGGL(k_limiter_f64, dim3((unsigned)((ntargets + LANES - 1) / LANES)), dim3(LANES), 0, s, in, out, n, sr, limit,
                        buffer_size, release_s, asc_coeff, cand, ntargets, blk, in_gain, scratch_delta, scratch_pos, block_max, nblk);
 }
