@@ -32,6 +32,8 @@ extern "C" int jt_open(int device_id, jt_ctx **out)
         JT_HIP(hipEventCreate(&h->ev0)); JT_HIP(hipEventCreate(&h->ev1));
         JT_HIP(hipEventCreate(&h->ev2)); JT_HIP(hipEventCreate(&h->ev3));
         JT_HIP(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
+        JT_HIP(hipStreamCreateWithFlags(&h->spec_ln.stream, hipStreamNonBlocking));
+        JT_HIP(hipEventCreateWithFlags(&h->spec_ln.fork, hipEventDisableTiming));
         for (int i = 0; i < 8; ++i) {
             JT_HIP(hipStreamCreateWithFlags(&h->aux[i], hipStreamNonBlocking));
             JT_HIP(hipEventCreateWithFlags(&h->ev_join[i], hipEventDisableTiming));
@@ -50,6 +52,9 @@ extern "C" void jt_close(jt_ctx *h)
     if (h->ev1) (void)hipEventDestroy(h->ev1);
     if (h->ev2) (void)hipEventDestroy(h->ev2);
     if (h->ev3) (void)hipEventDestroy(h->ev3);
+    if (h->spec_ln.stream) { (void)hipStreamSynchronize(h->spec_ln.stream); (void)hipStreamDestroy(h->spec_ln.stream); }
+    if (h->spec_ln.fork) (void)hipEventDestroy(h->spec_ln.fork);
+    if (h->spec_ln.pin) (void)hipHostFree(h->spec_ln.pin);
     if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
     for (int i = 0; i < 8; ++i) {
         if (h->aux[i]) { (void)hipStreamSynchronize(h->aux[i]); (void)hipStreamDestroy(h->aux[i]); }
@@ -123,10 +128,17 @@ extern "C" int jt_attach_device_pcm(jt_ctx *h, const void *dev_ptr, int64_t fram
     JT_API_END(h)
 }
 
+// an early Pass-3 measurement still reading the Pass-2 output must finish before that output is replaced
+static void spec_loudnorm_cancel(jt_ctx *h)
+{
+    if (h->spec_ln.pending) { JT_HIP(hipStreamSynchronize(h->spec_ln.stream)); h->spec_ln.pending = false; }
+}
+
 extern "C" int jt_upload_s16(jt_ctx *h, const int16_t *pcm, int64_t frames, int sr)
 {
     JT_API_BEGIN(h)
     JT_REQUIRE(pcm && frames > 0, JT_E_INVAL, "bad s16 arguments");
+    spec_loudnorm_cancel(h);
     h->s16_p2.ensure((size_t)frames);
     JT_HIP(hipMemcpyAsync(h->s16_p2.p, pcm, sizeof(int16_t) * (size_t)frames, hipMemcpyHostToDevice, h->stream));
     JT_HIP(hipStreamSynchronize(h->stream));
@@ -536,6 +548,34 @@ static void run_resample_s16(jt_ctx *h, const float *x, int64_t n, int in_rate, 
     *m_out = m;
 }
 
+// Pass 3 for a plan without limiter prefix (loudnorm's first-pass measurement of the s16 output: swr -> 192 kHz, K-weighting,
+// 100 ms block energies), queued behind the output stage on a stream that Pass 2 does not wait for.  Scratch and result buffers
+// of its own: the pass arenas are recycled by the next pass_begin.
+static void spec_loudnorm_enqueue(jt_ctx *h, const int16_t *s16, int64_t n, int rate)
+{
+    if (rate == 192000 || n <= 0 || getenv("JT_NO_EARLY_PASS3")) return;
+    auto &S = h->spec_ln;
+    SwrDev &sw = get_swr(h, rate, 192000);
+    const int64_t m_total = sw.out_len(n);
+    const int blk = (192000 + 5) / 10;
+    size_t dev_d = 0, pin_d = 0; jt_kweight_scratch_sizes(m_total, blk, &dev_d, &pin_d);
+    S.dev.ensure(dev_d);
+    if (pin_d > S.pin_cap) {
+        if (S.pin) JT_HIP(hipHostFree(S.pin));
+        S.pin = nullptr; S.pin_cap = 0;
+        JT_HIP(hipHostMalloc((void **)&S.pin, sizeof(double) * pin_d, hipHostMallocDefault));
+        S.pin_cap = pin_d;
+    }
+    h->stream_f.ensure((size_t)m_total);
+    JT_HIP(hipEventRecord(S.fork, h->stream));
+    JT_HIP(hipStreamWaitEvent(S.stream, S.fork, 0));
+    launch_resample_stream_s16_f32(s16, n, sw.bank_f.p, sw.bank_fs.p, sw.pl.phase_count, sw.pl.filter_length, sw.pl.center, sw.pl.step, m_total,
+                                   h->stream_f.p, S.stream);
+    const KwScratch ext{S.dev.p, S.pin};
+    jt_kweight_enqueue_f32(h, h->stream_f.p, m_total, 192000, blk, &S.kw, S.stream, &ext);
+    S.blk = blk; S.nfull = m_total / blk; S.pending = true;
+}
+
 extern "C" int jt_pass2(jt_ctx *h, const jt_filter_params *p, jt_analysis *out)
 {
     JT_API_BEGIN(h)
@@ -548,6 +588,7 @@ extern "C" int jt_pass2(jt_ctx *h, const jt_filter_params *p, jt_analysis *out)
     JT_HIP(hipEventRecord(h->ev0, h->stream));
     const int64_t n = h->n; const int sr = h->sr;
     const int out_rate = p->out_rate > 0 ? p->out_rate : 44100;
+    spec_loudnorm_cancel(h);
     jt_ctx::RegionSlot &slot = h->region_slot[0];
     slot.valid = false; h->region_slot[1].valid = false;            // both stage outputs are about to be replaced
     const bool announced = slot.armed; slot.armed = false;
@@ -602,6 +643,7 @@ extern "C" int jt_pass2(jt_ctx *h, const jt_filter_params *p, jt_analysis *out)
         regions = regions_resolve(slot.start_s, slot.dur_s, out_rate, h->m_p2, &RJ);
         if (regions) regions_enqueue(h, h->s16_p2.p, out_rate, &RJ, true);
     }
+    spec_loudnorm_enqueue(h, h->s16_p2.p, h->m_p2, out_rate);            // Pass 3's usual measurement, on its own stream (not joined)
     analysis_join(h, regions ? 2 : 1);
     h->out_rate = out_rate; h->m_p4 = 0;
     JT_HIP(hipEventRecord(h->ev1, h->stream));
@@ -668,6 +710,17 @@ static void loudnorm_measure_finish(const LoudnormJob &J, jt_loudnorm_stats *out
 
 static void pass3_core(jt_ctx *h, const int16_t *s16, int64_t m, int rate, const jt_limiter_plan *lim, jt_loudnorm_stats *out)
 {
+    if (h->spec_ln.pending) {
+        // Pass 2 already queued this measurement of its output for the no-prefix plan: collect it -- or let it finish (it owns the
+        // 192 kHz stream buffer) and measure what was asked for
+        JT_HIP(hipStreamSynchronize(h->spec_ln.stream));
+        h->spec_ln.pending = false;
+        if (s16 == h->s16_p2.p && m == h->m_p2 && !(lim && lim->needed)) {
+            LoudnormJob J; J.kw = h->spec_ln.kw; J.nfull = h->spec_ln.nfull; J.blk = h->spec_ln.blk;
+            loudnorm_measure_finish(J, out);
+            return;
+        }
+    }
     pass_begin(h, m * 192000 / rate + 1024, 1);
     LoudnormJob J;
     if (lim && lim->needed) {

@@ -192,7 +192,10 @@ void jt_astats_enqueue(jt_ctx *h, const float *x, int64_t n, int sr, AstatsJob *
                        unsigned long long *ehist = nullptr);     // ehist: the job's own 8192-bin histogram (default: the shared one)
 void jt_astats_finish(const AstatsJob *job, jt_astats *out);
 struct KwJob { const double *hc = nullptr; int64_t nchunks = 0, nfull = 0; int m = 1; };
-void jt_kweight_enqueue_f32(jt_ctx *h, const float *in, int64_t n, int rate, int blk, KwJob *job, hipStream_t s);
+// scratch of a job that outlives the pass arenas (the Pass-3 measurement started early by Pass 2): device doubles / pinned doubles
+struct KwScratch { double *dev = nullptr; double *pin = nullptr; };
+void jt_kweight_scratch_sizes(int64_t n, int blk, size_t *dev_doubles, size_t *pin_doubles);
+void jt_kweight_enqueue_f32(jt_ctx *h, const float *in, int64_t n, int rate, int blk, KwJob *job, hipStream_t s, const KwScratch *ext = nullptr);
 void jt_kweight_enqueue_f64(jt_ctx *h, const double *in, int64_t n, int rate, int blk, KwJob *job, hipStream_t s);
 // sums/peaks: nfull+1 entries (last = trailing partial block)
 void jt_kweight_finish(const KwJob *job, std::vector<double> &sums, std::vector<double> &peaks);
@@ -246,6 +249,13 @@ struct jt_ctx {
     }
     SwrDev swr[4]; int swr_next = 0;
     DevBuf<float> region_f; DevBuf<int16_t> region_s16;
+    // Pass 3's measurement of the Pass-2 output for the no-prefix plan (the usual one), queued by Pass 2 itself on a stream of
+    // its own as soon as the s16 output exists: it runs beside Pass 2's analysis tail and the host work between the passes.
+    // jt_pass3 collects it when the plan has no limiter prefix and measures normally otherwise.
+    struct SpecLoudnorm {
+        bool pending = false; KwJob kw; int64_t nfull = 0; int blk = 0;
+        DevBuf<double> dev; double *pin = nullptr; size_t pin_cap = 0; hipStream_t stream = nullptr; hipEvent_t fork = nullptr;
+    } spec_ln;
     // regions announced by jt_region_prefetch ([0] = stage 2, [1] = stage 4) and the results their pass stored
     struct RegionSlot { bool armed = false, valid = false; double start_s[2] = {0, 0}, dur_s[2] = {0, 0}; jt_region_sample out[2]; };
     RegionSlot region_slot[2];
@@ -267,6 +277,7 @@ inline void jt_drain(jt_ctx *h)
 {
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     for (int i = 0; i < 8; ++i) if (h->aux[i]) (void)hipStreamSynchronize(h->aux[i]);
+    if (h->spec_ln.stream) { (void)hipStreamSynchronize(h->spec_ln.stream); h->spec_ln.pending = false; }
 }
 #define JT_API_END(h) } catch (const JtError &e) { jt_drain(h); (h)->err = e.msg; return e.code; } \
     catch (const std::exception &e) { jt_drain(h); (h)->err = e.what(); return JT_E_HIP; } return JT_OK;

@@ -472,15 +472,26 @@ static void mat4_mul(const double *A, const double *B, double *C)
 
 // Per-100ms-block K-weighted energies and sample peaks of a device signal.  enqueue: both kernels + the async copy of the
 // per-chunk partials into the pinned arena; finish (after the pass's sync): per-block sums in chunk order.
+// chunk length: a divisor of the block, at most ~2400 samples, preferably a multiple of the 64-sample tile
+static int kw_chunks_per_block(int blk)
+{
+    int best = -1;
+    for (int q = 1; q <= 32; ++q) if (blk % q == 0 && blk / q <= 2400) { if (best < 0) best = q; if ((blk / q) % TW == 0) { best = q; break; } }
+    return best > 0 ? best : 1;
+}
+void jt_kweight_scratch_sizes(int64_t n, int blk, size_t *dev_doubles, size_t *pin_doubles)
+{
+    const int64_t L = blk / kw_chunks_per_block(blk), nchunks = (n + L - 1) / L;
+    *dev_doubles = 4 * (size_t)nchunks + 24 * 16 + 2 * (size_t)nchunks + 64;
+    *pin_doubles = 24 * 16 + 2 * (size_t)nchunks + 64;
+}
+
 template <typename TIn>
-static void kweight_enqueue(jt_ctx *h, const TIn *in, int64_t n, int rate, int blk, KwJob *job, hipStream_t st)
+static void kweight_enqueue(jt_ctx *h, const TIn *in, int64_t n, int rate, int blk, KwJob *job, hipStream_t st, const KwScratch *ext = nullptr)
 {
     BiquadF64 pre, rlb; jt_kweight_design(rate, &pre, &rlb);
     KwCoef k{pre.b0, pre.b1, pre.b2, pre.a1, pre.a2, rlb.b0, rlb.b1, rlb.b2, rlb.a1, rlb.a2};
-    // chunk length: a divisor of the block, at most ~2400 samples, preferably a multiple of the 64-sample tile
-    int m = 1, best = -1;
-    for (int q = 1; q <= 32; ++q) if (blk % q == 0 && blk / q <= 2400) { if (best < 0) best = q; if ((blk / q) % TW == 0) { best = q; break; } }
-    m = best > 0 ? best : 1;
+    const int m = kw_chunks_per_block(blk);
     const int64_t L = blk / m;
     const int64_t nchunks = (n + L - 1) / L;
     // homogeneous transition matrix (state s1,s2,t1,t2; input 0) and its powers F^L, F^2L, ...
@@ -488,7 +499,7 @@ static void kweight_enqueue(jt_ctx *h, const TIn *in, int64_t n, int rate, int b
     double FL[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1}, Bq[16];
     std::memcpy(Bq, F, sizeof(F));
     for (int64_t e = L; e > 0; e >>= 1) { if (e & 1) mat4_mul(FL, Bq, FL); mat4_mul(Bq, Bq, Bq); }
-    double *pw = h->pin.take<double>(24 * 16);            // pinned: the H2D source must stay valid until the pass's sync
+    double *pw = ext ? ext->pin : h->pin.take<double>(24 * 16);   // pinned: the H2D source must stay valid until the pass's sync
     double cur[16]; std::memcpy(cur, FL, sizeof(cur));
     int nterms = 1, npw = 0;
     for (int q = 0; q < 24; ++q) {
@@ -499,7 +510,7 @@ static void kweight_enqueue(jt_ctx *h, const TIn *in, int64_t n, int rate, int b
     }
     // device scratch: zs | pw | csum | cpeak.  Each job gets its own region of d_scr0 (several may be in flight in one pass).
     const size_t need = 4 * (size_t)nchunks + 24 * 16 + 2 * (size_t)nchunks;
-    double *base = h->kw_take(need);
+    double *base = ext ? ext->dev : h->kw_take(need);
     double *d_zs = base, *d_pw = base + 4 * (size_t)nchunks, *d_cs = d_pw + 24 * 16;
     if (npw) JT_HIP(hipMemcpyAsync(d_pw, pw, sizeof(double) * 16 * npw, hipMemcpyHostToDevice, st));
     const unsigned grid = (unsigned)((nchunks + LANES - 1) / LANES);
@@ -507,11 +518,11 @@ static void kweight_enqueue(jt_ctx *h, const TIn *in, int64_t n, int rate, int b
                        d_zs, (double *)nullptr, (double *)nullptr, nchunks);
     hipLaunchKernelGGL((k_kw<TIn, true>), dim3(grid), dim3(LANES), 0, st, in, n, L, k, d_zs, d_pw, nterms,
                        (double *)nullptr, d_cs, d_cs + nchunks, nchunks);
-    double *hc = h->pin.take<double>((size_t)nchunks * 2);
+    double *hc = ext ? ext->pin + 24 * 16 : h->pin.take<double>((size_t)nchunks * 2);
     JT_HIP(hipMemcpyAsync(hc, d_cs, sizeof(double) * nchunks * 2, hipMemcpyDeviceToHost, st));
     job->hc = hc; job->nchunks = nchunks; job->nfull = n / blk; job->m = m;
 }
-void jt_kweight_enqueue_f32(jt_ctx *h, const float *in, int64_t n, int rate, int blk, KwJob *job, hipStream_t s) { kweight_enqueue<float>(h, in, n, rate, blk, job, s); }
+void jt_kweight_enqueue_f32(jt_ctx *h, const float *in, int64_t n, int rate, int blk, KwJob *job, hipStream_t s, const KwScratch *ext) { kweight_enqueue<float>(h, in, n, rate, blk, job, s, ext); }
 void jt_kweight_enqueue_f64(jt_ctx *h, const double *in, int64_t n, int rate, int blk, KwJob *job, hipStream_t s) { kweight_enqueue<double>(h, in, n, rate, blk, job, s); }
 void jt_kweight_finish(const KwJob *job, std::vector<double> &sums, std::vector<double> &peaks)
 {

@@ -268,6 +268,39 @@ def test_announced_regions_without_a_rate_change_and_empty_regions(engine):
         engine.region_prefetch(3, st, du)                                # only stages 2 and 4 have outputs
 
 
+def test_early_pass3_measurement_equals_the_explicit_one(engine, monkeypatch):
+    """Pass 2 queues Pass 3's no-prefix measurement of its output on a stream of its own; jt_pass3 collects it.  Same kernels on
+    the same samples: the statistics must equal an explicit measurement bit for bit, a plan WITH a limiter prefix must not use
+    it, and replacing the Pass-2 output (jt_upload_s16) must discard it."""
+    from jivetalking_amd.engine import default_filter_params
+    x = synth.speech_like(16.0, SR, seed=47)
+    engine.upload_pcm(x, SR, 1)
+    p = default_filter_params()
+    keys = ("input_i", "input_tp", "input_lra", "input_thresh")
+    engine.pass2(p)
+    early = engine.pass3()                                           # collected from the job Pass 2 started
+    again = engine.pass3()                                           # nothing pending any more: measured on demand
+    monkeypatch.setenv("JT_NO_EARLY_PASS3", "1")
+    engine.pass2(p)
+    explicit = engine.pass3()
+    monkeypatch.delenv("JT_NO_EARLY_PASS3")
+    for k in keys:
+        assert early[k] == explicit[k] == again[k], k
+    # a plan with a limiter prefix measures the limited stream, with or without a pending early job
+    lim = L.LimiterPlan(1, 6.0, 0.5)
+    engine.pass2(p)
+    with_pending = engine.pass3(lim)
+    without = engine.pass3(lim)
+    assert all(with_pending[k] == without[k] for k in keys) and with_pending["input_i"] != early["input_i"]
+    # the Pass-2 output replaced after Pass 2: the early job belongs to the old samples
+    s16 = engine.download_s16(2)
+    engine.pass2(p)
+    engine.upload_s16((s16 // 2).astype(np.int16), 44100)
+    halved = engine.pass3()
+    ref = engine.op_loudnorm_measure_s16((s16 // 2).astype(np.int16), 44100)
+    assert all(halved[k] == ref[k] for k in keys) and halved["input_i"] < early["input_i"] - 5.0
+
+
 def test_two_runs_are_bit_identical(engine):
     x = synth.speech_like(20.0, SR, seed=43)
     engine.upload_pcm(x, SR, 1)
