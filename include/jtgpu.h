@@ -125,6 +125,13 @@ typedef struct {
  * BuildFilterSpec() (filters.go:968-989; golden chain filters_test.go:298-311).  Leaves the s16 @ out_rate
  * result resident on the device as stage 2. */
 int jt_pass2(jt_ctx *h, const jt_filter_params *p, jt_analysis *out);
+/* Optional: starts the head of the Pass-2 chain -- the highpass / lowpass cascade and anlmdn, whose parameters AdaptConfig takes
+ * from the base configuration, not from the Pass-1 measurements (adaptive.go: tuneBandlimitLowPass is a constant, the rumble
+ * filter and anlmdn are not tuned) -- on a stream of its own and returns at once, so that it runs while the host is still busy
+ * with interval building, VAD and the band measurements.  The next jt_pass2 continues from that intermediate signal when its
+ * parameters for those stages are identical (compared as the derived coefficients); otherwise the work is discarded and Pass 2
+ * runs from the input as usual.  Any other call on the handle except jt_band_rms / jt_region_prefetch retires it first. */
+int jt_pass2_prefetch(jt_ctx *h, const jt_filter_params *p);
 
 /* ---- region re-measure: replaces measureOutputRegionFromReader (analyser_output.go:95-227) over
  * "atrim=start:duration,asetpts=PTS-STARTPTS,astats=metadata=1:measure_perchannel=0,

@@ -32,6 +32,11 @@ extern "C" int jt_open(int device_id, jt_ctx **out)
         JT_HIP(hipEventCreate(&h->ev0)); JT_HIP(hipEventCreate(&h->ev1));
         JT_HIP(hipEventCreate(&h->ev2)); JT_HIP(hipEventCreate(&h->ev3));
         JT_HIP(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
+        int prio_least = 0, prio_greatest = 0;
+        JT_HIP(hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest));
+        // lowest priority: the small band-RMS launches the host is waiting for must get through beside it
+        JT_HIP(hipStreamCreateWithPriority(&h->spec_p2.stream, hipStreamNonBlocking, prio_least));
+        JT_HIP(hipEventCreateWithFlags(&h->spec_p2.done, hipEventDisableTiming));
         JT_HIP(hipStreamCreateWithFlags(&h->spec_ln.stream, hipStreamNonBlocking));
         JT_HIP(hipEventCreateWithFlags(&h->spec_ln.fork, hipEventDisableTiming));
         for (int i = 0; i < 8; ++i) {
@@ -52,6 +57,8 @@ extern "C" void jt_close(jt_ctx *h)
     if (h->ev1) (void)hipEventDestroy(h->ev1);
     if (h->ev2) (void)hipEventDestroy(h->ev2);
     if (h->ev3) (void)hipEventDestroy(h->ev3);
+    if (h->spec_p2.stream) { (void)hipStreamSynchronize(h->spec_p2.stream); (void)hipStreamDestroy(h->spec_p2.stream); }
+    if (h->spec_p2.done) (void)hipEventDestroy(h->spec_p2.done);
     if (h->spec_ln.stream) { (void)hipStreamSynchronize(h->spec_ln.stream); (void)hipStreamDestroy(h->spec_ln.stream); }
     if (h->spec_ln.fork) (void)hipEventDestroy(h->spec_ln.fork);
     if (h->spec_ln.pin) (void)hipHostFree(h->spec_ln.pin);
@@ -86,6 +93,11 @@ static void ensure_hann(jt_ctx *h, int N)
     JT_HIP(hipMemcpyAsync(h->hann.p, w.data(), sizeof(float) * N, hipMemcpyHostToDevice, h->stream));
     JT_HIP(hipStreamSynchronize(h->stream));
     h->hann_n = N;
+}
+
+void jt_spec_pass2_cancel(jt_ctx *h)
+{
+    if (h->spec_p2.pending) { h->spec_p2.pending = false; JT_HIP(hipStreamSynchronize(h->spec_p2.stream)); }
 }
 
 void jt_set_input_common(jt_ctx *h, int64_t frames, int sr, int ch)
@@ -442,7 +454,7 @@ static int64_t region_slot_samples(const jt_ctx::RegionSlot &sl, int rate)
 extern "C" int jt_band_rms(jt_ctx *h, double start_s, double dur_s, const double *lo_hz, const double *hi_hz,
                            int n_bands, double *out_db, int *ok)
 {
-    JT_API_BEGIN(h)
+    JT_API_BEGIN_KEEP(h)
     JT_REQUIRE(h->n > 0 && h->in_mono, JT_E_STATE, "band_rms: no input uploaded");
     JT_REQUIRE(lo_hz && hi_hz && out_db && n_bands > 0 && dur_s > 0 && start_s >= 0, JT_E_INVAL, "band_rms: bad arguments");
     // atrim=start:duration selects samples with start <= t < start+duration (pts-based)
@@ -477,17 +489,19 @@ extern "C" int jt_band_rms(jt_ctx *h, double start_s, double dur_s, const double
 }
 
 // ---------------------------------------------------------------- Pass 2
-static void run_anlmdn(jt_ctx *h, const float *in, float *out, int64_t n, int sr, double strength, double patch_s, double research_s, double smooth)
+static void run_anlmdn(jt_ctx *h, const float *in, float *out, int64_t n, int sr, double strength, double patch_s, double research_s, double smooth,
+                       hipStream_t st = nullptr)
 {
+    if (!st) st = h->stream;
     const int K = (int)std::llrint((double)std::llrint(patch_s * 1e6) * sr / 1e6);
     const int S = (int)std::llrint((double)std::llrint(research_s * 1e6) * sr / 1e6);
     JT_REQUIRE(K >= 1 && S >= 1, JT_E_INVAL, "anlmdn: patch/research too small");
     const float a = (float)strength, m = (float)smooth;
     const float lut_scale = 1.f / m * (float)(1 << 20);
     const float sw = (65536.f / (4 * K + 2)) / std::sqrt(a);
-    JT_HIP(hipEventRecord(h->ev2, h->stream));
-    launch_anlmdn(in, out, n, K, S, sw, m, lut_scale, h->stream);
-    JT_HIP(hipEventRecord(h->ev3, h->stream));
+    JT_HIP(hipEventRecord(h->ev2, st));
+    launch_anlmdn(in, out, n, K, S, sw, m, lut_scale, st);
+    JT_HIP(hipEventRecord(h->ev3, st));
 }
 
 static void run_afftdn(jt_ctx *h, const float *in, float *out, int64_t n, int sr, double nr, double nf, const double *bn)
@@ -548,6 +562,30 @@ static void run_resample_s16(jt_ctx *h, const float *x, int64_t n, int in_rate, 
     *m_out = m;
 }
 
+extern "C" int jt_pass2_prefetch(jt_ctx *h, const jt_filter_params *p)
+{
+    JT_API_BEGIN(h)                                           // (retires an earlier head first)
+    JT_REQUIRE(h->n > 0 && h->in_mono, JT_E_STATE, "pass2_prefetch: no input uploaded");
+    JT_REQUIRE(p, JT_E_INVAL, "pass2_prefetch: bad arguments");
+    jt_ctx::SpecPass2 &sp = h->spec_p2;
+    const int64_t n = h->n; const int sr = h->sr;
+    fill_biquads(p, sr, sp.st, &sp.nst);
+    sp.nlm = p->nlm_enabled != 0;
+    sp.nlm_p[0] = p->nlm_strength; sp.nlm_p[1] = p->nlm_patch_s; sp.nlm_p[2] = p->nlm_research_s; sp.nlm_p[3] = p->nlm_smooth;
+    if (sp.nst == 0 && !sp.nlm) return JT_OK;                 // nothing to start
+    h->work_a.ensure((size_t)n); h->work_b.ensure((size_t)n);
+    // the same buffer walk as jt_pass2: in_mono -> work_a -> work_b
+    const float *cur = h->in_mono; float *nxt = h->work_a.p; float *oth = h->work_b.p;
+    sp.stages = 0;
+    JT_HIP(hipEventRecord(h->ev_fork, h->stream));
+    JT_HIP(hipStreamWaitEvent(sp.stream, h->ev_fork, 0));     // everything queued so far (the input upload / down-mix) first
+    if (sp.nst > 0) { launch_biquad_f32(cur, nxt, n, sp.nst, sp.st, sp.stream); cur = nxt; std::swap(nxt, oth); sp.stages++; }
+    if (sp.nlm) { run_anlmdn(h, cur, nxt, n, sr, sp.nlm_p[0], sp.nlm_p[1], sp.nlm_p[2], sp.nlm_p[3], sp.stream); cur = nxt; std::swap(nxt, oth); sp.stages++; }
+    JT_HIP(hipEventRecord(sp.done, sp.stream));
+    sp.result = cur; sp.pending = true;
+    JT_API_END(h)
+}
+
 // Pass 3 for a plan without limiter prefix (loudnorm's first-pass measurement of the s16 output: swr -> 192 kHz, K-weighting,
 // 100 ms block energies), queued behind the output stage on a stream that Pass 2 does not wait for.  Scratch and result buffers
 // of its own: the pass arenas are recycled by the next pass_begin.
@@ -578,7 +616,7 @@ static void spec_loudnorm_enqueue(jt_ctx *h, const int16_t *s16, int64_t n, int 
 
 extern "C" int jt_pass2(jt_ctx *h, const jt_filter_params *p, jt_analysis *out)
 {
-    JT_API_BEGIN(h)
+    JT_API_BEGIN_KEEP(h)
     JT_REQUIRE(h->n > 0 && h->in_mono, JT_E_STATE, "pass2: no input uploaded");
     JT_REQUIRE(p && out, JT_E_INVAL, "pass2: bad arguments");
     JT_REQUIRE(!(p->fft_enabled && p->fft_track_noise), JT_E_UNSUPPORTED,
@@ -597,10 +635,23 @@ extern "C" int jt_pass2(jt_ctx *h, const jt_filter_params *p, jt_analysis *out)
     const float *cur = h->in_mono; float *nxt = h->work_a.p; float *oth = h->work_b.p;
     auto advance = [&]() { cur = nxt; std::swap(nxt, oth); };
     BiquadF32 st[2]; int nst = 0; fill_biquads(p, sr, st, &nst);
-    if (nst > 0) { launch_biquad_f32(cur, nxt, n, nst, st, h->stream); advance(); }
-    check_cancel(h);
     bool nlm_timed = false;
-    if (p->nlm_enabled) { run_anlmdn(h, cur, nxt, n, sr, p->nlm_strength, p->nlm_patch_s, p->nlm_research_s, p->nlm_smooth); advance(); nlm_timed = true; }
+    jt_ctx::SpecPass2 &sp = h->spec_p2;
+    const double nlm_p[4] = {p->nlm_strength, p->nlm_patch_s, p->nlm_research_s, p->nlm_smooth};
+    const bool head_ready = sp.pending && sp.nst == nst && (nst == 0 || !std::memcmp(sp.st, st, sizeof(BiquadF32) * nst)) &&
+                            sp.nlm == (p->nlm_enabled != 0) && (!sp.nlm || !std::memcmp(sp.nlm_p, nlm_p, sizeof(nlm_p)));
+    if (head_ready) {
+        // jt_pass2_prefetch ran exactly these stages on this input: continue from its result
+        sp.pending = false;
+        JT_HIP(hipStreamWaitEvent(h->stream, sp.done, 0));
+        for (int k = 0; k < sp.stages; ++k) advance();
+        nlm_timed = sp.nlm;
+    } else {
+        jt_spec_pass2_cancel(h);
+        if (nst > 0) { launch_biquad_f32(cur, nxt, n, nst, st, h->stream); advance(); }
+        check_cancel(h);
+        if (p->nlm_enabled) { run_anlmdn(h, cur, nxt, n, sr, p->nlm_strength, p->nlm_patch_s, p->nlm_research_s, p->nlm_smooth); advance(); nlm_timed = true; }
+    }
     check_cancel(h);
     if (p->fft_enabled) {
         double nf = p->fft_nf < 0 ? p->fft_nf : -50.0;

@@ -992,7 +992,7 @@ extern "C" int jt_host_pass4_spec(const jt_host_config *cfg, const jt_loudnorm_s
 static double secs_of(int64_t ns) { return qfmt("%f", (double)ns / 1e9); }    // regions travel through "%f"-formatted filter options
 
 static int analyse_core(jt_ctx *h, const jt_host_config *base, int frame_samples, jt_process_result *out,
-                        jt_host_config *eff_out)
+                        jt_host_config *eff_out, bool pass2_follows)
 {
     int rc;
     jt_analysis a1; std::memset(&a1, 0, sizeof(a1));
@@ -1005,6 +1005,16 @@ static int analyse_core(jt_ctx *h, const jt_host_config *base, int frame_samples
     if ((rc = jt_pass1(h, frame_samples, &a1, fss.data(), fpk.data(), nfr, meta.data(), cap_meta)) != JT_OK) return rc;
     out->pass_ms[0] = h->timers.pass1_ms;
     out->stage_ms[0] = now_ms() - t0; t0 = now_ms();
+    if (pass2_follows) {
+        // AdaptConfig takes the rumble filter, the band-limit filter and anlmdn from the base configuration, never from the
+        // measurements (jt_host_adapt: tuneBandlimitLowPass is a constant, the other two are not tuned): the GPU can start them now,
+        // while this thread builds intervals, runs the VAD and waits for the band measurements.  jt_pass2 checks the parameters.
+        jt_measurements none; std::memset(&none, 0, sizeof(none));
+        jt_host_config guess; jt_adaptive_diag dg;
+        jt_host_adapt(base, &none, &guess, &dg);
+        jt_filter_params fp; jt_host_filter_params(&guess, &fp);
+        (void)jt_pass2_prefetch(h, &fp);                      // best effort: Pass 2 runs from the input if this did not start
+    }
     std::vector<jt_interval> iv((size_t)(n / (sr / 5) + 16));
     int64_t niv = jt_host_build_intervals(sr, n, frame_samples, h->channels, fss.data(), fpk.data(), nfr, meta.data(), a1.n_frames_meta, 1,
                                           iv.data(), (int64_t)iv.size());
@@ -1047,7 +1057,7 @@ extern "C" int jt_analyse_only(jt_ctx *h, const jt_host_config *base, int frame_
     if (!h || !base || !out) return JT_E_INVAL;
     std::memset(out, 0, sizeof(*out));
     jt_host_config eff;
-    return analyse_core(h, base, frame_samples, out, &eff);
+    return analyse_core(h, base, frame_samples, out, &eff, false);
 }
 
 // generateLUFSOutputPath / lufsFilenameValue (processor.go:379-388): filepath.Dir / Base / Ext semantics for slash-separated paths
@@ -1083,7 +1093,7 @@ extern "C" int jt_process_audio_cb(jt_ctx *h, const jt_host_config *base, int fr
     };
     int rc; jt_host_config eff;
     emit(1, "Analysing", 0.0, 0.0, nullptr, nullptr, nullptr, nullptr);
-    if ((rc = analyse_core(h, base, frame_samples, out, &eff)) != JT_OK) return rc;
+    if ((rc = analyse_core(h, base, frame_samples, out, &eff, true)) != JT_OK) return rc;
     jt_measurements &m = out->input;
     const double dur = m.duration_s;
     emit(1, "Analysing", 1.0, dur, &m, nullptr, nullptr, nullptr);

@@ -252,6 +252,12 @@ struct jt_ctx {
     // Pass 3's measurement of the Pass-2 output for the no-prefix plan (the usual one), queued by Pass 2 itself on a stream of
     // its own as soon as the s16 output exists: it runs beside Pass 2's analysis tail and the host work between the passes.
     // jt_pass3 collects it when the plan has no limiter prefix and measures normally otherwise.
+    // Head of the Pass-2 chain (highpass / lowpass cascade + anlmdn: the stages whose parameters do not come from the Pass-1
+    // measurements) started by jt_pass2_prefetch while the host still works on those measurements.
+    struct SpecPass2 {
+        bool pending = false; int nst = 0; BiquadF32 st[2]; bool nlm = false; double nlm_p[4] = {0, 0, 0, 0};
+        const float *result = nullptr; int stages = 0; hipStream_t stream = nullptr; hipEvent_t done = nullptr;
+    } spec_p2;
     struct SpecLoudnorm {
         bool pending = false; KwJob kw; int64_t nfull = 0; int blk = 0;
         DevBuf<double> dev; double *pin = nullptr; size_t pin_cap = 0; hipStream_t stream = nullptr; hipEvent_t fork = nullptr;
@@ -270,7 +276,11 @@ struct jt_ctx {
 };
 
 // ---------------------------------------------------------------- C-ABI entry wrappers (jt_api.cpp, jt_io.cpp)
-#define JT_API_BEGIN(h) if (!(h)) return JT_E_INVAL; try { JT_HIP(hipSetDevice((h)->device));
+// Every entry point except the ones that belong between Pass 1 and Pass 2 (band RMS, region announcement, Pass 2 itself) first
+// retires a Pass-2 head that jt_pass2_prefetch may have left running: it reads the input and writes the Pass-2 work buffers.
+void jt_spec_pass2_cancel(jt_ctx *h);
+#define JT_API_BEGIN_KEEP(h) if (!(h)) return JT_E_INVAL; try { JT_HIP(hipSetDevice((h)->device));
+#define JT_API_BEGIN(h) JT_API_BEGIN_KEEP(h) jt_spec_pass2_cancel(h);
 // On failure the streams are drained before returning: a pass may have queued kernels and copies into the pinned arena, and the
 // next call is allowed to resize or reuse both.
 inline void jt_drain(jt_ctx *h)
@@ -278,6 +288,7 @@ inline void jt_drain(jt_ctx *h)
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     for (int i = 0; i < 8; ++i) if (h->aux[i]) (void)hipStreamSynchronize(h->aux[i]);
     if (h->spec_ln.stream) { (void)hipStreamSynchronize(h->spec_ln.stream); h->spec_ln.pending = false; }
+    if (h->spec_p2.stream) { (void)hipStreamSynchronize(h->spec_p2.stream); h->spec_p2.pending = false; }
 }
 #define JT_API_END(h) } catch (const JtError &e) { jt_drain(h); (h)->err = e.msg; return e.code; } \
     catch (const std::exception &e) { jt_drain(h); (h)->err = e.what(); return JT_E_HIP; } return JT_OK;
