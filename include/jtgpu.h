@@ -130,7 +130,9 @@ int jt_pass2(jt_ctx *h, const jt_filter_params *p, jt_analysis *out);
  * filter and anlmdn are not tuned) -- on a stream of its own and returns at once, so that it runs while the host is still busy
  * with interval building, VAD and the band measurements.  The next jt_pass2 continues from that intermediate signal when its
  * parameters for those stages are identical (compared as the derived coefficients); otherwise the work is discarded and Pass 2
- * runs from the input as usual.  Any other call on the handle except jt_band_rms / jt_region_prefetch retires it first. */
+ * runs from the input as usual.  It may be
+ * called as soon as the input is on the device: jt_pass1, jt_band_rms and jt_region_prefetch leave it running, any other call
+ * on the handle retires it first. */
 int jt_pass2_prefetch(jt_ctx *h, const jt_filter_params *p);
 
 /* ---- region re-measure: replaces measureOutputRegionFromReader (analyser_output.go:95-227) over

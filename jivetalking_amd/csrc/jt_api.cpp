@@ -344,7 +344,7 @@ static void analysis_complete(jt_ctx *h, const AnalysisJob &J, jt_analysis *out,
 extern "C" int jt_pass1(jt_ctx *h, int frame_samples, jt_analysis *out, double *frame_sumsq, double *frame_peak,
                         int64_t cap_frames, jt_frame_meta *meta, int64_t cap_meta)
 {
-    JT_API_BEGIN(h)
+    JT_API_BEGIN_KEEP(h)                      // (reads the input only: a running Pass-2 head is left alone)
     JT_REQUIRE(h->n > 0 && h->in_raw, JT_E_STATE, "pass1: no input uploaded");
     JT_REQUIRE(out && frame_samples > 0, JT_E_INVAL, "pass1: bad arguments");
     h->cancelled.store(0);
@@ -567,6 +567,7 @@ extern "C" int jt_pass2_prefetch(jt_ctx *h, const jt_filter_params *p)
     JT_API_BEGIN(h)                                           // (retires an earlier head first)
     JT_REQUIRE(h->n > 0 && h->in_mono, JT_E_STATE, "pass2_prefetch: no input uploaded");
     JT_REQUIRE(p, JT_E_INVAL, "pass2_prefetch: bad arguments");
+    if (getenv("JT_NO_PASS2_PREFETCH")) return JT_OK;         // (A/B switch: Pass 2 then runs every stage itself)
     jt_ctx::SpecPass2 &sp = h->spec_p2;
     const int64_t n = h->n; const int sr = h->sr;
     fill_biquads(p, sr, sp.st, &sp.nst);

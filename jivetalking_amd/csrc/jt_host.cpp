@@ -1001,20 +1001,20 @@ static int analyse_core(jt_ctx *h, const jt_host_config *base, int frame_samples
     const int64_t cap_meta = n / (sr / 10) + 2;
     std::vector<double> fss((size_t)nfr), fpk((size_t)nfr);
     std::vector<jt_frame_meta> meta((size_t)cap_meta);
-    double t0 = now_ms();
-    if ((rc = jt_pass1(h, frame_samples, &a1, fss.data(), fpk.data(), nfr, meta.data(), cap_meta)) != JT_OK) return rc;
-    out->pass_ms[0] = h->timers.pass1_ms;
-    out->stage_ms[0] = now_ms() - t0; t0 = now_ms();
     if (pass2_follows) {
         // AdaptConfig takes the rumble filter, the band-limit filter and anlmdn from the base configuration, never from the
-        // measurements (jt_host_adapt: tuneBandlimitLowPass is a constant, the other two are not tuned): the GPU can start them now,
-        // while this thread builds intervals, runs the VAD and waits for the band measurements.  jt_pass2 checks the parameters.
+        // measurements (jt_host_adapt: tuneBandlimitLowPass is a constant, the other two are not tuned): the GPU can start them at once,
+        // beside the Pass-1 analysis and while this thread builds intervals, runs the VAD and waits for the band measurements.  jt_pass2 checks the parameters.
         jt_measurements none; std::memset(&none, 0, sizeof(none));
         jt_host_config guess; jt_adaptive_diag dg;
         jt_host_adapt(base, &none, &guess, &dg);
         jt_filter_params fp; jt_host_filter_params(&guess, &fp);
         (void)jt_pass2_prefetch(h, &fp);                      // best effort: Pass 2 runs from the input if this did not start
     }
+    double t0 = now_ms();
+    if ((rc = jt_pass1(h, frame_samples, &a1, fss.data(), fpk.data(), nfr, meta.data(), cap_meta)) != JT_OK) return rc;
+    out->pass_ms[0] = h->timers.pass1_ms;
+    out->stage_ms[0] = now_ms() - t0; t0 = now_ms();
     std::vector<jt_interval> iv((size_t)(n / (sr / 5) + 16));
     int64_t niv = jt_host_build_intervals(sr, n, frame_samples, h->channels, fss.data(), fpk.data(), nfr, meta.data(), a1.n_frames_meta, 1,
                                           iv.data(), (int64_t)iv.size());

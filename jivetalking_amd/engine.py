@@ -134,6 +134,10 @@ class Engine:
         self._ck(self.lib.jt_pass2(self.h, C.byref(params), C.byref(a)))
         return _st2dict(a)
 
+    def pass2_prefetch(self, params):
+        """Start the head of the Pass-2 chain (biquads + anlmdn) early (jt_pass2_prefetch)."""
+        self._ck(self.lib.jt_pass2_prefetch(self.h, C.byref(params)))
+
     def region_measure(self, stage, start_s, dur_s):
         r = L.RegionSample()
         self._ck(self.lib.jt_region_measure(self.h, C.c_int(stage), C.c_double(start_s), C.c_double(dur_s), C.byref(r)))

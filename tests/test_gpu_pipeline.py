@@ -301,6 +301,37 @@ def test_early_pass3_measurement_equals_the_explicit_one(engine, monkeypatch):
     assert all(halved[k] == ref[k] for k in keys) and halved["input_i"] < early["input_i"] - 5.0
 
 
+def test_pass2_head_prefetch_changes_nothing_but_the_schedule(engine, monkeypatch):
+    """jt_pass2_prefetch runs the biquad cascade and anlmdn early, on another stream.  Pass 2 must produce the same samples and the
+    same analysis whether it continues from that head, finds it stale (different parameters) or never had one; calls that use the
+    work buffers in between retire it."""
+    from jivetalking_amd.engine import default_filter_params
+    x = synth.speech_like(14.0, SR, seed=48)
+    engine.upload_pcm(x, SR, 1)
+    p = default_filter_params()
+    a0 = engine.pass2(p); o0 = engine.download_s16(2).copy()                  # plain
+    engine.pass2_prefetch(p)
+    a1 = engine.pass2(p); o1 = engine.download_s16(2).copy()                  # continues from the head
+    assert np.array_equal(o0, o1) and a0["r128"]["integrated"] == a1["r128"]["integrated"] and a0["astats"]["rms_level"] == a1["astats"]["rms_level"]
+    q = default_filter_params(); q.hp_freq = 120.0
+    b0 = engine.pass2(q); r0 = engine.download_s16(2).copy()
+    engine.pass2_prefetch(p)                                                  # head for 80 Hz, Pass 2 asks for 120 Hz: discarded
+    b1 = engine.pass2(q); r1 = engine.download_s16(2).copy()
+    assert np.array_equal(r0, r1) and not np.array_equal(r0, o0) and b0["r128"]["integrated"] == b1["r128"]["integrated"]
+    engine.pass2_prefetch(p)
+    y = engine.op_anlmdn(x[:SR], SR)                                          # an operator call in between retires the head
+    engine.pass1(x.size)                                                      # Pass 1 and the band measurements leave a head alone
+    engine.pass2_prefetch(p)
+    engine.pass1(x.size); engine.band_rms(1.0, 2.0, [1000.0], [3000.0])
+    a2 = engine.pass2(p); o2 = engine.download_s16(2)
+    assert np.array_equal(o0, o2) and y.size == SR and a2["r128"]["integrated"] == a0["r128"]["integrated"]
+    # the orchestration: with and without the early head (and the early Pass-3 measurement) the run is the same run
+    r_on = H.process_audio(engine); out_on = engine.download_s16(4).copy()
+    monkeypatch.setenv("JT_NO_PASS2_PREFETCH", "1"); monkeypatch.setenv("JT_NO_EARLY_PASS3", "1")
+    r_off = H.process_audio(engine); out_off = engine.download_s16(4)
+    assert np.array_equal(out_on, out_off) and r_on.output_lufs == r_off.output_lufs and r_on.pass2_spec == r_off.pass2_spec
+
+
 def test_two_runs_are_bit_identical(engine):
     x = synth.speech_like(20.0, SR, seed=43)
     engine.upload_pcm(x, SR, 1)
