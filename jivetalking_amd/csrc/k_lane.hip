@@ -640,10 +640,15 @@ k_follow_states(const TIn *__restrict__ in, int64_t n, double att, double rel, i
             const int64_t t0 = my_base + pos;
             if (pos >= halo && ((pos - halo) % SC) == 0 && t0 < n) states[t0 / SC] = s;     // state BEFORE sample t0
             if (t0 >= 0 && t0 + TW <= n) {
-#pragma unroll 16
-                for (int j = 0; j < TW; ++j) {
-                    double a = (double)tile[lane][j]; a = fabs(a); a *= a;
-                    s += (a - s) * (a > s ? att : rel);
+                // the squares of 16 samples first (LDS reads and conversions in flight together), then the dependent chain on
+                // registers only: left to the scheduler, every second sample waited for its own LDS read
+#pragma unroll 1
+                for (int j0 = 0; j0 < TW; j0 += 16) {
+                    double a2[16];
+#pragma unroll
+                    for (int j = 0; j < 16; ++j) { double a = (double)tile[lane][j0 + j]; a = fabs(a); a2[j] = a * a; }
+#pragma unroll
+                    for (int j = 0; j < 16; ++j) s += (a2[j] - s) * (a2[j] > s ? att : rel);
                 }
             } else if (t0 + TW > 0 && t0 < n) {
                 for (int j = 0; j < TW; ++j) {
@@ -780,8 +785,11 @@ static void run_follow(const TIn *in, int64_t n, double att, double rel, double 
     int64_t halo = 4096;
     if (rho < 1.0 && rho > 0.0) halo = std::max<int64_t>(halo, (int64_t)std::ceil(18.0 / rho));   // 18 time constants ~ 1.5e-8
     halo = (halo + SC - 1) / SC * SC;
-    // chunk = halo / 8: a lane runs halo + chunk samples, so shorter chunks cut the serial length (halo/4 -> +2 ms, halo/8 best,
-    // halo/16 no better: the extra lanes re-read the halo and the launch becomes bandwidth-bound)
+    // chunk = halo / 8: a lane runs halo + chunk samples, so shorter chunks cut the serial length (halo/4 -> +1 ms, halo/8 best,
+    // halo/16 no better).  Measured with the chain or the staging compiled out: the dependent chain itself is 27 clk per sample
+    // (0.5 ms of each launch); the rest is the 9x re-read of the signal, 6.2 GB (f32) / 12.4 GB (f64) at ~4.5 TB/s -- the file
+    // is larger than the Infinity Cache, so the re-reads come from HBM.  Longer chunks (fewer re-reads) leave too few waves to
+    // cover the load latency with two tiles in flight and lose more than they save.
     int64_t chunk = std::max<int64_t>(1024, (halo / 8 + SC - 1) / SC * SC);
     int64_t nchunks = (n + chunk - 1) / chunk;
     hipLaunchKernelGGL((k_follow_states<TIn>), dim3((unsigned)((nchunks + LANES - 1) / LANES)), dim3(LANES), 0, s, in, n, att, rel, chunk, halo,
