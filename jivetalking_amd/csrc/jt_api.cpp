@@ -574,7 +574,7 @@ extern "C" int jt_pass2_prefetch(jt_ctx *h, const jt_filter_params *p)
     sp.nlm = p->nlm_enabled != 0;
     sp.nlm_p[0] = p->nlm_strength; sp.nlm_p[1] = p->nlm_patch_s; sp.nlm_p[2] = p->nlm_research_s; sp.nlm_p[3] = p->nlm_smooth;
     if (sp.nst == 0 && !sp.nlm) return JT_OK;                 // nothing to start
-    h->work_a.ensure((size_t)n); h->work_b.ensure((size_t)n);
+    h->work_a.ensure((size_t)n + 16); h->work_b.ensure((size_t)n + 16);
     // the same buffer walk as jt_pass2: in_mono -> work_a -> work_b
     const float *cur = h->in_mono; float *nxt = h->work_a.p; float *oth = h->work_b.p;
     sp.stages = 0;
@@ -632,7 +632,7 @@ extern "C" int jt_pass2(jt_ctx *h, const jt_filter_params *p, jt_analysis *out)
     slot.valid = false; h->region_slot[1].valid = false;            // both stage outputs are about to be replaced
     const bool announced = slot.armed; slot.armed = false;
     pass_begin(h, n, 1, announced ? region_slot_samples(slot, out_rate) : 0, announced ? 2 : 0);
-    h->work_a.ensure((size_t)n); h->work_b.ensure((size_t)n);
+    h->work_a.ensure((size_t)n + 16); h->work_b.ensure((size_t)n + 16);      // (+ slack: 16-byte group reads at the end of the signal)
     const float *cur = h->in_mono; float *nxt = h->work_a.p; float *oth = h->work_b.p;
     auto advance = [&]() { cur = nxt; std::swap(nxt, oth); };
     BiquadF32 st[2]; int nst = 0; fill_biquads(p, sr, st, &nst);
@@ -661,9 +661,9 @@ extern "C" int jt_pass2(jt_ctx *h, const jt_filter_params *p, jt_analysis *out)
     check_cancel(h);
     DynParams d; jt_dyn_design(p, sr, &d);
     if (d.gate_on || d.comp_on || d.deess_on) {
-        h->f64_a.ensure((size_t)n); if (d.deess_on) h->f64_b.ensure((size_t)n);
+        h->f64_a.ensure((size_t)n + 16); if (d.deess_on) h->f64_b.ensure((size_t)n + 16);
         h->d_scr3.ensure((size_t)(n / 256 + 4));
-        launch_dynamics(cur, nxt, h->f64_a.p, h->f64_b.p, h->d_scr3.p, n, d, h->stream); advance();
+        launch_dynamics(cur, nxt, h->f64_a.p, h->f64_b.p, h->d_scr3.p, n, d, h->stream, cur != h->in_mono); advance();
     }
     check_cancel(h);
     AnalysisJob J;

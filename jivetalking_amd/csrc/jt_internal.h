@@ -72,7 +72,9 @@ struct DynParams {
     double d_intensity, d_maxdess, d_iir;
 };
 void jt_dyn_design(const jt_filter_params *p, int sr, DynParams *d);
-void launch_dynamics(const float *in, float *out_f32, double *tmp64, double *tmp64b, double *states, int64_t n, const DynParams &d, hipStream_t s);
+// in_has_slack: 16 readable bytes behind in[n-1] and tmp64[n-1] (the LDS-streamed followers read whole 16-byte groups)
+void launch_dynamics(const float *in, float *out_f32, double *tmp64, double *tmp64b, double *states, int64_t n, const DynParams &d, hipStream_t s,
+                     bool in_has_slack = false);
 
 // astats (k_astats.hip)
 struct jt_ctx;

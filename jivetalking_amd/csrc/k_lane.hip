@@ -692,6 +692,74 @@ k_follow_states(const TIn *__restrict__ in, int64_t n, double att, double rel, i
     }
 }
 
+// The same follower with the samples streamed straight into LDS (global_load_lds_dwordx4, gfx950): loads in flight cost no
+// registers, so a lane can afford LONG chunks (few re-reads of the halo) and still have its HBM round trips covered -- with the
+// register-staged tiles above, chunks of a whole halo leave 63 waves that each wait for their own loads.
+// One wave per workgroup, lane = chunk.  A unit is 16 load instructions: instruction k moves, for every lane, the 16 bytes at
+// byte offset 16 k of that lane's row segment to LDS [slot][k][lane] (the hardware writes lane l at base + 16 l), so a lane
+// reads its own data back with conflict-free 16-byte reads.  8 slots of 16 KB; three units (48 instructions, the vmcnt budget)
+// are outstanding while one is consumed.  Requires 16-byte aligned rows and 16 bytes of readable slack behind the signal.
+template <typename TIn>
+__global__ void __launch_bounds__(64)
+k_follow_states_lds(const TIn *__restrict__ in, int64_t n, double att, double rel, int64_t chunk, int64_t halo,
+                    double *__restrict__ states, int64_t nchunks)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char fs_ring[];
+    constexpr int G = 16 / (int)sizeof(TIn);           // samples per 16-byte group
+    constexpr int US = 16 * G;                         // samples per unit (64 f32 / 32 f64)
+    constexpr int NS = 8, D = 3;
+    const int lane = threadIdx.x;
+    const int64_t c = (int64_t)blockIdx.x * LANES + lane;
+    const bool active = c < nchunks;
+    const int64_t row0 = c * chunk - halo;             // first sample of this lane's run (may be negative)
+    const int64_t total = halo + chunk;                // multiple of SC, hence of US
+    const int nu = (int)(total / US);
+    auto issue = [&](int u) {
+        unsigned char *slot = fs_ring + (size_t)(u % NS) * (16 * 1024);
+        const int64_t g0 = row0 + (int64_t)u * US;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            int64_t idx = g0 + k * G;
+            if (!active || idx < 0 || idx >= n) idx = 0;                     // never consumed: any valid address
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(in + idx),
+                                             (__attribute__((address_space(3))) void *)(slot + k * 1024), 16, 0, 0);
+        }
+    };
+    for (int u = 0; u < D && u < nu; ++u) issue(u);
+    double s = 0.0;
+    for (int u = 0; u < nu; ++u) {
+        if (u + D < nu) issue(u + D);
+        // unit u is complete once at most the younger units' loads are outstanding (loads retire in order)
+        const int left = nu - 1 - u;
+        if (left >= D) __builtin_amdgcn_s_waitcnt(0x0F70 | (48 & 15) | ((48 >> 4) << 14));
+        else if (left == 2) __builtin_amdgcn_s_waitcnt(0x0F70 | (32 & 15) | ((32 >> 4) << 14));
+        else if (left == 1) __builtin_amdgcn_s_waitcnt(0x0F70 | (16 & 15) | ((16 >> 4) << 14));
+        else __builtin_amdgcn_s_waitcnt(0x0F70);
+        __builtin_amdgcn_wave_barrier();
+        const int64_t pos = (int64_t)u * US, t0 = row0 + pos;
+        if (active) {
+            if (pos >= halo && ((pos - halo) % SC) == 0 && t0 < n) states[t0 / SC] = s;     // state BEFORE sample t0
+            const unsigned char *slot = fs_ring + (size_t)(u % NS) * (16 * 1024) + 16 * lane;
+            typedef TIn vecT __attribute__((ext_vector_type(G)));
+            double a2[US];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                const vecT v = *reinterpret_cast<const vecT *>(slot + k * 1024);
+#pragma unroll
+                for (int e = 0; e < G; ++e) { double a = (double)v[e]; a = fabs(a); a2[k * G + e] = a * a; }
+            }
+            if (t0 >= 0 && t0 + US <= n) {
+#pragma unroll
+                for (int j = 0; j < US; ++j) s += (a2[j] - s) * (a2[j] > s ? att : rel);
+            } else if (t0 + US > 0 && t0 < n) {
+#pragma unroll
+                for (int j = 0; j < US; ++j) { const int64_t idx = t0 + j; if (idx >= 0 && idx < n) s += (a2[j] - s) * (a2[j] > s ? att : rel); }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();               // the slot is re-targeted D units later, after this unit's reads were issued
+    }
+}
+
 // MODE 0: agate (af_agate.c gate()), MODE 1: acompressor (af_sidechaincompress.c compressor()); detection = rms
 template <int MODE, typename TIn, typename TOut>
 __global__ void __launch_bounds__(64)
@@ -779,7 +847,7 @@ k_deesser(const TIn *__restrict__ in, float *__restrict__ out, int64_t n, int64_
 }
 
 template <typename TIn>
-static void run_follow(const TIn *in, int64_t n, double att, double rel, double *states, hipStream_t s)
+static void run_follow(const TIn *in, int64_t n, double att, double rel, double *states, hipStream_t s, bool in_has_slack)
 {
     double rho = std::min(att, rel);
     int64_t halo = 4096;
@@ -790,6 +858,17 @@ static void run_follow(const TIn *in, int64_t n, double att, double rel, double 
     // (0.5 ms of each launch); the rest is the 9x re-read of the signal, 6.2 GB (f32) / 12.4 GB (f64) at ~4.5 TB/s -- the file
     // is larger than the Infinity Cache, so the re-reads come from HBM.  Longer chunks (fewer re-reads) leave too few waves to
     // cover the load latency with two tiles in flight and lose more than they save.
+    if (in_has_slack && (reinterpret_cast<uintptr_t>(in) & 15) == 0 && !getenv("JT_FOLLOW_TILES")) {
+        // LDS-streamed variant: chunks of a quarter halo (5x instead of 9x re-read; 250 waves for an hour of audio).  The vmcnt
+        // counter (63) caps a wave at 48 KB in flight, about one HBM round trip of the f32 follower's appetite and half of the f64
+        // one's, so longer chunks (fewer waves) start waiting for memory again: halo/2 and halo measured 1-2 ms worse.
+        const int64_t lchunk = std::max<int64_t>(1024, (halo / 4 + SC - 1) / SC * SC);
+        const int64_t lnch = (n + lchunk - 1) / lchunk;
+        auto k = k_follow_states_lds<TIn>;
+        JT_HIP(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+        hipLaunchKernelGGL(k, dim3((unsigned)((lnch + LANES - 1) / LANES)), dim3(LANES), 128 * 1024, s, in, n, att, rel, lchunk, halo, states, lnch);
+        return;
+    }
     int64_t chunk = std::max<int64_t>(1024, (halo / 8 + SC - 1) / SC * SC);
     int64_t nchunks = (n + chunk - 1) / chunk;
     hipLaunchKernelGGL((k_follow_states<TIn>), dim3((unsigned)((nchunks + LANES - 1) / LANES)), dim3(LANES), 0, s, in, n, att, rel, chunk, halo,
@@ -797,7 +876,8 @@ static void run_follow(const TIn *in, int64_t n, double att, double rel, double 
 }
 
 // scratch: states[(n/SC)+2] doubles, tmp64[n] doubles (gate output feeding the compressor), tmp64b[n] when the de-esser runs
-void launch_dynamics(const float *in, float *out_f32, double *tmp64, double *tmp64b, double *states, int64_t n, const DynParams &d, hipStream_t s)
+void launch_dynamics(const float *in, float *out_f32, double *tmp64, double *tmp64b, double *states, int64_t n, const DynParams &d, hipStream_t s,
+                     bool in_has_slack)
 {
     if (n <= 0) return;
     const int64_t nsub = (n + SC - 1) / SC;
@@ -806,13 +886,13 @@ void launch_dynamics(const float *in, float *out_f32, double *tmp64, double *tmp
     // stage outputs: gate -> tmp64 (if anything follows) ; comp -> tmp64b (if deesser follows) else f32 out
     const double *cur64 = nullptr; bool have64 = false;
     if (d.gate_on) {
-        run_follow<float>(in, n, d.g_attack, d.g_release, states, s);
+        run_follow<float>(in, n, d.g_attack, d.g_release, states, s, in_has_slack);
         if (d.comp_on || de) { hipLaunchKernelGGL((k_dyn_apply<0, float, double>), dim3(agrid), dim3(LANES), 0, s, in, tmp64, n, states, d, nsub); cur64 = tmp64; have64 = true; }
         else { hipLaunchKernelGGL((k_dyn_apply<0, float, float>), dim3(agrid), dim3(LANES), 0, s, in, out_f32, n, states, d, nsub); return; }
     }
     if (d.comp_on) {
-        if (have64) run_follow<double>(cur64, n, d.c_attack, d.c_release, states, s);
-        else run_follow<float>(in, n, d.c_attack, d.c_release, states, s);
+        if (have64) run_follow<double>(cur64, n, d.c_attack, d.c_release, states, s, in_has_slack);      // (tmp64 is allocated with the same slack)
+        else run_follow<float>(in, n, d.c_attack, d.c_release, states, s, in_has_slack);
         if (de) {
             if (have64) hipLaunchKernelGGL((k_dyn_apply<1, double, double>), dim3(agrid), dim3(LANES), 0, s, cur64, tmp64b, n, states, d, nsub);
             else hipLaunchKernelGGL((k_dyn_apply<1, float, double>), dim3(agrid), dim3(LANES), 0, s, in, tmp64b, n, states, d, nsub);

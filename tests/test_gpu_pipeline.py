@@ -332,6 +332,22 @@ def test_pass2_head_prefetch_changes_nothing_but_the_schedule(engine, monkeypatc
     assert np.array_equal(out_on, out_off) and r_on.output_lufs == r_off.output_lufs and r_on.pass2_spec == r_off.pass2_spec
 
 
+def test_lds_streamed_followers_match_the_tile_staged_ones(engine, monkeypatch):
+    """k_follow_states_lds (direct-to-LDS loads, longer chunks) against k_follow_states (JT_FOLLOW_TILES=1).  Both restart the
+    follower behind an 18-time-constant halo, at different places: the Pass-2 outputs may differ by the halo's 1.5e-8 relative
+    state error, i.e. by nothing once rounded to s16 -- at most a stray LSB."""
+    from jivetalking_amd.engine import default_filter_params
+    x = synth.speech_like(40.0, SR, seed=49)
+    engine.upload_pcm(x, SR, 1)
+    p = default_filter_params()
+    a = engine.pass2(p); o_lds = engine.download_s16(2).copy()
+    monkeypatch.setenv("JT_FOLLOW_TILES", "1")
+    b = engine.pass2(p); o_tile = engine.download_s16(2)
+    d = np.abs(o_lds.astype(np.int32) - o_tile.astype(np.int32))
+    assert d.max() <= 1 and np.count_nonzero(d) <= o_lds.size // 10000
+    assert abs(a["r128"]["integrated"] - b["r128"]["integrated"]) < 1e-6
+
+
 def test_two_runs_are_bit_identical(engine):
     x = synth.speech_like(20.0, SR, seed=43)
     engine.upload_pcm(x, SR, 1)
