@@ -321,7 +321,6 @@ k_biquad_f32(const float *__restrict__ in, float *__restrict__ out, int64_t n, i
     const int64_t c0 = (int64_t)blockIdx.x * LANES;
     const int nrows = (int)min((int64_t)LANES, nchunks - c0);
     const int64_t base0 = c0 * chunk - halo;
-    const int64_t my_base = base0 + (int64_t)lane * chunk;
     float w1a = 0.f, w2a = 0.f, w1b = 0.f, w2b = 0.f;
     const int64_t total = halo + chunk;
     float v[LANES];
@@ -331,11 +330,17 @@ k_biquad_f32(const float *__restrict__ in, float *__restrict__ out, int64_t n, i
         __syncthreads();
         if (pos + TW < total) rows_prefetch<float>(v, in, n, base0, chunk, pos + TW, lane);   // next tile's loads fly during this one
         if (lane < nrows) {
-#pragma unroll 8
-            for (int j = 0; j < TW; ++j) {
-                int64_t idx = my_base + pos + j;
-                float x = tile[lane][j];
-                if (idx >= 0) {     // before the file start the true state is exactly zero: keep it zero
+            // 16 samples at a time: their LDS reads first, the recurrence on registers, the stores after (left in one loop, every
+            // sample waited for its own LDS read).  Before the file start the true state is exactly zero and so is the staged input,
+            // which keeps every state at zero: no index test is needed
+#pragma unroll 1
+            for (int j0 = 0; j0 < TW; j0 += 16) {
+                float xs[16];
+#pragma unroll
+                for (int j = 0; j < 16; ++j) xs[j] = tile[lane][j0 + j];
+#pragma unroll
+                for (int j = 0; j < 16; ++j) {
+                    float x = xs[j];
                     float y = __fadd_rn(__fmul_rn(s0.b0, x), w1a);
                     w1a = __fadd_rn(__fadd_rn(__fmul_rn(s0.b1, x), w2a), __fmul_rn(s0.a1, y));
                     w2a = __fadd_rn(__fmul_rn(s0.b2, x), __fmul_rn(s0.a2, y));
@@ -346,8 +351,10 @@ k_biquad_f32(const float *__restrict__ in, float *__restrict__ out, int64_t n, i
                         w2b = __fadd_rn(__fmul_rn(s1.b2, x), __fmul_rn(s1.a2, y2));
                         x = y2;
                     }
+                    xs[j] = x;
                 }
-                tile[lane][j] = x;
+#pragma unroll
+                for (int j = 0; j < 16; ++j) tile[lane][j0 + j] = xs[j];
             }
         }
         __syncthreads();
