@@ -777,15 +777,15 @@ k_dyn_apply(const TIn *__restrict__ in, TOut *__restrict__ out, int64_t n, const
     const int64_t c0 = (int64_t)blockIdx.x * LANES;
     const int nrows = (int)min((int64_t)LANES, nsub - c0);
     const int64_t base0 = c0 * SC;
-    const int64_t my_base = base0 + (int64_t)lane * SC;
     double s = lane < nrows ? states[c0 + lane] : 0.0;
     for (int pos = 0; pos < SC; pos += TW) {
         tile_load<TIn, double>(tile, in, n, base0, SC, pos, lane, nrows);
         __syncthreads();
         if (lane < nrows) {
+            // (samples past the end of the stream are staged as zeros and never stored: no index test, so that the iterations can
+            // be unrolled and their gain curves -- independent of each other -- interleave)
+#pragma unroll 4
             for (int j = 0; j < TW; ++j) {
-                const int64_t idx = my_base + pos + j;
-                if (idx >= n) break;
                 const double v = tile[lane][j];
                 double a = fabs(v); a *= a;
                 double gain = 1.0, y;
