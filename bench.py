@@ -13,7 +13,7 @@ import sys
 import time
 
 # five HIP streams per context (main + four analysis chains): give each its own hardware queue (read at HIP runtime init)
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)

@@ -17,10 +17,11 @@ extern "C" int jt_open(int device_id, jt_ctx **out)
 {
     if (!out) return JT_E_INVAL;
     *out = nullptr;
-    // one context drives five streams (main + four analysis chains); ROCclr multiplexes streams onto GPU_MAX_HW_QUEUES (default 4)
+    // one context drives eleven streams (main, two sets of four analysis chains, two early-start streams); ROCclr multiplexes streams
+    // onto GPU_MAX_HW_QUEUES (default 4)
     // hardware queues, fixed when the runtime initialises.  Ask for more unless the host application already decided.
     static std::once_flag env_once;                    // handles may be opened from several threads (jt_process_files)
-    std::call_once(env_once, [] { setenv("GPU_MAX_HW_QUEUES", "8", 0); });
+    std::call_once(env_once, [] { setenv("GPU_MAX_HW_QUEUES", "16", 0); });
     int count = 0;
     if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) return JT_E_NOGPU;
     if (device_id < 0 || device_id >= count) return JT_E_INVAL;
