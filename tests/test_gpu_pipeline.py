@@ -346,6 +346,16 @@ def test_lds_streamed_followers_match_the_tile_staged_ones(engine, monkeypatch):
     d = np.abs(o_lds.astype(np.int32) - o_tile.astype(np.int32))
     assert d.max() <= 1 and np.count_nonzero(d) <= o_lds.size // 10000
     assert abs(a["r128"]["integrated"] - b["r128"]["integrated"]) < 1e-6
+    # lengths that are not a multiple of the 16-byte load group (the last group of the signal is read whole, into the buffers'
+    # slack), shorter than one chunk, and shorter than the halo
+    for n in (x.size - 3, 48000 * 3 + 1, 30011):
+        monkeypatch.delenv("JT_FOLLOW_TILES", raising=False)
+        engine.upload_pcm(x[:n], SR, 1)
+        engine.pass2(p); u = engine.download_s16(2).copy()
+        monkeypatch.setenv("JT_FOLLOW_TILES", "1")
+        engine.pass2(p); v = engine.download_s16(2)
+        dd = np.abs(u.astype(np.int32) - v.astype(np.int32))
+        assert u.size == v.size and dd.max() <= 1 and np.count_nonzero(dd) <= max(2, u.size // 10000), n
 
 
 def test_two_runs_are_bit_identical(engine):
