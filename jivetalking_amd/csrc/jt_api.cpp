@@ -584,7 +584,7 @@ extern "C" int jt_pass2_prefetch(jt_ctx *h, const jt_filter_params *p)
     if (sp.nst > 0) { launch_biquad_f32(cur, nxt, n, sp.nst, sp.st, sp.stream); cur = nxt; std::swap(nxt, oth); sp.stages++; }
     if (sp.nlm) { run_anlmdn(h, cur, nxt, n, sr, sp.nlm_p[0], sp.nlm_p[1], sp.nlm_p[2], sp.nlm_p[3], sp.stream); cur = nxt; std::swap(nxt, oth); sp.stages++; }
     JT_HIP(hipEventRecord(sp.done, sp.stream));
-    sp.result = cur; sp.pending = true;
+    sp.pending = true;
     JT_API_END(h)
 }
 

@@ -258,7 +258,7 @@ struct jt_ctx {
     // measurements) started by jt_pass2_prefetch while the host still works on those measurements.
     struct SpecPass2 {
         bool pending = false; int nst = 0; BiquadF32 st[2]; bool nlm = false; double nlm_p[4] = {0, 0, 0, 0};
-        const float *result = nullptr; int stages = 0; hipStream_t stream = nullptr; hipEvent_t done = nullptr;
+        int stages = 0; hipStream_t stream = nullptr; hipEvent_t done = nullptr;
     } spec_p2;
     struct SpecLoudnorm {
         bool pending = false; KwJob kw; int64_t nfull = 0; int blk = 0;
