@@ -12,7 +12,8 @@ import os
 import sys
 import time
 
-# five HIP streams per context (main + four analysis chains): give each its own hardware queue (read at HIP runtime init)
+# eleven HIP streams per context (main, two sets of four analysis chains, two early-start streams): ask for enough hardware
+# queues that they do not serialise behind each other (read at HIP runtime init)
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
