@@ -336,9 +336,15 @@ static void analysis_complete(jt_ctx *h, const AnalysisJob &J, jt_analysis *out,
 {
     (void)h;
     AnalysisHost A;
+    const bool timing = getenv("JT_HOST_TIMING") != nullptr;
+    std::chrono::steady_clock::time_point t0; if (timing) t0 = std::chrono::steady_clock::now();
     analysis_finish(J, &A);
     out->astats = A.astats;
+    std::chrono::steady_clock::time_point t1; if (timing) t1 = std::chrono::steady_clock::now();
     assemble_analysis(A, J.n, J.dualmono, out, meta, cap_meta);
+    if (timing) fprintf(stderr, "analysis_complete (n = %lld): finish %.3f ms, assemble %.3f ms\n", (long long)J.n,
+                        std::chrono::duration<double, std::milli>(t1 - t0).count(),
+                        std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t1).count());
 }
 
 // ---------------------------------------------------------------- Pass 1
