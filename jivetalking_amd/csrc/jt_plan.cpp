@@ -177,28 +177,28 @@ void jt_r128_finish(const double *bs, int64_t nblocks, int blk, int sr, bool dua
     double kept400 = 0, kept3000 = 0; int64_t nk400 = 0, nk3000 = 0;
     double rel400 = 0;
     o->M.assign(nblocks, 0.0); o->S.assign(nblocks, 0.0);
-    // per block: momentary / short-term loudness (the log10s) in parallel, un-panned values kept in M/S for the serial gating walk
+    // per block: window powers and momentary / short-term loudness (the log10s) in parallel; the powers and the un-panned
+    // loudness values are kept for the serial gating walk
+    std::vector<double> pw400((size_t)nblocks), pw3000((size_t)nblocks);
     jt_parallel_for(nblocks, [&](int64_t lo, int64_t hi, int) {
         for (int64_t k = lo; k < hi; ++k) {
             // window sums recomputed from the block energies each step (no add/sub drift)
             double p400 = 1e-12, p3000 = 1e-12;
             if (k >= 3)  { const double w400 = bs[k] + bs[k - 1] + bs[k - 2] + bs[k - 3]; p400 += w400; p400 /= bins400; }
             if (k >= 29) { double w = 0; for (int q = 29; q >= 0; --q) w += bs[k - q]; p3000 += w; p3000 /= bins3000; }
+            pw400[(size_t)k] = p400; pw3000[(size_t)k] = p3000;
             o->M[k] = LOUDNESS(p400); o->S[k] = LOUDNESS(p3000);
         }
     });
     for (int64_t k = 0; k < nblocks; ++k) {
-        double p400 = 1e-12, p3000 = 1e-12;
-        if (k >= 3)  { const double w400 = bs[k] + bs[k - 1] + bs[k - 2] + bs[k - 3]; p400 += w400; p400 /= bins400; }
         const double l400 = o->M[k], l3000 = o->S[k];
         if (l400 >= ABS_THRES) {
             h400[clipi(HIST_POS(l400), 0, HIST_SIZE - 1)]++;
-            kept400 += p400; nk400++;
+            kept400 += pw400[(size_t)k]; nk400++;
         }
         if (l3000 >= ABS_THRES) {
-            if (k >= 29) { double w = 0; for (int q = 29; q >= 0; --q) w += bs[k - q]; p3000 += w; p3000 /= bins3000; }
             h3000[clipi(HIST_POS(l3000), 0, HIST_SIZE - 1)]++;
-            kept3000 += p3000; nk3000++;
+            kept3000 += pw3000[(size_t)k]; nk3000++;
         }
         if (dualmono) { o->M[k] = l400 - pan_law; o->S[k] = l3000 - pan_law; }
     }
