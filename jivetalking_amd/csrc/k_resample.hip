@@ -266,6 +266,15 @@ k_upsample32(const TIn *__restrict__ in, int64_t n, const TTap *__restrict__ ban
     // All index arithmetic below is 32-bit and strength-reduced: the phase advances by `step` modulo P from one output to the next,
     // a lane's outputs of one item are m_base + j, and the end of the stream is a per-lane bound on j.  (Written with 64-bit
     // products, divisions and modulos per output, this loop spent ~150 scalar instructions per 32 FMAs.)
+    TAcc run_v = (TAcc)0; int run_sl = -1;                           // MODE 0: per-lane running maximum for block slot run_sl
+    auto flush_run = [&]() {
+        if (run_sl < 0) return;
+        TAcc v = run_v;
+#pragma unroll
+        for (int mm = 1; mm < 64; mm <<= 1) v = fmax(v, __shfl_xor(v, mm, 64));
+        if (lane == 0 && v > (TAcc)0) atomicMax(&slots[run_sl], (unsigned long long)__double_as_longlong((double)v));
+        run_v = (TAcc)0; run_sl = -1;
+    };
     for (int item0 = wave; item0 < nitems; item0 += PP_THREADS / 64) {
         const int item = __builtin_amdgcn_readfirstlane(item0);
         const int off = item / R, kc = item - off * R;
@@ -358,12 +367,11 @@ k_upsample32(const TIn *__restrict__ in, int64_t n, const TTap *__restrict__ ban
             }
             const int sl_lo = __builtin_amdgcn_readfirstlane(sl[0]), sl_hi = __builtin_amdgcn_readlane(sl[QL - 1], 63);
             if (sl_lo == sl_hi && sl_lo >= 0 && sl_lo < 8) {
-                TAcc v = vm[0];
+                // consecutive items of a wave almost always land in the same block too: the lanes keep running maxima and the
+                // wave reduces them once per block it touches (flush_run), not once per item
+                if (run_sl != sl_lo) { flush_run(); run_sl = sl_lo; }
 #pragma unroll
-                for (int u = 1; u < QL; ++u) v = fmax(v, vm[u]);
-#pragma unroll
-                for (int mm = 1; mm < 64; mm <<= 1) v = fmax(v, __shfl_xor(v, mm, 64));
-                if (lane == 0 && v > (TAcc)0) atomicMax(&slots[sl_lo], (unsigned long long)__double_as_longlong((double)v));
+                for (int u = 0; u < QL; ++u) run_v = fmax(run_v, vm[u]);
             } else {
 #pragma unroll
                 for (int u = 0; u < QL; ++u) {
@@ -377,6 +385,7 @@ k_upsample32(const TIn *__restrict__ in, int64_t n, const TTap *__restrict__ ban
         }
     }
     if (MODE == 0) {
+        flush_run();
         __syncthreads();
         if (tid < 8 && slots[tid]) {
             int64_t b = b_first + tid;
