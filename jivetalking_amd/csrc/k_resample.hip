@@ -355,12 +355,15 @@ k_upsample32(const TIn *__restrict__ in, int64_t n, const TTap *__restrict__ ban
             const int64_t base0 = s0 - center + L - 1;                              // `last` of tile sample 0 (block-uniform)
             const int64_t bq = (base0 < 0 ? base0 - (blk - 1) : base0) / blk;        // floor division, once per workgroup value
             const unsigned brem = (unsigned)(base0 - bq * blk);
+            const bool smallq = (unsigned)(T + L) < 2u * (unsigned)blk;
             int sl[QL]; TAcc vm[QL];
 #pragma unroll
             for (int u = 0; u < QL; ++u) {
                 const unsigned t = brem + (unsigned)(si + u * step);
                 const int64_t last = base0 + si + u * step;
-                int64_t b = bq + (int64_t)(t / (unsigned)blk);
+                // t < blk + T + L: with a tile shorter than two blocks the quotient is 0, 1 or 2 (two compares instead of a division)
+                const unsigned tq = smallq ? (unsigned)(t >= (unsigned)blk) + (unsigned)(t >= 2u * (unsigned)blk) : t / (unsigned)blk;
+                int64_t b = bq + (int64_t)tq;
                 if (b >= nblocks_alloc) b = nblocks_alloc - 1;
                 sl[u] = (int)(b - b_first);
                 vm[u] = (last >= 0 && last <= n - 1) ? vmax[u] : (TAcc)0;
