@@ -153,8 +153,8 @@ def main():
         nlm_roof = {"kernel": "k_anlmdn_pair<3>", "bound": "hbm", "achieved": round(nlm_bytes / nlm_avg_s / 1e9, 2),
                     "peak": 8000, "unit": "GB/s", "frac": round(nlm_bytes / nlm_avg_s / 1e9 / 8000, 5), "traffic": None,
                     "note": "vector-FP32 bound, not HBM bound (SURVEY §8d): add/mul-only recurrence (FFmpeg's unfused f32 order), "
-                            "so the applicable peak is the non-FMA packed rate.  Since the Pass-2 head is started before Pass 1 (jt_pass2_prefetch) this "
-                            "launch shares the GPU with the Pass-1 analysis chains: 11.9 ms alone (JT_NO_PASS2_PREFETCH=1), ~15 ms here",
+                            "so the applicable peak is the non-FMA packed rate.  This launch is the early Pass-2 head (jt_pass2_prefetch_after_pass1): "
+                            "it is queued behind the Pass-1 analysis kernels and shares the GPU with their tails",
                     "valu": {"achieved_TFLOPs": round(nlm_flops / nlm_avg_s / 1e12, 2), "peak_TFLOPs_no_fma": 78.6,
                              "frac": round(nlm_flops / nlm_avg_s / 1e12 / 78.6, 4)},
                     "avg_launch_ms": round(nlm_avg_s * 1e3, 3)}

@@ -134,6 +134,9 @@ int jt_pass2(jt_ctx *h, const jt_filter_params *p, jt_analysis *out);
  * called as soon as the input is on the device: jt_pass1, jt_band_rms and jt_region_prefetch leave it running, any other call
  * on the handle retires it first. */
 int jt_pass2_prefetch(jt_ctx *h, const jt_filter_params *p);
+/* The same head, queued by the next jt_pass1 right behind its own kernels instead of at once: the analysis the host is waiting
+ * for then takes its CU slots first and the head's large grid fills in around it. */
+int jt_pass2_prefetch_after_pass1(jt_ctx *h, const jt_filter_params *p);
 
 /* ---- region re-measure: replaces measureOutputRegionFromReader (analyser_output.go:95-227) over
  * "atrim=start:duration,asetpts=PTS-STARTPTS,astats=metadata=1:measure_perchannel=0,

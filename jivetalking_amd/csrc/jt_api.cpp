@@ -10,6 +10,7 @@
 #include <exception>
 
 static void check_cancel(jt_ctx *h) { if (h->cancelled.load()) throw JtError{JT_E_CANCELLED, "cancelled"}; }
+static void spec_pass2_start(jt_ctx *h, const jt_filter_params *p);     // the early Pass-2 head (defined with jt_pass2_prefetch)
 
 extern "C" const char *jt_version(void) { return "jtgpu 0.1 (gfx950)"; }
 
@@ -98,6 +99,7 @@ static void ensure_hann(jt_ctx *h, int N)
 
 void jt_spec_pass2_cancel(jt_ctx *h)
 {
+    h->spec_p2.armed = false;
     if (h->spec_p2.pending) { h->spec_p2.pending = false; JT_HIP(hipStreamSynchronize(h->spec_p2.stream)); }
 }
 
@@ -370,6 +372,8 @@ extern "C" int jt_pass1(jt_ctx *h, int frame_samples, jt_analysis *out, double *
     }
     AnalysisJob J;
     analysis_enqueue(h, h->in_mono, h->n, h->sr, true, h->sr / 10, &J);
+    // an announced Pass-2 head goes in behind the analysis: its 150 k workgroups would otherwise take every slot first
+    if (h->spec_p2.armed) { h->spec_p2.armed = false; spec_pass2_start(h, &h->spec_p2.armed_p); }
     JT_HIP(hipStreamSynchronize(h->stream));
     check_cancel(h);
     if (fst) {
@@ -575,12 +579,26 @@ extern "C" int jt_pass2_prefetch(jt_ctx *h, const jt_filter_params *p)
     JT_REQUIRE(h->n > 0 && h->in_mono, JT_E_STATE, "pass2_prefetch: no input uploaded");
     JT_REQUIRE(p, JT_E_INVAL, "pass2_prefetch: bad arguments");
     if (getenv("JT_NO_PASS2_PREFETCH")) return JT_OK;         // (A/B switch: Pass 2 then runs every stage itself)
+    spec_pass2_start(h, p);
+    JT_API_END(h)
+}
+extern "C" int jt_pass2_prefetch_after_pass1(jt_ctx *h, const jt_filter_params *p)
+{
+    JT_API_BEGIN(h)
+    JT_REQUIRE(h->n > 0 && h->in_mono, JT_E_STATE, "pass2_prefetch: no input uploaded");
+    JT_REQUIRE(p, JT_E_INVAL, "pass2_prefetch: bad arguments");
+    if (getenv("JT_NO_PASS2_PREFETCH")) return JT_OK;
+    h->spec_p2.armed_p = *p; h->spec_p2.armed = true;
+    JT_API_END(h)
+}
+static void spec_pass2_start(jt_ctx *h, const jt_filter_params *p)
+{
     jt_ctx::SpecPass2 &sp = h->spec_p2;
     const int64_t n = h->n; const int sr = h->sr;
     fill_biquads(p, sr, sp.st, &sp.nst);
     sp.nlm = p->nlm_enabled != 0;
     sp.nlm_p[0] = p->nlm_strength; sp.nlm_p[1] = p->nlm_patch_s; sp.nlm_p[2] = p->nlm_research_s; sp.nlm_p[3] = p->nlm_smooth;
-    if (sp.nst == 0 && !sp.nlm) return JT_OK;                 // nothing to start
+    if (sp.nst == 0 && !sp.nlm) return;                       // nothing to start
     h->work_a.ensure((size_t)n + 16); h->work_b.ensure((size_t)n + 16);
     // the same buffer walk as jt_pass2: in_mono -> work_a -> work_b
     const float *cur = h->in_mono; float *nxt = h->work_a.p; float *oth = h->work_b.p;
@@ -591,7 +609,6 @@ extern "C" int jt_pass2_prefetch(jt_ctx *h, const jt_filter_params *p)
     if (sp.nlm) { run_anlmdn(h, cur, nxt, n, sr, sp.nlm_p[0], sp.nlm_p[1], sp.nlm_p[2], sp.nlm_p[3], sp.stream); cur = nxt; std::swap(nxt, oth); sp.stages++; }
     JT_HIP(hipEventRecord(sp.done, sp.stream));
     sp.pending = true;
-    JT_API_END(h)
 }
 
 // Pass 3 for a plan without limiter prefix (loudnorm's first-pass measurement of the s16 output: swr -> 192 kHz, K-weighting,

@@ -1003,13 +1003,14 @@ static int analyse_core(jt_ctx *h, const jt_host_config *base, int frame_samples
     std::vector<jt_frame_meta> meta((size_t)cap_meta);
     if (pass2_follows) {
         // AdaptConfig takes the rumble filter, the band-limit filter and anlmdn from the base configuration, never from the
-        // measurements (jt_host_adapt: tuneBandlimitLowPass is a constant, the other two are not tuned): the GPU can start them at once,
-        // beside the Pass-1 analysis and while this thread builds intervals, runs the VAD and waits for the band measurements.  jt_pass2 checks the parameters.
+        // measurements (jt_host_adapt: tuneBandlimitLowPass is a constant, the other two are not tuned): the GPU can start them beside
+        // the Pass-1 analysis (jt_pass1 queues them right behind its own kernels) and keep going while this thread builds intervals,
+        // runs the VAD and waits for the band measurements.  jt_pass2 checks the parameters.
         jt_measurements none; std::memset(&none, 0, sizeof(none));
         jt_host_config guess; jt_adaptive_diag dg;
         jt_host_adapt(base, &none, &guess, &dg);
         jt_filter_params fp; jt_host_filter_params(&guess, &fp);
-        (void)jt_pass2_prefetch(h, &fp);                      // best effort: Pass 2 runs from the input if this did not start
+        (void)jt_pass2_prefetch_after_pass1(h, &fp);          // best effort: Pass 2 runs from the input if this did not start
     }
     double t0 = now_ms();
     if ((rc = jt_pass1(h, frame_samples, &a1, fss.data(), fpk.data(), nfr, meta.data(), cap_meta)) != JT_OK) return rc;

@@ -259,6 +259,7 @@ struct jt_ctx {
     struct SpecPass2 {
         bool pending = false; int nst = 0; BiquadF32 st[2]; bool nlm = false; double nlm_p[4] = {0, 0, 0, 0};
         int stages = 0; hipStream_t stream = nullptr; hipEvent_t done = nullptr;
+        bool armed = false; jt_filter_params armed_p;      // jt_pass2_prefetch_after_pass1: started by the next jt_pass1
     } spec_p2;
     struct SpecLoudnorm {
         bool pending = false; KwJob kw; int64_t nfull = 0; int blk = 0;

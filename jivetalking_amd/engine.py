@@ -138,6 +138,10 @@ class Engine:
         """Start the head of the Pass-2 chain (biquads + anlmdn) early (jt_pass2_prefetch)."""
         self._ck(self.lib.jt_pass2_prefetch(self.h, C.byref(params)))
 
+    def pass2_prefetch_after_pass1(self, params):
+        """Announce the Pass-2 head; the next pass1 queues it behind its own kernels (jt_pass2_prefetch_after_pass1)."""
+        self._ck(self.lib.jt_pass2_prefetch_after_pass1(self.h, C.byref(params)))
+
     def region_measure(self, stage, start_s, dur_s):
         r = L.RegionSample()
         self._ck(self.lib.jt_region_measure(self.h, C.c_int(stage), C.c_double(start_s), C.c_double(dur_s), C.byref(r)))

@@ -325,6 +325,13 @@ def test_pass2_head_prefetch_changes_nothing_but_the_schedule(engine, monkeypatc
     engine.pass1(x.size); engine.band_rms(1.0, 2.0, [1000.0], [3000.0])
     a2 = engine.pass2(p); o2 = engine.download_s16(2)
     assert np.array_equal(o0, o2) and y.size == SR and a2["r128"]["integrated"] == a0["r128"]["integrated"]
+    engine.pass2_prefetch_after_pass1(p)                                      # announced: Pass 1 starts it behind its own kernels
+    engine.pass1(x.size)
+    a3 = engine.pass2(p); o3 = engine.download_s16(2)
+    assert np.array_equal(o0, o3) and a3["r128"]["integrated"] == a0["r128"]["integrated"]
+    engine.pass2_prefetch_after_pass1(p)                                      # announced but no Pass 1 follows: nothing started, nothing lost
+    a4 = engine.pass2(p); o4 = engine.download_s16(2)
+    assert np.array_equal(o0, o4) and a4["r128"]["integrated"] == a0["r128"]["integrated"]
     # the orchestration: with and without the early head (and the early Pass-3 measurement) the run is the same run
     r_on = H.process_audio(engine); out_on = engine.download_s16(4).copy()
     monkeypatch.setenv("JT_NO_PASS2_PREFETCH", "1"); monkeypatch.setenv("JT_NO_EARLY_PASS3", "1")
