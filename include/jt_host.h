@@ -184,10 +184,18 @@ int jt_analyse_only(jt_ctx *h, const jt_host_config *base, int frame_samples, jt
  * (processor.go:78-330) reads inputPath through libavformat for every pass, writes a temp FLAC after Pass 2 and the final
  * "<name>-LUFS-<n>-processed.flac" after Pass 4 (processor.go:379-388).  Here: read the file once, jt_load_audio (decode on
  * the GPU), the four passes, jt_flac_encode(stage 4) and one write of the finished image.  flac_flags: JT_FLAC_MD5 or 0.
+ * The image is written to a hidden sibling ".processing-*.tmp.flac" and renamed over the final name only when complete
+ * (createSiblingTempPath + publishOutput, file_write.go:13-53); on any error or cancellation no temp file remains and an existing
+ * output of that name is left untouched.
  * output_path receives the written path (cap bytes).  io_ms: read, decode, encode, write (host wall clock).
  * Errors: JT_E_INVAL when the input cannot be opened/read or the output cannot be written, otherwise as the calls above. */
 int jt_process_file(jt_ctx *h, const char *input_path, const jt_host_config *base, int frame_samples, int flac_flags,
                     jt_progress_fn cb, void *user, jt_process_result *out, char *output_path, int cap, double io_ms[4]);
+
+/* Test seam: makes the next jt_process_file calls fail at temp creation / temp write / publish (the failures the reference injects
+ * through processorCreateSiblingTempPath, a failing encoder and processorRename: processor_test.go:552-627) so that the
+ * no-residue discipline can be tested.  All zero = normal operation. */
+void jt_host_test_inject_fault(int create_temp, int write, int rename_);
 
 /* Several files on one GPU — the reference's bounded worker pool (cmd/jivetalking/pool.go:122-228: `runBoundedPool` runs at most
  * N ProcessAudio calls at a time, one file's failure never stops the others, every file gets its own result).  Here a worker is a

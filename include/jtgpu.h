@@ -39,12 +39,27 @@ int  jt_open(int device_id, jt_ctx **out);
 void jt_close(jt_ctx *h);
 const char *jt_last_error(const jt_ctx *h);
 const char *jt_version(void);
-void jt_cancel(jt_ctx *h);                 /* may be called from another thread */
+/* ctx cancellation (frame_processor.go:116-118: ctx.Err() is checked per frame and is sticky for the whole ProcessAudio call).
+ * jt_cancel may be called from another thread at any time; every pass / measurement on the handle then returns JT_E_CANCELLED
+ * (a pass already queued on the GPU returns it when its kernels have drained, a few tens of ms) until a NEW JOB starts:
+ * jt_upload_pcm / jt_attach_device_pcm / jt_load_audio / jt_process_file clear the flag, or jt_reset_cancel does.  The passes
+ * themselves never clear it, so a cancel that lands between two passes is not lost.  The handle stays usable. */
+void jt_cancel(jt_ctx *h);
+void jt_reset_cancel(jt_ctx *h);
 
 /* ---- input: replaces audio.Reader.ReadFrame feeding abuffer (reader.go:129, frame_processor.go:131-146) ---- */
-/* interleaved f32 PCM in host memory; copied to HBM. channels 1 or 2 (2 => aformat=channel_layouts=mono
- * downmix, filters.go:607-615, float formats: (L+R)*M_SQRT1_2 per swresample rematrix). */
+/* interleaved f32 PCM in host memory; copied to HBM. channels 1 or 2.  2 => the aformat=channel_layouts=mono down-mix
+ * (filters.go:607-615) = libswresample's rematrix in the aresample libavfilter auto-inserts: Pass 1 and Pass 2 both hold a
+ * float-only filter (aspectralstats / anlmdn), so that converter's internal and output formats are FLTP whatever the decoder
+ * produced, auto_matrix does not normalise (maxval = INT_MAX), and mono = fl(fl(c*L) + fl(c*R)), c = (float)M_SQRT1_2
+ * (DESIGN.md section 3 has the derivation; a stereo file with L == R therefore comes out 3.01 dB hotter, as with FFmpeg). */
 int jt_upload_pcm(jt_ctx *h, const float *interleaved, int64_t frames, int sample_rate, int channels);
+/* The decoder's native sample format of the PCM just uploaded / attached (they reset it to float): integer sources were scaled
+ * by 2^(1-bits) to f32.  It matters in one place: the band-RMS graphs (analyser_bands.go:33) contain no float-only filter, so
+ * libavfilter runs their biquads in the source's own width -- s16p (float state, output truncated and clipped per stage) for
+ * <= 16-bit sources, s32p (double state) for 24/32-bit ones -- with an integer-normalised 0.5/0.5 down-mix, and astats divides
+ * by INT16_MAX / INT32_MAX.  jt_load_audio sets this from the file. */
+int jt_set_source_format(jt_ctx *h, int bits_per_sample, int is_float);
 /* same, but the PCM is already resident in device memory (hipMalloc'd by the caller, e.g. a torch tensor);
  * not copied, must stay alive until jt_close / next upload. */
 int jt_attach_device_pcm(jt_ctx *h, const void *dev_ptr, int64_t frames, int sample_rate, int channels);

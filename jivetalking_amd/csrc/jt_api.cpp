@@ -108,15 +108,16 @@ void jt_set_input_common(jt_ctx *h, int64_t frames, int sr, int ch)
     JT_REQUIRE(frames > 0, JT_E_INVAL, "empty input");
     JT_REQUIRE(sr >= 8000 && sr <= 384000, JT_E_INVAL, "unsupported sample rate");
     JT_REQUIRE(ch >= 1 && ch <= 8, JT_E_INVAL, "unsupported channel count");
-    // aformat=channel_layouts=mono goes through libswresample's layout-specific rematrix; only the stereo matrix (0.5 / 0.5) is
-    // restated here, so surround layouts are refused instead of being averaged with the wrong weights
+    // aformat=channel_layouts=mono goes through libswresample's layout-specific rematrix; only the stereo matrix is restated
+    // here (k_downmix), so surround layouts are refused instead of being averaged with the wrong weights
     JT_REQUIRE(ch <= 2, JT_E_UNSUPPORTED, "only mono and stereo inputs are down-mixed on the device (surround layouts need swresample's matrix)");
     h->n = frames; h->sr = sr; h->channels = ch;
     h->m_p2 = h->m_p4 = 0;
+    if (!h->hold_cancel) h->cancelled.store(0);           // a new job: jt_cancel() is sticky from here until the next input / jt_reset_cancel
     if (ch == 1) h->in_mono = h->in_raw;
     else {
         h->mono.ensure((size_t)frames);
-        launch_downmix(h->in_raw, h->mono.p, frames, ch, h->stream);
+        launch_downmix(h->in_raw, h->mono.p, frames, ch, 0, h->stream);
         h->in_mono = h->mono.p;
     }
 }
@@ -128,6 +129,7 @@ extern "C" int jt_upload_pcm(jt_ctx *h, const float *pcm, int64_t frames, int sr
     h->in_owned.ensure((size_t)frames * ch);
     JT_HIP(hipMemcpyAsync(h->in_owned.p, pcm, sizeof(float) * (size_t)frames * ch, hipMemcpyHostToDevice, h->stream));
     h->in_raw = h->in_owned.p;
+    h->src_fmt = 0;
     jt_set_input_common(h, frames, sr, ch);
     JT_HIP(hipStreamSynchronize(h->stream));
     JT_API_END(h)
@@ -138,6 +140,7 @@ extern "C" int jt_attach_device_pcm(jt_ctx *h, const void *dev_ptr, int64_t fram
     JT_API_BEGIN(h)
     JT_REQUIRE(dev_ptr && frames > 0, JT_E_INVAL, "bad device pcm arguments");
     h->in_raw = static_cast<const float *>(dev_ptr);
+    h->src_fmt = 0;
     jt_set_input_common(h, frames, sr, ch);
     JT_HIP(hipStreamSynchronize(h->stream));
     JT_API_END(h)
@@ -356,7 +359,7 @@ extern "C" int jt_pass1(jt_ctx *h, int frame_samples, jt_analysis *out, double *
     JT_API_BEGIN_KEEP(h)                      // (reads the input only: a running Pass-2 head is left alone)
     JT_REQUIRE(h->n > 0 && h->in_raw, JT_E_STATE, "pass1: no input uploaded");
     JT_REQUIRE(out && frame_samples > 0, JT_E_INVAL, "pass1: bad arguments");
-    h->cancelled.store(0);
+    check_cancel(h);
     JT_HIP(hipEventRecord(h->ev0, h->stream));
     std::memset(out, 0, sizeof(*out));
     const int64_t nfr = (h->n + frame_samples - 1) / frame_samples;
@@ -473,21 +476,31 @@ extern "C" int jt_band_rms(jt_ctx *h, double start_s, double dur_s, const double
     for (int b = 0; b < n_bands; ++b) { out_db[b] = NAN; if (ok) ok[b] = 0; }
     if (len <= 0) return JT_OK;
     JT_REQUIRE(n_bands <= 16, JT_E_INVAL, "band_rms: at most 16 bands per call");
-    BiquadF32 hp[16], lp[16]; int slot[16]; int nb = 0;
+    check_cancel(h);
+    double hp[16][5], lp[16][5]; int slot[16]; int nb = 0;
     for (int b = 0; b < n_bands; ++b) {
         // a corner at/above Nyquist has no valid biquad: the reference treats those bands as unmeasurable (non-finite)
         if (hi_hz[b] >= h->sr * 0.5 || lo_hz[b] >= h->sr * 0.5) { out_db[b] = NAN; if (ok) ok[b] = 1; continue; }
         double bh[3], ah[3], bl[3], al[3];
         jt_biquad_design(0, lo_hz[b], 0.707, h->sr, bh, ah, 0);
         jt_biquad_design(1, hi_hz[b], 0.707, h->sr, bl, al, 0);
-        hp[nb] = BiquadF32{(float)bh[0], (float)bh[1], (float)bh[2], -(float)ah[1], -(float)ah[2]};
-        lp[nb] = BiquadF32{(float)bl[0], (float)bl[1], (float)bl[2], -(float)al[1], -(float)al[2]};
+        for (int k = 0; k < 3; ++k) { hp[nb][k] = bh[k]; lp[nb][k] = bl[k]; }
+        hp[nb][3] = -ah[1]; hp[nb][4] = -ah[2]; lp[nb][3] = -al[1]; lp[nb][4] = -al[2];
         slot[nb++] = b;
     }
     if (nb > 0) {
+        // The band graph holds no float-only filter, so libavfilter keeps the decoder's integer width for it:
+        // s16p / s32p biquads, and for a stereo source a down-mix of its own (integer matrix, not Pass 1's 1/sqrt2).
+        const int mode = h->src_fmt;
+        const float *src = h->in_mono + s0;
+        if (mode != 0 && h->channels == 2) {
+            h->band_mono.ensure((size_t)len);
+            launch_downmix(h->in_raw + s0 * 2, h->band_mono.p, len, 2, mode, h->stream);
+            src = h->band_mono.p;
+        }
         h->d_scr1.ensure(16);
         JT_HIP(hipMemsetAsync(h->d_scr1.p, 0, sizeof(double) * 16, h->stream));
-        launch_band_rms(h->in_mono + s0, len, nb, hp, lp, h->d_scr1.p, h->stream);
+        launch_band_rms(src, len, nb, hp, lp, mode, h->d_scr1.p, h->stream);
         double sums[16];
         JT_HIP(hipMemcpyAsync(sums, h->d_scr1.p, sizeof(double) * 16, hipMemcpyDeviceToHost, h->stream));
         JT_HIP(hipStreamSynchronize(h->stream));
@@ -498,6 +511,17 @@ extern "C" int jt_band_rms(jt_ctx *h, double start_s, double dur_s, const double
     }
     JT_API_END(h)
 }
+
+extern "C" int jt_set_source_format(jt_ctx *h, int bits_per_sample, int is_float)
+{
+    if (!h) return JT_E_INVAL;
+    if (is_float) { if (bits_per_sample != 32 && bits_per_sample != 64) { h->err = "source format: float PCM is 32 or 64 bits"; return JT_E_INVAL; } h->src_fmt = 0; return JT_OK; }
+    if (bits_per_sample < 4 || bits_per_sample > 32) { h->err = "source format: integer PCM is 4..32 bits"; return JT_E_INVAL; }
+    h->src_fmt = bits_per_sample <= 16 ? 1 : 2;         // libavcodec hands 8/16-bit PCM and <= 16-bit FLAC out as (u8/)s16, wider as s32
+    return JT_OK;
+}
+
+extern "C" void jt_reset_cancel(jt_ctx *h) { if (h) h->cancelled.store(0); }
 
 // ---------------------------------------------------------------- Pass 2
 static void run_anlmdn(jt_ctx *h, const float *in, float *out, int64_t n, int sr, double strength, double patch_s, double research_s, double smooth,
@@ -646,7 +670,7 @@ extern "C" int jt_pass2(jt_ctx *h, const jt_filter_params *p, jt_analysis *out)
     JT_REQUIRE(p && out, JT_E_INVAL, "pass2: bad arguments");
     JT_REQUIRE(!(p->fft_enabled && p->fft_track_noise), JT_E_UNSUPPORTED,
                "pass2: afftdn tn=1 (noise tracking) is not implemented on the GPU path");
-    h->cancelled.store(0);
+    check_cancel(h);
     std::memset(out, 0, sizeof(*out));
     JT_HIP(hipEventRecord(h->ev0, h->stream));
     const int64_t n = h->n; const int sr = h->sr;
@@ -820,7 +844,7 @@ extern "C" int jt_pass3(jt_ctx *h, const jt_limiter_plan *lim, double target_i, 
     (void)target_i; (void)target_tp; (void)target_lra;
     JT_REQUIRE(h->m_p2 > 0, JT_E_STATE, "pass3: no Pass-2 output on device");
     JT_REQUIRE(out, JT_E_INVAL, "pass3: bad arguments");
-    h->cancelled.store(0);
+    check_cancel(h);
     JT_HIP(hipEventRecord(h->ev0, h->stream));
     pass3_core(h, h->s16_p2.p, h->m_p2, h->out_rate, lim, out);
     JT_HIP(hipEventRecord(h->ev1, h->stream));
@@ -835,7 +859,7 @@ extern "C" int jt_pass4(jt_ctx *h, const jt_limiter_plan *lim, const jt_loudnorm
     JT_API_BEGIN(h)
     JT_REQUIRE(h->m_p2 > 0, JT_E_STATE, "pass4: no Pass-2 output on device");
     JT_REQUIRE(ap && out, JT_E_INVAL, "pass4: bad arguments");
-    h->cancelled.store(0);
+    check_cancel(h);
     JT_HIP(hipEventRecord(h->ev0, h->stream));
     std::memset(out, 0, sizeof(*out));
     const int64_t m = h->m_p2; const int rate = h->out_rate;

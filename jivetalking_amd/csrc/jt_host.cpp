@@ -4,6 +4,9 @@
 // Scalar double arithmetic in the same order as the Go code so results are bit-identical; durations are Go
 // time.Duration nanoseconds (int64).  See include/jt_host.h for the file:line map.
 #include "jt_internal.h"
+#include <unistd.h>
+#include <sys/stat.h>
+#include <cerrno>
 #include "../../include/jt_host.h"
 #include <algorithm>
 #include <cstdarg>
@@ -1255,6 +1258,13 @@ extern "C" double jt_host_vad_floored_fraction(const jt_interval *ivp, int64_t n
 }
 
 // ---------------------------------------------------------------- file in, file out (processor.go:78-330)
+// fault injection for the no-residue tests (the reference injects the same three failures through its package-level seams
+// processorCreateSiblingTempPath / processorRename and a failing encoder: processor_test.go:552-627, normalise_test.go:573-820)
+static std::atomic<int> g_fault_create_temp{0}, g_fault_write{0}, g_fault_rename{0};
+extern "C" void jt_host_test_inject_fault(int create_temp, int write, int rename_)
+{
+    g_fault_create_temp.store(create_temp); g_fault_write.store(write); g_fault_rename.store(rename_);
+}
 extern "C" int jt_process_file(jt_ctx *h, const char *input_path, const jt_host_config *base, int frame_samples, int flac_flags,
                                jt_progress_fn cb, void *user, jt_process_result *out, char *output_path, int cap, double io_ms[4])
 {
@@ -1262,6 +1272,9 @@ extern "C" int jt_process_file(jt_ctx *h, const char *input_path, const jt_host_
     auto fail = [&](int code, const std::string &msg) { h->err = msg; return code; };
     auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     double t = now();
+    // the job starts here: a jt_cancel() from now on (during the read, the decode, any pass, the encode, the write) ends it
+    h->cancelled.store(0);
+    struct Hold { jt_ctx *h; Hold(jt_ctx *c) : h(c) { h->hold_cancel = true; } ~Hold() { h->hold_cancel = false; } } hold(h);
     // the file image goes straight into pinned memory (the handle's FLAC staging arena: nothing is in flight between files),
     // so the upload runs at the full PCIe rate instead of through HIP's pageable bounce buffers
     uint8_t *image = nullptr; size_t image_len = 0;
@@ -1282,6 +1295,7 @@ extern "C" int jt_process_file(jt_ctx *h, const char *input_path, const jt_host_
     }
     if (io_ms) io_ms[0] = now() - t;
     t = now();
+    if (h->cancelled.load()) return fail(JT_E_CANCELLED, "cancelled");
     jt_audio_meta meta;
     int rc = jt_load_audio(h, image, (int64_t)image_len, &meta);
     if (rc != JT_OK) return rc;
@@ -1298,11 +1312,28 @@ extern "C" int jt_process_file(jt_ctx *h, const char *input_path, const jt_host_
     if (jt_host_output_path(input_path, jt_host_lufs_filename_value(out->output_lufs), path, (int)sizeof path) < 0)
         return fail(JT_E_INVAL, "output path too long");
     {
-        FILE *f = fopen(path, "wb");
-        if (!f) return fail(JT_E_INVAL, std::string("failed to open output file: ") + path);
-        const size_t put = fwrite(data, 1, (size_t)len, f);
-        const int cl = fclose(f);
-        if (put != (size_t)len || cl != 0) { remove(path); return fail(JT_E_INVAL, std::string("failed to write output file: ") + path); }
+        // createSiblingTempPath(inputPath, "processing") + publishOutput (file_write.go:13-53, processor.go:126-135,206-213): the
+        // image goes to a hidden ".processing-*.tmp.flac" beside the input and is renamed over the final name only when complete;
+        // on any failure the temp file is removed and the final name is never touched.
+        std::string dir(path);
+        const size_t sl = dir.find_last_of('/');
+        dir = sl == std::string::npos ? "" : dir.substr(0, sl + 1);
+        std::string tmpl = dir + ".processing-XXXXXX.tmp.flac";
+        std::vector<char> tmp(tmpl.begin(), tmpl.end()); tmp.push_back(0);
+        const int fd = g_fault_create_temp ? -1 : mkstemps(tmp.data(), 9);
+        if (fd < 0) return fail(JT_E_INVAL, std::string("failed to create temporary output next to ") + input_path);
+        bool okw = !g_fault_write;
+        size_t off = 0;
+        while (okw && off < (size_t)len) {
+            const ssize_t w = write(fd, data + off, std::min<size_t>((size_t)len - off, (size_t)1 << 30));
+            if (w < 0) { if (errno == EINTR) continue; okw = false; break; }
+            off += (size_t)w;
+        }
+        if (fchmod(fd, 0644) != 0) { /* keep mkstemp's 0600: not fatal */ }
+        if (close(fd) != 0) okw = false;
+        if (!okw) { unlink(tmp.data()); return fail(JT_E_INVAL, std::string("failed to write temporary output ") + tmp.data()); }
+        if (h->cancelled.load()) { unlink(tmp.data()); return fail(JT_E_CANCELLED, "cancelled"); }
+        if (g_fault_rename || rename(tmp.data(), path) != 0) { unlink(tmp.data()); return fail(JT_E_INVAL, std::string("failed to publish output to ") + path); }
     }
     if (io_ms) io_ms[3] = now() - t;
     if (output_path && cap > 0) { strncpy(output_path, path, (size_t)cap - 1); output_path[cap - 1] = 0; }

@@ -58,7 +58,8 @@ void jt_loudnorm_finish(const double *block_sums, int64_t nblocks, int64_t s100,
 // lane-serial family
 void launch_frame_stats(const float *in, int64_t n_total /*frames*channels*/, int samples_per_frame,
                         double *sumsq, double *peak, int64_t nframes, hipStream_t s);
-void launch_downmix(const float *in, float *out, int64_t frames, int channels, hipStream_t s);
+// mode: 0 = float 1/sqrt2 (Pass 1 / Pass 2), 1 = s16 integer matrix, 2 = s32 via float 0.5 (the band graphs of integer sources)
+void launch_downmix(const float *in, float *out, int64_t frames, int channels, int mode, hipStream_t s);
 void launch_s16_to_f32(const int16_t *in, float *out, int64_t n, hipStream_t s);
 void launch_s16_to_f64(const int16_t *in, double *out, int64_t n, double gain, int gain_in_float, hipStream_t s);
 void launch_biquad_f32(const float *in, float *out, int64_t n, int nstages, const BiquadF32 *st, hipStream_t s);
@@ -79,7 +80,8 @@ void launch_dynamics(const float *in, float *out_f32, double *tmp64, double *tmp
 // astats (k_astats.hip)
 struct jt_ctx;
 void launch_biquad_di_f32(const float *in, float *out, int64_t n, BiquadF32 hp, BiquadF32 lp, hipStream_t s);
-void launch_band_rms(const float *in, int64_t n, int nbands, const BiquadF32 *hp, const BiquadF32 *lp, double *sums, hipStream_t s);
+// hp/lp: b0 b1 b2 -a1 -a2 as af_biquads.c's doubles; mode: negotiated sample format of the band graph (0 fltp, 1 s16p, 2 s32p)
+void launch_band_rms(const float *in, int64_t n, int nbands, const double (*hp)[5], const double (*lp)[5], int mode, double *sums, hipStream_t s);
 
 // limiter (exact, chunked at provably clean points)
 // limiter, first sweep (blk == 256): block maxima of |in| and out = in * gain; launch_limiter_f64 expects `out` to hold that copy
@@ -213,8 +215,11 @@ struct jt_ctx {
     hipEvent_t ev_fork = nullptr, ev_join[8] = {};
     std::string err;
     std::atomic<int> cancelled{0};
+    bool hold_cancel = false;            // inside jt_process_file: loading the input must not clear a cancel that already arrived
     // input
     int sr = 0, channels = 0; int64_t n = 0;
+    int src_fmt = 0;                    // the decoder's native sample format: 0 flt/dbl, 1 s16 (also u8), 2 s32 (24/32-bit integer)
+    DevBuf<float> band_mono;            // the band graphs' own down-mix of an integer stereo source
     const float *in_raw = nullptr;      // interleaved (owned or attached)
     DevBuf<float> in_owned;
     DevBuf<float> mono;                 // downmixed when channels == 2

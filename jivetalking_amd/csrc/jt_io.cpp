@@ -315,6 +315,7 @@ extern "C" int jt_load_audio(jt_ctx *h, const uint8_t *file, int64_t len, jt_aud
     h->n = 0; h->in_raw = nullptr; h->in_mono = nullptr; h->m_p2 = h->m_p4 = 0;
     decode_audio(h, file, len, false, true, &d, meta);
     h->in_raw = h->in_owned.p;
+    h->src_fmt = d.is_float ? 0 : (d.bits <= 16 ? 1 : 2);       // what libavcodec would hand to abuffer: flt/dbl, (u8/)s16, s32
     jt_set_input_common(h, d.frames, d.rate, d.channels);
     JT_HIP(hipStreamSynchronize(h->stream));
     JT_API_END(h)
@@ -325,6 +326,8 @@ extern "C" int jt_op_decode_audio(jt_ctx *h, const uint8_t *file, int64_t len, i
 {
     JT_API_BEGIN(h)
     AudioDecoded d;
+    // the decode reuses the owned input buffer: whatever input the handle held is gone afterwards (as in jt_load_audio)
+    h->n = 0; h->in_raw = nullptr; h->in_mono = nullptr; h->m_p2 = h->m_p4 = 0;
     decode_audio(h, file, len, pcm_i32 != nullptr, true, &d, meta);
     const int64_t nvals = d.frames * d.channels;
     if (pcm_i32 || pcm_f32) JT_REQUIRE(cap_values >= nvals, JT_E_INVAL, "decode: output buffer too small");

@@ -69,16 +69,28 @@ void jt_swr_plan(SwrPlanHost *p, int in_rate, int out_rate)
     while (b) { int64_t t = a % b; a = b; b = t; }
     const int64_t g = a;
     const int64_t pc_exact = out_rate / g;
-    if (pc_exact <= phase_count) phase_count = (int)pc_exact;
+    // exact_rational (swresample's default): when the exact phase count fits the 1024-entry bank, every output sits on a bank phase.
+    // Otherwise (22050 / 11025 -> 192000 need 1280 / 2560 phases; odd rates more) resample.c keeps 1024 phases and steps
+    //   index += dst_incr_div; frac += dst_incr_mod; carry at src_incr        (swri_resample, linear = 0)
+    // so output m uses bank row floor(m * in_rate * 1024 / out_rate) mod 1024 -- the row is NOT interpolated.  That sequence is
+    // periodic in pc_exact outputs, so it is restated here as an exact polyphase plan of pc_exact phases whose row for exact
+    // phase q is the 1024-grid row floor(q * 1024 / pc_exact): the kernels keep their integer phase stepping.
+    const bool exact = pc_exact <= phase_count;
+    if (exact) phase_count = (int)pc_exact;
+    else {
+        JT_REQUIRE(pc_exact <= 65536, JT_E_UNSUPPORTED, "resampler: the rate pair needs more than 65536 exact phases");
+        phase_count = (int)pc_exact;
+    }
     p->phase_count = phase_count; p->filter_length = L; p->center = (L - 1) / 2;
-    // per output sample the phase index advances by in_rate*phase_count/out_rate (an integer when exact_rational holds)
-    p->step = (int64_t)(in_rate / g) * (phase_count / (out_rate / g));
+    // per output sample the phase index advances by in_rate*phase_count/out_rate
+    p->step = exact ? (int64_t)(in_rate / g) * (phase_count / (out_rate / g)) : (int64_t)(in_rate / g);
     p->bank.assign((size_t)phase_count * L, 0.0);
     for (int ph = 0; ph < phase_count; ++ph) {
         double norm = 0.0;
         double *tab = &p->bank[(size_t)ph * L];
+        const double frac = exact ? (double)ph / phase_count : (double)(((int64_t)ph * 1024) / pc_exact) / 1024.0;
         for (int i = 0; i < L; ++i) {
-            const double x = M_PI * ((double)(i - p->center) - (double)ph / phase_count) * factor;
+            const double x = M_PI * ((double)(i - p->center) - frac) * factor;
             double y = (x == 0) ? 1.0 : std::sin(x) / x;
             const double w = 2.0 * x / (factor * L * M_PI);
             y *= bessel_i0(beta * std::sqrt(std::max(1 - w * w, 0.0)));

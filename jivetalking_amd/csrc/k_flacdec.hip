@@ -94,11 +94,14 @@ struct BitReader {
     // frames, so a refill straight from memory would make the whole wave wait for one lane's miss at nearly every sample;
     // topup() brings 64 bytes per lane at wave-uniform checkpoints instead (all loads in flight together, one wait).
     unsigned *ring; int lane; long long fill;
+    long long wend;             // first dword index that must not be fetched: the image is zero padded by >= 1024 bytes past its end, a
+                                // reader that runs that far (forged escape widths / block sizes in a look-alike header) stops with err
     __device__ __forceinline__ void init(const uint8_t *base, long long bitpos, long long total_bits, unsigned *ring_, int lane_)
     {
         w = reinterpret_cast<const unsigned *>(base);
         ring = ring_; lane = lane_;
         next = bitpos >> 5; acc = 0; cnt = 0; used = 0; limit = total_bits - bitpos; err = false;
+        wend = ((total_bits >> 5) + 224) & ~3ll;           // <= len + 896 bytes (+ one 64-byte top-up) < the padded allocation
         fill = next & ~3ll;
         topup(); topup(); topup();
         refill();
@@ -108,6 +111,7 @@ struct BitReader {
     __device__ __forceinline__ void topup()
     {
         if (fill - next < 40) {
+            if (fill + 16 > wend) { err = true; return; }
             const uint4 *src = reinterpret_cast<const uint4 *>(w + fill);
             const uint4 a = src[0], b = src[1], c = src[2], e = src[3];
             const unsigned v[16] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, c.x, c.y, c.z, c.w, e.x, e.y, e.z, e.w};
@@ -119,7 +123,10 @@ struct BitReader {
     __device__ __forceinline__ void refill()
     {
         if (cnt <= 32) {
-            const unsigned wv = next < fill ? ring[(int)(next & 63) * 64 + lane] : w[next];
+            unsigned wv = 0;
+            if (next < fill) wv = ring[(int)(next & 63) * 64 + lane];
+            else if (next < wend) wv = w[next];
+            else err = true;
             next++;
             acc |= (unsigned long long)__builtin_bswap32(wv) << (32 - cnt); cnt += 32;
         }
@@ -283,7 +290,7 @@ __global__ __launch_bounds__(64) void k_flac_parse(const uint8_t *__restrict__ d
             }
         } else if (st.type == 2) {
             for (int i = st.order; i < c.blocksize && !st.bad && !br.err; i++) {
-                if ((i & 15) == 0) br.topup();
+                if ((i & 15) == 0) { br.topup(); if (br.used > br.limit) br.err = true; }      // escaped partitions never reach unary()'s check
                 sub_residual(br, st);
             }
         }

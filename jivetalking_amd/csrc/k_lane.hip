@@ -188,24 +188,39 @@ __device__ inline void rows_commit(TL (*tile)[TW + 1], const TIn (&v)[LANES], in
 }
 
 // ------------------------------------------------------------------ small elementwise kernels
-__global__ void k_downmix(const float *__restrict__ in, float *__restrict__ out, int64_t frames, int channels)
+// aformat=channel_layouts=mono of a stereo source = the aresample libavfilter inserts in front of it (libswresample/rematrix.c).
+// swr_build_matrix2: FRONT_CENTER <- M_SQRT1_2 * FL + M_SQRT1_2 * FR; auto_matrix normalises the row to sum 1 only when the
+// converter's OUTPUT or INTERNAL sample format is an integer one (maxval = 1.0), for float formats maxval = INT_MAX and the
+// coefficients stay 1/sqrt(2).  Which formats those are is decided by the graph behind the down-mix:
+//   mode 0  output fltp, internal FLTP (Pass 1, Pass 2: a float-only filter follows, whatever the source format):
+//           float coefficients, mix_2_1 = fl(fl(c*L) + fl(c*R)), c = (float)M_SQRT1_2
+//   mode 1  the band graphs of a 16-bit source (output s16p, internal S16P): (L*16384 + R*16384 + 16384) >> 15 on the integers
+//   mode 2  the band graphs of a 24/32-bit source (output s32p, internal FLTP): coefficients 0.5, then flt -> s32 (llrintf, clip)
+__global__ void k_downmix(const float *__restrict__ in, float *__restrict__ out, int64_t frames, int channels, int mode)
 {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    // swresample rematrix stereo->mono for float sample formats: each input channel weighted
-    // M_SQRT1_2 then the matrix is normalised so the row sums to 1 (rematrix.c auto_matrix,
-    // maxcoef normalisation): 0.5 / 0.5.
+    const float c = 0.70710678118654752440f;
     for (; i < frames; i += stride) {
         if (channels == 2) {
             float2 v = reinterpret_cast<const float2 *>(in)[i];
-            out[i] = v.x * 0.5f + v.y * 0.5f;
+            if (mode == 0) out[i] = __fadd_rn(__fmul_rn(c, v.x), __fmul_rn(c, v.y));
+            else if (mode == 1) {
+                const int li = (int)rintf(v.x * 32768.0f), ri = (int)rintf(v.y * 32768.0f);
+                out[i] = (float)((li * 16384 + ri * 16384 + 16384) >> 15) * (1.0f / 32768.0f);
+            } else {
+                const float sm = __fadd_rn(0.5f * v.x, 0.5f * v.y);
+                double q = rint((double)sm * 2147483648.0);
+                q = q > 2147483647.0 ? 2147483647.0 : (q < -2147483648.0 ? -2147483648.0 : q);
+                out[i] = (float)(q * (1.0 / 2147483648.0));
+            }
         } else out[i] = in[i * channels];            // not reached: jt_set_input_common refuses layouts above stereo
     }
 }
-void launch_downmix(const float *in, float *out, int64_t frames, int channels, hipStream_t s)
+void launch_downmix(const float *in, float *out, int64_t frames, int channels, int mode, hipStream_t s)
 {
     int grid = (int)std::min<int64_t>((frames + 255) / 256, 4096);
-    hipLaunchKernelGGL(k_downmix, dim3(grid), dim3(256), 0, s, in, out, frames, channels);
+    hipLaunchKernelGGL(k_downmix, dim3(grid), dim3(256), 0, s, in, out, frames, channels, mode);
 }
 
 __global__ void k_s16_to_f32(const int16_t *__restrict__ in, float *__restrict__ out, int64_t n)
@@ -1183,19 +1198,40 @@ void launch_biquad_di_f32(const float *in, float *out, int64_t n, BiquadF32 hp, 
 // (direct form I, float state, as k_biquad_di_f32) and accumulates sum(z^2) in double; wave-reduced, one atomic per wave.
 // The chunks stream through a [64][TW+1] LDS tile (row-coalesced loads): read straight from global memory, one uncoalesced
 // load per sample per lane left the recurrence waiting on memory latency (1.2 ms for the 15 noise bands of a 10 s region).
-struct BandBiquads { BiquadF32 hp[16]; BiquadF32 lp[16]; };
-__global__ void __launch_bounds__(64)
+// MODE: the sample format libavfilter negotiates for the band graph (nothing in it is float-only, so the source's width survives,
+// DESIGN.md section 3): 0 = fltp (float sources), 1 = s16p, 2 = s32p.  af_biquads.c BIQUAD_FILTER(s16, int16_t, float, ..., 1) /
+// (s32, int32_t, double, ..., 1): float / double coefficients and state on the raw integer values, the recursion fed with the
+// unquantised outputs, every stage's output clipped and stored by a C cast (truncation toward zero); af_astats.c squares integer
+// samples divided by INT16_MAX / INT32_MAX.
+struct BandBiquads { double hp[16][5]; double lp[16][5]; };      // b0 b1 b2 a1 a2 (a1, a2 negated), af_biquads.c's doubles
+template <typename F> struct BandCoef { F b0, b1, b2, a1, a2; };
+template <typename F> __device__ __forceinline__ F band_di(F i2, F i1, F x, F o2, F o1, const BandCoef<F> &c);
+template <> __device__ __forceinline__ float band_di<float>(float i2, float i1, float x, float o2, float o1, const BandCoef<float> &c)
+{
+    return __fadd_rn(__fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(i2, c.b2), __fmul_rn(i1, c.b1)), __fmul_rn(x, c.b0)), __fmul_rn(o2, c.a2)), __fmul_rn(o1, c.a1));
+}
+template <> __device__ __forceinline__ double band_di<double>(double i2, double i1, double x, double o2, double o1, const BandCoef<double> &c)
+{
+    return __dadd_rn(__dadd_rn(__dadd_rn(__dadd_rn(__dmul_rn(i2, c.b2), __dmul_rn(i1, c.b1)), __dmul_rn(x, c.b0)), __dmul_rn(o2, c.a2)), __dmul_rn(o1, c.a1));
+}
+template <int MODE> __global__ void __launch_bounds__(64)
 k_band_rms(const float *__restrict__ in, int64_t n, int64_t chunk, int64_t halo, BandBiquads bq, double *__restrict__ sums, int64_t nchunks)
 {
+    typedef typename std::conditional<MODE == 2, double, float>::type F;
     __shared__ float tile[LANES][TW + 1];
     const int band = blockIdx.y, lane = threadIdx.x;
-    const BiquadF32 hp = bq.hp[band], lp = bq.lp[band];
+    BandCoef<F> hp, lp;
+    hp.b0 = (F)bq.hp[band][0]; hp.b1 = (F)bq.hp[band][1]; hp.b2 = (F)bq.hp[band][2]; hp.a1 = (F)bq.hp[band][3]; hp.a2 = (F)bq.hp[band][4];
+    lp.b0 = (F)bq.lp[band][0]; lp.b1 = (F)bq.lp[band][1]; lp.b2 = (F)bq.lp[band][2]; lp.a1 = (F)bq.lp[band][3]; lp.a2 = (F)bq.lp[band][4];
+    const F scale = MODE == 1 ? (F)32768.0 : (F)2147483648.0;
+    const F qmin = MODE == 1 ? (F)-32768.0 : (F)-2147483648.0, qmax = MODE == 1 ? (F)32767.0 : (F)2147483647.0;
+    const double norm = MODE == 1 ? 1.0 / 32767.0 : 1.0 / 2147483647.0;
     const int64_t c0 = (int64_t)blockIdx.x * LANES;
     const int nrows = (int)min((int64_t)LANES, nchunks - c0);
     const int64_t base0 = c0 * chunk - halo;
     const int64_t my_base = base0 + (int64_t)lane * chunk, my_lo = my_base + halo;
     double acc = 0.0;
-    float i1 = 0, i2 = 0, o1 = 0, o2 = 0, j1 = 0, j2 = 0, p1 = 0, p2 = 0;
+    F i1 = 0, i2 = 0, o1 = 0, o2 = 0, j1 = 0, j2 = 0, p1 = 0, p2 = 0;
     const int64_t total = halo + chunk;
     float v[LANES];
     rows_prefetch<float>(v, in, n, base0, chunk, 0, lane);
@@ -1208,14 +1244,22 @@ k_band_rms(const float *__restrict__ in, int64_t n, int64_t chunk, int64_t halo,
             for (int j = 0; j < TW; ++j) {
                 const int64_t k = my_base + pos + j;
                 if (k < 0 || k >= n) continue;          // before the region the state is exactly zero; nothing follows its end
-                const float x = tile[lane][j];
-                const float y = __fadd_rn(__fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(i2, hp.b2), __fmul_rn(i1, hp.b1)), __fmul_rn(x, hp.b0)),
-                                                    __fmul_rn(o2, hp.a2)), __fmul_rn(o1, hp.a1));
+                F x = (F)tile[lane][j];
+                if (MODE != 0) { x = x * scale; x = x > qmax ? qmax : x; }       // the integer sample itself (exact: a power of two)
+                const F y = band_di<F>(i2, i1, x, o2, o1, hp);
                 i2 = i1; i1 = x; o2 = o1; o1 = y;
-                const float z = __fadd_rn(__fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(j2, lp.b2), __fmul_rn(j1, lp.b1)), __fmul_rn(y, lp.b0)),
-                                                    __fmul_rn(p2, lp.a2)), __fmul_rn(p1, lp.a1));
-                j2 = j1; j1 = y; p2 = p1; p1 = z;
-                if (k >= my_lo) acc += (double)z * (double)z;
+                F y2 = y;
+                if (MODE != 0) { y2 = y < qmin ? qmin : (y > qmax ? qmax : y); y2 = MODE == 1 ? (F)truncf((float)y2) : (F)trunc((double)y2); }
+                const F z = band_di<F>(j2, j1, y2, p2, p1, lp);
+                j2 = j1; j1 = y2; p2 = p1; p1 = z;
+                if (k >= my_lo) {
+                    if (MODE == 0) acc += (double)z * (double)z;
+                    else {
+                        F zq = z < qmin ? qmin : (z > qmax ? qmax : z);
+                        const double nd = (MODE == 1 ? (double)truncf((float)zq) : trunc((double)zq)) * norm;
+                        acc += nd * nd;
+                    }
+                }
             }
         }
         __syncthreads();
@@ -1224,14 +1268,14 @@ k_band_rms(const float *__restrict__ in, int64_t n, int64_t chunk, int64_t halo,
     if (threadIdx.x == 0 && acc != 0.0) atomicAdd(&sums[band], acc);
 }
 
-void launch_band_rms(const float *in, int64_t n, int nbands, const BiquadF32 *hp, const BiquadF32 *lp, double *sums, hipStream_t s)
+void launch_band_rms(const float *in, int64_t n, int nbands, const double (*hp)[5], const double (*lp)[5], int mode, double *sums, hipStream_t s)
 {
     if (n <= 0 || nbands <= 0) return;
     BandBiquads bq;
     double rmax = 0.0;
     for (int b = 0; b < nbands && b < 16; ++b) {
-        bq.hp[b] = hp[b]; bq.lp[b] = lp[b];
-        rmax = std::max(rmax, std::max(std::sqrt(std::fabs((double)hp[b].a2)), std::sqrt(std::fabs((double)lp[b].a2))));
+        for (int k = 0; k < 5; ++k) { bq.hp[b][k] = hp[b][k]; bq.lp[b][k] = lp[b][k]; }
+        rmax = std::max(rmax, std::max(std::sqrt(std::fabs(hp[b][4])), std::sqrt(std::fabs(lp[b][4]))));
     }
     int64_t halo = 512;
     if (rmax > 0.0 && rmax < 1.0) halo = std::max<int64_t>(512, (int64_t)std::ceil(std::log(1e-10) / std::log(rmax)));
@@ -1241,5 +1285,8 @@ void launch_band_rms(const float *in, int64_t n, int nbands, const BiquadF32 *hp
     // thing that matters, the longest serial run per lane, close to the halo itself
     const int64_t chunk = 256;
     int64_t nchunks = (n + chunk - 1) / chunk;
-    hipLaunchKernelGGL(k_band_rms, dim3((unsigned)((nchunks + 63) / 64), (unsigned)nbands), dim3(64), 0, s, in, n, chunk, halo, bq, sums, nchunks);
+    const dim3 grid((unsigned)((nchunks + 63) / 64), (unsigned)nbands);
+    if (mode == 1) hipLaunchKernelGGL(k_band_rms<1>, grid, dim3(64), 0, s, in, n, chunk, halo, bq, sums, nchunks);
+    else if (mode == 2) hipLaunchKernelGGL(k_band_rms<2>, grid, dim3(64), 0, s, in, n, chunk, halo, bq, sums, nchunks);
+    else hipLaunchKernelGGL(k_band_rms<0>, grid, dim3(64), 0, s, in, n, chunk, halo, bq, sums, nchunks);
 }

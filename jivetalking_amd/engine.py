@@ -76,6 +76,16 @@ class Engine:
         self._ck(self.lib.jt_upload_pcm(self.h, pcm.ctypes.data_as(C.POINTER(C.c_float)), C.c_int64(frames),
                                         C.c_int(sample_rate), C.c_int(channels)))
 
+    def set_source_format(self, bits_per_sample, is_float=False):
+        """The decoder's native sample format of the uploaded PCM (jt_set_source_format): selects the band graphs' arithmetic."""
+        self._ck(self.lib.jt_set_source_format(self.h, C.c_int(bits_per_sample), C.c_int(1 if is_float else 0)))
+
+    def cancel(self):
+        self.lib.jt_cancel(self.h)
+
+    def reset_cancel(self):
+        self.lib.jt_reset_cancel(self.h)
+
     def attach_device_pcm(self, dev_ptr, frames, sample_rate, channels=1, keepalive=None):
         self._keep = keepalive
         self._ck(self.lib.jt_attach_device_pcm(self.h, C.c_void_p(dev_ptr), C.c_int64(frames), C.c_int(sample_rate), C.c_int(channels)))

@@ -113,7 +113,8 @@ HOST_SYMBOLS = ["jt_host_build_intervals", "jt_host_detect", "jt_host_finish_mea
                 "jt_process_audio", "jt_analyse_only", "jt_host_vad_detect", "jt_host_vad_split", "jt_host_vad_speech_runs",
                 "jt_host_vad_gap_tolerance", "jt_host_vad_gate_stats", "jt_host_vad_noise_seed",
                 "jt_host_vad_pick_low_cluster", "jt_host_vad_floored_fraction", "jt_host_sizeof",
-                "jt_host_lufs_filename_value", "jt_host_output_path", "jt_process_audio_cb", "jt_process_file", "jt_process_files"]
+                "jt_host_lufs_filename_value", "jt_host_output_path", "jt_process_audio_cb", "jt_process_file", "jt_process_files",
+                "jt_host_test_inject_fault"]
 
 
 def lib():
@@ -133,6 +134,7 @@ def lib():
     l.jt_host_calculate_linear_mode_target.restype = None
     l.jt_host_vad_split.restype = None
     l.jt_host_vad_gate_stats.restype = None
+    l.jt_host_test_inject_fault.restype = None
     return l
 
 
@@ -246,3 +248,8 @@ def output_path(input_path, lufs_value):
 
 def lufs_filename_value(lufs):
     return lib().jt_host_lufs_filename_value(C.c_double(lufs))
+
+
+def inject_fault(create_temp=0, write=0, rename=0):
+    """Test seam of jt_process_file's publish discipline (include/jt_host.h: jt_host_test_inject_fault)."""
+    lib().jt_host_test_inject_fault(C.c_int(create_temp), C.c_int(write), C.c_int(rename))

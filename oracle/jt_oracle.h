@@ -43,6 +43,10 @@ extern "C" {
 /* type: 0 = highpass, 1 = lowpass.  poles=2, width_type=q, normalize=1. */
 void orc_biquad_coeffs(int type, double freq, double q, int sample_rate, double b[3], double a[3]);
 double orc_band_rms_db(const float *in, int64_t n, int sample_rate, double lo_hz, double hi_hz);   /* analyser_bands.go:33 */
+/* the band graph in the sample format libavfilter negotiates for the source: 0 fltp, 1 s16p, 2 s32p (orc_basic.c) */
+double orc_band_rms_db_fmt(const float *in, int64_t n, int sample_rate, double lo_hz, double hi_hz, int mode);
+/* aformat=channel_layouts=mono of a stereo source (libswresample rematrix): 0 float 1/sqrt2, 1 s16 integer 0.5, 2 s32 via float 0.5 */
+void orc_downmix_stereo(const float *in, int64_t frames, int mode, float *out);
 void orc_biquad_tdii_f32(const float *in, float *out, int64_t n, const double b[3], const double a[3]);
 /* double-precision variant (band-RMS graphs run biquads on the decoder format; dbl used for s16/flt-agnostic checks) */
 void orc_biquad_tdii_f64(const double *in, double *out, int64_t n, const double b[3], const double a[3]);

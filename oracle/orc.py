@@ -50,6 +50,23 @@ def biquad_f32(x, kind, freq, sr, q=0.707):
     return y
 
 
+def band_rms_db_fmt(x, sr, lo_hz, hi_hz, mode):
+    """The band graph in the sample format libavfilter negotiates for the source: mode 0 fltp, 1 s16p, 2 s32p."""
+    x = np.ascontiguousarray(x, np.float32)
+    f = lib().orc_band_rms_db_fmt
+    f.restype = C.c_double
+    return float(f(_p(x, C.c_float), C.c_int64(x.size), C.c_int(sr), C.c_double(lo_hz), C.c_double(hi_hz), C.c_int(mode)))
+
+
+def downmix_stereo(interleaved, mode=0):
+    """aformat=channel_layouts=mono of a stereo source (libswresample rematrix): mode 0 = float 1/sqrt2 (Pass 1 / Pass 2),
+    1 = s16 integer matrix, 2 = s32 via float 0.5 (the band graphs of integer sources)."""
+    x = np.ascontiguousarray(interleaved, np.float32)
+    out = np.empty(x.size // 2, np.float32)
+    lib().orc_downmix_stereo(_p(x, C.c_float), C.c_int64(x.size // 2), C.c_int(mode), _p(out, C.c_float))
+    return out
+
+
 def band_rms_db(x, sr, lo_hz, hi_hz):
     """Band-limited Overall RMS of a region in dB (analyser_bands.go:33: highpass, lowpass, astats)."""
     x = np.ascontiguousarray(x, np.float32)

@@ -72,6 +72,97 @@ double orc_band_rms_db(const float *in, int64_t n, int sample_rate, double lo_hz
     return n > 0 ? 20.0 * log10(sqrt(acc / (double)n)) : -INFINITY;
 }
 
+/* The same band graph when libavfilter negotiates an INTEGER sample format for it.  Nothing in
+ *   aformat=channel_layouts=mono,atrim,asetpts,highpass,lowpass,astats      (analyser_bands.go:33)
+ * accepts only float, so the link formats are the intersection of abuffer's native decoder format with af_biquads.c's list
+ * {s16p, s32p, fltp, dblp}: a 16-bit FLAC/WAV source runs the biquads in s16p, a 24/32-bit one in s32p (avfiltergraph.c
+ * swap_sample_fmts keeps the source's width; DESIGN.md section 3 has the derivation).  af_biquads.c then instantiates
+ *   BIQUAD_FILTER(s16, int16_t, float,  INT16_MIN, INT16_MAX, 1)   BIQUAD_FILTER(s32, int32_t, double, INT32_MIN, INT32_MAX, 1)
+ * i.e. float (s16) / double (s32) coefficients and state working on the raw integer values, the recursion fed with the
+ * UNQUANTISED o1/o2, and every stage's output stored by a C cast (truncation toward zero) after clipping to the integer range.
+ * af_astats.c normalises integer samples by INT16_MAX / INT32_MAX (not 2^15 / 2^31) before squaring.
+ * mode: 0 = fltp (orc_band_rms_db), 1 = s16p, 2 = s32p.  `in` holds the mono region as float = integer * 2^(1-bits). */
+double orc_band_rms_db_fmt(const float *in, int64_t n, int sample_rate, double lo_hz, double hi_hz, int mode)
+{
+    if (mode == 0) return orc_band_rms_db(in, n, sample_rate, lo_hz, hi_hz);
+    double bh[3], ah[3], bl[3], al[3];
+    biquad_cookbook(0, lo_hz, 0.707, sample_rate, bh, ah);
+    biquad_cookbook(1, hi_hz, 0.707, sample_rate, bl, al);
+    double acc = 0.0;
+    if (mode == 1) {
+        const float hb0 = (float)bh[0], hb1 = (float)bh[1], hb2 = (float)bh[2], ha1 = -(float)ah[1], ha2 = -(float)ah[2];
+        const float lb0 = (float)bl[0], lb1 = (float)bl[1], lb2 = (float)bl[2], la1 = -(float)al[1], la2 = -(float)al[2];
+        float i1 = 0, i2 = 0, o1 = 0, o2 = 0, j1 = 0, j2 = 0, p1 = 0, p2 = 0;
+        for (int64_t k = 0; k < n; k++) {
+            const float x = (float)(int16_t)lrintf(in[k] * 32768.0f);
+            const float y = (((i2 * hb2 + i1 * hb1) + x * hb0) + o2 * ha2) + o1 * ha1;
+            i2 = i1; i1 = x; o2 = o1; o1 = y;
+            const int16_t q1 = y < (float)INT16_MIN ? INT16_MIN : (y > (float)INT16_MAX ? INT16_MAX : (int16_t)y);
+            const float x2 = (float)q1;
+            const float z = (((j2 * lb2 + j1 * lb1) + x2 * lb0) + p2 * la2) + p1 * la1;
+            j2 = j1; j1 = x2; p2 = p1; p1 = z;
+            const int16_t q2 = z < (float)INT16_MIN ? INT16_MIN : (z > (float)INT16_MAX ? INT16_MAX : (int16_t)z);
+            const double nd = (double)q2 / (double)INT16_MAX;
+            acc += nd * nd;
+        }
+    } else {
+        const double hb0 = bh[0], hb1 = bh[1], hb2 = bh[2], ha1 = -ah[1], ha2 = -ah[2];
+        const double lb0 = bl[0], lb1 = bl[1], lb2 = bl[2], la1 = -al[1], la2 = -al[2];
+        double i1 = 0, i2 = 0, o1 = 0, o2 = 0, j1 = 0, j2 = 0, p1 = 0, p2 = 0;
+        for (int64_t k = 0; k < n; k++) {
+            double xs = (double)in[k] * 2147483648.0;
+            if (xs > (double)INT32_MAX) xs = (double)INT32_MAX;
+            const double x = (double)(int32_t)llrint(xs);
+            const double y = (((i2 * hb2 + i1 * hb1) + x * hb0) + o2 * ha2) + o1 * ha1;
+            i2 = i1; i1 = x; o2 = o1; o1 = y;
+            const int32_t q1 = y < (double)INT32_MIN ? INT32_MIN : (y > (double)INT32_MAX ? INT32_MAX : (int32_t)y);
+            const double x2 = (double)q1;
+            const double z = (((j2 * lb2 + j1 * lb1) + x2 * lb0) + p2 * la2) + p1 * la1;
+            j2 = j1; j1 = x2; p2 = p1; p1 = z;
+            const int32_t q2 = z < (double)INT32_MIN ? INT32_MIN : (z > (double)INT32_MAX ? INT32_MAX : (int32_t)z);
+            const double nd = (double)q2 / (double)INT32_MAX;
+            acc += nd * nd;
+        }
+    }
+    return n > 0 ? 20.0 * log10(sqrt(acc / (double)n)) : -INFINITY;
+}
+
+/* aformat=channel_layouts=mono on a stereo source = the aresample libavfilter inserts in front of it; libswresample/rematrix.c:
+ * swr_build_matrix2 gives FRONT_CENTER <- M_SQRT1_2 * FL + M_SQRT1_2 * FR, and auto_matrix normalises the row to sum 1
+ * (maxval = 1.0) ONLY when the converter's OUTPUT or INTERNAL sample format is an integer one; for float/double internal +
+ * output formats maxval = INT_MAX and the coefficients stay 1/sqrt(2).  swr_init picks the internal format from the byte
+ * widths: S16P when input and output are both <= 2 bytes, else FLTP for inputs up to 4 bytes, else DBLP.
+ *   mode 0: output fltp (every graph with a float-only filter behind the down-mix: Pass 1, Pass 2 -- DESIGN.md section 3):
+ *           internal FLTP, float coefficients (float)M_SQRT1_2, mix_2_1 = fl(fl(c*L) + fl(c*R))      [swresample rematrix_template.c]
+ *   mode 1: s16 source in the band graph (output s16p): internal S16P, integer coefficients lrintf(0.5 * 32768) = 16384,
+ *           sum2_s16: (L*16384 + R*16384 + 16384) >> 15  (arithmetic shift)
+ *   mode 2: s32 source in the band graph (output s32p): internal FLTP (input is 4 bytes wide), normalised float coefficients 0.5,
+ *           then flt -> s32 by audioconvert: av_clipl_int32(llrintf(x * 2^31))
+ * in: interleaved stereo as float = integer * 2^(1-bits) (or the float samples themselves); out: mono in the same scaling. */
+void orc_downmix_stereo(const float *in, int64_t frames, int mode, float *out)
+{
+    const float c = (float)M_SQRT1_2;
+    for (int64_t i = 0; i < frames; i++) {
+        const float l = in[2 * i], r = in[2 * i + 1];
+        if (mode == 0) {
+            const float a = c * l, b = c * r;
+            out[i] = a + b;
+        } else if (mode == 1) {
+            const int li = (int)lrintf(l * 32768.0f), ri = (int)lrintf(r * 32768.0f);
+            const int m = (li * 16384 + ri * 16384 + 16384) >> 15;
+            out[i] = (float)m * (1.0f / 32768.0f);
+        } else {
+            const float a = 0.5f * l, b = 0.5f * r;
+            const float s = a + b;
+            double v = (double)s * 2147483648.0;
+            long long q = llrint(v);
+            if (q > INT32_MAX) q = INT32_MAX;
+            if (q < INT32_MIN) q = INT32_MIN;
+            out[i] = (float)((double)q / 2147483648.0);
+        }
+    }
+}
+
 /* BIQUAD_TDII_FILTER(flt, float, float, ...): float coefficients, float state. */
 void orc_biquad_tdii_f32(const float *in, float *out, int64_t n, const double b[3], const double a[3])
 {

@@ -34,7 +34,7 @@ static double bessel_i0(double x)
 
 typedef struct {
     int phase_count, filter_length, center;
-    int64_t src_incr_num, step;    /* output m reads around input position m*step/phase_count */
+    int64_t den, step;             /* output m has filter index floor(m*step/den): sample index / phase_count, phase % phase_count */
     double *bank;                  /* [phase_count][filter_length] */
 } SwrPlan;
 
@@ -58,8 +58,12 @@ static void swr_plan(SwrPlan *p, int in_rate, int out_rate)
     p->phase_count = phase_count;
     p->filter_length = filter_length;
     p->center = (filter_length - 1) / 2;
-    /* index advances by in_rate*phase_count/out_rate per output sample (exact when exact_rational) */
-    p->step = (int64_t)in_rate / g * (phase_count / (out_rate / g));
+    /* index advances by in_rate*phase_count/out_rate per output sample: an integer when the exact phase count fits the 1024-entry
+     * bank.  Otherwise (22050 or 11025 -> 192000: 1280 / 2560 exact phases) resample.c keeps 1024 phases and steps
+     * index += dst_incr_div; frac += dst_incr_mod; carry at src_incr  (swri_resample, linear = 0: the bank row is NOT interpolated),
+     * i.e. index_m = floor(m * in_rate * 1024 / out_rate). */
+    if (pc_exact <= 1024) { p->step = (int64_t)in_rate / g * (phase_count / (out_rate / g)); p->den = 1; }
+    else { int64_t gg = gcd64((int64_t)in_rate * phase_count, out_rate); p->step = (int64_t)in_rate * phase_count / gg; p->den = out_rate / gg; }
     p->bank = malloc(sizeof(double) * (size_t)phase_count * filter_length);
     const int tap_count = filter_length;
     const int center = p->center;
@@ -99,7 +103,7 @@ int64_t orc_swr_resample_f64(const double *in, int64_t n, int in_rate, int out_r
     swr_plan(&p, in_rate, out_rate);
     int64_t m = 0;
     for (;; m++) {
-        int64_t idx = m * p.step;
+        int64_t idx = m * p.step / p.den;
         int64_t si = idx / p.phase_count;
         int ph = (int)(idx % p.phase_count);
         if (flush) { if (si >= n) break; }
@@ -122,7 +126,7 @@ int64_t orc_swr_resample_f32(const float *in, int64_t n, int in_rate, int out_ra
     swr_plan(&p, in_rate, out_rate);
     int64_t m = 0;
     for (;; m++) {
-        int64_t idx = m * p.step;
+        int64_t idx = m * p.step / p.den;
         int64_t si = idx / p.phase_count;
         int ph = (int)(idx % p.phase_count);
         if (flush) { if (si >= n) break; }
@@ -324,7 +328,7 @@ void orc_ebur128_mono(const double *in, int64_t n, int sample_rate, int dualmono
             if (true_peak) {
                 int64_t pushed = idx + 1;
                 while (tp_cursor < tp_n) {
-                    int64_t ix = tp_cursor * plan.step;
+                    int64_t ix = tp_cursor * plan.step / plan.den;
                     int64_t si = ix / plan.phase_count;
                     if (si - plan.center + plan.filter_length - 1 > pushed - 1) break;
                     tp = FFMAX(tp, fabs(tp_up[tp_cursor]));

@@ -1,0 +1,228 @@
+"""Round-2 behaviours of the C ABI: sticky cancellation (frame_processor.go:116-118), the publish discipline of
+jt_process_file (file_write.go:13-53), the sample-format-dependent arithmetic libavfilter negotiates around the down-mix and the
+band graphs, rate pairs whose exact phase count exceeds swresample's 1024-entry bank, and hostile FLAC."""
+import glob
+import os
+import threading
+import time
+
+import numpy as np
+import pytest
+
+from jivetalking_amd import synth, hostlogic as H, _lib as L
+from jivetalking_amd.engine import Engine, default_filter_params
+
+pytestmark = pytest.mark.gpu
+SR = 48000
+
+
+# ---------------------------------------------------------------- cancellation
+def test_cancel_between_passes_is_sticky_and_handle_survives(engine):
+    x = synth.speech_like(12.0, SR, seed=41)
+    engine.upload_pcm(x, SR, 1)
+    engine.pass1(x.size)
+    engine.cancel()                                       # lands while the host would be running the VAD
+    with pytest.raises(L.JtError) as ei:
+        engine.pass2(default_filter_params())
+    assert ei.value.code == L.JT_E_CANCELLED
+    with pytest.raises(L.JtError) as ei:                  # still cancelled: the passes never clear the flag
+        engine.pass1(x.size)
+    assert ei.value.code == L.JT_E_CANCELLED
+    with pytest.raises(L.JtError) as ei:
+        H.process_audio(engine)
+    assert ei.value.code == L.JT_E_CANCELLED
+    engine.reset_cancel()
+    r = H.process_audio(engine)                           # the handle is usable again, same input
+    assert abs(r.output_lufs + 16.0) <= 0.1
+    engine.cancel()
+    engine.upload_pcm(x, SR, 1)                           # a new job clears it as well
+    r2 = H.process_audio(engine)
+    assert r2.output_lufs == r.output_lufs
+
+
+def test_cancel_from_second_thread_mid_process(engine):
+    x = np.tile(synth.speech_like(60.0, SR, seed=42), 10)  # 10 min: long enough that the call is still running when the cancel lands
+    engine.upload_pcm(x, SR, 1)
+    H.process_audio(engine)                               # warm (allocations, plans)
+    t_full0 = time.perf_counter(); H.process_audio(engine); t_full = time.perf_counter() - t_full0
+    hits = 0
+    for delay in (0.0005, 0.002, 0.25 * t_full, 0.5 * t_full, 0.8 * t_full):
+        engine.reset_cancel()
+        th = threading.Timer(delay, engine.cancel)
+        t0 = time.perf_counter(); th.start()
+        try:
+            H.process_audio(engine)
+            done = True
+        except L.JtError as e:
+            assert e.code == L.JT_E_CANCELLED
+            done = False
+        el = time.perf_counter() - t0
+        th.join()
+        if not done:
+            hits += 1
+            assert el < delay + 0.6 * t_full + 0.05, (delay, el, t_full)     # prompt: at most the pass that was in flight
+    assert hits >= 3
+    engine.reset_cancel()
+    assert abs(H.process_audio(engine).output_lufs + 16.0) <= 0.1
+
+
+# ---------------------------------------------------------------- publish discipline
+def _write_flac(tmp_path, engine, seconds=12.0, seed=43, name="talk.flac"):
+    x = synth.speech_like(seconds, 44100, seed=seed)
+    pcm = np.clip(np.rint(np.asarray(x, np.float64) * 32768), -32768, 32767).astype(np.int16)
+    data = engine.op_flac_encode(pcm, 44100)
+    p = tmp_path / name
+    p.write_bytes(data)
+    return str(p), pcm
+
+
+def test_process_file_publishes_atomically_and_leaves_no_residue(tmp_path, engine):
+    src, _ = _write_flac(tmp_path, engine)
+    res, out_path, _ = H.process_file(engine, src)
+    assert os.path.basename(out_path) == "talk-LUFS-16-processed.flac" and os.path.exists(out_path)
+    good = open(out_path, "rb").read()
+    assert sorted(os.listdir(tmp_path)) == ["talk-LUFS-16-processed.flac", "talk.flac"]      # no hidden temp left
+    # every injected failure: an error, no temp residue, and the previous output untouched (file_write.go, processor.go:130-135)
+    for kw in ({"create_temp": 1}, {"write": 1}, {"rename": 1}):
+        H.inject_fault(**kw)
+        try:
+            with pytest.raises(L.JtError):
+                H.process_file(engine, src)
+        finally:
+            H.inject_fault()
+        assert sorted(os.listdir(tmp_path)) == ["talk-LUFS-16-processed.flac", "talk.flac"], kw
+        assert open(out_path, "rb").read() == good
+    # cancelled before the publish: JT_E_CANCELLED, nothing new on disk
+    os.remove(out_path)
+    th = threading.Timer(0.001, engine.cancel); th.start()
+    try:
+        H.process_file(engine, src)
+        th.join()
+    except L.JtError as e:
+        th.join()
+        assert e.code == L.JT_E_CANCELLED
+        assert os.listdir(tmp_path) == ["talk.flac"]
+    engine.reset_cancel()
+    assert not glob.glob(str(tmp_path / ".processing-*"))
+
+
+# ---------------------------------------------------------------- down-mix and band graphs per source format
+def test_downmix_float_path_matches_oracle_bit_for_bit(engine, oracle):
+    a = synth.speech_like(5.0, SR, seed=44); b = synth.speech_like(5.0, SR, seed=45) * 0.7
+    st = np.empty(a.size * 2, np.float32); st[0::2] = a; st[1::2] = b
+    engine.upload_pcm(st, SR, 2)
+    ref = oracle.downmix_stereo(st, 0)
+    p1 = engine.pass1(a.size)
+    # per-decoder-frame sums come from the RAW interleaved samples (frameSumSquaresAndPeak), the analysis from the down-mix
+    e = oracle.ebur128(ref.astype(np.float64), SR, True, True)
+    assert abs(p1["r128"]["integrated"] - e["integrated"]) < 1e-6
+    assert abs(p1["astats"]["max_level"] - float(ref.max())) == 0.0 and abs(p1["astats"]["min_level"] - float(ref.min())) == 0.0
+    # not the integer-format 0.5/0.5 matrix: 3.01 dB apart
+    half = (0.5 * a + 0.5 * b).astype(np.float32)
+    assert abs(p1["r128"]["integrated"] - oracle.ebur128(half.astype(np.float64), SR, True, True)["integrated"] - 3.0103) < 0.01
+
+
+@pytest.mark.parametrize("bits,mode", [(16, 1), (24, 2)])
+def test_band_rms_integer_source_formats(engine, oracle, bits, mode):
+    """A 16-bit source runs the band graphs' biquads in s16p (float state, truncated + clipped per stage, astats / INT16_MAX), a
+    24-bit one in s32p (double state); stereo gets the integer-normalised down-mix.  1e-4 dB (halo restarts), quiet band included."""
+    q = float(1 << (bits - 1))
+    a = np.rint(np.asarray(synth.speech_like(9.0, SR, seed=46), np.float64) * q) / q
+    b = np.rint(np.asarray(synth.speech_like(9.0, SR, seed=47), np.float64) * 0.6 * q) / q
+    a = a.astype(np.float32); b = b.astype(np.float32)
+    lo = [70.0, 1000.0, 6000.0, 13000.0]; hi = [100.0, 3000.0, 9000.0, 19000.0]
+    for ch in (1, 2):
+        if ch == 1:
+            engine.upload_pcm(a, SR, 1); mono = a
+        else:
+            st = np.empty(a.size * 2, np.float32); st[0::2] = a; st[1::2] = b
+            engine.upload_pcm(st, SR, 2); mono = oracle.downmix_stereo(st, mode)
+        engine.set_source_format(bits, False)
+        got, ok = engine.band_rms(1.0, 6.5, lo, hi)
+        seg = mono[SR:SR + int(6.5 * SR)]
+        for k in range(len(lo)):
+            ref = oracle.band_rms_db_fmt(seg, SR, lo[k], hi[k], mode)
+            assert ok[k] == 1 and abs(got[k] - ref) < 1e-4, (bits, ch, k, got[k], ref)
+        if bits == 16 and ch == 1:
+            # the integer path is audibly different from the float one on a quiet band: that is the point of restating it
+            flt = oracle.band_rms_db_fmt(seg, SR, lo[0], hi[0], 0)
+            assert abs(flt - oracle.band_rms_db_fmt(seg, SR, lo[0], hi[0], 1)) > 1e-3
+
+
+def test_load_audio_sets_the_source_format(engine, oracle):
+    x = synth.speech_like(6.0, 44100, seed=48)
+    pcm = np.clip(np.rint(np.asarray(x, np.float64) * 32768), -32768, 32767).astype(np.int16)
+    engine.load_audio(engine.op_flac_encode(pcm, 44100))
+    got, _ = engine.band_rms(0.5, 4.0, [80.0], [125.0])
+    f = (pcm.astype(np.float32) / 32768.0)[22050:22050 + 4 * 44100]
+    assert abs(got[0] - oracle.band_rms_db_fmt(f, 44100, 80.0, 125.0, 1)) < 1e-4
+    engine.upload_pcm(pcm.astype(np.float32) / 32768.0, 44100, 1)            # a float upload resets it
+    got, _ = engine.band_rms(0.5, 4.0, [80.0], [125.0])
+    assert abs(got[0] - oracle.band_rms_db_fmt(f, 44100, 80.0, 125.0, 0)) < 1e-4
+
+
+# ---------------------------------------------------------------- rate pairs beyond the 1024-phase bank
+@pytest.mark.parametrize("sr", [22050, 11025])
+def test_true_peak_at_rates_with_more_than_1024_exact_phases(engine, oracle, sr):
+    """22050 -> 192000 needs 1280 exact phases, 11025 -> 192000 2560: swresample keeps its 1024-entry bank and truncates the phase
+    (resample.c, linear = 0).  Used to divide by zero."""
+    x = synth.speech_like(8.0, sr, seed=49)
+    got = engine.op_ebur128(x, sr, True)
+    ref = oracle.ebur128(x.astype(np.float64), sr, True, True)
+    assert abs(got["integrated"] - ref["integrated"]) < 1e-6
+    assert abs(got["true_peak"] / ref["true_peak"] - 1.0) < 1e-9
+    assert got["true_peak"] >= got["sample_peak"] * 0.999
+
+
+def test_22050_hz_file_runs_the_whole_pipeline(engine, oracle):
+    x = synth.speech_like(30.0, 22050, seed=50)
+    engine.upload_pcm(x, 22050, 1)
+    r = H.process_audio(engine)
+    p4 = engine.download_s16(4)
+    assert p4.size == x.size * 2
+    e = oracle.ebur128(p4.astype(np.float64) / 32768.0, 44100, True, True)
+    assert abs(e["integrated"] + 16.0) <= 0.1 and 20 * np.log10(e["true_peak"]) <= -1.0
+
+
+# ---------------------------------------------------------------- hostile FLAC
+def _crc8(b):
+    c = 0
+    for v in b:
+        c ^= v
+        for _ in range(8):
+            c = ((c << 1) ^ 0x07) & 0xFF if c & 0x80 else (c << 1) & 0xFF
+    return c
+
+
+def test_forged_header_with_escaped_partitions_is_rejected_not_faulted(engine, oracle):
+    """A frame header is easy to forge (CRC-8 only).  Block size 65535 with a residual partition escaped at 31 bits per sample would
+    walk ~250 KB past a short file; the reader must stop at the padded end and report a damaged stream."""
+    pcm = (1000 * np.random.default_rng(7).standard_normal(4096 * 3)).astype(np.int16)
+    good = bytearray(engine.op_flac_encode(pcm, 44100))
+    # STREAMINFO: allow block sizes up to 65535 so that the forged header is "legal"
+    good[8 + 2] = 0xFF; good[8 + 3] = 0xFF
+    first = 4 + 4 + 34
+    # skip the VORBIS_COMMENT block
+    pos = first
+    blen = int.from_bytes(good[pos + 1:pos + 4], "big"); pos += 4 + blen
+    # forged frame: sync, fixed blocksize code 7 (16-bit blocksize-1 follows), rate code from STREAMINFO (0), mono, 16 bit
+    hdr = bytearray([0xFF, 0xF8, 0x70, 0x08, 0x00, 0xFF, 0xFE])
+    hdr.append(_crc8(hdr))
+    # subframe: LPC order 1 (type 32), no wasted bits; warm-up 16 bits; precision 1 -> 4 bits, shift 5 bits, coefficient; then
+    # residual coding method 0, partition order 0, Rice parameter 15 = escape, width 31
+    bits = "0" + "100000" + "0" + "0" * 16 + "0000" + "00000" + "0" + "00" + "0000" + "1111" + "11111"
+    bits += "0" * ((8 - len(bits) % 8) % 8)
+    body = bytes(int(bits[i:i + 8], 2) for i in range(0, len(bits), 8))
+    evil = bytes(good[:pos]) + bytes(hdr) + body + bytes(64)
+    with pytest.raises(L.JtError) as ei:
+        engine.op_decode_audio(evil)
+    assert ei.value.code == L.JT_E_INVAL
+    # the handle survives and still decodes a good stream
+    good2 = engine.op_flac_encode(pcm, 44100)
+    dec, _, _ = engine.op_decode_audio(good2)
+    assert np.array_equal(dec[:, 0], pcm.astype(np.int32))
+    # truncations of a valid stream at every region of the last frame
+    for cut in (len(good2) - 1, len(good2) - 2, len(good2) - 700, pos + 9):
+        with pytest.raises(L.JtError) as ei:
+            engine.op_decode_audio(good2[:cut])
+        assert ei.value.code == L.JT_E_INVAL
