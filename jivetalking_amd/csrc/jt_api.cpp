@@ -569,6 +569,11 @@ static void run_afftdn(jt_ctx *h, const float *in, float *out, int64_t n, int sr
 static void fill_biquads(const jt_filter_params *p, int sr, BiquadF32 st[2], int *nst)
 {
     *nst = 0;
+    // af_biquads.c config_filter(): w0 = 2*pi*f/rate; "if (w0 > M_PI || w0 <= 0.) return AVERROR(EINVAL)" -- the graph does not configure.
+    // The reference's fixed 20.5 kHz band limit therefore fails Pass 2 for sources below 41 kHz (adaptive_bandlimit_lowpass.go:17-20
+    // states the assumption and applies no guard); the same error is reported here instead of running a meaningless filter.
+    if (p->hp_enabled) JT_REQUIRE(p->hp_freq > 0 && 2.0 * p->hp_freq <= (double)sr, JT_E_INVAL, "highpass: frequency outside (0, Nyquist] (af_biquads: EINVAL)");
+    if (p->lp_enabled) JT_REQUIRE(p->lp_freq > 0 && 2.0 * p->lp_freq <= (double)sr, JT_E_INVAL, "lowpass: frequency outside (0, Nyquist] (af_biquads: EINVAL)");
     if (p->hp_enabled) {
         double b[3], a[3]; jt_biquad_design(0, p->hp_freq, p->hp_q, sr, b, a, 1);
         st[(*nst)++] = BiquadF32{(float)b[0], (float)b[1], (float)b[2], -(float)a[1], -(float)a[2]};

@@ -20,7 +20,8 @@ def lib():
     global _LIB
     if _LIB is None:
         path = os.path.join(_HERE, "liboracle.so")
-        if not os.path.exists(path):
+        srcs = [os.path.join(_HERE, f) for f in os.listdir(_HERE) if f.endswith((".c", ".h"))]
+        if not os.path.exists(path) or any(os.path.getmtime(f) > os.path.getmtime(path) for f in srcs):
             build()
         _LIB = C.CDLL(path)
     return _LIB

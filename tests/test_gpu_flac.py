@@ -284,6 +284,7 @@ def test_load_audio_feeds_the_passes_like_upload_pcm(oracle):
         meta = a.load_audio(data)
         assert (meta["frames"], meta["channels"], meta["sample_rate"], meta["bits_per_sample"]) == (pcm.shape[0], 2, sr, 24)
         b.upload_pcm((pcm.astype(np.float64) / (1 << 23)).astype(np.float32), sr, 2)
+        b.set_source_format(24, False)              # what jt_load_audio records for a 24-bit file (its band graphs run in s32p)
         ra = hostlogic.process_audio(a, analyse_only=True)
         rb = hostlogic.process_audio(b, analyse_only=True)
         import ctypes as C
@@ -308,6 +309,7 @@ def test_process_file_flac_and_wav_in_flac_out(tmp_path, oracle):
     e = Engine()
     try:
         e.upload_pcm(pcm.astype(np.float32) / 32768.0, sr, 1)
+        e.set_source_format(16, False)              # as jt_load_audio records for a 16-bit file (its band graphs run in s16p)
         ref = hostlogic.process_audio(e)
         want = e.download_s16(4)
         outs = []

@@ -165,23 +165,36 @@ def test_load_audio_sets_the_source_format(engine, oracle):
 @pytest.mark.parametrize("sr", [22050, 11025])
 def test_true_peak_at_rates_with_more_than_1024_exact_phases(engine, oracle, sr):
     """22050 -> 192000 needs 1280 exact phases, 11025 -> 192000 2560: swresample keeps its 1024-entry bank and truncates the phase
-    (resample.c, linear = 0).  Used to divide by zero."""
+    (resample.c, linear = 0).  Used to divide by zero.
+    11025 is not a multiple of 10: f_ebur128.c slides a 4410-sample momentary window in steps of 1102 samples, the engine sums four
+    1102-sample blocks (4408 samples) -- a 0.002 LU difference, stated here and in DESIGN.md section 3."""
     x = synth.speech_like(8.0, sr, seed=49)
     got = engine.op_ebur128(x, sr, True)
     ref = oracle.ebur128(x.astype(np.float64), sr, True, True)
-    assert abs(got["integrated"] - ref["integrated"]) < 1e-6
+    assert abs(got["integrated"] - ref["integrated"]) < (1e-6 if sr % 10 == 0 else 5e-3)
     assert abs(got["true_peak"] / ref["true_peak"] - 1.0) < 1e-9
     assert got["true_peak"] >= got["sample_peak"] * 0.999
 
 
-def test_22050_hz_file_runs_the_whole_pipeline(engine, oracle):
+def test_22050_hz_file(engine, oracle):
+    """The reference's fixed 20.5 kHz band limit is above a 22.05 kHz file's Nyquist: af_biquads refuses to configure (EINVAL) and
+    Pass 2 fails (adaptive_bandlimit_lowpass.go:17-20 documents the assumption, no guard).  Same here; analysis-only works, and with
+    a band limit below Nyquist the whole pipeline runs (Pass-1 true peak through the truncated-phase resampler)."""
     x = synth.speech_like(30.0, 22050, seed=50)
     engine.upload_pcm(x, 22050, 1)
-    r = H.process_audio(engine)
-    p4 = engine.download_s16(4)
-    assert p4.size == x.size * 2
-    e = oracle.ebur128(p4.astype(np.float64) / 32768.0, 44100, True, True)
-    assert abs(e["integrated"] + 16.0) <= 0.1 and 20 * np.log10(e["true_peak"]) <= -1.0
+    a = H.process_audio(engine, analyse_only=True)
+    e = oracle.ebur128(x.astype(np.float64), 22050, True, True)
+    assert abs(a.input.input_i - e["integrated"]) < 0.002 and abs(a.input.input_tp - 20 * np.log10(e["true_peak"])) < 0.05
+    with pytest.raises(L.JtError) as ei:
+        H.process_audio(engine)
+    assert ei.value.code == L.JT_E_INVAL and "Nyquist" in str(ei.value)
+    # the granular passes with the band limit off: Pass 2 at 22.05 kHz (anlmdn K=132 S=44, afftdn 1024-point, 22.05 -> 44.1 kHz 2-phase)
+    engine.pass1(x.size, sample_rate=22050)
+    a2 = engine.pass2(default_filter_params(lp_enabled=0))
+    p2 = engine.download_s16(2)
+    assert p2.size == x.size * 2 and np.isfinite(a2["r128"]["integrated"]) and a2["r128"]["true_peak"] >= a2["r128"]["sample_peak"] * 0.999
+    f = oracle.ebur128(p2.astype(np.float64) / 32768.0, 44100, True, True)
+    assert abs(f["integrated"] - a2["r128"]["integrated"]) < 0.05          # the same signal before / after the 2x resample + s16
 
 
 # ---------------------------------------------------------------- hostile FLAC
