@@ -901,8 +901,8 @@ extern "C" int jt_pass4(jt_ctx *h, const jt_limiter_plan *lim, const jt_loudnorm
         launch_adeclick(h, sig, tmp, m, rate, ap->adeclick_threshold, ap->adeclick_window_ms, ap->adeclick_overlap_pct, 2.0, 2.0, gain,
                         h->declick_stats.p, h->stream);
         JT_HIP(hipEventRecord(h->ev3, h->stream));
-        unsigned long long *hs = h->pin.take<unsigned long long>(4);
-        JT_HIP(hipMemcpyAsync(hs, h->declick_stats.p, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));
+        unsigned long long *hs = h->pin.take<unsigned long long>(16);
+        JT_HIP(hipMemcpyAsync(hs, h->declick_stats.p, 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));
         dk_stats = hs;
         std::swap(sig, tmp);
         brick_gain = 1.0;
@@ -928,7 +928,11 @@ extern "C" int jt_pass4(jt_ctx *h, const jt_limiter_plan *lim, const jt_loudnorm
     check_cancel(h);
     if (dk_stats) {
         h->timers.declick_repaired = (int64_t)dk_stats[0]; h->timers.declick_heavy_windows = (int64_t)dk_stats[2];
-        if (getenv("JT_DK_PROFILE")) fprintf(stderr, "adeclick: second-pass windows %llu, third-pass windows %llu\n", dk_stats[2], dk_stats[3]);
+        if (getenv("JT_DK_PROFILE")) {
+            fprintf(stderr, "adeclick: repaired %llu, second-pass windows %llu, third-pass windows %llu; phase clocks (JT_DK_PROFILE build):", dk_stats[0], dk_stats[2], dk_stats[3]);
+            for (int i = 4; i < 12; ++i) fprintf(stderr, " %llu", dk_stats[i]);
+            fprintf(stderr, "\n");
+        }
         { float dms = 0; JT_HIP(hipEventElapsedTime(&dms, h->ev2, h->ev3)); h->timers.declick_ms = dms; }
         JT_REQUIRE(dk_stats[1] == 0, JT_E_HIP, "adeclick: singular interpolation matrix (af_adeclick.c would fail the graph)");
     }

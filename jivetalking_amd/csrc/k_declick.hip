@@ -29,6 +29,7 @@ struct DeclickParams {
     int W, hop, skip, ar, nburst;
     int sa;                       // doubles reserved for the sample buffer / factorisation block of the instance being launched
     int lb;                       // half-window buffer length (light instance)
+    int nw;                       // flag words kept per window (fast kernel)
     double threshold, gain;
     int64_t nwindows;
 };
@@ -494,6 +495,470 @@ k_adeclick(const double *__restrict__ in, double *__restrict__ out, int64_t n, D
 #endif
 }
 
+// =====================================================================================================================
+// k_adeclick_fast — the same filter with the floating-point SUMMATION ORDER relaxed (results within ~1e-12 of the sequential
+// code instead of bit-identical; the detector's decisions are the same unless |detection| sits within rounding of the threshold --
+// tests/test_gpu_ops.py counts the flips against the oracle).  The exact kernel above is issue-bound on its sequential chains
+// (profiles/r01_pmc_issue.txt); here every phase is written for instruction count instead:
+//   * autocorrelation on the matrix pipe: r[16m + a - b] = sum over 64-sample steps of C_m[a][b], C_m = X X_m^T with
+//     v_mfma_f64_16x16x4_f64 -- operand A is 64 consecutive samples (lane l = sample j0 + l), operand B the same stream 16 m samples
+//     earlier, m = 0..3: 4 LDS reads + 4 MFMAs per 64 samples instead of 64 x (2 LDS reads + mul + add) per lane-lag;
+//   * detection as a register-blocked FIR: a lane owns DQ consecutive outputs, the DQ + AR samples it needs slide through a
+//     register ring (fully unrolled, static indices), one LDS read + one broadcast coefficient read per DQ fused multiply-adds;
+//   * LDL^T in a diagonal-major ring blk[dg][i & (NC-1)] = entry (i + dg, i): the pivot column (and the pivot itself, lane 0) is ONE
+//     LDS read at lane-constant address + scalar offset, the column that enters the ring is written back to the same address, a
+//     trailing pair's address advances by one slot per pivot, the multipliers are taken from the pre-division column (d * l_b = the
+//     column entry itself) and 1/d is a reciprocal + two Newton steps;
+//   * fused multiply-adds everywhere a product feeds a sum.
+// Same capacity levels, work counter, overflow lists, packed factor stream and output handling as k_adeclick.
+namespace dkf { constexpr int DQ = 11; }
+typedef double dk_d4 __attribute__((ext_vector_type(4)));
+
+__device__ inline double dk_rcp(double d)
+{
+    double r = __builtin_amdgcn_rcp(d);
+    double e = __fma_rn(-d, r, 1.0); r = __fma_rn(r, e, r);
+    e = __fma_rn(-d, r, 1.0); r = __fma_rn(r, e, r);
+    return r;
+}
+
+template <int FCAP, int NC, int ND, bool HALF, int LEVEL>
+__global__ void __launch_bounds__(64, 3)                  // three waves per SIMD (<= 168 VGPRs): LDS admits ten waves per CU
+k_adeclick_fast(const double *__restrict__ in, double *__restrict__ out, int64_t n, DeclickParams P, double *scratch,
+                size_t scratch_per_wave, unsigned long long *__restrict__ stats, int *__restrict__ heavy)
+{
+    extern __shared__ unsigned char dk_smem[];
+    const int lane = threadIdx.x;
+    const int W = P.W, AR = P.ar;
+    constexpr int MAXAR = dk::MAXAR, CM = NC - 1, BWMAX = ND - 1, DQ = dkf::DQ;
+    static_assert((NC & (NC - 1)) == 0 && ND <= NC + 1 && BWMAX < NC, "ring geometry");
+    double *sbuf = reinterpret_cast<double *>(dk_smem);                // window samples ; later the ND x NC ring
+    double *rr = sbuf + P.sa;                                           // r[AR+1]                       [50]
+    double *ac = rr + 50;                                               // k[AR+1], zero padded          [64]
+    double *aux = ac + 64;                                              // aux[AR+1], aux[AR+1] = 0      [50]
+    double *lvec = aux + 50;                                            // multipliers (wide bands)      [50]
+    double *cvec = lvec + 50;                                           // pivot column (wide bands)     [50]
+    double *yring = cvec + 50;                                          // y of the rows in the ring     [NC]
+    unsigned long long *obits = reinterpret_cast<unsigned long long *>(yring + NC);            // [P.nw]
+    unsigned long long *fbits = obits + P.nw;                                                   // [P.nw]
+    unsigned short *index = reinterpret_cast<unsigned short *>(fbits + P.nw);                 // [FCAP + NC + ND]
+    unsigned char *bwv = reinterpret_cast<unsigned char *>(index + FCAP + NC + ND);            // [FCAP]
+    unsigned short *pairtab = reinterpret_cast<unsigned short *>(bwv + FCAP) - 64;
+    double *dscr = reinterpret_cast<double *>(obits);                   // r2[64] scratch of the autocorrelation (the flag words are dead then)
+    {
+        constexpr int NPAIR = ND * (ND - 1) / 2;
+        for (int t = lane + 64; t < NPAIR; t += 64) {
+            int a = (int)((sqrtf(8.0f * (float)t + 1.0f) - 1.0f) * 0.5f);
+            a += ((a + 1) * (a + 2) / 2 <= t); a -= (a * (a + 1) / 2 > t);
+            pairtab[t] = (unsigned short)(a | ((t - a * (a + 1) / 2) << 8));
+        }
+    }
+    auto fbit = [&](int pos) -> bool { return (fbits[pos >> 6] >> (pos & 63)) & 1ull; };
+    double *gL = scratch + (size_t)blockIdx.x * scratch_per_wave;
+    double *gD = gL + (size_t)W * MAXAR, *gY = gD + W, *gV = gY + W;
+    unsigned long long repaired = 0, singular = 0;
+    int a0, b0;
+    {
+        a0 = (int)((sqrtf(8.0f * (float)lane + 1.0f) - 1.0f) * 0.5f);
+        a0 += ((a0 + 1) * (a0 + 2) / 2 <= lane); a0 -= (a0 * (a0 + 1) / 2 > lane);
+        b0 = lane - a0 * (a0 + 1) / 2;
+    }
+    const int LB = HALF ? P.lb : W;
+    const int SB_B = W - LB;
+    const int SPLIT = HALF ? SB_B + AR : W;
+    const int PADE = 64;                                             // zeros kept behind the samples (the last 64-sample step runs past W)
+#ifdef JT_DK_PROFILE
+    unsigned long long tph[8] = {0,0,0,0,0,0,0,0}; unsigned long long tc = wall_clock64();
+#define DKF_MARK(i) { unsigned long long t_ = wall_clock64(); tph[i] += t_ - tc; tc = t_; }
+#else
+#define DKF_MARK(i)
+#endif
+    const int *worklist = LEVEL == 1 ? heavy : heavy + P.nwindows;
+    const int64_t nwork = LEVEL == 0 ? P.nwindows : (int64_t)stats[1 + LEVEL];
+    for (;;) {
+        unsigned long long wi_ = 0;
+        if (lane == 0) wi_ = atomicAdd(&stats[12 + LEVEL], 1ull);
+        const int64_t wi = (int64_t)(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(wi_ >> 32)) << 32) |
+                                     (unsigned)__builtin_amdgcn_readfirstlane((int)wi_));
+        if (wi >= nwork) break;
+        const int64_t w = LEVEL == 0 ? wi : (int64_t)worklist[wi];
+        const int64_t s0 = w * P.hop - P.skip;
+        const int64_t o0 = w * P.hop;
+        int sb = 0;
+        auto load_buf = [&](int base) {
+            sb = base;
+            for (int j = lane; j < LB + PADE; j += 64) {
+                const int64_t p = s0 + base + j;
+                sbuf[j] = (base + j < W && p >= 0 && p < n) ? __dmul_rn(in[p], P.gain) : 0.0;
+            }
+        };
+        load_buf(0);
+        DKF_MARK(0)
+        // ---- 2. autocorrelation on the matrix pipe
+        {
+            dk_d4 C0 = {0, 0, 0, 0}, C1 = {0, 0, 0, 0}, C2 = {0, 0, 0, 0}, C3 = {0, 0, 0, 0};
+            auto mfma_blocks = [&](int kb0, int kb1) {
+                const double *sj = sbuf - sb + lane;                       // sj[j0] = sample j0 + lane
+                for (int kb = kb0; kb < kb1; ++kb) {
+                    const int j0 = kb << 6;
+                    const double a = sj[j0];
+                    double b1, b2, b3;
+                    if (kb == 0) {                                          // samples before the window do not exist: zero terms
+                        b1 = lane >= 16 ? sj[-16] : 0.0; b2 = lane >= 32 ? sj[-32] : 0.0; b3 = lane >= 48 ? sj[-48] : 0.0;
+                    } else { b1 = sj[j0 - 16]; b2 = sj[j0 - 32]; b3 = sj[j0 - 48]; }
+                    C0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, a, C0, 0, 0, 0);
+                    C1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b1, C1, 0, 0, 0);
+                    C2 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b2, C2, 0, 0, 0);
+                    C3 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b3, C3, 0, 0, 0);
+                }
+            };
+            const int nblk = (W + 63) >> 6;
+            const int ka = HALF ? (SPLIT + 63) >> 6 : nblk;              // 64*ka <= LB and 64*ka - AR >= SB_B
+            mfma_blocks(0, ka);
+            if (HALF) { load_buf(SB_B); mfma_blocks(ka, nblk); }
+            // C_m[i][j] (i = 4 * reg + lane / 16, j = lane % 16) belongs to lag 16 m + i - j: every lane adds its sixteen entries into
+            // r2[lag] with LDS floating-point atomics (ds_add_f64; one wave, program order, conflicting lanes of an instruction are
+            // served in lane order: the sum order is fixed, the result reproducible)
+            __builtin_amdgcn_wave_barrier();
+            dscr[lane] = 0.0;
+            __builtin_amdgcn_wave_barrier();
+            const int lag0 = (lane >> 4) - (lane & 15);
+            const dk_d4 CC[4] = {C0, C1, C2, C3};
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int lag = lag0 + 16 * m + 4 * r;
+                    if (lag >= 0 && lag < 64) __hip_atomic_fetch_add(&dscr[lag], CC[m][r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+            const double rl = dscr[lane];
+            __builtin_amdgcn_wave_barrier();
+            if (lane <= AR) rr[lane] = rl * (1.0 / W);
+            __builtin_amdgcn_wave_barrier();
+        }
+        DKF_MARK(1)
+        // ---- 3. Levinson-Durbin (as k_adeclick)
+        double sigmae;
+        {
+            const double r0 = rr[0], r1 = rr[1];
+            const double k0 = -r1 / r0;
+            double areg = lane == 0 ? k0 : 0.0;
+            double alpha = r0 * (1.0 - k0 * k0);
+            for (int i = 1; i < AR; ++i) {
+                const double rrev = rr[lane < i ? i - lane : 0];
+                const double arev = __shfl(areg, lane < i ? i - lane - 1 : 0, 64);
+                const double prod = lane < i ? areg * rrev : 0.0;
+                __builtin_amdgcn_wave_barrier();
+                if (lane < MAXAR) lvec[lane] = prod;
+                __builtin_amdgcn_wave_barrier();
+                double eps = 0.0;
+                for (int j = 0; j < i; j += 8) {
+                    double t8[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) t8[u] = lvec[j + u];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) eps += t8[u];
+                }
+                eps += rr[i + 1];
+                const double ki = -eps / alpha;
+                alpha = alpha * (1.0 - ki * ki);
+                if (lane < i) areg = __fma_rn(ki, arev, areg);
+                else if (lane == i) areg = ki;
+            }
+            __builtin_amdgcn_wave_barrier();
+            const double aup = __shfl_up(areg, 1, 64);
+            ac[lane] = lane == 0 ? 1.0 : (lane <= AR ? aup : 0.0);                         // zero padded to 64 taps
+            sigmae = sqrt(alpha);
+            __builtin_amdgcn_wave_barrier();
+        }
+        DKF_MARK(2)
+        bool finite;
+        {
+            const double v = lane <= AR ? ac[lane] : 0.0;
+            finite = !__any(!isfinite(v));
+        }
+        int F = 0;
+        bool to_heavy = false;
+        if (finite) {
+            // ---- 4. detection: register-blocked FIR, DQ consecutive outputs per lane
+            const double thr = sigmae * P.threshold;
+            const int nword = (W + 63) >> 6;
+            for (int wd = lane; wd < nword + 1; wd += 64) obits[wd] = 0ull;
+            __builtin_amdgcn_wave_barrier();
+            auto detect_range = [&](int ia, int ib) {
+                const double *sj = sbuf - sb;
+                const int lo = ia - AR;                                  // lowest sample any real tap reads (held by the current buffer)
+                for (int base = ia; base < ib; base += 64 * DQ) {
+                    const int c0 = base + DQ * lane;
+                    if (c0 < ib) {
+                        double acc[DQ], ring[DQ];                          // ring[s mod DQ] = sample c0 + s, s in [-j, DQ - 1 - j] at tap j
+#pragma unroll
+                        for (int q = 0; q < DQ; ++q) { ring[q] = sj[c0 + q]; acc[q] = 0.0; }
+                        for (int jb = 0; jb <= AR; jb += DQ) {
+#pragma unroll
+                            for (int v = 0; v < DQ; ++v) {
+                                if (v > 0 && jb + v > AR) break;            // wave-uniform: the remaining taps are zero
+                                const double c = ac[jb + v];
+#pragma unroll
+                                for (int q = 0; q < DQ; ++q) acc[q] = __fma_rn(c, ring[(q - v + DQ) % DQ], acc[q]);
+                                int xi = c0 - (jb + v) - 1; xi = xi < lo ? lo : xi;
+                                ring[(DQ - 1 - v) % DQ] = sj[xi];
+                            }
+                        }
+                        unsigned m = 0;
+#pragma unroll
+                        for (int q = 0; q < DQ; ++q) m |= (fabs(acc[q]) > thr && c0 + q < ib) ? (1u << q) : 0u;
+                        if (m) {
+                            const int w0 = c0 >> 6, sh = c0 & 63;
+                            atomicOr(&obits[w0], (unsigned long long)m << sh);
+                            if (sh + DQ > 64 && (m >> (64 - sh))) atomicOr(&obits[w0 + 1], (unsigned long long)(m >> (64 - sh)));
+                        }
+                    }
+                }
+            };
+            if (HALF) {
+                // outputs [AR, W) split in two equal ranges; the upper one is served by buffer B (loaded), the lower one by buffer A
+                int dsp = AR + (W - AR + 1) / 2;
+                dsp = dsp < SPLIT ? SPLIT : dsp;                           // buffer B holds sample dsp - AR onwards
+                detect_range(dsp, W); load_buf(0); detect_range(AR, dsp);
+            } else detect_range(AR, W);
+            __builtin_amdgcn_wave_barrier();
+            // ---- 5./6. burst fusion, borders, index list (as k_adeclick: integer work)
+            for (int wd0 = 0; wd0 < nword; wd0 += 64) {
+                const int wd = wd0 + lane;
+                const bool inr = wd < nword;
+                const unsigned long long cur = inr ? obits[wd] : 0ull;
+                const unsigned long long prv = (inr && wd > 0) ? obits[wd - 1] : 0ull;
+                const unsigned long long nxt = (wd + 1 < nword) ? obits[wd + 1] : 0ull;
+                unsigned long long fused = cur;
+                const int nb = P.nburst < 64 ? P.nburst : 64;
+                for (int d1 = 1; d1 < nb; ++d1) {
+                    const unsigned long long below = (cur << d1) | (prv >> (64 - d1));
+                    unsigned long long above = 0ull;
+                    for (int d2 = 1; d1 + d2 <= nb; ++d2) above |= (cur >> d2) | (nxt << (64 - d2));
+                    fused |= below & above;
+                }
+                const int lo = AR - wd * 64, hi = (W - AR) - wd * 64;
+                const unsigned long long mlo = lo <= 0 ? ~0ull : (lo >= 64 ? 0ull : (~0ull << lo));
+                const unsigned long long mhi = hi >= 64 ? ~0ull : (hi <= 0 ? 0ull : ((1ull << hi) - 1ull));
+                unsigned long long fb = inr ? (fused & mlo & mhi) : 0ull;
+                if (inr) fbits[wd] = fb;
+                const int cnt = __popcll(fb);
+                int incl = cnt;
+#pragma unroll
+                for (int dd = 1; dd < 64; dd <<= 1) { const int o = __shfl_up(incl, dd, 64); incl += lane >= dd ? o : 0; }
+                int slot = F + incl - cnt;
+                while (fb) {
+                    const int bpos = __ffsll((long long)fb) - 1;
+                    if (slot < FCAP) index[slot] = (unsigned short)(wd * 64 + bpos);
+                    ++slot; fb &= fb - 1ull;
+                }
+                F += __builtin_amdgcn_readlane(incl, 63);
+            }
+            F = __builtin_amdgcn_readfirstlane(F);
+            to_heavy = F > FCAP;
+            if (!to_heavy) {
+                int bwmax = 0;
+                for (int k = lane; k < F; k += 64) {
+                    const int lim = (int)index[k] + AR;
+                    int lo = k, hi = min(F - 1, k + MAXAR);
+                    while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if ((int)index[mid] <= lim) lo = mid; else hi = mid - 1; }
+                    bwv[k] = (unsigned char)(lo - k);
+                    bwmax = max(bwmax, lo - k);
+                }
+                to_heavy = __any(bwmax > BWMAX);
+                // rows past the last one are "far away": every ring entry against them is aux[AR + 1] = 0
+                for (int k = F + lane; k < F + NC + ND && k < FCAP + NC + ND; k += 64) index[k] = 0xFFFF;
+            }
+        }
+        if (to_heavy) {
+            if (LEVEL == 0 && lane == 0) heavy[atomicAdd(&stats[2], 1ull)] = (int)w;
+            if (LEVEL == 1 && lane == 0) heavy[P.nwindows + (int64_t)atomicAdd(&stats[3], 1ull)] = (int)w;
+            continue;
+        }
+        DKF_MARK(3)
+        bool ok = true;
+        if (F > 0) {
+            // ---- 7. aux = autocorrelation(ac, AR, AR+1, ., 1.)
+            if (lane <= AR) {
+                double value = 0.0;
+                for (int j = lane; j <= AR; ++j) value = __fma_rn(ac[j], ac[j - lane], value);
+                aux[lane] = value;
+            } else if (lane == AR + 1) aux[lane] = 0.0;
+            __builtin_amdgcn_wave_barrier();
+            // ---- 8. right-hand side (flagged samples zeroed in the LDS copy, so the inner loop carries no flag test)
+            auto zero_flagged = [&]() {
+                const int nb = HALF ? LB : W;
+                for (int e = lane; e < F; e += 64) { const int o = (int)index[e] - sb; if (o >= 0 && o < nb) sbuf[o] = 0.0; }
+                __builtin_amdgcn_wave_barrier();
+            };
+            auto rhs_range = [&](int ea, int eb) {
+                const double *sj = sbuf - sb;
+                for (int e0 = ea; e0 < eb; e0 += 128) {
+                    int ie[2]; double val[2];
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) { const int e = e0 + 64 * q + lane; ie[q] = index[e < eb ? e : eb - 1]; val[q] = 0.0; }
+                    int j0 = -AR;
+                    for (; j0 + 7 <= AR; j0 += 8) {
+                        double xv[2][8], ax[8];
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) {
+                            const int j = j0 + u;
+                            ax[u] = aux[j < 0 ? -j : j];
+#pragma unroll
+                            for (int q = 0; q < 2; ++q) xv[q][u] = sj[ie[q] - j];
+                        }
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) { val[0] = __fma_rn(-xv[0][u], ax[u], val[0]); val[1] = __fma_rn(-xv[1][u], ax[u], val[1]); }
+                    }
+                    for (; j0 <= AR; ++j0) {
+                        const double ax = aux[j0 < 0 ? -j0 : j0];
+                        val[0] = __fma_rn(-sj[ie[0] - j0], ax, val[0]);
+                        val[1] = __fma_rn(-sj[ie[1] - j0], ax, val[1]);
+                    }
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) { const int e = e0 + 64 * q + lane; if (e < eb) gV[e] = val[q]; }
+                }
+            };
+            if (HALF) {
+                int ea = 0;
+                for (int e0 = 0; e0 < F; e0 += 64) { const int e = e0 + lane; ea += __popcll(__ballot(e < F && (int)index[e] + AR < LB)); }
+                zero_flagged();
+                rhs_range(0, ea);
+                if (ea < F) { load_buf(SB_B); zero_flagged(); rhs_range(ea, F); }
+            } else { zero_flagged(); rhs_range(0, F); }
+            __threadfence();
+            DKF_MARK(4)
+            // ---- 9. LDL^T, right-looking inside the band, in the diagonal-major ring; forward substitution fused
+            double *blk = sbuf;
+            __builtin_amdgcn_wave_barrier();
+            for (int t = lane; t < ND * NC; t += 64) {
+                const int dgi = t / NC, i = t & CM;
+                const int dlt = (int)index[i + dgi] - (int)index[i];
+                blk[t] = aux[dlt < AR + 1 ? dlt : AR + 1];
+            }
+            if (lane < NC) yring[lane] = lane < F ? dk_ld(&gV[lane]) : 0.0;
+            // right-hand sides of the rows about to enter the ring: 64 at a time through LDS (ac[] is dead).  A global load inside the
+            // pivot loop would put an s_waitcnt vmcnt(0) on every pivot, and that also waits for the factor stores of the same pivot.
+            double *vstage = ac;
+            int vbase = NC;
+            vstage[lane] = (vbase + lane < F) ? dk_ld(&gV[vbase + lane]) : 0.0;
+            size_t goff = 0;
+            const int dgl = lane < ND ? lane : ND - 1;                // this lane's diagonal of the pivot column
+            double *colp = blk + dgl * NC;
+            double *pairp = blk + (a0 - b0) * NC;                      // diagonal of this lane's trailing pair
+            __builtin_amdgcn_wave_barrier();
+            for (int k = 0; k < F; ++k) {
+                const int ks = k & CM;
+                const int bw = bwv[k];
+                const double colv = colp[ks];
+                const double yrow = yring[(k + lane) & CM];
+                const double d = dk_readlane(colv, 0), yk = dk_readlane(yrow, 0);
+                if (d == 0.0) { ok = false; break; }
+                const double rinv = dk_rcp(d);
+                const double l = colv * rinv;
+                const bool inband = (unsigned)(lane - 1) < (unsigned)bw;
+                if (lane <= bw) gL[goff + (lane ? lane - 1 : bw)] = lane ? l : yk * rinv;
+                goff += (size_t)bw + 1;
+                if (inband) yring[(k + lane) & CM] = __fma_rn(-l, yk, yrow);
+                const int npairs = bw * (bw + 1) / 2;
+                {
+                    const double la = __shfl(l, a0 + 1, 64), cb = __shfl(colv, b0 + 1, 64);
+                    double *ep = pairp + ((k + 1 + b0) & CM);
+                    if (lane < npairs) *ep = __fma_rn(-cb, la, *ep);
+                }
+                if (npairs > 64) {
+                    if (lane < MAXAR + 1) { lvec[lane] = l; cvec[lane] = colv; }
+                    __builtin_amdgcn_wave_barrier();
+                    for (int t = lane + 64; t < npairs; t += 64) {
+                        const int ab = pairtab[t], a = ab & 0xff, b = ab >> 8;
+                        double *e = blk + (a - b) * NC + ((k + 1 + b) & CM);
+                        *e = __fma_rn(-cvec[b + 1], lvec[a + 1], *e);
+                    }
+                }
+                // column k + NC takes the slot of column k (every diagonal), its right-hand side the slot of y_k
+                const int nj = k + NC;
+                if (nj < F) {
+                    if (nj >= vbase + 64) { vbase += 64; vstage[lane] = (vbase + lane < F) ? dk_ld(&gV[vbase + lane]) : 0.0; __builtin_amdgcn_wave_barrier(); }
+                    const double vn = vstage[nj - vbase];
+                    const int idn = index[nj + dgl];
+                    const int dlt = idn - __builtin_amdgcn_readfirstlane(idn);
+                    const double ent = aux[dlt < AR + 1 ? dlt : AR + 1];
+                    if (lane < ND) colp[ks] = ent;
+                    if (lane == 0) yring[ks] = vn;
+                }
+                __builtin_amdgcn_wave_barrier();
+            }
+            DKF_MARK(5)
+            if (ok) {
+                __threadfence();
+                // ---- 10. back substitution (as k_adeclick, fused multiply-adds)
+                double sw = 0.0;
+                for (int ib = F - 1; ib >= 0; ib -= 16) {
+                    double qr = 0.0; int ntr = 0, cnt = 0;
+                    if (lane < 16 && ib - lane >= 0) { ntr = bwv[ib - lane]; cnt = ntr + 1; }
+                    int pref = cnt;
+#pragma unroll
+                    for (int dd = 1; dd < 16; dd <<= 1) { const int o = __shfl_up(pref, dd, 64); pref += lane >= dd ? o : 0; }
+                    if (cnt) qr = dk_ld(&gL[goff - (size_t)pref + (size_t)ntr]);
+                    double Lr[16];
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) {
+                        const int nq = __builtin_amdgcn_readlane(ntr, q);
+                        const size_t oq = goff - (size_t)__builtin_amdgcn_readlane(pref, q);
+                        Lr[q] = lane < nq ? dk_ld(&gL[oq + lane]) : 0.0;
+                    }
+                    goff -= (size_t)__builtin_amdgcn_readlane(pref, 15);
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) {
+                        const int nt = __builtin_amdgcn_readlane(ntr, q);
+                        double v = dk_readlane(qr, q);
+                        // sum of the band's terms by a wave tree (terms beyond the band are zero)
+                        double term = lane < nt ? Lr[q] * sw : 0.0;
+                        if (nt > 0) {
+#pragma unroll
+                            for (int o = 32; o > 0; o >>= 1) term += __shfl_xor(term, o, 64);
+                            v -= term;
+                        }
+                        {
+                            const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(sw), 0x138, 0xf, 0xf, false);   // wave_shr:1
+                            const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(sw), 0x138, 0xf, 0xf, false);
+                            sw = lane == 0 ? v : __hiloint2double(hi, lo);
+                        }
+                    }
+                    if (lane < 16 && ib - 15 + lane >= 0) blk[ib - 15 + lane] = sw;
+                }
+                __builtin_amdgcn_wave_barrier();
+                for (int e = lane; e < F; e += 64) {
+                    const int pos = index[e];
+                    if (pos >= P.skip && pos < P.skip + P.hop && o0 + (pos - P.skip) < n) out[o0 + (pos - P.skip)] = blk[e];
+                }
+                repaired += (lane == 0) ? (unsigned long long)F : 0ull;
+            } else {
+                singular += (lane == 0) ? 1ull : 0ull;
+            }
+        }
+        DKF_MARK(6)
+        const bool rep = F > 0 && ok;
+        for (int j = lane; j < P.hop; j += 64) {
+            const int64_t o = o0 + j;
+            const int pos = P.skip + j;
+            if (o < n && !(rep && fbit(pos))) {
+                const int64_t p = s0 + pos;
+                out[o] = (p >= 0 && p < n) ? __dmul_rn(in[p], P.gain) : 0.0;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    if (lane == 0 && (repaired || singular)) { atomicAdd(&stats[0], repaired); atomicAdd(&stats[1], singular); }
+#ifdef JT_DK_PROFILE
+    DKF_MARK(7)
+    if (lane == 0) for (int i = 0; i < 8; ++i) atomicAdd(&stats[4 + i], tph[i]);
+#endif
+}
+
 // host side --------------------------------------------------------------------------------------------------------
 bool jt_adeclick_supported(int sample_rate, double window_ms, double overlap_pct, double ar_pct, int method, std::string *why)
 {
@@ -529,6 +994,40 @@ void launch_adeclick(jt_ctx *h, const double *in, double *out, int64_t n, int sa
     const size_t sm0 = smem_for(sa0, LIGHT, LBS), sm1 = smem_for(sa1, MID, dk::BS), sm2 = smem_for(sa2, dk::MAXW, dk::BS);
     JT_REQUIRE(sm2 <= 64 * 1024, JT_E_UNSUPPORTED, "adeclick: window does not fit the per-wave LDS budget");
     const size_t per_wave = (size_t)P.W * dk::MAXAR + 3 * (size_t)P.W;
+    const bool exact = getenv("JT_ADECLICK_EXACT") != nullptr;      // the bit-exact sequential-order kernel (parity tests / A-B); default: fast
+    h->declick_heavy.ensure(2 * (size_t)P.nwindows);
+#define DK_LAUNCH(KERN, GRID, SMEM, PP) do { auto k_ = KERN; \
+        JT_HIP(hipFuncSetAttribute((const void *)k_, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(SMEM))); \
+        hipLaunchKernelGGL(k_, dim3((unsigned)(GRID)), dim3(64), (SMEM), s, in, out, n, PP, h->declick_scr.p, per_wave, d_stats, h->declick_heavy.p); } while (0)
+    if (!exact) {
+        // fast kernel: ring NC columns x ND diagonals (bands up to ND - 1 rows); flag words sized by the window
+        P.nw = ((P.W + 63) >> 6) + 2;
+        constexpr int NC0 = 32, ND0 = 32, NC1 = 64, ND1 = dk::BS;
+        auto sa_fast = [&](bool half, int ring) { return ((half ? std::max(P.lb + 64, ring) : std::max(P.W + 64, ring)) + 1) & ~1; };
+        auto smem_fast = [&](int sa, int fcap, int nc, int nd) {
+            return sizeof(double) * (size_t)(sa + 50 + 64 + 50 + 50 + 50 + nc) + sizeof(unsigned long long) * 2 * (size_t)P.nw +
+                   2 * (size_t)(fcap + nc + nd) + (size_t)fcap + 2 * (size_t)std::max(0, nd * (nd - 1) / 2 - 64) + 16;
+        };
+        const int fa0 = sa_fast(half_ok, NC0 * ND0), fa1 = sa_fast(half_ok, NC1 * ND1), fa2 = sa_fast(false, NC1 * ND1);
+        const size_t fm0 = smem_fast(fa0, LIGHT, NC0, ND0), fm1 = smem_fast(fa1, MID, NC1, ND1), fm2 = smem_fast(fa2, dk::MAXW, NC1, ND1);
+        JT_REQUIRE(fm2 <= 64 * 1024, JT_E_UNSUPPORTED, "adeclick: window does not fit the per-wave LDS budget");
+        int v0 = (int)std::min<size_t>(12, (160 * 1024) / fm0);
+        const int v1 = (int)std::min<size_t>(8, (160 * 1024) / fm1), v2 = (int)std::min<size_t>(8, (160 * 1024) / fm2);
+        if (const char *ev = getenv("JT_DK_WAVES")) v0 = std::max(1, std::min(v0, atoi(ev)));
+        const int64_t f0 = std::min<int64_t>(P.nwindows, (int64_t)256 * v0), f1 = std::min<int64_t>(P.nwindows, (int64_t)256 * v1),
+                      f2 = std::min<int64_t>(P.nwindows, (int64_t)256 * v2);
+        h->declick_scr.ensure(per_wave * (size_t)std::max(f0, std::max(f1, f2)));
+        DeclickParams Q0 = P, Q1 = P, Q2 = P; Q0.sa = fa0; Q1.sa = fa1; Q2.sa = fa2;
+        if (half_ok) {
+            DK_LAUNCH((k_adeclick_fast<LIGHT, NC0, ND0, true, 0>), f0, fm0, Q0);
+            DK_LAUNCH((k_adeclick_fast<MID, NC1, ND1, true, 1>), f1, fm1, Q1);
+        } else {
+            DK_LAUNCH((k_adeclick_fast<LIGHT, NC0, ND0, false, 0>), f0, fm0, Q0);
+            DK_LAUNCH((k_adeclick_fast<MID, NC1, ND1, false, 1>), f1, fm1, Q1);
+        }
+        DK_LAUNCH((k_adeclick_fast<dk::MAXW, NC1, ND1, false, 2>), f2, fm2, Q2);
+        return;
+    }
     // resident waves per CU = what LDS admits (10 at the 44.1 kHz defaults).  With the windows handed out dynamically the time
     // falls monotonically with residency on the 60-min workload: 6 -> 33.8 ms, 7 -> 30.7, 8 -> 28.5, 9 -> 27.6
     int w0 = (int)std::min<size_t>(12, (160 * 1024) / sm0);
@@ -537,13 +1036,9 @@ void launch_adeclick(jt_ctx *h, const double *in, double *out, int64_t n, int sa
     const int64_t g0 = std::min<int64_t>(P.nwindows, (int64_t)256 * w0), g1 = std::min<int64_t>(P.nwindows, (int64_t)256 * w1),
                   g2 = std::min<int64_t>(P.nwindows, (int64_t)256 * w2);
     h->declick_scr.ensure(per_wave * (size_t)std::max(g0, std::max(g1, g2)));
-    h->declick_heavy.ensure(2 * (size_t)P.nwindows);
     DeclickParams P0 = P, P1 = P, P2 = P; P0.sa = sa0; P1.sa = sa1; P2.sa = sa2;
     // pass 0: 512 flags / 33 x 33 block per window; pass 1: the windows that overflowed that (bands wider than 32 rows: 7 % of the
     // bench signal), 1024 flags / 49 x 49; pass 2: anything denser still, full capacity.  List lengths are read on the device.
-#define DK_LAUNCH(KERN, GRID, SMEM, PP) do { auto k_ = KERN; \
-        JT_HIP(hipFuncSetAttribute((const void *)k_, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(SMEM))); \
-        hipLaunchKernelGGL(k_, dim3((unsigned)(GRID)), dim3(64), (SMEM), s, in, out, n, PP, h->declick_scr.p, per_wave, d_stats, h->declick_heavy.p); } while (0)
     if (half_ok) {
         DK_LAUNCH((k_adeclick<LIGHT, LBS, true, 0>), g0, sm0, P0);
         DK_LAUNCH((k_adeclick<MID, dk::BS, true, 1>), g1, sm1, P1);

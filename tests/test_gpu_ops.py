@@ -170,45 +170,85 @@ def test_alimiter_never_triggered_is_identity(engine, oracle):
 
 
 # ---------------------------------------------------------------- adeclick
+# Two kernels behind one entry point.  The default one relaxes the summation ORDER of af_adeclick.c's floating-point sums (matrix-pipe
+# autocorrelation, register-blocked detector, fused multiply-adds, reciprocal pivots): its bar is stated here -- identical detection
+# decisions (flips counted, none allowed on these signals) and |difference| <= 1e-9 on every sample (signals of order 1; the
+# difference is rounding of the AR fit amplified by the conditioning of the interpolation system, measured ~1e-12).
+# JT_ADECLICK_EXACT=1 selects the sequential-order kernel, which stays bit-identical to the oracle.
+import contextlib
+import os
+
+
+@contextlib.contextmanager
+def exact_adeclick():
+    os.environ["JT_ADECLICK_EXACT"] = "1"
+    try:
+        yield
+    finally:
+        del os.environ["JT_ADECLICK_EXACT"]
+
+
+def declick_close(got, ref, x, tol=1e-9):
+    """Returns (flips, max abs error).  A sample was repaired where the output differs from the input."""
+    flips = int(np.count_nonzero((ref != x) != (got != x)))
+    err = float(np.max(np.abs(got - ref))) if got.size else 0.0
+    assert flips == 0, f"{flips} detection decisions differ from the oracle"
+    assert err <= tol, f"max |gpu - oracle| = {err:g}"
+    return flips, err
+
+
 def test_adeclick_matches_oracle_speech(engine, oracle):
     x = (speech(6.0, 11, 44100) * 3.0).astype(np.float64)
     ref, nref = oracle.adeclick(x, 44100, 1.7, 55.0, 50.0, method="s", return_count=True)
-    got, ngot = engine.op_adeclick(x, 44100, 1.7, 55.0, 50.0, method="s", return_count=True)
     assert nref > 1000 and np.max(np.abs(ref - x)) > 1e-3          # the filter re-interpolated a sizeable part of the signal
+    got, ngot = engine.op_adeclick(x, 44100, 1.7, 55.0, 50.0, method="s", return_count=True)
     assert ngot == nref                                             # identical detection decisions
-    assert np.array_equal(got, ref)                                 # identical sums, identical order: bit-exact
+    flips, err = declick_close(got, ref, x)
+    print(f"adeclick fast kernel vs oracle: {nref} repaired samples, {flips} flips, max abs error {err:.3g}")
+    with exact_adeclick():
+        got, ngot = engine.op_adeclick(x, 44100, 1.7, 55.0, 50.0, method="s", return_count=True)
+    assert ngot == nref and np.array_equal(got, ref)                # identical sums, identical order: bit-exact
+    # reproducible: the LDS floating-point atomics of the autocorrelation are served in a fixed order
+    again = engine.op_adeclick(x, 44100, 1.7, 55.0, 50.0, method="s")
+    assert np.array_equal(again, engine.op_adeclick(x, 44100, 1.7, 55.0, 50.0, method="s"))
 
 
-def test_adeclick_click_on_tone_and_edges(engine, oracle):
+@pytest.mark.parametrize("exact", [False, True])
+def test_adeclick_click_on_tone_and_edges(engine, oracle, exact):
     sr = 44100
     t = np.arange(sr) / sr
     x = 0.3 * np.sin(2 * np.pi * 220 * t)
     x[20000] += 0.5; x[20001] -= 0.4; x[33333] += 0.25             # clicks, one of them a 2-sample burst
-    ref = oracle.adeclick(x, sr)
-    got = engine.op_adeclick(x, sr)
-    assert np.array_equal(got, ref)
-    assert abs(got[20000] - 0.3 * np.sin(2 * np.pi * 220 * 20000 / sr)) < 1e-3     # the click is gone
-    for n in (1, 100, 1212, 1213, 2425, 2426, 5000):               # shorter than a hop / a window, and ragged tails
-        y = noise(n, 0.05, n).astype(np.float64)
-        assert np.array_equal(engine.op_adeclick(y, sr), oracle.adeclick(y, sr))
-    z = np.zeros(6000)                                              # digital silence: the AR fit is not finite, windows pass through
-    assert np.array_equal(engine.op_adeclick(z, sr), z)
+    same = (lambda g, r, xx: np.array_equal(g, r)) if exact else (lambda g, r, xx: declick_close(g, r, xx) is not None)
+    with (exact_adeclick() if exact else contextlib.nullcontext()):
+        ref = oracle.adeclick(x, sr)
+        got = engine.op_adeclick(x, sr)
+        assert same(got, ref, x)
+        assert abs(got[20000] - 0.3 * np.sin(2 * np.pi * 220 * 20000 / sr)) < 1e-3     # the click is gone
+        for n in (1, 100, 1212, 1213, 2425, 2426, 5000):               # shorter than a hop / a window, and ragged tails
+            y = noise(n, 0.05, n).astype(np.float64)
+            assert same(engine.op_adeclick(y, sr), oracle.adeclick(y, sr), y)
+        z = np.zeros(6000)                                              # digital silence: the AR fit is not finite, windows pass through
+        assert np.array_equal(engine.op_adeclick(z, sr), z)
 
 
-def test_adeclick_other_thresholds_and_rates(engine, oracle):
+@pytest.mark.parametrize("exact", [False, True])
+def test_adeclick_other_thresholds_and_rates(engine, oracle, exact):
     x = (speech(3.0, 12, 48000) * 2.0).astype(np.float64)
-    for thr in (2.0, 4.0):                                           # w=50 ms at 48 kHz: AR order 48, the largest this build lays out
-        assert np.array_equal(engine.op_adeclick(x, 48000, thr, 50.0, 50.0), oracle.adeclick(x, 48000, thr, 50.0, 50.0))
-    assert np.array_equal(engine.op_adeclick(x, 48000, 1.7, 40.0, 75.0), oracle.adeclick(x, 48000, 1.7, 40.0, 75.0))
-    # dense flags (a third of the samples at t = 1.0): more than the light instance's 512-entry layout, so the windows go
-    # through the full-capacity second pass, and the band reaches the AR order
-    z = noise(12000, 0.05, 77).astype(np.float64)
-    ref, nz = oracle.adeclick(z, 44100, 1.0, 55.0, 50.0, return_count=True)
-    assert nz / (z.size / 1212) > 512
-    assert np.array_equal(engine.op_adeclick(z, 44100, 1.0, 55.0, 50.0), ref)
-    with pytest.raises(L.JtError) as ei:                             # 55 ms at 48 kHz needs order 52: refused, never approximated
-        engine.op_adeclick(x, 48000, 1.7, 55.0, 50.0)
-    assert ei.value.code == L.JT_E_UNSUPPORTED
+    same = (lambda g, r, xx: np.array_equal(g, r)) if exact else (lambda g, r, xx: declick_close(g, r, xx) is not None)
+    with (exact_adeclick() if exact else contextlib.nullcontext()):
+        for thr in (2.0, 4.0):                                           # w=50 ms at 48 kHz: AR order 48, the largest this build lays out
+            assert same(engine.op_adeclick(x, 48000, thr, 50.0, 50.0), oracle.adeclick(x, 48000, thr, 50.0, 50.0), x)
+        assert same(engine.op_adeclick(x, 48000, 1.7, 40.0, 75.0), oracle.adeclick(x, 48000, 1.7, 40.0, 75.0), x)
+        # dense flags (a third of the samples at t = 1.0): more than the light instance's 512-entry layout, so the windows go
+        # through the full-capacity second pass, and the band reaches the AR order
+        z = noise(12000, 0.05, 77).astype(np.float64)
+        ref, nz = oracle.adeclick(z, 44100, 1.0, 55.0, 50.0, return_count=True)
+        assert nz / (z.size / 1212) > 512
+        assert same(engine.op_adeclick(z, 44100, 1.0, 55.0, 50.0), ref, z)
+        with pytest.raises(L.JtError) as ei:                             # 55 ms at 48 kHz needs order 52: refused, never approximated
+            engine.op_adeclick(x, 48000, 1.7, 55.0, 50.0)
+        assert ei.value.code == L.JT_E_UNSUPPORTED
 
 
 # ---------------------------------------------------------------- resampler + s16

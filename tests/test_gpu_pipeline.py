@@ -89,8 +89,10 @@ def test_pass3_pass4_match_oracle(processed, oracle):
     assert repaired > 0                                                     # the repair stage is active on this material
     z = oracle.alimiter(y, 44100, 0.803526, 1.0, 50.0)
     ref = oracle.f64_to_s16(z.astype(np.float32).astype(np.float64))
-    # bit-exact: every sum of the AR fit / detection / LDL^T solve keeps af_adeclick.c's order, same limiter state machine
-    assert np.array_equal(ref, p4)
+    # the limiter is the oracle's state machine lane for lane; adeclick's default kernel relaxes the summation order (1e-12 on the
+    # f64 samples, tests/test_gpu_ops.py), which can only show at an exact .5 rounding tie of the s16 conversion
+    d = np.abs(ref.astype(np.int32) - p4.astype(np.int32))
+    assert d.max() <= 1 and np.count_nonzero(d) <= 2, (d.max(), np.count_nonzero(d))
 
 
 def test_region_samples_and_specs_present(processed):
@@ -427,7 +429,7 @@ def test_limiter_prefix_path_loud_peaky_input(engine, oracle):
     assert res.limiter.needed == 1
     m, ref = _oracle_pass34(oracle, p2, res)
     assert abs(res.measure.input_i - m["input_i"]) <= 0.011 and abs(res.measure.input_tp - m["input_tp"]) <= 0.011
-    assert np.array_equal(ref, p4)
+    d = np.abs(ref.astype(np.int32) - p4.astype(np.int32)); assert d.max() <= 1 and np.count_nonzero(d) <= 2      # (adeclick fast kernel: .5 ties only)
     e = oracle.ebur128(p4.astype(np.float64) / 32768.0, 44100, True, True)
     assert 20 * np.log10(e["true_peak"]) <= -1.0
 
@@ -455,7 +457,7 @@ def test_44k1_input_no_rate_change(engine, oracle):
     d = np.abs(ref2.astype(np.int32) - p2.astype(np.int32))
     assert d.max() <= 3 and d.mean() < 0.3
     m, ref4 = _oracle_pass34(oracle, p2, res)
-    assert np.array_equal(ref4, p4)
+    d = np.abs(ref4.astype(np.int32) - p4.astype(np.int32)); assert d.max() <= 1 and np.count_nonzero(d) <= 2
 
 
 def test_deesser_enabled_and_short_clip(engine, oracle):
