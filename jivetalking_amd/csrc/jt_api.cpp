@@ -932,6 +932,12 @@ extern "C" int jt_pass4(jt_ctx *h, const jt_limiter_plan *lim, const jt_loudnorm
             fprintf(stderr, "adeclick: repaired %llu, second-pass windows %llu, third-pass windows %llu; phase clocks (JT_DK_PROFILE build):", dk_stats[0], dk_stats[2], dk_stats[3]);
             for (int i = 4; i < 12; ++i) fprintf(stderr, " %llu", dk_stats[i]);
             fprintf(stderr, "\n");
+            std::vector<int> hist(192);
+            JT_HIP(hipMemcpy(hist.data(), h->declick_heavy.p + 2 * ((m + 1211) / 1212), 192 * sizeof(int), hipMemcpyDeviceToHost));
+            fprintf(stderr, "bwmax per window:"); for (int i = 0; i < 64; ++i) if (hist[i]) fprintf(stderr, " %d:%d", i, hist[i]);
+            fprintf(stderr, "\nbw per pivot:"); for (int i = 0; i < 64; ++i) if (hist[64 + i]) fprintf(stderr, " %d:%d", i, hist[64 + i]);
+            fprintf(stderr, "\nF/16 per window:"); for (int i = 0; i < 64; ++i) if (hist[128 + i]) fprintf(stderr, " %d:%d", i, hist[128 + i]);
+            fprintf(stderr, "\n");
         }
         { float dms = 0; JT_HIP(hipEventElapsedTime(&dms, h->ev2, h->ev3)); h->timers.declick_ms = dms; }
         JT_REQUIRE(dk_stats[1] == 0, JT_E_HIP, "adeclick: singular interpolation matrix (af_adeclick.c would fail the graph)");

@@ -587,9 +587,17 @@ k_adeclick_fast(const double *__restrict__ in, double *__restrict__ out, int64_t
         int sb = 0;
         auto load_buf = [&](int base) {
             sb = base;
-            for (int j = lane; j < LB + PADE; j += 64) {
-                const int64_t p = s0 + base + j;
-                sbuf[j] = (base + j < W && p >= 0 && p < n) ? __dmul_rn(in[p], P.gain) : 0.0;
+            // eight loads in flight per lane before the first LDS store (one load -> one store per trip left every trip waiting for
+            // a full memory latency: 21 trips per half window, four half windows per window)
+            for (int j0 = lane; j0 < LB + PADE; j0 += 64 * 8) {
+                double t[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int j = j0 + 64 * u; const int64_t p = s0 + base + j;
+                    t[u] = (j < LB + PADE && base + j < W && p >= 0 && p < n) ? in[p] : 0.0;
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) { const int j = j0 + 64 * u; if (j < LB + PADE) sbuf[j] = __dmul_rn(t[u], P.gain); }
             }
         };
         load_buf(0);
@@ -768,6 +776,15 @@ k_adeclick_fast(const double *__restrict__ in, double *__restrict__ out, int64_t
                     bwv[k] = (unsigned char)(lo - k);
                     bwmax = max(bwmax, lo - k);
                 }
+#ifdef JT_DK_HIST
+                if (LEVEL == 0) {
+                    int bm = bwmax;
+                    for (int o = 32; o > 0; o >>= 1) bm = max(bm, __shfl_xor(bm, o, 64));
+                    if (lane == 0) atomicAdd(&heavy[2 * P.nwindows + min(bm, 63)], 1);
+                    for (int k = lane; k < F; k += 64) atomicAdd(&heavy[2 * P.nwindows + 64 + min((int)bwv[k], 63)], 1);
+                    if (lane == 0) atomicAdd(&heavy[2 * P.nwindows + 128 + min(F >> 4, 63)], 1);
+                }
+#endif
                 to_heavy = __any(bwmax > BWMAX);
                 // rows past the last one are "far away": every ring entry against them is aux[AR + 1] = 0
                 for (int k = F + lane; k < F + NC + ND && k < FCAP + NC + ND; k += 64) index[k] = 0xFFFF;
@@ -845,30 +862,52 @@ k_adeclick_fast(const double *__restrict__ in, double *__restrict__ out, int64_t
             double *vstage = ac;
             int vbase = NC;
             vstage[lane] = (vbase + lane < F) ? dk_ld(&gV[vbase + lane]) : 0.0;
-            size_t goff = 0;
             const int dgl = lane < ND ? lane : ND - 1;                // this lane's diagonal of the pivot column
             double *colp = blk + dgl * NC;
             double *pairp = blk + (a0 - b0) * NC;                      // diagonal of this lane's trailing pair
+            // packed factor stream in global scratch: per pivot k the bw multipliers of its column (rows k+1 .. k+bw), then y_k / d_k
+            unsigned goff = 0;
             __builtin_amdgcn_wave_barrier();
+            int bw = bwv[0];
             for (int k = 0; k < F; ++k) {
                 const int ks = k & CM;
-                const int bw = bwv[k];
+                // every LDS read that does not depend on this pivot's arithmetic is issued up front (the chain per pivot is then:
+                // column read -> reciprocal -> multipliers -> lane permute -> update -> write, three LDS round trips instead of six)
                 const double colv = colp[ks];
                 const double yrow = yring[(k + lane) & CM];
+                double *ep = pairp + ((k + 1 + b0) & CM);
+                const double eold = *ep;
+                const int bwn = bwv[k + 1];
+                const int nj = k + NC;
+                int idn = 0; double vn = 0.0;
+                if (nj < F) {
+                    if (nj >= vbase + 64) { vbase += 64; vstage[lane] = (vbase + lane < F) ? dk_ld(&gV[vbase + lane]) : 0.0; __builtin_amdgcn_wave_barrier(); }
+                    idn = index[nj + dgl];
+                    vn = vstage[nj - vbase];
+                }
+                const double cb = __shfl(colv, b0 + 1, 64);
                 const double d = dk_readlane(colv, 0), yk = dk_readlane(yrow, 0);
                 if (d == 0.0) { ok = false; break; }
+                const int dlt = idn - __builtin_amdgcn_readfirstlane(idn);
+                const double ent = aux[dlt < AR + 1 ? dlt : AR + 1];
+#ifdef JT_DKX_NORCP
+                const double rinv = d * 1e-3;
+#else
                 const double rinv = dk_rcp(d);
+#endif
                 const double l = colv * rinv;
                 const bool inband = (unsigned)(lane - 1) < (unsigned)bw;
+                const double la = __shfl(l, a0 + 1, 64);
+#ifndef JT_DKX_NOSTORE
                 if (lane <= bw) gL[goff + (lane ? lane - 1 : bw)] = lane ? l : yk * rinv;
-                goff += (size_t)bw + 1;
+#endif
+                goff += (unsigned)bw + 1u;
                 if (inband) yring[(k + lane) & CM] = __fma_rn(-l, yk, yrow);
                 const int npairs = bw * (bw + 1) / 2;
-                {
-                    const double la = __shfl(l, a0 + 1, 64), cb = __shfl(colv, b0 + 1, 64);
-                    double *ep = pairp + ((k + 1 + b0) & CM);
-                    if (lane < npairs) *ep = __fma_rn(-cb, la, *ep);
-                }
+#ifndef JT_DKX_NOPAIR
+                if (lane < npairs) *ep = __fma_rn(-cb, la, eold);
+#endif
+#ifndef JT_DKX_NOWIDE
                 if (npairs > 64) {
                     if (lane < MAXAR + 1) { lvec[lane] = l; cvec[lane] = colv; }
                     __builtin_amdgcn_wave_barrier();
@@ -878,57 +917,62 @@ k_adeclick_fast(const double *__restrict__ in, double *__restrict__ out, int64_t
                         *e = __fma_rn(-cvec[b + 1], lvec[a + 1], *e);
                     }
                 }
+#endif
                 // column k + NC takes the slot of column k (every diagonal), its right-hand side the slot of y_k
-                const int nj = k + NC;
+#ifndef JT_DKX_NOENTER
                 if (nj < F) {
-                    if (nj >= vbase + 64) { vbase += 64; vstage[lane] = (vbase + lane < F) ? dk_ld(&gV[vbase + lane]) : 0.0; __builtin_amdgcn_wave_barrier(); }
-                    const double vn = vstage[nj - vbase];
-                    const int idn = index[nj + dgl];
-                    const int dlt = idn - __builtin_amdgcn_readfirstlane(idn);
-                    const double ent = aux[dlt < AR + 1 ? dlt : AR + 1];
                     if (lane < ND) colp[ks] = ent;
                     if (lane == 0) yring[ks] = vn;
                 }
+#endif
+                bw = __builtin_amdgcn_readfirstlane(bwn);
                 __builtin_amdgcn_wave_barrier();
             }
             DKF_MARK(5)
             if (ok) {
                 __threadfence();
-                // ---- 10. back substitution (as k_adeclick, fused multiply-adds)
-                double sw = 0.0;
-                for (int ib = F - 1; ib >= 0; ib -= 16) {
-                    double qr = 0.0; int ntr = 0, cnt = 0;
-                    if (lane < 16 && ib - lane >= 0) { ntr = bwv[ib - lane]; cnt = ntr + 1; }
-                    int pref = cnt;
+                // ---- 10. back substitution, column form: out[i] = y_i / d_i - A_i, where A_j collects L[i][j] * out[i] from every row i
+                // already solved.  Lane t holds A of row i - t; one step = broadcast of lane 0's row, one fused multiply-add, one lane
+                // shift (a dot-product form waits for a wave reduction per row).  L[i][i - t] is element t - 1 of pivot (i - t)'s packed
+                // segment: every lane walks the segment offsets of "its" pivot k = i - t downwards with the band widths in LDS
+                // (seg(k) = seg(k + 1) - (bw_k + 1)); lane 0 fetches y_i / d_i, the last element of row i's own segment.  Rows in
+                // batches of 16: their sixteen gathers are in flight together.
+                double A = 0.0;
+                unsigned segv;
+                {
+                    const int k1 = F - 1 - lane;                       // the pivot this lane meets first
+                    unsigned c = k1 >= 0 ? (unsigned)bwv[k1] + 1u : 0u, inc = c;
 #pragma unroll
-                    for (int dd = 1; dd < 16; dd <<= 1) { const int o = __shfl_up(pref, dd, 64); pref += lane >= dd ? o : 0; }
-                    if (cnt) qr = dk_ld(&gL[goff - (size_t)pref + (size_t)ntr]);
+                    for (int dd = 1; dd < 64; dd <<= 1) { const unsigned o = __shfl_up(inc, dd, 64); inc += lane >= dd ? o : 0u; }
+                    segv = goff - (inc - c);                            // = seg(k1) + bw_k1 + 1: the first step subtracts that pivot's segment
+                }
+                for (int ib = F - 1; ib >= 0; ib -= 16) {
                     double Lr[16];
 #pragma unroll
                     for (int q = 0; q < 16; ++q) {
-                        const int nq = __builtin_amdgcn_readlane(ntr, q);
-                        const size_t oq = goff - (size_t)__builtin_amdgcn_readlane(pref, q);
-                        Lr[q] = lane < nq ? dk_ld(&gL[oq + lane]) : 0.0;
+                        const int k = ib - q - lane;
+                        const int bwk = k >= 0 ? (int)bwv[k] : 0;
+                        segv -= (unsigned)bwk + 1u;
+                        const bool valid = k >= 0 && ib - q >= 0 && bwk >= lane;      // lane 0: always (its element is y/d)
+#ifndef JT_DKX_NOSTORE
+                        Lr[q] = valid ? dk_ld(&gL[segv + (lane ? (unsigned)lane - 1u : (unsigned)bwk)]) : 0.0;
+#else
+                        Lr[q] = valid ? 1e-3 : 0.0;
+#endif
                     }
-                    goff -= (size_t)__builtin_amdgcn_readlane(pref, 15);
+                    double xs = 0.0;                                    // lane q: solution of row ib - q
 #pragma unroll
                     for (int q = 0; q < 16; ++q) {
-                        const int nt = __builtin_amdgcn_readlane(ntr, q);
-                        double v = dk_readlane(qr, q);
-                        // sum of the band's terms by a wave tree (terms beyond the band are zero)
-                        double term = lane < nt ? Lr[q] * sw : 0.0;
-                        if (nt > 0) {
-#pragma unroll
-                            for (int o = 32; o > 0; o >>= 1) term += __shfl_xor(term, o, 64);
-                            v -= term;
-                        }
+                        const double x = dk_readlane(Lr[q], 0) - dk_readlane(A, 0);
+                        A = __fma_rn(Lr[q], x, A);
                         {
-                            const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(sw), 0x138, 0xf, 0xf, false);   // wave_shr:1
-                            const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(sw), 0x138, 0xf, 0xf, false);
-                            sw = lane == 0 ? v : __hiloint2double(hi, lo);
+                            const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(A), 0x130, 0xf, 0xf, true);    // wave_shl:1
+                            const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(A), 0x130, 0xf, 0xf, true);
+                            A = __hiloint2double(hi, lo);
                         }
+                        xs = lane == q ? x : xs;
                     }
-                    if (lane < 16 && ib - 15 + lane >= 0) blk[ib - 15 + lane] = sw;
+                    if (lane < 16 && ib - lane >= 0) blk[ib - lane] = xs;
                 }
                 __builtin_amdgcn_wave_barrier();
                 for (int e = lane; e < F; e += 64) {
@@ -942,13 +986,16 @@ k_adeclick_fast(const double *__restrict__ in, double *__restrict__ out, int64_t
         }
         DKF_MARK(6)
         const bool rep = F > 0 && ok;
-        for (int j = lane; j < P.hop; j += 64) {
-            const int64_t o = o0 + j;
-            const int pos = P.skip + j;
-            if (o < n && !(rep && fbit(pos))) {
-                const int64_t p = s0 + pos;
-                out[o] = (p >= 0 && p < n) ? __dmul_rn(in[p], P.gain) : 0.0;
+        for (int j0 = lane; j0 < P.hop; j0 += 64 * 8) {
+            double t[8]; bool wr[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int j = j0 + 64 * u, pos = P.skip + j; const int64_t o = o0 + j, p = s0 + pos;
+                wr[u] = j < P.hop && o < n && !(rep && fbit(pos));
+                t[u] = (wr[u] && p >= 0 && p < n) ? in[p] : 0.0;
             }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) if (wr[u]) out[o0 + j0 + 64 * u] = __dmul_rn(t[u], P.gain);
         }
         __builtin_amdgcn_wave_barrier();
     }
@@ -995,7 +1042,8 @@ void launch_adeclick(jt_ctx *h, const double *in, double *out, int64_t n, int sa
     JT_REQUIRE(sm2 <= 64 * 1024, JT_E_UNSUPPORTED, "adeclick: window does not fit the per-wave LDS budget");
     const size_t per_wave = (size_t)P.W * dk::MAXAR + 3 * (size_t)P.W;
     const bool exact = getenv("JT_ADECLICK_EXACT") != nullptr;      // the bit-exact sequential-order kernel (parity tests / A-B); default: fast
-    h->declick_heavy.ensure(2 * (size_t)P.nwindows);
+    h->declick_heavy.ensure(2 * (size_t)P.nwindows + 192);
+    if (getenv("JT_DK_PROFILE")) JT_HIP(hipMemsetAsync(h->declick_heavy.p + 2 * P.nwindows, 0, 192 * sizeof(int), s));
 #define DK_LAUNCH(KERN, GRID, SMEM, PP) do { auto k_ = KERN; \
         JT_HIP(hipFuncSetAttribute((const void *)k_, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(SMEM))); \
         hipLaunchKernelGGL(k_, dim3((unsigned)(GRID)), dim3(64), (SMEM), s, in, out, n, PP, h->declick_scr.p, per_wave, d_stats, h->declick_heavy.p); } while (0)
