@@ -865,6 +865,18 @@ k_adeclick_fast(const double *__restrict__ in, double *__restrict__ out, int64_t
             const int dgl = lane < ND ? lane : ND - 1;                // this lane's diagonal of the pivot column
             double *colp = blk + dgl * NC;
             double *pairp = blk + (a0 - b0) * NC;                      // diagonal of this lane's trailing pair
+            int a1, b1, a2, b2;                                         // pairs lane + 64 and lane + 128 (bands of 11 .. 18 rows)
+            {
+                auto unrank = [](int t, int &a, int &b) {
+                    a = (int)((sqrtf(8.0f * (float)t + 1.0f) - 1.0f) * 0.5f);
+                    a += ((a + 1) * (a + 2) / 2 <= t); a -= (a * (a + 1) / 2 > t);
+                    b = t - a * (a + 1) / 2;
+                };
+                unrank(lane + 64, a1, b1); unrank(lane + 128, a2, b2);
+                if (a1 - b1 >= ND) { a1 = b1 = 0; }                      // (never taken for ND >= 20; keeps the pointers inside the ring)
+                if (a2 - b2 >= ND) { a2 = b2 = 0; }
+            }
+            double *pairp1 = blk + (a1 - b1) * NC, *pairp2 = blk + (a2 - b2) * NC;
             // packed factor stream in global scratch: per pivot k the bw multipliers of its column (rows k+1 .. k+bw), then y_k / d_k
             unsigned goff = 0;
             __builtin_amdgcn_wave_barrier();
@@ -909,12 +921,25 @@ k_adeclick_fast(const double *__restrict__ in, double *__restrict__ out, int64_t
 #endif
 #ifndef JT_DKX_NOWIDE
                 if (npairs > 64) {
-                    if (lane < MAXAR + 1) { lvec[lane] = l; cvec[lane] = colv; }
-                    __builtin_amdgcn_wave_barrier();
-                    for (int t = lane + 64; t < npairs; t += 64) {
-                        const int ab = pairtab[t], a = ab & 0xff, b = ab >> 8;
-                        double *e = blk + (a - b) * NC + ((k + 1 + b) & CM);
-                        *e = __fma_rn(-cvec[b + 1], lvec[a + 1], *e);
+                    // pairs 64 .. 191 (bands up to 18 rows): this lane's second and third pair, operands by lane permute like the first
+                    {
+                        const double la1 = __shfl(l, a1 + 1, 64), cb1 = __shfl(colv, b1 + 1, 64);
+                        double *e1 = pairp1 + ((k + 1 + b1) & CM);
+                        if (lane + 64 < npairs) *e1 = __fma_rn(-cb1, la1, *e1);
+                    }
+                    if (npairs > 128) {
+                        const double la2 = __shfl(l, a2 + 1, 64), cb2 = __shfl(colv, b2 + 1, 64);
+                        double *e2 = pairp2 + ((k + 1 + b2) & CM);
+                        if (lane + 128 < npairs) *e2 = __fma_rn(-cb2, la2, *e2);
+                    }
+                    if (npairs > 192) {
+                        if (lane < MAXAR + 1) { lvec[lane] = l; cvec[lane] = colv; }
+                        __builtin_amdgcn_wave_barrier();
+                        for (int t = lane + 192; t < npairs; t += 64) {
+                            const int ab = pairtab[t], a = ab & 0xff, b = ab >> 8;
+                            double *e = blk + (a - b) * NC + ((k + 1 + b) & CM);
+                            *e = __fma_rn(-cvec[b + 1], lvec[a + 1], *e);
+                        }
                     }
                 }
 #endif
