@@ -126,7 +126,7 @@ typedef struct {
     int    nlm_enabled; double nlm_strength, nlm_patch_s, nlm_research_s, nlm_smooth;   /* anlmdn=s:p:r:m */
     int    fft_enabled; double fft_nr, fft_nf;                /* afftdn=nr:...:nf (nf 0 => FFmpeg default -50) */
     int    fft_custom;  double fft_band_noise[15];            /* nt=custom:bn= */
-    int    fft_track_noise;                                   /* tn=1 => JT_E_UNSUPPORTED */
+    int    fft_track_noise;                                   /* tn=1: the floor follows spectrally flat frames (adaptive.go:147-151) */
     int    gate_enabled; double gate_threshold, gate_ratio, gate_attack_ms, gate_release_ms,
                                 gate_range, gate_knee, gate_makeup;                     /* agate, detection=rms */
     int    comp_enabled; double comp_threshold, comp_ratio, comp_attack_ms, comp_release_ms,
@@ -276,6 +276,9 @@ int jt_op_afftdn_f32(jt_ctx *h, const float *in, float *out, int64_t n, int samp
                      double nr, double nf, const double *band_noise /* 15 or NULL */);
 /* agate -> acompressor -> deesser chain in double on float input, output rounded to float
  * (the dbl->flt conversion FFmpeg inserts before aspectralstats) */
+/* the same with tn=1 (track_noise); final_floor_db (optional) receives the tracked floor after the last frame */
+int jt_op_afftdn_tn_f32(jt_ctx *h, const float *in, float *out, int64_t n, int sample_rate,
+                        double nr, double nf, const double *band_noise, int track_noise, double *final_floor_db);
 int jt_op_dynamics(jt_ctx *h, const float *in, float *out, int64_t n, int sample_rate, const jt_filter_params *p);
 int jt_op_alimiter_f64(jt_ctx *h, const double *in, double *out, int64_t n, int sample_rate,
                        double limit, double attack_ms, double release_ms);

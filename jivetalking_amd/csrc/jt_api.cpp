@@ -539,12 +539,12 @@ static void run_anlmdn(jt_ctx *h, const float *in, float *out, int64_t n, int sr
     JT_HIP(hipEventRecord(h->ev3, st));
 }
 
-static void run_afftdn(jt_ctx *h, const float *in, float *out, int64_t n, int sr, double nr, double nf, const double *bn)
+static void run_afftdn(jt_ctx *h, const float *in, float *out, int64_t n, int sr, double nr, double nf, const double *bn, bool track = false)
 {
     AfftdnPlanHost pl; jt_afftdn_plan(&pl, sr, nr, nf, bn);
     ensure_twiddle(h, pl.L);
     const size_t nb = pl.nbands, bins = pl.bins;
-    const size_t ndbl = pl.W + nb + nb + nb * nb + bins + bins;
+    const size_t ndbl = pl.W + nb + nb + nb * nb + bins + bins + bins;
     h->af_tab.ensure(ndbl); h->af_bin2band.ensure(bins);
     // staged in the pinned arena: the copies stay valid until the pass's single synchronisation
     double *tab = h->pin.take<double>(ndbl); double *w = tab;
@@ -554,6 +554,7 @@ static void run_afftdn(jt_ctx *h, const float *in, float *out, int64_t n, int sr
     w = std::copy(pl.spread.begin(), pl.spread.end(), w);
     w = std::copy(pl.abs_var.begin(), pl.abs_var.end(), w);
     w = std::copy(pl.min_abs_var.begin(), pl.min_abs_var.end(), w);
+    w = std::copy(pl.rel_var.begin(), pl.rel_var.end(), w);
     int *b2b = h->pin.take<int>(bins);
     std::copy(pl.bin2band.begin(), pl.bin2band.end(), b2b);
     JT_HIP(hipMemcpyAsync(h->af_tab.p, tab, sizeof(double) * ndbl, hipMemcpyHostToDevice, h->stream));
@@ -562,8 +563,33 @@ static void run_afftdn(jt_ctx *h, const float *in, float *out, int64_t n, int sr
     d.A = pl.A; d.W = pl.W; d.L = pl.L; d.bins = pl.bins; d.nbands = pl.nbands; d.max_gain = pl.max_gain;
     d.bin2band = h->af_bin2band.p;
     d.window = h->af_tab.p; d.alpha = d.window + pl.W; d.beta = d.alpha + nb; d.spread = d.beta + nb;
-    d.abs_var = d.spread + nb * nb; d.min_abs_var = d.abs_var + bins; d.twiddle = h->twiddle.p;
-    launch_afftdn(in, out, n, d, 0, 96, h->stream);     // chunk length chosen from the frame count; 96 warm-up frames
+    d.abs_var = d.spread + nb * nb; d.min_abs_var = d.abs_var + bins; d.rel_var = d.min_abs_var + bins; d.twiddle = h->twiddle.p;
+    d.floor = pl.floor;
+    if (!track) { launch_afftdn(in, out, n, d, 0, 96, h->stream); return; }     // chunk length chosen from the frame count; 96 warm-up frames
+    // tn=1 (af_afftdn.c track_noise; what the reference emits when Noise.Floor == 0, adaptive.go:147-151).  The floor is a state
+    // that survives arbitrarily long stretches of speech (only spectrally flat frames move it), so a warm-up halo cannot restore
+    // it -- but the VOTE of a frame (is it flat, and which floor does it ask for) depends on that frame's magnitudes alone.  First
+    // sweep: every frame's vote, in parallel; then the first-order recurrence nf <- 0.9 nf + 0.1 vote over the frames on the host
+    // (N / 600 values); second sweep: the usual chunked kernel with the per-frame variances that recurrence implies.
+    const int64_t nframes = jt_afftdn_nframes(n, pl.A, pl.W);
+    h->af_track.ensure((size_t)(2 * nframes + 4));
+    d.track_out = h->af_track.p; d.mvseq = h->af_track.p + nframes + 1;
+    launch_afftdn(in, out, n, d, 0, 0, h->stream, 2);
+    std::vector<double> vote((size_t)nframes), mv((size_t)nframes + 1);
+    JT_HIP(hipMemcpyAsync(vote.data(), d.track_out, sizeof(double) * nframes, hipMemcpyDeviceToHost, h->stream));
+    JT_HIP(hipStreamSynchronize(h->stream));
+    check_cancel(h);
+    const double Cc = M_LN10 * 0.1;
+    double nfl = pl.noise_floor;
+    mv[0] = pl.floor * std::exp((100.0 + nfl) * Cc);
+    for (int64_t t = 0; t < nframes; ++t) {
+        if (!std::isnan(vote[(size_t)t])) { nfl = 0.1 * vote[(size_t)t] + nfl * 0.9; mv[(size_t)t + 1] = pl.floor * std::exp((100.0 + nfl) * Cc); }
+        else mv[(size_t)t + 1] = mv[(size_t)t];
+    }
+    h->af_last_floor = nfl;
+    JT_HIP(hipMemcpyAsync(h->af_track.p + nframes + 1, mv.data(), sizeof(double) * (nframes + 1), hipMemcpyHostToDevice, h->stream));
+    launch_afftdn(in, out, n, d, 0, 96, h->stream, 1);
+    JT_HIP(hipStreamSynchronize(h->stream));                 // (mv is a host vector: the upload must have left it)
 }
 
 static void fill_biquads(const jt_filter_params *p, int sr, BiquadF32 st[2], int *nst)
@@ -673,8 +699,6 @@ extern "C" int jt_pass2(jt_ctx *h, const jt_filter_params *p, jt_analysis *out)
     JT_API_BEGIN_KEEP(h)
     JT_REQUIRE(h->n > 0 && h->in_mono, JT_E_STATE, "pass2: no input uploaded");
     JT_REQUIRE(p && out, JT_E_INVAL, "pass2: bad arguments");
-    JT_REQUIRE(!(p->fft_enabled && p->fft_track_noise), JT_E_UNSUPPORTED,
-               "pass2: afftdn tn=1 (noise tracking) is not implemented on the GPU path");
     check_cancel(h);
     std::memset(out, 0, sizeof(*out));
     JT_HIP(hipEventRecord(h->ev0, h->stream));
@@ -709,7 +733,7 @@ extern "C" int jt_pass2(jt_ctx *h, const jt_filter_params *p, jt_analysis *out)
     check_cancel(h);
     if (p->fft_enabled) {
         double nf = p->fft_nf < 0 ? p->fft_nf : -50.0;
-        run_afftdn(h, cur, nxt, n, sr, p->fft_nr, nf, p->fft_custom ? p->fft_band_noise : nullptr); advance();
+        run_afftdn(h, cur, nxt, n, sr, p->fft_nr, nf, p->fft_custom ? p->fft_band_noise : nullptr, p->fft_track_noise != 0); advance();
     }
     check_cancel(h);
     DynParams d; jt_dyn_design(p, sr, &d);
@@ -1086,12 +1110,18 @@ extern "C" int jt_op_anlmdn_f32(jt_ctx *h, const float *in, float *out, int64_t 
 
 extern "C" int jt_op_afftdn_f32(jt_ctx *h, const float *in, float *out, int64_t n, int sr, double nr, double nf, const double *bn)
 {
+    return jt_op_afftdn_tn_f32(h, in, out, n, sr, nr, nf, bn, 0, nullptr);
+}
+extern "C" int jt_op_afftdn_tn_f32(jt_ctx *h, const float *in, float *out, int64_t n, int sr, double nr, double nf, const double *bn,
+                                   int track_noise, double *final_floor_db)
+{
     JT_API_BEGIN(h)
     JT_REQUIRE(in && out && n > 0, JT_E_INVAL, "op_afftdn: bad arguments");
     DevBuf<float> a, b; h2d(h, a, in, (size_t)n); b.ensure((size_t)n);
     pass_begin(h, 1 << 16, 1);
-    run_afftdn(h, a.p, b.p, n, sr, nr, nf, bn);
+    run_afftdn(h, a.p, b.p, n, sr, nr, nf, bn, track_noise != 0);
     d2h(h, out, b.p, (size_t)n);
+    if (final_floor_db) *final_floor_db = track_noise ? h->af_last_floor : nf;
     JT_API_END(h)
 }
 

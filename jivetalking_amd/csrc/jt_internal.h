@@ -114,15 +114,20 @@ void launch_aspectralstats(const float *in, int64_t n, int sr, int win_size, con
 // afftdn
 struct AfftdnPlanHost {
     int sr, A, W, L, bins, nbands;
-    std::vector<int> bin2band; std::vector<double> window, alpha, beta, spread, abs_var, min_abs_var;
-    double max_gain;
+    std::vector<int> bin2band; std::vector<double> window, alpha, beta, spread, abs_var, min_abs_var, rel_var;
+    double max_gain, floor = 0, noise_floor = 0;
 };
 void jt_afftdn_plan(AfftdnPlanHost *pl, int sr, double nr, double nf, const double *band_noise);
 struct AfftdnDev {
     int A, W, L, bins, nbands; double max_gain;
     const int *bin2band; const double *window, *alpha, *beta, *spread, *abs_var, *min_abs_var; const float2 *twiddle;
+    // noise tracking (tn=1): band shape, the magnitude floor of the flatness measure, max_var before frame t (mvseq[t]) and after it
+    // (mvseq[t + 1]); track_out[t] = the floor a spectrally flat frame votes for (NaN = frame not flat), written by the analysis mode
+    const double *rel_var = nullptr; double floor = 0; const double *mvseq = nullptr; double *track_out = nullptr;
 };
-void launch_afftdn(const float *in, float *out, int64_t n, const AfftdnDev &d, int frames_per_chunk, int warm_frames, hipStream_t s);
+// mode 0: static noise floor; 1: per-frame variances from d.mvseq (tn=1, second sweep); 2: tn=1 first sweep, writes d.track_out only
+void launch_afftdn(const float *in, float *out, int64_t n, const AfftdnDev &d, int frames_per_chunk, int warm_frames, hipStream_t s, int mode = 0);
+int64_t jt_afftdn_nframes(int64_t n, int A, int W);
 // anlmdn
 void launch_anlmdn(const float *in, float *out, int64_t n, int K, int S, float sw, float smooth, float lut_scale, hipStream_t s);
 
@@ -237,7 +242,7 @@ struct jt_ctx {
     DevBuf<float2> twiddle; int twiddle_n = 0; DevBuf<float> hann; int hann_n = 0;
     DevBuf<double> bank_d; DevBuf<float> bank_f;
     DevBuf<int64_t> lim_bounds, lim_pos; DevBuf<double> lim_delta;
-    DevBuf<int> af_bin2band; DevBuf<double> af_tab;
+    DevBuf<int> af_bin2band; DevBuf<double> af_tab, af_track; double af_last_floor = 0;      // af_track: tn=1 votes + per-frame max_var
     HostArena pin;
     // per-pass bump allocator over d_scr2 for the astats jobs: the three chains of different jobs run on different streams, so
     // every job needs its own scratch slice (sized at the start of the pass, never reallocated while work is queued)

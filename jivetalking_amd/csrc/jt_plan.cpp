@@ -441,6 +441,7 @@ void jt_afftdn_plan(AfftdnPlanHost *pl, int sr, double nr, double nf, const doub
       } }
     pl->abs_var.resize(bins); pl->min_abs_var.resize(bins);
     for (int i = 0; i < bins; i++) { pl->abs_var[i] = std::fmax(max_var * rel[i], 1.0); pl->min_abs_var[i] = gain_scale * pl->abs_var[i]; }
+    pl->rel_var.assign(rel.begin(), rel.begin() + bins); pl->floor = floor; pl->noise_floor = nf;      // (noise tracking, tn=1)
 }
 
 // ---------------------------------------------------------------- MD5 (RFC 1321) for the FLAC STREAMINFO signature

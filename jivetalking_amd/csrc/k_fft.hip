@@ -337,7 +337,7 @@ __device__ inline double fast_rcp(double a)
 // Band excitation sums: lanes hold consecutive bins, so each wave does a segmented shuffle reduction per bark band and the
 // <= 8 per-segment partials of a band are added in ascending-bin order by the band's thread (deterministic).
 // Overlap-add accumulator is a circular double buffer in LDS (no per-hop shifting).
-template <int LOG2N>
+template <int LOG2N, int MODE>
 __global__ void __launch_bounds__(FT)
 k_afftdn(const float *__restrict__ in, float *__restrict__ out, int64_t n, AfftdnDev d, int frames_per_chunk, int warm_frames,
          int64_t nframes)
@@ -368,7 +368,7 @@ k_afftdn(const float *__restrict__ in, float *__restrict__ out, int64_t n, Afftd
     const int64_t t_lo = (int64_t)blockIdx.x * frames_per_chunk;
     const int64_t t_hi = min(t_lo + frames_per_chunk, nframes);
     if (t_lo >= nframes) return;
-    const int64_t t0 = max((int64_t)0, t_lo - warm_frames);
+    const int64_t t0 = MODE == 2 ? t_lo : max((int64_t)0, t_lo - warm_frames);       // (the tracker's vote of a frame has no history)
 
     // ---- per-chunk constants
     for (int q = tid; q < H; q += FT) { double sn, cs; sincospi(2.0 * q / H, &sn, &cs); tw[q] = make_float2((float)cs, (float)-sn); }
@@ -392,7 +392,7 @@ k_afftdn(const float *__restrict__ in, float *__restrict__ out, int64_t n, Afftd
     }
     // bins owned: pair p -> k = tid + p*FT (bins k and H-k); slot 2*KP = bin H/2 (thread 0 only)
     constexpr int NBIN = 2 * KP + 1;
-    double prior[NBIN], av[NBIN], inv_av[NBIN], sqrt_av[NBIN];
+    double prior[NBIN], av[NBIN], inv_av[NBIN], sqrt_av[NBIN], rel[NBIN];
     int bband[NBIN], bseg[NBIN]; unsigned same[NBIN]; bool head[NBIN], valid[NBIN];
     float2 wk[KP];
 #pragma unroll
@@ -406,6 +406,7 @@ k_afftdn(const float *__restrict__ in, float *__restrict__ out, int64_t n, Afftd
             valid[e] = (k < HH) && !(side == 1 && false);
             const int bi = valid[e] ? bin : 0;
             prior[e] = 0.0; av[e] = d.abs_var[bi]; inv_av[e] = 1.0 / av[e]; sqrt_av[e] = sqrt(av[e]);
+            rel[e] = MODE == 1 ? d.rel_var[bi] : 0.0;
             bband[e] = valid[e] ? d.bin2band[bi] : -1 - e;
             const int row = (k >> 6);                                      // forward wave-row
             bseg[e] = side == 0 ? row : FSEG + 1 + (FSEG - 1 - row);
@@ -415,6 +416,7 @@ k_afftdn(const float *__restrict__ in, float *__restrict__ out, int64_t n, Afftd
         const int e = 2 * KP;
         valid[e] = (tid == 0);
         prior[e] = 0.0; av[e] = d.abs_var[HH]; inv_av[e] = 1.0 / av[e]; sqrt_av[e] = sqrt(av[e]);
+        rel[e] = MODE == 1 ? d.rel_var[HH] : 0.0;
         bband[e] = valid[e] ? d.bin2band[HH] : -100;
         bseg[e] = FSEG;
     }
@@ -484,6 +486,47 @@ k_afftdn(const float *__restrict__ in, float *__restrict__ out, int64_t n, Afftd
             } else { X[2 * p] = make_float2(0.f, 0.f); X[2 * p + 1] = make_float2(0.f, 0.f); }
         }
         { const float2 zk = Z[HH]; X[2 * KP] = make_float2(zk.x, -zk.y); }
+        if (MODE == 2) {
+            // af_afftdn.c track_noise: spectral_flatness() over the magnitudes above s->floor, floor_offset() over all of them.
+            // Block reduction (count, sum of logs, sum, max, min); thread 0 writes the frame's vote.
+            double cnt = 0.0, slog = 0.0, ssum = 0.0, mx = 0.0, mn = 1e300;
+#pragma unroll
+            for (int e = 0; e < NBIN; ++e) {
+                if (!valid[e]) continue;
+                const double mag = hypot((double)X[e].x, (double)X[e].y);
+                if (mag > d.floor) { cnt += 1.0; slog += log(mag); ssum += mag; }
+                mx = fmax(mx, mag); mn = fmin(mn, mag);
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                cnt += __shfl_down(cnt, o, 64); slog += __shfl_down(slog, o, 64); ssum += __shfl_down(ssum, o, 64);
+                mx = fmax(mx, __shfl_down(mx, o, 64)); mn = fmin(mn, __shfl_down(mn, o, 64));
+            }
+            __syncthreads();                                     // (part[] is free: nothing of this frame has used it)
+            if (lane == 0) { double *pp = part + (tid >> 6) * 5; pp[0] = cnt; pp[1] = slog; pp[2] = ssum; pp[3] = mx; pp[4] = mn; }
+            __syncthreads();
+            if (tid == 0) {
+                for (int w = 1; w < FT / 64; ++w) { const double *pp = part + w * 5; cnt += pp[0]; slog += pp[1]; ssum += pp[2]; mx = fmax(mx, pp[3]); mn = fmin(mn, pp[4]); }
+                const double size = fmax(cnt, 1.0);
+                const double num = exp(slog / size), den = ssum / size;
+                double vote = NAN;
+                if (num / den > 0.8) {
+                    const double offset = fmax(fabs(mx - den), fabs(mn - den)) / den;        // floor_offset option fo = 1.0
+                    vote = fmin(fmax(10.0 * log10(den) - 100.0 + offset, -90.0), -20.0);
+                }
+                d.track_out[t] = vote;
+            }
+            __syncthreads();
+            continue;
+        }
+        double mv_post = 0.0;
+        if (MODE == 1) {
+            // variances of this frame: the first-stage gains still see the floor as the previous frame left it, the masking
+            // limits the one this frame's vote produced (set_parameters() runs between the two loops of process_frame())
+            const double mv_pre = d.mvseq[t]; mv_post = d.mvseq[t + 1];
+#pragma unroll
+            for (int e = 0; e < NBIN; ++e) inv_av[e] = 1.0 / fmax(mv_pre * rel[e], 1.0);
+        }
 #pragma unroll
         for (int e = 0; e < NBIN; ++e) {
             const double xr = (double)X[e].x, xi = (double)X[e].y;
@@ -532,6 +575,7 @@ k_afftdn(const float *__restrict__ in, float *__restrict__ out, int64_t n, Afftd
 #pragma unroll
             for (int e = 0; e < NBIN; ++e) {
                 if (!valid[e]) continue;
+                if (MODE == 1) { av[e] = fmax(mv_post * rel[e], 1.0); sqrt_av[e] = sqrt(av[e]); }
                 const double amt = band_amt[bband[e]];
                 double g = g1[e];
                 double b;
@@ -586,11 +630,23 @@ k_afftdn(const float *__restrict__ in, float *__restrict__ out, int64_t n, Afftd
     }
 }
 
-void launch_afftdn(const float *in, float *out, int64_t n, const AfftdnDev &d, int frames_per_chunk, int warm_frames, hipStream_t s)
+int64_t jt_afftdn_nframes(int64_t n, int A, int W) { return (n + A - 1) / A + (W - A) / A; }
+
+template <int LOG2N>
+static void launch_afftdn_n(unsigned grid, size_t smem, int mode, const float *in, float *out, int64_t n, const AfftdnDev &d, int frames_per_chunk,
+                            int warm_frames, int64_t nframes, hipStream_t s)
+{
+#define AF_GO(M) do { JT_HIP(hipFuncSetAttribute((const void *)k_afftdn<LOG2N, M>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem)); \
+        hipLaunchKernelGGL((k_afftdn<LOG2N, M>), dim3(grid), dim3(FT), smem, s, in, out, n, d, frames_per_chunk, warm_frames, nframes); } while (0)
+    if (mode == 1) AF_GO(1); else if (mode == 2) AF_GO(2); else AF_GO(0);
+#undef AF_GO
+}
+
+void launch_afftdn(const float *in, float *out, int64_t n, const AfftdnDev &d, int frames_per_chunk, int warm_frames, hipStream_t s, int mode)
 {
     if (n <= 0) return;
     JT_REQUIRE(d.nbands <= AF_MAXBANDS, JT_E_UNSUPPORTED, "afftdn: too many bark bands");
-    int64_t nframes = (n + d.A - 1) / d.A + (d.W - d.A) / d.A;
+    int64_t nframes = jt_afftdn_nframes(n, d.A, d.W);
     if (frames_per_chunk <= 0) {
         // one resident round of workgroups: the kernel's register footprint admits 2 workgroups per CU (256 CUs), so 512 chunks;
         // never shorter than 128 frames (warm-up overhead) nor longer than 1024
@@ -601,16 +657,8 @@ void launch_afftdn(const float *in, float *out, int64_t n, const AfftdnDev &d, i
     size_t smem = sizeof(float2) * 3 * H + sizeof(double) * (((d.W + 1) & ~1) + nseg * AF_MAXBANDS + (size_t)d.nbands * d.nbands + 4 * AF_MAXBANDS)
                 + sizeof(int) * (nseg + 1 + 2 * AF_MAXBANDS);
     JT_REQUIRE(smem <= 160 * 1024, JT_E_UNSUPPORTED, "afftdn: window too long for this build");
-    if (d.L == 2048) {
-        JT_HIP(hipFuncSetAttribute((const void *)k_afftdn<11>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-        hipLaunchKernelGGL(k_afftdn<11>, dim3(grid), dim3(FT), smem, s, in, out, n, d, frames_per_chunk, warm_frames, nframes);
-    } else if (d.L == 4096) {
-        JT_HIP(hipFuncSetAttribute((const void *)k_afftdn<12>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-        hipLaunchKernelGGL(k_afftdn<12>, dim3(grid), dim3(FT), smem, s, in, out, n, d, frames_per_chunk, warm_frames, nframes);
-    } else if (d.L == 1024) {
-        JT_HIP(hipFuncSetAttribute((const void *)k_afftdn<10>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-        hipLaunchKernelGGL(k_afftdn<10>, dim3(grid), dim3(FT), smem, s, in, out, n, d, frames_per_chunk, warm_frames, nframes);
-    } else {
-        throw JtError{JT_E_UNSUPPORTED, "afftdn: unsupported FFT length"};
-    }
+    if (d.L == 2048) launch_afftdn_n<11>(grid, smem, mode, in, out, n, d, frames_per_chunk, warm_frames, nframes, s);
+    else if (d.L == 4096) launch_afftdn_n<12>(grid, smem, mode, in, out, n, d, frames_per_chunk, warm_frames, nframes, s);
+    else if (d.L == 1024) launch_afftdn_n<10>(grid, smem, mode, in, out, n, d, frames_per_chunk, warm_frames, nframes, s);
+    else throw JtError{JT_E_UNSUPPORTED, "afftdn: unsupported FFT length"};
 }

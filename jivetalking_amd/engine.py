@@ -220,15 +220,17 @@ class Engine:
                                            C.c_int64(x.size), C.c_int(sr), C.c_double(s), C.c_double(p), C.c_double(r), C.c_double(m)))
         return y
 
-    def op_afftdn(self, x, sr, nr=12.0, nf=-50.0, band_noise=None):
+    def op_afftdn(self, x, sr, nr=12.0, nf=-50.0, band_noise=None, track=False, return_floor=False):
         x = np.ascontiguousarray(x, np.float32); y = np.empty_like(x)
         bn = None
         if band_noise is not None:
             arr = np.ascontiguousarray(band_noise, np.float64)
             bn = arr.ctypes.data_as(C.POINTER(C.c_double))
-        self._ck(self.lib.jt_op_afftdn_f32(self.h, x.ctypes.data_as(C.POINTER(C.c_float)), y.ctypes.data_as(C.POINTER(C.c_float)),
-                                           C.c_int64(x.size), C.c_int(sr), C.c_double(nr), C.c_double(nf), bn))
-        return y
+        fl = C.c_double(0.0)
+        self._ck(self.lib.jt_op_afftdn_tn_f32(self.h, x.ctypes.data_as(C.POINTER(C.c_float)), y.ctypes.data_as(C.POINTER(C.c_float)),
+                                              C.c_int64(x.size), C.c_int(sr), C.c_double(nr), C.c_double(nf), bn,
+                                              C.c_int(1 if track else 0), C.byref(fl)))
+        return (y, fl.value) if return_floor else y
 
     def op_dynamics(self, x, sr, params):
         x = np.ascontiguousarray(x, np.float32); y = np.empty_like(x)

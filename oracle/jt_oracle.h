@@ -59,6 +59,9 @@ void orc_anlmdn_f32(const float *in, float *out, int64_t n, int sample_rate,
 /* band_noise: 15 custom band values (dB) or NULL for white. */
 void orc_afftdn_f32(const float *in, float *out, int64_t n, int sample_rate,
                     double nr_db, double nf_db, const double *band_noise);
+/* the same with tn=1 (track_noise): the floor follows spectrally flat frames; floor_series (optional) = floor in dB after each frame */
+void orc_afftdn_tn_f32(const float *in, float *out, int64_t n, int sample_rate,
+                       double nr_db, double nf_db, const double *band_noise, int track, double *floor_series, int64_t cap);
 
 /* ---- agate / acompressor / deesser (dbl) ---- */
 typedef struct {

@@ -94,7 +94,8 @@ def anlmdn(x, sr, s=0.00001, p=0.006, r=0.002, m=3.0):
     return y
 
 
-def afftdn(x, sr, nr=12.0, nf=-50.0, band_noise=None):
+def afftdn(x, sr, nr=12.0, nf=-50.0, band_noise=None, track=False, return_floor=False):
+    """afftdn=nr:nf[:nt=custom:bn=...][:tn=1].  return_floor: also the noise floor (dB) after every frame."""
     x = np.ascontiguousarray(x, np.float32)
     y = np.zeros_like(x)
     bn = None
@@ -102,9 +103,12 @@ def afftdn(x, sr, nr=12.0, nf=-50.0, band_noise=None):
         bn_arr = np.ascontiguousarray(band_noise, np.float64)
         assert bn_arr.size == 15
         bn = _p(bn_arr, C.c_double)
-    lib().orc_afftdn_f32(_p(x, C.c_float), _p(y, C.c_float), C.c_int64(x.size), C.c_int(sr),
-                         C.c_double(nr), C.c_double(nf), bn)
-    return y
+    adv = sr // 80
+    nfr = (x.size + adv - 1) // adv + 2
+    fl = np.zeros(nfr, np.float64)
+    lib().orc_afftdn_tn_f32(_p(x, C.c_float), _p(y, C.c_float), C.c_int64(x.size), C.c_int(sr),
+                            C.c_double(nr), C.c_double(nf), bn, C.c_int(1 if track else 0), _p(fl, C.c_double), C.c_int64(nfr))
+    return (y, fl) if return_floor else y
 
 
 class GateParams(C.Structure):

@@ -333,7 +333,36 @@ static void afftdn_free(Afftdn *s)
 
 /* process_frame(): per-bin a-priori-SNR gain with decision-directed prior, bark-band masking
  * limit, gain_smooth=0.  ratio = adaptivity (0.5) except on the very first frame (1.0). */
-static void process_frame(Afftdn *s, float *re, float *im, int first)
+/* track_noise (tn=1, af_afftdn.c process_frame): after the first-stage gains, when the frame's magnitude spectrum is flat
+ * (geometric / arithmetic mean of the bins above s->floor > 0.8) the noise floor moves a tenth of the way to
+ *   clip(10 log10(mean) - 100 + floor_offset * max|S - mean| / mean, -90, -20)        (floor_offset option 'fo' = 1.0)
+ * and set_parameters() re-derives abs_var / min_abs_var (rel_var, the band shape, stays); the masking limits of the SAME frame
+ * already use the new variances.  The reference emits tn=1 whenever Noise.Floor == 0 (adaptive.go:147-151; the default golden chain
+ * filters_test.go:298-311 carries it), starting from afftdn's default nf = -50 dB. */
+static void track_noise_update(Afftdn *s)
+{
+    double num = 0., den = 0., mx = 0.; int size = 0;
+    for (int n = 0; n < s->bin_count; n++) {
+        const double v = s->noisy_data[n];
+        if (v > s->floor) { num += log(v); den += v; size++; }
+    }
+    if (size < 1) size = 1;
+    num /= size; den /= size; num = exp(num);
+    if (num / den > 0.8) {
+        for (int n = 0; n < s->bin_count; n++) { const double p = fabs(s->noisy_data[n] - den); if (p > mx) mx = p; }
+        const double offset = 1.0 * (mx / den);
+        double new_floor = 10.0 * log10(den) - 100.0 + offset;
+        new_floor = FFMIN(FFMAX(new_floor, -90.), -20.);       /* av_clipd = FFMIN(FFMAX(a, amin), amax): a NaN (silent frame) becomes -90 */
+        s->noise_floor = 0.1 * new_floor + s->noise_floor * 0.9;
+        s->max_var = s->floor * exp((100.0 + s->noise_floor) * C_LN);
+        for (int i = 0; i < s->bin_count; i++) {
+            s->abs_var[i] = fmax(s->max_var * s->rel_var[i], 1.0);
+            s->min_abs_var[i] = s->gain_scale * s->abs_var[i];
+        }
+    }
+}
+
+static void process_frame(Afftdn *s, float *re, float *im, int first, int track)
 {
     const double ratio = first ? 1.0 : 0.5, rratio = 1. - ratio;
     const int nb = s->number_of_bands;
@@ -349,6 +378,7 @@ static void process_frame(Afftdn *s, float *re, float *im, int first)
         s->clean_data[i] = power * sqr_new_gain;
         s->gain[i] = new_gain;
     }
+    if (track) track_noise_update(s);
     for (int i = 0; i < nb; i++) { s->band_excit[i] = 0.0; s->band_amt[i] = 0.0; }
     for (int i = 0; i < s->bin_count; i++) s->band_excit[s->bin2band[i]] += s->clean_data[i];
     for (int i = 0; i < nb; i++) {
@@ -373,8 +403,17 @@ static void process_frame(Afftdn *s, float *re, float *im, int first)
     }
 }
 
+void orc_afftdn_tn_f32(const float *in, float *out, int64_t n, int sample_rate,
+                       double nr_db, double nf_db, const double *band_noise, int track, double *floor_series, int64_t cap);
 void orc_afftdn_f32(const float *in, float *out, int64_t n, int sample_rate,
                     double nr_db, double nf_db, const double *band_noise)
+{
+    orc_afftdn_tn_f32(in, out, n, sample_rate, nr_db, nf_db, band_noise, 0, NULL, 0);
+}
+
+/* floor_series (optional): the noise floor in dB after every frame (cap entries) */
+void orc_afftdn_tn_f32(const float *in, float *out, int64_t n, int sample_rate,
+                       double nr_db, double nf_db, const double *band_noise, int track, double *floor_series, int64_t cap)
 {
     Afftdn s;
     afftdn_init(&s, sample_rate, nr_db, nf_db, band_noise);
@@ -392,7 +431,8 @@ void orc_afftdn_f32(const float *in, float *out, int64_t n, int sample_rate,
         }
         for (int m = W; m < L; m++) { re[m] = 0.f; im[m] = 0.f; }
         orc_fft_c2c_f32(re, im, L);
-        process_frame(&s, re, im, t == 0);
+        process_frame(&s, re, im, t == 0, track);
+        if (floor_series && t < cap) floor_series[t] = s.noise_floor;
         /* inverse real transform: rebuild the conjugate half, inverse FFT via conj trick */
         for (int k = 1; k < L / 2; k++) { re[L - k] = re[k]; im[L - k] = -im[k]; }
         im[0] = 0.f; im[L / 2] = 0.f;

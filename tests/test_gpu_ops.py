@@ -122,6 +122,25 @@ def test_afftdn_custom_profile(engine, oracle):
     assert np.max(np.abs(got - ref)) < 2e-5
 
 
+def test_afftdn_noise_tracking_tn1(engine, oracle):
+    """afftdn=nr=12:nt=w:tn=1 -- the chain the reference emits when Noise.Floor == 0 (adaptive.go:147-151; the default golden string
+    filters_test.go:298-311).  The floor follows spectrally flat frames; the kernel gets it from a first sweep of per-frame votes
+    and a host recurrence, so long stretches without a flat frame (speech) and signals shorter than a chunk are both covered."""
+    sr = SR
+    quiet = noise(sr * 3, 10 ** (-58 / 20), 21)
+    x = np.concatenate([quiet, speech(9.0, 22) + noise(sr * 9, 10 ** (-58 / 20), 23), quiet * 2.5, speech(4.0, 24)]).astype(np.float32)
+    ref, fl = oracle.afftdn(x, sr, 12.0, -50.0, track=True, return_floor=True)
+    got, last = engine.op_afftdn(x, sr, 12.0, -50.0, track=True, return_floor=True)
+    assert fl.min() < -52.0 and np.ptp(fl) > 3.0                     # the tracker moved the floor, and moved it back up
+    nfr = (x.size + sr // 80 - 1) // (sr // 80) + 2
+    assert abs(last - fl[nfr - 1]) < 1e-3, (last, fl[nfr - 1])        # same votes, same recurrence (f32 FFT schedules differ: 1e-3 dB)
+    assert np.max(np.abs(got - ref)) < 2e-5                          # the bar of the static-floor kernel
+    assert np.max(np.abs(got - oracle.afftdn(x, sr, 12.0, -50.0))) > 1e-4      # and it is not the static filter
+    for n in (1, 599, 600, 601, 1801, 7000):
+        y = noise(n, 3e-3, n)
+        assert np.max(np.abs(engine.op_afftdn(y, sr, 12.0, -50.0, track=True) - oracle.afftdn(y, sr, 12.0, -50.0, track=True))) < 2e-5
+
+
 # ---------------------------------------------------------------- dynamics chain
 def _dyn_oracle(oracle, x, p, sr=SR):
     y = x.astype(np.float64)

@@ -169,15 +169,16 @@ def test_error_codes_and_refusals():
         x = synth.speech_like(8.0, SR, seed=41)
         e.upload_pcm(x, SR, 1)
         p = default_filter_params()
-        p.fft_enabled = 1; p.fft_track_noise = 1                   # afftdn tn=1 is refused, never approximated
-        with pytest.raises(L.JtError) as ei:
-            e.pass2(p)
-        assert ei.value.code == L.JT_E_UNSUPPORTED
         with pytest.raises(L.JtError) as ei:                        # Pass 3 before any Pass-2 output exists
             e.pass3()
         assert ei.value.code == L.JT_E_STATE
-        # the context stays usable after a refused call
-        p.fft_track_noise = 0
+        p.lp_freq = 30000.0                                          # a corner above Nyquist: af_biquads does not configure (EINVAL)
+        with pytest.raises(L.JtError) as ei:
+            e.pass2(p)
+        assert ei.value.code == L.JT_E_INVAL
+        # the context stays usable after a refused call; the reference's default chain (afftdn tn=1, filters_test.go:298-311) runs
+        p.lp_freq = 20500.0
+        p.fft_enabled = 1; p.fft_track_noise = 1
         a = e.pass2(p)
         assert np.isfinite(a["r128"]["integrated"])
 
