@@ -55,6 +55,62 @@ def cpu_baseline(sample_seconds, sr):
             "reference_self_published": "~18 xRT/file (README.md:105-125, unknown CPU, 3 files in flight)"}
 
 
+def e2e_legs(eng, x_dev, n, sr, seconds, base, hostlogic, Engine, device):
+    """End-to-end legs, reported next to `value` and never part of it (`value` has the input resident in HBM):
+      pcie : pinned host f32 file -> H2D -> four passes -> D2H of the s16 output into pinned memory, per file
+      file : jt_process_file on a 16-bit FLAC in /dev/shm -> "<name>-LUFS-16-processed.flac" beside it (read, GPU decode, four
+             passes, GPU encode, write), with and without the STREAMINFO MD5 (one dependent chain on one host core), and a batch
+             of files through jt_process_files (MD5 on), where each worker's MD5 hides behind the other workers' GPU phases."""
+    import shutil
+    import tempfile
+    import numpy as np
+    import torch
+    out = {}
+    xh = x_dev.cpu().pin_memory()
+    xn = xh.numpy()
+    m_cap = int(-(-n * 147 // 160)) + 16
+    yh = torch.empty(m_cap, dtype=torch.int16).pin_memory(); yn = yh.numpy()
+    ts = []
+    for it in range(4):
+        t0 = time.perf_counter()
+        eng.upload_pcm(xn, sr, 1)
+        r = hostlogic.process_audio(eng, base, 4096)
+        got = eng.download_s16_into(4, yn)
+        ts.append(time.perf_counter() - t0)
+    ts = ts[1:]
+    out["pcie"] = {"ms_per_file": round(min(ts) * 1e3, 2), "xRT": round(seconds / min(ts), 1), "h2d_bytes": int(n * 4), "d2h_bytes": int(got * 2),
+                   "note": "pinned host buffers both ways; upload, four passes, download of the final s16, per file, nothing overlapped"}
+    d = tempfile.mkdtemp(prefix="jtbench", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
+    try:
+        pcm = (x_dev * 32768.0).round().clamp(-32768, 32767).to(torch.int16).cpu().numpy()
+        src = os.path.join(d, "episode.flac")
+        open(src, "wb").write(eng.op_flac_encode(pcm, sr, md5=True))
+        res = {}
+        for md5 in (False, True):
+            tt = []
+            for it in range(3):
+                t0 = time.perf_counter()
+                r, outp, io = hostlogic.process_file(eng, src, base, 4096, md5=md5)
+                tt.append(time.perf_counter() - t0)
+            res["md5" if md5 else "no_md5"] = {"ms_per_file": round(min(tt[1:]) * 1e3, 2), "xRT": round(seconds / min(tt[1:]), 1),
+                                               "io_ms": dict(zip(["read", "decode", "encode", "write"], [round(v, 2) for v in io]))}
+        nb = 6
+        paths = []
+        for k in range(nb):
+            pk = os.path.join(d, f"batch{k}.flac"); shutil.copyfile(src, pk); paths.append(pk)
+        t0 = time.perf_counter()
+        failed, fr = hostlogic.process_files(paths, device=device, in_flight=3, base=base, md5=True)
+        tb = time.perf_counter() - t0
+        res["batch_md5"] = {"files": nb, "in_flight": 3, "failed": int(failed), "ms_per_file": round(tb / nb * 1e3, 2), "xRT": round(nb * seconds / tb, 1),
+                            "note": "jt_process_files, first-file allocations of the three worker handles included"}
+        res["input"] = {"format": "FLAC 16-bit mono", "bytes": os.path.getsize(src), "location": d.split("/jtbench")[0]}
+        out["file"] = res
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
+    eng.attach_device_pcm(x_dev.data_ptr(), n, sr, 1, keepalive=x_dev)
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -64,6 +120,7 @@ def main():
     ap.add_argument("--cpu-sample", type=float, default=20.0, help="seconds of audio for the CPU oracle baseline (0 = skip)")
     ap.add_argument("--rate", type=int, default=48000, help="input sample rate (BASELINE configs[4]: 96000)")
     ap.add_argument("--channels", type=int, default=1, help="input channels, 1 or 2 (configs[4]: 2, down-mixed on the device)")
+    ap.add_argument("--e2e", type=int, default=1, help="also time the end-to-end legs outside `value` (PCIe-inclusive, file to file); 0 = skip")
     ap.add_argument("--in-flight", type=int, default=1,
                     help="extra measurement (not `value`): K files per GPU processed concurrently, one context + host thread each "
                          "(BASELINE configs[3], throughput saturation); reported as `saturation`")
@@ -117,7 +174,9 @@ def main():
         nlm_ms.append(t["nlm_ms"]); dk_ms.append(t["declick_ms"]); p_ms.append([t["pass1_ms"], t["pass2_ms"], t["pass3_ms"], t["pass4_ms"]])
     barrier()
     dt = time.perf_counter() - t0
+    dt_rank = dt
     dt = shard.max_over_ranks(dt, device=f"cuda:{local_rank}")
+    per_rank_ms = shard.gather_over_ranks(dt_rank / args.steps * 1e3, device=f"cuda:{local_rank}")
 
     sat = None
     if args.in_flight > 1:
@@ -163,9 +222,10 @@ def main():
             dk_bytes = 16 * m                                  # adeclick: read f64 + write f64 per 44.1 kHz sample
             roof = {"kernel": "k_adeclick", "bound": "hbm", "achieved": round(dk_bytes / dk_avg_s / 1e9, 2), "peak": 8000,
                     "unit": "GB/s", "frac": round(dk_bytes / dk_avg_s / 1e9 / 8000, 5), "traffic": None,
-                    "note": "dominant kernel this round; not bandwidth bound: every window is a set of strictly ordered f64 chains "
-                            "(af_adeclick.c's summation order is kept bit for bit) and the kernel is instruction-issue bound "
-                            "(10 waves per CU, ~60 k wave-instructions per window: profiles/r01_pmc_issue.txt, DESIGN.md s4/s9)",
+                    "note": "dominant kernel; not bandwidth bound: a window is an AR fit, a detector and a banded LDL^T solve whose pivots "
+                            "are a dependent chain (k_adeclick_fast: matrix-pipe autocorrelation, register-blocked detector, "
+                            "diagonal-major LDS ring; ~35 k wave-instructions per window, SIMDs ~25 % busy, the rest is LDS / "
+                            "dependent-issue latency at 10 waves per CU: profiles/r02_pmc_issue.txt, DESIGN.md s4/s9)",
                     "avg_launch_ms": round(dk_avg_s * 1e3, 3), "repaired_samples": int(eng.timers()["declick_repaired"]),
                     "heavy_windows": int(eng.timers()["declick_heavy_windows"])}
         else:
@@ -173,19 +233,21 @@ def main():
         # HBM traffic per launch from the committed PMC passes (profiles/r01_pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE and
         # --pmc WRITE_SIZE in separate runs of this same command); FETCH_SIZE doubled per MI355X_MICROARCH.md's gfx950 note
         try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))["kernels"]
+            pmc_file = "r02_pmc_traffic.json" if os.path.exists(os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")) else "r01_pmc_traffic.json"
+            pmc = json.load(open(os.path.join(ROOT, "profiles", pmc_file)))["kernels"]
             for r_ in (roof, nlm_roof):
                 # a kernel launched as several template instances per step (adeclick's three capacity levels) is summed
-                ks = [v for k, v in pmc.items() if k == r_["kernel"] or k.startswith(r_["kernel"] + "<")] if r_ else []
+                ks = [v for k, v in pmc.items() if k == r_["kernel"] or k.startswith(r_["kernel"] + "<") or k.startswith(r_["kernel"] + "_fast<")] if r_ else []
                 if ks:
                     r_["traffic"] = int(sum(2 * k_["FETCH_SIZE_KB_max_call"] + k_["WRITE_SIZE_KB_max_call"] for k_ in ks) * 1024)
-                    r_["traffic_source"] = "profiles/r01_pmc_traffic.json (PMC pass of this command, not collected live)"
+                    r_["traffic_source"] = "profiles/" + pmc_file + " (PMC pass of this command, not collected live)"
         except (OSError, KeyError, ValueError):
             pass
         out = {
             "metric": "realtime factor (xRT) on 48 kHz mono speech, 1/2/4/8 GPUs; LUFS error vs ref",
             "value": round(value, 1), "unit": "xRT", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": round(dt / args.steps * 1e3, 3), "per_rank_ms_per_step": [round(v, 3) for v in per_rank_ms],
+            "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32/f64", "data": "synthetic",
             "config": {"workload": f"1 x {args.minutes:g} min {sr / 1000:g} kHz {'stereo' if args.channels == 2 else 'mono'} f32 PCM per GPU, full 4-pass pipeline, input resident in HBM",
                        "files_per_gpu_per_step": 1, "adeclick": "on (t=1.7 w=55 o=50 m=s, the reference default)",
@@ -223,6 +285,8 @@ def main():
                                 "note": "jt_load_audio of that image (44.1 kHz mono s16): H2D from pageable memory, find + parse + "
                                         "decode + finish kernels, host chain walk"},
             }
+        if world == 1 and args.e2e and args.channels == 1:
+            out["e2e"] = e2e_legs(eng, x, n, sr, seconds, base, hostlogic, Engine, local_rank)
         if world == 1 and args.cpu_sample > 0:
             out["cpu_baseline"] = cpu_baseline(args.cpu_sample, sr)
         print(json.dumps(out))

@@ -213,6 +213,14 @@ typedef struct {
 int jt_process_files(int device, const char *const *paths, int n_files, int in_flight, const jt_host_config *base,
                      int frame_samples, int flac_flags, jt_file_result *results);
 
+/* The same over several GPUs of the node (BASELINE configs[2] / configs[3]: files shard across the 8 x MI355X, no data-path
+ * collective): ONE shared queue, n_devices x in_flight_per_device workers, longest file first.  A device id may repeat in
+ * `devices` (two worker sets on one GPU).  device_of_file[i] (optional) receives the device that served paths[i].  This is the
+ * in-process alternative to one process per GPU (bench.py / torchrun, jivetalking_amd/shard.py): same sharding unit, but the
+ * queue is dynamic, so uneven file lengths do not leave a GPU idle. */
+int jt_process_files_multi(const int *devices, int n_devices, const char *const *paths, int n_files, int in_flight_per_device,
+                           const jt_host_config *base, int frame_samples, int flac_flags, jt_file_result *results, int *device_of_file);
+
 /* ---- granular detector steps (the reference table-tests each of these: analyser_vad_test.go) ---- */
 int    jt_host_vad_detect(const jt_interval *iv, int64_t n, double noise_floor_seed, jt_measurements *out);      /* detectVoiceActivity :728 */
 void   jt_host_vad_split(const jt_interval *iv, int64_t n, double seed, double *otsu_raw, double *split, double *floor_, double *margin, int *tol);

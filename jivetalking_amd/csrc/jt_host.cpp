@@ -1340,25 +1340,34 @@ extern "C" int jt_process_file(jt_ctx *h, const char *input_path, const jt_host_
     return JT_OK;
 }
 
-// ---------------------------------------------------------------- several files in flight on one GPU (pool.go:122-228)
-extern "C" int jt_process_files(int device, const char *const *paths, int n_files, int in_flight, const jt_host_config *base,
-                                int frame_samples, int flac_flags, jt_file_result *results)
+// ---------------------------------------------------------------- several files in flight on one or more GPUs (pool.go:122-228)
+// One shared queue, (devices x in_flight) workers: a worker is a host thread with a handle of its own on its device and takes
+// the next unclaimed file when it finishes one -- the reference's runBoundedPool semantics (a bounded number of ProcessAudio calls
+// at a time, a file's failure never stops the others), with the GPU as the bounded resource.  Files are handed out longest first
+// when their sizes are known (the on-disk size is the proxy), so the tail of the batch is made of short files.
+extern "C" int jt_process_files_multi(const int *devices, int n_devices, const char *const *paths, int n_files, int in_flight_per_device,
+                                      const jt_host_config *base, int frame_samples, int flac_flags, jt_file_result *results, int *device_of_file)
 {
-    if (!paths || !results || n_files < 0 || in_flight < 1) return JT_E_INVAL;
-    for (int i = 0; i < n_files; ++i) { std::memset(&results[i], 0, sizeof results[i]); results[i].rc = JT_E_STATE; }
+    if (!devices || n_devices < 1 || !paths || !results || n_files < 0 || in_flight_per_device < 1) return JT_E_INVAL;
+    for (int i = 0; i < n_files; ++i) { std::memset(&results[i], 0, sizeof results[i]); results[i].rc = JT_E_STATE; if (device_of_file) device_of_file[i] = -1; }
     if (n_files == 0) return 0;
-    const int workers = std::min(in_flight, n_files);
+    // longest first (LPT): order[] is the queue
+    std::vector<int> order((size_t)n_files); std::vector<long long> size((size_t)n_files, 0);
+    for (int i = 0; i < n_files; ++i) { order[(size_t)i] = i; struct stat st; if (paths[i] && stat(paths[i], &st) == 0) size[(size_t)i] = (long long)st.st_size; }
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return size[(size_t)a] > size[(size_t)b]; });
     std::atomic<int> next{0}, failed{0};
     auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
-    auto worker = [&]() {
+    auto worker = [&](int device) {
         jt_ctx *h = nullptr;
         const int orc = jt_open(device, &h);
         for (;;) {
-            const int i = next.fetch_add(1);
-            if (i >= n_files) break;
+            const int q = next.fetch_add(1);
+            if (q >= n_files) break;
+            const int i = order[(size_t)q];
             jt_file_result &r = results[i];
+            if (device_of_file) device_of_file[i] = device;
             const double t0 = now();
-            if (orc != JT_OK || !h) { r.rc = orc != JT_OK ? orc : JT_E_NOGPU; snprintf(r.error, sizeof r.error, "jt_open failed (%d)", r.rc); }
+            if (orc != JT_OK || !h) { r.rc = orc != JT_OK ? orc : JT_E_NOGPU; snprintf(r.error, sizeof r.error, "jt_open(%d) failed (%d)", device, r.rc); }
             else if (!paths[i]) { r.rc = JT_E_INVAL; snprintf(r.error, sizeof r.error, "null path"); }
             else {
                 r.rc = jt_process_file(h, paths[i], base, frame_samples, flac_flags, nullptr, nullptr, &r.result, r.output_path,
@@ -1370,9 +1379,19 @@ extern "C" int jt_process_files(int device, const char *const *paths, int n_file
         }
         if (h) jt_close(h);
     };
+    const int want = n_devices * in_flight_per_device;
+    const int workers = std::min(want, n_files);
     std::vector<std::thread> th;
-    for (int k = 1; k < workers; ++k) th.emplace_back(worker);
-    worker();
+    // worker w serves device w % n_devices: with fewer files than workers every device still gets one before any gets two
+    for (int w = 1; w < workers; ++w) th.emplace_back(worker, devices[w % n_devices]);
+    worker(devices[0]);
     for (auto &t : th) t.join();
     return failed.load();
+}
+
+extern "C" int jt_process_files(int device, const char *const *paths, int n_files, int in_flight, const jt_host_config *base,
+                                int frame_samples, int flac_flags, jt_file_result *results)
+{
+    if (in_flight < 1) return JT_E_INVAL;
+    return jt_process_files_multi(&device, 1, paths, n_files, in_flight, base, frame_samples, flac_flags, results, nullptr);
 }

@@ -185,6 +185,12 @@ class Engine:
         self._ck(self.lib.jt_download_s16(self.h, C.c_int(stage), out.ctypes.data_as(C.POINTER(C.c_int16)), C.c_int64(out.size), C.byref(n)))
         return out
 
+    def download_s16_into(self, stage, out):
+        """jt_download_s16 into a caller buffer (e.g. pinned memory); returns the sample count."""
+        n = C.c_int64()
+        self._ck(self.lib.jt_download_s16(self.h, C.c_int(stage), out.ctypes.data_as(C.POINTER(C.c_int16)), C.c_int64(out.size), C.byref(n)))
+        return n.value
+
     def flac_encode(self, stage, md5=True, return_info=False):
         """The stage output as a finished .flac file image (bytes), encoded on the GPU (include/jtgpu.h: jt_flac_encode)."""
         data = C.POINTER(C.c_uint8)(); n = C.c_int64(); info = L.FlacInfo()

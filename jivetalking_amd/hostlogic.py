@@ -114,7 +114,7 @@ HOST_SYMBOLS = ["jt_host_build_intervals", "jt_host_detect", "jt_host_finish_mea
                 "jt_host_vad_gap_tolerance", "jt_host_vad_gate_stats", "jt_host_vad_noise_seed",
                 "jt_host_vad_pick_low_cluster", "jt_host_vad_floored_fraction", "jt_host_sizeof",
                 "jt_host_lufs_filename_value", "jt_host_output_path", "jt_process_audio_cb", "jt_process_file", "jt_process_files",
-                "jt_host_test_inject_fault"]
+                "jt_host_test_inject_fault", "jt_process_files_multi"]
 
 
 def lib():
@@ -233,6 +233,21 @@ def process_files(paths, device=0, in_flight=2, base=None, frame_samples=4096, m
     if failed < 0:
         raise L.JtError(failed, "jt_process_files: bad arguments")
     return failed, res
+
+
+def process_files_multi(paths, devices=(0,), in_flight_per_device=2, base=None, frame_samples=4096, md5=True):
+    """jt_process_files_multi: one shared queue over several GPUs.  Returns (failed, results, device_of_file)."""
+    l = lib()
+    base = base or default_config()
+    n = len(paths)
+    arr = (C.c_char_p * n)(*[str(p).encode() for p in paths])
+    res = (FileResult * n)(); dev = (C.c_int * n)()
+    dv = (C.c_int * len(devices))(*devices)
+    failed = l.jt_process_files_multi(dv, C.c_int(len(devices)), arr, C.c_int(n), C.c_int(in_flight_per_device), C.byref(base),
+                                      C.c_int(frame_samples), C.c_int(1 if md5 else 0), res, dev)
+    if failed < 0:
+        raise L.JtError(failed, "jt_process_files_multi: bad arguments")
+    return failed, res, list(dev)
 
 
 SIZEOF_IDS[14] = FileResult

@@ -3,6 +3,7 @@ decoder.  FLAC is lossless, so the bar is bit-exact PCM after decode, every head
 that describes the stream truthfully (rate, channels, depth, total samples, min/max frame size, MD5 of the PCM) with the
 reference's fixed 4096-sample blocks (encoder.go:93-100)."""
 import hashlib
+import os
 
 import numpy as np
 import pytest
@@ -383,3 +384,32 @@ def test_process_files_pool_semantics(tmp_path, oracle):
         assert res[i].rc == 0 and res[i].result.output_lufs == want[j][0]
         assert open(res[i].output_path.decode(), "rb").read() == want[j][1]
         assert res[i].wall_ms > 0
+
+
+def test_process_files_multi_shared_queue(tmp_path, oracle):
+    """jt_process_files_multi over devices = {0, 0} (the only topology a one-GPU box offers): one shared queue, both worker sets get
+    work, every file has its own result identical to the single-file path, longest file first, failures isolated."""
+    from jivetalking_amd import hostlogic
+    sr = 48000
+    paths = []
+    for k, seconds in enumerate((12.0, 7.5, 15.0, 9.0, 13.0)):
+        x = np.asarray(synth.speech_like(seconds, sr, seed=41 + k), np.float64)
+        pcm = np.clip(np.rint(x * 32768), -32768, 32767).astype(np.int16)
+        p = tmp_path / f"multi{k}.wav"
+        p.write_bytes(_wav(1, 16, 1, sr, pcm.astype("<i2").tobytes(), extra_chunks=False))
+        paths.append(p)
+    e = Engine()
+    try:
+        want = [hostlogic.process_file(e, p)[0].output_lufs for p in paths]
+    finally:
+        e.close()
+    for p in tmp_path.glob("*-processed.flac"):
+        p.unlink()
+    failed, res, dev = hostlogic.process_files_multi(paths + [tmp_path / "absent.wav"], devices=(0, 0), in_flight_per_device=1)
+    assert failed == 1 and res[5].rc == L.JT_E_INVAL
+    assert all(d == 0 for d in dev)
+    for k in range(5):
+        assert res[k].rc == 0 and res[k].result.output_lufs == want[k] and os.path.exists(res[k].output_path.decode())
+    assert not list(tmp_path.glob(".processing-*"))
+    with pytest.raises(L.JtError):
+        hostlogic.process_files_multi(paths, devices=(), in_flight_per_device=1)
