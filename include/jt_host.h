@@ -166,7 +166,7 @@ int jt_process_audio(jt_ctx *h, const jt_host_config *base, int frame_samples, j
  * lifecycle points the reference emits (processor.go:80-158, normalise.go:737-772): pass start (progress 0) and pass end
  * (progress 1) of Analysing / Processing / Measuring / Normalising.  Pointers are valid only during the call:
  *   measurements : Pass-1 end, Pass-2 start and end;   config + diag : Pass-2 start only;   limiter_* : Pass-4 start only.
- * Intra-pass ticks (every 100 decoder frames in the reference) do not exist here: a pass is a few milliseconds. */
+ * Intra-pass ticks (every 100 decoder frames in the reference) are not sent by this entry point; jt_process_audio_ticks replays them. */
 typedef struct {
     int pass;                      /* 1 Analysing, 2 Processing, 3 Measuring, 4 Normalising (filters.go:340-345) */
     const char *pass_name;
@@ -178,7 +178,34 @@ typedef struct {
 } jt_progress_update;
 typedef void (*jt_progress_fn)(void *user, const jt_progress_update *u);
 int jt_process_audio_cb(jt_ctx *h, const jt_host_config *base, int frame_samples, jt_progress_fn cb, void *user, jt_process_result *out);
+/* The same plus the reference's intra-pass ticks: every 100th decoder frame of each pass (analyser.go:602-618, processor.go:320-335,
+ * normalise.go:292-301,1108-1117) with Progress computed as the reference computes it (Pass 1 scaled by BandPhaseProgressStart =
+ * 0.95, Passes 3/4 by samples and capped at 0.99) and Level = calculateFrameLevel (encoder.go:235-257) of the frame at that
+ * position, and the 17 "Analysing frequency bands" ticks on 0.95 .. 1.0 (analyser_band_runner.go:47-88).  A pass is one launch
+ * sequence on the GPU, so the ticks of a pass arrive together when it completes, before its end event. */
+int jt_process_audio_ticks(jt_ctx *h, const jt_host_config *base, int frame_samples, jt_progress_fn cb, void *user, jt_process_result *out);
+#define JT_FILE_PROGRESS_TICKS 0x100   /* jt_process_file flag (next to JT_FLAC_MD5): progress as jt_process_audio_ticks */
 int jt_analyse_only(jt_ctx *h, const jt_host_config *base, int frame_samples, jt_process_result *out);   /* AnalyseOnlyDetailed (processor.go:29-69) */
+
+/* ---- run record: the reference's per-file JSON document and its two sidecars (runrecord.go:15-51,
+ * runrecord_write.go:37-45), built from a jt_process_result exactly as MarshalRunRecord prints them: a sanitised map tree (NaN / Inf
+ * -> null, omitempty, embedded structs promoted, *_s seconds for durations), keys sorted at every level, two-space indent,
+ * encoding/json's number and string formats.  Every call returns the length of the full text (excluding the NUL) and writes at most
+ * cap - 1 bytes + NUL: call with cap = 0 to size the buffer.  `h` supplies the interval series of the handle's last Pass-1 analysis
+ * (interval_summary, .intervals.jsonl). */
+typedef struct {
+    const char *input_file;      /* filepath.Base(result.OutputPath) (analysis-only: the input's base name) */
+    const char *version;         /* RunVersion */
+    const char *executable;      /* resolveExecutablePath() */
+    const char *processed_at;    /* time.Now().Format(time.RFC3339) */
+    double duration_s;           /* InputMetadata.DurationSecs (<= 0: the measured duration) */
+    int sample_rate_hz, channels;
+} jt_run_provenance;
+int64_t jt_host_run_record_json(const jt_ctx *h, const jt_process_result *res, const jt_run_provenance *prov, int analysis_only, char *buf, int64_t cap);
+int64_t jt_host_intervals_jsonl(const jt_ctx *h, char *buf, int64_t cap);                        /* WriteIntervalsSidecar */
+int64_t jt_host_candidates_jsonl(const jt_process_result *res, char *buf, int64_t cap);          /* WriteCandidatesSidecar */
+/* loudnorm's print_format=json body (the text parseLoudnormStatsFile reads, normalise.go:143-165): ten "%.2f" string fields */
+int     jt_host_loudnorm_json(const jt_loudnorm_stats *stats, char *buf, int cap);
 
 /* File in, file out — the reference's per-file entry point as the CLI calls it: ProcessAudio(ctx, inputPath, config, cb)
  * (processor.go:78-330) reads inputPath through libavformat for every pass, writes a temp FLAC after Pass 2 and the final
@@ -231,6 +258,15 @@ void   jt_host_vad_gate_stats(const jt_interval *iv, int64_t n, double split, co
 int    jt_host_vad_noise_seed(const jt_interval *iv, int64_t n, double *noise_floor, double *threshold);           /* estimateNoiseFloorAndThreshold */
 int    jt_host_vad_pick_low_cluster(const jt_interval *iv, int64_t n, double split, jt_region *out);               /* pickLowClusterRegion :630 */
 double jt_host_vad_floored_fraction(const jt_interval *iv, int64_t n);                                             /* flooredFraction :708 */
+
+/* speech election steps (the reference table-tests them: analyser_candidates_speech_test.go) */
+double jt_host_score_speech_candidate(double rms_level, int64_t duration_ns, double noise_floor_db, double level_var);   /* scoreSpeechCandidateGrounded :326 */
+double jt_host_level_variance(const jt_interval *iv, int64_t n, int axis /* 0 momentary LUFS, 1 RMS */);                   /* levelVariance, _shared.go:301 */
+/* findBestSpeechRegion (:216): returns the number of candidates written (<= cap) and the elected region, or -1 when nothing is elected */
+int    jt_host_find_best_speech_region(const jt_region *regions, int n_regions, const jt_interval *iv, int64_t n_iv,
+                                       int has_noise_profile, double noise_floor_db, jt_region *best, jt_speech_candidate *cands, int cap);
+/* calculateFrameLevel (encoder.go:235-257): VU level of one s16 frame for ProgressUpdate.Level, dB clamped to [-70, 0] */
+double jt_host_frame_level_s16(const int16_t *pcm, int n);
 
 /* sizeof() of the ABI structs, for binding self-checks (0 interval, 1 measurements, 2 host_config, 3 process_result, ...) */
 int64_t jt_host_sizeof(int which);

@@ -237,6 +237,10 @@ int jt_op_decode_audio(jt_ctx *h, const uint8_t *file, int64_t len, int32_t *pcm
 int jt_output_len(jt_ctx *h, int stage, int64_t *n);
 int jt_download_s16(jt_ctx *h, int stage, int16_t *dst, int64_t cap, int64_t *n);
 
+/* calculateFrameLevel (encoder.go:235-257) for every frame_samples-long frame of a stage output: 20 log10(rms), clamped to the VU
+ * meter's [-70, 0] dB -- the Level the reference's progress ticks carry (processor.go:336-338, normalise.go:288,1119-1121). */
+int jt_output_frame_levels(jt_ctx *h, int stage, int frame_samples, double *levels_db, int64_t cap, int64_t *n_frames);
+
 /* ---- FLAC output leg: replaces createOutputEncoder + Encoder.WriteFrame/Flush/Close (encoder.go:54-110,145-215): the
  * reference hands every 4096-sample s16 frame to FFmpeg's flac encoder (compression_level 5) and muxes a .flac file.  Here
  * the stage output already in HBM is encoded on the GPU, one frame per wavefront, and the finished file image (fLaC marker,

@@ -119,7 +119,7 @@ SYMBOLS = [
     "jt_open", "jt_close", "jt_last_error", "jt_version", "jt_cancel", "jt_reset_cancel", "jt_set_source_format",
     "jt_upload_pcm", "jt_attach_device_pcm", "jt_upload_s16", "jt_load_audio", "jt_op_decode_audio",
     "jt_pass1", "jt_band_rms", "jt_pass2", "jt_pass2_prefetch", "jt_pass2_prefetch_after_pass1", "jt_region_measure", "jt_region_measure_pair", "jt_region_prefetch", "jt_pass3", "jt_pass4",
-    "jt_output_len", "jt_download_s16", "jt_flac_encode", "jt_op_flac_encode_s16", "jt_get_timers",
+    "jt_output_len", "jt_download_s16", "jt_output_frame_levels", "jt_flac_encode", "jt_op_flac_encode_s16", "jt_get_timers",
     "jt_op_biquad_f32", "jt_op_anlmdn_f32", "jt_op_afftdn_f32", "jt_op_afftdn_tn_f32", "jt_op_dynamics", "jt_op_alimiter_f64", "jt_op_adeclick_f64",
     "jt_op_resample_f32_to_s16", "jt_op_ebur128", "jt_op_astats", "jt_op_aspectralstats",
     "jt_op_loudnorm_measure_s16",

@@ -1063,6 +1063,33 @@ extern "C" int jt_download_s16(jt_ctx *h, int stage, int16_t *dst, int64_t cap, 
     JT_API_END(h)
 }
 
+// calculateFrameLevel (encoder.go:235-257) of every frame of a stage output: what the reference's OnFrame callbacks feed the VU
+// meter with (processor.go:336-338, normalise.go:288,1119-1121)
+extern "C" int jt_output_frame_levels(jt_ctx *h, int stage, int frame_samples, double *levels_db, int64_t cap, int64_t *n_frames)
+{
+    JT_API_BEGIN(h)
+    const int16_t *src = stage == 2 ? h->s16_p2.p : (stage == 4 ? h->s16_p4.p : nullptr);
+    const int64_t m = stage == 2 ? h->m_p2 : (stage == 4 ? h->m_p4 : 0);
+    JT_REQUIRE(src && m > 0, JT_E_STATE, "frame_levels: stage output not on device");
+    JT_REQUIRE(frame_samples > 0 && (levels_db || cap == 0), JT_E_INVAL, "frame_levels: bad arguments");
+    const int64_t nfr = (m + frame_samples - 1) / frame_samples;
+    if (n_frames) *n_frames = nfr;
+    const int64_t c = std::min(nfr, cap);
+    if (c > 0) {
+        DevBuf<double> d; d.ensure((size_t)nfr);
+        launch_frame_sumsq_s16(src, m, frame_samples, d.p, nfr, h->stream);
+        std::vector<double> ss((size_t)nfr);
+        JT_HIP(hipMemcpyAsync(ss.data(), d.p, sizeof(double) * nfr, hipMemcpyDeviceToHost, h->stream));
+        JT_HIP(hipStreamSynchronize(h->stream));
+        for (int64_t f = 0; f < c; ++f) {
+            const int64_t cnt = std::min<int64_t>(frame_samples, m - f * frame_samples);
+            const double rms = std::sqrt(ss[(size_t)f] / (double)cnt);
+            levels_db[f] = rms < 0.00001 ? -70.0 : std::max(-70.0, std::min(0.0, 20.0 * std::log10(rms)));
+        }
+    }
+    JT_API_END(h)
+}
+
 extern "C" int jt_get_timers(jt_ctx *h, jt_timers *out)
 {
     if (!h || !out) return JT_E_INVAL;

@@ -994,8 +994,37 @@ extern "C" int jt_host_pass4_spec(const jt_host_config *cfg, const jt_loudnorm_s
 // =====================================================================================================
 static double secs_of(int64_t ns) { return qfmt("%f", (double)ns / 1e9); }    // regions travel through "%f"-formatted filter options
 
+// Replay of the reference's intra-pass progress ticks (every 100th decoder frame: analyser.go:602-618, processor.go:320-335,
+// normalise.go:292-301,1108-1117; 17 band ticks: analyser_band_runner.go:47-88).  A pass is one launch sequence here, so the ticks
+// of a pass are emitted together when it completes, with the values the reference would have sent: progress from the frame count,
+// Level = calculateFrameLevel of the frame at that position.
+struct TickSink {
+    jt_progress_fn cb = nullptr; void *user = nullptr; bool ticks = false; double duration = 0;
+    void tick(int pass, const char *name, double progress, double level, const jt_measurements *ms = nullptr) const
+    {
+        if (!cb || !ticks) return;
+        jt_progress_update u; std::memset(&u, 0, sizeof(u));
+        u.pass = pass; u.pass_name = name; u.progress = progress; u.level = level; u.duration = duration; u.measurements = ms;
+        cb(user, &u);
+    }
+};
+static double level_from_sumsq(double sumsq, double count)
+{
+    if (count <= 0) return -70.0;
+    const double rms = std::sqrt(sumsq / count);
+    if (rms < 0.00001) return -70.0;
+    return std::max(-70.0, std::min(0.0, 20.0 * std::log10(rms)));
+}
+static double bandPhaseProgress(int completed, int total)       // analyser_band_runner.go:72-84
+{
+    if (total <= 0) return 0.95;
+    if (completed < 0) completed = 0;
+    const double p = 0.95 + (1.0 - 0.95) * ((double)completed / (double)total);
+    return p > 1.0 ? 1.0 : p;
+}
+
 static int analyse_core(jt_ctx *h, const jt_host_config *base, int frame_samples, jt_process_result *out,
-                        jt_host_config *eff_out, bool pass2_follows)
+                        jt_host_config *eff_out, bool pass2_follows, const TickSink *tk = nullptr)
 {
     int rc;
     jt_analysis a1; std::memset(&a1, 0, sizeof(a1));
@@ -1019,10 +1048,18 @@ static int analyse_core(jt_ctx *h, const jt_host_config *base, int frame_samples
     if ((rc = jt_pass1(h, frame_samples, &a1, fss.data(), fpk.data(), nfr, meta.data(), cap_meta)) != JT_OK) return rc;
     out->pass_ms[0] = h->timers.pass1_ms;
     out->stage_ms[0] = now_ms() - t0; t0 = now_ms();
+    if (tk && tk->ticks) {
+        const double est = ((double)n / sr) * sr / 4096.0;                    // estimatedTotalFrames (analyser.go:560-566)
+        for (int64_t fc = 0; fc < nfr && est > 0; fc += 100) {
+            const int64_t cnt = std::min<int64_t>((int64_t)frame_samples * h->channels, (n - fc * frame_samples) * h->channels);
+            tk->tick(1, "Analysing", std::min(0.95, (double)fc / est * 0.95), level_from_sumsq(fss[(size_t)fc], (double)cnt));
+        }
+    }
     std::vector<jt_interval> iv((size_t)(n / (sr / 5) + 16));
     int64_t niv = jt_host_build_intervals(sr, n, frame_samples, h->channels, fss.data(), fpk.data(), nfr, meta.data(), a1.n_frames_meta, 1,
                                           iv.data(), (int64_t)iv.size());
     if (niv > (int64_t)iv.size()) niv = (int64_t)iv.size();
+    h->last_intervals.assign(iv.begin(), iv.begin() + niv);
     jt_measurements &m = out->input;
     if ((rc = jt_host_detect(&a1, iv.data(), niv, (double)n / sr, base->target_i, 1, &m)) != JT_OK) return rc;
     out->stage_ms[1] = now_ms() - t0; t0 = now_ms();
@@ -1036,6 +1073,7 @@ static int analyse_core(jt_ctx *h, const jt_host_config *base, int frame_samples
             m.speech_profile.bands_measured = (ok[0] && ok[1]) ? 1 : 0;
         }
     }
+    if (tk) for (int b = 1; b <= 2; ++b) tk->tick(1, "Analysing frequency bands", bandPhaseProgress(b, 17), 0.0);
     // measureNoiseBands (analyser_noise_bands.go:65-119)
     if (m.has_noise_profile && m.noise_profile.duration_ns > 0) {
         double lo[15], hi[15], db[15]; int ok[15];
@@ -1047,6 +1085,7 @@ static int analyse_core(jt_ctx *h, const jt_host_config *base, int frame_samples
             m.noise_profile.band_noise_n = 15; m.noise_profile.bands_measured = finite >= 10 ? 1 : 0;
         }
     }
+    if (tk) for (int b = 3; b <= 17; ++b) tk->tick(1, "Analysing frequency bands", bandPhaseProgress(b, 17), 0.0);
     out->stage_ms[2] = now_ms() - t0; t0 = now_ms();
     jt_host_finish_measurements(&m);
     jt_host_adapt(base, &m, eff_out, &out->diag);
@@ -1083,9 +1122,19 @@ extern "C" int jt_host_output_path(const char *input_path, int lufs_value, char 
     return (int)r.size();
 }
 
-extern "C" int jt_process_audio_cb(jt_ctx *h, const jt_host_config *base, int frame_samples, jt_progress_fn cb, void *user, jt_process_result *out)
+static int process_audio_impl(jt_ctx *h, const jt_host_config *base, int frame_samples, jt_progress_fn cb, void *user, jt_process_result *out, bool ticks)
 {
     if (!h || !base || !out) return JT_E_INVAL;
+    TickSink tk; tk.cb = cb; tk.user = user; tk.ticks = ticks && cb; tk.duration = h->sr > 0 ? (double)h->n / h->sr : 0.0;
+    // calculateFrameLevel of the frames of a stage output, for the ticks of Passes 2-4
+    auto stage_levels = [&](int stage, std::vector<double> *lv) {
+        lv->clear();
+        if (!tk.ticks) return;
+        int64_t nf = 0;
+        if (jt_output_frame_levels(h, stage, 4096, nullptr, 0, &nf) != JT_OK || nf <= 0) return;
+        lv->resize((size_t)nf);
+        if (jt_output_frame_levels(h, stage, 4096, lv->data(), nf, &nf) != JT_OK) lv->clear();
+    };
     std::memset(out, 0, sizeof(*out));
     auto emit = [&](int pass, const char *name, double progress, double duration, const jt_measurements *ms, const jt_host_config *cfg,
                     const jt_adaptive_diag *dg, const jt_limiter_decision *lim) {
@@ -1097,7 +1146,7 @@ extern "C" int jt_process_audio_cb(jt_ctx *h, const jt_host_config *base, int fr
     };
     int rc; jt_host_config eff;
     emit(1, "Analysing", 0.0, 0.0, nullptr, nullptr, nullptr, nullptr);
-    if ((rc = analyse_core(h, base, frame_samples, out, &eff, true)) != JT_OK) return rc;
+    if ((rc = analyse_core(h, base, frame_samples, out, &eff, true, &tk)) != JT_OK) return rc;
     jt_measurements &m = out->input;
     const double dur = m.duration_s;
     emit(1, "Analysing", 1.0, dur, &m, nullptr, nullptr, nullptr);
@@ -1115,6 +1164,17 @@ extern "C" int jt_process_audio_cb(jt_ctx *h, const jt_host_config *base, int fr
     if ((rc = jt_pass2(h, &fp, &out->filtered)) != JT_OK) return rc;
     out->pass_ms[1] = h->timers.pass2_ms;
     out->stage_ms[4] = now_ms() - t0; t0 = now_ms();
+    std::vector<double> lv2;
+    stage_levels(2, &lv2);
+    if (tk.ticks && !lv2.empty()) {
+        // every 100th INPUT frame; Level = the filtered frame the sink had delivered by then (processor.go:320-338)
+        const int64_t nfr_in = (h->n + frame_samples - 1) / frame_samples;
+        const double est = ((double)h->n / h->sr) * h->sr / 4096.0;
+        for (int64_t fc = 100; fc <= nfr_in && est > 0; fc += 100) {
+            const size_t oi = (size_t)std::min<int64_t>((int64_t)lv2.size() - 1, fc * (int64_t)lv2.size() / std::max<int64_t>(1, nfr_in));
+            tk.tick(2, "Processing", std::min(1.0, (double)fc / est), lv2[oi], &m);
+        }
+    }
     emit(2, "Processing", 1.0, dur, &m, nullptr, nullptr, nullptr);
     auto measure_regions = [&](int stage, jt_region_sample *rt, jt_region_sample *sp) {
         if (!have_regions) return;
@@ -1134,6 +1194,12 @@ extern "C" int jt_process_audio_cb(jt_ctx *h, const jt_host_config *base, int fr
     if ((rc = jt_pass3(h, &plan, eff.target_i, eff.target_tp, eff.target_lra, &m3)) != JT_OK) return rc;
     out->pass_ms[2] = h->timers.pass3_ms;
     out->stage_ms[7] = now_ms() - t0; t0 = now_ms();
+    if (tk.ticks && !lv2.empty()) {
+        // Pass 3 reads the Pass-2 output frame by frame (normalise.go:285-301): progress by samples, capped at 0.99
+        const int64_t total = h->m_p2;
+        for (int64_t fc = 100; fc <= (int64_t)lv2.size(); fc += 100)
+            tk.tick(3, "Measuring", std::min(0.99, (double)std::min<int64_t>(fc * 4096, total) / (double)total), lv2[(size_t)fc - 1]);
+    }
     m3.input_i = qfmt("%.2f", m3.input_i); m3.input_tp = qfmt("%.2f", m3.input_tp);
     m3.input_lra = qfmt("%.2f", m3.input_lra); m3.input_thresh = qfmt("%.2f", m3.input_thresh);
     out->measure = m3;
@@ -1153,6 +1219,13 @@ extern "C" int jt_process_audio_cb(jt_ctx *h, const jt_host_config *base, int fr
     emit(4, "Normalising", 0.0, dur, nullptr, nullptr, nullptr, &out->limiter);
     if (have_regions) jt_region_prefetch(h, 4, reg_st, reg_du);
     if ((rc = jt_pass4(h, &plan, &ap, &out->final_, &out->loudnorm)) != JT_OK) return rc;
+    if (tk.ticks) {
+        std::vector<double> lv4;
+        stage_levels(4, &lv4);
+        const int64_t total = h->m_p4;
+        for (int64_t fc = 100; fc <= (int64_t)lv4.size(); fc += 100)
+            tk.tick(4, "Normalising", std::min(0.99, (double)std::min<int64_t>(fc * 4096, total) / (double)total), lv4[(size_t)fc - 1]);
+    }
     emit(4, "Normalising", 1.0, dur, nullptr, nullptr, nullptr, nullptr);
     out->pass_ms[3] = h->timers.pass4_ms;
     out->stage_ms[8] = now_ms() - t0; t0 = now_ms();
@@ -1165,9 +1238,17 @@ extern "C" int jt_process_audio_cb(jt_ctx *h, const jt_host_config *base, int fr
     return JT_OK;
 }
 
+extern "C" int jt_process_audio_cb(jt_ctx *h, const jt_host_config *base, int frame_samples, jt_progress_fn cb, void *user, jt_process_result *out)
+{
+    return process_audio_impl(h, base, frame_samples, cb, user, out, false);
+}
+extern "C" int jt_process_audio_ticks(jt_ctx *h, const jt_host_config *base, int frame_samples, jt_progress_fn cb, void *user, jt_process_result *out)
+{
+    return process_audio_impl(h, base, frame_samples, cb, user, out, true);
+}
 extern "C" int jt_process_audio(jt_ctx *h, const jt_host_config *base, int frame_samples, jt_process_result *out)
 {
-    return jt_process_audio_cb(h, base, frame_samples, nullptr, nullptr, out);
+    return process_audio_impl(h, base, frame_samples, nullptr, nullptr, out, false);
 }
 
 extern "C" int64_t jt_host_sizeof(int which)
@@ -1257,6 +1338,49 @@ extern "C" double jt_host_vad_floored_fraction(const jt_interval *ivp, int64_t n
     return counted == 0 ? 0 : fl / counted;
 }
 
+// ---- speech election steps (analyser_candidates_speech.go / _shared.go), exported for the reference's table tests
+extern "C" double jt_host_score_speech_candidate(double rms_level, int64_t duration_ns, double noise_floor_db, double level_var)
+{
+    jt_speech_candidate m; std::memset(&m, 0, sizeof m);
+    m.sample.rms_level = rms_level; m.region.duration_ns = duration_ns;
+    return scoreSpeechCandidateGrounded(m, noise_floor_db, level_var);
+}
+extern "C" double jt_host_level_variance(const jt_interval *ivp, int64_t n, int axis)
+{
+    if (n <= 0 || !ivp) return 0.0;
+    std::vector<jt_interval> r(ivp, ivp + n);
+    if (axis == 0) return levelVariance(r);
+    // axisRMS (analyser_vad.go:55-56,79): the same population variance over the per-interval RMS level
+    double s = 0; for (auto &x : r) s += x.rms_level; const double mean = s / (double)n;
+    double v = 0; for (auto &x : r) { const double d = x.rms_level - mean; v += d * d; }
+    return v / (double)n;
+}
+extern "C" int jt_host_find_best_speech_region(const jt_region *regions, int n_regions, const jt_interval *ivp, int64_t n_iv,
+                                               int has_noise_profile, double noise_floor_db, jt_region *best, jt_speech_candidate *cands, int cap)
+{
+    std::vector<jt_region> rg(regions, regions + (n_regions > 0 ? n_regions : 0));
+    std::vector<jt_interval> iv(ivp, ivp + (n_iv > 0 ? n_iv : 0));
+    BestResult r = findBestSpeechRegion(rg, iv, has_noise_profile != 0, noise_floor_db);
+    for (int i = 0; i < (int)r.cands.size() && i < cap; ++i) cands[i] = r.cands[(size_t)i];
+    if (!r.has) return -1;
+    if (best) *best = r.best;
+    return (int)r.cands.size();
+}
+// calculateFrameLevel (encoder.go:235-257): the VU level the progress callback carries -- 20 log10(rms) of one s16 frame, clamped
+// to [-70, 0]; an empty or all-zero frame reads -70.
+extern "C" double jt_host_frame_level_s16(const int16_t *pcm, int n)
+{
+    if (!pcm || n <= 0) return -70.0;
+    double sum = 0.0;
+    for (int i = 0; i < n; ++i) { const double v = (double)pcm[i] / 32768.0; sum += v * v; }
+    const double rms = std::sqrt(sum / (double)n);
+    if (rms < 0.00001) return -70.0;                       // "Floor near-silence before the log" (encoder.go:246-249)
+    double db = 20.0 * std::log10(rms);
+    if (db < -70.0) db = -70.0;
+    if (db > 0.0) db = 0.0;
+    return db;
+}
+
 // ---------------------------------------------------------------- file in, file out (processor.go:78-330)
 // fault injection for the no-residue tests (the reference injects the same three failures through its package-level seams
 // processorCreateSiblingTempPath / processorRename and a failing encoder: processor_test.go:552-627, normalise_test.go:573-820)
@@ -1300,11 +1424,11 @@ extern "C" int jt_process_file(jt_ctx *h, const char *input_path, const jt_host_
     int rc = jt_load_audio(h, image, (int64_t)image_len, &meta);
     if (rc != JT_OK) return rc;
     if (io_ms) io_ms[1] = now() - t;
-    rc = jt_process_audio_cb(h, base, frame_samples, cb, user, out);
+    rc = process_audio_impl(h, base, frame_samples, cb, user, out, (flac_flags & JT_FILE_PROGRESS_TICKS) != 0);
     if (rc != JT_OK) return rc;
     t = now();
     const uint8_t *data = nullptr; int64_t len = 0; jt_flac_info info;
-    rc = jt_flac_encode(h, 4, flac_flags, &data, &len, &info);
+    rc = jt_flac_encode(h, 4, flac_flags & JT_FLAC_MD5, &data, &len, &info);
     if (rc != JT_OK) return rc;
     if (io_ms) io_ms[2] = now() - t;
     t = now();

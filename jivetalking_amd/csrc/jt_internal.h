@@ -10,6 +10,7 @@
 #include <vector>
 #include <atomic>
 #include "../../include/jtgpu.h"
+#include "../../include/jt_host.h"
 
 struct JtError { int code; std::string msg; };
 
@@ -59,6 +60,7 @@ void jt_loudnorm_finish(const double *block_sums, int64_t nblocks, int64_t s100,
 void launch_frame_stats(const float *in, int64_t n_total /*frames*channels*/, int samples_per_frame,
                         double *sumsq, double *peak, int64_t nframes, hipStream_t s);
 // mode: 0 = float 1/sqrt2 (Pass 1 / Pass 2), 1 = s16 integer matrix, 2 = s32 via float 0.5 (the band graphs of integer sources)
+void launch_frame_sumsq_s16(const int16_t *in, int64_t n, int spf, double *sumsq, int64_t nframes, hipStream_t s);
 void launch_downmix(const float *in, float *out, int64_t frames, int channels, int mode, hipStream_t s);
 void launch_s16_to_f32(const int16_t *in, float *out, int64_t n, hipStream_t s);
 void launch_s16_to_f64(const int16_t *in, double *out, int64_t n, double gain, int gain_in_float, hipStream_t s);
@@ -284,6 +286,7 @@ struct jt_ctx {
     HostArena pin_pcm, pin_flac;
     // input leg: file image, frame candidates / parse results / frame table, planar and interleaved integer PCM
     DevBuf<unsigned char> in_file, in_tab; DevBuf<int> in_planar, in_i32;
+    std::vector<jt_interval> last_intervals;      // the 250 ms interval series of the last Pass-1 analysis (run record, sidecar)
     jt_timers timers{};
     hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr, ev3 = nullptr;
 };

@@ -325,6 +325,26 @@ void launch_frame_stats(const float *in, int64_t n_total, int spf, double *sumsq
     hipLaunchKernelGGL(k_frame_stats, dim3((unsigned)nframes), dim3(256), 0, s, in, n_total, spf, sumsq, peak, nframes);
 }
 
+// calculateFrameLevel (encoder.go:235-257) on the frames of a stage output: sum of squares of (s16 / 32768) per frame
+__global__ void k_frame_sumsq_s16(const int16_t *__restrict__ in, int64_t n, int spf, double *__restrict__ sumsq, int64_t nframes)
+{
+    const int64_t f = blockIdx.x;
+    if (f >= nframes) return;
+    const int64_t lo = f * (int64_t)spf, hi = min(lo + spf, n);
+    double acc = 0.0;
+    for (int64_t i = lo + threadIdx.x; i < hi; i += blockDim.x) { const double v = (double)in[i] * (1.0 / 32768.0); acc += v * v; }
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+    __shared__ double sa[4];
+    if ((threadIdx.x & 63) == 0) sa[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) { double a = 0; for (int k = 0; k < (int)(blockDim.x >> 6); ++k) a += sa[k]; sumsq[f] = a; }
+}
+void launch_frame_sumsq_s16(const int16_t *in, int64_t n, int spf, double *sumsq, int64_t nframes, hipStream_t s)
+{
+    if (nframes <= 0) return;
+    hipLaunchKernelGGL(k_frame_sumsq_s16, dim3((unsigned)nframes), dim3(256), 0, s, in, n, spf, sumsq, nframes);
+}
+
 // ------------------------------------------------------------------ biquad cascade (f32, TDII)
 // BIQUAD_TDII_FILTER(flt): out = b0*in + w1; w1 = b1*in + w2 + a1*out; w2 = b2*in + a2*out
 __global__ void __launch_bounds__(64)

@@ -114,7 +114,9 @@ HOST_SYMBOLS = ["jt_host_build_intervals", "jt_host_detect", "jt_host_finish_mea
                 "jt_host_vad_gap_tolerance", "jt_host_vad_gate_stats", "jt_host_vad_noise_seed",
                 "jt_host_vad_pick_low_cluster", "jt_host_vad_floored_fraction", "jt_host_sizeof",
                 "jt_host_lufs_filename_value", "jt_host_output_path", "jt_process_audio_cb", "jt_process_file", "jt_process_files",
-                "jt_host_test_inject_fault", "jt_process_files_multi"]
+                "jt_host_test_inject_fault", "jt_process_files_multi",
+                "jt_host_score_speech_candidate", "jt_host_level_variance", "jt_host_find_best_speech_region", "jt_host_frame_level_s16", "jt_process_audio_ticks",
+                "jt_host_run_record_json", "jt_host_intervals_jsonl", "jt_host_candidates_jsonl", "jt_host_loudnorm_json"]
 
 
 def lib():
@@ -135,6 +137,12 @@ def lib():
     l.jt_host_vad_split.restype = None
     l.jt_host_vad_gate_stats.restype = None
     l.jt_host_test_inject_fault.restype = None
+    l.jt_host_score_speech_candidate.restype = C.c_double
+    l.jt_host_level_variance.restype = C.c_double
+    l.jt_host_frame_level_s16.restype = C.c_double
+    l.jt_host_run_record_json.restype = C.c_int64
+    l.jt_host_intervals_jsonl.restype = C.c_int64
+    l.jt_host_candidates_jsonl.restype = C.c_int64
     return l
 
 
@@ -192,13 +200,14 @@ class ProgressUpdate(C.Structure):
 PROGRESS_FN = C.CFUNCTYPE(None, C.c_void_p, C.POINTER(ProgressUpdate))
 
 
-def process_audio_with_progress(engine, on_update, base=None, frame_samples=4096):
-    """jt_process_audio_cb: `on_update(ProgressUpdate)` is called synchronously at every pass start / end."""
+def process_audio_with_progress(engine, on_update, base=None, frame_samples=4096, ticks=False):
+    """jt_process_audio_cb: `on_update(ProgressUpdate)` is called synchronously at every pass start / end; ticks=True
+    (jt_process_audio_ticks) adds the reference's every-100-frames and band ticks."""
     l = lib()
     base = base or default_config()
     res = ProcessResult()
     fn = PROGRESS_FN(lambda user, u: on_update(u.contents))
-    rc = l.jt_process_audio_cb(engine.h, C.byref(base), C.c_int(frame_samples), fn, None, C.byref(res))
+    rc = (l.jt_process_audio_ticks if ticks else l.jt_process_audio_cb)(engine.h, C.byref(base), C.c_int(frame_samples), fn, None, C.byref(res))
     if rc != 0:
         raise L.JtError(rc, l.jt_last_error(engine.h).decode())
     return res
@@ -268,3 +277,36 @@ def lufs_filename_value(lufs):
 def inject_fault(create_temp=0, write=0, rename=0):
     """Test seam of jt_process_file's publish discipline (include/jt_host.h: jt_host_test_inject_fault)."""
     lib().jt_host_test_inject_fault(C.c_int(create_temp), C.c_int(write), C.c_int(rename))
+
+
+class RunProvenance(C.Structure):
+    _fields_ = [("input_file", C.c_char_p), ("version", C.c_char_p), ("executable", C.c_char_p), ("processed_at", C.c_char_p),
+                ("duration_s", C.c_double), ("sample_rate_hz", C.c_int), ("channels", C.c_int)]
+
+
+def _sized(call):
+    n = call(None, 0)
+    if n < 0:
+        raise L.JtError(int(n), "run record: bad arguments")
+    buf = C.create_string_buffer(int(n) + 1)
+    call(buf, int(n) + 1)
+    return buf.value.decode()
+
+
+def run_record_json(engine, res, input_file="", version="dev", executable="", processed_at="", duration_s=0.0, sample_rate_hz=0,
+                    channels=0, analysis_only=False):
+    """jt_host_run_record_json: the reference's RunRecord document (runrecord.go) as text."""
+    pv = RunProvenance(input_file.encode(), version.encode(), executable.encode(), processed_at.encode(), duration_s, sample_rate_hz, channels)
+    return _sized(lambda b, c: lib().jt_host_run_record_json(engine.h if engine else None, C.byref(res), C.byref(pv), C.c_int(int(analysis_only)), b, C.c_int64(c)))
+
+
+def intervals_jsonl(engine):
+    return _sized(lambda b, c: lib().jt_host_intervals_jsonl(engine.h, b, C.c_int64(c)))
+
+
+def candidates_jsonl(res):
+    return _sized(lambda b, c: lib().jt_host_candidates_jsonl(C.byref(res), b, C.c_int64(c)))
+
+
+def loudnorm_json(stats):
+    return _sized(lambda b, c: lib().jt_host_loudnorm_json(C.byref(stats), b, C.c_int(c)))

@@ -239,3 +239,89 @@ def test_forged_header_with_escaped_partitions_is_rejected_not_faulted(engine, o
         with pytest.raises(L.JtError) as ei:
             engine.op_decode_audio(good2[:cut])
         assert ei.value.code == L.JT_E_INVAL
+
+
+# ---------------------------------------------------------------- frame statistics, progress ticks, run record
+def test_frame_stats_match_frameSumSquaresAndPeak(engine):
+    """k_frame_stats against the Go loop it replaces (analyser_metrics.go:273-358): per decoder frame, sum(x^2) and max|x| over ALL
+    interleaved samples of the frame, in double; mono and stereo, ragged last frame.  Sums 1e-12 relative (tree order), peaks exact."""
+    for ch, secs in ((1, 3.3), (2, 2.1)):
+        x = synth.speech_like(secs, SR, seed=70 + ch)
+        if ch == 2:
+            st = np.empty(x.size * 2, np.float32); st[0::2] = x; st[1::2] = 0.5 * np.roll(x, 3); raw = st
+        else:
+            raw = x
+        engine.upload_pcm(raw, SR, ch)
+        p1 = engine.pass1(x.size)
+        spf = 4096 * ch
+        nfr = (x.size + 4095) // 4096
+        assert p1["frame_sumsq"].size == nfr
+        r64 = raw.astype(np.float64)
+        for f in (0, 1, nfr // 2, nfr - 1):
+            seg = r64[f * spf:(f + 1) * spf]
+            assert p1["frame_sumsq"][f] == pytest.approx(float(np.sum(seg * seg)), rel=1e-12)
+            assert p1["frame_peak"][f] == float(np.max(np.abs(seg)))
+        assert p1["n_input_frames"] == nfr
+
+
+def test_progress_ticks_replay_the_reference_cadence(engine):
+    """jt_process_audio_ticks: every 100th decoder frame of every pass (analyser.go:602-618, processor.go:320-335,
+    normalise.go:292-301,1108-1117) + the 17 band ticks on 0.95..1.0 (analyser_band_runner.go:47-88), between the pass start / end
+    events; Level = calculateFrameLevel of the frame at that position."""
+    x = np.tile(synth.speech_like(30.0, SR, seed=81), 4)            # 120 s: 1407 decoder frames -> 15 ticks in Pass 1
+    engine.upload_pcm(x, SR, 1)
+    seen = []
+    res = H.process_audio_with_progress(engine, lambda u: seen.append((u.pass_, u.pass_name.decode(), u.progress, u.level)), ticks=True)
+    plain = []
+    H.process_audio_with_progress(engine, lambda u: plain.append((u.pass_, u.pass_name.decode(), u.progress)))
+    assert len(plain) == 8                                                               # start / end per pass, nothing else
+    nfr = (x.size + 4095) // 4096
+    est = x.size / 4096.0
+    p1 = [s for s in seen if s[0] == 1 and s[1] == "Analysing"]
+    ticks1 = p1[1:-1]
+    assert p1[0][2] == 0.0 and p1[-1][2] == 1.0 and len(ticks1) == (nfr + 99) // 100
+    for k, t in enumerate(ticks1):
+        assert t[2] == pytest.approx(min(0.95, (100 * k) / est * 0.95)) and -70.0 <= t[3] <= 0.0
+    bands = [s for s in seen if s[1] == "Analysing frequency bands"]
+    assert len(bands) == 17 and bands[0][2] == pytest.approx(0.95 + 0.05 / 17) and bands[-1][2] == 1.0
+    assert [b[2] for b in bands] == sorted(b[2] for b in bands)
+    p2 = [s for s in seen if s[0] == 2]
+    assert len(p2) == 2 + nfr // 100 and all(0.0 <= s[2] <= 1.0 for s in p2)
+    m = engine.download_s16(4).size
+    for pno, name in ((3, "Measuring"), (4, "Normalising")):
+        pp = [s for s in seen if s[0] == pno]
+        assert pp[0][2] == 0.0 and pp[-1][2] == 1.0 and len(pp) == 2 + ((m + 4095) // 4096) // 100
+        assert all(s[2] <= 0.99 for s in pp[1:-1]) and [s[2] for s in pp] == sorted(s[2] for s in pp)
+    # the Level of a Pass-4 tick is the VU level of that output frame
+    out = engine.download_s16(4)
+    fr = out[99 * 4096:100 * 4096].astype(np.float64) / 32768.0
+    want = max(-70.0, min(0.0, 20 * np.log10(np.sqrt(np.mean(fr * fr)))))
+    assert [s for s in seen if s[0] == 4][1][3] == pytest.approx(want, abs=1e-9)
+    assert seen.index(bands[-1]) < seen.index(p2[0])                                      # order: Pass-1 ticks, bands, then Pass 2
+
+
+def test_run_record_of_a_real_run(engine):
+    """jt_host_run_record_json on a processed file: every stage block present, values are the result's own, interval_summary from the
+    handle's interval series, sidecars one line per interval / candidate (runrecord_write.go:37-45)."""
+    import json
+    x = synth.speech_like(40.0, SR, seed=91)
+    engine.upload_pcm(x, SR, 1)
+    res = H.process_audio(engine)
+    text = H.run_record_json(engine, res, input_file="talk-LUFS-16-processed.flac", version="dev", processed_at="2026-01-01T00:00:00Z",
+                             duration_s=40.0, sample_rate_hz=SR, channels=1)
+    rec = json.loads(text)
+    assert rec["loudness"]["stages"]["input"]["integrated_lufs"] == res.input.input_i
+    assert rec["loudness"]["stages"]["final"]["integrated_lufs"] == res.output_lufs and rec["normalisation"]["output_lufs"] == res.output_lufs
+    assert rec["normalisation"]["loudnorm_measured"]["normalization_type"] == "linear" and rec["normalisation"]["within_target"] is True
+    assert rec["noise"]["floor_source"] == "vad_percentile" and rec["filters"]["noise_reduction"]["afftdn_enabled"] in (True, False)
+    lines = H.intervals_jsonl(engine).splitlines()
+    assert rec["interval_summary"]["count"] == len(lines) > 100
+    first = json.loads(lines[0])
+    assert list(first)[:3] == ["timestamp", "rms_level", "peak_level"] and first["timestamp"] == 0 and "spectral_rolloff" in first
+    d = rec["interval_summary"]["rms_distribution"]
+    assert d["min_dbfs"] <= d["p10_dbfs"] <= d["p50_dbfs"] <= d["p90_dbfs"] <= d["max_dbfs"] and rec["interval_summary"]["largest_gap_db"] >= 0
+    cands = H.candidates_jsonl(res).splitlines()
+    assert len(cands) == res.input.n_candidates == rec["regions"]["speech"]["candidates_summary"]["evaluated_count"]
+    if res.input.has_noise_profile:
+        assert rec["regions"]["room_tone"]["elected"]["start_s"] == res.input.noise_profile.start_ns / 1e9
+        assert set(rec["regions"]["room_tone"]["samples"]) == {"input", "filtered", "final"}
