@@ -407,3 +407,65 @@ def test_output_path_and_lufs_filename_value():
     assert H.output_path("clip.wav", 16) == "clip-LUFS-16-processed.flac"
     for lufs, want in [(-16.4, 16), (-16.5, 17), (-16.6, 17), (15.5, 16)]:
         assert H.lufs_filename_value(lufs) == want
+
+
+# ------------------------------------------------------------------ per-builder cases (filters_test.go:468-989, 1414-1527)
+def _spec_for(lib, cfg, pass_no):
+    if pass_no != 4:
+        return H.filter_spec(cfg, pass_no)
+    ms = L.LoudnormStats(); ms.input_i, ms.input_tp, ms.input_lra, ms.input_thresh = -24.0, -5.0, 6.0, -34.0
+    dec = H.LimiterDecision(); dec.ceiling_db = -1.0
+    buf = C.create_string_buffer(4096); ap = L.LoudnormApply()
+    lib.jt_host_pass4_spec(C.byref(cfg), C.byref(ms), C.c_double(-0.5), C.byref(dec), C.c_int(48000), None, buf, C.c_int(4096), C.byref(ap))
+    return buf.value.decode()
+
+
+def _element(spec, prefix):
+    for el in spec.split(","):
+        if el.startswith(prefix):
+            return el
+    return ""
+
+
+def _apply(cfg, sets):
+    for k, v in sets.items():
+        if isinstance(v, dict):
+            sub = getattr(cfg, k)
+            for kk, vv in v.items():
+                setattr(sub, kk, vv)
+        elif isinstance(v, str):
+            setattr(cfg, k, v.encode())
+        else:
+            setattr(cfg, k, v)
+
+
+def test_filter_builder_cases(lib):
+    g = load("filter_builder_cases.json")
+    base_j = load("filter_specs.json")["test_base_config"]
+    for case in g["cases"]:
+        cfg = _cfg_from_json(base_j)
+        _apply(cfg, case["set"])
+        spec = _spec_for(lib, cfg, case["pass"])
+        for s in case.get("contains", []):
+            assert s in spec, (case["name"], s, spec)
+        for s in case.get("absent", []):
+            assert s not in spec, (case["name"], s, spec)
+        if "order" in case:
+            pos = [spec.index(s) for s in case["order"]]
+            assert pos == sorted(pos), (case["name"], spec)
+        if "element" in case:
+            assert _element(spec, case["element"]["prefix"]) == case["element"]["want"], (case["name"], spec)
+
+
+def test_default_adeclick_clause_and_shared_analysis_segments(lib):
+    g = load("filter_builder_cases.json")
+    cfg = H.default_config()
+    p4 = _spec_for(lib, cfg, 4)
+    assert _element(p4, "adeclick=") == g["default_adeclick"]["want_element"]
+    cfg2 = _cfg_from_json(load("filter_specs.json")["test_base_config"])
+    cfg2.analysis_enabled = 1; cfg2.target_i = -16.0
+    p2 = H.filter_spec(cfg2, 2)
+    for pre in ("astats=", "aspectralstats="):
+        assert _element(p2, pre) and _element(p2, pre) == _element(p4, pre)
+    pref = g["shared_analysis_segments"]["ebur128_prefix"]
+    assert _element(p4, "ebur128=") == pref and _element(p2, "ebur128=").startswith(pref)
