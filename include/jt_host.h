@@ -203,6 +203,8 @@ typedef struct {
 } jt_run_provenance;
 int64_t jt_host_run_record_json(const jt_ctx *h, const jt_process_result *res, const jt_run_provenance *prov, int analysis_only, char *buf, int64_t cap);
 int64_t jt_host_intervals_jsonl(const jt_ctx *h, char *buf, int64_t cap);                        /* WriteIntervalsSidecar */
+/* The interval series itself (AudioMeasurements.Regions.IntervalSamples): returns the count, copies at most cap entries */
+int64_t jt_host_last_intervals(const jt_ctx *h, jt_interval *out, int64_t cap);
 int64_t jt_host_candidates_jsonl(const jt_process_result *res, char *buf, int64_t cap);          /* WriteCandidatesSidecar */
 /* loudnorm's print_format=json body (the text parseLoudnormStatsFile reads, normalise.go:143-165): ten "%.2f" string fields */
 int     jt_host_loudnorm_json(const jt_loudnorm_stats *stats, char *buf, int cap);

@@ -1251,6 +1251,14 @@ extern "C" int jt_process_audio(jt_ctx *h, const jt_host_config *base, int frame
     return process_audio_impl(h, base, frame_samples, nullptr, nullptr, out, false);
 }
 
+extern "C" int64_t jt_host_last_intervals(const jt_ctx *h, jt_interval *out, int64_t cap)
+{
+    if (!h) return 0;
+    const int64_t n = (int64_t)h->last_intervals.size();
+    if (out) for (int64_t i = 0; i < n && i < cap; ++i) out[i] = h->last_intervals[(size_t)i];
+    return n;
+}
+
 extern "C" int64_t jt_host_sizeof(int which)
 {
     switch (which) {

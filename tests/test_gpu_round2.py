@@ -325,3 +325,18 @@ def test_run_record_of_a_real_run(engine):
     if res.input.has_noise_profile:
         assert rec["regions"]["room_tone"]["elected"]["start_s"] == res.input.noise_profile.start_ns / 1e9
         assert set(rec["regions"]["room_tone"]["samples"]) == {"input", "filtered", "final"}
+
+
+def test_granular_call_sequence_equals_the_one_call_mirror(tmp_path):
+    """tools/granular_harness.cpp: the call sequence of the cgo shim at the reference's engine seam (upload, pass1, intervals, VAD,
+    band RMS x2, AdaptConfig, pass2, regions, limiter plan, pass3, linear target, pass4, regions, download), compiled with g++ against
+    include/*.h, must give exactly what jt_process_audio gives: the same s16 samples, statistics and strings."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "granular_harness")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-I", os.path.join(root, "include"), os.path.join(root, "tools", "granular_harness.cpp"),
+                           "-L", os.path.join(root, "jivetalking_amd", "lib"), "-ljtgpu", "-Wl,-rpath," + os.path.join(root, "jivetalking_amd", "lib"), "-o", exe])
+    x = synth.speech_like(45.0, SR, seed=95)
+    p = tmp_path / "in.f32"; x.astype("<f4").tofile(p)
+    r = subprocess.run([exe, str(p), str(SR)], capture_output=True, text=True)
+    assert r.returncode == 0 and "identical" in r.stdout, (r.returncode, r.stdout, r.stderr)
