@@ -209,7 +209,7 @@ def main():
         nlm_bytes = 8 * n                                    # anlmdn: read f32 + write f32 per sample
         nlm_flops = n * (2 * S) * 6                          # patch-distance recurrence: 2 sub, 2 mul, 2 add per (sample, offset)
         pm = np.mean(np.array(p_ms), axis=0)
-        nlm_roof = {"kernel": "k_anlmdn_pair<3>", "bound": "hbm", "achieved": round(nlm_bytes / nlm_avg_s / 1e9, 2),
+        nlm_roof = {"kernel": "k_anlmdn_pair3", "bound": "hbm", "achieved": round(nlm_bytes / nlm_avg_s / 1e9, 2),
                     "peak": 8000, "unit": "GB/s", "frac": round(nlm_bytes / nlm_avg_s / 1e9 / 8000, 5), "traffic": None,
                     "note": "vector-FP32 bound, not HBM bound (SURVEY §8d): add/mul-only recurrence (FFmpeg's unfused f32 order), "
                             "so the applicable peak is the non-FMA packed rate.  This launch is the early Pass-2 head (jt_pass2_prefetch_after_pass1): "

@@ -250,6 +250,329 @@ k_anlmdn_pair(const float *__restrict__ in, float *__restrict__ out, int64_t n, 
     else nlm_pair_body<NOFF, false>(in, out, n, hs, gwin, fw, K, S, H, sw, smooth, lut_scale, nisl, lane);
 }
 
+// ------------------------------------------------------------------ hop-pair kernel, three offsets per lane, deferred weights
+// k_anlmdn_pair3 (2S = 192: the 48 kHz default).  Same recurrence, mapping and LDS window as k_anlmdn_pair<3>, but the weight
+// stage no longer runs inside the step loop.  Measured on speech (tools/nlm_engage.py): 47 % of the steps have a contributing
+// offset, and in 97 % of those only the offsets -6..-1, +1..+6 contribute (lanes 30..33: neighbouring shifts of a low-pass
+// signal), so a wave-wide weight stage spends 64 lanes on ~9 useful values.  Here:
+//   * the step loop only advances the recurrence and keeps, per block of 8 steps, the running minimum of the lane's distances
+//     (the 8 x 3 packed distances of the block stay in registers);
+//   * a block with a distance under the cut on lanes 30..33 only (and no negative distance) parks those four lanes' 24 packed
+//     distances in LDS (12 ds_write_b128 by four lanes);
+//   * every 64 steps the wave turns round: lane t owns output t of the block, walks the 12 near offsets in FFmpeg's ascending
+//     order (sequential P / Q sums, as af_anlmdn.c does), divides, and the 64 outputs of each hop leave as one coalesced store.
+//     Outputs without a contributing offset are the input sample: (0 + x) / (0 + 1);
+//   * any other block (a far offset under the cut, or a distance that went negative by round-off, which FFmpeg clamps in
+//     place) is replayed from the block's starting distances by the exact per-step path: clamp, wave-wide weights, DPP
+//     reduction; its outputs join the same coalesced store.
+// Every output is written exactly once (k_anlmdn_pair pre-stores the input and overwrites engaged outputs with scattered
+// 4-byte stores from two lanes: WRITE_SIZE 2.4x the output size in profiles/r01_pmc_traffic.json).
+#ifndef JT_NLM3_CB
+#define JT_NLM3_CB 64
+#endif
+constexpr int NLM3_S = 96, NLM3_NEAR0 = 30, NLM3_NL = 4, NLM3_CB = JT_NLM3_CB, NLM3_B8 = NLM3_CB / 8;
+constexpr unsigned long long NLM3_NEARMASK = 0xFull << NLM3_NEAR0;
+
+#ifdef JT_NLM_PROFILE
+__device__ unsigned long long g_nlm_prof[8];      // wave clocks: window fill, seed, steps, park, replay, turn-round; [6] blocks replayed, [7] blocks parked
+#define NLM_T(var) const unsigned long long var = __builtin_amdgcn_s_memtime()
+#define NLM_ACC(k, a, b) (nlm_pr[k] += (b) - (a))
+#define NLM_PROF_DECL unsigned long long nlm_pr[8] = {0, 0, 0, 0, 0, 0, 0, 0}
+#define NLM_PROF_FLUSH do { if (threadIdx.x == 0) for (int k_ = 0; k_ < 8; ++k_) atomicAdd(&g_nlm_prof[k_], nlm_pr[k_]); } while (0)
+#else
+#define NLM_T(var)
+#define NLM_ACC(k, a, b)
+#define NLM_PROF_DECL
+#define NLM_PROF_FLUSH
+#endif
+
+template <int V>
+__device__ inline void nlm3_step(f2 (&cache)[3], f2 (&hi)[4], f2 (&lo)[4], const f2 cm, const f2 cp, const f2 *pw, int K,
+                                 f2 (&cs)[8][3], float &mn)
+{
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+        const f2 a = cm - lo[(q + V) % 4];
+        const f2 b = cp - hi[(q + V) % 4];
+        cache[q] = cache[q] + (-(a * a) + b * b);
+    }
+    hi[V % 4] = pw[V + K];
+    lo[V % 4] = pw[V - K - 1];
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+        cs[V - 1][q] = cache[q];
+        mn = fminf(fminf(mn, cache[q].x), cache[q].y);
+    }
+}
+
+// The wave-wide weight stage of one step (both hops): FFmpeg's clamp, exact per-offset test, weights, lane-local sums, DPP
+// reduction; lanes 61 / 63 leave the two outputs in dst->x / dst->y (LDS).
+__device__ inline void nlm3_dense_stage(f2 (&cache)[3], int i, int d0, const f2 *fw, f2 *dst, float sw, float smooth,
+                                        float lut_scale, float nisl, int lane)
+{
+    f2 Pxy = f2{0.f, 0.f}, Qxy = f2{0.f, 0.f};
+    const f2 sw2 = f2{sw, sw}, ls2 = f2{lut_scale, lut_scale}, ns2 = f2{nisl, nisl};
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+        cache[q].x = __builtin_amdgcn_fmed3f(cache[q].x, 0.f, 3.0e38f);
+        cache[q].y = __builtin_amdgcn_fmed3f(cache[q].y, 0.f, 3.0e38f);
+        const f2 w = cache[q] * sw2;
+        f2 idx = w * ls2;
+        idx.x = truncf(idx.x); idx.y = truncf(idx.y);
+        const f2 ex = idx * ns2;
+        f2 wt;
+        wt.x = w.x >= smooth ? 0.f : __builtin_amdgcn_exp2f(ex.x);
+        wt.y = w.y >= smooth ? 0.f : __builtin_amdgcn_exp2f(ex.y);
+        Pxy = Pxy + wt * fw[i + d0 + q];
+        Qxy = Qxy + wt;
+    }
+    const bool odd = lane & 1, up = lane & 2;
+    const float s1 = odd ? Qxy.x : Pxy.x, o1 = odd ? Pxy.x : Qxy.x;
+    const float s2 = odd ? Qxy.y : Pxy.y, o2 = odd ? Pxy.y : Qxy.y;
+    const float x = s1 + JT_DPP(o1, 0xb1, 0xf);
+    const float y = s2 + JT_DPP(o2, 0xb1, 0xf);
+    const float s3 = up ? y : x, o3 = up ? x : y;
+    float z = s3 + JT_DPP(o3, 0x4e, 0xf);
+    z += JT_DPP(z, 0x114, 0xf);
+    z += JT_DPP(z, 0x118, 0xf);
+    z += __shfl_xor(z, 16, 64);
+    z += __shfl_xor(z, 32, 64);
+    const float pnum = JT_DPP(z, 0x111, 0xf);            // lane 61 <- Px (z = Qx), lane 63 <- Py (z = Qy)
+    if (lane == 61) reinterpret_cast<float *>(dst)[0] = __fadd_rn(pnum, fw[i].x) / __fadd_rn(z, 1.f);
+    if (lane == 63) reinterpret_cast<float *>(dst)[1] = __fadd_rn(pnum, fw[i].y) / __fadd_rn(z, 1.f);
+}
+
+// Exact per-step replay of `count` steps starting at step index i0 (slot vs0 of the consumer block), reading the window directly.
+__device__ inline void nlm3_slow_steps(f2 (&cache)[3], int i0, int count, int d0, int K, const f2 *fw, f2 *dslot, int vs0,
+                                       unsigned long long &dmask, float sw, float smooth, float lut_scale, float nisl, float dthr, int lane)
+{
+    for (int u = 0; u < count; ++u) {
+        const int i = i0 + u;
+        const f2 cm = fw[i - K - 1], cp = fw[i + K];
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            const f2 a = cm - fw[i + d0 + q - K - 1];
+            const f2 b = cp - fw[i + d0 + q + K];
+            cache[q] = cache[q] + (-(a * a) + b * b);
+        }
+        float dmin = 3.0e38f;
+#pragma unroll
+        for (int q = 0; q < 3; ++q) dmin = fminf(dmin, fminf(cache[q].x, cache[q].y));
+        if (__any(dmin < dthr)) {
+            nlm3_dense_stage(cache, i, d0, fw, dslot + vs0 + u, sw, smooth, lut_scale, nisl, lane);
+            dmask |= 1ull << (vs0 + u);
+        }
+    }
+}
+
+// Turn-round: lane t finishes output t of the block (v = vb + t) for both hops and the block leaves as two coalesced stores.
+__device__ inline void nlm3_consume(const f2 *fw, const f2 *slot, const f2 *dslot, unsigned long long emask, unsigned long long dmask,
+                                    int vb, int count, int H, float *__restrict__ out, int64_t hs, int64_t n,
+                                    float sw, float smooth, float lut_scale, float nisl, int lane)
+{
+    const int v = vb + lane, i = NLM3_S + v;
+    f2 o = fw[i];
+    if (emask | dmask) {
+        if (emask) {
+            f2 P = f2{0.f, 0.f}, Q = f2{0.f, 0.f};
+            const f2 sw2 = f2{sw, sw}, ls2 = f2{lut_scale, lut_scale}, ns2 = f2{nisl, nisl};
+#pragma unroll
+            for (int e = 0; e < NLM3_NL * 3; ++e) {
+                constexpr int j0 = NLM3_NEAR0 * 3;
+                const int j = j0 + e;
+                const int d = j - NLM3_S + (j >= NLM3_S ? 1 : 0);
+                const f2 c = slot[e * NLM3_CB + (lane & (NLM3_CB - 1))];
+                const f2 w = c * sw2;
+                f2 idx = w * ls2;
+                idx.x = truncf(idx.x); idx.y = truncf(idx.y);
+                const f2 ex = idx * ns2;
+                f2 wt;
+                wt.x = w.x >= smooth ? 0.f : __builtin_amdgcn_exp2f(ex.x);
+                wt.y = w.y >= smooth ? 0.f : __builtin_amdgcn_exp2f(ex.y);
+                P = P + wt * fw[i + d];
+                Q = Q + wt;
+            }
+            f2 r;
+            r.x = __fadd_rn(P.x, o.x) / __fadd_rn(Q.x, 1.f);
+            r.y = __fadd_rn(P.y, o.y) / __fadd_rn(Q.y, 1.f);
+            if ((emask >> lane) & 1) o = r;
+        }
+        if ((dmask >> lane) & 1) o = dslot[lane & (NLM3_CB - 1)];
+    }
+    if (lane < count) {
+        const int64_t oa = hs + v, ob = oa + H;
+        if (oa >= 0 && oa < n) out[oa] = o.x;
+        if (ob >= 0 && ob < n) out[ob] = o.y;
+    }
+}
+
+__global__ void __launch_bounds__(64)
+k_anlmdn_pair3(const float *__restrict__ in, float *__restrict__ out, int64_t n, int K, float sw, float smooth, float lut_scale)
+{
+    extern __shared__ float smem_nlm[];
+    constexpr int S = NLM3_S;
+    const int H = 2 * K + 1;
+    const int NW = H + 2 * (K + S);
+    const int NWP = NLM_PADF + NW + NLM_PADB;
+    f2 *win = reinterpret_cast<f2 *>(smem_nlm);            // [NWP] interleaved {hop A, hop B}
+    f2 *slot = win + NWP;                                  // [12][64] parked near-lane distances of the current block
+    f2 *dslot = slot + NLM3_NL * 3 * NLM3_CB;              // [65] outputs of replayed steps (+1: the hop's first step)
+    const int lane = threadIdx.x;
+    const int64_t hopA = (int64_t)blockIdx.x * 2;
+    const int64_t hs = hopA * H - (K + S);
+    const int64_t gwin = hs - (K + S);
+    NLM_PROF_DECL;
+    NLM_T(t_a);
+    constexpr int NLD = 24;                                 // window rows of 64 entries fetched in one batch
+    if (gwin - NLM_PADF >= 0 && gwin - NLM_PADF + NWP + H <= n && NWP <= 64 * NLD) {
+        // interior tile: every load of the window is issued before the first one is waited for (one memory round trip per wave
+        // instead of one per 64 entries); rows past the window re-read its last entry and are not stored
+        const float *src = in + (gwin - NLM_PADF);
+        float ax[NLD], ay[NLD];
+#pragma unroll
+        for (int r = 0; r < NLD; ++r) {
+            const int w = min(lane + 64 * r, NWP - 1);
+            ax[r] = __builtin_nontemporal_load(src + w);
+            ay[r] = __builtin_nontemporal_load(src + w + H);
+        }
+#pragma unroll
+        for (int r = 0; r < NLD; ++r) {
+            const int w = lane + 64 * r;
+            if (w < NWP) win[w] = f2{ax[r], ay[r]};
+        }
+    } else {
+        for (int w = lane; w < NWP; w += 64) {
+            const int64_t k = gwin - NLM_PADF + w, k2 = k + H;
+            win[w] = f2{(k >= 0 && k < n) ? in[k] : 0.f, (k2 >= 0 && k2 < n) ? in[k2] : 0.f};
+        }
+    }
+    __syncthreads();
+    NLM_T(t_b); NLM_ACC(0, t_a, t_b);
+    const f2 *fw = win + NLM_PADF + K;
+    const float nisl = -1.4426950408889634f / lut_scale;
+    const int j0 = lane * 3;
+    const int d0 = j0 - S + (j0 >= S ? 1 : 0);
+    f2 cache[3];
+#pragma unroll
+    for (int q = 0; q < 3; ++q) cache[q] = f2{0.f, 0.f};
+    // ---- seed: compute_distance_ssd over k = -K..K (ascending, mul then add).  The stream ring holds 8 positions and the centre
+    // samples arrive 8 steps ahead: a seed step is 9 packed instructions, so the 4-slot ring of the step loop (refill two steps
+    // ahead) would leave every refill ~70 cycles to land -- less than an LDS round trip
+    {
+        f2 st[8], ca[8], cb[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) { const int x = S + d0 + q - K; st[q] = fw[x]; }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) ca[u] = fw[S - K + u];
+        const f2 *pw = fw + S + d0 + 8 - K;                    // pw[u]: the stream position 8 ahead of step u
+        const f2 *pc = fw + S - K + 8;
+        for (int k0 = -K; k0 < K; k0 += 16) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) cb[u] = pc[u];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+#pragma unroll
+                for (int q = 0; q < 3; ++q) { const f2 dd = ca[u] - st[(q + u) % 8]; cache[q] = cache[q] + dd * dd; }
+                st[u % 8] = pw[u];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) ca[u] = pc[8 + u];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+#pragma unroll
+                for (int q = 0; q < 3; ++q) { const f2 dd = cb[u] - st[(q + u) % 8]; cache[q] = cache[q] + dd * dd; }
+                st[u % 8] = pw[8 + u];
+            }
+            pw += 16; pc += 16;
+        }
+        // k = K, the (2K+1)-th term: 2K % 16 == 0 puts it at ring position 0 with its centre already in ca[0]
+#pragma unroll
+        for (int q = 0; q < 3; ++q) { const f2 dd = ca[0] - st[q]; cache[q] = cache[q] + dd * dd; }
+    }
+    const float dthr = (smooth / sw) * 1.000002f;
+    NLM_T(t_c); NLM_ACC(1, t_b, t_c);
+    // ---- first step of the hop (no recurrence update): exact path, one output per hop
+    {
+        float dmin = 3.0e38f;
+#pragma unroll
+        for (int q = 0; q < 3; ++q) dmin = fminf(dmin, fminf(cache[q].x, cache[q].y));
+        const bool eng = __any(dmin < dthr);
+        if (eng) nlm3_dense_stage(cache, S, d0, fw, dslot + NLM3_CB, sw, smooth, lut_scale, nisl, lane);
+        if (lane == 0) {
+            const f2 o = eng ? dslot[NLM3_CB] : fw[S];
+            if (hs >= 0 && hs < n) out[hs] = o.x;
+            if (hs + H >= 0 && hs + H < n) out[hs + H] = o.y;
+        }
+    }
+    // ---- steps v = 1 .. 2K in blocks of 8; hi[(q+v)%4] = f[i + d0 + q + K], lo[...] = f[i + d0 + q - K - 1], v = (i - S) % 4
+    f2 hi[4], lo[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int xh = S + d0 + q + K; hi[q] = fw[xh];
+        const int xl = S + d0 + q - K - 1; lo[q] = fw[xl];
+    }
+    // the FIRST step's refill (slot 0 takes the values four positions ahead)
+    hi[0] = fw[S + d0 + 4 + K];
+    lo[0] = fw[S + d0 + 4 - K - 1];
+    f2 ma[4], pa[4], mb[4], pb[4];
+    nlm_centre4<false>(in, 0, fw, S + 1 - K - 1, H, ma);
+    nlm_centre4<false>(in, 0, fw, S + 1 + K, H, pa);
+    unsigned long long emask = 0, dmask = 0;
+    const int nb8 = K / 4;                                   // 2K / 8 blocks of eight steps
+    const bool near = lane >= NLM3_NEAR0 && lane < NLM3_NEAR0 + NLM3_NL;
+    for (int b8 = 0; b8 < nb8; ++b8) {
+        const int i0 = S + 1 + b8 * 8;
+        const int it = b8 % NLM3_B8;
+        const f2 *pw = fw + i0 + d0 + 4 - 1;
+        f2 cs[8][3], c0[3];
+        float mn = 3.0e38f;
+        NLM_T(t_0);
+#pragma unroll
+        for (int q = 0; q < 3; ++q) c0[q] = cache[q];
+        nlm_centre4<false>(in, 0, fw, i0 + 4 - K - 1, H, mb);
+        nlm_centre4<false>(in, 0, fw, i0 + 4 + K, H, pb);
+        nlm3_step<1>(cache, hi, lo, ma[0], pa[0], pw, K, cs, mn);
+        nlm3_step<2>(cache, hi, lo, ma[1], pa[1], pw, K, cs, mn);
+        nlm3_step<3>(cache, hi, lo, ma[2], pa[2], pw, K, cs, mn);
+        nlm3_step<4>(cache, hi, lo, ma[3], pa[3], pw, K, cs, mn);
+        nlm_centre4<false>(in, 0, fw, i0 + 8 - K - 1, H, ma);
+        nlm_centre4<false>(in, 0, fw, i0 + 8 + K, H, pa);
+        nlm3_step<5>(cache, hi, lo, mb[0], pb[0], pw, K, cs, mn);
+        nlm3_step<6>(cache, hi, lo, mb[1], pb[1], pw, K, cs, mn);
+        nlm3_step<7>(cache, hi, lo, mb[2], pb[2], pw, K, cs, mn);
+        nlm3_step<8>(cache, hi, lo, mb[3], pb[3], pw, K, cs, mn);
+        const unsigned long long bal = __ballot(mn < dthr);
+        NLM_T(t_1); NLM_ACC(2, t_0, t_1);
+        if (bal) {
+            if ((bal & ~NLM3_NEARMASK) || __any(mn < 0.f)) {
+#pragma unroll
+                for (int q = 0; q < 3; ++q) cache[q] = c0[q];
+                nlm3_slow_steps(cache, i0, 8, d0, K, fw, dslot, it * 8, dmask, sw, smooth, lut_scale, nisl, dthr, lane);
+                NLM_T(t_2); NLM_ACC(4, t_1, t_2); NLM_ACC(6, 0ull, 1ull);
+            } else {
+                if (near) {
+#pragma unroll
+                    for (int q = 0; q < 3; ++q) {
+#pragma unroll
+                        for (int u = 0; u < 8; u += 2)
+                            *reinterpret_cast<float4 *>(slot + ((lane - NLM3_NEAR0) * 3 + q) * NLM3_CB + it * 8 + u) =
+                                make_float4(cs[u][q].x, cs[u][q].y, cs[u + 1][q].x, cs[u + 1][q].y);
+                    }
+                }
+                emask |= 0xFFull << (it * 8);
+                NLM_T(t_2); NLM_ACC(3, t_1, t_2); NLM_ACC(7, 0ull, 1ull);
+            }
+        }
+        NLM_T(t_3);
+        if (it == NLM3_B8 - 1 || b8 == nb8 - 1) {
+            nlm3_consume(fw, slot, dslot, emask, dmask, 1 + (b8 - it) * 8, (it + 1) * 8, H, out, hs, n, sw, smooth, lut_scale, nisl, lane);
+            emask = dmask = 0;
+            NLM_T(t_4); NLM_ACC(5, t_3, t_4);
+        }
+    }
+    NLM_PROF_FLUSH;
+}
+
 // ------------------------------------------------------------------ generic path (any K, S)
 constexpr int NLM_TI = 64;     // outputs per weight tile
 
@@ -337,7 +660,21 @@ void launch_anlmdn(const float *in, float *out, int64_t n, int K, int S, float s
         size_t smem = sizeof(float) * 2 * (size_t)(NLM_PADF + NW + NLM_PADB);      // interleaved {hop A, hop B} window
         JT_REQUIRE(smem <= 64 * 1024, JT_E_UNSUPPORTED, "anlmdn: window exceeds the wave-per-hop LDS budget");
         const unsigned grid = (unsigned)((nhops + 1) / 2);
-        if (2 * S == 192) hipLaunchKernelGGL((k_anlmdn_pair<3>), dim3(grid), dim3(64), smem, s, in, out, n, K, S, sw, smooth, lut_scale, nhops);
+        if (2 * S == 192 && K % 8 == 0 && !getenv("JT_NLM_OLD")) {
+            smem += sizeof(float) * 2 * (size_t)(NLM3_NL * 3 * NLM3_CB + NLM3_CB + 1);
+            hipLaunchKernelGGL(k_anlmdn_pair3, dim3(grid), dim3(64), smem, s, in, out, n, K, sw, smooth, lut_scale);
+#ifdef JT_NLM_PROFILE
+            {
+                unsigned long long pr[8], z[8] = {0};
+                JT_HIP(hipStreamSynchronize(s));
+                JT_HIP(hipMemcpyFromSymbol(pr, HIP_SYMBOL(g_nlm_prof), sizeof pr));
+                JT_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_nlm_prof), z, sizeof z));
+                fprintf(stderr, "anlmdn wave clocks per pair (%u pairs): fill %.0f seed %.0f steps %.0f park %.0f replay %.0f turn %.0f; blocks replayed %.2f parked %.2f of %d\n",
+                        grid, (double)pr[0] / grid, (double)pr[1] / grid, (double)pr[2] / grid, (double)pr[3] / grid, (double)pr[4] / grid,
+                        (double)pr[5] / grid, (double)pr[6] / grid, (double)pr[7] / grid, K / 4);
+            }
+#endif
+        } else if (2 * S == 192) hipLaunchKernelGGL((k_anlmdn_pair<3>), dim3(grid), dim3(64), smem, s, in, out, n, K, S, sw, smooth, lut_scale, nhops);
         else hipLaunchKernelGGL((k_anlmdn_pair<6>), dim3(grid), dim3(64), smem, s, in, out, n, K, S, sw, smooth, lut_scale, nhops);
         return;
     }

@@ -102,6 +102,29 @@ def test_anlmdn_96k_six_offsets_per_lane(engine, oracle):
         assert np.max(np.abs(engine.op_anlmdn(y, 96000) - oracle.anlmdn(y, 96000))) < 1e-8
 
 
+def test_anlmdn_near_field_silence_and_mixed_blocks(engine, oracle):
+    """k_anlmdn_pair3's three routes: near-offset blocks (low-passed room tone: only shifts of a few samples fall under the cut),
+    replayed blocks (white noise: far offsets contribute; digital silence after signal: distances round to small negatives that
+    FFmpeg clamps in place) and untouched blocks (speech), with the transitions between them inside one file."""
+    from scipy.signal import lfilter
+    rng = np.random.default_rng(11)
+    room = lfilter([0.05], [1.0, -0.95], rng.standard_normal(SR)).astype(np.float64)
+    room *= 10 ** (-62 / 20) / np.std(room)
+    white = rng.standard_normal(SR // 2) * 10 ** (-66 / 20)
+    x = np.concatenate([room[:SR // 2], speech(1.0, 9), np.zeros(SR // 4), white, np.zeros(3000), room[SR // 2:],
+                        speech(0.5, 10) * 0.05 + room[:SR // 2]]).astype(np.float32)
+    ref = oracle.anlmdn(x, SR)
+    got = engine.op_anlmdn(x, SR)
+    assert np.max(np.abs(ref - x)) > 1e-6
+    assert np.max(np.abs(got - ref)) < 1e-5 * np.max(np.abs(x))
+    # near-offset route alone sums in FFmpeg's order: only the hardware exp separates it from the oracle
+    r = room.astype(np.float32)
+    assert np.max(np.abs(engine.op_anlmdn(r, SR) - oracle.anlmdn(r, SR))) < 2e-6 * np.max(np.abs(r))
+    # all-zero input: every offset of every lane contributes with weight 1 and the output is 0
+    z = np.zeros(5000, np.float32)
+    assert np.array_equal(engine.op_anlmdn(z, SR), z)
+
+
 # ---------------------------------------------------------------- afftdn
 def test_afftdn_matches_oracle(engine, oracle):
     x = speech(10.0, 5)
