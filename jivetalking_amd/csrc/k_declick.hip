@@ -511,6 +511,14 @@ k_adeclick(const double *__restrict__ in, double *__restrict__ out, int64_t n, D
 //     column entry itself) and 1/d is a reciprocal + two Newton steps;
 //   * fused multiply-adds everywhere a product feeds a sum.
 // Same capacity levels, work counter, overflow lists, packed factor stream and output handling as k_adeclick.
+#ifndef JT_DK_LOADBATCH
+#define JT_DK_LOADBATCH 8
+#endif
+#ifdef JT_DK_NOMFMA_DETECT
+#define getenv_dk_nomfma true
+#else
+#define getenv_dk_nomfma false
+#endif
 namespace dkf { constexpr int DQ = 11; }
 typedef double dk_d4 __attribute__((ext_vector_type(4)));
 
@@ -531,6 +539,10 @@ k_adeclick_fast(const double *__restrict__ in, double *__restrict__ out, int64_t
     const int lane = threadIdx.x;
     const int W = P.W, AR = P.ar;
     constexpr int MAXAR = dk::MAXAR, CM = NC - 1, BWMAX = ND - 1, DQ = dkf::DQ;
+    // ring row stride: one double of padding, so that the lanes of a pivot column (one per diagonal) and the pairs of a trailing
+    // update (diagonal a - b, slot k + 1 + b) fall on different LDS banks; with a stride of NC = 32 or 64 doubles every row started on
+    // the same bank and a column read was a 32-way conflict (SQ_LDS_BANK_CONFLICT was 41 % of the LDS cycles of the kernel)
+    constexpr int NCP = NC == 32 ? 41 : NC + 1;                 // 41 = 9 (mod 32): columns conflict-free, pairs at most two-way
     static_assert((NC & (NC - 1)) == 0 && ND <= NC + 1 && BWMAX < NC, "ring geometry");
     double *sbuf = reinterpret_cast<double *>(dk_smem);                // window samples ; later the ND x NC ring
     double *rr = sbuf + P.sa;                                           // r[AR+1]                       [50]
@@ -553,7 +565,6 @@ k_adeclick_fast(const double *__restrict__ in, double *__restrict__ out, int64_t
             pairtab[t] = (unsigned short)(a | ((t - a * (a + 1) / 2) << 8));
         }
     }
-    auto fbit = [&](int pos) -> bool { return (fbits[pos >> 6] >> (pos & 63)) & 1ull; };
     double *gL = scratch + (size_t)blockIdx.x * scratch_per_wave;
     double *gD = gL + (size_t)W * MAXAR, *gY = gD + W, *gV = gY + W;
     unsigned long long repaired = 0, singular = 0;
@@ -575,33 +586,57 @@ k_adeclick_fast(const double *__restrict__ in, double *__restrict__ out, int64_t
 #endif
     const int *worklist = LEVEL == 1 ? heavy : heavy + P.nwindows;
     const int64_t nwork = LEVEL == 0 ? P.nwindows : (int64_t)stats[1 + LEVEL];
+    // The work counter is fetched one window ahead: the atomic's round trip (and the drain of the previous window's stores that a
+    // wait on it implies) took 10 % of a window when the wave asked for its next window only after finishing the current one.
+    auto take = [&]() -> unsigned long long { unsigned long long v = 0; if (lane == 0) v = atomicAdd(&stats[12 + LEVEL], 1ull); return v; };
+    auto uniform64 = [](unsigned long long v) -> int64_t {
+        return (int64_t)(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(v >> 32)) << 32) |
+                         (unsigned)__builtin_amdgcn_readfirstlane((int)v));
+    };
+    int64_t wi = uniform64(take());
     for (;;) {
-        unsigned long long wi_ = 0;
-        if (lane == 0) wi_ = atomicAdd(&stats[12 + LEVEL], 1ull);
-        const int64_t wi = (int64_t)(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(wi_ >> 32)) << 32) |
-                                     (unsigned)__builtin_amdgcn_readfirstlane((int)wi_));
         if (wi >= nwork) break;
+        const unsigned long long wnext_ = take();                   // consumed after the first buffer load below
         const int64_t w = LEVEL == 0 ? wi : (int64_t)worklist[wi];
         const int64_t s0 = w * P.hop - P.skip;
         const int64_t o0 = w * P.hop;
+#ifdef JT_DK_SPLIT0
+        DKF_MARK(0)
+#endif
         int sb = 0;
-        auto load_buf = [&](int base) {
+        // Window positions [elo, ehi) of a load also leave as output (input * gain): the pass-through copy of the hop rides on the
+        // first load of each half instead of re-reading the hop from memory after the solve (that copy was 10 % of a window: three
+        // more load round trips behind the solver's stores).  Repaired samples overwrite theirs later, behind a fence.
+        auto load_buf = [&](int base, int elo = 0, int ehi = 0) {
             sb = base;
             // eight loads in flight per lane before the first LDS store (one load -> one store per trip left every trip waiting for
             // a full memory latency: 21 trips per half window, four half windows per window)
-            for (int j0 = lane; j0 < LB + PADE; j0 += 64 * 8) {
-                double t[8];
+            constexpr int NB = JT_DK_LOADBATCH;
+            for (int j0 = lane; j0 < LB + PADE; j0 += 64 * NB) {
+                double t[NB];
 #pragma unroll
-                for (int u = 0; u < 8; ++u) {
+                for (int u = 0; u < NB; ++u) {
                     const int j = j0 + 64 * u; const int64_t p = s0 + base + j;
                     t[u] = (j < LB + PADE && base + j < W && p >= 0 && p < n) ? in[p] : 0.0;
                 }
 #pragma unroll
-                for (int u = 0; u < 8; ++u) { const int j = j0 + 64 * u; if (j < LB + PADE) sbuf[j] = __dmul_rn(t[u], P.gain); }
+                for (int u = 0; u < NB; ++u) {
+                    const int j = j0 + 64 * u;
+                    const double g = __dmul_rn(t[u], P.gain);
+                    if (j < LB + PADE) sbuf[j] = g;
+                    const int pos = base + j;
+                    if (pos >= elo && pos < ehi && o0 + (pos - P.skip) < n) out[o0 + (pos - P.skip)] = g;
+                }
             }
         };
-        load_buf(0);
+        const int emid = HALF ? min(LB, P.skip + P.hop) : P.skip + P.hop;
+        load_buf(0, P.skip, emid);
+        wi = uniform64(wnext_);                                     // (the loads above were waited for; the atomic precedes them)
+#ifdef JT_DK_SPLIT0
+        DKF_MARK(7)
+#else
         DKF_MARK(0)
+#endif
         // ---- 2. autocorrelation on the matrix pipe
         {
             dk_d4 C0 = {0, 0, 0, 0}, C1 = {0, 0, 0, 0}, C2 = {0, 0, 0, 0}, C3 = {0, 0, 0, 0};
@@ -623,7 +658,7 @@ k_adeclick_fast(const double *__restrict__ in, double *__restrict__ out, int64_t
             const int nblk = (W + 63) >> 6;
             const int ka = HALF ? (SPLIT + 63) >> 6 : nblk;              // 64*ka <= LB and 64*ka - AR >= SB_B
             mfma_blocks(0, ka);
-            if (HALF) { load_buf(SB_B); mfma_blocks(ka, nblk); }
+            if (HALF) { load_buf(SB_B, emid, P.skip + P.hop); mfma_blocks(ka, nblk); }
             // C_m[i][j] (i = 4 * reg + lane / 16, j = lane % 16) belongs to lag 16 m + i - j: every lane adds its sixteen entries into
             // r2[lag] with LDS floating-point atomics (ds_add_f64; one wave, program order, conflicting lanes of an instruction are
             // served in lane order: the sum order is fixed, the result reproducible)
@@ -726,12 +761,63 @@ k_adeclick_fast(const double *__restrict__ in, double *__restrict__ out, int64_t
                     }
                 }
             };
+            // The same FIR on the matrix pipe.  A range of outputs [ia, ib) is cut into 16 segments of R outputs; output ia + i + R j is
+            // element (i, j) of  D = T X,  T[i][u] = a[i - u] (Toeplitz in the AR coefficients, the same 16 x 64 block for every block of
+            // 16 rows),  X[u][j] = x[ia + u + R j]:  per 16 rows, sixteen v_mfma_f64_16x16x4_f64 (K = 64 covers the AR + 16 samples a
+            // row block reaches back to), operand A from sixteen registers filled once per window, operand B one LDS read per lane and
+            // step (R odd: the sixteen segment starts fall on different banks).  256 outputs x 49 taps per 16 instructions instead of
+            // 11 outputs per 49 lane-FMAs; the sum order inside an MFMA is the hardware's (this kernel's results are order-relaxed anyway).
+            dk_d4 zero4 = {0, 0, 0, 0};
+            double areg[16];
+            if (!getenv_dk_nomfma) {
+#pragma unroll
+                for (int ks = 0; ks < 16; ++ks) {
+                    const int c = (lane & 15) + 48 - 4 * ks - (lane >> 4);
+                    areg[ks] = (c >= 0 && c <= AR) ? ac[c] : 0.0;
+                }
+            }
+            auto detect_range_mfma = [&](int ia, int ib) {
+                const double *sj = sbuf - sb;
+                const int lo = ia - AR;
+                const int len = ib - ia;
+                const int R = ((len + 15) >> 4) | 1;
+                const int lpos = ia - 48 + (lane >> 4) + R * (lane & 15);
+                for (int i0 = 0; i0 < R; i0 += 32) {
+                    dk_d4 C0 = zero4, C1 = zero4;
+                    const bool two = i0 + 16 < R;
+#pragma unroll
+                    for (int ks = 0; ks < 16; ++ks) {
+                        int p0 = lpos + i0 + 4 * ks; p0 = p0 < lo ? lo : p0;
+                        int p1 = lpos + i0 + 16 + 4 * ks; p1 = p1 < lo ? lo : p1;
+                        const double b0v = sj[p0];
+                        const double b1v = two ? sj[p1] : 0.0;
+                        C0 = __builtin_amdgcn_mfma_f64_16x16x4f64(areg[ks], b0v, C0, 0, 0, 0);
+                        C1 = __builtin_amdgcn_mfma_f64_16x16x4f64(areg[ks], b1v, C1, 0, 0, 0);
+                    }
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        const dk_d4 C = h ? C1 : C0;
+                        const int ib0 = i0 + 16 * h + (lane >> 4);                 // row of register 0; register r is row ib0 + 4 r
+                        const int n0 = ia + ib0 + R * (lane & 15);
+                        unsigned m = 0;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) m |= (fabs(C[r]) > thr && ib0 + 4 * r < R && n0 + 4 * r < ib) ? (1u << (4 * r)) : 0u;
+                        if (m) {
+                            const int w0 = n0 >> 6, sh = n0 & 63;
+                            atomicOr(&obits[w0], (unsigned long long)m << sh);
+                            if (sh + 13 > 64 && (m >> (64 - sh))) atomicOr(&obits[w0 + 1], (unsigned long long)(m >> (64 - sh)));
+                        }
+                    }
+                }
+            };
             if (HALF) {
                 // outputs [AR, W) split in two equal ranges; the upper one is served by buffer B (loaded), the lower one by buffer A
                 int dsp = AR + (W - AR + 1) / 2;
                 dsp = dsp < SPLIT ? SPLIT : dsp;                           // buffer B holds sample dsp - AR onwards
-                detect_range(dsp, W); load_buf(0); detect_range(AR, dsp);
-            } else detect_range(AR, W);
+                if (getenv_dk_nomfma) { detect_range(dsp, W); load_buf(0); detect_range(AR, dsp); }
+                else { detect_range_mfma(dsp, W); load_buf(0); detect_range_mfma(AR, dsp); }
+            } else if (getenv_dk_nomfma) detect_range(AR, W);
+            else detect_range_mfma(AR, W);
             __builtin_amdgcn_wave_barrier();
             // ---- 5./6. burst fusion, borders, index list (as k_adeclick: integer work)
             for (int wd0 = 0; wd0 < nword; wd0 += 64) {
@@ -854,7 +940,7 @@ k_adeclick_fast(const double *__restrict__ in, double *__restrict__ out, int64_t
             for (int t = lane; t < ND * NC; t += 64) {
                 const int dgi = t / NC, i = t & CM;
                 const int dlt = (int)index[i + dgi] - (int)index[i];
-                blk[t] = aux[dlt < AR + 1 ? dlt : AR + 1];
+                blk[dgi * NCP + i] = aux[dlt < AR + 1 ? dlt : AR + 1];
             }
             if (lane < NC) yring[lane] = lane < F ? dk_ld(&gV[lane]) : 0.0;
             // right-hand sides of the rows about to enter the ring: 64 at a time through LDS (ac[] is dead).  A global load inside the
@@ -863,8 +949,8 @@ k_adeclick_fast(const double *__restrict__ in, double *__restrict__ out, int64_t
             int vbase = NC;
             vstage[lane] = (vbase + lane < F) ? dk_ld(&gV[vbase + lane]) : 0.0;
             const int dgl = lane < ND ? lane : ND - 1;                // this lane's diagonal of the pivot column
-            double *colp = blk + dgl * NC;
-            double *pairp = blk + (a0 - b0) * NC;                      // diagonal of this lane's trailing pair
+            double *colp = blk + dgl * NCP;
+            double *pairp = blk + (a0 - b0) * NCP;                      // diagonal of this lane's trailing pair
             int a1, b1, a2, b2;                                         // pairs lane + 64 and lane + 128 (bands of 11 .. 18 rows)
             {
                 auto unrank = [](int t, int &a, int &b) {
@@ -876,7 +962,7 @@ k_adeclick_fast(const double *__restrict__ in, double *__restrict__ out, int64_t
                 if (a1 - b1 >= ND) { a1 = b1 = 0; }                      // (never taken for ND >= 20; keeps the pointers inside the ring)
                 if (a2 - b2 >= ND) { a2 = b2 = 0; }
             }
-            double *pairp1 = blk + (a1 - b1) * NC, *pairp2 = blk + (a2 - b2) * NC;
+            double *pairp1 = blk + (a1 - b1) * NCP, *pairp2 = blk + (a2 - b2) * NCP;
             // packed factor stream in global scratch: per pivot k the bw multipliers of its column (rows k+1 .. k+bw), then y_k / d_k
             unsigned goff = 0;
             __builtin_amdgcn_wave_barrier();
@@ -937,7 +1023,7 @@ k_adeclick_fast(const double *__restrict__ in, double *__restrict__ out, int64_t
                         __builtin_amdgcn_wave_barrier();
                         for (int t = lane + 192; t < npairs; t += 64) {
                             const int ab = pairtab[t], a = ab & 0xff, b = ab >> 8;
-                            double *e = blk + (a - b) * NC + ((k + 1 + b) & CM);
+                            double *e = blk + (a - b) * NCP + ((k + 1 + b) & CM);
                             *e = __fma_rn(-cvec[b + 1], lvec[a + 1], *e);
                         }
                     }
@@ -1010,18 +1096,6 @@ k_adeclick_fast(const double *__restrict__ in, double *__restrict__ out, int64_t
             }
         }
         DKF_MARK(6)
-        const bool rep = F > 0 && ok;
-        for (int j0 = lane; j0 < P.hop; j0 += 64 * 8) {
-            double t[8]; bool wr[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int j = j0 + 64 * u, pos = P.skip + j; const int64_t o = o0 + j, p = s0 + pos;
-                wr[u] = j < P.hop && o < n && !(rep && fbit(pos));
-                t[u] = (wr[u] && p >= 0 && p < n) ? in[p] : 0.0;
-            }
-#pragma unroll
-            for (int u = 0; u < 8; ++u) if (wr[u]) out[o0 + j0 + 64 * u] = __dmul_rn(t[u], P.gain);
-        }
         __builtin_amdgcn_wave_barrier();
     }
     if (lane == 0 && (repaired || singular)) { atomicAdd(&stats[0], repaired); atomicAdd(&stats[1], singular); }
@@ -1081,7 +1155,7 @@ void launch_adeclick(jt_ctx *h, const double *in, double *out, int64_t n, int sa
             return sizeof(double) * (size_t)(sa + 50 + 64 + 50 + 50 + 50 + nc) + sizeof(unsigned long long) * 2 * (size_t)P.nw +
                    2 * (size_t)(fcap + nc + nd) + (size_t)fcap + 2 * (size_t)std::max(0, nd * (nd - 1) / 2 - 64) + 16;
         };
-        const int fa0 = sa_fast(half_ok, NC0 * ND0), fa1 = sa_fast(half_ok, NC1 * ND1), fa2 = sa_fast(false, NC1 * ND1);
+        const int fa0 = sa_fast(half_ok, 41 * ND0), fa1 = sa_fast(half_ok, (NC1 + 1) * ND1), fa2 = sa_fast(false, (NC1 + 1) * ND1);
         const size_t fm0 = smem_fast(fa0, LIGHT, NC0, ND0), fm1 = smem_fast(fa1, MID, NC1, ND1), fm2 = smem_fast(fa2, dk::MAXW, NC1, ND1);
         JT_REQUIRE(fm2 <= 64 * 1024, JT_E_UNSUPPORTED, "adeclick: window does not fit the per-wave LDS budget");
         int v0 = (int)std::min<size_t>(12, (160 * 1024) / fm0);
