@@ -267,6 +267,12 @@ double jt_host_level_variance(const jt_interval *iv, int64_t n, int axis /* 0 mo
 /* findBestSpeechRegion (:216): returns the number of candidates written (<= cap) and the elected region, or -1 when nothing is elected */
 int    jt_host_find_best_speech_region(const jt_region *regions, int n_regions, const jt_interval *iv, int64_t n_iv,
                                        int has_noise_profile, double noise_floor_db, jt_region *best, jt_speech_candidate *cands, int cap);
+/* the steps inside the election, as the reference table-tests them (analyser_test.go:264-1026) */
+int64_t jt_host_intervals_in_range(const jt_interval *iv, int64_t n, int64_t start_ns, int64_t end_ns, jt_interval *out, int64_t cap);  /* getIntervalsInRange */
+double jt_host_score_interval_window(const jt_interval *iv, int64_t n);                                  /* scoreIntervalWindow */
+double jt_host_score_speech_interval_window(const jt_interval *iv, int64_t n);                           /* scoreSpeechIntervalWindow */
+int    jt_host_measure_speech_candidate(const jt_region *region, const jt_interval *iv, int64_t n, jt_speech_candidate *out);   /* measureSpeechCandidateFromIntervals; 0 = nil */
+int    jt_host_refine_golden_speech(const jt_region *cand, const jt_interval *iv, int64_t n, jt_region *out);                  /* refineToGoldenSpeechSubregion; 1 = refined */
 /* calculateFrameLevel (encoder.go:235-257): VU level of one s16 frame for ProgressUpdate.Level, dB clamped to [-70, 0] */
 double jt_host_frame_level_s16(const int16_t *pcm, int n);
 

@@ -1374,6 +1374,45 @@ extern "C" int jt_host_find_best_speech_region(const jt_region *regions, int n_r
     if (best) *best = r.best;
     return (int)r.cands.size();
 }
+// getIntervalsInRange (analyser_candidates_shared.go): intervals with start <= timestamp < end; returns the count, copies at most cap
+extern "C" int64_t jt_host_intervals_in_range(const jt_interval *ivp, int64_t n, int64_t start_ns, int64_t end_ns, jt_interval *out, int64_t cap)
+{
+    std::vector<jt_interval> iv(ivp, ivp + (n > 0 ? n : 0));
+    std::vector<jt_interval> r = getIntervalsInRange(iv, start_ns, end_ns);
+    for (size_t i = 0; i < r.size() && (int64_t)i < cap; ++i) out[i] = r[i];
+    return (int64_t)r.size();
+}
+// scoreIntervalWindow (room-tone refinement: mean RMS level, 0 for an empty window) and scoreSpeechIntervalWindow (golden speech window)
+extern "C" double jt_host_score_interval_window(const jt_interval *iv, int64_t n)
+{
+    if (n <= 0) return 0.0;
+    double s = 0; for (int64_t i = 0; i < n; ++i) s += iv[i].rms_level;
+    return s / (double)n;
+}
+extern "C" double jt_host_score_speech_interval_window(const jt_interval *iv, int64_t n)
+{
+    if (n <= 0) return 0.0;
+    ScoreSoA a; const size_t nc = (size_t)n;
+    a.kurt.resize(nc); a.flat.resize(nc); a.cent.resize(nc); a.rms.resize(nc); a.roll.resize(nc); a.flux.resize(nc);
+    for (size_t i = 0; i < nc; ++i) { a.kurt[i] = iv[i].spectral.kurtosis; a.flat[i] = iv[i].spectral.flatness; a.cent[i] = iv[i].spectral.centroid;
+                                      a.rms[i] = iv[i].rms_level; a.roll[i] = iv[i].spectral.rolloff; a.flux[i] = iv[i].spectral.flux; }
+    return scoreSpeechWindowSoA(a, 0, nc);
+}
+// measureSpeechCandidateFromIntervals: 0 when no interval lies in the region (the reference returns nil), 1 otherwise
+extern "C" int jt_host_measure_speech_candidate(const jt_region *region, const jt_interval *ivp, int64_t n, jt_speech_candidate *out)
+{
+    std::vector<jt_interval> iv(ivp, ivp + (n > 0 ? n : 0));
+    return measureSpeechCandidate(*region, iv, out) ? 1 : 0;
+}
+// refineToGoldenSpeechSubregion: the 60 s window of a longer region that scores best (first wins ties); *out = the candidate itself
+// when it is not longer than 60 s, has fewer than 30 s of intervals, or none.  Returns 1 when a sub-region was chosen, 0 when unchanged.
+extern "C" int jt_host_refine_golden_speech(const jt_region *cand, const jt_interval *ivp, int64_t n, jt_region *out)
+{
+    std::vector<jt_interval> iv(ivp, ivp + (n > 0 ? n : 0));
+    Refined r = refineToSubregion(cand->start_ns, cand->end_ns, cand->duration_ns, iv, 60 * kSecond, 30 * kSecond, true);
+    out->start_ns = r.start; out->end_ns = r.end; out->duration_ns = r.duration;
+    return r.ok ? 1 : 0;
+}
 // calculateFrameLevel (encoder.go:235-257): the VU level the progress callback carries -- 20 log10(rms) of one s16 frame, clamped
 // to [-70, 0]; an empty or all-zero frame reads -70.
 extern "C" double jt_host_frame_level_s16(const int16_t *pcm, int n)

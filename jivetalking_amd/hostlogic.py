@@ -116,7 +116,8 @@ HOST_SYMBOLS = ["jt_host_build_intervals", "jt_host_detect", "jt_host_finish_mea
                 "jt_host_lufs_filename_value", "jt_host_output_path", "jt_process_audio_cb", "jt_process_file", "jt_process_files",
                 "jt_host_test_inject_fault", "jt_process_files_multi",
                 "jt_host_score_speech_candidate", "jt_host_level_variance", "jt_host_find_best_speech_region", "jt_host_frame_level_s16", "jt_process_audio_ticks",
-                "jt_host_run_record_json", "jt_host_intervals_jsonl", "jt_host_last_intervals", "jt_host_candidates_jsonl", "jt_host_loudnorm_json"]
+                "jt_host_run_record_json", "jt_host_intervals_jsonl", "jt_host_last_intervals", "jt_host_candidates_jsonl", "jt_host_intervals_in_range",
+                "jt_host_score_interval_window", "jt_host_score_speech_interval_window", "jt_host_measure_speech_candidate", "jt_host_refine_golden_speech", "jt_host_loudnorm_json"]
 
 
 def lib():
@@ -143,6 +144,10 @@ def lib():
     l.jt_host_run_record_json.restype = C.c_int64
     l.jt_host_intervals_jsonl.restype = C.c_int64
     l.jt_host_candidates_jsonl.restype = C.c_int64
+    l.jt_host_last_intervals.restype = C.c_int64
+    l.jt_host_intervals_in_range.restype = C.c_int64
+    l.jt_host_score_interval_window.restype = C.c_double
+    l.jt_host_score_speech_interval_window.restype = C.c_double
     return l
 
 

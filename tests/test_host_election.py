@@ -121,3 +121,163 @@ def test_frame_level_clamps_to_the_meter_range(db, want):
     got = H.lib().jt_host_frame_level_s16(pcm.ctypes.data_as(C.POINTER(C.c_int16)), C.c_int(1024))
     assert math.isfinite(got) and got >= -70.0 and abs(got - want) <= 0.5
     assert H.lib().jt_host_frame_level_s16(None, C.c_int(0)) == -70.0
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# analyser_test.go:264-1026 — the steps inside the election, case for case
+# ---------------------------------------------------------------------------------------------------------------------
+def rms_intervals(start_ns, rms_levels):
+    """makeTestIntervals (analyser_test.go:253-262)"""
+    return [dict(timestamp_ns=start_ns + i * HOP, rms_level=v) for i, v in enumerate(rms_levels)]
+
+
+def speech_intervals(count, rms):
+    """makeSpeechTestIntervals (analyser_test.go:390-406)"""
+    return [dict(timestamp_ns=i * HOP, rms_level=rms, centroid=1500.0, entropy=0.5) for i in range(count)]
+
+
+def scorable(start_ns, count, kurtosis, flatness, centroid, rms):
+    """makeSpeechIntervalsScorable (analyser_test.go:586-601): ideal rolloff, low flux"""
+    return [dict(timestamp_ns=start_ns + i * HOP, rms_level=rms, kurtosis=kurtosis, flatness=flatness, centroid=centroid, rolloff=6000.0, flux=0.003)
+            for i in range(count)]
+
+
+def in_range(rows, start, end):
+    iv = H.make_intervals(rows)
+    out = (H.Interval * max(1, len(rows)))()
+    n = H.lib().jt_host_intervals_in_range(iv, C.c_int64(len(rows)), C.c_int64(start), C.c_int64(end), out, C.c_int64(len(rows)))
+    return [out[i].timestamp_ns for i in range(n)]
+
+
+@pytest.mark.parametrize("start,end,count,first,last", [
+    (0, 20 * SEC, 80, 0, 19750 * 1_000_000),                  # full range
+    (5 * SEC, 15 * SEC, 40, 5 * SEC, 14750 * 1_000_000),      # middle range
+    (25 * SEC, 30 * SEC, 0, None, None),                      # no overlap - before
+    (0, 2 * SEC, 8, 0, 1750 * 1_000_000),                     # partial overlap at start
+])
+def test_get_intervals_in_range(start, end, count, first, last):
+    """TestGetIntervalsInRange (analyser_test.go:264-333)"""
+    H.lib().jt_host_intervals_in_range.restype = C.c_int64
+    got = in_range(rms_intervals(0, [0.0] * 80), start, end)
+    assert len(got) == count
+    if count:
+        assert got[0] == first and got[-1] == last
+
+
+@pytest.mark.parametrize("vals,want", [([-70, -70, -70, -70], -70.0), ([-60, -70, -80, -70], -70.0), ([-65.5], -65.5), ([], 0.0)])
+def test_score_interval_window(vals, want):
+    """TestScoreIntervalWindow (analyser_test.go:335-383)"""
+    H.lib().jt_host_score_interval_window.restype = C.c_double
+    rows = rms_intervals(0, vals)
+    iv = H.make_intervals(rows) if rows else None
+    assert abs(H.lib().jt_host_score_interval_window(iv, C.c_int64(len(rows))) - want) <= 0.001
+
+
+def test_measure_speech_candidate_from_intervals():
+    """TestMeasureSpeechCandidateFromIntervals (analyser_test.go:408-468)"""
+    rows = [dict(timestamp_ns=i * HOP, rms_level=-20.0, peak_level=-8.0, centroid=1500.0, flatness=0.3, kurtosis=5.0, entropy=0.5) for i in range(40)]
+    rows[20]["peak_level"] = -5.0
+    c = H.SpeechCandidate()
+    reg = H.Region(0, 10 * SEC, 10 * SEC)
+    assert H.lib().jt_host_measure_speech_candidate(C.byref(reg), H.make_intervals(rows), C.c_int64(40), C.byref(c)) == 1
+    assert c.sample.rms_level == -20.0 and c.sample.peak_level == -5.0 and c.sample.crest_factor == 15.0 and c.sample.spectral.centroid == 1500.0
+    far = H.Region(100 * SEC, 110 * SEC, 10 * SEC)                                       # "returns nil for empty range"
+    assert H.lib().jt_host_measure_speech_candidate(C.byref(far), H.make_intervals(speech_intervals(40, -20.0)), C.c_int64(40), C.byref(c)) == 0
+
+
+def elect_np(regions, rows):
+    """findBestSpeechRegion(regions, intervals, nil, nil): no noise profile (the SNR term saturates)"""
+    iv = H.make_intervals(rows)
+    rg = (H.Region * max(1, len(regions)))(*[H.Region(a, b, b - a) for a, b in regions])
+    best = H.Region(); cands = (H.SpeechCandidate * 8)()
+    n = H.lib().jt_host_find_best_speech_region(rg, C.c_int(len(regions)), iv, C.c_int64(len(rows)), C.c_int(0), C.c_double(0.0), C.byref(best), cands, C.c_int(8))
+    return n, best, cands
+
+
+def test_find_best_speech_region_basics():
+    """TestFindBestSpeechRegion (analyser_test.go:470-520)"""
+    rows = speech_intervals(400, -18.0)
+    n, best, _ = elect_np([(0, 35 * SEC), (40 * SEC, 90 * SEC), (95 * SEC, 100 * SEC)], rows)
+    assert n == 3 and best.start_ns == 0                       # the longer adequate run does not outrank the first adequate one
+    n, _, _ = elect_np([], speech_intervals(200, -18.0))
+    assert n == -1                                             # nil BestRegion for empty input
+    n, _, _ = elect_np([(0, 35 * SEC), (40 * SEC, 80 * SEC)], rows)
+    assert n == 2                                              # every candidate is kept for the report
+
+
+def test_find_best_all_below_min_score_falls_back():
+    """TestFindBestSpeechRegion_AllBelowMinAcceptableScoreFallsBack (analyser_test.go:522-580)"""
+    def short_run(start, dur, rms):
+        return [dict(timestamp_ns=start + i * HOP, rms_level=rms, momentary_lufs=rms, peak_level=rms + 10.0) for i in range(dur // HOP)]
+    rows = short_run(0, 10 * SEC, -33.0) + short_run(15 * SEC, 10 * SEC, -27.0)
+    n, best, cands = elect([(0, 10 * SEC), (15 * SEC, 25 * SEC)], rows, -35.0)
+    assert n == 2 and best.start_ns == 15 * SEC
+    assert all(cands[i].score < 0.3 for i in range(2)) and cands[1].score > cands[0].score
+
+
+def noisy_alternating():
+    rows = []
+    for i in range(40):
+        rows.append(dict(timestamp_ns=i * HOP, rms_level=-35.0, kurtosis=15.0 if i % 2 == 0 else 1.0, flatness=0.8, centroid=7000.0, rolloff=12000.0, flux=0.05))
+    return rows
+
+
+@pytest.mark.parametrize("rows,lo,hi", [
+    (scorable(0, 40, 6.0, 0.1, 2000.0, -15.0), 0.80, 1.0),          # continuous speech - high quality
+    (noisy_alternating(), 0.0, 0.40),                               # pause-heavy window with high variance
+    ([], 0.0, 0.0),                                                 # empty intervals
+    (scorable(0, 40, 2.0, 0.8, 7000.0, -32.0), 0.25, 0.50),         # low kurtosis (flat spectrum)
+    (scorable(0, 40, 6.0, 0.1, 4400.0, -15.0), 0.75, 0.95),         # centroid at edge of voice range
+    (scorable(0, 40, 6.0, 0.1, 2000.0, -28.0), 0.75, 0.90),         # quiet speech (low RMS)
+])
+def test_score_speech_interval_window(rows, lo, hi):
+    """TestScoreSpeechIntervalWindow (analyser_test.go:603-723)"""
+    H.lib().jt_host_score_speech_interval_window.restype = C.c_double
+    iv = H.make_intervals(rows) if rows else None
+    s = H.lib().jt_host_score_speech_interval_window(iv, C.c_int64(len(rows)))
+    assert lo <= s <= hi and 0.0 <= s <= 1.0
+
+
+def refine(cand, rows):
+    out = H.Region()
+    reg = H.Region(cand[0], cand[0] + cand[1], cand[1])
+    r = H.lib().jt_host_refine_golden_speech(C.byref(reg), H.make_intervals(rows), C.c_int64(len(rows)), C.byref(out))
+    return r, out
+
+
+@pytest.mark.parametrize("cand,rows,want_start,want_dur,unchanged", [
+    ((10 * SEC, 40 * SEC), scorable(10 * SEC, 160, 6.0, 0.1, 2000.0, -15.0), 10 * SEC, 40 * SEC, True),                   # short region
+    ((0, 120 * SEC), scorable(0, 480, 6.0, 0.1, 2000.0, -15.0), 0, 60 * SEC, False),                                     # uniform quality: first window
+    ((0, 120 * SEC), scorable(0, 240, 3.0, 0.5, 2000.0, -25.0) + scorable(60 * SEC, 240, 8.0, 0.08, 2000.0, -12.0), 60 * SEC, 60 * SEC, False),
+    ((0, 90 * SEC), scorable(0, 100, 6.0, 0.1, 2000.0, -15.0), 0, 90 * SEC, True),                                       # insufficient intervals
+    ((200 * SEC, 120 * SEC), scorable(0, 480, 6.0, 0.1, 2000.0, -15.0), 200 * SEC, 120 * SEC, True),                     # no intervals in range
+])
+def test_refine_to_golden_speech_subregion(cand, rows, want_start, want_dur, unchanged):
+    """TestRefineToGoldenSpeechSubregion (analyser_test.go:725-847); the nil-candidate case has no C counterpart (a pointer is required)"""
+    r, out = refine(cand, rows)
+    assert (r == 0) == unchanged
+    assert out.start_ns == want_start and out.duration_ns == want_dur
+
+
+def test_find_best_with_refinement():
+    """TestFindBestSpeechRegion_WithRefinement (analyser_test.go:849-964)"""
+    rows = scorable(0, 240, 4.0, 0.3, 2000.0, -20.0) + scorable(60 * SEC, 240, 7.0, 0.1, 2000.0, -14.0)
+    n, best, cands = elect_np([(0, 120 * SEC)], rows)
+    assert n == 1 and cands[0].was_refined and cands[0].original_start_ns == 0 and cands[0].original_duration_ns == 120 * SEC
+    assert cands[0].region.duration_ns <= 60 * SEC
+    n, best, cands = elect_np([(0, 45 * SEC)], scorable(0, 180, 6.0, 0.1, 2000.0, -15.0))
+    assert n == 1 and not cands[0].was_refined and best.duration_ns == 45 * SEC
+    rows = scorable(0, 120, 2.0, 0.6, 3500.0, -28.0) + scorable(30 * SEC, 240, 8.0, 0.05, 2000.0, -12.0) + scorable(90 * SEC, 120, 2.0, 0.6, 3500.0, -28.0)
+    n, best, _ = elect_np([(0, 120 * SEC)], rows)
+    assert 30 * SEC <= best.start_ns <= 60 * SEC and best.duration_ns == 60 * SEC
+
+
+def test_find_best_snr_margin():
+    """TestFindBestSpeechRegion_SNRMarginCheck (analyser_test.go:966-1026)"""
+    rows = scorable(0, 140, 6.0, 0.1, 1500.0, -20.0)
+    _, _, wide = elect([(0, 35 * SEC)], rows, -55.0)
+    _, _, narrow = elect([(0, 35 * SEC)], rows, -30.0)
+    assert narrow[0].score < wide[0].score
+    _, _, nil_profile = elect_np([(0, 35 * SEC)], rows)
+    _, _, finite = elect([(0, 35 * SEC)], rows, -40.0)
+    assert nil_profile[0].score >= finite[0].score
