@@ -208,7 +208,9 @@ typedef struct {              /* loudnorm second pass options (normalise.go:1269
 /* ---- Pass 4: replaces applyLoudnormAndMeasure's sweep (normalise.go:924-1190) over
  * buildLoudnormFilterSpec() (normalise.go:1231-1334; golden normalise_test.go:2135-2223):
  * [volume,alimiter,]loudnorm(linear),aresample,adeclick,alimiter(brickwall),astats,aspectralstats,
- * ebur128,aformat(s16).  Leaves the final s16 on device as stage 4. */
+ * ebur128,aformat(s16).  Leaves the final s16 on device as stage 4.  When the second-pass values do not satisfy af_loudnorm's
+ * init() (a measured value missing / 0, projected peak above TP, measured LRA above LRA) the filter's dynamic mode runs instead
+ * (192 kHz, k_loudnorm.hip) and stats->normalization_type_dynamic = 1, as the reference's stats file would say. */
 int jt_pass4(jt_ctx *h, const jt_limiter_plan *lim, const jt_loudnorm_apply *ap,
              jt_analysis *out, jt_loudnorm_stats *stats);
 
@@ -286,6 +288,11 @@ int jt_op_afftdn_tn_f32(jt_ctx *h, const float *in, float *out, int64_t n, int s
 int jt_op_dynamics(jt_ctx *h, const float *in, float *out, int64_t n, int sample_rate, const jt_filter_params *p);
 int jt_op_alimiter_f64(jt_ctx *h, const double *in, double *out, int64_t n, int sample_rate,
                        double limit, double attack_ms, double release_ms);
+/* loudnorm's DYNAMIC mode (af_loudnorm.c) on a mono stream already at the filter's internal 192 kHz: what jt_pass4 runs, between an
+ * up- and a down-resample, when the second-pass preconditions fail (measured LRA above the LRA target, a measured value missing or
+ * printed as 0.00: the reference's "fell back to dynamic" case, normalise.go:687-693).  ap: I / TP / LRA, measured_*, offset (dB) as in
+ * the filter's options; the adeclick / brickwall fields are ignored.  Shorter than 3 s: the filter's own one-gain branch. */
+int jt_op_loudnorm_dynamic_f64(jt_ctx *h, const double *in192, int64_t n, const jt_loudnorm_apply *ap, double *out192, jt_loudnorm_stats *stats);
 /* adeclick=t:w:o[:m=s] on a double stream (af_adeclick.c; arorder=2, burst=2 defaults).  method: 1 = overlap-save. */
 int jt_op_adeclick_f64(jt_ctx *h, const double *in, double *out, int64_t n, int sr, double threshold, double window_ms,
                        double overlap_pct, int method, int64_t *n_repaired);

@@ -122,7 +122,7 @@ SYMBOLS = [
     "jt_output_len", "jt_download_s16", "jt_output_frame_levels", "jt_flac_encode", "jt_op_flac_encode_s16", "jt_get_timers",
     "jt_op_biquad_f32", "jt_op_anlmdn_f32", "jt_op_afftdn_f32", "jt_op_afftdn_tn_f32", "jt_op_dynamics", "jt_op_alimiter_f64", "jt_op_adeclick_f64",
     "jt_op_resample_f32_to_s16", "jt_op_ebur128", "jt_op_astats", "jt_op_aspectralstats",
-    "jt_op_loudnorm_measure_s16",
+    "jt_op_loudnorm_measure_s16", "jt_op_loudnorm_dynamic_f64",
 ]
 
 

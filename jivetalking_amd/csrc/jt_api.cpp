@@ -666,6 +666,15 @@ static void spec_pass2_start(jt_ctx *h, const jt_filter_params *p)
     sp.pending = true;
 }
 
+// af_loudnorm's flush frame re-enters filter_frame(), whose first statement feeds the frame to the INPUT meter: the last 2.9 s of a
+// stream of 3 s or more are metered twice (libavfilter/af_loudnorm.c: flush_frame -> filter_frame -> ff_ebur128_add_frames_double).
+// The measurement streams therefore carry a copy of their last 556 800 samples behind the end.
+static int64_t loudnorm_meter_len(int64_t m_total) { return m_total >= 576000 ? m_total + 556800 : m_total; }
+template <typename T> static void loudnorm_append_flush(T *stream, int64_t m_total, hipStream_t st)
+{
+    if (m_total >= 576000) JT_HIP(hipMemcpyAsync(stream + m_total, stream + (m_total - 556800), (size_t)556800 * sizeof(T), hipMemcpyDeviceToDevice, st));
+}
+
 // Pass 3 for a plan without limiter prefix (loudnorm's first-pass measurement of the s16 output: swr -> 192 kHz, K-weighting,
 // 100 ms block energies), queued behind the output stage on a stream that Pass 2 does not wait for.  Scratch and result buffers
 // of its own: the pass arenas are recycled by the next pass_begin.
@@ -676,7 +685,8 @@ static void spec_loudnorm_enqueue(jt_ctx *h, const int16_t *s16, int64_t n, int 
     SwrDev &sw = get_swr(h, rate, 192000);
     const int64_t m_total = sw.out_len(n);
     const int blk = (192000 + 5) / 10;
-    size_t dev_d = 0, pin_d = 0; jt_kweight_scratch_sizes(m_total, blk, &dev_d, &pin_d);
+    const int64_t m_meter = loudnorm_meter_len(m_total);
+    size_t dev_d = 0, pin_d = 0; jt_kweight_scratch_sizes(m_meter, blk, &dev_d, &pin_d);
     S.dev.ensure(dev_d);
     if (pin_d > S.pin_cap) {
         if (S.pin) JT_HIP(hipHostFree(S.pin));
@@ -684,14 +694,15 @@ static void spec_loudnorm_enqueue(jt_ctx *h, const int16_t *s16, int64_t n, int 
         JT_HIP(hipHostMalloc((void **)&S.pin, sizeof(double) * pin_d, hipHostMallocDefault));
         S.pin_cap = pin_d;
     }
-    h->stream_f.ensure((size_t)m_total);
+    h->stream_f.ensure((size_t)m_meter);
     JT_HIP(hipEventRecord(S.fork, h->stream));
     JT_HIP(hipStreamWaitEvent(S.stream, S.fork, 0));
     launch_resample_stream_s16_f32(s16, n, sw.bank_f.p, sw.bank_fs.p, sw.pl.phase_count, sw.pl.filter_length, sw.pl.center, sw.pl.step, m_total,
                                    h->stream_f.p, S.stream);
     const KwScratch ext{S.dev.p, S.pin};
-    jt_kweight_enqueue_f32(h, h->stream_f.p, m_total, 192000, blk, &S.kw, S.stream, &ext);
-    S.blk = blk; S.nfull = m_total / blk; S.pending = true;
+    loudnorm_append_flush(h->stream_f.p, m_total, S.stream);
+    jt_kweight_enqueue_f32(h, h->stream_f.p, m_meter, 192000, blk, &S.kw, S.stream, &ext);
+    S.blk = blk; S.nfull = m_meter / blk; S.pending = true;
 }
 
 extern "C" int jt_pass2(jt_ctx *h, const jt_filter_params *p, jt_analysis *out)
@@ -815,15 +826,18 @@ static void loudnorm_measure_enqueue(jt_ctx *h, const int16_t *s16, const double
     SwrDev &sw = get_swr(h, rate, 192000);
     const int64_t m_total = sw.out_len(n);
     const int blk = (192000 + 5) / 10;
-    J->blk = blk; J->nfull = m_total / blk;
+    const int64_t m_meter = loudnorm_meter_len(m_total);
+    J->blk = blk; J->nfull = m_meter / blk;
     if (s16) {
-        h->stream_f.ensure((size_t)m_total);
+        h->stream_f.ensure((size_t)m_meter);
         launch_resample_stream_s16_f32(s16, n, sw.bank_f.p, sw.bank_fs.p, sw.pl.phase_count, sw.pl.filter_length, sw.pl.center, sw.pl.step, m_total, h->stream_f.p, h->stream);
-        jt_kweight_enqueue_f32(h, h->stream_f.p, m_total, 192000, blk, &J->kw, h->stream);
+        loudnorm_append_flush(h->stream_f.p, m_total, h->stream);
+        jt_kweight_enqueue_f32(h, h->stream_f.p, m_meter, 192000, blk, &J->kw, h->stream);
     } else {
-        h->stream_d.ensure((size_t)m_total);
+        h->stream_d.ensure((size_t)m_meter);
         launch_resample_stream_f64(f64, n, sw.bank_d.p, sw.pl.phase_count, sw.pl.filter_length, sw.pl.center, sw.pl.step, m_total, h->stream_d.p, h->stream);
-        jt_kweight_enqueue_f64(h, h->stream_d.p, m_total, 192000, blk, &J->kw, h->stream);
+        loudnorm_append_flush(h->stream_d.p, m_total, h->stream);
+        jt_kweight_enqueue_f64(h, h->stream_d.p, m_meter, 192000, blk, &J->kw, h->stream);
     }
 }
 static void loudnorm_measure_finish(const LoudnormJob &J, jt_loudnorm_stats *out)
@@ -850,7 +864,7 @@ static void pass3_core(jt_ctx *h, const int16_t *s16, int64_t m, int rate, const
             return;
         }
     }
-    pass_begin(h, m * 192000 / rate + 1024, 1);
+    pass_begin(h, m * 192000 / rate + 600000, 1);
     LoudnormJob J;
     if (lim && lim->needed) {
         h->f64_a.ensure((size_t)m); h->f64_b.ensure((size_t)m);
@@ -882,6 +896,97 @@ extern "C" int jt_pass3(jt_ctx *h, const jt_limiter_plan *lim, double target_i, 
     JT_API_END(h)
 }
 
+// ---------------------------------------------------------------- loudnorm, dynamic mode (af_loudnorm.c; k_loudnorm.hip)
+// x: the stream at 192 kHz on the device with room for m + 576000 more doubles behind it; y: m doubles.  Synchronises the stream.
+struct LoudnormDynIn { double target_i, target_lra, target_tp, measured_i, measured_lra, measured_tp, measured_thresh, offset; bool linear, dual_mono; };
+static void loudnorm_dynamic_run(jt_ctx *h, double *x, int64_t m, const LoudnormDynIn &in, double *y, jt_loudnorm_stats *st)
+{
+    constexpr int F100 = 19200, F3000 = 576000, LBS = 40320, FINAL = F3000 - F100;
+    hipStream_t s = h->stream;
+    const double ch = in.dual_mono ? 2.0 : 1.0;
+    const double target_tp_lin = std::pow(10., in.target_tp / 20.);
+    auto finish_stats = [&](const std::vector<double> &bs_in, int64_t nfull_in, double pk_in, bool dynamic) {
+        KwJob oj; jt_kweight_enqueue_f64(h, y, m, 192000, F100, &oj, s);
+        JT_HIP(hipStreamSynchronize(s));
+        std::vector<double> bo, po; jt_kweight_finish(&oj, bo, po);
+        const int64_t nfo = m / F100;
+        double pko = 0; for (int64_t k = 0; k <= nfo; ++k) pko = std::max(pko, po[(size_t)k]);
+        if (st) {
+            jt_loudnorm_finish(bs_in.data(), nfull_in, F100, in.dual_mono, 1.0, &st->input_i, &st->input_lra, &st->input_thresh);
+            jt_loudnorm_finish(bo.data(), nfo, F100, in.dual_mono, 1.0, &st->output_i, &st->output_lra, &st->output_thresh);
+            st->input_tp = 20 * std::log10(pk_in); st->output_tp = 20 * std::log10(pko);
+            st->target_offset = in.target_i - st->output_i;
+            st->normalization_type_dynamic = dynamic ? 1 : 0;
+        }
+    };
+    if (m < F3000) {
+        // shorter than the 3 s the first frame asks for: the filter measures what it got and applies one gain (frame_type LINEAR_MODE)
+        KwJob ij; jt_kweight_enqueue_f64(h, x, m, 192000, F100, &ij, s);
+        JT_HIP(hipStreamSynchronize(s));
+        std::vector<double> bs, pk; jt_kweight_finish(&ij, bs, pk);
+        const int64_t nf = m / F100;
+        double peak = 0; for (int64_t k = 0; k <= nf; ++k) peak = std::max(peak, pk[(size_t)k]);
+        double gi, gl, gt; jt_loudnorm_finish(bs.data(), nf, F100, in.dual_mono, 1.0, &gi, &gl, &gt);
+        const double offset = std::pow(10., (in.target_i - gi) / 20.);
+        const double offset_tp = peak * offset;
+        const double g = offset_tp < target_tp_lin ? offset : target_tp_lin - peak;
+        launch_scale_f64(x, y, m, g, s);
+        finish_stats(bs, nf, peak, false);
+        return;
+    }
+    // input meter over the stream followed by its last 2.9 s again (the filter's flush frame passes through r128_in a second time)
+    JT_HIP(hipMemcpyAsync(x + m, x + (m - FINAL), (size_t)FINAL * sizeof(double), hipMemcpyDeviceToDevice, s));
+    const int64_t m_ext = m + FINAL;
+    KwJob ij; jt_kweight_enqueue_f64(h, x, m_ext, 192000, F100, &ij, s);
+    const int64_t rem = (m - F3000) % F100;
+    KwJob pj; const int64_t pad = rem ? F100 - rem : 0;
+    if (rem) {      // a trailing partial frame: its short-term window is not on block boundaries; measure a copy shifted so that it is
+        JT_HIP(hipMemsetAsync(y, 0, (size_t)pad * sizeof(double), s));
+        JT_HIP(hipMemcpyAsync(y + pad, x, (size_t)m * sizeof(double), hipMemcpyDeviceToDevice, s));
+        jt_kweight_enqueue_f64(h, y, m + pad, 192000, F100, &pj, s);
+    }
+    JT_HIP(hipStreamSynchronize(s));
+    std::vector<double> bs, pk; jt_kweight_finish(&ij, bs, pk);
+    const int64_t nfull_x = m / F100, nfull_ext = m_ext / F100;
+    double peak = 0; for (int64_t k = 0; k <= nfull_x; ++k) peak = std::max(peak, pk[(size_t)k]);
+    // per-frame series of the input meter: histogram gating as ebur128.c keeps it, updated block by block
+    const int64_t n_inner = (m - F3000 + F100 - 1) / F100;
+    std::vector<double> series((size_t)std::max<int64_t>(1, n_inner) * 3);
+    jt_loudnorm_series(bs.data(), nfull_x, F100, in.dual_mono, n_inner, series.data());
+    if (rem) {
+        std::vector<double> b2, p2; jt_kweight_finish(&pj, b2, p2);
+        const int64_t nb2 = (m + pad) / F100;
+        double e = 0; for (int q = 29; q >= 0; --q) e += b2[(size_t)(nb2 - 1 - q)];
+        e = e * ch / (double)F3000;
+        series[(size_t)(n_inner - 1) * 3] = e <= 0.0 ? -HUGE_VAL : 10 * (std::log(e) / std::log(10.0)) - 0.691;
+    }
+    LoudnormDynParams P; std::memset(&P, 0, sizeof(P));
+    P.target_i = in.target_i; P.target_lra = in.target_lra; P.target_tp_lin = target_tp_lin; P.measured_thresh = in.measured_thresh;
+    P.offset_lin = std::pow(10., in.offset / 20.);
+    {
+        double e = 0; for (int q = 0; q < 30; ++q) e += bs[(size_t)q];
+        e = e * ch / (double)F3000;
+        const double shortterm = e <= 0.0 ? -HUGE_VAL : 10 * (std::log(e) / std::log(10.0)) - 0.691;
+        double env;
+        if (shortterm < in.measured_thresh) { P.above0 = 0; env = shortterm <= -70. ? 0. : in.target_i - in.measured_i; }
+        else { P.above0 = 1; env = shortterm <= -70. ? 0. : in.target_i - shortterm; }
+        P.delta0 = std::pow(10., env / 20.);
+    }
+    {
+        double total = 0.0; const double sigma = 3.5, c1 = 1.0 / (sigma * std::sqrt(2.0 * M_PI)), c2 = 2.0 * std::pow(sigma, 2.0);
+        for (int i = 0; i < 21; i++) { const int xx = i - 10; P.weights[i] = c1 * std::exp(-(std::pow(xx, 2.0) / c2)); total += P.weights[i]; }
+        const double adjust = 1.0 / total;
+        for (int i = 0; i < 21; i++) P.weights[i] *= adjust;
+    }
+    jt_kweight_coeffs5(192000, P.kwb, P.kwa);
+    P.dual_mono = in.dual_mono ? 1 : 0; P.n_inner = n_inner; P.final_len = FINAL;
+    h->ln_ring.ensure(LBS); h->ln_series.ensure(series.size());
+    JT_HIP(hipMemcpyAsync(h->ln_series.p, series.data(), series.size() * sizeof(double), hipMemcpyHostToDevice, s));
+    launch_loudnorm_dynamic(x, m, P, h->ln_series.p, h->ln_ring.p, y, nullptr, s);
+    JT_HIP(hipGetLastError());
+    finish_stats(bs, nfull_ext, peak, true);
+}
+
 // ---------------------------------------------------------------- Pass 4
 extern "C" int jt_pass4(jt_ctx *h, const jt_limiter_plan *lim, const jt_loudnorm_apply *ap, jt_analysis *out, jt_loudnorm_stats *stats)
 {
@@ -897,13 +1002,16 @@ extern "C" int jt_pass4(jt_ctx *h, const jt_limiter_plan *lim, const jt_loudnorm
     const double offset_tp = ap->measured_tp + offset_db;
     const bool linear = (ap->measured_tp != 99 && ap->measured_thresh != -70 && ap->measured_lra != 0 && ap->measured_i != 0) &&
                         (offset_tp <= ap->target_tp) && (ap->measured_lra <= ap->target_lra);
-    JT_REQUIRE(linear, JT_E_UNSUPPORTED, "pass4: loudnorm would fall back to dynamic mode (not implemented on the GPU path)");
-    const double gain = std::pow(10., offset_db / 20.);
+    // not linear: the filter falls back to its dynamic mode at 192 kHz (the reference logs a warning and delivers the file,
+    // normalise.go:687-693); the gain then comes from loudnorm_dynamic_run below instead of one multiplication
+    const bool dyn = !linear;
+    const double gain = dyn ? 1.0 : std::pow(10., offset_db / 20.);
     h->timers.declick_ms = 0; h->timers.declick_repaired = 0;
     jt_ctx::RegionSlot &slot = h->region_slot[1];
     slot.valid = false;
     const bool announced = slot.armed; slot.armed = false;
-    pass_begin(h, m, 2, announced ? region_slot_samples(slot, rate) : 0, announced ? 2 : 0);
+    const int64_t m192 = dyn ? get_swr(h, rate, 192000).out_len(m) : 0;
+    pass_begin(h, dyn ? m192 + 700000 : m, dyn ? 6 : 2, announced ? region_slot_samples(slot, rate) : 0, announced ? 2 : 0);
     h->f64_a.ensure((size_t)m); h->f64_b.ensure((size_t)m);
     double *sig = h->f64_a.p, *tmp = h->f64_b.p;
     const bool pre = lim && lim->needed && lim->pre_gain_db > 0;
@@ -912,7 +1020,26 @@ extern "C" int jt_pass4(jt_ctx *h, const jt_limiter_plan *lim, const jt_loudnorm
     check_cancel(h);
     // loudnorm r128_in / r128_out statistics (libavfilter/ebur128.c) at the stream rate
     KwJob sj; const int sblk = (rate + 5) / 10;
-    if (stats) { fork_aux(h, 3, 3); jt_kweight_enqueue_f64(h, sig, m, rate, sblk, &sj, h->aux[3]); }   // joined with the analysis below
+    const bool stats_lin = stats && !dyn;
+    if (dyn) {
+        SwrDev &up = get_swr(h, rate, 192000);
+        h->stream_d.ensure((size_t)m192 + 576000 + 64); h->stream_y.ensure((size_t)m192 + 19200 + 64);
+        launch_resample_stream_f64(sig, m, up.bank_d.p, up.pl.phase_count, up.pl.filter_length, up.pl.center, up.pl.step, m192, h->stream_d.p, h->stream);
+        LoudnormDynIn din{ap->target_i, ap->target_lra, ap->target_tp, ap->measured_i, ap->measured_lra, ap->measured_tp, ap->measured_thresh,
+                          ap->offset, true, true};
+        jt_loudnorm_stats dst; std::memset(&dst, 0, sizeof(dst));
+        loudnorm_dynamic_run(h, h->stream_d.p, m192, din, h->stream_y.p, &dst);
+        if (stats) *stats = dst;
+        // the reference's own aresample back to the source rate (normalise.go:1293-1310); swr would deliver ceil(m192 * rate / 192000)
+        // samples, one more than m for some lengths: the pass keeps m
+        SwrDev &dn = get_swr(h, 192000, rate);
+        launch_swr_plain_f64(h->stream_y.p, m192, dn.bank_d.p, dn.pl.phase_count, dn.pl.filter_length, dn.pl.center, dn.pl.step,
+                             std::min<int64_t>(dn.out_len(m192), m), tmp, h->stream);
+        if (dn.out_len(m192) < m) JT_HIP(hipMemsetAsync(tmp + dn.out_len(m192), 0, (size_t)(m - dn.out_len(m192)) * sizeof(double), h->stream));
+        std::swap(sig, tmp);
+        check_cancel(h);
+    }
+    if (stats_lin) { fork_aux(h, 3, 3); jt_kweight_enqueue_f64(h, sig, m, rate, sblk, &sj, h->aux[3]); }   // joined with the analysis below
     // adeclick on the gained stream (af_adeclick.c), then the brickwall alimiter
     double brick_gain = gain;
     const unsigned long long *dk_stats = nullptr;
@@ -931,7 +1058,7 @@ extern "C" int jt_pass4(jt_ctx *h, const jt_limiter_plan *lim, const jt_loudnorm
         std::swap(sig, tmp);
         brick_gain = 1.0;
         // the brickwall writes the buffer the statistics job (aux stream 3) is still reading: join that chain first
-        if (stats) { JT_HIP(hipEventRecord(h->ev_join[3], h->aux[3])); JT_HIP(hipStreamWaitEvent(h->stream, h->ev_join[3], 0)); }
+        if (stats_lin) { JT_HIP(hipEventRecord(h->ev_join[3], h->aux[3])); JT_HIP(hipStreamWaitEvent(h->stream, h->ev_join[3], 0)); }
     }
     run_limiter(h, sig, tmp, m, rate, ap->brickwall_limit, 1.0, 50.0, brick_gain);
     std::swap(sig, tmp);
@@ -970,7 +1097,7 @@ extern "C" int jt_pass4(jt_ctx *h, const jt_limiter_plan *lim, const jt_loudnorm
     // finishes the output analysis
     std::exception_ptr stats_err;
     std::thread stats_thread;
-    if (stats) {
+    if (stats_lin) {
         stats_thread = std::thread([&]() {
             try {
                 const int64_t nfull = m / sblk;
@@ -1192,6 +1319,22 @@ extern "C" int jt_op_adeclick_f64(jt_ctx *h, const double *in, double *out, int6
     if (getenv("JT_DK_PROFILE")) { fprintf(stderr, "adeclick phase clocks:"); for (int i = 4; i < 12; ++i) fprintf(stderr, " %llu", st[i]); fprintf(stderr, " heavy %llu", st[2]); fprintf(stderr, "\n"); }
     if (n_repaired) *n_repaired = (int64_t)st[0];
     JT_REQUIRE(st[1] == 0, JT_E_HIP, "adeclick: singular interpolation matrix");
+    JT_API_END(h)
+}
+
+extern "C" int jt_op_loudnorm_dynamic_f64(jt_ctx *h, const double *in192, int64_t n, const jt_loudnorm_apply *ap, double *out192, jt_loudnorm_stats *stats)
+{
+    JT_API_BEGIN(h)
+    JT_REQUIRE(in192 && out192 && ap && n > 0, JT_E_INVAL, "op_loudnorm_dynamic: bad arguments");
+    pass_begin(h, n + 700000, 6);
+    h->stream_d.ensure((size_t)n + 576000 + 64); h->stream_y.ensure((size_t)n + 19200 + 64);
+    JT_HIP(hipMemcpyAsync(h->stream_d.p, in192, (size_t)n * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    LoudnormDynIn din{ap->target_i, ap->target_lra, ap->target_tp, ap->measured_i, ap->measured_lra, ap->measured_tp, ap->measured_thresh,
+                      ap->offset, true, true};
+    jt_loudnorm_stats st; std::memset(&st, 0, sizeof(st));
+    loudnorm_dynamic_run(h, h->stream_d.p, n, din, h->stream_y.p, &st);
+    if (stats) *stats = st;
+    d2h(h, out192, h->stream_y.p, (size_t)n);
     JT_API_END(h)
 }
 

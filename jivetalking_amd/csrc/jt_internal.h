@@ -136,6 +136,18 @@ void launch_anlmdn(const float *in, float *out, int64_t n, int K, int S, float s
 // adeclick (k_declick.hip)
 struct jt_ctx;
 bool jt_adeclick_supported(int sample_rate, double window_ms, double overlap_pct, double ar_pct, int method, std::string *why);
+// loudnorm, dynamic mode (k_loudnorm.hip): what the frame loop needs besides the stream and the per-frame series
+struct LoudnormDynParams {
+    double target_i, target_lra, target_tp_lin, measured_thresh, offset_lin, delta0;
+    double weights[21], kwb[5], kwa[5];
+    int above0, dual_mono;
+    int64_t n_inner; int final_len;
+};
+void jt_loudnorm_series(const double *bs, int64_t nfull, int64_t s100, bool dual_mono, int64_t n_inner, double *out);
+void jt_kweight_coeffs5(int sr, double b[5], double a[5]);
+void launch_loudnorm_dynamic(const double *x, int64_t n, const LoudnormDynParams &P, const double *series, double *ring, double *y, double *dbg, hipStream_t s);
+void launch_scale_f64(const double *in, double *out, int64_t n, double g, hipStream_t s);
+void launch_swr_plain_f64(const double *in, int64_t n, const double *bank, int P, int L, int center, int64_t step, int64_t m_total, double *out, hipStream_t s);
 void launch_adeclick(jt_ctx *h, const double *in, double *out, int64_t n, int sample_rate, double threshold, double window_ms,
                      double overlap_pct, double ar_pct, double burst, double gain, unsigned long long *d_stats, hipStream_t s);
 
@@ -237,6 +249,7 @@ struct jt_ctx {
     int64_t m_p2 = 0, m_p4 = 0; int out_rate = 0;
     DevBuf<double> f64_a, f64_b;        // f64 ping-pong at output rate
     DevBuf<float> stream_f; DevBuf<double> stream_d;   // 192 kHz loudnorm-measurement stream
+    DevBuf<double> stream_y, ln_ring, ln_series;       // loudnorm dynamic mode: output stream, limiter ring, per-frame series
     // scratch
     DevBuf<double> d_scr0, d_scr1, d_scr2, d_scr3;
     DevBuf<unsigned long long> ehist; DevBuf<float> as_g, as_p;

@@ -314,6 +314,66 @@ void jt_loudnorm_finish(const double *bs, int64_t nblocks, int64_t s100, bool du
     }
 }
 
+// Input-meter series for loudnorm's dynamic mode: after INNER frame k (k = 0 .. n_inner-1; frame k completes 100 ms block 30 + k
+// when it is a full frame) the short-term loudness (last 3 s), the gated integrated loudness and the relative threshold of everything
+// metered so far -- ff_ebur128_loudness_shortterm / _global / relative_threshold of r128_in (libavfilter/ebur128.c, histogram
+// gating).  out[3k .. 3k+2].  A trailing partial frame completes no block: its integrated / threshold values repeat the previous
+// frame's and its short-term entry is filled in by the caller from a shifted measurement.
+void jt_loudnorm_series(const double *bs, int64_t nfull, int64_t s100, bool dual_mono, int64_t n_inner, double *out)
+{
+    hist_init();
+    std::vector<unsigned long> bh(1000, 0);
+    const double ch = dual_mono ? 2.0 : 1.0;
+    double rel_sum = 0; long above = 0;
+    auto add_block = [&](int64_t k) {          // the 400 ms gating block that ends with 100 ms block k
+        if (k < 3 || k >= nfull) return;
+        const double sum = (bs[k - 3] + bs[k - 2] + bs[k - 1] + bs[k]) * ch / (double)(s100 * 4);
+        if (sum >= hist_b[0]) { const size_t j = hist_index(sum); ++bh[j]; rel_sum += hist_e[j]; ++above; }
+    };
+    for (int64_t k = 0; k < 30; ++k) add_block(k);
+    double g_prev = -HUGE_VAL, rt_prev = -70.0;
+    for (int64_t f = 0; f < n_inner; ++f) {
+        const int64_t k = 30 + f;
+        if (k < nfull) {
+            add_block(k);
+            double st = 0; for (int q = 29; q >= 0; --q) st += bs[k - q];
+            st = st * ch / (double)(s100 * 30);
+            out[3 * f] = st <= 0.0 ? -HUGE_VAL : e2l(st);
+            // the histogram sums are rebuilt in bin order, as ff_ebur128_relative_threshold / loudness_global walk them
+            double rel = 0; long cnt = 0;
+            for (int j = 0; j < 1000; ++j) { rel += bh[j] * hist_e[j]; cnt += (long)bh[j]; }
+            if (!cnt) { g_prev = -HUGE_VAL; rt_prev = -70.0; }
+            else {
+                rel = rel / (double)cnt * 0.1;
+                rt_prev = e2l(rel);
+                size_t stx;
+                if (rel < hist_b[0]) stx = 0; else { stx = hist_index(rel); if (rel > hist_e[stx]) ++stx; }
+                double g = 0; long c2 = 0;
+                for (size_t j = stx; j < 1000; ++j) { g += bh[j] * hist_e[j]; c2 += (long)bh[j]; }
+                g_prev = c2 ? e2l(g / (double)c2) : -HUGE_VAL;
+            }
+        } else out[3 * f] = -HUGE_VAL;         // (partial frame: the caller overwrites this)
+        out[3 * f + 1] = g_prev; out[3 * f + 2] = rt_prev;
+    }
+    (void)rel_sum; (void)above;
+}
+// ebur128_init_filter(): the two K-weighting biquads multiplied out into the 4th-order section the library runs
+void jt_kweight_coeffs5(int sr, double b[5], double a[5])
+{
+    BiquadF64 pre, rlb; jt_kweight_design(sr, &pre, &rlb);
+    const double pb[3] = {pre.b0, pre.b1, pre.b2}, pa[3] = {1.0, pre.a1, pre.a2}, rb[3] = {rlb.b0, rlb.b1, rlb.b2}, ra[3] = {1.0, rlb.a1, rlb.a2};
+    b[0] = pb[0] * rb[0];
+    b[1] = pb[0] * rb[1] + pb[1] * rb[0];
+    b[2] = pb[0] * rb[2] + pb[1] * rb[1] + pb[2] * rb[0];
+    b[3] = pb[1] * rb[2] + pb[2] * rb[1];
+    b[4] = pb[2] * rb[2];
+    a[0] = pa[0] * ra[0];
+    a[1] = pa[0] * ra[1] + pa[1] * ra[0];
+    a[2] = pa[0] * ra[2] + pa[1] * ra[1] + pa[2] * ra[0];
+    a[3] = pa[1] * ra[2] + pa[2] * ra[1];
+    a[4] = pa[2] * ra[2];
+}
+
 // ---------------------------------------------------------------- dynamics parameter derivation
 void jt_dyn_design(const jt_filter_params *p, int sr, DynParams *d)
 {

@@ -294,6 +294,16 @@ class Engine:
                 out[i, j] = getattr(hops[i], k)
         return out
 
+    def op_loudnorm_dynamic(self, x192, target_i=-16.0, target_lra=20.0, target_tp=-1.0, measured=None, offset=0.0):
+        """af_loudnorm's dynamic mode on a mono stream already at 192 kHz; measured = (I, LRA, TP, thresh) or None (first pass)."""
+        x = np.ascontiguousarray(x192, np.float64); y = np.empty_like(x)
+        mi, ml, mt, mth = measured if measured is not None else (0.0, 0.0, 99.0, -70.0)
+        ap = L.LoudnormApply(target_i, target_tp, target_lra, mi, mt, ml, mth, offset, 0, 0.0, 0.0, 0.0, 0, 1.0)
+        s = L.LoudnormStats()
+        self._ck(self.lib.jt_op_loudnorm_dynamic_f64(self.h, x.ctypes.data_as(C.POINTER(C.c_double)), C.c_int64(x.size), C.byref(ap),
+                                                     y.ctypes.data_as(C.POINTER(C.c_double)), C.byref(s)))
+        return y, _st2dict(s)
+
     def op_loudnorm_measure_s16(self, x, sr, limiter=None):
         x = np.ascontiguousarray(x, np.int16)
         s = L.LoudnormStats()

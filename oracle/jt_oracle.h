@@ -111,6 +111,19 @@ void orc_ebur128_mono(const double *in, int64_t n, int sample_rate, int dualmono
 typedef struct { double input_i, input_tp, input_lra, input_thresh; } orc_loudnorm_in;
 void orc_loudnorm_measure_mono(const double *in, int64_t n, int sample_rate, int dual_mono, orc_loudnorm_in *out);
 
+/* ---- loudnorm, dynamic mode (af_loudnorm.c) on a mono stream already at the filter's internal 192 kHz; `out` has room for n ---- */
+typedef struct {
+    double target_i, target_lra, target_tp;                            /* I=, LRA=, TP= (dB) */
+    double measured_i, measured_lra, measured_tp, measured_thresh;     /* 0 / 0 / 99 / -70 when not given (the filter's defaults) */
+    double offset;                                                     /* offset= (dB) */
+    int linear, dual_mono;
+} orc_loudnorm_params;
+typedef struct {
+    double input_i, input_tp, input_lra, input_thresh, output_i, output_tp, output_lra, output_thresh, target_offset;
+    int dynamic;                                                       /* normalization_type: 1 "dynamic", 0 "linear" */
+} orc_loudnorm_stats;
+int64_t orc_loudnorm_dynamic_mono(const double *in, int64_t n, int rate, const orc_loudnorm_params *p, double *out, orc_loudnorm_stats *st);
+
 /* ---- astats (af_astats.c) on mono, length=0.05 ---- */
 typedef struct {
     double dc_offset, min_level, max_level, min_difference, max_difference, mean_difference,

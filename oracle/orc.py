@@ -223,6 +223,30 @@ class LoudnormIn(C.Structure):
                 ("input_thresh", C.c_double)]
 
 
+class LoudnormParams(C.Structure):
+    _fields_ = [(k, C.c_double) for k in ("target_i", "target_lra", "target_tp", "measured_i", "measured_lra", "measured_tp", "measured_thresh", "offset")] + \
+               [("linear", C.c_int), ("dual_mono", C.c_int)]
+
+
+class LoudnormStats(C.Structure):
+    _fields_ = [(k, C.c_double) for k in ("input_i", "input_tp", "input_lra", "input_thresh", "output_i", "output_tp", "output_lra", "output_thresh",
+                                          "target_offset")] + [("dynamic", C.c_int)]
+
+
+def loudnorm_dynamic(x192, target_i=-16.0, target_lra=20.0, target_tp=-1.0, measured=None, offset=0.0, linear=True, dual_mono=True, rate=192000):
+    """af_loudnorm on a mono stream already at 192 kHz.  measured = (I, LRA, TP, thresh) or None (the filter's defaults: first pass).
+    Returns (output stream, stats dict)."""
+    x = np.ascontiguousarray(x192, np.float64)
+    y = np.zeros_like(x)
+    mi, ml, mt, mth = measured if measured is not None else (0.0, 0.0, 99.0, -70.0)
+    p = LoudnormParams(target_i, target_lra, target_tp, mi, ml, mt, mth, offset, int(linear), int(dual_mono))
+    st = LoudnormStats()
+    lib().orc_loudnorm_dynamic_mono.restype = C.c_int64
+    n = lib().orc_loudnorm_dynamic_mono(_p(x, C.c_double), C.c_int64(x.size), C.c_int(rate), C.byref(p), _p(y, C.c_double), C.byref(st))
+    assert n == x.size, (n, x.size)
+    return y, {k: getattr(st, k) for k, _ in LoudnormStats._fields_}
+
+
 def loudnorm_measure(x, sr, dual_mono=True):
     x = np.ascontiguousarray(x, np.float64)
     o = LoudnormIn()

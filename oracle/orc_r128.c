@@ -423,9 +423,15 @@ void orc_loudnorm_measure_mono(const double *in, int64_t n, int sample_rate, int
     double peak = 0;
     int64_t audio_index = 0, needed = s100 * 4, have = 0, st_counter = 0;
 
-    for (int64_t i = 0; i < n; i++) {
-        if (fabs(in[i]) > peak) peak = fabs(in[i]);
-        v[0] = in[i] - a[1] * v[1] - a[2] * v[2] - a[3] * v[3] - a[4] * v[4];
+    /* af_loudnorm.c: at EOF flush_frame() hands the last 2.9 s of the look-ahead buffer to filter_frame(), whose first statement is
+     * ff_ebur128_add_frames_double(r128_in, ...): a stream of 3 s or more is metered with its last 556 800 samples (at 192 kHz) twice */
+    const int64_t f3000 = (int64_t)llround(sample_rate * 3.0), fin = f3000 - (int64_t)llround(sample_rate * 0.1);
+    const int64_t n_meter = n >= f3000 ? n + fin : n;
+    for (int64_t ii = 0; ii < n_meter; ii++) {
+        const int64_t i_src = ii < n ? ii : n - fin + (ii - n);
+        const double x_in = in[i_src];
+        if (fabs(x_in) > peak) peak = fabs(x_in);
+        v[0] = x_in - a[1] * v[1] - a[2] * v[2] - a[3] * v[3] - a[4] * v[4];
         audio[audio_index] = b[0] * v[0] + b[1] * v[1] + b[2] * v[2] + b[3] * v[3] + b[4] * v[4];
         v[4] = v[3]; v[3] = v[2]; v[2] = v[1]; v[1] = v[0];
         /* libebur128 flushes denormals in v at the end of each add_frames call; values this small

@@ -340,3 +340,107 @@ def test_granular_call_sequence_equals_the_one_call_mirror(tmp_path):
     p = tmp_path / "in.f32"; x.astype("<f4").tofile(p)
     r = subprocess.run([exe, str(p), str(SR)], capture_output=True, text=True)
     assert r.returncode == 0 and "identical" in r.stdout, (r.returncode, r.stdout, r.stderr)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# loudnorm, dynamic mode: the fallback the reference only notices from the stats (normalise.go:687-693)
+# ---------------------------------------------------------------------------------------------------------------------
+def _stream192(seconds, seed, level=1.0):
+    from jivetalking_amd import synth
+    return synth.speech_like(seconds, 192000, seed=seed).astype(np.float64) * level
+
+
+def _ln_close(got, ref, gst, rst):
+    # same frame gains and limiter decisions; the input meter's sums run in a different order (chunked K-weighting scan): 1e-9 relative
+    assert got.shape == ref.shape
+    assert np.max(np.abs(got - ref)) <= 1e-9 * max(1.0, np.max(np.abs(ref))), np.max(np.abs(got - ref))
+    for k in ("input_i", "input_tp", "input_lra", "input_thresh", "output_i", "output_tp", "output_lra", "output_thresh", "target_offset"):
+        assert abs(gst[k] - rst[k]) < 1e-6, (k, gst[k], rst[k])
+
+
+@pytest.mark.gpu
+def test_loudnorm_dynamic_first_pass_matches_oracle(engine, oracle):
+    """No measured values (the filter's first pass): gains follow the input's short-term loudness; a hot signal keeps the
+    look-ahead limiter busy (attack / sustain / release all exercised: the output peaks sit on the ceiling)."""
+    x = _stream192(9.3, 31, 2.5)                       # a partial last frame (9.3 s is not a multiple of 100 ms at 192 kHz + resample lengths)
+    x = x[: x.size - 777]
+    ref, rst = oracle.loudnorm_dynamic(x, target_tp=-9.0)
+    got, gst = engine.op_loudnorm_dynamic(x, target_tp=-9.0)
+    assert rst["dynamic"] == 1 and gst["normalization_type_dynamic"] == 1
+    assert abs(np.max(np.abs(ref)) - 10 ** (-9 / 20)) < 1e-12          # the limiter worked: peaks sit on the -9 dB ceiling
+    _ln_close(got, ref, gst, rst)
+    ref, rst = oracle.loudnorm_dynamic(x)                              # and the default ceiling, which this signal stays under
+    got, gst = engine.op_loudnorm_dynamic(x)
+    _ln_close(got, ref, gst, rst)
+
+
+@pytest.mark.gpu
+def test_loudnorm_dynamic_quiet_start_and_second_pass(engine, oracle):
+    """A file that starts below the measured threshold: the gain ramps by 1.0058 per frame until the OUTPUT's short-term loudness
+    reaches the target (the one feedback path of the filter); second pass with measured values whose LRA exceeds the target."""
+    loud = _stream192(7.0, 32, 1.2)
+    x = np.concatenate([loud[: 192000 * 4] * 0.004, loud])
+    _, first = oracle.loudnorm_dynamic(x)
+    measured = (first["input_i"], 25.0, first["input_tp"], first["input_thresh"])       # LRA above the 20 LU target: not linear
+    ref, rst = oracle.loudnorm_dynamic(x, measured=measured, offset=0.37)
+    got, gst = engine.op_loudnorm_dynamic(x, measured=measured, offset=0.37)
+    assert rst["dynamic"] == 1
+    _ln_close(got, ref, gst, rst)
+    # exactly 3 s (no inner frame at all) and 3 s + one sample
+    for n in (576000, 576001, 576000 + 19200):
+        r2, s2 = oracle.loudnorm_dynamic(x[-n:])
+        g2, t2 = engine.op_loudnorm_dynamic(x[-n:])
+        _ln_close(g2, r2, t2, s2)
+
+
+@pytest.mark.gpu
+def test_loudnorm_dynamic_short_input_is_one_gain(engine, oracle):
+    """Shorter than the 3 s the first frame asks for: the filter measures what it got and applies a single gain (and reports
+    "linear")."""
+    x = _stream192(2.0, 33, 0.8)
+    ref, rst = oracle.loudnorm_dynamic(x)
+    got, gst = engine.op_loudnorm_dynamic(x)
+    assert rst["dynamic"] == 0 and gst["normalization_type_dynamic"] == 0
+    _ln_close(got, ref, gst, rst)
+    ratio = got[1000:1010] / x[1000:1010]
+    assert np.allclose(ratio, ratio[0], rtol=1e-12)
+
+
+@pytest.mark.gpu
+def test_pass4_falls_back_to_dynamic_loudnorm_like_the_filter(engine, oracle):
+    """jt_pass4 with second-pass values loudnorm rejects (measured LRA above the LRA target): up to 192 kHz, the dynamic filter, back to
+    the source rate, then adeclick, brickwall and s16 as usual -- against the same chain composed from the oracle's pieces."""
+    p2 = (synth.speech_like(6.5, 44100, seed=35) * 0.35 * 32767).astype(np.int16)
+    engine.upload_s16(p2, 44100)
+    first = engine.pass3(None, -16.0, -1.0, 20.0)
+    ap = L.LoudnormApply(-16.0, -1.0, 20.0, round(first["input_i"], 2), round(first["input_tp"], 2), 25.0, round(first["input_thresh"], 2), 0.5,
+                         1, 1.7, 55.0, 50.0, 1, 0.803526)
+    _, st = engine.pass4(None, ap)
+    assert st["normalization_type_dynamic"] == 1
+    got = engine.download_s16(4)
+    up = oracle.swr_f64(p2.astype(np.float64) / 32768.0, 44100, 192000, True)
+    y192, ost = oracle.loudnorm_dynamic(up, -16.0, 20.0, -1.0, measured=(ap.measured_i, ap.measured_lra, ap.measured_tp, ap.measured_thresh), offset=0.5)
+    assert ost["dynamic"] == 1
+    down = oracle.swr_f64(y192, 192000, 44100, True)[: p2.size]
+    z = oracle.alimiter(oracle.adeclick(down, 44100, 1.7, 55.0, 50.0, method="s"), 44100, 0.803526, 1.0, 50.0)
+    ref = oracle.f64_to_s16(z.astype(np.float32).astype(np.float64))
+    assert got.size == ref.size == p2.size
+    d = np.abs(ref.astype(np.int32) - got.astype(np.int32))
+    assert d.max() <= 1 and np.count_nonzero(d) <= max(4, got.size // 20000), (d.max(), np.count_nonzero(d))
+    for k in ("input_i", "input_lra", "input_thresh", "output_i", "output_lra", "output_thresh"):
+        assert abs(st[k] - ost[k]) < 1e-3, (k, st[k], ost[k])
+    assert abs(st["output_tp"] - ost["output_tp"]) < 1e-6
+
+
+@pytest.mark.gpu
+def test_process_audio_delivers_a_file_whose_lra_prints_as_zero(engine):
+    """A steady tone: loudness range 0.00 in the first-pass JSON, which af_loudnorm's init() treats as "not measured".  The reference
+    delivers such a file through the dynamic fallback (and says so in its stats); so does jt_process_audio."""
+    t = np.arange(int(SR * 12.0)) / SR
+    x = (0.05 * np.sin(2 * np.pi * 220.0 * t) * (1.0 + 0.0 * t)).astype(np.float32)
+    engine.upload_pcm(x, SR, 1)
+    base = H.default_config()
+    res = H.process_audio(engine, base)
+    assert res.measure.input_lra == 0.0
+    assert res.loudnorm.normalization_type_dynamic == 1
+    assert engine.download_s16(4).size == int(np.ceil(x.size * 147 / 160))
