@@ -988,24 +988,15 @@ k_adeclick_fast(const double *__restrict__ in, double *__restrict__ out, int64_t
                 if (d == 0.0) { ok = false; break; }
                 const int dlt = idn - __builtin_amdgcn_readfirstlane(idn);
                 const double ent = aux[dlt < AR + 1 ? dlt : AR + 1];
-#ifdef JT_DKX_NORCP
-                const double rinv = d * 1e-3;
-#else
                 const double rinv = dk_rcp(d);
-#endif
                 const double l = colv * rinv;
                 const bool inband = (unsigned)(lane - 1) < (unsigned)bw;
                 const double la = __shfl(l, a0 + 1, 64);
-#ifndef JT_DKX_NOSTORE
                 if (lane <= bw) gL[goff + (lane ? lane - 1 : bw)] = lane ? l : yk * rinv;
-#endif
                 goff += (unsigned)bw + 1u;
                 if (inband) yring[(k + lane) & CM] = __fma_rn(-l, yk, yrow);
                 const int npairs = bw * (bw + 1) / 2;
-#ifndef JT_DKX_NOPAIR
                 if (lane < npairs) *ep = __fma_rn(-cb, la, eold);
-#endif
-#ifndef JT_DKX_NOWIDE
                 if (npairs > 64) {
                     // pairs 64 .. 191 (bands up to 18 rows): this lane's second and third pair, operands by lane permute like the first
                     {
@@ -1028,14 +1019,11 @@ k_adeclick_fast(const double *__restrict__ in, double *__restrict__ out, int64_t
                         }
                     }
                 }
-#endif
                 // column k + NC takes the slot of column k (every diagonal), its right-hand side the slot of y_k
-#ifndef JT_DKX_NOENTER
                 if (nj < F) {
                     if (lane < ND) colp[ks] = ent;
                     if (lane == 0) yring[ks] = vn;
                 }
-#endif
                 bw = __builtin_amdgcn_readfirstlane(bwn);
                 __builtin_amdgcn_wave_barrier();
             }
@@ -1065,11 +1053,7 @@ k_adeclick_fast(const double *__restrict__ in, double *__restrict__ out, int64_t
                         const int bwk = k >= 0 ? (int)bwv[k] : 0;
                         segv -= (unsigned)bwk + 1u;
                         const bool valid = k >= 0 && ib - q >= 0 && bwk >= lane;      // lane 0: always (its element is y/d)
-#ifndef JT_DKX_NOSTORE
                         Lr[q] = valid ? dk_ld(&gL[segv + (lane ? (unsigned)lane - 1u : (unsigned)bwk)]) : 0.0;
-#else
-                        Lr[q] = valid ? 1e-3 : 0.0;
-#endif
                     }
                     double xs = 0.0;                                    // lane q: solution of row ib - q
 #pragma unroll
