@@ -251,7 +251,7 @@ k_anlmdn_pair(const float *__restrict__ in, float *__restrict__ out, int64_t n, 
 }
 
 // ------------------------------------------------------------------ hop-pair kernel, three offsets per lane, deferred weights
-// k_anlmdn_pair3 (2S = 192: the 48 kHz default).  Same recurrence, mapping and LDS window as k_anlmdn_pair<3>, but the weight
+// k_anlmdn_pair3<NOFF> (2S = 192 / 384: the 48 and 96 kHz defaults).  Same recurrence, mapping and LDS window as k_anlmdn_pair, but the weight
 // stage no longer runs inside the step loop.  Measured on speech (tools/nlm_engage.py): 47 % of the steps have a contributing
 // offset, and in 97 % of those only the offsets -6..-1, +1..+6 contribute (lanes 30..33: neighbouring shifts of a low-pass
 // signal), so a wave-wide weight stage spends 64 lanes on ~9 useful values.  Here:
@@ -270,8 +270,13 @@ k_anlmdn_pair(const float *__restrict__ in, float *__restrict__ out, int64_t n, 
 #ifndef JT_NLM3_CB
 #define JT_NLM3_CB 64
 #endif
-constexpr int NLM3_S = 96, NLM3_NEAR0 = 30, NLM3_NL = 4, NLM3_CB = JT_NLM3_CB, NLM3_B8 = NLM3_CB / 8;
-constexpr unsigned long long NLM3_NEARMASK = 0xFull << NLM3_NEAR0;
+constexpr int NLM3_CB = JT_NLM3_CB, NLM3_B8 = NLM3_CB / 8;
+// NOFF offsets per lane (3: 2S = 192, the 48 kHz default; 6: 2S = 384, 96 kHz).  The near lanes are the ones that own offsets -6 .. +6:
+// four lanes of three offsets, or two lanes of six -- twelve parked distances per step either way.
+template <int NOFF> struct Nlm3 {
+    static constexpr int S = 32 * NOFF, NL = 12 / NOFF, NEAR0 = 32 - NL / 2, R = nlm_ring(NOFF);
+    static constexpr unsigned long long NEARMASK = ((1ull << NL) - 1ull) << NEAR0;
+};
 
 #ifdef JT_NLM_PROFILE
 __device__ unsigned long long g_nlm_prof[8];      // wave clocks: window fill, seed, steps, park, replay, turn-round; [6] blocks replayed, [7] blocks parked
@@ -286,20 +291,21 @@ __device__ unsigned long long g_nlm_prof[8];      // wave clocks: window fill, s
 #define NLM_PROF_FLUSH
 #endif
 
-template <int V>
-__device__ inline void nlm3_step(f2 (&cache)[3], f2 (&hi)[4], f2 (&lo)[4], const f2 cm, const f2 cp, const f2 *pw, int K,
-                                 f2 (&cs)[8][3], float &mn)
+template <int NOFF, int V>
+__device__ inline void nlm3_step(f2 (&cache)[NOFF], f2 (&hi)[nlm_ring(NOFF)], f2 (&lo)[nlm_ring(NOFF)], const f2 cm, const f2 cp, const f2 *pw, int K,
+                                 f2 (&cs)[8][NOFF], float &mn)
 {
+    constexpr int R = nlm_ring(NOFF);
 #pragma unroll
-    for (int q = 0; q < 3; ++q) {
-        const f2 a = cm - lo[(q + V) % 4];
-        const f2 b = cp - hi[(q + V) % 4];
+    for (int q = 0; q < NOFF; ++q) {
+        const f2 a = cm - lo[(q + V) % R];
+        const f2 b = cp - hi[(q + V) % R];
         cache[q] = cache[q] + (-(a * a) + b * b);
     }
-    hi[V % 4] = pw[V + K];
-    lo[V % 4] = pw[V - K - 1];
+    hi[V % R] = pw[V + K];
+    lo[V % R] = pw[V - K - 1];
 #pragma unroll
-    for (int q = 0; q < 3; ++q) {
+    for (int q = 0; q < NOFF; ++q) {
         cs[V - 1][q] = cache[q];
         mn = fminf(fminf(mn, cache[q].x), cache[q].y);
     }
@@ -307,13 +313,14 @@ __device__ inline void nlm3_step(f2 (&cache)[3], f2 (&hi)[4], f2 (&lo)[4], const
 
 // The wave-wide weight stage of one step (both hops): FFmpeg's clamp, exact per-offset test, weights, lane-local sums, DPP
 // reduction; lanes 61 / 63 leave the two outputs in dst->x / dst->y (LDS).
-__device__ inline void nlm3_dense_stage(f2 (&cache)[3], int i, int d0, const f2 *fw, f2 *dst, float sw, float smooth,
+template <int NOFF>
+__device__ inline void nlm3_dense_stage(f2 (&cache)[NOFF], int i, int d0, const f2 *fw, f2 *dst, float sw, float smooth,
                                         float lut_scale, float nisl, int lane)
 {
     f2 Pxy = f2{0.f, 0.f}, Qxy = f2{0.f, 0.f};
     const f2 sw2 = f2{sw, sw}, ls2 = f2{lut_scale, lut_scale}, ns2 = f2{nisl, nisl};
 #pragma unroll
-    for (int q = 0; q < 3; ++q) {
+    for (int q = 0; q < NOFF; ++q) {
         cache[q].x = __builtin_amdgcn_fmed3f(cache[q].x, 0.f, 3.0e38f);
         cache[q].y = __builtin_amdgcn_fmed3f(cache[q].y, 0.f, 3.0e38f);
         const f2 w = cache[q] * sw2;
@@ -343,44 +350,47 @@ __device__ inline void nlm3_dense_stage(f2 (&cache)[3], int i, int d0, const f2 
 }
 
 // Exact per-step replay of `count` steps starting at step index i0 (slot vs0 of the consumer block), reading the window directly.
-__device__ inline void nlm3_slow_steps(f2 (&cache)[3], int i0, int count, int d0, int K, const f2 *fw, f2 *dslot, int vs0,
+template <int NOFF>
+__device__ inline void nlm3_slow_steps(f2 (&cache)[NOFF], int i0, int count, int d0, int K, const f2 *fw, f2 *dslot, int vs0,
                                        unsigned long long &dmask, float sw, float smooth, float lut_scale, float nisl, float dthr, int lane)
 {
     for (int u = 0; u < count; ++u) {
         const int i = i0 + u;
         const f2 cm = fw[i - K - 1], cp = fw[i + K];
 #pragma unroll
-        for (int q = 0; q < 3; ++q) {
+        for (int q = 0; q < NOFF; ++q) {
             const f2 a = cm - fw[i + d0 + q - K - 1];
             const f2 b = cp - fw[i + d0 + q + K];
             cache[q] = cache[q] + (-(a * a) + b * b);
         }
         float dmin = 3.0e38f;
 #pragma unroll
-        for (int q = 0; q < 3; ++q) dmin = fminf(dmin, fminf(cache[q].x, cache[q].y));
+        for (int q = 0; q < NOFF; ++q) dmin = fminf(dmin, fminf(cache[q].x, cache[q].y));
         if (__any(dmin < dthr)) {
-            nlm3_dense_stage(cache, i, d0, fw, dslot + vs0 + u, sw, smooth, lut_scale, nisl, lane);
+            nlm3_dense_stage<NOFF>(cache, i, d0, fw, dslot + vs0 + u, sw, smooth, lut_scale, nisl, lane);
             dmask |= 1ull << (vs0 + u);
         }
     }
 }
 
 // Turn-round: lane t finishes output t of the block (v = vb + t) for both hops and the block leaves as two coalesced stores.
+template <int NOFF>
 __device__ inline void nlm3_consume(const f2 *fw, const f2 *slot, const f2 *dslot, unsigned long long emask, unsigned long long dmask,
                                     int vb, int count, int H, float *__restrict__ out, int64_t hs, int64_t n,
                                     float sw, float smooth, float lut_scale, float nisl, int lane)
 {
-    const int v = vb + lane, i = NLM3_S + v;
+    constexpr int S_ = Nlm3<NOFF>::S;
+    const int v = vb + lane, i = S_ + v;
     f2 o = fw[i];
     if (emask | dmask) {
         if (emask) {
             f2 P = f2{0.f, 0.f}, Q = f2{0.f, 0.f};
             const f2 sw2 = f2{sw, sw}, ls2 = f2{lut_scale, lut_scale}, ns2 = f2{nisl, nisl};
 #pragma unroll
-            for (int e = 0; e < NLM3_NL * 3; ++e) {
-                constexpr int j0 = NLM3_NEAR0 * 3;
+            for (int e = 0; e < 12; ++e) {
+                constexpr int j0 = Nlm3<NOFF>::NEAR0 * NOFF;
                 const int j = j0 + e;
-                const int d = j - NLM3_S + (j >= NLM3_S ? 1 : 0);
+                const int d = j - S_ + (j >= S_ ? 1 : 0);
                 const f2 c = slot[e * NLM3_CB + (lane & (NLM3_CB - 1))];
                 const f2 w = c * sw2;
                 f2 idx = w * ls2;
@@ -406,24 +416,25 @@ __device__ inline void nlm3_consume(const f2 *fw, const f2 *slot, const f2 *dslo
     }
 }
 
+template <int NOFF>
 __global__ void __launch_bounds__(64)
 k_anlmdn_pair3(const float *__restrict__ in, float *__restrict__ out, int64_t n, int K, float sw, float smooth, float lut_scale)
 {
     extern __shared__ float smem_nlm[];
-    constexpr int S = NLM3_S;
+    constexpr int S = Nlm3<NOFF>::S, R = Nlm3<NOFF>::R, NEAR0 = Nlm3<NOFF>::NEAR0, NL = Nlm3<NOFF>::NL;
     const int H = 2 * K + 1;
     const int NW = H + 2 * (K + S);
     const int NWP = NLM_PADF + NW + NLM_PADB;
     f2 *win = reinterpret_cast<f2 *>(smem_nlm);            // [NWP] interleaved {hop A, hop B}
     f2 *slot = win + NWP;                                  // [12][64] parked near-lane distances of the current block
-    f2 *dslot = slot + NLM3_NL * 3 * NLM3_CB;              // [65] outputs of replayed steps (+1: the hop's first step)
+    f2 *dslot = slot + 12 * NLM3_CB;              // [65] outputs of replayed steps (+1: the hop's first step)
     const int lane = threadIdx.x;
     const int64_t hopA = (int64_t)blockIdx.x * 2;
     const int64_t hs = hopA * H - (K + S);
     const int64_t gwin = hs - (K + S);
     NLM_PROF_DECL;
     NLM_T(t_a);
-    constexpr int NLD = 24;                                 // window rows of 64 entries fetched in one batch
+    constexpr int NLD = NOFF == 3 ? 24 : 44;                // window rows of 64 entries fetched in one batch
     if (gwin - NLM_PADF >= 0 && gwin - NLM_PADF + NWP + H <= n && NWP <= 64 * NLD) {
         // interior tile: every load of the window is issued before the first one is waited for (one memory round trip per wave
         // instead of one per 64 entries); rows past the window re-read its last entry and are not stored
@@ -450,11 +461,11 @@ k_anlmdn_pair3(const float *__restrict__ in, float *__restrict__ out, int64_t n,
     NLM_T(t_b); NLM_ACC(0, t_a, t_b);
     const f2 *fw = win + NLM_PADF + K;
     const float nisl = -1.4426950408889634f / lut_scale;
-    const int j0 = lane * 3;
+    const int j0 = lane * NOFF;
     const int d0 = j0 - S + (j0 >= S ? 1 : 0);
-    f2 cache[3];
+    f2 cache[NOFF];
 #pragma unroll
-    for (int q = 0; q < 3; ++q) cache[q] = f2{0.f, 0.f};
+    for (int q = 0; q < NOFF; ++q) cache[q] = f2{0.f, 0.f};
     // ---- seed: compute_distance_ssd over k = -K..K (ascending, mul then add).  The stream ring holds 8 positions and the centre
     // samples arrive 8 steps ahead: a seed step is 9 packed instructions, so the 4-slot ring of the step loop (refill two steps
     // ahead) would leave every refill ~70 cycles to land -- less than an LDS round trip
@@ -472,7 +483,7 @@ k_anlmdn_pair3(const float *__restrict__ in, float *__restrict__ out, int64_t n,
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
 #pragma unroll
-                for (int q = 0; q < 3; ++q) { const f2 dd = ca[u] - st[(q + u) % 8]; cache[q] = cache[q] + dd * dd; }
+                for (int q = 0; q < NOFF; ++q) { const f2 dd = ca[u] - st[(q + u) % 8]; cache[q] = cache[q] + dd * dd; }
                 st[u % 8] = pw[u];
             }
 #pragma unroll
@@ -480,14 +491,14 @@ k_anlmdn_pair3(const float *__restrict__ in, float *__restrict__ out, int64_t n,
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
 #pragma unroll
-                for (int q = 0; q < 3; ++q) { const f2 dd = cb[u] - st[(q + u) % 8]; cache[q] = cache[q] + dd * dd; }
+                for (int q = 0; q < NOFF; ++q) { const f2 dd = cb[u] - st[(q + u) % 8]; cache[q] = cache[q] + dd * dd; }
                 st[u % 8] = pw[8 + u];
             }
             pw += 16; pc += 16;
         }
         // k = K, the (2K+1)-th term: 2K % 16 == 0 puts it at ring position 0 with its centre already in ca[0]
 #pragma unroll
-        for (int q = 0; q < 3; ++q) { const f2 dd = ca[0] - st[q]; cache[q] = cache[q] + dd * dd; }
+        for (int q = 0; q < NOFF; ++q) { const f2 dd = ca[0] - st[q]; cache[q] = cache[q] + dd * dd; }
     }
     const float dthr = (smooth / sw) * 1.000002f;
     NLM_T(t_c); NLM_ACC(1, t_b, t_c);
@@ -495,9 +506,9 @@ k_anlmdn_pair3(const float *__restrict__ in, float *__restrict__ out, int64_t n,
     {
         float dmin = 3.0e38f;
 #pragma unroll
-        for (int q = 0; q < 3; ++q) dmin = fminf(dmin, fminf(cache[q].x, cache[q].y));
+        for (int q = 0; q < NOFF; ++q) dmin = fminf(dmin, fminf(cache[q].x, cache[q].y));
         const bool eng = __any(dmin < dthr);
-        if (eng) nlm3_dense_stage(cache, S, d0, fw, dslot + NLM3_CB, sw, smooth, lut_scale, nisl, lane);
+        if (eng) nlm3_dense_stage<NOFF>(cache, S, d0, fw, dslot + NLM3_CB, sw, smooth, lut_scale, nisl, lane);
         if (lane == 0) {
             const f2 o = eng ? dslot[NLM3_CB] : fw[S];
             if (hs >= 0 && hs < n) out[hs] = o.x;
@@ -505,57 +516,57 @@ k_anlmdn_pair3(const float *__restrict__ in, float *__restrict__ out, int64_t n,
         }
     }
     // ---- steps v = 1 .. 2K in blocks of 8; hi[(q+v)%4] = f[i + d0 + q + K], lo[...] = f[i + d0 + q - K - 1], v = (i - S) % 4
-    f2 hi[4], lo[4];
+    f2 hi[R], lo[R];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
+    for (int q = 0; q < R; ++q) {
         const int xh = S + d0 + q + K; hi[q] = fw[xh];
         const int xl = S + d0 + q - K - 1; lo[q] = fw[xl];
     }
-    // the FIRST step's refill (slot 0 takes the values four positions ahead)
-    hi[0] = fw[S + d0 + 4 + K];
-    lo[0] = fw[S + d0 + 4 - K - 1];
+    // the FIRST step's refill (slot 0 takes the values R positions ahead)
+    hi[0] = fw[S + d0 + R + K];
+    lo[0] = fw[S + d0 + R - K - 1];
     f2 ma[4], pa[4], mb[4], pb[4];
     nlm_centre4<false>(in, 0, fw, S + 1 - K - 1, H, ma);
     nlm_centre4<false>(in, 0, fw, S + 1 + K, H, pa);
     unsigned long long emask = 0, dmask = 0;
     const int nb8 = K / 4;                                   // 2K / 8 blocks of eight steps
-    const bool near = lane >= NLM3_NEAR0 && lane < NLM3_NEAR0 + NLM3_NL;
+    const bool near = lane >= NEAR0 && lane < NEAR0 + NL;
     for (int b8 = 0; b8 < nb8; ++b8) {
         const int i0 = S + 1 + b8 * 8;
         const int it = b8 % NLM3_B8;
-        const f2 *pw = fw + i0 + d0 + 4 - 1;
-        f2 cs[8][3], c0[3];
+        const f2 *pw = fw + i0 + d0 + R - 1;
+        f2 cs[8][NOFF], c0[NOFF];
         float mn = 3.0e38f;
         NLM_T(t_0);
 #pragma unroll
-        for (int q = 0; q < 3; ++q) c0[q] = cache[q];
+        for (int q = 0; q < NOFF; ++q) c0[q] = cache[q];
         nlm_centre4<false>(in, 0, fw, i0 + 4 - K - 1, H, mb);
         nlm_centre4<false>(in, 0, fw, i0 + 4 + K, H, pb);
-        nlm3_step<1>(cache, hi, lo, ma[0], pa[0], pw, K, cs, mn);
-        nlm3_step<2>(cache, hi, lo, ma[1], pa[1], pw, K, cs, mn);
-        nlm3_step<3>(cache, hi, lo, ma[2], pa[2], pw, K, cs, mn);
-        nlm3_step<4>(cache, hi, lo, ma[3], pa[3], pw, K, cs, mn);
+        nlm3_step<NOFF, 1>(cache, hi, lo, ma[0], pa[0], pw, K, cs, mn);
+        nlm3_step<NOFF, 2>(cache, hi, lo, ma[1], pa[1], pw, K, cs, mn);
+        nlm3_step<NOFF, 3>(cache, hi, lo, ma[2], pa[2], pw, K, cs, mn);
+        nlm3_step<NOFF, 4>(cache, hi, lo, ma[3], pa[3], pw, K, cs, mn);
         nlm_centre4<false>(in, 0, fw, i0 + 8 - K - 1, H, ma);
         nlm_centre4<false>(in, 0, fw, i0 + 8 + K, H, pa);
-        nlm3_step<5>(cache, hi, lo, mb[0], pb[0], pw, K, cs, mn);
-        nlm3_step<6>(cache, hi, lo, mb[1], pb[1], pw, K, cs, mn);
-        nlm3_step<7>(cache, hi, lo, mb[2], pb[2], pw, K, cs, mn);
-        nlm3_step<8>(cache, hi, lo, mb[3], pb[3], pw, K, cs, mn);
+        nlm3_step<NOFF, 5>(cache, hi, lo, mb[0], pb[0], pw, K, cs, mn);
+        nlm3_step<NOFF, 6>(cache, hi, lo, mb[1], pb[1], pw, K, cs, mn);
+        nlm3_step<NOFF, 7>(cache, hi, lo, mb[2], pb[2], pw, K, cs, mn);
+        nlm3_step<NOFF, 8>(cache, hi, lo, mb[3], pb[3], pw, K, cs, mn);
         const unsigned long long bal = __ballot(mn < dthr);
         NLM_T(t_1); NLM_ACC(2, t_0, t_1);
         if (bal) {
-            if ((bal & ~NLM3_NEARMASK) || __any(mn < 0.f)) {
+            if ((bal & ~Nlm3<NOFF>::NEARMASK) || __any(mn < 0.f)) {
 #pragma unroll
-                for (int q = 0; q < 3; ++q) cache[q] = c0[q];
-                nlm3_slow_steps(cache, i0, 8, d0, K, fw, dslot, it * 8, dmask, sw, smooth, lut_scale, nisl, dthr, lane);
+                for (int q = 0; q < NOFF; ++q) cache[q] = c0[q];
+                nlm3_slow_steps<NOFF>(cache, i0, 8, d0, K, fw, dslot, it * 8, dmask, sw, smooth, lut_scale, nisl, dthr, lane);
                 NLM_T(t_2); NLM_ACC(4, t_1, t_2); NLM_ACC(6, 0ull, 1ull);
             } else {
                 if (near) {
 #pragma unroll
-                    for (int q = 0; q < 3; ++q) {
+                    for (int q = 0; q < NOFF; ++q) {
 #pragma unroll
                         for (int u = 0; u < 8; u += 2)
-                            *reinterpret_cast<float4 *>(slot + ((lane - NLM3_NEAR0) * 3 + q) * NLM3_CB + it * 8 + u) =
+                            *reinterpret_cast<float4 *>(slot + ((lane - NEAR0) * NOFF + q) * NLM3_CB + it * 8 + u) =
                                 make_float4(cs[u][q].x, cs[u][q].y, cs[u + 1][q].x, cs[u + 1][q].y);
                     }
                 }
@@ -565,7 +576,7 @@ k_anlmdn_pair3(const float *__restrict__ in, float *__restrict__ out, int64_t n,
         }
         NLM_T(t_3);
         if (it == NLM3_B8 - 1 || b8 == nb8 - 1) {
-            nlm3_consume(fw, slot, dslot, emask, dmask, 1 + (b8 - it) * 8, (it + 1) * 8, H, out, hs, n, sw, smooth, lut_scale, nisl, lane);
+            nlm3_consume<NOFF>(fw, slot, dslot, emask, dmask, 1 + (b8 - it) * 8, (it + 1) * 8, H, out, hs, n, sw, smooth, lut_scale, nisl, lane);
             emask = dmask = 0;
             NLM_T(t_4); NLM_ACC(5, t_3, t_4);
         }
@@ -660,9 +671,10 @@ void launch_anlmdn(const float *in, float *out, int64_t n, int K, int S, float s
         size_t smem = sizeof(float) * 2 * (size_t)(NLM_PADF + NW + NLM_PADB);      // interleaved {hop A, hop B} window
         JT_REQUIRE(smem <= 64 * 1024, JT_E_UNSUPPORTED, "anlmdn: window exceeds the wave-per-hop LDS budget");
         const unsigned grid = (unsigned)((nhops + 1) / 2);
-        if (2 * S == 192 && K % 8 == 0 && !getenv("JT_NLM_OLD")) {
-            smem += sizeof(float) * 2 * (size_t)(NLM3_NL * 3 * NLM3_CB + NLM3_CB + 1);
-            hipLaunchKernelGGL(k_anlmdn_pair3, dim3(grid), dim3(64), smem, s, in, out, n, K, sw, smooth, lut_scale);
+        if (K % 8 == 0 && !getenv("JT_NLM_OLD")) {
+            smem += sizeof(float) * 2 * (size_t)(12 * NLM3_CB + NLM3_CB + 1);
+            if (2 * S == 192) hipLaunchKernelGGL((k_anlmdn_pair3<3>), dim3(grid), dim3(64), smem, s, in, out, n, K, sw, smooth, lut_scale);
+            else hipLaunchKernelGGL((k_anlmdn_pair3<6>), dim3(grid), dim3(64), smem, s, in, out, n, K, sw, smooth, lut_scale);
 #ifdef JT_NLM_PROFILE
             {
                 unsigned long long pr[8], z[8] = {0};
