@@ -19,7 +19,7 @@ SKIP = ("tests/golden/ffmpeg/manifest.json is absent: the oracle is NOT pinned t
 # per-operator bars.  pcm: max |difference| (float) or LSB (s16); an FFmpeg build may contract a*b+c or vectorise a sum, so float
 # bars sit a few ulp above what the scalar restatement gives against itself.
 TOL = {"biquad_hp_lp": 2e-6, "anlmdn": 1e-5, "afftdn": 5e-5, "agate": 1e-9, "acompressor": 1e-9, "deesser": 1e-9, "alimiter": 1e-9,
-       "adeclick": 1e-6, "resample_s16": 1, "pass2_default_chain": 3, "downmix": 0.0}
+       "adeclick": 1e-6, "resample_s16": 1, "pass2_default_chain": 3, "downmix": 0.0, "loudnorm_dynamic": 1e-6}
 
 
 def manifest(root=GOLD):
@@ -67,12 +67,21 @@ class OracleOps:
             if op == "alimiter":
                 return o.alimiter(y, sr, a["limit"], a["attack"], a["release"])
             return o.adeclick(y, sr, a["t"], a["w"], a["o"], method=a["m"])
+        if op == "loudnorm_dynamic":
+            # s16 source: swr resamples in float (int_sample_fmt FLTP) and converts to the filter's double; the reference's aresample follows
+            up = o.swr_f32(x.astype(np.float32), sr, 192000, True).astype(np.float64)
+            y192, _ = self.loudnorm_dyn(up, a)
+            return o.swr_f64(y192, 192000, sr, True)
         if op == "pass2_default_chain":
             y = o.biquad_f32(o.biquad_f32(x.astype(np.float32), 0, 80.0, sr), 1, 20500.0, sr)
             y = o.afftdn(o.anlmdn(y, sr), sr, 12.0, -50.0, track=True).astype(np.float64)
             y = o.acompressor(o.agate(y, sr), sr)
             return o.f64_to_s16(o.swr_f64(y.astype(np.float32).astype(np.float64), sr, 44100, True))
         raise KeyError(op)
+
+    def loudnorm_dyn(self, up192, a):
+        m = tuple(a["measured"]) if a["measured"] else None
+        return self.o.loudnorm_dynamic(up192, a["target_i"], a["target_lra"], a["target_tp"], measured=m, offset=a["offset"])
 
     def band_rms(self, e, x):
         a, sr = e["args"], e["rate"]
@@ -171,9 +180,12 @@ def test_loader_selftest_with_oracle_made_vectors(oracle, tmp_path):
     x44 = np.rint(np.asarray(synth.speech_like(4.0, 44100, seed=6), np.float64) * 32768) / 32768
     np.savez_compressed(tmp_path / "t_ln.npz", x=x44)
     json.dump({k: "%.2f" % v for k, v in ops.loudnorm(el, x44).items()}, open(tmp_path / "t_ln.loudnorm.json", "w"))
-    json.dump({"ffmpeg": "selftest", "entries": ents + [eb, el]}, open(tmp_path / "manifest.json", "w"))
+    ed = {"name": "t_dyn", "kind": "pcm", "rate": 44100, "channels": 1, "source_format": "s16", "out_format": "f64le", "op": "loudnorm_dynamic",
+          "args": {"target_i": -16.0, "target_tp": -1.0, "target_lra": 20.0, "measured": [-24.0, 25.0, -6.0, -34.5], "offset": 0.5}}
+    np.savez_compressed(tmp_path / "t_dyn.npz", x=x44, y=ops.pcm(ed, x44))
+    json.dump({"ffmpeg": "selftest", "entries": ents + [eb, el, ed]}, open(tmp_path / "manifest.json", "w"))
     m = manifest(str(tmp_path))
-    assert len(m["entries"]) == 5
+    assert len(m["entries"]) == 6
     for e in m["entries"]:
         check_entry(ops, str(tmp_path), e)
     # a perturbed vector must fail
@@ -193,6 +205,8 @@ class EngineOps(OracleOps):
         g, a, sr, op = self.e, e["args"], e["rate"], e["op"]
         if op in ("downmix", "pass2_default_chain"):
             return super().pcm(e, x)
+        if op == "loudnorm_dynamic":
+            return super().pcm(e, x)                                      # resamplers from the oracle, the filter itself through loudnorm_dyn below
         x = self.mono(e, x)
         if op == "biquad_hp_lp":
             return g.op_biquad(x.astype(np.float32), sr, (1, a["hp"], a["q"]), (1, a["lp"], a["q"]))
@@ -206,6 +220,11 @@ class EngineOps(OracleOps):
             y = (x.astype(np.float32) * np.float32(10 ** (a["pre_gain_db"] / 20.0))).astype(np.float64)
             return g.op_alimiter(y, sr, a["limit"], a["attack"], a["release"]) if op == "alimiter" else g.op_adeclick(y, sr, a["t"], a["w"], a["o"], method=a["m"])
         return super().pcm(e, x)
+
+
+    def loudnorm_dyn(self, up192, a):
+        m = tuple(a["measured"]) if a["measured"] else None
+        return self.e.op_loudnorm_dynamic(up192, a["target_i"], a["target_lra"], a["target_tp"], measured=m, offset=a["offset"])
 
 
 @pytest.mark.gpu

@@ -85,6 +85,9 @@ def main():
     s441 = np.asarray(synth.speech_like(8.0, 44100, seed=104), np.float64)
     fx["speech_44k1_s16"] = (np.rint(s441 * 32768) / 32768, 44100, 1, "s16")
     fx["speech_44k1_s24"] = (np.rint(s441 * 8388608) / 8388608, 44100, 1, "s24")
+    fx["speech_44k1_s16_2s5"] = (fx["speech_44k1_s16"][0][: int(44100 * 2.5)].copy(), 44100, 1, "s16")
+    s30 = np.asarray(synth.speech_like(30.0, 44100, seed=105), np.float64)
+    fx["speech_44k1_s16_30s"] = (np.rint(s30 * 32768) / 32768, 44100, 1, "s16")
     paths = {}
     for name, (x, sr, ch, kind) in fx.items():
         paths[name] = os.path.join(tmp, name + ".wav")
@@ -166,6 +169,16 @@ def main():
     loudnorm_json("pass3_measure", P, "loudnorm=I=-16.0:TP=-1.0:LRA=20.0:dual_mono=true:print_format=json", "loudnorm_measure", {"prefix": None})
     loudnorm_json("pass3_measure_limited", P, "volume=6.0dB,alimiter=limit=0.500000:attack=5:release=100:level_in=1:level_out=1:level=0:latency=1:asc=1:asc_level=0.8,"
                   "loudnorm=I=-16.0:TP=-1.0:LRA=20.0:dual_mono=true:print_format=json", "loudnorm_measure", {"prefix": {"pre_gain_db": 6.0, "limit": 0.5}})
+    # the dynamic fallback of Pass 4 (second-pass values whose LRA exceeds the target) followed by the reference's own aresample, and the
+    # first pass on clips of 2.5 s (shorter than loudnorm's first frame: one gain), 4 s and 30 s: those pin how the filter's input meter
+    # treats its flush frame
+    raw_out("loudnorm_dynamic", P, "loudnorm=I=-16.00:TP=-1.00:LRA=20.0:measured_I=-24.00:measured_TP=-6.00:measured_LRA=25.00:measured_thresh=-34.50:offset=0.50:"
+            "dual_mono=true:linear=true:print_format=json,aresample=44100", "f64le", "loudnorm_dynamic",
+            {"target_i": -16.0, "target_tp": -1.0, "target_lra": 20.0, "measured": [-24.0, 25.0, -6.0, -34.5], "offset": 0.5}, rate=44100)
+    raw_out("loudnorm_dynamic_first_pass", P, "loudnorm=I=-16.0:TP=-9.0:LRA=20.0:dual_mono=true:print_format=json,aresample=44100", "f64le", "loudnorm_dynamic",
+            {"target_i": -16.0, "target_tp": -9.0, "target_lra": 20.0, "measured": None, "offset": 0.0}, rate=44100, note="a -9 dB ceiling keeps the limiter busy")
+    for nm, fxn in (("pass3_measure_2s5", "speech_44k1_s16_2s5"), ("pass3_measure_30s", "speech_44k1_s16_30s")):
+        loudnorm_json(nm, fxn, "loudnorm=I=-16.0:TP=-1.0:LRA=20.0:dual_mono=true:print_format=json", "loudnorm_measure", {"prefix": None})
     raw_out("alimiter_level", P, "volume=12.0dB,alimiter=limit=0.500000:attack=5:release=100:level_in=1:level_out=1:level=0:latency=1:asc=1:asc_level=0.8", "f64le", "alimiter",
             {"pre_gain_db": 12.0, "limit": 0.5, "attack": 5.0, "release": 100.0})
     raw_out("alimiter_brickwall", P, "volume=14.0dB,alimiter=limit=0.803526:attack=1:release=50:level_in=1:level_out=1:level=0:latency=1:asc=1:asc_level=0.8", "f64le", "alimiter",
