@@ -517,3 +517,39 @@ def test_full_size_60_minute_file_properties(oracle):
         assert np.array_equal(back[:, 0], out1.astype(np.int32)) and meta["flac_frames"] == info["frames"]
     finally:
         e.close()
+
+
+def test_config0_sixty_second_flac_file_against_the_oracle_chain(engine, oracle, tmp_path):
+    """BASELINE configs[0] end to end at its own size: a 60 s 48 kHz mono 16-bit FLAC goes in as a FILE (jt_process_file: decode on the
+    GPU, four passes, encode, atomic publish) and the delivered .flac is decoded by the RFC 9639 oracle decoder and compared with the
+    pipeline composed from the CPU oracle with the same effective parameters."""
+    from jivetalking_amd.engine import Engine
+    x16 = np.rint(np.asarray(synth.speech_like(60.0, SR, seed=77), np.float64) * 32767).astype(np.int16)
+    src = tmp_path / "episode.flac"
+    src.write_bytes(bytes(engine.op_flac_encode(x16, SR)))
+    res, out_path, _ = H.process_file(engine, str(src))
+    assert out_path.endswith("-processed.flac") and res.loudnorm.normalization_type_dynamic == 0
+    rc, dec, info = oracle.flac_decode(open(out_path, "rb").read())
+    assert rc == 0 and bytes(info.md5_stored) == bytes(info.md5_decoded)
+    p4 = dec[:, 0].astype(np.int16); p2 = engine.download_s16(2)
+    assert p4.size == p2.size == int(np.ceil(x16.size * 147 / 160)) and np.array_equal(p4, engine.download_s16(4))
+    # north_star: lands on -16 LUFS +/- 0.1, <= -1 dBTP, measured independently on the delivered PCM
+    e = oracle.ebur128(p4.astype(np.float64) / 32768.0, 44100, True, True)
+    assert abs(e["integrated"] + 16.0) <= 0.1 and 20 * np.log10(e["true_peak"]) <= -1.0
+    # Pass 2 against the oracle chain on the decoded input (s16 / 32768 exactly, as libswresample converts it)
+    x = x16.astype(np.float32) / np.float32(32768.0)
+    fp = L.FilterParams()
+    H.lib().jt_host_filter_params(C.byref(res.effective), C.byref(fp))
+    _, ref2 = oracle_pass2(oracle, x, fp, SR)
+    d2 = np.abs(ref2.astype(np.int32) - p2.astype(np.int32))
+    assert ref2.size == p2.size and d2.max() <= 3 and d2.mean() < 0.3, (d2.max(), d2.mean())
+    # Pass 3 and Pass 4 on the GPU's own Pass-2 output
+    assert res.limiter.needed == 0
+    up = oracle.swr_f32(p2.astype(np.float32) / 32768.0, 44100, 192000, True).astype(np.float64)
+    m = oracle.loudnorm_measure(up, 192000, True)
+    assert abs(res.measure.input_i - m["input_i"]) <= 0.011 and abs(res.measure.input_lra - m["input_lra"]) <= 0.011
+    gain = 10 ** ((res.effective_target_i - res.measure.input_i) / 20.0)
+    y = oracle.adeclick(p2.astype(np.float64) / 32768.0 * gain, 44100, 1.7, 55.0, 50.0, method="s")
+    ref4 = oracle.f64_to_s16(oracle.alimiter(y, 44100, 0.803526, 1.0, 50.0).astype(np.float32).astype(np.float64))
+    d4 = np.abs(ref4.astype(np.int32) - p4.astype(np.int32))
+    assert d4.max() <= 1 and np.count_nonzero(d4) <= 4, (d4.max(), np.count_nonzero(d4))
