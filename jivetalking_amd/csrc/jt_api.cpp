@@ -1039,7 +1039,9 @@ extern "C" int jt_pass4(jt_ctx *h, const jt_limiter_plan *lim, const jt_loudnorm
         std::swap(sig, tmp);
         check_cancel(h);
     }
-    if (stats_lin) { fork_aux(h, 3, 3); jt_kweight_enqueue_f64(h, sig, m, rate, sblk, &sj, h->aux[3]); }   // joined with the analysis below
+    const double *stats_src = sig;                        // the gained-by-nothing stream the loudnorm meters see (r128_in; r128_out = gain * it)
+    bool stats_queued = false, stats_on_spec = false;
+    if (stats_lin && !ap->adeclick_enabled) { fork_aux(h, 3, 3); jt_kweight_enqueue_f64(h, stats_src, m, rate, sblk, &sj, h->aux[3]); stats_queued = true; }
     // adeclick on the gained stream (af_adeclick.c), then the brickwall alimiter
     double brick_gain = gain;
     const unsigned long long *dk_stats = nullptr;
@@ -1057,8 +1059,17 @@ extern "C" int jt_pass4(jt_ctx *h, const jt_limiter_plan *lim, const jt_loudnorm
         dk_stats = hs;
         std::swap(sig, tmp);
         brick_gain = 1.0;
-        // the brickwall writes the buffer the statistics job (aux stream 3) is still reading: join that chain first
-        if (stats_lin) { JT_HIP(hipEventRecord(h->ev_join[3], h->aux[3])); JT_HIP(hipStreamWaitEvent(h->stream, h->ev_join[3], 0)); }
+        // the statistics job starts behind adeclick (beside it, its few workgroups waited for the persistent waves' CU slots for the whole
+        // launch: 9.5 ms in the kernel trace for 0.3 ms of work) and reads adeclick's INPUT, which the brickwall must therefore not reuse
+        if (stats_lin) {
+            // on the stream Pass 2 uses for the early Pass-3 measurement (idle now), so that no analysis chain queues behind it
+            JT_HIP(hipEventRecord(h->spec_ln.fork, h->stream));
+            JT_HIP(hipStreamWaitEvent(h->spec_ln.stream, h->spec_ln.fork, 0));
+            jt_kweight_enqueue_f64(h, stats_src, m, rate, sblk, &sj, h->spec_ln.stream);
+            stats_queued = true; stats_on_spec = true;
+        }
+        h->f64_c.ensure((size_t)m);
+        tmp = h->f64_c.p;
     }
     run_limiter(h, sig, tmp, m, rate, ap->brickwall_limit, 1.0, 50.0, brick_gain);
     std::swap(sig, tmp);
@@ -1074,6 +1085,7 @@ extern "C" int jt_pass4(jt_ctx *h, const jt_limiter_plan *lim, const jt_loudnorm
     const bool regions = announced && regions_resolve(slot.start_s, slot.dur_s, rate, m, &RJ);
     if (regions) regions_enqueue(h, h->s16_p4.p, rate, &RJ, true);         // beside the full-length analysis
     analysis_join(h, regions ? 2 : 1);
+    if (stats_on_spec) { JT_HIP(hipEventRecord(h->spec_ln.fork, h->spec_ln.stream)); JT_HIP(hipStreamWaitEvent(h->stream, h->spec_ln.fork, 0)); }
     JT_HIP(hipEventRecord(h->ev1, h->stream));
     JT_HIP(hipEventSynchronize(h->ev1));
     check_cancel(h);
@@ -1097,7 +1109,7 @@ extern "C" int jt_pass4(jt_ctx *h, const jt_limiter_plan *lim, const jt_loudnorm
     // finishes the output analysis
     std::exception_ptr stats_err;
     std::thread stats_thread;
-    if (stats_lin) {
+    if (stats_lin && stats_queued) {
         stats_thread = std::thread([&]() {
             try {
                 const int64_t nfull = m / sblk;

@@ -247,7 +247,7 @@ struct jt_ctx {
     DevBuf<float> work_a, work_b;       // f32 ping-pong at source rate
     DevBuf<int16_t> s16_p2, s16_p4;     // Pass-2 / Pass-4 outputs
     int64_t m_p2 = 0, m_p4 = 0; int out_rate = 0;
-    DevBuf<double> f64_a, f64_b;        // f64 ping-pong at output rate
+    DevBuf<double> f64_a, f64_b, f64_c; // f64 ping-pong at output rate (+ the brickwall's output when adeclick's input is still being metered)
     DevBuf<float> stream_f; DevBuf<double> stream_d;   // 192 kHz loudnorm-measurement stream
     DevBuf<double> stream_y, ln_ring, ln_series;       // loudnorm dynamic mode: output stream, limiter ring, per-frame series
     // scratch
