@@ -514,10 +514,11 @@ k_adeclick(const double *__restrict__ in, double *__restrict__ out, int64_t n, D
 #ifndef JT_DK_LOADBATCH
 #define JT_DK_LOADBATCH 8
 #endif
+// -DJT_DK_NOMFMA_DETECT: the detector FIR as lane FMAs over a rotating register window (the round's first version; A/B builds)
 #ifdef JT_DK_NOMFMA_DETECT
-#define getenv_dk_nomfma true
+constexpr bool kDetectOnLanes = true;
 #else
-#define getenv_dk_nomfma false
+constexpr bool kDetectOnLanes = false;
 #endif
 namespace dkf { constexpr int DQ = 11; }
 typedef double dk_d4 __attribute__((ext_vector_type(4)));
@@ -769,7 +770,7 @@ k_adeclick_fast(const double *__restrict__ in, double *__restrict__ out, int64_t
             // 11 outputs per 49 lane-FMAs; the sum order inside an MFMA is the hardware's (this kernel's results are order-relaxed anyway).
             dk_d4 zero4 = {0, 0, 0, 0};
             double areg[16];
-            if (!getenv_dk_nomfma) {
+            if (!kDetectOnLanes) {
 #pragma unroll
                 for (int ks = 0; ks < 16; ++ks) {
                     const int c = (lane & 15) + 48 - 4 * ks - (lane >> 4);
@@ -814,9 +815,9 @@ k_adeclick_fast(const double *__restrict__ in, double *__restrict__ out, int64_t
                 // outputs [AR, W) split in two equal ranges; the upper one is served by buffer B (loaded), the lower one by buffer A
                 int dsp = AR + (W - AR + 1) / 2;
                 dsp = dsp < SPLIT ? SPLIT : dsp;                           // buffer B holds sample dsp - AR onwards
-                if (getenv_dk_nomfma) { detect_range(dsp, W); load_buf(0); detect_range(AR, dsp); }
+                if (kDetectOnLanes) { detect_range(dsp, W); load_buf(0); detect_range(AR, dsp); }
                 else { detect_range_mfma(dsp, W); load_buf(0); detect_range_mfma(AR, dsp); }
-            } else if (getenv_dk_nomfma) detect_range(AR, W);
+            } else if (kDetectOnLanes) detect_range(AR, W);
             else detect_range_mfma(AR, W);
             __builtin_amdgcn_wave_barrier();
             // ---- 5./6. burst fusion, borders, index list (as k_adeclick: integer work)
