@@ -223,23 +223,43 @@ k_nf_main(const float *__restrict__ x, int64_t n, int tc, const float *__restric
     const int q = (tc - 1) >> 6, r = (tc - 1) & 63;
     const int64_t w0 = (int64_t)blockIdx.x * 4 + wave, nw = (int64_t)gridDim.x * 4;
     double nf = DBL_MAX; unsigned long long cnt = 0;
-    for (int64_t bs = w0; bs < nstartblocks; bs += nw) {
-        const int64_t i0 = bs * 64, iq = (bs + q) * 64, iq1 = iq + 64;
-        const int64_t ir = i0 + (63 - lane);
-        const float xr = ir < n ? fabsf(x[ir]) : 0.f;                                  // block bs, reversed lane order
-        const float xq = iq + lane < n ? fabsf(x[iq + lane]) : 0.f, xq1 = iq1 + lane < n ? fabsf(x[iq1 + lane]) : 0.f;
-        const float grev = wave_prefix_max(xr);                                        // lane j: max of block positions 63-j .. 63
-        const float pq = wave_prefix_max(xq), pq1 = wave_prefix_max(xq1);
-        const float g = __shfl(grev, 63 - lane, 64);                                   // suffix max from position `lane`
+    // a wave takes NF_U consecutive start blocks at a time: their end blocks overlap (block bs+q+1 of one is bs+q of the next), so
+    // 2 NF_U + 1 loads are in flight instead of 3 and each end block's prefix scan is shared
+    constexpr int NF_U = 4;
+    for (int64_t b0 = w0 * NF_U; b0 < nstartblocks; b0 += nw * NF_U) {
+        float xr[NF_U], xe[NF_U + 1], rqv[NF_U], bmv[NF_U];
+#pragma unroll
+        for (int u = 0; u < NF_U; ++u) {
+            const int64_t ir = (b0 + u) * 64 + (63 - lane);
+            xr[u] = ir < n ? fabsf(x[ir]) : 0.f;                                         // block bs, reversed lane order
+            const bool have = b0 + u < nstartblocks;
+            rqv[u] = (have && q >= 2) ? rq[b0 + u + 1] : 0.f;                            // blocks bs+1 .. bs+q-1
+            bmv[u] = (have && q >= 1) ? bm[b0 + u + q] : 0.f;                            // block bs+q, whole when the end wraps
+        }
+#pragma unroll
+        for (int u = 0; u <= NF_U; ++u) {
+            const int64_t ie = (b0 + q + u) * 64 + lane;
+            xe[u] = ie < n ? fabsf(x[ie]) : 0.f;
+        }
+        float pe[NF_U + 1];
+#pragma unroll
+        for (int u = 0; u <= NF_U; ++u) pe[u] = wave_prefix_max(xe[u]);
         const int el = lane + r;
-        const float pa = __shfl(pq, el & 63, 64), pb = __shfl(pq1, el & 63, 64);
-        float m = fmaxf(g, el < 64 ? pa : pb);
-        if (q >= 2) m = fmaxf(m, rq[bs + 1]);                                          // blocks bs+1 .. bs+q-1
-        if (el >= 64 && q >= 1) m = fmaxf(m, bm[bs + q]);                              // the end wrapped: block bs+q is whole too
-        const int64_t e = i0 + lane + tc - 1;
-        if (e < n) {
-            const double lp = (double)m;
-            if (lp < nf) { nf = lp; cnt = 1; } else if (lp == nf) cnt++;
+#pragma unroll
+        for (int u = 0; u < NF_U; ++u) {
+            const int64_t bs = b0 + u;
+            if (bs >= nstartblocks) break;
+            const float grev = wave_prefix_max(xr[u]);                                   // lane j: max of block positions 63-j .. 63
+            const float g = __shfl(grev, 63 - lane, 64);                                 // suffix max from position `lane`
+            const float pa = __shfl(pe[u], el & 63, 64), pb = __shfl(pe[u + 1], el & 63, 64);
+            float m = fmaxf(g, el < 64 ? pa : pb);
+            if (q >= 2) m = fmaxf(m, rqv[u]);
+            if (el >= 64 && q >= 1) m = fmaxf(m, bmv[u]);
+            const int64_t e = bs * 64 + lane + tc - 1;
+            if (e < n) {
+                const double lp = (double)m;
+                if (lp < nf) { nf = lp; cnt = 1; } else if (lp == nf) cnt++;
+            }
         }
     }
     for (int o = 32; o > 0; o >>= 1) {
@@ -418,7 +438,7 @@ void jt_astats_enqueue(jt_ctx *h, const float *x, int64_t n, int sr, AstatsJob *
             const int q = (tc - 1) >> 6;
             float *d_bm = reinterpret_cast<float *>(h->as_take(sizeof(float) * 2 * (size_t)nblocks)), *d_rq = d_bm + nblocks;
             const int64_t nstart = (n - tc + 1 + 63) / 64;                       // start blocks that contain a complete window start
-            nf_parts = (int)std::min<int64_t>((nstart + 3) / 4, nparts);
+            nf_parts = (int)std::min<int64_t>((nstart + 15) / 16, nparts);                 // 4 waves x 4 start blocks per pass
             hipLaunchKernelGGL(k_nf_blockmax, dim3((unsigned)std::min<int64_t>((nblocks + 3) / 4, 4096)), dim3(256), 0, sB, x, n, d_bm, nblocks);
             hipLaunchKernelGGL(k_nf_runmax, dim3((unsigned)((nblocks + 255) / 256)), dim3(256), 0, sB, d_bm, d_rq, nblocks, std::max(q - 1, 0));
             hipLaunchKernelGGL(k_nf_main, dim3(nf_parts), dim3(256), 0, sB, x, n, tc, d_bm, d_rq, nstart, d_nf);

@@ -53,6 +53,126 @@ __device__ inline void block_reduce_sum(float (&v)[K], float *scratch /* [K][4] 
     __syncthreads();
 }
 
+// In-place Stockham FFT of H = 2^LOG2H complex points by ONE wave (H/256 radix-4 butterflies per lane and stage, a radix-2 stage when
+// LOG2H is odd): every point of a stage is in registers before the first is written back, and the LDS operations of a wave are
+// ordered, so no barrier is needed.  Same butterflies, twiddle values and operation order as fft_stockham (bit-identical results).
+// What differs is where things sit in LDS, because the plain layout is bank-conflict bound (8-way on the stores of the stages with
+// Ns = 1, 4 and on the twiddle loads of Ns = 4..64):
+//  * point i is kept at fw_sk(i) = i + 4*(i >> 4) (four float2 of padding per sixteen points): the 16-point groups a stage with
+//    Ns = 4 scatters to then start 40 dwords apart, eight distinct bank groups;
+//  * the stage with Ns = 1 writes a lane's four consecutive outputs as two 16-byte stores;
+//  * each stage has its own twiddle rows (w, w^2, w^3 of k, contiguous: fw_tw_fill), read once per stage while k does not depend on
+//    the butterfly (Ns <= 64).
+__device__ __forceinline__ int fw_sk(int i) { return i + ((i >> 4) << 2); }
+template <int LOG2H> struct FwLayout {
+    static constexpr int H = 1 << LOG2H;
+    static constexpr int SKH = H + (H >> 2);                               // float2 per frame buffer
+    static constexpr int N4 = LOG2H / 2;                                   // radix-4 stages
+    static constexpr int TW4 = (((1 << (2 * N4)) - 4) / 3);                // 4 + 16 + ... + 4^(N4-1) rows of three
+    static constexpr int TWN = 3 * TW4 + ((LOG2H & 1) ? H / 2 : 0);        // float2 in the table
+    static constexpr int row0(int Ns) { return 3 * ((Ns - 4) / 3); }      // first float2 of the stage with this Ns (4 + ... + Ns/4 rows before)
+};
+// tws[row0(Ns) + 3 k + c] = exp(-2 pi i (c + 1) k / (4 Ns)); the radix-2 rows follow.  Every thread of the workgroup helps.
+template <int LOG2H, bool F32ANGLE = false>
+__device__ inline void fw_tw_fill(float2 *tws, int tid, int nthreads)
+{
+    using Lp = FwLayout<LOG2H>;
+    constexpr int H = Lp::H;
+    for (int i = tid; i < Lp::TWN; i += nthreads) {
+        int q;                                                             // angle index: exp(-2 pi i q / H)
+        if (i < 3 * Lp::TW4) {
+            const int r = i / 3, c = i - 3 * r;                            // row r of the concatenated stages: Ns = 4: rows 0..3, Ns = 16: 4..19, ...
+            int Ns = 4, base = 0;
+            while (r >= base + Ns) { base += Ns; Ns <<= 2; }
+            q = (c + 1) * (r - base) * (H / 4 / Ns);
+        } else q = (i - 3 * Lp::TW4);                                      // radix-2 stage: Ns = H/2, step 1
+        if (F32ANGLE) { float sn, cs; sincospif(2.0f * q / H, &sn, &cs); tws[i] = make_float2(cs, -sn); }       // (aspectralstats' table)
+        else { double sn, cs; sincospi(2.0 * q / H, &sn, &cs); tws[i] = make_float2((float)cs, (float)-sn); }
+    }
+}
+// One radix-4 stage of the 1024-point wave transform.  With j = lane + 64 q every padded index splits into a per-lane base and a
+// compile-time offset (lane < 64 never carries into the padding term), so the LDS operations use immediate offsets -- computed the
+// obvious way, the 150-odd loop-invariant addresses of a transform are hoisted into registers and spill:
+//   reads            fw_sk(j + 256 c)                = fw_sk(lane) + 80 q + 320 c
+//   writes, Ns = 1   fw_sk(4 j + c)                  = 4 lane + 4 (lane >> 2) + c + 320 q
+//           Ns = 4   k = lane & 3:   fw_sk(o + 4 c)  = 4 (lane - k) + k + 4 (lane >> 2) + 4 c + 320 q
+//           Ns = 16  k = lane & 15:  fw_sk(o + 16 c) = 4 (lane - k) + k + 16 (lane >> 4) + 20 c + 320 q
+//           Ns = 64  k = lane:       fw_sk(o + 64 c) = fw_sk(lane) + 80 c + 320 q
+//           Ns = 256 k = j:          fw_sk(o + 256 c) = fw_sk(lane) + 80 q + 320 c
+template <int LOG2H, bool INV, int NS>
+__device__ __forceinline__ void fw_stage4(float2 *a, const float2 *__restrict__ tws, int lane)
+{
+    static_assert(LOG2H == 10, "immediate-offset layout derived for 1024 points");
+    using Lp = FwLayout<LOG2H>;
+    constexpr int B4 = 4;
+    const float2 *al = a + fw_sk(lane);
+    float2 v[B4][4];
+#pragma unroll
+    for (int q = 0; q < B4; ++q) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) v[q][c] = al[80 * q + 320 * c];
+    }
+    float2 w1, w2, w3;
+    if (NS > 1 && NS <= 64) { const float2 *r = tws + Lp::row0(NS) + 3 * (lane & (NS - 1)); w1 = r[0]; w2 = r[1]; w3 = r[2]; }
+    const int kl = lane & (NS - 1);
+    float2 *wb = NS == 1 ? a + 4 * lane + 4 * (lane >> 2)
+               : NS == 4 ? a + 4 * (lane - kl) + kl + 4 * (lane >> 2)
+               : NS == 16 ? a + 4 * (lane - kl) + kl + 16 * (lane >> 4)
+               : a + fw_sk(lane);
+    constexpr int WC = NS == 1 ? 1 : NS == 4 ? 4 : NS == 16 ? 20 : NS == 64 ? 80 : 320;      // offset per output c
+    constexpr int WQ = NS == 256 ? 80 : 320;                                                 // offset per butterfly q
+#pragma unroll
+    for (int q = 0; q < B4; ++q) {
+        float2 v0 = v[q][0], v1 = v[q][1], v2 = v[q][2], v3 = v[q][3];
+        if (NS > 1) {
+            if (NS > 64) { const float2 *r = tws + Lp::row0(NS) + 3 * lane + 192 * q; w1 = r[0]; w2 = r[1]; w3 = r[2]; }   // k = lane + 64 q
+            float2 x1 = w1, x2 = w2, x3 = w3;
+            if (INV) { x1.y = -x1.y; x2.y = -x2.y; x3.y = -x3.y; }
+            float2 t;
+            t.x = v1.x * x1.x - v1.y * x1.y; t.y = v1.x * x1.y + v1.y * x1.x; v1 = t;
+            t.x = v2.x * x2.x - v2.y * x2.y; t.y = v2.x * x2.y + v2.y * x2.x; v2 = t;
+            t.x = v3.x * x3.x - v3.y * x3.y; t.y = v3.x * x3.y + v3.y * x3.x; v3 = t;
+        }
+        const float2 s02 = make_float2(v0.x + v2.x, v0.y + v2.y), d02 = make_float2(v0.x - v2.x, v0.y - v2.y);
+        const float2 s13 = make_float2(v1.x + v3.x, v1.y + v3.y), d13 = make_float2(v1.x - v3.x, v1.y - v3.y);
+        const float2 r13 = INV ? make_float2(-d13.y, d13.x) : make_float2(d13.y, -d13.x);
+        const float2 y0 = make_float2(s02.x + s13.x, s02.y + s13.y), y1 = make_float2(d02.x + r13.x, d02.y + r13.y);
+        const float2 y2 = make_float2(s02.x - s13.x, s02.y - s13.y), y3 = make_float2(d02.x - r13.x, d02.y - r13.y);
+        if (NS == 1) {                                                     // four consecutive points, 32-byte aligned in the padded layout
+            float4 *dst = reinterpret_cast<float4 *>(wb + WQ * q);
+            dst[0] = make_float4(y0.x, y0.y, y1.x, y1.y); dst[1] = make_float4(y2.x, y2.y, y3.x, y3.y);
+        } else { wb[WQ * q] = y0; wb[WQ * q + WC] = y1; wb[WQ * q + 2 * WC] = y2; wb[WQ * q + 3 * WC] = y3; }
+    }
+}
+template <int LOG2H, bool INV>
+__device__ inline void fft_wave(float2 *a, const float2 *__restrict__ tws, int lane)
+{
+    using Lp = FwLayout<LOG2H>;
+    constexpr int H = Lp::H, B2 = H / 2 / 64;
+    fw_stage4<LOG2H, INV, 1>(a, tws, lane);
+    if (Lp::N4 > 1) fw_stage4<LOG2H, INV, 4>(a, tws, lane);
+    if (Lp::N4 > 2) fw_stage4<LOG2H, INV, 16>(a, tws, lane);
+    if (Lp::N4 > 3) fw_stage4<LOG2H, INV, 64>(a, tws, lane);
+    if (Lp::N4 > 4) fw_stage4<LOG2H, INV, 256>(a, tws, lane);
+    if (Lp::N4 > 5) fw_stage4<LOG2H, INV, 1024>(a, tws, lane);
+    if (LOG2H & 1) {
+        constexpr int Ns = H / 2;
+        float2 v[B2][2];
+#pragma unroll
+        for (int q = 0; q < B2; ++q) { const int j = lane + 64 * q; v[q][0] = a[fw_sk(j)]; v[q][1] = a[fw_sk(j + H / 2)]; }
+#pragma unroll
+        for (int q = 0; q < B2; ++q) {
+            const int j = lane + 64 * q;                                   // k = j (Ns = H/2)
+            float2 w = tws[3 * Lp::TW4 + j];
+            if (INV) w.y = -w.y;
+            const float2 v0 = v[q][0], v1 = v[q][1];
+            float2 t; t.x = v1.x * w.x - v1.y * w.y; t.y = v1.x * w.y + v1.y * w.x;
+            a[fw_sk(j)] = make_float2(v0.x + t.x, v0.y + t.y);
+            a[fw_sk(j + Ns)] = make_float2(v0.x - t.x, v0.y - t.y);
+        }
+    }
+}
+
 // ------------------------------------------------------------------ aspectralstats
 // One WAVE per analysis unit, four independent waves per workgroup, no workgroup barriers after the table setup.
 // A unit = one hop whose statistics are wanted (+ its predecessor, whose magnitudes feed the flux term): two real FFTs of
@@ -65,64 +185,31 @@ constexpr int SP_LOG2 = 11, SP_N = 1 << SP_LOG2, SP_HALF = SP_N / 2, SP_Q = SP_H
 __device__ inline float wsumf(float v) { for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64); return v; }
 __device__ inline int sp_skew(int i) { return i + (i >> 4); }
 
-// in-place Stockham radix-4, H = 1024 complex points, one wave (64 lanes x 4 butterflies per stage)
-__device__ inline void fft1024_wave(float2 *a, const float2 *__restrict__ tw, int lane)
-{
-    constexpr int H = SP_HALF;
-    int Ns = 1;
-#pragma unroll 1
-    for (int st = 0; st < 5; ++st) {
-        float2 v[4][4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int j = lane + 64 * q;
-            v[q][0] = a[j]; v[q][1] = a[j + H / 4]; v[q][2] = a[j + H / 2]; v[q][3] = a[j + 3 * H / 4];
-        }
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int j = lane + 64 * q;
-            const int k = j & (Ns - 1);
-            float2 v0 = v[q][0], v1 = v[q][1], v2 = v[q][2], v3 = v[q][3];
-            if (Ns > 1) {
-                const int tq = k * (H / 4 / Ns);
-                const float2 w1 = tw[tq], w2 = tw[2 * tq], w3 = tw[3 * tq];
-                float2 t;
-                t.x = v1.x * w1.x - v1.y * w1.y; t.y = v1.x * w1.y + v1.y * w1.x; v1 = t;
-                t.x = v2.x * w2.x - v2.y * w2.y; t.y = v2.x * w2.y + v2.y * w2.x; v2 = t;
-                t.x = v3.x * w3.x - v3.y * w3.y; t.y = v3.x * w3.y + v3.y * w3.x; v3 = t;
-            }
-            const float2 s02 = make_float2(v0.x + v2.x, v0.y + v2.y), d02 = make_float2(v0.x - v2.x, v0.y - v2.y);
-            const float2 s13 = make_float2(v1.x + v3.x, v1.y + v3.y), d13 = make_float2(v1.x - v3.x, v1.y - v3.y);
-            const float2 r13 = make_float2(d13.y, -d13.x);            // -i * d13
-            const int o = ((j - k) << 2) + k;
-            a[o] = make_float2(s02.x + s13.x, s02.y + s13.y);
-            a[o + Ns] = make_float2(d02.x + r13.x, d02.y + r13.y);
-            a[o + 2 * Ns] = make_float2(s02.x - s13.x, s02.y - s13.y);
-            a[o + 3 * Ns] = make_float2(d02.x - r13.x, d02.y - r13.y);
-        }
-        Ns <<= 2;
-    }
-}
-
 // magnitudes |X[i]| / 2048, i < 1024, of the hann-windowed frame ending at sample (h+1)*1024, into mag[sp_skew(i)]
 __device__ inline void sp_frame_mags(const float *__restrict__ in, int64_t n, int64_t h, float2 *zbuf, const float2 *tw, const float *hann,
                                      const float2 (&wk)[8], float *mag, int lane)
 {
     const int64_t w0 = (h + 1) * (int64_t)SP_HALF - SP_N;
-#pragma unroll 4
+    const int zl = fw_sk(lane), zm0 = fw_sk(SP_HALF - lane);         // padded positions: point lane + 64 q at zl + 80 q, its mirror at zm0 - 80 q
+    float xv[32];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {                                   // clamped addresses: all the loads of the frame in flight at once
+        const int64_t k0 = w0 + 2 * (lane + 64 * q), k1 = k0 + 1;
+        const float a0 = in[min(max(k0, (int64_t)0), n - 1)], a1 = in[min(max(k1, (int64_t)0), n - 1)];
+        xv[2 * q] = (k0 >= 0 && k0 < n) ? a0 : 0.f; xv[2 * q + 1] = (k1 >= 0 && k1 < n) ? a1 : 0.f;
+    }
+#pragma unroll
     for (int q = 0; q < 16; ++q) {
         const int m = lane + 64 * q;
-        const int64_t k0 = w0 + 2 * m, k1 = k0 + 1;
-        const float x0 = (k0 >= 0 && k0 < n) ? in[k0] : 0.f, x1 = (k1 >= 0 && k1 < n) ? in[k1] : 0.f;
         const int i0 = 2 * m, i1 = 2 * m + 1;
-        zbuf[m] = make_float2(x0 * hann[i0 < SP_HALF ? i0 : SP_N - 1 - i0], x1 * hann[i1 < SP_HALF ? i1 : SP_N - 1 - i1]);
+        zbuf[zl + 80 * q] = make_float2(xv[2 * q] * hann[i0 < SP_HALF ? i0 : SP_N - 1 - i0], xv[2 * q + 1] * hann[i1 < SP_HALF ? i1 : SP_N - 1 - i1]);
     }
-    fft1024_wave(zbuf, tw, lane);
+    fft_wave<SP_LOG2 - 1, false>(zbuf, tw, lane);
     const float fscale = 1.f / SP_N;
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
         const int k = lane + 64 * q;                       // pair (k, 1024 - k), k < 512
-        const float2 zk = zbuf[k], zm = zbuf[(SP_HALF - k) & (SP_HALF - 1)];
+        const float2 zk = zbuf[zl + 80 * q], zm = zbuf[(q == 0 && lane == 0) ? 0 : zm0 - 80 * q];
         const float er = 0.5f * (zk.x + zm.x), ei = 0.5f * (zk.y - zm.y);          // E = (Zk + conj Zm)/2
         const float orr = 0.5f * (zk.y + zm.y), oi = -0.5f * (zk.x - zm.x);        // O = -i (Zk - conj Zm)/2
         if (k == 0) mag[sp_skew(0)] = fabsf((er + orr) * fscale);                 // X[0] = Re Z0 + Im Z0 (real)
@@ -132,7 +219,7 @@ __device__ inline void sp_frame_mags(const float *__restrict__ in, int64_t n, in
             mag[sp_skew(SP_HALF - k)] = hypotf((er - cr) * fscale, (ei - ci) * fscale);         // X[1024-k] = conj(E - W^k O)
         }
     }
-    if (lane == 0) { const float2 z = zbuf[SP_Q]; mag[sp_skew(SP_Q)] = hypotf(z.x * fscale, z.y * fscale); }   // X[512] = conj(Z[512])
+    if (lane == 0) { const float2 z = zbuf[fw_sk(SP_Q)]; mag[sp_skew(SP_Q)] = hypotf(z.x * fscale, z.y * fscale); }   // X[512] = conj(Z[512])
 }
 
 // sel_blk == 0: every hop (out[h]).  sel_blk > 0: only the hops whose props survive ebur128's 100 ms re-framing, i.e. for
@@ -141,33 +228,41 @@ __global__ void __launch_bounds__(64 * SP_WAVES)
 k_aspectralstats(const float *__restrict__ in, int64_t n, int sr, const float *__restrict__ hann_g,
                  jt_spectral *__restrict__ hops, int64_t nhops, int sel_blk, int64_t nframes)
 {
-    __shared__ float2 tw[SP_HALF];
+    using Lp = FwLayout<SP_LOG2 - 1>;
+    __shared__ float2 tw[Lp::TWN];                   // per-stage twiddle rows (fw_tw_fill, f32 angles)
     __shared__ float hann[SP_HALF];                  // the f32 hann table is exactly symmetric: w[i] == w[N-1-i]
-    __shared__ float2 zb[SP_WAVES][SP_HALF];
-    __shared__ float magb[SP_WAVES][SP_HALF + 64], prevb[SP_WAVES][SP_HALF + 64];
+    __shared__ float2 zb[SP_WAVES][Lp::SKH];         // padded layout (fw_sk)
+    __shared__ float magb[SP_WAVES][SP_HALF + 64];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    for (int q = tid; q < SP_HALF; q += 64 * SP_WAVES) { float sn, cs; sincospif(2.0f * q / SP_HALF, &sn, &cs); tw[q] = make_float2(cs, -sn); }
+    fw_tw_fill<SP_LOG2 - 1, true>(tw, tid, 64 * SP_WAVES);
     for (int q = tid; q < SP_HALF; q += 64 * SP_WAVES) hann[q] = hann_g[q];
     __syncthreads();
     float2 wk[8];
 #pragma unroll
     for (int q = 0; q < 8; ++q) { double sn, cs; sincospi(2.0 * (lane + 64 * q) / SP_N, &sn, &cs); wk[q] = make_float2((float)cs, (float)-sn); }
-    float2 *zbuf = zb[wave]; float *mag = magb[wave], *prev = prevb[wave];
+    float2 *zbuf = zb[wave]; float *mag = magb[wave];
     const float max_freq = (float)(sr / 2);
     const float scale = max_freq / (float)SP_HALF;
     const int64_t nunits = sel_blk > 0 ? nframes : nhops;
     const int64_t u0 = ((int64_t)blockIdx.x * SP_WAVES + wave) * SP_RUN;
     for (int64_t unit = u0; unit < u0 + SP_RUN && unit < nunits; ++unit) {
         const int64_t h = sel_blk > 0 ? min((unit * (int64_t)sel_blk) / SP_HALF, nhops - 1) : unit;
-        // previous hop's magnitudes (zeros before the first hop)
-        if (h == 0) { for (int i = lane; i < SP_HALF + 64; i += 64) prev[i] = 0.f; }
-        else sp_frame_mags(in, n, h - 1, zbuf, tw, hann, wk, prev, lane);
+        // previous hop's magnitudes (zeros before the first hop), kept in registers: bins lane + 64 q
+        float pv[16];
+        if (h == 0) {
+#pragma unroll
+            for (int q = 0; q < 16; ++q) pv[q] = 0.f;
+        } else {
+            sp_frame_mags(in, n, h - 1, zbuf, tw, hann, wk, mag, lane);
+#pragma unroll
+            for (int q = 0; q < 16; ++q) pv[q] = mag[sp_skew(lane + 64 * q)];
+        }
         sp_frame_mags(in, n, h, zbuf, tw, hann, wk, mag, lane);
         // pass 1
         float v[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
         float mx = 0.f;
         const float m0 = mag[sp_skew(0)];
-#pragma unroll 4
+#pragma unroll
         for (int q = 0; q < 16; ++q) {
             const int i = lane + 64 * q;
             const float m = mag[sp_skew(i)];
@@ -177,7 +272,7 @@ k_aspectralstats(const float *__restrict__ in, int64_t n, int sr, const float *_
             v[2] += logf(me);                            // flatness log-sum
             v[3] += me;                                  // flatness den
             v[4] += m * logf(m + FLT_EPSILON);           // entropy
-            const float df = m - prev[sp_skew(i)];
+            const float df = m - pv[q];
             v[5] += df * df;                             // flux
             if (i >= 1) { v[6] += (m - m0) / i; v[7] += m; }   // decrease
             mx = fmaxf(mx, m);
@@ -627,126 +722,6 @@ k_afftdn(const float *__restrict__ in, float *__restrict__ out, int64_t n, Afftd
         }
         off += A; if (off >= W) off -= W;
         __syncthreads();
-    }
-}
-
-// In-place Stockham FFT of H = 2^LOG2H complex points by ONE wave (H/256 radix-4 butterflies per lane and stage, a radix-2 stage when
-// LOG2H is odd): every point of a stage is in registers before the first is written back, and the LDS operations of a wave are
-// ordered, so no barrier is needed.  Same butterflies, twiddle values and operation order as fft_stockham (bit-identical results).
-// What differs is where things sit in LDS, because the plain layout is bank-conflict bound (8-way on the stores of the stages with
-// Ns = 1, 4 and on the twiddle loads of Ns = 4..64):
-//  * point i is kept at fw_sk(i) = i + 4*(i >> 4) (four float2 of padding per sixteen points): the 16-point groups a stage with
-//    Ns = 4 scatters to then start 40 dwords apart, eight distinct bank groups;
-//  * the stage with Ns = 1 writes a lane's four consecutive outputs as two 16-byte stores;
-//  * each stage has its own twiddle rows (w, w^2, w^3 of k, contiguous: fw_tw_fill), read once per stage while k does not depend on
-//    the butterfly (Ns <= 64).
-__device__ __forceinline__ int fw_sk(int i) { return i + ((i >> 4) << 2); }
-template <int LOG2H> struct FwLayout {
-    static constexpr int H = 1 << LOG2H;
-    static constexpr int SKH = H + (H >> 2);                               // float2 per frame buffer
-    static constexpr int N4 = LOG2H / 2;                                   // radix-4 stages
-    static constexpr int TW4 = (((1 << (2 * N4)) - 4) / 3);                // 4 + 16 + ... + 4^(N4-1) rows of three
-    static constexpr int TWN = 3 * TW4 + ((LOG2H & 1) ? H / 2 : 0);        // float2 in the table
-    static constexpr int row0(int Ns) { return 3 * ((Ns - 4) / 3); }      // first float2 of the stage with this Ns (4 + ... + Ns/4 rows before)
-};
-// tws[row0(Ns) + 3 k + c] = exp(-2 pi i (c + 1) k / (4 Ns)); the radix-2 rows follow.  Every thread of the workgroup helps.
-template <int LOG2H>
-__device__ inline void fw_tw_fill(float2 *tws, int tid, int nthreads)
-{
-    using Lp = FwLayout<LOG2H>;
-    constexpr int H = Lp::H;
-    for (int i = tid; i < Lp::TWN; i += nthreads) {
-        int q;                                                             // angle index: exp(-2 pi i q / H)
-        if (i < 3 * Lp::TW4) {
-            const int r = i / 3, c = i - 3 * r;                            // row r of the concatenated stages: Ns = 4: rows 0..3, Ns = 16: 4..19, ...
-            int Ns = 4, base = 0;
-            while (r >= base + Ns) { base += Ns; Ns <<= 2; }
-            q = (c + 1) * (r - base) * (H / 4 / Ns);
-        } else q = (i - 3 * Lp::TW4);                                      // radix-2 stage: Ns = H/2, step 1
-        double sn, cs; sincospi(2.0 * q / H, &sn, &cs);
-        tws[i] = make_float2((float)cs, (float)-sn);
-    }
-}
-// One radix-4 stage of the 1024-point wave transform.  With j = lane + 64 q every padded index splits into a per-lane base and a
-// compile-time offset (lane < 64 never carries into the padding term), so the LDS operations use immediate offsets -- computed the
-// obvious way, the 150-odd loop-invariant addresses of a transform are hoisted into registers and spill:
-//   reads            fw_sk(j + 256 c)                = fw_sk(lane) + 80 q + 320 c
-//   writes, Ns = 1   fw_sk(4 j + c)                  = 4 lane + 4 (lane >> 2) + c + 320 q
-//           Ns = 4   k = lane & 3:   fw_sk(o + 4 c)  = 4 (lane - k) + k + 4 (lane >> 2) + 4 c + 320 q
-//           Ns = 16  k = lane & 15:  fw_sk(o + 16 c) = 4 (lane - k) + k + 16 (lane >> 4) + 20 c + 320 q
-//           Ns = 64  k = lane:       fw_sk(o + 64 c) = fw_sk(lane) + 80 c + 320 q
-//           Ns = 256 k = j:          fw_sk(o + 256 c) = fw_sk(lane) + 80 q + 320 c
-template <int LOG2H, bool INV, int NS>
-__device__ __forceinline__ void fw_stage4(float2 *a, const float2 *__restrict__ tws, int lane)
-{
-    static_assert(LOG2H == 10, "immediate-offset layout derived for 1024 points");
-    using Lp = FwLayout<LOG2H>;
-    constexpr int B4 = 4;
-    const float2 *al = a + fw_sk(lane);
-    float2 v[B4][4];
-#pragma unroll
-    for (int q = 0; q < B4; ++q) {
-#pragma unroll
-        for (int c = 0; c < 4; ++c) v[q][c] = al[80 * q + 320 * c];
-    }
-    float2 w1, w2, w3;
-    if (NS > 1 && NS <= 64) { const float2 *r = tws + Lp::row0(NS) + 3 * (lane & (NS - 1)); w1 = r[0]; w2 = r[1]; w3 = r[2]; }
-    const int kl = lane & (NS - 1);
-    float2 *wb = NS == 1 ? a + 4 * lane + 4 * (lane >> 2)
-               : NS == 4 ? a + 4 * (lane - kl) + kl + 4 * (lane >> 2)
-               : NS == 16 ? a + 4 * (lane - kl) + kl + 16 * (lane >> 4)
-               : a + fw_sk(lane);
-    constexpr int WC = NS == 1 ? 1 : NS == 4 ? 4 : NS == 16 ? 20 : NS == 64 ? 80 : 320;      // offset per output c
-    constexpr int WQ = NS == 256 ? 80 : 320;                                                 // offset per butterfly q
-#pragma unroll
-    for (int q = 0; q < B4; ++q) {
-        float2 v0 = v[q][0], v1 = v[q][1], v2 = v[q][2], v3 = v[q][3];
-        if (NS > 1) {
-            if (NS > 64) { const float2 *r = tws + Lp::row0(NS) + 3 * lane + 192 * q; w1 = r[0]; w2 = r[1]; w3 = r[2]; }   // k = lane + 64 q
-            float2 x1 = w1, x2 = w2, x3 = w3;
-            if (INV) { x1.y = -x1.y; x2.y = -x2.y; x3.y = -x3.y; }
-            float2 t;
-            t.x = v1.x * x1.x - v1.y * x1.y; t.y = v1.x * x1.y + v1.y * x1.x; v1 = t;
-            t.x = v2.x * x2.x - v2.y * x2.y; t.y = v2.x * x2.y + v2.y * x2.x; v2 = t;
-            t.x = v3.x * x3.x - v3.y * x3.y; t.y = v3.x * x3.y + v3.y * x3.x; v3 = t;
-        }
-        const float2 s02 = make_float2(v0.x + v2.x, v0.y + v2.y), d02 = make_float2(v0.x - v2.x, v0.y - v2.y);
-        const float2 s13 = make_float2(v1.x + v3.x, v1.y + v3.y), d13 = make_float2(v1.x - v3.x, v1.y - v3.y);
-        const float2 r13 = INV ? make_float2(-d13.y, d13.x) : make_float2(d13.y, -d13.x);
-        const float2 y0 = make_float2(s02.x + s13.x, s02.y + s13.y), y1 = make_float2(d02.x + r13.x, d02.y + r13.y);
-        const float2 y2 = make_float2(s02.x - s13.x, s02.y - s13.y), y3 = make_float2(d02.x - r13.x, d02.y - r13.y);
-        if (NS == 1) {                                                     // four consecutive points, 32-byte aligned in the padded layout
-            float4 *dst = reinterpret_cast<float4 *>(wb + WQ * q);
-            dst[0] = make_float4(y0.x, y0.y, y1.x, y1.y); dst[1] = make_float4(y2.x, y2.y, y3.x, y3.y);
-        } else { wb[WQ * q] = y0; wb[WQ * q + WC] = y1; wb[WQ * q + 2 * WC] = y2; wb[WQ * q + 3 * WC] = y3; }
-    }
-}
-template <int LOG2H, bool INV>
-__device__ inline void fft_wave(float2 *a, const float2 *__restrict__ tws, int lane)
-{
-    using Lp = FwLayout<LOG2H>;
-    constexpr int H = Lp::H, B2 = H / 2 / 64;
-    fw_stage4<LOG2H, INV, 1>(a, tws, lane);
-    if (Lp::N4 > 1) fw_stage4<LOG2H, INV, 4>(a, tws, lane);
-    if (Lp::N4 > 2) fw_stage4<LOG2H, INV, 16>(a, tws, lane);
-    if (Lp::N4 > 3) fw_stage4<LOG2H, INV, 64>(a, tws, lane);
-    if (Lp::N4 > 4) fw_stage4<LOG2H, INV, 256>(a, tws, lane);
-    if (Lp::N4 > 5) fw_stage4<LOG2H, INV, 1024>(a, tws, lane);
-    if (LOG2H & 1) {
-        constexpr int Ns = H / 2;
-        float2 v[B2][2];
-#pragma unroll
-        for (int q = 0; q < B2; ++q) { const int j = lane + 64 * q; v[q][0] = a[fw_sk(j)]; v[q][1] = a[fw_sk(j + H / 2)]; }
-#pragma unroll
-        for (int q = 0; q < B2; ++q) {
-            const int j = lane + 64 * q;                                   // k = j (Ns = H/2)
-            float2 w = tws[3 * Lp::TW4 + j];
-            if (INV) w.y = -w.y;
-            const float2 v0 = v[q][0], v1 = v[q][1];
-            float2 t; t.x = v1.x * w.x - v1.y * w.y; t.y = v1.x * w.y + v1.y * w.x;
-            a[fw_sk(j)] = make_float2(v0.x + t.x, v0.y + t.y);
-            a[fw_sk(j + Ns)] = make_float2(v0.x - t.x, v0.y - t.y);
-        }
     }
 }
 
