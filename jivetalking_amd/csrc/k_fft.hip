@@ -1133,7 +1133,7 @@ k_afftdn_grp(const float *__restrict__ in, float *__restrict__ out, int64_t n, A
         AF_MARK(6);
     }
 #ifdef JT_AF_PROFILE
-    if (tid == 0) for (int i = 0; i < 8; ++i) atomicAdd(&af_prof[i], pc[i]);
+    if (tid == JT_AF_PROFILE * 64) for (int i = 0; i < 8; ++i) atomicAdd(&af_prof[i], pc[i]);
 #endif
 }
 

@@ -1,8 +1,8 @@
 #!/bin/bash
-# Phase clocks of k_afftdn_grp (-DJT_AF_PROFILE build, run on the GPU box): cycles per workgroup in each phase, modes 0/2/1
+# Phase clocks of k_afftdn_grp as wave $AF_WAVE sees them (-DJT_AF_PROFILE=<wave> build, run on the GPU box): cycles per workgroup in each phase, modes 0/2/1
 cd "$GRAFT_REPO_ROOT"
 touch jivetalking_amd/csrc/k_fft.hip
-make -s -C jivetalking_amd/csrc EXTRA="-DJT_AF_PROFILE" 2>&1 | grep -E " error"
+make -s -C jivetalking_amd/csrc EXTRA="-DJT_AF_PROFILE=${AF_WAVE:-0}" 2>&1 | grep -E " error"
 python - <<PY 2>&1 | grep -E "clocks|ms"
 import sys, time, numpy as np
 sys.path.insert(0, '.')
