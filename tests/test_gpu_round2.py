@@ -444,3 +444,24 @@ def test_process_audio_delivers_a_file_whose_lra_prints_as_zero(engine):
     assert res.measure.input_lra == 0.0
     assert res.loudnorm.normalization_type_dynamic == 1
     assert engine.download_s16(4).size == int(np.ceil(x.size * 147 / 160))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("sr,secs", [(48000, 23.7), (44100, 9.3), (48000, 0.31)])
+def test_afftdn_grouped_kernel_equals_the_frame_at_a_time_kernel(engine, sr, secs):
+    """k_afftdn_grp (eight frames per workgroup, one wave per frame's transforms) takes every sum in k_afftdn's order: static floor,
+    custom band profile and both sweeps of tn=1 must agree bit for bit (filters.go:563-600 chain; JT_AFFTDN_OLD selects the old kernel)."""
+    r = np.random.default_rng(3)
+    n = int(sr * secs)
+    x = (0.05 * r.standard_normal(n) * (0.1 + 0.9 * (np.sin(np.arange(n) * 1.3e-4) > 0)) + 0.01 * np.sin(np.arange(n) * 0.02)).astype(np.float32)
+    def both(**kw):
+        os.environ["JT_AFFTDN_OLD"] = "1"
+        try:
+            a = engine.op_afftdn(x, sr, 12.0, -50.0, **kw)
+        finally:
+            os.environ.pop("JT_AFFTDN_OLD", None)
+        return a, engine.op_afftdn(x, sr, 12.0, -50.0, **kw)
+    for kw in ({}, {"track": True}, {"band_noise": [-38.0 - 1.5 * i for i in range(15)]}):
+        a, b = both(**kw)
+        assert np.array_equal(a, b), kw
+    assert np.max(np.abs(a - x)) > 1e-4                       # (the filter did something)
