@@ -140,26 +140,45 @@ template <typename T> __device__ inline void store_quad(T *p, T a, T b, T c, T d
 // offsets in order: a lane collects four consecutive outputs in registers before one 16-byte store (j & 3 is wave-uniform), and a
 // tap row, once in SGPRs, serves the NW windows (64 periods apart) a lane keeps in registers.  Offsets straddling a quarter boundary
 // are evaluated by both neighbours, each keeping its own outputs.  Tap order per output is unchanged.
+// Output path (measured: 6.7 GB written for a 2.8 GB stream with one 16-byte store per lane and quad -- the 64 lanes of a store sit in
+// 64 different cache lines, a line is completed by eight stores ~4 phase rows apart, and with every CU holding hundreds of open lines
+// L2 evicts them half-filled; the kernel ran at the HBM write rate, whatever fed the FMAs).  A wave therefore collects 16 consecutive
+// outputs of each of its 64 x NW windows in an LDS tile ([NW][64][17]) and writes them out line-wise: lane = 4 * window-in-sixteen +
+// quarter, one store instruction covers sixteen windows x 64 contiguous bytes (f32; 128 for f64).
 template <typename TIn, typename TAcc, typename TTap, int NW>
 __device__ inline void upsample32_stream_quads(const TIn *xin, const TTap *__restrict__ bank, int P, int step, int64_t m_lo, int64_t m_total,
-                                               double in_scale, int skewed, TAcc *__restrict__ out_stream)
+                                               double in_scale, int skewed, TAcc *__restrict__ out_stream, TAcc *otile_all)
 {
-    constexpr int L = 32;
+    constexpr int L = 32, CH = 16, OS = CH + 1;
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // uniform: scalar taps
+    TAcc *ot = otile_all + (size_t)wave * NW * 64 * OS;
     const unsigned uP = (unsigned)P, ustep = (unsigned)step;
-    const int JW = P >> 2, jw0 = wave * JW, jw1 = jw0 + JW;
+    const int JW = P >> 2, jw0 = wave * JW, jw1 = jw0 + JW;               // JW is a multiple of 4: chunks start on 16-byte boundaries
     const int off_first = (int)(((unsigned)jw0 * ustep) / uP), off_last = (int)(((unsigned)(jw1 - 1) * ustep) / uP);
-    int jlim[NW]; TAcc *orow[NW];
+    // write-out of the chunk [jc0, jc0 + cnt): window rw of sixteen, quad c
+    const int rw = lane >> 2, c4 = (lane & 3) * 4;
+    auto flush = [&](int jc0, int cnt) {
 #pragma unroll
-    for (int w = 0; w < NW; ++w) {
-        const int64_t m_base = m_lo + (int64_t)P * (w * 64 + lane);
-        const int64_t left = m_total - m_base;
-        jlim[w] = left <= 0 ? 0 : (left >= (int64_t)P ? P : (int)left);
-        orow[w] = out_stream + m_base;
-    }
-    TAcc b0[NW], b1[NW], b2[NW];
+        for (int w = 0; w < NW; ++w) {
 #pragma unroll
-    for (int w = 0; w < NW; ++w) b0[w] = b1[w] = b2[w] = (TAcc)0;
+            for (int it = 0; it < 4; ++it) {
+                const int win = 16 * it + rw;
+                const TAcc *src = ot + ((size_t)w * 64 + win) * OS + c4;
+                const TAcc v0 = src[0], v1 = src[1], v2 = src[2], v3 = src[3];
+                const int64_t m_base = m_lo + (int64_t)P * (w * 64 + win);
+                const int64_t left = m_total - m_base;                     // outputs j < left exist
+                const int j = jc0 + c4;
+                if (c4 + 3 < cnt && j + 3 < left) store_quad(out_stream + m_base + j, v0, v1, v2, v3);
+                else {
+                    if (c4 < cnt && j < left) out_stream[m_base + j] = v0;
+                    if (c4 + 1 < cnt && j + 1 < left) out_stream[m_base + j + 1] = v1;
+                    if (c4 + 2 < cnt && j + 2 < left) out_stream[m_base + j + 2] = v2;
+                    if (c4 + 3 < cnt && j + 3 < left) out_stream[m_base + j + 3] = v3;
+                }
+            }
+        }
+    };
+    int jc0 = jw0;                                                       // first output of the open chunk
     for (int off0 = off_first; off0 <= off_last; ++off0) {
         const int off = __builtin_amdgcn_readfirstlane(off0);
         int j_lo = (int)(((unsigned)off * uP + ustep - 1u) / ustep), j_hi = (int)(((unsigned)(off + 1) * uP + ustep - 1u) / ustep);
@@ -184,11 +203,9 @@ __device__ inline void upsample32_stream_quads(const TIn *xin, const TTap *__res
             }
         }
         int ph = (int)(((unsigned)j_lo * ustep) % uP);
-        for (int j = j_lo; j < j_hi; ++j) {
-            const TTap *f = bank + (size_t)(unsigned)ph * L;
-            TTap tp[L];
-#pragma unroll
-            for (int i = 0; i < L; ++i) tp[i] = f[i];
+        // the next row's taps are requested before this row's FMAs (two rows of SGPRs, used alternately): with two waves per SIMD
+        // nothing else covers the scalar-cache round trip
+        auto row = [&](const TTap (&tp)[L], int j) {
             TAcc val[NW];
 #pragma unroll
             for (int w = 0; w < NW; ++w) val[w] = (TAcc)0;
@@ -197,20 +214,33 @@ __device__ inline void upsample32_stream_quads(const TIn *xin, const TTap *__res
 #pragma unroll
                 for (int w = 0; w < NW; ++w) val[w] = fma(xw[w][i], (TAcc)tp[i], val[w]);
             }
-            const int r = j & 3;
+            const int jj = j - jc0;
 #pragma unroll
-            for (int w = 0; w < NW; ++w) {
-                if (r == 3) { if (j < jlim[w]) store_quad(orow[w] + (j - 3), b0[w], b1[w], b2[w], val[w]); }
-                else {
-                    if (r == 0) b0[w] = val[w]; else if (r == 1) b1[w] = val[w]; else b2[w] = val[w];
-                    if (j + 1 == jlim[w]) {                           // the stream ends inside this group of four (last windows only)
-                        orow[w][j - r] = b0[w];
-                        if (r >= 1) orow[w][j - r + 1] = b1[w];
-                        if (r == 2) orow[w][j] = b2[w];
-                    }
-                }
+            for (int w = 0; w < NW; ++w) ot[((size_t)w * 64 + lane) * OS + jj] = val[w];
+            if (jj == CH - 1 || j == jw1 - 1) {                            // (wave-uniform)
+                __builtin_amdgcn_wave_barrier();
+                flush(jc0, jj + 1);
+                __builtin_amdgcn_wave_barrier();
+                jc0 = j + 1;
             }
-            ph += step; ph -= ph >= P ? P : 0;
+        };
+        auto fetch_row = [&](TTap (&tp)[L], int phase) {
+            const TTap *f = bank + (size_t)(unsigned)phase * L;
+#pragma unroll
+            for (int i = 0; i < L; ++i) tp[i] = f[i];
+        };
+        TTap ta[L], tb[L];
+        if (j_lo < j_hi) fetch_row(ta, ph);
+        for (int j = j_lo; j < j_hi; j += 2) {
+            int ph1 = ph + step; ph1 -= ph1 >= P ? P : 0;
+            int ph2 = ph1 + step; ph2 -= ph2 >= P ? P : 0;
+            fetch_row(tb, ph1);                                           // (a row past the last one of this offset is simply not used)
+            row(ta, j);
+            if (j + 1 < j_hi) {
+                fetch_row(ta, ph2);
+                row(tb, j + 1);
+            }
+            ph = ph2;
         }
     }
 }
@@ -256,8 +286,10 @@ k_upsample32(const TIn *__restrict__ in, int64_t n, const TTap *__restrict__ ban
     __syncthreads();
     if constexpr (MODE == 2 && QL == 1) {
         if ((P & 15) == 0 && (R == 1 || R == 2)) {
-            if (R == 2) upsample32_stream_quads<TIn, TAcc, TTap, 2>(xin, bank, P, step, m_lo, m_total, in_scale, skewed, out_stream);
-            else upsample32_stream_quads<TIn, TAcc, TTap, 1>(xin, bank, P, step, m_lo, m_total, in_scale, skewed, out_stream);
+            // the waves' output tiles sit behind the input tile (16-byte aligned)
+            TAcc *otile = reinterpret_cast<TAcc *>(smem_pp + (((size_t)(nin + (nin >> 5) + 4) * sizeof(TIn) + 15) & ~(size_t)15));
+            if (R == 2) upsample32_stream_quads<TIn, TAcc, TTap, 2>(xin, bank, P, step, m_lo, m_total, in_scale, skewed, out_stream, otile);
+            else upsample32_stream_quads<TIn, TAcc, TTap, 1>(xin, bank, P, step, m_lo, m_total, in_scale, skewed, out_stream, otile);
             return;
         }
     }
@@ -409,7 +441,9 @@ static bool launch_upsample32(const TIn *in, int64_t n, const TTap *bank, int P,
     if (MODE == 2 && ql == 1 && (P & 15) == 0 && R == 1)
         for (int r = 2; r > 1; r >>= 1) if (sizeof(TIn) * (size_t)(64 * r * step + 64) <= 80 * 1024) { R = r; break; }
     const int T = 64 * R * ql * (int)step, nin = T + 32;
-    const size_t smem = sizeof(TIn) * (size_t)(nin + (nin >> 5) + 4);
+    size_t smem = sizeof(TIn) * (size_t)(nin + (nin >> 5) + 4);
+    if (MODE == 2 && ql == 1 && (P & 15) == 0 && (R == 1 || R == 2))          // upsample32_stream_quads: + [4 waves][R][64][17] output tiles
+        smem = ((smem + 15) & ~(size_t)15) + sizeof(TAcc) * (size_t)(PP_THREADS / 64) * R * 64 * 17;
     if (smem > 150 * 1024) return false;
     const int64_t per_block = (int64_t)64 * R * ql * P;
     const unsigned grid = (unsigned)((m_total + per_block - 1) / per_block);
