@@ -12,9 +12,9 @@ import os
 import sys
 import time
 
-# eleven HIP streams per context (main, two sets of four analysis chains, two early-start streams): ask for enough hardware
-# queues that they do not serialise behind each other (read at HIP runtime init)
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+# seven HIP streams per context (main, four analysis chains, two early-start streams): a hardware queue each (read at HIP runtime
+# init); more queues than that oversubscribe the queue slots once several contexts share a GPU (jt_api.cpp, jt_open)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")        # before torch initialises HIP (jt_open asks for the same; see the note there)
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)

@@ -18,11 +18,14 @@ extern "C" int jt_open(int device_id, jt_ctx **out)
 {
     if (!out) return JT_E_INVAL;
     *out = nullptr;
-    // one context drives eleven streams (main, two sets of four analysis chains, two early-start streams); ROCclr multiplexes streams
-    // onto GPU_MAX_HW_QUEUES (default 4)
-    // hardware queues, fixed when the runtime initialises.  Ask for more unless the host application already decided.
+    // one context drives seven streams (main, four analysis chains, two early-start streams; one of them at low priority, which has a
+    // queue pool of its own); ROCclr multiplexes streams onto GPU_MAX_HW_QUEUES (default 4) hardware queues per priority, fixed when the
+    // runtime initialises.  Ask for 8 unless the host application already decided: every stream of a context then has a queue to itself.
+    // More is worse, not better: with 16 (32 queues in the process) several contexts on one GPU oversubscribe the hardware queue slots and
+    // the driver time-slices them -- three 10-minute files in flight took 25 ms each instead of 15, five took 390 ms, six did not finish
+    // (tools/inflight_probe.py; 8 queues: 15 ms per file at 4, 6 and 8 in flight).
     static std::once_flag env_once;                    // handles may be opened from several threads (jt_process_files)
-    std::call_once(env_once, [] { setenv("GPU_MAX_HW_QUEUES", "16", 0); });
+    std::call_once(env_once, [] { setenv("GPU_MAX_HW_QUEUES", "8", 0); });
     int count = 0;
     if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) return JT_E_NOGPU;
     if (device_id < 0 || device_id >= count) return JT_E_INVAL;
@@ -41,8 +44,10 @@ extern "C" int jt_open(int device_id, jt_ctx **out)
         JT_HIP(hipEventCreateWithFlags(&h->spec_p2.done, hipEventDisableTiming));
         JT_HIP(hipStreamCreateWithFlags(&h->spec_ln.stream, hipStreamNonBlocking));
         JT_HIP(hipEventCreateWithFlags(&h->spec_ln.fork, hipEventDisableTiming));
+        // the chains of announced output regions (aux[4..7]) are small: they run behind the full analysis on its four streams
         for (int i = 0; i < 8; ++i) {
-            JT_HIP(hipStreamCreateWithFlags(&h->aux[i], hipStreamNonBlocking));
+            if (i < 4) JT_HIP(hipStreamCreateWithFlags(&h->aux[i], hipStreamNonBlocking));
+            else h->aux[i] = h->aux[i - 4];
             JT_HIP(hipEventCreateWithFlags(&h->ev_join[i], hipEventDisableTiming));
         }
     } catch (const JtError &) { delete h; return JT_E_NOGPU; }
@@ -66,7 +71,7 @@ extern "C" void jt_close(jt_ctx *h)
     if (h->spec_ln.pin) (void)hipHostFree(h->spec_ln.pin);
     if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
     for (int i = 0; i < 8; ++i) {
-        if (h->aux[i]) { (void)hipStreamSynchronize(h->aux[i]); (void)hipStreamDestroy(h->aux[i]); }
+        if (h->aux[i] && !(i >= 4 && h->aux[i] == h->aux[i - 4])) { (void)hipStreamSynchronize(h->aux[i]); (void)hipStreamDestroy(h->aux[i]); }
         if (h->ev_join[i]) (void)hipEventDestroy(h->ev_join[i]);
     }
     delete h;

@@ -1,6 +1,6 @@
 """adeclick launch time inside Pass 4 on the bench workload (HIP events): min / median over N runs.  For A/B builds."""
 import os, sys
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 sys.path.insert(0, "/root/repo")
 import numpy as np, torch
 from jivetalking_amd import Engine, synth, hostlogic
