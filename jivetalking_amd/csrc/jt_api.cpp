@@ -570,6 +570,15 @@ static void run_afftdn(jt_ctx *h, const float *in, float *out, int64_t n, int sr
     d.window = h->af_tab.p; d.alpha = d.window + pl.W; d.beta = d.alpha + nb; d.spread = d.beta + nb;
     d.abs_var = d.spread + nb * nb; d.min_abs_var = d.abs_var + bins; d.rel_var = d.min_abs_var + bins; d.twiddle = h->twiddle.p;
     d.floor = pl.floor;
+    {
+        const int H = pl.L / 2, HH = H / 2;
+        int span = 1;
+        for (int r = 0; r * 64 < HH; ++r) {
+            span = std::max(span, pl.bin2band[(size_t)std::min(64 * r + 63, HH - 1)] - pl.bin2band[(size_t)(64 * r)] + 1);
+            span = std::max(span, pl.bin2band[(size_t)(H - 64 * r)] - pl.bin2band[(size_t)std::max(H - 64 * r - 63, HH + 1)] + 1);
+        }
+        d.seg_span = span;
+    }
     if (!track) { launch_afftdn(in, out, n, d, 0, 96, h->stream); return; }     // chunk length chosen from the frame count; 96 warm-up frames
     // tn=1 (af_afftdn.c track_noise; what the reference emits when Noise.Floor == 0, adaptive.go:147-151).  The floor is a state
     // that survives arbitrarily long stretches of speech (only spectrally flat frames move it), so a warm-up halo cannot restore

@@ -126,6 +126,9 @@ struct AfftdnDev {
     // noise tracking (tn=1): band shape, the magnitude floor of the flatness measure, max_var before frame t (mvseq[t]) and after it
     // (mvseq[t + 1]); track_out[t] = the floor a spectrally flat frame votes for (NaN = frame not flat), written by the analysis mode
     const double *rel_var = nullptr; double floor = 0; const double *mvseq = nullptr; double *track_out = nullptr;
+    // most bark bands any run of 64 consecutive bins (a wave's segment of either half of the spectrum) touches: row length of the
+    // (segment, band) partial sums in k_afftdn_grp
+    int seg_span = 0;
 };
 // mode 0: static noise floor; 1: per-frame variances from d.mvseq (tn=1, second sweep); 2: tn=1 first sweep, writes d.track_out only
 void launch_afftdn(const float *in, float *out, int64_t n, const AfftdnDev &d, int frames_per_chunk, int warm_frames, hipStream_t s, int mode = 0);

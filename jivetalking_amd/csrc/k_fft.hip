@@ -90,27 +90,29 @@ __device__ inline void fw_tw_fill(float2 *tws, int tid, int nthreads)
         else { double sn, cs; sincospi(2.0 * q / H, &sn, &cs); tws[i] = make_float2((float)cs, (float)-sn); }
     }
 }
-// One radix-4 stage of the 1024-point wave transform.  With j = lane + 64 q every padded index splits into a per-lane base and a
-// compile-time offset (lane < 64 never carries into the padding term), so the LDS operations use immediate offsets -- computed the
-// obvious way, the 150-odd loop-invariant addresses of a transform are hoisted into registers and spill:
-//   reads            fw_sk(j + 256 c)                = fw_sk(lane) + 80 q + 320 c
+// One radix-4 stage of the wave transform (H = 1024 or 2048: B4 = H / 256 butterflies per lane).  With j = lane + 64 q every padded
+// index splits into a per-lane base and a compile-time offset (lane < 64 never carries into the padding term), so the LDS operations
+// use immediate offsets -- computed the obvious way, the 150-odd loop-invariant addresses of a transform are hoisted into registers
+// and spill:
+//   reads            fw_sk(j + c H/4)                = fw_sk(lane) + 80 q + (5 H / 16) c
 //   writes, Ns = 1   fw_sk(4 j + c)                  = 4 lane + 4 (lane >> 2) + c + 320 q
 //           Ns = 4   k = lane & 3:   fw_sk(o + 4 c)  = 4 (lane - k) + k + 4 (lane >> 2) + 4 c + 320 q
 //           Ns = 16  k = lane & 15:  fw_sk(o + 16 c) = 4 (lane - k) + k + 16 (lane >> 4) + 20 c + 320 q
 //           Ns = 64  k = lane:       fw_sk(o + 64 c) = fw_sk(lane) + 80 c + 320 q
-//           Ns = 256 k = j:          fw_sk(o + 256 c) = fw_sk(lane) + 80 q + 320 c
+//           Ns = 256 k = lane + 64 (q & 3):  fw_sk(o + 256 c) = fw_sk(lane) + 80 (q & 3) + 1280 (q >> 2) + 320 c
 template <int LOG2H, bool INV, int NS>
 __device__ __forceinline__ void fw_stage4(float2 *a, const float2 *__restrict__ tws, int lane)
 {
-    static_assert(LOG2H == 10, "immediate-offset layout derived for 1024 points");
+    static_assert(LOG2H == 10 || LOG2H == 11, "immediate-offset layout derived for 1024 and 2048 points");
+    static_assert(NS <= 256, "stages up to Ns = 256");
     using Lp = FwLayout<LOG2H>;
-    constexpr int B4 = 4;
+    constexpr int B4 = Lp::H / 256, RC = 5 * Lp::H / 16;
     const float2 *al = a + fw_sk(lane);
     float2 v[B4][4];
 #pragma unroll
     for (int q = 0; q < B4; ++q) {
 #pragma unroll
-        for (int c = 0; c < 4; ++c) v[q][c] = al[80 * q + 320 * c];
+        for (int c = 0; c < 4; ++c) v[q][c] = al[80 * q + RC * c];
     }
     float2 w1, w2, w3;
     if (NS > 1 && NS <= 64) { const float2 *r = tws + Lp::row0(NS) + 3 * (lane & (NS - 1)); w1 = r[0]; w2 = r[1]; w3 = r[2]; }
@@ -120,12 +122,12 @@ __device__ __forceinline__ void fw_stage4(float2 *a, const float2 *__restrict__ 
                : NS == 16 ? a + 4 * (lane - kl) + kl + 16 * (lane >> 4)
                : a + fw_sk(lane);
     constexpr int WC = NS == 1 ? 1 : NS == 4 ? 4 : NS == 16 ? 20 : NS == 64 ? 80 : 320;      // offset per output c
-    constexpr int WQ = NS == 256 ? 80 : 320;                                                 // offset per butterfly q
 #pragma unroll
     for (int q = 0; q < B4; ++q) {
+        const int wq = NS == 256 ? 80 * (q & 3) + 1280 * (q >> 2) : 320 * q;                 // offset of butterfly q (compile time)
         float2 v0 = v[q][0], v1 = v[q][1], v2 = v[q][2], v3 = v[q][3];
         if (NS > 1) {
-            if (NS > 64) { const float2 *r = tws + Lp::row0(NS) + 3 * lane + 192 * q; w1 = r[0]; w2 = r[1]; w3 = r[2]; }   // k = lane + 64 q
+            if (NS > 64) { const float2 *r = tws + Lp::row0(NS) + 3 * lane + 192 * (q & 3); w1 = r[0]; w2 = r[1]; w3 = r[2]; }   // k = lane + 64 (q & 3)
             float2 x1 = w1, x2 = w2, x3 = w3;
             if (INV) { x1.y = -x1.y; x2.y = -x2.y; x3.y = -x3.y; }
             float2 t;
@@ -139,9 +141,9 @@ __device__ __forceinline__ void fw_stage4(float2 *a, const float2 *__restrict__ 
         const float2 y0 = make_float2(s02.x + s13.x, s02.y + s13.y), y1 = make_float2(d02.x + r13.x, d02.y + r13.y);
         const float2 y2 = make_float2(s02.x - s13.x, s02.y - s13.y), y3 = make_float2(d02.x - r13.x, d02.y - r13.y);
         if (NS == 1) {                                                     // four consecutive points, 32-byte aligned in the padded layout
-            float4 *dst = reinterpret_cast<float4 *>(wb + WQ * q);
+            float4 *dst = reinterpret_cast<float4 *>(wb + wq);
             dst[0] = make_float4(y0.x, y0.y, y1.x, y1.y); dst[1] = make_float4(y2.x, y2.y, y3.x, y3.y);
-        } else { wb[WQ * q] = y0; wb[WQ * q + WC] = y1; wb[WQ * q + 2 * WC] = y2; wb[WQ * q + 3 * WC] = y3; }
+        } else { wb[wq] = y0; wb[wq + WC] = y1; wb[wq + 2 * WC] = y2; wb[wq + 3 * WC] = y3; }
     }
 }
 template <int LOG2H, bool INV>
@@ -154,21 +156,22 @@ __device__ inline void fft_wave(float2 *a, const float2 *__restrict__ tws, int l
     if (Lp::N4 > 2) fw_stage4<LOG2H, INV, 16>(a, tws, lane);
     if (Lp::N4 > 3) fw_stage4<LOG2H, INV, 64>(a, tws, lane);
     if (Lp::N4 > 4) fw_stage4<LOG2H, INV, 256>(a, tws, lane);
-    if (Lp::N4 > 5) fw_stage4<LOG2H, INV, 1024>(a, tws, lane);
     if (LOG2H & 1) {
-        constexpr int Ns = H / 2;
+        // the radix-2 stage (Ns = H/2, k = j = lane + 64 q): points j and j + H/2 at fw_sk(lane) + 80 q (+ 5 H / 8), written back in place
+        float2 *al = a + fw_sk(lane);
+        const float2 *tl = tws + 3 * Lp::TW4 + lane;
+        constexpr int HO = 5 * H / 8;
         float2 v[B2][2];
 #pragma unroll
-        for (int q = 0; q < B2; ++q) { const int j = lane + 64 * q; v[q][0] = a[fw_sk(j)]; v[q][1] = a[fw_sk(j + H / 2)]; }
+        for (int q = 0; q < B2; ++q) { v[q][0] = al[80 * q]; v[q][1] = al[80 * q + HO]; }
 #pragma unroll
         for (int q = 0; q < B2; ++q) {
-            const int j = lane + 64 * q;                                   // k = j (Ns = H/2)
-            float2 w = tws[3 * Lp::TW4 + j];
+            float2 w = tl[64 * q];
             if (INV) w.y = -w.y;
             const float2 v0 = v[q][0], v1 = v[q][1];
             float2 t; t.x = v1.x * w.x - v1.y * w.y; t.y = v1.x * w.y + v1.y * w.x;
-            a[fw_sk(j)] = make_float2(v0.x + t.x, v0.y + t.y);
-            a[fw_sk(j + Ns)] = make_float2(v0.x - t.x, v0.y - t.y);
+            al[80 * q] = make_float2(v0.x + t.x, v0.y + t.y);
+            al[80 * q + HO] = make_float2(v0.x - t.x, v0.y - t.y);
         }
     }
 }
@@ -756,8 +759,8 @@ k_afftdn_grp(const float *__restrict__ in, float *__restrict__ out, int64_t n, A
     constexpr int ZP = NT + NT / 4;                             // fw_sk(i + NT) - fw_sk(i)
     float2 *zb = reinterpret_cast<float2 *>(smem_raw);          // [G][ZS]
     float2 *tw = zb + G * ZS;                                   // per-stage twiddle rows [Lp::TWN (+1)]
-    const int nb = d.nbands, pst = nb | 1;
-    double *part = reinterpret_cast<double *>(tw + ((Lp::TWN + 1) & ~1));          // [G][NSEG][pst]   (MODE 2: [G][G][5])
+    const int nb = d.nbands, pst = (d.seg_span > 0 ? d.seg_span : nb) | 1;          // (a segment's bands are consecutive)
+    double *part = reinterpret_cast<double *>(tw + ((Lp::TWN + 1) & ~1));          // [G][NSEG][pst]   (MODE 2: [G][G][5], G <= 8 < NSEG)
     double *spread = part + G * NSEG * pst;                     // [nb][nb]
     double *band_excit = spread + nb * nb;                      // [G][AF_MAXBANDS]
     double *band_amt = band_excit + G * AF_MAXBANDS;
@@ -1161,20 +1164,23 @@ void launch_afftdn(const float *in, float *out, int64_t n, const AfftdnDev &d, i
         frames_per_chunk = (int)std::min<int64_t>(1024, std::max<int64_t>(128, (nframes + 511) / 512));
     }
     unsigned grid = (unsigned)((nframes + frames_per_chunk - 1) / frames_per_chunk);
-    if (d.L == 2048 && d.W <= 2048 && !getenv("JT_AFFTDN_OLD")) {
-        // eight frames at a time, one wave per frame's transforms (k_afftdn_grp): 132 KB of LDS, one workgroup of eight waves per CU,
-        // so one resident round is 256 chunks
-        constexpr int G = 8, Hh = 1024, NSEGh = 2 * (Hh / 2 / 64) + 1;
+    if ((d.L == 2048 || d.L == 4096) && d.W <= d.L && !getenv("JT_AFFTDN_OLD")) {
+        // several frames at a time, one wave per frame's transforms (k_afftdn_grp): one workgroup per CU (132 KB of LDS with eight
+        // 2048-point frames, 150 KB with four 4096-point frames), so one resident round is 256 chunks
+        const bool big = d.L == 4096;
+        const int G = big ? 4 : 8, Hh = d.L / 2, NSEGh = 2 * (Hh / 2 / 64) + 1;
         if (auto_chunk) frames_per_chunk = (int)std::min<int64_t>(4096, std::max<int64_t>(128, (nframes + 255) / 256));
         grid = (unsigned)((nframes + frames_per_chunk - 1) / frames_per_chunk);
-        using Lp = FwLayout<10>;
-        const int pst = d.nbands | 1;
-        const size_t smem = sizeof(float2) * (G * Lp::SKH + ((Lp::TWN + 1) & ~1))
+        const int pst = (d.seg_span > 0 ? d.seg_span : d.nbands) | 1;
+        const size_t skh = big ? FwLayout<11>::SKH : FwLayout<10>::SKH, twn = big ? FwLayout<11>::TWN : FwLayout<10>::TWN;
+        const size_t smem = sizeof(float2) * (G * skh + ((twn + 1) & ~(size_t)1))
                           + sizeof(double) * ((size_t)G * NSEGh * pst + (size_t)d.nbands * d.nbands + 3 * G * AF_MAXBANDS + (6 + G + ((6 + G) & 1)) + ((d.W + 1) & ~1))
                           + sizeof(int) * (NSEGh + 1 + 2 * AF_MAXBANDS);
-#define AF_GRP(M) do { JT_HIP(hipFuncSetAttribute((const void *)k_afftdn_grp<11, M, G>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem)); \
-        hipLaunchKernelGGL((k_afftdn_grp<11, M, G>), dim3(grid), dim3(64 * G), smem, s, in, out, n, d, frames_per_chunk, warm_frames, nframes); } while (0)
-        if (mode == 1) AF_GRP(1); else if (mode == 2) AF_GRP(2); else AF_GRP(0);
+        JT_REQUIRE(smem <= 160 * 1024, JT_E_UNSUPPORTED, "afftdn: window too long for this build");
+#define AF_GRP(LG, M, GG) do { JT_HIP(hipFuncSetAttribute((const void *)k_afftdn_grp<LG, M, GG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem)); \
+        hipLaunchKernelGGL((k_afftdn_grp<LG, M, GG>), dim3(grid), dim3(64 * GG), smem, s, in, out, n, d, frames_per_chunk, warm_frames, nframes); } while (0)
+        if (big) { if (mode == 1) AF_GRP(12, 1, 4); else if (mode == 2) AF_GRP(12, 2, 4); else AF_GRP(12, 0, 4); }
+        else { if (mode == 1) AF_GRP(11, 1, 8); else if (mode == 2) AF_GRP(11, 2, 8); else AF_GRP(11, 0, 8); }
 #undef AF_GRP
 #ifdef JT_AF_PROFILE
         { unsigned long long pr[16]; JT_HIP(hipStreamSynchronize(s)); JT_HIP(hipMemcpyFromSymbol(pr, HIP_SYMBOL(af_prof), sizeof pr)); unsigned long long z[16] = {0};

@@ -447,9 +447,9 @@ def test_process_audio_delivers_a_file_whose_lra_prints_as_zero(engine):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("sr,secs", [(48000, 23.7), (44100, 9.3), (48000, 0.31)])
+@pytest.mark.parametrize("sr,secs", [(48000, 23.7), (44100, 9.3), (48000, 0.31), (96000, 11.9), (88200, 2.2)])
 def test_afftdn_grouped_kernel_equals_the_frame_at_a_time_kernel(engine, sr, secs):
-    """k_afftdn_grp (eight frames per workgroup, one wave per frame's transforms) takes every sum in k_afftdn's order: static floor,
+    """k_afftdn_grp (eight 2048-point or four 4096-point frames per workgroup, one wave per frame's transforms) takes every sum in k_afftdn's order: static floor,
     custom band profile and both sweeps of tn=1 must agree bit for bit (filters.go:563-600 chain; JT_AFFTDN_OLD selects the old kernel)."""
     r = np.random.default_rng(3)
     n = int(sr * secs)
