@@ -730,6 +730,7 @@ extern "C" int jt_pass2(jt_ctx *h, const jt_filter_params *p, jt_analysis *out)
     const int64_t n = h->n; const int sr = h->sr;
     const int out_rate = p->out_rate > 0 ? p->out_rate : 44100;
     spec_loudnorm_cancel(h);
+    h->lim_keep.valid = false;
     jt_ctx::RegionSlot &slot = h->region_slot[0];
     slot.valid = false; h->region_slot[1].valid = false;            // both stage outputs are about to be replaced
     const bool announced = slot.armed; slot.armed = false;
@@ -880,12 +881,14 @@ static void pass3_core(jt_ctx *h, const int16_t *s16, int64_t m, int rate, const
     }
     pass_begin(h, m * 192000 / rate + 600000, 1);
     LoudnormJob J;
+    h->lim_keep.valid = false;
     if (lim && lim->needed) {
         h->f64_a.ensure((size_t)m); h->f64_b.ensure((size_t)m);
         const bool pre = lim->pre_gain_db > 0;
         const double g = pre ? std::pow(10.0, lim->pre_gain_db / 20.0) : 1.0;
         launch_s16_to_f64(s16, h->f64_a.p, m, g, pre ? 1 : 0, h->stream);
         run_limiter(h, h->f64_a.p, h->f64_b.p, m, rate, lim->limit, 5.0, 100.0, 1.0);
+        h->lim_keep = {true, s16, m, rate, lim->pre_gain_db, lim->limit};
         loudnorm_measure_enqueue(h, nullptr, h->f64_b.p, m, rate, &J);
     } else {
         loudnorm_measure_enqueue(h, s16, nullptr, m, rate, &J);
@@ -1029,8 +1032,15 @@ extern "C" int jt_pass4(jt_ctx *h, const jt_limiter_plan *lim, const jt_loudnorm
     h->f64_a.ensure((size_t)m); h->f64_b.ensure((size_t)m);
     double *sig = h->f64_a.p, *tmp = h->f64_b.p;
     const bool pre = lim && lim->needed && lim->pre_gain_db > 0;
-    launch_s16_to_f64(h->s16_p2.p, sig, m, pre ? std::pow(10.0, lim->pre_gain_db / 20.0) : 1.0, pre ? 1 : 0, h->stream);
-    if (lim && lim->needed) { run_limiter(h, sig, tmp, m, rate, lim->limit, 5.0, 100.0, 1.0); std::swap(sig, tmp); }
+    const jt_ctx::LimKeep &lk = h->lim_keep;
+    const bool kept = lk.valid && lim && lim->needed && lk.src == h->s16_p2.p && lk.m == m && lk.rate == rate &&
+                      lk.pre_gain_db == lim->pre_gain_db && lk.limit == lim->limit && !getenv("JT_NO_LIM_KEEP");
+    h->lim_keep.valid = false;                                  // (this pass overwrites both buffers)
+    if (kept) std::swap(sig, tmp);                              // Pass 3 ran this prefix on these samples: its output is still in f64_b
+    else {
+        launch_s16_to_f64(h->s16_p2.p, sig, m, pre ? std::pow(10.0, lim->pre_gain_db / 20.0) : 1.0, pre ? 1 : 0, h->stream);
+        if (lim && lim->needed) { run_limiter(h, sig, tmp, m, rate, lim->limit, 5.0, 100.0, 1.0); std::swap(sig, tmp); }
+    }
     check_cancel(h);
     // loudnorm r128_in / r128_out statistics (libavfilter/ebur128.c) at the stream rate
     KwJob sj; const int sblk = (rate + 5) / 10;

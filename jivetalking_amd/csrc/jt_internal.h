@@ -251,6 +251,9 @@ struct jt_ctx {
     DevBuf<int16_t> s16_p2, s16_p4;     // Pass-2 / Pass-4 outputs
     int64_t m_p2 = 0, m_p4 = 0; int out_rate = 0;
     DevBuf<double> f64_a, f64_b, f64_c; // f64 ping-pong at output rate (+ the brickwall's output when adeclick's input is still being metered)
+    // Pass 3 leaves the alimiter prefix's output in f64_b; Pass 4 applies the same prefix to the same samples and takes it from there
+    // (set by pass3_core, dropped by anything that rewrites the Pass-2 output or the f64 buffers)
+    struct LimKeep { bool valid = false; const int16_t *src = nullptr; int64_t m = 0; int rate = 0; double pre_gain_db = 0, limit = 0; } lim_keep;
     DevBuf<float> stream_f; DevBuf<double> stream_d;   // 192 kHz loudnorm-measurement stream
     DevBuf<double> stream_y, ln_ring, ln_series;       // loudnorm dynamic mode: output stream, limiter ring, per-frame series
     // scratch

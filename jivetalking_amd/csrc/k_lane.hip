@@ -1022,7 +1022,8 @@ k_limiter_f64(const double *__restrict__ in, double *__restrict__ out, int64_t n
 {
     __shared__ double tx[LANES][TW + 1];
     __shared__ double te[LANES][TW + 1];
-    __shared__ int64_t s_lo[LANES], s_hi[LANES];
+    __shared__ int64_t s_lo[LANES], s_hi[LANES], s_len[LANES];
+    __shared__ int act[LANES];
     const int lane = threadIdx.x;
     const int64_t c = (int64_t)blockIdx.x * LANES + lane;
     int64_t lo = -1, hi = -1;
@@ -1049,6 +1050,12 @@ k_limiter_f64(const double *__restrict__ in, double *__restrict__ out, int64_t n
     int64_t max_len = my_len;
     for (int o = 32; o > 0; o >>= 1) max_len = max(max_len, __shfl_xor(max_len, o, 64));
     if (max_len == 0) return;                 // (one wave per workgroup: uniform) every segment of this workgroup stays at rest
+    // only the rows that run the state machine are staged (a workgroup usually has one or two of its 64 candidates hot: staging all
+    // 64 rows of every tile made this kernel read ~50 times what it needed)
+    s_len[lane] = my_len;
+    const unsigned long long hot_mask = __ballot(active);
+    const int nact = __popcll(hot_mask);
+    if (active) act[__popcll(hot_mask & ((1ull << lane) - 1ull))] = lane;
     __syncthreads();
     double *nextdelta = sdelta + (size_t)c * B;
     int64_t *nextpos = spos + (size_t)c * B;
@@ -1057,21 +1064,26 @@ k_limiter_f64(const double *__restrict__ in, double *__restrict__ out, int64_t n
     int nextiter = 0, nextlen = 0;
     for (int64_t pos = 0; pos < max_len; pos += TW) {
         // stage: row r, column = lane
-        for (int r0 = 0; r0 < LANES; r0 += 16) {
-            double vx[16], ve[16];
+        for (int a0 = 0; a0 < nact; a0 += 8) {
+            double vx[8], ve[8]; int rr[8];
 #pragma unroll
-            for (int q = 0; q < 16; ++q) {
-                const int64_t rl = s_lo[r0 + q];
+            for (int q = 0; q < 8; ++q) {
+                rr[q] = a0 + q < nact ? act[a0 + q] : -1;
+                if (rr[q] >= 0 && pos >= s_len[rr[q]]) rr[q] = -1;            // that segment is finished
+                vx[q] = 0.0; ve[q] = 0.0;
+                if (rr[q] < 0) continue;                                       // (uniform)
+                const int64_t rl = s_lo[rr[q]];
                 const int64_t ix = rl + pos + lane, ie = ix - (B - 1);
                 const int64_t cx = ix < 0 ? 0 : (ix >= n ? n - 1 : ix), ce = ie < 0 ? 0 : (ie >= n ? n - 1 : ie);
                 vx[q] = in[cx]; ve[q] = in[ce];
             }
 #pragma unroll
-            for (int q = 0; q < 16; ++q) {
-                const int64_t rl = s_lo[r0 + q];
+            for (int q = 0; q < 8; ++q) {
+                if (rr[q] < 0) continue;
+                const int64_t rl = s_lo[rr[q]];
                 const int64_t ix = rl + pos + lane, ie = ix - (B - 1);
-                tx[r0 + q][lane] = (rl >= 0 && ix < n) ? vx[q] * in_gain : 0.0;
-                te[r0 + q][lane] = (rl >= 0 && ie >= 0 && ie < n) ? ve[q] * in_gain : 0.0;
+                tx[rr[q]][lane] = ix < n ? vx[q] * in_gain : 0.0;
+                te[rr[q]][lane] = (ie >= 0 && ie < n) ? ve[q] * in_gain : 0.0;
             }
         }
         __syncthreads();
@@ -1156,10 +1168,10 @@ k_limiter_f64(const double *__restrict__ in, double *__restrict__ out, int64_t n
         }
         __syncthreads();
         // coalesced store of the emitted samples: row r column lane is sample lo_r + pos + lane - (B-1)
-#pragma unroll 4
-        for (int r = 0; r < LANES; ++r) {
+        for (int a = 0; a < nact; ++a) {
+            const int r = act[a];
+            if (pos >= s_len[r]) continue;
             const int64_t rl = s_lo[r];
-            if (rl < 0) continue;
             const int64_t e = rl + pos + lane - (B - 1);
             if (e >= rl && e < s_hi[r]) out[e] = te[r][lane];
         }

@@ -145,7 +145,7 @@ template <typename T> __device__ inline void store_quad(T *p, T a, T b, T c, T d
 // L2 evicts them half-filled; the kernel ran at the HBM write rate, whatever fed the FMAs).  A wave therefore collects 16 consecutive
 // outputs of each of its 64 x NW windows in an LDS tile ([NW][64][17]) and writes them out line-wise: lane = 4 * window-in-sixteen +
 // quarter, one store instruction covers sixteen windows x 64 contiguous bytes (f32; 128 for f64).
-template <typename TIn, typename TAcc, typename TTap, int NW>
+template <typename TIn, typename TAcc, typename TTap, int NW, int NWV = 4>
 __device__ inline void upsample32_stream_quads(const TIn *xin, const TTap *__restrict__ bank, int P, int step, int64_t m_lo, int64_t m_total,
                                                double in_scale, int skewed, TAcc *__restrict__ out_stream, TAcc *otile_all)
 {
@@ -153,7 +153,7 @@ __device__ inline void upsample32_stream_quads(const TIn *xin, const TTap *__res
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // uniform: scalar taps
     TAcc *ot = otile_all + (size_t)wave * NW * 64 * OS;
     const unsigned uP = (unsigned)P, ustep = (unsigned)step;
-    const int JW = P >> 2, jw0 = wave * JW, jw1 = jw0 + JW;               // JW is a multiple of 4: chunks start on 16-byte boundaries
+    const int JW = P / NWV, jw0 = wave * JW, jw1 = jw0 + JW;              // JW is a multiple of 4: chunks start on 16-byte boundaries
     const int off_first = (int)(((unsigned)jw0 * ustep) / uP), off_last = (int)(((unsigned)(jw1 - 1) * ustep) / uP);
     // write-out of the chunk [jc0, jc0 + cnt): window rw of sixteen, quad c
     const int rw = lane >> 2, c4 = (lane & 3) * 4;
@@ -430,6 +430,40 @@ k_upsample32(const TIn *__restrict__ in, int64_t n, const TTap *__restrict__ ban
     }
 }
 
+// The stream upsampler with eight waves per workgroup, for sources whose tile leaves room for one workgroup per CU only (f64: a tile
+// of 64 windows x 147 samples is 75 KB).  With one window per lane a row is 32 dependent FMAs, so a SIMD needs a second wave to keep
+// issuing: four waves per CU ran at 10 ms for the hour-long stream, eight at half that.
+template <typename TIn, typename TAcc, typename TTap>
+__global__ void __launch_bounds__(512)
+k_upsample32_stream8(const TIn *__restrict__ in, int64_t n, const TTap *__restrict__ bank, int P, int center, int step, int64_t m_total,
+                     double in_scale, TAcc *__restrict__ out_stream)
+{
+    constexpr int L = 32;
+    extern __shared__ unsigned char smem_pp[];
+    TIn *xin = reinterpret_cast<TIn *>(smem_pp);
+    const int T = 64 * step, nin = T + L;
+    const int tid = threadIdx.x;
+    const int64_t s0 = (int64_t)blockIdx.x * T;
+    const int64_t m_lo = (int64_t)blockIdx.x * 64 * P;
+    if (m_lo >= m_total) return;
+    if (s0 - center >= 0 && s0 - center + nin <= n) {
+        const TIn *src = in + (s0 - center);                         // interior workgroup: no reflection, no end of stream
+        for (int i = tid; i < nin; i += 512) xin[i] = src[i];
+    } else {
+        for (int i = tid; i < nin; i += 512) {
+            int64_t g = s0 - center + i;
+            TIn v = (TIn)0;
+            if (g < 0) g = -g;                                       // invert_initial_buffer(): in[-j] = in[j]
+            if (g < n) v = in[g];
+            else { int64_t r = 2 * n - 1 - g; if (r >= 0 && r < n) v = in[r]; }   // resample_flush()
+            xin[i] = v;
+        }
+    }
+    __syncthreads();
+    TAcc *otile = reinterpret_cast<TAcc *>(smem_pp + (((size_t)(nin + 4) * sizeof(TIn) + 15) & ~(size_t)15));
+    upsample32_stream_quads<TIn, TAcc, TTap, 1, 8>(xin, bank, P, step, m_lo, m_total, in_scale, 0, out_stream, otile);
+}
+
 template <typename TIn, typename TAcc, typename TTap, int MODE>
 static bool launch_upsample32(const TIn *in, int64_t n, const TTap *bank, int P, int L, int center, int64_t step, int64_t m_total,
                               double in_scale, int blk, double *block_tp, int64_t nblocks_alloc, TAcc *out, hipStream_t s)
@@ -440,6 +474,18 @@ static bool launch_upsample32(const TIn *in, int64_t n, const TTap *bank, int P,
     // stream output with per-lane window groups (upsample32_stream_quads): as many windows per lane as a <= 80 KB tile allows
     if (MODE == 2 && ql == 1 && (P & 15) == 0 && R == 1)
         for (int r = 2; r > 1; r >>= 1) if (sizeof(TIn) * (size_t)(64 * r * step + 64) <= 80 * 1024) { R = r; break; }
+    if constexpr (MODE == 2) {
+        if (ql == 1 && R == 1 && (P & 31) == 0 && (step & 1) && !getenv("JT_UPS_NO_STREAM8")) {
+            const size_t sm8 = ((sizeof(TIn) * (size_t)(64 * step + 32 + 4) + 15) & ~(size_t)15) + sizeof(TAcc) * (size_t)8 * 64 * 17;
+            if (sm8 <= 150 * 1024) {
+                auto k8 = k_upsample32_stream8<TIn, TAcc, TTap>;
+                JT_HIP(hipFuncSetAttribute((const void *)k8, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm8));
+                const int64_t pb = (int64_t)64 * P;
+                hipLaunchKernelGGL(k8, dim3((unsigned)((m_total + pb - 1) / pb)), dim3(512), sm8, s, in, n, bank, P, center, (int)step, m_total, in_scale, out);
+                return true;
+            }
+        }
+    }
     const int T = 64 * R * ql * (int)step, nin = T + 32;
     size_t smem = sizeof(TIn) * (size_t)(nin + (nin >> 5) + 4);
     if (MODE == 2 && ql == 1 && (P & 15) == 0 && (R == 1 || R == 2))          // upsample32_stream_quads: + [4 waves][R][64][17] output tiles
