@@ -21,6 +21,7 @@
 // k_anlmdn (generic path, any K/S): one workgroup per hop, one thread per offset, weights transposed through an LDS tile and
 //   summed in FFmpeg's sequential offset order.
 #include "jt_internal.h"
+#include <type_traits>
 
 // ------------------------------------------------------------------ wave-per-hop fast path
 #define JT_DPP(v, ctrl, rmask) __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), (ctrl), (rmask), 0xf, false))
@@ -418,7 +419,7 @@ __device__ inline void nlm3_consume(const f2 *fw, const f2 *slot, const f2 *dslo
 
 template <int NOFF>
 __global__ void __launch_bounds__(64)
-k_anlmdn_pair3(const float *__restrict__ in, float *__restrict__ out, int64_t n, int K, float sw, float smooth, float lut_scale)
+k_anlmdn_pair3(const float *__restrict__ in, float *__restrict__ out, int64_t n, int K, int Sreal, float sw, float smooth, float lut_scale)
 {
     extern __shared__ float smem_nlm[];
     constexpr int S = Nlm3<NOFF>::S, R = Nlm3<NOFF>::R, NEAR0 = Nlm3<NOFF>::NEAR0, NL = Nlm3<NOFF>::NL;
@@ -430,7 +431,9 @@ k_anlmdn_pair3(const float *__restrict__ in, float *__restrict__ out, int64_t n,
     f2 *dslot = slot + 12 * NLM3_CB;              // [65] outputs of replayed steps (+1: the hop's first step)
     const int lane = threadIdx.x;
     const int64_t hopA = (int64_t)blockIdx.x * 2;
-    const int64_t hs = hopA * H - (K + S);
+    // S is the lane layout's radius (64 lanes x NOFF offsets = -S..-1, 1..S); the filter's own radius Sreal <= S sets where the hops
+    // start, and the offsets beyond it are dummies: their distance is +inf from the seed on, so they never engage and weigh nothing
+    const int64_t hs = hopA * H - (K + Sreal);
     const int64_t gwin = hs - (K + S);
     NLM_PROF_DECL;
     NLM_T(t_a);
@@ -477,7 +480,8 @@ k_anlmdn_pair3(const float *__restrict__ in, float *__restrict__ out, int64_t n,
         for (int u = 0; u < 8; ++u) ca[u] = fw[S - K + u];
         const f2 *pw = fw + S + d0 + 8 - K;                    // pw[u]: the stream position 8 ahead of step u
         const f2 *pc = fw + S - K + 8;
-        for (int k0 = -K; k0 < K; k0 += 16) {
+        const int n16 = (2 * K) / 16;                                        // 2K + 1 terms: n16 rounds of sixteen, then 1 .. 16 more
+        for (int it16 = 0; it16 < n16; ++it16) {
 #pragma unroll
             for (int u = 0; u < 8; ++u) cb[u] = pc[u];
 #pragma unroll
@@ -496,9 +500,21 @@ k_anlmdn_pair3(const float *__restrict__ in, float *__restrict__ out, int64_t n,
             }
             pw += 16; pc += 16;
         }
-        // k = K, the (2K+1)-th term: 2K % 16 == 0 puts it at ring position 0 with its centre already in ca[0]
+        // the remaining 1 .. 16 terms (k ascending as before) straight from the window: one term when 2K is a multiple of 16
+#pragma unroll 1
+        for (int t = 16 * n16; t <= 2 * K; ++t) {
+            const f2 c = fw[S - K + t];
 #pragma unroll
-        for (int q = 0; q < NOFF; ++q) { const f2 dd = ca[0] - st[q]; cache[q] = cache[q] + dd * dd; }
+            for (int q = 0; q < NOFF; ++q) { const f2 dd = c - fw[S + d0 + q - K + t]; cache[q] = cache[q] + dd * dd; }
+        }
+    }
+    if (Sreal < S) {
+        const float inf = __builtin_inff();
+#pragma unroll
+        for (int q = 0; q < NOFF; ++q) {
+            const int j = j0 + q, d = j - S + (j >= S ? 1 : 0);
+            if (d < -Sreal || d > Sreal) cache[q] = f2{inf, inf};
+        }
     }
     const float dthr = (smooth / sw) * 1.000002f;
     NLM_T(t_c); NLM_ACC(1, t_b, t_c);
@@ -529,7 +545,7 @@ k_anlmdn_pair3(const float *__restrict__ in, float *__restrict__ out, int64_t n,
     nlm_centre4<false>(in, 0, fw, S + 1 - K - 1, H, ma);
     nlm_centre4<false>(in, 0, fw, S + 1 + K, H, pa);
     unsigned long long emask = 0, dmask = 0;
-    const int nb8 = K / 4;                                   // 2K / 8 blocks of eight steps
+    const int nb8 = (2 * K) / 8, r8 = 2 * K - 8 * nb8;       // blocks of eight steps, then r8 = 0, 2, 4 or 6 steps by the exact per-step path
     const bool near = lane >= NEAR0 && lane < NEAR0 + NL;
     for (int b8 = 0; b8 < nb8; ++b8) {
         const int i0 = S + 1 + b8 * 8;
@@ -575,11 +591,17 @@ k_anlmdn_pair3(const float *__restrict__ in, float *__restrict__ out, int64_t n,
             }
         }
         NLM_T(t_3);
-        if (it == NLM3_B8 - 1 || b8 == nb8 - 1) {
+        if (it == NLM3_B8 - 1 || (b8 == nb8 - 1 && r8 == 0)) {
             nlm3_consume<NOFF>(fw, slot, dslot, emask, dmask, 1 + (b8 - it) * 8, (it + 1) * 8, H, out, hs, n, sw, smooth, lut_scale, nisl, lane);
             emask = dmask = 0;
             NLM_T(t_4); NLM_ACC(5, t_3, t_4);
         }
+    }
+    if (r8) {
+        // 2K not a multiple of 8 (44.1 kHz: K = 265): the hop's last r8 steps, and whatever the last turn-round block still holds
+        const int it = nb8 % NLM3_B8;
+        nlm3_slow_steps<NOFF>(cache, S + 1 + nb8 * 8, r8, d0, K, fw, dslot, it * 8, dmask, sw, smooth, lut_scale, nisl, dthr, lane);
+        nlm3_consume<NOFF>(fw, slot, dslot, emask, dmask, 1 + (nb8 - it) * 8, it * 8 + r8, H, out, hs, n, sw, smooth, lut_scale, nisl, lane);
     }
     NLM_PROF_FLUSH;
 }
@@ -665,16 +687,19 @@ void launch_anlmdn(const float *in, float *out, int64_t n, int K, int S, float s
     const int H = 2 * K + 1;
     const int NW = H + 2 * (K + S);
     int64_t nhops = (n + (K + S) + H - 1) / H;
-    // 64 lanes x 3 adjacent offsets (48 / 44.1 kHz defaults) or x 6 (96 kHz), 2K a multiple of 8
-    const bool fast = ((2 * S) == 192 || (2 * S) == 384) && K % 4 == 0;
-    if (fast) {
-        size_t smem = sizeof(float) * 2 * (size_t)(NLM_PADF + NW + NLM_PADB);      // interleaved {hop A, hop B} window
-        JT_REQUIRE(smem <= 64 * 1024, JT_E_UNSUPPORTED, "anlmdn: window exceeds the wave-per-hop LDS budget");
+    // 64 lanes x 3 adjacent offsets (radius up to 96: the 44.1 / 48 kHz defaults) or x 6 (up to 192: 88.2 / 96 kHz); a radius below the
+    // layout's leaves dummy offsets at both ends, any patch length of 8 or more
+    const int Sl = S <= 96 ? 96 : (S <= 192 ? 192 : 0);
+    if (Sl && K >= 8 && !getenv("JT_NLM_GENERIC")) {
+        const int NWl = H + 2 * (K + Sl);
+        size_t smem = sizeof(float) * 2 * (size_t)(NLM_PADF + NWl + NLM_PADB);      // interleaved {hop A, hop B} window
         const unsigned grid = (unsigned)((nhops + 1) / 2);
-        if (K % 8 == 0 && !getenv("JT_NLM_OLD")) {
+        const bool exact_layout = 2 * S == 2 * Sl;
+        if (!(exact_layout && K % 4 == 0 && getenv("JT_NLM_OLD"))) {              // (JT_NLM_OLD: the round-1 kernel, A/B only)
             smem += sizeof(float) * 2 * (size_t)(12 * NLM3_CB + NLM3_CB + 1);
-            if (2 * S == 192) hipLaunchKernelGGL((k_anlmdn_pair3<3>), dim3(grid), dim3(64), smem, s, in, out, n, K, sw, smooth, lut_scale);
-            else hipLaunchKernelGGL((k_anlmdn_pair3<6>), dim3(grid), dim3(64), smem, s, in, out, n, K, sw, smooth, lut_scale);
+            JT_REQUIRE(smem <= 64 * 1024, JT_E_UNSUPPORTED, "anlmdn: window exceeds the wave-per-hop LDS budget");
+            if (Sl == 96) hipLaunchKernelGGL((k_anlmdn_pair3<3>), dim3(grid), dim3(64), smem, s, in, out, n, K, S, sw, smooth, lut_scale);
+            else hipLaunchKernelGGL((k_anlmdn_pair3<6>), dim3(grid), dim3(64), smem, s, in, out, n, K, S, sw, smooth, lut_scale);
 #ifdef JT_NLM_PROFILE
             {
                 unsigned long long pr[8], z[8] = {0};
@@ -686,8 +711,11 @@ void launch_anlmdn(const float *in, float *out, int64_t n, int K, int S, float s
                         (double)pr[5] / grid, (double)pr[6] / grid, (double)pr[7] / grid, K / 4);
             }
 #endif
-        } else if (2 * S == 192) hipLaunchKernelGGL((k_anlmdn_pair<3>), dim3(grid), dim3(64), smem, s, in, out, n, K, S, sw, smooth, lut_scale, nhops);
-        else hipLaunchKernelGGL((k_anlmdn_pair<6>), dim3(grid), dim3(64), smem, s, in, out, n, K, S, sw, smooth, lut_scale, nhops);
+        } else {
+            JT_REQUIRE(smem <= 64 * 1024, JT_E_UNSUPPORTED, "anlmdn: window exceeds the wave-per-hop LDS budget");
+            if (2 * S == 192) hipLaunchKernelGGL((k_anlmdn_pair<3>), dim3(grid), dim3(64), smem, s, in, out, n, K, S, sw, smooth, lut_scale, nhops);
+            else hipLaunchKernelGGL((k_anlmdn_pair<6>), dim3(grid), dim3(64), smem, s, in, out, n, K, S, sw, smooth, lut_scale, nhops);
+        }
         return;
     }
     int threads = ((2 * S + 63) / 64) * 64;

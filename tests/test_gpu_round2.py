@@ -465,3 +465,21 @@ def test_afftdn_grouped_kernel_equals_the_frame_at_a_time_kernel(engine, sr, sec
         a, b = both(**kw)
         assert np.array_equal(a, b), kw
     assert np.max(np.abs(a - x)) > 1e-4                       # (the filter did something)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("sr,secs", [(44100, 6.0), (88200, 2.5), (22050, 4.0), (48000, 3.0)])
+def test_anlmdn_hop_pair_kernel_at_rates_that_do_not_fill_the_lane_layout(engine, oracle, sr, secs):
+    """anlmdn=s=0.00001:p=0.006:r=0.002:m=3 (filters.go:95-100) at 44.1 kHz is K = 265 (odd) and S = 88: the wave-per-hop-pair kernel
+    runs it on the 96-offset lane layout with dummy end offsets and a short last block.  Against the generic kernel (one thread per
+    offset, FFmpeg's sequential sums; JT_NLM_GENERIC) the outputs agree to f32 round-off of the weighted mean, and both match the oracle."""
+    x = synth.speech_like(secs, sr, seed=21).astype(np.float32)
+    os.environ["JT_NLM_GENERIC"] = "1"
+    try:
+        g = engine.op_anlmdn(x, sr)
+    finally:
+        os.environ.pop("JT_NLM_GENERIC", None)
+    f = engine.op_anlmdn(x, sr)
+    assert np.max(np.abs(f - g)) < 2e-8
+    assert np.max(np.abs(f - x)) > 1e-5                       # (the filter engaged)
+    assert np.max(np.abs(f - oracle.anlmdn(x, sr))) < 1e-5
