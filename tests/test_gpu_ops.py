@@ -84,7 +84,8 @@ def test_anlmdn_speech_and_edges(engine, oracle):
     for n in (1, 500, 577, 578, 1345):
         y = noise(n, 1e-3, n)
         assert np.max(np.abs(engine.op_anlmdn(y, SR) - oracle.anlmdn(y, SR))) < 1e-8
-    # generic (workgroup-per-hop, sequential-order) path: 44.1 kHz gives 2S = 176, not a multiple of 64
+    # 44.1 kHz gives K = 265, 2S = 176: the hop-pair kernel with dummy end offsets and a short last block (the generic kernel, one
+    # thread per offset, is compared with it in test_gpu_round2.py)
     z = speech(2.0, 5, 44100)
     assert np.max(np.abs(engine.op_anlmdn(z, 44100) - oracle.anlmdn(z, 44100))) < 1e-5 * np.max(np.abs(z))
 

@@ -132,7 +132,7 @@ def test_stereo_downmix_and_silence_guard(engine, oracle):
 
 # ---------------------------------------------------------------- BASELINE.json configs[4]: 96 kHz stereo input
 def test_96k_stereo_downmix_and_resample_path(engine, oracle):
-    """96 kHz stereo with L != R: rematrix downmix (float formats: 1/sqrt2 each), Pass-1/2 at 96 kHz (anlmdn generic path K=576 S=192, afftdn 4096-point
+    """96 kHz stereo with L != R: rematrix downmix (float formats: 1/sqrt2 each), Pass-1/2 at 96 kHz (anlmdn K=576 S=192: six offsets per lane, afftdn 4096-point
     instance), 96 k -> 44.1 k polyphase (72 taps, 147 phases, step 320), true peak via 96 k -> 192 k; Pass 3/4 at 44.1 kHz."""
     sr = 96000
     a = synth.speech_like(40.0, sr, seed=31)
@@ -436,7 +436,7 @@ def test_limiter_prefix_path_loud_peaky_input(engine, oracle):
 
 
 def test_44k1_input_no_rate_change(engine, oracle):
-    """44.1 kHz input: anlmdn's generic kernel (2S = 176 is not a multiple of 64), afftdn with A = 551, and no resampler in the
+    """44.1 kHz input: anlmdn K = 265, S = 88 (the hop-pair kernel with dummy end offsets and a short last block), afftdn with A = 551, and no resampler in the
     output format conversion (aformat only converts dbl -> s16)."""
     sr = 44100
     x = synth.speech_like(30.0, sr, seed=52)
