@@ -1102,7 +1102,28 @@ k_limiter_f64(const double *__restrict__ in, double *__restrict__ out, int64_t n
                 for (int j = 0; j < jn; ++j) mx = fmax(mx, fabs(tx[lane][j]));
                 rest = mx <= limit;
             }
-            for (int j = 0; j < (rest ? 0 : jn); ++j) {
+            // A tile inside a release ramp -- no peak waiting in the list, nothing above the limit entering or leaving the look-ahead
+            // buffer -- runs the same statements with every peak branch dead: att += delta, the clamps, the output (a fifth of the
+            // instructions; a peak is followed by >= release * sr such samples)
+            bool ramp = false;
+            if (!rest && nextlen == 0 && B > 1) {
+                double mx = 0.0;
+                for (int j = 0; j < jn; ++j) mx = fmax(mx, fmax(fabs(tx[lane][j]), fabs(te[lane][j])));
+                ramp = mx <= limit;
+            }
+            if (ramp) {
+                for (int j = 0; j < jn; ++j) {
+                    att += delta;
+                    double o = te[lane][j] * att;
+                    if (att > 1.) { att = 1.; delta = 0.; nextiter = 0; nextlen = 0; nextpos[0] = -1; }
+                    if (att <= 0.) { att = 0.0000000000001; delta = (1.0 - att) / (sr * release); }
+                    if (att != 1. && (1. - att) < 0.0000000000001) att = 1.;
+                    if (delta != 0. && fabs(delta) < 0.00000000000001) delta = 0.;
+                    o = fmin(fmax(o, -limit), limit);
+                    te[lane][j] = o;
+                }
+            }
+            for (int j = 0; j < ((rest || ramp) ? 0 : jn); ++j) {
                 const int64_t i = lo + pos + j;
                 const double x = tx[lane][j];
                 double peak = fabs(x);
