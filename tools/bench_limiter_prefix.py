@@ -13,7 +13,7 @@ if os.environ.get("JT_NUMPY_INPUT"):      # bit-repeatable input for digests (th
     x = torch.from_numpy(synth.speech_like(mins * 60.0, sr, seed=1000).astype(np.float32)).to("cuda:0")
 n = x.numel()
 g = torch.Generator(device="cuda:0").manual_seed(7)
-pos = torch.randint(sr, n - sr, (int(mins * 40),), device="cuda:0", generator=g)          # 40 bursts a minute
+pos = torch.randint(sr, n - sr, (int(mins * float(os.environ.get("JT_BURSTS_PER_MIN", "40"))),), device="cuda:0", generator=g)    # bursts a minute (default 40)
 env = torch.hann_window(960, device="cuda:0")
 t = torch.arange(960, device="cuda:0")
 burst = (0.35 * env * torch.sin(2 * np.pi * 180.0 * t / sr)).float()
