@@ -483,3 +483,52 @@ def test_anlmdn_hop_pair_kernel_at_rates_that_do_not_fill_the_lane_layout(engine
     assert np.max(np.abs(f - g)) < 2e-8
     assert np.max(np.abs(f - x)) > 1e-5                       # (the filter engaged)
     assert np.max(np.abs(f - oracle.anlmdn(x, sr))) < 1e-5
+
+
+def _bursty_speech(sr, secs, seed):
+    """speech-like signal with plosive-like bursts: after the loudnorm gain its peaks would pass the ceiling, so the plan needs the prefix"""
+    x = synth.speech_like(secs, sr, seed=seed).astype(np.float32)
+    r = np.random.default_rng(seed)
+    t = np.arange(960)
+    burst = (0.35 * np.hanning(960) * np.sin(2 * np.pi * 180.0 * t / sr)).astype(np.float32)
+    for p in r.integers(sr, x.size - sr, size=max(4, int(secs / 60.0 * 60))):
+        x[p:p + 960] += burst
+    return x
+
+
+@pytest.mark.gpu
+def test_pass4_takes_the_limiter_prefix_pass3_left_behind(engine):
+    """Pass 3 (normalise.go:256-264) and Pass 4 (normalise.go:452-497) run the same alimiter prefix on the same Pass-2 output; Pass 4
+    reuses Pass 3's result instead of recomputing it.  The delivered samples must not change (JT_NO_LIM_KEEP recomputes)."""
+    sr = 48000
+    x = _bursty_speech(sr, 75.0, 5)
+    outs = []
+    for keep in (True, False):
+        if keep: os.environ.pop("JT_NO_LIM_KEEP", None)
+        else: os.environ["JT_NO_LIM_KEEP"] = "1"
+        try:
+            engine.upload_pcm(x, sr, 1)
+            r = H.process_audio(engine, H.default_config(), 4096)
+            assert r.limiter.needed == 1
+            y = np.empty(x.size, np.int16)
+            got = engine.download_s16_into(4, y)
+            outs.append(y[:got].copy())
+        finally:
+            os.environ.pop("JT_NO_LIM_KEEP", None)
+    assert outs[0].size == outs[1].size and np.array_equal(outs[0], outs[1])
+
+
+@pytest.mark.gpu
+def test_f64_stream_upsampler_with_eight_waves_equals_the_four_wave_kernel(engine):
+    """The limiter-prefix measurement resamples the limited f64 signal to 192 kHz (swr DBLP); k_upsample32_stream8 must give the
+    statistics the four-wave kernel gives, to the bit (JT_UPS_NO_STREAM8 selects the latter)."""
+    r = np.random.default_rng(8)
+    x = np.clip(np.round(0.2 * r.standard_normal(44100 * 21) * 32768.0), -32768, 32767).astype(np.int16)
+    lim = L.LimiterPlan(1, 0.25, 1.0)
+    a = engine.op_loudnorm_measure_s16(x, 44100, limiter=lim)
+    os.environ["JT_UPS_NO_STREAM8"] = "1"
+    try:
+        b = engine.op_loudnorm_measure_s16(x, 44100, limiter=lim)
+    finally:
+        os.environ.pop("JT_UPS_NO_STREAM8", None)
+    assert all(np.array_equal(np.asarray(a[k]), np.asarray(b[k]), equal_nan=True) for k in a)
