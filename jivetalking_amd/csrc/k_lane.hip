@@ -948,8 +948,10 @@ void launch_dynamics(const float *in, float *out_f32, double *tmp64, double *tmp
     if (de) {
         // a lane runs halo + chunk samples of ~85 f64 instructions each and one wave nearly saturates a SIMD's f64 issue: the launch
         // lasts as long as one lane's run while fewer than 1024 waves exist.  chunk 8192 (330 waves for an hour): 10.2 ms, 4096: 8.6,
-        // 3072: 8.0, 2048 (1320 waves, 9x redundant): 15.0
-        const int64_t halo = 16384, chunk = 3072;
+        // 3072: 8.0, 2048 (1320 waves, 9x redundant): 15.0.  The halo is what exactness needs (tools/deess_halo.py: against a halo of 262144,
+        // 16384 is bit-identical on speech, gated hiss, an 8 kHz tone and full-scale noise at every intensity; 8192 is off by one f32 ulp on
+        // full-scale noise at intensity 0.2, 4096 by 1e-5)
+        const int64_t halo = getenv("JT_DEESS_HALO") ? atoll(getenv("JT_DEESS_HALO")) : 16384, chunk = getenv("JT_DEESS_CHUNK") ? atoll(getenv("JT_DEESS_CHUNK")) : 3072;
         const int64_t nchunks = (n + chunk - 1) / chunk;
         const unsigned g = (unsigned)((nchunks + LANES - 1) / LANES);
         if (have64) hipLaunchKernelGGL((k_deesser<double>), dim3(g), dim3(LANES), 0, s, cur64, out_f32, n, chunk, halo, d, nchunks);
