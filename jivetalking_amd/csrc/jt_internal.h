@@ -1,6 +1,7 @@
 // jt_internal.h — shared declarations for libjtgpu.so (gfx950 only).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
@@ -30,6 +31,12 @@ template <typename T> struct DevBuf {
         release();
         if (count == 0) count = 1;
         JT_HIP(hipMalloc((void **)&p, count * sizeof(T)));
+        // Nothing may depend on what an allocation holds: new pages happen to be zero, recycled ones are not, and a handle that has
+        // processed a longer file keeps its stale samples behind a shorter one.  JT_POISON_ALLOC=1 fills every allocation with 0xFF bytes
+        // (NaNs / -1); tools/stale_memory.py and the whole GPU suite give the same results with it (tests/test_gpu_round2.py runs the
+        // former).  The fill runs on the null stream, which the handle's non-blocking streams do not wait for: synchronise before use.
+        static const bool poison = getenv("JT_POISON_ALLOC") != nullptr;
+        if (poison) { JT_HIP(hipMemset(p, 0xFF, count * sizeof(T))); JT_HIP(hipStreamSynchronize(nullptr)); }
         n = count;
     }
     void zero(hipStream_t s) { if (p) JT_HIP(hipMemsetAsync(p, 0, n * sizeof(T), s)); }

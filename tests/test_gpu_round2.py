@@ -532,3 +532,15 @@ def test_f64_stream_upsampler_with_eight_waves_equals_the_four_wave_kernel(engin
     finally:
         os.environ.pop("JT_UPS_NO_STREAM8", None)
     assert all(np.array_equal(np.asarray(a[k]), np.asarray(b[k]), equal_nan=True) for k in a)
+
+
+@pytest.mark.gpu
+def test_nothing_reads_memory_it_did_not_write():
+    """Every operator and the pipeline on a short file after a long, loud one on the same handle equal the fresh-handle results, with every
+    device allocation filled with 0xFF bytes beforehand (JT_POISON_ALLOC is read once per process: the check runs in its own)."""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, JT_POISON_ALLOC="1")
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "stale_memory.py")], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "stale-memory check: clean (poisoned allocations)" in r.stdout, r.stdout[-2000:]
