@@ -627,11 +627,12 @@ static void fill_biquads(const jt_filter_params *p, int sr, BiquadF32 st[2], int
 static void run_resample_s16(jt_ctx *h, const float *x, int64_t n, int in_rate, int out_rate, DevBuf<int16_t> &dst, int64_t *m_out)
 {
     if (in_rate == out_rate) {
+        // aformat alone (44.1 kHz input): flt -> dbl -> s16 as swresample converts; the f64 ping-pong buffer of the dynamics stage is
+        // free again at this point of the stream (a buffer allocated and freed here cost two device synchronisations per file)
         dst.ensure((size_t)n);
-        DevBuf<double> t; t.ensure((size_t)n);
-        launch_f32_to_f64(x, t.p, n, h->stream);
-        launch_f64_to_s16(t.p, dst.p, nullptr, n, 0, h->stream);
-        JT_HIP(hipStreamSynchronize(h->stream));
+        h->f64_a.ensure((size_t)n + 16);
+        launch_f32_to_f64(x, h->f64_a.p, n, h->stream);
+        launch_f64_to_s16(h->f64_a.p, dst.p, nullptr, n, 0, h->stream);
         *m_out = n;
         return;
     }

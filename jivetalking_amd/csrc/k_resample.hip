@@ -630,6 +630,36 @@ void launch_true_peak_f64(const double *in, int64_t n, const double *bank, int p
 }
 
 // f32 in (the dbl->flt->dbl rounded signal) -> DBLP resample -> s16
+// The stream-edge blocks of the 48 k -> 44.1 k output stage (the first block, whose taps reach before sample 0, and the last one or two,
+// which reach past the end), one wave per (block, output phase): in k_polyphase a block is one workgroup whose four waves walk the 147
+// phases one after another, each waiting for its 36 scalar tap loads -- 0.5 ms for two blocks, on the critical path of Pass 2.
+// Same sums as k_polyphase<float, double, double, 1> (ascending taps, one FMA per tap, rint and clip to s16).
+__global__ void __launch_bounds__(64)
+k_polyphase_edge_s16(const float *__restrict__ in, int64_t n, const double *__restrict__ bank, int P, int L, int center, int64_t step,
+                     int64_t m_total, int64_t skip_lo, int64_t skip_n, int16_t *__restrict__ out)
+{
+    const int64_t e = (int64_t)blockIdx.x / P; const int j = (int)((int64_t)blockIdx.x % P);
+    const int64_t bid = e < skip_lo ? e : e + skip_n;
+    const int64_t m = bid * 64 * P + j + (int64_t)P * threadIdx.x;
+    if (m >= m_total) return;
+    const int64_t idx = m * step;
+    const int ph = (int)(idx % P);
+    const int64_t g0 = idx / P - center;
+    const double *f = bank + (size_t)ph * L;
+    double val = 0.0;
+    for (int i = 0; i < L; ++i) {
+        int64_t g = g0 + i;
+        float v = 0.f;
+        if (g < 0) g = -g;                                           // invert_initial_buffer(): in[-j] = in[j]
+        if (g < n) v = in[g];
+        else { const int64_t r = 2 * n - 1 - g; if (r >= 0 && r < n) v = in[r]; }   // resample_flush()
+        val = fma((double)((double)v * 1.0), f[i], val);
+    }
+    double r = rint(val * 32768.0);
+    r = r < -32768.0 ? -32768.0 : (r > 32767.0 ? 32767.0 : r);
+    out[m] = (int16_t)r;
+}
+
 void launch_resample_to_s16(const float *in, int64_t n, const double *bank, int phase_count, int filter_length, int center,
                             int64_t step, int16_t *out, int64_t m, hipStream_t s)
 {
@@ -647,12 +677,20 @@ void launch_resample_to_s16(const float *in, int64_t n, const double *bank, int 
         b_hi = std::min<int64_t>(b_hi, g.grid);
         if (b_hi <= b_lo) b_lo = b_hi = 0;
     }
+    // the few edge blocks first (the two kernels write disjoint outputs): one wave per block and phase beside k_down147's interior;
+    // other geometries keep k_polyphase for every block
+    if (fast && b_hi > b_lo && g.R == 1 && !getenv("JT_EDGE_POLYPHASE")) {
+        const int64_t nedge = g.grid - (b_hi - b_lo);
+        if (nedge > 0) hipLaunchKernelGGL(k_polyphase_edge_s16, dim3((unsigned)(nedge * phase_count)), dim3(64), 0, s, in, n, bank, phase_count,
+                                          filter_length, center, step, m, b_lo, b_hi - b_lo, out);
+    } else {
+        auto k = k_polyphase<float, double, double, 1>;
+        JT_HIP(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)g.smem));
+        hipLaunchKernelGGL(k, dim3((unsigned)(g.grid - (b_hi - b_lo))), dim3(PP_THREADS), g.smem, s, in, n, bank, phase_count, filter_length,
+                           center, step, m, g.R, 1.0, 1, (unsigned long long *)nullptr, (int64_t)0, out, (double *)nullptr, fast ? 1 : 0,
+                           PPRemap{b_lo, b_hi - b_lo, 0});
+    }
     if (b_hi > b_lo) hipLaunchKernelGGL(k_down147, dim3((unsigned)b_hi), dim3(64), 0, s, in, n, bank, center, m, out);
-    auto k = k_polyphase<float, double, double, 1>;
-    JT_HIP(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)g.smem));
-    hipLaunchKernelGGL(k, dim3((unsigned)(g.grid - (b_hi - b_lo))), dim3(PP_THREADS), g.smem, s, in, n, bank, phase_count, filter_length,
-                       center, step, m, g.R, 1.0, 1, (unsigned long long *)nullptr, (int64_t)0, out, (double *)nullptr, fast ? 1 : 0,
-                       PPRemap{b_lo, b_hi - b_lo, 0});
 }
 
 // The same resample restricted to the outputs [m_first, m_first + m_count) of the m-sample result (the announced output regions
