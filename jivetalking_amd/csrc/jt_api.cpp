@@ -1240,10 +1240,10 @@ extern "C" int jt_output_frame_levels(jt_ctx *h, int stage, int frame_samples, d
     if (n_frames) *n_frames = nfr;
     const int64_t c = std::min(nfr, cap);
     if (c > 0) {
-        DevBuf<double> d; d.ensure((size_t)nfr);
-        launch_frame_sumsq_s16(src, m, frame_samples, d.p, nfr, h->stream);
+        h->d_scr3.ensure((size_t)nfr);                        // (a scratch of the passes, idle between them: no allocation per call)
+        launch_frame_sumsq_s16(src, m, frame_samples, h->d_scr3.p, nfr, h->stream);
         std::vector<double> ss((size_t)nfr);
-        JT_HIP(hipMemcpyAsync(ss.data(), d.p, sizeof(double) * nfr, hipMemcpyDeviceToHost, h->stream));
+        JT_HIP(hipMemcpyAsync(ss.data(), h->d_scr3.p, sizeof(double) * nfr, hipMemcpyDeviceToHost, h->stream));
         JT_HIP(hipStreamSynchronize(h->stream));
         for (int64_t f = 0; f < c; ++f) {
             const int64_t cnt = std::min<int64_t>(frame_samples, m - f * frame_samples);
