@@ -24,7 +24,7 @@ struct PPRemap { int64_t skip_lo, skip_n, out_base; };     // k_polyphase block 
 // MODE 1: flush-mode resample -> s16 (av_clip_int16(lrint(x*32768))), staged in LDS for coalesced stores
 // MODE 2: flush-mode resample -> TAcc stream (strided stores, merged in L2)
 template <typename TIn, typename TAcc, typename TTap, int MODE>
-__global__ void __launch_bounds__(PP_THREADS)
+__global__ void __launch_bounds__(1024)
 k_polyphase(const TIn *__restrict__ in, int64_t n, const TTap *__restrict__ bank, int P, int L, int center, int64_t step,
             int64_t m_total, int R, double in_scale, int blk, unsigned long long *__restrict__ block_tp, int64_t nblocks_alloc,
             int16_t *__restrict__ out_s16, TAcc *__restrict__ out_stream, int skip_interior, PPRemap rm)
@@ -48,7 +48,8 @@ k_polyphase(const TIn *__restrict__ in, int64_t n, const TTap *__restrict__ bank
     const int64_t nout = min((int64_t)64 * R * P, m_total - m_lo);
     if (nout <= 0) return;
     const int flush = MODE != 0;
-    for (int i = tid; i < nin; i += PP_THREADS) {
+    const int nthreads = blockDim.x;                                // 256, or 1024 when the tile leaves room for one workgroup per CU only
+    for (int i = tid; i < nin; i += nthreads) {
         int64_t g = s0 - center + i;
         TIn v = (TIn)0;
         if (g < 0) g = -g;                                           // invert_initial_buffer(): in[-j] = in[j]
@@ -61,7 +62,7 @@ k_polyphase(const TIn *__restrict__ in, int64_t n, const TTap *__restrict__ bank
     const int64_t b_first = (s0 - center + L - 1 < 0 ? 0 : (s0 - center + L - 1)) / blk;
     // work items: (j, kc) with j = first-output offset (phase selector) and kc = 64-lane chunk of same-phase outputs
     const int nitems = P * R;
-    for (int item = wave; item < nitems; item += PP_THREADS / 64) {
+    for (int item = wave; item < nitems; item += nthreads / 64) {
         const int j = item / R, kc = item - j * R;
         const int64_t m0 = m_lo + j;
         const int64_t idx0 = m0 * step;
@@ -115,7 +116,7 @@ k_polyphase(const TIn *__restrict__ in, int64_t n, const TTap *__restrict__ bank
             atomicMax(&block_tp[b], slots[tid]);
         }
     } else if (MODE == 1) {
-        for (int64_t i = tid; i < nout; i += PP_THREADS) out_s16[m_lo - rm.out_base + i] = otile[i];
+        for (int64_t i = tid; i < nout; i += nthreads) out_s16[m_lo - rm.out_base + i] = otile[i];
     }
 }
 
@@ -586,6 +587,9 @@ k_down147(const float *__restrict__ in, int64_t n, const double *__restrict__ ba
 }
 
 struct PPGeom { int R; int T; size_t smem; unsigned grid; };
+// a workgroup whose tile admits one workgroup per CU runs sixteen waves: the P phases are walked by the waves one after another, each
+// waiting for its scalar tap loads, and nothing else on the CU covers that (96 k -> 44.1 k: an 82 KB tile, 147 phases of 72 taps)
+static inline unsigned pp_threads(size_t smem) { return smem > 40 * 1024 ? 1024u : (unsigned)PP_THREADS; }
 template <typename TIn>
 static PPGeom pp_geometry(int64_t n, int P, int L, int64_t step, int64_t m_total, bool otile)
 {
@@ -611,7 +615,7 @@ void launch_true_peak_f32(const float *in, int64_t n, const double *bank, int ph
     JT_REQUIRE(g.smem <= 150 * 1024, JT_E_UNSUPPORTED, "true peak: rate ratio needs too large an LDS tile");
     auto k = k_polyphase<float, double, double, 0>;
     JT_HIP(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)g.smem));
-    hipLaunchKernelGGL(k, dim3(g.grid), dim3(PP_THREADS), g.smem, s, in, n, bank, phase_count, filter_length, center, step, m_total,
+    hipLaunchKernelGGL(k, dim3(g.grid), dim3(pp_threads(g.smem)), g.smem, s, in, n, bank, phase_count, filter_length, center, step, m_total,
                        g.R, 1.0, blk, (unsigned long long *)block_tp, nblocks_alloc, (int16_t *)nullptr, (double *)nullptr, 0, PPRemap{0, 0, 0});
 }
 
@@ -625,7 +629,7 @@ void launch_true_peak_f64(const double *in, int64_t n, const double *bank, int p
     JT_REQUIRE(g.smem <= 150 * 1024, JT_E_UNSUPPORTED, "true peak: rate ratio needs too large an LDS tile");
     auto k = k_polyphase<double, double, double, 0>;
     JT_HIP(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)g.smem));
-    hipLaunchKernelGGL(k, dim3(g.grid), dim3(PP_THREADS), g.smem, s, in, n, bank, phase_count, filter_length, center, step, m_total,
+    hipLaunchKernelGGL(k, dim3(g.grid), dim3(pp_threads(g.smem)), g.smem, s, in, n, bank, phase_count, filter_length, center, step, m_total,
                        g.R, 1.0, blk, (unsigned long long *)block_tp, nblocks_alloc, (int16_t *)nullptr, (double *)nullptr, 0, PPRemap{0, 0, 0});
 }
 
@@ -686,7 +690,7 @@ void launch_resample_to_s16(const float *in, int64_t n, const double *bank, int 
     } else {
         auto k = k_polyphase<float, double, double, 1>;
         JT_HIP(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)g.smem));
-        hipLaunchKernelGGL(k, dim3((unsigned)(g.grid - (b_hi - b_lo))), dim3(PP_THREADS), g.smem, s, in, n, bank, phase_count, filter_length,
+        hipLaunchKernelGGL(k, dim3((unsigned)(g.grid - (b_hi - b_lo))), dim3(pp_threads(g.smem)), g.smem, s, in, n, bank, phase_count, filter_length,
                            center, step, m, g.R, 1.0, 1, (unsigned long long *)nullptr, (int64_t)0, out, (double *)nullptr, fast ? 1 : 0,
                            PPRemap{b_lo, b_hi - b_lo, 0});
     }
@@ -706,7 +710,7 @@ int64_t launch_resample_range_to_s16(const float *in, int64_t n, const double *b
     JT_REQUIRE(m_count > 0 && m_first >= 0 && m_first + m_count <= m && (b_b - b_a + 1) * per_block <= dst_cap, JT_E_INVAL, "resample range: bad range");
     auto k = k_polyphase<float, double, double, 1>;
     JT_HIP(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)g.smem));
-    hipLaunchKernelGGL(k, dim3((unsigned)(b_b - b_a + 1)), dim3(PP_THREADS), g.smem, s, in, n, bank, phase_count, filter_length,
+    hipLaunchKernelGGL(k, dim3((unsigned)(b_b - b_a + 1)), dim3(pp_threads(g.smem)), g.smem, s, in, n, bank, phase_count, filter_length,
                        center, step, m, g.R, 1.0, 1, (unsigned long long *)nullptr, (int64_t)0, dst, (double *)nullptr, 0,
                        PPRemap{0, b_a, b_a * per_block});
     return m_first - b_a * per_block;
@@ -731,7 +735,7 @@ void launch_resample_stream_s16_f32(const int16_t *in, int64_t n, const float *b
     PPGeom g = pp_geometry<int16_t>(n, phase_count, filter_length, step, m_total, false);
     auto k = k_polyphase<int16_t, float, float, 2>;
     JT_HIP(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)g.smem));
-    hipLaunchKernelGGL(k, dim3(g.grid), dim3(PP_THREADS), g.smem, s, in, n, bankf, phase_count, filter_length, center, step, m_total,
+    hipLaunchKernelGGL(k, dim3(g.grid), dim3(pp_threads(g.smem)), g.smem, s, in, n, bankf, phase_count, filter_length, center, step, m_total,
                        g.R, 1.0 / 32768.0, 1, (unsigned long long *)nullptr, (int64_t)0, (int16_t *)nullptr, out, 0, PPRemap{0, 0, 0});
 }
 void launch_resample_stream_f64(const double *in, int64_t n, const double *bank, int phase_count, int filter_length, int center,
@@ -743,6 +747,6 @@ void launch_resample_stream_f64(const double *in, int64_t n, const double *bank,
     PPGeom g = pp_geometry<double>(n, phase_count, filter_length, step, m_total, false);
     auto k = k_polyphase<double, double, double, 2>;
     JT_HIP(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)g.smem));
-    hipLaunchKernelGGL(k, dim3(g.grid), dim3(PP_THREADS), g.smem, s, in, n, bank, phase_count, filter_length, center, step, m_total,
+    hipLaunchKernelGGL(k, dim3(g.grid), dim3(pp_threads(g.smem)), g.smem, s, in, n, bank, phase_count, filter_length, center, step, m_total,
                        g.R, 1.0, 1, (unsigned long long *)nullptr, (int64_t)0, (int16_t *)nullptr, out, 0, PPRemap{0, 0, 0});
 }
