@@ -1,10 +1,13 @@
 #!/usr/bin/env python
 """bench.py — realtime factor (xRT) of the four-pass speech-mastering path on MI355X.
 
-Contract: `python bench.py --gpus N --steps K --warmup W` (N>1 launched by torch.distributed.run, one rank per
-GPU).  A step = all four passes over one 60-min 48 kHz mono f32 file that is already resident in HBM
-(BASELINE.json configs[1]); files shard one per GPU, no data-path collective (scaling: weak).  Rank 0 prints ONE
-JSON line with `roofline` (dominant kernel by measured time) and `cpu_baseline` (oracle port, bounded sample, rank 0, N=1).
+Contract: `python bench.py --gpus N --steps K --warmup W`.  N>1 runs one rank per GPU: either launched by
+torch.distributed.run (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in the environment), or — when WORLD_SIZE is unset — bench.py
+spawns the N ranks itself (one process per device, LOCAL_RANK = device, rendezvous on 127.0.0.1) and FAILS when fewer than N
+devices are visible; it never falls back to fewer ranks.  A step = all four passes over one 60-min 48 kHz mono f32 file that is
+already resident in HBM (BASELINE.json configs[1]); files shard one per GPU, no data-path collective (scaling: weak).  Rank 0
+prints ONE JSON line with `roofline` (dominant kernel by measured time), `cpu_baseline` (oracle port, bounded sample, rank 0,
+N=1) and `saturation` (configs[3]'s per-GPU share: 32 ten-minute files queued over one GPU, several in flight).
 """
 import argparse
 import json
@@ -18,6 +21,63 @@ os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")        # before torch initialise
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+
+
+def spawn_ranks(argv, n, selftest):
+    """`--gpus N` without a launcher: N child processes of this script, one per device (the reference's worker pool has one worker
+    per file in flight, cmd/jivetalking/pool.go:122-153; here a worker is a rank that owns a GPU).  Children inherit stdout, rank 0
+    prints the line.  Any child failing fails the run; fewer than N visible devices fails it before anything is spawned."""
+    import socket
+    import subprocess
+    if not selftest:
+        import torch
+        have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+        if have < n:
+            raise SystemExit(f"bench.py --gpus {n}: {have} GPU(s) visible; refusing to run fewer ranks than asked for")
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), JT_BENCH_SPAWNED="1")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env))
+    rc = 0
+    try:
+        for pr in procs:
+            r_ = pr.wait()
+            if r_ != 0 and rc == 0:
+                rc = r_
+                for q in procs:
+                    if q.poll() is None:
+                        q.terminate()
+    finally:
+        for q in procs:
+            if q.poll() is None:
+                q.kill()
+    if rc:
+        raise SystemExit(f"bench.py --gpus {n}: a rank exited with status {rc}")
+
+
+def spawn_selftest(args, rank, world):
+    """`--selftest-spawn`: the launch path only (rendezvous on 127.0.0.1 over gloo, barrier, MAX / gather over ranks, one line from
+    rank 0) with a sleep for a step.  For the CPU test of the N-rank launch; the metric name says what it is."""
+    import torch.distributed as dist
+    from jivetalking_amd import shard
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    shard.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        time.sleep(0.01 * (1 + rank))
+    shard.barrier()
+    dt_rank = time.perf_counter() - t0
+    dt = shard.max_over_ranks(dt_rank)
+    per = shard.gather_over_ranks(dt_rank / args.steps * 1e3)
+    if rank == 0:
+        print(json.dumps({"metric": "spawn-selftest (no GPU work)", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                          "ms_per_step": round(dt / args.steps * 1e3, 3), "per_rank_ms_per_step": [round(v, 3) for v in per],
+                          "spawned_by_bench": bool(os.environ.get("JT_BENCH_SPAWNED"))}))
+    dist.destroy_process_group()
 
 
 def cpu_baseline(sample_seconds, sr):
@@ -55,21 +115,9 @@ def cpu_baseline(sample_seconds, sr):
             "reference_self_published": "~18 xRT/file (README.md:105-125, unknown CPU, 3 files in flight)"}
 
 
-def limiter_prefix_leg(eng, x_dev, n, sr, seconds, base, hostlogic):
-    """The same step on a file whose peaks would pass the ceiling after the loudnorm gain, so that the plan needs the alimiter prefix
-    (normalise.go:452-497): Pass 3 then measures the limited f64 signal and Pass 4 starts from it.  Real speech usually takes this path;
-    the bench's synthetic talker (crest factor ~12 dB) does not.  40 plosive-like bursts a minute are added to the bench signal.
-    Reported beside `value`, never part of it."""
-    import numpy as np
+def variant_leg(eng, y, x_dev, n, sr, seconds, base, hostlogic, what):
+    """The same step on another talker (reported beside `value`, never part of it): 5 steps, the best of the last 3."""
     import torch
-    dev = x_dev.device
-    y = x_dev.clone()
-    g = torch.Generator(device=dev).manual_seed(7)
-    pos = torch.randint(sr, n - sr, (max(1, int(seconds / 60.0 * 40)),), device=dev, generator=g)
-    t = torch.arange(960, device=dev)
-    burst = (0.35 * torch.hann_window(960, device=dev) * torch.sin(2 * np.pi * 180.0 * t / sr)).float()
-    idx = (pos[:, None] + t[None, :]).reshape(-1)
-    y.index_add_(0, idx, burst.repeat(pos.numel()))
     torch.cuda.synchronize()
     eng.attach_device_pcm(y.data_ptr(), n, sr, 1, keepalive=y)
     ts = []
@@ -77,9 +125,55 @@ def limiter_prefix_leg(eng, x_dev, n, sr, seconds, base, hostlogic):
         t0 = time.perf_counter(); r = hostlogic.process_audio(eng, base, 4096); ts.append(time.perf_counter() - t0)
     tm = eng.timers()
     eng.attach_device_pcm(x_dev.data_ptr(), n, sr, 1, keepalive=x_dev)
-    return {"ms_per_step": round(min(ts[2:]) * 1e3, 2), "xRT": round(seconds / min(ts[2:]), 1), "limiter_needed": int(r.limiter.needed),
+    spec = r.pass2_spec.decode()
+    return {"what": what, "ms_per_step": round(min(ts[2:]) * 1e3, 2), "xRT": round(seconds / min(ts[2:]), 1), "limiter_needed": int(r.limiter.needed),
+            "deesser_on": bool("deesser" in spec),
             "pass_ms": {"pass1": round(tm["pass1_ms"], 2), "pass2": round(tm["pass2_ms"], 2), "pass3": round(tm["pass3_ms"], 2), "pass4": round(tm["pass4_ms"], 2)},
             "output_lufs": round(r.output_lufs, 2), "output_dbtp": round(r.output_tp_db, 2)}
+
+
+def saturation_leg(eng, device, base, hostlogic, synth, sr, files, minutes, in_flight):
+    """BASELINE configs[3]'s per-GPU share (256 x 10 min over 8 GPUs = 32 files per GPU): `files` ten-minute 16-bit FLAC files in
+    /dev/shm, file to file through jt_process_files_multi({device}, in_flight) - read, GPU decode, four passes, GPU encode, write,
+    worker start-up (handles, first-file allocations) included.  Reported beside `value`, never part of it."""
+    import shutil
+    import tempfile
+    import torch
+    d = tempfile.mkdtemp(prefix="jtsat", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
+    out = {"files": files, "minutes_per_file": minutes, "in_flight": in_flight, "api": "jt_process_files_multi, devices = {%d}" % device}
+    try:
+        paths = []
+        seconds = minutes * 60.0
+        n = m = 0
+        for k in range(files):
+            x = synth.speech_like_torch(seconds, sr, seed=2000 + k, device=f"cuda:{device}", plosives_per_min=40.0 if k % 2 == 0 else 0.0)
+            n = x.numel(); m = int(-(-n * 147 // 160))
+            pcm = (x * 32768.0).round().clamp(-32768, 32767).to(torch.int16).cpu().numpy()
+            pk = os.path.join(d, f"ep{k:03d}.flac")
+            open(pk, "wb").write(eng.op_flac_encode(pcm, sr, md5=True)); paths.append(pk)
+            del x
+        alg = (8 * n + 8 * m) * files
+        for md5 in (True, False):
+            for q in os.listdir(d):
+                if q.endswith("-processed.flac"):
+                    os.unlink(os.path.join(d, q))
+            t0 = time.perf_counter()
+            failed, fr, _ = hostlogic.process_files_multi(paths, devices=(device,), in_flight_per_device=in_flight, base=base, md5=md5)
+            wall = time.perf_counter() - t0
+            busy = sum(float(fr[i].wall_ms) for i in range(files)) / 1e3 / in_flight           # the workers' own per-file time
+            out["md5" if md5 else "no_md5"] = {
+                "failed": int(failed), "wall_s": round(wall, 3), "files_per_s": round(files / wall, 2), "ms_per_file": round(wall / files * 1e3, 2),
+                "xRT": round(files * seconds / wall, 1), "startup_s": round(max(0.0, wall - busy), 3),
+                "pipeline_hbm": {"algorithmic_bytes": alg, "achieved_GBps": round(alg / wall / 1e9, 2), "peak_GBps": 8000,
+                                 "frac": round(alg / wall / 1e9 / 8000, 6)},
+                "output_lufs_range": [round(min(fr[i].result.output_lufs for i in range(files) if fr[i].rc == 0), 2),
+                                      round(max(fr[i].result.output_lufs for i in range(files) if fr[i].rc == 0), 2)] if failed < files else None}
+        out["note"] = ("md5 = the reference's FLAC (STREAMINFO MD5 computed, one dependent chain on a host core per file, hidden behind the other "
+                       "workers' GPU phases); half the files carry plosive bursts (limiter prefix), half do not; startup_s = wall minus the "
+                       "workers' own per-file time (handle creation and first-file allocations, which hipMalloc serialises)")
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
+    return out
 
 
 def e2e_legs(eng, x_dev, n, sr, seconds, base, hostlogic, Engine, device):
@@ -144,22 +238,40 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--minutes", type=float, default=60.0, help="audio minutes per file (BASELINE configs[1] = 60)")
-    ap.add_argument("--cpu-sample", type=float, default=20.0, help="seconds of audio for the CPU oracle baseline (0 = skip)")
+    ap.add_argument("--cpu-sample", type=float, default=60.0, help="seconds of audio for the CPU oracle baseline (0 = skip)")
     ap.add_argument("--rate", type=int, default=48000, help="input sample rate (BASELINE configs[4]: 96000)")
     ap.add_argument("--channels", type=int, default=1, help="input channels, 1 or 2 (configs[4]: 2, down-mixed on the device)")
     ap.add_argument("--e2e", type=int, default=1, help="also time the end-to-end legs outside `value` (PCIe-inclusive, file to file); 0 = skip")
     ap.add_argument("--in-flight", type=int, default=1,
                     help="extra measurement (not `value`): K files per GPU processed concurrently, one context + host thread each "
                          "(BASELINE configs[3], throughput saturation); reported as `saturation`")
+    ap.add_argument("--plosives", type=float, default=40.0,
+                    help="plosive bursts per minute in the bench talker (crest factor ~20 dB, as close-miked speech has: the loudnorm plan "
+                         "then needs the limiter prefix); 0 = the round-1/2 talker (crest ~12 dB, no prefix), which is reported as a leg")
+    ap.add_argument("--saturation", type=int, default=1, help="configs[3]'s per-GPU share as the `saturation` leg (N=1 only); 0 = skip")
+    ap.add_argument("--sat-files", type=int, default=32)
+    ap.add_argument("--sat-minutes", type=float, default=10.0)
+    ap.add_argument("--sat-in-flight", type=int, default=6)
+    ap.add_argument("--selftest-spawn", action="store_true", help="exercise the N-rank launch path only (gloo, no GPU work); for tests")
     args = ap.parse_args()
 
-    import torch
-    import torch.distributed as dist
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        return spawn_ranks(sys.argv[1:], args.gpus, args.selftest_spawn)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if args.gpus != world and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} != WORLD_SIZE {world}")
+    if args.gpus != world:
+        raise SystemExit(f"--gpus {args.gpus} != WORLD_SIZE {world}: refusing to report a different rank count than asked for")
+    if args.selftest_spawn:
+        return spawn_selftest(args, rank, world)
+
+    import torch
+    import torch.distributed as dist
+    have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    if have <= local_rank:
+        raise SystemExit(f"rank {rank}: device {local_rank} asked for, {have} GPU(s) visible")
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -168,7 +280,7 @@ def main():
     from jivetalking_amd import Engine, synth, hostlogic, shard
     sr = args.rate
     seconds = args.minutes * 60.0
-    x = synth.speech_like_torch(seconds, sr, seed=1000 + rank, device=f"cuda:{local_rank}")
+    x = synth.speech_like_torch(seconds, sr, seed=1000 + rank, device=f"cuda:{local_rank}", plosives_per_min=args.plosives)
     n = x.numel()
     if args.channels == 2:
         # second channel: the same talker 0.15 ms later and 2 dB down (interleaved L R L R ...)
@@ -277,6 +389,10 @@ def main():
             "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32/f64", "data": "synthetic",
             "config": {"workload": f"1 x {args.minutes:g} min {sr / 1000:g} kHz {'stereo' if args.channels == 2 else 'mono'} f32 PCM per GPU, full 4-pass pipeline, input resident in HBM",
+                       "talker": (f"synthetic speech, {args.plosives:g} plosive bursts per minute (crest factor ~20 dB)" if args.plosives > 0
+                                  else "synthetic speech without plosives (crest factor ~12 dB)"),
+                       "branch": {"limiter_prefix": bool(res.limiter.needed), "deesser": bool("deesser" in res.pass2_spec.decode()),
+                                  "loudnorm": "linear"},
                        "files_per_gpu_per_step": 1, "adeclick": "on (t=1.7 w=55 o=50 m=s, the reference default)",
                        "adaptive": "full host mirror (VAD, speech election, AdaptConfig, band RMS) in C++",
                        "pass2_spec": res.pass2_spec.decode()},
@@ -292,7 +408,7 @@ def main():
             "second_kernel": nlm_roof,
         }
         if sat is not None:
-            out["saturation"] = sat
+            out["resident_in_flight"] = sat
         if world == 1:
             # the file formats either side of the path, outside the timed region: Pass-4 output -> .flac image on
             # the GPU (with and without the host-side STREAMINFO MD5), and that image decoded again on the GPU by a second handle
@@ -314,7 +430,17 @@ def main():
             }
         if world == 1 and args.e2e and args.channels == 1:
             out["e2e"] = e2e_legs(eng, x, n, sr, seconds, base, hostlogic, Engine, local_rank)
-            out["limiter_prefix"] = limiter_prefix_leg(eng, x, n, sr, seconds, base, hostlogic)
+            dev_s = f"cuda:{local_rank}"
+            y = synth.speech_like_torch(seconds, sr, seed=1000 + rank, device=dev_s, plosives_per_min=0.0 if args.plosives > 0 else 40.0)
+            out["no_limiter_prefix" if args.plosives > 0 else "limiter_prefix"] = variant_leg(
+                eng, y, x, n, sr, seconds, base, hostlogic,
+                "the same talker without the plosive bursts (the round-1/2 bench voice)" if args.plosives > 0 else "the talker with 40 plosive bursts a minute")
+            y = synth.speech_like_torch(seconds, sr, seed=1000 + rank, device=dev_s, plosives_per_min=args.plosives, sib_gain=1.5)
+            out["deesser_on"] = variant_leg(eng, y, x, n, sr, seconds, base, hostlogic,
+                                            "the same talker with sibilants 15.6 dB stronger (6-9 kHz band near the body band): AdaptConfig switches the de-esser on")
+            del y
+        if world == 1 and args.saturation and args.channels == 1:
+            out["saturation"] = saturation_leg(eng, local_rank, base, hostlogic, synth, sr, args.sat_files, args.sat_minutes, args.sat_in_flight)
         if world == 1 and args.cpu_sample > 0:
             out["cpu_baseline"] = cpu_baseline(args.cpu_sample, sr)
         print(json.dumps(out))

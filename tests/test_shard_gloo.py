@@ -58,3 +58,35 @@ def test_two_rank_gloo_run(tmp_path):
     assert not set(res[0]["mine"]) & set(res[1]["mine"])
     assert res[0]["tmax"] == res[1]["tmax"] == 2.0            # MAX over ranks
     assert res[0]["total"] == res[1]["total"] == 8760.0       # every second of audio assigned exactly once
+
+
+def _run_bench(*argv, env=None):
+    e = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        e.pop(k, None)
+    e.update(env or {})
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + list(argv), env=e, stdout=subprocess.PIPE,
+                          stderr=subprocess.PIPE, text=True, timeout=300)
+
+
+def test_bench_spawns_its_own_ranks():
+    """`python bench.py --gpus 2` with no launcher in the environment: bench.py starts the two ranks itself (it used to
+    run one rank and print n_gpus 1).  --selftest-spawn swaps the GPU step for a sleep and RCCL for gloo, nothing else."""
+    import json
+    p = _run_bench("--gpus", "2", "--steps", "3", "--warmup", "0", "--selftest-spawn")
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1                                    # one line, from rank 0 only
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and len(out["per_rank_ms_per_step"]) == 2 and out["spawned_by_bench"] is True
+    assert out["per_rank_ms_per_step"][1] > out["per_rank_ms_per_step"][0] * 0.9     # rank order (rank 1 sleeps longer)
+    assert out["ms_per_step"] >= max(out["per_rank_ms_per_step"]) - 1e-6             # MAX over ranks
+
+
+def test_bench_refuses_fewer_devices_than_ranks():
+    """No GPU here: `--gpus 2` must fail before spawning anything, not fall back to one rank; a launcher-provided WORLD_SIZE that
+    disagrees with --gpus fails too."""
+    p = _run_bench("--gpus", "64", "--steps", "1", "--warmup", "0")
+    assert p.returncode != 0 and "refusing" in (p.stderr + p.stdout) and not any(ln.startswith("{") for ln in p.stdout.splitlines())
+    p = _run_bench("--gpus", "4", "--steps", "1", "--warmup", "0", "--selftest-spawn", env={"WORLD_SIZE": "2", "RANK": "0"})
+    assert p.returncode != 0 and "refusing" in (p.stderr + p.stdout)
