@@ -435,9 +435,9 @@ def main():
             out["no_limiter_prefix" if args.plosives > 0 else "limiter_prefix"] = variant_leg(
                 eng, y, x, n, sr, seconds, base, hostlogic,
                 "the same talker without the plosive bursts (the round-1/2 bench voice)" if args.plosives > 0 else "the talker with 40 plosive bursts a minute")
-            y = synth.speech_like_torch(seconds, sr, seed=1000 + rank, device=dev_s, plosives_per_min=args.plosives, sib_gain=1.5)
+            y = synth.speech_like_torch(seconds, sr, seed=1000 + rank, device=dev_s, plosives_per_min=args.plosives, sib_gain=4.0)
             out["deesser_on"] = variant_leg(eng, y, x, n, sr, seconds, base, hostlogic,
-                                            "the same talker with sibilants 15.6 dB stronger (6-9 kHz band near the body band): AdaptConfig switches the de-esser on")
+                                            "the same talker with sibilants 24 dB stronger (6-9 kHz band near the body band): AdaptConfig switches the de-esser on")
             del y
         if world == 1 and args.saturation and args.channels == 1:
             out["saturation"] = saturation_leg(eng, local_rank, base, hostlogic, synth, sr, args.sat_files, args.sat_minutes, args.sat_in_flight)

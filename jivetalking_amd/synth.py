@@ -111,7 +111,7 @@ def speech_like_torch(duration_s, sample_rate=48000, seed=0, device="cuda", spee
     F0 harmonics weighted by a three-formant envelope, syllable AM, sibilant noise bursts, low-passed room tone.
     `plosives_per_min` > 0 adds that many 20 ms plosive-like bursts a minute inside the phrases (peaks ~-9 dBFS over a -30 dBFS voice:
     the ~20 dB crest factor of a real close-miked talker, which makes the loudnorm plan need the limiter prefix, normalise.go:452-497);
-    `sib_gain` scales the sibilant bursts (0.25 = the default voice; ~1.5 puts the 6-9 kHz band within 6 dB of the body band, which
+    `sib_gain` scales the sibilant bursts (0.25 = the default voice; ~4 puts the 6-9 kHz band within 6 dB of the body band, which
     is what makes AdaptConfig switch the de-esser on, adaptive_deesser.go:45)."""
     import torch
     g = torch.Generator(device=device).manual_seed(int(seed))

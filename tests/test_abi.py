@@ -35,8 +35,8 @@ def test_binding_lists_every_header_symbol():
 
 
 def test_open_without_gpu_fails_loudly(lib):
-    import torch
-    if torch.cuda.is_available():
+    import os
+    if os.path.exists("/dev/kfd"):                # (no torch here: a second HIP runtime initialised in the test process hides the GPU from ours)
         pytest.skip("GPU present")
     h = C.c_void_p()
     rc = lib.jt_open(0, C.byref(h))

@@ -19,7 +19,7 @@ SKIP = ("tests/golden/ffmpeg/manifest.json is absent: the oracle is NOT pinned t
 # per-operator bars.  pcm: max |difference| (float) or LSB (s16); an FFmpeg build may contract a*b+c or vectorise a sum, so float
 # bars sit a few ulp above what the scalar restatement gives against itself.
 TOL = {"biquad_hp_lp": 2e-6, "anlmdn": 1e-5, "afftdn": 5e-5, "agate": 1e-9, "acompressor": 1e-9, "deesser": 1e-9, "alimiter": 1e-9,
-       "adeclick": 1e-6, "resample_s16": 1, "pass2_default_chain": 3, "downmix": 0.0, "loudnorm_dynamic": 1e-6}
+       "adeclick": 1e-6, "resample_s16": 1, "pass2_default_chain": 3, "downmix": 0.0, "loudnorm_dynamic": 1e-6, "swr_up": 2e-6}
 
 
 def manifest(root=GOLD):
@@ -61,6 +61,8 @@ class OracleOps:
             return o.deesser(x.astype(np.float64), sr, a["i"], a["m"], a["f"])
         if op == "resample_s16":
             return o.f64_to_s16(o.swr_f64(x.astype(np.float32).astype(np.float64), sr, a["out_rate"], True))
+        if op == "swr_up":
+            return o.swr_f32(x.astype(np.float32), sr, a["out_rate"], True)
         if op in ("alimiter", "adeclick"):
             g = np.float32(10 ** (a["pre_gain_db"] / 20.0))                 # af_volume.c precision=float on the s16 -> flt samples
             y = (x.astype(np.float32) * g).astype(np.float64)
@@ -105,15 +107,36 @@ class OracleOps:
         return o.loudnorm_measure(up, 192000, True)
 
 
+def alignment_report(got, want, maxlag=8192):
+    """Where `got` sits relative to `want`: the lag (in samples) that maximises their cross-correlation, the residual at that lag and the
+    length difference.  A wrong latency / priming / flush assumption then reads as "got is 384 samples late and 384
+    longer", not as a bare mismatch."""
+    g = np.asarray(got, np.float64); w = np.asarray(want, np.float64)
+    if g.size == 0 or w.size == 0:
+        return f"lengths {g.size} vs {w.size}"
+    L = 1 << int(np.ceil(np.log2(g.size + w.size)))
+    c = np.fft.irfft(np.fft.rfft(g, L) * np.conj(np.fft.rfft(w, L)), L)
+    lags = np.concatenate([np.arange(0, maxlag + 1), np.arange(-maxlag, 0)])
+    cand = np.concatenate([c[: maxlag + 1], c[L - maxlag:]])
+    lag = int(lags[int(np.argmax(cand))])                        # got[n + lag] ~ want[n]
+    lo = max(0, -lag); hi = min(w.size, g.size - lag)
+    res = float(np.max(np.abs(g[lo + lag:hi + lag] - w[lo:hi]))) if hi > lo else float("nan")
+    here = "aligned" if lag == 0 else (f"got is {lag} samples LATE" if lag > 0 else f"got is {-lag} samples EARLY")
+    return (f"best lag {lag:+d} ({here}); residual at that lag {res:.3g} over {max(0, hi - lo)} samples; "
+            f"length got {g.size} vs ffmpeg {w.size} ({g.size - w.size:+d}: head shift {lag:+d}, tail {g.size - w.size - lag:+d})")
+
+
 def compare_pcm(e, got, want):
-    assert got.size == want.size, f"{e['name']}: length {got.size} vs ffmpeg's {want.size} (alignment / flush assumption, DESIGN.md section 3)"
     tol = TOL[e["op"]]
-    if e["out_format"] == "s16le":
-        d = np.abs(got.astype(np.int64) - want.astype(np.int64))
-        assert d.max() <= tol, f"{e['name']}: {d.max()} LSB (bar {tol})"
-    else:
-        d = np.abs(np.asarray(got, np.float64) - np.asarray(want, np.float64))
-        assert d.max() <= tol, f"{e['name']}: max |difference| {d.max():.3g} (bar {tol})"
+    integer = e["out_format"] == "s16le"
+    if got.size != want.size:
+        raise AssertionError(f"{e['name']}: length {got.size} vs ffmpeg's {want.size} (alignment / flush assumption, DESIGN.md section 3): "
+                             + alignment_report(got, want))
+    d = np.abs(got.astype(np.int64) - want.astype(np.int64)) if integer else np.abs(np.asarray(got, np.float64) - np.asarray(want, np.float64))
+    if d.max() > tol:
+        at = int(np.argmax(d))
+        raise AssertionError(f"{e['name']}: max |difference| {d.max():.3g}{' LSB' if integer else ''} at sample {at} (bar {tol}); "
+                             + alignment_report(got, want))
     return float(d.max())
 
 
@@ -193,6 +216,48 @@ def test_loader_selftest_with_oracle_made_vectors(oracle, tmp_path):
     np.savez_compressed(tmp_path / "t_gate.npz", x=z["x"], y=y)
     with pytest.raises(AssertionError):
         check_entry(ops, str(tmp_path), ents[1])
+    # a vector that is right but 7 samples late and 7 longer must say so (what a wrong latency assumption looks like)
+    z = np.load(tmp_path / "t_biquad.npz")
+    np.savez_compressed(tmp_path / "t_biquad.npz", x=z["x"], y=np.concatenate([np.zeros(7, np.float32), z["y"]]))
+    with pytest.raises(AssertionError) as ei:
+        check_entry(ops, str(tmp_path), ents[0])
+    assert "best lag -7" in str(ei.value) and "7 samples EARLY" in str(ei.value) and "(-7:" in str(ei.value), str(ei.value)
+
+
+def _generator():
+    import importlib.util
+    sp = importlib.util.spec_from_file_location("gen_ffmpeg_golden", os.path.join(os.path.dirname(HERE), "tools", "gen_ffmpeg_golden.py"))
+    g = importlib.util.module_from_spec(sp); sp.loader.exec_module(g)
+    return g
+
+
+def test_alignment_probe_entries_go_through_the_loader(oracle, tmp_path):
+    """The impulse / step probes the generator adds for every alignment assumption of DESIGN.md section 3 (a01 anlmdn ... a06 swr):
+    every entry dispatches to an operator, and - with the oracle's own output standing in for ffmpeg's, in the generator's file
+    format - passes; the same output delayed by the filter's nominal latency fails with that latency in the message.  NOT a parity claim:
+    it proves that the day FFmpeg vectors arrive a wrong assumption is reported as a lag, not as a length error."""
+    g = _generator()
+    fx, ents = g.alignment_probes(seconds48=0.25, seconds44=0.25)
+    assert {e[0].split("_alignment")[0] for e in ents} == {"a01_anlmdn", "a02_afftdn", "a03_adeclick", "a04_alimiter_latency1", "a06_swr_48k_to_44k1", "a06_swr_44k1_to_192k"}
+    assert {e[0].rsplit("_", 2)[-2] + "_" + e[0].rsplit("_", 1)[-1] for e in ents} == {"imp_head", "imp_mid", "imp_tail", "step_mid"}
+    ops = OracleOps(oracle)
+    man = {"ffmpeg": "selftest", "entries": []}
+    for (nm, fxn, af, fmt, op, args, rate, note) in ents:
+        x, sr, ch, kind = fx[fxn]
+        e = {"name": nm, "kind": "pcm", "fixture": fxn, "rate": sr, "channels": ch, "source_format": kind, "af": af, "out_format": fmt,
+             "op": op, "args": args, "note": note}
+        np.savez_compressed(tmp_path / (nm + ".npz"), x=x, y=ops.pcm(e, x))
+        man["entries"].append(e)
+    json.dump(man, open(tmp_path / "manifest.json", "w"))
+    for e in manifest(str(tmp_path))["entries"]:
+        check_entry(ops, str(tmp_path), e)
+    # anlmdn as FFmpeg would deliver it WITHOUT its pts compensation: K + S = 384 samples late
+    e = [q for q in man["entries"] if q["name"] == "a01_anlmdn_alignment_imp_mid"][0]
+    z = np.load(tmp_path / (e["name"] + ".npz"))
+    np.savez_compressed(tmp_path / (e["name"] + ".npz"), x=z["x"], y=np.concatenate([np.zeros(384, np.float32), z["y"][:-384]]))
+    with pytest.raises(AssertionError) as ei:
+        check_entry(ops, str(tmp_path), e)
+    assert "best lag -384" in str(ei.value), str(ei.value)
 
 
 # ---------------------------------------------------------------- the HIP kernels against the same vectors

@@ -14,16 +14,22 @@ SR = 48000
 
 
 def _ten_minute_flacs(engine, d, count, minutes=10.0):
-    import torch
+    """`count` different files: a seeded 60 s talker repeated to length (numpy: torch's HIP runtime cannot be initialised after the
+    library's in one process), every second file with a plosive-like burst every 1.5 s so that its plan needs the limiter prefix."""
     paths = []
     for k in range(count):
-        x = synth.speech_like_torch(minutes * 60.0, SR, seed=300 + k, device="cuda:0", plosives_per_min=40.0 if k % 2 else 0.0)
-        pcm = (x * 32768.0).round().clamp(-32768, 32767).to(torch.int16).cpu().numpy()
+        base = np.asarray(synth.speech_like(min(60.0, minutes * 60.0), SR, seed=300 + k), np.float64)
+        x = np.tile(base, int(np.ceil(minutes * 60.0 / (base.size / SR))))[: int(minutes * 60.0 * SR)].copy()
+        if k % 2:
+            w = int(0.02 * SR)
+            burst = 0.35 * np.hanning(w) * np.sin(2 * np.pi * 180.0 * np.arange(w) / SR)
+            for pos in range(SR, x.size - SR, int(1.5 * SR)):
+                x[pos:pos + w] += burst
+        pcm = np.clip(np.rint(x * 32768), -32768, 32767).astype(np.int16)
         p = os.path.join(str(d), f"ten{k}.flac")
         with open(p, "wb") as f:
             f.write(engine.op_flac_encode(pcm, SR, md5=True))
         paths.append(p)
-        del x
     return paths
 
 

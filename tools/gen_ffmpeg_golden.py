@@ -39,6 +39,60 @@ def wav_bytes(x, sr, ch, kind):
     return hdr + b"data" + struct.pack("<I", len(data)) + data
 
 
+def probe_signal(sr, seconds, impulse_at=None, step_at=None, kind="f32", dither_dbfs=-80.0):
+    """Alignment probe: dither at `dither_dbfs` (the LCG of testutil_test.go, so that no filter sees digital silence) plus ONE unit
+    event - an impulse of 0.5 at sample `impulse_at`, or a step from 0 to 0.25 at sample `step_at`.  Where the event lands in a
+    filter's output IS the filter's latency compensation / priming / flush behaviour."""
+    n = int(sr * seconds)
+    lcg = np.empty(n, np.float64)
+    v = 12345
+    for i in range(n):
+        v = (v * 1664525 + 1013904223) & 0xFFFFFFFF
+        lcg[i] = v / float(0xFFFFFFFF) * 2.0 - 1.0
+    x = lcg * 10.0 ** (dither_dbfs / 20.0)
+    if impulse_at is not None:
+        x[int(impulse_at)] += 0.5
+    if step_at is not None:
+        x[int(step_at):] += 0.25
+    if kind == "s16":
+        return np.rint(x * 32768) / 32768
+    return x.astype(np.float32).astype(np.float64)
+
+
+def alignment_probes(seconds48=1.5, seconds44=1.5):
+    """One entry per alignment / flush assumption of DESIGN.md section 3 (numbered as there), each with an impulse at n = 0, one
+    mid-file and one as far before EOF as the filter's own reach (K+S for anlmdn, W = 3A for afftdn, W for adeclick, the look-ahead
+    for alimiter, the filter length for swr), and a step.  Returns (fixtures, entries):
+      fixtures[name] = (signal, rate, channels, kind)
+      entries = [(entry name, fixture, -af string, raw format, op, args, output rate or None, note)]"""
+    fx, ents = {}, []
+    n48, n44 = int(48000 * seconds48), int(44100 * seconds44)
+
+    def add(prefix, sr, kind, n, reach, af, fmt, op, args, rate, note):
+        events = {"imp_head": dict(impulse_at=0), "imp_mid": dict(impulse_at=n // 2), "imp_tail": dict(impulse_at=n - 1 - reach),
+                  "step_mid": dict(step_at=n // 2)}
+        for ev, kw in events.items():
+            fname = "probe_%dk_%s_%s_%d" % (sr // 1000, kind, ev, reach)
+            if fname not in fx:
+                fx[fname] = (probe_signal(sr, n / float(sr), kind=kind, **kw), sr, 1, kind)
+            ents.append(("%s_%s" % (prefix, ev), fname, af, fmt, op, args, rate, note))
+
+    add("a01_anlmdn_alignment", 48000, "f32", n48, 288 + 96, "anlmdn=s=0.00001:p=0.0060:r=0.0020:m=3", "f32le", "anlmdn",
+        {"s": 0.00001, "p": 0.0060, "r": 0.0020, "m": 3.0}, None, "DESIGN s3 (1): output n <-> input n, zero-padded tail of K+S")
+    add("a02_afftdn_alignment", 48000, "f32", n48, 1800, "afftdn=nr=12:nt=w:tn=0:nf=-55", "f32le", "afftdn", {"nr": 12.0, "nf": -55.0, "track": False}, None,
+        "DESIGN s3 (2): frame t covers [tA-(W-A), tA+A), zero history, zero-flushed tail")
+    add("a03_adeclick_alignment", 44100, "s16", n44, 2425, "volume=0.0dB,adeclick=t=1.7:w=55:o=50:m=s", "f64le", "adeclick",
+        {"pre_gain_db": 0.0, "t": 1.7, "w": 55.0, "o": 50.0, "m": "s"}, None, "DESIGN s3 (3): FIFO primed with (W-hop)/2 zeros, zero-padded last windows")
+    add("a04_alimiter_latency1_alignment", 44100, "s16", n44, 220,
+        "volume=6.0dB,alimiter=limit=0.250000:attack=5:release=100:level_in=1:level_out=1:level=0:latency=1:asc=1:asc_level=0.8", "f64le", "alimiter",
+        {"pre_gain_db": 6.0, "limit": 0.25, "attack": 5.0, "release": 100.0}, None, "DESIGN s3 (4): latency=1 trims lookahead-1 outputs, zero-flushed tail")
+    add("a06_swr_48k_to_44k1_alignment", 48000, "f32", n48, 32, "aformat=sample_rates=44100:channel_layouts=mono:sample_fmts=s16", "s16le", "resample_s16",
+        {"out_rate": 44100}, None, "DESIGN s3 (6): output m centred on input m*in/out, first output at m = 0, mirrored flush, length ceil(N*out/in)")
+    add("a06_swr_44k1_to_192k_alignment", 44100, "s16", n44, 32, "aresample=192000,aformat=sample_fmts=flt", "f32le", "swr_up",
+        {"out_rate": 192000}, None, "DESIGN s3 (6): the 192 kHz loudnorm / true-peak stream")
+    return fx, ents
+
+
 def run(ffmpeg, args):
     p = subprocess.run([ffmpeg, "-hide_banner", "-nostdin", "-y"] + args, capture_output=True, text=True)
     if p.returncode != 0:
@@ -88,6 +142,9 @@ def main():
     fx["speech_44k1_s16_2s5"] = (fx["speech_44k1_s16"][0][: int(44100 * 2.5)].copy(), 44100, 1, "s16")
     s30 = np.asarray(synth.speech_like(30.0, 44100, seed=105), np.float64)
     fx["speech_44k1_s16_30s"] = (np.rint(s30 * 32768) / 32768, 44100, 1, "s16")
+    fx["speech_44k1_s16_3s5"] = (fx["speech_44k1_s16"][0][: int(44100 * 3.5)].copy(), 44100, 1, "s16")
+    probe_fx, probe_entries = alignment_probes()
+    fx.update(probe_fx)
     paths = {}
     for name, (x, sr, ch, kind) in fx.items():
         paths[name] = os.path.join(tmp, name + ".wav")
@@ -177,13 +234,16 @@ def main():
             {"target_i": -16.0, "target_tp": -1.0, "target_lra": 20.0, "measured": [-24.0, 25.0, -6.0, -34.5], "offset": 0.5}, rate=44100)
     raw_out("loudnorm_dynamic_first_pass", P, "loudnorm=I=-16.0:TP=-9.0:LRA=20.0:dual_mono=true:print_format=json,aresample=44100", "f64le", "loudnorm_dynamic",
             {"target_i": -16.0, "target_tp": -9.0, "target_lra": 20.0, "measured": None, "offset": 0.0}, rate=44100, note="a -9 dB ceiling keeps the limiter busy")
-    for nm, fxn in (("pass3_measure_2s5", "speech_44k1_s16_2s5"), ("pass3_measure_30s", "speech_44k1_s16_30s")):
+    for nm, fxn in (("pass3_measure_2s5", "speech_44k1_s16_2s5"), ("a12a_loudnorm_flush_3s5", "speech_44k1_s16_3s5"), ("pass3_measure_30s", "speech_44k1_s16_30s")):
         loudnorm_json(nm, fxn, "loudnorm=I=-16.0:TP=-1.0:LRA=20.0:dual_mono=true:print_format=json", "loudnorm_measure", {"prefix": None})
     raw_out("alimiter_level", P, "volume=12.0dB,alimiter=limit=0.500000:attack=5:release=100:level_in=1:level_out=1:level=0:latency=1:asc=1:asc_level=0.8", "f64le", "alimiter",
             {"pre_gain_db": 12.0, "limit": 0.5, "attack": 5.0, "release": 100.0})
     raw_out("alimiter_brickwall", P, "volume=14.0dB,alimiter=limit=0.803526:attack=1:release=50:level_in=1:level_out=1:level=0:latency=1:asc=1:asc_level=0.8", "f64le", "alimiter",
             {"pre_gain_db": 14.0, "limit": 0.803526, "attack": 1.0, "release": 50.0})
     raw_out("adeclick", P, "volume=8.0dB,adeclick=t=1.7:w=55:o=50:m=s", "f64le", "adeclick", {"pre_gain_db": 8.0, "t": 1.7, "w": 55.0, "o": 50.0, "m": "s"})
+    # ---- one impulse / step probe per alignment assumption of DESIGN.md section 3
+    for (nm, fxn, af, fmt, op, args, rate, note) in probe_entries:
+        raw_out(nm, fxn, af, fmt, op, args, rate=rate, note=note)
     json.dump(manifest, open(os.path.join(a.out, "manifest.json"), "w"), indent=1)
     print("wrote %d entries to %s" % (len(manifest["entries"]), a.out))
 
