@@ -46,6 +46,11 @@ const char *jt_version(void);
  * themselves never clear it, so a cancel that lands between two passes is not lost.  The handle stays usable. */
 void jt_cancel(jt_ctx *h);
 void jt_reset_cancel(jt_ctx *h);
+/* A caller that arms its cancellation source BEFORE the first call of a job (Go: context.AfterFunc, then jt_process_file) brackets the
+ * job: jt_begin_job clears the flag once, and until jt_end_job no entry point clears it any more - a cancel that fires between the
+ * arming and the first call is then observed by that call instead of being wiped by its "new job" reset.  Brackets do not nest. */
+void jt_begin_job(jt_ctx *h);
+void jt_end_job(jt_ctx *h);
 
 /* ---- input: replaces audio.Reader.ReadFrame feeding abuffer (reader.go:129, frame_processor.go:131-146) ---- */
 /* interleaved f32 PCM in host memory; copied to HBM. channels 1 or 2.  2 => the aformat=channel_layouts=mono down-mix

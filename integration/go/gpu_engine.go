@@ -38,6 +38,7 @@ import (
 	"path/filepath"
 	"runtime/cgo"
 	"strconv"
+	"sync"
 	"sync/atomic"
 	"time"
 	"unsafe"
@@ -49,19 +50,77 @@ var (
 	gpuDeviceCount   = 1 // set from the CLI (e.g. rocm-smi count or JIVETALKING_GPUS)
 )
 
-// gpuEngine owns one jt_ctx: one per worker goroutine (the reference already gives each worker its own CloneForWorker config
-// and logger, pool.go:205, filters.go:368-373).
-type gpuEngine struct{ h *C.jt_ctx }
+// gpuEngine owns one jt_ctx.  Handles are expensive (streams, events, multi-GB device buffers and pinned arenas allocated by the
+// first file), so a worker goroutine borrows one from its device's free list and returns it: a handle is created once per
+// concurrent worker, not once per file (jt_process_file resets the per-job state itself).
+type gpuEngine struct {
+	h      *C.jt_ctx
+	device int
+	mu     sync.Mutex // guards h and gen against a cancel callback that is still running when the job ends
+	gen    uint64     // job generation: a callback armed for job g must not cancel job g+1 on the same handle
+	closed bool
+}
+
+var (
+	gpuPoolMu sync.Mutex
+	gpuPool   = map[int][]*gpuEngine{} // device -> idle handles
+)
 
 func openGPUEngine(device int) (*gpuEngine, error) {
 	var h *C.jt_ctx
 	if rc := C.jt_open(C.int(device), &h); rc != C.JT_OK {
 		return nil, fmt.Errorf("jt_open(device %d): code %d", device, int(rc))
 	}
-	return &gpuEngine{h: h}, nil
+	return &gpuEngine{h: h, device: device}, nil
 }
 
-func (e *gpuEngine) Close() { C.jt_close(e.h) }
+// acquireGPUEngine takes an idle handle of the next device (round-robin) or opens one.
+func acquireGPUEngine() (*gpuEngine, error) {
+	device := int(gpuDeviceCounter.Add(1)-1) % gpuDeviceCount
+	gpuPoolMu.Lock()
+	if idle := gpuPool[device]; len(idle) > 0 {
+		e := idle[len(idle)-1]
+		gpuPool[device] = idle[:len(idle)-1]
+		gpuPoolMu.Unlock()
+		return e, nil
+	}
+	gpuPoolMu.Unlock()
+	return openGPUEngine(device)
+}
+
+// release ends the job (late cancel callbacks of this job become no-ops) and returns the handle to its device's free list.
+func (e *gpuEngine) release() {
+	e.mu.Lock()
+	e.gen++
+	C.jt_end_job(e.h)
+	e.mu.Unlock()
+	gpuPoolMu.Lock()
+	gpuPool[e.device] = append(gpuPool[e.device], e)
+	gpuPoolMu.Unlock()
+}
+
+// Close destroys the handle (CloseGPUEngines at process exit; a handle that failed is closed instead of released).
+func (e *gpuEngine) Close() {
+	e.mu.Lock()
+	if !e.closed {
+		e.closed = true
+		e.gen++
+		C.jt_close(e.h)
+	}
+	e.mu.Unlock()
+}
+
+// CloseGPUEngines closes every idle handle (call once when the pools have drained).
+func CloseGPUEngines() {
+	gpuPoolMu.Lock()
+	defer gpuPoolMu.Unlock()
+	for d, idle := range gpuPool {
+		for _, e := range idle {
+			e.Close()
+		}
+		delete(gpuPool, d)
+	}
+}
 
 // err maps a C return code onto the reference's error conventions: ctx cancellation is returned as ctx.Err()
 // (frame_processor.go:116-118), everything else as a wrapped message.
@@ -80,9 +139,23 @@ func (e *gpuEngine) err(ctx context.Context, rc C.int, what string) error {
 	return fmt.Errorf("%s: %s", what, C.GoString(C.jt_last_error(e.h)))
 }
 
-// watch arms jt_cancel for the lifetime of a call: the flag is sticky on the C side until the next job starts.
+// watch brackets a job and arms jt_cancel for it.  jt_begin_job clears the sticky flag BEFORE the callback is armed and keeps the
+// job's own entry points from clearing it again, so a ctx cancelled between here and the first C call is observed by that call.
+// context.AfterFunc's stop() does not wait for a callback that has already started; the callback therefore takes e.mu and checks
+// the generation, and release / Close bump the generation under the same mutex: a late callback can neither touch a closed
+// handle nor cancel the next job on a reused one.
 func (e *gpuEngine) watch(ctx context.Context) (stop func() bool) {
-	return context.AfterFunc(ctx, func() { C.jt_cancel(e.h) })
+	e.mu.Lock()
+	gen := e.gen
+	C.jt_begin_job(e.h)
+	e.mu.Unlock()
+	return context.AfterFunc(ctx, func() {
+		e.mu.Lock()
+		if !e.closed && e.gen == gen {
+			C.jt_cancel(e.h)
+		}
+		e.mu.Unlock()
+	})
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -129,11 +202,11 @@ func ProcessAudioGPU(ctx context.Context, inputPath string, config *BaseFilterCo
 	if err := ctx.Err(); err != nil {
 		return nil, err
 	}
-	e, err := openGPUEngine(int(gpuDeviceCounter.Add(1)-1) % gpuDeviceCount)
+	e, err := acquireGPUEngine()
 	if err != nil {
 		return nil, err
 	}
-	defer e.Close()
+	defer e.release()
 	stop := e.watch(ctx)
 	defer stop()
 
@@ -163,11 +236,11 @@ func ProcessAudioGPU(ctx context.Context, inputPath string, config *BaseFilterCo
 
 // AnalyseOnlyDetailedGPU is the drop-in for AnalyseOnlyDetailed (processor.go:29-69): Pass 1 + AdaptConfig.
 func AnalyseOnlyDetailedGPU(ctx context.Context, inputPath string, config *BaseFilterConfig, progressCallback ProgressCallback) (*AnalysisResult, error) {
-	e, err := openGPUEngine(int(gpuDeviceCounter.Add(1)-1) % gpuDeviceCount)
+	e, err := acquireGPUEngine()
 	if err != nil {
 		return nil, err
 	}
-	defer e.Close()
+	defer e.release()
 	stop := e.watch(ctx)
 	defer stop()
 	if progressCallback != nil {
@@ -369,7 +442,7 @@ func (e *gpuEngine) writeFLAC(ctx context.Context, stage int, path string) error
 	if rc := C.jt_flac_encode(e.h, C.int(stage), C.JT_FLAC_MD5, &data, &n, &info); rc != C.JT_OK {
 		return e.err(ctx, rc, "flac encode")
 	}
-	tmp, err := processorCreateSiblingTempPath(path, "processing")
+	tmp, err := createSiblingTempPath(path, "processing")
 	if err != nil {
 		return err
 	}

@@ -381,7 +381,12 @@ extern "C" int jt_pass1(jt_ctx *h, int frame_samples, jt_analysis *out, double *
     AnalysisJob J;
     analysis_enqueue(h, h->in_mono, h->n, h->sr, true, h->sr / 10, &J);
     // an announced Pass-2 head goes in behind the analysis: its 150 k workgroups would otherwise take every slot first
-    if (h->spec_p2.armed) { h->spec_p2.armed = false; spec_pass2_start(h, &h->spec_p2.armed_p); }
+    if (h->spec_p2.armed) {
+        h->spec_p2.armed = false;
+        // best effort: a head that cannot be built (a source below 41 kHz puts the fixed 20.5 kHz low-pass past Nyquist: fill_biquads
+        // throws EINVAL) is dropped here, Pass 1 completes as it does in the reference, and jt_pass2 raises the error
+        try { spec_pass2_start(h, &h->spec_p2.armed_p); } catch (const JtError &e) { if (e.code != JT_E_INVAL) throw; }
+    }
     JT_HIP(hipStreamSynchronize(h->stream));
     check_cancel(h);
     if (fst) {
@@ -527,6 +532,8 @@ extern "C" int jt_set_source_format(jt_ctx *h, int bits_per_sample, int is_float
 }
 
 extern "C" void jt_reset_cancel(jt_ctx *h) { if (h) h->cancelled.store(0); }
+extern "C" void jt_begin_job(jt_ctx *h) { if (h) { h->cancelled.store(0); h->hold_cancel = true; } }
+extern "C" void jt_end_job(jt_ctx *h) { if (h) h->hold_cancel = false; }
 
 // ---------------------------------------------------------------- Pass 2
 static void run_anlmdn(jt_ctx *h, const float *in, float *out, int64_t n, int sr, double strength, double patch_s, double research_s, double smooth,

@@ -1444,8 +1444,8 @@ extern "C" int jt_process_file(jt_ctx *h, const char *input_path, const jt_host_
     auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     double t = now();
     // the job starts here: a jt_cancel() from now on (during the read, the decode, any pass, the encode, the write) ends it
-    h->cancelled.store(0);
-    struct Hold { jt_ctx *h; Hold(jt_ctx *c) : h(c) { h->hold_cancel = true; } ~Hold() { h->hold_cancel = false; } } hold(h);
+    if (!h->hold_cancel) h->cancelled.store(0);            // (inside a jt_begin_job bracket the caller has cleared it already)
+    struct Hold { jt_ctx *h; bool was; Hold(jt_ctx *c) : h(c), was(c->hold_cancel) { h->hold_cancel = true; } ~Hold() { h->hold_cancel = was; } } hold(h);
     // the file image goes straight into pinned memory (the handle's FLAC staging arena: nothing is in flight between files),
     // so the upload runs at the full PCIe rate instead of through HIP's pageable bounce buffers
     uint8_t *image = nullptr; size_t image_len = 0;

@@ -86,6 +86,13 @@ class Engine:
     def reset_cancel(self):
         self.lib.jt_reset_cancel(self.h)
 
+    def begin_job(self):
+        """jt_begin_job: clear the cancel flag once; nothing clears it again until end_job (a caller that arms its cancel source first)."""
+        self.lib.jt_begin_job(self.h)
+
+    def end_job(self):
+        self.lib.jt_end_job(self.h)
+
     def attach_device_pcm(self, dev_ptr, frames, sample_rate, channels=1, keepalive=None):
         self._keep = keepalive
         self._ck(self.lib.jt_attach_device_pcm(self.h, C.c_void_p(dev_ptr), C.c_int64(frames), C.c_int(sample_rate), C.c_int(channels)))

@@ -64,3 +64,38 @@ def test_a_device_that_cannot_be_opened_takes_no_files(engine, tmp_path):
     assert failed == 0 and dev == [0]                                                                # worker moves on to a spare one
     failed, res, dev = H.process_files_multi(paths, devices=(99,), in_flight_per_device=2)
     assert failed == 5 and all(res[k].rc != 0 and b"jt_open(99)" in res[k].error for k in range(5)) and dev == [-1] * 5
+
+
+def test_begin_job_keeps_a_cancel_that_arrives_before_the_first_call(engine, tmp_path):
+    """The Go shim arms context.AfterFunc before it calls jt_process_file; a ctx cancelled in between used to be wiped by the call's
+    own "new job" reset.  Inside a jt_begin_job bracket the first call observes it; after jt_end_job the handle behaves as before."""
+    paths = _ten_minute_flacs(engine, tmp_path, 1, minutes=0.2)
+    engine.begin_job()
+    engine.cancel()
+    with pytest.raises(L.JtError) as ei:
+        H.process_file(engine, paths[0])
+    assert ei.value.code == L.JT_E_CANCELLED
+    assert not [q for q in os.listdir(str(tmp_path)) if q.startswith(".processing-") or q.endswith("-processed.flac")]
+    engine.end_job()
+    engine.cancel()                                            # outside a bracket a new job clears the flag, as before
+    res, out_path, _ = H.process_file(engine, paths[0])
+    assert os.path.exists(out_path) and abs(res.output_lufs + 16.0) <= 0.1
+    engine.begin_job()                                         # a bracket with no cancel is an ordinary job
+    res2, out2, _ = H.process_file(engine, paths[0])
+    engine.end_job()
+    assert res2.output_lufs == res.output_lufs
+
+
+def test_pass1_completes_when_the_announced_pass2_head_cannot_be_built(engine):
+    """with the fixed 20.5 kHz low-pass announced as the early Pass-2 head, jt_pass1 of a 22.05 kHz file used to abort with
+    EINVAL mid-pass.  The reference completes Pass 1 and fails in Pass 2 (af_biquads refuses the corner): the head is dropped, Pass 1
+    returns its analysis, jt_pass2 raises."""
+    from jivetalking_amd.engine import default_filter_params
+    x = synth.speech_like(8.0, 22050, seed=51)
+    engine.upload_pcm(x, 22050, 1)
+    engine.pass2_prefetch_after_pass1(default_filter_params())
+    a = engine.pass1(x.size, sample_rate=22050)
+    assert a is not None
+    with pytest.raises(L.JtError) as ei:
+        engine.pass2(default_filter_params())
+    assert ei.value.code == L.JT_E_INVAL and "Nyquist" in str(ei.value)
