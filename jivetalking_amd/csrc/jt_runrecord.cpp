@@ -63,24 +63,49 @@ std::string go_float(double f)
     } else out += "0." + std::string((size_t)(-exp10 - 1), '0') + digits;
     return out;
 }
-// encoding/json string encoding with the default HTML escaping
+// encoding/json string encoding with the default HTML escaping (encode.go appendString, Go 1.22+: short forms for \b \f \n \r \t,
+// \u00XX for the other control bytes, \u003c \u003e \u0026, U+2028 / U+2029 escaped, every invalid UTF-8 byte replaced by \ufffd)
 std::string go_string(const std::string &s)
 {
     std::string o = "\"";
-    for (unsigned char c : s) {
-        switch (c) {
-        case '"': o += "\\\""; break;
-        case '\\': o += "\\\\"; break;
-        case '\n': o += "\\n"; break;
-        case '\r': o += "\\r"; break;
-        case '\t': o += "\\t"; break;
-        case '<': o += "\\u003c"; break;
-        case '>': o += "\\u003e"; break;
-        case '&': o += "\\u0026"; break;
-        default:
-            if (c < 0x20) { char b[8]; snprintf(b, sizeof b, "\\u%04x", c); o += b; }
-            else o.push_back((char)c);
+    const size_t n = s.size();
+    for (size_t i = 0; i < n;) {
+        const unsigned char c = (unsigned char)s[i];
+        if (c < 0x80) {
+            switch (c) {
+            case '"': o += "\\\""; break;
+            case '\\': o += "\\\\"; break;
+            case '\b': o += "\\b"; break;
+            case '\f': o += "\\f"; break;
+            case '\n': o += "\\n"; break;
+            case '\r': o += "\\r"; break;
+            case '\t': o += "\\t"; break;
+            case '<': o += "\\u003c"; break;
+            case '>': o += "\\u003e"; break;
+            case '&': o += "\\u0026"; break;
+            default:
+                if (c < 0x20) { char b[8]; snprintf(b, sizeof b, "\\u%04x", c); o += b; }
+                else o.push_back((char)c);
+            }
+            ++i;
+            continue;
         }
+        // decode one UTF-8 sequence as utf8.DecodeRuneInString does (shortest form, no surrogates, <= U+10FFFF)
+        int len = 0; unsigned cp = 0;
+        if (c >= 0xC2 && c <= 0xDF) { len = 2; cp = c & 0x1F; }
+        else if (c >= 0xE0 && c <= 0xEF) { len = 3; cp = c & 0x0F; }
+        else if (c >= 0xF0 && c <= 0xF4) { len = 4; cp = c & 0x07; }
+        bool ok = len != 0 && i + (size_t)len <= n;
+        for (int k = 1; ok && k < len; ++k) {
+            const unsigned char d = (unsigned char)s[i + (size_t)k];
+            if ((d & 0xC0) != 0x80) ok = false;
+            cp = (cp << 6) | (d & 0x3F);
+        }
+        if (ok && ((len == 3 && (cp < 0x800 || (cp >= 0xD800 && cp <= 0xDFFF))) || (len == 4 && (cp < 0x10000 || cp > 0x10FFFF)))) ok = false;
+        if (!ok) { o += "\\ufffd"; ++i; continue; }
+        if (cp == 0x2028 || cp == 0x2029) { o += cp == 0x2028 ? "\\u2028" : "\\u2029"; i += (size_t)len; continue; }
+        o.append(s, i, (size_t)len);
+        i += (size_t)len;
     }
     return o + "\"";
 }

@@ -301,7 +301,8 @@ def _sized(call):
 def run_record_json(engine, res, input_file="", version="dev", executable="", processed_at="", duration_s=0.0, sample_rate_hz=0,
                     channels=0, analysis_only=False):
     """jt_host_run_record_json: the reference's RunRecord document (runrecord.go) as text."""
-    pv = RunProvenance(input_file.encode(), version.encode(), executable.encode(), processed_at.encode(), duration_s, sample_rate_hz, channels)
+    enc = lambda v: v if isinstance(v, bytes) else v.encode()
+    pv = RunProvenance(enc(input_file), version.encode(), executable.encode(), processed_at.encode(), duration_s, sample_rate_hz, channels)
     return _sized(lambda b, c: lib().jt_host_run_record_json(engine.h if engine else None, C.byref(res), C.byref(pv), C.c_int(int(analysis_only)), b, C.c_int64(c)))
 
 

@@ -232,3 +232,21 @@ def test_loudnorm_json_body_round_trips_through_the_reference_parser_fields():
     s.normalization_type_dynamic = 1; s.input_i = -math.inf
     body = json.loads(H.loudnorm_json(s))
     assert body["normalization_type"] == "dynamic" and body["input_i"] == "-inf"
+
+
+def test_strings_are_escaped_as_encoding_json_does():
+    """encoding/json (encode.go appendString): \\b \\f \\n \\r \\t short forms, other control bytes \\u00XX, < > & as \\u003c \\u003e \\u0026, U+2028 /
+    U+2029 escaped, every invalid UTF-8 byte replaced by U+FFFD; valid multi-byte text passes through."""
+    res = H.ProcessResult()
+    name = b"a\x08b\x0cc\x01<d>&\"q\"\\ " + "\u00e9\u2028x\u2029\U0001F3A4".encode() + b" bad:\xff\xc0\xaf\xed\xa0\x80 end.flac"
+    import ctypes as C
+    pv = H.RunProvenance(name, b"v", b"x", b"t", 1.0, 48000, 1)
+    n = H.lib().jt_host_run_record_json(None, C.byref(res), C.byref(pv), C.c_int(0), None, C.c_int64(0))
+    buf = C.create_string_buffer(int(n) + 1)
+    H.lib().jt_host_run_record_json(None, C.byref(res), C.byref(pv), C.c_int(0), buf, C.c_int64(int(n) + 1))
+    raw = buf.value
+    want = (b'"a\\bb\\fc\\u0001\\u003cd\\u003e\\u0026\\"q\\"\\\\ ' + "\u00e9".encode() + b"\\u2028x\\u2029" + "\U0001F3A4".encode() +
+            b' bad:\\ufffd\\ufffd\\ufffd\\ufffd\\ufffd\\ufffd end.flac"')
+    assert want in raw, raw[raw.find(b"input_file"):raw.find(b"input_file") + 200]
+    rec = json.loads(raw.decode())                               # and it is valid JSON that decodes to the replaced text
+    assert rec["run"]["input_file"] == "a\x08b\x0cc\x01<d>&\"q\"\\ \u00e9\u2028x\u2029\U0001F3A4 bad:" + "\ufffd" * 6 + " end.flac"
