@@ -307,6 +307,9 @@ struct jt_ctx {
     struct RegionSlot { bool armed = false, valid = false; double start_s[2] = {0, 0}, dur_s[2] = {0, 0}; jt_region_sample out[2]; };
     RegionSlot region_slot[2];
     DevBuf<double> declick_scr; DevBuf<unsigned long long> declick_stats; DevBuf<int> declick_heavy;
+    // adeclick's split pipeline (front kernel -> solver kernels, k_declick.hip): per-window flagged count, index list, right-hand side, aux
+    DevBuf<int> declick_F, declick_lists; DevBuf<unsigned short> declick_idx; DevBuf<double> declick_rhs, declick_aux;
+    DevBuf<unsigned long long> declick_ctl;
     // FLAC output leg: frame records, byte offsets, summary, encoded frames; pinned host copies of the PCM (MD5) and the file
     DevBuf<unsigned char> fl_rec, fl_out; DevBuf<long long> fl_off; DevBuf<int16_t> fl_pcm;
     HostArena pin_pcm, pin_flac;

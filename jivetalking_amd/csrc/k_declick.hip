@@ -17,6 +17,7 @@
 //   * forward substitution fused into the factorisation sweep; back substitution walks the (short) band per row.
 // LDS per wave: the window's samples (f64), later reused as the 49x49 sliding block of the factorisation.
 #include "jt_internal.h"
+#include <utility>
 
 namespace dk {
 constexpr int MAXW = 4864;        // window samples (110 ms at 44.1 kHz); LDS: 8*MAXW bytes per wave
@@ -32,6 +33,17 @@ struct DeclickParams {
     int nw;                       // flag words kept per window (fast kernel)
     double threshold, gain;
     int64_t nwindows;
+};
+
+// Buffers of the split pipeline (front kernel -> solver kernels): per window a fixed slot of `wp` entries.
+struct DkSplit {
+    int *F;                        // [nwindows] flagged samples of the window
+    unsigned short *index;         // [nwindows * wp] their positions, ascending
+    double *rhs;                   // [nwindows * wp] right-hand side of the interpolation system
+    double *aux;                   // [nwindows * 56] autocorrelation of the AR coefficients (aux[AR + 1] = 0)
+    int *list32, *list64;          // windows whose band fits 31 rows / needs up to 48
+    unsigned long long *ctl;       // [0] / [1] list lengths, [2] / [3] work counters of the two solver launches
+    int wp;
 };
 
 __device__ inline double dk_ld(const double *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
@@ -531,10 +543,13 @@ __device__ inline double dk_rcp(double d)
     return r;
 }
 
-template <int FCAP, int NC, int ND, bool HALF, int LEVEL>
+// MODE 0: the whole filter in one kernel (as described above).  MODE 1: the FRONT of the split pipeline -- window load + pass-through
+// copy, AR fit, detector, index list, right-hand side -- which leaves F, index[], rhs[] and aux[] of every window with flagged samples
+// in global memory and appends the window to the solver list of its band class; k_dk_solve does the LDL^T and the substitutions.
+template <int FCAP, int NC, int ND, bool HALF, int LEVEL, int MODE = 0>
 __global__ void __launch_bounds__(64, 3)                  // three waves per SIMD (<= 168 VGPRs): LDS admits ten waves per CU
 k_adeclick_fast(const double *__restrict__ in, double *__restrict__ out, int64_t n, DeclickParams P, double *scratch,
-                size_t scratch_per_wave, unsigned long long *__restrict__ stats, int *__restrict__ heavy)
+                size_t scratch_per_wave, unsigned long long *__restrict__ stats, int *__restrict__ heavy, DkSplit S)
 {
     extern __shared__ unsigned char dk_smem[];
     const int lane = threadIdx.x;
@@ -724,7 +739,7 @@ k_adeclick_fast(const double *__restrict__ in, double *__restrict__ out, int64_t
             finite = !__any(!isfinite(v));
         }
         int F = 0;
-        bool to_heavy = false;
+        bool to_heavy = false, wide = false;
         if (finite) {
             // ---- 4. detection: register-blocked FIR, DQ consecutive outputs per lane
             const double thr = sigmae * P.threshold;
@@ -872,7 +887,8 @@ k_adeclick_fast(const double *__restrict__ in, double *__restrict__ out, int64_t
                     if (lane == 0) atomicAdd(&heavy[2 * P.nwindows + 128 + min(F >> 4, 63)], 1);
                 }
 #endif
-                to_heavy = __any(bwmax > BWMAX);
+                to_heavy = MODE == 1 ? false : __any(bwmax > BWMAX);
+                wide = __any(bwmax > 31);
                 // rows past the last one are "far away": every ring entry against them is aux[AR + 1] = 0
                 for (int k = F + lane; k < F + NC + ND && k < FCAP + NC + ND; k += 64) index[k] = 0xFFFF;
             }
@@ -898,6 +914,7 @@ k_adeclick_fast(const double *__restrict__ in, double *__restrict__ out, int64_t
                 for (int e = lane; e < F; e += 64) { const int o = (int)index[e] - sb; if (o >= 0 && o < nb) sbuf[o] = 0.0; }
                 __builtin_amdgcn_wave_barrier();
             };
+            double *gVw = MODE == 1 ? S.rhs + (size_t)w * S.wp : gV;
             auto rhs_range = [&](int ea, int eb) {
                 const double *sj = sbuf - sb;
                 for (int e0 = ea; e0 < eb; e0 += 128) {
@@ -923,7 +940,7 @@ k_adeclick_fast(const double *__restrict__ in, double *__restrict__ out, int64_t
                         val[1] = __fma_rn(-sj[ie[1] - j0], ax, val[1]);
                     }
 #pragma unroll
-                    for (int q = 0; q < 2; ++q) { const int e = e0 + 64 * q + lane; if (e < eb) gV[e] = val[q]; }
+                    for (int q = 0; q < 2; ++q) { const int e = e0 + 64 * q + lane; if (e < eb) gVw[e] = val[q]; }
                 }
             };
             if (HALF) {
@@ -933,6 +950,18 @@ k_adeclick_fast(const double *__restrict__ in, double *__restrict__ out, int64_t
                 rhs_range(0, ea);
                 if (ea < F) { load_buf(SB_B); zero_flagged(); rhs_range(ea, F); }
             } else { zero_flagged(); rhs_range(0, F); }
+            if (MODE == 1) {
+                // hand the window to the solver of its band class
+                for (int e = lane; e < F; e += 64) S.index[(size_t)w * S.wp + e] = index[e];
+                if (lane <= AR + 1) S.aux[(size_t)w * 56 + lane] = aux[lane];
+                if (lane == 0) {
+                    S.F[w] = F;
+                    const unsigned long long slot = atomicAdd(&S.ctl[wide ? 1 : 0], 1ull);
+                    (wide ? S.list64 : S.list32)[slot] = (int)w;
+                }
+                DKF_MARK(4)
+                continue;
+            }
             __threadfence();
             DKF_MARK(4)
             // ---- 9. LDL^T, right-looking inside the band, in the diagonal-major ring; forward substitution fused
@@ -1090,6 +1119,233 @@ k_adeclick_fast(const double *__restrict__ in, double *__restrict__ out, int64_t
 #endif
 }
 
+
+// =====================================================================================================================
+// k_dk_solve -- the solver of the split pipeline: LDL^T of the banded interpolation matrix, forward and back substitution, repaired
+// samples.  The factorisation keeps the sliding trailing block in REGISTERS: a window is served by a group of G lanes, lane t = diagonal
+// t, register s = column k0 + s, so entry (i + t, i) of the band lives in lane t.  A pivot then costs
+//   * its column is ONE register across the group's lanes (c[p]); the multipliers are that register times 1/d;
+//   * the trailing update of entry (k + b + t, k + b) is  c[p + b] -= colv[b] * l[t + b]:  the two operands are a broadcast read and a
+//     lane-shifted read of two small LDS vectors the group has just written (static offsets, no address arithmetic), b = 1 .. the
+//     widest band of the windows in the wave, in chunks of eight with a wave-uniform exit;
+//   * the column that enters the band is one original entry per lane (aux[index[k + BW + 1 + t] - index[k + BW + 1]]);
+//   * y slides through one register per lane (wave_shl:1), 1 / d_(k+1) is started as soon as lane 0 has updated its entry.
+// Registers are renamed by unrolling eight pivots and moved down by eight columns per block.  With the block out of LDS a window needs
+// 7 KB (its index list, right-hand side, band widths and the two vectors): G = 32 packs TWO windows into a wave (bands up to 31 rows:
+// 92 % of the bench's windows) and a CU holds twice as many windows as the one-kernel version; G = 64 takes the bands up to 48 rows.
+// Same operations on the same values as k_adeclick_fast's ring (multiplier = column entry * 1/d, update = fma(-colv[b], l[a], e),
+// 1/d = reciprocal + two Newton steps), so the repaired samples are bit-identical to that kernel's.
+__device__ inline double dk_group0(double v, int q, bool two)
+{
+    const int lo0 = __builtin_amdgcn_readlane(__double2loint(v), 0), hi0 = __builtin_amdgcn_readlane(__double2hiint(v), 0);
+    if (!two) return __hiloint2double(hi0, lo0);
+    const int lo1 = __builtin_amdgcn_readlane(__double2loint(v), 32), hi1 = __builtin_amdgcn_readlane(__double2hiint(v), 32);
+    return __hiloint2double(q ? hi1 : hi0, q ? lo1 : lo0);
+}
+__device__ inline double dk_wave_shl1(double v)
+{
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x130, 0xf, 0xf, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x130, 0xf, 0xf, true);
+    return __hiloint2double(hi, lo);
+}
+
+#ifndef DK_BCH
+#define DK_BCH 4
+#endif
+template <typename Fn, int... I>
+__device__ __forceinline__ void dk_all_rounds(Fn &&fn, std::integer_sequence<int, I...>)
+{
+    (void)(fn(std::integral_constant<int, I>{}) && ...);               // left to right, stops at the first round that declines
+}
+template <int G, int BW, int FC>
+__global__ void __launch_bounds__(64, G == 32 ? 3 : 1)
+k_dk_solve(double *__restrict__ out, int64_t n, DeclickParams P, DkSplit S, double *scratch, size_t scratch_per_slot,
+           unsigned long long *__restrict__ stats)
+{
+    extern __shared__ unsigned char dk_smem[];
+    constexpr int NW = 64 / G, CR = BW + 9;
+    constexpr bool TWO = NW == 2;
+    static_assert(G == 32 || G == 64, "group size");
+    static_assert(BW < G, "one lane per diagonal");
+    constexpr int IDXN = (FC + BW + 16 + G + 7) & ~7;                   // index entries kept per window (sentinels behind the last one)
+    constexpr int BWN = (FC + 16 + 7) & ~7, YN = (FC + BW + 16 + 7) & ~7;
+    constexpr size_t SLOTB = sizeof(double) * (size_t)(YN + 56 + 4 * G) + 2 * (size_t)IDXN + (size_t)BWN;
+    const int lane = threadIdx.x, gl = lane % G, q = lane / G;
+    const int AR = P.ar;
+    unsigned char *base = dk_smem + (size_t)q * SLOTB;
+    double *yv = reinterpret_cast<double *>(base);                      // [YN] right-hand side, later the solution
+    double *aux = yv + YN;                                              // [56]
+    double *CV = aux + 56;                                              // [2G] pivot column (slot 0: y_k), zeros behind G
+    double *LV = CV + 2 * G;                                            // [2G] multipliers, zeros behind G
+    unsigned short *idx = reinterpret_cast<unsigned short *>(LV + 2 * G);   // [IDXN]
+    unsigned char *bwv = reinterpret_cast<unsigned char *>(idx + IDXN);     // [BWN]
+    CV[G + gl] = 0.0; LV[G + gl] = 0.0;
+    double *gL = scratch + ((size_t)blockIdx.x * NW + q) * scratch_per_slot;
+    const int *list = G == 32 ? S.list32 : S.list64;
+    const int64_t nwork = (int64_t)S.ctl[G == 32 ? 0 : 1];
+    unsigned long long repaired = 0, singular = 0;
+    auto uniform64 = [](unsigned long long v) -> int64_t {
+        return (int64_t)(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(v >> 32)) << 32) |
+                         (unsigned)__builtin_amdgcn_readfirstlane((int)v));
+    };
+    auto take = [&]() -> unsigned long long { unsigned long long v = 0; if (lane == 0) v = atomicAdd(&S.ctl[G == 32 ? 2 : 3], (unsigned long long)NW); return v; };
+    int64_t wi = uniform64(take());
+    for (;;) {
+        if (wi >= nwork) break;
+        const unsigned long long wnext_ = take();
+        const bool have = wi + q < nwork;
+        const int64_t w = have ? (int64_t)list[wi + q] : 0;
+        const int F = have ? S.F[w] : 0;                               // uniform within the group
+        const int Fmax = TWO ? max(__builtin_amdgcn_readlane(F, 0), __builtin_amdgcn_readlane(F, 32)) : __builtin_amdgcn_readlane(F, 0);
+        const int64_t o0 = w * P.hop;
+        // ---- prologue: index list (sentinels behind it), right-hand side, aux
+        {
+            const unsigned short *gi = S.index + (size_t)w * S.wp;
+            const double *gr = S.rhs + (size_t)w * S.wp;
+            const int ni = min(IDXN, ((Fmax + BW + 16 + G) + 7) & ~7), ny = min(YN, Fmax + BW + 16);
+            for (int e = gl; e < ni; e += G) idx[e] = e < F ? gi[e] : (unsigned short)0xFFFF;
+            for (int e = gl; e < ny; e += G) yv[e] = e < F ? gr[e] : 0.0;
+            for (int e = gl; e < 56; e += G) aux[e] = (have && e <= AR + 1) ? S.aux[(size_t)w * 56 + e] : 0.0;
+        }
+        wi = uniform64(wnext_);
+        __builtin_amdgcn_wave_barrier();
+        // band width of every pivot (as k_adeclick_fast); zero behind the last one
+        {
+            const int nb = min(BWN, Fmax + 16);
+            for (int k = gl; k < nb; k += G) {
+                int bwk = 0;
+                if (k < F) {
+                    const int lim = (int)idx[k] + AR;
+                    int lo = k, hi = min(F - 1, k + dk::MAXAR);
+                    while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if ((int)idx[mid] <= lim) lo = mid; else hi = mid - 1; }
+                    bwk = lo - k;
+                }
+                bwv[k] = (unsigned char)bwk;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        // ---- LDL^T with the forward substitution fused
+        double c[CR];
+#pragma unroll
+        for (int s = 0; s < CR; ++s) {
+            if (s <= BW) { const int dlt = (int)idx[s + gl] - (int)idx[s]; c[s] = aux[dlt < AR + 1 ? dlt : AR + 1]; }
+            else c[s] = 0.0;
+        }
+        double yr = yv[gl];                                              // y of row k + gl
+        double rinv_n = dk_rcp(c[0]);
+        int dz_n = c[0] == 0.0;
+        bool okw = true;
+        unsigned goff = 0;
+        int bwk = bwv[0];
+        for (int k0 = 0; k0 < Fmax; k0 += 8) {
+            // one pivot; p (the register of its column) and the update's column offsets are compile-time constants
+            auto pivot = [&](auto pc) {
+                constexpr int p = decltype(pc)::value;
+                const int k = k0 + p;
+                const bool live = k < F;
+                const double colv = c[p];
+                const double rinv = dk_group0(rinv_n, q, TWO);
+                const double dzv = dk_group0(dz_n ? 1.0 : 0.0, q, TWO);
+                if (live && dzv != 0.0) okw = false;
+                const double l = colv * rinv;
+                CV[gl] = gl ? colv : yr;
+                LV[gl] = l;
+                __builtin_amdgcn_wave_barrier();
+                const int bwn = bwv[k + 1];
+                const int i0 = idx[k + BW + 1], i1 = idx[k + BW + 1 + gl];
+                const double ynew = yv[k + BW + 1];
+                const double yk = CV[0];
+                const int bmax = TWO ? max(__builtin_amdgcn_readlane(bwk, 0), __builtin_amdgcn_readlane(bwk, 32)) : __builtin_amdgcn_readlane(bwk, 0);
+                const int dlt = i1 - i0;
+                const double ent = aux[dlt < AR + 1 ? dlt : AR + 1];
+                // trailing update, DK_BCH columns per round, wave-uniform exit behind the widest band of the windows in the wave
+                auto round = [&](auto bc) -> bool {
+                    constexpr int b0 = 1 + DK_BCH * decltype(bc)::value;
+                    if (b0 > bmax) return false;
+                    asm volatile("" ::: "memory");                         // (keeps the reads of later rounds from being hoisted above their exit test: 120 registers)
+                    double cvb[DK_BCH], lvb[DK_BCH];
+#pragma unroll
+                    for (int u = 0; u < DK_BCH; ++u) if (b0 + u <= BW) { cvb[u] = CV[b0 + u]; lvb[u] = LV[gl + b0 + u]; }
+#pragma unroll
+                    for (int u = 0; u < DK_BCH; ++u) if (b0 + u <= BW) c[p + b0 + u] = __fma_rn(-cvb[u], lvb[u], c[p + b0 + u]);
+                    return true;
+                };
+                dk_all_rounds(round, std::make_integer_sequence<int, (BW + DK_BCH - 1) / DK_BCH>{});
+                // 1 / d of the next pivot: entry (k + 1, k + 1) is lane 0's c[p + 1]
+                rinv_n = dk_rcp(c[p + 1]); dz_n = c[p + 1] == 0.0;
+                // factor stream: the bw multipliers of the column, then y_k / d_k
+                if (live) {
+                    if (gl >= 1 && gl <= bwk) gL[goff + (unsigned)gl - 1u] = l;
+                    if (gl == 0) gL[goff + (unsigned)bwk] = yk * rinv;
+                    goff += (unsigned)bwk + 1u;
+                }
+                // forward substitution and the slide of y
+                const double yupd = __fma_rn(-l, yk, yr);
+                yr = dk_wave_shl1(yupd);
+                if (gl == BW) yr = ynew;
+                c[p + BW + 1] = ent;
+                bwk = bwn;
+                __builtin_amdgcn_wave_barrier();
+            };
+            pivot(std::integral_constant<int, 0>{}); pivot(std::integral_constant<int, 1>{}); pivot(std::integral_constant<int, 2>{});
+            pivot(std::integral_constant<int, 3>{}); pivot(std::integral_constant<int, 4>{}); pivot(std::integral_constant<int, 5>{});
+            pivot(std::integral_constant<int, 6>{}); pivot(std::integral_constant<int, 7>{});
+#pragma unroll
+            for (int s = 0; s <= BW; ++s) c[s] = c[s + 8];
+        }
+        // ---- back substitution, column form (as k_adeclick_fast): lane t of the group holds the sum collected for row i - t
+        {
+            __threadfence();
+            double A = 0.0;
+            unsigned segv;
+            {
+                const int k1 = F - 1 - gl;
+                const unsigned cc = k1 >= 0 ? (unsigned)bwv[k1] + 1u : 0u; unsigned inc = cc;
+#pragma unroll
+                for (int dd = 1; dd < G; dd <<= 1) { const unsigned o = __shfl_up(inc, dd, G); inc += gl >= dd ? o : 0u; }
+                segv = goff - (inc - cc);
+            }
+            for (int ib = Fmax - 1; ib >= 0; ib -= 16) {
+                // rows ib .. ib - 15 of the longer window; this group's window is F - Fmax rows shorter: its row index is shifted
+                double Lr[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int i = ib - r - (Fmax - F);                      // this window's row (negative: nothing to do yet / any more)
+                    const int k = i - gl;
+                    const int bwk2 = (k >= 0 && i >= 0 && i < F) ? (int)bwv[k] : 0;
+                    const bool act = i >= 0 && i < F && k >= 0;
+                    if (act) segv -= (unsigned)bwk2 + 1u;
+                    const bool valid = act && bwk2 >= gl;
+                    Lr[r] = valid ? dk_ld(&gL[segv + (gl ? (unsigned)gl - 1u : (unsigned)bwk2)]) : 0.0;
+                }
+                double xs = 0.0;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const double x = dk_group0(Lr[r], q, TWO) - dk_group0(A, q, TWO);
+                    A = __fma_rn(Lr[r], x, A);
+                    A = dk_wave_shl1(A);
+                    if (gl == G - 1) A = 0.0;                               // (the lane behind the group's last one belongs to the other window)
+                    xs = gl == r ? x : xs;
+                }
+                const int i = ib - gl - (Fmax - F);
+                if (gl < 16 && i >= 0 && i < F) yv[i] = xs;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (okw) {
+            for (int e = gl; e < F; e += G) {
+                const int pos = idx[e];
+                if (pos >= P.skip && pos < P.skip + P.hop && o0 + (pos - P.skip) < n) out[o0 + (pos - P.skip)] = yv[e];
+            }
+            repaired += gl == 0 ? (unsigned long long)F : 0ull;
+        } else {
+            singular += (gl == 0 && have) ? 1ull : 0ull;
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    if (gl == 0 && (repaired || singular)) { atomicAdd(&stats[0], repaired); atomicAdd(&stats[1], singular); }
+}
+
 // host side --------------------------------------------------------------------------------------------------------
 bool jt_adeclick_supported(int sample_rate, double window_ms, double overlap_pct, double ar_pct, int method, std::string *why)
 {
@@ -1131,6 +1387,9 @@ void launch_adeclick(jt_ctx *h, const double *in, double *out, int64_t n, int sa
 #define DK_LAUNCH(KERN, GRID, SMEM, PP) do { auto k_ = KERN; \
         JT_HIP(hipFuncSetAttribute((const void *)k_, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(SMEM))); \
         hipLaunchKernelGGL(k_, dim3((unsigned)(GRID)), dim3(64), (SMEM), s, in, out, n, PP, h->declick_scr.p, per_wave, d_stats, h->declick_heavy.p); } while (0)
+#define DKF_LAUNCH(KERN, GRID, SMEM, PP) do { auto k_ = KERN; \
+        JT_HIP(hipFuncSetAttribute((const void *)k_, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(SMEM))); \
+        hipLaunchKernelGGL(k_, dim3((unsigned)(GRID)), dim3(64), (SMEM), s, in, out, n, PP, h->declick_scr.p, per_wave, d_stats, h->declick_heavy.p, SP); } while (0)
     if (!exact) {
         // fast kernel: ring NC columns x ND diagonals (bands up to ND - 1 rows); flag words sized by the window
         P.nw = ((P.W + 63) >> 6) + 2;
@@ -1148,16 +1407,54 @@ void launch_adeclick(jt_ctx *h, const double *in, double *out, int64_t n, int sa
         if (const char *ev = getenv("JT_DK_WAVES")) v0 = std::max(1, std::min(v0, atoi(ev)));
         const int64_t f0 = std::min<int64_t>(P.nwindows, (int64_t)256 * v0), f1 = std::min<int64_t>(P.nwindows, (int64_t)256 * v1),
                       f2 = std::min<int64_t>(P.nwindows, (int64_t)256 * v2);
-        h->declick_scr.ensure(per_wave * (size_t)std::max(f0, std::max(f1, f2)));
+        if (getenv("JT_ADECLICK_FUSED")) h->declick_scr.ensure(per_wave * (size_t)std::max(f0, std::max(f1, f2)));
         DeclickParams Q0 = P, Q1 = P, Q2 = P; Q0.sa = fa0; Q1.sa = fa1; Q2.sa = fa2;
-        if (half_ok) {
-            DK_LAUNCH((k_adeclick_fast<LIGHT, NC0, ND0, true, 0>), f0, fm0, Q0);
-            DK_LAUNCH((k_adeclick_fast<MID, NC1, ND1, true, 1>), f1, fm1, Q1);
-        } else {
-            DK_LAUNCH((k_adeclick_fast<LIGHT, NC0, ND0, false, 0>), f0, fm0, Q0);
-            DK_LAUNCH((k_adeclick_fast<MID, NC1, ND1, false, 1>), f1, fm1, Q1);
+        DkSplit SP{};
+        // Split pipeline (default): the front kernel leaves every window's index list / right-hand side in global memory, two solver
+        // launches (bands up to 31 rows: two windows per wave; up to 48: one) factor and substitute with the trailing block in registers.
+        // JT_ADECLICK_FUSED=1 keeps everything in the one kernel of round 2 (A/B, and the reference the split is tested against).
+        const bool fused = getenv("JT_ADECLICK_FUSED") != nullptr;
+        if (!fused) {
+            constexpr int FCS = LIGHT, G32 = 32, BW32 = 31, G64 = 64, BW64 = 48;
+            const int wp = (P.W + 63) & ~63;
+            h->declick_F.ensure((size_t)P.nwindows); h->declick_lists.ensure(2 * (size_t)P.nwindows);
+            h->declick_idx.ensure((size_t)P.nwindows * wp); h->declick_rhs.ensure((size_t)P.nwindows * wp);
+            h->declick_aux.ensure((size_t)P.nwindows * 56); h->declick_ctl.ensure(8);
+            JT_HIP(hipMemsetAsync(h->declick_ctl.p, 0, 8 * sizeof(unsigned long long), s));
+            SP.F = h->declick_F.p; SP.index = h->declick_idx.p; SP.rhs = h->declick_rhs.p; SP.aux = h->declick_aux.p;
+            SP.list32 = h->declick_lists.p; SP.list64 = h->declick_lists.p + P.nwindows; SP.ctl = h->declick_ctl.p; SP.wp = wp;
+            auto slot_bytes = [&](int G, int BW) {
+                const int idxn = (FCS + BW + 16 + G + 7) & ~7, bwn = (FCS + 16 + 7) & ~7, yn = (FCS + BW + 16 + 7) & ~7;
+                return sizeof(double) * (size_t)(yn + 56 + 4 * G) + 2 * (size_t)idxn + (size_t)bwn;
+            };
+            const size_t sm32 = 2 * slot_bytes(G32, BW32) + 16, sm64 = slot_bytes(G64, BW64) + 16;
+            const int w32 = (int)std::min<size_t>(16, (160 * 1024) / sm32), w64 = (int)std::min<size_t>(8, (160 * 1024) / sm64);
+            const int64_t g32 = std::min<int64_t>((P.nwindows + 1) / 2, (int64_t)256 * w32), g64 = std::min<int64_t>(P.nwindows, (int64_t)256 * w64);
+            const size_t slot32 = (size_t)FCS * (BW32 + 1), slot64 = (size_t)FCS * (BW64 + 1);
+            // the level-1 / level-2 kernels below (windows with more than LIGHT flagged samples) index the same scratch per wave
+            h->declick_scr.ensure(std::max(per_wave * (size_t)std::max(f1, f2), std::max(slot32 * 2 * (size_t)g32, slot64 * (size_t)g64)));
+            if (half_ok) DKF_LAUNCH((k_adeclick_fast<LIGHT, NC0, ND0, true, 0, 1>), f0, fm0, Q0);
+            else DKF_LAUNCH((k_adeclick_fast<LIGHT, NC0, ND0, false, 0, 1>), f0, fm0, Q0);
+            {
+                auto k32 = k_dk_solve<G32, BW32, FCS>; auto k64 = k_dk_solve<G64, BW64, FCS>;
+                JT_HIP(hipFuncSetAttribute((const void *)k32, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm32));
+                JT_HIP(hipFuncSetAttribute((const void *)k64, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm64));
+                hipLaunchKernelGGL(k32, dim3((unsigned)g32), dim3(64), sm32, s, out, n, P, SP, h->declick_scr.p, slot32, d_stats);
+                hipLaunchKernelGGL(k64, dim3((unsigned)g64), dim3(64), sm64, s, out, n, P, SP, h->declick_scr.p, slot64, d_stats);
+            }
+            if (half_ok) DKF_LAUNCH((k_adeclick_fast<MID, NC1, ND1, true, 1>), f1, fm1, Q1);
+            else DKF_LAUNCH((k_adeclick_fast<MID, NC1, ND1, false, 1>), f1, fm1, Q1);
+            DKF_LAUNCH((k_adeclick_fast<dk::MAXW, NC1, ND1, false, 2>), f2, fm2, Q2);
+            return;
         }
-        DK_LAUNCH((k_adeclick_fast<dk::MAXW, NC1, ND1, false, 2>), f2, fm2, Q2);
+        if (half_ok) {
+            DKF_LAUNCH((k_adeclick_fast<LIGHT, NC0, ND0, true, 0>), f0, fm0, Q0);
+            DKF_LAUNCH((k_adeclick_fast<MID, NC1, ND1, true, 1>), f1, fm1, Q1);
+        } else {
+            DKF_LAUNCH((k_adeclick_fast<LIGHT, NC0, ND0, false, 0>), f0, fm0, Q0);
+            DKF_LAUNCH((k_adeclick_fast<MID, NC1, ND1, false, 1>), f1, fm1, Q1);
+        }
+        DKF_LAUNCH((k_adeclick_fast<dk::MAXW, NC1, ND1, false, 2>), f2, fm2, Q2);
         return;
     }
     // resident waves per CU = what LDS admits (10 at the 44.1 kHz defaults).  With the windows handed out dynamically the time
@@ -1180,4 +1477,5 @@ void launch_adeclick(jt_ctx *h, const double *in, double *out, int64_t n, int sa
     }
     DK_LAUNCH((k_adeclick<dk::MAXW, dk::BS, false, 2>), g2, sm2, P2);
 #undef DK_LAUNCH
+#undef DKF_LAUNCH
 }
