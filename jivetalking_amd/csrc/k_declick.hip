@@ -1267,7 +1267,12 @@ k_dk_solve(double *__restrict__ out, int64_t n, DeclickParams P, DkSplit S, doub
 #pragma unroll
                     for (int u = 0; u < DK_BCH; ++u) if (b0 + u <= BW) { cvb[u] = CV[b0 + u]; lvb[u] = LV[gl + b0 + u]; }
 #pragma unroll
-                    for (int u = 0; u < DK_BCH; ++u) if (b0 + u <= BW) c[p + b0 + u] = __fma_rn(-cvb[u], lvb[u], c[p + b0 + u]);
+                    for (int u = 0; u < DK_BCH; ++u) if (b0 + u <= BW) {
+                        c[p + b0 + u] = __fma_rn(-cvb[u], lvb[u], c[p + b0 + u]);
+                        // pin the result here: the optimiser otherwise sinks every round's FMAs below the reads of all later rounds
+                        // (their results are only used after the last round) and spills the operands it then holds for them
+                        asm volatile("" : "+v"(c[p + b0 + u]));
+                    }
                     return true;
                 };
                 dk_all_rounds(round, std::make_integer_sequence<int, (BW + DK_BCH - 1) / DK_BCH>{});
