@@ -67,6 +67,7 @@ extern "C" void jt_close(jt_ctx *h)
     if (h->spec_p2.stream) { (void)hipStreamSynchronize(h->spec_p2.stream); (void)hipStreamDestroy(h->spec_p2.stream); }
     if (h->spec_p2.done) (void)hipEventDestroy(h->spec_p2.done);
     if (h->spec_ln.stream) { (void)hipStreamSynchronize(h->spec_ln.stream); (void)hipStreamDestroy(h->spec_ln.stream); }
+    if (h->dk_stream) { (void)hipStreamSynchronize(h->dk_stream); (void)hipStreamDestroy(h->dk_stream); (void)hipEventDestroy(h->dk_ev[0]); (void)hipEventDestroy(h->dk_ev[1]); }
     if (h->spec_ln.fork) (void)hipEventDestroy(h->spec_ln.fork);
     if (h->spec_ln.pin) (void)hipHostFree(h->spec_ln.pin);
     if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);

@@ -310,6 +310,7 @@ struct jt_ctx {
     // adeclick's split pipeline (front kernel -> solver kernels, k_declick.hip): per-window flagged count, index list, right-hand side, aux
     DevBuf<int> declick_F, declick_lists; DevBuf<unsigned short> declick_idx; DevBuf<double> declick_rhs, declick_aux;
     DevBuf<unsigned long long> declick_ctl;
+    hipStream_t dk_stream = nullptr; hipEvent_t dk_ev[2] = {nullptr, nullptr};      // the wide-band solver's stream (created on first use)
     // FLAC output leg: frame records, byte offsets, summary, encoded frames; pinned host copies of the PCM (MD5) and the file
     DevBuf<unsigned char> fl_rec, fl_out; DevBuf<long long> fl_off; DevBuf<int16_t> fl_pcm;
     HostArena pin_pcm, pin_flac;

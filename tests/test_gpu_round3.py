@@ -99,3 +99,22 @@ def test_pass1_completes_when_the_announced_pass2_head_cannot_be_built(engine):
     with pytest.raises(L.JtError) as ei:
         engine.pass2(default_filter_params())
     assert ei.value.code == L.JT_E_INVAL and "Nyquist" in str(ei.value)
+
+
+def test_adeclick_split_pipeline_equals_the_one_kernel_version(engine, monkeypatch):
+    """adeclick runs as a front kernel (AR fit, detector, index list, right-hand side) plus register-resident solver kernels (two windows
+    per wave for bands up to 31 rows, one for bands up to 48).  Same operations on the same values as round 2's single kernel
+    (JT_ADECLICK_FUSED=1): the outputs are bit-identical, on speech, on speech with real clicks, and on a signal loud enough that most
+    windows take the wide-band solver."""
+    rng = np.random.default_rng(5)
+    for seed, gain, clicks in ((21, 1.0, 0), (22, 4.0, 150), (23, 16.0, 400)):
+        x = np.asarray(synth.speech_like(20.0, 44100, seed=seed), np.float64) * gain
+        if clicks:
+            pos = rng.integers(1000, x.size - 1000, clicks)
+            x[pos] += rng.uniform(-0.5, 0.5, clicks)
+        monkeypatch.setenv("JT_ADECLICK_FUSED", "1")
+        a = engine.op_adeclick(x, 44100)
+        monkeypatch.delenv("JT_ADECLICK_FUSED")
+        b = engine.op_adeclick(x, 44100)
+        assert np.array_equal(a, b), f"seed {seed}: {int((a != b).sum())} samples differ, max {np.abs(a - b).max():.3g}"
+        assert int((a != x).sum()) > 1000                          # the filter did repair samples
