@@ -193,6 +193,15 @@ typedef struct {              /* loudnorm print_format=json (normalise.go:64-75)
     int    normalization_type_dynamic;   /* 0 = "linear", 1 = "dynamic" */
 } jt_loudnorm_stats;
 
+/* Pass 3 started inside Pass 2 with the plan the caller WILL pass (normalise.go:373-561: the limiter plan is a function of Pass 2's
+ * integrated loudness and true peak alone).  Announce a planner before jt_pass2: as soon as those two values exist (the other analysis
+ * chains of Pass 2 are still running) jt_pass2 calls fn(user, integrated LUFS, true peak as a linear ratio, &plan) on the calling thread
+ * and, if the plan needs the limiter prefix, queues volume -> alimiter -> the 192 kHz measurement right away; jt_pass3 with an equal
+ * plan then collects the result instead of running it after Pass 2 has ended.  A schedule change only: same kernels, same inputs, same
+ * numbers (JT_NO_EARLY_PLAN=1 disables it; tests/test_gpu_round3.py compares).  The announcement lasts for one jt_pass2. */
+typedef int (*jt_plan_fn)(void *user, double integrated_lufs, double true_peak_linear, jt_limiter_plan *plan);
+int jt_pass3_plan_hook(jt_ctx *h, jt_plan_fn fn, void *user);
+
 /* ---- Pass 3: replaces measureWithLoudnorm's sweep (normalise.go:226-346) over
  * "<prefix>,loudnorm=I=-16.0:TP=-1.0:LRA=20.0:dual_mono=true:print_format=json:stats_file=..." (:257-268).
  * Only the input_* fields and target_offset are filled (the dynamic-mode output is discarded by the

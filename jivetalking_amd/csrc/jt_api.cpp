@@ -67,6 +67,8 @@ extern "C" void jt_close(jt_ctx *h)
     if (h->spec_p2.stream) { (void)hipStreamSynchronize(h->spec_p2.stream); (void)hipStreamDestroy(h->spec_p2.stream); }
     if (h->spec_p2.done) (void)hipEventDestroy(h->spec_p2.done);
     if (h->spec_ln.stream) { (void)hipStreamSynchronize(h->spec_ln.stream); (void)hipStreamDestroy(h->spec_ln.stream); }
+    if (h->early_p3.pin) (void)hipHostFree(h->early_p3.pin);
+    if (h->early_p3.ev[0]) { (void)hipEventDestroy(h->early_p3.ev[0]); (void)hipEventDestroy(h->early_p3.ev[1]); }
     if (h->dk_stream) { (void)hipStreamSynchronize(h->dk_stream); (void)hipStreamDestroy(h->dk_stream); (void)hipEventDestroy(h->dk_ev[0]); (void)hipEventDestroy(h->dk_ev[1]); }
     if (h->spec_ln.fork) (void)hipEventDestroy(h->spec_ln.fork);
     if (h->spec_ln.pin) (void)hipHostFree(h->spec_ln.pin);
@@ -728,6 +730,46 @@ static void spec_loudnorm_enqueue(jt_ctx *h, const int16_t *s16, int64_t n, int 
     S.blk = blk; S.nfull = m_meter / blk; S.pending = true;
 }
 
+extern "C" int jt_pass3_plan_hook(jt_ctx *h, jt_plan_fn fn, void *user)
+{
+    if (!h) return JT_E_INVAL;
+    h->early_p3.fn = fn; h->early_p3.user = user; h->early_p3.armed = fn != nullptr;
+    return JT_OK;
+}
+
+static void run_limiter(jt_ctx *h, const double *in, double *out, int64_t n, int sr, double limit, double attack_ms, double release_ms, double in_gain);
+
+// Pass 3 for a plan WITH the limiter prefix, queued on the main stream inside Pass 2 (behind the output stage, before the join with the
+// analysis chains): volume -> alimiter on the s16 output, swr (double) -> 192 kHz, K-weighting + block energies.  The same launches as
+// pass3_core's prefix branch; scratch and results of its own (the pass arenas hold Pass 2's analysis).
+static void early_pass3_enqueue(jt_ctx *h, const int16_t *s16, int64_t m, int rate, const jt_limiter_plan &lim)
+{
+    auto &E = h->early_p3;
+    SwrDev &sw = get_swr(h, rate, 192000);
+    const int64_t m_total = sw.out_len(m);
+    const int blk = (192000 + 5) / 10;
+    const int64_t m_meter = loudnorm_meter_len(m_total);
+    size_t dev_d = 0, pin_d = 0; jt_kweight_scratch_sizes(m_meter, blk, &dev_d, &pin_d);
+    E.dev.ensure(dev_d);
+    if (pin_d > E.pin_cap) {
+        if (E.pin) JT_HIP(hipHostFree(E.pin));
+        E.pin = nullptr; E.pin_cap = 0;
+        JT_HIP(hipHostMalloc((void **)&E.pin, sizeof(double) * pin_d, hipHostMallocDefault));
+        E.pin_cap = pin_d;
+    }
+    h->f64_a.ensure((size_t)m); h->f64_b.ensure((size_t)m); h->stream_d.ensure((size_t)m_meter);
+    const bool pre = lim.pre_gain_db > 0;
+    const double g = pre ? std::pow(10.0, lim.pre_gain_db / 20.0) : 1.0;
+    launch_s16_to_f64(s16, h->f64_a.p, m, g, pre ? 1 : 0, h->stream);
+    run_limiter(h, h->f64_a.p, h->f64_b.p, m, rate, lim.limit, 5.0, 100.0, 1.0);
+    h->lim_keep = {true, s16, m, rate, lim.pre_gain_db, lim.limit};
+    launch_resample_stream_f64(h->f64_b.p, m, sw.bank_d.p, sw.pl.phase_count, sw.pl.filter_length, sw.pl.center, sw.pl.step, m_total, h->stream_d.p, h->stream);
+    loudnorm_append_flush(h->stream_d.p, m_total, h->stream);
+    const KwScratch ext{E.dev.p, E.pin};
+    jt_kweight_enqueue_f64(h, h->stream_d.p, m_meter, 192000, blk, &E.kw, h->stream, &ext);
+    E.blk = blk; E.nfull = m_meter / blk; E.plan = lim; E.valid = true;
+}
+
 extern "C" int jt_pass2(jt_ctx *h, const jt_filter_params *p, jt_analysis *out)
 {
     JT_API_BEGIN_KEEP(h)
@@ -740,6 +782,8 @@ extern "C" int jt_pass2(jt_ctx *h, const jt_filter_params *p, jt_analysis *out)
     const int out_rate = p->out_rate > 0 ? p->out_rate : 44100;
     spec_loudnorm_cancel(h);
     h->lim_keep.valid = false;
+    h->early_p3.valid = false;
+    const bool plan_hook = h->early_p3.armed && !getenv("JT_NO_EARLY_PLAN"); h->early_p3.armed = false;
     jt_ctx::RegionSlot &slot = h->region_slot[0];
     slot.valid = false; h->region_slot[1].valid = false;            // both stage outputs are about to be replaced
     const bool announced = slot.armed; slot.armed = false;
@@ -808,6 +852,22 @@ extern "C" int jt_pass2(jt_ctx *h, const jt_filter_params *p, jt_analysis *out)
         if (regions) regions_enqueue(h, h->s16_p2.p, out_rate, &RJ, true);
     }
     spec_loudnorm_enqueue(h, h->s16_p2.p, h->m_p2, out_rate);            // Pass 3's usual measurement, on its own stream (not joined)
+    if (plan_hook && J.want_r128 && out_rate != 192000) {
+        // The limiter plan is a function of this pass's integrated loudness and true peak (K-weighting chain on aux[1], true peak on
+        // aux[3]): wait for those two chains only, ask the planner, and queue the prefix measurement while astats / aspectralstats / the
+        // regions are still running.  The values are the ones analysis_complete() will report below (same arithmetic, same inputs).
+        auto &E = h->early_p3;
+        if (!E.ev[0]) { JT_HIP(hipEventCreateWithFlags(&E.ev[0], hipEventDisableTiming)); JT_HIP(hipEventCreateWithFlags(&E.ev[1], hipEventDisableTiming)); }
+        JT_HIP(hipEventRecord(E.ev[0], h->aux[1])); JT_HIP(hipEventRecord(E.ev[1], h->aux[3]));
+        JT_HIP(hipEventSynchronize(E.ev[0])); JT_HIP(hipEventSynchronize(E.ev[1]));
+        check_cancel(h);
+        std::vector<double> bsum, bpk;
+        jt_kweight_finish(&J.kw, bsum, bpk);
+        R128Series r; jt_r128_finish(bsum.data(), J.nfull, J.blk, J.sr, J.dualmono, &r);
+        double tp = 0; for (int64_t k = 0; k < J.nfull; ++k) tp = std::max(tp, J.btp[(size_t)k]);
+        jt_limiter_plan plan; std::memset(&plan, 0, sizeof plan);
+        if (E.fn(E.user, r.integrated, tp, &plan) == JT_OK && plan.needed) early_pass3_enqueue(h, h->s16_p2.p, h->m_p2, out_rate, plan);
+    }
     analysis_join(h, regions ? 2 : 1);
     h->out_rate = out_rate; h->m_p4 = 0;
     JT_HIP(hipEventRecord(h->ev1, h->stream));
@@ -877,6 +937,18 @@ static void loudnorm_measure_finish(const LoudnormJob &J, jt_loudnorm_stats *out
 
 static void pass3_core(jt_ctx *h, const int16_t *s16, int64_t m, int rate, const jt_limiter_plan *lim, jt_loudnorm_stats *out)
 {
+    if (h->early_p3.valid) {
+        // Pass 2 ran this very measurement (jt_pass3_plan_hook) and synchronised behind it: take it if the plan is the one it was run with
+        auto &E = h->early_p3;
+        E.valid = false;
+        if (s16 == h->s16_p2.p && m == h->m_p2 && lim && lim->needed && E.plan.needed && lim->pre_gain_db == E.plan.pre_gain_db && lim->limit == E.plan.limit) {
+            if (h->spec_ln.pending) { JT_HIP(hipStreamSynchronize(h->spec_ln.stream)); h->spec_ln.pending = false; }   // (retire the no-prefix guess)
+            LoudnormJob J; J.kw = E.kw; J.nfull = E.nfull; J.blk = E.blk;
+            loudnorm_measure_finish(J, out);
+            return;
+        }
+        h->lim_keep.valid = false;
+    }
     if (h->spec_ln.pending) {
         // Pass 2 already queued this measurement of its output for the no-prefix plan: collect it -- or let it finish (it owns the
         // 192 kHz stream buffer) and measure what was asked for

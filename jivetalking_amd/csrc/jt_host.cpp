@@ -1161,7 +1161,20 @@ static int process_audio_impl(jt_ctx *h, const jt_host_config *base, int frame_s
     const bool have_regions = reg_du[0] > 0 || reg_du[1] > 0;
     if (have_regions) jt_region_prefetch(h, 2, reg_st, reg_du);
     double t0 = now_ms();
-    if ((rc = jt_pass2(h, &fp, &out->filtered)) != JT_OK) return rc;
+    // planLimiterForLoudnorm needs only Pass 2's integrated loudness and true peak (normalise.go:373-561): hand jt_pass2 the planner so
+    // that a plan with the limiter prefix starts Pass 3's measurement while the rest of Pass 2's analysis is still running.  The values
+    // go through the same "%.3f" print quantisation as below, so jt_pass3 is asked for exactly the plan that was started.
+    struct PlanCtx { const jt_host_config *eff; } pctx{&eff};
+    if (eff.loudnorm_enabled)
+        jt_pass3_plan_hook(h, [](void *u, double integrated, double tp_lin, jt_limiter_plan *plan) -> int {
+            const jt_host_config *e = static_cast<PlanCtx *>(u)->eff;
+            jt_limiter_decision dec;
+            jt_host_plan_limiter(qfmt("%.3f", integrated), linearRatioToDB(qfmt("%.3f", tp_lin)), e, &dec, plan);
+            return JT_OK;
+        }, &pctx);
+    rc = jt_pass2(h, &fp, &out->filtered);
+    jt_pass3_plan_hook(h, nullptr, nullptr);
+    if (rc != JT_OK) return rc;
     out->pass_ms[1] = h->timers.pass2_ms;
     out->stage_ms[4] = now_ms() - t0; t0 = now_ms();
     std::vector<double> lv2;

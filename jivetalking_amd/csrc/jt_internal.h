@@ -229,7 +229,7 @@ struct KwJob { const double *hc = nullptr; int64_t nchunks = 0, nfull = 0; int m
 struct KwScratch { double *dev = nullptr; double *pin = nullptr; };
 void jt_kweight_scratch_sizes(int64_t n, int blk, size_t *dev_doubles, size_t *pin_doubles);
 void jt_kweight_enqueue_f32(jt_ctx *h, const float *in, int64_t n, int rate, int blk, KwJob *job, hipStream_t s, const KwScratch *ext = nullptr);
-void jt_kweight_enqueue_f64(jt_ctx *h, const double *in, int64_t n, int rate, int blk, KwJob *job, hipStream_t s);
+void jt_kweight_enqueue_f64(jt_ctx *h, const double *in, int64_t n, int rate, int blk, KwJob *job, hipStream_t s, const KwScratch *ext = nullptr);
 // sums/peaks: nfull+1 entries (last = trailing partial block)
 void jt_kweight_finish(const KwJob *job, std::vector<double> &sums, std::vector<double> &peaks);
 size_t jt_arena_bytes_for(int64_t n);          // generous bound on the arena bytes one analysis of n samples stages
@@ -310,7 +310,13 @@ struct jt_ctx {
     // adeclick's split pipeline (front kernel -> solver kernels, k_declick.hip): per-window flagged count, index list, right-hand side, aux
     DevBuf<int> declick_F, declick_lists; DevBuf<unsigned short> declick_idx; DevBuf<double> declick_rhs, declick_aux;
     DevBuf<unsigned long long> declick_ctl;
-    hipStream_t dk_stream = nullptr; hipEvent_t dk_ev[2] = {nullptr, nullptr};      // the wide-band solver's stream (created on first use)
+    hipStream_t dk_stream = nullptr; hipEvent_t dk_ev[2] = {nullptr, nullptr};
+    // Pass 3 with the limiter prefix, started inside Pass 2 once its loudness / true peak are known (jt_pass3_plan_hook)
+    struct EarlyPass3 {
+        jt_plan_fn fn = nullptr; void *user = nullptr; bool armed = false;
+        bool valid = false; jt_limiter_plan plan{}; KwJob kw; int64_t nfull = 0; int blk = 0;
+        DevBuf<double> dev; double *pin = nullptr; size_t pin_cap = 0; hipEvent_t ev[2] = {nullptr, nullptr};
+    } early_p3;      // the wide-band solver's stream (created on first use)
     // FLAC output leg: frame records, byte offsets, summary, encoded frames; pinned host copies of the PCM (MD5) and the file
     DevBuf<unsigned char> fl_rec, fl_out; DevBuf<long long> fl_off; DevBuf<int16_t> fl_pcm;
     HostArena pin_pcm, pin_flac;

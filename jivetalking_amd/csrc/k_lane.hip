@@ -565,7 +565,7 @@ static void kweight_enqueue(jt_ctx *h, const TIn *in, int64_t n, int rate, int b
     job->hc = hc; job->nchunks = nchunks; job->nfull = n / blk; job->m = m;
 }
 void jt_kweight_enqueue_f32(jt_ctx *h, const float *in, int64_t n, int rate, int blk, KwJob *job, hipStream_t s, const KwScratch *ext) { kweight_enqueue<float>(h, in, n, rate, blk, job, s, ext); }
-void jt_kweight_enqueue_f64(jt_ctx *h, const double *in, int64_t n, int rate, int blk, KwJob *job, hipStream_t s) { kweight_enqueue<double>(h, in, n, rate, blk, job, s); }
+void jt_kweight_enqueue_f64(jt_ctx *h, const double *in, int64_t n, int rate, int blk, KwJob *job, hipStream_t s, const KwScratch *ext) { kweight_enqueue<double>(h, in, n, rate, blk, job, s, ext); }
 void jt_kweight_finish(const KwJob *job, std::vector<double> &sums, std::vector<double> &peaks)
 {
     const int64_t nfull = job->nfull, nchunks = job->nchunks;

@@ -118,3 +118,32 @@ def test_adeclick_split_pipeline_equals_the_one_kernel_version(engine, monkeypat
         b = engine.op_adeclick(x, 44100)
         assert np.array_equal(a, b), f"seed {seed}: {int((a != b).sum())} samples differ, max {np.abs(a - b).max():.3g}"
         assert int((a != x).sum()) > 1000                          # the filter did repair samples
+
+
+def test_pass3_started_inside_pass2_with_the_planned_prefix_equals_the_explicit_one(engine, monkeypatch):
+    """jt_pass3_plan_hook: a plan that needs the limiter prefix starts Pass 3's measurement inside Pass 2, as soon as Pass 2's loudness
+    and true peak exist.  A schedule change only - every number and every output sample equals the run without it
+    (JT_NO_EARLY_PLAN=1), on a talker whose plosives need the prefix and on one that does not."""
+    w = int(0.02 * SR)
+    burst = 0.35 * np.hanning(w) * np.sin(2 * np.pi * 180.0 * np.arange(w) / SR)
+    for seed, plosives in ((61, True), (62, False)):
+        x = np.asarray(synth.speech_like(45.0, SR, seed=seed), np.float64)
+        if plosives:
+            for pos in range(SR, x.size - SR, int(1.5 * SR)):
+                x[pos:pos + w] += burst
+        x = x.astype(np.float32)
+        res = []
+        for early in (False, True):
+            if early:
+                monkeypatch.delenv("JT_NO_EARLY_PLAN", raising=False)
+            else:
+                monkeypatch.setenv("JT_NO_EARLY_PLAN", "1")
+            engine.upload_pcm(x, SR, 1)
+            r = H.process_audio(engine)
+            res.append((int(r.limiter.needed), r.measure.input_i, r.measure.input_tp, r.measure.input_lra, r.measure.input_thresh,
+                        r.output_lufs, r.output_tp_db, r.filtered.r128.integrated, r.final_.r128.true_peak, engine.download_s16(4).tobytes(),
+                        engine.timers()["pass3_ms"]))
+        assert res[0][0] == (1 if plosives else 0)
+        assert res[0][:10] == res[1][:10], f"seed {seed}: the early start changed a result"
+        if plosives:
+            assert res[1][10] < res[0][10]                       # and Pass 3 itself only collects
