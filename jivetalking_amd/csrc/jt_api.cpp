@@ -851,8 +851,11 @@ extern "C" int jt_pass2(jt_ctx *h, const jt_filter_params *p, jt_analysis *out)
         regions = regions_resolve(slot.start_s, slot.dur_s, out_rate, h->m_p2, &RJ);
         if (regions) regions_enqueue(h, h->s16_p2.p, out_rate, &RJ, true);
     }
-    spec_loudnorm_enqueue(h, h->s16_p2.p, h->m_p2, out_rate);            // Pass 3's usual measurement, on its own stream (not joined)
-    if (plan_hook && J.want_r128 && out_rate != 192000) {
+    const bool plan_early = plan_hook && J.want_r128 && out_rate != 192000;
+    // Pass 3's measurement for the plan without a prefix, on its own stream (not joined): a guess when nobody can tell us the plan;
+    // with a planner it is queued below, once the plan says so (a file that needs the prefix then does not pay 3 ms of GPU work for it)
+    if (!plan_early) spec_loudnorm_enqueue(h, h->s16_p2.p, h->m_p2, out_rate);
+    if (plan_early) {
         // The limiter plan is a function of this pass's integrated loudness and true peak (K-weighting chain on aux[1], true peak on
         // aux[3]): wait for those two chains only, ask the planner, and queue the prefix measurement while astats / aspectralstats / the
         // regions are still running.  The values are the ones analysis_complete() will report below (same arithmetic, same inputs).
@@ -866,7 +869,9 @@ extern "C" int jt_pass2(jt_ctx *h, const jt_filter_params *p, jt_analysis *out)
         R128Series r; jt_r128_finish(bsum.data(), J.nfull, J.blk, J.sr, J.dualmono, &r);
         double tp = 0; for (int64_t k = 0; k < J.nfull; ++k) tp = std::max(tp, J.btp[(size_t)k]);
         jt_limiter_plan plan; std::memset(&plan, 0, sizeof plan);
-        if (E.fn(E.user, r.integrated, tp, &plan) == JT_OK && plan.needed) early_pass3_enqueue(h, h->s16_p2.p, h->m_p2, out_rate, plan);
+        const bool planned = E.fn(E.user, r.integrated, tp, &plan) == JT_OK;
+        if (planned && plan.needed) early_pass3_enqueue(h, h->s16_p2.p, h->m_p2, out_rate, plan);
+        else spec_loudnorm_enqueue(h, h->s16_p2.p, h->m_p2, out_rate);
     }
     analysis_join(h, regions ? 2 : 1);
     h->out_rate = out_rate; h->m_p4 = 0;
