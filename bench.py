@@ -359,28 +359,41 @@ def main():
         dk_avg_s = float(np.mean(dk_ms)) / 1e3
         if dk_avg_s > nlm_avg_s:
             dk_bytes = 16 * m                                  # adeclick: read f64 + write f64 per 44.1 kHz sample
-            roof = {"kernel": "k_adeclick", "bound": "hbm", "achieved": round(dk_bytes / dk_avg_s / 1e9, 2), "peak": 8000,
+            roof = {"kernel": "k_adeclick", "launches": "k_adeclick_fast<..., MODE 1> (front: fit, detector, right-hand side) + k_dk_solve<32> + k_dk_solve<64> "
+                                                        "(register-resident LDL^T, two windows / one window per wave) [+ k_adeclick_fast levels 1, 2 for overflow windows]",
+                    "bound": "hbm", "achieved": round(dk_bytes / dk_avg_s / 1e9, 2), "peak": 8000,
                     "unit": "GB/s", "frac": round(dk_bytes / dk_avg_s / 1e9 / 8000, 5), "traffic": None,
-                    "note": "dominant kernel; not bandwidth bound: a window is an AR fit, a detector and a banded LDL^T solve whose pivots "
-                            "are a dependent chain (k_adeclick_fast: matrix-pipe autocorrelation, register-blocked detector, "
-                            "diagonal-major LDS ring; ~35 k wave-instructions per window, SIMDs ~25 % busy, the rest is LDS / "
-                            "dependent-issue latency at 10 waves per CU: profiles/r02_pmc_issue.txt, DESIGN.md s4/s9)",
+                    "note": "dominant stage (HIP-event time over its launches); not bandwidth bound: a window is an AR fit, a detector and a banded "
+                            "LDL^T solve whose pivots are a dependent chain; the solvers keep the trailing block in registers and wait on LDS "
+                            "round trips 60 % of their wave time at 11 waves per CU (profiles/r03_pmc_issue.txt, DESIGN.md s4/s9)",
                     "avg_launch_ms": round(dk_avg_s * 1e3, 3), "repaired_samples": int(eng.timers()["declick_repaired"]),
                     "heavy_windows": int(eng.timers()["declick_heavy_windows"])}
         else:
             roof, nlm_roof = nlm_roof, None
-        # HBM traffic per launch from the committed PMC passes (profiles/r01_pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE and
-        # --pmc WRITE_SIZE in separate runs of this same command); FETCH_SIZE doubled per MI355X_MICROARCH.md's gfx950 note
+        # HBM traffic per launch from the round's committed PMC passes (profiles/r03_pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE and
+        # --pmc WRITE_SIZE in separate runs of this same command, tools/profile_round.sh); FETCH_SIZE doubled per MI355X_MICROARCH.md's
+        # gfx950 note.  The file records the sha256 of the kernel sources it was measured on: `traffic` is null once they have changed.
         try:
-            pmc_file = "r02_pmc_traffic.json" if os.path.exists(os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")) else "r01_pmc_traffic.json"
-            pmc = json.load(open(os.path.join(ROOT, "profiles", pmc_file)))["kernels"]
-            for r_ in (roof, nlm_roof):
-                # a kernel launched as several template instances per step (adeclick's three capacity levels) is summed
-                ks = [v for k, v in pmc.items() if k == r_["kernel"] or k.startswith(r_["kernel"] + "<") or k.startswith(r_["kernel"] + "_fast<")] if r_ else []
-                if ks:
-                    r_["traffic"] = int(sum(2 * k_["FETCH_SIZE_KB_max_call"] + k_["WRITE_SIZE_KB_max_call"] for k_ in ks) * 1024)
-                    r_["traffic_source"] = "profiles/" + pmc_file + " (PMC pass of this command, not collected live)"
-        except (OSError, KeyError, ValueError):
+            import hashlib
+            pmc_file = next(f for f in ("r03_pmc_traffic.json", "r02_pmc_traffic.json") if os.path.exists(os.path.join(ROOT, "profiles", f)))
+            pj = json.load(open(os.path.join(ROOT, "profiles", pmc_file)))
+            pmc = pj["kernels"]
+            sha = lambda f: hashlib.sha256(open(os.path.join(ROOT, "jivetalking_amd", "csrc", f), "rb").read()).hexdigest()[:16]
+            fresh = {f: pj.get("source_sha16", {}).get(f) == sha(f) for f in ("k_declick.hip", "k_nlm.hip")}
+            for r_, src, pref in ((roof, "k_declick.hip", ("k_adeclick", "k_dk_solve")), (nlm_roof, "k_nlm.hip", ("k_anlmdn_pair3",))):
+                if r_ is None:
+                    continue
+                if r_["kernel"].startswith("k_anlmdn"):
+                    src, pref = "k_nlm.hip", ("k_anlmdn_pair3",)
+                # a stage launched as several kernels / template instances per step (adeclick: front + two solvers + overflow levels) is summed
+                ks = [v for k, v in pmc.items() if any(k == q or k.startswith(q + "<") or k.startswith(q + "_fast<") for q in pref)]
+                if ks and fresh[src]:
+                    r_["traffic"] = int(sum(2 * k_.get("FETCH_SIZE_KB_max_call", 0.0) + k_.get("WRITE_SIZE_KB_max_call", 0.0) for k_ in ks) * 1024)
+                    r_["traffic_source"] = f"profiles/{pmc_file} (PMC passes of this command at git {pj.get('git', '?')}, {src} unchanged since; not collected live)"
+                else:
+                    r_["traffic"] = None
+                    r_["traffic_source"] = f"profiles/{pmc_file} was measured on another version of {src}: not reported"
+        except (OSError, KeyError, ValueError, StopIteration):
             pass
         out = {
             "metric": "realtime factor (xRT) on 48 kHz mono speech, 1/2/4/8 GPUs; LUFS error vs ref",

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Per-kernel issue/wait picture of one bench step (SQ counters, one PMC pass): where a kernel is instruction-issue bound vs parked
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-rm -rf gpurun_out/pmc_issue; timeout 600 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES --output-format csv -d gpurun_out/pmc_issue -o k -- python bench.py --steps 1 --warmup 1 --cpu-sample 0 --e2e 0 > gpurun_out/pmc_issue.log 2>&1
+rm -rf gpurun_out/pmc_issue; timeout 600 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES --output-format csv -d gpurun_out/pmc_issue -o k -- python bench.py --steps 1 --warmup 1 --cpu-sample 0 --e2e 0 --saturation 0 > gpurun_out/pmc_issue.log 2>&1
 python - <<EOF
 import csv, glob, re
 acc = {}

@@ -1,8 +1,17 @@
 """Fold the two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE counter_collection CSVs) into profiles/rNN_pmc_traffic.json:
 per kernel (short name) the largest call's counter value in KB and the call count."""
-import csv, json, re, sys
+import csv, hashlib, json, os, re, sys
 
 fetch_csv, write_csv, out = sys.argv[1], sys.argv[2], sys.argv[3]
+ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+
+
+def source_sha():
+    """sha256 (first 16 hex digits) of the kernel sources the roofline kernels live in: bench.py reports `traffic` only while these match"""
+    out = {}
+    for f in ("k_declick.hip", "k_nlm.hip"):
+        out[f] = hashlib.sha256(open(os.path.join(ROOT, "jivetalking_amd", "csrc", f), "rb").read()).hexdigest()[:16]
+    return out
 
 
 def short(name):
@@ -27,5 +36,6 @@ json.dump({"note": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate pass
                    "--cpu-sample 0`, 60-min workload; values in KB as reported, largest call per kernel (the full-file launch). "
                    "gfx950 FETCH_SIZE under-reports wide coalesced reads by 2x (MI355X_MICROARCH.md, HBM section); not corrected "
                    "here, bench.py doubles it.",
+           "source_sha16": source_sha(), "git": sys.argv[4] if len(sys.argv) > 4 else "",
            "kernels": res}, open(out, "w"), indent=1)
 print(len(res), "kernels ->", out)

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Kernel timeline of the last bench step (rocprofv3 --kernel-trace): start offset, duration, queue, name
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-rm -rf gpurun_out/tl; timeout 600 rocprofv3 --kernel-trace --output-format csv -d gpurun_out/tl -o k -- python bench.py --steps 2 --warmup 1 --cpu-sample 0 "$@" > gpurun_out/tl.log 2>&1
+rm -rf gpurun_out/tl; timeout 600 rocprofv3 --kernel-trace --output-format csv -d gpurun_out/tl -o k -- python bench.py --steps 2 --warmup 1 --cpu-sample 0 --e2e 0 --saturation 0 "$@" > gpurun_out/tl.log 2>&1
 python - <<EOF
 import csv, glob, re
 rows = []
