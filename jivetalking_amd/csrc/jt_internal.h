@@ -308,7 +308,7 @@ struct jt_ctx {
     RegionSlot region_slot[2];
     DevBuf<double> declick_scr; DevBuf<unsigned long long> declick_stats; DevBuf<int> declick_heavy;
     // adeclick's split pipeline (front kernel -> solver kernels, k_declick.hip): per-window flagged count, index list, right-hand side, aux
-    DevBuf<int> declick_F, declick_lists; DevBuf<unsigned short> declick_idx; DevBuf<double> declick_rhs, declick_aux;
+    DevBuf<int> declick_F, declick_lists; DevBuf<unsigned short> declick_idx; DevBuf<double> declick_rhs, declick_aux, declick_r;
     DevBuf<unsigned long long> declick_ctl;
     hipStream_t dk_stream = nullptr; hipEvent_t dk_ev[2] = {nullptr, nullptr};
     // Pass 3 with the limiter prefix, started inside Pass 2 once its loudness / true peak are known (jt_pass3_plan_hook)

@@ -44,6 +44,8 @@ struct DkSplit {
     int *list32, *list64;          // windows whose band fits 31 rows / needs up to 48
     unsigned long long *ctl;       // [0] / [1] list lengths, [2] / [3] work counters of the two solver launches
     int wp;
+    double *r;                     // [nwindows * 64] biased autocorrelation r[0 .. AR] (MODE 2 -> k_dk_levinson)
+    double *ac;                    // [nwindows * 64] AR polynomial k[0 .. AR], zero padded to 64 taps; ac[w * 64 + 63] = sigma_e
 };
 
 __device__ inline double dk_ld(const double *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
@@ -546,6 +548,10 @@ __device__ inline double dk_rcp(double d)
 // MODE 0: the whole filter in one kernel (as described above).  MODE 1: the FRONT of the split pipeline -- window load + pass-through
 // copy, AR fit, detector, index list, right-hand side -- which leaves F, index[], rhs[] and aux[] of every window with flagged samples
 // in global memory and appends the window to the solver list of its band class; k_dk_solve does the LDL^T and the substitutions.
+// The front itself runs as two launches with k_dk_levinson between them: MODE 2 = window load + pass-through copy + autocorrelation
+// (r[] to global memory), MODE 3 = detector .. right-hand side with the AR polynomial read back.  Levinson-Durbin is 48 strictly
+// sequential steps of a few flops: one wave per window spent a third of the front in it with one lane busy; one LANE per window
+// (k_dk_levinson) does the whole file's 131 k recursions in well under 0.1 ms.
 template <int FCAP, int NC, int ND, bool HALF, int LEVEL, int MODE = 0>
 __global__ void __launch_bounds__(64, 3)                  // three waves per SIMD (<= 168 VGPRs): LDS admits ten waves per CU
 k_adeclick_fast(const double *__restrict__ in, double *__restrict__ out, int64_t n, DeclickParams P, double *scratch,
@@ -646,7 +652,8 @@ k_adeclick_fast(const double *__restrict__ in, double *__restrict__ out, int64_t
             }
         };
         const int emid = HALF ? min(LB, P.skip + P.hop) : P.skip + P.hop;
-        load_buf(0, P.skip, emid);
+        if (MODE == 3) load_buf(HALF ? SB_B : 0);                   // (the detector starts on the upper half; MODE 2 wrote the pass-through copy)
+        else load_buf(0, P.skip, emid);
         wi = uniform64(wnext_);                                     // (the loads above were waited for; the atomic precedes them)
 #ifdef JT_DK_SPLIT0
         DKF_MARK(7)
@@ -654,7 +661,7 @@ k_adeclick_fast(const double *__restrict__ in, double *__restrict__ out, int64_t
         DKF_MARK(0)
 #endif
         // ---- 2. autocorrelation on the matrix pipe
-        {
+        if (MODE != 3) {
             dk_d4 C0 = {0, 0, 0, 0}, C1 = {0, 0, 0, 0}, C2 = {0, 0, 0, 0}, C3 = {0, 0, 0, 0};
             auto mfma_blocks = [&](int kb0, int kb1) {
                 const double *sj = sbuf - sb + lane;                       // sj[j0] = sample j0 + lane
@@ -696,11 +703,17 @@ k_adeclick_fast(const double *__restrict__ in, double *__restrict__ out, int64_t
             __builtin_amdgcn_wave_barrier();
             if (lane <= AR) rr[lane] = rl * (1.0 / W);
             __builtin_amdgcn_wave_barrier();
+            if (MODE == 2) { S.r[(size_t)w * 64 + lane] = lane <= AR ? rl * (1.0 / W) : 0.0; DKF_MARK(1) continue; }
         }
         DKF_MARK(1)
         // ---- 3. Levinson-Durbin (as k_adeclick)
         double sigmae;
-        {
+        if (MODE == 3) {
+            const double v = S.ac[(size_t)w * 64 + lane];
+            sigmae = dk_readlane(v, 63);
+            ac[lane] = lane == 63 ? 0.0 : v;
+            __builtin_amdgcn_wave_barrier();
+        } else {
             const double r0 = rr[0], r1 = rr[1];
             const double k0 = -r1 / r0;
             double areg = lane == 0 ? k0 : 0.0;
@@ -887,7 +900,7 @@ k_adeclick_fast(const double *__restrict__ in, double *__restrict__ out, int64_t
                     if (lane == 0) atomicAdd(&heavy[2 * P.nwindows + 128 + min(F >> 4, 63)], 1);
                 }
 #endif
-                to_heavy = MODE == 1 ? false : __any(bwmax > BWMAX);
+                to_heavy = (MODE == 1 || MODE == 3) ? false : __any(bwmax > BWMAX);
                 wide = __any(bwmax > 31);
                 // rows past the last one are "far away": every ring entry against them is aux[AR + 1] = 0
                 for (int k = F + lane; k < F + NC + ND && k < FCAP + NC + ND; k += 64) index[k] = 0xFFFF;
@@ -914,7 +927,7 @@ k_adeclick_fast(const double *__restrict__ in, double *__restrict__ out, int64_t
                 for (int e = lane; e < F; e += 64) { const int o = (int)index[e] - sb; if (o >= 0 && o < nb) sbuf[o] = 0.0; }
                 __builtin_amdgcn_wave_barrier();
             };
-            double *gVw = MODE == 1 ? S.rhs + (size_t)w * S.wp : gV;
+            double *gVw = (MODE == 1 || MODE == 3) ? S.rhs + (size_t)w * S.wp : gV;
             auto rhs_range = [&](int ea, int eb) {
                 const double *sj = sbuf - sb;
                 for (int e0 = ea; e0 < eb; e0 += 128) {
@@ -950,7 +963,7 @@ k_adeclick_fast(const double *__restrict__ in, double *__restrict__ out, int64_t
                 rhs_range(0, ea);
                 if (ea < F) { load_buf(SB_B); zero_flagged(); rhs_range(ea, F); }
             } else { zero_flagged(); rhs_range(0, F); }
-            if (MODE == 1) {
+            if (MODE == 1 || MODE == 3) {
                 // hand the window to the solver of its band class
                 for (int e = lane; e < F; e += 64) S.index[(size_t)w * S.wp + e] = index[e];
                 if (lane <= AR + 1) S.aux[(size_t)w * 56 + lane] = aux[lane];
@@ -1119,6 +1132,52 @@ k_adeclick_fast(const double *__restrict__ in, double *__restrict__ out, int64_t
 #endif
 }
 
+
+// Levinson-Durbin for every window of the file, ONE LANE PER WINDOW (autoregression() of af_adeclick.c; the same operations in the
+// same order as the in-kernel version above: products a[j] * r[i - j] summed j-ascending, one division per step, the coefficient
+// update as a fused multiply-add on the previous step's values).  Order 48 (55 ms windows at 44.1 kHz), fully unrolled: the
+// coefficients and r[] live in registers with static indices.  in: r[w * 64 + 0 .. 48]; out: ac[w * 64 + 0 .. 48] = 1, k_1 .. k_48,
+// zeros up to 62, sigma_e in slot 63.
+__global__ void __launch_bounds__(64, 2)
+k_dk_levinson(const double *__restrict__ rin, double *__restrict__ acout, int64_t nwindows)
+{
+    constexpr int AR = dk::MAXAR;
+    const int64_t w = (int64_t)blockIdx.x * 64 + threadIdx.x;
+    if (w >= nwindows) return;
+    double r[AR + 1], a[AR];
+    const double *rp = rin + (size_t)w * 64;
+#pragma unroll
+    for (int i = 0; i <= AR; ++i) r[i] = rp[i];
+    const double k0 = -r[1] / r[0];
+#pragma unroll
+    for (int j = 0; j < AR; ++j) a[j] = 0.0;
+    a[0] = k0;
+    double alpha = r[0] * (1.0 - k0 * k0);
+#pragma unroll
+    for (int i = 1; i < AR; ++i) {
+        double eps = 0.0;
+#pragma unroll
+        for (int j = 0; j < i; ++j) eps += a[j] * r[i - j];
+        eps += r[i + 1];
+        const double ki = -eps / alpha;
+        alpha = alpha * (1.0 - ki * ki);
+#pragma unroll
+        for (int j = 0; j < (i + 1) / 2; ++j) {
+            const int m = i - 1 - j;
+            const double aj = a[j], am = a[m];
+            a[j] = __fma_rn(ki, am, aj);
+            if (m != j) a[m] = __fma_rn(ki, aj, am);
+        }
+        a[i] = ki;
+    }
+    double *op = acout + (size_t)w * 64;
+    op[0] = 1.0;
+#pragma unroll
+    for (int j = 0; j < AR; ++j) op[j + 1] = a[j];
+#pragma unroll
+    for (int j = AR + 1; j < 63; ++j) op[j] = 0.0;
+    op[63] = sqrt(alpha);
+}
 
 // =====================================================================================================================
 // k_dk_solve -- the solver of the split pipeline: LDL^T of the banded interpolation matrix, forward and back substitution, repaired
@@ -1484,9 +1543,13 @@ void launch_adeclick(jt_ctx *h, const double *in, double *out, int64_t n, int sa
             h->declick_F.ensure((size_t)P.nwindows); h->declick_lists.ensure(2 * (size_t)P.nwindows);
             h->declick_idx.ensure((size_t)P.nwindows * wp); h->declick_rhs.ensure((size_t)P.nwindows * wp);
             h->declick_aux.ensure((size_t)P.nwindows * 56); h->declick_ctl.ensure(8);
+            // (r[] and the AR polynomial share one buffer: 64 doubles each per window)
+            const bool lev_split = P.ar == dk::MAXAR && !getenv("JT_DK_LEVINSON_IN_KERNEL");
+            if (lev_split) h->declick_r.ensure(2 * (size_t)P.nwindows * 64);
             JT_HIP(hipMemsetAsync(h->declick_ctl.p, 0, 8 * sizeof(unsigned long long), s));
             SP.F = h->declick_F.p; SP.index = h->declick_idx.p; SP.rhs = h->declick_rhs.p; SP.aux = h->declick_aux.p;
             SP.list32 = h->declick_lists.p; SP.list64 = h->declick_lists.p + P.nwindows; SP.ctl = h->declick_ctl.p; SP.wp = wp;
+            SP.r = lev_split ? h->declick_r.p : nullptr; SP.ac = lev_split ? h->declick_r.p + (size_t)P.nwindows * 64 : nullptr;
             auto slot_bytes = [&](int G, int BW) {
                 const int idxn = (FCS + BW + 16 + G + 7) & ~7, bwn = (FCS + 16 + 7) & ~7, yn = (FCS + BW + 16 + 7) & ~7;
                 return sizeof(double) * (size_t)(yn + 56 + 4 * G) + 2 * (size_t)idxn + (size_t)bwn;
@@ -1497,7 +1560,16 @@ void launch_adeclick(jt_ctx *h, const double *in, double *out, int64_t n, int sa
             const size_t slot32 = (size_t)FCS * (BW32 + 1), slot64 = (size_t)FCS * (BW64 + 1);
             // the level-1 / level-2 kernels below (windows with more than LIGHT flagged samples) index the same scratch per wave
             h->declick_scr.ensure(std::max(per_wave * (size_t)std::max(f1, f2), slot32 * 2 * (size_t)g32 + slot64 * (size_t)g64));
-            if (half_ok) DKF_LAUNCH((k_adeclick_fast<LIGHT, NC0, ND0, true, 0, 1>), f0, fm0, Q0);
+            if (lev_split) {
+                // autocorrelation (+ the pass-through copy) -> Levinson-Durbin, one lane per window -> detector .. right-hand side; the two
+                // front launches hand their windows out with the same counter, which is reset in between
+                if (half_ok) DKF_LAUNCH((k_adeclick_fast<LIGHT, NC0, ND0, true, 0, 2>), f0, fm0, Q0);
+                else DKF_LAUNCH((k_adeclick_fast<LIGHT, NC0, ND0, false, 0, 2>), f0, fm0, Q0);
+                hipLaunchKernelGGL(k_dk_levinson, dim3((unsigned)((P.nwindows + 63) / 64)), dim3(64), 0, s, SP.r, SP.ac, P.nwindows);
+                JT_HIP(hipMemsetAsync(d_stats + 12, 0, sizeof(unsigned long long), s));
+                if (half_ok) DKF_LAUNCH((k_adeclick_fast<LIGHT, NC0, ND0, true, 0, 3>), f0, fm0, Q0);
+                else DKF_LAUNCH((k_adeclick_fast<LIGHT, NC0, ND0, false, 0, 3>), f0, fm0, Q0);
+            } else if (half_ok) DKF_LAUNCH((k_adeclick_fast<LIGHT, NC0, ND0, true, 0, 1>), f0, fm0, Q0);
             else DKF_LAUNCH((k_adeclick_fast<LIGHT, NC0, ND0, false, 0, 1>), f0, fm0, Q0);
             {
                 auto k32 = k_dk_solve<G32, BW32, FCS>; auto k64 = k_dk_solve<G64, BW64, FCS>;

@@ -147,3 +147,57 @@ def test_pass3_started_inside_pass2_with_the_planned_prefix_equals_the_explicit_
         assert res[0][:10] == res[1][:10], f"seed {seed}: the early start changed a result"
         if plosives:
             assert res[1][10] < res[0][10]                       # and Pass 3 itself only collects
+
+
+def _parse_chain(spec):
+    out = []
+    for f in spec.split(","):
+        name, _, args = f.partition("=")
+        kv = {}
+        for a in args.split(":") if args else []:
+            k, _, v = a.partition("=")
+            kv[k] = v
+        out.append((name, kv))
+    return out
+
+
+def _close(a, b, rel=2e-3, abs_=2e-4):
+    try:
+        fa, fb = float(a), float(b)
+    except ValueError:
+        return a == b
+    return abs(fa - fb) <= max(abs_, rel * max(abs(fa), abs(fb)))
+
+
+@pytest.mark.parametrize("sr,seed,seconds", [(48000, 21, 45.0), (48000, 71, 60.0), (44100, 72, 40.0)])
+def test_decision_chain_on_gpu_pass1_equals_the_chain_on_oracle_pass1(engine, oracle, sr, seed, seconds):
+    """the end-to-end tests handed the GPU run's OWN effective parameters to the oracle chain, which pins the
+    kernels but not the decisions.  Here the reference's decision chain (interval builder -> VAD / elections -> band graphs ->
+    AdaptConfig -> chain string) runs twice: on the Pass-1 measurements of the HIP path (jt_analyse_only) and on the same measurements
+    taken by the CPU oracle (tests/oracle_pass1.py).  Elections land on the same 250 ms intervals, every filter is switched the same
+    way, and every printed parameter agrees to the measurement tolerances (2e-3 relative: aspectralstats' f32 FFT; bn to 0.1 dB)."""
+    import oracle_pass1 as P
+    x = synth.speech_like(seconds, sr, seed=seed)
+    engine.upload_pcm(x, sr, 1)
+    g = H.process_audio(engine, analyse_only=True)
+    m, eff, spec = P.decide(oracle, x, sr)
+    gm = g.input
+    # elections and switches: exact
+    assert (gm.has_speech_profile, gm.has_noise_profile, gm.voice_activated, gm.floor_source, gm.n_candidates, gm.n_speech_regions) == \
+           (m.has_speech_profile, m.has_noise_profile, m.voice_activated, m.floor_source, m.n_candidates, m.n_speech_regions)
+    if m.has_speech_profile:
+        assert (gm.speech_profile.region.start_ns, gm.speech_profile.region.duration_ns) == (m.speech_profile.region.start_ns, m.speech_profile.region.duration_ns)
+    if m.has_noise_profile:
+        assert (gm.noise_profile.start_ns, gm.noise_profile.duration_ns) == (m.noise_profile.start_ns, m.noise_profile.duration_ns)
+    assert abs(gm.input_i - m.input_i) <= 0.002 and abs(gm.floor - m.floor) <= 1e-3 and abs(gm.vad_split - m.vad_split) <= 1e-9
+    # the chain string: same filters in the same order, same switches, parameters to tolerance
+    cg, co = _parse_chain(H.filter_spec(g.effective, 2)), _parse_chain(spec)
+    assert [f[0] for f in cg] == [f[0] for f in co]
+    for (name, a), (_, b) in zip(cg, co):
+        assert a.keys() == b.keys(), name
+        for k in a:
+            if name == "afftdn" and k == "bn":
+                va, vb = [float(v) for v in a[k].split("|")], [float(v) for v in b[k].split("|")]
+                assert len(va) == len(vb) and max(abs(p - q) for p, q in zip(va, vb)) <= 0.1001, (a[k], b[k])
+            else:
+                assert _close(a[k], b[k]), (name, k, a[k], b[k])
