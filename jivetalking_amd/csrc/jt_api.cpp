@@ -46,7 +46,10 @@ extern "C" int jt_open(int device_id, jt_ctx **out)
         JT_HIP(hipEventCreateWithFlags(&h->spec_ln.fork, hipEventDisableTiming));
         // the chains of announced output regions (aux[4..7]) are small: they run behind the full analysis on its four streams
         for (int i = 0; i < 8; ++i) {
-            if (i < 4) JT_HIP(hipStreamCreateWithFlags(&h->aux[i], hipStreamNonBlocking));
+            // aux[3] carries the true-peak upsampler, the longest analysis kernel and (with the K-weighting) what Pass 2's limiter plan
+            // waits for: highest priority, so that it is not the one left waiting for CU slots
+            if (i == 3 && !getenv("JT_NO_TP_PRIORITY")) JT_HIP(hipStreamCreateWithPriority(&h->aux[i], hipStreamNonBlocking, prio_greatest));
+            else if (i < 4) JT_HIP(hipStreamCreateWithFlags(&h->aux[i], hipStreamNonBlocking));
             else h->aux[i] = h->aux[i - 4];
             JT_HIP(hipEventCreateWithFlags(&h->ev_join[i], hipEventDisableTiming));
         }
@@ -248,6 +251,12 @@ static void analysis_enqueue(jt_ctx *h, const float *x, int64_t n, int sr, bool 
     const int f = ln ? ln->first : 0;
     hipStream_t a0 = h->aux[f], a1 = h->aux[f + 1], a2 = h->aux[f + 2], a3 = h->aux[f + 3];
     fork_aux(h, f, f + 3, ln ? ln->from : nullptr);
+    // K-weighting goes FIRST on its stream (ahead of the noise-floor chain it shares it with): with the true peak it is what the limiter
+    // plan of Pass 2 waits for (jt_pass3_plan_hook); the chain's total is the same either way
+    if (J->want_r128) {
+        jt_kweight_enqueue_f32(h, x, n, sr, sr / 10, &J->kw, a1);
+        if (h->early_p3.mark_kw) { JT_HIP(hipEventRecord(h->early_p3.ev[0], a1)); h->early_p3.mark_kw = false; }
+    }
     if (J->want_astats) jt_astats_enqueue(h, x, n, sr, &J->as, a0, a1, a2, ln ? ln->ehist : nullptr);
     if (J->want_r128) {
         const int blk = sr / 10; const int64_t nfull = n / blk;
@@ -260,8 +269,6 @@ static void analysis_enqueue(jt_ctx *h, const float *x, int64_t n, int sr, bool 
         double *btp = h->pin.take<double>((size_t)nfull + 2);
         JT_HIP(hipMemcpyAsync(btp, d_tp, sizeof(double) * (nfull + 2), hipMemcpyDeviceToHost, a3));
         J->btp = btp;
-        // K-weighting rides behind the (short) noise-floor chain instead of behind the true-peak upsampler, the longest kernel
-        jt_kweight_enqueue_f32(h, x, n, sr, blk, &J->kw, a1);
     }
     if (J->want_spec) {
         const int win = 2048, hop = win / 2;
@@ -823,7 +830,16 @@ extern "C" int jt_pass2(jt_ctx *h, const jt_filter_params *p, jt_analysis *out)
     }
     check_cancel(h);
     AnalysisJob J;
+    const bool plan_early = plan_hook && out_rate != 192000;
+    if (plan_early) {
+        // what the limiter plan waits for: the K-weighting job (first on aux[1]: analysis_enqueue marks its end) and the true peak
+        // (aux[3], marked below before the region chains queue up behind it on the same stream)
+        auto &E = h->early_p3;
+        if (!E.ev[0]) { JT_HIP(hipEventCreateWithFlags(&E.ev[0], hipEventDisableTiming)); JT_HIP(hipEventCreateWithFlags(&E.ev[1], hipEventDisableTiming)); }
+        E.mark_kw = true;
+    }
     analysis_enqueue(h, cur, n, sr, true, sr / 10, &J, false);
+    if (plan_early) JT_HIP(hipEventRecord(h->early_p3.ev[1], h->aux[3]));
     // announced output regions: their samples are resampled separately (the same tap sums as the full output's) on the second
     // stream set, so that their analysis runs beside the output stage instead of after it
     RegionJobs RJ;
@@ -851,7 +867,6 @@ extern "C" int jt_pass2(jt_ctx *h, const jt_filter_params *p, jt_analysis *out)
         regions = regions_resolve(slot.start_s, slot.dur_s, out_rate, h->m_p2, &RJ);
         if (regions) regions_enqueue(h, h->s16_p2.p, out_rate, &RJ, true);
     }
-    const bool plan_early = plan_hook && J.want_r128 && out_rate != 192000;
     // Pass 3's measurement for the plan without a prefix, on its own stream (not joined): a guess when nobody can tell us the plan;
     // with a planner it is queued below, once the plan says so (a file that needs the prefix then does not pay 3 ms of GPU work for it)
     if (!plan_early) spec_loudnorm_enqueue(h, h->s16_p2.p, h->m_p2, out_rate);
@@ -860,8 +875,6 @@ extern "C" int jt_pass2(jt_ctx *h, const jt_filter_params *p, jt_analysis *out)
         // aux[3]): wait for those two chains only, ask the planner, and queue the prefix measurement while astats / aspectralstats / the
         // regions are still running.  The values are the ones analysis_complete() will report below (same arithmetic, same inputs).
         auto &E = h->early_p3;
-        if (!E.ev[0]) { JT_HIP(hipEventCreateWithFlags(&E.ev[0], hipEventDisableTiming)); JT_HIP(hipEventCreateWithFlags(&E.ev[1], hipEventDisableTiming)); }
-        JT_HIP(hipEventRecord(E.ev[0], h->aux[1])); JT_HIP(hipEventRecord(E.ev[1], h->aux[3]));
         JT_HIP(hipEventSynchronize(E.ev[0])); JT_HIP(hipEventSynchronize(E.ev[1]));
         check_cancel(h);
         std::vector<double> bsum, bpk;

@@ -313,7 +313,7 @@ struct jt_ctx {
     hipStream_t dk_stream = nullptr; hipEvent_t dk_ev[2] = {nullptr, nullptr};
     // Pass 3 with the limiter prefix, started inside Pass 2 once its loudness / true peak are known (jt_pass3_plan_hook)
     struct EarlyPass3 {
-        jt_plan_fn fn = nullptr; void *user = nullptr; bool armed = false;
+        jt_plan_fn fn = nullptr; void *user = nullptr; bool armed = false, mark_kw = false;
         bool valid = false; jt_limiter_plan plan{}; KwJob kw; int64_t nfull = 0; int blk = 0;
         DevBuf<double> dev; double *pin = nullptr; size_t pin_cap = 0; hipEvent_t ev[2] = {nullptr, nullptr};
     } early_p3;      // the wide-band solver's stream (created on first use)
