@@ -46,10 +46,7 @@ extern "C" int jt_open(int device_id, jt_ctx **out)
         JT_HIP(hipEventCreateWithFlags(&h->spec_ln.fork, hipEventDisableTiming));
         // the chains of announced output regions (aux[4..7]) are small: they run behind the full analysis on its four streams
         for (int i = 0; i < 8; ++i) {
-            // aux[3] carries the true-peak upsampler, the longest analysis kernel and (with the K-weighting) what Pass 2's limiter plan
-            // waits for: highest priority, so that it is not the one left waiting for CU slots
-            if (i == 3 && !getenv("JT_NO_TP_PRIORITY")) JT_HIP(hipStreamCreateWithPriority(&h->aux[i], hipStreamNonBlocking, prio_greatest));
-            else if (i < 4) JT_HIP(hipStreamCreateWithFlags(&h->aux[i], hipStreamNonBlocking));
+            if (i < 4) JT_HIP(hipStreamCreateWithFlags(&h->aux[i], hipStreamNonBlocking));
             else h->aux[i] = h->aux[i - 4];
             JT_HIP(hipEventCreateWithFlags(&h->ev_join[i], hipEventDisableTiming));
         }

@@ -89,10 +89,12 @@ def decide(orc, x, sr, base=None, frame_samples=4096):
         for i in range(15):
             lo, hi = C.c_double(), C.c_double()
             l.jt_host_afftdn_band_edges(C.c_int(i), C.byref(lo), C.byref(hi))
-            ok = hi.value < sr / 2
-            v = band(m.noise_profile.start_ns, m.noise_profile.duration_ns, lo.value, hi.value) if ok else float("nan")
-            m.noise_profile.band_noise[i] = q(v) if ok and np.isfinite(v) else 0.0
-            fin += 1 if ok and np.isfinite(v) else 0
+            # a corner at or above Nyquist (the 24 kHz band of a 48 kHz file): astats reports a non-finite RMS "as a matter of
+            # course" (analyser_noise_bands.go:97-103) and the value is stored as it is
+            below = hi.value < sr / 2 and lo.value < sr / 2
+            v = band(m.noise_profile.start_ns, m.noise_profile.duration_ns, lo.value, hi.value) if below else float("nan")
+            m.noise_profile.band_noise[i] = q(v) if np.isfinite(v) else v
+            fin += 1 if np.isfinite(v) else 0
         m.noise_profile.band_noise_n = 15
         m.noise_profile.bands_measured = 1 if fin >= 10 else 0
     l.jt_host_finish_measurements(C.byref(m))
