@@ -250,11 +250,11 @@ static void analysis_enqueue(jt_ctx *h, const float *x, int64_t n, int sr, bool 
     fork_aux(h, f, f + 3, ln ? ln->from : nullptr);
     // K-weighting goes FIRST on its stream (ahead of the noise-floor chain it shares it with): with the true peak it is what the limiter
     // plan of Pass 2 waits for (jt_pass3_plan_hook); the chain's total is the same either way
+    const bool r128_first = h->early_p3.mark_kw && J->want_r128;
     if (J->want_r128) {
         jt_kweight_enqueue_f32(h, x, n, sr, sr / 10, &J->kw, a1);
         if (h->early_p3.mark_kw) { JT_HIP(hipEventRecord(h->early_p3.ev[0], a1)); h->early_p3.mark_kw = false; }
     }
-    if (J->want_astats) jt_astats_enqueue(h, x, n, sr, &J->as, a0, a1, a2, ln ? ln->ehist : nullptr);
     if (J->want_r128) {
         const int blk = sr / 10; const int64_t nfull = n / blk;
         J->blk = blk; J->nfull = nfull;
@@ -266,7 +266,15 @@ static void analysis_enqueue(jt_ctx *h, const float *x, int64_t n, int sr, bool 
         double *btp = h->pin.take<double>((size_t)nfull + 2);
         JT_HIP(hipMemcpyAsync(btp, d_tp, sizeof(double) * (nfull + 2), hipMemcpyDeviceToHost, a3));
         J->btp = btp;
+        if (r128_first && !getenv("JT_NO_R128_FIRST")) {
+            // a planner waits for the true peak: the statistics nobody waits for (astats chains, spectral) start behind the upsampler
+            // instead of sharing the CUs with it (3.6 ms beside them, 1-1.5 ms without), and then run beside Pass 3's prefix chain
+            JT_HIP(hipEventRecord(h->early_p3.ev[1], a3));
+            JT_HIP(hipStreamWaitEvent(a0, h->early_p3.ev[1], 0)); JT_HIP(hipStreamWaitEvent(a1, h->early_p3.ev[1], 0));
+            JT_HIP(hipStreamWaitEvent(a2, h->early_p3.ev[1], 0));
+        }
     }
+    if (J->want_astats) jt_astats_enqueue(h, x, n, sr, &J->as, a0, a1, a2, ln ? ln->ehist : nullptr);
     if (J->want_spec) {
         const int win = 2048, hop = win / 2;
         const int64_t nhops = (n + hop - 1) / hop;
