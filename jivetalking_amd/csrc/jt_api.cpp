@@ -894,10 +894,21 @@ extern "C" int jt_pass2(jt_ctx *h, const jt_filter_params *p, jt_analysis *out)
     analysis_join(h, regions ? 2 : 1);
     h->out_rate = out_rate; h->m_p4 = 0;
     JT_HIP(hipEventRecord(h->ev1, h->stream));
-    JT_HIP(hipEventSynchronize(h->ev1));
-    check_cancel(h);
-    analysis_complete(h, J, out, nullptr, 0);
-    if (regions) { regions_finish(h, out_rate, RJ, slot.out); slot.valid = true; }
+    if (h->early_p3.valid) {
+        // the main stream still carries Pass 3's prefix chain (several ms): the analysis chains end long before it, so their host
+        // arithmetic (gating, merges, the per-frame assembly) runs while the GPU works instead of after it
+        for (int i = 0; i < 4 * (regions ? 2 : 1); ++i) JT_HIP(hipEventSynchronize(h->ev_join[i]));
+        check_cancel(h);
+        analysis_complete(h, J, out, nullptr, 0);
+        if (regions) { regions_finish(h, out_rate, RJ, slot.out); slot.valid = true; }
+        JT_HIP(hipEventSynchronize(h->ev1));
+        check_cancel(h);
+    } else {
+        JT_HIP(hipEventSynchronize(h->ev1));
+        check_cancel(h);
+        analysis_complete(h, J, out, nullptr, 0);
+        if (regions) { regions_finish(h, out_rate, RJ, slot.out); slot.valid = true; }
+    }
     out->n_input_frames = 0;
     float ms = 0; JT_HIP(hipEventElapsedTime(&ms, h->ev0, h->ev1)); h->timers.pass2_ms = ms;
     if (nlm_timed) { JT_HIP(hipEventElapsedTime(&ms, h->ev2, h->ev3)); h->timers.nlm_ms = ms; h->timers.nlm_launches = 1; }
