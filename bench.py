@@ -448,10 +448,25 @@ def main():
             out["no_limiter_prefix" if args.plosives > 0 else "limiter_prefix"] = variant_leg(
                 eng, y, x, n, sr, seconds, base, hostlogic,
                 "the same talker without the plosive bursts (the round-1/2 bench voice)" if args.plosives > 0 else "the talker with 40 plosive bursts a minute")
-            y = synth.speech_like_torch(seconds, sr, seed=1000 + rank, device=dev_s, plosives_per_min=args.plosives, sib_gain=4.0)
+            y = synth.speech_like_torch(seconds, sr, seed=1000 + rank, device=dev_s, plosives_per_min=args.plosives, sib_gain=1.4, sib_band=True)
             out["deesser_on"] = variant_leg(eng, y, x, n, sr, seconds, base, hostlogic,
-                                            "the same talker with sibilants 24 dB stronger (6-9 kHz band near the body band): AdaptConfig switches the de-esser on")
+                                            "the same talker with its sibilants concentrated in 6.75-8.25 kHz and 15 dB stronger (6-9 kHz band 4 dB under the "
+                                            "1-3 kHz body band): AdaptConfig switches the de-esser on")
             del y
+            # the one slow path: a file loudnorm cannot serve in linear mode (here: hiss so loud that the projected true peak passes the
+            # ceiling) goes through af_loudnorm's dynamic mode at 192 kHz, a sequential state machine (k_loudnorm.hip); ten minutes of it
+            nd = int(600 * sr)
+            yd = synth.speech_like_torch(600.0, sr, seed=1000 + rank, device=dev_s, plosives_per_min=args.plosives, sib_gain=4.0)
+            torch.cuda.synchronize()
+            eng.attach_device_pcm(yd.data_ptr(), nd, sr, 1, keepalive=yd)
+            td = []
+            for it in range(2):
+                t0 = time.perf_counter(); rd = hostlogic.process_audio(eng, base, 4096); td.append(time.perf_counter() - t0)
+            eng.attach_device_pcm(x.data_ptr(), n, sr, 1, keepalive=x)
+            out["dynamic_fallback"] = {"what": "10 min of the talker with broadband hiss bursts 24 dB up: loudnorm's linear mode is not possible, Pass 4 runs the dynamic "
+                                               "mode (normalise.go:687-693 only warns about it)", "ms_per_file": round(min(td) * 1e3, 1), "xRT": round(600.0 / min(td), 1),
+                                       "dynamic": int(rd.loudnorm.normalization_type_dynamic), "output_lufs": round(rd.output_lufs, 2), "output_dbtp": round(rd.output_tp_db, 2)}
+            del yd
         if world == 1 and args.saturation and args.channels == 1:
             out["saturation"] = saturation_leg(eng, local_rank, base, hostlogic, synth, sr, args.sat_files, args.sat_minutes, args.sat_in_flight)
         if world == 1 and args.cpu_sample > 0:

@@ -104,15 +104,16 @@ def speech_like(duration_s, sample_rate=48000, seed=0, speech_dbfs=-30.0, room_d
 
 
 def speech_like_torch(duration_s, sample_rate=48000, seed=0, device="cuda", speech_dbfs=-30.0, room_dbfs=-62.0,
-                      plosives_per_min=0.0, sib_gain=0.25):
+                      plosives_per_min=0.0, sib_gain=0.25, sib_band=False):
     """Speech-shaped f32 mono signal generated directly on the GPU (torch is plumbing for device memory only).
 
     Harmonic synthesis instead of recursive resonators (recursions do not vectorise): voiced phrases = sum of
     F0 harmonics weighted by a three-formant envelope, syllable AM, sibilant noise bursts, low-passed room tone.
     `plosives_per_min` > 0 adds that many 20 ms plosive-like bursts a minute inside the phrases (peaks ~-9 dBFS over a -30 dBFS voice:
     the ~20 dB crest factor of a real close-miked talker, which makes the loudnorm plan need the limiter prefix, normalise.go:452-497);
-    `sib_gain` scales the sibilant bursts (0.25 = the default voice; ~4 puts the 6-9 kHz band within 6 dB of the body band, which
-    is what makes AdaptConfig switch the de-esser on, adaptive_deesser.go:45)."""
+    `sib_gain` scales the sibilant bursts (0.25 = the default voice); `sib_band` concentrates them in 6.75-8.25 kHz (smoothed noise on a
+    7.5 kHz carrier instead of differenced white noise): with sib_gain ~0.5 the 6-9 kHz band then sits within 6 dB of the 1-3 kHz body
+    band, which is what makes AdaptConfig switch the de-esser on (adaptive_deesser.go:45)."""
     import torch
     g = torch.Generator(device=device).manual_seed(int(seed))
     sr = sample_rate
@@ -148,7 +149,11 @@ def speech_like_torch(duration_s, sample_rate=48000, seed=0, device="cuda", spee
     syl = 0.55 + 0.45 * torch.sin(2 * np.pi * (4.2 + 0.8 * torch.sin(2 * np.pi * 0.11 * t)) * t)
     v = v * torch.clamp(syl, min=0).float()
     nz = torch.randn(n, device=device, dtype=torch.float32, generator=g)
-    hp = nz - torch.roll(nz, 1)                   # crude high-pass -> sibilant-band emphasis
+    if sib_band:
+        lp = torch.nn.functional.avg_pool1d(nz[None, None, :], 32, stride=1, padding=16)[0, 0, :n]      # ~750 Hz of noise bandwidth
+        hp = lp * torch.cos(2 * np.pi * 7500.0 * t).float()
+    else:
+        hp = nz - torch.roll(nz, 1)               # crude high-pass -> sibilant-band emphasis
     sib_env = (torch.sin(2 * np.pi * 1.3 * t + 1.0) > 0.93).float()
     speech = (v / (v.std() + 1e-12) + float(sib_gain) * hp / (hp.std() + 1e-12) * sib_env) * gate_s
     act = gate_s > 0.5
