@@ -269,7 +269,7 @@ static void analysis_enqueue(jt_ctx *h, const float *x, int64_t n, int sr, bool 
         JT_HIP(hipMemsetAsync(d_tp, 0, sizeof(double) * (nfull + 2), a3));
         // (the regions' analyses run behind the full one on the same stream: a scratch pair each keeps their sizes apart)
         const int tps = ln ? 1 : 0;
-        h->tp_grp[tps].ensure((size_t)((n + sw.pl.center + 64) / 16 + 4)); h->tp_lb[tps].ensure((size_t)nfull + 4);
+        h->tp_grp[tps].ensure(2 * (size_t)((n + sw.pl.center + 64) / 16 + 2) + 8); h->tp_lb[tps].ensure((size_t)nfull + 4);
         launch_true_peak_f32(x, n, sw.bank_d.p, sw.pl.phase_count, sw.pl.filter_length, sw.pl.center, sw.pl.step, blk, d_tp, nfull + 1,
                              sw.out_len(n), a3, sw.bank_f.p, sw.tap_l1, h->tp_grp[tps].p, h->tp_lb[tps].p);
         double *btp = h->pin.take<double>((size_t)nfull + 2);

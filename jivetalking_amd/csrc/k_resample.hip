@@ -398,6 +398,7 @@ k_upsample32(const TIn *__restrict__ in, int64_t n, const TTap *__restrict__ ban
             const unsigned brem = (unsigned)(base0 - bq * blk);
             const bool smallq = (unsigned)(T + L) < 2u * (unsigned)blk;
             int sl[QL]; TAcc vm[QL];
+            int ubv[QL];
             TAcc errw = (TAcc)0;
             if (SCREEN) {
                 TAcc xm = (TAcc)0;
@@ -419,8 +420,20 @@ k_upsample32(const TIn *__restrict__ in, int64_t n, const TTap *__restrict__ ban
                     const bool valid = last >= 0 && last <= n - 1;
                     // upper bound of the group of 16 window positions this window starts in (tile-relative index; positive floats
                     // order like their bit patterns), lower bound towards the block
-                    if (valid) atomicMax(&ubl[(si + u * step) >> 4], __float_as_int((float)((vmax[u] + errw) * (TAcc)1.000001)));
+                    ubv[u] = valid ? __float_as_int((float)((vmax[u] + errw) * (TAcc)1.000001)) : 0;
                     vm[u] = valid ? (TAcc)fmax((vmax[u] - errw) * (TAcc)0.999999, (TAcc)0) : (TAcc)0;
+                }
+            }
+            if (SCREEN) {
+                if (QL == 4 && step == 1) {
+                    // si = 4 * (window index): the lane's four windows and those of the three other lanes of its quad start in the same
+                    // group of 16: one LDS atomic per quad instead of sixteen on one address
+                    int m = max(max(ubv[0], ubv[1]), max(ubv[QL > 2 ? 2 : 0], ubv[QL > 3 ? 3 : 0]));
+                    m = max(m, __shfl_xor(m, 1, 64)); m = max(m, __shfl_xor(m, 2, 64));
+                    if ((lane & 3) == 0 && m) atomicMax(&ubl[si >> 4], m);
+                } else {
+#pragma unroll
+                    for (int u = 0; u < QL; ++u) if (ubv[u]) atomicMax(&ubl[(si + u * step) >> 4], ubv[u]);
                 }
             }
             const int sl_lo = __builtin_amdgcn_readfirstlane(sl[0]), sl_hi = __builtin_amdgcn_readlane(sl[QL - 1], 63);
@@ -457,50 +470,68 @@ k_upsample32(const TIn *__restrict__ in, int64_t n, const TTap *__restrict__ ban
     }
 }
 
-// The f64 pass of the screened true peak: one thread per group of 16 window positions (k = w0 + center, w0 = first input sample of the
-// window).  A group whose upper bound is below the lower bound of the block(s) its windows report to cannot hold a block maximum and
-// leaves at once; the others evaluate their windows exactly as k_upsample32<float, double, double, 0> does (window k: outputs
-// m = P (k / step) + j for the phases j of offset k % step, taps ascending, one fused multiply-add per tap, attributed to the 100 ms
-// block of the window's last input sample, reflected before the stream, zero behind it).
+// The f64 pass of the screened true peak, in two launches.  k_tp_candidates: one thread per group of 16 window positions (k = w0 + center,
+// w0 = first input sample of the window); a group whose upper bound is below the lower bound of the block(s) its windows report to cannot
+// hold a block maximum; the others -- one to three per 100 ms block -- are appended to a list.  k_tp_refine: one wave per listed group,
+// lane = (window, phase): each lane evaluates one output exactly as k_upsample32<float, double, double, 0> does (window k: outputs
+// m = P (k / step) + j for the phases j of offset k % step, taps ascending, one fused multiply-add per tap, attributed to the 100 ms block
+// of the window's last input sample, reflected before the stream, zero behind it).
 __global__ void __launch_bounds__(256)
-k_tp_refine(const float *__restrict__ in, int64_t n, const double *__restrict__ bank, int P, int center, int step, int64_t m_total, int blk,
-            const int *__restrict__ ubgrp, int64_t ngrp, const unsigned long long *__restrict__ lb, unsigned long long *__restrict__ block_tp,
-            int64_t nblocks_alloc)
+k_tp_candidates(int64_t n, int center, int blk, const int *__restrict__ ubgrp, int64_t ngrp, const unsigned long long *__restrict__ lb,
+                int64_t nblocks_alloc, int *__restrict__ list, unsigned *__restrict__ count, unsigned cap)
 {
     const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= ngrp) return;
     const int ubits = ubgrp[g];
     if (ubits <= 0) return;
     const double ub = (double)__int_as_float(ubits);
-    auto block_of = [&](int64_t last) -> int64_t { int64_t b = last / blk; return b >= nblocks_alloc ? nblocks_alloc - 1 : b; };
-    {
-        const int64_t la = 16 * g - center + 31, lz = la + 15;
-        if (lz < 0 || la > n - 1) return;
-        const double l0 = __longlong_as_double((long long)lb[block_of(la < 0 ? 0 : la)]), l1 = __longlong_as_double((long long)lb[block_of(lz > n - 1 ? n - 1 : lz)]);
-        if (ub < fmin(l0, l1)) return;
-    }
-    for (int w = 0; w < 16; ++w) {
+    const int64_t la = 16 * g - center + 31, lz = la + 15;
+    if (lz < 0 || la > n - 1) return;
+    int64_t b0 = (la < 0 ? 0 : la) / blk, b1 = (lz > n - 1 ? n - 1 : lz) / blk;
+    b0 = b0 >= nblocks_alloc ? nblocks_alloc - 1 : b0; b1 = b1 >= nblocks_alloc ? nblocks_alloc - 1 : b1;
+    if (ub < fmin(__longlong_as_double((long long)lb[b0]), __longlong_as_double((long long)lb[b1]))) return;
+    const unsigned slot = atomicAdd(count, 1u);
+    if (slot < cap) list[slot] = (int)g;                     // (cap = every group: the list cannot overflow)
+}
+
+__global__ void __launch_bounds__(64)
+k_tp_refine(const float *__restrict__ in, int64_t n, const double *__restrict__ bank, int P, int center, int step, int64_t m_total, int blk,
+            const int *__restrict__ ubgrp, const unsigned long long *__restrict__ lb, unsigned long long *__restrict__ block_tp,
+            int64_t nblocks_alloc, const int *__restrict__ list, const unsigned *__restrict__ count)
+{
+    const int lane = threadIdx.x;
+    const unsigned total = *count;
+    const unsigned uP = (unsigned)P, ustep = (unsigned)step;
+    for (unsigned e = blockIdx.x; e < total; e += gridDim.x) {
+        const int64_t g = list[e];
+        const double ub = (double)__int_as_float(ubgrp[g]);
+        // lane = 4 * window + phase slot; a window has at most ceil(P / step) phases (4 or 5 here): slots beyond four take a second round
+        const int w = lane >> 2;
         const int64_t k = 16 * g + w, w0 = k - center, last = w0 + 31;
-        if (last < 0 || last > n - 1) continue;
-        const int64_t b = block_of(last);
-        if (ub < __longlong_as_double((long long)lb[b])) continue;
-        double x[32];
-#pragma unroll
-        for (int i = 0; i < 32; ++i) { int64_t q = w0 + i; if (q < 0) q = -q; x[i] = q < n ? (double)in[q] : 0.0; }
-        const unsigned off = (unsigned)(k % step), uP = (unsigned)P, ustep = (unsigned)step;
+        const bool inside = last >= 0 && last <= n - 1;
+        int64_t b = (inside ? last : 0) / blk; b = b >= nblocks_alloc ? nblocks_alloc - 1 : b;
+        const bool want = inside && !(ub < __longlong_as_double((long long)lb[b]));
+        const unsigned off = (unsigned)(k % step);
         const int64_t q = k / step;
         const int j_lo = (int)((off * uP + ustep - 1u) / ustep);
         int j_hi = (int)(((off + 1u) * uP + ustep - 1u) / ustep); j_hi = j_hi < P ? j_hi : P;
         double vmax = 0.0;
-        for (int j = j_lo; j < j_hi; ++j) {
-            if ((int64_t)P * q + j >= m_total) break;
-            const double *f = bank + (size_t)(((unsigned)j * ustep) % uP) * 32;
-            double val = 0.0;
+        if (want) {
+            double x[32];
 #pragma unroll
-            for (int i = 0; i < 32; ++i) val = fma(x[i], f[i], val);
-            vmax = fmax(vmax, fabs(val));
+            for (int i = 0; i < 32; ++i) { int64_t qi = w0 + i; if (qi < 0) qi = -qi; x[i] = qi < n ? (double)in[qi] : 0.0; }
+            for (int j = j_lo + (lane & 3); j < j_hi; j += 4) {
+                if ((int64_t)P * q + j >= m_total) break;
+                const double *f = bank + (size_t)(((unsigned)j * ustep) % uP) * 32;
+                double val = 0.0;
+#pragma unroll
+                for (int i = 0; i < 32; ++i) val = fma(x[i], f[i], val);
+                vmax = fmax(vmax, fabs(val));
+            }
         }
-        if (vmax > 0.0) atomicMax(&block_tp[b], (unsigned long long)__double_as_longlong(vmax));
+        // the four lanes of a window, then one atomic per window
+        vmax = fmax(vmax, __shfl_xor(vmax, 1, 64)); vmax = fmax(vmax, __shfl_xor(vmax, 2, 64));
+        if ((lane & 3) == 0 && vmax > 0.0) atomicMax(&block_tp[b], (unsigned long long)__double_as_longlong(vmax));
     }
 }
 
@@ -688,13 +719,17 @@ void launch_true_peak_f32(const float *in, int64_t n, const double *bank, int ph
     // tests/test_gpu_round3.py; JT_TP_F64=1 runs the f64 sweep over everything).  The tile of the f32 instance must fit ubl[]: 16 * 704 positions.
     if (bank_f && scr_grp && scr_lb && filter_length == 32 && step < phase_count && step <= 147 && !getenv("JT_TP_F64")) {
         const int64_t ngrp = (n + center + 64) / 16 + 2;
-        JT_HIP(hipMemsetAsync(scr_grp, 0, sizeof(int) * (size_t)ngrp, s));
+        JT_HIP(hipMemsetAsync(scr_grp, 0, sizeof(int) * (size_t)(ngrp + 4), s));
         JT_HIP(hipMemsetAsync(scr_lb, 0, sizeof(double) * (size_t)nblocks_alloc, s));
         const float err_k = (float)(2.5e-6 * tap_l1);
         if (launch_upsample32<float, float, float, 0>(in, n, bank_f, phase_count, filter_length, center, step, m_total, 1.0, blk, scr_lb,
                                                        nblocks_alloc, (float *)nullptr, s, scr_grp, err_k)) {
-            hipLaunchKernelGGL(k_tp_refine, dim3((unsigned)((ngrp + 255) / 256)), dim3(256), 0, s, in, n, bank, phase_count, center, (int)step, m_total,
-                               blk, scr_grp, ngrp, (const unsigned long long *)scr_lb, (unsigned long long *)block_tp, nblocks_alloc);
+            // candidate list and its counter live behind the group bounds (scr_grp has room for 2 * ngrp + 4 ints)
+            int *list = scr_grp + ngrp + 4; unsigned *count = (unsigned *)(scr_grp + ngrp);
+            hipLaunchKernelGGL(k_tp_candidates, dim3((unsigned)((ngrp + 255) / 256)), dim3(256), 0, s, n, center, blk, scr_grp, ngrp,
+                               (const unsigned long long *)scr_lb, nblocks_alloc, list, count, (unsigned)ngrp);
+            hipLaunchKernelGGL(k_tp_refine, dim3(8192), dim3(64), 0, s, in, n, bank, phase_count, center, (int)step, m_total, blk, scr_grp,
+                               (const unsigned long long *)scr_lb, (unsigned long long *)block_tp, nblocks_alloc, list, count);
             return;
         }
     }
