@@ -192,12 +192,6 @@ static SwrDev &get_swr(jt_ctx *h, int in_rate, int out_rate)
     e.bank_fs.release();
     if (exact) { e.bank_fs.ensure(bs.size()); JT_HIP(hipMemcpyAsync(e.bank_fs.p, bs.data(), sizeof(float) * bs.size(), hipMemcpyHostToDevice, h->stream)); }
     JT_HIP(hipStreamSynchronize(h->stream));
-    e.tap_l1 = 0.0;
-    for (int ph = 0; ph < e.pl.phase_count; ++ph) {
-        double a = 0.0;
-        for (int i = 0; i < e.pl.filter_length; ++i) a += std::fabs(e.pl.bank[(size_t)ph * e.pl.filter_length + i]);
-        e.tap_l1 = std::max(e.tap_l1, a);
-    }
     e.in_rate = in_rate; e.out_rate = out_rate;
     return e;
 }
@@ -267,11 +261,8 @@ static void analysis_enqueue(jt_ctx *h, const float *x, int64_t n, int sr, bool 
         SwrDev &sw = get_swr(h, sr, 192000);
         double *d_tp = ln && ln->tp ? ln->tp : (h->d_scr1.ensure((size_t)nfull + 2), h->d_scr1.p);
         JT_HIP(hipMemsetAsync(d_tp, 0, sizeof(double) * (nfull + 2), a3));
-        // (the regions' analyses run behind the full one on the same stream: a scratch pair each keeps their sizes apart)
-        const int tps = ln ? 1 : 0;
-        h->tp_grp[tps].ensure(2 * (size_t)((n + sw.pl.center + 64) / 16 + 2) + 8); h->tp_lb[tps].ensure((size_t)nfull + 4);
         launch_true_peak_f32(x, n, sw.bank_d.p, sw.pl.phase_count, sw.pl.filter_length, sw.pl.center, sw.pl.step, blk, d_tp, nfull + 1,
-                             sw.out_len(n), a3, sw.bank_f.p, sw.tap_l1, h->tp_grp[tps].p, h->tp_lb[tps].p);
+                             sw.out_len(n), a3);
         double *btp = h->pin.take<double>((size_t)nfull + 2);
         JT_HIP(hipMemcpyAsync(btp, d_tp, sizeof(double) * (nfull + 2), hipMemcpyDeviceToHost, a3));
         J->btp = btp;

@@ -106,8 +106,7 @@ int64_t launch_resample_range_to_s16(const float *in, int64_t n, const double *b
                                      int64_t step, int64_t m, int64_t m_first, int64_t m_count, int16_t *dst, int64_t dst_cap, hipStream_t s);
 int64_t jt_resample_range_cap(int64_t n, int phase_count, int filter_length, int64_t step, int64_t m, int64_t m_count);
 void launch_true_peak_f32(const float *in, int64_t n, const double *bank, int phase_count, int filter_length, int center,
-                          int64_t step, int blk, double *block_tp, int64_t nblocks_alloc, int64_t m_total, hipStream_t s,
-                          const float *bank_f = nullptr, double tap_l1 = 0.0, int *scr_grp = nullptr, double *scr_lb = nullptr);
+                          int64_t step, int blk, double *block_tp, int64_t nblocks_alloc, int64_t m_total, hipStream_t s);
 void launch_true_peak_f64(const double *in, int64_t n, const double *bank, int phase_count, int filter_length, int center,
                           int64_t step, int blk, double *block_tp, int64_t nblocks_alloc, int64_t m_total, hipStream_t s);
 // Pass-3 192 kHz streams (FLT path from s16, DBL path after the limiter prefix); K-weighted afterwards by launch_kweight_blocks_*
@@ -210,7 +209,6 @@ struct HostArena {
 // cached resampler plans (the kaiser bank depends on the rate pair only) with their device copies
 struct SwrDev {
     int in_rate = 0, out_rate = 0; SwrPlanHost pl; DevBuf<double> bank_d; DevBuf<float> bank_f;
-    double tap_l1 = 0.0;         // largest 1-norm of a phase's taps (bounds |output| <= tap_l1 * max|x|: the screened true peak)
     DevBuf<float> bank_fs;       // bank_f * 2^-15 (s16 sources: the int -> float scale folded into the taps); empty unless that product is exact
     int64_t out_len(int64_t n) const { return (int64_t)(((__int128)n * pl.phase_count + pl.step - 1) / pl.step); }
 };
@@ -312,7 +310,6 @@ struct jt_ctx {
     // adeclick's split pipeline (front kernel -> solver kernels, k_declick.hip): per-window flagged count, index list, right-hand side, aux
     DevBuf<int> declick_F, declick_lists; DevBuf<unsigned short> declick_idx; DevBuf<double> declick_rhs, declick_aux, declick_r;
     DevBuf<unsigned long long> declick_ctl;
-    DevBuf<int> tp_grp[2]; DevBuf<double> tp_lb[2];     // screened true peak: group upper bounds / block lower bounds ([0] full analyses, [1] regions)
     hipStream_t dk_stream = nullptr; hipEvent_t dk_ev[2] = {nullptr, nullptr};
     // Pass 3 with the limiter prefix, started inside Pass 2 once its loudness / true peak are known (jt_pass3_plan_hook)
     struct EarlyPass3 {

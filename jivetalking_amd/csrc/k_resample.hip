@@ -250,17 +250,10 @@ template <typename TIn, typename TAcc, typename TTap, int MODE, int QL>
 __global__ void __launch_bounds__(PP_THREADS)
 k_upsample32(const TIn *__restrict__ in, int64_t n, const TTap *__restrict__ bank, int P, int center, int step,
              int64_t m_total, int R, double in_scale, int blk, unsigned long long *__restrict__ block_tp, int64_t nblocks_alloc,
-             TAcc *__restrict__ out_stream, int skewed, int *__restrict__ ubgrp, float err_k)
+             TAcc *__restrict__ out_stream, int skewed)
 {
     constexpr int L = 32;
     constexpr int WL = L + QL - 1;                                    // QL > 1 only with step == 1
-    // SCREEN (true peak, float arithmetic): this sweep only BOUNDS the peaks.  Every output is evaluated in f32; with E = err_k * max|x| of
-    // the window (err_k = 2.5e-6 * the bank's largest tap 1-norm: 34 roundings of 2^-24 on sum |c_i x_i|), a window's f64 outputs lie
-    // within +-E of the f32 ones.  block_tp receives a LOWER bound of every block's true peak (max of value - E), ubgrp an UPPER bound per
-    // group of 16 window positions (max of value + E); k_tp_refine then re-evaluates in f64 -- with the arithmetic of the f64 instance of
-    // this kernel -- only the groups whose upper bound reaches their block's lower bound: one to three windows per 100 ms block.
-    constexpr bool SCREEN = MODE == 0 && sizeof(TAcc) == 4;
-    __shared__ int ubl[SCREEN ? 704 : 1];
     extern __shared__ unsigned char smem_pp[];
     TIn *xin = reinterpret_cast<TIn *>(smem_pp);          // staged in the input type (halves the LDS footprint for f32 / s16 sources)
     const int T = 64 * R * QL * step;
@@ -291,7 +284,6 @@ k_upsample32(const TIn *__restrict__ in, int64_t n, const TTap *__restrict__ ban
         }
     }
     if (MODE == 0 && tid < 8) slots[tid] = 0ull;
-    if (SCREEN) for (int i = tid; i < 704; i += PP_THREADS) ubl[i] = 0;
     __syncthreads();
     if constexpr (MODE == 2 && QL == 1) {
         if ((P & 15) == 0 && (R == 1 || R == 2)) {
@@ -398,14 +390,6 @@ k_upsample32(const TIn *__restrict__ in, int64_t n, const TTap *__restrict__ ban
             const unsigned brem = (unsigned)(base0 - bq * blk);
             const bool smallq = (unsigned)(T + L) < 2u * (unsigned)blk;
             int sl[QL]; TAcc vm[QL];
-            int ubv[QL];
-            TAcc errw = (TAcc)0;
-            if (SCREEN) {
-                TAcc xm = (TAcc)0;
-#pragma unroll
-                for (int i = 0; i < WL; ++i) xm = fmax(xm, fabs(xw[i]));
-                errw = (TAcc)err_k * xm;
-            }
 #pragma unroll
             for (int u = 0; u < QL; ++u) {
                 const unsigned t = brem + (unsigned)(si + u * step);
@@ -416,25 +400,6 @@ k_upsample32(const TIn *__restrict__ in, int64_t n, const TTap *__restrict__ ban
                 if (b >= nblocks_alloc) b = nblocks_alloc - 1;
                 sl[u] = (int)(b - b_first);
                 vm[u] = (last >= 0 && last <= n - 1) ? vmax[u] : (TAcc)0;
-                if (SCREEN) {
-                    const bool valid = last >= 0 && last <= n - 1;
-                    // upper bound of the group of 16 window positions this window starts in (tile-relative index; positive floats
-                    // order like their bit patterns), lower bound towards the block
-                    ubv[u] = valid ? __float_as_int((float)((vmax[u] + errw) * (TAcc)1.000001)) : 0;
-                    vm[u] = valid ? (TAcc)fmax((vmax[u] - errw) * (TAcc)0.999999, (TAcc)0) : (TAcc)0;
-                }
-            }
-            if (SCREEN) {
-                if (QL == 4 && step == 1) {
-                    // si = 4 * (window index): the lane's four windows and those of the three other lanes of its quad start in the same
-                    // group of 16: one LDS atomic per quad instead of sixteen on one address
-                    int m = max(max(ubv[0], ubv[1]), max(ubv[QL > 2 ? 2 : 0], ubv[QL > 3 ? 3 : 0]));
-                    m = max(m, __shfl_xor(m, 1, 64)); m = max(m, __shfl_xor(m, 2, 64));
-                    if ((lane & 3) == 0 && m) atomicMax(&ubl[si >> 4], m);
-                } else {
-#pragma unroll
-                    for (int u = 0; u < QL; ++u) if (ubv[u]) atomicMax(&ubl[(si + u * step) >> 4], ubv[u]);
-                }
             }
             const int sl_lo = __builtin_amdgcn_readfirstlane(sl[0]), sl_hi = __builtin_amdgcn_readlane(sl[QL - 1], 63);
             if (sl_lo == sl_hi && sl_lo >= 0 && sl_lo < 8) {
@@ -463,75 +428,6 @@ k_upsample32(const TIn *__restrict__ in, int64_t n, const TTap *__restrict__ ban
             if (b >= nblocks_alloc) b = nblocks_alloc - 1;
             atomicMax(&block_tp[b], slots[tid]);
         }
-        if (SCREEN) {
-            const int ng = (T + L + 15) >> 4;                            // window positions s0 .. s0 + T + L of this tile, 16 per group
-            for (int i = tid; i < ng && i < 704; i += PP_THREADS) if (ubl[i]) atomicMax(&ubgrp[(s0 >> 4) + i], ubl[i]);
-        }
-    }
-}
-
-// The f64 pass of the screened true peak, in two launches.  k_tp_candidates: one thread per group of 16 window positions (k = w0 + center,
-// w0 = first input sample of the window); a group whose upper bound is below the lower bound of the block(s) its windows report to cannot
-// hold a block maximum; the others -- one to three per 100 ms block -- are appended to a list.  k_tp_refine: one wave per listed group,
-// lane = (window, phase): each lane evaluates one output exactly as k_upsample32<float, double, double, 0> does (window k: outputs
-// m = P (k / step) + j for the phases j of offset k % step, taps ascending, one fused multiply-add per tap, attributed to the 100 ms block
-// of the window's last input sample, reflected before the stream, zero behind it).
-__global__ void __launch_bounds__(256)
-k_tp_candidates(int64_t n, int center, int blk, const int *__restrict__ ubgrp, int64_t ngrp, const unsigned long long *__restrict__ lb,
-                int64_t nblocks_alloc, int *__restrict__ list, unsigned *__restrict__ count, unsigned cap)
-{
-    const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (g >= ngrp) return;
-    const int ubits = ubgrp[g];
-    if (ubits <= 0) return;
-    const double ub = (double)__int_as_float(ubits);
-    const int64_t la = 16 * g - center + 31, lz = la + 15;
-    if (lz < 0 || la > n - 1) return;
-    int64_t b0 = (la < 0 ? 0 : la) / blk, b1 = (lz > n - 1 ? n - 1 : lz) / blk;
-    b0 = b0 >= nblocks_alloc ? nblocks_alloc - 1 : b0; b1 = b1 >= nblocks_alloc ? nblocks_alloc - 1 : b1;
-    if (ub < fmin(__longlong_as_double((long long)lb[b0]), __longlong_as_double((long long)lb[b1]))) return;
-    const unsigned slot = atomicAdd(count, 1u);
-    if (slot < cap) list[slot] = (int)g;                     // (cap = every group: the list cannot overflow)
-}
-
-__global__ void __launch_bounds__(64)
-k_tp_refine(const float *__restrict__ in, int64_t n, const double *__restrict__ bank, int P, int center, int step, int64_t m_total, int blk,
-            const int *__restrict__ ubgrp, const unsigned long long *__restrict__ lb, unsigned long long *__restrict__ block_tp,
-            int64_t nblocks_alloc, const int *__restrict__ list, const unsigned *__restrict__ count)
-{
-    const int lane = threadIdx.x;
-    const unsigned total = *count;
-    const unsigned uP = (unsigned)P, ustep = (unsigned)step;
-    for (unsigned e = blockIdx.x; e < total; e += gridDim.x) {
-        const int64_t g = list[e];
-        const double ub = (double)__int_as_float(ubgrp[g]);
-        // lane = 4 * window + phase slot; a window has at most ceil(P / step) phases (4 or 5 here): slots beyond four take a second round
-        const int w = lane >> 2;
-        const int64_t k = 16 * g + w, w0 = k - center, last = w0 + 31;
-        const bool inside = last >= 0 && last <= n - 1;
-        int64_t b = (inside ? last : 0) / blk; b = b >= nblocks_alloc ? nblocks_alloc - 1 : b;
-        const bool want = inside && !(ub < __longlong_as_double((long long)lb[b]));
-        const unsigned off = (unsigned)(k % step);
-        const int64_t q = k / step;
-        const int j_lo = (int)((off * uP + ustep - 1u) / ustep);
-        int j_hi = (int)(((off + 1u) * uP + ustep - 1u) / ustep); j_hi = j_hi < P ? j_hi : P;
-        double vmax = 0.0;
-        if (want) {
-            double x[32];
-#pragma unroll
-            for (int i = 0; i < 32; ++i) { int64_t qi = w0 + i; if (qi < 0) qi = -qi; x[i] = qi < n ? (double)in[qi] : 0.0; }
-            for (int j = j_lo + (lane & 3); j < j_hi; j += 4) {
-                if ((int64_t)P * q + j >= m_total) break;
-                const double *f = bank + (size_t)(((unsigned)j * ustep) % uP) * 32;
-                double val = 0.0;
-#pragma unroll
-                for (int i = 0; i < 32; ++i) val = fma(x[i], f[i], val);
-                vmax = fmax(vmax, fabs(val));
-            }
-        }
-        // the four lanes of a window, then one atomic per window
-        vmax = fmax(vmax, __shfl_xor(vmax, 1, 64)); vmax = fmax(vmax, __shfl_xor(vmax, 2, 64));
-        if ((lane & 3) == 0 && vmax > 0.0) atomicMax(&block_tp[b], (unsigned long long)__double_as_longlong(vmax));
     }
 }
 
@@ -571,8 +467,7 @@ k_upsample32_stream8(const TIn *__restrict__ in, int64_t n, const TTap *__restri
 
 template <typename TIn, typename TAcc, typename TTap, int MODE>
 static bool launch_upsample32(const TIn *in, int64_t n, const TTap *bank, int P, int L, int center, int64_t step, int64_t m_total,
-                              double in_scale, int blk, double *block_tp, int64_t nblocks_alloc, TAcc *out, hipStream_t s,
-                              int *ubgrp = nullptr, float err_k = 0.f)
+                              double in_scale, int blk, double *block_tp, int64_t nblocks_alloc, TAcc *out, hipStream_t s)
 {
     if (L != 32 || step >= P || step > 512) return false;
     const int ql = step == 1 ? 4 : 1;
@@ -603,12 +498,12 @@ static bool launch_upsample32(const TIn *in, int64_t n, const TTap *bank, int P,
         auto k = k_upsample32<TIn, TAcc, TTap, MODE, 4>;
         JT_HIP(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
         hipLaunchKernelGGL(k, dim3(grid), dim3(PP_THREADS), smem, s, in, n, bank, P, center, (int)step, m_total, R, in_scale, blk,
-                           (unsigned long long *)block_tp, nblocks_alloc, out, 0, ubgrp, err_k);
+                           (unsigned long long *)block_tp, nblocks_alloc, out, 0);
     } else {
         auto k = k_upsample32<TIn, TAcc, TTap, MODE, 1>;
         JT_HIP(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
         hipLaunchKernelGGL(k, dim3(grid), dim3(PP_THREADS), smem, s, in, n, bank, P, center, (int)step, m_total, R, in_scale, blk,
-                           (unsigned long long *)block_tp, nblocks_alloc, out, (step & 1) ? 0 : 1, ubgrp, err_k);
+                           (unsigned long long *)block_tp, nblocks_alloc, out, (step & 1) ? 0 : 1);
     }
     return true;
 }
@@ -711,28 +606,9 @@ static PPGeom pp_geometry(int64_t n, int P, int L, int64_t step, int64_t m_total
 }
 
 void launch_true_peak_f32(const float *in, int64_t n, const double *bank, int phase_count, int filter_length, int center,
-                          int64_t step, int blk, double *block_tp, int64_t nblocks_alloc, int64_t m_total, hipStream_t s,
-                          const float *bank_f, double tap_l1, int *scr_grp, double *scr_lb)
+                          int64_t step, int blk, double *block_tp, int64_t nblocks_alloc, int64_t m_total, hipStream_t s)
 {
     if (m_total <= 0) return;
-    // screened: f32 sweep for bounds, f64 for the one-to-three windows per block that can hold its maximum (same values as the f64 sweep,
-    // tests/test_gpu_round3.py; JT_TP_F64=1 runs the f64 sweep over everything).  The tile of the f32 instance must fit ubl[]: 16 * 704 positions.
-    if (bank_f && scr_grp && scr_lb && filter_length == 32 && step < phase_count && step <= 147 && !getenv("JT_TP_F64")) {
-        const int64_t ngrp = (n + center + 64) / 16 + 2;
-        JT_HIP(hipMemsetAsync(scr_grp, 0, sizeof(int) * (size_t)(ngrp + 4), s));
-        JT_HIP(hipMemsetAsync(scr_lb, 0, sizeof(double) * (size_t)nblocks_alloc, s));
-        const float err_k = (float)(2.5e-6 * tap_l1);
-        if (launch_upsample32<float, float, float, 0>(in, n, bank_f, phase_count, filter_length, center, step, m_total, 1.0, blk, scr_lb,
-                                                       nblocks_alloc, (float *)nullptr, s, scr_grp, err_k)) {
-            // candidate list and its counter live behind the group bounds (scr_grp has room for 2 * ngrp + 4 ints)
-            int *list = scr_grp + ngrp + 4; unsigned *count = (unsigned *)(scr_grp + ngrp);
-            hipLaunchKernelGGL(k_tp_candidates, dim3((unsigned)((ngrp + 255) / 256)), dim3(256), 0, s, n, center, blk, scr_grp, ngrp,
-                               (const unsigned long long *)scr_lb, nblocks_alloc, list, count, (unsigned)ngrp);
-            hipLaunchKernelGGL(k_tp_refine, dim3(8192), dim3(64), 0, s, in, n, bank, phase_count, center, (int)step, m_total, blk, scr_grp,
-                               (const unsigned long long *)scr_lb, (unsigned long long *)block_tp, nblocks_alloc, list, count);
-            return;
-        }
-    }
     if (launch_upsample32<float, double, double, 0>(in, n, bank, phase_count, filter_length, center, step, m_total, 1.0, blk, block_tp,
                                                    nblocks_alloc, (double *)nullptr, s)) return;
     PPGeom g = pp_geometry<float>(n, phase_count, filter_length, step, m_total, false);

@@ -201,32 +201,3 @@ def test_decision_chain_on_gpu_pass1_equals_the_chain_on_oracle_pass1(engine, or
                 assert len(va) == len(vb) and max(abs(p - q) for p, q in zip(va, vb)) <= 0.1001, (a[k], b[k])
             else:
                 assert _close(a[k], b[k]), (name, k, a[k], b[k])
-
-
-def _tp_signals():
-    rng = np.random.default_rng(9)
-    out = []
-    for sr in (48000, 44100, 22050, 96000):
-        out.append((sr, "speech", synth.speech_like(12.0, sr, seed=80 + sr % 7)))
-        t = np.arange(int(3.3 * sr)) / sr
-        out.append((sr, "tone near Nyquist", (0.7 * np.sin(2 * np.pi * (0.49 * sr) * t + 0.3)).astype(np.float32)))
-        out.append((sr, "fs/4 tone at 45 degrees", (0.5 * np.sin(2 * np.pi * (sr / 4) * t + np.pi / 4)).astype(np.float32)))
-        x = np.zeros(int(2.05 * sr), np.float32); x[[0, 17, sr // 2, sr, x.size - 40, x.size - 1]] = [0.9, -0.8, 0.7, -0.95, 0.6, 0.5]
-        out.append((sr, "isolated impulses incl. the edges", x))
-        out.append((sr, "full-scale noise", rng.uniform(-1, 1, int(2.5 * sr)).astype(np.float32)))
-        out.append((sr, "silence then a quiet tone", np.concatenate([np.zeros(sr, np.float32), (1e-4 * np.sin(2 * np.pi * 997 * t[:sr])).astype(np.float32)])))
-    return out
-
-
-def test_screened_true_peak_equals_the_f64_sweep(engine, monkeypatch):
-    """ebur128's true peak (swr to 192 kHz, 32 taps, f64) is computed as an f32 sweep that only BOUNDS every output (rigorous rounding
-    bound E = 2.5e-6 * ||taps||_1 * max|x| per window) plus an f64 re-evaluation of the window groups whose upper bound reaches their
-    100 ms block's lower bound.  The per-block maxima - every lavfi.r128.true_peak value - equal the f64 sweep's bit for bit
-    (JT_TP_F64=1), on speech, tones at Nyquist's edge, impulses at the stream's ends, full-scale noise and near-silence, at four rates."""
-    for sr, what, x in _tp_signals():
-        monkeypatch.setenv("JT_TP_F64", "1")
-        a = engine.op_ebur128(x, sr, True)
-        monkeypatch.delenv("JT_TP_F64")
-        b = engine.op_ebur128(x, sr, True)
-        assert a["true_peak"] == b["true_peak"] and np.array_equal(a["TP"], b["TP"]), (sr, what, a["true_peak"], b["true_peak"])
-        assert np.array_equal(a["SP"], b["SP"]) and a["integrated"] == b["integrated"]
