@@ -467,6 +467,23 @@ def main():
                                                "mode (normalise.go:687-693 only warns about it)", "ms_per_file": round(min(td) * 1e3, 1), "xRT": round(600.0 / min(td), 1),
                                        "dynamic": int(rd.loudnorm.normalization_type_dynamic), "output_lufs": round(rd.output_lufs, 2), "output_dbtp": round(rd.output_tp_db, 2)}
             del yd
+        if world == 1 and args.e2e and args.channels == 1 and sr == 48000:
+            # BASELINE configs[4]: 96 kHz stereo, L != R (down-mix on the device, anlmdn K=576 / S=192, 4096-point afftdn, 96 k -> 44.1 k resampler)
+            xs = synth.speech_like_torch(seconds, 96000, seed=1000 + rank, device=f"cuda:{local_rank}", plosives_per_min=args.plosives)
+            ns = xs.numel()
+            xs = torch.stack([xs, 0.8 * torch.roll(xs, 14)], dim=1).contiguous().view(-1)
+            torch.cuda.synchronize()
+            eng.attach_device_pcm(xs.data_ptr(), ns, 96000, 2, keepalive=xs)
+            ts = []
+            for it in range(4):
+                t0 = time.perf_counter(); rs = hostlogic.process_audio(eng, base, 4096); ts.append(time.perf_counter() - t0)
+            tm = eng.timers()
+            eng.attach_device_pcm(x.data_ptr(), n, sr, 1, keepalive=x)
+            out["stereo_96k"] = {"what": f"1 x {args.minutes:g} min 96 kHz stereo f32 (BASELINE configs[4]), input resident in HBM", "ms_per_step": round(min(ts[1:]) * 1e3, 2),
+                                 "xRT": round(seconds / min(ts[1:]), 1), "limiter_needed": int(rs.limiter.needed),
+                                 "pass_ms": {"pass1": round(tm["pass1_ms"], 2), "pass2": round(tm["pass2_ms"], 2), "pass3": round(tm["pass3_ms"], 2), "pass4": round(tm["pass4_ms"], 2)},
+                                 "anlmdn_ms": round(tm["nlm_ms"], 2), "output_lufs": round(rs.output_lufs, 2), "output_dbtp": round(rs.output_tp_db, 2)}
+            del xs
         if world == 1 and args.saturation and args.channels == 1:
             out["saturation"] = saturation_leg(eng, local_rank, base, hostlogic, synth, sr, args.sat_files, args.sat_minutes, args.sat_in_flight)
         if world == 1 and args.cpu_sample > 0:
