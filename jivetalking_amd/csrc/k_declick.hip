@@ -1260,12 +1260,12 @@ k_dk_solve(double *__restrict__ out, int64_t n, DeclickParams P, DkSplit S, doub
 {
     extern __shared__ unsigned char dk_smem[];
     constexpr int NW = 64 / G, CR = BW + 9;
-    constexpr bool TWO = NW == 2;
+    constexpr bool TWO = NW == 2, STAGE = G == 32;
     static_assert(G == 32 || G == 64, "group size");
     static_assert(BW < G, "one lane per diagonal");
     constexpr int IDXN = (FC + BW + 16 + G + 7) & ~7;                   // index entries kept per window (sentinels behind the last one)
     constexpr int BWN = (FC + 16 + 7) & ~7, YN = (FC + BW + 16 + 7) & ~7;
-    constexpr size_t SLOTB = sizeof(double) * (size_t)(YN + 56 + 4 * G) + 2 * (size_t)IDXN + (size_t)BWN;
+    constexpr size_t SLOTB = sizeof(double) * (size_t)(YN + 56 + 6 * G) + 2 * (size_t)IDXN + (size_t)BWN;
     const int lane = threadIdx.x, gl = lane % G, q = lane / G;
     const int AR = P.ar;
     unsigned char *base = dk_smem + (size_t)q * SLOTB;
@@ -1273,7 +1273,8 @@ k_dk_solve(double *__restrict__ out, int64_t n, DeclickParams P, DkSplit S, doub
     double *aux = yv + YN;                                              // [56]
     double *CV = aux + 56;                                              // [2G] pivot column (slot 0: y_k), zeros behind G
     double *LV = CV + 2 * G;                                            // [2G] multipliers, zeros behind G
-    unsigned short *idx = reinterpret_cast<unsigned short *>(LV + 2 * G);   // [IDXN]
+    double *stg = LV + 2 * G;                                           // [2G] staging ring of the factor stream
+    unsigned short *idx = reinterpret_cast<unsigned short *>(stg + 2 * G);  // [IDXN]
     unsigned char *bwv = reinterpret_cast<unsigned char *>(idx + IDXN);     // [BWN]
     CV[G + gl] = 0.0; LV[G + gl] = 0.0;
     const unsigned cva = dk_lds_addr(CV), lva = dk_lds_addr(LV + gl);
@@ -1338,7 +1339,7 @@ k_dk_solve(double *__restrict__ out, int64_t n, DeclickParams P, DkSplit S, doub
         double yr = yv[gl];                                              // y of row k + gl
         double rinv_n = dk_rcp(c[0]);
         bool okw = true;
-        unsigned goff = 0;
+        unsigned goff = 0, gfl = 0;                                      // next stream position / first position not yet in global memory
         int bwk = bwv[0];
         for (int k0 = 0; k0 < Fmax; k0 += 8) {
             // one pivot; p (the register of its column) and the update's column offsets are compile-time constants
@@ -1381,7 +1382,20 @@ k_dk_solve(double *__restrict__ out, int64_t n, DeclickParams P, DkSplit S, doub
                 // 1 / d of the next pivot: entry (k + 1, k + 1) is lane 0's c[p + 1]
                 rinv_n = dk_rcp(c[p + 1]);
                 // factor stream: the bw multipliers of the column, then y_k / d_k (lane 0), in one store
-                if (live) {
+                // (a global store per pivot cost a quarter of the factorisation: the stream is staged in a 2 G-entry LDS ring per window and
+                //  leaves G values at a time, one coalesced store per three or four pivots)
+                //  (G = 64: a pivot of the wide class appends 30-49 values, a flush every other pivot buys nothing: direct store)
+                if (STAGE) {
+                    if (live) {
+                        if (gl <= bwk) stg[(goff + (gl ? (unsigned)gl - 1u : (unsigned)bwk)) & (2u * G - 1u)] = gl ? l : yk * rinv;
+                        goff += (unsigned)bwk + 1u;
+                    }
+                    if (__any(goff - gfl >= (unsigned)G)) {
+                        __builtin_amdgcn_wave_barrier();
+                        if (goff - gfl >= (unsigned)G) { gL[gfl + (unsigned)gl] = stg[(gfl + (unsigned)gl) & (2u * G - 1u)]; gfl += (unsigned)G; }
+                        __builtin_amdgcn_wave_barrier();
+                    }
+                } else if (live) {
                     if (gl <= bwk) gL[goff + (gl ? (unsigned)gl - 1u : (unsigned)bwk)] = gl ? l : yk * rinv;
                     goff += (unsigned)bwk + 1u;
                 }
@@ -1399,6 +1413,8 @@ k_dk_solve(double *__restrict__ out, int64_t n, DeclickParams P, DkSplit S, doub
 #pragma unroll
             for (int s = 0; s <= BW; ++s) c[s] = c[s + 8];
         }
+        __builtin_amdgcn_wave_barrier();
+        if (STAGE && (unsigned)gl < goff - gfl) gL[gfl + (unsigned)gl] = stg[(gfl + (unsigned)gl) & (2u * G - 1u)];      // what is left in the ring
         DKS_MARK(1)
         // ---- back substitution, column form (as k_adeclick_fast): lane t of the group holds the sum collected for row i - t
         {
@@ -1552,7 +1568,7 @@ void launch_adeclick(jt_ctx *h, const double *in, double *out, int64_t n, int sa
             SP.r = lev_split ? h->declick_r.p : nullptr; SP.ac = lev_split ? h->declick_r.p + (size_t)P.nwindows * 64 : nullptr;
             auto slot_bytes = [&](int G, int BW) {
                 const int idxn = (FCS + BW + 16 + G + 7) & ~7, bwn = (FCS + 16 + 7) & ~7, yn = (FCS + BW + 16 + 7) & ~7;
-                return sizeof(double) * (size_t)(yn + 56 + 4 * G) + 2 * (size_t)idxn + (size_t)bwn;
+                return sizeof(double) * (size_t)(yn + 56 + 6 * G) + 2 * (size_t)idxn + (size_t)bwn;
             };
             const size_t sm32 = 2 * slot_bytes(G32, BW32) + 16, sm64 = slot_bytes(G64, BW64) + 16;
             const int w32 = (int)std::min<size_t>(16, (160 * 1024) / sm32), w64 = (int)std::min<size_t>(8, (160 * 1024) / sm64);
