@@ -208,3 +208,36 @@ def test_decision_chain_on_gpu_pass1_equals_the_chain_on_oracle_pass1(engine, or
                 assert len(va) == len(vb) and max(abs(p - q) for p, q in zip(va, vb)) <= 0.1001, (a[k], b[k])
             else:
                 assert _close(a[k], b[k]), (name, k, a[k], b[k])
+
+
+def test_limiter_prefix_branch_matches_the_oracle_chain(engine, oracle):
+    """The branch the bench's `value` is measured on: a talker with plosives whose plan needs the limiter prefix.
+    Pass 3 (volume -> alimiter on the s16 output, swr in double to 192 kHz, loudnorm's first-pass statistics) and Pass 4 (the limited
+    signal x linear gain -> adeclick -> brickwall alimiter -> s16) against the same chain composed from the CPU oracle, given the GPU
+    run's Pass-2 output: statistics equal at the JSON's %.2f, final PCM within 1 LSB at rounding ties, landing -16 LUFS / <= -1 dBTP."""
+    w = int(0.02 * SR)
+    burst = 0.35 * np.hanning(w) * np.sin(2 * np.pi * 180.0 * np.arange(w) / SR)
+    x = np.asarray(synth.speech_like(30.0, SR, seed=91), np.float64)
+    for pos in range(SR, x.size - SR, int(1.5 * SR)):
+        x[pos:pos + w] += burst
+    engine.upload_pcm(x.astype(np.float32), SR, 1)
+    res = H.process_audio(engine)
+    p2, p4 = engine.download_s16(2), engine.download_s16(4)
+    assert res.limiter.needed == 1
+    pre_db = float("%.1f" % max(res.limiter.pre_gain_db, 0.0))
+    limit = float("%.6f" % (10 ** (res.limiter.ceiling_db / 20.0)))
+    src = p2.astype(np.float64) / 32768.0
+    if pre_db > 0:
+        src = (src.astype(np.float32) * np.float32(10 ** (pre_db / 20.0))).astype(np.float64)      # af_volume, precision=float
+    lim = oracle.alimiter(src, 44100, limit, 5.0, 100.0)
+    m = oracle.loudnorm_measure(oracle.swr_f64(lim, 44100, 192000, True), 192000, True)
+    assert abs(res.measure.input_i - m["input_i"]) <= 0.011 and abs(res.measure.input_tp - m["input_tp"]) <= 0.011
+    assert abs(res.measure.input_lra - m["input_lra"]) <= 0.011 and abs(res.measure.input_thresh - m["input_thresh"]) <= 0.011
+    gain = 10 ** ((res.effective_target_i - res.measure.input_i) / 20.0)
+    y = oracle.adeclick(lim * gain, 44100, 1.7, 55.0, 50.0, method="s")
+    z = oracle.alimiter(y, 44100, 0.803526, 1.0, 50.0)
+    ref = oracle.f64_to_s16(z.astype(np.float32).astype(np.float64))
+    d = np.abs(ref.astype(np.int32) - p4.astype(np.int32))
+    assert d.max() <= 1 and np.count_nonzero(d) <= 4, (int(d.max()), int(np.count_nonzero(d)))
+    e = oracle.ebur128(p4.astype(np.float64) / 32768.0, 44100, True, True)
+    assert abs(e["integrated"] + 16.0) <= 0.1 and 20 * np.log10(e["true_peak"]) <= -1.0
