@@ -157,9 +157,16 @@ def saturation_leg(eng, device, base, hostlogic, synth, sr, files, minutes, in_f
             for q in os.listdir(d):
                 if q.endswith("-processed.flac"):
                     os.unlink(os.path.join(d, q))
-            t0 = time.perf_counter()
-            failed, fr, _ = hostlogic.process_files_multi(paths, devices=(device,), in_flight_per_device=in_flight, base=base, md5=md5)
-            wall = time.perf_counter() - t0
+            wall = None
+            for rep in range(2):                      # best of two: a one-second batch is sensitive to whatever else the host is doing
+                for q in os.listdir(d):
+                    if q.endswith("-processed.flac"):
+                        os.unlink(os.path.join(d, q))
+                t0 = time.perf_counter()
+                failed_, fr_, _ = hostlogic.process_files_multi(paths, devices=(device,), in_flight_per_device=in_flight, base=base, md5=md5)
+                w_ = time.perf_counter() - t0
+                if wall is None or w_ < wall:
+                    wall, failed, fr = w_, failed_, fr_
             busy = sum(float(fr[i].wall_ms) for i in range(files)) / 1e3 / in_flight           # the workers' own per-file time
             out["md5" if md5 else "no_md5"] = {
                 "failed": int(failed), "wall_s": round(wall, 3), "files_per_s": round(files / wall, 2), "ms_per_file": round(wall / files * 1e3, 2),
