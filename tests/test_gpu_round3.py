@@ -241,3 +241,29 @@ def test_limiter_prefix_branch_matches_the_oracle_chain(engine, oracle):
     assert d.max() <= 1 and np.count_nonzero(d) <= 4, (int(d.max()), int(np.count_nonzero(d)))
     e = oracle.ebur128(p4.astype(np.float64) / 32768.0, 44100, True, True)
     assert abs(e["integrated"] + 16.0) <= 0.1 and 20 * np.log10(e["true_peak"]) <= -1.0
+
+
+def test_round3_paths_equal_their_switched_off_versions_on_a_long_file(engine, monkeypatch):
+    """Twenty minutes (BASELINE configs[1] in small; tools/ab_pipeline_fused.py does the same on the 60-min bench file): the split adeclick
+    pipeline, Levinson-Durbin one lane per window and Pass 3 started inside Pass 2 are kernel / schedule changes only - the delivered PCM
+    and every reported number equal the run with each of them switched off."""
+    import hashlib
+    w = int(0.02 * SR)
+    burst = 0.35 * np.hanning(w) * np.sin(2 * np.pi * 180.0 * np.arange(w) / SR)
+    base = np.asarray(synth.speech_like(60.0, SR, seed=95), np.float64)
+    for pos in range(SR, base.size - SR, int(1.5 * SR)):
+        base[pos:pos + w] += burst
+    x = np.tile(base.astype(np.float32), 20)
+
+    def run():
+        engine.upload_pcm(x, SR, 1)
+        r = H.process_audio(engine)
+        return (hashlib.md5(engine.download_s16(4).tobytes()).hexdigest(), r.output_lufs, r.output_tp_db, r.measure.input_i, r.measure.input_tp,
+                int(r.limiter.needed), r.final_.r128.true_peak, engine.timers()["declick_repaired"])
+    ref = run()
+    assert ref[5] == 1 and abs(ref[1] + 16.0) <= 0.1 and ref[2] <= -1.0
+    for var in ("JT_ADECLICK_FUSED", "JT_NO_EARLY_PLAN", "JT_DK_LEVINSON_IN_KERNEL"):
+        monkeypatch.setenv(var, "1")
+        got = run()
+        monkeypatch.delenv(var)
+        assert got == ref, var
