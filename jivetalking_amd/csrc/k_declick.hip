@@ -42,8 +42,10 @@ struct DkSplit {
     double *rhs;                   // [nwindows * wp] right-hand side of the interpolation system
     double *aux;                   // [nwindows * 56] autocorrelation of the AR coefficients (aux[AR + 1] = 0)
     int *list32, *list64;          // windows whose band fits 31 rows / needs up to 48
-    unsigned long long *ctl;       // [0] / [1] list lengths, [2] / [3] work counters of the two solver launches
+    unsigned long long *ctl;       // [0] / [1] list lengths, [2] / [3] work counters of the two solver launches, [32 + 16 x] / [160 + 16 x] the
+                                   // per-XCD window heads of the two front launches (a 128-byte line each)
     int wp;
+    int xcd;                       // 1: the front launches hand windows out per XCD (contiguous eighths of the file)
     double *r;                     // [nwindows * 64] biased autocorrelation r[0 .. AR] (MODE 2 -> k_dk_levinson)
     double *ac;                    // [nwindows * 64] AR polynomial k[0 .. AR], zero padded to 64 taps; ac[w * 64 + 63] = sigma_e
 };
@@ -610,12 +612,44 @@ k_adeclick_fast(const double *__restrict__ in, double *__restrict__ out, int64_t
     const int64_t nwork = LEVEL == 0 ? P.nwindows : (int64_t)stats[1 + LEVEL];
     // The work counter is fetched one window ahead: the atomic's round trip (and the drain of the previous window's stores that a
     // wait on it implies) took 10 % of a window when the wave asked for its next window only after finishing the current one.
-    auto take = [&]() -> unsigned long long { unsigned long long v = 0; if (lane == 0) v = atomicAdd(&stats[12 + LEVEL], 1ull); return v; };
+    // The two front launches of the split pipeline hand the windows out PER XCD (HW_REG_XCC_ID), each XCD working through a contiguous
+    // eighth of the file with a head of its own, on a 128-byte line of its own, and moving on to the next XCD's eighth when its own is
+    // done.  Two things come of it.  (1) One head for the whole chip was a bottleneck: 2560 waves at 23-50 us per window are 50-110
+    // returning atomics per us on one word, which saturates near 90 (MI355X_MICROARCH.md, "dequeue"); eight heads took 0.5 ms off the
+    // autocorrelation launch (1.70 -> 1.17 ms) and 0.2 ms off the detector launch -- with the eight heads in ONE line the launches were
+    // 0.2 ms SLOWER than with one head.  (2) Consecutive windows share half their samples, and with one counter neighbours landed on
+    // different XCDs (eight private L2s), so every half window came from HBM twice per launch (PMC FETCH_SIZE was exactly two file
+    // lengths): 2.4 -> 1.6 GB and 3.7 -> 2.0 GB.  Placement is a speed matter only: every window is still taken exactly once, whatever
+    // the register returns.
+    constexpr bool XH = LEVEL == 0 && (MODE == 2 || MODE == 3);
+    unsigned long long *xheads = nullptr; int xcur = 0;
+    if constexpr (XH) if (S.xcd) {
+        unsigned id; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(id));
+        xcur = (int)(id & 7u); xheads = S.ctl + (MODE == 2 ? 32 : 160);                  // one 128-byte line per head
+    }
+    auto xbase = [&](int x) -> int64_t { return nwork * x / 8; };
+    auto take = [&]() -> unsigned long long {
+        unsigned long long v = 0;
+        if (lane == 0) v = atomicAdd(xheads ? &xheads[16 * xcur] : &stats[12 + LEVEL], 1ull);
+        return v;
+    };
     auto uniform64 = [](unsigned long long v) -> int64_t {
         return (int64_t)(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(v >> 32)) << 32) |
                          (unsigned)__builtin_amdgcn_readfirstlane((int)v));
     };
-    int64_t wi = uniform64(take());
+    // ticket -> window (wave-uniform); a ticket beyond the XCD's eighth sends the wave to the next eighth, at most seven times
+    auto resolve = [&](unsigned long long t_) -> int64_t {
+        int64_t v = uniform64(t_);
+        if (!xheads) return v;
+        for (int tries = 0;;) {
+            const int64_t b = xbase(xcur);
+            if (v < xbase(xcur + 1) - b) return b + v;
+            if (++tries == 8) return nwork;
+            xcur = (xcur + 1) & 7;
+            v = uniform64(take());
+        }
+    };
+    int64_t wi = resolve(take());
     for (;;) {
         if (wi >= nwork) break;
         const unsigned long long wnext_ = take();                   // consumed after the first buffer load below
@@ -654,7 +688,7 @@ k_adeclick_fast(const double *__restrict__ in, double *__restrict__ out, int64_t
         const int emid = HALF ? min(LB, P.skip + P.hop) : P.skip + P.hop;
         if (MODE == 3) load_buf(HALF ? SB_B : 0);                   // (the detector starts on the upper half; MODE 2 wrote the pass-through copy)
         else load_buf(0, P.skip, emid);
-        wi = uniform64(wnext_);                                     // (the loads above were waited for; the atomic precedes them)
+        wi = resolve(wnext_);                                       // (the loads above were waited for; the atomic precedes them)
 #ifdef JT_DK_SPLIT0
         DKF_MARK(7)
 #else
@@ -914,6 +948,10 @@ k_adeclick_fast(const double *__restrict__ in, double *__restrict__ out, int64_t
         DKF_MARK(3)
         bool ok = true;
         if (F > 0) {
+            // the window's place in the list of its band class is asked for here and used at the hand-over below: the atomic's round
+            // trip hides behind the right-hand side instead of standing at the end of the window
+            unsigned long long lslot_ = 0;
+            if ((MODE == 1 || MODE == 3) && lane == 0) lslot_ = atomicAdd(&S.ctl[wide ? 1 : 0], 1ull);
             // ---- 7. aux = autocorrelation(ac, AR, AR+1, ., 1.)
             if (lane <= AR) {
                 double value = 0.0;
@@ -969,8 +1007,7 @@ k_adeclick_fast(const double *__restrict__ in, double *__restrict__ out, int64_t
                 if (lane <= AR + 1) S.aux[(size_t)w * 56 + lane] = aux[lane];
                 if (lane == 0) {
                     S.F[w] = F;
-                    const unsigned long long slot = atomicAdd(&S.ctl[wide ? 1 : 0], 1ull);
-                    (wide ? S.list64 : S.list32)[slot] = (int)w;
+                    (wide ? S.list64 : S.list32)[lslot_] = (int)w;
                 }
                 DKF_MARK(4)
                 continue;
@@ -1558,13 +1595,14 @@ void launch_adeclick(jt_ctx *h, const double *in, double *out, int64_t n, int sa
             const int wp = (P.W + 63) & ~63;
             h->declick_F.ensure((size_t)P.nwindows); h->declick_lists.ensure(2 * (size_t)P.nwindows);
             h->declick_idx.ensure((size_t)P.nwindows * wp); h->declick_rhs.ensure((size_t)P.nwindows * wp);
-            h->declick_aux.ensure((size_t)P.nwindows * 56); h->declick_ctl.ensure(8);
+            h->declick_aux.ensure((size_t)P.nwindows * 56); h->declick_ctl.ensure(288);
             // (r[] and the AR polynomial share one buffer: 64 doubles each per window)
             const bool lev_split = P.ar == dk::MAXAR && !getenv("JT_DK_LEVINSON_IN_KERNEL");
             if (lev_split) h->declick_r.ensure(2 * (size_t)P.nwindows * 64);
-            JT_HIP(hipMemsetAsync(h->declick_ctl.p, 0, 8 * sizeof(unsigned long long), s));
+            JT_HIP(hipMemsetAsync(h->declick_ctl.p, 0, 288 * sizeof(unsigned long long), s));
             SP.F = h->declick_F.p; SP.index = h->declick_idx.p; SP.rhs = h->declick_rhs.p; SP.aux = h->declick_aux.p;
             SP.list32 = h->declick_lists.p; SP.list64 = h->declick_lists.p + P.nwindows; SP.ctl = h->declick_ctl.p; SP.wp = wp;
+            SP.xcd = getenv("JT_DK_NO_XCD") ? 0 : 1;
             SP.r = lev_split ? h->declick_r.p : nullptr; SP.ac = lev_split ? h->declick_r.p + (size_t)P.nwindows * 64 : nullptr;
             auto slot_bytes = [&](int G, int BW) {
                 const int idxn = (FCS + BW + 16 + G + 7) & ~7, bwn = (FCS + 16 + 7) & ~7, yn = (FCS + BW + 16 + 7) & ~7;
@@ -1598,12 +1636,17 @@ void launch_adeclick(jt_ctx *h, const double *in, double *out, int64_t n, int sa
                     JT_HIP(hipEventCreateWithFlags(&h->dk_ev[0], hipEventDisableTiming));
                     JT_HIP(hipEventCreateWithFlags(&h->dk_ev[1], hipEventDisableTiming));
                 }
+                if (getenv("JT_DK_SERIAL")) {
+                    hipLaunchKernelGGL(k64, dim3((unsigned)g64), dim3(64), sm64, s, out, n, P, SP, h->declick_scr.p + slot32 * 2 * (size_t)g32, slot64, d_stats);
+                    hipLaunchKernelGGL(k32, dim3((unsigned)g32), dim3(64), sm32, s, out, n, P, SP, h->declick_scr.p, slot32, d_stats);
+                } else {
                 JT_HIP(hipEventRecord(h->dk_ev[0], s));
                 JT_HIP(hipStreamWaitEvent(h->dk_stream, h->dk_ev[0], 0));
                 hipLaunchKernelGGL(k64, dim3((unsigned)g64), dim3(64), sm64, h->dk_stream, out, n, P, SP, h->declick_scr.p + slot32 * 2 * (size_t)g32, slot64, d_stats);
                 JT_HIP(hipEventRecord(h->dk_ev[1], h->dk_stream));
                 hipLaunchKernelGGL(k32, dim3((unsigned)g32), dim3(64), sm32, s, out, n, P, SP, h->declick_scr.p, slot32, d_stats);
                 JT_HIP(hipStreamWaitEvent(s, h->dk_ev[1], 0));
+                }
             }
             if (half_ok) DKF_LAUNCH((k_adeclick_fast<MID, NC1, ND1, true, 1>), f1, fm1, Q1);
             else DKF_LAUNCH((k_adeclick_fast<MID, NC1, ND1, false, 1>), f1, fm1, Q1);
