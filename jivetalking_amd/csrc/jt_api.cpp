@@ -749,7 +749,10 @@ extern "C" int jt_pass3_plan_hook(jt_ctx *h, jt_plan_fn fn, void *user)
     return JT_OK;
 }
 
-static void run_limiter(jt_ctx *h, const double *in, double *out, int64_t n, int sr, double limit, double attack_ms, double release_ms, double in_gain);
+// s16 != nullptr: `in` is WRITTEN first (the s16 -> dbl conversion with the volume stage, fused into the limiter's first sweep)
+struct LimS16 { const int16_t *s16 = nullptr; double vol = 1.0; int vol_in_float = 0; };
+static void run_limiter(jt_ctx *h, double *in, double *out, int64_t n, int sr, double limit, double attack_ms, double release_ms, double in_gain,
+                        const LimS16 &src = LimS16{});
 
 // Pass 3 for a plan WITH the limiter prefix, queued on the main stream inside Pass 2 (behind the output stage, before the join with the
 // analysis chains): volume -> alimiter on the s16 output, swr (double) -> 192 kHz, K-weighting + block energies.  The same launches as
@@ -772,8 +775,7 @@ static void early_pass3_enqueue(jt_ctx *h, const int16_t *s16, int64_t m, int ra
     h->f64_a.ensure((size_t)m); h->f64_b.ensure((size_t)m); h->stream_d.ensure((size_t)m_meter);
     const bool pre = lim.pre_gain_db > 0;
     const double g = pre ? std::pow(10.0, lim.pre_gain_db / 20.0) : 1.0;
-    launch_s16_to_f64(s16, h->f64_a.p, m, g, pre ? 1 : 0, h->stream);
-    run_limiter(h, h->f64_a.p, h->f64_b.p, m, rate, lim.limit, 5.0, 100.0, 1.0);
+    run_limiter(h, h->f64_a.p, h->f64_b.p, m, rate, lim.limit, 5.0, 100.0, 1.0, LimS16{s16, g, pre ? 1 : 0});
     h->lim_keep = {true, s16, m, rate, lim.pre_gain_db, lim.limit};
     launch_resample_stream_f64(h->f64_b.p, m, sw.bank_d.p, sw.pl.phase_count, sw.pl.filter_length, sw.pl.center, sw.pl.step, m_total, h->stream_d.p, h->stream);
     loudnorm_append_flush(h->stream_d.p, m_total, h->stream);
@@ -916,8 +918,8 @@ extern "C" int jt_pass2(jt_ctx *h, const jt_filter_params *p, jt_analysis *out)
 }
 
 // ---------------------------------------------------------------- limiter driver (clean-point segmentation)
-static void run_limiter(jt_ctx *h, const double *in, double *out, int64_t n, int sr, double limit, double attack_ms,
-                        double release_ms, double in_gain)
+static void run_limiter(jt_ctx *h, double *in, double *out, int64_t n, int sr, double limit, double attack_ms,
+                        double release_ms, double in_gain, const LimS16 &src)
 {
     const double attack = attack_ms / 1000., release = release_ms / 1000.;
     int B = (int)(sr * attack * 1); if (B < 1) B = 1;
@@ -925,7 +927,11 @@ static void run_limiter(jt_ctx *h, const double *in, double *out, int64_t n, int
     const int blk = 256;
     const int64_t nblk = (n + blk - 1) / blk;
     h->d_scr3.ensure((size_t)nblk);
-    launch_absmax_copy_f64(in, out, n, in_gain, h->d_scr3.p, nblk, h->stream);      // blk == 256
+    if (src.s16 && !getenv("JT_NO_LIM_S16")) launch_absmax_conv_s16(src.s16, in, out, n, src.vol, src.vol_in_float, in_gain, h->d_scr3.p, nblk, h->stream);
+    else {
+        if (src.s16) launch_s16_to_f64(src.s16, in, n, src.vol, src.vol_in_float, h->stream);
+        launch_absmax_copy_f64(in, out, n, in_gain, h->d_scr3.p, nblk, h->stream);      // blk == 256
+    }
     // a position p is clean when no sample in the previous (B + release*sr + 4) samples exceeds the limit; segment starts are
     // picked on the device (one candidate per 2048 samples), so the limiter needs no host round trip
     const int need = (int)std::ceil((B + release * sr + 4.0) / blk) + 1;
@@ -1001,8 +1007,7 @@ static void pass3_core(jt_ctx *h, const int16_t *s16, int64_t m, int rate, const
         h->f64_a.ensure((size_t)m); h->f64_b.ensure((size_t)m);
         const bool pre = lim->pre_gain_db > 0;
         const double g = pre ? std::pow(10.0, lim->pre_gain_db / 20.0) : 1.0;
-        launch_s16_to_f64(s16, h->f64_a.p, m, g, pre ? 1 : 0, h->stream);
-        run_limiter(h, h->f64_a.p, h->f64_b.p, m, rate, lim->limit, 5.0, 100.0, 1.0);
+        run_limiter(h, h->f64_a.p, h->f64_b.p, m, rate, lim->limit, 5.0, 100.0, 1.0, LimS16{s16, g, pre ? 1 : 0});
         h->lim_keep = {true, s16, m, rate, lim->pre_gain_db, lim->limit};
         loudnorm_measure_enqueue(h, nullptr, h->f64_b.p, m, rate, &J);
     } else {
@@ -1153,8 +1158,9 @@ extern "C" int jt_pass4(jt_ctx *h, const jt_limiter_plan *lim, const jt_loudnorm
     h->lim_keep.valid = false;                                  // (this pass overwrites both buffers)
     if (kept) std::swap(sig, tmp);                              // Pass 3 ran this prefix on these samples: its output is still in f64_b
     else {
-        launch_s16_to_f64(h->s16_p2.p, sig, m, pre ? std::pow(10.0, lim->pre_gain_db / 20.0) : 1.0, pre ? 1 : 0, h->stream);
-        if (lim && lim->needed) { run_limiter(h, sig, tmp, m, rate, lim->limit, 5.0, 100.0, 1.0); std::swap(sig, tmp); }
+        const double vol = pre ? std::pow(10.0, lim->pre_gain_db / 20.0) : 1.0;
+        if (lim && lim->needed) { run_limiter(h, sig, tmp, m, rate, lim->limit, 5.0, 100.0, 1.0, LimS16{h->s16_p2.p, vol, pre ? 1 : 0}); std::swap(sig, tmp); }
+        else launch_s16_to_f64(h->s16_p2.p, sig, m, vol, pre ? 1 : 0, h->stream);
     }
     check_cancel(h);
     // loudnorm r128_in / r128_out statistics (libavfilter/ebur128.c) at the stream rate

@@ -95,6 +95,8 @@ void launch_band_rms(const float *in, int64_t n, int nbands, const double (*hp)[
 // limiter (exact, chunked at provably clean points)
 // limiter, first sweep (blk == 256): block maxima of |in| and out = in * gain; launch_limiter_f64 expects `out` to hold that copy
 void launch_absmax_copy_f64(const double *in, double *out, int64_t n, double gain, double *out_max, int64_t nblk, hipStream_t s);
+void launch_absmax_conv_s16(const int16_t *in, double *conv, double *out, int64_t n, double vol, int vol_in_float, double gain, double *out_max,
+                            int64_t nblk, hipStream_t s);
 void launch_limiter_f64(const double *in, double *out, int64_t n, int sr, double limit, int buffer_size,
                         double release_s, double asc_coeff, const double *block_max, int64_t nblk, int blk, int need, int target,
                         int64_t *cand, int64_t ntargets, double in_gain, double *scratch_delta, int64_t *scratch_pos, hipStream_t s);

@@ -505,6 +505,20 @@ k_kw(const TIn *__restrict__ in, int64_t n, int64_t L, KwCoef k, const double *_
 }
 #undef KW2_STEP
 
+// Per-block sums / peaks from the per-chunk partials, in chunk order (what the host loop of jt_kweight_finish did over 360 k chunks of an
+// hour at 192 kHz, 0.4 ms on the critical path between Pass 3 and Pass 4, behind a 5.8 MB copy): one thread per 100 ms block, the chunks
+// past the last full block fold into the trailing partial block.
+__global__ void __launch_bounds__(64)
+k_kw_blocks(const double *__restrict__ csum, const double *__restrict__ cpeak, int64_t nchunks, int m, int64_t nfull, double *__restrict__ out)
+{
+    const int64_t b = (int64_t)blockIdx.x * 64 + threadIdx.x;
+    if (b > nfull) return;
+    const int64_t c0 = b * m, c1 = b == nfull ? nchunks : min(nchunks, c0 + m);
+    double sum = 0.0, pk = 0.0;
+    for (int64_t c = c0; c < c1; ++c) { sum += csum[c]; pk = fmax(pk, cpeak[c]); }
+    out[b] = sum; out[nfull + 1 + b] = pk;
+}
+
 static void mat4_mul(const double *A, const double *B, double *C)
 {
     double t[16];
@@ -560,21 +574,19 @@ static void kweight_enqueue(jt_ctx *h, const TIn *in, int64_t n, int rate, int b
                        d_zs, (double *)nullptr, (double *)nullptr, nchunks);
     hipLaunchKernelGGL((k_kw<TIn, true>), dim3(grid), dim3(LANES), 0, st, in, n, L, k, d_zs, d_pw, nterms,
                        (double *)nullptr, d_cs, d_cs + nchunks, nchunks);
-    double *hc = ext ? ext->pin + 24 * 16 : h->pin.take<double>((size_t)nchunks * 2);
-    JT_HIP(hipMemcpyAsync(hc, d_cs, sizeof(double) * nchunks * 2, hipMemcpyDeviceToHost, st));
-    job->hc = hc; job->nchunks = nchunks; job->nfull = n / blk; job->m = m;
+    // block sums / peaks into the (now dead) zero-state region, (nfull + 1) entries each; only those travel to the host
+    const int64_t nfull = n / blk;
+    hipLaunchKernelGGL(k_kw_blocks, dim3((unsigned)((nfull + 1 + 63) / 64)), dim3(64), 0, st, d_cs, d_cs + nchunks, nchunks, m, nfull, d_zs);
+    double *hc = ext ? ext->pin + 24 * 16 : h->pin.take<double>((size_t)(nfull + 1) * 2);
+    JT_HIP(hipMemcpyAsync(hc, d_zs, sizeof(double) * (size_t)(nfull + 1) * 2, hipMemcpyDeviceToHost, st));
+    job->hc = hc; job->nchunks = nchunks; job->nfull = nfull; job->m = m;
 }
 void jt_kweight_enqueue_f32(jt_ctx *h, const float *in, int64_t n, int rate, int blk, KwJob *job, hipStream_t s, const KwScratch *ext) { kweight_enqueue<float>(h, in, n, rate, blk, job, s, ext); }
 void jt_kweight_enqueue_f64(jt_ctx *h, const double *in, int64_t n, int rate, int blk, KwJob *job, hipStream_t s, const KwScratch *ext) { kweight_enqueue<double>(h, in, n, rate, blk, job, s, ext); }
 void jt_kweight_finish(const KwJob *job, std::vector<double> &sums, std::vector<double> &peaks)
 {
-    const int64_t nfull = job->nfull, nchunks = job->nchunks;
-    sums.assign((size_t)nfull + 1, 0.0); peaks.assign((size_t)nfull + 1, 0.0);
-    for (int64_t c = 0; c < nchunks; ++c) {
-        const int64_t b = std::min<int64_t>(c / job->m, nfull);
-        sums[(size_t)b] += job->hc[(size_t)c];
-        peaks[(size_t)b] = std::max(peaks[(size_t)b], job->hc[(size_t)(nchunks + c)]);
-    }
+    const int64_t nfull = job->nfull;
+    sums.assign(job->hc, job->hc + (size_t)nfull + 1); peaks.assign(job->hc + (size_t)nfull + 1, job->hc + 2 * ((size_t)nfull + 1));
 }
 
 // ------------------------------------------------------------------ agate -> acompressor -> deesser (double)
@@ -985,6 +997,45 @@ k_absmax_copy_f64(const double *__restrict__ in, double *__restrict__ out, int64
         for (int off = 32; off > 0; off >>= 1) m = fmax(m, __shfl_down(m, off, 64));
         if (lane == 0) out_max[b] = m;
     }
+}
+// The same sweep fed by the s16 Pass-2 output (the limiter prefix of Pass 3 / Pass 4: volume -> alimiter): the s16 -> dbl conversion of
+// k_s16_to_f64 (same arithmetic, incl. the float-precision volume stage) is done here, `conv` receives the converted signal the
+// limiter's hot segments read, `out` = conv * gain.  Saves a launch and one 8-byte read per sample on the Pass-3 critical path.
+__global__ void __launch_bounds__(256)
+k_absmax_conv_s16(const int16_t *__restrict__ in, double *__restrict__ conv, double *__restrict__ out, int64_t n, double vol, int vol_in_float,
+                  double gain, double *__restrict__ out_max, int64_t nblk)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t w = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    auto cv = [&](int16_t x) -> double {
+        if (vol_in_float) { float v = (float)x * (1.0f / 32768.0f); v = v * (float)vol; return (double)v; }
+        return (double)x * (1.0 / 32768.0) * vol;
+    };
+    for (int q = 0; q < 8; ++q) {
+        const int64_t b = w * 8 + q;
+        if (b >= nblk) return;
+        const int64_t base = b * 256;
+        double m = 0.0;
+        if (base + 256 <= n) {
+            const short4 x = *reinterpret_cast<const short4 *>(in + base + 4 * lane);           // (base is a multiple of 256: 8-byte aligned)
+            const double v0 = cv(x.x), v1 = cv(x.y), v2 = cv(x.z), v3 = cv(x.w);
+            m = fmax(fmax(fabs(v0), fabs(v1)), fmax(fabs(v2), fabs(v3)));
+            *reinterpret_cast<double2 *>(conv + base + 4 * lane) = double2{v0, v1};
+            *reinterpret_cast<double2 *>(conv + base + 4 * lane + 2) = double2{v2, v3};
+            *reinterpret_cast<double2 *>(out + base + 4 * lane) = double2{v0 * gain, v1 * gain};
+            *reinterpret_cast<double2 *>(out + base + 4 * lane + 2) = double2{v2 * gain, v3 * gain};
+        } else {
+            for (int64_t i = base + lane; i < n; i += 64) { const double v = cv(in[i]); m = fmax(m, fabs(v)); conv[i] = v; out[i] = v * gain; }
+        }
+        for (int off = 32; off > 0; off >>= 1) m = fmax(m, __shfl_down(m, off, 64));
+        if (lane == 0) out_max[b] = m;
+    }
+}
+void launch_absmax_conv_s16(const int16_t *in, double *conv, double *out, int64_t n, double vol, int vol_in_float, double gain, double *out_max,
+                            int64_t nblk, hipStream_t s)
+{
+    if (nblk <= 0) return;
+    hipLaunchKernelGGL(k_absmax_conv_s16, dim3((unsigned)((nblk + 31) / 32)), dim3(256), 0, s, in, conv, out, n, vol, vol_in_float, gain, out_max, nblk);
 }
 void launch_absmax_copy_f64(const double *in, double *out, int64_t n, double gain, double *out_max, int64_t nblk, hipStream_t s)
 {

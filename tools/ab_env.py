@@ -1,5 +1,5 @@
 """A/B of an environment switch inside ONE process (alternating runs, so clocks and box are shared): declick / step times.
-usage: ab_env.py JT_DK_NO_XCD [runs]"""
+usage: ab_env.py JT_DK_NO_XCD [runs] [plosives per minute: 40 = the bench talker (limiter prefix branch)]"""
 import os, sys
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 sys.path.insert(0, "/root/repo")
@@ -7,7 +7,8 @@ import numpy as np, torch
 from jivetalking_amd import Engine, synth, hostlogic
 var = sys.argv[1]; n_runs = int(sys.argv[2]) if len(sys.argv) > 2 else 8
 sr = 48000
-x = synth.speech_like_torch(3600.0, sr, seed=1000, device="cuda:0")
+pl = float(sys.argv[3]) if len(sys.argv) > 3 else 0.0
+x = synth.speech_like_torch(3600.0, sr, seed=1000, device="cuda:0", plosives_per_min=pl)
 e = Engine(0)
 e.attach_device_pcm(x.data_ptr(), x.numel(), sr, 1, keepalive=x)
 base = hostlogic.default_config()
