@@ -146,24 +146,25 @@ template <typename T> __device__ inline void store_quad(T *p, T a, T b, T c, T d
 // L2 evicts them half-filled; the kernel ran at the HBM write rate, whatever fed the FMAs).  A wave therefore collects 16 consecutive
 // outputs of each of its 64 x NW windows in an LDS tile ([NW][64][17]) and writes them out line-wise: lane = 4 * window-in-sixteen +
 // quarter, one store instruction covers sixteen windows x 64 contiguous bytes (f32; 128 for f64).
-template <typename TIn, typename TAcc, typename TTap, int NW, int NWV = 4>
+template <typename TIn, typename TAcc, typename TTap, int NW, int NWV = 4, int CHN = 16>
 __device__ inline void upsample32_stream_quads(const TIn *xin, const TTap *__restrict__ bank, int P, int step, int64_t m_lo, int64_t m_total,
                                                double in_scale, int skewed, TAcc *__restrict__ out_stream, TAcc *otile_all)
 {
-    constexpr int L = 32, CH = 16, OS = CH + 1;
+    constexpr int L = 32, CH = CHN, OS = CH + 1, QPW = CH / 4;         // QPW quads per window in a chunk: 64 / QPW windows per store instruction
+    static_assert(CH == 16 || CH == 8, "chunk length");
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // uniform: scalar taps
     TAcc *ot = otile_all + (size_t)wave * NW * 64 * OS;
     const unsigned uP = (unsigned)P, ustep = (unsigned)step;
     const int JW = P / NWV, jw0 = wave * JW, jw1 = jw0 + JW;              // JW is a multiple of 4: chunks start on 16-byte boundaries
     const int off_first = (int)(((unsigned)jw0 * ustep) / uP), off_last = (int)(((unsigned)(jw1 - 1) * ustep) / uP);
     // write-out of the chunk [jc0, jc0 + cnt): window rw of sixteen, quad c
-    const int rw = lane >> 2, c4 = (lane & 3) * 4;
+    const int rw = lane / QPW, c4 = (lane % QPW) * 4;
     auto flush = [&](int jc0, int cnt) {
 #pragma unroll
         for (int w = 0; w < NW; ++w) {
 #pragma unroll
-            for (int it = 0; it < 4; ++it) {
-                const int win = 16 * it + rw;
+            for (int it = 0; it < QPW; ++it) {
+                const int win = (64 / QPW) * it + rw;
                 const TAcc *src = ot + ((size_t)w * 64 + win) * OS + c4;
                 const TAcc v0 = src[0], v1 = src[1], v2 = src[2], v3 = src[3];
                 const int64_t m_base = m_lo + (int64_t)P * (w * 64 + win);
@@ -359,11 +360,7 @@ k_upsample32(const TIn *__restrict__ in, int64_t n, const TTap *__restrict__ ban
             jlim[u] = left <= 0 ? 0 : (left >= (int64_t)P ? P : (int)left);
         }
         int ph = (int)(((unsigned)j_lo * ustep) % uP);
-        for (int j = j_lo; j < j_hi; ++j) {
-            const TTap *f = bank + (size_t)(unsigned)ph * L;
-            TTap tp[L];
-#pragma unroll
-            for (int i = 0; i < L; ++i) tp[i] = f[i];
+        auto row = [&](const TTap (&tp)[L], int j) {
             // tap-major, window-minor: the QL accumulation chains advance together (each chain keeps its ascending tap order), so
             // consecutive FMAs are independent
             TAcc val[QL];
@@ -379,6 +376,18 @@ k_upsample32(const TIn *__restrict__ in, int64_t n, const TTap *__restrict__ ban
                 if (MODE == 0) vmax[u] = j < jlim[u] ? fmax(vmax[u], fabs(val[u])) : vmax[u];
                 else if (j < jlim[u]) out_stream[m_base + (int64_t)P * u + j] = val[u];
             }
+        };
+        auto fetch_row = [&](TTap (&tp)[L], int phase) {
+            const TTap *f = bank + (size_t)(unsigned)phase * L;
+#pragma unroll
+            for (int i = 0; i < L; ++i) tp[i] = f[i];
+        };
+        // (requesting the next row's taps before this row's FMAs, as the stream variant does, made these instances SLOWER: 3.0 -> 3.5 ms
+        // and 3.5 -> 3.7 ms -- with four waves per SIMD the scalar round trip is already covered and the second row of SGPRs spills)
+        for (int j = j_lo; j < j_hi; ++j) {
+            TTap tp[L];
+            fetch_row(tp, ph);
+            row(tp, j);
             ph += step; ph -= ph >= P ? P : 0;
         }
         if (MODE == 0) {
@@ -433,13 +442,14 @@ k_upsample32(const TIn *__restrict__ in, int64_t n, const TTap *__restrict__ ban
 
 // The stream upsampler with eight waves per workgroup, for sources whose tile leaves room for one workgroup per CU only (f64: a tile
 // of 64 windows x 147 samples is 75 KB).  With one window per lane a row is 32 dependent FMAs, so a SIMD needs a second wave to keep
-// issuing: four waves per CU ran at 10 ms for the hour-long stream, eight at half that.
-template <typename TIn, typename TAcc, typename TTap>
-__global__ void __launch_bounds__(512)
+// issuing: four waves per CU ran at 10 ms for the hour-long stream, eight at half that, SIXTEEN (four per SIMD; the output chunks
+// halved to eight samples so that sixteen [64][9] tiles fit beside the input tile, 149 KB) at 3.3 ms instead of 4.3.  93 VGPRs.
+template <typename TIn, typename TAcc, typename TTap, int NWV = 8, int CHN = 16>
+__global__ void __launch_bounds__(64 * NWV)
 k_upsample32_stream8(const TIn *__restrict__ in, int64_t n, const TTap *__restrict__ bank, int P, int center, int step, int64_t m_total,
                      double in_scale, TAcc *__restrict__ out_stream)
 {
-    constexpr int L = 32;
+    constexpr int L = 32, NT = 64 * NWV;
     extern __shared__ unsigned char smem_pp[];
     TIn *xin = reinterpret_cast<TIn *>(smem_pp);
     const int T = 64 * step, nin = T + L;
@@ -449,9 +459,9 @@ k_upsample32_stream8(const TIn *__restrict__ in, int64_t n, const TTap *__restri
     if (m_lo >= m_total) return;
     if (s0 - center >= 0 && s0 - center + nin <= n) {
         const TIn *src = in + (s0 - center);                         // interior workgroup: no reflection, no end of stream
-        for (int i = tid; i < nin; i += 512) xin[i] = src[i];
+        for (int i = tid; i < nin; i += NT) xin[i] = src[i];
     } else {
-        for (int i = tid; i < nin; i += 512) {
+        for (int i = tid; i < nin; i += NT) {
             int64_t g = s0 - center + i;
             TIn v = (TIn)0;
             if (g < 0) g = -g;                                       // invert_initial_buffer(): in[-j] = in[j]
@@ -462,7 +472,7 @@ k_upsample32_stream8(const TIn *__restrict__ in, int64_t n, const TTap *__restri
     }
     __syncthreads();
     TAcc *otile = reinterpret_cast<TAcc *>(smem_pp + (((size_t)(nin + 4) * sizeof(TIn) + 15) & ~(size_t)15));
-    upsample32_stream_quads<TIn, TAcc, TTap, 1, 8>(xin, bank, P, step, m_lo, m_total, in_scale, 0, out_stream, otile);
+    upsample32_stream_quads<TIn, TAcc, TTap, 1, NWV, CHN>(xin, bank, P, step, m_lo, m_total, in_scale, 0, out_stream, otile);
 }
 
 template <typename TIn, typename TAcc, typename TTap, int MODE>
@@ -477,7 +487,16 @@ static bool launch_upsample32(const TIn *in, int64_t n, const TTap *bank, int P,
         for (int r = 2; r > 1; r >>= 1) if (sizeof(TIn) * (size_t)(64 * r * step + 64) <= 80 * 1024) { R = r; break; }
     if constexpr (MODE == 2) {
         if (ql == 1 && R == 1 && (P & 31) == 0 && (step & 1) && !getenv("JT_UPS_NO_STREAM8")) {
-            const size_t sm8 = ((sizeof(TIn) * (size_t)(64 * step + 32 + 4) + 15) & ~(size_t)15) + sizeof(TAcc) * (size_t)8 * 64 * 17;
+            const size_t tile8 = (sizeof(TIn) * (size_t)(64 * step + 32 + 4) + 15) & ~(size_t)15;
+            const size_t sm16 = tile8 + sizeof(TAcc) * (size_t)16 * 64 * 9;
+            if ((P % 64) == 0 && sm16 <= 150 * 1024 && !getenv("JT_UPS_NO_STREAM16")) {
+                auto k16 = k_upsample32_stream8<TIn, TAcc, TTap, 16, 8>;
+                JT_HIP(hipFuncSetAttribute((const void *)k16, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm16));
+                const int64_t pb = (int64_t)64 * P;
+                hipLaunchKernelGGL(k16, dim3((unsigned)((m_total + pb - 1) / pb)), dim3(1024), sm16, s, in, n, bank, P, center, (int)step, m_total, in_scale, out);
+                return true;
+            }
+            const size_t sm8 = tile8 + sizeof(TAcc) * (size_t)8 * 64 * 17;
             if (sm8 <= 150 * 1024) {
                 auto k8 = k_upsample32_stream8<TIn, TAcc, TTap>;
                 JT_HIP(hipFuncSetAttribute((const void *)k8, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm8));
