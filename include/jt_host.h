@@ -106,7 +106,8 @@ typedef struct {
     int gate_enabled; double gate_threshold, gate_ratio, gate_attack, gate_release, gate_range, gate_knee, gate_makeup; int gate_detection_set;
     int comp_enabled; double comp_threshold_db, comp_ratio, comp_attack, comp_release, comp_makeup_db, comp_knee, comp_mix;
     int deess_enabled; double deess_intensity, deess_amount, deess_frequency;
-    int adeclick_enabled; double adeclick_threshold, adeclick_window, adeclick_overlap; int adeclick_method_s;
+    int adeclick_enabled; double adeclick_threshold, adeclick_window, adeclick_overlap;
+    int adeclick_method_s;         /* AdeclickConfig.Method (filters.go:240-246,958-960): 1 = "s" (the default config), 0 = "" (option omitted: af_adeclick.c's m=a), 2 = "a" */
     int loudnorm_enabled; double target_i, target_tp, target_lra; int dual_mono, linear;
 } jt_host_config;
 

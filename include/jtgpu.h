@@ -307,7 +307,8 @@ int jt_op_alimiter_f64(jt_ctx *h, const double *in, double *out, int64_t n, int 
  * printed as 0.00: the reference's "fell back to dynamic" case, normalise.go:687-693).  ap: I / TP / LRA, measured_*, offset (dB) as in
  * the filter's options; the adeclick / brickwall fields are ignored.  Shorter than 3 s: the filter's own one-gain branch. */
 int jt_op_loudnorm_dynamic_f64(jt_ctx *h, const double *in192, int64_t n, const jt_loudnorm_apply *ap, double *out192, jt_loudnorm_stats *stats);
-/* adeclick=t:w:o[:m=s] on a double stream (af_adeclick.c; arorder=2, burst=2 defaults).  method: 1 = overlap-save. */
+/* adeclick=t:w:o[:m=s] on a double stream (af_adeclick.c; arorder=2, burst=2 defaults).  method: 1 = overlap-save (m=s, what
+ * filters.go:513-521 configures), 0 = overlap-add (m=a, FFmpeg's own default: the sequential-order kernel + a product buffer). */
 int jt_op_adeclick_f64(jt_ctx *h, const double *in, double *out, int64_t n, int sr, double threshold, double window_ms,
                        double overlap_pct, int method, int64_t *n_repaired);
 int jt_op_resample_f32_to_s16(jt_ctx *h, const float *in, int64_t n, int in_rate, int out_rate,

@@ -516,7 +516,15 @@ func defaultsToC(d *filterConfigDefaults) C.jt_host_config {
 	s := d.Deesser
 	c.deess_enabled, c.deess_intensity, c.deess_amount, c.deess_frequency = b2i(s.Enabled), C.double(s.Intensity), C.double(s.Amount), C.double(s.Frequency)
 	a := d.Adeclick
-	c.adeclick_enabled, c.adeclick_threshold, c.adeclick_window, c.adeclick_overlap, c.adeclick_method_s = b2i(a.Enabled), C.double(a.Threshold), C.double(a.Window), C.double(a.Overlap), b2i(a.Method == "s")
+	c.adeclick_enabled, c.adeclick_threshold, c.adeclick_window, c.adeclick_overlap = b2i(a.Enabled), C.double(a.Threshold), C.double(a.Window), C.double(a.Overlap)
+	switch a.Method { // "" leaves the option out: af_adeclick.c's own default, overlap-add
+	case "s":
+		c.adeclick_method_s = 1
+	case "a":
+		c.adeclick_method_s = 2
+	default:
+		c.adeclick_method_s = 0
+	}
 	l := d.Loudnorm
 	c.loudnorm_enabled, c.target_i, c.target_tp, c.target_lra, c.dual_mono, c.linear = b2i(l.Enabled), C.double(l.TargetI), C.double(l.TargetTP), C.double(l.TargetLRA), b2i(l.DualMono), b2i(l.Linear)
 	return c
@@ -537,8 +545,10 @@ func effectiveConfigFromC(c *C.jt_host_config) *EffectiveFilterConfig {
 		det = "rms"
 	}
 	method := ""
-	if c.adeclick_method_s != 0 {
+	if c.adeclick_method_s == 1 {
 		method = "s"
+	} else if c.adeclick_method_s == 2 {
+		method = "a"
 	}
 	d := filterConfigDefaults{
 		Downmix:          DownmixConfig{Enabled: c.downmix_enabled != 0},

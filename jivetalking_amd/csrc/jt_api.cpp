@@ -1197,7 +1197,7 @@ extern "C" int jt_pass4(jt_ctx *h, const jt_limiter_plan *lim, const jt_loudnorm
         JT_HIP(hipMemsetAsync(h->declick_stats.p, 0, 16 * sizeof(unsigned long long), h->stream));
         JT_HIP(hipEventRecord(h->ev2, h->stream));
         launch_adeclick(h, sig, tmp, m, rate, ap->adeclick_threshold, ap->adeclick_window_ms, ap->adeclick_overlap_pct, 2.0, 2.0, gain,
-                        h->declick_stats.p, h->stream);
+                        h->declick_stats.p, h->stream, ap->adeclick_method);
         JT_HIP(hipEventRecord(h->ev3, h->stream));
         unsigned long long *hs = h->pin.take<unsigned long long>(16);
         JT_HIP(hipMemcpyAsync(hs, h->declick_stats.p, 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));
@@ -1469,7 +1469,7 @@ extern "C" int jt_op_adeclick_f64(jt_ctx *h, const double *in, double *out, int6
     DevBuf<double> a, b; h2d(h, a, in, (size_t)n); b.ensure((size_t)n);
     h->declick_stats.ensure(16);
     JT_HIP(hipMemsetAsync(h->declick_stats.p, 0, 16 * sizeof(unsigned long long), h->stream));
-    launch_adeclick(h, a.p, b.p, n, sr, threshold, window_ms, overlap_pct, 2.0, 2.0, 1.0, h->declick_stats.p, h->stream);
+    launch_adeclick(h, a.p, b.p, n, sr, threshold, window_ms, overlap_pct, 2.0, 2.0, 1.0, h->declick_stats.p, h->stream, method);
     unsigned long long st[16] = {0};
     JT_HIP(hipMemcpyAsync(st, h->declick_stats.p, sizeof(st), hipMemcpyDeviceToHost, h->stream));
     d2h(h, out, b.p, (size_t)n);

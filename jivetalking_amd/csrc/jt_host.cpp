@@ -966,7 +966,8 @@ extern "C" int jt_host_pass4_spec(const jt_host_config *cfg, const jt_loudnorm_s
     if (source_rate > 0) join(s, sfmt("aresample=%d", source_rate));
     if (cfg->adeclick_enabled) {
         std::string a = sfmt("adeclick=t=%.1f:w=%.0f:o=%.0f", cfg->adeclick_threshold, cfg->adeclick_window, cfg->adeclick_overlap);
-        if (cfg->adeclick_method_s) a += ":m=s";
+        if (cfg->adeclick_method_s == 1) a += ":m=s";                  // AdeclickConfig.Method: "" -> nothing (af_adeclick.c defaults to m=a), "s", "a"
+        else if (cfg->adeclick_method_s == 2) a += ":m=a";
         join(s, a);
     }
     join(s, sfmt("alimiter=limit=%.6f:attack=1:release=50:level_in=1:level_out=1:level=0:latency=1:asc=1:asc_level=0.8", DbToLinear(brickDB)));
@@ -983,7 +984,7 @@ extern "C" int jt_host_pass4_spec(const jt_host_config *cfg, const jt_loudnorm_s
         ap->offset = qfmt("%.2f", offset);
         ap->adeclick_enabled = cfg->adeclick_enabled; ap->adeclick_threshold = qfmt("%.1f", cfg->adeclick_threshold);
         ap->adeclick_window_ms = qfmt("%.0f", cfg->adeclick_window); ap->adeclick_overlap_pct = qfmt("%.0f", cfg->adeclick_overlap);
-        ap->adeclick_method = cfg->adeclick_method_s ? 1 : 0;
+        ap->adeclick_method = cfg->adeclick_method_s == 1 ? 1 : 0;
         ap->brickwall_limit = qfmt("%.6f", DbToLinear(brickDB));
     }
     return (int)s.size();

@@ -161,7 +161,7 @@ void launch_loudnorm_dynamic(const double *x, int64_t n, const LoudnormDynParams
 void launch_scale_f64(const double *in, double *out, int64_t n, double g, hipStream_t s);
 void launch_swr_plain_f64(const double *in, int64_t n, const double *bank, int P, int L, int center, int64_t step, int64_t m_total, double *out, hipStream_t s);
 void launch_adeclick(jt_ctx *h, const double *in, double *out, int64_t n, int sample_rate, double threshold, double window_ms,
-                     double overlap_pct, double ar_pct, double burst, double gain, unsigned long long *d_stats, hipStream_t s);
+                     double overlap_pct, double ar_pct, double burst, double gain, unsigned long long *d_stats, hipStream_t s, int method = 1);
 
 // FLAC encoder (k_flac.hip): analyse + scan fill recs/offs/summary, emit writes the frames at their byte offsets
 size_t jt_flac_rec_bytes(int64_t nframes);
@@ -310,7 +310,7 @@ struct jt_ctx {
     RegionSlot region_slot[2];
     DevBuf<double> declick_scr; DevBuf<unsigned long long> declick_stats; DevBuf<int> declick_heavy;
     // adeclick's split pipeline (front kernel -> solver kernels, k_declick.hip): per-window flagged count, index list, right-hand side, aux
-    DevBuf<int> declick_F, declick_lists; DevBuf<unsigned short> declick_idx; DevBuf<double> declick_rhs, declick_aux, declick_r;
+    DevBuf<int> declick_F, declick_lists; DevBuf<unsigned short> declick_idx; DevBuf<double> declick_rhs, declick_aux, declick_r, declick_wlut, declick_prod;
     DevBuf<unsigned long long> declick_ctl;
     hipStream_t dk_stream = nullptr; hipEvent_t dk_ev[2] = {nullptr, nullptr};
     // Pass 3 with the limiter prefix, started inside Pass 2 once its loudness / true peak are known (jt_pass3_plan_hook)

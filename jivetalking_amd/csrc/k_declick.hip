@@ -33,6 +33,11 @@ struct DeclickParams {
     int nw;                       // flag words kept per window (fast kernel)
     double threshold, gain;
     int64_t nwindows;
+    // method 'a' (overlap-add, af_adeclick.c filter_channel: buf[j] += dst[j] * window_func_lut[j]): every window's W products go to
+    // `prod` (wp doubles per window), k_dk_overlap_add sums them per output sample in window order.  method 1 = 's' (overlap-save).
+    int method, wp;
+    const double *wlut;            // [W] sin(pi i / W) * (1 - overlap) * pi / 2
+    double *prod;                  // [nwindows * wp]
 };
 
 // Buffers of the split pipeline (front kernel -> solver kernels): per window a fixed slot of `wp` entries.
@@ -482,10 +487,11 @@ k_adeclick(const double *__restrict__ in, double *__restrict__ out, int64_t n, D
                     // lanes 0..15 now hold the solutions of rows ib-15 .. ib: park them in LDS (the factorisation block is dead)
                     if (lane < 16 && ib - 15 + lane >= 0) blk[ib - 15 + lane] = sw;
                 }
-                // repaired samples of this window's output hop, all at once
+                // repaired samples of this window's output hop, all at once (overlap-add: of the whole window, weighted)
                 for (int e = lane; e < F; e += 64) {
                     const int pos = index[e];
-                    if (pos >= P.skip && pos < P.skip + P.hop && o0 + (pos - P.skip) < n) out[o0 + (pos - P.skip)] = blk[e];
+                    if (P.method == 0) P.prod[(size_t)w * P.wp + pos] = __dmul_rn(blk[e], P.wlut[pos]);
+                    else if (pos >= P.skip && pos < P.skip + P.hop && o0 + (pos - P.skip) < n) out[o0 + (pos - P.skip)] = blk[e];
                 }
                 repaired += (lane == 0) ? (unsigned long long)F : 0ull;
             } else {
@@ -495,6 +501,16 @@ k_adeclick(const double *__restrict__ in, double *__restrict__ out, int64_t n, D
         DK_MARK(6)
         // ---- 11. overlap-save output of the samples that were not repaired: out[w*hop + j] = src[skip + j]
         const bool rep = F > 0 && ok;
+        if (P.method == 0) {
+            // overlap-add: dst[pos] * lut[pos] of every window sample that was not repaired
+            for (int pos = lane; pos < W; pos += 64) {
+                if (rep && fbit(pos)) continue;
+                const int64_t p = s0 + pos;
+                const double v = (p >= 0 && p < n) ? __dmul_rn(in[p], P.gain) : 0.0;
+                P.prod[(size_t)w * P.wp + pos] = __dmul_rn(v, P.wlut[pos]);
+            }
+            continue;
+        }
         for (int j = lane; j < P.hop; j += 64) {
             const int64_t o = o0 + j;
             const int pos = P.skip + j;
@@ -1523,28 +1539,56 @@ k_dk_solve(double *__restrict__ out, int64_t n, DeclickParams P, DkSplit S, doub
 }
 
 // host side --------------------------------------------------------------------------------------------------------
+// Overlap-add of method 'a': af_adeclick.c adds every window's W weighted samples into a buffer that starts at zero and hands out the
+// first hop of it, so output sample p = k * hop + j is ((0 + c[k - i_max]) + ...) + c[k], c[k - i] = window (k - i)'s product at offset
+// j + i * hop, the windows in the order they were processed (one add per window, unfused).
+__global__ void __launch_bounds__(256)
+k_dk_overlap_add(const double *__restrict__ prod, double *__restrict__ out, int64_t n, int hop, int W, int wp)
+{
+    const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (p >= n) return;
+    const int64_t k = p / hop; const int j = (int)(p - k * hop);
+    double acc = 0.0;
+    for (int i = (W - 1 - j) / hop; i >= 0; --i) {
+        if (k - i < 0) continue;
+        acc = __dadd_rn(acc, prod[(size_t)(k - i) * wp + j + i * hop]);
+    }
+    out[p] = acc;
+}
+
 bool jt_adeclick_supported(int sample_rate, double window_ms, double overlap_pct, double ar_pct, int method, std::string *why)
 {
     int W = (int)(sample_rate * window_ms / 1000.); if (W < 100) W = 100;
     int ar = (int)(W * ar_pct / 100.); if (ar < 1) ar = 1;
     (void)overlap_pct;
-    if (method != 1) { if (why) *why = "adeclick: only the overlap-save method (m=s) is built"; return false; }
+    if (method != 0 && method != 1) { if (why) *why = "adeclick: method must be 0 (overlap-add, m=a) or 1 (overlap-save, m=s)"; return false; }
     if (W > dk::MAXW) { if (why) *why = "adeclick: window too long for this build"; return false; }
     if (ar > dk::MAXAR) { if (why) *why = "adeclick: AR order above 48 is not built"; return false; }
     return true;
 }
 
 void launch_adeclick(jt_ctx *h, const double *in, double *out, int64_t n, int sample_rate, double threshold, double window_ms,
-                     double overlap_pct, double ar_pct, double burst, double gain, unsigned long long *d_stats, hipStream_t s)
+                     double overlap_pct, double ar_pct, double burst, double gain, unsigned long long *d_stats, hipStream_t s, int method)
 {
     DeclickParams P;
     P.W = (int)(sample_rate * window_ms / 1000.); if (P.W < 100) P.W = 100;
     P.ar = (int)(P.W * ar_pct / 100.); if (P.ar < 1) P.ar = 1;
     P.nburst = (int)(P.W * burst / 1000.);
     P.hop = (int)(P.W * (1. - (overlap_pct / 100.))); if (P.hop < 1) P.hop = 1;
-    P.skip = (P.W - P.hop) / 2;
+    P.skip = method ? (P.W - P.hop) / 2 : 0;
     P.threshold = threshold; P.gain = gain;
     P.nwindows = (n + P.hop - 1) / P.hop;
+    P.method = method; P.wp = (P.W + 7) & ~7; P.wlut = nullptr; P.prod = nullptr;
+    if (method == 0) {
+        // overlap-add is not the reference's configuration (filters.go:513-521 sets m=s): it takes the sequential-order kernel, which has
+        // two output sites, and pays a product buffer of W doubles per window
+        std::vector<double> lut((size_t)P.W);
+        for (int i = 0; i < P.W; ++i) lut[(size_t)i] = std::sin(M_PI * i / P.W) * (1. - (overlap_pct / 100.)) * M_PI_2;
+        h->declick_wlut.ensure((size_t)P.W); h->declick_prod.ensure((size_t)P.nwindows * P.wp);
+        JT_HIP(hipMemcpyAsync(h->declick_wlut.p, lut.data(), sizeof(double) * (size_t)P.W, hipMemcpyHostToDevice, s));
+        JT_HIP(hipStreamSynchronize(s));                       // (pageable source about to go out of scope)
+        P.wlut = h->declick_wlut.p; P.prod = h->declick_prod.p;
+    }
     constexpr int LIGHT = 512, LBS = 33, MID = 1024;
     // half-window buffer: every +-AR neighbourhood must fit one of the two halves (lb >= (W + 2 AR) / 2), multiple of 8
     P.lb = ((P.W + 2 * P.ar + 1) / 2 + 16 + 7) & ~7;
@@ -1557,7 +1601,7 @@ void launch_adeclick(jt_ctx *h, const double *in, double *out, int64_t n, int sa
     const size_t sm0 = smem_for(sa0, LIGHT, LBS), sm1 = smem_for(sa1, MID, dk::BS), sm2 = smem_for(sa2, dk::MAXW, dk::BS);
     JT_REQUIRE(sm2 <= 64 * 1024, JT_E_UNSUPPORTED, "adeclick: window does not fit the per-wave LDS budget");
     const size_t per_wave = (size_t)P.W * dk::MAXAR + 3 * (size_t)P.W;
-    const bool exact = getenv("JT_ADECLICK_EXACT") != nullptr;      // the bit-exact sequential-order kernel (parity tests / A-B); default: fast
+    const bool exact = getenv("JT_ADECLICK_EXACT") != nullptr || method == 0;   // the bit-exact sequential-order kernel (parity tests / A-B, m=a); default: fast
     h->declick_heavy.ensure(2 * (size_t)P.nwindows + 192);
     if (getenv("JT_DK_PROFILE")) JT_HIP(hipMemsetAsync(h->declick_heavy.p + 2 * P.nwindows, 0, 192 * sizeof(int), s));
 #define DK_LAUNCH(KERN, GRID, SMEM, PP) do { auto k_ = KERN; \
@@ -1689,6 +1733,7 @@ void launch_adeclick(jt_ctx *h, const double *in, double *out, int64_t n, int sa
         DK_LAUNCH((k_adeclick<MID, dk::BS, false, 1>), g1, sm1, P1);
     }
     DK_LAUNCH((k_adeclick<dk::MAXW, dk::BS, false, 2>), g2, sm2, P2);
+    if (method == 0) hipLaunchKernelGGL(k_dk_overlap_add, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, P.prod, out, n, P.hop, P.W, P.wp);
 #undef DK_LAUNCH
 #undef DKF_LAUNCH
 }

@@ -294,6 +294,29 @@ def test_adeclick_other_thresholds_and_rates(engine, oracle, exact):
         assert ei.value.code == L.JT_E_UNSUPPORTED
 
 
+def test_adeclick_overlap_add_method_is_bit_exact(engine, oracle):
+    """adeclick m=a (af_adeclick.c's own default; the reference sets m=s, filters.go:513-521, and exposes Method to callers,
+    filters.go:958-960): every window is weighted by the sine lookup and added into the output in window order.  The build routes it
+    through the sequential-order kernel, so the bar is bit-identity with the oracle -- speech with many repairs, 75 % overlap (four
+    windows per sample), clicks on a tone, ragged lengths around the hop / window, silence."""
+    x = (speech(4.0, 13, 44100) * 3.0).astype(np.float64)
+    ref, nref = oracle.adeclick(x, 44100, 1.7, 55.0, 50.0, method="a", return_count=True)
+    got, ngot = engine.op_adeclick(x, 44100, 1.7, 55.0, 50.0, method="a", return_count=True)
+    assert nref > 1000 and ngot == nref and np.array_equal(got, ref)
+    assert not np.array_equal(ref, oracle.adeclick(x, 44100, 1.7, 55.0, 50.0, method="s"))     # (it is a different filter)
+    y = (speech(2.0, 14, 48000) * 2.0).astype(np.float64)
+    assert np.array_equal(engine.op_adeclick(y, 48000, 1.7, 40.0, 75.0, method="a"), oracle.adeclick(y, 48000, 1.7, 40.0, 75.0, method="a"))
+    sr = 44100
+    t = np.arange(sr // 2) / sr
+    z = 0.3 * np.sin(2 * np.pi * 220 * t); z[9000] += 0.5; z[9001] -= 0.4
+    assert np.array_equal(engine.op_adeclick(z, sr, method="a"), oracle.adeclick(z, sr, method="a"))
+    for n in (1, 100, 1212, 1213, 2425, 2426, 5000):
+        v = noise(n, 0.05, n).astype(np.float64)
+        assert np.array_equal(engine.op_adeclick(v, sr, method="a"), oracle.adeclick(v, sr, method="a")), n
+    q = np.zeros(6000)
+    assert np.array_equal(engine.op_adeclick(q, sr, method="a"), oracle.adeclick(q, sr, method="a"))
+
+
 # ---------------------------------------------------------------- resampler + s16
 def test_resample_48k_to_44k1_s16_matches_oracle(engine, oracle):
     x = speech(5.0, 11)

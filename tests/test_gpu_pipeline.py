@@ -95,6 +95,26 @@ def test_pass3_pass4_match_oracle(processed, oracle):
     assert d.max() <= 1 and np.count_nonzero(d) <= 2, (d.max(), np.count_nonzero(d))
 
 
+def test_pass4_with_adeclick_method_omitted_runs_overlap_add(engine, oracle):
+    """AdeclickConfig.Method == "" (filters.go:958-960 appends m= only when set): af_adeclick.c then runs its default, overlap-add.  The
+    whole four-pass job with that setting against the oracle's Pass-4 chain composed with method 'a'."""
+    x = synth.speech_like(20.0, SR, seed=21)
+    engine.upload_pcm(x, SR, 1)
+    base = H.default_config(); base.adeclick_method_s = 0
+    res = H.process_audio(engine, base)
+    spec = res.pass4_spec.decode()
+    assert "adeclick=t=1.7:w=55:o=50," in spec and ":m=s" not in spec
+    p2, p4 = engine.download_s16(2), engine.download_s16(4)
+    assert res.limiter.needed == 0 and res.loudnorm.normalization_type_dynamic == 0
+    gain = 10 ** ((res.effective_target_i - res.measure.input_i) / 20.0)
+    y, repaired = oracle.adeclick(p2.astype(np.float64) / 32768.0 * gain, 44100, 1.7, 55.0, 50.0, method="a", return_count=True)
+    assert repaired > 0
+    ref = oracle.f64_to_s16(oracle.alimiter(y, 44100, 0.803526, 1.0, 50.0).astype(np.float32).astype(np.float64))
+    assert np.array_equal(ref, p4)                                          # sequential-order kernel + ordered overlap-add: bit-exact
+    engine.upload_pcm(x, SR, 1)
+    assert not np.array_equal(p4, (H.process_audio(engine), engine.download_s16(4))[1])     # (m=s delivers different samples)
+
+
 def test_region_samples_and_specs_present(processed):
     _, res, _, _ = processed
     assert res.pass2_spec.decode().startswith("aformat=channel_layouts=mono,highpass=f=80")
