@@ -366,7 +366,8 @@ def main():
         dk_avg_s = float(np.mean(dk_ms)) / 1e3
         if dk_avg_s > nlm_avg_s:
             dk_bytes = 16 * m                                  # adeclick: read f64 + write f64 per 44.1 kHz sample
-            roof = {"kernel": "k_adeclick", "launches": "k_adeclick_fast<..., MODE 1> (front: fit, detector, right-hand side) + k_dk_solve<32> + k_dk_solve<64> "
+            roof = {"kernel": "k_adeclick", "launches": "k_adeclick_fast<..., MODE 2> (autocorrelation + pass-through copy) -> k_dk_levinson (one lane per window) -> "
+                                                        "k_adeclick_fast<..., MODE 3> (detector, right-hand side) -> k_dk_solve<32> || k_dk_solve<64> "
                                                         "(register-resident LDL^T, two windows / one window per wave) [+ k_adeclick_fast levels 1, 2 for overflow windows]",
                     "bound": "hbm", "achieved": round(dk_bytes / dk_avg_s / 1e9, 2), "peak": 8000,
                     "unit": "GB/s", "frac": round(dk_bytes / dk_avg_s / 1e9 / 8000, 5), "traffic": None,
@@ -387,7 +388,7 @@ def main():
             pmc = pj["kernels"]
             sha = lambda f: hashlib.sha256(open(os.path.join(ROOT, "jivetalking_amd", "csrc", f), "rb").read()).hexdigest()[:16]
             fresh = {f: pj.get("source_sha16", {}).get(f) == sha(f) for f in ("k_declick.hip", "k_nlm.hip")}
-            for r_, src, pref in ((roof, "k_declick.hip", ("k_adeclick", "k_dk_solve")), (nlm_roof, "k_nlm.hip", ("k_anlmdn_pair3",))):
+            for r_, src, pref in ((roof, "k_declick.hip", ("k_adeclick", "k_dk_solve", "k_dk_levinson")), (nlm_roof, "k_nlm.hip", ("k_anlmdn_pair3",))):
                 if r_ is None:
                     continue
                 if r_["kernel"].startswith("k_anlmdn"):
