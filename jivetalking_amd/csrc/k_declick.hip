@@ -24,6 +24,9 @@ constexpr int MAXW = 4864;        // window samples (110 ms at 44.1 kHz); LDS: 8
 constexpr int MAXAR = 48;         // AR order the sliding block is laid out for (2 % of a 55 ms window at 44.1 kHz)
 constexpr int BS = MAXAR + 1;     // sliding block side
 constexpr int NWORD = MAXW / 64;  // 64-sample flag words per window
+// the sequential-order kernel (k_adeclick) lays its per-lag arrays out for 64 entries and takes AR orders up to 62 (lane = lag, and the
+// lane after the last ring row stores the entering right-hand side): 55 ms windows at 48 kHz are order 52
+constexpr int XMAXAR = 64, XAR_LIMIT = 62, XBS = XAR_LIMIT + 1;
 }
 
 struct DeclickParams {
@@ -83,14 +86,14 @@ k_adeclick(const double *__restrict__ in, double *__restrict__ out, int64_t n, D
     extern __shared__ unsigned char dk_smem[];
     const int lane = threadIdx.x;
     const int W = P.W, AR = P.ar;
-    constexpr int BS = BSD, MAXAR = dk::MAXAR;
+    constexpr int BS = BSD, MAXAR = dk::XMAXAR;
     double *sbuf = reinterpret_cast<double *>(dk_smem);                // window samples [LB] ; later the BS x BS sliding block
     double *rr = sbuf + P.sa;                                           // r[AR+1]
-    double *ac = rr + dk::BS + 1;                                       // acoefficients k[AR+1]
-    double *aux = ac + dk::BS + 1;                                      // aux[AR+1]
-    double *lvec = aux + dk::BS + 1;                                    // pivot column multipliers (bands wider than 10 rows)
-    double *ywin = lvec + dk::BS + 1;                                   // sliding right-hand side / y
-    unsigned long long *obits = reinterpret_cast<unsigned long long *>(ywin + dk::BS + 1);   // [NWORD] detector flags (bit = sample)
+    double *ac = rr + dk::XMAXAR + 2;                                       // acoefficients k[AR+1]
+    double *aux = ac + dk::XMAXAR + 2;                                      // aux[AR+1]
+    double *lvec = aux + dk::XMAXAR + 2;                                    // pivot column multipliers (bands wider than 10 rows)
+    double *ywin = lvec + dk::XMAXAR + 2;                                   // sliding right-hand side / y
+    unsigned long long *obits = reinterpret_cast<unsigned long long *>(ywin + dk::XMAXAR + 2);   // [NWORD] detector flags (bit = sample)
     unsigned long long *fbits = obits + dk::NWORD;                                            // [NWORD] flags after fusion / border clearing
     unsigned short *index = reinterpret_cast<unsigned short *>(fbits + dk::NWORD);          // [FCAP]
     unsigned char *bwv = reinterpret_cast<unsigned char *>(index + FCAP);                    // [FCAP] band width per pivot
@@ -1563,7 +1566,7 @@ bool jt_adeclick_supported(int sample_rate, double window_ms, double overlap_pct
     (void)overlap_pct;
     if (method != 0 && method != 1) { if (why) *why = "adeclick: method must be 0 (overlap-add, m=a) or 1 (overlap-save, m=s)"; return false; }
     if (W > dk::MAXW) { if (why) *why = "adeclick: window too long for this build"; return false; }
-    if (ar > dk::MAXAR) { if (why) *why = "adeclick: AR order above 48 is not built"; return false; }
+    if (ar > dk::XAR_LIMIT) { if (why) *why = "adeclick: AR order above 62 is not built"; return false; }
     return true;
 }
 
@@ -1595,13 +1598,17 @@ void launch_adeclick(jt_ctx *h, const double *in, double *out, int64_t n, int sa
     const bool half_ok = P.lb < P.W && P.ar < P.lb / 4;
     auto sa_for = [&](bool half, int bs) { return ((half ? std::max(P.lb, bs * bs) : std::max(P.W, bs * bs)) + 1) & ~1; };
     auto smem_for = [&](int sa, int fcap, int bs) {
-        return sizeof(double) * (size_t)(sa + 5 * (dk::BS + 1)) + sizeof(unsigned long long) * 2 * dk::NWORD + (size_t)fcap * 3 + 16 + (size_t)bs * (bs - 1);
+        return sizeof(double) * (size_t)(sa + 5 * (dk::XMAXAR + 2)) + sizeof(unsigned long long) * 2 * dk::NWORD + (size_t)fcap * 3 + 16 + (size_t)bs * (bs - 1);
     };
-    const int sa0 = sa_for(half_ok, LBS), sa1 = sa_for(half_ok, dk::BS), sa2 = sa_for(false, dk::BS);
-    const size_t sm0 = smem_for(sa0, LIGHT, LBS), sm1 = smem_for(sa1, MID, dk::BS), sm2 = smem_for(sa2, dk::MAXW, dk::BS);
-    JT_REQUIRE(sm2 <= 64 * 1024, JT_E_UNSUPPORTED, "adeclick: window does not fit the per-wave LDS budget");
-    const size_t per_wave = (size_t)P.W * dk::MAXAR + 3 * (size_t)P.W;
-    const bool exact = getenv("JT_ADECLICK_EXACT") != nullptr || method == 0;   // the bit-exact sequential-order kernel (parity tests / A-B, m=a); default: fast
+    // the bit-exact sequential-order kernel: parity tests / A-B, m=a, and AR orders above the 48 the fast kernels are laid out for
+    // (its overflow levels then carry a 63 x 63 block instead of 49 x 49)
+    const bool wide_ar = P.ar > dk::MAXAR;
+    const bool exact = getenv("JT_ADECLICK_EXACT") != nullptr || method == 0 || wide_ar;
+    const int bsx = wide_ar ? dk::XBS : dk::BS;
+    const int sa0 = sa_for(half_ok, LBS), sa1 = sa_for(half_ok, bsx), sa2 = sa_for(false, bsx);
+    const size_t sm0 = smem_for(sa0, LIGHT, LBS), sm1 = smem_for(sa1, MID, bsx), sm2 = smem_for(sa2, dk::MAXW, bsx);
+    JT_REQUIRE(sm2 <= 64 * 1024 || !exact, JT_E_UNSUPPORTED, "adeclick: window does not fit the per-wave LDS budget");
+    const size_t per_wave = (size_t)P.W * (exact ? dk::XMAXAR : dk::MAXAR) + 3 * (size_t)P.W;
     h->declick_heavy.ensure(2 * (size_t)P.nwindows + 192);
     if (getenv("JT_DK_PROFILE")) JT_HIP(hipMemsetAsync(h->declick_heavy.p + 2 * P.nwindows, 0, 192 * sizeof(int), s));
 #define DK_LAUNCH(KERN, GRID, SMEM, PP) do { auto k_ = KERN; \
@@ -1725,6 +1732,11 @@ void launch_adeclick(jt_ctx *h, const double *in, double *out, int64_t n, int sa
     DeclickParams P0 = P, P1 = P, P2 = P; P0.sa = sa0; P1.sa = sa1; P2.sa = sa2;
     // pass 0: 512 flags / 33 x 33 block per window; pass 1: the windows that overflowed that (bands wider than 32 rows: 7 % of the
     // bench signal), 1024 flags / 49 x 49; pass 2: anything denser still, full capacity.  List lengths are read on the device.
+    if (wide_ar) {
+        if (half_ok) { DK_LAUNCH((k_adeclick<LIGHT, LBS, true, 0>), g0, sm0, P0); DK_LAUNCH((k_adeclick<MID, dk::XBS, true, 1>), g1, sm1, P1); }
+        else { DK_LAUNCH((k_adeclick<LIGHT, LBS, false, 0>), g0, sm0, P0); DK_LAUNCH((k_adeclick<MID, dk::XBS, false, 1>), g1, sm1, P1); }
+        DK_LAUNCH((k_adeclick<dk::MAXW, dk::XBS, false, 2>), g2, sm2, P2);
+    } else {
     if (half_ok) {
         DK_LAUNCH((k_adeclick<LIGHT, LBS, true, 0>), g0, sm0, P0);
         DK_LAUNCH((k_adeclick<MID, dk::BS, true, 1>), g1, sm1, P1);
@@ -1733,6 +1745,7 @@ void launch_adeclick(jt_ctx *h, const double *in, double *out, int64_t n, int sa
         DK_LAUNCH((k_adeclick<MID, dk::BS, false, 1>), g1, sm1, P1);
     }
     DK_LAUNCH((k_adeclick<dk::MAXW, dk::BS, false, 2>), g2, sm2, P2);
+    }
     if (method == 0) hipLaunchKernelGGL(k_dk_overlap_add, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, P.prod, out, n, P.hop, P.W, P.wp);
 #undef DK_LAUNCH
 #undef DKF_LAUNCH

@@ -289,9 +289,24 @@ def test_adeclick_other_thresholds_and_rates(engine, oracle, exact):
         ref, nz = oracle.adeclick(z, 44100, 1.0, 55.0, 50.0, return_count=True)
         assert nz / (z.size / 1212) > 512
         assert same(engine.op_adeclick(z, 44100, 1.0, 55.0, 50.0), ref, z)
-        with pytest.raises(L.JtError) as ei:                             # 55 ms at 48 kHz needs order 52: refused, never approximated
-            engine.op_adeclick(x, 48000, 1.7, 55.0, 50.0)
+        with pytest.raises(L.JtError) as ei:                             # 66 ms at 48 kHz needs order 63: refused, never approximated
+            engine.op_adeclick(x, 48000, 1.7, 66.0, 50.0)
         assert ei.value.code == L.JT_E_UNSUPPORTED
+
+
+def test_adeclick_ar_orders_above_48_take_the_sequential_kernel(engine, oracle):
+    """55 ms windows at 48 kHz (a job whose output stage keeps the source rate: ResampleConfig off) are 2640 samples, AR order 52;
+    65 ms are order 62, the largest the sequential-order kernel lays out.  Bit-identical to the oracle, both methods, including a
+    dense-flag signal whose windows go through the 63 x 63 overflow levels."""
+    x = (speech(3.0, 15, 48000) * 2.0).astype(np.float64)
+    for w, m in ((55.0, "s"), (55.0, "a"), (64.9, "s")):
+        ref, nref = oracle.adeclick(x, 48000, 1.7, w, 50.0, method=m, return_count=True)
+        got, ngot = engine.op_adeclick(x, 48000, 1.7, w, 50.0, method=m, return_count=True)
+        assert nref > 100 and ngot == nref and np.array_equal(got, ref), (w, m)
+    z = noise(16000, 0.05, 78).astype(np.float64)
+    ref, nz = oracle.adeclick(z, 48000, 1.0, 55.0, 50.0, return_count=True)
+    assert nz / (z.size / 1320) > 512
+    assert np.array_equal(engine.op_adeclick(z, 48000, 1.0, 55.0, 50.0), ref)
 
 
 def test_adeclick_overlap_add_method_is_bit_exact(engine, oracle):
