@@ -183,6 +183,33 @@ def saturation_leg(eng, device, base, hostlogic, synth, sr, files, minutes, in_f
     return out
 
 
+def dynamic_batch_leg(eng, device, base, hostlogic, synth, sr, files, minutes, plosives):
+    """The dynamic-loudnorm fallback is one wave walking the frames of a file (k_loudnorm.hip): a single file cannot use the GPU, a
+    batch can - `files` such files at once through jt_process_files_multi, one worker each.  File to file (FLAC in /dev/shm)."""
+    import shutil
+    import tempfile
+    import torch
+    d = tempfile.mkdtemp(prefix="jtdyn", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
+    try:
+        paths = []
+        for k in range(files):
+            x = synth.speech_like_torch(minutes * 60.0, sr, seed=3000 + k, device=f"cuda:{device}", plosives_per_min=plosives, sib_gain=4.0)
+            pcm = (x * 32768.0).round().clamp(-32768, 32767).to(torch.int16).cpu().numpy()
+            pk = os.path.join(d, f"dyn{k:02d}.flac")
+            open(pk, "wb").write(eng.op_flac_encode(pcm, sr, md5=True)); paths.append(pk)
+            del x
+        t0 = time.perf_counter()
+        failed, fr, _ = hostlogic.process_files_multi(paths, devices=(device,), in_flight_per_device=files, base=base, md5=False)
+        wall = time.perf_counter() - t0
+        return {"files": files, "minutes_per_file": minutes, "in_flight": files, "failed": int(failed), "wall_s": round(wall, 2),
+                "xRT_aggregate": round(files * minutes * 60.0 / wall, 1),
+                "dynamic_files": int(sum(1 for i in range(files) if fr[i].rc == 0 and fr[i].result.loudnorm.normalization_type_dynamic)),
+                "note": "throughput of a batch of such files on one GPU (each worker's Pass 4 is one wave on one CU, the workers run side by side); "
+                        "the single-file figure above is the latency"}
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
+
+
 def e2e_legs(eng, x_dev, n, sr, seconds, base, hostlogic, Engine, device):
     """End-to-end legs, reported next to `value` and never part of it (`value` has the input resident in HBM):
       pcie : pinned host f32 file -> H2D -> four passes -> D2H of the s16 output into pinned memory, per file
@@ -259,6 +286,7 @@ def main():
     ap.add_argument("--sat-files", type=int, default=32)
     ap.add_argument("--sat-minutes", type=float, default=10.0)
     ap.add_argument("--sat-in-flight", type=int, default=6)
+    ap.add_argument("--dyn-files", type=int, default=8, help="files of the dynamic-loudnorm batch leg (0 = skip)")
     ap.add_argument("--selftest-spawn", action="store_true", help="exercise the N-rank launch path only (gloo, no GPU work); for tests")
     args = ap.parse_args()
 
@@ -475,6 +503,8 @@ def main():
                                                "mode (normalise.go:687-693 only warns about it)", "ms_per_file": round(min(td) * 1e3, 1), "xRT": round(600.0 / min(td), 1),
                                        "dynamic": int(rd.loudnorm.normalization_type_dynamic), "output_lufs": round(rd.output_lufs, 2), "output_dbtp": round(rd.output_tp_db, 2)}
             del yd
+            if args.dyn_files > 0:
+                out["dynamic_fallback"]["batch"] = dynamic_batch_leg(eng, local_rank, base, hostlogic, synth, sr, args.dyn_files, 10.0, args.plosives)
         if world == 1 and args.e2e and args.channels == 1 and sr == 48000:
             # BASELINE configs[4]: 96 kHz stereo, L != R (down-mix on the device, anlmdn K=576 / S=192, 4096-point afftdn, 96 k -> 44.1 k resampler)
             xs = synth.speech_like_torch(seconds, 96000, seed=1000 + rank, device=f"cuda:{local_rank}", plosives_per_min=args.plosives)

@@ -69,6 +69,7 @@ extern "C" void jt_close(jt_ctx *h)
     if (h->spec_ln.stream) { (void)hipStreamSynchronize(h->spec_ln.stream); (void)hipStreamDestroy(h->spec_ln.stream); }
     if (h->early_p3.pin) (void)hipHostFree(h->early_p3.pin);
     if (h->early_p3.ev[0]) { (void)hipEventDestroy(h->early_p3.ev[0]); (void)hipEventDestroy(h->early_p3.ev[1]); }
+    if (h->dyn_stream) { (void)hipStreamSynchronize(h->dyn_stream); (void)hipStreamDestroy(h->dyn_stream); (void)hipEventDestroy(h->dyn_ev[0]); (void)hipEventDestroy(h->dyn_ev[1]); }
     if (h->dk_stream) { (void)hipStreamSynchronize(h->dk_stream); (void)hipStreamDestroy(h->dk_stream); (void)hipEventDestroy(h->dk_ev[0]); (void)hipEventDestroy(h->dk_ev[1]); }
     if (h->spec_ln.fork) (void)hipEventDestroy(h->spec_ln.fork);
     if (h->spec_ln.pin) (void)hipHostFree(h->spec_ln.pin);
@@ -78,6 +79,7 @@ extern "C" void jt_close(jt_ctx *h)
         if (h->ev_join[i]) (void)hipEventDestroy(h->ev_join[i]);
     }
     delete h;
+    jt_graveyard().drain();                                    // (the frees above have waited for the device anyway)
 }
 
 extern "C" const char *jt_last_error(const jt_ctx *h) { return h ? h->err.c_str() : "null handle"; }
@@ -726,7 +728,7 @@ static void spec_loudnorm_enqueue(jt_ctx *h, const int16_t *s16, int64_t n, int 
     size_t dev_d = 0, pin_d = 0; jt_kweight_scratch_sizes(m_meter, blk, &dev_d, &pin_d);
     S.dev.ensure(dev_d);
     if (pin_d > S.pin_cap) {
-        if (S.pin) JT_HIP(hipHostFree(S.pin));
+        if (S.pin) jt_graveyard().put(S.pin, sizeof(double) * S.pin_cap, 1);
         S.pin = nullptr; S.pin_cap = 0;
         JT_HIP(hipHostMalloc((void **)&S.pin, sizeof(double) * pin_d, hipHostMallocDefault));
         S.pin_cap = pin_d;
@@ -767,7 +769,7 @@ static void early_pass3_enqueue(jt_ctx *h, const int16_t *s16, int64_t m, int ra
     size_t dev_d = 0, pin_d = 0; jt_kweight_scratch_sizes(m_meter, blk, &dev_d, &pin_d);
     E.dev.ensure(dev_d);
     if (pin_d > E.pin_cap) {
-        if (E.pin) JT_HIP(hipHostFree(E.pin));
+        if (E.pin) jt_graveyard().put(E.pin, sizeof(double) * E.pin_cap, 1);
         E.pin = nullptr; E.pin_cap = 0;
         JT_HIP(hipHostMalloc((void **)&E.pin, sizeof(double) * pin_d, hipHostMallocDefault));
         E.pin_cap = pin_d;
@@ -1119,8 +1121,23 @@ static void loudnorm_dynamic_run(jt_ctx *h, double *x, int64_t m, const Loudnorm
     P.dual_mono = in.dual_mono ? 1 : 0; P.n_inner = n_inner; P.final_len = FINAL;
     h->ln_ring.ensure(LBS); h->ln_series.ensure(series.size());
     JT_HIP(hipMemcpyAsync(h->ln_series.p, series.data(), series.size() * sizeof(double), hipMemcpyHostToDevice, s));
-    launch_loudnorm_dynamic(x, m, P, h->ln_series.p, h->ln_ring.p, y, nullptr, s);
+    // One wave for seconds: on a stream of the HIGH-priority queue pool, which nothing else in the library uses.  On the main stream the
+    // kernel occupied one of the process's eight normal-priority hardware queues for its whole run and every stream of every other
+    // handle that ROCclr had mapped onto that queue stood still behind it -- with the handles' seven streams each spread over those
+    // eight queues, a batch of such files ran (nearly) one file at a time.
+    if (!h->dyn_stream) {
+        int plo = 0, phi = 0;
+        JT_HIP(hipDeviceGetStreamPriorityRange(&plo, &phi));
+        JT_HIP(hipStreamCreateWithPriority(&h->dyn_stream, hipStreamNonBlocking, phi));
+        JT_HIP(hipEventCreateWithFlags(&h->dyn_ev[0], hipEventDisableTiming)); JT_HIP(hipEventCreateWithFlags(&h->dyn_ev[1], hipEventDisableTiming));
+    }
+    JT_HIP(hipEventRecord(h->dyn_ev[0], s));
+    JT_HIP(hipStreamWaitEvent(h->dyn_stream, h->dyn_ev[0], 0));
+    launch_loudnorm_dynamic(x, m, P, h->ln_series.p, h->ln_ring.p, y, nullptr, h->dyn_stream);
     JT_HIP(hipGetLastError());
+    // the HOST waits for it: a wait queued on the main stream would sit at the head of that stream's hardware queue for seconds and hold
+    // up the other handles' streams behind it just as the kernel itself did (tools/ubench/long_kernel_blocks.hip)
+    JT_HIP(hipStreamSynchronize(h->dyn_stream));
     finish_stats(bs, nfull_ext, peak, true);
 }
 

@@ -10,6 +10,8 @@
 #include <string>
 #include <vector>
 #include <atomic>
+#include <mutex>
+#include <utility>
 #include "../../include/jtgpu.h"
 #include "../../include/jt_host.h"
 
@@ -18,6 +20,26 @@ struct JtError { int code; std::string msg; };
 #define JT_HIP(expr) do { hipError_t e__ = (expr); if (e__ != hipSuccess) { \
     throw JtError{JT_E_HIP, std::string(#expr) + ": " + hipGetErrorString(e__)}; } } while (0)
 #define JT_REQUIRE(cond, code, text) do { if (!(cond)) throw JtError{(code), (text)}; } while (0)
+
+// Superseded allocations.  hipFree / hipHostFree wait for the WHOLE DEVICE to go idle before they return: a handle that outgrows a buffer
+// in the middle of a pass (a longer file than it has seen, a pass that needs more than the previous one) used to stall until every
+// other handle's queued work had finished -- several workers on one GPU (jt_process_files_multi) synchronised each other at every
+// such growth, and a worker behind a 4-second dynamic-loudnorm kernel waited for all of it (tools/probe_dynamic_concurrency.py: N
+// handles took N times as long).  A buffer that is replaced is parked here instead, still valid for whatever is in flight on it, and
+// freed when a handle closes or when more than JT_GRAVEYARD_GB (default 24) have piled up -- a free does its own device-wide wait,
+// which is what makes it safe at any time.
+struct DevGraveyard {
+    std::mutex m; std::vector<std::pair<void *, int>> v; size_t bytes = 0;
+    void put(void *p, size_t b, int host) { std::lock_guard<std::mutex> g(m); v.emplace_back(p, host); bytes += b; }
+    size_t parked() { std::lock_guard<std::mutex> g(m); return bytes; }
+    void drain() {
+        std::vector<std::pair<void *, int>> w;
+        { std::lock_guard<std::mutex> g(m); w.swap(v); bytes = 0; }
+        for (auto &e : w) { if (e.second) (void)hipHostFree(e.first); else (void)hipFree(e.first); }
+    }
+    static size_t limit() { static const size_t l = (size_t)(getenv("JT_GRAVEYARD_GB") ? atof(getenv("JT_GRAVEYARD_GB")) : 24.0) * (size_t)1 << 30; return l; }
+};
+inline DevGraveyard &jt_graveyard() { static DevGraveyard *g = new DevGraveyard(); return *g; }    // (never destroyed: the runtime may be gone at exit)
 
 // Simple owning device buffer
 template <typename T> struct DevBuf {
@@ -28,9 +50,12 @@ template <typename T> struct DevBuf {
     void release() { if (p) { (void)hipFree(p); p = nullptr; n = 0; } }
     void ensure(size_t count) {
         if (count <= n && p) return;
-        release();
+        DevGraveyard &gy = jt_graveyard();
+        if (p) { gy.put(p, n * sizeof(T), 0); p = nullptr; n = 0; if (gy.parked() > DevGraveyard::limit()) gy.drain(); }
         if (count == 0) count = 1;
-        JT_HIP(hipMalloc((void **)&p, count * sizeof(T)));
+        hipError_t e_ = hipMalloc((void **)&p, count * sizeof(T));
+        if (e_ == hipErrorOutOfMemory) { (void)hipGetLastError(); gy.drain(); e_ = hipMalloc((void **)&p, count * sizeof(T)); }
+        if (e_ != hipSuccess) { p = nullptr; throw JtError{JT_E_HIP, std::string("hipMalloc: ") + hipGetErrorString(e_)}; }
         // Nothing may depend on what an allocation holds: new pages happen to be zero, recycled ones are not, and a handle that has
         // processed a longer file keeps its stale samples behind a shorter one.  JT_POISON_ALLOC=1 fills every allocation with 0xFF bytes
         // (NaNs / -1); tools/stale_memory.py and the whole GPU suite give the same results with it (tests/test_gpu_round2.py runs the
@@ -196,7 +221,7 @@ struct HostArena {
     void begin(size_t bytes) {
         off = 0;
         if (bytes <= cap) return;
-        if (p) { (void)hipHostFree(p); p = nullptr; cap = 0; }
+        if (p) { jt_graveyard().put(p, cap, 1); p = nullptr; cap = 0; }
         size_t want = bytes + bytes / 2 + (1u << 20);
         JT_HIP(hipHostMalloc((void **)&p, want, hipHostMallocDefault));
         cap = want;
@@ -313,6 +338,7 @@ struct jt_ctx {
     DevBuf<int> declick_F, declick_lists; DevBuf<unsigned short> declick_idx; DevBuf<double> declick_rhs, declick_aux, declick_r, declick_wlut, declick_prod;
     DevBuf<unsigned long long> declick_ctl;
     hipStream_t dk_stream = nullptr; hipEvent_t dk_ev[2] = {nullptr, nullptr};
+    hipStream_t dyn_stream = nullptr; hipEvent_t dyn_ev[2] = {nullptr, nullptr};     // the dynamic-loudnorm kernel's stream (high-priority pool)
     // Pass 3 with the limiter prefix, started inside Pass 2 once its loudness / true peak are known (jt_pass3_plan_hook)
     struct EarlyPass3 {
         jt_plan_fn fn = nullptr; void *user = nullptr; bool armed = false, mark_kw = false;

@@ -354,7 +354,11 @@ void launch_swr_plain_f64(const double *in, int64_t n, const double *bank, int P
 }
 void launch_loudnorm_dynamic(const double *x, int64_t n, const LoudnormDynParams &P, const double *series, double *ring, double *y, double *dbg, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_loudnorm_dynamic, dim3(1), dim3(64), 0, s, x, n, P, series, ring, y, dbg);
+    // 96 KB of (unused) dynamic LDS: the workgroup then has a CU to itself.  Several files in flight each run one such wave, and the
+    // dispatcher packed them onto the first CU with room -- the same SIMDs -- where each ran 1.5x slower than alone.
+    static const int reserve = getenv("JT_DYN_NO_CU_RESERVE") ? 0 : 96 * 1024;
+    if (reserve) (void)hipFuncSetAttribute((const void *)k_loudnorm_dynamic, hipFuncAttributeMaxDynamicSharedMemorySize, reserve);
+    hipLaunchKernelGGL(k_loudnorm_dynamic, dim3(1), dim3(64), reserve, s, x, n, P, series, ring, y, dbg);
 }
 void launch_scale_f64(const double *in, double *out, int64_t n, double g, hipStream_t s)
 {
