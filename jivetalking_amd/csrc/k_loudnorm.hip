@@ -319,6 +319,366 @@ k_loudnorm_dynamic(const double *__restrict__ x, int64_t n, LoudnormDynParams P,
     if (lane == 0 && dbg) { dbg[0] = (double)produced; dbg[1] = (double)above; dbg[2] = (double)s.state; dbg[3] = prev_delta; }
 }
 
+// =====================================================================================================================
+// The same state machine run by a WORKGROUP of sixteen waves with the frame the limiter is editing held in LDS.
+// The one-wave kernel above keeps the 210 ms ring in global memory and pays a memory round trip for every dependent step: a frame the
+// limiter works on is ~130 such steps (44 peaks a frame on a file driven into the ceiling: detect, attack ramp, sustain, ...), 0.8 ms.
+// What the limiter touches in one call is the frame it is about to hand out plus the 1932 samples behind it (the envelope segments are
+// applied 10 ms ahead of the output position, the peak test reads 12 samples further).  So: that range (less its first 768 samples:
+// LDS holds 20 364 doubles) is loaded into LDS when the call starts, every access to it goes to LDS, anything outside falls through
+// to the ring in global memory, and the window is written back (ring) and the frame out (clamped) when the call ends.  All threads carry the same
+// state and take the same decisions (every decision reads values all threads see alike); the elementwise passes, the block maximum
+// and the search for the first candidate are spread over the 1024 threads.  Same arithmetic on the same values in the same order per
+// element as the one-wave kernel, hence the same output bit for bit (tests/test_gpu_round3.py).
+#ifndef JT_LN_WG
+#define JT_LN_WG 512
+#endif
+constexpr int LN_WG = JT_LN_WG;
+// LDS window: ring positions index0 + [LN_LO, LN_LO + LN_CACHE) -- the frame from its 768th sample on plus the 1932 samples of look-ahead
+// behind it (the peak detector starts 1920 samples into the frame: everything it normally reads is inside; with the look-ahead left in
+// global memory every peak near the end of a frame cost a dozen dependent memory round trips).  The first 768 samples of the frame are
+// touched by a few envelope segments per frame only and stay in global memory: 160 KB of LDS hold 20 364 doubles, not 21 132.
+#ifdef JT_LN_PROFILE
+__device__ unsigned long long g_ln_prof[12];        // wall_clock64 ticks (100 MHz): [0] fill, [1] window load, [2] limiter loop, [3] write-back + out; [5] scale passes, [6] detect calls
+#define LNP_T0 const unsigned long long lnp_t0_ = wall_clock64();
+#define LNP_ADD(i) do { if (threadIdx.x == 0) g_ln_prof[i] += wall_clock64() - lnp_t0_; } while (0)
+#define LNP_CNT(i) do { if (threadIdx.x == 0) g_ln_prof[i] += 1; } while (0)
+#else
+#define LNP_T0
+#define LNP_ADD(i)
+#define LNP_CNT(i)
+#endif
+constexpr int LN_LO = 768, LN_CACHE = LN_F100 + LN_ATT + 12 - LN_LO;
+struct LnRing {
+    double *ring, *cache; int index0;
+    __device__ int rel(int i) const { const int r = i - index0; return r < 0 ? r + LN_LBS : r; }
+    __device__ double rd(int i) const { const unsigned c = (unsigned)(rel(i) - LN_LO); return c < (unsigned)LN_CACHE ? cache[c] : ln_ld(&ring[i]); }
+    __device__ void wr(int i, double v) const { const unsigned c = (unsigned)(rel(i) - LN_LO); if (c < (unsigned)LN_CACHE) cache[c] = v; else ln_st(&ring[i], v); }
+};
+__device__ inline int ln_mod(int i) { i %= LN_LBS; return i < 0 ? i + LN_LBS : i; }
+
+// Envelope segment, wave 0 only (no barriers: one wave's LDS operations execute in order)
+template <typename F>
+__device__ void lnv_ring_scale(const LnRing &R, int env_index, int cnt, F env, int lane)
+{
+    LNP_CNT(5);
+    LNP_T0
+    const int r0 = R.rel(env_index % LN_LBS) - LN_LO;
+    if (r0 >= 0 && r0 + cnt <= LN_CACHE) {                          // the whole segment lies in the window: LDS only
+        for (int j = lane; j < cnt; j += 64) R.cache[r0 + j] *= env(j);
+    } else {
+        for (int j = lane; j < cnt; j += 64) { const int i = (env_index + j) % LN_LBS; R.wr(i, R.rd(i) * env(j)); }
+        __threadfence();
+    }
+    __builtin_amdgcn_wave_barrier();
+    LNP_ADD(7);
+}
+// cnt <= 40320: at most NBF elements per thread, all loads of a thread in flight before its first store
+constexpr int LN_NBF = 20;
+template <typename F>
+__device__ void lnw_ring_fill(double *ring, int base, const double *__restrict__ src, int64_t src_len, int cnt, F f, int tid)
+{
+    LNP_T0
+    for (int j0 = tid; j0 < cnt; j0 += LN_WG * LN_NBF) {
+        double t[LN_NBF];
+#pragma unroll
+        for (int u = 0; u < LN_NBF; ++u) { const int j = j0 + LN_WG * u; t[u] = (j < cnt && j < src_len) ? src[j] : 0.0; }
+#pragma unroll
+        for (int u = 0; u < LN_NBF; ++u) { const int j = j0 + LN_WG * u; if (j < cnt) ln_st(&ring[(base + j) % LN_LBS], j < src_len ? f(t[u], j) : 0.); }
+    }
+    __threadfence();
+    __syncthreads();
+    LNP_ADD(0);
+}
+__device__ double lnv_ring_absmax(const LnRing &R, int base, int count, int lane)
+{
+    double m = 0.0;
+    for (int j = lane; j < count; j += 64) m = fmax(m, fabs(R.rd((base + j) % LN_LBS)));
+    return ln_wave_max(m);
+}
+// ln_detect_peak() on the LDS window, wave 0 only: the same walk (blocks of 1024 rejected by their maximum, candidates 64 at a time, the
+// order-dependent tail serially), every read a few LDS cycles instead of a memory round trip; the "no larger sample among the next ten"
+// test is one 10-lane read instead of ten dependent ones.
+__device__ int lnv_detect_peak_(const LnRing &R, LnState &s, int offset, int nb, double ceiling, double *peak_value, int lane)
+{
+    LNP_CNT(6);
+    const int base = ln_mod(s.lbi + offset + LN_ATT);
+    // positions base + [-1, e) inside the window: plain indexing up to e (nearly always enough); beyond it, the general accessor
+    const int c0 = R.rel(base) - LN_LO;
+    const int e = c0 >= 1 ? LN_CACHE - c0 : 0;
+    auto at = [&](int n) -> double { return n < e ? fabs(R.cache[c0 + n]) : fabs(R.rd(ln_mod(base + n))); };
+    if (s.first) s.prev_smp = at(-1);
+    if (nb <= 0) return -1;
+    s.prev_smp = at(0);
+    if (nb == 1) return -1;
+    int n_start = 1;
+    const double *q = R.cache + c0;                                  // q[n] = window sample base + n, valid for -1 <= n < e
+    // first candidate in [c, min(c + 64, lim)): the whole chunk inside the window (a wave-uniform test) reads LDS directly -- through the
+    // general accessor every read is a branch of its own with a memory load on its other side, which kept the compiler from batching
+    auto chunk = [&](int c, int lim) -> int {
+        const int n = c + lane;
+        bool cand = false;
+        if (c + 65 <= e) { if (n < lim) { const double t = fabs(q[n]); cand = t > ceiling && fabs(q[n - 1]) <= t && fabs(q[n + 1]) <= t; } }
+        else if (n < lim) { const double t = at(n); cand = t > ceiling && at(n - 1) <= t && at(n + 1) <= t; }
+        const unsigned long long bal = __ballot(cand);
+        return bal ? c + (__ffsll((long long)bal) - 1) : -1;
+    };
+    for (;;) {
+        int n1 = -1;
+        int b0 = n_start;
+
+        // a signal held down by the limiter has its next peak within a couple of hundred samples: look there first
+        for (int k = 0; k < 4 && b0 < nb && n1 < 0; ++k, b0 += 64) n1 = chunk(b0, nb);
+        for (; b0 < nb && n1 < 0; b0 += 1024) {
+            const int bc = min(1024, nb - b0);
+            double t16[16]; double mx = 0.0;
+            if (b0 + 1024 <= e) {
+#pragma unroll
+                for (int u = 0; u < 16; ++u) { const int j = lane + 64 * u; t16[u] = j < bc ? fabs(q[b0 + j]) : 0.0; }
+            } else {
+#pragma unroll
+                for (int u = 0; u < 16; ++u) { const int j = lane + 64 * u; t16[u] = j < bc ? at(b0 + j) : 0.0; }
+            }
+#pragma unroll
+            for (int u = 0; u < 16; ++u) mx = fmax(mx, t16[u]);
+            if (!(ln_wave_max(mx) > ceiling)) continue;
+            for (int c = b0; c < b0 + bc && n1 < 0; c += 64) n1 = chunk(c, b0 + bc);
+        }
+        if (n1 < 0) { s.prev_smp = at(nb - 1); return -1; }
+        double pv = at(n1 - 1);
+        int m = n1;
+        for (;;) {
+            const bool dir = m + 13 <= e;                                   // (wave-uniform)
+            const double t = dir ? fabs(q[m]) : at(m);
+            const bool larger = lane >= 2 && lane < 12 && (dir ? fabs(q[m + lane]) : at(m + lane)) > t;
+            const bool detected = __ballot(larger) == 0ull;
+            if (detected) { s.prev_smp = t; s.peak_index = ln_mod(base + m); *peak_value = t; return m; }
+            ++m;
+            if (m >= nb) { s.prev_smp = pv; return -1; }
+            const double t2 = at(m);
+            if (pv <= t2 && at(m + 1) <= t2 && t2 > ceiling) continue;
+            pv = t2; ++m;
+            break;
+        }
+        s.prev_smp = pv;
+        if (m >= nb) return -1;
+        n_start = m;
+    }
+}
+__device__ int lnv_detect_peak(const LnRing &R, LnState &s, int offset, int nb, double ceiling, double *peak_value, int lane)
+{
+    LNP_T0
+    const int r = lnv_detect_peak_(R, s, offset, nb, ceiling, peak_value, lane);
+    LNP_ADD(4);
+    return r;
+}
+__device__ void lnw_true_peak_limiter(double *ring, double *cache, LnState &s, double *out, int nb, double ceiling, int tid)
+{
+    const int index0 = s.lbi;
+    LnRing R{ring, cache, index0};
+    __syncthreads();
+    unsigned long long lnp_a_ = 0, lnp_b_ = 0;
+#ifdef JT_LN_PROFILE
+    lnp_a_ = wall_clock64();
+#endif
+    for (int n0 = tid; n0 < LN_CACHE; n0 += LN_WG * LN_NBF) {
+        double t[LN_NBF];
+#pragma unroll
+        for (int u = 0; u < LN_NBF; ++u) { const int n = n0 + LN_WG * u; t[u] = n < LN_CACHE ? ln_ld(&ring[(index0 + LN_LO + n) % LN_LBS]) : 0.0; }
+#pragma unroll
+        for (int u = 0; u < LN_NBF; ++u) { const int n = n0 + LN_WG * u; if (n < LN_CACHE) cache[n] = t[u]; }
+    }
+    __syncthreads();
+#ifdef JT_LN_PROFILE
+    lnp_b_ = wall_clock64(); if (tid == 0) g_ln_prof[1] += lnp_b_ - lnp_a_;
+#endif
+    // the state machine itself is ONE wave's work (every step depends on the one before): wave 0 runs it on the window, the other
+    // fifteen wait at the barrier below -- run by all sixteen alike it took four times as long, four waves sharing each SIMD
+    if (tid < 64) {
+    const int lane = tid;
+    int smp_cnt = 0;
+    if (s.first) {
+        const double mx = lnv_ring_absmax(R, 0, LN_ATT, lane);
+        if (mx > ceiling) {
+            s.gr1 = ceiling / mx;
+            s.state = LIM_SUSTAIN;
+            const double g = s.gr1;
+            lnv_ring_scale(R, 0, LN_ATT, [&](int) { return g; }, lane);
+        }
+    }
+    do {
+        switch (s.state) {
+        case LIM_OUT: {
+            double pkv = 0.0;
+            const int pd = lnv_detect_peak(R, s, smp_cnt, nb - smp_cnt, ceiling, &pkv, lane);
+            if (pd != -1) {
+                s.env_cnt = 0;
+                smp_cnt += (pd - s.attack_length);
+                s.gr0 = 1.; s.gr1 = ceiling / pkv;
+                s.state = LIM_ATTACK;
+                s.env_index = s.peak_index - s.attack_length;
+                if (s.env_index < 0) s.env_index += LN_LBS;
+                s.env_index += s.env_cnt;
+                if (s.env_index > LN_LBS) s.env_index -= LN_LBS;
+            } else smp_cnt = nb;
+            break; }
+        case LIM_ATTACK: {
+            int cnt = s.attack_length - s.env_cnt; if (cnt > nb - smp_cnt) cnt = nb - smp_cnt; if (cnt < 0) cnt = 0;
+            const double g0 = s.gr0, g1 = s.gr1; const int c0 = s.env_cnt, al = s.attack_length;
+            lnv_ring_scale(R, s.env_index, cnt, [&](int j) { return g0 - ((double)(c0 + j) / (al - 1) * (g0 - g1)); }, lane);
+            s.env_index = (s.env_index + cnt) % LN_LBS; s.env_cnt += cnt; smp_cnt += cnt;
+            if (smp_cnt < nb) { s.env_cnt = 0; s.attack_length = LN_ATT; s.state = LIM_SUSTAIN; }
+            break; }
+        case LIM_SUSTAIN: {
+            double pkv = 0.0;
+            const int pd = lnv_detect_peak(R, s, smp_cnt, nb, ceiling, &pkv, lane);
+            if (pd == -1) { s.state = LIM_RELEASE; s.gr0 = s.gr1; s.gr1 = 1.; s.env_cnt = 0; break; }
+            const double gr = ceiling / pkv;
+            if (gr < s.gr1) {
+                s.state = LIM_ATTACK;
+                s.attack_length = pd; if (s.attack_length <= 1) s.attack_length = 2;
+                s.gr0 = s.gr1; s.gr1 = gr; s.env_cnt = 0;
+                break;
+            }
+            int cnt = pd; if (cnt > nb - smp_cnt) cnt = nb - smp_cnt; if (cnt < 0) cnt = 0;
+            const double g = s.gr1;
+            lnv_ring_scale(R, s.env_index, cnt, [&](int) { return g; }, lane);
+            s.env_index = (s.env_index + cnt) % LN_LBS; s.env_cnt = cnt; smp_cnt += cnt;
+            break; }
+        case LIM_RELEASE: {
+            int cnt = LN_REL - s.env_cnt; if (cnt > nb - smp_cnt) cnt = nb - smp_cnt; if (cnt < 0) cnt = 0;
+            const double g0 = s.gr0, g1 = s.gr1; const int c0 = s.env_cnt;
+            lnv_ring_scale(R, s.env_index, cnt, [&](int j) { return g0 + (((double)(c0 + j) / (LN_REL - 1)) * (g1 - g0)); }, lane);
+            s.env_index = (s.env_index + cnt) % LN_LBS; s.env_cnt += cnt; smp_cnt += cnt;
+            if (smp_cnt < nb) { s.env_cnt = 0; s.state = LIM_OUT; }
+            break; }
+        }
+    } while (smp_cnt < nb);
+    }
+    __syncthreads();
+#ifdef JT_LN_PROFILE
+    lnp_a_ = wall_clock64(); if (tid == 0) g_ln_prof[2] += lnp_a_ - lnp_b_;
+#endif
+    // the window goes back into the ring -- the envelope segments run 1920 samples AHEAD of the output position, so the look-ahead part
+    // has been edited too -- and the frame goes out, clamped
+    for (int n = tid; n < LN_CACHE; n += LN_WG) ln_st(&ring[(index0 + LN_LO + n) % LN_LBS], cache[n]);
+    for (int n0 = tid; n0 < nb; n0 += LN_WG * LN_NBF) {
+        double t[LN_NBF];
+#pragma unroll
+        for (int u = 0; u < LN_NBF; ++u) {
+            const int n = n0 + LN_WG * u;
+            t[u] = n >= nb ? 0.0 : (n >= LN_LO ? cache[n - LN_LO] : ln_ld(&ring[(index0 + n) % LN_LBS]));
+        }
+#pragma unroll
+        for (int u = 0; u < LN_NBF; ++u) {
+            const int n = n0 + LN_WG * u;
+            if (n >= nb) continue;
+            double v = t[u];
+            if (fabs(v) > ceiling) v = ceiling * (v < 0 ? -1 : 1);
+            out[n] = v;
+        }
+    }
+    __threadfence();
+    __syncthreads();
+#ifdef JT_LN_PROFILE
+    if (tid == 0) g_ln_prof[3] += wall_clock64() - lnp_a_;
+#endif
+    (void)lnp_a_; (void)lnp_b_;
+}
+
+__global__ void __launch_bounds__(LN_WG)
+k_loudnorm_dynamic_wg(const double *__restrict__ x, int64_t n, LoudnormDynParams P, const double *__restrict__ series, double *__restrict__ ring,
+                      double *__restrict__ y, double *__restrict__ dbg)
+{
+    extern __shared__ double ln_cache[];                            // [LN_CACHE]; the output meter's tile aliases its head
+    __shared__ double delta[30], w[21], oe[30];
+    double *tile = ln_cache;
+    const int tid = threadIdx.x;
+    if (tid < 30) { delta[tid] = P.delta0; oe[tid] = 0.0; }
+    if (tid < 21) w[tid] = P.weights[tid];
+    __syncthreads();
+    const double ceiling = P.target_tp_lin, offset = P.offset_lin;
+    LnState s; s.gr0 = 1.; s.gr1 = 1.; s.prev_smp = 0.; s.lbi = 0; s.state = LIM_OUT; s.peak_index = 0; s.env_index = 0; s.env_cnt = 0;
+    s.attack_length = LN_ATT; s.first = true;
+    int index = 1, above = P.above0;
+    double prev_delta = P.delta0;
+    double kv1 = 0, kv2 = 0, kv3 = 0, kv4 = 0;                      // the output meter's filter state (thread 0)
+    int oe_pos = 0;
+    auto out_energy = [&](const double *src, int cnt) {
+        double sum = 0.0;
+        for (int c0 = 0; c0 < cnt; c0 += 1024) {
+            const int m = min(1024, cnt - c0);
+            __syncthreads();
+            for (int j = tid; j < m; j += LN_WG) tile[j] = src[c0 + j];
+            __syncthreads();
+            if (tid == 0) {
+                for (int j = 0; j < m; ++j) {
+                    const double v0 = tile[j] - P.kwa[1] * kv1 - P.kwa[2] * kv2 - P.kwa[3] * kv3 - P.kwa[4] * kv4;
+                    const double o = P.kwb[0] * v0 + P.kwb[1] * kv1 + P.kwb[2] * kv2 + P.kwb[3] * kv3 + P.kwb[4] * kv4;
+                    kv4 = kv3; kv3 = kv2; kv2 = kv1; kv1 = v0;
+                    sum += o * o;
+                }
+            }
+        }
+        __syncthreads();
+        if (tid == 0) { oe[oe_pos] = sum; }
+        oe_pos = (oe_pos + 1) % 30;
+        __syncthreads();
+    };
+    { const double d0 = P.delta0; lnw_ring_fill(ring, 0, x, n, LN_LBS, [&](double v, int) { return v * d0 * offset; }, tid); }
+    lnw_true_peak_limiter(ring, ln_cache, s, y, LN_F100, ceiling, tid);
+    s.first = false;
+    if (!above) out_energy(y, LN_F100);
+    int64_t produced = LN_F100, abs_in = LN_LBS;
+    for (int64_t k = 0; k < P.n_inner; ++k) {
+        const int nb = (int)min<int64_t>(LN_F100, n - LN_F3000 - k * LN_F100);
+        const double gain = ln_gaussian(delta, w, index + 10 < 30 ? index + 10 : index + 10 - 30);
+        const double gain_next = ln_gaussian(delta, w, index + 11 < 30 ? index + 11 : index + 11 - 30);
+        lnw_ring_fill(ring, s.lbi, x + abs_in, n - abs_in, nb, [&](double v, int j) { return v * (gain + (((double)j / nb) * (gain_next - gain))) * offset; }, tid);
+        s.lbi = (s.lbi + nb) % LN_LBS;
+        s.lbi = (s.lbi + (LN_F100 - nb)) % LN_LBS;
+        lnw_true_peak_limiter(ring, ln_cache, s, y + produced, nb, ceiling, tid);
+        const double shortterm = series[3 * k], global = series[3 * k + 1], relthr = series[3 * k + 2];
+        if (above == 0) {
+            if (shortterm > P.measured_thresh) prev_delta *= 1.0058;
+            out_energy(y + produced, nb);
+            double e = 0.0; for (int q = 0; q < 30; ++q) e += oe[q];
+            e = e * (P.dual_mono ? 2.0 : 1.0) / (double)LN_F3000;
+            const double st_out = e <= 0.0 ? -HUGE_VAL : 10 * (log(e) / log(10.0)) - 0.691;
+            if (st_out >= P.target_i) above = 1;
+        }
+        double d;
+        if (shortterm < relthr || shortterm <= -70. || above == 0) d = prev_delta;
+        else {
+            const double env_global = fabs(shortterm - global) < (P.target_lra / 2.) ? shortterm - global
+                                                                                     : (P.target_lra / 2.) * ((shortterm - global) < 0 ? -1 : 1);
+            const double env_shortterm = P.target_i - shortterm;
+            d = pow(10., (env_global + env_shortterm) / 20.);
+        }
+        __syncthreads();
+        if (tid == 0) delta[index] = d;
+        __syncthreads();
+        prev_delta = d;
+        index++; if (index >= 30) index -= 30;
+        produced += nb; abs_in += nb;
+    }
+    {
+        const double gain = ln_gaussian(delta, w, index + 10 < 30 ? index + 10 : index + 10 - 30);
+        const double *src = x + (n - P.final_len);
+        s.lbi = 0;
+        lnw_ring_fill(ring, 0, src, P.final_len, LN_LBS, [&](double v, int) { return v * gain * offset; }, tid);
+        int64_t src_index = LN_LBS;
+        for (int i = 0; i < P.final_len / LN_F100; ++i) {
+            lnw_true_peak_limiter(ring, ln_cache, s, y + produced, LN_F100, ceiling, tid);
+            lnw_ring_fill(ring, s.lbi, src + src_index, P.final_len - src_index, LN_F100, [&](double v, int) { return v * gain * offset; }, tid);
+            src_index = min<int64_t>(src_index + LN_F100, P.final_len);
+            s.lbi = (s.lbi + LN_F100) % LN_LBS;
+            produced += LN_F100;
+        }
+    }
+    if (tid == 0 && dbg) { dbg[0] = (double)produced; dbg[1] = (double)above; dbg[2] = (double)s.state; dbg[3] = prev_delta; }
+}
+
 __global__ void k_scale_f64(const double *__restrict__ in, double *__restrict__ out, int64_t n, double g)
 {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -354,6 +714,21 @@ void launch_swr_plain_f64(const double *in, int64_t n, const double *bank, int P
 }
 void launch_loudnorm_dynamic(const double *x, int64_t n, const LoudnormDynParams &P, const double *series, double *ring, double *y, double *dbg, hipStream_t s)
 {
+    if (!getenv("JT_DYN_ONE_WAVE")) {
+        // sixteen waves, the frame being limited and its look-ahead in LDS (159 KB: the workgroup has its CU to itself)
+        const int smem = LN_CACHE * (int)sizeof(double);
+        (void)hipFuncSetAttribute((const void *)k_loudnorm_dynamic_wg, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+#ifdef JT_LN_PROFILE
+        { unsigned long long z[12] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_ln_prof), z, sizeof z); }
+#endif
+        hipLaunchKernelGGL(k_loudnorm_dynamic_wg, dim3(1), dim3(LN_WG), smem, s, x, n, P, series, ring, y, dbg);
+#ifdef JT_LN_PROFILE
+        { unsigned long long z[12]; (void)hipStreamSynchronize(s); (void)hipMemcpyFromSymbol(z, HIP_SYMBOL(g_ln_prof), sizeof z);
+          fprintf(stderr, "loudnorm dynamic (%lld frames): fill %.1f ms, window load %.1f, limiter loop %.1f (detect %.1f, scale %.1f), write-back + out %.1f; %llu scale passes, %llu detect calls \n",
+                  (long long)P.n_inner, z[0] / 1e5, z[1] / 1e5, z[2] / 1e5, z[4] / 1e5, z[7] / 1e5, z[3] / 1e5, z[5], z[6]); }
+#endif
+        return;
+    }
     // 96 KB of (unused) dynamic LDS: the workgroup then has a CU to itself.  Several files in flight each run one such wave, and the
     // dispatcher packed them onto the first CU with room -- the same SIMDs -- where each ran 1.5x slower than alone.
     static const int reserve = getenv("JT_DYN_NO_CU_RESERVE") ? 0 : 96 * 1024;

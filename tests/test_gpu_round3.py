@@ -267,3 +267,26 @@ def test_round3_paths_equal_their_switched_off_versions_on_a_long_file(engine, m
         got = run()
         monkeypatch.delenv(var)
         assert got == ref, var
+
+
+@pytest.mark.gpu
+def test_dynamic_loudnorm_workgroup_kernel_equals_the_one_wave_kernel(engine, monkeypatch):
+    """The dynamic-mode fallback runs as a workgroup with the limiter's frame in LDS (k_loudnorm_dynamic_wg); JT_DYN_ONE_WAVE=1 keeps the
+    one-wave kernel that walks the ring in global memory.  Same arithmetic on the same values: the 192 kHz outputs are bit-identical --
+    a stream the limiter holds down continuously (the reference's +13 dB offset= into a -1 dBTP ceiling), one it touches now and
+    then (-9 dBTP), a quiet start (the output-meter phase), and a length that ends in a partial frame."""
+    from jivetalking_amd import synth
+    x = synth.speech_like(21.0, 192000, seed=41).astype(np.float64) * 2.5
+    x = np.concatenate([x[: 192000 * 3] * 0.004, x])[: -4321]
+    outs = {}
+    for mode in ("wg", "one"):
+        if mode == "one":
+            monkeypatch.setenv("JT_DYN_ONE_WAVE", "1")
+        else:
+            monkeypatch.delenv("JT_DYN_ONE_WAVE", raising=False)
+        outs[mode] = [engine.op_loudnorm_dynamic(x, target_tp=tp, offset=off)[0] for tp, off in ((-9.0, 0.0), (-1.0, 13.0), (-1.0, 0.0))]
+    monkeypatch.delenv("JT_DYN_ONE_WAVE", raising=False)
+    for a, b in zip(outs["wg"], outs["one"]):
+        assert np.array_equal(a, b)
+    assert abs(np.max(np.abs(outs["wg"][0])) - 10 ** (-9 / 20)) < 1e-12       # the limiter worked
+
