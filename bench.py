@@ -184,7 +184,7 @@ def saturation_leg(eng, device, base, hostlogic, synth, sr, files, minutes, in_f
 
 
 def dynamic_batch_leg(eng, device, base, hostlogic, synth, sr, files, minutes, plosives):
-    """The dynamic-loudnorm fallback is one wave walking the frames of a file (k_loudnorm.hip): a single file cannot use the GPU, a
+    """The dynamic-loudnorm fallback is one workgroup walking the frames of a file (k_loudnorm.hip): a single file cannot use the GPU, a
     batch can - `files` such files at once through jt_process_files_multi, one worker each.  File to file (FLAC in /dev/shm)."""
     import shutil
     import tempfile
@@ -204,7 +204,7 @@ def dynamic_batch_leg(eng, device, base, hostlogic, synth, sr, files, minutes, p
         return {"files": files, "minutes_per_file": minutes, "in_flight": files, "failed": int(failed), "wall_s": round(wall, 2),
                 "xRT_aggregate": round(files * minutes * 60.0 / wall, 1),
                 "dynamic_files": int(sum(1 for i in range(files) if fr[i].rc == 0 and fr[i].result.loudnorm.normalization_type_dynamic)),
-                "note": "throughput of a batch of such files on one GPU (each worker's Pass 4 is one wave on one CU, the workers run side by side); "
+                "note": "throughput of a batch of such files on one GPU (each worker's dynamic-loudnorm kernel is one workgroup on one CU, the workers run side by side); "
                         "the single-file figure above is the latency"}
     finally:
         shutil.rmtree(d, ignore_errors=True)

@@ -324,8 +324,8 @@ k_loudnorm_dynamic(const double *__restrict__ x, int64_t n, LoudnormDynParams P,
 // The one-wave kernel above keeps the 210 ms ring in global memory and pays a memory round trip for every dependent step: a frame the
 // limiter works on is ~130 such steps (44 peaks a frame on a file driven into the ceiling: detect, attack ramp, sustain, ...), 0.8 ms.
 // What the limiter touches in one call is the frame it is about to hand out plus the 1932 samples behind it (the envelope segments are
-// applied 10 ms ahead of the output position, the peak test reads 12 samples further).  So: that range (less its first 768 samples:
-// LDS holds 20 364 doubles) is loaded into LDS when the call starts, every access to it goes to LDS, anything outside falls through
+// applied 10 ms ahead of the output position, the peak test reads 12 samples further).  So: that range (less its first 832 samples:
+// LDS holds 20 300 doubles) is loaded into LDS when the call starts, every access to it goes to LDS, anything outside falls through
 // to the ring in global memory, and the window is written back (ring) and the frame out (clamped) when the call ends.  All threads carry the same
 // state and take the same decisions (every decision reads values all threads see alike); the elementwise passes, the block maximum
 // and the search for the first candidate are spread over the 1024 threads.  Same arithmetic on the same values in the same order per
@@ -334,21 +334,26 @@ k_loudnorm_dynamic(const double *__restrict__ x, int64_t n, LoudnormDynParams P,
 #define JT_LN_WG 512
 #endif
 constexpr int LN_WG = JT_LN_WG;
-// LDS window: ring positions index0 + [LN_LO, LN_LO + LN_CACHE) -- the frame from its 768th sample on plus the 1932 samples of look-ahead
-// behind it (the peak detector starts 1920 samples into the frame: everything it normally reads is inside; with the look-ahead left in
-// global memory every peak near the end of a frame cost a dozen dependent memory round trips).  The first 768 samples of the frame are
-// touched by a few envelope segments per frame only and stay in global memory: 160 KB of LDS hold 20 364 doubles, not 21 132.
 #ifdef JT_LN_PROFILE
-__device__ unsigned long long g_ln_prof[12];        // wall_clock64 ticks (100 MHz): [0] fill, [1] window load, [2] limiter loop, [3] write-back + out; [5] scale passes, [6] detect calls
-#define LNP_T0 const unsigned long long lnp_t0_ = wall_clock64();
-#define LNP_ADD(i) do { if (threadIdx.x == 0) g_ln_prof[i] += wall_clock64() - lnp_t0_; } while (0)
-#define LNP_CNT(i) do { if (threadIdx.x == 0) g_ln_prof[i] += 1; } while (0)
+// phase clocks (tools/prof_dynamic_phases.sh): accumulated in LDS by thread 0 (a GLOBAL read-modify-write per event cost more than the
+// events it measured) and stored once per kernel; shader cycles (clock64)
+__device__ unsigned long long g_ln_prof[16];        // [0] fill, [1] window load, [2] limiter loop, [3] write-back + out, [4] detect, [7] scale; [5] scale passes, [6] detect calls, [8] / [9] left the window / general walks
+__shared__ unsigned long long lnp_acc[16];
+#define LNP_T0 const unsigned long long lnp_t0_ = clock64();
+#define LNP_ADD(i) do { if (threadIdx.x == 0) lnp_acc[i] += clock64() - lnp_t0_; } while (0)
+#define LNP_CNT(i) do { if (threadIdx.x == 0) lnp_acc[i] += 1; } while (0)
 #else
 #define LNP_T0
 #define LNP_ADD(i)
 #define LNP_CNT(i)
 #endif
-constexpr int LN_LO = 768, LN_CACHE = LN_F100 + LN_ATT + 12 - LN_LO;
+// LDS window: ring positions index0 + [LN_LO, LN_LO + LN_CACHE), index0 = the frame about to go out.  LN_LO = 1920: the peak detector
+// reads from 1920 samples (the 10 ms look-ahead) into the frame on, 19 200 samples ahead of the output position at most and a few
+// hundred as a rule, so a window of 20 300 doubles (what 160 KB of LDS hold beside the other arrays) that STARTS there keeps the
+// detector inside LDS up to the last sample of the frame; started at the frame's first sample it ended 245 samples short of that, and
+// the 3 % of the detector's calls that then walked the ring in global memory took two thirds of the kernel's time.  The first 1920
+// samples of the frame are only touched by the first envelope segments of a call and stay in global memory (batched read-modify-write).
+constexpr int LN_LO = LN_ATT, LN_CACHE = 20300;
 struct LnRing {
     double *ring, *cache; int index0;
     __device__ int rel(int i) const { const int r = i - index0; return r < 0 ? r + LN_LBS : r; }
@@ -359,15 +364,28 @@ __device__ inline int ln_mod(int i) { i %= LN_LBS; return i < 0 ? i + LN_LBS : i
 
 // Envelope segment, wave 0 only (no barriers: one wave's LDS operations execute in order)
 template <typename F>
-__device__ void lnv_ring_scale(const LnRing &R, int env_index, int cnt, F env, int lane)
+__device__ __forceinline__ void lnv_ring_scale(const LnRing &R, int env_index, int cnt, F env, int lane)
 {
     LNP_CNT(5);
     LNP_T0
     const int r0 = R.rel(env_index % LN_LBS) - LN_LO;
     if (r0 >= 0 && r0 + cnt <= LN_CACHE) {                          // the whole segment lies in the window: LDS only
-        for (int j = lane; j < cnt; j += 64) R.cache[r0 + j] *= env(j);
+        double *c = R.cache + r0;
+        for (int j0 = lane; j0 < cnt; j0 += 64 * 8) {                 // eight reads in flight per lane
+            double t[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { const int j = j0 + 64 * u; t[u] = j < cnt ? c[j] : 0.0; }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { const int j = j0 + 64 * u; if (j < cnt) c[j] = t[u] * env(j); }
+        }
     } else {
-        for (int j = lane; j < cnt; j += 64) { const int i = (env_index + j) % LN_LBS; R.wr(i, R.rd(i) * env(j)); }
+        for (int j0 = lane; j0 < cnt; j0 += 64 * 8) {                 // (window or ring, element by element; eight reads in flight)
+            double t[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { const int j = j0 + 64 * u; t[u] = j < cnt ? R.rd((env_index + j) % LN_LBS) : 0.0; }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { const int j = j0 + 64 * u; if (j < cnt) R.wr((env_index + j) % LN_LBS, t[u] * env(j)); }
+        }
         __threadfence();
     }
     __builtin_amdgcn_wave_barrier();
@@ -376,7 +394,11 @@ __device__ void lnv_ring_scale(const LnRing &R, int env_index, int cnt, F env, i
 // cnt <= 40320: at most NBF elements per thread, all loads of a thread in flight before its first store
 constexpr int LN_NBF = 20;
 template <typename F>
-__device__ void lnw_ring_fill(double *ring, int base, const double *__restrict__ src, int64_t src_len, int cnt, F f, int tid)
+// `hot[k]`: ring samples 64 k .. 64 k + 63 may hold one above the ceiling.  Set here from the values written (base and the waves' strides
+// are multiples of 64: a wave writes one aligned block per step); everything the limiter does afterwards multiplies by gains <= 1, so a
+// clear flag stays true.  The detector's walk outside the LDS window skips blocks whose flag is clear without touching memory.
+__device__ __forceinline__ void lnw_ring_fill(double *ring, int base, const double *__restrict__ src, int64_t src_len, int cnt, F f, int tid,
+                                              unsigned char *hot, double ceiling)
 {
     LNP_T0
     for (int j0 = tid; j0 < cnt; j0 += LN_WG * LN_NBF) {
@@ -384,75 +406,135 @@ __device__ void lnw_ring_fill(double *ring, int base, const double *__restrict__
 #pragma unroll
         for (int u = 0; u < LN_NBF; ++u) { const int j = j0 + LN_WG * u; t[u] = (j < cnt && j < src_len) ? src[j] : 0.0; }
 #pragma unroll
-        for (int u = 0; u < LN_NBF; ++u) { const int j = j0 + LN_WG * u; if (j < cnt) ln_st(&ring[(base + j) % LN_LBS], j < src_len ? f(t[u], j) : 0.); }
+        for (int u = 0; u < LN_NBF; ++u) {
+            const int j = j0 + LN_WG * u;
+            const bool wr = j < cnt;
+            const double v = (wr && j < src_len) ? f(t[u], j) : 0.;
+            const int i = (base + j) % LN_LBS;
+            if (wr) ln_st(&ring[i], v);
+            const unsigned long long act = __ballot(wr), h = __ballot(wr && fabs(v) > ceiling);
+            if (wr && (tid & 63) == 0) hot[i >> 6] = act == ~0ull ? (unsigned char)(h != 0) : (unsigned char)(hot[i >> 6] | (h != 0));
+        }
     }
     __threadfence();
     __syncthreads();
     LNP_ADD(0);
 }
-__device__ double lnv_ring_absmax(const LnRing &R, int base, int count, int lane)
+__device__ __forceinline__ double lnv_ring_absmax(const LnRing &R, int base, int count, int lane)
 {
     double m = 0.0;
     for (int j = lane; j < count; j += 64) m = fmax(m, fabs(R.rd((base + j) % LN_LBS)));
     return ln_wave_max(m);
 }
-// ln_detect_peak() on the LDS window, wave 0 only: the same walk (blocks of 1024 rejected by their maximum, candidates 64 at a time, the
-// order-dependent tail serially), every read a few LDS cycles instead of a memory round trip; the "no larger sample among the next ten"
-// test is one 10-lane read instead of ten dependent ones.
-__device__ int lnv_detect_peak_(const LnRing &R, LnState &s, int offset, int nb, double ceiling, double *peak_value, int lane)
+// ln_detect_peak() on the LDS window, wave 0 only.  Two functions.
+//   lnv_detect_window: everything it reads lies in the window (q[n] = |sample base + n| for -1 <= n < e).  No accessor, no branch with a
+//   memory load on its other side, and every value the wave agrees on -- positions, the candidate's value, its neighbours -- is moved
+//   to scalar registers explicitly (readfirstlane): left to the compiler, the "uniform" control flow of the walk was vector compares
+//   and exec-mask save / restore around every read, 2 000 shader cycles per 64-position step.  Returns the peak's position, -1 (no peak
+//   before nb), or -2 with *resume set when the walk would leave the window: the general function then redoes that search step.
+//   lnv_detect_general: the same walk through the accessor (window or ring), from any starting position.
+// Same walk as ln_detect_peak: candidates in ascending order (64 positions at a time, the next 256 first, then 1024-position blocks
+// rejected by their maximum), the order-dependent tail serially; the "no larger sample among the next ten" test is one 10-lane read.
+__device__ __forceinline__ double ln_rfl(double v)
 {
-    LNP_CNT(6);
-    const int base = ln_mod(s.lbi + offset + LN_ATT);
-    // positions base + [-1, e) inside the window: plain indexing up to e (nearly always enough); beyond it, the general accessor
-    const int c0 = R.rel(base) - LN_LO;
-    const int e = c0 >= 1 ? LN_CACHE - c0 : 0;
-    auto at = [&](int n) -> double { return n < e ? fabs(R.cache[c0 + n]) : fabs(R.rd(ln_mod(base + n))); };
-    if (s.first) s.prev_smp = at(-1);
-    if (nb <= 0) return -1;
-    s.prev_smp = at(0);
-    if (nb == 1) return -1;
-    int n_start = 1;
-    const double *q = R.cache + c0;                                  // q[n] = window sample base + n, valid for -1 <= n < e
-    // first candidate in [c, min(c + 64, lim)): the whole chunk inside the window (a wave-uniform test) reads LDS directly -- through the
-    // general accessor every read is a branch of its own with a memory load on its other side, which kept the compiler from batching
-    auto chunk = [&](int c, int lim) -> int {
-        const int n = c + lane;
-        bool cand = false;
-        if (c + 65 <= e) { if (n < lim) { const double t = fabs(q[n]); cand = t > ceiling && fabs(q[n - 1]) <= t && fabs(q[n + 1]) <= t; } }
-        else if (n < lim) { const double t = at(n); cand = t > ceiling && at(n - 1) <= t && at(n + 1) <= t; }
-        const unsigned long long bal = __ballot(cand);
-        return bal ? c + (__ffsll((long long)bal) - 1) : -1;
+    return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v)), __builtin_amdgcn_readfirstlane(__double2loint(v)));
+}
+__device__ __forceinline__ double ln_rl(double v, int l)
+{
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
+}
+__device__ __forceinline__ int lnv_detect_window(const double *q, int e, LnState &s, int nb, double ceiling, double *peak_value, int base, int lane, int *resume)
+{
+    // first candidate among the 256 positions from c on (all inside the window: c + 257 <= e): twelve reads in flight, four ballots.
+    // (With one 64-position step at a time and the three reads of a position behind each other's compare -- what `a && b && c` compiles
+    // to -- a step was three LDS round trips, 500 shader cycles, and the walk is nothing but such steps.)
+    auto group = [&](int c, int lim) -> int {
+        double t[4], l[4], r[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) { const int n = c + 64 * g + lane; t[g] = fabs(q[n]); l[g] = fabs(q[n - 1]); r[g] = fabs(q[n + 1]); }
+        int found = -1;
+#pragma unroll
+        for (int g = 3; g >= 0; --g) {
+            const int n = c + 64 * g + lane;
+            const bool cand = (n < lim) & (t[g] > ceiling) & (l[g] <= t[g]) & (r[g] <= t[g]);
+            const unsigned long long bal = __ballot(cand);
+            if (bal) found = c + 64 * g + (__ffsll((long long)bal) - 1);
+        }
+        return found;
     };
+    int n_start = 1;
+#ifdef JT_LN_PROFILE
+    unsigned long long pc_ = clock64();
+#define LNW_SEC(i) { const unsigned long long c_ = clock64(); if (threadIdx.x == 0) lnp_acc[i] += c_ - pc_; pc_ = c_; }
+#else
+#define LNW_SEC(i)
+#endif
     for (;;) {
         int n1 = -1;
         int b0 = n_start;
-
         // a signal held down by the limiter has its next peak within a couple of hundred samples: look there first
-        for (int k = 0; k < 4 && b0 < nb && n1 < 0; ++k, b0 += 64) n1 = chunk(b0, nb);
+        for (int k = 0; k < 2 && b0 < nb && n1 < 0; ++k, b0 += 256) {
+            if (b0 + 257 > e) { *resume = n_start; return -2; }
+            n1 = group(b0, nb);
+        }
         for (; b0 < nb && n1 < 0; b0 += 1024) {
+            if (b0 + 1025 > e) { *resume = n_start; return -2; }
             const int bc = min(1024, nb - b0);
-            double t16[16]; double mx = 0.0;
-            if (b0 + 1024 <= e) {
+            double mx = 0.0;
 #pragma unroll
-                for (int u = 0; u < 16; ++u) { const int j = lane + 64 * u; t16[u] = j < bc ? fabs(q[b0 + j]) : 0.0; }
-            } else {
-#pragma unroll
-                for (int u = 0; u < 16; ++u) { const int j = lane + 64 * u; t16[u] = j < bc ? at(b0 + j) : 0.0; }
-            }
-#pragma unroll
-            for (int u = 0; u < 16; ++u) mx = fmax(mx, t16[u]);
-            if (!(ln_wave_max(mx) > ceiling)) continue;
-            for (int c = b0; c < b0 + bc && n1 < 0; c += 64) n1 = chunk(c, b0 + bc);
+            for (int u = 0; u < 16; ++u) { const int j = lane + 64 * u; const double t = fabs(q[b0 + j]); mx = fmax(mx, j < bc ? t : 0.0); }
+            if (!__any(mx > ceiling)) continue;
+            for (int c = b0; c < b0 + bc && n1 < 0; c += 256) n1 = group(c, b0 + bc);
+        }
+        LNW_SEC(11)
+        if (n1 < 0) { s.prev_smp = ln_rfl(fabs(q[nb - 1])); return -1; }
+        int m = n1;
+        if (m + 15 > e) { *resume = n_start; return -2; }
+        double pv = ln_rfl(fabs(q[m - 1]));
+        for (;;) {
+            // one read serves the whole step: lane i holds |x[m - 1 + i]|, i = 0 .. 15
+            if (m + 15 > e) { *resume = n_start; return -2; }
+            const double v = fabs(q[m - 1 + (lane & 15)]);
+            const double t = ln_rl(v, 1);
+            const bool larger = lane >= 3 && lane < 13 && v > t;                 // x[m + 2] .. x[m + 11]
+            if (__ballot(larger) == 0ull) { s.prev_smp = t; s.peak_index = ln_mod(base + m); *peak_value = t; LNW_SEC(12) return m; }
+            // rejected: prev_smp keeps the value it had; the next sample is tested against that stale value
+            ++m;
+            if (m >= nb) { s.prev_smp = pv; return -1; }
+            const double t2 = ln_rl(v, 2);                                       // x[m] (the new m)
+            if (pv <= t2 && ln_rl(v, 3) <= t2 && t2 > ceiling) continue;          // a candidate again, still with the stale value
+            pv = t2; ++m;
+            break;
+        }
+        s.prev_smp = pv;
+        LNW_SEC(12)
+        if (m >= nb) return -1;
+        n_start = m;
+    }
+}
+__device__ __forceinline__ int lnv_detect_general(const LnRing &R, const unsigned char *hot, LnState &s, int nb, double ceiling, double *peak_value,
+                                                  int base, int lane, int n_start)
+{
+    auto at = [&](int n) -> double { return fabs(R.rd(ln_mod(base + n))); };
+    for (;;) {
+        int n1 = -1;
+        for (int c = n_start; c < nb && n1 < 0; c += 64) {
+            // the 64 positions from c on lie in (at most) two aligned ring blocks: neither hot, no candidate, no read
+            const int i0 = ln_mod(base + c), i1 = i0 + 63 >= LN_LBS ? i0 + 63 - LN_LBS : i0 + 63;
+            if (!(hot[i0 >> 6] | hot[i1 >> 6])) continue;
+            const int n = c + lane;
+            bool cand = false;
+            if (n < nb) { const double t = at(n), l = at(n - 1), r = at(n + 1); cand = (t > ceiling) & (l <= t) & (r <= t); }
+            const unsigned long long bal = __ballot(cand);
+            if (bal) n1 = c + (__ffsll((long long)bal) - 1);
         }
         if (n1 < 0) { s.prev_smp = at(nb - 1); return -1; }
         double pv = at(n1 - 1);
         int m = n1;
         for (;;) {
-            const bool dir = m + 13 <= e;                                   // (wave-uniform)
-            const double t = dir ? fabs(q[m]) : at(m);
-            const bool larger = lane >= 2 && lane < 12 && (dir ? fabs(q[m + lane]) : at(m + lane)) > t;
-            const bool detected = __ballot(larger) == 0ull;
-            if (detected) { s.prev_smp = t; s.peak_index = ln_mod(base + m); *peak_value = t; return m; }
+            const double t = at(m);
+            const bool larger = lane >= 2 && lane < 12 && at(m + lane) > t;
+            if (__ballot(larger) == 0ull) { s.prev_smp = t; s.peak_index = ln_mod(base + m); *peak_value = t; return m; }
             ++m;
             if (m >= nb) { s.prev_smp = pv; return -1; }
             const double t2 = at(m);
@@ -465,21 +547,43 @@ __device__ int lnv_detect_peak_(const LnRing &R, LnState &s, int offset, int nb,
         n_start = m;
     }
 }
-__device__ int lnv_detect_peak(const LnRing &R, LnState &s, int offset, int nb, double ceiling, double *peak_value, int lane)
+__device__ __forceinline__ int lnv_detect_peak_(const LnRing &R, const unsigned char *hot, LnState &s, int offset, int nb, double ceiling, double *peak_value, int lane)
+{
+    LNP_CNT(6);
+    const int base = ln_mod(s.lbi + offset + LN_ATT);
+    const int c0 = __builtin_amdgcn_readfirstlane(R.rel(base) - LN_LO);
+    auto at = [&](int n) -> double { return fabs(R.rd(ln_mod(base + n))); };
+    if (s.first) s.prev_smp = at(-1);
+    if (nb <= 0) return -1;
+    s.prev_smp = at(0);
+    if (nb == 1) return -1;
+    int n_start = 1;
+    if (c0 >= 0) {                                                   // base is inside the window (the walk reads base + n - 1, n >= 1)
+        const int r = lnv_detect_window(R.cache + c0, LN_CACHE - c0, s, nb, ceiling, peak_value, base, lane, &n_start);
+        if (r != -2) return r;
+        LNP_CNT(8);
+    }
+    LNP_CNT(9);
+    LNP_T0
+    const int rg = lnv_detect_general(R, hot, s, nb, ceiling, peak_value, base, lane, n_start);
+    LNP_ADD(10);
+    return rg;
+}
+__device__ __forceinline__ int lnv_detect_peak(const LnRing &R, const unsigned char *hot, LnState &s, int offset, int nb, double ceiling, double *peak_value, int lane)
 {
     LNP_T0
-    const int r = lnv_detect_peak_(R, s, offset, nb, ceiling, peak_value, lane);
+    const int r = lnv_detect_peak_(R, hot, s, offset, nb, ceiling, peak_value, lane);
     LNP_ADD(4);
     return r;
 }
-__device__ void lnw_true_peak_limiter(double *ring, double *cache, LnState &s, double *out, int nb, double ceiling, int tid)
+__device__ __forceinline__ void lnw_true_peak_limiter(double *ring, double *cache, const unsigned char *hot, LnState &s, double *out, int nb, double ceiling, int tid)
 {
     const int index0 = s.lbi;
     LnRing R{ring, cache, index0};
     __syncthreads();
     unsigned long long lnp_a_ = 0, lnp_b_ = 0;
 #ifdef JT_LN_PROFILE
-    lnp_a_ = wall_clock64();
+    lnp_a_ = clock64();
 #endif
     for (int n0 = tid; n0 < LN_CACHE; n0 += LN_WG * LN_NBF) {
         double t[LN_NBF];
@@ -490,7 +594,7 @@ __device__ void lnw_true_peak_limiter(double *ring, double *cache, LnState &s, d
     }
     __syncthreads();
 #ifdef JT_LN_PROFILE
-    lnp_b_ = wall_clock64(); if (tid == 0) g_ln_prof[1] += lnp_b_ - lnp_a_;
+    lnp_b_ = clock64(); if (tid == 0) lnp_acc[1] += lnp_b_ - lnp_a_;
 #endif
     // the state machine itself is ONE wave's work (every step depends on the one before): wave 0 runs it on the window, the other
     // fifteen wait at the barrier below -- run by all sixteen alike it took four times as long, four waves sharing each SIMD
@@ -507,10 +611,11 @@ __device__ void lnw_true_peak_limiter(double *ring, double *cache, LnState &s, d
         }
     }
     do {
+        // (one call site for the detector: OUT scans what is left of the frame, SUSTAIN a frame's length from where it stands)
+        double pkv = 0.0; int pd = -1;
+        if (s.state == LIM_OUT || s.state == LIM_SUSTAIN) pd = lnv_detect_peak(R, hot, s, smp_cnt, s.state == LIM_OUT ? nb - smp_cnt : nb, ceiling, &pkv, lane);
         switch (s.state) {
         case LIM_OUT: {
-            double pkv = 0.0;
-            const int pd = lnv_detect_peak(R, s, smp_cnt, nb - smp_cnt, ceiling, &pkv, lane);
             if (pd != -1) {
                 s.env_cnt = 0;
                 smp_cnt += (pd - s.attack_length);
@@ -530,8 +635,6 @@ __device__ void lnw_true_peak_limiter(double *ring, double *cache, LnState &s, d
             if (smp_cnt < nb) { s.env_cnt = 0; s.attack_length = LN_ATT; s.state = LIM_SUSTAIN; }
             break; }
         case LIM_SUSTAIN: {
-            double pkv = 0.0;
-            const int pd = lnv_detect_peak(R, s, smp_cnt, nb, ceiling, &pkv, lane);
             if (pd == -1) { s.state = LIM_RELEASE; s.gr0 = s.gr1; s.gr1 = 1.; s.env_cnt = 0; break; }
             const double gr = ceiling / pkv;
             if (gr < s.gr1) {
@@ -557,7 +660,7 @@ __device__ void lnw_true_peak_limiter(double *ring, double *cache, LnState &s, d
     }
     __syncthreads();
 #ifdef JT_LN_PROFILE
-    lnp_a_ = wall_clock64(); if (tid == 0) g_ln_prof[2] += lnp_a_ - lnp_b_;
+    lnp_a_ = clock64(); if (tid == 0) lnp_acc[2] += lnp_a_ - lnp_b_;
 #endif
     // the window goes back into the ring -- the envelope segments run 1920 samples AHEAD of the output position, so the look-ahead part
     // has been edited too -- and the frame goes out, clamped
@@ -581,7 +684,7 @@ __device__ void lnw_true_peak_limiter(double *ring, double *cache, LnState &s, d
     __threadfence();
     __syncthreads();
 #ifdef JT_LN_PROFILE
-    if (tid == 0) g_ln_prof[3] += wall_clock64() - lnp_a_;
+    if (tid == 0) lnp_acc[3] += clock64() - lnp_a_;
 #endif
     (void)lnp_a_; (void)lnp_b_;
 }
@@ -592,10 +695,14 @@ k_loudnorm_dynamic_wg(const double *__restrict__ x, int64_t n, LoudnormDynParams
 {
     extern __shared__ double ln_cache[];                            // [LN_CACHE]; the output meter's tile aliases its head
     __shared__ double delta[30], w[21], oe[30];
+    __shared__ unsigned char hot[LN_LBS / 64];
     double *tile = ln_cache;
     const int tid = threadIdx.x;
     if (tid < 30) { delta[tid] = P.delta0; oe[tid] = 0.0; }
     if (tid < 21) w[tid] = P.weights[tid];
+#ifdef JT_LN_PROFILE
+    if (tid < 16) lnp_acc[tid] = 0;
+#endif
     __syncthreads();
     const double ceiling = P.target_tp_lin, offset = P.offset_lin;
     LnState s; s.gr0 = 1.; s.gr1 = 1.; s.prev_smp = 0.; s.lbi = 0; s.state = LIM_OUT; s.peak_index = 0; s.env_index = 0; s.env_cnt = 0;
@@ -625,58 +732,77 @@ k_loudnorm_dynamic_wg(const double *__restrict__ x, int64_t n, LoudnormDynParams
         oe_pos = (oe_pos + 1) % 30;
         __syncthreads();
     };
-    { const double d0 = P.delta0; lnw_ring_fill(ring, 0, x, n, LN_LBS, [&](double v, int) { return v * d0 * offset; }, tid); }
-    lnw_true_peak_limiter(ring, ln_cache, s, y, LN_F100, ceiling, tid);
-    s.first = false;
-    if (!above) out_energy(y, LN_F100);
-    int64_t produced = LN_F100, abs_in = LN_LBS;
-    for (int64_t k = 0; k < P.n_inner; ++k) {
-        const int nb = (int)min<int64_t>(LN_F100, n - LN_F3000 - k * LN_F100);
-        const double gain = ln_gaussian(delta, w, index + 10 < 30 ? index + 10 : index + 10 - 30);
-        const double gain_next = ln_gaussian(delta, w, index + 11 < 30 ? index + 11 : index + 11 - 30);
-        lnw_ring_fill(ring, s.lbi, x + abs_in, n - abs_in, nb, [&](double v, int j) { return v * (gain + (((double)j / nb) * (gain_next - gain))) * offset; }, tid);
-        s.lbi = (s.lbi + nb) % LN_LBS;
-        s.lbi = (s.lbi + (LN_F100 - nb)) % LN_LBS;
-        lnw_true_peak_limiter(ring, ln_cache, s, y + produced, nb, ceiling, tid);
-        const double shortterm = series[3 * k], global = series[3 * k + 1], relthr = series[3 * k + 2];
-        if (above == 0) {
-            if (shortterm > P.measured_thresh) prev_delta *= 1.0058;
-            out_energy(y + produced, nb);
-            double e = 0.0; for (int q = 0; q < 30; ++q) e += oe[q];
-            e = e * (P.dual_mono ? 2.0 : 1.0) / (double)LN_F3000;
-            const double st_out = e <= 0.0 ? -HUGE_VAL : 10 * (log(e) / log(10.0)) - 0.691;
-            if (st_out >= P.target_i) above = 1;
+    // FIRST_FRAME (the first 210 ms with the initial gain, 100 ms out), the INNER_FRAMEs, the FINAL_FRAME's 29 steps: ONE loop with ONE
+    // call of the limiter -- inlined at three call sites the kernel was 108 KB of code, more than the instruction cache holds, and the
+    // one wave that walks the state machine waited for instruction fetches
+    const int nfinal = (int)(P.final_len / LN_F100);
+    const int64_t total = 1 + P.n_inner + nfinal;
+    const double *fsrc = x + (n - P.final_len);
+    int64_t produced = 0, abs_in = LN_LBS, src_index = LN_LBS;
+    double gain_final = 0.0;
+    for (int64_t it = 0; it < total; ++it) {
+        int nb = LN_F100;
+        if (it == 0) {
+            const double d0 = P.delta0;
+            lnw_ring_fill(ring, 0, x, n, LN_LBS, [&](double v, int) { return v * d0 * offset; }, tid, hot, ceiling);
+        } else if (it <= P.n_inner) {
+            const int64_t k = it - 1;
+            nb = (int)min<int64_t>(LN_F100, n - LN_F3000 - k * LN_F100);
+            const double gain = ln_gaussian(delta, w, index + 10 < 30 ? index + 10 : index + 10 - 30);
+            const double gain_next = ln_gaussian(delta, w, index + 11 < 30 ? index + 11 : index + 11 - 30);
+            lnw_ring_fill(ring, s.lbi, x + abs_in, n - abs_in, nb, [&](double v, int j) { return v * (gain + (((double)j / nb) * (gain_next - gain))) * offset; }, tid, hot, ceiling);
+            s.lbi = (s.lbi + nb) % LN_LBS;
+            s.lbi = (s.lbi + (LN_F100 - nb)) % LN_LBS;
+        } else if (it == P.n_inner + 1) {
+            // FINAL_FRAME: the last 2.9 s again from the look-ahead buffer, one gain
+            gain_final = ln_gaussian(delta, w, index + 10 < 30 ? index + 10 : index + 10 - 30);
+            const double gain = gain_final;
+            s.lbi = 0;
+            lnw_ring_fill(ring, 0, fsrc, P.final_len, LN_LBS, [&](double v, int) { return v * gain * offset; }, tid, hot, ceiling);
         }
-        double d;
-        if (shortterm < relthr || shortterm <= -70. || above == 0) d = prev_delta;
-        else {
-            const double env_global = fabs(shortterm - global) < (P.target_lra / 2.) ? shortterm - global
-                                                                                     : (P.target_lra / 2.) * ((shortterm - global) < 0 ? -1 : 1);
-            const double env_shortterm = P.target_i - shortterm;
-            d = pow(10., (env_global + env_shortterm) / 20.);
-        }
-        __syncthreads();
-        if (tid == 0) delta[index] = d;
-        __syncthreads();
-        prev_delta = d;
-        index++; if (index >= 30) index -= 30;
-        produced += nb; abs_in += nb;
-    }
-    {
-        const double gain = ln_gaussian(delta, w, index + 10 < 30 ? index + 10 : index + 10 - 30);
-        const double *src = x + (n - P.final_len);
-        s.lbi = 0;
-        lnw_ring_fill(ring, 0, src, P.final_len, LN_LBS, [&](double v, int) { return v * gain * offset; }, tid);
-        int64_t src_index = LN_LBS;
-        for (int i = 0; i < P.final_len / LN_F100; ++i) {
-            lnw_true_peak_limiter(ring, ln_cache, s, y + produced, LN_F100, ceiling, tid);
-            lnw_ring_fill(ring, s.lbi, src + src_index, P.final_len - src_index, LN_F100, [&](double v, int) { return v * gain * offset; }, tid);
+        lnw_true_peak_limiter(ring, ln_cache, hot, s, y + produced, nb, ceiling, tid);
+        if (it == 0) {
+            s.first = false;
+            if (!above) out_energy(y, LN_F100);
+            produced = LN_F100;
+        } else if (it <= P.n_inner) {
+            const int64_t k = it - 1;
+            const double shortterm = series[3 * k], global = series[3 * k + 1], relthr = series[3 * k + 2];
+            if (above == 0) {
+                if (shortterm > P.measured_thresh) prev_delta *= 1.0058;
+                out_energy(y + produced, nb);
+                double e = 0.0; for (int q = 0; q < 30; ++q) e += oe[q];
+                e = e * (P.dual_mono ? 2.0 : 1.0) / (double)LN_F3000;
+                const double st_out = e <= 0.0 ? -HUGE_VAL : 10 * (log(e) / log(10.0)) - 0.691;
+                if (st_out >= P.target_i) above = 1;
+            }
+            double d;
+            if (shortterm < relthr || shortterm <= -70. || above == 0) d = prev_delta;
+            else {
+                const double env_global = fabs(shortterm - global) < (P.target_lra / 2.) ? shortterm - global
+                                                                                         : (P.target_lra / 2.) * ((shortterm - global) < 0 ? -1 : 1);
+                const double env_shortterm = P.target_i - shortterm;
+                d = pow(10., (env_global + env_shortterm) / 20.);
+            }
+            __syncthreads();
+            if (tid == 0) delta[index] = d;
+            __syncthreads();
+            prev_delta = d;
+            index++; if (index >= 30) index -= 30;
+            produced += nb; abs_in += nb;
+        } else {
+            const double gain = gain_final;
+            lnw_ring_fill(ring, s.lbi, fsrc + src_index, P.final_len - src_index, LN_F100, [&](double v, int) { return v * gain * offset; }, tid, hot, ceiling);
             src_index = min<int64_t>(src_index + LN_F100, P.final_len);
             s.lbi = (s.lbi + LN_F100) % LN_LBS;
             produced += LN_F100;
         }
     }
     if (tid == 0 && dbg) { dbg[0] = (double)produced; dbg[1] = (double)above; dbg[2] = (double)s.state; dbg[3] = prev_delta; }
+#ifdef JT_LN_PROFILE
+    __syncthreads();
+    if (tid < 16) g_ln_prof[tid] = lnp_acc[tid];
+#endif
 }
 
 __global__ void k_scale_f64(const double *__restrict__ in, double *__restrict__ out, int64_t n, double g)
@@ -719,13 +845,13 @@ void launch_loudnorm_dynamic(const double *x, int64_t n, const LoudnormDynParams
         const int smem = LN_CACHE * (int)sizeof(double);
         (void)hipFuncSetAttribute((const void *)k_loudnorm_dynamic_wg, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
 #ifdef JT_LN_PROFILE
-        { unsigned long long z[12] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_ln_prof), z, sizeof z); }
+        { unsigned long long z[16] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_ln_prof), z, sizeof z); }
 #endif
         hipLaunchKernelGGL(k_loudnorm_dynamic_wg, dim3(1), dim3(LN_WG), smem, s, x, n, P, series, ring, y, dbg);
 #ifdef JT_LN_PROFILE
-        { unsigned long long z[12]; (void)hipStreamSynchronize(s); (void)hipMemcpyFromSymbol(z, HIP_SYMBOL(g_ln_prof), sizeof z);
-          fprintf(stderr, "loudnorm dynamic (%lld frames): fill %.1f ms, window load %.1f, limiter loop %.1f (detect %.1f, scale %.1f), write-back + out %.1f; %llu scale passes, %llu detect calls \n",
-                  (long long)P.n_inner, z[0] / 1e5, z[1] / 1e5, z[2] / 1e5, z[4] / 1e5, z[7] / 1e5, z[3] / 1e5, z[5], z[6]); }
+        { unsigned long long z[16]; (void)hipStreamSynchronize(s); (void)hipMemcpyFromSymbol(z, HIP_SYMBOL(g_ln_prof), sizeof z);
+          fprintf(stderr, "loudnorm dynamic (%lld frames), shader Mcycles: fill %.1f, window load %.1f, limiter loop %.1f (detect %.1f, scale %.1f), write-back + out %.1f; %llu scale passes, %llu detect calls (%llu left the window, %llu general walks: %.1f Mcycles; in the window: search %.1f, test + walk %.1f)\n",
+                  (long long)P.n_inner, z[0] / 1e6, z[1] / 1e6, z[2] / 1e6, z[4] / 1e6, z[7] / 1e6, z[3] / 1e6, z[5], z[6], z[8], z[9], z[10] / 1e6, z[11] / 1e6, z[12] / 1e6); }
 #endif
         return;
     }
