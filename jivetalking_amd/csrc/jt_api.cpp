@@ -69,7 +69,6 @@ extern "C" void jt_close(jt_ctx *h)
     if (h->spec_ln.stream) { (void)hipStreamSynchronize(h->spec_ln.stream); (void)hipStreamDestroy(h->spec_ln.stream); }
     if (h->early_p3.pin) (void)hipHostFree(h->early_p3.pin);
     if (h->early_p3.ev[0]) { (void)hipEventDestroy(h->early_p3.ev[0]); (void)hipEventDestroy(h->early_p3.ev[1]); }
-    if (h->dyn_stream) { (void)hipStreamSynchronize(h->dyn_stream); (void)hipStreamDestroy(h->dyn_stream); (void)hipEventDestroy(h->dyn_ev[0]); (void)hipEventDestroy(h->dyn_ev[1]); }
     if (h->dk_stream) { (void)hipStreamSynchronize(h->dk_stream); (void)hipStreamDestroy(h->dk_stream); (void)hipEventDestroy(h->dk_ev[0]); (void)hipEventDestroy(h->dk_ev[1]); }
     if (h->spec_ln.fork) (void)hipEventDestroy(h->spec_ln.fork);
     if (h->spec_ln.pin) (void)hipHostFree(h->spec_ln.pin);
@@ -1121,23 +1120,11 @@ static void loudnorm_dynamic_run(jt_ctx *h, double *x, int64_t m, const Loudnorm
     P.dual_mono = in.dual_mono ? 1 : 0; P.n_inner = n_inner; P.final_len = FINAL;
     h->ln_ring.ensure(LBS); h->ln_series.ensure(series.size());
     JT_HIP(hipMemcpyAsync(h->ln_series.p, series.data(), series.size() * sizeof(double), hipMemcpyHostToDevice, s));
-    // One wave for seconds: on a stream of the HIGH-priority queue pool, which nothing else in the library uses.  On the main stream the
-    // kernel occupied one of the process's eight normal-priority hardware queues for its whole run and every stream of every other
-    // handle that ROCclr had mapped onto that queue stood still behind it -- with the handles' seven streams each spread over those
-    // eight queues, a batch of such files ran (nearly) one file at a time.
-    if (!h->dyn_stream) {
-        int plo = 0, phi = 0;
-        JT_HIP(hipDeviceGetStreamPriorityRange(&plo, &phi));
-        JT_HIP(hipStreamCreateWithPriority(&h->dyn_stream, hipStreamNonBlocking, phi));
-        JT_HIP(hipEventCreateWithFlags(&h->dyn_ev[0], hipEventDisableTiming)); JT_HIP(hipEventCreateWithFlags(&h->dyn_ev[1], hipEventDisableTiming));
-    }
-    JT_HIP(hipEventRecord(h->dyn_ev[0], s));
-    JT_HIP(hipStreamWaitEvent(h->dyn_stream, h->dyn_ev[0], 0));
-    launch_loudnorm_dynamic(x, m, P, h->ln_series.p, h->ln_ring.p, y, nullptr, h->dyn_stream);
+    // (the workgroup kernel runs as a sequence of launches of a few milliseconds each on the main stream: a launch that lasts a second
+    // holds up every other handle's stream that shares its hardware queue, k_loudnorm.hip)
+    h->ln_carry.ensure(256);
+    launch_loudnorm_dynamic(x, m, P, h->ln_series.p, h->ln_ring.p, y, nullptr, s, h->ln_carry.p);
     JT_HIP(hipGetLastError());
-    // the HOST waits for it: a wait queued on the main stream would sit at the head of that stream's hardware queue for seconds and hold
-    // up the other handles' streams behind it just as the kernel itself did (tools/ubench/long_kernel_blocks.hip)
-    JT_HIP(hipStreamSynchronize(h->dyn_stream));
     finish_stats(bs, nfull_ext, peak, true);
 }
 

@@ -182,7 +182,9 @@ struct LoudnormDynParams {
 };
 void jt_loudnorm_series(const double *bs, int64_t nfull, int64_t s100, bool dual_mono, int64_t n_inner, double *out);
 void jt_kweight_coeffs5(int sr, double b[5], double a[5]);
-void launch_loudnorm_dynamic(const double *x, int64_t n, const LoudnormDynParams &P, const double *series, double *ring, double *y, double *dbg, hipStream_t s);
+// carry: LN_CARRY = 256 doubles of device memory (the state one launch of the workgroup kernel hands to the next)
+void launch_loudnorm_dynamic(const double *x, int64_t n, const LoudnormDynParams &P, const double *series, double *ring, double *y, double *dbg, hipStream_t s,
+                             double *carry);
 void launch_scale_f64(const double *in, double *out, int64_t n, double g, hipStream_t s);
 void launch_swr_plain_f64(const double *in, int64_t n, const double *bank, int P, int L, int center, int64_t step, int64_t m_total, double *out, hipStream_t s);
 void launch_adeclick(jt_ctx *h, const double *in, double *out, int64_t n, int sample_rate, double threshold, double window_ms,
@@ -289,7 +291,7 @@ struct jt_ctx {
     // (set by pass3_core, dropped by anything that rewrites the Pass-2 output or the f64 buffers)
     struct LimKeep { bool valid = false; const int16_t *src = nullptr; int64_t m = 0; int rate = 0; double pre_gain_db = 0, limit = 0; } lim_keep;
     DevBuf<float> stream_f; DevBuf<double> stream_d;   // 192 kHz loudnorm-measurement stream
-    DevBuf<double> stream_y, ln_ring, ln_series;       // loudnorm dynamic mode: output stream, limiter ring, per-frame series
+    DevBuf<double> stream_y, ln_ring, ln_series, ln_carry;       // loudnorm dynamic mode: output stream, limiter ring, per-frame series
     // scratch
     DevBuf<double> d_scr0, d_scr1, d_scr2, d_scr3;
     DevBuf<unsigned long long> ehist; DevBuf<float> as_g, as_p;
@@ -338,7 +340,6 @@ struct jt_ctx {
     DevBuf<int> declick_F, declick_lists; DevBuf<unsigned short> declick_idx; DevBuf<double> declick_rhs, declick_aux, declick_r, declick_wlut, declick_prod;
     DevBuf<unsigned long long> declick_ctl;
     hipStream_t dk_stream = nullptr; hipEvent_t dk_ev[2] = {nullptr, nullptr};
-    hipStream_t dyn_stream = nullptr; hipEvent_t dyn_ev[2] = {nullptr, nullptr};     // the dynamic-loudnorm kernel's stream (high-priority pool)
     // Pass 3 with the limiter prefix, started inside Pass 2 once its loudness / true peak are known (jt_pass3_plan_hook)
     struct EarlyPass3 {
         jt_plan_fn fn = nullptr; void *user = nullptr; bool armed = false, mark_kw = false;

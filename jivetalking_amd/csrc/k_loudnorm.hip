@@ -691,15 +691,22 @@ __device__ __forceinline__ void lnw_true_peak_limiter(double *ring, double *cach
 
 __global__ void __launch_bounds__(LN_WG)
 k_loudnorm_dynamic_wg(const double *__restrict__ x, int64_t n, LoudnormDynParams P, const double *__restrict__ series, double *__restrict__ ring,
-                      double *__restrict__ y, double *__restrict__ dbg)
+                      double *__restrict__ y, double *__restrict__ dbg, double *__restrict__ carry, int64_t it_begin, int64_t it_end)
 {
+    // One launch walks the steps [it_begin, it_end) of the file (step 0 = FIRST_FRAME, then the INNER_FRAMEs, then the FINAL_FRAME's 29)
+    // and hands everything it knows to the next launch through `carry` (LN_CARRY doubles).  A single launch for the whole file ran for
+    // a second and more, and a kernel that long holds up every stream ROCclr has mapped onto its hardware queue (other files' passes on
+    // the same GPU); a stream of the high-priority pool avoided that but brought the process to 24 hardware queues, which the driver
+    // time-slices: everything else on the GPU ran at half speed from then on.
     extern __shared__ double ln_cache[];                            // [LN_CACHE]; the output meter's tile aliases its head
     __shared__ double delta[30], w[21], oe[30];
     __shared__ unsigned char hot[LN_LBS / 64];
     double *tile = ln_cache;
     const int tid = threadIdx.x;
-    if (tid < 30) { delta[tid] = P.delta0; oe[tid] = 0.0; }
+    const bool fresh = it_begin == 0;
+    if (tid < 30) { delta[tid] = fresh ? P.delta0 : carry[16 + tid]; oe[tid] = fresh ? 0.0 : carry[46 + tid]; }
     if (tid < 21) w[tid] = P.weights[tid];
+    if (!fresh) for (int k = tid; k < LN_LBS / 64; k += LN_WG) hot[k] = reinterpret_cast<const unsigned char *>(carry + 96)[k];
 #ifdef JT_LN_PROFILE
     if (tid < 16) lnp_acc[tid] = 0;
 #endif
@@ -711,6 +718,15 @@ k_loudnorm_dynamic_wg(const double *__restrict__ x, int64_t n, LoudnormDynParams
     double prev_delta = P.delta0;
     double kv1 = 0, kv2 = 0, kv3 = 0, kv4 = 0;                      // the output meter's filter state (thread 0)
     int oe_pos = 0;
+    int64_t produced = 0, abs_in = LN_LBS, src_index = LN_LBS;
+    double gain_final = 0.0;
+    if (!fresh) {
+        s.gr0 = carry[0]; s.gr1 = carry[1]; s.prev_smp = carry[2]; s.lbi = (int)carry[3]; s.state = (int)carry[4]; s.peak_index = (int)carry[5];
+        s.env_index = (int)carry[6]; s.env_cnt = (int)carry[7]; s.attack_length = (int)carry[8]; s.first = carry[9] != 0.0;
+        index = (int)carry[10]; above = (int)carry[11]; prev_delta = carry[12]; oe_pos = (int)carry[13];
+        kv1 = carry[76]; kv2 = carry[77]; kv3 = carry[78]; kv4 = carry[79];
+        produced = (int64_t)carry[80]; abs_in = (int64_t)carry[81]; src_index = (int64_t)carry[82]; gain_final = carry[83];
+    }
     auto out_energy = [&](const double *src, int cnt) {
         double sum = 0.0;
         for (int c0 = 0; c0 < cnt; c0 += 1024) {
@@ -738,9 +754,7 @@ k_loudnorm_dynamic_wg(const double *__restrict__ x, int64_t n, LoudnormDynParams
     const int nfinal = (int)(P.final_len / LN_F100);
     const int64_t total = 1 + P.n_inner + nfinal;
     const double *fsrc = x + (n - P.final_len);
-    int64_t produced = 0, abs_in = LN_LBS, src_index = LN_LBS;
-    double gain_final = 0.0;
-    for (int64_t it = 0; it < total; ++it) {
+    for (int64_t it = it_begin; it < total && it < it_end; ++it) {
         int nb = LN_F100;
         if (it == 0) {
             const double d0 = P.delta0;
@@ -799,6 +813,17 @@ k_loudnorm_dynamic_wg(const double *__restrict__ x, int64_t n, LoudnormDynParams
         }
     }
     if (tid == 0 && dbg) { dbg[0] = (double)produced; dbg[1] = (double)above; dbg[2] = (double)s.state; dbg[3] = prev_delta; }
+    // hand-over to the next launch (thread 0 is in the wave that ran the limiter: its copy of the state is the live one)
+    __syncthreads();
+    if (tid == 0) {
+        carry[0] = s.gr0; carry[1] = s.gr1; carry[2] = s.prev_smp; carry[3] = s.lbi; carry[4] = s.state; carry[5] = s.peak_index;
+        carry[6] = s.env_index; carry[7] = s.env_cnt; carry[8] = s.attack_length; carry[9] = s.first ? 1.0 : 0.0;
+        carry[10] = index; carry[11] = above; carry[12] = prev_delta; carry[13] = oe_pos;
+        carry[76] = kv1; carry[77] = kv2; carry[78] = kv3; carry[79] = kv4;
+        carry[80] = (double)produced; carry[81] = (double)abs_in; carry[82] = (double)src_index; carry[83] = gain_final;
+    }
+    if (tid < 30) { carry[16 + tid] = delta[tid]; carry[46 + tid] = oe[tid]; }
+    for (int k = tid; k < LN_LBS / 64; k += LN_WG) reinterpret_cast<unsigned char *>(carry + 96)[k] = hot[k];
 #ifdef JT_LN_PROFILE
     __syncthreads();
     if (tid < 16) g_ln_prof[tid] = lnp_acc[tid];
@@ -838,21 +863,17 @@ void launch_swr_plain_f64(const double *in, int64_t n, const double *bank, int P
 {
     if (m_total > 0) hipLaunchKernelGGL(k_swr_plain_f64, dim3((unsigned)((m_total + 255) / 256)), dim3(256), 0, s, in, n, bank, P, L, center, step, m_total, out);
 }
-void launch_loudnorm_dynamic(const double *x, int64_t n, const LoudnormDynParams &P, const double *series, double *ring, double *y, double *dbg, hipStream_t s)
+void launch_loudnorm_dynamic(const double *x, int64_t n, const LoudnormDynParams &P, const double *series, double *ring, double *y, double *dbg, hipStream_t s,
+                             double *carry)
 {
     if (!getenv("JT_DYN_ONE_WAVE")) {
-        // sixteen waves, the frame being limited and its look-ahead in LDS (159 KB: the workgroup has its CU to itself)
+        // eight waves, the limiter's window in LDS (159 KB: the workgroup has its CU to itself); LN_STEPS steps of the file per launch
         const int smem = LN_CACHE * (int)sizeof(double);
         (void)hipFuncSetAttribute((const void *)k_loudnorm_dynamic_wg, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-#ifdef JT_LN_PROFILE
-        { unsigned long long z[16] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_ln_prof), z, sizeof z); }
-#endif
-        hipLaunchKernelGGL(k_loudnorm_dynamic_wg, dim3(1), dim3(LN_WG), smem, s, x, n, P, series, ring, y, dbg);
-#ifdef JT_LN_PROFILE
-        { unsigned long long z[16]; (void)hipStreamSynchronize(s); (void)hipMemcpyFromSymbol(z, HIP_SYMBOL(g_ln_prof), sizeof z);
-          fprintf(stderr, "loudnorm dynamic (%lld frames), shader Mcycles: fill %.1f, window load %.1f, limiter loop %.1f (detect %.1f, scale %.1f), write-back + out %.1f; %llu scale passes, %llu detect calls (%llu left the window, %llu general walks: %.1f Mcycles; in the window: search %.1f, test + walk %.1f)\n",
-                  (long long)P.n_inner, z[0] / 1e6, z[1] / 1e6, z[2] / 1e6, z[4] / 1e6, z[7] / 1e6, z[3] / 1e6, z[5], z[6], z[8], z[9], z[10] / 1e6, z[11] / 1e6, z[12] / 1e6); }
-#endif
+        const int64_t total = 1 + P.n_inner + P.final_len / LN_F100;
+        static const int64_t steps = getenv("JT_DYN_STEPS") ? std::max(1, atoi(getenv("JT_DYN_STEPS"))) : 64;
+        for (int64_t it = 0; it < total; it += steps)
+            hipLaunchKernelGGL(k_loudnorm_dynamic_wg, dim3(1), dim3(LN_WG), smem, s, x, n, P, series, ring, y, dbg, carry, it, std::min(total, it + steps));
         return;
     }
     // 96 KB of (unused) dynamic LDS: the workgroup then has a CU to itself.  Several files in flight each run one such wave, and the
