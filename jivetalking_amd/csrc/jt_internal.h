@@ -124,7 +124,7 @@ void launch_absmax_conv_s16(const int16_t *in, double *conv, double *out, int64_
                             int64_t nblk, hipStream_t s);
 void launch_limiter_f64(const double *in, double *out, int64_t n, int sr, double limit, int buffer_size,
                         double release_s, double asc_coeff, const double *block_max, int64_t nblk, int blk, int need, int target,
-                        int64_t *cand, int64_t ntargets, double in_gain, double *scratch_delta, int64_t *scratch_pos, hipStream_t s);
+                        int64_t *cand, int64_t ntargets, double in_gain, double *scratch_delta, int64_t *scratch_pos, hipStream_t s, double *scratch_lp);
 
 // resampler / true peak
 void launch_resample_to_s16(const float *in, int64_t n, const double *bank, int phase_count, int filter_length, int center,
@@ -298,7 +298,7 @@ struct jt_ctx {
     DevBuf<jt_spectral> spec_hops;
     DevBuf<float2> twiddle; int twiddle_n = 0; DevBuf<float> hann; int hann_n = 0;
     DevBuf<double> bank_d; DevBuf<float> bank_f;
-    DevBuf<int64_t> lim_bounds, lim_pos; DevBuf<double> lim_delta;
+    DevBuf<int64_t> lim_bounds, lim_pos; DevBuf<double> lim_delta, lim_lp;
     DevBuf<int> af_bin2band; DevBuf<double> af_tab, af_track; double af_last_floor = 0;      // af_track: tn=1 votes + per-frame max_var
     HostArena pin;
     // per-pass bump allocator over d_scr2 for the astats jobs: the three chains of different jobs run on different streams, so

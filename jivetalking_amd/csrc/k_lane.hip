@@ -1074,7 +1074,7 @@ __global__ void k_lim_bounds(const double *__restrict__ mx, int64_t nblk, int ne
 __global__ void __launch_bounds__(64)
 k_limiter_f64(const double *__restrict__ in, double *__restrict__ out, int64_t n, int sr, double limit, int B,
               double release, double asc_coeff, const int64_t *__restrict__ cand, int64_t ntargets, int blk, double in_gain,
-              double *__restrict__ sdelta, int64_t *__restrict__ spos, const double *__restrict__ block_max, int64_t nblk)
+              double *__restrict__ sdelta, int64_t *__restrict__ spos, const double *__restrict__ block_max, int64_t nblk, double *__restrict__ slp)
 {
     __shared__ double tx[LANES][TW + 1];
     __shared__ double te[LANES][TW + 1];
@@ -1115,6 +1115,10 @@ k_limiter_f64(const double *__restrict__ in, double *__restrict__ out, int64_t n
     __syncthreads();
     double *nextdelta = sdelta + (size_t)c * B;
     int64_t *nextpos = spos + (size_t)c * B;
+    // limit / |pending peak| beside every list entry: the filter recomputes that quotient from its sample buffer for every entry it
+    // compares a new peak with (a division per entry and sample above the limit); it is the same quotient, of the same operands, that
+    // was formed when the entry's sample was the new peak
+    double *nextlp = slp + (size_t)c * B;
     if (active) nextpos[0] = -1;      // list entries are always written (with their -1 terminator) before they are read
     double att = 1.0, delta = 0.0, asc = 0.0; int asc_c = 0;
     int nextiter = 0, nextlen = 0;
@@ -1182,26 +1186,27 @@ k_limiter_f64(const double *__restrict__ in, double *__restrict__ out, int64_t n
                 double peak = fabs(x);
                 if (peak > limit) { asc += peak; asc_c++; }
                 if (peak > limit) {
-                    double patt = fmin(limit / peak, 1.);
+                    const double lp = limit / peak;
+                    double patt = fmin(lp, 1.);
                     double rdelta = (1.0 - patt) / (sr * release);
-                    double dl = (limit / peak - att) / B * 1;
+                    double dl = (lp - att) / B * 1;
                     bool found = false;
                     if (dl < delta) {
                         delta = dl;
-                        nextpos[0] = i; nextpos[1 % B] = -1; nextdelta[0] = rdelta;
+                        nextpos[0] = i; nextpos[1 % B] = -1; nextdelta[0] = rdelta; nextlp[0] = lp;
                         nextlen = 1; nextiter = 0;
                     } else {
                         int k;
                         for (k = nextiter; k < nextiter + nextlen; k++) {
                             int jj = k % B;
-                            double ppeak = fabs(in[nextpos[jj]] * in_gain);
-                            double pdelta = (limit / peak - limit / ppeak) / (double)((i - nextpos[jj]) / 1);
+                            double pdelta = (lp - nextlp[jj]) / (double)((i - nextpos[jj]) / 1);
                             if (pdelta < nextdelta[jj]) { nextdelta[jj] = pdelta; found = true; break; }
                         }
                         if (found) {
                             nextlen = k - nextiter + 1;
                             nextpos[(nextiter + nextlen) % B] = i;
                             nextdelta[(nextiter + nextlen) % B] = rdelta;
+                            nextlp[(nextiter + nextlen) % B] = lp;
                             nextpos[(nextiter + nextlen + 1) % B] = -1;
                             nextlen++;
                         }
@@ -1227,8 +1232,7 @@ k_limiter_f64(const double *__restrict__ in, double *__restrict__ out, int64_t n
                     delta = rd;
                     if (nextlen > 1) {
                         int64_t pnext = nextpos[(nextiter + 1) % B];
-                        double ppeak = fabs(in[pnext] * in_gain);
-                        double pdelta = (limit / ppeak - att) / (double)(pnext - eidx);
+                        double pdelta = (nextlp[(nextiter + 1) % B] - att) / (double)(pnext - eidx);
                         if (pdelta < delta) delta = pdelta;
                     }
                     nextlen -= 1;
@@ -1258,13 +1262,13 @@ k_limiter_f64(const double *__restrict__ in, double *__restrict__ out, int64_t n
 
 void launch_limiter_f64(const double *in, double *out, int64_t n, int sr, double limit, int buffer_size,
                         double release_s, double asc_coeff, const double *block_max, int64_t nblk, int blk, int need, int target,
-                        int64_t *cand, int64_t ntargets, double in_gain, double *scratch_delta, int64_t *scratch_pos, hipStream_t s)
+                        int64_t *cand, int64_t ntargets, double in_gain, double *scratch_delta, int64_t *scratch_pos, hipStream_t s, double *scratch_lp)
 {
     if (n <= 0) return;
     hipLaunchKernelGGL(k_lim_bounds, dim3((unsigned)((ntargets + 255) / 256)), dim3(256), 0, s, block_max, nblk, need, target,
                        std::fabs(in_gain), limit, cand, ntargets);
     hipLaunchKernelGGL(k_limiter_f64, dim3((unsigned)((ntargets + LANES - 1) / LANES)), dim3(LANES), 0, s, in, out, n, sr, limit,
-                       buffer_size, release_s, asc_coeff, cand, ntargets, blk, in_gain, scratch_delta, scratch_pos, block_max, nblk);
+                       buffer_size, release_s, asc_coeff, cand, ntargets, blk, in_gain, scratch_delta, scratch_pos, block_max, nblk, scratch_lp);
 }
 
 // ------------------------------------------------------------------ biquad pair, direct form I (f32)
