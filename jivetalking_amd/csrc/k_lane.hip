@@ -1122,6 +1122,8 @@ k_limiter_f64(const double *__restrict__ in, double *__restrict__ out, int64_t n
     if (active) nextpos[0] = -1;      // list entries are always written (with their -1 terminator) before they are read
     double att = 1.0, delta = 0.0, asc = 0.0; int asc_c = 0;
     int nextiter = 0, nextlen = 0;
+    // ring indices: x % B for 0 <= x < 2 B (nextiter < B, nextlen <= B) without the integer division a run-time B costs per use
+    auto wrapB = [&](int x) -> int { return x >= B ? x - B : x; };
     for (int64_t pos = 0; pos < max_len; pos += TW) {
         // stage: row r, column = lane
         for (int a0 = 0; a0 < nact; a0 += 8) {
@@ -1188,26 +1190,29 @@ k_limiter_f64(const double *__restrict__ in, double *__restrict__ out, int64_t n
                 if (peak > limit) {
                     const double lp = limit / peak;
                     double patt = fmin(lp, 1.);
-                    double rdelta = (1.0 - patt) / (sr * release);
+                    // (rdelta is only stored with a new list entry: its division is left to the two places that make one -- a hot
+                    // sample is a handful of f64 divisions on one lane, and they are the kernel's time)
+                    auto rdelta_of = [&]() -> double { return (1.0 - patt) / (sr * release); };
                     double dl = (lp - att) / B * 1;
                     bool found = false;
                     if (dl < delta) {
                         delta = dl;
-                        nextpos[0] = i; nextpos[1 % B] = -1; nextdelta[0] = rdelta; nextlp[0] = lp;
+                        nextpos[0] = i; nextpos[B == 1 ? 0 : 1] = -1; nextdelta[0] = rdelta_of(); nextlp[0] = lp;
                         nextlen = 1; nextiter = 0;
                     } else {
                         int k;
                         for (k = nextiter; k < nextiter + nextlen; k++) {
-                            int jj = k % B;
+                            int jj = wrapB(k);
                             double pdelta = (lp - nextlp[jj]) / (double)((i - nextpos[jj]) / 1);
                             if (pdelta < nextdelta[jj]) { nextdelta[jj] = pdelta; found = true; break; }
                         }
                         if (found) {
                             nextlen = k - nextiter + 1;
-                            nextpos[(nextiter + nextlen) % B] = i;
-                            nextdelta[(nextiter + nextlen) % B] = rdelta;
-                            nextlp[(nextiter + nextlen) % B] = lp;
-                            nextpos[(nextiter + nextlen + 1) % B] = -1;
+                            const int jn_ = wrapB(nextiter + nextlen);
+                            nextpos[jn_] = i;
+                            nextdelta[jn_] = rdelta_of();
+                            nextlp[jn_] = lp;
+                            nextpos[wrapB(jn_ + 1)] = -1;
                             nextlen++;
                         }
                     }
@@ -1231,13 +1236,14 @@ k_limiter_f64(const double *__restrict__ in, double *__restrict__ out, int64_t n
                     }
                     delta = rd;
                     if (nextlen > 1) {
-                        int64_t pnext = nextpos[(nextiter + 1) % B];
-                        double pdelta = (nextlp[(nextiter + 1) % B] - att) / (double)(pnext - eidx);
+                        const int j1_ = wrapB(nextiter + 1);
+                        int64_t pnext = nextpos[j1_];
+                        double pdelta = (nextlp[j1_] - att) / (double)(pnext - eidx);
                         if (pdelta < delta) delta = pdelta;
                     }
                     nextlen -= 1;
                     nextpos[nextiter] = -1;
-                    nextiter = (nextiter + 1) % B;
+                    nextiter = wrapB(nextiter + 1);
                 }
                 if (att > 1.) { att = 1.; delta = 0.; nextiter = 0; nextlen = 0; nextpos[0] = -1; }
                 if (att <= 0.) { att = 0.0000000000001; delta = (1.0 - att) / (sr * release); }
@@ -1267,6 +1273,8 @@ void launch_limiter_f64(const double *in, double *out, int64_t n, int sr, double
     if (n <= 0) return;
     hipLaunchKernelGGL(k_lim_bounds, dim3((unsigned)((ntargets + 255) / 256)), dim3(256), 0, s, block_max, nblk, need, target,
                        std::fabs(in_gain), limit, cand, ntargets);
+    // (the rings in LDS -- 3 x B doubles for each of up to four hot segments -- made one hot sample 10 % cheaper and the launch 50 % longer:
+    // 21 KB more LDS per workgroup halves the workgroups a CU holds, and there are 1 200 of them, most with nothing to do)
     hipLaunchKernelGGL(k_limiter_f64, dim3((unsigned)((ntargets + LANES - 1) / LANES)), dim3(LANES), 0, s, in, out, n, sr, limit,
                        buffer_size, release_s, asc_coeff, cand, ntargets, blk, in_gain, scratch_delta, scratch_pos, block_max, nblk, scratch_lp);
 }
