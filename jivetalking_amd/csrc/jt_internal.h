@@ -317,6 +317,8 @@ struct jt_ctx {
         double *r = d_scr0.p + kw_off; kw_off += (doubles + 7) & ~(size_t)7; return r;
     }
     SwrDev swr[4]; int swr_next = 0;
+    // K-weighting: homogeneous-response tables of the one-sweep kernel, per (rate, chunk length)
+    struct KwTab { int rate = 0; int64_t L = 0; std::vector<double> g; DevBuf<double> dev; } kw_tab[8]; int kw_tab_next = 0;
     DevBuf<float> region_f; DevBuf<int16_t> region_s16;
     // Pass 3's measurement of the Pass-2 output for the no-prefix plan (the usual one), queued by Pass 2 itself on a stream of
     // its own as soon as the s16 output exists: it runs beside Pass 2's analysis tail and the host work between the passes.

@@ -503,6 +503,97 @@ k_kw(const TIn *__restrict__ in, int64_t n, int64_t L, KwCoef k, const double *_
         else { zs_out[my_c * 4 + 0] = s1; zs_out[my_c * 4 + 1] = s2; zs_out[my_c * 4 + 2] = t1; zs_out[my_c * 4 + 3] = t2; }
     }
 }
+// ONE sweep instead of two (round 3).  With zs the chunk's zero-state output and h_j = g_j . s0 the homogeneous response to the state s0
+// carried into the chunk, the chunk's energy is sum (zs_j + h_j)^2 = sum zs_j^2 + 2 s0 . (sum zs_j g_j) + s0' (sum g_j g_j') s0: the sweep
+// that produces the zero-state end states also accumulates sum zs^2 and the four sums zs_j g_j[k] (g_j: the output at step j of a chunk
+// started from the k-th unit state with no input, a table per (rate, L) that every lane reads at the same j: scalar loads), and
+// k_kw_fix puts the carried state in afterwards, one thread per chunk.  The second sweep re-read the whole signal (5.5 GB for an hour at
+// 192 kHz) to do the same thing sample by sample.  Rounding differs from the two-sweep form at the 1e-13 level (the three terms cancel
+// the start-up transient of the zero-state run); JT_KW_TWO_SWEEPS=1 keeps the old form.
+template <typename TIn>
+__global__ void __launch_bounds__(64)
+k_kw1(const TIn *__restrict__ in, int64_t n, int64_t L, KwCoef k, const double *__restrict__ g, double *__restrict__ zs_out,
+      double *__restrict__ csum, double *__restrict__ cpeak, double *__restrict__ cross, int64_t nchunks)
+{
+    __shared__ TIn tile[LANES][TW + 1];
+    __shared__ __attribute__((aligned(32))) double gt[TW * 4];      // the table rows of the current 64-sample step (read at a wave-uniform index: LDS broadcasts)
+    const int lane = threadIdx.x;
+    const int64_t c0 = (int64_t)blockIdx.x * LANES;
+    const int nrows = (int)min((int64_t)LANES, nchunks - c0);
+    const int64_t base0 = c0 * L;
+    const int64_t my_c = c0 + lane;
+    const int64_t my_base = base0 + (int64_t)lane * L;
+    double s1 = 0, s2 = 0, t1 = 0, t2 = 0;
+    double acc = 0.0, pk = 0.0, zz = 0.0, x0c = 0.0, x1c = 0.0, x2c = 0.0, x3c = 0.0;
+    TIn v[LANES];
+    rows_prefetch<TIn>(v, in, n, base0, L, 0, lane);
+    for (int64_t pos = 0; pos < L; pos += TW) {
+        rows_commit<TIn, TIn>(tile, v, n, base0, L, pos, lane, nrows);
+        if (pos + lane < L) {
+            const double4 gv = *reinterpret_cast<const double4 *>(g + 4 * (pos + lane));
+            *reinterpret_cast<double4 *>(gt + 4 * lane) = gv;
+        }
+        __syncthreads();
+        if (pos + TW < L) rows_prefetch<TIn>(v, in, n, base0, L, pos + TW, lane);
+        if (lane < nrows) {
+            const int64_t t0 = my_base + pos;
+            const double *gp = gt;
+            if (pos + TW <= L && t0 + TW <= n) {
+#pragma unroll 16
+                for (int j = 0; j < TW; ++j) {
+                    const double x0 = (double)tile[lane][j];
+                    KW2_STEP(x0)
+                    acc = fma(zz, zz, acc); pk = fmax(pk, fabs(x0));
+                    x0c = fma(zz, gp[4 * j + 0], x0c); x1c = fma(zz, gp[4 * j + 1], x1c); x2c = fma(zz, gp[4 * j + 2], x2c); x3c = fma(zz, gp[4 * j + 3], x3c);
+                }
+            } else {
+                for (int j = 0; j < TW; ++j) {
+                    if (pos + j >= L || t0 + j >= n) break;
+                    const double x0 = (double)tile[lane][j];
+                    KW2_STEP(x0)
+                    acc = fma(zz, zz, acc); pk = fmax(pk, fabs(x0));
+                    x0c = fma(zz, gp[4 * j + 0], x0c); x1c = fma(zz, gp[4 * j + 1], x1c); x2c = fma(zz, gp[4 * j + 2], x2c); x3c = fma(zz, gp[4 * j + 3], x3c);
+                }
+            }
+        }
+        __syncthreads();
+    }
+    if (lane < nrows) {
+        csum[my_c] = acc; cpeak[my_c] = pk;
+        zs_out[my_c * 4 + 0] = s1; zs_out[my_c * 4 + 1] = s2; zs_out[my_c * 4 + 2] = t1; zs_out[my_c * 4 + 3] = t2;
+        cross[my_c * 4 + 0] = x0c; cross[my_c * 4 + 1] = x1c; cross[my_c * 4 + 2] = x2c; cross[my_c * 4 + 3] = x3c;
+    }
+}
+// csum[c] += 2 s0 . cross[c] + s0' G s0, s0 = the state carried into chunk c (the series k_kw<., true> starts from); G = sum g_j g_j' over the
+// chunk's length (the last chunk may be shorter: Gt), upper triangle row-major
+struct KwGram { double f[10], t[10]; };
+__global__ void __launch_bounds__(64)
+k_kw_fix(const double *__restrict__ zs_in, const double *__restrict__ fpow, int nterms, const double *__restrict__ cross, KwGram G,
+         double *__restrict__ csum, int64_t nchunks)
+{
+    const int64_t c = (int64_t)blockIdx.x * 64 + threadIdx.x;
+    if (c >= nchunks) return;
+    double s[4] = {0, 0, 0, 0};
+    for (int q = 0; q < nterms; ++q) {
+        const int64_t cc = c - 1 - q;
+        if (cc < 0) break;
+        const double e0 = zs_in[cc * 4 + 0], e1 = zs_in[cc * 4 + 1], e2 = zs_in[cc * 4 + 2], e3 = zs_in[cc * 4 + 3];
+        if (q == 0) { s[0] += e0; s[1] += e1; s[2] += e2; s[3] += e3; }
+        else {
+            const double *M = fpow + (size_t)(q - 1) * 16;
+            s[0] += M[0] * e0 + M[1] * e1 + M[2] * e2 + M[3] * e3;
+            s[1] += M[4] * e0 + M[5] * e1 + M[6] * e2 + M[7] * e3;
+            s[2] += M[8] * e0 + M[9] * e1 + M[10] * e2 + M[11] * e3;
+            s[3] += M[12] * e0 + M[13] * e1 + M[14] * e2 + M[15] * e3;
+        }
+    }
+    const double *Gm = c == nchunks - 1 ? G.t : G.f;
+    double lin = 0.0, quad = 0.0;
+    for (int a = 0; a < 4; ++a) lin += s[a] * cross[c * 4 + a];
+    int u = 0;
+    for (int a = 0; a < 4; ++a) for (int b = a; b < 4; ++b, ++u) quad += (a == b ? 1.0 : 2.0) * Gm[u] * s[a] * s[b];
+    csum[c] = csum[c] + 2.0 * lin + quad;
+}
 #undef KW2_STEP
 
 // Per-block sums / peaks from the per-chunk partials, in chunk order (what the host loop of jt_kweight_finish did over 360 k chunks of an
@@ -538,7 +629,7 @@ static int kw_chunks_per_block(int blk)
 void jt_kweight_scratch_sizes(int64_t n, int blk, size_t *dev_doubles, size_t *pin_doubles)
 {
     const int64_t L = blk / kw_chunks_per_block(blk), nchunks = (n + L - 1) / L;
-    *dev_doubles = 4 * (size_t)nchunks + 24 * 16 + 2 * (size_t)nchunks + 64;
+    *dev_doubles = 4 * (size_t)nchunks + 24 * 16 + 2 * (size_t)nchunks + 4 * (size_t)nchunks + 64;
     *pin_doubles = 24 * 16 + 2 * (size_t)nchunks + 64;
 }
 
@@ -564,16 +655,52 @@ static void kweight_enqueue(jt_ctx *h, const TIn *in, int64_t n, int rate, int b
         std::memcpy(pw + 16 * npw, cur, sizeof(cur)); npw++; nterms++;
         mat4_mul(cur, FL, cur);
     }
-    // device scratch: zs | pw | csum | cpeak.  Each job gets its own region of d_scr0 (several may be in flight in one pass).
-    const size_t need = 4 * (size_t)nchunks + 24 * 16 + 2 * (size_t)nchunks;
+    // device scratch: zs | pw | csum | cpeak | cross.  Each job gets its own region of d_scr0 (several may be in flight in one pass).
+    const size_t need = 4 * (size_t)nchunks + 24 * 16 + 2 * (size_t)nchunks + 4 * (size_t)nchunks;
     double *base = ext ? ext->dev : h->kw_take(need);
-    double *d_zs = base, *d_pw = base + 4 * (size_t)nchunks, *d_cs = d_pw + 24 * 16;
+    double *d_zs = base, *d_pw = base + 4 * (size_t)nchunks, *d_cs = d_pw + 24 * 16, *d_cross = d_cs + 2 * (size_t)nchunks;
     if (npw) JT_HIP(hipMemcpyAsync(d_pw, pw, sizeof(double) * 16 * npw, hipMemcpyHostToDevice, st));
     const unsigned grid = (unsigned)((nchunks + LANES - 1) / LANES);
-    hipLaunchKernelGGL((k_kw<TIn, false>), dim3(grid), dim3(LANES), 0, st, in, n, L, k, (const double *)nullptr, (const double *)nullptr, 0,
-                       d_zs, (double *)nullptr, (double *)nullptr, nchunks);
-    hipLaunchKernelGGL((k_kw<TIn, true>), dim3(grid), dim3(LANES), 0, st, in, n, L, k, d_zs, d_pw, nterms,
-                       (double *)nullptr, d_cs, d_cs + nchunks, nchunks);
+    const bool two_sweeps = getenv("JT_KW_TWO_SWEEPS") != nullptr;
+    if (two_sweeps) {
+        hipLaunchKernelGGL((k_kw<TIn, false>), dim3(grid), dim3(LANES), 0, st, in, n, L, k, (const double *)nullptr, (const double *)nullptr, 0,
+                           d_zs, (double *)nullptr, (double *)nullptr, nchunks);
+        hipLaunchKernelGGL((k_kw<TIn, true>), dim3(grid), dim3(LANES), 0, st, in, n, L, k, d_zs, d_pw, nterms,
+                           (double *)nullptr, d_cs, d_cs + nchunks, nchunks);
+    } else {
+        // homogeneous-response table of this (rate, L): g[j][k] = output at step j from the k-th unit state, no input (same statements as
+        // KW2_STEP); cached on the handle
+        jt_ctx::KwTab *T = nullptr;
+        for (auto &t : h->kw_tab) if (t.rate == rate && t.L == L) T = &t;
+        if (!T) {
+            T = &h->kw_tab[h->kw_tab_next++ % 8];
+            T->rate = rate; T->L = L; T->g.assign((size_t)4 * L, 0.0);
+            for (int u = 0; u < 4; ++u) {
+                double s1 = u == 0, s2 = u == 1, t1 = u == 2, t2 = u == 3;
+                for (int64_t j = 0; j < L; ++j) {
+                    const double y = s1;                                   // fma(b0, 0, s1)
+                    s1 = std::fma(-k.a1, y, s2); s2 = std::fma(-k.a2, y, 0.0);
+                    const double zz = std::fma(k.c0, y, t1);
+                    t1 = std::fma(-k.d1, zz, std::fma(k.c1, y, t2)); t2 = std::fma(-k.d2, zz, k.c2 * y);
+                    T->g[(size_t)4 * j + u] = zz;
+                }
+            }
+            T->dev.ensure((size_t)4 * L);
+            JT_HIP(hipMemcpy(T->dev.p, T->g.data(), sizeof(double) * 4 * (size_t)L, hipMemcpyHostToDevice));
+        }
+        KwGram G; std::memset(&G, 0, sizeof G);
+        const int64_t tail = n - (nchunks - 1) * L;                        // samples of the last chunk (1 .. L)
+        for (int64_t j = 0; j < L; ++j) {
+            int u = 0;
+            for (int a = 0; a < 4; ++a) for (int b = a; b < 4; ++b, ++u) {
+                const double p_ = T->g[(size_t)4 * j + a] * T->g[(size_t)4 * j + b];
+                G.f[u] += p_; if (j < tail) G.t[u] += p_;
+            }
+        }
+        hipLaunchKernelGGL((k_kw1<TIn>), dim3(grid), dim3(LANES), 0, st, in, n, L, k, (const double *)T->dev.p, d_zs, d_cs, d_cs + nchunks, d_cross, nchunks);
+        hipLaunchKernelGGL(k_kw_fix, dim3((unsigned)((nchunks + 63) / 64)), dim3(64), 0, st, (const double *)d_zs, (const double *)d_pw, nterms,
+                           (const double *)d_cross, G, d_cs, nchunks);
+    }
     // block sums / peaks into the (now dead) zero-state region, (nfull + 1) entries each; only those travel to the host
     const int64_t nfull = n / blk;
     hipLaunchKernelGGL(k_kw_blocks, dim3((unsigned)((nfull + 1 + 63) / 64)), dim3(64), 0, st, d_cs, d_cs + nchunks, nchunks, m, nfull, d_zs);
