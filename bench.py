@@ -477,6 +477,10 @@ def main():
                                 "note": "jt_load_audio of that image (44.1 kHz mono s16): H2D from pageable memory, find + parse + "
                                         "decode + finish kernels, host chain walk"},
             }
+        # (before the other legs: after them the same batch ran 20-70 % slower -- the GPU and the host have been busy for half a minute
+        # by then -- and this one is BASELINE configs[3]'s share)
+        if world == 1 and args.saturation and args.channels == 1:
+            out["saturation"] = saturation_leg(eng, local_rank, base, hostlogic, synth, sr, args.sat_files, args.sat_minutes, args.sat_in_flight)
         if world == 1 and args.e2e and args.channels == 1:
             out["e2e"] = e2e_legs(eng, x, n, sr, seconds, base, hostlogic, Engine, local_rank)
             dev_s = f"cuda:{local_rank}"
@@ -522,8 +526,6 @@ def main():
                                  "pass_ms": {"pass1": round(tm["pass1_ms"], 2), "pass2": round(tm["pass2_ms"], 2), "pass3": round(tm["pass3_ms"], 2), "pass4": round(tm["pass4_ms"], 2)},
                                  "anlmdn_ms": round(tm["nlm_ms"], 2), "output_lufs": round(rs.output_lufs, 2), "output_dbtp": round(rs.output_tp_db, 2)}
             del xs
-        if world == 1 and args.saturation and args.channels == 1:
-            out["saturation"] = saturation_leg(eng, local_rank, base, hostlogic, synth, sr, args.sat_files, args.sat_minutes, args.sat_in_flight)
         if world == 1 and args.cpu_sample > 0:
             out["cpu_baseline"] = cpu_baseline(args.cpu_sample, sr)
         print(json.dumps(out))
