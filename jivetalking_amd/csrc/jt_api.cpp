@@ -44,12 +44,16 @@ extern "C" int jt_open(int device_id, jt_ctx **out)
         JT_HIP(hipEventCreateWithFlags(&h->spec_p2.done, hipEventDisableTiming));
         JT_HIP(hipStreamCreateWithFlags(&h->spec_ln.stream, hipStreamNonBlocking));
         JT_HIP(hipEventCreateWithFlags(&h->spec_ln.fork, hipEventDisableTiming));
-        // the chains of announced output regions (aux[4..7]) are small: they run behind the full analysis on its four streams
+        // the chains of announced output regions (aux[4..7]) are small: aliases of other streams, picked by pass_begin
         for (int i = 0; i < 8; ++i) {
             if (i < 4) JT_HIP(hipStreamCreateWithFlags(&h->aux[i], hipStreamNonBlocking));
-            else h->aux[i] = h->aux[i - 4];
+            else h->aux[i] = h->aux[(i + 3) % 4];
             JT_HIP(hipEventCreateWithFlags(&h->ev_join[i], hipEventDisableTiming));
         }
+        JT_HIP(hipStreamCreateWithFlags(&h->dk_stream, hipStreamNonBlocking));
+        JT_HIP(hipEventCreateWithFlags(&h->dk_ev[0], hipEventDisableTiming)); JT_HIP(hipEventCreateWithFlags(&h->dk_ev[1], hipEventDisableTiming));
+        for (int i = 0; i < 6; ++i) JT_HIP(hipEventCreateWithFlags(&h->ev_chain[i], hipEventDisableTiming));
+        JT_HIP(hipEventCreateWithFlags(&h->ev_stats, hipEventDisableTiming));
     } catch (const JtError &) { delete h; return JT_E_NOGPU; }
     *out = h;
     return JT_OK;
@@ -74,9 +78,11 @@ extern "C" void jt_close(jt_ctx *h)
     if (h->spec_ln.pin) (void)hipHostFree(h->spec_ln.pin);
     if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
     for (int i = 0; i < 8; ++i) {
-        if (h->aux[i] && !(i >= 4 && h->aux[i] == h->aux[i - 4])) { (void)hipStreamSynchronize(h->aux[i]); (void)hipStreamDestroy(h->aux[i]); }
+        if (h->aux[i] && i < 4) { (void)hipStreamSynchronize(h->aux[i]); (void)hipStreamDestroy(h->aux[i]); }
         if (h->ev_join[i]) (void)hipEventDestroy(h->ev_join[i]);
     }
+    for (int i = 0; i < 6; ++i) if (h->ev_chain[i]) (void)hipEventDestroy(h->ev_chain[i]);
+    if (h->ev_stats) (void)hipEventDestroy(h->ev_stats);
     delete h;
     jt_graveyard().drain();                                    // (the frees above have waited for the device anyway)
 }
@@ -202,6 +208,14 @@ static SwrDev &get_swr(jt_ctx *h, int in_rate, int out_rate)
 static void pass_begin(jt_ctx *h, int64_t max_samples, int analyses, int64_t extra_samples = 0, int extra_jobs = 0)
 {
     ensure_twiddle(h, 2048); ensure_hann(h, 2048);
+    {   // the chains of the announced output regions (analysis lanes 4..7): all four on the stream adeclick's second solver uses
+        // (idle outside adeclick), so that they run beside the pass's full-length analysis.  Behind the full chains on their own four
+        // streams (JT_REGION_ROT=r: region chain i behind full chain (i + r) % 4) they end 0.4 ms later at best (r = 3, the longest
+        // region chain behind the shortest full chain) -- tools/ab_env.py JT_REGION_ROT=-,0,3
+        const char *rv = getenv("JT_REGION_ROT");
+        const int rot = rv ? atoi(rv) & 3 : 3;
+        for (int i = 0; i < 4; ++i) h->aux[4 + i] = rv ? h->aux[(i + rot) % 4] : h->dk_stream;
+    }
     const size_t na = (size_t)std::max(1, analyses), ne = (size_t)std::max(0, extra_jobs);
     h->pin.begin(jt_arena_bytes_for(max_samples) * na + jt_arena_bytes_for(extra_samples) * ne + (4u << 20));
     h->kw_begin((size_t)(max_samples / 512 + 1024) * 8 * na + ((size_t)(extra_samples / 512 + 1024) * 8 + (size_t)extra_samples / 128 + 16384) * ne);   // + the regions' own scratch
@@ -254,6 +268,7 @@ static void analysis_enqueue(jt_ctx *h, const float *x, int64_t n, int sr, bool 
     const bool r128_first = h->early_p3.mark_kw && J->want_r128;
     if (J->want_r128) {
         jt_kweight_enqueue_f32(h, x, n, sr, sr / 10, &J->kw, a1);
+        if (!f) JT_HIP(hipEventRecord(h->ev_chain[5], a1));
         if (h->early_p3.mark_kw) { JT_HIP(hipEventRecord(h->early_p3.ev[0], a1)); h->early_p3.mark_kw = false; }
     }
     if (J->want_r128) {
@@ -276,6 +291,7 @@ static void analysis_enqueue(jt_ctx *h, const float *x, int64_t n, int sr, bool 
         }
     }
     if (J->want_astats) jt_astats_enqueue(h, x, n, sr, &J->as, a0, a1, a2, ln ? ln->ehist : nullptr);
+    if (!f) JT_HIP(hipEventRecord(h->ev_chain[4], a2));
     if (J->want_spec) {
         const int win = 2048, hop = win / 2;
         const int64_t nhops = (n + hop - 1) / hop;
@@ -289,18 +305,26 @@ static void analysis_enqueue(jt_ctx *h, const float *x, int64_t n, int sr, bool 
         if (nout > 0) JT_HIP(hipMemcpyAsync(hops, d_hops, sizeof(jt_spectral) * nout, hipMemcpyDeviceToHost, a2));
         J->hops = hops;
     }
+    if (!f) for (int i = 0; i < 4; ++i) JT_HIP(hipEventRecord(h->ev_chain[i], h->aux[i]));
     if (join) analysis_join(h, f ? 2 : 1);
 }
 
-static void analysis_finish(const AnalysisJob &J, AnalysisHost *A)
+// staged: the job is the pass's full-length analysis and may still be running; each part of the host arithmetic waits for the chain
+// that feeds it (ev_chain) and runs while the later chains -- true peak and aspectralstats end last -- are still on the GPU
+static void analysis_finish(jt_ctx *h, const AnalysisJob &J, AnalysisHost *A, bool staged)
 {
-    if (J.want_astats) jt_astats_finish(&J.as, &A->astats);
+    auto wait = [&](int i) { if (staged) JT_HIP(hipEventSynchronize(h->ev_chain[i])); };
+    std::vector<double> bsum, bpk;
     if (J.want_r128) {
-        const int64_t nfull = J.nfull;
-        A->blk = J.blk; A->nblocks = nfull;
-        std::vector<double> bsum, bpk;
+        wait(5);
+        A->blk = J.blk; A->nblocks = J.nfull;
         jt_kweight_finish(&J.kw, bsum, bpk);
-        jt_r128_finish(bsum.data(), nfull, J.blk, J.sr, J.dualmono, &A->r128);
+        jt_r128_finish(bsum.data(), J.nfull, J.blk, J.sr, J.dualmono, &A->r128);
+    }
+    if (J.want_astats) { wait(0); wait(1); wait(4); jt_astats_finish(&J.as, &A->astats); }
+    if (J.want_r128) {
+        wait(3);
+        const int64_t nfull = J.nfull;
         A->tp_cum.assign(nfull, 0.0); A->sp_cum.assign(nfull, 0.0);
         double tp = 0, sp = 0;
         for (int64_t k = 0; k < nfull; ++k) {
@@ -311,7 +335,7 @@ static void analysis_finish(const AnalysisJob &J, AnalysisHost *A)
         sp = std::max(sp, bpk[(size_t)nfull]); tp = std::max(tp, J.btp[(size_t)nfull]);
         A->sp_final = sp; A->tp_final = tp;
     }
-    if (J.want_spec) { A->hops = J.hops; A->nhops = J.nhops; A->nout = J.nout; }
+    if (J.want_spec) { wait(2); A->hops = J.hops; A->nhops = J.nhops; A->nout = J.nout; }
 }
 
 static void spectral_add(jt_spectral *a, const jt_spectral &b)
@@ -358,13 +382,16 @@ static void assemble_analysis(const AnalysisHost &A, int64_t n, bool dualmono, j
     out->r128.target_threshold = A.r128.rel_threshold;
 }
 
-static void analysis_complete(jt_ctx *h, const AnalysisJob &J, jt_analysis *out, jt_frame_meta *meta, int64_t cap_meta)
+static void analysis_complete(jt_ctx *h, const AnalysisJob &J, jt_analysis *out, jt_frame_meta *meta, int64_t cap_meta, bool staged = false)
 {
-    (void)h;
     AnalysisHost A;
     const bool timing = getenv("JT_HOST_TIMING") != nullptr;
     std::chrono::steady_clock::time_point t0; if (timing) t0 = std::chrono::steady_clock::now();
-    analysis_finish(J, &A);
+    if (staged && getenv("JT_NO_STAGED_FINISH")) {          // (the round-2 order: everything after the last chain)
+        for (int i = 0; i < 4; ++i) JT_HIP(hipEventSynchronize(h->ev_chain[i]));
+        staged = false;
+    }
+    analysis_finish(h, J, &A, staged);
     out->astats = A.astats;
     std::chrono::steady_clock::time_point t1; if (timing) t1 = std::chrono::steady_clock::now();
     assemble_analysis(A, J.n, J.dualmono, out, meta, cap_meta);
@@ -403,6 +430,7 @@ extern "C" int jt_pass1(jt_ctx *h, int frame_samples, jt_analysis *out, double *
         // throws EINVAL) is dropped here, Pass 1 completes as it does in the reference, and jt_pass2 raises the error
         try { spec_pass2_start(h, &h->spec_p2.armed_p); } catch (const JtError &e) { if (e.code != JT_E_INVAL) throw; }
     }
+    analysis_complete(h, J, out, meta, cap_meta, true);       // (chain by chain, while the later chains still run)
     JT_HIP(hipStreamSynchronize(h->stream));
     check_cancel(h);
     if (fst) {
@@ -410,7 +438,6 @@ extern "C" int jt_pass1(jt_ctx *h, int frame_samples, jt_analysis *out, double *
         std::copy(fst, fst + c, frame_sumsq);
         std::copy(fst + nfr, fst + nfr + c, frame_peak);
     }
-    analysis_complete(h, J, out, meta, cap_meta);
     out->n_input_frames = nfr;
     JT_HIP(hipEventRecord(h->ev1, h->stream));
     JT_HIP(hipEventSynchronize(h->ev1));
@@ -900,16 +927,16 @@ extern "C" int jt_pass2(jt_ctx *h, const jt_filter_params *p, jt_analysis *out)
     if (h->early_p3.valid) {
         // the main stream still carries Pass 3's prefix chain (several ms): the analysis chains end long before it, so their host
         // arithmetic (gating, merges, the per-frame assembly) runs while the GPU works instead of after it
+        analysis_complete(h, J, out, nullptr, 0, true);         // (the full-length chains first: the regions' run behind them)
         for (int i = 0; i < 4 * (regions ? 2 : 1); ++i) JT_HIP(hipEventSynchronize(h->ev_join[i]));
         check_cancel(h);
-        analysis_complete(h, J, out, nullptr, 0);
         if (regions) { regions_finish(h, out_rate, RJ, slot.out); slot.valid = true; }
         JT_HIP(hipEventSynchronize(h->ev1));
         check_cancel(h);
     } else {
+        analysis_complete(h, J, out, nullptr, 0, true);
         JT_HIP(hipEventSynchronize(h->ev1));
         check_cancel(h);
-        analysis_complete(h, J, out, nullptr, 0);
         if (regions) { regions_finish(h, out_rate, RJ, slot.out); slot.valid = true; }
     }
     out->n_input_frames = 0;
@@ -1190,7 +1217,10 @@ extern "C" int jt_pass4(jt_ctx *h, const jt_limiter_plan *lim, const jt_loudnorm
     }
     const double *stats_src = sig;                        // the gained-by-nothing stream the loudnorm meters see (r128_in; r128_out = gain * it)
     bool stats_queued = false, stats_on_spec = false;
-    if (stats_lin && !ap->adeclick_enabled) { fork_aux(h, 3, 3); jt_kweight_enqueue_f64(h, stats_src, m, rate, sblk, &sj, h->aux[3]); stats_queued = true; }
+    if (stats_lin && !ap->adeclick_enabled) {
+        fork_aux(h, 3, 3); jt_kweight_enqueue_f64(h, stats_src, m, rate, sblk, &sj, h->aux[3]); stats_queued = true;
+        JT_HIP(hipEventRecord(h->ev_stats, h->aux[3]));
+    }
     // adeclick on the gained stream (af_adeclick.c), then the brickwall alimiter
     double brick_gain = gain;
     const unsigned long long *dk_stats = nullptr;
@@ -1215,6 +1245,7 @@ extern "C" int jt_pass4(jt_ctx *h, const jt_limiter_plan *lim, const jt_loudnorm
             JT_HIP(hipEventRecord(h->spec_ln.fork, h->stream));
             JT_HIP(hipStreamWaitEvent(h->spec_ln.stream, h->spec_ln.fork, 0));
             jt_kweight_enqueue_f64(h, stats_src, m, rate, sblk, &sj, h->spec_ln.stream);
+            JT_HIP(hipEventRecord(h->ev_stats, h->spec_ln.stream));
             stats_queued = true; stats_on_spec = true;
         }
         h->f64_c.ensure((size_t)m);
@@ -1236,6 +1267,22 @@ extern "C" int jt_pass4(jt_ctx *h, const jt_limiter_plan *lim, const jt_loudnorm
     analysis_join(h, regions ? 2 : 1);
     if (stats_on_spec) { JT_HIP(hipEventRecord(h->spec_ln.fork, h->spec_ln.stream)); JT_HIP(hipStreamWaitEvent(h->stream, h->spec_ln.fork, 0)); }
     JT_HIP(hipEventRecord(h->ev1, h->stream));
+    // host tail, while the output analysis is still on the GPU: the loudnorm statistics (two gated integrations over the 100 ms blocks
+    // of a job that ended before the analysis began), then the analysis itself chain by chain as its chains end
+    if (stats_lin && stats_queued) {
+        JT_HIP(hipEventSynchronize(h->ev_stats));
+        const int64_t nfull = m / sblk;
+        std::vector<double> bsum, bpk;
+        jt_kweight_finish(&sj, bsum, bpk);
+        double pk = 0; for (int64_t k = 0; k <= nfull; ++k) pk = std::max(pk, bpk[(size_t)k]);
+        jt_loudnorm_finish(bsum.data(), nfull, sblk, true, 1.0, &stats->input_i, &stats->input_lra, &stats->input_thresh);
+        jt_loudnorm_finish(bsum.data(), nfull, sblk, true, gain * gain, &stats->output_i, &stats->output_lra, &stats->output_thresh);
+        stats->input_tp = 20 * std::log10(pk);
+        stats->output_tp = 20 * std::log10(pk * gain);
+        stats->target_offset = ap->target_i - stats->output_i;
+        stats->normalization_type_dynamic = 0;
+    }
+    analysis_complete(h, J, out, nullptr, 0, true);
     JT_HIP(hipEventSynchronize(h->ev1));
     check_cancel(h);
     if (dk_stats) {
@@ -1254,30 +1301,6 @@ extern "C" int jt_pass4(jt_ctx *h, const jt_limiter_plan *lim, const jt_loudnorm
         { float dms = 0; JT_HIP(hipEventElapsedTime(&dms, h->ev2, h->ev3)); h->timers.declick_ms = dms; }
         JT_REQUIRE(dk_stats[1] == 0, JT_E_HIP, "adeclick: singular interpolation matrix (af_adeclick.c would fail the graph)");
     }
-    // host tail: the loudnorm statistics (two gated integrations over the 100 ms blocks) run on a second thread while this one
-    // finishes the output analysis
-    std::exception_ptr stats_err;
-    std::thread stats_thread;
-    if (stats_lin && stats_queued) {
-        stats_thread = std::thread([&]() {
-            try {
-                const int64_t nfull = m / sblk;
-                std::vector<double> bsum, bpk;
-                jt_kweight_finish(&sj, bsum, bpk);
-                double pk = 0; for (int64_t k = 0; k <= nfull; ++k) pk = std::max(pk, bpk[(size_t)k]);
-                jt_loudnorm_finish(bsum.data(), nfull, sblk, true, 1.0, &stats->input_i, &stats->input_lra, &stats->input_thresh);
-                jt_loudnorm_finish(bsum.data(), nfull, sblk, true, gain * gain, &stats->output_i, &stats->output_lra, &stats->output_thresh);
-                stats->input_tp = 20 * std::log10(pk);
-                stats->output_tp = 20 * std::log10(pk * gain);
-                stats->target_offset = ap->target_i - stats->output_i;
-                stats->normalization_type_dynamic = 0;
-            } catch (...) { stats_err = std::current_exception(); }
-        });
-    }
-    try { analysis_complete(h, J, out, nullptr, 0); }
-    catch (...) { if (stats_thread.joinable()) stats_thread.join(); throw; }
-    if (stats_thread.joinable()) stats_thread.join();
-    if (stats_err) std::rethrow_exception(stats_err);
     if (regions) { regions_finish(h, rate, RJ, slot.out); slot.valid = true; }
     float ms = 0; JT_HIP(hipEventElapsedTime(&ms, h->ev0, h->ev1)); h->timers.pass4_ms = ms;
     JT_API_END(h)
@@ -1523,7 +1546,7 @@ extern "C" int jt_op_ebur128(jt_ctx *h, const float *in, int64_t n, int sr, int 
     AnalysisJob J; J.want_astats = false; J.want_spec = false;
     analysis_enqueue(h, a.p, n, sr, dualmono != 0, 0, &J);
     JT_HIP(hipStreamSynchronize(h->stream));
-    AnalysisHost A; analysis_finish(J, &A);
+    AnalysisHost A; analysis_finish(h, J, &A, false);
     out->integrated = A.r128.integrated; out->lra = A.r128.lra; out->lra_low = A.r128.lra_low; out->lra_high = A.r128.lra_high;
     out->momentary = A.nblocks ? A.r128.M[A.nblocks - 1] : NAN; out->shortterm = A.nblocks ? A.r128.S[A.nblocks - 1] : NAN;
     out->true_peak = A.tp_final; out->sample_peak = A.sp_final; out->target_threshold = A.r128.rel_threshold;
@@ -1558,7 +1581,7 @@ extern "C" int jt_op_aspectralstats(jt_ctx *h, const float *in, int64_t n, int s
     AnalysisJob J; J.want_astats = false; J.want_r128 = false;
     analysis_enqueue(h, a.p, n, sr, false, 0, &J);
     JT_HIP(hipStreamSynchronize(h->stream));
-    AnalysisHost A; analysis_finish(J, &A);
+    AnalysisHost A; analysis_finish(h, J, &A, false);
     for (int64_t k = 0; k < std::min(cap, A.nhops); ++k) hops[k] = A.hops[(size_t)k];
     if (n_hops) *n_hops = A.nhops;
     JT_API_END(h)

@@ -271,6 +271,9 @@ struct jt_ctx {
     // onto them and joined back into `stream` with events, so latency-bound kernels overlap instead of queueing
     hipStream_t aux[8] = {};                   // [0..3] the analysis chains of a pass, [4..7] the chains of announced output regions
     hipEvent_t ev_fork = nullptr, ev_join[8] = {};
+    // marks inside the full-length analysis of a pass (analysis_enqueue): [0..3] the ends of its four chains, [4] the astats part of
+    // chain 2 (before aspectralstats), [5] the K-weighting job of chain 1 (before the noise floor); ev_stats: Pass 4's loudnorm statistics
+    hipEvent_t ev_chain[6] = {}, ev_stats = nullptr;
     std::string err;
     std::atomic<int> cancelled{0};
     bool hold_cancel = false;            // inside jt_process_file: loading the input must not clear a cancel that already arrived

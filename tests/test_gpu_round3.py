@@ -317,3 +317,30 @@ def test_k_weighting_one_sweep_agrees_with_two_sweeps(engine, monkeypatch):
                 live = np.isfinite(b[key]) & (b[key] > -70.0)
                 assert live.any() and np.max(np.abs(a[key][live] - b[key][live])) < tol, (sr, key)
 
+
+@pytest.mark.gpu
+def test_host_arithmetic_staged_behind_the_analysis_chains_reports_the_same_numbers(engine, monkeypatch):
+    """The host side of a pass's analysis (gating, LRA, astats merges, the per-frame assembly) runs chain by chain while the later chains
+    are still on the GPU, and the announced output regions are measured on a stream of their own: schedule changes only.  Every
+    measurement of the run record (input, filtered, final, the four region samples, both loudnorm records) equals the run that waits for
+    the whole analysis first (JT_NO_STAGED_FINISH) with the regions behind the full chains (JT_REGION_ROT)."""
+    import ctypes as C
+    w = int(0.02 * SR)
+    burst = 0.35 * np.hanning(w) * np.sin(2 * np.pi * 180.0 * np.arange(w) / SR)
+    base = np.asarray(synth.speech_like(60.0, SR, seed=97), np.float64)
+    for pos in range(SR, base.size - SR, int(1.5 * SR)):        # (plosive-like bursts: the limiter-prefix branch, Pass 3 inside Pass 2)
+        base[pos:pos + w] += burst
+    x = np.tile(base.astype(np.float32), 3)
+
+    def run():
+        engine.upload_pcm(x, SR, 1)
+        r = H.process_audio(engine)
+        parts = (r.input, r.filtered, r.measure, r.final_, r.loudnorm, r.filtered_room_tone, r.filtered_speech, r.final_room_tone, r.final_speech)
+        return [C.string_at(C.addressof(p), C.sizeof(p)) for p in parts] + [engine.download_s16(4).tobytes()]
+    ref = run()
+    for env in ({"JT_NO_STAGED_FINISH": "1"}, {"JT_REGION_ROT": "0"}, {"JT_REGION_ROT": "3", "JT_NO_STAGED_FINISH": "1"}):
+        for k, v in env.items(): monkeypatch.setenv(k, v)
+        got = run()
+        for k in env: monkeypatch.delenv(k)
+        assert got == ref, env
+
