@@ -236,6 +236,7 @@ struct AnalysisHost {
 struct AnalysisJob {
     AstatsJob as; KwJob kw; const double *btp = nullptr; const jt_spectral *hops = nullptr;
     int64_t n = 0, nfull = 0, nhops = 0, nout = 0; int blk = 0, sr = 0; bool dualmono = false, want_astats = true, want_r128 = true, want_spec = true;
+    bool astats_levels_only = false;
 };
 
 // sets = 2: also the chains of the announced output regions (aux[4..7])
@@ -290,7 +291,7 @@ static void analysis_enqueue(jt_ctx *h, const float *x, int64_t n, int sr, bool 
             JT_HIP(hipStreamWaitEvent(a2, h->early_p3.ev[1], 0));
         }
     }
-    if (J->want_astats) jt_astats_enqueue(h, x, n, sr, &J->as, a0, a1, a2, ln ? ln->ehist : nullptr);
+    if (J->want_astats) jt_astats_enqueue(h, x, n, sr, &J->as, a0, a1, a2, ln ? ln->ehist : nullptr, J->astats_levels_only);
     if (!f) JT_HIP(hipEventRecord(h->ev_chain[4], a2));
     if (J->want_spec) {
         const int win = 2048, hop = win / 2;
@@ -491,6 +492,7 @@ static void regions_enqueue(jt_ctx *h, const int16_t *src, int rate, RegionJobs 
             ln.first = 4; ln.tp = scr; ln.hops = reinterpret_cast<jt_spectral *>(scr + nfull + 2);
             ln.ehist = reinterpret_cast<unsigned long long *>(scr + nfull + 2 + hop_d);
         }
+        R->J[r].astats_levels_only = !getenv("JT_REGION_FULL_ASTATS");      // (regions_finish reads the levels and the crest factor only)
         analysis_enqueue(h, h->region_f.p + (r ? R->len[0] : 0), R->len[r], rate, false, rate / 10, &R->J[r], false, own_lanes ? &ln : nullptr);
     }
 }

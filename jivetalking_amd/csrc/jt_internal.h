@@ -248,10 +248,11 @@ struct AstatsJob {
     const unsigned char *hb = nullptr; const unsigned long long *eh = nullptr;
     size_t o_part = 0, o_runs = 0, o_nf = 0, o_smin = 0, o_smax = 0;
     int nparts = 0, nf_parts = 0, nsig = 0; bool have_nf = false; int64_t n = 0;
+    bool levels_only = false;       // RMS / peak level and crest factor only (the announced regions' samples)
 };
 // sA: reduce -> min/max -> runs; sB: noise floor; sC: exp-average sigma chain (three independent chains; pass the same stream to serialise)
 void jt_astats_enqueue(jt_ctx *h, const float *x, int64_t n, int sr, AstatsJob *job, hipStream_t sA, hipStream_t sB, hipStream_t sC,
-                       unsigned long long *ehist = nullptr);     // ehist: the job's own 8192-bin histogram (default: the shared one)
+                       unsigned long long *ehist = nullptr, bool levels_only = false);     // ehist: the job's own 8192-bin histogram (default: the shared one)
 void jt_astats_finish(const AstatsJob *job, jt_astats *out);
 struct KwJob { const double *hc = nullptr; int64_t nchunks = 0, nfull = 0; int m = 1; };
 // scratch of a job that outlives the pass arenas (the Pass-3 measurement started early by Pass 2): device doubles / pinned doubles

@@ -404,7 +404,7 @@ size_t jt_arena_bytes_for(int64_t n)
 }
 
 void jt_astats_enqueue(jt_ctx *h, const float *x, int64_t n, int sr, AstatsJob *job, hipStream_t sA, hipStream_t sB, hipStream_t sC,
-                       unsigned long long *ehist)
+                       unsigned long long *ehist, bool levels_only)
 {
     const double time_constant = 0.05;
     const double mult = std::exp((-1 / time_constant / sr));
@@ -427,6 +427,14 @@ void jt_astats_enqueue(jt_ctx *h, const float *x, int64_t n, int sr, AstatsJob *
     if (ehist) JT_HIP(hipMemsetAsync(ehist, 0, sizeof(unsigned long long) * 8192, sA));
     else { h->ehist.ensure(8192); h->ehist.zero(sA); ehist = h->ehist.p; }
     hipLaunchKernelGGL(k_as_reduce, dim3(nparts), dim3(AS_T), 0, sA, x, n, d_part, ehist);
+    if (levels_only) {
+        // a region sample reports the RMS / peak levels and the crest factor only (regions_finish): one sweep instead of nine launches
+        unsigned char *hb = h->pin.take<unsigned char>(o_runs);
+        JT_HIP(hipMemcpyAsync(hb + o_part, base + o_part, o_runs - o_part, hipMemcpyDeviceToHost, sA));
+        *job = AstatsJob{};
+        job->hb = hb; job->o_part = o_part; job->nparts = nparts; job->n = n; job->levels_only = true;
+        return;
+    }
     hipLaunchKernelGGL(k_as_minmax, dim3(1), dim3(64), 0, sA, d_part, nparts, d_mm);
     hipLaunchKernelGGL(k_as_runs, dim3(nparts), dim3(AS_T), 0, sA, x, n, d_mm, d_runs);
     const bool have_nf = n >= tc;
@@ -471,6 +479,19 @@ void jt_astats_finish(const AstatsJob *job, jt_astats *out)
     const int nparts = job->nparts, nf_parts = job->nf_parts, nsig = job->nsig; const bool have_nf = job->have_nf;
     const unsigned long long *eh = job->eh;
     const AsPartial *pp = reinterpret_cast<const AsPartial *>(job->hb + job->o_part);
+    if (job->levels_only) {
+        AsPartial a = pp[0];
+        for (int i = 1; i < nparts; ++i) { const AsPartial &b = pp[i]; a.min = std::min(a.min, b.min); a.max = std::max(a.max, b.max); a.sx += b.sx; a.sx2 += b.sx2; a.count += b.count; }
+        std::memset(out, 0, sizeof(*out));
+        if (a.count == 0) return;
+        const double count = (double)a.count;
+        out->dc_offset = a.sx / count; out->min_level = a.min; out->max_level = a.max;
+        out->peak_level = std::log10(std::max(-a.min, a.max)) * 20;
+        out->rms_level = std::log10(std::sqrt(a.sx2 / count)) * 20;
+        out->crest_factor = a.sx2 ? std::max(-a.min, a.max) / std::sqrt(a.sx2 / count) : 1;
+        out->number_of_samples = count;
+        return;
+    }
     const AsRuns *pr = reinterpret_cast<const AsRuns *>(job->hb + job->o_runs);
     const AsNF *pn = reinterpret_cast<const AsNF *>(job->hb + job->o_nf);
     const double *smin = reinterpret_cast<const double *>(job->hb + job->o_smin), *smax = reinterpret_cast<const double *>(job->hb + job->o_smax);

@@ -338,7 +338,8 @@ def test_host_arithmetic_staged_behind_the_analysis_chains_reports_the_same_numb
         parts = (r.input, r.filtered, r.measure, r.final_, r.loudnorm, r.filtered_room_tone, r.filtered_speech, r.final_room_tone, r.final_speech)
         return [C.string_at(C.addressof(p), C.sizeof(p)) for p in parts] + [engine.download_s16(4).tobytes()]
     ref = run()
-    for env in ({"JT_NO_STAGED_FINISH": "1"}, {"JT_REGION_ROT": "0"}, {"JT_REGION_ROT": "3", "JT_NO_STAGED_FINISH": "1"}):
+    # (JT_REGION_FULL_ASTATS: the regions' astats with all its chains instead of the one sweep their three reported fields need)
+    for env in ({"JT_NO_STAGED_FINISH": "1"}, {"JT_REGION_ROT": "0"}, {"JT_REGION_ROT": "3", "JT_NO_STAGED_FINISH": "1"}, {"JT_REGION_FULL_ASTATS": "1"}):
         for k, v in env.items(): monkeypatch.setenv(k, v)
         got = run()
         for k in env: monkeypatch.delenv(k)
