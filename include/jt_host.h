@@ -107,7 +107,7 @@ typedef struct {
     int comp_enabled; double comp_threshold_db, comp_ratio, comp_attack, comp_release, comp_makeup_db, comp_knee, comp_mix;
     int deess_enabled; double deess_intensity, deess_amount, deess_frequency;
     int adeclick_enabled; double adeclick_threshold, adeclick_window, adeclick_overlap;
-    int adeclick_method_s;         /* AdeclickConfig.Method (filters.go:240-246,958-960): 1 = "s" (the default config), 0 = "" (option omitted: af_adeclick.c's m=a), 2 = "a" */
+    int adeclick_method_s;         /* AdeclickConfig.Method (filters.go:240-246,958-960): 1 = "s" (the default config), 0 = "" (option omitted: af_adeclick.c's m=a), 2 = "a"; 3 = "save", 4 = "add" (the option table's long names: same methods, printed verbatim in the spec) */
     int loudnorm_enabled; double target_i, target_tp, target_lra; int dual_mono, linear;
 } jt_host_config;
 
@@ -250,6 +250,19 @@ int jt_process_files(int device, const char *const *paths, int n_files, int in_f
  * queue is dynamic, so uneven file lengths do not leave a GPU idle. */
 int jt_process_files_multi(const int *devices, int n_devices, const char *const *paths, int n_files, int in_flight_per_device,
                            const jt_host_config *base, int frame_samples, int flac_flags, jt_file_result *results, int *device_of_file);
+
+/* A caller-owned handle pool for more than one batch (a long-running host: the Go shim pools its handles the same way): the handles
+ * are opened once -- jt_process_files_multi opens and closes one pool per call, 0.1 s of a sub-second batch -- and every batch reuses
+ * them with their buffers warm.  max_workers > 0 caps the worker count (devices x in_flight_per_device otherwise).  A device that
+ * cannot be opened gets no worker (its worker tries the devices nobody serves); a pool without any worker fails every file of a batch
+ * with the first jt_open error.  jt_handle_pool_workers returns the number of handles and writes the device of each (sorted by device).
+ * One batch at a time per pool; different pools are independent.  Semantics of a batch: pool.go:122-153, as above. */
+typedef struct jt_handle_pool jt_handle_pool;
+int  jt_handle_pool_open(const int *devices, int n_devices, int in_flight_per_device, int max_workers, jt_handle_pool **out);
+int  jt_handle_pool_workers(const jt_handle_pool *pool, int *devices_out, int cap);
+int  jt_handle_pool_process_files(jt_handle_pool *pool, const char *const *paths, int n_files, const jt_host_config *base, int frame_samples, int flac_flags,
+                           jt_file_result *results, int *device_of_file);
+void jt_handle_pool_close(jt_handle_pool *pool);
 
 /* ---- granular detector steps (the reference table-tests each of these: analyser_vad_test.go) ---- */
 int    jt_host_vad_detect(const jt_interval *iv, int64_t n, double noise_floor_seed, jt_measurements *out);      /* detectVoiceActivity :728 */

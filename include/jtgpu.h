@@ -52,6 +52,25 @@ void jt_reset_cancel(jt_ctx *h);
 void jt_begin_job(jt_ctx *h);
 void jt_end_job(jt_ctx *h);
 
+/* ---- options.  The library reads no environment variable and writes none: what used to be JT_* variables is set here, per handle,
+ * and read by the launchers (a Go host runs many goroutines; getenv / setenv beside them is a data race).  key / value are short
+ * ASCII strings; a boolean takes "1" / "0" (or "true" / "false", "on" / "off"; NULL or "" = on).
+ *   schedule switches (same results either way; the tests run both): no_pass2_prefetch, no_early_pass3, no_early_plan, no_lim_keep,
+ *     no_staged_finish, no_r128_first, region_rot (0..3, -1 = default), region_full_astats
+ *   kernel selection: adeclick_exact (the sequential-order adeclick kernel, bit-exact to af_adeclick.c's summation order),
+ *     nlm_generic (the any-geometry anlmdn kernel), p3_unfused / analysis_unfused / dyn_unfused (the stand-alone kernels of stages
+ *     that are fused by default: what the fused forms are tested against)
+ *   diagnostics: host_timing (host-stage timings on stderr)
+ *   process-wide (h == NULL): graveyard_gb (gigabytes of superseded buffers parked before they are freed, default 24, 0 = free at
+ *     once), poison_alloc (fill every new device allocation with 0xFF bytes; test switch)
+ * Superseded kernel generations and tuning knobs (nlm_old, afftdn_old, adeclick_fused, dyn_one_wave, kw_two_sweeps, follow_tiles,
+ * dk_waves, ...) exist only in the A/B build of the library (make ab -> libjtgpu_ab.so, jt_build_flags() & 1): the default build
+ * answers JT_E_UNSUPPORTED for them, an unknown key or a malformed value is JT_E_INVAL.
+ * GPU_MAX_HW_QUEUES (ROCclr's hardware-queue count, read when the process first touches HIP) is the HOST's to set before that moment:
+ * 8 gives every stream of a handle its own queue; the default 4 works, a few per cent slower. */
+int jt_set_option(jt_ctx *h, const char *key, const char *value);
+int jt_build_flags(void);                                   /* bit 0: A/B build (JT_AB) */
+
 /* ---- input: replaces audio.Reader.ReadFrame feeding abuffer (reader.go:129, frame_processor.go:131-146) ---- */
 /* interleaved f32 PCM in host memory; copied to HBM. channels 1 or 2.  2 => the aformat=channel_layouts=mono down-mix
  * (filters.go:607-615) = libswresample's rematrix in the aresample libavfilter auto-inserts: Pass 1 and Pass 2 both hold a

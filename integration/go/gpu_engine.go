@@ -44,6 +44,15 @@ import (
 	"unsafe"
 )
 
+// ROCclr reads GPU_MAX_HW_QUEUES once, when the process first touches HIP.  A handle drives eight streams; with 8 hardware queues each
+// has one to itself (DESIGN.md: files in flight).  libjtgpu.so neither reads nor writes the environment (getenv / setenv beside running
+// goroutines is a data race), so the host sets it here, in init(), before cgo can have called into HIP; an operator's own value wins.
+func init() {
+	if _, ok := os.LookupEnv("GPU_MAX_HW_QUEUES"); !ok {
+		os.Setenv("GPU_MAX_HW_QUEUES", "8")
+	}
+}
+
 // gpuDeviceCounter hands worker goroutines their GPU round-robin (files shard one per GPU; no exchange between them).
 var (
 	gpuDeviceCounter atomic.Int64
@@ -59,6 +68,7 @@ type gpuEngine struct {
 	mu     sync.Mutex // guards h and gen against a cancel callback that is still running when the job ends
 	gen    uint64     // job generation: a callback armed for job g must not cancel job g+1 on the same handle
 	closed bool
+	lastRC C.int // the code of the last failed engine call (err records it): what finish decides on for the granular seam
 }
 
 var (
@@ -88,6 +98,17 @@ func acquireGPUEngine() (*gpuEngine, error) {
 	return openGPUEngine(device)
 }
 
+// finish ends a job: a handle whose job ended with anything but success or a cancellation (JT_E_HIP, an allocation failure, ...) is
+// closed, not pooled - the next file then opens a fresh one, as every file did before handles were pooled, and one bad handle cannot
+// fail the files after it.
+func (e *gpuEngine) finish(rc C.int) {
+	if rc == C.JT_OK || rc == C.JT_E_CANCELLED || rc == C.JT_E_INVAL || rc == C.JT_E_UNSUPPORTED || rc == C.JT_E_SILENT {
+		e.release() // (bad input / refused request / silent audio: the handle itself is fine)
+		return
+	}
+	e.Close()
+}
+
 // release ends the job (late cancel callbacks of this job become no-ops) and returns the handle to its device's free list.
 func (e *gpuEngine) release() {
 	e.mu.Lock()
@@ -99,7 +120,7 @@ func (e *gpuEngine) release() {
 	gpuPoolMu.Unlock()
 }
 
-// Close destroys the handle (CloseGPUEngines at process exit; a handle that failed is closed instead of released).
+// Close destroys the handle (CloseGPUEngines when the worker pool has drained; finish closes a handle whose job failed).
 func (e *gpuEngine) Close() {
 	e.mu.Lock()
 	if !e.closed {
@@ -110,7 +131,9 @@ func (e *gpuEngine) Close() {
 	e.mu.Unlock()
 }
 
-// CloseGPUEngines closes every idle handle (call once when the pools have drained).
+// CloseGPUEngines closes every idle handle and with them their multi-GB device buffers and pinned arenas.  Wire it where the CLI's
+// pools end: `defer processor.CloseGPUEngines()` next to runBoundedPool's wg.Wait() (cmd/jivetalking/pool.go:122-153) and in
+// runAnalysisPool - INTEGRATION.md shows both lines.  Nothing else frees pooled handles.
 func CloseGPUEngines() {
 	gpuPoolMu.Lock()
 	defer gpuPoolMu.Unlock()
@@ -125,6 +148,9 @@ func CloseGPUEngines() {
 // err maps a C return code onto the reference's error conventions: ctx cancellation is returned as ctx.Err()
 // (frame_processor.go:116-118), everything else as a wrapped message.
 func (e *gpuEngine) err(ctx context.Context, rc C.int, what string) error {
+	if rc != C.JT_OK {
+		e.lastRC = rc
+	}
 	switch rc {
 	case C.JT_OK:
 		return nil
@@ -206,9 +232,13 @@ func ProcessAudioGPU(ctx context.Context, inputPath string, config *BaseFilterCo
 	if err != nil {
 		return nil, err
 	}
-	defer e.release()
+	var rc C.int = C.JT_OK
+	defer func() { e.finish(rc) }()
 	stop := e.watch(ctx)
 	defer stop()
+	if err := validateAdeclickMethod(config.Adeclick.Method); err != nil {
+		return nil, err
+	}
 
 	base := hostConfigToC(config)
 	res := (*C.jt_process_result)(C.calloc(1, C.size_t(unsafe.Sizeof(C.jt_process_result{}))))
@@ -223,7 +253,7 @@ func ProcessAudioGPU(ctx context.Context, inputPath string, config *BaseFilterCo
 	if progressCallback != nil {
 		cb = C.jt_trampoline_ptr()
 	}
-	rc := C.jt_process_file(e.h, cpath, &base, 4096, C.JT_FLAC_MD5|C.JT_FILE_PROGRESS_TICKS, cb, unsafe.Pointer(uintptr(hnd)), res, &outPath[0], 4096, nil)
+	rc = C.jt_process_file(e.h, cpath, &base, 4096, C.JT_FLAC_MD5|C.JT_FILE_PROGRESS_TICKS, cb, unsafe.Pointer(uintptr(hnd)), res, &outPath[0], 4096, nil)
 	if rc != C.JT_OK {
 		what := "processing failed"
 		if res.pass_ms[0] == 0 {
@@ -240,7 +270,8 @@ func AnalyseOnlyDetailedGPU(ctx context.Context, inputPath string, config *BaseF
 	if err != nil {
 		return nil, err
 	}
-	defer e.release()
+	var rc C.int = C.JT_OK
+	defer func() { e.finish(rc) }()
 	stop := e.watch(ctx)
 	defer stop()
 	if progressCallback != nil {
@@ -248,12 +279,13 @@ func AnalyseOnlyDetailedGPU(ctx context.Context, inputPath string, config *BaseF
 	}
 	start := time.Now()
 	if _, err := e.loadFile(ctx, inputPath); err != nil {
+		rc = e.lastRC
 		return nil, fmt.Errorf("analysis failed: %w", err)
 	}
 	base := hostConfigToC(config)
 	res := (*C.jt_process_result)(C.calloc(1, C.size_t(unsafe.Sizeof(C.jt_process_result{}))))
 	defer C.free(unsafe.Pointer(res))
-	if rc := C.jt_analyse_only(e.h, &base, 4096, res); rc != C.JT_OK {
+	if rc = C.jt_analyse_only(e.h, &base, 4096, res); rc != C.JT_OK {
 		return nil, fmt.Errorf("analysis failed: %w", e.err(ctx, rc, "pass 1"))
 	}
 	m := measurementsFromC(&res.input, e)
@@ -517,18 +549,33 @@ func defaultsToC(d *filterConfigDefaults) C.jt_host_config {
 	c.deess_enabled, c.deess_intensity, c.deess_amount, c.deess_frequency = b2i(s.Enabled), C.double(s.Intensity), C.double(s.Amount), C.double(s.Frequency)
 	a := d.Adeclick
 	c.adeclick_enabled, c.adeclick_threshold, c.adeclick_window, c.adeclick_overlap = b2i(a.Enabled), C.double(a.Threshold), C.double(a.Window), C.double(a.Overlap)
-	switch a.Method { // "" leaves the option out: af_adeclick.c's own default, overlap-add
-	case "s":
-		c.adeclick_method_s = 1
-	case "a":
-		c.adeclick_method_s = 2
-	default:
-		c.adeclick_method_s = 0
-	}
+	c.adeclick_method_s = C.int(adeclickMethodCode(a.Method))
 	l := d.Loudnorm
 	c.loudnorm_enabled, c.target_i, c.target_tp, c.target_lra, c.dual_mono, c.linear = b2i(l.Enabled), C.double(l.TargetI), C.double(l.TargetTP), C.double(l.TargetLRA), b2i(l.DualMono), b2i(l.Linear)
 	return c
 }
+// adeclickMethodNames: AdeclickConfig.Method goes into the filter spec verbatim (filters.go:958-960), and af_adeclick's option table
+// names each method twice ("a" / "add", "s" / "save").  The code keeps the spelling so that the spec text and the effective config
+// round-trip; "" leaves the option out (af_adeclick.c's default, overlap-add).  Anything else would make FFmpeg fail the graph:
+// validateAdeclickMethod reports it before a job starts instead of running a different method silently.
+var adeclickMethodNames = map[int]string{0: "", 1: "s", 2: "a", 3: "save", 4: "add"}
+
+func adeclickMethodCode(method string) int {
+	for code, name := range adeclickMethodNames {
+		if name == method {
+			return code
+		}
+	}
+	return -1
+}
+
+func validateAdeclickMethod(method string) error {
+	if adeclickMethodCode(method) < 0 {
+		return fmt.Errorf("adeclick: unknown method %q (af_adeclick accepts a, add, s, save)", method)
+	}
+	return nil
+}
+
 func hostConfigToC(cfg *BaseFilterConfig) C.jt_host_config { return defaultsToC(&cfg.filterConfigDefaults) }
 func effectiveConfigToC(cfg *EffectiveFilterConfig) C.jt_host_config {
 	d := filterConfigDefaults(*cfg)
@@ -544,12 +591,7 @@ func effectiveConfigFromC(c *C.jt_host_config) *EffectiveFilterConfig {
 	if c.gate_detection_set != 0 {
 		det = "rms"
 	}
-	method := ""
-	if c.adeclick_method_s == 1 {
-		method = "s"
-	} else if c.adeclick_method_s == 2 {
-		method = "a"
-	}
+	method := adeclickMethodNames[int(c.adeclick_method_s)]
 	d := filterConfigDefaults{
 		Downmix:          DownmixConfig{Enabled: c.downmix_enabled != 0},
 		Analysis:         AnalysisConfig{Enabled: c.analysis_enabled != 0},

@@ -4,7 +4,8 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libjtgpu.so")
-_LIB = None
+LIB_PATH_AB = os.path.join(_HERE, "lib", "libjtgpu_ab.so")
+_LIBS = {}
 
 JT_OK, JT_E_INVAL, JT_E_NOGPU, JT_E_HIP, JT_E_STATE, JT_E_UNSUPPORTED, JT_E_CANCELLED, JT_E_SILENT = 0, -1, -2, -3, -4, -5, -6, -7
 
@@ -116,7 +117,7 @@ class AudioMeta(C.Structure):
 
 # every symbol include/jtgpu.h declares
 SYMBOLS = [
-    "jt_open", "jt_close", "jt_last_error", "jt_version", "jt_cancel", "jt_reset_cancel", "jt_begin_job", "jt_end_job", "jt_pass3_plan_hook", "jt_set_source_format",
+    "jt_open", "jt_close", "jt_last_error", "jt_version", "jt_set_option", "jt_build_flags", "jt_cancel", "jt_reset_cancel", "jt_begin_job", "jt_end_job", "jt_pass3_plan_hook", "jt_set_source_format",
     "jt_upload_pcm", "jt_attach_device_pcm", "jt_upload_s16", "jt_load_audio", "jt_op_decode_audio",
     "jt_pass1", "jt_band_rms", "jt_pass2", "jt_pass2_prefetch", "jt_pass2_prefetch_after_pass1", "jt_region_measure", "jt_region_measure_pair", "jt_region_prefetch", "jt_pass3", "jt_pass4",
     "jt_output_len", "jt_download_s16", "jt_output_frame_levels", "jt_flac_encode", "jt_op_flac_encode_s16", "jt_get_timers",
@@ -126,15 +127,20 @@ SYMBOLS = [
 ]
 
 
-def load():
-    """Load libjtgpu.so.  Raises (never falls back) when the HIP extension has not been built."""
-    global _LIB
-    if _LIB is not None:
-        return _LIB
-    if not os.path.exists(LIB_PATH):
-        raise ImportError(f"{LIB_PATH} not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
+def load(ab=False):
+    """Load libjtgpu.so (ab=True: libjtgpu_ab.so, the A/B build with the superseded kernel generations and tuning knobs, `make ab`).
+    Raises (never falls back) when the HIP extension has not been built."""
+    key = "ab" if ab else "default"
+    if key in _LIBS:
+        return _LIBS[key]
+    path = LIB_PATH_AB if ab else LIB_PATH
+    if not os.path.exists(path):
+        raise ImportError(f"{path} not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
                           "(hipcc --offload-arch=gfx950). There is no CPU fallback for the product path.")
-    lib = C.CDLL(LIB_PATH)
+    # ROCclr's hardware-queue count is read when the process first touches HIP and belongs to the host application (jtgpu.h, jt_set_option):
+    # the library does not touch the environment, this binding -- the host here -- asks for one queue per stream of a handle
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+    lib = C.CDLL(path)
     lib.jt_last_error.restype = C.c_char_p
     lib.jt_version.restype = C.c_char_p
     lib.jt_close.restype = None
@@ -142,5 +148,13 @@ def load():
     lib.jt_reset_cancel.restype = None
     lib.jt_begin_job.restype = None
     lib.jt_end_job.restype = None
-    _LIB = lib
+    assert bool(lib.jt_build_flags() & 1) == bool(ab), "library flavour does not match its file name"
+    _LIBS[key] = lib
     return lib
+
+
+def set_global_option(key, value, ab=False):
+    """jt_set_option(NULL, ...): process-wide keys (graveyard_gb, poison_alloc) of one library flavour."""
+    rc = load(ab).jt_set_option(None, str(key).encode(), str(value).encode())
+    if rc != 0:
+        raise JtError(rc, f"jt_set_option(NULL, {key!r}, {value!r})")

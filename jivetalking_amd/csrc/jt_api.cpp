@@ -8,9 +8,14 @@
 #include <mutex>
 #include <thread>
 #include <exception>
+#include <cctype>
 
 static void check_cancel(jt_ctx *h) { if (h->cancelled.load()) throw JtError{JT_E_CANCELLED, "cancelled"}; }
 static void spec_pass2_start(jt_ctx *h, const jt_filter_params *p);     // the early Pass-2 head (defined with jt_pass2_prefetch)
+
+#ifdef JT_AB
+static void opts_from_env(JtOpts *o);
+#endif
 
 extern "C" const char *jt_version(void) { return "jtgpu 0.1 (gfx950)"; }
 
@@ -20,17 +25,20 @@ extern "C" int jt_open(int device_id, jt_ctx **out)
     *out = nullptr;
     // one context drives seven streams (main, four analysis chains, two early-start streams; one of them at low priority, which has a
     // queue pool of its own); ROCclr multiplexes streams onto GPU_MAX_HW_QUEUES (default 4) hardware queues per priority, fixed when the
-    // runtime initialises.  Ask for 8 unless the host application already decided: every stream of a context then has a queue to itself.
-    // More is worse, not better: with 16 (32 queues in the process) several contexts on one GPU oversubscribe the hardware queue slots and
-    // the driver time-slices them -- three 10-minute files in flight took 25 ms each instead of 15, five took 390 ms, six did not finish
-    // (tools/inflight_probe.py; 8 queues: 15 ms per file at 4, 6 and 8 in flight).
-    static std::once_flag env_once;                    // handles may be opened from several threads (jt_process_files)
-    std::call_once(env_once, [] { setenv("GPU_MAX_HW_QUEUES", "8", 0); });
+    // runtime initialises.  8 gives every stream of a context a queue to itself -- but that variable belongs to the HOST: it must be in
+    // the environment before the process touches HIP (the Go shim sets it in init(), jivetalking_amd/_lib.py before it loads this
+    // library).  The library itself neither reads nor writes the environment.  More than 8 is worse, not better: with 16
+    // (32 queues in the process) several contexts on one GPU oversubscribe the hardware queue slots and the driver time-slices them --
+    // three 10-minute files in flight took 25 ms each instead of 15, five took 390 ms, six did not finish (tools/inflight_probe.py;
+    // 8 queues: 15 ms per file at 4, 6 and 8 in flight).  The default of 4 is safe, a few per cent slower.
     int count = 0;
     if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) return JT_E_NOGPU;
     if (device_id < 0 || device_id >= count) return JT_E_INVAL;
     jt_ctx *h = new jt_ctx();
     h->device = device_id;
+#ifdef JT_AB
+    opts_from_env(&h->opts);
+#endif
     try {
         JT_HIP(hipSetDevice(device_id));
         JT_HIP(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
@@ -89,6 +97,88 @@ extern "C" void jt_close(jt_ctx *h)
 
 extern "C" const char *jt_last_error(const jt_ctx *h) { return h ? h->err.c_str() : "null handle"; }
 extern "C" void jt_cancel(jt_ctx *h) { if (h) h->cancelled.store(1); }
+
+// ---------------------------------------------------------------- options (include/jtgpu.h: jt_set_option)
+static bool opt_bool(const char *v, bool *out)
+{
+    if (!v || !*v || !strcmp(v, "1") || !strcmp(v, "true") || !strcmp(v, "on")) { *out = true; return true; }
+    if (!strcmp(v, "0") || !strcmp(v, "false") || !strcmp(v, "off")) { *out = false; return true; }
+    return false;
+}
+static bool opt_int(const char *v, int *out)
+{
+    if (!v || !*v) return false;
+    char *end = nullptr; const long x = strtol(v, &end, 10);
+    if (*end || x < -1000000 || x > 1000000) return false;
+    *out = (int)x; return true;
+}
+int jt_opts_set(JtOpts *o, const char *key, const char *value)
+{
+    if (!o || !key) return JT_E_INVAL;
+#define X(k) if (!strcmp(key, #k)) return opt_bool(value, &o->k) ? JT_OK : JT_E_INVAL;
+    JT_OPT_BOOLS(X)
+#undef X
+#define X(k) if (!strcmp(key, #k)) return opt_int(value, &o->k) ? JT_OK : JT_E_INVAL;
+    JT_OPT_INTS(X)
+#undef X
+#ifdef JT_AB
+#define X(k) if (!strcmp(key, #k)) return opt_bool(value, &o->k) ? JT_OK : JT_E_INVAL;
+    JT_OPT_AB_BOOLS(X)
+#undef X
+#define X(k) if (!strcmp(key, #k)) return opt_int(value, &o->k) ? JT_OK : JT_E_INVAL;
+    JT_OPT_AB_INTS(X)
+#undef X
+#else
+#define X(k) if (!strcmp(key, #k)) return JT_E_UNSUPPORTED;
+    JT_OPT_AB_BOOLS(X) JT_OPT_AB_INTS(X)
+#undef X
+#endif
+    return JT_E_INVAL;
+}
+extern "C" int jt_build_flags(void)
+{
+#ifdef JT_AB
+    return 1;
+#else
+    return 0;
+#endif
+}
+extern "C" int jt_set_option(jt_ctx *h, const char *key, const char *value)
+{
+    if (!key) { if (h) h->err = "set_option: null key"; return JT_E_INVAL; }
+    if (!h) {
+        // process-wide keys
+        if (!strcmp(key, "graveyard_gb")) {
+            if (!value || !*value) return JT_E_INVAL;
+            char *end = nullptr; const double gb = strtod(value, &end);
+            if (*end || !(gb >= 0)) return JT_E_INVAL;
+            DevGraveyard::set_limit_gb(gb); return JT_OK;
+        }
+        if (!strcmp(key, "poison_alloc")) { bool b = false; if (!opt_bool(value, &b)) return JT_E_INVAL; jt_poison_alloc().store(b ? 1 : 0); return JT_OK; }
+        return JT_E_INVAL;
+    }
+    const int rc = jt_opts_set(&h->opts, key, value);
+    if (rc == JT_OK && !strcmp(key, "host_timing")) jt_host_timing().store(h->opts.host_timing ? 1 : 0);
+    if (rc == JT_E_UNSUPPORTED) h->err = std::string("set_option: '") + key + "' selects a superseded kernel generation or a tuning knob: JT_AB build only (libjtgpu_ab.so)";
+    else if (rc != JT_OK) h->err = std::string("set_option: unknown key or bad value: ") + key + "=" + (value ? value : "");
+    return rc;
+}
+#ifdef JT_AB
+// the A/B build keeps the tools' JT_<KEY>=value switches working: imported ONCE per handle at jt_open, under a lock
+static void opts_from_env(JtOpts *o)
+{
+    static std::mutex m; std::lock_guard<std::mutex> g(m);
+    auto imp = [&](const char *k) {
+        std::string e = "JT_"; for (const char *c = k; *c; ++c) e += (char)toupper((unsigned char)*c);
+        if (const char *v = getenv(e.c_str())) (void)jt_opts_set(o, k, v);
+    };
+#define X(k) imp(#k);
+    JT_OPT_BOOLS(X) JT_OPT_INTS(X) JT_OPT_AB_BOOLS(X) JT_OPT_AB_INTS(X)
+#undef X
+    if (const char *v = getenv("JT_GRAVEYARD_GB")) DevGraveyard::set_limit_gb(atof(v));
+    if (getenv("JT_POISON_ALLOC")) jt_poison_alloc().store(1);
+}
+#endif
 
 // ---------------------------------------------------------------- helpers
 static void ensure_twiddle(jt_ctx *h, int N)
@@ -212,8 +302,8 @@ static void pass_begin(jt_ctx *h, int64_t max_samples, int analyses, int64_t ext
         // (idle outside adeclick), so that they run beside the pass's full-length analysis.  Behind the full chains on their own four
         // streams (JT_REGION_ROT=r: region chain i behind full chain (i + r) % 4) they end 0.4 ms later at best (r = 3, the longest
         // region chain behind the shortest full chain) -- tools/ab_env.py JT_REGION_ROT=-,0,3
-        const char *rv = getenv("JT_REGION_ROT");
-        const int rot = rv ? atoi(rv) & 3 : 3;
+        const bool rv = h->opts.region_rot >= 0;
+        const int rot = rv ? h->opts.region_rot & 3 : 3;
         for (int i = 0; i < 4; ++i) h->aux[4 + i] = rv ? h->aux[(i + rot) % 4] : h->dk_stream;
     }
     const size_t na = (size_t)std::max(1, analyses), ne = (size_t)std::max(0, extra_jobs);
@@ -283,7 +373,7 @@ static void analysis_enqueue(jt_ctx *h, const float *x, int64_t n, int sr, bool 
         double *btp = h->pin.take<double>((size_t)nfull + 2);
         JT_HIP(hipMemcpyAsync(btp, d_tp, sizeof(double) * (nfull + 2), hipMemcpyDeviceToHost, a3));
         J->btp = btp;
-        if (r128_first && !getenv("JT_NO_R128_FIRST")) {
+        if (r128_first && !h->opts.no_r128_first) {
             // a planner waits for the true peak: the statistics nobody waits for (astats chains, spectral) start behind the upsampler
             // instead of sharing the CUs with it (3.6 ms beside them, 1-1.5 ms without), and then run beside Pass 3's prefix chain
             JT_HIP(hipEventRecord(h->early_p3.ev[1], a3));
@@ -386,9 +476,9 @@ static void assemble_analysis(const AnalysisHost &A, int64_t n, bool dualmono, j
 static void analysis_complete(jt_ctx *h, const AnalysisJob &J, jt_analysis *out, jt_frame_meta *meta, int64_t cap_meta, bool staged = false)
 {
     AnalysisHost A;
-    const bool timing = getenv("JT_HOST_TIMING") != nullptr;
+    const bool timing = h->opts.host_timing;
     std::chrono::steady_clock::time_point t0; if (timing) t0 = std::chrono::steady_clock::now();
-    if (staged && getenv("JT_NO_STAGED_FINISH")) {          // (the round-2 order: everything after the last chain)
+    if (staged && h->opts.no_staged_finish) {          // (the round-2 order: everything after the last chain)
         for (int i = 0; i < 4; ++i) JT_HIP(hipEventSynchronize(h->ev_chain[i]));
         staged = false;
     }
@@ -492,7 +582,7 @@ static void regions_enqueue(jt_ctx *h, const int16_t *src, int rate, RegionJobs 
             ln.first = 4; ln.tp = scr; ln.hops = reinterpret_cast<jt_spectral *>(scr + nfull + 2);
             ln.ehist = reinterpret_cast<unsigned long long *>(scr + nfull + 2 + hop_d);
         }
-        R->J[r].astats_levels_only = !getenv("JT_REGION_FULL_ASTATS");      // (regions_finish reads the levels and the crest factor only)
+        R->J[r].astats_levels_only = !h->opts.region_full_astats;      // (regions_finish reads the levels and the crest factor only)
         analysis_enqueue(h, h->region_f.p + (r ? R->len[0] : 0), R->len[r], rate, false, rate / 10, &R->J[r], false, own_lanes ? &ln : nullptr);
     }
 }
@@ -592,7 +682,7 @@ static void run_anlmdn(jt_ctx *h, const float *in, float *out, int64_t n, int sr
     const float lut_scale = 1.f / m * (float)(1 << 20);
     const float sw = (65536.f / (4 * K + 2)) / std::sqrt(a);
     JT_HIP(hipEventRecord(h->ev2, st));
-    launch_anlmdn(in, out, n, K, S, sw, m, lut_scale, st);
+    launch_anlmdn(in, out, n, K, S, sw, m, lut_scale, st, h->opts);
     JT_HIP(hipEventRecord(h->ev3, st));
 }
 
@@ -631,7 +721,7 @@ static void run_afftdn(jt_ctx *h, const float *in, float *out, int64_t n, int sr
         }
         d.seg_span = span;
     }
-    if (!track) { launch_afftdn(in, out, n, d, 0, 96, h->stream); return; }     // chunk length chosen from the frame count; 96 warm-up frames
+    if (!track) { launch_afftdn(in, out, n, d, 0, 96, h->stream, h->opts); return; }     // chunk length chosen from the frame count; 96 warm-up frames
     // tn=1 (af_afftdn.c track_noise; what the reference emits when Noise.Floor == 0, adaptive.go:147-151).  The floor is a state
     // that survives arbitrarily long stretches of speech (only spectrally flat frames move it), so a warm-up halo cannot restore
     // it -- but the VOTE of a frame (is it flat, and which floor does it ask for) depends on that frame's magnitudes alone.  First
@@ -640,7 +730,7 @@ static void run_afftdn(jt_ctx *h, const float *in, float *out, int64_t n, int sr
     const int64_t nframes = jt_afftdn_nframes(n, pl.A, pl.W);
     h->af_track.ensure((size_t)(2 * nframes + 4));
     d.track_out = h->af_track.p; d.mvseq = h->af_track.p + nframes + 1;
-    launch_afftdn(in, out, n, d, 0, 0, h->stream, 2);
+    launch_afftdn(in, out, n, d, 0, 0, h->stream, h->opts, 2);
     std::vector<double> vote((size_t)nframes), mv((size_t)nframes + 1);
     JT_HIP(hipMemcpyAsync(vote.data(), d.track_out, sizeof(double) * nframes, hipMemcpyDeviceToHost, h->stream));
     JT_HIP(hipStreamSynchronize(h->stream));
@@ -654,7 +744,7 @@ static void run_afftdn(jt_ctx *h, const float *in, float *out, int64_t n, int sr
     }
     h->af_last_floor = nfl;
     JT_HIP(hipMemcpyAsync(h->af_track.p + nframes + 1, mv.data(), sizeof(double) * (nframes + 1), hipMemcpyHostToDevice, h->stream));
-    launch_afftdn(in, out, n, d, 0, 96, h->stream, 1);
+    launch_afftdn(in, out, n, d, 0, 96, h->stream, h->opts, 1);
     JT_HIP(hipStreamSynchronize(h->stream));                 // (mv is a host vector: the upload must have left it)
 }
 
@@ -691,7 +781,7 @@ static void run_resample_s16(jt_ctx *h, const float *x, int64_t n, int in_rate, 
     SwrDev &sw = get_swr(h, in_rate, out_rate);
     const int64_t m = sw.out_len(n);                      // ceil(n*out/in)
     dst.ensure((size_t)m);
-    launch_resample_to_s16(x, n, sw.bank_d.p, sw.pl.phase_count, sw.pl.filter_length, sw.pl.center, sw.pl.step, dst.p, m, h->stream);
+    launch_resample_to_s16(x, n, sw.bank_d.p, sw.pl.phase_count, sw.pl.filter_length, sw.pl.center, sw.pl.step, dst.p, m, h->stream, h->opts);
     *m_out = m;
 }
 
@@ -700,7 +790,7 @@ extern "C" int jt_pass2_prefetch(jt_ctx *h, const jt_filter_params *p)
     JT_API_BEGIN(h)                                           // (retires an earlier head first)
     JT_REQUIRE(h->n > 0 && h->in_mono, JT_E_STATE, "pass2_prefetch: no input uploaded");
     JT_REQUIRE(p, JT_E_INVAL, "pass2_prefetch: bad arguments");
-    if (getenv("JT_NO_PASS2_PREFETCH")) return JT_OK;         // (A/B switch: Pass 2 then runs every stage itself)
+    if (h->opts.no_pass2_prefetch) return JT_OK;              // (A/B switch: Pass 2 then runs every stage itself)
     spec_pass2_start(h, p);
     JT_API_END(h)
 }
@@ -709,7 +799,7 @@ extern "C" int jt_pass2_prefetch_after_pass1(jt_ctx *h, const jt_filter_params *
     JT_API_BEGIN(h)
     JT_REQUIRE(h->n > 0 && h->in_mono, JT_E_STATE, "pass2_prefetch: no input uploaded");
     JT_REQUIRE(p, JT_E_INVAL, "pass2_prefetch: bad arguments");
-    if (getenv("JT_NO_PASS2_PREFETCH")) return JT_OK;
+    if (h->opts.no_pass2_prefetch) return JT_OK;
     h->spec_p2.armed_p = *p; h->spec_p2.armed = true;
     JT_API_END(h)
 }
@@ -747,7 +837,7 @@ template <typename T> static void loudnorm_append_flush(T *stream, int64_t m_tot
 // of its own: the pass arenas are recycled by the next pass_begin.
 static void spec_loudnorm_enqueue(jt_ctx *h, const int16_t *s16, int64_t n, int rate)
 {
-    if (rate == 192000 || n <= 0 || getenv("JT_NO_EARLY_PASS3")) return;
+    if (rate == 192000 || n <= 0 || h->opts.no_early_pass3) return;
     auto &S = h->spec_ln;
     SwrDev &sw = get_swr(h, rate, 192000);
     const int64_t m_total = sw.out_len(n);
@@ -758,7 +848,7 @@ static void spec_loudnorm_enqueue(jt_ctx *h, const int16_t *s16, int64_t n, int 
     if (pin_d > S.pin_cap) {
         if (S.pin) jt_graveyard().put(S.pin, sizeof(double) * S.pin_cap, 1);
         S.pin = nullptr; S.pin_cap = 0;
-        JT_HIP(hipHostMalloc((void **)&S.pin, sizeof(double) * pin_d, hipHostMallocDefault));
+        JT_HIP(DevGraveyard::host_malloc((void **)&S.pin, sizeof(double) * pin_d));
         S.pin_cap = pin_d;
     }
     h->stream_f.ensure((size_t)m_meter);
@@ -799,7 +889,7 @@ static void early_pass3_enqueue(jt_ctx *h, const int16_t *s16, int64_t m, int ra
     if (pin_d > E.pin_cap) {
         if (E.pin) jt_graveyard().put(E.pin, sizeof(double) * E.pin_cap, 1);
         E.pin = nullptr; E.pin_cap = 0;
-        JT_HIP(hipHostMalloc((void **)&E.pin, sizeof(double) * pin_d, hipHostMallocDefault));
+        JT_HIP(DevGraveyard::host_malloc((void **)&E.pin, sizeof(double) * pin_d));
         E.pin_cap = pin_d;
     }
     h->f64_a.ensure((size_t)m); h->f64_b.ensure((size_t)m); h->stream_d.ensure((size_t)m_meter);
@@ -807,7 +897,7 @@ static void early_pass3_enqueue(jt_ctx *h, const int16_t *s16, int64_t m, int ra
     const double g = pre ? std::pow(10.0, lim.pre_gain_db / 20.0) : 1.0;
     run_limiter(h, h->f64_a.p, h->f64_b.p, m, rate, lim.limit, 5.0, 100.0, 1.0, LimS16{s16, g, pre ? 1 : 0});
     h->lim_keep = {true, s16, m, rate, lim.pre_gain_db, lim.limit};
-    launch_resample_stream_f64(h->f64_b.p, m, sw.bank_d.p, sw.pl.phase_count, sw.pl.filter_length, sw.pl.center, sw.pl.step, m_total, h->stream_d.p, h->stream);
+    launch_resample_stream_f64(h->f64_b.p, m, sw.bank_d.p, sw.pl.phase_count, sw.pl.filter_length, sw.pl.center, sw.pl.step, m_total, h->stream_d.p, h->stream, h->opts);
     loudnorm_append_flush(h->stream_d.p, m_total, h->stream);
     const KwScratch ext{E.dev.p, E.pin};
     jt_kweight_enqueue_f64(h, h->stream_d.p, m_meter, 192000, blk, &E.kw, h->stream, &ext);
@@ -827,7 +917,7 @@ extern "C" int jt_pass2(jt_ctx *h, const jt_filter_params *p, jt_analysis *out)
     spec_loudnorm_cancel(h);
     h->lim_keep.valid = false;
     h->early_p3.valid = false;
-    const bool plan_hook = h->early_p3.armed && !getenv("JT_NO_EARLY_PLAN"); h->early_p3.armed = false;
+    const bool plan_hook = h->early_p3.armed && !h->opts.no_early_plan; h->early_p3.armed = false;
     jt_ctx::RegionSlot &slot = h->region_slot[0];
     slot.valid = false; h->region_slot[1].valid = false;            // both stage outputs are about to be replaced
     const bool announced = slot.armed; slot.armed = false;
@@ -863,7 +953,7 @@ extern "C" int jt_pass2(jt_ctx *h, const jt_filter_params *p, jt_analysis *out)
     if (d.gate_on || d.comp_on || d.deess_on) {
         h->f64_a.ensure((size_t)n + 16); if (d.deess_on) h->f64_b.ensure((size_t)n + 16);
         h->d_scr3.ensure((size_t)(n / 256 + 4));
-        launch_dynamics(cur, nxt, h->f64_a.p, h->f64_b.p, h->d_scr3.p, n, d, h->stream, cur != h->in_mono); advance();
+        launch_dynamics(cur, nxt, h->f64_a.p, h->f64_b.p, h->d_scr3.p, n, d, h->stream, h->opts, cur != h->in_mono); advance();
     }
     check_cancel(h);
     AnalysisJob J;
@@ -957,7 +1047,7 @@ static void run_limiter(jt_ctx *h, double *in, double *out, int64_t n, int sr, d
     const int blk = 256;
     const int64_t nblk = (n + blk - 1) / blk;
     h->d_scr3.ensure((size_t)nblk);
-    if (src.s16 && !getenv("JT_NO_LIM_S16")) launch_absmax_conv_s16(src.s16, in, out, n, src.vol, src.vol_in_float, in_gain, h->d_scr3.p, nblk, h->stream);
+    if (src.s16 && !JT_AB_ON(h->opts.no_lim_s16)) launch_absmax_conv_s16(src.s16, in, out, n, src.vol, src.vol_in_float, in_gain, h->d_scr3.p, nblk, h->stream);
     else {
         if (src.s16) launch_s16_to_f64(src.s16, in, n, src.vol, src.vol_in_float, h->stream);
         launch_absmax_copy_f64(in, out, n, in_gain, h->d_scr3.p, nblk, h->stream);      // blk == 256
@@ -989,7 +1079,7 @@ static void loudnorm_measure_enqueue(jt_ctx *h, const int16_t *s16, const double
         jt_kweight_enqueue_f32(h, h->stream_f.p, m_meter, 192000, blk, &J->kw, h->stream);
     } else {
         h->stream_d.ensure((size_t)m_meter);
-        launch_resample_stream_f64(f64, n, sw.bank_d.p, sw.pl.phase_count, sw.pl.filter_length, sw.pl.center, sw.pl.step, m_total, h->stream_d.p, h->stream);
+        launch_resample_stream_f64(f64, n, sw.bank_d.p, sw.pl.phase_count, sw.pl.filter_length, sw.pl.center, sw.pl.step, m_total, h->stream_d.p, h->stream, h->opts);
         loudnorm_append_flush(h->stream_d.p, m_total, h->stream);
         jt_kweight_enqueue_f64(h, h->stream_d.p, m_meter, 192000, blk, &J->kw, h->stream);
     }
@@ -1152,7 +1242,7 @@ static void loudnorm_dynamic_run(jt_ctx *h, double *x, int64_t m, const Loudnorm
     // (the workgroup kernel runs as a sequence of launches of a few milliseconds each on the main stream: a launch that lasts a second
     // holds up every other handle's stream that shares its hardware queue, k_loudnorm.hip)
     h->ln_carry.ensure(256);
-    launch_loudnorm_dynamic(x, m, P, h->ln_series.p, h->ln_ring.p, y, nullptr, s, h->ln_carry.p);
+    launch_loudnorm_dynamic(x, m, P, h->ln_series.p, h->ln_ring.p, y, nullptr, s, h->ln_carry.p, h->opts);
     JT_HIP(hipGetLastError());
     finish_stats(bs, nfull_ext, peak, true);
 }
@@ -1187,7 +1277,7 @@ extern "C" int jt_pass4(jt_ctx *h, const jt_limiter_plan *lim, const jt_loudnorm
     const bool pre = lim && lim->needed && lim->pre_gain_db > 0;
     const jt_ctx::LimKeep &lk = h->lim_keep;
     const bool kept = lk.valid && lim && lim->needed && lk.src == h->s16_p2.p && lk.m == m && lk.rate == rate &&
-                      lk.pre_gain_db == lim->pre_gain_db && lk.limit == lim->limit && !getenv("JT_NO_LIM_KEEP");
+                      lk.pre_gain_db == lim->pre_gain_db && lk.limit == lim->limit && !h->opts.no_lim_keep;
     h->lim_keep.valid = false;                                  // (this pass overwrites both buffers)
     if (kept) std::swap(sig, tmp);                              // Pass 3 ran this prefix on these samples: its output is still in f64_b
     else {
@@ -1202,7 +1292,7 @@ extern "C" int jt_pass4(jt_ctx *h, const jt_limiter_plan *lim, const jt_loudnorm
     if (dyn) {
         SwrDev &up = get_swr(h, rate, 192000);
         h->stream_d.ensure((size_t)m192 + 576000 + 64); h->stream_y.ensure((size_t)m192 + 19200 + 64);
-        launch_resample_stream_f64(sig, m, up.bank_d.p, up.pl.phase_count, up.pl.filter_length, up.pl.center, up.pl.step, m192, h->stream_d.p, h->stream);
+        launch_resample_stream_f64(sig, m, up.bank_d.p, up.pl.phase_count, up.pl.filter_length, up.pl.center, up.pl.step, m192, h->stream_d.p, h->stream, h->opts);
         LoudnormDynIn din{ap->target_i, ap->target_lra, ap->target_tp, ap->measured_i, ap->measured_lra, ap->measured_tp, ap->measured_thresh,
                           ap->offset, true, true};
         jt_loudnorm_stats dst; std::memset(&dst, 0, sizeof(dst));
@@ -1289,7 +1379,7 @@ extern "C" int jt_pass4(jt_ctx *h, const jt_limiter_plan *lim, const jt_loudnorm
     check_cancel(h);
     if (dk_stats) {
         h->timers.declick_repaired = (int64_t)dk_stats[0]; h->timers.declick_heavy_windows = (int64_t)dk_stats[2];
-        if (getenv("JT_DK_PROFILE")) {
+        if (JT_AB_ON(h->opts.dk_profile)) {
             fprintf(stderr, "adeclick: repaired %llu, second-pass windows %llu, third-pass windows %llu; phase clocks (JT_DK_PROFILE build):", dk_stats[0], dk_stats[2], dk_stats[3]);
             for (int i = 4; i < 12; ++i) fprintf(stderr, " %llu", dk_stats[i]);
             fprintf(stderr, "\n");
@@ -1472,7 +1562,7 @@ extern "C" int jt_op_dynamics(jt_ctx *h, const float *in, float *out, int64_t n,
     DevBuf<float> a, b; h2d(h, a, in, (size_t)n); b.ensure((size_t)n);
     DynParams d; jt_dyn_design(p, sr, &d);
     DevBuf<double> t1, t2, st; t1.ensure((size_t)n); t2.ensure((size_t)n); st.ensure((size_t)(n / 256 + 4));
-    launch_dynamics(a.p, b.p, t1.p, t2.p, st.p, n, d, h->stream);
+    launch_dynamics(a.p, b.p, t1.p, t2.p, st.p, n, d, h->stream, h->opts);
     d2h(h, out, b.p, (size_t)n);
     JT_API_END(h)
 }
@@ -1502,7 +1592,7 @@ extern "C" int jt_op_adeclick_f64(jt_ctx *h, const double *in, double *out, int6
     unsigned long long st[16] = {0};
     JT_HIP(hipMemcpyAsync(st, h->declick_stats.p, sizeof(st), hipMemcpyDeviceToHost, h->stream));
     d2h(h, out, b.p, (size_t)n);
-    if (getenv("JT_DK_PROFILE")) { fprintf(stderr, "adeclick phase clocks:"); for (int i = 4; i < 12; ++i) fprintf(stderr, " %llu", st[i]); fprintf(stderr, " heavy %llu", st[2]); fprintf(stderr, "\n"); }
+    if (JT_AB_ON(h->opts.dk_profile)) { fprintf(stderr, "adeclick phase clocks:"); for (int i = 4; i < 12; ++i) fprintf(stderr, " %llu", st[i]); fprintf(stderr, " heavy %llu", st[2]); fprintf(stderr, "\n"); }
     if (n_repaired) *n_repaired = (int64_t)st[0];
     JT_REQUIRE(st[1] == 0, JT_E_HIP, "adeclick: singular interpolation matrix");
     JT_API_END(h)

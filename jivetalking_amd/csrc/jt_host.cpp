@@ -530,7 +530,7 @@ extern "C" int64_t jt_host_build_intervals(int sr, int64_t n_samples, int frame_
         int nt = 1;
         jt_parallel_for(n_meta, [&](int64_t lo, int64_t hi, int) { quant_range(lo, hi); }, &nt);
         meta = qmeta.data();
-        if (getenv("JT_HOST_TIMING")) fprintf(stderr, "quant prepass %.3f ms (%d parts)\n", now_ms() - tq0, nt);
+        if (jt_host_timing().load(std::memory_order_relaxed)) fprintf(stderr, "quant prepass %.3f ms (%d parts)\n", now_ms() - tq0, nt);
     }
     auto add_meta = [&](const jt_frame_meta &m) {
         bool has = !std::isnan(m.momentary);
@@ -614,7 +614,7 @@ static void detect_vad(const std::vector<jt_interval> &iv, double seed, jt_measu
     }
     const double tv1 = now_ms();
     BestResult br = findBestSpeechRegion(runs, iv, haveProfile, floor_);
-    if (getenv("JT_HOST_TIMING")) fprintf(stderr, "vad: runs+noise %.3f ms, best speech %.3f ms\n", tv1 - tv0, now_ms() - tv1);
+    if (jt_host_timing().load(std::memory_order_relaxed)) fprintf(stderr, "vad: runs+noise %.3f ms, best speech %.3f ms\n", tv1 - tv0, now_ms() - tv1);
     m->n_candidates = (int)std::min<size_t>(br.cands.size(), JT_MAX_REGIONS);
     for (int i = 0; i < m->n_candidates; ++i) m->candidates[i] = br.cands[i];
     bool elected = false; jt_region electedRegion{};
@@ -677,7 +677,7 @@ extern "C" int jt_host_detect(const jt_analysis *p1, const jt_interval *ivp, int
 
     const double td1 = now_ms();
     detect_vad(iv, m->floor_prescan, m);
-    if (getenv("JT_HOST_TIMING")) fprintf(stderr, "detect: seed %.3f ms, vad %.3f ms\n", td1 - td0, now_ms() - td1);
+    if (jt_host_timing().load(std::memory_order_relaxed)) fprintf(stderr, "detect: seed %.3f ms, vad %.3f ms\n", td1 - td0, now_ms() - td1);
     return JT_OK;
 }
 
@@ -966,8 +966,12 @@ extern "C" int jt_host_pass4_spec(const jt_host_config *cfg, const jt_loudnorm_s
     if (source_rate > 0) join(s, sfmt("aresample=%d", source_rate));
     if (cfg->adeclick_enabled) {
         std::string a = sfmt("adeclick=t=%.1f:w=%.0f:o=%.0f", cfg->adeclick_threshold, cfg->adeclick_window, cfg->adeclick_overlap);
-        if (cfg->adeclick_method_s == 1) a += ":m=s";                  // AdeclickConfig.Method: "" -> nothing (af_adeclick.c defaults to m=a), "s", "a"
+        // AdeclickConfig.Method goes into the spec verbatim (filters.go:958-960): "" -> nothing (af_adeclick.c defaults to m=a); af_adeclick's
+        // option table names each method twice, "s" / "save" and "a" / "add"
+        if (cfg->adeclick_method_s == 1) a += ":m=s";
         else if (cfg->adeclick_method_s == 2) a += ":m=a";
+        else if (cfg->adeclick_method_s == 3) a += ":m=save";
+        else if (cfg->adeclick_method_s == 4) a += ":m=add";
         join(s, a);
     }
     join(s, sfmt("alimiter=limit=%.6f:attack=1:release=50:level_in=1:level_out=1:level=0:latency=1:asc=1:asc_level=0.8", DbToLinear(brickDB)));
@@ -984,7 +988,7 @@ extern "C" int jt_host_pass4_spec(const jt_host_config *cfg, const jt_loudnorm_s
         ap->offset = qfmt("%.2f", offset);
         ap->adeclick_enabled = cfg->adeclick_enabled; ap->adeclick_threshold = qfmt("%.1f", cfg->adeclick_threshold);
         ap->adeclick_window_ms = qfmt("%.0f", cfg->adeclick_window); ap->adeclick_overlap_pct = qfmt("%.0f", cfg->adeclick_overlap);
-        ap->adeclick_method = cfg->adeclick_method_s == 1 ? 1 : 0;
+        ap->adeclick_method = (cfg->adeclick_method_s == 1 || cfg->adeclick_method_s == 3) ? 1 : 0;
         ap->brickwall_limit = qfmt("%.6f", DbToLinear(brickDB));
     }
     return (int)s.size();
@@ -1530,23 +1534,31 @@ extern "C" int jt_process_file(jt_ctx *h, const char *input_path, const jt_host_
 // the next unclaimed file when it finishes one -- the reference's runBoundedPool semantics (a bounded number of ProcessAudio calls
 // at a time, a file's failure never stops the others), with the GPU as the bounded resource.  Files are handed out longest first
 // when their sizes are known (the on-disk size is the proxy), so the tail of the batch is made of short files.
-extern "C" int jt_process_files_multi(const int *devices, int n_devices, const char *const *paths, int n_files, int in_flight_per_device,
-                                      const jt_host_config *base, int frame_samples, int flac_flags, jt_file_result *results, int *device_of_file)
+// A pool owns its handles: they are opened once (in parallel: hipMalloc serialises a worker's first-file allocations anyway) and serve
+// any number of batches -- what a long-running host wants (the Go shim pools handles the same way), and what keeps 0.1 s of start-up
+// out of every sub-second batch.  A device that cannot be opened gets no worker; its worker tries the devices nobody serves yet.
+struct jt_handle_pool {
+    std::vector<int> devices;
+    int in_flight = 1;
+    struct Worker { jt_ctx *h; int device; };
+    std::vector<Worker> workers;
+    int open_rc = JT_OK, open_dev = -1;
+    std::mutex busy;                        // one batch at a time
+};
+
+extern "C" int jt_handle_pool_open(const int *devices, int n_devices, int in_flight_per_device, int max_workers, jt_handle_pool **out)
 {
-    if (!devices || n_devices < 1 || !paths || !results || n_files < 0 || in_flight_per_device < 1) return JT_E_INVAL;
-    for (int i = 0; i < n_files; ++i) { std::memset(&results[i], 0, sizeof results[i]); results[i].rc = JT_E_STATE; if (device_of_file) device_of_file[i] = -1; }
-    if (n_files == 0) return 0;
-    // longest first (LPT): order[] is the queue
-    std::vector<int> order((size_t)n_files); std::vector<long long> size((size_t)n_files, 0);
-    for (int i = 0; i < n_files; ++i) { order[(size_t)i] = i; struct stat st; if (paths[i] && stat(paths[i], &st) == 0) size[(size_t)i] = (long long)st.st_size; }
-    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return size[(size_t)a] > size[(size_t)b]; });
-    std::atomic<int> next{0}, failed{0}, opened{0}, open_rc{JT_OK}, open_dev{-1};
-    std::vector<char> claimed((size_t)n_files, 0);
-    auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    if (!out) return JT_E_INVAL;
+    *out = nullptr;
+    if (!devices || n_devices < 1 || in_flight_per_device < 1) return JT_E_INVAL;
+    jt_handle_pool *P = new jt_handle_pool();
+    P->devices.assign(devices, devices + n_devices); P->in_flight = in_flight_per_device;
     const int want = n_devices * in_flight_per_device;
-    const int workers = std::min(want, n_files);
-    std::atomic<int> spare{workers};                 // devices[workers..] have no worker of their own (fewer files than devices)
-    auto worker = [&](int device) {
+    const int workers = max_workers > 0 ? std::min(want, max_workers) : want;
+    std::atomic<int> spare{workers};                 // devices[workers..] have no worker of their own (fewer workers than devices)
+    std::atomic<int> open_rc{JT_OK}, open_dev{-1};
+    std::mutex m;
+    auto open_one = [&](int device) {
         jt_ctx *h = nullptr;
         int orc = jt_open(device, &h);
         while ((orc != JT_OK || !h) && workers < n_devices) {
@@ -1557,19 +1569,73 @@ extern "C" int jt_process_files_multi(const int *devices, int n_devices, const c
             device = devices[k]; h = nullptr; orc = jt_open(device, &h);
         }
         if (orc != JT_OK || !h) {
-            // a worker without a device takes nothing from the queue: the files stay for the workers that have one (pool.go:122-153 -
-            // one failure never stops the others); only when NO worker opened a handle are the files failed, below
             int ok = JT_OK;
             if (open_rc.compare_exchange_strong(ok, orc != JT_OK ? orc : JT_E_NOGPU)) open_dev.store(device);
             return;
         }
-        opened.fetch_add(1);
+        std::lock_guard<std::mutex> g(m);
+        P->workers.push_back({h, device});
+    };
+    std::vector<std::thread> th;
+    // worker w serves device w % n_devices: with fewer workers than slots every device still gets one before any gets two
+    for (int w = 1; w < workers; ++w) th.emplace_back(open_one, devices[w % n_devices]);
+    open_one(devices[0]);
+    for (auto &t : th) t.join();
+    P->open_rc = open_rc.load(); P->open_dev = open_dev.load();
+    // (deterministic worker order: by device, so that a report of "which worker served what" reads the same run to run)
+    std::stable_sort(P->workers.begin(), P->workers.end(), [](const jt_handle_pool::Worker &a, const jt_handle_pool::Worker &b) { return a.device < b.device; });
+    *out = P;
+    return JT_OK;
+}
+
+extern "C" int jt_handle_pool_workers(const jt_handle_pool *P, int *devices_out, int cap)
+{
+    if (!P) return JT_E_INVAL;
+    for (int i = 0; i < (int)P->workers.size() && i < cap && devices_out; ++i) devices_out[i] = P->workers[(size_t)i].device;
+    return (int)P->workers.size();
+}
+
+extern "C" void jt_handle_pool_close(jt_handle_pool *P)
+{
+    if (!P) return;
+    {
+        std::lock_guard<std::mutex> g(P->busy);          // a batch still running ends first; nobody may start one on a pool being closed
+        std::vector<std::thread> th;
+        for (auto &w : P->workers) th.emplace_back([h = w.h] { jt_close(h); });
+        for (auto &t : th) t.join();
+        P->workers.clear();
+    }
+    delete P;
+}
+
+extern "C" int jt_handle_pool_process_files(jt_handle_pool *P, const char *const *paths, int n_files, const jt_host_config *base, int frame_samples, int flac_flags,
+                                     jt_file_result *results, int *device_of_file)
+{
+    if (!P || !paths || !results || n_files < 0) return JT_E_INVAL;
+    std::lock_guard<std::mutex> busy(P->busy);
+    for (int i = 0; i < n_files; ++i) { std::memset(&results[i], 0, sizeof results[i]); results[i].rc = JT_E_STATE; if (device_of_file) device_of_file[i] = -1; }
+    if (n_files == 0) return 0;
+    if (P->workers.empty()) {
+        // no worker has a device: every file fails with the reason the first jt_open gave (pool.go:122-153 - a result per file)
+        const int rc = P->open_rc != JT_OK ? P->open_rc : JT_E_NOGPU;
+        for (int i = 0; i < n_files; ++i) {
+            results[i].rc = rc;
+            snprintf(results[i].error, sizeof results[i].error, "jt_open(%d) failed (%d): no worker has a device", P->open_dev, rc);
+        }
+        return n_files;
+    }
+    // longest first (LPT): order[] is the queue
+    std::vector<int> order((size_t)n_files); std::vector<long long> size((size_t)n_files, 0);
+    for (int i = 0; i < n_files; ++i) { order[(size_t)i] = i; struct stat st; if (paths[i] && stat(paths[i], &st) == 0) size[(size_t)i] = (long long)st.st_size; }
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return size[(size_t)a] > size[(size_t)b]; });
+    std::atomic<int> next{0}, failed{0};
+    auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    auto worker = [&](jt_ctx *h, int device) {
         for (;;) {
             const int q = next.fetch_add(1);
             if (q >= n_files) break;
             const int i = order[(size_t)q];
             jt_file_result &r = results[i];
-            claimed[(size_t)i] = 1;
             if (device_of_file) device_of_file[i] = device;
             const double t0 = now();
             if (!paths[i]) { r.rc = JT_E_INVAL; snprintf(r.error, sizeof r.error, "null path"); }
@@ -1581,21 +1647,38 @@ extern "C" int jt_process_files_multi(const int *devices, int n_devices, const c
             r.wall_ms = now() - t0;
             if (r.rc != JT_OK) failed.fetch_add(1);
         }
-        jt_close(h);
     };
-    std::vector<std::thread> th;
-    // worker w serves device w % n_devices: with fewer files than workers every device still gets one before any gets two
-    for (int w = 1; w < workers; ++w) th.emplace_back(worker, devices[w % n_devices]);
-    worker(devices[0]);
-    for (auto &t : th) t.join();
-    if (opened.load() == 0) {
-        for (int i = 0; i < n_files; ++i) if (!claimed[(size_t)i]) {
-            results[i].rc = open_rc.load() != JT_OK ? open_rc.load() : JT_E_NOGPU;
-            snprintf(results[i].error, sizeof results[i].error, "jt_open(%d) failed (%d): no worker has a device", open_dev.load(), results[i].rc);
-            failed.fetch_add(1);
+    const size_t nw = std::min<size_t>(P->workers.size(), (size_t)n_files);
+    // with fewer files than workers, take one worker per device before a second on any (the workers are sorted by device)
+    std::vector<size_t> pick;
+    if (nw < P->workers.size()) {
+        std::vector<char> used(P->workers.size(), 0);
+        while (pick.size() < nw) {
+            int last = INT32_MIN; bool any = false;
+            for (size_t w = 0; w < P->workers.size() && pick.size() < nw; ++w)
+                if (!used[w] && P->workers[w].device != last) { used[w] = 1; pick.push_back(w); last = P->workers[w].device; any = true; }
+            if (!any) break;
         }
-    }
+    } else for (size_t w = 0; w < nw; ++w) pick.push_back(w);
+    std::vector<std::thread> th;
+    for (size_t k = 1; k < pick.size(); ++k) th.emplace_back(worker, P->workers[pick[k]].h, P->workers[pick[k]].device);
+    worker(P->workers[pick[0]].h, P->workers[pick[0]].device);
+    for (auto &t : th) t.join();
     return failed.load();
+}
+
+extern "C" int jt_process_files_multi(const int *devices, int n_devices, const char *const *paths, int n_files, int in_flight_per_device,
+                                      const jt_host_config *base, int frame_samples, int flac_flags, jt_file_result *results, int *device_of_file)
+{
+    if (!devices || n_devices < 1 || !paths || !results || n_files < 0 || in_flight_per_device < 1) return JT_E_INVAL;
+    if (n_files == 0) return 0;
+    // a pool for the length of the call (a caller with more than one batch keeps its own: jt_handle_pool_open)
+    jt_handle_pool *P = nullptr;
+    const int rc = jt_handle_pool_open(devices, n_devices, in_flight_per_device, n_files, &P);
+    if (rc != JT_OK) return rc;
+    const int failed = jt_handle_pool_process_files(P, paths, n_files, base, frame_samples, flac_flags, results, device_of_file);
+    jt_handle_pool_close(P);
+    return failed;
 }
 
 extern "C" int jt_process_files(int device, const char *const *paths, int n_files, int in_flight, const jt_host_config *base,

@@ -26,7 +26,7 @@ struct JtError { int code; std::string msg; };
 // other handle's queued work had finished -- several workers on one GPU (jt_process_files_multi) synchronised each other at every
 // such growth, and a worker behind a 4-second dynamic-loudnorm kernel waited for all of it (tools/probe_dynamic_concurrency.py: N
 // handles took N times as long).  A buffer that is replaced is parked here instead, still valid for whatever is in flight on it, and
-// freed when a handle closes or when more than JT_GRAVEYARD_GB (default 24) have piled up -- a free does its own device-wide wait,
+// freed when a handle closes or when more than graveyard_gb (jt_set_option, default 24) have piled up -- a free does its own device-wide wait,
 // which is what makes it safe at any time.
 struct DevGraveyard {
     std::mutex m; std::vector<std::pair<void *, int>> v; size_t bytes = 0;
@@ -37,9 +37,24 @@ struct DevGraveyard {
         { std::lock_guard<std::mutex> g(m); w.swap(v); bytes = 0; }
         for (auto &e : w) { if (e.second) (void)hipHostFree(e.first); else (void)hipFree(e.first); }
     }
-    static size_t limit() { static const size_t l = (size_t)(getenv("JT_GRAVEYARD_GB") ? atof(getenv("JT_GRAVEYARD_GB")) : 24.0) * (size_t)1 << 30; return l; }
+    // bytes parked before a drain (jt_set_option(NULL, "graveyard_gb", ...); 0 = free at once)
+    static std::atomic<size_t> &limit_ref() { static std::atomic<size_t> l{(size_t)24 << 30}; return l; }
+    static size_t limit() { return limit_ref().load(std::memory_order_relaxed); }
+    static void set_limit_gb(double gb) { if (!(gb >= 0)) gb = 0; if (gb > 4096) gb = 4096; limit_ref().store((size_t)(gb * (double)((size_t)1 << 30))); }
+    // pinned allocations park here as well: a hipHostMalloc that fails while gigabytes sit parked drains and tries once more
+    static hipError_t host_malloc(void **p, size_t bytes);
 };
 inline DevGraveyard &jt_graveyard() { static DevGraveyard *g = new DevGraveyard(); return *g; }    // (never destroyed: the runtime may be gone at exit)
+inline hipError_t DevGraveyard::host_malloc(void **p, size_t bytes)
+{
+    hipError_t e = hipHostMalloc(p, bytes, hipHostMallocDefault);
+    if (e != hipSuccess && jt_graveyard().parked() > 0) { (void)hipGetLastError(); jt_graveyard().drain(); e = hipHostMalloc(p, bytes, hipHostMallocDefault); }
+    return e;
+}
+// jt_set_option(NULL, "poison_alloc", "1"): every device allocation is filled with 0xFF bytes (tools/stale_memory.py, the GPU suite under it)
+inline std::atomic<int> &jt_poison_alloc() { static std::atomic<int> v{0}; return v; }
+// host-stage timings on stderr from the handle-less host functions (set with any handle's host_timing option)
+inline std::atomic<int> &jt_host_timing() { static std::atomic<int> v{0}; return v; }
 
 // Simple owning device buffer
 template <typename T> struct DevBuf {
@@ -48,6 +63,7 @@ template <typename T> struct DevBuf {
     DevBuf(const DevBuf &) = delete; DevBuf &operator=(const DevBuf &) = delete;
     ~DevBuf() { release(); }
     void release() { if (p) { (void)hipFree(p); p = nullptr; n = 0; } }
+    void retire() { if (p) { jt_graveyard().put(p, n * sizeof(T), 0); p = nullptr; n = 0; } }     // still valid for work in flight; freed later
     void ensure(size_t count) {
         if (count <= n && p) return;
         DevGraveyard &gy = jt_graveyard();
@@ -57,15 +73,45 @@ template <typename T> struct DevBuf {
         if (e_ == hipErrorOutOfMemory) { (void)hipGetLastError(); gy.drain(); e_ = hipMalloc((void **)&p, count * sizeof(T)); }
         if (e_ != hipSuccess) { p = nullptr; throw JtError{JT_E_HIP, std::string("hipMalloc: ") + hipGetErrorString(e_)}; }
         // Nothing may depend on what an allocation holds: new pages happen to be zero, recycled ones are not, and a handle that has
-        // processed a longer file keeps its stale samples behind a shorter one.  JT_POISON_ALLOC=1 fills every allocation with 0xFF bytes
+        // processed a longer file keeps its stale samples behind a shorter one.  The process-wide option poison_alloc fills every allocation with 0xFF bytes
         // (NaNs / -1); tools/stale_memory.py and the whole GPU suite give the same results with it (tests/test_gpu_round2.py runs the
         // former).  The fill runs on the null stream, which the handle's non-blocking streams do not wait for: synchronise before use.
-        static const bool poison = getenv("JT_POISON_ALLOC") != nullptr;
-        if (poison) { JT_HIP(hipMemset(p, 0xFF, count * sizeof(T))); JT_HIP(hipStreamSynchronize(nullptr)); }
+        if (jt_poison_alloc().load(std::memory_order_relaxed)) { JT_HIP(hipMemset(p, 0xFF, count * sizeof(T))); JT_HIP(hipStreamSynchronize(nullptr)); }
         n = count;
     }
     void zero(hipStream_t s) { if (p) JT_HIP(hipMemsetAsync(p, 0, n * sizeof(T), s)); }
 };
+
+// ---------------------------------------------------------------- configuration surface
+// The library reads NO environment variable on the per-file path (a Go host runs dozens of goroutines: getenv / setenv races are
+// undefined behaviour).  Everything that used to be a JT_* variable is a field here, set through jt_set_option(h, key, value) and
+// read by the launchers.  Default build: the schedule switches the tests run both ways, the parity kernels, diagnostics.  JT_AB
+// build (make ab -> libjtgpu_ab.so): also the superseded kernel generations and the tuning knobs, compiled in for A/B runs; only
+// that build imports JT_<KEY> variables, once, inside jt_open.
+#define JT_OPT_BOOLS(X) \
+    X(no_pass2_prefetch) X(no_early_pass3) X(no_early_plan) X(no_lim_keep) X(no_staged_finish) X(no_r128_first) \
+    X(region_full_astats) X(host_timing) X(adeclick_exact) X(nlm_generic) X(p3_unfused) X(analysis_unfused) X(dyn_unfused)
+#define JT_OPT_INTS(X) X(region_rot)
+#define JT_OPT_AB_BOOLS(X) \
+    X(nlm_old) X(afftdn_old) X(adeclick_fused) X(dk_levinson_in_kernel) X(dk_no_xcd) X(dk_serial) X(dk_profile) X(dyn_one_wave) \
+    X(dyn_no_cu_reserve) X(kw_two_sweeps) X(follow_tiles) X(ups_no_stream8) X(ups_no_stream16) X(edge_polyphase) X(no_lim_s16)
+#define JT_OPT_AB_INTS(X) X(dk_waves) X(dyn_steps) X(deess_chunk) X(deess_halo)
+struct JtOpts {
+#define X(k) bool k = false;
+    JT_OPT_BOOLS(X) JT_OPT_AB_BOOLS(X)
+#undef X
+#define X(k) int k = 0;
+    JT_OPT_AB_INTS(X)
+#undef X
+    int region_rot = -1;                 // -1: the announced regions' chains on adeclick's second stream; r: region chain i behind full chain (i + r) % 4
+};
+#ifdef JT_AB
+#define JT_AB_ON(expr) (expr)
+#else
+#define JT_AB_ON(expr) false
+#endif
+// 0 = set, JT_E_INVAL = unknown key / bad value, JT_E_UNSUPPORTED = a key of the JT_AB build asked of the default build
+int jt_opts_set(JtOpts *o, const char *key, const char *value);
 
 // ---------------------------------------------------------------- host-side plans
 struct BiquadF32 { float b0, b1, b2, a1, a2; };      // TDII, a1/a2 already negated
@@ -109,7 +155,7 @@ struct DynParams {
 void jt_dyn_design(const jt_filter_params *p, int sr, DynParams *d);
 // in_has_slack: 16 readable bytes behind in[n-1] and tmp64[n-1] (the LDS-streamed followers read whole 16-byte groups)
 void launch_dynamics(const float *in, float *out_f32, double *tmp64, double *tmp64b, double *states, int64_t n, const DynParams &d, hipStream_t s,
-                     bool in_has_slack = false);
+                     const JtOpts &o, bool in_has_slack = false);
 
 // astats (k_astats.hip)
 struct jt_ctx;
@@ -128,7 +174,7 @@ void launch_limiter_f64(const double *in, double *out, int64_t n, int sr, double
 
 // resampler / true peak
 void launch_resample_to_s16(const float *in, int64_t n, const double *bank, int phase_count, int filter_length, int center,
-                            int64_t step, int16_t *out, int64_t m, hipStream_t s);
+                            int64_t step, int16_t *out, int64_t m, hipStream_t s, const JtOpts &o);
 int64_t launch_resample_range_to_s16(const float *in, int64_t n, const double *bank, int phase_count, int filter_length, int center,
                                      int64_t step, int64_t m, int64_t m_first, int64_t m_count, int16_t *dst, int64_t dst_cap, hipStream_t s);
 int64_t jt_resample_range_cap(int64_t n, int phase_count, int filter_length, int64_t step, int64_t m, int64_t m_count);
@@ -140,7 +186,7 @@ void launch_true_peak_f64(const double *in, int64_t n, const double *bank, int p
 void launch_resample_stream_s16_f32(const int16_t *in, int64_t n, const float *bankf, const float *bankf_scaled, int phase_count, int filter_length, int center,
                                     int64_t step, int64_t m_total, float *out, hipStream_t s);
 void launch_resample_stream_f64(const double *in, int64_t n, const double *bank, int phase_count, int filter_length, int center,
-                                int64_t step, int64_t m_total, double *out, hipStream_t s);
+                                int64_t step, int64_t m_total, double *out, hipStream_t s, const JtOpts &o);
 void launch_f64_to_s16(const double *in, int16_t *out, float *out_f32, int64_t n, int round_via_float, hipStream_t s);
 void launch_f32_to_f64(const float *in, double *out, int64_t n, hipStream_t s);
 
@@ -165,10 +211,10 @@ struct AfftdnDev {
     int seg_span = 0;
 };
 // mode 0: static noise floor; 1: per-frame variances from d.mvseq (tn=1, second sweep); 2: tn=1 first sweep, writes d.track_out only
-void launch_afftdn(const float *in, float *out, int64_t n, const AfftdnDev &d, int frames_per_chunk, int warm_frames, hipStream_t s, int mode = 0);
+void launch_afftdn(const float *in, float *out, int64_t n, const AfftdnDev &d, int frames_per_chunk, int warm_frames, hipStream_t s, const JtOpts &o, int mode = 0);
 int64_t jt_afftdn_nframes(int64_t n, int A, int W);
 // anlmdn
-void launch_anlmdn(const float *in, float *out, int64_t n, int K, int S, float sw, float smooth, float lut_scale, hipStream_t s);
+void launch_anlmdn(const float *in, float *out, int64_t n, int K, int S, float sw, float smooth, float lut_scale, hipStream_t s, const JtOpts &o);
 
 // adeclick (k_declick.hip)
 struct jt_ctx;
@@ -184,7 +230,7 @@ void jt_loudnorm_series(const double *bs, int64_t nfull, int64_t s100, bool dual
 void jt_kweight_coeffs5(int sr, double b[5], double a[5]);
 // carry: LN_CARRY = 256 doubles of device memory (the state one launch of the workgroup kernel hands to the next)
 void launch_loudnorm_dynamic(const double *x, int64_t n, const LoudnormDynParams &P, const double *series, double *ring, double *y, double *dbg, hipStream_t s,
-                             double *carry);
+                             double *carry, const JtOpts &o);
 void launch_scale_f64(const double *in, double *out, int64_t n, double g, hipStream_t s);
 void launch_swr_plain_f64(const double *in, int64_t n, const double *bank, int P, int L, int center, int64_t step, int64_t m_total, double *out, hipStream_t s);
 void launch_adeclick(jt_ctx *h, const double *in, double *out, int64_t n, int sample_rate, double threshold, double window_ms,
@@ -225,7 +271,7 @@ struct HostArena {
         if (bytes <= cap) return;
         if (p) { jt_graveyard().put(p, cap, 1); p = nullptr; cap = 0; }
         size_t want = bytes + bytes / 2 + (1u << 20);
-        JT_HIP(hipHostMalloc((void **)&p, want, hipHostMallocDefault));
+        JT_HIP(DevGraveyard::host_malloc((void **)&p, want));
         cap = want;
     }
     template <typename T> T *take(size_t count) {
@@ -267,6 +313,7 @@ size_t jt_arena_bytes_for(int64_t n);          // generous bound on the arena by
 // ---------------------------------------------------------------- context
 struct jt_ctx {
     int device = 0;
+    JtOpts opts;
     hipStream_t stream = nullptr;
     // auxiliary streams: the independent parts of an analysis (astats chains, true peak + K-weighting, spectral) are forked
     // onto them and joined back into `stream` with events, so latency-bound kernels overlap instead of queueing
@@ -376,6 +423,11 @@ inline void jt_drain(jt_ctx *h)
     for (int i = 0; i < 8; ++i) if (h->aux[i]) (void)hipStreamSynchronize(h->aux[i]);
     if (h->spec_ln.stream) { (void)hipStreamSynchronize(h->spec_ln.stream); h->spec_ln.pending = false; }
     if (h->spec_p2.stream) { (void)hipStreamSynchronize(h->spec_p2.stream); h->spec_p2.pending = false; }
+    // adeclick's second solver has a stream of its own (aux[4..7] alias it only after the first pass_begin and not under region_rot)
+    if (h->dk_stream) (void)hipStreamSynchronize(h->dk_stream);
+    // nothing a failed pass queued may be collected by a later call: Pass 3's early measurements, the kept limiter prefix, region slots
+    h->early_p3.valid = false; h->early_p3.mark_kw = false; h->lim_keep.valid = false;
+    h->region_slot[0].valid = h->region_slot[1].valid = false;
 }
 #define JT_API_END(h) } catch (const JtError &e) { jt_drain(h); (h)->err = e.msg; return e.code; } \
     catch (const std::exception &e) { jt_drain(h); (h)->err = e.what(); return JT_E_HIP; } return JT_OK;

@@ -1603,14 +1603,15 @@ void launch_adeclick(jt_ctx *h, const double *in, double *out, int64_t n, int sa
     // the bit-exact sequential-order kernel: parity tests / A-B, m=a, and AR orders above the 48 the fast kernels are laid out for
     // (its overflow levels then carry a 63 x 63 block instead of 49 x 49)
     const bool wide_ar = P.ar > dk::MAXAR;
-    const bool exact = getenv("JT_ADECLICK_EXACT") != nullptr || method == 0 || wide_ar;
+    const JtOpts &O = h->opts;
+    const bool exact = O.adeclick_exact || method == 0 || wide_ar;
     const int bsx = wide_ar ? dk::XBS : dk::BS;
     const int sa0 = sa_for(half_ok, LBS), sa1 = sa_for(half_ok, bsx), sa2 = sa_for(false, bsx);
     const size_t sm0 = smem_for(sa0, LIGHT, LBS), sm1 = smem_for(sa1, MID, bsx), sm2 = smem_for(sa2, dk::MAXW, bsx);
     JT_REQUIRE(sm2 <= 64 * 1024 || !exact, JT_E_UNSUPPORTED, "adeclick: window does not fit the per-wave LDS budget");
     const size_t per_wave = (size_t)P.W * (exact ? dk::XMAXAR : dk::MAXAR) + 3 * (size_t)P.W;
     h->declick_heavy.ensure(2 * (size_t)P.nwindows + 192);
-    if (getenv("JT_DK_PROFILE")) JT_HIP(hipMemsetAsync(h->declick_heavy.p + 2 * P.nwindows, 0, 192 * sizeof(int), s));
+    if (JT_AB_ON(O.dk_profile)) JT_HIP(hipMemsetAsync(h->declick_heavy.p + 2 * P.nwindows, 0, 192 * sizeof(int), s));
 #define DK_LAUNCH(KERN, GRID, SMEM, PP) do { auto k_ = KERN; \
         JT_HIP(hipFuncSetAttribute((const void *)k_, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(SMEM))); \
         hipLaunchKernelGGL(k_, dim3((unsigned)(GRID)), dim3(64), (SMEM), s, in, out, n, PP, h->declick_scr.p, per_wave, d_stats, h->declick_heavy.p); } while (0)
@@ -1631,16 +1632,16 @@ void launch_adeclick(jt_ctx *h, const double *in, double *out, int64_t n, int sa
         JT_REQUIRE(fm2 <= 64 * 1024, JT_E_UNSUPPORTED, "adeclick: window does not fit the per-wave LDS budget");
         int v0 = (int)std::min<size_t>(12, (160 * 1024) / fm0);
         const int v1 = (int)std::min<size_t>(8, (160 * 1024) / fm1), v2 = (int)std::min<size_t>(8, (160 * 1024) / fm2);
-        if (const char *ev = getenv("JT_DK_WAVES")) v0 = std::max(1, std::min(v0, atoi(ev)));
+        if (JT_AB_ON(O.dk_waves > 0)) v0 = std::max(1, std::min(v0, O.dk_waves));
         const int64_t f0 = std::min<int64_t>(P.nwindows, (int64_t)256 * v0), f1 = std::min<int64_t>(P.nwindows, (int64_t)256 * v1),
                       f2 = std::min<int64_t>(P.nwindows, (int64_t)256 * v2);
-        if (getenv("JT_ADECLICK_FUSED")) h->declick_scr.ensure(per_wave * (size_t)std::max(f0, std::max(f1, f2)));
+        if (JT_AB_ON(O.adeclick_fused)) h->declick_scr.ensure(per_wave * (size_t)std::max(f0, std::max(f1, f2)));
         DeclickParams Q0 = P, Q1 = P, Q2 = P; Q0.sa = fa0; Q1.sa = fa1; Q2.sa = fa2;
         DkSplit SP{};
         // Split pipeline (default): the front kernel leaves every window's index list / right-hand side in global memory, two solver
         // launches (bands up to 31 rows: two windows per wave; up to 48: one) factor and substitute with the trailing block in registers.
-        // JT_ADECLICK_FUSED=1 keeps everything in the one kernel of round 2 (A/B, and the reference the split is tested against).
-        const bool fused = getenv("JT_ADECLICK_FUSED") != nullptr;
+        // Option adeclick_fused (JT_AB build) keeps everything in the one kernel of round 2 (A/B, and the reference the split is tested against).
+        const bool fused = JT_AB_ON(O.adeclick_fused);
         if (!fused) {
             constexpr int FCS = LIGHT, G32 = 32, BW32 = 31, G64 = 64, BW64 = 48;
             const int wp = (P.W + 63) & ~63;
@@ -1648,12 +1649,12 @@ void launch_adeclick(jt_ctx *h, const double *in, double *out, int64_t n, int sa
             h->declick_idx.ensure((size_t)P.nwindows * wp); h->declick_rhs.ensure((size_t)P.nwindows * wp);
             h->declick_aux.ensure((size_t)P.nwindows * 56); h->declick_ctl.ensure(288);
             // (r[] and the AR polynomial share one buffer: 64 doubles each per window)
-            const bool lev_split = P.ar == dk::MAXAR && !getenv("JT_DK_LEVINSON_IN_KERNEL");
+            const bool lev_split = P.ar == dk::MAXAR && !JT_AB_ON(O.dk_levinson_in_kernel);
             if (lev_split) h->declick_r.ensure(2 * (size_t)P.nwindows * 64);
             JT_HIP(hipMemsetAsync(h->declick_ctl.p, 0, 288 * sizeof(unsigned long long), s));
             SP.F = h->declick_F.p; SP.index = h->declick_idx.p; SP.rhs = h->declick_rhs.p; SP.aux = h->declick_aux.p;
             SP.list32 = h->declick_lists.p; SP.list64 = h->declick_lists.p + P.nwindows; SP.ctl = h->declick_ctl.p; SP.wp = wp;
-            SP.xcd = getenv("JT_DK_NO_XCD") ? 0 : 1;
+            SP.xcd = JT_AB_ON(O.dk_no_xcd) ? 0 : 1;
             SP.r = lev_split ? h->declick_r.p : nullptr; SP.ac = lev_split ? h->declick_r.p + (size_t)P.nwindows * 64 : nullptr;
             auto slot_bytes = [&](int G, int BW) {
                 const int idxn = (FCS + BW + 16 + G + 7) & ~7, bwn = (FCS + 16 + 7) & ~7, yn = (FCS + BW + 16 + 7) & ~7;
@@ -1687,7 +1688,7 @@ void launch_adeclick(jt_ctx *h, const double *in, double *out, int64_t n, int sa
                     JT_HIP(hipEventCreateWithFlags(&h->dk_ev[0], hipEventDisableTiming));
                     JT_HIP(hipEventCreateWithFlags(&h->dk_ev[1], hipEventDisableTiming));
                 }
-                if (getenv("JT_DK_SERIAL")) {
+                if (JT_AB_ON(O.dk_serial)) {
                     hipLaunchKernelGGL(k64, dim3((unsigned)g64), dim3(64), sm64, s, out, n, P, SP, h->declick_scr.p + slot32 * 2 * (size_t)g32, slot64, d_stats);
                     hipLaunchKernelGGL(k32, dim3((unsigned)g32), dim3(64), sm32, s, out, n, P, SP, h->declick_scr.p, slot32, d_stats);
                 } else {
@@ -1702,7 +1703,7 @@ void launch_adeclick(jt_ctx *h, const double *in, double *out, int64_t n, int sa
             if (half_ok) DKF_LAUNCH((k_adeclick_fast<MID, NC1, ND1, true, 1>), f1, fm1, Q1);
             else DKF_LAUNCH((k_adeclick_fast<MID, NC1, ND1, false, 1>), f1, fm1, Q1);
             DKF_LAUNCH((k_adeclick_fast<dk::MAXW, NC1, ND1, false, 2>), f2, fm2, Q2);
-            if (getenv("JT_DK_PROFILE")) {
+            if (JT_AB_ON(O.dk_profile)) {
                 unsigned long long c[8];
                 JT_HIP(hipStreamSynchronize(s));
                 JT_HIP(hipMemcpy(c, h->declick_ctl.p, sizeof c, hipMemcpyDeviceToHost));
@@ -1711,6 +1712,7 @@ void launch_adeclick(jt_ctx *h, const double *in, double *out, int64_t n, int sa
             }
             return;
         }
+#ifdef JT_AB
         if (half_ok) {
             DKF_LAUNCH((k_adeclick_fast<LIGHT, NC0, ND0, true, 0>), f0, fm0, Q0);
             DKF_LAUNCH((k_adeclick_fast<MID, NC1, ND1, true, 1>), f1, fm1, Q1);
@@ -1719,13 +1721,14 @@ void launch_adeclick(jt_ctx *h, const double *in, double *out, int64_t n, int sa
             DKF_LAUNCH((k_adeclick_fast<MID, NC1, ND1, false, 1>), f1, fm1, Q1);
         }
         DKF_LAUNCH((k_adeclick_fast<dk::MAXW, NC1, ND1, false, 2>), f2, fm2, Q2);
+#endif
         return;
     }
     // resident waves per CU = what LDS admits (10 at the 44.1 kHz defaults).  With the windows handed out dynamically the time
     // falls monotonically with residency on the 60-min workload: 6 -> 33.8 ms, 7 -> 30.7, 8 -> 28.5, 9 -> 27.6
     int w0 = (int)std::min<size_t>(12, (160 * 1024) / sm0);
     const int w1 = (int)std::min<size_t>(8, (160 * 1024) / sm1), w2 = (int)std::min<size_t>(8, (160 * 1024) / sm2);
-    if (const char *ev = getenv("JT_DK_WAVES")) w0 = std::max(1, std::min(w0, atoi(ev)));      // occupancy experiments
+    if (JT_AB_ON(O.dk_waves > 0)) w0 = std::max(1, std::min(w0, O.dk_waves));      // occupancy experiments
     const int64_t g0 = std::min<int64_t>(P.nwindows, (int64_t)256 * w0), g1 = std::min<int64_t>(P.nwindows, (int64_t)256 * w1),
                   g2 = std::min<int64_t>(P.nwindows, (int64_t)256 * w2);
     h->declick_scr.ensure(per_wave * (size_t)std::max(g0, std::max(g1, g2)));

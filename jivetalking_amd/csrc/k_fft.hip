@@ -1152,7 +1152,7 @@ static void launch_afftdn_n(unsigned grid, size_t smem, int mode, const float *i
 #undef AF_GO
 }
 
-void launch_afftdn(const float *in, float *out, int64_t n, const AfftdnDev &d, int frames_per_chunk, int warm_frames, hipStream_t s, int mode)
+void launch_afftdn(const float *in, float *out, int64_t n, const AfftdnDev &d, int frames_per_chunk, int warm_frames, hipStream_t s, const JtOpts &o, int mode)
 {
     if (n <= 0) return;
     JT_REQUIRE(d.nbands <= AF_MAXBANDS, JT_E_UNSUPPORTED, "afftdn: too many bark bands");
@@ -1164,7 +1164,7 @@ void launch_afftdn(const float *in, float *out, int64_t n, const AfftdnDev &d, i
         frames_per_chunk = (int)std::min<int64_t>(1024, std::max<int64_t>(128, (nframes + 511) / 512));
     }
     unsigned grid = (unsigned)((nframes + frames_per_chunk - 1) / frames_per_chunk);
-    if ((d.L == 2048 || d.L == 4096) && d.W <= d.L && !getenv("JT_AFFTDN_OLD")) {
+    if ((d.L == 2048 || d.L == 4096) && d.W <= d.L && !JT_AB_ON(o.afftdn_old)) {
         // several frames at a time, one wave per frame's transforms (k_afftdn_grp): one workgroup per CU (132 KB of LDS with eight
         // 2048-point frames, 150 KB with four 4096-point frames), so one resident round is 256 chunks
         const bool big = d.L == 4096;
@@ -1193,8 +1193,12 @@ void launch_afftdn(const float *in, float *out, int64_t n, const AfftdnDev &d, i
     size_t smem = sizeof(float2) * 3 * H + sizeof(double) * (((d.W + 1) & ~1) + nseg * AF_MAXBANDS + (size_t)d.nbands * d.nbands + 4 * AF_MAXBANDS)
                 + sizeof(int) * (nseg + 1 + 2 * AF_MAXBANDS);
     JT_REQUIRE(smem <= 160 * 1024, JT_E_UNSUPPORTED, "afftdn: window too long for this build");
+    // (the frame-at-a-time kernel serves the 1024-point window; its 2048 / 4096-point instances are superseded by k_afftdn_grp: JT_AB build)
+#ifdef JT_AB
     if (d.L == 2048) launch_afftdn_n<11>(grid, smem, mode, in, out, n, d, frames_per_chunk, warm_frames, nframes, s);
     else if (d.L == 4096) launch_afftdn_n<12>(grid, smem, mode, in, out, n, d, frames_per_chunk, warm_frames, nframes, s);
-    else if (d.L == 1024) launch_afftdn_n<10>(grid, smem, mode, in, out, n, d, frames_per_chunk, warm_frames, nframes, s);
+    else
+#endif
+    if (d.L == 1024) launch_afftdn_n<10>(grid, smem, mode, in, out, n, d, frames_per_chunk, warm_frames, nframes, s);
     else throw JtError{JT_E_UNSUPPORTED, "afftdn: unsupported FFT length"};
 }

@@ -661,12 +661,18 @@ static void kweight_enqueue(jt_ctx *h, const TIn *in, int64_t n, int rate, int b
     double *d_zs = base, *d_pw = base + 4 * (size_t)nchunks, *d_cs = d_pw + 24 * 16, *d_cross = d_cs + 2 * (size_t)nchunks;
     if (npw) JT_HIP(hipMemcpyAsync(d_pw, pw, sizeof(double) * 16 * npw, hipMemcpyHostToDevice, st));
     const unsigned grid = (unsigned)((nchunks + LANES - 1) / LANES);
-    const bool two_sweeps = getenv("JT_KW_TWO_SWEEPS") != nullptr;
+#ifdef JT_AB
+    const bool two_sweeps = h->opts.kw_two_sweeps;
+#else
+    constexpr bool two_sweeps = false;
+#endif
     if (two_sweeps) {
+#ifdef JT_AB
         hipLaunchKernelGGL((k_kw<TIn, false>), dim3(grid), dim3(LANES), 0, st, in, n, L, k, (const double *)nullptr, (const double *)nullptr, 0,
                            d_zs, (double *)nullptr, (double *)nullptr, nchunks);
         hipLaunchKernelGGL((k_kw<TIn, true>), dim3(grid), dim3(LANES), 0, st, in, n, L, k, d_zs, d_pw, nterms,
                            (double *)nullptr, d_cs, d_cs + nchunks, nchunks);
+#endif
     } else {
         // homogeneous-response table of this (rate, L): g[j][k] = output at step j from the k-th unit state, no input (same statements as
         // KW2_STEP); cached on the handle
@@ -674,6 +680,9 @@ static void kweight_enqueue(jt_ctx *h, const TIn *in, int64_t n, int rate, int b
         for (auto &t : h->kw_tab) if (t.rate == rate && t.L == L) T = &t;
         if (!T) {
             T = &h->kw_tab[h->kw_tab_next++ % 8];
+            // an evicted slot's table may still be read by a sweep in flight on another stream of this handle (more than eight (rate, chunk
+            // length) pairs on one pooled handle): the old buffer is parked, never overwritten
+            T->dev.retire();
             T->rate = rate; T->L = L; T->g.assign((size_t)4 * L, 0.0);
             for (int u = 0; u < 4; ++u) {
                 double s1 = u == 0, s2 = u == 1, t1 = u == 2, t2 = u == 3;
@@ -1028,7 +1037,7 @@ k_deesser(const TIn *__restrict__ in, float *__restrict__ out, int64_t n, int64_
 }
 
 template <typename TIn>
-static void run_follow(const TIn *in, int64_t n, double att, double rel, double *states, hipStream_t s, bool in_has_slack)
+static void run_follow(const TIn *in, int64_t n, double att, double rel, double *states, hipStream_t s, bool in_has_slack, const JtOpts &o)
 {
     double rho = std::min(att, rel);
     int64_t halo = 4096;
@@ -1039,7 +1048,7 @@ static void run_follow(const TIn *in, int64_t n, double att, double rel, double 
     // (0.5 ms of each launch); the rest is the 9x re-read of the signal, 6.2 GB (f32) / 12.4 GB (f64) at ~4.5 TB/s -- the file
     // is larger than the Infinity Cache, so the re-reads come from HBM.  Longer chunks (fewer re-reads) leave too few waves to
     // cover the load latency with two tiles in flight and lose more than they save.
-    if (in_has_slack && (reinterpret_cast<uintptr_t>(in) & 15) == 0 && !getenv("JT_FOLLOW_TILES")) {
+    if (in_has_slack && (reinterpret_cast<uintptr_t>(in) & 15) == 0 && !JT_AB_ON(o.follow_tiles)) {
         // LDS-streamed variant: chunks of a quarter halo (5x instead of 9x re-read; 250 waves for an hour of audio).  The vmcnt
         // counter (63) caps a wave at 48 KB in flight, about one HBM round trip of the f32 follower's appetite and half of the f64
         // one's, so longer chunks (fewer waves) start waiting for memory again: halo/2 and halo measured 1-2 ms worse.
@@ -1058,7 +1067,7 @@ static void run_follow(const TIn *in, int64_t n, double att, double rel, double 
 
 // scratch: states[(n/SC)+2] doubles, tmp64[n] doubles (gate output feeding the compressor), tmp64b[n] when the de-esser runs
 void launch_dynamics(const float *in, float *out_f32, double *tmp64, double *tmp64b, double *states, int64_t n, const DynParams &d, hipStream_t s,
-                     bool in_has_slack)
+                     const JtOpts &o, bool in_has_slack)
 {
     if (n <= 0) return;
     const int64_t nsub = (n + SC - 1) / SC;
@@ -1067,13 +1076,13 @@ void launch_dynamics(const float *in, float *out_f32, double *tmp64, double *tmp
     // stage outputs: gate -> tmp64 (if anything follows) ; comp -> tmp64b (if deesser follows) else f32 out
     const double *cur64 = nullptr; bool have64 = false;
     if (d.gate_on) {
-        run_follow<float>(in, n, d.g_attack, d.g_release, states, s, in_has_slack);
+        run_follow<float>(in, n, d.g_attack, d.g_release, states, s, in_has_slack, o);
         if (d.comp_on || de) { hipLaunchKernelGGL((k_dyn_apply<0, float, double>), dim3(agrid), dim3(LANES), 0, s, in, tmp64, n, states, d, nsub); cur64 = tmp64; have64 = true; }
         else { hipLaunchKernelGGL((k_dyn_apply<0, float, float>), dim3(agrid), dim3(LANES), 0, s, in, out_f32, n, states, d, nsub); return; }
     }
     if (d.comp_on) {
-        if (have64) run_follow<double>(cur64, n, d.c_attack, d.c_release, states, s, in_has_slack);      // (tmp64 is allocated with the same slack)
-        else run_follow<float>(in, n, d.c_attack, d.c_release, states, s, in_has_slack);
+        if (have64) run_follow<double>(cur64, n, d.c_attack, d.c_release, states, s, in_has_slack, o);      // (tmp64 is allocated with the same slack)
+        else run_follow<float>(in, n, d.c_attack, d.c_release, states, s, in_has_slack, o);
         if (de) {
             if (have64) hipLaunchKernelGGL((k_dyn_apply<1, double, double>), dim3(agrid), dim3(LANES), 0, s, cur64, tmp64b, n, states, d, nsub);
             else hipLaunchKernelGGL((k_dyn_apply<1, float, double>), dim3(agrid), dim3(LANES), 0, s, in, tmp64b, n, states, d, nsub);
@@ -1090,7 +1099,7 @@ void launch_dynamics(const float *in, float *out_f32, double *tmp64, double *tmp
         // 3072: 8.0, 2048 (1320 waves, 9x redundant): 15.0.  The halo is what exactness needs (tools/deess_halo.py: against a halo of 262144,
         // 16384 is bit-identical on speech, gated hiss, an 8 kHz tone and full-scale noise at every intensity; 8192 is off by one f32 ulp on
         // full-scale noise at intensity 0.2, 4096 by 1e-5)
-        const int64_t halo = getenv("JT_DEESS_HALO") ? atoll(getenv("JT_DEESS_HALO")) : 16384, chunk = getenv("JT_DEESS_CHUNK") ? atoll(getenv("JT_DEESS_CHUNK")) : 3072;
+        const int64_t halo = JT_AB_ON(o.deess_halo > 0) ? o.deess_halo : 16384, chunk = JT_AB_ON(o.deess_chunk > 0) ? o.deess_chunk : 3072;
         const int64_t nchunks = (n + chunk - 1) / chunk;
         const unsigned g = (unsigned)((nchunks + LANES - 1) / LANES);
         if (have64) hipLaunchKernelGGL((k_deesser<double>), dim3(g), dim3(LANES), 0, s, cur64, out_f32, n, chunk, halo, d, nchunks);

@@ -864,23 +864,26 @@ void launch_swr_plain_f64(const double *in, int64_t n, const double *bank, int P
     if (m_total > 0) hipLaunchKernelGGL(k_swr_plain_f64, dim3((unsigned)((m_total + 255) / 256)), dim3(256), 0, s, in, n, bank, P, L, center, step, m_total, out);
 }
 void launch_loudnorm_dynamic(const double *x, int64_t n, const LoudnormDynParams &P, const double *series, double *ring, double *y, double *dbg, hipStream_t s,
-                             double *carry)
+                             double *carry, const JtOpts &o)
 {
-    if (!getenv("JT_DYN_ONE_WAVE")) {
+    (void)o;
+    if (!JT_AB_ON(o.dyn_one_wave)) {
         // eight waves, the limiter's window in LDS (159 KB: the workgroup has its CU to itself); LN_STEPS steps of the file per launch
         const int smem = LN_CACHE * (int)sizeof(double);
-        (void)hipFuncSetAttribute((const void *)k_loudnorm_dynamic_wg, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+        JT_HIP(hipFuncSetAttribute((const void *)k_loudnorm_dynamic_wg, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
         const int64_t total = 1 + P.n_inner + P.final_len / LN_F100;
-        static const int64_t steps = getenv("JT_DYN_STEPS") ? std::max(1, atoi(getenv("JT_DYN_STEPS"))) : 64;
+        const int64_t steps = JT_AB_ON(o.dyn_steps > 0) ? o.dyn_steps : 64;
         for (int64_t it = 0; it < total; it += steps)
             hipLaunchKernelGGL(k_loudnorm_dynamic_wg, dim3(1), dim3(LN_WG), smem, s, x, n, P, series, ring, y, dbg, carry, it, std::min(total, it + steps));
         return;
     }
     // 96 KB of (unused) dynamic LDS: the workgroup then has a CU to itself.  Several files in flight each run one such wave, and the
     // dispatcher packed them onto the first CU with room -- the same SIMDs -- where each ran 1.5x slower than alone.
-    static const int reserve = getenv("JT_DYN_NO_CU_RESERVE") ? 0 : 96 * 1024;
-    if (reserve) (void)hipFuncSetAttribute((const void *)k_loudnorm_dynamic, hipFuncAttributeMaxDynamicSharedMemorySize, reserve);
+#ifdef JT_AB
+    const int reserve = o.dyn_no_cu_reserve ? 0 : 96 * 1024;
+    if (reserve) JT_HIP(hipFuncSetAttribute((const void *)k_loudnorm_dynamic, hipFuncAttributeMaxDynamicSharedMemorySize, reserve));
     hipLaunchKernelGGL(k_loudnorm_dynamic, dim3(1), dim3(64), reserve, s, x, n, P, series, ring, y, dbg);
+#endif
 }
 void launch_scale_f64(const double *in, double *out, int64_t n, double g, hipStream_t s)
 {

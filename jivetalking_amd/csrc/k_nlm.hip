@@ -681,7 +681,7 @@ __global__ void k_anlmdn(const float *__restrict__ in, float *__restrict__ out, 
     }
 }
 
-void launch_anlmdn(const float *in, float *out, int64_t n, int K, int S, float sw, float smooth, float lut_scale, hipStream_t s)
+void launch_anlmdn(const float *in, float *out, int64_t n, int K, int S, float sw, float smooth, float lut_scale, hipStream_t s, const JtOpts &o)
 {
     if (n <= 0) return;
     const int H = 2 * K + 1;
@@ -690,12 +690,12 @@ void launch_anlmdn(const float *in, float *out, int64_t n, int K, int S, float s
     // 64 lanes x 3 adjacent offsets (radius up to 96: the 44.1 / 48 kHz defaults) or x 6 (up to 192: 88.2 / 96 kHz); a radius below the
     // layout's leaves dummy offsets at both ends, any patch length of 8 or more
     const int Sl = S <= 96 ? 96 : (S <= 192 ? 192 : 0);
-    if (Sl && K >= 8 && !getenv("JT_NLM_GENERIC")) {
+    if (Sl && K >= 8 && !o.nlm_generic) {
         const int NWl = H + 2 * (K + Sl);
         size_t smem = sizeof(float) * 2 * (size_t)(NLM_PADF + NWl + NLM_PADB);      // interleaved {hop A, hop B} window
         const unsigned grid = (unsigned)((nhops + 1) / 2);
         const bool exact_layout = 2 * S == 2 * Sl;
-        if (!(exact_layout && K % 4 == 0 && getenv("JT_NLM_OLD"))) {              // (JT_NLM_OLD: the round-1 kernel, A/B only)
+        if (!(exact_layout && K % 4 == 0 && JT_AB_ON(o.nlm_old))) {               // (nlm_old: the round-1 kernel, JT_AB build only)
             smem += sizeof(float) * 2 * (size_t)(12 * NLM3_CB + NLM3_CB + 1);
             JT_REQUIRE(smem <= 64 * 1024, JT_E_UNSUPPORTED, "anlmdn: window exceeds the wave-per-hop LDS budget");
             if (Sl == 96) hipLaunchKernelGGL((k_anlmdn_pair3<3>), dim3(grid), dim3(64), smem, s, in, out, n, K, S, sw, smooth, lut_scale);
@@ -712,9 +712,11 @@ void launch_anlmdn(const float *in, float *out, int64_t n, int K, int S, float s
             }
 #endif
         } else {
+#ifdef JT_AB
             JT_REQUIRE(smem <= 64 * 1024, JT_E_UNSUPPORTED, "anlmdn: window exceeds the wave-per-hop LDS budget");
             if (2 * S == 192) hipLaunchKernelGGL((k_anlmdn_pair<3>), dim3(grid), dim3(64), smem, s, in, out, n, K, S, sw, smooth, lut_scale, nhops);
             else hipLaunchKernelGGL((k_anlmdn_pair<6>), dim3(grid), dim3(64), smem, s, in, out, n, K, S, sw, smooth, lut_scale, nhops);
+#endif
         }
         return;
     }

@@ -477,8 +477,9 @@ k_upsample32_stream8(const TIn *__restrict__ in, int64_t n, const TTap *__restri
 
 template <typename TIn, typename TAcc, typename TTap, int MODE>
 static bool launch_upsample32(const TIn *in, int64_t n, const TTap *bank, int P, int L, int center, int64_t step, int64_t m_total,
-                              double in_scale, int blk, double *block_tp, int64_t nblocks_alloc, TAcc *out, hipStream_t s)
+                              double in_scale, int blk, double *block_tp, int64_t nblocks_alloc, TAcc *out, hipStream_t s, const JtOpts *o = nullptr)
 {
+    (void)o;
     if (L != 32 || step >= P || step > 512) return false;
     const int ql = step == 1 ? 4 : 1;
     int R = (int)std::max<int64_t>(1, 4096 / (64 * ql * step));
@@ -486,10 +487,10 @@ static bool launch_upsample32(const TIn *in, int64_t n, const TTap *bank, int P,
     if (MODE == 2 && ql == 1 && (P & 15) == 0 && R == 1)
         for (int r = 2; r > 1; r >>= 1) if (sizeof(TIn) * (size_t)(64 * r * step + 64) <= 80 * 1024) { R = r; break; }
     if constexpr (MODE == 2) {
-        if (ql == 1 && R == 1 && (P & 31) == 0 && (step & 1) && !getenv("JT_UPS_NO_STREAM8")) {
+        if (ql == 1 && R == 1 && (P & 31) == 0 && (step & 1) && !JT_AB_ON(o && o->ups_no_stream8)) {
             const size_t tile8 = (sizeof(TIn) * (size_t)(64 * step + 32 + 4) + 15) & ~(size_t)15;
             const size_t sm16 = tile8 + sizeof(TAcc) * (size_t)16 * 64 * 9;
-            if ((P % 64) == 0 && sm16 <= 150 * 1024 && !getenv("JT_UPS_NO_STREAM16")) {
+            if ((P % 64) == 0 && sm16 <= 150 * 1024 && !JT_AB_ON(o && o->ups_no_stream16)) {
                 auto k16 = k_upsample32_stream8<TIn, TAcc, TTap, 16, 8>;
                 JT_HIP(hipFuncSetAttribute((const void *)k16, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm16));
                 const int64_t pb = (int64_t)64 * P;
@@ -684,7 +685,7 @@ k_polyphase_edge_s16(const float *__restrict__ in, int64_t n, const double *__re
 }
 
 void launch_resample_to_s16(const float *in, int64_t n, const double *bank, int phase_count, int filter_length, int center,
-                            int64_t step, int16_t *out, int64_t m, hipStream_t s)
+                            int64_t step, int16_t *out, int64_t m, hipStream_t s, const JtOpts &o)
 {
     if (m <= 0) return;
     PPGeom g = pp_geometry<float>(n, phase_count, filter_length, step, m, true);
@@ -702,7 +703,7 @@ void launch_resample_to_s16(const float *in, int64_t n, const double *bank, int 
     }
     // the few edge blocks first (the two kernels write disjoint outputs): one wave per block and phase beside k_down147's interior;
     // other geometries keep k_polyphase for every block
-    if (fast && b_hi > b_lo && g.R == 1 && !getenv("JT_EDGE_POLYPHASE")) {
+    if (fast && b_hi > b_lo && g.R == 1 && !JT_AB_ON(o.edge_polyphase)) {
         const int64_t nedge = g.grid - (b_hi - b_lo);
         if (nedge > 0) hipLaunchKernelGGL(k_polyphase_edge_s16, dim3((unsigned)(nedge * phase_count)), dim3(64), 0, s, in, n, bank, phase_count,
                                           filter_length, center, step, m, b_lo, b_hi - b_lo, out);
@@ -758,11 +759,11 @@ void launch_resample_stream_s16_f32(const int16_t *in, int64_t n, const float *b
                        g.R, 1.0 / 32768.0, 1, (unsigned long long *)nullptr, (int64_t)0, (int16_t *)nullptr, out, 0, PPRemap{0, 0, 0});
 }
 void launch_resample_stream_f64(const double *in, int64_t n, const double *bank, int phase_count, int filter_length, int center,
-                                int64_t step, int64_t m_total, double *out, hipStream_t s)
+                                int64_t step, int64_t m_total, double *out, hipStream_t s, const JtOpts &o)
 {
     if (m_total <= 0) return;
     if (launch_upsample32<double, double, double, 2>(in, n, bank, phase_count, filter_length, center, step, m_total, 1.0, 1,
-                                                    (double *)nullptr, (int64_t)0, out, s)) return;
+                                                    (double *)nullptr, (int64_t)0, out, s, &o)) return;
     PPGeom g = pp_geometry<double>(n, phase_count, filter_length, step, m_total, false);
     auto k = k_polyphase<double, double, double, 2>;
     JT_HIP(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)g.smem));

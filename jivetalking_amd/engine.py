@@ -46,13 +46,27 @@ def _flac_info(info):
 
 
 class Engine:
-    def __init__(self, device=0):
-        self.lib = L.load()
+    def __init__(self, device=0, ab=None, **options):
+        """ab=True: the A/B build of the library (superseded kernel generations, tuning knobs; it also imports JT_<KEY> variables at
+        jt_open, which is how tools/ switch kernels: JT_USE_AB_LIB=1 JT_NLM_OLD=1 python tools/...).  options: jt_set_option pairs."""
+        if ab is None:
+            import os
+            ab = bool(os.environ.get("JT_USE_AB_LIB"))
+        self.lib = L.load(ab)
+        self.ab = bool(ab)
         self.h = C.c_void_p()
         rc = self.lib.jt_open(C.c_int(device), C.byref(self.h))
         if rc != 0:
             raise L.JtError(rc, "jt_open failed (no MI355X visible?)")
         self._keep = None
+        for k, v in options.items():
+            self.set_option(k, v)
+
+    def set_option(self, key, value=True):
+        """jt_set_option: the switches that used to be JT_* environment variables (include/jtgpu.h lists the keys)."""
+        if isinstance(value, bool):
+            value = "1" if value else "0"
+        self._ck(self.lib.jt_set_option(self.h, str(key).encode(), str(value).encode()))
 
     def close(self):
         if self.h:

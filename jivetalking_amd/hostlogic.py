@@ -114,14 +114,17 @@ HOST_SYMBOLS = ["jt_host_build_intervals", "jt_host_detect", "jt_host_finish_mea
                 "jt_host_vad_gap_tolerance", "jt_host_vad_gate_stats", "jt_host_vad_noise_seed",
                 "jt_host_vad_pick_low_cluster", "jt_host_vad_floored_fraction", "jt_host_sizeof",
                 "jt_host_lufs_filename_value", "jt_host_output_path", "jt_process_audio_cb", "jt_process_file", "jt_process_files",
-                "jt_host_test_inject_fault", "jt_process_files_multi",
+                "jt_host_test_inject_fault", "jt_process_files_multi", "jt_handle_pool_open", "jt_handle_pool_workers", "jt_handle_pool_process_files", "jt_handle_pool_close",
                 "jt_host_score_speech_candidate", "jt_host_level_variance", "jt_host_find_best_speech_region", "jt_host_frame_level_s16", "jt_process_audio_ticks",
                 "jt_host_run_record_json", "jt_host_intervals_jsonl", "jt_host_last_intervals", "jt_host_candidates_jsonl", "jt_host_intervals_in_range",
                 "jt_host_score_interval_window", "jt_host_score_speech_interval_window", "jt_host_measure_speech_candidate", "jt_host_refine_golden_speech", "jt_host_loudnorm_json"]
 
 
-def lib():
-    l = L.load()
+def lib(engine=None):
+    """The library an engine was opened on (default or A/B build), with the host entry points' return types set; the default build otherwise."""
+    l = engine.lib if engine is not None else L.load()
+    if getattr(l, "_jt_host_ready", False):
+        return l
     l.jt_host_sizeof.restype = C.c_int64
     l.jt_host_build_intervals.restype = C.c_int64
     l.jt_host_loudnorm_internal_target_tp.restype = C.c_double
@@ -148,6 +151,8 @@ def lib():
     l.jt_host_intervals_in_range.restype = C.c_int64
     l.jt_host_score_interval_window.restype = C.c_double
     l.jt_host_score_speech_interval_window.restype = C.c_double
+    l.jt_handle_pool_close.restype = None
+    l._jt_host_ready = True
     return l
 
 
@@ -186,7 +191,7 @@ def make_intervals(rows):
 
 def process_audio(engine, base=None, frame_samples=4096, analyse_only=False):
     """jt_process_audio / jt_analyse_only on the PCM already uploaded to `engine`."""
-    l = lib()
+    l = lib(engine)
     base = base or default_config()
     res = ProcessResult()
     fn = l.jt_analyse_only if analyse_only else l.jt_process_audio
@@ -208,7 +213,7 @@ PROGRESS_FN = C.CFUNCTYPE(None, C.c_void_p, C.POINTER(ProgressUpdate))
 def process_audio_with_progress(engine, on_update, base=None, frame_samples=4096, ticks=False):
     """jt_process_audio_cb: `on_update(ProgressUpdate)` is called synchronously at every pass start / end; ticks=True
     (jt_process_audio_ticks) adds the reference's every-100-frames and band ticks."""
-    l = lib()
+    l = lib(engine)
     base = base or default_config()
     res = ProcessResult()
     fn = PROGRESS_FN(lambda user, u: on_update(u.contents))
@@ -220,7 +225,7 @@ def process_audio_with_progress(engine, on_update, base=None, frame_samples=4096
 
 def process_file(engine, input_path, base=None, frame_samples=4096, md5=True):
     """jt_process_file: file in (FLAC / WAV), "<name>-LUFS-<n>-processed.flac" out.  Returns (result, output path, io_ms)."""
-    l = lib()
+    l = lib(engine)
     base = base or default_config()
     res = ProcessResult(); out = C.create_string_buffer(4096); io = (C.c_double * 4)()
     rc = l.jt_process_file(engine.h, str(input_path).encode(), C.byref(base), C.c_int(frame_samples), C.c_int(1 if md5 else 0),
@@ -264,6 +269,47 @@ def process_files_multi(paths, devices=(0,), in_flight_per_device=2, base=None, 
     return failed, res, list(dev)
 
 
+class Pool:
+    """jt_handle_pool_*: handles opened once, reused by every batch (jt_process_files_multi opens and closes a pool per call)."""
+
+    def __init__(self, devices=(0,), in_flight_per_device=2, max_workers=0, ab=False):
+        self.lib = lib() if not ab else lib(type("E", (), {"lib": L.load(ab=True)})())
+        self.p = C.c_void_p()
+        dv = (C.c_int * len(devices))(*devices)
+        rc = self.lib.jt_handle_pool_open(dv, C.c_int(len(devices)), C.c_int(in_flight_per_device), C.c_int(max_workers), C.byref(self.p))
+        if rc != 0:
+            raise L.JtError(rc, "jt_handle_pool_open: bad arguments")
+
+    def workers(self):
+        """The device of every open handle (sorted by device); empty when no device could be opened."""
+        cap = 4096
+        dv = (C.c_int * cap)()
+        n = self.lib.jt_handle_pool_workers(self.p, dv, C.c_int(cap))
+        return [int(dv[i]) for i in range(min(n, cap))]
+
+    def process_files(self, paths, base=None, frame_samples=4096, md5=True):
+        """Returns (failed, results, device_of_file) like process_files_multi."""
+        base = base or default_config()
+        n = len(paths)
+        arr = (C.c_char_p * n)(*[str(p).encode() for p in paths])
+        res = (FileResult * n)(); dev = (C.c_int * n)()
+        failed = self.lib.jt_handle_pool_process_files(self.p, arr, C.c_int(n), C.byref(base), C.c_int(frame_samples), C.c_int(1 if md5 else 0), res, dev)
+        if failed < 0:
+            raise L.JtError(failed, "jt_handle_pool_process_files: bad arguments")
+        return failed, res, list(dev)
+
+    def close(self):
+        if self.p:
+            self.lib.jt_handle_pool_close(self.p)
+            self.p = C.c_void_p()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+
 SIZEOF_IDS[14] = FileResult
 
 
@@ -303,11 +349,11 @@ def run_record_json(engine, res, input_file="", version="dev", executable="", pr
     """jt_host_run_record_json: the reference's RunRecord document (runrecord.go) as text."""
     enc = lambda v: v if isinstance(v, bytes) else v.encode()
     pv = RunProvenance(enc(input_file), version.encode(), executable.encode(), processed_at.encode(), duration_s, sample_rate_hz, channels)
-    return _sized(lambda b, c: lib().jt_host_run_record_json(engine.h if engine else None, C.byref(res), C.byref(pv), C.c_int(int(analysis_only)), b, C.c_int64(c)))
+    return _sized(lambda b, c: lib(engine).jt_host_run_record_json(engine.h if engine else None, C.byref(res), C.byref(pv), C.c_int(int(analysis_only)), b, C.c_int64(c)))
 
 
 def intervals_jsonl(engine):
-    return _sized(lambda b, c: lib().jt_host_intervals_jsonl(engine.h, b, C.c_int64(c)))
+    return _sized(lambda b, c: lib(engine).jt_host_intervals_jsonl(engine.h, b, C.c_int64(c)))
 
 
 def candidates_jsonl(res):

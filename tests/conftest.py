@@ -44,3 +44,31 @@ def engine():
     e = Engine(0)
     yield e
     e.close()
+
+
+@pytest.fixture(scope="session")
+def engine_ab():
+    """A handle on the A/B build of the library (libjtgpu_ab.so, `make ab`): the superseded kernel generations and tuning knobs the
+    default build does not contain, for the tests that hold the current kernels against the ones they replaced."""
+    from jivetalking_amd import Engine
+    e = Engine(0, ab=True)
+    yield e
+    e.close()
+
+
+import contextlib
+
+# what jt_set_option's keys fall back to
+_OPTION_DEFAULTS = {"region_rot": "-1"}
+
+
+@contextlib.contextmanager
+def options(engine, **kv):
+    """jt_set_option for the length of a with-block (the switches that used to be JT_* environment variables), restored afterwards."""
+    try:
+        for k, v in kv.items():
+            engine.set_option(k, v)
+        yield engine
+    finally:
+        for k in kv:
+            engine.set_option(k, _OPTION_DEFAULTS.get(k, "0"))

@@ -217,18 +217,14 @@ def test_alimiter_never_triggered_is_identity(engine, oracle):
 # autocorrelation, register-blocked detector, fused multiply-adds, reciprocal pivots): its bar is stated here -- identical detection
 # decisions (flips counted, none allowed on these signals) and |difference| <= 1e-9 on every sample (signals of order 1; the
 # difference is rounding of the AR fit amplified by the conditioning of the interpolation system, measured ~1e-12).
-# JT_ADECLICK_EXACT=1 selects the sequential-order kernel, which stays bit-identical to the oracle.
+# The option adeclick_exact (jt_set_option) selects the sequential-order kernel, which stays bit-identical to the oracle.
 import contextlib
 import os
+from conftest import options
 
 
-@contextlib.contextmanager
-def exact_adeclick():
-    os.environ["JT_ADECLICK_EXACT"] = "1"
-    try:
-        yield
-    finally:
-        del os.environ["JT_ADECLICK_EXACT"]
+def exact_adeclick(engine):
+    return options(engine, adeclick_exact=True)
 
 
 def declick_close(got, ref, x, tol=1e-9):
@@ -248,7 +244,7 @@ def test_adeclick_matches_oracle_speech(engine, oracle):
     assert ngot == nref                                             # identical detection decisions
     flips, err = declick_close(got, ref, x)
     print(f"adeclick fast kernel vs oracle: {nref} repaired samples, {flips} flips, max abs error {err:.3g}")
-    with exact_adeclick():
+    with exact_adeclick(engine):
         got, ngot = engine.op_adeclick(x, 44100, 1.7, 55.0, 50.0, method="s", return_count=True)
     assert ngot == nref and np.array_equal(got, ref)                # identical sums, identical order: bit-exact
     # reproducible: the LDS floating-point atomics of the autocorrelation are served in a fixed order
@@ -263,7 +259,7 @@ def test_adeclick_click_on_tone_and_edges(engine, oracle, exact):
     x = 0.3 * np.sin(2 * np.pi * 220 * t)
     x[20000] += 0.5; x[20001] -= 0.4; x[33333] += 0.25             # clicks, one of them a 2-sample burst
     same = (lambda g, r, xx: np.array_equal(g, r)) if exact else (lambda g, r, xx: declick_close(g, r, xx) is not None)
-    with (exact_adeclick() if exact else contextlib.nullcontext()):
+    with (exact_adeclick(engine) if exact else contextlib.nullcontext()):
         ref = oracle.adeclick(x, sr)
         got = engine.op_adeclick(x, sr)
         assert same(got, ref, x)
@@ -279,7 +275,7 @@ def test_adeclick_click_on_tone_and_edges(engine, oracle, exact):
 def test_adeclick_other_thresholds_and_rates(engine, oracle, exact):
     x = (speech(3.0, 12, 48000) * 2.0).astype(np.float64)
     same = (lambda g, r, xx: np.array_equal(g, r)) if exact else (lambda g, r, xx: declick_close(g, r, xx) is not None)
-    with (exact_adeclick() if exact else contextlib.nullcontext()):
+    with (exact_adeclick(engine) if exact else contextlib.nullcontext()):
         for thr in (2.0, 4.0):                                           # w=50 ms at 48 kHz: AR order 48, the largest this build lays out
             assert same(engine.op_adeclick(x, 48000, thr, 50.0, 50.0), oracle.adeclick(x, 48000, thr, 50.0, 50.0), x)
         assert same(engine.op_adeclick(x, 48000, 1.7, 40.0, 75.0), oracle.adeclick(x, 48000, 1.7, 40.0, 75.0), x)

@@ -5,6 +5,7 @@ import numpy as np
 import pytest
 
 from jivetalking_amd import synth, hostlogic as H, _lib as L
+from conftest import options
 
 pytestmark = pytest.mark.gpu
 SR = 48000
@@ -294,7 +295,7 @@ def test_announced_regions_without_a_rate_change_and_empty_regions(engine):
         engine.region_prefetch(3, st, du)                                # only stages 2 and 4 have outputs
 
 
-def test_early_pass3_measurement_equals_the_explicit_one(engine, monkeypatch):
+def test_early_pass3_measurement_equals_the_explicit_one(engine):
     """Pass 2 queues Pass 3's no-prefix measurement of its output on a stream of its own; jt_pass3 collects it.  Same kernels on
     the same samples: the statistics must equal an explicit measurement bit for bit, a plan WITH a limiter prefix must not use
     it, and replacing the Pass-2 output (jt_upload_s16) must discard it."""
@@ -306,10 +307,9 @@ def test_early_pass3_measurement_equals_the_explicit_one(engine, monkeypatch):
     engine.pass2(p)
     early = engine.pass3()                                           # collected from the job Pass 2 started
     again = engine.pass3()                                           # nothing pending any more: measured on demand
-    monkeypatch.setenv("JT_NO_EARLY_PASS3", "1")
-    engine.pass2(p)
-    explicit = engine.pass3()
-    monkeypatch.delenv("JT_NO_EARLY_PASS3")
+    with options(engine, no_early_pass3=True):
+        engine.pass2(p)
+        explicit = engine.pass3()
     for k in keys:
         assert early[k] == explicit[k] == again[k], k
     # a plan with a limiter prefix measures the limited stream, with or without a pending early job
@@ -327,7 +327,7 @@ def test_early_pass3_measurement_equals_the_explicit_one(engine, monkeypatch):
     assert all(halved[k] == ref[k] for k in keys) and halved["input_i"] < early["input_i"] - 5.0
 
 
-def test_pass2_head_prefetch_changes_nothing_but_the_schedule(engine, monkeypatch):
+def test_pass2_head_prefetch_changes_nothing_but_the_schedule(engine):
     """jt_pass2_prefetch runs the biquad cascade and anlmdn early, on another stream.  Pass 2 must produce the same samples and the
     same analysis whether it continues from that head, finds it stale (different parameters) or never had one; calls that use the
     work buffers in between retire it."""
@@ -360,33 +360,33 @@ def test_pass2_head_prefetch_changes_nothing_but_the_schedule(engine, monkeypatc
     assert np.array_equal(o0, o4) and a4["r128"]["integrated"] == a0["r128"]["integrated"]
     # the orchestration: with and without the early head (and the early Pass-3 measurement) the run is the same run
     r_on = H.process_audio(engine); out_on = engine.download_s16(4).copy()
-    monkeypatch.setenv("JT_NO_PASS2_PREFETCH", "1"); monkeypatch.setenv("JT_NO_EARLY_PASS3", "1")
-    r_off = H.process_audio(engine); out_off = engine.download_s16(4)
+    with options(engine, no_pass2_prefetch=True, no_early_pass3=True):
+        r_off = H.process_audio(engine); out_off = engine.download_s16(4)
     assert np.array_equal(out_on, out_off) and r_on.output_lufs == r_off.output_lufs and r_on.pass2_spec == r_off.pass2_spec
 
 
-def test_lds_streamed_followers_match_the_tile_staged_ones(engine, monkeypatch):
-    """k_follow_states_lds (direct-to-LDS loads, longer chunks) against k_follow_states (JT_FOLLOW_TILES=1).  Both restart the
+def test_lds_streamed_followers_match_the_tile_staged_ones(engine_ab):
+    """k_follow_states_lds (direct-to-LDS loads, longer chunks) against k_follow_states (option follow_tiles, A/B build).  Both restart the
     follower behind an 18-time-constant halo, at different places: the Pass-2 outputs may differ by the halo's 1.5e-8 relative
     state error, i.e. by nothing once rounded to s16 -- at most a stray LSB."""
     from jivetalking_amd.engine import default_filter_params
+    engine = engine_ab
     x = synth.speech_like(40.0, SR, seed=49)
     engine.upload_pcm(x, SR, 1)
     p = default_filter_params()
     a = engine.pass2(p); o_lds = engine.download_s16(2).copy()
-    monkeypatch.setenv("JT_FOLLOW_TILES", "1")
-    b = engine.pass2(p); o_tile = engine.download_s16(2)
+    with options(engine, follow_tiles=True):
+        b = engine.pass2(p); o_tile = engine.download_s16(2)
     d = np.abs(o_lds.astype(np.int32) - o_tile.astype(np.int32))
     assert d.max() <= 1 and np.count_nonzero(d) <= o_lds.size // 10000
     assert abs(a["r128"]["integrated"] - b["r128"]["integrated"]) < 1e-6
     # lengths that are not a multiple of the 16-byte load group (the last group of the signal is read whole, into the buffers'
     # slack), shorter than one chunk, and shorter than the halo
     for n in (x.size - 3, 48000 * 3 + 1, 30011):
-        monkeypatch.delenv("JT_FOLLOW_TILES", raising=False)
         engine.upload_pcm(x[:n], SR, 1)
         engine.pass2(p); u = engine.download_s16(2).copy()
-        monkeypatch.setenv("JT_FOLLOW_TILES", "1")
-        engine.pass2(p); v = engine.download_s16(2)
+        with options(engine, follow_tiles=True):
+            engine.pass2(p); v = engine.download_s16(2)
         dd = np.abs(u.astype(np.int32) - v.astype(np.int32))
         assert u.size == v.size and dd.max() <= 1 and np.count_nonzero(dd) <= max(2, u.size // 10000), n
 

@@ -11,6 +11,7 @@ import pytest
 
 from jivetalking_amd import synth, hostlogic as H, _lib as L
 from jivetalking_amd.engine import Engine, default_filter_params
+from conftest import options
 
 pytestmark = pytest.mark.gpu
 SR = 48000
@@ -448,18 +449,16 @@ def test_process_audio_delivers_a_file_whose_lra_prints_as_zero(engine):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("sr,secs", [(48000, 23.7), (44100, 9.3), (48000, 0.31), (96000, 11.9), (88200, 2.2)])
-def test_afftdn_grouped_kernel_equals_the_frame_at_a_time_kernel(engine, sr, secs):
+def test_afftdn_grouped_kernel_equals_the_frame_at_a_time_kernel(engine_ab, sr, secs):
     """k_afftdn_grp (eight 2048-point or four 4096-point frames per workgroup, one wave per frame's transforms) takes every sum in k_afftdn's order: static floor,
-    custom band profile and both sweeps of tn=1 must agree bit for bit (filters.go:563-600 chain; JT_AFFTDN_OLD selects the old kernel)."""
+    custom band profile and both sweeps of tn=1 must agree bit for bit (filters.go:563-600 chain; option afftdn_old of the A/B build selects the old kernel)."""
+    engine = engine_ab
     r = np.random.default_rng(3)
     n = int(sr * secs)
     x = (0.05 * r.standard_normal(n) * (0.1 + 0.9 * (np.sin(np.arange(n) * 1.3e-4) > 0)) + 0.01 * np.sin(np.arange(n) * 0.02)).astype(np.float32)
     def both(**kw):
-        os.environ["JT_AFFTDN_OLD"] = "1"
-        try:
+        with options(engine, afftdn_old=True):
             a = engine.op_afftdn(x, sr, 12.0, -50.0, **kw)
-        finally:
-            os.environ.pop("JT_AFFTDN_OLD", None)
         return a, engine.op_afftdn(x, sr, 12.0, -50.0, **kw)
     for kw in ({}, {"track": True}, {"band_noise": [-38.0 - 1.5 * i for i in range(15)]}):
         a, b = both(**kw)
@@ -472,13 +471,10 @@ def test_afftdn_grouped_kernel_equals_the_frame_at_a_time_kernel(engine, sr, sec
 def test_anlmdn_hop_pair_kernel_at_rates_that_do_not_fill_the_lane_layout(engine, oracle, sr, secs):
     """anlmdn=s=0.00001:p=0.006:r=0.002:m=3 (filters.go:95-100) at 44.1 kHz is K = 265 (odd) and S = 88: the wave-per-hop-pair kernel
     runs it on the 96-offset lane layout with dummy end offsets and a short last block.  Against the generic kernel (one thread per
-    offset, FFmpeg's sequential sums; JT_NLM_GENERIC) the outputs agree to f32 round-off of the weighted mean, and both match the oracle."""
+    offset, FFmpeg's sequential sums; option nlm_generic) the outputs agree to f32 round-off of the weighted mean, and both match the oracle."""
     x = synth.speech_like(secs, sr, seed=21).astype(np.float32)
-    os.environ["JT_NLM_GENERIC"] = "1"
-    try:
+    with options(engine, nlm_generic=True):
         g = engine.op_anlmdn(x, sr)
-    finally:
-        os.environ.pop("JT_NLM_GENERIC", None)
     f = engine.op_anlmdn(x, sr)
     assert np.max(np.abs(f - g)) < 2e-8
     assert np.max(np.abs(f - x)) > 1e-5                       # (the filter engaged)
@@ -499,48 +495,43 @@ def _bursty_speech(sr, secs, seed):
 @pytest.mark.gpu
 def test_pass4_takes_the_limiter_prefix_pass3_left_behind(engine):
     """Pass 3 (normalise.go:256-264) and Pass 4 (normalise.go:452-497) run the same alimiter prefix on the same Pass-2 output; Pass 4
-    reuses Pass 3's result instead of recomputing it.  The delivered samples must not change (JT_NO_LIM_KEEP recomputes)."""
+    reuses Pass 3's result instead of recomputing it.  The delivered samples must not change (option no_lim_keep recomputes)."""
     sr = 48000
     x = _bursty_speech(sr, 75.0, 5)
     outs = []
     for keep in (True, False):
-        if keep: os.environ.pop("JT_NO_LIM_KEEP", None)
-        else: os.environ["JT_NO_LIM_KEEP"] = "1"
-        try:
+        with options(engine, no_lim_keep=not keep):
             engine.upload_pcm(x, sr, 1)
             r = H.process_audio(engine, H.default_config(), 4096)
             assert r.limiter.needed == 1
             y = np.empty(x.size, np.int16)
             got = engine.download_s16_into(4, y)
             outs.append(y[:got].copy())
-        finally:
-            os.environ.pop("JT_NO_LIM_KEEP", None)
     assert outs[0].size == outs[1].size and np.array_equal(outs[0], outs[1])
 
 
 @pytest.mark.gpu
-def test_f64_stream_upsampler_with_eight_waves_equals_the_four_wave_kernel(engine):
+def test_f64_stream_upsampler_with_eight_waves_equals_the_four_wave_kernel(engine_ab):
     """The limiter-prefix measurement resamples the limited f64 signal to 192 kHz (swr DBLP); k_upsample32_stream8 must give the
-    statistics the four-wave kernel gives, to the bit (JT_UPS_NO_STREAM8 selects the latter)."""
+    statistics the four-wave kernel gives, to the bit (option ups_no_stream8 of the A/B build selects the latter; p3_unfused: the stand-alone
+    upsampler, which the fused Pass-3 sweep otherwise replaces)."""
+    engine = engine_ab
     r = np.random.default_rng(8)
     x = np.clip(np.round(0.2 * r.standard_normal(44100 * 21) * 32768.0), -32768, 32767).astype(np.int16)
     lim = L.LimiterPlan(1, 0.25, 1.0)
-    a = engine.op_loudnorm_measure_s16(x, 44100, limiter=lim)
-    os.environ["JT_UPS_NO_STREAM8"] = "1"
-    try:
-        b = engine.op_loudnorm_measure_s16(x, 44100, limiter=lim)
-    finally:
-        os.environ.pop("JT_UPS_NO_STREAM8", None)
+    with options(engine, p3_unfused=True):
+        a = engine.op_loudnorm_measure_s16(x, 44100, limiter=lim)
+        with options(engine, ups_no_stream8=True):
+            b = engine.op_loudnorm_measure_s16(x, 44100, limiter=lim)
     assert all(np.array_equal(np.asarray(a[k]), np.asarray(b[k]), equal_nan=True) for k in a)
 
 
 @pytest.mark.gpu
 def test_nothing_reads_memory_it_did_not_write():
     """Every operator and the pipeline on a short file after a long, loud one on the same handle equal the fresh-handle results, with every
-    device allocation filled with 0xFF bytes beforehand (JT_POISON_ALLOC is read once per process: the check runs in its own)."""
+    device allocation filled with 0xFF bytes beforehand (the process-wide option poison_alloc: the check runs in a process of its own)."""
     import subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, JT_POISON_ALLOC="1")
-    r = subprocess.run([sys.executable, os.path.join(root, "tools", "stale_memory.py")], env=env, capture_output=True, text=True, timeout=600)
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "stale_memory.py"), "--poison"], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     assert "stale-memory check: clean (poisoned allocations)" in r.stdout, r.stdout[-2000:]

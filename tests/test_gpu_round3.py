@@ -8,6 +8,7 @@ import pytest
 
 from jivetalking_amd import synth, hostlogic as H, _lib as L
 from jivetalking_amd.engine import Engine
+from conftest import options
 
 pytestmark = pytest.mark.gpu
 SR = 48000
@@ -101,36 +102,35 @@ def test_pass1_completes_when_the_announced_pass2_head_cannot_be_built(engine):
     assert ei.value.code == L.JT_E_INVAL and "Nyquist" in str(ei.value)
 
 
-def test_adeclick_split_pipeline_equals_the_one_kernel_version(engine, monkeypatch):
+def test_adeclick_split_pipeline_equals_the_one_kernel_version(engine_ab):
     """adeclick runs as a front kernel (AR fit, detector, index list, right-hand side) plus register-resident solver kernels (two windows
     per wave for bands up to 31 rows, one for bands up to 48).  Same operations on the same values as round 2's single kernel
-    (JT_ADECLICK_FUSED=1): the outputs are bit-identical, on speech, on speech with real clicks, and on a signal loud enough that most
+    (option adeclick_fused of the A/B build): the outputs are bit-identical, on speech, on speech with real clicks, and on a signal loud enough that most
     windows take the wide-band solver."""
+    engine = engine_ab
     rng = np.random.default_rng(5)
     for seed, gain, clicks in ((21, 1.0, 0), (22, 4.0, 150), (23, 16.0, 400)):
         x = np.asarray(synth.speech_like(20.0, 44100, seed=seed), np.float64) * gain
         if clicks:
             pos = rng.integers(1000, x.size - 1000, clicks)
             x[pos] += rng.uniform(-0.5, 0.5, clicks)
-        monkeypatch.setenv("JT_ADECLICK_FUSED", "1")
-        a = engine.op_adeclick(x, 44100)
-        monkeypatch.delenv("JT_ADECLICK_FUSED")
+        with options(engine, adeclick_fused=True):
+            a = engine.op_adeclick(x, 44100)
         b = engine.op_adeclick(x, 44100)
         assert np.array_equal(a, b), f"seed {seed}: {int((a != b).sum())} samples differ, max {np.abs(a - b).max():.3g}"
         assert int((a != x).sum()) > 1000                          # the filter did repair samples
     # another rate: 32 kHz (W = 1760, AR order 35: Levinson-Durbin stays inside the front kernel, the solvers run with a shorter band)
     x = np.asarray(synth.speech_like(15.0, 32000, seed=24), np.float64) * 3.0
-    monkeypatch.setenv("JT_ADECLICK_FUSED", "1")
-    a = engine.op_adeclick(x, 32000)
-    monkeypatch.delenv("JT_ADECLICK_FUSED")
+    with options(engine, adeclick_fused=True):
+        a = engine.op_adeclick(x, 32000)
     b = engine.op_adeclick(x, 32000)
     assert np.array_equal(a, b) and int((a != x).sum()) > 500
 
 
-def test_pass3_started_inside_pass2_with_the_planned_prefix_equals_the_explicit_one(engine, monkeypatch):
+def test_pass3_started_inside_pass2_with_the_planned_prefix_equals_the_explicit_one(engine):
     """jt_pass3_plan_hook: a plan that needs the limiter prefix starts Pass 3's measurement inside Pass 2, as soon as Pass 2's loudness
     and true peak exist.  A schedule change only - every number and every output sample equals the run without it
-    (JT_NO_EARLY_PLAN=1), on a talker whose plosives need the prefix and on one that does not."""
+    (option no_early_plan), on a talker whose plosives need the prefix and on one that does not."""
     w = int(0.02 * SR)
     burst = 0.35 * np.hanning(w) * np.sin(2 * np.pi * 180.0 * np.arange(w) / SR)
     for seed, plosives in ((61, True), (62, False)):
@@ -141,10 +141,7 @@ def test_pass3_started_inside_pass2_with_the_planned_prefix_equals_the_explicit_
         x = x.astype(np.float32)
         res = []
         for early in (False, True):
-            if early:
-                monkeypatch.delenv("JT_NO_EARLY_PLAN", raising=False)
-            else:
-                monkeypatch.setenv("JT_NO_EARLY_PLAN", "1")
+            engine.set_option("no_early_plan", not early)        # (ends on early = True: the default)
             engine.upload_pcm(x, SR, 1)
             r = H.process_audio(engine)
             res.append((int(r.limiter.needed), r.measure.input_i, r.measure.input_tp, r.measure.input_lra, r.measure.input_thresh,
@@ -243,11 +240,12 @@ def test_limiter_prefix_branch_matches_the_oracle_chain(engine, oracle):
     assert abs(e["integrated"] + 16.0) <= 0.1 and 20 * np.log10(e["true_peak"]) <= -1.0
 
 
-def test_round3_paths_equal_their_switched_off_versions_on_a_long_file(engine, monkeypatch):
+def test_round3_paths_equal_their_switched_off_versions_on_a_long_file(engine_ab):
     """Twenty minutes (BASELINE configs[1] in small; tools/ab_pipeline_fused.py does the same on the 60-min bench file): the split adeclick
     pipeline, Levinson-Durbin one lane per window and Pass 3 started inside Pass 2 are kernel / schedule changes only - the delivered PCM
-    and every reported number equal the run with each of them switched off."""
+    and every reported number equal the run with each of them switched off (A/B build: it holds the one-kernel adeclick)."""
     import hashlib
+    engine = engine_ab
     w = int(0.02 * SR)
     burst = 0.35 * np.hanning(w) * np.sin(2 * np.pi * 180.0 * np.arange(w) / SR)
     base = np.asarray(synth.speech_like(60.0, SR, seed=95), np.float64)
@@ -262,16 +260,15 @@ def test_round3_paths_equal_their_switched_off_versions_on_a_long_file(engine, m
                 int(r.limiter.needed), r.final_.r128.true_peak, engine.timers()["declick_repaired"])
     ref = run()
     assert ref[5] == 1 and abs(ref[1] + 16.0) <= 0.1 and ref[2] <= -1.0
-    for var in ("JT_ADECLICK_FUSED", "JT_NO_EARLY_PLAN", "JT_DK_LEVINSON_IN_KERNEL"):
-        monkeypatch.setenv(var, "1")
-        got = run()
-        monkeypatch.delenv(var)
+    for var in ("adeclick_fused", "no_early_plan", "dk_levinson_in_kernel"):
+        with options(engine, **{var: True}):
+            got = run()
         assert got == ref, var
 
 
 @pytest.mark.gpu
-def test_dynamic_loudnorm_workgroup_kernel_equals_the_one_wave_kernel(engine, monkeypatch):
-    """The dynamic-mode fallback runs as a workgroup with the limiter's frame in LDS (k_loudnorm_dynamic_wg); JT_DYN_ONE_WAVE=1 keeps the
+def test_dynamic_loudnorm_workgroup_kernel_equals_the_one_wave_kernel(engine_ab):
+    """The dynamic-mode fallback runs as a workgroup with the limiter's frame in LDS (k_loudnorm_dynamic_wg); option dyn_one_wave (A/B build) keeps the
     one-wave kernel that walks the ring in global memory.  Same arithmetic on the same values: the 192 kHz outputs are bit-identical --
     a stream the limiter holds down continuously (the reference's +13 dB offset= into a -1 dBTP ceiling), one it touches now and
     then (-9 dBTP), a quiet start (the output-meter phase), and a length that ends in a partial frame."""
@@ -280,21 +277,17 @@ def test_dynamic_loudnorm_workgroup_kernel_equals_the_one_wave_kernel(engine, mo
     x = np.concatenate([x[: 192000 * 3] * 0.004, x])[: -4321]
     outs = {}
     for mode in ("wg", "one"):
-        if mode == "one":
-            monkeypatch.setenv("JT_DYN_ONE_WAVE", "1")
-        else:
-            monkeypatch.delenv("JT_DYN_ONE_WAVE", raising=False)
-        outs[mode] = [engine.op_loudnorm_dynamic(x, target_tp=tp, offset=off)[0] for tp, off in ((-9.0, 0.0), (-1.0, 13.0), (-1.0, 0.0))]
-    monkeypatch.delenv("JT_DYN_ONE_WAVE", raising=False)
+        with options(engine_ab, dyn_one_wave=(mode == "one")):
+            outs[mode] = [engine_ab.op_loudnorm_dynamic(x, target_tp=tp, offset=off)[0] for tp, off in ((-9.0, 0.0), (-1.0, 13.0), (-1.0, 0.0))]
     for a, b in zip(outs["wg"], outs["one"]):
         assert np.array_equal(a, b)
     assert abs(np.max(np.abs(outs["wg"][0])) - 10 ** (-9 / 20)) < 1e-12       # the limiter worked
 
 
 @pytest.mark.gpu
-def test_k_weighting_one_sweep_agrees_with_two_sweeps(engine, monkeypatch):
+def test_k_weighting_one_sweep_agrees_with_two_sweeps(engine_ab):
     """K-weighting as one sweep (zero-state energies + cross terms with the homogeneous-response table, the carried state added per
-    chunk afterwards) against the two-sweep form it replaces (JT_KW_TWO_SWEEPS=1): the momentary / short-term series and the gated
+    chunk afterwards) against the two-sweep form it replaces (option kw_two_sweeps, A/B build): the momentary / short-term series and the gated
     figures agree to 1e-7 LU on every block above the -70 LUFS gate (1e-9 on speech) -- speech, and a signal with a DC offset and a
     30 Hz rumble: the carried state of the RLB high-pass is large there and the three terms cancel most of each other, which is where
     the one-sweep form loses digits (tools/kw_probe.py: 4e-9 LU at a DC offset of 0.3 under -34 LUFS of programme, 4e-5 LU on blocks
@@ -305,11 +298,9 @@ def test_k_weighting_one_sweep_agrees_with_two_sweeps(engine, monkeypatch):
         x = synth.speech_like(secs, sr, seed=51).astype(np.float32)[: t.size]
         y = (0.3 + 0.2 * np.sin(2 * np.pi * 30.0 * t) + 0.01 * rng.standard_normal(t.size)).astype(np.float32)
         for sig in (x, y):
-            monkeypatch.delenv("JT_KW_TWO_SWEEPS", raising=False)
-            a = engine.op_ebur128(sig, sr)
-            monkeypatch.setenv("JT_KW_TWO_SWEEPS", "1")
-            b = engine.op_ebur128(sig, sr)
-            monkeypatch.delenv("JT_KW_TWO_SWEEPS", raising=False)
+            a = engine_ab.op_ebur128(sig, sr)
+            with options(engine_ab, kw_two_sweeps=True):
+                b = engine_ab.op_ebur128(sig, sr)
             tol = 1e-9 if sig is x else 1e-7
             assert abs(a["integrated"] - b["integrated"]) < tol and abs(a["lra"] - b["lra"]) < tol
             assert np.array_equal(np.isfinite(a["M"]), np.isfinite(b["M"]))
@@ -319,11 +310,11 @@ def test_k_weighting_one_sweep_agrees_with_two_sweeps(engine, monkeypatch):
 
 
 @pytest.mark.gpu
-def test_host_arithmetic_staged_behind_the_analysis_chains_reports_the_same_numbers(engine, monkeypatch):
+def test_host_arithmetic_staged_behind_the_analysis_chains_reports_the_same_numbers(engine):
     """The host side of a pass's analysis (gating, LRA, astats merges, the per-frame assembly) runs chain by chain while the later chains
     are still on the GPU, and the announced output regions are measured on a stream of their own: schedule changes only.  Every
     measurement of the run record (input, filtered, final, the four region samples, both loudnorm records) equals the run that waits for
-    the whole analysis first (JT_NO_STAGED_FINISH) with the regions behind the full chains (JT_REGION_ROT)."""
+    the whole analysis first (option no_staged_finish) with the regions behind the full chains (region_rot)."""
     import ctypes as C
     w = int(0.02 * SR)
     burst = 0.35 * np.hanning(w) * np.sin(2 * np.pi * 180.0 * np.arange(w) / SR)
@@ -338,10 +329,9 @@ def test_host_arithmetic_staged_behind_the_analysis_chains_reports_the_same_numb
         parts = (r.input, r.filtered, r.measure, r.final_, r.loudnorm, r.filtered_room_tone, r.filtered_speech, r.final_room_tone, r.final_speech)
         return [C.string_at(C.addressof(p), C.sizeof(p)) for p in parts] + [engine.download_s16(4).tobytes()]
     ref = run()
-    # (JT_REGION_FULL_ASTATS: the regions' astats with all its chains instead of the one sweep their three reported fields need)
-    for env in ({"JT_NO_STAGED_FINISH": "1"}, {"JT_REGION_ROT": "0"}, {"JT_REGION_ROT": "3", "JT_NO_STAGED_FINISH": "1"}, {"JT_REGION_FULL_ASTATS": "1"}):
-        for k, v in env.items(): monkeypatch.setenv(k, v)
-        got = run()
-        for k in env: monkeypatch.delenv(k)
+    # (region_full_astats: the regions' astats with all its chains instead of the one sweep their three reported fields need)
+    for env in ({"no_staged_finish": "1"}, {"region_rot": "0"}, {"region_rot": "3", "no_staged_finish": "1"}, {"region_full_astats": "1"}):
+        with options(engine, **env):
+            got = run()
         assert got == ref, env
 

@@ -469,3 +469,14 @@ def test_default_adeclick_clause_and_shared_analysis_segments(lib):
         assert _element(p2, pre) and _element(p2, pre) == _element(p4, pre)
     pref = g["shared_analysis_segments"]["ebur128_prefix"]
     assert _element(p4, "ebur128=") == pref and _element(p2, "ebur128=").startswith(pref)
+
+
+def test_adeclick_method_spellings_go_into_the_spec_verbatim(lib):
+    """AdeclickConfig.Method is written into the filter spec as given (filters.go:958-960) and af_adeclick's option table names each
+    method twice: "s" / "save", "a" / "add"; "" leaves the option out.  The long names select the same kernels."""
+    import ctypes as C
+    want = {0: None, 1: "m=s", 2: "m=a", 3: "m=save", 4: "m=add"}
+    for code, text in want.items():
+        cfg = H.default_config(); cfg.adeclick_method_s = code
+        el = _element(_spec_for(lib, cfg, 4), "adeclick=")
+        assert el.startswith("adeclick=") and (":m=" not in el if text is None else el.endswith(":" + text)), (code, el)

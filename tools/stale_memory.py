@@ -1,10 +1,12 @@
 """Does anything read memory it did not write?  (1) every operator and the whole pipeline on a short file after a long, loud one on the same
-handle must equal the same call on a fresh handle; (2) run with JT_POISON_ALLOC=1 (allocations filled with 0xFF) the results must not move
-either.  python tools/stale_memory.py"""
+handle must equal the same call on a fresh handle; (2) run with --poison (the process-wide option poison_alloc: allocations filled with 0xFF)
+the results must not move either.  python tools/stale_memory.py [--poison]"""
 import os, sys, hashlib, numpy as np
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
 from jivetalking_amd import Engine, synth, hostlogic as H, _lib as L
 from jivetalking_amd.engine import default_filter_params
+POISON = "--poison" in sys.argv
+if POISON: L.set_global_option("poison_alloc", "1")
 def dig(o):
     h = hashlib.sha256()
     def walk(v):
@@ -40,4 +42,4 @@ for sr in (48000, 44100):
     used = ops(e, short, sr)
     for k in fresh:
         if fresh[k] != used[k]: bad += 1; print("DIFFERS after a longer file:", sr, k, fresh[k], used[k])
-print("stale-memory check:", "clean" if bad == 0 else "%d differences" % bad, "(poisoned allocations)" if os.environ.get("JT_POISON_ALLOC") else "")
+print("stale-memory check:", "clean" if bad == 0 else "%d differences" % bad, "(poisoned allocations)" if POISON else "")
