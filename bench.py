@@ -7,7 +7,8 @@ spawns the N ranks itself (one process per device, LOCAL_RANK = device, rendezvo
 devices are visible; it never falls back to fewer ranks.  A step = all four passes over one 60-min 48 kHz mono f32 file that is
 already resident in HBM (BASELINE.json configs[1]); files shard one per GPU, no data-path collective (scaling: weak).  Rank 0
 prints ONE JSON line with `roofline` (dominant kernel by measured time), `cpu_baseline` (oracle port, bounded sample, rank 0,
-N=1) and `saturation` (configs[3]'s per-GPU share: 32 ten-minute files queued over one GPU, several in flight).
+N=1) and `saturation` (BASELINE configs[3]: 32 x N ten-minute files queued over the N GPUs, file to file, several in flight per GPU;
+at N = 8 that is the configuration's 256 files).
 """
 import argparse
 import json
@@ -73,10 +74,17 @@ def spawn_selftest(args, rank, world):
     dt_rank = time.perf_counter() - t0
     dt = shard.max_over_ranks(dt_rank)
     per = shard.gather_over_ranks(dt_rank / args.steps * 1e3)
+    # the configs[3] leg through the same code as on the GPUs (sharding, barriers, MAX / gather over ranks, the JSON), with a sleep
+    # of 2 ms for a file
+    def fake_batch(paths, md5):
+        time.sleep(0.002 * len(paths) * (1 + rank))
+        return 0, [2.0 * (1 + rank)] * len(paths), [-16.0 - 0.01 * rank] * len(paths)
+    sat = saturation_leg(rank, world, rank, args.sat_files, args.sat_minutes, args.sat_in_flight, 48000,
+                         lambda idx: [f"/nonexistent/ep{k:03d}.flac" for k in idx], fake_batch, shard.barrier, "cpu", "selftest: a sleep per file")
     if rank == 0:
         print(json.dumps({"metric": "spawn-selftest (no GPU work)", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                           "ms_per_step": round(dt / args.steps * 1e3, 3), "per_rank_ms_per_step": [round(v, 3) for v in per],
-                          "spawned_by_bench": bool(os.environ.get("JT_BENCH_SPAWNED"))}))
+                          "spawned_by_bench": bool(os.environ.get("JT_BENCH_SPAWNED")), "saturation": sat}))
     dist.destroy_process_group()
 
 
@@ -115,6 +123,21 @@ def cpu_baseline(sample_seconds, sr):
             "reference_self_published": "~18 xRT/file (README.md:105-125, unknown CPU, 3 files in flight)"}
 
 
+def oracle_landing_job(path):
+    """Checker leg, run as a child process on one host core: the reference's Pass-4 chain composed from the CPU oracle (oracle/chain.py)
+    on the Pass-2 output the GPU produced for the dynamic-fallback file, with the spec string the host logic printed.  Writes
+    <path>.json: where the ORACLE's chain lands (integrated loudness, true peak), for the bench line to print beside the GPU's."""
+    import numpy as np
+    from oracle import chain
+    t0 = time.perf_counter()
+    z = np.load(path, allow_pickle=False)
+    spec = open(path + ".spec").read()
+    r = chain.pass4(z, 44100, spec)
+    land = chain.landing(r["s16"], 44100)
+    json.dump({"oracle_output_lufs": round(land["output_lufs"], 2), "oracle_output_dbtp": round(land["output_dbtp"], 2), "oracle_dynamic": int(r["dynamic"]),
+               "oracle_cpu_s": round(time.perf_counter() - t0, 1), "s16_md5": __import__("hashlib").md5(r["s16"].tobytes()).hexdigest()}, open(path + ".json", "w"))
+
+
 def variant_leg(eng, y, x_dev, n, sr, seconds, base, hostlogic, what):
     """The same step on another talker (reported beside `value`, never part of it): 5 steps, the best of the last 3."""
     import torch
@@ -132,55 +155,93 @@ def variant_leg(eng, y, x_dev, n, sr, seconds, base, hostlogic, what):
             "output_lufs": round(r.output_lufs, 2), "output_dbtp": round(r.output_tp_db, 2)}
 
 
-def saturation_leg(eng, device, base, hostlogic, synth, sr, files, minutes, in_flight):
-    """BASELINE configs[3]'s per-GPU share (256 x 10 min over 8 GPUs = 32 files per GPU): `files` ten-minute 16-bit FLAC files in
-    /dev/shm, file to file through jt_process_files_multi({device}, in_flight) - read, GPU decode, four passes, GPU encode, write,
-    worker start-up (handles, first-file allocations) included.  Reported beside `value`, never part of it."""
+def saturation_leg(rank, world, device, files_per_gpu, minutes, in_flight, sr, make_files, run_batch, sync, dist_device, api):
+    """BASELINE configs[3] (256 x 10 min queued over 8 GPUs = 32 files per GPU): `files_per_gpu * world` ten-minute files, sharded
+    over the ranks longest first (shard.assign_files: the reference's pool hands files to whichever worker is free,
+    cmd/jivetalking/pool.go:122-153; here a rank owns a GPU and its share is fixed up front, no exchange between ranks), each rank
+    running its share file to file through a handle pool on its own device with `in_flight` files at a time.  Barrier on both sides,
+    wall = MAX over ranks, so the figure is the whole job's.  Reported beside `value`, never part of it.
+      make_files(indices) -> paths   the rank's input files (index = position in the global batch)
+      run_batch(paths, md5) -> (failed, [per-file wall ms], [output LUFS of the files that succeeded])
+      sync()                         barrier over ranks (+ device synchronize)"""
+    from jivetalking_amd import shard
+    total = files_per_gpu * world
+    seconds = minutes * 60.0
+    mine = shard.assign_files(total, world, rank, [seconds] * total)
+    paths = make_files(mine)
+    n = int(round(seconds * sr)); m = int(-(-n * 147 // 160))
+    alg = (8 * n + 8 * m) * total
+    out = {"files": total, "minutes_per_file": minutes, "in_flight_per_gpu": in_flight, "n_gpus": world, "api": api,
+           "files_per_device": [int(v) for v in shard.gather_over_ranks(len(mine), device=dist_device)]}
+    for md5 in (True, False):
+        best = None
+        for rep in range(2):                      # best of two: a one-second batch is sensitive to whatever else the host is doing
+            sync()
+            t0 = time.perf_counter()
+            failed, per_file_ms, lufs = run_batch(paths, md5)
+            w_rank = time.perf_counter() - t0
+            sync()
+            wall = shard.max_over_ranks(w_rank, device=dist_device)
+            per_rank = shard.gather_over_ranks(w_rank, device=dist_device)
+            failed_all = int(round(shard.sum_over_ranks(failed, device=dist_device)))
+            busy = shard.max_over_ranks(sum(per_file_ms) / 1e3 / max(1, in_flight), device=dist_device)     # the workers' own per-file time
+            lo = -shard.max_over_ranks(-min(lufs) if lufs else -1e9, device=dist_device)
+            hi = shard.max_over_ranks(max(lufs) if lufs else -1e9, device=dist_device)
+            if best is None or wall < best["wall_s"]:
+                best = {"failed": failed_all, "wall_s": wall, "per_device_wall_s": [round(v, 3) for v in per_rank], "busy": busy, "lo": lo, "hi": hi}
+        wall = best["wall_s"]
+        out["md5" if md5 else "no_md5"] = {
+            "failed": best["failed"], "wall_s": round(wall, 3), "per_device_wall_s": best["per_device_wall_s"],
+            "files_per_s": round(total / wall, 2), "ms_per_file": round(wall / total * 1e3, 2),
+            "xRT": round(total * seconds / wall, 1), "startup_s": round(max(0.0, wall - best["busy"]), 3),
+            "pipeline_hbm": {"algorithmic_bytes": alg, "achieved_GBps": round(alg / wall / 1e9, 2), "peak_GBps": 8000 * world,
+                             "frac": round(alg / wall / 1e9 / (8000 * world), 6)},
+            "output_lufs_range": [round(best["lo"], 2), round(best["hi"], 2)] if best["failed"] < total else None}
+    out["note"] = ("md5 = the reference's FLAC (STREAMINFO MD5 computed, one dependent chain on a host core per file, hidden behind the other "
+                   "workers' GPU phases); half the files carry plosive bursts (limiter prefix), half do not; the handles are opened before the "
+                   "timed region (jt_handle_pool_open: a long-running host opens them once) and startup_s = wall minus the workers' own "
+                   "per-file time (first-file allocations, which hipMalloc serialises)")
+    return out
+
+
+def saturation_on_gpu(args, eng, rank, world, device, base, hostlogic, synth, sr):
+    """The saturation leg on real devices: this rank's share of the batch as 16-bit FLAC files in /dev/shm, one handle pool on its GPU."""
     import shutil
     import tempfile
     import torch
-    d = tempfile.mkdtemp(prefix="jtsat", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
-    out = {"files": files, "minutes_per_file": minutes, "in_flight": in_flight, "api": "jt_process_files_multi, devices = {%d}" % device}
+    import torch.distributed as dist
+    d = tempfile.mkdtemp(prefix=f"jtsat{rank}_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
+    pool = hostlogic.Pool(devices=(device,), in_flight_per_device=args.sat_in_flight)
     try:
-        paths = []
-        seconds = minutes * 60.0
-        n = m = 0
-        for k in range(files):
-            x = synth.speech_like_torch(seconds, sr, seed=2000 + k, device=f"cuda:{device}", plosives_per_min=40.0 if k % 2 == 0 else 0.0)
-            n = x.numel(); m = int(-(-n * 147 // 160))
-            pcm = (x * 32768.0).round().clamp(-32768, 32767).to(torch.int16).cpu().numpy()
-            pk = os.path.join(d, f"ep{k:03d}.flac")
-            open(pk, "wb").write(eng.op_flac_encode(pcm, sr, md5=True)); paths.append(pk)
-            del x
-        alg = (8 * n + 8 * m) * files
-        for md5 in (True, False):
+        def make_files(indices):
+            paths = []
+            for k in indices:
+                x = synth.speech_like_torch(args.sat_minutes * 60.0, sr, seed=2000 + k, device=f"cuda:{device}", plosives_per_min=40.0 if k % 2 == 0 else 0.0)
+                pcm = (x * 32768.0).round().clamp(-32768, 32767).to(torch.int16).cpu().numpy()
+                pk = os.path.join(d, f"ep{k:03d}.flac")
+                open(pk, "wb").write(eng.op_flac_encode(pcm, sr, md5=True)); paths.append(pk)
+                del x
+            return paths
+
+        def run_batch(paths, md5):
             for q in os.listdir(d):
                 if q.endswith("-processed.flac"):
                     os.unlink(os.path.join(d, q))
-            wall = None
-            for rep in range(2):                      # best of two: a one-second batch is sensitive to whatever else the host is doing
-                for q in os.listdir(d):
-                    if q.endswith("-processed.flac"):
-                        os.unlink(os.path.join(d, q))
-                t0 = time.perf_counter()
-                failed_, fr_, _ = hostlogic.process_files_multi(paths, devices=(device,), in_flight_per_device=in_flight, base=base, md5=md5)
-                w_ = time.perf_counter() - t0
-                if wall is None or w_ < wall:
-                    wall, failed, fr = w_, failed_, fr_
-            busy = sum(float(fr[i].wall_ms) for i in range(files)) / 1e3 / in_flight           # the workers' own per-file time
-            out["md5" if md5 else "no_md5"] = {
-                "failed": int(failed), "wall_s": round(wall, 3), "files_per_s": round(files / wall, 2), "ms_per_file": round(wall / files * 1e3, 2),
-                "xRT": round(files * seconds / wall, 1), "startup_s": round(max(0.0, wall - busy), 3),
-                "pipeline_hbm": {"algorithmic_bytes": alg, "achieved_GBps": round(alg / wall / 1e9, 2), "peak_GBps": 8000,
-                                 "frac": round(alg / wall / 1e9 / 8000, 6)},
-                "output_lufs_range": [round(min(fr[i].result.output_lufs for i in range(files) if fr[i].rc == 0), 2),
-                                      round(max(fr[i].result.output_lufs for i in range(files) if fr[i].rc == 0), 2)] if failed < files else None}
-        out["note"] = ("md5 = the reference's FLAC (STREAMINFO MD5 computed, one dependent chain on a host core per file, hidden behind the other "
-                       "workers' GPU phases); half the files carry plosive bursts (limiter prefix), half do not; startup_s = wall minus the "
-                       "workers' own per-file time (handle creation and first-file allocations, which hipMalloc serialises)")
+            failed, fr, _ = pool.process_files(paths, base=base, md5=md5)
+            return int(failed), [float(fr[i].wall_ms) for i in range(len(paths))], [float(fr[i].result.output_lufs) for i in range(len(paths)) if fr[i].rc == 0]
+
+        def sync():
+            if world > 1:
+                dist.barrier()
+            torch.cuda.synchronize()
+
+        out = saturation_leg(rank, world, device, args.sat_files, args.sat_minutes, args.sat_in_flight, sr, make_files, run_batch, sync,
+                             f"cuda:{device}", "jt_handle_pool_process_files, one pool per rank on its own device, files sharded by shard.assign_files")
+        out["pool_workers_per_device"] = [int(v) for v in __import__("jivetalking_amd").shard.gather_over_ranks(len(pool.workers()), device=f"cuda:{device}")]
+        return out
     finally:
+        pool.close()
         shutil.rmtree(d, ignore_errors=True)
-    return out
 
 
 def dynamic_batch_leg(eng, device, base, hostlogic, synth, sr, files, minutes, plosives):
@@ -282,14 +343,20 @@ def main():
     ap.add_argument("--plosives", type=float, default=40.0,
                     help="plosive bursts per minute in the bench talker (crest factor ~20 dB, as close-miked speech has: the loudnorm plan "
                          "then needs the limiter prefix); 0 = the round-1/2 talker (crest ~12 dB, no prefix), which is reported as a leg")
-    ap.add_argument("--saturation", type=int, default=1, help="configs[3]'s per-GPU share as the `saturation` leg (N=1 only); 0 = skip")
-    ap.add_argument("--sat-files", type=int, default=32)
+    ap.add_argument("--saturation", type=int, default=1, help="BASELINE configs[3] as the `saturation` leg (sat-files x N ten-minute files over the N GPUs); 0 = skip")
+    ap.add_argument("--sat-files", type=int, default=32, help="files PER GPU of the saturation leg (configs[3]: 256 over 8 GPUs = 32)")
     ap.add_argument("--sat-minutes", type=float, default=10.0)
     ap.add_argument("--sat-in-flight", type=int, default=6)
     ap.add_argument("--dyn-files", type=int, default=8, help="files of the dynamic-loudnorm batch leg (0 = skip)")
+    ap.add_argument("--oracle-landing", type=int, default=1,
+                    help="run the CPU oracle's Pass-4 chain on the dynamic-fallback file (one host core, in the background, joined before the line is printed) "
+                         "and print where it lands beside the GPU's landing; 0 = skip")
+    ap.add_argument("--oracle-landing-job", default=None, help=argparse.SUPPRESS)
     ap.add_argument("--selftest-spawn", action="store_true", help="exercise the N-rank launch path only (gloo, no GPU work); for tests")
     args = ap.parse_args()
 
+    if args.oracle_landing_job:
+        return oracle_landing_job(args.oracle_landing_job)
     if args.gpus < 1:
         raise SystemExit("--gpus must be >= 1")
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
@@ -373,6 +440,49 @@ def main():
         sat = {"files_in_flight_per_gpu": args.in_flight, "xRT": round(world * args.in_flight * args.steps * seconds / dt2, 1),
                "ms_per_file": round(dt2 / (args.in_flight * args.steps) * 1e3, 3)}
         for e2 in engs[1:]: e2.close()
+    # BASELINE configs[3]: every rank takes part (its share of the batch on its own GPU); straight after the timed steps -- behind the
+    # other legs (half a minute of e2e, 96 kHz and fallback runs) the same batch measured 20-70 % slower
+    io_legs = None
+    if rank == 0 and world == 1:
+        # the file formats either side of the path, outside the timed region: Pass-4 output -> .flac image on
+        # the GPU (with and without the host-side STREAMINFO MD5), and that image decoded again on the GPU by a second handle
+        enc = [eng.flac_encode(4, md5=False, return_info=True)[1] for _ in range(3)]
+        image, enc_md5 = eng.flac_encode(4, md5=True, return_info=True)
+        e3 = Engine(local_rank)
+        dec = [e3.load_audio(image) for _ in range(3)]
+        e3.close()
+        io_legs = {
+            "flac_encode": {"gpu_ms": round(min(i["gpu_ms"] for i in enc), 3), "total_ms": round(min(i["total_ms"] for i in enc), 3),
+                            "bytes": enc_md5["bytes"], "ratio_vs_s16": round(enc_md5["bytes"] / (2.0 * enc_md5["total_samples"]), 4),
+                            "frames": enc_md5["frames"], "md5_host_ms": round(enc_md5["md5_ms"], 1),
+                            "note": "jt_flac_encode(stage 4): analyse + scan + emit kernels, D2H of the image into pinned memory; "
+                                    "the MD5 is one dependent chain on one host core and is optional (JT_FLAC_MD5)"},
+            "flac_decode": {"gpu_ms": round(min(d["gpu_ms"] for d in dec), 3), "total_ms": round(min(d["total_ms"] for d in dec), 3),
+                            "frames": dec[0]["flac_frames"], "candidates": dec[0]["flac_candidates"],
+                            "note": "jt_load_audio of that image (44.1 kHz mono s16): H2D from pageable memory, find + parse + "
+                                    "decode + finish kernels, host chain walk"},
+        }
+    dk_parity = None
+    if rank == 0 and world == 1 and args.e2e:
+        # adeclick's default kernel against the sequential-order one (option adeclick_exact: bit-exact to the oracle) on THIS file, outside
+        # the timed region: the delivered s16 of the last timed step against one more step with the exact kernel
+        import numpy as np
+        fast = eng.download_s16(4).copy(); rep_fast = int(eng.timers()["declick_repaired"])
+        eng.set_option("adeclick_exact", True)
+        hostlogic.process_audio(eng, base, 4096)
+        exact = eng.download_s16(4); rep_exact = int(eng.timers()["declick_repaired"])
+        eng.set_option("adeclick_exact", False)
+        dd = np.abs(fast.astype(np.int32) - exact.astype(np.int32)) if fast.size == exact.size else None
+        dk_parity = {"repaired_fast": rep_fast, "repaired_exact": rep_exact, "s16_samples": int(fast.size),
+                     "s16_samples_differing": int(np.count_nonzero(dd)) if dd is not None else None,
+                     "s16_max_abs_diff_lsb": int(dd.max()) if dd is not None else None,
+                     "note": "default adeclick kernel (summation order relaxed) vs the sequential-order kernel on the bench file, whole job; "
+                             "tests/test_gpu_round4.py holds the same comparison to a bound on a 20-minute file"}
+        del fast, exact, dd
+        hostlogic.process_audio(eng, base, 4096)                       # (the default kernel's output back in place for the legs below)
+    sat_leg = None
+    if args.saturation and args.channels == 1:
+        sat_leg = saturation_on_gpu(args, eng, rank, world, local_rank, base, hostlogic, synth, sr)
     if rank == 0:
         import numpy as np
         m = int(-(-n * 147 // 160))
@@ -403,7 +513,7 @@ def main():
                             "LDL^T solve whose pivots are a dependent chain; the solvers keep the trailing block in registers and wait on LDS "
                             "round trips 60 % of their wave time at 11 waves per CU (profiles/r03_pmc_issue.txt, DESIGN.md s4/s9)",
                     "avg_launch_ms": round(dk_avg_s * 1e3, 3), "repaired_samples": int(eng.timers()["declick_repaired"]),
-                    "heavy_windows": int(eng.timers()["declick_heavy_windows"])}
+                    "heavy_windows": int(eng.timers()["declick_heavy_windows"]), "fast_vs_exact": dk_parity}
         else:
             roof, nlm_roof = nlm_roof, None
         # HBM traffic per launch from the round's committed PMC passes (profiles/r03_pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE and
@@ -458,29 +568,10 @@ def main():
         }
         if sat is not None:
             out["resident_in_flight"] = sat
-        if world == 1:
-            # the file formats either side of the path, outside the timed region: Pass-4 output -> .flac image on
-            # the GPU (with and without the host-side STREAMINFO MD5), and that image decoded again on the GPU by a second handle
-            enc = [eng.flac_encode(4, md5=False, return_info=True)[1] for _ in range(3)]
-            image, enc_md5 = eng.flac_encode(4, md5=True, return_info=True)
-            e3 = Engine(local_rank)
-            dec = [e3.load_audio(image) for _ in range(3)]
-            e3.close()
-            out["io_legs"] = {
-                "flac_encode": {"gpu_ms": round(min(i["gpu_ms"] for i in enc), 3), "total_ms": round(min(i["total_ms"] for i in enc), 3),
-                                "bytes": enc_md5["bytes"], "ratio_vs_s16": round(enc_md5["bytes"] / (2.0 * enc_md5["total_samples"]), 4),
-                                "frames": enc_md5["frames"], "md5_host_ms": round(enc_md5["md5_ms"], 1),
-                                "note": "jt_flac_encode(stage 4): analyse + scan + emit kernels, D2H of the image into pinned memory; "
-                                        "the MD5 is one dependent chain on one host core and is optional (JT_FLAC_MD5)"},
-                "flac_decode": {"gpu_ms": round(min(d["gpu_ms"] for d in dec), 3), "total_ms": round(min(d["total_ms"] for d in dec), 3),
-                                "frames": dec[0]["flac_frames"], "candidates": dec[0]["flac_candidates"],
-                                "note": "jt_load_audio of that image (44.1 kHz mono s16): H2D from pageable memory, find + parse + "
-                                        "decode + finish kernels, host chain walk"},
-            }
-        # (before the other legs: after them the same batch ran 20-70 % slower -- the GPU and the host have been busy for half a minute
-        # by then -- and this one is BASELINE configs[3]'s share)
-        if world == 1 and args.saturation and args.channels == 1:
-            out["saturation"] = saturation_leg(eng, local_rank, base, hostlogic, synth, sr, args.sat_files, args.sat_minutes, args.sat_in_flight)
+        if io_legs is not None:
+            out["io_legs"] = io_legs
+        if sat_leg is not None:
+            out["saturation"] = sat_leg
         if world == 1 and args.e2e and args.channels == 1:
             out["e2e"] = e2e_legs(eng, x, n, sr, seconds, base, hostlogic, Engine, local_rank)
             dev_s = f"cuda:{local_rank}"
@@ -502,6 +593,19 @@ def main():
             td = []
             for it in range(2):
                 t0 = time.perf_counter(); rd = hostlogic.process_audio(eng, base, 4096); td.append(time.perf_counter() - t0)
+            oracle_job = None
+            if args.oracle_landing:
+                # the oracle's landing for this very file: its chain takes minutes of one core, so it runs in a child
+                # process beside the remaining legs and is collected before the line is printed
+                import subprocess
+                import tempfile
+                import numpy as np
+                od = tempfile.mkdtemp(prefix="jtorc", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
+                np.save(os.path.join(od, "p2.npy"), eng.download_s16(2))
+                open(os.path.join(od, "p2.npy.spec"), "w").write(rd.pass4_spec.decode())
+                oracle_job = (subprocess.Popen([sys.executable, os.path.abspath(__file__), "--oracle-landing-job", os.path.join(od, "p2.npy")],
+                                               stdout=subprocess.DEVNULL, stderr=subprocess.PIPE), od, time.perf_counter(),
+                              __import__("hashlib").md5(eng.download_s16(4).tobytes()).hexdigest())
             eng.attach_device_pcm(x.data_ptr(), n, sr, 1, keepalive=x)
             out["dynamic_fallback"] = {"what": "10 min of the talker with broadband hiss bursts 24 dB up: loudnorm's linear mode is not possible, Pass 4 runs the dynamic "
                                                "mode (normalise.go:687-693 only warns about it)", "ms_per_file": round(min(td) * 1e3, 1), "xRT": round(600.0 / min(td), 1),
@@ -528,6 +632,20 @@ def main():
             del xs
         if world == 1 and args.cpu_sample > 0:
             out["cpu_baseline"] = cpu_baseline(args.cpu_sample, sr)
+        if world == 1 and args.e2e and args.channels == 1 and "dynamic_fallback" in out and oracle_job is not None:
+            import shutil
+            pr, od, t_start, gpu_md5 = oracle_job
+            try:
+                pr.wait(timeout=max(5.0, 420.0 - (time.perf_counter() - t_start)))
+                oj = json.load(open(os.path.join(od, "p2.npy.json")))
+                oj["s16_identical_to_gpu"] = bool(oj.pop("s16_md5") == gpu_md5)
+                oj["note"] = ("the reference's Pass-4 chain restated by the CPU oracle (oracle/chain.py) on the GPU's Pass-2 output of this file, same spec "
+                              "string: if it lands where the GPU lands, the landing is the restated af_loudnorm's behaviour on this file, not a kernel's")
+                out["dynamic_fallback"]["oracle"] = oj
+            except Exception as ex:                                   # (a checker leg must not cost the bench line)
+                pr.kill()
+                out["dynamic_fallback"]["oracle"] = {"error": f"{type(ex).__name__}: {ex}", "stderr": (pr.stderr.read() or b"").decode()[-400:]}
+            shutil.rmtree(od, ignore_errors=True)
         print(json.dumps(out))
     eng.close()
     if world > 1:

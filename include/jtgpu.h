@@ -35,6 +35,7 @@ extern "C" {
 typedef struct jt_ctx jt_ctx;
 
 /* ---- lifecycle ---- */
+int  jt_device_count(void);                       /* HIP devices visible to this process (0 when there is none or HIP cannot initialise) */
 int  jt_open(int device_id, jt_ctx **out);
 void jt_close(jt_ctx *h);
 const char *jt_last_error(const jt_ctx *h);

@@ -19,6 +19,13 @@ static void opts_from_env(JtOpts *o);
 
 extern "C" const char *jt_version(void) { return "jtgpu 0.1 (gfx950)"; }
 
+extern "C" int jt_device_count(void)
+{
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    return count < 0 ? 0 : count;
+}
+
 extern "C" int jt_open(int device_id, jt_ctx **out)
 {
     if (!out) return JT_E_INVAL;

@@ -72,3 +72,28 @@ def options(engine, **kv):
     finally:
         for k in kv:
             engine.set_option(k, _OPTION_DEFAULTS.get(k, "0"))
+
+
+_TALKER_DIR = None
+
+
+def bench_talker(seconds, sr=48000, seed=1000, plosives=40.0, sib_gain=0.25):
+    """bench.py's talker (synth.speech_like_torch: aperiodic, generated on the device) as a numpy array.  torch's HIP runtime and the
+    library's cannot both be initialised in one process, so a child process generates it; cached for the session under /dev/shm."""
+    import atexit
+    import shutil
+    import subprocess
+    import tempfile
+    import numpy as np
+    global _TALKER_DIR
+    if _TALKER_DIR is None:
+        _TALKER_DIR = tempfile.mkdtemp(prefix="jttalk", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
+        atexit.register(shutil.rmtree, _TALKER_DIR, True)
+    path = os.path.join(_TALKER_DIR, f"t{seconds:g}_{sr}_{seed}_{plosives:g}_{sib_gain:g}.npy")
+    if not os.path.exists(path):
+        code = ("import sys, numpy as np; sys.path.insert(0, %r); from jivetalking_amd import synth; "
+                "x = synth.speech_like_torch(%r, %d, seed=%d, device='cuda:0', plosives_per_min=%r, sib_gain=%r); np.save(%r, x.cpu().numpy())"
+                % (ROOT, float(seconds), int(sr), int(seed), float(plosives), float(sib_gain), path))
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stderr[-2000:]
+    return np.load(path, mmap_mode="r")

@@ -55,6 +55,56 @@ def test_ten_minute_files_in_flight_equal_one_at_a_time(engine, tmp_path):
     assert not [q for q in os.listdir(str(tmp_path)) if q.startswith(".processing-")]
 
 
+def test_every_visible_device_serves_the_shared_queue(engine, tmp_path):
+    """BASELINE configs[2] / configs[3] in small, on whatever the box has: jt_process_files_multi over ALL visible devices (HIP's own
+    count, jt_device_count) with two workers each.  Every device serves at least one file when there are at least as many files as
+    devices (pool.go:122-153: whichever worker is free takes the next file), the outputs are byte-identical to the same files one at a
+    time on one handle, and a caller-owned pool (jt_handle_pool_*) gives the same bytes batch after batch with its handles kept open.
+    With one visible device this is the single-device test with device_of_file checked; on an 8-GPU node it drives all eight."""
+    ndev = L.device_count()
+    assert ndev >= 1
+    devices = tuple(range(ndev))
+    nfiles = max(6, 2 * ndev)
+    paths = _ten_minute_flacs(engine, tmp_path, nfiles, minutes=1.0)
+    want = []
+    for p in paths:
+        res, out_path, _ = H.process_file(engine, p)
+        want.append((res.output_lufs, res.output_tp_db, int(res.limiter.needed), open(out_path, "rb").read()))
+        os.unlink(out_path)
+
+    def check(failed, res, dev, what):
+        assert failed == 0, what
+        assert set(dev) == set(devices), f"{what}: devices that served files {sorted(set(dev))}, visible {devices}"
+        for k in range(nfiles):
+            r = res[k]
+            assert r.rc == 0 and dev[k] in devices
+            assert (r.result.output_lufs, r.result.output_tp_db, int(r.result.limiter.needed)) == want[k][:3], (what, k)
+            assert open(r.output_path.decode(), "rb").read() == want[k][3], f"{what}: file {k} (device {dev[k]}) differs from the one-at-a-time bytes"
+            os.unlink(r.output_path.decode())
+    check(*H.process_files_multi(paths, devices=devices, in_flight_per_device=2), "jt_process_files_multi")
+    with H.Pool(devices=devices, in_flight_per_device=2) as pool:
+        assert sorted(set(pool.workers())) == list(devices) and len(pool.workers()) == 2 * ndev
+        for batch in range(2):                                  # the same handles, warm the second time
+            check(*pool.process_files(paths), f"pool batch {batch}")
+        failed, res, dev = pool.process_files(paths[:1])        # fewer files than workers: still served, by some device
+        assert failed == 0 and dev[0] in devices
+        os.unlink(res[0].output_path.decode())
+    assert not [q for q in os.listdir(str(tmp_path)) if q.startswith(".processing-")]
+
+
+def test_a_pool_without_any_device_fails_every_file_of_every_batch(engine, tmp_path):
+    paths = _ten_minute_flacs(engine, tmp_path, 2, minutes=0.2)
+    with H.Pool(devices=(99,), in_flight_per_device=2) as pool:
+        assert pool.workers() == []
+        for _ in range(2):
+            failed, res, dev = pool.process_files(paths)
+            assert failed == 2 and dev == [-1, -1] and all(res[k].rc != 0 and b"jt_open(99)" in res[k].error for k in range(2))
+    with H.Pool(devices=(99, 0), in_flight_per_device=1) as pool:      # the worker of the dead device finds nothing else to serve
+        assert pool.workers() == [0]
+        failed, res, dev = pool.process_files(paths)
+        assert failed == 0 and dev == [0, 0]
+
+
 def test_a_device_that_cannot_be_opened_takes_no_files(engine, tmp_path):
     """a worker whose jt_open failed used to pop files and fail them in microseconds.  devices = {0, 99}: every file is
     served by device 0; devices = {99}: every file fails with the open error, none is left in its initial state."""

@@ -73,7 +73,7 @@ def test_bench_spawns_its_own_ranks():
     """`python bench.py --gpus 2` with no launcher in the environment: bench.py starts the two ranks itself (it used to
     run one rank and print n_gpus 1).  --selftest-spawn swaps the GPU step for a sleep and RCCL for gloo, nothing else."""
     import json
-    p = _run_bench("--gpus", "2", "--steps", "3", "--warmup", "0", "--selftest-spawn")
+    p = _run_bench("--gpus", "2", "--steps", "3", "--warmup", "0", "--selftest-spawn", "--sat-files", "7")
     assert p.returncode == 0, p.stderr[-2000:]
     lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1                                    # one line, from rank 0 only
@@ -81,6 +81,17 @@ def test_bench_spawns_its_own_ranks():
     assert out["n_gpus"] == 2 and len(out["per_rank_ms_per_step"]) == 2 and out["spawned_by_bench"] is True
     assert out["per_rank_ms_per_step"][1] > out["per_rank_ms_per_step"][0] * 0.9     # rank order (rank 1 sleeps longer)
     assert out["ms_per_step"] >= max(out["per_rank_ms_per_step"]) - 1e-6             # MAX over ranks
+    # BASELINE configs[3]'s leg goes through the same launch: sat-files per GPU x 2 ranks, sharded longest first, every device's
+    # count and wall reported, the whole job's wall = MAX over ranks
+    sat = out["saturation"]
+    assert sat["n_gpus"] == 2 and sat["files"] == 2 * 7 and sat["files_per_device"] == [7, 7]
+    for leg in ("md5", "no_md5"):
+        r = sat[leg]
+        assert r["failed"] == 0 and len(r["per_device_wall_s"]) == 2
+        assert r["wall_s"] >= max(r["per_device_wall_s"]) - 2e-3 and r["per_device_wall_s"][1] > r["per_device_wall_s"][0]      # (rank 1's files sleep longer)
+        assert abs(r["files_per_s"] - sat["files"] / r["wall_s"]) / r["files_per_s"] < 0.02
+        assert r["pipeline_hbm"]["peak_GBps"] == 16000 and 0 < r["pipeline_hbm"]["frac"]
+        assert r["output_lufs_range"] == [-16.01, -16.0]                                                                       # MIN / MAX over ranks
 
 
 def test_bench_refuses_fewer_devices_than_ranks():
