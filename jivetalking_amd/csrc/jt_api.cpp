@@ -315,7 +315,7 @@ static void pass_begin(jt_ctx *h, int64_t max_samples, int analyses, int64_t ext
     }
     const size_t na = (size_t)std::max(1, analyses), ne = (size_t)std::max(0, extra_jobs);
     h->pin.begin(jt_arena_bytes_for(max_samples) * na + jt_arena_bytes_for(extra_samples) * ne + (4u << 20));
-    h->kw_begin((size_t)(max_samples / 512 + 1024) * 8 * na + ((size_t)(extra_samples / 512 + 1024) * 8 + (size_t)extra_samples / 128 + 16384) * ne);   // + the regions' own scratch
+    h->kw_begin((size_t)(max_samples / 512 + 1024) * 12 * na + ((size_t)(extra_samples / 512 + 1024) * 8 + (size_t)extra_samples / 128 + 16384) * ne);   // + the regions' own scratch
     h->as_begin(((size_t)(2u << 20) + (size_t)max_samples / 6) * na + ((size_t)(2u << 20) + (size_t)extra_samples / 6) * ne);
     // the remaining analysis scratch is shared by jobs that are serialised on one stream; size it now, while nothing is queued
     h->d_scr1.ensure((size_t)(max_samples / 400 + 16));
@@ -839,6 +839,62 @@ template <typename T> static void loudnorm_append_flush(T *stream, int64_t m_tot
     if (m_total >= 576000) JT_HIP(hipMemcpyAsync(stream + m_total, stream + (m_total - 556800), (size_t)556800 * sizeof(T), hipMemcpyDeviceToDevice, st));
 }
 
+// loudnorm's input meter over a signal at `rate` (the Pass-2 output as s16, or the limiter prefix's f64 output): swr -> 192 kHz,
+// K-weighting, 100 ms block energies and sample peaks, the flush frame included.  One sweep that never stores the 192 kHz stream
+// (k_p3_fused) when the rate pair allows it (44.1 kHz: the reference's output rate); the stand-alone pair -- upsampler into
+// stream_f / stream_d, k_kw1 over it -- otherwise and under the option p3_unfused (what the fused sweep is tested against).
+// ext: scratch that outlives the pass arenas (sized by p3_scratch_sizes); null = the pass arenas.
+static bool p3_fused_ok(jt_ctx *h, const SwrDev &sw, int64_t m_total)
+{
+    const int blk = (192000 + 5) / 10;
+    const int64_t flush = loudnorm_meter_len(m_total) - m_total;
+    return !h->opts.p3_unfused && jt_p3_fused_supported(sw.pl.phase_count, sw.pl.filter_length, sw.pl.step, blk, flush);
+}
+static void p3_scratch_sizes(jt_ctx *h, int64_t n, int rate, size_t *dev_d, size_t *pin_d)
+{
+    SwrDev &sw = get_swr(h, rate, 192000);
+    const int64_t m_total = sw.out_len(n);
+    jt_kweight_scratch_sizes(loudnorm_meter_len(m_total), (192000 + 5) / 10, dev_d, pin_d, p3_fused_ok(h, sw, m_total) ? sw.pl.phase_count : 0);
+}
+static void p3_measure_enqueue(jt_ctx *h, const int16_t *s16, const double *f64, int64_t n, int rate, KwJob *kw, int64_t *nfull, int *blk_out,
+                               hipStream_t st, const KwScratch *ext)
+{
+    SwrDev &sw = get_swr(h, rate, 192000);
+    const int64_t m_total = sw.out_len(n);
+    const int blk = (192000 + 5) / 10;
+    const int64_t m_meter = loudnorm_meter_len(m_total);
+    *blk_out = blk; *nfull = m_meter / blk;
+    if (p3_fused_ok(h, sw, m_total)) {
+        const int P = sw.pl.phase_count;
+        if (h->p3_mpow_P != P) {
+            // the fold's matrices F^(JW w) depend on the 192 kHz K-weighting coefficients and the period only: once per handle
+            BiquadF64 pre, rlb; jt_kweight_design(192000, &pre, &rlb);
+            KwCoef k{pre.b0, pre.b1, pre.b2, pre.a1, pre.a2, rlb.b0, rlb.b1, rlb.b2, rlb.a1, rlb.a2};
+            double tab[16 * 16]; const int cnt = jt_p3_fold_powers(k, P, tab);
+            h->p3_mpow.retire(); h->p3_mpow.ensure((size_t)cnt);
+            JT_HIP(hipMemcpy(h->p3_mpow.p, tab, sizeof(double) * (size_t)cnt, hipMemcpyHostToDevice));
+            h->p3_mpow_P = P;
+        }
+        const double *mpow = h->p3_mpow.p;
+        jt_kweight_enqueue_sweep(h, m_meter, 192000, blk, P, kw, st, ext, [&](const KwSweep &W) {
+            if (s16) launch_p3_fused_s16(s16, n, sw.bank_f.p, sw.bank_fs.p, P, sw.pl.center, sw.pl.step, m_total, m_meter - m_total, W, mpow, st);
+            else launch_p3_fused_f64(f64, n, sw.bank_d.p, P, sw.pl.center, sw.pl.step, m_total, m_meter - m_total, W, mpow, st);
+        });
+        return;
+    }
+    if (s16) {
+        h->stream_f.ensure((size_t)m_meter);
+        launch_resample_stream_s16_f32(s16, n, sw.bank_f.p, sw.bank_fs.p, sw.pl.phase_count, sw.pl.filter_length, sw.pl.center, sw.pl.step, m_total, h->stream_f.p, st);
+        loudnorm_append_flush(h->stream_f.p, m_total, st);
+        jt_kweight_enqueue_f32(h, h->stream_f.p, m_meter, 192000, blk, kw, st, ext);
+    } else {
+        h->stream_d.ensure((size_t)m_meter);
+        launch_resample_stream_f64(f64, n, sw.bank_d.p, sw.pl.phase_count, sw.pl.filter_length, sw.pl.center, sw.pl.step, m_total, h->stream_d.p, st, h->opts);
+        loudnorm_append_flush(h->stream_d.p, m_total, st);
+        jt_kweight_enqueue_f64(h, h->stream_d.p, m_meter, 192000, blk, kw, st, ext);
+    }
+}
+
 // Pass 3 for a plan without limiter prefix (loudnorm's first-pass measurement of the s16 output: swr -> 192 kHz, K-weighting,
 // 100 ms block energies), queued behind the output stage on a stream that Pass 2 does not wait for.  Scratch and result buffers
 // of its own: the pass arenas are recycled by the next pass_begin.
@@ -846,11 +902,7 @@ static void spec_loudnorm_enqueue(jt_ctx *h, const int16_t *s16, int64_t n, int 
 {
     if (rate == 192000 || n <= 0 || h->opts.no_early_pass3) return;
     auto &S = h->spec_ln;
-    SwrDev &sw = get_swr(h, rate, 192000);
-    const int64_t m_total = sw.out_len(n);
-    const int blk = (192000 + 5) / 10;
-    const int64_t m_meter = loudnorm_meter_len(m_total);
-    size_t dev_d = 0, pin_d = 0; jt_kweight_scratch_sizes(m_meter, blk, &dev_d, &pin_d);
+    size_t dev_d = 0, pin_d = 0; p3_scratch_sizes(h, n, rate, &dev_d, &pin_d);
     S.dev.ensure(dev_d);
     if (pin_d > S.pin_cap) {
         if (S.pin) jt_graveyard().put(S.pin, sizeof(double) * S.pin_cap, 1);
@@ -858,15 +910,11 @@ static void spec_loudnorm_enqueue(jt_ctx *h, const int16_t *s16, int64_t n, int 
         JT_HIP(DevGraveyard::host_malloc((void **)&S.pin, sizeof(double) * pin_d));
         S.pin_cap = pin_d;
     }
-    h->stream_f.ensure((size_t)m_meter);
     JT_HIP(hipEventRecord(S.fork, h->stream));
     JT_HIP(hipStreamWaitEvent(S.stream, S.fork, 0));
-    launch_resample_stream_s16_f32(s16, n, sw.bank_f.p, sw.bank_fs.p, sw.pl.phase_count, sw.pl.filter_length, sw.pl.center, sw.pl.step, m_total,
-                                   h->stream_f.p, S.stream);
     const KwScratch ext{S.dev.p, S.pin};
-    loudnorm_append_flush(h->stream_f.p, m_total, S.stream);
-    jt_kweight_enqueue_f32(h, h->stream_f.p, m_meter, 192000, blk, &S.kw, S.stream, &ext);
-    S.blk = blk; S.nfull = m_meter / blk; S.pending = true;
+    p3_measure_enqueue(h, s16, nullptr, n, rate, &S.kw, &S.nfull, &S.blk, S.stream, &ext);
+    S.pending = true;
 }
 
 extern "C" int jt_pass3_plan_hook(jt_ctx *h, jt_plan_fn fn, void *user)
@@ -887,11 +935,7 @@ static void run_limiter(jt_ctx *h, double *in, double *out, int64_t n, int sr, d
 static void early_pass3_enqueue(jt_ctx *h, const int16_t *s16, int64_t m, int rate, const jt_limiter_plan &lim)
 {
     auto &E = h->early_p3;
-    SwrDev &sw = get_swr(h, rate, 192000);
-    const int64_t m_total = sw.out_len(m);
-    const int blk = (192000 + 5) / 10;
-    const int64_t m_meter = loudnorm_meter_len(m_total);
-    size_t dev_d = 0, pin_d = 0; jt_kweight_scratch_sizes(m_meter, blk, &dev_d, &pin_d);
+    size_t dev_d = 0, pin_d = 0; p3_scratch_sizes(h, m, rate, &dev_d, &pin_d);
     E.dev.ensure(dev_d);
     if (pin_d > E.pin_cap) {
         if (E.pin) jt_graveyard().put(E.pin, sizeof(double) * E.pin_cap, 1);
@@ -899,16 +943,14 @@ static void early_pass3_enqueue(jt_ctx *h, const int16_t *s16, int64_t m, int ra
         JT_HIP(DevGraveyard::host_malloc((void **)&E.pin, sizeof(double) * pin_d));
         E.pin_cap = pin_d;
     }
-    h->f64_a.ensure((size_t)m); h->f64_b.ensure((size_t)m); h->stream_d.ensure((size_t)m_meter);
+    h->f64_a.ensure((size_t)m); h->f64_b.ensure((size_t)m);
     const bool pre = lim.pre_gain_db > 0;
     const double g = pre ? std::pow(10.0, lim.pre_gain_db / 20.0) : 1.0;
     run_limiter(h, h->f64_a.p, h->f64_b.p, m, rate, lim.limit, 5.0, 100.0, 1.0, LimS16{s16, g, pre ? 1 : 0});
     h->lim_keep = {true, s16, m, rate, lim.pre_gain_db, lim.limit};
-    launch_resample_stream_f64(h->f64_b.p, m, sw.bank_d.p, sw.pl.phase_count, sw.pl.filter_length, sw.pl.center, sw.pl.step, m_total, h->stream_d.p, h->stream, h->opts);
-    loudnorm_append_flush(h->stream_d.p, m_total, h->stream);
     const KwScratch ext{E.dev.p, E.pin};
-    jt_kweight_enqueue_f64(h, h->stream_d.p, m_meter, 192000, blk, &E.kw, h->stream, &ext);
-    E.blk = blk; E.nfull = m_meter / blk; E.plan = lim; E.valid = true;
+    p3_measure_enqueue(h, nullptr, h->f64_b.p, m, rate, &E.kw, &E.nfull, &E.blk, h->stream, &ext);
+    E.plan = lim; E.valid = true;
 }
 
 extern "C" int jt_pass2(jt_ctx *h, const jt_filter_params *p, jt_analysis *out)
@@ -1074,22 +1116,7 @@ static void run_limiter(jt_ctx *h, double *in, double *out, int64_t n, int sr, d
 struct LoudnormJob { KwJob kw; int64_t nfull = 0; int blk = 0; };
 static void loudnorm_measure_enqueue(jt_ctx *h, const int16_t *s16, const double *f64, int64_t n, int rate, LoudnormJob *J)
 {
-    SwrDev &sw = get_swr(h, rate, 192000);
-    const int64_t m_total = sw.out_len(n);
-    const int blk = (192000 + 5) / 10;
-    const int64_t m_meter = loudnorm_meter_len(m_total);
-    J->blk = blk; J->nfull = m_meter / blk;
-    if (s16) {
-        h->stream_f.ensure((size_t)m_meter);
-        launch_resample_stream_s16_f32(s16, n, sw.bank_f.p, sw.bank_fs.p, sw.pl.phase_count, sw.pl.filter_length, sw.pl.center, sw.pl.step, m_total, h->stream_f.p, h->stream);
-        loudnorm_append_flush(h->stream_f.p, m_total, h->stream);
-        jt_kweight_enqueue_f32(h, h->stream_f.p, m_meter, 192000, blk, &J->kw, h->stream);
-    } else {
-        h->stream_d.ensure((size_t)m_meter);
-        launch_resample_stream_f64(f64, n, sw.bank_d.p, sw.pl.phase_count, sw.pl.filter_length, sw.pl.center, sw.pl.step, m_total, h->stream_d.p, h->stream, h->opts);
-        loudnorm_append_flush(h->stream_d.p, m_total, h->stream);
-        jt_kweight_enqueue_f64(h, h->stream_d.p, m_meter, 192000, blk, &J->kw, h->stream);
-    }
+    p3_measure_enqueue(h, s16, f64, n, rate, &J->kw, &J->nfull, &J->blk, h->stream, nullptr);
 }
 static void loudnorm_measure_finish(const LoudnormJob &J, jt_loudnorm_stats *out)
 {

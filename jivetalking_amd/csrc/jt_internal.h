@@ -187,6 +187,15 @@ void launch_resample_stream_s16_f32(const int16_t *in, int64_t n, const float *b
                                     int64_t step, int64_t m_total, float *out, hipStream_t s);
 void launch_resample_stream_f64(const double *in, int64_t n, const double *bank, int phase_count, int filter_length, int center,
                                 int64_t step, int64_t m_total, double *out, hipStream_t s, const JtOpts &o);
+// Pass 3 in one sweep (k_p3_fused, k_resample.hip): the sweep of a K-weighting job whose chunks are the resampler's periods; the 192 kHz
+// stream is never stored.  flush: loudnorm's flush frame, the last `flush` outputs metered again behind the stream (0: none).
+struct KwSweep; struct KwCoef;
+bool jt_p3_fused_supported(int phase_count, int filter_length, int64_t step, int blk, int64_t flush);
+int  jt_p3_fold_powers(const KwCoef &k, int P, double *out);
+void launch_p3_fused_s16(const int16_t *in, int64_t n, const float *bankf, const float *bankf_scaled, int P, int center, int64_t step, int64_t m_total,
+                         int64_t flush, const KwSweep &W, const double *mpow_dev, hipStream_t s);
+void launch_p3_fused_f64(const double *in, int64_t n, const double *bank, int P, int center, int64_t step, int64_t m_total, int64_t flush, const KwSweep &W,
+                         const double *mpow_dev, hipStream_t s);
 void launch_f64_to_s16(const double *in, int16_t *out, float *out_f32, int64_t n, int round_via_float, hipStream_t s);
 void launch_f32_to_f64(const float *in, double *out, int64_t n, hipStream_t s);
 
@@ -301,9 +310,21 @@ void jt_astats_enqueue(jt_ctx *h, const float *x, int64_t n, int sr, AstatsJob *
                        unsigned long long *ehist = nullptr, bool levels_only = false);     // ehist: the job's own 8192-bin histogram (default: the shared one)
 void jt_astats_finish(const AstatsJob *job, jt_astats *out);
 struct KwJob { const double *hc = nullptr; int64_t nchunks = 0, nfull = 0; int m = 1; };
+// BS.1770 K-weighting as two transposed-DF2 biquads (pre-filter shelf b/a, RLB high-pass c/d): k_lane.hip KW2_STEP
+struct KwCoef { double b0, b1, b2, a1, a2, c0, c1, c2, d1, d2; };
+// What a sweep over L-sample chunks leaves per chunk c (k_kw1, or a kernel that produces the signal itself): the zero-state end state
+// zs[4c..], sum zs^2 in csum[c], max |x| in cpeak[c], the four sums zs_j g_j[k] in cross[4c..]; gtab = the homogeneous-response table
+// g[j][k] (j < L) on the device and on the host, tail = samples of the last chunk.  (two_sweeps: the A/B build's older form.)
+struct KwSweep {
+    KwCoef k; int64_t L = 0, nchunks = 0, tail = 0; const double *gtab = nullptr, *gtab_host = nullptr;
+    double *zs = nullptr, *csum = nullptr, *cpeak = nullptr, *cross = nullptr; const double *pw = nullptr; int nterms = 0; bool two_sweeps = false;
+};
 // scratch of a job that outlives the pass arenas (the Pass-3 measurement started early by Pass 2): device doubles / pinned doubles
 struct KwScratch { double *dev = nullptr; double *pin = nullptr; };
-void jt_kweight_scratch_sizes(int64_t n, int blk, size_t *dev_doubles, size_t *pin_doubles);
+void jt_kweight_scratch_sizes(int64_t n, int blk, size_t *dev_doubles, size_t *pin_doubles, int64_t chunk_len = 0);
+// the K-weighting job around a caller-supplied sweep (chunk_len > 0: that chunk length, a divisor of blk)
+void jt_kweight_enqueue_sweep(jt_ctx *h, int64_t n, int rate, int blk, int64_t chunk_len, KwJob *job, hipStream_t s, const KwScratch *ext,
+                              const std::function<void(const KwSweep &)> &sweep);
 void jt_kweight_enqueue_f32(jt_ctx *h, const float *in, int64_t n, int rate, int blk, KwJob *job, hipStream_t s, const KwScratch *ext = nullptr);
 void jt_kweight_enqueue_f64(jt_ctx *h, const double *in, int64_t n, int rate, int blk, KwJob *job, hipStream_t s, const KwScratch *ext = nullptr);
 // sums/peaks: nfull+1 entries (last = trailing partial block)
@@ -370,6 +391,7 @@ struct jt_ctx {
     SwrDev swr[4]; int swr_next = 0;
     // K-weighting: homogeneous-response tables of the one-sweep kernel, per (rate, chunk length)
     struct KwTab { int rate = 0; int64_t L = 0; std::vector<double> g; DevBuf<double> dev; } kw_tab[8]; int kw_tab_next = 0;
+    DevBuf<double> p3_mpow; int p3_mpow_P = 0;         // the fused Pass-3 sweep's fold matrices (k_p3_fused), per period length
     DevBuf<float> region_f; DevBuf<int16_t> region_s16;
     // Pass 3's measurement of the Pass-2 output for the no-prefix plan (the usual one), queued by Pass 2 itself on a stream of
     // its own as soon as the s16 output exists: it runs beside Pass 2's analysis tail and the host work between the passes.

@@ -429,7 +429,7 @@ void launch_biquad_f32(const float *in, float *out, int64_t n, int nstages, cons
 // Chunks are sub-divisions of the 100 ms blocks; the host adds the per-chunk partials of each block in order.
 // Both biquads run in transposed direct form II with fused multiply-adds (same transfer function as the FILTER macro of
 // f_ebur128.c; rounding differs at 1e-16).
-struct KwCoef { double b0, b1, b2, a1, a2, c0, c1, c2, d1, d2; };
+// (struct KwCoef: jt_internal.h)
 
 #define KW2_STEP(X)                                                     \
     {                                                                    \
@@ -626,20 +626,24 @@ static int kw_chunks_per_block(int blk)
     for (int q = 1; q <= 32; ++q) if (blk % q == 0 && blk / q <= 2400) { if (best < 0) best = q; if ((blk / q) % TW == 0) { best = q; break; } }
     return best > 0 ? best : 1;
 }
-void jt_kweight_scratch_sizes(int64_t n, int blk, size_t *dev_doubles, size_t *pin_doubles)
+void jt_kweight_scratch_sizes(int64_t n, int blk, size_t *dev_doubles, size_t *pin_doubles, int64_t chunk_len)
 {
-    const int64_t L = blk / kw_chunks_per_block(blk), nchunks = (n + L - 1) / L;
+    const int64_t L = chunk_len > 0 ? chunk_len : blk / kw_chunks_per_block(blk), nchunks = (n + L - 1) / L;
     *dev_doubles = 4 * (size_t)nchunks + 24 * 16 + 2 * (size_t)nchunks + 4 * (size_t)nchunks + 64;
     *pin_doubles = 24 * 16 + 2 * (size_t)nchunks + 64;
 }
 
-template <typename TIn>
-static void kweight_enqueue(jt_ctx *h, const TIn *in, int64_t n, int rate, int blk, KwJob *job, hipStream_t st, const KwScratch *ext = nullptr)
+// The job around a K-weighting sweep: chunk plan, transition-matrix powers, scratch, homogeneous-response table; then `sweep` (k_kw1 over a
+// signal in memory -- or a kernel that PRODUCES the signal and never stores it: the fused Pass-3 measurement, k_resample.hip), k_kw_fix,
+// k_kw_blocks and the copy of the block sums.  chunk_len > 0 forces the chunk length (a divisor of blk).
+static void kweight_job(jt_ctx *h, int64_t n, int rate, int blk, int64_t chunk_len, KwJob *job, hipStream_t st, const KwScratch *ext,
+                        const std::function<void(const KwSweep &)> &sweep)
 {
     BiquadF64 pre, rlb; jt_kweight_design(rate, &pre, &rlb);
     KwCoef k{pre.b0, pre.b1, pre.b2, pre.a1, pre.a2, rlb.b0, rlb.b1, rlb.b2, rlb.a1, rlb.a2};
-    const int m = kw_chunks_per_block(blk);
+    const int m = chunk_len > 0 ? (int)(blk / chunk_len) : kw_chunks_per_block(blk);
     const int64_t L = blk / m;
+    JT_REQUIRE(L * m == blk, JT_E_INVAL, "K-weighting: the chunk length must divide the 100 ms block");
     const int64_t nchunks = (n + L - 1) / L;
     // homogeneous transition matrix (state s1,s2,t1,t2; input 0) and its powers F^L, F^2L, ...
     double F[16] = {-k.a1, 1, 0, 0,   -k.a2, 0, 0, 0,   k.c1 - k.d1 * k.c0, 0, -k.d1, 1,   k.c2 - k.d2 * k.c0, 0, -k.d2, 0};
@@ -660,19 +664,13 @@ static void kweight_enqueue(jt_ctx *h, const TIn *in, int64_t n, int rate, int b
     double *base = ext ? ext->dev : h->kw_take(need);
     double *d_zs = base, *d_pw = base + 4 * (size_t)nchunks, *d_cs = d_pw + 24 * 16, *d_cross = d_cs + 2 * (size_t)nchunks;
     if (npw) JT_HIP(hipMemcpyAsync(d_pw, pw, sizeof(double) * 16 * npw, hipMemcpyHostToDevice, st));
-    const unsigned grid = (unsigned)((nchunks + LANES - 1) / LANES);
+    KwSweep SW; SW.k = k; SW.L = L; SW.nchunks = nchunks; SW.zs = d_zs; SW.csum = d_cs; SW.cpeak = d_cs + nchunks; SW.cross = d_cross;
+    SW.pw = d_pw; SW.nterms = nterms; SW.two_sweeps = false;
 #ifdef JT_AB
-    const bool two_sweeps = h->opts.kw_two_sweeps;
-#else
-    constexpr bool two_sweeps = false;
+    SW.two_sweeps = h->opts.kw_two_sweeps;
 #endif
-    if (two_sweeps) {
-#ifdef JT_AB
-        hipLaunchKernelGGL((k_kw<TIn, false>), dim3(grid), dim3(LANES), 0, st, in, n, L, k, (const double *)nullptr, (const double *)nullptr, 0,
-                           d_zs, (double *)nullptr, (double *)nullptr, nchunks);
-        hipLaunchKernelGGL((k_kw<TIn, true>), dim3(grid), dim3(LANES), 0, st, in, n, L, k, d_zs, d_pw, nterms,
-                           (double *)nullptr, d_cs, d_cs + nchunks, nchunks);
-#endif
+    if (SW.two_sweeps) {
+        sweep(SW);
     } else {
         // homogeneous-response table of this (rate, L): g[j][k] = output at step j from the k-th unit state, no input (same statements as
         // KW2_STEP); cached on the handle
@@ -706,7 +704,8 @@ static void kweight_enqueue(jt_ctx *h, const TIn *in, int64_t n, int rate, int b
                 G.f[u] += p_; if (j < tail) G.t[u] += p_;
             }
         }
-        hipLaunchKernelGGL((k_kw1<TIn>), dim3(grid), dim3(LANES), 0, st, in, n, L, k, (const double *)T->dev.p, d_zs, d_cs, d_cs + nchunks, d_cross, nchunks);
+        SW.gtab = T->dev.p; SW.gtab_host = T->g.data(); SW.tail = tail;
+        sweep(SW);
         hipLaunchKernelGGL(k_kw_fix, dim3((unsigned)((nchunks + 63) / 64)), dim3(64), 0, st, (const double *)d_zs, (const double *)d_pw, nterms,
                            (const double *)d_cross, G, d_cs, nchunks);
     }
@@ -717,8 +716,30 @@ static void kweight_enqueue(jt_ctx *h, const TIn *in, int64_t n, int rate, int b
     JT_HIP(hipMemcpyAsync(hc, d_zs, sizeof(double) * (size_t)(nfull + 1) * 2, hipMemcpyDeviceToHost, st));
     job->hc = hc; job->nchunks = nchunks; job->nfull = nfull; job->m = m;
 }
+template <typename TIn>
+static void kweight_enqueue(jt_ctx *h, const TIn *in, int64_t n, int rate, int blk, KwJob *job, hipStream_t st, const KwScratch *ext = nullptr)
+{
+    kweight_job(h, n, rate, blk, 0, job, st, ext, [&](const KwSweep &W) {
+        const unsigned grid = (unsigned)((W.nchunks + LANES - 1) / LANES);
+        if (W.two_sweeps) {
+#ifdef JT_AB
+            hipLaunchKernelGGL((k_kw<TIn, false>), dim3(grid), dim3(LANES), 0, st, in, n, W.L, W.k, (const double *)nullptr, (const double *)nullptr, 0,
+                               W.zs, (double *)nullptr, (double *)nullptr, W.nchunks);
+            hipLaunchKernelGGL((k_kw<TIn, true>), dim3(grid), dim3(LANES), 0, st, in, n, W.L, W.k, (const double *)W.zs, W.pw, W.nterms,
+                               (double *)nullptr, W.csum, W.cpeak, W.nchunks);
+#endif
+            return;
+        }
+        hipLaunchKernelGGL((k_kw1<TIn>), dim3(grid), dim3(LANES), 0, st, in, n, W.L, W.k, W.gtab, W.zs, W.csum, W.cpeak, W.cross, W.nchunks);
+    });
+}
 void jt_kweight_enqueue_f32(jt_ctx *h, const float *in, int64_t n, int rate, int blk, KwJob *job, hipStream_t s, const KwScratch *ext) { kweight_enqueue<float>(h, in, n, rate, blk, job, s, ext); }
 void jt_kweight_enqueue_f64(jt_ctx *h, const double *in, int64_t n, int rate, int blk, KwJob *job, hipStream_t s, const KwScratch *ext) { kweight_enqueue<double>(h, in, n, rate, blk, job, s, ext); }
+void jt_kweight_enqueue_sweep(jt_ctx *h, int64_t n, int rate, int blk, int64_t chunk_len, KwJob *job, hipStream_t s, const KwScratch *ext,
+                              const std::function<void(const KwSweep &)> &sweep)
+{
+    kweight_job(h, n, rate, blk, chunk_len, job, s, ext, sweep);
+}
 void jt_kweight_finish(const KwJob *job, std::vector<double> &sums, std::vector<double> &peaks)
 {
     const int64_t nfull = job->nfull;

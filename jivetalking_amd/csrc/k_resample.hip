@@ -475,6 +475,304 @@ k_upsample32_stream8(const TIn *__restrict__ in, int64_t n, const TTap *__restri
     upsample32_stream_quads<TIn, TAcc, TTap, 1, NWV, CHN>(xin, bank, P, step, m_lo, m_total, in_scale, 0, out_stream, otile);
 }
 
+// ------------------------------------------------------------------ Pass 3 in one sweep: swr -> 192 kHz, K-weighting, sample peak, chunk partials
+// loudnorm's first pass (normalise.go:226-346) resamples the Pass-2 output to 192 kHz and meters it.  As two kernels the 192 kHz stream
+// (4.35 samples per input sample, f64 behind the limiter prefix: 5.5 GB for an hour) was written to HBM by the upsampler and read back by
+// the K-weighting sweep -- 15 GB of the step's 77 GB of traffic, 4.5 ms on the critical path.  Here the stream never
+// leaves the registers: a thread of k_upsample32_stream8's layout produces a contiguous run of JW = P / NWV outputs of one polyphase
+// period (lane = period, wave = j-range) in ascending order, so it runs the K-weighting recurrence over that run FROM ZERO STATE as
+// the samples appear and keeps what k_kw1 keeps per chunk: the end state, sum zs^2, max |x| and the four sums zs_j g_j[k].  The filter is
+// linear, so the NWV runs of a period fold into the period's own zero-state results exactly: with s_w the state the period's zero-state
+// run carries into run w (s_0 = 0, s_{w+1} = F^JW s_w + e_w) and r_w = c_w + G s_w (G = sum_j g_j g_j'),
+//   sum y^2 = sum_w (q_w + 2 s_w . c_w + s_w' G s_w),   cross = sum_w r_w' F^(JW w),   end state = s_NWV,
+// a few hundred flops per period, done by the first wave from partials parked in the (dead) input tile.  A chunk of the K-weighting job
+// is then one PERIOD (640 outputs at 44.1 -> 192 kHz: 30 chunks per 100 ms block) and k_kw_fix / k_kw_blocks run unchanged.
+// The meter also takes loudnorm's flush frame -- the last 556 800 samples again, behind the stream (jt_api.cpp loudnorm_meter_len): that is
+// a whole number of periods, so chunk c past the end of the stream is period c - flush / P; only the chunk that holds the stream's last
+// sample mixes two periods and goes to k_p3_boundary (one workgroup).  Every 192 kHz sample is the tap sum, in the tap order, of the
+// stand-alone upsampler: sample peaks are bit-identical, energies agree to the rounding of a different chunking (1e-12 LU).
+struct P3Merge {
+    double FJ[16];          // F^JW
+    double G[10];           // sum_{j < JW} g_j g_j', upper triangle row-major
+    double Gt[10];          // the same over the rows of the tail chunk's last, partial run
+    const double *Mpow;     // [NWV][16]: F^(JW w), device
+};
+struct P3Section { int64_t chunk0, chunk_end, period_delta; unsigned block0; };     // chunks [chunk0, chunk_end): source period = chunk + period_delta
+
+#define P3_KW_STEP(X)                                                   \
+    {                                                                    \
+        const double xx = (X);                                           \
+        const double y = fma(k.b0, xx, s1);                              \
+        s1 = fma(-k.a1, y, fma(k.b1, xx, s2));                           \
+        s2 = fma(-k.a2, y, k.b2 * xx);                                   \
+        zz = fma(k.c0, y, t1);                                           \
+        t1 = fma(-k.d1, zz, fma(k.c1, y, t2));                           \
+        t2 = fma(-k.d2, zz, k.c2 * y);                                   \
+    }
+
+template <typename TIn, typename TAcc, typename TTap, int NWV>
+__global__ void __launch_bounds__(64 * NWV)
+k_p3_fused(const TIn *__restrict__ in, int64_t n, const TTap *__restrict__ bank, int P, int center, int step, double in_scale,
+           P3Section secA, P3Section secB, int64_t tail_chunk, int tail_rows, KwCoef k, const double *__restrict__ gtab, P3Merge M,
+           double *__restrict__ zs_out, double *__restrict__ csum, double *__restrict__ cpeak, double *__restrict__ cross)
+{
+    constexpr int L = 32, NT = 64 * NWV, PS = 10;                       // PS doubles parked per thread
+    extern __shared__ unsigned char smem_pp[];
+    TIn *xin = reinterpret_cast<TIn *>(smem_pp);
+    const int T = 64 * step, nin = T + L;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane((int)(tid >> 6));
+    const bool inB = blockIdx.x >= secB.block0;
+    const P3Section sec = inB ? secB : secA;
+    const int64_t c0 = sec.chunk0 + (int64_t)(blockIdx.x - sec.block0) * 64;        // first chunk of this workgroup
+    if (c0 >= sec.chunk_end) return;
+    const int nrows = (int)min((int64_t)64, sec.chunk_end - c0);
+    const int64_t q0 = c0 + sec.period_delta;                                        // first source period
+    const int64_t s0 = q0 * step;
+    if (s0 - center >= 0 && s0 - center + nin <= n) {
+        const TIn *src = in + (s0 - center);                         // interior workgroup: no reflection, no end of stream
+        for (int i = tid; i < nin; i += NT) xin[i] = src[i];
+    } else {
+        for (int i = tid; i < nin; i += NT) {
+            int64_t g = s0 - center + i;
+            TIn v = (TIn)0;
+            if (g < 0) g = -g;                                       // invert_initial_buffer(): in[-j] = in[j]
+            if (g < n) v = in[g];
+            else { int64_t r = 2 * n - 1 - g; if (r >= 0 && r < n) v = in[r]; }   // resample_flush()
+            xin[i] = v;
+        }
+    }
+    __syncthreads();
+    const unsigned uP = (unsigned)P, ustep = (unsigned)step;
+    const int JW = P / NWV, jw0 = wave * JW, jw1 = jw0 + JW;
+    const int off_first = (int)(((unsigned)jw0 * ustep) / uP), off_last = (int)(((unsigned)(jw1 - 1) * ustep) / uP);
+    // rows of this lane's chunk that exist (every row, except in the stream's last chunk)
+    const int jlim = lane < nrows ? ((c0 + lane == tail_chunk) ? tail_rows : P) : 0;
+    double s1 = 0, s2 = 0, t1 = 0, t2 = 0, zz = 0, acc = 0, pk = 0, x0c = 0, x1c = 0, x2c = 0, x3c = 0;
+    for (int off0 = off_first; off0 <= off_last; ++off0) {
+        const int off = __builtin_amdgcn_readfirstlane(off0);
+        int j_lo = (int)(((unsigned)off * uP + ustep - 1u) / ustep), j_hi = (int)(((unsigned)(off + 1) * uP + ustep - 1u) / ustep);
+        j_lo = j_lo > jw0 ? j_lo : jw0; j_hi = j_hi < jw1 ? j_hi : jw1;
+        TAcc xw[L];
+        {
+            const TIn *wp = xin + (off + step * lane);
+            if (in_scale == 1.0) {
+#pragma unroll
+                for (int i = 0; i < L; ++i) xw[i] = (TAcc)wp[i];
+            } else {
+#pragma unroll
+                for (int i = 0; i < L; ++i) xw[i] = (TAcc)((TAcc)wp[i] * (TAcc)in_scale);
+            }
+        }
+        int ph = (int)(((unsigned)j_lo * ustep) % uP);
+        auto row = [&](const TTap (&tp)[L], int j) {
+            TAcc val = (TAcc)0;
+#pragma unroll
+            for (int i = 0; i < L; ++i) val = fma(xw[i], (TAcc)tp[i], val);
+            const double *gp = gtab + 4 * (j - jw0);                    // wave-uniform: scalar loads
+            const double g0 = gp[0], g1 = gp[1], g2 = gp[2], g3 = gp[3];
+            if (j < jlim) {
+                const double u = (double)val;
+                P3_KW_STEP(u)
+                acc = fma(zz, zz, acc); pk = fmax(pk, fabs(u));
+                x0c = fma(zz, g0, x0c); x1c = fma(zz, g1, x1c); x2c = fma(zz, g2, x2c); x3c = fma(zz, g3, x3c);
+            }
+        };
+        auto fetch_row = [&](TTap (&tp)[L], int phase) {
+            const TTap *f = bank + (size_t)(unsigned)phase * L;
+#pragma unroll
+            for (int i = 0; i < L; ++i) tp[i] = f[i];
+        };
+        TTap ta[L], tb[L];
+        if (j_lo < j_hi) fetch_row(ta, ph);
+        for (int j = j_lo; j < j_hi; j += 2) {
+            int ph1 = ph + step; ph1 -= ph1 >= P ? P : 0;
+            int ph2 = ph1 + step; ph2 -= ph2 >= P ? P : 0;
+            fetch_row(tb, ph1);
+            row(ta, j);
+            if (j + 1 < j_hi) {
+                fetch_row(ta, ph2);
+                row(tb, j + 1);
+            }
+            ph = ph2;
+        }
+    }
+    __syncthreads();                                                    // every wave is done with the input tile: park the runs' results in it
+    double *park = reinterpret_cast<double *>(smem_pp);
+    {
+        double *pp = park + ((size_t)wave * 64 + lane) * PS;
+        pp[0] = s1; pp[1] = s2; pp[2] = t1; pp[3] = t2; pp[4] = acc; pp[5] = pk; pp[6] = x0c; pp[7] = x1c; pp[8] = x2c; pp[9] = x3c;
+    }
+    __syncthreads();
+    if (wave != 0 || lane >= nrows) return;
+    // fold the NWV runs of this lane's period (in order) into the period's zero-state results
+    const int w_last = jlim >= P ? NWV - 1 : (jlim - 1) / JW;           // the tail chunk ends inside run w_last
+    double s[4] = {0, 0, 0, 0}, Q = 0, PK = 0, C[4] = {0, 0, 0, 0};
+    for (int w = 0; w <= w_last; ++w) {
+        const double *pp = park + ((size_t)w * 64 + lane) * PS;
+        const double e[4] = {pp[0], pp[1], pp[2], pp[3]}, q = pp[4], c[4] = {pp[6], pp[7], pp[8], pp[9]};
+        PK = fmax(PK, pp[5]);
+        const double *Gm = (jlim < P && w == w_last) ? M.Gt : M.G;
+        // Gs = G s (symmetric, upper triangle stored)
+        double Gs[4];
+        {
+            const double g00 = Gm[0], g01 = Gm[1], g02 = Gm[2], g03 = Gm[3], g11 = Gm[4], g12 = Gm[5], g13 = Gm[6], g22 = Gm[7], g23 = Gm[8], g33 = Gm[9];
+            Gs[0] = g00 * s[0] + g01 * s[1] + g02 * s[2] + g03 * s[3];
+            Gs[1] = g01 * s[0] + g11 * s[1] + g12 * s[2] + g13 * s[3];
+            Gs[2] = g02 * s[0] + g12 * s[1] + g22 * s[2] + g23 * s[3];
+            Gs[3] = g03 * s[0] + g13 * s[1] + g23 * s[2] + g33 * s[3];
+        }
+        double lin = 0, quad = 0, r[4];
+        for (int a = 0; a < 4; ++a) { lin += s[a] * c[a]; quad += s[a] * Gs[a]; r[a] = c[a] + Gs[a]; }
+        Q += q + 2.0 * lin + quad;
+        const double *Mw = M.Mpow + 16 * w;                             // F^(JW w), row-major: (state after JW w steps)[l] = sum_k Mw[l][k] s[k]
+        for (int kk = 0; kk < 4; ++kk) C[kk] += r[0] * Mw[0 * 4 + kk] + r[1] * Mw[1 * 4 + kk] + r[2] * Mw[2 * 4 + kk] + r[3] * Mw[3 * 4 + kk];
+        double ns[4];
+        for (int a = 0; a < 4; ++a) ns[a] = M.FJ[a * 4 + 0] * s[0] + M.FJ[a * 4 + 1] * s[1] + M.FJ[a * 4 + 2] * s[2] + M.FJ[a * 4 + 3] * s[3] + e[a];
+        for (int a = 0; a < 4; ++a) s[a] = ns[a];
+    }
+    const int64_t c = c0 + lane;
+    zs_out[c * 4 + 0] = s[0]; zs_out[c * 4 + 1] = s[1]; zs_out[c * 4 + 2] = s[2]; zs_out[c * 4 + 3] = s[3];
+    csum[c] = Q; cpeak[c] = PK;
+    cross[c * 4 + 0] = C[0]; cross[c * 4 + 1] = C[1]; cross[c * 4 + 2] = C[2]; cross[c * 4 + 3] = C[3];
+}
+
+// The one chunk that holds the stream's last sample when the flush copy follows it: rows below `t1` come from period `qa`, the rest from
+// period `qb` (= qa - flush / P).  One workgroup: 64 lanes evaluate the P tap sums (same taps, same order), lane 0 runs the chunk's
+// zero-state recurrence over them.
+template <typename TIn, typename TAcc, typename TTap>
+__global__ void __launch_bounds__(64)
+k_p3_boundary(const TIn *__restrict__ in, int64_t n, const TTap *__restrict__ bank, int P, int center, int step, double in_scale, int64_t qa, int64_t qb,
+              int n_first, int rows, int64_t chunk, KwCoef k, const double *__restrict__ gtab, double *__restrict__ zs_out, double *__restrict__ csum,
+              double *__restrict__ cpeak, double *__restrict__ cross)
+{
+    constexpr int L = 32;
+    extern __shared__ unsigned char smem_pp[];
+    double *u = reinterpret_cast<double *>(smem_pp);
+    for (int j = threadIdx.x; j < rows; j += 64) {
+        const int64_t q = j < n_first ? qa : qb;
+        const int off = (int)(((unsigned)j * (unsigned)step) / (unsigned)P), ph = (int)(((unsigned)j * (unsigned)step) % (unsigned)P);
+        const int64_t g0 = q * step + off - center;
+        const TTap *f = bank + (size_t)ph * L;
+        TAcc val = (TAcc)0;
+        for (int i = 0; i < L; ++i) {
+            int64_t g = g0 + i;
+            TIn v = (TIn)0;
+            if (g < 0) g = -g;
+            if (g < n) v = in[g];
+            else { const int64_t r = 2 * n - 1 - g; if (r >= 0 && r < n) v = in[r]; }
+            const TAcc xv = in_scale == 1.0 ? (TAcc)v : (TAcc)((TAcc)v * (TAcc)in_scale);
+            val = fma(xv, (TAcc)f[i], val);
+        }
+        u[j] = (double)val;
+    }
+    __syncthreads();
+    if (threadIdx.x != 0) return;
+    double s1 = 0, s2 = 0, t1 = 0, t2 = 0, zz = 0, acc = 0, pk = 0, xc[4] = {0, 0, 0, 0};
+    for (int j = 0; j < rows; ++j) {
+        const double x = u[j];
+        P3_KW_STEP(x)
+        acc = fma(zz, zz, acc); pk = fmax(pk, fabs(x));
+        for (int a = 0; a < 4; ++a) xc[a] = fma(zz, gtab[4 * j + a], xc[a]);
+    }
+    zs_out[chunk * 4 + 0] = s1; zs_out[chunk * 4 + 1] = s2; zs_out[chunk * 4 + 2] = t1; zs_out[chunk * 4 + 3] = t2;
+    csum[chunk] = acc; cpeak[chunk] = pk;
+    for (int a = 0; a < 4; ++a) cross[chunk * 4 + a] = xc[a];
+}
+#undef P3_KW_STEP
+
+static void p3_mat4_mul(const double *A, const double *B, double *C)
+{
+    double t[16];
+    for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) { double s = 0; for (int q = 0; q < 4; ++q) s += A[i * 4 + q] * B[q * 4 + j]; t[i * 4 + j] = s; }
+    std::memcpy(C, t, sizeof(t));
+}
+
+constexpr int P3_NWV = 8;                                           // waves per workgroup of k_p3_fused = runs per period
+// can this (rate pair, block) be measured by the fused sweep?  (44.1 kHz -> 192 kHz: P = 640, step = 147)
+bool jt_p3_fused_supported(int phase_count, int filter_length, int64_t step, int blk, int64_t flush)
+{
+    return filter_length == 32 && step < phase_count && (step & 1) && phase_count % 64 == 0 && blk % phase_count == 0 && flush % phase_count == 0 &&
+           phase_count % P3_NWV == 0 && phase_count <= 2400 && (size_t)(64 * step + 36) * sizeof(double) <= 100 * 1024;
+}
+
+// F^(JW w), w < P3_NWV, for the fold (JW = P / P3_NWV): depends on the K-weighting coefficients and the period only -- the caller uploads it once
+int jt_p3_fold_powers(const KwCoef &k, int P, double *out /* P3_NWV * 16 */)
+{
+    const int JW = P / P3_NWV;
+    double F[16] = {-k.a1, 1, 0, 0,   -k.a2, 0, 0, 0,   k.c1 - k.d1 * k.c0, 0, -k.d1, 1,   k.c2 - k.d2 * k.c0, 0, -k.d2, 0};
+    double FJ[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1}, Bq[16];
+    std::memcpy(Bq, F, sizeof F);
+    for (int e = JW; e > 0; e >>= 1) { if (e & 1) p3_mat4_mul(FJ, Bq, FJ); p3_mat4_mul(Bq, Bq, Bq); }
+    double cur[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+    for (int w = 0; w < P3_NWV; ++w) { std::memcpy(out + 16 * w, cur, sizeof cur); p3_mat4_mul(FJ, cur, cur); }
+    return P3_NWV * 16;
+}
+
+// The sweep of a K-weighting job over chunks of P outputs (jt_kweight_enqueue_sweep with chunk_len = P): m_total outputs of the resampler,
+// followed by the last `flush` of them again (0: no flush frame).  mpow_dev: jt_p3_fold_powers' table on the device.
+template <typename TIn, typename TAcc, typename TTap>
+static void launch_p3_fused_t(const TIn *in, int64_t n, const TTap *bank, int P, int center, int64_t step, int64_t m_total, int64_t flush, double in_scale,
+                              const KwSweep &W, const double *mpow_dev, hipStream_t s)
+{
+    constexpr int NWV = P3_NWV;
+    const int JW = P / NWV;
+    JT_REQUIRE(W.L == P && P % NWV == 0 && W.gtab && W.gtab_host, JT_E_INVAL, "fused Pass-3 sweep: chunk length must be the period");
+    const int64_t m_meter = m_total + flush;
+    JT_REQUIRE(W.nchunks == (m_meter + P - 1) / P, JT_E_INVAL, "fused Pass-3 sweep: chunk count");
+    // constants of the fold: F^JW, its powers, the Gram matrices of the table's first JW rows
+    const KwCoef &k = W.k;
+    double F[16] = {-k.a1, 1, 0, 0,   -k.a2, 0, 0, 0,   k.c1 - k.d1 * k.c0, 0, -k.d1, 1,   k.c2 - k.d2 * k.c0, 0, -k.d2, 0};
+    P3Merge M; std::memset(&M, 0, sizeof M);
+    double FJ[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1}, Bq[16];
+    std::memcpy(Bq, F, sizeof F);
+    for (int e = JW; e > 0; e >>= 1) { if (e & 1) p3_mat4_mul(FJ, Bq, FJ); p3_mat4_mul(Bq, Bq, Bq); }
+    std::memcpy(M.FJ, FJ, sizeof FJ);
+    M.Mpow = mpow_dev;
+    const int64_t c_b = m_total / P; const int t1 = (int)(m_total - c_b * P);
+    const int64_t tail_chunk = W.nchunks - 1; const int tail_rows = (int)(m_meter - tail_chunk * P);
+    const int tail_run_rows = tail_rows >= P ? JW : tail_rows - ((tail_rows - 1) / JW) * JW;
+    for (int j = 0; j < JW; ++j) {
+        int u = 0;
+        for (int a = 0; a < 4; ++a) for (int b = a; b < 4; ++b, ++u) {
+            const double p_ = W.gtab_host[(size_t)4 * j + a] * W.gtab_host[(size_t)4 * j + b];
+            M.G[u] += p_; if (j < tail_run_rows) M.Gt[u] += p_;
+        }
+    }
+    P3Section A{0, 0, 0, 0}, B{0, 0, 0, 0};
+    const bool mixed = flush > 0 && t1 > 0;
+    if (flush > 0) {
+        A.chunk_end = c_b;                                              // whole periods of the stream itself
+        B.chunk0 = c_b + (mixed ? 1 : 0); B.chunk_end = W.nchunks; B.period_delta = -(flush / P);
+    } else A.chunk_end = W.nchunks;                                     // (the last chunk is the tail: t1 rows, or P)
+    const unsigned nbA = (unsigned)((A.chunk_end - A.chunk0 + 63) / 64), nbB = (unsigned)((std::max<int64_t>(0, B.chunk_end - B.chunk0) + 63) / 64);
+    A.block0 = 0; B.block0 = nbA;
+    if (!(flush > 0)) B.block0 = nbA + 1;                               // (no block belongs to B)
+    const size_t tile = (sizeof(TIn) * (size_t)(64 * step + 32 + 4) + 15) & ~(size_t)15;
+    const size_t smem = std::max(tile, sizeof(double) * (size_t)NWV * 64 * 10);
+    auto kf = k_p3_fused<TIn, TAcc, TTap, NWV>;
+    JT_HIP(hipFuncSetAttribute((const void *)kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    if (nbA + nbB > 0)
+        hipLaunchKernelGGL(kf, dim3(nbA + (flush > 0 ? nbB : 0)), dim3(64 * NWV), smem, s, in, n, bank, P, center, (int)step, in_scale, A, B, tail_chunk, tail_rows,
+                           W.k, W.gtab, M, W.zs, W.csum, W.cpeak, W.cross);
+    if (mixed) {
+        const int rows = c_b == tail_chunk ? tail_rows : P;
+        auto kb = k_p3_boundary<TIn, TAcc, TTap>;
+        hipLaunchKernelGGL(kb, dim3(1), dim3(64), sizeof(double) * (size_t)P, s, in, n, bank, P, center, (int)step, in_scale, c_b, c_b - flush / P, t1, rows, c_b,
+                           W.k, W.gtab, W.zs, W.csum, W.cpeak, W.cross);
+    }
+}
+void launch_p3_fused_s16(const int16_t *in, int64_t n, const float *bankf, const float *bankf_scaled, int P, int center, int64_t step, int64_t m_total,
+                         int64_t flush, const KwSweep &W, const double *mpow_dev, hipStream_t s)
+{
+    launch_p3_fused_t<int16_t, float, float>(in, n, bankf_scaled ? bankf_scaled : bankf, P, center, step, m_total, flush, bankf_scaled ? 1.0 : 1.0 / 32768.0,
+                                             W, mpow_dev, s);
+}
+void launch_p3_fused_f64(const double *in, int64_t n, const double *bank, int P, int center, int64_t step, int64_t m_total, int64_t flush, const KwSweep &W,
+                         const double *mpow_dev, hipStream_t s)
+{
+    launch_p3_fused_t<double, double, double>(in, n, bank, P, center, step, m_total, flush, 1.0, W, mpow_dev, s);
+}
+
 template <typename TIn, typename TAcc, typename TTap, int MODE>
 static bool launch_upsample32(const TIn *in, int64_t n, const TTap *bank, int P, int L, int center, int64_t step, int64_t m_total,
                               double in_scale, int blk, double *block_tp, int64_t nblocks_alloc, TAcc *out, hipStream_t s, const JtOpts *o = nullptr)
