@@ -138,6 +138,41 @@ def oracle_landing_job(path):
                "oracle_cpu_s": round(time.perf_counter() - t0, 1), "s16_md5": __import__("hashlib").md5(r["s16"].tobytes()).hexdigest()}, open(path + ".json", "w"))
 
 
+def compute_aware_floor(n, m, sr, prefix, repaired, windows):
+    """Per stage max(algorithmic bytes / 8 TB/s, flops / the vector peak of the type the reference computes that stage in): the time below
+    which no implementation of these filters' arithmetic can go on this chip, and the honest denominator for a path SURVEY 8(d) called
+    HBM-bound before adeclick and the f64 FIRs were written.  Peaks: HBM 8 TB/s and f32 FMA 157.3 TFLOP/s (MI355X_MICROARCH.md); f64
+    and non-FMA f32 at half that, 78.6 (f64 FMA counted as 2; the add / mul-only f32 recurrence of anlmdn cannot use FMA without leaving
+    FFmpeg's rounding).  Flop counts are the filters' own operation counts per sample / frame / window."""
+    HBM, F32, F32NF, F64 = 8e12, 157.3e12, 78.6e12, 78.6e12
+    m192 = n * 192000 // sr
+    st = []
+
+    def add(name, nbytes, flops, peak, note):
+        t = max(nbytes / HBM, flops / peak if peak else 0.0)
+        st.append({"stage": name, "bytes": int(nbytes), "flops": int(flops), "bound": "hbm" if nbytes / HBM >= (flops / peak if peak else 0.0) else "flops",
+                   "floor_ms": round(t * 1e3, 3), "note": note})
+    # one analysis = astats (one read, ~40 f64 flops a sample) + aspectralstats (2048-point f32 FFT per 1024-sample hop) + ebur128
+    # (K-weighting 14 f64 FMA a sample, x4 true peak: 4 x 32 f64 FMA a sample)
+    for name, k in (("pass1 analysis", n), ("pass2 analysis", n), ("pass4 analysis", m)):
+        add(name, 4 * k, k * (40 + 28 + 256) + (k / 1024.0) * 5 * 2048 * 11 * 0.5, F64, "astats + ebur128 (K-weighting, x4 true peak: f64) + aspectralstats (f32 FFT counted at the f64 rate's twice)")
+    add("highpass + lowpass", 8 * n, 18 * n, F32, "two f32 biquads")
+    add("anlmdn", 8 * n, n * 192 * 6, F32NF, "sliding SSD over 192 offsets, 6 non-FMA f32 flops per (sample, offset)")
+    frames = n / (sr / 80.0)
+    add("afftdn", 8 * n, frames * (2 * 5 * 2048 * 11) * 0.5 + frames * 1025 * 40, F64, "two 2048-point f32 transforms per 600-sample frame (at twice the f64 rate) + f64 gain curves per bin")
+    add("agate + acompressor", 24 * n, 2 * 100 * n, F64, "f32 -> f64 -> f32 with one log / exp gain curve each")
+    add("48 -> 44.1 kHz + s16", 4 * n + 2 * m, 72 * m, F64, "36-tap f64 polyphase")
+    if prefix:
+        add("limiter prefix", 2 * m + 8 * m, 4 * m, F64, "s16 -> f64, alimiter at rest almost everywhere")
+    add("pass3 measurement", (8 if prefix else 2) * m, m192 * (64 + 28), F64 if prefix else F32, "swr to 192 kHz (32 taps) + K-weighting; the 192 kHz stream is not algorithmic traffic")
+    add("adeclick", 16 * m, windows * (2 * 2425 * 49 * 2 + 2 * 48 * 48) + repaired * 2 * (2 * 49 + 30 * 30 + 4 * 30), F64,
+        "per window: 49-lag autocorrelation + 49-tap detector + Levinson-Durbin; per flagged sample (two windows each): right-hand side, banded LDL^T (~30 rows), substitution")
+    add("brickwall alimiter + s16", 16 * m + 8 * m + 6 * m, 6 * m, F64, "f64 in / out, f32 + s16 out")
+    total = sum(x["floor_ms"] for x in st)
+    return {"floor_ms": round(total, 3), "stages": st,
+            "peaks": {"hbm_TBps": 8.0, "f32_fma_TFLOPs": 157.3, "f32_no_fma_TFLOPs": 78.6, "f64_TFLOPs": 78.6}}
+
+
 def variant_leg(eng, y, x_dev, n, sr, seconds, base, hostlogic, what):
     """The same step on another talker (reported beside `value`, never part of it): 5 steps, the best of the last 3."""
     import torch
@@ -509,6 +544,9 @@ def main():
                                                         "(register-resident LDL^T, two windows / one window per wave) [+ k_adeclick_fast levels 1, 2 for overflow windows]",
                     "bound": "hbm", "achieved": round(dk_bytes / dk_avg_s / 1e9, 2), "peak": 8000,
                     "unit": "GB/s", "frac": round(dk_bytes / dk_avg_s / 1e9 / 8000, 5), "traffic": None,
+                    "bound_by_counters": "dependent LDS round trips / f64 issue (waves waiting > 50 % of their time, profiles/*_pmc_issue.txt); the HBM "
+                                         "fraction above is the contract's figure for the dominant kernel, the f64 figure below is the ceiling that applies",
+                    "f64": None,
                     "note": "dominant stage (HIP-event time over its launches); not bandwidth bound: a window is an AR fit, a detector and a banded "
                             "LDL^T solve whose pivots are a dependent chain; the solvers keep the trailing block in registers and wait on LDS "
                             "round trips 60 % of their wave time at 11 waves per CU (profiles/r03_pmc_issue.txt, DESIGN.md s4/s9)",
@@ -562,10 +600,19 @@ def main():
             "stage_wall_ms": dict(zip(["pass1", "intervals_vad", "bands", "adapt", "pass2", "regions2", "plan", "pass3", "pass4", "regions4"],
                                       [round(float(v), 3) for v in res.stage_ms])),
             "pipeline_hbm": {"algorithmic_bytes_per_file": alg_bytes_file,
-                             "achieved_GBps": round(alg_bytes_file * world * args.steps / dt / 1e9, 2), "peak_GBps": 8000},
+                             "achieved_GBps": round(alg_bytes_file * world * args.steps / dt / 1e9, 2), "peak_GBps": 8000,
+                             "frac": round(alg_bytes_file * world * args.steps / dt / 1e9 / 8000, 6)},
+            "compute_aware_floor": None,
             "roofline": roof,
             "second_kernel": nlm_roof,
         }
+        fl = compute_aware_floor(n, m, sr, bool(res.limiter.needed), int(eng.timers()["declick_repaired"]), (m + 1211) // 1212)
+        fl["step_over_floor"] = round(dt / args.steps * 1e3 / fl["floor_ms"], 2)
+        out["compute_aware_floor"] = fl
+        if roof.get("kernel") == "k_adeclick":
+            dkf = next(x for x in fl["stages"] if x["stage"] == "adeclick")["flops"]
+            roof["f64"] = {"flops": dkf, "achieved_TFLOPs": round(dkf / dk_avg_s / 1e12, 2), "peak_TFLOPs": 78.6, "frac": round(dkf / dk_avg_s / 1e12 / 78.6, 4),
+                           "note": "the stage's own f64 operation count (compute_aware_floor) over its HIP-event time, against the f64 vector peak"}
         if sat is not None:
             out["resident_in_flight"] = sat
         if io_legs is not None:

@@ -317,8 +317,14 @@ static void pass_begin(jt_ctx *h, int64_t max_samples, int analyses, int64_t ext
     h->pin.begin(jt_arena_bytes_for(max_samples) * na + jt_arena_bytes_for(extra_samples) * ne + (4u << 20));
     h->kw_begin((size_t)(max_samples / 512 + 1024) * 12 * na + ((size_t)(extra_samples / 512 + 1024) * 8 + (size_t)extra_samples / 128 + 16384) * ne);   // + the regions' own scratch
     h->as_begin(((size_t)(2u << 20) + (size_t)max_samples / 6) * na + ((size_t)(2u << 20) + (size_t)extra_samples / 6) * ne);
-    // the remaining analysis scratch is shared by jobs that are serialised on one stream; size it now, while nothing is queued
-    h->d_scr1.ensure((size_t)(max_samples / 400 + 16));
+    // per-100 ms true-peak maxima of every analysis of the pass (the full-length one and the announced regions'): atomicMax targets, so
+    // they start from zero -- ONE fill for the pass, queued on the main stream ahead of every fork, instead of one per analysis
+    {
+        const size_t slab = (size_t)(max_samples / 400 + 16) * na + (size_t)(extra_samples / 400 + 16) * ne;
+        h->d_scr1.ensure(slab);
+        JT_HIP(hipMemsetAsync(h->d_scr1.p, 0, sizeof(double) * slab, h->stream));
+        h->tp_off = 0; h->tp_cap = slab;
+    }
     h->spec_hops.ensure((size_t)(max_samples / 512 + 16));
     h->ehist.ensure(8192);
 }
@@ -345,7 +351,7 @@ static void analysis_join(jt_ctx *h, int sets = 1)
 // where one analysis runs: the four streams aux[first .. first+3] and its block-true-peak / hop / histogram scratch (null = the
 // context's shared buffers, which serialise jobs on one stream set)
 // `from`: the stream whose queued work produces the signal (null = the main stream)
-struct AnalysisLanes { int first = 0; double *tp = nullptr; jt_spectral *hops = nullptr; unsigned long long *ehist = nullptr; hipStream_t from = nullptr; };
+struct AnalysisLanes { int first = 0; bool direct = false; hipStream_t from = nullptr; };      // direct: small results go straight into the pinned arena
 static void fork_aux(jt_ctx *h, int first, int last, hipStream_t from = nullptr)
 {
     JT_HIP(hipEventRecord(h->ev_fork, from ? from : h->stream));
@@ -373,8 +379,8 @@ static void analysis_enqueue(jt_ctx *h, const float *x, int64_t n, int sr, bool 
         const int blk = sr / 10; const int64_t nfull = n / blk;
         J->blk = blk; J->nfull = nfull;
         SwrDev &sw = get_swr(h, sr, 192000);
-        double *d_tp = ln && ln->tp ? ln->tp : (h->d_scr1.ensure((size_t)nfull + 2), h->d_scr1.p);
-        JT_HIP(hipMemsetAsync(d_tp, 0, sizeof(double) * (nfull + 2), a3));
+        JT_REQUIRE(h->tp_off + (size_t)nfull + 2 <= h->tp_cap, JT_E_HIP, "true-peak scratch exhausted");
+        double *d_tp = h->d_scr1.p + h->tp_off; h->tp_off += ((size_t)nfull + 2 + 7) & ~(size_t)7;      // (zeroed by pass_begin)
         launch_true_peak_f32(x, n, sw.bank_d.p, sw.pl.phase_count, sw.pl.filter_length, sw.pl.center, sw.pl.step, blk, d_tp, nfull + 1,
                              sw.out_len(n), a3);
         double *btp = h->pin.take<double>((size_t)nfull + 2);
@@ -388,7 +394,7 @@ static void analysis_enqueue(jt_ctx *h, const float *x, int64_t n, int sr, bool 
             JT_HIP(hipStreamWaitEvent(a2, h->early_p3.ev[1], 0));
         }
     }
-    if (J->want_astats) jt_astats_enqueue(h, x, n, sr, &J->as, a0, a1, a2, ln ? ln->ehist : nullptr, J->astats_levels_only);
+    if (J->want_astats) jt_astats_enqueue(h, x, n, sr, &J->as, a0, a1, a2, nullptr, J->astats_levels_only);
     if (!f) JT_HIP(hipEventRecord(h->ev_chain[4], a2));
     if (J->want_spec) {
         const int win = 2048, hop = win / 2;
@@ -397,10 +403,15 @@ static void analysis_enqueue(jt_ctx *h, const float *x, int64_t n, int sr, bool 
         if (sel_blk > 0) nframes = n / sel_blk + ((n % sel_blk) ? 1 : 0);
         const int64_t nout = sel_blk > 0 ? nframes : nhops;
         J->nhops = nhops; J->nout = nout;
-        jt_spectral *d_hops = ln && ln->hops ? ln->hops : (h->spec_hops.ensure((size_t)std::max<int64_t>(nout, 1)), h->spec_hops.p);
-        launch_aspectralstats(x, n, sr, win, h->twiddle.p, h->hann.p, d_hops, nhops, sel_blk, nframes, a2);
         jt_spectral *hops = h->pin.take<jt_spectral>((size_t)std::max<int64_t>(nout, 1));
-        if (nout > 0) JT_HIP(hipMemcpyAsync(hops, d_hops, sizeof(jt_spectral) * nout, hipMemcpyDeviceToHost, a2));
+        if (ln && ln->direct) {
+            // an announced region: a few dozen records, written by the kernel straight into the pinned arena (no copy to queue)
+            launch_aspectralstats(x, n, sr, win, h->twiddle.p, h->hann.p, hops, nhops, sel_blk, nframes, a2);
+        } else {
+            h->spec_hops.ensure((size_t)std::max<int64_t>(nout, 1));
+            launch_aspectralstats(x, n, sr, win, h->twiddle.p, h->hann.p, h->spec_hops.p, nhops, sel_blk, nframes, a2);
+            if (nout > 0) JT_HIP(hipMemcpyAsync(hops, h->spec_hops.p, sizeof(jt_spectral) * nout, hipMemcpyDeviceToHost, a2));
+        }
         J->hops = hops;
     }
     if (!f) for (int i = 0; i < 4; ++i) JT_HIP(hipEventRecord(h->ev_chain[i], h->aux[i]));
@@ -577,18 +588,14 @@ static bool regions_resolve(const double start_s[2], const double dur_s[2], int 
 static void regions_enqueue(jt_ctx *h, const int16_t *src, int rate, RegionJobs *R, bool own_lanes, hipStream_t from = nullptr)
 {
     h->region_f.ensure((size_t)(R->len[0] + R->len[1] + 1));
-    for (int r = 0; r < 2; ++r)
-        if (R->want[r]) launch_s16_to_f32(src ? src + R->s0[r] : R->src[r], h->region_f.p + (r ? R->len[0] : 0), R->len[r], from ? from : h->stream);
+    {   // both regions' samples in one launch
+        const int16_t *s0 = R->want[0] ? (src ? src + R->s0[0] : R->src[0]) : nullptr, *s1 = R->want[1] ? (src ? src + R->s0[1] : R->src[1]) : nullptr;
+        launch_s16_to_f32_pair(s0, R->want[0] ? R->len[0] : 0, s1, R->want[1] ? R->len[1] : 0, h->region_f.p, h->region_f.p + R->len[0], from ? from : h->stream);
+    }
     for (int r = 0; r < 2; ++r) {
         if (!R->want[r]) continue;
         AnalysisLanes ln; ln.from = from;
-        if (own_lanes) {
-            const int64_t nfull = R->len[r] / (rate / 10), nout = nfull + 2;
-            const size_t hop_d = (sizeof(jt_spectral) * (size_t)nout + 7) / 8;
-            double *scr = h->kw_take((size_t)nfull + 2 + hop_d + 8192);
-            ln.first = 4; ln.tp = scr; ln.hops = reinterpret_cast<jt_spectral *>(scr + nfull + 2);
-            ln.ehist = reinterpret_cast<unsigned long long *>(scr + nfull + 2 + hop_d);
-        }
+        if (own_lanes) { ln.first = 4; ln.direct = true; }
         R->J[r].astats_levels_only = !h->opts.region_full_astats;      // (regions_finish reads the levels and the crest factor only)
         analysis_enqueue(h, h->region_f.p + (r ? R->len[0] : 0), R->len[r], rate, false, rate / 10, &R->J[r], false, own_lanes ? &ln : nullptr);
     }
@@ -699,9 +706,9 @@ static void run_afftdn(jt_ctx *h, const float *in, float *out, int64_t n, int sr
     ensure_twiddle(h, pl.L);
     const size_t nb = pl.nbands, bins = pl.bins;
     const size_t ndbl = pl.W + nb + nb + nb * nb + bins + bins + bins;
-    h->af_tab.ensure(ndbl); h->af_bin2band.ensure(bins);
-    // staged in the pinned arena: the copies stay valid until the pass's single synchronisation
-    double *tab = h->pin.take<double>(ndbl); double *w = tab;
+    h->af_tab.ensure(ndbl + (bins + 1) / 2);
+    // staged in the pinned arena: the copy stays valid until the pass's single synchronisation (tables | bin -> band map: one upload)
+    double *tab = h->pin.take<double>(ndbl + (bins + 1) / 2); double *w = tab;
     w = std::copy(pl.window.begin(), pl.window.end(), w);
     w = std::copy(pl.alpha.begin(), pl.alpha.end(), w);
     w = std::copy(pl.beta.begin(), pl.beta.end(), w);
@@ -709,13 +716,12 @@ static void run_afftdn(jt_ctx *h, const float *in, float *out, int64_t n, int sr
     w = std::copy(pl.abs_var.begin(), pl.abs_var.end(), w);
     w = std::copy(pl.min_abs_var.begin(), pl.min_abs_var.end(), w);
     w = std::copy(pl.rel_var.begin(), pl.rel_var.end(), w);
-    int *b2b = h->pin.take<int>(bins);
+    int *b2b = reinterpret_cast<int *>(tab + ndbl);
     std::copy(pl.bin2band.begin(), pl.bin2band.end(), b2b);
-    JT_HIP(hipMemcpyAsync(h->af_tab.p, tab, sizeof(double) * ndbl, hipMemcpyHostToDevice, h->stream));
-    JT_HIP(hipMemcpyAsync(h->af_bin2band.p, b2b, sizeof(int) * bins, hipMemcpyHostToDevice, h->stream));
+    JT_HIP(hipMemcpyAsync(h->af_tab.p, tab, sizeof(double) * (ndbl + (bins + 1) / 2), hipMemcpyHostToDevice, h->stream));
     AfftdnDev d;
     d.A = pl.A; d.W = pl.W; d.L = pl.L; d.bins = pl.bins; d.nbands = pl.nbands; d.max_gain = pl.max_gain;
-    d.bin2band = h->af_bin2band.p;
+    d.bin2band = reinterpret_cast<const int *>(h->af_tab.p + ndbl);
     d.window = h->af_tab.p; d.alpha = d.window + pl.W; d.beta = d.alpha + nb; d.spread = d.beta + nb;
     d.abs_var = d.spread + nb * nb; d.min_abs_var = d.abs_var + bins; d.rel_var = d.min_abs_var + bins; d.twiddle = h->twiddle.p;
     d.floor = pl.floor;
@@ -1353,14 +1359,12 @@ extern "C" int jt_pass4(jt_ctx *h, const jt_limiter_plan *lim, const jt_loudnorm
     if (ap->adeclick_enabled) {
         std::string why;
         JT_REQUIRE(jt_adeclick_supported(rate, ap->adeclick_window_ms, ap->adeclick_overlap_pct, 2.0, ap->adeclick_method, &why), JT_E_UNSUPPORTED, why);
-        h->declick_stats.ensure(16);
-        JT_HIP(hipMemsetAsync(h->declick_stats.p, 0, 16 * sizeof(unsigned long long), h->stream));
         JT_HIP(hipEventRecord(h->ev2, h->stream));
         launch_adeclick(h, sig, tmp, m, rate, ap->adeclick_threshold, ap->adeclick_window_ms, ap->adeclick_overlap_pct, 2.0, 2.0, gain,
-                        h->declick_stats.p, h->stream, ap->adeclick_method);
+                        nullptr, h->stream, ap->adeclick_method);
         JT_HIP(hipEventRecord(h->ev3, h->stream));
         unsigned long long *hs = h->pin.take<unsigned long long>(16);
-        JT_HIP(hipMemcpyAsync(hs, h->declick_stats.p, 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));
+        JT_HIP(hipMemcpyAsync(hs, h->declick_ctl.p + 288, 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));
         dk_stats = hs;
         std::swap(sig, tmp);
         brick_gain = 1.0;
@@ -1620,11 +1624,9 @@ extern "C" int jt_op_adeclick_f64(jt_ctx *h, const double *in, double *out, int6
     std::string why;
     JT_REQUIRE(jt_adeclick_supported(sr, window_ms, overlap_pct, 2.0, method, &why), JT_E_UNSUPPORTED, why);
     DevBuf<double> a, b; h2d(h, a, in, (size_t)n); b.ensure((size_t)n);
-    h->declick_stats.ensure(16);
-    JT_HIP(hipMemsetAsync(h->declick_stats.p, 0, 16 * sizeof(unsigned long long), h->stream));
-    launch_adeclick(h, a.p, b.p, n, sr, threshold, window_ms, overlap_pct, 2.0, 2.0, 1.0, h->declick_stats.p, h->stream, method);
+    launch_adeclick(h, a.p, b.p, n, sr, threshold, window_ms, overlap_pct, 2.0, 2.0, 1.0, nullptr, h->stream, method);
     unsigned long long st[16] = {0};
-    JT_HIP(hipMemcpyAsync(st, h->declick_stats.p, sizeof(st), hipMemcpyDeviceToHost, h->stream));
+    JT_HIP(hipMemcpyAsync(st, h->declick_ctl.p + 288, sizeof(st), hipMemcpyDeviceToHost, h->stream));
     d2h(h, out, b.p, (size_t)n);
     if (JT_AB_ON(h->opts.dk_profile)) { fprintf(stderr, "adeclick phase clocks:"); for (int i = 4; i < 12; ++i) fprintf(stderr, " %llu", st[i]); fprintf(stderr, " heavy %llu", st[2]); fprintf(stderr, "\n"); }
     if (n_repaired) *n_repaired = (int64_t)st[0];

@@ -141,6 +141,7 @@ void launch_frame_stats(const float *in, int64_t n_total /*frames*channels*/, in
 void launch_frame_sumsq_s16(const int16_t *in, int64_t n, int spf, double *sumsq, int64_t nframes, hipStream_t s);
 void launch_downmix(const float *in, float *out, int64_t frames, int channels, int mode, hipStream_t s);
 void launch_s16_to_f32(const int16_t *in, float *out, int64_t n, hipStream_t s);
+void launch_s16_to_f32_pair(const int16_t *in0, int64_t n0, const int16_t *in1, int64_t n1, float *out0, float *out1, hipStream_t s);   // two ranges, one launch
 void launch_s16_to_f64(const int16_t *in, double *out, int64_t n, double gain, int gain_in_float, hipStream_t s);
 void launch_biquad_f32(const float *in, float *out, int64_t n, int nstages, const BiquadF32 *st, hipStream_t s);
 struct DynParams {
@@ -382,6 +383,7 @@ struct jt_ctx {
         unsigned char *r = reinterpret_cast<unsigned char *>(d_scr2.p) + as_off; as_off += (bytes + 255) & ~(size_t)255; return r;
     }
     // per-pass bump allocator over d_scr0 for the K-weighting jobs (several can be in flight before the pass's sync)
+    size_t tp_off = 0, tp_cap = 0;      // bump allocator over d_scr1: the per-block true-peak maxima of a pass (zeroed once by pass_begin)
     size_t kw_off = 0;
     void kw_begin(size_t doubles) { d_scr0.ensure(doubles); kw_off = 0; }
     double *kw_take(size_t doubles) {
@@ -390,7 +392,7 @@ struct jt_ctx {
     }
     SwrDev swr[4]; int swr_next = 0;
     // K-weighting: homogeneous-response tables of the one-sweep kernel, per (rate, chunk length)
-    struct KwTab { int rate = 0; int64_t L = 0; std::vector<double> g; DevBuf<double> dev; } kw_tab[8]; int kw_tab_next = 0;
+    struct KwTab { int rate = 0; int64_t L = 0; std::vector<double> g; DevBuf<double> dev; int nterms = 1; double gram[10]; } kw_tab[8]; int kw_tab_next = 0;   // g: table [L][4] | powers of F^L
     DevBuf<double> p3_mpow; int p3_mpow_P = 0;         // the fused Pass-3 sweep's fold matrices (k_p3_fused), per period length
     DevBuf<float> region_f; DevBuf<int16_t> region_s16;
     // Pass 3's measurement of the Pass-2 output for the no-prefix plan (the usual one), queued by Pass 2 itself on a stream of

@@ -27,14 +27,18 @@ __device__ inline unsigned long long wsumu(unsigned long long v) { for (int o = 
 __device__ inline unsigned long long woru(unsigned long long v) { for (int o = 32; o > 0; o >>= 1) v |= __shfl_down(v, o, 64); return v; }
 __device__ inline unsigned long long wandu(unsigned long long v) { for (int o = 32; o > 0; o >>= 1) v &= __shfl_down(v, o, 64); return v; }
 
+// HIST = false: without the entropy histogram (the announced regions' samples report levels only: no LDS atomics, no zeroed buffer)
+template <bool HIST>
 __global__ void __launch_bounds__(AS_T)
 k_as_reduce(const float *__restrict__ x, int64_t n, AsPartial *__restrict__ part, unsigned long long *__restrict__ ehist)
 {
-    __shared__ unsigned int lh[8192];
+    __shared__ unsigned int lh[HIST ? 8192 : 1];
     __shared__ AsPartial sp[AS_T / 64];
     const int tid = threadIdx.x;
-    for (int i = tid; i < 8192; i += AS_T) lh[i] = 0;
-    __syncthreads();
+    if (HIST) {
+        for (int i = tid; i < 8192; i += AS_T) lh[i] = 0;
+        __syncthreads();
+    }
     double mn = DBL_MAX, mx = -DBL_MAX, mnz = DBL_MAX, sx = 0, sx2 = 0, mind = DBL_MAX, maxd = 0, d1 = 0, d2 = 0;
     unsigned long long zr = 0, mor = 0, mand = ~0ull, cnt = 0;
     const int64_t stride = (int64_t)gridDim.x * AS_T;
@@ -61,9 +65,11 @@ k_as_reduce(const float *__restrict__ x, int64_t n, AsPartial *__restrict__ part
             const int cs = d > 0 ? 1 : -1;
             zr += (cs != ps);
         }
-        int h = (int)rint(fmin(fmax(ad, 0.0), 1.0) * 8191.0);
-        h = h < 0 ? 0 : (h > 8191 ? 8191 : h);
-        atomicAdd(&lh[h], 1u);
+        if (HIST) {
+            int h = (int)rint(fmin(fmax(ad, 0.0), 1.0) * 8191.0);
+            h = h < 0 ? 0 : (h > 8191 ? 8191 : h);
+            atomicAdd(&lh[h], 1u);
+        }
         const long long iv = (long long)llrint(d * 2147483648.0);
         mor |= (unsigned long long)iv; mand &= (unsigned long long)iv;
         cnt++;
@@ -92,23 +98,28 @@ k_as_reduce(const float *__restrict__ x, int64_t n, AsPartial *__restrict__ part
         }
         part[blockIdx.x] = a;
     }
-    for (int i = tid; i < 8192; i += AS_T) if (lh[i]) atomicAdd(&ehist[i], (unsigned long long)lh[i]);
-}
-
-__global__ void k_as_minmax(const AsPartial *__restrict__ part, int nparts, double *__restrict__ mm)
-{
-    double mn = DBL_MAX, mx = -DBL_MAX;
-    for (int i = threadIdx.x; i < nparts; i += 64) { mn = fmin(mn, part[i].min); mx = fmax(mx, part[i].max); }
-    mn = wmin(mn); mx = wmax(mx);
-    if (threadIdx.x == 0) { mm[0] = mn; mm[1] = mx; }
+    if (HIST) for (int i = tid; i < 8192; i += AS_T) if (lh[i]) atomicAdd(&ehist[i], (unsigned long long)lh[i]);
 }
 
 // run statistics at the global extrema: min_count = #samples == min; min_runs = sum over maximal runs of len^2
+// (the global extrema come from the reduce sweep's partials: every workgroup folds them itself -- at most 2048 entries -- instead of a
+// one-workgroup launch in between; workgroup 0 leaves them in mm[] for the host)
 __global__ void __launch_bounds__(AS_T)
-k_as_runs(const float *__restrict__ x, int64_t n, const double *__restrict__ mm, AsRuns *__restrict__ part)
+k_as_runs(const float *__restrict__ x, int64_t n, const AsPartial *__restrict__ rpart, int nrparts, double *__restrict__ mm, AsRuns *__restrict__ part)
 {
     __shared__ AsRuns sp[AS_T / 64];
-    const float gmin = (float)mm[0], gmax = (float)mm[1];
+    __shared__ double smm[2][AS_T / 64];
+    {
+        double mn = DBL_MAX, mx = -DBL_MAX;
+        for (int i = threadIdx.x; i < nrparts; i += AS_T) { mn = fmin(mn, rpart[i].min); mx = fmax(mx, rpart[i].max); }
+        mn = wmin(mn); mx = wmax(mx);
+        if ((threadIdx.x & 63) == 0) { smm[0][threadIdx.x >> 6] = mn; smm[1][threadIdx.x >> 6] = mx; }
+        __syncthreads();
+    }
+    double gmn = smm[0][0], gmx = smm[1][0];
+    for (int w = 1; w < AS_T / 64; ++w) { gmn = fmin(gmn, smm[0][w]); gmx = fmax(gmx, smm[1][w]); }
+    if (blockIdx.x == 0 && threadIdx.x == 0) { mm[0] = gmn; mm[1] = gmx; }
+    const float gmin = (float)gmn, gmax = (float)gmx;
     double c0 = 0, r0 = 0, c1 = 0, r1 = 0;
     const int64_t stride = (int64_t)gridDim.x * AS_T;
     for (int64_t i = (int64_t)blockIdx.x * AS_T + threadIdx.x; i < n; i += stride) {
@@ -320,38 +331,36 @@ k_as_zs(const float *__restrict__ x, int64_t n, double mult, double mult_chunk, 
     if (lane == 63) { blkA[blockIdx.x] = A; blkB[blockIdx.x] = B; }
 }
 
-// carry scan over the per-block affine maps (one map per 64 chunks, composed in k_as_zs): state entering every block.
-// One wave; 64 maps per round by a wave-level inclusive scan, the loads of the next round issued ahead.
-__global__ void __launch_bounds__(64)
-k_as_scan(const double *__restrict__ blkA, const double *__restrict__ blkB, double *__restrict__ blk_in, int64_t nblocks)
-{
-    const int lane = threadIdx.x;
-    double carry_in = 0.0;
-    double nA = lane < nblocks ? blkA[lane] : 1.0, nB = lane < nblocks ? blkB[lane] : 0.0;
-    for (int64_t base = 0; base < nblocks; base += 64) {
-        double A = nA, B = nB;
-        const int64_t nx = base + 64 + lane;
-        nA = nx < nblocks ? blkA[nx] : 1.0; nB = nx < nblocks ? blkB[nx] : 0.0;
-        for (int o = 1; o < 64; o <<= 1) {
-            const double Ap = __shfl_up(A, o, 64), Bp = __shfl_up(B, o, 64);
-            if (lane >= o) { B = A * Bp + B; A = A * Ap; }
-        }
-        const double s_after = A * carry_in + B;
-        double prev = __shfl_up(s_after, 1, 64);
-        if (lane == 0) prev = carry_in;
-        if (base + lane < nblocks) blk_in[base + lane] = prev;
-        carry_in = __shfl(s_after, 63, 64);
-    }
-}
-
+// (the carry scan over the per-block affine maps -- the state entering every block of 64 chunks -- is done by each k_as_sigma workgroup for
+// its own block: the wave-level inclusive scan in rounds of 64 maps that a one-wave kernel used to run in between, stopped at the block)
 __global__ void __launch_bounds__(64)
 k_as_sigma(const float *__restrict__ x, int64_t n, int tc, double mult, double mult_chunk, const double *__restrict__ zs,
-           const double *__restrict__ blk_in, double *__restrict__ out_min, double *__restrict__ out_max, int64_t nchunks)
+           const double *__restrict__ blkA, const double *__restrict__ blkB, double *__restrict__ out_min, double *__restrict__ out_max, int64_t nchunks)
 {
     __shared__ float tile[64][65];
     const int lane = threadIdx.x;
     const int64_t c0 = (int64_t)blockIdx.x * 64;
     const int nrows = (int)min((int64_t)64, nchunks - c0);
+    // state entering this block: the maps of blocks 0 .. blockIdx.x - 1 composed in order (rounds of 64, the next round's loads issued ahead)
+    double block_in = 0.0;
+    {
+        const int64_t nb = blockIdx.x;
+        double carry_in = 0.0;
+        double nA = lane < nb ? blkA[lane] : 1.0, nB = lane < nb ? blkB[lane] : 0.0;
+        for (int64_t base = 0; base < nb; base += 64) {
+            double A = nA, B = nB;
+            const int64_t nx = base + 64 + lane;
+            nA = nx < nb ? blkA[nx] : 1.0; nB = nx < nb ? blkB[nx] : 0.0;
+            for (int o = 1; o < 64; o <<= 1) {
+                const double Ap = __shfl_up(A, o, 64), Bp = __shfl_up(B, o, 64);
+                if (lane >= o) { B = A * Bp + B; A = A * Ap; }
+            }
+            const double s_after = A * carry_in + B;
+            // the state after map nb - 1 is what enters this block (the same lane's value the one-wave scan kernel stored for it)
+            carry_in = __shfl(s_after, (int)min((int64_t)63, nb - 1 - base), 64);
+        }
+        block_in = carry_in;
+    }
     // state entering this lane's chunk: the block's entering state pushed through the preceding chunks of the block
     double avg;
     {
@@ -361,7 +370,7 @@ k_as_sigma(const float *__restrict__ x, int64_t n, int tc, double mult, double m
             const double Ap = __shfl_up(A, o, 64), Bp = __shfl_up(B, o, 64);
             if (lane >= o) { B = A * Bp + B; A = A * Ap; }
         }
-        const double cin = blk_in[blockIdx.x];
+        const double cin = block_in;
         const double s_after = A * cin + B;
         avg = __shfl_up(s_after, 1, 64);
         if (lane == 0) avg = cin;
@@ -412,9 +421,10 @@ void jt_astats_enqueue(jt_ctx *h, const float *x, int64_t n, int sr, AstatsJob *
     const int nparts = (int)std::min<int64_t>((n + AS_T - 1) / AS_T, 2048);
     const int64_t nchunks = (n + ZC - 1) / ZC;
     const int nsig = (int)((nchunks + 63) / 64);
-    // scratch layout (bytes): [head: partials | runs | nf | mm[2] | smin[nsig] | smax[nsig]] | zs[nchunks] | carry[nchunks]
-    const size_t o_part = 0, o_runs = o_part + sizeof(AsPartial) * nparts, o_nf = o_runs + sizeof(AsRuns) * nparts,
-                 o_mm = o_nf + sizeof(AsNF) * nparts, o_smin = o_mm + 16, o_smax = o_smin + 8 * (size_t)nsig,
+    // scratch layout (bytes): [head: partials | runs | mm[2] | entropy histogram[8192] | nf | smin[nsig] | smax[nsig]] | zs[nchunks] | carry[nchunks]
+    // (what one chain writes is contiguous: chain A partials .. histogram, chain B nf, chain C smin | smax -- one copy per chain)
+    const size_t o_part = 0, o_runs = o_part + sizeof(AsPartial) * nparts, o_mm = o_runs + sizeof(AsRuns) * nparts, o_eh = o_mm + 16,
+                 o_nf = o_eh + 8 * (size_t)8192, o_smin = o_nf + sizeof(AsNF) * nparts, o_smax = o_smin + 8 * (size_t)nsig,
                  head = o_smax + 8 * (size_t)nsig, o_zs = head, o_carry = o_zs + 8 * (size_t)nchunks,
                  total = o_carry + 8 * 3 * (size_t)nsig;      // blkA | blkB | blk_in
     unsigned char *base = h->as_take(total);
@@ -424,19 +434,21 @@ void jt_astats_enqueue(jt_ctx *h, const float *x, int64_t n, int sr, AstatsJob *
     double *d_mm = reinterpret_cast<double *>(base + o_mm), *d_zs = reinterpret_cast<double *>(base + o_zs),
            *d_carry = reinterpret_cast<double *>(base + o_carry), *d_smin = reinterpret_cast<double *>(base + o_smin),
            *d_smax = reinterpret_cast<double *>(base + o_smax);
-    if (ehist) JT_HIP(hipMemsetAsync(ehist, 0, sizeof(unsigned long long) * 8192, sA));
-    else { h->ehist.ensure(8192); h->ehist.zero(sA); ehist = h->ehist.p; }
-    hipLaunchKernelGGL(k_as_reduce, dim3(nparts), dim3(AS_T), 0, sA, x, n, d_part, ehist);
+    (void)ehist;                                                       // every job has its own histogram inside its scratch block
+    ehist = reinterpret_cast<unsigned long long *>(base + o_eh);
     if (levels_only) {
-        // a region sample reports the RMS / peak levels and the crest factor only (regions_finish): one sweep instead of nine launches
+        // a region sample reports the RMS / peak levels and the crest factor only (regions_finish): one sweep instead of nine launches,
+        // its few partials written straight into the pinned arena (device-visible host memory: no copy to queue)
         unsigned char *hb = h->pin.take<unsigned char>(o_runs);
-        JT_HIP(hipMemcpyAsync(hb + o_part, base + o_part, o_runs - o_part, hipMemcpyDeviceToHost, sA));
+        hipLaunchKernelGGL(k_as_reduce<false>, dim3(nparts), dim3(AS_T), 0, sA, x, n, reinterpret_cast<AsPartial *>(hb + o_part), ehist);
         *job = AstatsJob{};
         job->hb = hb; job->o_part = o_part; job->nparts = nparts; job->n = n; job->levels_only = true;
         return;
+    } else {
+        JT_HIP(hipMemsetAsync(ehist, 0, sizeof(unsigned long long) * 8192, sA));
+        hipLaunchKernelGGL(k_as_reduce<true>, dim3(nparts), dim3(AS_T), 0, sA, x, n, d_part, ehist);
     }
-    hipLaunchKernelGGL(k_as_minmax, dim3(1), dim3(64), 0, sA, d_part, nparts, d_mm);
-    hipLaunchKernelGGL(k_as_runs, dim3(nparts), dim3(AS_T), 0, sA, x, n, d_mm, d_runs);
+    hipLaunchKernelGGL(k_as_runs, dim3(nparts), dim3(AS_T), 0, sA, x, n, (const AsPartial *)d_part, nparts, d_mm, d_runs);
     const bool have_nf = n >= tc;
     int nf_parts = nparts;
     if (have_nf) {
@@ -458,17 +470,14 @@ void jt_astats_enqueue(jt_ctx *h, const float *x, int64_t n, int sr, AstatsJob *
         }
     }
     const double mult_chunk = std::pow(mult, (double)ZC);
-    double *d_blkA = d_carry, *d_blkB = d_carry + nsig, *d_blkin = d_carry + 2 * (size_t)nsig;
+    double *d_blkA = d_carry, *d_blkB = d_carry + nsig;
     hipLaunchKernelGGL(k_as_zs, dim3((unsigned)nsig), dim3(64), 0, sC, x, n, mult, mult_chunk, d_zs, d_blkA, d_blkB, nchunks);
-    hipLaunchKernelGGL(k_as_scan, dim3(1), dim3(64), 0, sC, d_blkA, d_blkB, d_blkin, (int64_t)nsig);
-    hipLaunchKernelGGL(k_as_sigma, dim3((unsigned)nsig), dim3(64), 0, sC, x, n, tc, mult, mult_chunk, d_zs, d_blkin, d_smin, d_smax, nchunks);
+    hipLaunchKernelGGL(k_as_sigma, dim3((unsigned)nsig), dim3(64), 0, sC, x, n, tc, mult, mult_chunk, d_zs, (const double *)d_blkA, (const double *)d_blkB, d_smin, d_smax, nchunks);
     unsigned char *hb = h->pin.take<unsigned char>(head);
-    unsigned long long *eh = h->pin.take<unsigned long long>(8192);
+    const unsigned long long *eh = reinterpret_cast<const unsigned long long *>(hb + o_eh);
     // one copy per chain, each covering the bytes that chain wrote (the chains may run on different streams)
-    JT_HIP(hipMemcpyAsync(hb + o_part, base + o_part, o_nf - o_part, hipMemcpyDeviceToHost, sA));          // partials | runs
-    JT_HIP(hipMemcpyAsync(hb + o_mm, base + o_mm, 16, hipMemcpyDeviceToHost, sA));
-    JT_HIP(hipMemcpyAsync(eh, ehist, sizeof(unsigned long long) * 8192, hipMemcpyDeviceToHost, sA));
-    if (have_nf) JT_HIP(hipMemcpyAsync(hb + o_nf, base + o_nf, o_mm - o_nf, hipMemcpyDeviceToHost, sB));
+    JT_HIP(hipMemcpyAsync(hb + o_part, base + o_part, o_nf - o_part, hipMemcpyDeviceToHost, sA));          // partials | runs | mm | histogram
+    if (have_nf) JT_HIP(hipMemcpyAsync(hb + o_nf, base + o_nf, o_smin - o_nf, hipMemcpyDeviceToHost, sB));
     JT_HIP(hipMemcpyAsync(hb + o_smin, base + o_smin, head - o_smin, hipMemcpyDeviceToHost, sC));
     job->hb = hb; job->eh = eh; job->o_part = o_part; job->o_runs = o_runs; job->o_nf = o_nf; job->o_smin = o_smin; job->o_smax = o_smax;
     job->nparts = nparts; job->nf_parts = nf_parts; job->nsig = nsig; job->have_nf = have_nf; job->n = n;

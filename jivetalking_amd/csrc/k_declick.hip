@@ -1573,6 +1573,11 @@ bool jt_adeclick_supported(int sample_rate, double window_ms, double overlap_pct
 void launch_adeclick(jt_ctx *h, const double *in, double *out, int64_t n, int sample_rate, double threshold, double window_ms,
                      double overlap_pct, double ar_pct, double burst, double gain, unsigned long long *d_stats, hipStream_t s, int method)
 {
+    // control words (per-XCD work heads, list lengths: [0, 288)) and the stage's statistics ([288, 304)) share one buffer and ONE fill;
+    // d_stats == nullptr: the statistics live there (jt_adeclick_stats)
+    h->declick_ctl.ensure(304);
+    JT_HIP(hipMemsetAsync(h->declick_ctl.p, 0, 304 * sizeof(unsigned long long), s));
+    if (!d_stats) d_stats = h->declick_ctl.p + 288;
     DeclickParams P;
     P.W = (int)(sample_rate * window_ms / 1000.); if (P.W < 100) P.W = 100;
     P.ar = (int)(P.W * ar_pct / 100.); if (P.ar < 1) P.ar = 1;
@@ -1647,11 +1652,10 @@ void launch_adeclick(jt_ctx *h, const double *in, double *out, int64_t n, int sa
             const int wp = (P.W + 63) & ~63;
             h->declick_F.ensure((size_t)P.nwindows); h->declick_lists.ensure(2 * (size_t)P.nwindows);
             h->declick_idx.ensure((size_t)P.nwindows * wp); h->declick_rhs.ensure((size_t)P.nwindows * wp);
-            h->declick_aux.ensure((size_t)P.nwindows * 56); h->declick_ctl.ensure(288);
+            h->declick_aux.ensure((size_t)P.nwindows * 56);
             // (r[] and the AR polynomial share one buffer: 64 doubles each per window)
             const bool lev_split = P.ar == dk::MAXAR && !JT_AB_ON(O.dk_levinson_in_kernel);
             if (lev_split) h->declick_r.ensure(2 * (size_t)P.nwindows * 64);
-            JT_HIP(hipMemsetAsync(h->declick_ctl.p, 0, 288 * sizeof(unsigned long long), s));
             SP.F = h->declick_F.p; SP.index = h->declick_idx.p; SP.rhs = h->declick_rhs.p; SP.aux = h->declick_aux.p;
             SP.list32 = h->declick_lists.p; SP.list64 = h->declick_lists.p + P.nwindows; SP.ctl = h->declick_ctl.p; SP.wp = wp;
             SP.xcd = JT_AB_ON(O.dk_no_xcd) ? 0 : 1;
@@ -1672,7 +1676,7 @@ void launch_adeclick(jt_ctx *h, const double *in, double *out, int64_t n, int sa
                 if (half_ok) DKF_LAUNCH((k_adeclick_fast<LIGHT, NC0, ND0, true, 0, 2>), f0, fm0, Q0);
                 else DKF_LAUNCH((k_adeclick_fast<LIGHT, NC0, ND0, false, 0, 2>), f0, fm0, Q0);
                 hipLaunchKernelGGL(k_dk_levinson, dim3((unsigned)((P.nwindows + 63) / 64)), dim3(64), 0, s, SP.r, SP.ac, P.nwindows);
-                JT_HIP(hipMemsetAsync(d_stats + 12, 0, sizeof(unsigned long long), s));
+                if (!SP.xcd) JT_HIP(hipMemsetAsync(d_stats + 12, 0, sizeof(unsigned long long), s));      // (the per-XCD heads of the two launches are separate words)
                 if (half_ok) DKF_LAUNCH((k_adeclick_fast<LIGHT, NC0, ND0, true, 0, 3>), f0, fm0, Q0);
                 else DKF_LAUNCH((k_adeclick_fast<LIGHT, NC0, ND0, false, 0, 3>), f0, fm0, Q0);
             } else if (half_ok) DKF_LAUNCH((k_adeclick_fast<LIGHT, NC0, ND0, true, 0, 1>), f0, fm0, Q0);

@@ -234,6 +234,22 @@ void launch_s16_to_f32(const int16_t *in, float *out, int64_t n, hipStream_t s)
     int grid = (int)std::min<int64_t>((n + 255) / 256, 4096);
     hipLaunchKernelGGL(k_s16_to_f32, dim3(grid), dim3(256), 0, s, in, out, n);
 }
+__global__ void k_s16_to_f32_pair(const int16_t *__restrict__ in0, int64_t n0, const int16_t *__restrict__ in1, int64_t n1, float *__restrict__ out0,
+                                  float *__restrict__ out1)
+{
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; i < n0 + n1; i += stride) {
+        if (i < n0) out0[i] = (float)in0[i] * (1.0f / 32768.0f);
+        else out1[i - n0] = (float)in1[i - n0] * (1.0f / 32768.0f);
+    }
+}
+void launch_s16_to_f32_pair(const int16_t *in0, int64_t n0, const int16_t *in1, int64_t n1, float *out0, float *out1, hipStream_t s)
+{
+    if (n0 + n1 <= 0) return;
+    const int grid = (int)std::min<int64_t>((n0 + n1 + 255) / 256, 4096);
+    hipLaunchKernelGGL(k_s16_to_f32_pair, dim3(grid), dim3(256), 0, s, in0, n0, in1, n1, out0, out1);
+}
 
 // s16 -> dbl (audioconvert: x * (1.0/(1<<15))), optional volume stage in float precision
 // (af_volume.c precision=float: s16 -> flt, scale in float, then flt -> dbl).
@@ -564,36 +580,9 @@ k_kw1(const TIn *__restrict__ in, int64_t n, int64_t L, KwCoef k, const double *
         cross[my_c * 4 + 0] = x0c; cross[my_c * 4 + 1] = x1c; cross[my_c * 4 + 2] = x2c; cross[my_c * 4 + 3] = x3c;
     }
 }
-// csum[c] += 2 s0 . cross[c] + s0' G s0, s0 = the state carried into chunk c (the series k_kw<., true> starts from); G = sum g_j g_j' over the
-// chunk's length (the last chunk may be shorter: Gt), upper triangle row-major
+// csum[c] += 2 s0 . cross[c] + s0' G s0, s0 = the state carried into chunk c; G = sum g_j g_j' over the chunk's length (the last chunk may
+// be shorter: Gt), upper triangle row-major (k_kw_fixblocks)
 struct KwGram { double f[10], t[10]; };
-__global__ void __launch_bounds__(64)
-k_kw_fix(const double *__restrict__ zs_in, const double *__restrict__ fpow, int nterms, const double *__restrict__ cross, KwGram G,
-         double *__restrict__ csum, int64_t nchunks)
-{
-    const int64_t c = (int64_t)blockIdx.x * 64 + threadIdx.x;
-    if (c >= nchunks) return;
-    double s[4] = {0, 0, 0, 0};
-    for (int q = 0; q < nterms; ++q) {
-        const int64_t cc = c - 1 - q;
-        if (cc < 0) break;
-        const double e0 = zs_in[cc * 4 + 0], e1 = zs_in[cc * 4 + 1], e2 = zs_in[cc * 4 + 2], e3 = zs_in[cc * 4 + 3];
-        if (q == 0) { s[0] += e0; s[1] += e1; s[2] += e2; s[3] += e3; }
-        else {
-            const double *M = fpow + (size_t)(q - 1) * 16;
-            s[0] += M[0] * e0 + M[1] * e1 + M[2] * e2 + M[3] * e3;
-            s[1] += M[4] * e0 + M[5] * e1 + M[6] * e2 + M[7] * e3;
-            s[2] += M[8] * e0 + M[9] * e1 + M[10] * e2 + M[11] * e3;
-            s[3] += M[12] * e0 + M[13] * e1 + M[14] * e2 + M[15] * e3;
-        }
-    }
-    const double *Gm = c == nchunks - 1 ? G.t : G.f;
-    double lin = 0.0, quad = 0.0;
-    for (int a = 0; a < 4; ++a) lin += s[a] * cross[c * 4 + a];
-    int u = 0;
-    for (int a = 0; a < 4; ++a) for (int b = a; b < 4; ++b, ++u) quad += (a == b ? 1.0 : 2.0) * Gm[u] * s[a] * s[b];
-    csum[c] = csum[c] + 2.0 * lin + quad;
-}
 #undef KW2_STEP
 
 // Per-block sums / peaks from the per-chunk partials, in chunk order (what the host loop of jt_kweight_finish did over 360 k chunks of an
@@ -607,6 +596,52 @@ k_kw_blocks(const double *__restrict__ csum, const double *__restrict__ cpeak, i
     const int64_t c0 = b * m, c1 = b == nfull ? nchunks : min(nchunks, c0 + m);
     double sum = 0.0, pk = 0.0;
     for (int64_t c = c0; c < c1; ++c) { sum += csum[c]; pk = fmax(pk, cpeak[c]); }
+    out[b] = sum; out[nfull + 1 + b] = pk;
+}
+
+// k_kw_fix and k_kw_blocks as one launch, one thread per 100 ms block: the state carried into the block's first chunk from the series,
+// then chunk by chunk s <- F^L s + e_c (the series' own recurrence; fpow[0..15] = F^L), the carried-state terms added to each chunk's
+// zero-state energy, the block's sum and peak formed in chunk order.  Two launches and a pass over csum fewer per K-weighting job (nine
+// jobs per file).
+__global__ void __launch_bounds__(64)
+k_kw_fixblocks(const double *__restrict__ zs_in, const double *__restrict__ fpow, int nterms, const double *__restrict__ cross, KwGram G,
+               const double *__restrict__ csum, const double *__restrict__ cpeak, int64_t nchunks, int m, int64_t nfull, double *__restrict__ out)
+{
+    const int64_t b = (int64_t)blockIdx.x * 64 + threadIdx.x;
+    if (b > nfull) return;
+    const int64_t c0 = b * m, c1 = b == nfull ? nchunks : min(nchunks, c0 + m);
+    double s[4] = {0, 0, 0, 0};
+    for (int q = 0; q < nterms; ++q) {
+        const int64_t cc = c0 - 1 - q;
+        if (cc < 0) break;
+        const double e0 = zs_in[cc * 4 + 0], e1 = zs_in[cc * 4 + 1], e2 = zs_in[cc * 4 + 2], e3 = zs_in[cc * 4 + 3];
+        if (q == 0) { s[0] += e0; s[1] += e1; s[2] += e2; s[3] += e3; }
+        else {
+            const double *M = fpow + (size_t)(q - 1) * 16;
+            s[0] += M[0] * e0 + M[1] * e1 + M[2] * e2 + M[3] * e3;
+            s[1] += M[4] * e0 + M[5] * e1 + M[6] * e2 + M[7] * e3;
+            s[2] += M[8] * e0 + M[9] * e1 + M[10] * e2 + M[11] * e3;
+            s[3] += M[12] * e0 + M[13] * e1 + M[14] * e2 + M[15] * e3;
+        }
+    }
+    double sum = 0.0, pk = 0.0;
+    for (int64_t c = c0; c < c1; ++c) {
+        const double *Gm = c == nchunks - 1 ? G.t : G.f;
+        double lin = 0.0, quad = 0.0;
+        for (int a = 0; a < 4; ++a) lin += s[a] * cross[c * 4 + a];
+        int u = 0;
+        for (int a = 0; a < 4; ++a) for (int bb = a; bb < 4; ++bb, ++u) quad += (a == bb ? 1.0 : 2.0) * Gm[u] * s[a] * s[bb];
+        sum += csum[c] + 2.0 * lin + quad;
+        pk = fmax(pk, cpeak[c]);
+        if (c + 1 < c1) {
+            const double e0 = zs_in[c * 4 + 0], e1 = zs_in[c * 4 + 1], e2 = zs_in[c * 4 + 2], e3 = zs_in[c * 4 + 3];
+            const double n0 = fpow[0] * s[0] + fpow[1] * s[1] + fpow[2] * s[2] + fpow[3] * s[3] + e0;
+            const double n1 = fpow[4] * s[0] + fpow[5] * s[1] + fpow[6] * s[2] + fpow[7] * s[3] + e1;
+            const double n2 = fpow[8] * s[0] + fpow[9] * s[1] + fpow[10] * s[2] + fpow[11] * s[3] + e2;
+            const double n3 = fpow[12] * s[0] + fpow[13] * s[1] + fpow[14] * s[2] + fpow[15] * s[3] + e3;
+            s[0] = n0; s[1] = n1; s[2] = n2; s[3] = n3;
+        }
+    }
     out[b] = sum; out[nfull + 1 + b] = pk;
 }
 
@@ -629,8 +664,8 @@ static int kw_chunks_per_block(int blk)
 void jt_kweight_scratch_sizes(int64_t n, int blk, size_t *dev_doubles, size_t *pin_doubles, int64_t chunk_len)
 {
     const int64_t L = chunk_len > 0 ? chunk_len : blk / kw_chunks_per_block(blk), nchunks = (n + L - 1) / L;
-    *dev_doubles = 4 * (size_t)nchunks + 24 * 16 + 2 * (size_t)nchunks + 4 * (size_t)nchunks + 64;
-    *pin_doubles = 24 * 16 + 2 * (size_t)nchunks + 64;
+    *dev_doubles = 10 * (size_t)nchunks + 64;                                      // chunk partials (the block sums / peaks go straight to the host)
+    *pin_doubles = 2 * (size_t)(n / blk + 1) + 64;
 }
 
 // The job around a K-weighting sweep: chunk plan, transition-matrix powers, scratch, homogeneous-response table; then `sweep` (k_kw1 over a
@@ -645,77 +680,84 @@ static void kweight_job(jt_ctx *h, int64_t n, int rate, int blk, int64_t chunk_l
     const int64_t L = blk / m;
     JT_REQUIRE(L * m == blk, JT_E_INVAL, "K-weighting: the chunk length must divide the 100 ms block");
     const int64_t nchunks = (n + L - 1) / L;
-    // homogeneous transition matrix (state s1,s2,t1,t2; input 0) and its powers F^L, F^2L, ...
-    double F[16] = {-k.a1, 1, 0, 0,   -k.a2, 0, 0, 0,   k.c1 - k.d1 * k.c0, 0, -k.d1, 1,   k.c2 - k.d2 * k.c0, 0, -k.d2, 0};
-    double FL[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1}, Bq[16];
-    std::memcpy(Bq, F, sizeof(F));
-    for (int64_t e = L; e > 0; e >>= 1) { if (e & 1) mat4_mul(FL, Bq, FL); mat4_mul(Bq, Bq, Bq); }
-    double *pw = ext ? ext->pin : h->pin.take<double>(24 * 16);   // pinned: the H2D source must stay valid until the pass's sync
-    double cur[16]; std::memcpy(cur, FL, sizeof(cur));
-    int nterms = 1, npw = 0;
-    for (int q = 0; q < 24; ++q) {
-        double mx = 0; for (double v : cur) mx = std::max(mx, std::fabs(v));
-        if (mx < 1e-19) break;
-        std::memcpy(pw + 16 * npw, cur, sizeof(cur)); npw++; nterms++;
-        mat4_mul(cur, FL, cur);
+    // Everything that depends on (rate, L) alone is built once per handle and stays on the device: the homogeneous-response table
+    // g[j][k] (the output at step j from the k-th unit state, no input: same statements as KW2_STEP), the powers F^L, F^2L, ... of the
+    // homogeneous transition matrix (state s1, s2, t1, t2) until they vanish, the Gram matrix of a full chunk.  (It used to be rebuilt and
+    // uploaded by every job: nine small copies per file.)
+    jt_ctx::KwTab *T = nullptr;
+    for (auto &t : h->kw_tab) if (t.rate == rate && t.L == L) T = &t;
+    if (!T) {
+        T = &h->kw_tab[h->kw_tab_next++ % 8];
+        // an evicted slot's table may still be read by a sweep in flight on another stream of this handle (more than eight (rate, chunk
+        // length) pairs on one pooled handle): the old buffer is parked, never overwritten
+        T->dev.retire();
+        T->rate = rate; T->L = L; T->g.assign((size_t)4 * L + 24 * 16, 0.0);
+        for (int u = 0; u < 4; ++u) {
+            double s1 = u == 0, s2 = u == 1, t1 = u == 2, t2 = u == 3;
+            for (int64_t j = 0; j < L; ++j) {
+                const double y = s1;                                   // fma(b0, 0, s1)
+                s1 = std::fma(-k.a1, y, s2); s2 = std::fma(-k.a2, y, 0.0);
+                const double zz = std::fma(k.c0, y, t1);
+                t1 = std::fma(-k.d1, zz, std::fma(k.c1, y, t2)); t2 = std::fma(-k.d2, zz, k.c2 * y);
+                T->g[(size_t)4 * j + u] = zz;
+            }
+        }
+        double F[16] = {-k.a1, 1, 0, 0,   -k.a2, 0, 0, 0,   k.c1 - k.d1 * k.c0, 0, -k.d1, 1,   k.c2 - k.d2 * k.c0, 0, -k.d2, 0};
+        double FL[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1}, Bq[16];
+        std::memcpy(Bq, F, sizeof(F));
+        for (int64_t e = L; e > 0; e >>= 1) { if (e & 1) mat4_mul(FL, Bq, FL); mat4_mul(Bq, Bq, Bq); }
+        double cur[16]; std::memcpy(cur, FL, sizeof(cur));
+        double *pw = T->g.data() + (size_t)4 * L;
+        T->nterms = 1;
+        for (int q = 0; q < 24; ++q) {
+            double mx = 0; for (double v : cur) mx = std::max(mx, std::fabs(v));
+            if (mx < 1e-19) break;
+            std::memcpy(pw + 16 * q, cur, sizeof(cur)); T->nterms++;
+            mat4_mul(cur, FL, cur);
+        }
+        std::memset(T->gram, 0, sizeof T->gram);
+        for (int64_t j = 0; j < L; ++j) {
+            int u = 0;
+            for (int a = 0; a < 4; ++a) for (int b = a; b < 4; ++b, ++u) T->gram[u] += T->g[(size_t)4 * j + a] * T->g[(size_t)4 * j + b];
+        }
+        T->dev.ensure(T->g.size());
+        JT_HIP(hipMemcpy(T->dev.p, T->g.data(), sizeof(double) * T->g.size(), hipMemcpyHostToDevice));
     }
-    // device scratch: zs | pw | csum | cpeak | cross.  Each job gets its own region of d_scr0 (several may be in flight in one pass).
-    const size_t need = 4 * (size_t)nchunks + 24 * 16 + 2 * (size_t)nchunks + 4 * (size_t)nchunks;
+    const double *d_pw = T->dev.p + (size_t)4 * L;
+    const int nterms = T->nterms;
+    // device scratch: zs | csum | cpeak | cross.  Each job gets its own region of d_scr0 (several may be in flight in one pass).
+    const size_t need = 4 * (size_t)nchunks + 2 * (size_t)nchunks + 4 * (size_t)nchunks;
     double *base = ext ? ext->dev : h->kw_take(need);
-    double *d_zs = base, *d_pw = base + 4 * (size_t)nchunks, *d_cs = d_pw + 24 * 16, *d_cross = d_cs + 2 * (size_t)nchunks;
-    if (npw) JT_HIP(hipMemcpyAsync(d_pw, pw, sizeof(double) * 16 * npw, hipMemcpyHostToDevice, st));
+    double *d_zs = base, *d_cs = base + 4 * (size_t)nchunks, *d_cross = d_cs + 2 * (size_t)nchunks;
     KwSweep SW; SW.k = k; SW.L = L; SW.nchunks = nchunks; SW.zs = d_zs; SW.csum = d_cs; SW.cpeak = d_cs + nchunks; SW.cross = d_cross;
     SW.pw = d_pw; SW.nterms = nterms; SW.two_sweeps = false;
 #ifdef JT_AB
     SW.two_sweeps = h->opts.kw_two_sweeps;
 #endif
+    const int64_t nfull = n / blk;
+    // block sums / peaks, (nfull + 1) entries each: all that travels to the host -- written by the kernel straight into pinned,
+    // device-visible host memory (no copy to queue behind it)
+    double *hc = ext ? ext->pin : h->pin.take<double>((size_t)(nfull + 1) * 2);
+    double *d_out = hc;
     if (SW.two_sweeps) {
         sweep(SW);
+        hipLaunchKernelGGL(k_kw_blocks, dim3((unsigned)((nfull + 1 + 63) / 64)), dim3(64), 0, st, d_cs, d_cs + nchunks, nchunks, m, nfull, d_out);
     } else {
-        // homogeneous-response table of this (rate, L): g[j][k] = output at step j from the k-th unit state, no input (same statements as
-        // KW2_STEP); cached on the handle
-        jt_ctx::KwTab *T = nullptr;
-        for (auto &t : h->kw_tab) if (t.rate == rate && t.L == L) T = &t;
-        if (!T) {
-            T = &h->kw_tab[h->kw_tab_next++ % 8];
-            // an evicted slot's table may still be read by a sweep in flight on another stream of this handle (more than eight (rate, chunk
-            // length) pairs on one pooled handle): the old buffer is parked, never overwritten
-            T->dev.retire();
-            T->rate = rate; T->L = L; T->g.assign((size_t)4 * L, 0.0);
-            for (int u = 0; u < 4; ++u) {
-                double s1 = u == 0, s2 = u == 1, t1 = u == 2, t2 = u == 3;
-                for (int64_t j = 0; j < L; ++j) {
-                    const double y = s1;                                   // fma(b0, 0, s1)
-                    s1 = std::fma(-k.a1, y, s2); s2 = std::fma(-k.a2, y, 0.0);
-                    const double zz = std::fma(k.c0, y, t1);
-                    t1 = std::fma(-k.d1, zz, std::fma(k.c1, y, t2)); t2 = std::fma(-k.d2, zz, k.c2 * y);
-                    T->g[(size_t)4 * j + u] = zz;
-                }
-            }
-            T->dev.ensure((size_t)4 * L);
-            JT_HIP(hipMemcpy(T->dev.p, T->g.data(), sizeof(double) * 4 * (size_t)L, hipMemcpyHostToDevice));
-        }
-        KwGram G; std::memset(&G, 0, sizeof G);
+        KwGram G; std::memcpy(G.f, T->gram, sizeof G.f); std::memset(G.t, 0, sizeof G.t);
         const int64_t tail = n - (nchunks - 1) * L;                        // samples of the last chunk (1 .. L)
-        for (int64_t j = 0; j < L; ++j) {
+        if (tail == L) std::memcpy(G.t, G.f, sizeof G.t);
+        else for (int64_t j = 0; j < tail; ++j) {
             int u = 0;
-            for (int a = 0; a < 4; ++a) for (int b = a; b < 4; ++b, ++u) {
-                const double p_ = T->g[(size_t)4 * j + a] * T->g[(size_t)4 * j + b];
-                G.f[u] += p_; if (j < tail) G.t[u] += p_;
-            }
+            for (int a = 0; a < 4; ++a) for (int b = a; b < 4; ++b, ++u) G.t[u] += T->g[(size_t)4 * j + a] * T->g[(size_t)4 * j + b];
         }
         SW.gtab = T->dev.p; SW.gtab_host = T->g.data(); SW.tail = tail;
         sweep(SW);
-        hipLaunchKernelGGL(k_kw_fix, dim3((unsigned)((nchunks + 63) / 64)), dim3(64), 0, st, (const double *)d_zs, (const double *)d_pw, nterms,
-                           (const double *)d_cross, G, d_cs, nchunks);
+        hipLaunchKernelGGL(k_kw_fixblocks, dim3((unsigned)((nfull + 1 + 63) / 64)), dim3(64), 0, st, (const double *)d_zs, d_pw, nterms, (const double *)d_cross, G,
+                           (const double *)d_cs, (const double *)(d_cs + nchunks), nchunks, m, nfull, d_out);
     }
-    // block sums / peaks into the (now dead) zero-state region, (nfull + 1) entries each; only those travel to the host
-    const int64_t nfull = n / blk;
-    hipLaunchKernelGGL(k_kw_blocks, dim3((unsigned)((nfull + 1 + 63) / 64)), dim3(64), 0, st, d_cs, d_cs + nchunks, nchunks, m, nfull, d_zs);
-    double *hc = ext ? ext->pin + 24 * 16 : h->pin.take<double>((size_t)(nfull + 1) * 2);
-    JT_HIP(hipMemcpyAsync(hc, d_zs, sizeof(double) * (size_t)(nfull + 1) * 2, hipMemcpyDeviceToHost, st));
     job->hc = hc; job->nchunks = nchunks; job->nfull = nfull; job->m = m;
 }
+
 template <typename TIn>
 static void kweight_enqueue(jt_ctx *h, const TIn *in, int64_t n, int rate, int blk, KwJob *job, hipStream_t st, const KwScratch *ext = nullptr)
 {

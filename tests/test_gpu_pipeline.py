@@ -511,7 +511,7 @@ def test_full_size_60_minute_file_properties(oracle):
     import hashlib
     from jivetalking_amd import Engine
     sr = 48000
-    # the bench talker itself (aperiodic over the hour: 14 400 different 250 ms intervals for the VAD / election / Otsu logic), made on
+    # the bench talker itself (aperiodic over the hour: 14 063 different 250 ms intervals for the VAD / election / Otsu logic), made on
     # the device by a child process (a tiled minute exercised that logic on 60 near-copies)
     from conftest import bench_talker
     x = np.asarray(bench_talker(3600.0, sr, 1000, 40.0), np.float32)
@@ -522,8 +522,9 @@ def test_full_size_60_minute_file_properties(oracle):
         r1 = H.process_audio(e)
         out1 = e.download_s16(4)
         assert out1.size == -(-n * 147 // 160)
-        # the host logic at full size: 14 400 intervals, a speech region and a room-tone region elected, the limiter-prefix branch
-        assert H.lib(e).jt_host_last_intervals(e.h, None, C.c_int64(0)) == 14400
+        # the host logic at full size: 14 063 intervals (an interval closes on the first 4096-sample decoder frame that brings it to 250 ms:
+        # three frames, 256 ms, analyser_metrics.go:165-428), a speech region and a room-tone region elected, the limiter-prefix branch
+        assert H.lib(e).jt_host_last_intervals(e.h, None, C.c_int64(0)) == -(-n // (3 * 4096))
         assert r1.input.has_noise_profile == 1 and r1.input.n_candidates >= 1 and r1.limiter.needed == 1 and r1.has_region_samples == 1
         r2 = H.process_audio(e)
         out2 = e.download_s16(4)
