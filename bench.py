@@ -554,12 +554,12 @@ def main():
                     "heavy_windows": int(eng.timers()["declick_heavy_windows"]), "fast_vs_exact": dk_parity}
         else:
             roof, nlm_roof = nlm_roof, None
-        # HBM traffic per launch from the round's committed PMC passes (profiles/r03_pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE and
+        # HBM traffic per launch from the round's committed PMC passes (profiles/r04_pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE and
         # --pmc WRITE_SIZE in separate runs of this same command, tools/profile_round.sh); FETCH_SIZE doubled per MI355X_MICROARCH.md's
         # gfx950 note.  The file records the sha256 of the kernel sources it was measured on: `traffic` is null once they have changed.
         try:
             import hashlib
-            pmc_file = next(f for f in ("r03_pmc_traffic.json", "r02_pmc_traffic.json") if os.path.exists(os.path.join(ROOT, "profiles", f)))
+            pmc_file = next(f for f in ("r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json") if os.path.exists(os.path.join(ROOT, "profiles", f)))
             pj = json.load(open(os.path.join(ROOT, "profiles", pmc_file)))
             pmc = pj["kernels"]
             sha = lambda f: hashlib.sha256(open(os.path.join(ROOT, "jivetalking_amd", "csrc", f), "rb").read()).hexdigest()[:16]
