@@ -1013,6 +1013,115 @@ k_follow_states_lds(const TIn *__restrict__ in, int64_t n, double att, double re
     }
 }
 
+// The follower as ONE CONSUMER AND THREE PRODUCERS (round 4).  A launch of k_follow_states_lds lasts as long as ONE lane's serial run
+// (halo + chunk = 54 k samples) whatever the file's length -- 1.6 ms (f32) / 2.2 ms (f64) for ten minutes and for an hour alike -- for
+// two reasons found this round: (1) global_load_lds lands 16 KB per CU every 0.65 us (MI355X_MICROARCH.md, "ldsdma-fill": 25 GB/s per
+// CU) and one workgroup per CU was streaming its 843 / 1686 units through it; (2) the one wave spent 32 cycles of issue a sample
+// (convert, square, the recurrence's six instructions at four cycles per f64 instruction) in series with the recurrence's dependent
+// chain.  Here the workgroup has four waves on four SIMDs.  Waves 1-3 load the rows with ordinary 16-byte vector loads, ROW-COALESCED
+// (an instruction covers four rows x 256 contiguous bytes; unit u belongs to wave 1 + u % 3, two units in flight per wave in registers),
+// convert and square them and leave |x|^2 as doubles in an LDS ring, transposed so that the consumer lane of a row reads its own
+// values with conflict-free 16-byte reads; wave 0 runs nothing but the recurrence, sixteen values at a time from registers.  One
+// s_barrier per unit.  Same statements on the same values in the same order: bit-identical states.
+template <typename TIn>
+__global__ void __launch_bounds__(256)
+k_follow_states_pc(const TIn *__restrict__ in, int64_t n, double att, double rel, int64_t chunk, int64_t halo,
+                   double *__restrict__ states, int64_t nchunks)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char fs_ring[];
+    constexpr int G = 16 / (int)sizeof(TIn);           // samples per 16-byte group
+    constexpr int US = 16 * G;                         // samples per unit and row (64 f32 / 32 f64): 256 bytes
+    constexpr int NP = 3;                              // producers = slots of the squared ring
+    constexpr int PL = 1024 + 16;                      // bytes of one plane [64 rows] of double2 (+ 16: the producers' writes spread over the banks)
+    constexpr int SLOT = US / 2 * PL;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int64_t c0 = (int64_t)blockIdx.x * LANES;
+    const int64_t total = halo + chunk;                // multiple of SC, hence of US
+    const int nu = (int)(total / US);
+    typedef double d2 __attribute__((ext_vector_type(2)));
+    typedef TIn vecT __attribute__((ext_vector_type(G)));
+    if (wave != 0) {
+        const int sub = lane >> 4, seg = lane & 15;    // instruction i covers rows 4 i + sub, this lane the 16 bytes at sample seg * G of the unit
+        auto producer = [&](auto qc) {
+            constexpr int Q = decltype(qc)::value;
+            vecT ra[16], rb[16];
+            auto load = [&](vecT (&r)[16], int u) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const int64_t cc = c0 + 4 * i + sub;
+                    int64_t idx = cc * chunk - halo + (int64_t)u * US + seg * G;
+                    if (cc >= nchunks || idx < 0 || idx >= n) idx = 0;              // never consumed: any valid address
+                    r[i] = *reinterpret_cast<const vecT *>(in + idx);
+                }
+            };
+            auto convert = [&](const vecT (&r)[16], int u) {
+                unsigned char *slot = fs_ring + (size_t)(u % NP) * SLOT;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const int row = 4 * i + sub;
+#pragma unroll
+                    for (int e = 0; e < G; e += 2) {
+                        double a = (double)r[i][e], b = (double)r[i][e + 1];
+                        a = fabs(a); b = fabs(b);
+                        d2 w; w.x = a * a; w.y = b * b;
+                        *reinterpret_cast<d2 *>(slot + (size_t)((seg * G + e) / 2) * PL + 16 * row) = w;
+                    }
+                }
+            };
+            if (Q < nu) load(ra, Q);
+            if (Q + NP < nu) load(rb, Q + NP);
+            for (int u6 = 0; u6 < nu; u6 += 2 * NP) {
+#pragma unroll
+                for (int d = 0; d < 2 * NP; ++d) {
+                    const int u = u6 + d;
+                    if (u >= nu) break;
+                    if (d % NP == Q) {
+                        // the older of this wave's two units in flight is complete once only the younger one's sixteen loads are outstanding
+                        if (u + NP < nu) __builtin_amdgcn_s_waitcnt(0x0F70 | (16 & 15) | ((16 >> 4) << 14));
+                        else __builtin_amdgcn_s_waitcnt(0x0F70);
+                        if (d < NP) { convert(ra, u); if (u + 2 * NP < nu) load(ra, u + 2 * NP); }
+                        else { convert(rb, u); if (u + 2 * NP < nu) load(rb, u + 2 * NP); }
+                    }
+                    __syncthreads();   // unit u's squares are in slot u % 3; the consumer finished that slot's previous tenant three barriers ago
+                }
+            }
+        };
+        if (wave == 1) producer(std::integral_constant<int, 0>{});
+        else if (wave == 2) producer(std::integral_constant<int, 1>{});
+        else producer(std::integral_constant<int, 2>{});
+        return;
+    }
+    const int64_t c = c0 + lane;
+    const bool active = c < nchunks;
+    const int64_t row0 = c * chunk - halo;             // first sample of this lane's run (may be negative)
+    double s = 0.0;
+    for (int u = 0; u < nu; ++u) {
+        __syncthreads();
+        const int64_t pos = (int64_t)u * US, t0 = row0 + pos;
+        if (!active) continue;
+        if (pos >= halo && ((pos - halo) % SC) == 0 && t0 < n) states[t0 / SC] = s;     // state BEFORE sample t0
+        const unsigned char *src = fs_ring + (size_t)(u % NP) * SLOT + 16 * lane;
+        const bool inside = t0 >= 0 && t0 + US <= n;
+        if (!inside && !(t0 + US > 0 && t0 < n)) continue;
+#pragma unroll
+        for (int b = 0; b < US; b += 16) {
+            double a2[16];
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                const d2 w = *reinterpret_cast<const d2 *>(src + (size_t)(b / 2 + r) * PL);
+                a2[2 * r] = w.x; a2[2 * r + 1] = w.y;
+            }
+            if (inside) {
+#pragma unroll
+                for (int j = 0; j < 16; ++j) s += (a2[j] - s) * (a2[j] > s ? att : rel);
+            } else {
+#pragma unroll
+                for (int j = 0; j < 16; ++j) { const int64_t idx = t0 + b + j; if (idx >= 0 && idx < n) s += (a2[j] - s) * (a2[j] > s ? att : rel); }
+            }
+        }
+    }
+}
+
 // MODE 0: agate (af_agate.c gate()), MODE 1: acompressor (af_sidechaincompress.c compressor()); detection = rms
 template <int MODE, typename TIn, typename TOut>
 __global__ void __launch_bounds__(64)
@@ -1115,11 +1224,23 @@ static void run_follow(const TIn *in, int64_t n, double att, double rel, double 
         // LDS-streamed variant: chunks of a quarter halo (5x instead of 9x re-read; 250 waves for an hour of audio).  The vmcnt
         // counter (63) caps a wave at 48 KB in flight, about one HBM round trip of the f32 follower's appetite and half of the f64
         // one's, so longer chunks (fewer waves) start waiting for memory again: halo/2 and halo measured 1-2 ms worse.
-        const int64_t lchunk = std::max<int64_t>(1024, (halo / 4 + SC - 1) / SC * SC);
+        const int div = JT_AB_ON(o.follow_div > 0) ? o.follow_div : 4;
+        const int64_t lchunk = std::max<int64_t>(1024, (halo / div + SC - 1) / SC * SC);
         const int64_t lnch = (n + lchunk - 1) / lchunk;
+        if (!JT_AB_ON(o.follow_one_wave)) {
+            // one consumer + three producers (k_follow_states_pc): three slots of squared doubles
+            constexpr int US = 16 * (16 / (int)sizeof(TIn));
+            const int smem = 3 * (US / 2) * (1024 + 16);
+            auto k = k_follow_states_pc<TIn>;
+            JT_HIP(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+            hipLaunchKernelGGL(k, dim3((unsigned)((lnch + LANES - 1) / LANES)), dim3(4 * LANES), smem, s, in, n, att, rel, lchunk, halo, states, lnch);
+            return;
+        }
+#ifdef JT_AB
         auto k = k_follow_states_lds<TIn>;
         JT_HIP(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
         hipLaunchKernelGGL(k, dim3((unsigned)((lnch + LANES - 1) / LANES)), dim3(LANES), 128 * 1024, s, in, n, att, rel, lchunk, halo, states, lnch);
+#endif
         return;
     }
     int64_t chunk = std::max<int64_t>(1024, (halo / 8 + SC - 1) / SC * SC);
