@@ -1,7 +1,7 @@
 """Digest of the analysis operators' outputs (astats, aspectralstats, ebur128) on fixed inputs: run before and after a kernel change that
 must not move a bit.  python tools/ab_analysis.py"""
 import os, sys, hashlib, numpy as np
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', '..'))
 import torch
 from jivetalking_amd import Engine, synth
 e = Engine(0)

@@ -1,7 +1,7 @@
 """48 k -> 44.1 k output stage: the one-wave-per-phase edge kernel against k_polyphase on the edge blocks (JT_EDGE_POLYPHASE), lengths around
 the block size.  python tools/ab_edge.py"""
 import os, sys, numpy as np
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', '..'))
 from jivetalking_amd import Engine
 e = Engine(0)
 bad = 0

@@ -2,7 +2,7 @@
 at the rates whose defaults do not fill the layout (44.1 / 88.2 / 22.05 kHz) and at 48 / 96 kHz; max |difference| and timing.
 python tools/ab_nlm_generic.py [check|time <rate>]"""
 import os, sys, numpy as np
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', '..'))
 from jivetalking_amd import Engine, synth
 what = sys.argv[1] if len(sys.argv) > 1 else "check"
 e = Engine(0)

@@ -2,7 +2,7 @@
 (f64 stream) on fixed inputs: run before and after a change of the stream upsampler that must not move a bit.
 `time`: a few launches on a 60-min 44.1 kHz stream for rocprofv3 --stats.  python tools/ab_ups.py check|time"""
 import os, sys, numpy as np
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', '..'))
 from jivetalking_amd import Engine
 what = sys.argv[1] if len(sys.argv) > 1 else "check"
 e = Engine(0)

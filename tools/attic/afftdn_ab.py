@@ -1,7 +1,7 @@
 """afftdn: the grouped kernel (k_afftdn_grp) against the frame-at-a-time kernel (JT_AFFTDN_OLD=1): outputs must be bit-identical
 (static floor, custom profile, tn=1), `time`: launches of both on a 60-min file for rocprofv3 --stats.  python tools/afftdn_ab.py check|time"""
 import os, sys, time, numpy as np
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', '..'))
 import torch
 from jivetalking_amd import Engine, synth
 what = sys.argv[1] if len(sys.argv) > 1 else "check"

@@ -1,7 +1,7 @@
 """jt_process_files on copies of one FLAC (JT_BATCH_MINUTES, default 60; JT_BATCH_MD5=0 switches the MD5 off) in /dev/shm, MD5 on: ms per file against files in flight (the MD5 of a file is one
 host core for ~380 ms; workers hide it behind each other's GPU phases).  python tools/batch_md5.py [files] [in_flight,...]"""
 import os, sys, time, shutil, tempfile
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', '..'))
 import torch
 from jivetalking_amd import Engine, synth, hostlogic
 nb = int(sys.argv[1]) if len(sys.argv) > 1 else 16

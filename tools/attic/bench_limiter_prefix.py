@@ -3,7 +3,7 @@ speech, not for the bench's synthetic talker): plosive-like bursts are added to 
 python tools/bench_limiter_prefix.py [minutes]"""
 import os, sys, time
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', '..'))
 import numpy as np, torch
 from jivetalking_amd import Engine, synth, hostlogic
 mins = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0

@@ -2,7 +2,7 @@
 warm handle.  python tools/cold_start.py [minutes]"""
 import os, sys, time
 t00 = time.perf_counter()
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', '..'))
 import numpy as np
 from jivetalking_amd import Engine, hostlogic
 mins = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0

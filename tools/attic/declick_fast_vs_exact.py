@@ -3,7 +3,7 @@ oracle) INSIDE the four-pass job on a long file: repaired-sample counts, deliver
 Pass-4 input itself (Pass-2 output x the loudnorm gain): detector decisions that flip, largest f64 difference.
 python tools/declick_fast_vs_exact.py [minutes] [plosives_per_min]"""
 import json, sys, os, time, numpy as np
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', '..'))
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 import torch
 from jivetalking_amd import Engine, synth, hostlogic as H

@@ -1,7 +1,7 @@
 """Randomised A/B of this round's kernel rewrites against the kernels they replaced (each has an environment switch): random rates, lengths
 and seeds; bit-identity where the arithmetic order was kept, f32 round-off where it was not.  python tools/fuzz_ab.py [cases]"""
 import os, sys, numpy as np
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', '..'))
 from jivetalking_amd import Engine, synth, _lib as L
 ncases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 e = Engine(0)

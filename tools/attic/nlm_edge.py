@@ -1,7 +1,7 @@
 """anlmdn: hop-pair kernel against the generic kernel over sample rates (8-96 kHz: every patch length parity, radii far below the lane layout) and
 lengths around the hop size; prints mismatches above f32 round-off.  python tools/nlm_edge.py"""
 import os, sys, numpy as np
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', '..'))
 from jivetalking_amd import Engine, synth
 e = Engine(0)
 def run(generic, x, sr):

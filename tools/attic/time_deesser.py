@@ -1,7 +1,7 @@
 """The gate -> compressor -> de-esser chain with the de-esser on (AdaptConfig enables it on sibilant voices; the bench voice leaves it off):
 run under rocprofv3 --kernel-trace --stats.  python tools/time_deesser.py"""
 import os, sys, numpy as np
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', '..'))
 import torch
 from jivetalking_amd import Engine, synth
 from jivetalking_amd.engine import default_filter_params

@@ -2,7 +2,7 @@
 every-100-frames and band ticks, which need the per-frame levels of each stage output).  python tools/time_ticks.py"""
 import os, sys, time
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', '..'))
 import numpy as np, torch
 from jivetalking_amd import Engine, synth, hostlogic
 sr = 48000

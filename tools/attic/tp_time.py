@@ -1,7 +1,7 @@
 """ebur128 op alone (30-min synthetic file): run under rocprofv3 --kernel-trace --stats to read the true-peak kernel in isolation.
 python tools/tp_time.py [rate]"""
 import sys, numpy as np
-import os; sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
+import os; sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', '..'))
 import torch
 from jivetalking_amd import Engine, synth
 SR = int(sys.argv[1]) if len(sys.argv) > 1 else 48000
