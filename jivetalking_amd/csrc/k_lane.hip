@@ -1026,7 +1026,7 @@ k_follow_states_lds(const TIn *__restrict__ in, int64_t n, double att, double re
 template <typename TIn>
 __global__ void __launch_bounds__(256)
 k_follow_states_pc(const TIn *__restrict__ in, int64_t n, double att, double rel, int64_t chunk, int64_t halo,
-                   double *__restrict__ states, int64_t nchunks)
+                   double *__restrict__ states, int64_t nchunks, int dbg)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char fs_ring[];
     constexpr int G = 16 / (int)sizeof(TIn);           // samples per 16-byte group
@@ -1045,12 +1045,20 @@ k_follow_states_pc(const TIn *__restrict__ in, int64_t n, double att, double rel
         auto producer = [&](auto qc) {
             constexpr int Q = decltype(qc)::value;
             vecT ra[16], rb[16];
+            // first sample of this lane's 16 bytes in unit 0 of each of its sixteen rows (kept in registers: the per-load address is one
+            // 64-bit add and a range test instead of a 64-bit multiply); a row past the last chunk never passes the range test
+            int64_t base[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int64_t cc = c0 + 4 * i + sub;
+                base[i] = cc < nchunks ? cc * chunk - halo + seg * G : n;
+            }
             auto load = [&](vecT (&r)[16], int u) {
+                const int64_t uo = (int64_t)u * US;
 #pragma unroll
                 for (int i = 0; i < 16; ++i) {
-                    const int64_t cc = c0 + 4 * i + sub;
-                    int64_t idx = cc * chunk - halo + (int64_t)u * US + seg * G;
-                    if (cc >= nchunks || idx < 0 || idx >= n) idx = 0;              // never consumed: any valid address
+                    int64_t idx = base[i] + uo;
+                    if (idx < 0 || idx >= n) idx = 0;                                // never consumed: any valid address
                     r[i] = *reinterpret_cast<const vecT *>(in + idx);
                 }
             };
@@ -1075,7 +1083,7 @@ k_follow_states_pc(const TIn *__restrict__ in, int64_t n, double att, double rel
                 for (int d = 0; d < 2 * NP; ++d) {
                     const int u = u6 + d;
                     if (u >= nu) break;
-                    if (d % NP == Q) {
+                    if (d % NP == Q && !(dbg & 1)) {
                         // the older of this wave's two units in flight is complete once only the younger one's sixteen loads are outstanding
                         if (u + NP < nu) __builtin_amdgcn_s_waitcnt(0x0F70 | (16 & 15) | ((16 >> 4) << 14));
                         else __builtin_amdgcn_s_waitcnt(0x0F70);
@@ -1103,6 +1111,7 @@ k_follow_states_pc(const TIn *__restrict__ in, int64_t n, double att, double rel
         const unsigned char *src = fs_ring + (size_t)(u % NP) * SLOT + 16 * lane;
         const bool inside = t0 >= 0 && t0 + US <= n;
         if (!inside && !(t0 + US > 0 && t0 < n)) continue;
+        if (dbg & 2) continue;
 #pragma unroll
         for (int b = 0; b < US; b += 16) {
             double a2[16];
@@ -1111,12 +1120,22 @@ k_follow_states_pc(const TIn *__restrict__ in, int64_t n, double att, double rel
                 const d2 w = *reinterpret_cast<const d2 *>(src + (size_t)(b / 2 + r) * PL);
                 a2[2 * r] = w.x; a2[2 * r + 1] = w.y;
             }
+            // s += (a - s) * (a > s ? att : rel), with the select moved behind the multiplication: both products start as soon as the
+            // difference exists and the comparison runs beside them, so a step's dependent chain is sub -> mul -> select -> add instead
+            // of compare -> select -> mul -> add behind the subtraction.  The same product, the same sum: bit-identical.  (The empty
+            // asm keeps the compiler from folding the two products back into one product of the selected coefficient.)
+            auto step = [&](double a) {
+                const double d = a - s;
+                double pa = d * att, pr = d * rel;
+                asm volatile("" : "+v"(pa), "+v"(pr));
+                s += a > s ? pa : pr;
+            };
             if (inside) {
 #pragma unroll
-                for (int j = 0; j < 16; ++j) s += (a2[j] - s) * (a2[j] > s ? att : rel);
+                for (int j = 0; j < 16; ++j) step(a2[j]);
             } else {
 #pragma unroll
-                for (int j = 0; j < 16; ++j) { const int64_t idx = t0 + b + j; if (idx >= 0 && idx < n) s += (a2[j] - s) * (a2[j] > s ? att : rel); }
+                for (int j = 0; j < 16; ++j) { const int64_t idx = t0 + b + j; if (idx >= 0 && idx < n) step(a2[j]); }
             }
         }
     }
@@ -1224,7 +1243,9 @@ static void run_follow(const TIn *in, int64_t n, double att, double rel, double 
         // LDS-streamed variant: chunks of a quarter halo (5x instead of 9x re-read; 250 waves for an hour of audio).  The vmcnt
         // counter (63) caps a wave at 48 KB in flight, about one HBM round trip of the f32 follower's appetite and half of the f64
         // one's, so longer chunks (fewer waves) start waiting for memory again: halo/2 and halo measured 1-2 ms worse.
-        const int div = JT_AB_ON(o.follow_div > 0) ? o.follow_div : 4;
+        // chunk = halo / div: the run is halo + chunk long, the signal is read 1 + div times.  Files up to ~20 minutes are small enough
+        // for 9 x (their traffic stays under a millisecond of HBM time); longer ones keep 5 x
+        const int div = JT_AB_ON(o.follow_div > 0) ? o.follow_div : (n <= ((int64_t)1 << 26) ? 8 : 4);
         const int64_t lchunk = std::max<int64_t>(1024, (halo / div + SC - 1) / SC * SC);
         const int64_t lnch = (n + lchunk - 1) / lchunk;
         if (!JT_AB_ON(o.follow_one_wave)) {
@@ -1233,7 +1254,7 @@ static void run_follow(const TIn *in, int64_t n, double att, double rel, double 
             const int smem = 3 * (US / 2) * (1024 + 16);
             auto k = k_follow_states_pc<TIn>;
             JT_HIP(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
-            hipLaunchKernelGGL(k, dim3((unsigned)((lnch + LANES - 1) / LANES)), dim3(4 * LANES), smem, s, in, n, att, rel, lchunk, halo, states, lnch);
+            hipLaunchKernelGGL(k, dim3((unsigned)((lnch + LANES - 1) / LANES)), dim3(4 * LANES), smem, s, in, n, att, rel, lchunk, halo, states, lnch, JT_AB_ON(o.follow_dbg) ? o.follow_dbg : 0);
             return;
         }
 #ifdef JT_AB
