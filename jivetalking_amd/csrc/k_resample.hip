@@ -687,7 +687,10 @@ static void p3_mat4_mul(const double *A, const double *B, double *C)
     std::memcpy(C, t, sizeof(t));
 }
 
-constexpr int P3_NWV = 8;                                           // waves per workgroup of k_p3_fused = runs per period
+#ifndef JT_P3_NWV
+#define JT_P3_NWV 8
+#endif
+constexpr int P3_NWV = JT_P3_NWV;                                   // waves per workgroup of k_p3_fused = runs per period (8: two workgroups per CU; 16: one)
 // can this (rate pair, block) be measured by the fused sweep?  (44.1 kHz -> 192 kHz: P = 640, step = 147)
 bool jt_p3_fused_supported(int phase_count, int filter_length, int64_t step, int blk, int64_t flush)
 {
