@@ -54,6 +54,10 @@ extern "C" int jt_open(int device_id, jt_ctx **out)
         JT_HIP(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
         int prio_least = 0, prio_greatest = 0;
         JT_HIP(hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest));
+        // the analysis chains run at the low priority too (the same queue class as the early Pass-2 head: no third pool of hardware queues):
+        // inside Pass 2 the main stream then carries the critical chain -- output stage, limiter prefix, Pass 3's sweep -- past the
+        // statistics nobody waits for (-0.45 ms per file); where a pass ends with its analysis the chains are alone anyway
+        const bool aux_low = true;
         // lowest priority: the small band-RMS launches the host is waiting for must get through beside it
         JT_HIP(hipStreamCreateWithPriority(&h->spec_p2.stream, hipStreamNonBlocking, prio_least));
         JT_HIP(hipEventCreateWithFlags(&h->spec_p2.done, hipEventDisableTiming));
@@ -61,7 +65,7 @@ extern "C" int jt_open(int device_id, jt_ctx **out)
         JT_HIP(hipEventCreateWithFlags(&h->spec_ln.fork, hipEventDisableTiming));
         // the chains of announced output regions (aux[4..7]) are small: aliases of other streams, picked by pass_begin
         for (int i = 0; i < 8; ++i) {
-            if (i < 4) JT_HIP(hipStreamCreateWithFlags(&h->aux[i], hipStreamNonBlocking));
+            if (i < 4) JT_HIP(hipStreamCreateWithPriority(&h->aux[i], hipStreamNonBlocking, aux_low ? prio_least : 0));
             else h->aux[i] = h->aux[(i + 3) % 4];
             JT_HIP(hipEventCreateWithFlags(&h->ev_join[i], hipEventDisableTiming));
         }
