@@ -386,7 +386,7 @@ static void analysis_enqueue(jt_ctx *h, const float *x, int64_t n, int sr, bool 
         JT_REQUIRE(h->tp_off + (size_t)nfull + 2 <= h->tp_cap, JT_E_HIP, "true-peak scratch exhausted");
         double *d_tp = h->d_scr1.p + h->tp_off; h->tp_off += ((size_t)nfull + 2 + 7) & ~(size_t)7;      // (zeroed by pass_begin)
         launch_true_peak_f32(x, n, sw.bank_d.p, sw.pl.phase_count, sw.pl.filter_length, sw.pl.center, sw.pl.step, blk, d_tp, nfull + 1,
-                             sw.out_len(n), a3);
+                             sw.out_len(n), a3, &h->opts);
         double *btp = h->pin.take<double>((size_t)nfull + 2);
         JT_HIP(hipMemcpyAsync(btp, d_tp, sizeof(double) * (nfull + 2), hipMemcpyDeviceToHost, a3));
         J->btp = btp;

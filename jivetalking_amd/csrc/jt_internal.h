@@ -94,7 +94,7 @@ template <typename T> struct DevBuf {
 #define JT_OPT_INTS(X) X(region_rot)
 #define JT_OPT_AB_BOOLS(X) \
     X(nlm_old) X(afftdn_old) X(adeclick_fused) X(dk_levinson_in_kernel) X(dk_no_xcd) X(dk_serial) X(dk_profile) X(dyn_one_wave) \
-    X(dyn_no_cu_reserve) X(kw_two_sweeps) X(follow_tiles) X(follow_one_wave) X(ups_no_stream8) X(ups_no_stream16) X(edge_polyphase) X(no_lim_s16)
+    X(dyn_no_cu_reserve) X(kw_two_sweeps) X(follow_tiles) X(follow_one_wave) X(tp_old) X(ups_no_stream8) X(ups_no_stream16) X(edge_polyphase) X(no_lim_s16)
 #define JT_OPT_AB_INTS(X) X(dk_waves) X(dyn_steps) X(deess_chunk) X(deess_halo) X(follow_div) X(follow_dbg)
 struct JtOpts {
 #define X(k) bool k = false;
@@ -180,9 +180,9 @@ int64_t launch_resample_range_to_s16(const float *in, int64_t n, const double *b
                                      int64_t step, int64_t m, int64_t m_first, int64_t m_count, int16_t *dst, int64_t dst_cap, hipStream_t s);
 int64_t jt_resample_range_cap(int64_t n, int phase_count, int filter_length, int64_t step, int64_t m, int64_t m_count);
 void launch_true_peak_f32(const float *in, int64_t n, const double *bank, int phase_count, int filter_length, int center,
-                          int64_t step, int blk, double *block_tp, int64_t nblocks_alloc, int64_t m_total, hipStream_t s);
+                          int64_t step, int blk, double *block_tp, int64_t nblocks_alloc, int64_t m_total, hipStream_t s, const JtOpts *o = nullptr);
 void launch_true_peak_f64(const double *in, int64_t n, const double *bank, int phase_count, int filter_length, int center,
-                          int64_t step, int blk, double *block_tp, int64_t nblocks_alloc, int64_t m_total, hipStream_t s);
+                          int64_t step, int blk, double *block_tp, int64_t nblocks_alloc, int64_t m_total, hipStream_t s, const JtOpts *o = nullptr);
 // Pass-3 192 kHz streams (FLT path from s16, DBL path after the limiter prefix); K-weighted afterwards by launch_kweight_blocks_*
 void launch_resample_stream_s16_f32(const int16_t *in, int64_t n, const float *bankf, const float *bankf_scaled, int phase_count, int filter_length, int center,
                                     int64_t step, int64_t m_total, float *out, hipStream_t s);

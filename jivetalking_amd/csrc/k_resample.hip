@@ -776,6 +776,115 @@ void launch_p3_fused_f64(const double *in, int64_t n, const double *bank, int P,
     launch_p3_fused_t<double, double, double>(in, n, bank, P, center, step, m_total, flush, 1.0, W, mpow_dev, s);
 }
 
+// ------------------------------------------------------------------ true peak at fractional ratios (44.1 kHz -> 192 kHz) in the stream layout
+// k_upsample32<.., MODE 0, QL = 1> gives a workgroup four waves and every wave whole windows: a tap row fetched into SGPRs feeds 64 x 32
+// FMAs of ONE dependent chain per lane, and the kernel took twice the time of the 48 kHz instance (four chains per lane) for the same
+// 22 GFMA.  This is k_p3_fused's layout without the K-weighting: lane = polyphase period, eight waves share the 64-period input tile
+// (38 KB of f32: three workgroups per CU), a wave walks its eighth of the period's outputs in order with the next tap row in flight, and
+// keeps the running maximum of |y| per lane for the 100 ms block its window ends in (ebur128's assignment: the block of the window's
+// last input sample, as the kernel it replaces).  The same tap sums in the same order, the same block for every output: bit-identical
+// block maxima.
+template <typename TIn, typename TAcc, typename TTap, int NWV>
+__global__ void __launch_bounds__(64 * NWV)
+k_tp_stream(const TIn *__restrict__ in, int64_t n, const TTap *__restrict__ bank, int P, int center, int step, int64_t m_total, int blk,
+            unsigned long long *__restrict__ block_tp, int64_t nblocks_alloc)
+{
+    constexpr int L = 32, NT = 64 * NWV;
+    extern __shared__ unsigned char smem_pp[];
+    __shared__ unsigned long long slots[8];
+    TIn *xin = reinterpret_cast<TIn *>(smem_pp);
+    const int T = 64 * step, nin = T + L;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane((int)(tid >> 6));
+    const int64_t s0 = (int64_t)blockIdx.x * T;
+    const int64_t m_lo = (int64_t)blockIdx.x * 64 * P;
+    if (m_lo >= m_total) return;
+    if (s0 - center >= 0 && s0 - center + nin <= n) {
+        const TIn *src = in + (s0 - center);
+        for (int i = tid; i < nin; i += NT) xin[i] = src[i];
+    } else {
+        for (int i = tid; i < nin; i += NT) {
+            int64_t g = s0 - center + i;
+            TIn v = (TIn)0;
+            if (g < 0) g = -g;                                       // invert_initial_buffer(): in[-j] = in[j]
+            if (g < n) v = in[g];                                    // (the true-peak stream is never flushed: nothing behind the end)
+            xin[i] = v;
+        }
+    }
+    if (tid < 8) slots[tid] = 0ull;
+    __syncthreads();
+    const unsigned uP = (unsigned)P, ustep = (unsigned)step;
+    const int JW = P / NWV, jw0 = wave * JW, jw1 = jw0 + JW;
+    const int off_first = (int)(((unsigned)jw0 * ustep) / uP), off_last = (int)(((unsigned)(jw1 - 1) * ustep) / uP);
+    const int64_t m_base = m_lo + (int64_t)P * lane;
+    const int64_t left = m_total - m_base;
+    const int jlim = left <= 0 ? 0 : (left >= (int64_t)P ? P : (int)left);   // outputs j < jlim of this lane's period exist
+    const int64_t base0 = s0 - center + L - 1;                                // `last` input sample of the window at tile sample 0
+    const int64_t b_first = (base0 < 0 ? 0 : base0) / blk;
+    TAcc run_v = (TAcc)0; int run_sl = -1;
+    auto flush_run = [&]() {
+        if (run_sl >= 0 && run_v > (TAcc)0) {
+            const unsigned long long bits = (unsigned long long)__double_as_longlong((double)run_v);
+            if (run_sl < 8) atomicMax(&slots[run_sl], bits); else atomicMax(&block_tp[b_first + run_sl], bits);
+        }
+        run_v = (TAcc)0;
+    };
+    for (int off0 = off_first; off0 <= off_last; ++off0) {
+        const int off = __builtin_amdgcn_readfirstlane(off0);
+        int j_lo = (int)(((unsigned)off * uP + ustep - 1u) / ustep), j_hi = (int)(((unsigned)(off + 1) * uP + ustep - 1u) / ustep);
+        j_lo = j_lo > jw0 ? j_lo : jw0; j_hi = j_hi < jw1 ? j_hi : jw1;
+        const int si = off + step * lane;
+        TAcc xw[L];
+        {
+            const TIn *wp = xin + si;
+#pragma unroll
+            for (int i = 0; i < L; ++i) xw[i] = (TAcc)wp[i];
+        }
+        TAcc vmax = (TAcc)0;
+        int ph = (int)(((unsigned)j_lo * ustep) % uP);
+        auto row = [&](const TTap (&tp)[L], int j) {
+            TAcc val = (TAcc)0;
+#pragma unroll
+            for (int i = 0; i < L; ++i) val = fma(xw[i], (TAcc)tp[i], val);
+            vmax = j < jlim ? fmax(vmax, fabs(val)) : vmax;
+        };
+        auto fetch_row = [&](TTap (&tp)[L], int phase) {
+            const TTap *f = bank + (size_t)(unsigned)phase * L;
+#pragma unroll
+            for (int i = 0; i < L; ++i) tp[i] = f[i];
+        };
+        TTap ta[L], tb[L];
+        if (j_lo < j_hi) fetch_row(ta, ph);
+        for (int j = j_lo; j < j_hi; j += 2) {
+            int ph1 = ph + step; ph1 -= ph1 >= P ? P : 0;
+            int ph2 = ph1 + step; ph2 -= ph2 >= P ? P : 0;
+            fetch_row(tb, ph1);
+            row(ta, j);
+            if (j + 1 < j_hi) {
+                fetch_row(ta, ph2);
+                row(tb, j + 1);
+            }
+            ph = ph2;
+        }
+        // the 100 ms block of this window's last input sample (windows that end before the signal or behind it count for nothing)
+        const int64_t last = base0 + si;
+        if (last >= 0 && last <= n - 1 && vmax > (TAcc)0) {
+            int64_t b = last / blk;
+            if (b >= nblocks_alloc) b = nblocks_alloc - 1;
+            const int sl = (int)(b - b_first);
+            if (sl != run_sl) { flush_run(); run_sl = sl; }
+            run_v = fmax(run_v, vmax);
+        }
+    }
+    flush_run();
+    __syncthreads();
+    if (tid < 8 && slots[tid]) {
+        int64_t b = b_first + tid;
+        if (b >= nblocks_alloc) b = nblocks_alloc - 1;
+        atomicMax(&block_tp[b], slots[tid]);
+    }
+}
+constexpr int TP_NWV = 8;
+
 template <typename TIn, typename TAcc, typename TTap, int MODE>
 static bool launch_upsample32(const TIn *in, int64_t n, const TTap *bank, int P, int L, int center, int64_t step, int64_t m_total,
                               double in_scale, int blk, double *block_tp, int64_t nblocks_alloc, TAcc *out, hipStream_t s, const JtOpts *o = nullptr)
@@ -783,6 +892,17 @@ static bool launch_upsample32(const TIn *in, int64_t n, const TTap *bank, int P,
     (void)o;
     if (L != 32 || step >= P || step > 512) return false;
     const int ql = step == 1 ? 4 : 1;
+    if constexpr (MODE == 0) {
+        const size_t tile = (sizeof(TIn) * (size_t)(64 * step + 32 + 4) + 15) & ~(size_t)15;
+        if (ql == 1 && (step & 1) && P % (2 * TP_NWV) == 0 && tile <= 96 * 1024 && !JT_AB_ON(o && o->tp_old)) {
+            auto kt = k_tp_stream<TIn, TAcc, TTap, TP_NWV>;
+            JT_HIP(hipFuncSetAttribute((const void *)kt, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tile));
+            const int64_t pb = (int64_t)64 * P;
+            hipLaunchKernelGGL(kt, dim3((unsigned)((m_total + pb - 1) / pb)), dim3(64 * TP_NWV), tile, s, in, n, bank, P, center, (int)step, m_total, blk,
+                               (unsigned long long *)block_tp, nblocks_alloc);
+            return true;
+        }
+    }
     int R = (int)std::max<int64_t>(1, 4096 / (64 * ql * step));
     // stream output with per-lane window groups (upsample32_stream_quads): as many windows per lane as a <= 80 KB tile allows
     if (MODE == 2 && ql == 1 && (P & 15) == 0 && R == 1)
@@ -927,11 +1047,11 @@ static PPGeom pp_geometry(int64_t n, int P, int L, int64_t step, int64_t m_total
 }
 
 void launch_true_peak_f32(const float *in, int64_t n, const double *bank, int phase_count, int filter_length, int center,
-                          int64_t step, int blk, double *block_tp, int64_t nblocks_alloc, int64_t m_total, hipStream_t s)
+                          int64_t step, int blk, double *block_tp, int64_t nblocks_alloc, int64_t m_total, hipStream_t s, const JtOpts *o)
 {
     if (m_total <= 0) return;
     if (launch_upsample32<float, double, double, 0>(in, n, bank, phase_count, filter_length, center, step, m_total, 1.0, blk, block_tp,
-                                                   nblocks_alloc, (double *)nullptr, s)) return;
+                                                   nblocks_alloc, (double *)nullptr, s, o)) return;
     PPGeom g = pp_geometry<float>(n, phase_count, filter_length, step, m_total, false);
     JT_REQUIRE(g.smem <= 150 * 1024, JT_E_UNSUPPORTED, "true peak: rate ratio needs too large an LDS tile");
     auto k = k_polyphase<float, double, double, 0>;
@@ -941,11 +1061,11 @@ void launch_true_peak_f32(const float *in, int64_t n, const double *bank, int ph
 }
 
 void launch_true_peak_f64(const double *in, int64_t n, const double *bank, int phase_count, int filter_length, int center,
-                          int64_t step, int blk, double *block_tp, int64_t nblocks_alloc, int64_t m_total, hipStream_t s)
+                          int64_t step, int blk, double *block_tp, int64_t nblocks_alloc, int64_t m_total, hipStream_t s, const JtOpts *o)
 {
     if (m_total <= 0) return;
     if (launch_upsample32<double, double, double, 0>(in, n, bank, phase_count, filter_length, center, step, m_total, 1.0, blk, block_tp,
-                                                    nblocks_alloc, (double *)nullptr, s)) return;
+                                                    nblocks_alloc, (double *)nullptr, s, o)) return;
     PPGeom g = pp_geometry<double>(n, phase_count, filter_length, step, m_total, false);
     JT_REQUIRE(g.smem <= 150 * 1024, JT_E_UNSUPPORTED, "true peak: rate ratio needs too large an LDS tile");
     auto k = k_polyphase<double, double, double, 0>;
