@@ -210,7 +210,7 @@ def saturation_leg(rank, world, device, files_per_gpu, minutes, in_flight, sr, m
            "files_per_device": [int(v) for v in shard.gather_over_ranks(len(mine), device=dist_device)]}
     for md5 in (True, False):
         best = None
-        for rep in range(2):                      # best of two: a one-second batch is sensitive to whatever else the host is doing
+        for rep in range(3):                      # best of three: a sub-second, partly host-bound batch is sensitive to whatever else the shared host is doing
             sync()
             t0 = time.perf_counter()
             failed, per_file_ms, lufs = run_batch(paths, md5)

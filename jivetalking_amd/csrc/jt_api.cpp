@@ -57,7 +57,11 @@ extern "C" int jt_open(int device_id, jt_ctx **out)
         // the analysis chains run at the low priority too (the same queue class as the early Pass-2 head: no third pool of hardware queues):
         // inside Pass 2 the main stream then carries the critical chain -- output stage, limiter prefix, Pass 3's sweep -- past the
         // statistics nobody waits for (-0.45 ms per file); where a pass ends with its analysis the chains are alone anyway
+#ifdef JT_AB
+        const bool aux_low = getenv("JT_AUX_NORMAL") == nullptr;      // (A/B build only: the analysis chains back in the normal class)
+#else
         const bool aux_low = true;
+#endif
         // lowest priority: the small band-RMS launches the host is waiting for must get through beside it
         JT_HIP(hipStreamCreateWithPriority(&h->spec_p2.stream, hipStreamNonBlocking, prio_least));
         JT_HIP(hipEventCreateWithFlags(&h->spec_p2.done, hipEventDisableTiming));

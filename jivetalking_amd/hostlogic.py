@@ -272,7 +272,10 @@ def process_files_multi(paths, devices=(0,), in_flight_per_device=2, base=None, 
 class Pool:
     """jt_handle_pool_*: handles opened once, reused by every batch (jt_process_files_multi opens and closes a pool per call)."""
 
-    def __init__(self, devices=(0,), in_flight_per_device=2, max_workers=0, ab=False):
+    def __init__(self, devices=(0,), in_flight_per_device=2, max_workers=0, ab=None):
+        if ab is None:
+            import os
+            ab = bool(os.environ.get("JT_USE_AB_LIB"))               # (as Engine: how tools/ select the A/B build)
         self.lib = lib() if not ab else lib(type("E", (), {"lib": L.load(ab=True)})())
         self.p = C.c_void_p()
         dv = (C.c_int * len(devices))(*devices)
