@@ -1065,11 +1065,15 @@ extern "C" int jt_pass2(jt_ctx *h, const jt_filter_params *p, jt_analysis *out)
         // aux[3]): wait for those two chains only, ask the planner, and queue the prefix measurement while astats / aspectralstats / the
         // regions are still running.  The values are the ones analysis_complete() will report below (same arithmetic, same inputs).
         auto &E = h->early_p3;
-        JT_HIP(hipEventSynchronize(E.ev[0])); JT_HIP(hipEventSynchronize(E.ev[1]));
+        // (the gating of the loudness -- 36 000 blocks of an hour, a histogram and the LRA percentiles -- runs while the true-peak sweep,
+        // which ends later than the K-weighting job, is still on the GPU)
+        JT_HIP(hipEventSynchronize(E.ev[0]));
         check_cancel(h);
         std::vector<double> bsum, bpk;
         jt_kweight_finish(&J.kw, bsum, bpk);
         R128Series r; jt_r128_finish(bsum.data(), J.nfull, J.blk, J.sr, J.dualmono, &r);
+        JT_HIP(hipEventSynchronize(E.ev[1]));
+        check_cancel(h);
         double tp = 0; for (int64_t k = 0; k < J.nfull; ++k) tp = std::max(tp, J.btp[(size_t)k]);
         jt_limiter_plan plan; std::memset(&plan, 0, sizeof plan);
         const bool planned = E.fn(E.user, r.integrated, tp, &plan) == JT_OK;
