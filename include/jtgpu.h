@@ -59,8 +59,8 @@ void jt_end_job(jt_ctx *h);
  *   schedule switches (same results either way; the tests run both): no_pass2_prefetch, no_early_pass3, no_early_plan, no_lim_keep,
  *     no_staged_finish, no_r128_first, region_rot (0..3, -1 = default), region_full_astats
  *   kernel selection: adeclick_exact (the sequential-order adeclick kernel, bit-exact to af_adeclick.c's summation order),
- *     nlm_generic (the any-geometry anlmdn kernel), p3_unfused / analysis_unfused / dyn_unfused (the stand-alone kernels of stages
- *     that are fused by default: what the fused forms are tested against)
+ *     nlm_generic (the any-geometry anlmdn kernel), p3_unfused (Pass 3 as stand-alone upsampler + K-weighting kernels: what the fused
+ *     sweep is tested against), limiter_lanes (alimiter with a lane per segment: what the wave-per-segment kernel is tested against)
  *   diagnostics: host_timing (host-stage timings on stderr)
  *   process-wide (h == NULL): graveyard_gb (gigabytes of superseded buffers parked before they are freed, default 24, 0 = free at
  *     once), poison_alloc (fill every new device allocation with 0xFF bytes; test switch)

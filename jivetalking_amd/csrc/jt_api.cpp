@@ -1127,7 +1127,7 @@ static void run_limiter(jt_ctx *h, double *in, double *out, int64_t n, int sr, d
     h->lim_bounds.ensure((size_t)ntargets);
     h->lim_delta.ensure((size_t)ntargets * B); h->lim_pos.ensure((size_t)ntargets * B); h->lim_lp.ensure((size_t)ntargets * B);
     launch_limiter_f64(in, out, n, sr, limit, B, release, asc_coeff, h->d_scr3.p, nblk, blk, need, target, h->lim_bounds.p, ntargets,
-                       in_gain, h->lim_delta.p, h->lim_pos.p, h->stream, h->lim_lp.p);
+                       in_gain, h->lim_delta.p, h->lim_pos.p, h->stream, h->lim_lp.p, h->opts.limiter_lanes, JT_AB_ON(h->opts.lim_profile));
 }
 
 // loudnorm (dynamic-mode first pass) input statistics of a signal at `rate`, measured after swr -> 192 kHz

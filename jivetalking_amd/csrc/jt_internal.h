@@ -90,11 +90,11 @@ template <typename T> struct DevBuf {
 // that build imports JT_<KEY> variables, once, inside jt_open.
 #define JT_OPT_BOOLS(X) \
     X(no_pass2_prefetch) X(no_early_pass3) X(no_early_plan) X(no_lim_keep) X(no_staged_finish) X(no_r128_first) \
-    X(region_full_astats) X(host_timing) X(adeclick_exact) X(nlm_generic) X(p3_unfused) X(analysis_unfused) X(dyn_unfused)
+    X(region_full_astats) X(host_timing) X(adeclick_exact) X(nlm_generic) X(p3_unfused) X(limiter_lanes)
 #define JT_OPT_INTS(X) X(region_rot)
 #define JT_OPT_AB_BOOLS(X) \
     X(nlm_old) X(afftdn_old) X(adeclick_fused) X(dk_levinson_in_kernel) X(dk_no_xcd) X(dk_serial) X(dk_profile) X(dyn_one_wave) \
-    X(dyn_no_cu_reserve) X(kw_two_sweeps) X(follow_tiles) X(follow_one_wave) X(tp_old) X(ups_no_stream8) X(ups_no_stream16) X(edge_polyphase) X(no_lim_s16)
+    X(dyn_no_cu_reserve) X(kw_two_sweeps) X(follow_tiles) X(follow_one_wave) X(tp_old) X(lim_profile) X(ups_no_stream8) X(ups_no_stream16) X(edge_polyphase) X(no_lim_s16)
 #define JT_OPT_AB_INTS(X) X(dk_waves) X(dyn_steps) X(deess_chunk) X(deess_halo) X(follow_div) X(follow_dbg)
 struct JtOpts {
 #define X(k) bool k = false;
@@ -171,7 +171,8 @@ void launch_absmax_conv_s16(const int16_t *in, double *conv, double *out, int64_
                             int64_t nblk, hipStream_t s);
 void launch_limiter_f64(const double *in, double *out, int64_t n, int sr, double limit, int buffer_size,
                         double release_s, double asc_coeff, const double *block_max, int64_t nblk, int blk, int need, int target,
-                        int64_t *cand, int64_t ntargets, double in_gain, double *scratch_delta, int64_t *scratch_pos, hipStream_t s, double *scratch_lp);
+                        int64_t *cand, int64_t ntargets, double in_gain, double *scratch_delta, int64_t *scratch_pos, hipStream_t s, double *scratch_lp,
+                        bool lane_per_segment = false, bool lim_profile = false);      // lane_per_segment: k_limiter_f64 instead of k_limiter_wave
 
 // resampler / true peak
 void launch_resample_to_s16(const float *in, int64_t n, const double *bank, int phase_count, int filter_length, int center,

@@ -1625,15 +1625,262 @@ k_limiter_f64(const double *__restrict__ in, double *__restrict__ out, int64_t n
     }
 }
 
+// The same state machine with ONE HOT SEGMENT PER WAVE AT A TIME (round 4).  k_limiter_f64 gives a lane a segment, and a launch lasts as long
+// as its longest segment: plosives closer than the release time chain into one, and a sample above the limit costs ~1000 cycles there --
+// for every such sample the filter walks its list of pending peaks until the first entry whose slope the new peak undercuts (a division
+// and three loads per entry, one after the other), while 62 of the wave's 64 lanes have no segment to run.  Here the wave takes its hot
+// segments one after the other and all lanes work on the current one: the samples of a tile are loaded coalesced (lane = sample) and handed
+// round by v_readlane, the scalar state lives replicated in every lane (all branches are wave-uniform), the pending-peak list sits in LDS
+// (one list at a time: 24 B bytes), and the walk over it is ONE step -- lane k evaluates entry k, a ballot finds the first hit.  Tiles at
+// rest are skipped (the first sweep already wrote them), tiles inside a release ramp run the five statements that are alive there.  The
+// same statements on the same values in the same order as the filter: bit-identical output.
+__device__ __forceinline__ double lim_bcast(double v, int j)
+{
+    const long long u = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_readlane((int)u, j), hi = __builtin_amdgcn_readlane((int)(u >> 32), j);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
+}
+__device__ __forceinline__ double lim_wave_max(double v) { for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o, 64)); return v; }
+
+__global__ void __launch_bounds__(64)
+k_limiter_wave(const double *__restrict__ in, double *__restrict__ out, int64_t n, int sr, double limit, int B,
+               double release, double asc_coeff, const int64_t *__restrict__ cand, int64_t ntargets, int blk, double in_gain,
+               const double *__restrict__ block_max, int64_t nblk, unsigned long long *__restrict__ prof)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char lw_smem[];
+#ifdef JT_AB
+    // phase clocks of the A/B build (option lim_profile): [0..2] wave cycles in rest / ramp / hot tiles, [3..5] their tile counts, [6] hot
+    // samples (above the limit), [7] the longest workgroup, [8] segments, [9] list entries tested
+    unsigned long long pc[3] = {0, 0, 0}, pn[3] = {0, 0, 0}, phot = 0, ptest = 0; const unsigned long long pt_start = wall_clock64();
+#define LW_MARK(i) { const unsigned long long t_ = wall_clock64(); pc[i] += t_ - ptc; pn[i]++; ptc = t_; }
+#else
+#define LW_MARK(i)
+#endif
+    int64_t *nextpos = reinterpret_cast<int64_t *>(lw_smem);
+    double *nextdelta = reinterpret_cast<double *>(nextpos + B), *nextlp = nextdelta + B;
+    __shared__ int64_t s_lo[LANES], s_hi[LANES];
+    __shared__ int act[LANES];
+    const int lane = threadIdx.x;
+    const int64_t c = (int64_t)blockIdx.x * LANES + lane;
+    int64_t lo_l = -1, hi_l = -1;
+    if (c < ntargets && cand[c] >= 0) {
+        lo_l = cand[c] * blk;
+        hi_l = n;
+        for (int64_t q = c + 1; q < ntargets; ++q) { const int64_t v = cand[q]; if (v >= 0) { hi_l = v * blk; break; } }
+        if (lo_l >= n) { lo_l = -1; hi_l = -1; }
+    }
+    if (lo_l >= 0) {
+        // (as k_limiter_f64: a segment in which nothing is above the limit, its look-ahead into the next one included, stays at rest)
+        const double g = fabs(in_gain);
+        const int64_t b0 = lo_l / blk, b1 = min(nblk - 1, (hi_l + B - 2) / blk);
+        bool hot = false;
+        for (int64_t b = b0; b <= b1; ++b) hot |= block_max[b] * g > limit;
+        if (!hot) { lo_l = -1; hi_l = -1; }
+    }
+    s_lo[lane] = lo_l; s_hi[lane] = hi_l;
+    const unsigned long long hot_mask = __ballot(lo_l >= 0);
+    const int nact = __popcll(hot_mask);
+    if (nact == 0) return;
+    if (lo_l >= 0) act[__popcll(hot_mask & ((1ull << lane) - 1ull))] = lane;
+    __syncthreads();
+    auto wrapB = [&](int x) -> int { return x >= B ? x - B : x; };
+    for (int a = 0; a < nact; ++a) {
+        const int r = act[a];
+        const int64_t lo = s_lo[r], hi = s_hi[r];
+        const int64_t len = (hi - lo) + B - 1;          // iterations i = lo .. hi + B - 2: iteration i pushes in[i] and emits sample i - (B - 1)
+        nextpos[0] = -1;
+        double att = 1.0, delta = 0.0, asc = 0.0; int asc_c = 0;
+        int nextiter = 0, nextlen = 0;
+        // the sample entering the look-ahead buffer and the one leaving it, lane = sample of the tile; the next tile's pair is in flight
+        // while the current tile is worked on
+        auto fetch = [&](int64_t pos, double &vx, double &ve) {
+            const int64_t ix = lo + pos + lane, ie = ix - (B - 1);
+            const int64_t cx = ix < 0 ? 0 : (ix >= n ? n - 1 : ix), ce = ie < 0 ? 0 : (ie >= n ? n - 1 : ie);
+            vx = in[cx]; ve = in[ce];
+        };
+        // (four tiles ahead: a ramp tile takes a fifth of a memory round trip since its gains are formed first)
+        constexpr int PF = 4;
+        double nvx[PF], nve[PF], cvx[PF], cve[PF];
+#pragma unroll
+        for (int t = 0; t < PF; ++t) { nvx[t] = 0.0; nve[t] = 0.0; if ((int64_t)t * TW < len) fetch((int64_t)t * TW, nvx[t], nve[t]); }
+#ifdef JT_AB
+        unsigned long long ptc = wall_clock64();
+#endif
+        for (int64_t pos0 = 0; pos0 < len; pos0 += PF * TW) {
+#pragma unroll
+        for (int t = 0; t < PF; ++t) { cvx[t] = nvx[t]; cve[t] = nve[t]; }
+#pragma unroll
+        for (int t = 0; t < PF; ++t) { const int64_t pn = pos0 + (int64_t)(PF + t) * TW; if (pn < len) fetch(pn, nvx[t], nve[t]); }
+#pragma unroll
+        for (int t = 0; t < PF; ++t) {
+            const int64_t pos = pos0 + (int64_t)t * TW;
+            if (pos >= len) break;
+            const int64_t ix = lo + pos + lane, ie = ix - (B - 1);
+            const double xv = ix < n ? cvx[t] * in_gain : 0.0;
+            const double ev = (ie >= 0 && ie < n) ? cve[t] * in_gain : 0.0;
+            const int jn = (int)min((int64_t)TW, len - pos);
+            bool rest = att == 1. && delta == 0. && nextlen == 0 && asc_c == 0;
+            if (rest) rest = !__ballot(lane < jn && fabs(xv) > limit);         // (nothing above the limit <=> the maximum is not)
+            if (rest) { LW_MARK(0) continue; }          // att stays 1: the outputs are in * in_gain, which the first sweep has written
+            double ov = ev;
+            // one sample of af_alimiter.c's loop, all lanes in step (every branch is wave-uniform)
+            auto full_step = [&](int j) {
+                const int64_t i = lo + pos + j;
+                const double x = lim_bcast(xv, j);
+                double peak = fabs(x);
+                if (peak > limit) { asc += peak; asc_c++; }
+                if (peak > limit) {
+#ifdef JT_AB
+                    phot++; ptest += (unsigned long long)nextlen;
+#endif
+                    const double lp = limit / peak;
+                    const double patt = fmin(lp, 1.);
+                    auto rdelta_of = [&]() -> double { return (1.0 - patt) / (sr * release); };
+                    const double dl = (lp - att) / B * 1;
+                    if (dl < delta) {
+                        delta = dl;
+                        nextpos[0] = i; nextpos[B == 1 ? 0 : 1] = -1; nextdelta[0] = rdelta_of(); nextlp[0] = lp;
+                        nextlen = 1; nextiter = 0;
+                    } else {
+                        // the filter's walk `for k: pdelta = (lp - lp_k) / (i - pos_k); if (pdelta < delta_k) { delta_k = pdelta; break; }`:
+                        // no entry changes before the first hit, so the entries can be tested side by side
+                        int kf = -1; double pdf = 0.0;
+                        for (int base = 0; base < nextlen; base += LANES) {
+                            const int kk = base + lane;
+                            bool hit = false; double pd = 0.0;
+                            if (kk < nextlen) {
+                                const int jj = wrapB(nextiter + kk);
+                                pd = (lp - nextlp[jj]) / (double)((i - nextpos[jj]) / 1);
+                                hit = pd < nextdelta[jj];
+                            }
+                            const unsigned long long bal = __ballot(hit);
+                            if (bal) { const int f = __ffsll((long long)bal) - 1; kf = base + f; pdf = lim_bcast(pd, f); break; }
+                        }
+                        if (kf >= 0) {
+                            nextdelta[wrapB(nextiter + kf)] = pdf;
+                            nextlen = kf + 1;
+                            const int jn_ = wrapB(nextiter + nextlen);
+                            nextpos[jn_] = i;
+                            nextdelta[jn_] = rdelta_of();
+                            nextlp[jn_] = lp;
+                            nextpos[wrapB(jn_ + 1)] = -1;
+                            nextlen++;
+                        }
+                    }
+                }
+                const int64_t eidx = i - (B - 1);            // sample leaving the look-ahead buffer
+                double bufv = lim_bcast(ev, j);
+                if (B == 1) bufv = x;
+                peak = fabs(bufv);
+                if (peak > limit) { asc -= peak; asc_c--; }
+                att += delta;
+                double o = bufv * att;
+                if (nextlen > 0 && nextpos[nextiter] == eidx && eidx >= 0) {
+                    double rd = (1.0 - att) / (sr * release);
+                    if (asc_c > 0) {
+                        double a_att = limit / (asc_coeff * asc) * (double)asc_c;
+                        if (a_att > att) {
+                            double d2 = fmax((a_att - att) / (sr * release), rd / 10);
+                            if (d2 < rd) rd = d2;
+                        }
+                    }
+                    delta = rd;
+                    if (nextlen > 1) {
+                        const int j1_ = wrapB(nextiter + 1);
+                        const int64_t pnext = nextpos[j1_];
+                        const double pdelta = (nextlp[j1_] - att) / (double)(pnext - eidx);
+                        if (pdelta < delta) delta = pdelta;
+                    }
+                    nextlen -= 1;
+                    nextpos[nextiter] = -1;
+                    nextiter = wrapB(nextiter + 1);
+                }
+                if (att > 1.) { att = 1.; delta = 0.; nextiter = 0; nextlen = 0; nextpos[0] = -1; }
+                if (att <= 0.) { att = 0.0000000000001; delta = (1.0 - att) / (sr * release); }
+                if (att != 1. && (1. - att) < 0.0000000000001) att = 1.;
+                if (delta != 0. && fabs(delta) < 0.00000000000001) delta = 0.;
+                o = fmin(fmax(o, -limit), limit);
+
+                if (lane == j) ov = o;
+            };
+            // EVENTS are the samples at which the filter does more than `att += delta; out = delayed * att`: a sample above the limit
+            // entering the look-ahead buffer or leaving it, the pending peak at the head of the list leaving, and a gain that touches one of
+            // the per-sample clamps (above 1, at or below 0, within 1e-13 of 1).  A release ramp is thousands of samples without one (with
+            // asc a release lasts up to ten times the release time), and run as written its five statements are a dependent chain of ~200
+            // cycles a sample: nine tenths of the launch.  So between events the gains att_j = att_(j-1) + delta are formed first, IN ORDER
+            // (additions that round as the filter's do), lane j keeping att_j, and every output is its own product; the events themselves go
+            // through full_step.
+            bool had_event = false;
+            int j = 0;
+            while (j < jn) {
+                const int64_t head = nextlen > 0 ? nextpos[nextiter] : (int64_t)-1;
+                const unsigned long long evm = __ballot(lane >= j && lane < jn && (fabs(xv) > limit || fabs(ev) > limit || (head >= 0 && ie == head)));
+                int f = evm ? __ffsll((long long)evm) - 1 : jn;
+                if (f > j && !(delta != 0. && fabs(delta) < 0.00000000000001)) {
+                    double aj = 0.0, run = att;
+                    if (j == 0 && f == TW) {
+#pragma unroll
+                        for (int q = 0; q < TW; ++q) { run += delta; aj = lane == q ? run : aj; }
+                    } else {
+                        for (int q = j; q < f; ++q) { run += delta; aj = lane == q ? run : aj; }
+                    }
+                    const bool mine = lane >= j && lane < f;
+                    const unsigned long long tm = __ballot(mine && (aj > 1. || aj <= 0. || (aj != 1. && (1. - aj) < 0.0000000000001)));
+                    const int f2 = tm ? __ffsll((long long)tm) - 1 : f;      // the first gain that touches a clamp: that sample is an event too
+                    if (lane >= j && lane < f2) ov = fmin(fmax(ev * aj, -limit), limit);
+                    if (f2 > j) att = lim_bcast(aj, f2 - 1);
+                    j = f2;
+                    if (f2 == f && f == jn) break;
+                    f = f2;
+                } else f = j;
+                if (j < jn) { full_step(j); ++j; had_event = true; }
+            }
+            const bool ramp = !had_event; (void)ramp;
+            if (lane < jn && ie >= lo && ie < hi) out[ie] = ov;
+#ifdef JT_AB
+            if (ramp) LW_MARK(1) else LW_MARK(2)
+#endif
+        }
+        }
+    }
+#ifdef JT_AB
+    if (prof && lane == 0) {
+        for (int i = 0; i < 3; ++i) { atomicAdd(&prof[i], pc[i]); atomicAdd(&prof[3 + i], pn[i]); }
+        atomicAdd(&prof[6], phot); atomicMax(&prof[7], wall_clock64() - pt_start); atomicAdd(&prof[8], (unsigned long long)nact); atomicAdd(&prof[9], ptest);
+    }
+#endif
+#undef LW_MARK
+}
+
 void launch_limiter_f64(const double *in, double *out, int64_t n, int sr, double limit, int buffer_size,
                         double release_s, double asc_coeff, const double *block_max, int64_t nblk, int blk, int need, int target,
-                        int64_t *cand, int64_t ntargets, double in_gain, double *scratch_delta, int64_t *scratch_pos, hipStream_t s, double *scratch_lp)
+                        int64_t *cand, int64_t ntargets, double in_gain, double *scratch_delta, int64_t *scratch_pos, hipStream_t s, double *scratch_lp,
+                        bool lane_per_segment, bool lim_profile)
 {
     if (n <= 0) return;
+    (void)lim_profile;
     hipLaunchKernelGGL(k_lim_bounds, dim3((unsigned)((ntargets + 255) / 256)), dim3(256), 0, s, block_max, nblk, need, target,
                        std::fabs(in_gain), limit, cand, ntargets);
-    // (the rings in LDS -- 3 x B doubles for each of up to four hot segments -- made one hot sample 10 % cheaper and the launch 50 % longer:
-    // 21 KB more LDS per workgroup halves the workgroups a CU holds, and there are 1 200 of them, most with nothing to do)
+    // one hot segment per wave at a time, the pending-peak list (24 B bytes) in LDS; look-ahead buffers too long for that keep a lane per segment
+    const size_t smem = 24 * (size_t)buffer_size;
+    if (smem <= 96 * 1024 && !lane_per_segment) {
+        JT_HIP(hipFuncSetAttribute((const void *)k_limiter_wave, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        unsigned long long *prof = nullptr;
+#ifdef JT_AB
+        if (lim_profile) { prof = reinterpret_cast<unsigned long long *>(scratch_lp); JT_HIP(hipMemsetAsync(prof, 0, 16 * sizeof(unsigned long long), s)); }
+#endif
+        hipLaunchKernelGGL(k_limiter_wave, dim3((unsigned)((ntargets + LANES - 1) / LANES)), dim3(LANES), smem, s, in, out, n, sr, limit,
+                           buffer_size, release_s, asc_coeff, cand, ntargets, blk, in_gain, block_max, nblk, prof);
+#ifdef JT_AB
+        if (prof) {
+            unsigned long long c[16];
+            JT_HIP(hipStreamSynchronize(s)); JT_HIP(hipMemcpy(c, prof, sizeof c, hipMemcpyDeviceToHost));
+            fprintf(stderr, "limiter (B = %d, %lld samples): wave cycles (100 MHz clock) rest %llu ramp %llu hot %llu; tiles %llu / %llu / %llu; samples above the limit %llu, "
+                            "list entries tested %llu; %llu hot segments; longest workgroup %llu\n", buffer_size, (long long)n, c[0], c[1], c[2], c[3], c[4], c[5], c[6], c[9], c[8], c[7]);
+        }
+#endif
+        return;
+    }
     hipLaunchKernelGGL(k_limiter_f64, dim3((unsigned)((ntargets + LANES - 1) / LANES)), dim3(LANES), 0, s, in, out, n, sr, limit,
                        buffer_size, release_s, asc_coeff, cand, ntargets, blk, in_gain, scratch_delta, scratch_pos, block_max, nblk, scratch_lp);
 }
