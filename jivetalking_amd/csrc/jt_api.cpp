@@ -1114,7 +1114,11 @@ static void run_limiter(jt_ctx *h, double *in, double *out, int64_t n, int sr, d
     const int blk = 256;
     const int64_t nblk = (n + blk - 1) / blk;
     h->d_scr3.ensure((size_t)nblk);
-    if (src.s16 && !JT_AB_ON(h->opts.no_lim_s16)) launch_absmax_conv_s16(src.s16, in, out, n, src.vol, src.vol_in_float, in_gain, h->d_scr3.p, nblk, h->stream);
+    // the wave-per-segment limiter reads the few samples of its hot segments from the s16 source itself: the converted signal is not stored
+    const bool from16 = src.s16 && !JT_AB_ON(h->opts.no_lim_s16) && jt_limiter_wave_ok(B) && !h->opts.limiter_lanes;
+    const LimSrc16 s16src{src.s16, src.vol, src.vol_in_float};
+    if (from16) launch_absmax_conv_s16(src.s16, nullptr, out, n, src.vol, src.vol_in_float, in_gain, h->d_scr3.p, nblk, h->stream);
+    else if (src.s16 && !JT_AB_ON(h->opts.no_lim_s16)) launch_absmax_conv_s16(src.s16, in, out, n, src.vol, src.vol_in_float, in_gain, h->d_scr3.p, nblk, h->stream);
     else {
         if (src.s16) launch_s16_to_f64(src.s16, in, n, src.vol, src.vol_in_float, h->stream);
         launch_absmax_copy_f64(in, out, n, in_gain, h->d_scr3.p, nblk, h->stream);      // blk == 256
@@ -1127,7 +1131,7 @@ static void run_limiter(jt_ctx *h, double *in, double *out, int64_t n, int sr, d
     h->lim_bounds.ensure((size_t)ntargets);
     h->lim_delta.ensure((size_t)ntargets * B); h->lim_pos.ensure((size_t)ntargets * B); h->lim_lp.ensure((size_t)ntargets * B);
     launch_limiter_f64(in, out, n, sr, limit, B, release, asc_coeff, h->d_scr3.p, nblk, blk, need, target, h->lim_bounds.p, ntargets,
-                       in_gain, h->lim_delta.p, h->lim_pos.p, h->stream, h->lim_lp.p, h->opts.limiter_lanes, JT_AB_ON(h->opts.lim_profile));
+                       in_gain, h->lim_delta.p, h->lim_pos.p, h->stream, h->lim_lp.p, h->opts.limiter_lanes, JT_AB_ON(h->opts.lim_profile), from16 ? &s16src : nullptr);
 }
 
 // loudnorm (dynamic-mode first pass) input statistics of a signal at `rate`, measured after swr -> 192 kHz

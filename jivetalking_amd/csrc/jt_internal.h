@@ -169,10 +169,13 @@ void launch_band_rms(const float *in, int64_t n, int nbands, const double (*hp)[
 void launch_absmax_copy_f64(const double *in, double *out, int64_t n, double gain, double *out_max, int64_t nblk, hipStream_t s);
 void launch_absmax_conv_s16(const int16_t *in, double *conv, double *out, int64_t n, double vol, int vol_in_float, double gain, double *out_max,
                             int64_t nblk, hipStream_t s);
+struct LimSrc16 { const int16_t *p; double vol; int vol_in_float; };
 void launch_limiter_f64(const double *in, double *out, int64_t n, int sr, double limit, int buffer_size,
                         double release_s, double asc_coeff, const double *block_max, int64_t nblk, int blk, int need, int target,
                         int64_t *cand, int64_t ntargets, double in_gain, double *scratch_delta, int64_t *scratch_pos, hipStream_t s, double *scratch_lp,
-                        bool lane_per_segment = false, bool lim_profile = false);      // lane_per_segment: k_limiter_f64 instead of k_limiter_wave
+                        bool lane_per_segment = false, bool lim_profile = false, const LimSrc16 *src16 = nullptr);
+// lane_per_segment: k_limiter_f64 instead of k_limiter_wave; src16: the wave kernel converts its hot segments from the s16 source (in may be null)
+bool jt_limiter_wave_ok(int buffer_size);
 
 // resampler / true peak
 void launch_resample_to_s16(const float *in, int64_t n, const double *bank, int phase_count, int filter_length, int center,

@@ -1340,8 +1340,9 @@ k_absmax_copy_f64(const double *__restrict__ in, double *__restrict__ out, int64
     }
 }
 // The same sweep fed by the s16 Pass-2 output (the limiter prefix of Pass 3 / Pass 4: volume -> alimiter): the s16 -> dbl conversion of
-// k_s16_to_f64 (same arithmetic, incl. the float-precision volume stage) is done here, `conv` receives the converted signal the
-// limiter's hot segments read, `out` = conv * gain.  Saves a launch and one 8-byte read per sample on the Pass-3 critical path.
+// k_s16_to_f64 (same arithmetic, incl. the float-precision volume stage) is done here, `out` = converted * gain; `conv` (may be null)
+// receives the converted signal for a limiter kernel that reads doubles -- k_limiter_wave converts the few samples of its hot segments
+// from the s16 source itself, so the prefix no longer writes 8 bytes per sample that 1.5 % of the samples are read back from.
 __global__ void __launch_bounds__(256)
 k_absmax_conv_s16(const int16_t *__restrict__ in, double *__restrict__ conv, double *__restrict__ out, int64_t n, double vol, int vol_in_float,
                   double gain, double *__restrict__ out_max, int64_t nblk)
@@ -1361,12 +1362,14 @@ k_absmax_conv_s16(const int16_t *__restrict__ in, double *__restrict__ conv, dou
             const short4 x = *reinterpret_cast<const short4 *>(in + base + 4 * lane);           // (base is a multiple of 256: 8-byte aligned)
             const double v0 = cv(x.x), v1 = cv(x.y), v2 = cv(x.z), v3 = cv(x.w);
             m = fmax(fmax(fabs(v0), fabs(v1)), fmax(fabs(v2), fabs(v3)));
-            *reinterpret_cast<double2 *>(conv + base + 4 * lane) = double2{v0, v1};
-            *reinterpret_cast<double2 *>(conv + base + 4 * lane + 2) = double2{v2, v3};
+            if (conv) {
+                *reinterpret_cast<double2 *>(conv + base + 4 * lane) = double2{v0, v1};
+                *reinterpret_cast<double2 *>(conv + base + 4 * lane + 2) = double2{v2, v3};
+            }
             *reinterpret_cast<double2 *>(out + base + 4 * lane) = double2{v0 * gain, v1 * gain};
             *reinterpret_cast<double2 *>(out + base + 4 * lane + 2) = double2{v2 * gain, v3 * gain};
         } else {
-            for (int64_t i = base + lane; i < n; i += 64) { const double v = cv(in[i]); m = fmax(m, fabs(v)); conv[i] = v; out[i] = v * gain; }
+            for (int64_t i = base + lane; i < n; i += 64) { const double v = cv(in[i]); m = fmax(m, fabs(v)); if (conv) conv[i] = v; out[i] = v * gain; }
         }
         for (int off = 32; off > 0; off >>= 1) m = fmax(m, __shfl_down(m, off, 64));
         if (lane == 0) out_max[b] = m;
@@ -1642,11 +1645,21 @@ __device__ __forceinline__ double lim_bcast(double v, int j)
 }
 __device__ __forceinline__ double lim_wave_max(double v) { for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o, 64)); return v; }
 
+// S16: the signal is the s16 Pass-2 output behind the volume stage (vol, in float precision when vol_in_float): converted as k_absmax_conv_s16 does
+template <bool S16>
 __global__ void __launch_bounds__(64)
-k_limiter_wave(const double *__restrict__ in, double *__restrict__ out, int64_t n, int sr, double limit, int B,
+k_limiter_wave(const void *__restrict__ in_v, double *__restrict__ out, int64_t n, int sr, double limit, int B,
                double release, double asc_coeff, const int64_t *__restrict__ cand, int64_t ntargets, int blk, double in_gain,
-               const double *__restrict__ block_max, int64_t nblk, unsigned long long *__restrict__ prof)
+               const double *__restrict__ block_max, int64_t nblk, unsigned long long *__restrict__ prof, double vol, int vol_in_float)
 {
+    const double *in = static_cast<const double *>(in_v);
+    const int16_t *in16 = static_cast<const int16_t *>(in_v);
+    auto sample = [&](int64_t i) -> double {
+        if (!S16) return in[i];
+        const int16_t x = in16[i];
+        if (vol_in_float) { float v = (float)x * (1.0f / 32768.0f); v = v * (float)vol; return (double)v; }
+        return (double)x * (1.0 / 32768.0) * vol;
+    };
     extern __shared__ __attribute__((aligned(16))) unsigned char lw_smem[];
 #ifdef JT_AB
     // phase clocks of the A/B build (option lim_profile): [0..2] wave cycles in rest / ramp / hot tiles, [3..5] their tile counts, [6] hot
@@ -1696,7 +1709,7 @@ k_limiter_wave(const double *__restrict__ in, double *__restrict__ out, int64_t 
         auto fetch = [&](int64_t pos, double &vx, double &ve) {
             const int64_t ix = lo + pos + lane, ie = ix - (B - 1);
             const int64_t cx = ix < 0 ? 0 : (ix >= n ? n - 1 : ix), ce = ie < 0 ? 0 : (ie >= n ? n - 1 : ie);
-            vx = in[cx]; ve = in[ce];
+            vx = sample(cx); ve = sample(ce);
         };
         // (four tiles ahead: a ramp tile takes a fifth of a memory round trip since its gains are formed first)
         constexpr int PF = 4;
@@ -1852,25 +1865,32 @@ k_limiter_wave(const double *__restrict__ in, double *__restrict__ out, int64_t 
 #undef LW_MARK
 }
 
+bool jt_limiter_wave_ok(int buffer_size) { return 24 * (size_t)buffer_size <= 96 * 1024; }
 void launch_limiter_f64(const double *in, double *out, int64_t n, int sr, double limit, int buffer_size,
                         double release_s, double asc_coeff, const double *block_max, int64_t nblk, int blk, int need, int target,
                         int64_t *cand, int64_t ntargets, double in_gain, double *scratch_delta, int64_t *scratch_pos, hipStream_t s, double *scratch_lp,
-                        bool lane_per_segment, bool lim_profile)
+                        bool lane_per_segment, bool lim_profile, const LimSrc16 *src16)
 {
     if (n <= 0) return;
     (void)lim_profile;
+    JT_REQUIRE(!src16 || (jt_limiter_wave_ok(buffer_size) && !lane_per_segment), JT_E_INVAL, "limiter: an s16 source needs the wave-per-segment kernel");
     hipLaunchKernelGGL(k_lim_bounds, dim3((unsigned)((ntargets + 255) / 256)), dim3(256), 0, s, block_max, nblk, need, target,
                        std::fabs(in_gain), limit, cand, ntargets);
     // one hot segment per wave at a time, the pending-peak list (24 B bytes) in LDS; look-ahead buffers too long for that keep a lane per segment
     const size_t smem = 24 * (size_t)buffer_size;
-    if (smem <= 96 * 1024 && !lane_per_segment) {
-        JT_HIP(hipFuncSetAttribute((const void *)k_limiter_wave, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    if (jt_limiter_wave_ok(buffer_size) && !lane_per_segment) {
+        JT_HIP(hipFuncSetAttribute((const void *)k_limiter_wave<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
         unsigned long long *prof = nullptr;
 #ifdef JT_AB
         if (lim_profile) { prof = reinterpret_cast<unsigned long long *>(scratch_lp); JT_HIP(hipMemsetAsync(prof, 0, 16 * sizeof(unsigned long long), s)); }
 #endif
-        hipLaunchKernelGGL(k_limiter_wave, dim3((unsigned)((ntargets + LANES - 1) / LANES)), dim3(LANES), smem, s, in, out, n, sr, limit,
-                           buffer_size, release_s, asc_coeff, cand, ntargets, blk, in_gain, block_max, nblk, prof);
+        if (src16) {
+            JT_HIP(hipFuncSetAttribute((const void *)k_limiter_wave<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+            hipLaunchKernelGGL(k_limiter_wave<true>, dim3((unsigned)((ntargets + LANES - 1) / LANES)), dim3(LANES), smem, s, (const void *)src16->p, out, n, sr, limit,
+                               buffer_size, release_s, asc_coeff, cand, ntargets, blk, in_gain, block_max, nblk, prof, src16->vol, src16->vol_in_float);
+        } else
+        hipLaunchKernelGGL(k_limiter_wave<false>, dim3((unsigned)((ntargets + LANES - 1) / LANES)), dim3(LANES), smem, s, (const void *)in, out, n, sr, limit,
+                           buffer_size, release_s, asc_coeff, cand, ntargets, blk, in_gain, block_max, nblk, prof, 1.0, 0);
 #ifdef JT_AB
         if (prof) {
             unsigned long long c[16];
