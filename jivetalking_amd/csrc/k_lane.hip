@@ -1321,6 +1321,34 @@ k_absmax_copy_f64(const double *__restrict__ in, double *__restrict__ out, int64
 {
     const int lane = threadIdx.x & 63;
     const int64_t w = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if ((w * 8 + 8) * 256 <= n) {
+        // a wave's eight blocks, all sixteen loads in flight before the first is used (one block at a time left a wave with two loads in
+        // flight and the sweep at 3.3 TB/s)
+        const int64_t base0 = w * 8 * 256;
+        double2 v[16];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            v[2 * q] = *reinterpret_cast<const double2 *>(in + base0 + q * 256 + 2 * lane);
+            v[2 * q + 1] = *reinterpret_cast<const double2 *>(in + base0 + q * 256 + 128 + 2 * lane);
+        }
+        double mq[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            mq[q] = fmax(fmax(fabs(v[2 * q].x), fabs(v[2 * q].y)), fmax(fabs(v[2 * q + 1].x), fabs(v[2 * q + 1].y)));
+            *reinterpret_cast<double2 *>(out + base0 + q * 256 + 2 * lane) = double2{v[2 * q].x * gain, v[2 * q].y * gain};
+            *reinterpret_cast<double2 *>(out + base0 + q * 256 + 128 + 2 * lane) = double2{v[2 * q + 1].x * gain, v[2 * q + 1].y * gain};
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) mq[q] = fmax(mq[q], __shfl_down(mq[q], off, 64));
+        }
+        if (lane == 0) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) out_max[w * 8 + q] = mq[q];
+        }
+        return;
+    }
     for (int q = 0; q < 8; ++q) {
         const int64_t b = w * 8 + q;
         if (b >= nblk) return;
@@ -1353,6 +1381,36 @@ k_absmax_conv_s16(const int16_t *__restrict__ in, double *__restrict__ conv, dou
         if (vol_in_float) { float v = (float)x * (1.0f / 32768.0f); v = v * (float)vol; return (double)v; }
         return (double)x * (1.0 / 32768.0) * vol;
     };
+    if ((w * 8 + 8) * 256 <= n) {
+        // (as k_absmax_copy_f64: the wave's eight loads first)
+        const int64_t base0 = w * 8 * 256;
+        short4 xs[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) xs[q] = *reinterpret_cast<const short4 *>(in + base0 + q * 256 + 4 * lane);
+        double mq[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const double v0 = cv(xs[q].x), v1 = cv(xs[q].y), v2 = cv(xs[q].z), v3 = cv(xs[q].w);
+            mq[q] = fmax(fmax(fabs(v0), fabs(v1)), fmax(fabs(v2), fabs(v3)));
+            const int64_t o = base0 + q * 256 + 4 * lane;
+            if (conv) {
+                *reinterpret_cast<double2 *>(conv + o) = double2{v0, v1};
+                *reinterpret_cast<double2 *>(conv + o + 2) = double2{v2, v3};
+            }
+            *reinterpret_cast<double2 *>(out + o) = double2{v0 * gain, v1 * gain};
+            *reinterpret_cast<double2 *>(out + o + 2) = double2{v2 * gain, v3 * gain};
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) mq[q] = fmax(mq[q], __shfl_down(mq[q], off, 64));
+        }
+        if (lane == 0) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) out_max[w * 8 + q] = mq[q];
+        }
+        return;
+    }
     for (int q = 0; q < 8; ++q) {
         const int64_t b = w * 8 + q;
         if (b >= nblk) return;
