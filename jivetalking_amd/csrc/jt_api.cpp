@@ -59,8 +59,9 @@ extern "C" int jt_open(int device_id, jt_ctx **out)
         // statistics nobody waits for (-0.45 ms per file); where a pass ends with its analysis the chains are alone anyway
 #ifdef JT_AB
         const bool aux_low = getenv("JT_AUX_NORMAL") == nullptr;      // (A/B build only: the analysis chains back in the normal class)
+        const bool tp_normal = getenv("JT_TP_LOW") == nullptr;
 #else
-        const bool aux_low = true;
+        const bool aux_low = true, tp_normal = true;
 #endif
         // lowest priority: the small band-RMS launches the host is waiting for must get through beside it
         JT_HIP(hipStreamCreateWithPriority(&h->spec_p2.stream, hipStreamNonBlocking, prio_least));
@@ -69,7 +70,9 @@ extern "C" int jt_open(int device_id, jt_ctx **out)
         JT_HIP(hipEventCreateWithFlags(&h->spec_ln.fork, hipEventDisableTiming));
         // the chains of announced output regions (aux[4..7]) are small: aliases of other streams, picked by pass_begin
         for (int i = 0; i < 8; ++i) {
-            if (i < 4) JT_HIP(hipStreamCreateWithPriority(&h->aux[i], hipStreamNonBlocking, aux_low ? prio_least : 0));
+            // (aux[3] carries the true-peak sweep, the longest chain of every analysis and, in Pass 2, what the limiter plan waits for: it
+            // stays in the normal class so that its workgroups are placed before the other statistics')
+            if (i < 4) JT_HIP(hipStreamCreateWithPriority(&h->aux[i], hipStreamNonBlocking, (aux_low && !(i == 3 && tp_normal)) ? prio_least : 0));
             else h->aux[i] = h->aux[(i + 3) % 4];
             JT_HIP(hipEventCreateWithFlags(&h->ev_join[i], hipEventDisableTiming));
         }
