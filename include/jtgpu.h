@@ -301,7 +301,9 @@ int jt_op_flac_encode_s16(jt_ctx *h, const int16_t *pcm, int64_t n, int sample_r
 typedef struct { double pass1_ms, pass2_ms, pass3_ms, pass4_ms; double nlm_ms; int64_t nlm_launches;
                  int64_t declick_repaired;   /* samples adeclick re-interpolated in the last Pass 4 (diagnostic) */
                  double declick_ms;          /* adeclick kernel time in the last Pass 4 */
-                 int64_t declick_heavy_windows; /* windows that needed the full-capacity second pass */ } jt_timers;
+                 int64_t declick_heavy_windows; /* windows that needed the full-capacity second pass */
+                 int64_t tp_units_total,     /* last long analysis, branch-and-bound true peak: units of the signal ... */
+                         tp_units_evaluated; /* ... and those whose 192 kHz outputs were evaluated (seeds + kept units) */ } jt_timers;
 int jt_get_timers(jt_ctx *h, jt_timers *out);
 
 /* =====================================================================================

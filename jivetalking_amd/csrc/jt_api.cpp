@@ -127,7 +127,7 @@ static bool opt_int(const char *v, int *out)
 {
     if (!v || !*v) return false;
     char *end = nullptr; const long x = strtol(v, &end, 10);
-    if (*end || x < -1000000 || x > 1000000) return false;
+    if (*end || x < -1000000 || x > ((long)1 << 30)) return false;
     *out = (int)x; return true;
 }
 int jt_opts_set(JtOpts *o, const char *key, const char *value)
@@ -294,6 +294,12 @@ static SwrDev &get_swr(jt_ctx *h, int in_rate, int out_rate)
     SwrDev &e = h->swr[h->swr_next]; h->swr_next = (h->swr_next + 1) % 4;
     JT_HIP(hipStreamSynchronize(h->stream));             // the slot's old banks may still be read by queued kernels
     jt_swr_plan(&e.pl, in_rate, out_rate);
+    e.l1max = 0;
+    for (int ph = 0; ph < e.pl.phase_count; ++ph) {
+        double a = 0;
+        for (int t = 0; t < e.pl.filter_length; ++t) a += std::fabs(e.pl.bank[(size_t)ph * e.pl.filter_length + t]);
+        e.l1max = std::max(e.l1max, a);
+    }
     std::vector<float> bf(e.pl.bank.size());
     for (size_t i = 0; i < bf.size(); ++i) bf[i] = (float)e.pl.bank[i];
     e.bank_d.ensure(e.pl.bank.size()); e.bank_f.ensure(bf.size());
@@ -334,7 +340,7 @@ static void pass_begin(jt_ctx *h, int64_t max_samples, int analyses, int64_t ext
         const size_t slab = (size_t)(max_samples / 400 + 16) * na + (size_t)(extra_samples / 400 + 16) * ne;
         h->d_scr1.ensure(slab);
         JT_HIP(hipMemsetAsync(h->d_scr1.p, 0, sizeof(double) * slab, h->stream));
-        h->tp_off = 0; h->tp_cap = slab;
+        h->tp_off = 0; h->tp_cap = slab; h->tp_scr_off = 0;
     }
     h->spec_hops.ensure((size_t)(max_samples / 512 + 16));
     h->ehist.ensure(8192);
@@ -349,6 +355,7 @@ struct AnalysisHost {
 };
 struct AnalysisJob {
     AstatsJob as; KwJob kw; const double *btp = nullptr; const jt_spectral *hops = nullptr;
+    const int *tp_kept = nullptr; int64_t tp_units = 0, tp_seeds = 0;      // branch-and-bound true peak: units kept by round 2 (pinned), units, seeds
     int64_t n = 0, nfull = 0, nhops = 0, nout = 0; int blk = 0, sr = 0; bool dualmono = false, want_astats = true, want_r128 = true, want_spec = true;
     bool astats_levels_only = false;
 };
@@ -392,8 +399,27 @@ static void analysis_enqueue(jt_ctx *h, const float *x, int64_t n, int sr, bool 
         SwrDev &sw = get_swr(h, sr, 192000);
         JT_REQUIRE(h->tp_off + (size_t)nfull + 2 <= h->tp_cap, JT_E_HIP, "true-peak scratch exhausted");
         double *d_tp = h->d_scr1.p + h->tp_off; h->tp_off += ((size_t)nfull + 2 + 7) & ~(size_t)7;      // (zeroed by pass_begin)
-        launch_true_peak_f32(x, n, sw.bank_d.p, sw.pl.phase_count, sw.pl.filter_length, sw.pl.center, sw.pl.step, blk, d_tp, nfull + 1,
-                             sw.out_len(n), a3, &h->opts);
+        // long signals: only the units that can move the running maximum are evaluated (k_resample.hip, branch and bound); the unit
+        // bounds and lists of the pass's long analysis live in tp_scr (a second long analysis in the same pass runs exhaustively)
+        bool pruned = false;
+        if (!h->opts.tp_unpruned && n >= (int64_t)h->opts.tp_prune_min) {
+            const size_t need = jt_tp_prune_scratch_bytes(n, sw.pl.phase_count, sw.pl.filter_length, sw.pl.step, blk);
+            if (need && h->tp_scr_off == 0) {
+                h->tp_scr.ensure(need);
+                const int *kept = nullptr;
+                pruned = launch_true_peak_f32_pruned(x, n, sw.bank_d.p, sw.pl.phase_count, sw.pl.filter_length, sw.pl.center, sw.pl.step, blk, d_tp,
+                                                     nfull + 1, sw.out_len(n), sw.l1max, h->tp_scr.p, need, a3, &kept, &J->tp_units, &J->tp_seeds);
+                if (pruned) {
+                    h->tp_scr_off = need;
+                    int *hk = h->pin.take<int>(2);
+                    JT_HIP(hipMemcpyAsync(hk, kept, sizeof(int), hipMemcpyDeviceToHost, a3));
+                    J->tp_kept = hk;
+                }
+            }
+        }
+        if (!pruned)
+            launch_true_peak_f32(x, n, sw.bank_d.p, sw.pl.phase_count, sw.pl.filter_length, sw.pl.center, sw.pl.step, blk, d_tp, nfull + 1,
+                                 sw.out_len(n), a3, &h->opts);
         double *btp = h->pin.take<double>((size_t)nfull + 2);
         JT_HIP(hipMemcpyAsync(btp, d_tp, sizeof(double) * (nfull + 2), hipMemcpyDeviceToHost, a3));
         J->btp = btp;
@@ -454,6 +480,7 @@ static void analysis_finish(jt_ctx *h, const AnalysisJob &J, AnalysisHost *A, bo
         // trailing partial frame: peaks still update (f_ebur128.c runs the per-sample loop over it)
         sp = std::max(sp, bpk[(size_t)nfull]); tp = std::max(tp, J.btp[(size_t)nfull]);
         A->sp_final = sp; A->tp_final = tp;
+        if (J.tp_kept) { h->timers.tp_units_total = J.tp_units; h->timers.tp_units_evaluated = J.tp_seeds + *J.tp_kept; }
     }
     if (J.want_spec) { wait(2); A->hops = J.hops; A->nhops = J.nhops; A->nout = J.nout; }
 }

@@ -90,8 +90,8 @@ template <typename T> struct DevBuf {
 // that build imports JT_<KEY> variables, once, inside jt_open.
 #define JT_OPT_BOOLS(X) \
     X(no_pass2_prefetch) X(no_early_pass3) X(no_early_plan) X(no_lim_keep) X(no_staged_finish) X(no_r128_first) \
-    X(region_full_astats) X(host_timing) X(adeclick_exact) X(nlm_generic) X(p3_unfused) X(limiter_lanes)
-#define JT_OPT_INTS(X) X(region_rot)
+    X(region_full_astats) X(host_timing) X(adeclick_exact) X(nlm_generic) X(p3_unfused) X(limiter_lanes) X(tp_unpruned)
+#define JT_OPT_INTS(X) X(region_rot) X(tp_prune_min)
 #define JT_OPT_AB_BOOLS(X) \
     X(nlm_old) X(afftdn_old) X(adeclick_fused) X(dk_levinson_in_kernel) X(dk_no_xcd) X(dk_serial) X(dk_profile) X(dyn_one_wave) \
     X(dyn_no_cu_reserve) X(kw_two_sweeps) X(follow_tiles) X(follow_one_wave) X(tp_old) X(lim_profile) X(ups_no_stream8) X(ups_no_stream16) X(edge_polyphase) X(no_lim_s16)
@@ -103,6 +103,7 @@ struct JtOpts {
 #define X(k) int k = 0;
     JT_OPT_AB_INTS(X)
 #undef X
+    int tp_prune_min = 1 << 20;          // signals at least this long take the branch-and-bound true peak (k_resample.hip); shorter ones the exhaustive kernels
     int region_rot = -1;                 // -1: the announced regions' chains on adeclick's second stream; r: region chain i behind full chain (i + r) % 4
 };
 #ifdef JT_AB
@@ -185,6 +186,12 @@ int64_t launch_resample_range_to_s16(const float *in, int64_t n, const double *b
 int64_t jt_resample_range_cap(int64_t n, int phase_count, int filter_length, int64_t step, int64_t m, int64_t m_count);
 void launch_true_peak_f32(const float *in, int64_t n, const double *bank, int phase_count, int filter_length, int center,
                           int64_t step, int blk, double *block_tp, int64_t nblocks_alloc, int64_t m_total, hipStream_t s, const JtOpts *o = nullptr);
+// branch-and-bound true peak (block maxima of the evaluated units only: the PREFIX maximum is what equals the exhaustive kernels');
+// false = plan / length not served.  l1max = the largest l1 norm of a tap row
+size_t jt_tp_prune_scratch_bytes(int64_t n, int phase_count, int filter_length, int64_t step, int blk);
+bool launch_true_peak_f32_pruned(const float *in, int64_t n, const double *bank, int phase_count, int filter_length, int center, int64_t step,
+                                 int blk, double *block_tp, int64_t nblocks_alloc, int64_t m_total, double l1max, void *scratch,
+                                 size_t scratch_bytes, hipStream_t s, const int **kept_dev = nullptr, int64_t *units = nullptr, int64_t *seeds = nullptr);
 void launch_true_peak_f64(const double *in, int64_t n, const double *bank, int phase_count, int filter_length, int center,
                           int64_t step, int blk, double *block_tp, int64_t nblocks_alloc, int64_t m_total, hipStream_t s, const JtOpts *o = nullptr);
 // Pass-3 192 kHz streams (FLT path from s16, DBL path after the limiter prefix); K-weighted afterwards by launch_kweight_blocks_*
@@ -298,6 +305,7 @@ struct HostArena {
 // cached resampler plans (the kaiser bank depends on the rate pair only) with their device copies
 struct SwrDev {
     int in_rate = 0, out_rate = 0; SwrPlanHost pl; DevBuf<double> bank_d; DevBuf<float> bank_f;
+    double l1max = 0;            // largest l1 norm of a tap row (the true peak's branch-and-bound bound)
     DevBuf<float> bank_fs;       // bank_f * 2^-15 (s16 sources: the int -> float scale folded into the taps); empty unless that product is exact
     int64_t out_len(int64_t n) const { return (int64_t)(((__int128)n * pl.phase_count + pl.step - 1) / pl.step); }
 };
@@ -387,6 +395,7 @@ struct jt_ctx {
         unsigned char *r = reinterpret_cast<unsigned char *>(d_scr2.p) + as_off; as_off += (bytes + 255) & ~(size_t)255; return r;
     }
     // per-pass bump allocator over d_scr0 for the K-weighting jobs (several can be in flight before the pass's sync)
+    DevBuf<unsigned char> tp_scr; size_t tp_scr_off = 0;     // the branch-and-bound true peak's unit bounds / lists (one long analysis per pass)
     size_t tp_off = 0, tp_cap = 0;      // bump allocator over d_scr1: the per-block true-peak maxima of a pass (zeroed once by pass_begin)
     size_t kw_off = 0;
     void kw_begin(size_t doubles) { d_scr0.ensure(doubles); kw_off = 0; }

@@ -885,6 +885,359 @@ k_tp_stream(const TIn *__restrict__ in, int64_t n, const TTap *__restrict__ bank
 }
 constexpr int TP_NWV = 8;
 
+// ---------------------------------------------------------------- true peak by branch and bound (round 4)
+// ebur128's true peak reaches the host logic only as a RUNNING maximum (lavfi.r128.true_peak of frame k = the largest |y| of the
+// 192 kHz stream up to frame k: analysis_finish folds the per-100 ms maxima with a prefix max).  An output is a 32-tap sum, so
+// |y| <= A * max|x over its window| with A = the largest l1 norm of a tap row (times 1 + 1e-9: the 32 roundings of the FMA chain are
+// below 4e-15 of that bound).  A UNIT (one polyphase period at fractional ratios, 256 consecutive windows at integer ratios) whose
+// bound does not exceed an |y| that was evaluated EXACTLY in an earlier unit cannot move the running maximum at any frame and is
+// not evaluated at all.  Two rounds: (1) k_tp_bounds sweeps the signal once (max |x| per unit) and names the loudest unit of every
+// group of 64 as a seed, k_tp_list_* evaluates the seeds exactly (E[g], and a coarse maximum per 64 groups); (2) k_tp_select keeps
+// the units whose bound exceeds the largest seed result of the groups BEFORE theirs, k_tp_list_* evaluates those.  Every evaluated
+// output is the same tap sum in the same order attributed to the same 100 ms block as in k_upsample32 / k_tp_stream: the block
+// maxima of evaluated units are bit-identical, the others stay zero, and the prefix maximum -- all anybody reads -- is identical.
+// What is saved depends on the signal: speech keeps the units within 20 log10(A) ~ 6 dB of the loudest peak so far.
+struct TpPruneDev {
+    float *amax; int *seed, *list, *cnt; unsigned long long *E, *Ec;
+    int64_t n_units, n_groups; int G;       // periods per unit
+};
+
+__device__ inline float tp_load_abs(const float *__restrict__ in, int64_t n, int64_t g)
+{
+    if (g < 0) g = -g;                                               // invert_initial_buffer(): in[-j] = in[j]
+    return g < n ? fabsf(in[g]) : 0.0f;                              // (the true-peak stream is never flushed)
+}
+
+// one workgroup (four waves) per group of 64 units; a wave reads a unit's span (S + 31 samples) with coalesced loads
+__global__ void __launch_bounds__(256)
+k_tp_bounds(const float *__restrict__ in, int64_t n, int center, int S, TpPruneDev D)
+{
+    __shared__ float gmax[64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t g = blockIdx.x;
+    const int span = S + 31;
+    const bool interior = (g * 64) * S - center >= 0 && (g * 64 + 64) * S - center + 31 <= n;
+#pragma unroll 4
+    for (int k = 0; k < 16; ++k) {
+        const int ul = wave * 16 + k;
+        const int64_t u = g * 64 + ul;
+        float v = 0.0f;
+        if (u < D.n_units) {
+            const int64_t base = u * S - center;
+            if (interior) { for (int i = lane; i < span; i += 64) v = fmaxf(v, fabsf(in[base + i])); }
+            else { for (int i = lane; i < span; i += 64) v = fmaxf(v, tp_load_abs(in, n, base + i)); }
+        }
+#pragma unroll
+        for (int mm = 1; mm < 64; mm <<= 1) v = fmaxf(v, __shfl_xor(v, mm, 64));
+        if (lane == 0) { gmax[ul] = v; if (u < D.n_units) D.amax[u] = v; }
+    }
+    __syncthreads();
+    if (wave == 0) {
+        // the loudest unit of the group (ties: the earliest)
+        unsigned long long key = ((unsigned long long)__float_as_uint(gmax[lane]) << 32) | (unsigned)(63 - lane);
+        if (g * 64 + lane >= D.n_units) key = 0ull;
+#pragma unroll
+        for (int mm = 1; mm < 64; mm <<= 1) {
+            const unsigned long long o = ((unsigned long long)(unsigned)__shfl_xor((int)(key >> 32), mm, 64) << 32) | (unsigned)__shfl_xor((int)(unsigned)key, mm, 64);
+            key = o > key ? o : key;
+        }
+        if (lane == 0) {
+            D.seed[g] = (int)(g * 64 + (63 - (int)(key & 63u)));
+            D.E[g] = 0ull;
+            if ((g & 63) == 0) D.Ec[g >> 6] = 0ull;
+            if (g == 0) *D.cnt = 0;
+        }
+    }
+}
+
+// round 2's list: a wave per group; lbp = the largest exact |y| of the seeds of all EARLIER groups
+__global__ void __launch_bounds__(256)
+k_tp_select(TpPruneDev D, double A)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t g = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (g >= D.n_groups) return;
+    const int64_t c = g >> 6;
+    unsigned long long lb = 0ull;
+    for (int64_t k = lane; k < c; k += 64) { const unsigned long long v = D.Ec[k]; lb = v > lb ? v : lb; }
+    if (lane < (int)(g & 63)) { const unsigned long long v = D.E[c * 64 + lane]; lb = v > lb ? v : lb; }
+    double lbp = __longlong_as_double((long long)lb);               // (non-negative doubles order like their bit patterns)
+#pragma unroll
+    for (int mm = 1; mm < 64; mm <<= 1) lbp = fmax(lbp, __shfl_xor(lbp, mm, 64));
+    const int64_t u = g * 64 + lane;
+    const bool keep = u < D.n_units && (int)u != D.seed[g] && (double)D.amax[u] * A > lbp;
+    const unsigned long long m = __ballot(keep);
+    const int total = __popcll(m);
+    int base = 0;
+    if (lane == 0 && total) base = atomicAdd(D.cnt, total);
+    base = __shfl(base, 0, 64);
+    if (keep) D.list[base + __popcll(m & ((1ull << lane) - 1ull))] = (int)u;
+}
+
+// fractional ratios (k_tp_stream's layout over a GATHERED tile): lane = one listed period, eight waves share the 64 rows and walk an
+// eighth of the period's outputs each; rows are step + 31 samples at an odd stride
+template <int NWV>
+__global__ void __launch_bounds__(64 * NWV)
+k_tp_list_period(const float *__restrict__ in, int64_t n, const double *__restrict__ bank, int P, int center, int step, int64_t m_total, int blk,
+                 unsigned long long *__restrict__ block_tp, int64_t nblocks_alloc, TpPruneDev D, const int *__restrict__ list, int count_host,
+                 int seeds)
+{
+    constexpr int L = 32, NT = 64 * NWV;
+    extern __shared__ unsigned char smem_pp[];
+    __shared__ unsigned long long lmax[64][2];
+    __shared__ int qs[64];
+    float *xin = reinterpret_cast<float *>(smem_pp);
+    const int RW = step + L - 1, RS = RW | 1;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane((int)(tid >> 6));
+    const int count = seeds ? count_host : *D.cnt;
+    const unsigned uP = (unsigned)P, ustep = (unsigned)step;
+    const int JW = P / NWV, jw0 = wave * JW, jw1 = jw0 + JW;
+    const int off_first = (int)(((unsigned)jw0 * ustep) / uP), off_last = (int)(((unsigned)(jw1 - 1) * ustep) / uP);
+    for (int chunk = blockIdx.x; (int64_t)chunk * 64 < count; chunk += gridDim.x) {
+        const int e = chunk * 64 + lane;
+        const bool valid = e < count;
+        if (wave == 0) { qs[lane] = list[valid ? e : count - 1]; lmax[lane][0] = 0ull; lmax[lane][1] = 0ull; }
+        __syncthreads();
+        for (int r = wave; r < 64; r += NWV) {
+            const int64_t g0 = (int64_t)qs[r] * step - center;
+            float *row = xin + (size_t)r * RS;
+            if (g0 >= 0 && g0 + RW <= n) { for (int i = lane; i < RW; i += 64) row[i] = in[g0 + i]; }
+            else {
+                for (int i = lane; i < RW; i += 64) {
+                    int64_t g = g0 + i;
+                    if (g < 0) g = -g;
+                    row[i] = g < n ? in[g] : 0.0f;
+                }
+            }
+        }
+        __syncthreads();
+        const int64_t q = qs[lane];
+        const int64_t left = m_total - q * P;
+        const int jlim = left <= 0 ? 0 : (left >= (int64_t)P ? P : (int)left);
+        const int64_t base0 = q * step - center + L - 1;                  // `last` input sample of the period's first window
+        const int64_t b_first = (base0 < 0 ? 0 : base0) / blk;
+        double run_v = 0.0; int run_sl = -1;
+        auto flush_run = [&]() {
+            if (run_sl >= 0 && run_v > 0.0 && valid) atomicMax(&lmax[lane][run_sl], (unsigned long long)__double_as_longlong(run_v));
+            run_v = 0.0;
+        };
+        for (int off0 = off_first; off0 <= off_last; ++off0) {
+            const int off = __builtin_amdgcn_readfirstlane(off0);
+            int j_lo = (int)(((unsigned)off * uP + ustep - 1u) / ustep), j_hi = (int)(((unsigned)(off + 1) * uP + ustep - 1u) / ustep);
+            j_lo = j_lo > jw0 ? j_lo : jw0; j_hi = j_hi < jw1 ? j_hi : jw1;
+            double xw[L];
+            {
+                const float *wp = xin + off + RS * lane;
+#pragma unroll
+                for (int i = 0; i < L; ++i) xw[i] = (double)wp[i];
+            }
+            double vmax = 0.0;
+            int ph = (int)(((unsigned)j_lo * ustep) % uP);
+            auto row = [&](const double (&tp)[L], int j) {
+                double val = 0.0;
+#pragma unroll
+                for (int i = 0; i < L; ++i) val = fma(xw[i], tp[i], val);
+                vmax = j < jlim ? fmax(vmax, fabs(val)) : vmax;
+            };
+            auto fetch_row = [&](double (&tp)[L], int phase) {
+                const double *f = bank + (size_t)(unsigned)phase * L;
+#pragma unroll
+                for (int i = 0; i < L; ++i) tp[i] = f[i];
+            };
+            double ta[L], tb[L];
+            if (j_lo < j_hi) fetch_row(ta, ph);
+            for (int j = j_lo; j < j_hi; j += 2) {
+                int ph1 = ph + step; ph1 -= ph1 >= P ? P : 0;
+                int ph2 = ph1 + step; ph2 -= ph2 >= P ? P : 0;
+                fetch_row(tb, ph1);
+                row(ta, j);
+                if (j + 1 < j_hi) {
+                    fetch_row(ta, ph2);
+                    row(tb, j + 1);
+                }
+                ph = ph2;
+            }
+            const int64_t last = base0 + off;
+            if (last >= 0 && last <= n - 1 && vmax > 0.0) {
+                const int sl = (int)(last / blk - b_first);               // 0 or 1: a period is shorter than a block
+                if (sl != run_sl) { flush_run(); run_sl = sl; }
+                run_v = fmax(run_v, vmax);
+            }
+        }
+        flush_run();
+        __syncthreads();
+        if (tid < 128) {
+            const int l = tid >> 1, sl = tid & 1;
+            const unsigned long long v = lmax[l][sl];
+            const int64_t ql = qs[l];
+            const int64_t bl0 = ql * step - center + L - 1;
+            int64_t b = (bl0 < 0 ? 0 : bl0) / blk + sl;
+            if (b >= nblocks_alloc) b = nblocks_alloc - 1;
+            if (v && chunk * 64 + l < count) atomicMax(&block_tp[b], v);
+        }
+        if (seeds && tid < 64 && valid) {
+            const unsigned long long a = lmax[lane][0], b = lmax[lane][1], v = a > b ? a : b;
+            D.E[e] = v;
+            if (v) atomicMax(&D.Ec[e >> 6], v);
+        }
+        __syncthreads();
+    }
+}
+
+// integer ratios (step == 1; k_upsample32<.., 0, 4>'s item): a wave per listed unit of 256 consecutive windows, four windows per lane
+__global__ void __launch_bounds__(256)
+k_tp_list_q4(const float *__restrict__ in, int64_t n, const double *__restrict__ bank, int P, int center, int64_t m_total, int blk,
+             unsigned long long *__restrict__ block_tp, int64_t nblocks_alloc, TpPruneDev D, const int *__restrict__ list, int count_host, int seeds)
+{
+    constexpr int L = 32, QL = 4, WL = L + QL - 1, TW = 256 + 36;
+    __shared__ __attribute__((aligned(16))) float tiles[4][TW];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane((int)(tid >> 6));
+    const int count = seeds ? count_host : *D.cnt;
+    float *xin = tiles[wave];
+    for (int e0 = blockIdx.x * 4; e0 < count; e0 += gridDim.x * 4) {
+        const int e = e0 + wave;                                       // (wave-uniform)
+        if (e < count) {
+            const int64_t w0 = (int64_t)list[e] * 256;                 // first window of the unit (= its period index: step == 1)
+            const int64_t g0 = w0 - center;
+            if (g0 >= 0 && g0 + TW <= n) { for (int i = lane; i < TW; i += 64) xin[i] = in[g0 + i]; }
+            else {
+                for (int i = lane; i < TW; i += 64) {
+                    int64_t g = g0 + i;
+                    if (g < 0) g = -g;
+                    xin[i] = g < n ? in[g] : 0.0f;
+                }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();                               // (a wave's LDS operations complete in order)
+        if (e < count) {
+            const int64_t w0 = (int64_t)list[e] * 256;
+            double xw[WL];
+            {
+                typedef float vecT __attribute__((ext_vector_type(4)));
+                const vecT *vp = reinterpret_cast<const vecT *>(xin + lane * QL);
+#pragma unroll
+                for (int k = 0; k < (WL + 3) / 4; ++k) {
+                    const vecT t = vp[k];
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) if (k * 4 + c < WL) xw[k * 4 + c] = (double)t[c];
+                }
+            }
+            double vmax[QL]; int jlim[QL];
+#pragma unroll
+            for (int u = 0; u < QL; ++u) {
+                vmax[u] = 0.0;
+                const int64_t left = m_total - (w0 + lane * QL + u) * P;
+                jlim[u] = left <= 0 ? 0 : (left >= (int64_t)P ? P : (int)left);
+            }
+            for (int j = 0; j < P; ++j) {
+                double tp[L];
+                const double *f = bank + (size_t)j * L;
+#pragma unroll
+                for (int i = 0; i < L; ++i) tp[i] = f[i];
+                double val[QL];
+#pragma unroll
+                for (int u = 0; u < QL; ++u) val[u] = 0.0;
+#pragma unroll
+                for (int i = 0; i < L; ++i) {
+#pragma unroll
+                    for (int u = 0; u < QL; ++u) val[u] = fma(xw[u + i], tp[i], val[u]);
+                }
+#pragma unroll
+                for (int u = 0; u < QL; ++u) vmax[u] = j < jlim[u] ? fmax(vmax[u], fabs(val[u])) : vmax[u];
+            }
+            // 100 ms block of each window's last input sample: a unit touches two blocks at most
+            const int64_t base0 = w0 - center + L - 1;
+            const int64_t b_first = (base0 < 0 ? 0 : base0) / blk;
+            double v0 = 0.0, v1 = 0.0;
+#pragma unroll
+            for (int u = 0; u < QL; ++u) {
+                const int64_t last = base0 + lane * QL + u;
+                if (last >= 0 && last <= n - 1) {
+                    if (last / blk == b_first) v0 = fmax(v0, vmax[u]); else v1 = fmax(v1, vmax[u]);
+                }
+            }
+#pragma unroll
+            for (int mm = 1; mm < 64; mm <<= 1) { v0 = fmax(v0, __shfl_xor(v0, mm, 64)); v1 = fmax(v1, __shfl_xor(v1, mm, 64)); }
+            if (lane == 0) {
+                int64_t b0 = b_first, b1 = b_first + 1;
+                if (b0 >= nblocks_alloc) b0 = nblocks_alloc - 1;
+                if (b1 >= nblocks_alloc) b1 = nblocks_alloc - 1;
+                if (v0 > 0.0) atomicMax(&block_tp[b0], (unsigned long long)__double_as_longlong(v0));
+                if (v1 > 0.0) atomicMax(&block_tp[b1], (unsigned long long)__double_as_longlong(v1));
+                if (seeds) {
+                    const unsigned long long v = (unsigned long long)__double_as_longlong(fmax(v0, v1));
+                    D.E[e] = v;
+                    if (v) atomicMax(&D.Ec[e >> 6], v);
+                }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+static inline size_t tp_al(size_t b) { return (b + 255) & ~(size_t)255; }
+// periods per unit for a plan the pruned path serves, 0 otherwise
+static int tp_prune_unit(int P, int L, int64_t step, int blk)
+{
+    if (L != 32 || step >= P) return 0;
+    if (step == 1) return 256 + 36 < blk ? 256 : 0;
+    if ((step & 1) && P % (2 * TP_NWV) == 0 && step + 32 < blk && ((size_t)64 * ((step + 31) | 1) * 4) <= 96 * 1024) return 1;
+    return 0;
+}
+size_t jt_tp_prune_scratch_bytes(int64_t n, int P, int L, int64_t step, int blk)
+{
+    const int G = tp_prune_unit(P, L, step, blk);
+    if (!G) return 0;
+    const int64_t m_total = (int64_t)(((__int128)n * P + step - 1) / step);
+    const int64_t n_units = ((m_total + P - 1) / P + G - 1) / G, n_groups = (n_units + 63) / 64;
+    return tp_al(4 * (size_t)n_units) * 2 + tp_al(4 * (size_t)n_groups) + tp_al(8 * (size_t)n_groups) + tp_al(8 * (size_t)(n_groups / 64 + 1)) + 256;
+}
+// false: this plan / length is not served (the caller runs the exhaustive kernels)
+bool launch_true_peak_f32_pruned(const float *in, int64_t n, const double *bank, int P, int L, int center, int64_t step, int blk, double *block_tp,
+                                 int64_t nblocks_alloc, int64_t m_total, double l1max, void *scratch, size_t scratch_bytes, hipStream_t s,
+                                 const int **kept_dev, int64_t *units, int64_t *seeds)
+{
+    const int G = tp_prune_unit(P, L, step, blk);
+    if (!G || m_total <= 0 || !scratch || !(l1max > 0)) return false;
+    TpPruneDev D;
+    D.G = G;
+    D.n_units = ((m_total + P - 1) / P + G - 1) / G; D.n_groups = (D.n_units + 63) / 64;
+    if (D.n_groups < 2 || D.n_units >= (int64_t)1 << 31) return false;
+    unsigned char *p = (unsigned char *)scratch; size_t o = 0;
+    D.amax = (float *)(p + o); o += tp_al(4 * (size_t)D.n_units);
+    D.list = (int *)(p + o); o += tp_al(4 * (size_t)D.n_units);
+    D.seed = (int *)(p + o); o += tp_al(4 * (size_t)D.n_groups);
+    D.E = (unsigned long long *)(p + o); o += tp_al(8 * (size_t)D.n_groups);
+    D.Ec = (unsigned long long *)(p + o); o += tp_al(8 * (size_t)(D.n_groups / 64 + 1));
+    D.cnt = (int *)(p + o); o += 256;
+    if (o > scratch_bytes) return false;
+    if (kept_dev) *kept_dev = D.cnt;
+    if (units) *units = D.n_units;
+    if (seeds) *seeds = D.n_groups;
+    const double A = l1max * (1.0 + 1e-9);
+    const int S = G * (int)step;
+    hipLaunchKernelGGL(k_tp_bounds, dim3((unsigned)D.n_groups), dim3(256), 0, s, in, n, center, S, D);
+    unsigned long long *btp = (unsigned long long *)block_tp;
+    if (G == 1) {
+        auto k = k_tp_list_period<TP_NWV>;
+        const size_t tile = (size_t)64 * ((step + 31) | 1) * 4;
+        JT_HIP(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tile));
+        const unsigned g1 = (unsigned)((D.n_groups + 63) / 64), g2 = (unsigned)std::min<int64_t>((D.n_units + 63) / 64, 4096);
+        hipLaunchKernelGGL(k, dim3(g1), dim3(64 * TP_NWV), tile, s, in, n, bank, P, center, (int)step, m_total, blk, btp, nblocks_alloc, D,
+                           (const int *)D.seed, (int)D.n_groups, 1);
+        hipLaunchKernelGGL(k_tp_select, dim3((unsigned)((D.n_groups + 3) / 4)), dim3(256), 0, s, D, A);
+        hipLaunchKernelGGL(k, dim3(g2), dim3(64 * TP_NWV), tile, s, in, n, bank, P, center, (int)step, m_total, blk, btp, nblocks_alloc, D,
+                           (const int *)D.list, 0, 0);
+    } else {
+        const unsigned g1 = (unsigned)((D.n_groups + 3) / 4), g2 = (unsigned)std::min<int64_t>((D.n_units + 3) / 4, 16384);
+        hipLaunchKernelGGL(k_tp_list_q4, dim3(g1), dim3(256), 0, s, in, n, bank, P, center, m_total, blk, btp, nblocks_alloc, D, (const int *)D.seed,
+                           (int)D.n_groups, 1);
+        hipLaunchKernelGGL(k_tp_select, dim3((unsigned)((D.n_groups + 3) / 4)), dim3(256), 0, s, D, A);
+        hipLaunchKernelGGL(k_tp_list_q4, dim3(g2), dim3(256), 0, s, in, n, bank, P, center, m_total, blk, btp, nblocks_alloc, D, (const int *)D.list, 0, 0);
+    }
+    return true;
+}
+
 template <typename TIn, typename TAcc, typename TTap, int MODE>
 static bool launch_upsample32(const TIn *in, int64_t n, const TTap *bank, int P, int L, int center, int64_t step, int64_t m_total,
                               double in_scale, int blk, double *block_tp, int64_t nblocks_alloc, TAcc *out, hipStream_t s, const JtOpts *o = nullptr)

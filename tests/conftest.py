@@ -59,7 +59,7 @@ def engine_ab():
 import contextlib
 
 # what jt_set_option's keys fall back to
-_OPTION_DEFAULTS = {"region_rot": "-1"}
+_OPTION_DEFAULTS = {"region_rot": "-1", "tp_prune_min": str(1 << 20)}
 
 
 @contextlib.contextmanager
