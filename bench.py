@@ -387,6 +387,8 @@ def main():
                     help="run the CPU oracle's Pass-4 chain on the dynamic-fallback file (one host core, in the background, joined before the line is printed) "
                          "and print where it lands beside the GPU's landing; 0 = skip")
     ap.add_argument("--oracle-landing-job", default=None, help=argparse.SUPPRESS)
+    ap.add_argument("--option", action="append", default=[], metavar="KEY=VALUE",
+                    help="jt_set_option on the bench engine (A/B runs: tp_unpruned=1, host_timing=1, ...); recorded in config.options")
     ap.add_argument("--selftest-spawn", action="store_true", help="exercise the N-rank launch path only (gloo, no GPU work); for tests")
     args = ap.parse_args()
 
@@ -424,6 +426,9 @@ def main():
         x = torch.stack([x, 0.8 * torch.roll(x, 14)], dim=1).contiguous().view(-1)
     torch.cuda.synchronize()
     eng = Engine(local_rank)
+    for kv in args.option:
+        k, _, v = kv.partition("=")
+        eng.set_option(k, v if v else "1")
     eng.attach_device_pcm(x.data_ptr(), n, sr, args.channels, keepalive=x)
 
     base = hostlogic.default_config()
@@ -450,6 +455,7 @@ def main():
         nlm_ms.append(t["nlm_ms"]); dk_ms.append(t["declick_ms"]); p_ms.append([t["pass1_ms"], t["pass2_ms"], t["pass3_ms"], t["pass4_ms"]])
     barrier()
     dt = time.perf_counter() - t0
+    tpu = eng.timers()
     dt_rank = dt
     dt = shard.max_over_ranks(dt, device=f"cuda:{local_rank}")
     per_rank_ms = shard.gather_over_ranks(dt_rank / args.steps * 1e3, device=f"cuda:{local_rank}")
@@ -592,6 +598,9 @@ def main():
                                   "loudnorm": "linear"},
                        "files_per_gpu_per_step": 1, "adeclick": "on (t=1.7 w=55 o=50 m=s, the reference default)",
                        "adaptive": "full host mirror (VAD, speech election, AdaptConfig, band RMS) in C++",
+                       "true_peak": ("branch and bound: %d of %d units of the final analysis evaluated" % (tpu["tp_units_evaluated"], tpu["tp_units_total"])
+                                     if tpu["tp_units_total"] else "exhaustive"),
+                       "options": list(args.option),
                        "pass2_spec": res.pass2_spec.decode()},
             "result": {"output_lufs": round(res.output_lufs, 3), "output_dbtp": round(res.output_tp_db, 3),
                        "input_lufs": round(res.input_lufs, 3), "within_target": bool(res.within_target)},

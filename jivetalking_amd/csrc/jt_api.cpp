@@ -441,8 +441,9 @@ static void analysis_enqueue(jt_ctx *h, const float *x, int64_t n, int sr, bool 
         const int64_t nout = sel_blk > 0 ? nframes : nhops;
         J->nhops = nhops; J->nout = nout;
         jt_spectral *hops = h->pin.take<jt_spectral>((size_t)std::max<int64_t>(nout, 1));
-        if (ln && ln->direct) {
-            // an announced region: a few dozen records, written by the kernel straight into the pinned arena (no copy to queue)
+        if ((ln && ln->direct) || (sel_blk > 0 && !h->opts.no_spec_direct)) {
+            // selected frames (one 104-byte record per 100 ms: 3.7 MB for an hour; an announced region: a few dozen records): written
+            // by the kernel straight into the pinned arena -- the copy behind the kernel was 0.4 ms at the end of the pass's longest chain
             launch_aspectralstats(x, n, sr, win, h->twiddle.p, h->hann.p, hops, nhops, sel_blk, nframes, a2);
         } else {
             h->spec_hops.ensure((size_t)std::max<int64_t>(nout, 1));
@@ -561,6 +562,10 @@ extern "C" int jt_pass1(jt_ctx *h, int frame_samples, jt_analysis *out, double *
     out->n_input_frames = nfr;
     pass_begin(h, h->n, 1);
     const double *fst = nullptr;
+    AnalysisJob J;
+    // the analysis chains fork first: the per-decoder-frame sums then run beside them on the main stream instead of ahead of them
+    // (the fork waits for everything queued on the main stream: 0.3 ms of every Pass 1 with the sums in front)
+    analysis_enqueue(h, h->in_mono, h->n, h->sr, true, h->sr / 10, &J, false);
     if (frame_sumsq && frame_peak) {
         h->d_scr3.ensure((size_t)nfr * 2);
         launch_frame_stats(h->in_raw, h->n * h->channels, frame_samples * h->channels, h->d_scr3.p, h->d_scr3.p + nfr, nfr, h->stream);
@@ -568,8 +573,7 @@ extern "C" int jt_pass1(jt_ctx *h, int frame_samples, jt_analysis *out, double *
         JT_HIP(hipMemcpyAsync(tmp, h->d_scr3.p, sizeof(double) * nfr * 2, hipMemcpyDeviceToHost, h->stream));
         fst = tmp;
     }
-    AnalysisJob J;
-    analysis_enqueue(h, h->in_mono, h->n, h->sr, true, h->sr / 10, &J);
+    analysis_join(h);
     // an announced Pass-2 head goes in behind the analysis: its 150 k workgroups would otherwise take every slot first
     if (h->spec_p2.armed) {
         h->spec_p2.armed = false;

@@ -288,6 +288,17 @@ k_nf_main(const float *__restrict__ x, int64_t n, int tc, const float *__restric
 
 // exponential power average: zero-state response of each chunk (one thread per chunk, coalesced through LDS rows)
 constexpr int ZC = 1024;     // chunk length
+// tile step `pos` of the 64 chunks from c0: row q = chunk c0 + q, lane = sample pos + lane of it (coalesced rows, 64 loads in flight)
+__device__ inline void as_rows_load(float (&v)[64], const float *__restrict__ x, int64_t n, int64_t c0, int pos, int lane)
+{
+#pragma unroll
+    for (int q = 0; q < 64; ++q) { const int64_t idx = (c0 + q) * ZC + pos + lane; v[q] = x[idx < n ? idx : n - 1]; }
+}
+__device__ inline void as_rows_commit(float (*tile)[65], const float (&v)[64], int64_t n, int64_t c0, int pos, int lane, int nrows)
+{
+#pragma unroll
+    for (int q = 0; q < 64; ++q) { const int64_t idx = (c0 + q) * ZC + pos + lane; tile[q][lane] = (q < nrows && idx < n) ? v[q] : 0.f; }
+}
 __global__ void __launch_bounds__(64)
 k_as_zs(const float *__restrict__ x, int64_t n, double mult, double mult_chunk, double *__restrict__ zs, double *__restrict__ blkA,
         double *__restrict__ blkB, int64_t nchunks)
@@ -298,20 +309,28 @@ k_as_zs(const float *__restrict__ x, int64_t n, double mult, double mult_chunk, 
     const int nrows = (int)min((int64_t)64, nchunks - c0);
     double z = 0.0;
     const double om = 1.0 - mult;
+    // (round 4) the next tile's 64 row loads are in flight while this one is consumed, and a lane reads its 64 samples of the tile into
+    // registers before the recurrence starts: written as "load, store, barrier, read a sample, use it", every step of the chain waited
+    // for an LDS round trip and every tile for an HBM one (0.40 ms for an hour alone, five f64 operations per sample)
+    float v[64];
+    as_rows_load(v, x, n, c0, 0, lane);
     for (int pos = 0; pos < ZC; pos += 64) {
-        float v[16];
-        for (int r0 = 0; r0 < 64; r0 += 16) {
-#pragma unroll
-            for (int q = 0; q < 16; ++q) { int64_t idx = (c0 + r0 + q) * ZC + pos + lane; v[q] = x[idx < n ? idx : n - 1]; }
-#pragma unroll
-            for (int q = 0; q < 16; ++q) { int64_t idx = (c0 + r0 + q) * ZC + pos + lane; tile[r0 + q][lane] = (r0 + q < nrows && idx < n) ? v[q] : 0.f; }
-        }
+        as_rows_commit(tile, v, n, c0, pos, lane, nrows);
         __syncthreads();
+        if (pos + 64 < ZC) as_rows_load(v, x, n, c0, pos + 64, lane);
         if (lane < nrows) {
             const int64_t base = (c0 + lane) * ZC + pos;
-#pragma unroll 8
-            for (int j = 0; j < 64; ++j) {
-                if (base + j < n) { double d = (double)tile[lane][j]; z = z * mult + om * d * d; }
+            if (base + 64 <= n) {
+                float xs[64];
+#pragma unroll
+                for (int j = 0; j < 64; ++j) xs[j] = tile[lane][j];
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int j = 0; j < 64; ++j) { double d = (double)xs[j]; z = z * mult + om * d * d; }
+            } else {
+                for (int j = 0; j < 64; ++j) {
+                    if (base + j < n) { double d = (double)tile[lane][j]; z = z * mult + om * d * d; }
+                }
             }
         }
         __syncthreads();
@@ -377,24 +396,33 @@ k_as_sigma(const float *__restrict__ x, int64_t n, int tc, double mult, double m
     }
     double mn = DBL_MAX, mx = 0.0;
     const double om = 1.0 - mult;
+    float v[64];
+    as_rows_load(v, x, n, c0, 0, lane);
     for (int pos = 0; pos < ZC; pos += 64) {
-        float v[16];
-        for (int r0 = 0; r0 < 64; r0 += 16) {
-#pragma unroll
-            for (int q = 0; q < 16; ++q) { int64_t idx = (c0 + r0 + q) * ZC + pos + lane; v[q] = x[idx < n ? idx : n - 1]; }
-#pragma unroll
-            for (int q = 0; q < 16; ++q) { int64_t idx = (c0 + r0 + q) * ZC + pos + lane; tile[r0 + q][lane] = (r0 + q < nrows && idx < n) ? v[q] : 0.f; }
-        }
+        as_rows_commit(tile, v, n, c0, pos, lane, nrows);
         __syncthreads();
+        if (pos + 64 < ZC) as_rows_load(v, x, n, c0, pos + 64, lane);
         if (lane < nrows) {
             const int64_t base = (c0 + lane) * ZC + pos;
-#pragma unroll 8
-            for (int j = 0; j < 64; ++j) {
-                const int64_t idx = base + j;
-                if (idx < n) {
-                    double d = (double)tile[lane][j];
+            if (base + 64 <= n && base >= tc) {
+                float xs[64];
+#pragma unroll
+                for (int j = 0; j < 64; ++j) xs[j] = tile[lane][j];
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int j = 0; j < 64; ++j) {
+                    double d = (double)xs[j];
                     avg = avg * mult + om * d * d;
-                    if (idx >= tc) { mx = fmax(mx, avg); mn = fmin(mn, avg); }
+                    mx = fmax(mx, avg); mn = fmin(mn, avg);
+                }
+            } else {
+                for (int j = 0; j < 64; ++j) {
+                    const int64_t idx = base + j;
+                    if (idx < n) {
+                        double d = (double)tile[lane][j];
+                        avg = avg * mult + om * d * d;
+                        if (idx >= tc) { mx = fmax(mx, avg); mn = fmin(mn, avg); }
+                    }
                 }
             }
         }

@@ -526,6 +526,11 @@ k_kw(const TIn *__restrict__ in, int64_t n, int64_t L, KwCoef k, const double *_
 // k_kw_fix puts the carried state in afterwards, one thread per chunk.  The second sweep re-read the whole signal (5.5 GB for an hour at
 // 192 kHz) to do the same thing sample by sample.  Rounding differs from the two-sweep form at the 1e-13 level (the three terms cancel
 // the start-up transient of the zero-state run); JT_KW_TWO_SWEEPS=1 keeps the old form.
+// (round 4) The sweep ran five times slower than its 15 f64 operations per sample cost: the compiler put every LDS read -- the sample,
+// and the table row, which sat in LDS too -- directly in front of its use behind an s_waitcnt lgkmcnt(0), two or three exposed LDS round
+// trips per sample.  Now four samples and their four table rows are read from LDS into registers a block ahead, with scheduling
+// barriers between "request the next block" and "compute this one".  Same statements per sample, in the same order.  (The rows are
+// wave-uniform, but as scalar loads two blocks of them are 64 SGPRs beside 20 of coefficients: the allocator spilled the lot.)
 template <typename TIn>
 __global__ void __launch_bounds__(64)
 k_kw1(const TIn *__restrict__ in, int64_t n, int64_t L, KwCoef k, const double *__restrict__ g, double *__restrict__ zs_out,
@@ -543,6 +548,7 @@ k_kw1(const TIn *__restrict__ in, int64_t n, int64_t L, KwCoef k, const double *
     double acc = 0.0, pk = 0.0, zz = 0.0, x0c = 0.0, x1c = 0.0, x2c = 0.0, x3c = 0.0;
     TIn v[LANES];
     rows_prefetch<TIn>(v, in, n, base0, L, 0, lane);
+    constexpr int KB = 4;                                            // samples per block
     for (int64_t pos = 0; pos < L; pos += TW) {
         rows_commit<TIn, TIn>(tile, v, n, base0, L, pos, lane, nrows);
         if (pos + lane < L) {
@@ -555,12 +561,33 @@ k_kw1(const TIn *__restrict__ in, int64_t n, int64_t L, KwCoef k, const double *
             const int64_t t0 = my_base + pos;
             const double *gp = gt;
             if (pos + TW <= L && t0 + TW <= n) {
-#pragma unroll 16
-                for (int j = 0; j < TW; ++j) {
-                    const double x0 = (double)tile[lane][j];
-                    KW2_STEP(x0)
-                    acc = fma(zz, zz, acc); pk = fmax(pk, fabs(x0));
-                    x0c = fma(zz, gp[4 * j + 0], x0c); x1c = fma(zz, gp[4 * j + 1], x1c); x2c = fma(zz, gp[4 * j + 2], x2c); x3c = fma(zz, gp[4 * j + 3], x3c);
+                TIn xa[KB], xb[KB]; double ga[4 * KB], gb[4 * KB];
+                auto request = [&](TIn (&xs)[KB], double (&gs)[4 * KB], int j0) {
+#pragma unroll
+                    for (int u = 0; u < KB; ++u) xs[u] = tile[lane][j0 + u];
+#pragma unroll
+                    for (int u = 0; u < 4 * KB; ++u) gs[u] = gp[4 * j0 + u];
+                };
+                auto compute = [&](const TIn (&xs)[KB], const double (&gs)[4 * KB]) {
+#pragma unroll
+                    for (int u = 0; u < KB; ++u) {
+                        const double x0 = (double)xs[u];
+                        KW2_STEP(x0)
+                        acc = fma(zz, zz, acc); pk = fmax(pk, fabs(x0));
+                        x0c = fma(zz, gs[4 * u + 0], x0c); x1c = fma(zz, gs[4 * u + 1], x1c); x2c = fma(zz, gs[4 * u + 2], x2c); x3c = fma(zz, gs[4 * u + 3], x3c);
+                    }
+                };
+                request(xa, ga, 0);
+#pragma unroll
+                for (int jb = 0; jb < TW; jb += 2 * KB) {
+                    request(xb, gb, jb + KB);
+                    __builtin_amdgcn_sched_barrier(0);
+                    compute(xa, ga);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (jb + 2 * KB < TW) request(xa, ga, jb + 2 * KB);
+                    __builtin_amdgcn_sched_barrier(0);
+                    compute(xb, gb);
+                    __builtin_amdgcn_sched_barrier(0);
                 }
             } else {
                 for (int j = 0; j < TW; ++j) {
