@@ -294,11 +294,24 @@ static SwrDev &get_swr(jt_ctx *h, int in_rate, int out_rate)
     SwrDev &e = h->swr[h->swr_next]; h->swr_next = (h->swr_next + 1) % 4;
     JT_HIP(hipStreamSynchronize(h->stream));             // the slot's old banks may still be read by queued kernels
     jt_swr_plan(&e.pl, in_rate, out_rate);
-    e.l1max = 0;
-    for (int ph = 0; ph < e.pl.phase_count; ++ph) {
-        double a = 0;
-        for (int t = 0; t < e.pl.filter_length; ++t) a += std::fabs(e.pl.bank[(size_t)ph * e.pl.filter_length + t]);
-        e.l1max = std::max(e.l1max, a);
+    {   // norms of the tap rows for the true peak's bounds (k_resample.hip, k_tp_bounds)
+        const int L = e.pl.filter_length;
+        double a1 = 0, t0 = 0, m1 = 1e300;
+        for (int ph = 0; ph < e.pl.phase_count; ++ph) {
+            double a = 0, t = 0;
+            for (int i = 0; i < L; ++i) { const double v = e.pl.bank[(size_t)ph * L + i]; a += std::fabs(v); t += v; }
+            a1 = std::max(a1, a); t0 = std::max(t0, std::fabs(t));
+        }
+        for (int c = 0; c < L; ++c) {                         // one reference tap for every row: the one with the smallest worst case
+            double worst = 0;
+            for (int ph = 0; ph < e.pl.phase_count; ++ph) {
+                double m = 0;
+                for (int i = 0; i < L; ++i) m += std::fabs(e.pl.bank[(size_t)ph * L + i]) * std::abs(i - c);
+                worst = std::max(worst, m);
+            }
+            m1 = std::min(m1, worst);
+        }
+        e.tp_norms[0] = a1; e.tp_norms[1] = t0; e.tp_norms[2] = m1;
     }
     std::vector<float> bf(e.pl.bank.size());
     for (size_t i = 0; i < bf.size(); ++i) bf[i] = (float)e.pl.bank[i];
@@ -389,9 +402,14 @@ static void analysis_enqueue(jt_ctx *h, const float *x, int64_t n, int sr, bool 
     // plan of Pass 2 waits for (jt_pass3_plan_hook); the chain's total is the same either way
     const bool r128_first = h->early_p3.mark_kw && J->want_r128;
     if (J->want_r128) {
-        jt_kweight_enqueue_f32(h, x, n, sr, sr / 10, &J->kw, a1);
-        if (!f) JT_HIP(hipEventRecord(h->ev_chain[5], a1));
-        if (h->early_p3.mark_kw) { JT_HIP(hipEventRecord(h->early_p3.ev[0], a1)); h->early_p3.mark_kw = false; }
+        // a planner waits for this job (Pass 2): it runs in the normal priority class, on the stream adeclick's second solver uses in
+        // Pass 4 (idle here; the announced regions' chains queue up behind it), instead of among the low-priority statistics
+        hipStream_t akw = a1;
+        if (r128_first && !f && h->dk_stream && !h->opts.no_r128_first) { akw = h->dk_stream; JT_HIP(hipStreamWaitEvent(akw, h->ev_fork, 0)); }
+        jt_kweight_enqueue_f32(h, x, n, sr, sr / 10, &J->kw, akw);
+        if (!f) JT_HIP(hipEventRecord(h->ev_chain[5], akw));
+        if (h->early_p3.mark_kw) { JT_HIP(hipEventRecord(h->early_p3.ev[0], akw)); h->early_p3.mark_kw = false; }
+        if (akw != a1) JT_HIP(hipStreamWaitEvent(a1, h->ev_chain[5], 0));          // (the pass's join of aux[1] then covers the job)
     }
     if (J->want_r128) {
         const int blk = sr / 10; const int64_t nfull = n / blk;
@@ -408,7 +426,7 @@ static void analysis_enqueue(jt_ctx *h, const float *x, int64_t n, int sr, bool 
                 h->tp_scr.ensure(need);
                 const int *kept = nullptr;
                 pruned = launch_true_peak_f32_pruned(x, n, sw.bank_d.p, sw.pl.phase_count, sw.pl.filter_length, sw.pl.center, sw.pl.step, blk, d_tp,
-                                                     nfull + 1, sw.out_len(n), sw.l1max, h->tp_scr.p, need, a3, &kept, &J->tp_units, &J->tp_seeds);
+                                                     nfull + 1, sw.out_len(n), sw.tp_norms, h->tp_scr.p, need, a3, &kept, &J->tp_units, &J->tp_seeds);
                 if (pruned) {
                     h->tp_scr_off = need;
                     int *hk = h->pin.take<int>(2);
@@ -431,8 +449,8 @@ static void analysis_enqueue(jt_ctx *h, const float *x, int64_t n, int sr, bool 
             JT_HIP(hipStreamWaitEvent(a2, h->early_p3.ev[1], 0));
         }
     }
-    if (J->want_astats) jt_astats_enqueue(h, x, n, sr, &J->as, a0, a1, a2, nullptr, J->astats_levels_only);
-    if (!f) JT_HIP(hipEventRecord(h->ev_chain[4], a2));
+    // aspectralstats first on its stream: it is the longest kernel of an analysis (an in-wave FFT per 100 ms frame) and used to start
+    // behind the two sweeps of the exponential-average chain; those now follow it
     if (J->want_spec) {
         const int win = 2048, hop = win / 2;
         const int64_t nhops = (n + hop - 1) / hop;
@@ -452,6 +470,8 @@ static void analysis_enqueue(jt_ctx *h, const float *x, int64_t n, int sr, bool 
         }
         J->hops = hops;
     }
+    if (J->want_astats) jt_astats_enqueue(h, x, n, sr, &J->as, a0, a1, a2, nullptr, J->astats_levels_only);
+    if (!f) JT_HIP(hipEventRecord(h->ev_chain[4], a2));
     if (!f) for (int i = 0; i < 4; ++i) JT_HIP(hipEventRecord(h->ev_chain[i], h->aux[i]));
     if (join) analysis_join(h, f ? 2 : 1);
 }
@@ -1077,6 +1097,11 @@ extern "C" int jt_pass2(jt_ctx *h, const jt_filter_params *p, jt_analysis *out)
             for (int r = 0; r < 2; ++r) if (RJ.want[r]) cap[r] = jt_resample_range_cap(n, sw.pl.phase_count, sw.pl.filter_length, sw.pl.step, m, RJ.len[r]);
             h->region_s16.ensure((size_t)(cap[0] + cap[1] + 1));
             fork_aux(h, 4, 4);
+            if (plan_early && !h->opts.no_r128_first) {
+                // nobody waits for the regions: their resampling (1.4 ms of the output stage's arithmetic) starts once the two chains the
+                // limiter plan waits for have ended, instead of beside them
+                JT_HIP(hipStreamWaitEvent(h->aux[4], h->early_p3.ev[0], 0)); JT_HIP(hipStreamWaitEvent(h->aux[4], h->early_p3.ev[1], 0));
+            }
             for (int r = 0; r < 2; ++r) {
                 if (!RJ.want[r]) continue;
                 int16_t *dst = h->region_s16.p + (r ? cap[0] : 0);
@@ -1101,18 +1126,28 @@ extern "C" int jt_pass2(jt_ctx *h, const jt_filter_params *p, jt_analysis *out)
         auto &E = h->early_p3;
         // (the gating of the loudness -- 36 000 blocks of an hour, a histogram and the LRA percentiles -- runs while the true-peak sweep,
         // which ends later than the K-weighting job, is still on the GPU)
+        const bool timing = h->opts.host_timing;
+        auto now = [] { return std::chrono::steady_clock::now(); };
+        auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+        const auto tq = now();
         JT_HIP(hipEventSynchronize(E.ev[0]));
+        const auto t0 = now();
         check_cancel(h);
         std::vector<double> bsum, bpk;
         jt_kweight_finish(&J.kw, bsum, bpk);
-        R128Series r; jt_r128_finish(bsum.data(), J.nfull, J.blk, J.sr, J.dualmono, &r);
+        R128Series r; jt_r128_finish(bsum.data(), J.nfull, J.blk, J.sr, J.dualmono, &r, true);
+        const auto t1 = now();
         JT_HIP(hipEventSynchronize(E.ev[1]));
+        const auto t2 = now();
         check_cancel(h);
         double tp = 0; for (int64_t k = 0; k < J.nfull; ++k) tp = std::max(tp, J.btp[(size_t)k]);
         jt_limiter_plan plan; std::memset(&plan, 0, sizeof plan);
         const bool planned = E.fn(E.user, r.integrated, tp, &plan) == JT_OK;
+        const auto t3 = now();
         if (planned && plan.needed) early_pass3_enqueue(h, h->s16_p2.p, h->m_p2, out_rate, plan);
         else spec_loudnorm_enqueue(h, h->s16_p2.p, h->m_p2, out_rate);
+        if (timing) fprintf(stderr, "plan hook: wait for K-weighting %.3f ms, gating %.3f, wait for true peak %.3f, plan %.3f, enqueue %.3f\n",
+                            ms(tq, t0), ms(t0, t1), ms(t1, t2), ms(t2, t3), ms(t3, now()));
     }
     analysis_join(h, regions ? 2 : 1);
     h->out_rate = out_rate; h->m_p4 = 0;

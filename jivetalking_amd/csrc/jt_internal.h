@@ -129,7 +129,7 @@ void jt_swr_plan(SwrPlanHost *p, int in_rate, int out_rate);
 
 // R128 host finishing (f_ebur128.c gating / LRA on per-100ms block energies)
 struct R128Series { std::vector<double> M, S; double integrated, lra, lra_low, lra_high, rel_threshold; };
-void jt_r128_finish(const double *block_sums, int64_t nblocks, int blk, int sr, bool dualmono, R128Series *out);
+void jt_r128_finish(const double *block_sums, int64_t nblocks, int blk, int sr, bool dualmono, R128Series *out, bool integrated_only = false);
 // libebur128-style (af_loudnorm.c) finishing on per-100ms block energies
 void jt_loudnorm_finish(const double *block_sums, int64_t nblocks, int64_t s100, bool dual_mono, double scale_energy,
                         double *i, double *lra, double *thresh);
@@ -187,10 +187,10 @@ int64_t jt_resample_range_cap(int64_t n, int phase_count, int filter_length, int
 void launch_true_peak_f32(const float *in, int64_t n, const double *bank, int phase_count, int filter_length, int center,
                           int64_t step, int blk, double *block_tp, int64_t nblocks_alloc, int64_t m_total, hipStream_t s, const JtOpts *o = nullptr);
 // branch-and-bound true peak (block maxima of the evaluated units only: the PREFIX maximum is what equals the exhaustive kernels');
-// false = plan / length not served.  l1max = the largest l1 norm of a tap row
+// false = plan / length not served.  norms = SwrDev::tp_norms
 size_t jt_tp_prune_scratch_bytes(int64_t n, int phase_count, int filter_length, int64_t step, int blk);
 bool launch_true_peak_f32_pruned(const float *in, int64_t n, const double *bank, int phase_count, int filter_length, int center, int64_t step,
-                                 int blk, double *block_tp, int64_t nblocks_alloc, int64_t m_total, double l1max, void *scratch,
+                                 int blk, double *block_tp, int64_t nblocks_alloc, int64_t m_total, const double norms[3], void *scratch,
                                  size_t scratch_bytes, hipStream_t s, const int **kept_dev = nullptr, int64_t *units = nullptr, int64_t *seeds = nullptr);
 void launch_true_peak_f64(const double *in, int64_t n, const double *bank, int phase_count, int filter_length, int center,
                           int64_t step, int blk, double *block_tp, int64_t nblocks_alloc, int64_t m_total, hipStream_t s, const JtOpts *o = nullptr);
@@ -305,7 +305,7 @@ struct HostArena {
 // cached resampler plans (the kaiser bank depends on the rate pair only) with their device copies
 struct SwrDev {
     int in_rate = 0, out_rate = 0; SwrPlanHost pl; DevBuf<double> bank_d; DevBuf<float> bank_f;
-    double l1max = 0;            // largest l1 norm of a tap row (the true peak's branch-and-bound bound)
+    double tp_norms[3] = {0, 0, 0};   // over the tap rows: max sum |t_i|, max |sum t_i|, max sum |t_i| |i - c| (c fixed): the true peak's branch-and-bound bounds
     DevBuf<float> bank_fs;       // bank_f * 2^-15 (s16 sources: the int -> float scale folded into the taps); empty unless that product is exact
     int64_t out_len(int64_t n) const { return (int64_t)(((__int128)n * pl.phase_count + pl.step - 1) / pl.step); }
 };

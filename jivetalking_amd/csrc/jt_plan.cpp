@@ -180,7 +180,7 @@ inline int HIST_POS(double l) { return (int)((l - ABS_THRES) * HIST_GRAIN); }
 inline int clipi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
 }
 
-void jt_r128_finish(const double *bs, int64_t nblocks, int blk, int sr, bool dualmono, R128Series *o)
+void jt_r128_finish(const double *bs, int64_t nblocks, int blk, int sr, bool dualmono, R128Series *o, bool integrated_only)
 {
     (void)blk;
     const double pan_law = -3.01029995663978;
@@ -188,26 +188,33 @@ void jt_r128_finish(const double *bs, int64_t nblocks, int blk, int sr, bool dua
     std::vector<unsigned> h400(HIST_SIZE, 0), h3000(HIST_SIZE, 0);
     double kept400 = 0, kept3000 = 0; int64_t nk400 = 0, nk3000 = 0;
     double rel400 = 0;
-    o->M.assign(nblocks, 0.0); o->S.assign(nblocks, 0.0);
+    // integrated_only (the limiter-plan hook of Pass 2, which waits for nothing else): the 3 s windows, their logarithms and the
+    // loudness range are left out; `integrated` and `rel_threshold` come out of the same statements as in the full run
+    o->M.assign(nblocks, 0.0); o->S.assign(integrated_only ? 0 : nblocks, 0.0);
     // per block: window powers and momentary / short-term loudness (the log10s) in parallel; the powers and the un-panned
     // loudness values are kept for the serial gating walk
-    std::vector<double> pw400((size_t)nblocks), pw3000((size_t)nblocks);
+    std::vector<double> pw400((size_t)nblocks), pw3000((size_t)(integrated_only ? 0 : nblocks));
     jt_parallel_for(nblocks, [&](int64_t lo, int64_t hi, int) {
         for (int64_t k = lo; k < hi; ++k) {
             // window sums recomputed from the block energies each step (no add/sub drift)
             double p400 = 1e-12, p3000 = 1e-12;
             if (k >= 3)  { const double w400 = bs[k] + bs[k - 1] + bs[k - 2] + bs[k - 3]; p400 += w400; p400 /= bins400; }
+            pw400[(size_t)k] = p400;
+            o->M[k] = LOUDNESS(p400);
+            if (integrated_only) continue;
             if (k >= 29) { double w = 0; for (int q = 29; q >= 0; --q) w += bs[k - q]; p3000 += w; p3000 /= bins3000; }
-            pw400[(size_t)k] = p400; pw3000[(size_t)k] = p3000;
-            o->M[k] = LOUDNESS(p400); o->S[k] = LOUDNESS(p3000);
+            pw3000[(size_t)k] = p3000;
+            o->S[k] = LOUDNESS(p3000);
         }
     });
     for (int64_t k = 0; k < nblocks; ++k) {
-        const double l400 = o->M[k], l3000 = o->S[k];
+        const double l400 = o->M[k];
         if (l400 >= ABS_THRES) {
             h400[clipi(HIST_POS(l400), 0, HIST_SIZE - 1)]++;
             kept400 += pw400[(size_t)k]; nk400++;
         }
+        if (integrated_only) continue;
+        const double l3000 = o->S[k];
         if (l3000 >= ABS_THRES) {
             h3000[clipi(HIST_POS(l3000), 0, HIST_SIZE - 1)]++;
             kept3000 += pw3000[(size_t)k]; nk3000++;

@@ -898,8 +898,9 @@ constexpr int TP_NWV = 8;
 // maxima of evaluated units are bit-identical, the others stay zero, and the prefix maximum -- all anybody reads -- is identical.
 // What is saved depends on the signal: speech keeps the units within 20 log10(A) ~ 6 dB of the loudest peak so far.
 struct TpPruneDev {
-    float *amax; int *seed, *list, *cnt; unsigned long long *E, *Ec;
+    float *amax; int *seed, *list, *cnt; unsigned long long *E, *Ec;      // amax: the unit's BOUND (rounded up)
     int64_t n_units, n_groups; int G;       // periods per unit
+    double A, T0, M1;                       // tap-row norms: max sum |t|, max |sum t|, max sum |t_i| |i - c| (times 1 + 1e-9)
 };
 
 __device__ inline float tp_load_abs(const float *__restrict__ in, int64_t n, int64_t g)
@@ -908,7 +909,11 @@ __device__ inline float tp_load_abs(const float *__restrict__ in, int64_t n, int
     return g < n ? fabsf(in[g]) : 0.0f;                              // (the true-peak stream is never flushed)
 }
 
-// one workgroup (four waves) per group of 64 units; a wave reads a unit's span (S + 31 samples) with coalesced loads
+// one workgroup (four waves) per group of 64 units; a wave reads a unit's span (S + 31 samples) with coalesced loads.
+// Two bounds on every |y| of the unit, a = max |x|, d = max |x[i+1] - x[i]| over the span (reflection / padding included):
+//   |y| = |sum t_i x_i| <= a sum |t_i|                                                      (any signal)
+//   |y| = |x_c sum t_i + sum t_i (x_i - x_c)| <= a |sum t_i| + d sum |t_i| |i - c|          (smooth signals: speech peaks)
+// the unit's bound is the smaller (the second is ~1.3 a on voiced speech where the first is 2 a: half as many units survive)
 __global__ void __launch_bounds__(256)
 k_tp_bounds(const float *__restrict__ in, int64_t n, int center, int S, TpPruneDev D)
 {
@@ -921,15 +926,33 @@ k_tp_bounds(const float *__restrict__ in, int64_t n, int center, int S, TpPruneD
     for (int k = 0; k < 16; ++k) {
         const int ul = wave * 16 + k;
         const int64_t u = g * 64 + ul;
-        float v = 0.0f;
+        float v = 0.0f, dv = 0.0f;
         if (u < D.n_units) {
             const int64_t base = u * S - center;
-            if (interior) { for (int i = lane; i < span; i += 64) v = fmaxf(v, fabsf(in[base + i])); }
-            else { for (int i = lane; i < span; i += 64) v = fmaxf(v, tp_load_abs(in, n, base + i)); }
+            if (interior) {
+                for (int i = lane; i < span; i += 64) {
+                    const float a = in[base + i], b = in[base + (i + 1 < span ? i + 1 : i)];
+                    v = fmaxf(v, fabsf(a)); dv = fmaxf(dv, fabsf(b - a));
+                }
+            } else {
+                auto at = [&](int64_t gi) -> float { if (gi < 0) gi = -gi; return gi < n ? in[gi] : 0.0f; };
+                for (int i = lane; i < span; i += 64) {
+                    const float a = at(base + i), b = at(base + (i + 1 < span ? i + 1 : i));
+                    v = fmaxf(v, fabsf(a)); dv = fmaxf(dv, fabsf(b - a));
+                }
+            }
         }
 #pragma unroll
-        for (int mm = 1; mm < 64; mm <<= 1) v = fmaxf(v, __shfl_xor(v, mm, 64));
-        if (lane == 0) { gmax[ul] = v; if (u < D.n_units) D.amax[u] = v; }
+        for (int mm = 1; mm < 64; mm <<= 1) { v = fmaxf(v, __shfl_xor(v, mm, 64)); dv = fmaxf(dv, __shfl_xor(dv, mm, 64)); }
+        if (lane == 0) {
+            gmax[ul] = v;
+            if (u < D.n_units) {
+                // (b - a in f32 is within half an ulp of the exact difference: 1 + 1e-6 on d covers it; NaN / Inf fall to the first bound or keep the unit)
+                const double b1 = (double)v * D.A, b2 = (double)v * D.T0 + (double)dv * (1.0 + 1e-6) * D.M1 + (v > 0.0f ? 1e-30 : 0.0);   // (+ a difference flushed to zero)
+                const double b = (b2 < b1) ? b2 : b1;
+                D.amax[u] = __double2float_ru(b);
+            }
+        }
     }
     __syncthreads();
     if (wave == 0) {
@@ -952,7 +975,7 @@ k_tp_bounds(const float *__restrict__ in, int64_t n, int center, int S, TpPruneD
 
 // round 2's list: a wave per group; lbp = the largest exact |y| of the seeds of all EARLIER groups
 __global__ void __launch_bounds__(256)
-k_tp_select(TpPruneDev D, double A)
+k_tp_select(TpPruneDev D)
 {
     const int lane = threadIdx.x & 63;
     const int64_t g = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -965,7 +988,7 @@ k_tp_select(TpPruneDev D, double A)
 #pragma unroll
     for (int mm = 1; mm < 64; mm <<= 1) lbp = fmax(lbp, __shfl_xor(lbp, mm, 64));
     const int64_t u = g * 64 + lane;
-    const bool keep = u < D.n_units && (int)u != D.seed[g] && (double)D.amax[u] * A > lbp;
+    const bool keep = u < D.n_units && (int)u != D.seed[g] && (double)D.amax[u] > lbp;
     const unsigned long long m = __ballot(keep);
     const int total = __popcll(m);
     int base = 0;
@@ -982,7 +1005,7 @@ k_tp_list_period(const float *__restrict__ in, int64_t n, const double *__restri
                  unsigned long long *__restrict__ block_tp, int64_t nblocks_alloc, TpPruneDev D, const int *__restrict__ list, int count_host,
                  int seeds)
 {
-    constexpr int L = 32, NT = 64 * NWV;
+    constexpr int L = 32;
     extern __shared__ unsigned char smem_pp[];
     __shared__ unsigned long long lmax[64][2];
     __shared__ int qs[64];
@@ -1194,11 +1217,11 @@ size_t jt_tp_prune_scratch_bytes(int64_t n, int P, int L, int64_t step, int blk)
 }
 // false: this plan / length is not served (the caller runs the exhaustive kernels)
 bool launch_true_peak_f32_pruned(const float *in, int64_t n, const double *bank, int P, int L, int center, int64_t step, int blk, double *block_tp,
-                                 int64_t nblocks_alloc, int64_t m_total, double l1max, void *scratch, size_t scratch_bytes, hipStream_t s,
+                                 int64_t nblocks_alloc, int64_t m_total, const double norms[3], void *scratch, size_t scratch_bytes, hipStream_t s,
                                  const int **kept_dev, int64_t *units, int64_t *seeds)
 {
     const int G = tp_prune_unit(P, L, step, blk);
-    if (!G || m_total <= 0 || !scratch || !(l1max > 0)) return false;
+    if (!G || m_total <= 0 || !scratch || !(norms[0] > 0)) return false;
     TpPruneDev D;
     D.G = G;
     D.n_units = ((m_total + P - 1) / P + G - 1) / G; D.n_groups = (D.n_units + 63) / 64;
@@ -1214,7 +1237,7 @@ bool launch_true_peak_f32_pruned(const float *in, int64_t n, const double *bank,
     if (kept_dev) *kept_dev = D.cnt;
     if (units) *units = D.n_units;
     if (seeds) *seeds = D.n_groups;
-    const double A = l1max * (1.0 + 1e-9);
+    D.A = norms[0] * (1.0 + 1e-9); D.T0 = norms[1] * (1.0 + 1e-9); D.M1 = norms[2] * (1.0 + 1e-9);
     const int S = G * (int)step;
     hipLaunchKernelGGL(k_tp_bounds, dim3((unsigned)D.n_groups), dim3(256), 0, s, in, n, center, S, D);
     unsigned long long *btp = (unsigned long long *)block_tp;
@@ -1225,14 +1248,14 @@ bool launch_true_peak_f32_pruned(const float *in, int64_t n, const double *bank,
         const unsigned g1 = (unsigned)((D.n_groups + 63) / 64), g2 = (unsigned)std::min<int64_t>((D.n_units + 63) / 64, 4096);
         hipLaunchKernelGGL(k, dim3(g1), dim3(64 * TP_NWV), tile, s, in, n, bank, P, center, (int)step, m_total, blk, btp, nblocks_alloc, D,
                            (const int *)D.seed, (int)D.n_groups, 1);
-        hipLaunchKernelGGL(k_tp_select, dim3((unsigned)((D.n_groups + 3) / 4)), dim3(256), 0, s, D, A);
+        hipLaunchKernelGGL(k_tp_select, dim3((unsigned)((D.n_groups + 3) / 4)), dim3(256), 0, s, D);
         hipLaunchKernelGGL(k, dim3(g2), dim3(64 * TP_NWV), tile, s, in, n, bank, P, center, (int)step, m_total, blk, btp, nblocks_alloc, D,
                            (const int *)D.list, 0, 0);
     } else {
         const unsigned g1 = (unsigned)((D.n_groups + 3) / 4), g2 = (unsigned)std::min<int64_t>((D.n_units + 3) / 4, 16384);
         hipLaunchKernelGGL(k_tp_list_q4, dim3(g1), dim3(256), 0, s, in, n, bank, P, center, m_total, blk, btp, nblocks_alloc, D, (const int *)D.seed,
                            (int)D.n_groups, 1);
-        hipLaunchKernelGGL(k_tp_select, dim3((unsigned)((D.n_groups + 3) / 4)), dim3(256), 0, s, D, A);
+        hipLaunchKernelGGL(k_tp_select, dim3((unsigned)((D.n_groups + 3) / 4)), dim3(256), 0, s, D);
         hipLaunchKernelGGL(k_tp_list_q4, dim3(g2), dim3(256), 0, s, in, n, bank, P, center, m_total, blk, btp, nblocks_alloc, D, (const int *)D.list, 0, 0);
     }
     return true;
