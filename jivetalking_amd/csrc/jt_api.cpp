@@ -995,7 +995,8 @@ extern "C" int jt_pass3_plan_hook(jt_ctx *h, jt_plan_fn fn, void *user)
 // s16 != nullptr: `in` is WRITTEN first (the s16 -> dbl conversion with the volume stage, fused into the limiter's first sweep)
 struct LimS16 { const int16_t *s16 = nullptr; double vol = 1.0; int vol_in_float = 0; };
 static void run_limiter(jt_ctx *h, double *in, double *out, int64_t n, int sr, double limit, double attack_ms, double release_ms, double in_gain,
-                        const LimS16 &src = LimS16{});
+                        const LimS16 &src = LimS16{}, const LimOut16 *o16 = nullptr);
+static bool limiter_can_emit16(jt_ctx *h, int sr, double attack_ms);
 
 // Pass 3 for a plan WITH the limiter prefix, queued on the main stream inside Pass 2 (behind the output stage, before the join with the
 // analysis chains): volume -> alimiter on the s16 output, swr (double) -> 192 kHz, K-weighting + block energies.  The same launches as
@@ -1174,8 +1175,14 @@ extern "C" int jt_pass2(jt_ctx *h, const jt_filter_params *p, jt_analysis *out)
 }
 
 // ---------------------------------------------------------------- limiter driver (clean-point segmentation)
+// the brickwall may leave as float + s16 (LimOut16) when the wave-per-segment kernel serves this look-ahead length
+static bool limiter_can_emit16(jt_ctx *h, int sr, double attack_ms)
+{
+    int B = (int)(sr * (attack_ms / 1000.) * 1); if (B < 1) B = 1;
+    return jt_limiter_wave_ok(B) && !h->opts.limiter_lanes && !h->opts.brickwall_f64;
+}
 static void run_limiter(jt_ctx *h, double *in, double *out, int64_t n, int sr, double limit, double attack_ms,
-                        double release_ms, double in_gain, const LimS16 &src)
+                        double release_ms, double in_gain, const LimS16 &src, const LimOut16 *o16)
 {
     const double attack = attack_ms / 1000., release = release_ms / 1000.;
     int B = (int)(sr * attack * 1); if (B < 1) B = 1;
@@ -1190,7 +1197,7 @@ static void run_limiter(jt_ctx *h, double *in, double *out, int64_t n, int sr, d
     else if (src.s16 && !JT_AB_ON(h->opts.no_lim_s16)) launch_absmax_conv_s16(src.s16, in, out, n, src.vol, src.vol_in_float, in_gain, h->d_scr3.p, nblk, h->stream);
     else {
         if (src.s16) launch_s16_to_f64(src.s16, in, n, src.vol, src.vol_in_float, h->stream);
-        launch_absmax_copy_f64(in, out, n, in_gain, h->d_scr3.p, nblk, h->stream);      // blk == 256
+        launch_absmax_copy_f64(in, out, n, in_gain, h->d_scr3.p, nblk, h->stream, o16);      // blk == 256
     }
     // a position p is clean when no sample in the previous (B + release*sr + 4) samples exceeds the limit; segment starts are
     // picked on the device (one candidate per 2048 samples), so the limiter needs no host round trip
@@ -1200,7 +1207,7 @@ static void run_limiter(jt_ctx *h, double *in, double *out, int64_t n, int sr, d
     h->lim_bounds.ensure((size_t)ntargets);
     h->lim_delta.ensure((size_t)ntargets * B); h->lim_pos.ensure((size_t)ntargets * B); h->lim_lp.ensure((size_t)ntargets * B);
     launch_limiter_f64(in, out, n, sr, limit, B, release, asc_coeff, h->d_scr3.p, nblk, blk, need, target, h->lim_bounds.p, ntargets,
-                       in_gain, h->lim_delta.p, h->lim_pos.p, h->stream, h->lim_lp.p, h->opts.limiter_lanes, JT_AB_ON(h->opts.lim_profile), from16 ? &s16src : nullptr);
+                       in_gain, h->lim_delta.p, h->lim_pos.p, h->stream, h->lim_lp.p, h->opts.limiter_lanes, JT_AB_ON(h->opts.lim_profile), from16 ? &s16src : nullptr, o16);
 }
 
 // loudnorm (dynamic-mode first pass) input statistics of a signal at `rate`, measured after swr -> 192 kHz
@@ -1466,13 +1473,21 @@ extern "C" int jt_pass4(jt_ctx *h, const jt_limiter_plan *lim, const jt_loudnorm
         h->f64_c.ensure((size_t)m);
         tmp = h->f64_c.p;
     }
-    run_limiter(h, sig, tmp, m, rate, ap->brickwall_limit, 1.0, 50.0, brick_gain);
-    std::swap(sig, tmp);
-    check_cancel(h);
-    // dbl -> flt (aspectralstats) -> dbl (ebur128) -> s16
+    // dbl -> flt (aspectralstats) -> dbl (ebur128) -> s16.  Nothing reads the brickwall's doubles but that conversion: its two kernels
+    // write the float and the s16 themselves (the first sweep wherever the limiter rests, the wave kernel its hot segments) instead of
+    // 8 bytes per sample that a third sweep reads back (option brickwall_f64: the three-sweep form, same bytes)
     h->work_a.ensure((size_t)m);
     h->s16_p4.ensure((size_t)m);
-    launch_f64_to_s16(sig, h->s16_p4.p, h->work_a.p, m, 1, h->stream);
+    if (limiter_can_emit16(h, rate, 1.0)) {
+        const LimOut16 o16{h->s16_p4.p, h->work_a.p};
+        run_limiter(h, sig, tmp, m, rate, ap->brickwall_limit, 1.0, 50.0, brick_gain, LimS16{}, &o16);
+        check_cancel(h);
+    } else {
+        run_limiter(h, sig, tmp, m, rate, ap->brickwall_limit, 1.0, 50.0, brick_gain);
+        std::swap(sig, tmp);
+        check_cancel(h);
+        launch_f64_to_s16(sig, h->s16_p4.p, h->work_a.p, m, 1, h->stream);
+    }
     h->m_p4 = m;
     AnalysisJob J;
     analysis_enqueue(h, h->work_a.p, m, rate, true, rate / 10, &J, false);

@@ -90,7 +90,7 @@ template <typename T> struct DevBuf {
 // that build imports JT_<KEY> variables, once, inside jt_open.
 #define JT_OPT_BOOLS(X) \
     X(no_pass2_prefetch) X(no_early_pass3) X(no_early_plan) X(no_lim_keep) X(no_staged_finish) X(no_r128_first) \
-    X(region_full_astats) X(host_timing) X(adeclick_exact) X(nlm_generic) X(p3_unfused) X(limiter_lanes) X(tp_unpruned) X(no_spec_direct)
+    X(region_full_astats) X(host_timing) X(adeclick_exact) X(nlm_generic) X(p3_unfused) X(limiter_lanes) X(tp_unpruned) X(no_spec_direct) X(brickwall_f64)
 #define JT_OPT_INTS(X) X(region_rot) X(tp_prune_min)
 #define JT_OPT_AB_BOOLS(X) \
     X(nlm_old) X(afftdn_old) X(adeclick_fused) X(dk_levinson_in_kernel) X(dk_no_xcd) X(dk_serial) X(dk_profile) X(dyn_one_wave) \
@@ -167,14 +167,15 @@ void launch_band_rms(const float *in, int64_t n, int nbands, const double (*hp)[
 
 // limiter (exact, chunked at provably clean points)
 // limiter, first sweep (blk == 256): block maxima of |in| and out = in * gain; launch_limiter_f64 expects `out` to hold that copy
-void launch_absmax_copy_f64(const double *in, double *out, int64_t n, double gain, double *out_max, int64_t nblk, hipStream_t s);
+struct LimOut16 { int16_t *s16; float *f32; };        // the limiter's output as k_f64_to_s16(round_via_float = 1) would convert it (the brickwall of Pass 4)
+void launch_absmax_copy_f64(const double *in, double *out, int64_t n, double gain, double *out_max, int64_t nblk, hipStream_t s, const LimOut16 *o16 = nullptr);
 void launch_absmax_conv_s16(const int16_t *in, double *conv, double *out, int64_t n, double vol, int vol_in_float, double gain, double *out_max,
                             int64_t nblk, hipStream_t s);
 struct LimSrc16 { const int16_t *p; double vol; int vol_in_float; };
 void launch_limiter_f64(const double *in, double *out, int64_t n, int sr, double limit, int buffer_size,
                         double release_s, double asc_coeff, const double *block_max, int64_t nblk, int blk, int need, int target,
                         int64_t *cand, int64_t ntargets, double in_gain, double *scratch_delta, int64_t *scratch_pos, hipStream_t s, double *scratch_lp,
-                        bool lane_per_segment = false, bool lim_profile = false, const LimSrc16 *src16 = nullptr);
+                        bool lane_per_segment = false, bool lim_profile = false, const LimSrc16 *src16 = nullptr, const LimOut16 *o16 = nullptr);
 // lane_per_segment: k_limiter_f64 instead of k_limiter_wave; src16: the wave kernel converts its hot segments from the s16 source (in may be null)
 bool jt_limiter_wave_ok(int buffer_size);
 

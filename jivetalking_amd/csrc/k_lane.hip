@@ -1343,11 +1343,31 @@ void launch_dynamics(const float *in, float *out_f32, double *tmp64, double *tmp
 // The limiter's first sweep, fused: per-256-sample maxima of |in| (clean points, hot segments) and out = in * gain, the
 // limiter's output wherever it stays at rest.  One wave per block of 256 samples (four per lane as two 16-byte loads), eight
 // blocks per wave, no LDS.
+// TO16 (the brickwall at the end of Pass 4, whose output nothing reads but the s16 conversion): the product leaves as what
+// k_f64_to_s16(round_via_float = 1) makes of it -- the float and the s16 -- instead of as a double that a further sweep converts
+__device__ __forceinline__ void lim_emit16(double v, int16_t *o16, float *o32, int64_t i)
+{
+    const float f = (float)v;
+    o32[i] = f;
+    double r = rint((double)f * 32768.0);
+    r = r < -32768.0 ? -32768.0 : (r > 32767.0 ? 32767.0 : r);
+    o16[i] = (int16_t)r;
+}
+template <bool TO16>
 __global__ void __launch_bounds__(256)
-k_absmax_copy_f64(const double *__restrict__ in, double *__restrict__ out, int64_t n, double gain, double *__restrict__ out_max, int64_t nblk)
+k_absmax_copy_f64(const double *__restrict__ in, double *__restrict__ out, int64_t n, double gain, double *__restrict__ out_max, int64_t nblk,
+                  int16_t *__restrict__ o16, float *__restrict__ o32)
 {
     const int lane = threadIdx.x & 63;
     const int64_t w = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    auto put2 = [&](int64_t i, double a, double b) {
+        if (!TO16) { *reinterpret_cast<double2 *>(out + i) = double2{a, b}; return; }
+        const float fa = (float)a, fb = (float)b;
+        *reinterpret_cast<float2 *>(o32 + i) = float2{fa, fb};
+        double ra = rint((double)fa * 32768.0), rb = rint((double)fb * 32768.0);
+        ra = ra < -32768.0 ? -32768.0 : (ra > 32767.0 ? 32767.0 : ra); rb = rb < -32768.0 ? -32768.0 : (rb > 32767.0 ? 32767.0 : rb);
+        *reinterpret_cast<short2 *>(o16 + i) = short2{(short)(int16_t)ra, (short)(int16_t)rb};
+    };
     if ((w * 8 + 8) * 256 <= n) {
         // a wave's eight blocks, all sixteen loads in flight before the first is used (one block at a time left a wave with two loads in
         // flight and the sweep at 3.3 TB/s)
@@ -1362,8 +1382,8 @@ k_absmax_copy_f64(const double *__restrict__ in, double *__restrict__ out, int64
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
             mq[q] = fmax(fmax(fabs(v[2 * q].x), fabs(v[2 * q].y)), fmax(fabs(v[2 * q + 1].x), fabs(v[2 * q + 1].y)));
-            *reinterpret_cast<double2 *>(out + base0 + q * 256 + 2 * lane) = double2{v[2 * q].x * gain, v[2 * q].y * gain};
-            *reinterpret_cast<double2 *>(out + base0 + q * 256 + 128 + 2 * lane) = double2{v[2 * q + 1].x * gain, v[2 * q + 1].y * gain};
+            put2(base0 + q * 256 + 2 * lane, v[2 * q].x * gain, v[2 * q].y * gain);
+            put2(base0 + q * 256 + 128 + 2 * lane, v[2 * q + 1].x * gain, v[2 * q + 1].y * gain);
         }
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) {
@@ -1385,10 +1405,13 @@ k_absmax_copy_f64(const double *__restrict__ in, double *__restrict__ out, int64
             const double2 v0 = *reinterpret_cast<const double2 *>(in + base + 2 * lane);
             const double2 v1 = *reinterpret_cast<const double2 *>(in + base + 128 + 2 * lane);
             m = fmax(fmax(fabs(v0.x), fabs(v0.y)), fmax(fabs(v1.x), fabs(v1.y)));
-            *reinterpret_cast<double2 *>(out + base + 2 * lane) = double2{v0.x * gain, v0.y * gain};
-            *reinterpret_cast<double2 *>(out + base + 128 + 2 * lane) = double2{v1.x * gain, v1.y * gain};
+            put2(base + 2 * lane, v0.x * gain, v0.y * gain);
+            put2(base + 128 + 2 * lane, v1.x * gain, v1.y * gain);
         } else {
-            for (int64_t i = base + lane; i < n; i += 64) { const double v = in[i]; m = fmax(m, fabs(v)); out[i] = v * gain; }
+            for (int64_t i = base + lane; i < n; i += 64) {
+                const double v = in[i]; m = fmax(m, fabs(v));
+                if (TO16) lim_emit16(v * gain, o16, o32, i); else out[i] = v * gain;
+            }
         }
         for (int off = 32; off > 0; off >>= 1) m = fmax(m, __shfl_down(m, off, 64));
         if (lane == 0) out_max[b] = m;
@@ -1466,10 +1489,11 @@ void launch_absmax_conv_s16(const int16_t *in, double *conv, double *out, int64_
     if (nblk <= 0) return;
     hipLaunchKernelGGL(k_absmax_conv_s16, dim3((unsigned)((nblk + 31) / 32)), dim3(256), 0, s, in, conv, out, n, vol, vol_in_float, gain, out_max, nblk);
 }
-void launch_absmax_copy_f64(const double *in, double *out, int64_t n, double gain, double *out_max, int64_t nblk, hipStream_t s)
+void launch_absmax_copy_f64(const double *in, double *out, int64_t n, double gain, double *out_max, int64_t nblk, hipStream_t s, const LimOut16 *o16)
 {
     if (nblk <= 0) return;
-    hipLaunchKernelGGL(k_absmax_copy_f64, dim3((unsigned)((nblk + 31) / 32)), dim3(256), 0, s, in, out, n, gain, out_max, nblk);
+    if (o16) hipLaunchKernelGGL(k_absmax_copy_f64<true>, dim3((unsigned)((nblk + 31) / 32)), dim3(256), 0, s, in, out, n, gain, out_max, nblk, o16->s16, o16->f32);
+    else hipLaunchKernelGGL(k_absmax_copy_f64<false>, dim3((unsigned)((nblk + 31) / 32)), dim3(256), 0, s, in, out, n, gain, out_max, nblk, (int16_t *)nullptr, (float *)nullptr);
 }
 
 // Segment starts ("clean points") chosen on the device.  A block b is clean when the `need` blocks before it are all at or
@@ -1735,7 +1759,8 @@ template <bool S16>
 __global__ void __launch_bounds__(64)
 k_limiter_wave(const void *__restrict__ in_v, double *__restrict__ out, int64_t n, int sr, double limit, int B,
                double release, double asc_coeff, const int64_t *__restrict__ cand, int64_t ntargets, int blk, double in_gain,
-               const double *__restrict__ block_max, int64_t nblk, unsigned long long *__restrict__ prof, double vol, int vol_in_float)
+               const double *__restrict__ block_max, int64_t nblk, unsigned long long *__restrict__ prof, double vol, int vol_in_float,
+               int16_t *__restrict__ o16, float *__restrict__ o32)
 {
     const double *in = static_cast<const double *>(in_v);
     const int16_t *in16 = static_cast<const int16_t *>(in_v);
@@ -1934,7 +1959,7 @@ k_limiter_wave(const void *__restrict__ in_v, double *__restrict__ out, int64_t 
                 if (j < jn) { full_step(j); ++j; had_event = true; }
             }
             const bool ramp = !had_event; (void)ramp;
-            if (lane < jn && ie >= lo && ie < hi) out[ie] = ov;
+            if (lane < jn && ie >= lo && ie < hi) { if (o16) lim_emit16(ov, o16, o32, ie); else out[ie] = ov; }      // (o16: the brickwall, straight to the float / s16 outputs)
 #ifdef JT_AB
             if (ramp) LW_MARK(1) else LW_MARK(2)
 #endif
@@ -1954,10 +1979,11 @@ bool jt_limiter_wave_ok(int buffer_size) { return 24 * (size_t)buffer_size <= 96
 void launch_limiter_f64(const double *in, double *out, int64_t n, int sr, double limit, int buffer_size,
                         double release_s, double asc_coeff, const double *block_max, int64_t nblk, int blk, int need, int target,
                         int64_t *cand, int64_t ntargets, double in_gain, double *scratch_delta, int64_t *scratch_pos, hipStream_t s, double *scratch_lp,
-                        bool lane_per_segment, bool lim_profile, const LimSrc16 *src16)
+                        bool lane_per_segment, bool lim_profile, const LimSrc16 *src16, const LimOut16 *o16)
 {
     if (n <= 0) return;
     (void)lim_profile;
+    JT_REQUIRE(!o16 || (jt_limiter_wave_ok(buffer_size) && !lane_per_segment), JT_E_INVAL, "limiter: the s16 output needs the wave-per-segment kernel");
     JT_REQUIRE(!src16 || (jt_limiter_wave_ok(buffer_size) && !lane_per_segment), JT_E_INVAL, "limiter: an s16 source needs the wave-per-segment kernel");
     hipLaunchKernelGGL(k_lim_bounds, dim3((unsigned)((ntargets + 255) / 256)), dim3(256), 0, s, block_max, nblk, need, target,
                        std::fabs(in_gain), limit, cand, ntargets);
@@ -1972,10 +1998,12 @@ void launch_limiter_f64(const double *in, double *out, int64_t n, int sr, double
         if (src16) {
             JT_HIP(hipFuncSetAttribute((const void *)k_limiter_wave<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
             hipLaunchKernelGGL(k_limiter_wave<true>, dim3((unsigned)((ntargets + LANES - 1) / LANES)), dim3(LANES), smem, s, (const void *)src16->p, out, n, sr, limit,
-                               buffer_size, release_s, asc_coeff, cand, ntargets, blk, in_gain, block_max, nblk, prof, src16->vol, src16->vol_in_float);
+                               buffer_size, release_s, asc_coeff, cand, ntargets, blk, in_gain, block_max, nblk, prof, src16->vol, src16->vol_in_float,
+                               o16 ? o16->s16 : (int16_t *)nullptr, o16 ? o16->f32 : (float *)nullptr);
         } else
         hipLaunchKernelGGL(k_limiter_wave<false>, dim3((unsigned)((ntargets + LANES - 1) / LANES)), dim3(LANES), smem, s, (const void *)in, out, n, sr, limit,
-                           buffer_size, release_s, asc_coeff, cand, ntargets, blk, in_gain, block_max, nblk, prof, 1.0, 0);
+                           buffer_size, release_s, asc_coeff, cand, ntargets, blk, in_gain, block_max, nblk, prof, 1.0, 0,
+                           o16 ? o16->s16 : (int16_t *)nullptr, o16 ? o16->f32 : (float *)nullptr);
 #ifdef JT_AB
         if (prof) {
             unsigned long long c[16];
