@@ -78,8 +78,9 @@ extern "C" int jt_open(int device_id, jt_ctx **out)
         }
         JT_HIP(hipStreamCreateWithFlags(&h->dk_stream, hipStreamNonBlocking));
         JT_HIP(hipEventCreateWithFlags(&h->dk_ev[0], hipEventDisableTiming)); JT_HIP(hipEventCreateWithFlags(&h->dk_ev[1], hipEventDisableTiming));
-        for (int i = 0; i < 6; ++i) JT_HIP(hipEventCreateWithFlags(&h->ev_chain[i], hipEventDisableTiming));
+        for (int i = 0; i < 7; ++i) JT_HIP(hipEventCreateWithFlags(&h->ev_chain[i], hipEventDisableTiming));
         JT_HIP(hipEventCreateWithFlags(&h->ev_stats, hipEventDisableTiming));
+        JT_HIP(hipEventCreateWithFlags(&h->ev_nf, hipEventDisableTiming));
     } catch (const JtError &) { delete h; return JT_E_NOGPU; }
     *out = h;
     return JT_OK;
@@ -107,7 +108,8 @@ extern "C" void jt_close(jt_ctx *h)
         if (h->aux[i] && i < 4) { (void)hipStreamSynchronize(h->aux[i]); (void)hipStreamDestroy(h->aux[i]); }
         if (h->ev_join[i]) (void)hipEventDestroy(h->ev_join[i]);
     }
-    for (int i = 0; i < 6; ++i) if (h->ev_chain[i]) (void)hipEventDestroy(h->ev_chain[i]);
+    for (int i = 0; i < 7; ++i) if (h->ev_chain[i]) (void)hipEventDestroy(h->ev_chain[i]);
+    if (h->ev_nf) (void)hipEventDestroy(h->ev_nf);
     if (h->ev_stats) (void)hipEventDestroy(h->ev_stats);
     delete h;
     jt_graveyard().drain();                                    // (the frees above have waited for the device anyway)
@@ -401,6 +403,7 @@ static void analysis_enqueue(jt_ctx *h, const float *x, int64_t n, int sr, bool 
     // K-weighting goes FIRST on its stream (ahead of the noise-floor chain it shares it with): with the true peak it is what the limiter
     // plan of Pass 2 waits for (jt_pass3_plan_hook); the chain's total is the same either way
     const bool r128_first = h->early_p3.mark_kw && J->want_r128;
+    hipStream_t a_nf = a1;          // the stream of astats' noise-floor chain
     if (J->want_r128) {
         // a planner waits for this job (Pass 2): it runs in the normal priority class, on the stream adeclick's second solver uses in
         // Pass 4 (idle here; the announced regions' chains queue up behind it), instead of among the low-priority statistics
@@ -409,7 +412,12 @@ static void analysis_enqueue(jt_ctx *h, const float *x, int64_t n, int sr, bool 
         jt_kweight_enqueue_f32(h, x, n, sr, sr / 10, &J->kw, akw);
         if (!f) JT_HIP(hipEventRecord(h->ev_chain[5], akw));
         if (h->early_p3.mark_kw) { JT_HIP(hipEventRecord(h->early_p3.ev[0], akw)); h->early_p3.mark_kw = false; }
-        if (akw != a1) JT_HIP(hipStreamWaitEvent(a1, h->ev_chain[5], 0));          // (the pass's join of aux[1] then covers the job)
+        if (akw != a1) {
+            JT_HIP(hipStreamWaitEvent(a1, h->ev_chain[5], 0));          // (the pass's join of aux[1] then covers the job)
+            // the noise-floor chain stays behind the job on that stream: at low priority beside Pass 3's sweep it ended last of all (3.3 ms
+            // for 0.5 ms of work) and the pass with it
+            if (!h->opts.nf_low) a_nf = akw;
+        }
     }
     if (J->want_r128) {
         const int blk = sr / 10; const int64_t nfull = n / blk;
@@ -469,8 +477,12 @@ static void analysis_enqueue(jt_ctx *h, const float *x, int64_t n, int sr, bool 
             if (nout > 0) JT_HIP(hipMemcpyAsync(hops, h->spec_hops.p, sizeof(jt_spectral) * nout, hipMemcpyDeviceToHost, a2));
         }
         J->hops = hops;
+        if (!f) JT_HIP(hipEventRecord(h->ev_chain[6], a2));       // (the exponential-average chain of astats follows on this stream)
     }
-    if (J->want_astats) jt_astats_enqueue(h, x, n, sr, &J->as, a0, a1, a2, nullptr, J->astats_levels_only);
+    if (J->want_astats) {
+        jt_astats_enqueue(h, x, n, sr, &J->as, a0, a_nf, a2, nullptr, J->astats_levels_only);
+        if (a_nf != a1) { JT_HIP(hipEventRecord(h->ev_nf, a_nf)); JT_HIP(hipStreamWaitEvent(a1, h->ev_nf, 0)); }      // (joined and waited for through aux[1])
+    }
     if (!f) JT_HIP(hipEventRecord(h->ev_chain[4], a2));
     if (!f) for (int i = 0; i < 4; ++i) JT_HIP(hipEventRecord(h->ev_chain[i], h->aux[i]));
     if (join) analysis_join(h, f ? 2 : 1);
@@ -478,7 +490,8 @@ static void analysis_enqueue(jt_ctx *h, const float *x, int64_t n, int sr, bool 
 
 // staged: the job is the pass's full-length analysis and may still be running; each part of the host arithmetic waits for the chain
 // that feeds it (ev_chain) and runs while the later chains -- true peak and aspectralstats end last -- are still on the GPU
-static void analysis_finish(jt_ctx *h, const AnalysisJob &J, AnalysisHost *A, bool staged)
+// astats_later: the caller collects astats itself, after everything else (its noise-floor chain is usually the last to end)
+static void analysis_finish(jt_ctx *h, const AnalysisJob &J, AnalysisHost *A, bool staged, bool astats_later = false)
 {
     auto wait = [&](int i) { if (staged) JT_HIP(hipEventSynchronize(h->ev_chain[i])); };
     std::vector<double> bsum, bpk;
@@ -488,7 +501,7 @@ static void analysis_finish(jt_ctx *h, const AnalysisJob &J, AnalysisHost *A, bo
         jt_kweight_finish(&J.kw, bsum, bpk);
         jt_r128_finish(bsum.data(), J.nfull, J.blk, J.sr, J.dualmono, &A->r128);
     }
-    if (J.want_astats) { wait(0); wait(1); wait(4); jt_astats_finish(&J.as, &A->astats); }
+    if (J.want_astats && !astats_later) { wait(0); wait(1); wait(4); jt_astats_finish(&J.as, &A->astats); }
     if (J.want_r128) {
         wait(3);
         const int64_t nfull = J.nfull;
@@ -503,7 +516,7 @@ static void analysis_finish(jt_ctx *h, const AnalysisJob &J, AnalysisHost *A, bo
         A->sp_final = sp; A->tp_final = tp;
         if (J.tp_kept) { h->timers.tp_units_total = J.tp_units; h->timers.tp_units_evaluated = J.tp_seeds + *J.tp_kept; }
     }
-    if (J.want_spec) { wait(2); A->hops = J.hops; A->nhops = J.nhops; A->nout = J.nout; }
+    if (J.want_spec) { wait(6); A->hops = J.hops; A->nhops = J.nhops; A->nout = J.nout; }
 }
 
 static void spectral_add(jt_spectral *a, const jt_spectral &b)
@@ -559,10 +572,16 @@ static void analysis_complete(jt_ctx *h, const AnalysisJob &J, jt_analysis *out,
         for (int i = 0; i < 4; ++i) JT_HIP(hipEventSynchronize(h->ev_chain[i]));
         staged = false;
     }
-    analysis_finish(h, J, &A, staged);
-    out->astats = A.astats;
+    // astats last: its noise-floor chain (low priority, behind the K-weighting job) is usually the last chain of a pass to end, and the
+    // per-frame assembly (36 000 records for an hour) needs none of it
+    analysis_finish(h, J, &A, staged, true);
     std::chrono::steady_clock::time_point t1; if (timing) t1 = std::chrono::steady_clock::now();
     assemble_analysis(A, J.n, J.dualmono, out, meta, cap_meta);
+    if (J.want_astats) {
+        if (staged) { JT_HIP(hipEventSynchronize(h->ev_chain[0])); JT_HIP(hipEventSynchronize(h->ev_chain[1])); JT_HIP(hipEventSynchronize(h->ev_chain[4])); }
+        jt_astats_finish(&J.as, &A.astats);
+    }
+    out->astats = A.astats;
     if (timing) fprintf(stderr, "analysis_complete (n = %lld): finish %.3f ms, assemble %.3f ms\n", (long long)J.n,
                         std::chrono::duration<double, std::milli>(t1 - t0).count(),
                         std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t1).count());

@@ -90,7 +90,7 @@ template <typename T> struct DevBuf {
 // that build imports JT_<KEY> variables, once, inside jt_open.
 #define JT_OPT_BOOLS(X) \
     X(no_pass2_prefetch) X(no_early_pass3) X(no_early_plan) X(no_lim_keep) X(no_staged_finish) X(no_r128_first) \
-    X(region_full_astats) X(host_timing) X(adeclick_exact) X(nlm_generic) X(p3_unfused) X(limiter_lanes) X(tp_unpruned) X(no_spec_direct) X(brickwall_f64)
+    X(region_full_astats) X(host_timing) X(adeclick_exact) X(nlm_generic) X(p3_unfused) X(limiter_lanes) X(tp_unpruned) X(no_spec_direct) X(brickwall_f64) X(nf_low)
 #define JT_OPT_INTS(X) X(region_rot) X(tp_prune_min)
 #define JT_OPT_AB_BOOLS(X) \
     X(nlm_old) X(afftdn_old) X(adeclick_fused) X(dk_levinson_in_kernel) X(dk_no_xcd) X(dk_serial) X(dk_profile) X(dyn_one_wave) \
@@ -356,7 +356,7 @@ struct jt_ctx {
     hipEvent_t ev_fork = nullptr, ev_join[8] = {};
     // marks inside the full-length analysis of a pass (analysis_enqueue): [0..3] the ends of its four chains, [4] the astats part of
     // chain 2 (before aspectralstats), [5] the K-weighting job of chain 1 (before the noise floor); ev_stats: Pass 4's loudnorm statistics
-    hipEvent_t ev_chain[6] = {}, ev_stats = nullptr;
+    hipEvent_t ev_chain[7] = {}, ev_stats = nullptr, ev_nf = nullptr;
     std::string err;
     std::atomic<int> cancelled{0};
     bool hold_cancel = false;            // inside jt_process_file: loading the input must not clear a cancel that already arrived
