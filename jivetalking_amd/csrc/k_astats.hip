@@ -360,25 +360,22 @@ k_as_sigma(const float *__restrict__ x, int64_t n, int tc, double mult, double m
     const int lane = threadIdx.x;
     const int64_t c0 = (int64_t)blockIdx.x * 64;
     const int nrows = (int)min((int64_t)64, nchunks - c0);
-    // state entering this block: the maps of blocks 0 .. blockIdx.x - 1 composed in order (rounds of 64, the next round's loads issued ahead)
+    // state entering this block: the maps of blocks 0 .. blockIdx.x - 1 composed in order.  Lane l composes its run of ceil(nb / 64)
+    // consecutive maps serially (its loads all in flight at once), one wave scan joins the 64 runs: a round of 64 maps per scan (41 scans
+    // for an hour, each behind its own loads) was 40 % of a workgroup's life -- the prologue is latency, and nothing else was running yet
     double block_in = 0.0;
+    float v[64];
+    as_rows_load(v, x, n, c0, 0, lane);                  // (the first tile's rows are on their way meanwhile)
     {
         const int64_t nb = blockIdx.x;
-        double carry_in = 0.0;
-        double nA = lane < nb ? blkA[lane] : 1.0, nB = lane < nb ? blkB[lane] : 0.0;
-        for (int64_t base = 0; base < nb; base += 64) {
-            double A = nA, B = nB;
-            const int64_t nx = base + 64 + lane;
-            nA = nx < nb ? blkA[nx] : 1.0; nB = nx < nb ? blkB[nx] : 0.0;
-            for (int o = 1; o < 64; o <<= 1) {
-                const double Ap = __shfl_up(A, o, 64), Bp = __shfl_up(B, o, 64);
-                if (lane >= o) { B = A * Bp + B; A = A * Ap; }
-            }
-            const double s_after = A * carry_in + B;
-            // the state after map nb - 1 is what enters this block (the same lane's value the one-wave scan kernel stored for it)
-            carry_in = __shfl(s_after, (int)min((int64_t)63, nb - 1 - base), 64);
+        const int64_t K = (nb + 63) / 64, lo = (int64_t)lane * K, hi = min(nb, lo + K);
+        double A = 1.0, B = 0.0;
+        for (int64_t j = lo; j < hi; ++j) { const double a = blkA[j], b = blkB[j]; B = a * B + b; A = a * A; }
+        for (int o = 1; o < 64; o <<= 1) {
+            const double Ap = __shfl_up(A, o, 64), Bp = __shfl_up(B, o, 64);
+            if (lane >= o) { B = A * Bp + B; A = A * Ap; }
         }
-        block_in = carry_in;
+        block_in = __shfl(B, 63, 64);                    // (the composite applied to the state 0 the file starts from)
     }
     // state entering this lane's chunk: the block's entering state pushed through the preceding chunks of the block
     double avg;
@@ -396,8 +393,6 @@ k_as_sigma(const float *__restrict__ x, int64_t n, int tc, double mult, double m
     }
     double mn = DBL_MAX, mx = 0.0;
     const double om = 1.0 - mult;
-    float v[64];
-    as_rows_load(v, x, n, c0, 0, lane);
     for (int pos = 0; pos < ZC; pos += 64) {
         as_rows_commit(tile, v, n, c0, pos, lane, nrows);
         __syncthreads();
