@@ -57,10 +57,15 @@ void jt_end_job(jt_ctx *h);
  * and read by the launchers (a Go host runs many goroutines; getenv / setenv beside them is a data race).  key / value are short
  * ASCII strings; a boolean takes "1" / "0" (or "true" / "false", "on" / "off"; NULL or "" = on).
  *   schedule switches (same results either way; the tests run both): no_pass2_prefetch, no_early_pass3, no_early_plan, no_lim_keep,
- *     no_staged_finish, no_r128_first, region_rot (0..3, -1 = default), region_full_astats
+ *     no_staged_finish, no_r128_first, region_rot (0..3, -1 = default), region_full_astats, no_spec_direct (aspectralstats' records
+ *     through a device buffer and a copy instead of straight into the pinned arena), nf_low (Pass 2: astats' noise-floor chain among the
+ *     low-priority statistics instead of behind the K-weighting job)
  *   kernel selection: adeclick_exact (the sequential-order adeclick kernel, bit-exact to af_adeclick.c's summation order),
  *     nlm_generic (the any-geometry anlmdn kernel), p3_unfused (Pass 3 as stand-alone upsampler + K-weighting kernels: what the fused
- *     sweep is tested against), limiter_lanes (alimiter with a lane per segment: what the wave-per-segment kernel is tested against)
+ *     sweep is tested against), limiter_lanes (alimiter with a lane per segment: what the wave-per-segment kernel is tested against),
+ *     tp_unpruned (ebur128's true peak by the exhaustive kernels: what the branch-and-bound path is tested against), tp_prune_min
+ *     (integer: the shortest signal, in samples, that takes the branch-and-bound path; default 1048576), brickwall_f64 (Pass 4's
+ *     brickwall as doubles + a dbl -> flt -> s16 sweep instead of writing the float and the s16 itself)
  *   diagnostics: host_timing (host-stage timings on stderr)
  *   process-wide (h == NULL): graveyard_gb (gigabytes of superseded buffers parked before they are freed, default 24, 0 = free at
  *     once), poison_alloc (fill every new device allocation with 0xFF bytes; test switch)
