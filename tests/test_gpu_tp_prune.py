@@ -74,3 +74,24 @@ def test_branch_and_bound_true_peak_inside_the_passes(engine, n):
     assert got[0][0] == got[1][0] and np.array_equal(got[0][1], got[1][1], equal_nan=True) and got[0][2] == got[1][2]
     t = engine.timers()
     assert t["tp_units_total"] >= n // 256
+
+
+def test_branch_and_bound_true_peak_through_the_four_passes(engine):
+    """The whole job (jt_process_audio) on three minutes of the bench talker with the default true peak and with the exhaustive kernels:
+    the limiter plan (it reads Pass 2's true peak), every reported true peak (input, filtered, final, loudnorm's), the regions' and
+    the delivered bytes are identical -- Pass 2 and Pass 4 analyse 48 kHz and 44.1 kHz signals above the default threshold (2^20
+    samples), so both list kernels run."""
+    from conftest import bench_talker
+    from jivetalking_amd import hostlogic as H
+    x = np.asarray(bench_talker(180.0, 48000, 1021, 40.0), np.float32)
+    engine.upload_pcm(x, 48000, 1)
+    got = []
+    for unpruned in (False, True):
+        with options(engine, tp_unpruned=unpruned):
+            r = H.process_audio(engine)
+            t = engine.timers()
+            got.append((engine.download_s16(4).tobytes(), r.input.input_tp, r.filtered.r128.true_peak, r.final_.r128.true_peak, r.output_tp_db,
+                        r.output_lufs, int(r.limiter.needed), r.limiter.limit if hasattr(r.limiter, "limit") else 0.0))
+            if not unpruned:
+                assert 0 < t["tp_units_evaluated"] < t["tp_units_total"]
+    assert got[0] == got[1]
