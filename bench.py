@@ -503,7 +503,7 @@ def main():
                             "note": "jt_load_audio of that image (44.1 kHz mono s16): H2D from pageable memory, find + parse + "
                                     "decode + finish kernels, host chain walk"},
         }
-    dk_parity = None
+    dk_parity = None; tp_parity = None
     if rank == 0 and world == 1 and args.e2e:
         # adeclick's default kernel against the sequential-order one (option adeclick_exact: bit-exact to the oracle) on THIS file, outside
         # the timed region: the delivered s16 of the last timed step against one more step with the exact kernel
@@ -520,7 +520,18 @@ def main():
                      "note": "default adeclick kernel (summation order relaxed) vs the sequential-order kernel on the bench file, whole job; "
                              "tests/test_gpu_round4.py holds the same comparison to a bound on a 20-minute file"}
         del fast, exact, dd
-        hostlogic.process_audio(eng, base, 4096)                       # (the default kernel's output back in place for the legs below)
+        # the branch-and-bound true peak against the exhaustive kernels (option tp_unpruned) on THIS file, whole job, outside the timed region
+        r_bb = hostlogic.process_audio(eng, base, 4096)                # (also: the default adeclick kernel's output back in place for the legs below)
+        b_bb = eng.download_s16(4).copy()
+        eng.set_option("tp_unpruned", True)
+        r_ex = hostlogic.process_audio(eng, base, 4096)
+        b_ex = eng.download_s16(4)
+        eng.set_option("tp_unpruned", False)
+        tp_fields = lambda r: (r.input.input_tp, r.filtered.r128.true_peak, r.final_.r128.true_peak, r.output_tp_db, r.output_lufs, int(r.limiter.needed))
+        tp_parity = {"reported_true_peaks_identical": tp_fields(r_bb) == tp_fields(r_ex), "s16_identical": bool(np.array_equal(b_bb, b_ex)),
+                     "note": "input / filtered / final true peak, the landing and the delivered s16 of the job with the branch-and-bound true "
+                             "peak and with the exhaustive kernels; tests/test_gpu_tp_prune.py holds the per-frame running maxima bit-identical"}
+        del b_bb, b_ex
     sat_leg = None
     if args.saturation and args.channels == 1:
         sat_leg = saturation_on_gpu(args, eng, rank, world, local_rank, base, hostlogic, synth, sr)
@@ -600,6 +611,7 @@ def main():
                        "adaptive": "full host mirror (VAD, speech election, AdaptConfig, band RMS) in C++",
                        "true_peak": ("branch and bound: %d of %d units of the final analysis evaluated" % (tpu["tp_units_evaluated"], tpu["tp_units_total"])
                                      if tpu["tp_units_total"] else "exhaustive"),
+                       "true_peak_vs_exhaustive": tp_parity,
                        "options": list(args.option),
                        "pass2_spec": res.pass2_spec.decode()},
             "result": {"output_lufs": round(res.output_lufs, 3), "output_dbtp": round(res.output_tp_db, 3),
