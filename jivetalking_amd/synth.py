@@ -138,7 +138,11 @@ def speech_like_torch(duration_s, sample_rate=48000, seed=0, device="cuda", spee
     g1 = gate_t[torch.clamp(idx + 1, max=grid - 1)]
     gate_s = g0 + (g1 - g0) * frac
     f0 = 150 + 50 * torch.sin(2 * np.pi * 0.23 * t + 1.1) + 15 * torch.sin(2 * np.pi * 1.7 * t)
-    phase = torch.cumsum(f0 / sr, 0) * (2 * np.pi)
+    # the phase is the integral of f0 in closed form: torch's device-side cumsum (a decoupled look-back scan) sums 10^8 doubles in an order
+    # that varies from run to run, and with it the last bits of every sample of the talker -- the bench file was not the same file twice
+    del f0
+    w1, w2 = 2 * np.pi * 0.23, 2 * np.pi * 1.7
+    phase = (150 * t - (50 / w1) * torch.cos(w1 * t + 1.1) - (15 / w2) * torch.cos(w2 * t)) * (2 * np.pi)
     v = torch.zeros(n, device=device, dtype=torch.float32)
 
     def formant(f):
@@ -172,6 +176,13 @@ def speech_like_torch(duration_s, sample_rate=48000, seed=0, device="cuda", spee
         burst = (0.35 * torch.hann_window(w, device=device) * torch.sin(2 * np.pi * 180.0 * tt / sr)).float()
         keep = gate_s[pos] > 0.5                                   # bursts belong to phrases, not to the room tone
         pos = pos[keep] if bool(keep.any()) else pos
+        # bursts that would overlap an earlier one are dropped: index_add_ adds with atomics, and two bursts on the same samples were summed in
+        # an order that varied from run to run (a last-bit difference that the peak normalisation below then spread over the whole file)
+        pos, _ = torch.sort(pos)
+        if pos.numel() > 1:
+            ok = torch.ones_like(pos, dtype=torch.bool)
+            ok[1:] = (pos[1:] - pos[:-1]) >= w          # (a run of three close bursts may lose its third for nothing: fine)
+            pos = pos[ok]
         x.index_add_(0, (pos[:, None] + tt[None, :]).reshape(-1), burst.repeat(pos.numel()))
     peak = x.abs().max()
     lim = 10 ** (-3.0 / 20.0)
