@@ -135,7 +135,8 @@ void jt_host_plan_limiter(double output_i, double output_tp_db, const jt_host_co
 void jt_host_calculate_linear_mode_target(double measured_i, double measured_tp, double desired_i, double target_tp,
                                           double *effective_i, double *offset, int *linear_possible);  /* :614-632 */
 double jt_host_loudnorm_internal_target_tp(double target_i, double measured_tp, double measured_i);  /* :583-585 */
-/* buildLoudnormFilterSpec (normalise.go:1231-1334) + the numeric jt_loudnorm_apply it implies */
+/* buildLoudnormFilterSpec (normalise.go:1231-1334) + the numeric jt_loudnorm_apply it implies.  Returns the spec's length, or
+ * JT_E_INVAL when adeclick is enabled with a method code outside 0..4 (jt_process_audio / jt_process_file refuse it the same way) */
 int  jt_host_pass4_spec(const jt_host_config *cfg, const jt_loudnorm_stats *measurement, double offset, const jt_limiter_decision *lim,
                         int source_rate, const char *stats_path, char *buf, int cap, jt_loudnorm_apply *apply);
 
@@ -263,6 +264,12 @@ int  jt_handle_pool_workers(const jt_handle_pool *pool, int *devices_out, int ca
 int  jt_handle_pool_process_files(jt_handle_pool *pool, const char *const *paths, int n_files, const jt_host_config *base, int frame_samples, int flac_flags,
                            jt_file_result *results, int *device_of_file);
 void jt_handle_pool_close(jt_handle_pool *pool);
+/* Where the pool's last batch spent its time, summed over the files (ms; a diagnostic for the host that sizes in_flight_per_device):
+ * [0] waiting for a free I/O set of the handle, [1] reading the input, [2] decode, [3] the four passes + host logic, [4] encode
+ * (the handle's thread); [5] waiting for a finisher thread, [6] the STREAMINFO MD5, [7] temp write + rename (a finisher thread);
+ * [8] files counted.  Returns JT_POOL_STATS, writes at most cap values. */
+#define JT_POOL_STATS 9
+int  jt_handle_pool_stats(jt_handle_pool *pool, double *out, int cap);
 
 /* ---- granular detector steps (the reference table-tests each of these: analyser_vad_test.go) ---- */
 int    jt_host_vad_detect(const jt_interval *iv, int64_t n, double noise_floor_seed, jt_measurements *out);      /* detectVoiceActivity :728 */

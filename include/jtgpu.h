@@ -37,6 +37,14 @@ typedef struct jt_ctx jt_ctx;
 /* ---- lifecycle ---- */
 int  jt_device_count(void);                       /* HIP devices visible to this process (0 when there is none or HIP cannot initialise) */
 int  jt_open(int device_id, jt_ctx **out);
+/* jt_open for a handle that shares its GPU with other handles (pool.go:122-153: a bounded number of ProcessAudio calls in flight).
+ * n_streams: 0 (= jt_open) or >= 8: a HIP stream per chain (fastest for ONE file at a time); 1: every chain on one stream; 2: main +
+ * one low-priority stream.  The runtime multiplexes all streams of a process onto a handful of hardware queues, and one file's event
+ * waits stall every stream that shares a queue with them: several handles on one GPU want ONE stream each (ten-minute files, eight in
+ * flight: 10 ms per file against 15-100 with eight streams each).  flags: JT_OPEN_BLOCKING_SYNC = host waits sleep on an interrupt
+ * instead of spinning on the completion signal (a pool otherwise burns a host core per handle).  Results are identical either way. */
+#define JT_OPEN_BLOCKING_SYNC 0x1
+int  jt_open_ex(int device_id, int n_streams, int flags, jt_ctx **out);
 void jt_close(jt_ctx *h);
 const char *jt_last_error(const jt_ctx *h);
 const char *jt_version(void);
@@ -66,9 +74,12 @@ void jt_end_job(jt_ctx *h);
  *     tp_unpruned (ebur128's true peak by the exhaustive kernels: what the branch-and-bound path is tested against), tp_prune_min
  *     (integer: the shortest signal, in samples, that takes the branch-and-bound path; default 1048576), brickwall_f64 (Pass 4's
  *     brickwall as doubles + a dbl -> flt -> s16 sweep instead of writing the float and the s16 itself)
- *   diagnostics: host_timing (host-stage timings on stderr)
+ *   diagnostics: host_timing (host-stage timings on stderr; PROCESS-WIDE although it is set through a handle: the host stages are
+ *     plain functions without one, the last writer wins for every handle of the process)
  *   process-wide (h == NULL): graveyard_gb (gigabytes of superseded buffers parked before they are freed, default 24, 0 = free at
- *     once), poison_alloc (fill every new device allocation with 0xFF bytes; test switch)
+ *     once), poison_alloc (fill every new device allocation with 0xFF bytes; test switch), pool_streams (HIP streams per handle of a
+ *     handle pool with three or more handles per device: default 1, see jt_open_ex), pool_blocking_sync (those handles' host waits
+ *     sleep instead of spinning: default 1), host_timing.  Each library flavour (libjtgpu.so, libjtgpu_ab.so) keeps its own copy.
  * Superseded kernel generations and tuning knobs (nlm_old, afftdn_old, adeclick_fused, dyn_one_wave, kw_two_sweeps, follow_tiles,
  * dk_waves, ...) exist only in the A/B build of the library (make ab -> libjtgpu_ab.so, jt_build_flags() & 1): the default build
  * answers JT_E_UNSUPPORTED for them, an unknown key or a malformed value is JT_E_INVAL.

@@ -76,10 +76,25 @@ var (
 	gpuPool   = map[int][]*gpuEngine{} // device -> idle handles
 )
 
+// gpuWorkersPerDevice is how many ProcessAudioGPU calls the CLI keeps in flight per GPU (SetGPUWorkersPerDevice, called where
+// runBoundedPool sizes its pool: workers / GPUDeviceCount()).  Three or more handles on one GPU are opened with ONE HIP stream each and
+// polling host waits (jt_open_ex): the runtime multiplexes every stream of the process onto a handful of hardware queues, and with
+// eight streams per handle one file's event waits stall the other files' streams (ten-minute files, eight in flight: 10 ms per file
+// against 15-100), while spinning waits would hold one host core per handle.  One or two handles keep a stream per chain (jt_open).
+var gpuWorkersPerDevice atomic.Int32
+
+// SetGPUWorkersPerDevice tells the engine layer how many files the caller keeps in flight per GPU.  Handles already open keep the
+// mode they were opened in; call it before the pool starts (or CloseGPUEngines first).
+func SetGPUWorkersPerDevice(n int) { gpuWorkersPerDevice.Store(int32(n)) }
+
 func openGPUEngine(device int) (*gpuEngine, error) {
 	var h *C.jt_ctx
-	if rc := C.jt_open(C.int(device), &h); rc != C.JT_OK {
-		return nil, fmt.Errorf("jt_open(device %d): code %d", device, int(rc))
+	streams, flags := C.int(0), C.int(0)
+	if gpuWorkersPerDevice.Load() >= 3 {
+		streams, flags = 1, C.JT_OPEN_BLOCKING_SYNC
+	}
+	if rc := C.jt_open_ex(C.int(device), streams, flags, &h); rc != C.JT_OK {
+		return nil, fmt.Errorf("jt_open_ex(device %d): code %d", device, int(rc))
 	}
 	return &gpuEngine{h: h, device: device}, nil
 }

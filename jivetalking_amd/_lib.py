@@ -118,7 +118,7 @@ class AudioMeta(C.Structure):
 
 # every symbol include/jtgpu.h declares
 SYMBOLS = [
-    "jt_device_count", "jt_open", "jt_close", "jt_last_error", "jt_version", "jt_set_option", "jt_build_flags", "jt_cancel", "jt_reset_cancel", "jt_begin_job", "jt_end_job", "jt_pass3_plan_hook", "jt_set_source_format",
+    "jt_device_count", "jt_open", "jt_open_ex", "jt_close", "jt_last_error", "jt_version", "jt_set_option", "jt_build_flags", "jt_cancel", "jt_reset_cancel", "jt_begin_job", "jt_end_job", "jt_pass3_plan_hook", "jt_set_source_format",
     "jt_upload_pcm", "jt_attach_device_pcm", "jt_upload_s16", "jt_load_audio", "jt_op_decode_audio",
     "jt_pass1", "jt_band_rms", "jt_pass2", "jt_pass2_prefetch", "jt_pass2_prefetch_after_pass1", "jt_region_measure", "jt_region_measure_pair", "jt_region_prefetch", "jt_pass3", "jt_pass4",
     "jt_output_len", "jt_download_s16", "jt_output_frame_levels", "jt_flac_encode", "jt_op_flac_encode_s16", "jt_get_timers",

@@ -26,32 +26,43 @@ extern "C" int jt_device_count(void)
     return count < 0 ? 0 : count;
 }
 
-extern "C" int jt_open(int device_id, jt_ctx **out)
+extern "C" int jt_open_ex(int device_id, int n_streams, int flags, jt_ctx **out)
 {
     if (!out) return JT_E_INVAL;
     *out = nullptr;
-    // one context drives seven streams (main, four analysis chains, two early-start streams; one of them at low priority, which has a
-    // queue pool of its own); ROCclr multiplexes streams onto GPU_MAX_HW_QUEUES (default 4) hardware queues per priority, fixed when the
-    // runtime initialises.  8 gives every stream of a context a queue to itself -- but that variable belongs to the HOST: it must be in
-    // the environment before the process touches HIP (the Go shim sets it in init(), jivetalking_amd/_lib.py before it loads this
-    // library).  The library itself neither reads nor writes the environment.  More than 8 is worse, not better: with 16
-    // (32 queues in the process) several contexts on one GPU oversubscribe the hardware queue slots and the driver time-slices them --
-    // three 10-minute files in flight took 25 ms each instead of 15, five took 390 ms, six did not finish (tools/inflight_probe.py;
-    // 8 queues: 15 ms per file at 4, 6 and 8 in flight).  The default of 4 is safe, a few per cent slower.
+    // A context drives up to eight streams (main, four analysis chains, two early-start streams, adeclick's second solver; half of them
+    // at low priority, which has a queue pool of its own); ROCclr multiplexes streams onto GPU_MAX_HW_QUEUES (default 4) hardware queues
+    // per priority, fixed when the runtime initialises.  8 gives every stream of ONE context a queue to itself -- but that variable
+    // belongs to the HOST: it must be in the environment before the process touches HIP (the Go shim sets it in init(),
+    // jivetalking_amd/_lib.py before it loads this library).  The library itself neither reads nor writes the
+    // environment.  More than 8 is worse, not better: with 16 (32 queues in the process) several contexts on one GPU oversubscribe the
+    // hardware queue slots and the driver time-slices them (tools/inflight_probe.py).
+    // n_streams: 0 / >= 8 = all of them (one file alone is fastest that way: its chains overlap each other);
+    // 1 = every chain on the main stream, 2 = main + one low-priority stream for the statistics chains and the early Pass-2 head.
+    // Several contexts on one GPU (a handle pool) want FEW streams each: with six contexts x eight streams on eight hardware queues
+    // every event wait of one file is a barrier packet in a queue that other files' streams share, and the files serialise each other.
     int count = 0;
     if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) return JT_E_NOGPU;
     if (device_id < 0 || device_id >= count) return JT_E_INVAL;
+    if (n_streams < 0 || (flags & ~JT_OPEN_BLOCKING_SYNC)) return JT_E_INVAL;
     jt_ctx *h = new jt_ctx();
     h->device = device_id;
+    h->n_streams = (n_streams == 0 || n_streams >= 8) ? 8 : (n_streams >= 2 ? 2 : 1);
+    // JT_OPEN_BLOCKING_SYNC: every host wait of this handle sleeps on an interrupt (hipEventBlockingSync) instead of spinning on the
+    // completion signal -- a pool of handles otherwise burns one host core per handle for the length of the batch
+    h->blocking = (flags & JT_OPEN_BLOCKING_SYNC) != 0;
+    const unsigned evb = h->blocking ? hipEventBlockingSync : 0u;
 #ifdef JT_AB
     opts_from_env(&h->opts);
 #endif
     try {
         JT_HIP(hipSetDevice(device_id));
         JT_HIP(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
-        JT_HIP(hipEventCreate(&h->ev0)); JT_HIP(hipEventCreate(&h->ev1));
-        JT_HIP(hipEventCreate(&h->ev2)); JT_HIP(hipEventCreate(&h->ev3));
-        JT_HIP(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
+        h->owned_streams.push_back(h->stream);
+        JT_HIP(hipEventCreateWithFlags(&h->ev0, evb)); JT_HIP(hipEventCreateWithFlags(&h->ev1, evb));
+        JT_HIP(hipEventCreateWithFlags(&h->ev2, evb)); JT_HIP(hipEventCreateWithFlags(&h->ev3, evb));
+        JT_HIP(hipEventCreateWithFlags(&h->ev_block, hipEventDisableTiming | evb));
+        JT_HIP(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming | evb));
         int prio_least = 0, prio_greatest = 0;
         JT_HIP(hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest));
         // the analysis chains run at the low priority too (the same queue class as the early Pass-2 head: no third pool of hardware queues):
@@ -63,51 +74,59 @@ extern "C" int jt_open(int device_id, jt_ctx **out)
 #else
         const bool aux_low = true, tp_normal = true;
 #endif
+        auto own = [&](hipStream_t *s, bool low) {
+            if (low) JT_HIP(hipStreamCreateWithPriority(s, hipStreamNonBlocking, prio_least));
+            else JT_HIP(hipStreamCreateWithFlags(s, hipStreamNonBlocking));
+            h->owned_streams.push_back(*s);
+        };
+        hipStream_t second = h->stream;
+        if (h->n_streams == 2) own(&second, true);
         // lowest priority: the small band-RMS launches the host is waiting for must get through beside it
-        JT_HIP(hipStreamCreateWithPriority(&h->spec_p2.stream, hipStreamNonBlocking, prio_least));
-        JT_HIP(hipEventCreateWithFlags(&h->spec_p2.done, hipEventDisableTiming));
-        JT_HIP(hipStreamCreateWithFlags(&h->spec_ln.stream, hipStreamNonBlocking));
-        JT_HIP(hipEventCreateWithFlags(&h->spec_ln.fork, hipEventDisableTiming));
+        if (h->n_streams == 8) own(&h->spec_p2.stream, true); else h->spec_p2.stream = second;
+        JT_HIP(hipEventCreateWithFlags(&h->spec_p2.done, hipEventDisableTiming | evb));
+        if (h->n_streams == 8) own(&h->spec_ln.stream, false); else h->spec_ln.stream = h->stream;
+        JT_HIP(hipEventCreateWithFlags(&h->spec_ln.fork, hipEventDisableTiming | evb));
         // the chains of announced output regions (aux[4..7]) are small: aliases of other streams, picked by pass_begin
         for (int i = 0; i < 8; ++i) {
             // (aux[3] carries the true-peak sweep, the longest chain of every analysis and, in Pass 2, what the limiter plan waits for: it
             // stays in the normal class so that its workgroups are placed before the other statistics')
-            if (i < 4) JT_HIP(hipStreamCreateWithPriority(&h->aux[i], hipStreamNonBlocking, (aux_low && !(i == 3 && tp_normal)) ? prio_least : 0));
-            else h->aux[i] = h->aux[(i + 3) % 4];
-            JT_HIP(hipEventCreateWithFlags(&h->ev_join[i], hipEventDisableTiming));
+            if (i < 4) {
+                if (h->n_streams == 8) own(&h->aux[i], aux_low && !(i == 3 && tp_normal));
+                else h->aux[i] = i == 3 ? h->stream : second;
+            } else h->aux[i] = h->aux[(i + 3) % 4];
+            JT_HIP(hipEventCreateWithFlags(&h->ev_join[i], hipEventDisableTiming | evb));
         }
-        JT_HIP(hipStreamCreateWithFlags(&h->dk_stream, hipStreamNonBlocking));
-        JT_HIP(hipEventCreateWithFlags(&h->dk_ev[0], hipEventDisableTiming)); JT_HIP(hipEventCreateWithFlags(&h->dk_ev[1], hipEventDisableTiming));
-        for (int i = 0; i < 7; ++i) JT_HIP(hipEventCreateWithFlags(&h->ev_chain[i], hipEventDisableTiming));
-        JT_HIP(hipEventCreateWithFlags(&h->ev_stats, hipEventDisableTiming));
-        JT_HIP(hipEventCreateWithFlags(&h->ev_nf, hipEventDisableTiming));
-    } catch (const JtError &) { delete h; return JT_E_NOGPU; }
+        if (h->n_streams == 8) own(&h->dk_stream, false); else h->dk_stream = h->stream;
+        JT_HIP(hipEventCreateWithFlags(&h->dk_ev[0], hipEventDisableTiming | evb)); JT_HIP(hipEventCreateWithFlags(&h->dk_ev[1], hipEventDisableTiming | evb));
+        for (int i = 0; i < 7; ++i) JT_HIP(hipEventCreateWithFlags(&h->ev_chain[i], hipEventDisableTiming | evb));
+        JT_HIP(hipEventCreateWithFlags(&h->ev_stats, hipEventDisableTiming | evb));
+        JT_HIP(hipEventCreateWithFlags(&h->ev_nf, hipEventDisableTiming | evb));
+    } catch (const JtError &) { jt_close(h); return JT_E_NOGPU; }
     *out = h;
     return JT_OK;
 }
+extern "C" int jt_open(int device_id, jt_ctx **out) { return jt_open_ex(device_id, 0, 0, out); }
 
 extern "C" void jt_close(jt_ctx *h)
 {
     if (!h) return;
     (void)hipSetDevice(h->device);
-    if (h->stream) { (void)hipStreamSynchronize(h->stream); (void)hipStreamDestroy(h->stream); }
+    for (hipStream_t s : h->owned_streams) (void)hipStreamSynchronize(s);
+    for (hipStream_t s : h->owned_streams) (void)hipStreamDestroy(s);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
     if (h->ev2) (void)hipEventDestroy(h->ev2);
     if (h->ev3) (void)hipEventDestroy(h->ev3);
-    if (h->spec_p2.stream) { (void)hipStreamSynchronize(h->spec_p2.stream); (void)hipStreamDestroy(h->spec_p2.stream); }
+    if (h->ev_block) (void)hipEventDestroy(h->ev_block);
     if (h->spec_p2.done) (void)hipEventDestroy(h->spec_p2.done);
-    if (h->spec_ln.stream) { (void)hipStreamSynchronize(h->spec_ln.stream); (void)hipStreamDestroy(h->spec_ln.stream); }
     if (h->early_p3.pin) (void)hipHostFree(h->early_p3.pin);
     if (h->early_p3.ev[0]) { (void)hipEventDestroy(h->early_p3.ev[0]); (void)hipEventDestroy(h->early_p3.ev[1]); }
-    if (h->dk_stream) { (void)hipStreamSynchronize(h->dk_stream); (void)hipStreamDestroy(h->dk_stream); (void)hipEventDestroy(h->dk_ev[0]); (void)hipEventDestroy(h->dk_ev[1]); }
+    if (h->dk_ev[0]) (void)hipEventDestroy(h->dk_ev[0]);
+    if (h->dk_ev[1]) (void)hipEventDestroy(h->dk_ev[1]);
     if (h->spec_ln.fork) (void)hipEventDestroy(h->spec_ln.fork);
     if (h->spec_ln.pin) (void)hipHostFree(h->spec_ln.pin);
     if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
-    for (int i = 0; i < 8; ++i) {
-        if (h->aux[i] && i < 4) { (void)hipStreamSynchronize(h->aux[i]); (void)hipStreamDestroy(h->aux[i]); }
-        if (h->ev_join[i]) (void)hipEventDestroy(h->ev_join[i]);
-    }
+    for (int i = 0; i < 8; ++i) if (h->ev_join[i]) (void)hipEventDestroy(h->ev_join[i]);
     for (int i = 0; i < 7; ++i) if (h->ev_chain[i]) (void)hipEventDestroy(h->ev_chain[i]);
     if (h->ev_nf) (void)hipEventDestroy(h->ev_nf);
     if (h->ev_stats) (void)hipEventDestroy(h->ev_stats);
@@ -174,6 +193,9 @@ extern "C" int jt_set_option(jt_ctx *h, const char *key, const char *value)
             if (*end || !(gb >= 0)) return JT_E_INVAL;
             DevGraveyard::set_limit_gb(gb); return JT_OK;
         }
+        if (!strcmp(key, "pool_streams")) { int v = 0; if (!opt_int(value, &v) || v < 0) return JT_E_INVAL; jt_pool_streams().store(v); return JT_OK; }
+        if (!strcmp(key, "pool_blocking_sync")) { bool b = false; if (!opt_bool(value, &b)) return JT_E_INVAL; jt_pool_blocking().store(b ? 1 : 0); return JT_OK; }
+        if (!strcmp(key, "host_timing")) { bool b = false; if (!opt_bool(value, &b)) return JT_E_INVAL; jt_host_timing().store(b ? 1 : 0); return JT_OK; }
         if (!strcmp(key, "poison_alloc")) { bool b = false; if (!opt_bool(value, &b)) return JT_E_INVAL; jt_poison_alloc().store(b ? 1 : 0); return JT_OK; }
         return JT_E_INVAL;
     }
@@ -208,7 +230,7 @@ static void ensure_twiddle(jt_ctx *h, int N)
     for (int k = 0; k < N / 2; ++k) { double a = -2.0 * M_PI * k / N; tw[k] = make_float2((float)std::cos(a), (float)std::sin(a)); }
     h->twiddle.ensure(N / 2);
     JT_HIP(hipMemcpyAsync(h->twiddle.p, tw.data(), sizeof(float2) * (N / 2), hipMemcpyHostToDevice, h->stream));
-    JT_HIP(hipStreamSynchronize(h->stream));
+    JT_HIP(jt_stream_sync(h, h->stream));
     h->twiddle_n = N;
 }
 static void ensure_hann(jt_ctx *h, int N)
@@ -218,14 +240,14 @@ static void ensure_hann(jt_ctx *h, int N)
     for (int i = 0; i < N; ++i) w[i] = (float)(.5 * (1 - std::cos(2 * M_PI * i / (N - 1))));
     h->hann.ensure(N);
     JT_HIP(hipMemcpyAsync(h->hann.p, w.data(), sizeof(float) * N, hipMemcpyHostToDevice, h->stream));
-    JT_HIP(hipStreamSynchronize(h->stream));
+    JT_HIP(jt_stream_sync(h, h->stream));
     h->hann_n = N;
 }
 
 void jt_spec_pass2_cancel(jt_ctx *h)
 {
     h->spec_p2.armed = false;
-    if (h->spec_p2.pending) { h->spec_p2.pending = false; JT_HIP(hipStreamSynchronize(h->spec_p2.stream)); }
+    if (h->spec_p2.pending) { h->spec_p2.pending = false; JT_HIP(jt_stream_sync(h, h->spec_p2.stream)); }
 }
 
 void jt_set_input_common(jt_ctx *h, int64_t frames, int sr, int ch)
@@ -256,7 +278,7 @@ extern "C" int jt_upload_pcm(jt_ctx *h, const float *pcm, int64_t frames, int sr
     h->in_raw = h->in_owned.p;
     h->src_fmt = 0;
     jt_set_input_common(h, frames, sr, ch);
-    JT_HIP(hipStreamSynchronize(h->stream));
+    JT_HIP(jt_stream_sync(h, h->stream));
     JT_API_END(h)
 }
 
@@ -267,14 +289,14 @@ extern "C" int jt_attach_device_pcm(jt_ctx *h, const void *dev_ptr, int64_t fram
     h->in_raw = static_cast<const float *>(dev_ptr);
     h->src_fmt = 0;
     jt_set_input_common(h, frames, sr, ch);
-    JT_HIP(hipStreamSynchronize(h->stream));
+    JT_HIP(jt_stream_sync(h, h->stream));
     JT_API_END(h)
 }
 
 // an early Pass-3 measurement still reading the Pass-2 output must finish before that output is replaced
 static void spec_loudnorm_cancel(jt_ctx *h)
 {
-    if (h->spec_ln.pending) { JT_HIP(hipStreamSynchronize(h->spec_ln.stream)); h->spec_ln.pending = false; }
+    if (h->spec_ln.pending) { JT_HIP(jt_stream_sync(h, h->spec_ln.stream)); h->spec_ln.pending = false; }
 }
 
 extern "C" int jt_upload_s16(jt_ctx *h, const int16_t *pcm, int64_t frames, int sr)
@@ -284,7 +306,7 @@ extern "C" int jt_upload_s16(jt_ctx *h, const int16_t *pcm, int64_t frames, int 
     spec_loudnorm_cancel(h);
     h->s16_p2.ensure((size_t)frames);
     JT_HIP(hipMemcpyAsync(h->s16_p2.p, pcm, sizeof(int16_t) * (size_t)frames, hipMemcpyHostToDevice, h->stream));
-    JT_HIP(hipStreamSynchronize(h->stream));
+    JT_HIP(jt_stream_sync(h, h->stream));
     h->m_p2 = frames; h->out_rate = sr; h->m_p4 = 0;
     JT_API_END(h)
 }
@@ -294,7 +316,7 @@ static SwrDev &get_swr(jt_ctx *h, int in_rate, int out_rate)
 {
     for (auto &e : h->swr) if (e.in_rate == in_rate && e.out_rate == out_rate) return e;
     SwrDev &e = h->swr[h->swr_next]; h->swr_next = (h->swr_next + 1) % 4;
-    JT_HIP(hipStreamSynchronize(h->stream));             // the slot's old banks may still be read by queued kernels
+    JT_HIP(jt_stream_sync(h, h->stream));             // the slot's old banks may still be read by queued kernels
     jt_swr_plan(&e.pl, in_rate, out_rate);
     {   // norms of the tap rows for the true peak's bounds (k_resample.hip, k_tp_bounds)
         const int L = e.pl.filter_length;
@@ -327,7 +349,7 @@ static SwrDev &get_swr(jt_ctx *h, int in_rate, int out_rate)
     for (size_t i = 0; i < bf.size(); ++i) { bs[i] = std::ldexp(bf[i], -15); if (std::ldexp(bs[i], 15) != bf[i] || (bs[i] != 0 && !std::isnormal(bs[i]))) exact = false; }
     e.bank_fs.release();
     if (exact) { e.bank_fs.ensure(bs.size()); JT_HIP(hipMemcpyAsync(e.bank_fs.p, bs.data(), sizeof(float) * bs.size(), hipMemcpyHostToDevice, h->stream)); }
-    JT_HIP(hipStreamSynchronize(h->stream));
+    JT_HIP(jt_stream_sync(h, h->stream));
     e.in_rate = in_rate; e.out_rate = out_rate;
     return e;
 }
@@ -395,6 +417,8 @@ static void fork_aux(jt_ctx *h, int first, int last, hipStream_t from = nullptr)
 static void analysis_enqueue(jt_ctx *h, const float *x, int64_t n, int sr, bool dualmono, int sel_blk, AnalysisJob *J, bool join = true,
                              const AnalysisLanes *ln = nullptr)
 {
+    // pass_begin sizes the K-weighting and true-peak slabs for 100 ms blocks of at least 800 samples (the rates jt_upload_pcm accepts)
+    JT_REQUIRE(sr >= 8000 && sr <= 384000, JT_E_UNSUPPORTED, "analysis: sample rates outside 8-384 kHz are not measured on the device");
     J->n = n; J->sr = sr; J->dualmono = dualmono;
     // fork: x is ready once everything queued on the main stream so far has run
     const int f = ln ? ln->first : 0;
@@ -493,7 +517,7 @@ static void analysis_enqueue(jt_ctx *h, const float *x, int64_t n, int sr, bool 
 // astats_later: the caller collects astats itself, after everything else (its noise-floor chain is usually the last to end)
 static void analysis_finish(jt_ctx *h, const AnalysisJob &J, AnalysisHost *A, bool staged, bool astats_later = false)
 {
-    auto wait = [&](int i) { if (staged) JT_HIP(hipEventSynchronize(h->ev_chain[i])); };
+    auto wait = [&](int i) { if (staged) JT_HIP(jt_event_wait(h, h->ev_chain[i])); };
     std::vector<double> bsum, bpk;
     if (J.want_r128) {
         wait(5);
@@ -569,7 +593,7 @@ static void analysis_complete(jt_ctx *h, const AnalysisJob &J, jt_analysis *out,
     const bool timing = h->opts.host_timing;
     std::chrono::steady_clock::time_point t0; if (timing) t0 = std::chrono::steady_clock::now();
     if (staged && h->opts.no_staged_finish) {          // (the round-2 order: everything after the last chain)
-        for (int i = 0; i < 4; ++i) JT_HIP(hipEventSynchronize(h->ev_chain[i]));
+        for (int i = 0; i < 4; ++i) JT_HIP(jt_event_wait(h, h->ev_chain[i]));
         staged = false;
     }
     // astats last: its noise-floor chain (low priority, behind the K-weighting job) is usually the last chain of a pass to end, and the
@@ -578,7 +602,7 @@ static void analysis_complete(jt_ctx *h, const AnalysisJob &J, jt_analysis *out,
     std::chrono::steady_clock::time_point t1; if (timing) t1 = std::chrono::steady_clock::now();
     assemble_analysis(A, J.n, J.dualmono, out, meta, cap_meta);
     if (J.want_astats) {
-        if (staged) { JT_HIP(hipEventSynchronize(h->ev_chain[0])); JT_HIP(hipEventSynchronize(h->ev_chain[1])); JT_HIP(hipEventSynchronize(h->ev_chain[4])); }
+        if (staged) { JT_HIP(jt_event_wait(h, h->ev_chain[0])); JT_HIP(jt_event_wait(h, h->ev_chain[1])); JT_HIP(jt_event_wait(h, h->ev_chain[4])); }
         jt_astats_finish(&J.as, &A.astats);
     }
     out->astats = A.astats;
@@ -621,7 +645,7 @@ extern "C" int jt_pass1(jt_ctx *h, int frame_samples, jt_analysis *out, double *
         try { spec_pass2_start(h, &h->spec_p2.armed_p); } catch (const JtError &e) { if (e.code != JT_E_INVAL) throw; }
     }
     analysis_complete(h, J, out, meta, cap_meta, true);       // (chain by chain, while the later chains still run)
-    JT_HIP(hipStreamSynchronize(h->stream));
+    JT_HIP(jt_stream_sync(h, h->stream));
     check_cancel(h);
     if (fst) {
         const int64_t c = std::min(nfr, cap_frames);
@@ -630,7 +654,7 @@ extern "C" int jt_pass1(jt_ctx *h, int frame_samples, jt_analysis *out, double *
     }
     out->n_input_frames = nfr;
     JT_HIP(hipEventRecord(h->ev1, h->stream));
-    JT_HIP(hipEventSynchronize(h->ev1));
+    JT_HIP(jt_event_wait(h, h->ev1));
     float ms = 0; JT_HIP(hipEventElapsedTime(&ms, h->ev0, h->ev1)); h->timers.pass1_ms = ms;
     JT_API_END(h)
 }
@@ -743,7 +767,7 @@ extern "C" int jt_band_rms(jt_ctx *h, double start_s, double dur_s, const double
         launch_band_rms(src, len, nb, hp, lp, mode, h->d_scr1.p, h->stream);
         double sums[16];
         JT_HIP(hipMemcpyAsync(sums, h->d_scr1.p, sizeof(double) * 16, hipMemcpyDeviceToHost, h->stream));
-        JT_HIP(hipStreamSynchronize(h->stream));
+        JT_HIP(jt_stream_sync(h, h->stream));
         for (int k = 0; k < nb; ++k) {
             out_db[slot[k]] = 20 * std::log10(std::sqrt(sums[k] / (double)len));
             if (ok) ok[slot[k]] = 1;   // astats Overall.RMS_level key present (may be -inf on digital silence)
@@ -827,7 +851,7 @@ static void run_afftdn(jt_ctx *h, const float *in, float *out, int64_t n, int sr
     launch_afftdn(in, out, n, d, 0, 0, h->stream, h->opts, 2);
     std::vector<double> vote((size_t)nframes), mv((size_t)nframes + 1);
     JT_HIP(hipMemcpyAsync(vote.data(), d.track_out, sizeof(double) * nframes, hipMemcpyDeviceToHost, h->stream));
-    JT_HIP(hipStreamSynchronize(h->stream));
+    JT_HIP(jt_stream_sync(h, h->stream));
     check_cancel(h);
     const double Cc = M_LN10 * 0.1;
     double nfl = pl.noise_floor;
@@ -839,7 +863,7 @@ static void run_afftdn(jt_ctx *h, const float *in, float *out, int64_t n, int sr
     h->af_last_floor = nfl;
     JT_HIP(hipMemcpyAsync(h->af_track.p + nframes + 1, mv.data(), sizeof(double) * (nframes + 1), hipMemcpyHostToDevice, h->stream));
     launch_afftdn(in, out, n, d, 0, 96, h->stream, h->opts, 1);
-    JT_HIP(hipStreamSynchronize(h->stream));                 // (mv is a host vector: the upload must have left it)
+    JT_HIP(jt_stream_sync(h, h->stream));                 // (mv is a host vector: the upload must have left it)
 }
 
 static void fill_biquads(const jt_filter_params *p, int sr, BiquadF32 st[2], int *nst)
@@ -1099,7 +1123,7 @@ extern "C" int jt_pass2(jt_ctx *h, const jt_filter_params *p, jt_analysis *out)
         // what the limiter plan waits for: the K-weighting job (first on aux[1]: analysis_enqueue marks its end) and the true peak
         // (aux[3], marked below before the region chains queue up behind it on the same stream)
         auto &E = h->early_p3;
-        if (!E.ev[0]) { JT_HIP(hipEventCreateWithFlags(&E.ev[0], hipEventDisableTiming)); JT_HIP(hipEventCreateWithFlags(&E.ev[1], hipEventDisableTiming)); }
+        if (!E.ev[0]) { const unsigned evb = hipEventDisableTiming | (h->blocking ? hipEventBlockingSync : 0u); JT_HIP(hipEventCreateWithFlags(&E.ev[0], evb)); JT_HIP(hipEventCreateWithFlags(&E.ev[1], evb)); }
         E.mark_kw = true;
     }
     analysis_enqueue(h, cur, n, sr, true, sr / 10, &J, false);
@@ -1150,14 +1174,14 @@ extern "C" int jt_pass2(jt_ctx *h, const jt_filter_params *p, jt_analysis *out)
         auto now = [] { return std::chrono::steady_clock::now(); };
         auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
         const auto tq = now();
-        JT_HIP(hipEventSynchronize(E.ev[0]));
+        JT_HIP(jt_event_wait(h, E.ev[0]));
         const auto t0 = now();
         check_cancel(h);
         std::vector<double> bsum, bpk;
         jt_kweight_finish(&J.kw, bsum, bpk);
         R128Series r; jt_r128_finish(bsum.data(), J.nfull, J.blk, J.sr, J.dualmono, &r, true);
         const auto t1 = now();
-        JT_HIP(hipEventSynchronize(E.ev[1]));
+        JT_HIP(jt_event_wait(h, E.ev[1]));
         const auto t2 = now();
         check_cancel(h);
         double tp = 0; for (int64_t k = 0; k < J.nfull; ++k) tp = std::max(tp, J.btp[(size_t)k]);
@@ -1176,14 +1200,14 @@ extern "C" int jt_pass2(jt_ctx *h, const jt_filter_params *p, jt_analysis *out)
         // the main stream still carries Pass 3's prefix chain (several ms): the analysis chains end long before it, so their host
         // arithmetic (gating, merges, the per-frame assembly) runs while the GPU works instead of after it
         analysis_complete(h, J, out, nullptr, 0, true);         // (the full-length chains first: the regions' run behind them)
-        for (int i = 0; i < 4 * (regions ? 2 : 1); ++i) JT_HIP(hipEventSynchronize(h->ev_join[i]));
+        for (int i = 0; i < 4 * (regions ? 2 : 1); ++i) JT_HIP(jt_event_wait(h, h->ev_join[i]));
         check_cancel(h);
         if (regions) { regions_finish(h, out_rate, RJ, slot.out); slot.valid = true; }
-        JT_HIP(hipEventSynchronize(h->ev1));
+        JT_HIP(jt_event_wait(h, h->ev1));
         check_cancel(h);
     } else {
         analysis_complete(h, J, out, nullptr, 0, true);
-        JT_HIP(hipEventSynchronize(h->ev1));
+        JT_HIP(jt_event_wait(h, h->ev1));
         check_cancel(h);
         if (regions) { regions_finish(h, out_rate, RJ, slot.out); slot.valid = true; }
     }
@@ -1253,7 +1277,7 @@ static void pass3_core(jt_ctx *h, const int16_t *s16, int64_t m, int rate, const
         auto &E = h->early_p3;
         E.valid = false;
         if (s16 == h->s16_p2.p && m == h->m_p2 && lim && lim->needed && E.plan.needed && lim->pre_gain_db == E.plan.pre_gain_db && lim->limit == E.plan.limit) {
-            if (h->spec_ln.pending) { JT_HIP(hipStreamSynchronize(h->spec_ln.stream)); h->spec_ln.pending = false; }   // (retire the no-prefix guess)
+            if (h->spec_ln.pending) { JT_HIP(jt_stream_sync(h, h->spec_ln.stream)); h->spec_ln.pending = false; }   // (retire the no-prefix guess)
             LoudnormJob J; J.kw = E.kw; J.nfull = E.nfull; J.blk = E.blk;
             loudnorm_measure_finish(J, out);
             return;
@@ -1263,7 +1287,7 @@ static void pass3_core(jt_ctx *h, const int16_t *s16, int64_t m, int rate, const
     if (h->spec_ln.pending) {
         // Pass 2 already queued this measurement of its output for the no-prefix plan: collect it -- or let it finish (it owns the
         // 192 kHz stream buffer) and measure what was asked for
-        JT_HIP(hipStreamSynchronize(h->spec_ln.stream));
+        JT_HIP(jt_stream_sync(h, h->spec_ln.stream));
         h->spec_ln.pending = false;
         if (s16 == h->s16_p2.p && m == h->m_p2 && !(lim && lim->needed)) {
             LoudnormJob J; J.kw = h->spec_ln.kw; J.nfull = h->spec_ln.nfull; J.blk = h->spec_ln.blk;
@@ -1284,7 +1308,7 @@ static void pass3_core(jt_ctx *h, const int16_t *s16, int64_t m, int rate, const
     } else {
         loudnorm_measure_enqueue(h, s16, nullptr, m, rate, &J);
     }
-    JT_HIP(hipStreamSynchronize(h->stream));
+    JT_HIP(jt_stream_sync(h, h->stream));
     loudnorm_measure_finish(J, out);
 }
 
@@ -1299,7 +1323,7 @@ extern "C" int jt_pass3(jt_ctx *h, const jt_limiter_plan *lim, double target_i, 
     JT_HIP(hipEventRecord(h->ev0, h->stream));
     pass3_core(h, h->s16_p2.p, h->m_p2, h->out_rate, lim, out);
     JT_HIP(hipEventRecord(h->ev1, h->stream));
-    JT_HIP(hipEventSynchronize(h->ev1));
+    JT_HIP(jt_event_wait(h, h->ev1));
     float ms = 0; JT_HIP(hipEventElapsedTime(&ms, h->ev0, h->ev1)); h->timers.pass3_ms = ms;
     JT_API_END(h)
 }
@@ -1315,7 +1339,7 @@ static void loudnorm_dynamic_run(jt_ctx *h, double *x, int64_t m, const Loudnorm
     const double target_tp_lin = std::pow(10., in.target_tp / 20.);
     auto finish_stats = [&](const std::vector<double> &bs_in, int64_t nfull_in, double pk_in, bool dynamic) {
         KwJob oj; jt_kweight_enqueue_f64(h, y, m, 192000, F100, &oj, s);
-        JT_HIP(hipStreamSynchronize(s));
+        JT_HIP(jt_stream_sync(h, s));
         std::vector<double> bo, po; jt_kweight_finish(&oj, bo, po);
         const int64_t nfo = m / F100;
         double pko = 0; for (int64_t k = 0; k <= nfo; ++k) pko = std::max(pko, po[(size_t)k]);
@@ -1330,7 +1354,7 @@ static void loudnorm_dynamic_run(jt_ctx *h, double *x, int64_t m, const Loudnorm
     if (m < F3000) {
         // shorter than the 3 s the first frame asks for: the filter measures what it got and applies one gain (frame_type LINEAR_MODE)
         KwJob ij; jt_kweight_enqueue_f64(h, x, m, 192000, F100, &ij, s);
-        JT_HIP(hipStreamSynchronize(s));
+        JT_HIP(jt_stream_sync(h, s));
         std::vector<double> bs, pk; jt_kweight_finish(&ij, bs, pk);
         const int64_t nf = m / F100;
         double peak = 0; for (int64_t k = 0; k <= nf; ++k) peak = std::max(peak, pk[(size_t)k]);
@@ -1353,7 +1377,7 @@ static void loudnorm_dynamic_run(jt_ctx *h, double *x, int64_t m, const Loudnorm
         JT_HIP(hipMemcpyAsync(y + pad, x, (size_t)m * sizeof(double), hipMemcpyDeviceToDevice, s));
         jt_kweight_enqueue_f64(h, y, m + pad, 192000, F100, &pj, s);
     }
-    JT_HIP(hipStreamSynchronize(s));
+    JT_HIP(jt_stream_sync(h, s));
     std::vector<double> bs, pk; jt_kweight_finish(&ij, bs, pk);
     const int64_t nfull_x = m / F100, nfull_ext = m_ext / F100;
     double peak = 0; for (int64_t k = 0; k <= nfull_x; ++k) peak = std::max(peak, pk[(size_t)k]);
@@ -1519,7 +1543,7 @@ extern "C" int jt_pass4(jt_ctx *h, const jt_limiter_plan *lim, const jt_loudnorm
     // host tail, while the output analysis is still on the GPU: the loudnorm statistics (two gated integrations over the 100 ms blocks
     // of a job that ended before the analysis began), then the analysis itself chain by chain as its chains end
     if (stats_lin && stats_queued) {
-        JT_HIP(hipEventSynchronize(h->ev_stats));
+        JT_HIP(jt_event_wait(h, h->ev_stats));
         const int64_t nfull = m / sblk;
         std::vector<double> bsum, bpk;
         jt_kweight_finish(&sj, bsum, bpk);
@@ -1532,7 +1556,7 @@ extern "C" int jt_pass4(jt_ctx *h, const jt_limiter_plan *lim, const jt_loudnorm
         stats->normalization_type_dynamic = 0;
     }
     analysis_complete(h, J, out, nullptr, 0, true);
-    JT_HIP(hipEventSynchronize(h->ev1));
+    JT_HIP(jt_event_wait(h, h->ev1));
     check_cancel(h);
     if (dk_stats) {
         h->timers.declick_repaired = (int64_t)dk_stats[0]; h->timers.declick_heavy_windows = (int64_t)dk_stats[2];
@@ -1587,7 +1611,7 @@ extern "C" int jt_region_measure_pair(jt_ctx *h, int stage, const double start_s
     pass_begin(h, std::max<int64_t>(RJ.len[0] + RJ.len[1], 1), 2);
     regions_enqueue(h, src, rate, &RJ, false);
     analysis_join(h);
-    JT_HIP(hipStreamSynchronize(h->stream));
+    JT_HIP(jt_stream_sync(h, h->stream));
     regions_finish(h, rate, RJ, out);
     JT_API_END(h)
 }
@@ -1618,7 +1642,7 @@ extern "C" int jt_download_s16(jt_ctx *h, int stage, int16_t *dst, int64_t cap, 
     JT_REQUIRE(src && m > 0, JT_E_STATE, "download: stage output not on device");
     JT_REQUIRE(dst && cap >= m, JT_E_INVAL, "download: buffer too small");
     JT_HIP(hipMemcpyAsync(dst, src, sizeof(int16_t) * m, hipMemcpyDeviceToHost, h->stream));
-    JT_HIP(hipStreamSynchronize(h->stream));
+    JT_HIP(jt_stream_sync(h, h->stream));
     if (n) *n = m;
     JT_API_END(h)
 }
@@ -1640,7 +1664,7 @@ extern "C" int jt_output_frame_levels(jt_ctx *h, int stage, int frame_samples, d
         launch_frame_sumsq_s16(src, m, frame_samples, h->d_scr3.p, nfr, h->stream);
         std::vector<double> ss((size_t)nfr);
         JT_HIP(hipMemcpyAsync(ss.data(), h->d_scr3.p, sizeof(double) * nfr, hipMemcpyDeviceToHost, h->stream));
-        JT_HIP(hipStreamSynchronize(h->stream));
+        JT_HIP(jt_stream_sync(h, h->stream));
         for (int64_t f = 0; f < c; ++f) {
             const int64_t cnt = std::min<int64_t>(frame_samples, m - f * frame_samples);
             const double rms = std::sqrt(ss[(size_t)f] / (double)cnt);
@@ -1666,7 +1690,7 @@ template <typename T> static void h2d(jt_ctx *h, DevBuf<T> &b, const T *src, siz
 template <typename T> static void d2h(jt_ctx *h, T *dst, const T *src, size_t n)
 {
     JT_HIP(hipMemcpyAsync(dst, src, sizeof(T) * n, hipMemcpyDeviceToHost, h->stream));
-    JT_HIP(hipStreamSynchronize(h->stream));
+    JT_HIP(jt_stream_sync(h, h->stream));
 }
 
 extern "C" int jt_op_biquad_f32(jt_ctx *h, const float *in, float *out, int64_t n, int sr,
@@ -1792,7 +1816,7 @@ extern "C" int jt_op_ebur128(jt_ctx *h, const float *in, int64_t n, int sr, int 
     pass_begin(h, n, 1);
     AnalysisJob J; J.want_astats = false; J.want_spec = false;
     analysis_enqueue(h, a.p, n, sr, dualmono != 0, 0, &J);
-    JT_HIP(hipStreamSynchronize(h->stream));
+    JT_HIP(jt_stream_sync(h, h->stream));
     AnalysisHost A; analysis_finish(h, J, &A, false);
     out->integrated = A.r128.integrated; out->lra = A.r128.lra; out->lra_low = A.r128.lra_low; out->lra_high = A.r128.lra_high;
     out->momentary = A.nblocks ? A.r128.M[A.nblocks - 1] : NAN; out->shortterm = A.nblocks ? A.r128.S[A.nblocks - 1] : NAN;
@@ -1814,7 +1838,7 @@ extern "C" int jt_op_astats(jt_ctx *h, const float *in, int64_t n, int sr, jt_as
     DevBuf<float> a; h2d(h, a, in, (size_t)n);
     pass_begin(h, n, 1);
     AstatsJob J; jt_astats_enqueue(h, a.p, n, sr, &J, h->stream, h->stream, h->stream);
-    JT_HIP(hipStreamSynchronize(h->stream));
+    JT_HIP(jt_stream_sync(h, h->stream));
     jt_astats_finish(&J, out);
     JT_API_END(h)
 }
@@ -1827,7 +1851,7 @@ extern "C" int jt_op_aspectralstats(jt_ctx *h, const float *in, int64_t n, int s
     pass_begin(h, n, 1);
     AnalysisJob J; J.want_astats = false; J.want_r128 = false;
     analysis_enqueue(h, a.p, n, sr, false, 0, &J);
-    JT_HIP(hipStreamSynchronize(h->stream));
+    JT_HIP(jt_stream_sync(h, h->stream));
     AnalysisHost A; analysis_finish(h, J, &A, false);
     for (int64_t k = 0; k < std::min(cap, A.nhops); ++k) hops[k] = A.hops[(size_t)k];
     if (n_hops) *n_hops = A.nhops;

@@ -16,6 +16,8 @@
 #include <chrono>
 #include <thread>
 #include <atomic>
+#include <condition_variable>
+#include <deque>
 
 static double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 namespace {
@@ -953,6 +955,8 @@ extern "C" void jt_host_calculate_linear_mode_target(double mi, double mtp, doub
 extern "C" int jt_host_pass4_spec(const jt_host_config *cfg, const jt_loudnorm_stats *ms, double offset, const jt_limiter_decision *lim,
                                   int source_rate, const char *stats_path, char *buf, int cap, jt_loudnorm_apply *ap)
 {
+    // AdeclickConfig.Method is one of five spellings (filters.go:240-246); any other code would print no m= option and run overlap-add silently
+    if (cfg->adeclick_enabled && (cfg->adeclick_method_s < 0 || cfg->adeclick_method_s > 4)) return JT_E_INVAL;
     double internalTP = jt_host_loudnorm_internal_target_tp(cfg->target_i, ms->input_tp, ms->input_i);
     double emittedTP = std::max(-9.0, std::min(internalTP, 0.0));
     double brickDB = cfg->target_tp - 0.9;
@@ -1130,6 +1134,7 @@ extern "C" int jt_host_output_path(const char *input_path, int lufs_value, char 
 static int process_audio_impl(jt_ctx *h, const jt_host_config *base, int frame_samples, jt_progress_fn cb, void *user, jt_process_result *out, bool ticks)
 {
     if (!h || !base || !out) return JT_E_INVAL;
+    if (base->adeclick_enabled && (base->adeclick_method_s < 0 || base->adeclick_method_s > 4)) { h->err = "adeclick_method_s must be 0..4"; return JT_E_INVAL; }
     TickSink tk; tk.cb = cb; tk.user = user; tk.ticks = ticks && cb; tk.duration = h->sr > 0 ? (double)h->n / h->sr : 0.0;
     // calculateFrameLevel of the frames of a stage output, for the ticks of Passes 2-4
     auto stage_levels = [&](int stage, std::vector<double> *lv) {
@@ -1232,7 +1237,7 @@ static int process_audio_impl(jt_ctx *h, const jt_host_config *base, int frame_s
     out->effective_target_i = effI; out->offset = offset; out->linear_possible = lin;
     jt_host_config effcfg = eff; effcfg.target_i = effI;
     jt_loudnorm_apply ap;
-    jt_host_pass4_spec(&effcfg, &m3, offset, &out->limiter, h->out_rate, nullptr, out->pass4_spec, (int)sizeof(out->pass4_spec), &ap);
+    if (jt_host_pass4_spec(&effcfg, &m3, offset, &out->limiter, h->out_rate, nullptr, out->pass4_spec, (int)sizeof(out->pass4_spec), &ap) < 0) { h->err = "adeclick_method_s must be 0..4"; return JT_E_INVAL; }
     emit(3, "Measuring", 1.0, dur, nullptr, nullptr, nullptr, nullptr);
     emit(4, "Normalising", 0.0, dur, nullptr, nullptr, nullptr, &out->limiter);
     if (have_regions) jt_region_prefetch(h, 4, reg_st, reg_du);
@@ -1454,17 +1459,28 @@ extern "C" void jt_host_test_inject_fault(int create_temp, int write, int rename
 {
     g_fault_create_temp.store(create_temp); g_fault_write.store(write); g_fault_rename.store(rename_);
 }
-extern "C" int jt_process_file(jt_ctx *h, const char *input_path, const jt_host_config *base, int frame_samples, int flac_flags,
-                               jt_progress_fn cb, void *user, jt_process_result *out, char *output_path, int cap, double io_ms[4])
+// A file's job in two halves.  file_front: read, decode, four passes, encode -- everything that needs the handle.  file_tail: the
+// STREAMINFO MD5 (one dependent chain: 64 ms of a host core per ten minutes of audio), the sibling temp file, the rename -- nothing
+// that needs the GPU or the handle's device buffers, only the two pinned buffers of the handle's current I/O set.  jt_process_file
+// runs both on the calling thread; a handle pool gives the tail to a finisher thread and starts the handle's next file in the other
+// I/O set (the MD5 used to hold the handle: 64 of a ten-minute file's 80 ms).
+namespace {
+double wall_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+struct FileTail {
+    uint8_t *image = nullptr; int64_t len = 0;            // the finished .flac image (pinned, STREAMINFO signature still zero when pcm != null)
+    const int16_t *pcm = nullptr; size_t n_pcm = 0;       // what the signature covers (pinned); null = no signature wanted / already in place
+    std::string input_path, final_path;
+    const std::atomic<int> *cancelled = nullptr;          // the handle's flag when the tail runs inside the handle's own job
+};
+int file_front(jt_ctx *h, const char *input_path, const jt_host_config *base, int frame_samples, int flac_flags,
+               jt_progress_fn cb, void *user, jt_process_result *out, FileTail *tail, double io_ms[4])
 {
-    if (!h || !input_path || !out) return JT_E_INVAL;
     auto fail = [&](int code, const std::string &msg) { h->err = msg; return code; };
-    auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
-    double t = now();
+    double t = wall_ms();
     // the job starts here: a jt_cancel() from now on (during the read, the decode, any pass, the encode, the write) ends it
     if (!h->hold_cancel) h->cancelled.store(0);            // (inside a jt_begin_job bracket the caller has cleared it already)
     struct Hold { jt_ctx *h; bool was; Hold(jt_ctx *c) : h(c), was(c->hold_cancel) { h->hold_cancel = true; } ~Hold() { h->hold_cancel = was; } } hold(h);
-    // the file image goes straight into pinned memory (the handle's FLAC staging arena: nothing is in flight between files),
+    // the file image goes straight into pinned memory (the I/O set's FLAC staging arena: nothing of this set is in flight),
     // so the upload runs at the full PCIe rate instead of through HIP's pageable bounce buffers
     uint8_t *image = nullptr; size_t image_len = 0;
     {
@@ -1474,58 +1490,88 @@ extern "C" int jt_process_file(jt_ctx *h, const char *input_path, const jt_host_
         if (sz <= 0) { fclose(f); return fail(JT_E_INVAL, std::string("empty input file: ") + input_path); }
         try {
             if (hipSetDevice(h->device) != hipSuccess) throw JtError{JT_E_HIP, "hipSetDevice failed"};
-            h->pin_flac.begin((size_t)sz + 64);
-            image = h->pin_flac.take<uint8_t>((size_t)sz);
+            h->pin_flac().begin((size_t)sz + 64);
+            image = h->pin_flac().take<uint8_t>((size_t)sz);
         } catch (const JtError &e) { fclose(f); return fail(e.code, e.msg); }
         image_len = (size_t)sz;
         const size_t got = fread(image, 1, image_len, f);
         fclose(f);
         if (got != image_len) return fail(JT_E_INVAL, std::string("short read on input file: ") + input_path);
     }
-    if (io_ms) io_ms[0] = now() - t;
-    t = now();
+    if (io_ms) io_ms[0] = wall_ms() - t;
+    t = wall_ms();
     if (h->cancelled.load()) return fail(JT_E_CANCELLED, "cancelled");
     jt_audio_meta meta;
     int rc = jt_load_audio(h, image, (int64_t)image_len, &meta);
     if (rc != JT_OK) return rc;
-    if (io_ms) io_ms[1] = now() - t;
+    if (io_ms) io_ms[1] = wall_ms() - t;
     rc = process_audio_impl(h, base, frame_samples, cb, user, out, (flac_flags & JT_FILE_PROGRESS_TICKS) != 0);
     if (rc != JT_OK) return rc;
-    t = now();
+    t = wall_ms();
     const uint8_t *data = nullptr; int64_t len = 0; jt_flac_info info;
-    rc = jt_flac_encode(h, 4, flac_flags & JT_FLAC_MD5, &data, &len, &info);
+    rc = jt_flac_encode_file(h, 4, (flac_flags & JT_FLAC_MD5) ? JT_FLAC_MD5_DEFER : 0, &data, &len, &info);
     if (rc != JT_OK) return rc;
-    if (io_ms) io_ms[2] = now() - t;
-    t = now();
+    if (io_ms) io_ms[2] = wall_ms() - t;
     char path[4096];
     if (jt_host_output_path(input_path, jt_host_lufs_filename_value(out->output_lufs), path, (int)sizeof path) < 0)
         return fail(JT_E_INVAL, "output path too long");
-    {
-        // createSiblingTempPath(inputPath, "processing") + publishOutput (file_write.go:13-53, processor.go:126-135,206-213): the
-        // image goes to a hidden ".processing-*.tmp.flac" beside the input and is renamed over the final name only when complete;
-        // on any failure the temp file is removed and the final name is never touched.
-        std::string dir(path);
-        const size_t sl = dir.find_last_of('/');
-        dir = sl == std::string::npos ? "" : dir.substr(0, sl + 1);
-        std::string tmpl = dir + ".processing-XXXXXX.tmp.flac";
-        std::vector<char> tmp(tmpl.begin(), tmpl.end()); tmp.push_back(0);
-        const int fd = g_fault_create_temp ? -1 : mkstemps(tmp.data(), 9);
-        if (fd < 0) return fail(JT_E_INVAL, std::string("failed to create temporary output next to ") + input_path);
-        bool okw = !g_fault_write;
-        size_t off = 0;
-        while (okw && off < (size_t)len) {
-            const ssize_t w = write(fd, data + off, std::min<size_t>((size_t)len - off, (size_t)1 << 30));
-            if (w < 0) { if (errno == EINTR) continue; okw = false; break; }
-            off += (size_t)w;
-        }
-        if (fchmod(fd, 0644) != 0) { /* keep mkstemp's 0600: not fatal */ }
-        if (close(fd) != 0) okw = false;
-        if (!okw) { unlink(tmp.data()); return fail(JT_E_INVAL, std::string("failed to write temporary output ") + tmp.data()); }
-        if (h->cancelled.load()) { unlink(tmp.data()); return fail(JT_E_CANCELLED, "cancelled"); }
-        if (g_fault_rename || rename(tmp.data(), path) != 0) { unlink(tmp.data()); return fail(JT_E_INVAL, std::string("failed to publish output to ") + path); }
+    tail->image = const_cast<uint8_t *>(data); tail->len = len;          // (the handle's own pinned arena)
+    tail->pcm = h->flac_deferred.pcm; tail->n_pcm = h->flac_deferred.n;
+    tail->input_path = input_path; tail->final_path = path;
+    return JT_OK;
+}
+// returns JT_OK or the code + message jt_process_file reports; ms[0] = the MD5, ms[1] = write + rename
+int file_tail(const FileTail &t, std::string *err, double ms[2])
+{
+    double t0 = wall_ms();
+    if (t.pcm) {
+        // STREAMINFO: "fLaC" + 4 header bytes + 18 bytes of block sizes / rate / length, then the 16-byte signature (RFC 9639 section 8.2)
+        uint8_t md5[16];
+        jt_md5(t.pcm, sizeof(int16_t) * t.n_pcm, md5);
+        memcpy(t.image + 26, md5, 16);
     }
-    if (io_ms) io_ms[3] = now() - t;
-    if (output_path && cap > 0) { strncpy(output_path, path, (size_t)cap - 1); output_path[cap - 1] = 0; }
+    if (ms) ms[0] = wall_ms() - t0;
+    t0 = wall_ms();
+    // createSiblingTempPath(inputPath, "processing") + publishOutput (file_write.go:13-53, processor.go:126-135,206-213): the
+    // image goes to a hidden ".processing-*.tmp.flac" beside the input and is renamed over the final name only when complete;
+    // on any failure the temp file is removed and the final name is never touched.
+    std::string dir(t.final_path);
+    const size_t sl = dir.find_last_of('/');
+    dir = sl == std::string::npos ? "" : dir.substr(0, sl + 1);
+    std::string tmpl = dir + ".processing-XXXXXX.tmp.flac";
+    std::vector<char> tmp(tmpl.begin(), tmpl.end()); tmp.push_back(0);
+    const int fd = g_fault_create_temp ? -1 : mkstemps(tmp.data(), 9);
+    if (fd < 0) { *err = std::string("failed to create temporary output next to ") + t.input_path; return JT_E_INVAL; }
+    bool okw = !g_fault_write;
+    size_t off = 0;
+    while (okw && off < (size_t)t.len) {
+        const ssize_t w = write(fd, t.image + off, std::min<size_t>((size_t)t.len - off, (size_t)1 << 30));
+        if (w < 0) { if (errno == EINTR) continue; okw = false; break; }
+        off += (size_t)w;
+    }
+    if (fchmod(fd, 0644) != 0) { /* keep mkstemp's 0600: not fatal */ }
+    if (close(fd) != 0) okw = false;
+    if (!okw) { unlink(tmp.data()); *err = std::string("failed to write temporary output ") + tmp.data(); return JT_E_INVAL; }
+    if (t.cancelled && t.cancelled->load()) { unlink(tmp.data()); *err = "cancelled"; return JT_E_CANCELLED; }
+    if (g_fault_rename || rename(tmp.data(), t.final_path.c_str()) != 0) { unlink(tmp.data()); *err = std::string("failed to publish output to ") + t.final_path; return JT_E_INVAL; }
+    if (ms) ms[1] = wall_ms() - t0;
+    return JT_OK;
+}
+} // namespace
+
+extern "C" int jt_process_file(jt_ctx *h, const char *input_path, const jt_host_config *base, int frame_samples, int flac_flags,
+                               jt_progress_fn cb, void *user, jt_process_result *out, char *output_path, int cap, double io_ms[4])
+{
+    if (!h || !input_path || !out) return JT_E_INVAL;
+    FileTail tail;
+    int rc = file_front(h, input_path, base, frame_samples, flac_flags, cb, user, out, &tail, io_ms);
+    if (rc != JT_OK) return rc;
+    tail.cancelled = &h->cancelled;
+    double ms[2] = {0, 0}; std::string err;
+    rc = file_tail(tail, &err, ms);
+    if (rc != JT_OK) { h->err = err; return rc; }
+    if (io_ms) { io_ms[2] += ms[0]; io_ms[3] = ms[1]; }       // (the signature counts as part of the encode, as before)
+    if (output_path && cap > 0) { strncpy(output_path, tail.final_path.c_str(), (size_t)cap - 1); output_path[cap - 1] = 0; }
     return JT_OK;
 }
 
@@ -1540,10 +1586,26 @@ extern "C" int jt_process_file(jt_ctx *h, const char *input_path, const jt_host_
 struct jt_handle_pool {
     std::vector<int> devices;
     int in_flight = 1;
+    int n_streams = 0, open_flags = 0;      // what the handles were opened with (a handle that fails is replaced by one of the same kind)
     struct Worker { jt_ctx *h; int device; };
     std::vector<Worker> workers;
     int open_rc = JT_OK, open_dev = -1;
     std::mutex busy;                        // one batch at a time
+    // finisher threads: the tails of finished files (STREAMINFO MD5, temp file, rename; file_tail) -- as many as there are handles
+    std::mutex fm; std::condition_variable fcv; std::deque<std::function<void()>> fq; bool fstop = false;
+    std::vector<std::thread> finishers;
+    // where the last batch's time went, summed over its files (ms): waiting for a free I/O set, read, decode, passes, encode on the
+    // handle's thread; waiting for a finisher, MD5, write + rename on a finisher thread
+    std::mutex sm; double stats[JT_POOL_STATS] = {0};
+    void add_stats(const double *v) { std::lock_guard<std::mutex> l(sm); for (int i = 0; i < JT_POOL_STATS; ++i) stats[i] += v[i]; }
+    void finisher_loop() {
+        for (;;) {
+            std::function<void()> job;
+            { std::unique_lock<std::mutex> l(fm); fcv.wait(l, [&] { return fstop || !fq.empty(); }); if (fq.empty()) return; job = std::move(fq.front()); fq.pop_front(); }
+            job();
+        }
+    }
+    void finish_async(std::function<void()> job) { { std::lock_guard<std::mutex> l(fm); fq.push_back(std::move(job)); } fcv.notify_one(); }
 };
 
 extern "C" int jt_handle_pool_open(const int *devices, int n_devices, int in_flight_per_device, int max_workers, jt_handle_pool **out)
@@ -1558,15 +1620,18 @@ extern "C" int jt_handle_pool_open(const int *devices, int n_devices, int in_fli
     std::atomic<int> spare{workers};                 // devices[workers..] have no worker of their own (fewer workers than devices)
     std::atomic<int> open_rc{JT_OK}, open_dev{-1};
     std::mutex m;
+    // three or more handles on a device: one stream each and sleeping host waits (jt_open_ex; include/jtgpu.h says why)
+    const bool shared = in_flight_per_device >= 3;
+    const int ns = shared ? jt_pool_streams().load() : 0, of = shared && jt_pool_blocking().load() ? JT_OPEN_BLOCKING_SYNC : 0;
     auto open_one = [&](int device) {
         jt_ctx *h = nullptr;
-        int orc = jt_open(device, &h);
+        int orc = jt_open_ex(device, ns, of, &h);
         while ((orc != JT_OK || !h) && workers < n_devices) {
             const int k = spare.fetch_add(1);
             if (k >= n_devices) break;
             int ok = JT_OK;
             if (open_rc.compare_exchange_strong(ok, orc != JT_OK ? orc : JT_E_NOGPU)) open_dev.store(device);
-            device = devices[k]; h = nullptr; orc = jt_open(device, &h);
+            device = devices[k]; h = nullptr; orc = jt_open_ex(device, ns, of, &h);
         }
         if (orc != JT_OK || !h) {
             int ok = JT_OK;
@@ -1581,7 +1646,8 @@ extern "C" int jt_handle_pool_open(const int *devices, int n_devices, int in_fli
     for (int w = 1; w < workers; ++w) th.emplace_back(open_one, devices[w % n_devices]);
     open_one(devices[0]);
     for (auto &t : th) t.join();
-    P->open_rc = open_rc.load(); P->open_dev = open_dev.load();
+    P->open_rc = open_rc.load(); P->open_dev = open_dev.load(); P->n_streams = ns; P->open_flags = of;
+    for (size_t i = 0; i < P->workers.size(); ++i) P->finishers.emplace_back([P] { P->finisher_loop(); });
     // (deterministic worker order: by device, so that a report of "which worker served what" reads the same run to run)
     std::stable_sort(P->workers.begin(), P->workers.end(), [](const jt_handle_pool::Worker &a, const jt_handle_pool::Worker &b) { return a.device < b.device; });
     *out = P;
@@ -1595,11 +1661,22 @@ extern "C" int jt_handle_pool_workers(const jt_handle_pool *P, int *devices_out,
     return (int)P->workers.size();
 }
 
+extern "C" int jt_handle_pool_stats(jt_handle_pool *P, double *out, int cap)
+{
+    if (!P || !out || cap < 0) return JT_E_INVAL;
+    std::lock_guard<std::mutex> l(P->sm);
+    for (int i = 0; i < JT_POOL_STATS && i < cap; ++i) out[i] = P->stats[i];
+    return JT_POOL_STATS;
+}
+
 extern "C" void jt_handle_pool_close(jt_handle_pool *P)
 {
     if (!P) return;
     {
         std::lock_guard<std::mutex> g(P->busy);          // a batch still running ends first; nobody may start one on a pool being closed
+        { std::lock_guard<std::mutex> l(P->fm); P->fstop = true; }
+        P->fcv.notify_all();
+        for (auto &t : P->finishers) t.join();
         std::vector<std::thread> th;
         for (auto &w : P->workers) th.emplace_back([h = w.h] { jt_close(h); });
         for (auto &t : th) t.join();
@@ -1613,6 +1690,7 @@ extern "C" int jt_handle_pool_process_files(jt_handle_pool *P, const char *const
 {
     if (!P || !paths || !results || n_files < 0) return JT_E_INVAL;
     std::lock_guard<std::mutex> busy(P->busy);
+    { std::lock_guard<std::mutex> l(P->sm); for (double &v : P->stats) v = 0; }
     for (int i = 0; i < n_files; ++i) { std::memset(&results[i], 0, sizeof results[i]); results[i].rc = JT_E_STATE; if (device_of_file) device_of_file[i] = -1; }
     if (n_files == 0) return 0;
     if (P->workers.empty()) {
@@ -1629,24 +1707,59 @@ extern "C" int jt_handle_pool_process_files(jt_handle_pool *P, const char *const
     for (int i = 0; i < n_files; ++i) { order[(size_t)i] = i; struct stat st; if (paths[i] && stat(paths[i], &st) == 0) size[(size_t)i] = (long long)st.st_size; }
     std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return size[(size_t)a] > size[(size_t)b]; });
     std::atomic<int> next{0}, failed{0};
-    auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
-    auto worker = [&](jt_ctx *h, int device) {
-        for (;;) {
+    // a handle that ends a file with anything but a verdict about that FILE (bad input, unsupported, silent, cancelled) is not
+    // trusted with another: it is closed and replaced, and a worker whose replacement cannot be opened stops taking files (a handle
+    // that fails in microseconds would otherwise claim most of the queue)
+    auto file_verdict = [](int rc) { return rc == JT_OK || rc == JT_E_CANCELLED || rc == JT_E_INVAL || rc == JT_E_UNSUPPORTED || rc == JT_E_SILENT; };
+    auto worker = [&](jt_handle_pool::Worker *W) {
+        // two I/O sets per handle: a file's tail runs on a finisher thread from set k while the handle fills set 1 - k
+        struct Gate { std::mutex m; std::condition_variable cv; bool busy = false;
+                      void wait_free() { std::unique_lock<std::mutex> l(m); cv.wait(l, [&] { return !busy; }); }
+                      void release() { { std::lock_guard<std::mutex> l(m); busy = false; } cv.notify_all(); } } gate[2];
+        int set = 0;
+        while (W->h) {
             const int q = next.fetch_add(1);
             if (q >= n_files) break;
             const int i = order[(size_t)q];
             jt_file_result &r = results[i];
-            if (device_of_file) device_of_file[i] = device;
-            const double t0 = now();
-            if (!paths[i]) { r.rc = JT_E_INVAL; snprintf(r.error, sizeof r.error, "null path"); }
-            else {
-                r.rc = jt_process_file(h, paths[i], base, frame_samples, flac_flags, nullptr, nullptr, &r.result, r.output_path,
-                                       (int)sizeof r.output_path, nullptr);
-                if (r.rc != JT_OK) snprintf(r.error, sizeof r.error, "%s", jt_last_error(h));
+            if (device_of_file) device_of_file[i] = W->device;
+            const double t0 = wall_ms();
+            if (!paths[i]) { r.rc = JT_E_INVAL; snprintf(r.error, sizeof r.error, "null path"); r.wall_ms = wall_ms() - t0; failed.fetch_add(1); continue; }
+            gate[set].wait_free();
+            double st[JT_POOL_STATS] = {0}, io[4] = {0, 0, 0, 0};
+            st[0] = wall_ms() - t0;
+            W->h->io_set = set;
+            auto tail = std::make_shared<FileTail>();
+            r.rc = file_front(W->h, paths[i], base, frame_samples, flac_flags, nullptr, nullptr, &r.result, tail.get(), io);
+            const double t_front = wall_ms();
+            st[1] = io[0]; st[2] = io[1]; st[4] = io[2]; st[3] = (t_front - t0) - st[0] - io[0] - io[1] - io[2]; st[8] = 1;
+            if (r.rc != JT_OK) {
+                snprintf(r.error, sizeof r.error, "%s", jt_last_error(W->h));
+                r.wall_ms = wall_ms() - t0; failed.fetch_add(1);
+                P->add_stats(st);
+                if (!file_verdict(r.rc)) {
+                    gate[0].wait_free(); gate[1].wait_free();          // (tails still read the old handle's pinned buffers)
+                    jt_close(W->h); W->h = nullptr;
+                    if (jt_open_ex(W->device, P->n_streams, P->open_flags, &W->h) != JT_OK) W->h = nullptr;
+                }
+                continue;
             }
-            r.wall_ms = now() - t0;
-            if (r.rc != JT_OK) failed.fetch_add(1);
+            { std::lock_guard<std::mutex> l(gate[set].m); gate[set].busy = true; }
+            Gate *g = &gate[set];
+            std::vector<double> stv(st, st + JT_POOL_STATS);
+            P->finish_async([tail, &r, &failed, g, t0, t_front, stv, P] {
+                std::string err; double ms[2] = {0, 0};
+                std::vector<double> sv(stv); sv[5] = wall_ms() - t_front;
+                r.rc = file_tail(*tail, &err, ms);
+                sv[6] = ms[0]; sv[7] = ms[1]; P->add_stats(sv.data());
+                if (r.rc != JT_OK) { snprintf(r.error, sizeof r.error, "%s", err.c_str()); failed.fetch_add(1); }
+                else { strncpy(r.output_path, tail->final_path.c_str(), sizeof r.output_path - 1); r.output_path[sizeof r.output_path - 1] = 0; }
+                r.wall_ms = wall_ms() - t0;
+                g->release();
+            });
+            set ^= 1;
         }
+        gate[0].wait_free(); gate[1].wait_free();
     };
     const size_t nw = std::min<size_t>(P->workers.size(), (size_t)n_files);
     // with fewer files than workers, take one worker per device before a second on any (the workers are sorted by device)
@@ -1661,9 +1774,12 @@ extern "C" int jt_handle_pool_process_files(jt_handle_pool *P, const char *const
         }
     } else for (size_t w = 0; w < nw; ++w) pick.push_back(w);
     std::vector<std::thread> th;
-    for (size_t k = 1; k < pick.size(); ++k) th.emplace_back(worker, P->workers[pick[k]].h, P->workers[pick[k]].device);
-    worker(P->workers[pick[0]].h, P->workers[pick[0]].device);
+    for (size_t k = 1; k < pick.size(); ++k) th.emplace_back(worker, &P->workers[pick[k]]);
+    worker(&P->workers[pick[0]]);
     for (auto &t : th) t.join();
+    // workers whose handle could not be replaced leave the pool; files nobody took (every worker gone) keep JT_E_STATE and count as failed
+    P->workers.erase(std::remove_if(P->workers.begin(), P->workers.end(), [](const jt_handle_pool::Worker &w) { return !w.h; }), P->workers.end());
+    for (int i = 0; i < n_files; ++i) if (results[i].rc == JT_E_STATE && !results[i].error[0]) { snprintf(results[i].error, sizeof results[i].error, "no worker left to take the file"); failed.fetch_add(1); }
     return failed.load();
 }
 

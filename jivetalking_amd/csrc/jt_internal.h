@@ -12,6 +12,8 @@
 #include <atomic>
 #include <mutex>
 #include <utility>
+#include <ctime>
+#include <sched.h>
 #include "../../include/jtgpu.h"
 #include "../../include/jt_host.h"
 
@@ -55,6 +57,10 @@ inline hipError_t DevGraveyard::host_malloc(void **p, size_t bytes)
 inline std::atomic<int> &jt_poison_alloc() { static std::atomic<int> v{0}; return v; }
 // host-stage timings on stderr from the handle-less host functions (set with any handle's host_timing option)
 inline std::atomic<int> &jt_host_timing() { static std::atomic<int> v{0}; return v; }
+// what jt_handle_pool_open asks of jt_open_ex when a device gets three or more handles: streams per handle (default 1) and whether
+// their host waits sleep (default yes); jt_set_option(NULL, "pool_streams" / "pool_blocking_sync", ..)
+inline std::atomic<int> &jt_pool_streams() { static std::atomic<int> v{1}; return v; }
+inline std::atomic<int> &jt_pool_blocking() { static std::atomic<int> v{1}; return v; }
 
 // Simple owning device buffer
 template <typename T> struct DevBuf {
@@ -266,7 +272,9 @@ void launch_flac_emit(const int16_t *pcm, int64_t n, int sr_code, int sr_extra_b
                       const long long *offs, uint8_t *out, void *summary, hipStream_t s);
 // fork-join over [0, n) on the process-wide worker pool (jt_plan.cpp); fn(lo, hi, part)
 void jt_parallel_for(int64_t n, const std::function<void(int64_t, int64_t, int)> &fn, int *nparts_out = nullptr);
-void jt_md5(const void *data, size_t len, uint8_t out[16]);      // RFC 1321 (jt_plan.cpp), STREAMINFO signature
+#define JT_FLAC_MD5_DEFER 0x200      /* internal flag of jt_flac_encode: the PCM is copied to pinned memory, the caller hashes it and patches STREAMINFO (bytes 26..41 of the image) */
+void jt_md5(const void *data, size_t len, uint8_t out[16]);
+int jt_flac_encode_file(jt_ctx *h, int stage, int flags, const uint8_t **data, int64_t *len, jt_flac_info *info);      // jt_io.cpp      // RFC 1321 (jt_plan.cpp), STREAMINFO signature
 
 // FLAC / WAV input leg (k_flacdec.hip); the structs mirror the kernels' layouts
 struct JtFlacStream { int channels = 0, bps = 0, sample_rate = 0, min_blocksize = 0, max_blocksize = 0; long long total_samples = 0, audio_offset = 0, len = 0; };
@@ -350,6 +358,8 @@ struct jt_ctx {
     int device = 0;
     JtOpts opts;
     hipStream_t stream = nullptr;
+    int n_streams = 8; std::vector<hipStream_t> owned_streams;      // jt_open_ex: which of the streams below are aliases
+    bool blocking = false; hipEvent_t ev_block = nullptr;          // JT_OPEN_BLOCKING_SYNC: host waits sleep instead of spinning (jt_stream_sync)
     // auxiliary streams: the independent parts of an analysis (astats chains, true peak + K-weighting, spectral) are forked
     // onto them and joined back into `stream` with events, so latency-bound kernels overlap instead of queueing
     hipStream_t aux[8] = {};                   // [0..3] the analysis chains of a pass, [4..7] the chains of announced output regions
@@ -439,7 +449,12 @@ struct jt_ctx {
     } early_p3;      // the wide-band solver's stream (created on first use)
     // FLAC output leg: frame records, byte offsets, summary, encoded frames; pinned host copies of the PCM (MD5) and the file
     DevBuf<unsigned char> fl_rec, fl_out; DevBuf<long long> fl_off; DevBuf<int16_t> fl_pcm;
-    HostArena pin_pcm, pin_flac;
+    // two sets: a handle pool hands a finished file's MD5 + write to a finisher thread and starts the next file in the other set
+    HostArena io_pcm[2], io_flac[2]; int io_set = 0;
+    HostArena io_small;                                           // the file legs' small device->host results (counts, summaries, frame candidates): pinned, so that the copies do not wait inside the runtime
+    HostArena &pin_pcm() { return io_pcm[io_set]; }
+    HostArena &pin_flac() { return io_flac[io_set]; }
+    struct FlacDeferred { const int16_t *pcm = nullptr; size_t n = 0; } flac_deferred;      // JT_FLAC_MD5_DEFER: what the caller still has to hash
     // input leg: file image, frame candidates / parse results / frame table, planar and interleaved integer PCM
     DevBuf<unsigned char> in_file, in_tab; DevBuf<int> in_planar, in_i32;
     std::vector<jt_interval> last_intervals;      // the 250 ms interval series of the last Pass-1 analysis (run record, sidecar)
@@ -453,6 +468,28 @@ struct jt_ctx {
 void jt_spec_pass2_cancel(jt_ctx *h);
 #define JT_API_BEGIN_KEEP(h) if (!(h)) return JT_E_INVAL; try { JT_HIP(hipSetDevice((h)->device));
 #define JT_API_BEGIN(h) JT_API_BEGIN_KEEP(h) jt_spec_pass2_cancel(h);
+// Host waits of a handle.  Every wait of the HIP runtime on this part spins on the completion signal for as long as it lasts --
+// hipStreamSynchronize, hipEventSynchronize (with or without hipEventBlockingSync), and copies into pageable memory alike
+// (tools/ubench/wait_cpu.hip: 40 ms of CPU for a 40 ms kernel) -- so a pool of handles burns a host core per handle.  A handle opened
+// with JT_OPEN_BLOCKING_SYNC polls instead: hipEventQuery, a few yields, then 50 us sleeps (a wait ends at most that much late; a
+// file has a dozen of them).
+inline hipError_t jt_event_wait(jt_ctx *h, hipEvent_t ev)
+{
+    if (!h->blocking) return hipEventSynchronize(ev);
+    for (int i = 0;; ++i) {
+        const hipError_t e = hipEventQuery(ev);
+        if (e != hipErrorNotReady) return e;
+        (void)hipGetLastError();                               // (hipErrorNotReady is sticky in the thread's last-error slot)
+        if (i < 4) sched_yield();
+        else { timespec ts{0, 50000}; nanosleep(&ts, nullptr); }
+    }
+}
+inline hipError_t jt_stream_sync(jt_ctx *h, hipStream_t s)
+{
+    if (!h->blocking) return hipStreamSynchronize(s);
+    const hipError_t e = hipEventRecord(h->ev_block, s);      // (one host thread drives a handle: one event is enough)
+    return e != hipSuccess ? e : jt_event_wait(h, h->ev_block);
+}
 // On failure the streams are drained before returning: a pass may have queued kernels and copies into the pinned arena, and the
 // next call is allowed to resize or reuse both.
 inline void jt_drain(jt_ctx *h)

@@ -33,47 +33,50 @@ void flac_encode_core(jt_ctx *h, const int16_t *d_pcm, int64_t n, int rate, int 
         else if (rate < 65536) { sr_code = 13; sr_bytes = 2; sr_val = rate; }
         else if (rate % 10 == 0 && rate / 10 < 65536) { sr_code = 14; sr_bytes = 2; sr_val = rate / 10; }
     }
-    const bool want_md5 = (flags & JT_FLAC_MD5) != 0;
+    const bool defer_md5 = (flags & JT_FLAC_MD5_DEFER) != 0, want_md5 = (flags & JT_FLAC_MD5) != 0 || defer_md5;
+    h->flac_deferred = {};
     h->fl_rec.ensure(jt_flac_rec_bytes(nframes));
     h->fl_off.ensure((size_t)nframes + 8);
     unsigned char *d_sum = h->fl_rec.p + (jt_flac_rec_bytes(nframes) - 256);
     // the PCM travels to the host on an auxiliary stream while the analysis runs (only the MD5 needs it)
     int16_t *h_pcm = nullptr;
     if (want_md5) {
-        h->pin_pcm.begin(sizeof(int16_t) * (size_t)n + 64);
-        h_pcm = h->pin_pcm.take<int16_t>((size_t)n);
+        h->pin_pcm().begin(sizeof(int16_t) * (size_t)n + 64);
+        h_pcm = h->pin_pcm().take<int16_t>((size_t)n);
         JT_HIP(hipEventRecord(h->ev_fork, h->stream));
         JT_HIP(hipStreamWaitEvent(h->aux[0], h->ev_fork, 0));
         JT_HIP(hipMemcpyAsync(h_pcm, d_pcm, sizeof(int16_t) * (size_t)n, hipMemcpyDeviceToHost, h->aux[0]));
     }
     JT_HIP(hipEventRecord(h->ev0, h->stream));
     launch_flac_analyse(d_pcm, n, sr_code, sr_bytes, sr_val, h->fl_rec.p, h->fl_off.p, d_sum, h->stream);
-    FlacSummary sum{};
+    h->io_small.begin(4096);
+    FlacSummary &sum = *h->io_small.take<FlacSummary>(1), &sum2 = *h->io_small.take<FlacSummary>(1);
+    sum = FlacSummary{}; sum2 = FlacSummary{};
     JT_HIP(hipMemcpyAsync(&sum, d_sum, sizeof sum, hipMemcpyDeviceToHost, h->stream));
-    JT_HIP(hipStreamSynchronize(h->stream));
+    JT_HIP(jt_stream_sync(h, h->stream));
     JT_REQUIRE(sum.total > 0, JT_E_HIP, "flac: analysis produced no frames");
 
     static const char vendor[] = "jivetalking-amd jtgpu 0.1";
     const int vlen = (int)sizeof(vendor) - 1;
     const int header_bytes = 4 + 4 + 34 + 4 + 4 + vlen + 4;
     h->fl_out.ensure((size_t)sum.total + 64);
-    h->pin_flac.begin((size_t)header_bytes + (size_t)sum.total + 64);
-    uint8_t *file = h->pin_flac.take<uint8_t>((size_t)header_bytes + (size_t)sum.total);
+    h->pin_flac().begin((size_t)header_bytes + (size_t)sum.total + 64);
+    uint8_t *file = h->pin_flac().take<uint8_t>((size_t)header_bytes + (size_t)sum.total);
     launch_flac_emit(d_pcm, n, sr_code, sr_bytes, sr_val, h->fl_rec.p, h->fl_off.p, h->fl_out.p, d_sum, h->stream);
     JT_HIP(hipEventRecord(h->ev1, h->stream));
     JT_HIP(hipMemcpyAsync(file + header_bytes, h->fl_out.p, (size_t)sum.total, hipMemcpyDeviceToHost, h->stream));
-    FlacSummary sum2{};
     JT_HIP(hipMemcpyAsync(&sum2, d_sum, sizeof sum2, hipMemcpyDeviceToHost, h->stream));
 
     uint8_t md5[16] = {0};
     double md5_ms = 0.0;
     if (want_md5) {
-        JT_HIP(hipStreamSynchronize(h->aux[0]));
+        JT_HIP(jt_stream_sync(h, h->aux[0]));
         const double m0 = flac_now_ms();
-        jt_md5(h_pcm, sizeof(int16_t) * (size_t)n, md5);
+        if (defer_md5) { h->flac_deferred.pcm = h_pcm; h->flac_deferred.n = (size_t)n; }
+        else jt_md5(h_pcm, sizeof(int16_t) * (size_t)n, md5);
         md5_ms = flac_now_ms() - m0;
     }
-    JT_HIP(hipStreamSynchronize(h->stream));
+    JT_HIP(jt_stream_sync(h, h->stream));
     JT_REQUIRE(sum2.mismatches == 0, JT_E_HIP, "flac: emitted size differs from the analysed size");
     float gpu_ms = 0.f;
     JT_HIP(hipEventElapsedTime(&gpu_ms, h->ev0, h->ev1));
@@ -101,14 +104,25 @@ void flac_encode_core(jt_ctx *h, const int16_t *d_pcm, int64_t n, int rate, int 
 }
 } // namespace
 
-extern "C" int jt_flac_encode(jt_ctx *h, int stage, int flags, const uint8_t **data, int64_t *len, jt_flac_info *info)
+static void flac_encode_stage(jt_ctx *h, int stage, int flags, const uint8_t **data, int64_t *len, jt_flac_info *info)
 {
-    JT_API_BEGIN(h)
     JT_REQUIRE(data && len, JT_E_INVAL, "flac: null output arguments");
     const int16_t *src = stage == 2 ? h->s16_p2.p : (stage == 4 ? h->s16_p4.p : nullptr);
     const int64_t m = stage == 2 ? h->m_p2 : (stage == 4 ? h->m_p4 : 0);
     JT_REQUIRE(src && m > 0, JT_E_STATE, "flac: stage output not on device");
     flac_encode_core(h, src, m, h->out_rate, flags, data, len, info);
+}
+extern "C" int jt_flac_encode(jt_ctx *h, int stage, int flags, const uint8_t **data, int64_t *len, jt_flac_info *info)
+{
+    JT_API_BEGIN(h)
+    flac_encode_stage(h, stage, flags & JT_FLAC_MD5, data, len, info);
+    JT_API_END(h)
+}
+// jt_process_file's encoder call: with JT_FLAC_MD5_DEFER the signature is left zero and h->flac_deferred names the pinned PCM to hash
+int jt_flac_encode_file(jt_ctx *h, int stage, int flags, const uint8_t **data, int64_t *len, jt_flac_info *info)
+{
+    JT_API_BEGIN(h)
+    flac_encode_stage(h, stage, flags & (JT_FLAC_MD5 | JT_FLAC_MD5_DEFER), data, len, info);
     JT_API_END(h)
 }
 
@@ -171,9 +185,14 @@ void decode_flac(jt_ctx *h, const uint8_t *file, int64_t len, int64_t start, boo
     // candidates: expected frame count plus room for look-alikes
     const int64_t expect = st.total_samples > 0 ? st.total_samples / std::max(16, st.min_blocksize) + 2 : (len - pos) / 16 + 2;
     int cap = (int)std::min<int64_t>((int64_t)1 << 28, expect * 2 + (len - pos) / 2048 + 4096);
-    std::vector<JtFlacCand> cands; std::vector<JtFlacParsed> parsed;
+    // (device -> host results land in the handle's small pinned arena: a copy into pageable memory waits inside the runtime, spinning)
+    JtFlacCand *cands = nullptr; JtFlacParsed *parsed = nullptr;
+    int *counts = nullptr;                                    // [0] candidates found, [1] subframe decode errors
     int ncand = 0;
     for (int attempt = 0; attempt < 2; attempt++) {
+        h->io_small.begin(4096 + (sizeof(JtFlacCand) + sizeof(JtFlacParsed)) * (size_t)cap + 256);      // (nothing of the arena is in flight here)
+        counts = h->io_small.take<int>(16); counts[0] = counts[1] = 0;
+        cands = h->io_small.take<JtFlacCand>((size_t)cap); parsed = h->io_small.take<JtFlacParsed>((size_t)cap);
         const size_t tab_bytes = 256 + sizeof(JtFlacCand) * (size_t)cap + sizeof(JtFlacParsed) * (size_t)cap;
         h->in_tab.ensure(tab_bytes);
         int *d_count = reinterpret_cast<int *>(h->in_tab.p);
@@ -181,15 +200,15 @@ void decode_flac(jt_ctx *h, const uint8_t *file, int64_t len, int64_t start, boo
         JtFlacParsed *d_parsed = reinterpret_cast<JtFlacParsed *>(h->in_tab.p + 256 + sizeof(JtFlacCand) * (size_t)cap);
         JT_HIP(hipMemsetAsync(d_count, 0, 256, h->stream));
         launch_flacdec_find(h->in_file.p, st, d_cand, d_count, cap, h->stream);
-        JT_HIP(hipMemcpyAsync(&ncand, d_count, sizeof(int), hipMemcpyDeviceToHost, h->stream));
-        JT_HIP(hipStreamSynchronize(h->stream));
+        JT_HIP(hipMemcpyAsync(&counts[0], d_count, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+        JT_HIP(jt_stream_sync(h, h->stream));
+        ncand = counts[0];
         if (ncand > cap) { cap = ncand + 1024; continue; }
         JT_REQUIRE(ncand > 0, JT_E_INVAL, "flac: no frame headers found");
         launch_flacdec_parse(h->in_file.p, st, d_cand, ncand, d_parsed, h->stream);
-        cands.resize((size_t)ncand); parsed.resize((size_t)ncand);
-        JT_HIP(hipMemcpyAsync(cands.data(), d_cand, sizeof(JtFlacCand) * (size_t)ncand, hipMemcpyDeviceToHost, h->stream));
-        JT_HIP(hipMemcpyAsync(parsed.data(), d_parsed, sizeof(JtFlacParsed) * (size_t)ncand, hipMemcpyDeviceToHost, h->stream));
-        JT_HIP(hipStreamSynchronize(h->stream));
+        JT_HIP(hipMemcpyAsync(cands, d_cand, sizeof(JtFlacCand) * (size_t)ncand, hipMemcpyDeviceToHost, h->stream));
+        JT_HIP(hipMemcpyAsync(parsed, d_parsed, sizeof(JtFlacParsed) * (size_t)ncand, hipMemcpyDeviceToHost, h->stream));
+        JT_HIP(jt_stream_sync(h, h->stream));
         break;
     }
     JT_REQUIRE(ncand <= cap, JT_E_HIP, "flac: candidate table overflow");
@@ -230,9 +249,9 @@ void decode_flac(jt_ctx *h, const uint8_t *file, int64_t len, int64_t start, boo
     JT_HIP(hipMemcpyAsync(d_frames, frames.data(), ftab, hipMemcpyHostToDevice, h->stream));
     launch_flacdec_decode(h->in_file.p, st, d_frames, (long long)frames.size(), total, h->in_planar.p, d_err,
                           want_i32 ? h->in_i32.p : nullptr, want_f32 ? h->in_owned.p : nullptr, h->stream);
-    int nerr = 0;
-    JT_HIP(hipMemcpyAsync(&nerr, d_err, sizeof(int), hipMemcpyDeviceToHost, h->stream));
-    JT_HIP(hipStreamSynchronize(h->stream));
+    JT_HIP(hipMemcpyAsync(&counts[1], d_err, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    JT_HIP(jt_stream_sync(h, h->stream));
+    const int nerr = counts[1];
     JT_REQUIRE(nerr == 0, JT_E_INVAL, "flac: subframe decode error");
     out->frames = total; out->channels = st.channels; out->rate = st.sample_rate; out->bits = st.bps; out->is_float = 0; out->format = 1;
     out->flac_frames = (int64_t)frames.size(); out->cands = ncand;
@@ -276,7 +295,7 @@ void decode_wav(jt_ctx *h, const uint8_t *file, int64_t len, bool want_i32, bool
     if (want_i32) h->in_i32.ensure(nvals);
     if (want_f32) h->in_owned.ensure(nvals);
     launch_pcm_convert(h->in_file.p, (long long)nvals, fmt, want_f32 ? h->in_owned.p : nullptr, want_i32 ? h->in_i32.p : nullptr, h->stream);
-    JT_HIP(hipStreamSynchronize(h->stream));
+    JT_HIP(jt_stream_sync(h, h->stream));
     out->frames = frames; out->channels = ch; out->rate = rate; out->bits = bits; out->is_float = tag == 3; out->format = 2;
 }
 
@@ -295,7 +314,7 @@ void decode_audio(jt_ctx *h, const uint8_t *file, int64_t len, bool want_i32, bo
     else if (!memcmp(file, "RIFF", 4)) decode_wav(h, file, len, want_i32, want_f32, out);
     else throw JtError{JT_E_UNSUPPORTED, "audio: only FLAC and RIFF/WAVE inputs are decoded on the device"};
     JT_HIP(hipEventRecord(h->ev1, h->stream));
-    JT_HIP(hipStreamSynchronize(h->stream));
+    JT_HIP(jt_stream_sync(h, h->stream));
     float gpu_ms = 0.f;
     JT_HIP(hipEventElapsedTime(&gpu_ms, h->ev0, h->ev1));
     if (meta) {
@@ -317,7 +336,7 @@ extern "C" int jt_load_audio(jt_ctx *h, const uint8_t *file, int64_t len, jt_aud
     h->in_raw = h->in_owned.p;
     h->src_fmt = d.is_float ? 0 : (d.bits <= 16 ? 1 : 2);       // what libavcodec would hand to abuffer: flt/dbl, (u8/)s16, s32
     jt_set_input_common(h, d.frames, d.rate, d.channels);
-    JT_HIP(hipStreamSynchronize(h->stream));
+    JT_HIP(jt_stream_sync(h, h->stream));
     JT_API_END(h)
 }
 
@@ -333,7 +352,7 @@ extern "C" int jt_op_decode_audio(jt_ctx *h, const uint8_t *file, int64_t len, i
     if (pcm_i32 || pcm_f32) JT_REQUIRE(cap_values >= nvals, JT_E_INVAL, "decode: output buffer too small");
     if (pcm_i32) JT_HIP(hipMemcpyAsync(pcm_i32, h->in_i32.p, sizeof(int32_t) * (size_t)nvals, hipMemcpyDeviceToHost, h->stream));
     if (pcm_f32) JT_HIP(hipMemcpyAsync(pcm_f32, h->in_owned.p, sizeof(float) * (size_t)nvals, hipMemcpyDeviceToHost, h->stream));
-    JT_HIP(hipStreamSynchronize(h->stream));
+    JT_HIP(jt_stream_sync(h, h->stream));
     JT_API_END(h)
 }
 

@@ -1689,8 +1689,8 @@ void launch_adeclick(jt_ctx *h, const double *in, double *out, int64_t n, int sa
                 // on a stream of its own
                 if (!h->dk_stream) {
                     JT_HIP(hipStreamCreateWithFlags(&h->dk_stream, hipStreamNonBlocking));
-                    JT_HIP(hipEventCreateWithFlags(&h->dk_ev[0], hipEventDisableTiming));
-                    JT_HIP(hipEventCreateWithFlags(&h->dk_ev[1], hipEventDisableTiming));
+                    JT_HIP(hipEventCreateWithFlags(&h->dk_ev[0], hipEventDisableTiming | (h->blocking ? hipEventBlockingSync : 0u)));
+                    JT_HIP(hipEventCreateWithFlags(&h->dk_ev[1], hipEventDisableTiming | (h->blocking ? hipEventBlockingSync : 0u)));
                 }
                 if (JT_AB_ON(O.dk_serial)) {
                     hipLaunchKernelGGL(k64, dim3((unsigned)g64), dim3(64), sm64, s, out, n, P, SP, h->declick_scr.p + slot32 * 2 * (size_t)g32, slot64, d_stats);

@@ -46,7 +46,7 @@ def _flac_info(info):
 
 
 class Engine:
-    def __init__(self, device=0, ab=None, **options):
+    def __init__(self, device=0, ab=None, streams=0, blocking_sync=False, **options):
         """ab=True: the A/B build of the library (superseded kernel generations, tuning knobs; it also imports JT_<KEY> variables at
         jt_open, which is how tools/ switch kernels: JT_USE_AB_LIB=1 JT_NLM_OLD=1 python tools/...).  options: jt_set_option pairs."""
         if ab is None:
@@ -55,7 +55,7 @@ class Engine:
         self.lib = L.load(ab)
         self.ab = bool(ab)
         self.h = C.c_void_p()
-        rc = self.lib.jt_open(C.c_int(device), C.byref(self.h))
+        rc = self.lib.jt_open_ex(C.c_int(device), C.c_int(int(streams)), C.c_int(1 if blocking_sync else 0), C.byref(self.h))      # (0, 0) = jt_open
         if rc != 0:
             raise L.JtError(rc, "jt_open failed (no MI355X visible?)")
         self._keep = None

@@ -1,0 +1,123 @@
+"""Round-5 behaviours.  A handle that shares its GPU (jt_open_ex: one or two HIP streams instead of eight, sleeping host waits) gives
+the bytes the default handle gives; a handle pool's finisher threads (STREAMINFO MD5 + temp file + rename off the handle's thread,
+two I/O sets per handle) give the files the one-at-a-time path gives, with the reference's no-residue discipline
+(file_write.go:13-53, processor_test.go:552-627) intact; configuration errors the C side used to accept silently are refused."""
+import os
+
+import numpy as np
+import pytest
+
+from jivetalking_amd import synth, hostlogic as H, _lib as L
+from jivetalking_amd.engine import Engine
+
+pytestmark = pytest.mark.gpu
+SR = 48000
+
+
+def _talker(seconds, seed, bursts):
+    x = np.asarray(synth.speech_like(seconds, SR, seed=seed), np.float64).copy()
+    if bursts:
+        w = int(0.02 * SR)
+        b = 0.35 * np.hanning(w) * np.sin(2 * np.pi * 180.0 * np.arange(w) / SR)
+        for pos in range(SR, x.size - SR, int(1.5 * SR)):
+            x[pos:pos + w] += b
+    return x.astype(np.float32)
+
+
+def _flacs(engine, d, count, seconds):
+    paths = []
+    for k in range(count):
+        pcm = np.clip(np.rint(_talker(seconds + 3.0 * k, 700 + k, k % 2).astype(np.float64) * 32768), -32768, 32767).astype(np.int16)
+        p = os.path.join(str(d), f"r5_{k}.flac")
+        with open(p, "wb") as f:
+            f.write(engine.op_flac_encode(pcm, SR, md5=True))
+        paths.append(p)
+    return paths
+
+
+@pytest.mark.parametrize("streams,blocking", [(1, False), (1, True), (2, True)])
+def test_few_streams_and_sleeping_waits_give_the_default_handles_bytes(engine, streams, blocking):
+    """jt_open_ex(n_streams, JT_OPEN_BLOCKING_SYNC) changes where kernels queue and how the host waits, nothing else: both limiter
+    plans, every measurement of the result and both stage outputs are equal to the eight-stream handle's."""
+    with Engine(0, streams=streams, blocking_sync=blocking) as e:
+        for bursts in (0, 1):
+            x = _talker(50.0, 41 + bursts, bursts)
+            engine.upload_pcm(x, SR, 1); want = H.process_audio(engine)
+            w2, w4 = engine.download_s16(2), engine.download_s16(4)
+            e.upload_pcm(x, SR, 1); got = H.process_audio(e)
+            assert int(want.limiter.needed) == bursts
+            assert np.array_equal(e.download_s16(2), w2) and np.array_equal(e.download_s16(4), w4)
+            for f in ("input_lufs", "output_lufs", "output_tp_db", "effective_target_i", "offset"):
+                assert getattr(got, f) == getattr(want, f), f
+            assert bytes(got.pass2_spec) == bytes(want.pass2_spec) and bytes(got.pass4_spec) == bytes(want.pass4_spec)
+            assert e.flac_encode(4) == engine.flac_encode(4)
+
+
+@pytest.mark.parametrize("md5", [True, False])
+def test_pool_finishers_write_the_files_the_calling_thread_writes(engine, oracle, tmp_path, md5):
+    """Seven files of different lengths through a pool of three handles (one stream each, finisher threads, two I/O sets per handle:
+    a handle's third file reuses the first one's pinned buffers) against jt_process_file one at a time: byte-identical files, and the
+    STREAMINFO signature in each is the MD5 of the PCM the oracle's RFC 9639 decoder reads back (all zero when it was not asked for)."""
+    paths = _flacs(engine, tmp_path, 7, 20.0)
+    want = []
+    for p in paths:
+        res, out_path, _ = H.process_file(engine, p, md5=md5)
+        want.append((res.output_lufs, open(out_path, "rb").read()))
+        os.unlink(out_path)
+    with H.Pool(devices=(0,), in_flight_per_device=3) as pool:
+        for batch in range(2):
+            failed, res, dev = pool.process_files(paths, md5=md5)
+            assert failed == 0
+            for k in range(7):
+                img = open(res[k].output_path.decode(), "rb").read()
+                assert res[k].rc == 0 and res[k].result.output_lufs == want[k][0] and img == want[k][1], (batch, k)
+                rc, dec, info = oracle.flac_decode(img)
+                assert rc == 0
+                if md5:
+                    assert bytes(info.md5_stored) == bytes(info.md5_decoded) != bytes(16)
+                else:
+                    assert bytes(info.md5_stored) == bytes(16)
+                os.unlink(res[k].output_path.decode())
+    assert not [q for q in os.listdir(str(tmp_path)) if q.startswith(".processing-")]
+
+
+def test_pool_tail_failures_leave_no_residue_and_the_pool_stays_usable(engine, tmp_path):
+    """The three failures the reference injects (temp creation, temp write, publish) now happen on a finisher thread: every file of
+    the batch reports its own error, nothing is left beside the inputs, and the next batch on the same pool succeeds."""
+    paths = _flacs(engine, tmp_path, 4, 12.0)
+    before = sorted(os.listdir(str(tmp_path)))
+    with H.Pool(devices=(0,), in_flight_per_device=3) as pool:
+        for fault, text in ((dict(create_temp=1), b"failed to create temporary output"), (dict(write=1), b"failed to write temporary output"),
+                            (dict(rename=1), b"failed to publish output")):
+            H.inject_fault(**fault)
+            try:
+                failed, res, _ = pool.process_files(paths)
+            finally:
+                H.inject_fault()
+            assert failed == 4 and all(res[k].rc == L.JT_E_INVAL and text in res[k].error for k in range(4)), fault
+            assert sorted(os.listdir(str(tmp_path))) == before, fault
+        failed, res, _ = pool.process_files(paths)
+        assert failed == 0 and len(pool.workers()) == 3
+        for k in range(4):
+            os.unlink(res[k].output_path.decode())
+
+
+def test_an_adeclick_method_code_outside_the_table_is_refused(engine):
+    """AdeclickConfig.Method codes are 0..4; 5 or -1 used to print no m= option and run overlap-add silently."""
+    x = _talker(20.0, 5, 0)
+    engine.upload_pcm(x, SR, 1)
+    for bad in (5, -1):
+        cfg = H.default_config(); cfg.adeclick_method_s = bad
+        with pytest.raises(L.JtError) as ei:
+            H.process_audio(engine, cfg)
+        assert ei.value.code == L.JT_E_INVAL
+    cfg = H.default_config(); cfg.adeclick_enabled = 0; cfg.adeclick_method_s = 9      # (not consulted when the filter is off)
+    H.process_audio(engine, cfg)
+
+
+def test_analysis_refuses_rates_its_scratch_is_not_sized_for(engine):
+    """the K-weighting / true-peak slabs assume 100 ms blocks of at least 800 samples."""
+    x = _talker(5.0, 6, 0)
+    with pytest.raises(L.JtError) as ei:
+        engine.op_ebur128(x, 4000, True)
+    assert ei.value.code == L.JT_E_UNSUPPORTED

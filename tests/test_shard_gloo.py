@@ -5,6 +5,8 @@ import subprocess
 import sys
 import textwrap
 
+import pytest
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 WORKER = textwrap.dedent('''
@@ -91,6 +93,9 @@ def test_bench_spawns_its_own_ranks():
         assert r["wall_s"] >= max(r["per_device_wall_s"]) - 2e-3 and r["per_device_wall_s"][1] > r["per_device_wall_s"][0]      # (rank 1's files sleep longer)
         assert abs(r["files_per_s"] - sat["files"] / r["wall_s"]) / r["files_per_s"] < 0.02
         assert r["pipeline_hbm"]["peak_GBps"] == 16000 and 0 < r["pipeline_hbm"]["frac"]
+        # all three runs reported, host accounting in the line (VERDICT r4 next #1c)
+        assert len(r["wall_s_runs"]) == 3 and r["wall_s"] == min(r["wall_s_runs"]) and r["wall_s_is"] == "best of 3" and r["wall_s_median"] >= r["wall_s"]
+        assert r["host"]["host_cores"] >= 1 and r["host"]["cpu_s_per_file"] >= 0 and r["host"]["cores_needed_at_8_gpus"] == pytest.approx(r["host"]["cores_busy"] * 4, abs=0.11)
         assert r["output_lufs_range"] == [-16.01, -16.0]                                                                       # MIN / MAX over ranks
 
 
