@@ -135,6 +135,8 @@ def load(ab=False):
     if key in _LIBS:
         return _LIBS[key]
     path = LIB_PATH_AB if ab else LIB_PATH
+    if not ab and os.environ.get("JT_LIB_PATH"):          # (tools/: A/B of two builds of the library inside one gpurun call)
+        path = os.environ["JT_LIB_PATH"]
     if not os.path.exists(path):
         raise ImportError(f"{path} not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
                           "(hipcc --offload-arch=gfx950). There is no CPU fallback for the product path.")

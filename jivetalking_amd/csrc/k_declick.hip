@@ -1289,16 +1289,19 @@ __device__ __forceinline__ void dk_round_reads(unsigned cva, unsigned lva, doubl
 {
     ((cvb[U] = dk_lds_rd<(B0 + U) * 8>(cva), lvb[U] = dk_lds_rd<(B0 + U) * 8>(lva)), ...);
 }
-template <int N> __device__ __forceinline__ void dk_lds_wait(double *a, double *b)
+// wait until at most CNT younger LDS operations are outstanding (LDS operations of a wave return in order): the N + N reads of the
+// round that is about to be used are complete, the next round's (CNT of them, already issued) may still be in flight
+template <int N, int CNT> __device__ __forceinline__ void dk_lds_wait(double *a, double *b)
 {
+    static_assert(CNT >= 0 && CNT <= 15, "lgkmcnt is four bits");
     if constexpr (N == 4)
-        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]));
+        asm volatile("s_waitcnt lgkmcnt(%8)" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]) : "n"(CNT));
     else if constexpr (N == 3)
-        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(b[0]), "+v"(b[1]), "+v"(b[2]));
+        asm volatile("s_waitcnt lgkmcnt(%6)" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(b[0]), "+v"(b[1]), "+v"(b[2]) : "n"(CNT));
     else if constexpr (N == 2)
-        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a[0]), "+v"(a[1]), "+v"(b[0]), "+v"(b[1]));
+        asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(a[0]), "+v"(a[1]), "+v"(b[0]), "+v"(b[1]) : "n"(CNT));
     else
-        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a[0]), "+v"(b[0]));
+        asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(a[0]), "+v"(b[0]) : "n"(CNT));
 }
 __device__ __forceinline__ unsigned dk_lds_addr(const void *p)
 {
@@ -1333,7 +1336,14 @@ k_dk_solve(double *__restrict__ out, int64_t n, DeclickParams P, DkSplit S, doub
     unsigned short *idx = reinterpret_cast<unsigned short *>(stg + 2 * G);  // [IDXN]
     unsigned char *bwv = reinterpret_cast<unsigned char *>(idx + IDXN);     // [BWN]
     CV[G + gl] = 0.0; LV[G + gl] = 0.0;
-    const unsigned cva = dk_lds_addr(CV), lva = dk_lds_addr(LV + gl);
+    // per-column base registers of the trailing update's LDS reads (see the pivot's rounds): opaque to the optimiser
+    typedef const __attribute__((address_space(3))) double *dk_ldsp;
+    dk_ldsp cvp[DK_BCH], lvp[DK_BCH];
+#pragma unroll
+    for (int u = 0; u < DK_BCH; ++u) {
+        cvp[u] = (dk_ldsp)(CV + 1 + u); lvp[u] = (dk_ldsp)(LV + gl + 1 + u);
+        asm volatile("" : "+v"(cvp[u]), "+v"(lvp[u]));
+    }
     double *gL = scratch + ((size_t)blockIdx.x * NW + q) * scratch_per_slot;
     const int *list = G == 32 ? S.list32 : S.list64;
     const int64_t nwork = (int64_t)S.ctl[G == 32 ? 0 : 1];
@@ -1414,25 +1424,50 @@ k_dk_solve(double *__restrict__ out, int64_t n, DeclickParams P, DkSplit S, doub
                 const int i0 = idx[k + BW + 1], i1 = idx[k + BW + 1 + gl];
                 const double ynew = yv[k + BW + 1];
                 const double yk = CV[0];
-                const int bmax = TWO ? max(__builtin_amdgcn_readlane(bwk, 0), __builtin_amdgcn_readlane(bwk, 32)) : __builtin_amdgcn_readlane(bwk, 0);
                 const int dlt = i1 - i0;
                 const double ent = aux[dlt < AR + 1 ? dlt : AR + 1];
-                // trailing update, DK_BCH columns per round, wave-uniform exit behind the widest band of the windows in the wave
+                // trailing update, DK_BCH columns per round, wave-uniform exit behind the widest band of the windows in the wave.
+                // SOFTWARE-PIPELINED (round 5): a round's 2 x DK_BCH LDS reads are issued one round AHEAD of its FMAs, into the other of
+                // two register buffers, and the wait before a round's FMAs leaves the next round's reads in flight (lgkmcnt counts the
+                // younger operations; LDS returns in order).  Issued and awaited back to back, every round exposed a full LDS round trip
+                // (~100 cycles) in front of 32 cycles of FMAs, seven times per pivot, with three waves per SIMD to cover it (round 4's
+                // counters: 32 % active, 57 % waiting).  Same operands, same FMAs, same order: bit-identical.
+                // The reads are ordinary LDS loads (the compiler's own s_waitcnt pass then knows what is in flight: an asm read whose
+                // result is awaited a round later is invisible to it, and a register move or spill of the still-empty result register
+                // silently reads garbage).  What the asm reads of round 4 were for -- keeping neighbouring 8-byte reads from being merged
+                // into ds_read2_b64, 8 LDS cycles instead of 2 + 2 -- is done by giving every column of a round its own, opaque base
+                // register (cvp[u], lvp[u]: set once per wave): reads from different base registers are never merged.
+                // sched_barrier keeps the issue order: next round's reads, this round's FMAs.
+                const int bmax = TWO ? max(__builtin_amdgcn_readlane(bwk, 0), __builtin_amdgcn_readlane(bwk, 32)) : __builtin_amdgcn_readlane(bwk, 0);
+                double cvb[2][DK_BCH], lvb[2][DK_BCH];
+                if (1 <= bmax) {
+#pragma unroll
+                    for (int u = 0; u < DK_BCH; ++u) if (1 + u <= BW) { cvb[0][u] = cvp[u][0]; lvb[0][u] = lvp[u][0]; }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
                 auto round = [&](auto bc) -> bool {
-                    constexpr int b0 = 1 + DK_BCH * decltype(bc)::value;
+                    constexpr int R = decltype(bc)::value;
+                    constexpr int b0 = 1 + DK_BCH * R;
                     if (b0 > bmax) return false;
-                    constexpr int NB = b0 + DK_BCH - 1 <= BW ? DK_BCH : BW - b0 + 1;
-                    double cvb[DK_BCH], lvb[DK_BCH];
-                    dk_round_reads<b0>(cva, lva, cvb, lvb, std::make_integer_sequence<int, NB>{});
-                    dk_lds_wait<NB>(cvb, lvb);
+                    constexpr int b0n = b0 + DK_BCH;
+                    bool next = false;
+                    if constexpr (b0n <= BW) {
+                        next = b0n <= bmax;
+                        if (next) {
+#pragma unroll
+                            for (int u = 0; u < DK_BCH; ++u) if (b0n + u <= BW) { cvb[(R + 1) & 1][u] = cvp[u][DK_BCH * (R + 1)]; lvb[(R + 1) & 1][u] = lvp[u][DK_BCH * (R + 1)]; }
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+                    }
 #pragma unroll
                     for (int u = 0; u < DK_BCH; ++u) if (b0 + u <= BW) {
-                        c[p + b0 + u] = __fma_rn(-cvb[u], lvb[u], c[p + b0 + u]);
+                        c[p + b0 + u] = __fma_rn(-cvb[R & 1][u], lvb[R & 1][u], c[p + b0 + u]);
                         // pin the result here: the optimiser otherwise sinks every round's FMAs below the reads of all later rounds
                         // (their results are only used after the last round) and spills the operands it then holds for them
                         asm volatile("" : "+v"(c[p + b0 + u]));
                     }
-                    return true;
+                    __builtin_amdgcn_sched_barrier(0);
+                    return next;
                 };
                 dk_all_rounds(round, std::make_integer_sequence<int, (BW + DK_BCH - 1) / DK_BCH>{});
                 // 1 / d of the next pivot: entry (k + 1, k + 1) is lane 0's c[p + 1]

@@ -20,7 +20,8 @@ if os.environ.get("JT_PROBE_LIKE_BENCH"):
         e.attach_device_pcm(x.data_ptr(), x.numel(), sr, 1, keepalive=x); hostlogic.process_audio(e, base, 4096)
     torch.cuda.synchronize()
 else:
-    engs = [Engine(0) for _ in range(K)]
+    S = int(os.environ.get("JT_PROBE_STREAMS", "0"))
+    engs = [Engine(0, streams=S, blocking_sync=bool(S)) for _ in range(K)]
     for e in engs:
         e.attach_device_pcm(x.data_ptr(), x.numel(), sr, 1, keepalive=x); hostlogic.process_audio(e, base, 4096)
 names = ["pass1", "vad", "bands", "adapt", "pass2", "regions2", "plan", "pass3", "pass4", "regions4"]
