@@ -190,7 +190,7 @@ def variant_leg(eng, y, x_dev, n, sr, seconds, base, hostlogic, what):
             "output_lufs": round(r.output_lufs, 2), "output_dbtp": round(r.output_tp_db, 2)}
 
 
-def saturation_leg(rank, world, device, files_per_gpu, minutes, in_flight, sr, make_files, run_batch, sync, dist_device, api):
+def saturation_leg(rank, world, device, files_per_gpu, minutes, in_flight, sr, make_files, run_batch, sync, dist_device, api, prepare=None):
     """BASELINE configs[3] (256 x 10 min queued over 8 GPUs = 32 files per GPU): `files_per_gpu * world` ten-minute files, sharded
     over the ranks longest first (shard.assign_files: the reference's pool hands files to whichever worker is free,
     cmd/jivetalking/pool.go:122-153; here a rank owns a GPU and its share is fixed up front, no exchange between ranks), each rank
@@ -198,7 +198,9 @@ def saturation_leg(rank, world, device, files_per_gpu, minutes, in_flight, sr, m
     wall = MAX over ranks, so the figure is the whole job's.  Reported beside `value`, never part of it.
       make_files(indices) -> paths   the rank's input files (index = position in the global batch)
       run_batch(paths, md5) -> (failed, [per-file wall ms], [output LUFS of the files that succeeded])
-      sync()                         barrier over ranks (+ device synchronize)"""
+      sync()                         barrier over ranks (+ device synchronize)
+      prepare()                      untimed housekeeping before a run (removing the previous run's outputs: freeing 0.8 GB of tmpfs pages
+                                     is 0.1 s of the host's time and no part of the job)"""
     from jivetalking_amd import shard
     total = files_per_gpu * world
     seconds = minutes * 60.0
@@ -213,6 +215,8 @@ def saturation_leg(rank, world, device, files_per_gpu, minutes, in_flight, sr, m
     for md5 in (True, False):
         runs = []
         for rep in range(3):                      # three runs, ALL reported: a sub-second batch that ends on host work (the last files' MD5) moves with the shared host
+            if prepare is not None:
+                prepare()
             sync()
             ru0 = resource.getrusage(resource.RUSAGE_SELF); t0 = time.perf_counter()
             got = run_batch(paths, md5)
@@ -261,9 +265,12 @@ def saturation_on_gpu(args, eng, rank, world, device, base, hostlogic, synth, sr
     import torch
     import torch.distributed as dist
     d = tempfile.mkdtemp(prefix=f"jtsat{rank}_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
-    pool = hostlogic.Pool(devices=(device,), in_flight_per_device=args.sat_in_flight)
+    pool = None
     try:
         def make_files(indices):
+            nonlocal pool
+            from jivetalking_amd import Engine
+            eng = Engine(device, streams=1)              # (the input files' encoder: closed again before the pool's handles open)
             paths = []
             for k in indices:
                 x = synth.speech_like_torch(args.sat_minutes * 60.0, sr, seed=2000 + k, device=f"cuda:{device}", plosives_per_min=40.0 if k % 2 == 0 else 0.0)
@@ -271,12 +278,17 @@ def saturation_on_gpu(args, eng, rank, world, device, base, hostlogic, synth, sr
                 pk = os.path.join(d, f"ep{k:03d}.flac")
                 open(pk, "wb").write(eng.op_flac_encode(pcm, sr, md5=True)); paths.append(pk)
                 del x
+            eng.close()
+            torch.cuda.synchronize(); torch.cuda.empty_cache()
+            pool = hostlogic.Pool(devices=(device,), in_flight_per_device=args.sat_in_flight)
             return paths
 
-        def run_batch(paths, md5):
+        def prepare():
             for q in os.listdir(d):
                 if q.endswith("-processed.flac"):
                     os.unlink(os.path.join(d, q))
+
+        def run_batch(paths, md5):
             failed, fr, _ = pool.process_files(paths, base=base, md5=md5)
             return (int(failed), [float(fr[i].wall_ms) for i in range(len(paths))], [float(fr[i].result.output_lufs) for i in range(len(paths)) if fr[i].rc == 0],
                     pool.stats())
@@ -287,11 +299,12 @@ def saturation_on_gpu(args, eng, rank, world, device, base, hostlogic, synth, sr
             torch.cuda.synchronize()
 
         out = saturation_leg(rank, world, device, args.sat_files, args.sat_minutes, args.sat_in_flight, sr, make_files, run_batch, sync,
-                             f"cuda:{device}", "jt_handle_pool_process_files, one pool per rank on its own device, files sharded by shard.assign_files")
+                             f"cuda:{device}", "jt_handle_pool_process_files, one pool per rank on its own device, files sharded by shard.assign_files", prepare=prepare)
         out["pool_workers_per_device"] = [int(v) for v in __import__("jivetalking_amd").shard.gather_over_ranks(len(pool.workers()), device=f"cuda:{device}")]
         return out
     finally:
-        pool.close()
+        if pool is not None:
+            pool.close()
         shutil.rmtree(d, ignore_errors=True)
 
 
@@ -548,9 +561,8 @@ def main():
                      "note": "input / filtered / final true peak, the landing and the delivered s16 of the job with the branch-and-bound true "
                              "peak and with the exhaustive kernels; tests/test_gpu_tp_prune.py holds the per-frame running maxima bit-identical"}
         del b_bb, b_ex
-    sat_leg = None
-    if args.saturation and args.channels == 1:
-        sat_leg = saturation_on_gpu(args, eng, rank, world, local_rank, base, hostlogic, synth, sr)
+    sat_leg = None            # (configs[3] runs LAST, with this handle closed: see the end of main)
+    out = None
     if rank == 0:
         import numpy as np
         m = int(-(-n * 147 // 160))
@@ -561,18 +573,22 @@ def main():
         nlm_bytes = 8 * n                                    # anlmdn: read f32 + write f32 per sample
         nlm_flops = n * (2 * S) * 6                          # patch-distance recurrence: 2 sub, 2 mul, 2 add per (sample, offset)
         pm = np.mean(np.array(p_ms), axis=0)
-        nlm_roof = {"kernel": "k_anlmdn_pair3", "bound": "hbm", "achieved": round(nlm_bytes / nlm_avg_s / 1e9, 2),
+        nlm_roof = {"kernel": "k_anlmdn_pair3<3>", "why_this_kernel": "the longest single kernel of a step by rocprofv3 --kernel-trace --stats "
+                                                                      "(profiles/r05_kernel_stats_60min.csv); the longest STAGE, adeclick, is five launches: `dominant_stage`",
+                    "bound": "hbm", "achieved": round(nlm_bytes / nlm_avg_s / 1e9, 2),
                     "peak": 8000, "unit": "GB/s", "frac": round(nlm_bytes / nlm_avg_s / 1e9 / 8000, 5), "traffic": None,
-                    "note": "vector-FP32 bound, not HBM bound (SURVEY §8d): add/mul-only recurrence (FFmpeg's unfused f32 order), "
-                            "so the applicable peak is the non-FMA packed rate.  This launch is the early Pass-2 head (jt_pass2_prefetch_after_pass1): "
-                            "it is queued behind the Pass-1 analysis kernels and shares the GPU with their tails",
+                    "algorithmic_bytes_per_launch": nlm_bytes,
+                    "note": "8 N algorithmic bytes (read f32 + write f32) over the kernel's HIP-event time.  The kernel is vector-FP32 bound, not HBM "
+                            "bound (SURVEY 8d): an add/mul-only recurrence in FFmpeg's unfused f32 order, so the ceiling that applies is `valu` (the "
+                            "non-FMA vector rate), where it runs at the issue limit of its instruction mix (NOTES.md, round 4).  This launch is the "
+                            "early Pass-2 head (jt_pass2_prefetch_after_pass1): queued behind the Pass-1 analysis kernels, it shares the GPU with their tails",
                     "valu": {"achieved_TFLOPs": round(nlm_flops / nlm_avg_s / 1e12, 2), "peak_TFLOPs_no_fma": 78.6,
                              "frac": round(nlm_flops / nlm_avg_s / 1e12 / 78.6, 4)},
                     "avg_launch_ms": round(nlm_avg_s * 1e3, 3)}
         dk_avg_s = float(np.mean(dk_ms)) / 1e3
-        if dk_avg_s > nlm_avg_s:
+        if True:
             dk_bytes = 16 * m                                  # adeclick: read f64 + write f64 per 44.1 kHz sample
-            roof = {"kernel": "k_adeclick", "launches": "k_adeclick_fast<..., MODE 2> (autocorrelation + pass-through copy) -> k_dk_levinson (one lane per window) -> "
+            roof = {"kernel": "k_adeclick", "stage": "adeclick (five launches, timed with HIP events on its stream)", "launches": "k_adeclick_fast<..., MODE 2> (autocorrelation + pass-through copy) -> k_dk_levinson (one lane per window) -> "
                                                         "k_adeclick_fast<..., MODE 3> (detector, right-hand side) -> k_dk_solve<32> || k_dk_solve<64> "
                                                         "(register-resident LDL^T, two windows / one window per wave) [+ k_adeclick_fast levels 1, 2 for overflow windows]",
                     "bound": "hbm", "achieved": round(dk_bytes / dk_avg_s / 1e9, 2), "peak": 8000,
@@ -585,14 +601,12 @@ def main():
                             "round trips 60 % of their wave time at 11 waves per CU (profiles/r03_pmc_issue.txt, DESIGN.md s4/s9)",
                     "avg_launch_ms": round(dk_avg_s * 1e3, 3), "repaired_samples": int(eng.timers()["declick_repaired"]),
                     "heavy_windows": int(eng.timers()["declick_heavy_windows"]), "fast_vs_exact": dk_parity}
-        else:
-            roof, nlm_roof = nlm_roof, None
         # HBM traffic per launch from the round's committed PMC passes (profiles/r04_pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE and
         # --pmc WRITE_SIZE in separate runs of this same command, tools/profile_round.sh); FETCH_SIZE doubled per MI355X_MICROARCH.md's
         # gfx950 note.  The file records the sha256 of the kernel sources it was measured on: `traffic` is null once they have changed.
         try:
             import hashlib
-            pmc_file = next(f for f in ("r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json") if os.path.exists(os.path.join(ROOT, "profiles", f)))
+            pmc_file = next(f for f in ("r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json") if os.path.exists(os.path.join(ROOT, "profiles", f)))
             pj = json.load(open(os.path.join(ROOT, "profiles", pmc_file)))
             pmc = pj["kernels"]
             sha = lambda f: hashlib.sha256(open(os.path.join(ROOT, "jivetalking_amd", "csrc", f), "rb").read()).hexdigest()[:16]
@@ -640,8 +654,8 @@ def main():
                              "achieved_GBps": round(alg_bytes_file * world * args.steps / dt / 1e9, 2), "peak_GBps": 8000,
                              "frac": round(alg_bytes_file * world * args.steps / dt / 1e9 / 8000, 6)},
             "compute_aware_floor": None,
-            "roofline": roof,
-            "second_kernel": nlm_roof,
+            "roofline": nlm_roof,
+            "dominant_stage": roof,
         }
         fl = compute_aware_floor(n, m, sr, bool(res.limiter.needed), int(eng.timers()["declick_repaired"]), (m + 1211) // 1212)
         fl["step_over_floor"] = round(dt / args.steps * 1e3 / fl["floor_ms"], 2)
@@ -654,8 +668,6 @@ def main():
             out["resident_in_flight"] = sat
         if io_legs is not None:
             out["io_legs"] = io_legs
-        if sat_leg is not None:
-            out["saturation"] = sat_leg
         if world == 1 and args.e2e and args.channels == 1:
             out["e2e"] = e2e_legs(eng, x, n, sr, seconds, base, hostlogic, Engine, local_rank)
             dev_s = f"cuda:{local_rank}"
@@ -730,8 +742,16 @@ def main():
                 pr.kill()
                 out["dynamic_fallback"]["oracle"] = {"error": f"{type(ex).__name__}: {ex}", "stderr": (pr.stderr.read() or b"").decode()[-400:]}
             shutil.rmtree(od, ignore_errors=True)
-        print(json.dumps(out))
+    # BASELINE configs[3], every rank: the handle the legs above used is closed first.  An open handle keeps its eight HIP streams on the
+    # process's hardware queues, and the pool's one-stream handles would share queues with each other behind them (measured: 13.5 ms per
+    # file beside an idle eight-stream handle, 10.1 without it) -- a batch host has the pool and nothing else.
     eng.close()
+    if args.saturation and args.channels == 1:
+        sat_leg = saturation_on_gpu(args, None, rank, world, local_rank, base, hostlogic, synth, sr)
+    if rank == 0:
+        if sat_leg is not None:
+            out["saturation"] = sat_leg
+        print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
 

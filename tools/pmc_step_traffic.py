@@ -1,5 +1,10 @@
 """HBM counter traffic of ONE step of the bench (our kernels between two consecutive k_frame_stats launches, the second step of the run):
-sum of 2 x FETCH_SIZE + WRITE_SIZE (KB as reported; FETCH_SIZE doubled per MI355X_MICROARCH.md's gfx950 note), per kernel and in total.
+per kernel and in total, as reported (FETCH_SIZE + WRITE_SIZE) and corrected (2 x FETCH_SIZE + WRITE_SIZE).
+The correction is CALIBRATED, not assumed (tools/fetch_calib.sh -> profiles/r05_fetch_calib.txt, 2 GiB sweeps on gfx950 / rocprofv3 of
+ROCm 7.2): every coalesced read width this library uses -- 2, 4, 8 and 16 bytes per lane -- reports exactly 0.500 of the bytes moved,
+WRITE_SIZE reports 1.000 at every width.  Every kernel here reads PCM as 64-lane-coalesced rows, so the factor
+applies to all of them; for an UNcoalesced reader (a lane walking its own chunk straight from global memory: 6.2 x over-fetch in the
+calibration) the doubling of the over-fetched lines is not calibrated, and no kernel of the step reads that way.
 usage: pmc_step_traffic.py profiles/rNN_pmc_fetch_size.csv profiles/rNN_pmc_write_size.csv"""
 import csv, re, sys, collections
 
@@ -27,4 +32,5 @@ rows = sorted(tot.items(), key=lambda kv: -(2 * kv[1][0] + kv[1][1]))
 S = sum(2 * f + w for _, (f, w) in rows)
 for n, (f, w) in rows[:25]:
     print("%-50s fetch x2 %7.2f GB  write %7.2f GB" % (n[:50], 2 * f / 1e9, w / 1e9))
-print("one step, all of our kernels: %.1f GB (2 x FETCH_SIZE + WRITE_SIZE)" % (S / 1e9))
+R = sum(f + w for _, (f, w) in rows)
+print("one step, all of our kernels: %.1f GB corrected (2 x FETCH_SIZE + WRITE_SIZE; calibration: profiles/r05_fetch_calib.txt), %.1f GB as reported" % (S / 1e9, R / 1e9))
