@@ -266,7 +266,9 @@ int  jt_handle_pool_process_files(jt_handle_pool *pool, const char *const *paths
 void jt_handle_pool_close(jt_handle_pool *pool);
 /* Where the pool's last batch spent its time, summed over the files (ms; a diagnostic for the host that sizes in_flight_per_device):
  * [0] waiting for a free I/O set of the handle, [1] reading the input, [2] decode, [3] the four passes + host logic, [4] encode
- * (the handle's thread); [5] waiting for a finisher thread, [6] the STREAMINFO MD5, [7] temp write + rename (a finisher thread);
+ * (the handle's thread); [5] from the end of the handle's work on the file to the start of its write (a free finisher thread, or the
+ * remainder of an MD5 that started inside Pass 4), [6] the STREAMINFO MD5 (it starts when Pass 4's s16 is complete and runs beside the
+ * output analysis and the encode), [7] temp write + rename (a finisher thread);
  * [8] files counted.  Returns JT_POOL_STATS, writes at most cap values. */
 #define JT_POOL_STATS 9
 int  jt_handle_pool_stats(jt_handle_pool *pool, double *out, int cap);

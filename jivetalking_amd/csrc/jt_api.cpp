@@ -62,6 +62,7 @@ extern "C" int jt_open_ex(int device_id, int n_streams, int flags, jt_ctx **out)
         JT_HIP(hipEventCreateWithFlags(&h->ev0, evb)); JT_HIP(hipEventCreateWithFlags(&h->ev1, evb));
         JT_HIP(hipEventCreateWithFlags(&h->ev2, evb)); JT_HIP(hipEventCreateWithFlags(&h->ev3, evb));
         JT_HIP(hipEventCreateWithFlags(&h->ev_block, hipEventDisableTiming | evb));
+        JT_HIP(hipEventCreateWithFlags(&h->ev_pcm[0], hipEventDisableTiming)); JT_HIP(hipEventCreateWithFlags(&h->ev_pcm[1], hipEventDisableTiming));
         JT_HIP(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming | evb));
         int prio_least = 0, prio_greatest = 0;
         JT_HIP(hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest));
@@ -118,6 +119,8 @@ extern "C" void jt_close(jt_ctx *h)
     if (h->ev2) (void)hipEventDestroy(h->ev2);
     if (h->ev3) (void)hipEventDestroy(h->ev3);
     if (h->ev_block) (void)hipEventDestroy(h->ev_block);
+    if (h->ev_pcm[0]) (void)hipEventDestroy(h->ev_pcm[0]);
+    if (h->ev_pcm[1]) (void)hipEventDestroy(h->ev_pcm[1]);
     if (h->spec_p2.done) (void)hipEventDestroy(h->spec_p2.done);
     if (h->early_p3.pin) (void)hipHostFree(h->early_p3.pin);
     if (h->early_p3.ev[0]) { (void)hipEventDestroy(h->early_p3.ev[0]); (void)hipEventDestroy(h->early_p3.ev[1]); }
@@ -1532,6 +1535,8 @@ extern "C" int jt_pass4(jt_ctx *h, const jt_limiter_plan *lim, const jt_loudnorm
         launch_f64_to_s16(sig, h->s16_p4.p, h->work_a.p, m, 1, h->stream);
     }
     h->m_p4 = m;
+    h->pcm_early = {};
+    if (h->p4_output_hook) h->p4_output_hook(h);                // (a handle pool: PCM to the host, MD5 started -- jt_internal.h)
     AnalysisJob J;
     analysis_enqueue(h, h->work_a.p, m, rate, true, rate / 10, &J, false);
     RegionJobs RJ;

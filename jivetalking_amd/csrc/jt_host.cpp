@@ -1773,33 +1773,88 @@ extern "C" int jt_handle_pool_process_files(jt_handle_pool *P, const char *const
             st[0] = wall_ms() - t0;
             W->h->io_set = set;
             auto tail = std::make_shared<FileTail>();
+            // One finisher job per file.  With the MD5 wanted it starts INSIDE Pass 4, the moment the delivered s16 is complete
+            // (jt_ctx::p4_output_hook): the PCM goes to the host and the signature's dependent chain (64 ms per ten minutes) runs
+            // beside the output analysis, the encode and the image's download; the job then waits for the front's verdict and writes.
+            struct Early { std::mutex m; std::condition_variable cv; int front = 0;          // 0 pending, 1 ok, -1 failed
+                           bool started = false; const int16_t *pcm = nullptr; size_t n = 0; hipEvent_t ev = nullptr; int device = 0;
+                           std::vector<double> st; double t_front = 0; };
+            auto early = std::make_shared<Early>();
+            Gate *g = &gate[set];
+            auto finish = [tail, early, &r, &failed, g, t0, P] {
+                std::string err; double ms[2] = {0, 0}; uint8_t md5[16]; bool md5_ok = true;
+                if (early->started) {
+                    const double m0 = wall_ms();
+                    hipError_t e = hipSetDevice(early->device);
+                    while (e == hipSuccess) {
+                        e = hipEventQuery(early->ev);
+                        if (e != hipErrorNotReady) break;
+                        (void)hipGetLastError(); e = hipSuccess;
+                        timespec ts{0, 50000}; nanosleep(&ts, nullptr);
+                    }
+                    md5_ok = e == hipSuccess;
+                    if (md5_ok) jt_md5(early->pcm, sizeof(int16_t) * early->n, md5);
+                    ms[0] = wall_ms() - m0;
+                    std::unique_lock<std::mutex> l(early->m);
+                    early->cv.wait(l, [&] { return early->front != 0; });
+                    if (early->front < 0) { l.unlock(); g->release(); return; }          // (the worker has reported the front's error)
+                }
+                std::vector<double> sv(early->st); sv[5] = wall_ms() - early->t_front;
+                int rc = JT_OK;
+                if (early->started && !md5_ok) { rc = JT_E_HIP; err = "the PCM's copy for the STREAMINFO signature failed"; }
+                else {
+                    if (early->started) memcpy(tail->image + 26, md5, 16);                 // (tail->pcm is null: file_tail does not hash again)
+                    double tms[2] = {0, 0};
+                    rc = file_tail(*tail, &err, tms);
+                    ms[0] += tms[0]; ms[1] = tms[1];
+                }
+                sv[6] = ms[0]; sv[7] = ms[1]; P->add_stats(sv.data());
+                r.rc = rc;
+                if (rc != JT_OK) { snprintf(r.error, sizeof r.error, "%s", err.c_str()); failed.fetch_add(1); }
+                else { strncpy(r.output_path, tail->final_path.c_str(), sizeof r.output_path - 1); r.output_path[sizeof r.output_path - 1] = 0; }
+                r.wall_ms = wall_ms() - t0;
+                g->release();
+            };
+            if (flac_flags & JT_FLAC_MD5) {
+                const int dev = W->device;
+                W->h->p4_output_hook = [early, g, P, finish, set, dev](jt_ctx *hh) {
+                    const size_t n = (size_t)hh->m_p4;
+                    hh->pin_pcm().begin(sizeof(int16_t) * n + 64);
+                    int16_t *pcm = hh->pin_pcm().take<int16_t>(n);
+                    JT_HIP(hipMemcpyAsync(pcm, hh->s16_p4.p, sizeof(int16_t) * n, hipMemcpyDeviceToHost, hh->stream));
+                    JT_HIP(hipEventRecord(hh->ev_pcm[set], hh->stream));
+                    hh->pcm_early.pcm = pcm; hh->pcm_early.n = n;
+                    early->pcm = pcm; early->n = n; early->ev = hh->ev_pcm[set]; early->device = dev; early->started = true;
+                    { std::lock_guard<std::mutex> l(g->m); g->busy = true; }
+                    P->finish_async(finish);
+                };
+            }
             r.rc = file_front(W->h, paths[i], base, frame_samples, flac_flags, nullptr, nullptr, &r.result, tail.get(), io);
+            W->h->p4_output_hook = nullptr;
             const double t_front = wall_ms();
             st[1] = io[0]; st[2] = io[1]; st[4] = io[2]; st[3] = (t_front - t0) - st[0] - io[0] - io[1] - io[2]; st[8] = 1;
+            early->st.assign(st, st + JT_POOL_STATS); early->t_front = t_front;
             if (r.rc != JT_OK) {
                 snprintf(r.error, sizeof r.error, "%s", jt_last_error(W->h));
                 r.wall_ms = wall_ms() - t0; failed.fetch_add(1);
                 P->add_stats(st);
+                if (early->started) { { std::lock_guard<std::mutex> l(early->m); early->front = -1; } early->cv.notify_all(); }
                 if (!file_verdict(r.rc)) {
-                    gate[0].wait_free(); gate[1].wait_free();          // (tails still read the old handle's pinned buffers)
+                    gate[0].wait_free(); gate[1].wait_free();          // (finisher jobs still read the old handle's pinned buffers and events)
                     jt_close(W->h); W->h = nullptr;
                     if (jt_open_ex(W->device, P->n_streams, P->open_flags, &W->h) != JT_OK) W->h = nullptr;
                 }
                 continue;
             }
-            { std::lock_guard<std::mutex> l(gate[set].m); gate[set].busy = true; }
-            Gate *g = &gate[set];
-            std::vector<double> stv(st, st + JT_POOL_STATS);
-            P->finish_async([tail, &r, &failed, g, t0, t_front, stv, P] {
-                std::string err; double ms[2] = {0, 0};
-                std::vector<double> sv(stv); sv[5] = wall_ms() - t_front;
-                r.rc = file_tail(*tail, &err, ms);
-                sv[6] = ms[0]; sv[7] = ms[1]; P->add_stats(sv.data());
-                if (r.rc != JT_OK) { snprintf(r.error, sizeof r.error, "%s", err.c_str()); failed.fetch_add(1); }
-                else { strncpy(r.output_path, tail->final_path.c_str(), sizeof r.output_path - 1); r.output_path[sizeof r.output_path - 1] = 0; }
-                r.wall_ms = wall_ms() - t0;
-                g->release();
-            });
+            if (early->started) {
+                // (an MD5 job that Pass 4 started but whose PCM the encoder did not adopt -- it cannot happen on this path -- would leave
+                //  the signature to file_tail as well: tail->pcm is only null when the encoder found pcm_early)
+                { std::lock_guard<std::mutex> l(early->m); early->front = 1; }
+                early->cv.notify_all();
+            } else {
+                { std::lock_guard<std::mutex> l(g->m); g->busy = true; }
+                P->finish_async(finish);
+            }
             set ^= 1;
         }
         gate[0].wait_free(); gate[1].wait_free();

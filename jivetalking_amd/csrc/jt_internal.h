@@ -360,6 +360,12 @@ struct jt_ctx {
     hipStream_t stream = nullptr;
     int n_streams = 8; std::vector<hipStream_t> owned_streams;      // jt_open_ex: which of the streams below are aliases
     bool blocking = false; hipEvent_t ev_block = nullptr;          // JT_OPEN_BLOCKING_SYNC: host waits sleep instead of spinning (jt_stream_sync)
+    // jt_pass4 calls this (when set) as soon as the delivered s16 is complete on the main stream, BEFORE the output analysis is queued: a
+    // handle pool copies the PCM to the host there and starts the file's STREAMINFO MD5 (64 ms of a host core per ten minutes) while the
+    // analysis, the FLAC encode and the download of the image are still to come.  pcm_early names that copy for jt_flac_encode.
+    std::function<void(jt_ctx *)> p4_output_hook;
+    struct PcmEarly { const int16_t *pcm = nullptr; size_t n = 0; } pcm_early;
+    hipEvent_t ev_pcm[2] = {nullptr, nullptr};                      // end of that copy, per I/O set
     // auxiliary streams: the independent parts of an analysis (astats chains, true peak + K-weighting, spectral) are forked
     // onto them and joined back into `stream` with events, so latency-bound kernels overlap instead of queueing
     hipStream_t aux[8] = {};                   // [0..3] the analysis chains of a pass, [4..7] the chains of announced output regions

@@ -40,7 +40,9 @@ void flac_encode_core(jt_ctx *h, const int16_t *d_pcm, int64_t n, int rate, int 
     unsigned char *d_sum = h->fl_rec.p + (jt_flac_rec_bytes(nframes) - 256);
     // the PCM travels to the host on an auxiliary stream while the analysis runs (only the MD5 needs it)
     int16_t *h_pcm = nullptr;
-    if (want_md5) {
+    // (a pool's Pass 4 has copied the PCM already and somebody is hashing it: jt_ctx::p4_output_hook)
+    const bool pcm_there = defer_md5 && h->pcm_early.pcm && h->pcm_early.n == (size_t)n && d_pcm == h->s16_p4.p;
+    if (want_md5 && !pcm_there) {
         h->pin_pcm().begin(sizeof(int16_t) * (size_t)n + 64);
         h_pcm = h->pin_pcm().take<int16_t>((size_t)n);
         JT_HIP(hipEventRecord(h->ev_fork, h->stream));
@@ -69,7 +71,7 @@ void flac_encode_core(jt_ctx *h, const int16_t *d_pcm, int64_t n, int rate, int 
 
     uint8_t md5[16] = {0};
     double md5_ms = 0.0;
-    if (want_md5) {
+    if (want_md5 && !pcm_there) {
         JT_HIP(jt_stream_sync(h, h->aux[0]));
         const double m0 = flac_now_ms();
         if (defer_md5) { h->flac_deferred.pcm = h_pcm; h->flac_deferred.n = (size_t)n; }
