@@ -73,7 +73,8 @@ void jt_end_job(jt_ctx *h);
  *     sweep is tested against), limiter_lanes (alimiter with a lane per segment: what the wave-per-segment kernel is tested against),
  *     tp_unpruned (ebur128's true peak by the exhaustive kernels: what the branch-and-bound path is tested against), tp_prune_min
  *     (integer: the shortest signal, in samples, that takes the branch-and-bound path; default 1048576), brickwall_f64 (Pass 4's
- *     brickwall as doubles + a dbl -> flt -> s16 sweep instead of writing the float and the s16 itself)
+ *     brickwall as doubles + a dbl -> flt -> s16 sweep instead of writing the float and the s16 itself), ln_no_batch (dynamic-mode
+ *     loudnorm: the limiter's harmless peaks one detector call at a time instead of a frame's worth in one step; same bytes)
  *   diagnostics: host_timing (host-stage timings on stderr; PROCESS-WIDE although it is set through a handle: the host stages are
  *     plain functions without one, the last writer wins for every handle of the process)
  *   process-wide (h == NULL): graveyard_gb (gigabytes of superseded buffers parked before they are freed, default 24, 0 = free at

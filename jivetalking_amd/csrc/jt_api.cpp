@@ -1414,7 +1414,7 @@ static void loudnorm_dynamic_run(jt_ctx *h, double *x, int64_t m, const Loudnorm
         for (int i = 0; i < 21; i++) P.weights[i] *= adjust;
     }
     jt_kweight_coeffs5(192000, P.kwb, P.kwa);
-    P.dual_mono = in.dual_mono ? 1 : 0; P.n_inner = n_inner; P.final_len = FINAL;
+    P.dual_mono = in.dual_mono ? 1 : 0; P.n_inner = n_inner; P.final_len = FINAL; P.no_batch = h->opts.ln_no_batch ? 1 : 0;
     h->ln_ring.ensure(LBS); h->ln_series.ensure(series.size());
     JT_HIP(hipMemcpyAsync(h->ln_series.p, series.data(), series.size() * sizeof(double), hipMemcpyHostToDevice, s));
     // (the workgroup kernel runs as a sequence of launches of a few milliseconds each on the main stream: a launch that lasts a second

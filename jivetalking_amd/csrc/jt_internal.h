@@ -96,7 +96,7 @@ template <typename T> struct DevBuf {
 // that build imports JT_<KEY> variables, once, inside jt_open.
 #define JT_OPT_BOOLS(X) \
     X(no_pass2_prefetch) X(no_early_pass3) X(no_early_plan) X(no_lim_keep) X(no_staged_finish) X(no_r128_first) \
-    X(region_full_astats) X(host_timing) X(adeclick_exact) X(nlm_generic) X(p3_unfused) X(limiter_lanes) X(tp_unpruned) X(no_spec_direct) X(brickwall_f64) X(nf_low)
+    X(region_full_astats) X(host_timing) X(adeclick_exact) X(nlm_generic) X(p3_unfused) X(limiter_lanes) X(tp_unpruned) X(no_spec_direct) X(brickwall_f64) X(nf_low) X(ln_no_batch)
 #define JT_OPT_INTS(X) X(region_rot) X(tp_prune_min)
 #define JT_OPT_AB_BOOLS(X) \
     X(nlm_old) X(afftdn_old) X(adeclick_fused) X(dk_levinson_in_kernel) X(dk_no_xcd) X(dk_serial) X(dk_profile) X(dyn_one_wave) \
@@ -253,6 +253,7 @@ struct LoudnormDynParams {
     double weights[21], kwb[5], kwa[5];
     int above0, dual_mono;
     int64_t n_inner; int final_len;
+    int no_batch;      // option ln_no_batch: the limiter's harmless peaks one detector call at a time (what the batched step is tested against)
 };
 void jt_loudnorm_series(const double *bs, int64_t nfull, int64_t s100, bool dual_mono, int64_t n_inner, double *out);
 void jt_kweight_coeffs5(int sr, double b[5], double a[5]);

@@ -576,7 +576,52 @@ __device__ __forceinline__ int lnv_detect_peak(const LnRing &R, const unsigned c
     LNP_ADD(4);
     return r;
 }
-__device__ __forceinline__ void lnw_true_peak_limiter(double *ring, double *cache, const unsigned char *hot, LnState &s, double *out, int nb, double ceiling, int tid)
+// SUSTAIN, all harmless peaks of the frame's remainder at once (round 5).  While the limiter holds a signal down, detect_peak() finds a
+// peak every few hundred samples and almost every one of them needs no more reduction than is already applied (ceiling / peak >= gr1:
+// within a stretch of continuous limiting gr1 only ever falls, so only a new record peak is "harmful"): the filter then multiplies the
+// samples up to that peak by gr1 and looks for the next one -- ~600 times a second, one dependent detector call each.  The batch finds,
+// among the positions n = 1 .. R (R = what is left of the frame; q[n] = |sample scan_start + n|, all inside the LDS window),
+//   h = the first DETECTED peak whose reduction would be stronger (ceiling / q[n] < gr1), and
+//   l = the last detected peak before h (or before the frame's end when there is no h),
+// so that the caller can apply gr1 up to l in ONE segment and resume the filter's own statements there (its next detector call then finds
+// h, or what lies behind the frame's end, exactly as it would have after walking the harmless peaks one by one).
+// "Detected" is the filter's own outcome, stated without its prev_smp bookkeeping:
+//   |q[n-1]| <= |q[n]| >= |q[n+1]|,  |q[n]| > ceiling,  no |q[n+i]| > |q[n]| for i = 2 .. 11.
+// detect_peak() leaves prev_smp stale after a REJECTED candidate m (a local maximum with a larger sample L at l' in m+2 .. m+11), which
+// can make positions m+1 .. l'-2 candidates that a fresh prev_smp would not, or the other way round -- but every one of those has l' inside
+// its own window of ten and is rejected either way, and at l'-1 the candidate test fails on `next <= this` under both (q[l'] > q[m] >=
+// q[l'-1]), which refreshes prev_smp before l'.  The detected SET is therefore the clean predicate's; a call that starts at a detected peak
+// (n = 0 there) cannot return that peak again, which is "n >= 1" here.  Returns l (0: none), *lprev = the detected peak before l (0: none).
+__device__ __forceinline__ int lnv_sustain_batch(const double *q, int R, double ceiling, double gr1, int lane, int *lprev)
+{
+    int l = 0, lp = 0;
+    for (int c = 1; c <= R; c += 64) {
+        const int n = c + lane;
+        const double t = fabs(q[n]), a = fabs(q[n - 1]), b = fabs(q[n + 1]);
+        bool det = (n <= R) & (t > ceiling) & (a <= t) & (b <= t);
+        if (__ballot(det) == 0ull) continue;
+        if (det) {
+#pragma unroll
+            for (int i = 2; i < 12; ++i) det &= !(fabs(q[n + i]) > t);
+        }
+        const unsigned long long dm = __ballot(det);
+        if (dm == 0ull) continue;
+        const bool harm = det && (ceiling / t < gr1);               // the filter's own comparison: gain_reduction < s->gain_reduction[1]
+        const unsigned long long hm = __ballot(harm);
+        unsigned long long before = dm;
+        if (hm) before = dm & ((1ull << (__ffsll((long long)hm) - 1)) - 1ull);
+        if (before) {
+            const int hi = 63 - __clzll((long long)before);
+            const unsigned long long rest = before & ~(1ull << hi);
+            lp = rest ? c + (63 - __clzll((long long)rest)) : l;
+            l = c + hi;
+        }
+        if (hm) break;
+    }
+    *lprev = lp;
+    return l;
+}
+__device__ __forceinline__ void lnw_true_peak_limiter(double *ring, double *cache, const unsigned char *hot, LnState &s, double *out, int nb, double ceiling, int tid, bool batch_off)
 {
     const int index0 = s.lbi;
     LnRing R{ring, cache, index0};
@@ -611,6 +656,27 @@ __device__ __forceinline__ void lnw_true_peak_limiter(double *ring, double *cach
         }
     }
     do {
+        if (s.state == LIM_SUSTAIN && !batch_off) {
+            // every harmless peak of the frame's remainder in one segment (lnv_sustain_batch); the scan start is ring position
+            // lbi + smp_cnt + 1920 = window entry smp_cnt, and n <= nb - smp_cnt keeps n + 11 inside the window
+            // Two conditions make the one-segment form the filter's own result.  (1) What the batch scans must be what the per-peak walk
+            // would have scanned: the segment [env_index, env_index + l) must not reach into positions the scan still has to read.  As
+            // a rule env_index IS the scan start (or trails it by 1920: the first frame's episode), and every sample is read before it
+            // is scaled; but FINAL_FRAME refills the ring from position 0 with the limiter's state untouched, after which env_index can
+            // stand AHEAD of the scan -- there the walk stays per peak.  (2) A detector call returns a peak at n <= nb - 1 only.
+            int lprev = 0, lb = 0;
+            const int dist = ln_mod(s.lbi + smp_cnt + LN_ATT - s.env_index);           // how far env_index trails the scan start
+            const int Rb = min(nb - smp_cnt, nb - 1);
+            if (dist + Rb + 12 <= LN_LBS) lb = lnv_sustain_batch(R.cache + smp_cnt, Rb, ceiling, s.gr1, lane, &lprev);
+            if (lb > 0) {
+                const double g = s.gr1;
+                lnv_ring_scale(R, s.env_index, lb, [&](int) { return g; }, lane);
+                s.prev_smp = fabs(R.cache[smp_cnt + lb]);
+                s.peak_index = ln_mod(s.lbi + smp_cnt + LN_ATT + lb);
+                s.env_index = (s.env_index + lb) % LN_LBS; s.env_cnt = lb - lprev; smp_cnt += lb;
+                continue;
+            }
+        }
         // (one call site for the detector: OUT scans what is left of the frame, SUSTAIN a frame's length from where it stands)
         double pkv = 0.0; int pd = -1;
         if (s.state == LIM_OUT || s.state == LIM_SUSTAIN) pd = lnv_detect_peak(R, hot, s, smp_cnt, s.state == LIM_OUT ? nb - smp_cnt : nb, ceiling, &pkv, lane);
@@ -774,7 +840,7 @@ k_loudnorm_dynamic_wg(const double *__restrict__ x, int64_t n, LoudnormDynParams
             s.lbi = 0;
             lnw_ring_fill(ring, 0, fsrc, P.final_len, LN_LBS, [&](double v, int) { return v * gain * offset; }, tid, hot, ceiling);
         }
-        lnw_true_peak_limiter(ring, ln_cache, hot, s, y + produced, nb, ceiling, tid);
+        lnw_true_peak_limiter(ring, ln_cache, hot, s, y + produced, nb, ceiling, tid, P.no_batch != 0);
         if (it == 0) {
             s.first = false;
             if (!above) out_energy(y, LN_F100);

@@ -121,3 +121,23 @@ def test_analysis_refuses_rates_its_scratch_is_not_sized_for(engine):
     with pytest.raises(L.JtError) as ei:
         engine.op_ebur128(x, 4000, True)
     assert ei.value.code == L.JT_E_UNSUPPORTED
+
+
+@pytest.mark.parametrize("tp,level", [(-9.0, 2.5), (-20.0, 2.5), (-3.0, 6.0)])
+def test_dynamic_loudnorm_batched_sustain_equals_the_per_peak_walk(engine, oracle, tp, level):
+    """Round 5: while af_loudnorm's limiter holds a signal down, the harmless peaks of a frame's remainder are consumed in one step
+    (lnv_sustain_batch) instead of one detector call each.  Same bytes as the per-peak walk (option ln_no_batch) on signals that are
+    limited lightly, continuously, and hard enough that new record peaks keep arriving; and the oracle's output within the dynamic
+    tests' bar."""
+    x = synth.speech_like(12.7, 192000, seed=57).astype(np.float64) * level
+    x = x[: x.size - 333]
+    try:
+        engine.set_option("ln_no_batch", True)
+        want, wst = engine.op_loudnorm_dynamic(x, target_tp=tp)
+    finally:
+        engine.set_option("ln_no_batch", False)
+    got, gst = engine.op_loudnorm_dynamic(x, target_tp=tp)
+    assert gst["normalization_type_dynamic"] == 1 and np.array_equal(got, want) and gst == wst
+    ref, rst = oracle.loudnorm_dynamic(x, target_tp=tp)
+    assert np.max(np.abs(got - ref)) <= 1e-9 * max(1.0, np.max(np.abs(ref)))
+    assert abs(np.max(np.abs(ref)) - 10 ** (tp / 20)) < 1e-12          # the limiter worked throughout: peaks sit on the ceiling
