@@ -462,7 +462,7 @@ __device__ __forceinline__ int lnv_detect_window(const double *q, int e, LnState
         }
         return found;
     };
-    int n_start = 1;
+    int n_start = *resume;                                          // (1, or the first position the SUSTAIN batch has not judged yet)
 #ifdef JT_LN_PROFILE
     unsigned long long pc_ = clock64();
 #define LNW_SEC(i) { const unsigned long long c_ = clock64(); if (threadIdx.x == 0) lnp_acc[i] += c_ - pc_; pc_ = c_; }
@@ -547,7 +547,7 @@ __device__ __forceinline__ int lnv_detect_general(const LnRing &R, const unsigne
         n_start = m;
     }
 }
-__device__ __forceinline__ int lnv_detect_peak_(const LnRing &R, const unsigned char *hot, LnState &s, int offset, int nb, double ceiling, double *peak_value, int lane)
+__device__ __forceinline__ int lnv_detect_peak_(const LnRing &R, const unsigned char *hot, LnState &s, int offset, int nb, double ceiling, double *peak_value, int lane, int n_first)
 {
     LNP_CNT(6);
     const int base = ln_mod(s.lbi + offset + LN_ATT);
@@ -557,7 +557,7 @@ __device__ __forceinline__ int lnv_detect_peak_(const LnRing &R, const unsigned 
     if (nb <= 0) return -1;
     s.prev_smp = at(0);
     if (nb == 1) return -1;
-    int n_start = 1;
+    int n_start = n_first;
     if (c0 >= 0) {                                                   // base is inside the window (the walk reads base + n - 1, n >= 1)
         const int r = lnv_detect_window(R.cache + c0, LN_CACHE - c0, s, nb, ceiling, peak_value, base, lane, &n_start);
         if (r != -2) return r;
@@ -569,10 +569,10 @@ __device__ __forceinline__ int lnv_detect_peak_(const LnRing &R, const unsigned 
     LNP_ADD(10);
     return rg;
 }
-__device__ __forceinline__ int lnv_detect_peak(const LnRing &R, const unsigned char *hot, LnState &s, int offset, int nb, double ceiling, double *peak_value, int lane)
+__device__ __forceinline__ int lnv_detect_peak(const LnRing &R, const unsigned char *hot, LnState &s, int offset, int nb, double ceiling, double *peak_value, int lane, int n_first = 1)
 {
     LNP_T0
-    const int r = lnv_detect_peak_(R, hot, s, offset, nb, ceiling, peak_value, lane);
+    const int r = lnv_detect_peak_(R, hot, s, offset, nb, ceiling, peak_value, lane, n_first);
     LNP_ADD(4);
     return r;
 }
@@ -583,8 +583,9 @@ __device__ __forceinline__ int lnv_detect_peak(const LnRing &R, const unsigned c
 // among the positions n = 1 .. R (R = what is left of the frame; q[n] = |sample scan_start + n|, all inside the LDS window),
 //   h = the first DETECTED peak whose reduction would be stronger (ceiling / q[n] < gr1), and
 //   l = the last detected peak before h (or before the frame's end when there is no h),
-// so that the caller can apply gr1 up to l in ONE segment and resume the filter's own statements there (its next detector call then finds
-// h, or what lies behind the frame's end, exactly as it would have after walking the harmless peaks one by one).
+// so that the caller can apply gr1 up to l in ONE segment and resume the filter's own statements there: with h it takes the SUSTAIN ->
+// ATTACK transition the detector call from l would have led to (peak_delta = h - l), without h that call starts behind the positions
+// the batch has judged already (what lies behind the frame's end decides between sustain, attack and release, as before).
 // "Detected" is the filter's own outcome, stated without its prev_smp bookkeeping:
 //   |q[n-1]| <= |q[n]| >= |q[n+1]|,  |q[n]| > ceiling,  no |q[n+i]| > |q[n]| for i = 2 .. 11.
 // detect_peak() leaves prev_smp stale after a REJECTED candidate m (a local maximum with a larger sample L at l' in m+2 .. m+11), which
@@ -592,31 +593,65 @@ __device__ __forceinline__ int lnv_detect_peak(const LnRing &R, const unsigned c
 // its own window of ten and is rejected either way, and at l'-1 the candidate test fails on `next <= this` under both (q[l'] > q[m] >=
 // q[l'-1]), which refreshes prev_smp before l'.  The detected SET is therefore the clean predicate's; a call that starts at a detected peak
 // (n = 0 there) cannot return that peak again, which is "n >= 1" here.  Returns l (0: none), *lprev = the detected peak before l (0: none).
-__device__ __forceinline__ int lnv_sustain_batch(const double *q, int R, double ceiling, double gr1, int lane, int *lprev)
+__device__ __forceinline__ int lnv_sustain_batch(const double *q, int R, double ceiling, double gr1, int lane, int *lprev, int *harm_n, double *harm_v)
 {
     int l = 0, lp = 0;
-    for (int c = 1; c <= R; c += 64) {
-        const int n = c + lane;
-        const double t = fabs(q[n]), a = fabs(q[n - 1]), b = fabs(q[n + 1]);
-        bool det = (n <= R) & (t > ceiling) & (a <= t) & (b <= t);
-        if (__ballot(det) == 0ull) continue;
-        if (det) {
+    bool stop = false;
+    *harm_n = 0; *harm_v = 0.0;
+    // 256 positions per trip: the twelve reads of four 64-position groups are in flight together (one LDS round trip per trip instead of
+    // one per group: the walk is nothing but such trips), the groups are then judged in order
+    for (int c0 = 1; c0 <= R && !stop; c0 += 256) {
+        double tt[4], aa[4], bb[4];
 #pragma unroll
-            for (int i = 2; i < 12; ++i) det &= !(fabs(q[n + i]) > t);
+        for (int g = 0; g < 4; ++g) { const int n = c0 + 64 * g + lane; tt[g] = fabs(q[n]); aa[g] = fabs(q[n - 1]); bb[g] = fabs(q[n + 1]); }
+        bool cand[4]; bool anyc = false;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int n = c0 + 64 * g + lane;
+            cand[g] = (n <= R) & (tt[g] > ceiling) & (aa[g] <= tt[g]) & (bb[g] <= tt[g]);
+            anyc |= cand[g];
         }
-        const unsigned long long dm = __ballot(det);
-        if (dm == 0ull) continue;
-        const bool harm = det && (ceiling / t < gr1);               // the filter's own comparison: gain_reduction < s->gain_reduction[1]
-        const unsigned long long hm = __ballot(harm);
-        unsigned long long before = dm;
-        if (hm) before = dm & ((1ull << (__ffsll((long long)hm) - 1)) - 1ull);
-        if (before) {
-            const int hi = 63 - __clzll((long long)before);
-            const unsigned long long rest = before & ~(1ull << hi);
-            lp = rest ? c + (63 - __clzll((long long)rest)) : l;
-            l = c + hi;
+        if (__ballot(anyc) == 0ull) continue;
+        // the ten samples behind every position of the trip (not only behind its candidates: no divergent branch, so all forty reads are
+        // in flight together -- judged group by group behind their own branch, a trip waited for up to four more LDS round trips)
+        double mx[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int n = c0 + 64 * g + lane;
+            double m = 0.0;
+#ifdef JT_LN_BATCH_ALLGROUPS
+            {
+#else
+            if (__ballot(cand[g])) {                                   // (wave-uniform: only the groups that hold a candidate)
+#endif
+                double v[10];
+#pragma unroll
+                for (int i = 0; i < 10; ++i) v[i] = q[n + 2 + i];
+#pragma unroll
+                for (int i = 0; i < 10; ++i) m = fmax(m, fabs(v[i]));
+            }
+            mx[g] = m;
         }
-        if (hm) break;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            if (stop) break;
+            const int c = c0 + 64 * g;
+            const double t = tt[g];
+            const bool det = cand[g] && !(mx[g] > t);
+            const unsigned long long dm = __ballot(det);
+            if (dm == 0ull) continue;
+            const bool harm = det && (ceiling / t < gr1);               // the filter's own comparison: gain_reduction < s->gain_reduction[1]
+            const unsigned long long hm = __ballot(harm);
+            unsigned long long before = dm;
+            if (hm) before = dm & ((1ull << (__ffsll((long long)hm) - 1)) - 1ull);
+            if (before) {
+                const int hi = 63 - __clzll((long long)before);
+                const unsigned long long rest = before & ~(1ull << hi);
+                lp = rest ? c + (63 - __clzll((long long)rest)) : l;
+                l = c + hi;
+            }
+            if (hm) { const int f = __ffsll((long long)hm) - 1; *harm_n = c + f; *harm_v = ln_rl(t, f); stop = true; }
+        }
     }
     *lprev = lp;
     return l;
@@ -656,6 +691,7 @@ __device__ __forceinline__ void lnw_true_peak_limiter(double *ring, double *cach
         }
     }
     do {
+        int n_first = 1;
         if (s.state == LIM_SUSTAIN && !batch_off) {
             // every harmless peak of the frame's remainder in one segment (lnv_sustain_batch); the scan start is ring position
             // lbi + smp_cnt + 1920 = window entry smp_cnt, and n <= nb - smp_cnt keeps n + 11 inside the window
@@ -664,22 +700,35 @@ __device__ __forceinline__ void lnw_true_peak_limiter(double *ring, double *cach
             // a rule env_index IS the scan start (or trails it by 1920: the first frame's episode), and every sample is read before it
             // is scaled; but FINAL_FRAME refills the ring from position 0 with the limiter's state untouched, after which env_index can
             // stand AHEAD of the scan -- there the walk stays per peak.  (2) A detector call returns a peak at n <= nb - 1 only.
-            int lprev = 0, lb = 0;
+            int lprev = 0, lb = 0, hn = 0; double hv = 0.0;
             const int dist = ln_mod(s.lbi + smp_cnt + LN_ATT - s.env_index);           // how far env_index trails the scan start
             const int Rb = min(nb - smp_cnt, nb - 1);
-            if (dist + Rb + 12 <= LN_LBS) lb = lnv_sustain_batch(R.cache + smp_cnt, Rb, ceiling, s.gr1, lane, &lprev);
+            if (dist + Rb + 12 <= LN_LBS) {
+                lb = lnv_sustain_batch(R.cache + smp_cnt, Rb, ceiling, s.gr1, lane, &lprev, &hn, &hv);
+                n_first = Rb - lb + 1;                                                  // (nothing detected in (l, Rb])
+            }
+            const int scan0 = smp_cnt;
             if (lb > 0) {
                 const double g = s.gr1;
                 lnv_ring_scale(R, s.env_index, lb, [&](int) { return g; }, lane);
                 s.prev_smp = fabs(R.cache[smp_cnt + lb]);
                 s.peak_index = ln_mod(s.lbi + smp_cnt + LN_ATT + lb);
                 s.env_index = (s.env_index + lb) % LN_LBS; s.env_cnt = lb - lprev; smp_cnt += lb;
+            }
+            if (hn > 0) {
+                // the detector call from l returns h: peak_delta = h - l, and its reduction is the stronger one (the batch's own test)
+                const int pdh = hn - lb;
+                s.prev_smp = hv; s.peak_index = ln_mod(s.lbi + scan0 + LN_ATT + hn);
+                s.state = LIM_ATTACK;
+                s.attack_length = pdh; if (s.attack_length <= 1) s.attack_length = 2;
+                s.gr0 = s.gr1; s.gr1 = ceiling / hv; s.env_cnt = 0;
                 continue;
             }
+            if (smp_cnt >= nb) continue;
         }
         // (one call site for the detector: OUT scans what is left of the frame, SUSTAIN a frame's length from where it stands)
         double pkv = 0.0; int pd = -1;
-        if (s.state == LIM_OUT || s.state == LIM_SUSTAIN) pd = lnv_detect_peak(R, hot, s, smp_cnt, s.state == LIM_OUT ? nb - smp_cnt : nb, ceiling, &pkv, lane);
+        if (s.state == LIM_OUT || s.state == LIM_SUSTAIN) pd = lnv_detect_peak(R, hot, s, smp_cnt, s.state == LIM_OUT ? nb - smp_cnt : nb, ceiling, &pkv, lane, n_first);
         switch (s.state) {
         case LIM_OUT: {
             if (pd != -1) {
@@ -939,8 +988,19 @@ void launch_loudnorm_dynamic(const double *x, int64_t n, const LoudnormDynParams
         JT_HIP(hipFuncSetAttribute((const void *)k_loudnorm_dynamic_wg, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
         const int64_t total = 1 + P.n_inner + P.final_len / LN_F100;
         const int64_t steps = JT_AB_ON(o.dyn_steps > 0) ? o.dyn_steps : 64;
-        for (int64_t it = 0; it < total; it += steps)
+        for (int64_t it = 0; it < total; it += steps) {
             hipLaunchKernelGGL(k_loudnorm_dynamic_wg, dim3(1), dim3(LN_WG), smem, s, x, n, P, series, ring, y, dbg, carry, it, std::min(total, it + steps));
+#ifdef JT_LN_PROFILE
+            if (it == 8 * steps || it + steps >= total) {   // phase clocks of the ninth launch (inner frames) and of the last one (the flush): tools/prof_dynamic_phases.sh
+                unsigned long long pr[16];
+                JT_HIP(hipStreamSynchronize(s)); JT_HIP(hipMemcpyFromSymbol(pr, HIP_SYMBOL(g_ln_prof), sizeof pr));
+                const double st = (double)(std::min(total, it + steps) - it);
+                fprintf(stderr, "loudnorm dynamic, launch at step %lld (%g steps), kcycles per step: fill %.1f, window load %.1f, limiter %.1f (detect %.1f, scale %.1f), write-back + out %.1f; "
+                                "per step: %.1f scale passes, %.1f detector calls\n", (long long)it, st, pr[0] / st / 1e3, pr[1] / st / 1e3, pr[2] / st / 1e3, pr[4] / st / 1e3,
+                        pr[7] / st / 1e3, pr[3] / st / 1e3, pr[5] / st, pr[6] / st);
+            }
+#endif
+        }
         return;
     }
     // 96 KB of (unused) dynamic LDS: the workgroup then has a CU to itself.  Several files in flight each run one such wave, and the
