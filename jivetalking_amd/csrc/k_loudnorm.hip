@@ -353,7 +353,10 @@ __shared__ unsigned long long lnp_acc[16];
 // detector inside LDS up to the last sample of the frame; started at the frame's first sample it ended 245 samples short of that, and
 // the 3 % of the detector's calls that then walked the ring in global memory took two thirds of the kernel's time.  The first 1920
 // samples of the frame are only touched by the first envelope segments of a call and stay in global memory (batched read-modify-write).
-constexpr int LN_LO = LN_ATT, LN_CACHE = 20300;
+constexpr int LN_LO = LN_ATT, LN_CACHE = 19960;
+// (round 5: 340 entries fewer than the 20 300 that fit, for the frame's detected-peak bitmap; the window still reaches 760 samples behind
+//  the frame's last one, and a held-down signal has its next peak within a couple of hundred)
+constexpr int LN_BMW = (LN_CACHE + 63) / 64;                      // bitmap words: bit b of word k = window entry 64 k + b is a detected peak
 struct LnRing {
     double *ring, *cache; int index0;
     __device__ int rel(int i) const { const int r = i - index0; return r < 0 ? r + LN_LBS : r; }
@@ -656,7 +659,90 @@ __device__ __forceinline__ int lnv_sustain_batch(const double *q, int R, double 
     *lprev = lp;
     return l;
 }
-__device__ __forceinline__ void lnw_true_peak_limiter(double *ring, double *cache, const unsigned char *hot, LnState &s, double *out, int nb, double ceiling, int tid, bool batch_off)
+// ---- the frame's detected peaks as a bitmap (round 5).  "Detected" as in lnv_sustain_batch's comment: a pure function of the samples,
+// so all the workgroup's waves can judge the window's entries side by side before the one wave that walks the state machine starts: a word
+// per 64 consecutive entries, one ballot each.  Entry w needs w - 1 and w + 1 .. w + 11 inside the window.
+__device__ __forceinline__ void lnw_build_bitmap(const double *cache, unsigned long long *bm, double ceiling, int tid)
+{
+    const int lane = tid & 63, wv = tid >> 6;
+    for (int k = wv; k < LN_BMW; k += LN_WG / 64) {
+        const int w = 64 * k + lane;
+        const bool in = w >= 1 && w + 11 < LN_CACHE;
+        const double t = in ? fabs(cache[w]) : 0.0, a = in ? fabs(cache[w - 1]) : 0.0, b = in ? fabs(cache[w + 1]) : 0.0;
+        bool det = in & (t > ceiling) & (a <= t) & (b <= t);
+        if (__ballot(det)) {
+            double m = 0.0;
+            if (in) {
+                double v[10];
+#pragma unroll
+                for (int i = 0; i < 10; ++i) v[i] = cache[w + 2 + i];
+#pragma unroll
+                for (int i = 0; i < 10; ++i) m = fmax(m, fabs(v[i]));
+            }
+            det = det && !(m > t);
+        }
+        const unsigned long long mk = __ballot(det);
+        if (lane == 0) bm[k] = mk;
+    }
+}
+// first detected entry in [from, to] (window entries, from >= 1); -1: none.  64 words per trip.
+__device__ __forceinline__ int lnv_bitmap_first(const unsigned long long *bm, int from, int to, int lane)
+{
+    if (to >= LN_CACHE - 12) to = LN_CACHE - 13;
+    for (int k0 = from >> 6; 64 * k0 <= to; k0 += 64) {
+        const int k = k0 + lane;
+        unsigned long long m = (k < LN_BMW && 64 * k <= to) ? bm[k] : 0ull;
+        if (64 * k < from) m &= ~0ull << (from - 64 * k);             // (only the first word of the range can start inside it)
+        if (64 * k + 63 > to) { const int keep = to - 64 * k + 1; m = keep >= 64 ? m : (keep <= 0 ? 0ull : m & ((1ull << keep) - 1ull)); }
+        const unsigned long long any = __ballot(m != 0ull);
+        if (any) {
+            const int fl = __ffsll((long long)any) - 1;
+            const int lo = __builtin_amdgcn_readlane((int)(unsigned)m, fl), hi = __builtin_amdgcn_readlane((int)(unsigned)(m >> 32), fl);
+            const unsigned long long mw = ((unsigned long long)(unsigned)hi << 32) | (unsigned)lo;
+            return 64 * (k0 + fl) + (__ffsll((long long)mw) - 1);
+        }
+    }
+    return -1;
+}
+// The SUSTAIN batch on the bitmap: window entries [from, to]; returns l (last harmless detected entry before the first harmful one, -1:
+// none), *hn / *hv the first harmful entry and its magnitude (-1: none), *lprev the detected entry before l (-1: none).
+__device__ __forceinline__ int lnv_sustain_batch_bm(const double *cache, const unsigned long long *bm, int from, int to, double ceiling, double gr1, int lane,
+                                                    int *lprev, int *hn, double *hv)
+{
+    int l = -1, lp = -1;
+    *hn = -1; *hv = 0.0;
+    for (int k0 = from >> 6; 64 * k0 <= to; k0 += 64) {
+        const int k = k0 + lane;
+        unsigned long long m = (k < LN_BMW && 64 * k <= to) ? bm[k] : 0ull;
+        if (64 * k < from) m &= ~0ull << (from - 64 * k);
+        if (64 * k + 63 > to) { const int keep = to - 64 * k + 1; m = keep >= 64 ? m : (keep <= 0 ? 0ull : m & ((1ull << keep) - 1ull)); }
+        if (__ballot(m != 0ull) == 0ull) continue;
+        // a lane walks the few peaks of its own word in order
+        int first_h = -1, last_ok = -1, prev_ok = -1; double hval = 0.0;
+        while (m) {
+            const int pos = 64 * k + (__ffsll((long long)m) - 1);
+            m &= m - 1ull;
+            const double t = fabs(cache[pos]);
+            if (ceiling / t < gr1) { first_h = pos; hval = t; break; }      // the filter's own comparison: gain_reduction < s->gain_reduction[1]
+            prev_ok = last_ok; last_ok = pos;
+        }
+        const unsigned long long hb = __ballot(first_h >= 0);
+        const int fl = hb ? __ffsll((long long)hb) - 1 : 63;
+        const unsigned long long okb = __ballot(last_ok >= 0) & (fl >= 63 ? ~0ull : ((2ull << fl) - 1ull));
+        if (okb) {
+            const int hl = 63 - __clzll((long long)okb);
+            const int nl = __builtin_amdgcn_readlane(last_ok, hl), np = __builtin_amdgcn_readlane(prev_ok, hl);
+            const unsigned long long below = okb & ~(1ull << hl);
+            lp = np >= 0 ? np : (below ? __builtin_amdgcn_readlane(last_ok, 63 - __clzll((long long)below)) : l);
+            l = nl;
+        }
+        if (hb) { *hn = __builtin_amdgcn_readlane(first_h, fl); *hv = ln_rl(hval, fl); break; }
+    }
+    *lprev = lp;
+    return l;
+}
+__device__ __forceinline__ void lnw_true_peak_limiter(double *ring, double *cache, const unsigned char *hot, LnState &s, double *out, int nb, double ceiling, int tid, bool batch_off,
+                                                      unsigned long long *bm)
 {
     const int index0 = s.lbi;
     LnRing R{ring, cache, index0};
@@ -676,11 +762,26 @@ __device__ __forceinline__ void lnw_true_peak_limiter(double *ring, double *cach
 #ifdef JT_LN_PROFILE
     lnp_b_ = clock64(); if (tid == 0) lnp_acc[1] += lnp_b_ - lnp_a_;
 #endif
+    if (!batch_off) { lnw_build_bitmap(cache, bm, ceiling, tid); __syncthreads(); }
+#ifdef JT_LN_PROFILE
+    { const unsigned long long c_ = clock64(); if (tid == 0) lnp_acc[11] += c_ - lnp_b_; lnp_b_ = c_; }
+#endif
     // the state machine itself is ONE wave's work (every step depends on the one before): wave 0 runs it on the window, the other
     // fifteen wait at the barrier below -- run by all sixteen alike it took four times as long, four waves sharing each SIMD
     if (tid < 64) {
     const int lane = tid;
     int smp_cnt = 0;
+    // the bitmap describes the window as loaded; it stays true for the entries the scan has not reached as long as every envelope
+    // segment is applied AT or BEHIND the scan position (the rule; see the batch's comment for the exception)
+    bool bm_ok = !batch_off;
+    // A segment [env_index, env_index + cnt) leaves alone what the scan has still to read when it starts at or behind the scan position --
+    // r = its offset from the frame's first ring position, the scan stands at offset smp_cnt + 1920 -- or wholly behind the window, and
+    // its wrapped part (a start far behind reaches round the ring) ends before the scan position too.  (Measured from the scan position
+    // alone, "30 000 behind" passed for "behind": it is 10 320 AHEAD, inside the window.)
+    auto seg_keeps_bitmap = [&](int cnt) {
+        const int r = R.rel(s.env_index % LN_LBS);
+        return (r <= smp_cnt + LN_LO || r - LN_LO >= LN_CACHE) && (r + cnt - LN_LBS <= smp_cnt + LN_LO);
+    };
     if (s.first) {
         const double mx = lnv_ring_absmax(R, 0, LN_ATT, lane);
         if (mx > ceiling) {
@@ -692,43 +793,59 @@ __device__ __forceinline__ void lnw_true_peak_limiter(double *ring, double *cach
     }
     do {
         int n_first = 1;
+        double pkv = 0.0; int pd = -1; bool have_pd = false;
+        if (s.state == LIM_OUT && bm_ok) {
+            // detect_peak(smp_cnt, nb - smp_cnt): the first detected entry among n = 1 .. nb - smp_cnt - 1, all inside the window
+            const int e = lnv_bitmap_first(bm, smp_cnt + 1, nb - 1, lane);
+            have_pd = true;
+            if (e >= 0) { pd = e - smp_cnt; pkv = fabs(R.cache[e]); s.prev_smp = pkv; s.peak_index = ln_mod(s.lbi + LN_ATT + e); }
+        }
         if (s.state == LIM_SUSTAIN && !batch_off) {
-            // every harmless peak of the frame's remainder in one segment (lnv_sustain_batch); the scan start is ring position
-            // lbi + smp_cnt + 1920 = window entry smp_cnt, and n <= nb - smp_cnt keeps n + 11 inside the window
-            // Two conditions make the one-segment form the filter's own result.  (1) What the batch scans must be what the per-peak walk
-            // would have scanned: the segment [env_index, env_index + l) must not reach into positions the scan still has to read.  As
-            // a rule env_index IS the scan start (or trails it by 1920: the first frame's episode), and every sample is read before it
-            // is scaled; but FINAL_FRAME refills the ring from position 0 with the limiter's state untouched, after which env_index can
-            // stand AHEAD of the scan -- there the walk stays per peak.  (2) A detector call returns a peak at n <= nb - 1 only.
-            int lprev = 0, lb = 0, hn = 0; double hv = 0.0;
-            const int dist = ln_mod(s.lbi + smp_cnt + LN_ATT - s.env_index);           // how far env_index trails the scan start
+            // every harmless peak of the frame's remainder in one segment; the scan start is ring position lbi + smp_cnt + 1920 = window
+            // entry smp_cnt.  Two conditions make the one-segment form the filter's own result.  (1) What the batch scans must be what the
+            // per-peak walk would have scanned: the segment [env_index, env_index + l) must not reach into positions the scan still has to
+            // read.  As a rule env_index IS the scan start (or trails it by 1920: the first frame's episode), and every sample is read
+            // before it is scaled; but FINAL_FRAME refills the ring from position 0 with the limiter's state untouched, after which
+            // env_index can stand AHEAD of the scan -- there the walk stays per peak.  (2) A detector call returns a peak at n <= nb - 1 only.
             const int Rb = min(nb - smp_cnt, nb - 1);
-            if (dist + Rb + 12 <= LN_LBS) {
-                lb = lnv_sustain_batch(R.cache + smp_cnt, Rb, ceiling, s.gr1, lane, &lprev, &hn, &hv);
+            if (seg_keeps_bitmap(Rb)) {
+                int lprev = 0, lb = 0, hn = 0; double hv = 0.0;
+                const int scan0 = smp_cnt;
+                if (bm_ok) {
+                    int lpe = -1, hne = -1;
+                    const int le = lnv_sustain_batch_bm(R.cache, bm, scan0 + 1, scan0 + Rb, ceiling, s.gr1, lane, &lpe, &hne, &hv);
+                    lb = le >= 0 ? le - scan0 : 0; lprev = lpe >= 0 ? lpe - scan0 : 0; hn = hne >= 0 ? hne - scan0 : 0;
+                } else lb = lnv_sustain_batch(R.cache + smp_cnt, Rb, ceiling, s.gr1, lane, &lprev, &hn, &hv);
                 n_first = Rb - lb + 1;                                                  // (nothing detected in (l, Rb])
+                if (lb > 0) {
+                    const double g = s.gr1;
+                    lnv_ring_scale(R, s.env_index, lb, [&](int) { return g; }, lane);
+                    s.prev_smp = fabs(R.cache[smp_cnt + lb]);
+                    s.peak_index = ln_mod(s.lbi + smp_cnt + LN_ATT + lb);
+                    s.env_index = (s.env_index + lb) % LN_LBS; s.env_cnt = lb - lprev; smp_cnt += lb;
+                }
+                if (hn > 0) {
+                    // the detector call from l returns h: peak_delta = h - l, and its reduction is the stronger one (the batch's own test)
+                    const int pdh = hn - lb;
+                    s.prev_smp = hv; s.peak_index = ln_mod(s.lbi + scan0 + LN_ATT + hn);
+                    s.state = LIM_ATTACK;
+                    s.attack_length = pdh; if (s.attack_length <= 1) s.attack_length = 2;
+                    s.gr0 = s.gr1; s.gr1 = ceiling / hv; s.env_cnt = 0;
+                    continue;
+                }
+                if (smp_cnt >= nb) continue;
+                if (bm_ok) {
+                    // the call from l scans n = 1 .. nb - 1 from there: what lies behind the frame's remainder, as far as the window reaches
+                    const int lim = smp_cnt + nb - 1, wlim = min(lim, LN_CACHE - 13);
+                    const int e = lnv_bitmap_first(bm, scan0 + Rb + 1, wlim, lane);
+                    if (e >= 0) { have_pd = true; pd = e - smp_cnt; pkv = fabs(R.cache[e]); s.prev_smp = pkv; s.peak_index = ln_mod(s.lbi + LN_ATT + e); }
+                    else if (wlim == lim) have_pd = true;                               // (pd = -1: release)
+                    else n_first = wlim - smp_cnt + 1;
+                }
             }
-            const int scan0 = smp_cnt;
-            if (lb > 0) {
-                const double g = s.gr1;
-                lnv_ring_scale(R, s.env_index, lb, [&](int) { return g; }, lane);
-                s.prev_smp = fabs(R.cache[smp_cnt + lb]);
-                s.peak_index = ln_mod(s.lbi + smp_cnt + LN_ATT + lb);
-                s.env_index = (s.env_index + lb) % LN_LBS; s.env_cnt = lb - lprev; smp_cnt += lb;
-            }
-            if (hn > 0) {
-                // the detector call from l returns h: peak_delta = h - l, and its reduction is the stronger one (the batch's own test)
-                const int pdh = hn - lb;
-                s.prev_smp = hv; s.peak_index = ln_mod(s.lbi + scan0 + LN_ATT + hn);
-                s.state = LIM_ATTACK;
-                s.attack_length = pdh; if (s.attack_length <= 1) s.attack_length = 2;
-                s.gr0 = s.gr1; s.gr1 = ceiling / hv; s.env_cnt = 0;
-                continue;
-            }
-            if (smp_cnt >= nb) continue;
         }
         // (one call site for the detector: OUT scans what is left of the frame, SUSTAIN a frame's length from where it stands)
-        double pkv = 0.0; int pd = -1;
-        if (s.state == LIM_OUT || s.state == LIM_SUSTAIN) pd = lnv_detect_peak(R, hot, s, smp_cnt, s.state == LIM_OUT ? nb - smp_cnt : nb, ceiling, &pkv, lane, n_first);
+        if (!have_pd && (s.state == LIM_OUT || s.state == LIM_SUSTAIN)) pd = lnv_detect_peak(R, hot, s, smp_cnt, s.state == LIM_OUT ? nb - smp_cnt : nb, ceiling, &pkv, lane, n_first);
         switch (s.state) {
         case LIM_OUT: {
             if (pd != -1) {
@@ -745,6 +862,7 @@ __device__ __forceinline__ void lnw_true_peak_limiter(double *ring, double *cach
         case LIM_ATTACK: {
             int cnt = s.attack_length - s.env_cnt; if (cnt > nb - smp_cnt) cnt = nb - smp_cnt; if (cnt < 0) cnt = 0;
             const double g0 = s.gr0, g1 = s.gr1; const int c0 = s.env_cnt, al = s.attack_length;
+            if (!seg_keeps_bitmap(cnt)) bm_ok = false;
             lnv_ring_scale(R, s.env_index, cnt, [&](int j) { return g0 - ((double)(c0 + j) / (al - 1) * (g0 - g1)); }, lane);
             s.env_index = (s.env_index + cnt) % LN_LBS; s.env_cnt += cnt; smp_cnt += cnt;
             if (smp_cnt < nb) { s.env_cnt = 0; s.attack_length = LN_ATT; s.state = LIM_SUSTAIN; }
@@ -760,12 +878,14 @@ __device__ __forceinline__ void lnw_true_peak_limiter(double *ring, double *cach
             }
             int cnt = pd; if (cnt > nb - smp_cnt) cnt = nb - smp_cnt; if (cnt < 0) cnt = 0;
             const double g = s.gr1;
+            if (!seg_keeps_bitmap(cnt)) bm_ok = false;
             lnv_ring_scale(R, s.env_index, cnt, [&](int) { return g; }, lane);
             s.env_index = (s.env_index + cnt) % LN_LBS; s.env_cnt = cnt; smp_cnt += cnt;
             break; }
         case LIM_RELEASE: {
             int cnt = LN_REL - s.env_cnt; if (cnt > nb - smp_cnt) cnt = nb - smp_cnt; if (cnt < 0) cnt = 0;
             const double g0 = s.gr0, g1 = s.gr1; const int c0 = s.env_cnt;
+            if (!seg_keeps_bitmap(cnt)) bm_ok = false;
             lnv_ring_scale(R, s.env_index, cnt, [&](int j) { return g0 + (((double)(c0 + j) / (LN_REL - 1)) * (g1 - g0)); }, lane);
             s.env_index = (s.env_index + cnt) % LN_LBS; s.env_cnt += cnt; smp_cnt += cnt;
             if (smp_cnt < nb) { s.env_cnt = 0; s.state = LIM_OUT; }
@@ -816,6 +936,7 @@ k_loudnorm_dynamic_wg(const double *__restrict__ x, int64_t n, LoudnormDynParams
     extern __shared__ double ln_cache[];                            // [LN_CACHE]; the output meter's tile aliases its head
     __shared__ double delta[30], w[21], oe[30];
     __shared__ unsigned char hot[LN_LBS / 64];
+    __shared__ unsigned long long ln_bm[LN_BMW];                    // the frame's detected peaks (lnw_build_bitmap)
     double *tile = ln_cache;
     const int tid = threadIdx.x;
     const bool fresh = it_begin == 0;
@@ -889,7 +1010,7 @@ k_loudnorm_dynamic_wg(const double *__restrict__ x, int64_t n, LoudnormDynParams
             s.lbi = 0;
             lnw_ring_fill(ring, 0, fsrc, P.final_len, LN_LBS, [&](double v, int) { return v * gain * offset; }, tid, hot, ceiling);
         }
-        lnw_true_peak_limiter(ring, ln_cache, hot, s, y + produced, nb, ceiling, tid, P.no_batch != 0);
+        lnw_true_peak_limiter(ring, ln_cache, hot, s, y + produced, nb, ceiling, tid, P.no_batch != 0, ln_bm);
         if (it == 0) {
             s.first = false;
             if (!above) out_energy(y, LN_F100);

@@ -141,3 +141,24 @@ def test_dynamic_loudnorm_batched_sustain_equals_the_per_peak_walk(engine, oracl
     ref, rst = oracle.loudnorm_dynamic(x, target_tp=tp)
     assert np.max(np.abs(got - ref)) <= 1e-9 * max(1.0, np.max(np.abs(ref)))
     assert abs(np.max(np.abs(ref)) - 10 ** (tp / 20)) < 1e-12          # the limiter worked throughout: peaks sit on the ceiling
+
+
+@pytest.mark.parametrize("seed,level,tp,off,quiet_s,cut", [(41, 2.5, -9.0, 0.0, 3.0, 4321), (7, 2.5, -9.0, 0.0, 0.0, 0), (8, 4.0, -6.0, 3.0, 1.5, 19199),
+                                                             (9, 1.2, -12.0, 0.0, 0.0, 777), (10, 8.0, -1.0, 13.0, 2.9, 1), (11, 3.0, -15.0, 6.0, 0.3, 9600)])
+def test_dynamic_loudnorm_batched_limiter_on_awkward_streams(engine, seed, level, tp, off, quiet_s, cut):
+    """The bitmap / batched limiter against the per-peak walk on streams chosen for the state machine's corners: a quiet start (the
+    output-meter phase), levels that keep new record peaks coming, offsets, lengths that end in a partial frame -- and the flush, where
+    af_loudnorm refills its ring from position 0 with the limiter's state untouched, so that envelope segments can land AHEAD of the scan
+    (the case the first version of the batch got wrong: 62 538 samples of the first configuration differed)."""
+    x = synth.speech_like(11.0, 192000, seed=seed).astype(np.float64) * level
+    if quiet_s > 0:
+        x = np.concatenate([x[: int(192000 * quiet_s)] * 0.004, x])
+    if cut:
+        x = x[: x.size - cut]
+    try:
+        engine.set_option("ln_no_batch", True)
+        want, wst = engine.op_loudnorm_dynamic(x, target_tp=tp, offset=off)
+    finally:
+        engine.set_option("ln_no_batch", False)
+    got, gst = engine.op_loudnorm_dynamic(x, target_tp=tp, offset=off)
+    assert np.array_equal(got, want) and gst == wst
