@@ -659,6 +659,11 @@ __device__ __forceinline__ int lnv_sustain_batch(const double *q, int R, double 
     *lprev = lp;
     return l;
 }
+// SUSTAIN segments (one constant gain over a stretch of the window) that wave 0 has decided but not applied: all waves multiply them
+// into the window side by side when the state machine has finished the frame -- one wave's read-modify-write of up to 19 200 LDS entries
+// per segment was a third of the limiter's time.  Allowed while nothing reads those entries before the frame goes out: the detector works
+// ahead of every segment (bm_ok), and an envelope segment that would overlap a pending one is applied after the pending ones.
+struct LnPending { int n; int start[4], len[4]; double g[4]; };
 // ---- the frame's detected peaks as a bitmap (round 5).  "Detected" as in lnv_sustain_batch's comment: a pure function of the samples,
 // so all the workgroup's waves can judge the window's entries side by side before the one wave that walks the state machine starts: a word
 // per 64 consecutive entries, one ballot each.  Entry w needs w - 1 and w + 1 .. w + 11 inside the window.
@@ -742,7 +747,7 @@ __device__ __forceinline__ int lnv_sustain_batch_bm(const double *cache, const u
     return l;
 }
 __device__ __forceinline__ void lnw_true_peak_limiter(double *ring, double *cache, const unsigned char *hot, LnState &s, double *out, int nb, double ceiling, int tid, bool batch_off,
-                                                      unsigned long long *bm)
+                                                      unsigned long long *bm, LnPending *pend)
 {
     const int index0 = s.lbi;
     LnRing R{ring, cache, index0};
@@ -782,6 +787,32 @@ __device__ __forceinline__ void lnw_true_peak_limiter(double *ring, double *cach
         const int r = R.rel(s.env_index % LN_LBS);
         return (r <= smp_cnt + LN_LO || r - LN_LO >= LN_CACHE) && (r + cnt - LN_LBS <= smp_cnt + LN_LO);
     };
+    int npend = 0;                                                  // (wave-uniform copy of pend->n)
+    auto flush_pending = [&]() {
+        for (int k = 0; k < npend; ++k) { const double g = pend->g[k]; lnv_ring_scale(R, ln_mod(index0 + LN_LO + pend->start[k]), pend->len[k], [&](int) { return g; }, lane); }
+        npend = 0;
+    };
+    // a constant-gain segment: deferred when it lies inside the window and the detector never looks back (bm_ok), applied now otherwise
+    auto sustain_scale = [&](int env_index, int cnt, double g) {
+        if (cnt <= 0) return;
+        const int r0 = R.rel(env_index % LN_LBS) - LN_LO;
+        if (bm_ok && r0 >= 0 && r0 + cnt <= LN_CACHE && npend < 4) {
+            if (lane == 0) { pend->start[npend] = r0; pend->len[npend] = cnt; pend->g[npend] = g; }
+            ++npend;
+            return;
+        }
+        flush_pending();                                               // (order: what was decided first is multiplied first)
+        lnv_ring_scale(R, env_index, cnt, [&](int) { return g; }, lane);
+    };
+    // an envelope segment that is applied at once: pending segments it overlaps (it never does on the paths seen so far) go first
+    auto before_immediate = [&](int env_index, int cnt) {
+        if (!npend) return;
+        const int a = R.rel(env_index % LN_LBS) - LN_LO;
+        bool hit = false;
+        for (int k = 0; k < npend; ++k) hit |= a < pend->start[k] + pend->len[k] && a + cnt > pend->start[k];
+        hit |= a + cnt > LN_LBS - LN_LO;                               // (wraps round the ring: rare enough not to be worth the arithmetic)
+        if (hit) flush_pending();
+    };
     if (s.first) {
         const double mx = lnv_ring_absmax(R, 0, LN_ATT, lane);
         if (mx > ceiling) {
@@ -818,8 +849,7 @@ __device__ __forceinline__ void lnw_true_peak_limiter(double *ring, double *cach
                 } else lb = lnv_sustain_batch(R.cache + smp_cnt, Rb, ceiling, s.gr1, lane, &lprev, &hn, &hv);
                 n_first = Rb - lb + 1;                                                  // (nothing detected in (l, Rb])
                 if (lb > 0) {
-                    const double g = s.gr1;
-                    lnv_ring_scale(R, s.env_index, lb, [&](int) { return g; }, lane);
+                    sustain_scale(s.env_index, lb, s.gr1);
                     s.prev_smp = fabs(R.cache[smp_cnt + lb]);
                     s.peak_index = ln_mod(s.lbi + smp_cnt + LN_ATT + lb);
                     s.env_index = (s.env_index + lb) % LN_LBS; s.env_cnt = lb - lprev; smp_cnt += lb;
@@ -862,7 +892,8 @@ __device__ __forceinline__ void lnw_true_peak_limiter(double *ring, double *cach
         case LIM_ATTACK: {
             int cnt = s.attack_length - s.env_cnt; if (cnt > nb - smp_cnt) cnt = nb - smp_cnt; if (cnt < 0) cnt = 0;
             const double g0 = s.gr0, g1 = s.gr1; const int c0 = s.env_cnt, al = s.attack_length;
-            if (!seg_keeps_bitmap(cnt)) bm_ok = false;
+            if (!seg_keeps_bitmap(cnt)) { bm_ok = false; flush_pending(); }
+            before_immediate(s.env_index, cnt);
             lnv_ring_scale(R, s.env_index, cnt, [&](int j) { return g0 - ((double)(c0 + j) / (al - 1) * (g0 - g1)); }, lane);
             s.env_index = (s.env_index + cnt) % LN_LBS; s.env_cnt += cnt; smp_cnt += cnt;
             if (smp_cnt < nb) { s.env_cnt = 0; s.attack_length = LN_ATT; s.state = LIM_SUSTAIN; }
@@ -877,23 +908,32 @@ __device__ __forceinline__ void lnw_true_peak_limiter(double *ring, double *cach
                 break;
             }
             int cnt = pd; if (cnt > nb - smp_cnt) cnt = nb - smp_cnt; if (cnt < 0) cnt = 0;
-            const double g = s.gr1;
-            if (!seg_keeps_bitmap(cnt)) bm_ok = false;
-            lnv_ring_scale(R, s.env_index, cnt, [&](int) { return g; }, lane);
+            if (!seg_keeps_bitmap(cnt)) { bm_ok = false; flush_pending(); }
+            sustain_scale(s.env_index, cnt, s.gr1);
             s.env_index = (s.env_index + cnt) % LN_LBS; s.env_cnt = cnt; smp_cnt += cnt;
             break; }
         case LIM_RELEASE: {
             int cnt = LN_REL - s.env_cnt; if (cnt > nb - smp_cnt) cnt = nb - smp_cnt; if (cnt < 0) cnt = 0;
             const double g0 = s.gr0, g1 = s.gr1; const int c0 = s.env_cnt;
-            if (!seg_keeps_bitmap(cnt)) bm_ok = false;
+            if (!seg_keeps_bitmap(cnt)) { bm_ok = false; flush_pending(); }
+            before_immediate(s.env_index, cnt);
             lnv_ring_scale(R, s.env_index, cnt, [&](int j) { return g0 + (((double)(c0 + j) / (LN_REL - 1)) * (g1 - g0)); }, lane);
             s.env_index = (s.env_index + cnt) % LN_LBS; s.env_cnt += cnt; smp_cnt += cnt;
             if (smp_cnt < nb) { s.env_cnt = 0; s.state = LIM_OUT; }
             break; }
         }
     } while (smp_cnt < nb);
+    if (lane == 0) pend->n = npend;
     }
     __syncthreads();
+    {   // the pending SUSTAIN segments, all waves (disjoint stretches of the window: any order among them gives the same products)
+        const int np = pend->n;
+        for (int k = 0; k < np; ++k) {
+            const int st = pend->start[k], len = pend->len[k]; const double g = pend->g[k];
+            for (int j = tid; j < len; j += LN_WG) cache[st + j] *= g;
+        }
+        if (np) __syncthreads();
+    }
 #ifdef JT_LN_PROFILE
     lnp_a_ = clock64(); if (tid == 0) lnp_acc[2] += lnp_a_ - lnp_b_;
 #endif
@@ -936,6 +976,7 @@ k_loudnorm_dynamic_wg(const double *__restrict__ x, int64_t n, LoudnormDynParams
     extern __shared__ double ln_cache[];                            // [LN_CACHE]; the output meter's tile aliases its head
     __shared__ double delta[30], w[21], oe[30];
     __shared__ unsigned char hot[LN_LBS / 64];
+    __shared__ LnPending ln_pend;
     __shared__ unsigned long long ln_bm[LN_BMW];                    // the frame's detected peaks (lnw_build_bitmap)
     double *tile = ln_cache;
     const int tid = threadIdx.x;
@@ -1010,7 +1051,7 @@ k_loudnorm_dynamic_wg(const double *__restrict__ x, int64_t n, LoudnormDynParams
             s.lbi = 0;
             lnw_ring_fill(ring, 0, fsrc, P.final_len, LN_LBS, [&](double v, int) { return v * gain * offset; }, tid, hot, ceiling);
         }
-        lnw_true_peak_limiter(ring, ln_cache, hot, s, y + produced, nb, ceiling, tid, P.no_batch != 0, ln_bm);
+        lnw_true_peak_limiter(ring, ln_cache, hot, s, y + produced, nb, ceiling, tid, P.no_batch != 0, ln_bm, &ln_pend);
         if (it == 0) {
             s.first = false;
             if (!above) out_energy(y, LN_F100);
