@@ -517,7 +517,11 @@ namespace {
 #define JT_MD5_STEP(f, a, b, c, d, x, t, s) do { (a) += f((b), (c), (d)) + (x) + (t); (a) = ((a) << (s)) | ((a) >> (32 - (s))); (a) += (b); } while (0)
 #define JT_F1(x, y, z) ((z) ^ ((x) & ((y) ^ (z))))
 #define JT_F2(x, y, z) JT_F1(z, x, y)
-#define JT_F3(x, y, z) ((x) ^ (y) ^ (z))
+// round 2 with G(b, c, d) = (b & d) | (c & ~d) taken apart: the two terms have no bit in common, so they may be ADDED, and (c & ~d) does
+// not involve b -- the value the previous step has just produced -- so it joins the sum off the chain: b -> and -> add -> rotate -> add
+// instead of b -> xor -> and -> xor -> add -> rotate -> add (the chain is all a single stream's MD5 is: +7 % measured)
+#define JT_MD5_STEP2(a, b, c, d, x, t, s) do { (a) += ((c) & ~(d)) + (x) + (t); (a) += ((b) & (d)); (a) = ((a) << (s)) | ((a) >> (32 - (s))); (a) += (b); } while (0)
+#define JT_F3(x, y, z) ((x) ^ ((y) ^ (z)))
 #define JT_F4(x, y, z) ((y) ^ ((x) | ~(z)))
 inline void md5_blocks(uint32_t st[4], const unsigned char *p, size_t nblocks)
 {
@@ -534,14 +538,14 @@ inline void md5_blocks(uint32_t st[4], const unsigned char *p, size_t nblocks)
         JT_MD5_STEP(JT_F1, c, d, a, b, w[10], 0xffff5bb1, 17); JT_MD5_STEP(JT_F1, b, c, d, a, w[11], 0x895cd7be, 22);
         JT_MD5_STEP(JT_F1, a, b, c, d, w[12], 0x6b901122, 7); JT_MD5_STEP(JT_F1, d, a, b, c, w[13], 0xfd987193, 12);
         JT_MD5_STEP(JT_F1, c, d, a, b, w[14], 0xa679438e, 17); JT_MD5_STEP(JT_F1, b, c, d, a, w[15], 0x49b40821, 22);
-        JT_MD5_STEP(JT_F2, a, b, c, d, w[1], 0xf61e2562, 5);  JT_MD5_STEP(JT_F2, d, a, b, c, w[6], 0xc040b340, 9);
-        JT_MD5_STEP(JT_F2, c, d, a, b, w[11], 0x265e5a51, 14); JT_MD5_STEP(JT_F2, b, c, d, a, w[0], 0xe9b6c7aa, 20);
-        JT_MD5_STEP(JT_F2, a, b, c, d, w[5], 0xd62f105d, 5);  JT_MD5_STEP(JT_F2, d, a, b, c, w[10], 0x02441453, 9);
-        JT_MD5_STEP(JT_F2, c, d, a, b, w[15], 0xd8a1e681, 14); JT_MD5_STEP(JT_F2, b, c, d, a, w[4], 0xe7d3fbc8, 20);
-        JT_MD5_STEP(JT_F2, a, b, c, d, w[9], 0x21e1cde6, 5);  JT_MD5_STEP(JT_F2, d, a, b, c, w[14], 0xc33707d6, 9);
-        JT_MD5_STEP(JT_F2, c, d, a, b, w[3], 0xf4d50d87, 14); JT_MD5_STEP(JT_F2, b, c, d, a, w[8], 0x455a14ed, 20);
-        JT_MD5_STEP(JT_F2, a, b, c, d, w[13], 0xa9e3e905, 5); JT_MD5_STEP(JT_F2, d, a, b, c, w[2], 0xfcefa3f8, 9);
-        JT_MD5_STEP(JT_F2, c, d, a, b, w[7], 0x676f02d9, 14); JT_MD5_STEP(JT_F2, b, c, d, a, w[12], 0x8d2a4c8a, 20);
+        JT_MD5_STEP2(a, b, c, d, w[1], 0xf61e2562, 5);  JT_MD5_STEP2(d, a, b, c, w[6], 0xc040b340, 9);
+        JT_MD5_STEP2(c, d, a, b, w[11], 0x265e5a51, 14); JT_MD5_STEP2(b, c, d, a, w[0], 0xe9b6c7aa, 20);
+        JT_MD5_STEP2(a, b, c, d, w[5], 0xd62f105d, 5);  JT_MD5_STEP2(d, a, b, c, w[10], 0x02441453, 9);
+        JT_MD5_STEP2(c, d, a, b, w[15], 0xd8a1e681, 14); JT_MD5_STEP2(b, c, d, a, w[4], 0xe7d3fbc8, 20);
+        JT_MD5_STEP2(a, b, c, d, w[9], 0x21e1cde6, 5);  JT_MD5_STEP2(d, a, b, c, w[14], 0xc33707d6, 9);
+        JT_MD5_STEP2(c, d, a, b, w[3], 0xf4d50d87, 14); JT_MD5_STEP2(b, c, d, a, w[8], 0x455a14ed, 20);
+        JT_MD5_STEP2(a, b, c, d, w[13], 0xa9e3e905, 5); JT_MD5_STEP2(d, a, b, c, w[2], 0xfcefa3f8, 9);
+        JT_MD5_STEP2(c, d, a, b, w[7], 0x676f02d9, 14); JT_MD5_STEP2(b, c, d, a, w[12], 0x8d2a4c8a, 20);
         JT_MD5_STEP(JT_F3, a, b, c, d, w[5], 0xfffa3942, 4);  JT_MD5_STEP(JT_F3, d, a, b, c, w[8], 0x8771f681, 11);
         JT_MD5_STEP(JT_F3, c, d, a, b, w[11], 0x6d9d6122, 16); JT_MD5_STEP(JT_F3, b, c, d, a, w[14], 0xfde5380c, 23);
         JT_MD5_STEP(JT_F3, a, b, c, d, w[1], 0xa4beea44, 4);  JT_MD5_STEP(JT_F3, d, a, b, c, w[4], 0x4bdecfa9, 11);
