@@ -68,6 +68,8 @@ def test_pool_finishers_write_the_files_the_calling_thread_writes(engine, oracle
         for batch in range(2):
             failed, res, dev = pool.process_files(paths, md5=md5)
             assert failed == 0
+            st = pool.stats()                          # jt_handle_pool_stats: per-file means of the batch just run
+            assert st["passes"] > 0 and st["decode"] > 0 and st["write"] > 0 and (st["md5"] > 0) == md5
             for k in range(7):
                 img = open(res[k].output_path.decode(), "rb").read()
                 assert res[k].rc == 0 and res[k].result.output_lufs == want[k][0] and img == want[k][1], (batch, k)
