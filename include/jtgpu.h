@@ -80,7 +80,8 @@ void jt_end_job(jt_ctx *h);
  *   process-wide (h == NULL): graveyard_gb (gigabytes of superseded buffers parked before they are freed, default 24, 0 = free at
  *     once), poison_alloc (fill every new device allocation with 0xFF bytes; test switch), pool_streams (HIP streams per handle of a
  *     handle pool with three or more handles per device: default 1, see jt_open_ex), pool_blocking_sync (those handles' host waits
- *     sleep instead of spinning: default 1), host_timing.  Each library flavour (libjtgpu.so, libjtgpu_ab.so) keeps its own copy.
+ *     sleep instead of spinning: default 1), host_timing, early_temp_min_kb (jt_process_file creates, reserves and maps its temporary
+ *     output while the passes run when the output is expected to reach this size: default 32768 = 32 MiB).  Each library flavour (libjtgpu.so, libjtgpu_ab.so) keeps its own copy.
  * Superseded kernel generations and tuning knobs (nlm_old, afftdn_old, adeclick_fused, dyn_one_wave, kw_two_sweeps, follow_tiles,
  * dk_waves, ...) exist only in the A/B build of the library (make ab -> libjtgpu_ab.so, jt_build_flags() & 1): the default build
  * answers JT_E_UNSUPPORTED for them, an unknown key or a malformed value is JT_E_INVAL.

@@ -1584,7 +1584,7 @@ int file_front(jt_ctx *h, const char *input_path, const jt_host_config *base, in
     if (io_ms) io_ms[1] = wall_ms() - t;
     {
         const size_t est = (size_t)((double)meta.frames * 44100.0 / (double)std::max(1, meta.sample_rate) * 2.0 * 0.48) + ((size_t)1 << 20);
-        if (est >= ((size_t)32 << 20) && !g_fault_create_temp) { tail->pre = std::make_shared<PreTemp>(); tail->pre->start(input_path, est); }
+        if (est >= ((size_t)jt_early_temp_min_kb().load() << 10) && !g_fault_create_temp) { tail->pre = std::make_shared<PreTemp>(); tail->pre->start(input_path, est); }
     }
     rc = process_audio_impl(h, base, frame_samples, cb, user, out, (flac_flags & JT_FILE_PROGRESS_TICKS) != 0);
     if (rc != JT_OK) { tail->pre.reset(); return rc; }

@@ -164,3 +164,55 @@ def test_dynamic_loudnorm_batched_limiter_on_awkward_streams(engine, seed, level
         engine.set_option("ln_no_batch", False)
     got, gst = engine.op_loudnorm_dynamic(x, target_tp=tp, offset=off)
     assert np.array_equal(got, want) and gst == wst
+
+
+def _noise_flac(engine, d, seconds):
+    rng = np.random.default_rng(99)
+    pcm = np.clip(np.rint(rng.standard_normal(int(seconds * SR)) * 6000), -32768, 32767).astype(np.int16)
+    p = os.path.join(str(d), "r5_noise.flac")
+    with open(p, "wb") as f:
+        f.write(engine.op_flac_encode(pcm, SR, md5=True))
+    return p
+
+
+def test_the_early_temporary_file_gives_the_late_ones_bytes_and_leaves_no_residue(engine, tmp_path):
+    """jt_process_file creates, reserves (0.48 x the 44.1 kHz s16 size + 1 MiB) and maps its ".processing-*" file while the passes run
+    when the output will be large; early_temp_min_kb = 0 brings short files onto that path.  Speech (the estimate holds: mapped copy +
+    truncate) and a minute of white noise (the FLAC is twice the estimate: the mapping is dropped, the reserved file extended and
+    written) come out byte-identical to the files the ordinary path writes, alone and through a pool; the three injected failures
+    (file_write.go:13-53, processor_test.go:552-627) and a cancelled job leave nothing beside the inputs."""
+    paths = _flacs(engine, tmp_path, 2, 15.0) + [_noise_flac(engine, tmp_path, 60.0)]
+    before = sorted(os.listdir(str(tmp_path)))
+    want = []
+    for p in paths:
+        res, out_path, _ = H.process_file(engine, p, md5=True)
+        want.append(open(out_path, "rb").read()); os.unlink(out_path)
+    assert len(want[2]) > 0.48 * 2 * 60 * 44100 + (1 << 20)                 # (the under-estimated one)
+    L.set_global_option("early_temp_min_kb", 0)
+    try:
+        for k, p in enumerate(paths):
+            for md5 in (True, False):
+                res, out_path, _ = H.process_file(engine, p, md5=md5)
+                img = open(out_path, "rb").read(); os.unlink(out_path)
+                assert img[:26] == want[k][:26] and img[42:] == want[k][42:] and (img[26:42] == want[k][26:42]) == md5, (k, md5)
+        with H.Pool(devices=(0,), in_flight_per_device=3) as pool:
+            failed, res, _ = pool.process_files(paths, md5=True)
+            assert failed == 0
+            for k in range(3):
+                assert open(res[k].output_path.decode(), "rb").read() == want[k]
+                os.unlink(res[k].output_path.decode())
+            for fault in (dict(create_temp=1), dict(write=1), dict(rename=1)):
+                H.inject_fault(**fault)
+                try:
+                    failed, res, _ = pool.process_files(paths)
+                    with pytest.raises(L.JtError):
+                        H.process_file(engine, paths[0])
+                finally:
+                    H.inject_fault()
+                assert failed == 3 and sorted(os.listdir(str(tmp_path))) == before, fault
+        cfg = H.default_config(); cfg.adeclick_method_s = 7                 # the passes fail after the early file was started
+        with pytest.raises(L.JtError):
+            H.process_file(engine, paths[0], base=cfg)
+        assert sorted(os.listdir(str(tmp_path))) == before
+    finally:
+        L.set_global_option("early_temp_min_kb", 32768)
