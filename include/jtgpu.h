@@ -74,7 +74,8 @@ void jt_end_job(jt_ctx *h);
  *     tp_unpruned (ebur128's true peak by the exhaustive kernels: what the branch-and-bound path is tested against), tp_prune_min
  *     (integer: the shortest signal, in samples, that takes the branch-and-bound path; default 1048576), brickwall_f64 (Pass 4's
  *     brickwall as doubles + a dbl -> flt -> s16 sweep instead of writing the float and the s16 itself), ln_no_batch (dynamic-mode
- *     loudnorm: the limiter's harmless peaks one detector call at a time instead of a frame's worth in one step; same bytes)
+ *     loudnorm: the limiter's harmless peaks one detector call at a time instead of a frame's worth in one step; same bytes),
+ *     ln_no_stream (dynamic-mode loudnorm: every frame through the one-workgroup kernel instead of the data-parallel stream path; same bytes)
  *   diagnostics: host_timing (host-stage timings on stderr; PROCESS-WIDE although it is set through a handle: the host stages are
  *     plain functions without one, the last writer wins for every handle of the process)
  *   process-wide (h == NULL): graveyard_gb (gigabytes of superseded buffers parked before they are freed, default 24, 0 = free at
@@ -321,7 +322,9 @@ typedef struct { double pass1_ms, pass2_ms, pass3_ms, pass4_ms; double nlm_ms; i
                  double declick_ms;          /* adeclick kernel time in the last Pass 4 */
                  int64_t declick_heavy_windows; /* windows that needed the full-capacity second pass */
                  int64_t tp_units_total,     /* last long analysis, branch-and-bound true peak: units of the signal ... */
-                         tp_units_evaluated; /* ... and those whose 192 kHz outputs were evaluated (seeds + kept units) */ } jt_timers;
+                         tp_units_evaluated; /* ... and those whose 192 kHz outputs were evaluated (seeds + kept units) */
+                 int64_t ln_stream_frames,   /* last dynamic-mode loudnorm: 100 ms frames its data-parallel stream path covered ... */
+                         ln_stream_why;      /* ... and why its last attempt ended (0: ran to the last full frame) */ } jt_timers;
 int jt_get_timers(jt_ctx *h, jt_timers *out);
 
 /* =====================================================================================

@@ -98,7 +98,8 @@ class Timers(C.Structure):
     _fields_ = [("pass1_ms", C.c_double), ("pass2_ms", C.c_double), ("pass3_ms", C.c_double),
                 ("pass4_ms", C.c_double), ("nlm_ms", C.c_double), ("nlm_launches", C.c_int64),
                 ("declick_repaired", C.c_int64), ("declick_ms", C.c_double), ("declick_heavy_windows", C.c_int64),
-                ("tp_units_total", C.c_int64), ("tp_units_evaluated", C.c_int64)]
+                ("tp_units_total", C.c_int64), ("tp_units_evaluated", C.c_int64),
+                ("ln_stream_frames", C.c_int64), ("ln_stream_why", C.c_int64)]
 
 
 class FlacInfo(C.Structure):

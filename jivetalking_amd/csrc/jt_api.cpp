@@ -1415,15 +1415,31 @@ static void loudnorm_dynamic_run(jt_ctx *h, double *x, int64_t m, const Loudnorm
         for (int i = 0; i < 21; i++) P.weights[i] *= adjust;
     }
     jt_kweight_coeffs5(192000, P.kwb, P.kwa);
-    P.dual_mono = in.dual_mono ? 1 : 0; P.n_inner = n_inner; P.final_len = FINAL; P.no_batch = h->opts.ln_no_batch ? 1 : 0;
+    P.dual_mono = in.dual_mono ? 1 : 0; P.n_inner = n_inner; P.final_len = FINAL; P.no_batch = h->opts.ln_no_batch ? 1 : 0; P.stream_stop = h->opts.ln_stream_stop;
     h->ln_ring.ensure(LBS); h->ln_series.ensure(series.size());
     JT_HIP(hipMemcpyAsync(h->ln_series.p, series.data(), series.size() * sizeof(double), hipMemcpyHostToDevice, s));
     // (the workgroup kernel runs as a sequence of launches of a few milliseconds each on the main stream: a launch that lasts a second
     // holds up every other handle's stream that shares its hardware queue, k_loudnorm.hip)
     h->ln_carry.ensure(256);
-    launch_loudnorm_dynamic(x, m, P, h->ln_series.p, h->ln_ring.p, y, nullptr, s, h->ln_carry.p, h->opts);
+    // the stream path's scratch (k_loudnorm.hip): ~0.7 bytes per 192 kHz sample
+    LnsBufs lns{}; const bool stream = !h->opts.ln_no_stream && !h->opts.ln_no_batch && n_inner > 128;
+    if (stream) {
+        h->ln_scratch.ensure(jt_lns_scratch_bytes(m, n_inner, nullptr, nullptr));
+        jt_lns_scratch_bytes(m, n_inner, &lns, h->ln_scratch.p);
+        JT_HIP(hipMemsetAsync(lns.ctl, 0, sizeof(LnsCtl), s));
+    }
+    launch_loudnorm_dynamic(x, m, P, h->ln_series.p, h->ln_ring.p, y, nullptr, s, h->ln_carry.p, h->opts, stream ? &lns : nullptr);
     JT_HIP(hipGetLastError());
     finish_stats(bs, nfull_ext, peak, true);
+    h->timers.ln_stream_frames = 0; h->timers.ln_stream_why = 0;
+    if (stream) {
+        // (diagnostic; the stream has been waited for)  frames the stream path covered, and why its last attempt stopped where it did
+        h->io_small.begin(256);
+        LnsCtl *c = h->io_small.take<LnsCtl>(1);
+        JT_HIP(hipMemcpyAsync(c, lns.ctl, sizeof(LnsCtl), hipMemcpyDeviceToHost, s));
+        JT_HIP(jt_stream_sync(h, s));
+        h->timers.ln_stream_frames = c->frames; h->timers.ln_stream_why = c->why;
+    }
 }
 
 // ---------------------------------------------------------------- Pass 4

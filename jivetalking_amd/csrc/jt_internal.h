@@ -99,8 +99,8 @@ template <typename T> struct DevBuf {
 // that build imports JT_<KEY> variables, once, inside jt_open.
 #define JT_OPT_BOOLS(X) \
     X(no_pass2_prefetch) X(no_early_pass3) X(no_early_plan) X(no_lim_keep) X(no_staged_finish) X(no_r128_first) \
-    X(region_full_astats) X(host_timing) X(adeclick_exact) X(nlm_generic) X(p3_unfused) X(limiter_lanes) X(tp_unpruned) X(no_spec_direct) X(brickwall_f64) X(nf_low) X(ln_no_batch)
-#define JT_OPT_INTS(X) X(region_rot) X(tp_prune_min)
+    X(region_full_astats) X(host_timing) X(adeclick_exact) X(nlm_generic) X(p3_unfused) X(limiter_lanes) X(tp_unpruned) X(no_spec_direct) X(brickwall_f64) X(nf_low) X(ln_no_batch) X(ln_no_stream)
+#define JT_OPT_INTS(X) X(region_rot) X(tp_prune_min) X(ln_stream_stop)
 #define JT_OPT_AB_BOOLS(X) \
     X(nlm_old) X(afftdn_old) X(adeclick_fused) X(dk_levinson_in_kernel) X(dk_no_xcd) X(dk_serial) X(dk_profile) X(dyn_one_wave) \
     X(dyn_no_cu_reserve) X(kw_two_sweeps) X(follow_tiles) X(follow_one_wave) X(tp_old) X(lim_profile) X(ups_no_stream8) X(ups_no_stream16) X(edge_polyphase) X(no_lim_s16)
@@ -113,6 +113,7 @@ struct JtOpts {
     JT_OPT_AB_INTS(X)
 #undef X
     int tp_prune_min = 1 << 20;          // signals at least this long take the branch-and-bound true peak (k_resample.hip); shorter ones the exhaustive kernels
+    int ln_stream_stop = 0;              // test switch: the dynamic mode's stream path ends an attempt before every frame whose number is a multiple of this (as its ring-end corner does)
     int region_rot = -1;                 // -1: the announced regions' chains on adeclick's second stream; r: region chain i behind full chain (i + r) % 4
 };
 #ifdef JT_AB
@@ -256,13 +257,20 @@ struct LoudnormDynParams {
     double weights[21], kwb[5], kwa[5];
     int above0, dual_mono;
     int64_t n_inner; int final_len;
+    int stream_stop;   // option ln_stream_stop (test switch)
     int no_batch;      // option ln_no_batch: the limiter's harmless peaks one detector call at a time (what the batched step is tested against)
 };
 void jt_loudnorm_series(const double *bs, int64_t nfull, int64_t s100, bool dual_mono, int64_t n_inner, double *out);
 void jt_kweight_coeffs5(int sr, double b[5], double a[5]);
+// the stream path of the dynamic mode (k_loudnorm.hip): an envelope segment the limiter's state machine decided on, the control block
+// the kernels of one attempt share, and the scratch they work in (jt_lns_scratch_bytes carves one allocation)
+struct LnsSeg { long long t; int len, kind, c0, al; double g0, g1; };                 // kind: 0 constant g0, 1 attack ramp, 2 release ramp; +256: second layer
+struct LnsCtl { int active, ok, ka, kbe, npk, nseg, why, attempts; long long frames; };   // why: 1 state not in its steady form, 2 peak list full, 3 segment list full, 4 ring-end corner
+struct LnsBufs { LnsCtl *ctl; double *G, *Gn, *E; unsigned long long *bm; unsigned short *woff; int *bcnt, *boff; long long *pk_t; double *pk_v; LnsSeg *seg; int pk_cap, seg_cap; };
+size_t jt_lns_scratch_bytes(int64_t n, int64_t n_inner, LnsBufs *B, unsigned char *base);
 // carry: LN_CARRY = 256 doubles of device memory (the state one launch of the workgroup kernel hands to the next)
 void launch_loudnorm_dynamic(const double *x, int64_t n, const LoudnormDynParams &P, const double *series, double *ring, double *y, double *dbg, hipStream_t s,
-                             double *carry, const JtOpts &o);
+                             double *carry, const JtOpts &o, const LnsBufs *stream = nullptr);
 void launch_scale_f64(const double *in, double *out, int64_t n, double g, hipStream_t s);
 void launch_swr_plain_f64(const double *in, int64_t n, const double *bank, int P, int L, int center, int64_t step, int64_t m_total, double *out, hipStream_t s);
 void launch_adeclick(jt_ctx *h, const double *in, double *out, int64_t n, int sample_rate, double threshold, double window_ms,
@@ -397,6 +405,7 @@ struct jt_ctx {
     // (set by pass3_core, dropped by anything that rewrites the Pass-2 output or the f64 buffers)
     struct LimKeep { bool valid = false; const int16_t *src = nullptr; int64_t m = 0; int rate = 0; double pre_gain_db = 0, limit = 0; } lim_keep;
     DevBuf<float> stream_f; DevBuf<double> stream_d;   // 192 kHz loudnorm-measurement stream
+    DevBuf<unsigned char> ln_scratch;                             // loudnorm dynamic mode, stream path: LnsBufs
     DevBuf<double> stream_y, ln_ring, ln_series, ln_carry;       // loudnorm dynamic mode: output stream, limiter ring, per-frame series
     // scratch
     DevBuf<double> d_scr0, d_scr1, d_scr2, d_scr3;

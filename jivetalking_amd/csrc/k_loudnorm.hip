@@ -980,6 +980,12 @@ k_loudnorm_dynamic_wg(const double *__restrict__ x, int64_t n, LoudnormDynParams
     __shared__ unsigned long long ln_bm[LN_BMW];                    // the frame's detected peaks (lnw_build_bitmap)
     double *tile = ln_cache;
     const int tid = threadIdx.x;
+    if (it_begin > 0) {
+        // carry[84] = the next step to run: the stream path (below) may have covered this launch's steps, or some of them, meanwhile
+        const int64_t next_it = (int64_t)carry[84];
+        if (it_end <= next_it) return;
+        if (it_begin < next_it) it_begin = next_it;
+    }
     const bool fresh = it_begin == 0;
     if (tid < 30) { delta[tid] = fresh ? P.delta0 : carry[16 + tid]; oe[tid] = fresh ? 0.0 : carry[46 + tid]; }
     if (tid < 21) w[tid] = P.weights[tid];
@@ -1098,6 +1104,7 @@ k_loudnorm_dynamic_wg(const double *__restrict__ x, int64_t n, LoudnormDynParams
         carry[10] = index; carry[11] = above; carry[12] = prev_delta; carry[13] = oe_pos;
         carry[76] = kv1; carry[77] = kv2; carry[78] = kv3; carry[79] = kv4;
         carry[80] = (double)produced; carry[81] = (double)abs_in; carry[82] = (double)src_index; carry[83] = gain_final;
+        carry[84] = (double)min<int64_t>(total, it_end);
     }
     if (tid < 30) { carry[16 + tid] = delta[tid]; carry[46 + tid] = oe[tid]; }
     for (int k = tid; k < LN_LBS / 64; k += LN_WG) reinterpret_cast<unsigned char *>(carry + 96)[k] = hot[k];
@@ -1105,6 +1112,393 @@ k_loudnorm_dynamic_wg(const double *__restrict__ x, int64_t n, LoudnormDynParams
     __syncthreads();
     if (tid < 16) g_ln_prof[tid] = lnp_acc[tid];
 #endif
+}
+
+// =====================================================================================================================
+// Round 5, the STREAM PATH: the steady state of the dynamic mode as data-parallel sweeps around a state machine that touches no samples.
+//
+// Once the "not yet above threshold" phase is over (above_threshold is a latch) nothing the limiter does feeds back into the frame gains:
+// delta[k] is a function of the INPUT meter's series alone.  And between the first frame's special case and the flush the limiter's ring
+// is a sliding window over ONE linear stream L[t] = x[t] * gain(t) * offset: ring position = t mod 40320, the envelope position is always
+// the scan position (10 ms ahead of the output position), every detector call reads samples no envelope has reached yet.  So for the
+// full INNER frames [ka, kb) after a launch of the workgroup kernel has handed its state over:
+//   k_lns_begin    the frame gains of all those frames (the candidate deltas side by side, the "keep the previous one" chain by one thread)
+//   k_lns_fill     L into the OUTPUT buffer, whole GPU (the ring's current 110 ms are copied in front of it: they may carry envelope already)
+//   k_lns_bitmap / _scan / _scatter   the detected peaks of L -- a pure function of the samples (lnv_sustain_batch's comment) -- as a
+//                  sorted list (time, magnitude)
+//   k_lns_machine  ONE wave walks af_loudnorm's OUT / ATTACK / SUSTAIN / RELEASE machine frame by frame over that LIST (64 entries at a
+//                  time in registers) and writes the envelope segments it decides on to a second list: no sample is read or written
+//   k_lns_apply    the segments multiplied into L, whole GPU.  A sample is multiplied at most twice -- by the tail of a RELEASE and then
+//                  by the head of the ATTACK of a peak detected less than 10 ms after the release ended -- and floating-point products
+//                  do not commute, so those attacks are a second layer applied after everything else
+//   k_lns_finish   clamp, and the window the next frame needs goes back into the ring for the workgroup kernel (last partial frame, flush)
+// What the list cannot know: a detector call of SUSTAIN that starts in a frame's last ten samples and finds nothing for 100 ms reads up to
+// 11 samples PAST the ring's 210 ms -- the filter wraps to the frame's first samples, which the envelope has already edited.  The machine
+// checks that corner (is any sample of those last twelve above the ceiling?) and, if so, stops BEFORE that frame: what it has is
+// committed, the workgroup kernel carries on from there, and a later attempt takes over again.  Same for a full segment or peak list.
+// Everything is enqueued without a host round trip: every kernel of an attempt looks at the control block the first one fills.
+constexpr int LNS_BW = 64;                                   // bitmap words per block of k_lns_bitmap (4096 samples)
+__device__ __forceinline__ long long lns_rl64(long long v, int l)
+{
+    return ((long long)__builtin_amdgcn_readlane((int)(v >> 32), l) << 32) | (unsigned)__builtin_amdgcn_readlane((int)v, l);
+}
+__global__ void __launch_bounds__(256)
+k_lns_begin(const double *__restrict__ carry, const double *__restrict__ series, LoudnormDynParams P, LnsBufs B, int ka, int kb)
+{
+    __shared__ int go;
+    __shared__ double chunk[256];
+    __shared__ double w[21];
+    __shared__ double prev_s;
+    const int tid = threadIdx.x;
+    if (tid == 0) {
+        LnsCtl *c = B.ctl;
+        const int lbi = (int)carry[3], state = (int)carry[4];
+        bool ok = carry[84] == (double)(ka + 1) && carry[11] == 1.0 && carry[9] == 0.0;
+        ok = ok && lbi == (int)(((long long)ka * LN_F100) % LN_LBS);                             // (the frame's fill advances it to its output position)
+        if (state != LIM_OUT) ok = ok && (int)carry[6] == (lbi + LN_F100 + LN_ATT) % LN_LBS;     // the envelope stands at the scan position
+        if (state != LIM_ATTACK) ok = ok && (int)carry[8] == LN_ATT;
+        c->active = ok ? 1 : 0; c->ok = 0; c->ka = ka; c->kbe = ka; c->npk = 0; c->nseg = 0; c->why = ok ? 0 : 1; c->attempts += 1;
+        go = ok ? 1 : 0;
+        prev_s = carry[12];
+    }
+    if (tid < 21) w[tid] = P.weights[tid];
+    __syncthreads();
+    if (!go) return;
+    const int index = (int)carry[10], nf = kb - ka;
+    if (tid < 30) B.E[tid] = carry[16 + (index + tid) % 30];                                  // the 30 most recent deltas, oldest first
+    // delta[k]: the INNER_FRAME branch of the workgroup kernel with above == 1 (a candidate, or "keep the previous one")
+    for (int j0 = 0; j0 < nf; j0 += 256) {
+        const int j = j0 + tid;
+        double d = -1.0;
+        if (j < nf) {
+            const int k = ka + j;
+            const double shortterm = series[3 * (long long)k], global = series[3 * (long long)k + 1], relthr = series[3 * (long long)k + 2];
+            if (!(shortterm < relthr || shortterm <= -70.)) {
+                const double env_global = fabs(shortterm - global) < (P.target_lra / 2.) ? shortterm - global
+                                                                                         : (P.target_lra / 2.) * ((shortterm - global) < 0 ? -1 : 1);
+                const double env_shortterm = P.target_i - shortterm;
+                d = pow(10., (env_global + env_shortterm) / 20.);
+            }
+        }
+        chunk[tid] = d;
+        __syncthreads();
+        if (tid == 0) {
+            double prev = prev_s;
+            const int m = min(256, nf - j0);
+            for (int q = 0; q < m; ++q) { double v = chunk[q]; if (v < 0.0) v = prev; chunk[q] = v; prev = v; }
+            prev_s = prev;
+        }
+        __syncthreads();
+        if (j < nf) B.E[30 + j] = chunk[tid];
+        __syncthreads();
+    }
+    __threadfence();
+    __syncthreads();
+    // gain / gain_next of frame ka + j: ln_gaussian over the ring as it stands BEFORE the frame = E[j .. j + 30), start at its oldest entry
+    for (int j = tid; j < nf; j += 256) {
+        double g = 0., gn = 0.;
+        for (int i = 0; i < 21; i++) g += B.E[j + i] * w[i];
+        for (int i = 0; i < 21; i++) gn += B.E[j + 1 + i] * w[i];
+        B.G[ka + j] = g; B.Gn[ka + j] = gn;
+    }
+}
+// L[t] for the fills of frames [ka, kb) (frame k fills t = LBS + k F100 + j with the ramp from gain to gain_next), and in front of it the
+// ring as the workgroup kernel left it: t in [(ka + 1) F100, (ka + 1) F100 + LBS - F100)
+__global__ void __launch_bounds__(256)
+k_lns_fill(const double *__restrict__ x, double *__restrict__ y, const double *__restrict__ ring, LnsBufs B, int ka, int kb, double offset)
+{
+    if (!B.ctl->active) return;
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long nfill = (long long)(kb - ka) * LN_F100, nring = LN_LBS - LN_F100;
+    if (i < nfill) {
+        const int k = ka + (int)(i / LN_F100), j = (int)(i % LN_F100);
+        const int nb = LN_F100;
+        const double gain = B.G[k], gain_next = B.Gn[k];
+        const long long t = (long long)LN_LBS + (long long)ka * LN_F100 + i;
+        y[t] = x[t] * (gain + (((double)j / nb) * (gain_next - gain))) * offset;
+    } else if (i < nfill + nring) {
+        const long long t = (long long)(ka + 1) * LN_F100 + (i - nfill);
+        y[t] = ring[t % LN_LBS];
+    }
+}
+// detected peaks of L[tb0, tb1) as a bitmap (bit b of word w: t = 64 w + b), the words' popcounts as offsets inside their block of 64
+// words and the block's total; lnw_build_bitmap's test on the linear stream
+__global__ void __launch_bounds__(256)
+k_lns_bitmap(const double *__restrict__ y, LnsBufs B, long long tb0, long long tb1, double ceiling, long long blk0)
+{
+    if (!B.ctl->active) return;
+    __shared__ int wc[LNS_BW];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const long long blk = blk0 + blockIdx.x;
+    for (int i = 0; i < LNS_BW / 4; ++i) {
+        const int wl = wv * (LNS_BW / 4) + i;
+        const long long wd = blk * LNS_BW + wl, t = wd * 64 + lane;
+        const bool in = t >= tb0 && t < tb1;
+        const double v = in ? fabs(y[t]) : 0.0, a = in ? fabs(y[t - 1]) : 0.0, b = in ? fabs(y[t + 1]) : 0.0;
+        bool det = in & (v > ceiling) & (a <= v) & (b <= v);
+        if (__ballot(det)) {
+            double m = 0.0;
+            if (in) {
+                double u[10];
+#pragma unroll
+                for (int q = 0; q < 10; ++q) u[q] = y[t + 2 + q];
+#pragma unroll
+                for (int q = 0; q < 10; ++q) m = fmax(m, fabs(u[q]));
+            }
+            det = det && !(m > v);
+        }
+        const unsigned long long mk = __ballot(det);
+        if (lane == 0) { B.bm[wd] = mk; wc[wl] = __popcll(mk); }
+    }
+    __syncthreads();
+    if (tid < 64) {
+        const int c = wc[tid];
+        int incl = c;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_up(incl, d, 64); if (tid >= d) incl += o; }
+        B.woff[blk * LNS_BW + tid] = (unsigned short)(incl - c);
+        if (tid == 63) B.bcnt[blockIdx.x] = incl;
+    }
+}
+__global__ void __launch_bounds__(1024)
+k_lns_scan(LnsBufs B, int nblk)
+{
+    if (!B.ctl->active) return;
+    __shared__ int part[1024];
+    const int tid = threadIdx.x, per = (nblk + 1023) / 1024, lo = min(nblk, tid * per), hi = min(nblk, lo + per);
+    int sum = 0;
+    for (int q = lo; q < hi; ++q) sum += B.bcnt[q];
+    part[tid] = sum;
+    __syncthreads();
+    for (int d = 1; d < 1024; d <<= 1) { const int o = tid >= d ? part[tid - d] : 0; __syncthreads(); part[tid] += o; __syncthreads(); }
+    int run = part[tid] - sum;
+    for (int q = lo; q < hi; ++q) { B.boff[q] = run; run += B.bcnt[q]; }
+    if (tid == 1023) {
+        const int total = part[1023];
+        B.ctl->npk = total;
+        if (total > B.pk_cap) { B.ctl->active = 0; B.ctl->why = 2; }
+    }
+}
+__global__ void __launch_bounds__(256)
+k_lns_scatter(const double *__restrict__ y, LnsBufs B, long long blk0, int nblk)
+{
+    if (!B.ctl->active) return;
+    const long long q = (long long)blockIdx.x * 256 + threadIdx.x;                            // word of the range
+    if (q >= (long long)nblk * LNS_BW) return;
+    const long long wd = blk0 * LNS_BW + q;
+    unsigned long long m = B.bm[wd];
+    long long off = (long long)B.boff[q / LNS_BW] + B.woff[wd];
+    while (m) {
+        const long long t = wd * 64 + (__ffsll((long long)m) - 1);
+        m &= m - 1ull;
+        B.pk_t[off] = t; B.pk_v[off] = fabs(y[t]); ++off;
+    }
+}
+// the limiter's state machine over the peak list: lnw_true_peak_limiter's loop with the bitmap queries answered by the list and the ring
+// operations written down as segments.  Times are absolute sample positions; the frame with output position T0 scans from T0 + c + 1920
+// (c = the filter's smp_cnt), which is also where its envelope stands.
+__global__ void __launch_bounds__(64)
+k_lns_machine(double *__restrict__ carry, LoudnormDynParams P, LnsBufs B, const double *__restrict__ y, int ka, int kb)
+{
+    LnsCtl *ctl = B.ctl;
+    if (!ctl->active) return;
+    const int lane = threadIdx.x;
+    const long long npk = ctl->npk;
+    const double ceiling = P.target_tp_lin;
+    const int nb = LN_F100;
+    double gr0 = carry[0], gr1 = carry[1], prev_smp = carry[2];
+    int state = (int)carry[4], peak_index = (int)carry[5], env_cnt = (int)carry[7], att = (int)carry[8];
+    bool layer2 = false;
+    int nseg = 0;
+    // the list's window: entry wbase + lane in this lane's registers
+    long long wbase = 0, wt = 0; double wvv = 0.0; long long cur = 0;
+    const long long TINF = 0x7fffffffffffffffll;
+    auto refill = [&](long long b) { wbase = b; const long long i = b + lane; wt = i < npk ? B.pk_t[i] : TINF; wvv = i < npk ? B.pk_v[i] : 0.0; };
+    refill(0);
+    // cur := the first entry later than ts (cur never goes back: ts does not between detector calls)
+    auto advance = [&](long long ts) {
+        for (;;) {
+            if (cur >= wbase + 64 || cur < wbase) refill(cur);
+            const int off = (int)(cur - wbase);
+            const unsigned long long m = __ballot(wt > ts) & (~0ull << off);
+            if (m) { cur = wbase + (__ffsll((long long)m) - 1); return; }
+            cur = wbase + 64;
+        }
+    };
+    bool ovf = false;
+    auto emit = [&](int kind, long long t, int len, double g0, double g1, int c0, int al) {
+        if (len <= 0) return;
+        if (nseg >= B.seg_cap) { ovf = true; return; }
+        if (lane == 0) { LnsSeg sg; sg.t = t; sg.len = len; sg.kind = kind | (layer2 && kind == 1 ? 256 : 0); sg.c0 = c0; sg.al = al; sg.g0 = g0; sg.g1 = g1; B.seg[nseg] = sg; }
+        ++nseg;
+    };
+    int k = ka, why = 0;
+    for (; k < kb; ++k) {
+        if (P.stream_stop > 0 && k > ka && k % P.stream_stop == 0) { why = 5; break; }       // (test switch)
+        const long long T0 = (long long)(k + 1) * LN_F100;
+        // the frame is taken whole or not at all
+        const double s_gr0 = gr0, s_gr1 = gr1, s_prev = prev_smp; const int s_state = state, s_pi = peak_index, s_ec = env_cnt, s_att = att, s_nseg = nseg;
+        const bool s_l2 = layer2;
+        bool hazard = false;
+        int c = 0;
+        do {
+            const long long ts = T0 + c + LN_ATT;
+            switch (state) {
+            case LIM_OUT: {
+                // detect_peak(c, nb - c): the first detected peak among n = 1 .. nb - c - 1
+                advance(ts);
+                const int off = (int)(cur - wbase);
+                const long long e = lns_rl64(wt, off);
+                if (e <= ts + (nb - c) - 1) {
+                    const double pkv = ln_rl(wvv, off);
+                    const int pd = (int)(e - ts);
+                    prev_smp = pkv; peak_index = (int)(e % LN_LBS);
+                    env_cnt = 0;
+                    layer2 = pd < att;                                                          // the attack starts before the scan position: over a release's tail
+                    c += pd - att;
+                    gr0 = 1.; gr1 = ceiling / pkv;
+                    state = LIM_ATTACK;
+                } else c = nb;
+                break; }
+            case LIM_ATTACK: {
+                int cnt = att - env_cnt; if (cnt > nb - c) cnt = nb - c; if (cnt < 0) cnt = 0;
+                emit(1, ts, cnt, gr0, gr1, env_cnt, att);
+                env_cnt += cnt; c += cnt;
+                if (c < nb) { env_cnt = 0; att = LN_ATT; state = LIM_SUSTAIN; layer2 = false; }
+                break; }
+            case LIM_SUSTAIN: {
+                // the batch (lnv_sustain_batch_bm): the harmless peaks of [ts + 1, ts + Rb] in one segment, the first harmful one into ATTACK
+                const int Rb = min(nb - c, nb - 1);
+                long long l_t = -1, lp_t = -1, h_t = -1; double l_v = 0.0, h_v = 0.0;
+                advance(ts);
+                for (long long scan = cur;;) {
+                    if (scan >= wbase + 64 || scan < wbase) refill(scan);
+                    const int off = (int)(scan - wbase);
+                    const bool inr = wt <= ts + Rb && lane >= off;
+                    const bool harm = inr && (ceiling / wvv < gr1);                              // the filter's own comparison: gain_reduction < s->gain_reduction[1]
+                    const unsigned long long im = __ballot(inr), hm = __ballot(harm);
+                    const unsigned long long okm = hm ? im & ((1ull << (__ffsll((long long)hm) - 1)) - 1ull) : im;
+                    if (okm) {
+                        const int hi = 63 - __clzll((long long)okm);
+                        const unsigned long long rest = okm & ~(1ull << hi);
+                        lp_t = rest ? lns_rl64(wt, 63 - __clzll((long long)rest)) : l_t;
+                        l_t = lns_rl64(wt, hi); l_v = ln_rl(wvv, hi);
+                    }
+                    if (hm) { const int f = __ffsll((long long)hm) - 1; h_t = lns_rl64(wt, f); h_v = ln_rl(wvv, f); break; }
+                    if (im != (~0ull << off)) break;                                             // the range ends inside this window
+                    scan = wbase + 64;
+                }
+                const int lb = l_t >= 0 ? (int)(l_t - ts) : 0, lprev = lp_t >= 0 ? (int)(lp_t - ts) : 0;
+                if (lb > 0) {
+                    emit(0, ts, lb, gr1, 0., 0, 0);
+                    prev_smp = l_v; peak_index = (int)(l_t % LN_LBS);
+                    env_cnt = lb - lprev; c += lb;
+                }
+                if (h_t >= 0) {
+                    const int pdh = (int)(h_t - ts) - lb;
+                    prev_smp = h_v; peak_index = (int)(h_t % LN_LBS);
+                    state = LIM_ATTACK;
+                    att = pdh; if (att <= 1) att = 2;
+                    gr0 = gr1; gr1 = ceiling / h_v; env_cnt = 0;
+                    break;
+                }
+                if (c >= nb) break;
+                // the call from there scans n = 1 .. nb - 1: what lies behind the frame's remainder
+                const long long ts2 = T0 + c + LN_ATT, lim = ts2 + nb - 1, zone = T0 + LN_LBS - 12;
+                advance(ts + Rb);
+                const int off = (int)(cur - wbase);
+                const long long e = lns_rl64(wt, off);
+                bool found = e <= lim;
+                if (lim >= zone && !(found && e < zone)) {
+                    // the scan reaches the ring's last twelve samples, whose test reads past its end (the filter wraps to samples the
+                    // envelope has edited): only harmless when none of them can be a candidate at all
+                    const long long t = zone + lane;
+                    const bool hot = lane < 12 && t <= lim && t < T0 + LN_LBS && fabs(y[t]) > ceiling;
+                    if (__ballot(hot)) { hazard = true; break; }
+                    found = false;
+                }
+                if (found) {
+                    const double pkv = ln_rl(wvv, off);
+                    const int pd = (int)(e - ts2);
+                    prev_smp = pkv; peak_index = (int)(e % LN_LBS);
+                    const double gr = ceiling / pkv;
+                    if (gr < gr1) {
+                        state = LIM_ATTACK;
+                        att = pd; if (att <= 1) att = 2;
+                        gr0 = gr1; gr1 = gr; env_cnt = 0;
+                        break;
+                    }
+                    int cnt = pd; if (cnt > nb - c) cnt = nb - c; if (cnt < 0) cnt = 0;
+                    emit(0, ts2, cnt, gr1, 0., 0, 0);
+                    env_cnt = cnt; c += cnt;
+                } else { state = LIM_RELEASE; gr0 = gr1; gr1 = 1.; env_cnt = 0; }
+                break; }
+            case LIM_RELEASE: {
+                int cnt = LN_REL - env_cnt; if (cnt > nb - c) cnt = nb - c; if (cnt < 0) cnt = 0;
+                emit(2, ts, cnt, gr0, gr1, env_cnt, 0);
+                env_cnt += cnt; c += cnt;
+                if (c < nb) { env_cnt = 0; state = LIM_OUT; }
+                break; }
+            }
+        } while (c < nb);
+        if (hazard || ovf) {
+            gr0 = s_gr0; gr1 = s_gr1; prev_smp = s_prev; state = s_state; peak_index = s_pi; env_cnt = s_ec; att = s_att; nseg = s_nseg; layer2 = s_l2;
+            why = ovf ? 3 : 4;
+            break;
+        }
+    }
+    const int kbe = k;
+    if (lane == 0) { ctl->kbe = kbe; ctl->nseg = nseg; ctl->why = why; ctl->ok = kbe > ka ? 1 : 0; if (kbe > ka) ctl->frames += kbe - ka; }
+    if (kbe == ka) return;
+    // hand-over to the workgroup kernel: the state at the start of inner frame kbe (step kbe + 1)
+    const int index_ka = (int)carry[10], index_new = (index_ka + (kbe - ka)) % 30;
+    const int lbi = (int)(((long long)kbe * LN_F100) % LN_LBS);
+    const double dv = lane < 30 ? B.E[(kbe - ka) + lane] : 0.0;
+    const double pdl = B.E[30 + (kbe - ka) - 1];
+    __builtin_amdgcn_wave_barrier();
+    if (lane < 30) carry[16 + (index_new + lane) % 30] = dv;
+    if (lane == 0) {
+        carry[0] = gr0; carry[1] = gr1; carry[2] = prev_smp; carry[3] = lbi; carry[4] = state; carry[5] = peak_index;
+        carry[6] = (lbi + LN_F100 + LN_ATT) % LN_LBS; carry[7] = env_cnt; carry[8] = att; carry[9] = 0.0;
+        carry[10] = index_new; carry[12] = pdl;
+        carry[80] = (double)((long long)(kbe + 1) * LN_F100); carry[81] = (double)((long long)LN_LBS + (long long)kbe * LN_F100);
+        carry[84] = (double)(kbe + 1);
+    }
+}
+__global__ void __launch_bounds__(256)
+k_lns_apply(double *__restrict__ y, LnsBufs B, int layer)
+{
+    if (!B.ctl->ok) return;
+    const int nseg = B.ctl->nseg;
+    for (int q = blockIdx.x; q < nseg; q += gridDim.x) {
+        const LnsSeg sg = B.seg[q];
+        if ((sg.kind >> 8) != layer) continue;
+        const int kind = sg.kind & 255;
+        double *p = y + sg.t;
+        const double g0 = sg.g0, g1 = sg.g1; const int c0 = sg.c0, al = sg.al;
+        if (kind == 0) for (int j = threadIdx.x; j < sg.len; j += 256) p[j] *= g0;
+        else if (kind == 1) for (int j = threadIdx.x; j < sg.len; j += 256) p[j] *= g0 - ((double)(c0 + j) / (al - 1) * (g0 - g1));
+        else for (int j = threadIdx.x; j < sg.len; j += 256) p[j] *= g0 + (((double)(c0 + j) / (LN_REL - 1)) * (g1 - g0));
+    }
+}
+// the frames go out (clamped); the 110 ms behind them go back into the ring, with the flags of its 64-sample blocks (lnw_ring_fill)
+__global__ void __launch_bounds__(256)
+k_lns_finish(double *__restrict__ y, double *__restrict__ ring, double *__restrict__ carry, LnsBufs B, double ceiling)
+{
+    if (!B.ctl->ok) return;
+    const long long t0 = (long long)(B.ctl->ka + 1) * LN_F100, t1 = (long long)(B.ctl->kbe + 1) * LN_F100;
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    unsigned char *hot = reinterpret_cast<unsigned char *>(carry + 96);
+    if (i < LN_LBS) {
+        const long long t = t1 + i;
+        const int r = (int)(t % LN_LBS);
+        bool h = true;
+        if (i < LN_LBS - LN_F100) { const double v = y[t]; ring[r] = v; h = fabs(v) > ceiling; }
+        const unsigned long long hm = __ballot(h);
+        if ((threadIdx.x & 63) == 0) hot[r >> 6] = (unsigned char)(hm != 0);
+    }
+    const long long t = t0 + i;
+    if (t < t1) { double v = y[t]; if (fabs(v) > ceiling) v = ceiling * (v < 0 ? -1 : 1); y[t] = v; }
 }
 
 __global__ void k_scale_f64(const double *__restrict__ in, double *__restrict__ out, int64_t n, double g)
@@ -1140,8 +1534,51 @@ void launch_swr_plain_f64(const double *in, int64_t n, const double *bank, int P
 {
     if (m_total > 0) hipLaunchKernelGGL(k_swr_plain_f64, dim3((unsigned)((m_total + 255) / 256)), dim3(256), 0, s, in, n, bank, P, L, center, step, m_total, out);
 }
+size_t jt_lns_scratch_bytes(int64_t n, int64_t n_inner, LnsBufs *B, unsigned char *base)
+{
+    // one allocation, carved up (256-byte aligned pieces); base == nullptr: size only
+    size_t off = 0;
+    auto take = [&](size_t bytes) { unsigned char *p = base ? base + off : nullptr; off += (bytes + 255) & ~(size_t)255; return p; };
+    const int64_t nwords = n / 64 + 2 * LNS_BW, nblk = nwords / LNS_BW + 2;
+    const int64_t pk_cap = n / 48 + 1024, seg_cap = 64 * n_inner + 1024;
+    LnsBufs b{};
+    b.ctl = reinterpret_cast<LnsCtl *>(take(sizeof(LnsCtl)));
+    b.G = reinterpret_cast<double *>(take(sizeof(double) * (size_t)(n_inner + 64)));
+    b.Gn = reinterpret_cast<double *>(take(sizeof(double) * (size_t)(n_inner + 64)));
+    b.E = reinterpret_cast<double *>(take(sizeof(double) * (size_t)(n_inner + 128)));
+    b.bm = reinterpret_cast<unsigned long long *>(take(sizeof(unsigned long long) * (size_t)nwords));
+    b.woff = reinterpret_cast<unsigned short *>(take(sizeof(unsigned short) * (size_t)nwords));
+    b.bcnt = reinterpret_cast<int *>(take(sizeof(int) * (size_t)nblk));
+    b.boff = reinterpret_cast<int *>(take(sizeof(int) * (size_t)nblk));
+    b.pk_t = reinterpret_cast<long long *>(take(sizeof(long long) * (size_t)pk_cap));
+    b.pk_v = reinterpret_cast<double *>(take(sizeof(double) * (size_t)pk_cap));
+    b.seg = reinterpret_cast<LnsSeg *>(take(sizeof(LnsSeg) * (size_t)seg_cap));
+    b.pk_cap = (int)std::min<int64_t>(pk_cap, 0x7fffffff); b.seg_cap = (int)std::min<int64_t>(seg_cap, 0x7fffffff);
+    if (B) *B = b;
+    return off;
+}
+// one attempt of the stream path at inner frames [ka, kb): every kernel looks at the control block k_lns_begin fills, nothing waits for the host
+static void lns_attempt(const double *x, const LoudnormDynParams &P, const double *series, double *ring, double *y, double *carry, const LnsBufs &B,
+                        int ka, int kb, hipStream_t s)
+{
+    const int64_t t_start = (int64_t)(ka + 1) * LN_F100, l_end = (int64_t)LN_LBS + (int64_t)kb * LN_F100;
+    const int64_t tb0 = t_start + 1, tb1 = l_end - 11;
+    const int64_t blk0 = tb0 / (64 * LNS_BW), blk1 = (tb1 - 1) / (64 * LNS_BW);
+    const int nblk = (int)(blk1 - blk0 + 1);
+    const int64_t nfill = (int64_t)(kb - ka) * LN_F100 + (LN_LBS - LN_F100);
+    hipLaunchKernelGGL(k_lns_begin, dim3(1), dim3(256), 0, s, carry, series, P, B, ka, kb);
+    hipLaunchKernelGGL(k_lns_fill, dim3((unsigned)((nfill + 255) / 256)), dim3(256), 0, s, x, y, ring, B, ka, kb, P.offset_lin);
+    hipLaunchKernelGGL(k_lns_bitmap, dim3((unsigned)nblk), dim3(256), 0, s, y, B, (long long)tb0, (long long)tb1, P.target_tp_lin, (long long)blk0);
+    hipLaunchKernelGGL(k_lns_scan, dim3(1), dim3(1024), 0, s, B, nblk);
+    hipLaunchKernelGGL(k_lns_scatter, dim3((unsigned)(((int64_t)nblk * LNS_BW + 255) / 256)), dim3(256), 0, s, y, B, (long long)blk0, nblk);
+    hipLaunchKernelGGL(k_lns_machine, dim3(1), dim3(64), 0, s, carry, P, B, y, ka, kb);
+    hipLaunchKernelGGL(k_lns_apply, dim3(2048), dim3(256), 0, s, y, B, 0);
+    hipLaunchKernelGGL(k_lns_apply, dim3(2048), dim3(256), 0, s, y, B, 1);
+    const int64_t nfin = std::max<int64_t>(LN_LBS, (int64_t)(kb - ka) * LN_F100);
+    hipLaunchKernelGGL(k_lns_finish, dim3((unsigned)((nfin + 255) / 256)), dim3(256), 0, s, y, ring, carry, B, P.target_tp_lin);
+}
 void launch_loudnorm_dynamic(const double *x, int64_t n, const LoudnormDynParams &P, const double *series, double *ring, double *y, double *dbg, hipStream_t s,
-                             double *carry, const JtOpts &o)
+                             double *carry, const JtOpts &o, const LnsBufs *stream)
 {
     (void)o;
     if (!JT_AB_ON(o.dyn_one_wave)) {
@@ -1152,6 +1589,14 @@ void launch_loudnorm_dynamic(const double *x, int64_t n, const LoudnormDynParams
         const int64_t steps = JT_AB_ON(o.dyn_steps > 0) ? o.dyn_steps : 64;
         for (int64_t it = 0; it < total; it += steps) {
             hipLaunchKernelGGL(k_loudnorm_dynamic_wg, dim3(1), dim3(LN_WG), smem, s, x, n, P, series, ring, y, dbg, carry, it, std::min(total, it + steps));
+            if (stream && !P.no_batch) {
+                // the stream path takes over behind launches 0, 1, 2, 4, 8, ... (a file that starts quietly has not latched above_threshold
+                // at the first ones; an attempt that stopped at one of its corners leaves the rest to a later one)
+                const int64_t chunk = it / steps, nb_last = n - LN_F3000 - (P.n_inner - 1) * LN_F100;
+                const int64_t kb = nb_last == LN_F100 ? P.n_inner : P.n_inner - 1, ka = it + steps - 1;
+                const bool pow2 = chunk <= 2 || (chunk & (chunk - 1)) == 0;
+                if (pow2 && kb - ka >= 32 && it + steps < total) lns_attempt(x, P, series, ring, y, carry, *stream, (int)ka, (int)kb, s);
+            }
 #ifdef JT_LN_PROFILE
             if (it == 8 * steps || it + steps >= total) {   // phase clocks of the ninth launch (inner frames) and of the last one (the flush): tools/prof_dynamic_phases.sh
                 unsigned long long pr[16];
