@@ -343,8 +343,14 @@ static SwrDev &get_swr(jt_ctx *h, int in_rate, int out_rate)
     }
     std::vector<float> bf(e.pl.bank.size());
     for (size_t i = 0; i < bf.size(); ++i) bf[i] = (float)e.pl.bank[i];
-    e.bank_d.ensure(e.pl.bank.size()); e.bank_f.ensure(bf.size());
+    e.bank_d.ensure(e.pl.bank.size()); e.bank_f.ensure(bf.size()); e.bank_dT.ensure(e.pl.bank.size());
     JT_HIP(hipMemcpyAsync(e.bank_d.p, e.pl.bank.data(), sizeof(double) * e.pl.bank.size(), hipMemcpyHostToDevice, h->stream));
+    {
+        const int L = e.pl.filter_length, P = e.pl.phase_count;
+        std::vector<double> bt(e.pl.bank.size());
+        for (int ph = 0; ph < P; ++ph) for (int i = 0; i < L; ++i) bt[(size_t)i * P + ph] = e.pl.bank[(size_t)ph * L + i];
+        JT_HIP(hipMemcpy(e.bank_dT.p, bt.data(), sizeof(double) * bt.size(), hipMemcpyHostToDevice));
+    }
     JT_HIP(hipMemcpyAsync(e.bank_f.p, bf.data(), sizeof(float) * bf.size(), hipMemcpyHostToDevice, h->stream));
     // s16 sources are scaled by 2^-15 before the taps (swr's s16 -> flt conversion); a power of two commutes with the rounding of
     // every fused multiply-add, so the scale may live in the taps instead -- as long as no scaled tap leaves the normal range
@@ -1439,6 +1445,9 @@ static void loudnorm_dynamic_run(jt_ctx *h, double *x, int64_t m, const Loudnorm
         JT_HIP(hipMemcpyAsync(c, lns.ctl, sizeof(LnsCtl), hipMemcpyDeviceToHost, s));
         JT_HIP(jt_stream_sync(h, s));
         h->timers.ln_stream_frames = c->frames; h->timers.ln_stream_why = c->why;
+        if (jt_host_timing().load(std::memory_order_relaxed))
+            fprintf(stderr, "loudnorm dynamic, stream path: %lld frames in %d attempts; last attempt: frames [%d, %d), %d peaks, %d segments, %d machine steps, %d list windows, %.2f Mcycles, why %d\n",
+                    (long long)c->frames, c->attempts, c->ka, c->kbe, c->npk, c->nseg, c->iters, c->refills, c->cycles / 1e6, c->why);
     }
 }
 
@@ -1497,7 +1506,7 @@ extern "C" int jt_pass4(jt_ctx *h, const jt_limiter_plan *lim, const jt_loudnorm
         // samples, one more than m for some lengths: the pass keeps m
         SwrDev &dn = get_swr(h, 192000, rate);
         launch_swr_plain_f64(h->stream_y.p, m192, dn.bank_d.p, dn.pl.phase_count, dn.pl.filter_length, dn.pl.center, dn.pl.step,
-                             std::min<int64_t>(dn.out_len(m192), m), tmp, h->stream);
+                             std::min<int64_t>(dn.out_len(m192), m), tmp, h->stream, h->opts.swr_untiled ? nullptr : dn.bank_dT.p);
         if (dn.out_len(m192) < m) JT_HIP(hipMemsetAsync(tmp + dn.out_len(m192), 0, (size_t)(m - dn.out_len(m192)) * sizeof(double), h->stream));
         std::swap(sig, tmp);
         check_cancel(h);

@@ -99,7 +99,7 @@ template <typename T> struct DevBuf {
 // that build imports JT_<KEY> variables, once, inside jt_open.
 #define JT_OPT_BOOLS(X) \
     X(no_pass2_prefetch) X(no_early_pass3) X(no_early_plan) X(no_lim_keep) X(no_staged_finish) X(no_r128_first) \
-    X(region_full_astats) X(host_timing) X(adeclick_exact) X(nlm_generic) X(p3_unfused) X(limiter_lanes) X(tp_unpruned) X(no_spec_direct) X(brickwall_f64) X(nf_low) X(ln_no_batch) X(ln_no_stream)
+    X(region_full_astats) X(host_timing) X(adeclick_exact) X(nlm_generic) X(p3_unfused) X(limiter_lanes) X(tp_unpruned) X(no_spec_direct) X(brickwall_f64) X(nf_low) X(ln_no_batch) X(ln_no_stream) X(swr_untiled)
 #define JT_OPT_INTS(X) X(region_rot) X(tp_prune_min) X(ln_stream_stop)
 #define JT_OPT_AB_BOOLS(X) \
     X(nlm_old) X(afftdn_old) X(adeclick_fused) X(dk_levinson_in_kernel) X(dk_no_xcd) X(dk_serial) X(dk_profile) X(dyn_one_wave) \
@@ -265,14 +265,15 @@ void jt_kweight_coeffs5(int sr, double b[5], double a[5]);
 // the stream path of the dynamic mode (k_loudnorm.hip): an envelope segment the limiter's state machine decided on, the control block
 // the kernels of one attempt share, and the scratch they work in (jt_lns_scratch_bytes carves one allocation)
 struct LnsSeg { long long t; int len, kind, c0, al; double g0, g1; };                 // kind: 0 constant g0, 1 attack ramp, 2 release ramp; +256: second layer
-struct LnsCtl { int active, ok, ka, kbe, npk, nseg, why, attempts; long long frames; };   // why: 1 state not in its steady form, 2 peak list full, 3 segment list full, 4 ring-end corner
+struct LnsCtl { int active, ok, ka, kbe, npk, nseg, why, attempts; long long frames; int iters, refills; long long cycles; };   // why: 1 state not in its steady form, 2 peak list full, 3 segment list full, 4 ring-end corner
 struct LnsBufs { LnsCtl *ctl; double *G, *Gn, *E; unsigned long long *bm; unsigned short *woff; int *bcnt, *boff; long long *pk_t; double *pk_v; LnsSeg *seg; int pk_cap, seg_cap; };
 size_t jt_lns_scratch_bytes(int64_t n, int64_t n_inner, LnsBufs *B, unsigned char *base);
 // carry: LN_CARRY = 256 doubles of device memory (the state one launch of the workgroup kernel hands to the next)
 void launch_loudnorm_dynamic(const double *x, int64_t n, const LoudnormDynParams &P, const double *series, double *ring, double *y, double *dbg, hipStream_t s,
                              double *carry, const JtOpts &o, const LnsBufs *stream = nullptr);
 void launch_scale_f64(const double *in, double *out, int64_t n, double g, hipStream_t s);
-void launch_swr_plain_f64(const double *in, int64_t n, const double *bank, int P, int L, int center, int64_t step, int64_t m_total, double *out, hipStream_t s);
+void launch_swr_plain_f64(const double *in, int64_t n, const double *bank, int P, int L, int center, int64_t step, int64_t m_total, double *out, hipStream_t s,
+                          const double *bankT = nullptr);     // bankT[i * P + phase]: the bank transposed (the tiled kernel)
 void launch_adeclick(jt_ctx *h, const double *in, double *out, int64_t n, int sample_rate, double threshold, double window_ms,
                      double overlap_pct, double ar_pct, double burst, double gain, unsigned long long *d_stats, hipStream_t s, int method = 1);
 
@@ -326,6 +327,7 @@ struct HostArena {
 // cached resampler plans (the kaiser bank depends on the rate pair only) with their device copies
 struct SwrDev {
     int in_rate = 0, out_rate = 0; SwrPlanHost pl; DevBuf<double> bank_d; DevBuf<float> bank_f;
+    DevBuf<double> bank_dT;      // bank_d transposed, [tap][phase] (k_swr_tile_f64)
     double tp_norms[3] = {0, 0, 0};   // over the tap rows: max sum |t_i|, max |sum t_i|, max sum |t_i| |i - c| (c fixed): the true peak's branch-and-bound bounds
     DevBuf<float> bank_fs;       // bank_f * 2^-15 (s16 sources: the int -> float scale folded into the taps); empty unless that product is exact
     int64_t out_len(int64_t n) const { return (int64_t)(((__int128)n * pl.phase_count + pl.step - 1) / pl.step); }

@@ -1157,7 +1157,9 @@ k_lns_begin(const double *__restrict__ carry, const double *__restrict__ series,
         ok = ok && lbi == (int)(((long long)ka * LN_F100) % LN_LBS);                             // (the frame's fill advances it to its output position)
         if (state != LIM_OUT) ok = ok && (int)carry[6] == (lbi + LN_F100 + LN_ATT) % LN_LBS;     // the envelope stands at the scan position
         if (state != LIM_ATTACK) ok = ok && (int)carry[8] == LN_ATT;
-        c->active = ok ? 1 : 0; c->ok = 0; c->ka = ka; c->kbe = ka; c->npk = 0; c->nseg = 0; c->why = ok ? 0 : 1; c->attempts += 1;
+        c->active = ok ? 1 : 0; c->ok = 0; c->attempts += 1;
+        if (ok) { c->ka = ka; c->kbe = ka; c->npk = 0; c->nseg = 0; c->why = 0; }                // (the diagnostics are the last ACTIVE attempt's)
+        else if (c->frames == 0) c->why = 1;
         go = ok ? 1 : 0;
         prev_s = carry[12];
     }
@@ -1208,8 +1210,8 @@ __global__ void __launch_bounds__(256)
 k_lns_fill(const double *__restrict__ x, double *__restrict__ y, const double *__restrict__ ring, LnsBufs B, int ka, int kb, double offset)
 {
     if (!B.ctl->active) return;
-    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
     const long long nfill = (long long)(kb - ka) * LN_F100, nring = LN_LBS - LN_F100;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < nfill + nring; i += (long long)gridDim.x * 256)
     if (i < nfill) {
         const int k = ka + (int)(i / LN_F100), j = (int)(i % LN_F100);
         const int nb = LN_F100;
@@ -1224,12 +1226,14 @@ k_lns_fill(const double *__restrict__ x, double *__restrict__ y, const double *_
 // detected peaks of L[tb0, tb1) as a bitmap (bit b of word w: t = 64 w + b), the words' popcounts as offsets inside their block of 64
 // words and the block's total; lnw_build_bitmap's test on the linear stream
 __global__ void __launch_bounds__(256)
-k_lns_bitmap(const double *__restrict__ y, LnsBufs B, long long tb0, long long tb1, double ceiling, long long blk0)
+k_lns_bitmap(const double *__restrict__ y, LnsBufs B, long long tb0, long long tb1, double ceiling, long long blk0, int nblk)
 {
     if (!B.ctl->active) return;
     __shared__ int wc[LNS_BW];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const long long blk = blk0 + blockIdx.x;
+    for (int bq = blockIdx.x; bq < nblk; bq += gridDim.x) {
+    const long long blk = blk0 + bq;
+    __syncthreads();
     for (int i = 0; i < LNS_BW / 4; ++i) {
         const int wl = wv * (LNS_BW / 4) + i;
         const long long wd = blk * LNS_BW + wl, t = wd * 64 + lane;
@@ -1257,7 +1261,8 @@ k_lns_bitmap(const double *__restrict__ y, LnsBufs B, long long tb0, long long t
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_up(incl, d, 64); if (tid >= d) incl += o; }
         B.woff[blk * LNS_BW + tid] = (unsigned short)(incl - c);
-        if (tid == 63) B.bcnt[blockIdx.x] = incl;
+        if (tid == 63) B.bcnt[bq] = incl;
+    }
     }
 }
 __global__ void __launch_bounds__(1024)
@@ -1283,8 +1288,7 @@ __global__ void __launch_bounds__(256)
 k_lns_scatter(const double *__restrict__ y, LnsBufs B, long long blk0, int nblk)
 {
     if (!B.ctl->active) return;
-    const long long q = (long long)blockIdx.x * 256 + threadIdx.x;                            // word of the range
-    if (q >= (long long)nblk * LNS_BW) return;
+    for (long long q = (long long)blockIdx.x * 256 + threadIdx.x; q < (long long)nblk * LNS_BW; q += (long long)gridDim.x * 256) {   // q: word of the range
     const long long wd = blk0 * LNS_BW + q;
     unsigned long long m = B.bm[wd];
     long long off = (long long)B.boff[q / LNS_BW] + B.woff[wd];
@@ -1292,6 +1296,7 @@ k_lns_scatter(const double *__restrict__ y, LnsBufs B, long long blk0, int nblk)
         const long long t = wd * 64 + (__ffsll((long long)m) - 1);
         m &= m - 1ull;
         B.pk_t[off] = t; B.pk_v[off] = fabs(y[t]); ++off;
+    }
     }
 }
 // the limiter's state machine over the peak list: lnw_true_peak_limiter's loop with the bitmap queries answered by the list and the ring
@@ -1313,7 +1318,28 @@ k_lns_machine(double *__restrict__ carry, LoudnormDynParams P, LnsBufs B, const 
     // the list's window: entry wbase + lane in this lane's registers
     long long wbase = 0, wt = 0; double wvv = 0.0; long long cur = 0;
     const long long TINF = 0x7fffffffffffffffll;
-    auto refill = [&](long long b) { wbase = b; const long long i = b + lane; wt = i < npk ? B.pk_t[i] : TINF; wvv = i < npk ? B.pk_v[i] : 0.0; };
+    // The list reaches the wave through LDS: 4096 entries, refilled 1024 at a time with all of a refill's loads in flight together -- a
+    // 64-entry window straight from memory was one exposed round trip per frame (a frame of a held-down signal holds about 64 peaks):
+    // 2 400 cycles per machine step, all of it that wait.  One wave: its LDS operations execute in order, no barrier.
+    constexpr int LCAP = 4096, LCH = 1024;
+    __shared__ long long lt[LCAP];
+    __shared__ double lv[LCAP];
+    long long lhi = 0;                                                   // list entries [.., lhi) are in LDS (those before cur are dead)
+    int n_refill = 0, n_iter = 0;
+    const long long clk0 = clock64();
+    auto refill = [&](long long b) {
+        while (b + 64 > lhi) {
+            // (b >= cur: everything before b is dead, so [lhi, lhi + LCH) fits whenever lhi - b <= LCAP - LCH, and lhi < b + 64 here)
+            long long tt[LCH / 64]; double vv[LCH / 64];
+#pragma unroll
+            for (int u = 0; u < LCH / 64; ++u) { const long long i = lhi + 64 * u + lane; tt[u] = i < npk ? B.pk_t[i] : TINF; vv[u] = i < npk ? B.pk_v[i] : 0.0; }
+#pragma unroll
+            for (int u = 0; u < LCH / 64; ++u) { const int q = (int)((lhi + 64 * u + lane) & (LCAP - 1)); lt[q] = tt[u]; lv[q] = vv[u]; }
+            lhi += LCH; ++n_refill;
+        }
+        const int q = (int)((b + lane) & (LCAP - 1));
+        wt = lt[q]; wvv = lv[q]; wbase = b;
+    };
     refill(0);
     // cur := the first entry later than ts (cur never goes back: ts does not between detector calls)
     auto advance = [&](long long ts) {
@@ -1343,6 +1369,7 @@ k_lns_machine(double *__restrict__ carry, LoudnormDynParams P, LnsBufs B, const 
         int c = 0;
         do {
             const long long ts = T0 + c + LN_ATT;
+            ++n_iter;
             switch (state) {
             case LIM_OUT: {
                 // detect_peak(c, nb - c): the first detected peak among n = 1 .. nb - c - 1
@@ -1384,9 +1411,11 @@ k_lns_machine(double *__restrict__ carry, LoudnormDynParams P, LnsBufs B, const 
                         lp_t = rest ? lns_rl64(wt, 63 - __clzll((long long)rest)) : l_t;
                         l_t = lns_rl64(wt, hi); l_v = ln_rl(wvv, hi);
                     }
-                    if (hm) { const int f = __ffsll((long long)hm) - 1; h_t = lns_rl64(wt, f); h_v = ln_rl(wvv, f); break; }
-                    if (im != (~0ull << off)) break;                                             // the range ends inside this window
-                    scan = wbase + 64;
+                    // (cur follows the scan: what it has passed lies at or before the next scan position, and a window left behind
+                    //  would have to be fetched again)
+                    if (hm) { const int f = __ffsll((long long)hm) - 1; h_t = lns_rl64(wt, f); h_v = ln_rl(wvv, f); cur = wbase + f; break; }
+                    if (im != (~0ull << off)) { cur = wbase + off + __popcll(im); break; }          // the range ends inside this window
+                    scan = wbase + 64; cur = scan;
                 }
                 const int lb = l_t >= 0 ? (int)(l_t - ts) : 0, lprev = lp_t >= 0 ? (int)(lp_t - ts) : 0;
                 if (lb > 0) {
@@ -1448,6 +1477,7 @@ k_lns_machine(double *__restrict__ carry, LoudnormDynParams P, LnsBufs B, const 
         }
     }
     const int kbe = k;
+    if (lane == 0) { ctl->iters = n_iter; ctl->refills = n_refill; ctl->cycles = clock64() - clk0; }
     if (lane == 0) { ctl->kbe = kbe; ctl->nseg = nseg; ctl->why = why; ctl->ok = kbe > ka ? 1 : 0; if (kbe > ka) ctl->frames += kbe - ka; }
     if (kbe == ka) return;
     // hand-over to the workgroup kernel: the state at the start of inner frame kbe (step kbe + 1)
@@ -1487,8 +1517,9 @@ k_lns_finish(double *__restrict__ y, double *__restrict__ ring, double *__restri
 {
     if (!B.ctl->ok) return;
     const long long t0 = (long long)(B.ctl->ka + 1) * LN_F100, t1 = (long long)(B.ctl->kbe + 1) * LN_F100;
-    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
     unsigned char *hot = reinterpret_cast<unsigned char *>(carry + 96);
+    const long long ntot = max((long long)LN_LBS, t1 - t0);
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < ntot; i += (long long)gridDim.x * 256) {
     if (i < LN_LBS) {
         const long long t = t1 + i;
         const int r = (int)(t % LN_LBS);
@@ -1499,6 +1530,7 @@ k_lns_finish(double *__restrict__ y, double *__restrict__ ring, double *__restri
     }
     const long long t = t0 + i;
     if (t < t1) { double v = y[t]; if (fabs(v) > ceiling) v = ceiling * (v < 0 ? -1 : 1); y[t] = v; }
+    }
 }
 
 __global__ void k_scale_f64(const double *__restrict__ in, double *__restrict__ out, int64_t n, double g)
@@ -1528,11 +1560,52 @@ __global__ void k_swr_plain_f64(const double *__restrict__ in, int64_t n, const 
     }
     out[m] = val;
 }
+// The same sums for a block of 256 consecutive outputs with the inputs they share in LDS (256 step / P + L samples: 10 KB at 192 -> 44.1 kHz,
+// loaded once, coalesced, the edges' reflections resolved on the way in) and the taps from the TRANSPOSED bank bankT[i][phase]: the lanes
+// of a wave sit on 64 different phases, which in the bank's own layout are 64 different cache lines per tap and in the transposed one
+// the ten lines of one row.  Same products in the same order per output (taps ascending, multiply then add).  The one-thread-per-output
+// kernel above took 16.6 ms for ten minutes -- the longest kernel of a file that takes the dynamic mode once its limiter was out of the way.
+__global__ void __launch_bounds__(256)
+k_swr_tile_f64(const double *__restrict__ in, int64_t n, const double *__restrict__ bankT, int P, int L, int center, int64_t step, int64_t m_total,
+               double *__restrict__ out)
+{
+    extern __shared__ double swr_tile[];
+    const int tid = threadIdx.x;
+    const int64_t m0 = (int64_t)blockIdx.x * 256, mlast = min(m_total - 1, m0 + 255);
+    const int64_t s0 = (m0 * step) / P - center, s1 = (mlast * step) / P - center + L;
+    const int cnt = (int)(s1 - s0);
+    for (int j = tid; j < cnt; j += 256) {
+        int64_t g = s0 + j;
+        double v = 0.0;
+        if (g < 0) g = -g;                                           // invert_initial_buffer(): in[-j] = in[j]
+        if (g < n) v = in[g];
+        else { const int64_t r = 2 * n - 1 - g; if (r >= 0 && r < n) v = in[r]; }   // resample_flush()
+        swr_tile[j] = v;
+    }
+    __syncthreads();
+    const int64_t m = m0 + tid;
+    if (m >= m_total) return;
+    const int64_t idx = m * step;
+    const int ph = (int)(idx % P);
+    const double *t = swr_tile + (int)(idx / P - center - s0);
+    const double *f = bankT + ph;
+    double val = 0.0;
+#pragma unroll 4
+    for (int i = 0; i < L; ++i) val += t[i] * f[(size_t)i * P];
+    out[m] = val;
+}
 }  // namespace
 
-void launch_swr_plain_f64(const double *in, int64_t n, const double *bank, int P, int L, int center, int64_t step, int64_t m_total, double *out, hipStream_t s)
+void launch_swr_plain_f64(const double *in, int64_t n, const double *bank, int P, int L, int center, int64_t step, int64_t m_total, double *out, hipStream_t s,
+                          const double *bankT)
 {
-    if (m_total > 0) hipLaunchKernelGGL(k_swr_plain_f64, dim3((unsigned)((m_total + 255) / 256)), dim3(256), 0, s, in, n, bank, P, L, center, step, m_total, out);
+    if (m_total <= 0) return;
+    const size_t smem = sizeof(double) * (size_t)((255 * step) / P + L + 2);
+    if (bankT && smem <= 48 * 1024) {
+        hipLaunchKernelGGL(k_swr_tile_f64, dim3((unsigned)((m_total + 255) / 256)), dim3(256), smem, s, in, n, bankT, P, L, center, step, m_total, out);
+        return;
+    }
+    hipLaunchKernelGGL(k_swr_plain_f64, dim3((unsigned)((m_total + 255) / 256)), dim3(256), 0, s, in, n, bank, P, L, center, step, m_total, out);
 }
 size_t jt_lns_scratch_bytes(int64_t n, int64_t n_inner, LnsBufs *B, unsigned char *base)
 {
@@ -1567,15 +1640,17 @@ static void lns_attempt(const double *x, const LoudnormDynParams &P, const doubl
     const int nblk = (int)(blk1 - blk0 + 1);
     const int64_t nfill = (int64_t)(kb - ka) * LN_F100 + (LN_LBS - LN_F100);
     hipLaunchKernelGGL(k_lns_begin, dim3(1), dim3(256), 0, s, carry, series, P, B, ka, kb);
-    hipLaunchKernelGGL(k_lns_fill, dim3((unsigned)((nfill + 255) / 256)), dim3(256), 0, s, x, y, ring, B, ka, kb, P.offset_lin);
-    hipLaunchKernelGGL(k_lns_bitmap, dim3((unsigned)nblk), dim3(256), 0, s, y, B, (long long)tb0, (long long)tb1, P.target_tp_lin, (long long)blk0);
+    // (grids of a fixed size that stride over their ranges: an attempt that turns out not to run costs eight empty launches, not eight big ones)
+    auto grid = [](int64_t items) { return dim3((unsigned)std::max<int64_t>(1, std::min<int64_t>(8192, (items + 255) / 256))); };
+    hipLaunchKernelGGL(k_lns_fill, grid(nfill), dim3(256), 0, s, x, y, ring, B, ka, kb, P.offset_lin);
+    hipLaunchKernelGGL(k_lns_bitmap, dim3((unsigned)std::min(nblk, 8192)), dim3(256), 0, s, y, B, (long long)tb0, (long long)tb1, P.target_tp_lin, (long long)blk0, nblk);
     hipLaunchKernelGGL(k_lns_scan, dim3(1), dim3(1024), 0, s, B, nblk);
-    hipLaunchKernelGGL(k_lns_scatter, dim3((unsigned)(((int64_t)nblk * LNS_BW + 255) / 256)), dim3(256), 0, s, y, B, (long long)blk0, nblk);
+    hipLaunchKernelGGL(k_lns_scatter, grid((int64_t)nblk * LNS_BW), dim3(256), 0, s, y, B, (long long)blk0, nblk);
     hipLaunchKernelGGL(k_lns_machine, dim3(1), dim3(64), 0, s, carry, P, B, y, ka, kb);
-    hipLaunchKernelGGL(k_lns_apply, dim3(2048), dim3(256), 0, s, y, B, 0);
-    hipLaunchKernelGGL(k_lns_apply, dim3(2048), dim3(256), 0, s, y, B, 1);
+    hipLaunchKernelGGL(k_lns_apply, dim3(4096), dim3(256), 0, s, y, B, 0);
+    hipLaunchKernelGGL(k_lns_apply, dim3(4096), dim3(256), 0, s, y, B, 1);
     const int64_t nfin = std::max<int64_t>(LN_LBS, (int64_t)(kb - ka) * LN_F100);
-    hipLaunchKernelGGL(k_lns_finish, dim3((unsigned)((nfin + 255) / 256)), dim3(256), 0, s, y, ring, carry, B, P.target_tp_lin);
+    hipLaunchKernelGGL(k_lns_finish, grid(nfin), dim3(256), 0, s, y, ring, carry, B, P.target_tp_lin);
 }
 void launch_loudnorm_dynamic(const double *x, int64_t n, const LoudnormDynParams &P, const double *series, double *ring, double *y, double *dbg, hipStream_t s,
                              double *carry, const JtOpts &o, const LnsBufs *stream)
@@ -1587,21 +1662,24 @@ void launch_loudnorm_dynamic(const double *x, int64_t n, const LoudnormDynParams
         JT_HIP(hipFuncSetAttribute((const void *)k_loudnorm_dynamic_wg, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
         const int64_t total = 1 + P.n_inner + P.final_len / LN_F100;
         const int64_t steps = JT_AB_ON(o.dyn_steps > 0) ? o.dyn_steps : 64;
-        for (int64_t it = 0; it < total; it += steps) {
-            hipLaunchKernelGGL(k_loudnorm_dynamic_wg, dim3(1), dim3(LN_WG), smem, s, x, n, P, series, ring, y, dbg, carry, it, std::min(total, it + steps));
-            if (stream && !P.no_batch) {
-                // the stream path takes over behind launches 0, 1, 2, 4, 8, ... (a file that starts quietly has not latched above_threshold
-                // at the first ones; an attempt that stopped at one of its corners leaves the rest to a later one)
-                const int64_t chunk = it / steps, nb_last = n - LN_F3000 - (P.n_inner - 1) * LN_F100;
-                const int64_t kb = nb_last == LN_F100 ? P.n_inner : P.n_inner - 1, ka = it + steps - 1;
-                const bool pow2 = chunk <= 2 || (chunk & (chunk - 1)) == 0;
-                if (pow2 && kb - ka >= 32 && it + steps < total) lns_attempt(x, P, series, ring, y, carry, *stream, (int)ka, (int)kb, s);
-            }
+        const bool use_stream = stream && !P.no_batch;
+        const int64_t nb_last = n - LN_F3000 - (P.n_inner - 1) * LN_F100, kb = nb_last == LN_F100 ? P.n_inner : P.n_inner - 1;
+        int chunk = 0;
+        for (int64_t it = 0, end = 0; it < total; it = end, ++chunk) {
+            // with the stream path behind it the workgroup kernel normally runs the first 8 steps and the last 30: launches of 8, 8, 16,
+            // 32, ... 256 steps (each skips what the stream path has covered meanwhile: carry[84]), an attempt of the stream path behind
+            // the first seven and then every fourth -- a file that starts quietly latches above_threshold late, and an attempt that
+            // stopped at one of its corners leaves the rest to a later one
+            const int64_t len = !use_stream ? steps : (chunk < 2 ? 8 : std::min<int64_t>(256, (int64_t)8 << (chunk - 1)));
+            end = std::min(total, it + len);
+            hipLaunchKernelGGL(k_loudnorm_dynamic_wg, dim3(1), dim3(LN_WG), smem, s, x, n, P, series, ring, y, dbg, carry, it, end);
+            if (use_stream && (chunk <= 6 || chunk % 4 == 0) && kb - (end - 1) >= 32 && end < total)
+                lns_attempt(x, P, series, ring, y, carry, *stream, (int)(end - 1), (int)kb, s);
 #ifdef JT_LN_PROFILE
-            if (it == 8 * steps || it + steps >= total) {   // phase clocks of the ninth launch (inner frames) and of the last one (the flush): tools/prof_dynamic_phases.sh
+            if (chunk == 8 || end >= total) {   // phase clocks of the ninth launch (inner frames) and of the last one (the flush): tools/prof_dynamic_phases.sh
                 unsigned long long pr[16];
                 JT_HIP(hipStreamSynchronize(s)); JT_HIP(hipMemcpyFromSymbol(pr, HIP_SYMBOL(g_ln_prof), sizeof pr));
-                const double st = (double)(std::min(total, it + steps) - it);
+                const double st = (double)(end - it);
                 fprintf(stderr, "loudnorm dynamic, launch at step %lld (%g steps), kcycles per step: fill %.1f, window load %.1f, limiter %.1f (detect %.1f, scale %.1f), write-back + out %.1f; "
                                 "per step: %.1f scale passes, %.1f detector calls\n", (long long)it, st, pr[0] / st / 1e3, pr[1] / st / 1e3, pr[2] / st / 1e3, pr[4] / st / 1e3,
                         pr[7] / st / 1e3, pr[3] / st / 1e3, pr[5] / st, pr[6] / st);
