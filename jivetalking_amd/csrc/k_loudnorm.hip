@@ -1285,7 +1285,7 @@ k_lns_scan(LnsBufs B, int nblk)
     }
 }
 __global__ void __launch_bounds__(256)
-k_lns_scatter(const double *__restrict__ y, LnsBufs B, long long blk0, int nblk)
+k_lns_scatter(const double *__restrict__ y, LnsBufs B, long long blk0, int nblk, double ceiling)
 {
     if (!B.ctl->active) return;
     for (long long q = (long long)blockIdx.x * 256 + threadIdx.x; q < (long long)nblk * LNS_BW; q += (long long)gridDim.x * 256) {   // q: word of the range
@@ -1295,7 +1295,8 @@ k_lns_scatter(const double *__restrict__ y, LnsBufs B, long long blk0, int nblk)
     while (m) {
         const long long t = wd * 64 + (__ffsll((long long)m) - 1);
         m &= m - 1ull;
-        B.pk_t[off] = t; B.pk_v[off] = fabs(y[t]); ++off;
+        const double v = fabs(y[t]);
+        B.pk_t[off] = (int)t; B.pk_v[off] = v; B.pk_g[off] = ceiling / v; ++off;                // (ceiling / peak_value: the filter's gain reduction of this peak)
     }
     }
 }
@@ -1308,82 +1309,82 @@ k_lns_machine(double *__restrict__ carry, LoudnormDynParams P, LnsBufs B, const 
     LnsCtl *ctl = B.ctl;
     if (!ctl->active) return;
     const int lane = threadIdx.x;
-    const long long npk = ctl->npk;
+    const int npk = ctl->npk;
     const double ceiling = P.target_tp_lin;
-    const int nb = LN_F100;
-    double gr0 = carry[0], gr1 = carry[1], prev_smp = carry[2];
-    int state = (int)carry[4], peak_index = (int)carry[5], env_cnt = (int)carry[7], att = (int)carry[8];
+    const int nb = LN_F100, stop_every = P.stream_stop, seg_cap = B.seg_cap;
+    double gr0 = carry[0], gr1 = carry[1];
+    int state = (int)carry[4], env_cnt = (int)carry[7], att = (int)carry[8];
+    int last_pk = -1;                                                    // list entry of the last detected peak (prev_smp / peak_index of the hand-over)
     bool layer2 = false;
     int nseg = 0;
-    // the list's window: entry wbase + lane in this lane's registers
-    long long wbase = 0, wt = 0; double wvv = 0.0; long long cur = 0;
-    const long long TINF = 0x7fffffffffffffffll;
-    // The list reaches the wave through LDS: 4096 entries, refilled 1024 at a time with all of a refill's loads in flight together -- a
-    // 64-entry window straight from memory was one exposed round trip per frame (a frame of a held-down signal holds about 64 peaks):
-    // 2 400 cycles per machine step, all of it that wait.  One wave: its LDS operations execute in order, no barrier.
-    constexpr int LCAP = 4096, LCH = 1024;
-    __shared__ long long lt[LCAP];
-    __shared__ double lv[LCAP];
-    long long lhi = 0;                                                   // list entries [.., lhi) are in LDS (those before cur are dead)
+    // One wave runs alone and issues an instruction every five cycles: the machine is bound by its instruction count (2 400 cycles per step
+    // with 64-bit times and a division per window; a memory round trip hidden or not made no difference).  Hence 32-bit times (the host
+    // sends files of 2^31 samples and more to the workgroup kernel), the peaks' gain reductions ceiling / |peak| precomputed by the
+    // scatter kernel (the only thing the machine ever does with a magnitude), and the list through LDS: 4096 entries, refilled 1024 at a
+    // time with all of a refill's loads in flight together.  One wave: its LDS operations execute in order, no barrier.
+    constexpr int LCAP = 4096, LCH = 1024, TINF = 0x7fffffff;
+    __shared__ int lt[LCAP];
+    __shared__ double lg[LCAP];
+    int wbase = 0, wt = 0, cur = 0, lhi = 0;                             // window: entry wbase + lane in this lane's registers; [.., lhi) in LDS
+    double wg = 0.0;
     int n_refill = 0, n_iter = 0;
     const long long clk0 = clock64();
-    auto refill = [&](long long b) {
+    auto refill = [&](int b) {
         while (b + 64 > lhi) {
             // (b >= cur: everything before b is dead, so [lhi, lhi + LCH) fits whenever lhi - b <= LCAP - LCH, and lhi < b + 64 here)
-            long long tt[LCH / 64]; double vv[LCH / 64];
+            int tt[LCH / 64]; double gg[LCH / 64];
 #pragma unroll
-            for (int u = 0; u < LCH / 64; ++u) { const long long i = lhi + 64 * u + lane; tt[u] = i < npk ? B.pk_t[i] : TINF; vv[u] = i < npk ? B.pk_v[i] : 0.0; }
+            for (int u = 0; u < LCH / 64; ++u) { const int i = lhi + 64 * u + lane; tt[u] = i < npk ? B.pk_t[i] : TINF; gg[u] = i < npk ? B.pk_g[i] : 2.0; }
 #pragma unroll
-            for (int u = 0; u < LCH / 64; ++u) { const int q = (int)((lhi + 64 * u + lane) & (LCAP - 1)); lt[q] = tt[u]; lv[q] = vv[u]; }
+            for (int u = 0; u < LCH / 64; ++u) { const int q = (lhi + 64 * u + lane) & (LCAP - 1); lt[q] = tt[u]; lg[q] = gg[u]; }
             lhi += LCH; ++n_refill;
         }
-        const int q = (int)((b + lane) & (LCAP - 1));
-        wt = lt[q]; wvv = lv[q]; wbase = b;
+        const int q = (b + lane) & (LCAP - 1);
+        wt = lt[q]; wg = lg[q]; wbase = b;
     };
     refill(0);
     // cur := the first entry later than ts (cur never goes back: ts does not between detector calls)
-    auto advance = [&](long long ts) {
+    auto advance = [&](int ts) {
         for (;;) {
             if (cur >= wbase + 64 || cur < wbase) refill(cur);
-            const int off = (int)(cur - wbase);
+            const int off = cur - wbase;
             const unsigned long long m = __ballot(wt > ts) & (~0ull << off);
             if (m) { cur = wbase + (__ffsll((long long)m) - 1); return; }
             cur = wbase + 64;
         }
     };
     bool ovf = false;
-    auto emit = [&](int kind, long long t, int len, double g0, double g1, int c0, int al) {
+    auto emit = [&](int kind, int t, int len, double g0, double g1, int c0, int al) {
         if (len <= 0) return;
-        if (nseg >= B.seg_cap) { ovf = true; return; }
+        if (nseg >= seg_cap) { ovf = true; return; }
         if (lane == 0) { LnsSeg sg; sg.t = t; sg.len = len; sg.kind = kind | (layer2 && kind == 1 ? 256 : 0); sg.c0 = c0; sg.al = al; sg.g0 = g0; sg.g1 = g1; B.seg[nseg] = sg; }
         ++nseg;
     };
     int k = ka, why = 0;
     for (; k < kb; ++k) {
-        if (P.stream_stop > 0 && k > ka && k % P.stream_stop == 0) { why = 5; break; }       // (test switch)
-        const long long T0 = (long long)(k + 1) * LN_F100;
+        if (stop_every > 0 && k > ka && k % stop_every == 0) { why = 5; break; }              // (test switch)
+        const int T0 = (k + 1) * LN_F100;
         // the frame is taken whole or not at all
-        const double s_gr0 = gr0, s_gr1 = gr1, s_prev = prev_smp; const int s_state = state, s_pi = peak_index, s_ec = env_cnt, s_att = att, s_nseg = nseg;
+        const double s_gr0 = gr0, s_gr1 = gr1; const int s_state = state, s_lp = last_pk, s_ec = env_cnt, s_att = att, s_nseg = nseg;
         const bool s_l2 = layer2;
         bool hazard = false;
         int c = 0;
         do {
-            const long long ts = T0 + c + LN_ATT;
+            const int ts = T0 + c + LN_ATT;
             ++n_iter;
             switch (state) {
             case LIM_OUT: {
                 // detect_peak(c, nb - c): the first detected peak among n = 1 .. nb - c - 1
                 advance(ts);
-                const int off = (int)(cur - wbase);
-                const long long e = lns_rl64(wt, off);
+                const int off = cur - wbase;
+                const int e = __builtin_amdgcn_readlane(wt, off);
                 if (e <= ts + (nb - c) - 1) {
-                    const double pkv = ln_rl(wvv, off);
-                    const int pd = (int)(e - ts);
-                    prev_smp = pkv; peak_index = (int)(e % LN_LBS);
+                    const int pd = e - ts;
+                    last_pk = cur;
                     env_cnt = 0;
                     layer2 = pd < att;                                                          // the attack starts before the scan position: over a release's tail
                     c += pd - att;
-                    gr0 = 1.; gr1 = ceiling / pkv;
+                    gr0 = 1.; gr1 = ln_rl(wg, off);                                              // ceiling / peak_value
                     state = LIM_ATTACK;
                 } else c = nb;
                 break; }
@@ -1396,61 +1397,60 @@ k_lns_machine(double *__restrict__ carry, LoudnormDynParams P, LnsBufs B, const 
             case LIM_SUSTAIN: {
                 // the batch (lnv_sustain_batch_bm): the harmless peaks of [ts + 1, ts + Rb] in one segment, the first harmful one into ATTACK
                 const int Rb = min(nb - c, nb - 1);
-                long long l_t = -1, lp_t = -1, h_t = -1; double l_v = 0.0, h_v = 0.0;
+                int l_t = -1, lp_t = -1, h_t = -1, l_i = -1, h_i = -1; double h_g = 0.0;
                 advance(ts);
-                for (long long scan = cur;;) {
+                for (int scan = cur;;) {
                     if (scan >= wbase + 64 || scan < wbase) refill(scan);
-                    const int off = (int)(scan - wbase);
+                    const int off = scan - wbase;
                     const bool inr = wt <= ts + Rb && lane >= off;
-                    const bool harm = inr && (ceiling / wvv < gr1);                              // the filter's own comparison: gain_reduction < s->gain_reduction[1]
+                    const bool harm = inr && (wg < gr1);                                          // the filter's own comparison: gain_reduction < s->gain_reduction[1]
                     const unsigned long long im = __ballot(inr), hm = __ballot(harm);
                     const unsigned long long okm = hm ? im & ((1ull << (__ffsll((long long)hm) - 1)) - 1ull) : im;
                     if (okm) {
                         const int hi = 63 - __clzll((long long)okm);
                         const unsigned long long rest = okm & ~(1ull << hi);
-                        lp_t = rest ? lns_rl64(wt, 63 - __clzll((long long)rest)) : l_t;
-                        l_t = lns_rl64(wt, hi); l_v = ln_rl(wvv, hi);
+                        lp_t = rest ? __builtin_amdgcn_readlane(wt, 63 - __clzll((long long)rest)) : l_t;
+                        l_t = __builtin_amdgcn_readlane(wt, hi); l_i = wbase + hi;
                     }
                     // (cur follows the scan: what it has passed lies at or before the next scan position, and a window left behind
                     //  would have to be fetched again)
-                    if (hm) { const int f = __ffsll((long long)hm) - 1; h_t = lns_rl64(wt, f); h_v = ln_rl(wvv, f); cur = wbase + f; break; }
+                    if (hm) { const int f = __ffsll((long long)hm) - 1; h_t = __builtin_amdgcn_readlane(wt, f); h_g = ln_rl(wg, f); h_i = wbase + f; cur = h_i; break; }
                     if (im != (~0ull << off)) { cur = wbase + off + __popcll(im); break; }          // the range ends inside this window
                     scan = wbase + 64; cur = scan;
                 }
-                const int lb = l_t >= 0 ? (int)(l_t - ts) : 0, lprev = lp_t >= 0 ? (int)(lp_t - ts) : 0;
+                const int lb = l_t >= 0 ? l_t - ts : 0, lprev = lp_t >= 0 ? lp_t - ts : 0;
                 if (lb > 0) {
                     emit(0, ts, lb, gr1, 0., 0, 0);
-                    prev_smp = l_v; peak_index = (int)(l_t % LN_LBS);
+                    last_pk = l_i;
                     env_cnt = lb - lprev; c += lb;
                 }
                 if (h_t >= 0) {
-                    const int pdh = (int)(h_t - ts) - lb;
-                    prev_smp = h_v; peak_index = (int)(h_t % LN_LBS);
+                    const int pdh = (h_t - ts) - lb;
+                    last_pk = h_i;
                     state = LIM_ATTACK;
                     att = pdh; if (att <= 1) att = 2;
-                    gr0 = gr1; gr1 = ceiling / h_v; env_cnt = 0;
+                    gr0 = gr1; gr1 = h_g; env_cnt = 0;
                     break;
                 }
                 if (c >= nb) break;
                 // the call from there scans n = 1 .. nb - 1: what lies behind the frame's remainder
-                const long long ts2 = T0 + c + LN_ATT, lim = ts2 + nb - 1, zone = T0 + LN_LBS - 12;
+                const int ts2 = T0 + c + LN_ATT, lim = ts2 + nb - 1, zone = T0 + LN_LBS - 12;
                 advance(ts + Rb);
-                const int off = (int)(cur - wbase);
-                const long long e = lns_rl64(wt, off);
+                const int off = cur - wbase;
+                const int e = __builtin_amdgcn_readlane(wt, off);
                 bool found = e <= lim;
                 if (lim >= zone && !(found && e < zone)) {
                     // the scan reaches the ring's last twelve samples, whose test reads past its end (the filter wraps to samples the
                     // envelope has edited): only harmless when none of them can be a candidate at all
-                    const long long t = zone + lane;
+                    const int t = zone + lane;
                     const bool hot = lane < 12 && t <= lim && t < T0 + LN_LBS && fabs(y[t]) > ceiling;
                     if (__ballot(hot)) { hazard = true; break; }
                     found = false;
                 }
                 if (found) {
-                    const double pkv = ln_rl(wvv, off);
-                    const int pd = (int)(e - ts2);
-                    prev_smp = pkv; peak_index = (int)(e % LN_LBS);
-                    const double gr = ceiling / pkv;
+                    const double gr = ln_rl(wg, off);
+                    const int pd = e - ts2;
+                    last_pk = cur;
                     if (gr < gr1) {
                         state = LIM_ATTACK;
                         att = pd; if (att <= 1) att = 2;
@@ -1471,7 +1471,7 @@ k_lns_machine(double *__restrict__ carry, LoudnormDynParams P, LnsBufs B, const 
             }
         } while (c < nb);
         if (hazard || ovf) {
-            gr0 = s_gr0; gr1 = s_gr1; prev_smp = s_prev; state = s_state; peak_index = s_pi; env_cnt = s_ec; att = s_att; nseg = s_nseg; layer2 = s_l2;
+            gr0 = s_gr0; gr1 = s_gr1; state = s_state; last_pk = s_lp; env_cnt = s_ec; att = s_att; nseg = s_nseg; layer2 = s_l2;
             why = ovf ? 3 : 4;
             break;
         }
@@ -1488,7 +1488,8 @@ k_lns_machine(double *__restrict__ carry, LoudnormDynParams P, LnsBufs B, const 
     __builtin_amdgcn_wave_barrier();
     if (lane < 30) carry[16 + (index_new + lane) % 30] = dv;
     if (lane == 0) {
-        carry[0] = gr0; carry[1] = gr1; carry[2] = prev_smp; carry[3] = lbi; carry[4] = state; carry[5] = peak_index;
+        carry[0] = gr0; carry[1] = gr1; carry[3] = lbi; carry[4] = state;
+        if (last_pk >= 0) { carry[2] = B.pk_v[last_pk]; carry[5] = (double)(B.pk_t[last_pk] % LN_LBS); }      // prev_smp, peak_index
         carry[6] = (lbi + LN_F100 + LN_ATT) % LN_LBS; carry[7] = env_cnt; carry[8] = att; carry[9] = 0.0;
         carry[10] = index_new; carry[12] = pdl;
         carry[80] = (double)((long long)(kbe + 1) * LN_F100); carry[81] = (double)((long long)LN_LBS + (long long)kbe * LN_F100);
@@ -1623,8 +1624,9 @@ size_t jt_lns_scratch_bytes(int64_t n, int64_t n_inner, LnsBufs *B, unsigned cha
     b.woff = reinterpret_cast<unsigned short *>(take(sizeof(unsigned short) * (size_t)nwords));
     b.bcnt = reinterpret_cast<int *>(take(sizeof(int) * (size_t)nblk));
     b.boff = reinterpret_cast<int *>(take(sizeof(int) * (size_t)nblk));
-    b.pk_t = reinterpret_cast<long long *>(take(sizeof(long long) * (size_t)pk_cap));
+    b.pk_t = reinterpret_cast<int *>(take(sizeof(int) * (size_t)pk_cap));
     b.pk_v = reinterpret_cast<double *>(take(sizeof(double) * (size_t)pk_cap));
+    b.pk_g = reinterpret_cast<double *>(take(sizeof(double) * (size_t)pk_cap));
     b.seg = reinterpret_cast<LnsSeg *>(take(sizeof(LnsSeg) * (size_t)seg_cap));
     b.pk_cap = (int)std::min<int64_t>(pk_cap, 0x7fffffff); b.seg_cap = (int)std::min<int64_t>(seg_cap, 0x7fffffff);
     if (B) *B = b;
@@ -1645,7 +1647,7 @@ static void lns_attempt(const double *x, const LoudnormDynParams &P, const doubl
     hipLaunchKernelGGL(k_lns_fill, grid(nfill), dim3(256), 0, s, x, y, ring, B, ka, kb, P.offset_lin);
     hipLaunchKernelGGL(k_lns_bitmap, dim3((unsigned)std::min(nblk, 8192)), dim3(256), 0, s, y, B, (long long)tb0, (long long)tb1, P.target_tp_lin, (long long)blk0, nblk);
     hipLaunchKernelGGL(k_lns_scan, dim3(1), dim3(1024), 0, s, B, nblk);
-    hipLaunchKernelGGL(k_lns_scatter, grid((int64_t)nblk * LNS_BW), dim3(256), 0, s, y, B, (long long)blk0, nblk);
+    hipLaunchKernelGGL(k_lns_scatter, grid((int64_t)nblk * LNS_BW), dim3(256), 0, s, y, B, (long long)blk0, nblk, P.target_tp_lin);
     hipLaunchKernelGGL(k_lns_machine, dim3(1), dim3(64), 0, s, carry, P, B, y, ka, kb);
     hipLaunchKernelGGL(k_lns_apply, dim3(4096), dim3(256), 0, s, y, B, 0);
     hipLaunchKernelGGL(k_lns_apply, dim3(4096), dim3(256), 0, s, y, B, 1);
