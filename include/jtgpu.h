@@ -325,7 +325,8 @@ typedef struct { double pass1_ms, pass2_ms, pass3_ms, pass4_ms; double nlm_ms; i
                  int64_t tp_units_total,     /* last long analysis, branch-and-bound true peak: units of the signal ... */
                          tp_units_evaluated; /* ... and those whose 192 kHz outputs were evaluated (seeds + kept units) */
                  int64_t ln_stream_frames,   /* last dynamic-mode loudnorm: 100 ms frames its data-parallel stream path covered ... */
-                         ln_stream_why;      /* ... and why its last attempt ended (0: ran to the last full frame) */ } jt_timers;
+                         ln_stream_why;      /* ... and why its attempts ended, bit r = reason r: 0 ran to the last full frame, 1 limiter state not in
+                                                its steady form, 2 peak list full, 3 segment list full, 4 ring-end corner, 5 test switch */ } jt_timers;
 int jt_get_timers(jt_ctx *h, jt_timers *out);
 
 /* =====================================================================================

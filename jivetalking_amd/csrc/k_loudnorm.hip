@@ -1159,7 +1159,7 @@ k_lns_begin(const double *__restrict__ carry, const double *__restrict__ series,
         if (state != LIM_ATTACK) ok = ok && (int)carry[8] == LN_ATT;
         c->active = ok ? 1 : 0; c->ok = 0; c->attempts += 1;
         if (ok) { c->ka = ka; c->kbe = ka; c->npk = 0; c->nseg = 0; c->why = 0; }                // (the diagnostics are the last ACTIVE attempt's)
-        else if (c->frames == 0) c->why = 1;
+        else if (c->frames == 0) { c->why = 1; c->why_mask |= 2; }
         go = ok ? 1 : 0;
         prev_s = carry[12];
     }
@@ -1281,7 +1281,7 @@ k_lns_scan(LnsBufs B, int nblk)
     if (tid == 1023) {
         const int total = part[1023];
         B.ctl->npk = total;
-        if (total > B.pk_cap) { B.ctl->active = 0; B.ctl->why = 2; }
+        if (total > B.pk_cap) { B.ctl->active = 0; B.ctl->why = 2; B.ctl->why_mask |= 4; }
     }
 }
 __global__ void __launch_bounds__(256)
@@ -1469,7 +1469,7 @@ k_lns_machine(double *__restrict__ carry, LoudnormDynParams P, LnsBufs B, const 
                 if (c < nb) { env_cnt = 0; state = LIM_OUT; }
                 break; }
             }
-        } while (c < nb);
+        } while (c < nb && !hazard && !ovf);
         if (hazard || ovf) {
             gr0 = s_gr0; gr1 = s_gr1; state = s_state; last_pk = s_lp; env_cnt = s_ec; att = s_att; nseg = s_nseg; layer2 = s_l2;
             why = ovf ? 3 : 4;
@@ -1478,7 +1478,7 @@ k_lns_machine(double *__restrict__ carry, LoudnormDynParams P, LnsBufs B, const 
     }
     const int kbe = k;
     if (lane == 0) { ctl->iters = n_iter; ctl->refills = n_refill; ctl->cycles = clock64() - clk0; }
-    if (lane == 0) { ctl->kbe = kbe; ctl->nseg = nseg; ctl->why = why; ctl->ok = kbe > ka ? 1 : 0; if (kbe > ka) ctl->frames += kbe - ka; }
+    if (lane == 0) { ctl->kbe = kbe; ctl->nseg = nseg; ctl->why = why; ctl->why_mask |= 1 << why; ctl->ok = kbe > ka ? 1 : 0; if (kbe > ka) ctl->frames += kbe - ka; }
     if (kbe == ka) return;
     // hand-over to the workgroup kernel: the state at the start of inner frame kbe (step kbe + 1)
     const int index_ka = (int)carry[10], index_new = (index_ka + (kbe - ka)) % 30;

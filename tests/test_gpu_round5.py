@@ -216,3 +216,66 @@ def test_the_early_temporary_file_gives_the_late_ones_bytes_and_leaves_no_residu
         assert sorted(os.listdir(str(tmp_path))) == before
     finally:
         L.set_global_option("early_temp_min_kb", 32768)
+
+
+def _dyn_three_ways(engine, x, tp, off, stop=0):
+    """default (stream path) / the workgroup kernel alone (ln_no_stream) -> (outputs, stats, frames the stream path covered, reason mask)"""
+    try:
+        engine.set_option("ln_no_stream", True)
+        want, wst = engine.op_loudnorm_dynamic(x, target_tp=tp, offset=off)
+    finally:
+        engine.set_option("ln_no_stream", False)
+    try:
+        engine.set_option("ln_stream_stop", stop)
+        got, gst = engine.op_loudnorm_dynamic(x, target_tp=tp, offset=off)
+    finally:
+        engine.set_option("ln_stream_stop", 0)
+    t = engine.timers()
+    return want, wst, got, gst, int(t["ln_stream_frames"]), int(t["ln_stream_why"])
+
+
+@pytest.mark.parametrize("seed,level,tp,off,quiet_s,cut,stop", [(41, 2.5, -9.0, 0.0, 0.0, 0, 0), (7, 2.5, -20.0, 0.0, 0.0, 333, 0), (8, 4.0, -6.0, 3.0, 1.5, 19199, 37),
+                                                                  (10, 8.0, -1.0, 13.0, 2.9, 1, 0), (12, 6.0, -3.0, 0.0, 0.0, 0, 11), (9, 1.2, -12.0, 0.0, 0.0, 777, 0)])
+def test_dynamic_loudnorm_stream_path_equals_the_workgroup_kernel(engine, seed, level, tp, off, quiet_s, cut, stop):
+    """Round 5: between the first frames and the flush the dynamic mode's frames are data-parallel sweeps (gains, fill, detected peaks as a
+    sorted list, envelope segments applied, clamp) around ONE wave that walks af_loudnorm's limiter machine over the peak list without
+    touching a sample.  Same samples and stats as the one-workgroup kernel on 45 s streams limited lightly, continuously and hard, with
+    offsets, quiet starts and ragged ends; with the test switch that ends an attempt every `stop` frames (what the ring-end corner does)
+    the kernel and the stream path hand the state back and forth a dozen times, same samples again."""
+    x = synth.speech_like(45.0, 192000, seed=seed).astype(np.float64) * level
+    if quiet_s > 0:
+        x = np.concatenate([x[: int(192000 * quiet_s)] * 0.004, x])
+    if cut:
+        x = x[: x.size - cut]
+    want, wst, got, gst, frames, why = _dyn_three_ways(engine, x, tp, off, stop)
+    assert np.array_equal(got, want) and gst == wst and gst["normalization_type_dynamic"] == 1
+    n_inner = (x.size - 576000 + 19199) // 19200
+    if stop:
+        assert 0 < frames < n_inner - 8 and why & (1 << 5)
+    else:
+        assert frames >= n_inner - 9 and why == 1                       # everything behind the first launch's 8 steps up to the last full frame
+
+
+def test_dynamic_loudnorm_stream_path_stops_at_the_ring_end_corner(engine, oracle):
+    """What the peak list cannot know.  A SUSTAIN detector call that starts in a frame's last ten samples and finds nothing for 100 ms
+    tests candidates in the ring's last twelve positions against samples PAST the ring's end: af_loudnorm wraps to the frame's first
+    samples.  Built here: spike B 5 samples before the end of its frame's scan range (first peak: attack, then SUSTAIN from B), spike C
+    19 197 samples later (ring position 40 312 of 40 320) and a LARGER spike D nine samples behind C -- in the stream C is no peak (D within
+    its next ten), in the filter's ring C's next ten wrap to the quiet start of the frame and C IS one.  The machine must notice that its
+    list does not apply, stop before that frame and let the workgroup kernel (the filter's own walk) take it: same samples, reason 4 seen."""
+    rng = np.random.default_rng(5)
+    n = 192000 * 40
+    x = (rng.random(n) * 2.0 - 1.0) * 1e-3
+    T0 = 101 * 19200
+    for t, a in ((T0 + 21115, 0.5), (T0 + 40312, 0.5), (T0 + 40321, 0.56)):
+        x[t] = a
+    want, wst, got, gst, frames, why = _dyn_three_ways(engine, x, -1.0, 0.0)
+    assert np.array_equal(got, want) and gst == wst
+    assert why & (1 << 4) and frames > 150                                # stopped at the corner, and a later attempt took over again
+    ref, rst = oracle.loudnorm_dynamic(x, target_tp=-1.0)                 # (the filter's own walk: C is a peak there)
+    assert np.max(np.abs(got - ref)) <= 1e-9 * max(1.0, np.max(np.abs(ref)))
+    c = 101 * 19200 + 40312
+    assert abs(abs(ref[c]) - 10 ** (-1.0 / 20)) < 1e-9                    # brought down to the ceiling by its own attack, not clipped from 140
+    y2 = x.copy(); y2[T0 + 40321] = 0.4                                   # without the larger spike the list's answer is the ring's answer...
+    want, wst, got, gst, frames, why = _dyn_three_ways(engine, y2, -1.0, 0.0)
+    assert np.array_equal(got, want) and why & (1 << 4)                   # ... but the machine cannot know that: it still hands the frame over
