@@ -1433,6 +1433,10 @@ static void loudnorm_dynamic_run(jt_ctx *h, double *x, int64_t m, const Loudnorm
         h->ln_scratch.ensure(jt_lns_scratch_bytes(m, n_inner, nullptr, nullptr));
         jt_lns_scratch_bytes(m, n_inner, &lns, h->ln_scratch.p);
         JT_HIP(hipMemsetAsync(lns.ctl, 0, sizeof(LnsCtl), s));
+        // (test switch, negative values: -1 = a peak list of 64 entries, -N = a segment list of N entries: the two "list full" ways out)
+        if (h->opts.ln_stream_stop == -1) lns.pk_cap = 64;
+        else if (h->opts.ln_stream_stop < -1) lns.seg_cap = std::min(lns.seg_cap, -h->opts.ln_stream_stop);
+        if (h->opts.ln_stream_stop < 0) P.stream_stop = 0;
     }
     launch_loudnorm_dynamic(x, m, P, h->ln_series.p, h->ln_ring.p, y, nullptr, s, h->ln_carry.p, h->opts, stream ? &lns : nullptr);
     JT_HIP(hipGetLastError());

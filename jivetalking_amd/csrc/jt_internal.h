@@ -113,7 +113,8 @@ struct JtOpts {
     JT_OPT_AB_INTS(X)
 #undef X
     int tp_prune_min = 1 << 20;          // signals at least this long take the branch-and-bound true peak (k_resample.hip); shorter ones the exhaustive kernels
-    int ln_stream_stop = 0;              // test switch: the dynamic mode's stream path ends an attempt before every frame whose number is a multiple of this (as its ring-end corner does)
+    int ln_stream_stop = 0;              // test switch: the dynamic mode's stream path ends an attempt before every frame whose number is a multiple of this (as its
+                                         // ring-end corner does); -1: a peak list of 64 entries, -N: a segment list of N entries (its two "list full" ways out)
     int region_rot = -1;                 // -1: the announced regions' chains on adeclick's second stream; r: region chain i behind full chain (i + r) % 4
 };
 #ifdef JT_AB

@@ -279,3 +279,14 @@ def test_dynamic_loudnorm_stream_path_stops_at_the_ring_end_corner(engine, oracl
     y2 = x.copy(); y2[T0 + 40321] = 0.4                                   # without the larger spike the list's answer is the ring's answer...
     want, wst, got, gst, frames, why = _dyn_three_ways(engine, y2, -1.0, 0.0)
     assert np.array_equal(got, want) and why & (1 << 4)                   # ... but the machine cannot know that: it still hands the frame over
+
+
+@pytest.mark.parametrize("stop,bit", [(-1, 2), (-300, 3)])
+def test_dynamic_loudnorm_stream_path_with_full_lists(engine, stop, bit):
+    """The stream path's two bounded lists: detected peaks (sized for one peak per 48 samples of the file; a clipped plateau is one per
+    sample) and envelope segments (64 per frame).  A full peak list cancels the attempt, a full segment list ends it before the frame that
+    would not fit; the workgroup kernel does the rest.  Forced with the test switch: same samples, the reason reported."""
+    x = synth.speech_like(30.0, 192000, seed=77).astype(np.float64) * 3.0
+    want, wst, got, gst, frames, why = _dyn_three_ways(engine, x, -9.0, 0.0, stop)
+    assert np.array_equal(got, want) and gst == wst and why & (1 << bit)
+    assert frames == 0 if stop == -1 else 0 < frames <= 262                # (several attempts, each as far as its 300 segments reach)
