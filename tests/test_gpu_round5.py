@@ -290,3 +290,25 @@ def test_dynamic_loudnorm_stream_path_with_full_lists(engine, stop, bit):
     want, wst, got, gst, frames, why = _dyn_three_ways(engine, x, -9.0, 0.0, stop)
     assert np.array_equal(got, want) and gst == wst and why & (1 << bit)
     assert frames == 0 if stop == -1 else 0 < frames <= 262                # (several attempts, each as far as its 300 segments reach)
+
+
+def test_dynamic_loudnorm_stream_path_waits_for_the_above_threshold_latch(engine, oracle):
+    """A file that starts below the measured threshold: af_loudnorm ramps its gain by 1.0058 per frame until the OUTPUT's short-term loudness
+    reaches the target (above_threshold, a latch) -- the one feedback from the limiter's output into the gains.  The stream path's first
+    attempts find the latch open and do nothing (reason 1), the workgroup kernel meters its own output until it closes, a later attempt
+    takes the rest: same samples as the workgroup kernel alone, and the oracle's within the dynamic tests' bar."""
+    x = synth.speech_like(40.0, 192000, seed=23).astype(np.float64) * 2.5
+    x[: 192000 * 9] *= 0.002
+    meas = (-23.0, 7.0, -2.0, -33.0)
+    try:
+        engine.set_option("ln_no_stream", True)
+        want, wst = engine.op_loudnorm_dynamic(x, target_tp=-6.0, measured=meas)
+    finally:
+        engine.set_option("ln_no_stream", False)
+    got, gst = engine.op_loudnorm_dynamic(x, target_tp=-6.0, measured=meas)
+    t = engine.timers()
+    assert np.array_equal(got, want) and gst == wst
+    n_inner = (x.size - 576000 + 19199) // 19200
+    assert int(t["ln_stream_why"]) & 2 and 100 < int(t["ln_stream_frames"]) < n_inner - 40      # the first attempts waited; a later one ran
+    ref, rst = oracle.loudnorm_dynamic(x, target_tp=-6.0, measured=meas)
+    assert np.max(np.abs(got - ref)) <= 1e-9 * max(1.0, np.max(np.abs(ref)))
