@@ -309,8 +309,8 @@ def saturation_on_gpu(args, eng, rank, world, device, base, hostlogic, synth, sr
 
 
 def dynamic_batch_leg(eng, device, base, hostlogic, synth, sr, files, minutes, plosives):
-    """The dynamic-loudnorm fallback is one workgroup walking the frames of a file (k_loudnorm.hip): a single file cannot use the GPU, a
-    batch can - `files` such files at once through jt_process_files_multi, one worker each.  File to file (FLAC in /dev/shm)."""
+    """The dynamic-loudnorm fallback's serial part is one wave walking a peak list (k_loudnorm.hip, stream path): a single file leaves the
+    GPU idle meanwhile, a batch does not - `files` such files at once through a handle pool, one worker each.  File to file (FLAC in /dev/shm)."""
     import shutil
     import tempfile
     import torch
@@ -323,14 +323,22 @@ def dynamic_batch_leg(eng, device, base, hostlogic, synth, sr, files, minutes, p
             pk = os.path.join(d, f"dyn{k:02d}.flac")
             open(pk, "wb").write(eng.op_flac_encode(pcm, sr, md5=True)); paths.append(pk)
             del x
-        t0 = time.perf_counter()
-        failed, fr, _ = hostlogic.process_files_multi(paths, devices=(device,), in_flight_per_device=files, base=base, md5=False)
-        wall = time.perf_counter() - t0
-        return {"files": files, "minutes_per_file": minutes, "in_flight": files, "failed": int(failed), "wall_s": round(wall, 2),
+        walls = []
+        with hostlogic.Pool(devices=(device,), in_flight_per_device=files) as pool:
+            for run in range(3):                                   # (the first batch opens the handles' 192 kHz streams: 2 GB each)
+                t0 = time.perf_counter()
+                failed, fr, _ = pool.process_files(paths, base=base, md5=False)
+                walls.append(time.perf_counter() - t0)
+                for i in range(files):
+                    if fr[i].rc == 0:
+                        os.unlink(fr[i].output_path.decode())
+        wall = min(walls[1:])
+        return {"files": files, "minutes_per_file": minutes, "in_flight": files, "failed": int(failed), "wall_s": round(wall, 3),
+                "wall_s_runs": [round(w, 3) for w in walls], "wall_s_is": "best of the two batches after the first (which allocates)",
                 "xRT_aggregate": round(files * minutes * 60.0 / wall, 1),
                 "dynamic_files": int(sum(1 for i in range(files) if fr[i].rc == 0 and fr[i].result.loudnorm.normalization_type_dynamic)),
-                "note": "throughput of a batch of such files on one GPU (each worker's dynamic-loudnorm kernel is one workgroup on one CU, the workers run side by side); "
-                        "the single-file figure above is the latency"}
+                "note": "throughput of a batch of such files through a handle pool on one GPU, file to file; the single-file figure above is the latency "
+                        "of one file alone (its state machine is one wave: several files side by side hide it)"}
     finally:
         shutil.rmtree(d, ignore_errors=True)
 
