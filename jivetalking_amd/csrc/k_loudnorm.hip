@@ -1595,12 +1595,63 @@ k_swr_tile_f64(const double *__restrict__ in, int64_t n, const double *__restric
     for (int i = 0; i < L; ++i) val += t[i] * f[(size_t)i * P];
     out[m] = val;
 }
+// Four outputs per thread.  Outputs P apart share their phase, i.e. their taps: thread t of a block computes m0 + t, m0 + t + P, m0 + t + 2P,
+// m0 + t + 3P with ONE tap fetch per tap and four independent sums (k_swr_tile_f64: one fetch and one dependent multiply-add chain per
+// output).  The block's inputs ((4P - 1) step / P + L samples: 22 KB at 192 -> 44.1 kHz) go through LDS as before.  Same sums.
+// (The tap rows in LDS too -- 49 phases x 5 outputs per block -- was slower than either: 4.2 ms against 3.4, the block spends as long
+//  filling 78 KB of LDS as it spends computing.)
+constexpr int SWR_K = 4;
+__global__ void __launch_bounds__(256)
+k_swr_tile4_f64(const double *__restrict__ in, int64_t n, const double *__restrict__ bankT, int P, int L, int center, int64_t step, int64_t m_total,
+                double *__restrict__ out, int tile_len)
+{
+    extern __shared__ double swr_tile4[];
+    const int tid = threadIdx.x;
+    const int64_t m0 = (int64_t)blockIdx.x * SWR_K * P;
+    const int64_t s0 = (m0 * step) / P - center;
+    for (int e = tid; e < tile_len; e += blockDim.x) {
+        int64_t g = s0 + e;
+        double v = 0.0;
+        if (g < 0) g = -g;                                           // invert_initial_buffer(): in[-j] = in[j]
+        if (g < n) v = in[g];
+        else { const int64_t r = 2 * n - 1 - g; if (r >= 0 && r < n) v = in[r]; }   // resample_flush()
+        swr_tile4[e] = v;
+    }
+    __syncthreads();
+    if (tid >= P) return;
+    const int64_t m = m0 + tid;
+    if (m >= m_total) return;
+    const int64_t idx = m * step;
+    const int ph = (int)(idx % P);
+    const double *t = swr_tile4 + (int)(idx / P - center - s0);     // output m + k P starts k * step samples further on
+    const double *f = bankT + ph;
+    double v0 = 0.0, v1 = 0.0, v2 = 0.0, v3 = 0.0;
+#pragma unroll 2
+    for (int i = 0; i < L; ++i) {
+        const double c = f[(size_t)i * P];
+        v0 += t[i] * c; v1 += t[i + step] * c; v2 += t[i + 2 * step] * c; v3 += t[i + 3 * step] * c;
+    }
+    out[m] = v0;
+    if (m + P < m_total) out[m + P] = v1;
+    if (m + 2 * (int64_t)P < m_total) out[m + 2 * (int64_t)P] = v2;
+    if (m + 3 * (int64_t)P < m_total) out[m + 3 * (int64_t)P] = v3;
+}
 }  // namespace
 
 void launch_swr_plain_f64(const double *in, int64_t n, const double *bank, int P, int L, int center, int64_t step, int64_t m_total, double *out, hipStream_t s,
                           const double *bankT)
 {
     if (m_total <= 0) return;
+    if (bankT && P >= 64 && P <= 256) {
+        const int tile_len = (int)(((int64_t)(SWR_K * P - 1) * step) / P + L + 2);
+        const size_t lds = sizeof(double) * (size_t)tile_len;
+        if (lds <= 48 * 1024) {
+            const int64_t per_block = (int64_t)SWR_K * P;
+            hipLaunchKernelGGL(k_swr_tile4_f64, dim3((unsigned)((m_total + per_block - 1) / per_block)), dim3((unsigned)((P + 63) / 64 * 64)), lds, s,
+                               in, n, bankT, P, L, center, step, m_total, out, tile_len);
+            return;
+        }
+    }
     const size_t smem = sizeof(double) * (size_t)((255 * step) / P + L + 2);
     if (bankT && smem <= 48 * 1024) {
         hipLaunchKernelGGL(k_swr_tile_f64, dim3((unsigned)((m_total + 255) / 256)), dim3(256), smem, s, in, n, bankT, P, L, center, step, m_total, out);
