@@ -76,7 +76,8 @@ void jt_end_job(jt_ctx *h);
  *     brickwall as doubles + a dbl -> flt -> s16 sweep instead of writing the float and the s16 itself), ln_no_batch (dynamic-mode
  *     loudnorm: the limiter's harmless peaks one detector call at a time instead of a frame's worth in one step; same bytes),
  *     ln_no_stream (dynamic-mode loudnorm: every frame through the one-workgroup kernel instead of the data-parallel stream path; same bytes),
- *     swr_untiled (the dynamic mode's 192 kHz -> source-rate aresample one thread per output instead of the LDS-tiled kernel; same bytes)
+ *     swr_untiled (the dynamic mode's 192 kHz -> source-rate aresample one thread per output instead of the LDS-tiled kernel; same bytes),
+ *     flac_no_ahead (mono FLAC input: a parse walk and a decode walk per frame, as for stereo, instead of one walk that does both; same samples)
  *   diagnostics: host_timing (host-stage timings on stderr; PROCESS-WIDE although it is set through a handle: the host stages are
  *     plain functions without one, the last writer wins for every handle of the process)
  *   process-wide (h == NULL): graveyard_gb (gigabytes of superseded buffers parked before they are freed, default 24, 0 = free at

@@ -99,7 +99,7 @@ template <typename T> struct DevBuf {
 // that build imports JT_<KEY> variables, once, inside jt_open.
 #define JT_OPT_BOOLS(X) \
     X(no_pass2_prefetch) X(no_early_pass3) X(no_early_plan) X(no_lim_keep) X(no_staged_finish) X(no_r128_first) \
-    X(region_full_astats) X(host_timing) X(adeclick_exact) X(nlm_generic) X(p3_unfused) X(limiter_lanes) X(tp_unpruned) X(no_spec_direct) X(brickwall_f64) X(nf_low) X(ln_no_batch) X(ln_no_stream) X(swr_untiled)
+    X(region_full_astats) X(host_timing) X(adeclick_exact) X(nlm_generic) X(p3_unfused) X(limiter_lanes) X(tp_unpruned) X(no_spec_direct) X(brickwall_f64) X(nf_low) X(ln_no_batch) X(ln_no_stream) X(swr_untiled) X(flac_no_ahead)
 #define JT_OPT_INTS(X) X(region_rot) X(tp_prune_min) X(ln_stream_stop)
 #define JT_OPT_AB_BOOLS(X) \
     X(nlm_old) X(afftdn_old) X(adeclick_fused) X(dk_levinson_in_kernel) X(dk_no_xcd) X(dk_serial) X(dk_profile) X(dyn_one_wave) \
@@ -297,6 +297,9 @@ struct JtFlacParsed { long long end; int ok, wasted_any; long long sub_bit[8]; }
 struct JtFlacFrame { long long pos, out_offset; int blocksize, ch_assign; long long sub_bit[8]; };
 void launch_flacdec_find(const uint8_t *file, const JtFlacStream &s, JtFlacCand *cands, int *count, int cap, hipStream_t st);
 void launch_flacdec_parse(const uint8_t *file, const JtFlacStream &s, const JtFlacCand *cands, int ncand, JtFlacParsed *out, hipStream_t st);
+// mono streams: every candidate parsed AND decoded by one walk, into its own row of max_blocksize samples; the chain's rows gathered
+void launch_flacdec_decode_cand(const uint8_t *file, const JtFlacStream &s, const JtFlacCand *cands, int ncand, int *rows, JtFlacParsed *parsed, hipStream_t st);
+void launch_flacdec_finish_cand(const JtFlacStream &s, const JtFlacFrame *frames, long long nframes, const int *rows, int *out_i32, float *out_f32, hipStream_t st);
 void launch_flacdec_decode(const uint8_t *file, const JtFlacStream &s, const JtFlacFrame *frames, long long nframes, long long total,
                            int *planar, int *errs, int *out_i32, float *out_f32, hipStream_t st);
 void launch_pcm_convert(const uint8_t *raw, long long nvals, int fmt, float *out_f32, int *out_i32, hipStream_t st);

@@ -192,6 +192,7 @@ void decode_flac(jt_ctx *h, const uint8_t *file, int64_t len, int64_t start, boo
     JtFlacCand *cands = nullptr; JtFlacParsed *parsed = nullptr;
     int *counts = nullptr;                                    // [0] candidates found, [1] subframe decode errors
     int ncand = 0;
+    bool ahead = false;                                       // mono: the candidates' samples are decoded already, one row each
     for (int attempt = 0; attempt < 2; attempt++) {
         h->io_small.begin(4096 + (sizeof(JtFlacCand) + sizeof(JtFlacParsed)) * (size_t)cap + 256);      // (nothing of the arena is in flight here)
         counts = h->io_small.take<int>(16); counts[0] = counts[1] = 0;
@@ -208,7 +209,12 @@ void decode_flac(jt_ctx *h, const uint8_t *file, int64_t len, int64_t start, boo
         ncand = counts[0]; tm1 = flac_now_ms();
         if (ncand > cap) { cap = ncand + 1024; continue; }
         JT_REQUIRE(ncand > 0, JT_E_INVAL, "flac: no frame headers found");
-        launch_flacdec_parse(h->in_file.p, st, d_cand, ncand, d_parsed, h->stream);
+        // mono: one walk per candidate parses AND decodes it, into a row of its own (k_flacdec.hip, k_flac_decode_cand)
+        ahead = st.channels == 1 && !h->opts.flac_no_ahead && (int64_t)ncand * st.max_blocksize < ((int64_t)1 << 31);
+        if (ahead) {
+            h->in_planar.ensure((size_t)ncand * (size_t)st.max_blocksize + 64);
+            launch_flacdec_decode_cand(h->in_file.p, st, d_cand, ncand, h->in_planar.p, d_parsed, h->stream);
+        } else launch_flacdec_parse(h->in_file.p, st, d_cand, ncand, d_parsed, h->stream);
         JT_HIP(hipMemcpyAsync(cands, d_cand, sizeof(JtFlacCand) * (size_t)ncand, hipMemcpyDeviceToHost, h->stream));
         JT_HIP(hipMemcpyAsync(parsed, d_parsed, sizeof(JtFlacParsed) * (size_t)ncand, hipMemcpyDeviceToHost, h->stream));
         JT_HIP(jt_stream_sync(h, h->stream));
@@ -255,6 +261,7 @@ void decode_flac(jt_ctx *h, const uint8_t *file, int64_t len, int64_t start, boo
         else JT_REQUIRE(c.number == (int64_t)frames.size(), JT_E_INVAL, "flac: frame number out of sequence");
         JtFlacFrame f; f.pos = c.pos; f.out_offset = total; f.blocksize = c.blocksize; f.ch_assign = c.ch_assign;
         for (int k = 0; k < 8; k++) f.sub_bit[k] = pr.sub_bit[k];
+        if (ahead) f.sub_bit[7] = ci;                          // (mono: slots 1..7 are free) the candidate whose row holds this frame's samples
         frames.push_back(f);
         total += c.blocksize; cur = pr.end;
     }
@@ -264,7 +271,7 @@ void decode_flac(jt_ctx *h, const uint8_t *file, int64_t len, int64_t start, boo
 
     tm3 = flac_now_ms();
     const size_t nvals = (size_t)total * (size_t)st.channels;
-    h->in_planar.ensure(nvals + 64);
+    if (!ahead) h->in_planar.ensure(nvals + 64);
     if (want_i32) h->in_i32.ensure(nvals);
     if (want_f32) h->in_owned.ensure(nvals);
     const size_t ftab = sizeof(JtFlacFrame) * frames.size();
@@ -273,6 +280,10 @@ void decode_flac(jt_ctx *h, const uint8_t *file, int64_t len, int64_t start, boo
     JtFlacFrame *d_frames = reinterpret_cast<JtFlacFrame *>(h->in_tab.p + 256);
     JT_HIP(hipMemsetAsync(d_err, 0, 256, h->stream));
     JT_HIP(hipMemcpyAsync(d_frames, frames.data(), ftab, hipMemcpyHostToDevice, h->stream));
+    if (ahead) {
+        launch_flacdec_finish_cand(st, d_frames, (long long)frames.size(), h->in_planar.p,
+                                   want_i32 ? h->in_i32.p : nullptr, want_f32 ? h->in_owned.p : nullptr, h->stream);
+    } else
     launch_flacdec_decode(h->in_file.p, st, d_frames, (long long)frames.size(), total, h->in_planar.p, d_err,
                           want_i32 ? h->in_i32.p : nullptr, want_f32 ? h->in_owned.p : nullptr, h->stream);
     JT_HIP(hipMemcpyAsync(&counts[1], d_err, sizeof(int), hipMemcpyDeviceToHost, h->stream));

@@ -397,6 +397,131 @@ __global__ __launch_bounds__(64) void k_flac_decode(const uint8_t *__restrict__ 
     if (live && (st.bad || br.err)) atomicAdd(errs, 1);
 }
 
+// ---------------------------------------------------------------------------------------------------------------- decode ahead of the chain (mono)
+// A mono frame's only subframe starts right behind the frame header: no parse result is needed to decode it, and the walk that decodes
+// it is the walk k_flac_parse makes to find the frame's end.  So for mono streams ONE kernel does both: one lane per CANDIDATE
+// (look-alikes included: they decode to garbage nobody reads, inside the reader's own bounds), the samples into the candidate's own row
+// of max_blocksize entries, the frame's end / padding / CRC-16 verdict into the table the host's chain walk reads; k_flac_finish_cand
+// then gathers the rows of the frames the chain kept.  (Both kernels are one lane per frame, one wave per SIMD: an hour's file and a
+// ten minutes' alike took 3.3 ms each; side by side on two streams they took 6.6 -- the walk is bound by something they share --
+// so the parse had to go, not move.)  The datapath is k_flac_decode's (the same functions, the same wave-uniform choices).
+__global__ __launch_bounds__(64) void k_flac_decode_cand(const uint8_t *__restrict__ d, StreamInfo si, const Cand *__restrict__ cands, int ncand,
+                                                         int *__restrict__ rows, Parsed *__restrict__ out)
+{
+    __shared__ unsigned crc_tab[256];
+    for (int t = threadIdx.x; t < 256; t += 64) {
+        unsigned c = (unsigned)t << 8;
+        for (int k = 0; k < 8; k++) c = (c & 0x8000) ? (c << 1) ^ 0x8005 : (c << 1);
+        crc_tab[t] = c & 0xffff;
+    }
+    __shared__ int tile[64 * ROW];
+    __shared__ int hist[32 * 64], coef[32 * 64];
+    __shared__ unsigned ring[64 * 64];
+    __shared__ int rowbs[64];
+    constexpr int NT = 12;
+    const int lane = threadIdx.x;
+    const int idx = blockIdx.x * 64 + lane;
+    const bool live = idx < ncand;
+    Cand c; c.pos = si.audio_offset; c.hdr_len = 0; c.blocksize = 0; c.number = 0; c.ch_assign = 0; c.variable = 0;
+    if (live) c = cands[idx];
+    BitReader br; SubState st; st.type = 0; st.constv = 0; st.wasted = 0; st.bad = false; st.order = 0; st.prec = 0; st.bps = 1; st.shift = 0;
+    const long long start_bit = (c.pos + c.hdr_len) * 8;
+    br.init(d, start_bit, si.len * 8, ring, lane);
+    if (live) sub_begin<true>(br, st, c.blocksize, si.bps, hist, coef, lane);
+    const int bs = live ? c.blocksize : 0;
+    rowbs[lane] = bs;
+    int maxbs = bs;
+#pragma unroll
+    for (int m = 1; m < 64; m <<= 1) { const int o = __shfl_xor(maxbs, m); maxbs = o > maxbs ? o : maxbs; }
+    const bool pred = live && st.type == 2 && st.order > 0;
+    const bool in_regs = !__any(pred && st.order > NT);
+    const bool narrow = !__any(pred && st.bps + st.prec + (31 - __clz(st.order > 0 ? st.order : 1)) > 32) && si.bps <= 22;
+    int cr[NT], hr[NT];
+#pragma unroll
+    for (int j = 0; j < NT; j++) { cr[j] = (pred && j < st.order) ? coef[j * 64 + lane] : 0; hr[j] = 0; }
+    __syncthreads();
+    const long long row0 = (long long)blockIdx.x * 64 * si.max_bs;
+    for (int i0 = 0; i0 < maxbs; i0 += 64) {
+        if (i0 < bs) {
+            const int n = bs - i0 < 64 ? bs - i0 : 64;
+            if (in_regs) {
+                for (int q = 0; q < n; q++) {
+                    if ((q & 15) == 0) br.topup();
+                    const int i = i0 + q;
+                    int v;
+                    if (st.type == 0) v = st.constv;
+                    else if (st.type == 1) v = br.s(st.bps);
+                    else if (i < st.order) v = hist[(i & 31) * 64 + lane];
+                    else {
+                        const int r = sub_residual(br, st);
+                        if (narrow) {
+                            int a = 0;
+#pragma unroll
+                            for (int j = 0; j < NT; j++) a += __mul24(cr[j], hr[j]);
+                            v = r + (a >> st.shift);
+                        } else {
+                            long long a = 0;
+#pragma unroll
+                            for (int j = 0; j < NT; j++) a += (long long)cr[j] * (long long)hr[j];
+                            v = r + (int)(a >> st.shift);
+                        }
+                    }
+#pragma unroll
+                    for (int j = NT - 1; j > 0; j--) hr[j] = hr[j - 1];
+                    hr[0] = v;
+                    tile[lane * ROW + q] = (int)((unsigned)v << st.wasted);
+                }
+            } else {
+                for (int q = 0; q < n; q++) {
+                    if ((q & 15) == 0) br.topup();
+                    const int v = sub_step<true>(br, st, i0 + q, hist, coef, lane);
+                    tile[lane * ROW + q] = (int)((unsigned)v << st.wasted);
+                }
+            }
+        }
+        __syncthreads();
+        for (int r = 0; r < 64; r++) {
+            const int rb = rowbs[r];
+            if (i0 + lane < rb) rows[row0 + (long long)r * si.max_bs + i0 + lane] = tile[r * ROW + lane];
+        }
+        __syncthreads();
+    }
+    // what k_flac_parse establishes about a frame, from the same walk: zero padding to the byte, the CRC-16 over the whole frame, its end
+    if (live) {
+        Parsed pr; pr.ok = 0; pr.end = 0; pr.wasted_any = st.wasted ? 1 : 0;
+        for (int ch = 0; ch < 8; ch++) pr.sub_bit[ch] = 0;
+        pr.sub_bit[0] = start_bit;
+        bool bad = st.bad || br.err || br.used > br.limit;
+        if (!bad) {
+            const int padbits = (int)((8 - ((start_bit + br.used) & 7)) & 7);
+            if (br.u(padbits) != 0) bad = true;
+            const long long crc_pos = (start_bit + br.used) >> 3;
+            const unsigned stored = br.u(16);
+            if (br.used > br.limit || br.err) bad = true;
+            if (!bad) {
+                unsigned crc = 0;
+                for (long long b = c.pos; b < crc_pos; b++) crc = ((crc << 8) ^ crc_tab[((crc >> 8) ^ d[b]) & 0xff]) & 0xffff;
+                if (crc == stored) { pr.ok = 1; pr.end = crc_pos + 2; }
+            }
+        }
+        out[idx] = pr;
+    }
+}
+// one block per frame of the chain: its candidate's row (index in sub_bit[7]) to the output
+__global__ __launch_bounds__(256) void k_flac_finish_cand(const Frame *__restrict__ frames, int max_bs, const int *__restrict__ rows,
+                                                          int *__restrict__ out_i32, float *__restrict__ out_f32, float scale)
+{
+    const Frame fr = frames[blockIdx.x];
+    const long long ci = fr.sub_bit[7];
+    const int *src = rows + ci * max_bs;
+    for (int i = threadIdx.x; i < fr.blocksize; i += blockDim.x) {
+        const long long s = fr.out_offset + i;
+        const int v = src[i];
+        if (out_i32) out_i32[s] = v;
+        if (out_f32) out_f32[s] = (float)v * scale;
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------------------- finish
 // one block per frame: stereo decorrelation, interleave, optional f32 conversion
 __global__ __launch_bounds__(256) void k_flac_finish(const Frame *__restrict__ frames, int channels, long long total,
@@ -479,6 +604,21 @@ void launch_flacdec_decode(const uint8_t *file, const JtFlacStream &s, const JtF
                        reinterpret_cast<const fd::Frame *>(frames), nsub, total, planar, errs);
     hipLaunchKernelGGL(fd::k_flac_finish, dim3((unsigned)nframes), dim3(256), 0, st, reinterpret_cast<const fd::Frame *>(frames),
                        s.channels, total, planar, out_i32, out_f32, (float)(1.0 / (double)(1ull << (s.bps - 1))));
+    JT_HIP(hipGetLastError());
+}
+void launch_flacdec_decode_cand(const uint8_t *file, const JtFlacStream &s, const JtFlacCand *cands, int ncand, int *rows, JtFlacParsed *parsed, hipStream_t st)
+{
+    if (ncand <= 0) return;
+    hipLaunchKernelGGL(fd::k_flac_decode_cand, dim3((unsigned)((ncand + 63) / 64)), dim3(64), 0, st, file, mk_si(s),
+                       reinterpret_cast<const fd::Cand *>(cands), ncand, rows, reinterpret_cast<fd::Parsed *>(parsed));
+    JT_HIP(hipGetLastError());
+}
+void launch_flacdec_finish_cand(const JtFlacStream &s, const JtFlacFrame *frames, long long nframes, const int *rows,
+                                int *out_i32, float *out_f32, hipStream_t st)
+{
+    if (nframes <= 0) return;
+    hipLaunchKernelGGL(fd::k_flac_finish_cand, dim3((unsigned)nframes), dim3(256), 0, st, reinterpret_cast<const fd::Frame *>(frames), s.max_blocksize,
+                       rows, out_i32, out_f32, (float)(1.0 / (double)(1ull << (s.bps - 1))));
     JT_HIP(hipGetLastError());
 }
 void launch_pcm_convert(const uint8_t *raw, long long nvals, int fmt, float *out_f32, int *out_i32, hipStream_t st)

@@ -312,3 +312,44 @@ def test_dynamic_loudnorm_stream_path_waits_for_the_above_threshold_latch(engine
     assert int(t["ln_stream_why"]) & 2 and 100 < int(t["ln_stream_frames"]) < n_inner - 40      # the first attempts waited; a later one ran
     ref, rst = oracle.loudnorm_dynamic(x, target_tp=-6.0, measured=meas)
     assert np.max(np.abs(got - ref)) <= 1e-9 * max(1.0, np.max(np.abs(ref)))
+
+
+def test_mono_flac_one_walk_per_candidate_equals_parse_then_decode(engine, oracle):
+    """Round 5: for mono streams one kernel walks each frame candidate once -- samples into the candidate's own row, end / padding /
+    CRC-16 verdict into the table the host's chain walk reads -- instead of a parse walk and a decode walk (option flac_no_ahead, the
+    path stereo keeps).  Same samples for every predictor / residual coding / block size the oracle's coverage encoder writes, with
+    look-alike headers inside verbatim frames, and the same refusal of a damaged stream."""
+    rng = np.random.default_rng(12)
+    datas = []
+    for mode, bps, order, bs in ((0, 16, 8, 4096), (1, 8, 3, 4096), (2, 24, 32, 4096), (2 | 8, 16, 12, 1152), (2 | 16, 20, 5, 4096), (1 | 32, 12, 2, 1152), (1 | 16 | 8, 16, 8, 576)):
+        x = (rng.standard_normal((30000 + 77, 1)).cumsum(0) * (1 << (bps - 6)) / 30).clip(-(1 << (bps - 1)), (1 << (bps - 1)) - 1).astype(np.int32)
+        if mode & 8:
+            x[:512] &= ~7
+        datas.append((oracle.flac_encode(x, 44100, bps, bs, mode, order), x))
+    noise = rng.integers(-32768, 32768, 4096 * 5).astype(np.int16)                   # verbatim frames; a header look-alike inside one
+    hdr = bytes([0xff, 0xf8, 0xc9, 0x08, 0x02]); c8 = 0
+    for b in hdr:
+        c8 ^= b
+        for _ in range(8):
+            c8 = ((c8 << 1) ^ 0x07) & 0xff if c8 & 0x80 else (c8 << 1) & 0xff
+    noise[5000:5003] = np.frombuffer(hdr + bytes([c8]), ">i2")
+    datas.append((engine.op_flac_encode(noise, 44100), noise.astype(np.int32)[:, None]))
+    for data, x in datas:
+        got, _, meta = engine.op_decode_audio(data)
+        try:
+            engine.set_option("flac_no_ahead", True)
+            want, _, wmeta = engine.op_decode_audio(data)
+        finally:
+            engine.set_option("flac_no_ahead", False)
+        for k in ("gpu_ms", "total_ms"):
+            meta.pop(k, None); wmeta.pop(k, None)
+        assert np.array_equal(got, x) and np.array_equal(want, x) and meta == wmeta
+    bad = bytearray(datas[0][0]); bad[len(bad) // 2] ^= 0x10
+    for flag in (False, True):
+        try:
+            engine.set_option("flac_no_ahead", flag)
+            with pytest.raises(L.JtError) as ei:
+                engine.op_decode_audio(bytes(bad))
+            assert ei.value.code == L.JT_E_INVAL
+        finally:
+            engine.set_option("flac_no_ahead", False)

@@ -11,6 +11,8 @@ x = synth.speech_like_torch(3600.0, 48000, seed=1000, device="cuda:0", plosives_
 pcm = (x * 32768.0).round().clamp(-32768, 32767).to(torch.int16).cpu().numpy(); del x
 e = Engine(0)
 if os.environ.get("JT_HT"): e.set_option("host_timing", "1")
+for kv in filter(None, os.environ.get("JT_OPTS", "").split(",")):      # JT_OPTS=key=value,key=value
+    e.set_option(*kv.split("=", 1))
 p = os.path.join(d, "ep.flac"); open(p, "wb").write(e.op_flac_encode(pcm, 48000, md5=True))
 for i in range(runs + 1):
     t0 = time.perf_counter(); res, out, io = H.process_file(e, p, md5=md5); dt = (time.perf_counter() - t0) * 1e3
