@@ -30,7 +30,8 @@ def oracle_pass2(orc, x, fp, sr):
     if fp.deess_enabled:
         yd = orc.deesser(yd, sr, fp.deess_i, fp.deess_m, fp.deess_f)
     yf = yd.astype(np.float32)          # dbl -> flt before aspectralstats
-    s16 = orc.f64_to_s16(orc.swr_f64(yf.astype(np.float64), sr, 44100, True))
+    # (a 44.1 kHz source: libswresample sets up no resampler for equal rates, aresample=44100 only converts the format)
+    s16 = orc.f64_to_s16(yf.astype(np.float64) if sr == 44100 else orc.swr_f64(yf.astype(np.float64), sr, 44100, True))
     return yf, s16
 
 

@@ -1,0 +1,44 @@
+"""Pass 2 of random files on the GPU against the same chain composed from the CPU oracle with the GPU run's effective parameters
+(highpass, lowpass, anlmdn, afftdn, agate, acompressor, deesser, dbl -> flt, swr -> 44.1 kHz s16): room tone of different levels and
+colours, pauses, strong sibilance (the de-esser), 48 / 44.1 kHz.  The bar is the suite's: <= 3 LSB of s16 anywhere, < 0.3 LSB on average
+(afftdn's f32 transform schedule).  usage: fuzz_pass2.py [cases] [seed]"""
+import sys, time, ctypes as C, numpy as np, torch
+sys.path.insert(0, '.'); sys.path.insert(0, 'tests')
+from jivetalking_amd import Engine, synth, hostlogic as H, _lib as L
+from oracle import orc
+from test_gpu_pipeline import oracle_pass2
+cases = int(sys.argv[1]) if len(sys.argv) > 1 else 10
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 9)
+e = Engine(0)
+bad = 0; worst = 0; wmean = 0.0; sw = {}
+for c in range(cases):
+    sr = int(rng.choice([48000, 48000, 44100]))
+    secs = float(rng.uniform(16.0, 30.0))
+    kind = int(rng.integers(0, 5))
+    seed = int(rng.integers(1, 10**6))
+    if kind == 4:                                            # sibilants concentrated in 6.75-8.25 kHz: AdaptConfig switches the de-esser on
+        x = synth.speech_like_torch(secs, sr, seed=seed, device="cuda:0", sib_gain=float(rng.uniform(0.4, 1.5)), sib_band=True).cpu().numpy().astype(np.float64)
+    else:
+        x = np.asarray(synth.speech_like(secs, sr, seed=seed, speech_dbfs=float(rng.uniform(-36, -24)), room_dbfs=float(rng.uniform(-75, -50))), np.float64)
+    x *= float(10 ** rng.uniform(-1.0, 0.2))
+    if kind in (1, 2, 3):
+        nz = rng.standard_normal(x.size)
+        if kind == 2:
+            nz = np.convolve(nz, np.ones(24) / 24, mode="same") * 4
+        x += nz * float(10 ** rng.uniform(-3.75, -2.2))
+    if kind == 3:
+        a = int(rng.integers(0, x.size - 5 * sr)); x[a: a + int(rng.uniform(1.5, 4.0) * sr)] *= 0.003
+    x = np.clip(x, -1, 1).astype(np.float32)
+    e.upload_pcm(x, sr, 1)
+    res = H.process_audio(e)
+    p2 = e.download_s16(2)
+    fp = L.FilterParams(); H.lib().jt_host_filter_params(C.byref(res.effective), C.byref(fp))
+    t0 = time.time()
+    _, ref = oracle_pass2(orc, x, fp, sr)
+    d = np.abs(ref.astype(np.int32) - p2.astype(np.int32)) if ref.size == p2.size else np.array([99])
+    key = (int(fp.nlm_enabled), int(fp.fft_enabled), int(fp.fft_custom), int(fp.gate_enabled), int(fp.comp_enabled), int(fp.deess_enabled))
+    sw[key] = sw.get(key, 0) + 1
+    ok = ref.size == p2.size and d.max() <= 3 and d.mean() < 0.3
+    bad += not ok; worst = max(worst, int(d.max())); wmean = max(wmean, float(d.mean()))
+    print(f"case {c:2d} {sr} Hz {secs:4.1f} s kind {kind} switches nlm/fft/custom/gate/comp/deess {key}: max {int(d.max())} LSB, mean {d.mean():.4f} (oracle {time.time() - t0:.1f} s){'' if ok else '   <-- OVER THE BAR'}", flush=True)
+print(f"{cases} cases, {bad} over the bar; worst max {worst} LSB, worst mean {wmean:.4f}; switch combinations seen: {sw}")
