@@ -1,6 +1,6 @@
 """Pass 2 of random files on the GPU against the same chain composed from the CPU oracle with the GPU run's effective parameters
 (highpass, lowpass, anlmdn, afftdn, agate, acompressor, deesser, dbl -> flt, swr -> 44.1 kHz s16): room tone of different levels and
-colours, pauses, strong sibilance (the de-esser), 48 / 44.1 kHz.  The bar is the suite's: <= 3 LSB of s16 anywhere, < 0.3 LSB on average
+colours, pauses, strong sibilance (the de-esser), 48 / 44.1 / 96 kHz, mono and stereo (L != R: the downmix first).  The bar is the suite's: <= 3 LSB of s16 anywhere, < 0.3 LSB on average
 (afftdn's f32 transform schedule).  usage: fuzz_pass2.py [cases] [seed]"""
 import sys, time, ctypes as C, numpy as np, torch
 sys.path.insert(0, '.'); sys.path.insert(0, 'tests')
@@ -12,8 +12,9 @@ rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 9)
 e = Engine(0)
 bad = 0; worst = 0; wmean = 0.0; sw = {}
 for c in range(cases):
-    sr = int(rng.choice([48000, 48000, 44100]))
-    secs = float(rng.uniform(16.0, 30.0))
+    sr = int(rng.choice([48000, 48000, 44100, 96000]))
+    ch = int(rng.choice([1, 1, 2]))
+    secs = float(rng.uniform(16.0, 30.0)) * (0.6 if sr == 96000 else 1.0)
     kind = int(rng.integers(0, 5))
     seed = int(rng.integers(1, 10**6))
     if kind == 4:                                            # sibilants concentrated in 6.75-8.25 kHz: AdaptConfig switches the de-esser on
@@ -29,7 +30,13 @@ for c in range(cases):
     if kind == 3:
         a = int(rng.integers(0, x.size - 5 * sr)); x[a: a + int(rng.uniform(1.5, 4.0) * sr)] *= 0.003
     x = np.clip(x, -1, 1).astype(np.float32)
-    e.upload_pcm(x, sr, 1)
+    if ch == 2:                                              # L != R: the rematrix downmix (float formats: 1 / sqrt 2 each) comes first
+        other = (np.roll(x, int(rng.integers(1, 200))) * np.float32(rng.uniform(0.3, 1.0))).astype(np.float32)
+        st = np.empty(x.size * 2, np.float32); st[0::2] = x; st[1::2] = other
+        e.upload_pcm(st, sr, 2)
+        x = orc.downmix_stereo(st, 0)
+    else:
+        e.upload_pcm(x, sr, 1)
     res = H.process_audio(e)
     p2 = e.download_s16(2)
     fp = L.FilterParams(); H.lib().jt_host_filter_params(C.byref(res.effective), C.byref(fp))
@@ -40,5 +47,5 @@ for c in range(cases):
     sw[key] = sw.get(key, 0) + 1
     ok = ref.size == p2.size and d.max() <= 3 and d.mean() < 0.3
     bad += not ok; worst = max(worst, int(d.max())); wmean = max(wmean, float(d.mean()))
-    print(f"case {c:2d} {sr} Hz {secs:4.1f} s kind {kind} switches nlm/fft/custom/gate/comp/deess {key}: max {int(d.max())} LSB, mean {d.mean():.4f} (oracle {time.time() - t0:.1f} s){'' if ok else '   <-- OVER THE BAR'}", flush=True)
+    print(f"case {c:2d} {sr} Hz x{ch} {secs:4.1f} s kind {kind} switches nlm/fft/custom/gate/comp/deess {key}: max {int(d.max())} LSB, mean {d.mean():.4f} (oracle {time.time() - t0:.1f} s){'' if ok else '   <-- OVER THE BAR'}", flush=True)
 print(f"{cases} cases, {bad} over the bar; worst max {worst} LSB, worst mean {wmean:.4f}; switch combinations seen: {sw}")
