@@ -1,7 +1,7 @@
 """Pass 2 of random files on the GPU against the same chain composed from the CPU oracle with the GPU run's effective parameters
 (highpass, lowpass, anlmdn, afftdn, agate, acompressor, deesser, dbl -> flt, swr -> 44.1 kHz s16): room tone of different levels and
 colours, pauses, strong sibilance (the de-esser), 48 / 44.1 / 96 kHz, mono and stereo (L != R: the downmix first).  The bar is the suite's: <= 3 LSB of s16 anywhere, < 0.3 LSB on average
-(afftdn's f32 transform schedule).  usage: fuzz_pass2.py [cases] [seed]"""
+(afftdn's f32 transform schedule).  usage: fuzz_pass2.py [cases] [seed] [kind 0..4, default random]"""
 import sys, time, ctypes as C, numpy as np, torch
 sys.path.insert(0, '.'); sys.path.insert(0, 'tests')
 from jivetalking_amd import Engine, synth, hostlogic as H, _lib as L
@@ -15,10 +15,10 @@ for c in range(cases):
     sr = int(rng.choice([48000, 48000, 44100, 96000]))
     ch = int(rng.choice([1, 1, 2]))
     secs = float(rng.uniform(16.0, 30.0)) * (0.6 if sr == 96000 else 1.0)
-    kind = int(rng.integers(0, 5))
+    kind = int(sys.argv[3]) if len(sys.argv) > 3 else int(rng.integers(0, 5))
     seed = int(rng.integers(1, 10**6))
     if kind == 4:                                            # sibilants concentrated in 6.75-8.25 kHz: AdaptConfig switches the de-esser on
-        x = synth.speech_like_torch(secs, sr, seed=seed, device="cuda:0", sib_gain=float(rng.uniform(0.4, 1.5)), sib_band=True).cpu().numpy().astype(np.float64)
+        x = synth.speech_like_torch(secs, sr, seed=seed, device="cuda:0", sib_gain=float(rng.uniform(0.6, 2.5)), sib_band=True).cpu().numpy().astype(np.float64)
     else:
         x = np.asarray(synth.speech_like(secs, sr, seed=seed, speech_dbfs=float(rng.uniform(-36, -24)), room_dbfs=float(rng.uniform(-75, -50))), np.float64)
     x *= float(10 ** rng.uniform(-1.0, 0.2))
