@@ -30,7 +30,13 @@ def ops(e, x, sr):
     out["resample"] = dig(e.op_resample_s16(x, sr, 44100)) if sr != 44100 else "-"
     out["ebur128"] = dig(e.op_ebur128(x, sr)); out["astats"] = dig(e.op_astats(x, sr)); out["spectral"] = dig(e.op_aspectralstats(x, sr))
     out["ln_measure"] = dig(e.op_loudnorm_measure_s16(s16, 44100)); out["ln_measure_lim"] = dig(e.op_loudnorm_measure_s16(s16, 44100, limiter=L.LimiterPlan(1, 0.25, 1.0)))
-    out["flac"] = dig(e.op_flac_encode(s16, 44100, md5=True))
+    img = e.op_flac_encode(s16, 44100, md5=True)
+    out["flac"] = dig(img)
+    out["flac_decode"] = dig(e.op_decode_audio(img)[0])                                          # mono: one walk per candidate, rows gathered
+    # dynamic-mode loudnorm at 192 kHz (the stream path behind the first launch): the signal stretched to 192 kHz by repetition, driven into the ceiling
+    x192 = np.repeat(x.astype(np.float64), 192000 // sr + 1)[: int(192000 * (x.size / sr) * 1.9)] * 3.0
+    y192, st192 = e.op_loudnorm_dynamic(x192, target_tp=-9.0)
+    out["ln_dynamic"] = dig(y192) + dig(st192)
     e.upload_pcm(x, sr, 1); r = H.process_audio(e, H.default_config(), 4096)
     y = np.empty(x.size, np.int16); got = e.download_s16_into(4, y); out["pipeline"] = dig(y[:got])
     return out
