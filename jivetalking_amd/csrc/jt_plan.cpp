@@ -248,14 +248,14 @@ void jt_r128_finish(const double *bs, int64_t nblocks, int blk, int sr, bool dua
 
 // ---------------------------------------------------------------- libavfilter/ebur128.c (af_loudnorm.c statistics)
 namespace {
-double hist_e[1000], hist_b[1001]; bool hist_ok = false;
-void hist_init()
+double hist_e[1000], hist_b[1001]; std::once_flag hist_once;
+void hist_init()        // (a pool's workers arrive here together)
 {
-    if (hist_ok) return;
-    hist_b[0] = std::pow(10.0, (-70.0 + 0.691) / 10.0);
-    for (int i = 0; i < 1000; ++i) hist_e[i] = std::pow(10.0, ((double)i / 10.0 - 69.95 + 0.691) / 10.0);
-    for (int i = 1; i < 1001; ++i) hist_b[i] = std::pow(10.0, ((double)i / 10.0 - 70.0 + 0.691) / 10.0);
-    hist_ok = true;
+    std::call_once(hist_once, [] {
+        hist_b[0] = std::pow(10.0, (-70.0 + 0.691) / 10.0);
+        for (int i = 0; i < 1000; ++i) hist_e[i] = std::pow(10.0, ((double)i / 10.0 - 69.95 + 0.691) / 10.0);
+        for (int i = 1; i < 1001; ++i) hist_b[i] = std::pow(10.0, ((double)i / 10.0 - 70.0 + 0.691) / 10.0);
+    });
 }
 size_t hist_index(double e)
 {
