@@ -1368,10 +1368,13 @@ k_lns_machine(double *__restrict__ carry, LoudnormDynParams P, LnsBufs B, const 
         const double s_gr0 = gr0, s_gr1 = gr1; const int s_state = state, s_lp = last_pk, s_ec = env_cnt, s_att = att, s_nseg = nseg;
         const bool s_l2 = layer2;
         bool hazard = false;
-        int c = 0;
+        int c = 0, guard = 0;
         do {
             const int ts = T0 + c + LN_ATT;
             ++n_iter;
+            // (every step consumes a sample or changes state towards one that does: a frame cannot take more steps than it has samples.
+            //  A frame that does is handed to the workgroup kernel like the ring-end corner -- never a spinning wave)
+            if (++guard > 2 * LN_F100) { hazard = true; break; }
             switch (state) {
             case LIM_OUT: {
                 // detect_peak(c, nb - c): the first detected peak among n = 1 .. nb - c - 1
