@@ -1726,7 +1726,7 @@ void launch_loudnorm_dynamic(const double *x, int64_t n, const LoudnormDynParams
             // 32, ... 256 steps (each skips what the stream path has covered meanwhile: carry[84]), an attempt of the stream path behind
             // the first seven and then every fourth -- a file that starts quietly latches above_threshold late, and an attempt that
             // stopped at one of its corners leaves the rest to a later one
-            const int64_t len = !use_stream ? steps : (chunk < 2 ? 8 : std::min<int64_t>(256, (int64_t)8 << (chunk - 1)));
+            const int64_t len = !use_stream ? steps : (chunk < 2 ? 8 : chunk >= 7 ? 256 : (int64_t)8 << (chunk - 1));      // (8, 8, 16, .. 256, 256, ..)
             end = std::min(total, it + len);
             hipLaunchKernelGGL(k_loudnorm_dynamic_wg, dim3(1), dim3(LN_WG), smem, s, x, n, P, series, ring, y, dbg, carry, it, end);
             if (use_stream && (chunk <= 6 || chunk % 4 == 0) && kb - (end - 1) >= 32 && end < total)

@@ -353,3 +353,19 @@ def test_mono_flac_one_walk_per_candidate_equals_parse_then_decode(engine, oracl
             assert ei.value.code == L.JT_E_INVAL
         finally:
             engine.set_option("flac_no_ahead", False)
+
+
+def test_dynamic_loudnorm_on_a_stream_of_twenty_five_minutes(engine):
+    """The launcher's schedule (workgroup-kernel launches of 8, 8, 16 .. 256, 256, .. steps with attempts of the stream path between them)
+    on a file long enough for more than sixty launches -- where the first version's `8 << (launch - 1)` had overflowed and the launches'
+    step ranges turned into garbage (a GPU memory fault on every dynamic-mode file longer than 23 minutes; found by
+    tools/long_dynamic.py, which also runs 2.9 hours = 0.93 of the 2^31 samples the stream path's 32-bit times allow).  Same samples as
+    the workgroup kernel alone, all full frames behind the first launch covered."""
+    unit = synth.speech_like(60.0, 192000, seed=77).astype(np.float64) * 2.5
+    n = int(25.2 * 60 * 192000) - 4321
+    x = np.tile(unit, n // unit.size + 1)[:n]
+    x[:: 192000 * 97] *= 1.7
+    want, wst, got, gst, frames, why = _dyn_three_ways(engine, x, -9.0, 0.0)
+    assert np.array_equal(got, want) and gst == wst
+    n_inner = (x.size - 576000 + 19199) // 19200
+    assert n_inner + 30 > 14080 and frames >= n_inner - 9 and why == 1
