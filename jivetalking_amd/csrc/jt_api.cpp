@@ -1428,7 +1428,7 @@ static void loudnorm_dynamic_run(jt_ctx *h, double *x, int64_t m, const Loudnorm
     // holds up every other handle's stream that shares its hardware queue, k_loudnorm.hip)
     h->ln_carry.ensure(256);
     // the stream path's scratch (k_loudnorm.hip): ~0.7 bytes per 192 kHz sample
-    LnsBufs lns{}; const bool stream = !h->opts.ln_no_stream && !h->opts.ln_no_batch && n_inner > 48 && m < ((int64_t)1 << 31) - (1 << 20);      // (its times are 32-bit: up to 3 h at 192 kHz)
+    LnsBufs lns{}; const bool stream = !h->opts.ln_no_stream && !h->opts.ln_no_batch && n_inner > 48;
     if (stream) {
         h->ln_scratch.ensure(jt_lns_scratch_bytes(m, n_inner, nullptr, nullptr));
         jt_lns_scratch_bytes(m, n_inner, &lns, h->ln_scratch.p);

@@ -265,8 +265,8 @@ void jt_loudnorm_series(const double *bs, int64_t nfull, int64_t s100, bool dual
 void jt_kweight_coeffs5(int sr, double b[5], double a[5]);
 // the stream path of the dynamic mode (k_loudnorm.hip): an envelope segment the limiter's state machine decided on, the control block
 // the kernels of one attempt share, and the scratch they work in (jt_lns_scratch_bytes carves one allocation)
-struct LnsSeg { int t, len, kind, c0, al, pad; double g0, g1; };                 // kind: 0 constant g0, 1 attack ramp, 2 release ramp; +256: second layer
-struct LnsCtl { int active, ok, ka, kbe, npk, nseg, why, attempts; long long frames; int iters, refills; long long cycles; int why_mask, pad; };   // why_mask: bit r = an attempt ended for reason r   // why: 1 state not in its steady form, 2 peak list full, 3 segment list full, 4 ring-end corner
+struct LnsSeg { int t, len, kind, c0, al, pad; double g0, g1; };                 // t: relative to the attempt's first output sample (LnsCtl::tbase); kind: 0 constant g0, 1 attack ramp, 2 release ramp; +256: second layer
+struct LnsCtl { int active, ok, ka, kbe, npk, nseg, why, attempts; long long frames; int iters, refills; long long cycles; int why_mask, pad; long long tbase; };   // why_mask: bit r = an attempt ended for reason r   // why: 1 state not in its steady form, 2 peak list full, 3 segment list full, 4 ring-end corner
 struct LnsBufs { LnsCtl *ctl; double *G, *Gn, *E; unsigned long long *bm; unsigned short *woff; int *bcnt, *boff; int *pk_t; double *pk_v, *pk_g; LnsSeg *seg; int pk_cap, seg_cap; };
 size_t jt_lns_scratch_bytes(int64_t n, int64_t n_inner, LnsBufs *B, unsigned char *base);
 // carry: LN_CARRY = 256 doubles of device memory (the state one launch of the workgroup kernel hands to the next)

@@ -1138,6 +1138,7 @@ k_loudnorm_dynamic_wg(const double *__restrict__ x, int64_t n, LoudnormDynParams
 // committed, the workgroup kernel carries on from there, and a later attempt takes over again.  Same for a full segment or peak list.
 // Everything is enqueued without a host round trip: every kernel of an attempt looks at the control block the first one fills.
 constexpr int LNS_BW = 64;                                   // bitmap words per block of k_lns_bitmap (4096 samples)
+constexpr int LNS_MAXF = 100000;                             // frames per attempt: 1.92e9 samples, what the list's 32-bit relative times hold
 __device__ __forceinline__ long long lns_rl64(long long v, int l)
 {
     return ((long long)__builtin_amdgcn_readlane((int)(v >> 32), l) << 32) | (unsigned)__builtin_amdgcn_readlane((int)v, l);
@@ -1158,7 +1159,7 @@ k_lns_begin(const double *__restrict__ carry, const double *__restrict__ series,
         if (state != LIM_OUT) ok = ok && (int)carry[6] == (lbi + LN_F100 + LN_ATT) % LN_LBS;     // the envelope stands at the scan position
         if (state != LIM_ATTACK) ok = ok && (int)carry[8] == LN_ATT;
         c->active = ok ? 1 : 0; c->ok = 0; c->attempts += 1;
-        if (ok) { c->ka = ka; c->kbe = ka; c->npk = 0; c->nseg = 0; c->why = 0; }                // (the diagnostics are the last ACTIVE attempt's)
+        if (ok) { c->ka = ka; c->kbe = ka; c->npk = 0; c->nseg = 0; c->why = 0; c->tbase = (long long)(ka + 1) * LN_F100; }   // (the diagnostics are the last ACTIVE attempt's)
         else if (c->frames == 0) { c->why = 1; c->why_mask |= 2; }
         go = ok ? 1 : 0;
         prev_s = carry[12];
@@ -1288,6 +1289,7 @@ __global__ void __launch_bounds__(256)
 k_lns_scatter(const double *__restrict__ y, LnsBufs B, long long blk0, int nblk, double ceiling)
 {
     if (!B.ctl->active) return;
+    const long long tbase = B.ctl->tbase;                          // (list times are relative to the attempt's first output sample: 32 bits)
     for (long long q = (long long)blockIdx.x * 256 + threadIdx.x; q < (long long)nblk * LNS_BW; q += (long long)gridDim.x * 256) {   // q: word of the range
     const long long wd = blk0 * LNS_BW + q;
     unsigned long long m = B.bm[wd];
@@ -1296,12 +1298,13 @@ k_lns_scatter(const double *__restrict__ y, LnsBufs B, long long blk0, int nblk,
         const long long t = wd * 64 + (__ffsll((long long)m) - 1);
         m &= m - 1ull;
         const double v = fabs(y[t]);
-        B.pk_t[off] = (int)t; B.pk_v[off] = v; B.pk_g[off] = ceiling / v; ++off;                // (ceiling / peak_value: the filter's gain reduction of this peak)
+        B.pk_t[off] = (int)(t - tbase); B.pk_v[off] = v; B.pk_g[off] = ceiling / v; ++off;                // (ceiling / peak_value: the filter's gain reduction of this peak)
     }
     }
 }
 // the limiter's state machine over the peak list: lnw_true_peak_limiter's loop with the bitmap queries answered by the list and the ring
-// operations written down as segments.  Times are absolute sample positions; the frame with output position T0 scans from T0 + c + 1920
+// operations written down as segments.  Times are sample positions relative to the attempt's first output sample (32 bits: an attempt
+// covers at most LNS_MAXF frames); the frame with output position T0 scans from T0 + c + 1920
 // (c = the filter's smp_cnt), which is also where its envelope stands.
 __global__ void __launch_bounds__(64)
 k_lns_machine(double *__restrict__ carry, LoudnormDynParams P, LnsBufs B, const double *__restrict__ y, int ka, int kb)
@@ -1312,14 +1315,15 @@ k_lns_machine(double *__restrict__ carry, LoudnormDynParams P, LnsBufs B, const 
     const int npk = ctl->npk;
     const double ceiling = P.target_tp_lin;
     const int nb = LN_F100, stop_every = P.stream_stop, seg_cap = B.seg_cap;
+    const long long tbase = ctl->tbase;
     double gr0 = carry[0], gr1 = carry[1];
     int state = (int)carry[4], env_cnt = (int)carry[7], att = (int)carry[8];
     int last_pk = -1;                                                    // list entry of the last detected peak (prev_smp / peak_index of the hand-over)
     bool layer2 = false;
     int nseg = 0;
     // One wave runs alone and issues an instruction every five cycles: the machine is bound by its instruction count (2 400 cycles per step
-    // with 64-bit times and a division per window; a memory round trip hidden or not made no difference).  Hence 32-bit times (the host
-    // sends files of 2^31 samples and more to the workgroup kernel), the peaks' gain reductions ceiling / |peak| precomputed by the
+    // with 64-bit times and a division per window; a memory round trip hidden or not made no difference).  Hence 32-bit times (relative
+    // to the attempt's first output sample; an attempt covers at most LNS_MAXF frames), the peaks' gain reductions ceiling / |peak| precomputed by the
     // scatter kernel (the only thing the machine ever does with a magnitude), and the list through LDS: 4096 entries, refilled 1024 at a
     // time with all of a refill's loads in flight together.  One wave: its LDS operations execute in order, no barrier.
     constexpr int LCAP = 4096, LCH = 1024, TINF = 0x7fffffff;
@@ -1363,7 +1367,7 @@ k_lns_machine(double *__restrict__ carry, LoudnormDynParams P, LnsBufs B, const 
     int k = ka, why = 0;
     for (; k < kb; ++k) {
         if (stop_every > 0 && k > ka && k % stop_every == 0) { why = 5; break; }              // (test switch)
-        const int T0 = (k + 1) * LN_F100;
+        const int T0 = (k - ka) * LN_F100;                                                     // relative to tbase, like the list's times
         // the frame is taken whole or not at all
         const double s_gr0 = gr0, s_gr1 = gr1; const int s_state = state, s_lp = last_pk, s_ec = env_cnt, s_att = att, s_nseg = nseg;
         const bool s_l2 = layer2;
@@ -1446,7 +1450,7 @@ k_lns_machine(double *__restrict__ carry, LoudnormDynParams P, LnsBufs B, const 
                     // the scan reaches the ring's last twelve samples, whose test reads past its end (the filter wraps to samples the
                     // envelope has edited): only harmless when none of them can be a candidate at all
                     const int t = zone + lane;
-                    const bool hot = lane < 12 && t <= lim && t < T0 + LN_LBS && fabs(y[t]) > ceiling;
+                    const bool hot = lane < 12 && t <= lim && t < T0 + LN_LBS && fabs(y[tbase + t]) > ceiling;
                     if (__ballot(hot)) { hazard = true; break; }
                     found = false;
                 }
@@ -1492,7 +1496,7 @@ k_lns_machine(double *__restrict__ carry, LoudnormDynParams P, LnsBufs B, const 
     if (lane < 30) carry[16 + (index_new + lane) % 30] = dv;
     if (lane == 0) {
         carry[0] = gr0; carry[1] = gr1; carry[3] = lbi; carry[4] = state;
-        if (last_pk >= 0) { carry[2] = B.pk_v[last_pk]; carry[5] = (double)(B.pk_t[last_pk] % LN_LBS); }      // prev_smp, peak_index
+        if (last_pk >= 0) { carry[2] = B.pk_v[last_pk]; carry[5] = (double)((tbase + B.pk_t[last_pk]) % LN_LBS); }      // prev_smp, peak_index
         carry[6] = (lbi + LN_F100 + LN_ATT) % LN_LBS; carry[7] = env_cnt; carry[8] = att; carry[9] = 0.0;
         carry[10] = index_new; carry[12] = pdl;
         carry[80] = (double)((long long)(kbe + 1) * LN_F100); carry[81] = (double)((long long)LN_LBS + (long long)kbe * LN_F100);
@@ -1508,7 +1512,7 @@ k_lns_apply(double *__restrict__ y, LnsBufs B, int layer)
         const LnsSeg sg = B.seg[q];
         if ((sg.kind >> 8) != layer) continue;
         const int kind = sg.kind & 255;
-        double *p = y + sg.t;
+        double *p = y + B.ctl->tbase + sg.t;
         const double g0 = sg.g0, g1 = sg.g1; const int c0 = sg.c0, al = sg.al;
         if (kind == 0) for (int j = threadIdx.x; j < sg.len; j += 256) p[j] *= g0;
         else if (kind == 1) for (int j = threadIdx.x; j < sg.len; j += 256) p[j] *= g0 - ((double)(c0 + j) / (al - 1) * (g0 - g1));
@@ -1730,7 +1734,7 @@ void launch_loudnorm_dynamic(const double *x, int64_t n, const LoudnormDynParams
             end = std::min(total, it + len);
             hipLaunchKernelGGL(k_loudnorm_dynamic_wg, dim3(1), dim3(LN_WG), smem, s, x, n, P, series, ring, y, dbg, carry, it, end);
             if (use_stream && (chunk <= 6 || chunk % 4 == 0) && kb - (end - 1) >= 32 && end < total)
-                lns_attempt(x, P, series, ring, y, carry, *stream, (int)(end - 1), (int)kb, s);
+                lns_attempt(x, P, series, ring, y, carry, *stream, (int)(end - 1), (int)std::min<int64_t>(kb, end - 1 + LNS_MAXF), s);      // (the rest: a later attempt)
 #ifdef JT_LN_PROFILE
             if (chunk == 8 || end >= total) {   // phase clocks of the ninth launch (inner frames) and of the last one (the flush): tools/prof_dynamic_phases.sh
                 unsigned long long pr[16];

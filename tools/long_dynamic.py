@@ -1,5 +1,5 @@
-"""The dynamic mode's stream path near the end of its 32-bit times: a 192 kHz stream of `hours` (default 2.9: 2.0e9 samples, the host's limit is
-2^31 - 2^20) against the one-workgroup kernel.  Needs ~35 GB of host memory per stream.  usage: long_dynamic.py [hours]"""
+"""The dynamic mode's stream path on long streams: a 192 kHz stream of `hours` (default 2.9: 2.0e9 samples; 3.5 h = 2.4e9 is past 2^31 and
+past one attempt's 100 000 frames) against the one-workgroup kernel.  Needs ~35 GB of host memory per stream.  usage: long_dynamic.py [hours]"""
 import sys, time, numpy as np
 sys.path.insert(0, '.')
 from jivetalking_amd import Engine, synth
