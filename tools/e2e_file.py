@@ -7,7 +7,7 @@ from jivetalking_amd import Engine, synth, hostlogic as H
 md5 = bool(int(sys.argv[1])) if len(sys.argv) > 1 else False
 runs = int(sys.argv[2]) if len(sys.argv) > 2 else 5
 d = tempfile.mkdtemp(prefix="jte2e", dir="/dev/shm")
-x = synth.speech_like_torch(3600.0, 48000, seed=1000, device="cuda:0", plosives_per_min=40.0)
+x = synth.speech_like_torch(float(os.environ.get("JT_SECS", "3600")), 48000, seed=1000, device="cuda:0", plosives_per_min=40.0)
 pcm = (x * 32768.0).round().clamp(-32768, 32767).to(torch.int16).cpu().numpy(); del x
 e = Engine(0)
 if os.environ.get("JT_HT"): e.set_option("host_timing", "1")
