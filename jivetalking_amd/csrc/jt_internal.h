@@ -267,7 +267,10 @@ void jt_kweight_coeffs5(int sr, double b[5], double a[5]);
 // the kernels of one attempt share, and the scratch they work in (jt_lns_scratch_bytes carves one allocation)
 struct LnsSeg { int t, len, kind, c0, al, pad; double g0, g1; };                 // t: relative to the attempt's first output sample (LnsCtl::tbase); kind: 0 constant g0, 1 attack ramp, 2 release ramp; +256: second layer
 struct LnsCtl { int active, ok, ka, kbe, npk, nseg, why, attempts; long long frames; int iters, refills; long long cycles; int why_mask, pad; long long tbase; };   // why_mask: bit r = an attempt ended for reason r   // why: 1 state not in its steady form, 2 peak list full, 3 segment list full, 4 ring-end corner
-struct LnsBufs { LnsCtl *ctl; double *G, *Gn, *E; unsigned long long *bm; unsigned short *woff; int *bcnt, *boff; int *pk_t; double *pk_v, *pk_g; LnsSeg *seg; int pk_cap, seg_cap; };
+// what a frame's scan range (its output position + 1920, one frame long) holds of the peak list: entries [fi, fe), the last one's time, the
+// next entry's time and gain reduction, the smallest gain reduction inside (k_lns_frames; the machine's O(1) test for a frame SUSTAIN passes)
+struct LnsFrame { int fi, fe, l_t, e_t; double ming, e_g; };
+struct LnsBufs { LnsCtl *ctl; double *G, *Gn, *E; unsigned long long *bm; unsigned short *woff; int *bcnt, *boff; int *pk_t; double *pk_v, *pk_g; LnsSeg *seg; int pk_cap, seg_cap; LnsFrame *fr; };
 size_t jt_lns_scratch_bytes(int64_t n, int64_t n_inner, LnsBufs *B, unsigned char *base);
 // carry: LN_CARRY = 256 doubles of device memory (the state one launch of the workgroup kernel hands to the next)
 void launch_loudnorm_dynamic(const double *x, int64_t n, const LoudnormDynParams &P, const double *series, double *ring, double *y, double *dbg, hipStream_t s,

@@ -1302,6 +1302,31 @@ k_lns_scatter(const double *__restrict__ y, LnsBufs B, long long blk0, int nblk,
     }
     }
 }
+// per frame of the attempt: what its scan range holds of the list (LnsFrame).  One thread per frame, two binary searches and a walk over the
+// frame's own ~64 entries.
+__global__ void __launch_bounds__(256)
+k_lns_frames(LnsBufs B, int ka, int kb)
+{
+    if (!B.ctl->active) return;
+    const int npk = B.ctl->npk;
+    for (int f = blockIdx.x * 256 + threadIdx.x; f < kb - ka; f += gridDim.x * 256) {
+        const int ts = f * LN_F100 + LN_ATT;                          // relative to tbase
+        auto first_after = [&](int t) {                               // first entry with time > t
+            int lo = 0, hi = npk;
+            while (lo < hi) { const int mid = (lo + hi) >> 1; if (B.pk_t[mid] > t) hi = mid; else lo = mid + 1; }
+            return lo;
+        };
+        LnsFrame r;
+        r.fi = first_after(ts); r.fe = first_after(ts + LN_F100 - 1);
+        double m = 2.0;
+        for (int i = r.fi; i < r.fe; ++i) m = fmin(m, B.pk_g[i]);
+        r.ming = m;
+        r.l_t = r.fe > r.fi ? B.pk_t[r.fe - 1] : -1;
+        r.e_t = r.fe < npk ? B.pk_t[r.fe] : 0x7fffffff;
+        r.e_g = r.fe < npk ? B.pk_g[r.fe] : 2.0;
+        B.fr[f] = r;
+    }
+}
 // the limiter's state machine over the peak list: lnw_true_peak_limiter's loop with the bitmap queries answered by the list and the ring
 // operations written down as segments.  Times are sample positions relative to the attempt's first output sample (32 bits: an attempt
 // covers at most LNS_MAXF frames); the frame with output position T0 scans from T0 + c + 1920
@@ -1326,9 +1351,13 @@ k_lns_machine(double *__restrict__ carry, LoudnormDynParams P, LnsBufs B, const 
     // to the attempt's first output sample; an attempt covers at most LNS_MAXF frames), the peaks' gain reductions ceiling / |peak| precomputed by the
     // scatter kernel (the only thing the machine ever does with a magnitude), and the list through LDS: 4096 entries, refilled 1024 at a
     // time with all of a refill's loads in flight together.  One wave: its LDS operations execute in order, no barrier.
-    constexpr int LCAP = 4096, LCH = 1024, TINF = 0x7fffffff;
+    constexpr int LCAP = 2048, LCH = 512, TINF = 0x7fffffff;
     __shared__ int lt[LCAP];
     __shared__ double lg[LCAP];
+    // the frames' records (k_lns_frames), 512 at a time the same way: a frame SUSTAIN passes costs the machine one of these and no list entry
+    constexpr int FCH = 512;
+    __shared__ LnsFrame lfr[FCH];
+    int fr_lo = 0, fr_hi = 0;                                            // records of frames [fr_lo, fr_hi) (relative to ka) are in LDS
     int wbase = 0, wt = 0, cur = 0, lhi = 0;                             // window: entry wbase + lane in this lane's registers; [.., lhi) in LDS
     double wg = 0.0;
     int n_refill = 0, n_iter = 0;
@@ -1373,6 +1402,25 @@ k_lns_machine(double *__restrict__ carry, LoudnormDynParams P, LnsBufs B, const 
         const bool s_l2 = layer2;
         bool hazard = false;
         int c = 0, guard = 0;
+        if (state == LIM_SUSTAIN) {
+            // The frame SUSTAIN passes: its scan range [ts + 1, ts + nb - 1] holds peaks, all harmless (batch: one segment up to the last
+            // one, l), the next peak lies within nb - 1 of l and is harmless too (the detector call behind the remainder: the gain held to
+            // the frame's end), and that call stays clear of the ring's last twelve samples.  Two segments of the same gain that meet are
+            // one: the whole frame at gr1.  Everything it needs is the frame's record.
+            const int f = k - ka;
+            if (f >= fr_hi) {
+                fr_lo = f; fr_hi = min(kb - ka, f + FCH);
+                for (int q = lane; q < fr_hi - fr_lo; q += 64) lfr[q] = B.fr[fr_lo + q];
+            }
+            const LnsFrame r = lfr[f - fr_lo];
+            const int ts = T0 + LN_ATT, lb = r.l_t - ts;
+            if (r.fe > r.fi && r.ming >= gr1 && lb < LN_F100 - 11 && r.e_t <= r.l_t + nb - 1 && r.e_g >= gr1) {
+                emit(0, ts, nb, gr1, 0., 0, 0);
+                last_pk = r.fe; env_cnt = nb - lb; cur = r.fe;
+                c = nb; ++n_iter;
+            }
+        }
+        if (c < nb)
         do {
             const int ts = T0 + c + LN_ATT;
             ++n_iter;
@@ -1686,6 +1734,7 @@ size_t jt_lns_scratch_bytes(int64_t n, int64_t n_inner, LnsBufs *B, unsigned cha
     b.pk_v = reinterpret_cast<double *>(take(sizeof(double) * (size_t)pk_cap));
     b.pk_g = reinterpret_cast<double *>(take(sizeof(double) * (size_t)pk_cap));
     b.seg = reinterpret_cast<LnsSeg *>(take(sizeof(LnsSeg) * (size_t)seg_cap));
+    b.fr = reinterpret_cast<LnsFrame *>(take(sizeof(LnsFrame) * (size_t)(n_inner + 64)));
     b.pk_cap = (int)std::min<int64_t>(pk_cap, 0x7fffffff); b.seg_cap = (int)std::min<int64_t>(seg_cap, 0x7fffffff);
     if (B) *B = b;
     return off;
@@ -1706,6 +1755,7 @@ static void lns_attempt(const double *x, const LoudnormDynParams &P, const doubl
     hipLaunchKernelGGL(k_lns_bitmap, dim3((unsigned)std::min(nblk, 8192)), dim3(256), 0, s, y, B, (long long)tb0, (long long)tb1, P.target_tp_lin, (long long)blk0, nblk);
     hipLaunchKernelGGL(k_lns_scan, dim3(1), dim3(1024), 0, s, B, nblk);
     hipLaunchKernelGGL(k_lns_scatter, grid((int64_t)nblk * LNS_BW), dim3(256), 0, s, y, B, (long long)blk0, nblk, P.target_tp_lin);
+    hipLaunchKernelGGL(k_lns_frames, grid(kb - ka), dim3(256), 0, s, B, ka, kb);
     hipLaunchKernelGGL(k_lns_machine, dim3(1), dim3(64), 0, s, carry, P, B, y, ka, kb);
     hipLaunchKernelGGL(k_lns_apply, dim3(4096), dim3(256), 0, s, y, B, 0);
     hipLaunchKernelGGL(k_lns_apply, dim3(4096), dim3(256), 0, s, y, B, 1);
