@@ -77,7 +77,7 @@ def options(engine, **kv):
 _TALKER_DIR = None
 
 
-def bench_talker(seconds, sr=48000, seed=1000, plosives=40.0, sib_gain=0.25):
+def bench_talker(seconds, sr=48000, seed=1000, plosives=40.0, sib_gain=0.25, sib_band=False):
     """bench.py's talker (synth.speech_like_torch: aperiodic, generated on the device) as a numpy array.  torch's HIP runtime and the
     library's cannot both be initialised in one process, so a child process generates it; cached for the session under /dev/shm."""
     import atexit
@@ -89,11 +89,11 @@ def bench_talker(seconds, sr=48000, seed=1000, plosives=40.0, sib_gain=0.25):
     if _TALKER_DIR is None:
         _TALKER_DIR = tempfile.mkdtemp(prefix="jttalk", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
         atexit.register(shutil.rmtree, _TALKER_DIR, True)
-    path = os.path.join(_TALKER_DIR, f"t{seconds:g}_{sr}_{seed}_{plosives:g}_{sib_gain:g}.npy")
+    path = os.path.join(_TALKER_DIR, f"t{seconds:g}_{sr}_{seed}_{plosives:g}_{sib_gain:g}_{int(sib_band)}.npy")
     if not os.path.exists(path):
         code = ("import sys, numpy as np; sys.path.insert(0, %r); from jivetalking_amd import synth; "
-                "x = synth.speech_like_torch(%r, %d, seed=%d, device='cuda:0', plosives_per_min=%r, sib_gain=%r); np.save(%r, x.cpu().numpy())"
-                % (ROOT, float(seconds), int(sr), int(seed), float(plosives), float(sib_gain), path))
+                "x = synth.speech_like_torch(%r, %d, seed=%d, device='cuda:0', plosives_per_min=%r, sib_gain=%r, sib_band=%r); np.save(%r, x.cpu().numpy())"
+                % (ROOT, float(seconds), int(sr), int(seed), float(plosives), float(sib_gain), bool(sib_band), path))
         r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900)
         assert r.returncode == 0, r.stderr[-2000:]
     return np.load(path, mmap_mode="r")

@@ -60,11 +60,12 @@ def oracle_pass1(orc, x, sr, frame_samples=4096):
     return a, meta, nframes, fss, fpk
 
 
-def decide(orc, x, sr, base=None, frame_samples=4096):
-    """The reference's Pass-1 decision chain on oracle measurements.  Returns (measurements, effective config, Pass-2 chain string)."""
+def decide(orc, x, sr, base=None, frame_samples=4096, pass1=None):
+    """The reference's Pass-1 decision chain on oracle measurements.  Returns (measurements, effective config, Pass-2 chain string).
+    `pass1` = a precomputed oracle_pass1(orc, x, sr, frame_samples) (the fuzz tests measure many files side by side on the host's cores)."""
     l = H.lib()
     base = base or H.default_config()
-    a, meta, nframes, fss, fpk = oracle_pass1(orc, x, sr, frame_samples)
+    a, meta, nframes, fss, fpk = pass1 if pass1 is not None else oracle_pass1(orc, x, sr, frame_samples)
     n = x.size
     iv = (H.Interval * (n // (sr // 5) + 16))()
     niv = l.jt_host_build_intervals(C.c_int(sr), C.c_int64(n), C.c_int(frame_samples), C.c_int(1),
