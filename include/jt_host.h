@@ -37,6 +37,12 @@ int64_t jt_host_build_intervals(int sample_rate, int64_t n_samples, int frame_sa
                                 const double *frame_sumsq, const double *frame_peak, int64_t n_frames,
                                 const jt_frame_meta *meta, int64_t n_meta, int quantize,
                                 jt_interval *out, int64_t cap);
+/* The same for decoder frames of DIFFERENT lengths (a variable-blocksize FLAC stream: analyser.go:588-600 reads every frame's own
+ * NbSamples): frame_lens[f] = samples per channel of frame f (their sum = n_samples).  frame_lens == NULL: frames of frame_samples. */
+int64_t jt_host_build_intervals_v(int sample_rate, int64_t n_samples, int frame_samples, const int32_t *frame_lens, int channels,
+                                  const double *frame_sumsq, const double *frame_peak, int64_t n_frames,
+                                  const jt_frame_meta *meta, int64_t n_meta, int quantize,
+                                  jt_interval *out, int64_t cap);
 
 /* ---- regions / profiles (analyser.go:25-135) ---- */
 typedef struct { int64_t start_ns, end_ns, duration_ns; } jt_region;
@@ -162,6 +168,9 @@ typedef struct {
 int jt_host_lufs_filename_value(double output_lufs);
 int jt_host_output_path(const char *input_path, int lufs_value, char *out, int cap);
 
+/* frame_samples (here and in every entry point below): the decoder's frame length, which closes the 250 ms analysis intervals
+ * (analyser.go:588-600) and paces the progress ticks.  0 = the input's own cadence (jtgpu.h: jt_input_frame_layout) -- what the
+ * reference sees for this file; a positive value overrides it (the caller decoded the file itself and knows its frames). */
 int jt_process_audio(jt_ctx *h, const jt_host_config *base, int frame_samples, jt_process_result *out);
 
 /* ProgressUpdate / ProgressCallback (progress.go:5-39).  The callback runs synchronously on the calling thread at the same

@@ -39,10 +39,12 @@ int  jt_device_count(void);                       /* HIP devices visible to this
 int  jt_open(int device_id, jt_ctx **out);
 /* jt_open for a handle that shares its GPU with other handles (pool.go:122-153: a bounded number of ProcessAudio calls in flight).
  * n_streams: 0 (= jt_open) or >= 8: a HIP stream per chain (fastest for ONE file at a time); 1: every chain on one stream; 2: main +
- * one low-priority stream.  The runtime multiplexes all streams of a process onto a handful of hardware queues, and one file's event
+ * one low-priority stream; 3 .. 7 are taken as 2 (there is no layout between "two" and "one per chain"); negative: JT_E_INVAL.  The runtime multiplexes all streams of a process onto a handful of hardware queues, and one file's event
  * waits stall every stream that shares a queue with them: several handles on one GPU want ONE stream each (ten-minute files, eight in
- * flight: 10 ms per file against 15-100 with eight streams each).  flags: JT_OPEN_BLOCKING_SYNC = host waits sleep on an interrupt
- * instead of spinning on the completion signal (a pool otherwise burns a host core per handle).  Results are identical either way. */
+ * flight: 10 ms per file against 15-100 with eight streams each).  flags: JT_OPEN_BLOCKING_SYNC = host waits POLL the
+ * completion event (hipEventQuery: a few yields, then 50 us sleeps) instead of spinning on the completion signal inside the runtime --
+ * every wait of the HIP runtime on this part spins, with or without hipEventBlockingSync, so a pool otherwise burns a host core per
+ * handle; a wait ends at most 50 us late.  Results are identical either way. */
 #define JT_OPEN_BLOCKING_SYNC 0x1
 int  jt_open_ex(int device_id, int n_streams, int flags, jt_ctx **out);
 void jt_close(jt_ctx *h);
@@ -149,7 +151,9 @@ typedef struct {
 /* ---- Pass 1: replaces collectAnalysisFrames' runFilterGraph sweep (analyser.go:538-650) over
  * "aformat=channel_layouts=mono,astats=...,aspectralstats=win_size=2048:win_func=hann:measure=all,
  *  ebur128=metadata=1:peak=sample+true:dualmono=true:target=-16" (filters.go:42-45,624-626,684-689).
- * frame_samples = decoder frame size (4096 for FLAC).  frame_sumsq/frame_peak: per decoder frame
+ * frame_samples = decoder frame size: what Reader.ReadFrame (reader.go:129) hands the frame loop per call.  0 = THE INPUT'S OWN
+ * CADENCE (jt_input_frame_layout below): the block size(s) of the FLAC stream / the WAV demuxer's packet jt_load_audio saw, 4096 for
+ * PCM that was uploaded.  frame_sumsq/frame_peak: per decoder frame
  * sum(x^2) and max|x| on the RAW (pre-downmix, all channels) samples as frameSumSquaresAndPeak computes
  * them (analyser_metrics.go:273-358); caller arrays of n_input_frames entries (or NULL).
  * meta: caller array for the 100 ms output frames (cap_meta entries, or NULL). */
@@ -284,8 +288,23 @@ typedef struct {
     double duration_s;           /* Metadata.Duration (reader.go:22-27) */
     int64_t flac_frames; int flac_candidates;
     double gpu_ms, total_ms;
+    /* The decoder's frame cadence -- what Reader.ReadFrame (reader.go:129-169) would deliver for this file, which is what closes the
+     * reference's 250 ms analysis intervals (analyser.go:588-600) and paces its progress ticks (analyser.go:602, processor.go:274):
+     *   FLAC: one AVFrame per FLAC frame = the stream's block size (every frame but the last); a stream whose frames differ in length
+     *         (variable blocking strategy, or a fixed-blocksize stream with odd frames) has decoder_frames_variable = 1,
+     *         decoder_frame_samples = its longest frame, and its per-frame lengths in jt_input_frame_layout;
+     *   WAV:  libavformat/wavdec.c wav_read_packet: packets of max_size = 4096 BYTES rounded down to whole sample blocks
+     *         (block_align = channels x bytes per sample; one block when that is larger), one AVFrame per packet:
+     *         1024 samples of mono f32, 2048 of mono s16, 1365 of mono s24, 512 of stereo f32 ... (restated from FFmpeg's
+     *         sources, which are absent here: DESIGN section 3, assumption 12). */
+    int decoder_frame_samples, decoder_frames_variable;
+    int64_t decoder_frames;      /* how many frames ReadFrame would deliver */
 } jt_audio_meta;
 int jt_load_audio(jt_ctx *h, const uint8_t *file, int64_t len, jt_audio_meta *meta);
+/* The cadence of the handle's current input (set by jt_load_audio; 4096 and constant after jt_upload_pcm / jt_attach_device_pcm):
+ * *frame_samples = the constant frame length (the longest frame of a variable stream), *n_frames = the frame count; when the frames
+ * differ in length *variable = 1 and lens (cap entries, or NULL) receives min(cap, n_frames) per-frame lengths.  Any pointer may be NULL. */
+int jt_input_frame_layout(jt_ctx *h, int *frame_samples, int *variable, int64_t *n_frames, int32_t *lens, int64_t cap);
 /* operator-level entry (parity tests): the decoded samples back on the host, interleaved; either pointer may be NULL */
 int jt_op_decode_audio(jt_ctx *h, const uint8_t *file, int64_t len, int32_t *pcm_i32, float *pcm_f32, int64_t cap_values,
                        jt_audio_meta *meta);

@@ -268,7 +268,9 @@ func ProcessAudioGPU(ctx context.Context, inputPath string, config *BaseFilterCo
 	if progressCallback != nil {
 		cb = C.jt_trampoline_ptr()
 	}
-	rc = C.jt_process_file(e.h, cpath, &base, 4096, C.JT_FLAC_MD5|C.JT_FILE_PROGRESS_TICKS, cb, unsafe.Pointer(uintptr(hnd)), res, &outPath[0], 4096, nil)
+	// frame_samples = 0: the file's own decoder-frame cadence (the stream's FLAC block size(s), the WAV demuxer's 4096-byte packets) --
+	// what Reader.ReadFrame hands the reference's frame loop, which closes its 250 ms intervals (analyser.go:588-600)
+	rc = C.jt_process_file(e.h, cpath, &base, 0, C.JT_FLAC_MD5|C.JT_FILE_PROGRESS_TICKS, cb, unsafe.Pointer(uintptr(hnd)), res, &outPath[0], 4096, nil)
 	if rc != C.JT_OK {
 		what := "processing failed"
 		if res.pass_ms[0] == 0 {
@@ -300,7 +302,7 @@ func AnalyseOnlyDetailedGPU(ctx context.Context, inputPath string, config *BaseF
 	base := hostConfigToC(config)
 	res := (*C.jt_process_result)(C.calloc(1, C.size_t(unsafe.Sizeof(C.jt_process_result{}))))
 	defer C.free(unsafe.Pointer(res))
-	if rc = C.jt_analyse_only(e.h, &base, 4096, res); rc != C.JT_OK {
+	if rc = C.jt_analyse_only(e.h, &base, 0, res); rc != C.JT_OK { // (0: the loaded file's own frame cadence)
 		return nil, fmt.Errorf("analysis failed: %w", e.err(ctx, rc, "pass 1"))
 	}
 	m := measurementsFromC(&res.input, e)

@@ -48,8 +48,10 @@ extern "C" int jt_open_ex(int device_id, int n_streams, int flags, jt_ctx **out)
     jt_ctx *h = new jt_ctx();
     h->device = device_id;
     h->n_streams = (n_streams == 0 || n_streams >= 8) ? 8 : (n_streams >= 2 ? 2 : 1);
-    // JT_OPEN_BLOCKING_SYNC: every host wait of this handle sleeps on an interrupt (hipEventBlockingSync) instead of spinning on the
-    // completion signal -- a pool of handles otherwise burns one host core per handle for the length of the batch
+    // JT_OPEN_BLOCKING_SYNC: every host wait of this handle POLLS its event (jt_event_wait: hipEventQuery, a few yields, then 50 us
+    // sleeps) instead of spinning on the completion signal inside the runtime -- a pool of handles otherwise burns one host core per
+    // handle for the length of the batch.  (The events are still created with hipEventBlockingSync, which this runtime ignores:
+    // tools/ubench/wait_cpu.hip.)  n_streams 3 .. 7 are taken as 2, as jtgpu.h says.
     h->blocking = (flags & JT_OPEN_BLOCKING_SYNC) != 0;
     const unsigned evb = h->blocking ? hipEventBlockingSync : 0u;
 #ifdef JT_AB
@@ -263,6 +265,7 @@ void jt_set_input_common(jt_ctx *h, int64_t frames, int sr, int ch)
     // here (k_downmix), so surround layouts are refused instead of being averaged with the wrong weights
     JT_REQUIRE(ch <= 2, JT_E_UNSUPPORTED, "only mono and stereo inputs are down-mixed on the device (surround layouts need swresample's matrix)");
     h->n = frames; h->sr = sr; h->channels = ch;
+    h->dec_frame_samples = 4096; h->dec_frames = (frames + 4095) / 4096; h->dec_frame_lens.clear();      // (jt_load_audio overrides: the file's own)
     h->m_p2 = h->m_p4 = 0;
     if (!h->hold_cancel) h->cancelled.store(0);           // a new job: jt_cancel() is sticky from here until the next input / jt_reset_cancel
     if (ch == 1) h->in_mono = h->in_raw;
@@ -271,6 +274,18 @@ void jt_set_input_common(jt_ctx *h, int64_t frames, int sr, int ch)
         launch_downmix(h->in_raw, h->mono.p, frames, ch, 0, h->stream);
         h->in_mono = h->mono.p;
     }
+}
+
+extern "C" int jt_input_frame_layout(jt_ctx *h, int *frame_samples, int *variable, int64_t *n_frames, int32_t *lens, int64_t cap)
+{
+    JT_API_BEGIN_KEEP(h)
+    JT_REQUIRE(h->n > 0, JT_E_STATE, "frame layout: no input");
+    const bool var = !h->dec_frame_lens.empty();
+    if (frame_samples) *frame_samples = h->dec_frame_samples;
+    if (variable) *variable = var ? 1 : 0;
+    if (n_frames) *n_frames = var ? (int64_t)h->dec_frame_lens.size() : (h->n + h->dec_frame_samples - 1) / h->dec_frame_samples;
+    if (lens && var) std::copy(h->dec_frame_lens.begin(), h->dec_frame_lens.begin() + std::min<int64_t>(cap, (int64_t)h->dec_frame_lens.size()), lens);
+    JT_API_END(h)
 }
 
 extern "C" int jt_upload_pcm(jt_ctx *h, const float *pcm, int64_t frames, int sr, int ch)
@@ -627,11 +642,14 @@ extern "C" int jt_pass1(jt_ctx *h, int frame_samples, jt_analysis *out, double *
 {
     JT_API_BEGIN_KEEP(h)                      // (reads the input only: a running Pass-2 head is left alone)
     JT_REQUIRE(h->n > 0 && h->in_raw, JT_E_STATE, "pass1: no input uploaded");
-    JT_REQUIRE(out && frame_samples > 0, JT_E_INVAL, "pass1: bad arguments");
+    JT_REQUIRE(out && frame_samples >= 0, JT_E_INVAL, "pass1: bad arguments");
     check_cancel(h);
     JT_HIP(hipEventRecord(h->ev0, h->stream));
     std::memset(out, 0, sizeof(*out));
-    const int64_t nfr = (h->n + frame_samples - 1) / frame_samples;
+    // frame_samples == 0: the input's own cadence (jt_input_frame_layout), frame by frame when the stream's frames differ in length
+    const bool var_frames = frame_samples == 0 && !h->dec_frame_lens.empty();
+    if (frame_samples == 0) frame_samples = h->dec_frame_samples;
+    const int64_t nfr = var_frames ? (int64_t)h->dec_frame_lens.size() : (h->n + frame_samples - 1) / frame_samples;
     out->n_input_frames = nfr;
     pass_begin(h, h->n, 1);
     const double *fst = nullptr;
@@ -641,7 +659,8 @@ extern "C" int jt_pass1(jt_ctx *h, int frame_samples, jt_analysis *out, double *
     analysis_enqueue(h, h->in_mono, h->n, h->sr, true, h->sr / 10, &J, false);
     if (frame_sumsq && frame_peak) {
         h->d_scr3.ensure((size_t)nfr * 2);
-        launch_frame_stats(h->in_raw, h->n * h->channels, frame_samples * h->channels, h->d_scr3.p, h->d_scr3.p + nfr, nfr, h->stream);
+        if (var_frames) launch_frame_stats_var(h->in_raw, h->channels, h->d_frame_off.p, h->d_scr3.p, h->d_scr3.p + nfr, nfr, h->stream);
+        else launch_frame_stats(h->in_raw, h->n * h->channels, frame_samples * h->channels, h->d_scr3.p, h->d_scr3.p + nfr, nfr, h->stream);
         double *tmp = h->pin.take<double>((size_t)nfr * 2);
         JT_HIP(hipMemcpyAsync(tmp, h->d_scr3.p, sizeof(double) * nfr * 2, hipMemcpyDeviceToHost, h->stream));
         fst = tmp;

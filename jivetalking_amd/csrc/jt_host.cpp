@@ -6,6 +6,7 @@
 #include "jt_internal.h"
 #include <unistd.h>
 #include <sys/stat.h>
+#include <sys/vfs.h>
 #include <fcntl.h>
 #include <sys/mman.h>
 #include <cerrno>
@@ -493,6 +494,13 @@ extern "C" int64_t jt_host_build_intervals(int sr, int64_t n_samples, int frame_
                                            const double *fss, const double *fpk, int64_t n_frames,
                                            const jt_frame_meta *meta, int64_t n_meta, int quantize, jt_interval *out, int64_t cap)
 {
+    return jt_host_build_intervals_v(sr, n_samples, frame_samples, nullptr, channels, fss, fpk, n_frames, meta, n_meta, quantize, out, cap);
+}
+
+extern "C" int64_t jt_host_build_intervals_v(int sr, int64_t n_samples, int frame_samples, const int32_t *frame_lens, int channels,
+                                             const double *fss, const double *fpk, int64_t n_frames,
+                                             const jt_frame_meta *meta, int64_t n_meta, int quantize, jt_interval *out, int64_t cap)
+{
     struct IA { int frameCount = 0; double rawSS = 0; int64_t rawN = 0; double rawPk = 0; jt_spectral spec = spec_zero(); bool specFound = false;
                 double mSum = 0, sSum = 0, tpMax = 0, spMax = 0; };
     IA acc; int64_t nout = 0; int64_t intervalStart = 0; int64_t processed = 0;
@@ -550,7 +558,8 @@ extern "C" int64_t jt_host_build_intervals(int sr, int64_t n_samples, int frame_
         acc.mSum += M; acc.sSum += S; acc.frameCount++;
     };
     for (int64_t f = 0; f < n_frames; ++f) {
-        int64_t nb = std::min<int64_t>(frame_samples, n_samples - f * (int64_t)frame_samples);
+        // inputFrame.NbSamples() (analyser.go:592): the frame's own length
+        int64_t nb = frame_lens ? (int64_t)frame_lens[f] : std::min<int64_t>(frame_samples, n_samples - f * (int64_t)frame_samples);
         int64_t t = (int64_t)((double)processed / (double)sr * 1e9);
         processed += nb;
         acc.rawSS += fss[f]; acc.rawN += nb * channels; if (fpk[f] > acc.rawPk) acc.rawPk = fpk[f];
@@ -1040,7 +1049,14 @@ static int analyse_core(jt_ctx *h, const jt_host_config *base, int frame_samples
     int rc;
     jt_analysis a1; std::memset(&a1, 0, sizeof(a1));
     const int64_t n = h->n; const int sr = h->sr;
-    const int64_t nfr = (n + frame_samples - 1) / frame_samples;
+    // frame_samples == 0: the input's own decoder-frame cadence (what Reader.ReadFrame would deliver for this file: jt_load_audio
+    // recorded it), frame by frame when the stream's frames differ in length; a positive value is the caller's
+    const int32_t *flens = (frame_samples == 0 && !h->dec_frame_lens.empty()) ? h->dec_frame_lens.data() : nullptr;
+    const int fs_arg = frame_samples;                         // (jt_pass1 resolves 0 the same way)
+    if (frame_samples < 0) { h->err = "frame_samples must be 0 (the input's own cadence) or positive"; return JT_E_INVAL; }
+    if (frame_samples == 0) frame_samples = h->dec_frame_samples;
+    if (frame_samples <= 0) return JT_E_INVAL;
+    const int64_t nfr = flens ? (int64_t)h->dec_frame_lens.size() : (n + frame_samples - 1) / frame_samples;
     const int64_t cap_meta = n / (sr / 10) + 2;
     std::vector<double> fss((size_t)nfr), fpk((size_t)nfr);
     std::vector<jt_frame_meta> meta((size_t)cap_meta);
@@ -1056,19 +1072,20 @@ static int analyse_core(jt_ctx *h, const jt_host_config *base, int frame_samples
         (void)jt_pass2_prefetch_after_pass1(h, &fp);          // best effort: Pass 2 runs from the input if this did not start
     }
     double t0 = now_ms();
-    if ((rc = jt_pass1(h, frame_samples, &a1, fss.data(), fpk.data(), nfr, meta.data(), cap_meta)) != JT_OK) return rc;
+    if ((rc = jt_pass1(h, fs_arg, &a1, fss.data(), fpk.data(), nfr, meta.data(), cap_meta)) != JT_OK) return rc;
     out->pass_ms[0] = h->timers.pass1_ms;
     out->stage_ms[0] = now_ms() - t0; t0 = now_ms();
     if (tk && tk->ticks) {
         const double est = ((double)n / sr) * sr / 4096.0;                    // estimatedTotalFrames (analyser.go:560-566)
         for (int64_t fc = 0; fc < nfr && est > 0; fc += 100) {
-            const int64_t cnt = std::min<int64_t>((int64_t)frame_samples * h->channels, (n - fc * frame_samples) * h->channels);
+            const int64_t cnt = flens ? (int64_t)flens[fc] * h->channels
+                                      : std::min<int64_t>((int64_t)frame_samples * h->channels, (n - fc * frame_samples) * h->channels);
             tk->tick(1, "Analysing", std::min(0.95, (double)fc / est * 0.95), level_from_sumsq(fss[(size_t)fc], (double)cnt));
         }
     }
     std::vector<jt_interval> iv((size_t)(n / (sr / 5) + 16));
-    int64_t niv = jt_host_build_intervals(sr, n, frame_samples, h->channels, fss.data(), fpk.data(), nfr, meta.data(), a1.n_frames_meta, 1,
-                                          iv.data(), (int64_t)iv.size());
+    int64_t niv = jt_host_build_intervals_v(sr, n, frame_samples, flens, h->channels, fss.data(), fpk.data(), nfr, meta.data(), a1.n_frames_meta, 1,
+                                            iv.data(), (int64_t)iv.size());
     if (niv > (int64_t)iv.size()) niv = (int64_t)iv.size();
     h->last_intervals.assign(iv.begin(), iv.begin() + niv);
     jt_measurements &m = out->input;
@@ -1193,7 +1210,8 @@ static int process_audio_impl(jt_ctx *h, const jt_host_config *base, int frame_s
     stage_levels(2, &lv2);
     if (tk.ticks && !lv2.empty()) {
         // every 100th INPUT frame; Level = the filtered frame the sink had delivered by then (processor.go:320-338)
-        const int64_t nfr_in = (h->n + frame_samples - 1) / frame_samples;
+        const int fsz = frame_samples > 0 ? frame_samples : h->dec_frame_samples;
+        const int64_t nfr_in = (frame_samples == 0 && !h->dec_frame_lens.empty()) ? (int64_t)h->dec_frame_lens.size() : (h->n + fsz - 1) / fsz;
         const double est = ((double)h->n / h->sr) * h->sr / 4096.0;
         for (int64_t fc = 100; fc <= nfr_in && est > 0; fc += 100) {
             const size_t oi = (size_t)std::min<int64_t>((int64_t)lv2.size() - 1, fc * (int64_t)lv2.size() / std::max<int64_t>(1, nfr_in));
@@ -1601,6 +1619,48 @@ int file_front(jt_ctx *h, const char *input_path, const jt_host_config *base, in
     tail->input_path = input_path; tail->final_path = path;
     return JT_OK;
 }
+// one page cache for every reader of the file?  (tmpfs, ext*, xfs, btrfs, f2fs, overlayfs on those, ramfs, zfs); anything else -- NFS, CIFS /
+// SMB, FUSE, 9p, Lustre, Ceph ... -- is treated as shared with other hosts
+bool jt_fd_is_local(int fd)
+{
+    struct statfs sf;
+    if (fstatfs(fd, &sf) != 0) return false;
+    switch ((unsigned long)sf.f_type) {
+    case 0x01021994ul /* tmpfs */: case 0xEF53ul /* ext2/3/4 */: case 0x58465342ul /* xfs */: case 0x9123683Eul /* btrfs */:
+    case 0xF2F52010ul /* f2fs */: case 0x794C7630ul /* overlayfs */: case 0x858458F6ul /* ramfs */: case 0x2FC12FC1ul /* zfs */:
+        return true;
+    default: return false;
+    }
+}
+// munmap off the caller's thread: one lazily started reaper per process, joined by its static destructor (process exit / dlclose)
+void jt_unmap_later(uint8_t *m, size_t n)
+{
+    struct Reaper {
+        std::mutex mu; std::condition_variable cv; std::vector<std::pair<uint8_t *, size_t>> q; bool stop = false, started = false; std::thread th;
+        void run() {
+            std::unique_lock<std::mutex> l(mu);
+            for (;;) {
+                cv.wait(l, [&] { return stop || !q.empty(); });
+                if (q.empty()) return;
+                auto jobs = std::move(q); q.clear();
+                l.unlock();
+                for (auto &j : jobs) munmap(j.first, j.second);
+                l.lock();
+            }
+        }
+        ~Reaper() { { std::lock_guard<std::mutex> l(mu); stop = true; cv.notify_all(); } if (th.joinable()) th.join(); }
+    };
+    static Reaper R;
+    {
+        std::lock_guard<std::mutex> l(R.mu);
+        if (!R.started) {
+            try { R.th = std::thread([] { R.run(); }); R.started = true; }
+            catch (const std::system_error &) { /* no thread to be had: unmap here */ }
+        }
+        if (R.started) { R.q.emplace_back(m, n); R.cv.notify_all(); return; }
+    }
+    munmap(m, n);
+}
 // returns JT_OK or the code + message jt_process_file reports; ms[0] = the MD5, ms[1] = write + rename
 int file_tail(const FileTail &t, std::string *err, double ms[2])
 {
@@ -1642,12 +1702,18 @@ int file_tail(const FileTail &t, std::string *err, double ms[2])
     const double tw1 = wall_ms();
     // tearing the mapping down (43 000 dirty shared pages: 9-11 ms) is nobody's business but this process's: it happens on a thread of
     // its own AFTER the file has been published (beside the truncate it fought it for the address-space lock: 8-12 ms instead of 4)
-    struct Unmap { uint8_t *m = nullptr; size_t n = 0; ~Unmap() { if (m) { uint8_t *mm = m; const size_t nn = n; std::thread([mm, nn] { munmap(mm, nn); }).detach(); } } } unmap_later;
+    // (the library's reaper thread, not a detached one: nothing of this library runs after it is unloaded, and a thread that cannot be
+    //  created means an inline munmap instead of std::terminate in a destructor: ADVICE r5)
+    struct Unmap { uint8_t *m = nullptr; size_t n = 0; ~Unmap() { if (m) jt_unmap_later(m, n); } } unmap_later;
     if (t.pre && t.pre->map && copied) { unmap_later.m = t.pre->map; unmap_later.n = t.pre->reserved; t.pre->map = nullptr; }
     else if (t.pre) t.pre->unmap();
     const double tw2 = wall_ms();
     if (fd < 0) fd = g_fault_create_temp ? -1 : mkstemps(tmp.data(), 9);
     if (fd < 0) { *err = std::string("failed to create temporary output next to ") + t.input_path; return JT_E_INVAL; }
+    // A shared mapping's dirty pages reach a NETWORK filesystem at msync / munmap, not at close(): published by rename with the mapping
+    // still live, another client could read stale or zero blocks.  Local filesystems (one page cache) keep the fast path; anywhere else
+    // the written range is flushed synchronously before the file gets its final name.
+    if (copied && unmap_later.m && !jt_fd_is_local(fd) && msync(unmap_later.m, (size_t)t.len, MS_SYNC) != 0) copied = false;
     bool okw = !g_fault_write && (copied || io_slices(fd, t.image, (size_t)t.len, true, reserved));
     if (okw && reserved > (size_t)t.len && ftruncate(fd, (off_t)t.len) != 0) okw = false;      // (the estimate's surplus)
     if (fchmod(fd, 0644) != 0) { /* keep mkstemp's 0600: not fatal */ }
@@ -1817,9 +1883,20 @@ extern "C" int jt_handle_pool_process_files(jt_handle_pool *P, const char *const
         // two I/O sets per handle: a file's tail runs on a finisher thread from set k while the handle fills set 1 - k
         struct Gate { std::mutex m; std::condition_variable cv; bool busy = false;
                       void wait_free() { std::unique_lock<std::mutex> l(m); cv.wait(l, [&] { return !busy; }); }
-                      void release() { { std::lock_guard<std::mutex> l(m); busy = false; } cv.notify_all(); } } gate[2];
+                      // (notify UNDER the lock: the gates live on this worker's stack, and a worker that saw !busy between an unlock and
+                      //  a later notify could leave the frame while the finisher was still about to touch the condition variable: ADVICE r5)
+                      void release() { std::lock_guard<std::mutex> l(m); busy = false; cv.notify_all(); } } gate[2];
+        // set by a finisher job that met a HIP failure (its event query / device selection): the handle's stream may have faulted, and
+        // the worker only learns of front errors by itself -- it checks this before it takes the next file, drains both gates and
+        // replaces the handle exactly as it does for a front failure
+        auto suspect = std::make_shared<std::atomic<int>>(0);
         int set = 0;
         while (W->h) {
+            if (suspect->exchange(0)) {
+                gate[0].wait_free(); gate[1].wait_free();
+                jt_close(W->h); W->h = nullptr;
+                if (jt_open_ex(W->device, P->n_streams, P->open_flags, &W->h) != JT_OK) { W->h = nullptr; break; }
+            }
             const int q = next.fetch_add(1);
             if (q >= n_files) break;
             const int i = order[(size_t)q];
@@ -1840,7 +1917,7 @@ extern "C" int jt_handle_pool_process_files(jt_handle_pool *P, const char *const
                            std::vector<double> st; double t_front = 0; };
             auto early = std::make_shared<Early>();
             Gate *g = &gate[set];
-            auto finish = [tail, early, &r, &failed, g, t0, P] {
+            auto finish = [tail, early, &r, &failed, g, t0, P, suspect] {
                 std::string err; double ms[2] = {0, 0}; uint8_t md5[16]; bool md5_ok = true;
                 if (early->started) {
                     const double m0 = wall_ms();
@@ -1860,7 +1937,7 @@ extern "C" int jt_handle_pool_process_files(jt_handle_pool *P, const char *const
                 }
                 std::vector<double> sv(early->st); sv[5] = wall_ms() - early->t_front;
                 int rc = JT_OK;
-                if (early->started && !md5_ok) { rc = JT_E_HIP; err = "the PCM's copy for the STREAMINFO signature failed"; }
+                if (early->started && !md5_ok) { rc = JT_E_HIP; err = "the PCM's copy for the STREAMINFO signature failed"; suspect->store(1); }
                 else {
                     if (early->started) memcpy(tail->image + 26, md5, 16);                 // (tail->pcm is null: file_tail does not hash again)
                     double tms[2] = {0, 0};
@@ -1917,6 +1994,10 @@ extern "C" int jt_handle_pool_process_files(jt_handle_pool *P, const char *const
             set ^= 1;
         }
         gate[0].wait_free(); gate[1].wait_free();
+        if (W->h && suspect->exchange(0)) {                   // (a failure reported by the batch's last finisher jobs: the next batch gets a fresh handle)
+            jt_close(W->h); W->h = nullptr;
+            if (jt_open_ex(W->device, P->n_streams, P->open_flags, &W->h) != JT_OK) W->h = nullptr;
+        }
     };
     const size_t nw = std::min<size_t>(P->workers.size(), (size_t)n_files);
     // with fewer files than workers, take one worker per device before a second on any (the workers are sorted by device)

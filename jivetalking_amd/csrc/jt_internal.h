@@ -151,6 +151,8 @@ void launch_frame_stats(const float *in, int64_t n_total /*frames*channels*/, in
                         double *sumsq, double *peak, int64_t nframes, hipStream_t s);
 // mode: 0 = float 1/sqrt2 (Pass 1 / Pass 2), 1 = s16 integer matrix, 2 = s32 via float 0.5 (the band graphs of integer sources)
 void launch_frame_sumsq_s16(const int16_t *in, int64_t n, int spf, double *sumsq, int64_t nframes, hipStream_t s);
+// frames of different lengths: off[f] .. off[f + 1] = frame f's range in samples per channel (nframes + 1 entries on the device)
+void launch_frame_stats_var(const float *in, int channels, const int64_t *off, double *sumsq, double *peak, int64_t nframes, hipStream_t s);
 void launch_downmix(const float *in, float *out, int64_t frames, int channels, int mode, hipStream_t s);
 void launch_s16_to_f32(const int16_t *in, float *out, int64_t n, hipStream_t s);
 void launch_s16_to_f32_pair(const int16_t *in0, int64_t n0, const int16_t *in1, int64_t n1, float *out0, float *out1, hipStream_t s);   // two ranges, one launch
@@ -400,6 +402,10 @@ struct jt_ctx {
     // input
     int sr = 0, channels = 0; int64_t n = 0;
     int src_fmt = 0;                    // the decoder's native sample format: 0 flt/dbl, 1 s16 (also u8), 2 s32 (24/32-bit integer)
+    // the decoder's frame cadence of the current input (what frame_samples = 0 means; jtgpu.h: jt_input_frame_layout): jt_load_audio
+    // sets it from the file, every other way of handing over PCM leaves 4096 / constant.  dec_frame_lens is non-empty only when the
+    // frames differ in length (a variable-blocksize FLAC); d_frame_off = their start offsets (n + 1 entries) for k_frame_stats_var.
+    int dec_frame_samples = 4096; int64_t dec_frames = 0; std::vector<int32_t> dec_frame_lens; DevBuf<int64_t> d_frame_off;
     DevBuf<float> band_mono;            // the band graphs' own down-mix of an integer stereo source
     const float *in_raw = nullptr;      // interleaved (owned or attached)
     DevBuf<float> in_owned;

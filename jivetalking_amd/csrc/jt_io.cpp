@@ -141,7 +141,9 @@ extern "C" int jt_op_flac_encode_s16(jt_ctx *h, const int16_t *pcm, int64_t n, i
 
 // ---------------------------------------------------------------- input leg: FLAC / WAV file image -> PCM on the device
 namespace {
-struct AudioDecoded { int64_t frames = 0; int channels = 0, rate = 0, bits = 0, is_float = 0, format = 0; int64_t flac_frames = 0; int cands = 0; };
+struct AudioDecoded { int64_t frames = 0; int channels = 0, rate = 0, bits = 0, is_float = 0, format = 0; int64_t flac_frames = 0; int cands = 0;
+                      // the decoder's frame cadence (jtgpu.h: jt_audio_meta): constant length, or per-frame lengths when they differ
+                      int dec_frame_samples = 4096; int64_t dec_frames = 0; std::vector<int32_t> frame_lens; };
 
 uint32_t rd_le32(const uint8_t *p) { return (uint32_t)p[0] | (uint32_t)p[1] << 8 | (uint32_t)p[2] << 16 | (uint32_t)p[3] << 24; }
 uint32_t rd_le16(const uint8_t *p) { return (uint32_t)p[0] | (uint32_t)p[1] << 8; }
@@ -193,10 +195,13 @@ void decode_flac(jt_ctx *h, const uint8_t *file, int64_t len, int64_t start, boo
     int *counts = nullptr;                                    // [0] candidates found, [1] subframe decode errors
     int ncand = 0;
     bool ahead = false;                                       // mono: the candidates' samples are decoded already, one row each
+    // The DEVICE tables are sized for the capacity; the pinned host copies only for the candidates actually found (a stream
+    // without a sample count or with a tiny declared block size makes the capacity ~ len / 8 entries of 112 bytes -- gigabytes of
+    // pinned memory per handle for a table that then holds a few thousand rows).  A table that cannot be pinned is a verdict about
+    // the FILE (JT_E_UNSUPPORTED), not about the handle.
+    h->io_small.begin(4096);                                                                            // (nothing of the arena is in flight here)
+    counts = h->io_small.take<int>(16); counts[0] = counts[1] = 0;
     for (int attempt = 0; attempt < 2; attempt++) {
-        h->io_small.begin(4096 + (sizeof(JtFlacCand) + sizeof(JtFlacParsed)) * (size_t)cap + 256);      // (nothing of the arena is in flight here)
-        counts = h->io_small.take<int>(16); counts[0] = counts[1] = 0;
-        cands = h->io_small.take<JtFlacCand>((size_t)cap); parsed = h->io_small.take<JtFlacParsed>((size_t)cap);
         const size_t tab_bytes = 256 + sizeof(JtFlacCand) * (size_t)cap + sizeof(JtFlacParsed) * (size_t)cap;
         h->in_tab.ensure(tab_bytes);
         int *d_count = reinterpret_cast<int *>(h->in_tab.p);
@@ -209,6 +214,12 @@ void decode_flac(jt_ctx *h, const uint8_t *file, int64_t len, int64_t start, boo
         ncand = counts[0]; tm1 = flac_now_ms();
         if (ncand > cap) { cap = ncand + 1024; continue; }
         JT_REQUIRE(ncand > 0, JT_E_INVAL, "flac: no frame headers found");
+        const size_t host_tab = (sizeof(JtFlacCand) + sizeof(JtFlacParsed)) * (size_t)ncand + 4096 + 256;
+        JT_REQUIRE(host_tab <= ((size_t)1 << 31), JT_E_UNSUPPORTED, "flac: too many frame-header candidates for this file (not a stream this decoder takes)");
+        try { h->io_small.begin(host_tab); }
+        catch (const JtError &) { throw JtError{JT_E_UNSUPPORTED, "flac: the candidate table of this file cannot be pinned"}; }
+        counts = h->io_small.take<int>(16); counts[0] = ncand; counts[1] = 0;
+        cands = h->io_small.take<JtFlacCand>((size_t)ncand); parsed = h->io_small.take<JtFlacParsed>((size_t)ncand);
         // mono: one walk per candidate parses AND decodes it, into a row of its own (k_flacdec.hip, k_flac_decode_cand)
         ahead = st.channels == 1 && !h->opts.flac_no_ahead && (int64_t)ncand * st.max_blocksize < ((int64_t)1 << 31);
         if (ahead) {
@@ -295,6 +306,18 @@ void decode_flac(jt_ctx *h, const uint8_t *file, int64_t len, int64_t start, boo
     JT_REQUIRE(nerr == 0, JT_E_INVAL, "flac: subframe decode error");
     out->frames = total; out->channels = st.channels; out->rate = st.sample_rate; out->bits = st.bps; out->is_float = 0; out->format = 1;
     out->flac_frames = (int64_t)frames.size(); out->cands = ncand;
+    // one AVFrame per FLAC frame (libavcodec/flacdec.c): constant when every frame but the last has the first one's length
+    out->dec_frame_samples = frames[0].blocksize; out->dec_frames = (int64_t)frames.size();
+    bool constant = true; int longest = 0;
+    for (size_t i = 0; i < frames.size(); i++) {
+        longest = std::max(longest, frames[i].blocksize);
+        if (i + 1 < frames.size() ? frames[i].blocksize != frames[0].blocksize : frames[i].blocksize > frames[0].blocksize) constant = false;
+    }
+    if (!constant) {
+        out->dec_frame_samples = longest;
+        out->frame_lens.resize(frames.size());
+        for (size_t i = 0; i < frames.size(); i++) out->frame_lens[i] = frames[i].blocksize;
+    }
 }
 
 // RIFF/WAVE: chunk walk on the host, sample unpacking on the device
@@ -337,6 +360,15 @@ void decode_wav(jt_ctx *h, const uint8_t *file, int64_t len, bool want_i32, bool
     launch_pcm_convert(h->in_file.p, (long long)nvals, fmt, want_f32 ? h->in_owned.p : nullptr, want_i32 ? h->in_i32.p : nullptr, h->stream);
     JT_HIP(jt_stream_sync(h, h->stream));
     out->frames = frames; out->channels = ch; out->rate = rate; out->bits = bits; out->is_float = tag == 3; out->format = 2;
+    // libavformat/wavdec.c wav_read_packet: size = max_size (AVOption, default 4096 bytes); with block_align > 1 at least one block and
+    // rounded down to whole blocks; the PCM decoder makes one AVFrame of every packet
+    {
+        const int balign = bytes * ch;
+        int size = 4096;
+        if (balign > 1) { if (size < balign) size = balign; size = size / balign * balign; }
+        out->dec_frame_samples = size / balign;
+        out->dec_frames = (frames + out->dec_frame_samples - 1) / out->dec_frame_samples;
+    }
 }
 
 void decode_audio(jt_ctx *h, const uint8_t *file, int64_t len, bool want_i32, bool want_f32, AudioDecoded *out, jt_audio_meta *meta)
@@ -362,6 +394,7 @@ void decode_audio(jt_ctx *h, const uint8_t *file, int64_t len, bool want_i32, bo
         meta->format = out->format; meta->sample_rate = out->rate; meta->channels = out->channels; meta->bits_per_sample = out->bits;
         meta->is_float = out->is_float; meta->frames = out->frames; meta->duration_s = (double)out->frames / (double)out->rate;
         meta->flac_frames = out->flac_frames; meta->flac_candidates = out->cands; meta->gpu_ms = gpu_ms; meta->total_ms = flac_now_ms() - t0;
+        meta->decoder_frame_samples = out->dec_frame_samples; meta->decoder_frames_variable = out->frame_lens.empty() ? 0 : 1; meta->decoder_frames = out->dec_frames;
     }
 }
 } // namespace
@@ -376,6 +409,15 @@ extern "C" int jt_load_audio(jt_ctx *h, const uint8_t *file, int64_t len, jt_aud
     h->in_raw = h->in_owned.p;
     h->src_fmt = d.is_float ? 0 : (d.bits <= 16 ? 1 : 2);       // what libavcodec would hand to abuffer: flt/dbl, (u8/)s16, s32
     jt_set_input_common(h, d.frames, d.rate, d.channels);
+    // the file's own frame cadence: what frame_samples = 0 means from here on (jt_pass1, jt_process_audio, ...)
+    h->dec_frame_samples = d.dec_frame_samples; h->dec_frames = d.dec_frames; h->dec_frame_lens = std::move(d.frame_lens);
+    if (!h->dec_frame_lens.empty()) {
+        const size_t nf = h->dec_frame_lens.size();
+        std::vector<int64_t> off(nf + 1); off[0] = 0;
+        for (size_t i = 0; i < nf; i++) off[i + 1] = off[i] + h->dec_frame_lens[i];
+        h->d_frame_off.ensure(nf + 1);
+        JT_HIP(hipMemcpy(h->d_frame_off.p, off.data(), sizeof(int64_t) * (nf + 1), hipMemcpyHostToDevice));
+    }
     JT_HIP(jt_stream_sync(h, h->stream));
     JT_API_END(h)
 }

@@ -1722,11 +1722,8 @@ void launch_adeclick(jt_ctx *h, const double *in, double *out, int64_t n, int sa
                 JT_HIP(hipFuncSetAttribute((const void *)k64, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm64));
                 // the two solver launches are independent (disjoint windows, disjoint scratch): the wide-band one runs beside the other
                 // on a stream of its own
-                if (!h->dk_stream) {
-                    JT_HIP(hipStreamCreateWithFlags(&h->dk_stream, hipStreamNonBlocking));
-                    JT_HIP(hipEventCreateWithFlags(&h->dk_ev[0], hipEventDisableTiming | (h->blocking ? hipEventBlockingSync : 0u)));
-                    JT_HIP(hipEventCreateWithFlags(&h->dk_ev[1], hipEventDisableTiming | (h->blocking ? hipEventBlockingSync : 0u)));
-                }
+                // (dk_stream and dk_ev[] belong to the handle: jt_open_ex creates them -- an alias of the main stream for a one-stream handle)
+                if (!h->dk_stream || !h->dk_ev[0] || !h->dk_ev[1]) throw JtError{JT_E_STATE, "adeclick: the handle has no solver stream"};
                 if (JT_AB_ON(O.dk_serial)) {
                     hipLaunchKernelGGL(k64, dim3((unsigned)g64), dim3(64), sm64, s, out, n, P, SP, h->declick_scr.p + slot32 * 2 * (size_t)g32, slot64, d_stats);
                     hipLaunchKernelGGL(k32, dim3((unsigned)g32), dim3(64), sm32, s, out, n, P, SP, h->declick_scr.p, slot32, d_stats);

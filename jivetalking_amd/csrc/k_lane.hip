@@ -341,6 +341,39 @@ void launch_frame_stats(const float *in, int64_t n_total, int spf, double *sumsq
     hipLaunchKernelGGL(k_frame_stats, dim3((unsigned)nframes), dim3(256), 0, s, in, n_total, spf, sumsq, peak, nframes);
 }
 
+// the same for decoder frames of different lengths (a variable-blocksize FLAC stream): frame f = samples off[f] .. off[f + 1] per channel
+__global__ void k_frame_stats_var(const float *__restrict__ in, int channels, const int64_t *__restrict__ off, double *__restrict__ sumsq,
+                                  double *__restrict__ peak, int64_t nframes)
+{
+    int64_t f = blockIdx.x;
+    if (f >= nframes) return;
+    const int64_t lo = off[f] * channels, hi = off[f + 1] * channels;
+    double acc = 0.0, pk = 0.0;
+    for (int64_t i = lo + threadIdx.x; i < hi; i += blockDim.x) {
+        double v = (double)in[i];
+        acc += v * v;
+        pk = fmax(pk, fabs(v));
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        acc += __shfl_down(acc, o, 64);
+        pk = fmax(pk, __shfl_down(pk, o, 64));
+    }
+    __shared__ double sa[4], sp[4];
+    int w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { sa[w] = acc; sp[w] = pk; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double a = 0, p = 0;
+        for (int k = 0; k < (int)(blockDim.x >> 6); ++k) { a += sa[k]; p = fmax(p, sp[k]); }
+        sumsq[f] = a; peak[f] = p;
+    }
+}
+void launch_frame_stats_var(const float *in, int channels, const int64_t *off, double *sumsq, double *peak, int64_t nframes, hipStream_t s)
+{
+    if (nframes <= 0) return;
+    hipLaunchKernelGGL(k_frame_stats_var, dim3((unsigned)nframes), dim3(256), 0, s, in, channels, off, sumsq, peak, nframes);
+}
+
 // calculateFrameLevel (encoder.go:235-257) on the frames of a stage output: sum of squares of (s16 / 32768) per frame
 __global__ void k_frame_sumsq_s16(const int16_t *__restrict__ in, int64_t n, int spf, double *__restrict__ sumsq, int64_t nframes)
 {

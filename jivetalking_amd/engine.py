@@ -121,6 +121,16 @@ class Engine:
         self._ck(self.lib.jt_load_audio(self.h, buf.ctypes.data_as(C.POINTER(C.c_uint8)), C.c_int64(buf.size), C.byref(m)))
         return _st2dict(m)
 
+    def input_frame_layout(self):
+        """jt_input_frame_layout: (frame_samples, variable, n_frames, per-frame lengths or None) of the handle's current input."""
+        fs, var, nf = C.c_int(), C.c_int(), C.c_int64()
+        self._ck(self.lib.jt_input_frame_layout(self.h, C.byref(fs), C.byref(var), C.byref(nf), None, C.c_int64(0)))
+        lens = None
+        if var.value:
+            lens = np.zeros(nf.value, np.int32)
+            self._ck(self.lib.jt_input_frame_layout(self.h, None, None, None, lens.ctypes.data_as(C.POINTER(C.c_int32)), C.c_int64(nf.value)))
+        return fs.value, bool(var.value), nf.value, lens
+
     def op_decode_audio(self, data, want_i32=True):
         """Decoded samples back on the host: (int32 [frames, ch] or None, f32 [frames, ch], meta)."""
         buf = np.frombuffer(bytes(data), np.uint8); m = L.AudioMeta()

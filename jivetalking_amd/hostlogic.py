@@ -106,7 +106,7 @@ SIZEOF_IDS = {0: Interval, 1: Measurements, 2: HostConfig, 3: ProcessResult, 4: 
               6: LimiterDecision, 7: AdaptiveDiag, 8: L.FilterParams, 9: L.LoudnormApply, 10: L.Analysis, 11: L.RegionSample,
               12: L.FlacInfo, 13: L.AudioMeta, 15: L.Timers}
 
-HOST_SYMBOLS = ["jt_host_build_intervals", "jt_host_detect", "jt_host_finish_measurements", "jt_host_afftdn_band_edges",
+HOST_SYMBOLS = ["jt_host_build_intervals", "jt_host_build_intervals_v", "jt_host_detect", "jt_host_finish_measurements", "jt_host_afftdn_band_edges",
                 "jt_host_default_config", "jt_host_adapt", "jt_host_filter_spec", "jt_host_filter_params",
                 "jt_host_calculate_limiter_ceiling", "jt_host_calculate_pre_gain", "jt_host_plan_limiter",
                 "jt_host_calculate_linear_mode_target", "jt_host_loudnorm_internal_target_tp", "jt_host_pass4_spec",
@@ -127,6 +127,7 @@ def lib(engine=None):
         return l
     l.jt_host_sizeof.restype = C.c_int64
     l.jt_host_build_intervals.restype = C.c_int64
+    l.jt_host_build_intervals_v.restype = C.c_int64
     l.jt_host_loudnorm_internal_target_tp.restype = C.c_double
     l.jt_host_vad_floored_fraction.restype = C.c_double
     l.jt_host_finish_measurements.restype = None
@@ -223,8 +224,9 @@ def process_audio_with_progress(engine, on_update, base=None, frame_samples=4096
     return res
 
 
-def process_file(engine, input_path, base=None, frame_samples=4096, md5=True):
-    """jt_process_file: file in (FLAC / WAV), "<name>-LUFS-<n>-processed.flac" out.  Returns (result, output path, io_ms)."""
+def process_file(engine, input_path, base=None, frame_samples=0, md5=True):
+    """jt_process_file: file in (FLAC / WAV), "<name>-LUFS-<n>-processed.flac" out.  Returns (result, output path, io_ms).
+    frame_samples = 0 (here and in the batch entry points): the file's own decoder-frame cadence, as the reference sees it."""
     l = lib(engine)
     base = base or default_config()
     res = ProcessResult(); out = C.create_string_buffer(4096); io = (C.c_double * 4)()
@@ -240,7 +242,7 @@ class FileResult(C.Structure):
                 ("result", ProcessResult)]
 
 
-def process_files(paths, device=0, in_flight=2, base=None, frame_samples=4096, md5=True):
+def process_files(paths, device=0, in_flight=2, base=None, frame_samples=0, md5=True):
     """jt_process_files: at most `in_flight` files at a time on one GPU, one result per path (failures do not stop the others)."""
     l = lib()
     base = base or default_config()
@@ -254,7 +256,7 @@ def process_files(paths, device=0, in_flight=2, base=None, frame_samples=4096, m
     return failed, res
 
 
-def process_files_multi(paths, devices=(0,), in_flight_per_device=2, base=None, frame_samples=4096, md5=True):
+def process_files_multi(paths, devices=(0,), in_flight_per_device=2, base=None, frame_samples=0, md5=True):
     """jt_process_files_multi: one shared queue over several GPUs.  Returns (failed, results, device_of_file)."""
     l = lib()
     base = base or default_config()
@@ -290,7 +292,7 @@ class Pool:
         n = self.lib.jt_handle_pool_workers(self.p, dv, C.c_int(cap))
         return [int(dv[i]) for i in range(min(n, cap))]
 
-    def process_files(self, paths, base=None, frame_samples=4096, md5=True):
+    def process_files(self, paths, base=None, frame_samples=0, md5=True):
         """Returns (failed, results, device_of_file) like process_files_multi."""
         base = base or default_config()
         n = len(paths)

@@ -163,6 +163,86 @@ void orc_downmix_stereo(const float *in, int64_t frames, int mode, float *out)
     }
 }
 
+/* aformat=channel_layouts=mono on ANY source layout (filters.go:607-615): libswresample/rematrix.c swr_build_matrix2 with the default
+ * mix levels (center_mix_level = surround_mix_level = M_SQRT1_2, lfe_mix_level = 0, no matrix encoding) and FRONT_CENTER as the one
+ * output channel:
+ *   FC <- 1.0 * FC                      (identity; with FL / FR present the entry is overwritten by center_mix_level * sqrt(2))
+ *   FC <- M_SQRT1_2 * (FL + FR)         ("unaccounted & AV_CH_LAYOUT_STEREO")
+ *   FC <- surround_mix_level * M_SQRT1_2 * BC, likewise each of BL / BR and SL / SR     (the branches for an output without back /
+ *         side / front-left channels)
+ *   FC <- M_SQRT1_2 * (FLC + FRC),  FC <- lfe_mix_level (0) * LFE
+ * then auto_matrix's normalisation: the row is divided by the sum of its |coefficients| when that sum exceeds maxval = 1.0, which is
+ * the case ONLY when the converter's output or internal sample format is an integer one (as orc_downmix_stereo above; float graphs
+ * keep the raw coefficients).  A source without a layout (PCM WAV without a channel mask) gets av_channel_layout_default(channels)
+ * in swr_init: 2.1, 4.0, 5.0(back), 5.1(back), 6.1, 7.1 for 3 .. 8 channels.  Channels arrive in native order (ascending mask bit).
+ * swri_rematrix for one output channel with k non-zero coefficients: k = 1 copy / mix_1_1, k = 2 mix_2_1 (in1 * c1 + in2 * c2),
+ * k >= 3 the generic loop  v = 0; v += in_j * matrix_flt[j] (float products, float sums, channel order)  or, in S16P,
+ * v += in_j * matrix32[j]; out = (v + 16384) >> 15 with matrix32 = lrintf(coefficient * 32768) (mix_2_1's native_matrix carries
+ * lrintf's remainder from one coefficient to the next; with two equal halves there is none).
+ * mask 0 = the default layout of `channels`.  modes as orc_downmix_stereo.  Returns 0, or -1 for a layout this restatement does not
+ * cover (channels beyond SIDE_RIGHT, or a channel count that does not match the mask). */
+uint64_t orc_default_layout(int channels)
+{
+    static const uint64_t def[9] = {0, 0x4, 0x3, 0xB, 0x107, 0x37, 0x3F, 0x70F, 0x63F};
+    return channels >= 1 && channels <= 8 ? def[channels] : 0;
+}
+int orc_downmix_coeffs(int channels, uint64_t mask, int normalise, double coef[8])
+{
+    if (!mask) mask = orc_default_layout(channels);
+    if (!mask || (mask >> 11)) return -1;
+    int nb = 0; for (int b = 0; b < 11; b++) nb += (int)((mask >> b) & 1);
+    if (nb != channels || channels > 8) return -1;
+    const int stereo = (mask & 3) != 0;
+    int c = 0; double sum = 0.0;
+    for (int b = 0; b < 11; b++) {
+        if (!((mask >> b) & 1)) continue;
+        double v;
+        switch (b) {
+        case 0: case 1: v = M_SQRT1_2; break;                                   /* FL FR */
+        case 2: v = stereo ? M_SQRT1_2 * sqrt(2.0) : 1.0; break;                /* FC */
+        case 3: v = 0.0; break;                                                 /* LFE */
+        case 6: case 7: v = M_SQRT1_2; break;                                   /* FLC FRC */
+        default: v = M_SQRT1_2 * M_SQRT1_2; break;                              /* BL BR BC SL SR */
+        }
+        coef[c++] = v; sum += fabs(v);
+    }
+    if (normalise && sum > 1.0) for (int i = 0; i < channels; i++) coef[i] /= sum;
+    return 0;
+}
+int orc_downmix_layout(const float *in, int64_t frames, int channels, uint64_t mask, int mode, float *out)
+{
+    double coef[8];
+    if (orc_downmix_coeffs(channels, mask, mode != 0, coef) != 0) return -1;
+    int nz[8], k = 0;
+    for (int c = 0; c < channels; c++) if (coef[c] != 0.0) nz[k++] = c;
+    float cf[8]; int ci[8]; double rem = 0.0;
+    for (int j = 0; j < k; j++) cf[j] = (float)coef[nz[j]];
+    if (k == 2) {                     /* native_matrix of mix_2_1 (swri_rematrix_init): the remainder is carried over ALL inputs of the row */
+        for (int c = 0; c < channels; c++) { const double target = coef[c] * 32768 + rem; const int q = (int)lrintf((float)target); rem += target - q; for (int j = 0; j < k; j++) if (nz[j] == c) ci[j] = q; }
+    } else for (int j = 0; j < k; j++) ci[j] = (int)lrintf((float)(coef[nz[j]] * 32768));
+    for (int64_t i = 0; i < frames; i++) {
+        const float *x = in + i * channels;
+        if (mode == 1) {
+            int v = 0;
+            if (k == 1) v = ((int)lrintf(x[nz[0]] * 32768.0f) * ci[0] + 16384) >> 15;
+            else { for (int j = 0; j < k; j++) v += (int)lrintf(x[nz[j]] * 32768.0f) * ci[j]; v = (v + 16384) >> 15; }
+            out[i] = (float)(int16_t)v * (1.0f / 32768.0f);
+            continue;
+        }
+        float v;
+        if (k == 1) v = cf[0] == 1.0f ? x[nz[0]] : x[nz[0]] * cf[0];
+        else if (k == 2) { const float a = x[nz[0]] * cf[0], b = x[nz[1]] * cf[1]; v = a + b; }
+        else { v = 0.0f; for (int j = 0; j < k; j++) { const float p = x[nz[j]] * cf[j]; v = v + p; } }
+        if (mode == 0) { out[i] = v; continue; }
+        double d = (double)v * 2147483648.0;
+        long long q = llrint(d);
+        if (q > INT32_MAX) q = INT32_MAX;
+        if (q < INT32_MIN) q = INT32_MIN;
+        out[i] = (float)((double)q / 2147483648.0);
+    }
+    return 0;
+}
+
 /* BIQUAD_TDII_FILTER(flt, float, float, ...): float coefficients, float state. */
 void orc_biquad_tdii_f32(const float *in, float *out, int64_t n, const double b[3], const double a[3])
 {

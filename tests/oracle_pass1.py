@@ -15,7 +15,10 @@ ASTATS_MAP = {"peak_level": "peak_level_db", "rms_level": "rms_level_db", "rms_p
               "noise_floor": "noise_floor_db", "bit_depth": "abs_peak_count"}
 
 
-def oracle_pass1(orc, x, sr, frame_samples=4096):
+def oracle_pass1(orc, x, sr, frame_samples=4096, frame_lens=None, raw=None):
+    """`frame_lens`: per-frame lengths of a stream whose decoder frames differ (a variable-blocksize FLAC); `raw`: the interleaved
+    source of a stereo file (channels = raw.size // x.size) -- the per-frame sum(x^2) / peak are taken on the RAW samples of all
+    channels (analyser_metrics.go:273-358), everything else on the down-mix x."""
     x = np.ascontiguousarray(x, np.float32)
     n = x.size
     blk = sr // 10
@@ -53,32 +56,43 @@ def oracle_pass1(orc, x, sr, frame_samples=4096):
     r.true_peak = float(e["TP"][nfull - 1]) if nfull else 0.0
     r.sample_peak = float(e["SP"][nfull - 1]) if nfull else 0.0
     r.target_threshold = e["target_threshold"]
+    src = np.asarray(x if raw is None else raw, np.float64)
+    ch = src.size // n
+    if frame_lens is not None:
+        off = np.concatenate([[0], np.cumsum(np.asarray(frame_lens, np.int64))]) * ch
+        assert off[-1] == src.size
+        fss = np.ascontiguousarray(np.add.reduceat(src * src, off[:-1]))
+        fpk = np.ascontiguousarray(np.maximum.reduceat(np.abs(src), off[:-1]))
+        return a, meta, nframes, fss, fpk
     nfr = (n + frame_samples - 1) // frame_samples
-    pad = np.zeros(nfr * frame_samples, np.float64); pad[:n] = x
-    fr = pad.reshape(nfr, frame_samples)
+    pad = np.zeros(nfr * frame_samples * ch, np.float64); pad[:src.size] = src
+    fr = pad.reshape(nfr, frame_samples * ch)
     fss = np.ascontiguousarray((fr * fr).sum(axis=1)); fpk = np.ascontiguousarray(np.abs(fr).max(axis=1))
     return a, meta, nframes, fss, fpk
 
 
-def decide(orc, x, sr, base=None, frame_samples=4096, pass1=None):
+def decide(orc, x, sr, base=None, frame_samples=4096, pass1=None, frame_lens=None, raw=None, band_mode=0, band_x=None, want_intervals=False):
     """The reference's Pass-1 decision chain on oracle measurements.  Returns (measurements, effective config, Pass-2 chain string).
     `pass1` = a precomputed oracle_pass1(orc, x, sr, frame_samples) (the fuzz tests measure many files side by side on the host's cores)."""
     l = H.lib()
     base = base or H.default_config()
-    a, meta, nframes, fss, fpk = pass1 if pass1 is not None else oracle_pass1(orc, x, sr, frame_samples)
+    a, meta, nframes, fss, fpk = pass1 if pass1 is not None else oracle_pass1(orc, x, sr, frame_samples, frame_lens, raw)
     n = x.size
+    ch = 1 if raw is None else raw.size // n
     iv = (H.Interval * (n // (sr // 5) + 16))()
-    niv = l.jt_host_build_intervals(C.c_int(sr), C.c_int64(n), C.c_int(frame_samples), C.c_int(1),
-                                    fss.ctypes.data_as(C.POINTER(C.c_double)), fpk.ctypes.data_as(C.POINTER(C.c_double)), C.c_int64(fss.size),
-                                    meta, C.c_int64(nframes), C.c_int(1), iv, C.c_int64(len(iv)))
+    fl = None if frame_lens is None else np.ascontiguousarray(frame_lens, np.int32)
+    niv = l.jt_host_build_intervals_v(C.c_int(sr), C.c_int64(n), C.c_int(frame_samples), None if fl is None else fl.ctypes.data_as(C.POINTER(C.c_int32)), C.c_int(ch),
+                                      fss.ctypes.data_as(C.POINTER(C.c_double)), fpk.ctypes.data_as(C.POINTER(C.c_double)), C.c_int64(fss.size),
+                                      meta, C.c_int64(nframes), C.c_int(1), iv, C.c_int64(len(iv)))
     m = H.Measurements()
     rc = l.jt_host_detect(C.byref(a), iv, C.c_int64(min(niv, len(iv))), C.c_double(n / sr), C.c_double(base.target_i), C.c_int(1), C.byref(m))
     assert rc == 0, rc
     q = lambda v: float("%f" % v)
 
     def band(start_ns, dur_ns, lo, hi):
-        s0 = int(round(start_ns * 1e-9 * sr)); seg = x[s0:s0 + int(round(dur_ns * 1e-9 * sr))]
-        return orc.band_rms_db_fmt(np.ascontiguousarray(seg, np.float32), sr, lo, hi, 0)
+        bx = x if band_x is None else band_x          # (an integer stereo source: the band graphs' own integer down-mix)
+        s0 = int(round(start_ns * 1e-9 * sr)); seg = bx[s0:s0 + int(round(dur_ns * 1e-9 * sr))]
+        return orc.band_rms_db_fmt(np.ascontiguousarray(seg, np.float32), sr, lo, hi, band_mode)
 
     if m.has_speech_profile and m.speech_profile.region.duration_ns > 0:
         rg = m.speech_profile.region
@@ -100,4 +114,6 @@ def decide(orc, x, sr, base=None, frame_samples=4096, pass1=None):
         m.noise_profile.bands_measured = 1 if fin >= 10 else 0
     l.jt_host_finish_measurements(C.byref(m))
     eff, diag = H.adapt(base, m)
+    if want_intervals:
+        return m, eff, H.filter_spec(eff, 2), [iv[i] for i in range(min(niv, len(iv)))]
     return m, eff, H.filter_spec(eff, 2)

@@ -1,0 +1,186 @@
+"""Round 6: the decoder's frame cadence comes from the FILE (missing #3 / next #2)."""
+import ctypes as C
+import struct
+
+import numpy as np
+import pytest
+
+from jivetalking_amd import synth, hostlogic as H, _lib as L
+
+pytestmark = pytest.mark.gpu
+
+
+def _wav(x, rate, ch, kind):
+    """RIFF/WAVE image of interleaved samples in [-1, 1): kind 's16' | 's24' | 'f32'."""
+    if kind == "f32":
+        payload, tag, bits = np.asarray(x, "<f4").tobytes(), 3, 32
+    elif kind == "s16":
+        payload, tag, bits = np.clip(np.rint(np.asarray(x, np.float64) * 32768), -32768, 32767).astype("<i2").tobytes(), 1, 16
+    else:
+        v = np.clip(np.rint(np.asarray(x, np.float64) * 8388608), -8388608, 8388607).astype("<i4")
+        payload, tag, bits = v.view(np.uint8).reshape(-1, 4)[:, :3].tobytes(), 1, 24
+    align = ch * bits // 8
+    fmt = struct.pack("<HHIIHH", tag, ch, rate, rate * align, align, bits)
+    body = b"fmt " + struct.pack("<I", len(fmt)) + fmt + b"data" + struct.pack("<I", len(payload)) + payload
+    return b"RIFF" + struct.pack("<I", 4 + len(body)) + b"WAVE" + body
+
+
+def _reference_interval_starts(frame_lens, sr):
+    """analyser.go:588-600 as written, on frame lengths alone: for every decoder frame t = samples so far / rate as a time.Duration
+    (truncated nanoseconds), the frame is counted into the open interval, THEN the interval is closed (with the open interval's start
+    as its timestamp) if t - start >= 250 ms and the next one starts at t; a trailing interval that saw samples is appended
+    (analyser.go:635-638).  Returns [(timestamp_ns, samples in the interval)]."""
+    out = []; start = 0; processed = 0; acc = 0
+    for nb in frame_lens:
+        t = int(float(processed) / float(sr) * 1e9)
+        processed += int(nb); acc += int(nb)
+        if t - start >= 250_000_000:
+            out.append((start, acc)); start = t; acc = 0
+    if acc > 0:
+        out.append((start, acc))
+    return out
+
+
+CASES = [
+    # name, rate, channels, container / sample format, the cadence the reference's decoder would deliver
+    ("wav_s16_44k1_mono", 44100, 1, "s16", 2048),          # wavdec.c: 4096-byte packets = 2048 s16 samples
+    ("wav_f32_44k1_mono", 44100, 1, "f32", 1024),          # = 1024 f32 samples
+    ("wav_s24_48k_mono", 48000, 1, "s24", 1365),           # 4096 // 3 * 3 = 4095 bytes
+    ("wav_s16_44k1_stereo", 44100, 2, "s16", 1024),        # block_align 4
+    ("flac_1152_44k1", 44100, 1, ("flac", 1152, 2), 1152),
+    ("flac_4608_48k", 48000, 1, ("flac", 4608, 2), 4608),
+    ("flac_variable_48k", 48000, 1, ("flac", 4096, 2 | 32), None),      # frames alternate 4096 / 2048: per-frame lengths
+    ("flac_576_stereo_44k1", 44100, 2, ("flac", 576, 2 | 192), 576),
+]
+
+
+@pytest.mark.parametrize("name,sr,ch,fmt,cadence", CASES, ids=[c[0] for c in CASES])
+def test_decoder_frame_cadence_comes_from_the_file(engine, oracle, name, sr, ch, fmt, cadence):
+    """The reference closes its 250 ms analysis intervals on DECODER-FRAME boundaries (analyser.go:588-600; the frames are whatever
+    Reader.ReadFrame delivers, reader.go:129): the FLAC stream's own block size(s), the WAV demuxer's 4096-byte packets.  With
+    frame_samples = 0 the library takes that cadence from the file jt_load_audio decoded.  Held here, per file:
+      * jt_audio_meta / jt_input_frame_layout report the cadence the rule gives;
+      * the interval series (jt_host_last_intervals) has exactly the reference rule's count and timestamps, and every interval's RMS
+        level is the RMS of exactly the samples the rule puts in it (1e-9 dB);
+      * the decision chain (VAD, elections, band graphs in the source's format, AdaptConfig, chain string) equals the CPU oracle's
+        with the same framing: same elections on the same intervals, same switches, printed parameters within 2e-3;
+      * and a 4096 cadence (what the library assumed for every file until round 5) gives DIFFERENT interval boundaries for this file --
+        the test would not notice a regression to the constant otherwise."""
+    import oracle_pass1 as P
+    from test_gpu_fuzz import _parse, _close
+    secs = 42.0
+    a = np.asarray(synth.speech_like(secs, sr, seed=661), np.float64)
+    b = np.roll(a, 23) * 0.7
+    if isinstance(fmt, tuple):
+        _, bs, mode = fmt
+        q = 32768.0
+        pcm = np.clip(np.rint((a if ch == 1 else np.stack([a, b], axis=1)) * q), -32768, 32767).astype(np.int32)
+        data = oracle.flac_encode(pcm, sr, 16, bs, mode, 8)
+        raw = (pcm.astype(np.float32) / np.float32(q)).reshape(-1)
+        band_mode = 1
+    else:
+        inter = a if ch == 1 else np.stack([a, b], axis=1).reshape(-1)
+        data = _wav(inter, sr, ch, fmt)
+        if fmt == "f32":
+            raw, band_mode = np.asarray(inter, np.float32), 0
+        elif fmt == "s16":
+            raw, band_mode = (np.clip(np.rint(inter * 32768), -32768, 32767) / 32768.0).astype(np.float32), 1
+        else:
+            raw, band_mode = (np.clip(np.rint(inter * 8388608), -8388608, 8388607) / 8388608.0).astype(np.float32), 2
+    meta = engine.load_audio(data)
+    n = meta["frames"]
+    fs, var, nfr, lens = engine.input_frame_layout()
+    if cadence is not None:
+        assert (meta["decoder_frame_samples"], meta["decoder_frames_variable"]) == (cadence, 0) and (fs, var) == (cadence, False)
+        assert nfr == meta["decoder_frames"] == -(-n // cadence)
+        frame_lens = [cadence] * (n // cadence) + ([n % cadence] if n % cadence else [])
+    else:
+        assert meta["decoder_frames_variable"] == 1 and var and lens is not None and int(lens.sum()) == n
+        assert set(lens[:-1].tolist()) == {4096, 2048} and meta["decoder_frame_samples"] == 4096 and nfr == lens.size == meta["decoder_frames"]
+        frame_lens = lens.tolist()
+    g = H.process_audio(engine, frame_samples=0, analyse_only=True)
+    iv = (H.Interval * 4096)()
+    niv = H.lib().jt_host_last_intervals(engine.h, iv, C.c_int64(4096))
+    want = _reference_interval_starts(frame_lens, sr)
+    assert niv == len(want)
+    assert [iv[i].timestamp_ns for i in range(niv)] == [w[0] for w in want]
+    mono = oracle.downmix_stereo(raw, 0) if ch == 2 else raw
+    pos = 0
+    r64 = raw.astype(np.float64)
+    for i, (_, cnt) in enumerate(want):
+        seg = r64[pos * ch:(pos + cnt) * ch]; pos += cnt
+        rms = float(np.sqrt(np.mean(seg * seg)))
+        ref_db = -120.0 if rms < 1e-5 else 20 * np.log10(rms)
+        assert abs(iv[i].rms_level - ref_db) < 1e-9, (i, iv[i].rms_level, ref_db)
+    assert pos == n
+    # a 4096 cadence closes other intervals for this file (except where the file's frames are 2048 long: the frame that trips the 250 ms
+    # test then starts on a multiple of 4096 at both rates -- 6 x 2048 = 3 x 4096 -- and the two cadences give the same series)
+    w4096 = _reference_interval_starts([4096] * (n // 4096) + ([n % 4096] if n % 4096 else []), sr)
+    assert ([w[0] for w in w4096] != [w[0] for w in want]) == (cadence != 2048)
+    # the decision chain against the oracle's with the same framing
+    kw = dict(frame_lens=np.asarray(frame_lens, np.int32)) if cadence is None else dict(frame_samples=cadence)
+    band_x = oracle.downmix_stereo(raw, band_mode) if ch == 2 and band_mode else None       # integer sources: the band graphs' integer matrix
+    m, eff, spec = P.decide(oracle, mono, sr, raw=raw if ch == 2 else None, band_mode=band_mode, band_x=band_x, **kw)
+    gm = g.input
+    assert (gm.has_speech_profile, gm.has_noise_profile, gm.voice_activated, gm.floor_source, gm.n_candidates, gm.n_speech_regions) == \
+           (m.has_speech_profile, m.has_noise_profile, m.voice_activated, m.floor_source, m.n_candidates, m.n_speech_regions)
+    if m.has_speech_profile:
+        assert (gm.speech_profile.region.start_ns, gm.speech_profile.region.duration_ns) == (m.speech_profile.region.start_ns, m.speech_profile.region.duration_ns)
+    if m.has_noise_profile:
+        assert (gm.noise_profile.start_ns, gm.noise_profile.duration_ns) == (m.noise_profile.start_ns, m.noise_profile.duration_ns)
+    cg, co = _parse(H.filter_spec(g.effective, 2)), _parse(spec)
+    assert [f[0] for f in cg] == [f[0] for f in co]
+    for (fname, pa), (_, pb) in zip(cg, co):
+        assert pa.keys() == pb.keys(), fname
+        for k in pa:
+            if fname == "afftdn" and k == "bn":
+                va, vb = [float(v) for v in pa[k].split("|")], [float(v) for v in pb[k].split("|")]
+                assert len(va) == len(vb) and max(abs(p - q) for p, q in zip(va, vb)) <= 0.1001, (pa[k], pb[k])
+            else:
+                assert _close(pa[k], pb[k]), (fname, k, pa[k], pb[k])
+
+
+def test_frame_samples_zero_after_an_upload_is_4096_and_an_override_wins(engine):
+    """PCM that was uploaded has no file behind it: frame_samples = 0 means 4096 then (the reference's FLAC encoder's frame, what
+    every earlier round assumed), and a positive frame_samples always overrides the file's cadence (a caller that decodes the file
+    itself knows its frames)."""
+    sr = 44100
+    x = synth.speech_like(20.0, sr, seed=662)
+    engine.upload_pcm(x, sr, 1)
+    assert engine.input_frame_layout()[:3] == (4096, False, -(-x.size // 4096))
+    H.process_audio(engine, frame_samples=0, analyse_only=True)
+    a = H.intervals_jsonl(engine)
+    H.process_audio(engine, frame_samples=4096, analyse_only=True)
+    assert H.intervals_jsonl(engine) == a
+    engine.load_audio(_wav(x, sr, 1, "f32"))
+    H.process_audio(engine, frame_samples=0, analyse_only=True)
+    b = H.intervals_jsonl(engine)
+    assert b != a
+    H.process_audio(engine, frame_samples=4096, analyse_only=True)
+    assert H.intervals_jsonl(engine) == a
+    with pytest.raises(L.JtError) as ei:
+        H.process_audio(engine, frame_samples=-1, analyse_only=True)
+    assert ei.value.code == L.JT_E_INVAL
+
+
+def test_progress_ticks_follow_the_files_cadence(engine):
+    """The reference ticks every 100th decoder frame (analyser.go:602-618, processor.go:320-335) with Progress = frames / (duration x
+    rate / 4096): a 1024-sample cadence gives four times the Pass-1 ticks of a 4096 one, and their progress values climb four times
+    slower per tick (capped at 0.95)."""
+    sr = 48000
+    x = synth.speech_like(40.0, sr, seed=663)
+    counts = {}
+    for kind, want in (("f32", 1024), ("s16", 2048)):
+        engine.load_audio(_wav(x, sr, 1, kind))
+        ticks = []
+        H.process_audio_with_progress(engine, lambda u: ticks.append((u.pass_, (u.pass_name or b"").decode(), u.progress)), frame_samples=0, ticks=True)
+        p1 = [t for t in ticks if t[0] == 1 and t[1] == "Analysing" and 0.0 < t[2] < 0.95]
+        nfr = -(-x.size // want)
+        est = x.size / 4096.0
+        counts[kind] = len([t for t in ticks if t[0] == 1 and t[1] == "Analysing"])
+        # every 100th frame: fc = 100, 200, ... < nfr with progress fc / est * 0.95 (those below the cap)
+        exp = [min(0.95, fc / est * 0.95) for fc in range(100, nfr, 100)]
+        exp = [e for e in exp if e < 0.95]
+        got = sorted(t[2] for t in p1)
+        assert len(got) == len(exp) and all(abs(a - b) < 1e-12 for a, b in zip(got, exp)), (kind, len(got), len(exp), got[:5], exp[:5])
+    assert counts["f32"] > counts["s16"]
