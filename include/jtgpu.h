@@ -96,12 +96,22 @@ int jt_set_option(jt_ctx *h, const char *key, const char *value);
 int jt_build_flags(void);                                   /* bit 0: A/B build (JT_AB) */
 
 /* ---- input: replaces audio.Reader.ReadFrame feeding abuffer (reader.go:129, frame_processor.go:131-146) ---- */
-/* interleaved f32 PCM in host memory; copied to HBM. channels 1 or 2.  2 => the aformat=channel_layouts=mono down-mix
+/* interleaved f32 PCM in host memory; copied to HBM. channels 1 .. 8.  2 => the aformat=channel_layouts=mono down-mix
  * (filters.go:607-615) = libswresample's rematrix in the aresample libavfilter auto-inserts: Pass 1 and Pass 2 both hold a
  * float-only filter (aspectralstats / anlmdn), so that converter's internal and output formats are FLTP whatever the decoder
  * produced, auto_matrix does not normalise (maxval = INT_MAX), and mono = fl(fl(c*L) + fl(c*R)), c = (float)M_SQRT1_2
  * (DESIGN.md section 3 has the derivation; a stereo file with L == R therefore comes out 3.01 dB hotter, as with FFmpeg). */
 int jt_upload_pcm(jt_ctx *h, const float *interleaved, int64_t frames, int sample_rate, int channels);
+/* The same with the source's channel layout (libavutil / WAVEFORMATEXTENSIBLE bit order: FL 0x1, FR 0x2, FC 0x4, LFE 0x8, BL 0x10,
+ * BR 0x20, FLC 0x40, FRC 0x80, BC 0x100, SL 0x200, SR 0x400; channels interleaved in ascending bit order).  channel_mask = 0: the
+ * default layout of the channel count, which is what swr_init gives a source without one (av_channel_layout_default: mono, stereo,
+ * 2.1, 4.0, 5.0, 5.1, 6.1, 7.1) -- jt_upload_pcm.  The mono down-mix is libswresample's default rematrix row for a FRONT_CENTER
+ * output (swr_build_matrix2, center_mix_level = surround_mix_level = M_SQRT1_2, lfe_mix_level = 0):
+ *   FC 1.0;  FL, FR, FLC, FRC 1/sqrt 2 each;  BL, BR, BC, SL, SR 0.5 each;  LFE 0 -- unnormalised in the float graphs of Pass 1 / 2
+ * (as the stereo case above), divided by the sum of the coefficients in the band graphs of an integer source (jt_set_source_format);
+ * products and sums in float, channel order (swri_rematrix's generic loop; two non-zero inputs: mix_2_1).
+ * JT_E_UNSUPPORTED: channels beyond SIDE_RIGHT, or a mask whose bit count is not `channels`. */
+int jt_upload_pcm_layout(jt_ctx *h, const float *interleaved, int64_t frames, int sample_rate, int channels, uint64_t channel_mask);
 /* The decoder's native sample format of the PCM just uploaded / attached (they reset it to float): integer sources were scaled
  * by 2^(1-bits) to f32.  It matters in one place: the band-RMS graphs (analyser_bands.go:33) contain no float-only filter, so
  * libavfilter runs their biquads in the source's own width -- s16p (float state, output truncated and clipped per stage) for
@@ -277,8 +287,9 @@ int jt_pass4(jt_ctx *h, const jt_limiter_plan *lim, const jt_loudnorm_apply *ap,
  * again over the file.  `file` is the whole file image in host memory: FLAC (RFC 9639: any block size, 4..24 bits, 1..8
  * channels, all predictor / residual / stereo modes; an ID3v2 tag in front is skipped) is decoded on the GPU; RIFF/WAVE PCM
  * (u8, s16, s24, s32, f32, f64, WAVE_FORMAT_EXTENSIBLE) is unpacked on the GPU.  Afterwards the handle is in the state
- * jt_upload_pcm() leaves it in — mono or stereo only, surround files are refused with JT_E_UNSUPPORTED like jt_upload_pcm does
- * (jt_op_decode_audio decodes any layout) — (interleaved f32 at the file's rate; integer PCM scaled by 2^(1-bits) exactly as
+ * jt_upload_pcm_layout() leaves it in — up to eight channels in the file's layout (FLAC: libavcodec's flac_channel_layouts for the
+ * channel count; WAVE_FORMAT_EXTENSIBLE: dwChannelMask; plain WAV: the default layout of the channel count), layouts with channels
+ * beyond SIDE_RIGHT are refused with JT_E_UNSUPPORTED (jt_op_decode_audio decodes any layout) — (interleaved f32 at the file's rate; integer PCM scaled by 2^(1-bits) exactly as
  * libswresample's s16/s32 -> flt conversion does).  Errors: JT_E_INVAL for a damaged or truncated stream (frame CRC-16 /
  * header CRC-8 / sample count), JT_E_UNSUPPORTED for other containers or 32-bit FLAC. */
 typedef struct {
@@ -299,6 +310,7 @@ typedef struct {
      *         sources, which are absent here: DESIGN section 3, assumption 12). */
     int decoder_frame_samples, decoder_frames_variable;
     int64_t decoder_frames;      /* how many frames ReadFrame would deliver */
+    uint64_t channel_mask;       /* the layout the down-mix used (libavutil / WAVEFORMATEXTENSIBLE bit order): the file's, or the default of its channel count */
 } jt_audio_meta;
 int jt_load_audio(jt_ctx *h, const uint8_t *file, int64_t len, jt_audio_meta *meta);
 /* The cadence of the handle's current input (set by jt_load_audio; 4096 and constant after jt_upload_pcm / jt_attach_device_pcm):

@@ -116,12 +116,13 @@ class AudioMeta(C.Structure):
     _fields_ = [("format", C.c_int), ("sample_rate", C.c_int), ("channels", C.c_int), ("bits_per_sample", C.c_int),
                 ("is_float", C.c_int), ("frames", C.c_int64), ("duration_s", C.c_double), ("flac_frames", C.c_int64),
                 ("flac_candidates", C.c_int), ("gpu_ms", C.c_double), ("total_ms", C.c_double),
-                ("decoder_frame_samples", C.c_int), ("decoder_frames_variable", C.c_int), ("decoder_frames", C.c_int64)]
+                ("decoder_frame_samples", C.c_int), ("decoder_frames_variable", C.c_int), ("decoder_frames", C.c_int64),
+                ("channel_mask", C.c_uint64)]
 
 # every symbol include/jtgpu.h declares
 SYMBOLS = [
     "jt_device_count", "jt_open", "jt_open_ex", "jt_close", "jt_last_error", "jt_version", "jt_set_option", "jt_build_flags", "jt_cancel", "jt_reset_cancel", "jt_begin_job", "jt_end_job", "jt_pass3_plan_hook", "jt_set_source_format",
-    "jt_upload_pcm", "jt_attach_device_pcm", "jt_upload_s16", "jt_load_audio", "jt_op_decode_audio", "jt_input_frame_layout",
+    "jt_upload_pcm", "jt_upload_pcm_layout", "jt_attach_device_pcm", "jt_upload_s16", "jt_load_audio", "jt_op_decode_audio", "jt_input_frame_layout",
     "jt_pass1", "jt_band_rms", "jt_pass2", "jt_pass2_prefetch", "jt_pass2_prefetch_after_pass1", "jt_region_measure", "jt_region_measure_pair", "jt_region_prefetch", "jt_pass3", "jt_pass4",
     "jt_output_len", "jt_download_s16", "jt_output_frame_levels", "jt_flac_encode", "jt_op_flac_encode_s16", "jt_get_timers",
     "jt_op_biquad_f32", "jt_op_anlmdn_f32", "jt_op_afftdn_f32", "jt_op_afftdn_tn_f32", "jt_op_dynamics", "jt_op_alimiter_f64", "jt_op_adeclick_f64",

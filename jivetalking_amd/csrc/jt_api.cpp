@@ -256,22 +256,24 @@ void jt_spec_pass2_cancel(jt_ctx *h)
     if (h->spec_p2.pending) { h->spec_p2.pending = false; JT_HIP(jt_stream_sync(h, h->spec_p2.stream)); }
 }
 
-void jt_set_input_common(jt_ctx *h, int64_t frames, int sr, int ch)
+void jt_set_input_common(jt_ctx *h, int64_t frames, int sr, int ch, unsigned long long mask)
 {
     JT_REQUIRE(frames > 0, JT_E_INVAL, "empty input");
     JT_REQUIRE(sr >= 8000 && sr <= 384000, JT_E_INVAL, "unsupported sample rate");
     JT_REQUIRE(ch >= 1 && ch <= 8, JT_E_INVAL, "unsupported channel count");
-    // aformat=channel_layouts=mono goes through libswresample's layout-specific rematrix; only the stereo matrix is restated
-    // here (k_downmix), so surround layouts are refused instead of being averaged with the wrong weights
-    JT_REQUIRE(ch <= 2, JT_E_UNSUPPORTED, "only mono and stereo inputs are down-mixed on the device (surround layouts need swresample's matrix)");
-    h->n = frames; h->sr = sr; h->channels = ch;
+    // aformat=channel_layouts=mono (filters.go:607-615) goes through libswresample's layout-specific rematrix: restated for every
+    // layout of FL FR FC LFE BL BR FLC FRC BC SL SR (k_lane.hip: jt_downmix_row); anything else is refused, not averaged with
+    // the wrong weights
+    DownmixRow row;
+    JT_REQUIRE(jt_downmix_row(ch, mask, 0, &row), JT_E_UNSUPPORTED, "this channel layout is not down-mixed on the device (channels beyond SIDE_RIGHT, or a mask that does not match the channel count)");
+    h->n = frames; h->sr = sr; h->channels = ch; h->ch_mask = mask;
     h->dec_frame_samples = 4096; h->dec_frames = (frames + 4095) / 4096; h->dec_frame_lens.clear();      // (jt_load_audio overrides: the file's own)
     h->m_p2 = h->m_p4 = 0;
     if (!h->hold_cancel) h->cancelled.store(0);           // a new job: jt_cancel() is sticky from here until the next input / jt_reset_cancel
-    if (ch == 1) h->in_mono = h->in_raw;
+    if (ch == 1 && row.k == 1 && row.cf[0] == 1.0f) h->in_mono = h->in_raw;      // (a lone FRONT_CENTER: the identity row)
     else {
         h->mono.ensure((size_t)frames);
-        launch_downmix(h->in_raw, h->mono.p, frames, ch, 0, h->stream);
+        launch_downmix(h->in_raw, h->mono.p, frames, ch, 0, row, h->stream);
         h->in_mono = h->mono.p;
     }
 }
@@ -288,17 +290,21 @@ extern "C" int jt_input_frame_layout(jt_ctx *h, int *frame_samples, int *variabl
     JT_API_END(h)
 }
 
-extern "C" int jt_upload_pcm(jt_ctx *h, const float *pcm, int64_t frames, int sr, int ch)
+extern "C" int jt_upload_pcm_layout(jt_ctx *h, const float *pcm, int64_t frames, int sr, int ch, uint64_t channel_mask)
 {
     JT_API_BEGIN(h)
-    JT_REQUIRE(pcm && frames > 0 && ch >= 1, JT_E_INVAL, "bad pcm arguments");
+    JT_REQUIRE(pcm && frames > 0 && ch >= 1 && ch <= 8, JT_E_INVAL, "bad pcm arguments");
     h->in_owned.ensure((size_t)frames * ch);
     JT_HIP(hipMemcpyAsync(h->in_owned.p, pcm, sizeof(float) * (size_t)frames * ch, hipMemcpyHostToDevice, h->stream));
     h->in_raw = h->in_owned.p;
     h->src_fmt = 0;
-    jt_set_input_common(h, frames, sr, ch);
+    jt_set_input_common(h, frames, sr, ch, channel_mask);
     JT_HIP(jt_stream_sync(h, h->stream));
     JT_API_END(h)
+}
+extern "C" int jt_upload_pcm(jt_ctx *h, const float *pcm, int64_t frames, int sr, int ch)
+{
+    return jt_upload_pcm_layout(h, pcm, frames, sr, ch, 0);
 }
 
 extern "C" int jt_attach_device_pcm(jt_ctx *h, const void *dev_ptr, int64_t frames, int sr, int ch)
@@ -786,9 +792,11 @@ extern "C" int jt_band_rms(jt_ctx *h, double start_s, double dur_s, const double
         // s16p / s32p biquads, and for a stereo source a down-mix of its own (integer matrix, not Pass 1's 1/sqrt2).
         const int mode = h->src_fmt;
         const float *src = h->in_mono + s0;
-        if (mode != 0 && h->channels == 2) {
+        if (mode != 0 && (h->channels >= 2 || h->in_mono != h->in_raw)) {
+            DownmixRow row;
+            JT_REQUIRE(jt_downmix_row(h->channels, h->ch_mask, mode, &row), JT_E_UNSUPPORTED, "band_rms: channel layout not covered");
             h->band_mono.ensure((size_t)len);
-            launch_downmix(h->in_raw + s0 * 2, h->band_mono.p, len, 2, mode, h->stream);
+            launch_downmix(h->in_raw + s0 * h->channels, h->band_mono.p, len, h->channels, mode, row, h->stream);
             src = h->band_mono.p;
         }
         h->d_scr1.ensure(16);

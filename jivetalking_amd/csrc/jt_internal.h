@@ -153,7 +153,13 @@ void launch_frame_stats(const float *in, int64_t n_total /*frames*channels*/, in
 void launch_frame_sumsq_s16(const int16_t *in, int64_t n, int spf, double *sumsq, int64_t nframes, hipStream_t s);
 // frames of different lengths: off[f] .. off[f + 1] = frame f's range in samples per channel (nframes + 1 entries on the device)
 void launch_frame_stats_var(const float *in, int channels, const int64_t *off, double *sumsq, double *peak, int64_t nframes, hipStream_t s);
-void launch_downmix(const float *in, float *out, int64_t frames, int channels, int mode, hipStream_t s);
+// aformat=channel_layouts=mono: libswresample's default rematrix row for one FRONT_CENTER output (k_lane.hip, k_downmix).  k = inputs with
+// a non-zero coefficient (native channel order), nz[] their channel indices, cf[] the float coefficients, ci[] the S16P integer ones
+struct DownmixRow { int k; int stereo; int nz[8]; float cf[8]; int ci[8]; };
+// false: a layout the restatement does not cover (channels beyond SIDE_RIGHT, a mask that does not match the channel count)
+bool jt_downmix_row(int channels, unsigned long long mask, int mode, DownmixRow *row);
+unsigned long long jt_default_layout(int channels);          // av_channel_layout_default: what swr_init gives a source without a layout
+void launch_downmix(const float *in, float *out, int64_t frames, int channels, int mode, const DownmixRow &row, hipStream_t s);
 void launch_s16_to_f32(const int16_t *in, float *out, int64_t n, hipStream_t s);
 void launch_s16_to_f32_pair(const int16_t *in0, int64_t n0, const int16_t *in1, int64_t n1, float *out0, float *out1, hipStream_t s);   // two ranges, one launch
 void launch_s16_to_f64(const int16_t *in, double *out, int64_t n, double gain, int gain_in_float, hipStream_t s);
@@ -402,6 +408,7 @@ struct jt_ctx {
     // input
     int sr = 0, channels = 0; int64_t n = 0;
     int src_fmt = 0;                    // the decoder's native sample format: 0 flt/dbl, 1 s16 (also u8), 2 s32 (24/32-bit integer)
+    unsigned long long ch_mask = 0;     // the source's channel layout (WAVEFORMATEXTENSIBLE / libavutil bit order); 0 = the default layout of its channel count
     // the decoder's frame cadence of the current input (what frame_samples = 0 means; jtgpu.h: jt_input_frame_layout): jt_load_audio
     // sets it from the file, every other way of handing over PCM leaves 4096 / constant.  dec_frame_lens is non-empty only when the
     // frames differ in length (a variable-blocksize FLAC); d_frame_off = their start offsets (n + 1 entries) for k_frame_stats_var.
@@ -541,4 +548,4 @@ inline void jt_drain(jt_ctx *h)
 #define JT_API_END(h) } catch (const JtError &e) { jt_drain(h); (h)->err = e.msg; return e.code; } \
     catch (const std::exception &e) { jt_drain(h); (h)->err = e.what(); return JT_E_HIP; } return JT_OK;
 // input state shared by jt_upload_pcm / jt_attach_device_pcm / jt_load_audio: h->in_raw is set, derive the mono signal
-void jt_set_input_common(jt_ctx *h, int64_t frames, int sr, int ch);
+void jt_set_input_common(jt_ctx *h, int64_t frames, int sr, int ch, unsigned long long mask = 0);

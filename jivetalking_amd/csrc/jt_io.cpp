@@ -143,7 +143,8 @@ extern "C" int jt_op_flac_encode_s16(jt_ctx *h, const int16_t *pcm, int64_t n, i
 namespace {
 struct AudioDecoded { int64_t frames = 0; int channels = 0, rate = 0, bits = 0, is_float = 0, format = 0; int64_t flac_frames = 0; int cands = 0;
                       // the decoder's frame cadence (jtgpu.h: jt_audio_meta): constant length, or per-frame lengths when they differ
-                      int dec_frame_samples = 4096; int64_t dec_frames = 0; std::vector<int32_t> frame_lens; };
+                      int dec_frame_samples = 4096; int64_t dec_frames = 0; std::vector<int32_t> frame_lens;
+                      unsigned long long ch_mask = 0; };      // 0: no layout in the file (swr_init then takes the default of the channel count)
 
 uint32_t rd_le32(const uint8_t *p) { return (uint32_t)p[0] | (uint32_t)p[1] << 8 | (uint32_t)p[2] << 16 | (uint32_t)p[3] << 24; }
 uint32_t rd_le16(const uint8_t *p) { return (uint32_t)p[0] | (uint32_t)p[1] << 8; }
@@ -306,6 +307,11 @@ void decode_flac(jt_ctx *h, const uint8_t *file, int64_t len, int64_t start, boo
     JT_REQUIRE(nerr == 0, JT_E_INVAL, "flac: subframe decode error");
     out->frames = total; out->channels = st.channels; out->rate = st.sample_rate; out->bits = st.bps; out->is_float = 0; out->format = 1;
     out->flac_frames = (int64_t)frames.size(); out->cands = ncand;
+    {   // libavcodec/flac.c flac_channel_layouts[]: mono, stereo, 3.0, quad, 5.0 (side), 5.1 (side), 6.1, 7.1 -- the stream's channel
+        // order is those layouts' native order (a WAVEFORMATEXTENSIBLE_CHANNEL_MASK comment that overrides it is not read)
+        static const unsigned long long lay[9] = {0, 0x4, 0x3, 0x7, 0x33, 0x607, 0x60F, 0x70F, 0x63F};
+        out->ch_mask = lay[st.channels];
+    }
     // one AVFrame per FLAC frame (libavcodec/flacdec.c): constant when every frame but the last has the first one's length
     out->dec_frame_samples = frames[0].blocksize; out->dec_frames = (int64_t)frames.size();
     bool constant = true; int longest = 0;
@@ -332,7 +338,7 @@ void decode_wav(jt_ctx *h, const uint8_t *file, int64_t len, bool want_i32, bool
         if (!memcmp(file + pos, "fmt ", 4)) {
             JT_REQUIRE(sz >= 16 && pos + 8 + 16 <= len, JT_E_INVAL, "wav: short fmt chunk");
             tag = (int)rd_le16(body); ch = (int)rd_le16(body + 2); rate = (int)rd_le32(body + 4); align = (int)rd_le16(body + 12); bits = (int)rd_le16(body + 14);
-            if (tag == 0xfffe) { JT_REQUIRE(sz >= 40 && pos + 8 + 40 <= len, JT_E_INVAL, "wav: short extensible fmt chunk"); tag = (int)rd_le16(body + 24); }
+            if (tag == 0xfffe) { JT_REQUIRE(sz >= 40 && pos + 8 + 40 <= len, JT_E_INVAL, "wav: short extensible fmt chunk"); tag = (int)rd_le16(body + 24); out->ch_mask = rd_le32(body + 20); }
             have_fmt = true;
         } else if (!memcmp(file + pos, "data", 4)) {
             data_off = pos + 8;
@@ -394,6 +400,7 @@ void decode_audio(jt_ctx *h, const uint8_t *file, int64_t len, bool want_i32, bo
         meta->format = out->format; meta->sample_rate = out->rate; meta->channels = out->channels; meta->bits_per_sample = out->bits;
         meta->is_float = out->is_float; meta->frames = out->frames; meta->duration_s = (double)out->frames / (double)out->rate;
         meta->flac_frames = out->flac_frames; meta->flac_candidates = out->cands; meta->gpu_ms = gpu_ms; meta->total_ms = flac_now_ms() - t0;
+        meta->channel_mask = out->ch_mask ? out->ch_mask : jt_default_layout(out->channels);
         meta->decoder_frame_samples = out->dec_frame_samples; meta->decoder_frames_variable = out->frame_lens.empty() ? 0 : 1; meta->decoder_frames = out->dec_frames;
     }
 }
@@ -408,7 +415,7 @@ extern "C" int jt_load_audio(jt_ctx *h, const uint8_t *file, int64_t len, jt_aud
     decode_audio(h, file, len, false, true, &d, meta);
     h->in_raw = h->in_owned.p;
     h->src_fmt = d.is_float ? 0 : (d.bits <= 16 ? 1 : 2);       // what libavcodec would hand to abuffer: flt/dbl, (u8/)s16, s32
-    jt_set_input_common(h, d.frames, d.rate, d.channels);
+    jt_set_input_common(h, d.frames, d.rate, d.channels, d.ch_mask);
     // the file's own frame cadence: what frame_samples = 0 means from here on (jt_pass1, jt_process_audio, ...)
     h->dec_frame_samples = d.dec_frame_samples; h->dec_frames = d.dec_frames; h->dec_frame_lens = std::move(d.frame_lens);
     if (!h->dec_frame_lens.empty()) {

@@ -196,13 +196,13 @@ __device__ inline void rows_commit(TL (*tile)[TW + 1], const TIn (&v)[LANES], in
 //           float coefficients, mix_2_1 = fl(fl(c*L) + fl(c*R)), c = (float)M_SQRT1_2
 //   mode 1  the band graphs of a 16-bit source (output s16p, internal S16P): (L*16384 + R*16384 + 16384) >> 15 on the integers
 //   mode 2  the band graphs of a 24/32-bit source (output s32p, internal FLTP): coefficients 0.5, then flt -> s32 (llrintf, clip)
-__global__ void k_downmix(const float *__restrict__ in, float *__restrict__ out, int64_t frames, int channels, int mode)
+__global__ void k_downmix(const float *__restrict__ in, float *__restrict__ out, int64_t frames, int channels, int mode, DownmixRow row)
 {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     int64_t stride = (int64_t)gridDim.x * blockDim.x;
     const float c = 0.70710678118654752440f;
     for (; i < frames; i += stride) {
-        if (channels == 2) {
+        if (row.stereo) {
             float2 v = reinterpret_cast<const float2 *>(in)[i];
             if (mode == 0) out[i] = __fadd_rn(__fmul_rn(c, v.x), __fmul_rn(c, v.y));
             else if (mode == 1) {
@@ -214,13 +214,82 @@ __global__ void k_downmix(const float *__restrict__ in, float *__restrict__ out,
                 q = q > 2147483647.0 ? 2147483647.0 : (q < -2147483648.0 ? -2147483648.0 : q);
                 out[i] = (float)(q * (1.0 / 2147483648.0));
             }
-        } else out[i] = in[i * channels];            // not reached: jt_set_input_common refuses layouts above stereo
+            continue;
+        }
+        // any other layout (swri_rematrix for one output channel): k = 1 copy / mix_1_1, k = 2 mix_2_1, k >= 3 the generic loop
+        // v = 0; v += in_j * c_j in channel order, float products and float sums (S16P: integer products, (v + 16384) >> 15)
+        const float *x = in + i * channels;
+        if (mode == 1) {
+            int v = 0;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) if (j < row.k) v += (int)rintf(x[row.nz[j]] * 32768.0f) * row.ci[j];
+            out[i] = (float)(short)((v + 16384) >> 15) * (1.0f / 32768.0f);
+            continue;
+        }
+        float v;
+        if (row.k == 1) v = row.cf[0] == 1.0f ? x[row.nz[0]] : __fmul_rn(x[row.nz[0]], row.cf[0]);
+        else if (row.k == 2) v = __fadd_rn(__fmul_rn(x[row.nz[0]], row.cf[0]), __fmul_rn(x[row.nz[1]], row.cf[1]));
+        else {
+            v = 0.0f;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) if (j < row.k) v = __fadd_rn(v, __fmul_rn(x[row.nz[j]], row.cf[j]));
+        }
+        if (mode == 0) { out[i] = v; continue; }
+        double q = rint((double)v * 2147483648.0);
+        q = q > 2147483647.0 ? 2147483647.0 : (q < -2147483648.0 ? -2147483648.0 : q);
+        out[i] = (float)(q * (1.0 / 2147483648.0));
     }
 }
-void launch_downmix(const float *in, float *out, int64_t frames, int channels, int mode, hipStream_t s)
+unsigned long long jt_default_layout(int channels)
+{
+    // libavutil/channel_layout.c, channel_layout_map[]: the first entry with that many channels -- mono, stereo, 2.1, 4.0, 5.0 (back),
+    // 5.1 (back), 6.1, 7.1
+    static const unsigned long long def[9] = {0, 0x4, 0x3, 0xB, 0x107, 0x37, 0x3F, 0x70F, 0x63F};
+    return channels >= 1 && channels <= 8 ? def[channels] : 0;
+}
+// libswresample/rematrix.c swr_build_matrix2, defaults (center_mix_level = surround_mix_level = M_SQRT1_2, lfe_mix_level = 0), one
+// FRONT_CENTER output: FL / FR M_SQRT1_2 each; FC 1.0 (center_mix_level * sqrt(2) when FL / FR are there); BC, BL / BR, SL / SR
+// surround_mix_level * M_SQRT1_2 each; FLC / FRC M_SQRT1_2 each; LFE 0.  auto_matrix divides the row by the sum of its |coefficients|
+// when that exceeds maxval = 1.0 -- only when the converter's output or internal format is an integer one (modes 1, 2: the band graphs
+// of integer sources); float graphs keep the raw coefficients (mode 0).
+bool jt_downmix_row(int channels, unsigned long long mask, int mode, DownmixRow *row)
+{
+    if (!mask) mask = jt_default_layout(channels);
+    if (!mask || (mask >> 11) || channels < 1 || channels > 8) return false;
+    int nb = 0; for (int b = 0; b < 11; ++b) nb += (int)((mask >> b) & 1);
+    if (nb != channels) return false;
+    const bool stereo = (mask & 3) != 0;
+    double coef[8]; double sum = 0.0; int c = 0;
+    for (int b = 0; b < 11; ++b) {
+        if (!((mask >> b) & 1)) continue;
+        double v;
+        switch (b) {
+        case 0: case 1: case 6: case 7: v = M_SQRT1_2; break;
+        case 2: v = stereo ? M_SQRT1_2 * std::sqrt(2.0) : 1.0; break;
+        case 3: v = 0.0; break;
+        default: v = M_SQRT1_2 * M_SQRT1_2; break;
+        }
+        coef[c++] = v; sum += std::fabs(v);
+    }
+    if (mode != 0 && sum > 1.0) for (int i = 0; i < channels; ++i) coef[i] /= sum;
+    std::memset(row, 0, sizeof *row);
+    row->stereo = mask == 0x3 ? 1 : 0;                   // FL + FR: the two-channel fast path (same statements, constants folded)
+    for (int i = 0; i < channels; ++i) if (coef[i] != 0.0) row->nz[row->k++] = i;
+    for (int j = 0; j < row->k; ++j) row->cf[j] = (float)coef[row->nz[j]];
+    if (row->k == 2) {
+        // mix_2_1's native_matrix (swri_rematrix_init): lrintf's remainder is carried from one input of the row to the next
+        double rem = 0.0;
+        for (int i = 0; i < channels; ++i) {
+            const double target = coef[i] * 32768 + rem; const int q = (int)lrintf((float)target); rem += target - q;
+            for (int j = 0; j < row->k; ++j) if (row->nz[j] == i) row->ci[j] = q;
+        }
+    } else for (int j = 0; j < row->k; ++j) row->ci[j] = (int)lrintf((float)(coef[row->nz[j]] * 32768));
+    return true;
+}
+void launch_downmix(const float *in, float *out, int64_t frames, int channels, int mode, const DownmixRow &row, hipStream_t s)
 {
     int grid = (int)std::min<int64_t>((frames + 255) / 256, 4096);
-    hipLaunchKernelGGL(k_downmix, dim3(grid), dim3(256), 0, s, in, out, frames, channels, mode);
+    hipLaunchKernelGGL(k_downmix, dim3(grid), dim3(256), 0, s, in, out, frames, channels, mode, row);
 }
 
 __global__ void k_s16_to_f32(const int16_t *__restrict__ in, float *__restrict__ out, int64_t n)

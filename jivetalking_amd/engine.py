@@ -84,11 +84,12 @@ class Engine:
             raise L.JtError(rc, self.lib.jt_last_error(self.h).decode())
 
     # ---- input
-    def upload_pcm(self, pcm, sample_rate, channels=1):
+    def upload_pcm(self, pcm, sample_rate, channels=1, channel_mask=0):
+        """jt_upload_pcm_layout: channel_mask = the source's layout (0: the default layout of the channel count)."""
         pcm = np.ascontiguousarray(pcm, np.float32)
         frames = pcm.size // channels
-        self._ck(self.lib.jt_upload_pcm(self.h, pcm.ctypes.data_as(C.POINTER(C.c_float)), C.c_int64(frames),
-                                        C.c_int(sample_rate), C.c_int(channels)))
+        self._ck(self.lib.jt_upload_pcm_layout(self.h, pcm.ctypes.data_as(C.POINTER(C.c_float)), C.c_int64(frames),
+                                               C.c_int(sample_rate), C.c_int(channels), C.c_uint64(channel_mask)))
 
     def set_source_format(self, bits_per_sample, is_float=False):
         """The decoder's native sample format of the uploaded PCM (jt_set_source_format): selects the band graphs' arithmetic."""

@@ -47,6 +47,10 @@ double orc_band_rms_db(const float *in, int64_t n, int sample_rate, double lo_hz
 double orc_band_rms_db_fmt(const float *in, int64_t n, int sample_rate, double lo_hz, double hi_hz, int mode);
 /* aformat=channel_layouts=mono of a stereo source (libswresample rematrix): 0 float 1/sqrt2, 1 s16 integer 0.5, 2 s32 via float 0.5 */
 void orc_downmix_stereo(const float *in, int64_t frames, int mode, float *out);
+/* any layout up to 8 channels -> mono (swr_build_matrix2's default matrix): see orc_basic.c; mask 0 = av_channel_layout_default(channels) */
+uint64_t orc_default_layout(int channels);
+int orc_downmix_coeffs(int channels, uint64_t mask, int normalise, double coef[8]);
+int orc_downmix_layout(const float *in, int64_t frames, int channels, uint64_t mask, int mode, float *out);
 void orc_biquad_tdii_f32(const float *in, float *out, int64_t n, const double b[3], const double a[3]);
 /* double-precision variant (band-RMS graphs run biquads on the decoder format; dbl used for s16/flt-agnostic checks) */
 void orc_biquad_tdii_f64(const double *in, double *out, int64_t n, const double b[3], const double a[3]);

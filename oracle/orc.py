@@ -68,6 +68,24 @@ def downmix_stereo(interleaved, mode=0):
     return out
 
 
+def downmix_layout(interleaved, channels, mask=0, mode=0):
+    """aformat=channel_layouts=mono of any layout up to 8 channels (swr_build_matrix2's default matrix; mask 0 = the default layout of
+    the channel count); modes as downmix_stereo.  Raises ValueError for a layout the restatement does not cover."""
+    x = np.ascontiguousarray(interleaved, np.float32)
+    out = np.empty(x.size // channels, np.float32)
+    rc = lib().orc_downmix_layout(_p(x, C.c_float), C.c_int64(x.size // channels), C.c_int(channels), C.c_uint64(mask), C.c_int(mode), _p(out, C.c_float))
+    if rc != 0:
+        raise ValueError("layout not covered")
+    return out
+
+
+def downmix_coeffs(channels, mask=0, normalise=False):
+    c = (C.c_double * 8)()
+    if lib().orc_downmix_coeffs(C.c_int(channels), C.c_uint64(mask), C.c_int(int(normalise)), c) != 0:
+        raise ValueError("layout not covered")
+    return np.array(c[:channels])
+
+
 def band_rms_db(x, sr, lo_hz, hi_hz):
     """Band-limited Overall RMS of a region in dB (analyser_bands.go:33: highpass, lowpass, astats)."""
     x = np.ascontiguousarray(x, np.float32)

@@ -262,14 +262,21 @@ def test_wav_formats(engine):
     assert ei.value.code == L.JT_E_UNSUPPORTED
 
 
-def test_surround_layouts_are_refused_not_averaged(engine, oracle):
-    x = coverage_signal(np.random.default_rng(2), 9000, 6, 16)
-    data = oracle.flac_encode(x, 48000, 16, 4096, 2, 8)
-    with pytest.raises(L.JtError) as ei:
-        engine.load_audio(data)
-    assert ei.value.code == L.JT_E_UNSUPPORTED
-    i32, _, _ = engine.op_decode_audio(data)                           # the decoder itself handles the layout
-    assert np.array_equal(i32, x)
+def test_layouts_beyond_the_restated_matrix_are_refused_not_averaged(engine, oracle):
+    """Round 6: surround layouts of FL FR FC LFE BL BR FLC FRC BC SL SR are down-mixed with libswresample's default matrix
+    (tests/test_gpu_round6.py holds them against the oracle's); what stays refused is a layout with channels the restated matrix has no
+    row for (top channels) and a mask that does not match the channel count -- JT_E_UNSUPPORTED, never an average with made-up weights."""
+    x = np.zeros((4000, 3), np.float32).reshape(-1)
+    for mask in (0x804, 0x3):                      # FC + top centre (bit 11); two bits for three channels
+        with pytest.raises(L.JtError) as ei:
+            engine.upload_pcm(x, 48000, 3, channel_mask=mask)
+        assert ei.value.code == L.JT_E_UNSUPPORTED
+    x6 = coverage_signal(np.random.default_rng(2), 9000, 6, 16)
+    data = oracle.flac_encode(x6, 48000, 16, 4096, 2, 8)
+    meta = engine.load_audio(data)                                     # 5.1 (side): libavcodec's layout for a six-channel FLAC
+    assert (meta["channels"], meta["channel_mask"]) == (6, 0x60F)
+    i32, _, _ = engine.op_decode_audio(data)
+    assert np.array_equal(i32, x6)
 
 
 def test_load_audio_feeds_the_passes_like_upload_pcm(oracle):
