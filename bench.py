@@ -12,6 +12,7 @@ at N = 8 that is the configuration's 256 files).
 """
 import argparse
 import json
+import math
 import os
 import sys
 import time
@@ -33,7 +34,8 @@ def spawn_ranks(argv, n, selftest):
     if not selftest:
         import torch
         have = torch.cuda.device_count() if torch.cuda.is_available() else 0
-        if have < n:
+        need = 1 if "--share-device" in argv else n                       # (--share-device: every rank on device 0, a host-side rehearsal)
+        if have < need:
             raise SystemExit(f"bench.py --gpus {n}: {have} GPU(s) visible; refusing to run fewer ranks than asked for")
     with socket.socket() as sk:
         sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]
@@ -258,7 +260,7 @@ def saturation_leg(rank, world, device, files_per_gpu, minutes, in_flight, sr, m
     return out
 
 
-def saturation_on_gpu(args, eng, rank, world, device, base, hostlogic, synth, sr):
+def saturation_on_gpu(args, eng, rank, world, device, base, hostlogic, synth, sr, cp_dev=None):
     """The saturation leg on real devices: this rank's share of the batch as 16-bit FLAC files in /dev/shm, one handle pool on its GPU."""
     import shutil
     import tempfile
@@ -298,9 +300,10 @@ def saturation_on_gpu(args, eng, rank, world, device, base, hostlogic, synth, sr
                 dist.barrier()
             torch.cuda.synchronize()
 
+        cp_dev = cp_dev or f"cuda:{device}"
         out = saturation_leg(rank, world, device, args.sat_files, args.sat_minutes, args.sat_in_flight, sr, make_files, run_batch, sync,
-                             f"cuda:{device}", "jt_handle_pool_process_files, one pool per rank on its own device, files sharded by shard.assign_files", prepare=prepare)
-        out["pool_workers_per_device"] = [int(v) for v in __import__("jivetalking_amd").shard.gather_over_ranks(len(pool.workers()), device=f"cuda:{device}")]
+                             cp_dev, "jt_handle_pool_process_files, one pool per rank on its own device, files sharded by shard.assign_files", prepare=prepare)
+        out["pool_workers_per_device"] = [int(v) for v in __import__("jivetalking_amd").shard.gather_over_ranks(len(pool.workers()), device=cp_dev)]
         return out
     finally:
         if pool is not None:
@@ -383,14 +386,20 @@ def e2e_legs(eng, x_dev, n, sr, seconds, base, hostlogic, Engine, device):
                 os.unlink(outp)                    # (untimed: publishing over last run's 150 MB output made the rename free its pages, 15 ms of "write")
             res["md5" if md5 else "no_md5"] = {"ms_per_file": round(min(tt[1:]) * 1e3, 2), "xRT": round(seconds / min(tt[1:]), 1),
                                                "io_ms": dict(zip(["read", "decode", "encode", "write"], [round(v, 2) for v in io]))}
-        nb = 6
+        # A pool sized for ITS files: a file's tail -- the STREAMINFO MD5, one dependent chain on one host core -- holds one of
+        # its handle's two I/O sets for md5_ms while the handle's front takes front_ms per file, so ceil(md5_ms / front_ms) tails are in flight
+        # per front at full rate: that many handles, plus one.  (Three handles left the GPU idle behind the finishers: 144 ms per file.)
+        front_ms = res["no_md5"]["ms_per_file"]; md5_ms = max(0.0, res["md5"]["ms_per_file"] - front_ms)
+        K = int(min(8, math.ceil(md5_ms / max(front_ms, 1e-3)) + 1)) if md5_ms > 0 else 3
+        K = max(2, K)
+        nb = 2 * K
         paths = []
         for k in range(nb):
             pk = os.path.join(d, f"batch{k}.flac"); shutil.copyfile(src, pk); paths.append(pk)
         # (a pool that has processed one batch already: jt_process_files opens fresh handles per call, and their first-file allocations --
         #  gigabytes of device and pinned memory -- made this figure jump between 215 and 410 ms from run to run)
         tbs = []
-        with hostlogic.Pool(devices=(device,), in_flight_per_device=3) as pool:
+        with hostlogic.Pool(devices=(device,), in_flight_per_device=K) as pool:
             for run in range(3):
                 t0 = time.perf_counter()
                 failed, fr, _ = pool.process_files(paths, base=base, md5=True)
@@ -398,10 +407,13 @@ def e2e_legs(eng, x_dev, n, sr, seconds, base, hostlogic, Engine, device):
                 for i in range(nb):
                     if fr[i].rc == 0:
                         os.unlink(fr[i].output_path.decode())
+            pstats = pool.stats()
         tb = min(tbs[1:])
-        res["batch_md5"] = {"files": nb, "in_flight": 3, "failed": int(failed), "ms_per_file": round(tb / nb * 1e3, 2), "xRT": round(nb * seconds / tb, 1),
-                            "wall_s_runs": [round(v, 3) for v in tbs],
-                            "note": "six 60-minute files through a handle pool of three (MD5 on finisher threads); best of the two batches after the first, which allocates"}
+        res["batch_md5"] = {"files": nb, "in_flight": K, "failed": int(failed), "ms_per_file": round(tb / nb * 1e3, 2), "xRT": round(nb * seconds / tb, 1),
+                            "wall_s_runs": [round(v, 3) for v in tbs], "pool_sized_from": {"front_ms": front_ms, "md5_ms": round(md5_ms, 2)},
+                            "stage_ms_per_file": pstats,
+                            "note": f"{nb} 60-minute files through a handle pool of {K} = min(8, ceil(md5_ms / front_ms) + 1) handles (MD5 on finisher threads); "
+                                    "best of the two batches after the first, which allocates"}
         res["input"] = {"format": "FLAC 16-bit mono", "bytes": os.path.getsize(src), "location": d.split("/jtbench")[0]}
         out["file"] = res
     finally:
@@ -438,6 +450,13 @@ def main():
     ap.add_argument("--option", action="append", default=[], metavar="KEY=VALUE",
                     help="jt_set_option on the bench engine (A/B runs: tp_unpruned=1, host_timing=1, ...); recorded in config.options")
     ap.add_argument("--selftest-spawn", action="store_true", help="exercise the N-rank launch path only (gloo, no GPU work); for tests")
+    ap.add_argument("--control-plane", choices=("gloo", "nccl"), default="gloo",
+                    help="the process group behind the barrier and the MAX / SUM / gather over ranks (the only cross-rank traffic there is: the data path "
+                         "has no collective).  gloo (default): CPU tensors over loopback TCP -- a barrier and a MAX need no RCCL, no device memory and no IPC "
+                         "handles; nccl: RCCL, as rounds 1-5 had it")
+    ap.add_argument("--share-device", action="store_true",
+                    help="HOST-SIDE REHEARSAL of the N-rank job on a box with ONE GPU: every rank uses device 0.  Measures what eight ranks cost the host "
+                         "(threads, /dev/shm, pinned memory, finisher cores) for real; the GPU is shared N ways, so the line is no scaling number and says so")
     args = ap.parse_args()
 
     if args.oracle_landing_job:
@@ -457,12 +476,23 @@ def main():
     import torch
     import torch.distributed as dist
     have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    if args.share_device:
+        local_rank = 0                                       # every rank on device 0 (host-side rehearsal: --share-device)
     if have <= local_rank:
         raise SystemExit(f"rank {rank}: device {local_rank} asked for, {have} GPU(s) visible")
     torch.cuda.set_device(local_rank)
+    # control plane: a barrier and a few scalars over the ranks -- gloo on CPU tensors by default (no RCCL communicator, no device buffers,
+    # no IPC handles); the data path has no collective at all (files shard by rank: jivetalking_amd/shard.py)
+    cp_dev = "cpu" if args.control_plane == "gloo" else f"cuda:{local_rank}"
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.control_plane == "gloo":
+            os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")          # one node: loopback (the container's hostname may not resolve)
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            if args.share_device:
+                raise SystemExit("--share-device needs --control-plane gloo (RCCL refuses two ranks on one device)")
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     from jivetalking_amd import Engine, synth, hostlogic, shard
     sr = args.rate
@@ -505,8 +535,8 @@ def main():
     dt = time.perf_counter() - t0
     tpu = eng.timers()
     dt_rank = dt
-    dt = shard.max_over_ranks(dt, device=f"cuda:{local_rank}")
-    per_rank_ms = shard.gather_over_ranks(dt_rank / args.steps * 1e3, device=f"cuda:{local_rank}")
+    dt = shard.max_over_ranks(dt, device=cp_dev)
+    per_rank_ms = shard.gather_over_ranks(dt_rank / args.steps * 1e3, device=cp_dev)
 
     sat = None
     if args.in_flight > 1:
@@ -525,7 +555,7 @@ def main():
         for t_ in th: t_.start()
         for t_ in th: t_.join()
         barrier()
-        dt2 = shard.max_over_ranks(time.perf_counter() - t1, device=f"cuda:{local_rank}")
+        dt2 = shard.max_over_ranks(time.perf_counter() - t1, device=cp_dev)
         sat = {"files_in_flight_per_gpu": args.in_flight, "xRT": round(world * args.in_flight * args.steps * seconds / dt2, 1),
                "ms_per_file": round(dt2 / (args.in_flight * args.steps) * 1e3, 3)}
         for e2 in engs[1:]: e2.close()
@@ -625,7 +655,7 @@ def main():
         # gfx950 note.  The file records the sha256 of the kernel sources it was measured on: `traffic` is null once they have changed.
         try:
             import hashlib
-            pmc_file = next(f for f in ("r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json") if os.path.exists(os.path.join(ROOT, "profiles", f)))
+            pmc_file = next(f for f in ("r06_pmc_traffic.json", "r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json") if os.path.exists(os.path.join(ROOT, "profiles", f)))
             pj = json.load(open(os.path.join(ROOT, "profiles", pmc_file)))
             pmc = pj["kernels"]
             sha = lambda f: hashlib.sha256(open(os.path.join(ROOT, "jivetalking_amd", "csrc", f), "rb").read()).hexdigest()[:16]
@@ -676,6 +706,13 @@ def main():
             "roofline": nlm_roof,
             "dominant_stage": roof,
         }
+        if world > 1:
+            out["control_plane"] = {"backend": args.control_plane, "what": "barrier + MAX / SUM / gather of scalars over the ranks; no collective on the data path"}
+        if args.share_device:
+            out["metric"] += " [--share-device: %d ranks on ONE GPU, a host-side rehearsal, NOT a scaling number]" % world
+            out["share_device"] = {"ranks": world, "devices_used": 1,
+                                   "note": "every rank opened device 0: the GPU's time is shared N ways, what the line measures is the HOST side of the N-rank job "
+                                           "(threads, pinned memory, /dev/shm, finisher cores: saturation.*.host), on the box that has the one GPU"}
         fl = compute_aware_floor(n, m, sr, bool(res.limiter.needed), int(eng.timers()["declick_repaired"]), (m + 1211) // 1212)
         fl["step_over_floor"] = round(dt / args.steps * 1e3 / fl["floor_ms"], 2)
         out["compute_aware_floor"] = fl
@@ -766,7 +803,7 @@ def main():
     # file beside an idle eight-stream handle, 10.1 without it) -- a batch host has the pool and nothing else.
     eng.close()
     if args.saturation and args.channels == 1:
-        sat_leg = saturation_on_gpu(args, None, rank, world, local_rank, base, hostlogic, synth, sr)
+        sat_leg = saturation_on_gpu(args, None, rank, world, local_rank, base, hostlogic, synth, sr, cp_dev)
     if rank == 0:
         if sat_leg is not None:
             out["saturation"] = sat_leg

@@ -232,6 +232,11 @@ int     jt_host_loudnorm_json(const jt_loudnorm_stats *stats, char *buf, int cap
 int jt_process_file(jt_ctx *h, const char *input_path, const jt_host_config *base, int frame_samples, int flac_flags,
                     jt_progress_fn cb, void *user, jt_process_result *out, char *output_path, int cap, double io_ms[4]);
 
+/* Host topology: the NUMA node a device hangs off (its PCI address's numa_node in sysfs) and how many of that node's CPUs this process
+ * may run on; -1 / 0 when the host does not say (one node, a VM).  A handle pool binds its worker threads and finisher jobs -- and,
+ * through first touch, the pinned I/O sets they allocate -- to that node (option pool_numa, process-wide, default on). */
+int jt_host_device_numa_node(int device, int *n_cpus);
+
 /* Test seam: makes the next jt_process_file calls fail at temp creation / temp write / publish (the failures the reference injects
  * through processorCreateSiblingTempPath, a failing encoder and processorRename: processor_test.go:552-627) so that the
  * no-residue discipline can be tested.  All zero = normal operation. */

@@ -199,6 +199,7 @@ extern "C" int jt_set_option(jt_ctx *h, const char *key, const char *value)
             DevGraveyard::set_limit_gb(gb); return JT_OK;
         }
         if (!strcmp(key, "pool_streams")) { int v = 0; if (!opt_int(value, &v) || v < 0) return JT_E_INVAL; jt_pool_streams().store(v); return JT_OK; }
+        if (!strcmp(key, "pool_numa")) { bool b = false; if (!opt_bool(value, &b)) return JT_E_INVAL; jt_pool_numa().store(b ? 1 : 0); return JT_OK; }
         if (!strcmp(key, "pool_blocking_sync")) { bool b = false; if (!opt_bool(value, &b)) return JT_E_INVAL; jt_pool_blocking().store(b ? 1 : 0); return JT_OK; }
         if (!strcmp(key, "host_timing")) { bool b = false; if (!opt_bool(value, &b)) return JT_E_INVAL; jt_host_timing().store(b ? 1 : 0); return JT_OK; }
         if (!strcmp(key, "early_temp_min_kb")) { int v = 0; if (!opt_int(value, &v) || v < 0) return JT_E_INVAL; jt_early_temp_min_kb().store(v); return JT_OK; }

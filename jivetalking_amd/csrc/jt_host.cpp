@@ -21,6 +21,10 @@
 #include <atomic>
 #include <condition_variable>
 #include <deque>
+#include <map>
+#include <sched.h>
+#include <pthread.h>
+#include <cctype>
 
 static double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 namespace {
@@ -1751,6 +1755,73 @@ extern "C" int jt_process_file(jt_ctx *h, const char *input_path, const jt_host_
 // A pool owns its handles: they are opened once (in parallel: hipMalloc serialises a worker's first-file allocations anyway) and serve
 // any number of batches -- what a long-running host wants (the Go shim pools handles the same way), and what keeps 0.1 s of start-up
 // out of every sub-second batch.  A device that cannot be opened gets no worker; its worker tries the devices nobody serves yet.
+
+// ---------------------------------------------------------------- host topology
+// A pool's worker thread, its finisher jobs and the pinned, file-sized I/O sets they touch first belong on the NUMA node the GPU hangs
+// off: on a two-socket host (2 x EPYC 9575F on the GPU box, profiles/r05_gpubox_probe.txt) eight pools' threads otherwise land wherever
+// the scheduler puts them and half of the pinned traffic crosses the socket link.  The node comes from the device's PCI address
+// (hipDeviceGetPCIBusId -> /sys/bus/pci/devices/<addr>/numa_node -> /sys/devices/system/node/node<k>/cpulist), intersected with the CPUs
+// the process is allowed (a cpuset / taskset is respected); a host without that information (one node, a VM: numa_node = -1) is left alone.
+// Pinned memory follows the threads: hipHostMalloc's pages are faulted in by the thread that calls it (first touch, default policy).
+// Option pool_numa (process-wide, default on).
+namespace {
+struct DeviceCpus { bool ok = false; int node = -1; cpu_set_t set; };
+const DeviceCpus &device_cpus(int device)
+{
+    static std::mutex m; static std::map<int, DeviceCpus> cache;
+    std::lock_guard<std::mutex> l(m);
+    auto it = cache.find(device);
+    if (it != cache.end()) return it->second;
+    DeviceCpus d; CPU_ZERO(&d.set);
+    char bus[64] = {0};
+    if (hipDeviceGetPCIBusId(bus, (int)sizeof bus, device) == hipSuccess) {
+        for (char *c = bus; *c; ++c) *c = (char)std::tolower((unsigned char)*c);
+        char path[256]; snprintf(path, sizeof path, "/sys/bus/pci/devices/%s/numa_node", bus);
+        int node = -1;
+        if (FILE *f = fopen(path, "r")) { if (fscanf(f, "%d", &node) != 1) node = -1; fclose(f); }
+        if (node >= 0) {
+            snprintf(path, sizeof path, "/sys/devices/system/node/node%d/cpulist", node);
+            if (FILE *f = fopen(path, "r")) {
+                char buf[4096] = {0};
+                if (fgets(buf, sizeof buf, f)) {
+                    int n = 0;
+                    for (char *p = buf; *p && *p != '\n';) {                    // "0-63,128-191"
+                        char *e; long a = strtol(p, &e, 10); if (e == p) break; long b = a;
+                        if (*e == '-') { p = e + 1; b = strtol(p, &e, 10); }
+                        for (long c = a; c <= b && c < CPU_SETSIZE; ++c) { CPU_SET((int)c, &d.set); ++n; }
+                        p = *e == ',' ? e + 1 : e;
+                    }
+                    cpu_set_t allowed;
+                    if (n > 0 && sched_getaffinity(0, sizeof allowed, &allowed) == 0) {
+                        CPU_AND(&d.set, &d.set, &allowed);
+                        d.ok = CPU_COUNT(&d.set) > 0; d.node = node;
+                    }
+                }
+                fclose(f);
+            }
+        }
+    }
+    return cache.emplace(device, d).first->second;
+}
+// binds the calling thread for the lifetime of the object (a pool's batch runs its first worker on the CALLER's thread: restored afterwards)
+struct NodeBinding {
+    bool bound = false; cpu_set_t old;
+    explicit NodeBinding(int device) {
+        if (!jt_pool_numa().load()) return;
+        const DeviceCpus &d = device_cpus(device);
+        if (!d.ok || pthread_getaffinity_np(pthread_self(), sizeof old, &old) != 0) return;
+        bound = pthread_setaffinity_np(pthread_self(), sizeof d.set, &d.set) == 0;
+    }
+    ~NodeBinding() { if (bound) (void)pthread_setaffinity_np(pthread_self(), sizeof old, &old); }
+};
+} // namespace
+extern "C" int jt_host_device_numa_node(int device, int *n_cpus)
+{
+    const DeviceCpus &d = device_cpus(device);
+    if (n_cpus) *n_cpus = d.ok ? CPU_COUNT(&d.set) : 0;
+    return d.ok ? d.node : -1;
+}
+
 struct jt_handle_pool {
     std::vector<int> devices;
     int in_flight = 1;
@@ -1792,6 +1863,7 @@ extern "C" int jt_handle_pool_open(const int *devices, int n_devices, int in_fli
     const bool shared = in_flight_per_device >= 3;
     const int ns = shared ? jt_pool_streams().load() : 0, of = shared && jt_pool_blocking().load() ? JT_OPEN_BLOCKING_SYNC : 0;
     auto open_one = [&](int device) {
+        NodeBinding nb(device);                  // (the handle's first pinned arenas are allocated here)
         jt_ctx *h = nullptr;
         int orc = jt_open_ex(device, ns, of, &h);
         while ((orc != JT_OK || !h) && workers < n_devices) {
@@ -1880,6 +1952,7 @@ extern "C" int jt_handle_pool_process_files(jt_handle_pool *P, const char *const
     // that fails in microseconds would otherwise claim most of the queue)
     auto file_verdict = [](int rc) { return rc == JT_OK || rc == JT_E_CANCELLED || rc == JT_E_INVAL || rc == JT_E_UNSUPPORTED || rc == JT_E_SILENT; };
     auto worker = [&](jt_handle_pool::Worker *W) {
+        NodeBinding nb(W->device);               // this thread, and through first touch the I/O sets it pins, on the GPU's NUMA node
         // two I/O sets per handle: a file's tail runs on a finisher thread from set k while the handle fills set 1 - k
         struct Gate { std::mutex m; std::condition_variable cv; bool busy = false;
                       void wait_free() { std::unique_lock<std::mutex> l(m); cv.wait(l, [&] { return !busy; }); }
@@ -1917,7 +1990,9 @@ extern "C" int jt_handle_pool_process_files(jt_handle_pool *P, const char *const
                            std::vector<double> st; double t_front = 0; };
             auto early = std::make_shared<Early>();
             Gate *g = &gate[set];
-            auto finish = [tail, early, &r, &failed, g, t0, P, suspect] {
+            const int fdev = W->device;
+            auto finish = [tail, early, &r, &failed, g, t0, P, suspect, fdev] {
+                NodeBinding nb(fdev);            // (a finisher thread serves whichever device's file comes next)
                 std::string err; double ms[2] = {0, 0}; uint8_t md5[16]; bool md5_ok = true;
                 if (early->started) {
                     const double m0 = wall_ms();

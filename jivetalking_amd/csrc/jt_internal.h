@@ -61,6 +61,7 @@ inline std::atomic<int> &jt_host_timing() { static std::atomic<int> v{0}; return
 // their host waits sleep (default yes); jt_set_option(NULL, "pool_streams" / "pool_blocking_sync", ..)
 inline std::atomic<int> &jt_pool_streams() { static std::atomic<int> v{1}; return v; }
 inline std::atomic<int> &jt_pool_blocking() { static std::atomic<int> v{1}; return v; }
+inline std::atomic<int> &jt_pool_numa() { static std::atomic<int> v{1}; return v; }       // option pool_numa: a pool's threads run on their GPU's NUMA node
 // jt_process_file creates, reserves and maps its temporary output while the passes run when the output is expected to reach this many
 // KiB (default 32 MiB: about 35 minutes of speech); jt_set_option(NULL, "early_temp_min_kb", ..) lets tests reach that path with short files
 inline std::atomic<long long> &jt_early_temp_min_kb() { static std::atomic<long long> v{32 << 10}; return v; }

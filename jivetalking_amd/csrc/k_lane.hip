@@ -1253,11 +1253,17 @@ k_follow_states_pc(const TIn *__restrict__ in, int64_t n, double att, double rel
             // difference exists and the comparison runs beside them, so a step's dependent chain is sub -> mul -> select -> add instead
             // of compare -> select -> mul -> add behind the subtraction.  The same product, the same sum: bit-identical.  (The empty
             // asm keeps the compiler from folding the two products back into one product of the selected coefficient.)
+            // Round 6: one product instead of two, the coefficient selected by the SIGN OF THE DIFFERENCE: a > s <=> d > 0 (the difference of
+            // two finite doubles is zero only when they are equal and carries the comparison's sign), and d > 0 is a 32-bit signed compare
+            // of its high word (> 0: positive and not +0; a positive d whose high word is zero is a subnormal below 2^-1042, which no
+            // difference of squared samples against a state that started at zero can be).  A lone wave is ISSUE-bound and an f64
+            // instruction costs 9 ticks against 5 for a 32-bit one (profiles/r02_gfx950_op_costs.txt): sub 9 + cmp 5 + 2 x cndmask 10 + mul 9
+            // + add 9 = 42 ticks a sample where "both products, then select" was sub + 2 mul + cmp_f64 + 2 cndmask + add = 55.  The same
+            // product of the same two doubles, the same sum: bit-identical states (the A/B build's one-wave kernel is held to it).
             auto step = [&](double a) {
                 const double d = a - s;
-                double pa = d * att, pr = d * rel;
-                asm volatile("" : "+v"(pa), "+v"(pr));
-                s += a > s ? pa : pr;
+                const double c = __double2hiint(d) > 0 ? att : rel;
+                s += d * c;
             };
             if (inside) {
 #pragma unroll
@@ -1535,22 +1541,28 @@ k_absmax_conv_s16(const int16_t *__restrict__ in, double *__restrict__ conv, dou
     };
     if ((w * 8 + 8) * 256 <= n) {
         // (as k_absmax_copy_f64: the wave's eight loads first)
+        // Round 6: a lane takes samples 2 l, 2 l + 1 of each HALF of a 256-sample block (as k_absmax_copy_f64 does), so that every store
+        // instruction of the wave covers 1024 CONTIGUOUS bytes; with four consecutive samples per lane each of the two 16-byte stores
+        // touched every other 16 bytes of 2 KB -- half-written lines twice over, and the sweep sat at 85 % stalled on its stores
         const int64_t base0 = w * 8 * 256;
-        short4 xs[8];
+        short2 xa[8], xb[8];
 #pragma unroll
-        for (int q = 0; q < 8; ++q) xs[q] = *reinterpret_cast<const short4 *>(in + base0 + q * 256 + 4 * lane);
+        for (int q = 0; q < 8; ++q) {
+            xa[q] = *reinterpret_cast<const short2 *>(in + base0 + q * 256 + 2 * lane);
+            xb[q] = *reinterpret_cast<const short2 *>(in + base0 + q * 256 + 128 + 2 * lane);
+        }
         double mq[8];
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
-            const double v0 = cv(xs[q].x), v1 = cv(xs[q].y), v2 = cv(xs[q].z), v3 = cv(xs[q].w);
+            const double v0 = cv(xa[q].x), v1 = cv(xa[q].y), v2 = cv(xb[q].x), v3 = cv(xb[q].y);
             mq[q] = fmax(fmax(fabs(v0), fabs(v1)), fmax(fabs(v2), fabs(v3)));
-            const int64_t o = base0 + q * 256 + 4 * lane;
+            const int64_t o = base0 + q * 256 + 2 * lane;
             if (conv) {
                 *reinterpret_cast<double2 *>(conv + o) = double2{v0, v1};
-                *reinterpret_cast<double2 *>(conv + o + 2) = double2{v2, v3};
+                *reinterpret_cast<double2 *>(conv + o + 128) = double2{v2, v3};
             }
             *reinterpret_cast<double2 *>(out + o) = double2{v0 * gain, v1 * gain};
-            *reinterpret_cast<double2 *>(out + o + 2) = double2{v2 * gain, v3 * gain};
+            *reinterpret_cast<double2 *>(out + o + 128) = double2{v2 * gain, v3 * gain};
         }
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) {

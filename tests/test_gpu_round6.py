@@ -278,3 +278,43 @@ def test_surround_files_through_the_whole_path(engine, oracle):
     p1 = engine.pass1(n)
     ref = oracle.downmix_layout(x3, 3, 0, 0)
     assert p1["astats"]["max_level"] == float(ref.max()) and p1["astats"]["min_level"] == float(ref.min())
+
+
+def test_pool_numa_binding_changes_no_byte_and_restores_the_callers_affinity(engine, oracle):
+    """VERDICT r5 next #6b: a handle pool binds its worker threads and finisher jobs to the NUMA node its GPU hangs off (option pool_numa,
+    default on).  The first worker of a batch runs on the CALLING thread: its affinity must be what it was afterwards; the outputs must be
+    the same bytes with the binding on and off; and the node the library reports is what sysfs says for the device's PCI address."""
+    import ctypes as C, hashlib, os, shutil, tempfile
+    lib = H.lib()
+    ncpu = C.c_int()
+    node = lib.jt_host_device_numa_node(C.c_int(0), C.byref(ncpu))
+    assert node >= -1 and (ncpu.value > 0) == (node >= 0)
+    if node >= 0:
+        cpus = open(f"/sys/devices/system/node/node{node}/cpulist").read().strip()
+        assert cpus and ncpu.value <= (os.cpu_count() or 1)
+    d = tempfile.mkdtemp(prefix="jtnm", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
+    try:
+        paths = []
+        for k in range(6):
+            x = synth.speech_like(20.0 + 3 * k, 48000, seed=690 + k)
+            pcm = np.clip(np.rint(np.asarray(x, np.float64) * 32768), -32768, 32767).astype(np.int16)
+            p = os.path.join(d, f"n{k}.flac")
+            with open(p, "wb") as f:
+                f.write(engine.op_flac_encode(pcm, 48000, md5=True))
+            paths.append(p)
+        before = os.sched_getaffinity(0)
+        hashes = []
+        for numa in (1, 0, 1):
+            assert lib.jt_set_option(None, b"pool_numa", str(numa).encode()) == 0
+            with H.Pool((0,), 3) as P:
+                failed, fr, _ = P.process_files(paths, md5=True)
+                assert failed == 0
+                hs = hashlib.md5()
+                for r in fr:
+                    hs.update(open(r.output_path.decode(), "rb").read()); os.unlink(r.output_path.decode())
+                hashes.append(hs.hexdigest())
+            assert os.sched_getaffinity(0) == before
+        assert hashes[0] == hashes[1] == hashes[2]
+    finally:
+        lib.jt_set_option(None, b"pool_numa", b"1")
+        shutil.rmtree(d, ignore_errors=True)
