@@ -105,7 +105,7 @@ template <typename T> struct DevBuf {
 #define JT_OPT_AB_BOOLS(X) \
     X(nlm_old) X(afftdn_old) X(adeclick_fused) X(dk_levinson_in_kernel) X(dk_no_xcd) X(dk_serial) X(dk_profile) X(dyn_one_wave) \
     X(dyn_no_cu_reserve) X(kw_two_sweeps) X(follow_tiles) X(follow_one_wave) X(tp_old) X(lim_profile) X(ups_no_stream8) X(ups_no_stream16) X(edge_polyphase) X(no_lim_s16)
-#define JT_OPT_AB_INTS(X) X(dk_waves) X(dyn_steps) X(deess_chunk) X(deess_halo) X(follow_div) X(follow_div64) X(follow_nofma) X(follow_dbg)
+#define JT_OPT_AB_INTS(X) X(dk_waves) X(dyn_steps) X(deess_chunk) X(deess_halo) X(follow_div) X(follow_dbg)
 struct JtOpts {
 #define X(k) bool k = false;
     JT_OPT_BOOLS(X) JT_OPT_AB_BOOLS(X)

@@ -1231,7 +1231,6 @@ k_follow_states_pc(const TIn *__restrict__ in, int64_t n, double att, double rel
     const int64_t c = c0 + lane;
     const bool active = c < nchunks;
     const int64_t row0 = c * chunk - halo;             // first sample of this lane's run (may be negative)
-    const bool nofma = (dbg & 4) != 0;                 // (A/B: product and sum rounded separately, as the reference statement)
     double s = 0.0;
     for (int u = 0; u < nu; ++u) {
         __syncthreads();
@@ -1261,15 +1260,10 @@ k_follow_states_pc(const TIn *__restrict__ in, int64_t n, double att, double rel
             // instruction costs 9 ticks against 5 for a 32-bit one (profiles/r02_gfx950_op_costs.txt): sub 9 + cmp 5 + 2 x cndmask 10 + mul 9
             // + add 9 = 42 ticks a sample where "both products, then select" was sub + 2 mul + cmp_f64 + 2 cndmask + add = 55.  The same
             // product of the same two doubles, the same sum: bit-identical states (the A/B build's one-wave kernel is held to it).
-            // ... and the product and the sum as ONE fused multiply-add (35 ticks): the reference rounds the product before it adds it
-            // (C, no contraction), so a step's state now differs from the reference statement's by at most half an ulp -- which the
-            // recurrence contracts like any other perturbation (factor 1 - rho a sample: the accumulated drift stays below 1e-16 / rho =
-            // 2.4e-13 relative), five orders of magnitude under the 1.5e-8 the warm-up halo leaves at every chunk start by design.  The
-            // states are only the STARTING points of k_dyn_apply's 256-sample runs, which restate the filter's arithmetic exactly.
             auto step = [&](double a) {
                 const double d = a - s;
                 const double c = __double2hiint(d) > 0 ? att : rel;
-                s = nofma ? s + d * c : __fma_rn(d, c, s);
+                s += d * c;
             };
             if (inside) {
 #pragma unroll
@@ -1386,8 +1380,7 @@ static void run_follow(const TIn *in, int64_t n, double att, double rel, double 
         // one's, so longer chunks (fewer waves) start waiting for memory again: halo/2 and halo measured 1-2 ms worse.
         // chunk = halo / div: the run is halo + chunk long, the signal is read 1 + div times.  Files up to ~20 minutes are small enough
         // for 9 x (their traffic stays under a millisecond of HBM time); longer ones keep 5 x
-        int div = JT_AB_ON(o.follow_div > 0) ? o.follow_div : (n <= ((int64_t)1 << 26) ? 8 : 4);
-        if (sizeof(TIn) == 8 && JT_AB_ON(o.follow_div64 > 0)) div = o.follow_div64;
+        const int div = JT_AB_ON(o.follow_div > 0) ? o.follow_div : (n <= ((int64_t)1 << 26) ? 8 : 4);
         const int64_t lchunk = std::max<int64_t>(1024, (halo / div + SC - 1) / SC * SC);
         const int64_t lnch = (n + lchunk - 1) / lchunk;
         if (!JT_AB_ON(o.follow_one_wave)) {
@@ -1396,8 +1389,7 @@ static void run_follow(const TIn *in, int64_t n, double att, double rel, double 
             const int smem = 3 * (US / 2) * (1024 + 16);
             auto k = k_follow_states_pc<TIn>;
             JT_HIP(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
-            hipLaunchKernelGGL(k, dim3((unsigned)((lnch + LANES - 1) / LANES)), dim3(4 * LANES), smem, s, in, n, att, rel, lchunk, halo, states, lnch,
-                               (JT_AB_ON(o.follow_dbg) ? o.follow_dbg : 0) | (JT_AB_ON(o.follow_nofma) ? 4 : 0));
+            hipLaunchKernelGGL(k, dim3((unsigned)((lnch + LANES - 1) / LANES)), dim3(4 * LANES), smem, s, in, n, att, rel, lchunk, halo, states, lnch, JT_AB_ON(o.follow_dbg) ? o.follow_dbg : 0);
             return;
         }
 #ifdef JT_AB
