@@ -1774,7 +1774,13 @@ const DeviceCpus &device_cpus(int device)
     if (it != cache.end()) return it->second;
     DeviceCpus d; CPU_ZERO(&d.set);
     char bus[64] = {0};
-    if (hipDeviceGetPCIBusId(bus, (int)sizeof bus, device) == hipSuccess) {
+    int count = 0;
+    // (a device index the runtime does not know is not asked about: a failed HIP call leaves its error as the calling thread's "last
+    //  error", and the next launch check on that thread would report it)
+    const bool known = hipGetDeviceCount(&count) == hipSuccess && device >= 0 && device < count;
+    if (!known) (void)hipGetLastError();
+    if (known && hipDeviceGetPCIBusId(bus, (int)sizeof bus, device) != hipSuccess) { (void)hipGetLastError(); bus[0] = 0; }
+    if (bus[0]) {
         for (char *c = bus; *c; ++c) *c = (char)std::tolower((unsigned char)*c);
         char path[256]; snprintf(path, sizeof path, "/sys/bus/pci/devices/%s/numa_node", bus);
         int node = -1;

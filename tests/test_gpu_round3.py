@@ -102,7 +102,7 @@ def test_a_pool_without_any_device_fails_every_file_of_every_batch(engine, tmp_p
     with H.Pool(devices=(99, 0), in_flight_per_device=1) as pool:      # the worker of the dead device finds nothing else to serve
         assert pool.workers() == [0]
         failed, res, dev = pool.process_files(paths)
-        assert failed == 0 and dev == [0, 0]
+        assert failed == 0 and dev == [0, 0], [(r.rc, r.error) for r in res]
 
 
 def test_a_device_that_cannot_be_opened_takes_no_files(engine, tmp_path):
