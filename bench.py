@@ -62,13 +62,25 @@ def spawn_ranks(argv, n, selftest):
         raise SystemExit(f"bench.py --gpus {n}: a rank exited with status {rc}")
 
 
+def quiet_stdout(fn):
+    """Run fn with file descriptor 1 pointing at stderr: gloo's transport announces "[Gloo] Rank r is connected to N peer ranks" on the
+    process's STDOUT while the group forms, and rank 0's stdout carries exactly one JSON line."""
+    sys.stdout.flush()
+    keep = os.dup(1)
+    try:
+        os.dup2(2, 1)
+        return fn()
+    finally:
+        sys.stdout.flush()
+        os.dup2(keep, 1); os.close(keep)
+
+
 def spawn_selftest(args, rank, world):
     """`--selftest-spawn`: the launch path only (rendezvous on 127.0.0.1 over gloo, barrier, MAX / gather over ranks, one line from
     rank 0) with a sleep for a step.  For the CPU test of the N-rank launch; the metric name says what it is."""
     import torch.distributed as dist
     from jivetalking_amd import shard
-    dist.init_process_group("gloo", rank=rank, world_size=world)
-    shard.barrier()
+    quiet_stdout(lambda: (dist.init_process_group("gloo", rank=rank, world_size=world), shard.barrier()))
     t0 = time.perf_counter()
     for _ in range(args.steps):
         time.sleep(0.01 * (1 + rank))
@@ -488,7 +500,7 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if args.control_plane == "gloo":
             os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")          # one node: loopback (the container's hostname may not resolve)
-            dist.init_process_group("gloo", rank=rank, world_size=world)
+            quiet_stdout(lambda: (dist.init_process_group("gloo", rank=rank, world_size=world), dist.barrier()))
         else:
             if args.share_device:
                 raise SystemExit("--share-device needs --control-plane gloo (RCCL refuses two ranks on one device)")

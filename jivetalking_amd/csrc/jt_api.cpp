@@ -11,7 +11,9 @@
 #include <cctype>
 
 static void check_cancel(jt_ctx *h) { if (h->cancelled.load()) throw JtError{JT_E_CANCELLED, "cancelled"}; }
-static void spec_pass2_start(jt_ctx *h, const jt_filter_params *p);     // the early Pass-2 head (defined with jt_pass2_prefetch)
+// the early Pass-2 head (defined with jt_pass2_prefetch).  phase 0: all of it behind everything queued on the main stream; 1: the
+// biquad cascade only, beside whatever is queued (jt_pass1 calls it BEFORE its analysis chains); 2: the rest (anlmdn) behind the main stream
+static void spec_pass2_start(jt_ctx *h, const jt_filter_params *p, int phase = 0);
 
 #ifdef JT_AB
 static void opts_from_env(JtOpts *o);
@@ -661,6 +663,14 @@ extern "C" int jt_pass1(jt_ctx *h, int frame_samples, jt_analysis *out, double *
     pass_begin(h, h->n, 1);
     const double *fst = nullptr;
     AnalysisJob J;
+    // Round 6: the announced Pass-2 head's BIQUAD cascade (a thin, latency-bound sweep that needs nothing but the input) goes in FIRST, on its
+    // low-priority stream beside the analysis chains; anlmdn -- 150 k workgroups that would take every slot -- still waits for the analysis
+    // (below).  Schedule only: option no_early_biquad keeps the cascade behind the analysis too.
+    bool head_split = false;
+    if (h->spec_p2.armed && !h->opts.no_early_biquad) {
+        try { spec_pass2_start(h, &h->spec_p2.armed_p, 1); head_split = true; }
+        catch (const JtError &e) { if (e.code != JT_E_INVAL) throw; h->spec_p2.armed = false; }      // (dropped as below: jt_pass2 raises the error)
+    }
     // the analysis chains fork first: the per-decoder-frame sums then run beside them on the main stream instead of ahead of them
     // (the fork waits for everything queued on the main stream: 0.3 ms of every Pass 1 with the sums in front)
     analysis_enqueue(h, h->in_mono, h->n, h->sr, true, h->sr / 10, &J, false);
@@ -678,7 +688,7 @@ extern "C" int jt_pass1(jt_ctx *h, int frame_samples, jt_analysis *out, double *
         h->spec_p2.armed = false;
         // best effort: a head that cannot be built (a source below 41 kHz puts the fixed 20.5 kHz low-pass past Nyquist: fill_biquads
         // throws EINVAL) is dropped here, Pass 1 completes as it does in the reference, and jt_pass2 raises the error
-        try { spec_pass2_start(h, &h->spec_p2.armed_p); } catch (const JtError &e) { if (e.code != JT_E_INVAL) throw; }
+        try { spec_pass2_start(h, &h->spec_p2.armed_p, head_split ? 2 : 0); } catch (const JtError &e) { if (e.code != JT_E_INVAL) throw; }
     }
     analysis_complete(h, J, out, meta, cap_meta, true);       // (chain by chain, while the later chains still run)
     JT_HIP(jt_stream_sync(h, h->stream));
@@ -959,21 +969,27 @@ extern "C" int jt_pass2_prefetch_after_pass1(jt_ctx *h, const jt_filter_params *
     h->spec_p2.armed_p = *p; h->spec_p2.armed = true;
     JT_API_END(h)
 }
-static void spec_pass2_start(jt_ctx *h, const jt_filter_params *p)
+static void spec_pass2_start(jt_ctx *h, const jt_filter_params *p, int phase)
 {
     jt_ctx::SpecPass2 &sp = h->spec_p2;
     const int64_t n = h->n; const int sr = h->sr;
-    fill_biquads(p, sr, sp.st, &sp.nst);
-    sp.nlm = p->nlm_enabled != 0;
-    sp.nlm_p[0] = p->nlm_strength; sp.nlm_p[1] = p->nlm_patch_s; sp.nlm_p[2] = p->nlm_research_s; sp.nlm_p[3] = p->nlm_smooth;
+    if (phase != 2) {
+        fill_biquads(p, sr, sp.st, &sp.nst);
+        sp.nlm = p->nlm_enabled != 0;
+        sp.nlm_p[0] = p->nlm_strength; sp.nlm_p[1] = p->nlm_patch_s; sp.nlm_p[2] = p->nlm_research_s; sp.nlm_p[3] = p->nlm_smooth;
+        sp.stages = 0;
+    }
     if (sp.nst == 0 && !sp.nlm) return;                       // nothing to start
     h->work_a.ensure((size_t)n + 16); h->work_b.ensure((size_t)n + 16);
     // the same buffer walk as jt_pass2: in_mono -> work_a -> work_b
     const float *cur = h->in_mono; float *nxt = h->work_a.p; float *oth = h->work_b.p;
-    sp.stages = 0;
     JT_HIP(hipEventRecord(h->ev_fork, h->stream));
-    JT_HIP(hipStreamWaitEvent(sp.stream, h->ev_fork, 0));     // everything queued so far (the input upload / down-mix) first
-    if (sp.nst > 0) { launch_biquad_f32(cur, nxt, n, sp.nst, sp.st, sp.stream); cur = nxt; std::swap(nxt, oth); sp.stages++; }
+    JT_HIP(hipStreamWaitEvent(sp.stream, h->ev_fork, 0));     // everything queued so far (the input upload / down-mix; phase 2: Pass 1's analysis) first
+    if (sp.nst > 0) {
+        if (phase != 2) { launch_biquad_f32(cur, nxt, n, sp.nst, sp.st, sp.stream); sp.stages++; }
+        cur = nxt; std::swap(nxt, oth);
+    }
+    if (phase == 1) return;                                   // (anlmdn follows in phase 2, on the same stream)
     if (sp.nlm) { run_anlmdn(h, cur, nxt, n, sr, sp.nlm_p[0], sp.nlm_p[1], sp.nlm_p[2], sp.nlm_p[3], sp.stream); cur = nxt; std::swap(nxt, oth); sp.stages++; }
     JT_HIP(hipEventRecord(sp.done, sp.stream));
     sp.pending = true;
