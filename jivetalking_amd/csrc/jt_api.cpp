@@ -853,9 +853,13 @@ static void run_anlmdn(jt_ctx *h, const float *in, float *out, int64_t n, int sr
     JT_HIP(hipEventRecord(h->ev3, st));
 }
 
-static void run_afftdn(jt_ctx *h, const float *in, float *out, int64_t n, int sr, double nr, double nf, const double *bn, bool track = false)
+// The filter's tables (window, band maps, variances: ~20 KB) are planned on the host and uploaded on the main stream.  jt_pass2 does
+// that BEFORE it makes the main stream wait for the early head: queued behind the wait, the upload -- an SDMA copy with its own
+// signalling -- sat between anlmdn's last workgroup and afftdn's first (0.19 ms of every step, profiles/r05_timeline_one_step.txt).
+struct AfftdnPrep { AfftdnPlanHost pl; AfftdnDev d; };
+static void afftdn_prepare(jt_ctx *h, int sr, double nr, double nf, const double *bn, AfftdnPrep *P)
 {
-    AfftdnPlanHost pl; jt_afftdn_plan(&pl, sr, nr, nf, bn);
+    AfftdnPlanHost &pl = P->pl; jt_afftdn_plan(&pl, sr, nr, nf, bn);
     ensure_twiddle(h, pl.L);
     const size_t nb = pl.nbands, bins = pl.bins;
     const size_t ndbl = pl.W + nb + nb + nb * nb + bins + bins + bins;
@@ -887,6 +891,14 @@ static void run_afftdn(jt_ctx *h, const float *in, float *out, int64_t n, int sr
         }
         d.seg_span = span;
     }
+    P->d = d;
+}
+static void run_afftdn(jt_ctx *h, const float *in, float *out, int64_t n, int sr, double nr, double nf, const double *bn, bool track = false,
+                       const AfftdnPrep *prep = nullptr)
+{
+    AfftdnPrep local;
+    if (!prep) { afftdn_prepare(h, sr, nr, nf, bn, &local); prep = &local; }
+    const AfftdnPlanHost &pl = prep->pl; AfftdnDev d = prep->d;
     if (!track) { launch_afftdn(in, out, n, d, 0, 96, h->stream, h->opts); return; }     // chunk length chosen from the frame count; 96 warm-up frames
     // tn=1 (af_afftdn.c track_noise; what the reference emits when Noise.Floor == 0, adaptive.go:147-151).  The floor is a state
     // that survives arbitrarily long stretches of speech (only spectrally flat frames move it), so a warm-up halo cannot restore
@@ -1146,6 +1158,9 @@ extern "C" int jt_pass2(jt_ctx *h, const jt_filter_params *p, jt_analysis *out)
     const double nlm_p[4] = {p->nlm_strength, p->nlm_patch_s, p->nlm_research_s, p->nlm_smooth};
     const bool head_ready = sp.pending && sp.nst == nst && (nst == 0 || !std::memcmp(sp.st, st, sizeof(BiquadF32) * nst)) &&
                             sp.nlm == (p->nlm_enabled != 0) && (!sp.nlm || !std::memcmp(sp.nlm_p, nlm_p, sizeof(nlm_p)));
+    AfftdnPrep af_prep; bool af_ready = false;
+    const double af_nf = p->fft_nf < 0 ? p->fft_nf : -50.0;
+    if (p->fft_enabled) { afftdn_prepare(h, sr, p->fft_nr, af_nf, p->fft_custom ? p->fft_band_noise : nullptr, &af_prep); af_ready = true; }
     if (head_ready) {
         // jt_pass2_prefetch ran exactly these stages on this input: continue from its result
         sp.pending = false;
@@ -1160,8 +1175,7 @@ extern "C" int jt_pass2(jt_ctx *h, const jt_filter_params *p, jt_analysis *out)
     }
     check_cancel(h);
     if (p->fft_enabled) {
-        double nf = p->fft_nf < 0 ? p->fft_nf : -50.0;
-        run_afftdn(h, cur, nxt, n, sr, p->fft_nr, nf, p->fft_custom ? p->fft_band_noise : nullptr, p->fft_track_noise != 0); advance();
+        run_afftdn(h, cur, nxt, n, sr, p->fft_nr, af_nf, p->fft_custom ? p->fft_band_noise : nullptr, p->fft_track_noise != 0, af_ready ? &af_prep : nullptr); advance();
     }
     check_cancel(h);
     DynParams d; jt_dyn_design(p, sr, &d);

@@ -228,7 +228,9 @@ void jt_r128_finish(const double *bs, int64_t nblocks, int blk, int sr, bool dua
     if (nk400) {
         int gate = clipi(HIST_POS(rel400), 0, HIST_SIZE - 1);
         double isum = 0; uint64_t nint = 0;
-        for (int i = gate; i < HIST_SIZE; ++i) { nint += h400[i]; isum += h400[i] * ENERGY(i / (double)HIST_GRAIN + ABS_THRES); }
+        // (an empty bin adds 0 * e = +0.0 to a non-negative sum, i.e. nothing: only occupied bins pay for their pow() -- a few hundred of
+        //  the 7501; the walk sits on the limiter plan's critical path inside Pass 2)
+        for (int i = gate; i < HIST_SIZE; ++i) if (h400[i]) { nint += h400[i]; isum += h400[i] * ENERGY(i / (double)HIST_GRAIN + ABS_THRES); }
         if (nint) { o->integrated = LOUDNESS(isum / nint); if (dualmono) o->integrated -= pan_law; }
     }
     if (nk3000) {
