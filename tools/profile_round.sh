@@ -15,6 +15,7 @@ timeout 900 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/
 cp $O/fetch/k_counter_collection.csv $O/${tag}_pmc_fetch_size.csv; cp $O/write/k_counter_collection.csv $O/${tag}_pmc_write_size.csv
 python tools/pmc_summary.py $O/${tag}_pmc_fetch_size.csv $O/${tag}_pmc_write_size.csv $O/${tag}_pmc_traffic.json "$git"
 bash tools/pmc_issue.sh > $O/${tag}_pmc_issue.txt 2>&1
+bash tools/pmc_mix.sh $O/${tag}_kernel_stats_60min.csv > $O/${tag}_pmc_mix.txt 2>&1
 bash tools/timeline.sh > $O/${tag}_timeline_one_step.txt 2>&1
 python bench.py > $O/${tag}_bench_60min.json 2> $O/bench.err
 ls -la $O | head -30; tail -3 $O/${tag}_kernel_ms_per_step.txt; head -c 600 $O/${tag}_bench_60min.json
