@@ -336,10 +336,13 @@ func (e *gpuEngine) loadFile(ctx context.Context, path string) (*C.jt_audio_meta
 }
 
 // uploadPCM replaces the ReadFrame -> AVBuffersrcAddFrameFlags feed of Pass 1/2 (frame_processor.go:131-146).  bits / isFloat
-// describe the decoder's native sample format (it selects the band graphs' arithmetic: include/jtgpu.h jt_set_source_format).
-func (e *gpuEngine) uploadPCM(ctx context.Context, pcm []float32, sampleRate, channels, bits int, isFloat bool) error {
+// describe the decoder's native sample format (it selects the band graphs' arithmetic: include/jtgpu.h jt_set_source_format);
+// channelMask is the decoder context's channel layout (AVChannelLayout.u.mask for native-order layouts; 0 when the decoder reports
+// none: libswresample then assumes the default layout of the channel count, and so does the library) -- it selects the row of
+// libswresample's default matrix that aformat=channel_layouts=mono applies (filters.go:607-615).
+func (e *gpuEngine) uploadPCM(ctx context.Context, pcm []float32, sampleRate, channels, bits int, isFloat bool, channelMask uint64) error {
 	frames := len(pcm) / channels
-	if rc := C.jt_upload_pcm(e.h, (*C.float)(unsafe.Pointer(&pcm[0])), C.int64_t(frames), C.int(sampleRate), C.int(channels)); rc != C.JT_OK {
+	if rc := C.jt_upload_pcm_layout(e.h, (*C.float)(unsafe.Pointer(&pcm[0])), C.int64_t(frames), C.int(sampleRate), C.int(channels), C.uint64_t(channelMask)); rc != C.JT_OK {
 		return e.err(ctx, rc, "upload")
 	}
 	f := C.int(0)
@@ -352,8 +355,30 @@ func (e *gpuEngine) uploadPCM(ctx context.Context, pcm []float32, sampleRate, ch
 // analyse replaces collectAnalysisFrames' sweep (analyser.go:538-650): per-decoder-frame sum(x^2) / peak (OnInputFrame,
 // analyser_metrics.go:273-358) and one record per 100 ms ebur128 output frame (OnFrame, analyser.go:621-630), then the interval
 // series exactly as intervalAccumulator builds it.
+//
+// frameSamples is what Reader.ReadFrame delivers per call (it closes the 250 ms intervals, analyser.go:588-600): the caller's own
+// decoder's frame length after uploadPCM, or 0 after loadFile = the file's own cadence as jt_load_audio recorded it (the FLAC
+// stream's block size -- frame by frame when the frames differ in length -- or the WAV demuxer's 4096-byte packets).
 func (e *gpuEngine) analyse(ctx context.Context, frameSamples int, totalFrames int64, sampleRate, channels int) (*C.jt_analysis, []C.jt_interval, error) {
-	nFrames := (totalFrames + int64(frameSamples) - 1) / int64(frameSamples)
+	var lens []C.int32_t
+	fs := C.int(frameSamples)
+	nFrames := int64(0)
+	if frameSamples == 0 {
+		var variable C.int
+		var nf C.int64_t
+		if rc := C.jt_input_frame_layout(e.h, &fs, &variable, &nf, nil, 0); rc != C.JT_OK {
+			return nil, nil, e.err(ctx, rc, "frame layout")
+		}
+		nFrames = int64(nf)
+		if variable != 0 {
+			lens = make([]C.int32_t, nFrames)
+			if rc := C.jt_input_frame_layout(e.h, nil, nil, nil, &lens[0], C.int64_t(nFrames)); rc != C.JT_OK {
+				return nil, nil, e.err(ctx, rc, "frame layout")
+			}
+		}
+	} else {
+		nFrames = (totalFrames + int64(frameSamples) - 1) / int64(frameSamples)
+	}
 	nMeta := totalFrames/int64(sampleRate/10) + 2
 	a := new(C.jt_analysis)
 	ss := make([]C.double, nFrames)
@@ -364,7 +389,11 @@ func (e *gpuEngine) analyse(ctx context.Context, frameSamples int, totalFrames i
 		return nil, nil, e.err(ctx, rc, "pass 1")
 	}
 	iv := make([]C.jt_interval, totalFrames/int64(sampleRate/5)+16)
-	n := C.jt_host_build_intervals(C.int(sampleRate), C.int64_t(totalFrames), C.int(frameSamples), C.int(channels), &ss[0], &pk[0], C.int64_t(nFrames),
+	var lp *C.int32_t
+	if len(lens) > 0 {
+		lp = &lens[0]
+	}
+	n := C.jt_host_build_intervals_v(C.int(sampleRate), C.int64_t(totalFrames), fs, lp, C.int(channels), &ss[0], &pk[0], C.int64_t(nFrames),
 		&meta[0], a.n_frames_meta, 1, &iv[0], C.int64_t(len(iv)))
 	return a, iv[:int(n)], nil
 }
