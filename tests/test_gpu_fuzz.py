@@ -312,6 +312,22 @@ def test_fuzz_flac_200_random_cases(engine, oracle):
     assert not bad, bad
 
 
+# ------------------------------------------------------------------------------------------------ cadence and layouts (tools/fuzz_cadence.py)
+def test_fuzz_cadence_and_layouts_48_random_files(engine, oracle):
+    """Round 6's input leg on random material (a fixed slice of tools/fuzz_cadence.py): 48 files of random container (FLAC with block sizes
+    192 .. 4608, fixed and variable; WAV u8 / s16 / s24 / f32 / f64, plain and WAVE_FORMAT_EXTENSIBLE), rate (22.05 .. 96 kHz), 1 .. 8
+    channels in random layouts, 3 .. 40 s.  Per file: the decoder-frame cadence the library reports = the rule's (FLAC: the stream's
+    frames; WAV: wavdec's 4096-byte packets of whole sample blocks); the interval series of jt_analyse_only(frame_samples = 0) =
+    analyser.go:588-600 on those frames (count, timestamps, per-interval RMS to 1e-9 dB); astats' Min / Max level of the down-mix
+    BIT-identical to the oracle's libswresample matrix for the layout; and for every fourth file the whole job twice (identical bytes) with
+    the landing re-measured by the oracle's ebur128 (0.011 LU).  Bar: 48 of 48."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import fuzz_cadence
+    bad, failures = fuzz_cadence.run(engine, 48, 606, verbose=False)
+    assert bad == 0, failures
+
+
 # ------------------------------------------------------------------------------------------------ handle pool on a random mix (tools/fuzz_pool.py)
 def _wav16(x16, rate, ch):
     payload = x16.astype("<i2").tobytes(); align = 2 * ch
