@@ -286,7 +286,7 @@ int jt_pass4(jt_ctx *h, const jt_limiter_plan *lim, const jt_loudnorm_apply *ap,
 /* ---- input leg: replaces audio.OpenAudioFile + Reader.ReadFrame (reader.go:29-169), which every pass of the reference runs
  * again over the file.  `file` is the whole file image in host memory: FLAC (RFC 9639: any block size, 4..24 bits, 1..8
  * channels, all predictor / residual / stereo modes; an ID3v2 tag in front is skipped) is decoded on the GPU; RIFF/WAVE PCM
- * (u8, s16, s24, s32, f32, f64, WAVE_FORMAT_EXTENSIBLE) is unpacked on the GPU.  Afterwards the handle is in the state
+ * (u8, s16, s24, s32, f32, f64, WAVE_FORMAT_EXTENSIBLE; RF64 / BW64 with their ds64 sizes) is unpacked on the GPU.  Afterwards the handle is in the state
  * jt_upload_pcm_layout() leaves it in — up to eight channels in the file's layout (FLAC: libavcodec's flac_channel_layouts for the
  * channel count; WAVE_FORMAT_EXTENSIBLE: dwChannelMask; plain WAV: the default layout of the channel count), layouts with channels
  * beyond SIDE_RIGHT are refused with JT_E_UNSUPPORTED (jt_op_decode_audio decodes any layout) — (interleaved f32 at the file's rate; integer PCM scaled by 2^(1-bits) exactly as

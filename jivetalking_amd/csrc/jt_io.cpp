@@ -332,10 +332,18 @@ void decode_wav(jt_ctx *h, const uint8_t *file, int64_t len, bool want_i32, bool
     JT_REQUIRE(len >= 12 && !memcmp(file + 8, "WAVE", 4), JT_E_UNSUPPORTED, "wav: not a RIFF/WAVE file");
     int64_t pos = 12; int tag = 0, ch = 0, rate = 0, bits = 0, align = 0; bool have_fmt = false;
     int64_t data_off = -1, data_len = 0;
+    // RF64 / BW64 (EBU Tech 3306; libavformat's wav demuxer reads them too, wavdec.c: the "ds64" chunk): the 32-bit sizes are 0xFFFFFFFF
+    // and the 64-bit ones -- RIFF size, data size, sample count -- sit in a ds64 chunk that must come first
+    const bool rf64 = !memcmp(file, "RF64", 4) || !memcmp(file, "BW64", 4);
+    int64_t ds64_data = -1;
     while (pos + 8 <= len) {
         const uint32_t sz = rd_le32(file + pos + 4);
         const uint8_t *body = file + pos + 8;
-        if (!memcmp(file + pos, "fmt ", 4)) {
+        if (rf64 && !memcmp(file + pos, "ds64", 4)) {
+            JT_REQUIRE(sz >= 24 && pos + 8 + 24 <= len, JT_E_INVAL, "wav: short ds64 chunk");
+            ds64_data = (int64_t)rd_le32(body + 8) | (int64_t)rd_le32(body + 12) << 32;
+            JT_REQUIRE(ds64_data >= 0, JT_E_INVAL, "wav: bad ds64 data size");
+        } else if (!memcmp(file + pos, "fmt ", 4)) {
             JT_REQUIRE(sz >= 16 && pos + 8 + 16 <= len, JT_E_INVAL, "wav: short fmt chunk");
             tag = (int)rd_le16(body); ch = (int)rd_le16(body + 2); rate = (int)rd_le32(body + 4); align = (int)rd_le16(body + 12); bits = (int)rd_le16(body + 14);
             if (tag == 0xfffe) { JT_REQUIRE(sz >= 40 && pos + 8 + 40 <= len, JT_E_INVAL, "wav: short extensible fmt chunk"); tag = (int)rd_le16(body + 24); out->ch_mask = rd_le32(body + 20); }
@@ -343,7 +351,8 @@ void decode_wav(jt_ctx *h, const uint8_t *file, int64_t len, bool want_i32, bool
         } else if (!memcmp(file + pos, "data", 4)) {
             data_off = pos + 8;
             data_len = std::min<int64_t>((int64_t)sz, len - data_off);      // a streamed writer may leave 0xFFFFFFFF / short sizes
-            if (sz == 0xffffffffu || sz == 0) data_len = len - data_off;
+            if (sz == 0xffffffffu && rf64 && ds64_data >= 0) data_len = std::min<int64_t>(ds64_data, len - data_off);
+            else if (sz == 0xffffffffu || sz == 0) data_len = len - data_off;
             break;
         }
         pos += 8 + (int64_t)sz + (sz & 1);
@@ -389,7 +398,7 @@ void decode_audio(jt_ctx *h, const uint8_t *file, int64_t len, bool want_i32, bo
         JT_REQUIRE(start + 4 < len, JT_E_INVAL, "audio: ID3 tag longer than the file");
     }
     if (!memcmp(file + start, "fLaC", 4)) decode_flac(h, file, len, start, want_i32, want_f32, out);
-    else if (!memcmp(file, "RIFF", 4)) decode_wav(h, file, len, want_i32, want_f32, out);
+    else if (!memcmp(file, "RIFF", 4) || !memcmp(file, "RF64", 4) || !memcmp(file, "BW64", 4)) decode_wav(h, file, len, want_i32, want_f32, out);
     else throw JtError{JT_E_UNSUPPORTED, "audio: only FLAC and RIFF/WAVE inputs are decoded on the device"};
     JT_HIP(hipEventRecord(h->ev1, h->stream));
     JT_HIP(jt_stream_sync(h, h->stream));

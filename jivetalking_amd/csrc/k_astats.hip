@@ -122,8 +122,7 @@ k_as_runs(const float *__restrict__ x, int64_t n, const AsPartial *__restrict__ 
     const float gmin = (float)gmn, gmax = (float)gmx;
     double c0 = 0, r0 = 0, c1 = 0, r1 = 0;
     const int64_t stride = (int64_t)gridDim.x * AS_T;
-    for (int64_t i = (int64_t)blockIdx.x * AS_T + threadIdx.x; i < n; i += stride) {
-        const float v = x[i];
+    auto look = [&](int64_t i, float v) {
         if (v == gmin) {
             c0 += 1;
             if (i == 0 || x[i - 1] != gmin) { int64_t j = i + 1; while (j < n && x[j] == gmin) ++j; double len = (double)(j - i); r0 += len * len; }
@@ -132,7 +131,18 @@ k_as_runs(const float *__restrict__ x, int64_t n, const AsPartial *__restrict__ 
             c1 += 1;
             if (i == 0 || x[i - 1] != gmax) { int64_t j = i + 1; while (j < n && x[j] == gmax) ++j; double len = (double)(j - i); r1 += len * len; }
         }
+    };
+    // (round 6) eight loads of a thread in flight per trip: a sweep that almost never finds anything was 5 % active and 91 % waiting with one.
+    // Counts and squared run lengths are integers in doubles: the sums are exact in any order
+    int64_t i = (int64_t)blockIdx.x * AS_T + threadIdx.x;
+    for (; i + 7 * stride < n; i += 8 * stride) {
+        float v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = x[i + k * stride];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) if (v[k] == gmin || v[k] == gmax) look(i + k * stride, v[k]);
     }
+    for (; i < n; i += stride) look(i, x[i]);
     c0 = wsum(c0); r0 = wsum(r0); c1 = wsum(c1); r1 = wsum(r1);
     if ((threadIdx.x & 63) == 0) sp[threadIdx.x >> 6] = AsRuns{c0, r0, c1, r1};
     __syncthreads();
@@ -209,7 +219,24 @@ k_nf_blockmax(const float *__restrict__ x, int64_t n, float *__restrict__ bm, in
 {
     const int lane = threadIdx.x & 63;
     const int64_t w = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 6, nw = ((int64_t)gridDim.x * 256) >> 6;
-    for (int64_t b = w; b < nblocks; b += nw) {
+    // (round 6) four blocks of a wave per trip, their loads in flight together: one load, six dependent shuffles and a store per trip left
+    // the sweep 11 % active and 85 % waiting.  Maxima: the same values whatever the order
+    int64_t b = w;
+    for (; b + 3 * nw < nblocks; b += 4 * nw) {
+        float v[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { const int64_t i = (b + k * nw) * 64 + lane; v[k] = i < n ? fabsf(x[i]) : 0.f; }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v[k] = fmaxf(v[k], __shfl_xor(v[k], o, 64));
+        }
+        if (lane == 0) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) bm[b + k * nw] = v[k];
+        }
+    }
+    for (; b < nblocks; b += nw) {
         const int64_t i = b * 64 + lane;
         float v = i < n ? fabsf(x[i]) : 0.f;
         for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));

@@ -3,6 +3,7 @@ decoder.  FLAC is lossless, so the bar is bit-exact PCM after decode, every head
 that describes the stream truthfully (rate, channels, depth, total samples, min/max frame size, MD5 of the PCM) with the
 reference's fixed 4096-sample blocks (encoder.go:93-100)."""
 import hashlib
+import struct
 import os
 
 import numpy as np
@@ -260,6 +261,24 @@ def test_wav_formats(engine):
     with pytest.raises(L.JtError) as ei:
         engine.op_decode_audio(_wav(2, 4, 1, 8000, bytes(100)))          # ADPCM
     assert ei.value.code == L.JT_E_UNSUPPORTED
+
+
+def test_rf64_files_are_read_with_their_ds64_sizes(engine):
+    """RF64 / BW64 (EBU Tech 3306: what a recorder writes once a WAV passes 4 GB; libavformat's wav demuxer reads them, wavdec.c): magic
+    "RF64", every 32-bit size 0xFFFFFFFF, the real data size in the ds64 chunk -- and trailing chunks BEHIND the data must not be taken
+    for samples.  Same samples, same cadence (the wav demuxer's 4096-byte packets) as the RIFF form of the file."""
+    rng = np.random.default_rng(77)
+    x = (rng.standard_normal(20000 * 2) * 0.1).astype("<f4")
+    payload = x.tobytes()
+    fmt = struct.pack("<HHIIHH", 3, 2, 48000, 48000 * 8, 8, 32)
+    ds64 = struct.pack("<QQQI", 0, len(payload), 20000, 0)
+    tail = b"LIST" + struct.pack("<I", 8) + b"INFOxxxx"                       # a chunk behind the data
+    for magic in (b"RF64", b"BW64"):
+        img = (magic + struct.pack("<I", 0xFFFFFFFF) + b"WAVE" + b"ds64" + struct.pack("<I", len(ds64)) + ds64 +
+               b"fmt " + struct.pack("<I", len(fmt)) + fmt + b"data" + struct.pack("<I", 0xFFFFFFFF) + payload + tail)
+        _, f32, meta = engine.op_decode_audio(img, want_i32=False)
+        assert (meta["format"], meta["channels"], meta["frames"], meta["is_float"], meta["decoder_frame_samples"]) == (2, 2, 20000, 1, 512)
+        assert np.array_equal(f32.reshape(-1), x)
 
 
 def test_layouts_beyond_the_restated_matrix_are_refused_not_averaged(engine, oracle):
