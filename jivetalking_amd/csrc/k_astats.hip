@@ -215,9 +215,10 @@ __device__ inline float wave_prefix_max(float v)
 // their (q-1)-wide running maxima are two tiny pre-passes; the main kernel is three DPP scans and three lane permutes per
 // 64 outputs.  Maxima are order independent, so the result equals the sequential filter's.
 __global__ void __launch_bounds__(256)
-k_nf_blockmax(const float *__restrict__ x, int64_t n, float *__restrict__ bm, int64_t nblocks)
+k_nf_blockmax(const float *__restrict__ x, int64_t n, float *__restrict__ bm, int64_t nblocks, unsigned *__restrict__ ub_min)
 {
     const int lane = threadIdx.x & 63;
+    if (blockIdx.x == 0 && threadIdx.x == 0) *ub_min = 0x7f800000u;          // +inf: k_nf_runmax (next on this stream) takes minima into it
     const int64_t w = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 6, nw = ((int64_t)gridDim.x * 256) >> 6;
     // (round 6) four blocks of a wave per trip, their loads in flight together: one load, six dependent shuffles and a store per trip left
     // the sweep 11 % active and 85 % waiting.  Maxima: the same values whatever the order
@@ -244,17 +245,30 @@ k_nf_blockmax(const float *__restrict__ x, int64_t n, float *__restrict__ bm, in
     }
 }
 __global__ void __launch_bounds__(256)
-k_nf_runmax(const float *__restrict__ bm, float *__restrict__ rq, int64_t nblocks, int width)
+k_nf_runmax(const float *__restrict__ bm, float *__restrict__ rq, int64_t nblocks, int width, int64_t nstartblocks, unsigned *__restrict__ ub_min)
 {
+    // Round 6, branch and bound for the noise floor (the MINIMUM over all 50 ms windows of the window's peak, and how many windows reach it):
+    // every window that starts in block b lies inside blocks b .. b + width + 2, so UB(b) = max bm[b .. b + width + 2] bounds its peak from
+    // above, and the minimum of UB over the start blocks bounds the noise floor from above -- from block maxima alone.  k_nf_main then
+    // skips every start block whose windows all contain a whole block louder than that (rq[b + 1] > bound: they can neither be the
+    // minimum nor tie with it) without touching its samples.  Exact: a window that reaches the minimum is never skipped.
     const int64_t b = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (b >= nblocks) return;
-    float m = 0.f;
-    for (int k = 0; k < width && b + k < nblocks; ++k) m = fmaxf(m, bm[b + k]);
-    rq[b] = m;
+    float ub = __uint_as_float(0x7f800000u);
+    if (b < nblocks) {
+        float m = 0.f;
+        for (int k = 0; k < width && b + k < nblocks; ++k) m = fmaxf(m, bm[b + k]);
+        rq[b] = m;
+        if (b < nstartblocks) {
+            for (int k = width; k < width + 3 && b + k < nblocks; ++k) m = fmaxf(m, bm[b + k]);
+            ub = m;
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1) ub = fminf(ub, __shfl_xor(ub, o, 64));
+    if ((threadIdx.x & 63) == 0 && ub < __uint_as_float(0x7f800000u)) atomicMin(ub_min, __float_as_uint(ub));      // (non-negative floats order like their bits)
 }
 __global__ void __launch_bounds__(256)
 k_nf_main(const float *__restrict__ x, int64_t n, int tc, const float *__restrict__ bm, const float *__restrict__ rq, int64_t nstartblocks,
-          AsNF *__restrict__ part)
+          AsNF *__restrict__ part, const unsigned *__restrict__ ub_min)
 {
     __shared__ AsNF sp[4];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -264,7 +278,16 @@ k_nf_main(const float *__restrict__ x, int64_t n, int tc, const float *__restric
     // a wave takes NF_U consecutive start blocks at a time: their end blocks overlap (block bs+q+1 of one is bs+q of the next), so
     // 2 NF_U + 1 loads are in flight instead of 3 and each end block's prefix scan is shared
     constexpr int NF_U = 4;
+    const float bound = ub_min ? __uint_as_float(*ub_min) : __uint_as_float(0x7f800000u);
     for (int64_t b0 = w0 * NF_U; b0 < nstartblocks; b0 += nw * NF_U) {
+        if (q >= 2 && ub_min) {
+            // (wave-uniform) every start block of the group holds, in each of its windows, a whole block louder than the bound: nothing here
+            // can be the minimum or tie with it
+            bool skip = true;
+#pragma unroll
+            for (int u = 0; u < NF_U; ++u) if (b0 + u < nstartblocks && !(rq[b0 + u + 1] > bound)) skip = false;
+            if (skip) continue;
+        }
         float xr[NF_U], xe[NF_U + 1], rqv[NF_U], bmv[NF_U];
 #pragma unroll
         for (int u = 0; u < NF_U; ++u) {
@@ -507,11 +530,12 @@ void jt_astats_enqueue(jt_ctx *h, const float *x, int64_t n, int sr, AstatsJob *
             const int64_t nblocks = (n + 63) / 64 + 2;
             const int q = (tc - 1) >> 6;
             float *d_bm = reinterpret_cast<float *>(h->as_take(sizeof(float) * 2 * (size_t)nblocks)), *d_rq = d_bm + nblocks;
+            unsigned *d_ub = reinterpret_cast<unsigned *>(h->as_take(256));
             const int64_t nstart = (n - tc + 1 + 63) / 64;                       // start blocks that contain a complete window start
             nf_parts = (int)std::min<int64_t>((nstart + 15) / 16, nparts);                 // 4 waves x 4 start blocks per pass
-            hipLaunchKernelGGL(k_nf_blockmax, dim3((unsigned)std::min<int64_t>((nblocks + 3) / 4, 4096)), dim3(256), 0, sB, x, n, d_bm, nblocks);
-            hipLaunchKernelGGL(k_nf_runmax, dim3((unsigned)((nblocks + 255) / 256)), dim3(256), 0, sB, d_bm, d_rq, nblocks, std::max(q - 1, 0));
-            hipLaunchKernelGGL(k_nf_main, dim3(nf_parts), dim3(256), 0, sB, x, n, tc, d_bm, d_rq, nstart, d_nf);
+            hipLaunchKernelGGL(k_nf_blockmax, dim3((unsigned)std::min<int64_t>((nblocks + 3) / 4, 4096)), dim3(256), 0, sB, x, n, d_bm, nblocks, d_ub);
+            hipLaunchKernelGGL(k_nf_runmax, dim3((unsigned)((nblocks + 255) / 256)), dim3(256), 0, sB, d_bm, d_rq, nblocks, std::max(q - 1, 0), nstart, d_ub);
+            hipLaunchKernelGGL(k_nf_main, dim3(nf_parts), dim3(256), 0, sB, x, n, tc, d_bm, d_rq, nstart, d_nf, h->opts.nf_unpruned ? nullptr : d_ub);
         } else {                                   // very low sample rates: van Herk arrays in HBM
             h->as_g.ensure((size_t)n); h->as_p.ensure((size_t)n);
             const int64_t nb = (n + tc - 1) / tc;

@@ -318,3 +318,30 @@ def test_pool_numa_binding_changes_no_byte_and_restores_the_callers_affinity(eng
     finally:
         lib.jt_set_option(None, b"pool_numa", b"1")
         shutil.rmtree(d, ignore_errors=True)
+
+
+def test_noise_floor_branch_and_bound_equals_the_exhaustive_sweep(engine, oracle):
+    """astats' Noise_floor / Noise_floor_count (af_astats.c: the minimum over all 50 ms windows of the window's peak, and how many windows
+    reach it) by branch and bound, round 6: an upper bound of the minimum from block maxima alone (k_nf_runmax), then k_nf_main skips every
+    start block whose windows all contain a whole block louder than the bound.  Exact by construction -- held here against the exhaustive
+    sweep (option nf_unpruned) and the oracle on speech with pauses, digital silence in the middle (ties: thousands of windows at 0),
+    a constant signal (every window ties), a quiet tail, full-scale noise, and lengths around the window and block sizes."""
+    from conftest import options
+    rng = np.random.default_rng(665)
+    sr = 48000
+    sp = np.asarray(synth.speech_like(30.0, sr, seed=665), np.float32)
+    z = sp.copy(); z[7 * sr: 9 * sr] = 0.0
+    tail = sp.copy(); tail[-3 * sr:] *= 1e-3
+    cases = [("speech", sp), ("digital silence inside", z), ("constant", np.full(5 * sr, 0.25, np.float32)), ("quiet tail", tail),
+             ("noise", rng.uniform(-1, 1, 4 * sr).astype(np.float32)), ("one window", sp[: 2400]), ("window + 1", sp[: 2401]),
+             ("3 blocks", sp[: 2400 + 129]), ("44.1 kHz", np.asarray(synth.speech_like(12.0, 44100, seed=666), np.float32))]
+    for name, x in cases:
+        rate = 44100 if name == "44.1 kHz" else sr
+        a = engine.op_astats(x, rate)
+        with options(engine, nf_unpruned=True):
+            b = engine.op_astats(x, rate)
+        assert (a["noise_floor"], a["noise_floor_count"]) == (b["noise_floor"], b["noise_floor_count"]), (name, a["noise_floor"], b["noise_floor"], a["noise_floor_count"], b["noise_floor_count"])
+        ref = oracle.astats(x.astype(np.float64), rate)
+        assert a["noise_floor_count"] == ref["noise_floor_count"], (name, a["noise_floor_count"], ref["noise_floor_count"])
+        if np.isfinite(ref["noise_floor_db"]):
+            assert abs(a["noise_floor"] - ref["noise_floor_db"]) <= 1e-9 * max(1.0, abs(ref["noise_floor_db"])), (name, a["noise_floor"], ref["noise_floor_db"])
