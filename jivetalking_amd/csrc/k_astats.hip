@@ -220,24 +220,31 @@ k_nf_blockmax(const float *__restrict__ x, int64_t n, float *__restrict__ bm, in
     const int lane = threadIdx.x & 63;
     if (blockIdx.x == 0 && threadIdx.x == 0) *ub_min = 0x7f800000u;          // +inf: k_nf_runmax (next on this stream) takes minima into it
     const int64_t w = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 6, nw = ((int64_t)gridDim.x * 256) >> 6;
-    // (round 6) four blocks of a wave per trip, their loads in flight together: one load, six dependent shuffles and a store per trip left
-    // the sweep 11 % active and 85 % waiting.  Maxima: the same values whatever the order
-    int64_t b = w;
-    for (; b + 3 * nw < nblocks; b += 4 * nw) {
-        float v[4];
+    // (round 6) a lane takes FOUR consecutive samples (one 16-byte load), a wave 256 = four blocks, two such groups per trip: a block's
+    // maximum is a 4-step exchange inside its 16 lanes.  One 4-byte load, six dependent shuffles and a store per block left the sweep
+    // 11 % active and 85 % waiting.  Maxima: the same values whatever the order.
+    const int64_t ngroups = (nblocks + 3) / 4;
+    if ((reinterpret_cast<uintptr_t>(x) & 15) == 0) {
+        for (int64_t g = w; g < ngroups; g += 2 * nw) {
+            float4 v[2];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) { const int64_t i = (b + k * nw) * 64 + lane; v[k] = i < n ? fabsf(x[i]) : 0.f; }
+            for (int k = 0; k < 2; ++k) {
+                const int64_t i = (g + k * nw) * 256 + 4 * lane;
+                if (g + k * nw < ngroups && i + 3 < n) v[k] = *reinterpret_cast<const float4 *>(x + i);
+                else { v[k].x = i < n ? x[i] : 0.f; v[k].y = i + 1 < n ? x[i + 1] : 0.f; v[k].z = i + 2 < n ? x[i + 2] : 0.f; v[k].w = 0.f; if (g + k * nw >= ngroups) v[k].x = v[k].y = v[k].z = 0.f; }
+            }
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
+            for (int k = 0; k < 2; ++k) {
+                float m = fmaxf(fmaxf(fabsf(v[k].x), fabsf(v[k].y)), fmaxf(fabsf(v[k].z), fabsf(v[k].w)));
 #pragma unroll
-            for (int k = 0; k < 4; ++k) v[k] = fmaxf(v[k], __shfl_xor(v[k], o, 64));
+                for (int o = 8; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+                const int64_t blk = (g + k * nw) * 4 + (lane >> 4);
+                if ((lane & 15) == 0 && g + k * nw < ngroups && blk < nblocks) bm[blk] = m;
+            }
         }
-        if (lane == 0) {
-#pragma unroll
-            for (int k = 0; k < 4; ++k) bm[b + k * nw] = v[k];
-        }
+        return;
     }
-    for (; b < nblocks; b += nw) {
+    for (int64_t b = w; b < nblocks; b += nw) {
         const int64_t i = b * 64 + lane;
         float v = i < n ? fabsf(x[i]) : 0.f;
         for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
@@ -252,19 +259,30 @@ k_nf_runmax(const float *__restrict__ bm, float *__restrict__ rq, int64_t nblock
     // above, and the minimum of UB over the start blocks bounds the noise floor from above -- from block maxima alone.  k_nf_main then
     // skips every start block whose windows all contain a whole block louder than that (rq[b + 1] > bound: they can neither be the
     // minimum nor tie with it) without touching its samples.  Exact: a window that reaches the minimum is never skipped.
-    const int64_t b = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    // the workgroup's 256 + width + 3 block maxima through LDS (one coalesced read; a thread then walks its width + 3 neighbours there: read
+    // straight from memory, the walk's 39 dependent L2 round trips made this the longest kernel of the chain once k_nf_main was pruned).
+    // Block maxima are >= 0, so the zeros behind the last block change no maximum.
+    extern __shared__ float nf_tile[];
+    const int64_t b0 = (int64_t)blockIdx.x * 256;
+    const int span = 256 + width + 3;
+    for (int i = threadIdx.x; i < span; i += 256) { const int64_t g = b0 + i; nf_tile[i] = g < nblocks ? bm[g] : 0.f; }
+    __syncthreads();
+    const int64_t b = b0 + threadIdx.x;
     float ub = __uint_as_float(0x7f800000u);
     if (b < nblocks) {
+        const float *t = nf_tile + threadIdx.x;
         float m = 0.f;
-        for (int k = 0; k < width && b + k < nblocks; ++k) m = fmaxf(m, bm[b + k]);
+        for (int k = 0; k < width; ++k) m = fmaxf(m, t[k]);
         rq[b] = m;
         if (b < nstartblocks) {
-            for (int k = width; k < width + 3 && b + k < nblocks; ++k) m = fmaxf(m, bm[b + k]);
+            for (int k = width; k < width + 3; ++k) m = fmaxf(m, t[k]);
             ub = m;
         }
     }
     for (int o = 32; o > 0; o >>= 1) ub = fminf(ub, __shfl_xor(ub, o, 64));
-    if ((threadIdx.x & 63) == 0 && ub < __uint_as_float(0x7f800000u)) atomicMin(ub_min, __float_as_uint(ub));      // (non-negative floats order like their bits)
+    // (non-negative floats order like their bits.)  A wave that cannot lower the bound does not touch it: 42 000 atomics on one word were
+    // most of this kernel's time; after the first few hundred waves hardly any improves the minimum
+    if ((threadIdx.x & 63) == 0 && ub < __uint_as_float(__hip_atomic_load(ub_min, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) atomicMin(ub_min, __float_as_uint(ub));
 }
 __global__ void __launch_bounds__(256)
 k_nf_main(const float *__restrict__ x, int64_t n, int tc, const float *__restrict__ bm, const float *__restrict__ rq, int64_t nstartblocks,
@@ -534,7 +552,7 @@ void jt_astats_enqueue(jt_ctx *h, const float *x, int64_t n, int sr, AstatsJob *
             const int64_t nstart = (n - tc + 1 + 63) / 64;                       // start blocks that contain a complete window start
             nf_parts = (int)std::min<int64_t>((nstart + 15) / 16, nparts);                 // 4 waves x 4 start blocks per pass
             hipLaunchKernelGGL(k_nf_blockmax, dim3((unsigned)std::min<int64_t>((nblocks + 3) / 4, 4096)), dim3(256), 0, sB, x, n, d_bm, nblocks, d_ub);
-            hipLaunchKernelGGL(k_nf_runmax, dim3((unsigned)((nblocks + 255) / 256)), dim3(256), 0, sB, d_bm, d_rq, nblocks, std::max(q - 1, 0), nstart, d_ub);
+            hipLaunchKernelGGL(k_nf_runmax, dim3((unsigned)((nblocks + 255) / 256)), dim3(256), sizeof(float) * (size_t)(256 + std::max(q - 1, 0) + 3), sB, d_bm, d_rq, nblocks, std::max(q - 1, 0), nstart, d_ub);
             hipLaunchKernelGGL(k_nf_main, dim3(nf_parts), dim3(256), 0, sB, x, n, tc, d_bm, d_rq, nstart, d_nf, h->opts.nf_unpruned ? nullptr : d_ub);
         } else {                                   // very low sample rates: van Herk arrays in HBM
             h->as_g.ensure((size_t)n); h->as_p.ensure((size_t)n);
