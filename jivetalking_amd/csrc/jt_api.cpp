@@ -538,7 +538,10 @@ static void analysis_enqueue(jt_ctx *h, const float *x, int64_t n, int sr, bool 
         if (!f) JT_HIP(hipEventRecord(h->ev_chain[6], a2));       // (the exponential-average chain of astats follows on this stream)
     }
     if (J->want_astats) {
-        jt_astats_enqueue(h, x, n, sr, &J->as, a0, a_nf, a2, nullptr, J->astats_levels_only);
+        // astats' exponential-average chain (k_as_zs -> k_as_sigma) rides behind the REDUCE chain (round 6): behind aspectralstats, the
+        // longest kernel of an analysis, it made that stream the last to end in Pass 1 and in the final analysis (2.2 + 0.2 + 0.2 ms against
+        // 1.3 + 0.3 for the reduce chain); option as_avg_behind_spec = the old place.  The same launches, another queue
+        jt_astats_enqueue(h, x, n, sr, &J->as, a0, a_nf, h->opts.as_avg_behind_spec ? a2 : a0, nullptr, J->astats_levels_only);
         if (a_nf != a1) { JT_HIP(hipEventRecord(h->ev_nf, a_nf)); JT_HIP(hipStreamWaitEvent(a1, h->ev_nf, 0)); }      // (joined and waited for through aux[1])
     }
     if (!f) JT_HIP(hipEventRecord(h->ev_chain[4], a2));

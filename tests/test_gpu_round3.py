@@ -380,7 +380,10 @@ def test_host_arithmetic_staged_behind_the_analysis_chains_reports_the_same_numb
         return [C.string_at(C.addressof(p), C.sizeof(p)) for p in parts] + [engine.download_s16(4).tobytes()]
     ref = run()
     # (region_full_astats: the regions' astats with all its chains instead of the one sweep their three reported fields need)
-    for env in ({"no_staged_finish": "1"}, {"region_rot": "0"}, {"region_rot": "3", "no_staged_finish": "1"}, {"region_full_astats": "1"}):
+    # (round 6: the early head's biquads beside Pass 1's analysis, astats' exponential-average chain behind its reduce chain, the noise
+    #  floor by branch and bound -- schedule / pruning only: every measurement and every delivered byte the same without them)
+    for env in ({"no_staged_finish": "1"}, {"region_rot": "0"}, {"region_rot": "3", "no_staged_finish": "1"}, {"region_full_astats": "1"},
+                {"no_early_biquad": "1"}, {"as_avg_behind_spec": "1"}, {"nf_unpruned": "1"}, {"no_early_biquad": "1", "as_avg_behind_spec": "1", "nf_unpruned": "1"}):
         with options(engine, **env):
             got = run()
         assert got == ref, env
