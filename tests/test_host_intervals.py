@@ -92,3 +92,57 @@ def test_metadata_quantisation_matches_printf(lib):
         assert iv[i].momentary_lufs == w["m"] / w["cnt"]
         for k in L.SPECTRAL_KEYS:
             assert getattr(iv[i].spectral, k) == w["sp"][k] / w["cnt"]
+
+
+# ---------------------------------------------------------------- decoder frames of different lengths (round 6)
+def _rule(frame_lens, sr):
+    """analyser.go:588-600 on frame lengths: [(interval timestamp, samples in it)]"""
+    out = []; start = 0; processed = 0; acc = 0
+    for nb in frame_lens:
+        t = int(float(processed) / float(sr) * 1e9)
+        processed += int(nb); acc += int(nb)
+        if t - start >= 250_000_000:
+            out.append((start, acc)); start = t; acc = 0
+    if acc > 0:
+        out.append((start, acc))
+    return out
+
+
+def _build_v(lib, sr, lens, F, ch, ss, pk):
+    n = int(np.sum(lens)) if lens is not None else None
+    out = (H.Interval * 4096)()
+    la = None if lens is None else np.ascontiguousarray(lens, np.int32)
+    k = lib.jt_host_build_intervals_v(sr, C.c_int64(n), F, None if la is None else la.ctypes.data_as(C.POINTER(C.c_int32)), ch,
+                                      ss.ctypes.data_as(C.POINTER(C.c_double)), pk.ctypes.data_as(C.POINTER(C.c_double)), C.c_int64(ss.size),
+                                      (L.FrameMeta * 0)(), C.c_int64(0), 0, out, C.c_int64(len(out)))
+    return [out[i] for i in range(k)]
+
+
+@pytest.mark.parametrize("sr,pattern", [(48000, (4096, 2048)), (44100, (1152, 576, 4608)), (96000, (16, 4096, 192)), (44100, (1024,))])
+def test_intervals_from_frames_of_different_lengths(lib, sr, pattern):
+    """jt_host_build_intervals_v (a variable-blocksize FLAC stream: analyser.go:592 reads every frame's own NbSamples): interval count,
+    timestamps and the samples each interval holds follow the rule frame by frame; with all lengths equal it is jt_host_build_intervals."""
+    rng = np.random.default_rng(sr + len(pattern))
+    lens = []
+    while sum(lens) < sr * 20:
+        lens.append(int(pattern[len(lens) % len(pattern)]))
+    lens[-1] = max(1, lens[-1] - 7)                                    # (a short last frame)
+    lens = np.asarray(lens, np.int32)
+    amp = rng.uniform(0.01, 0.5, lens.size)
+    ss = amp * amp * lens; pk = amp.copy()                             # a constant |x| = amp per frame
+    iv = _build_v(lib, sr, lens, int(lens.max()), 1, ss, pk)
+    want = _rule(lens.tolist(), sr)
+    assert [i.timestamp_ns for i in iv] == [w[0] for w in want]
+    pos = 0; f = 0
+    for i, (_, cnt) in enumerate(want):
+        e = 0.0; n = 0; p = 0.0
+        while n < cnt:
+            e += ss[f]; n += int(lens[f]); p = max(p, pk[f]); f += 1
+        assert n == cnt
+        rms = math.sqrt(e / n)
+        assert abs(iv[i].rms_level - (-120.0 if rms < 1e-5 else 20 * math.log10(rms))) < 1e-9
+        assert abs(iv[i].peak_level - 20 * math.log10(p)) < 1e-9
+    if len(pattern) == 1:
+        n = int(lens.sum()); F = pattern[0]
+        same = build(lib, sr, n, F, 1, ss, pk, (L.FrameMeta * 0)(), 0)
+        assert [(a.timestamp_ns, a.rms_level, a.peak_level) for a in same] == [(a.timestamp_ns, a.rms_level, a.peak_level) for a in iv]

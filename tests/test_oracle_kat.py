@@ -317,3 +317,50 @@ def test_flac_format_coverage_roundtrips(oracle):
                 le = x.astype("<i4").tobytes() if bps > 24 else b"".join(
                     x.astype("<i4").reshape(-1, 1).view(np.uint8)[:, : (bps + 7) // 8].tobytes() for _ in (0,))
                 assert bytes(info.md5_stored) == bytes(info.md5_decoded) == hashlib.md5(le).digest()
+
+
+# ---------------------------------------------------------------- libswresample's default rematrix row for a mono output (round 6)
+def test_downmix_matrix_rows_known_answers():
+    """orc_downmix_coeffs against the row swr_build_matrix2 builds for a FRONT_CENTER output with the default mix levels (center =
+    surround = 1/sqrt 2, LFE = 0), worked by hand from libswresample/rematrix.c: FL / FR 1/sqrt 2 ("unaccounted & AV_CH_LAYOUT_STEREO"),
+    FC 1 (identity; center_mix_level * sqrt 2 when FL / FR are there), back / side / back-centre surround_mix_level * 1/sqrt 2 = 0.5,
+    front-of-centre 1/sqrt 2, LFE 0; av_channel_layout_default for sources without a layout; auto_matrix's normalisation (integer
+    formats: the row divided by the sum of its coefficients)."""
+    from oracle import orc
+    r = 0.7071067811865476
+    known = {
+        (1, 0x4): [1.0],
+        (2, 0x3): [r, r],
+        (3, 0x7): [r, r, 1.0],                                 # (FC: M_SQRT1_2 * sqrt(2) = 1 + 2.2e-16 in double, 1.0f as the float coefficient)
+        (3, 0): [r, r, 0.0],                                   # no layout -> 2.1 (FL FR LFE)
+        (4, 0x33): [r, r, 0.5, 0.5],                           # quad
+        (4, 0): [r, r, 1.0, 0.5],                              # -> 4.0 (FL FR FC BC)
+        (5, 0x607): [r, r, 1.0, 0.5, 0.5],                     # 5.0(side)
+        (6, 0x3F): [r, r, 1.0, 0.0, 0.5, 0.5],                 # 5.1 (back)
+        (6, 0): [r, r, 1.0, 0.0, 0.5, 0.5],
+        (7, 0x70F): [r, r, 1.0, 0.0, 0.5, 0.5, 0.5],           # 6.1: FL FR FC LFE BC SL SR
+        (8, 0x63F): [r, r, 1.0, 0.0, 0.5, 0.5, 0.5, 0.5],      # 7.1
+        (8, 0xFF): [r, r, 1.0, 0.0, 0.5, 0.5, r, r],           # 7.1(wide): FLC / FRC
+    }
+    for (ch, mask), want in known.items():
+        got = orc.downmix_coeffs(ch, mask)
+        assert np.allclose(got, want, rtol=0, atol=3e-16), (ch, hex(mask), got)
+        norm = orc.downmix_coeffs(ch, mask, True)
+        s = float(np.sum(np.abs(want)))
+        assert np.allclose(norm, np.asarray(want) / (s if s > 1.0 else 1.0), rtol=0, atol=3e-16), (ch, hex(mask), norm)
+    for ch, mask in ((3, 0x804), (3, 0x3), (9, 0)):             # a top channel, a mask that does not match the count, too many channels
+        with pytest.raises(ValueError):
+            orc.downmix_coeffs(ch, mask)
+    # the generic loop on a known frame: 5.1, float graph (unnormalised, float products and sums in channel order)
+    x = np.array([0.25, -0.5, 0.125, 0.9, 0.0625, -0.03125], np.float32)
+    want = np.float32(0.0)
+    for v, c in zip(x, [r, r, 1.0, 0.0, 0.5, 0.5]):
+        if c:
+            want = np.float32(want + np.float32(np.float32(v) * np.float32(c)))
+    assert orc.downmix_layout(x, 6, 0x3F, 0)[0] == want
+    # S16P: integer products with lrintf(coefficient / sum * 32768), (v + 16384) >> 15
+    xi = (np.array([8192, -16384, 4096, 30000, 2048, -1024]) / 32768.0).astype(np.float32)
+    s = 2 * r + 1.0 + 0.5 + 0.5
+    ci = [int(np.rint(np.float32(c / s * 32768))) for c in (r, r, 1.0, 0.5, 0.5)]
+    v = 8192 * ci[0] - 16384 * ci[1] + 4096 * ci[2] + 2048 * ci[3] - 1024 * ci[4]
+    assert orc.downmix_layout(xi, 6, 0x3F, 1)[0] == np.float32(((v + 16384) >> 15) / 32768.0)
