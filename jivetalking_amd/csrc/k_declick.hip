@@ -56,7 +56,9 @@ struct DkSplit {
     int xcd;                       // 1: the front launches hand windows out per XCD (contiguous eighths of the file)
     double *r;                     // [nwindows * 64] biased autocorrelation r[0 .. AR] (MODE 2 -> k_dk_levinson)
     double *ac;                    // [nwindows * 64] AR polynomial k[0 .. AR], zero padded to 64 taps; ac[w * 64 + 63] = sigma_e
+    unsigned *hist;                // [2][DK_HIST] windows per flagged-sample count of the two lists (k_dk_sort_*: longest window first)
 };
+constexpr int DK_HIST = 520;      // counts 0 .. 513 used (the solvers' capacity is 512 flagged samples)
 
 __device__ inline double dk_ld(const double *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
@@ -1027,6 +1029,7 @@ k_adeclick_fast(const double *__restrict__ in, double *__restrict__ out, int64_t
                 if (lane == 0) {
                     S.F[w] = F;
                     (wide ? S.list64 : S.list32)[lslot_] = (int)w;
+                    atomicAdd(&S.hist[(wide ? DK_HIST : 0) + min(F, DK_HIST - 1)], 1u);
                 }
                 DKF_MARK(4)
                 continue;
@@ -1252,15 +1255,25 @@ k_dk_levinson(const double *__restrict__ rin, double *__restrict__ acout, int64_
 // 1/d = reciprocal + two Newton steps), so the repaired samples are bit-identical to that kernel's.
 __device__ inline double dk_group0(double v, int q, bool two)
 {
-#ifndef JT_DK_NO_SWIZZLE
-    // two groups of 32 lanes: ds_swizzle in bit-mask mode with and_mask = 0 hands every lane the value of lane 0 of its group of 32
-    // (two LDS-pipe instructions; through v_readlane it takes four reads, four moves and two selects)
+#ifndef JT_DK_NO_DPP_BCAST
+    // two groups of 32 lanes, on the vector pipe: row_newbcast:0 hands every row of 16 lanes its own lane 0 (one 64-bit DPP move), then
+    // row_bcast:15 copies lane 15 of rows 0 and 2 -- lane 0's / lane 32's value by now -- over rows 1 and 3.  Three moves and no LDS
+    // round trip on a chain that has one broadcast per pivot and one per substitution row (round 6; ds_swizzle with and_mask = 0, two
+    // LDS-pipe instructions, was -0.1 ms slower over the two solver launches; through v_readlane it takes four reads, four moves and two selects)
+    if (two) {
+        long long x = __double_as_longlong(v);
+        x = __builtin_amdgcn_update_dpp(x, x, 0x150, 0xf, 0xf, false);
+        int lo = (int)x, hi = (int)(x >> 32);
+        lo = __builtin_amdgcn_update_dpp(lo, lo, 0x142, 0xa, 0xf, false);
+        hi = __builtin_amdgcn_update_dpp(hi, hi, 0x142, 0xa, 0xf, false);
+        return __hiloint2double(hi, lo);
+    }
+#else
     if (two) return __hiloint2double(__builtin_amdgcn_ds_swizzle(__double2hiint(v), 0), __builtin_amdgcn_ds_swizzle(__double2loint(v), 0));
 #endif
     const int lo0 = __builtin_amdgcn_readlane(__double2loint(v), 0), hi0 = __builtin_amdgcn_readlane(__double2hiint(v), 0);
-    if (!two) return __hiloint2double(hi0, lo0);
-    const int lo1 = __builtin_amdgcn_readlane(__double2loint(v), 32), hi1 = __builtin_amdgcn_readlane(__double2hiint(v), 32);
-    return __hiloint2double(q ? hi1 : hi0, q ? lo1 : lo0);
+    (void)q;
+    return __hiloint2double(hi0, lo0);
 }
 __device__ inline double dk_wave_shl1(double v)
 {
@@ -1356,8 +1369,14 @@ k_dk_solve(double *__restrict__ out, int64_t n, DeclickParams P, DkSplit S, doub
 #ifdef JT_DK_PROFILE
     unsigned long long tph[4] = {0, 0, 0, 0}; unsigned long long tc = wall_clock64();
 #define DKS_MARK(i) { unsigned long long t_ = wall_clock64(); tph[i] += t_ - tc; tc = t_; }
+    // sub-phases of a pivot (shader clocks; every mark first waits for the LDS operations in flight, so a phase owns the round trips it started; stores to memory are not waited for)
+    unsigned long long tps[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tcs = 0;
+#define DKS_SUB0() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); tcs = __builtin_amdgcn_s_memtime(); }
+#define DKS_SUB(i) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); const unsigned long long t_ = __builtin_amdgcn_s_memtime(); tps[i] += t_ - tcs; tcs = t_; }
 #else
 #define DKS_MARK(i)
+#define DKS_SUB0()
+#define DKS_SUB(i)
 #endif
     int64_t wi = uniform64(take());
     for (;;) {
@@ -1373,9 +1392,21 @@ k_dk_solve(double *__restrict__ out, int64_t n, DeclickParams P, DkSplit S, doub
             const unsigned short *gi = S.index + (size_t)w * S.wp;
             const double *gr = S.rhs + (size_t)w * S.wp;
             const int ni = min(IDXN, ((Fmax + BW + 16 + G) + 7) & ~7), ny = min(YN, Fmax + BW + 16);
-            for (int e = gl; e < ni; e += G) idx[e] = e < F ? gi[e] : (unsigned short)0xFFFF;
-            for (int e = gl; e < ny; e += G) yv[e] = e < F ? gr[e] : 0.0;
-            for (int e = gl; e < 56; e += G) aux[e] = (have && e <= AR + 1) ? S.aux[(size_t)w * 56 + e] : 0.0;
+            // every load of a trip is issued before the first LDS store (one load -> one store per trip left each of the ~20 trips of a
+            // window of 230 flagged samples waiting for a memory round trip of its own: 20 us of a wave's 165 us per pair of windows)
+            constexpr int PB = 8;
+            double ta[(56 + G - 1) / G];
+#pragma unroll
+            for (int u = 0; u < (56 + G - 1) / G; ++u) { const int e = gl + u * G; ta[u] = (have && e <= AR + 1 && e < 56) ? S.aux[(size_t)w * 56 + e] : 0.0; }
+            for (int e0 = gl; e0 < max(ni, ny); e0 += PB * G) {
+                unsigned short ti[PB]; double ty[PB];
+#pragma unroll
+                for (int u = 0; u < PB; ++u) { const int e = e0 + u * G; ti[u] = e < F ? gi[e] : (unsigned short)0xFFFF; ty[u] = e < F ? gr[e] : 0.0; }
+#pragma unroll
+                for (int u = 0; u < PB; ++u) { const int e = e0 + u * G; if (e < ni) idx[e] = ti[u]; if (e < ny) yv[e] = ty[u]; }
+            }
+#pragma unroll
+            for (int u = 0; u < (56 + G - 1) / G; ++u) { const int e = gl + u * G; if (e < 56) aux[e] = ta[u]; }
         }
         wi = uniform64(wnext_);
         __builtin_amdgcn_wave_barrier();
@@ -1413,6 +1444,7 @@ k_dk_solve(double *__restrict__ out, int64_t n, DeclickParams P, DkSplit S, doub
                 constexpr int p = decltype(pc)::value;
                 const int k = k0 + p;
                 const bool live = k < F;
+                DKS_SUB0()
                 const double colv = c[p];
                 const double rinv = dk_group0(rinv_n, q, TWO);
                 if (live && rinv != rinv) okw = false;                     // d == 0: the reciprocal's Newton steps turn +-inf into NaN
@@ -1420,12 +1452,14 @@ k_dk_solve(double *__restrict__ out, int64_t n, DeclickParams P, DkSplit S, doub
                 CV[gl] = gl ? colv : yr;
                 LV[gl] = l;
                 __builtin_amdgcn_wave_barrier();
+                DKS_SUB(0)
                 const int bwn = bwv[k + 1];
                 const int i0 = idx[k + BW + 1], i1 = idx[k + BW + 1 + gl];
                 const double ynew = yv[k + BW + 1];
                 const double yk = CV[0];
                 const int dlt = i1 - i0;
                 const double ent = aux[dlt < AR + 1 ? dlt : AR + 1];
+                DKS_SUB(1)
                 // trailing update, DK_BCH columns per round, wave-uniform exit behind the widest band of the windows in the wave.
                 // SOFTWARE-PIPELINED (round 5): a round's 2 x DK_BCH LDS reads are issued one round AHEAD of its FMAs, into the other of
                 // two register buffers, and the wait before a round's FMAs leaves the next round's reads in flight (lgkmcnt counts the
@@ -1470,8 +1504,11 @@ k_dk_solve(double *__restrict__ out, int64_t n, DeclickParams P, DkSplit S, doub
                     return next;
                 };
                 dk_all_rounds(round, std::make_integer_sequence<int, (BW + DK_BCH - 1) / DK_BCH>{});
+                DKS_SUB(2)
                 // 1 / d of the next pivot: entry (k + 1, k + 1) is lane 0's c[p + 1]
                 rinv_n = dk_rcp(c[p + 1]);
+                asm volatile("" : "+v"(rinv_n));
+                DKS_SUB(3)
                 // factor stream: the bw multipliers of the column, then y_k / d_k (lane 0), in one store
                 // (a global store per pivot cost a quarter of the factorisation: the stream is staged in a 2 G-entry LDS ring per window and
                 //  leaves G values at a time, one coalesced store per three or four pivots)
@@ -1490,6 +1527,7 @@ k_dk_solve(double *__restrict__ out, int64_t n, DeclickParams P, DkSplit S, doub
                     if (gl <= bwk) gL[goff + (gl ? (unsigned)gl - 1u : (unsigned)bwk)] = gl ? l : yk * rinv;
                     goff += (unsigned)bwk + 1u;
                 }
+                DKS_SUB(4)
                 // forward substitution and the slide of y
                 const double yupd = __fma_rn(-l, yk, yr);
                 yr = dk_wave_shl1(yupd);
@@ -1497,6 +1535,7 @@ k_dk_solve(double *__restrict__ out, int64_t n, DeclickParams P, DkSplit S, doub
                 c[p + BW + 1] = ent;
                 bwk = bwn;
                 __builtin_amdgcn_wave_barrier();
+                DKS_SUB(5)
             };
             pivot(std::integral_constant<int, 0>{}); pivot(std::integral_constant<int, 1>{}); pivot(std::integral_constant<int, 2>{});
             pivot(std::integral_constant<int, 3>{}); pivot(std::integral_constant<int, 4>{}); pivot(std::integral_constant<int, 5>{});
@@ -1573,7 +1612,47 @@ k_dk_solve(double *__restrict__ out, int64_t n, DeclickParams P, DkSplit S, doub
 #ifdef JT_DK_PROFILE
     DKS_MARK(3)
     if (lane == 0 && G == 32) for (int i = 0; i < 4; ++i) atomicAdd(&S.ctl[4 + i], tph[i]);
+    if (lane == 0) for (int i = 0; i < 6; ++i) atomicAdd(&S.ctl[(G == 32 ? 8 : 16) + i], tps[i]);
 #endif
+}
+
+// k_dk_sort_scan / _scatter -- the two solver lists, longest window first (counting sort by the window's flagged samples F: the front
+// kernel counts the windows per F as it appends them, one workgroup per list turns the counts into first places, one thread per window
+// takes a place).
+// A wave of the <32> solver serves two windows and runs for the LONGER one; a launch ends with its last window.  The front kernels append
+// the windows in the order their waves finish, file order more or less: speech alternates between windows with a few dozen flagged
+// samples and windows with ~300, so neighbours in the list paired 166 flagged samples on average with a partner of 229 (the bench file:
+// sum of max(F) over the pairs = 1.38 x half the sum of F), and the <48> launch's last windows were as likely long as short.  Sorted,
+// a pair's windows differ by a sample or two and the longest windows start first.  A window's result does not depend on its partner
+// or its place in the list (the partner only adds update rounds on structural zeros), so the order inside one F is left to the atomics.
+__global__ void __launch_bounds__(1024)
+k_dk_sort_scan(DkSplit S)
+{
+    // hist[f] <- number of windows of the list with MORE flagged samples than f: the first place of the count's windows in the sorted list
+    __shared__ unsigned a[2][1024];
+    unsigned *h = S.hist + blockIdx.x * DK_HIST;
+    const int t = threadIdx.x, f = DK_HIST - 1 - t;                   // t ascends as the count descends
+    unsigned v = t < DK_HIST ? h[f] : 0u;
+    const unsigned own = v;
+    int cur = 0;
+    a[0][t] = v;
+    __syncthreads();
+    for (int d = 1; d < 1024; d <<= 1) {
+        v = a[cur][t] + (t >= d ? a[cur][t - d] : 0u);
+        cur ^= 1;
+        a[cur][t] = v;
+        __syncthreads();
+    }
+    if (t < DK_HIST) h[f] = v - own;
+}
+__global__ void __launch_bounds__(256)
+k_dk_sort_scatter(DkSplit S, int64_t nwindows, int *__restrict__ sorted)
+{
+    const int cls = blockIdx.y;
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (int64_t)S.ctl[cls]) return;
+    const int w = (cls ? S.list64 : S.list32)[i];
+    sorted[(size_t)cls * nwindows + atomicAdd(&S.hist[cls * DK_HIST + min(max(S.F[w], 0), DK_HIST - 1)], 1u)] = w;
 }
 
 // host side --------------------------------------------------------------------------------------------------------
@@ -1610,8 +1689,8 @@ void launch_adeclick(jt_ctx *h, const double *in, double *out, int64_t n, int sa
 {
     // control words (per-XCD work heads, list lengths: [0, 288)) and the stage's statistics ([288, 304)) share one buffer and ONE fill;
     // d_stats == nullptr: the statistics live there (jt_adeclick_stats)
-    h->declick_ctl.ensure(304);
-    JT_HIP(hipMemsetAsync(h->declick_ctl.p, 0, 304 * sizeof(unsigned long long), s));
+    h->declick_ctl.ensure(304 + DK_HIST);                               // (+ 2 x DK_HIST 32-bit counts of the list sort)
+    JT_HIP(hipMemsetAsync(h->declick_ctl.p, 0, (304 + DK_HIST) * sizeof(unsigned long long), s));
     if (!d_stats) d_stats = h->declick_ctl.p + 288;
     DeclickParams P;
     P.W = (int)(sample_rate * window_ms / 1000.); if (P.W < 100) P.W = 100;
@@ -1685,7 +1764,7 @@ void launch_adeclick(jt_ctx *h, const double *in, double *out, int64_t n, int sa
         if (!fused) {
             constexpr int FCS = LIGHT, G32 = 32, BW32 = 31, G64 = 64, BW64 = 48;
             const int wp = (P.W + 63) & ~63;
-            h->declick_F.ensure((size_t)P.nwindows); h->declick_lists.ensure(2 * (size_t)P.nwindows);
+            h->declick_F.ensure((size_t)P.nwindows); h->declick_lists.ensure(4 * (size_t)P.nwindows);      // two lists as appended, two sorted
             h->declick_idx.ensure((size_t)P.nwindows * wp); h->declick_rhs.ensure((size_t)P.nwindows * wp);
             h->declick_aux.ensure((size_t)P.nwindows * 56);
             // (r[] and the AR polynomial share one buffer: 64 doubles each per window)
@@ -1693,6 +1772,7 @@ void launch_adeclick(jt_ctx *h, const double *in, double *out, int64_t n, int sa
             if (lev_split) h->declick_r.ensure(2 * (size_t)P.nwindows * 64);
             SP.F = h->declick_F.p; SP.index = h->declick_idx.p; SP.rhs = h->declick_rhs.p; SP.aux = h->declick_aux.p;
             SP.list32 = h->declick_lists.p; SP.list64 = h->declick_lists.p + P.nwindows; SP.ctl = h->declick_ctl.p; SP.wp = wp;
+            SP.hist = reinterpret_cast<unsigned *>(h->declick_ctl.p + 304);
             SP.xcd = JT_AB_ON(O.dk_no_xcd) ? 0 : 1;
             SP.r = lev_split ? h->declick_r.p : nullptr; SP.ac = lev_split ? h->declick_r.p + (size_t)P.nwindows * 64 : nullptr;
             auto slot_bytes = [&](int G, int BW) {
@@ -1716,6 +1796,12 @@ void launch_adeclick(jt_ctx *h, const double *in, double *out, int64_t n, int sa
                 else DKF_LAUNCH((k_adeclick_fast<LIGHT, NC0, ND0, false, 0, 3>), f0, fm0, Q0);
             } else if (half_ok) DKF_LAUNCH((k_adeclick_fast<LIGHT, NC0, ND0, true, 0, 1>), f0, fm0, Q0);
             else DKF_LAUNCH((k_adeclick_fast<LIGHT, NC0, ND0, false, 0, 1>), f0, fm0, Q0);
+            if (!O.dk_unsorted) {
+                hipLaunchKernelGGL(k_dk_sort_scan, dim3(2), dim3(1024), 0, s, SP);
+                hipLaunchKernelGGL(k_dk_sort_scatter, dim3((unsigned)((P.nwindows + 255) / 256), 2), dim3(256), 0, s, SP, (int64_t)P.nwindows,
+                                   h->declick_lists.p + 2 * (size_t)P.nwindows);
+                SP.list32 = h->declick_lists.p + 2 * (size_t)P.nwindows; SP.list64 = h->declick_lists.p + 3 * (size_t)P.nwindows;
+            }
             {
                 auto k32 = k_dk_solve<G32, BW32, FCS>; auto k64 = k_dk_solve<G64, BW64, FCS>;
                 JT_HIP(hipFuncSetAttribute((const void *)k32, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm32));
@@ -1740,11 +1826,29 @@ void launch_adeclick(jt_ctx *h, const double *in, double *out, int64_t n, int sa
             else DKF_LAUNCH((k_adeclick_fast<MID, NC1, ND1, false, 1>), f1, fm1, Q1);
             DKF_LAUNCH((k_adeclick_fast<dk::MAXW, NC1, ND1, false, 2>), f2, fm2, Q2);
             if (JT_AB_ON(O.dk_profile)) {
-                unsigned long long c[8];
+                unsigned long long c[24];
                 JT_HIP(hipStreamSynchronize(s));
                 JT_HIP(hipMemcpy(c, h->declick_ctl.p, sizeof c, hipMemcpyDeviceToHost));
                 fprintf(stderr, "adeclick split: %llu windows in the 31-row class, %llu in the 48-row class; solver<32> clocks (prologue, factorisation, "
                                 "back substitution, output): %llu %llu %llu %llu\n", c[0], c[1], c[4], c[5], c[6], c[7]);
+                // how the lists pair and queue the windows: a wave of the <32> solver runs for the LONGER of its two windows, a launch ends
+                // with its last window
+                fprintf(stderr, "  pivot sub-phases, shader clocks summed over waves (broadcast + multiplier + column store, scalar LDS reads, update rounds, "
+                                "reciprocal, stream staging, forward substitution): <32> %llu %llu %llu %llu %llu %llu  <48> %llu %llu %llu %llu %llu %llu\n",
+                        c[8], c[9], c[10], c[11], c[12], c[13], c[16], c[17], c[18], c[19], c[20], c[21]);
+                std::vector<int> hF((size_t)P.nwindows), hl((size_t)2 * P.nwindows);      // (the lists the solvers ran on: sorted unless dk_unsorted)
+                JT_HIP(hipMemcpy(hF.data(), h->declick_F.p, sizeof(int) * hF.size(), hipMemcpyDeviceToHost));
+                JT_HIP(hipMemcpy(hl.data(), SP.list32, sizeof(int) * hl.size(), hipMemcpyDeviceToHost));
+                for (int cls = 0; cls < 2; ++cls) {
+                    const int *l = hl.data() + (cls ? P.nwindows : 0); const int64_t m = (int64_t)c[cls];
+                    int64_t sum = 0, summax = 0, hist[9] = {0}; int fmx = 0;
+                    for (int64_t i = 0; i < m; ++i) { const int f = hF[l[i]]; sum += f; fmx = std::max(fmx, f); ++hist[std::min(8, f / 64)]; }
+                    for (int64_t i = 0; i < m; i += 2) summax += std::max(hF[l[i]], i + 1 < m ? hF[l[i + 1]] : 0);
+                    fprintf(stderr, "  class %d: %lld windows, F sum %lld (mean %.1f, max %d), sum over list pairs of max(F) %lld (x%.3f of half the sum); F/64 histogram:",
+                            cls ? 48 : 31, (long long)m, (long long)sum, m ? (double)sum / m : 0., fmx, (long long)summax, sum ? 2.0 * summax / sum : 0.);
+                    for (int b = 0; b < 9; ++b) fprintf(stderr, " %lld", (long long)hist[b]);
+                    fprintf(stderr, "\n");
+                }
             }
             return;
         }

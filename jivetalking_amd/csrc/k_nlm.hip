@@ -697,6 +697,9 @@ void launch_anlmdn(const float *in, float *out, int64_t n, int K, int S, float s
         const bool exact_layout = 2 * S == 2 * Sl;
         if (!(exact_layout && K % 4 == 0 && JT_AB_ON(o.nlm_old))) {               // (nlm_old: the round-1 kernel, JT_AB build only)
             smem += sizeof(float) * 2 * (size_t)(12 * NLM3_CB + NLM3_CB + 1);
+#ifdef JT_NLM_PADSMEM
+            smem += JT_NLM_PADSMEM;                // (tools/ab_builds.py: waves per CU by LDS, the occupancy sweep)
+#endif
             JT_REQUIRE(smem <= 64 * 1024, JT_E_UNSUPPORTED, "anlmdn: window exceeds the wave-per-hop LDS budget");
             if (Sl == 96) hipLaunchKernelGGL((k_anlmdn_pair3<3>), dim3(grid), dim3(64), smem, s, in, out, n, K, S, sw, smooth, lut_scale);
             else hipLaunchKernelGGL((k_anlmdn_pair3<6>), dim3(grid), dim3(64), smem, s, in, out, n, K, S, sw, smooth, lut_scale);
