@@ -56,9 +56,12 @@ struct DkSplit {
     int xcd;                       // 1: the front launches hand windows out per XCD (contiguous eighths of the file)
     double *r;                     // [nwindows * 64] biased autocorrelation r[0 .. AR] (MODE 2 -> k_dk_levinson)
     double *ac;                    // [nwindows * 64] AR polynomial k[0 .. AR], zero padded to 64 taps; ac[w * 64 + 63] = sigma_e
-    unsigned *hist;                // [2][DK_HIST] windows per flagged-sample count of the two lists (k_dk_sort_*: longest window first)
+    unsigned *hist;                // [2][DK_HIST] x DK_HSTRIDE: windows per flagged-sample count of the two lists (k_dk_sort_*: longest window first)
 };
 constexpr int DK_HIST = 520;      // counts 0 .. 513 used (the solvers' capacity is 512 flagged samples)
+// one count per 128-byte line: the scatter's 131 k returning atomics land on ~130 hot counts, and sixteen counts to a line made every line a
+// queue of ~10 k atomics served one after another (0.108 ms for the launch; a line of its own per count: 0.048)
+constexpr int DK_HSTRIDE = 32;
 
 __device__ inline double dk_ld(const double *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
@@ -1029,7 +1032,7 @@ k_adeclick_fast(const double *__restrict__ in, double *__restrict__ out, int64_t
                 if (lane == 0) {
                     S.F[w] = F;
                     (wide ? S.list64 : S.list32)[lslot_] = (int)w;
-                    atomicAdd(&S.hist[(wide ? DK_HIST : 0) + min(F, DK_HIST - 1)], 1u);
+                    atomicAdd(&S.hist[(size_t)((wide ? DK_HIST : 0) + min(F, DK_HIST - 1)) * DK_HSTRIDE], 1u);
                 }
                 DKF_MARK(4)
                 continue;
@@ -1630,9 +1633,9 @@ k_dk_sort_scan(DkSplit S)
 {
     // hist[f] <- number of windows of the list with MORE flagged samples than f: the first place of the count's windows in the sorted list
     __shared__ unsigned a[2][1024];
-    unsigned *h = S.hist + blockIdx.x * DK_HIST;
+    unsigned *h = S.hist + (size_t)blockIdx.x * DK_HIST * DK_HSTRIDE;
     const int t = threadIdx.x, f = DK_HIST - 1 - t;                   // t ascends as the count descends
-    unsigned v = t < DK_HIST ? h[f] : 0u;
+    unsigned v = t < DK_HIST ? h[(size_t)f * DK_HSTRIDE] : 0u;
     const unsigned own = v;
     int cur = 0;
     a[0][t] = v;
@@ -1643,7 +1646,7 @@ k_dk_sort_scan(DkSplit S)
         a[cur][t] = v;
         __syncthreads();
     }
-    if (t < DK_HIST) h[f] = v - own;
+    if (t < DK_HIST) h[(size_t)f * DK_HSTRIDE] = v - own;
 }
 __global__ void __launch_bounds__(256)
 k_dk_sort_scatter(DkSplit S, int64_t nwindows, int *__restrict__ sorted)
@@ -1652,7 +1655,7 @@ k_dk_sort_scatter(DkSplit S, int64_t nwindows, int *__restrict__ sorted)
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= (int64_t)S.ctl[cls]) return;
     const int w = (cls ? S.list64 : S.list32)[i];
-    sorted[(size_t)cls * nwindows + atomicAdd(&S.hist[cls * DK_HIST + min(max(S.F[w], 0), DK_HIST - 1)], 1u)] = w;
+    sorted[(size_t)cls * nwindows + atomicAdd(&S.hist[(size_t)(cls * DK_HIST + min(max(S.F[w], 0), DK_HIST - 1)) * DK_HSTRIDE], 1u)] = w;
 }
 
 // host side --------------------------------------------------------------------------------------------------------
@@ -1689,8 +1692,9 @@ void launch_adeclick(jt_ctx *h, const double *in, double *out, int64_t n, int sa
 {
     // control words (per-XCD work heads, list lengths: [0, 288)) and the stage's statistics ([288, 304)) share one buffer and ONE fill;
     // d_stats == nullptr: the statistics live there (jt_adeclick_stats)
-    h->declick_ctl.ensure(304 + DK_HIST);                               // (+ 2 x DK_HIST 32-bit counts of the list sort)
-    JT_HIP(hipMemsetAsync(h->declick_ctl.p, 0, (304 + DK_HIST) * sizeof(unsigned long long), s));
+    constexpr size_t CTLN = 304 + (size_t)DK_HIST * DK_HSTRIDE;          // (+ 2 x DK_HIST 32-bit counts of the list sort, a 128-byte line each)
+    h->declick_ctl.ensure(CTLN);
+    JT_HIP(hipMemsetAsync(h->declick_ctl.p, 0, CTLN * sizeof(unsigned long long), s));
     if (!d_stats) d_stats = h->declick_ctl.p + 288;
     DeclickParams P;
     P.W = (int)(sample_rate * window_ms / 1000.); if (P.W < 100) P.W = 100;
