@@ -236,6 +236,10 @@ int jt_process_file(jt_ctx *h, const char *input_path, const jt_host_config *bas
  * may run on; -1 / 0 when the host does not say (one node, a VM).  A handle pool binds its worker threads and finisher jobs -- and,
  * through first touch, the pinned I/O sets they allocate -- to that node (option pool_numa, process-wide, default on). */
 int jt_host_device_numa_node(int device, int *n_cpus);
+/* Test entry: the loudnorm statistics bin a block energy into ebur128.c's 1000-bin histogram (find_histogram_index: a bisection over
+ * the boundaries); the library finds the same bin from a table keyed by the double's top 20 bits plus a comparison against the
+ * boundaries.  Returns how many of the n energies (and of the 1001 boundaries with their neighbours) land in a different bin: 0. */
+int64_t jt_host_hist_index_check(const double *e, int64_t n);
 
 /* Test seam: makes the next jt_process_file calls fail at temp creation / temp write / publish (the failures the reference injects
  * through processorCreateSiblingTempPath, a failing encoder and processorRename: processor_test.go:552-627) so that the

@@ -1062,8 +1062,12 @@ static int analyse_core(jt_ctx *h, const jt_host_config *base, int frame_samples
     if (frame_samples <= 0) return JT_E_INVAL;
     const int64_t nfr = flens ? (int64_t)h->dec_frame_lens.size() : (n + frame_samples - 1) / frame_samples;
     const int64_t cap_meta = n / (sr / 10) + 2;
-    std::vector<double> fss((size_t)nfr), fpk((size_t)nfr);
-    std::vector<jt_frame_meta> meta((size_t)cap_meta);
+    // the handle's own scratch, grown and never cleared (jt_pass1 writes nfr sums / peaks and a1.n_frames_meta records, nothing else is
+    // read): an hour's frame records are 4.9 MB, and a fresh zeroed vector per call was 0.3 ms of page faults before Pass 1's first launch
+    std::vector<double> &fss = h->host_fss, &fpk = h->host_fpk;
+    std::vector<jt_frame_meta> &meta = h->host_meta;
+    if (fss.size() < (size_t)nfr) { fss.resize((size_t)nfr); fpk.resize((size_t)nfr); }
+    if (meta.size() < (size_t)cap_meta) meta.resize((size_t)cap_meta);
     if (pass2_follows) {
         // AdaptConfig takes the rumble filter, the band-limit filter and anlmdn from the base configuration, never from the
         // measurements (jt_host_adapt: tuneBandlimitLowPass is a constant, the other two are not tuned): the GPU can start them beside

@@ -500,6 +500,8 @@ struct jt_ctx {
     // input leg: file image, frame candidates / parse results / frame table, planar and interleaved integer PCM
     DevBuf<unsigned char> in_file, in_tab; DevBuf<int> in_planar, in_i32;
     std::vector<jt_interval> last_intervals;      // the 250 ms interval series of the last Pass-1 analysis (run record, sidecar)
+    std::vector<double> host_fss, host_fpk;       // analyse_core's per-decoder-frame sums / peaks and 100 ms frame records: grown, never cleared
+    std::vector<jt_frame_meta> host_meta;
     jt_timers timers{};
     hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr, ev3 = nullptr;
 };

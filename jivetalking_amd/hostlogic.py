@@ -114,7 +114,7 @@ HOST_SYMBOLS = ["jt_host_build_intervals", "jt_host_build_intervals_v", "jt_host
                 "jt_host_vad_gap_tolerance", "jt_host_vad_gate_stats", "jt_host_vad_noise_seed",
                 "jt_host_vad_pick_low_cluster", "jt_host_vad_floored_fraction", "jt_host_sizeof",
                 "jt_host_lufs_filename_value", "jt_host_output_path", "jt_process_audio_cb", "jt_process_file", "jt_process_files",
-                "jt_host_test_inject_fault", "jt_host_device_numa_node", "jt_process_files_multi", "jt_handle_pool_open", "jt_handle_pool_workers", "jt_handle_pool_process_files", "jt_handle_pool_close", "jt_handle_pool_stats",
+                "jt_host_test_inject_fault", "jt_host_device_numa_node", "jt_host_hist_index_check", "jt_process_files_multi", "jt_handle_pool_open", "jt_handle_pool_workers", "jt_handle_pool_process_files", "jt_handle_pool_close", "jt_handle_pool_stats",
                 "jt_host_score_speech_candidate", "jt_host_level_variance", "jt_host_find_best_speech_region", "jt_host_frame_level_s16", "jt_process_audio_ticks",
                 "jt_host_run_record_json", "jt_host_intervals_jsonl", "jt_host_last_intervals", "jt_host_candidates_jsonl", "jt_host_intervals_in_range",
                 "jt_host_score_interval_window", "jt_host_score_speech_interval_window", "jt_host_measure_speech_candidate", "jt_host_refine_golden_speech", "jt_host_loudnorm_json"]

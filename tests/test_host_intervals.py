@@ -146,3 +146,13 @@ def test_intervals_from_frames_of_different_lengths(lib, sr, pattern):
         n = int(lens.sum()); F = pattern[0]
         same = build(lib, sr, n, F, 1, ss, pk, (L.FrameMeta * 0)(), 0)
         assert [(a.timestamp_ns, a.rms_level, a.peak_level) for a in same] == [(a.timestamp_ns, a.rms_level, a.peak_level) for a in iv]
+
+
+def test_loudnorm_histogram_bin_by_table_is_the_bisections(lib):
+    # ebur128.c's find_histogram_index is a bisection over 1001 boundaries; the library reads a table keyed by the double's top 20 bits
+    # and compares against the boundaries themselves (jt_plan.cpp: hist_index).  Same bin for two million energies spread over the
+    # range (and beyond both ends), for energies a few ulps around every boundary (the entry checks those itself), for tiny / huge values.
+    lib.jt_host_hist_index_check.restype = C.c_int64
+    rng = np.random.default_rng(5)
+    e = np.concatenate([10.0 ** rng.uniform(-9, 5, 2_000_000), np.array([0.0, 1e-300, 1.17e-7, 1.18e-7, 2.0 ** -24, 2.0 ** 11, 2.0 ** 12, 1e30, np.inf])])
+    assert lib.jt_host_hist_index_check(e.ctypes.data_as(C.POINTER(C.c_double)), C.c_int64(e.size)) == 0

@@ -12,10 +12,11 @@ e = Engine(0)
 e.attach_device_pcm(x.data_ptr(), x.numel(), sr, 1, keepalive=x)
 base = hostlogic.default_config()
 rows = []
+import time
 for i in range(10):
-    r = hostlogic.process_audio(e, base, 4096)
-    if i >= 2: rows.append(list(r.stage_ms) + list(r.pass_ms))
+    t0 = time.perf_counter(); r = hostlogic.process_audio(e, base, 4096); dt = (time.perf_counter() - t0) * 1e3
+    if i >= 2: rows.append(list(r.stage_ms) + list(r.pass_ms) + [dt])
 m = np.median(np.array(rows), axis=0)
 names = ["pass1", "intervals+VAD", "bands", "adapt", "pass2", "regions(2)", "plan", "pass3", "pass4", "regions(4)"]
 print("host wall ms: " + ", ".join(f"{n} {v:.3f}" for n, v in zip(names, m[:10])) + f"; sum {m[:10].sum():.3f}")
-print("GPU event ms: pass 1 / 2 / 3 / 4 " + " / ".join(f"{v:.3f}" for v in m[10:14]))
+print("GPU event ms: pass 1 / 2 / 3 / 4 " + " / ".join(f"{v:.3f}" for v in m[10:14]) + f"; wall of the call {m[14]:.3f} ms (outside the stages: {m[14] - m[:10].sum():.3f})")
