@@ -650,16 +650,16 @@ def main():
         if True:
             dk_bytes = 16 * m                                  # adeclick: read f64 + write f64 per 44.1 kHz sample
             roof = {"kernel": "k_adeclick", "stage": "adeclick (five launches, timed with HIP events on its stream)", "launches": "k_adeclick_fast<..., MODE 2> (autocorrelation + pass-through copy) -> k_dk_levinson (one lane per window) -> "
-                                                        "k_adeclick_fast<..., MODE 3> (detector, right-hand side) -> k_dk_solve<32> || k_dk_solve<64> "
+                                                        "k_adeclick_fast<..., MODE 3> (detector, right-hand side) -> k_dk_sort_scan / _scatter (solver lists, longest window first) -> k_dk_solve<32> || k_dk_solve<64> "
                                                         "(register-resident LDL^T, two windows / one window per wave) [+ k_adeclick_fast levels 1, 2 for overflow windows]",
                     "bound": "hbm", "achieved": round(dk_bytes / dk_avg_s / 1e9, 2), "peak": 8000,
                     "unit": "GB/s", "frac": round(dk_bytes / dk_avg_s / 1e9 / 8000, 5), "traffic": None,
-                    "bound_by_counters": "dependent LDS round trips / f64 issue (waves waiting > 50 % of their time, profiles/*_pmc_issue.txt); the HBM "
+                    "bound_by_counters": "a wave's serial chain of dependent LDS round trips and f64 operations at the occupancy LDS capacity admits (waves waiting > 50 % of their time, profiles/*_pmc_issue.txt; half the LDS reads, a shorter broadcast or deeper gathers leave the time where it is: NOTES.md, round 6); the HBM "
                                          "fraction above is the contract's figure for the dominant kernel, the f64 figure below is the ceiling that applies",
                     "f64": None,
                     "note": "dominant stage (HIP-event time over its launches); not bandwidth bound: a window is an AR fit, a detector and a banded "
-                            "LDL^T solve whose pivots are a dependent chain; the solvers keep the trailing block in registers and wait on LDS "
-                            "round trips 60 % of their wave time at 11 waves per CU (profiles/r03_pmc_issue.txt, DESIGN.md s4/s9)",
+                            "LDL^T solve whose pivots are a dependent chain; the solvers keep the trailing block in registers and wait "
+                            "53 % of their wave time at 10-11 waves per CU (profiles/r06_pmc_issue.txt, DESIGN.md s4 / s4a)",
                     "avg_launch_ms": round(dk_avg_s * 1e3, 3), "repaired_samples": int(eng.timers()["declick_repaired"]),
                     "heavy_windows": int(eng.timers()["declick_heavy_windows"]), "fast_vs_exact": dk_parity}
         # HBM traffic per launch from the round's committed PMC passes (profiles/r04_pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE and

@@ -555,12 +555,11 @@ static void analysis_enqueue(jt_ctx *h, const float *x, int64_t n, int sr, bool 
 static void analysis_finish(jt_ctx *h, const AnalysisJob &J, AnalysisHost *A, bool staged, bool astats_later = false)
 {
     auto wait = [&](int i) { if (staged) JT_HIP(jt_event_wait(h, h->ev_chain[i])); };
-    std::vector<double> bsum, bpk;
+    const double *bsum = J.kw.hc, *bpk = J.kw.hc ? J.kw.hc + (size_t)J.nfull + 1 : nullptr;      // (in place: KwJob::hc = (nfull + 1) sums, then as many peaks)
     if (J.want_r128) {
         wait(5);
         A->blk = J.blk; A->nblocks = J.nfull;
-        jt_kweight_finish(&J.kw, bsum, bpk);
-        jt_r128_finish(bsum.data(), J.nfull, J.blk, J.sr, J.dualmono, &A->r128);
+        jt_r128_finish(bsum, J.nfull, J.blk, J.sr, J.dualmono, &A->r128);
     }
     if (J.want_astats && !astats_later) { wait(0); wait(1); wait(4); jt_astats_finish(&J.as, &A->astats); }
     if (J.want_r128) {
@@ -626,7 +625,11 @@ static void assemble_analysis(const AnalysisHost &A, int64_t n, bool dualmono, j
 
 static void analysis_complete(jt_ctx *h, const AnalysisJob &J, jt_analysis *out, jt_frame_meta *meta, int64_t cap_meta, bool staged = false)
 {
-    AnalysisHost A;
+    // one per host thread, keeping its vectors' storage (five series of an hour's 36 000 blocks: 1.4 MB of fresh, page-faulting memory
+    // per analysis otherwise); everything else starts as in a fresh object
+    static thread_local AnalysisHost A_tl;
+    AnalysisHost &A = A_tl;
+    A.hops = nullptr; A.nblocks = A.nhops = A.nout = 0; A.blk = 0; A.tp_cum.clear(); A.sp_cum.clear(); A.r128.M.clear(); A.r128.S.clear();
     const bool timing = h->opts.host_timing;
     std::chrono::steady_clock::time_point t0; if (timing) t0 = std::chrono::steady_clock::now();
     if (staged && h->opts.no_staged_finish) {          // (the round-2 order: everything after the last chain)
@@ -1248,9 +1251,10 @@ extern "C" int jt_pass2(jt_ctx *h, const jt_filter_params *p, jt_analysis *out)
         JT_HIP(jt_event_wait(h, E.ev[0]));
         const auto t0 = now();
         check_cancel(h);
-        std::vector<double> bsum, bpk;
-        jt_kweight_finish(&J.kw, bsum, bpk);
-        R128Series r; jt_r128_finish(bsum.data(), J.nfull, J.blk, J.sr, J.dualmono, &r, true);
+        // (the block sums are read where the kernel left them -- pinned host memory -- and the series keeps its storage from file to file:
+        //  copies and fresh 0.3 MB vectors were a third of this stretch, which the main stream's next kernel waits for)
+        static thread_local R128Series r;
+        jt_r128_finish(J.kw.hc, J.nfull, J.blk, J.sr, J.dualmono, &r, true);
         const auto t1 = now();
         JT_HIP(jt_event_wait(h, E.ev[1]));
         const auto t2 = now();

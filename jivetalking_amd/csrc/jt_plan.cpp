@@ -185,7 +185,13 @@ void jt_r128_finish(const double *bs, int64_t nblocks, int blk, int sr, bool dua
     (void)blk;
     const double pan_law = -3.01029995663978;
     const int bins400 = sr * 4 / 10, bins3000 = sr * 3;
-    std::vector<unsigned> h400(HIST_SIZE, 0), h3000(HIST_SIZE, 0);
+    // scratch that keeps its storage from call to call, per host thread.  The names used below are LOCAL references to the calling
+    // thread's instances: a thread_local named inside a jt_parallel_for body would be the pool worker's own (empty) object.
+    static thread_local std::vector<unsigned> tl_h400, tl_h3000;
+    static thread_local std::vector<double> tl_pw400, tl_pw3000;
+    std::vector<unsigned> &h400 = tl_h400, &h3000 = tl_h3000;
+    std::vector<double> &pw400 = tl_pw400, &pw3000 = tl_pw3000;
+    h400.assign(HIST_SIZE, 0); h3000.assign(HIST_SIZE, 0);
     double kept400 = 0, kept3000 = 0; int64_t nk400 = 0, nk3000 = 0;
     double rel400 = 0;
     // integrated_only (the limiter-plan hook of Pass 2, which waits for nothing else): the 3 s windows, their logarithms and the
@@ -193,7 +199,7 @@ void jt_r128_finish(const double *bs, int64_t nblocks, int blk, int sr, bool dua
     o->M.assign(nblocks, 0.0); o->S.assign(integrated_only ? 0 : nblocks, 0.0);
     // per block: window powers and momentary / short-term loudness (the log10s) in parallel; the powers and the un-panned
     // loudness values are kept for the serial gating walk
-    std::vector<double> pw400((size_t)nblocks), pw3000((size_t)(integrated_only ? 0 : nblocks));
+    pw400.resize((size_t)nblocks); pw3000.resize((size_t)(integrated_only ? 0 : nblocks));
     jt_parallel_for(nblocks, [&](int64_t lo, int64_t hi, int) {
         for (int64_t k = lo; k < hi; ++k) {
             // window sums recomputed from the block energies each step (no add/sub drift)
@@ -306,11 +312,13 @@ void jt_loudnorm_finish(const double *bs, int64_t nblocks, int64_t s100, bool du
                         double *out_i, double *out_lra, double *out_thresh)
 {
     hist_init();
-    std::vector<unsigned long> bh(1000, 0), sh(1000, 0);
+    static thread_local std::vector<unsigned long> tl_bh, tl_sh, tl_pbh, tl_psh;      // (local references: see jt_r128_finish)
+    std::vector<unsigned long> &bh = tl_bh, &sh = tl_sh, &pbh = tl_pbh, &psh = tl_psh;
+    bh.assign(1000, 0); sh.assign(1000, 0);
     const double ch = dual_mono ? 2.0 : 1.0;
     // gating blocks: 400 ms every 100 ms; short-term blocks: 3 s, first at 3 s then every 1 s.  Histogram counts are
     // order-independent, so the blocks are binned in parallel parts and the counts added.
-    std::vector<unsigned long> pbh((size_t)JT_MAX_PARTS * 1000, 0), psh((size_t)JT_MAX_PARTS * 1000, 0);
+    pbh.assign((size_t)JT_MAX_PARTS * 1000, 0); psh.assign((size_t)JT_MAX_PARTS * 1000, 0);
     int nparts = 1;
     jt_parallel_for(nblocks, [&](int64_t lo, int64_t hi, int part) {
         unsigned long *b = &pbh[(size_t)part * 1000], *sm = &psh[(size_t)part * 1000];
