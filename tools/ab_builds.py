@@ -13,7 +13,7 @@ def child(n_runs, minutes):
     from jivetalking_amd import Engine, synth, hostlogic
     sr = 48000
     x = synth.speech_like_torch(minutes * 60.0, sr, seed=1000, device="cuda:0", plosives_per_min=40.0)
-    e = Engine(0)
+    e = Engine(0, ab=os.environ.get("JT_AB_CHILD") == "1")
     e.attach_device_pcm(x.data_ptr(), x.numel(), sr, 1, keepalive=x)
     base = hostlogic.default_config()
     rows = []
@@ -38,7 +38,12 @@ if __name__ == "__main__":
     res = {p: [] for p in a}
     for r in range(rounds):
         for p in a:
-            env = dict(os.environ, JT_LIB_PATH=os.path.abspath(p))
+            # "lib.so@VAR=1,VAR2=x": environment of that variant's process (the A/B build imports JT_<KEY> at jt_open: "ab@JT_DK_SERIAL=1")
+            path, _, assigns = p.partition("@")
+            env = dict(os.environ)
+            if path == "ab": env["JT_AB_CHILD"] = "1"
+            else: env["JT_LIB_PATH"] = os.path.abspath(path)
+            for a_ in filter(None, assigns.split(",")): k_, _, v_ = a_.partition("="); env[k_] = v_
             out = subprocess.run([sys.executable, os.path.abspath(__file__), "--child", str(runs), str(minutes)], env=env,
                                  capture_output=True, text=True)
             got = [ln for ln in out.stdout.splitlines() if ln.startswith("ABROWS ")]
