@@ -1188,7 +1188,11 @@ extern "C" int jt_pass2(jt_ctx *h, const jt_filter_params *p, jt_analysis *out)
     if (head_ready) {
         // jt_pass2_prefetch ran exactly these stages on this input: continue from its result
         sp.pending = false;
-        JT_HIP(hipStreamWaitEvent(h->stream, sp.done, 0));
+        // The head runs on a queue of its own; a queue that waits for another queue's event takes ~0.1 ms to notice it on this part
+        // (anlmdn's end to afftdn's start: 100-140 us in every timeline), a host thread that spins on the event ~10 us, and this thread has
+        // nothing to queue that could start before the head is done.  Option p2_device_join: the wait inside the queue, as before.
+        if (h->opts.p2_device_join || sp.stream == h->stream) JT_HIP(hipStreamWaitEvent(h->stream, sp.done, 0));      // (a one-stream handle: nothing to hand over)
+        else { JT_HIP(jt_event_wait(h, sp.done)); check_cancel(h); }
         for (int k = 0; k < sp.stages; ++k) advance();
         nlm_timed = sp.nlm;
     } else {

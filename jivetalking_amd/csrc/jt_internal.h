@@ -100,7 +100,7 @@ template <typename T> struct DevBuf {
 // that build imports JT_<KEY> variables, once, inside jt_open.
 #define JT_OPT_BOOLS(X) \
     X(no_pass2_prefetch) X(no_early_biquad) X(no_early_pass3) X(no_early_plan) X(no_lim_keep) X(no_staged_finish) X(no_r128_first) \
-    X(region_full_astats) X(host_timing) X(adeclick_exact) X(nlm_generic) X(p3_unfused) X(limiter_lanes) X(tp_unpruned) X(no_spec_direct) X(brickwall_f64) X(nf_low) X(nf_unpruned) X(as_avg_behind_spec) X(ln_no_batch) X(ln_no_stream) X(swr_untiled) X(flac_no_ahead) X(dk_unsorted)
+    X(region_full_astats) X(host_timing) X(adeclick_exact) X(nlm_generic) X(p3_unfused) X(limiter_lanes) X(tp_unpruned) X(no_spec_direct) X(brickwall_f64) X(nf_low) X(nf_unpruned) X(as_avg_behind_spec) X(ln_no_batch) X(ln_no_stream) X(swr_untiled) X(flac_no_ahead) X(dk_unsorted) X(p2_device_join) X(dk_device_join)
 #define JT_OPT_INTS(X) X(region_rot) X(tp_prune_min) X(ln_stream_stop)
 #define JT_OPT_AB_BOOLS(X) \
     X(nlm_old) X(afftdn_old) X(adeclick_fused) X(dk_levinson_in_kernel) X(dk_no_xcd) X(dk_serial) X(dk_profile) X(dyn_one_wave) \

@@ -1823,7 +1823,11 @@ void launch_adeclick(jt_ctx *h, const double *in, double *out, int64_t n, int sa
                 hipLaunchKernelGGL(k64, dim3((unsigned)g64), dim3(64), sm64, h->dk_stream, out, n, P, SP, h->declick_scr.p + slot32 * 2 * (size_t)g32, slot64, d_stats);
                 JT_HIP(hipEventRecord(h->dk_ev[1], h->dk_stream));
                 hipLaunchKernelGGL(k32, dim3((unsigned)g32), dim3(64), sm32, s, out, n, P, SP, h->declick_scr.p, slot32, d_stats);
-                JT_HIP(hipStreamWaitEvent(s, h->dk_ev[1], 0));
+                // the wide-band launch ends last (5.5 against 4.3 ms on the bench file); a queue takes ~70-140 us to notice another queue's event
+                // on this part, a spinning host thread ~25 (jt_pass2's head) -- and this thread has nothing to queue that could start
+                // before the solvers are done.  Handles that poll with sleeps (pools) and option dk_device_join keep the wait in the queue.
+                if (h->blocking || h->dk_stream == s || O.dk_device_join) JT_HIP(hipStreamWaitEvent(s, h->dk_ev[1], 0));
+                else JT_HIP(jt_event_wait(h, h->dk_ev[1]));
                 }
             }
             if (half_ok) DKF_LAUNCH((k_adeclick_fast<MID, NC1, ND1, true, 1>), f1, fm1, Q1);

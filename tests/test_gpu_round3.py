@@ -384,7 +384,8 @@ def test_host_arithmetic_staged_behind_the_analysis_chains_reports_the_same_numb
     #  floor by branch and bound -- schedule / pruning only: every measurement and every delivered byte the same without them)
     for env in ({"no_staged_finish": "1"}, {"region_rot": "0"}, {"region_rot": "3", "no_staged_finish": "1"}, {"region_full_astats": "1"},
                 {"no_early_biquad": "1"}, {"as_avg_behind_spec": "1"}, {"nf_unpruned": "1"}, {"no_early_biquad": "1", "as_avg_behind_spec": "1", "nf_unpruned": "1"},
-                {"dk_unsorted": "1"}):      # (adeclick's solver lists in the order the front kernels appended them: pairing and queue order only)
+                {"dk_unsorted": "1"},       # (adeclick's solver lists in the order the front kernels appended them: pairing and queue order only)
+                {"p2_device_join": "1", "dk_device_join": "1"}):      # (the two joins a step waits on inside the queue instead of on the host thread)
         with options(engine, **env):
             got = run()
         assert got == ref, env
