@@ -69,7 +69,12 @@ void jt_end_job(jt_ctx *h);
  *   schedule switches (same results either way; the tests run both): no_pass2_prefetch, no_early_pass3, no_early_plan, no_lim_keep,
  *     no_staged_finish, no_r128_first, region_rot (0..3, -1 = default), region_full_astats, no_spec_direct (aspectralstats' records
  *     through a device buffer and a copy instead of straight into the pinned arena), nf_low (Pass 2: astats' noise-floor chain among the
- *     low-priority statistics instead of behind the K-weighting job)
+ *     low-priority statistics instead of behind the K-weighting job), no_early_biquad (the early Pass-2 head's biquads behind Pass 1's
+ *     analysis instead of beside it), as_avg_behind_spec (astats' exponential-average chain behind aspectralstats instead of behind
+ *     its reduce chain), dk_unsorted (adeclick's solver lists in the order the front kernels appended them instead of longest window
+ *     first), p2_device_join / dk_device_join (Pass 2's main stream waits for the early head / Pass 4's for the wide-band solver
+ *     inside the queue -- hipStreamWaitEvent -- instead of on the host thread, which launches ~0.1 ms sooner on this part; handles
+ *     that poll with sleeps and one-stream handles always wait inside the queue)
  *   kernel selection: adeclick_exact (the sequential-order adeclick kernel, bit-exact to af_adeclick.c's summation order),
  *     nlm_generic (the any-geometry anlmdn kernel), p3_unfused (Pass 3 as stand-alone upsampler + K-weighting kernels: what the fused
  *     sweep is tested against), limiter_lanes (alimiter with a lane per segment: what the wave-per-segment kernel is tested against),
@@ -79,7 +84,8 @@ void jt_end_job(jt_ctx *h);
  *     loudnorm: the limiter's harmless peaks one detector call at a time instead of a frame's worth in one step; same bytes),
  *     ln_no_stream (dynamic-mode loudnorm: every frame through the one-workgroup kernel instead of the data-parallel stream path; same bytes),
  *     swr_untiled (the dynamic mode's 192 kHz -> source-rate aresample one thread per output instead of the LDS-tiled kernel; same bytes),
- *     flac_no_ahead (mono FLAC input: a parse walk and a decode walk per frame, as for stereo, instead of one walk that does both; same samples)
+ *     flac_no_ahead (mono FLAC input: a parse walk and a decode walk per frame, as for stereo, instead of one walk that does both; same samples),
+ *     nf_unpruned (astats' noise floor with every 50 ms window evaluated instead of by branch and bound; same value)
  *   diagnostics: host_timing (host-stage timings on stderr; PROCESS-WIDE although it is set through a handle: the host stages are
  *     plain functions without one, the last writer wins for every handle of the process)
  *   process-wide (h == NULL): graveyard_gb (gigabytes of superseded buffers parked before they are freed, default 24, 0 = free at
