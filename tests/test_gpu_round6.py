@@ -345,3 +345,26 @@ def test_noise_floor_branch_and_bound_equals_the_exhaustive_sweep(engine, oracle
         assert a["noise_floor_count"] == ref["noise_floor_count"], (name, a["noise_floor_count"], ref["noise_floor_count"])
         if np.isfinite(ref["noise_floor_db"]):
             assert abs(a["noise_floor"] - ref["noise_floor_db"]) <= 1e-9 * max(1.0, abs(ref["noise_floor_db"])), (name, a["noise_floor"], ref["noise_floor_db"])
+
+
+def test_adeclick_solver_lists_sorted_or_not_repair_the_same_samples(engine):
+    """The split adeclick's solver lists are sorted by the windows' flagged-sample counts (k_dk_sort_scan / _scatter: a wave's two windows
+    match, the longest start first); option dk_unsorted keeps the order the front kernels appended them in.  A window's result does not
+    depend on its partner or its place: the same doubles and the same repaired count either way -- on a signal whose windows alternate
+    between a few clicks and hundreds (what makes the sorted pairs differ from the appended ones), at 44.1 and 48 kHz, both methods."""
+    from conftest import options
+    rng = np.random.default_rng(6161)
+    for sr, method in ((44100, "s"), (48000, "s"), (44100, "a")):
+        n = 40 * sr
+        x = 0.2 * np.sin(2 * np.pi * 180.0 * np.arange(n) / sr) + 0.02 * rng.standard_normal(n)
+        # sparse clicks everywhere, dense click bursts in every third 55 ms window
+        idx = rng.choice(n, 4000, replace=False); x[idx] += rng.choice([-1.0, 1.0], idx.size) * rng.uniform(0.3, 0.9, idx.size)
+        w = int(sr * 0.055)
+        for s0 in range(0, n - w, 3 * w):
+            k = rng.choice(w, 160, replace=False); x[s0 + k] += rng.choice([-1.0, 1.0], k.size) * rng.uniform(0.2, 0.8, k.size)
+        x = np.clip(x, -1.0, 1.0)
+        ya, ca = engine.op_adeclick(x, sr, t=2.0, w=55.0, o=75.0, method=method, return_count=True)
+        with options(engine, dk_unsorted=True):
+            yb, cb = engine.op_adeclick(x, sr, t=2.0, w=55.0, o=75.0, method=method, return_count=True)
+        assert ca == cb and ca > 10000, (sr, method, ca, cb)
+        assert np.array_equal(ya.view(np.uint64), yb.view(np.uint64)), (sr, method, int(np.count_nonzero(ya != yb)))
